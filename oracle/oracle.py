@@ -1,0 +1,542 @@
+"""ctypes front-end of the CPU oracle (oracle/dforacle.c).
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product (datafusion_amd / libdfgpu.so)
+never does.  Tables are pyarrow Tables; every operator returns a pyarrow Table so the
+parity tests read like the reference's `assert_batches_sorted_eq!` tests.
+
+Expression trees for the oracle are plain tuples (independent of the product's IR):
+    ("col", name) | ("lit", python_value, pa.DataType) | ("cast", expr, pa.DataType)
+    ("bin", op, lhs, rhs)   op in + - * = != < <= > >= and or
+    ("is_null", expr) | ("not", expr)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from decimal import Decimal
+
+import numpy as np
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ORC_I32, ORC_I64, ORC_I128, ORC_F64, ORC_U8, ORC_U32, ORC_U64 = 1, 2, 3, 4, 5, 6, 7
+JOIN_TYPES = {
+    "Inner": 0, "Left": 1, "Right": 2, "Full": 3, "LeftSemi": 4, "RightSemi": 5,
+    "LeftAnti": 6, "RightAnti": 7, "LeftMark": 8, "RightMark": 9,
+}
+NULL_EQUALITY = {"NullEqualsNothing": 0, "NullEqualsNull": 1}
+
+
+class OrcCol(C.Structure):
+    _fields_ = [("type", C.c_int32), ("_pad", C.c_int32), ("n", C.c_int64),
+                ("data", C.c_void_p), ("valid", C.c_void_p)]
+
+
+def build():
+    """(re)build liboracle with the committed Makefile."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libdforacle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_filter_indices.restype = C.c_int64
+        _LIB.orc_group_intern.restype = C.c_int64
+    return _LIB
+
+
+def orc_type(t: pa.DataType) -> int:
+    if pa.types.is_int32(t) or pa.types.is_date32(t):
+        return ORC_I32
+    if pa.types.is_int64(t) or pa.types.is_timestamp(t):
+        return ORC_I64
+    if pa.types.is_decimal128(t):
+        return ORC_I128
+    if pa.types.is_float64(t):
+        return ORC_F64
+    if pa.types.is_uint8(t):
+        return ORC_U8
+    if pa.types.is_uint32(t):
+        return ORC_U32
+    if pa.types.is_uint64(t):
+        return ORC_U64
+    raise TypeError(f"oracle: unsupported type {t}")
+
+
+_NP = {ORC_I32: np.int32, ORC_I64: np.int64, ORC_F64: np.float64, ORC_U8: np.uint8,
+       ORC_U32: np.uint32, ORC_U64: np.uint64}
+
+
+def _flat(arr) -> pa.Array:
+    if isinstance(arr, pa.ChunkedArray):
+        arr = arr.combine_chunks() if arr.num_chunks != 1 else arr.chunk(0)
+    if arr.offset != 0:
+        arr = pa.concat_arrays([arr])  # re-materialise at offset 0
+    return arr
+
+
+def values_np(arr) -> np.ndarray:
+    """raw fixed-width values as numpy (decimal128 -> (n,2) uint64 lo/hi)."""
+    arr = _flat(arr)
+    t = orc_type(arr.type)
+    buf = arr.buffers()[1]
+    n = len(arr)
+    if n == 0 or buf is None:
+        return np.zeros((0, 2), np.uint64) if t == ORC_I128 else np.zeros(0, _NP[t])
+    if t == ORC_I128:
+        return np.frombuffer(buf, dtype=np.uint64, count=2 * n).reshape(n, 2)
+    return np.frombuffer(buf, dtype=_NP[t], count=n)
+
+
+class _ColHolder:
+    """keeps numpy/arrow buffers alive while the C struct points at them"""
+
+    def __init__(self, arr):
+        arr = _flat(arr)
+        self.arr = arr
+        self.values = np.ascontiguousarray(values_np(arr))
+        vb = arr.buffers()[0] if arr.null_count else None
+        self.valid = np.frombuffer(vb, dtype=np.uint8).copy() if vb is not None else None
+        self.c = OrcCol(orc_type(arr.type), 0, len(arr), self.values.ctypes.data if self.values.size else 0,
+                        self.valid.ctypes.data if self.valid is not None else 0)
+
+
+def _cols(arrs):
+    holders = [_ColHolder(a) for a in arrs]
+    carr = (OrcCol * len(holders))(*[h.c for h in holders])
+    return holders, carr
+
+
+def _from_values(values: np.ndarray, typ: pa.DataType, valid: np.ndarray | None = None) -> pa.Array:
+    """numpy raw values (+ optional bool validity) -> pyarrow array of `typ`."""
+    n = values.shape[0]
+    data = pa.py_buffer(np.ascontiguousarray(values).tobytes())
+    vbuf = None
+    nulls = 0
+    if valid is not None and not valid.all():
+        vbuf = pa.py_buffer(np.packbits(valid.astype(np.uint8), bitorder="little").tobytes())
+        nulls = int(n - valid.sum())
+    return pa.Array.from_buffers(typ, n, [vbuf, data], null_count=nulls)
+
+
+def take(table: pa.Table, idx: np.ndarray) -> pa.Table:
+    """arrow `take` with -1 = NULL row (joins/utils.rs:1332-1386 build_batch_from_indices)."""
+    ind = pa.array(idx, type=pa.int64(), mask=(idx < 0))
+    return pa.Table.from_arrays([_flat(table.column(i)).take(ind) for i in range(table.num_columns)],
+                                schema=table.schema)
+
+
+# ----------------------------------------------------------------------------- join
+
+def hash_join(left: pa.Table, right: pa.Table, on, join_type="Inner", null_equality="NullEqualsNothing",
+              mode=0, small_build_threshold=1024, min_key_density=0.15, return_indices=False):
+    """HashJoinExec: left = build side, right = probe side (hash_join/exec.rs:752).
+    Output schema = left columns ++ right columns (Inner/Left/Right/Full), left only for
+    Left{Semi,Anti}, right only for Right{Semi,Anti}, + `mark` for *Mark joins
+    (joins/utils.rs:build_join_schema)."""
+    L = lib()
+    bh, bk = _cols([left.column(l) for l, _ in on])
+    ph, pk = _cols([right.column(r) for _, r in on])
+    ob, op_, om = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_uint8)()
+    n = C.c_int64()
+    used = C.c_int()
+    jt = JOIN_TYPES[join_type]
+    rc = L.orc_hash_join(bk, pk, len(on), jt, NULL_EQUALITY[null_equality], mode,
+                         C.c_int64(small_build_threshold), C.c_double(min_key_density),
+                         C.byref(ob), C.byref(op_), C.byref(om), C.byref(n), C.byref(used))
+    if rc != 0:
+        raise RuntimeError(f"orc_hash_join rc={rc}")
+    cnt = n.value
+    bi = np.ctypeslib.as_array(ob, shape=(cnt,)).copy() if cnt else np.zeros(0, np.int64)
+    pi = np.ctypeslib.as_array(op_, shape=(cnt,)).copy() if cnt else np.zeros(0, np.int64)
+    mk = np.ctypeslib.as_array(om, shape=(cnt,)).copy().astype(bool) if (cnt and om) else np.zeros(0, bool)
+    for p in (ob, op_, om):
+        if p:
+            L.orc_free(p)
+    if return_indices:
+        return bi, pi, mk, bool(used.value)
+    if join_type in ("Inner", "Left", "Right", "Full"):
+        lt, rt = take(left, bi), take(right, pi)
+        names = [f.name for f in left.schema] + [f.name for f in right.schema]
+        out = pa.Table.from_arrays(list(lt.columns) + list(rt.columns), names=names)
+    elif join_type in ("LeftSemi", "LeftAnti"):
+        out = take(left, bi)
+    elif join_type in ("RightSemi", "RightAnti"):
+        out = take(right, pi)
+    elif join_type == "LeftMark":
+        out = take(left, bi).append_column("mark", pa.array(mk))
+    else:
+        out = take(right, pi).append_column("mark", pa.array(mk))
+    return out
+
+
+def partitioned_inner_join_i64(build_keys: np.ndarray, probe_keys: np.ndarray, nthreads: int):
+    """CPU-baseline leg: RepartitionExec(Hash) x2 -> HashJoinExec(Partitioned); returns (pairs, checksum)."""
+    L = lib()
+    b = np.ascontiguousarray(build_keys, dtype=np.int64)
+    p = np.ascontiguousarray(probe_keys, dtype=np.int64)
+    pairs, chk = C.c_int64(), C.c_uint64()
+    L.orc_partitioned_inner_join_i64(C.c_void_p(b.ctypes.data), C.c_int64(len(b)), C.c_void_p(p.ctypes.data),
+                                     C.c_int64(len(p)), nthreads, C.byref(pairs), C.byref(chk))
+    return pairs.value, chk.value
+
+
+# ---------------------------------------------------------------------- expressions
+
+def _decimal_unscaled(v, scale: int) -> int:
+    return int(Decimal(str(v)).scaleb(scale).to_integral_value())
+
+
+def _i128_np(ints) -> np.ndarray:
+    out = np.zeros((len(ints), 2), np.uint64)
+    for i, v in enumerate(ints):
+        v &= (1 << 128) - 1
+        out[i, 0] = v & 0xFFFFFFFFFFFFFFFF
+        out[i, 1] = v >> 64
+    return out
+
+
+def _lit_values(value, typ: pa.DataType) -> np.ndarray:
+    t = orc_type(typ)
+    if t == ORC_I128:
+        return _i128_np([_decimal_unscaled(value, typ.scale)])
+    if pa.types.is_date32(typ) and not isinstance(value, (int, np.integer)):
+        value = pa.scalar(value, type=pa.date32()).cast(pa.int32()).as_py()
+    return np.array([value], dtype=_NP[t])
+
+
+def _clamp_dec(p, s):
+    return pa.decimal128(min(38, p), min(38, s))
+
+
+def arith_result_type(op: str, lt: pa.DataType, rt: pa.DataType) -> pa.DataType:
+    """arrow-arith decimal result typing as relied on by BinaryExpr (expr-common/src/
+    type_coercion/binary.rs:168-186): add/sub -> scale max(s1,s2), precision
+    max(s1,s2)+max(p1-s1,p2-s2)+1; mul -> (p1+p2+1, s1+s2); both clamped to 38 (arrow-rs
+    clamps, it does not raise).  Golden: tpch/plans/q1.slt.part:45-46, answers q1:42-45."""
+    if pa.types.is_decimal128(lt) and pa.types.is_decimal128(rt):
+        p1, s1, p2, s2 = lt.precision, lt.scale, rt.precision, rt.scale
+        if op in "+-":
+            s = max(s1, s2)
+            return _clamp_dec(s + max(p1 - s1, p2 - s2) + 1, s)
+        if op == "*":
+            return _clamp_dec(p1 + p2 + 1, s1 + s2)
+    if lt != rt:
+        raise TypeError(f"oracle arith: operand types differ {lt} vs {rt} (planner inserts casts)")
+    return lt
+
+
+class Datum:
+    """ColumnarValue (physical-expr-common): array or scalar + validity"""
+
+    def __init__(self, values, typ, valid=None, scalar=False):
+        self.values, self.typ, self.valid, self.scalar = values, typ, valid, scalar
+
+    def to_array(self, n) -> pa.Array:
+        vals, valid = self.values, self.valid
+        if self.scalar:
+            vals = np.repeat(vals, n, axis=0)
+            valid = None if valid is None else np.repeat(valid, n)
+        if pa.types.is_boolean(self.typ):
+            return pa.array(vals.astype(bool), mask=None if valid is None else ~valid)
+        return _from_values(vals, self.typ, valid)
+
+
+def _and_valid(a, b, n):
+    def ex(d):
+        if d.valid is None:
+            return None
+        return np.repeat(d.valid, n) if d.scalar else d.valid
+    va, vb = ex(a), ex(b)
+    if va is None:
+        return vb
+    if vb is None:
+        return va
+    return va & vb
+
+
+def evaluate(expr, table: pa.Table) -> Datum:
+    """PhysicalExpr::evaluate (physical-expr-common/src/physical_expr.rs:88) for the node
+    kinds on the hot path (Column column.rs:121, Literal, CastExpr, BinaryExpr
+    binary.rs:536-656, IsNull, Not)."""
+    L = lib()
+    n = table.num_rows
+    kind = expr[0]
+    if kind == "col":
+        arr = _flat(table.column(expr[1]))
+        if pa.types.is_boolean(arr.type):
+            vals = np.asarray(arr.fill_null(False).to_numpy(zero_copy_only=False), dtype=bool)
+            valid = None if arr.null_count == 0 else ~np.asarray(arr.is_null().to_numpy(zero_copy_only=False))
+            return Datum(vals, arr.type, valid)
+        valid = None
+        if arr.null_count:
+            valid = ~np.asarray(arr.is_null().to_numpy(zero_copy_only=False))
+        return Datum(values_np(arr), arr.type, valid)
+    if kind == "lit":
+        _, value, typ = expr
+        if value is None:
+            t = orc_type(typ)
+            z = np.zeros((1, 2), np.uint64) if t == ORC_I128 else np.zeros(1, _NP[t])
+            return Datum(z, typ, np.array([False]), scalar=True)
+        if pa.types.is_boolean(typ):
+            return Datum(np.array([bool(value)]), typ, None, scalar=True)
+        return Datum(_lit_values(value, typ), typ, None, scalar=True)
+    if kind == "cast":
+        d = evaluate(expr[1], table)
+        to = expr[2]
+        src, dst = orc_type(d.typ), orc_type(to)
+        m = d.values.shape[0]
+        if dst == ORC_I128:
+            out = np.zeros((m, 2), np.uint64)
+            L.orc_cast_to_i128(src, C.c_void_p(np.ascontiguousarray(d.values).ctypes.data), C.c_int64(m), C.c_void_p(out.ctypes.data))
+            from_scale = d.typ.scale if pa.types.is_decimal128(d.typ) else 0
+            if to.scale > from_scale:
+                out2 = np.zeros_like(out)
+                L.orc_decimal_rescale_up(C.c_void_p(out.ctypes.data), C.c_int64(m), to.scale - from_scale, C.c_void_p(out2.ctypes.data))
+                out = out2
+            elif to.scale < from_scale:
+                raise NotImplementedError("oracle: decimal scale-down cast")
+            return Datum(out, to, d.valid, d.scalar)
+        if dst == ORC_F64 and src in (ORC_I32, ORC_I64):
+            return Datum(d.values.astype(np.float64), to, d.valid, d.scalar)
+        if dst == ORC_I64 and src == ORC_I32:
+            return Datum(d.values.astype(np.int64), to, d.valid, d.scalar)
+        if dst == src:
+            return Datum(d.values, to, d.valid, d.scalar)
+        raise NotImplementedError(f"oracle cast {d.typ} -> {to}")
+    if kind == "is_null":
+        d = evaluate(expr[1], table)
+        m = 1 if d.scalar else n
+        v = np.zeros(m, bool) if d.valid is None else ~d.valid
+        return Datum(v, pa.bool_(), None, d.scalar)
+    if kind == "not":
+        d = evaluate(expr[1], table)
+        return Datum(~d.values.astype(bool), pa.bool_(), d.valid, d.scalar)
+    if kind == "bin":
+        _, op, le, re_ = expr
+        a, b = evaluate(le, table), evaluate(re_, table)
+        if op in ("and", "or"):
+            # Kleene logic (arrow and_kleene / or_kleene, binary.rs:543-603)
+            av = np.repeat(a.values, n) if a.scalar else a.values
+            bv = np.repeat(b.values, n) if b.scalar else b.values
+            avd = np.ones(n, bool) if a.valid is None else (np.repeat(a.valid, n) if a.scalar else a.valid)
+            bvd = np.ones(n, bool) if b.valid is None else (np.repeat(b.valid, n) if b.scalar else b.valid)
+            at, bt = av.astype(bool) & avd, bv.astype(bool) & bvd
+            af, bf = (~av.astype(bool)) & avd, (~bv.astype(bool)) & bvd
+            if op == "and":
+                val, valid = at & bt, (at & bt) | af | bf
+            else:
+                val, valid = at | bt, at | bt | (af & bf)
+            return Datum(val, pa.bool_(), None if valid.all() else valid)
+        scalar = a.scalar and b.scalar
+        m = 1 if scalar else n
+        valid = _and_valid(a, b, m) if not scalar else (None if (a.valid is None and b.valid is None) else
+                                                         np.array([bool((a.valid is None or a.valid[0]) and (b.valid is None or b.valid[0]))]))
+        if op in ("+", "-", "*"):
+            rt = arith_result_type(op, a.typ, b.typ)
+            av, bv = a, b
+            if pa.types.is_decimal128(rt) and op in "+-":
+                # arrow-arith rescales both sides to the result scale before add/sub
+                av = _rescale(a, rt.scale)
+                bv = _rescale(b, rt.scale)
+            t = orc_type(rt)
+            out = np.zeros((m, 2), np.uint64) if t == ORC_I128 else np.zeros(m, _NP[t])
+            x, y = np.ascontiguousarray(av.values), np.ascontiguousarray(bv.values)
+            rc = L.orc_arith({"+": 0, "-": 1, "*": 2}[op], t, C.c_void_p(x.ctypes.data), int(av.scalar and not scalar),
+                             C.c_void_p(y.ctypes.data), int(bv.scalar and not scalar), C.c_int64(m), C.c_void_p(out.ctypes.data))
+            assert rc == 0
+            return Datum(out, rt, valid, scalar)
+        ops = {"=": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5}
+        if op in ops:
+            av, bv = a, b
+            if pa.types.is_decimal128(a.typ) and pa.types.is_decimal128(b.typ) and a.typ.scale != b.typ.scale:
+                s = max(a.typ.scale, b.typ.scale)
+                av, bv = _rescale(a, s), _rescale(b, s)
+            elif orc_type(a.typ) != orc_type(b.typ):
+                raise TypeError(f"oracle cmp: {a.typ} vs {b.typ}")
+            bits = np.zeros((m + 7) // 8, np.uint8)
+            x, y = np.ascontiguousarray(av.values), np.ascontiguousarray(bv.values)
+            rc = L.orc_cmp(ops[op], orc_type(av.typ), C.c_void_p(x.ctypes.data), int(av.scalar and not scalar),
+                           C.c_void_p(y.ctypes.data), int(bv.scalar and not scalar), C.c_int64(m), C.c_void_p(bits.ctypes.data))
+            assert rc == 0
+            vals = np.unpackbits(bits, bitorder="little")[:m].astype(bool)
+            return Datum(vals, pa.bool_(), valid, scalar)
+    raise NotImplementedError(f"oracle expr {expr!r}")
+
+
+def _rescale(d: Datum, scale: int) -> Datum:
+    if d.typ.scale == scale:
+        return d
+    L = lib()
+    m = d.values.shape[0]
+    out = np.zeros((m, 2), np.uint64)
+    L.orc_decimal_rescale_up(C.c_void_p(np.ascontiguousarray(d.values).ctypes.data), C.c_int64(m), scale - d.typ.scale,
+                             C.c_void_p(out.ctypes.data))
+    return Datum(out, pa.decimal128(min(38, d.typ.precision + scale - d.typ.scale), scale), d.valid, d.scalar)
+
+
+def project(table: pa.Table, exprs) -> pa.Table:
+    """ProjectionExec (projection.rs:713-740): exprs = [(expr, name)]"""
+    n = table.num_rows
+    return pa.Table.from_arrays([evaluate(e, table).to_array(n) for e, _ in exprs], names=[nm for _, nm in exprs])
+
+
+def filter(table: pa.Table, predicate, projection=None) -> pa.Table:
+    """FilterExec (filter.rs:1367-1444): evaluate predicate, optional embedded projection
+    (column indices/names), filter_record_batch; NULL predicate rows are dropped."""
+    L = lib()
+    n = table.num_rows
+    d = evaluate(predicate, table)
+    mask = d.values.astype(bool)
+    valid = d.valid
+    if d.scalar:
+        mask = np.repeat(mask, n)
+        valid = None if valid is None else np.repeat(valid, n)
+    bits = np.packbits(mask.astype(np.uint8), bitorder="little")
+    vbits = None if valid is None else np.packbits(valid.astype(np.uint8), bitorder="little")
+    idx = np.zeros(max(n, 1), np.int64)
+    if bits.size == 0:
+        bits = np.zeros(1, np.uint8)
+    k = L.orc_filter_indices(C.c_void_p(bits.ctypes.data), C.c_void_p(vbits.ctypes.data) if vbits is not None else None,
+                             C.c_int64(n), C.c_void_p(idx.ctypes.data))
+    if projection is not None:
+        table = table.select(projection)
+    return take(table, idx[:k])
+
+
+# ------------------------------------------------------------------------ aggregate
+
+def sum_result_type(t: pa.DataType) -> pa.DataType:
+    """SUM(Decimal128(p,s)) -> Decimal128(min(38,p+10), s) (functions-aggregate/src/sum.rs:232-260)"""
+    if pa.types.is_decimal128(t):
+        return pa.decimal128(min(38, t.precision + 10), t.scale)
+    if pa.types.is_int32(t) or pa.types.is_int64(t):
+        return pa.int64()
+    return t
+
+
+def avg_result_type(t: pa.DataType) -> pa.DataType:
+    """AVG(Decimal128(p,s)) -> Decimal128(min(38,p+4), min(38,s+4)) (average.rs:219-252)"""
+    if pa.types.is_decimal128(t):
+        return pa.decimal128(min(38, t.precision + 4), min(38, t.scale + 4))
+    return pa.float64()
+
+
+def aggregate(table: pa.Table, group_by, aggs) -> pa.Table:
+    """AggregateExec mode=Single (aggregates/mod.rs:839, aggregate_hash_table/common.rs:205-300).
+    group_by = [(expr, name)], aggs = [(func, expr_or_None, name)] with func in
+    sum/avg/count/min/max.  Output = group columns ++ aggregate columns, groups in first-seen
+    order."""
+    L = lib()
+    n = table.num_rows
+    key_arrs = [evaluate(e, table).to_array(n) for e, _ in group_by]
+    if key_arrs:
+        kh, kc = _cols(key_arrs)
+        gids = np.zeros(max(n, 1), np.int64)
+        first = np.zeros(max(n, 1), np.int64)
+        ng = L.orc_group_intern(kc, len(key_arrs), C.c_int64(n), C.c_void_p(gids.ctypes.data), C.c_void_p(first.ctypes.data))
+        first = first[:ng]
+    else:
+        # no GROUP BY -> AggregateStream: exactly one output row even for empty input
+        ng, gids, first = 1, np.zeros(max(n, 1), np.int64), np.zeros(0, np.int64)
+    out_cols, names = [], []
+    for (e, nm), arr in zip(group_by, key_arrs):
+        out_cols.append(arr.take(pa.array(first, type=pa.int64())))
+        names.append(nm)
+    for func, e, nm in aggs:
+        if func == "count" and e is None:
+            varr = pa.array(np.zeros(n, np.int64))  # COUNT(*) counts rows
+        else:
+            varr = evaluate(e, table).to_array(n)
+        if pa.types.is_int32(varr.type) and func in ("sum", "avg"):
+            varr = varr.cast(pa.int64())
+        vh, vc = _cols([varr])
+        t = orc_type(varr.type)
+        seen = np.zeros(max(ng, 1), np.uint8)
+
+        def acc(op, out):
+            rc = L.orc_accumulate(op, C.byref(vc[0]), C.c_void_p(gids.ctypes.data), C.c_int64(ng), None,
+                                  C.c_void_p(out.ctypes.data), C.c_void_p(seen.ctypes.data))
+            assert rc == 0
+            return out
+
+        def zeros(tt):
+            return np.zeros((max(ng, 1), 2), np.uint64) if tt == ORC_I128 else np.zeros(max(ng, 1), _NP[tt])
+
+        if func == "count":
+            cnt = acc(3, np.zeros(max(ng, 1), np.int64))
+            out_cols.append(pa.array(cnt[:ng], type=pa.int64()))
+        elif func in ("sum", "min", "max"):
+            vals = acc({"sum": 0, "min": 1, "max": 2}[func], zeros(t))
+            rt = sum_result_type(varr.type) if func == "sum" else varr.type
+            out_cols.append(_from_values(vals[:ng], rt, seen[:ng].astype(bool)))
+        elif func == "avg":
+            sums = acc(0, zeros(t))
+            valid = seen[:ng].astype(bool).copy()
+            cnt = acc(3, np.zeros(max(ng, 1), np.int64))
+            rt = avg_result_type(varr.type)
+            if t == ORC_I128:
+                # AvgGroupsAccumulator<Decimal128> (average.rs:934-960) + DecimalAverager
+                st = sum_result_type(varr.type)
+                outv = np.zeros((max(ng, 1), 2), np.uint64)
+                rc = L.orc_decimal_avg(C.c_void_p(sums.ctypes.data), C.c_void_p(cnt.ctypes.data), C.c_int64(ng), st.scale, rt.scale,
+                                       C.c_void_p(outv.ctypes.data))
+                if rc != 0:
+                    raise ArithmeticError("Arithmetic Overflow in AvgAccumulator")
+                out_cols.append(_from_values(outv[:ng], rt, valid))
+            else:
+                s = sums.astype(np.float64)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    av = s[:ng] / cnt[:ng].astype(np.float64)  # sum / count as f64 (average.rs:374-395)
+                out_cols.append(_from_values(np.where(valid, av, 0.0), pa.float64(), valid))
+        else:
+            raise NotImplementedError(func)
+        names.append(nm)
+    return pa.Table.from_arrays(out_cols, names=names)
+
+
+# ---------------------------------------------------------------- repartition / sort
+
+def create_hashes(arrs, seed: int) -> np.ndarray:
+    L = lib()
+    h, c = _cols(arrs)
+    n = len(h[0].arr)
+    out = np.zeros(max(n, 1), np.uint64)
+    L.orc_create_hashes(c, len(arrs), C.c_int64(n), C.c_uint64(seed), C.c_void_p(out.ctypes.data))
+    return out[:n]
+
+
+def hash_partition(table: pa.Table, key_names, nparts: int):
+    """RepartitionExec Hash (repartition/mod.rs:1111-1150) -> list of nparts Tables, input
+    order preserved inside each partition."""
+    L = lib()
+    n = table.num_rows
+    h, c = _cols([table.column(k) for k in key_names])
+    part = np.zeros(max(n, 1), np.uint32)
+    L.orc_hash_partition(c, len(key_names), C.c_int64(n), nparts, C.c_void_p(part.ctypes.data))
+    part = part[:n]
+    return [take(table, np.nonzero(part == p)[0].astype(np.int64)) for p in range(nparts)], part
+
+
+def sort(table: pa.Table, keys, fetch=None) -> pa.Table:
+    """SortExec (sorts/sort.rs:1366): keys = [(name, descending, nulls_first)], optional
+    fetch = TopK (topk/mod.rs:397)."""
+    L = lib()
+    n = table.num_rows
+    h, c = _cols([table.column(k) for k, _, _ in keys])
+    desc = np.array([int(d) for _, d, _ in keys], np.uint8)
+    nf = np.array([int(f) for _, _, f in keys], np.uint8)
+    idx = np.zeros(max(n, 1), np.int64)
+    L.orc_lexsort(c, C.c_void_p(desc.ctypes.data), C.c_void_p(nf.ctypes.data), len(keys), C.c_int64(n), C.c_void_p(idx.ctypes.data))
+    idx = idx[:n]
+    if fetch is not None:
+        idx = idx[:fetch]
+    return take(table, idx)
