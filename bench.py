@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric: rows/sec + GB/s HBM of the TPC-H Q3 hash join
+(orders ⋈ lineitem on orderkey, Q3 payload projection) at SF100 on 1/2/4/8 MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one full pass of the hot path over device-resident inputs:
+  N = 1 : HashJoinExec build (collect_left_input) + probe (whole lineitem) -> output table.
+  N > 1 : each rank holds a 1/N row range of both tables (what N scans would produce),
+          RepartitionExec(Hash) on the join key = K10 partition kernel + RCCL all-to-all,
+          then the local build + probe.  Total work is fixed (SF100) => "strong" scaling.
+value = (build rows + probe rows summed over ranks) / max-over-ranks wall time of the K steps.
+Inputs are generated on device (no dataset download possible) before the timed region.
+
+Extra objects on the JSON line:
+  roofline     — dominant kernel (join_probe_materialize): algorithmic bytes per launch /
+                 average launch duration measured with HIP events on the library stream,
+                 against the 8.0 TB/s HBM3E spec peak.
+  cpu_baseline — the CPU restatement (oracle/, kind "port") of DataFusion's partitioned hash
+                 join, timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+BUILD_COLS = ["o_orderdate", "o_shippriority"]
+PROBE_COLS = ["l_orderkey", "l_extendedprice", "l_discount"]
+
+
+def algorithmic_bytes(nb, np_, nout):
+    """read each referenced input column once + write the output once:
+    build {o_orderkey 8, o_orderdate 4, o_shippriority 4} = 16 B/row, probe {l_orderkey 8,
+    l_extendedprice 16, l_discount 16} = 40 B/row, output 48 B/row"""
+    return nb * 16 + np_ * 40 + nout * 48
+
+
+def cpu_baseline(sample_sf, threads):
+    """oracle leg: RepartitionExec(Hash) x2 -> HashJoinExec(Partitioned), one thread per partition"""
+    import numpy as np
+
+    from datafusion_amd import tpch
+    from oracle import oracle
+    i = np.arange(tpch.n_orders(sample_sf), dtype=np.int64)
+    bk = tpch.order_key(i)
+    pk = np.repeat(bk, tpch.line_count(i))
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        pairs, _chk = oracle.partitioned_inner_join_i64(bk, pk, threads)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    assert pairs == len(pk)
+    return {"value": (len(bk) + len(pk)) / best, "unit": "rows/s", "cores": threads, "kind": "port",
+            "sample": f"orders x lineitem keys at SF{sample_sf:g} ({len(bk)} build + {len(pk)} probe rows), "
+                      f"{threads} partitions/threads, 8192-row probe batches, key-only pairs (no payload gather)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor (BASELINE: 100)")
+    ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from datafusion_amd import _lib, ops
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    _lib.init(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from datafusion_amd import tpch
+    n_orders = tpch.n_orders(args.sf)
+    b, e = n_orders * rank // world, n_orders * (rank + 1) // world
+    orders = ops.tpch_orders(args.sf, b, e).select(["o_orderkey", "o_orderdate", "o_shippriority"])
+    lineitem = ops.tpch_lineitem(args.sf, b, e).select(["l_orderkey", "l_extendedprice", "l_discount"])
+    nb_local, np_local = orders.num_rows, lineitem.num_rows
+    ops.sync()
+
+    def step():
+        o, l = orders, lineitem
+        if world > 1:
+            from datafusion_amd.exchange import hash_exchange
+            o = hash_exchange(orders, ["o_orderkey"])
+            l = hash_exchange(lineitem, ["l_orderkey"])
+        ht = ops.JoinHashTable(o, ["o_orderkey"])
+        out = ht.probe(l, ["l_orderkey"], "Inner", BUILD_COLS, PROBE_COLS)
+        n_out = out.num_rows
+        info = ht.info()
+        out.free()
+        ht.free()
+        if world > 1:
+            o.free()
+            l.free()
+        return n_out, info
+
+    def barrier():
+        ops.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ops.profile_enable(True)
+    ops.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    n_out = 0
+    for _ in range(args.steps):
+        n_out, info = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+
+    tot = torch.tensor([float(nb_local), float(np_local), float(n_out), dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(mx[3])
+    nb, np_, nout = int(tot[0]), int(tot[1]), int(tot[2])
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        rows_per_s = (nb + np_) / (dt / args.steps)
+        alg = algorithmic_bytes(nb, np_, nout)
+        dom = stats.get("join_probe_materialize", {"calls": 0, "total_ms": 0.0, "bytes": 0})
+        roof = None
+        if dom["calls"]:
+            avg_ms = dom["total_ms"] / dom["calls"]
+            per_launch = dom["bytes"] / dom["calls"]
+            achieved = per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "join_probe_materialize", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
+        kernels = {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in stats.items()}
+        line = {
+            "metric": "tpch_q3_hash_join_rows_per_sec", "value": rows_per_s, "unit": "rows/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int64 keys / decimal128 payload", "data": "synthetic",
+            "config": {"workload": f"INNER hash-join orders⋈lineitem on o_orderkey, TPC-H SF{args.sf:g}, Q3 payload "
+                                   "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
+                       "build_rows": nb, "probe_rows": np_, "output_rows": nout,
+                       "join_table": "array_map" if info.used_array_map else "hash_map",
+                       "parallelism": "single GPU" if world == 1 else f"hash-repartition all-to-all x{world}"},
+            "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),
+            "hbm_frac_whole_step": round(alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "roofline": roof, "kernels": kernels,
+        }
+        if not args.no_cpu:
+            threads = os.cpu_count() or 1
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sf, threads)
+            line["speedup_vs_cpu_port"] = round(rows_per_s / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

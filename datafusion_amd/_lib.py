@@ -1,0 +1,107 @@
+"""ctypes binding of libdfgpu.so (include/dfgpu.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing the
+import fails loudly; if no MI355X is visible `dfgpu_init` fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfgpu.so")
+
+
+class DfgpuError(RuntimeError):
+    """DataFusionError::External equivalent raised for any non-zero return code."""
+
+
+class Field(C.Structure):
+    _fields_ = [("type", C.c_int32), ("precision", C.c_int32), ("scale", C.c_int32), ("nullable", C.c_int32)]
+
+
+class ColumnView(C.Structure):
+    _fields_ = [("field", Field), ("length", C.c_int64), ("null_count", C.c_int64), ("data", C.c_void_p),
+                ("validity", C.c_void_p), ("name", C.c_char_p)]
+
+
+class ExprNode(C.Structure):
+    _fields_ = [("op", C.c_int32), ("column", C.c_int32), ("left", C.c_int32), ("right", C.c_int32),
+                ("field", Field), ("is_null", C.c_int32), ("_pad", C.c_int32), ("lit_lo", C.c_uint64),
+                ("lit_hi", C.c_uint64)]
+
+
+class Expr(C.Structure):
+    _fields_ = [("nodes", C.POINTER(ExprNode)), ("n_nodes", C.c_int32), ("root", C.c_int32)]
+
+
+class JoinOptions(C.Structure):
+    _fields_ = [("perfect_hash_join_small_build_threshold", C.c_int64),
+                ("perfect_hash_join_min_key_density", C.c_double), ("table_mode", C.c_int32),
+                ("force_hash_collisions", C.c_int32)]
+
+
+class JoinInfo(C.Structure):
+    _fields_ = [("build_rows", C.c_int64), ("table_bytes", C.c_int64), ("used_array_map", C.c_int32),
+                ("build_keys_unique", C.c_int32), ("probe_rows", C.c_int64), ("output_rows", C.c_int64)]
+
+
+class AggSpec(C.Structure):
+    _fields_ = [("func", C.c_int32), ("has_arg", C.c_int32), ("arg", Expr), ("name", C.c_char_p)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("calls", C.c_int64), ("total_ms", C.c_double),
+                ("algorithmic_bytes", C.c_int64)]
+
+
+# every symbol include/dfgpu.h declares (tests/test_abi.py checks the library exports them all)
+SYMBOLS = [
+    "dfgpu_abi_version", "dfgpu_init", "dfgpu_shutdown", "dfgpu_device_count", "dfgpu_last_error", "dfgpu_sync",
+    "dfgpu_stream", "dfgpu_mem_stats", "dfgpu_mem_trim", "dfgpu_table_import", "dfgpu_table_export",
+    "dfgpu_table_alloc", "dfgpu_table_free", "dfgpu_table_num_rows", "dfgpu_table_num_columns", "dfgpu_table_column",
+    "dfgpu_table_select", "dfgpu_table_hstack", "dfgpu_table_concat", "dfgpu_table_slice", "dfgpu_expr_type",
+    "dfgpu_filter", "dfgpu_project", "dfgpu_join_build", "dfgpu_join_probe", "dfgpu_join_emit_unmatched",
+    "dfgpu_join_get_info", "dfgpu_join_free", "dfgpu_agg_create", "dfgpu_agg_update", "dfgpu_agg_emit",
+    "dfgpu_agg_free", "dfgpu_sort", "dfgpu_partition", "dfgpu_hash_columns", "dfgpu_tpch_orders",
+    "dfgpu_tpch_lineitem", "dfgpu_tpch_customer", "dfgpu_profile_enable", "dfgpu_profile_reset",
+    "dfgpu_profile_count", "dfgpu_profile_get",
+]
+
+_lib = None
+_initialised_device = None
+
+
+def load() -> C.CDLL:
+    """dlopen libdfgpu.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C datafusion_amd/csrc` "
+                "(or __graft_entry__.build()). There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.dfgpu_last_error.restype = C.c_char_p
+        _lib.dfgpu_stream.restype = C.c_void_p
+        for name in SYMBOLS:
+            getattr(_lib, name)  # AttributeError here = header/library mismatch
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise DfgpuError(load().dfgpu_last_error().decode("utf-8", "replace"))
+
+
+def init(device: int | None = None) -> C.CDLL:
+    """bind this process to one GPU (LOCAL_RANK under torchrun, else 0)"""
+    global _initialised_device
+    lib = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if _initialised_device is None:
+        check(lib.dfgpu_init(device))
+        _initialised_device = device
+    elif _initialised_device != device:
+        raise DfgpuError(f"already bound to device {_initialised_device}")
+    return lib

@@ -1,0 +1,128 @@
+// device.hpp — CDNA4 (gfx950, wave64) device-side helpers shared by all kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfgpu {
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;  // 4 waves: one per SIMD
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+
+// number of set bits of `mask` strictly below this lane (v_mbcnt_lo/hi)
+__device__ __forceinline__ unsigned mbcnt(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+
+// inclusive wave scan (64 lanes) via DPP-lowered shuffles
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_sum(T v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    if ((int)lane_id() >= d) v += o;
+  }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ----------------------------------------------------------------------------- hashing
+// Same mixer as oracle/dforacle.c (murmur3 fmix64).  The reference hashes with foldhash
+// (common/src/hash_utils.rs:27,41) whose values are unpinned by any reference test.
+__host__ __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+__host__ __device__ __forceinline__ uint64_t hash_u64(uint64_t v, uint64_t seed) {
+  return fmix64(v ^ seed ^ 0x9E3779B97F4A7C15ULL);
+}
+constexpr uint64_t SEED_JOIN = 0xA98409FE2C1A0E6CULL;         // HASH_JOIN_SEED analogue (hash_join/exec.rs:105)
+constexpr uint64_t SEED_AGG = 0x51D7348D9B2F63A5ULL;          // AGGREGATION_HASH_SEED analogue (aggregates/mod.rs:236)
+constexpr uint64_t SEED_REPARTITION = 0ULL;                   // REPARTITION_RANDOM_STATE (repartition/mod.rs:650)
+
+// ------------------------------------------------------------------------- key columns
+// A key column as seen by hashing / equality kernels.
+struct KeyCol {
+  const void* data;
+  const uint64_t* valid;  // may be null
+  int32_t type;           // dfgpu_type
+  int32_t width;          // bytes
+};
+constexpr int MAX_KEYS = 8;
+struct KeySet {
+  KeyCol c[MAX_KEYS];
+  int n;
+};
+
+__device__ __forceinline__ bool bit_at(const uint64_t* words, int64_t i) { return (words[i >> 6] >> (i & 63)) & 1ull; }
+
+// value widened to (lo, hi): signed ints sign-extended, floats by bit pattern with
+// -0.0 -> +0.0 (hash_utils.rs:258-276)
+__device__ __forceinline__ void load_words(const KeyCol& k, int64_t i, uint64_t& lo, uint64_t& hi) {
+  hi = 0;
+  switch (k.type) {
+    case 1: case 8: lo = (uint64_t)(int64_t)((const int32_t*)k.data)[i]; break;  // INT32 / DATE32
+    case 6: lo = ((const uint32_t*)k.data)[i]; break;
+    case 2: case 7: lo = ((const uint64_t*)k.data)[i]; break;
+    case 4: { uint64_t b = ((const uint64_t*)k.data)[i]; lo = (b << 1) == 0 ? 0 : b; break; }
+    case 5: lo = ((const uint8_t*)k.data)[i]; break;
+    case 3: { const uint64_t* p = (const uint64_t*)k.data + 2 * i; lo = p[0]; hi = p[1]; break; }
+    default: lo = 0;
+  }
+}
+__device__ __forceinline__ uint64_t hash_value(const KeyCol& k, int64_t i, uint64_t seed) {
+  uint64_t lo, hi;
+  load_words(k, i, lo, hi);
+  uint64_t h = hash_u64(lo, seed);
+  if (k.type == 3) h = fmix64(hi ^ h);
+  return h;
+}
+// create_hashes semantics (hash_utils.rs:1239-1252): col 0 seeds with `seed`, col i>=1
+// re-seeds with the running hash; NULL leaves the running hash (initially 0) untouched.
+__device__ __forceinline__ uint64_t hash_row(const KeySet& ks, int64_t i, uint64_t seed, bool& any_null) {
+  uint64_t h = 0;
+  any_null = false;
+  for (int c = 0; c < ks.n; c++) {
+    if (ks.c[c].valid && !bit_at(ks.c[c].valid, i)) { any_null = true; continue; }
+    h = hash_value(ks.c[c], i, c == 0 ? seed : h);
+  }
+  return h;
+}
+// equal_rows_arr (joins/utils.rs:2191-2260)
+__device__ __forceinline__ bool keys_equal(const KeySet& a, int64_t ia, const KeySet& b, int64_t ib, bool null_equals_null) {
+  for (int c = 0; c < a.n; c++) {
+    bool va = !a.c[c].valid || bit_at(a.c[c].valid, ia);
+    bool vb = !b.c[c].valid || bit_at(b.c[c].valid, ib);
+    if (!va || !vb) {
+      if (null_equals_null && !va && !vb) continue;
+      return false;
+    }
+    uint64_t alo, ahi, blo, bhi;
+    load_words(a.c[c], ia, alo, ahi);
+    load_words(b.c[c], ib, blo, bhi);
+    if (alo != blo || ahi != bhi) return false;
+  }
+  return true;
+}
+
+// grid sizing for HBM-bound grid-stride kernels: enough workgroups to fill 256 CUs x 8
+inline int grid_for(int64_t work_items, int per_block) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 256 * 8) b = 256 * 8;
+  return (int)b;
+}
+
+}  // namespace dfgpu

@@ -1,0 +1,191 @@
+// internal.hpp — host-side plumbing shared by every translation unit of libdfgpu.so:
+// error channel, HBM pool allocator, stream, launch/profiling helpers, Column/Table.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dfgpu.h"
+
+namespace dfgpu {
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+void set_last_error(const std::string& msg);
+
+#define DFGPU_HIP(expr)                                                                         \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      throw ::dfgpu::Error(std::string("HIP error ") + hipGetErrorString(_e) + " at " #expr);  \
+  } while (0)
+
+#define DFGPU_CHECK(cond, msg)                     \
+  do {                                             \
+    if (!(cond)) throw ::dfgpu::Error(std::string(msg)); \
+  } while (0)
+
+// Wraps a C-ABI entry point body: exceptions -> error code + thread-local message.
+template <typename F>
+int guarded(F&& f) noexcept {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return 1;
+  } catch (...) {
+    set_last_error("unknown error");
+    return 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Runtime: one per process (one process per GPU).
+struct Runtime {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool initialised = false;
+  int num_cus = 256;
+
+  // pool allocator: size-bucketed free lists; blocks are reused in stream order (all work is
+  // enqueued on `stream`, so a block freed by the host after its last kernel was enqueued can
+  // be handed to the next kernel safely).
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;
+  std::map<void*, size_t> live;  // ptr -> capacity
+  int64_t in_use = 0, cached = 0, peak = 0;
+
+  void* alloc(size_t bytes);
+  void free(void* p);
+  void trim();
+
+  // profiling
+  bool profiling = false;
+  struct Rec {
+    std::string name;
+    hipEvent_t a, b;
+    int64_t bytes;
+  };
+  std::vector<Rec> recs;
+  std::vector<dfgpu_kernel_stat> stats;  // aggregated by collect()
+  void collect();
+};
+
+Runtime& rt();
+void require_init();
+
+// RAII event pair around a kernel launch when profiling is on.
+struct ProfileScope {
+  hipEvent_t a = nullptr, b = nullptr;
+  const char* name;
+  int64_t bytes;
+  ProfileScope(const char* name, int64_t algorithmic_bytes);
+  ~ProfileScope();
+};
+
+// Refcounted device buffer from the pool.
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  explicit DevBuf(size_t n);
+  ~DevBuf();
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+using BufPtr = std::shared_ptr<DevBuf>;
+inline BufPtr make_buf(size_t bytes) { return std::make_shared<DevBuf>(bytes ? bytes : 1); }
+BufPtr make_zero_buf(size_t bytes);
+
+// scratch helper for small host<->device scalars
+void d2h(void* dst, const void* src, size_t n);  // synchronous w.r.t. the library stream
+void h2d_async(void* dst, const void* src, size_t n);
+
+// ---------------------------------------------------------------------------------------
+inline int type_width(int t) {
+  switch (t) {
+    case DFGPU_INT32: case DFGPU_UINT32: case DFGPU_DATE32: return 4;
+    case DFGPU_INT64: case DFGPU_UINT64: case DFGPU_FLOAT64: return 8;
+    case DFGPU_DECIMAL128: return 16;
+    case DFGPU_UINT8: return 1;
+    case DFGPU_BOOL: return 0;  // bit-packed
+  }
+  throw Error("unknown dfgpu_type " + std::to_string(t));
+}
+inline size_t bitmap_bytes(int64_t n) { return (size_t)((n + 63) / 64) * 8; }  // padded to 64-bit words
+inline size_t data_bytes(int t, int64_t n) { return t == DFGPU_BOOL ? bitmap_bytes(n) : (size_t)n * type_width(t); }
+inline bool is_integer_like(int t) {
+  return t == DFGPU_INT32 || t == DFGPU_INT64 || t == DFGPU_UINT8 || t == DFGPU_UINT32 || t == DFGPU_UINT64 || t == DFGPU_DATE32;
+}
+inline bool is_signed_type(int t) { return t == DFGPU_INT32 || t == DFGPU_INT64 || t == DFGPU_DATE32 || t == DFGPU_DECIMAL128; }
+std::string type_name(const dfgpu_field& f);
+
+struct Column {
+  dfgpu_field field{};
+  std::string name;
+  int64_t length = 0;
+  int64_t null_count = 0;  // -1 = unknown (validity present, not counted)
+  BufPtr data;             // values (or bit-packed booleans), 64-bit word padded
+  size_t data_offset = 0;  // byte offset of row 0 inside `data` (partition outputs share one buffer)
+  BufPtr validity;         // optional bitmap, 64-bit word padded; nullptr = all valid
+
+  const void* ptr() const { return data ? (const char*)data->ptr + data_offset : nullptr; }
+  const uint64_t* valid_words() const { return validity ? validity->as<uint64_t>() : nullptr; }
+  bool has_nulls() const { return validity != nullptr; }
+};
+
+struct Table {
+  std::vector<Column> cols;
+  int64_t nrows = 0;
+};
+
+inline Table* unwrap(dfgpu_table_t t) {
+  DFGPU_CHECK(t != nullptr, "null table handle");
+  return reinterpret_cast<Table*>(t);
+}
+inline dfgpu_table_t wrap(Table* t) { return reinterpret_cast<dfgpu_table_t>(t); }
+
+Column alloc_column(const dfgpu_field& f, const std::string& name, int64_t n, bool with_validity = false);
+
+// ----------------------------------------------------------------- primitives (scan.hip)
+// exclusive prefix sum of popcount(mask_word & valid_word) per 64-row word -> u64 offsets
+// (ceil(nrows/64) + 1 entries; the last is the total). valid may be null.
+void scan_mask_popcounts(const uint64_t* mask, const uint64_t* valid, int64_t nrows, uint64_t* out_prefix);
+// exclusive prefix sum of u32 counts -> u64 (n + 1 entries)
+void scan_u32(const uint32_t* in, int64_t n, uint64_t* out_prefix);
+uint64_t read_u64(const uint64_t* dev);
+
+// ----------------------------------------------------------------- compaction (filter.hip)
+// out = rows of `in` whose mask bit (and mask_valid bit) is set, order preserved.
+Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_t* mask, const uint64_t* mask_valid);
+// take: out[i] = in[idx[i]] ; idx < 0 -> NULL.  idx is a device array of int64.
+Column gather_column(const Column& in, const int64_t* idx, int64_t n, bool idx_may_be_null);
+// clear bits beyond n in the last word of a bitmap (keeps padding deterministic)
+void count_nulls(Column& c);
+
+// ----------------------------------------------------------------- expressions (expr.hip)
+struct Datum {  // ColumnarValue: array or scalar
+  Column col;   // for scalars: length-1 column resident on device? no: host literal below
+  bool scalar = false;
+  bool scalar_null = false;
+  uint64_t lit_lo = 0, lit_hi = 0;  // scalar bits (sign-extended ints / f64 bits)
+};
+dfgpu_field expr_type(const dfgpu_expr& e, const Table& input);
+Datum evaluate(const dfgpu_expr& e, const Table& input);
+Column datum_to_column(const Datum& d, int64_t n, const std::string& name);
+
+// ----------------------------------------------------------------- hashing (partition.hip)
+void hash_columns(const std::vector<const Column*>& keys, int64_t n, uint64_t seed, uint64_t* out, bool force_collisions);
+
+}  // namespace dfgpu

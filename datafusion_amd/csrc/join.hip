@@ -1,0 +1,644 @@
+// join.hip — K1..K5: HashJoinExec build + probe on device.
+//
+// Build (collect_left_input, physical-plan/src/joins/hash_join/exec.rs:2569-2776):
+//   * direct-address table  = ArrayMap (joins/array_map.rs:103-236), chosen by the reference's
+//     own gating try_create_array_map (exec.rs:111-191): one integer key, range < threshold or
+//     rows/(range+1) > min density.  data[key-min] = row+1, duplicates chained through next[].
+//   * chained hash table    = JoinHashMap (joins/join_hash_map.rs:144-338): head[hash & mask] =
+//     row+1, next[row] = previous head.  Built with one atomicExch per row (no locks).
+//   NULL keys are not inserted under NullEqualsNothing (joins/utils.rs:2127-2164).
+// Probe (HashJoinStream::process_probe_batch, hash_join/stream.rs:740-1000), whole partition
+//   per call instead of 8192-row batches:
+//   pass 1: per probe row walk the chain, compare REAL keys (equal_rows_arr, joins/utils.rs:
+//           2191-2260 — K4 fused), produce a per-row output count; one wave64 = 64 rows, its
+//           total goes to a per-word count (ballot/popcount when counts are 0/1);
+//   scan  : exclusive prefix of the per-word counts (scan.hip);
+//   pass 2: emit.  Fast path (<=1 match per probe row: unique build keys, or semi/anti):
+//           pass 1 stored the matched build row per probe row; pass 2 is a fused
+//           compaction of the probe columns + gather of the build columns (K5) that writes
+//           output rows in probe order.  General M:N path: (build_idx, probe_idx) pairs, then
+//           arrow-`take`-style gathers (build_batch_from_indices, joins/utils.rs:1332-1386).
+// Output order = probe order, then chain order (unordered by contract for duplicates).
+#include "device.hpp"
+#include "internal.hpp"
+
+namespace dfgpu {
+
+Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_t* mask, const uint64_t* mask_valid);
+void pack_bytes_to_bitmap(const uint8_t* bytes, int64_t n, uint64_t* words);
+
+struct JoinTable {
+  Table build;
+  std::vector<int> key_cols;
+  int null_equality = 0;
+  bool array_map = false;
+  bool keys_unique = true;
+  bool force_collisions = false;
+  BufPtr heads;  // u32: ArrayMap data[] or hash heads[]
+  BufPtr next;   // u32 per build row (null when array_map && unique)
+  uint64_t am_offset = 0, am_size = 0;
+  uint64_t hash_mask = 0;
+  BufPtr visited;  // u8 per build row, lazily allocated
+  dfgpu_join_info info{};
+};
+
+struct ProbeCtx {
+  KeySet bkeys, pkeys;
+  const uint32_t* heads;
+  const uint32_t* next;
+  uint64_t am_offset, am_size, hash_mask;
+  int null_equals_null;
+  int force_collisions;
+};
+
+static KeySet make_keyset(const Table& t, const std::vector<int>& cols) {
+  KeySet ks{};
+  DFGPU_CHECK((int)cols.size() <= MAX_KEYS, "too many join key columns");
+  ks.n = (int)cols.size();
+  for (int i = 0; i < ks.n; i++) {
+    DFGPU_CHECK(cols[i] >= 0 && cols[i] < (int)t.cols.size(), "join key column index out of range");
+    const Column& c = t.cols[cols[i]];
+    DFGPU_CHECK(c.field.type != DFGPU_BOOL, "Boolean join keys are not supported on the GPU path");
+    ks.c[i] = KeyCol{c.ptr(), c.valid_words(), c.field.type, type_width(c.field.type)};
+  }
+  return ks;
+}
+
+// ------------------------------------------------------------------------ build kernels
+struct MinMax {
+  long long smin, smax;
+  unsigned long long valid;
+};
+__global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMax* out) {
+  long long mn = INT64_MAX, mx = INT64_MIN;
+  unsigned long long cnt = 0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (k.valid && !bit_at(k.valid, i)) continue;
+    uint64_t lo, hi;
+    load_words(k, i, lo, hi);
+    long long v = (long long)lo;
+    mn = v < mn ? v : mn;
+    mx = v > mx ? v : mx;
+    cnt++;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    long long omn = __shfl_xor(mn, d, 64), omx = __shfl_xor(mx, d, 64);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+    cnt += __shfl_xor(cnt, d, 64);
+  }
+  if (lane_id() == 0 && cnt) {
+    atomicMin(&out->smin, mn);
+    atomicMax(&out->smax, mx);
+    atomicAdd(&out->valid, cnt);
+  }
+}
+
+// ArrayMap::fill_data (array_map.rs:205-236), lock-free: data[key-min] <- row+1, the previous
+// occupant becomes next[row] (chain order is arbitrary; the reference's is ascending).
+__global__ __launch_bounds__(BLOCK) void k_am_build(KeyCol k, int64_t n, uint64_t offset, uint32_t* data, uint32_t* next, int* dup_flag) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (k.valid && !bit_at(k.valid, i)) continue;
+    uint64_t lo, hi;
+    load_words(k, i, lo, hi);
+    uint32_t old = atomicExch(&data[lo - offset], (uint32_t)i + 1u);
+    if (old) {
+      if (next) next[i] = old;
+      else *dup_flag = 1;
+    }
+  }
+}
+
+// JoinHashMap::update_from_iter (join_hash_map.rs:307-338), lock-free
+__global__ __launch_bounds__(BLOCK) void k_hm_build(KeySet ks, int64_t n, uint64_t mask, int null_equals_null, int force_collisions,
+                                                    uint32_t* heads, uint32_t* next) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    bool any_null;
+    uint64_t h = hash_row(ks, i, SEED_JOIN, any_null);
+    if (any_null && !null_equals_null) continue;
+    if (force_collisions) h = 0;
+    uint32_t old = atomicExch(&heads[h & mask], (uint32_t)i + 1u);
+    next[i] = old;
+  }
+}
+// are the build KEYS unique?  (lets the probe stop at the first match)
+__global__ __launch_bounds__(BLOCK) void k_hm_check_unique(KeySet ks, int64_t n, int null_equals_null, const uint32_t* next, int* dup_flag) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint32_t cur = next[i];
+    while (cur) {
+      if (keys_equal(ks, i, ks, (int64_t)cur - 1, null_equals_null)) { *dup_flag = 1; break; }
+      cur = next[cur - 1];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------ probe kernels
+template <bool AM>
+__device__ __forceinline__ uint32_t chain_head(const ProbeCtx& c, int64_t p) {
+  if (AM) {
+    const KeyCol& k = c.pkeys.c[0];
+    if (k.valid && !bit_at(k.valid, p)) return 0;  // ArrayMap is never built with NULL==NULL + NULL build keys
+    uint64_t lo, hi;
+    load_words(k, p, lo, hi);
+    uint64_t idx = lo - c.am_offset;
+    return idx < c.am_size ? c.heads[idx] : 0u;
+  } else {
+    bool any_null;
+    uint64_t h = hash_row(c.pkeys, p, SEED_JOIN, any_null);
+    if (any_null && !c.null_equals_null) return 0;
+    if (c.force_collisions) h = 0;
+    return c.heads[h & c.hash_mask];
+  }
+}
+template <bool AM>
+__device__ __forceinline__ bool chain_match(const ProbeCtx& c, int64_t b, int64_t p) {
+  if (AM) return true;  // direct addressing: same slot <=> same key
+  return keys_equal(c.bkeys, b, c.pkeys, p, c.null_equals_null);
+}
+
+// per-row output multiplicity for the probe-side part of each JoinType
+// (adjust_indices_by_join_type, joins/utils.rs:1432-1488)
+__device__ __forceinline__ uint32_t out_count(int join_type, uint32_t nmatch) {
+  switch (join_type) {
+    case DFGPU_JOIN_INNER: case DFGPU_JOIN_LEFT: return nmatch;
+    case DFGPU_JOIN_RIGHT: case DFGPU_JOIN_FULL: return nmatch ? nmatch : 1u;
+    case DFGPU_JOIN_RIGHT_SEMI: return nmatch ? 1u : 0u;
+    case DFGPU_JOIN_RIGHT_ANTI: return nmatch ? 0u : 1u;
+    case DFGPU_JOIN_RIGHT_MARK: return 1u;
+    default: return 0u;  // LeftSemi / LeftAnti / LeftMark: emitted from the visited bitmap
+  }
+}
+
+constexpr int PROBE_UNROLL = 4;
+
+// pass 1, at-most-one-match flavour: writes first_match[p] = build row + 1 (0 = none) and one
+// ballot word per 64 probe rows (bit = row produces an output row for this join type).
+template <bool AM>
+__global__ __launch_bounds__(BLOCK) void k_probe_first(ProbeCtx c, int64_t np, int invert, uint32_t* __restrict__ first_match,
+                                                       uint64_t* __restrict__ mask, uint8_t* __restrict__ visited) {
+  const int64_t n_words = (np + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w0 = wave * PROBE_UNROLL; w0 < n_words; w0 += n_waves * PROBE_UNROLL) {
+    uint32_t cur[PROBE_UNROLL];
+#pragma unroll
+    for (int j = 0; j < PROBE_UNROLL; j++) {
+      int64_t p = ((w0 + j) << 6) + lane_id();
+      cur[j] = p < np ? chain_head<AM>(c, p) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < PROBE_UNROLL; j++) {
+      int64_t p = ((w0 + j) << 6) + lane_id();
+      uint32_t m = cur[j];
+      if (!AM) {
+        while (m && !chain_match<AM>(c, (int64_t)m - 1, p)) m = c.next[m - 1];
+      }
+      if (p < np) {
+        if (first_match) first_match[p] = m;
+        if (visited && m) visited[m - 1] = 1;
+      }
+      uint64_t word = ballot64(p < np && ((m != 0) != (invert != 0)));
+      if (lane_id() == 0 && w0 + j < n_words) mask[w0 + j] = word;
+    }
+  }
+}
+
+// pass 1, general M:N flavour: row_counts[p] = output rows of probe row p, word_counts[w] = sum
+template <bool AM>
+__global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, int join_type, uint32_t* __restrict__ row_counts,
+                                                       uint32_t* __restrict__ word_counts, uint8_t* __restrict__ visited) {
+  const int64_t n_words = (np + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    int64_t p = (w << 6) + lane_id();
+    uint32_t cnt = 0;
+    if (p < np) {
+      uint32_t nmatch = 0;
+      uint32_t cur = chain_head<AM>(c, p);
+      while (cur) {
+        int64_t b = (int64_t)cur - 1;
+        if (chain_match<AM>(c, b, p)) {
+          nmatch++;
+          if (visited) visited[b] = 1;
+        }
+        cur = c.next ? c.next[b] : 0u;
+      }
+      cnt = out_count(join_type, nmatch);
+      row_counts[p] = cnt;
+    }
+    uint32_t tot = wave_sum(cnt);
+    if (lane_id() == 0) word_counts[w] = tot;
+  }
+}
+
+// pass 2, general flavour: emit (build_idx, probe_idx) pairs; -1 = NULL side
+template <bool AM>
+__global__ __launch_bounds__(BLOCK) void k_probe_emit(ProbeCtx c, int64_t np, int join_type, const uint32_t* __restrict__ row_counts,
+                                                      const uint64_t* __restrict__ prefix, int64_t* __restrict__ out_build,
+                                                      int64_t* __restrict__ out_probe, uint8_t* __restrict__ out_mark) {
+  const int64_t n_words = (np + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  const bool emit_pairs = join_type == DFGPU_JOIN_INNER || join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_RIGHT || join_type == DFGPU_JOIN_FULL;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    int64_t p = (w << 6) + lane_id();
+    uint32_t cnt = p < np ? row_counts[p] : 0u;
+    uint32_t inc = wave_inclusive_sum(cnt);
+    int64_t o = (int64_t)prefix[w] + (inc - cnt);
+    if (cnt == 0) continue;
+    uint32_t nmatch = 0;
+    if (emit_pairs || join_type == DFGPU_JOIN_RIGHT_MARK) {
+      uint32_t cur = chain_head<AM>(c, p);
+      while (cur) {
+        int64_t b = (int64_t)cur - 1;
+        if (chain_match<AM>(c, b, p)) {
+          if (emit_pairs) { out_build[o] = b; out_probe[o] = p; o++; }
+          nmatch++;
+        }
+        cur = c.next ? c.next[b] : 0u;
+      }
+    }
+    if (emit_pairs) {
+      if (nmatch == 0) { out_build[o] = -1; out_probe[o] = p; }  // Right / Full: unmatched probe row
+    } else {
+      out_probe[o] = p;
+      if (out_build) out_build[o] = -1;
+      if (out_mark) out_mark[o] = nmatch ? 1 : 0;
+    }
+  }
+}
+
+// pass 2, fast flavour: fused compaction of the probe columns + gather of the build columns
+constexpr int MAX_JOIN_COLS = 12;
+struct JoinCopyCols {
+  const void* src[MAX_JOIN_COLS];
+  void* dst[MAX_JOIN_COLS];
+  int width[MAX_JOIN_COLS];
+  int n_build;  // first n_build entries gather from the build side, the rest stream the probe side
+  int n;
+};
+template <typename T>
+__device__ __forceinline__ void jcopy(const void* src, void* dst, int64_t s, int64_t d) {
+  reinterpret_cast<T*>(dst)[d] = reinterpret_cast<const T*>(src)[s];
+}
+__global__ __launch_bounds__(BLOCK) void k_join_materialize(JoinCopyCols cols, const uint64_t* __restrict__ mask,
+                                                            const uint64_t* __restrict__ prefix,
+                                                            const uint32_t* __restrict__ first_match, int64_t np) {
+  const int64_t n_words = (np + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  const unsigned lane = lane_id();
+  for (int64_t w0 = wave * PROBE_UNROLL; w0 < n_words; w0 += n_waves * PROBE_UNROLL) {
+    bool sel[PROBE_UNROLL];
+    int64_t dst[PROBE_UNROLL], brow[PROBE_UNROLL];
+#pragma unroll
+    for (int j = 0; j < PROBE_UNROLL; j++) {
+      int64_t w = w0 + j;
+      uint64_t m = w < n_words ? mask[w] : 0ull;
+      sel[j] = (m >> lane) & 1ull;
+      dst[j] = 0;
+      brow[j] = 0;
+      if (sel[j]) {
+        dst[j] = (int64_t)(prefix[w] + mbcnt(m));
+        brow[j] = (int64_t)first_match[(w << 6) + lane] - 1;
+      }
+    }
+    for (int c = 0; c < cols.n; c++) {
+      const int width = cols.width[c];
+      const bool from_build = c < cols.n_build;
+#pragma unroll
+      for (int j = 0; j < PROBE_UNROLL; j++) {
+        if (!sel[j]) continue;
+        int64_t s = from_build ? brow[j] : ((w0 + j) << 6) + lane;
+        switch (width) {
+          case 16: jcopy<uint4>(cols.src[c], cols.dst[c], s, dst[j]); break;
+          case 8: jcopy<uint64_t>(cols.src[c], cols.dst[c], s, dst[j]); break;
+          case 4: jcopy<uint32_t>(cols.src[c], cols.dst[c], s, dst[j]); break;
+          case 1: jcopy<uint8_t>(cols.src[c], cols.dst[c], s, dst[j]); break;
+        }
+      }
+    }
+  }
+}
+
+// unmatched / matched build rows from the visited bytes (process_unmatched_build_batch, stream.rs:1002-)
+__global__ __launch_bounds__(BLOCK) void k_visited_mask(const uint8_t* __restrict__ visited, int64_t n, int want_visited, uint64_t* __restrict__ mask) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    int64_t i = (w << 6) + lane_id();
+    uint64_t word = ballot64(i < n && ((visited[i] != 0) == (want_visited != 0)));
+    if (lane_id() == 0) mask[w] = word;
+  }
+}
+
+// --------------------------------------------------------------------------------- host
+static ProbeCtx make_ctx(const JoinTable& jt, const Table& probe, const std::vector<int>& pk) {
+  ProbeCtx c{};
+  c.bkeys = make_keyset(jt.build, jt.key_cols);
+  c.pkeys = make_keyset(probe, pk);
+  for (int i = 0; i < c.bkeys.n; i++) {
+    int bt = c.bkeys.c[i].type == DFGPU_DATE32 ? DFGPU_INT32 : c.bkeys.c[i].type;
+    int pt = c.pkeys.c[i].type == DFGPU_DATE32 ? DFGPU_INT32 : c.pkeys.c[i].type;
+    DFGPU_CHECK(bt == pt, "join key types differ between build and probe side (the planner inserts casts)");
+  }
+  c.heads = jt.heads->as<uint32_t>();
+  c.next = jt.next ? jt.next->as<uint32_t>() : nullptr;
+  c.am_offset = jt.am_offset;
+  c.am_size = jt.am_size;
+  c.hash_mask = jt.hash_mask;
+  c.null_equals_null = jt.null_equality == DFGPU_NULL_EQUALS_NULL;
+  c.force_collisions = jt.force_collisions;
+  return c;
+}
+
+static Column mark_column(const uint8_t* bytes, int64_t n) {
+  dfgpu_field f{};
+  f.type = DFGPU_BOOL;
+  Column c = alloc_column(f, "mark", n);
+  pack_bytes_to_bitmap(bytes, n, c.data->as<uint64_t>());
+  return c;
+}
+
+static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts) {
+  Runtime& r = rt();
+  auto jt = std::make_unique<JoinTable>();
+  jt->build = build;
+  jt->key_cols = key_cols;
+  jt->null_equality = null_equality;
+  jt->force_collisions = opts.force_hash_collisions != 0;
+  const int64_t nb = build.nrows;
+  DFGPU_CHECK(nb < 0xFFFFFFFFll, "build side has >= u32::MAX rows (the reference switches to JoinHashMapU64; not supported on GPU)");
+  KeySet ks = make_keyset(build, key_cols);
+  jt->info.build_rows = nb;
+
+  // ---- try_create_array_map gating (hash_join/exec.rs:111-191)
+  bool use_am = false;
+  if (opts.table_mode != 1 && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64) {
+    const Column& kc = build.cols[key_cols[0]];
+    bool null_block = null_equality == DFGPU_NULL_EQUALS_NULL && kc.has_nulls();
+    if (!null_block && nb > 0) {
+      BufPtr mm = make_buf(sizeof(MinMax));
+      static const MinMax init{INT64_MAX, INT64_MIN, 0};
+      h2d_async(mm->ptr, &init, sizeof init);
+      k_key_minmax<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, mm->as<MinMax>());
+      MinMax res;
+      d2h(&res, mm->ptr, sizeof res);
+      if (res.valid > 0) {
+        uint64_t range = (uint64_t)res.smax - (uint64_t)res.smin;  // ArrayMap::calculate_range (wrapping)
+        double dense = (double)nb / ((double)range + 1.0);
+        bool ok = range != UINT64_MAX &&
+                  !(range >= (uint64_t)opts.perfect_hash_join_small_build_threshold && dense <= opts.perfect_hash_join_min_key_density);
+        if (opts.table_mode == 2) ok = range != UINT64_MAX;
+        if (ok && range < (1ull << 34)) {  // HBM guard: <= 64 GiB of u32 slots
+          use_am = true;
+          jt->am_offset = (uint64_t)res.smin;
+          jt->am_size = range + 1;
+        }
+      }
+    }
+  }
+  DFGPU_CHECK(!(opts.table_mode == 2 && !use_am), "direct-address join table requested but not applicable");
+
+  BufPtr flag = make_zero_buf(4);
+  int dup = 0;
+  if (use_am) {
+    jt->array_map = true;
+    jt->heads = make_zero_buf(jt->am_size * 4);
+    {
+      ProfileScope ps("join_build_array_map", nb * ks.c[0].width);
+      k_am_build<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, jt->am_offset, jt->heads->as<uint32_t>(), nullptr, flag->as<int>());
+    }
+    d2h(&dup, flag->ptr, 4);
+    if (dup) {  // duplicates: rebuild with chains
+      DFGPU_HIP(hipMemsetAsync(jt->heads->ptr, 0, jt->am_size * 4, r.stream));
+      jt->next = make_zero_buf((size_t)nb * 4);
+      ProfileScope ps("join_build_array_map", nb * ks.c[0].width);
+      k_am_build<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, jt->am_offset, jt->heads->as<uint32_t>(), jt->next->as<uint32_t>(), flag->as<int>());
+    }
+    jt->info.table_bytes = (int64_t)jt->am_size * 4 + (dup ? nb * 4 : 0);
+  } else {
+    uint64_t cap = 64;
+    while (cap < (uint64_t)nb * 2) cap <<= 1;
+    jt->hash_mask = cap - 1;
+    jt->heads = make_zero_buf(cap * 4);
+    jt->next = make_zero_buf((size_t)(nb ? nb : 1) * 4);
+    if (nb) {
+      int64_t kb = 0;
+      for (int i = 0; i < ks.n; i++) kb += nb * ks.c[i].width;
+      {
+        ProfileScope ps("join_build_hash_map", kb + nb * 8);
+        k_hm_build<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks, nb, jt->hash_mask, null_equality == DFGPU_NULL_EQUALS_NULL, jt->force_collisions,
+                                                                jt->heads->as<uint32_t>(), jt->next->as<uint32_t>());
+      }
+      ProfileScope ps("join_build_check_unique", kb + nb * 4);
+      k_hm_check_unique<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks, nb, null_equality == DFGPU_NULL_EQUALS_NULL, jt->next->as<uint32_t>(), flag->as<int>());
+      d2h(&dup, flag->ptr, 4);
+    }
+    jt->info.table_bytes = (int64_t)cap * 4 + nb * 4;
+  }
+  DFGPU_HIP(hipGetLastError());
+  jt->keys_unique = dup == 0;
+  jt->info.used_array_map = use_am;
+  jt->info.build_keys_unique = jt->keys_unique;
+  return jt;
+}
+
+static bool needs_visited(int join_type) {
+  return join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_FULL || join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI ||
+         join_type == DFGPU_JOIN_LEFT_MARK;
+}
+
+static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
+                        const std::vector<int>& pout) {
+  Runtime& r = rt();
+  DFGPU_CHECK(pk.size() == jt.key_cols.size(), "probe key count differs from build key count");
+  const int64_t np = probe.nrows;
+  const int64_t n_words = (np + 63) / 64;
+  ProbeCtx ctx = make_ctx(jt, probe, pk);
+  for (int c : bout) DFGPU_CHECK(c >= 0 && c < (int)jt.build.cols.size(), "build output column out of range");
+  for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
+  uint8_t* visited = nullptr;
+  if (needs_visited(join_type)) {
+    if (!jt.visited) jt.visited = make_zero_buf((size_t)jt.build.nrows + 64);
+    visited = jt.visited->as<uint8_t>();
+  }
+  jt.info.probe_rows += np;
+  int64_t key_bytes = 0;
+  for (int i = 0; i < ctx.pkeys.n; i++) key_bytes += np * ctx.pkeys.c[i].width;
+  Table out;
+
+  const bool probe_side_only = join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI;
+  const bool build_side_only = join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI || join_type == DFGPU_JOIN_LEFT_MARK;
+  bool payload_nullable = false;
+  for (int c : bout) payload_nullable |= jt.build.cols[c].has_nulls();
+  for (int c : pout) payload_nullable |= probe.cols[c].has_nulls();
+  const bool fast_inner = join_type == DFGPU_JOIN_INNER && jt.keys_unique && !payload_nullable &&
+                          (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS;
+
+  // LeftSemi/LeftAnti/LeftMark must mark EVERY matching build row: first-match suffices only for unique keys
+  if (np > 0 && (probe_side_only || (build_side_only && jt.keys_unique) || fast_inner)) {
+    // ---- at most one match per probe row
+    BufPtr mask = make_buf(bitmap_bytes(np));
+    BufPtr first = fast_inner ? make_buf((size_t)np * 4) : nullptr;
+    {
+      ProfileScope ps("join_probe_lookup", key_bytes + (fast_inner ? np * 4 : 0) + np / 8);
+      int g = grid_for(n_words, (BLOCK / WAVE) * PROBE_UNROLL);
+      int invert = join_type == DFGPU_JOIN_RIGHT_ANTI;
+      if (jt.array_map)
+        k_probe_first<true><<<g, BLOCK, 0, r.stream>>>(ctx, np, invert, first ? first->as<uint32_t>() : nullptr, mask->as<uint64_t>(), visited);
+      else
+        k_probe_first<false><<<g, BLOCK, 0, r.stream>>>(ctx, np, invert, first ? first->as<uint32_t>() : nullptr, mask->as<uint64_t>(), visited);
+      DFGPU_HIP(hipGetLastError());
+    }
+    if (probe_side_only) {
+      out = compact_table(probe, pout, mask->as<uint64_t>(), nullptr);
+    } else if (build_side_only) {
+      out.nrows = 0;  // emitted by dfgpu_join_emit_unmatched
+      for (int c : bout) out.cols.push_back(alloc_column(jt.build.cols[c].field, jt.build.cols[c].name, 0));
+    } else {
+      BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
+      scan_mask_popcounts(mask->as<uint64_t>(), nullptr, np, prefix->as<uint64_t>());
+      const int64_t n_out = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+      out.nrows = n_out;
+      JoinCopyCols jc{};
+      int64_t bytes = np / 8 + np * 4;
+      for (int c : bout) {
+        const Column& sc = jt.build.cols[c];
+        out.cols.push_back(alloc_column(sc.field, sc.name, n_out));
+        jc.src[jc.n] = sc.ptr();
+        jc.dst[jc.n] = out.cols.back().data->ptr;
+        jc.width[jc.n] = type_width(sc.field.type);
+        bytes += 2 * n_out * jc.width[jc.n];
+        jc.n++;
+      }
+      jc.n_build = jc.n;
+      for (int c : pout) {
+        const Column& sc = probe.cols[c];
+        out.cols.push_back(alloc_column(sc.field, sc.name, n_out));
+        jc.src[jc.n] = sc.ptr();
+        jc.dst[jc.n] = out.cols.back().data->ptr;
+        jc.width[jc.n] = type_width(sc.field.type);
+        bytes += (np + n_out) * jc.width[jc.n];
+        jc.n++;
+      }
+      if (n_out > 0 && jc.n > 0) {
+        ProfileScope ps("join_probe_materialize", bytes);
+        k_join_materialize<<<grid_for(n_words, (BLOCK / WAVE) * PROBE_UNROLL), BLOCK, 0, r.stream>>>(jc, mask->as<uint64_t>(), prefix->as<uint64_t>(),
+                                                                                                      first->as<uint32_t>(), np);
+        DFGPU_HIP(hipGetLastError());
+      }
+    }
+  } else {
+    // ---- general M:N path: counts -> scan -> pairs -> gathers
+    BufPtr row_counts = make_buf((size_t)(np ? np : 1) * 4);
+    BufPtr word_counts = make_buf((size_t)(n_words ? n_words : 1) * 4);
+    BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
+    int g = grid_for(n_words, BLOCK / WAVE);
+    if (np) {
+      ProfileScope ps("join_probe_count", key_bytes + np * 4);
+      if (jt.array_map) k_probe_count<true><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), visited);
+      else k_probe_count<false><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), visited);
+      DFGPU_HIP(hipGetLastError());
+    }
+    scan_u32(word_counts->as<uint32_t>(), n_words, prefix->as<uint64_t>());
+    const int64_t n_out = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+    BufPtr ob = make_buf((size_t)(n_out ? n_out : 1) * 8), op = make_buf((size_t)(n_out ? n_out : 1) * 8);
+    BufPtr om = join_type == DFGPU_JOIN_RIGHT_MARK ? make_buf((size_t)n_out + 64) : nullptr;
+    if (n_out) {
+      ProfileScope ps("join_probe_emit", key_bytes + np * 4 + n_out * 16);
+      if (jt.array_map)
+        k_probe_emit<true><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), ob->as<int64_t>(), op->as<int64_t>(), om ? om->as<uint8_t>() : nullptr);
+      else
+        k_probe_emit<false><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), ob->as<int64_t>(), op->as<int64_t>(), om ? om->as<uint8_t>() : nullptr);
+      DFGPU_HIP(hipGetLastError());
+    }
+    out.nrows = n_out;
+    const bool build_null_possible = join_type == DFGPU_JOIN_RIGHT || join_type == DFGPU_JOIN_FULL;
+    if (join_type != DFGPU_JOIN_RIGHT_MARK)
+      for (int c : bout) out.cols.push_back(gather_column(jt.build.cols[c], ob->as<int64_t>(), n_out, build_null_possible));
+    for (int c : pout) out.cols.push_back(gather_column(probe.cols[c], op->as<int64_t>(), n_out, false));
+    if (join_type == DFGPU_JOIN_RIGHT_MARK) out.cols.push_back(mark_column(om->as<uint8_t>(), n_out));
+  }
+  jt.info.output_rows += out.nrows;
+  return out;
+}
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+
+extern "C" {
+
+int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int null_equality, const dfgpu_join_options* opts, dfgpu_join_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(nkeys >= 1 && key_cols && out, "join needs at least one key column");
+    dfgpu_join_options o{1024, 0.15, 0, 0};  // config.rs:913,923 defaults
+    if (opts) o = *opts;
+    auto jt = join_build(*unwrap(build), std::vector<int>(key_cols, key_cols + nkeys), null_equality, o);
+    *out = reinterpret_cast<dfgpu_join_t>(jt.release());
+  });
+}
+
+int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type, const int* build_out_cols, int n_build_out,
+                     const int* probe_out_cols, int n_probe_out, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(ht && out, "null argument");
+    JoinTable* jt = reinterpret_cast<JoinTable*>(ht);
+    DFGPU_CHECK(join_type >= DFGPU_JOIN_INNER && join_type <= DFGPU_JOIN_RIGHT_MARK, "bad join type");
+    std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
+    std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
+    auto o = std::make_unique<Table>(join_probe(*jt, *unwrap(probe), pk, join_type, bo, po));
+    *out = wrap(o.release());
+  });
+}
+
+int dfgpu_join_emit_unmatched(dfgpu_join_t ht, int join_type, const int* build_out_cols, int n_build_out, const dfgpu_field* probe_fields,
+                              const char* const* probe_names, int n_probe_out, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    JoinTable* jt = reinterpret_cast<JoinTable*>(ht);
+    DFGPU_CHECK(needs_visited(join_type), "join type has no build-side emission");
+    Runtime& r = rt();
+    const int64_t nb = jt->build.nrows;
+    if (!jt->visited) jt->visited = make_zero_buf((size_t)nb + 64);
+    std::vector<int> bo(build_out_cols, build_out_cols + n_build_out);
+    auto o = std::make_unique<Table>();
+    if (join_type == DFGPU_JOIN_LEFT_MARK) {
+      o->nrows = nb;
+      for (int c : bo) o->cols.push_back(jt->build.cols[c]);
+      o->cols.push_back(mark_column(jt->visited->as<uint8_t>(), nb));
+    } else {
+      BufPtr mask = make_buf(bitmap_bytes(nb));
+      int want_visited = join_type == DFGPU_JOIN_LEFT_SEMI;
+      if (nb) k_visited_mask<<<grid_for((nb + 63) / 64, BLOCK / WAVE), BLOCK, 0, r.stream>>>(jt->visited->as<uint8_t>(), nb, want_visited, mask->as<uint64_t>());
+      *o = compact_table(jt->build, bo, mask->as<uint64_t>(), nullptr);
+      if (join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_FULL) {
+        // unmatched build rows carry an all-NULL probe side
+        for (int i = 0; i < n_probe_out; i++) {
+          Column c = alloc_column(probe_fields[i], probe_names && probe_names[i] ? probe_names[i] : "", o->nrows);
+          if (o->nrows) DFGPU_HIP(hipMemsetAsync(c.data->ptr, 0, data_bytes(c.field.type, o->nrows), r.stream));
+          c.validity = make_zero_buf(bitmap_bytes(o->nrows));
+          c.null_count = o->nrows;
+          o->cols.push_back(std::move(c));
+        }
+      }
+    }
+    jt->info.output_rows += o->nrows;
+    *out = wrap(o.release());
+  });
+}
+
+int dfgpu_join_get_info(dfgpu_join_t ht, dfgpu_join_info* out) {
+  return guarded([&] { *out = reinterpret_cast<JoinTable*>(ht)->info; });
+}
+int dfgpu_join_free(dfgpu_join_t ht) {
+  return guarded([&] { delete reinterpret_cast<JoinTable*>(ht); });
+}
+
+}  // extern "C"

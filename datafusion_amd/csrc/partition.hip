@@ -1,0 +1,224 @@
+// partition.hip — K1 + K10: row hashing and RepartitionExec(Hash).
+//
+// BatchPartitioner::partition_iter, Hash arm (physical-plan/src/repartition/mod.rs:1111-1150):
+// partition = create_hashes(keys; REPARTITION seed 0) % n; each partition keeps input order.
+// On device: one wave64 owns 64 rows; per partition p the wave's membership is one ballot, so
+//   pass 1  part id per row + per-(partition, word) counts  (popcount of the ballot),
+//   scan    one exclusive scan over the partition-major count matrix gives every
+//           (partition, word) its output offset in a single partition-major buffer,
+//   pass 2  scatter: dst = offset[p][word] + mbcnt(ballot(part == p)) -> stable, coalesced
+//           per partition.
+// The n output tables are zero-copy slices of that one buffer per column (what the RCCL
+// all-to-all sends from: contiguous per destination).
+#include "device.hpp"
+#include "internal.hpp"
+
+namespace dfgpu {
+
+Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_t* mask, const uint64_t* mask_valid);
+
+__global__ __launch_bounds__(BLOCK) void k_hash_rows(KeySet ks, int64_t n, uint64_t seed, int force_collisions, uint64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    bool any_null;
+    uint64_t h = hash_row(ks, i, seed, any_null);
+    out[i] = force_collisions ? 0 : h;
+  }
+}
+
+static KeySet keyset_of(const std::vector<const Column*>& keys) {
+  KeySet ks{};
+  DFGPU_CHECK((int)keys.size() <= MAX_KEYS && !keys.empty(), "bad number of key columns");
+  ks.n = (int)keys.size();
+  for (int i = 0; i < ks.n; i++) {
+    DFGPU_CHECK(keys[i]->field.type != DFGPU_BOOL, "Boolean hash keys are not supported on the GPU path");
+    ks.c[i] = KeyCol{keys[i]->ptr(), keys[i]->valid_words(), keys[i]->field.type, type_width(keys[i]->field.type)};
+  }
+  return ks;
+}
+
+void hash_columns(const std::vector<const Column*>& keys, int64_t n, uint64_t seed, uint64_t* out, bool force_collisions) {
+  if (n == 0) return;
+  KeySet ks = keyset_of(keys);
+  int64_t bytes = n * 8;
+  for (int i = 0; i < ks.n; i++) bytes += n * ks.c[i].width;
+  ProfileScope ps("hash_rows", bytes);
+  k_hash_rows<<<grid_for(n, BLOCK), BLOCK, 0, rt().stream>>>(ks, n, seed, force_collisions, out);
+  DFGPU_HIP(hipGetLastError());
+}
+
+constexpr int MAX_PARTS = 64;
+
+// pass 1: counts[p * n_words + w] = rows of word w routed to partition p; part[i] = partition
+__global__ __launch_bounds__(BLOCK) void k_part_count(KeySet ks, int64_t n, int nparts, uint8_t* __restrict__ part, uint32_t* __restrict__ counts) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    int64_t i = (w << 6) + lane_id();
+    int p = -1;
+    if (i < n) {
+      bool any_null;
+      uint64_t h = hash_row(ks, i, SEED_REPARTITION, any_null);
+      p = (int)(h % (uint64_t)nparts);
+      part[i] = (uint8_t)p;
+    }
+    uint32_t mine = 0;
+    for (int q = 0; q < nparts; q++) {
+      uint32_t c = (uint32_t)__popcll(ballot64(p == q));
+      if ((int)lane_id() == q) mine = c;
+    }
+    if ((int)lane_id() < nparts) counts[(int64_t)lane_id() * n_words + w] = mine;
+  }
+}
+
+constexpr int PART_MAX_COLS = 12;
+struct PartCols {
+  const void* src[PART_MAX_COLS];
+  void* dst[PART_MAX_COLS];
+  int width[PART_MAX_COLS];
+  int n;
+};
+template <typename T>
+__device__ __forceinline__ void pcopy(const void* src, void* dst, int64_t s, int64_t d) {
+  reinterpret_cast<T*>(dst)[d] = reinterpret_cast<const T*>(src)[s];
+}
+__global__ __launch_bounds__(BLOCK) void k_part_scatter(PartCols cols, const uint8_t* __restrict__ part, const uint64_t* __restrict__ prefix, int64_t n, int nparts) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    int64_t i = (w << 6) + lane_id();
+    int p = i < n ? (int)part[i] : -1;
+    int64_t dst = 0;
+    for (int q = 0; q < nparts; q++) {
+      uint64_t m = ballot64(p == q);
+      if (p == q) dst = (int64_t)prefix[(int64_t)q * n_words + w] + mbcnt(m);
+    }
+    if (p < 0) continue;
+    for (int c = 0; c < cols.n; c++) {
+      switch (cols.width[c]) {
+        case 16: pcopy<uint4>(cols.src[c], cols.dst[c], i, dst); break;
+        case 8: pcopy<uint64_t>(cols.src[c], cols.dst[c], i, dst); break;
+        case 4: pcopy<uint32_t>(cols.src[c], cols.dst[c], i, dst); break;
+        case 1: pcopy<uint8_t>(cols.src[c], cols.dst[c], i, dst); break;
+      }
+    }
+  }
+}
+// mask of rows routed to partition q (fallback path for nullable / Boolean payload columns)
+__global__ __launch_bounds__(BLOCK) void k_part_mask(const uint8_t* __restrict__ part, int64_t n, int q, uint64_t* __restrict__ mask) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    int64_t i = (w << 6) + lane_id();
+    uint64_t m = ballot64(i < n && part[i] == q);
+    if (lane_id() == 0) mask[w] = m;
+  }
+}
+
+static std::vector<Table> partition_table(const Table& in, const std::vector<int>& key_cols, int nparts) {
+  Runtime& r = rt();
+  DFGPU_CHECK(nparts >= 1 && nparts <= MAX_PARTS, "dfgpu_partition supports 1..64 partitions");
+  const int64_t n = in.nrows;
+  const int64_t n_words = (n + 63) / 64;
+  std::vector<const Column*> keys;
+  for (int c : key_cols) {
+    DFGPU_CHECK(c >= 0 && c < (int)in.cols.size(), "partition key column out of range");
+    keys.push_back(&in.cols[c]);
+  }
+  KeySet ks = keyset_of(keys);
+  std::vector<Table> outs(nparts);
+  if (n == 0) {
+    for (auto& o : outs) {
+      o.nrows = 0;
+      for (auto& c : in.cols) o.cols.push_back(alloc_column(c.field, c.name, 0));
+    }
+    return outs;
+  }
+  BufPtr part = make_buf((size_t)n + 64);
+  BufPtr counts = make_buf((size_t)nparts * n_words * 4);
+  BufPtr prefix = make_buf((size_t)(nparts * n_words + 1) * 8);
+  int64_t key_bytes = 0;
+  for (int i = 0; i < ks.n; i++) key_bytes += n * ks.c[i].width;
+  {
+    ProfileScope ps("partition_count", key_bytes + n);
+    k_part_count<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(ks, n, nparts, part->as<uint8_t>(), counts->as<uint32_t>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  scan_u32(counts->as<uint32_t>(), (int64_t)nparts * n_words, prefix->as<uint64_t>());
+  // partition boundaries = prefix at the start of each partition's row of the matrix
+  std::vector<uint64_t> bounds(nparts + 1);
+  for (int p = 0; p < nparts; p++)
+    DFGPU_HIP(hipMemcpyAsync(&bounds[p], prefix->as<uint64_t>() + (int64_t)p * n_words, 8, hipMemcpyDeviceToHost, r.stream));
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  bounds[nparts] = (uint64_t)n;
+
+  bool simple = true;
+  for (auto& c : in.cols) simple &= !c.validity && c.field.type != DFGPU_BOOL;
+  if (simple) {
+    std::vector<Column> whole;
+    for (auto& c : in.cols) whole.push_back(alloc_column(c.field, c.name, n));
+    for (size_t c0 = 0; c0 < in.cols.size(); c0 += PART_MAX_COLS) {
+      PartCols pc{};
+      int64_t bytes = n;
+      pc.n = (int)std::min<size_t>(PART_MAX_COLS, in.cols.size() - c0);
+      for (int k = 0; k < pc.n; k++) {
+        pc.src[k] = in.cols[c0 + k].ptr();
+        pc.dst[k] = whole[c0 + k].data->ptr;
+        pc.width[k] = type_width(in.cols[c0 + k].field.type);
+        bytes += 2 * n * pc.width[k];
+      }
+      ProfileScope ps("partition_scatter", bytes);
+      k_part_scatter<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(pc, part->as<uint8_t>(), prefix->as<uint64_t>(), n, nparts);
+      DFGPU_HIP(hipGetLastError());
+    }
+    for (int p = 0; p < nparts; p++) {
+      outs[p].nrows = (int64_t)(bounds[p + 1] - bounds[p]);
+      for (size_t ci = 0; ci < in.cols.size(); ci++) {
+        Column c = whole[ci];
+        c.length = outs[p].nrows;
+        c.data_offset = (size_t)bounds[p] * type_width(c.field.type);
+        outs[p].cols.push_back(std::move(c));
+      }
+    }
+  } else {
+    std::vector<int> all;
+    for (int i = 0; i < (int)in.cols.size(); i++) all.push_back(i);
+    BufPtr mask = make_buf(bitmap_bytes(n));
+    for (int p = 0; p < nparts; p++) {
+      k_part_mask<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(part->as<uint8_t>(), n, p, mask->as<uint64_t>());
+      outs[p] = compact_table(in, all, mask->as<uint64_t>(), nullptr);
+    }
+  }
+  return outs;
+}
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+
+extern "C" {
+
+int dfgpu_hash_columns(dfgpu_table_t input, const int* key_cols, int nkeys, uint64_t seed, uint64_t* out_device) {
+  return guarded([&] {
+    require_init();
+    Table* t = unwrap(input);
+    std::vector<const Column*> keys;
+    for (int i = 0; i < nkeys; i++) {
+      DFGPU_CHECK(key_cols[i] >= 0 && key_cols[i] < (int)t->cols.size(), "key column out of range");
+      keys.push_back(&t->cols[key_cols[i]]);
+    }
+    hash_columns(keys, t->nrows, seed, out_device, false);
+  });
+}
+
+int dfgpu_partition(dfgpu_table_t input, const int* key_cols, int nkeys, int nparts, dfgpu_table_t* outs) {
+  return guarded([&] {
+    require_init();
+    auto parts = partition_table(*unwrap(input), std::vector<int>(key_cols, key_cols + nkeys), nparts);
+    for (int p = 0; p < nparts; p++) outs[p] = wrap(new Table(std::move(parts[p])));
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// scan.hip — device-wide exclusive prefix sums (u32 counts -> u64 offsets).  Three launches:
+// per-chunk reduce, single-workgroup scan of the chunk sums, per-chunk downsweep.  The input
+// is a functor so the popcount of selection-mask words is computed on the fly (the mask is
+// read twice = 2 x N/8 bytes, negligible against the columns it selects).
+#include "device.hpp"
+#include "internal.hpp"
+
+namespace dfgpu {
+
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_CHUNK = BLOCK * SCAN_ITEMS;  // 2048 elements per workgroup
+
+struct InU32 {
+  const uint32_t* p;
+  __device__ __forceinline__ uint32_t operator()(int64_t i) const { return p[i]; }
+};
+struct InMaskPopc {
+  const uint64_t* mask;
+  const uint64_t* valid;
+  int64_t nrows;
+  __device__ __forceinline__ uint32_t operator()(int64_t w) const {
+    uint64_t m = mask[w];
+    if (valid) m &= valid[w];
+    int64_t rem = nrows - w * 64;
+    if (rem < 64) m &= (rem <= 0) ? 0ull : ((~0ull) >> (64 - rem));
+    return (uint32_t)__popcll(m);
+  }
+};
+
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t* total) {
+  __shared__ uint64_t wsum[BLOCK / WAVE];
+  uint64_t inc = wave_inclusive_sum(v);
+  int w = threadIdx.x >> 6;
+  if (lane_id() == 63) wsum[w] = inc;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < BLOCK / WAVE; i++) {
+    if (i < w) base += wsum[i];
+    tot += wsum[i];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+template <typename In>
+__global__ __launch_bounds__(BLOCK) void k_scan_reduce(In in, int64_t n, uint64_t* chunk_sums) {
+  int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint64_t s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++)
+    if (base + j < n) s += in(base + j);
+  uint64_t tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
+}
+
+// one workgroup: in-place exclusive scan of the chunk sums; writes the grand total to *total
+__global__ __launch_bounds__(BLOCK) void k_scan_sums(uint64_t* sums, int64_t n_chunks, uint64_t* total) {
+  uint64_t carry = 0;
+  for (int64_t base = 0; base < n_chunks; base += BLOCK) {
+    int64_t i = base + threadIdx.x;
+    uint64_t v = i < n_chunks ? sums[i] : 0;
+    uint64_t tot;
+    uint64_t ex = block_exclusive_scan(v, &tot);
+    if (i < n_chunks) sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+template <typename In>
+__global__ __launch_bounds__(BLOCK) void k_scan_down(In in, int64_t n, const uint64_t* chunk_base, uint64_t* out) {
+  int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint64_t s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    v[j] = base + j < n ? in(base + j) : 0;
+    s += v[j];
+  }
+  uint64_t tot;
+  uint64_t ex = block_exclusive_scan(s, &tot) + chunk_base[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+}
+
+template <typename In>
+static void run_scan(In in, int64_t n, uint64_t* out, const char* name) {
+  Runtime& r = rt();
+  if (n == 0) {
+    DFGPU_HIP(hipMemsetAsync(out, 0, 8, r.stream));
+    return;
+  }
+  int64_t n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  BufPtr sums = make_buf((size_t)n_chunks * 8);
+  ProfileScope ps(name, 0);
+  k_scan_reduce<<<(unsigned)n_chunks, BLOCK, 0, r.stream>>>(in, n, sums->as<uint64_t>());
+  k_scan_sums<<<1, BLOCK, 0, r.stream>>>(sums->as<uint64_t>(), n_chunks, out + n);
+  k_scan_down<<<(unsigned)n_chunks, BLOCK, 0, r.stream>>>(in, n, sums->as<uint64_t>(), out);
+  DFGPU_HIP(hipGetLastError());
+}
+
+void scan_mask_popcounts(const uint64_t* mask, const uint64_t* valid, int64_t nrows, uint64_t* out_prefix) {
+  int64_t n_words = (nrows + 63) / 64;
+  run_scan(InMaskPopc{mask, valid, nrows}, n_words, out_prefix, "scan_mask_popcounts");
+}
+void scan_u32(const uint32_t* in, int64_t n, uint64_t* out_prefix) { run_scan(InU32{in}, n, out_prefix, "scan_u32"); }
+
+}  // namespace dfgpu

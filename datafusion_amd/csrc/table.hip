@@ -1,0 +1,367 @@
+// table.hip — device tables (Arrow-layout columns in HBM) and the Arrow C Data Interface
+// boundary: import (host RecordBatch -> HBM, pinned with hipHostRegister + async copies on a
+// side stream) and export (HBM -> host struct array with release callbacks).
+#include "internal.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace dfgpu {
+
+// ---------------------------------------------------------------- format strings
+static dfgpu_field parse_format(const char* fmt, bool nullable) {
+  dfgpu_field f{};
+  f.nullable = nullable ? 1 : 0;
+  std::string s(fmt);
+  if (s == "i") f.type = DFGPU_INT32;
+  else if (s == "l") f.type = DFGPU_INT64;
+  else if (s == "g") f.type = DFGPU_FLOAT64;
+  else if (s == "C") f.type = DFGPU_UINT8;
+  else if (s == "I") f.type = DFGPU_UINT32;
+  else if (s == "L") f.type = DFGPU_UINT64;
+  else if (s == "tdD") f.type = DFGPU_DATE32;
+  else if (s == "b") f.type = DFGPU_BOOL;
+  else if (s.rfind("d:", 0) == 0) {
+    int p = 0, sc = 0, bits = 128;
+    int n = std::sscanf(s.c_str(), "d:%d,%d,%d", &p, &sc, &bits);
+    DFGPU_CHECK(n >= 2 && bits == 128, "unsupported decimal format '" + s + "' (only Decimal128)");
+    f.type = DFGPU_DECIMAL128;
+    f.precision = p;
+    f.scale = sc;
+  } else {
+    // Utf8/Utf8View/Dictionary/nested: the GPU rule leaves such operators on the CPU
+    throw Error("unsupported Arrow type format '" + s + "' for GPU execution");
+  }
+  return f;
+}
+static std::string format_of(const dfgpu_field& f) {
+  switch (f.type) {
+    case DFGPU_INT32: return "i";
+    case DFGPU_INT64: return "l";
+    case DFGPU_FLOAT64: return "g";
+    case DFGPU_UINT8: return "C";
+    case DFGPU_UINT32: return "I";
+    case DFGPU_UINT64: return "L";
+    case DFGPU_DATE32: return "tdD";
+    case DFGPU_BOOL: return "b";
+    case DFGPU_DECIMAL128: return "d:" + std::to_string(f.precision) + "," + std::to_string(f.scale);
+  }
+  throw Error("format_of: bad type");
+}
+
+// ---------------------------------------------------------------- import
+struct Uploader {
+  hipStream_t copy_stream = nullptr;
+  std::vector<void*> registered;
+  std::vector<void*> staged;  // host temporaries to free after the copies
+  Uploader() { DFGPU_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); }
+  void upload(void* dst, const void* src, size_t n) {
+    if (n == 0) return;
+    // pin large host buffers so the copy engine streams at PCIe rate without a bounce buffer
+    if (n >= (size_t(8) << 20)) {
+      if (hipHostRegister(const_cast<void*>(src), n, hipHostRegisterDefault) == hipSuccess) registered.push_back(const_cast<void*>(src));
+      else (void)hipGetLastError();
+    }
+    DFGPU_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, copy_stream));
+  }
+  void finish() {
+    DFGPU_HIP(hipStreamSynchronize(copy_stream));
+    for (void* p : registered) (void)hipHostUnregister(p);
+    for (void* p : staged) std::free(p);
+    registered.clear();
+    staged.clear();
+  }
+  ~Uploader() {
+    if (copy_stream) {
+      (void)hipStreamSynchronize(copy_stream);
+      for (void* p : registered) (void)hipHostUnregister(p);
+      for (void* p : staged) std::free(p);
+      (void)hipStreamDestroy(copy_stream);
+    }
+  }
+};
+
+// copy `n` bits starting at bit `offset` of src into a fresh word-padded host bitmap
+static uint64_t* shift_bitmap(const uint8_t* src, int64_t offset, int64_t n) {
+  size_t bytes = bitmap_bytes(n);
+  uint64_t* out = (uint64_t*)std::calloc(bytes ? bytes : 8, 1);
+  uint8_t* o = (uint8_t*)out;
+  if ((offset & 7) == 0) {
+    std::memcpy(o, src + (offset >> 3), (size_t)((n + 7) / 8));
+  } else {
+    for (int64_t i = 0; i < n; i++) {
+      int64_t s = offset + i;
+      if ((src[s >> 3] >> (s & 7)) & 1) o[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
+  }
+  // clear padding bits beyond n
+  if (n & 63) out[n >> 6] &= (~0ull) >> (64 - (n & 63));
+  return out;
+}
+
+static Column import_column(const ArrowArray* a, const ArrowSchema* s, int64_t parent_offset, int64_t nrows, Uploader& up) {
+  DFGPU_CHECK(s->dictionary == nullptr, std::string("dictionary-encoded column '") + (s->name ? s->name : "") + "' is not supported on the GPU path");
+  Column c;
+  c.field = parse_format(s->format, (s->flags & 2) != 0);
+  c.name = s->name ? s->name : "";
+  c.length = nrows;
+  DFGPU_CHECK(a->n_buffers == 2, "expected 2 buffers for a fixed-width column");
+  int64_t off = a->offset + parent_offset;
+  DFGPU_CHECK(a->length >= nrows + parent_offset || a->length == nrows, "child array shorter than struct");
+  const uint8_t* validity = (const uint8_t*)a->buffers[0];
+  const uint8_t* data = (const uint8_t*)a->buffers[1];
+  if (c.field.type == DFGPU_BOOL) {
+    c.data = make_buf(bitmap_bytes(nrows) + 16);
+    if (nrows) {
+      uint64_t* h = shift_bitmap(data, off, nrows);
+      up.staged.push_back(h);
+      up.upload(c.data->ptr, h, bitmap_bytes(nrows));
+    }
+  } else {
+    int w = type_width(c.field.type);
+    c.data = make_buf((size_t)nrows * w + 16);
+    if (nrows) up.upload(c.data->ptr, data + (size_t)off * w, (size_t)nrows * w);
+  }
+  if (validity && a->null_count != 0 && nrows) {
+    uint64_t* h = shift_bitmap(validity, off, nrows);
+    int64_t valid = 0;
+    for (size_t wd = 0; wd < bitmap_bytes(nrows) / 8; wd++) valid += __builtin_popcountll(h[wd]);
+    if (valid != nrows) {
+      c.validity = make_buf(bitmap_bytes(nrows));
+      c.null_count = nrows - valid;
+      up.staged.push_back(h);
+      up.upload(c.validity->ptr, h, bitmap_bytes(nrows));
+    } else {
+      std::free(h);
+    }
+  }
+  return c;
+}
+
+// ---------------------------------------------------------------- export
+struct ExportPrivate {
+  std::vector<void*> host_buffers;
+  std::vector<const void*> buffer_ptrs;
+  std::vector<ArrowArray*> children;
+};
+static void release_array(ArrowArray* a) {
+  if (!a || !a->release) return;
+  auto* p = (ExportPrivate*)a->private_data;
+  for (ArrowArray* c : p->children) {
+    if (c->release) c->release(c);
+    delete c;
+  }
+  for (void* b : p->host_buffers) std::free(b);
+  delete p;
+  a->release = nullptr;
+}
+struct SchemaPrivate {
+  std::string format, name;
+  std::vector<ArrowSchema*> children;
+};
+static void release_schema(ArrowSchema* s) {
+  if (!s || !s->release) return;
+  auto* p = (SchemaPrivate*)s->private_data;
+  for (ArrowSchema* c : p->children) {
+    if (c->release) c->release(c);
+    delete c;
+  }
+  delete p;
+  s->release = nullptr;
+}
+static void fill_schema(ArrowSchema* s, const std::string& fmt, const std::string& name, bool nullable) {
+  auto* p = new SchemaPrivate{fmt, name, {}};
+  std::memset(s, 0, sizeof(*s));
+  s->format = p->format.c_str();
+  s->name = p->name.c_str();
+  s->flags = nullable ? 2 : 0;
+  s->release = release_schema;
+  s->private_data = p;
+}
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+
+extern "C" {
+
+int dfgpu_table_import(struct ArrowArray* array, struct ArrowSchema* schema, dfgpu_table_t* out) {
+  int rc = guarded([&] {
+    require_init();
+    DFGPU_CHECK(array && schema && out, "null argument");
+    DFGPU_CHECK(std::string(schema->format) == "+s", "dfgpu_table_import expects a struct array (RecordBatch)");
+    DFGPU_CHECK(array->n_children == schema->n_children, "array/schema children mismatch");
+    auto t = std::make_unique<Table>();
+    t->nrows = array->length;
+    Uploader up;
+    for (int64_t i = 0; i < array->n_children; i++)
+      t->cols.push_back(import_column(array->children[i], schema->children[i], array->offset, array->length, up));
+    up.finish();
+    *out = wrap(t.release());
+  });
+  // the call consumes both structures whether or not it succeeded
+  if (array && array->release) array->release(array);
+  if (schema && schema->release) schema->release(schema);
+  return rc;
+}
+
+int dfgpu_table_export(dfgpu_table_t th, struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+  return guarded([&] {
+    require_init();
+    Table* t = unwrap(th);
+    DFGPU_CHECK(out_array && out_schema, "null argument");
+    DFGPU_HIP(hipStreamSynchronize(rt().stream));
+    auto* ap = new ExportPrivate();
+    fill_schema(out_schema, "+s", "", false);
+    auto* sp = (SchemaPrivate*)out_schema->private_data;
+    for (Column& c : t->cols) {
+      if (c.validity && c.null_count < 0) count_nulls(c);
+      auto* ca = new ArrowArray();
+      std::memset(ca, 0, sizeof(*ca));
+      auto* cp = new ExportPrivate();
+      size_t db = data_bytes(c.field.type, c.length);
+      void* hd = std::malloc(db ? db : 8);
+      if (db) DFGPU_HIP(hipMemcpy(hd, c.ptr(), db, hipMemcpyDeviceToHost));
+      void* hv = nullptr;
+      if (c.validity && c.null_count != 0) {
+        size_t vb = bitmap_bytes(c.length);
+        hv = std::malloc(vb ? vb : 8);
+        if (vb) DFGPU_HIP(hipMemcpy(hv, c.validity->ptr, vb, hipMemcpyDeviceToHost));
+        cp->host_buffers.push_back(hv);
+      }
+      cp->host_buffers.push_back(hd);
+      cp->buffer_ptrs = {hv, hd};
+      ca->length = c.length;
+      ca->null_count = hv ? c.null_count : 0;
+      ca->n_buffers = 2;
+      ca->buffers = cp->buffer_ptrs.data();
+      ca->release = release_array;
+      ca->private_data = cp;
+      ap->children.push_back(ca);
+      auto* cs = new ArrowSchema();
+      fill_schema(cs, format_of(c.field), c.name, true);
+      sp->children.push_back(cs);
+    }
+    std::memset(out_array, 0, sizeof(*out_array));
+    ap->buffer_ptrs = {nullptr};
+    out_array->length = t->nrows;
+    out_array->n_buffers = 1;
+    out_array->buffers = ap->buffer_ptrs.data();
+    out_array->n_children = (int64_t)ap->children.size();
+    out_array->children = ap->children.data();
+    out_array->release = release_array;
+    out_array->private_data = ap;
+    out_schema->n_children = (int64_t)sp->children.size();
+    out_schema->children = sp->children.data();
+  });
+}
+
+int dfgpu_table_alloc(int ncols, const dfgpu_field* fields, const char* const* names, int64_t nrows, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    auto t = std::make_unique<Table>();
+    t->nrows = nrows;
+    for (int i = 0; i < ncols; i++) t->cols.push_back(alloc_column(fields[i], names && names[i] ? names[i] : "", nrows));
+    *out = wrap(t.release());
+  });
+}
+
+int dfgpu_table_free(dfgpu_table_t t) {
+  return guarded([&] { delete reinterpret_cast<Table*>(t); });
+}
+int dfgpu_table_num_rows(dfgpu_table_t t, int64_t* out) {
+  return guarded([&] { *out = unwrap(t)->nrows; });
+}
+int dfgpu_table_num_columns(dfgpu_table_t t, int* out) {
+  return guarded([&] { *out = (int)unwrap(t)->cols.size(); });
+}
+int dfgpu_table_column(dfgpu_table_t th, int i, dfgpu_column_view* out) {
+  return guarded([&] {
+    Table* t = unwrap(th);
+    DFGPU_CHECK(i >= 0 && i < (int)t->cols.size(), "column index out of range");
+    Column& c = t->cols[i];
+    if (c.validity && c.null_count < 0) count_nulls(c);
+    out->field = c.field;
+    out->length = c.length;
+    out->null_count = c.null_count;
+    out->data = c.ptr();
+    out->validity = c.validity ? (const uint8_t*)c.validity->ptr : nullptr;
+    out->name = c.name.c_str();
+  });
+}
+int dfgpu_table_select(dfgpu_table_t th, const int* cols, int ncols, dfgpu_table_t* out) {
+  return guarded([&] {
+    Table* t = unwrap(th);
+    auto o = std::make_unique<Table>();
+    o->nrows = t->nrows;
+    for (int i = 0; i < ncols; i++) {
+      DFGPU_CHECK(cols[i] >= 0 && cols[i] < (int)t->cols.size(), "column index out of range");
+      o->cols.push_back(t->cols[cols[i]]);
+    }
+    *out = wrap(o.release());
+  });
+}
+int dfgpu_table_hstack(dfgpu_table_t a, dfgpu_table_t b, dfgpu_table_t* out) {
+  return guarded([&] {
+    Table *ta = unwrap(a), *tb = unwrap(b);
+    DFGPU_CHECK(ta->nrows == tb->nrows, "hstack: row counts differ");
+    auto o = std::make_unique<Table>(*ta);
+    for (auto& c : tb->cols) o->cols.push_back(c);
+    *out = wrap(o.release());
+  });
+}
+
+int dfgpu_table_slice(dfgpu_table_t th, int64_t offset, int64_t length, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    Table* t = unwrap(th);
+    DFGPU_CHECK(offset >= 0 && length >= 0 && offset + length <= t->nrows, "slice out of range");
+    auto o = std::make_unique<Table>();
+    o->nrows = length;
+    for (auto& c : t->cols) {
+      DFGPU_CHECK(c.field.type != DFGPU_BOOL && !c.validity, "slice: Boolean / nullable columns not supported yet");
+      Column n = alloc_column(c.field, c.name, length);
+      int w = type_width(c.field.type);
+      if (length)
+        DFGPU_HIP(hipMemcpyAsync(n.data->ptr, (const char*)c.ptr() + (size_t)offset * w, (size_t)length * w, hipMemcpyDeviceToDevice, rt().stream));
+      o->cols.push_back(std::move(n));
+    }
+    *out = wrap(o.release());
+  });
+}
+
+int dfgpu_table_concat(const dfgpu_table_t* parts, int nparts, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(nparts >= 1, "concat of zero tables");
+    Table* first = unwrap(parts[0]);
+    int64_t total = 0;
+    for (int p = 0; p < nparts; p++) {
+      Table* t = unwrap(parts[p]);
+      DFGPU_CHECK(t->cols.size() == first->cols.size(), "concat: schema mismatch");
+      total += t->nrows;
+    }
+    auto o = std::make_unique<Table>();
+    o->nrows = total;
+    for (size_t ci = 0; ci < first->cols.size(); ci++) {
+      const Column& fc = first->cols[ci];
+      Column n = alloc_column(fc.field, fc.name, total);
+      DFGPU_CHECK(fc.field.type != DFGPU_BOOL, "concat: Boolean columns not supported yet");
+      int w = type_width(fc.field.type);
+      int64_t off = 0;
+      for (int p = 0; p < nparts; p++) {
+        Table* t = unwrap(parts[p]);
+        const Column& c = t->cols[ci];
+        DFGPU_CHECK(c.field.type == fc.field.type, "concat: column type mismatch");
+        DFGPU_CHECK(!c.validity, "concat: nullable columns not supported yet");
+        if (t->nrows)
+          DFGPU_HIP(hipMemcpyAsync((char*)n.data->ptr + (size_t)off * w, c.ptr(), (size_t)t->nrows * w, hipMemcpyDeviceToDevice, rt().stream));
+        off += t->nrows;
+      }
+      o->cols.push_back(std::move(n));
+    }
+    *out = wrap(o.release());
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+"""Multi-GPU hash-repartition exchange = RepartitionExec(Partitioning::Hash) across GPUs
+(physical-plan/src/repartition/mod.rs:1097-1150, :1626): each rank splits its rows by
+hash(keys; seed 0) % world_size with the K10 partition kernel (contiguous per-destination
+slices of one buffer per column), then one all-to-all(v) per column moves slice r of every
+rank to rank r.  In-process tokio channels of the reference become RCCL over xGMI
+(torch.distributed backend "nccl"); on CPU the same collective code runs over gloo in tests.
+
+One process per GPU.  torch is plumbing only: it wraps the library's HBM buffers as tensors
+(zero-copy, __cuda_array_interface__) so RCCL can send from / receive into them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+_W = {1: 4, 2: 8, 3: 16, 4: 8, 5: 1, 6: 4, 7: 8, 8: 4}  # dfgpu_type -> bytes
+
+
+class _DevMem:
+    """exposes a raw HBM range through __cuda_array_interface__ (uint8)"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _as_tensor(ptr: int, nbytes: int):
+    import torch
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device="cuda")
+    return torch.as_tensor(_DevMem(ptr, nbytes), device="cuda")
+
+
+def exchange_counts(send_counts, group=None):
+    """all ranks learn how many rows every peer sends them: returns recv_counts (list[int])"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    s = torch.tensor(list(send_counts), dtype=torch.int64, device=dev)
+    r = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(r, s, group=group)
+    return [int(x) for x in r.cpu().tolist()]
+
+
+def all_to_all_bytes(send, send_counts, recv, recv_counts, width, group=None):
+    """one all-to-all(v) of a column: `send`/`recv` are flat uint8 tensors, counts are rows"""
+    import torch.distributed as dist
+    dist.all_to_all_single(recv, send, output_split_sizes=[c * width for c in recv_counts],
+                           input_split_sizes=[c * width for c in send_counts], group=group)
+
+
+def hash_exchange(table, keys, group=None):
+    """DeviceTable -> DeviceTable holding every row (from all ranks) whose key hash routes here"""
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib, ops
+    from ._lib import Field, check
+    from .table import DeviceTable
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return table
+    lib = _lib.load()
+    parts = ops.partition(table, keys, world)
+    send_counts = [p.num_rows for p in parts]
+    recv_counts = exchange_counts(send_counts, group)
+    total = sum(recv_counts)
+    ncols = table.num_columns
+    views0 = [parts[0].column_view(i) for i in range(ncols)]
+    fields = (Field * ncols)(*[v.field for v in views0])
+    names = (C.c_char_p * ncols)(*[v.name for v in views0])
+    out = C.c_void_p()
+    check(lib.dfgpu_table_alloc(ncols, fields, names, C.c_int64(total), C.byref(out)))
+    result = DeviceTable(out)
+    ops.sync()  # partition kernels ran on the library stream; RCCL runs on torch's
+    n_send = sum(send_counts)
+    for i in range(ncols):
+        v = views0[i]
+        if v.validity:
+            raise _lib.DfgpuError("hash_exchange: nullable columns are not supported yet")
+        w = _W[v.field.type]
+        # partition outputs are consecutive slices of one buffer: partition 0's pointer is its start
+        send = _as_tensor(v.data, n_send * w)
+        rv = result.column_view(i)
+        recv = _as_tensor(rv.data, total * w)
+        all_to_all_bytes(send, send_counts, recv, recv_counts, w, group)
+    torch.cuda.synchronize()
+    for p in parts:
+        p.free()
+    return result
+
+
+def route(hashes: np.ndarray, world: int) -> np.ndarray:
+    """destination rank of a row = hash % world (BatchPartitioner hash arm, repartition/mod.rs:1111-1150)"""
+    return (hashes % np.uint64(world)).astype(np.int64)

@@ -1,0 +1,196 @@
+"""Host-side mirror of the PhysicalExpr node kinds the GPU path evaluates
+(physical-expr-common/src/physical_expr.rs:76; concrete nodes in physical-expr/src/expressions/:
+column.rs `Column`, literal.rs `Literal`, cast.rs `CastExpr`, binary.rs `BinaryExpr`,
+is_null.rs `IsNullExpr`, is_not_null.rs `IsNotNullExpr`, not.rs `NotExpr`).
+
+The trees are lowered to the flat `dfgpu_expr_node[]` IR of include/dfgpu.h; typing (decimal
+result precision/scale, operand checks) happens inside the library so a Rust shim can pass
+trees through unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+from decimal import Decimal
+
+import pyarrow as pa
+
+from ._lib import Expr, ExprNode, Field
+from .table import field_of
+
+# dfgpu_expr_op
+OP_COLUMN, OP_LITERAL, OP_CAST = 1, 2, 3
+_BINARY = {"+": 10, "-": 11, "*": 12, "=": 20, "!=": 21, "<": 22, "<=": 23, ">": 24, ">=": 25, "and": 30, "or": 31}
+OP_NOT, OP_IS_NULL, OP_IS_NOT_NULL = 32, 33, 34
+
+
+class PhysicalExpr:
+    def children(self):
+        return []
+
+    # operator sugar so tests can write col("a") + lit(1)
+    def __add__(self, o): return BinaryExpr(self, "+", _wrap(o))
+    def __sub__(self, o): return BinaryExpr(self, "-", _wrap(o))
+    def __mul__(self, o): return BinaryExpr(self, "*", _wrap(o))
+    def __rsub__(self, o): return BinaryExpr(_wrap(o), "-", self)
+    def __radd__(self, o): return BinaryExpr(_wrap(o), "+", self)
+    def __rmul__(self, o): return BinaryExpr(_wrap(o), "*", self)
+    def __lt__(self, o): return BinaryExpr(self, "<", _wrap(o))
+    def __le__(self, o): return BinaryExpr(self, "<=", _wrap(o))
+    def __gt__(self, o): return BinaryExpr(self, ">", _wrap(o))
+    def __ge__(self, o): return BinaryExpr(self, ">=", _wrap(o))
+    def eq(self, o): return BinaryExpr(self, "=", _wrap(o))
+    def ne(self, o): return BinaryExpr(self, "!=", _wrap(o))
+    def and_(self, o): return BinaryExpr(self, "and", _wrap(o))
+    def or_(self, o): return BinaryExpr(self, "or", _wrap(o))
+    def is_null(self): return IsNullExpr(self)
+    def is_not_null(self): return IsNotNullExpr(self)
+    def not_(self): return NotExpr(self)
+    def cast(self, t): return CastExpr(self, t)
+
+
+class Column(PhysicalExpr):
+    """Column::new(name, index) — index may be omitted and resolved against a schema"""
+
+    def __init__(self, name: str, index: int | None = None):
+        self.name, self.index = name, index
+
+    def __repr__(self):
+        return f"{self.name}@{self.index}"
+
+
+class Literal(PhysicalExpr):
+    """Literal::new(ScalarValue)"""
+
+    def __init__(self, value, type_: pa.DataType):
+        self.value, self.type = value, type_
+
+    def __repr__(self):
+        return f"{self.value}:{self.type}"
+
+
+class CastExpr(PhysicalExpr):
+    def __init__(self, expr: PhysicalExpr, cast_type: pa.DataType):
+        self.expr, self.cast_type = expr, cast_type
+
+    def children(self):
+        return [self.expr]
+
+
+class BinaryExpr(PhysicalExpr):
+    """BinaryExpr::new(left, op, right)"""
+
+    def __init__(self, left: PhysicalExpr, op: str, right: PhysicalExpr):
+        if op not in _BINARY:
+            raise ValueError(f"operator {op!r} is not supported on the GPU path")
+        self.left, self.op, self.right = left, op, right
+
+    def children(self):
+        return [self.left, self.right]
+
+    def __repr__(self):
+        return f"({self.left!r} {self.op} {self.right!r})"
+
+
+class IsNullExpr(PhysicalExpr):
+    def __init__(self, arg): self.arg = arg
+    def children(self): return [self.arg]
+
+
+class IsNotNullExpr(PhysicalExpr):
+    def __init__(self, arg): self.arg = arg
+    def children(self): return [self.arg]
+
+
+class NotExpr(PhysicalExpr):
+    def __init__(self, arg): self.arg = arg
+    def children(self): return [self.arg]
+
+
+def col(name, index=None) -> Column:
+    return Column(name, index)
+
+
+def lit(value, type_: pa.DataType | None = None) -> Literal:
+    if type_ is None:
+        if isinstance(value, bool):
+            type_ = pa.bool_()
+        elif isinstance(value, int):
+            type_ = pa.int64()
+        elif isinstance(value, float):
+            type_ = pa.float64()
+        else:
+            raise TypeError("lit(): give an explicit arrow type")
+    return Literal(value, type_)
+
+
+def _wrap(v):
+    return v if isinstance(v, PhysicalExpr) else lit(v)
+
+
+def _literal_bits(value, t: pa.DataType):
+    """(lo, hi) 128-bit two's complement of the literal (f64: IEEE bits in lo)"""
+    if pa.types.is_float64(t):
+        return struct.unpack("<Q", struct.pack("<d", float(value)))[0], 0
+    if pa.types.is_decimal128(t):
+        v = int(Decimal(str(value)).scaleb(t.scale).to_integral_value())
+    elif pa.types.is_date32(t) and not isinstance(value, int):
+        v = pa.scalar(value, type=pa.date32()).cast(pa.int32()).as_py()
+    elif pa.types.is_boolean(t):
+        v = 1 if value else 0
+    else:
+        v = int(value)
+    v &= (1 << 128) - 1
+    return v & 0xFFFFFFFFFFFFFFFF, v >> 64
+
+
+class LoweredExpr:
+    """keeps the node array alive while the C struct points at it"""
+
+    def __init__(self, nodes):
+        self.nodes = (ExprNode * len(nodes))(*nodes)
+        self.c = Expr(C.cast(self.nodes, C.POINTER(ExprNode)), len(nodes), len(nodes) - 1)
+
+
+def lower(expr: PhysicalExpr, column_names) -> LoweredExpr:
+    """post-order flattening; the root is the last node"""
+    nodes: list[ExprNode] = []
+    names = list(column_names)
+
+    def emit(e) -> int:
+        n = ExprNode()
+        n.left = n.right = -1
+        n.column = -1
+        if isinstance(e, Column):
+            n.op = OP_COLUMN
+            if e.index is not None:
+                n.column = e.index
+            else:
+                if names.count(e.name) != 1:
+                    raise KeyError(f"column {e.name!r} not found or ambiguous in {names}")
+                n.column = names.index(e.name)
+        elif isinstance(e, Literal):
+            n.op = OP_LITERAL
+            n.field = field_of(e.type)
+            if e.value is None:
+                n.is_null = 1
+            else:
+                n.lit_lo, n.lit_hi = _literal_bits(e.value, e.type)
+        elif isinstance(e, CastExpr):
+            n.left = emit(e.expr)
+            n.op = OP_CAST
+            n.field = field_of(e.cast_type)
+        elif isinstance(e, BinaryExpr):
+            n.left = emit(e.left)
+            n.right = emit(e.right)
+            n.op = _BINARY[e.op]
+        elif isinstance(e, (IsNullExpr, IsNotNullExpr, NotExpr)):
+            n.left = emit(e.arg)
+            n.op = {IsNullExpr: OP_IS_NULL, IsNotNullExpr: OP_IS_NOT_NULL, NotExpr: OP_NOT}[type(e)]
+        else:
+            raise TypeError(f"{type(e).__name__} is not supported on the GPU path")
+        nodes.append(n)
+        return len(nodes) - 1
+
+    emit(expr)
+    return LoweredExpr(nodes)

@@ -1,0 +1,258 @@
+"""Operator-level calls into libdfgpu.so — thin, typed wrappers of the C ABI entry points.
+The ExecutionPlan-shaped layer (physical_plan.py) is built on these.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import pyarrow as pa
+
+from . import _lib
+from ._lib import AggSpec, Expr, Field, JoinInfo, JoinOptions, KernelStat, check
+from .expr import PhysicalExpr, lower
+from .table import DeviceTable, field_of
+
+JOIN_TYPES = {"Inner": 0, "Left": 1, "Right": 2, "Full": 3, "LeftSemi": 4, "RightSemi": 5, "LeftAnti": 6,
+              "RightAnti": 7, "LeftMark": 8, "RightMark": 9}
+NULL_EQUALITY = {"NullEqualsNothing": 0, "NullEqualsNull": 1}
+AGG_MODES = {"Partial": 0, "Final": 1, "FinalPartitioned": 2, "Single": 3, "SinglePartitioned": 4}
+AGG_FUNCS = {"sum": 0, "min": 1, "max": 2, "count": 3, "avg": 4}
+
+
+def _ints(values):
+    return (C.c_int * max(1, len(values)))(*values)
+
+
+def filter(table: DeviceTable, predicate: PhysicalExpr, projection=None) -> DeviceTable:
+    """FilterExec: predicate + optional embedded projection (filter.rs:85)"""
+    lib = _lib.init()
+    names = table.column_names
+    le = lower(predicate, names)
+    out = C.c_void_p()
+    if projection is None:
+        check(lib.dfgpu_filter(table.handle, C.byref(le.c), None, 0, C.byref(out)))
+    else:
+        idx = [table.index_of(c) for c in projection]
+        check(lib.dfgpu_filter(table.handle, C.byref(le.c), _ints(idx), len(idx), C.byref(out)))
+    return DeviceTable(out)
+
+
+def project(table: DeviceTable, exprs) -> DeviceTable:
+    """ProjectionExec: exprs = [(PhysicalExpr, name)] (projection.rs:439)"""
+    lib = _lib.init()
+    names = table.column_names
+    lowered = [lower(e, names) for e, _ in exprs]
+    arr = (Expr * len(exprs))(*[l.c for l in lowered])
+    cnames = (C.c_char_p * len(exprs))(*[n.encode() for _, n in exprs])
+    out = C.c_void_p()
+    check(lib.dfgpu_project(table.handle, arr, cnames, len(exprs), C.byref(out)))
+    return DeviceTable(out)
+
+
+class JoinHashTable:
+    """JoinLeftData (hash_join/exec.rs:195-240): the built side of a hash join"""
+
+    def __init__(self, build: DeviceTable, on_left, null_equality="NullEqualsNothing", table_mode=0,
+                 small_build_threshold=1024, min_key_density=0.15, force_hash_collisions=False):
+        lib = _lib.init()
+        self.build = build  # keep alive
+        self.key_idx = [build.index_of(k) for k in on_left]
+        opts = JoinOptions(small_build_threshold, min_key_density, table_mode, int(force_hash_collisions))
+        self._h = C.c_void_p()
+        check(lib.dfgpu_join_build(build.handle, _ints(self.key_idx), len(self.key_idx), NULL_EQUALITY[null_equality],
+                                   C.byref(opts), C.byref(self._h)))
+
+    def probe(self, probe: DeviceTable, on_right, join_type="Inner", build_cols=None, probe_cols=None) -> DeviceTable:
+        lib = _lib.load()
+        pk = [probe.index_of(k) for k in on_right]
+        bc = list(range(self.build.num_columns)) if build_cols is None else [self.build.index_of(c) for c in build_cols]
+        pc = list(range(probe.num_columns)) if probe_cols is None else [probe.index_of(c) for c in probe_cols]
+        if join_type in ("LeftSemi", "LeftAnti", "LeftMark"):
+            pc = []
+        if join_type in ("RightSemi", "RightAnti", "RightMark"):
+            bc = []
+        out = C.c_void_p()
+        check(lib.dfgpu_join_probe(self._h, probe.handle, _ints(pk), JOIN_TYPES[join_type], _ints(bc), len(bc), _ints(pc),
+                                   len(pc), C.byref(out)))
+        return DeviceTable(out)
+
+    def emit_unmatched(self, join_type, build_cols=None, probe_schema: pa.Schema | None = None) -> DeviceTable:
+        """process_unmatched_build_batch (stream.rs:1002-): build rows by visited state"""
+        lib = _lib.load()
+        bc = list(range(self.build.num_columns)) if build_cols is None else [self.build.index_of(c) for c in build_cols]
+        fields = [field_of(f.type) for f in probe_schema] if probe_schema is not None else []
+        names = [f.name.encode() for f in probe_schema] if probe_schema is not None else []
+        farr = (Field * max(1, len(fields)))(*fields)
+        narr = (C.c_char_p * max(1, len(names)))(*names)
+        out = C.c_void_p()
+        check(lib.dfgpu_join_emit_unmatched(self._h, JOIN_TYPES[join_type], _ints(bc), len(bc), farr, narr, len(fields), C.byref(out)))
+        return DeviceTable(out)
+
+    def info(self) -> JoinInfo:
+        i = JoinInfo()
+        check(_lib.load().dfgpu_join_get_info(self._h, C.byref(i)))
+        return i
+
+    def free(self):
+        if self._h:
+            _lib.load().dfgpu_join_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def hash_join(left: DeviceTable, right: DeviceTable, on, join_type="Inner", null_equality="NullEqualsNothing",
+              build_cols=None, probe_cols=None, **build_opts) -> DeviceTable:
+    """HashJoinExec over whole tables: left = build side, right = probe side"""
+    ht = JoinHashTable(left, [l for l, _ in on], null_equality, **build_opts)
+    out = ht.probe(right, [r for _, r in on], join_type, build_cols, probe_cols)
+    if join_type in ("Left", "Full", "LeftSemi", "LeftAnti", "LeftMark"):
+        psch = None
+        if join_type in ("Left", "Full"):
+            rs = right.schema
+            pnames = rs.names if probe_cols is None else [right.column_names[right.index_of(c)] for c in probe_cols]
+            psch = pa.schema([rs.field(rs.get_field_index(n)) if rs.names.count(n) == 1 else rs.field(right.index_of(n)) for n in pnames])
+        tail = ht.emit_unmatched(join_type, build_cols, psch)
+        if join_type in ("Left", "Full"):
+            # concat needs equal nullability handling: go through the generic concat
+            out = concat_tables([out, tail])
+        else:
+            out = tail
+    ht.free()
+    return out
+
+
+def concat_tables(parts) -> DeviceTable:
+    """concat_batches; falls back to a host round trip when a part carries NULLs (not a hot path)"""
+    try:
+        return DeviceTable.concat(parts)
+    except _lib.DfgpuError:
+        tables = [p.to_arrow() for p in parts]
+        return DeviceTable.from_arrow(pa.concat_tables([t.cast(tables[0].schema) for t in tables]))
+
+
+def partition(table: DeviceTable, keys, nparts: int):
+    """RepartitionExec Partitioning::Hash(keys, nparts) -> list of DeviceTables"""
+    lib = _lib.init()
+    idx = [table.index_of(k) for k in keys]
+    outs = (C.c_void_p * nparts)()
+    check(lib.dfgpu_partition(table.handle, _ints(idx), len(idx), nparts, outs))
+    return [DeviceTable(C.c_void_p(h)) for h in outs]
+
+
+def sort(table: DeviceTable, keys, fetch=None) -> DeviceTable:
+    """SortExec: keys = [(column, descending, nulls_first)]; fetch = TopK limit"""
+    lib = _lib.init()
+    idx = [table.index_of(k) for k, _, _ in keys]
+    desc = (C.c_uint8 * len(keys))(*[int(d) for _, d, _ in keys])
+    nf = (C.c_uint8 * len(keys))(*[int(f) for _, _, f in keys])
+    out = C.c_void_p()
+    check(lib.dfgpu_sort(table.handle, _ints(idx), desc, nf, len(keys), C.c_int64(-1 if fetch is None else fetch), C.byref(out)))
+    return DeviceTable(out)
+
+
+class GroupedAggregate:
+    """AggregateExec state: group_by = [(expr, name)], aggs = [(func, expr|None, name)]"""
+
+    def __init__(self, mode, input_names, group_by, aggs):
+        lib = _lib.init()
+        self._keep = []
+        g_low = [lower(e, input_names) for e, _ in group_by]
+        self._keep += g_low
+        garr = (Expr * max(1, len(g_low)))(*[l.c for l in g_low])
+        gnames = (C.c_char_p * max(1, len(group_by)))(*[n.encode() for _, n in group_by])
+        specs = []
+        for func, e, name in aggs:
+            s = AggSpec()
+            s.func = AGG_FUNCS[func]
+            s.has_arg = 0 if e is None else 1
+            if e is not None:
+                l = lower(e, input_names)
+                self._keep.append(l)
+                s.arg = l.c
+            s.name = name.encode()
+            specs.append(s)
+        sarr = (AggSpec * max(1, len(specs)))(*specs)
+        self._h = C.c_void_p()
+        check(lib.dfgpu_agg_create(AGG_MODES[mode], garr, gnames, len(group_by), sarr, len(specs), C.byref(self._h)))
+
+    def update(self, table: DeviceTable):
+        check(_lib.load().dfgpu_agg_update(self._h, table.handle))
+
+    def emit(self) -> DeviceTable:
+        out = C.c_void_p()
+        check(_lib.load().dfgpu_agg_emit(self._h, C.byref(out)))
+        return DeviceTable(out)
+
+    def free(self):
+        if self._h:
+            _lib.load().dfgpu_agg_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def aggregate(table: DeviceTable, group_by, aggs, mode="Single") -> DeviceTable:
+    a = GroupedAggregate(mode, table.column_names, group_by, aggs)
+    a.update(table)
+    out = a.emit()
+    a.free()
+    return out
+
+
+# ------------------------------------------------------------------ synthetic workload
+def tpch_orders(sf: float, begin=0, end=-1) -> DeviceTable:
+    out = C.c_void_p()
+    check(_lib.init().dfgpu_tpch_orders(C.c_double(sf), C.c_int64(begin), C.c_int64(end), C.byref(out)))
+    return DeviceTable(out)
+
+
+def tpch_lineitem(sf: float, begin=0, end=-1, float_money=False) -> DeviceTable:
+    out = C.c_void_p()
+    check(_lib.init().dfgpu_tpch_lineitem(C.c_double(sf), C.c_int64(begin), C.c_int64(end), int(float_money), C.byref(out)))
+    return DeviceTable(out)
+
+
+def tpch_customer(sf: float, begin=0, end=-1) -> DeviceTable:
+    out = C.c_void_p()
+    check(_lib.init().dfgpu_tpch_customer(C.c_double(sf), C.c_int64(begin), C.c_int64(end), C.byref(out)))
+    return DeviceTable(out)
+
+
+# ----------------------------------------------------------------------------- metrics
+def sync():
+    check(_lib.load().dfgpu_sync())
+
+
+def profile_enable(on=True):
+    check(_lib.init().dfgpu_profile_enable(int(on)))
+
+
+def profile_reset():
+    check(_lib.load().dfgpu_profile_reset())
+
+
+def profile_stats():
+    lib = _lib.load()
+    n = C.c_int()
+    check(lib.dfgpu_profile_count(C.byref(n)))
+    out = {}
+    for i in range(n.value):
+        s = KernelStat()
+        check(lib.dfgpu_profile_get(i, C.byref(s)))
+        out[s.name.decode()] = {"calls": s.calls, "total_ms": s.total_ms, "bytes": s.algorithmic_bytes}
+    return out
+
+
+def mem_stats():
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    check(_lib.load().dfgpu_mem_stats(C.byref(a), C.byref(b), C.byref(c)))
+    return {"in_use": a.value, "cached": b.value, "peak": c.value}

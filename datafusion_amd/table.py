@@ -1,0 +1,175 @@
+"""DeviceTable: a RecordBatch whose column buffers live in HBM (handle into libdfgpu.so).
+
+Crossing the boundary uses the Arrow C Data Interface exactly as the reference's own FFI
+streams do (datafusion/ffi/src/record_batch_stream.rs:105-114,156-172 wrap a StructArray in
+FFI_ArrowArray + FFI_ArrowSchema).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import pyarrow as pa
+
+from . import _lib
+from ._lib import ColumnView, Field, check
+
+# dfgpu_type
+INT32, INT64, DECIMAL128, FLOAT64, UINT8, UINT32, UINT64, DATE32, BOOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
+
+
+class ArrowSchema(C.Structure):
+    pass
+
+
+class ArrowArray(C.Structure):
+    pass
+
+
+ArrowSchema._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64),
+                        ("n_children", C.c_int64), ("children", C.POINTER(C.POINTER(ArrowSchema))),
+                        ("dictionary", C.POINTER(ArrowSchema)), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                       ("n_children", C.c_int64), ("buffers", C.POINTER(C.c_void_p)),
+                       ("children", C.POINTER(C.POINTER(ArrowArray))), ("dictionary", C.POINTER(ArrowArray)),
+                       ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+def field_of(t: pa.DataType) -> Field:
+    if pa.types.is_int32(t):
+        return Field(INT32, 0, 0, 1)
+    if pa.types.is_int64(t):
+        return Field(INT64, 0, 0, 1)
+    if pa.types.is_decimal128(t):
+        return Field(DECIMAL128, t.precision, t.scale, 1)
+    if pa.types.is_float64(t):
+        return Field(FLOAT64, 0, 0, 1)
+    if pa.types.is_uint8(t):
+        return Field(UINT8, 0, 0, 1)
+    if pa.types.is_uint32(t):
+        return Field(UINT32, 0, 0, 1)
+    if pa.types.is_uint64(t):
+        return Field(UINT64, 0, 0, 1)
+    if pa.types.is_date32(t):
+        return Field(DATE32, 0, 0, 1)
+    if pa.types.is_boolean(t):
+        return Field(BOOL, 0, 0, 1)
+    raise TypeError(f"type {t} is not supported on the GPU path")
+
+
+def arrow_type_of(f: Field) -> pa.DataType:
+    return {INT32: pa.int32(), INT64: pa.int64(), FLOAT64: pa.float64(), UINT8: pa.uint8(), UINT32: pa.uint32(),
+            UINT64: pa.uint64(), DATE32: pa.date32(), BOOL: pa.bool_()}.get(f.type) or pa.decimal128(f.precision, f.scale)
+
+
+class DeviceTable:
+    """owning wrapper of a dfgpu_table_t"""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+
+    # ------------------------------------------------------------------ construction
+    @staticmethod
+    def from_arrow(data) -> "DeviceTable":
+        lib = _lib.init()
+        if isinstance(data, pa.Table):
+            batches = data.combine_chunks().to_batches()
+            if len(batches) == 0:
+                batch = pa.RecordBatch.from_arrays([pa.array([], type=f.type) for f in data.schema], schema=data.schema)
+            elif len(batches) == 1:
+                batch = batches[0]
+            else:
+                batch = pa.Table.from_batches(batches).combine_chunks().to_batches()[0]
+        else:
+            batch = data
+        arr, sch = ArrowArray(), ArrowSchema()
+        batch._export_to_c(C.addressof(arr), C.addressof(sch))
+        out = C.c_void_p()
+        check(lib.dfgpu_table_import(C.byref(arr), C.byref(sch), C.byref(out)))
+        return DeviceTable(out)
+
+    def to_arrow(self) -> pa.Table:
+        lib = _lib.load()
+        arr, sch = ArrowArray(), ArrowSchema()
+        check(lib.dfgpu_table_export(self._h, C.byref(arr), C.byref(sch)))
+        batch = pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+        return pa.Table.from_batches([batch])
+
+    # ------------------------------------------------------------------ inspection
+    @property
+    def handle(self) -> C.c_void_p:
+        if self._h is None:
+            raise _lib.DfgpuError("table already freed")
+        return self._h
+
+    @property
+    def num_rows(self) -> int:
+        n = C.c_int64()
+        check(_lib.load().dfgpu_table_num_rows(self.handle, C.byref(n)))
+        return n.value
+
+    @property
+    def num_columns(self) -> int:
+        n = C.c_int()
+        check(_lib.load().dfgpu_table_num_columns(self.handle, C.byref(n)))
+        return n.value
+
+    def column_view(self, i: int) -> ColumnView:
+        v = ColumnView()
+        check(_lib.load().dfgpu_table_column(self.handle, i, C.byref(v)))
+        return v
+
+    @property
+    def column_names(self):
+        return [self.column_view(i).name.decode() for i in range(self.num_columns)]
+
+    @property
+    def schema(self) -> pa.Schema:
+        views = [self.column_view(i) for i in range(self.num_columns)]
+        return pa.schema([pa.field(v.name.decode(), arrow_type_of(v.field)) for v in views])
+
+    def index_of(self, name_or_index) -> int:
+        if isinstance(name_or_index, int):
+            return name_or_index
+        names = self.column_names
+        if names.count(name_or_index) != 1:
+            raise KeyError(f"column {name_or_index!r} not found or ambiguous in {names}")
+        return names.index(name_or_index)
+
+    def nbytes(self) -> int:
+        total = 0
+        for i in range(self.num_columns):
+            v = self.column_view(i)
+            w = {INT32: 4, INT64: 8, DECIMAL128: 16, FLOAT64: 8, UINT8: 1, UINT32: 4, UINT64: 8, DATE32: 4}.get(v.field.type)
+            total += (v.length + 7) // 8 if w is None else v.length * w
+        return total
+
+    # ------------------------------------------------------------------ zero-copy ops
+    def select(self, cols) -> "DeviceTable":
+        idx = [self.index_of(c) for c in cols]
+        arr = (C.c_int * len(idx))(*idx)
+        out = C.c_void_p()
+        check(_lib.load().dfgpu_table_select(self.handle, arr, len(idx), C.byref(out)))
+        return DeviceTable(out)
+
+    def slice(self, offset: int, length: int) -> "DeviceTable":
+        out = C.c_void_p()
+        check(_lib.load().dfgpu_table_slice(self.handle, C.c_int64(offset), C.c_int64(length), C.byref(out)))
+        return DeviceTable(out)
+
+    @staticmethod
+    def concat(parts) -> "DeviceTable":
+        arr = (C.c_void_p * len(parts))(*[p.handle for p in parts])
+        out = C.c_void_p()
+        check(_lib.load().dfgpu_table_concat(arr, len(parts), C.byref(out)))
+        return DeviceTable(out)
+
+    def free(self):
+        if self._h is not None:
+            _lib.load().dfgpu_table_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,337 @@
+/*
+ * dfgpu.h — C ABI of libdfgpu.so: MI355X-native (gfx950) execution backend for
+ * DataFusion's vectorized physical operators.
+ *
+ * This is the drop-in boundary.  The reference has no C-friendly ABI for
+ * operators (datafusion-ffi is Rust<->Rust: stabby vectors + async-ffi wakers,
+ * datafusion/ffi/README.md:61-74), so what a Rust `ExecutionPlan` shim binds is this
+ * header; data crosses as Arrow C Data Interface structs, layout-identical to the
+ * `FFI_ArrowArray`/`FFI_ArrowSchema` pair the reference's own FFI streams carry
+ * (datafusion/ffi/src/arrow_wrappers.rs:31,72-75; record_batch_stream.rs:105-114).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/datafusion/).  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is in
+ *     dfgpu_last_error() (thread-local), mirroring `Result<_, DataFusionError>`.
+ *   - one process drives one GPU (dfgpu_init(device)); all work is enqueued on the
+ *     library's own HIP stream; calls are synchronous w.r.t. results they return
+ *     (row counts), asynchronous otherwise.  dfgpu_sync() drains the stream.
+ *   - handles are owned by exactly one caller and freed exactly once.  A join table
+ *     (dfgpu_join_t) is immutable after build and may be probed by many callers
+ *     (CollectLeft: one build shared by all probe partitions, hash_join/exec.rs:1503-1523).
+ *   - device columns are Arrow-layout buffers in HBM: fixed-width values, optional
+ *     validity bitmap (LSB first, 1 = valid), Boolean columns bit-packed.
+ */
+#ifndef DFGPU_H
+#define DFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFGPU_ABI_VERSION 1
+
+/* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+
+/* ------------------------------------------------------------------ types */
+
+typedef enum dfgpu_type {
+  DFGPU_INT32 = 1,
+  DFGPU_INT64 = 2,
+  DFGPU_DECIMAL128 = 3, /* 16-byte LE two's complement + (precision, scale) */
+  DFGPU_FLOAT64 = 4,
+  DFGPU_UINT8 = 5, /* dictionary codes / packed 1-byte strings */
+  DFGPU_UINT32 = 6,
+  DFGPU_UINT64 = 7,
+  DFGPU_DATE32 = 8, /* days since epoch, int32 */
+  DFGPU_BOOL = 9    /* bit-packed */
+} dfgpu_type;
+
+typedef struct dfgpu_field {
+  int32_t type; /* dfgpu_type */
+  int32_t precision;
+  int32_t scale;
+  int32_t nullable;
+} dfgpu_field;
+
+/* read-only view of one device column */
+typedef struct dfgpu_column_view {
+  dfgpu_field field;
+  int64_t length;
+  int64_t null_count;
+  const void* data;        /* device pointer */
+  const uint8_t* validity; /* device pointer or NULL */
+  const char* name;        /* owned by the table */
+} dfgpu_column_view;
+
+typedef struct dfgpu_table_s* dfgpu_table_t;
+typedef struct dfgpu_join_s* dfgpu_join_t;
+typedef struct dfgpu_agg_s* dfgpu_agg_t;
+
+/* JoinType (common/src/join_type.rs) — same order as the reference enum */
+typedef enum dfgpu_join_type {
+  DFGPU_JOIN_INNER = 0,
+  DFGPU_JOIN_LEFT = 1,
+  DFGPU_JOIN_RIGHT = 2,
+  DFGPU_JOIN_FULL = 3,
+  DFGPU_JOIN_LEFT_SEMI = 4,
+  DFGPU_JOIN_RIGHT_SEMI = 5,
+  DFGPU_JOIN_LEFT_ANTI = 6,
+  DFGPU_JOIN_RIGHT_ANTI = 7,
+  DFGPU_JOIN_LEFT_MARK = 8,
+  DFGPU_JOIN_RIGHT_MARK = 9
+} dfgpu_join_type;
+
+/* NullEquality (common/src/null_equality.rs) */
+typedef enum dfgpu_null_equality { DFGPU_NULL_EQUALS_NOTHING = 0, DFGPU_NULL_EQUALS_NULL = 1 } dfgpu_null_equality;
+
+/* ------------------------------------------------------- lifecycle / errors */
+
+int dfgpu_abi_version(void);
+/* bind this process to `device` and create the library stream + memory pool */
+int dfgpu_init(int device);
+int dfgpu_shutdown(void);
+int dfgpu_device_count(int* out);
+/* thread-local message of the last failing call ("" if none) */
+const char* dfgpu_last_error(void);
+/* drain the library stream */
+int dfgpu_sync(void);
+/* the hipStream_t all kernels are launched on (as void*) */
+void* dfgpu_stream(void);
+
+/* pool statistics: bytes currently handed out / cached / high-water mark.
+ * Counterpart of MemoryReservation accounting (execution/src/memory_pool/mod.rs:188). */
+int dfgpu_mem_stats(int64_t* in_use, int64_t* cached, int64_t* peak);
+int dfgpu_mem_trim(void);
+
+/* ------------------------------------------------------------------ tables */
+
+/* Import a RecordBatch (a struct array, as exported by arrow-rs `to_ffi` /
+ * pyarrow `_export_to_c`): host buffers are copied to HBM with async H2D copies.
+ * Consumes `array` and `schema` (calls their release callbacks).
+ * Replaces: the input side of ExecutionPlan::execute (physical-plan/src/
+ * execution_plan.rs:696-700) for batches produced by a CPU child. */
+int dfgpu_table_import(struct ArrowArray* array, struct ArrowSchema* schema, dfgpu_table_t* out);
+/* Export to host memory as a struct array + schema owned by the caller (release
+ * callbacks set).  Replaces: the RecordBatch items a SendableRecordBatchStream yields. */
+int dfgpu_table_export(dfgpu_table_t t, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+/* allocate a table of uninitialised device columns (filled by generators / exchange) */
+int dfgpu_table_alloc(int ncols, const dfgpu_field* fields, const char* const* names, int64_t nrows, dfgpu_table_t* out);
+int dfgpu_table_free(dfgpu_table_t t);
+int dfgpu_table_num_rows(dfgpu_table_t t, int64_t* out);
+int dfgpu_table_num_columns(dfgpu_table_t t, int* out);
+int dfgpu_table_column(dfgpu_table_t t, int i, dfgpu_column_view* out);
+/* zero-copy column subset / reorder (RecordBatch::project) */
+int dfgpu_table_select(dfgpu_table_t t, const int* cols, int ncols, dfgpu_table_t* out);
+/* zero-copy horizontal concatenation of two tables with equal row counts */
+int dfgpu_table_hstack(dfgpu_table_t a, dfgpu_table_t b, dfgpu_table_t* out);
+/* vertical concatenation (arrow-select concat_batches, hash_join/exec.rs:2705) */
+int dfgpu_table_concat(const dfgpu_table_t* parts, int nparts, dfgpu_table_t* out);
+/* contiguous row range copy (RecordBatch::slice) */
+int dfgpu_table_slice(dfgpu_table_t t, int64_t offset, int64_t length, dfgpu_table_t* out);
+
+/* ------------------------------------------------------------- expressions */
+
+/* PhysicalExpr trees (physical-expr-common/src/physical_expr.rs:76) cross the ABI as a
+ * flat node array; the Rust shim lowers Column / Literal / CastExpr / BinaryExpr /
+ * IsNullExpr / NotExpr into it (anything else keeps the CPU operator). */
+typedef enum dfgpu_expr_op {
+  DFGPU_EXPR_COLUMN = 1,  /* expressions/column.rs:121 */
+  DFGPU_EXPR_LITERAL = 2, /* expressions/literal.rs */
+  DFGPU_EXPR_CAST = 3,    /* expressions/cast.rs */
+  DFGPU_EXPR_ADD = 10,    /* BinaryExpr, expressions/binary.rs:536-656 */
+  DFGPU_EXPR_SUB = 11,
+  DFGPU_EXPR_MUL = 12,
+  DFGPU_EXPR_EQ = 20,
+  DFGPU_EXPR_NE = 21,
+  DFGPU_EXPR_LT = 22,
+  DFGPU_EXPR_LE = 23,
+  DFGPU_EXPR_GT = 24,
+  DFGPU_EXPR_GE = 25,
+  DFGPU_EXPR_AND = 30,
+  DFGPU_EXPR_OR = 31,
+  DFGPU_EXPR_NOT = 32,
+  DFGPU_EXPR_IS_NULL = 33,
+  DFGPU_EXPR_IS_NOT_NULL = 34
+} dfgpu_expr_op;
+
+typedef struct dfgpu_expr_node {
+  int32_t op;          /* dfgpu_expr_op */
+  int32_t column;      /* COLUMN: index into the input table */
+  int32_t left, right; /* child node indices, -1 = none */
+  dfgpu_field field;   /* LITERAL: literal type; CAST: target type; else ignored */
+  int32_t is_null;     /* LITERAL: SQL NULL */
+  int32_t _pad;
+  uint64_t lit_lo, lit_hi; /* LITERAL bits: int sign-extended to 128 / f64 bits in lit_lo */
+} dfgpu_expr_node;
+
+typedef struct dfgpu_expr {
+  const dfgpu_expr_node* nodes;
+  int32_t n_nodes;
+  int32_t root;
+} dfgpu_expr;
+
+/* result type of an expression over a table (PhysicalExpr::data_type, :80) */
+int dfgpu_expr_type(const dfgpu_expr* e, dfgpu_table_t input, dfgpu_field* out);
+
+/* --------------------------------------------------------------- operators */
+
+/* FilterExec (physical-plan/src/filter.rs:85; FilterExecStream::poll_next :1367-1444):
+ * evaluate `predicate` -> boolean mask, optional embedded projection (column indices,
+ * NULL = all), compaction of every projected column preserving row order; rows whose
+ * predicate is NULL are dropped (arrow-select filter_record_batch). */
+int dfgpu_filter(dfgpu_table_t input, const dfgpu_expr* predicate, const int* projection, int nproj,
+                 dfgpu_table_t* out);
+
+/* ProjectionExec (physical-plan/src/projection.rs:439,713-740): evaluate n expressions */
+int dfgpu_project(dfgpu_table_t input, const dfgpu_expr* exprs, const char* const* names, int n,
+                  dfgpu_table_t* out);
+
+typedef struct dfgpu_join_options {
+  /* execution.perfect_hash_join_small_build_threshold (common/src/config.rs:913) */
+  int64_t perfect_hash_join_small_build_threshold;
+  /* execution.perfect_hash_join_min_key_density (config.rs:923) */
+  double perfect_hash_join_min_key_density;
+  /* 0 = follow the reference's gating (hash_join/exec.rs:111-191); 1 = force hash map;
+   * 2 = force direct-address table (error if not applicable) */
+  int32_t table_mode;
+  /* test hook = cargo feature `force_hash_collisions` (common/src/hash_utils.rs:1186-1197):
+   * every key hashes to 0 so only the key re-check (K4) keeps results right */
+  int32_t force_hash_collisions;
+} dfgpu_join_options;
+
+/* collect_left_input (physical-plan/src/joins/hash_join/exec.rs:2569-2776): build the
+ * join table over the whole build side.  `build` must stay alive until dfgpu_join_free
+ * (the handle holds a reference).  key_cols index into `build`. */
+int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int null_equality,
+                     const dfgpu_join_options* opts, dfgpu_join_t* out);
+/* HashJoinStream::process_probe_batch (hash_join/stream.rs:740-1000): probe one probe
+ * table (any size — the whole partition, not 8192-row batches) and materialise the output
+ * for `join_type`.  Output columns = build_out_cols of the build table followed by
+ * probe_out_cols of the probe table (the `projection` of HashJoinExec, exec.rs:752);
+ * *Semi/*Anti emit one side only; *Mark append a Boolean `mark` column.
+ * For Left/Full/LeftSemi/LeftAnti/LeftMark the probe call emits only what is known per
+ * probe batch (matched pairs) and records visited build rows; call
+ * dfgpu_join_emit_unmatched once all probe tables are done (stream.rs:1002-). */
+int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type,
+                     const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out,
+                     dfgpu_table_t* out);
+int dfgpu_join_emit_unmatched(dfgpu_join_t ht, int join_type, const int* build_out_cols, int n_build_out,
+                              const dfgpu_field* probe_fields, const char* const* probe_names, int n_probe_out,
+                              dfgpu_table_t* out);
+/* BuildProbeJoinMetrics (joins/utils.rs:1756-1800) + which table was built */
+typedef struct dfgpu_join_info {
+  int64_t build_rows;
+  int64_t table_bytes;
+  int32_t used_array_map; /* 1 = direct-address table (ArrayMap, joins/array_map.rs:103) */
+  int32_t build_keys_unique;
+  int64_t probe_rows;  /* accumulated over probe calls */
+  int64_t output_rows; /* accumulated */
+} dfgpu_join_info;
+int dfgpu_join_get_info(dfgpu_join_t ht, dfgpu_join_info* out);
+int dfgpu_join_free(dfgpu_join_t ht);
+
+/* AggregateMode (physical-plan/src/aggregates/mod.rs:289-400) */
+typedef enum dfgpu_agg_mode {
+  DFGPU_AGG_PARTIAL = 0,          /* raw input -> partial state (state_fields) */
+  DFGPU_AGG_FINAL = 1,            /* partial state -> final values */
+  DFGPU_AGG_FINAL_PARTITIONED = 2,
+  DFGPU_AGG_SINGLE = 3,           /* raw input -> final values */
+  DFGPU_AGG_SINGLE_PARTITIONED = 4
+} dfgpu_agg_mode;
+typedef enum dfgpu_agg_func { DFGPU_AGG_SUM = 0, DFGPU_AGG_MIN = 1, DFGPU_AGG_MAX = 2, DFGPU_AGG_COUNT = 3, DFGPU_AGG_AVG = 4 } dfgpu_agg_func;
+typedef struct dfgpu_agg_spec {
+  int32_t func;          /* dfgpu_agg_func */
+  int32_t has_arg;       /* 0 = COUNT(*) */
+  dfgpu_expr arg;        /* argument expression over the input (raw modes) */
+  const char* name;      /* output column name */
+} dfgpu_agg_spec;
+
+/* AggregateExec (aggregates/mod.rs:839): group keys + accumulators
+ * (GroupValues group_values/mod.rs:93, GroupsAccumulator expr-common/src/
+ * groups_accumulator.rs:105).  In FINAL modes the input is the partial-state schema the
+ * reference uses (group cols, then per aggregate: SUM -> [sum]; COUNT -> [count];
+ * MIN/MAX -> [value]; AVG -> [count u64, sum]; sum.rs:281-301, average.rs:317-360) and
+ * `arg`/`group_by` expressions are ignored beyond their count. */
+int dfgpu_agg_create(int mode, const dfgpu_expr* group_by, const char* const* group_names, int n_group,
+                     const dfgpu_agg_spec* aggs, int n_aggs, dfgpu_agg_t* out);
+/* aggregate_batch_inner (aggregate_hash_table/common.rs:205-236) over a whole table */
+int dfgpu_agg_update(dfgpu_agg_t h, dfgpu_table_t input);
+/* next_output_batch_inner (common.rs:247-300): emit all groups */
+int dfgpu_agg_emit(dfgpu_agg_t h, dfgpu_table_t* out);
+int dfgpu_agg_free(dfgpu_agg_t h);
+
+/* SortExec (physical-plan/src/sorts/sort.rs:1366; sort_batch :894-914) and TopK
+ * (topk/mod.rs:397) when fetch >= 0. */
+int dfgpu_sort(dfgpu_table_t input, const int* key_cols, const uint8_t* descending, const uint8_t* nulls_first,
+               int nkeys, int64_t fetch, dfgpu_table_t* out);
+
+/* RepartitionExec, Partitioning::Hash (physical-plan/src/repartition/mod.rs:1097-1150):
+ * partition = create_hashes(keys; seed 0) % nparts; row order preserved inside each
+ * partition.  outs[nparts].  Also the per-GPU routing step of the multi-GPU exchange. */
+int dfgpu_partition(dfgpu_table_t input, const int* key_cols, int nkeys, int nparts, dfgpu_table_t* outs);
+/* create_hashes (common/src/hash_utils.rs:1239) for tests / routing checks */
+int dfgpu_hash_columns(dfgpu_table_t input, const int* key_cols, int nkeys, uint64_t seed, uint64_t* out_device);
+
+/* ------------------------------------------------------ synthetic workload */
+
+/* Deterministic TPC-H-shaped generator (counter-based PRNG, any slice
+ * reproducible; bit-identical numpy mirror in datafusion_amd/tpch.py).  Rows
+ * [order_begin, order_end) of `orders`, and the lineitem rows of exactly those orders.
+ * Schemas follow benchmarks/src/tpch/mod.rs:93-122 restricted to the columns Q1/Q3 read. */
+int dfgpu_tpch_orders(double scale_factor, int64_t order_begin, int64_t order_end, dfgpu_table_t* out);
+int dfgpu_tpch_lineitem(double scale_factor, int64_t order_begin, int64_t order_end, int32_t float_money,
+                        dfgpu_table_t* out);
+int dfgpu_tpch_customer(double scale_factor, int64_t begin, int64_t end, dfgpu_table_t* out);
+
+/* ----------------------------------------------------------------- metrics */
+
+/* per-kernel HIP-event timing on the library stream (BaselineMetrics.elapsed_compute
+ * analogue, physical-expr-common/src/metrics/baseline.rs:53-75) */
+int dfgpu_profile_enable(int on);
+int dfgpu_profile_reset(void);
+/* number of distinct kernel names recorded since the last reset */
+int dfgpu_profile_count(int* out);
+typedef struct dfgpu_kernel_stat {
+  char name[64];
+  int64_t calls;
+  double total_ms;
+  int64_t algorithmic_bytes; /* bytes the launch had to move (inputs read once + outputs written once) */
+} dfgpu_kernel_stat;
+int dfgpu_profile_get(int i, dfgpu_kernel_stat* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFGPU_H */

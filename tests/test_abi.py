@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: libdfgpu.so loads without a GPU, exports every
+symbol include/dfgpu.h declares, and refuses to run (loudly) when no MI355X is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from datafusion_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "dfgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfgpu_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dfgpu.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names, "python binding list out of sync with the header"
+
+
+def test_abi_version():
+    assert _lib.load().dfgpu_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives the ABI structs (LP64): keep ctypes mirrors in sync
+    assert C.sizeof(_lib.Field) == 16
+    assert C.sizeof(_lib.ExprNode) == 56
+    assert C.sizeof(_lib.Expr) == 16
+    assert C.sizeof(_lib.JoinOptions) == 24
+    assert C.sizeof(_lib.JoinInfo) == 40
+    assert C.sizeof(_lib.KernelStat) == 88
+    from datafusion_amd.table import ArrowArray, ArrowSchema
+    assert C.sizeof(ArrowSchema) == 72 and C.sizeof(ArrowArray) == 80
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    n = C.c_int(-1)
+    assert lib.dfgpu_device_count(C.byref(n)) == 0 and n.value == 0
+    assert lib.dfgpu_init(0) != 0
+    assert b"no HIP device" in lib.dfgpu_last_error()
+    # operators refuse to run before init
+    out = C.c_void_p()
+    assert lib.dfgpu_tpch_orders(C.c_double(0.001), C.c_int64(0), C.c_int64(-1), C.byref(out)) != 0
+    assert b"dfgpu_init" in lib.dfgpu_last_error()
+
+
+def test_expression_lowering():
+    import pyarrow as pa
+    from datafusion_amd.expr import col, lit, lower
+    e = (col("l_extendedprice") * (lit(1, pa.decimal128(20, 0)) - col("l_discount")))
+    l = lower(e, ["l_orderkey", "l_extendedprice", "l_discount"])
+    assert l.c.n_nodes == 5 and l.c.root == 4
+    ops = [l.nodes[i].op for i in range(5)]
+    assert ops == [1, 2, 1, 11, 12]
+    assert l.nodes[0].column == 1 and l.nodes[2].column == 2
+    assert l.nodes[1].lit_lo == 1 and l.nodes[1].field.precision == 20
+    neg = lower(lit(-5, pa.int64()), [])
+    assert neg.nodes[0].lit_lo == 2**64 - 5 and neg.nodes[0].lit_hi == 2**64 - 1

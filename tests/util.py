@@ -41,3 +41,43 @@ def assert_tables_equal(actual: pa.Table, expected: pa.Table, ordered=False, che
         assert rows(actual) == rows(expected)
     else:
         assert sorted_rows(actual) == sorted_rows(expected)
+
+
+def to_oracle_expr(e):
+    """product PhysicalExpr tree -> the oracle's tuple AST (test glue only)"""
+    from datafusion_amd import expr as X
+    if isinstance(e, X.Column):
+        return ("col", e.name)
+    if isinstance(e, X.Literal):
+        return ("lit", e.value, e.type)
+    if isinstance(e, X.CastExpr):
+        return ("cast", to_oracle_expr(e.expr), e.cast_type)
+    if isinstance(e, X.BinaryExpr):
+        return ("bin", e.op, to_oracle_expr(e.left), to_oracle_expr(e.right))
+    if isinstance(e, X.IsNullExpr):
+        return ("is_null", to_oracle_expr(e.arg))
+    if isinstance(e, X.IsNotNullExpr):
+        return ("not", ("is_null", to_oracle_expr(e.arg)))
+    if isinstance(e, X.NotExpr):
+        return ("not", to_oracle_expr(e.arg))
+    raise TypeError(e)
+
+
+def random_table(rng, n, spec, null_frac=0.0):
+    """spec: {name: (pa type, low, high)}; uniform ints (decimals as unscaled ints)"""
+    import numpy as np
+    from decimal import Decimal
+    cols = {}
+    for name, (typ, lo, hi) in spec.items():
+        vals = rng.integers(lo, hi, size=n)
+        mask = rng.random(n) < null_frac if null_frac > 0 else None
+        if pa.types.is_decimal128(typ):
+            py = [Decimal(int(v)).scaleb(-typ.scale) for v in vals]
+            cols[name] = pa.array(py, type=typ, mask=mask)
+        elif pa.types.is_float64(typ):
+            cols[name] = pa.array(vals.astype(np.float64) / 7.0, type=typ, mask=mask)
+        elif pa.types.is_date32(typ):
+            cols[name] = pa.array(vals.astype(np.int32), type=pa.int32(), mask=mask).cast(pa.date32())
+        else:
+            cols[name] = pa.array(vals, type=typ, mask=mask)
+    return pa.table(cols)
