@@ -485,7 +485,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     BufPtr mask = make_buf(bitmap_bytes(np));
     BufPtr first = fast_inner ? make_buf((size_t)np * 4) : nullptr;
     {
-      ProfileScope ps("join_probe_lookup", key_bytes + (fast_inner ? np * 4 : 0) + np / 8);
+      ProfileScope ps("join_probe_lookup", key_bytes);  // algorithmic: the probe keys (table reads / match ids are overhead)
       int g = grid_for(n_words, (BLOCK / WAVE) * PROBE_UNROLL);
       int invert = join_type == DFGPU_JOIN_RIGHT_ANTI;
       if (jt.array_map)
@@ -505,7 +505,9 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       const int64_t n_out = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
       out.nrows = n_out;
       JoinCopyCols jc{};
-      int64_t bytes = np / 8 + np * 4;
+      // algorithmic bytes: probe payload read once, build payload read per output row, output
+      // written once (mask / match-id traffic is overhead and not counted)
+      int64_t bytes = 0;
       for (int c : bout) {
         const Column& sc = jt.build.cols[c];
         out.cols.push_back(alloc_column(sc.field, sc.name, n_out));

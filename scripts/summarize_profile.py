@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Summarise a scripts/profile.sh run (rocprofv3 rocpd sqlite outputs) into profiles/<tag>.md/.json.
+
+  python scripts/summarize_profile.py gpurun_out/<tag> profiles/<tag>
+
+Kernel durations come from `rocprofv3 --kernel-trace --stats`; HBM traffic from two separate
+`--pmc` passes (FETCH_SIZE, WRITE_SIZE; TCC has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2 —
+MI355X_MICROARCH.md §rocprofv3 PMC slots).  gfx950 correction (same guide, §HBM): FETCH_SIZE
+reports 1/2 of the bytes of a coalesced streaming read, so read bytes = FETCH_SIZE*1024*2;
+this is calibrated inside the same run on k_key_minmax, which reads exactly 8 B x build rows.
+"""
+import json
+import os
+import sqlite3
+import sys
+
+
+def q(db, sql):
+    con = sqlite3.connect(db)
+    try:
+        return list(con.execute(sql))
+    finally:
+        con.close()
+
+
+def short(name):
+    n = name.replace("void ", "").split("(")[0]
+    return n.replace("dfgpu::", "")
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    bench = None
+    for line in open(os.path.join(src, "bench.json")):
+        if line.startswith("{"):
+            bench = json.loads(line)
+    kern = {short(r[0]): {"calls": r[1], "total_us": r[2], "avg_us": r[3], "pct": r[4]}
+            for r in q(os.path.join(src, "stats", "trace_results.db"), "select name,total_calls,total_duration,average,percentage from top_kernels")}
+    def pmc(sub):
+        return {short(r[0]): r[1] for r in q(os.path.join(src, sub, "pmc_results.db"),
+                "select kernel_name, avg(value) from counters_collection group by 1")}
+    fetch, write = pmc("pmc_fetch"), pmc("pmc_write")
+    nb = bench["config"]["build_rows"] if bench else None
+    calib = None
+    if nb and "k_key_minmax" in fetch:
+        calib = nb * 8 / (fetch["k_key_minmax"] * 1024)
+    rows = []
+    for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_us"]):
+        f, w = fetch.get(k), write.get(k)
+        rd = f * 1024 * 2 if f is not None else None
+        wr = w * 1024 if w is not None else None
+        tr = (rd or 0) + (wr or 0) if (f is not None or w is not None) else None
+        rows.append({"kernel": k, **v, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "read_bytes_corrected": rd, "write_bytes": wr,
+                     "traffic_bytes": tr, "traffic_GBps": (tr / (v["avg_us"] * 1e-6) / 1e9) if tr else None})
+    out = {"bench": bench, "fetch_size_calibration_factor_measured": calib, "kernels": rows}
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    json.dump(out, open(dst + ".json", "w"), indent=1)
+    with open(dst + ".md", "w") as f:
+        f.write(f"# rocprofv3 summary — {os.path.basename(src)}\n\n")
+        if bench:
+            f.write("bench line: `" + json.dumps({k: bench[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step")}) + "`\n\n")
+            f.write("roofline: `" + json.dumps(bench.get("roofline")) + "`\n\n")
+        f.write(f"FETCH_SIZE calibration (bytes k_key_minmax must read / FETCH_SIZE*1024): {calib}\n\n")
+        f.write("| kernel | calls | avg µs | % | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | HBM traffic GB/launch (read x2 corrected) | GB/s |\n|---|---:|---:|---:|---:|---:|---:|---:|\n")
+        for r in rows:
+            fmt = lambda x, d=1: "" if x is None else f"{x:.{d}f}"
+            f.write(f"| {r['kernel']} | {r['calls']} | {r['avg_us']:.1f} | {r['pct']:.1f} | {fmt(r['FETCH_SIZE_KB'],0)} | {fmt(r['WRITE_SIZE_KB'],0)} | "
+                    f"{fmt(r['traffic_bytes']/1e9 if r['traffic_bytes'] else None,2)} | {fmt(r['traffic_GBps'],0)} |\n")
+    print(open(dst + ".md").read())
+
+
+if __name__ == "__main__":
+    main()
