@@ -47,7 +47,7 @@ class JoinInfo(C.Structure):
 
 
 class AggSpec(C.Structure):
-    _fields_ = [("func", C.c_int32), ("has_arg", C.c_int32), ("arg", Expr), ("name", C.c_char_p)]
+    _fields_ = [("func", C.c_int32), ("has_arg", C.c_int32), ("arg", Expr), ("name", C.c_char_p), ("return_field", Field)]
 
 
 class KernelStat(C.Structure):

@@ -1,9 +1,756 @@
-// aggregate.hip — placeholder, replaced by the real K6/K7 implementation
+// aggregate.hip — K6/K6'/K7/K7': AggregateExec (hash group-by) on device.
+//
+// Reference: AggregateHashTable::aggregate_batch_inner (physical-plan/src/aggregates/
+// aggregate_hash_table/common.rs:205-236) = evaluate keys/args -> GroupValues::intern
+// (group_values/single_group_by/primitive.rs:138-179, multi_group_by/mod.rs:455-520) ->
+// GroupsAccumulator::update_batch / merge_batch per aggregate (functions-aggregate-common/src/
+// aggregate/groups_accumulator/prim_op.rs:89-118, accumulate.rs:373-470).
+//
+// Device design (whole partition per update, not 8192-row batches):
+//   intern   : open-addressing table in HBM whose slots hold a REPRESENTATIVE ROW id (row+1).
+//              A slot is claimed with one agent-scope atomicCAS and lowered with atomicMin, so
+//              the representative of a key is its first row and key comparison only ever reads
+//              the immutable input columns (no inter-workgroup publish/consume hazards).
+//              Representatives -> row bitmask -> popcount prefix (scan.hip) -> dense group ids in
+//              FIRST-SEEN ORDER, exactly the reference's numbering (group_values/mod.rs:88-92).
+//              The table starts small and is regrown on overflow (probe length guard).
+//   update   : each row re-probes the (now read-only, cache-resident for low cardinality) table
+//              to find its group id, then accumulates.  Low cardinality: LDS-privatised
+//              accumulators per workgroup, replicated across lanes to spread same-address LDS
+//              atomics, flushed once with global atomics.  High cardinality: global atomics.
+//              SUM(Decimal128) = wrapping i128 add as two u64 atomics with carry (order-
+//              independent => bit-exact, sum.rs:308-320); Float64 sums are atomics in arbitrary
+//              order (1e-6 relative tolerance).
+//   emit     : group key columns (gather of representative rows) + state or final columns;
+//              AVG(Decimal128) = (sum * 10^(ts-ss)) / count truncating (DecimalAverager::avg,
+//              functions-aggregate-common/src/utils.rs:157-176).
+#include "device.hpp"
 #include "internal.hpp"
-using namespace dfgpu;
-extern "C" {
-int dfgpu_agg_create(int, const dfgpu_expr*, const char* const*, int, const dfgpu_agg_spec*, int, dfgpu_agg_t*) { return guarded([] { throw Error("dfgpu_agg_create: not implemented"); }); }
-int dfgpu_agg_update(dfgpu_agg_t, dfgpu_table_t) { return guarded([] { throw Error("dfgpu_agg_update: not implemented"); }); }
-int dfgpu_agg_emit(dfgpu_agg_t, dfgpu_table_t*) { return guarded([] { throw Error("dfgpu_agg_emit: not implemented"); }); }
-int dfgpu_agg_free(dfgpu_agg_t) { return 0; }
+
+namespace dfgpu {
+
+void pack_bytes_to_bitmap(const uint8_t* bytes, int64_t n, uint64_t* words);
+
+constexpr int MAX_AGGS = 12;
+constexpr uint32_t PROBE_LIMIT = 256;  // longer probe sequence => table too full => regrow
+
+// accumulator kinds
+enum AccKind : int { ACC_SUM_I64 = 0, ACC_SUM_I128 = 1, ACC_SUM_F64 = 2, ACC_MIN_I64 = 3, ACC_MAX_I64 = 4, ACC_COUNT = 5, ACC_COUNT_STAR = 6 };
+// how a value is loaded & widened
+enum ValKind : int { VAL_I32 = 0, VAL_I64 = 1, VAL_I128 = 2, VAL_F64 = 3, VAL_U8 = 4, VAL_F64_ORDERED = 5, VAL_I32_TO_F64 = 6, VAL_I64_TO_F64 = 7, VAL_U32 = 8, VAL_U64 = 9 };
+
+struct AccDesc {
+  const void* values;          // input value column (null for COUNT(*))
+  const uint64_t* valid;       // optional validity
+  unsigned long long* acc_lo;  // [ngroups] low word / i64 / f64 bits / count
+  unsigned long long* acc_hi;  // [ngroups] high word (i128 only)
+  uint32_t* seen;              // [ngroups] non-null value seen (NullState)
+  int kind;                    // AccKind
+  int val;                     // ValKind
+};
+struct AccSet {
+  AccDesc a[MAX_AGGS];
+  int n;
+};
+
+__device__ __forceinline__ int64_t f64_ordered(double d) {
+  int64_t b = __double_as_longlong(d);
+  return b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
 }
+__host__ __device__ __forceinline__ double f64_from_ordered(int64_t k) {
+  int64_t b = k ^ (int64_t)((uint64_t)(k >> 63) >> 1);
+  double d;
+#ifdef __HIP_DEVICE_COMPILE__
+  d = __longlong_as_double(b);
+#else
+  std::memcpy(&d, &b, 8);
+#endif
+  return d;
+}
+
+// value of row i as (lo, hi) according to ValKind
+__device__ __forceinline__ void load_value(const AccDesc& d, int64_t i, uint64_t& lo, uint64_t& hi) {
+  hi = 0;
+  switch (d.val) {
+    case VAL_I32: { int64_t v = ((const int32_t*)d.values)[i]; lo = (uint64_t)v; hi = (uint64_t)(v >> 63); break; }
+    case VAL_U32: lo = ((const uint32_t*)d.values)[i]; break;
+    case VAL_I64: { int64_t v = ((const int64_t*)d.values)[i]; lo = (uint64_t)v; hi = (uint64_t)(v >> 63); break; }
+    case VAL_U64: lo = ((const uint64_t*)d.values)[i]; break;
+    case VAL_U8: lo = ((const uint8_t*)d.values)[i]; break;
+    case VAL_I128: { const uint64_t* p = (const uint64_t*)d.values + 2 * i; lo = p[0]; hi = p[1]; break; }
+    case VAL_F64: lo = ((const uint64_t*)d.values)[i]; break;
+    case VAL_F64_ORDERED: lo = (uint64_t)f64_ordered(((const double*)d.values)[i]); break;
+    case VAL_I32_TO_F64: lo = (uint64_t)__double_as_longlong((double)((const int32_t*)d.values)[i]); break;
+    case VAL_I64_TO_F64: lo = (uint64_t)__double_as_longlong((double)((const int64_t*)d.values)[i]); break;
+  }
+}
+
+// one accumulation into (lo, hi) cells that may live in LDS or HBM
+__device__ __forceinline__ void accumulate_cell(int kind, unsigned long long* lo_cell, unsigned long long* hi_cell, uint64_t lo, uint64_t hi) {
+  switch (kind) {
+    case ACC_SUM_I64: atomicAdd(lo_cell, (unsigned long long)lo); break;
+    case ACC_SUM_I128: {
+      unsigned long long old = atomicAdd(lo_cell, (unsigned long long)lo);
+      unsigned long long carry = (old + lo) < old ? 1ull : 0ull;  // this add wrapped the low word
+      atomicAdd(hi_cell, (unsigned long long)hi + carry);
+      break;
+    }
+    case ACC_SUM_F64: atomicAdd(reinterpret_cast<double*>(lo_cell), __longlong_as_double((long long)lo)); break;
+    case ACC_MIN_I64: atomicMin(reinterpret_cast<long long*>(lo_cell), (long long)lo); break;
+    case ACC_MAX_I64: atomicMax(reinterpret_cast<long long*>(lo_cell), (long long)lo); break;
+    default: atomicAdd(lo_cell, 1ull); break;  // COUNT / COUNT(*)
+  }
+}
+__host__ __device__ __forceinline__ unsigned long long acc_identity(int kind) {
+  if (kind == ACC_MIN_I64) return (unsigned long long)INT64_MAX;
+  if (kind == ACC_MAX_I64) return (unsigned long long)INT64_MIN;
+  return 0ull;
+}
+
+// ------------------------------------------------------------------------------ intern
+struct InternCtx {
+  KeySet keys;       // concatenated [existing group keys ; input keys]
+  uint32_t* slots;   // representative row + 1, 0 = empty
+  uint64_t mask;     // capacity - 1
+};
+
+__device__ __forceinline__ uint64_t group_hash(const KeySet& ks, int64_t i) {
+  uint64_t h = SEED_AGG;
+  for (int c = 0; c < ks.n; c++) {
+    if (ks.c[c].valid && !bit_at(ks.c[c].valid, i)) h = fmix64(h ^ 0x6E756C6CULL);  // NULL is a group value
+    else h = hash_value(ks.c[c], i, h);
+  }
+  return h;
+}
+
+// GroupValues::intern, claim phase: every row finds or claims the slot of its key; the slot ends
+// up holding the smallest row id of the key (first-seen representative).
+__global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, int* overflow) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    uint64_t s = group_hash(c.keys, i) & c.mask;
+    const uint32_t me = (uint32_t)i + 1u;
+    uint32_t steps = 0;
+    for (;;) {
+      uint32_t cur = __hip_atomic_load(&c.slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == 0u) {
+        cur = atomicCAS(&c.slots[s], 0u, me);
+        if (cur == 0u) break;  // claimed
+      }
+      if (cur == me) break;
+      if (keys_equal(c.keys, (int64_t)cur - 1, c.keys, i, true)) {
+        if (me < cur) atomicMin(&c.slots[s], me);
+        break;
+      }
+      s = (s + 1) & c.mask;
+      if (++steps > PROBE_LIMIT) {
+        __hip_atomic_store(overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
+  }
+}
+// representatives -> row bitmask
+__global__ __launch_bounds__(BLOCK) void k_mark_reps(const uint32_t* __restrict__ slots, uint64_t capacity, unsigned long long* __restrict__ rep_mask) {
+  for (uint64_t s = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; s < capacity; s += (uint64_t)gridDim.x * BLOCK) {
+    uint32_t v = slots[s];
+    if (v) atomicOr(&rep_mask[(v - 1) >> 6], 1ull << ((v - 1) & 63));
+  }
+}
+// slot -> dense group id (rank of its representative among all representatives), gid -> rep row
+__global__ __launch_bounds__(BLOCK) void k_slot_gids(const uint32_t* __restrict__ slots, uint64_t capacity, const uint64_t* __restrict__ rep_mask,
+                                                     const uint64_t* __restrict__ prefix, uint32_t* __restrict__ slot_gid, int64_t* __restrict__ rep_row) {
+  for (uint64_t s = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; s < capacity; s += (uint64_t)gridDim.x * BLOCK) {
+    uint32_t v = slots[s];
+    if (!v) continue;
+    uint64_t r = v - 1;
+    uint64_t below = rep_mask[r >> 6] & ((1ull << (r & 63)) - 1ull);
+    uint32_t gid = (uint32_t)(prefix[r >> 6] + __popcll(below));
+    slot_gid[s] = gid;
+    rep_row[gid] = (int64_t)r;
+  }
+}
+
+__device__ __forceinline__ uint32_t lookup_gid(const InternCtx& c, const uint32_t* __restrict__ slot_gid, int64_t i) {
+  uint64_t s = group_hash(c.keys, i) & c.mask;
+  for (;;) {
+    uint32_t cur = c.slots[s];
+    if (cur == (uint32_t)i + 1u || keys_equal(c.keys, (int64_t)cur - 1, c.keys, i, true)) return slot_gid[s];
+    s = (s + 1) & c.mask;
+  }
+}
+
+// ------------------------------------------------------------------------------ update
+// HBM accumulators, one global atomic per (row, aggregate)
+__global__ __launch_bounds__(BLOCK) void k_accumulate_global(InternCtx c, const uint32_t* __restrict__ slot_gid, int has_groups, int64_t row_offset,
+                                                            int64_t n, AccSet accs) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint32_t gid = has_groups ? lookup_gid(c, slot_gid, row_offset + i) : 0u;
+    for (int k = 0; k < accs.n; k++) {
+      const AccDesc& d = accs.a[k];
+      if (d.kind != ACC_COUNT_STAR && d.valid && !bit_at(d.valid, i)) continue;
+      uint64_t lo = 0, hi = 0;
+      if (d.kind != ACC_COUNT_STAR && d.kind != ACC_COUNT) load_value(d, i, lo, hi);
+      accumulate_cell(d.kind, d.acc_lo + gid, d.acc_hi ? d.acc_hi + gid : nullptr, lo, hi);
+      if (d.seen) d.seen[gid] = 1u;
+    }
+  }
+}
+
+// LDS-privatised accumulators: cell(rep, agg, gid) in shared memory, flushed once per workgroup
+constexpr int LDS_CELLS = 2048;  // 2 x 8 B x 2048 = 32 KiB of accumulators + 8 KiB of flags per workgroup
+__global__ __launch_bounds__(BLOCK) void k_accumulate_lds(InternCtx c, const uint32_t* __restrict__ slot_gid, int has_groups, int64_t row_offset,
+                                                         int64_t n, AccSet accs, int ngroups, int nrep) {
+  __shared__ unsigned long long s_lo[LDS_CELLS];
+  __shared__ unsigned long long s_hi[LDS_CELLS];
+  __shared__ uint32_t s_seen[LDS_CELLS];
+  const int per_rep = accs.n * ngroups;
+  const int cells = per_rep * nrep;
+  for (int x = threadIdx.x; x < cells; x += BLOCK) {
+    int k = (x % per_rep) / ngroups;
+    s_lo[x] = acc_identity(accs.a[k].kind);
+    s_hi[x] = 0ull;
+    s_seen[x] = 0u;
+  }
+  __syncthreads();
+  const int rep = (int)(threadIdx.x % (unsigned)nrep);
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint32_t gid = has_groups ? lookup_gid(c, slot_gid, row_offset + i) : 0u;
+    for (int k = 0; k < accs.n; k++) {
+      const AccDesc& d = accs.a[k];
+      if (d.kind != ACC_COUNT_STAR && d.valid && !bit_at(d.valid, i)) continue;
+      uint64_t lo = 0, hi = 0;
+      if (d.kind != ACC_COUNT_STAR && d.kind != ACC_COUNT) load_value(d, i, lo, hi);
+      int cell = rep * per_rep + k * ngroups + (int)gid;
+      accumulate_cell(d.kind, &s_lo[cell], &s_hi[cell], lo, hi);
+      s_seen[cell] = 1u;
+    }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < cells; x += BLOCK) {
+    if (!s_seen[x]) continue;
+    int within = x % per_rep;
+    int k = within / ngroups, gid = within % ngroups;
+    const AccDesc& d = accs.a[k];
+    int kind = d.kind;
+    if (kind == ACC_COUNT || kind == ACC_COUNT_STAR) kind = ACC_SUM_I64;  // merge counts by adding
+    accumulate_cell(kind, d.acc_lo + gid, d.acc_hi ? d.acc_hi + gid : nullptr, s_lo[x], s_hi[x]);
+    if (d.seen) d.seen[gid] = 1u;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fill_u64(unsigned long long v, int64_t n, unsigned long long* out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = v;
+}
+
+// -------------------------------------------------------------------------------- emit
+// mode: 0 copy i64 (lo), 1 i128 (lo,hi), 2 ordered-i64 -> f64, 3 i64 -> i32 narrowing, 4 i64 -> u8
+__global__ __launch_bounds__(BLOCK) void k_emit_values(int mode, const unsigned long long* lo, const unsigned long long* hi, const uint32_t* seen,
+                                                       int64_t n, void* out, uint8_t* valid_bytes) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    bool ok = !seen || seen[i] != 0;
+    switch (mode) {
+      case 0: ((unsigned long long*)out)[i] = ok ? lo[i] : 0ull; break;
+      case 1: ((unsigned long long*)out)[2 * i] = ok ? lo[i] : 0ull; ((unsigned long long*)out)[2 * i + 1] = ok ? hi[i] : 0ull; break;
+      case 2: ((double*)out)[i] = ok ? f64_from_ordered((int64_t)lo[i]) : 0.0; break;
+      case 3: ((int32_t*)out)[i] = ok ? (int32_t)(int64_t)lo[i] : 0; break;
+      case 4: ((uint8_t*)out)[i] = ok ? (uint8_t)lo[i] : 0; break;
+    }
+    if (valid_bytes) valid_bytes[i] = ok ? 1 : 0;
+  }
+}
+// AVG finalisation.  decimal: (sum * mul) / count, truncating; f64: sum / count
+__global__ __launch_bounds__(BLOCK) void k_emit_avg(int is_decimal, const unsigned long long* lo, const unsigned long long* hi, const unsigned long long* cnt,
+                                                    i128 mul, int64_t n, void* out, uint8_t* valid_bytes, int* overflow) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    unsigned long long c = cnt[i];
+    bool ok = c != 0;
+    if (is_decimal) {
+      i128 r = 0;
+      if (ok) {
+        i128 s = (i128)(((u128)hi[i] << 64) | (u128)lo[i]);
+        if (__builtin_mul_overflow(s, mul, &r)) *overflow = 1;  // sum.mul_checked
+        r = r / (i128)c;
+      }
+      ((i128*)out)[i] = r;
+    } else {
+      ((double*)out)[i] = ok ? __longlong_as_double((long long)lo[i]) / (double)c : 0.0;
+    }
+    valid_bytes[i] = ok ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------- host
+struct AggState {
+  int func;               // dfgpu_agg_func
+  bool has_arg;
+  std::vector<dfgpu_expr_node> nodes;
+  int root = 0;
+  std::string name;
+  dfgpu_field in_type{};  // argument type (raw modes) / state value type (final modes)
+  dfgpu_field ret{};      // planner-declared return type (type 0 = derive from in_type)
+  bool typed = false;
+  // accumulator storage
+  BufPtr lo, hi, seen;    // primary accumulator (sum / min / max / count)
+  BufPtr cnt;             // AVG: row count
+};
+
+struct Aggregate {
+  int mode;
+  std::vector<std::vector<dfgpu_expr_node>> group_nodes;
+  std::vector<int> group_roots;
+  std::vector<std::string> group_names;
+  std::vector<AggState> aggs;
+  Table group_keys;  // dense, gid order
+  int64_t ngroups = 0;
+  int64_t capacity_hint = 1 << 16;
+  bool final_mode() const { return mode == DFGPU_AGG_FINAL || mode == DFGPU_AGG_FINAL_PARTITIONED; }
+  bool partial_out() const { return mode == DFGPU_AGG_PARTIAL; }
+};
+
+static dfgpu_field fld(int type, int p = 0, int s = 0) {
+  dfgpu_field f{};
+  f.type = type;
+  f.precision = p;
+  f.scale = s;
+  f.nullable = 1;
+  return f;
+}
+// SUM result type (functions-aggregate/src/sum.rs:232-260)
+static dfgpu_field sum_type(const dfgpu_field& t) {
+  switch (t.type) {
+    case DFGPU_DECIMAL128: return fld(DFGPU_DECIMAL128, std::min(38, t.precision + 10), t.scale);
+    case DFGPU_INT32: case DFGPU_INT64: case DFGPU_UINT8: return fld(DFGPU_INT64);
+    case DFGPU_UINT32: case DFGPU_UINT64: return fld(DFGPU_UINT64);
+    case DFGPU_FLOAT64: return fld(DFGPU_FLOAT64);
+  }
+  throw Error("SUM over " + type_name(t) + " is not supported on the GPU path");
+}
+// AVG result type (functions-aggregate/src/average.rs:219-252)
+static dfgpu_field avg_type(const dfgpu_field& t) {
+  if (t.type == DFGPU_DECIMAL128) return fld(DFGPU_DECIMAL128, std::min(38, t.precision + 4), std::min(38, t.scale + 4));
+  return fld(DFGPU_FLOAT64);
+}
+// the type the AVG sum state carries
+static dfgpu_field avg_sum_type(const dfgpu_field& t) {
+  if (t.type == DFGPU_DECIMAL128) return sum_type(t);
+  return fld(DFGPU_FLOAT64);
+}
+
+static BufPtr filled(int64_t n, unsigned long long v) {
+  BufPtr b = make_buf((size_t)(n ? n : 1) * 8);
+  if (n) k_fill_u64<<<grid_for(n, BLOCK), BLOCK, 0, rt().stream>>>(v, n, b->as<unsigned long long>());
+  return b;
+}
+static BufPtr grown(const BufPtr& old, int64_t old_n, int64_t new_n, unsigned long long fill, int elem = 8) {
+  BufPtr b;
+  if (elem == 8) b = filled(new_n, fill);
+  else b = make_zero_buf((size_t)(new_n ? new_n : 1) * elem);
+  if (old && old_n) DFGPU_HIP(hipMemcpyAsync(b->ptr, old->ptr, (size_t)old_n * elem, hipMemcpyDeviceToDevice, rt().stream));
+  return b;
+}
+
+// what one aggregate accumulates, given its input column type
+struct AccPlan {
+  int kind, val;
+  bool needs_hi;
+};
+static AccPlan plan_for(int func, const dfgpu_field& t, bool merging_counts) {
+  switch (func) {
+    case DFGPU_AGG_COUNT:
+      // Final modes merge partial counts by summing them (count.rs merge_batch)
+      if (merging_counts) return {ACC_SUM_I64, t.type == DFGPU_UINT64 ? VAL_U64 : VAL_I64, false};
+      return {ACC_COUNT, VAL_I64, false};
+    case DFGPU_AGG_SUM:
+    case DFGPU_AGG_AVG:
+      switch (t.type) {
+        case DFGPU_DECIMAL128: return {ACC_SUM_I128, VAL_I128, true};
+        case DFGPU_INT32: return func == DFGPU_AGG_AVG ? AccPlan{ACC_SUM_F64, VAL_I32_TO_F64, false} : AccPlan{ACC_SUM_I64, VAL_I32, false};
+        case DFGPU_INT64: return func == DFGPU_AGG_AVG ? AccPlan{ACC_SUM_F64, VAL_I64_TO_F64, false} : AccPlan{ACC_SUM_I64, VAL_I64, false};
+        case DFGPU_UINT8: return {ACC_SUM_I64, VAL_U8, false};
+        case DFGPU_UINT32: return {ACC_SUM_I64, VAL_U32, false};
+        case DFGPU_UINT64: return {ACC_SUM_I64, VAL_U64, false};
+        case DFGPU_FLOAT64: return {ACC_SUM_F64, VAL_F64, false};
+      }
+      break;
+    case DFGPU_AGG_MIN:
+    case DFGPU_AGG_MAX: {
+      int k = func == DFGPU_AGG_MIN ? ACC_MIN_I64 : ACC_MAX_I64;
+      switch (t.type) {
+        case DFGPU_INT32: case DFGPU_DATE32: return {k, VAL_I32, false};
+        case DFGPU_INT64: return {k, VAL_I64, false};
+        case DFGPU_UINT8: return {k, VAL_U8, false};
+        case DFGPU_UINT32: return {k, VAL_U32, false};
+        case DFGPU_FLOAT64: return {k, VAL_F64_ORDERED, false};
+        case DFGPU_DECIMAL128:
+          // 64-bit atomics only: exact for precision <= 18 (every TPC-H money column is Decimal128(15,2))
+          DFGPU_CHECK(t.precision <= 18, "MIN/MAX over Decimal128 with precision > 18 is not supported on the GPU path");
+          return {k, VAL_I128, false};  // low word sign-carrying: values fit in i64
+      }
+      break;
+    }
+  }
+  throw Error("aggregate over " + type_name(t) + " is not supported on the GPU path");
+}
+
+static void agg_update(Aggregate& A, const Table& in) {
+  Runtime& r = rt();
+  const int64_t n = in.nrows;
+  const int ngk = (int)A.group_roots.size();
+  const bool final_mode = A.final_mode();
+
+  // ---- evaluate group keys and aggregate arguments (evaluate_batch, common.rs:169-197)
+  std::vector<Column> key_cols;
+  for (int g = 0; g < ngk; g++) {
+    if (final_mode) {
+      DFGPU_CHECK(g < (int)in.cols.size(), "final aggregate input has too few columns");
+      key_cols.push_back(in.cols[g]);
+    } else {
+      dfgpu_expr e{A.group_nodes[g].data(), (int)A.group_nodes[g].size(), A.group_roots[g]};
+      key_cols.push_back(datum_to_column(evaluate(e, in), n, A.group_names[g]));
+    }
+    key_cols.back().name = A.group_names[g];
+  }
+  // argument / state columns per aggregate
+  struct Inputs { Column v; Column c; bool has_v = false, has_c = false; };
+  std::vector<Inputs> inputs(A.aggs.size());
+  int state_col = ngk;
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    if (final_mode) {
+      // partial-state schema: AVG -> [count, sum]; others -> one column (average.rs:317-360, sum.rs:281-301)
+      if (a.func == DFGPU_AGG_AVG) {
+        DFGPU_CHECK(state_col + 1 < (int)in.cols.size(), "final aggregate input has too few state columns");
+        inputs[k].c = in.cols[state_col++];
+        inputs[k].has_c = true;
+      }
+      DFGPU_CHECK(state_col < (int)in.cols.size(), "final aggregate input has too few state columns");
+      inputs[k].v = in.cols[state_col++];
+      inputs[k].has_v = true;
+    } else if (a.has_arg) {
+      dfgpu_expr e{a.nodes.data(), (int)a.nodes.size(), a.root};
+      inputs[k].v = datum_to_column(evaluate(e, in), n, a.name);
+      inputs[k].has_v = true;
+    }
+    if (!a.typed) {
+      if (inputs[k].has_v) a.in_type = inputs[k].v.field;
+      else a.in_type = fld(DFGPU_INT64);
+      a.typed = true;
+    }
+  }
+
+  // ---- intern (GroupValues::intern)
+  const int64_t G0 = A.ngroups;
+  int64_t G1 = G0;
+  InternCtx ictx{};
+  BufPtr slots, slot_gid;
+  std::vector<Column> cat_keys;  // [existing group keys ; input keys]
+  if (ngk > 0) {
+    const int64_t total = G0 + n;
+    DFGPU_CHECK(total < 0xFFFFFFFFll, "aggregate input exceeds u32 row ids");
+    for (int g = 0; g < ngk; g++) {
+      if (G0 == 0) {
+        cat_keys.push_back(key_cols[g]);
+      } else {
+        const Column& gk = A.group_keys.cols[g];
+        const Column& ik = key_cols[g];
+        DFGPU_CHECK(gk.field.type == ik.field.type, "group key type changed between batches");
+        Column cc = alloc_column(gk.field, gk.name, total, gk.validity || ik.validity);
+        int w = type_width(gk.field.type);
+        DFGPU_HIP(hipMemcpyAsync(cc.data->ptr, gk.ptr(), (size_t)G0 * w, hipMemcpyDeviceToDevice, r.stream));
+        if (n) DFGPU_HIP(hipMemcpyAsync((char*)cc.data->ptr + (size_t)G0 * w, ik.ptr(), (size_t)n * w, hipMemcpyDeviceToDevice, r.stream));
+        DFGPU_CHECK(!cc.validity, "incremental aggregation over nullable group keys is not supported on the GPU path yet");
+        cat_keys.push_back(std::move(cc));
+      }
+    }
+    ictx.keys.n = ngk;
+    DFGPU_CHECK(ngk <= MAX_KEYS, "too many group-by columns");
+    for (int g = 0; g < ngk; g++) {
+      DFGPU_CHECK(cat_keys[g].field.type != DFGPU_BOOL, "Boolean group keys are not supported on the GPU path");
+      ictx.keys.c[g] = KeyCol{cat_keys[g].ptr(), cat_keys[g].valid_words(), cat_keys[g].field.type, type_width(cat_keys[g].field.type)};
+    }
+    int64_t key_bytes = 0;
+    for (int g = 0; g < ngk; g++) key_bytes += total * type_width(cat_keys[g].field.type);
+    BufPtr flag = make_zero_buf(4);
+    uint64_t cap = (uint64_t)A.capacity_hint;
+    const uint64_t cap_max = [&] { uint64_t c = 64; while (c < (uint64_t)total * 2) c <<= 1; return c; }();
+    if (cap > cap_max) cap = cap_max;
+    for (;;) {
+      slots = make_zero_buf(cap * 4);
+      ictx.slots = slots->as<uint32_t>();
+      ictx.mask = cap - 1;
+      if (total) {
+        ProfileScope ps("agg_intern_claim", key_bytes);
+        k_intern_claim<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx, total, flag->as<int>());
+        DFGPU_HIP(hipGetLastError());
+      }
+      int ovf = 0;
+      d2h(&ovf, flag->ptr, 4);
+      if (!ovf) break;
+      DFGPU_CHECK(cap < cap_max, "group table overflow at maximum capacity");
+      cap = std::min<uint64_t>(cap_max, cap * 16);
+      DFGPU_HIP(hipMemsetAsync(flag->ptr, 0, 4, r.stream));
+    }
+    A.capacity_hint = (int64_t)cap;
+    const int64_t n_words = (total + 63) / 64;
+    BufPtr rep_mask = make_zero_buf((size_t)(n_words ? n_words : 1) * 8);
+    BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
+    k_mark_reps<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(slots->as<uint32_t>(), cap, rep_mask->as<unsigned long long>());
+    scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, total, prefix->as<uint64_t>());
+    G1 = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+    slot_gid = make_buf(cap * 4);
+    BufPtr rep_row = make_buf((size_t)(G1 ? G1 : 1) * 8);
+    k_slot_gids<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(slots->as<uint32_t>(), cap, rep_mask->as<uint64_t>(), prefix->as<uint64_t>(),
+                                                                        slot_gid->as<uint32_t>(), rep_row->as<int64_t>());
+    DFGPU_HIP(hipGetLastError());
+    // new dense group key columns = representative rows (first-seen order)
+    Table gk;
+    gk.nrows = G1;
+    for (int g = 0; g < ngk; g++) gk.cols.push_back(gather_column(cat_keys[g], rep_row->as<int64_t>(), G1, false));
+    A.group_keys = std::move(gk);
+  } else {
+    G1 = 1;  // no GROUP BY: AggregateStream, one output row even for empty input
+  }
+
+  // ---- grow accumulators to G1 groups
+  AccSet accs{};
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    AccPlan p = plan_for(a.func, a.in_type, final_mode);
+    a.lo = grown(a.lo, G0, G1, acc_identity(p.kind));
+    if (p.needs_hi) a.hi = grown(a.hi, G0, G1, 0ull);
+    a.seen = grown(a.seen, G0, G1, 0, 4);
+    if (a.func == DFGPU_AGG_AVG) a.cnt = grown(a.cnt, G0, G1, 0ull);
+    AccDesc d{};
+    d.kind = (a.func == DFGPU_AGG_COUNT && !a.has_arg && !final_mode) ? ACC_COUNT_STAR : p.kind;
+    d.val = p.val;
+    d.values = inputs[k].has_v ? inputs[k].v.ptr() : nullptr;
+    d.valid = inputs[k].has_v ? inputs[k].v.valid_words() : nullptr;
+    d.acc_lo = a.lo->as<unsigned long long>();
+    d.acc_hi = a.hi ? a.hi->as<unsigned long long>() : nullptr;
+    d.seen = a.seen->as<uint32_t>();
+    DFGPU_CHECK(accs.n < MAX_AGGS, "too many aggregates for one GPU aggregate node");
+    accs.a[accs.n++] = d;
+    if (a.func == DFGPU_AGG_AVG) {
+      // companion count accumulator: raw modes count non-null args, final modes add partial counts
+      AccDesc c{};
+      c.acc_lo = a.cnt->as<unsigned long long>();
+      if (final_mode) {
+        c.kind = ACC_SUM_I64;
+        c.val = VAL_U64;
+        c.values = inputs[k].c.ptr();
+        c.valid = inputs[k].c.valid_words();
+      } else {
+        c.kind = ACC_COUNT;
+        c.val = VAL_I64;
+        c.values = d.values;
+        c.valid = d.valid;
+      }
+      DFGPU_CHECK(accs.n < MAX_AGGS, "too many aggregates for one GPU aggregate node");
+      accs.a[accs.n++] = c;
+    }
+  }
+  if (n == 0 || accs.n == 0) {
+    A.ngroups = G1;
+    return;
+  }
+  // ---- accumulate (update_batch / merge_batch)
+  int64_t bytes = 0;
+  for (int k = 0; k < accs.n; k++)
+    if (accs.a[k].values) bytes += n * 8;
+  const int per_rep = accs.n * (int)std::min<int64_t>(G1, LDS_CELLS + 1);
+  const uint32_t* sg = slot_gid ? slot_gid->as<uint32_t>() : nullptr;
+  if (G1 * accs.n <= LDS_CELLS) {
+    int nrep = std::max(1, std::min(64, LDS_CELLS / per_rep));
+    // power of two so that consecutive lanes spread over the replicas
+    int p2 = 1;
+    while (p2 * 2 <= nrep) p2 *= 2;
+    ProfileScope ps("agg_accumulate_lds", bytes);
+    k_accumulate_lds<<<grid_for(n, BLOCK * 8), BLOCK, 0, r.stream>>>(ictx, sg, ngk > 0, G0, n, accs, (int)G1, p2);
+  } else {
+    ProfileScope ps("agg_accumulate_global", bytes);
+    k_accumulate_global<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(ictx, sg, ngk > 0, G0, n, accs);
+  }
+  DFGPU_HIP(hipGetLastError());
+  A.ngroups = G1;
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // temporaries (evaluated columns, tables) are released on return
+}
+
+static Column emit_column(const dfgpu_field& f, const std::string& name, int mode, const BufPtr& lo, const BufPtr& hi, const BufPtr& seen, int64_t n,
+                          bool nullable) {
+  Column c = alloc_column(f, name, n);
+  if (n == 0) return c;
+  BufPtr vb = nullable ? make_buf((size_t)n + 64) : nullptr;
+  k_emit_values<<<grid_for(n, BLOCK), BLOCK, 0, rt().stream>>>(mode, lo->as<unsigned long long>(), hi ? hi->as<unsigned long long>() : nullptr,
+                                                               nullable ? seen->as<uint32_t>() : nullptr, n, c.data->ptr, vb ? vb->as<uint8_t>() : nullptr);
+  DFGPU_HIP(hipGetLastError());
+  if (nullable) {
+    c.validity = make_buf(bitmap_bytes(n));
+    pack_bytes_to_bitmap(vb->as<uint8_t>(), n, c.validity->as<uint64_t>());
+    c.null_count = -1;
+    count_nulls(c);
+  }
+  return c;
+}
+
+static Table agg_emit(Aggregate& A) {
+  Runtime& r = rt();
+  const int ngk = (int)A.group_roots.size();
+  if (ngk == 0 && A.ngroups == 0) {
+    // no input at all: still one row (accumulators at identity)
+    Table empty;
+    empty.nrows = 0;
+    agg_update(A, empty);
+  }
+  const int64_t G = A.ngroups;
+  Table out;
+  out.nrows = G;
+  for (int g = 0; g < ngk; g++) {
+    if (G == 0 && (int)A.group_keys.cols.size() <= g) throw Error("aggregate emitted before any input: group key types unknown");
+    out.cols.push_back(A.group_keys.cols[g]);
+  }
+  for (AggState& a : A.aggs) {
+    DFGPU_CHECK(a.typed || G == 0, "aggregate emitted before any input");
+    if (!a.typed) {
+      a.in_type = fld(DFGPU_INT64);
+      a.typed = true;
+    }
+    const bool fin = A.final_mode();
+    AccPlan p = plan_for(a.func, a.in_type, fin);
+    // value type of the primary accumulator when emitted
+    auto value_field = [&]() -> dfgpu_field {
+      switch (a.func) {
+        case DFGPU_AGG_COUNT: return fld(DFGPU_INT64);
+        case DFGPU_AGG_SUM: return fin ? a.in_type : sum_type(a.in_type);
+        case DFGPU_AGG_AVG: return fin ? a.in_type : avg_sum_type(a.in_type);
+        default: return a.in_type;
+      }
+    };
+    dfgpu_field vf = value_field();
+    int mode = 0;
+    if (p.kind == ACC_SUM_I128) mode = 1;
+    else if (p.val == VAL_F64_ORDERED) mode = 2;
+    else if (vf.type == DFGPU_INT32 || vf.type == DFGPU_DATE32) mode = 3;
+    else if (vf.type == DFGPU_UINT8) mode = 4;
+    if (a.func == DFGPU_AGG_AVG) {
+      if (A.partial_out()) {
+        // state_fields of AVG: [count: UInt64, sum] (average.rs:317-360)
+        out.cols.push_back(emit_column(fld(DFGPU_UINT64), a.name + "[count]", 0, a.cnt, nullptr, nullptr, G, false));
+        out.cols.push_back(emit_column(vf, a.name + "[sum]", mode, a.lo, a.hi, a.seen, G, true));
+      } else {
+        // raw modes: in_type = argument type Decimal(p,s) -> AVG type Decimal(min(38,p+4), min(38,s+4))
+        // (average.rs:219-252).  final modes: in_type = the sum state Decimal(min(38,p+10), s); the
+        // planner-declared return type is used when given, else p is recovered as sum_p - 10.
+        dfgpu_field base = a.in_type;
+        dfgpu_field rt_;
+        i128 mul = 1;
+        bool dec = base.type == DFGPU_DECIMAL128;
+        if (dec) {
+          int s = base.scale;
+          int arg_p = fin ? std::max(1, base.precision - 10) : base.precision;
+          rt_ = a.ret.type == DFGPU_DECIMAL128 ? a.ret : fld(DFGPU_DECIMAL128, std::min(38, arg_p + 4), std::min(38, s + 4));
+          DFGPU_CHECK(rt_.scale >= s, "AVG return scale smaller than the sum scale");
+          for (int i = s; i < rt_.scale; i++) mul *= 10;
+        } else {
+          rt_ = fld(DFGPU_FLOAT64);
+        }
+        Column c = alloc_column(rt_, a.name, G);
+        if (G) {
+          BufPtr vb = make_buf((size_t)G + 64);
+          BufPtr ovf = make_zero_buf(4);
+          k_emit_avg<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(dec, a.lo->as<unsigned long long>(), a.hi ? a.hi->as<unsigned long long>() : nullptr,
+                                                                 a.cnt->as<unsigned long long>(), mul, G, c.data->ptr, vb->as<uint8_t>(), ovf->as<int>());
+          int o = 0;
+          d2h(&o, ovf->ptr, 4);
+          DFGPU_CHECK(!o, "Arithmetic Overflow in AvgAccumulator");
+          c.validity = make_buf(bitmap_bytes(G));
+          pack_bytes_to_bitmap(vb->as<uint8_t>(), G, c.validity->as<uint64_t>());
+          c.null_count = -1;
+          count_nulls(c);
+        }
+        out.cols.push_back(std::move(c));
+      }
+      continue;
+    }
+    bool nullable = a.func != DFGPU_AGG_COUNT;
+    if (vf.type == DFGPU_DECIMAL128 && p.kind != ACC_SUM_I128) {
+      // widen the i64 MIN/MAX accumulator to i128: hi = sign(lo)
+      Column c = emit_column(fld(DFGPU_INT64), a.name, 0, a.lo, nullptr, a.seen, G, nullable);
+      Column w = alloc_column(vf, a.name, G);
+      if (G) {
+        dfgpu_expr_node nodes[2]{};
+        nodes[0].op = DFGPU_EXPR_COLUMN; nodes[0].column = 0; nodes[0].left = nodes[0].right = -1;
+        nodes[1].op = DFGPU_EXPR_CAST; nodes[1].left = 0; nodes[1].right = -1; nodes[1].field = fld(DFGPU_DECIMAL128, vf.precision, 0);
+        Table t1;
+        t1.nrows = G;
+        t1.cols.push_back(c);
+        dfgpu_expr e{nodes, 2, 1};
+        Column casted = datum_to_column(evaluate(e, t1), G, a.name);
+        casted.field = vf;
+        w = casted;
+      }
+      out.cols.push_back(std::move(w));
+      continue;
+    }
+    out.cols.push_back(emit_column(vf, a.name, mode, a.lo, a.hi, a.seen, G, nullable));
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  return out;
+}
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+
+extern "C" {
+
+int dfgpu_agg_create(int mode, const dfgpu_expr* group_by, const char* const* group_names, int n_group, const dfgpu_agg_spec* aggs, int n_aggs,
+                     dfgpu_agg_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(mode >= DFGPU_AGG_PARTIAL && mode <= DFGPU_AGG_SINGLE_PARTITIONED, "bad aggregate mode");
+    auto A = std::make_unique<Aggregate>();
+    A->mode = mode;
+    for (int g = 0; g < n_group; g++) {
+      A->group_nodes.emplace_back(group_by[g].nodes, group_by[g].nodes + group_by[g].n_nodes);
+      A->group_roots.push_back(group_by[g].root);
+      A->group_names.push_back(group_names && group_names[g] ? group_names[g] : "");
+    }
+    for (int k = 0; k < n_aggs; k++) {
+      AggState a;
+      a.func = aggs[k].func;
+      DFGPU_CHECK(a.func >= DFGPU_AGG_SUM && a.func <= DFGPU_AGG_AVG, "unsupported aggregate function");
+      a.has_arg = aggs[k].has_arg != 0;
+      DFGPU_CHECK(a.has_arg || a.func == DFGPU_AGG_COUNT, "only COUNT may omit its argument");
+      if (a.has_arg && aggs[k].arg.nodes) {
+        a.nodes.assign(aggs[k].arg.nodes, aggs[k].arg.nodes + aggs[k].arg.n_nodes);
+        a.root = aggs[k].arg.root;
+      }
+      a.name = aggs[k].name ? aggs[k].name : "";
+      a.ret = aggs[k].return_field;
+      A->aggs.push_back(std::move(a));
+    }
+    *out = reinterpret_cast<dfgpu_agg_t>(A.release());
+  });
+}
+
+int dfgpu_agg_update(dfgpu_agg_t h, dfgpu_table_t input) {
+  return guarded([&] {
+    require_init();
+    agg_update(*reinterpret_cast<Aggregate*>(h), *unwrap(input));
+  });
+}
+
+int dfgpu_agg_emit(dfgpu_agg_t h, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    auto t = std::make_unique<Table>(agg_emit(*reinterpret_cast<Aggregate*>(h)));
+    *out = wrap(t.release());
+  });
+}
+
+int dfgpu_agg_free(dfgpu_agg_t h) {
+  return guarded([&] { delete reinterpret_cast<Aggregate*>(h); });
+}
+
+}  // extern "C"

@@ -240,7 +240,7 @@ int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int nu
  * table (any size — the whole partition, not 8192-row batches) and materialise the output
  * for `join_type`.  Output columns = build_out_cols of the build table followed by
  * probe_out_cols of the probe table (the `projection` of HashJoinExec, exec.rs:752);
- * *Semi/*Anti emit one side only; *Mark append a Boolean `mark` column.
+ * Semi / Anti joins emit one side only; Mark joins append a Boolean `mark` column.
  * For Left/Full/LeftSemi/LeftAnti/LeftMark the probe call emits only what is known per
  * probe batch (matched pairs) and records visited build rows; call
  * dfgpu_join_emit_unmatched once all probe tables are done (stream.rs:1002-). */
@@ -276,6 +276,10 @@ typedef struct dfgpu_agg_spec {
   int32_t has_arg;       /* 0 = COUNT(*) */
   dfgpu_expr arg;        /* argument expression over the input (raw modes) */
   const char* name;      /* output column name */
+  /* planner-declared return type (AggregateFunctionExpr::field); type 0 = derive from the
+   * argument type.  Give it in FINAL modes for AVG(Decimal128), whose precision cannot be
+   * recovered from the clamped sum-state type. */
+  dfgpu_field return_field;
 } dfgpu_agg_spec;
 
 /* AggregateExec (aggregates/mod.rs:839): group keys + accumulators

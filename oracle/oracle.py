@@ -430,14 +430,24 @@ def avg_result_type(t: pa.DataType) -> pa.DataType:
     return pa.float64()
 
 
-def aggregate(table: pa.Table, group_by, aggs) -> pa.Table:
-    """AggregateExec mode=Single (aggregates/mod.rs:839, aggregate_hash_table/common.rs:205-300).
+def aggregate(table: pa.Table, group_by, aggs, mode="Single") -> pa.Table:
+    """AggregateExec (aggregates/mod.rs:839, aggregate_hash_table/common.rs:205-300).
     group_by = [(expr, name)], aggs = [(func, expr_or_None, name)] with func in
     sum/avg/count/min/max.  Output = group columns ++ aggregate columns, groups in first-seen
-    order."""
+    order.  mode (AggregateMode, aggregates/mod.rs:289-400):
+      Single / SinglePartitioned : raw rows -> final values
+      Partial                    : raw rows -> state columns (AVG -> `name[count]` UInt64 +
+                                   `name[sum]`; others one column; average.rs:317-360, sum.rs:281-301)
+      Final / FinalPartitioned   : state columns (same layout, group columns first) -> final values;
+                                   aggregate expressions are ignored (merge_batch path)."""
     L = lib()
     n = table.num_rows
-    key_arrs = [evaluate(e, table).to_array(n) for e, _ in group_by]
+    final = mode in ("Final", "FinalPartitioned")
+    partial = mode == "Partial"
+    if final:
+        key_arrs = [_flat(table.column(i)) for i in range(len(group_by))]
+    else:
+        key_arrs = [evaluate(e, table).to_array(n) for e, _ in group_by]
     if key_arrs:
         kh, kc = _cols(key_arrs)
         gids = np.zeros(max(n, 1), np.int64)
@@ -451,43 +461,70 @@ def aggregate(table: pa.Table, group_by, aggs) -> pa.Table:
     for (e, nm), arr in zip(group_by, key_arrs):
         out_cols.append(arr.take(pa.array(first, type=pa.int64())))
         names.append(nm)
+
+    def zeros(tt):
+        return np.zeros((max(ng, 1), 2), np.uint64) if tt == ORC_I128 else np.zeros(max(ng, 1), _NP[tt])
+
+    def acc(op, varr):
+        """one orc_accumulate call -> (values, seen)"""
+        vh, vc = _cols([varr])
+        t = orc_type(varr.type)
+        out = np.zeros(max(ng, 1), np.int64) if op == 3 else zeros(t)
+        seen = np.zeros(max(ng, 1), np.uint8)
+        rc = L.orc_accumulate(op, C.byref(vc[0]), C.c_void_p(gids.ctypes.data), C.c_int64(ng), None,
+                              C.c_void_p(out.ctypes.data), C.c_void_p(seen.ctypes.data))
+        assert rc == 0
+        return out, seen[:ng].astype(bool)
+
+    state_col = len(group_by)
     for func, e, nm in aggs:
-        if func == "count" and e is None:
+        cnt_state = None
+        if final:
+            if func == "avg":
+                cnt_state = _flat(table.column(state_col)); state_col += 1
+            varr = _flat(table.column(state_col)); state_col += 1
+        elif func == "count" and e is None:
             varr = pa.array(np.zeros(n, np.int64))  # COUNT(*) counts rows
         else:
             varr = evaluate(e, table).to_array(n)
-        if pa.types.is_int32(varr.type) and func in ("sum", "avg"):
+        if not final and func in ("sum", "avg") and (pa.types.is_int32(varr.type) or pa.types.is_uint8(varr.type)):
             varr = varr.cast(pa.int64())
-        vh, vc = _cols([varr])
+        if not final and func == "avg" and pa.types.is_int64(varr.type):
+            varr = varr.cast(pa.float64())  # AVG over integers is coerced to Float64 (average.rs coerce_types)
         t = orc_type(varr.type)
-        seen = np.zeros(max(ng, 1), np.uint8)
-
-        def acc(op, out):
-            rc = L.orc_accumulate(op, C.byref(vc[0]), C.c_void_p(gids.ctypes.data), C.c_int64(ng), None,
-                                  C.c_void_p(out.ctypes.data), C.c_void_p(seen.ctypes.data))
-            assert rc == 0
-            return out
-
-        def zeros(tt):
-            return np.zeros((max(ng, 1), 2), np.uint64) if tt == ORC_I128 else np.zeros(max(ng, 1), _NP[tt])
-
         if func == "count":
-            cnt = acc(3, np.zeros(max(ng, 1), np.int64))
-            out_cols.append(pa.array(cnt[:ng], type=pa.int64()))
+            if final:
+                vals, _ = acc(0, varr.cast(pa.int64()))  # merge partial counts by summing
+            else:
+                vals, _ = acc(3, varr)
+            out_cols.append(pa.array(vals[:ng], type=pa.int64()))
+            names.append(nm)
         elif func in ("sum", "min", "max"):
-            vals = acc({"sum": 0, "min": 1, "max": 2}[func], zeros(t))
-            rt = sum_result_type(varr.type) if func == "sum" else varr.type
-            out_cols.append(_from_values(vals[:ng], rt, seen[:ng].astype(bool)))
+            vals, seen = acc({"sum": 0, "min": 1, "max": 2}[func], varr)
+            rt = varr.type if (final or func != "sum") else sum_result_type(varr.type)
+            out_cols.append(_from_values(vals[:ng], rt, seen))
+            names.append(nm)
         elif func == "avg":
-            sums = acc(0, zeros(t))
-            valid = seen[:ng].astype(bool).copy()
-            cnt = acc(3, np.zeros(max(ng, 1), np.int64))
-            rt = avg_result_type(varr.type)
+            sums, seen = acc(0, varr)
+            if final:
+                cnt, _ = acc(0, cnt_state.cast(pa.int64()))
+                sum_t = varr.type
+            else:
+                cnt, _ = acc(3, varr)
+                sum_t = sum_result_type(varr.type) if t == ORC_I128 else pa.float64()
+            if partial:
+                out_cols.append(pa.array(cnt[:ng].astype(np.uint64), type=pa.uint64()))
+                names.append(nm + "[count]")
+                out_cols.append(_from_values(sums[:ng], sum_t, seen))
+                names.append(nm + "[sum]")
+                continue
+            valid = cnt[:ng] > 0
             if t == ORC_I128:
                 # AvgGroupsAccumulator<Decimal128> (average.rs:934-960) + DecimalAverager
-                st = sum_result_type(varr.type)
+                arg_p = max(1, sum_t.precision - 10) if final else varr.type.precision
+                rt = pa.decimal128(min(38, arg_p + 4), min(38, sum_t.scale + 4))
                 outv = np.zeros((max(ng, 1), 2), np.uint64)
-                rc = L.orc_decimal_avg(C.c_void_p(sums.ctypes.data), C.c_void_p(cnt.ctypes.data), C.c_int64(ng), st.scale, rt.scale,
+                rc = L.orc_decimal_avg(C.c_void_p(sums.ctypes.data), C.c_void_p(cnt.ctypes.data), C.c_int64(ng), sum_t.scale, rt.scale,
                                        C.c_void_p(outv.ctypes.data))
                 if rc != 0:
                     raise ArithmeticError("Arithmetic Overflow in AvgAccumulator")
@@ -497,9 +534,9 @@ def aggregate(table: pa.Table, group_by, aggs) -> pa.Table:
                 with np.errstate(divide="ignore", invalid="ignore"):
                     av = s[:ng] / cnt[:ng].astype(np.float64)  # sum / count as f64 (average.rs:374-395)
                 out_cols.append(_from_values(np.where(valid, av, 0.0), pa.float64(), valid))
+            names.append(nm)
         else:
             raise NotImplementedError(func)
-        names.append(nm)
     return pa.Table.from_arrays(out_cols, names=names)
 
 
