@@ -31,7 +31,7 @@ namespace dfgpu {
 
 void pack_bytes_to_bitmap(const uint8_t* bytes, int64_t n, uint64_t* words);
 
-constexpr int MAX_AGGS = 12;
+constexpr int MAX_AGGS = 16;
 constexpr uint32_t PROBE_LIMIT = 256;  // longer probe sequence => table too full => regrow
 
 // accumulator kinds

@@ -44,14 +44,23 @@ def exchange_counts(send_counts, group=None):
 
 
 def all_to_all_bytes(send, send_counts, recv, recv_counts, width, group=None):
-    """one all-to-all(v) of a column: `send`/`recv` are flat uint8 tensors, counts are rows"""
+    """one all-to-all(v) of a column: `send`/`recv` are flat uint8 tensors, counts are rows.
+    The buffers are viewed with the widest element type dividing `width` so per-peer element
+    counts stay small (a 2.4 GB split of Decimal128 values is 300 M int64 elements, not 2.4 G bytes)."""
+    import torch
     import torch.distributed as dist
-    dist.all_to_all_single(recv, send, output_split_sizes=[c * width for c in recv_counts],
-                           input_split_sizes=[c * width for c in send_counts], group=group)
+    unit, dtype = (8, torch.int64) if width % 8 == 0 else (4, torch.int32) if width % 4 == 0 else (1, torch.uint8)
+    if send.data_ptr() % unit or recv.data_ptr() % unit:
+        unit, dtype = 1, torch.uint8
+    k = width // unit
+    dist.all_to_all_single(recv.view(dtype), send.view(dtype), output_split_sizes=[c * k for c in recv_counts],
+                           input_split_sizes=[c * k for c in send_counts], group=group)
 
 
-def hash_exchange(table, keys, group=None):
-    """DeviceTable -> DeviceTable holding every row (from all ranks) whose key hash routes here"""
+def hash_exchange(table, keys, group=None, force=False):
+    """DeviceTable -> DeviceTable holding every row (from all ranks) whose key hash routes here.
+    force=True runs the partition + all-to-all path even for a single rank (used to exercise the
+    RCCL plumbing on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
 
@@ -60,7 +69,7 @@ def hash_exchange(table, keys, group=None):
     from .table import DeviceTable
 
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return table
     lib = _lib.load()
     parts = ops.partition(table, keys, world)

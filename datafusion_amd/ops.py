@@ -161,6 +161,13 @@ class GroupedAggregate:
     def __init__(self, mode, input_names, group_by, aggs):
         lib = _lib.init()
         self._keep = []
+        final = mode in ("Final", "FinalPartitioned")
+        if final:
+            # Final modes read the partial-state schema positionally (group columns first); the
+            # original argument expressions do not exist in that schema and are not evaluated
+            from .expr import Column
+            group_by = [(Column(n, i), n) for i, (_, n) in enumerate(group_by)]
+            aggs = [(f, None if f == "count" and e is None else Column("state", 0), n) for f, e, n in aggs]
         g_low = [lower(e, input_names) for e, _ in group_by]
         self._keep += g_low
         garr = (Expr * max(1, len(g_low)))(*[l.c for l in g_low])

@@ -86,3 +86,24 @@ def test_partition_then_join_equals_global_join():
     lp, rp = ops.partition(DeviceTable.from_arrow(l), ["a"], 4), ops.partition(DeviceTable.from_arrow(r), ["b"], 4)
     outs = [ops.hash_join(a, b, [("a", "b")], "Inner").to_arrow() for a, b in zip(lp, rp)]
     assert_tables_equal(pa.concat_tables(outs), oracle.hash_join(l, r, [("a", "b")], "Inner"))
+
+
+def test_exchange_plumbing_single_rank_rccl():
+    """one-rank RCCL group on the GPU box: partition -> zero-copy torch views of library HBM ->
+    all_to_all_single -> received table; with world=1 the result must equal the input"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from datafusion_amd import ops
+    from datafusion_amd.exchange import hash_exchange
+    from datafusion_amd.table import DeviceTable
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    t = random_table(np.random.default_rng(2), 100_000, {"k": (pa.int64(), 0, 10**6), "d": (pa.decimal128(15, 2), 0, 10**6), "q": (pa.int32(), 0, 9)})
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        out = hash_exchange(DeviceTable.from_arrow(t), ["k"], force=True)
+        assert_tables_equal(out.to_arrow(), t, ordered=True)
+    finally:
+        dist.destroy_process_group()

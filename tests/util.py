@@ -18,12 +18,12 @@ def i32_table(columns, data, repeat=1):
 
 def rows(table: pa.Table):
     """list of row tuples (python values)"""
-    cols = [c.to_pylist() for c in table.columns]
+    cols = [[("NaN" if isinstance(v, float) and v != v else v) for v in c.to_pylist()] for c in table.columns]
     return [tuple(c[i] for c in cols) for i in range(table.num_rows)]
 
 
 def _key(row):
-    return tuple((v is None, 0 if v is None else v) for v in row)
+    return tuple((v is None, v == "NaN", 0 if (v is None or v == "NaN") else v) for v in row)
 
 
 def sorted_rows(table: pa.Table):
