@@ -14,7 +14,9 @@ value = (build rows + probe rows summed over ranks) / max-over-ranks wall time o
 Inputs are generated on device (no dataset download possible) before the timed region.
 
 Extra objects on the JSON line:
-  roofline     — dominant kernel (join_probe_materialize): algorithmic bytes per launch /
+  roofline     — dominant kernel (join_probe_fused = k_join_probe_fused: lookup + output offsets +
+                 materialisation in one pass; join_probe_materialize when --probe-mode 1):
+                 algorithmic bytes per launch /
                  average launch duration measured with HIP events on the library stream,
                  against the 8.0 TB/s HBM3E spec peak.
   cpu_baseline — the CPU restatement (oracle/, kind "port") of DataFusion's partitioned hash
@@ -72,6 +74,7 @@ def main():
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor (BASELINE: 100)")
     ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--probe-mode", type=int, default=0, help="0 auto (single-pass probe), 1 two-pass, 2 single-pass")
     args = ap.parse_args()
 
     import torch
@@ -105,7 +108,12 @@ def main():
             from datafusion_amd.exchange import hash_exchange
             o = hash_exchange(orders, ["o_orderkey"])
             l = hash_exchange(lineitem, ["l_orderkey"])
-        ht = ops.JoinHashTable(o, ["o_orderkey"])
+        # N > 1: hash routing leaves each rank 1/N of the keys over the same key range; the reference's
+        # density gate (perfect_hash_join_min_key_density = 0.15, config.rs:923) would then pick the
+        # chained hash map (documented caveat, hash_join/exec.rs:590-605).  On the GPU the direct-
+        # address table stays the better structure down to ~1/32 density (its memset + sparse reads
+        # cost less than 2-3 random 64 B sectors per probe row), so the bench sets that knob.
+        ht = ops.JoinHashTable(o, ["o_orderkey"], min_key_density=0.15 if world == 1 else 1.0 / 32, probe_mode=args.probe_mode)
         out = ht.probe(l, ["l_orderkey"], "Inner", BUILD_COLS, PROBE_COLS)
         n_out = out.num_rows
         info = ht.info()
@@ -148,13 +156,14 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         rows_per_s = (nb + np_) / (dt / args.steps)
         alg = algorithmic_bytes(nb, np_, nout)
-        dom = stats.get("join_probe_materialize", {"calls": 0, "total_ms": 0.0, "bytes": 0})
+        dom_name = "join_probe_fused" if "join_probe_fused" in stats else "join_probe_materialize"
+        dom = stats.get(dom_name, {"calls": 0, "total_ms": 0.0, "bytes": 0})
         roof = None
         if dom["calls"]:
             avg_ms = dom["total_ms"] / dom["calls"]
             per_launch = dom["bytes"] / dom["calls"]
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "join_probe_materialize", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
         kernels = {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in stats.items()}

@@ -34,6 +34,7 @@ struct JoinTable {
   bool array_map = false;
   bool keys_unique = true;
   bool force_collisions = false;
+  int probe_mode = 0;  // 0 auto, 1 two-pass, 2 single-pass
   BufPtr heads;  // u32: ArrayMap data[] or hash heads[]
   BufPtr next;   // u32 per build row (null when array_map && unique)
   uint64_t am_offset = 0, am_size = 0;
@@ -69,17 +70,30 @@ struct MinMax {
   long long smin, smax;
   unsigned long long valid;
 };
+constexpr int BUILD_UNROLL = 4;  // independent key loads in flight per thread
 __global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMax* out) {
   long long mn = INT64_MAX, mx = INT64_MIN;
   unsigned long long cnt = 0;
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    if (k.valid && !bit_at(k.valid, i)) continue;
-    uint64_t lo, hi;
-    load_words(k, i, lo, hi);
-    long long v = (long long)lo;
-    mn = v < mn ? v : mn;
-    mx = v > mx ? v : mx;
-    cnt++;
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += stride * BUILD_UNROLL) {
+    uint64_t lo[BUILD_UNROLL];
+    bool ok[BUILD_UNROLL];
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      int64_t i = i0 + j * stride;
+      ok[j] = i < n && !(k.valid && !bit_at(k.valid, i));
+      uint64_t hi;
+      lo[j] = 0;
+      if (ok[j]) load_words(k, i, lo[j], hi);
+    }
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      if (!ok[j]) continue;
+      long long v = (long long)lo[j];
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+      cnt++;
+    }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -98,14 +112,27 @@ __global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMa
 // ArrayMap::fill_data (array_map.rs:205-236), lock-free: data[key-min] <- row+1, the previous
 // occupant becomes next[row] (chain order is arbitrary; the reference's is ascending).
 __global__ __launch_bounds__(BLOCK) void k_am_build(KeyCol k, int64_t n, uint64_t offset, uint32_t* data, uint32_t* next, int* dup_flag) {
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    if (k.valid && !bit_at(k.valid, i)) continue;
-    uint64_t lo, hi;
-    load_words(k, i, lo, hi);
-    uint32_t old = atomicExch(&data[lo - offset], (uint32_t)i + 1u);
-    if (old) {
-      if (next) next[i] = old;
-      else *dup_flag = 1;
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += stride * BUILD_UNROLL) {
+    uint64_t lo[BUILD_UNROLL];
+    bool ok[BUILD_UNROLL];
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      int64_t i = i0 + j * stride;
+      ok[j] = i < n && !(k.valid && !bit_at(k.valid, i));
+      uint64_t hi;
+      lo[j] = 0;
+      if (ok[j]) load_words(k, i, lo[j], hi);
+    }
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      if (!ok[j]) continue;
+      int64_t i = i0 + j * stride;
+      uint32_t old = atomicExch(&data[lo[j] - offset], (uint32_t)i + 1u);
+      if (old) {
+        if (next) next[i] = old;
+        else *dup_flag = 1;
+      }
     }
   }
 }
@@ -323,6 +350,145 @@ __global__ __launch_bounds__(BLOCK) void k_join_materialize(JoinCopyCols cols, c
   }
 }
 
+// ---------------------------------------------------------------- single-pass probe (K3+K4+K5 fused)
+// At most one match per probe row (unique build keys / probe-side semi+anti) and non-nullable
+// payload: lookup, output-offset computation and materialisation happen in ONE kernel, so the
+// probe keys are read once and neither match ids nor masks ever reach HBM.  The global output
+// offset of a tile (1024 probe rows = one workgroup pass) comes from a decoupled look-back over
+// per-tile {status, count} words: a tile publishes its own count (AGG), then wave 0 walks back
+// 64 predecessors at a time until it meets an inclusive prefix (PFX), and finally publishes
+// its own inclusive prefix.  Tiles are handed out in order by an atomic ticket (a few consecutive
+// tiles per ticket, processed in order), so a tile only ever waits on tiles whose workgroup is
+// already resident => forward progress without a cooperative launch or any residency assumption.
+// Cross-workgroup traffic is one 8-byte agent-scope atomic granule {status, count} per tile —
+// the form MI355X_MICROARCH.md lists as valid without fences (per-XCD L2s are not coherent).
+// Output order = probe order, as the two-pass path and the reference (exec.rs:3349).
+constexpr int FUSED_WORDS = 4;                                   // 64-row words per wave per tile
+constexpr int FUSED_TILE_WORDS = FUSED_WORDS * (BLOCK / WAVE);   // 16 words = 1024 rows per tile
+constexpr int FUSED_TILES_PER_TICKET = 4;                        // consecutive tiles per ticket
+constexpr uint64_t TS_AGG = 1ull << 62, TS_PFX = 2ull << 62, TS_VAL = (1ull << 62) - 1;
+
+__device__ __forceinline__ uint64_t ts_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ts_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct FusedCtl {
+  uint64_t total;    // out: number of output rows
+  unsigned ticket;   // next tile to hand out
+  unsigned _pad;
+};
+
+template <bool AM>
+__global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopyCols cols, int64_t np, int invert, uint64_t* __restrict__ tile_state,
+                                                            FusedCtl* __restrict__ ctl) {
+  __shared__ unsigned s_tile;
+  __shared__ uint32_t s_wcount[BLOCK / WAVE];
+  __shared__ uint64_t s_prefix;
+  const int64_t n_words = (np + 63) >> 6;
+  const int64_t n_tiles = (n_words + FUSED_TILE_WORDS - 1) / FUSED_TILE_WORDS;
+  const unsigned lane = lane_id();
+  const int wv = threadIdx.x >> 6;
+  for (int64_t tile = 0, batch_end = 0;; tile++) {
+    if (tile == batch_end) {
+      // one returning device-scope atomic per FUSED_TILES_PER_TICKET tiles: a single head word
+      // saturates near 88 dequeues/us (MI355X_MICROARCH.md "dequeue"), i.e. 6.7 ms for the 586 k
+      // tiles of the SF100 probe side if every tile took its own ticket
+      if (threadIdx.x == 0) s_tile = atomicAdd(&ctl->ticket, 1u);
+      __syncthreads();
+      tile = (int64_t)s_tile * FUSED_TILES_PER_TICKET;
+      batch_end = tile + FUSED_TILES_PER_TICKET;
+      __syncthreads();  // everyone has read s_tile before thread 0 can overwrite it
+    }
+    if (tile >= n_tiles) return;
+    const int64_t w0 = tile * FUSED_TILE_WORDS + (int64_t)wv * FUSED_WORDS;
+
+    // ---- lookup (all independent table loads first: memory-level parallelism)
+    uint32_t m[FUSED_WORDS];
+#pragma unroll
+    for (int j = 0; j < FUSED_WORDS; j++) {
+      int64_t p = ((w0 + j) << 6) + lane;
+      m[j] = p < np ? chain_head<AM>(c, p) : 0u;
+    }
+    uint64_t word[FUSED_WORDS];
+    uint32_t wave_cnt = 0;
+#pragma unroll
+    for (int j = 0; j < FUSED_WORDS; j++) {
+      int64_t p = ((w0 + j) << 6) + lane;
+      if (!AM) {
+        while (m[j] && !chain_match<AM>(c, (int64_t)m[j] - 1, p)) m[j] = c.next[m[j] - 1];
+      }
+      word[j] = ballot64(p < np && ((m[j] != 0) != (invert != 0)));
+      wave_cnt += (uint32_t)__popcll(word[j]);
+    }
+    if (lane == 0) s_wcount[wv] = wave_cnt;
+    __syncthreads();
+
+    // ---- tile prefix by decoupled look-back (wave 0)
+    if (wv == 0) {
+      uint64_t agg = 0;
+#pragma unroll
+      for (int i = 0; i < BLOCK / WAVE; i++) agg += s_wcount[i];
+      uint64_t excl = 0;
+      if (tile > 0) {
+        if (lane == 0) ts_store(&tile_state[tile], TS_AGG | agg);
+        int64_t base = tile - 1;
+        for (;;) {
+          const int64_t idx = base - (int64_t)lane;
+          uint64_t s;
+          int first_pfx;
+          for (;;) {
+            s = idx >= 0 ? ts_load(&tile_state[idx]) : TS_PFX;  // virtual inclusive prefix 0 before tile 0
+            const uint64_t empty = ballot64((s >> 62) == 0);
+            const uint64_t pfx = ballot64((s >> 62) == 2);
+            first_pfx = pfx ? __builtin_ctzll(pfx) : 64;
+            const int first_empty = empty ? __builtin_ctzll(empty) : 64;
+            if (first_empty > first_pfx || (!pfx && !empty)) break;  // everything up to the nearest prefix is published
+            __builtin_amdgcn_s_sleep(1);
+          }
+          excl += wave_sum((int)lane <= first_pfx ? (s & TS_VAL) : 0ull);
+          if (first_pfx < 64) break;
+          base -= 64;
+        }
+      }
+      if (lane == 0) {
+        ts_store(&tile_state[tile], TS_PFX | (excl + agg));
+        s_prefix = excl;
+        if (tile == n_tiles - 1) ctl->total = excl + agg;
+      }
+    }
+    __syncthreads();
+    uint64_t wave_base = s_prefix;
+#pragma unroll
+    for (int i = 0; i < BLOCK / WAVE; i++)
+      if (i < wv) wave_base += s_wcount[i];
+
+    // ---- materialise: probe columns stream, build columns gather, rows land in probe order
+    bool sel[FUSED_WORDS];
+    int64_t dst[FUSED_WORDS];
+#pragma unroll
+    for (int j = 0; j < FUSED_WORDS; j++) {
+      sel[j] = (word[j] >> lane) & 1ull;
+      dst[j] = (int64_t)(wave_base + mbcnt(word[j]));
+      wave_base += (uint32_t)__popcll(word[j]);
+    }
+    for (int cidx = 0; cidx < cols.n; cidx++) {
+      const int width = cols.width[cidx];
+      const bool from_build = cidx < cols.n_build;
+#pragma unroll
+      for (int j = 0; j < FUSED_WORDS; j++) {
+        if (!sel[j]) continue;
+        int64_t s = from_build ? (int64_t)m[j] - 1 : ((w0 + j) << 6) + lane;
+        switch (width) {
+          case 16: jcopy<uint4>(cols.src[cidx], cols.dst[cidx], s, dst[j]); break;
+          case 8: jcopy<uint64_t>(cols.src[cidx], cols.dst[cidx], s, dst[j]); break;
+          case 4: jcopy<uint32_t>(cols.src[cidx], cols.dst[cidx], s, dst[j]); break;
+          case 1: jcopy<uint8_t>(cols.src[cidx], cols.dst[cidx], s, dst[j]); break;
+        }
+      }
+    }
+    __syncthreads();  // s_wcount / s_prefix are reused by the next tile
+  }
+}
+
 // unmatched / matched build rows from the visited bytes (process_unmatched_build_batch, stream.rs:1002-)
 __global__ __launch_bounds__(BLOCK) void k_visited_mask(const uint8_t* __restrict__ visited, int64_t n, int want_visited, uint64_t* __restrict__ mask) {
   const int64_t n_words = (n + 63) >> 6;
@@ -370,6 +536,7 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
   jt->key_cols = key_cols;
   jt->null_equality = null_equality;
   jt->force_collisions = opts.force_hash_collisions != 0;
+  jt->probe_mode = opts.probe_mode;
   const int64_t nb = build.nrows;
   DFGPU_CHECK(nb < 0xFFFFFFFFll, "build side has >= u32::MAX rows (the reference switches to JoinHashMapU64; not supported on GPU)");
   KeySet ks = make_keyset(build, key_cols);
@@ -479,8 +646,74 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const bool fast_inner = join_type == DFGPU_JOIN_INNER && jt.keys_unique && !payload_nullable &&
                           (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS;
 
+  // single-pass flavour: output columns are allocated for the upper bound (np rows) because the
+  // row count is only known when the kernel ends; HBM is sized for that (288 GB), but keep a
+  // guard so a huge probe side with a tiny result falls back to the exact two-pass allocation
+  int64_t out_row_bytes = 0;
+  for (int c : bout) out_row_bytes += type_width(jt.build.cols[c].field.type);
+  for (int c : pout) out_row_bytes += type_width(probe.cols[c].field.type);
+  const bool fused_ok = np > 0 && np < (1ll << 40) && !payload_nullable && (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS &&
+                        bout.size() + pout.size() > 0 && (fast_inner || probe_side_only);
+  bool use_fused = fused_ok && jt.probe_mode != 1;
+  if (use_fused && jt.probe_mode == 0) {
+    size_t free_b = 0, total_b = 0;
+    DFGPU_HIP(hipMemGetInfo(&free_b, &total_b));
+    int64_t avail = (int64_t)free_b + r.cached;
+    if (np * out_row_bytes > avail / 2) use_fused = false;
+  }
+  DFGPU_CHECK(!(jt.probe_mode == 2 && !use_fused), "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
+
+  if (use_fused) {
+    const int64_t n_tiles = (n_words + FUSED_TILE_WORDS - 1) / FUSED_TILE_WORDS;
+    BufPtr state = make_zero_buf((size_t)n_tiles * 8);
+    BufPtr ctl = make_zero_buf(sizeof(FusedCtl));
+    JoinCopyCols jc{};
+    int64_t bytes_in = key_bytes, bytes_per_out = 0;
+    bool key_is_payload = false;
+    for (int c : bout) {
+      const Column& sc = jt.build.cols[c];
+      out.cols.push_back(alloc_column(sc.field, sc.name, np));
+      jc.src[jc.n] = sc.ptr();
+      jc.dst[jc.n] = out.cols.back().data->ptr;
+      jc.width[jc.n] = type_width(sc.field.type);
+      bytes_per_out += 2 * jc.width[jc.n];
+      jc.n++;
+    }
+    jc.n_build = jc.n;
+    for (int c : pout) {
+      const Column& sc = probe.cols[c];
+      out.cols.push_back(alloc_column(sc.field, sc.name, np));
+      jc.src[jc.n] = sc.ptr();
+      jc.dst[jc.n] = out.cols.back().data->ptr;
+      jc.width[jc.n] = type_width(sc.field.type);
+      bool is_key = false;
+      for (int k : pk) is_key |= k == c;
+      key_is_payload |= is_key;
+      if (!is_key) bytes_in += np * jc.width[jc.n];  // a key column that is also payload is read once
+      bytes_per_out += jc.width[jc.n];
+      jc.n++;
+    }
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (r.profiling) {
+      DFGPU_HIP(hipEventCreate(&ea));
+      DFGPU_HIP(hipEventCreate(&eb));
+      DFGPU_HIP(hipEventRecord(ea, r.stream));
+    }
+    const int invert = join_type == DFGPU_JOIN_RIGHT_ANTI;
+    const int g = (int)std::min<int64_t>((n_tiles + FUSED_TILES_PER_TICKET - 1) / FUSED_TILES_PER_TICKET, (int64_t)r.num_cus * 8);
+    if (jt.array_map) k_join_probe_fused<true><<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, state->as<uint64_t>(), ctl->as<FusedCtl>());
+    else k_join_probe_fused<false><<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, state->as<uint64_t>(), ctl->as<FusedCtl>());
+    DFGPU_HIP(hipGetLastError());
+    if (r.profiling) DFGPU_HIP(hipEventRecord(eb, r.stream));
+    const int64_t n_out = (int64_t)read_u64(&ctl->as<FusedCtl>()->total);
+    // algorithmic bytes (SURVEY 8d config 3 ii): every referenced probe column once, build payload per
+    // output row, output written once; known only now that n_out is
+    if (r.profiling) r.recs.push_back(Runtime::Rec{"join_probe_fused", ea, eb, bytes_in + n_out * bytes_per_out});
+    out.nrows = n_out;
+    for (Column& c : out.cols) c.length = n_out;
+    (void)key_is_payload;
+  } else if (np > 0 && (probe_side_only || (build_side_only && jt.keys_unique) || fast_inner)) {
   // LeftSemi/LeftAnti/LeftMark must mark EVERY matching build row: first-match suffices only for unique keys
-  if (np > 0 && (probe_side_only || (build_side_only && jt.keys_unique) || fast_inner)) {
     // ---- at most one match per probe row
     BufPtr mask = make_buf(bitmap_bytes(np));
     BufPtr first = fast_inner ? make_buf((size_t)np * 4) : nullptr;
@@ -579,7 +812,7 @@ int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int nu
   return guarded([&] {
     require_init();
     DFGPU_CHECK(nkeys >= 1 && key_cols && out, "join needs at least one key column");
-    dfgpu_join_options o{1024, 0.15, 0, 0};  // config.rs:913,923 defaults
+    dfgpu_join_options o{1024, 0.15, 0, 0, 0, 0};  // config.rs:913,923 defaults
     if (opts) o = *opts;
     auto jt = join_build(*unwrap(build), std::vector<int>(key_cols, key_cols + nkeys), null_equality, o);
     *out = reinterpret_cast<dfgpu_join_t>(jt.release());

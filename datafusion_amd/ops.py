@@ -53,11 +53,11 @@ class JoinHashTable:
     """JoinLeftData (hash_join/exec.rs:195-240): the built side of a hash join"""
 
     def __init__(self, build: DeviceTable, on_left, null_equality="NullEqualsNothing", table_mode=0,
-                 small_build_threshold=1024, min_key_density=0.15, force_hash_collisions=False):
+                 small_build_threshold=1024, min_key_density=0.15, force_hash_collisions=False, probe_mode=0):
         lib = _lib.init()
         self.build = build  # keep alive
         self.key_idx = [build.index_of(k) for k in on_left]
-        opts = JoinOptions(small_build_threshold, min_key_density, table_mode, int(force_hash_collisions))
+        opts = JoinOptions(small_build_threshold, min_key_density, table_mode, int(force_hash_collisions), probe_mode, 0)
         self._h = C.c_void_p()
         check(lib.dfgpu_join_build(build.handle, _ints(self.key_idx), len(self.key_idx), NULL_EQUALITY[null_equality],
                                    C.byref(opts), C.byref(self._h)))

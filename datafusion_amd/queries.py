@@ -1,0 +1,139 @@
+"""TPC-H Q1 and Q3 as the operator DAGs DataFusion's planner produces, executed operator by
+operator on device tables (BASELINE.json configs 4 and 5).
+
+The plans are the reference's pinned physical plans, node for node:
+  Q1  datafusion/sqllogictest/test_files/tpch/plans/q1.slt.part:42-58
+  Q3  datafusion/sqllogictest/test_files/tpch/plans/q3.slt.part:44-76
+Each `RepartitionExec(Hash)` of the plan is `exchange.hash_exchange` (partition kernel + RCCL
+all-to-all) when a process group with more than one rank is active and a no-op otherwise; the
+`SortPreservingMergeExec` at the root gathers the per-rank top rows to every rank and merges.
+
+String columns: l_returnflag / l_linestatus are 1-byte codes (UInt8 = the ASCII byte) and
+c_mktsegment is a UInt8 dictionary code (tpch.SEGMENTS order), as produced by the generator
+(SURVEY.md §7 "Strings: first pass").
+"""
+from __future__ import annotations
+
+import datetime
+
+import pyarrow as pa
+
+from . import ops
+from .expr import col, lit
+from .table import DeviceTable
+
+DATE_Q1 = datetime.date(1998, 9, 2)
+DATE_Q3 = datetime.date(1995, 3, 15)
+SEGMENT_BUILDING = 1  # tpch.SEGMENTS.index("BUILDING")
+ONE = lit(1, pa.decimal128(20, 0))  # Int64(1) coerced to Decimal128(20,0), type_coercion/binary.rs:1257-1273
+
+
+def _world(group=None) -> int:
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(group)
+    except ImportError:
+        pass
+    return 1
+
+
+def _repartition(table: DeviceTable, keys, group=None) -> DeviceTable:
+    """RepartitionExec: partitioning=Hash(keys, N)"""
+    if _world(group) == 1:
+        return table
+    from .exchange import hash_exchange
+    return hash_exchange(table, keys, group)
+
+
+def _merge_sorted(table: DeviceTable, keys, fetch, group=None) -> DeviceTable:
+    """SortPreservingMergeExec(fetch): every rank contributes its (already sorted, <= fetch rows)
+    partition; the merged result is replicated on all ranks.  The inputs are a handful of rows,
+    so they travel as host objects and the merge is one more device sort."""
+    if _world(group) == 1:
+        return table
+    import torch.distributed as dist
+    mine = table.to_arrow()
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, mine, group=group)
+    merged = DeviceTable.from_arrow(pa.concat_tables(parts))
+    return ops.sort(merged, keys, fetch=fetch)
+
+
+# ------------------------------------------------------------------------------------ Q1
+Q1_GROUP_BY = [(col("l_returnflag"), "l_returnflag"), (col("l_linestatus"), "l_linestatus")]
+
+
+def q1_aggs():
+    ce = col("__common_expr_1")
+    return [("sum", col("l_quantity"), "sum_qty"), ("sum", col("l_extendedprice"), "sum_base_price"), ("sum", ce, "sum_disc_price"),
+            ("sum", ce * (ONE + col("l_tax")), "sum_charge"), ("avg", col("l_quantity"), "avg_qty"),
+            ("avg", col("l_extendedprice"), "avg_price"), ("avg", col("l_discount"), "avg_disc"), ("count", None, "count_order")]
+
+
+def q1(lineitem: DeviceTable, group=None) -> DeviceTable:
+    """q1.slt.part:50-58, bottom-up: FilterExec(l_shipdate <= 1998-09-02, projection) ->
+    ProjectionExec(__common_expr_1 = l_extendedprice * (1 - l_discount), ...) ->
+    AggregateExec(Partial) -> RepartitionExec(Hash(flag, status)) -> AggregateExec(FinalPartitioned)
+    -> SortExec -> SortPreservingMergeExec.  With one partition DataFusion plans a single
+    AggregateExec(Single) instead of Partial/Final; so do we."""
+    f = ops.filter(lineitem, col("l_shipdate") <= lit(DATE_Q1, pa.date32()),
+                   ["l_extendedprice", "l_discount", "l_quantity", "l_tax", "l_returnflag", "l_linestatus"])
+    p = ops.project(f, [(col("l_extendedprice") * (ONE - col("l_discount")), "__common_expr_1"), (col("l_quantity"), "l_quantity"),
+                        (col("l_extendedprice"), "l_extendedprice"), (col("l_discount"), "l_discount"), (col("l_tax"), "l_tax"),
+                        (col("l_returnflag"), "l_returnflag"), (col("l_linestatus"), "l_linestatus")])
+    f.free()
+    keys = [("l_returnflag", False, False), ("l_linestatus", False, False)]
+    if _world(group) == 1:
+        agg = ops.aggregate(p, Q1_GROUP_BY, q1_aggs(), "Single")
+        p.free()
+    else:
+        partial = ops.aggregate(p, Q1_GROUP_BY, q1_aggs(), "Partial")
+        p.free()
+        routed = _repartition(partial, ["l_returnflag", "l_linestatus"], group)
+        agg = ops.aggregate(routed, Q1_GROUP_BY, q1_aggs(), "FinalPartitioned")
+    out = ops.sort(agg, keys)
+    agg.free()
+    return _merge_sorted(out, keys, None, group)
+
+
+# ------------------------------------------------------------------------------------ Q3
+Q3_SORT = [("revenue", True, True), ("o_orderdate", False, False)]  # revenue DESC (NULLS FIRST), o_orderdate ASC NULLS LAST
+
+
+def q3(customer: DeviceTable, orders: DeviceTable, lineitem: DeviceTable, group=None, stats: dict | None = None) -> DeviceTable:
+    """q3.slt.part:61-76, bottom-up.  `stats` (optional) receives intermediate row counts."""
+    # 09) FilterExec: c_mktsegment = BUILDING, projection=[c_custkey]; 08) Repartition Hash(c_custkey)
+    c = ops.filter(customer, col("c_mktsegment").eq(lit(SEGMENT_BUILDING, pa.uint8())), ["c_custkey"])
+    c_r = _repartition(c, ["c_custkey"], group)
+    # 12) FilterExec: o_orderdate < 1995-03-15; 11) Repartition Hash(o_custkey)
+    o = ops.filter(orders, col("o_orderdate") < lit(DATE_Q3, pa.date32()), ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+    o_r = _repartition(o, ["o_custkey"], group)
+    # 07) HashJoinExec RightSemi on (c_custkey, o_custkey), projection=[o_orderkey, o_orderdate, o_shippriority]
+    ht = ops.JoinHashTable(c_r, ["c_custkey"])
+    semi = ht.probe(o_r, ["o_custkey"], "RightSemi", probe_cols=["o_orderkey", "o_orderdate", "o_shippriority"])
+    ht.free()
+    # 06) Repartition Hash(o_orderkey)
+    semi_r = _repartition(semi, ["o_orderkey"], group)
+    # 15) FilterExec: l_shipdate > 1995-03-15, projection=[l_orderkey, l_extendedprice, l_discount]; 14) Repartition Hash(l_orderkey)
+    l = ops.filter(lineitem, col("l_shipdate") > lit(DATE_Q3, pa.date32()), ["l_orderkey", "l_extendedprice", "l_discount"])
+    l_r = _repartition(l, ["l_orderkey"], group)
+    # 05) HashJoinExec Inner on (o_orderkey, l_orderkey), projection=[o_orderdate, o_shippriority, l_orderkey, l_extendedprice, l_discount]
+    ht2 = ops.JoinHashTable(semi_r, ["o_orderkey"])
+    j = ht2.probe(l_r, ["l_orderkey"], "Inner", ["o_orderdate", "o_shippriority"], ["l_orderkey", "l_extendedprice", "l_discount"])
+    ht2.free()
+    if stats is not None:
+        stats.update(customer_filtered=c.num_rows, orders_filtered=o.num_rows, semi_join=semi.num_rows, lineitem_filtered=l.num_rows, join=j.num_rows)
+    # 04) AggregateExec SinglePartitioned gby=[l_orderkey, o_orderdate, o_shippriority], sum(l_extendedprice * (1 - l_discount))
+    gb = [(col("l_orderkey"), "l_orderkey"), (col("o_orderdate"), "o_orderdate"), (col("o_shippriority"), "o_shippriority")]
+    agg = ops.aggregate(j, gb, [("sum", col("l_extendedprice") * (ONE - col("l_discount")), "revenue")], "SinglePartitioned")
+    if stats is not None:
+        stats.update(groups=agg.num_rows)
+    for t in {id(x): x for x in (c, c_r, o, o_r, semi, semi_r, l, l_r, j)}.values():
+        t.free()
+    # 03) SortExec TopK(fetch=10) [revenue DESC, o_orderdate ASC NULLS LAST]; 02) ProjectionExec reorder
+    top = ops.sort(agg, Q3_SORT, fetch=10)
+    agg.free()
+    out = top.select(["l_orderkey", "revenue", "o_orderdate", "o_shippriority"])
+    # 01) SortPreservingMergeExec fetch=10
+    return _merge_sorted(out, Q3_SORT, 10, group)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 1
+#define DFGPU_ABI_VERSION 2
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -229,6 +229,12 @@ typedef struct dfgpu_join_options {
   /* test hook = cargo feature `force_hash_collisions` (common/src/hash_utils.rs:1186-1197):
    * every key hashes to 0 so only the key re-check (K4) keeps results right */
   int32_t force_hash_collisions;
+  /* probe strategy when a probe row has at most one match (unique build keys, RightSemi/RightAnti)
+   * and the payload is non-nullable: 0 = auto (single pass when the np-row upper bound of the
+   * output fits comfortably in HBM), 1 = two passes (lookup -> scan -> materialise, exact
+   * allocation), 2 = single pass (lookup + decoupled look-back offsets + materialise fused) */
+  int32_t probe_mode;
+  int32_t _pad;
 } dfgpu_join_options;
 
 /* collect_left_input (physical-plan/src/joins/hash_join/exec.rs:2569-2776): build the

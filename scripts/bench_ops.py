@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Per-operator measurements for the SURVEY.md §8(d) configs that bench.py's single JSON line
+does not cover (bench.py = config 3, the Q3 hash join):
+
+  config 2  FilterExec + projection, lineitem SF10, three selectivities, Q3 and Q1 projections
+  config 4  TPC-H Q1 (filter -> projection -> grouped aggregate -> sort), SF100, one GPU
+  config 4' high-cardinality GROUP BY l_orderkey (150 M groups at SF100)
+  config 5  TPC-H Q3 end to end (the reference's physical plan), one GPU
+  K10       RepartitionExec(Hash) of the Q3 lineitem projection into 8 partitions
+  K11/K12   SortExec of orders by (o_orderdate, o_orderkey) and TopK(10)
+
+For every case: rows/s over the input rows, algorithmic GB/s (referenced input columns read once
++ output written once, per §8d) over the wall time of the device region (inputs resident in HBM,
+stream drained on both sides), fraction of the 8.0 TB/s HBM peak, and the per-kernel HIP-event
+breakdown recorded by the library.  One JSON object per line on stdout; `--md FILE` also writes
+a markdown table (copied into profiles/ by the round's profiling script).
+
+  python scripts/bench_ops.py [--sf 100] [--filter-sf 10] [--iters 3] [--only q1,q3,...]
+"""
+import argparse
+import datetime
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=float, default=100.0)
+    ap.add_argument("--filter-sf", type=float, default=10.0)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--md", default="")
+    args = ap.parse_args()
+    only = set(x for x in args.only.split(",") if x)
+
+    import pyarrow as pa
+
+    from datafusion_amd import _lib, ops, queries
+    from datafusion_amd.expr import col, lit
+    _lib.init(0)
+    results = []
+
+    def want(name):
+        return not only or name in only
+
+    def measure(name, fn, rows, alg_bytes, note=""):
+        """fn() -> object with .free() or list of them (freed outside the timed region)"""
+        def free(o):
+            for x in (o if isinstance(o, (list, tuple)) else [o]):
+                if x is not None and hasattr(x, "free"):
+                    x.free()
+        free(fn())  # warm-up (also grows the memory pool)
+        ops.sync()
+        ops.profile_enable(True)
+        ops.profile_reset()
+        times = []
+        for _ in range(args.iters):
+            ops.sync()
+            t0 = time.perf_counter()
+            o = fn()
+            ops.sync()
+            times.append(time.perf_counter() - t0)
+            free(o)
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+        best = min(times)
+        b = alg_bytes() if callable(alg_bytes) else alg_bytes
+        kern = {k: round(v["total_ms"] / args.iters, 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
+        rec = {"case": name, "rows": rows, "ms": round(best * 1e3, 3), "ms_median": round(sorted(times)[len(times) // 2] * 1e3, 3),
+               "rows_per_s": rows / best, "algorithmic_bytes": b, "algorithmic_gb_per_s": round(b / best / 1e9, 1),
+               "hbm_frac": round(b / best / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms_per_iter": kern, "note": note}
+        results.append(rec)
+        print(json.dumps(rec), flush=True)
+
+    # ------------------------------------------------------------------ config 2: filter
+    if want("filter"):
+        li = ops.tpch_lineitem(args.filter_sf)
+        n = li.num_rows
+        q3p = ["l_orderkey", "l_extendedprice", "l_discount"]                                             # 40 B/row
+        q1p = ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus"]    # 66 B/row
+        d = lambda y, m, dd: lit(datetime.date(y, m, dd), pa.date32())
+        preds = [("shipdate<=1998-09-02", col("l_shipdate") <= d(1998, 9, 2)), ("shipdate>1995-03-15", col("l_shipdate") > d(1995, 3, 15)),
+                 ("shipdate in 1994", (col("l_shipdate") >= d(1994, 1, 1)).and_(col("l_shipdate") <= d(1994, 12, 31)))]
+        for pname, pred in preds:
+            for projname, proj, w in (("q3proj", q3p, 40), ("q1proj", q1p, 66)):
+                holder = {}
+
+                def run(pred=pred, proj=proj):
+                    o = ops.filter(li, pred, proj)
+                    holder["n"] = o.num_rows
+                    return o
+                measure(f"filter[{pname},{projname}] SF{args.filter_sf:g}", run, n, lambda w=w: n * 4 + n * w + holder["n"] * w,
+                        note="bytes = N*4 (predicate col) + N*W (projected cols read) + sel*N*W (written)")
+                results[-1]["selectivity"] = round(holder["n"] / n, 4)
+        li.free()
+        ops.sync()
+
+    # ------------------------------------------------------------------ config 4: Q1
+    if want("q1") or want("agg_highcard") or want("partition"):
+        li = ops.tpch_lineitem(args.sf)
+        n = li.num_rows
+        if want("q1"):
+            measure(f"Q1 SF{args.sf:g} (filter+project+aggregate 8 aggs/4 groups+sort)", lambda: queries.q1(li), n, n * 70,
+                    note="bytes = 7 referenced columns: l_shipdate 4 + 4 x Decimal128 64 + 2 x u8 flags = 70 B/row; output 4 rows")
+            holder = {}
+            f = ops.filter(li, col("l_shipdate") <= lit(queries.DATE_Q1, pa.date32()),
+                           ["l_extendedprice", "l_discount", "l_quantity", "l_tax", "l_returnflag", "l_linestatus"])
+            p = ops.project(f, [(col("l_extendedprice") * (queries.ONE - col("l_discount")), "__common_expr_1"), (col("l_quantity"), "l_quantity"),
+                                (col("l_extendedprice"), "l_extendedprice"), (col("l_discount"), "l_discount"), (col("l_tax"), "l_tax"),
+                                (col("l_returnflag"), "l_returnflag"), (col("l_linestatus"), "l_linestatus")])
+            f.free()
+            m = p.num_rows
+            measure(f"Q1 AggregateExec only SF{args.sf:g}", lambda: ops.aggregate(p, queries.Q1_GROUP_BY, queries.q1_aggs(), "Single"), m, m * (16 * 5 + 2),
+                    note="input = projected table (5 Decimal128 + 2 u8 = 82 B/row)")
+            p.free()
+        if want("agg_highcard"):
+            t = li.select(["l_orderkey", "l_extendedprice"])
+            holder = {}
+
+            def run():
+                o = ops.aggregate(t, [(col("l_orderkey"), "l_orderkey")], [("sum", col("l_extendedprice"), "s")], "Single")
+                holder["g"] = o.num_rows
+                return o
+            measure(f"GROUP BY l_orderkey SUM(l_extendedprice) SF{args.sf:g}", run, n, lambda: n * 24 + holder["g"] * 24,
+                    note="bytes = N*(8+16) in + groups*(8+16) out")
+            results[-1]["groups"] = holder["g"]
+            t.free()
+        if want("partition"):
+            t = li.select(["l_orderkey", "l_extendedprice", "l_discount"])
+            measure(f"RepartitionExec Hash(l_orderkey) -> 8 partitions SF{args.sf:g}", lambda: ops.partition(t, ["l_orderkey"], 8), n, 2 * n * 40,
+                    note="bytes = 2*N*40 (every column read once, written once)")
+            t.free()
+        li.free()
+        ops.sync()
+
+    # ------------------------------------------------------------------ sort / TopK
+    if want("sort"):
+        o = ops.tpch_orders(args.sf)
+        n = o.num_rows
+        keys = [("o_orderdate", False, False), ("o_orderkey", True, False)]
+        measure(f"SortExec orders by (o_orderdate, o_orderkey DESC) SF{args.sf:g}", lambda: ops.sort(o, keys), n, 2 * n * 24,
+                note="bytes = 2*N*24 (4 columns read once, written once); radix passes are overhead")
+        measure(f"TopK(10) orders by (o_orderdate, o_orderkey DESC) SF{args.sf:g}", lambda: ops.sort(o, keys, fetch=10), n, n * 12,
+                note="bytes = N*12 (key columns read once)")
+        o.free()
+        ops.sync()
+
+    # ------------------------------------------------------------------ config 5 (one GPU): Q3
+    if want("q3"):
+        c, o, li = ops.tpch_customer(args.sf), ops.tpch_orders(args.sf), ops.tpch_lineitem(args.sf)
+        li4 = li.select(["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
+        li.free()
+        stats = {}
+        queries.q3(c, o, li4, stats=stats).free()
+        nc, no, nl = c.num_rows, o.num_rows, li4.num_rows
+        # §8d config 5: sum over operators of referenced input column bytes + output bytes
+        b = (nc * (8 + 1) + stats["customer_filtered"] * 8                      # customer filter
+             + no * 24 + stats["orders_filtered"] * 24                          # orders filter (4 cols)
+             + stats["customer_filtered"] * 8 + stats["orders_filtered"] * 24 + stats["semi_join"] * 16   # semi join
+             + nl * 44 + stats["lineitem_filtered"] * 40                        # lineitem filter
+             + stats["semi_join"] * 16 + stats["lineitem_filtered"] * 40 + stats["join"] * 48             # inner join
+             + stats["join"] * 48 + stats["groups"] * 32                        # aggregate
+             + stats["groups"] * 20)                                            # top-k keys
+        measure(f"Q3 SF{args.sf:g} end to end, 1 GPU", lambda: queries.q3(c, o, li4), nc + no + nl, b,
+                note="bytes = sum over the plan's operators of referenced input columns + outputs (intermediate counts below)")
+        results[-1]["intermediate_rows"] = stats
+        for t in (c, o, li4):
+            t.free()
+
+    if args.md:
+        with open(args.md, "w") as f:
+            f.write("| case | input rows | ms (best) | G rows/s | algorithmic GB | GB/s | % of 8 TB/s | top kernels (ms/iter) |\n|---|---:|---:|---:|---:|---:|---:|---|\n")
+            for r in results:
+                top = ", ".join(f"{k} {v}" for k, v in list(r["kernel_ms_per_iter"].items())[:5])
+                f.write(f"| {r['case']} | {r['rows']} | {r['ms']} | {r['rows_per_s'] / 1e9:.2f} | {r['algorithmic_bytes'] / 1e9:.2f} | "
+                        f"{r['algorithmic_gb_per_s']} | {100 * r['hbm_frac']:.1f} | {top} |\n")
+
+
+if __name__ == "__main__":
+    main()

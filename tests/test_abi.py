@@ -27,19 +27,26 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert _lib.load().dfgpu_abi_version() == 1
+    assert _lib.load().dfgpu_abi_version() == 2
 
 
-def test_struct_layouts_match_header():
-    # sizes the C compiler gives the ABI structs (LP64): keep ctypes mirrors in sync
-    assert C.sizeof(_lib.Field) == 16
-    assert C.sizeof(_lib.ExprNode) == 56
-    assert C.sizeof(_lib.Expr) == 16
-    assert C.sizeof(_lib.JoinOptions) == 24
-    assert C.sizeof(_lib.JoinInfo) == 40
-    assert C.sizeof(_lib.KernelStat) == 88
+def test_struct_layouts_match_header(tmp_path):
+    """sizes the C compiler gives the ABI structs of include/dfgpu.h (LP64) == the ctypes mirrors"""
+    import subprocess
+    names = {"dfgpu_field": _lib.Field, "dfgpu_expr_node": _lib.ExprNode, "dfgpu_expr": _lib.Expr, "dfgpu_join_options": _lib.JoinOptions,
+             "dfgpu_join_info": _lib.JoinInfo, "dfgpu_kernel_stat": _lib.KernelStat, "dfgpu_agg_spec": _lib.AggSpec,
+             "dfgpu_column_view": _lib.ColumnView}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "dfgpu.h"\nint main(void){' +
+                   "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) +
+                   'printf("ArrowSchema %zu\\nArrowArray %zu\\n", sizeof(struct ArrowSchema), sizeof(struct ArrowArray));return 0;}')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n, t in names.items():
+        assert int(got[n]) == C.sizeof(t), (n, got[n], C.sizeof(t))
     from datafusion_amd.table import ArrowArray, ArrowSchema
-    assert C.sizeof(ArrowSchema) == 72 and C.sizeof(ArrowArray) == 80
+    assert int(got["ArrowSchema"]) == C.sizeof(ArrowSchema) == 72 and int(got["ArrowArray"]) == C.sizeof(ArrowArray) == 80
 
 
 def test_no_cpu_fallback_without_gpu():

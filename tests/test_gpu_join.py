@@ -52,10 +52,44 @@ def test_unique_build_fast_path_preserves_probe_order():
     rng = np.random.default_rng(5)
     build = pa.table({"k": pa.array(rng.permutation(5000)[:4000] * 3, type=pa.int64()), "v": pa.array(np.arange(4000), type=pa.int32())})
     probe = random_table(rng, 50_001, {"k2": (pa.int64(), -10, 15100), "p": (pa.decimal128(15, 2), 0, 10**7)})
+    exp = oracle.hash_join(build, probe, [("k", "k2")], "Inner")
     for mode in (0, 1):
-        got = gpu_join(build, probe, [("k", "k2")], "Inner", table_mode=mode)
-        exp = oracle.hash_join(build, probe, [("k", "k2")], "Inner")
-        assert_tables_equal(got, exp, ordered=True)
+        for probe_mode in (1, 2):   # two-pass (lookup -> scan -> materialise) and fused single pass
+            got = gpu_join(build, probe, [("k", "k2")], "Inner", table_mode=mode, probe_mode=probe_mode)
+            assert_tables_equal(got, exp, ordered=True)
+
+
+@pytest.mark.parametrize("np_rows", [1, 63, 1024, 1025, 70_000, 3_000_001])
+@pytest.mark.parametrize("table_mode", [0, 1])
+def test_single_pass_probe_lookback_many_tiles(np_rows, table_mode):
+    """single-pass probe: 1024-row tiles chained by decoupled look-back; 3 M rows = 2930 tiles, so
+    look-back windows span > 64 predecessors; ragged tails; selectivity ~ 50 %; result in probe
+    order and identical to the two-pass path and the oracle"""
+    from oracle import oracle
+    rng = np.random.default_rng(np_rows)
+    nb = 40_000
+    build = pa.table({"k": pa.array(rng.permutation(2 * nb)[:nb].astype(np.int64) * 2, type=pa.int64()),
+                      "v": pa.array(np.arange(nb), type=pa.int32()), "d": pa.array(np.arange(nb) + 8000, type=pa.int32()).cast(pa.date32())})
+    probe = random_table(rng, np_rows, {"k2": (pa.int64(), -5, 4 * nb + 5), "p": (pa.decimal128(15, 2), 0, 10**7), "q": (pa.float64(), 0, 1)})
+    exp = oracle.hash_join(build, probe, [("k", "k2")], "Inner")
+    one = gpu_join(build, probe, [("k", "k2")], "Inner", table_mode=table_mode, probe_mode=2)
+    two = gpu_join(build, probe, [("k", "k2")], "Inner", table_mode=table_mode, probe_mode=1)
+    assert_tables_equal(one, exp, ordered=True)
+    assert_tables_equal(two, exp, ordered=True)
+    for jt in ("RightSemi", "RightAnti"):
+        e = oracle.hash_join(build, probe, [("k", "k2")], jt)
+        assert_tables_equal(gpu_join(build, probe, [("k", "k2")], jt, table_mode=table_mode, probe_mode=2), e, ordered=True)
+        assert_tables_equal(gpu_join(build, probe, [("k", "k2")], jt, table_mode=table_mode, probe_mode=1), e, ordered=True)
+
+
+def test_single_pass_probe_rejects_inapplicable():
+    """duplicate build keys (M:N) cannot use the single-pass kernel: explicit request fails loudly, auto falls back"""
+    from datafusion_amd import _lib
+    build = pa.table({"k": pa.array([1, 1, 2], type=pa.int64()), "v": pa.array([1, 2, 3], type=pa.int32())})
+    probe = pa.table({"k2": pa.array([1, 2, 3], type=pa.int64())})
+    with pytest.raises(_lib.DfgpuError):
+        gpu_join(build, probe, [("k", "k2")], "Inner", probe_mode=2)
+    assert gpu_join(build, probe, [("k", "k2")], "Inner").num_rows == 3
 
 
 def test_multi_column_and_decimal_keys():

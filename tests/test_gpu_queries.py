@@ -1,0 +1,69 @@
+"""BASELINE configs 4 and 5 at scales the oracle finishes in seconds: TPC-H Q1 and Q3 as the
+reference's pinned physical plans (tpch/plans/q1.slt.part:50-58, q3.slt.part:61-76), every
+operator on the GPU, compared with the same plan composed from the CPU oracle's operators.
+Decimal128 results are bit-exact; Q3's TopK is fully ordered (ties broken by the stable sort on
+both sides over the same first-seen group order)."""
+import datetime
+
+import pyarrow as pa
+import pytest
+
+from tests.util import assert_tables_equal, to_oracle_expr
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_q1(li):
+    from datafusion_amd import queries as Q
+    from datafusion_amd.expr import col, lit
+    from oracle import oracle
+    f = oracle.filter(li, to_oracle_expr(col("l_shipdate") <= lit(Q.DATE_Q1, pa.date32())),
+                      ["l_extendedprice", "l_discount", "l_quantity", "l_tax", "l_returnflag", "l_linestatus"])
+    p = oracle.project(f, [(to_oracle_expr(col("l_extendedprice") * (Q.ONE - col("l_discount"))), "__common_expr_1")] +
+                       [(("col", n), n) for n in ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus"]])
+    agg = oracle.aggregate(p, [(to_oracle_expr(e), n) for e, n in Q.Q1_GROUP_BY],
+                           [(fn, None if e is None else to_oracle_expr(e), n) for fn, e, n in Q.q1_aggs()], "Single")
+    return oracle.sort(agg, [("l_returnflag", False, False), ("l_linestatus", False, False)])
+
+
+def oracle_q3(c, o, l):
+    from datafusion_amd import queries as Q
+    from datafusion_amd.expr import col, lit
+    from oracle import oracle
+    cf = oracle.filter(c, to_oracle_expr(col("c_mktsegment").eq(lit(Q.SEGMENT_BUILDING, pa.uint8()))), ["c_custkey"])
+    of = oracle.filter(o, to_oracle_expr(col("o_orderdate") < lit(Q.DATE_Q3, pa.date32())), ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+    semi = oracle.hash_join(cf, of, [("c_custkey", "o_custkey")], "RightSemi").select(["o_orderkey", "o_orderdate", "o_shippriority"])
+    lf = oracle.filter(l, to_oracle_expr(col("l_shipdate") > lit(Q.DATE_Q3, pa.date32())), ["l_orderkey", "l_extendedprice", "l_discount"])
+    j = oracle.hash_join(semi, lf, [("o_orderkey", "l_orderkey")], "Inner").select(["o_orderdate", "o_shippriority", "l_orderkey", "l_extendedprice", "l_discount"])
+    gb = [(("col", "l_orderkey"), "l_orderkey"), (("col", "o_orderdate"), "o_orderdate"), (("col", "o_shippriority"), "o_shippriority")]
+    agg = oracle.aggregate(j, gb, [("sum", to_oracle_expr(col("l_extendedprice") * (Q.ONE - col("l_discount"))), "revenue")], "Single")
+    top = oracle.sort(agg, Q.Q3_SORT, fetch=10)
+    return top.select(["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]), dict(
+        customer_filtered=cf.num_rows, orders_filtered=of.num_rows, semi_join=semi.num_rows, lineitem_filtered=lf.num_rows, join=j.num_rows, groups=agg.num_rows)
+
+
+@pytest.mark.parametrize("sf", [0.002, 0.05])
+def test_q1_matches_oracle_plan(sf):
+    from datafusion_amd import ops, queries, tpch
+    got = queries.q1(ops.tpch_lineitem(sf)).to_arrow()
+    exp = oracle_q1(tpch.lineitem(sf))
+    assert got.column_names == ["l_returnflag", "l_linestatus", "sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price",
+                                "avg_disc", "count_order"]
+    # result types pinned by the reference's plan/answer files (q1.slt.part:45-46, answers/q1.slt.part:42-45)
+    assert got.schema.field("sum_disc_price").type == pa.decimal128(38, 4)
+    assert got.schema.field("sum_charge").type == pa.decimal128(38, 6)
+    assert got.schema.field("avg_qty").type == pa.decimal128(19, 6)
+    assert_tables_equal(got, exp, ordered=True)
+
+
+@pytest.mark.parametrize("sf", [0.002, 0.05])
+def test_q3_matches_oracle_plan(sf):
+    from datafusion_amd import ops, queries, tpch
+    stats = {}
+    got = queries.q3(ops.tpch_customer(sf), ops.tpch_orders(sf), ops.tpch_lineitem(sf), stats=stats).to_arrow()
+    exp, exp_stats = oracle_q3(tpch.customer(sf), tpch.orders(sf), tpch.lineitem(sf))
+    assert stats == exp_stats
+    assert got.column_names == ["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]
+    assert got.schema.field("revenue").type == pa.decimal128(38, 4)
+    assert got.num_rows == min(10, exp_stats["groups"])
+    assert_tables_equal(got, exp, ordered=True)
