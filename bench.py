@@ -74,7 +74,9 @@ def main():
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor (BASELINE: 100)")
     ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--probe-mode", type=int, default=0, help="0 auto (single-pass probe), 1 two-pass, 2 single-pass")
+    ap.add_argument("--probe-mode", type=int, default=3,
+                    help="3 single pass, unordered output (default: in Q3 the join feeds AggregateExec, no ancestor needs the probe "
+                         "order); 0/1 two passes, output in probe order; 2 single pass ordered (look-back)")
     args = ap.parse_args()
 
     import torch
@@ -102,18 +104,16 @@ def main():
     nb_local, np_local = orders.num_rows, lineitem.num_rows
     ops.sync()
 
-    def step():
+    def step(probe_mode=args.probe_mode):
         o, l = orders, lineitem
         if world > 1:
             from datafusion_amd.exchange import hash_exchange
             o = hash_exchange(orders, ["o_orderkey"])
             l = hash_exchange(lineitem, ["l_orderkey"])
-        # N > 1: hash routing leaves each rank 1/N of the keys over the same key range; the reference's
-        # density gate (perfect_hash_join_min_key_density = 0.15, config.rs:923) would then pick the
-        # chained hash map (documented caveat, hash_join/exec.rs:590-605).  On the GPU the direct-
-        # address table stays the better structure down to ~1/32 density (its memset + sparse reads
-        # cost less than 2-3 random 64 B sectors per probe row), so the bench sets that knob.
-        ht = ops.JoinHashTable(o, ["o_orderkey"], min_key_density=0.15 if world == 1 else 1.0 / 32, probe_mode=args.probe_mode)
+        # join-table choice follows the library default (direct-address down to key density 1/64, see
+        # DFGPU_DEFAULT_MIN_KEY_DENSITY in include/dfgpu.h): at N > 1 hash routing leaves each rank 1/N of
+        # the keys over the same key range (density 0.25/N)
+        ht = ops.JoinHashTable(o, ["o_orderkey"], probe_mode=probe_mode)
         out = ht.probe(l, ["l_orderkey"], "Inner", BUILD_COLS, PROBE_COLS)
         n_out = out.num_rows
         info = ht.info()
@@ -143,6 +143,16 @@ def main():
     dt = time.perf_counter() - t0
     stats = ops.profile_stats()
     ops.profile_enable(False)
+    # secondary, outside the contract's timed region: the same step with output in probe order
+    # (two passes), for plans where an ancestor does need HashJoinExec's probe-side ordering
+    ordered_ms = None
+    if args.probe_mode == 3:
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(0)
+        barrier()
+        ordered_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
     tot = torch.tensor([float(nb_local), float(np_local), float(n_out), dt], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -175,11 +185,15 @@ def main():
                                    "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
                        "build_rows": nb, "probe_rows": np_, "output_rows": nout,
                        "join_table": "array_map" if info.used_array_map else "hash_map",
+                       "probe": {0: "two_pass_ordered", 1: "two_pass_ordered", 2: "single_pass_ordered", 3: "single_pass_unordered"}[args.probe_mode],
                        "parallelism": "single GPU" if world == 1 else f"hash-repartition all-to-all x{world}"},
             "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),
             "hbm_frac_whole_step": round(alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
             "roofline": roof, "kernels": kernels,
         }
+        if ordered_ms is not None:
+            line["ordered_output_two_pass"] = {"ms_per_step": round(ordered_ms, 3), "rows_per_s": (nb + np_) / (ordered_ms * 1e-3),
+                                               "hbm_frac_whole_step": round(alg / (ordered_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4)}
         if not args.no_cpu:
             threads = os.cpu_count() or 1
             line["cpu_baseline"] = cpu_baseline(args.cpu_sf, threads)

@@ -353,65 +353,121 @@ __global__ __launch_bounds__(BLOCK) void k_join_materialize(JoinCopyCols cols, c
 // ---------------------------------------------------------------- single-pass probe (K3+K4+K5 fused)
 // At most one match per probe row (unique build keys / probe-side semi+anti) and non-nullable
 // payload: lookup, output-offset computation and materialisation happen in ONE kernel, so the
-// probe keys are read once and neither match ids nor masks ever reach HBM.  The global output
-// offset of a tile (1024 probe rows = one workgroup pass) comes from a decoupled look-back over
-// per-tile {status, count} words: a tile publishes its own count (AGG), then wave 0 walks back
-// 64 predecessors at a time until it meets an inclusive prefix (PFX), and finally publishes
-// its own inclusive prefix.  Tiles are handed out in order by an atomic ticket (a few consecutive
-// tiles per ticket, processed in order), so a tile only ever waits on tiles whose workgroup is
-// already resident => forward progress without a cooperative launch or any residency assumption.
-// Cross-workgroup traffic is one 8-byte agent-scope atomic granule {status, count} per tile —
-// the form MI355X_MICROARCH.md lists as valid without fences (per-XCD L2s are not coherent).
-// Output order = probe order, as the two-pass path and the reference (exec.rs:3349).
-constexpr int FUSED_WORDS = 4;                                   // 64-row words per wave per tile
-constexpr int FUSED_TILE_WORDS = FUSED_WORDS * (BLOCK / WAVE);   // 16 words = 1024 rows per tile
-constexpr int FUSED_TILES_PER_TICKET = 4;                        // consecutive tiles per ticket
+// probe keys are read once and neither match ids nor masks ever reach HBM.  A tile = one
+// workgroup pass over 256*W probe rows.  Two ways to place a tile's rows in the output:
+//
+//  UNORDERED (probe_mode 3) — for plans that do not need the probe order (the join feeds an
+//    aggregate / repartition, as in TPC-H Q3): wave 0 claims the tile's output range with ONE
+//    returning atomicAdd on a cursor.  Rows stay in probe order inside a tile; tiles land in
+//    claim order.  No tile waits on another tile; one workgroup per tile, no persistence.
+//  ORDERED (probe_mode 2) — output in probe order like the reference (exec.rs:3349): the global
+//    offset of a tile comes from a decoupled look-back over per-tile {status, count} words: a
+//    tile publishes its count (AGG), wave 0 walks back 256 predecessors per round until it meets
+//    an inclusive prefix (PFX), then publishes its own.  Tiles are handed out in order by an
+//    atomic ticket, so a tile only ever waits on tiles whose workgroup is already resident =>
+//    forward progress without a cooperative launch or any residency assumption.  Cross-
+//    workgroup traffic is one 8-byte agent-scope atomic granule per tile — the form
+//    MI355X_MICROARCH.md lists as valid without fences (per-XCD L2s are not coherent).
+//    Measured on the SF100 Q3 join this is SLOWER than the two-pass path (15.4 vs 12.5 ms: each
+//    look-back round is an agent-scope load queued behind the CU's own streaming loads, 3-5 us,
+//    with the whole workgroup parked on it), so `auto` keeps two passes for ordered output.
 constexpr uint64_t TS_AGG = 1ull << 62, TS_PFX = 2ull << 62, TS_VAL = (1ull << 62) - 1;
 
 __device__ __forceinline__ uint64_t ts_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ts_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-struct FusedCtl {
-  uint64_t total;    // out: number of output rows
-  unsigned ticket;   // next tile to hand out
-  unsigned _pad;
+struct alignas(128) FusedCtl {
+  unsigned long long total;  // out: number of output rows (ordered: last tile's inclusive prefix; unordered: the cursor)
+  char _pad0[120];           // the ticket lives on its own cache line: both words are hot atomics
+  unsigned ticket;           // ordered mode: next tile to hand out
+  char _pad1[124];
 };
 
-template <bool AM>
+// wave 0 of a tile in ordered mode: exclusive prefix of `agg` over all earlier tiles
+__device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* __restrict__ tile_state, int64_t tile, uint64_t agg) {
+  const unsigned lane = lane_id();
+  uint64_t excl = 0;
+  if (tile > 0) {
+    if (lane == 0) ts_store(&tile_state[tile], TS_AGG | agg);
+    // each lane polls LB consecutive predecessors, nearest first => a 64*LB-tile window per round
+    constexpr int LB = 4;
+    int64_t base = tile - 1;
+    for (;;) {
+      uint64_t sum, pfx_lanes;
+      for (;;) {
+        uint64_t st[LB];
+#pragma unroll
+        for (int q = 0; q < LB; q++) {
+          const int64_t idx = base - ((int64_t)lane * LB + q);
+          st[q] = idx >= 0 ? ts_load(&tile_state[idx]) : TS_PFX;  // virtual inclusive prefix 0 before tile 0
+        }
+        sum = 0;
+        bool lane_pfx = false, lane_block = false;  // block = an unpublished tile sits before this lane's first prefix
+#pragma unroll
+        for (int q = 0; q < LB; q++) {
+          const unsigned status = (unsigned)(st[q] >> 62);
+          if (!lane_pfx && !lane_block) {
+            if (status == 0) lane_block = true;
+            else {
+              sum += st[q] & TS_VAL;
+              lane_pfx = status == 2;
+            }
+          }
+        }
+        pfx_lanes = ballot64(lane_pfx);
+        const uint64_t block_lanes = ballot64(lane_block);
+        const int first_pfx = pfx_lanes ? __builtin_ctzll(pfx_lanes) : 64;
+        const int first_block = block_lanes ? __builtin_ctzll(block_lanes) : 64;
+        // lanes before the nearest prefix lane must be fully published (a blocked lane never
+        // reports a prefix, so first_block != first_pfx)
+        if (first_block > first_pfx || !block_lanes) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const int first_pfx = pfx_lanes ? __builtin_ctzll(pfx_lanes) : 64;
+      excl += wave_sum((int)lane <= first_pfx ? sum : 0ull);
+      if (first_pfx < 64) break;
+      base -= 64 * LB;
+    }
+  }
+  if (lane == 0) ts_store(&tile_state[tile], TS_PFX | (excl + agg));
+  return excl;
+}
+
+template <bool AM, int W, bool ORDERED>
 __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopyCols cols, int64_t np, int invert, uint64_t* __restrict__ tile_state,
                                                             FusedCtl* __restrict__ ctl) {
   __shared__ unsigned s_tile;
   __shared__ uint32_t s_wcount[BLOCK / WAVE];
   __shared__ uint64_t s_prefix;
+  constexpr int TILE_WORDS = W * (BLOCK / WAVE);
   const int64_t n_words = (np + 63) >> 6;
-  const int64_t n_tiles = (n_words + FUSED_TILE_WORDS - 1) / FUSED_TILE_WORDS;
+  const int64_t n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
   const unsigned lane = lane_id();
   const int wv = threadIdx.x >> 6;
-  for (int64_t tile = 0, batch_end = 0;; tile++) {
-    if (tile == batch_end) {
-      // one returning device-scope atomic per FUSED_TILES_PER_TICKET tiles: a single head word
-      // saturates near 88 dequeues/us (MI355X_MICROARCH.md "dequeue"), i.e. 6.7 ms for the 586 k
-      // tiles of the SF100 probe side if every tile took its own ticket
+  for (;;) {
+    int64_t tile = blockIdx.x;
+    if (ORDERED) {
+      // every tile takes its OWN ticket: handing one workgroup several consecutive tiles would make
+      // tile 4k wait on the AGG of tile 4k-1, which its owner only reaches after finishing
+      // 4k-4..4k-2 => a fully serial chain
       if (threadIdx.x == 0) s_tile = atomicAdd(&ctl->ticket, 1u);
       __syncthreads();
-      tile = (int64_t)s_tile * FUSED_TILES_PER_TICKET;
-      batch_end = tile + FUSED_TILES_PER_TICKET;
-      __syncthreads();  // everyone has read s_tile before thread 0 can overwrite it
+      tile = s_tile;
+      if (tile >= n_tiles) return;
     }
-    if (tile >= n_tiles) return;
-    const int64_t w0 = tile * FUSED_TILE_WORDS + (int64_t)wv * FUSED_WORDS;
+    const int64_t w0 = tile * TILE_WORDS + (int64_t)wv * W;
 
     // ---- lookup (all independent table loads first: memory-level parallelism)
-    uint32_t m[FUSED_WORDS];
+    uint32_t m[W];
 #pragma unroll
-    for (int j = 0; j < FUSED_WORDS; j++) {
+    for (int j = 0; j < W; j++) {
       int64_t p = ((w0 + j) << 6) + lane;
       m[j] = p < np ? chain_head<AM>(c, p) : 0u;
     }
-    uint64_t word[FUSED_WORDS];
+    uint64_t word[W];  // wave-uniform (SGPR pairs)
     uint32_t wave_cnt = 0;
 #pragma unroll
-    for (int j = 0; j < FUSED_WORDS; j++) {
+    for (int j = 0; j < W; j++) {
       int64_t p = ((w0 + j) << 6) + lane;
       if (!AM) {
         while (m[j] && !chain_match<AM>(c, (int64_t)m[j] - 1, p)) m[j] = c.next[m[j] - 1];
@@ -422,38 +478,19 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
     if (lane == 0) s_wcount[wv] = wave_cnt;
     __syncthreads();
 
-    // ---- tile prefix by decoupled look-back (wave 0)
+    // ---- where the tile's rows go (wave 0)
     if (wv == 0) {
       uint64_t agg = 0;
 #pragma unroll
       for (int i = 0; i < BLOCK / WAVE; i++) agg += s_wcount[i];
       uint64_t excl = 0;
-      if (tile > 0) {
-        if (lane == 0) ts_store(&tile_state[tile], TS_AGG | agg);
-        int64_t base = tile - 1;
-        for (;;) {
-          const int64_t idx = base - (int64_t)lane;
-          uint64_t s;
-          int first_pfx;
-          for (;;) {
-            s = idx >= 0 ? ts_load(&tile_state[idx]) : TS_PFX;  // virtual inclusive prefix 0 before tile 0
-            const uint64_t empty = ballot64((s >> 62) == 0);
-            const uint64_t pfx = ballot64((s >> 62) == 2);
-            first_pfx = pfx ? __builtin_ctzll(pfx) : 64;
-            const int first_empty = empty ? __builtin_ctzll(empty) : 64;
-            if (first_empty > first_pfx || (!pfx && !empty)) break;  // everything up to the nearest prefix is published
-            __builtin_amdgcn_s_sleep(1);
-          }
-          excl += wave_sum((int)lane <= first_pfx ? (s & TS_VAL) : 0ull);
-          if (first_pfx < 64) break;
-          base -= 64;
-        }
+      if (ORDERED) {
+        excl = lookback_exclusive(tile_state, tile, agg);
+        if (lane == 0 && tile == n_tiles - 1) ctl->total = excl + agg;
+      } else if (lane == 0 && agg) {
+        excl = atomicAdd(&ctl->total, (unsigned long long)agg);
       }
-      if (lane == 0) {
-        ts_store(&tile_state[tile], TS_PFX | (excl + agg));
-        s_prefix = excl;
-        if (tile == n_tiles - 1) ctl->total = excl + agg;
-      }
+      if (lane == 0) s_prefix = excl;
     }
     __syncthreads();
     uint64_t wave_base = s_prefix;
@@ -461,31 +498,27 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
     for (int i = 0; i < BLOCK / WAVE; i++)
       if (i < wv) wave_base += s_wcount[i];
 
-    // ---- materialise: probe columns stream, build columns gather, rows land in probe order
-    bool sel[FUSED_WORDS];
-    int64_t dst[FUSED_WORDS];
-#pragma unroll
-    for (int j = 0; j < FUSED_WORDS; j++) {
-      sel[j] = (word[j] >> lane) & 1ull;
-      dst[j] = (int64_t)(wave_base + mbcnt(word[j]));
-      wave_base += (uint32_t)__popcll(word[j]);
-    }
+    // ---- materialise: probe columns stream, build columns gather; probe order inside the tile
     for (int cidx = 0; cidx < cols.n; cidx++) {
       const int width = cols.width[cidx];
       const bool from_build = cidx < cols.n_build;
+      uint64_t ob = wave_base;
 #pragma unroll
-      for (int j = 0; j < FUSED_WORDS; j++) {
-        if (!sel[j]) continue;
-        int64_t s = from_build ? (int64_t)m[j] - 1 : ((w0 + j) << 6) + lane;
+      for (int j = 0; j < W; j++) {
+        const int64_t d = (int64_t)(ob + mbcnt(word[j]));
+        ob += (uint32_t)__popcll(word[j]);
+        if (!((word[j] >> lane) & 1ull)) continue;
+        const int64_t s = from_build ? (int64_t)m[j] - 1 : ((w0 + j) << 6) + lane;
         switch (width) {
-          case 16: jcopy<uint4>(cols.src[cidx], cols.dst[cidx], s, dst[j]); break;
-          case 8: jcopy<uint64_t>(cols.src[cidx], cols.dst[cidx], s, dst[j]); break;
-          case 4: jcopy<uint32_t>(cols.src[cidx], cols.dst[cidx], s, dst[j]); break;
-          case 1: jcopy<uint8_t>(cols.src[cidx], cols.dst[cidx], s, dst[j]); break;
+          case 16: jcopy<uint4>(cols.src[cidx], cols.dst[cidx], s, d); break;
+          case 8: jcopy<uint64_t>(cols.src[cidx], cols.dst[cidx], s, d); break;
+          case 4: jcopy<uint32_t>(cols.src[cidx], cols.dst[cidx], s, d); break;
+          case 1: jcopy<uint8_t>(cols.src[cidx], cols.dst[cidx], s, d); break;
         }
       }
     }
-    __syncthreads();  // s_wcount / s_prefix are reused by the next tile
+    if (!ORDERED) return;
+    __syncthreads();  // s_tile / s_wcount / s_prefix are reused by the next tile
   }
 }
 
@@ -537,6 +570,7 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
   jt->null_equality = null_equality;
   jt->force_collisions = opts.force_hash_collisions != 0;
   jt->probe_mode = opts.probe_mode;
+  if (const char* e = getenv("DFGPU_PROBE_MODE")) jt->probe_mode = atoi(e);  // experiment override
   const int64_t nb = build.nrows;
   DFGPU_CHECK(nb < 0xFFFFFFFFll, "build side has >= u32::MAX rows (the reference switches to JoinHashMapU64; not supported on GPU)");
   KeySet ks = make_keyset(build, key_cols);
@@ -647,29 +681,35 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
                           (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS;
 
   // single-pass flavour: output columns are allocated for the upper bound (np rows) because the
-  // row count is only known when the kernel ends; HBM is sized for that (288 GB), but keep a
-  // guard so a huge probe side with a tiny result falls back to the exact two-pass allocation
+  // row count is only known when the kernel ends; HBM is sized for that (288 GB)
   int64_t out_row_bytes = 0;
   for (int c : bout) out_row_bytes += type_width(jt.build.cols[c].field.type);
   for (int c : pout) out_row_bytes += type_width(probe.cols[c].field.type);
-  const bool fused_ok = np > 0 && np < (1ll << 40) && !payload_nullable && (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS &&
+  const bool fused_ok = np < (1ll << 40) && !payload_nullable && (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS &&
                         bout.size() + pout.size() > 0 && (fast_inner || probe_side_only);
-  bool use_fused = fused_ok && jt.probe_mode != 1;
-  if (use_fused && jt.probe_mode == 0) {
+  // probe_mode: 0 auto = two passes (ordered, exact allocation); 2 / 3 = single pass ordered / unordered
+  const bool use_fused = fused_ok && np > 0 && (jt.probe_mode == 2 || jt.probe_mode == 3);
+  DFGPU_CHECK(!((jt.probe_mode == 2 || jt.probe_mode == 3) && !fused_ok),
+              "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
+  if (use_fused) {
     size_t free_b = 0, total_b = 0;
     DFGPU_HIP(hipMemGetInfo(&free_b, &total_b));
-    int64_t avail = (int64_t)free_b + r.cached;
-    if (np * out_row_bytes > avail / 2) use_fused = false;
+    DFGPU_CHECK(np * out_row_bytes <= (int64_t)free_b + r.cached, "single-pass probe: the np-row upper bound of the output does not fit in HBM");
   }
-  DFGPU_CHECK(!(jt.probe_mode == 2 && !use_fused), "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
 
   if (use_fused) {
-    const int64_t n_tiles = (n_words + FUSED_TILE_WORDS - 1) / FUSED_TILE_WORDS;
-    BufPtr state = make_zero_buf((size_t)n_tiles * 8);
+    static const int fused_words = [] {  // tuning knob: rows per tile = 256 x this
+      const char* e = getenv("DFGPU_FUSED_WORDS");
+      int w = e ? atoi(e) : 8;
+      return w == 4 ? 4 : 8;
+    }();
+    const bool ordered = jt.probe_mode != 3;
+    const int64_t tile_words = (int64_t)fused_words * (BLOCK / WAVE);
+    const int64_t n_tiles = (n_words + tile_words - 1) / tile_words;
+    BufPtr state = ordered ? make_zero_buf((size_t)n_tiles * 8) : nullptr;
     BufPtr ctl = make_zero_buf(sizeof(FusedCtl));
     JoinCopyCols jc{};
     int64_t bytes_in = key_bytes, bytes_per_out = 0;
-    bool key_is_payload = false;
     for (int c : bout) {
       const Column& sc = jt.build.cols[c];
       out.cols.push_back(alloc_column(sc.field, sc.name, np));
@@ -688,7 +728,6 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       jc.width[jc.n] = type_width(sc.field.type);
       bool is_key = false;
       for (int k : pk) is_key |= k == c;
-      key_is_payload |= is_key;
       if (!is_key) bytes_in += np * jc.width[jc.n];  // a key column that is also payload is read once
       bytes_per_out += jc.width[jc.n];
       jc.n++;
@@ -700,18 +739,26 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       DFGPU_HIP(hipEventRecord(ea, r.stream));
     }
     const int invert = join_type == DFGPU_JOIN_RIGHT_ANTI;
-    const int g = (int)std::min<int64_t>((n_tiles + FUSED_TILES_PER_TICKET - 1) / FUSED_TILES_PER_TICKET, (int64_t)r.num_cus * 8);
-    if (jt.array_map) k_join_probe_fused<true><<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, state->as<uint64_t>(), ctl->as<FusedCtl>());
-    else k_join_probe_fused<false><<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, state->as<uint64_t>(), ctl->as<FusedCtl>());
+    // ordered: persistent workgroups pulling tickets; unordered: one workgroup per tile
+    const unsigned g = ordered ? (unsigned)std::min<int64_t>(n_tiles, (int64_t)r.num_cus * 8) : (unsigned)n_tiles;
+    uint64_t* st = state ? state->as<uint64_t>() : nullptr;
+    auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>()); };
+    auto pick_w = [&](auto w4, auto w8) { fused_words == 4 ? launch(w4) : launch(w8); };
+    if (jt.array_map) {
+      if (ordered) pick_w(k_join_probe_fused<true, 4, true>, k_join_probe_fused<true, 8, true>);
+      else pick_w(k_join_probe_fused<true, 4, false>, k_join_probe_fused<true, 8, false>);
+    } else {
+      if (ordered) pick_w(k_join_probe_fused<false, 4, true>, k_join_probe_fused<false, 8, true>);
+      else pick_w(k_join_probe_fused<false, 4, false>, k_join_probe_fused<false, 8, false>);
+    }
     DFGPU_HIP(hipGetLastError());
     if (r.profiling) DFGPU_HIP(hipEventRecord(eb, r.stream));
-    const int64_t n_out = (int64_t)read_u64(&ctl->as<FusedCtl>()->total);
+    const int64_t n_out = (int64_t)read_u64(reinterpret_cast<const uint64_t*>(&ctl->as<FusedCtl>()->total));
     // algorithmic bytes (SURVEY 8d config 3 ii): every referenced probe column once, build payload per
     // output row, output written once; known only now that n_out is
     if (r.profiling) r.recs.push_back(Runtime::Rec{"join_probe_fused", ea, eb, bytes_in + n_out * bytes_per_out});
     out.nrows = n_out;
     for (Column& c : out.cols) c.length = n_out;
-    (void)key_is_payload;
   } else if (np > 0 && (probe_side_only || (build_side_only && jt.keys_unique) || fast_inner)) {
   // LeftSemi/LeftAnti/LeftMark must mark EVERY matching build row: first-match suffices only for unique keys
     // ---- at most one match per probe row
@@ -812,7 +859,7 @@ int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int nu
   return guarded([&] {
     require_init();
     DFGPU_CHECK(nkeys >= 1 && key_cols && out, "join needs at least one key column");
-    dfgpu_join_options o{1024, 0.15, 0, 0, 0, 0};  // config.rs:913,923 defaults
+    dfgpu_join_options o{1024, DFGPU_DEFAULT_MIN_KEY_DENSITY, 0, 0, 0, 0};
     if (opts) o = *opts;
     auto jt = join_build(*unwrap(build), std::vector<int>(key_cols, key_cols + nkeys), null_equality, o);
     *out = reinterpret_cast<dfgpu_join_t>(jt.release());

@@ -17,6 +17,8 @@ JOIN_TYPES = {"Inner": 0, "Left": 1, "Right": 2, "Full": 3, "LeftSemi": 4, "Righ
 NULL_EQUALITY = {"NullEqualsNothing": 0, "NullEqualsNull": 1}
 AGG_MODES = {"Partial": 0, "Final": 1, "FinalPartitioned": 2, "Single": 3, "SinglePartitioned": 4}
 AGG_FUNCS = {"sum": 0, "min": 1, "max": 2, "count": 3, "avg": 4}
+GPU_MIN_KEY_DENSITY = 1.0 / 64.0      # DFGPU_DEFAULT_MIN_KEY_DENSITY (include/dfgpu.h); the reference's CPU default is 0.15
+PROBE_MODES = {"auto": 0, "two_pass": 1, "single_pass_ordered": 2, "single_pass_unordered": 3}
 
 
 def _ints(values):
@@ -53,7 +55,7 @@ class JoinHashTable:
     """JoinLeftData (hash_join/exec.rs:195-240): the built side of a hash join"""
 
     def __init__(self, build: DeviceTable, on_left, null_equality="NullEqualsNothing", table_mode=0,
-                 small_build_threshold=1024, min_key_density=0.15, force_hash_collisions=False, probe_mode=0):
+                 small_build_threshold=1024, min_key_density=GPU_MIN_KEY_DENSITY, force_hash_collisions=False, probe_mode=0):
         lib = _lib.init()
         self.build = build  # keep alive
         self.key_idx = [build.index_of(k) for k in on_left]

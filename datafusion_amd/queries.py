@@ -101,7 +101,8 @@ def q1(lineitem: DeviceTable, group=None) -> DeviceTable:
 Q3_SORT = [("revenue", True, True), ("o_orderdate", False, False)]  # revenue DESC (NULLS FIRST), o_orderdate ASC NULLS LAST
 
 
-def q3(customer: DeviceTable, orders: DeviceTable, lineitem: DeviceTable, group=None, stats: dict | None = None) -> DeviceTable:
+def q3(customer: DeviceTable, orders: DeviceTable, lineitem: DeviceTable, group=None, stats: dict | None = None,
+       probe_mode: int = ops.PROBE_MODES["single_pass_unordered"]) -> DeviceTable:
     """q3.slt.part:61-76, bottom-up.  `stats` (optional) receives intermediate row counts."""
     # 09) FilterExec: c_mktsegment = BUILDING, projection=[c_custkey]; 08) Repartition Hash(c_custkey)
     c = ops.filter(customer, col("c_mktsegment").eq(lit(SEGMENT_BUILDING, pa.uint8())), ["c_custkey"])
@@ -110,7 +111,9 @@ def q3(customer: DeviceTable, orders: DeviceTable, lineitem: DeviceTable, group=
     o = ops.filter(orders, col("o_orderdate") < lit(DATE_Q3, pa.date32()), ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
     o_r = _repartition(o, ["o_custkey"], group)
     # 07) HashJoinExec RightSemi on (c_custkey, o_custkey), projection=[o_orderkey, o_orderdate, o_shippriority]
-    ht = ops.JoinHashTable(c_r, ["c_custkey"])
+    # (both joins feed a RepartitionExec / AggregateExec: no ancestor needs the probe-side order, so the
+    # planner may take the unordered single-pass probe)
+    ht = ops.JoinHashTable(c_r, ["c_custkey"], probe_mode=probe_mode)
     semi = ht.probe(o_r, ["o_custkey"], "RightSemi", probe_cols=["o_orderkey", "o_orderdate", "o_shippriority"])
     ht.free()
     # 06) Repartition Hash(o_orderkey)
@@ -119,7 +122,7 @@ def q3(customer: DeviceTable, orders: DeviceTable, lineitem: DeviceTable, group=
     l = ops.filter(lineitem, col("l_shipdate") > lit(DATE_Q3, pa.date32()), ["l_orderkey", "l_extendedprice", "l_discount"])
     l_r = _repartition(l, ["l_orderkey"], group)
     # 05) HashJoinExec Inner on (o_orderkey, l_orderkey), projection=[o_orderdate, o_shippriority, l_orderkey, l_extendedprice, l_discount]
-    ht2 = ops.JoinHashTable(semi_r, ["o_orderkey"])
+    ht2 = ops.JoinHashTable(semi_r, ["o_orderkey"], probe_mode=probe_mode)
     j = ht2.probe(l_r, ["l_orderkey"], "Inner", ["o_orderdate", "o_shippriority"], ["l_orderkey", "l_extendedprice", "l_discount"])
     ht2.free()
     if stats is not None:

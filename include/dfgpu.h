@@ -218,10 +218,18 @@ int dfgpu_filter(dfgpu_table_t input, const dfgpu_expr* predicate, const int* pr
 int dfgpu_project(dfgpu_table_t input, const dfgpu_expr* exprs, const char* const* names, int n,
                   dfgpu_table_t* out);
 
+/* Default of perfect_hash_join_min_key_density when `opts` is NULL.  The reference ships 0.15
+ * (common/src/config.rs:923), tuned for CPU caches; on MI355X the direct-address table stays the
+ * better structure far below that (its memset + one sequential-ish 4 B read per probe row cost less
+ * than the 1.5-2 random 64 B sectors per probe row of a chained hash table: 7.1 ms vs < 2 ms for
+ * the 324 M-row probe of TPC-H Q3 at SF100, density 0.024).  The knob is the reference's own; only
+ * its default differs.  Results do not depend on the table kind. */
+#define DFGPU_DEFAULT_MIN_KEY_DENSITY (1.0 / 64.0)
+
 typedef struct dfgpu_join_options {
-  /* execution.perfect_hash_join_small_build_threshold (common/src/config.rs:913) */
+  /* execution.perfect_hash_join_small_build_threshold (common/src/config.rs:913), default 1024 */
   int64_t perfect_hash_join_small_build_threshold;
-  /* execution.perfect_hash_join_min_key_density (config.rs:923) */
+  /* execution.perfect_hash_join_min_key_density (config.rs:923), default DFGPU_DEFAULT_MIN_KEY_DENSITY */
   double perfect_hash_join_min_key_density;
   /* 0 = follow the reference's gating (hash_join/exec.rs:111-191); 1 = force hash map;
    * 2 = force direct-address table (error if not applicable) */
@@ -230,9 +238,14 @@ typedef struct dfgpu_join_options {
    * every key hashes to 0 so only the key re-check (K4) keeps results right */
   int32_t force_hash_collisions;
   /* probe strategy when a probe row has at most one match (unique build keys, RightSemi/RightAnti)
-   * and the payload is non-nullable: 0 = auto (single pass when the np-row upper bound of the
-   * output fits comfortably in HBM), 1 = two passes (lookup -> scan -> materialise, exact
-   * allocation), 2 = single pass (lookup + decoupled look-back offsets + materialise fused) */
+   * and the payload is non-nullable:
+   *   0 = auto: two passes (lookup -> scan -> materialise), output in probe order, exact allocation;
+   *   1 = two passes (same as auto today);
+   *   2 = single pass, output in probe order (decoupled look-back; slower than two passes on MI355X);
+   *   3 = single pass, UNORDERED: probe order inside 2048-row tiles, tiles in arbitrary order.  For
+   *       plans where no ancestor needs the probe-side ordering (HashJoinExec::maintains_input_order,
+   *       joins/hash_join/exec.rs:1024-1040,1352, would have to report false for the shim node).
+   * Modes 2/3 allocate the output for the probe-row upper bound and fail if they are not applicable. */
   int32_t probe_mode;
   int32_t _pad;
 } dfgpu_join_options;

@@ -57,6 +57,8 @@ def test_unique_build_fast_path_preserves_probe_order():
         for probe_mode in (1, 2):   # two-pass (lookup -> scan -> materialise) and fused single pass
             got = gpu_join(build, probe, [("k", "k2")], "Inner", table_mode=mode, probe_mode=probe_mode)
             assert_tables_equal(got, exp, ordered=True)
+        got = gpu_join(build, probe, [("k", "k2")], "Inner", table_mode=mode, probe_mode=3)   # unordered single pass
+        assert_tables_equal(got, exp, ordered=False)
 
 
 @pytest.mark.parametrize("np_rows", [1, 63, 1024, 1025, 70_000, 3_000_001])
@@ -76,10 +78,20 @@ def test_single_pass_probe_lookback_many_tiles(np_rows, table_mode):
     two = gpu_join(build, probe, [("k", "k2")], "Inner", table_mode=table_mode, probe_mode=1)
     assert_tables_equal(one, exp, ordered=True)
     assert_tables_equal(two, exp, ordered=True)
+    assert_same_rows_any_tile_order(gpu_join(build, probe, [("k", "k2")], "Inner", table_mode=table_mode, probe_mode=3), exp)
     for jt in ("RightSemi", "RightAnti"):
         e = oracle.hash_join(build, probe, [("k", "k2")], jt)
         assert_tables_equal(gpu_join(build, probe, [("k", "k2")], jt, table_mode=table_mode, probe_mode=2), e, ordered=True)
         assert_tables_equal(gpu_join(build, probe, [("k", "k2")], jt, table_mode=table_mode, probe_mode=1), e, ordered=True)
+        assert_same_rows_any_tile_order(gpu_join(build, probe, [("k", "k2")], jt, table_mode=table_mode, probe_mode=3), e)
+
+
+def assert_same_rows_any_tile_order(got, exp):
+    """unordered single-pass output: the same multiset of rows (tiles land in claim order)"""
+    assert got.num_rows == exp.num_rows and got.schema.types == exp.schema.types
+    names = got.column_names
+    key = [(n, "ascending") for n in names]
+    assert got.sort_by(key).equals(exp.rename_columns(names).sort_by(key))
 
 
 def test_single_pass_probe_rejects_inapplicable():
@@ -87,8 +99,9 @@ def test_single_pass_probe_rejects_inapplicable():
     from datafusion_amd import _lib
     build = pa.table({"k": pa.array([1, 1, 2], type=pa.int64()), "v": pa.array([1, 2, 3], type=pa.int32())})
     probe = pa.table({"k2": pa.array([1, 2, 3], type=pa.int64())})
-    with pytest.raises(_lib.DfgpuError):
-        gpu_join(build, probe, [("k", "k2")], "Inner", probe_mode=2)
+    for pm in (2, 3):
+        with pytest.raises(_lib.DfgpuError):
+            gpu_join(build, probe, [("k", "k2")], "Inner", probe_mode=pm)
     assert gpu_join(build, probe, [("k", "k2")], "Inner").num_rows == 3
 
 
@@ -118,11 +131,14 @@ def test_array_map_gating_matches_reference_rules():
     dense = DeviceTable.from_arrow(pa.table({"k": pa.array(range(0, 4000, 2), type=pa.int64())}))
     sparse = DeviceTable.from_arrow(pa.table({"k": pa.array(range(0, 400000, 200), type=pa.int64())}))
     small = DeviceTable.from_arrow(pa.table({"k": pa.array([5, 900], type=pa.int64())}))
-    assert ops.JoinHashTable(dense, ["k"]).info().used_array_map == 1
-    assert ops.JoinHashTable(sparse, ["k"]).info().used_array_map == 0
-    assert ops.JoinHashTable(small, ["k"]).info().used_array_map == 1
+    ref = dict(small_build_threshold=1024, min_key_density=0.15)   # the reference's defaults, config.rs:913,923
+    assert ops.JoinHashTable(dense, ["k"], **ref).info().used_array_map == 1
+    assert ops.JoinHashTable(sparse, ["k"], **ref).info().used_array_map == 0      # density 0.005
+    assert ops.JoinHashTable(small, ["k"], **ref).info().used_array_map == 1
+    assert ops.JoinHashTable(sparse, ["k"], min_key_density=0.001).info().used_array_map == 1
+    assert ops.JoinHashTable(sparse, ["k"]).info().used_array_map == 0             # GPU default 1/64 still rejects 0.005
     neg = DeviceTable.from_arrow(pa.table({"k": pa.array([-(2**63), 2**63 - 1], type=pa.int64())}))
-    assert ops.JoinHashTable(neg, ["k"]).info().used_array_map == 0  # full-range overflow guard, exec.rs:6907
+    assert ops.JoinHashTable(neg, ["k"], **ref).info().used_array_map == 0  # full-range overflow guard, exec.rs:6907
 
 
 def test_tpch_join_shape_small_sf():

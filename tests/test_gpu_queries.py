@@ -56,11 +56,12 @@ def test_q1_matches_oracle_plan(sf):
     assert_tables_equal(got, exp, ordered=True)
 
 
+@pytest.mark.parametrize("probe_mode", [0, 3], ids=["ordered_probe", "unordered_probe"])
 @pytest.mark.parametrize("sf", [0.002, 0.05])
-def test_q3_matches_oracle_plan(sf):
+def test_q3_matches_oracle_plan(sf, probe_mode):
     from datafusion_amd import ops, queries, tpch
     stats = {}
-    got = queries.q3(ops.tpch_customer(sf), ops.tpch_orders(sf), ops.tpch_lineitem(sf), stats=stats).to_arrow()
+    got = queries.q3(ops.tpch_customer(sf), ops.tpch_orders(sf), ops.tpch_lineitem(sf), stats=stats, probe_mode=probe_mode).to_arrow()
     exp, exp_stats = oracle_q3(tpch.customer(sf), tpch.orders(sf), tpch.lineitem(sf))
     assert stats == exp_stats
     assert got.column_names == ["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]
