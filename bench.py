@@ -184,7 +184,7 @@ def main():
             "config": {"workload": f"INNER hash-join orders⋈lineitem on o_orderkey, TPC-H SF{args.sf:g}, Q3 payload "
                                    "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
                        "build_rows": nb, "probe_rows": np_, "output_rows": nout,
-                       "join_table": "array_map" if info.used_array_map else "hash_map",
+                       "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map"}[info.table_kind],
                        "probe": {0: "two_pass_ordered", 1: "two_pass_ordered", 2: "single_pass_ordered", 3: "single_pass_unordered"}[args.probe_mode],
                        "parallelism": "single GPU" if world == 1 else f"hash-repartition all-to-all x{world}"},
             "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),

@@ -43,7 +43,8 @@ class JoinOptions(C.Structure):
 
 class JoinInfo(C.Structure):
     _fields_ = [("build_rows", C.c_int64), ("table_bytes", C.c_int64), ("used_array_map", C.c_int32),
-                ("build_keys_unique", C.c_int32), ("probe_rows", C.c_int64), ("output_rows", C.c_int64)]
+                ("build_keys_unique", C.c_int32), ("probe_rows", C.c_int64), ("output_rows", C.c_int64),
+                ("table_kind", C.c_int32), ("build_keys_ascending", C.c_int32)]
 
 
 class AggSpec(C.Structure):

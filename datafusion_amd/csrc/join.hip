@@ -4,6 +4,13 @@
 //   * direct-address table  = ArrayMap (joins/array_map.rs:103-236), chosen by the reference's
 //     own gating try_create_array_map (exec.rs:111-191): one integer key, range < threshold or
 //     rows/(range+1) > min density.  data[key-min] = row+1, duplicates chained through next[].
+//   * rank map (GPU-native, no reference counterpart) = direct addressing compressed 16x: one bit per
+//     key value of the range + an exclusive popcount directory per 64-bit word.  For UNIQUE integer
+//     keys the rank of a present key is its position in key order; row id = rank when the build keys
+//     arrive in ascending order (TPC-H primary keys, and anything filtered from them), else
+//     perm[rank].  A 600 M-value range costs 150 MB (MALL-resident) instead of ArrayMap's 2.4 GB, so
+//     the memset, the build atomics and the probe lookups stop streaming the table through HBM.
+//     Falls back to ArrayMap / JoinHashMap when the build side has duplicate keys.
 //   * chained hash table    = JoinHashMap (joins/join_hash_map.rs:144-338): head[hash & mask] =
 //     row+1, next[row] = previous head.  Built with one atomicExch per row (no locks).
 //   NULL keys are not inserted under NullEqualsNothing (joins/utils.rs:2127-2164).
@@ -27,11 +34,15 @@ namespace dfgpu {
 Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_t* mask, const uint64_t* mask_valid);
 void pack_bytes_to_bitmap(const uint8_t* bytes, int64_t n, uint64_t* words);
 
+enum TableKind : int { KIND_HASH = 0, KIND_ARRAY = 1, KIND_RANK = 2 };
+constexpr double RANK_MAP_MIN_KEY_DENSITY = 1.0 / 256.0;  // 64 B of bitmap + directory per build row at the limit
+
 struct JoinTable {
   Table build;
   std::vector<int> key_cols;
   int null_equality = 0;
   bool array_map = false;
+  int kind = 0;  // TableKind
   bool keys_unique = true;
   bool force_collisions = false;
   int probe_mode = 0;  // 0 auto, 1 two-pass, 2 single-pass
@@ -39,6 +50,7 @@ struct JoinTable {
   BufPtr next;   // u32 per build row (null when array_map && unique)
   uint64_t am_offset = 0, am_size = 0;
   uint64_t hash_mask = 0;
+  BufPtr rank_bits, rank_prefix, rank_perm;  // rank map: u64 bitmap, u64 exclusive popcount prefix per word, optional u32 perm
   BufPtr visited;  // u8 per build row, lazily allocated
   dfgpu_join_info info{};
 };
@@ -47,6 +59,9 @@ struct ProbeCtx {
   KeySet bkeys, pkeys;
   const uint32_t* heads;
   const uint32_t* next;
+  const uint64_t* rank_bits;    // KIND_RANK
+  const uint64_t* rank_prefix;
+  const uint32_t* rank_perm;    // null when the build keys are in ascending order (row id == rank)
   uint64_t am_offset, am_size, hash_mask;
   int null_equals_null;
   int force_collisions;
@@ -65,34 +80,70 @@ static KeySet make_keyset(const Table& t, const std::vector<int>& cols) {
   return ks;
 }
 
+// ---- typed key access.  The generic load_words() switches on the column type per element; the
+// compiler then cannot hoist loads out of the switch arms and waits on every single one
+// (s_waitcnt vmcnt(0) after each global_load in the ISA).  Hot kernels are therefore instantiated
+// per key type so that N independent loads are issued back-to-back.
+enum KeyT : int { KT_I32 = 0, KT_U32 = 1, KT_I64 = 2, KT_U8 = 3, KT_ANY = 4 };
+template <int KT>
+__device__ __forceinline__ uint64_t load_key(const KeyCol& k, int64_t i) {
+  if (KT == KT_I32) return (uint64_t)(int64_t)((const int32_t*)k.data)[i];
+  if (KT == KT_U32) return ((const uint32_t*)k.data)[i];
+  if (KT == KT_I64) return ((const uint64_t*)k.data)[i];
+  if (KT == KT_U8) return ((const uint8_t*)k.data)[i];
+  uint64_t lo, hi;
+  load_words(k, i, lo, hi);
+  return lo;
+}
+
 // ------------------------------------------------------------------------ build kernels
 struct MinMax {
   long long smin, smax;
   unsigned long long valid;
+  unsigned unsorted;  // set when some key is <= its predecessor (or a NULL key exists): keys are not strictly ascending
+  unsigned _pad;
 };
 constexpr int BUILD_UNROLL = 4;  // independent key loads in flight per thread
+// min / max / valid count of the build key (ArrayMap::try_new bounds, array_map.rs:175-203) and whether
+// the keys are strictly ascending in row order (=> unique, and rank == row id for the rank map).
+// One workgroup reduces through LDS and issues ONE set of atomics: per-wave atomics on a single
+// line serialise at ~12 ns each and tripled this kernel's time.
+template <int KT, bool HASV>
 __global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMax* out) {
   long long mn = INT64_MAX, mx = INT64_MIN;
   unsigned long long cnt = 0;
+  bool unsorted = false;
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += stride * BUILD_UNROLL) {
-    uint64_t lo[BUILD_UNROLL];
-    bool ok[BUILD_UNROLL];
+    uint64_t lo[BUILD_UNROLL], plo[BUILD_UNROLL];
+    bool ok[BUILD_UNROLL], pok[BUILD_UNROLL];
 #pragma unroll
-    for (int j = 0; j < BUILD_UNROLL; j++) {
+    for (int j = 0; j < BUILD_UNROLL; j++) {  // unconditional (clamped) loads: all 2 x BUILD_UNROLL in flight together
       int64_t i = i0 + j * stride;
-      ok[j] = i < n && !(k.valid && !bit_at(k.valid, i));
-      uint64_t hi;
-      lo[j] = 0;
-      if (ok[j]) load_words(k, i, lo[j], hi);
+      int64_t ic = i < n ? i : n - 1;
+      lo[j] = load_key<KT>(k, ic);
+      plo[j] = load_key<KT>(k, ic > 0 ? ic - 1 : 0);  // neighbour's line: an L1/L2 hit
     }
 #pragma unroll
     for (int j = 0; j < BUILD_UNROLL; j++) {
+      int64_t i = i0 + j * stride;
+      ok[j] = i < n;
+      pok[j] = i < n && i > 0;
+      if (HASV) {
+        ok[j] = ok[j] && bit_at(k.valid, i < n ? i : n - 1);
+        pok[j] = pok[j] && bit_at(k.valid, (i < n ? i : n - 1) > 0 ? (i < n ? i : n - 1) - 1 : 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      int64_t i = i0 + j * stride;
+      if (i < n && !ok[j]) unsorted = true;  // NULL key
       if (!ok[j]) continue;
       long long v = (long long)lo[j];
       mn = v < mn ? v : mn;
       mx = v > mx ? v : mx;
       cnt++;
+      if (pok[j] && (long long)plo[j] >= v) unsorted = true;
     }
   }
 #pragma unroll
@@ -102,15 +153,102 @@ __global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMa
     mx = omx > mx ? omx : mx;
     cnt += __shfl_xor(cnt, d, 64);
   }
-  if (lane_id() == 0 && cnt) {
-    atomicMin(&out->smin, mn);
-    atomicMax(&out->smax, mx);
-    atomicAdd(&out->valid, cnt);
+  const bool wave_unsorted = ballot64(unsorted) != 0;
+  __shared__ long long s_mn[BLOCK / WAVE], s_mx[BLOCK / WAVE];
+  __shared__ unsigned long long s_cnt[BLOCK / WAVE];
+  __shared__ unsigned s_uns[BLOCK / WAVE];
+  const int wv = threadIdx.x >> 6;
+  if (lane_id() == 0) { s_mn[wv] = mn; s_mx[wv] = mx; s_cnt[wv] = cnt; s_uns[wv] = wave_unsorted; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned uns = 0;
+    for (int i = 1; i < BLOCK / WAVE; i++) {
+      mn = s_mn[i] < mn ? s_mn[i] : mn;
+      mx = s_mx[i] > mx ? s_mx[i] : mx;
+      cnt += s_cnt[i];
+    }
+    for (int i = 0; i < BLOCK / WAVE; i++) uns |= s_uns[i];
+    if (cnt) {
+      atomicMin(&out->smin, mn);
+      atomicMax(&out->smax, mx);
+      atomicAdd(&out->valid, cnt);
+    }
+    if (uns) atomicOr(&out->unsorted, 1u);
+  }
+}
+
+// rank map build, step 1: one bit per present key value.  Strictly ascending keys are unique by
+// construction; otherwise the returned old word detects duplicates.
+constexpr int SETBITS_RUN = 4;  // ascending variant: consecutive rows per lane
+template <int KT, bool HASV, bool ASCENDING>
+__global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uint64_t offset, unsigned long long* __restrict__ bits, int* dup_flag) {
+  if (ASCENDING) {
+    // a lane owns SETBITS_RUN consecutive rows => ascending keys; the bits that fall in the same 64-bit
+    // word are merged in registers and leave as ONE fire-and-forget atomic (TPC-H orderkeys come in
+    // dense runs of 8: one atomic per 4 rows).  A wave still reads one contiguous 2 KB span.
+    const int64_t n_runs = (n + SETBITS_RUN - 1) / SETBITS_RUN;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < n_runs; t += (int64_t)gridDim.x * BLOCK) {
+      uint64_t idx[SETBITS_RUN];
+#pragma unroll
+      for (int q = 0; q < SETBITS_RUN; q++) {
+        int64_t i = t * SETBITS_RUN + q;
+        idx[q] = load_key<KT>(k, i < n ? i : n - 1) - offset;  // the clamped tail repeats the last key: same bit again
+      }
+      uint64_t w = idx[0] >> 6;
+      unsigned long long v = 1ull << (idx[0] & 63);
+#pragma unroll
+      for (int q = 1; q < SETBITS_RUN; q++) {
+        if ((idx[q] >> 6) != w) {
+          atomicOr(&bits[w], v);
+          w = idx[q] >> 6;
+          v = 0;
+        }
+        v |= 1ull << (idx[q] & 63);
+      }
+      atomicOr(&bits[w], v);
+    }
+    return;
+  }
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += stride * BUILD_UNROLL) {
+    uint64_t lo[BUILD_UNROLL];
+    bool ok[BUILD_UNROLL];
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      int64_t i = i0 + j * stride;
+      lo[j] = load_key<KT>(k, i < n ? i : n - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      int64_t i = i0 + j * stride;
+      ok[j] = i < n;
+      if (HASV) ok[j] = ok[j] && bit_at(k.valid, i < n ? i : n - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      if (!ok[j]) continue;
+      const uint64_t idx = lo[j] - offset;
+      const unsigned long long bit = 1ull << (idx & 63);
+      if (atomicOr(&bits[idx >> 6], bit) & bit) *dup_flag = 1;  // the old word detects duplicate keys
+    }
+  }
+}
+// rank map build, step 2 (keys not in ascending row order): perm[rank(key_i)] = i
+__global__ __launch_bounds__(BLOCK) void k_rank_perm(KeyCol k, int64_t n, uint64_t offset, const uint64_t* __restrict__ bits,
+                                                     const uint64_t* __restrict__ prefix, uint32_t* __restrict__ perm) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (k.valid && !bit_at(k.valid, i)) continue;
+    uint64_t lo, hi;
+    load_words(k, i, lo, hi);
+    const uint64_t idx = lo - offset;
+    const uint64_t w = bits[idx >> 6];
+    perm[(uint32_t)prefix[idx >> 6] + (uint32_t)__popcll(w & ((1ull << (idx & 63)) - 1ull))] = (uint32_t)i;
   }
 }
 
 // ArrayMap::fill_data (array_map.rs:205-236), lock-free: data[key-min] <- row+1, the previous
 // occupant becomes next[row] (chain order is arbitrary; the reference's is ascending).
+template <int KT, bool HASV>
 __global__ __launch_bounds__(BLOCK) void k_am_build(KeyCol k, int64_t n, uint64_t offset, uint32_t* data, uint32_t* next, int* dup_flag) {
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += stride * BUILD_UNROLL) {
@@ -119,10 +257,13 @@ __global__ __launch_bounds__(BLOCK) void k_am_build(KeyCol k, int64_t n, uint64_
 #pragma unroll
     for (int j = 0; j < BUILD_UNROLL; j++) {
       int64_t i = i0 + j * stride;
-      ok[j] = i < n && !(k.valid && !bit_at(k.valid, i));
-      uint64_t hi;
-      lo[j] = 0;
-      if (ok[j]) load_words(k, i, lo[j], hi);
+      lo[j] = load_key<KT>(k, i < n ? i : n - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      int64_t i = i0 + j * stride;
+      ok[j] = i < n;
+      if (HASV) ok[j] = ok[j] && bit_at(k.valid, i < n ? i : n - 1);
     }
 #pragma unroll
     for (int j = 0; j < BUILD_UNROLL; j++) {
@@ -161,15 +302,20 @@ __global__ __launch_bounds__(BLOCK) void k_hm_check_unique(KeySet ks, int64_t n,
 }
 
 // ------------------------------------------------------------------------ probe kernels
-template <bool AM>
+template <int KIND>
 __device__ __forceinline__ uint32_t chain_head(const ProbeCtx& c, int64_t p) {
-  if (AM) {
+  if (KIND != KIND_HASH) {
     const KeyCol& k = c.pkeys.c[0];
-    if (k.valid && !bit_at(k.valid, p)) return 0;  // ArrayMap is never built with NULL==NULL + NULL build keys
+    if (k.valid && !bit_at(k.valid, p)) return 0;  // direct-address tables are never built with NULL==NULL + NULL build keys
     uint64_t lo, hi;
     load_words(k, p, lo, hi);
     uint64_t idx = lo - c.am_offset;
-    return idx < c.am_size ? c.heads[idx] : 0u;
+    if (idx >= c.am_size) return 0u;
+    if (KIND == KIND_ARRAY) return c.heads[idx];
+    const uint64_t bits = c.rank_bits[idx >> 6];
+    if (!((bits >> (idx & 63)) & 1ull)) return 0u;
+    const uint32_t rank = (uint32_t)c.rank_prefix[idx >> 6] + (uint32_t)__popcll(bits & ((1ull << (idx & 63)) - 1ull));
+    return (c.rank_perm ? c.rank_perm[rank] : rank) + 1u;
   } else {
     bool any_null;
     uint64_t h = hash_row(c.pkeys, p, SEED_JOIN, any_null);
@@ -178,10 +324,81 @@ __device__ __forceinline__ uint32_t chain_head(const ProbeCtx& c, int64_t p) {
     return c.heads[h & c.hash_mask];
   }
 }
-template <bool AM>
+template <int KIND>
 __device__ __forceinline__ bool chain_match(const ProbeCtx& c, int64_t b, int64_t p) {
-  if (AM) return true;  // direct addressing: same slot <=> same key
+  if (KIND != KIND_HASH) return true;  // direct addressing: same slot <=> same key
   return keys_equal(c.bkeys, b, c.pkeys, p, c.null_equals_null);
+}
+
+// match ids (build row + 1, 0 = none) of N consecutive 64-row probe words for this lane.  Every
+// stage (keys -> validity -> table words -> perm) issues its N loads together; out-of-range lanes
+// load a clamped address and are masked afterwards, so there is no branch between the loads.
+template <int KIND, int KT, int N>
+__device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int64_t np, uint32_t (&m)[N]) {
+  const unsigned lane = lane_id();
+  if (KIND == KIND_HASH) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      int64_t p = ((w0 + j) << 6) + lane;
+      m[j] = p < np ? chain_head<KIND>(c, p) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      int64_t p = ((w0 + j) << 6) + lane;
+      while (m[j] && !chain_match<KIND>(c, (int64_t)m[j] - 1, p)) m[j] = c.next[m[j] - 1];
+    }
+    return;
+  }
+  const KeyCol& k = c.pkeys.c[0];
+  uint64_t idx[N];
+  bool ok[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    int64_t p = ((w0 + j) << 6) + lane;
+    ok[j] = p < np;
+    idx[j] = load_key<KT>(k, ok[j] ? p : np - 1) - c.am_offset;
+  }
+  if (k.valid) {  // direct-address tables are never built with NULL==NULL + NULL build keys: a NULL probe key matches nothing
+    uint64_t vw[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      int64_t p = ((w0 + j) << 6) + lane;
+      vw[j] = k.valid[(p < np ? p : np - 1) >> 6];
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) ok[j] = ok[j] && ((vw[j] >> lane) & 1ull);  // p & 63 == lane
+  }
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    ok[j] = ok[j] && idx[j] < c.am_size;
+    if (!ok[j]) idx[j] = 0;
+  }
+  if (KIND == KIND_ARRAY) {
+#pragma unroll
+    for (int j = 0; j < N; j++) m[j] = c.heads[idx[j]];
+#pragma unroll
+    for (int j = 0; j < N; j++) m[j] = ok[j] ? m[j] : 0u;
+  } else {
+    uint64_t bits[N], pre[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      bits[j] = c.rank_bits[idx[j] >> 6];
+      pre[j] = c.rank_prefix[idx[j] >> 6];
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const bool hit = ok[j] && ((bits[j] >> (idx[j] & 63)) & 1ull);
+      const uint32_t rank = (uint32_t)pre[j] + (uint32_t)__popcll(bits[j] & ((1ull << (idx[j] & 63)) - 1ull));
+      m[j] = hit ? rank + 1u : 0u;
+    }
+    if (c.rank_perm) {
+      uint32_t row[N];
+#pragma unroll
+      for (int j = 0; j < N; j++) row[j] = c.rank_perm[m[j] ? m[j] - 1 : 0u];  // clamped, unconditional: N loads in flight
+#pragma unroll
+      for (int j = 0; j < N; j++) m[j] = m[j] ? row[j] + 1u : 0u;
+    }
+  }
 }
 
 // per-row output multiplicity for the probe-side part of each JoinType
@@ -201,38 +418,30 @@ constexpr int PROBE_UNROLL = 4;
 
 // pass 1, at-most-one-match flavour: writes first_match[p] = build row + 1 (0 = none) and one
 // ballot word per 64 probe rows (bit = row produces an output row for this join type).
-template <bool AM>
+template <int KIND, int KT>
 __global__ __launch_bounds__(BLOCK) void k_probe_first(ProbeCtx c, int64_t np, int invert, uint32_t* __restrict__ first_match,
                                                        uint64_t* __restrict__ mask, uint8_t* __restrict__ visited) {
   const int64_t n_words = (np + 63) >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t w0 = wave * PROBE_UNROLL; w0 < n_words; w0 += n_waves * PROBE_UNROLL) {
-    uint32_t cur[PROBE_UNROLL];
+    uint32_t m[PROBE_UNROLL];
+    lookup_words<KIND, KT, PROBE_UNROLL>(c, w0, np, m);
 #pragma unroll
     for (int j = 0; j < PROBE_UNROLL; j++) {
       int64_t p = ((w0 + j) << 6) + lane_id();
-      cur[j] = p < np ? chain_head<AM>(c, p) : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < PROBE_UNROLL; j++) {
-      int64_t p = ((w0 + j) << 6) + lane_id();
-      uint32_t m = cur[j];
-      if (!AM) {
-        while (m && !chain_match<AM>(c, (int64_t)m - 1, p)) m = c.next[m - 1];
-      }
       if (p < np) {
-        if (first_match) first_match[p] = m;
-        if (visited && m) visited[m - 1] = 1;
+        if (first_match) first_match[p] = m[j];
+        if (visited && m[j]) visited[m[j] - 1] = 1;
       }
-      uint64_t word = ballot64(p < np && ((m != 0) != (invert != 0)));
+      uint64_t word = ballot64(p < np && ((m[j] != 0) != (invert != 0)));
       if (lane_id() == 0 && w0 + j < n_words) mask[w0 + j] = word;
     }
   }
 }
 
 // pass 1, general M:N flavour: row_counts[p] = output rows of probe row p, word_counts[w] = sum
-template <bool AM>
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, int join_type, uint32_t* __restrict__ row_counts,
                                                        uint32_t* __restrict__ word_counts, uint8_t* __restrict__ visited) {
   const int64_t n_words = (np + 63) >> 6;
@@ -243,10 +452,10 @@ __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, i
     uint32_t cnt = 0;
     if (p < np) {
       uint32_t nmatch = 0;
-      uint32_t cur = chain_head<AM>(c, p);
+      uint32_t cur = chain_head<KIND>(c, p);
       while (cur) {
         int64_t b = (int64_t)cur - 1;
-        if (chain_match<AM>(c, b, p)) {
+        if (chain_match<KIND>(c, b, p)) {
           nmatch++;
           if (visited) visited[b] = 1;
         }
@@ -261,7 +470,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, i
 }
 
 // pass 2, general flavour: emit (build_idx, probe_idx) pairs; -1 = NULL side
-template <bool AM>
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_probe_emit(ProbeCtx c, int64_t np, int join_type, const uint32_t* __restrict__ row_counts,
                                                       const uint64_t* __restrict__ prefix, int64_t* __restrict__ out_build,
                                                       int64_t* __restrict__ out_probe, uint8_t* __restrict__ out_mark) {
@@ -277,10 +486,10 @@ __global__ __launch_bounds__(BLOCK) void k_probe_emit(ProbeCtx c, int64_t np, in
     if (cnt == 0) continue;
     uint32_t nmatch = 0;
     if (emit_pairs || join_type == DFGPU_JOIN_RIGHT_MARK) {
-      uint32_t cur = chain_head<AM>(c, p);
+      uint32_t cur = chain_head<KIND>(c, p);
       while (cur) {
         int64_t b = (int64_t)cur - 1;
-        if (chain_match<AM>(c, b, p)) {
+        if (chain_match<KIND>(c, b, p)) {
           if (emit_pairs) { out_build[o] = b; out_probe[o] = p; o++; }
           nmatch++;
         }
@@ -371,6 +580,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_materialize(JoinCopyCols cols, c
 //    Measured on the SF100 Q3 join this is SLOWER than the two-pass path (15.4 vs 12.5 ms: each
 //    look-back round is an agent-scope load queued behind the CU's own streaming loads, 3-5 us,
 //    with the whole workgroup parked on it), so `auto` keeps two passes for ordered output.
+constexpr int FUSED_W = 8;  // 64-row words per wave per tile: 2048-row tiles (4 and 8 measured equal, 16 slower: 142 VGPRs)
 constexpr uint64_t TS_AGG = 1ull << 62, TS_PFX = 2ull << 62, TS_VAL = (1ull << 62) - 1;
 
 __device__ __forceinline__ uint64_t ts_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -433,7 +643,7 @@ __device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* __restrict__ ti
   return excl;
 }
 
-template <bool AM, int W, bool ORDERED>
+template <int KIND, int KT, int W, bool ORDERED>
 __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopyCols cols, int64_t np, int invert, uint64_t* __restrict__ tile_state,
                                                             FusedCtl* __restrict__ ctl) {
   __shared__ unsigned s_tile;
@@ -457,21 +667,14 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
     }
     const int64_t w0 = tile * TILE_WORDS + (int64_t)wv * W;
 
-    // ---- lookup (all independent table loads first: memory-level parallelism)
+    // ---- lookup (every stage issues its W loads back-to-back: memory-level parallelism)
     uint32_t m[W];
-#pragma unroll
-    for (int j = 0; j < W; j++) {
-      int64_t p = ((w0 + j) << 6) + lane;
-      m[j] = p < np ? chain_head<AM>(c, p) : 0u;
-    }
+    lookup_words<KIND, KT, W>(c, w0, np, m);
     uint64_t word[W];  // wave-uniform (SGPR pairs)
     uint32_t wave_cnt = 0;
 #pragma unroll
     for (int j = 0; j < W; j++) {
       int64_t p = ((w0 + j) << 6) + lane;
-      if (!AM) {
-        while (m[j] && !chain_match<AM>(c, (int64_t)m[j] - 1, p)) m[j] = c.next[m[j] - 1];
-      }
       word[j] = ballot64(p < np && ((m[j] != 0) != (invert != 0)));
       wave_cnt += (uint32_t)__popcll(word[j]);
     }
@@ -535,6 +738,38 @@ __global__ __launch_bounds__(BLOCK) void k_visited_mask(const uint8_t* __restric
 }
 
 // --------------------------------------------------------------------------------- host
+// call f(std::integral_constant<int, KIND>) for the table kind chosen at build time
+template <typename F>
+static void with_kind(int kind, F&& f) {
+  switch (kind) {
+    case KIND_ARRAY: f(std::integral_constant<int, KIND_ARRAY>{}); break;
+    case KIND_RANK: f(std::integral_constant<int, KIND_RANK>{}); break;
+    default: f(std::integral_constant<int, KIND_HASH>{}); break;
+  }
+}
+template <typename F>
+static void with_key_type(int dfgpu_type, F&& f) {
+  switch (dfgpu_type) {
+    case DFGPU_INT32: case DFGPU_DATE32: f(std::integral_constant<int, KT_I32>{}); break;
+    case DFGPU_UINT32: f(std::integral_constant<int, KT_U32>{}); break;
+    case DFGPU_INT64: f(std::integral_constant<int, KT_I64>{}); break;
+    case DFGPU_UINT8: f(std::integral_constant<int, KT_U8>{}); break;
+    default: throw Error("key type has no direct-address instantiation");
+  }
+}
+// f(KIND, KT): the hash table kind hashes any key set (KT_ANY); the direct-address kinds have one integer key
+template <typename F>
+static void with_kind_and_key(int kind, int probe_key_type, F&& f) {
+  if (kind == KIND_HASH) {
+    f(std::integral_constant<int, KIND_HASH>{}, std::integral_constant<int, KT_ANY>{});
+    return;
+  }
+  with_key_type(probe_key_type, [&](auto kt) {
+    if (kind == KIND_ARRAY) f(std::integral_constant<int, KIND_ARRAY>{}, kt);
+    else f(std::integral_constant<int, KIND_RANK>{}, kt);
+  });
+}
+
 static ProbeCtx make_ctx(const JoinTable& jt, const Table& probe, const std::vector<int>& pk) {
   ProbeCtx c{};
   c.bkeys = make_keyset(jt.build, jt.key_cols);
@@ -544,8 +779,11 @@ static ProbeCtx make_ctx(const JoinTable& jt, const Table& probe, const std::vec
     int pt = c.pkeys.c[i].type == DFGPU_DATE32 ? DFGPU_INT32 : c.pkeys.c[i].type;
     DFGPU_CHECK(bt == pt, "join key types differ between build and probe side (the planner inserts casts)");
   }
-  c.heads = jt.heads->as<uint32_t>();
+  c.heads = jt.heads ? jt.heads->as<uint32_t>() : nullptr;
   c.next = jt.next ? jt.next->as<uint32_t>() : nullptr;
+  c.rank_bits = jt.rank_bits ? jt.rank_bits->as<uint64_t>() : nullptr;
+  c.rank_prefix = jt.rank_prefix ? jt.rank_prefix->as<uint64_t>() : nullptr;
+  c.rank_perm = jt.rank_perm ? jt.rank_perm->as<uint32_t>() : nullptr;
   c.am_offset = jt.am_offset;
   c.am_size = jt.am_size;
   c.hash_mask = jt.hash_mask;
@@ -576,52 +814,116 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
   KeySet ks = make_keyset(build, key_cols);
   jt->info.build_rows = nb;
 
-  // ---- try_create_array_map gating (hash_join/exec.rs:111-191)
-  bool use_am = false;
+  // ---- key statistics: ArrayMap::try_new bounds (array_map.rs:175-203) + ascending-order check
+  bool have_stats = false, ascending = false;
+  uint64_t range = 0;
+  long long kmin = 0;
   if (opts.table_mode != 1 && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64) {
     const Column& kc = build.cols[key_cols[0]];
     bool null_block = null_equality == DFGPU_NULL_EQUALS_NULL && kc.has_nulls();
     if (!null_block && nb > 0) {
       BufPtr mm = make_buf(sizeof(MinMax));
-      static const MinMax init{INT64_MAX, INT64_MIN, 0};
+      static const MinMax init{INT64_MAX, INT64_MIN, 0, 0, 0};
       h2d_async(mm->ptr, &init, sizeof init);
-      k_key_minmax<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, mm->as<MinMax>());
+      {
+        ProfileScope ps("join_build_key_stats", nb * ks.c[0].width);
+        const int g = std::min(grid_for(nb, BLOCK * BUILD_UNROLL), 2048);
+        with_key_type(ks.c[0].type, [&](auto kt) {
+          constexpr int T = decltype(kt)::value;
+          if (ks.c[0].valid) k_key_minmax<T, true><<<g, BLOCK, 0, r.stream>>>(ks.c[0], nb, mm->as<MinMax>());
+          else k_key_minmax<T, false><<<g, BLOCK, 0, r.stream>>>(ks.c[0], nb, mm->as<MinMax>());
+        });
+      }
       MinMax res;
       d2h(&res, mm->ptr, sizeof res);
       if (res.valid > 0) {
-        uint64_t range = (uint64_t)res.smax - (uint64_t)res.smin;  // ArrayMap::calculate_range (wrapping)
-        double dense = (double)nb / ((double)range + 1.0);
-        bool ok = range != UINT64_MAX &&
-                  !(range >= (uint64_t)opts.perfect_hash_join_small_build_threshold && dense <= opts.perfect_hash_join_min_key_density);
-        if (opts.table_mode == 2) ok = range != UINT64_MAX;
-        if (ok && range < (1ull << 34)) {  // HBM guard: <= 64 GiB of u32 slots
-          use_am = true;
-          jt->am_offset = (uint64_t)res.smin;
-          jt->am_size = range + 1;
-        }
+        range = (uint64_t)res.smax - (uint64_t)res.smin;  // ArrayMap::calculate_range (wrapping)
+        have_stats = range != UINT64_MAX;
+        kmin = res.smin;
+        ascending = res.unsorted == 0;
       }
     }
   }
-  DFGPU_CHECK(!(opts.table_mode == 2 && !use_am), "direct-address join table requested but not applicable");
+  const double dense = have_stats ? (double)nb / ((double)range + 1.0) : 0.0;
+  // try_create_array_map gating (hash_join/exec.rs:111-191) with the caller's knob values
+  bool am_ok = have_stats && !(range >= (uint64_t)opts.perfect_hash_join_small_build_threshold && dense <= opts.perfect_hash_join_min_key_density);
+  if (opts.table_mode == 2) am_ok = have_stats;
+  am_ok = am_ok && range < (1ull << 34);  // HBM guard: <= 64 GiB of u32 slots
+  // rank map: 1/4 byte per value of the range, so it pays far below ArrayMap's density gate
+  bool rank_ok = have_stats && (opts.table_mode == 0 || opts.table_mode == 3) && range < (1ull << 40) &&
+                 (range < (uint64_t)opts.perfect_hash_join_small_build_threshold || dense >= RANK_MAP_MIN_KEY_DENSITY || opts.table_mode == 3);
+  DFGPU_CHECK(!(opts.table_mode == 2 && !am_ok), "direct-address join table requested but not applicable");
+  DFGPU_CHECK(!(opts.table_mode == 3 && !rank_ok), "rank-map join table requested but not applicable");
 
   BufPtr flag = make_zero_buf(4);
   int dup = 0;
-  if (use_am) {
+  if (rank_ok) {
+    const int64_t n_words = (int64_t)(range >> 6) + 1;
+    jt->rank_bits = make_zero_buf((size_t)n_words * 8);
+    {
+      ProfileScope ps("join_build_rank_map", nb * ks.c[0].width);
+      int g = std::min(grid_for(nb, BLOCK * BUILD_UNROLL), 2048);
+      unsigned long long* bits = jt->rank_bits->as<unsigned long long>();
+      with_key_type(ks.c[0].type, [&](auto kt) {
+        constexpr int T = decltype(kt)::value;
+        // ascending implies no NULL keys
+        if (ascending) k_rank_setbits<T, false, true><<<g, BLOCK, 0, r.stream>>>(ks.c[0], nb, (uint64_t)kmin, bits, flag->as<int>());
+        else if (ks.c[0].valid) k_rank_setbits<T, true, false><<<g, BLOCK, 0, r.stream>>>(ks.c[0], nb, (uint64_t)kmin, bits, flag->as<int>());
+        else k_rank_setbits<T, false, false><<<g, BLOCK, 0, r.stream>>>(ks.c[0], nb, (uint64_t)kmin, bits, flag->as<int>());
+      });
+    }
+    if (!ascending) d2h(&dup, flag->ptr, 4);
+    if (!dup) {
+      jt->kind = KIND_RANK;
+      jt->am_offset = (uint64_t)kmin;
+      jt->am_size = range + 1;
+      jt->rank_prefix = make_buf((size_t)(n_words + 1) * 8);
+      scan_mask_popcounts(jt->rank_bits->as<uint64_t>(), nullptr, n_words * 64, jt->rank_prefix->as<uint64_t>());
+      if (!ascending) {
+        jt->rank_perm = make_buf((size_t)nb * 4);
+        ProfileScope ps("join_build_rank_perm", nb * (ks.c[0].width + 4));
+        k_rank_perm<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, (uint64_t)kmin, jt->rank_bits->as<uint64_t>(), jt->rank_prefix->as<uint64_t>(),
+                                                                  jt->rank_perm->as<uint32_t>());
+      }
+      jt->info.table_bytes = n_words * 16 + (ascending ? 0 : nb * 4);
+    } else {
+      DFGPU_CHECK(opts.table_mode != 3, "rank-map join table requested but the build keys are not unique");
+      jt->rank_bits.reset();
+    }
+  }
+  if (jt->kind != KIND_RANK && am_ok) {
+    jt->kind = KIND_ARRAY;
     jt->array_map = true;
+    jt->am_offset = (uint64_t)kmin;
+    jt->am_size = range + 1;
     jt->heads = make_zero_buf(jt->am_size * 4);
+    auto am_build = [&](uint32_t* next) {
+      const int g = std::min(grid_for(nb, BLOCK * BUILD_UNROLL), 2048);
+      with_key_type(ks.c[0].type, [&](auto kt) {
+        constexpr int T = decltype(kt)::value;
+        if (ks.c[0].valid) k_am_build<T, true><<<g, BLOCK, 0, r.stream>>>(ks.c[0], nb, jt->am_offset, jt->heads->as<uint32_t>(), next, flag->as<int>());
+        else k_am_build<T, false><<<g, BLOCK, 0, r.stream>>>(ks.c[0], nb, jt->am_offset, jt->heads->as<uint32_t>(), next, flag->as<int>());
+      });
+    };
+    // duplicates already known (the rank map saw them): build the chains in the first pass
+    if (dup) jt->next = make_zero_buf((size_t)nb * 4);
     {
       ProfileScope ps("join_build_array_map", nb * ks.c[0].width);
-      k_am_build<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, jt->am_offset, jt->heads->as<uint32_t>(), nullptr, flag->as<int>());
+      am_build(dup ? jt->next->as<uint32_t>() : nullptr);
     }
-    d2h(&dup, flag->ptr, 4);
-    if (dup) {  // duplicates: rebuild with chains
-      DFGPU_HIP(hipMemsetAsync(jt->heads->ptr, 0, jt->am_size * 4, r.stream));
-      jt->next = make_zero_buf((size_t)nb * 4);
-      ProfileScope ps("join_build_array_map", nb * ks.c[0].width);
-      k_am_build<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, jt->am_offset, jt->heads->as<uint32_t>(), jt->next->as<uint32_t>(), flag->as<int>());
+    if (!dup) {
+      d2h(&dup, flag->ptr, 4);
+      if (dup) {  // duplicates: rebuild with chains
+        DFGPU_HIP(hipMemsetAsync(jt->heads->ptr, 0, jt->am_size * 4, r.stream));
+        jt->next = make_zero_buf((size_t)nb * 4);
+        ProfileScope ps("join_build_array_map", nb * ks.c[0].width);
+        am_build(jt->next->as<uint32_t>());
+      }
     }
     jt->info.table_bytes = (int64_t)jt->am_size * 4 + (dup ? nb * 4 : 0);
-  } else {
+  } else if (jt->kind != KIND_RANK) {
+    jt->kind = KIND_HASH;
+    dup = 0;
     uint64_t cap = 64;
     while (cap < (uint64_t)nb * 2) cap <<= 1;
     jt->hash_mask = cap - 1;
@@ -643,8 +945,10 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
   }
   DFGPU_HIP(hipGetLastError());
   jt->keys_unique = dup == 0;
-  jt->info.used_array_map = use_am;
+  jt->info.used_array_map = jt->kind == KIND_ARRAY;
   jt->info.build_keys_unique = jt->keys_unique;
+  jt->info.table_kind = jt->kind;
+  jt->info.build_keys_ascending = ascending;
   return jt;
 }
 
@@ -698,13 +1002,8 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   }
 
   if (use_fused) {
-    static const int fused_words = [] {  // tuning knob: rows per tile = 256 x this
-      const char* e = getenv("DFGPU_FUSED_WORDS");
-      int w = e ? atoi(e) : 8;
-      return w == 4 ? 4 : 8;
-    }();
     const bool ordered = jt.probe_mode != 3;
-    const int64_t tile_words = (int64_t)fused_words * (BLOCK / WAVE);
+    const int64_t tile_words = (int64_t)FUSED_W * (BLOCK / WAVE);
     const int64_t n_tiles = (n_words + tile_words - 1) / tile_words;
     BufPtr state = ordered ? make_zero_buf((size_t)n_tiles * 8) : nullptr;
     BufPtr ctl = make_zero_buf(sizeof(FusedCtl));
@@ -743,14 +1042,11 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     const unsigned g = ordered ? (unsigned)std::min<int64_t>(n_tiles, (int64_t)r.num_cus * 8) : (unsigned)n_tiles;
     uint64_t* st = state ? state->as<uint64_t>() : nullptr;
     auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>()); };
-    auto pick_w = [&](auto w4, auto w8) { fused_words == 4 ? launch(w4) : launch(w8); };
-    if (jt.array_map) {
-      if (ordered) pick_w(k_join_probe_fused<true, 4, true>, k_join_probe_fused<true, 8, true>);
-      else pick_w(k_join_probe_fused<true, 4, false>, k_join_probe_fused<true, 8, false>);
-    } else {
-      if (ordered) pick_w(k_join_probe_fused<false, 4, true>, k_join_probe_fused<false, 8, true>);
-      else pick_w(k_join_probe_fused<false, 4, false>, k_join_probe_fused<false, 8, false>);
-    }
+    with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
+      constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
+      if (ordered) launch(k_join_probe_fused<K, T, FUSED_W, true>);
+      else launch(k_join_probe_fused<K, T, FUSED_W, false>);
+    });
     DFGPU_HIP(hipGetLastError());
     if (r.profiling) DFGPU_HIP(hipEventRecord(eb, r.stream));
     const int64_t n_out = (int64_t)read_u64(reinterpret_cast<const uint64_t*>(&ctl->as<FusedCtl>()->total));
@@ -768,10 +1064,10 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       ProfileScope ps("join_probe_lookup", key_bytes);  // algorithmic: the probe keys (table reads / match ids are overhead)
       int g = grid_for(n_words, (BLOCK / WAVE) * PROBE_UNROLL);
       int invert = join_type == DFGPU_JOIN_RIGHT_ANTI;
-      if (jt.array_map)
-        k_probe_first<true><<<g, BLOCK, 0, r.stream>>>(ctx, np, invert, first ? first->as<uint32_t>() : nullptr, mask->as<uint64_t>(), visited);
-      else
-        k_probe_first<false><<<g, BLOCK, 0, r.stream>>>(ctx, np, invert, first ? first->as<uint32_t>() : nullptr, mask->as<uint64_t>(), visited);
+      with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
+        k_probe_first<decltype(kd)::value, decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, invert, first ? first->as<uint32_t>() : nullptr,
+                                                                                           mask->as<uint64_t>(), visited);
+      });
       DFGPU_HIP(hipGetLastError());
     }
     if (probe_side_only) {
@@ -822,8 +1118,9 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     int g = grid_for(n_words, BLOCK / WAVE);
     if (np) {
       ProfileScope ps("join_probe_count", key_bytes + np * 4);
-      if (jt.array_map) k_probe_count<true><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), visited);
-      else k_probe_count<false><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), visited);
+      with_kind(jt.kind, [&](auto kt) {
+        k_probe_count<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), visited);
+      });
       DFGPU_HIP(hipGetLastError());
     }
     scan_u32(word_counts->as<uint32_t>(), n_words, prefix->as<uint64_t>());
@@ -832,10 +1129,9 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     BufPtr om = join_type == DFGPU_JOIN_RIGHT_MARK ? make_buf((size_t)n_out + 64) : nullptr;
     if (n_out) {
       ProfileScope ps("join_probe_emit", key_bytes + np * 4 + n_out * 16);
-      if (jt.array_map)
-        k_probe_emit<true><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), ob->as<int64_t>(), op->as<int64_t>(), om ? om->as<uint8_t>() : nullptr);
-      else
-        k_probe_emit<false><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), ob->as<int64_t>(), op->as<int64_t>(), om ? om->as<uint8_t>() : nullptr);
+      with_kind(jt.kind, [&](auto kt) {
+        k_probe_emit<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), ob->as<int64_t>(), op->as<int64_t>(), om ? om->as<uint8_t>() : nullptr);
+      });
       DFGPU_HIP(hipGetLastError());
     }
     out.nrows = n_out;

@@ -231,8 +231,10 @@ typedef struct dfgpu_join_options {
   int64_t perfect_hash_join_small_build_threshold;
   /* execution.perfect_hash_join_min_key_density (config.rs:923), default DFGPU_DEFAULT_MIN_KEY_DENSITY */
   double perfect_hash_join_min_key_density;
-  /* 0 = follow the reference's gating (hash_join/exec.rs:111-191); 1 = force hash map;
-   * 2 = force direct-address table (error if not applicable) */
+  /* 0 = auto: rank map (GPU-native compressed direct addressing: 1 bit per value of the key range +
+   *     popcount directory; unique integer keys, range/rows <= 256) -> else ArrayMap by the reference's
+   *     gating (hash_join/exec.rs:111-191) with the two knobs above -> else chained hash table;
+   * 1 = force chained hash table; 2 = force ArrayMap; 3 = force rank map (2/3: error if not applicable) */
   int32_t table_mode;
   /* test hook = cargo feature `force_hash_collisions` (common/src/hash_utils.rs:1186-1197):
    * every key hashes to 0 so only the key re-check (K4) keeps results right */
@@ -277,6 +279,8 @@ typedef struct dfgpu_join_info {
   int32_t build_keys_unique;
   int64_t probe_rows;  /* accumulated over probe calls */
   int64_t output_rows; /* accumulated */
+  int32_t table_kind;  /* 0 = chained hash table (JoinHashMap), 1 = ArrayMap, 2 = rank map (bitmap + popcount directory) */
+  int32_t build_keys_ascending; /* 1 = single integer key, strictly ascending in row order */
 } dfgpu_join_info;
 int dfgpu_join_get_info(dfgpu_join_t ht, dfgpu_join_info* out);
 int dfgpu_join_free(dfgpu_join_t ht);

@@ -53,7 +53,7 @@ def test_unique_build_fast_path_preserves_probe_order():
     build = pa.table({"k": pa.array(rng.permutation(5000)[:4000] * 3, type=pa.int64()), "v": pa.array(np.arange(4000), type=pa.int32())})
     probe = random_table(rng, 50_001, {"k2": (pa.int64(), -10, 15100), "p": (pa.decimal128(15, 2), 0, 10**7)})
     exp = oracle.hash_join(build, probe, [("k", "k2")], "Inner")
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         for probe_mode in (1, 2):   # two-pass (lookup -> scan -> materialise) and fused single pass
             got = gpu_join(build, probe, [("k", "k2")], "Inner", table_mode=mode, probe_mode=probe_mode)
             assert_tables_equal(got, exp, ordered=True)
@@ -62,7 +62,7 @@ def test_unique_build_fast_path_preserves_probe_order():
 
 
 @pytest.mark.parametrize("np_rows", [1, 63, 1024, 1025, 70_000, 3_000_001])
-@pytest.mark.parametrize("table_mode", [0, 1])
+@pytest.mark.parametrize("table_mode", [0, 1, 2])
 def test_single_pass_probe_lookback_many_tiles(np_rows, table_mode):
     """single-pass probe: 1024-row tiles chained by decoupled look-back; 3 M rows = 2930 tiles, so
     look-back windows span > 64 predecessors; ragged tails; selectivity ~ 50 %; result in probe
@@ -126,11 +126,14 @@ def test_empty_sides():
 
 
 def test_array_map_gating_matches_reference_rules():
+    """try_create_array_map (exec.rs:111-191) with the reference's knob values.  The keys carry one
+    duplicate so that the GPU-native rank map (unique keys only) steps aside and the reference's
+    own choice between ArrayMap and JoinHashMap is what is observed."""
     from datafusion_amd import ops
     from datafusion_amd.table import DeviceTable
-    dense = DeviceTable.from_arrow(pa.table({"k": pa.array(range(0, 4000, 2), type=pa.int64())}))
-    sparse = DeviceTable.from_arrow(pa.table({"k": pa.array(range(0, 400000, 200), type=pa.int64())}))
-    small = DeviceTable.from_arrow(pa.table({"k": pa.array([5, 900], type=pa.int64())}))
+    dense = DeviceTable.from_arrow(pa.table({"k": pa.array(list(range(0, 4000, 2)) + [0], type=pa.int64())}))
+    sparse = DeviceTable.from_arrow(pa.table({"k": pa.array(list(range(0, 400000, 200)) + [0], type=pa.int64())}))
+    small = DeviceTable.from_arrow(pa.table({"k": pa.array([5, 900, 5], type=pa.int64())}))
     ref = dict(small_build_threshold=1024, min_key_density=0.15)   # the reference's defaults, config.rs:913,923
     assert ops.JoinHashTable(dense, ["k"], **ref).info().used_array_map == 1
     assert ops.JoinHashTable(sparse, ["k"], **ref).info().used_array_map == 0      # density 0.005
@@ -138,7 +141,48 @@ def test_array_map_gating_matches_reference_rules():
     assert ops.JoinHashTable(sparse, ["k"], min_key_density=0.001).info().used_array_map == 1
     assert ops.JoinHashTable(sparse, ["k"]).info().used_array_map == 0             # GPU default 1/64 still rejects 0.005
     neg = DeviceTable.from_arrow(pa.table({"k": pa.array([-(2**63), 2**63 - 1], type=pa.int64())}))
-    assert ops.JoinHashTable(neg, ["k"], **ref).info().used_array_map == 0  # full-range overflow guard, exec.rs:6907
+    assert ops.JoinHashTable(neg, ["k"], **ref).info().table_kind == 0  # full-range overflow guard, exec.rs:6907
+
+
+def test_rank_map_selection():
+    """GPU-native table for unique integer keys: bitmap + popcount directory; row id = rank when the
+    build keys are ascending, perm[rank] otherwise; duplicates fall back to the reference's tables"""
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.table import DeviceTable
+    asc = DeviceTable.from_arrow(pa.table({"k": pa.array(range(-50, 400000, 7), type=pa.int64())}))
+    i = ops.JoinHashTable(asc, ["k"]).info()
+    assert (i.table_kind, i.build_keys_ascending, i.build_keys_unique) == (2, 1, 1)
+    rng = np.random.default_rng(0)
+    shuffled = DeviceTable.from_arrow(pa.table({"k": pa.array(rng.permutation(100000) * 3, type=pa.int32())}))
+    i = ops.JoinHashTable(shuffled, ["k"]).info()
+    assert (i.table_kind, i.build_keys_ascending, i.build_keys_unique) == (2, 0, 1)
+    dups = DeviceTable.from_arrow(pa.table({"k": pa.array([1, 2, 3, 2], type=pa.int64())}))
+    i = ops.JoinHashTable(dups, ["k"]).info()
+    assert (i.table_kind, i.build_keys_unique) == (1, 0)
+    with pytest.raises(_lib.DfgpuError):
+        ops.JoinHashTable(dups, ["k"], table_mode=3)
+    very_sparse = DeviceTable.from_arrow(pa.table({"k": pa.array(range(0, 3_000_000, 1000), type=pa.int64())}))   # density 1/1000 < 1/256
+    assert ops.JoinHashTable(very_sparse, ["k"]).info().table_kind == 0
+    assert ops.JoinHashTable(asc, ["k"], table_mode=1).info().table_kind == 0
+    assert ops.JoinHashTable(asc, ["k"], table_mode=2).info().table_kind == 1
+
+
+@pytest.mark.parametrize("join_type", ALL_TYPES)
+@pytest.mark.parametrize("order", ["ascending", "shuffled", "with_nulls"])
+def test_unique_build_keys_all_table_kinds_agree(join_type, order):
+    """unique build keys: rank map (mode 3 / auto), ArrayMap (2) and hash map (1) give the oracle's rows for every JoinType"""
+    from oracle import oracle
+    rng = np.random.default_rng(21)
+    nb = 5000
+    keys = np.sort(rng.permutation(3 * nb)[:nb]).astype(np.int64) - 700
+    if order != "ascending":
+        keys = rng.permutation(keys)
+    mask = (rng.random(nb) < 0.05) if order == "with_nulls" else None
+    left = pa.table({"a": pa.array(keys, type=pa.int64(), mask=mask), "x": pa.array(np.arange(nb), type=pa.int32())})
+    right = random_table(rng, 20_000, {"b": (pa.int64(), -900, 3 * nb), "z": (pa.float64(), 0, 1000)}, null_frac=0.05)
+    exp = oracle.hash_join(left, right, [("a", "b")], join_type)
+    for mode in (0, 1, 2, 3):
+        assert_tables_equal(gpu_join(left, right, [("a", "b")], join_type, table_mode=mode), exp)
 
 
 def test_tpch_join_shape_small_sf():

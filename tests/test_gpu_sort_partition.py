@@ -88,22 +88,32 @@ def test_partition_then_join_equals_global_join():
     assert_tables_equal(pa.concat_tables(outs), oracle.hash_join(l, r, [("a", "b")], "Inner"))
 
 
+_RCCL_WORKER = r"""
+import os, sys
+import numpy as np, pyarrow as pa, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["DFGPU_ROOT"])
+from datafusion_amd.exchange import hash_exchange
+from datafusion_amd.table import DeviceTable
+from tests.util import assert_tables_equal, random_table
+t = random_table(np.random.default_rng(2), 100_000, {"k": (pa.int64(), 0, 10**6), "d": (pa.decimal128(15, 2), 0, 10**6), "q": (pa.int32(), 0, 9)})
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+out = hash_exchange(DeviceTable.from_arrow(t), ["k"], force=True)
+assert_tables_equal(out.to_arrow(), t, ordered=True)
+print("EXCHANGE_OK", flush=True)
+os._exit(0)   # RCCL teardown in a one-rank group has aborted on some boxes; the result is already checked
+"""
+
+
 def test_exchange_plumbing_single_rank_rccl():
     """one-rank RCCL group on the GPU box: partition -> zero-copy torch views of library HBM ->
-    all_to_all_single -> received table; with world=1 the result must equal the input"""
+    all_to_all_single -> received table; with world=1 the result must equal the input.  Runs in a
+    child process so that RCCL state (and its teardown) cannot touch the rest of the session."""
     import os
-    import torch
-    import torch.distributed as dist
-    from datafusion_amd import ops
-    from datafusion_amd.exchange import hash_exchange
-    from datafusion_amd.table import DeviceTable
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    t = random_table(np.random.default_rng(2), 100_000, {"k": (pa.int64(), 0, 10**6), "d": (pa.decimal128(15, 2), 0, 10**6), "q": (pa.int32(), 0, 9)})
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1)
-    try:
-        out = hash_exchange(DeviceTable.from_arrow(t), ["k"], force=True)
-        assert_tables_equal(out.to_arrow(), t, ordered=True)
-    finally:
-        dist.destroy_process_group()
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", DFGPU_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORKER], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert "EXCHANGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
