@@ -29,6 +29,26 @@ __device__ __forceinline__ T wave_inclusive_sum(T v) {
   }
   return v;
 }
+// ---- DPP (data-parallel primitive) lane movement: VALU-only, no LDS crossbar traffic (ds_bpermute)
+// ctrl: 0x110+n = row_shr:n (within a row of 16 lanes), 0x142 = row_bcast15, 0x143 = row_bcast31
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_move_u64(uint64_t v) {  // lanes without a source (or in a masked-off row) read 0
+  unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xF, true);
+  unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xF, true);
+  return ((uint64_t)hi << 32) | lo;
+}
+// inclusive wave prefix sum (mod 2^64) in 6 DPP steps: Hillis-Steele inside each 16-lane row, then
+// row 0's total into row 1 and row 2's into row 3 (row_bcast15), then lanes 0-31's total into rows 2-3
+__device__ __forceinline__ uint64_t wave_inclusive_sum_dpp(uint64_t v) {
+  v += dpp_move_u64<0x111, 0xF>(v);
+  v += dpp_move_u64<0x112, 0xF>(v);
+  v += dpp_move_u64<0x114, 0xF>(v);
+  v += dpp_move_u64<0x118, 0xF>(v);
+  v += dpp_move_u64<0x142, 0xA>(v);
+  v += dpp_move_u64<0x143, 0xC>(v);
+  return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
