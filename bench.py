@@ -176,6 +176,15 @@ def main():
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
+        if roof:  # HBM bytes per launch from the committed PMC passes (scripts/profile.sh), when taken on this very workload
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                wl = tr["workload"]
+                if tr["kernel"] == dom_name and (wl["build_rows"], wl["probe_rows"], wl["output_rows"]) == (nb, np_, nout) and world == 1:
+                    roof["traffic"] = tr["traffic_bytes_per_launch"]
+                    roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr["source"]
+            except (OSError, KeyError, ValueError):
+                pass
         kernels = {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in stats.items()}
         line = {
             "metric": "tpch_q3_hash_join_rows_per_sec", "value": rows_per_s, "unit": "rows/s", "n_gpus": world,

@@ -7,7 +7,9 @@ Kernel durations come from `rocprofv3 --kernel-trace --stats`; HBM traffic from 
 `--pmc` passes (FETCH_SIZE, WRITE_SIZE; TCC has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2 —
 MI355X_MICROARCH.md §rocprofv3 PMC slots).  gfx950 correction (same guide, §HBM): FETCH_SIZE
 reports 1/2 of the bytes of a coalesced streaming read, so read bytes = FETCH_SIZE*1024*2;
-this is calibrated inside the same run on k_key_minmax, which reads exactly 8 B x build rows.
+this is calibrated inside the same run on k_rank_setbits, which reads exactly 8 B x build rows.
+Also refreshes profiles/traffic.json (per-launch PMC traffic of the dominant kernel), which bench.py
+attaches to its roofline object when the workload matches.
 """
 import json
 import os
@@ -41,9 +43,11 @@ def main():
                 "select kernel_name, avg(value) from counters_collection group by 1")}
     fetch, write = pmc("pmc_fetch"), pmc("pmc_write")
     nb = bench["config"]["build_rows"] if bench else None
+    # calibration kernel: k_rank_setbits (ascending variant) reads exactly the 8-byte build keys, nothing else
     calib = None
-    if nb and "k_key_minmax" in fetch:
-        calib = nb * 8 / (fetch["k_key_minmax"] * 1024)
+    cal_k = next((k for k in fetch if k.startswith("k_rank_setbits")), None) or next((k for k in fetch if k.startswith("k_key_minmax")), None)
+    if nb and cal_k:
+        calib = nb * 8 / (fetch[cal_k] * 1024)
     rows = []
     for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_us"]):
         f, w = fetch.get(k), write.get(k)
@@ -60,12 +64,20 @@ def main():
         if bench:
             f.write("bench line: `" + json.dumps({k: bench[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step")}) + "`\n\n")
             f.write("roofline: `" + json.dumps(bench.get("roofline")) + "`\n\n")
-        f.write(f"FETCH_SIZE calibration (bytes k_key_minmax must read / FETCH_SIZE*1024): {calib}\n\n")
+        f.write(f"FETCH_SIZE calibration (bytes {cal_k} must read / FETCH_SIZE*1024): {calib}\n\n")
         f.write("| kernel | calls | avg µs | % | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | HBM traffic GB/launch (read x2 corrected) | GB/s |\n|---|---:|---:|---:|---:|---:|---:|---:|\n")
         for r in rows:
             fmt = lambda x, d=1: "" if x is None else f"{x:.{d}f}"
             f.write(f"| {r['kernel']} | {r['calls']} | {r['avg_us']:.1f} | {r['pct']:.1f} | {fmt(r['FETCH_SIZE_KB'],0)} | {fmt(r['WRITE_SIZE_KB'],0)} | "
                     f"{fmt(r['traffic_bytes']/1e9 if r['traffic_bytes'] else None,2)} | {fmt(r['traffic_GBps'],0)} |\n")
+    dom = next((r for r in rows if r["kernel"].startswith("k_join_probe_fused")), None)
+    if dom and dom["traffic_bytes"] and bench:
+        tj = os.path.join(os.path.dirname(dst) or ".", "traffic.json")
+        json.dump({"kernel": "join_probe_fused", "device_kernel": dom["kernel"], "traffic_bytes_per_launch": int(dom["traffic_bytes"]),
+                   "read_bytes_corrected": int(dom["read_bytes_corrected"] or 0), "write_bytes": int(dom["write_bytes"] or 0),
+                   "fetch_size_calibration": calib, "avg_launch_us_rocprof": dom["avg_us"], "source": os.path.basename(dst) + ".json",
+                   "workload": {k: bench["config"][k] for k in ("build_rows", "probe_rows", "output_rows", "join_table", "probe")}},
+                  open(tj, "w"), indent=1)
     print(open(dst + ".md").read())
 
 
