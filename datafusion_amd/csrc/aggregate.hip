@@ -24,8 +24,11 @@
 //   emit     : group key columns (gather of representative rows) + state or final columns;
 //              AVG(Decimal128) = (sum * 10^(ts-ss)) / count truncating (DecimalAverager::avg,
 //              functions-aggregate-common/src/utils.rs:157-176).
+#include <algorithm>
+
 #include "device.hpp"
 #include "internal.hpp"
+#include "rowprog_host.hpp"
 
 namespace dfgpu {
 
@@ -125,9 +128,12 @@ __device__ __forceinline__ uint64_t group_hash(const KeySet& ks, int64_t i) {
 
 // GroupValues::intern, claim phase: every row finds or claims the slot of its key; the slot ends
 // up holding the smallest row id of the key (first-seen representative).
-__global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, int* overflow) {
+// `row_mask` (optional): bit r covers concatenated row mask_offset + r; rows below mask_offset (the existing
+// groups) are always interned.
+__global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, int* overflow, const uint64_t* __restrict__ row_mask, int64_t mask_offset) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (row_mask && i >= mask_offset && !bit_at(row_mask, i - mask_offset)) continue;
     uint64_t s = group_hash(c.keys, i) & c.mask;
     const uint32_t me = (uint32_t)i + 1u;
     uint32_t steps = 0;
@@ -304,6 +310,8 @@ struct Aggregate {
   Table group_keys;  // dense, gid order
   int64_t ngroups = 0;
   int64_t capacity_hint = 1 << 16;
+  std::vector<uint16_t> small_keys;  // small-domain interning: host mirror of the group keys (byte g of key i = column g)
+  int64_t fused_updates = 0;         // updates that took the fused (rowprog) path
   bool final_mode() const { return mode == DFGPU_AGG_FINAL || mode == DFGPU_AGG_FINAL_PARTITIONED; }
   bool partial_out() const { return mode == DFGPU_AGG_PARTIAL; }
 };
@@ -393,7 +401,480 @@ static AccPlan plan_for(int func, const dfgpu_field& t, bool merging_counts) {
   throw Error("aggregate over " + type_name(t) + " is not supported on the GPU path");
 }
 
-static void agg_update(Aggregate& A, const Table& in) {
+// ------------------------------------------------------------------ fused update (rowprog)
+// FilterExec predicate + ProjectionExec expressions + aggregate arguments evaluated per row in
+// registers (rowprog.hpp), then accumulated — one pass over the referenced input columns.
+struct FusedAcc {
+  unsigned long long* acc_lo;
+  unsigned long long* acc_hi;
+  uint32_t* seen;
+  int16_t kind;  // AccKind
+  int16_t reg;   // value register, -1 = none (COUNT(*))
+};
+struct FusedAccSet {
+  FusedAcc a[MAX_AGGS];
+  int n;
+};
+enum GidMode : int { GID_NONE = 0, GID_SMALL = 1, GID_HASH = 2 };
+constexpr int SMALL_DOMAIN = 1 << 16;  // up to two 1-byte group keys address a gid table directly
+struct GidSpec {
+  int mode;
+  int key_reg0, key_reg1;     // GID_SMALL: registers holding the key bytes (key_reg1 = -1: one key)
+  const uint32_t* gid_table;  // GID_SMALL: [SMALL_DOMAIN] key bytes -> dense group id
+  InternCtx ictx;             // GID_HASH
+  const uint32_t* slot_gid;
+  int64_t row_offset;         // GID_HASH: index of input row 0 in the concatenated key columns
+};
+
+__device__ __forceinline__ uint32_t small_key(const RpRegs& r, int k0, int k1) {
+  uint32_t k = r.w0[k0] & 0xFFu;
+  if (k1 >= 0) k |= (r.w0[k1] & 0xFFu) << 8;
+  return k;
+}
+
+// GroupValues::intern for 1-byte keys: first[key] = smallest passing row holding that key.  A wave
+// elects one lane per distinct key (its lowest lane = its smallest row), and a cached read of the
+// current minimum filters almost every atomic once the first rows have been seen.
+template <int NREG>
+__global__ __launch_bounds__(BLOCK) void k_small_first_rows(RowProgram p, int n_prologue, int n_pred_end, int pred_reg, int key_reg0, int key_reg1,
+                                                           int64_t n, uint32_t* __restrict__ first) {
+  RP_DECLARE_REGS(r, NREG);
+  rp_exec(p, 0, n_prologue, r);
+  const int64_t n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
+    bool active = i < n;
+    if (active) {
+      rp_load_row(p, i, r);
+      rp_exec(p, n_prologue, n_pred_end, r);
+      if (pred_reg >= 0) active = rp_true(r, pred_reg);
+      if (active) rp_exec(p, n_pred_end, p.n_ins, r);
+    }
+    const uint32_t key = active ? small_key(r, key_reg0, key_reg1) : 0u;
+    uint64_t todo = ballot64(active);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
+      const uint64_t same = ballot64(active && key == k);
+      if ((int)lane_id() == leader) {
+        const uint32_t row = (uint32_t)i;
+        if (row < __hip_atomic_load(&first[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&first[k], row);
+      }
+      todo &= ~same;
+    }
+  }
+}
+
+template <bool USE_LDS, int NREG>
+__global__ __launch_bounds__(BLOCK) void k_agg_fused(RowProgram p, int n_prologue, int n_pred_end, int pred_reg, GidSpec g, FusedAccSet accs, int64_t n,
+                                                    int ngroups, int nrep) {
+  __shared__ unsigned long long s_lo[USE_LDS ? LDS_CELLS : 1];
+  __shared__ unsigned long long s_hi[USE_LDS ? LDS_CELLS : 1];
+  __shared__ uint32_t s_seen[USE_LDS ? LDS_CELLS : 1];
+  // LDS cell of (aggregate k, group gid, replica rep) = (k * ngroups + gid) * nrep + rep: the replicas of one
+  // accumulator are adjacent, so the lanes of a wave (rep = lane % nrep) spread over the LDS banks
+  const int cells = accs.n * ngroups * nrep;
+  if (USE_LDS) {
+    for (int x = threadIdx.x; x < cells; x += BLOCK) {
+      int k = x / (ngroups * nrep);
+      s_lo[x] = acc_identity(accs.a[k].kind);
+      s_hi[x] = 0ull;
+      s_seen[x] = 0u;
+    }
+    __syncthreads();
+  }
+  const int rep = (int)(threadIdx.x & (unsigned)(nrep - 1));
+  RP_DECLARE_REGS(r, NREG);
+  rp_exec(p, 0, n_prologue, r);
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    rp_load_row(p, i, r);
+    if (pred_reg >= 0) {
+      rp_exec(p, n_prologue, n_pred_end, r);
+      if (!rp_true(r, pred_reg)) continue;
+    }
+    rp_exec(p, n_pred_end, p.n_ins, r);
+    uint32_t gid = 0;
+    if (g.mode == GID_SMALL) gid = g.gid_table[small_key(r, g.key_reg0, g.key_reg1)];
+    else if (g.mode == GID_HASH) gid = lookup_gid(g.ictx, g.slot_gid, g.row_offset + i);
+    for (int k = 0; k < accs.n; k++) {
+      const FusedAcc& d = accs.a[k];
+      uint64_t lo = 0, hi = 0;
+      if (d.reg >= 0) {
+        if (rp_is_null(r, d.reg)) continue;
+        lo = r.lo(d.reg);
+        hi = r.hi(d.reg);
+      }
+      if (USE_LDS) {
+        const int cell = (k * ngroups + (int)gid) * nrep + rep;
+        accumulate_cell(d.kind, &s_lo[cell], &s_hi[cell], lo, hi);
+        s_seen[cell] = 1u;
+      } else {
+        accumulate_cell(d.kind, d.acc_lo + gid, d.acc_hi ? d.acc_hi + gid : nullptr, lo, hi);
+        if (d.seen) d.seen[gid] = 1u;
+      }
+    }
+  }
+  if (USE_LDS) {
+    __syncthreads();
+    // fold the replicas of each (aggregate, group) cell, one thread per cell, then one global update
+    const int per = accs.n * ngroups;
+    for (int x = threadIdx.x; x < per; x += BLOCK) {
+      const int k = x / ngroups, gid = x % ngroups;
+      const FusedAcc& d = accs.a[k];
+      int kind = d.kind;
+      bool any = false;
+      unsigned long long lo = acc_identity(kind), hi = 0ull;
+      for (int q = 0; q < nrep; q++) {
+        const int cell = x * nrep + q;
+        if (!s_seen[cell]) continue;
+        any = true;
+        const unsigned long long vlo = s_lo[cell], vhi = s_hi[cell];
+        switch (kind) {
+          case ACC_SUM_I128: { unsigned long long o = lo; lo += vlo; hi += vhi + (lo < o ? 1ull : 0ull); break; }
+          case ACC_SUM_F64: lo = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)lo) + __longlong_as_double((long long)vlo)); break;
+          case ACC_MIN_I64: lo = (unsigned long long)min((long long)lo, (long long)vlo); break;
+          case ACC_MAX_I64: lo = (unsigned long long)max((long long)lo, (long long)vlo); break;
+          default: lo += vlo; break;  // SUM_I64 / COUNT / COUNT(*)
+        }
+      }
+      if (!any) continue;
+      if (kind == ACC_COUNT || kind == ACC_COUNT_STAR) kind = ACC_SUM_I64;  // merge counts by adding
+      accumulate_cell(kind, d.acc_lo + gid, d.acc_hi ? d.acc_hi + gid : nullptr, lo, hi);
+      if (d.seen) d.seen[gid] = 1u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_and_words(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, int64_t nw, uint64_t* __restrict__ out) {
+  for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < nw; w += (int64_t)gridDim.x * BLOCK) out[w] = a[w] & b[w];
+}
+static void and_bitmaps(const uint64_t* a, const uint64_t* b, int64_t nw, uint64_t* out) {
+  if (nw) k_and_words<<<grid_for(nw, BLOCK), BLOCK, 0, rt().stream>>>(a, b, nw, out);
+}
+
+static bool g_fusion_enabled = true;
+void set_fusion_enabled(bool on) { g_fusion_enabled = on; }
+bool fusion_enabled() { return g_fusion_enabled; }
+
+// ------------------------------------------------------------------------------ host
+// GroupValues::intern over materialised key columns (hash table of representative rows)
+struct InternResult {
+  InternCtx ictx{};
+  BufPtr slots, slot_gid;
+  std::vector<Column> cat_keys;  // [existing group keys ; input keys] — referenced by ictx
+  int64_t G1 = 0;
+};
+static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_cols, int64_t n, const uint64_t* row_mask) {
+  Runtime& r = rt();
+  InternResult R;
+  const int ngk = (int)key_cols.size();
+  const int64_t G0 = A.ngroups;
+  const int64_t total = G0 + n;
+  DFGPU_CHECK(total < 0xFFFFFFFFll, "aggregate input exceeds u32 row ids");
+  for (int g = 0; g < ngk; g++) {
+    if (G0 == 0) {
+      R.cat_keys.push_back(key_cols[g]);
+    } else {
+      const Column& gk = A.group_keys.cols[g];
+      const Column& ik = key_cols[g];
+      DFGPU_CHECK(gk.field.type == ik.field.type, "group key type changed between batches");
+      Column cc = alloc_column(gk.field, gk.name, total, gk.validity || ik.validity);
+      int w = type_width(gk.field.type);
+      DFGPU_HIP(hipMemcpyAsync(cc.data->ptr, gk.ptr(), (size_t)G0 * w, hipMemcpyDeviceToDevice, r.stream));
+      if (n) DFGPU_HIP(hipMemcpyAsync((char*)cc.data->ptr + (size_t)G0 * w, ik.ptr(), (size_t)n * w, hipMemcpyDeviceToDevice, r.stream));
+      DFGPU_CHECK(!cc.validity, "incremental aggregation over nullable group keys is not supported on the GPU path yet");
+      R.cat_keys.push_back(std::move(cc));
+    }
+  }
+  InternCtx& ictx = R.ictx;
+  ictx.keys.n = ngk;
+  DFGPU_CHECK(ngk <= MAX_KEYS, "too many group-by columns");
+  for (int g = 0; g < ngk; g++) {
+    DFGPU_CHECK(R.cat_keys[g].field.type != DFGPU_BOOL, "Boolean group keys are not supported on the GPU path");
+    ictx.keys.c[g] = KeyCol{R.cat_keys[g].ptr(), R.cat_keys[g].valid_words(), R.cat_keys[g].field.type, type_width(R.cat_keys[g].field.type)};
+  }
+  int64_t key_bytes = 0;
+  for (int g = 0; g < ngk; g++) key_bytes += total * type_width(R.cat_keys[g].field.type);
+  BufPtr flag = make_zero_buf(4);
+  uint64_t cap = (uint64_t)A.capacity_hint;
+  const uint64_t cap_max = [&] { uint64_t c = 64; while (c < (uint64_t)total * 2) c <<= 1; return c; }();
+  if (cap > cap_max) cap = cap_max;
+  for (;;) {
+    R.slots = make_zero_buf(cap * 4);
+    ictx.slots = R.slots->as<uint32_t>();
+    ictx.mask = cap - 1;
+    if (total) {
+      ProfileScope ps("agg_intern_claim", key_bytes);
+      k_intern_claim<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx, total, flag->as<int>(), row_mask, G0);
+      DFGPU_HIP(hipGetLastError());
+    }
+    int ovf = 0;
+    d2h(&ovf, flag->ptr, 4);
+    if (!ovf) break;
+    DFGPU_CHECK(cap < cap_max, "group table overflow at maximum capacity");
+    cap = std::min<uint64_t>(cap_max, cap * 16);
+    DFGPU_HIP(hipMemsetAsync(flag->ptr, 0, 4, r.stream));
+  }
+  A.capacity_hint = (int64_t)cap;
+  const int64_t n_words = (total + 63) / 64;
+  BufPtr rep_mask = make_zero_buf((size_t)(n_words ? n_words : 1) * 8);
+  BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
+  k_mark_reps<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(R.slots->as<uint32_t>(), cap, rep_mask->as<unsigned long long>());
+  scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, total, prefix->as<uint64_t>());
+  R.G1 = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+  R.slot_gid = make_buf(cap * 4);
+  BufPtr rep_row = make_buf((size_t)(R.G1 ? R.G1 : 1) * 8);
+  k_slot_gids<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(R.slots->as<uint32_t>(), cap, rep_mask->as<uint64_t>(), prefix->as<uint64_t>(),
+                                                                      R.slot_gid->as<uint32_t>(), rep_row->as<int64_t>());
+  DFGPU_HIP(hipGetLastError());
+  // new dense group key columns = representative rows (first-seen order)
+  Table gk;
+  gk.nrows = R.G1;
+  for (int g = 0; g < ngk; g++) gk.cols.push_back(gather_column(R.cat_keys[g], rep_row->as<int64_t>(), R.G1, false));
+  A.group_keys = std::move(gk);
+  return R;
+}
+
+// grow every accumulator to G1 groups; returns the accumulation plan per aggregate
+static std::vector<AccPlan> grow_accumulators(Aggregate& A, int64_t G0, int64_t G1) {
+  std::vector<AccPlan> plans;
+  const bool final_mode = A.final_mode();
+  for (AggState& a : A.aggs) {
+    AccPlan p = plan_for(a.func, a.in_type, final_mode);
+    a.lo = grown(a.lo, G0, G1, acc_identity(p.kind));
+    if (p.needs_hi) a.hi = grown(a.hi, G0, G1, 0ull);
+    a.seen = grown(a.seen, G0, G1, 0, 4);
+    if (a.func == DFGPU_AGG_AVG) a.cnt = grown(a.cnt, G0, G1, 0ull);
+    plans.push_back(p);
+  }
+  return plans;
+}
+
+static bool is_plain_column(const std::vector<dfgpu_expr_node>& nodes, int root, int* col) {
+  if (root < 0 || root >= (int)nodes.size() || nodes[root].op != DFGPU_EXPR_COLUMN) return false;
+  *col = nodes[root].column;
+  return true;
+}
+
+// Small-domain interning (every group key is a non-null 1-byte column): returns false when not applicable.
+static bool small_domain_applicable(const Aggregate& A, const Table& in, std::vector<int>& key_cols) {
+  const int ngk = (int)A.group_roots.size();
+  if (ngk < 1 || ngk > 2) return false;
+  key_cols.clear();
+  for (int g = 0; g < ngk; g++) {
+    int c = -1;
+    if (!is_plain_column(A.group_nodes[g], A.group_roots[g], &c)) return false;
+    if (c < 0 || c >= (int)in.cols.size()) return false;
+    if (in.cols[c].field.type != DFGPU_UINT8 || in.cols[c].validity) return false;
+    key_cols.push_back(c);
+  }
+  if (A.ngroups > 0) {
+    for (int g = 0; g < ngk; g++)
+      if (A.group_keys.cols[g].field.type != DFGPU_UINT8 || A.group_keys.cols[g].validity) return false;
+  }
+  return true;
+}
+
+// Returns false (nothing changed) when the forest cannot be fused; the caller then takes the
+// column-at-a-time path.
+static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pred, std::string& why) {
+  Runtime& r = rt();
+  const int64_t n = in.nrows;
+  const int ngk = (int)A.group_roots.size();
+  if (A.final_mode() || n == 0 || !g_fusion_enabled) {
+    why = "not a raw-input update";
+    return false;
+  }
+  std::vector<int> small_cols;
+  const bool small = small_domain_applicable(A, in, small_cols);
+  const int gid_mode = ngk == 0 ? GID_NONE : small ? GID_SMALL : GID_HASH;
+
+  // ---- compile: predicate, (small mode) key bytes, aggregate arguments
+  RowProgramCompiler comp(in);
+  if (pred) comp.set_predicate(*pred);
+  int key_out[2] = {-1, -1};
+  if (gid_mode == GID_SMALL)
+    for (int g = 0; g < ngk; g++) {
+      dfgpu_expr e{A.group_nodes[g].data(), (int)A.group_nodes[g].size(), A.group_roots[g]};
+      key_out[g] = comp.add_output(e);
+    }
+  std::vector<int> arg_out(A.aggs.size(), -1);
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    if (!a.has_arg) continue;
+    dfgpu_expr e{a.nodes.data(), (int)a.nodes.size(), a.root};
+    arg_out[k] = comp.add_output(e);
+    dfgpu_field t = comp.output_type(arg_out[k]);
+    if (a.typed) DFGPU_CHECK(a.in_type.type == t.type, "aggregate argument type changed between batches");
+    // conversions the accumulator expects (plan_for): AVG over ints sums f64; MIN/MAX(f64) on the ordered key
+    AccPlan p = plan_for(a.func, t, false);
+    if (p.val == VAL_I32_TO_F64 || p.val == VAL_I64_TO_F64) comp.convert_output(arg_out[k], RP_I2F, t);
+    else if (p.val == VAL_F64_ORDERED) comp.convert_output(arg_out[k], RP_F64ORD, t);
+  }
+  CompiledProgram cp;
+  if (!comp.finish(cp, why)) return false;
+
+  // key-only program for the small-domain intern pass (touches the predicate and key columns only)
+  CompiledProgram kp;
+  if (gid_mode == GID_SMALL) {
+    RowProgramCompiler kc(in);
+    if (pred) kc.set_predicate(*pred);
+    for (int g = 0; g < ngk; g++) {
+      dfgpu_expr e{A.group_nodes[g].data(), (int)A.group_nodes[g].size(), A.group_roots[g]};
+      kc.add_output(e);
+    }
+    if (!kc.finish(kp, why)) return false;
+  }
+
+  // ---- from here on state is modified
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    if (!a.typed) {
+      a.in_type = a.has_arg ? cp.out_types[arg_out[k]] : fld(DFGPU_INT64);
+      a.typed = true;
+    }
+  }
+  const int64_t G0 = A.ngroups;
+  int64_t G1 = G0;
+  GidSpec gs{};
+  gs.mode = gid_mode;
+  gs.key_reg0 = gs.key_reg1 = -1;
+  InternResult IR;
+  BufPtr gid_table, pred_mask_keepalive;
+  std::vector<Column> key_cols_keepalive;
+  if (gid_mode == GID_NONE) {
+    G1 = 1;
+  } else if (gid_mode == GID_SMALL) {
+    // host mirror of the existing groups' keys
+    if ((int64_t)A.small_keys.size() != G0) {
+      A.small_keys.assign((size_t)G0, 0);
+      for (int g = 0; g < ngk && G0; g++) {
+        std::vector<uint8_t> b((size_t)G0);
+        d2h(b.data(), A.group_keys.cols[g].ptr(), (size_t)G0);
+        for (int64_t i = 0; i < G0; i++) A.small_keys[(size_t)i] |= (uint16_t)(b[(size_t)i] << (8 * g));
+      }
+    }
+    BufPtr first = make_buf((size_t)SMALL_DOMAIN * 4);
+    DFGPU_HIP(hipMemsetAsync(first->ptr, 0xFF, (size_t)SMALL_DOMAIN * 4, r.stream));
+    {
+      ProfileScope ps("agg_small_domain_intern", n * kp.input_bytes_per_row);
+      auto kern = kp.n_regs <= 16 ? k_small_first_rows<16> : k_small_first_rows<32>;
+      kern<<<grid_for(n, BLOCK * 8), BLOCK, 0, r.stream>>>(kp.prog, kp.n_prologue, kp.n_pred_end, kp.pred_reg, kp.out_regs[0],
+                                                           ngk > 1 ? kp.out_regs[1] : -1, n, first->as<uint32_t>());
+      DFGPU_HIP(hipGetLastError());
+    }
+    std::vector<uint32_t> hfirst((size_t)SMALL_DOMAIN);
+    d2h(hfirst.data(), first->ptr, (size_t)SMALL_DOMAIN * 4);
+    std::vector<uint32_t> table((size_t)SMALL_DOMAIN, 0u);
+    std::vector<bool> known((size_t)SMALL_DOMAIN, false);
+    for (int64_t gidx = 0; gidx < G0; gidx++) {
+      table[A.small_keys[(size_t)gidx]] = (uint32_t)gidx;
+      known[A.small_keys[(size_t)gidx]] = true;
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> fresh;  // (first row, key)
+    for (uint32_t k = 0; k < (uint32_t)SMALL_DOMAIN; k++)
+      if (hfirst[k] != 0xFFFFFFFFu && !known[k]) fresh.push_back({hfirst[k], k});
+    std::sort(fresh.begin(), fresh.end());  // first-seen order (group_values/mod.rs:88-92)
+    for (auto& fk : fresh) {
+      table[fk.second] = (uint32_t)A.small_keys.size();
+      A.small_keys.push_back((uint16_t)fk.second);
+    }
+    G1 = (int64_t)A.small_keys.size();
+    gid_table = make_buf((size_t)SMALL_DOMAIN * 4);
+    h2d_async(gid_table->ptr, table.data(), (size_t)SMALL_DOMAIN * 4);
+    // dense group key columns rebuilt from the host mirror
+    Table gk;
+    gk.nrows = G1;
+    for (int g = 0; g < ngk; g++) {
+      Column c = alloc_column(in.cols[small_cols[g]].field, A.group_names[g], G1);
+      std::vector<uint8_t> b((size_t)(G1 ? G1 : 1));
+      for (int64_t i = 0; i < G1; i++) b[(size_t)i] = (uint8_t)(A.small_keys[(size_t)i] >> (8 * g));
+      if (G1) h2d_async(c.data->ptr, b.data(), (size_t)G1);
+      DFGPU_HIP(hipStreamSynchronize(r.stream));  // b and table are host temporaries
+      gk.cols.push_back(std::move(c));
+    }
+    A.group_keys = std::move(gk);
+    gs.key_reg0 = cp.out_regs[key_out[0]];
+    gs.key_reg1 = ngk > 1 ? cp.out_regs[key_out[1]] : -1;
+    gs.gid_table = gid_table->as<uint32_t>();
+  } else {
+    // hash interning needs the key columns in memory: plain column references are used in place
+    for (int g = 0; g < ngk; g++) {
+      int c = -1;
+      if (is_plain_column(A.group_nodes[g], A.group_roots[g], &c)) {
+        DFGPU_CHECK(c >= 0 && c < (int)in.cols.size(), "Column index out of range");
+        key_cols_keepalive.push_back(in.cols[c]);
+      } else {
+        dfgpu_expr e{A.group_nodes[g].data(), (int)A.group_nodes[g].size(), A.group_roots[g]};
+        key_cols_keepalive.push_back(datum_to_column(evaluate(e, in), n, A.group_names[g]));
+      }
+      key_cols_keepalive.back().name = A.group_names[g];
+    }
+    const uint64_t* row_mask = nullptr;
+    Column mask_col;
+    if (pred) {
+      // rows failing the predicate must not create groups: intern under the predicate's mask
+      mask_col = datum_to_column(evaluate(*pred, in), n, "");
+      DFGPU_CHECK(mask_col.field.type == DFGPU_BOOL, "Cannot create filter with non-boolean predicate");
+      if (mask_col.validity) {
+        BufPtr m = make_buf(bitmap_bytes(n));
+        int64_t nw = (n + 63) / 64;
+        and_bitmaps(mask_col.data->as<uint64_t>(), mask_col.valid_words(), nw, m->as<uint64_t>());
+        pred_mask_keepalive = m;
+      } else {
+        pred_mask_keepalive = mask_col.data;
+      }
+      row_mask = pred_mask_keepalive->as<uint64_t>();
+    }
+    IR = intern_keys(A, key_cols_keepalive, n, row_mask);
+    G1 = IR.G1;
+    gs.ictx = IR.ictx;
+    gs.slot_gid = IR.slot_gid->as<uint32_t>();
+    gs.row_offset = G0;
+  }
+
+  // ---- accumulators
+  std::vector<AccPlan> plans = grow_accumulators(A, G0, G1);
+  FusedAccSet accs{};
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    FusedAcc d{};
+    d.kind = (int16_t)((a.func == DFGPU_AGG_COUNT && !a.has_arg) ? ACC_COUNT_STAR : plans[k].kind);
+    d.reg = (int16_t)(a.has_arg ? cp.out_regs[arg_out[k]] : -1);
+    d.acc_lo = a.lo->as<unsigned long long>();
+    d.acc_hi = a.hi ? a.hi->as<unsigned long long>() : nullptr;
+    d.seen = a.seen->as<uint32_t>();
+    DFGPU_CHECK(accs.n < MAX_AGGS, "too many aggregates for one GPU aggregate node");
+    accs.a[accs.n++] = d;
+    if (a.func == DFGPU_AGG_AVG) {
+      FusedAcc c{};
+      c.kind = ACC_COUNT;  // counts the non-null arguments
+      c.reg = d.reg;
+      c.acc_lo = a.cnt->as<unsigned long long>();
+      DFGPU_CHECK(accs.n < MAX_AGGS, "too many aggregates for one GPU aggregate node");
+      accs.a[accs.n++] = c;
+    }
+  }
+  if (accs.n > 0) {
+    const int64_t bytes = n * cp.input_bytes_per_row;
+    if (G1 * accs.n <= LDS_CELLS) {
+      int nrep = 1;
+      while (nrep * 2 <= 32 && (int64_t)nrep * 2 * G1 * accs.n <= LDS_CELLS) nrep *= 2;
+      ProfileScope ps("agg_fused_lds", bytes);
+      auto kern = cp.n_regs <= 16 ? k_agg_fused<true, 16> : k_agg_fused<true, 32>;
+      kern<<<grid_for(n, BLOCK * 8), BLOCK, 0, r.stream>>>(cp.prog, cp.n_prologue, cp.n_pred_end, cp.pred_reg, gs, accs, n, (int)G1, nrep);
+    } else {
+      ProfileScope ps("agg_fused_global", bytes);
+      auto kern = cp.n_regs <= 16 ? k_agg_fused<false, 16> : k_agg_fused<false, 32>;
+      kern<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(cp.prog, cp.n_prologue, cp.n_pred_end, cp.pred_reg, gs, accs, n, (int)std::min<int64_t>(G1, INT32_MAX), 1);
+    }
+    DFGPU_HIP(hipGetLastError());
+  }
+  A.ngroups = G1;
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // temporaries are released on return
+  return true;
+}
+
+static void agg_update_unfused(Aggregate& A, const Table& in) {
   Runtime& r = rt();
   const int64_t n = in.nrows;
   const int ngk = (int)A.group_roots.size();
@@ -442,85 +923,21 @@ static void agg_update(Aggregate& A, const Table& in) {
   // ---- intern (GroupValues::intern)
   const int64_t G0 = A.ngroups;
   int64_t G1 = G0;
-  InternCtx ictx{};
-  BufPtr slots, slot_gid;
-  std::vector<Column> cat_keys;  // [existing group keys ; input keys]
+  InternResult IR;
   if (ngk > 0) {
-    const int64_t total = G0 + n;
-    DFGPU_CHECK(total < 0xFFFFFFFFll, "aggregate input exceeds u32 row ids");
-    for (int g = 0; g < ngk; g++) {
-      if (G0 == 0) {
-        cat_keys.push_back(key_cols[g]);
-      } else {
-        const Column& gk = A.group_keys.cols[g];
-        const Column& ik = key_cols[g];
-        DFGPU_CHECK(gk.field.type == ik.field.type, "group key type changed between batches");
-        Column cc = alloc_column(gk.field, gk.name, total, gk.validity || ik.validity);
-        int w = type_width(gk.field.type);
-        DFGPU_HIP(hipMemcpyAsync(cc.data->ptr, gk.ptr(), (size_t)G0 * w, hipMemcpyDeviceToDevice, r.stream));
-        if (n) DFGPU_HIP(hipMemcpyAsync((char*)cc.data->ptr + (size_t)G0 * w, ik.ptr(), (size_t)n * w, hipMemcpyDeviceToDevice, r.stream));
-        DFGPU_CHECK(!cc.validity, "incremental aggregation over nullable group keys is not supported on the GPU path yet");
-        cat_keys.push_back(std::move(cc));
-      }
-    }
-    ictx.keys.n = ngk;
-    DFGPU_CHECK(ngk <= MAX_KEYS, "too many group-by columns");
-    for (int g = 0; g < ngk; g++) {
-      DFGPU_CHECK(cat_keys[g].field.type != DFGPU_BOOL, "Boolean group keys are not supported on the GPU path");
-      ictx.keys.c[g] = KeyCol{cat_keys[g].ptr(), cat_keys[g].valid_words(), cat_keys[g].field.type, type_width(cat_keys[g].field.type)};
-    }
-    int64_t key_bytes = 0;
-    for (int g = 0; g < ngk; g++) key_bytes += total * type_width(cat_keys[g].field.type);
-    BufPtr flag = make_zero_buf(4);
-    uint64_t cap = (uint64_t)A.capacity_hint;
-    const uint64_t cap_max = [&] { uint64_t c = 64; while (c < (uint64_t)total * 2) c <<= 1; return c; }();
-    if (cap > cap_max) cap = cap_max;
-    for (;;) {
-      slots = make_zero_buf(cap * 4);
-      ictx.slots = slots->as<uint32_t>();
-      ictx.mask = cap - 1;
-      if (total) {
-        ProfileScope ps("agg_intern_claim", key_bytes);
-        k_intern_claim<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx, total, flag->as<int>());
-        DFGPU_HIP(hipGetLastError());
-      }
-      int ovf = 0;
-      d2h(&ovf, flag->ptr, 4);
-      if (!ovf) break;
-      DFGPU_CHECK(cap < cap_max, "group table overflow at maximum capacity");
-      cap = std::min<uint64_t>(cap_max, cap * 16);
-      DFGPU_HIP(hipMemsetAsync(flag->ptr, 0, 4, r.stream));
-    }
-    A.capacity_hint = (int64_t)cap;
-    const int64_t n_words = (total + 63) / 64;
-    BufPtr rep_mask = make_zero_buf((size_t)(n_words ? n_words : 1) * 8);
-    BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
-    k_mark_reps<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(slots->as<uint32_t>(), cap, rep_mask->as<unsigned long long>());
-    scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, total, prefix->as<uint64_t>());
-    G1 = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
-    slot_gid = make_buf(cap * 4);
-    BufPtr rep_row = make_buf((size_t)(G1 ? G1 : 1) * 8);
-    k_slot_gids<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(slots->as<uint32_t>(), cap, rep_mask->as<uint64_t>(), prefix->as<uint64_t>(),
-                                                                        slot_gid->as<uint32_t>(), rep_row->as<int64_t>());
-    DFGPU_HIP(hipGetLastError());
-    // new dense group key columns = representative rows (first-seen order)
-    Table gk;
-    gk.nrows = G1;
-    for (int g = 0; g < ngk; g++) gk.cols.push_back(gather_column(cat_keys[g], rep_row->as<int64_t>(), G1, false));
-    A.group_keys = std::move(gk);
+    IR = intern_keys(A, key_cols, n, nullptr);
+    G1 = IR.G1;
   } else {
     G1 = 1;  // no GROUP BY: AggregateStream, one output row even for empty input
   }
+  InternCtx& ictx = IR.ictx;
 
   // ---- grow accumulators to G1 groups
+  std::vector<AccPlan> plans = grow_accumulators(A, G0, G1);
   AccSet accs{};
   for (size_t k = 0; k < A.aggs.size(); k++) {
     AggState& a = A.aggs[k];
-    AccPlan p = plan_for(a.func, a.in_type, final_mode);
-    a.lo = grown(a.lo, G0, G1, acc_identity(p.kind));
-    if (p.needs_hi) a.hi = grown(a.hi, G0, G1, 0ull);
-    a.seen = grown(a.seen, G0, G1, 0, 4);
-    if (a.func == DFGPU_AGG_AVG) a.cnt = grown(a.cnt, G0, G1, 0ull);
+    const AccPlan& p = plans[k];
     AccDesc d{};
     d.kind = (a.func == DFGPU_AGG_COUNT && !a.has_arg && !final_mode) ? ACC_COUNT_STAR : p.kind;
     d.val = p.val;
@@ -559,7 +976,7 @@ static void agg_update(Aggregate& A, const Table& in) {
   for (int k = 0; k < accs.n; k++)
     if (accs.a[k].values) bytes += n * 8;
   const int per_rep = accs.n * (int)std::min<int64_t>(G1, LDS_CELLS + 1);
-  const uint32_t* sg = slot_gid ? slot_gid->as<uint32_t>() : nullptr;
+  const uint32_t* sg = IR.slot_gid ? IR.slot_gid->as<uint32_t>() : nullptr;
   if (G1 * accs.n <= LDS_CELLS) {
     int nrep = std::max(1, std::min(64, LDS_CELLS / per_rep));
     // power of two so that consecutive lanes spread over the replicas
@@ -575,6 +992,28 @@ static void agg_update(Aggregate& A, const Table& in) {
   A.ngroups = G1;
   DFGPU_HIP(hipStreamSynchronize(r.stream));  // temporaries (evaluated columns, tables) are released on return
 }
+
+// aggregate_batch_inner over a whole table, optionally under a FilterExec predicate fused in front
+static void agg_update(Aggregate& A, const Table& in, const dfgpu_expr* pred = nullptr) {
+  std::string why;
+  if (agg_update_fused(A, in, pred, why)) {
+    A.fused_updates++;
+    return;
+  }
+  if (!pred) {
+    agg_update_unfused(A, in);
+    return;
+  }
+  // unfused fallback of the fused node: FilterExec, then the aggregate over its output
+  Datum m = evaluate(*pred, in);
+  DFGPU_CHECK(m.col.field.type == DFGPU_BOOL, "Cannot create filter with non-boolean predicate");
+  Column mc = datum_to_column(m, in.nrows, "");
+  std::vector<int> all(in.cols.size());
+  for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
+  Table filtered = compact_table(in, all, mc.data->as<uint64_t>(), mc.valid_words());
+  agg_update_unfused(A, filtered);
+}
+
 
 static Column emit_column(const dfgpu_field& f, const std::string& name, int mode, const BufPtr& lo, const BufPtr& hi, const BufPtr& seen, int64_t n,
                           bool nullable) {
@@ -739,6 +1178,21 @@ int dfgpu_agg_update(dfgpu_agg_t h, dfgpu_table_t input) {
     require_init();
     agg_update(*reinterpret_cast<Aggregate*>(h), *unwrap(input));
   });
+}
+
+int dfgpu_agg_update_filtered(dfgpu_agg_t h, dfgpu_table_t input, const dfgpu_expr* predicate) {
+  return guarded([&] {
+    require_init();
+    agg_update(*reinterpret_cast<Aggregate*>(h), *unwrap(input), predicate);
+  });
+}
+
+int dfgpu_agg_fused_updates(dfgpu_agg_t h, int64_t* out) {
+  return guarded([&] { *out = reinterpret_cast<Aggregate*>(h)->fused_updates; });
+}
+
+int dfgpu_set_fusion(int on) {
+  return guarded([&] { set_fusion_enabled(on != 0); });
 }
 
 int dfgpu_agg_emit(dfgpu_agg_t h, dfgpu_table_t* out) {

@@ -22,19 +22,19 @@ static dfgpu_field mkfield(int type, int p = 0, int s = 0) {
   f.nullable = 1;
   return f;
 }
-static bool same_type(const dfgpu_field& a, const dfgpu_field& b) {
+bool same_field_type(const dfgpu_field& a, const dfgpu_field& b) {
   if (a.type != b.type) return false;
   if (a.type == DFGPU_DECIMAL128) return a.precision == b.precision && a.scale == b.scale;
   return true;
 }
-static dfgpu_field arith_type(int op, const dfgpu_field& l, const dfgpu_field& r) {
+dfgpu_field arith_result_type(int op, const dfgpu_field& l, const dfgpu_field& r) {
   if (l.type == DFGPU_DECIMAL128 && r.type == DFGPU_DECIMAL128) {
     int p1 = l.precision, s1 = l.scale, p2 = r.precision, s2 = r.scale;
     if (op == DFGPU_EXPR_MUL) return mkfield(DFGPU_DECIMAL128, std::min(38, p1 + p2 + 1), std::min(38, s1 + s2));
     int s = std::max(s1, s2);
     return mkfield(DFGPU_DECIMAL128, std::min(38, s + std::max(p1 - s1, p2 - s2) + 1), s);
   }
-  DFGPU_CHECK(same_type(l, r), "arithmetic operand types differ: " + type_name(l) + " vs " + type_name(r) + " (the planner inserts casts)");
+  DFGPU_CHECK(same_field_type(l, r), "arithmetic operand types differ: " + type_name(l) + " vs " + type_name(r) + " (the planner inserts casts)");
   DFGPU_CHECK(l.type == DFGPU_INT32 || l.type == DFGPU_INT64 || l.type == DFGPU_FLOAT64,
               "arithmetic on " + type_name(l) + " is not supported on the GPU path");
   return mkfield(l.type);
@@ -51,7 +51,7 @@ static dfgpu_field node_type(const dfgpu_expr& e, int idx, const Table& in) {
     case DFGPU_EXPR_CAST:
       return n.field;
     case DFGPU_EXPR_ADD: case DFGPU_EXPR_SUB: case DFGPU_EXPR_MUL:
-      return arith_type(n.op, node_type(e, n.left, in), node_type(e, n.right, in));
+      return arith_result_type(n.op, node_type(e, n.left, in), node_type(e, n.right, in));
     case DFGPU_EXPR_EQ: case DFGPU_EXPR_NE: case DFGPU_EXPR_LT: case DFGPU_EXPR_LE: case DFGPU_EXPR_GT: case DFGPU_EXPR_GE:
     case DFGPU_EXPR_AND: case DFGPU_EXPR_OR: case DFGPU_EXPR_NOT: case DFGPU_EXPR_IS_NULL: case DFGPU_EXPR_IS_NOT_NULL:
       return mkfield(DFGPU_BOOL);
@@ -247,7 +247,7 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
   hipStream_t st = rt().stream;
   auto unsupported = [&]() { throw Error("cast " + type_name(from) + " -> " + type_name(to) + " is not supported on the GPU path"); };
   int ft = from.type == DFGPU_DATE32 ? DFGPU_INT32 : from.type;
-  if (same_type(from, to)) return src;
+  if (same_field_type(from, to)) return src;
   ProfileScope ps("cast", len * (type_width(from.type) + type_width(to.type)));
   if (to.type == DFGPU_DECIMAL128) {
     int fs = from.type == DFGPU_DECIMAL128 ? from.scale : 0;
@@ -340,7 +340,7 @@ static Datum eval_binary(const dfgpu_expr_node& n, const Datum& a, const Datum& 
       DFGPU_CHECK(l == rr, "comparison operand types differ: " + type_name(lt) + " vs " + type_name(rtp));
     }
   } else {
-    out_field = arith_type(op, lt, rtp);
+    out_field = arith_result_type(op, lt, rtp);
     if (out_field.type == DFGPU_DECIMAL128 && op != DFGPU_EXPR_MUL) {
       ma = pow10_i128(out_field.scale - lt.scale);
       mb = pow10_i128(out_field.scale - rtp.scale);

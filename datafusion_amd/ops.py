@@ -190,8 +190,20 @@ class GroupedAggregate:
         self._h = C.c_void_p()
         check(lib.dfgpu_agg_create(AGG_MODES[mode], garr, gnames, len(group_by), sarr, len(specs), C.byref(self._h)))
 
-    def update(self, table: DeviceTable):
-        check(_lib.load().dfgpu_agg_update(self._h, table.handle))
+    def update(self, table: DeviceTable, predicate: PhysicalExpr | None = None):
+        """aggregate_batch_inner over a whole table; `predicate` = a FilterExec fused in front of this node
+        (rows whose predicate is false/NULL are skipped) — evaluated in the same pass as the arguments"""
+        if predicate is None:
+            check(_lib.load().dfgpu_agg_update(self._h, table.handle))
+        else:
+            le = lower(predicate, table.column_names)
+            check(_lib.load().dfgpu_agg_update_filtered(self._h, table.handle, C.byref(le.c)))
+
+    @property
+    def fused_updates(self) -> int:
+        n = C.c_int64()
+        check(_lib.load().dfgpu_agg_fused_updates(self._h, C.byref(n)))
+        return n.value
 
     def emit(self) -> DeviceTable:
         out = C.c_void_p()
@@ -210,12 +222,19 @@ class GroupedAggregate:
             pass
 
 
-def aggregate(table: DeviceTable, group_by, aggs, mode="Single") -> DeviceTable:
+def aggregate(table: DeviceTable, group_by, aggs, mode="Single", predicate: PhysicalExpr | None = None, info: dict | None = None) -> DeviceTable:
     a = GroupedAggregate(mode, table.column_names, group_by, aggs)
-    a.update(table)
+    a.update(table, predicate)
+    if info is not None:
+        info["fused_updates"] = a.fused_updates
     out = a.emit()
     a.free()
     return out
+
+
+def set_fusion(on: bool):
+    """expression fusion (rowprog) on/off, process-wide; off = column-at-a-time evaluation everywhere"""
+    check(_lib.init().dfgpu_set_fusion(int(on)))
 
 
 # ------------------------------------------------------------------ synthetic workload

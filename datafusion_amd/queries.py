@@ -71,27 +71,47 @@ def q1_aggs():
             ("avg", col("l_extendedprice"), "avg_price"), ("avg", col("l_discount"), "avg_disc"), ("count", None, "count_order")]
 
 
-def q1(lineitem: DeviceTable, group=None) -> DeviceTable:
+def q1_aggs_inlined():
+    """q1_aggs() with the ProjectionExec inlined: `__common_expr_1` spelled out over lineitem's columns
+    (the fused node's value numbering finds the common subexpression again)"""
+    ce = col("l_extendedprice") * (ONE - col("l_discount"))
+    return [("sum", col("l_quantity"), "sum_qty"), ("sum", col("l_extendedprice"), "sum_base_price"), ("sum", ce, "sum_disc_price"),
+            ("sum", ce * (ONE + col("l_tax")), "sum_charge"), ("avg", col("l_quantity"), "avg_qty"),
+            ("avg", col("l_extendedprice"), "avg_price"), ("avg", col("l_discount"), "avg_disc"), ("count", None, "count_order")]
+
+
+def q1(lineitem: DeviceTable, group=None, fused: bool = True) -> DeviceTable:
     """q1.slt.part:50-58, bottom-up: FilterExec(l_shipdate <= 1998-09-02, projection) ->
     ProjectionExec(__common_expr_1 = l_extendedprice * (1 - l_discount), ...) ->
     AggregateExec(Partial) -> RepartitionExec(Hash(flag, status)) -> AggregateExec(FinalPartitioned)
     -> SortExec -> SortPreservingMergeExec.  With one partition DataFusion plans a single
-    AggregateExec(Single) instead of Partial/Final; so do we."""
-    f = ops.filter(lineitem, col("l_shipdate") <= lit(DATE_Q1, pa.date32()),
-                   ["l_extendedprice", "l_discount", "l_quantity", "l_tax", "l_returnflag", "l_linestatus"])
-    p = ops.project(f, [(col("l_extendedprice") * (ONE - col("l_discount")), "__common_expr_1"), (col("l_quantity"), "l_quantity"),
-                        (col("l_extendedprice"), "l_extendedprice"), (col("l_discount"), "l_discount"), (col("l_tax"), "l_tax"),
-                        (col("l_returnflag"), "l_returnflag"), (col("l_linestatus"), "l_linestatus")])
-    f.free()
+    AggregateExec(Single) instead of Partial/Final; so do we.
+
+    fused=True (what the optimizer rule substitutes): FilterExec + ProjectionExec + AggregateExec as ONE
+    node — predicate, projection expressions and accumulation in a single pass over lineitem's seven
+    referenced columns (dfgpu_agg_update_filtered).  fused=False runs the three operators one after the
+    other, materialising the filter's and the projection's outputs."""
+    pred = col("l_shipdate") <= lit(DATE_Q1, pa.date32())
+    first_mode = "Single" if _world(group) == 1 else "Partial"
+    if fused:
+        first = ops.aggregate(lineitem, Q1_GROUP_BY, q1_aggs_inlined(), first_mode, predicate=pred)
+    else:
+        f = ops.filter(lineitem, pred, ["l_extendedprice", "l_discount", "l_quantity", "l_tax", "l_returnflag", "l_linestatus"])
+        p = ops.project(f, [(col("l_extendedprice") * (ONE - col("l_discount")), "__common_expr_1"), (col("l_quantity"), "l_quantity"),
+                            (col("l_extendedprice"), "l_extendedprice"), (col("l_discount"), "l_discount"), (col("l_tax"), "l_tax"),
+                            (col("l_returnflag"), "l_returnflag"), (col("l_linestatus"), "l_linestatus")])
+        f.free()
+        first = ops.aggregate(p, Q1_GROUP_BY, q1_aggs(), first_mode)
+        p.free()
     keys = [("l_returnflag", False, False), ("l_linestatus", False, False)]
     if _world(group) == 1:
-        agg = ops.aggregate(p, Q1_GROUP_BY, q1_aggs(), "Single")
-        p.free()
+        agg = first
     else:
-        partial = ops.aggregate(p, Q1_GROUP_BY, q1_aggs(), "Partial")
-        p.free()
-        routed = _repartition(partial, ["l_returnflag", "l_linestatus"], group)
+        routed = _repartition(first, ["l_returnflag", "l_linestatus"], group)
         agg = ops.aggregate(routed, Q1_GROUP_BY, q1_aggs(), "FinalPartitioned")
+        if routed is not first:
+            routed.free()
+        first.free()
     out = ops.sort(agg, keys)
     agg.free()
     return _merge_sorted(out, keys, None, group)

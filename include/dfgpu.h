@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 2
+#define DFGPU_ABI_VERSION 3
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -315,6 +315,18 @@ int dfgpu_agg_create(int mode, const dfgpu_expr* group_by, const char* const* gr
                      const dfgpu_agg_spec* aggs, int n_aggs, dfgpu_agg_t* out);
 /* aggregate_batch_inner (aggregate_hash_table/common.rs:205-236) over a whole table */
 int dfgpu_agg_update(dfgpu_agg_t h, dfgpu_table_t input);
+/* The same with a FilterExec predicate fused in front (filter.rs:1396-1419 -> common.rs:205-236): rows whose
+ * predicate is false or NULL neither create groups nor accumulate.  What the optimizer rule substitutes for
+ * AggregateExec(ProjectionExec(FilterExec(x))) — e.g. TPC-H Q1, tpch/plans/q1.slt.part:50-58: the projection's
+ * expressions are inlined into the group/argument expressions, and predicate + expressions + accumulation run
+ * as ONE pass over the referenced input columns (rowprog: per-row register program, no intermediate columns).
+ * predicate == NULL is dfgpu_agg_update. */
+int dfgpu_agg_update_filtered(dfgpu_agg_t h, dfgpu_table_t input, const dfgpu_expr* predicate);
+/* number of updates of `h` that ran fused (0 when the expression forest did not fit the register program and
+ * the column-at-a-time evaluator was used; results are identical either way) */
+int dfgpu_agg_fused_updates(dfgpu_agg_t h, int64_t* out);
+/* process-wide switch for expression fusion (default on); off = always column-at-a-time (A/B measurements, tests) */
+int dfgpu_set_fusion(int on);
 /* next_output_batch_inner (common.rs:247-300): emit all groups */
 int dfgpu_agg_emit(dfgpu_agg_t h, dfgpu_table_t* out);
 int dfgpu_agg_free(dfgpu_agg_t h);

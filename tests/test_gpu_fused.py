@@ -1,0 +1,168 @@
+"""Fused FilterExec -> ProjectionExec -> AggregateExec node (dfgpu_agg_update_filtered; rowprog register
+programs) against the CPU oracle's filter -> aggregate composition, and against the column-at-a-time GPU
+path (dfgpu_set_fusion(0)).  Integer / Decimal128 bit-exact, Float64 sums within 1e-6 relative."""
+import datetime
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from tests.test_gpu_aggregate import assert_agg_equal, oracle_agg
+from tests.util import random_table, to_oracle_expr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[True, False], ids=["fused", "column_at_a_time"])
+def fusion(request):
+    from datafusion_amd import ops
+    ops.set_fusion(request.param)
+    yield request.param
+    ops.set_fusion(True)
+
+
+def gpu(table, group_by, aggs, predicate=None, mode="Single", batches=1):
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    a = ops.GroupedAggregate(mode, table.column_names, group_by, aggs)
+    n = table.num_rows
+    step = max(1, (n + batches - 1) // batches)
+    for o in range(0, max(n, 1), step):
+        a.update(DeviceTable.from_arrow(table.slice(o, step)), predicate)
+    fused = a.fused_updates
+    out = a.emit().to_arrow()
+    a.free()
+    return out, fused
+
+
+def oracle(table, group_by, aggs, predicate=None, mode="Single"):
+    from oracle import oracle as O
+    if predicate is not None:
+        table = O.filter(table, to_oracle_expr(predicate), table.column_names)
+    return oracle_agg(table, group_by, aggs, mode)
+
+
+def flags_table(rng, n, null_frac=0.0, nflags=3):
+    t = random_table(rng, n, {"d": (pa.decimal128(15, 2), -10**9, 10**9), "e": (pa.decimal128(15, 2), 0, 11), "i": (pa.int32(), -1000, 1000),
+                              "f": (pa.float64(), -10**6, 10**6), "dt": (pa.date32(), 8000, 10000), "k": (pa.int64(), 0, 50)}, null_frac=null_frac)
+    rf = pa.array(rng.integers(65, 65 + nflags, size=n).astype(np.uint8))
+    ls = pa.array(rng.integers(70, 72, size=n).astype(np.uint8))
+    return t.append_column("rf", rf).append_column("ls", ls)
+
+
+def test_q1_shape_is_fused_and_matches(fusion):
+    """8 aggregates over 4 groups keyed by two 1-byte columns, under the Q1 predicate"""
+    from datafusion_amd import queries as Q, tpch
+    from datafusion_amd.expr import col, lit
+    li = tpch.lineitem(0.02)
+    pred = col("l_shipdate") <= lit(datetime.date(1995, 6, 1), pa.date32())   # ~50 % selectivity at this cut
+    got, fused = gpu(li, Q.Q1_GROUP_BY, Q.q1_aggs_inlined(), pred)
+    assert fused == (1 if fusion else 0)
+    exp = oracle(li, Q.Q1_GROUP_BY, Q.q1_aggs_inlined(), pred)
+    assert got.schema.field("sum_charge").type == pa.decimal128(38, 6) and got.schema.field("avg_disc").type == pa.decimal128(19, 6)
+    assert_agg_equal(got, exp, ordered=True)
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.15])
+def test_small_domain_keys_with_nullable_arguments_and_kleene_predicate(fusion, null_frac):
+    from datafusion_amd.expr import col, lit
+    t = flags_table(np.random.default_rng(5), 200_000, null_frac)
+    one = lit(1, pa.decimal128(20, 0))
+    # NULL predicate rows are dropped (filter.rs:1396-1419); OR with a NULL side is Kleene
+    pred = (col("dt") > lit(8500, pa.int32()).cast(pa.date32())).and_((col("i") < lit(500, pa.int32())).or_(col("f") > lit(0.0)))
+    aggs = [("sum", col("d") * (one - col("e")), "s"), ("avg", col("d"), "a"), ("min", col("d"), "mn"), ("max", col("f"), "mx"),
+            ("sum", col("i") + col("i"), "si"), ("count", col("i"), "ci"), ("count", None, "c"), ("avg", col("i"), "ai"), ("sum", col("f") * col("f"), "sf")]
+    gb = [(col("rf"), "rf"), (col("ls"), "ls")]
+    got, fused = gpu(t, gb, aggs, pred)
+    assert fused == (1 if fusion else 0)
+    assert_agg_equal(got, oracle(t, gb, aggs, pred), ordered=True)
+
+
+def test_groups_seen_only_in_filtered_out_rows_are_not_created(fusion):
+    from datafusion_amd.expr import col, lit
+    rf = pa.array(np.array([1, 1, 2, 2, 3, 3, 1, 4], dtype=np.uint8))
+    v = pa.array([10, 20, 30, 40, 50, 60, 70, 80], type=pa.int64())
+    t = pa.table({"rf": rf, "v": v})
+    pred = col("v") > lit(35)                     # rows of group 1 at the front fail; group 1 is first seen at row 6
+    got, _ = gpu(t, [(col("rf"), "rf")], [("sum", col("v"), "s"), ("count", None, "c")], pred)
+    assert got.to_pydict() == {"rf": [2, 3, 1, 4], "s": [40, 110, 70, 80], "c": [1, 2, 1, 1]}
+    # hash-interned keys (Int64) take the masked intern path
+    t2 = pa.table({"k": pa.array([1, 1, 2, 2, 3, 3, 1, 4], type=pa.int64()), "v": v})
+    got2, _ = gpu(t2, [(col("k"), "k")], [("sum", col("v"), "s"), ("count", None, "c")], pred)
+    assert got2.to_pydict() == {"k": [2, 3, 1, 4], "s": [40, 110, 70, 80], "c": [1, 2, 1, 1]}
+
+
+@pytest.mark.parametrize("ngroups", [7, 3000, 150_000])
+def test_hash_keys_with_predicate(fusion, ngroups):
+    from datafusion_amd.expr import col, lit
+    rng = np.random.default_rng(ngroups)
+    t = random_table(rng, 250_000, {"k": (pa.int64(), 0, ngroups), "d": (pa.decimal128(15, 2), -10**9, 10**9), "e": (pa.decimal128(15, 2), 0, 11),
+                                    "dt": (pa.date32(), 8000, 10000)}, null_frac=0.05)
+    pred = col("dt") >= lit(9000, pa.int32()).cast(pa.date32())
+    one = lit(1, pa.decimal128(20, 0))
+    aggs = [("sum", col("d") * (one - col("e")), "rev"), ("count", col("d"), "c"), ("max", col("dt"), "mx")]
+    got, fused = gpu(t, [(col("k"), "k")], aggs, pred)
+    assert fused == (1 if fusion else 0)
+    assert_agg_equal(got, oracle(t, [(col("k"), "k")], aggs, pred), ordered=True)
+
+
+def test_no_group_by_with_predicate(fusion):
+    from datafusion_amd.expr import col, lit
+    t = flags_table(np.random.default_rng(9), 100_000, 0.1)
+    pred = col("k").ne(lit(7))
+    aggs = [("sum", col("d"), "s"), ("count", None, "c"), ("avg", col("f"), "a"), ("min", col("dt"), "m")]
+    got, _ = gpu(t, [], aggs, pred)
+    assert_agg_equal(got, oracle(t, [], aggs, pred))
+    none_pass, _ = gpu(t, [], aggs, col("k") < lit(-1))
+    assert none_pass.to_pylist() == [{"s": None, "c": 0, "a": None, "m": None}]
+
+
+@pytest.mark.parametrize("batches", [2, 5])
+def test_incremental_updates_keep_first_seen_group_order(fusion, batches):
+    """several update() calls on one handle (HashAggregate sees its input batch by batch): small-domain and hash keys"""
+    from datafusion_amd.expr import col, lit
+    t = flags_table(np.random.default_rng(21), 60_000, 0.0, nflags=9)
+    pred = col("i") > lit(-900, pa.int32())
+    aggs = [("sum", col("d"), "s"), ("avg", col("e"), "a"), ("count", None, "c")]
+    for gb in ([(col("rf"), "rf"), (col("ls"), "ls")], [(col("k"), "k")]):
+        got, fused = gpu(t, gb, aggs, pred, batches=batches)
+        assert fused == (batches if fusion else 0)
+        assert_agg_equal(got, oracle(t, gb, aggs, pred), ordered=True)
+
+
+def test_int32_wrapping_casts_and_is_null_in_arguments(fusion):
+    from datafusion_amd.expr import col, lit
+    big = 2**31 - 5
+    t = pa.table({"g": pa.array(np.arange(1000, dtype=np.uint8) % 3), "i": pa.array([big, -big, 7, None] * 250, type=pa.int32()),
+                  "j": pa.array(np.arange(1000), type=pa.int64())})
+    aggs = [("sum", col("i") + col("i"), "wrap32"),                       # Int32 + Int32 wraps at 32 bits before the Int64 sum
+            ("sum", col("i").cast(pa.int64()) * col("j"), "wide"),
+            ("sum", col("j").cast(pa.decimal128(20, 2)), "dec"),
+            ("avg", col("i").cast(pa.float64()) * lit(0.5), "favg"),
+            ("count", col("i"), "nn")]
+    pred = col("i").is_not_null().or_(col("j") < lit(500))
+    got, _ = gpu(t, [(col("g"), "g")], aggs, pred)
+    assert_agg_equal(got, oracle(t, [(col("g"), "g")], aggs, pred), ordered=True)
+
+
+def test_forest_that_does_not_fit_falls_back_with_identical_results():
+    """more input columns than the register program takes: the node runs column-at-a-time (fused_updates == 0)"""
+    from datafusion_amd.expr import col, lit
+    rng = np.random.default_rng(2)
+    spec = {f"c{i}": (pa.int64(), -100, 100) for i in range(13)}
+    t = random_table(rng, 20_000, spec).append_column("g", pa.array(rng.integers(0, 5, size=20_000).astype(np.uint8)))
+    aggs = [("sum", col(f"c{i}"), f"s{i}") for i in range(13)]
+    pred = col("c0") > lit(-50)
+    got, fused = gpu(t, [(col("g"), "g")], aggs, pred)
+    assert fused == 0
+    assert_agg_equal(got, oracle(t, [(col("g"), "g")], aggs, pred), ordered=True)
+
+
+def test_errors_match_the_unfused_path():
+    from datafusion_amd import _lib
+    from datafusion_amd.expr import col, lit
+    t = pa.table({"a": pa.array([1, 2], type=pa.int64()), "b": pa.array([1, 2], type=pa.int32())})
+    with pytest.raises(_lib.DfgpuError, match="arithmetic operand types differ"):
+        gpu(t, [], [("sum", col("a") + col("b"), "s")], col("a") > lit(0))
+    with pytest.raises(_lib.DfgpuError, match="non-boolean predicate"):
+        gpu(t, [], [("sum", col("a"), "s")], col("a") + lit(1))
