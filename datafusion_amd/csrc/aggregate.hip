@@ -25,6 +25,8 @@
 //              AVG(Decimal128) = (sum * 10^(ts-ss)) / count truncating (DecimalAverager::avg,
 //              functions-aggregate-common/src/utils.rs:157-176).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "device.hpp"
 #include "internal.hpp"
@@ -544,6 +546,216 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fused(RowProgram p, int n_prologu
   }
 }
 
+// ------------------------------------------------------- single-pass small-domain fused node
+// Low-cardinality groups keyed by up to two 1-byte columns (TPC-H Q1: l_returnflag, l_linestatus), or no
+// GROUP BY at all: ONE pass over the input does FilterExec + ProjectionExec + intern + accumulate.
+//   * no interning pre-pass: a workgroup maps key bytes -> local slot through a tiny LDS table (LDS CAS);
+//     accumulators are flushed into HBM arrays indexed by the KEY itself (domain 1 / 256 / 65536) and the
+//     first passing row of every key is tracked with min(), so the host can number the groups in first-seen
+//     order afterwards (group_values/mod.rs:88-92) and a tiny merge kernel folds key-indexed partials into
+//     the dense accumulators.
+//   * SUM(Decimal128) without carries: the 128-bit value is split into limbs of 43 + 43 + 42 bits that are
+//     added with fire-and-forget ds_add_u64 (no returned value, no dependent second atomic).  A limb cell
+//     holds < 2^43 per add and a workgroup adds < 2^20 rows, so no limb sum can wrap 64 bits; the limbs are
+//     recombined mod 2^128 at flush time — bit-identical to wrapping i128 addition in any order.
+//   * row i+stride's column loads are issued before row i is interpreted (rp_issue_row / rp_commit_row).
+constexpr int SM_MAX_CELLS = 48;    // LDS cells per group (an i128 sum takes 3)
+constexpr int SM_MAX_L = 256;       // local slots per workgroup
+constexpr uint64_t LIMB_MASK = (1ull << 43) - 1ull;
+struct SmallAcc {
+  unsigned long long* tmp_lo;  // [domain] key-indexed partials
+  unsigned long long* tmp_hi;  // [domain], i128 sums only
+  int16_t kind;                // AccKind
+  int16_t reg;                 // value register, -1 = none (COUNT(*))
+  int16_t cell0;               // first LDS cell of this accumulator
+  int16_t pad;
+};
+struct SmallAccSet {
+  SmallAcc a[MAX_AGGS];
+  int n;
+  int ncell;
+  uint8_t cell_kind[SM_MAX_CELLS];  // AccKind whose identity initialises the cell
+};
+
+__device__ __forceinline__ int small_local_slot(uint32_t* s_key, int L, uint32_t key) {
+  const uint32_t want = key + 1u;
+  int slot = (int)((key * 0x9E3779B1u) >> 20) & (L - 1);
+  for (int probe = 0; probe < L; probe++) {
+    uint32_t cur = s_key[slot];
+    if (cur == want) return slot;
+    if (cur == 0u) {
+      cur = atomicCAS(&s_key[slot], 0u, want);
+      if (cur == 0u || cur == want) return slot;
+    }
+    slot = (slot + 1) & (L - 1);
+  }
+  return -1;
+}
+
+// LDS limb cells += the 128-bit value (lo, hi): three fire-and-forget ds_add_u64
+__device__ __forceinline__ void lds_add_limbs(unsigned long long* c, int plane, uint64_t lo, uint64_t hi) {
+  atomicAdd(c, (unsigned long long)(lo & LIMB_MASK));
+  atomicAdd(c + plane, (unsigned long long)(((lo >> 43) | (hi << 21)) & LIMB_MASK));
+  atomicAdd(c + 2 * plane, (unsigned long long)((int64_t)hi >> 22));
+}
+
+// rows [begin, end) of the input.  LDS: register file (TileProgram) | accumulator cells | seen | keys | first rows.
+template <bool PREFETCH>
+__global__ __launch_bounds__(BLOCK) void k_agg_fused_tile(TileProgram p, int pred_opnd, int key_opnd0, int key_opnd1, SmallAccSet accs, int64_t begin,
+                                                         int64_t end, int L, int nrep, uint32_t* __restrict__ g_first, uint32_t* __restrict__ g_seen) {
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  TileRegs t;
+  t.wide = reinterpret_cast<char*>(s_raw) + threadIdx.x * 16;
+  t.narrow = reinterpret_cast<char*>(s_raw) + (size_t)p.n_wide * (BLOCK * 16) + threadIdx.x * 8;
+  t.nulls = 0u;
+  unsigned long long* s_cell = reinterpret_cast<unsigned long long*>(s_raw + tile_regfile_bytes(p.n_wide, p.n_narrow));
+  const int plane = L * nrep;  // cell(c, slot, rep) = (c * L + slot) * nrep + rep
+  const int ncells = accs.ncell * plane;
+  uint32_t* s_seen = (uint32_t*)(s_cell + ncells);  // [slot * nrep + rep] bit k = accumulator k saw a value
+  uint32_t* s_key = s_seen + plane;                 // [L] key + 1, 0 = free
+  uint32_t* s_first = s_key + L;                    // [L] smallest passing row of the slot's key
+  for (int x = threadIdx.x; x < ncells; x += BLOCK) s_cell[x] = acc_identity(accs.cell_kind[x / plane]);
+  for (int x = threadIdx.x; x < plane; x += BLOCK) s_seen[x] = 0u;
+  for (int x = threadIdx.x; x < L; x += BLOCK) {
+    s_key[x] = 0u;
+    s_first[x] = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  const int rep = (int)(threadIdx.x & (unsigned)(nrep - 1));
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  int64_t i = begin + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  RpRaw raw;
+  if (PREFETCH && i < end) tp_issue_row(p, i, raw);
+  for (; i < end; i += stride) {
+    if (!PREFETCH) tp_issue_row(p, i, raw);
+    tp_commit_row(p, raw, t);
+    if (PREFETCH && i + stride < end) tp_issue_row(p, i + stride, raw);
+    if (pred_opnd >= 0) {
+      tp_exec(p, 0, p.n_pred_end, t);
+      if (!tp_true(p, t, (uint32_t)pred_opnd)) continue;
+    }
+    tp_exec(p, p.n_pred_end, p.n_ins, t);
+    uint32_t key = 0u;
+    if (key_opnd0 >= 0) {
+      uint64_t klo, khi;
+      bool kn;
+      tp_fetch(p, t, (uint32_t)key_opnd0, klo, khi, kn);
+      key = (uint32_t)klo & 0xFFu;
+      if (key_opnd1 >= 0) {
+        tp_fetch(p, t, (uint32_t)key_opnd1, klo, khi, kn);
+        key |= ((uint32_t)klo & 0xFFu) << 8;
+      }
+    }
+    const int slot = small_local_slot(s_key, L, key);
+    if (slot >= 0) {
+      if ((uint32_t)i < s_first[slot]) atomicMin(&s_first[slot], (uint32_t)i);
+      const int base = slot * nrep + rep;
+      uint32_t seen = 0u;
+      for (int k = 0; k < accs.n; k++) {
+        const SmallAcc& d = accs.a[k];
+        uint64_t lo = 0, hi = 0;
+        if (d.reg >= 0) {
+          bool isnull;
+          tp_fetch(p, t, (uint32_t)d.reg, lo, hi, isnull);
+          if (isnull) continue;
+        }
+        seen |= 1u << k;
+        unsigned long long* c = s_cell + d.cell0 * plane + base;
+        switch (d.kind) {
+          case ACC_SUM_I128: lds_add_limbs(c, plane, lo, hi); break;
+          case ACC_SUM_I64: atomicAdd(c, (unsigned long long)lo); break;
+          case ACC_SUM_F64: atomicAdd(reinterpret_cast<double*>(c), __longlong_as_double((long long)lo)); break;
+          case ACC_MIN_I64: atomicMin(reinterpret_cast<long long*>(c), (long long)lo); break;
+          case ACC_MAX_I64: atomicMax(reinterpret_cast<long long*>(c), (long long)lo); break;
+          default: atomicAdd(c, 1ull); break;  // COUNT / COUNT(*)
+        }
+      }
+      if (seen & ~s_seen[base]) atomicOr(&s_seen[base], seen);
+    } else {
+      // more distinct keys in this workgroup than local slots: straight to the key-indexed HBM partials
+      if ((uint32_t)i < __hip_atomic_load(&g_first[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&g_first[key], (uint32_t)i);
+      uint32_t seen = 0u;
+      for (int k = 0; k < accs.n; k++) {
+        const SmallAcc& d = accs.a[k];
+        uint64_t lo = 0, hi = 0;
+        if (d.reg >= 0) {
+          bool isnull;
+          tp_fetch(p, t, (uint32_t)d.reg, lo, hi, isnull);
+          if (isnull) continue;
+        }
+        seen |= 1u << k;
+        accumulate_cell(d.kind, d.tmp_lo + key, d.tmp_hi ? d.tmp_hi + key : nullptr, lo, hi);
+      }
+      if (seen) atomicOr(&g_seen[key], seen);
+    }
+  }
+  __syncthreads();
+  // fold the replicas of each (slot, accumulator), then one update of the key-indexed partials
+  for (int x = threadIdx.x; x < L * accs.n; x += BLOCK) {
+    const int slot = x / accs.n, k = x % accs.n;
+    const uint32_t kv = s_key[slot];
+    if (!kv) continue;
+    const uint32_t key = kv - 1u;
+    uint32_t seen = 0u;
+    for (int q = 0; q < nrep; q++) seen |= s_seen[slot * nrep + q];
+    if (!((seen >> k) & 1u)) continue;
+    const SmallAcc& d = accs.a[k];
+    const unsigned long long* c = s_cell + d.cell0 * plane + slot * nrep;
+    int kind = d.kind;
+    unsigned long long lo = acc_identity(kind), hi = 0ull;
+    if (kind == ACC_SUM_I128) {
+      unsigned long long s0 = 0, s1 = 0, s2 = 0;
+      for (int q = 0; q < nrep; q++) {
+        s0 += c[q];
+        s1 += c[plane + q];
+        s2 += c[2 * plane + q];
+      }
+      u128 v = (u128)s0 + ((u128)s1 << 43) + (u128)((i128)(int64_t)s2 << 86);
+      lo = (unsigned long long)v;
+      hi = (unsigned long long)(v >> 64);
+    } else {
+      for (int q = 0; q < nrep; q++) {
+        const unsigned long long v = c[q];
+        switch (kind) {
+          case ACC_SUM_F64: lo = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)lo) + __longlong_as_double((long long)v)); break;
+          case ACC_MIN_I64: lo = (unsigned long long)min((long long)lo, (long long)v); break;
+          case ACC_MAX_I64: lo = (unsigned long long)max((long long)lo, (long long)v); break;
+          default: lo += v; break;  // SUM_I64 / COUNT / COUNT(*)
+        }
+      }
+      if (kind == ACC_COUNT || kind == ACC_COUNT_STAR) kind = ACC_SUM_I64;  // merge counts by adding
+    }
+    accumulate_cell(kind, d.tmp_lo + key, d.tmp_hi ? d.tmp_hi + key : nullptr, lo, hi);
+    atomicOr(&g_seen[key], 1u << k);
+  }
+  for (int slot = threadIdx.x; slot < L; slot += BLOCK)
+    if (s_key[slot] && s_first[slot] != 0xFFFFFFFFu) atomicMin(&g_first[s_key[slot] - 1u], s_first[slot]);
+}
+
+// key-indexed partials of the touched keys -> dense accumulators (one thread per (key, destination)).
+// Several destinations may share one source: SUM(x) and AVG(x) accumulate the same sum once.
+struct MergeDst {
+  unsigned long long* lo[MAX_AGGS];
+  unsigned long long* hi[MAX_AGGS];
+  uint32_t* seen[MAX_AGGS];
+  int src[MAX_AGGS];  // index into SmallAccSet::a
+  int n;
+};
+__global__ __launch_bounds__(BLOCK) void k_small_merge(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ gids, int n_keys, SmallAccSet accs,
+                                                      MergeDst dst, const uint32_t* __restrict__ g_seen) {
+  const int x = blockIdx.x * BLOCK + threadIdx.x;
+  if (x >= n_keys * dst.n) return;
+  const int t = x / dst.n, e = x % dst.n;
+  const int k = dst.src[e];
+  const uint32_t key = keys[t], gid = gids[t];
+  if (!((g_seen[key] >> k) & 1u)) return;
+  const SmallAcc& d = accs.a[k];
+  int kind = d.kind;
+  if (kind == ACC_COUNT || kind == ACC_COUNT_STAR) kind = ACC_SUM_I64;
+  accumulate_cell(kind, dst.lo[e] + gid, dst.hi[e] ? dst.hi[e] + gid : nullptr, d.tmp_lo[key], d.tmp_hi ? d.tmp_hi[key] : 0ull);
+  if (dst.seen[e]) dst.seen[e][gid] = 1u;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_and_words(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, int64_t nw, uint64_t* __restrict__ out) {
   for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < nw; w += (int64_t)gridDim.x * BLOCK) out[w] = a[w] & b[w];
 }
@@ -674,6 +886,444 @@ static bool small_domain_applicable(const Aggregate& A, const Table& in, std::ve
   return true;
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : dflt;
+}
+
+// rebuilds A.group_keys (dense, gid order) from the host mirror of the 1-byte keys
+static void small_rebuild_group_keys(Aggregate& A, const Table& in, const std::vector<int>& small_cols) {
+  Runtime& r = rt();
+  const int ngk = (int)small_cols.size();
+  const int64_t G1 = (int64_t)A.small_keys.size();
+  Table gk;
+  gk.nrows = G1;
+  for (int g = 0; g < ngk; g++) {
+    Column c = alloc_column(in.cols[small_cols[g]].field, A.group_names[g], G1);
+    std::vector<uint8_t> b((size_t)(G1 ? G1 : 1));
+    for (int64_t i = 0; i < G1; i++) b[(size_t)i] = (uint8_t)(A.small_keys[(size_t)i] >> (8 * g));
+    if (G1) h2d_async(c.data->ptr, b.data(), (size_t)G1);
+    DFGPU_HIP(hipStreamSynchronize(r.stream));  // b is a host temporary
+    gk.cols.push_back(std::move(c));
+  }
+  A.group_keys = std::move(gk);
+}
+static void small_sync_host_keys(Aggregate& A, int ngk) {
+  const int64_t G0 = A.ngroups;
+  if ((int64_t)A.small_keys.size() == G0) return;
+  A.small_keys.assign((size_t)G0, 0);
+  for (int g = 0; g < ngk && G0; g++) {
+    std::vector<uint8_t> b((size_t)G0);
+    d2h(b.data(), A.group_keys.cols[g].ptr(), (size_t)G0);
+    for (int64_t i = 0; i < G0; i++) A.small_keys[(size_t)i] |= (uint16_t)(b[(size_t)i] << (8 * g));
+  }
+}
+
+// ---------------------------------------------------------------- runtime-specialised node (jit.hip)
+// Argument block of the generated kernel: the layout below is repeated textually in the generated source.
+struct AggNodeArgs {
+  const void* col[RP_MAX_COLS];
+  const uint64_t* valid[RP_MAX_COLS];
+  unsigned long long* tmp_lo[MAX_AGGS];
+  unsigned long long* tmp_hi[MAX_AGGS];
+  uint32_t* g_first;
+  uint32_t* g_seen;
+  int64_t begin, end;
+  int L, nrep;
+};
+static_assert(RP_MAX_COLS == 10 && MAX_AGGS == 16, "update the Args struct in agg_node_source");
+
+// HIP source of the single-pass small-domain node for ONE expression forest and accumulator set: the skeleton
+// is k_agg_fused_tile's (local key slots, limb cells, replica fold, key-indexed partials); the interpreter is
+// replaced by the forest's straight-line code and every per-accumulator switch by its one live arm.
+static std::string agg_node_source(const CompiledProgram& cp, const SmallAccSet& accs, const std::vector<int>& acc_val, int key_val0, int key_val1) {
+  auto S = [](long long v) { return std::to_string(v); };
+  std::string src;
+  src += R"SRC(
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+typedef unsigned long long U64;
+typedef long long I64;
+typedef unsigned int U32;
+typedef int I32;
+typedef unsigned char U8;
+#define BLOCK 256
+#define LIMB_MASK ((1ull << 43) - 1ull)
+struct Args {
+  const void* col[10];
+  const U64* valid[10];
+  U64* tmp_lo[16];
+  U64* tmp_hi[16];
+  unsigned int* g_first;
+  unsigned int* g_seen;
+  long long begin, end;
+  int L, nrep;
+};
+enum { SUM_I64 = 0, SUM_I128 = 1, SUM_F64 = 2, MIN_I64 = 3, MAX_I64 = 4, COUNT = 5, COUNT_STAR = 6 };
+__device__ __forceinline__ double v2f(i128 x) { return __longlong_as_double((long long)(U64)x); }
+__device__ __forceinline__ i128 f2v(double d) { return (i128)(u128)(U64)__double_as_longlong(d); }
+__device__ __forceinline__ long long f64ord(U64 bits) { long long b = (long long)bits; return b ^ (long long)((U64)(b >> 63) >> 1); }
+__device__ __forceinline__ bool kt(i128 v, bool n) { return !n && ((int)v & 1); }
+__device__ __forceinline__ bool kf(i128 v, bool n) { return !n && !((int)v & 1); }
+__device__ __forceinline__ U64 identity_of(int kind) {
+  return kind == MIN_I64 ? 0x7fffffffffffffffull : kind == MAX_I64 ? 0x8000000000000000ull : 0ull;
+}
+__device__ __forceinline__ int local_slot(unsigned int* s_key, int L, unsigned int key) {
+  const unsigned int want = key + 1u;
+  int slot = (int)((key * 0x9E3779B1u) >> 20) & (L - 1);
+  for (int probe = 0; probe < L; probe++) {
+    unsigned int cur = s_key[slot];
+    if (cur == want) return slot;
+    if (cur == 0u) {
+      cur = atomicCAS(&s_key[slot], 0u, want);
+      if (cur == 0u || cur == want) return slot;
+    }
+    slot = (slot + 1) & (L - 1);
+  }
+  return -1;
+}
+__device__ __forceinline__ void global_accumulate(int kind, U64* lo_cell, U64* hi_cell, U64 lo, U64 hi) {
+  switch (kind) {
+    case SUM_I64: atomicAdd(lo_cell, lo); break;
+    case SUM_I128: {
+      U64 old = atomicAdd(lo_cell, lo);
+      atomicAdd(hi_cell, hi + ((old + lo) < old ? 1ull : 0ull));
+      break;
+    }
+    case SUM_F64: atomicAdd(reinterpret_cast<double*>(lo_cell), __longlong_as_double((long long)lo)); break;
+    case MIN_I64: atomicMin(reinterpret_cast<long long*>(lo_cell), (long long)lo); break;
+    case MAX_I64: atomicMax(reinterpret_cast<long long*>(lo_cell), (long long)lo); break;
+    default: atomicAdd(lo_cell, 1ull); break;
+  }
+}
+)SRC";
+  src += "#define NACC " + S(accs.n) + "\n#define NCELL " + S(accs.ncell) + "\n";
+  src += "__device__ __forceinline__ int acc_kind(int k) { switch (k) {";
+  for (int k = 0; k < accs.n; k++) src += " case " + S(k) + ": return " + S(accs.a[k].kind) + ";";
+  src += " default: return 0; } }\n";
+  src += "__device__ __forceinline__ int acc_cell0(int k) { switch (k) {";
+  for (int k = 0; k < accs.n; k++) src += " case " + S(k) + ": return " + S(accs.a[k].cell0) + ";";
+  src += " default: return 0; } }\n";
+  src += "__device__ __forceinline__ int cell_kind(int c) { switch (c) {";
+  for (int c = 0; c < accs.ncell; c++) src += " case " + S(c) + ": return " + S(accs.cell_kind[c]) + ";";
+  src += " default: return 0; } }\n";
+  src += R"SRC(
+extern "C" __global__ __launch_bounds__(BLOCK) void agg_node(Args a) {
+  extern __shared__ U64 s_cell[];  // cell(c, slot, rep) = (c * L + slot) * nrep + rep
+  const int L = a.L, nrep = a.nrep, plane = L * nrep, ncells = NCELL * plane;
+  unsigned int* s_seen = (unsigned int*)(s_cell + ncells);
+  unsigned int* s_key = s_seen + plane;
+  unsigned int* s_first = s_key + L;
+  for (int x = threadIdx.x; x < ncells; x += BLOCK) s_cell[x] = identity_of(cell_kind(x / plane));
+  for (int x = threadIdx.x; x < plane; x += BLOCK) s_seen[x] = 0u;
+  for (int x = threadIdx.x; x < L; x += BLOCK) { s_key[x] = 0u; s_first[x] = 0xFFFFFFFFu; }
+  __syncthreads();
+  const int rep = (int)(threadIdx.x & (unsigned)(nrep - 1));
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = a.begin + (long long)blockIdx.x * BLOCK + threadIdx.x; i < a.end; i += stride) {
+)SRC";
+  src += cp.src_loads;
+  src += cp.src_pred;
+  if (cp.src_pred_val >= 0) src += "    if (N" + S(cp.src_pred_val) + " || !((int)V" + S(cp.src_pred_val) + " & 1)) continue;\n";
+  src += cp.src_outs;
+  src += "    unsigned int key = 0u;\n";
+  if (key_val0 >= 0) src += "    key = (unsigned int)V" + S(key_val0) + " & 0xFFu;\n";
+  if (key_val1 >= 0) src += "    key |= ((unsigned int)V" + S(key_val1) + " & 0xFFu) << 8;\n";
+  src += R"SRC(    const int slot = local_slot(s_key, L, key);
+    unsigned int seen = 0u;
+    if (slot >= 0) {
+      if ((unsigned int)i < s_first[slot]) atomicMin(&s_first[slot], (unsigned int)i);
+      const int base = slot * nrep + rep;
+)SRC";
+  auto value_of = [&](int k, std::string& vlo, std::string& vhi, std::string& guard) {
+    if (acc_val[k] >= 0) {
+      vlo = "(U64)V" + S(acc_val[k]);
+      vhi = "(U64)((u128)V" + S(acc_val[k]) + " >> 64)";
+      guard = "if (!N" + S(acc_val[k]) + ") ";
+    } else {
+      vlo = vhi = "0ull";
+      guard = "";
+    }
+  };
+  for (int k = 0; k < accs.n; k++) {
+    std::string vlo, vhi, guard;
+    value_of(k, vlo, vhi, guard);
+    const std::string c = "(s_cell + " + S(accs.a[k].cell0) + " * plane + base)";
+    src += "      " + guard + "{ seen |= " + S(1u << k) + "u; ";
+    switch (accs.a[k].kind) {
+      case ACC_SUM_I128:
+        src += "const U64 lo = " + vlo + ", hi = " + vhi + "; U64* c = " + c + "; atomicAdd(c, lo & LIMB_MASK); atomicAdd(c + plane, ((lo >> 43) | (hi << 21)) & LIMB_MASK); "
+               "atomicAdd(c + 2 * plane, (U64)((long long)hi >> 22));";
+        break;
+      case ACC_SUM_I64: src += "atomicAdd(" + c + ", " + vlo + ");"; break;
+      case ACC_SUM_F64: src += "atomicAdd(reinterpret_cast<double*>" + c + ", __longlong_as_double((long long)" + vlo + "));"; break;
+      case ACC_MIN_I64: src += "atomicMin(reinterpret_cast<long long*>" + c + ", (long long)" + vlo + ");"; break;
+      case ACC_MAX_I64: src += "atomicMax(reinterpret_cast<long long*>" + c + ", (long long)" + vlo + ");"; break;
+      default: src += "atomicAdd(" + c + ", 1ull);"; break;
+    }
+    src += " }\n";
+  }
+  src += "      if (seen & ~s_seen[base]) atomicOr(&s_seen[base], seen);\n    } else {\n";
+  src += "      if ((unsigned int)i < a.g_first[key]) atomicMin(&a.g_first[key], (unsigned int)i);\n";
+  for (int k = 0; k < accs.n; k++) {
+    std::string vlo, vhi, guard;
+    value_of(k, vlo, vhi, guard);
+    src += "      " + guard + "{ seen |= " + S(1u << k) + "u; global_accumulate(" + S(accs.a[k].kind) + ", a.tmp_lo[" + S(k) + "] + key, a.tmp_hi[" + S(k) +
+           "] ? a.tmp_hi[" + S(k) + "] + key : nullptr, " + vlo + ", " + vhi + "); }\n";
+  }
+  src += R"SRC(      if (seen) atomicOr(&a.g_seen[key], seen);
+    }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < L * NACC; x += BLOCK) {
+    const int slot = x / NACC, k = x % NACC;
+    const unsigned int kv = s_key[slot];
+    if (!kv) continue;
+    const unsigned int key = kv - 1u;
+    unsigned int seen = 0u;
+    for (int q = 0; q < nrep; q++) seen |= s_seen[slot * nrep + q];
+    if (!((seen >> k) & 1u)) continue;
+    const U64* c = s_cell + acc_cell0(k) * plane + slot * nrep;
+    int kind = acc_kind(k);
+    U64 lo = identity_of(kind), hi = 0ull;
+    if (kind == SUM_I128) {
+      U64 s0 = 0, s1 = 0, s2 = 0;
+      for (int q = 0; q < nrep; q++) { s0 += c[q]; s1 += c[plane + q]; s2 += c[2 * plane + q]; }
+      u128 v = (u128)s0 + ((u128)s1 << 43) + (u128)((i128)(long long)s2 << 86);
+      lo = (U64)v;
+      hi = (U64)(v >> 64);
+    } else {
+      for (int q = 0; q < nrep; q++) {
+        const U64 v = c[q];
+        switch (kind) {
+          case SUM_F64: lo = (U64)__double_as_longlong(__longlong_as_double((long long)lo) + __longlong_as_double((long long)v)); break;
+          case MIN_I64: lo = (U64)min((long long)lo, (long long)v); break;
+          case MAX_I64: lo = (U64)max((long long)lo, (long long)v); break;
+          default: lo += v; break;
+        }
+      }
+      if (kind == COUNT || kind == COUNT_STAR) kind = SUM_I64;
+    }
+    global_accumulate(kind, a.tmp_lo[k] + key, a.tmp_hi[k] ? a.tmp_hi[k] + key : nullptr, lo, hi);
+    atomicOr(&a.g_seen[key], 1u << k);
+  }
+  for (int slot = threadIdx.x; slot < L; slot += BLOCK)
+    if (s_key[slot] && s_first[slot] != 0xFFFFFFFFu) atomicMin(&a.g_first[s_key[slot] - 1u], s_first[slot]);
+}
+)SRC";
+  return src;
+}
+
+// The single-pass small-domain node (k_agg_fused_tile).  `cp` = predicate + key bytes + arguments.
+// Returns false (state untouched) when the forest has no tile form or the LDS budget does not fit.
+constexpr size_t TILE_LDS_BUDGET = 64 * 1024;  // per workgroup: at least two workgroups per CU (160 KiB LDS)
+static bool agg_update_small_single_pass(Aggregate& A, const Table& in, const CompiledProgram& cp, const std::vector<int>& small_cols, const int* key_out,
+                                         const std::vector<int>& arg_out) {
+  Runtime& r = rt();
+  const int64_t n = in.nrows;
+  const int ngk = (int)small_cols.size();
+  const int D = ngk == 0 ? 1 : ngk == 1 ? 256 : SMALL_DOMAIN;
+  DFGPU_CHECK(n < 0xFFFFFFFFll, "aggregate input exceeds u32 row ids");
+  const TileProgram& T = cp.tile;
+  if (T.n_wide < 0) return false;
+  const size_t regfile = tile_regfile_bytes(T.n_wide, T.n_narrow);
+  if (regfile + 4096 > TILE_LDS_BUDGET) return false;
+  // ---- accumulator entries and their LDS cells
+  struct Entry { int agg; bool is_avg_count; int kind; int opnd; int val; };
+  std::vector<Entry> entries;
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    dfgpu_field t = a.typed ? a.in_type : (a.has_arg ? cp.out_types[arg_out[k]] : fld(DFGPU_INT64));
+    AccPlan pl = plan_for(a.func, t, false);
+    int kind = (a.func == DFGPU_AGG_COUNT && !a.has_arg) ? ACC_COUNT_STAR : pl.kind;
+    int opnd = a.has_arg ? cp.tile_outs[arg_out[k]] : -1;
+    int val = a.has_arg ? cp.src_out_vals[arg_out[k]] : -1;
+    entries.push_back({(int)k, false, kind, opnd, val});
+    if (a.func == DFGPU_AGG_AVG) entries.push_back({(int)k, true, ACC_COUNT, opnd, val});
+  }
+  DFGPU_CHECK((int)entries.size() <= MAX_AGGS, "too many aggregates for one GPU aggregate node");
+  SmallAccSet accs{};
+  std::vector<int> src_of(entries.size(), -1);  // entry -> unique accumulator: SUM(x) and AVG(x) share one sum
+  std::vector<int> acc_val;                     // unique accumulator -> value id in the generated source
+  int ncell = 0;
+  for (size_t ei = 0; ei < entries.size(); ei++) {
+    const Entry& e = entries[ei];
+    for (int u = 0; u < accs.n && src_of[ei] < 0; u++)
+      if (accs.a[u].kind == e.kind && accs.a[u].reg == e.opnd) src_of[ei] = u;
+    if (src_of[ei] >= 0) continue;
+    const int w = e.kind == ACC_SUM_I128 ? 3 : 1;
+    if (ncell + w > SM_MAX_CELLS) return false;
+    src_of[ei] = accs.n;
+    acc_val.push_back(e.val);
+    SmallAcc& d = accs.a[accs.n++];
+    d.kind = (int16_t)e.kind;
+    d.reg = (int16_t)e.opnd;
+    d.cell0 = (int16_t)ncell;
+    for (int j = 0; j < w; j++) accs.cell_kind[ncell + j] = (uint8_t)(e.kind == ACC_SUM_I128 ? ACC_SUM_I64 : e.kind);
+    ncell += w;
+  }
+  accs.ncell = ncell;
+  if (accs.n == 0) return false;
+  // LDS left for accumulator planes: (slot, replica) entries of ncell cells + a seen word
+  const size_t plane_bytes = (size_t)ncell * 8 + 4;
+  const int plane_max = (int)std::min<size_t>((TILE_LDS_BUDGET - regfile - 2048) / plane_bytes, 4096);
+  auto slots_for = [&](int64_t groups) {
+    int L = 1;
+    while (L < groups && L < SM_MAX_L && L < D) L *= 2;
+    return L;
+  };
+  if (D > 1 && slots_for(std::max<int64_t>(A.ngroups, 1)) > plane_max) return false;  // too many groups for LDS: two-pass node
+
+  // ---- key-indexed partials (reset per range)
+  std::vector<BufPtr> keep;
+  for (int k = 0; k < accs.n; k++) {
+    SmallAcc& d = accs.a[k];
+    BufPtr lo = make_buf((size_t)D * 8);
+    keep.push_back(lo);
+    d.tmp_lo = lo->as<unsigned long long>();
+    if (d.kind == ACC_SUM_I128) {
+      BufPtr hi = make_buf((size_t)D * 8);
+      keep.push_back(hi);
+      d.tmp_hi = hi->as<unsigned long long>();
+    }
+  }
+  BufPtr g_first = make_buf((size_t)D * 4);
+  BufPtr g_seen = make_buf((size_t)D * 4);
+  const int ko0 = ngk > 0 ? cp.tile_outs[key_out[0]] : -1, ko1 = ngk > 1 ? cp.tile_outs[key_out[1]] : -1;
+  const bool prefetch = env_int("DFGPU_AGG_PREFETCH", 1) != 0;
+  DFGPU_HIP(hipFuncSetAttribute((const void*)k_agg_fused_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_BUDGET));
+  DFGPU_HIP(hipFuncSetAttribute((const void*)k_agg_fused_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_BUDGET));
+
+  // large inputs run the node specialised for this forest (jit.hip); DFGPU_JIT=0 keeps the interpreter
+  const int64_t jit_min_rows = env_int("DFGPU_JIT_MIN_ROWS", 1 << 22);
+  const int plane_max_jit = (int)std::min<size_t>((TILE_LDS_BUDGET - 2048) / plane_bytes, 4096);
+  hipFunction_t jit_fn = nullptr;
+  if (env_int("DFGPU_JIT", 1) != 0 && n >= jit_min_rows) {
+    try {
+      jit_fn = jit_get(agg_node_source(cp, accs, acc_val, ngk > 0 ? cp.src_out_vals[key_out[0]] : -1, ngk > 1 ? cp.src_out_vals[key_out[1]] : -1), "agg_node");
+    } catch (const Error& e) {
+      if (env_int("DFGPU_JIT_STRICT", 0)) throw;
+      fprintf(stderr, "[dfgpu] node specialisation failed, using the interpreter: %s\n", e.what());
+    }
+  }
+
+  auto run_range = [&](int64_t begin, int64_t end) {
+    const int64_t m = end - begin;
+    for (int k = 0; k < accs.n; k++) {
+      SmallAcc& d = accs.a[k];
+      k_fill_u64<<<grid_for(D, BLOCK), BLOCK, 0, r.stream>>>(acc_identity(d.kind), D, d.tmp_lo);
+      if (d.tmp_hi) DFGPU_HIP(hipMemsetAsync(d.tmp_hi, 0, (size_t)D * 8, r.stream));
+    }
+    DFGPU_HIP(hipMemsetAsync(g_first->ptr, 0xFF, (size_t)D * 4, r.stream));
+    DFGPU_HIP(hipMemsetAsync(g_seen->ptr, 0, (size_t)D * 4, r.stream));
+    // local slots: the groups known so far (unknown: 16), replicas: what the LDS budget leaves, up to one per lane
+    const bool use_jit = jit_fn != nullptr && m >= jit_min_rows;
+    const int pmax = use_jit ? plane_max_jit : plane_max;
+    int L = D == 1 ? 1 : slots_for(A.ngroups > 0 ? A.ngroups : 16);
+    while (L > 1 && L > pmax) L /= 2;
+    int nrep = 1;
+    while (nrep * 2 <= WAVE && L * nrep * 2 <= pmax) nrep *= 2;
+    if (m > 0) {
+      const int plane = L * nrep;
+      const size_t cell_bytes = (size_t)ncell * plane * 8 + (size_t)plane * 4 + (size_t)L * 8;
+      int grid = grid_for(m, BLOCK * 4);
+      const int64_t min_grid = (m >> 20) + 1;  // < 2^20 rows per workgroup: limb sums cannot wrap (see kernel header)
+      if (grid < min_grid) grid = (int)min_grid;
+      if (use_jit) {
+        ProfileScope ps("agg_fused_jit", m * cp.input_bytes_per_row);
+        AggNodeArgs args{};
+        for (int c = 0; c < T.n_cols; c++) {
+          args.col[c] = T.col_data[c];
+          args.valid[c] = T.col_valid[c];
+        }
+        for (int k = 0; k < accs.n; k++) {
+          args.tmp_lo[k] = accs.a[k].tmp_lo;
+          args.tmp_hi[k] = accs.a[k].tmp_hi;
+        }
+        args.g_first = g_first->as<uint32_t>();
+        args.g_seen = g_seen->as<uint32_t>();
+        args.begin = begin;
+        args.end = end;
+        args.L = L;
+        args.nrep = nrep;
+        jit_launch(jit_fn, grid, BLOCK, cell_bytes, &args, sizeof(args));
+      } else {
+        ProfileScope ps("agg_fused_tile", m * cp.input_bytes_per_row);
+        const size_t lds = regfile + cell_bytes;
+        if (prefetch) k_agg_fused_tile<true><<<grid, BLOCK, lds, r.stream>>>(T, cp.tile_pred, ko0, ko1, accs, begin, end, L, nrep, g_first->as<uint32_t>(), g_seen->as<uint32_t>());
+        else k_agg_fused_tile<false><<<grid, BLOCK, lds, r.stream>>>(T, cp.tile_pred, ko0, ko1, accs, begin, end, L, nrep, g_first->as<uint32_t>(), g_seen->as<uint32_t>());
+        DFGPU_HIP(hipGetLastError());
+      }
+    }
+    // ---- number the new groups in first-seen order
+    const int64_t G0 = A.ngroups;
+    std::vector<uint32_t> hfirst((size_t)D);
+    d2h(hfirst.data(), g_first->ptr, (size_t)D * 4);
+    std::vector<uint32_t> touched_keys, touched_gids;
+    if (ngk == 0) {
+      touched_keys.push_back(0);
+      touched_gids.push_back(0);
+      A.ngroups = 1;  // AggregateStream: one output row even for empty input
+    } else {
+      small_sync_host_keys(A, ngk);
+      std::vector<int64_t> gid_of((size_t)D, -1);
+      for (int64_t g = 0; g < G0; g++) gid_of[A.small_keys[(size_t)g]] = g;
+      std::vector<std::pair<uint32_t, uint32_t>> fresh;  // (first row, key)
+      for (uint32_t k = 0; k < (uint32_t)D; k++)
+        if (hfirst[k] != 0xFFFFFFFFu && gid_of[k] < 0) fresh.push_back({hfirst[k], k});
+      std::sort(fresh.begin(), fresh.end());  // first-seen order (group_values/mod.rs:88-92)
+      for (auto& fk : fresh) {
+        gid_of[fk.second] = (int64_t)A.small_keys.size();
+        A.small_keys.push_back((uint16_t)fk.second);
+      }
+      for (uint32_t k = 0; k < (uint32_t)D; k++)
+        if (hfirst[k] != 0xFFFFFFFFu) {
+          touched_keys.push_back(k);
+          touched_gids.push_back((uint32_t)gid_of[k]);
+        }
+      if (!fresh.empty() || (int)A.group_keys.cols.size() != ngk) small_rebuild_group_keys(A, in, small_cols);
+      A.ngroups = (int64_t)A.small_keys.size();
+    }
+    const int64_t G1 = A.ngroups;
+    grow_accumulators(A, G0, G1);
+    // ---- merge the key-indexed partials
+    const int K = (int)touched_keys.size();
+    if (K > 0) {
+      MergeDst dst{};
+      dst.n = (int)entries.size();
+      for (int ei = 0; ei < dst.n; ei++) {
+        const Entry& e = entries[(size_t)ei];
+        AggState& a = A.aggs[(size_t)e.agg];
+        dst.src[ei] = src_of[(size_t)ei];
+        if (e.is_avg_count) {
+          dst.lo[ei] = a.cnt->as<unsigned long long>();
+        } else {
+          dst.lo[ei] = a.lo->as<unsigned long long>();
+          dst.hi[ei] = a.hi ? a.hi->as<unsigned long long>() : nullptr;
+          dst.seen[ei] = a.seen->as<uint32_t>();
+        }
+      }
+      BufPtr dk = make_buf((size_t)K * 4), dg = make_buf((size_t)K * 4);
+      h2d_async(dk->ptr, touched_keys.data(), (size_t)K * 4);
+      h2d_async(dg->ptr, touched_gids.data(), (size_t)K * 4);
+      k_small_merge<<<grid_for((int64_t)K * dst.n, BLOCK), BLOCK, 0, r.stream>>>(dk->as<uint32_t>(), dg->as<uint32_t>(), K, accs, dst, g_seen->as<uint32_t>());
+      DFGPU_HIP(hipGetLastError());
+      DFGPU_HIP(hipStreamSynchronize(r.stream));  // host vectors are released on return
+    }
+  };
+  // The first update of a large input learns the number of groups from a short prefix, so the bulk runs with
+  // exactly-sized local tables and as many accumulator replicas as LDS allows.
+  const int64_t prefix = 1 << 18;
+  if (A.ngroups == 0 && D > 1 && n > 4 * prefix) {
+    run_range(0, prefix);
+    run_range(prefix, n);
+  } else {
+    run_range(0, n);
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  return true;
+}
+
 // Returns false (nothing changed) when the forest cannot be fused; the caller then takes the
 // column-at-a-time path.
 static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pred, std::string& why) {
@@ -733,6 +1383,9 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
       a.typed = true;
     }
   }
+  if (gid_mode != GID_HASH && env_int("DFGPU_AGG_SINGLE_PASS", 1) != 0 &&
+      agg_update_small_single_pass(A, in, cp, small_cols, key_out, arg_out))
+    return true;
   const int64_t G0 = A.ngroups;
   int64_t G1 = G0;
   GidSpec gs{};

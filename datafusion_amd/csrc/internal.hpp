@@ -185,6 +185,18 @@ dfgpu_field expr_type(const dfgpu_expr& e, const Table& input);
 Datum evaluate(const dfgpu_expr& e, const Table& input);
 Column datum_to_column(const Datum& d, int64_t n, const std::string& name);
 
+// ----------------------------------------------------------------- runtime specialisation (jit.hip)
+// compiles `source` with hiprtc for gfx950 (cached per process by source text) and returns `kernel_name`
+hipFunction_t jit_get(const std::string& source, const char* kernel_name);
+// launches on the library stream; `args` is the kernel's single by-value argument struct
+void jit_launch(hipFunction_t fn, int grid, int block, size_t lds_bytes, void* args, size_t args_bytes);
+
+// ----------------------------------------------------------------- runtime specialisation (jit.hip)
+// compiles `source` with hiprtc for gfx950 (cached per process by source text) and returns `kernel_name`
+hipFunction_t jit_get(const std::string& source, const char* kernel_name);
+// launches on the library stream; `args` is the kernel's single by-value argument struct
+void jit_launch(hipFunction_t fn, int grid, int block, size_t lds_bytes, void* args, size_t args_bytes);
+
 // ----------------------------------------------------------------- hashing (partition.hip)
 void hash_columns(const std::vector<const Column*>& keys, int64_t n, uint64_t seed, uint64_t* out, bool force_collisions);
 

@@ -4,6 +4,10 @@
 // (the reference's planner does the same at plan level: `__common_expr_1` in
 // sqllogictest/test_files/tpch/plans/q1.slt.part:45-46); literal-only subtrees are folded with
 // the column-at-a-time evaluator's own scalar path so both evaluators agree bit for bit.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
 #include "rowprog_host.hpp"
 
 namespace dfgpu {
@@ -23,7 +27,7 @@ static i128 pow10(int k) {
 }
 static int physical_type(int t) { return t == DFGPU_DATE32 ? DFGPU_INT32 : t; }
 
-int RowProgramCompiler::emit(uint8_t op, int a, int b, uint32_t aux, int slot, bool lit_null) {
+int RowProgramCompiler::emit(uint8_t op, int a, int b, uint32_t aux, int slot, bool lit_null, bool wide) {
   auto key = std::make_tuple((int)op, a, b, aux, slot);
   auto it = cse_.find(key);
   if (it != cse_.end()) return it->second;
@@ -34,6 +38,7 @@ int RowProgramCompiler::emit(uint8_t op, int a, int b, uint32_t aux, int slot, b
   v.aux = aux;
   v.slot = slot;
   v.lit_null = lit_null;
+  v.wide = wide;
   v.seg = (op == RP_LIT) ? 0 : (op == 0xFF ? -1 : seg_);
   vals_.push_back(v);
   int id = (int)vals_.size() - 1;
@@ -51,7 +56,8 @@ RpValue RowProgramCompiler::column(int idx) {
     slot = (int)slot_col_.size() - 1;
     if (slot >= RP_MAX_COLS) fail("more than " + std::to_string(RP_MAX_COLS) + " input columns");
   }
-  return RpValue{emit(0xFF, -1, -1, 0, slot), in_.cols[idx].field};
+  const int ct = in_.cols[idx].field.type;
+  return RpValue{emit(0xFF, -1, -1, 0, slot, false, ct == DFGPU_DECIMAL128 || ct == DFGPU_UINT64), in_.cols[idx].field};
 }
 
 RpValue RowProgramCompiler::literal(const dfgpu_field& f, uint64_t lo, uint64_t hi, bool is_null) {
@@ -80,7 +86,7 @@ RpValue RowProgramCompiler::rescale(RpValue x, int by_digits) {
     return literal_i128(x.type, (i128)(bits * (u128)pow10(by_digits)));
   }
   RpValue m = literal_i128(mk(DFGPU_DECIMAL128, 38, 0), pow10(by_digits));
-  return RpValue{emit(RP_MUL, x.id, m.id, 0), x.type};
+  return RpValue{emit(RP_MUL, x.id, m.id, 0, -1, false, true), x.type};
 }
 
 // fold `op` over literal operands through expr.hip's scalar path (no kernel is launched for scalars)
@@ -187,7 +193,7 @@ RpValue RowProgramCompiler::lower_binary(int op, RpValue a, RpValue b) {
         a = rescale(a, out.scale - lt.scale);
         b = rescale(b, out.scale - rtp.scale);
       }
-      return RpValue{emit(iop, a.id, b.id, 0), out};
+      return RpValue{emit(iop, a.id, b.id, 0, -1, false, true), out};
     }
     case DFGPU_INT32: return RpValue{emit(RP_SEXT32, emit(iop, a.id, b.id, 0), -2, 0), out};
     case DFGPU_INT64: return RpValue{emit(RP_SEXT64, emit(iop, a.id, b.id, 0), -2, 0), out};
@@ -366,6 +372,181 @@ bool RowProgramCompiler::finish(CompiledProgram& cp, std::string& why) {
   for (const RpValue& o : outs_) {
     cp.out_regs.push_back(reg[o.id]);
     cp.out_types.push_back(o.type);
+  }
+  // ---- the same forest as a TileProgram: literals become operands, lane registers are allocated per width class
+  {
+    TileProgram& T = cp.tile;
+    T = TileProgram{};
+    std::vector<int> treg(nv, -1);      // class-local register index
+    std::vector<bool> wbusy(64, false), nbusy(64, false);
+    int n_wide = 0, n_narrow = 0;
+    auto talloc = [&](bool wide) -> int {
+      std::vector<bool>& busy_c = wide ? wbusy : nbusy;
+      for (int r2 = 0; r2 < 64; r2++)
+        if (!busy_c[r2]) {
+          busy_c[r2] = true;
+          int& hi = wide ? n_wide : n_narrow;
+          hi = std::max(hi, r2 + 1);
+          return r2;
+        }
+      return -1;
+    };
+    for (int v = 0; v < nv; v++)
+      if (vals_[v].op == 0xFF) treg[v] = talloc(vals_[v].wide);
+    struct Pending { int v; };
+    std::vector<Pending> emitted;
+    for (int i = 0; i < n_ins; i++) {
+      const int v = order[i];
+      const Val& x = vals_[v];
+      if (x.op == RP_LIT) continue;
+      auto release = [&](int o) {
+        if (o < 0) return;
+        if (vals_[o].op == 0xFF || vals_[o].op == RP_LIT) return;
+        if (last_use[o] == i && treg[o] >= 0) (vals_[o].wide ? wbusy : nbusy)[treg[o]] = false;
+      };
+      release(x.a);
+      if (x.b != x.a) release(x.b);
+      treg[v] = talloc(x.wide);
+      emitted.push_back({v});
+    }
+    const bool fits = n_wide + n_narrow <= 32 && (int)emitted.size() <= RP_MAX_INS;
+    if (fits) {
+      auto opnd = [&](int v) -> uint8_t {
+        if (vals_[v].op == RP_LIT) return (uint8_t)(TP_LIT | vals_[v].slot);
+        return (uint8_t)(vals_[v].wide ? treg[v] : n_wide + treg[v]);
+      };
+      T.n_ins = 0;
+      T.n_pred_end = 0;
+      for (const Pending& e : emitted) {
+        const Val& x = vals_[e.v];
+        RpIns ins{};
+        ins.op = x.op;
+        ins.dst = opnd(e.v);
+        ins.a = opnd(x.a);
+        ins.b = x.b >= 0 ? opnd(x.b) : ins.a;
+        ins.aux = x.aux;
+        T.ins[T.n_ins++] = ins;
+        if (x.seg <= 1) T.n_pred_end = T.n_ins;
+      }
+      T.n_cols = n_cols;
+      for (int v = 0; v < nv; v++)
+        if (vals_[v].op == 0xFF) T.col_reg[vals_[v].slot] = opnd(v);
+      for (int sl = 0; sl < n_cols; sl++) {
+        T.col_data[sl] = P.col_data[sl];
+        T.col_valid[sl] = P.col_valid[sl];
+        T.col_kind[sl] = P.col_kind[sl];
+      }
+      for (size_t i = 0; i < lits_.size(); i++) {
+        T.lit_lo[i] = lits_[i].first;
+        T.lit_hi[i] = lits_[i].second;
+      }
+      for (int v = 0; v < nv; v++)
+        if (vals_[v].op == RP_LIT && vals_[v].lit_null) T.lit_nulls |= 1u << vals_[v].slot;
+      T.n_wide = n_wide;
+      T.n_narrow = n_narrow;
+      cp.tile_pred = pred_ >= 0 ? opnd(pred_) : -1;
+      for (const RpValue& o : outs_) cp.tile_outs.push_back(opnd(o.id));
+    } else {
+      T.n_wide = T.n_narrow = -1;  // no tile form
+    }
+  }
+  // ---- the same forest as HIP source (one `const i128 V<id>` + `const bool N<id>` per value)
+  {
+    auto V = [](int v) { return "V" + std::to_string(v); };
+    auto N = [](int v) { return "N" + std::to_string(v); };
+    auto hex = [](uint64_t x) {
+      char b[32];
+      snprintf(b, sizeof b, "0x%016llxull", (unsigned long long)x);
+      return std::string(b);
+    };
+    static const char* cmp_ops[] = {"==", "!=", "<", "<=", ">", ">="};
+    auto cmp_str = [&](uint32_t aux) -> const char* {
+      switch (aux) {
+        case DFGPU_EXPR_EQ: return cmp_ops[0];
+        case DFGPU_EXPR_NE: return cmp_ops[1];
+        case DFGPU_EXPR_LT: return cmp_ops[2];
+        case DFGPU_EXPR_LE: return cmp_ops[3];
+        case DFGPU_EXPR_GT: return cmp_ops[4];
+        default: return cmp_ops[5];
+      }
+    };
+    std::string loads, pred_src, outs_src;
+    for (int v = 0; v < nv; v++) {
+      const Val& x = vals_[v];
+      if (x.op != 0xFF) continue;
+      const std::string sl = std::to_string(x.slot), c = "C" + sl;
+      std::string decl, widen;
+      switch (P.col_kind[x.slot]) {
+        case RPL_I32: decl = "const I32 " + c + " = ((const I32*)a.col[" + sl + "])[i];"; widen = "(i128)" + c; break;
+        case RPL_U32: decl = "const U32 " + c + " = ((const U32*)a.col[" + sl + "])[i];"; widen = "(i128)" + c; break;
+        case RPL_I64: decl = "const I64 " + c + " = ((const I64*)a.col[" + sl + "])[i];"; widen = "(i128)" + c; break;
+        case RPL_U64: case RPL_F64: decl = "const U64 " + c + " = ((const U64*)a.col[" + sl + "])[i];"; widen = "(i128)(u128)" + c; break;
+        case RPL_U8: decl = "const U8 " + c + " = ((const U8*)a.col[" + sl + "])[i];"; widen = "(i128)" + c; break;
+        case RPL_I128: decl = "const i128 " + c + " = ((const i128*)a.col[" + sl + "])[i];"; widen = c; break;
+        default: decl = "const U64 " + c + " = (((const U64*)a.col[" + sl + "])[i >> 6] >> (i & 63)) & 1ull;"; widen = "(i128)" + c; break;
+      }
+      loads += "    " + decl + "\n    const i128 " + V(v) + " = " + widen + ";\n";
+      if (P.col_valid[x.slot]) loads += "    const bool " + N(v) + " = !((a.valid[" + sl + "][i >> 6] >> (i & 63)) & 1ull);\n";
+      else loads += "    const bool " + N(v) + " = false;\n";
+    }
+    for (int i = 0; i < n_ins; i++) {
+      const int v = order[i];
+      const Val& x = vals_[v];
+      std::string st;
+      const std::string A = x.a >= 0 ? V(x.a) : "", B = x.b >= 0 ? V(x.b) : A;
+      const std::string NA = x.a >= 0 ? N(x.a) : "false", NB = x.b >= 0 ? N(x.b) : NA;
+      std::string val, nul = "(" + NA + " || " + NB + ")";
+      switch (x.op) {
+        case RP_LIT:
+          val = "(i128)(((u128)" + hex(lits_[x.slot].second) + " << 64) | (u128)" + hex(lits_[x.slot].first) + ")";
+          nul = x.lit_null ? "true" : "false";
+          break;
+        case RP_ADD: val = "(i128)((u128)" + A + " + (u128)" + B + ")"; break;
+        case RP_SUB: val = "(i128)((u128)" + A + " - (u128)" + B + ")"; break;
+        case RP_MUL: val = "(i128)((u128)" + A + " * (u128)" + B + ")"; break;
+        case RP_SEXT32: val = "(i128)(I32)(U32)(U64)" + A; nul = NA; break;
+        case RP_SEXT64: val = "(i128)(I64)(U64)" + A; nul = NA; break;
+        case RP_FADD: val = "f2v(v2f(" + A + ") + v2f(" + B + "))"; break;
+        case RP_FSUB: val = "f2v(v2f(" + A + ") - v2f(" + B + "))"; break;
+        case RP_FMUL: val = "f2v(v2f(" + A + ") * v2f(" + B + "))"; break;
+        case RP_I2F: val = "f2v((double)(I64)(U64)" + A + ")"; nul = NA; break;
+        case RP_F64ORD: val = "(i128)f64ord((U64)" + A + ")"; nul = NA; break;
+        case RP_CMP: val = "(i128)(" + A + " " + cmp_str(x.aux) + " " + B + ")"; break;
+        case RP_FCMP: val = "(i128)(f64ord((U64)" + A + ") " + cmp_str(x.aux) + " f64ord((U64)" + B + "))"; break;
+        case RP_AND:
+          val = "(i128)(kt(" + A + "," + NA + ") && kt(" + B + "," + NB + "))";
+          nul = "!((kt(" + A + "," + NA + ") && kt(" + B + "," + NB + ")) || kf(" + A + "," + NA + ") || kf(" + B + "," + NB + "))";
+          break;
+        case RP_OR:
+          val = "(i128)(kt(" + A + "," + NA + ") || kt(" + B + "," + NB + "))";
+          nul = "!(kt(" + A + "," + NA + ") || kt(" + B + "," + NB + ") || (kf(" + A + "," + NA + ") && kf(" + B + "," + NB + ")))";
+          break;
+        case RP_NOT: val = "(i128)((" + A + " & 1) ^ 1)"; nul = NA; break;
+        case RP_IS_NULL: val = "(i128)(" + NA + ")"; nul = "false"; break;
+        case RP_IS_NOT_NULL: val = "(i128)(!" + NA + ")"; nul = "false"; break;
+        default: val = A; nul = NA; break;  // RP_MOV
+      }
+      st = "    const i128 " + V(v) + " = " + val + ";\n    const bool " + N(v) + " = " + nul + ";\n";
+      if (x.seg <= 1) pred_src += st;  // literals (seg 0) are declared with the predicate: visible to both segments
+      else outs_src += st;
+    }
+    cp.src_loads = loads;
+    cp.src_pred = pred_src;
+    cp.src_outs = outs_src;
+    cp.src_pred_val = pred_;
+    for (const RpValue& o : outs_) cp.src_out_vals.push_back(o.id);
+  }
+  if (const char* dump = std::getenv("DFGPU_RP_DUMP"); dump && *dump == '1') {
+    static const char* names[] = {"lit", "add", "sub", "mul", "sext32", "sext64", "fadd", "fsub", "fmul", "i2f", "f64ord", "cmp", "fcmp", "and", "or", "not",
+                                  "is_null", "is_not_null", "mov", "mul64", "add64", "sub64", "cmp64"};
+    fprintf(stderr, "[rowprog] cols=%d regs=%d ins=%d (prologue %d, predicate end %d, pred reg %d)\n", n_cols, cp.n_regs, n_ins, n_prologue, n_pred_end, cp.pred_reg);
+    for (int i = 0; i < n_ins; i++)
+      fprintf(stderr, "  %2d: r%-2d = %-8s r%-2d r%-2d aux=%u\n", i, P.ins[i].dst, P.ins[i].op < 23 ? names[P.ins[i].op] : "?", P.ins[i].a, P.ins[i].b, P.ins[i].aux);
+    for (size_t o = 0; o < cp.out_regs.size(); o++) fprintf(stderr, "  out%zu = r%d (%s)\n", o, cp.out_regs[o], type_name(cp.out_types[o]).c_str());
+    fprintf(stderr, "[tileprog] wide=%d narrow=%d ins=%d (predicate end %d, pred operand %d)\n", cp.tile.n_wide, cp.tile.n_narrow, cp.tile.n_ins, cp.tile.n_pred_end, cp.tile_pred);
+    for (int i = 0; i < cp.tile.n_ins; i++)
+      fprintf(stderr, "  %2d: %3d = %-8s %3d %3d aux=%u\n", i, cp.tile.ins[i].dst, cp.tile.ins[i].op < 23 ? names[cp.tile.ins[i].op] : "?", cp.tile.ins[i].a, cp.tile.ins[i].b, cp.tile.ins[i].aux);
+    for (size_t o = 0; o < cp.tile_outs.size(); o++) fprintf(stderr, "  out%zu = %d\n", o, cp.tile_outs[o]);
   }
   return true;
 }

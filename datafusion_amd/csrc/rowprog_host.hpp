@@ -3,6 +3,7 @@
 // stays the fallback whenever a forest does not fit the register file.
 #pragma once
 #include <map>
+#include <string>
 #include <tuple>
 
 #include "internal.hpp"
@@ -28,6 +29,17 @@ struct CompiledProgram {
   std::vector<int> out_regs;
   std::vector<dfgpu_field> out_types;
   int64_t input_bytes_per_row = 0;  // widths of the referenced input columns (algorithmic bytes)
+  // the same forest for the LDS register file interpreter (rowprog.hpp, TileProgram)
+  TileProgram tile{};
+  int tile_pred = -1;          // operand byte of the predicate, -1 = none
+  std::vector<int> tile_outs;  // operand byte per output
+  // the same forest as HIP source for runtime-specialised kernels (jit.hip): statements over `i` (row) and
+  // `a.col[s]` / `a.valid[s]` defining, per value v, `const i128 V<v>` and `const bool N<v>` (NULL flag)
+  std::string src_loads;       // column loads + widening
+  std::string src_pred;        // predicate segment
+  std::string src_outs;        // output segment
+  int src_pred_val = -1;       // value id of the predicate (V<id> / N<id>), -1 = none
+  std::vector<int> src_out_vals;
 };
 
 class RowProgramCompiler {
@@ -51,6 +63,7 @@ class RowProgramCompiler {
     int seg = 2;      // 0 prologue literal, 1 predicate, 2 outputs
     int slot = -1;    // column slot / literal index
     bool lit_null = false;
+    bool wide = false;  // needs a 16-byte register (Decimal128 / UInt64); else the value fits 64 bits sign-extended
   };
   const Table& in_;
   std::vector<Val> vals_;
@@ -63,7 +76,7 @@ class RowProgramCompiler {
   bool failed_ = false;
   std::string why_;
 
-  int emit(uint8_t op, int a, int b, uint32_t aux, int slot = -1, bool lit_null = false);
+  int emit(uint8_t op, int a, int b, uint32_t aux, int slot = -1, bool lit_null = false, bool wide = false);
   RpValue column(int idx);
   RpValue literal(const dfgpu_field& f, uint64_t lo, uint64_t hi, bool is_null);
   RpValue literal_i128(const dfgpu_field& f, i128 v);

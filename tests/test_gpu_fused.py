@@ -1,6 +1,6 @@
 """Fused FilterExec -> ProjectionExec -> AggregateExec node (dfgpu_agg_update_filtered; rowprog register
-programs) against the CPU oracle's filter -> aggregate composition, and against the column-at-a-time GPU
-path (dfgpu_set_fusion(0)).  Integer / Decimal128 bit-exact, Float64 sums within 1e-6 relative."""
+programs, interpreted or compiled into the kernel at plan time) against the CPU oracle's filter -> aggregate
+composition, and against the column-at-a-time GPU path (dfgpu_set_fusion(0)).  Integer / Decimal128 bit-exact, Float64 sums within 1e-6 relative."""
 import datetime
 
 import numpy as np
@@ -13,11 +13,25 @@ from tests.util import random_table, to_oracle_expr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[True, False], ids=["fused", "column_at_a_time"])
+@pytest.fixture(params=["specialised", "interpreted", "column_at_a_time"])
 def fusion(request):
+    """three evaluators of the same node: the forest compiled into the kernel at plan time (jit.hip; forced for
+    every input size here), the per-row register-program interpreter, and column-at-a-time"""
+    import os
+
     from datafusion_amd import ops
-    ops.set_fusion(request.param)
-    yield request.param
+    ops.set_fusion(request.param != "column_at_a_time")
+    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
+    if request.param == "specialised":
+        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+    else:
+        os.environ["DFGPU_JIT"] = "0"
+    yield request.param != "column_at_a_time"
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     ops.set_fusion(True)
 
 
