@@ -7,9 +7,11 @@
 
 A step = one full pass of the hot path over device-resident inputs:
   N = 1 : HashJoinExec build (collect_left_input) + probe (whole lineitem) -> output table.
-  N > 1 : each rank holds a 1/N row range of both tables (what N scans would produce),
-          RepartitionExec(Hash) on the join key = K10 partition kernel + RCCL all-to-all,
-          then the local build + probe.  Total work is fixed (SF100) => "strong" scaling.
+  N > 1 : each rank holds a 1/N row range of both tables (what N scans would produce).  The exchange that
+          moves fewer bytes per GPU is used (SURVEY §8e): PartitionMode::CollectLeft = RCCL all-gather of the
+          build side (B(N-1)/N bytes received per GPU) when B*N < B+P — the SF100 Q3 join up to N = 8 — else
+          PartitionMode::Partitioned = K10 partition kernel + RCCL all-to-all of both sides; then the local
+          build + probe.  Total work is fixed (SF100) => "strong" scaling.
 value = (build rows + probe rows summed over ranks) / max-over-ranks wall time of the K steps.
 Inputs are generated on device (no dataset download possible) before the timed region.
 
@@ -74,6 +76,8 @@ def main():
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor (BASELINE: 100)")
     ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--exchange", choices=["auto", "broadcast", "repartition"], default="auto",
+                    help="N > 1: all-gather the build side (CollectLeft) or hash-repartition both sides (Partitioned); auto = fewer bytes")
     ap.add_argument("--probe-mode", type=int, default=3,
                     help="3 single pass, unordered output (default: in Q3 the join feeds AggregateExec, no ancestor needs the probe "
                          "order); 0/1 two passes, output in probe order; 2 single pass ordered (look-back)")
@@ -104,9 +108,21 @@ def main():
     nb_local, np_local = orders.num_rows, lineitem.num_rows
     ops.sync()
 
+    exchange = "none"
+    if world > 1:
+        from datafusion_amd.exchange import broadcast_build_moves_fewer_bytes
+        t4 = torch.tensor([float(nb_local), float(np_local)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t4)
+        exchange = args.exchange
+        if exchange == "auto":
+            exchange = "broadcast" if broadcast_build_moves_fewer_bytes(int(t4[0]) * 16, int(t4[1]) * 40, world) else "repartition"
+
     def step(probe_mode=args.probe_mode):
         o, l = orders, lineitem
-        if world > 1:
+        if exchange == "broadcast":
+            from datafusion_amd.exchange import broadcast_table
+            o = broadcast_table(orders)
+        elif exchange == "repartition":
             from datafusion_amd.exchange import hash_exchange
             o = hash_exchange(orders, ["o_orderkey"])
             l = hash_exchange(lineitem, ["l_orderkey"])
@@ -119,7 +135,9 @@ def main():
         info = ht.info()
         out.free()
         ht.free()
-        if world > 1:
+        if exchange == "broadcast":
+            o.free()
+        elif exchange == "repartition":
             o.free()
             l.free()
         return n_out, info
@@ -146,7 +164,7 @@ def main():
     # secondary, outside the contract's timed region: the same step with output in probe order
     # (two passes), for plans where an ancestor does need HashJoinExec's probe-side ordering
     ordered_ms = None
-    if args.probe_mode == 3:
+    if args.probe_mode == 3 and world == 1:
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -195,7 +213,9 @@ def main():
                        "build_rows": nb, "probe_rows": np_, "output_rows": nout,
                        "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map"}[info.table_kind],
                        "probe": {0: "two_pass_ordered", 1: "two_pass_ordered", 2: "single_pass_ordered", 3: "single_pass_unordered"}[args.probe_mode],
-                       "parallelism": "single GPU" if world == 1 else f"hash-repartition all-to-all x{world}"},
+                       "parallelism": "single GPU" if world == 1 else
+                       (f"CollectLeft: RCCL all-gather of the build side x{world}, probe side stays range-partitioned" if exchange == "broadcast"
+                        else f"Partitioned: hash-repartition all-to-all of both sides x{world}")},
             "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),
             "hbm_frac_whole_step": round(alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
             "roofline": roof, "kernels": kernels,
@@ -203,14 +223,17 @@ def main():
         if ordered_ms is not None:
             line["ordered_output_two_pass"] = {"ms_per_step": round(ordered_ms, 3), "rows_per_s": (nb + np_) / (ordered_ms * 1e-3),
                                                "hbm_frac_whole_step": round(alg / (ordered_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4)}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is reported by the single-GPU run only
             threads = os.cpu_count() or 1
             line["cpu_baseline"] = cpu_baseline(args.cpu_sf, threads)
             line["speedup_vs_cpu_port"] = round(rows_per_s / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        # RCCL teardown has aborted on some boxes after all work was done and checked; the line is out, leave now
+        os._exit(0)
 
 
 if __name__ == "__main__":

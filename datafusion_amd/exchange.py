@@ -101,6 +101,88 @@ def hash_exchange(table, keys, group=None, force=False):
     return result
 
 
+def gather_counts(count, group=None):
+    """every rank learns every rank's row count (rank order)"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.tensor([int(count)], dtype=torch.int64, device=dev)
+    allc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, mine, group=group)
+    return [int(x) for x in allc.cpu().tolist()]
+
+
+def all_gather_bytes(send, recv, counts, width, group=None):
+    """all-gather of one column: `send` = this rank's rows, `recv` = all rows in rank order (flat uint8 tensors,
+    counts in rows).  Equal shards take one all_gather_into_tensor straight into `recv`; ragged shards are
+    broadcast rank by rank into their slice (no staging copy either way)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    unit, dtype = (8, torch.int64) if width % 8 == 0 else (4, torch.int32) if width % 4 == 0 else (1, torch.uint8)
+    if send.data_ptr() % unit or recv.data_ptr() % unit:
+        unit, dtype = 1, torch.uint8
+    if len(set(counts)) == 1:
+        if counts[0]:
+            dist.all_gather_into_tensor(recv.view(dtype), send.view(dtype), group=group)
+        return
+    off = 0
+    for r in range(world):
+        nb = counts[r] * width
+        if nb:
+            piece = recv[off:off + nb]
+            if r == rank:
+                piece.copy_(send[:nb])
+            src = dist.get_global_rank(group, r) if group is not None else r
+            dist.broadcast(piece.view(dtype) if (piece.data_ptr() % unit == 0) else piece, src=src, group=group)
+        off += nb
+
+
+def broadcast_table(table, group=None, force=False):
+    """DeviceTable -> DeviceTable holding the rows of ALL ranks in rank order: the build side of a
+    PartitionMode::CollectLeft hash join (hash_join/exec.rs:1325-1328: one side collected whole, the probe side
+    stays partitioned), as one all-gather per column over RCCL.  Chosen instead of hash-repartitioning both sides
+    when it moves fewer bytes per GPU: build_bytes * N < build_bytes + probe_bytes."""
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib, ops
+    from ._lib import Field, check
+    from .table import DeviceTable
+
+    world = dist.get_world_size(group)
+    if world == 1 and not force:
+        return table
+    lib = _lib.load()
+    counts = gather_counts(table.num_rows, group)
+    total = sum(counts)
+    ncols = table.num_columns
+    views = [table.column_view(i) for i in range(ncols)]
+    fields = (Field * ncols)(*[v.field for v in views])
+    names = (C.c_char_p * ncols)(*[v.name for v in views])
+    out = C.c_void_p()
+    check(lib.dfgpu_table_alloc(ncols, fields, names, C.c_int64(total), C.byref(out)))
+    result = DeviceTable(out)
+    ops.sync()  # the producer kernels ran on the library stream; RCCL runs on torch's
+    for i in range(ncols):
+        v = views[i]
+        if v.validity:
+            raise _lib.DfgpuError("broadcast_table: nullable columns are not supported yet")
+        w = _W[v.field.type]
+        send = _as_tensor(v.data, table.num_rows * w)
+        recv = _as_tensor(result.column_view(i).data, total * w)
+        all_gather_bytes(send, recv, counts, w, group)
+    torch.cuda.synchronize()
+    return result
+
+
+def broadcast_build_moves_fewer_bytes(build_bytes, probe_bytes, world):
+    """per-GPU received bytes: all-gather of the build side = B (N-1)/N, hash repartition of both = (B+P)(N-1)/N^2"""
+    return build_bytes * world < build_bytes + probe_bytes
+
+
 def route(hashes: np.ndarray, world: int) -> np.ndarray:
     """destination rank of a row = hash % world (BatchPartitioner hash arm, repartition/mod.rs:1111-1150)"""
     return (hashes % np.uint64(world)).astype(np.int64)

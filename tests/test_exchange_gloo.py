@@ -90,6 +90,47 @@ def test_hash_exchange_over_gloo(tmp_path, world):
     assert sorted(got, key=key) == sorted(exp, key=key)
 
 
+def _gather_worker(rank, world, port, ragged, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from datafusion_amd.exchange import all_gather_bytes, gather_counts
+    n = 1000 + (37 * rank if ragged else 0)
+    out = {}
+    for width, dtype in ((16, np.uint64), (8, np.int64), (4, np.int32), (1, np.uint8)):
+        k = max(1, width // np.dtype(dtype).itemsize)
+        mine = (np.arange(n * k, dtype=np.int64) + 10**6 * rank).astype(dtype)
+        counts = gather_counts(n)
+        assert counts == [1000 + (37 * r if ragged else 0) for r in range(world)]
+        send = torch.from_numpy(np.frombuffer(mine.tobytes(), dtype=np.uint8).copy())
+        recv = torch.empty(sum(counts) * width, dtype=torch.uint8)
+        all_gather_bytes(send, recv, counts, width)
+        out[width] = recv.numpy().tobytes()
+    pickle.dump(out, open(os.path.join(outdir, f"g{rank}.pkl"), "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ragged", [(2, False), (3, True)])
+def test_broadcast_build_all_gather_over_gloo(tmp_path, world, ragged):
+    """CollectLeft build side: every rank ends up with all ranks' rows in rank order (equal and ragged shards)"""
+    port = _free_port()
+    mp.spawn(_gather_worker, args=(world, port, ragged, str(tmp_path)), nprocs=world, join=True)
+    res = [pickle.load(open(tmp_path / f"g{r}.pkl", "rb")) for r in range(world)]
+    for width, dtype in ((16, np.uint64), (8, np.int64), (4, np.int32), (1, np.uint8)):
+        k = max(1, width // np.dtype(dtype).itemsize)
+        exp = b"".join((np.arange((1000 + (37 * r if ragged else 0)) * k, dtype=np.int64) + 10**6 * r).astype(dtype).tobytes() for r in range(world))
+        for r in range(world):
+            assert res[r][width] == exp
+
+
+def test_broadcast_vs_repartition_choice():
+    from datafusion_amd.exchange import broadcast_build_moves_fewer_bytes
+    b, p = 150_000_000 * 16, 600_000_000 * 40   # the SF100 Q3 join of bench.py
+    assert all(broadcast_build_moves_fewer_bytes(b, p, n) for n in (2, 4, 8))
+    assert not broadcast_build_moves_fewer_bytes(p, b, 2)
+
+
 def test_route_is_hash_mod_world():
     from datafusion_amd.exchange import route
     h = np.array([0, 1, 7, 8, 2**64 - 1], dtype=np.uint64)

@@ -93,7 +93,7 @@ import os, sys
 import numpy as np, pyarrow as pa, torch
 import torch.distributed as dist
 sys.path.insert(0, os.environ["DFGPU_ROOT"])
-from datafusion_amd.exchange import hash_exchange
+from datafusion_amd.exchange import broadcast_table, hash_exchange
 from datafusion_amd.table import DeviceTable
 from tests.util import assert_tables_equal, random_table
 t = random_table(np.random.default_rng(2), 100_000, {"k": (pa.int64(), 0, 10**6), "d": (pa.decimal128(15, 2), 0, 10**6), "q": (pa.int32(), 0, 9)})
@@ -101,6 +101,9 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
 out = hash_exchange(DeviceTable.from_arrow(t), ["k"], force=True)
 assert_tables_equal(out.to_arrow(), t, ordered=True)
+# CollectLeft build side: all-gather of every column (one rank: the gathered table is the input)
+bc = broadcast_table(DeviceTable.from_arrow(t), force=True)
+assert_tables_equal(bc.to_arrow(), t, ordered=True)
 print("EXCHANGE_OK", flush=True)
 os._exit(0)   # RCCL teardown in a one-rank group has aborted on some boxes; the result is already checked
 """
