@@ -96,9 +96,15 @@ def main():
     torch.cuda.set_device(local_rank)
     _lib.init(local_rank)
     dist = None
-    if world > 1:
+    forced = world == 1 and args.exchange != "auto"  # one-rank rehearsal of the N > 1 exchange code on a 1-GPU box
+    if world > 1 or forced:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if forced:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29544")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from datafusion_amd import tpch
     n_orders = tpch.n_orders(args.sf)
@@ -108,7 +114,7 @@ def main():
     nb_local, np_local = orders.num_rows, lineitem.num_rows
     ops.sync()
 
-    exchange = "none"
+    exchange = args.exchange if forced else "none"
     if world > 1:
         from datafusion_amd.exchange import broadcast_build_moves_fewer_bytes
         t4 = torch.tensor([float(nb_local), float(np_local)], dtype=torch.float64, device="cuda")
@@ -121,11 +127,11 @@ def main():
         o, l = orders, lineitem
         if exchange == "broadcast":
             from datafusion_amd.exchange import broadcast_table
-            o = broadcast_table(orders)
+            o = broadcast_table(orders, force=forced)
         elif exchange == "repartition":
             from datafusion_amd.exchange import hash_exchange
-            o = hash_exchange(orders, ["o_orderkey"])
-            l = hash_exchange(lineitem, ["l_orderkey"])
+            o = hash_exchange(orders, ["o_orderkey"], force=forced)
+            l = hash_exchange(lineitem, ["l_orderkey"], force=forced)
         # join-table choice follows the library default (direct-address down to key density 1/64, see
         # DFGPU_DEFAULT_MIN_KEY_DENSITY in include/dfgpu.h): at N > 1 hash routing leaves each rank 1/N of
         # the keys over the same key range (density 0.25/N)

@@ -4,189 +4,298 @@
 // sort.rs:894-914); TopK::insert_batch row-encodes the sort keys with arrow-row's RowConverter and
 // keeps the k smallest rows in a heap (physical-plan/src/topk/mod.rs:397-470).
 //
-// Device design: the same idea as arrow-row — every row's sort key is normalised into an
-// order-preserving byte string (per column: optional null byte placed by `nulls_first`, value
-// big-endian with the sign bit flipped / f64 total-order transform, all value bytes inverted for
-// DESC) — packed into up to three u64 words.  Then
-//   full sort : stable LSD radix sort (8-bit digits) of (key words, row id); digits on which all
-//               rows agree are skipped; one wave64 owns one tile and ranks its 64-row chunks with
-//               ballot-built peer masks, so the scatter is stable and deterministic;
-//   TopK      : MSD radix *select* — one histogram pass per key byte narrows the candidate set to
-//               the bucket holding the k-th row — then the few survivors are compacted and fully
-//               sorted.  (Q3: k = 10 over ~10^6 groups = 1-2 passes.)
-// Finally the output columns are gathered by the sorted row ids (take).  Ties keep input order.
+// Device design: the idea of arrow-row — one order-preserving fixed-width key per row, compared as
+// an unsigned integer — but RANGE-COMPRESSED, because every radix pass moves the whole key:
+//   1. k_key_ranges : min / max of each key column's order-preserving transform (sign bit flipped,
+//                     f64 total order) over the non-null rows.
+//   2. k_pack_keys  : key = concatenation, most significant column first, of
+//                       [null flag bit if the column is nullable][value - min (ASC) or max - value (DESC)]
+//                     in ceil(log2(max - min + 1)) bits per column — TPC-H (o_orderdate, o_orderkey DESC)
+//                     packs into 42 bits of ONE u64 instead of 12 normalised bytes.
+//   3. full sort    : stable LSD radix sort of (key words, u32 row id) over the used bits only, up to
+//                     8 bits per pass.  A pass = per-tile digit histogram -> exclusive scan -> scatter.
+//                     The scatter ranks a 256-row chunk with wave64 ballot peer masks + a cross-wave
+//                     prefix in LDS, stages the tile sorted by digit in LDS and writes every digit's
+//                     run contiguously (coalesced), instead of one scattered 8-byte store per row.
+//      TopK         : MSD radix select over the same digits narrows the candidates to the bucket
+//                     holding the k-th row (Q3: k = 10), then the few survivors are sorted.
+//   4. take         : output columns gathered by the sorted row ids.  Ties keep input order (stable).
+#include <algorithm>
+
 #include "device.hpp"
 #include "internal.hpp"
 
 namespace dfgpu {
 
 constexpr int MAX_SORT_KEYS = 8;
-constexpr int MAX_KEY_BYTES = 24;
+constexpr int MAX_KEY_WORDS = 3;  // 192 packed bits
 
-struct SortCol {
+struct PackCol {
   const void* data;
   const uint64_t* valid;
   int type;
   int desc;
   int nulls_first;
-  int with_null_byte;
+  int has_null_bit;
+  uint64_t base_lo, base_hi;  // min (ASC) or max (DESC) of the transformed value
+  int bits;                   // value field width
+  int shift;                  // bit offset of the value field in the packed key; the null bit sits at shift + bits
 };
-struct SortCols {
-  SortCol c[MAX_SORT_KEYS];
+struct PackCols {
+  PackCol c[MAX_SORT_KEYS];
   int n;
-  int key_bytes;
 };
 
-__device__ __forceinline__ int value_bytes(int type) {
+// order-preserving transform of row i of a key column to an unsigned 128-bit integer
+__device__ __forceinline__ u128 key_transform(int type, const void* data, int64_t i) {
   switch (type) {
-    case DFGPU_INT32: case DFGPU_UINT32: case DFGPU_DATE32: return 4;
-    case DFGPU_INT64: case DFGPU_UINT64: case DFGPU_FLOAT64: return 8;
-    case DFGPU_DECIMAL128: return 16;
-    default: return 1;
+    case DFGPU_INT32: case DFGPU_DATE32: return (u128)((uint32_t)((const int32_t*)data)[i] ^ 0x80000000u);
+    case DFGPU_UINT32: return (u128)((const uint32_t*)data)[i];
+    case DFGPU_INT64: return (u128)(((const uint64_t*)data)[i] ^ 0x8000000000000000ull);
+    case DFGPU_UINT64: return (u128)((const uint64_t*)data)[i];
+    case DFGPU_FLOAT64: {
+      uint64_t b = ((const uint64_t*)data)[i];
+      return (u128)((b >> 63) ? ~b : (b ^ 0x8000000000000000ull));  // f64::total_cmp order
+    }
+    case DFGPU_DECIMAL128: {
+      const uint64_t* p = (const uint64_t*)data + 2 * i;
+      return ((u128)(p[1] ^ 0x8000000000000000ull) << 64) | (u128)p[0];
+    }
+    default: return (u128)((const uint8_t*)data)[i];
   }
 }
 
-// normalised key of row i, MSB-first into kb[0..key_bytes)
-__device__ __forceinline__ void encode_row(const SortCols& sc, int64_t i, uint8_t* kb) {
-  int pos = 0;
-  for (int k = 0; k < sc.n; k++) {
-    const SortCol& c = sc.c[k];
-    bool ok = !c.valid || bit_at(c.valid, i);
-    if (c.with_null_byte) kb[pos++] = ok ? 1 : (c.nulls_first ? 0 : 2);
-    int nb = value_bytes(c.type);
-    uint64_t lo = 0, hi = 0;
-    if (ok) {
-      switch (c.type) {
-        case DFGPU_INT32: case DFGPU_DATE32: lo = (uint32_t)((const int32_t*)c.data)[i] ^ 0x80000000u; break;
-        case DFGPU_UINT32: lo = ((const uint32_t*)c.data)[i]; break;
-        case DFGPU_INT64: lo = ((const uint64_t*)c.data)[i] ^ 0x8000000000000000ull; break;
-        case DFGPU_UINT64: lo = ((const uint64_t*)c.data)[i]; break;
-        case DFGPU_FLOAT64: {
-          uint64_t b = ((const uint64_t*)c.data)[i];
-          lo = (b >> 63) ? ~b : (b ^ 0x8000000000000000ull);  // f64::total_cmp order
-          break;
-        }
-        case DFGPU_DECIMAL128: {
-          const uint64_t* p = (const uint64_t*)c.data + 2 * i;
-          lo = p[0];
-          hi = p[1] ^ 0x8000000000000000ull;
-          break;
-        }
-        default: lo = ((const uint8_t*)c.data)[i]; break;
+// per-block min / max of every key column's transform over valid rows: out[(block * n + col) * 2 + {0,1}]
+__global__ __launch_bounds__(BLOCK) void k_key_ranges(PackCols pc, int64_t n, u128* __restrict__ out) {
+  __shared__ u128 s_mn[BLOCK / WAVE], s_mx[BLOCK / WAVE];
+  for (int c = 0; c < pc.n; c++) {
+    const PackCol& k = pc.c[c];
+    u128 mn = ~(u128)0, mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+      if (k.valid && !bit_at(k.valid, i)) continue;
+      u128 t = key_transform(k.type, k.data, i);
+      mn = t < mn ? t : mn;
+      mx = t > mx ? t : mx;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      uint64_t olo = __shfl_xor((uint64_t)mn, d, 64), ohi = __shfl_xor((uint64_t)(mn >> 64), d, 64);
+      u128 o = ((u128)ohi << 64) | olo;
+      mn = o < mn ? o : mn;
+      olo = __shfl_xor((uint64_t)mx, d, 64);
+      ohi = __shfl_xor((uint64_t)(mx >> 64), d, 64);
+      o = ((u128)ohi << 64) | olo;
+      mx = o > mx ? o : mx;
+    }
+    if (lane_id() == 0) {
+      s_mn[threadIdx.x >> 6] = mn;
+      s_mx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < BLOCK / WAVE; w++) {
+        mn = s_mn[w] < mn ? s_mn[w] : mn;
+        mx = s_mx[w] > mx ? s_mx[w] : mx;
       }
-      if (c.desc) { lo = ~lo; hi = ~hi; }
+      out[((int64_t)blockIdx.x * pc.n + c) * 2] = mn;
+      out[((int64_t)blockIdx.x * pc.n + c) * 2 + 1] = mx;
     }
-    for (int b = nb - 1; b >= 0; b--) {
-      uint8_t byte = b >= 8 ? (uint8_t)(hi >> ((b - 8) * 8)) : (uint8_t)(lo >> (b * 8));
-      kb[pos++] = byte;
-    }
+    __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_norm_keys(SortCols sc, int64_t n, int nwords, uint64_t* __restrict__ w0, uint64_t* __restrict__ w1,
-                                                     uint64_t* __restrict__ w2, uint32_t* __restrict__ idx) {
+// OR a value of up to 64 bits into a 192-bit key at bit offset `shift` (static word indices: stays in registers)
+__device__ __forceinline__ void or_bits(uint64_t& w0, uint64_t& w1, uint64_t& w2, int shift, uint64_t v) {
+  const int wi = shift >> 6, sb = shift & 63;
+  const uint64_t lo = v << sb, hi = sb ? (v >> (64 - sb)) : 0ull;
+  if (wi == 0) { w0 |= lo; w1 |= hi; }
+  else if (wi == 1) { w1 |= lo; w2 |= hi; }
+  else if (wi == 2) { w2 |= lo; }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pack_keys(PackCols pc, int64_t n, int nwords, uint64_t* __restrict__ o0, uint64_t* __restrict__ o1,
+                                                     uint64_t* __restrict__ o2, uint32_t* __restrict__ idx) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    uint8_t kb[MAX_KEY_BYTES];
-#pragma unroll
-    for (int b = 0; b < MAX_KEY_BYTES; b++) kb[b] = 0;
-    encode_row(sc, i, kb);
-    uint64_t w[3] = {0, 0, 0};
-#pragma unroll
-    for (int b = 0; b < MAX_KEY_BYTES; b++) w[b >> 3] |= (uint64_t)kb[b] << ((7 - (b & 7)) * 8);
-    w0[i] = w[0];
-    if (nwords > 1) w1[i] = w[1];
-    if (nwords > 2) w2[i] = w[2];
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
+    for (int c = 0; c < pc.n; c++) {
+      const PackCol& k = pc.c[c];
+      const bool ok = !k.valid || bit_at(k.valid, i);
+      if (ok && k.bits > 0) {
+        const u128 t = key_transform(k.type, k.data, i);
+        const u128 base = ((u128)k.base_hi << 64) | k.base_lo;
+        const u128 e = k.desc ? base - t : t - base;
+        or_bits(w0, w1, w2, k.shift, (uint64_t)e);
+        if (k.bits > 64) or_bits(w0, w1, w2, k.shift + 64, (uint64_t)(e >> 64));
+      }
+      // null flag: NULLS FIRST => nulls 0 / values 1; NULLS LAST => values 0 / nulls 1
+      if (k.has_null_bit && (ok == (k.nulls_first != 0))) or_bits(w0, w1, w2, k.shift + k.bits, 1ull);
+    }
+    o0[i] = w0;
+    if (nwords > 1) o1[i] = w1;
+    if (nwords > 2) o2[i] = w2;
     idx[i] = (uint32_t)i;
   }
 }
 
-// byte `b` (0 = most significant) of the normalised key of element i
+// ------------------------------------------------------------------------------ LSD radix pass
+// A digit never straddles a key word: (word, shift, bits <= 8).
+// rows per thread: a tile of BLOCK * items rows is staged in LDS (keys + ids), 2048 rows for 1-2 key words
+constexpr int rs_items(int nwords) { return nwords >= 3 ? 4 : 8; }
 struct KeyWords {
-  const uint64_t* w[3];
+  const uint64_t* w[MAX_KEY_WORDS];
 };
-__device__ __forceinline__ unsigned key_byte(const KeyWords& k, int64_t i, int b) { return (unsigned)(k.w[b >> 3][i] >> ((7 - (b & 7)) * 8)) & 0xFFu; }
+struct SortBufs {
+  uint64_t* w[MAX_KEY_WORDS];
+  uint32_t* idx;
+};
 
-// global histogram of every key byte (decides which LSD passes can be skipped)
-__global__ __launch_bounds__(BLOCK) void k_all_digit_hist(KeyWords k, int64_t n, int key_bytes, unsigned long long* __restrict__ hist) {
-  __shared__ unsigned int sh[MAX_KEY_BYTES * 256];
-  for (int x = threadIdx.x; x < key_bytes * 256; x += BLOCK) sh[x] = 0;
-  __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
-    for (int b = 0; b < key_bytes; b++) atomicAdd(&sh[b * 256 + key_byte(k, i, b)], 1u);
-  __syncthreads();
-  for (int x = threadIdx.x; x < key_bytes * 256; x += BLOCK)
-    if (sh[x]) atomicAdd(&hist[x], (unsigned long long)sh[x]);
-}
-
-// per-tile digit histogram; one wave per tile.  counts[digit * n_tiles + tile]
-__global__ __launch_bounds__(WAVE) void k_tile_hist(KeyWords k, int64_t n, int byte, int64_t tile, int64_t n_tiles, uint32_t* __restrict__ counts) {
+// per-tile digit histogram: counts[digit * n_tiles + tile]
+__global__ __launch_bounds__(BLOCK) void k_rs_hist(const uint64_t* __restrict__ word, int64_t n, int shift, int bits, int items, int64_t n_tiles,
+                                                   uint32_t* __restrict__ counts) {
   __shared__ unsigned int sh[256];
+  const unsigned mask = (1u << bits) - 1u;
   for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    for (int x = threadIdx.x; x < 256; x += WAVE) sh[x] = 0;
+    sh[threadIdx.x] = 0;
     __syncthreads();
-    int64_t lo = t * tile, hi = lo + tile < n ? lo + tile : n;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += WAVE) atomicAdd(&sh[key_byte(k, i, byte)], 1u);
+    const int64_t lo = t * (int64_t)(BLOCK * items);
+    for (int c = 0; c < items; c++) {
+      const int64_t i = lo + c * BLOCK + threadIdx.x;
+      if (i < n) atomicAdd(&sh[(unsigned)(word[i] >> shift) & mask], 1u);
+    }
     __syncthreads();
-    for (int x = threadIdx.x; x < 256; x += WAVE) counts[(int64_t)x * n_tiles + t] = sh[x];
+    if ((int)threadIdx.x <= (int)mask) counts[(int64_t)threadIdx.x * n_tiles + t] = sh[threadIdx.x];
     __syncthreads();
   }
 }
 
-struct SortBufs {
-  uint64_t* w[3];
-  uint32_t* idx;
-};
-// stable scatter of one tile by one digit
-__global__ __launch_bounds__(WAVE) void k_tile_scatter(KeyWords k, const uint32_t* __restrict__ idx_in, int64_t n, int byte, int nwords, int64_t tile,
-                                                       int64_t n_tiles, const uint64_t* __restrict__ offsets, SortBufs out) {
-  __shared__ unsigned long long off[256];
+// stable scatter of one tile by one digit, staged through LDS so that every digit's run is written contiguously
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void k_rs_scatter(KeyWords k, const uint32_t* __restrict__ idx_in, int64_t n, int dword, int shift, int bits, int64_t n_tiles,
+                                                     const uint64_t* __restrict__ offsets, SortBufs out) {
+  constexpr int RS_ITEMS = rs_items(NW);
+  constexpr int RS_TILE = BLOCK * RS_ITEMS;
+  __shared__ uint64_t s_key[NW][RS_TILE];
+  __shared__ uint32_t s_idx[RS_TILE];
+  __shared__ uint8_t s_dig[RS_TILE];
+  __shared__ unsigned int s_wave[BLOCK / WAVE][256];  // per-wave digit counts of the current chunk
+  __shared__ unsigned int s_run[256];                 // rows of each digit seen in earlier chunks of the tile
+  __shared__ unsigned int s_start[256];               // exclusive scan of the tile's digit counts
+  __shared__ unsigned long long s_goff[256];          // global output offset of each digit's run
+  const unsigned mask = (1u << bits) - 1u;
+  const int wave = threadIdx.x >> 6;
   for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    for (int x = threadIdx.x; x < 256; x += WAVE) off[x] = offsets[(int64_t)x * n_tiles + t];
+    const int64_t lo = t * RS_TILE;
+    const int tile_rows = (int)((n - lo) < RS_TILE ? (n - lo) : RS_TILE);
+    s_run[threadIdx.x] = 0;
+    for (int w = 0; w < BLOCK / WAVE; w++) s_wave[w][threadIdx.x] = 0;
+    if ((int)threadIdx.x <= (int)mask) s_goff[threadIdx.x] = offsets[(int64_t)threadIdx.x * n_tiles + t];
     __syncthreads();
-    int64_t lo = t * tile, hi = lo + tile < n ? lo + tile : n;
-    for (int64_t base = lo; base < hi; base += WAVE) {
-      int64_t i = base + threadIdx.x;
-      bool in = i < hi;
-      unsigned d = in ? key_byte(k, i, byte) : 0u;
-      // peers = lanes of this chunk with the same digit
-      uint64_t peers = ballot64(in);
+    uint64_t key[NW][RS_ITEMS];
+    uint32_t id[RS_ITEMS];
+    unsigned dig[RS_ITEMS], rank[RS_ITEMS];
+    // ---- pass 1: stable rank of every row among the tile's rows with the same digit
 #pragma unroll
-      for (int b = 0; b < 8; b++) {
-        uint64_t bal = ballot64((d >> b) & 1u);
-        peers &= ((d >> b) & 1u) ? bal : ~bal;
+    for (int c = 0; c < RS_ITEMS; c++) {
+      const int j = c * BLOCK + threadIdx.x;
+      const bool in = j < tile_rows;
+      if (in) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) key[w][c] = k.w[w][lo + j];
+        id[c] = idx_in[lo + j];
+      } else {
+#pragma unroll
+        for (int w = 0; w < NW; w++) key[w][c] = 0;
+        id[c] = 0;
       }
-      unsigned rank = mbcnt(peers);
-      unsigned long long dst = in ? off[d] + rank : 0ull;
-      __syncthreads();
-      if (in && rank == 0) off[d] += (unsigned long long)__popcll(peers);
+      uint64_t kw = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+        if (w == dword) kw = key[w][c];
+      dig[c] = in ? ((unsigned)(kw >> shift) & mask) : 0u;
+      uint64_t peers = ballot64(in);
+      for (int b = 0; b < bits; b++) {
+        const uint64_t bal = ballot64((dig[c] >> b) & 1u);
+        peers &= ((dig[c] >> b) & 1u) ? bal : ~bal;
+      }
+      const unsigned r_in_wave = mbcnt(peers);
+      if (in && r_in_wave == 0) s_wave[wave][dig[c]] = (unsigned)__popcll(peers);
       __syncthreads();
       if (in) {
-        out.w[0][dst] = k.w[0][i];
-        if (nwords > 1) out.w[1][dst] = k.w[1][i];
-        if (nwords > 2) out.w[2][dst] = k.w[2][i];
-        out.idx[dst] = idx_in[i];
+        unsigned r = s_run[dig[c]] + r_in_wave;
+        for (int w = 0; w < wave; w++) r += s_wave[w][dig[c]];
+        rank[c] = r;
+      }
+      __syncthreads();
+      {
+        unsigned tot = 0;
+        for (int w = 0; w < BLOCK / WAVE; w++) {
+          tot += s_wave[w][threadIdx.x];
+          s_wave[w][threadIdx.x] = 0;
+        }
+        s_run[threadIdx.x] += tot;
+      }
+      __syncthreads();
+    }
+    // ---- exclusive scan of the digit counts (256 threads, wave scan + wave totals)
+    {
+      const unsigned cnt = s_run[threadIdx.x];
+      const unsigned inc = wave_inclusive_sum<unsigned>(cnt);
+      if (lane_id() == 63) s_wave[0][wave] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; w++) base += s_wave[0][w];
+      s_start[threadIdx.x] = base + inc - cnt;
+      __syncthreads();
+      if (threadIdx.x < BLOCK / WAVE) s_wave[0][threadIdx.x] = 0;
+    }
+    // ---- pass 2: stage the tile sorted by digit
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; c++) {
+      const int j = c * BLOCK + threadIdx.x;
+      if (j < tile_rows) {
+        const unsigned q = s_start[dig[c]] + rank[c];
+#pragma unroll
+        for (int w = 0; w < NW; w++) s_key[w][q] = key[w][c];
+        s_idx[q] = id[c];
+        s_dig[q] = (uint8_t)dig[c];
+      }
+    }
+    __syncthreads();
+    // ---- pass 3: contiguous runs out
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; c++) {
+      const int q = c * BLOCK + threadIdx.x;
+      if (q < tile_rows) {
+        const unsigned d = s_dig[q];
+        const unsigned long long dst = s_goff[d] + (unsigned)(q - (int)s_start[d]);
+#pragma unroll
+        for (int w = 0; w < NW; w++) out.w[w][dst] = s_key[w][q];
+        out.idx[dst] = s_idx[q];
       }
     }
     __syncthreads();
   }
 }
 
-// TopK narrowing: histogram of byte `b` over candidate rows
-__global__ __launch_bounds__(BLOCK) void k_select_hist(KeyWords k, const uint8_t* __restrict__ state, int64_t n, int byte, unsigned long long* __restrict__ hist) {
+// ------------------------------------------------------------------------------ TopK narrowing
+// histogram of one digit over candidate rows
+__global__ __launch_bounds__(BLOCK) void k_select_hist(const uint64_t* __restrict__ word, const uint8_t* __restrict__ state, int64_t n, int shift, int bits,
+                                                       unsigned long long* __restrict__ hist) {
   __shared__ unsigned int sh[256];
-  for (int x = threadIdx.x; x < 256; x += BLOCK) sh[x] = 0;
+  const unsigned mask = (1u << bits) - 1u;
+  sh[threadIdx.x] = 0;
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
-    if (state[i] == 1) atomicAdd(&sh[key_byte(k, i, byte)], 1u);
+    if (state[i] == 1) atomicAdd(&sh[(unsigned)(word[i] >> shift) & mask], 1u);
   __syncthreads();
-  for (int x = threadIdx.x; x < 256; x += BLOCK)
-    if (sh[x]) atomicAdd(&hist[x], (unsigned long long)sh[x]);
+  if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
 }
 // state: 0 out, 1 candidate, 2 selected.  digit < pivot -> selected, == pivot stays candidate, > out
-__global__ __launch_bounds__(BLOCK) void k_select_apply(KeyWords k, uint8_t* __restrict__ state, int64_t n, int byte, unsigned pivot) {
+__global__ __launch_bounds__(BLOCK) void k_select_apply(const uint64_t* __restrict__ word, uint8_t* __restrict__ state, int64_t n, int shift, int bits, unsigned pivot) {
+  const unsigned mask = (1u << bits) - 1u;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     if (state[i] != 1) continue;
-    unsigned d = key_byte(k, i, byte);
+    unsigned d = (unsigned)(word[i] >> shift) & mask;
     state[i] = d < pivot ? 2 : (d == pivot ? 1 : 0);
   }
 }
@@ -219,39 +328,43 @@ __global__ __launch_bounds__(BLOCK) void k_mask_to_ids(const uint64_t* __restric
     if ((m >> lane_id()) & 1ull) ids[prefix[w] + mbcnt(m)] = (w << 6) + lane_id();
   }
 }
-
 __global__ void k_iota_u32(int64_t n, uint32_t* out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)i;
 }
 
 // ------------------------------------------------------------------------------- host
+struct Digit {
+  int word, shift, bits;
+};
 struct SortedKeys {
-  BufPtr w[3];
+  BufPtr w[MAX_KEY_WORDS];
   BufPtr idx;
   int nwords = 0;
 };
 
-// stable LSD radix sort of n (key, idx) elements; returns the buffers holding the result
-static SortedKeys radix_sort(SortedKeys in, int64_t n, int key_bytes) {
-  Runtime& r = rt();
-  if (n <= 1) return in;
-  const int nwords = in.nwords;
-  KeyWords kw{{in.w[0]->as<uint64_t>(), nwords > 1 ? in.w[1]->as<uint64_t>() : nullptr, nwords > 2 ? in.w[2]->as<uint64_t>() : nullptr}};
-  // which digits vary?
-  BufPtr gh = make_zero_buf((size_t)key_bytes * 256 * 8);
-  k_all_digit_hist<<<grid_for(n, BLOCK * 4), BLOCK, 0, r.stream>>>(kw, n, key_bytes, gh->as<unsigned long long>());
-  std::vector<unsigned long long> h((size_t)key_bytes * 256);
-  d2h(h.data(), gh->ptr, h.size() * 8);
-  std::vector<int> active;
-  for (int b = key_bytes - 1; b >= 0; b--) {  // least significant byte first
-    bool constant = false;
-    for (int d = 0; d < 256; d++)
-      if (h[(size_t)b * 256 + d] == (unsigned long long)n) constant = true;
-    if (!constant) active.push_back(b);
+// digits of a packed key of `total_bits` bits, least significant first; <= 8 bits each, none straddles a word
+static std::vector<Digit> key_digits(int total_bits) {
+  std::vector<Digit> ds;
+  for (int w = 0; w * 64 < total_bits; w++) {
+    const int wbits = std::min(64, total_bits - w * 64);
+    const int nd = (wbits + 7) / 8;
+    int pos = 0;
+    for (int d = 0; d < nd; d++) {
+      const int b = (wbits - pos + (nd - d) - 1) / (nd - d);  // spread the bits evenly over the passes
+      ds.push_back({w, pos, b});
+      pos += b;
+    }
   }
-  if (active.empty()) return in;
-  int64_t tile = (n + 4095) / 4096;
-  tile = std::max<int64_t>(512, std::min<int64_t>(8192, (tile + 63) / 64 * 64));
+  return ds;
+}
+
+// stable LSD radix sort of n (key, idx) elements over the given digits; returns the buffers holding the result
+static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>& digits) {
+  Runtime& r = rt();
+  if (n <= 1 || digits.empty()) return in;
+  const int nwords = in.nwords;
+  const int items = rs_items(nwords);
+  const int64_t tile = (int64_t)BLOCK * items;
   const int64_t n_tiles = (n + tile - 1) / tile;
   SortedKeys cur = in, alt;
   alt.nwords = nwords;
@@ -259,18 +372,37 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, int key_bytes) {
   alt.idx = make_buf((size_t)n * 4);
   BufPtr counts = make_buf((size_t)256 * n_tiles * 4);
   BufPtr offsets = make_buf((size_t)(256 * n_tiles + 1) * 8);
-  int grid = (int)std::min<int64_t>(n_tiles, 256 * 16);
-  for (int b : active) {
-    KeyWords ck{{cur.w[0]->as<uint64_t>(), nwords > 1 ? cur.w[1]->as<uint64_t>() : nullptr, nwords > 2 ? cur.w[2]->as<uint64_t>() : nullptr}};
-    SortBufs ob{{alt.w[0]->as<uint64_t>(), nwords > 1 ? alt.w[1]->as<uint64_t>() : nullptr, nwords > 2 ? alt.w[2]->as<uint64_t>() : nullptr}, alt.idx->as<uint32_t>()};
-    ProfileScope ps("radix_sort_pass", n * (nwords * 8 + 4) * 2);
-    k_tile_hist<<<grid, WAVE, 0, r.stream>>>(ck, n, b, tile, n_tiles, counts->as<uint32_t>());
-    scan_u32(counts->as<uint32_t>(), 256 * n_tiles, offsets->as<uint64_t>());
-    k_tile_scatter<<<grid, WAVE, 0, r.stream>>>(ck, cur.idx->as<uint32_t>(), n, b, nwords, tile, n_tiles, offsets->as<uint64_t>(), ob);
+  const int grid = (int)std::min<int64_t>(n_tiles, 256 * 8);
+  for (const Digit& d : digits) {
+    KeyWords ck{};
+    SortBufs ob{};
+    for (int wd = 0; wd < nwords; wd++) {
+      ck.w[wd] = cur.w[wd]->as<uint64_t>();
+      ob.w[wd] = alt.w[wd]->as<uint64_t>();
+    }
+    ob.idx = alt.idx->as<uint32_t>();
+    const int nb = 1 << d.bits;
+    ProfileScope ps("radix_sort_pass", n * 8 + n * (nwords * 8 + 4) * 2);
+    k_rs_hist<<<grid, BLOCK, 0, r.stream>>>(ck.w[d.word], n, d.shift, d.bits, items, n_tiles, counts->as<uint32_t>());
+    scan_u32(counts->as<uint32_t>(), (int64_t)nb * n_tiles, offsets->as<uint64_t>());
+    switch (nwords) {
+      case 1: k_rs_scatter<1><<<grid, BLOCK, 0, r.stream>>>(ck, cur.idx->as<uint32_t>(), n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+      case 2: k_rs_scatter<2><<<grid, BLOCK, 0, r.stream>>>(ck, cur.idx->as<uint32_t>(), n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+      default: k_rs_scatter<3><<<grid, BLOCK, 0, r.stream>>>(ck, cur.idx->as<uint32_t>(), n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+    }
     DFGPU_HIP(hipGetLastError());
     std::swap(cur, alt);
   }
   return cur;
+}
+
+static int bits_for(u128 range) {
+  int b = 0;
+  while (range) {
+    b++;
+    range >>= 1;
+  }
+  return b;
 }
 
 static Table sort_table(const Table& in, const std::vector<int>& key_cols, const uint8_t* desc, const uint8_t* nulls_first, int64_t fetch) {
@@ -278,19 +410,16 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
   const int64_t n = in.nrows;
   DFGPU_CHECK(n < 0xFFFFFFFFll, "sort input exceeds u32 row ids");
   DFGPU_CHECK(!key_cols.empty() && (int)key_cols.size() <= MAX_SORT_KEYS, "bad number of sort keys");
-  SortCols sc{};
-  sc.n = (int)key_cols.size();
-  int kbytes = 0;
-  for (int k = 0; k < sc.n; k++) {
+  PackCols pc{};
+  pc.n = (int)key_cols.size();
+  int64_t key_col_bytes = 0;
+  for (int k = 0; k < pc.n; k++) {
     DFGPU_CHECK(key_cols[k] >= 0 && key_cols[k] < (int)in.cols.size(), "sort key column out of range");
     const Column& c = in.cols[key_cols[k]];
     DFGPU_CHECK(c.field.type != DFGPU_BOOL, "Boolean sort keys are not supported on the GPU path");
-    sc.c[k] = SortCol{c.ptr(), c.valid_words(), c.field.type, desc[k] != 0, nulls_first[k] != 0, c.validity != nullptr};
-    kbytes += (c.validity ? 1 : 0) + (c.field.type == DFGPU_UINT8 ? 1 : type_width(c.field.type));
+    pc.c[k] = PackCol{c.ptr(), c.valid_words(), c.field.type, desc[k] != 0, nulls_first[k] != 0, c.validity != nullptr, 0, 0, 0, 0};
+    key_col_bytes += n * (c.field.type == DFGPU_UINT8 ? 1 : type_width(c.field.type));
   }
-  DFGPU_CHECK(kbytes <= MAX_KEY_BYTES, "normalised sort key longer than 24 bytes is not supported on the GPU path");
-  sc.key_bytes = kbytes;
-  const int nwords = (kbytes + 7) / 8;
   int64_t n_out = fetch >= 0 ? std::min(fetch, n) : n;
 
   Table out;
@@ -299,74 +428,104 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     for (auto& c : in.cols) out.cols.push_back(alloc_column(c.field, c.name, 0));
     return out;
   }
-  SortedKeys sk;
-  sk.nwords = nwords;
-  for (int wd = 0; wd < nwords; wd++) sk.w[wd] = make_buf((size_t)n * 8);
-  sk.idx = make_buf((size_t)n * 4);
+  // ---- value ranges -> field widths and positions (last key column = least significant)
   {
-    int64_t kb = 0;
-    for (int k = 0; k < sc.n; k++) kb += n * (sc.c[k].type == DFGPU_UINT8 ? 1 : type_width(sc.c[k].type));
-    ProfileScope ps("sort_normalize_keys", kb + n * (nwords * 8 + 4));
-    k_norm_keys<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(sc, n, nwords, sk.w[0]->as<uint64_t>(), nwords > 1 ? sk.w[1]->as<uint64_t>() : nullptr,
-                                                           nwords > 2 ? sk.w[2]->as<uint64_t>() : nullptr, sk.idx->as<uint32_t>());
-    DFGPU_HIP(hipGetLastError());
-  }
-  BufPtr remap;  // survivor position -> original row id (TopK path)
-  int64_t m = n;
-  if (fetch >= 0 && n > 4096 && n_out < n / 4) {
-    // ---- TopK: MSD radix select narrows to the rows that can still be among the first k
-    KeyWords kw{{sk.w[0]->as<uint64_t>(), nwords > 1 ? sk.w[1]->as<uint64_t>() : nullptr, nwords > 2 ? sk.w[2]->as<uint64_t>() : nullptr}};
-    BufPtr state = make_buf((size_t)n + 64);
-    k_fill_bytes<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(1, n, state->as<uint8_t>());
-    BufPtr hist = make_buf(256 * 8);
-    int64_t selected = 0, candidates = n;
-    for (int b = 0; b < kbytes && selected + candidates > std::max<int64_t>(4096, 2 * n_out); b++) {
-      DFGPU_HIP(hipMemsetAsync(hist->ptr, 0, 256 * 8, r.stream));
-      ProfileScope ps("topk_select_pass", n * 9);
-      k_select_hist<<<grid_for(n, BLOCK * 4), BLOCK, 0, r.stream>>>(kw, state->as<uint8_t>(), n, b, hist->as<unsigned long long>());
-      unsigned long long h[256];
-      d2h(h, hist->ptr, sizeof h);
-      int64_t need = n_out - selected, acc = 0;
-      unsigned pivot = 255;
-      for (unsigned d = 0; d < 256; d++) {
-        if (acc + (int64_t)h[d] >= need) { pivot = d; break; }
-        acc += (int64_t)h[d];
+    const int grid = grid_for(n, BLOCK * 4);
+    BufPtr rb = make_buf((size_t)grid * pc.n * 2 * sizeof(u128));
+    {
+      ProfileScope ps("sort_key_ranges", key_col_bytes);
+      k_key_ranges<<<grid, BLOCK, 0, r.stream>>>(pc, n, rb->as<u128>());
+      DFGPU_HIP(hipGetLastError());
+    }
+    std::vector<u128> h((size_t)grid * pc.n * 2);
+    d2h(h.data(), rb->ptr, h.size() * sizeof(u128));
+    int pos = 0;
+    for (int k = pc.n - 1; k >= 0; k--) {
+      u128 mn = ~(u128)0, mx = 0;
+      for (int b = 0; b < grid; b++) {
+        mn = std::min(mn, h[((size_t)b * pc.n + k) * 2]);
+        mx = std::max(mx, h[((size_t)b * pc.n + k) * 2 + 1]);
       }
-      k_select_apply<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(kw, state->as<uint8_t>(), n, b, pivot);
-      selected += acc;
-      candidates = (int64_t)h[pivot];
+      PackCol& c = pc.c[k];
+      if (mn > mx) mn = mx = 0;  // no valid row
+      const u128 base = c.desc ? mx : mn;
+      c.base_lo = (uint64_t)base;
+      c.base_hi = (uint64_t)(base >> 64);
+      c.bits = bits_for(mx - mn);
+      c.shift = pos;
+      pos += c.bits + (c.has_null_bit ? 1 : 0);
     }
-    // compact survivors (selected + remaining candidates), preserving input order
-    const int64_t n_words = (n + 63) / 64;
-    BufPtr mask = make_buf(bitmap_bytes(n));
-    BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
-    k_state_mask<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(state->as<uint8_t>(), n, mask->as<uint64_t>());
-    scan_mask_popcounts(mask->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
-    m = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
-    remap = make_buf((size_t)m * 8);
-    k_mask_to_ids<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(mask->as<uint64_t>(), prefix->as<uint64_t>(), n, remap->as<int64_t>());
-    // survivors' normalised keys, re-indexed 0..m-1
-    SortedKeys sv;
-    sv.nwords = nwords;
-    dfgpu_field f64w{};
-    f64w.type = DFGPU_UINT64;
-    for (int wd = 0; wd < nwords; wd++) {
-      Column kc;
-      kc.field = f64w;
-      kc.length = n;
-      kc.data = sk.w[wd];
-      sv.w[wd] = gather_column(kc, remap->as<int64_t>(), m, false).data;
+    DFGPU_CHECK(pos <= 64 * MAX_KEY_WORDS, "packed sort key longer than 192 bits is not supported on the GPU path");
+    const int total_bits = pos;
+    const int nwords = std::max(1, (total_bits + 63) / 64);
+    SortedKeys sk;
+    sk.nwords = nwords;
+    for (int wd = 0; wd < nwords; wd++) sk.w[wd] = make_buf((size_t)n * 8);
+    sk.idx = make_buf((size_t)n * 4);
+    {
+      ProfileScope ps("sort_pack_keys", key_col_bytes + n * (nwords * 8 + 4));
+      k_pack_keys<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(pc, n, nwords, sk.w[0]->as<uint64_t>(), nwords > 1 ? sk.w[1]->as<uint64_t>() : nullptr,
+                                                             nwords > 2 ? sk.w[2]->as<uint64_t>() : nullptr, sk.idx->as<uint32_t>());
+      DFGPU_HIP(hipGetLastError());
     }
-    // survivor ids 0..m-1 are positions into `remap`
-    sv.idx = make_buf((size_t)(m ? m : 1) * 4);
-    if (m) k_iota_u32<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(m, sv.idx->as<uint32_t>());
-    sk = sv;
+    const std::vector<Digit> digits = key_digits(total_bits);  // least significant first
+    BufPtr remap;                                               // survivor position -> original row id (TopK path)
+    int64_t m = n;
+    if (fetch >= 0 && n > 4096 && n_out < n / 4 && !digits.empty()) {
+      // ---- TopK: MSD radix select narrows to the rows that can still be among the first k
+      BufPtr state = make_buf((size_t)n + 64);
+      k_fill_bytes<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(1, n, state->as<uint8_t>());
+      BufPtr hist = make_buf(256 * 8);
+      int64_t selected = 0, candidates = n;
+      for (int di = (int)digits.size() - 1; di >= 0 && selected + candidates > std::max<int64_t>(4096, 2 * n_out); di--) {
+        const Digit& d = digits[(size_t)di];
+        DFGPU_HIP(hipMemsetAsync(hist->ptr, 0, 256 * 8, r.stream));
+        ProfileScope ps("topk_select_pass", n * 9);
+        k_select_hist<<<grid_for(n, BLOCK * 4), BLOCK, 0, r.stream>>>(sk.w[d.word]->as<uint64_t>(), state->as<uint8_t>(), n, d.shift, d.bits, hist->as<unsigned long long>());
+        unsigned long long hh[256];
+        d2h(hh, hist->ptr, sizeof hh);
+        int64_t need = n_out - selected, acc = 0;
+        unsigned pivot = (1u << d.bits) - 1u;
+        for (unsigned v = 0; v < (1u << d.bits); v++) {
+          if (acc + (int64_t)hh[v] >= need) { pivot = v; break; }
+          acc += (int64_t)hh[v];
+        }
+        k_select_apply<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(sk.w[d.word]->as<uint64_t>(), state->as<uint8_t>(), n, d.shift, d.bits, pivot);
+        selected += acc;
+        candidates = (int64_t)hh[pivot];
+      }
+      // compact survivors (selected + remaining candidates), preserving input order
+      const int64_t n_words = (n + 63) / 64;
+      BufPtr mask = make_buf(bitmap_bytes(n));
+      BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
+      k_state_mask<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(state->as<uint8_t>(), n, mask->as<uint64_t>());
+      scan_mask_popcounts(mask->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
+      m = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+      remap = make_buf((size_t)(m ? m : 1) * 8);
+      k_mask_to_ids<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(mask->as<uint64_t>(), prefix->as<uint64_t>(), n, remap->as<int64_t>());
+      // survivors' packed keys, re-indexed 0..m-1
+      SortedKeys sv;
+      sv.nwords = nwords;
+      dfgpu_field f64w{};
+      f64w.type = DFGPU_UINT64;
+      for (int wd = 0; wd < nwords; wd++) {
+        Column kc;
+        kc.field = f64w;
+        kc.length = n;
+        kc.data = sk.w[wd];
+        sv.w[wd] = gather_column(kc, remap->as<int64_t>(), m, false).data;
+      }
+      // survivor ids 0..m-1 are positions into `remap`
+      sv.idx = make_buf((size_t)(m ? m : 1) * 4);
+      if (m) k_iota_u32<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(m, sv.idx->as<uint32_t>());
+      sk = sv;
+    }
+    SortedKeys sorted = radix_sort(sk, m, digits);
+    BufPtr take_idx = make_buf((size_t)n_out * 8);
+    k_idx_to_i64<<<grid_for(n_out, BLOCK), BLOCK, 0, r.stream>>>(sorted.idx->as<uint32_t>(), remap ? remap->as<int64_t>() : nullptr, n_out, take_idx->as<int64_t>());
+    DFGPU_HIP(hipGetLastError());
+    for (auto& c : in.cols) out.cols.push_back(gather_column(c, take_idx->as<int64_t>(), n_out, false));
   }
-  SortedKeys sorted = radix_sort(sk, m, kbytes);
-  BufPtr take_idx = make_buf((size_t)n_out * 8);
-  k_idx_to_i64<<<grid_for(n_out, BLOCK), BLOCK, 0, r.stream>>>(sorted.idx->as<uint32_t>(), remap ? remap->as<int64_t>() : nullptr, n_out, take_idx->as<int64_t>());
-  DFGPU_HIP(hipGetLastError());
-  for (auto& c : in.cols) out.cols.push_back(gather_column(c, take_idx->as<int64_t>(), n_out, false));
   DFGPU_HIP(hipStreamSynchronize(r.stream));
   return out;
 }

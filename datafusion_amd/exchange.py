@@ -43,18 +43,53 @@ def exchange_counts(send_counts, group=None):
     return [int(x) for x in r.cpu().tolist()]
 
 
-def all_to_all_bytes(send, send_counts, recv, recv_counts, width, group=None):
+MAX_MESSAGE_BYTES = 1 << 30   # per-peer message bound: multi-GB single sends have misbehaved over RCCL (SF100 rehearsal)
+
+
+def all_to_all_bytes(send, send_counts, recv, recv_counts, width, group=None, max_message_bytes=None):
     """one all-to-all(v) of a column: `send`/`recv` are flat uint8 tensors, counts are rows.
     The buffers are viewed with the widest element type dividing `width` so per-peer element
-    counts stay small (a 2.4 GB split of Decimal128 values is 300 M int64 elements, not 2.4 G bytes)."""
+    counts stay small (a 2.4 GB split of Decimal128 values is 300 M int64 elements, not 2.4 G bytes).
+    Splits larger than `max_message_bytes` go in several rounds: round k moves the k-th fraction of every
+    per-peer slice through contiguous staging tensors."""
     import torch
     import torch.distributed as dist
+    limit = MAX_MESSAGE_BYTES if max_message_bytes is None else max_message_bytes
     unit, dtype = (8, torch.int64) if width % 8 == 0 else (4, torch.int32) if width % 4 == 0 else (1, torch.uint8)
     if send.data_ptr() % unit or recv.data_ptr() % unit:
         unit, dtype = 1, torch.uint8
     k = width // unit
-    dist.all_to_all_single(recv.view(dtype), send.view(dtype), output_split_sizes=[c * k for c in recv_counts],
-                           input_split_sizes=[c * k for c in send_counts], group=group)
+    world = len(send_counts)
+    # every rank must run the same number of rounds: agree on the largest split anywhere
+    biggest = max(list(send_counts) + list(recv_counts) + [0]) * width
+    dev = send.device
+    t = torch.tensor([biggest], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(t.item()) // limit))
+    if rounds == 1:
+        dist.all_to_all_single(recv.view(dtype), send.view(dtype), output_split_sizes=[c * k for c in recv_counts],
+                               input_split_sizes=[c * k for c in send_counts], group=group)
+        return
+    s_off = [0] * world
+    r_off = [0] * world
+    for j in range(1, world):
+        s_off[j] = s_off[j - 1] + send_counts[j - 1]
+        r_off[j] = r_off[j - 1] + recv_counts[j - 1]
+    for rd in range(rounds):
+        s_rng = [(c * rd // rounds, c * (rd + 1) // rounds) for c in send_counts]
+        r_rng = [(c * rd // rounds, c * (rd + 1) // rounds) for c in recv_counts]
+        stage_in = torch.cat([send[(s_off[j] + lo) * width:(s_off[j] + hi) * width] for j, (lo, hi) in enumerate(s_rng)])
+        n_in = sum(hi - lo for lo, hi in r_rng)
+        stage_out = torch.empty(n_in * width, dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(stage_out.view(dtype) if stage_out.data_ptr() % unit == 0 else stage_out,
+                               stage_in.view(dtype) if stage_in.data_ptr() % unit == 0 else stage_in,
+                               output_split_sizes=[(hi - lo) * (k if stage_out.data_ptr() % unit == 0 else width) for lo, hi in r_rng],
+                               input_split_sizes=[(hi - lo) * (k if stage_in.data_ptr() % unit == 0 else width) for lo, hi in s_rng], group=group)
+        o = 0
+        for j, (lo, hi) in enumerate(r_rng):
+            nb = (hi - lo) * width
+            recv[(r_off[j] + lo) * width:(r_off[j] + hi) * width].copy_(stage_out[o:o + nb])
+            o += nb
 
 
 def hash_exchange(table, keys, group=None, force=False):
@@ -124,20 +159,21 @@ def all_gather_bytes(send, recv, counts, width, group=None):
     unit, dtype = (8, torch.int64) if width % 8 == 0 else (4, torch.int32) if width % 4 == 0 else (1, torch.uint8)
     if send.data_ptr() % unit or recv.data_ptr() % unit:
         unit, dtype = 1, torch.uint8
-    if len(set(counts)) == 1:
+    if len(set(counts)) == 1 and counts[0] * width <= MAX_MESSAGE_BYTES:
         if counts[0]:
             dist.all_gather_into_tensor(recv.view(dtype), send.view(dtype), group=group)
         return
     off = 0
+    step = max(1, MAX_MESSAGE_BYTES // width)   # rows per message
     for r in range(world):
-        nb = counts[r] * width
-        if nb:
-            piece = recv[off:off + nb]
+        src = dist.get_global_rank(group, r) if group is not None else r
+        for lo in range(0, counts[r], step):
+            hi = min(counts[r], lo + step)
+            piece = recv[(off + lo) * width:(off + hi) * width]
             if r == rank:
-                piece.copy_(send[:nb])
-            src = dist.get_global_rank(group, r) if group is not None else r
+                piece.copy_(send[lo * width:hi * width])
             dist.broadcast(piece.view(dtype) if (piece.data_ptr() % unit == 0) else piece, src=src, group=group)
-        off += nb
+        off += counts[r]
 
 
 def broadcast_table(table, group=None, force=False):

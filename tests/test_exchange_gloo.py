@@ -37,7 +37,7 @@ def _table_slice(seed, rank, world):
     return build, probe, build.slice(lo_b, hi_b - lo_b), probe.slice(lo_p, hi_p - lo_p)
 
 
-def _exchange_cpu(table, key, world):
+def _exchange_cpu(table, key, world, max_message_bytes=None):
     """RepartitionExec(Hash) over gloo: partition (oracle) -> counts all-to-all -> one all-to-all(v) per column"""
     from datafusion_amd.exchange import all_to_all_bytes, exchange_counts
     from oracle import oracle
@@ -50,7 +50,7 @@ def _exchange_cpu(table, key, world):
         send_np = np.concatenate([np.frombuffer(oracle.values_np(p.column(name)).tobytes(), dtype=np.uint8) for p in parts]) if table.num_rows else np.zeros(0, np.uint8)
         send = torch.from_numpy(send_np.copy())
         recv = torch.empty(sum(recv_counts) * width, dtype=torch.uint8)
-        all_to_all_bytes(send, send_counts, recv, recv_counts, width)
+        all_to_all_bytes(send, send_counts, recv, recv_counts, width, max_message_bytes=max_message_bytes)
         out[name] = pa.Array.from_buffers(table.schema.field(name).type, sum(recv_counts), [None, pa.py_buffer(recv.numpy().tobytes())])
     return pa.table(out)
 
@@ -63,7 +63,7 @@ def _worker(rank, world, port, seed, outdir):
     from oracle import oracle
     _, _, my_build, my_probe = _table_slice(seed, rank, world)
     b = _exchange_cpu(my_build, "a", world)
-    p = _exchange_cpu(my_probe, "b", world)
+    p = _exchange_cpu(my_probe, "b", world, max_message_bytes=7000)   # several rounds per column (splits are ~40-60 KB)
     # routing contract: hash(key; seed 0) % world == rank for every received row
     for t, k in ((b, "a"), (p, "b")):
         h = oracle.create_hashes([t.column(k)], 0)
