@@ -1114,6 +1114,474 @@ extern "C" __global__ __launch_bounds__(BLOCK) void agg_node(Args a) {
   return src;
 }
 
+// ---------------------------------------------------------------- specialised node: one dense integer group key
+// GROUP BY <integer expression> with many groups (TPC-H: l_orderkey, o_custkey, l_partkey ...).  Hash interning
+// costs several random HBM accesses per row (slot, representative row's key, group id, accumulator): 125 ms for
+// 600 M rows / 150 M groups.  Integer keys that fill at least 1/64 of their value range are interned by RANK
+// instead, the structure of the join's rank map (join.hip): one bit per value of the range, group number =
+// number of set bits below the key's bit (popcount directory) — a 600 M-value range is a 75 MB bitmap that stays
+// in MALL / L2, and group numbers ascend with the key, so clustered input accumulates into neighbouring cells.
+//   minmax     : range of the key over the passing rows                      (generated, reads predicate + key)
+//   setbits    : bitmap[key - min] = 1                                        (generated)
+//   scan       : exclusive popcount prefix per bitmap word                    (scan.hip)
+//   accumulate : g = prefix[w] + popc(bits[w] & below); first_row[g] = min(row); cells[.][g] op= value  (generated)
+//   emit       : groups renumbered by first row (the reference's first-seen order), keys rebuilt from bit positions
+struct DenseNodeArgs {
+  const void* col[RP_MAX_COLS];
+  const uint64_t* valid[RP_MAX_COLS];
+  long long* minmax;             // [0] min, [1] max of the key
+  uint32_t* flags;               // [0] any NULL key among the passing rows, [1] passing rows with a key
+  unsigned long long* bits;      // bitmap over [kmin, kmax]
+  const uint64_t* prefix;        // exclusive popcount prefix per bitmap word
+  uint32_t* first_row;           // [G]
+  unsigned long long* cells;     // [ncellwords][G]
+  uint32_t* seen;                // [G]
+  int64_t kmin;
+  int64_t G;                     // groups incl. the NULL group (last) when present
+  int64_t null_group;            // group number of the NULL key, -1 = none
+  int64_t begin, end;
+};
+struct DenseAcc {
+  int kind;  // AccKind
+  int val;   // value id in the generated source, -1 = none (COUNT(*))
+  int cell;  // cell word (i128 sums: lo at cell, hi at cell + 1)
+};
+
+static std::string agg_dense_node_source(const CompiledProgram& cp, int key_val, const std::vector<DenseAcc>& accs) {
+  auto S = [](long long v) { return std::to_string(v); };
+  std::string row;  // per-row prologue shared by the three kernels (unused values are dead code in minmax / setbits)
+  row += cp.src_loads;
+  row += cp.src_pred;
+  if (cp.src_pred_val >= 0) row += "    if (N" + S(cp.src_pred_val) + " || !((int)V" + S(cp.src_pred_val) + " & 1)) continue;\n";
+  row += cp.src_outs;
+  row += "    const bool knull = N" + S(key_val) + ";\n    const long long key = (long long)(U64)V" + S(key_val) + ";\n";
+  std::string src = R"SRC(
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+typedef unsigned long long U64;
+typedef long long I64;
+typedef unsigned int U32;
+typedef int I32;
+typedef unsigned char U8;
+#define BLOCK 256
+struct Args {
+  const void* col[10];
+  const U64* valid[10];
+  long long* minmax;
+  U32* flags;
+  U64* bits;
+  const U64* prefix;
+  U32* first_row;
+  U64* cells;
+  U32* seen;
+  long long kmin;
+  long long G;
+  long long null_group;
+  long long begin, end;
+};
+__device__ __forceinline__ double v2f(i128 x) { return __longlong_as_double((long long)(U64)x); }
+__device__ __forceinline__ i128 f2v(double d) { return (i128)(u128)(U64)__double_as_longlong(d); }
+__device__ __forceinline__ long long f64ord(U64 bits) { long long b = (long long)bits; return b ^ (long long)((U64)(b >> 63) >> 1); }
+__device__ __forceinline__ bool kt(i128 v, bool n) { return !n && ((int)v & 1); }
+__device__ __forceinline__ bool kf(i128 v, bool n) { return !n && !((int)v & 1); }
+// Segmented inclusive scans over the lanes of a wave: a run = adjacent lanes holding the same group (`head` marks
+// its first lane).  The run's last lane ends up with the run's total, so clustered input issues ONE atomic per run
+// and accumulator instead of one per row.  Every lane of the wave must be executing.
+#define SEG_SCAN(STEP)                                        \
+  bool f = head;                                              \
+  const int lane = threadIdx.x & 63;                          \
+  _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) {        \
+    const int fo = __shfl_up((int)f, d, 64);                  \
+    STEP                                                      \
+    if (lane >= d && !f) f = fo != 0;                         \
+  }
+__device__ __forceinline__ U64 seg_add_u64(U64 v, bool head) {
+  SEG_SCAN(const U64 o = __shfl_up(v, d, 64); if (lane >= d && !f) v += o;)
+  return v;
+}
+__device__ __forceinline__ u128 seg_add_u128(u128 v, bool head) {
+  SEG_SCAN(const U64 ol = __shfl_up((U64)v, d, 64); const U64 oh = __shfl_up((U64)(v >> 64), d, 64); if (lane >= d && !f) v += ((u128)oh << 64) | ol;)
+  return v;
+}
+__device__ __forceinline__ double seg_add_f64(double v, bool head) {
+  SEG_SCAN(const double o = __shfl_up(v, d, 64); if (lane >= d && !f) v += o;)
+  return v;
+}
+__device__ __forceinline__ long long seg_min_i64(long long v, bool head) {
+  SEG_SCAN(const long long o = __shfl_up(v, d, 64); if (lane >= d && !f) v = o < v ? o : v;)
+  return v;
+}
+__device__ __forceinline__ long long seg_max_i64(long long v, bool head) {
+  SEG_SCAN(const long long o = __shfl_up(v, d, 64); if (lane >= d && !f) v = o > v ? o : v;)
+  return v;
+}
+
+extern "C" __global__ __launch_bounds__(BLOCK) void dense_minmax(Args a) {
+  long long mn = 0x7fffffffffffffffll, mx = -0x7fffffffffffffffll - 1;
+  unsigned any_null = 0u, rows = 0u;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = a.begin + (long long)blockIdx.x * BLOCK + threadIdx.x; i < a.end; i += stride) {
+)SRC";
+  src += row;
+  src += R"SRC(    if (knull) { any_null = 1u; continue; }
+    rows = 1u;
+    mn = key < mn ? key : mn;
+    mx = key > mx ? key : mx;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const long long omn = __shfl_xor(mn, d, 64), omx = __shfl_xor(mx, d, 64);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+    any_null |= __shfl_xor(any_null, d, 64);
+    rows |= __shfl_xor(rows, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (rows) {
+      atomicMin(a.minmax, mn);
+      atomicMax(a.minmax + 1, mx);
+      atomicOr(a.flags + 1, 1u);
+    }
+    if (any_null) atomicOr(a.flags, 1u);
+  }
+}
+
+// Bits only ever go 0 -> 1, so the plain (possibly stale) read is a safe filter: it can only cause a redundant atomic.
+extern "C" __global__ __launch_bounds__(BLOCK) void dense_setbits(Args a) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  const long long n_round = a.begin + (a.end - a.begin + BLOCK - 1) / BLOCK * BLOCK;
+  for (long long i = a.begin + (long long)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += stride) {
+    long long idx = -1 - (long long)(threadIdx.x & 63);
+    if (i < a.end) do {
+)SRC";
+  src += row;
+  src += R"SRC(      if (!knull) idx = key - a.kmin;
+    } while (0);
+    const long long prev = __shfl_up(idx, 1, 64);
+    if (idx >= 0 && ((threadIdx.x & 63) == 0 || prev != idx)) {
+      const U64 bit = 1ull << (idx & 63);
+      U64* w = a.bits + (idx >> 6);
+      if (!(*w & bit)) atomicOr(w, bit);
+    }
+  }
+}
+
+extern "C" __global__ __launch_bounds__(BLOCK) void dense_accumulate(Args a) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  const long long n_round = a.begin + (a.end - a.begin + BLOCK - 1) / BLOCK * BLOCK;
+  const int lane_ = threadIdx.x & 63;
+  for (long long i = a.begin + (long long)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += stride) {
+    long long g = -1 - (long long)lane_;  // dropped rows: a run of their own, nothing to add
+)SRC";
+  for (size_t k = 0; k < accs.size(); k++) {
+    src += "    U64 X" + S((long long)k) + "lo = 0ull, X" + S((long long)k) + "hi = 0ull; bool X" + S((long long)k) + "ok = false;\n";
+  }
+  src += "    if (i < a.end) do {\n";
+  src += row;
+  src += R"SRC(      g = a.null_group;
+      if (!knull) {
+        const U64 idx = (U64)(key - a.kmin);
+        g = (long long)(a.prefix[idx >> 6] + __popcll(a.bits[idx >> 6] & ((1ull << (idx & 63)) - 1ull)));
+      }
+)SRC";
+  for (size_t k = 0; k < accs.size(); k++) {
+    const DenseAcc& c = accs[k];
+    const std::string X = "X" + S((long long)k);
+    if (c.val >= 0) {
+      src += "      " + X + "ok = !N" + S(c.val) + "; " + X + "lo = (U64)V" + S(c.val) + "; " + X + "hi = (U64)((u128)V" + S(c.val) + " >> 64);\n";
+    } else {
+      src += "      " + X + "ok = true;\n";
+    }
+  }
+  src += R"SRC(    } while (0);
+    const long long gprev = __shfl_up(g, 1, 64), gnext = __shfl_down(g, 1, 64);
+    const bool head = lane_ == 0 || gprev != g;
+    const bool tail = (lane_ == 63 || gnext != g) && g >= 0;
+    const U64 run_len = seg_add_u64(1ull, head);
+    if (tail) {
+      const unsigned first = (unsigned)(i - (long long)run_len + 1);  // the run's rows are consecutive
+      unsigned* fr = a.first_row + g;
+      if (first < *fr) atomicMin(fr, first);
+    }
+    unsigned seen = 0u;
+)SRC";
+  for (size_t k = 0; k < accs.size(); k++) {
+    const DenseAcc& c = accs[k];
+    const std::string X = "X" + S((long long)k);
+    const bool maybe_null = c.val >= 0 && cp.src_maybe_null[(size_t)c.val];
+    const std::string cell = "(a.cells + " + S(c.cell) + " * a.G + g)";
+    // number of contributing rows of the run: the run length unless the value can be NULL
+    const std::string cnt = maybe_null ? "seg_add_u64(" + X + "ok ? 1ull : 0ull, head)" : "run_len";
+    src += "    {\n      const U64 cnt = " + cnt + ";\n";
+    switch (c.kind) {
+      case ACC_SUM_I128:
+        src += "      const u128 t = seg_add_u128(" + X + "ok ? (((u128)" + X + "hi << 64) | " + X + "lo) : (u128)0, head);\n"
+               "      if (tail && cnt) { seen |= " + S(1ll << k) + "u; const U64 lo = (U64)t, hi = (U64)(t >> 64); const U64 old = atomicAdd(" + cell +
+               ", lo); atomicAdd(" + cell + " + a.G, hi + ((old + lo) < old ? 1ull : 0ull)); }\n";
+        break;
+      case ACC_SUM_I64:
+        src += "      const U64 t = seg_add_u64(" + X + "ok ? " + X + "lo : 0ull, head);\n      if (tail && cnt) { seen |= " + S(1ll << k) + "u; atomicAdd(" + cell + ", t); }\n";
+        break;
+      case ACC_SUM_F64:
+        src += "      const double t = seg_add_f64(" + X + "ok ? __longlong_as_double((long long)" + X + "lo) : 0.0, head);\n      if (tail && cnt) { seen |= " +
+               S(1ll << k) + "u; atomicAdd(reinterpret_cast<double*>" + cell + ", t); }\n";
+        break;
+      case ACC_MIN_I64:
+        src += "      const long long t = seg_min_i64(" + X + "ok ? (long long)" + X + "lo : 0x7fffffffffffffffll, head);\n      if (tail && cnt) { seen |= " +
+               S(1ll << k) + "u; atomicMin(reinterpret_cast<long long*>" + cell + ", t); }\n";
+        break;
+      case ACC_MAX_I64:
+        src += "      const long long t = seg_max_i64(" + X + "ok ? (long long)" + X + "lo : (-0x7fffffffffffffffll - 1), head);\n      if (tail && cnt) { seen |= " +
+               S(1ll << k) + "u; atomicMax(reinterpret_cast<long long*>" + cell + ", t); }\n";
+        break;
+      default:
+        src += "      if (tail && cnt) { seen |= " + S(1ll << k) + "u; atomicAdd(" + cell + ", cnt); }\n";
+        break;
+    }
+    src += "    }\n";
+  }
+  src += "    if (tail && (seen & ~a.seen[g])) atomicOr(a.seen + g, seen);\n  }\n}\n";
+  return src;
+}
+
+// first rows -> bitmap over row numbers
+__global__ __launch_bounds__(BLOCK) void k_mark_first_rows(const uint32_t* __restrict__ first_row, int64_t G, unsigned long long* __restrict__ rep_mask) {
+  for (int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x; g < G; g += (int64_t)gridDim.x * BLOCK) {
+    const uint32_t fr = first_row[g];
+    atomicOr(&rep_mask[fr >> 6], 1ull << (fr & 63));
+  }
+}
+struct DenseEmit {
+  unsigned long long* dst[2 * MAX_AGGS];  // destination arrays [G], first-seen order
+  int src_word[2 * MAX_AGGS];             // cell word copied to dst
+  int n_dst;
+  uint32_t* seen_dst[MAX_AGGS];
+  int seen_bit[MAX_AGGS];
+  int n_seen;
+};
+// key-order group g -> first-seen number; accumulators and seen flags permuted
+__global__ __launch_bounds__(BLOCK) void k_dense_permute(const uint32_t* __restrict__ first_row, const unsigned long long* __restrict__ cells,
+                                                        const uint32_t* __restrict__ seen, int64_t G, const uint64_t* __restrict__ rep_mask,
+                                                        const uint64_t* __restrict__ prefix, uint32_t* __restrict__ new_gid, DenseEmit e) {
+  for (int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x; g < G; g += (int64_t)gridDim.x * BLOCK) {
+    const uint32_t fr = first_row[g];
+    const uint64_t below = rep_mask[fr >> 6] & ((1ull << (fr & 63)) - 1ull);
+    const int64_t ng = (int64_t)(prefix[fr >> 6] + __popcll(below));
+    new_gid[g] = (uint32_t)ng;
+    for (int d = 0; d < e.n_dst; d++) e.dst[d][ng] = cells[(int64_t)e.src_word[d] * G + g];
+    const uint32_t sb = seen[g];
+    for (int d = 0; d < e.n_seen; d++) e.seen_dst[d][ng] = (sb >> e.seen_bit[d]) & 1u;
+  }
+}
+// set bits of the key bitmap -> key values at their groups' first-seen numbers
+__global__ __launch_bounds__(BLOCK) void k_dense_keys(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ prefix, int64_t n_words, int64_t kmin,
+                                                     const uint32_t* __restrict__ new_gid, unsigned long long* __restrict__ key_out) {
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const uint64_t m = bits[w];
+    if ((m >> lane_id()) & 1ull) {
+      const int64_t g = (int64_t)(prefix[w] + mbcnt(m));
+      key_out[new_gid[g]] = (unsigned long long)(kmin + (w << 6) + (int64_t)lane_id());
+    }
+  }
+}
+
+// The specialised dense-key node.  Returns false (state untouched) when it does not apply.
+static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_expr* pred) {
+  Runtime& r = rt();
+  const int64_t n = in.nrows;
+  if (env_int("DFGPU_JIT", 1) == 0 || A.group_roots.size() != 1 || A.ngroups != 0) return false;
+  if (n < env_int("DFGPU_JIT_MIN_ROWS", 1 << 22) || n >= 0xFFFFFFFFll) return false;
+  // ---- compile: predicate, key expression, aggregate arguments
+  std::string why;
+  RowProgramCompiler comp(in);
+  if (pred) comp.set_predicate(*pred);
+  dfgpu_expr ke{A.group_nodes[0].data(), (int)A.group_nodes[0].size(), A.group_roots[0]};
+  const int key_out = comp.add_output(ke);
+  const dfgpu_field kf = comp.output_type(key_out);
+  if (!(kf.type == DFGPU_INT32 || kf.type == DFGPU_INT64 || kf.type == DFGPU_DATE32 || kf.type == DFGPU_UINT32 || kf.type == DFGPU_UINT8)) return false;
+  std::vector<int> arg_out(A.aggs.size(), -1);
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    if (!a.has_arg) continue;
+    dfgpu_expr e{a.nodes.data(), (int)a.nodes.size(), a.root};
+    arg_out[k] = comp.add_output(e);
+    dfgpu_field t = comp.output_type(arg_out[k]);
+    if (a.typed) DFGPU_CHECK(a.in_type.type == t.type, "aggregate argument type changed between batches");
+    AccPlan p = plan_for(a.func, t, false);
+    if (p.val == VAL_I32_TO_F64 || p.val == VAL_I64_TO_F64) comp.convert_output(arg_out[k], RP_I2F, t);
+    else if (p.val == VAL_F64_ORDERED) comp.convert_output(arg_out[k], RP_F64ORD, t);
+  }
+  CompiledProgram cp;
+  if (!comp.finish(cp, why)) return false;
+  // ---- accumulator cells
+  struct Ent { int agg; bool is_avg_count; int kind; int cell; int seen_bit; };
+  std::vector<Ent> entries;
+  std::vector<DenseAcc> accs;
+  std::vector<int> cell_kind;
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    dfgpu_field t = a.typed ? a.in_type : (a.has_arg ? cp.out_types[(size_t)arg_out[k]] : fld(DFGPU_INT64));
+    AccPlan pl = plan_for(a.func, t, false);
+    const int kind = (a.func == DFGPU_AGG_COUNT && !a.has_arg) ? ACC_COUNT_STAR : pl.kind;
+    const int val = a.has_arg ? cp.src_out_vals[(size_t)arg_out[k]] : -1;
+    auto unique = [&](int kd) {
+      for (size_t u = 0; u < accs.size(); u++)
+        if (accs[u].kind == kd && accs[u].val == val) return (int)u;
+      accs.push_back({kd, val, (int)cell_kind.size()});
+      cell_kind.push_back(kd == ACC_SUM_I128 ? ACC_SUM_I64 : kd);
+      if (kd == ACC_SUM_I128) cell_kind.push_back(ACC_SUM_I64);
+      return (int)accs.size() - 1;
+    };
+    int u = unique(kind);
+    entries.push_back({(int)k, false, kind, accs[(size_t)u].cell, u});
+    if (a.func == DFGPU_AGG_AVG) {
+      int uc = unique(ACC_COUNT);
+      entries.push_back({(int)k, true, ACC_COUNT, accs[(size_t)uc].cell, uc});
+    }
+  }
+  if (accs.size() > 32 || entries.size() > (size_t)MAX_AGGS) return false;
+  const std::string source = agg_dense_node_source(cp, cp.src_out_vals[(size_t)key_out], accs);
+  hipFunction_t f_minmax = nullptr, f_setbits = nullptr, f_acc = nullptr;
+  try {
+    f_minmax = jit_get(source, "dense_minmax");
+    f_setbits = jit_get(source, "dense_setbits");
+    f_acc = jit_get(source, "dense_accumulate");
+  } catch (const Error& e) {
+    if (env_int("DFGPU_JIT_STRICT", 0)) throw;
+    fprintf(stderr, "[dfgpu] node specialisation failed, using the interpreter: %s\n", e.what());
+    return false;
+  }
+  DenseNodeArgs args{};
+  for (int c = 0; c < cp.prog.n_cols; c++) {
+    args.col[c] = cp.prog.col_data[c];
+    args.valid[c] = cp.prog.col_valid[c];
+  }
+  args.begin = 0;
+  args.end = n;
+  const int grid = grid_for(n, BLOCK);
+  // ---- key range (no state is modified until the node is known to apply)
+  BufPtr mm = make_buf(16), flags = make_zero_buf(8);
+  const long long init_mm[2] = {INT64_MAX, INT64_MIN};
+  h2d_async(mm->ptr, init_mm, 16);
+  args.minmax = mm->as<long long>();
+  args.flags = flags->as<uint32_t>();
+  int64_t key_bytes = n * (kf.type == DFGPU_INT64 ? 8 : kf.type == DFGPU_UINT8 ? 1 : 4);
+  {
+    ProfileScope ps("agg_dense_key_range", key_bytes);
+    jit_launch(f_minmax, grid, BLOCK, 0, &args, sizeof(args));
+  }
+  long long hmm[2];
+  uint32_t hflags[2];
+  d2h(hmm, mm->ptr, 16);
+  d2h(hflags, flags->ptr, 8);
+  const bool any_rows = hflags[1] != 0, null_group = hflags[0] != 0;
+  uint64_t range = any_rows ? (uint64_t)hmm[1] - (uint64_t)hmm[0] + 1 : 0;
+  // dense enough: at most 64 bitmap bits per input row (the join's rank-map gate), and a bounded bitmap
+  if (range > (1ull << 36) || range > (uint64_t)n * 64) return false;
+  // ---- from here on state is modified
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    if (!a.typed) {
+      a.in_type = a.has_arg ? cp.out_types[(size_t)arg_out[k]] : fld(DFGPU_INT64);
+      a.typed = true;
+    }
+  }
+  const int64_t n_words = (int64_t)((range + 63) / 64) + 1;
+  BufPtr bits = make_zero_buf((size_t)n_words * 8);
+  BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
+  args.bits = bits->as<unsigned long long>();
+  args.kmin = any_rows ? hmm[0] : 0;
+  if (any_rows) {
+    ProfileScope ps("agg_dense_setbits", key_bytes);
+    jit_launch(f_setbits, grid, BLOCK, 0, &args, sizeof(args));
+  }
+  scan_mask_popcounts(bits->as<uint64_t>(), nullptr, n_words * 64, prefix->as<uint64_t>());
+  const int64_t Gk = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+  const int64_t G = Gk + (null_group ? 1 : 0);
+  const int ncw = (int)cell_kind.size();
+  BufPtr first_row = make_buf((size_t)std::max<int64_t>(G, 1) * 4);
+  DFGPU_HIP(hipMemsetAsync(first_row->ptr, 0xFF, (size_t)std::max<int64_t>(G, 1) * 4, r.stream));
+  BufPtr seen = make_zero_buf((size_t)std::max<int64_t>(G, 1) * 4);
+  BufPtr cells = make_buf((size_t)std::max(1, ncw) * std::max<int64_t>(G, 1) * 8);
+  for (int w = 0; w < ncw && G; w++)
+    k_fill_u64<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(acc_identity(cell_kind[(size_t)w]), G, cells->as<unsigned long long>() + (int64_t)w * G);
+  args.prefix = prefix->as<uint64_t>();
+  args.first_row = first_row->as<uint32_t>();
+  args.cells = cells->as<unsigned long long>();
+  args.seen = seen->as<uint32_t>();
+  args.G = G;
+  args.null_group = null_group ? Gk : -1;
+  if (G) {
+    ProfileScope ps("agg_dense_accumulate", n * cp.input_bytes_per_row);
+    jit_launch(f_acc, grid, BLOCK, 0, &args, sizeof(args));
+  }
+  // ---- first-seen order (group_values/mod.rs:88-92), keys rebuilt from the bit positions
+  const int64_t row_words = (n + 63) / 64;
+  BufPtr rep_mask = make_zero_buf((size_t)row_words * 8);
+  BufPtr rprefix = make_buf((size_t)(row_words + 1) * 8);
+  if (G) k_mark_first_rows<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(first_row->as<uint32_t>(), G, rep_mask->as<unsigned long long>());
+  scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, n, rprefix->as<uint64_t>());
+  DFGPU_CHECK((int64_t)read_u64(rprefix->as<uint64_t>() + row_words) == G, "dense-key node: first-row marks do not match the group count");
+  grow_accumulators(A, 0, G);
+  DenseEmit e{};
+  for (const Ent& en : entries) {
+    AggState& a = A.aggs[(size_t)en.agg];
+    if (en.is_avg_count) {
+      e.dst[e.n_dst] = a.cnt->as<unsigned long long>();
+      e.src_word[e.n_dst++] = en.cell;
+    } else {
+      e.dst[e.n_dst] = a.lo->as<unsigned long long>();
+      e.src_word[e.n_dst++] = en.cell;
+      if (en.kind == ACC_SUM_I128) {
+        e.dst[e.n_dst] = a.hi->as<unsigned long long>();
+        e.src_word[e.n_dst++] = en.cell + 1;
+      }
+      e.seen_dst[e.n_seen] = a.seen->as<uint32_t>();
+      e.seen_bit[e.n_seen++] = en.seen_bit;
+    }
+  }
+  BufPtr new_gid = make_buf((size_t)std::max<int64_t>(G, 1) * 4);
+  BufPtr key_i64 = make_zero_buf((size_t)std::max<int64_t>(G, 1) * 8);
+  if (G) {
+    ProfileScope ps("agg_dense_emit", G * (4 + 8 * (int64_t)e.n_dst));
+    k_dense_permute<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(first_row->as<uint32_t>(), cells->as<unsigned long long>(), seen->as<uint32_t>(), G,
+                                                                rep_mask->as<uint64_t>(), rprefix->as<uint64_t>(), new_gid->as<uint32_t>(), e);
+    k_dense_keys<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(bits->as<uint64_t>(), prefix->as<uint64_t>(), n_words, args.kmin, new_gid->as<uint32_t>(),
+                                                                          key_i64->as<unsigned long long>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  Column kc = alloc_column(kf, A.group_names[0], G);
+  if (G) {
+    int mode = 0;
+    if (kf.type == DFGPU_INT32 || kf.type == DFGPU_DATE32 || kf.type == DFGPU_UINT32) mode = 3;
+    else if (kf.type == DFGPU_UINT8) mode = 4;
+    k_emit_values<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(mode, key_i64->as<unsigned long long>(), nullptr, nullptr, G, kc.data->ptr, nullptr);
+    DFGPU_HIP(hipGetLastError());
+    if (null_group) {
+      // the NULL group's first-seen number
+      uint32_t ng = 0;
+      d2h(&ng, new_gid->as<uint32_t>() + Gk, 4);
+      std::vector<uint8_t> vb((size_t)G, 1);
+      vb[ng] = 0;
+      BufPtr dvb = make_buf((size_t)G + 64);
+      h2d_async(dvb->ptr, vb.data(), (size_t)G);
+      kc.validity = make_buf(bitmap_bytes(G));
+      pack_bytes_to_bitmap(dvb->as<uint8_t>(), G, kc.validity->as<uint64_t>());
+      kc.null_count = 1;
+      DFGPU_HIP(hipStreamSynchronize(r.stream));
+    }
+  }
+  Table gk;
+  gk.nrows = G;
+  gk.cols.push_back(std::move(kc));
+  A.group_keys = std::move(gk);
+  A.ngroups = G;
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  return true;
+}
+
 // The single-pass small-domain node (k_agg_fused_tile).  `cp` = predicate + key bytes + arguments.
 // Returns false (state untouched) when the forest has no tile form or the LDS budget does not fit.
 constexpr size_t TILE_LDS_BUDGET = 64 * 1024;  // per workgroup: at least two workgroups per CU (160 KiB LDS)
@@ -1337,6 +1805,7 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
   std::vector<int> small_cols;
   const bool small = small_domain_applicable(A, in, small_cols);
   const int gid_mode = ngk == 0 ? GID_NONE : small ? GID_SMALL : GID_HASH;
+  if (gid_mode == GID_HASH && A.ngroups == 0 && agg_update_dense_key_jit(A, in, pred)) return true;
 
   // ---- compile: predicate, (small mode) key bytes, aggregate arguments
   RowProgramCompiler comp(in);

@@ -18,7 +18,7 @@ namespace dfgpu {
 
 struct JitEntry {
   hipModule_t module = nullptr;
-  hipFunction_t fn = nullptr;
+  std::unordered_map<std::string, hipFunction_t> fns;
 };
 static std::mutex g_jit_mu;
 static std::unordered_map<std::string, JitEntry> g_jit_cache;
@@ -33,8 +33,16 @@ static int64_t g_jit_compiles = 0;
 
 hipFunction_t jit_get(const std::string& source, const char* kernel_name) {
   std::lock_guard<std::mutex> g(g_jit_mu);
+  auto function_of = [&](JitEntry& e) {
+    auto f = e.fns.find(kernel_name);
+    if (f != e.fns.end()) return f->second;
+    hipFunction_t fn = nullptr;
+    DFGPU_HIP(hipModuleGetFunction(&fn, e.module, kernel_name));
+    e.fns.emplace(kernel_name, fn);
+    return fn;
+  };
   auto it = g_jit_cache.find(source);
-  if (it != g_jit_cache.end()) return it->second.fn;
+  if (it != g_jit_cache.end()) return function_of(it->second);
   auto t0 = std::chrono::steady_clock::now();
   hiprtcProgram prog;
   DFGPU_RTC(hiprtcCreateProgram(&prog, source.c_str(), "dfgpu_node.hip", 0, nullptr, nullptr));
@@ -55,11 +63,10 @@ hipFunction_t jit_get(const std::string& source, const char* kernel_name) {
   DFGPU_RTC(hiprtcDestroyProgram(&prog));
   JitEntry e;
   DFGPU_HIP(hipModuleLoadData(&e.module, code.data()));
-  DFGPU_HIP(hipModuleGetFunction(&e.fn, e.module, kernel_name));
-  g_jit_cache.emplace(source, e);
+  auto ins = g_jit_cache.emplace(source, e);
   g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   g_jit_compiles++;
-  return e.fn;
+  return function_of(ins.first->second);
 }
 
 void jit_launch(hipFunction_t fn, int grid, int block, size_t lds_bytes, void* args, size_t args_bytes) {

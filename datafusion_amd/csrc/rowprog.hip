@@ -471,9 +471,11 @@ bool RowProgramCompiler::finish(CompiledProgram& cp, std::string& why) {
       }
     };
     std::string loads, pred_src, outs_src;
+    std::vector<bool> maybe_null((size_t)nv, false);
     for (int v = 0; v < nv; v++) {
       const Val& x = vals_[v];
       if (x.op != 0xFF) continue;
+      maybe_null[(size_t)v] = P.col_valid[x.slot] != nullptr;
       const std::string sl = std::to_string(x.slot), c = "C" + sl;
       std::string decl, widen;
       switch (P.col_kind[x.slot]) {
@@ -526,6 +528,11 @@ bool RowProgramCompiler::finish(CompiledProgram& cp, std::string& why) {
         case RP_IS_NOT_NULL: val = "(i128)(!" + NA + ")"; nul = "false"; break;
         default: val = A; nul = NA; break;  // RP_MOV
       }
+      switch (x.op) {
+        case RP_LIT: maybe_null[(size_t)v] = x.lit_null; break;
+        case RP_IS_NULL: case RP_IS_NOT_NULL: maybe_null[(size_t)v] = false; break;
+        default: maybe_null[(size_t)v] = (x.a >= 0 && maybe_null[(size_t)x.a]) || (x.b >= 0 && maybe_null[(size_t)x.b]); break;
+      }
       st = "    const i128 " + V(v) + " = " + val + ";\n    const bool " + N(v) + " = " + nul + ";\n";
       if (x.seg <= 1) pred_src += st;  // literals (seg 0) are declared with the predicate: visible to both segments
       else outs_src += st;
@@ -534,6 +541,7 @@ bool RowProgramCompiler::finish(CompiledProgram& cp, std::string& why) {
     cp.src_pred = pred_src;
     cp.src_outs = outs_src;
     cp.src_pred_val = pred_;
+    cp.src_maybe_null = maybe_null;
     for (const RpValue& o : outs_) cp.src_out_vals.push_back(o.id);
   }
   if (const char* dump = std::getenv("DFGPU_RP_DUMP"); dump && *dump == '1') {

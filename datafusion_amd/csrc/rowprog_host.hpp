@@ -40,6 +40,7 @@ struct CompiledProgram {
   std::string src_outs;        // output segment
   int src_pred_val = -1;       // value id of the predicate (V<id> / N<id>), -1 = none
   std::vector<int> src_out_vals;
+  std::vector<bool> src_maybe_null;  // per value id: can N<id> ever be true?
 };
 
 class RowProgramCompiler {
