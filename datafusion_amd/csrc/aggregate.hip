@@ -759,7 +759,7 @@ __global__ __launch_bounds__(BLOCK) void k_small_merge(const uint32_t* __restric
 __global__ __launch_bounds__(BLOCK) void k_and_words(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, int64_t nw, uint64_t* __restrict__ out) {
   for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < nw; w += (int64_t)gridDim.x * BLOCK) out[w] = a[w] & b[w];
 }
-static void and_bitmaps(const uint64_t* a, const uint64_t* b, int64_t nw, uint64_t* out) {
+void and_bitmaps(const uint64_t* a, const uint64_t* b, int64_t nw, uint64_t* out) {
   if (nw) k_and_words<<<grid_for(nw, BLOCK), BLOCK, 0, rt().stream>>>(a, b, nw, out);
 }
 

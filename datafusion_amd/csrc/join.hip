@@ -649,7 +649,7 @@ __device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* __restrict__ ti
 
 template <int KIND, int KT, int W, bool ORDERED>
 __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopyCols cols, int64_t np, int invert, uint64_t* __restrict__ tile_state,
-                                                            FusedCtl* __restrict__ ctl) {
+                                                            FusedCtl* __restrict__ ctl, const uint64_t* __restrict__ row_mask) {
   __shared__ unsigned s_tile;
   __shared__ uint32_t s_wcount[BLOCK / WAVE];
   __shared__ uint64_t s_prefix;
@@ -680,6 +680,8 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
     for (int j = 0; j < W; j++) {
       int64_t p = ((w0 + j) << 6) + lane;
       word[j] = ballot64(p < np && ((m[j] != 0) != (invert != 0)));
+      // a FilterExec fused below the probe side: rows whose predicate is false / NULL do not exist for the join
+      if (row_mask) word[j] &= (w0 + j < n_words) ? row_mask[w0 + j] : 0ull;
       wave_cnt += (uint32_t)__popcll(word[j]);
     }
     if (lane == 0) s_wcount[wv] = wave_cnt;
@@ -962,7 +964,7 @@ static bool needs_visited(int join_type) {
 }
 
 static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
-                        const std::vector<int>& pout) {
+                        const std::vector<int>& pout, const uint64_t* row_mask = nullptr, bool* mask_consumed = nullptr) {
   Runtime& r = rt();
   DFGPU_CHECK(pk.size() == jt.key_cols.size(), "probe key count differs from build key count");
   const int64_t np = probe.nrows;
@@ -999,6 +1001,12 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const bool use_fused = fused_ok && np > 0 && (jt.probe_mode == 2 || jt.probe_mode == 3);
   DFGPU_CHECK(!((jt.probe_mode == 2 || jt.probe_mode == 3) && !fused_ok),
               "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
+  if (row_mask) {
+    // only the single-pass probe applies a probe-side row mask in place; otherwise the caller filters first
+    DFGPU_CHECK(mask_consumed != nullptr, "probe row mask without a fallback");
+    *mask_consumed = use_fused;
+    if (!use_fused) return Table{};
+  }
   if (use_fused) {
     size_t free_b = 0, total_b = 0;
     DFGPU_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1045,7 +1053,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     // ordered: persistent workgroups pulling tickets; unordered: one workgroup per tile
     const unsigned g = ordered ? (unsigned)std::min<int64_t>(n_tiles, (int64_t)r.num_cus * 8) : (unsigned)n_tiles;
     uint64_t* st = state ? state->as<uint64_t>() : nullptr;
-    auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>()); };
+    auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>(), row_mask); };
     with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
       constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
       if (ordered) launch(k_join_probe_fused<K, T, FUSED_W, true>);
@@ -1176,6 +1184,40 @@ int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_
     std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
     std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
     auto o = std::make_unique<Table>(join_probe(*jt, *unwrap(probe), pk, join_type, bo, po));
+    *out = wrap(o.release());
+  });
+}
+
+int dfgpu_join_probe_filtered(dfgpu_join_t ht, dfgpu_table_t probe, const dfgpu_expr* probe_predicate, const int* probe_key_cols, int join_type,
+                              const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(ht && out && probe_predicate, "null argument");
+    JoinTable* jt = reinterpret_cast<JoinTable*>(ht);
+    DFGPU_CHECK(join_type >= DFGPU_JOIN_INNER && join_type <= DFGPU_JOIN_RIGHT_MARK, "bad join type");
+    const Table& pt = *unwrap(probe);
+    std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
+    std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
+    // FilterExec predicate -> row mask (NULL => dropped, filter.rs:1396-1419)
+    Datum m = evaluate(*probe_predicate, pt);
+    DFGPU_CHECK(m.col.field.type == DFGPU_BOOL, "Cannot create filter with non-boolean predicate");
+    Column mc = datum_to_column(m, pt.nrows, "");
+    BufPtr mask = mc.data;
+    if (mc.validity) {
+      mask = make_buf(bitmap_bytes(pt.nrows));
+      and_bitmaps(mc.data->as<uint64_t>(), mc.valid_words(), (pt.nrows + 63) / 64, mask->as<uint64_t>());
+    }
+    bool consumed = false;
+    Table res = join_probe(*jt, pt, pk, join_type, bo, po, mask->as<uint64_t>(), &consumed);
+    if (!consumed) {
+      // general path: FilterExec materialised, then the probe
+      std::vector<int> all(pt.cols.size());
+      for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
+      Table filtered = compact_table(pt, all, mask->as<uint64_t>(), nullptr);
+      res = join_probe(*jt, filtered, pk, join_type, bo, po);
+    }
+    DFGPU_HIP(hipStreamSynchronize(rt().stream));
+    auto o = std::make_unique<Table>(std::move(res));
     *out = wrap(o.release());
   });
 }

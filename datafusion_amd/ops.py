@@ -65,7 +65,10 @@ class JoinHashTable:
         check(lib.dfgpu_join_build(build.handle, _ints(self.key_idx), len(self.key_idx), NULL_EQUALITY[null_equality],
                                    C.byref(opts), C.byref(self._h)))
 
-    def probe(self, probe: DeviceTable, on_right, join_type="Inner", build_cols=None, probe_cols=None) -> DeviceTable:
+    def probe(self, probe: DeviceTable, on_right, join_type="Inner", build_cols=None, probe_cols=None,
+              predicate: PhysicalExpr | None = None) -> DeviceTable:
+        """`predicate` = a FilterExec fused below the probe side: with the single-pass probe its row mask is applied
+        inside the probe kernel and the filtered probe table is never materialised (dfgpu_join_probe_filtered)"""
         lib = _lib.load()
         pk = [probe.index_of(k) for k in on_right]
         bc = list(range(self.build.num_columns)) if build_cols is None else [self.build.index_of(c) for c in build_cols]
@@ -75,8 +78,13 @@ class JoinHashTable:
         if join_type in ("RightSemi", "RightAnti", "RightMark"):
             bc = []
         out = C.c_void_p()
-        check(lib.dfgpu_join_probe(self._h, probe.handle, _ints(pk), JOIN_TYPES[join_type], _ints(bc), len(bc), _ints(pc),
-                                   len(pc), C.byref(out)))
+        if predicate is None:
+            check(lib.dfgpu_join_probe(self._h, probe.handle, _ints(pk), JOIN_TYPES[join_type], _ints(bc), len(bc), _ints(pc),
+                                       len(pc), C.byref(out)))
+        else:
+            le = lower(predicate, probe.column_names)
+            check(lib.dfgpu_join_probe_filtered(self._h, probe.handle, C.byref(le.c), _ints(pk), JOIN_TYPES[join_type], _ints(bc), len(bc),
+                                                _ints(pc), len(pc), C.byref(out)))
         return DeviceTable(out)
 
     def emit_unmatched(self, join_type, build_cols=None, probe_schema: pa.Schema | None = None) -> DeviceTable:
@@ -230,6 +238,13 @@ def aggregate(table: DeviceTable, group_by, aggs, mode="Single", predicate: Phys
     out = a.emit()
     a.free()
     return out
+
+
+def jit_stats():
+    """(distinct nodes compiled with hiprtc, total compile ms) of this process"""
+    n, ms = C.c_int64(), C.c_double()
+    check(_lib.init().dfgpu_jit_stats(C.byref(n), C.byref(ms)))
+    return n.value, ms.value
 
 
 def set_fusion(on: bool):

@@ -118,12 +118,45 @@ def q1(lineitem: DeviceTable, group=None, fused: bool = True) -> DeviceTable:
 
 
 # ------------------------------------------------------------------------------------ Q3
+def _q3_fused_filters(customer, orders, lineitem, stats, probe_mode):
+    c = ops.filter(customer, col("c_mktsegment").eq(lit(SEGMENT_BUILDING, pa.uint8())), ["c_custkey"])
+    ht = ops.JoinHashTable(c, ["c_custkey"], probe_mode=probe_mode)
+    # 12) FilterExec o_orderdate < 1995-03-15 + 07) HashJoinExec RightSemi on (c_custkey, o_custkey)
+    semi = ht.probe(orders, ["o_custkey"], "RightSemi", probe_cols=["o_orderkey", "o_orderdate", "o_shippriority"],
+                    predicate=col("o_orderdate") < lit(DATE_Q3, pa.date32()))
+    ht.free()
+    # 15) FilterExec l_shipdate > 1995-03-15 + 05) HashJoinExec Inner on (o_orderkey, l_orderkey)
+    ht2 = ops.JoinHashTable(semi, ["o_orderkey"], probe_mode=probe_mode)
+    j = ht2.probe(lineitem, ["l_orderkey"], "Inner", ["o_orderdate", "o_shippriority"], ["l_orderkey", "l_extendedprice", "l_discount"],
+                  predicate=col("l_shipdate") > lit(DATE_Q3, pa.date32()))
+    ht2.free()
+    if stats is not None:
+        stats.update(customer_filtered=c.num_rows, semi_join=semi.num_rows, join=j.num_rows)
+    gb = [(col("l_orderkey"), "l_orderkey"), (col("o_orderdate"), "o_orderdate"), (col("o_shippriority"), "o_shippriority")]
+    agg = ops.aggregate(j, gb, [("sum", col("l_extendedprice") * (ONE - col("l_discount")), "revenue")], "SinglePartitioned")
+    if stats is not None:
+        stats.update(groups=agg.num_rows)
+    for t in (c, semi, j):
+        t.free()
+    top = ops.sort(agg, Q3_SORT, fetch=10)
+    agg.free()
+    return top.select(["l_orderkey", "revenue", "o_orderdate", "o_shippriority"])
+
+
 Q3_SORT = [("revenue", True, True), ("o_orderdate", False, False)]  # revenue DESC (NULLS FIRST), o_orderdate ASC NULLS LAST
 
 
 def q3(customer: DeviceTable, orders: DeviceTable, lineitem: DeviceTable, group=None, stats: dict | None = None,
-       probe_mode: int = ops.PROBE_MODES["single_pass_unordered"]) -> DeviceTable:
-    """q3.slt.part:61-76, bottom-up.  `stats` (optional) receives intermediate row counts."""
+       probe_mode: int = ops.PROBE_MODES["single_pass_unordered"], fused: bool = True) -> DeviceTable:
+    """q3.slt.part:61-76, bottom-up.  `stats` (optional) receives intermediate row counts.
+
+    fused=True (what the optimizer rule substitutes on one GPU): the FilterExecs on orders and lineitem are fused
+    below the probe side of their HashJoinExec (dfgpu_join_probe_filtered) — the single-pass probe applies the
+    predicate's row mask in the probe kernel, so neither filtered table is materialised.  With a repartition
+    between filter and join (N > 1) the filters stay separate operators, as in the reference plan."""
+    fuse_filters = fused and _world(group) == 1 and probe_mode in (ops.PROBE_MODES["single_pass_unordered"], ops.PROBE_MODES["single_pass_ordered"])
+    if fuse_filters:
+        return _q3_fused_filters(customer, orders, lineitem, stats, probe_mode)
     # 09) FilterExec: c_mktsegment = BUILDING, projection=[c_custkey]; 08) Repartition Hash(c_custkey)
     c = ops.filter(customer, col("c_mktsegment").eq(lit(SEGMENT_BUILDING, pa.uint8())), ["c_custkey"])
     c_r = _repartition(c, ["c_custkey"], group)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 3
+#define DFGPU_ABI_VERSION 4
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -268,6 +268,12 @@ int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int nu
 int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type,
                      const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out,
                      dfgpu_table_t* out);
+/* The same with a FilterExec fused below the probe side (filter.rs:1396-1419 -> hash_join/stream.rs:687-1000):
+ * probe rows whose predicate is false or NULL do not exist for the join.  With the single-pass probe the predicate's
+ * row mask is applied inside the probe kernel and the filtered probe table is never materialised; every other
+ * probe flavour filters first.  What the optimizer rule substitutes for FilterExec -> HashJoinExec(probe side). */
+int dfgpu_join_probe_filtered(dfgpu_join_t ht, dfgpu_table_t probe, const dfgpu_expr* probe_predicate, const int* probe_key_cols, int join_type,
+                              const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out, dfgpu_table_t* out);
 int dfgpu_join_emit_unmatched(dfgpu_join_t ht, int join_type, const int* build_out_cols, int n_build_out,
                               const dfgpu_field* probe_fields, const char* const* probe_names, int n_probe_out,
                               dfgpu_table_t* out);
@@ -327,6 +333,10 @@ int dfgpu_agg_update_filtered(dfgpu_agg_t h, dfgpu_table_t input, const dfgpu_ex
 int dfgpu_agg_fused_updates(dfgpu_agg_t h, int64_t* out);
 /* process-wide switch for expression fusion (default on); off = always column-at-a-time (A/B measurements, tests) */
 int dfgpu_set_fusion(int on);
+/* Plan-time specialisation (jit.hip): for inputs of at least DFGPU_JIT_MIN_ROWS rows (default 4 Mi) the fused
+ * aggregate node is compiled for its expression forest with hiprtc (cached per process by source text); this reports
+ * how many distinct nodes were compiled and the total compile time.  DFGPU_JIT=0 keeps the interpreter. */
+int dfgpu_jit_stats(int64_t* compiles, double* compile_ms);
 /* next_output_batch_inner (common.rs:247-300): emit all groups */
 int dfgpu_agg_emit(dfgpu_agg_t h, dfgpu_table_t* out);
 int dfgpu_agg_free(dfgpu_agg_t h);

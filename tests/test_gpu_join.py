@@ -199,3 +199,33 @@ def test_tpch_join_shape_small_sf():
         ["o_orderdate", "o_shippriority", "l_orderkey", "l_extendedprice", "l_discount"])
     assert got.num_rows == l.num_rows
     assert_tables_equal(got, exp, ordered=True)
+
+
+@pytest.mark.parametrize("join_type", ["Inner", "RightSemi", "RightAnti", "Right", "LeftSemi"])
+@pytest.mark.parametrize("probe_mode", [0, 3], ids=["two_pass", "single_pass"])
+def test_probe_side_filter_fused_into_the_probe(join_type, probe_mode):
+    """FilterExec below the probe side (dfgpu_join_probe_filtered): with the single-pass probe the predicate's row
+    mask is applied in the probe kernel; every other flavour filters first.  NULL predicate rows are dropped."""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    from tests.util import to_oracle_expr
+    rng = np.random.default_rng(17)
+    build = pa.table({"k": pa.array(rng.permutation(9000)[:6000], type=pa.int64()), "v": pa.array(np.arange(6000), type=pa.int32())})
+    probe = random_table(rng, 40_001, {"k2": (pa.int64(), -10, 9100), "p": (pa.decimal128(15, 2), 0, 10**7), "d": (pa.date32(), 8000, 9000)})
+    dn = random_table(rng, 40_001, {"dn": (pa.int32(), 0, 100)}, null_frac=0.2).column("dn")   # nullable predicate input
+    probe = probe.append_column("dn", dn)
+    pred = (col("d") > lit(8500, pa.int32()).cast(pa.date32())).and_(col("dn") < lit(70, pa.int32()))
+    if probe_mode == 3 and join_type not in ("Inner", "RightSemi", "RightAnti"):
+        pytest.skip("the single-pass probe serves at most one match per probe row and probe-side output only")
+    ht = ops.JoinHashTable(DeviceTable.from_arrow(build), ["k"], probe_mode=probe_mode)
+    pcols = ["k2", "p"]
+    got = ht.probe(DeviceTable.from_arrow(probe), ["k2"], join_type, ["v"], pcols, predicate=pred)
+    if join_type == "LeftSemi":
+        got = ht.emit_unmatched(join_type, ["v"])
+    got = got.to_arrow()
+    filtered = oracle.filter(probe, to_oracle_expr(pred), probe.column_names)
+    exp = oracle.hash_join(build, filtered, [("k", "k2")], join_type)
+    keep = {"Inner": ["v", "k2", "p"], "Right": ["v", "k2", "p"], "RightSemi": pcols, "RightAnti": pcols, "LeftSemi": ["v"]}[join_type]
+    assert_tables_equal(got, exp.select(keep))

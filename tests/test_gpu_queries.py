@@ -56,13 +56,16 @@ def test_q1_matches_oracle_plan(sf):
     assert_tables_equal(got, exp, ordered=True)
 
 
-@pytest.mark.parametrize("probe_mode", [0, 3], ids=["ordered_probe", "unordered_probe"])
+@pytest.mark.parametrize("probe_mode,fused", [(0, False), (3, False), (3, True)], ids=["ordered_probe", "unordered_probe", "filters_fused_into_probes"])
 @pytest.mark.parametrize("sf", [0.002, 0.05])
-def test_q3_matches_oracle_plan(sf, probe_mode):
+def test_q3_matches_oracle_plan(sf, probe_mode, fused):
     from datafusion_amd import ops, queries, tpch
     stats = {}
-    got = queries.q3(ops.tpch_customer(sf), ops.tpch_orders(sf), ops.tpch_lineitem(sf), stats=stats, probe_mode=probe_mode).to_arrow()
+    got = queries.q3(ops.tpch_customer(sf), ops.tpch_orders(sf), ops.tpch_lineitem(sf), stats=stats, probe_mode=probe_mode, fused=fused).to_arrow()
     exp, exp_stats = oracle_q3(tpch.customer(sf), tpch.orders(sf), tpch.lineitem(sf))
+    if fused:   # the filtered tables are never materialised: no row counts for them
+        assert "lineitem_filtered" not in stats
+        exp_stats = {k: v for k, v in exp_stats.items() if k in stats}
     assert stats == exp_stats
     assert got.column_names == ["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]
     assert got.schema.field("revenue").type == pa.decimal128(38, 4)
