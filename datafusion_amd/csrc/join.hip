@@ -65,6 +65,7 @@ struct ProbeCtx {
   uint64_t am_offset, am_size, hash_mask;
   int null_equals_null;
   int force_collisions;
+  const uint64_t* row_mask;     // optional: probe rows whose bit is 0 do not exist (FilterExec fused below the probe side)
 };
 
 static KeySet make_keyset(const Table& t, const std::vector<int>& cols) {
@@ -344,7 +345,8 @@ __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int6
 #pragma unroll
     for (int j = 0; j < N; j++) {
       int64_t p = ((w0 + j) << 6) + lane;
-      m[j] = p < np ? chain_head<KIND>(c, p) : 0u;
+      const bool live = p < np && (!c.row_mask || ((c.row_mask[w0 + j] >> lane) & 1ull));
+      m[j] = live ? chain_head<KIND>(c, p) : 0u;
     }
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -361,6 +363,7 @@ __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int6
     int64_t p = ((w0 + j) << 6) + lane;
     ok[j] = p < np;
     idx[j] = load_key<KT>(k, ok[j] ? p : np - 1) - c.am_offset;
+    if (c.row_mask) ok[j] = ok[j] && ((c.row_mask[w0 + j] >> lane) & 1ull);  // filtered-out rows skip the table lookups
   }
   if (k.valid) {  // direct-address tables are never built with NULL==NULL + NULL build keys: a NULL probe key matches nothing
     uint64_t vw[N];
@@ -1053,6 +1056,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     // ordered: persistent workgroups pulling tickets; unordered: one workgroup per tile
     const unsigned g = ordered ? (unsigned)std::min<int64_t>(n_tiles, (int64_t)r.num_cus * 8) : (unsigned)n_tiles;
     uint64_t* st = state ? state->as<uint64_t>() : nullptr;
+    ctx.row_mask = row_mask;
     auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>(), row_mask); };
     with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
       constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
