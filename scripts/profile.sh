@@ -19,9 +19,9 @@ cd $R
 python - <<PY > $OUT/ops_kernels.md 2>&1
 import sqlite3
 con = sqlite3.connect("$OUT/stats_ops/trace_results.db")
-print("| kernel | calls | avg us | total ms | % |\n|---|---:|---:|---:|---:|")
+print("| kernel | calls | avg ms | total ms | % |\n|---|---:|---:|---:|---:|")
 for n, c, tot, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 40"):
-    print(f"| {n.replace('void ', '').split('(')[0].replace('dfgpu::', '')} | {c} | {avg / 1e3:.1f} | {tot / 1e6:.2f} | {pct:.1f} |")
+    print(f"| {n.replace('void ', '').split('(')[0].replace('dfgpu::', '')} | {c} | {avg / 1e3:.3f} | {tot / 1e3:.1f} | {pct:.1f} |")
 PY
 # keep only the small summaries (gpurun_out merge is capped at 64 MiB)
 find $OUT -name '*kernel_trace.csv' -size +8M -delete
