@@ -2,12 +2,12 @@
 //
 // BatchPartitioner::partition_iter, Hash arm (physical-plan/src/repartition/mod.rs:1111-1150):
 // partition = create_hashes(keys; REPARTITION seed 0) % n; each partition keeps input order.
-// On device: one wave64 owns 64 rows; per partition p the wave's membership is one ballot, so
-//   pass 1  part id per row + per-(partition, word) counts  (popcount of the ballot),
+// On device: one workgroup owns a 2048-row tile; per partition p a wave's membership is one ballot, so
+//   pass 1  part id per row + per-(partition, tile) counts  (popcounts of the ballots),
 //   scan    one exclusive scan over the partition-major count matrix gives every
-//           (partition, word) its output offset in a single partition-major buffer,
-//   pass 2  scatter: dst = offset[p][word] + mbcnt(ballot(part == p)) -> stable, coalesced
-//           per partition.
+//           (partition, tile) its output offset in a single partition-major buffer,
+//   pass 2  scatter: the tile is staged in LDS sorted by partition (stable), every partition's
+//           run is written contiguously.
 // The n output tables are zero-copy slices of that one buffer per column (what the RCCL
 // all-to-all sends from: contiguous per destination).
 #include "device.hpp"
@@ -47,27 +47,38 @@ void hash_columns(const std::vector<const Column*>& keys, int64_t n, uint64_t se
 }
 
 constexpr int MAX_PARTS = 64;
+constexpr int PT_ITEMS = 8;                 // rows per thread
+constexpr int PT_TILE = BLOCK * PT_ITEMS;   // 2048 rows per workgroup tile
 
-// pass 1: counts[p * n_words + w] = rows of word w routed to partition p; part[i] = partition
-__global__ __launch_bounds__(BLOCK) void k_part_count(KeySet ks, int64_t n, int nparts, uint8_t* __restrict__ part, uint32_t* __restrict__ counts) {
-  const int64_t n_words = (n + 63) >> 6;
-  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
-  for (int64_t w = wave; w < n_words; w += n_waves) {
-    int64_t i = (w << 6) + lane_id();
-    int p = -1;
-    if (i < n) {
-      bool any_null;
-      uint64_t h = hash_row(ks, i, SEED_REPARTITION, any_null);
-      p = (int)(h % (uint64_t)nparts);
-      part[i] = (uint8_t)p;
-    }
+// pass 1: part[i] = partition of row i; counts[p * n_tiles + t] = rows of tile t routed to partition p.
+// Per 64 rows the membership of a partition is one ballot; lane q keeps partition q's running count.
+__global__ __launch_bounds__(BLOCK) void k_part_count(KeySet ks, int64_t n, int nparts, int64_t n_tiles, uint8_t* __restrict__ part,
+                                                      uint32_t* __restrict__ counts) {
+  __shared__ unsigned int sh[MAX_PARTS];
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    if (threadIdx.x < MAX_PARTS) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t lo = t * PT_TILE;
     uint32_t mine = 0;
-    for (int q = 0; q < nparts; q++) {
-      uint32_t c = (uint32_t)__popcll(ballot64(p == q));
-      if ((int)lane_id() == q) mine = c;
+#pragma unroll
+    for (int c = 0; c < PT_ITEMS; c++) {
+      const int64_t i = lo + c * BLOCK + threadIdx.x;
+      int p = -1;
+      if (i < n) {
+        bool any_null;
+        uint64_t h = hash_row(ks, i, SEED_REPARTITION, any_null);
+        p = (int)(h % (uint64_t)nparts);
+        part[i] = (uint8_t)p;
+      }
+      for (int q = 0; q < nparts; q++) {
+        uint32_t cnt = (uint32_t)__popcll(ballot64(p == q));
+        if ((int)lane_id() == q) mine += cnt;
+      }
     }
-    if ((int)lane_id() < nparts) counts[(int64_t)lane_id() * n_words + w] = mine;
+    if ((int)lane_id() < nparts && mine) atomicAdd(&sh[lane_id()], mine);
+    __syncthreads();
+    if ((int)threadIdx.x < nparts) counts[(int64_t)threadIdx.x * n_tiles + t] = sh[threadIdx.x];
+    __syncthreads();
   }
 }
 
@@ -79,28 +90,98 @@ struct PartCols {
   int n;
 };
 template <typename T>
-__device__ __forceinline__ void pcopy(const void* src, void* dst, int64_t s, int64_t d) {
-  reinterpret_cast<T*>(dst)[d] = reinterpret_cast<const T*>(src)[s];
-}
-__global__ __launch_bounds__(BLOCK) void k_part_scatter(PartCols cols, const uint8_t* __restrict__ part, const uint64_t* __restrict__ prefix, int64_t n, int nparts) {
-  const int64_t n_words = (n + 63) >> 6;
-  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
-  for (int64_t w = wave; w < n_words; w += n_waves) {
-    int64_t i = (w << 6) + lane_id();
-    int p = i < n ? (int)part[i] : -1;
-    int64_t dst = 0;
-    for (int q = 0; q < nparts; q++) {
-      uint64_t m = ballot64(p == q);
-      if (p == q) dst = (int64_t)prefix[(int64_t)q * n_words + w] + mbcnt(m);
+__device__ __forceinline__ void stage_column(const void* __restrict__ src, void* __restrict__ dst, void* s_val, const uint8_t* s_dig, const unsigned* s_start,
+                                             const unsigned long long* s_goff, int64_t lo, int tile_rows, const unsigned (&q)[PT_ITEMS]) {
+  T* sv = reinterpret_cast<T*>(s_val);
+#pragma unroll
+  for (int c = 0; c < PT_ITEMS; c++) {
+    const int j = c * BLOCK + threadIdx.x;
+    if (j < tile_rows) sv[q[c]] = reinterpret_cast<const T*>(src)[lo + j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < PT_ITEMS; c++) {
+    const int qq = c * BLOCK + threadIdx.x;
+    if (qq < tile_rows) {
+      const unsigned p = s_dig[qq];
+      reinterpret_cast<T*>(dst)[s_goff[p] + (unsigned)(qq - (int)s_start[p])] = sv[qq];
     }
-    if (p < 0) continue;
+  }
+  __syncthreads();
+}
+// pass 2: stable scatter of one tile.  Every row's position inside the tile sorted by partition is computed once
+// (wave64 ballot peer masks + a cross-wave prefix in LDS, as sort.hip's radix pass); each column is then staged
+// through LDS in that order and every partition's run is written contiguously — 2048 / nparts rows per run
+// instead of the ~8-row runs a 64-row wave scatters on its own (measured 33 % of HBM peak).
+__global__ __launch_bounds__(BLOCK) void k_part_scatter(PartCols cols, const uint8_t* __restrict__ part, const uint64_t* __restrict__ prefix, int64_t n,
+                                                        int nparts, int nbits, int64_t n_tiles) {
+  __shared__ uint4 s_val[PT_TILE];
+  __shared__ uint8_t s_dig[PT_TILE];
+  __shared__ unsigned int s_wave[BLOCK / WAVE][MAX_PARTS];
+  __shared__ unsigned int s_run[MAX_PARTS], s_start[MAX_PARTS];
+  __shared__ unsigned long long s_goff[MAX_PARTS];
+  const int wave = threadIdx.x >> 6;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t lo = t * PT_TILE;
+    const int tile_rows = (int)((n - lo) < PT_TILE ? (n - lo) : PT_TILE);
+    if (threadIdx.x < MAX_PARTS) {
+      s_run[threadIdx.x] = 0;
+      for (int w = 0; w < BLOCK / WAVE; w++) s_wave[w][threadIdx.x] = 0;
+      if ((int)threadIdx.x < nparts) s_goff[threadIdx.x] = prefix[(int64_t)threadIdx.x * n_tiles + t];
+    }
+    __syncthreads();
+    unsigned dig[PT_ITEMS], rank[PT_ITEMS], q[PT_ITEMS];
+#pragma unroll
+    for (int c = 0; c < PT_ITEMS; c++) {
+      const int j = c * BLOCK + threadIdx.x;
+      const bool in = j < tile_rows;
+      dig[c] = in ? part[lo + j] : 0u;
+      uint64_t peers = ballot64(in);
+      for (int b = 0; b < nbits; b++) {
+        const uint64_t bal = ballot64((dig[c] >> b) & 1u);
+        peers &= ((dig[c] >> b) & 1u) ? bal : ~bal;
+      }
+      const unsigned r_in_wave = mbcnt(peers);
+      if (in && r_in_wave == 0) s_wave[wave][dig[c]] = (unsigned)__popcll(peers);
+      __syncthreads();
+      if (in) {
+        unsigned r = s_run[dig[c]] + r_in_wave;
+        for (int w = 0; w < wave; w++) r += s_wave[w][dig[c]];
+        rank[c] = r;
+      }
+      __syncthreads();
+      if (threadIdx.x < MAX_PARTS) {
+        unsigned tot = 0;
+        for (int w = 0; w < BLOCK / WAVE; w++) {
+          tot += s_wave[w][threadIdx.x];
+          s_wave[w][threadIdx.x] = 0;
+        }
+        s_run[threadIdx.x] += tot;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < WAVE) {  // exclusive scan of the <= 64 partition counts: one wave
+      const unsigned cnt = s_run[threadIdx.x];
+      const unsigned inc = wave_inclusive_sum<unsigned>(cnt);
+      s_start[threadIdx.x] = inc - cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PT_ITEMS; c++) {
+      const int j = c * BLOCK + threadIdx.x;
+      q[c] = 0;
+      if (j < tile_rows) {
+        q[c] = s_start[dig[c]] + rank[c];
+        s_dig[q[c]] = (uint8_t)dig[c];
+      }
+    }
+    __syncthreads();
     for (int c = 0; c < cols.n; c++) {
       switch (cols.width[c]) {
-        case 16: pcopy<uint4>(cols.src[c], cols.dst[c], i, dst); break;
-        case 8: pcopy<uint64_t>(cols.src[c], cols.dst[c], i, dst); break;
-        case 4: pcopy<uint32_t>(cols.src[c], cols.dst[c], i, dst); break;
-        case 1: pcopy<uint8_t>(cols.src[c], cols.dst[c], i, dst); break;
+        case 16: stage_column<uint4>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, tile_rows, q); break;
+        case 8: stage_column<uint64_t>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, tile_rows, q); break;
+        case 4: stage_column<uint32_t>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, tile_rows, q); break;
+        case 1: stage_column<uint8_t>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, tile_rows, q); break;
       }
     }
   }
@@ -136,21 +217,25 @@ static std::vector<Table> partition_table(const Table& in, const std::vector<int
     }
     return outs;
   }
+  const int64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
+  const int tile_grid = (int)std::min<int64_t>(n_tiles, 256 * 8);
+  int nbits = 0;
+  while ((1 << nbits) < nparts) nbits++;
   BufPtr part = make_buf((size_t)n + 64);
-  BufPtr counts = make_buf((size_t)nparts * n_words * 4);
-  BufPtr prefix = make_buf((size_t)(nparts * n_words + 1) * 8);
+  BufPtr counts = make_buf((size_t)nparts * n_tiles * 4);
+  BufPtr prefix = make_buf((size_t)(nparts * n_tiles + 1) * 8);
   int64_t key_bytes = 0;
   for (int i = 0; i < ks.n; i++) key_bytes += n * ks.c[i].width;
   {
     ProfileScope ps("partition_count", key_bytes + n);
-    k_part_count<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(ks, n, nparts, part->as<uint8_t>(), counts->as<uint32_t>());
+    k_part_count<<<tile_grid, BLOCK, 0, r.stream>>>(ks, n, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>());
     DFGPU_HIP(hipGetLastError());
   }
-  scan_u32(counts->as<uint32_t>(), (int64_t)nparts * n_words, prefix->as<uint64_t>());
+  scan_u32(counts->as<uint32_t>(), (int64_t)nparts * n_tiles, prefix->as<uint64_t>());
   // partition boundaries = prefix at the start of each partition's row of the matrix
   std::vector<uint64_t> bounds(nparts + 1);
   for (int p = 0; p < nparts; p++)
-    DFGPU_HIP(hipMemcpyAsync(&bounds[p], prefix->as<uint64_t>() + (int64_t)p * n_words, 8, hipMemcpyDeviceToHost, r.stream));
+    DFGPU_HIP(hipMemcpyAsync(&bounds[p], prefix->as<uint64_t>() + (int64_t)p * n_tiles, 8, hipMemcpyDeviceToHost, r.stream));
   DFGPU_HIP(hipStreamSynchronize(r.stream));
   bounds[nparts] = (uint64_t)n;
 
@@ -170,7 +255,7 @@ static std::vector<Table> partition_table(const Table& in, const std::vector<int
         bytes += 2 * n * pc.width[k];
       }
       ProfileScope ps("partition_scatter", bytes);
-      k_part_scatter<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(pc, part->as<uint8_t>(), prefix->as<uint64_t>(), n, nparts);
+      k_part_scatter<<<tile_grid, BLOCK, 0, r.stream>>>(pc, part->as<uint8_t>(), prefix->as<uint64_t>(), n, nparts, nbits, n_tiles);
       DFGPU_HIP(hipGetLastError());
     }
     for (int p = 0; p < nparts; p++) {
