@@ -47,8 +47,10 @@ def algorithmic_bytes(nb, np_, nout):
     return nb * 16 + np_ * 40 + nout * 48
 
 
-def cpu_baseline(sample_sf, threads):
-    """oracle leg: RepartitionExec(Hash) x2 -> HashJoinExec(Partitioned), one thread per partition"""
+def cpu_baseline(sample_sf, cores):
+    """oracle leg: RepartitionExec(Hash) x2 -> HashJoinExec(Partitioned), one thread per partition
+    (target_partitions); the best of a few partition counts up to the core count is reported, since one
+    partition per core is not the fastest setting on a many-core NUMA host"""
     import numpy as np
 
     from datafusion_amd import tpch
@@ -56,16 +58,34 @@ def cpu_baseline(sample_sf, threads):
     i = np.arange(tpch.n_orders(sample_sf), dtype=np.int64)
     bk = tpch.order_key(i)
     pk = np.repeat(bk, tpch.line_count(i))
-    best = None
-    for _ in range(2):
+    best, best_t, tried = None, None, {}
+    for threads in sorted({max(1, cores), max(1, cores // 2), max(1, cores // 4), min(cores, 32)}, reverse=True):
         t0 = time.perf_counter()
         pairs, _chk = oracle.partitioned_inner_join_i64(bk, pk, threads)
         dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    assert pairs == len(pk)
-    return {"value": (len(bk) + len(pk)) / best, "unit": "rows/s", "cores": threads, "kind": "port",
-            "sample": f"orders x lineitem keys at SF{sample_sf:g} ({len(bk)} build + {len(pk)} probe rows), "
-                      f"{threads} partitions/threads, 8192-row probe batches, key-only pairs (no payload gather)"}
+        assert pairs == len(pk)
+        tried[threads] = round((len(bk) + len(pk)) / dt)
+        if best is None or dt < best:
+            best, best_t = dt, threads
+    out = {"value": (len(bk) + len(pk)) / best, "unit": "rows/s", "cores": best_t, "kind": "port",
+           "sample": f"orders x lineitem keys at SF{sample_sf:g} ({len(bk)} build + {len(pk)} probe rows), "
+                     f"{best_t} partitions/threads (best of {tried} rows/s; host has {cores} cores), 8192-row probe batches, key-only pairs (no payload gather)"}
+    try:  # independent production CPU engine on the same sample: Arrow Acero hash join
+        import pyarrow as pa
+        pa.set_cpu_count(cores)
+        b = pa.table({"k": bk, "bi": np.arange(len(bk), dtype=np.int64)})
+        p = pa.table({"k": pk, "pi": np.arange(len(pk), dtype=np.int64)})
+        t_best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            j = p.join(b, keys="k", join_type="inner")
+            dt = time.perf_counter() - t0
+            assert j.num_rows == len(pk)
+            t_best = dt if t_best is None else min(t_best, dt)
+        out["acero_rows_per_s"] = (len(bk) + len(pk)) / t_best
+    except Exception as e:  # noqa: BLE001 - the Acero leg is a sanity bound, never required
+        out["acero_error"] = str(e)[:200]
+    return out
 
 
 def main():

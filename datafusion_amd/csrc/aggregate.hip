@@ -1246,22 +1246,30 @@ extern "C" __global__ __launch_bounds__(BLOCK) void dense_minmax(Args a) {
   }
 }
 
-// Bits only ever go 0 -> 1, so the plain (possibly stale) read is a safe filter: it can only cause a redundant atomic.
+// Adjacent lanes that target the same bitmap word are merged (segmented OR) into ONE atomic per word and wave;
+// bits only ever go 0 -> 1, so the plain (possibly stale) read is a safe filter: it can only cause a redundant atomic.
+__device__ __forceinline__ U64 seg_or_u64(U64 v, bool head) {
+  SEG_SCAN(const U64 o = __shfl_up(v, d, 64); if (lane >= d && !f) v |= o;)
+  return v;
+}
 extern "C" __global__ __launch_bounds__(BLOCK) void dense_setbits(Args a) {
   const long long stride = (long long)gridDim.x * BLOCK;
   const long long n_round = a.begin + (a.end - a.begin + BLOCK - 1) / BLOCK * BLOCK;
   for (long long i = a.begin + (long long)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += stride) {
-    long long idx = -1 - (long long)(threadIdx.x & 63);
+    long long idx = -1;
     if (i < a.end) do {
 )SRC";
   src += row;
   src += R"SRC(      if (!knull) idx = key - a.kmin;
     } while (0);
-    const long long prev = __shfl_up(idx, 1, 64);
-    if (idx >= 0 && ((threadIdx.x & 63) == 0 || prev != idx)) {
-      const U64 bit = 1ull << (idx & 63);
-      U64* w = a.bits + (idx >> 6);
-      if (!(*w & bit)) atomicOr(w, bit);
+    const long long w = idx >= 0 ? (idx >> 6) : -1 - (long long)(threadIdx.x & 63);
+    const long long wprev = __shfl_up(w, 1, 64), wnext = __shfl_down(w, 1, 64);
+    const bool head = (threadIdx.x & 63) == 0 || wprev != w;
+    const bool tail = (threadIdx.x & 63) == 63 || wnext != w;
+    const U64 acc = seg_or_u64(idx >= 0 ? 1ull << (idx & 63) : 0ull, head);
+    if (idx >= 0 && tail) {
+      U64* p = a.bits + w;
+      if ((*p & acc) != acc) atomicOr(p, acc);
     }
   }
 }
@@ -1344,11 +1352,19 @@ extern "C" __global__ __launch_bounds__(BLOCK) void dense_accumulate(Args a) {
   return src;
 }
 
-// first rows -> bitmap over row numbers
+// first rows -> bitmap over row numbers.  Neighbouring groups of clustered input have neighbouring first rows:
+// adjacent lanes targeting the same bitmap word are merged into one atomicOr (device-scope atomics are the cost).
 __global__ __launch_bounds__(BLOCK) void k_mark_first_rows(const uint32_t* __restrict__ first_row, int64_t G, unsigned long long* __restrict__ rep_mask) {
-  for (int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x; g < G; g += (int64_t)gridDim.x * BLOCK) {
-    const uint32_t fr = first_row[g];
-    atomicOr(&rep_mask[fr >> 6], 1ull << (fr & 63));
+  const int64_t g_round = (G + BLOCK - 1) / BLOCK * BLOCK;
+  for (int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x; g < g_round; g += (int64_t)gridDim.x * BLOCK) {
+    const bool in = g < G;
+    const uint32_t fr = in ? first_row[g] : 0u;
+    const int64_t w = in ? (int64_t)(fr >> 6) : -1 - (int64_t)lane_id();
+    const int64_t wprev = __shfl_up(w, 1, 64), wnext = __shfl_down(w, 1, 64);
+    const bool head = lane_id() == 0 || wprev != w;
+    const bool tail = lane_id() == 63 || wnext != w;
+    const uint64_t acc = wave_seg_or(in ? 1ull << (fr & 63) : 0ull, head);
+    if (in && tail) atomicOr(&rep_mask[w], (unsigned long long)acc);
   }
 }
 struct DenseEmit {

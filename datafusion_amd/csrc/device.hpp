@@ -49,6 +49,24 @@ __device__ __forceinline__ uint64_t wave_inclusive_sum_dpp(uint64_t v) {
   return v;
 }
 
+// inclusive segmented OR over adjacent lanes (`head` = first lane of a run): the run's last lane ends up with the
+// OR of the whole run.  Lets a wave merge the bits it sets in one bitmap word into ONE atomicOr.  Every lane of
+// the wave must be executing.
+__device__ __forceinline__ uint64_t wave_seg_or(uint64_t v, bool head) {
+  bool f = head;
+  const unsigned lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(v, d, 64);
+    const int fo = __shfl_up((int)f, d, 64);
+    if (lane >= (unsigned)d && !f) {
+      v |= o;
+      f = fo != 0;
+    }
+  }
+  return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
