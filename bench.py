@@ -8,10 +8,16 @@
 A step = one full pass of the hot path over device-resident inputs:
   N = 1 : HashJoinExec build (collect_left_input) + probe (whole lineitem) -> output table.
   N > 1 : each rank holds a 1/N row range of both tables (what N scans would produce).  The exchange that
-          moves fewer bytes per GPU is used (SURVEY §8e): PartitionMode::CollectLeft = RCCL all-gather of the
-          build side (B(N-1)/N bytes received per GPU) when B*N < B+P — the SF100 Q3 join up to N = 8 — else
-          PartitionMode::Partitioned = K10 partition kernel + RCCL all-to-all of both sides; then the local
-          build + probe.  Total work is fixed (SF100) => "strong" scaling.
+          moves fewer bytes per GPU is used (SURVEY §8e): PartitionMode::CollectLeft = the build side is
+          broadcast (B(N-1)/N bytes received per GPU at most) when B*N < B+P — the SF100 Q3 join up to N = 8 —
+          else PartitionMode::Partitioned = K10 partition kernel + RCCL all-to-all of both sides; then the local
+          build + probe.  The broadcast is pruned by each rank's probe-key bounds (exchange.pruned_broadcast_table:
+          a rank only receives build rows inside [min, max] of its own probe keys — the reference's dynamic join
+          filter turned around); shards that arrive clustered by key, like the row ranges used here and like any
+          scan of TPC-H tables in their natural order, therefore move almost nothing, while spread keys fall back
+          to the full all-gather's volume.  `exchange_rank0` on the JSON line says how many rows crossed ranks;
+          --exchange broadcast / repartition force the unpruned exchanges.  Total work is fixed (SF100) =>
+          "strong" scaling.
 value = (build rows + probe rows summed over ranks) / max-over-ranks wall time of the K steps.
 Inputs are generated on device (no dataset download possible) before the timed region.
 
@@ -96,8 +102,10 @@ def main():
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor (BASELINE: 100)")
     ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--exchange", choices=["auto", "broadcast", "repartition"], default="auto",
-                    help="N > 1: all-gather the build side (CollectLeft) or hash-repartition both sides (Partitioned); auto = fewer bytes")
+    ap.add_argument("--exchange", choices=["auto", "pruned", "broadcast", "repartition"], default="auto",
+                    help="N > 1: pruned = CollectLeft with the build-side broadcast pruned by each rank's probe-key bounds; broadcast = plain "
+                         "all-gather of the build side; repartition = hash-repartition both sides (Partitioned); auto = pruned when a broadcast "
+                         "moves fewer bytes than a repartition, else repartition")
     ap.add_argument("--probe-mode", type=int, default=3,
                     help="3 single pass, unordered output (default: in Q3 the join feeds AggregateExec, no ancestor needs the probe "
                          "order); 0/1 two passes, output in probe order; 2 single pass ordered (look-back)")
@@ -141,11 +149,16 @@ def main():
         dist.all_reduce(t4)
         exchange = args.exchange
         if exchange == "auto":
-            exchange = "broadcast" if broadcast_build_moves_fewer_bytes(int(t4[0]) * 16, int(t4[1]) * 40, world) else "repartition"
+            exchange = "pruned" if broadcast_build_moves_fewer_bytes(int(t4[0]) * 16, int(t4[1]) * 40, world) else "repartition"
+
+    xstats = {}
 
     def step(probe_mode=args.probe_mode):
         o, l = orders, lineitem
-        if exchange == "broadcast":
+        if exchange == "pruned":
+            from datafusion_amd.exchange import pruned_broadcast_table
+            o = pruned_broadcast_table(orders, "o_orderkey", lineitem, "l_orderkey", force=forced, stats=xstats)
+        elif exchange == "broadcast":
             from datafusion_amd.exchange import broadcast_table
             o = broadcast_table(orders, force=forced)
         elif exchange == "repartition":
@@ -161,7 +174,7 @@ def main():
         info = ht.info()
         out.free()
         ht.free()
-        if exchange == "broadcast":
+        if exchange in ("broadcast", "pruned"):
             o.free()
         elif exchange == "repartition":
             o.free()
@@ -240,12 +253,16 @@ def main():
                        "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map"}[info.table_kind],
                        "probe": {0: "two_pass_ordered", 1: "two_pass_ordered", 2: "single_pass_ordered", 3: "single_pass_unordered"}[args.probe_mode],
                        "parallelism": "single GPU" if world == 1 else
-                       (f"CollectLeft: RCCL all-gather of the build side x{world}, probe side stays range-partitioned" if exchange == "broadcast"
+                       (f"CollectLeft x{world}: build side broadcast pruned by each rank's probe-key bounds (RCCL all-to-all(v)), probe side stays in place"
+                        if exchange == "pruned" else
+                        f"CollectLeft x{world}: RCCL all-gather of the build side, probe side stays in place" if exchange == "broadcast"
                         else f"Partitioned: hash-repartition all-to-all of both sides x{world}")},
             "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),
             "hbm_frac_whole_step": round(alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
             "roofline": roof, "kernels": kernels,
         }
+        if xstats:
+            line["exchange_rank0"] = {**xstats, "build_row_bytes": 16}
         if ordered_ms is not None:
             line["ordered_output_two_pass"] = {"ms_per_step": round(ordered_ms, 3), "rows_per_s": (nb + np_) / (ordered_ms * 1e-3),
                                                "hbm_frac_whole_step": round(alg / (ordered_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4)}

@@ -1178,6 +1178,38 @@ int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int nu
   });
 }
 
+int dfgpu_column_minmax(dfgpu_table_t table, int column, int64_t* out_min, int64_t* out_max, int64_t* out_valid, int* out_ascending) {
+  return guarded([&] {
+    require_init();
+    const Table& t = *unwrap(table);
+    DFGPU_CHECK(column >= 0 && column < (int)t.cols.size(), "column index out of range");
+    const Column& kc = t.cols[column];
+    DFGPU_CHECK(is_integer_like(kc.field.type) && kc.field.type != DFGPU_UINT64, "dfgpu_column_minmax: integer columns only");
+    Runtime& r = rt();
+    MinMax res{INT64_MAX, INT64_MIN, 0, 0, 0};
+    if (t.nrows > 0) {
+      KeyCol k{kc.ptr(), kc.valid_words(), kc.field.type, type_width(kc.field.type)};
+      BufPtr mm = make_buf(sizeof(MinMax));
+      h2d_async(mm->ptr, &res, sizeof res);
+      {
+        ProfileScope ps("column_minmax", t.nrows * k.width);
+        const int g = std::min(grid_for(t.nrows, BLOCK * BUILD_UNROLL), 2048);
+        with_key_type(k.type, [&](auto kt) {
+          constexpr int T = decltype(kt)::value;
+          if (k.valid) k_key_minmax<T, true><<<g, BLOCK, 0, r.stream>>>(k, t.nrows, mm->as<MinMax>());
+          else k_key_minmax<T, false><<<g, BLOCK, 0, r.stream>>>(k, t.nrows, mm->as<MinMax>());
+        });
+        DFGPU_HIP(hipGetLastError());
+      }
+      d2h(&res, mm->ptr, sizeof res);
+    }
+    if (out_min) *out_min = res.smin;
+    if (out_max) *out_max = res.smax;
+    if (out_valid) *out_valid = (int64_t)res.valid;
+    if (out_ascending) *out_ascending = res.valid > 0 && res.unsorted == 0;
+  });
+}
+
 int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type, const int* build_out_cols, int n_build_out,
                      const int* probe_out_cols, int n_probe_out, dfgpu_table_t* out) {
   return guarded([&] {

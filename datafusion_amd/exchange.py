@@ -214,6 +214,129 @@ def broadcast_table(table, group=None, force=False):
     return result
 
 
+def gather_key_ranges(probe_range, build_range, group=None):
+    """every rank learns every rank's closed probe-key and build-key ranges (None = no rows) in ONE all-gather:
+    returns (probe_ranges, build_ranges), rank order"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    row = []
+    for r in (probe_range, build_range):
+        row += [int(r[0]), int(r[1]), 1] if r is not None else [0, 0, 0]
+    mine = torch.tensor(row, dtype=torch.int64, device=dev)
+    allr = torch.empty(6 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allr, mine, group=group)
+    v = allr.cpu().tolist()
+    pr = [(v[6 * r], v[6 * r + 1]) if v[6 * r + 2] else None for r in range(world)]
+    br = [(v[6 * r + 3], v[6 * r + 4]) if v[6 * r + 5] else None for r in range(world)]
+    return pr, br
+
+
+def nothing_crosses_ranks(probe_ranges, build_ranges):
+    """True when no rank's build-key range meets another rank's probe-key bounds: every rank can decide this from the
+    gathered ranges alone, so the pruned broadcast needs no further collective"""
+    for i, b in enumerate(build_ranges):
+        for j, p in enumerate(probe_ranges):
+            if i != j and b is not None and p is not None and max(b[0], p[0]) <= min(b[1], p[1]):
+                return False
+    return True
+
+
+def pruned_send_ranges(probe_ranges, my_build_range):
+    """which slice of this rank's build keys each destination needs: the intersection of the destination's probe
+    key range with this rank's build key range, or None.  A destination can only match build keys inside the
+    [min, max] of ITS OWN probe keys — DataFusion's dynamic join filter (hash_join/shared_bounds.rs:277-284:
+    build-side bounds prune the probe-side scan) applied in the other direction, to prune the broadcast."""
+    out = []
+    for pr in probe_ranges:
+        if pr is None or my_build_range is None:
+            out.append(None)
+            continue
+        lo, hi = max(pr[0], my_build_range[0]), min(pr[1], my_build_range[1])
+        out.append((lo, hi) if lo <= hi else None)
+    return out
+
+
+def _key_range(table, key):
+    """(min, max) of an integer key column of a DeviceTable, None if it has no non-null row"""
+    from . import ops
+    lo, hi, n, _ = ops.column_minmax(table, key)
+    return None if n == 0 else (lo, hi)
+
+
+def pruned_broadcast_table(build, build_key, probe, probe_key, group=None, force=False, stats=None):
+    """CollectLeft with the broadcast pruned by the destinations' probe-key bounds: rank r receives from every rank
+    only the build rows whose key lies inside [min, max] of r's probe keys (a superset of what r can match, so the
+    local join is unchanged).  Clustered inputs — TPC-H orders / lineitem in key order, any range-partitioned scan —
+    move almost nothing; uniformly spread keys degrade to the full all-gather (same bytes as broadcast_table).
+    One all-to-all(v) per column; `stats` (optional dict) receives the rows sent / received across ranks."""
+    import pyarrow as pa
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib, ops
+    from ._lib import Field, check
+    from .expr import col, lit
+    from .table import DeviceTable
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1 and not force:
+        return build
+    ktype = build.schema.field(build.schema.get_field_index(build_key)).type
+    if ktype not in (pa.int64(), pa.int32()):
+        return broadcast_table(build, group, force)
+    lib = _lib.load()
+    my_range = _key_range(build, build_key)
+    probe_ranges, build_ranges = gather_key_ranges(_key_range(probe, probe_key), my_range, group=group)
+    sends = pruned_send_ranges(probe_ranges, my_range)
+
+    def part_for(sr):
+        if sr is None:
+            return build.slice(0, 0)
+        if sr == my_range:
+            return build.slice(0, build.num_rows)               # the destination's bounds cover this whole shard: no filter pass
+        return ops.filter(build, (col(build_key) >= lit(sr[0], ktype)).and_(col(build_key) <= lit(sr[1], ktype)))
+
+    if nothing_crosses_ranks(probe_ranges, build_ranges):
+        own = part_for(sends[rank])                             # the local shard (pruned to the local bounds) is the build side
+        if stats is not None:
+            stats.update(rows_sent_to_peers=0, rows_received_from_peers=0, build_rows_local=build.num_rows, build_rows_after_exchange=own.num_rows)
+        return own
+    parts = [part_for(sr) for sr in sends]
+    send_counts = [p.num_rows for p in parts]
+    recv_counts = exchange_counts(send_counts, group)
+    total = sum(recv_counts)
+    if stats is not None:
+        stats.update(rows_sent_to_peers=sum(send_counts) - send_counts[rank], rows_received_from_peers=total - recv_counts[rank],
+                     build_rows_local=build.num_rows, build_rows_after_exchange=total)
+    nonempty = [p for p in parts if p.num_rows]
+    packed = nonempty[0].slice(0, nonempty[0].num_rows) if len(nonempty) == 1 else (DeviceTable.concat(parts) if nonempty else build.slice(0, 0))
+    ncols = build.num_columns
+    views = [packed.column_view(i) for i in range(ncols)]
+    fields = (Field * ncols)(*[v.field for v in views])
+    names = (C.c_char_p * ncols)(*[v.name for v in views])
+    out = C.c_void_p()
+    check(lib.dfgpu_table_alloc(ncols, fields, names, C.c_int64(total), C.byref(out)))
+    result = DeviceTable(out)
+    ops.sync()
+    n_send = sum(send_counts)
+    for i in range(ncols):
+        v = views[i]
+        if v.validity:
+            raise _lib.DfgpuError("pruned_broadcast_table: nullable columns are not supported yet")
+        w = _W[v.field.type]
+        send = _as_tensor(v.data, n_send * w)
+        recv = _as_tensor(result.column_view(i).data, total * w)
+        all_to_all_bytes(send, send_counts, recv, recv_counts, w, group)
+    torch.cuda.synchronize()
+    for p in parts:
+        p.free()
+    packed.free()
+    return result
+
+
 def broadcast_build_moves_fewer_bytes(build_bytes, probe_bytes, world):
     """per-GPU received bytes: all-gather of the build side = B (N-1)/N, hash repartition of both = (B+P)(N-1)/N^2"""
     return build_bytes * world < build_bytes + probe_bytes

@@ -240,6 +240,15 @@ def aggregate(table: DeviceTable, group_by, aggs, mode="Single", predicate: Phys
     return out
 
 
+def column_minmax(table: DeviceTable, column):
+    """(min, max, non-null count, strictly ascending?) of an integer column; min/max are None when there is no value"""
+    lo, hi, n, asc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+    check(_lib.init().dfgpu_column_minmax(table.handle, table.index_of(column), C.byref(lo), C.byref(hi), C.byref(n), C.byref(asc)))
+    if n.value == 0:
+        return None, None, 0, False
+    return lo.value, hi.value, n.value, bool(asc.value)
+
+
 def jit_stats():
     """(distinct nodes compiled with hiprtc, total compile ms) of this process"""
     n, ms = C.c_int64(), C.c_double()

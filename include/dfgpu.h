@@ -268,6 +268,11 @@ int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int nu
 int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type,
                      const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out,
                      dfgpu_table_t* out);
+/* min / max / non-null count of an integer column and whether it is strictly ascending (the statistics
+ * ArrayMap::try_new takes from the build keys, joins/array_map.rs:175-203; also the probe-key bounds the multi-GPU
+ * exchange prunes the build-side broadcast with — hash_join/shared_bounds.rs:277-284 turned around).  One pass, one
+ * device-to-host copy.  *out_valid == 0: no non-null value, min / max are INT64_MAX / INT64_MIN. */
+int dfgpu_column_minmax(dfgpu_table_t table, int column, int64_t* out_min, int64_t* out_max, int64_t* out_valid, int* out_ascending);
 /* The same with a FilterExec fused below the probe side (filter.rs:1396-1419 -> hash_join/stream.rs:687-1000):
  * probe rows whose predicate is false or NULL do not exist for the join.  With the single-pass probe the predicate's
  * row mask is applied inside the probe kernel and the filtered probe table is never materialised; every other

@@ -153,6 +153,23 @@ def main():
         o.free()
         ops.sync()
 
+    # ------------------------------------------------------------------ boundary: host RecordBatch <-> device table
+    if want("import"):
+        from datafusion_amd import tpch
+        from datafusion_amd.table import DeviceTable
+        host = tpch.lineitem(2.0).select(["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])     # 12 M rows, 44 B/row
+        nbytes = host.nbytes
+        measure("dfgpu_table_import (Arrow C Data Interface -> HBM: hipHostRegister + async copy), 12 M lineitem rows x 44 B",
+                lambda: DeviceTable.from_arrow(host), host.num_rows, nbytes, note="bytes = host buffer bytes; PCIe Gen5 x16 = 63 GB/s")
+        dev = DeviceTable.from_arrow(host)
+        holder = {}
+
+        def export():
+            holder["t"] = dev.to_arrow()
+            return None
+        measure("dfgpu_table_export (HBM -> Arrow C Data Interface), same table", export, host.num_rows, nbytes, note="bytes = host buffer bytes")
+        dev.free()
+
     # ------------------------------------------------------------------ config 5 (one GPU): Q3
     if want("q3"):
         c, o, li = ops.tpch_customer(args.sf), ops.tpch_orders(args.sf), ops.tpch_lineitem(args.sf)

@@ -124,6 +124,72 @@ def test_broadcast_build_all_gather_over_gloo(tmp_path, world, ragged):
             assert res[r][width] == exp
 
 
+def _pruned_worker(rank, world, port, clustered, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from datafusion_amd.exchange import all_to_all_bytes, exchange_counts, gather_key_ranges, nothing_crosses_ranks, pruned_send_ranges
+    rng = np.random.default_rng(99)
+    nb, npr = 6000, 20000
+    bkeys = np.sort(rng.permutation(50_000)[:nb]).astype(np.int64)
+    pkeys = rng.integers(0, 50_000, npr).astype(np.int64)
+    if clustered:
+        pkeys = np.sort(pkeys)          # range-partitioned scans: each rank's probe keys cover a narrow range
+    my_b = bkeys[nb * rank // world: nb * (rank + 1) // world]
+    my_p = pkeys[npr * rank // world: npr * (rank + 1) // world]
+    if rank == world - 1 and not clustered:
+        my_p = my_p[:0]                 # a rank without probe rows asks for nothing
+    my_b_range = (int(my_b.min()), int(my_b.max())) if len(my_b) else None
+    ranges, branges = gather_key_ranges((int(my_p.min()), int(my_p.max())) if len(my_p) else None, my_b_range)
+    assert branges[rank] == my_b_range
+    assert not nothing_crosses_ranks(ranges, branges)      # random build keys: some always fall inside another rank's probe bounds
+    sends = pruned_send_ranges(ranges, my_b_range)
+    parts = [my_b[:0] if sr is None else my_b[(my_b >= sr[0]) & (my_b <= sr[1])] for sr in sends]
+    send_counts = [len(x) for x in parts]
+    recv_counts = exchange_counts(send_counts)
+    send = torch.from_numpy(np.frombuffer(np.concatenate(parts).tobytes(), dtype=np.uint8).copy()) if sum(send_counts) else torch.empty(0, dtype=torch.uint8)
+    recv = torch.empty(sum(recv_counts) * 8, dtype=torch.uint8)
+    all_to_all_bytes(send, send_counts, recv, recv_counts, 8)
+    got_b = np.frombuffer(recv.numpy().tobytes(), dtype=np.int64)
+    local_join = np.sort(my_p[np.isin(my_p, got_b)])
+    pickle.dump({"join": local_join, "received": len(got_b), "sent_to_peers": sum(send_counts) - send_counts[rank]}, open(os.path.join(outdir, f"p{rank}.pkl"), "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("clustered", [True, False], ids=["range_clustered_probe", "spread_probe"])
+def test_bounds_pruned_broadcast_over_gloo(tmp_path, clustered):
+    """pruned CollectLeft: every rank receives the build keys inside its own probe-key bounds; the union of the local
+    joins equals the global join, and clustered probe shards pull far fewer build rows than a full broadcast"""
+    world = 3
+    port = _free_port()
+    mp.spawn(_pruned_worker, args=(world, port, clustered, str(tmp_path)), nprocs=world, join=True)
+    res = [pickle.load(open(tmp_path / f"p{r}.pkl", "rb")) for r in range(world)]
+    rng = np.random.default_rng(99)
+    bkeys = np.sort(rng.permutation(50_000)[:6000]).astype(np.int64)
+    pkeys = rng.integers(0, 50_000, 20000).astype(np.int64)
+    if clustered:
+        pkeys = np.sort(pkeys)
+    else:
+        pkeys = pkeys[:20000 * (world - 1) // world]      # the last rank dropped its probe rows
+    exp = np.sort(pkeys[np.isin(pkeys, bkeys)])
+    got = np.sort(np.concatenate([r["join"] for r in res]))
+    assert (got == exp).all() and len(got) == len(exp)
+    full_broadcast = 6000 * (world - 1)                   # build rows that cross ranks in a plain all-gather
+    moved = sum(r["sent_to_peers"] for r in res)
+    assert moved <= full_broadcast
+    if clustered:
+        assert moved < full_broadcast // 4
+
+
+def test_pruned_broadcast_fast_path_decision():
+    from datafusion_amd.exchange import nothing_crosses_ranks
+    # aligned range shards (what bench.py's row ranges are): probe bounds inside the local build range
+    assert nothing_crosses_ranks([(1, 90), (101, 190), None], [(1, 100), (101, 200), (201, 300)])
+    assert not nothing_crosses_ranks([(1, 150), (101, 190)], [(1, 100), (101, 200)])
+    assert nothing_crosses_ranks([None, None], [(1, 100), (50, 200)])
+
+
 def test_broadcast_vs_repartition_choice():
     from datafusion_amd.exchange import broadcast_build_moves_fewer_bytes
     b, p = 150_000_000 * 16, 600_000_000 * 40   # the SF100 Q3 join of bench.py

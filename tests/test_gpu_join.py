@@ -229,3 +229,20 @@ def test_probe_side_filter_fused_into_the_probe(join_type, probe_mode):
     exp = oracle.hash_join(build, filtered, [("k", "k2")], join_type)
     keep = {"Inner": ["v", "k2", "p"], "Right": ["v", "k2", "p"], "RightSemi": pcols, "RightAnti": pcols, "LeftSemi": ["v"]}[join_type]
     assert_tables_equal(got, exp.select(keep))
+
+
+def test_column_minmax_statistics():
+    """dfgpu_column_minmax: the key statistics the join build and the pruned multi-GPU exchange use"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(3)
+    v = rng.integers(-10**12, 10**12, 100_001)
+    t = DeviceTable.from_arrow(pa.table({"a": pa.array(v, type=pa.int64()), "s": pa.array(np.arange(100_001) * 3 - 7, type=pa.int32()),
+                                         "n": pa.array([None if i % 5 == 0 else int(x % 1000) for i, x in enumerate(v)], type=pa.int64())}))
+    assert ops.column_minmax(t, "a") == (int(v.min()), int(v.max()), 100_001, False)
+    assert ops.column_minmax(t, "s") == (-7, 300_000 - 7, 100_001, True)
+    lo, hi, n, asc = ops.column_minmax(t, "n")
+    keep = [int(x % 1000) for i, x in enumerate(v) if i % 5]
+    assert (lo, hi, n, asc) == (min(keep), max(keep), len(keep), False)
+    empty = DeviceTable.from_arrow(pa.table({"a": pa.array([], type=pa.int64())}))
+    assert ops.column_minmax(empty, "a") == (None, None, 0, False)

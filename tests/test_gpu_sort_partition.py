@@ -93,7 +93,7 @@ import os, sys
 import numpy as np, pyarrow as pa, torch
 import torch.distributed as dist
 sys.path.insert(0, os.environ["DFGPU_ROOT"])
-from datafusion_amd.exchange import broadcast_table, hash_exchange
+from datafusion_amd.exchange import broadcast_table, hash_exchange, pruned_broadcast_table
 from datafusion_amd.table import DeviceTable
 from tests.util import assert_tables_equal, random_table
 t = random_table(np.random.default_rng(2), 100_000, {"k": (pa.int64(), 0, 10**6), "d": (pa.decimal128(15, 2), 0, 10**6), "q": (pa.int32(), 0, 9)})
@@ -104,6 +104,15 @@ assert_tables_equal(out.to_arrow(), t, ordered=True)
 # CollectLeft build side: all-gather of every column (one rank: the gathered table is the input)
 bc = broadcast_table(DeviceTable.from_arrow(t), force=True)
 assert_tables_equal(bc.to_arrow(), t, ordered=True)
+# bounds-pruned CollectLeft: the probe keys cover [200000, 600000] -> only build rows inside those bounds arrive
+import pyarrow.compute as pc
+probe = pa.table({"k2": pa.array(np.random.default_rng(3).integers(200_000, 600_001, 50_000), type=pa.int64())})
+xs = {}
+pb = pruned_broadcast_table(DeviceTable.from_arrow(t), "k", DeviceTable.from_arrow(probe), "k2", force=True, stats=xs)
+lo, hi = pc.min(probe.column("k2")).as_py(), pc.max(probe.column("k2")).as_py()
+exp = t.filter(pc.and_(pc.greater_equal(t.column("k"), lo), pc.less_equal(t.column("k"), hi)))
+assert_tables_equal(pb.to_arrow(), exp, ordered=True)
+assert xs["build_rows_after_exchange"] == exp.num_rows < t.num_rows
 print("EXCHANGE_OK", flush=True)
 os._exit(0)   # RCCL teardown in a one-rank group has aborted on some boxes; the result is already checked
 """
