@@ -1,0 +1,390 @@
+"""Host-side mirror of the reference's operator / plugin surface for the hot path.
+
+The reference plugs new operators in through two traits: `ExecutionPlan`
+(physical-plan/src/execution_plan.rs:102 — `name` :110, `children` :268, `with_new_children` :435,
+`execute(partition, ctx)` :696-700) and `PhysicalOptimizerRule`
+(session/src/physical_optimizer.rs:52-84 — `optimize`, `name`, `schema_check`).  Rust cannot be compiled in
+this image (INTEGRATION.md shows the shim a maintainer adds), so this module is the same surface in Python
+over the same C ABI: plan nodes carry the reference's names and constructor arguments, `GpuOffloadRule.optimize`
+rewrites a reference-shaped physical plan bottom-up exactly as the Rust rule would, and `execute()` runs the
+node on device tables.  Parity tests build the plans pinned in the reference's own plan files
+(sqllogictest/test_files/tpch/plans/q1.slt.part:50-58, q3.slt.part:61-76) node for node.
+
+What the rule substitutes (everything else is left as it is — on the CPU in the Rust shim, here the plain
+per-operator GPU node):
+  AggregateExec(ProjectionExec?(FilterExec?(x)))    -> GpuFusedAggregateExec   one pass, dfgpu_agg_update_filtered
+  HashJoinExec(build, FilterExec(probe))             -> GpuHashJoinExec         predicate applied inside the probe kernel
+  CoalesceBatchesExec / CoalescePartitionsExec       -> removed                 (whole partitions per launch)
+  RepartitionExec(Hash) on one GPU                   -> removed                 (one partition per GPU)
+"""
+from __future__ import annotations
+
+from . import ops
+from .expr import BinaryExpr, CastExpr, Column, IsNotNullExpr, IsNullExpr, Literal, NotExpr, PhysicalExpr
+from .table import DeviceTable
+
+
+# --------------------------------------------------------------------------- expression helpers
+def substitute(e: PhysicalExpr, mapping: dict) -> PhysicalExpr:
+    """replace Column references by the expressions a ProjectionExec computed them from (projection.rs:713-746
+    `update_expr`: how the reference pushes expressions through projections)"""
+    if isinstance(e, Column):
+        return mapping.get(e.name, e)
+    if isinstance(e, Literal):
+        return e
+    if isinstance(e, CastExpr):
+        return CastExpr(substitute(e.expr, mapping), e.cast_type)
+    if isinstance(e, BinaryExpr):
+        return BinaryExpr(substitute(e.left, mapping), e.op, substitute(e.right, mapping))
+    if isinstance(e, IsNullExpr):
+        return IsNullExpr(substitute(e.arg, mapping))
+    if isinstance(e, IsNotNullExpr):
+        return IsNotNullExpr(substitute(e.arg, mapping))
+    if isinstance(e, NotExpr):
+        return NotExpr(substitute(e.arg, mapping))
+    raise TypeError(f"unsupported expression node {type(e).__name__}")
+
+
+def columns_of(e: PhysicalExpr, out=None) -> set:
+    out = set() if out is None else out
+    if isinstance(e, Column):
+        out.add(e.name)
+    for c in e.children():
+        columns_of(c, out)
+    return out
+
+
+# --------------------------------------------------------------------------------- plan nodes
+class ExecutionPlan:
+    """execution_plan.rs:102.  `execute` returns the node's whole output partition as a device table
+    (the pull-stream contract lives at the Rust boundary only)."""
+
+    def name(self) -> str:
+        return type(self).__name__
+
+    def children(self) -> list:
+        return []
+
+    def with_new_children(self, children: list) -> "ExecutionPlan":
+        raise NotImplementedError
+
+    def execute(self, partition: int = 0) -> DeviceTable:
+        raise NotImplementedError
+
+    def detail(self) -> str:
+        return ""
+
+    def _run_child(self, child: "ExecutionPlan"):
+        """(table, owned): leaf tables belong to the caller and are never freed by a plan"""
+        t = child.execute()
+        return t, not isinstance(child, MemoryExec)
+
+    def _pass_through(self, child: "ExecutionPlan") -> DeviceTable:
+        """output = the child's output; a leaf's table is handed on as a zero-copy view the parent may free"""
+        t, owned = self._run_child(child)
+        return t if owned else t.select(list(range(t.num_columns)))
+
+
+class MemoryExec(ExecutionPlan):
+    """DataSourceExec over an in-memory table (datasource/src/memory.rs:58) — here: a device-resident table"""
+
+    def __init__(self, table: DeviceTable, name: str = ""):
+        self.table, self.label = table, name
+
+    def with_new_children(self, children):
+        return self
+
+    def execute(self, partition=0):
+        return self.table
+
+    def detail(self):
+        return f"{self.label} rows={self.table.num_rows}"
+
+
+class _Unary(ExecutionPlan):
+    def children(self):
+        return [self.input]
+
+
+class FilterExec(_Unary):
+    """FilterExec::try_new(predicate, input) with an optional embedded projection (filter.rs:85)"""
+
+    def __init__(self, predicate: PhysicalExpr, input: ExecutionPlan, projection=None):
+        self.predicate, self.input, self.projection = predicate, input, projection
+
+    def with_new_children(self, c):
+        return FilterExec(self.predicate, c[0], self.projection)
+
+    def execute(self, partition=0):
+        t, owned = self._run_child(self.input)
+        out = ops.filter(t, self.predicate, self.projection)
+        if owned:
+            t.free()
+        return out
+
+    def detail(self):
+        return f"{self.predicate!r}" + (f", projection={self.projection}" if self.projection else "")
+
+
+class ProjectionExec(_Unary):
+    """ProjectionExec::try_new(exprs = [(expr, name)], input) (projection.rs:439)"""
+
+    def __init__(self, exprs, input: ExecutionPlan):
+        self.exprs, self.input = exprs, input
+
+    def with_new_children(self, c):
+        return ProjectionExec(self.exprs, c[0])
+
+    def execute(self, partition=0):
+        t, owned = self._run_child(self.input)
+        out = ops.project(t, self.exprs)
+        if owned:
+            t.free()
+        return out
+
+    def detail(self):
+        return ", ".join(f"{e!r} as {n}" for e, n in self.exprs)
+
+
+class CoalesceBatchesExec(_Unary):
+    """coalesce/mod.rs:63 — batch-size bookkeeping; a device partition is already one batch"""
+
+    def __init__(self, input: ExecutionPlan, target_batch_size: int = 8192):
+        self.input, self.target_batch_size = input, target_batch_size
+
+    def with_new_children(self, c):
+        return CoalesceBatchesExec(c[0], self.target_batch_size)
+
+    def execute(self, partition=0):
+        return self._pass_through(self.input)
+
+
+class RepartitionExec(_Unary):
+    """RepartitionExec::try_new(input, Partitioning::Hash(keys, n)) (repartition/mod.rs:1626).  One process per
+    GPU: the exchange is RCCL (exchange.hash_exchange); with a single GPU there is one partition and nothing moves."""
+
+    def __init__(self, input: ExecutionPlan, keys, n_partitions: int, group=None):
+        self.input, self.keys, self.n_partitions, self.group = input, keys, n_partitions, group
+
+    def with_new_children(self, c):
+        return RepartitionExec(c[0], self.keys, self.n_partitions, self.group)
+
+    def execute(self, partition=0):
+        from .queries import _repartition, _world
+        if _world(self.group) == 1:
+            return self._pass_through(self.input)
+        t, owned = self._run_child(self.input)
+        out = _repartition(t, self.keys, self.group)
+        if owned:
+            t.free()
+        return out
+
+    def detail(self):
+        return f"Hash({self.keys}, {self.n_partitions})"
+
+
+class HashJoinExec(ExecutionPlan):
+    """HashJoinExec::try_new(left = build, right = probe, on, filter = None, join_type, projection, mode,
+    null_equality) (joins/hash_join/exec.rs:752).  `projection` = (build columns, probe columns)."""
+
+    def __init__(self, left: ExecutionPlan, right: ExecutionPlan, on, join_type="Inner", projection=None, null_equality="NullEqualsNothing",
+                 probe_mode=0):
+        self.left, self.right, self.on, self.join_type = left, right, on, join_type
+        self.projection, self.null_equality, self.probe_mode = projection, null_equality, probe_mode
+
+    def children(self):
+        return [self.left, self.right]
+
+    def with_new_children(self, c):
+        return HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode)
+
+    def _probe(self, ht, probe_table, predicate=None):
+        bc, pc = self.projection if self.projection else (None, None)
+        return ht.probe(probe_table, [r for _, r in self.on], self.join_type, bc, pc, predicate=predicate)
+
+    def execute(self, partition=0, probe_predicate=None):
+        if self.join_type not in ("Inner", "RightSemi", "RightAnti", "Right", "RightMark"):
+            # build-side emission (Left / Full / LeftSemi / LeftAnti / LeftMark): the general path of ops.hash_join
+            assert probe_predicate is None
+            b, bo = self._run_child(self.left)
+            p, po = self._run_child(self.right)
+            bc, pc = self.projection if self.projection else (None, None)
+            out = ops.hash_join(b, p, self.on, self.join_type, self.null_equality, bc, pc)
+            for t, o in ((b, bo), (p, po)):
+                if o:
+                    t.free()
+            return out
+        b, bo = self._run_child(self.left)
+        ht = ops.JoinHashTable(b, [l for l, _ in self.on], self.null_equality, probe_mode=self.probe_mode)
+        p, po = self._run_child(self.right)
+        out = self._probe(ht, p, probe_predicate)
+        ht.free()
+        for t, o in ((b, bo), (p, po)):
+            if o:
+                t.free()
+        return out
+
+    def detail(self):
+        return f"join_type={self.join_type}, on={self.on}" + (f", projection={self.projection}" if self.projection else "")
+
+
+class AggregateExec(_Unary):
+    """AggregateExec::try_new(mode, group_by = [(expr, name)], aggr_expr = [(func, arg | None, name)], input)
+    (aggregates/mod.rs:839)"""
+
+    def __init__(self, mode: str, group_by, aggr_expr, input: ExecutionPlan):
+        self.mode, self.group_by, self.aggr_expr, self.input = mode, group_by, aggr_expr, input
+
+    def with_new_children(self, c):
+        return AggregateExec(self.mode, self.group_by, self.aggr_expr, c[0])
+
+    def execute(self, partition=0):
+        t, owned = self._run_child(self.input)
+        out = ops.aggregate(t, self.group_by, self.aggr_expr, self.mode)
+        if owned:
+            t.free()
+        return out
+
+    def detail(self):
+        return f"mode={self.mode}, gby=[{', '.join(n for _, n in self.group_by)}], aggr=[{', '.join(n for _, _, n in self.aggr_expr)}]"
+
+
+class SortExec(_Unary):
+    """SortExec::new(expr = [(column, descending, nulls_first)], input).with_fetch(fetch) (sorts/sort.rs:1366);
+    with fetch it is the reference's TopK (topk/mod.rs:397)"""
+
+    def __init__(self, expr, input: ExecutionPlan, fetch=None):
+        self.expr, self.input, self.fetch = expr, input, fetch
+
+    def with_new_children(self, c):
+        return SortExec(self.expr, c[0], self.fetch)
+
+    def execute(self, partition=0):
+        t, owned = self._run_child(self.input)
+        out = ops.sort(t, self.expr, self.fetch)
+        if owned:
+            t.free()
+        return out
+
+    def detail(self):
+        return ("TopK(fetch=%d), " % self.fetch if self.fetch is not None else "") + str([(c, "DESC" if d else "ASC") for c, d, _ in self.expr])
+
+
+# ------------------------------------------------------------------------------ fused GPU nodes
+class GpuFusedAggregateExec(_Unary):
+    """FilterExec + ProjectionExec + AggregateExec as one node: predicate, inlined argument expressions and
+    accumulation in a single pass over the input's referenced columns (dfgpu_agg_update_filtered; the kernel is
+    specialised for the forest with hiprtc for large inputs, jit.hip).  Output schema = the AggregateExec's."""
+
+    def __init__(self, mode, group_by, aggr_expr, predicate, input: ExecutionPlan):
+        self.mode, self.group_by, self.aggr_expr, self.predicate, self.input = mode, group_by, aggr_expr, predicate, input
+
+    def with_new_children(self, c):
+        return GpuFusedAggregateExec(self.mode, self.group_by, self.aggr_expr, self.predicate, c[0])
+
+    def execute(self, partition=0):
+        t, owned = self._run_child(self.input)
+        out = ops.aggregate(t, self.group_by, self.aggr_expr, self.mode, predicate=self.predicate)
+        if owned:
+            t.free()
+        return out
+
+    def detail(self):
+        return f"mode={self.mode}, predicate={self.predicate!r}, gby=[{', '.join(n for _, n in self.group_by)}], aggr=[{', '.join(n for _, _, n in self.aggr_expr)}]"
+
+
+class GpuHashJoinExec(HashJoinExec):
+    """HashJoinExec with the FilterExec of its probe side fused below it (dfgpu_join_probe_filtered)"""
+
+    def __init__(self, join: HashJoinExec, probe_predicate: PhysicalExpr, probe_input: ExecutionPlan, probe_mode=None):
+        super().__init__(join.left, probe_input, join.on, join.join_type, join.projection, join.null_equality,
+                         join.probe_mode if probe_mode is None else probe_mode)
+        self.probe_predicate = probe_predicate
+
+    def with_new_children(self, c):
+        j = HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode)
+        return GpuHashJoinExec(j, self.probe_predicate, c[1])
+
+    def execute(self, partition=0):
+        return super().execute(partition, probe_predicate=self.probe_predicate)
+
+    def detail(self):
+        return super().detail() + f", probe_predicate={self.probe_predicate!r}"
+
+
+# --------------------------------------------------------------------------------------- the rule
+class GpuOffloadRule:
+    """PhysicalOptimizerRule (session/src/physical_optimizer.rs:52-84), appended with
+    SessionStateBuilder::with_physical_optimizer_rule (core/src/execution/session_state.rs:1407-1415) so that it
+    runs after the built-in rules have fixed distribution, ordering and join sides.  `unordered_probe=True` lets
+    joins whose parent does not need the probe-side order (an aggregate or a repartition) take the single-pass
+    unordered probe — the rule knows the parent because it rewrites bottom-up and fixes the child when it
+    visits the parent."""
+
+    def __init__(self, world_size: int = 1, unordered_probe: bool = True):
+        self.world_size, self.unordered_probe = world_size, unordered_probe
+
+    def name(self) -> str:
+        return "gpu_offload_amd"
+
+    def schema_check(self) -> bool:
+        return True
+
+    def optimize(self, plan: ExecutionPlan) -> ExecutionPlan:
+        return self._rewrite(plan, parent_needs_order=True)
+
+    # transform_up: children first (tree_node.rs), then this node.  `needs_order` = some ancestor observes this
+    # node's output order (maintains_input_order / required_input_ordering in the reference's terms)
+    def _rewrite(self, node: ExecutionPlan, parent_needs_order: bool) -> ExecutionPlan:
+        kids = []
+        for i, c in enumerate(node.children()):
+            if isinstance(node, (AggregateExec, GpuFusedAggregateExec, RepartitionExec, SortExec)):
+                need = False                                   # these consume their input in any order
+            elif isinstance(node, HashJoinExec):
+                need = parent_needs_order and i == 1           # only the probe side's order shows in the output
+            else:
+                need = parent_needs_order                      # FilterExec / ProjectionExec / CoalesceBatchesExec keep it
+            kids.append(self._rewrite(c, need))
+        if kids:
+            node = node.with_new_children(kids)
+        # bookkeeping nodes that have no meaning for whole-partition device tables
+        if isinstance(node, CoalesceBatchesExec):
+            return node.input
+        if isinstance(node, RepartitionExec) and self.world_size == 1:
+            return node.input
+        if isinstance(node, HashJoinExec) and not isinstance(node, GpuHashJoinExec):
+            probe_mode = ops.PROBE_MODES["single_pass_unordered"] if (self.unordered_probe and not parent_needs_order and
+                                                                      node.join_type in ("Inner", "RightSemi", "RightAnti")) else node.probe_mode
+            node = HashJoinExec(node.left, node.right, node.on, node.join_type, node.projection, node.null_equality, probe_mode)
+            probe = node.right
+            if isinstance(probe, FilterExec) and node.join_type in ("Inner", "RightSemi", "RightAnti", "Right", "RightMark"):
+                needed = set(r for _, r in node.on) | set((node.projection or (None, None))[1] or [])
+                # the FilterExec's embedded projection must keep what the join reads (it always does in a valid plan)
+                if probe.projection is None or needed <= set(probe.projection):
+                    return GpuHashJoinExec(node, probe.predicate, probe.input, probe_mode)
+            return node
+        if isinstance(node, AggregateExec) and node.mode in ("Single", "SinglePartitioned", "Partial"):
+            child, mapping, predicate = node.input, {}, None
+            if isinstance(child, ProjectionExec):
+                mapping = {n: e for e, n in child.exprs}
+                child = child.input
+            if isinstance(child, FilterExec):
+                predicate = child.predicate
+                child = child.input
+            if mapping or predicate is not None:
+                gb = [(substitute(e, mapping), n) for e, n in node.group_by]
+                aggs = [(f, None if e is None else substitute(e, mapping), n) for f, e, n in node.aggr_expr]
+                return GpuFusedAggregateExec(node.mode, gb, aggs, predicate, child)
+        return node
+
+
+def displayable(plan: ExecutionPlan, indent: int = 0) -> str:
+    """DisplayableExecutionPlan::indent (display.rs): one line per node, children indented"""
+    line = "  " * indent + plan.name() + (": " + plan.detail() if plan.detail() else "")
+    return "\n".join([line] + [displayable(c, indent + 1) for c in plan.children()])
+
+
+def collect(plan: ExecutionPlan) -> DeviceTable:
+    """physical_plan::collect for a single-partition plan; the caller owns the result"""
+    out = plan.execute(0)
+    return out.select(list(range(out.num_columns))) if isinstance(plan, MemoryExec) else out
