@@ -137,11 +137,15 @@ def take(table: pa.Table, idx: np.ndarray) -> pa.Table:
 # ----------------------------------------------------------------------------- join
 
 def hash_join(left: pa.Table, right: pa.Table, on, join_type="Inner", null_equality="NullEqualsNothing",
-              mode=0, small_build_threshold=1024, min_key_density=0.15, return_indices=False):
+              mode=0, small_build_threshold=1024, min_key_density=0.15, return_indices=False, join_filter=None):
     """HashJoinExec: left = build side, right = probe side (hash_join/exec.rs:752).
     Output schema = left columns ++ right columns (Inner/Left/Right/Full), left only for
     Left{Semi,Anti}, right only for Right{Semi,Anti}, + `mark` for *Mark joins
-    (joins/utils.rs:build_join_schema)."""
+    (joins/utils.rs:build_join_schema).
+    join_filter = (expr over intermediate columns named f0, f1, ..., [(column index, "Left" | "Right"), ...]):
+    JoinFilter (joins/join_filter.rs) — see _hash_join_filtered."""
+    if join_filter is not None:
+        return _hash_join_filtered(left, right, on, join_type, null_equality, mode, small_build_threshold, min_key_density, join_filter)
     L = lib()
     bh, bk = _cols([left.column(l) for l, _ in on])
     ph, pk = _cols([right.column(r) for _, r in on])
@@ -176,6 +180,53 @@ def hash_join(left: pa.Table, right: pa.Table, on, join_type="Inner", null_equal
     else:
         out = take(right, pi).append_column("mark", pa.array(mk))
     return out
+
+
+def _hash_join_filtered(left, right, on, join_type, null_equality, mode, small_build_threshold, min_key_density, join_filter):
+    """HashJoinExec with a JoinFilter.  The reference first finds the key-equal (build, probe) pairs, then
+    apply_join_filter_to_indices (joins/utils.rs:1248-1318) builds the intermediate batch from the filter's
+    column_indices, evaluates the expression and keeps the pairs whose value is TRUE (NULL = false); only those
+    pairs mark build rows visited and go through adjust_indices_by_join_type (joins/utils.rs:1432-1488,
+    hash_join/stream.rs:687-1000).  Unmatched rows of outer / anti / mark joins are therefore rows without a
+    PASSING pair."""
+    expr, cols = join_filter
+    bi, pi, _, _ = hash_join(left, right, on, "Inner", null_equality, mode, small_build_threshold, min_key_density, return_indices=True)
+    inter = pa.table({f"f{i}": (take(left, bi) if side == "Left" else take(right, pi)).column(idx) for i, (idx, side) in enumerate(cols)}) \
+        if len(bi) else pa.table({f"f{i}": pa.array([], type=(left if side == "Left" else right).schema.field(idx).type) for i, (idx, side) in enumerate(cols)})
+    d = evaluate(expr, inter)
+    vals = np.repeat(d.values, len(bi)) if d.scalar else d.values
+    keep = np.asarray(vals, dtype=bool)
+    v = None if d.valid is None else (np.repeat(d.valid, len(bi)) if d.scalar else d.valid)
+    if v is not None:
+        keep = keep & v
+    bi, pi = bi[keep], pi[keep]
+    nl, nr = left.num_rows, right.num_rows
+    l_hit, r_hit = np.zeros(nl, bool), np.zeros(nr, bool)
+    l_hit[bi] = True
+    r_hit[pi] = True
+    l_un, r_un = np.nonzero(~l_hit)[0].astype(np.int64), np.nonzero(~r_hit)[0].astype(np.int64)
+    both = lambda b, p: pa.Table.from_arrays(list(take(left, b).columns) + list(take(right, p).columns),
+                                             names=[f.name for f in left.schema] + [f.name for f in right.schema])
+    neg = lambda k: np.full(k, -1, np.int64)
+    if join_type == "Inner":
+        return both(bi, pi)
+    if join_type == "Left":
+        return both(np.concatenate([bi, l_un]), np.concatenate([pi, neg(len(l_un))]))
+    if join_type == "Right":
+        return both(np.concatenate([bi, neg(len(r_un))]), np.concatenate([pi, r_un]))
+    if join_type == "Full":
+        return both(np.concatenate([bi, neg(len(r_un)), l_un]), np.concatenate([pi, r_un, neg(len(l_un))]))
+    if join_type == "LeftSemi":
+        return take(left, np.nonzero(l_hit)[0].astype(np.int64))
+    if join_type == "LeftAnti":
+        return take(left, l_un)
+    if join_type == "RightSemi":
+        return take(right, np.nonzero(r_hit)[0].astype(np.int64))
+    if join_type == "RightAnti":
+        return take(right, r_un)
+    if join_type == "LeftMark":
+        return left.append_column("mark", pa.array(l_hit))
+    return right.append_column("mark", pa.array(r_hit))
 
 
 def partitioned_inner_join_i64(build_keys: np.ndarray, probe_keys: np.ndarray, nthreads: int):
