@@ -35,6 +35,11 @@ class Expr(C.Structure):
     _fields_ = [("nodes", C.POINTER(ExprNode)), ("n_nodes", C.c_int32), ("root", C.c_int32)]
 
 
+class JoinFilter(C.Structure):
+    """dfgpu_join_filter"""
+    _fields_ = [("expression", Expr), ("column_index", C.POINTER(C.c_int32)), ("column_side", C.POINTER(C.c_int32)), ("n_columns", C.c_int32)]
+
+
 class JoinOptions(C.Structure):
     _fields_ = [("perfect_hash_join_small_build_threshold", C.c_int64),
                 ("perfect_hash_join_min_key_density", C.c_double), ("table_mode", C.c_int32),
@@ -62,7 +67,7 @@ SYMBOLS = [
     "dfgpu_stream", "dfgpu_mem_stats", "dfgpu_mem_trim", "dfgpu_table_import", "dfgpu_table_export",
     "dfgpu_table_alloc", "dfgpu_table_free", "dfgpu_table_num_rows", "dfgpu_table_num_columns", "dfgpu_table_column",
     "dfgpu_table_select", "dfgpu_table_hstack", "dfgpu_table_concat", "dfgpu_table_slice", "dfgpu_expr_type",
-    "dfgpu_filter", "dfgpu_project", "dfgpu_join_build", "dfgpu_join_probe", "dfgpu_join_probe_filtered", "dfgpu_column_minmax", "dfgpu_join_emit_unmatched",
+    "dfgpu_filter", "dfgpu_project", "dfgpu_join_build", "dfgpu_join_probe", "dfgpu_join_probe_filtered", "dfgpu_join_probe_with_filter", "dfgpu_column_minmax", "dfgpu_join_emit_unmatched",
     "dfgpu_join_get_info", "dfgpu_join_free", "dfgpu_agg_create", "dfgpu_agg_update", "dfgpu_agg_update_filtered", "dfgpu_agg_fused_updates", "dfgpu_set_fusion", "dfgpu_jit_stats", "dfgpu_agg_emit",
     "dfgpu_agg_free", "dfgpu_sort", "dfgpu_partition", "dfgpu_hash_columns", "dfgpu_tpch_orders",
     "dfgpu_tpch_lineitem", "dfgpu_tpch_customer", "dfgpu_profile_enable", "dfgpu_profile_reset",

@@ -734,6 +734,62 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
   }
 }
 
+// ---------------------------------------------------------------- JoinFilter (joins/join_filter.rs)
+// apply_join_filter_to_indices (joins/utils.rs:1248-1318): key-equal pairs -> intermediate batch -> filter
+// expression -> pairs whose value is TRUE.  Only passing pairs count as matches (visited bits, probe hits).
+__global__ __launch_bounds__(BLOCK) void k_pair_tally(const int64_t* __restrict__ ob, const int64_t* __restrict__ op, const uint64_t* __restrict__ pass, int64_t m,
+                                                     uint32_t* __restrict__ probe_hits, uint8_t* __restrict__ visited) {
+  for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < m; j += (int64_t)gridDim.x * BLOCK) {
+    if (!bit_at(pass, j)) continue;
+    atomicAdd(&probe_hits[op[j]], 1u);
+    if (visited) visited[ob[j]] = 1;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_pairs_compact(const int64_t* __restrict__ ob, const int64_t* __restrict__ op, const uint64_t* __restrict__ pass,
+                                                        const uint64_t* __restrict__ prefix, int64_t m, int64_t* __restrict__ ob2, int64_t* __restrict__ op2) {
+  const int64_t n_words = (m + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    uint64_t mk = pass[w];
+    const int64_t rem = m - (w << 6);
+    if (rem < 64) mk &= (~0ull) >> (64 - rem);
+    if ((mk >> lane_id()) & 1ull) {
+      const int64_t d = (int64_t)(prefix[w] + mbcnt(mk)), j = (w << 6) + lane_id();
+      ob2[d] = ob[j];
+      op2[d] = op[j];
+    }
+  }
+}
+// mask[p] = (probe row p has a passing pair) == want; bytes[p] (optional) = has a passing pair
+__global__ __launch_bounds__(BLOCK) void k_hits_mask(const uint32_t* __restrict__ hits, int64_t np, int want, uint64_t* __restrict__ mask, uint8_t* __restrict__ bytes) {
+  const int64_t n_words = (np + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const int64_t p = (w << 6) + lane_id();
+    const bool hit = p < np && hits[p] != 0;
+    if (bytes && p < np) bytes[p] = hit ? 1 : 0;
+    const uint64_t word = ballot64(p < np && (hit == (want != 0)));
+    if (lane_id() == 0) mask[w] = word;
+  }
+}
+// row ids of the set bits -> idx[base + rank]; build[base + rank] = -1 (unmatched probe rows of Right / Full joins)
+__global__ __launch_bounds__(BLOCK) void k_append_unmatched(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ prefix, int64_t np, int64_t base,
+                                                           int64_t* __restrict__ ob2, int64_t* __restrict__ op2) {
+  const int64_t n_words = (np + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const uint64_t mk = mask[w];
+    if ((mk >> lane_id()) & 1ull) {
+      const int64_t d = base + (int64_t)(prefix[w] + mbcnt(mk));
+      ob2[d] = -1;
+      op2[d] = (w << 6) + lane_id();
+    }
+  }
+}
+
 // unmatched / matched build rows from the visited bytes (process_unmatched_build_batch, stream.rs:1002-)
 __global__ __launch_bounds__(BLOCK) void k_visited_mask(const uint8_t* __restrict__ visited, int64_t n, int want_visited, uint64_t* __restrict__ mask) {
   const int64_t n_words = (n + 63) >> 6;
@@ -1161,6 +1217,104 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   return out;
 }
 
+// HashJoinExec with a JoinFilter: the general (pairs) path with the filter between pair generation and the
+// per-JoinType adjustment.  Not a tuned path: pairs and the intermediate batch are materialised.
+static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
+                                    const std::vector<int>& pout, const dfgpu_join_filter& jf) {
+  Runtime& r = rt();
+  DFGPU_CHECK(pk.size() == jt.key_cols.size(), "probe key count differs from build key count");
+  for (int c : bout) DFGPU_CHECK(c >= 0 && c < (int)jt.build.cols.size(), "build output column out of range");
+  for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
+  const int64_t np = probe.nrows;
+  const int64_t n_words = (np + 63) / 64;
+  ProbeCtx ctx = make_ctx(jt, probe, pk);
+  jt.info.probe_rows += np;
+  // ---- key-equal pairs (an Inner join on the keys; nothing is marked visited yet)
+  BufPtr row_counts = make_buf((size_t)(np ? np : 1) * 4), word_counts = make_buf((size_t)(n_words ? n_words : 1) * 4);
+  BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
+  const int g = grid_for(n_words, BLOCK / WAVE);
+  if (np) with_kind(jt.kind, [&](auto kt) {
+    k_probe_count<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, DFGPU_JOIN_INNER, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), nullptr);
+  });
+  scan_u32(word_counts->as<uint32_t>(), n_words, prefix->as<uint64_t>());
+  const int64_t m = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+  BufPtr ob = make_buf((size_t)(m ? m : 1) * 8), op = make_buf((size_t)(m ? m : 1) * 8);
+  if (m) with_kind(jt.kind, [&](auto kt) {
+    k_probe_emit<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, DFGPU_JOIN_INNER, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), ob->as<int64_t>(), op->as<int64_t>(), nullptr);
+  });
+  DFGPU_HIP(hipGetLastError());
+  // ---- intermediate batch + filter expression -> pass mask over the pairs
+  Table inter;
+  inter.nrows = m;
+  for (int i = 0; i < jf.n_columns; i++) {
+    const bool left = jf.column_side[i] == 0;
+    const Table& side = left ? jt.build : probe;
+    DFGPU_CHECK(jf.column_index[i] >= 0 && jf.column_index[i] < (int)side.cols.size(), "join filter column index out of range");
+    inter.cols.push_back(gather_column(side.cols[jf.column_index[i]], (left ? ob : op)->as<int64_t>(), m, false));
+  }
+  const int64_t m_words = (m + 63) / 64;
+  BufPtr pass = make_zero_buf((size_t)(m_words ? m_words : 1) * 8);
+  if (m) {
+    Datum d = evaluate(jf.expression, inter);
+    DFGPU_CHECK(d.col.field.type == DFGPU_BOOL, "join filter expression must be Boolean");
+    Column mc = datum_to_column(d, m, "");
+    if (mc.validity) and_bitmaps(mc.data->as<uint64_t>(), mc.valid_words(), m_words, pass->as<uint64_t>());
+    else pass = mc.data;
+  }
+  // ---- matches = passing pairs
+  BufPtr hits = make_zero_buf((size_t)(np ? np : 1) * 4);
+  uint8_t* visited = nullptr;
+  if (needs_visited(join_type)) {
+    if (!jt.visited) jt.visited = make_zero_buf((size_t)jt.build.nrows + 64);
+    visited = jt.visited->as<uint8_t>();
+  }
+  if (m) k_pair_tally<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(ob->as<int64_t>(), op->as<int64_t>(), pass->as<uint64_t>(), m, hits->as<uint32_t>(), visited);
+  Table out;
+  const bool pairs_out = join_type == DFGPU_JOIN_INNER || join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_RIGHT || join_type == DFGPU_JOIN_FULL;
+  if (pairs_out) {
+    BufPtr pprefix = make_buf((size_t)(m_words + 1) * 8);
+    scan_mask_popcounts(pass->as<uint64_t>(), nullptr, m, pprefix->as<uint64_t>());
+    const int64_t n_pass = m ? (int64_t)read_u64(pprefix->as<uint64_t>() + m_words) : 0;
+    int64_t n_un = 0;
+    BufPtr umask, uprefix;
+    const bool probe_outer = join_type == DFGPU_JOIN_RIGHT || join_type == DFGPU_JOIN_FULL;
+    if (probe_outer && np) {
+      umask = make_buf(bitmap_bytes(np));
+      uprefix = make_buf((size_t)(n_words + 1) * 8);
+      k_hits_mask<<<g, BLOCK, 0, r.stream>>>(hits->as<uint32_t>(), np, 0, umask->as<uint64_t>(), nullptr);
+      scan_mask_popcounts(umask->as<uint64_t>(), nullptr, np, uprefix->as<uint64_t>());
+      n_un = (int64_t)read_u64(uprefix->as<uint64_t>() + n_words);
+    }
+    const int64_t n_out = n_pass + n_un;
+    BufPtr ob2 = make_buf((size_t)(n_out ? n_out : 1) * 8), op2 = make_buf((size_t)(n_out ? n_out : 1) * 8);
+    if (n_pass) k_pairs_compact<<<grid_for(m_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(ob->as<int64_t>(), op->as<int64_t>(), pass->as<uint64_t>(), pprefix->as<uint64_t>(), m,
+                                                                                        ob2->as<int64_t>(), op2->as<int64_t>());
+    if (n_un) k_append_unmatched<<<g, BLOCK, 0, r.stream>>>(umask->as<uint64_t>(), uprefix->as<uint64_t>(), np, n_pass, ob2->as<int64_t>(), op2->as<int64_t>());
+    DFGPU_HIP(hipGetLastError());
+    out.nrows = n_out;
+    for (int c : bout) out.cols.push_back(gather_column(jt.build.cols[c], ob2->as<int64_t>(), n_out, probe_outer));
+    for (int c : pout) out.cols.push_back(gather_column(probe.cols[c], op2->as<int64_t>(), n_out, false));
+  } else if (join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI) {
+    BufPtr mask = make_zero_buf(bitmap_bytes(np ? np : 1));
+    if (np) k_hits_mask<<<g, BLOCK, 0, r.stream>>>(hits->as<uint32_t>(), np, join_type == DFGPU_JOIN_RIGHT_SEMI, mask->as<uint64_t>(), nullptr);
+    out = compact_table(probe, pout, mask->as<uint64_t>(), nullptr);
+  } else if (join_type == DFGPU_JOIN_RIGHT_MARK) {
+    BufPtr mask = make_zero_buf(bitmap_bytes(np ? np : 1));
+    BufPtr bytes = make_zero_buf((size_t)np + 64);
+    if (np) k_hits_mask<<<g, BLOCK, 0, r.stream>>>(hits->as<uint32_t>(), np, 1, mask->as<uint64_t>(), bytes->as<uint8_t>());
+    out.nrows = np;
+    for (int c : pout) out.cols.push_back(probe.cols[c]);
+    out.cols.push_back(mark_column(bytes->as<uint8_t>(), np));
+  } else {
+    // LeftSemi / LeftAnti / LeftMark: emitted from the visited bits by dfgpu_join_emit_unmatched
+    out.nrows = 0;
+    for (int c : bout) out.cols.push_back(alloc_column(jt.build.cols[c].field, jt.build.cols[c].name, 0));
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  jt.info.output_rows += out.nrows;
+  return out;
+}
+
 }  // namespace dfgpu
 
 using namespace dfgpu;
@@ -1254,6 +1408,20 @@ int dfgpu_join_probe_filtered(dfgpu_join_t ht, dfgpu_table_t probe, const dfgpu_
     }
     DFGPU_HIP(hipStreamSynchronize(rt().stream));
     auto o = std::make_unique<Table>(std::move(res));
+    *out = wrap(o.release());
+  });
+}
+
+int dfgpu_join_probe_with_filter(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type, const dfgpu_join_filter* filter,
+                                 const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(ht && out && filter && filter->n_columns >= 0, "null argument");
+    JoinTable* jt = reinterpret_cast<JoinTable*>(ht);
+    DFGPU_CHECK(join_type >= DFGPU_JOIN_INNER && join_type <= DFGPU_JOIN_RIGHT_MARK, "bad join type");
+    std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
+    std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
+    auto o = std::make_unique<Table>(join_probe_with_filter(*jt, *unwrap(probe), pk, join_type, bo, po, *filter));
     *out = wrap(o.release());
   });
 }

@@ -8,7 +8,7 @@ import ctypes as C
 import pyarrow as pa
 
 from . import _lib
-from ._lib import AggSpec, Expr, Field, JoinInfo, JoinOptions, KernelStat, check
+from ._lib import AggSpec, Expr, Field, JoinFilter, JoinInfo, JoinOptions, KernelStat, check
 from .expr import PhysicalExpr, lower
 from .table import DeviceTable, field_of
 
@@ -66,9 +66,11 @@ class JoinHashTable:
                                    C.byref(opts), C.byref(self._h)))
 
     def probe(self, probe: DeviceTable, on_right, join_type="Inner", build_cols=None, probe_cols=None,
-              predicate: PhysicalExpr | None = None) -> DeviceTable:
+              predicate: PhysicalExpr | None = None, join_filter=None) -> DeviceTable:
         """`predicate` = a FilterExec fused below the probe side: with the single-pass probe its row mask is applied
-        inside the probe kernel and the filtered probe table is never materialised (dfgpu_join_probe_filtered)"""
+        inside the probe kernel and the filtered probe table is never materialised (dfgpu_join_probe_filtered).
+        `join_filter` = JoinFilter (joins/join_filter.rs): (expression over intermediate columns f0, f1, ...,
+        [(column index, "Left" | "Right"), ...]); key-equal pairs whose filter value is not TRUE are not matches."""
         lib = _lib.load()
         pk = [probe.index_of(k) for k in on_right]
         bc = list(range(self.build.num_columns)) if build_cols is None else [self.build.index_of(c) for c in build_cols]
@@ -78,6 +80,17 @@ class JoinHashTable:
         if join_type in ("RightSemi", "RightAnti", "RightMark"):
             bc = []
         out = C.c_void_p()
+        if join_filter is not None:
+            if predicate is not None:
+                raise _lib.DfgpuError("a fused probe-side predicate and a join filter cannot be combined: filter the probe side first")
+            fexpr, fcols = join_filter
+            le = lower(fexpr, [f"f{i}" for i in range(len(fcols))])
+            idx = (C.c_int32 * max(1, len(fcols)))(*[int(i) for i, _ in fcols])
+            side = (C.c_int32 * max(1, len(fcols)))(*[0 if sd == "Left" else 1 for _, sd in fcols])
+            jf = JoinFilter(le.c, idx, side, len(fcols))
+            check(lib.dfgpu_join_probe_with_filter(self._h, probe.handle, _ints(pk), JOIN_TYPES[join_type], C.byref(jf), _ints(bc), len(bc), _ints(pc),
+                                                   len(pc), C.byref(out)))
+            return DeviceTable(out)
         if predicate is None:
             check(lib.dfgpu_join_probe(self._h, probe.handle, _ints(pk), JOIN_TYPES[join_type], _ints(bc), len(bc), _ints(pc),
                                        len(pc), C.byref(out)))
@@ -117,10 +130,10 @@ class JoinHashTable:
 
 
 def hash_join(left: DeviceTable, right: DeviceTable, on, join_type="Inner", null_equality="NullEqualsNothing",
-              build_cols=None, probe_cols=None, **build_opts) -> DeviceTable:
+              build_cols=None, probe_cols=None, join_filter=None, **build_opts) -> DeviceTable:
     """HashJoinExec over whole tables: left = build side, right = probe side"""
     ht = JoinHashTable(left, [l for l, _ in on], null_equality, **build_opts)
-    out = ht.probe(right, [r for _, r in on], join_type, build_cols, probe_cols)
+    out = ht.probe(right, [r for _, r in on], join_type, build_cols, probe_cols, join_filter=join_filter)
     if join_type in ("Left", "Full", "LeftSemi", "LeftAnti", "LeftMark"):
         psch = None
         if join_type in ("Left", "Full"):

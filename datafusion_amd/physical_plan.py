@@ -188,28 +188,29 @@ class HashJoinExec(ExecutionPlan):
     null_equality) (joins/hash_join/exec.rs:752).  `projection` = (build columns, probe columns)."""
 
     def __init__(self, left: ExecutionPlan, right: ExecutionPlan, on, join_type="Inner", projection=None, null_equality="NullEqualsNothing",
-                 probe_mode=0):
+                 probe_mode=0, filter=None):
         self.left, self.right, self.on, self.join_type = left, right, on, join_type
         self.projection, self.null_equality, self.probe_mode = projection, null_equality, probe_mode
+        self.filter = filter   # JoinFilter: (expression over f0, f1, ..., [(column index, "Left" | "Right"), ...])
 
     def children(self):
         return [self.left, self.right]
 
     def with_new_children(self, c):
-        return HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode)
+        return HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode, self.filter)
 
     def _probe(self, ht, probe_table, predicate=None):
         bc, pc = self.projection if self.projection else (None, None)
-        return ht.probe(probe_table, [r for _, r in self.on], self.join_type, bc, pc, predicate=predicate)
+        return ht.probe(probe_table, [r for _, r in self.on], self.join_type, bc, pc, predicate=predicate, join_filter=self.filter)
 
     def execute(self, partition=0, probe_predicate=None):
-        if self.join_type not in ("Inner", "RightSemi", "RightAnti", "Right", "RightMark"):
+        if self.filter is not None or self.join_type not in ("Inner", "RightSemi", "RightAnti", "Right", "RightMark"):
             # build-side emission (Left / Full / LeftSemi / LeftAnti / LeftMark): the general path of ops.hash_join
             assert probe_predicate is None
             b, bo = self._run_child(self.left)
             p, po = self._run_child(self.right)
             bc, pc = self.projection if self.projection else (None, None)
-            out = ops.hash_join(b, p, self.on, self.join_type, self.null_equality, bc, pc)
+            out = ops.hash_join(b, p, self.on, self.join_type, self.null_equality, bc, pc, join_filter=self.filter)
             for t, o in ((b, bo), (p, po)):
                 if o:
                     t.free()
@@ -302,7 +303,7 @@ class GpuHashJoinExec(HashJoinExec):
         self.probe_predicate = probe_predicate
 
     def with_new_children(self, c):
-        j = HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode)
+        j = HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode, self.filter)
         return GpuHashJoinExec(j, self.probe_predicate, c[1])
 
     def execute(self, partition=0):
@@ -355,9 +356,10 @@ class GpuOffloadRule:
         if isinstance(node, HashJoinExec) and not isinstance(node, GpuHashJoinExec):
             probe_mode = ops.PROBE_MODES["single_pass_unordered"] if (self.unordered_probe and not parent_needs_order and
                                                                       node.join_type in ("Inner", "RightSemi", "RightAnti")) else node.probe_mode
-            node = HashJoinExec(node.left, node.right, node.on, node.join_type, node.projection, node.null_equality, probe_mode)
+            node = HashJoinExec(node.left, node.right, node.on, node.join_type, node.projection, node.null_equality,
+                                node.probe_mode if node.filter is not None else probe_mode, node.filter)
             probe = node.right
-            if isinstance(probe, FilterExec) and node.join_type in ("Inner", "RightSemi", "RightAnti", "Right", "RightMark"):
+            if node.filter is None and isinstance(probe, FilterExec) and node.join_type in ("Inner", "RightSemi", "RightAnti", "Right", "RightMark"):
                 needed = set(r for _, r in node.on) | set((node.projection or (None, None))[1] or [])
                 # the FilterExec's embedded projection must keep what the join reads (it always does in a valid plan)
                 if probe.projection is None or needed <= set(probe.projection):

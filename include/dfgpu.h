@@ -268,6 +268,19 @@ int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int nu
 int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type,
                      const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out,
                      dfgpu_table_t* out);
+/* JoinFilter (physical-plan/src/joins/join_filter.rs): a residual predicate over columns of both sides.  The
+ * expression's Column i is the i-th (column_index, column_side) entry — the reference's intermediate batch
+ * (apply_join_filter_to_indices, joins/utils.rs:1248-1318).  Key-equal pairs whose filter value is not TRUE are
+ * not matches: they mark no build row visited and leave outer / anti / mark rows unmatched. */
+typedef struct dfgpu_join_filter {
+  dfgpu_expr expression;
+  const int32_t* column_index; /* index into its side's table */
+  const int32_t* column_side;  /* 0 = left (build side), 1 = right (probe side) */
+  int32_t n_columns;
+} dfgpu_join_filter;
+int dfgpu_join_probe_with_filter(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type, const dfgpu_join_filter* filter,
+                                 const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out, dfgpu_table_t* out);
+
 /* min / max / non-null count of an integer column and whether it is strictly ascending (the statistics
  * ArrayMap::try_new takes from the build keys, joins/array_map.rs:175-203; also the probe-key bounds the multi-GPU
  * exchange prunes the build-side broadcast with — hash_join/shared_bounds.rs:277-284 turned around).  One pass, one

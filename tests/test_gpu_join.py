@@ -246,3 +246,46 @@ def test_column_minmax_statistics():
     assert (lo, hi, n, asc) == (min(keep), max(keep), len(keep), False)
     empty = DeviceTable.from_arrow(pa.table({"a": pa.array([], type=pa.int64())}))
     assert ops.column_minmax(empty, "a") == (None, None, 0, False)
+
+
+FILTER_CASES = load_golden("hash_join_filter.json")
+
+
+def _filter_of(case):
+    """(GPU expression over f0.., oracle expression, column list) of a golden JoinFilter"""
+    from datafusion_amd.expr import col, lit
+    f, e = case["filter"], case["filter"]["expr"]
+    lhs = col(f"f{e['left']}")
+    rhs = col(f"f{e['right_col']}") if "right_col" in e else lit(e["right_lit"], pa.int32())
+    gpu = {">": lhs > rhs, "!=": lhs.ne(rhs), "<": lhs < rhs, "=": lhs.eq(rhs), ">=": lhs >= rhs, "<=": lhs <= rhs}[e["op"]]
+    return gpu, [(i, side) for i, side in f["columns"]]
+
+
+@pytest.mark.parametrize("opts", [dict(table_mode=0), dict(table_mode=1), dict(table_mode=1, force_hash_collisions=True)],
+                         ids=["phj_auto", "hash_map", "forced_collisions"])
+@pytest.mark.parametrize("case", FILTER_CASES, ids=[c["name"] for c in FILTER_CASES])
+def test_reference_snapshots_with_join_filter(case, opts):
+    """the reference's join_*_with_filter tests (hash_join/exec.rs:4422-5830) through dfgpu_join_probe_with_filter"""
+    left = i32_table(case["left"]["columns"], case["left"]["data"])
+    right = i32_table(case["right"]["columns"], case["right"]["data"])
+    out = gpu_join(left, right, [tuple(p) for p in case["on"]], case["join_type"], case["null_equality"], join_filter=_filter_of(case), **opts)
+    assert out.column_names == case["expected_columns"], case["source"]
+    key = lambda row: tuple((v is None, 0 if v is None else v) for v in row)
+    assert sorted_rows(out) == sorted([tuple(r) for r in case["expected_rows"]], key=key), case["source"]
+
+
+@pytest.mark.parametrize("join_type", ALL_TYPES)
+def test_random_join_filter_vs_oracle(join_type):
+    from datafusion_amd.expr import col
+    from oracle import oracle
+    from tests.util import to_oracle_expr
+    rng = np.random.default_rng(23)
+    left = random_table(rng, 2500, {"a": (pa.int64(), 0, 300), "x": (pa.decimal128(15, 2), 0, 10**6), "y": (pa.int32(), 0, 100)}, null_frac=0.05)
+    right = random_table(rng, 6000, {"b": (pa.int64(), 0, 350), "z": (pa.decimal128(15, 2), 0, 10**6), "w": (pa.int32(), 0, 100)}, null_frac=0.05)
+    # residual predicate over both sides with NULLs on both: left.x > right.z AND left.y != right.w
+    gpu_expr = (col("f0") > col("f1")).and_(col("f2").ne(col("f3")))
+    cols = [(1, "Left"), (1, "Right"), (2, "Left"), (2, "Right")]
+    for mode in (0, 1):
+        got = gpu_join(left, right, [("a", "b")], join_type, join_filter=(gpu_expr, cols), table_mode=mode)
+        exp = oracle.hash_join(left, right, [("a", "b")], join_type, join_filter=(to_oracle_expr(gpu_expr), cols))
+        assert_tables_equal(got, exp)
