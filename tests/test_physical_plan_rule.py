@@ -1,0 +1,59 @@
+"""GpuOffloadRule rewrites (no GPU needed: the rule only looks at the plan's shape).  The plans are the reference's
+pinned TPC-H Q1 / Q3 physical plans (tpch/plans/q1.slt.part:50-58, q3.slt.part:61-76) as built in
+tests/test_gpu_physical_plan.py, over stub leaf tables."""
+from tests.test_gpu_physical_plan import names, q1_plan, q3_plan
+
+
+class StubTable:
+    def __init__(self, n):
+        self.num_rows = n
+
+
+def test_q1_plan_rewrite_shape_and_display():
+    from datafusion_amd import physical_plan as P
+    plan = q1_plan(StubTable(6_001_215))
+    assert names(plan) == ["SortExec", "AggregateExec", "CoalesceBatchesExec", "RepartitionExec", "AggregateExec", "ProjectionExec", "CoalesceBatchesExec",
+                           "FilterExec", "MemoryExec"]
+    rule = P.GpuOffloadRule()
+    opt = rule.optimize(plan)
+    assert names(opt) == ["SortExec", "AggregateExec", "GpuFusedAggregateExec", "MemoryExec"]
+    fused = opt.children()[0].children()[0]
+    assert fused.mode == "Partial" and fused.predicate is not None
+    # the ProjectionExec's __common_expr_1 is inlined into the aggregate arguments
+    txt = P.displayable(opt)
+    assert "__common_expr_1" not in txt.split("GpuFusedAggregateExec")[1].split("\n")[0].split("aggr=")[0]
+    assert "GpuFusedAggregateExec: mode=Partial, predicate=(l_shipdate@None <= " in txt
+    # with more than one GPU the RepartitionExec stays (it becomes the RCCL exchange)
+    assert "RepartitionExec" in names(P.GpuOffloadRule(world_size=8).optimize(plan))
+
+
+def test_q3_plan_rewrite_shape():
+    from datafusion_amd import ops, physical_plan as P
+    plan = q3_plan(StubTable(15_000), StubTable(150_000), StubTable(600_000))
+    assert names(plan).count("RepartitionExec") == 4 and names(plan).count("CoalesceBatchesExec") == 9
+    opt = P.GpuOffloadRule().optimize(plan)
+    assert names(opt) == ["ProjectionExec", "SortExec", "AggregateExec", "GpuHashJoinExec", "GpuHashJoinExec", "FilterExec", "MemoryExec", "MemoryExec", "MemoryExec"]
+    inner = opt.children()[0].children()[0].children()[0]
+    semi = inner.children()[0]
+    assert inner.join_type == "Inner" and semi.join_type == "RightSemi"
+    assert inner.probe_mode == semi.probe_mode == ops.PROBE_MODES["single_pass_unordered"]
+    assert repr(inner.probe_predicate).startswith("(l_shipdate@None > ") and repr(semi.probe_predicate).startswith("(o_orderdate@None < ")
+    # ordered probes when the rule is told not to reorder
+    keep = P.GpuOffloadRule(unordered_probe=False).optimize(plan)
+    assert all(n.probe_mode == 0 for n in _walk(keep) if isinstance(n, P.HashJoinExec))
+
+
+def test_join_with_a_join_filter_keeps_its_probe_side_filter_separate():
+    from datafusion_amd import physical_plan as P
+    from datafusion_amd.expr import col, lit
+    jf = (col("f0") > col("f1"), [(1, "Left"), (1, "Right")])
+    j = P.HashJoinExec(P.MemoryExec(StubTable(1)), P.FilterExec(col("w") > lit(1), P.MemoryExec(StubTable(1))), [("k", "k2")], "Inner", filter=jf)
+    opt = P.GpuOffloadRule().optimize(P.AggregateExec("Single", [], [("count", None, "c")], j))
+    assert names(opt) == ["AggregateExec", "HashJoinExec", "MemoryExec", "FilterExec", "MemoryExec"]
+    assert opt.children()[0].filter is jf
+
+
+def _walk(plan):
+    yield plan
+    for ch in plan.children():
+        yield from _walk(ch)
