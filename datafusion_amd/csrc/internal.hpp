@@ -131,6 +131,15 @@ inline bool is_integer_like(int t) {
 inline bool is_signed_type(int t) { return t == DFGPU_INT32 || t == DFGPU_INT64 || t == DFGPU_DATE32 || t == DFGPU_DECIMAL128; }
 std::string type_name(const dfgpu_field& f);
 
+// cached integer-column statistics (dfgpu_column_minmax): the device-table twin of the scan statistics the reference
+// keeps per column (ColumnStatistics min_value / max_value, common/src/stats.rs).  Shared by zero-copy views of the
+// same rows (select / hstack); tables are immutable, so the cache never goes stale.
+struct ColStats {
+  long long min = 0, max = 0;
+  int64_t valid = 0;
+  bool ascending = false;
+};
+
 struct Column {
   dfgpu_field field{};
   std::string name;
@@ -139,6 +148,7 @@ struct Column {
   BufPtr data;             // values (or bit-packed booleans), 64-bit word padded
   size_t data_offset = 0;  // byte offset of row 0 inside `data` (partition outputs share one buffer)
   BufPtr validity;         // optional bitmap, 64-bit word padded; nullptr = all valid
+  std::shared_ptr<ColStats> stats;  // filled lazily by dfgpu_column_minmax; never set on columns whose rows differ from the source
 
   const void* ptr() const { return data ? (const char*)data->ptr + data_offset : nullptr; }
   const uint64_t* valid_words() const { return validity ? validity->as<uint64_t>() : nullptr; }

@@ -1335,13 +1335,18 @@ int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int nu
 int dfgpu_column_minmax(dfgpu_table_t table, int column, int64_t* out_min, int64_t* out_max, int64_t* out_valid, int* out_ascending) {
   return guarded([&] {
     require_init();
-    const Table& t = *unwrap(table);
+    Table& t = *unwrap(table);
     DFGPU_CHECK(column >= 0 && column < (int)t.cols.size(), "column index out of range");
-    const Column& kc = t.cols[column];
+    Column& kc = t.cols[column];
     DFGPU_CHECK(is_integer_like(kc.field.type) && kc.field.type != DFGPU_UINT64, "dfgpu_column_minmax: integer columns only");
     Runtime& r = rt();
     MinMax res{INT64_MAX, INT64_MIN, 0, 0, 0};
-    if (t.nrows > 0) {
+    if (kc.stats) {  // computed before for these rows (tables are immutable)
+      res.smin = kc.stats->min;
+      res.smax = kc.stats->max;
+      res.valid = (unsigned long long)kc.stats->valid;
+      res.unsorted = kc.stats->ascending ? 0u : 1u;
+    } else if (t.nrows > 0) {
       KeyCol k{kc.ptr(), kc.valid_words(), kc.field.type, type_width(kc.field.type)};
       BufPtr mm = make_buf(sizeof(MinMax));
       h2d_async(mm->ptr, &res, sizeof res);
@@ -1356,6 +1361,7 @@ int dfgpu_column_minmax(dfgpu_table_t table, int column, int64_t* out_min, int64
         DFGPU_HIP(hipGetLastError());
       }
       d2h(&res, mm->ptr, sizeof res);
+      kc.stats = std::make_shared<ColStats>(ColStats{res.smin, res.smax, (int64_t)res.valid, res.valid > 0 && res.unsorted == 0});
     }
     if (out_min) *out_min = res.smin;
     if (out_max) *out_max = res.smax;

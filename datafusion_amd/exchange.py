@@ -296,7 +296,7 @@ def pruned_broadcast_table(build, build_key, probe, probe_key, group=None, force
         if sr is None:
             return build.slice(0, 0)
         if sr == my_range:
-            return build.slice(0, build.num_rows)               # the destination's bounds cover this whole shard: no filter pass
+            return build.select(list(range(build.num_columns)))  # the bounds cover this whole shard: a zero-copy view, no filter pass
         return ops.filter(build, (col(build_key) >= lit(sr[0], ktype)).and_(col(build_key) <= lit(sr[1], ktype)))
 
     if nothing_crosses_ranks(probe_ranges, build_ranges):
@@ -312,7 +312,7 @@ def pruned_broadcast_table(build, build_key, probe, probe_key, group=None, force
         stats.update(rows_sent_to_peers=sum(send_counts) - send_counts[rank], rows_received_from_peers=total - recv_counts[rank],
                      build_rows_local=build.num_rows, build_rows_after_exchange=total)
     nonempty = [p for p in parts if p.num_rows]
-    packed = nonempty[0].slice(0, nonempty[0].num_rows) if len(nonempty) == 1 else (DeviceTable.concat(parts) if nonempty else build.slice(0, 0))
+    packed = nonempty[0].select(list(range(nonempty[0].num_columns))) if len(nonempty) == 1 else (DeviceTable.concat(parts) if nonempty else build.slice(0, 0))
     ncols = build.num_columns
     views = [packed.column_view(i) for i in range(ncols)]
     fields = (Field * ncols)(*[v.field for v in views])
