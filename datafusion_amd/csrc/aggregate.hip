@@ -352,9 +352,10 @@ static BufPtr filled(int64_t n, unsigned long long v) {
   if (n) k_fill_u64<<<grid_for(n, BLOCK), BLOCK, 0, rt().stream>>>(v, n, b->as<unsigned long long>());
   return b;
 }
-static BufPtr grown(const BufPtr& old, int64_t old_n, int64_t new_n, unsigned long long fill, int elem = 8) {
+static BufPtr grown(const BufPtr& old, int64_t old_n, int64_t new_n, unsigned long long fill, int elem = 8, bool init = true) {
   BufPtr b;
-  if (elem == 8) b = filled(new_n, fill);
+  if (!init) b = make_buf((size_t)(new_n ? new_n : 1) * elem);  // the caller overwrites every element
+  else if (elem == 8) b = filled(new_n, fill);
   else b = make_zero_buf((size_t)(new_n ? new_n : 1) * elem);
   if (old && old_n) DFGPU_HIP(hipMemcpyAsync(b->ptr, old->ptr, (size_t)old_n * elem, hipMemcpyDeviceToDevice, rt().stream));
   return b;
@@ -847,15 +848,16 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
 }
 
 // grow every accumulator to G1 groups; returns the accumulation plan per aggregate
-static std::vector<AccPlan> grow_accumulators(Aggregate& A, int64_t G0, int64_t G1) {
+// init = false: the new cells are left uninitialised (a caller that writes all G1 of them itself)
+static std::vector<AccPlan> grow_accumulators(Aggregate& A, int64_t G0, int64_t G1, bool init = true) {
   std::vector<AccPlan> plans;
   const bool final_mode = A.final_mode();
   for (AggState& a : A.aggs) {
     AccPlan p = plan_for(a.func, a.in_type, final_mode);
-    a.lo = grown(a.lo, G0, G1, acc_identity(p.kind));
-    if (p.needs_hi) a.hi = grown(a.hi, G0, G1, 0ull);
-    a.seen = grown(a.seen, G0, G1, 0, 4);
-    if (a.func == DFGPU_AGG_AVG) a.cnt = grown(a.cnt, G0, G1, 0ull);
+    a.lo = grown(a.lo, G0, G1, acc_identity(p.kind), 8, init);
+    if (p.needs_hi) a.hi = grown(a.hi, G0, G1, 0ull, 8, init);
+    a.seen = grown(a.seen, G0, G1, 0, 4, init);
+    if (a.func == DFGPU_AGG_AVG) a.cnt = grown(a.cnt, G0, G1, 0ull, 8, init);
     plans.push_back(p);
   }
   return plans;
@@ -1540,7 +1542,7 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   if (G) k_mark_first_rows<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(first_row->as<uint32_t>(), G, rep_mask->as<unsigned long long>());
   scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, n, rprefix->as<uint64_t>());
   DFGPU_CHECK((int64_t)read_u64(rprefix->as<uint64_t>() + row_words) == G, "dense-key node: first-row marks do not match the group count");
-  grow_accumulators(A, 0, G);
+  grow_accumulators(A, 0, G, /*init=*/false);  // new_gid is a permutation of 0..G-1: k_dense_permute writes every cell
   DenseEmit e{};
   for (const Ent& en : entries) {
     AggState& a = A.aggs[(size_t)en.agg];
