@@ -102,3 +102,88 @@ def test_sort_fuzz(seed):
     fetch = None if rng.integers(0, 2) == 0 else int(rng.integers(0, max(1, n)))
     got = ops.sort(DeviceTable.from_arrow(t), keys, fetch).to_arrow()
     assert_tables_equal(got, oracle.sort(t, keys, fetch), ordered=True)    # both sides are stable: ties compare position by position
+
+
+# ------------------------------------------------------------------------------------ expressions
+def _gen_expr(rng, typ, depth):
+    """random well-typed PhysicalExpr of arrow type `typ` over the columns of EXPR_SPEC (the planner's coercions are
+    already applied: both operands of an arithmetic / comparison node have the same type)"""
+    from datafusion_amd.expr import col, lit
+    leaves = {"i32": ["i", "j"], "i64": ["k", "m"], "dec": ["d", "e"], "f64": ["f", "g"], "date": ["dt"]}
+    if typ == "bool":
+        kind = rng.integers(0, 6) if depth > 0 else 0
+        if kind <= 2:      # comparison of two same-typed values
+            t = str(rng.choice(["i32", "i64", "dec", "f64", "date"]))
+            a, b = _gen_expr(rng, t, depth - 1), _gen_expr(rng, t, depth - 1)
+            op = str(rng.choice(["=", "!=", "<", "<=", ">", ">="]))
+            return {"=": a.eq(b), "!=": a.ne(b), "<": a < b, "<=": a <= b, ">": a > b, ">=": a >= b}[op]
+        if kind == 3:
+            return _gen_expr(rng, "bool", depth - 1).and_(_gen_expr(rng, "bool", depth - 1))
+        if kind == 4:
+            return _gen_expr(rng, "bool", depth - 1).or_(_gen_expr(rng, "bool", depth - 1))
+        inner = _gen_expr(rng, str(rng.choice(["i32", "dec", "bool"])), depth - 1)
+        return inner.is_null() if typ != "bool" or rng.integers(0, 2) else (inner.not_() if _is_bool(inner) else inner.is_not_null())
+    if depth <= 0 or rng.integers(0, 3) == 0:
+        if typ != "date" and rng.integers(0, 4) == 0:
+            return {"i32": lambda: lit(int(rng.integers(-50, 50)), pa.int32()), "i64": lambda: lit(int(rng.integers(-10**6, 10**6))),
+                    "dec": lambda: lit(f"{int(rng.integers(-999, 999))}.{int(rng.integers(0, 100)):02d}", pa.decimal128(15, 2)),
+                    "f64": lambda: lit(float(rng.integers(-100, 100)) / 8.0)}[typ]()
+        return col(str(rng.choice(leaves[typ])))
+    if typ == "date":
+        return col("dt")
+    if typ == "i64" and rng.integers(0, 4) == 0:
+        return _gen_expr(rng, "i32", depth - 1).cast(pa.int64())
+    if typ == "f64" and rng.integers(0, 4) == 0:
+        return _gen_expr(rng, str(rng.choice(["i32", "i64"])), depth - 1).cast(pa.float64())
+    a, b = _gen_expr(rng, typ, depth - 1), _gen_expr(rng, typ, depth - 1)
+    op = str(rng.choice(["+", "-", "*"])) if typ != "dec" else str(rng.choice(["+", "-"]))   # decimal products: one level, below
+    return {"+": a + b, "-": a - b, "*": a * b}[op]
+
+
+def _is_bool(e):
+    from datafusion_amd.expr import BinaryExpr, IsNotNullExpr, IsNullExpr, NotExpr
+    return isinstance(e, (IsNullExpr, IsNotNullExpr, NotExpr)) or (isinstance(e, BinaryExpr) and e.op in ("=", "!=", "<", "<=", ">", ">=", "and", "or"))
+
+
+EXPR_SPEC = {"i": (pa.int32(), -1000, 1000), "j": (pa.int32(), -40000, 40000), "k": (pa.int64(), -10**9, 10**9), "m": (pa.int64(), -5, 5),
+             "d": (pa.decimal128(15, 2), -10**9, 10**9), "e": (pa.decimal128(15, 2), 0, 11), "f": (pa.float64(), -10**6, 10**6), "g": (pa.float64(), -3, 3),
+             "dt": (pa.date32(), 8000, 10000)}
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_expression_fuzz_projection_filter_and_fused_arguments(seed):
+    """random expression forests: ProjectionExec / FilterExec column-at-a-time and as aggregate arguments of the fused
+    node (register program, specialised HIP source) vs the oracle's evaluator — bit-exact, Float64 sums 1e-6"""
+    import os
+
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle as O
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.integers(1, 20_000))
+    t = random_table(rng, n, EXPR_SPEC, float(rng.choice([0.0, 0.15])))
+    dev = DeviceTable.from_arrow(t)
+    exprs = [(_gen_expr(rng, str(rng.choice(["i32", "i64", "dec", "f64", "bool"])), int(rng.integers(1, 4))), f"x{j}") for j in range(4)]
+    exprs.append((col("d") * (_gen_expr(rng, "dec", 1)), "prod"))                 # one decimal product (precision 31+)
+    got = ops.project(dev, exprs).to_arrow()
+    exp = O.project(t, [(to_oracle_expr(e), nm) for e, nm in exprs])
+    assert_tables_equal(got, exp, ordered=True)
+    pred = _gen_expr(rng, "bool", int(rng.integers(1, 4)))
+    assert_tables_equal(ops.filter(dev, pred).to_arrow(), O.filter(t, to_oracle_expr(pred), t.column_names), ordered=True)
+    # the same forest inside the fused aggregate node
+    numeric = [(e, nm) for e, nm in exprs if not _is_bool(e)]
+    aggs = [("sum", e, f"s_{nm}") for e, nm in numeric] + [("count", e, f"c_{nm}") for e, nm in exprs[:2] if not _is_bool(e)] + [("count", None, "n")]
+    src = O.filter(t, to_oracle_expr(pred), t.column_names)
+    want = oracle_agg(src, [], aggs, "Single")
+    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
+    try:
+        for env in ({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"}, {"DFGPU_JIT": "0"}):
+            os.environ.update(env)
+            assert_agg_equal(ops.aggregate(dev, [], aggs, "Single", predicate=pred).to_arrow(), want)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
