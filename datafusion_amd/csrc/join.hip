@@ -26,6 +26,8 @@
 //           output rows in probe order.  General M:N path: (build_idx, probe_idx) pairs, then
 //           arrow-`take`-style gathers (build_batch_from_indices, joins/utils.rs:1332-1386).
 // Output order = probe order, then chain order (unordered by contract for duplicates).
+#include <cstdlib>
+
 #include "device.hpp"
 #include "internal.hpp"
 
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_first(ProbeCtx c, int64_t np, i
         if (visited && m[j]) visited[m[j] - 1] = 1;
       }
       uint64_t word = ballot64(p < np && ((m[j] != 0) != (invert != 0)));
+      if (c.row_mask && w0 + j < n_words) word &= c.row_mask[w0 + j];  // filtered-out probe rows do not exist (anti joins included)
       if (lane_id() == 0 && w0 + j < n_words) mask[w0 + j] = word;
     }
   }
@@ -1060,19 +1063,23 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const bool use_fused = fused_ok && np > 0 && (jt.probe_mode == 2 || jt.probe_mode == 3);
   DFGPU_CHECK(!((jt.probe_mode == 2 || jt.probe_mode == 3) && !fused_ok),
               "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
+  // A probe-side row mask is applied in place by the at-most-one-match probes (single pass, or lookup -> scan ->
+  // materialise); the general pairs path needs the caller to filter first.
+  const bool one_match_path = np > 0 && (probe_side_only || fast_inner);
+  const bool use_fused_now = use_fused;
   if (row_mask) {
-    // only the single-pass probe applies a probe-side row mask in place; otherwise the caller filters first
     DFGPU_CHECK(mask_consumed != nullptr, "probe row mask without a fallback");
-    *mask_consumed = use_fused;
-    if (!use_fused) return Table{};
+    *mask_consumed = use_fused || one_match_path;
+    if (!*mask_consumed) return Table{};
+    ctx.row_mask = row_mask;
   }
-  if (use_fused) {
+  if (use_fused_now) {
     size_t free_b = 0, total_b = 0;
     DFGPU_HIP(hipMemGetInfo(&free_b, &total_b));
     DFGPU_CHECK(np * out_row_bytes <= (int64_t)free_b + r.cached, "single-pass probe: the np-row upper bound of the output does not fit in HBM");
   }
 
-  if (use_fused) {
+  if (use_fused_now) {
     const bool ordered = jt.probe_mode != 3;
     const int64_t tile_words = (int64_t)FUSED_W * (BLOCK / WAVE);
     const int64_t n_tiles = (n_words + tile_words - 1) / tile_words;
