@@ -65,7 +65,7 @@ class KernelStat(C.Structure):
 SYMBOLS = [
     "dfgpu_abi_version", "dfgpu_init", "dfgpu_shutdown", "dfgpu_device_count", "dfgpu_last_error", "dfgpu_sync",
     "dfgpu_stream", "dfgpu_mem_stats", "dfgpu_mem_trim", "dfgpu_table_import", "dfgpu_table_export",
-    "dfgpu_table_alloc", "dfgpu_table_free", "dfgpu_table_num_rows", "dfgpu_table_num_columns", "dfgpu_table_column",
+    "dfgpu_table_alloc", "dfgpu_table_dictionary_lookup", "dfgpu_table_free", "dfgpu_table_num_rows", "dfgpu_table_num_columns", "dfgpu_table_column",
     "dfgpu_table_select", "dfgpu_table_hstack", "dfgpu_table_concat", "dfgpu_table_slice", "dfgpu_expr_type",
     "dfgpu_filter", "dfgpu_project", "dfgpu_join_build", "dfgpu_join_probe", "dfgpu_join_probe_filtered", "dfgpu_join_probe_with_filter", "dfgpu_column_minmax", "dfgpu_join_emit_unmatched",
     "dfgpu_join_get_info", "dfgpu_join_free", "dfgpu_agg_create", "dfgpu_agg_update", "dfgpu_agg_update_filtered", "dfgpu_agg_fused_updates", "dfgpu_set_fusion", "dfgpu_jit_stats", "dfgpu_agg_emit",

@@ -791,6 +791,7 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
       const Column& ik = key_cols[g];
       DFGPU_CHECK(gk.field.type == ik.field.type, "group key type changed between batches");
       Column cc = alloc_column(gk.field, gk.name, total, gk.validity || ik.validity);
+      cc.dict = gk.dict ? gk.dict : ik.dict;
       int w = type_width(gk.field.type);
       DFGPU_HIP(hipMemcpyAsync(cc.data->ptr, gk.ptr(), (size_t)G0 * w, hipMemcpyDeviceToDevice, r.stream));
       if (n) DFGPU_HIP(hipMemcpyAsync((char*)cc.data->ptr + (size_t)G0 * w, ik.ptr(), (size_t)n * w, hipMemcpyDeviceToDevice, r.stream));
@@ -902,6 +903,7 @@ static void small_rebuild_group_keys(Aggregate& A, const Table& in, const std::v
   gk.nrows = G1;
   for (int g = 0; g < ngk; g++) {
     Column c = alloc_column(in.cols[small_cols[g]].field, A.group_names[g], G1);
+    c.dict = in.cols[small_cols[g]].dict;
     std::vector<uint8_t> b((size_t)(G1 ? G1 : 1));
     for (int64_t i = 0; i < G1; i++) b[(size_t)i] = (uint8_t)(A.small_keys[(size_t)i] >> (8 * g));
     if (G1) h2d_async(c.data->ptr, b.data(), (size_t)G1);
@@ -1571,6 +1573,10 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
     DFGPU_HIP(hipGetLastError());
   }
   Column kc = alloc_column(kf, A.group_names[0], G);
+  {
+    int key_col = -1;
+    if (is_plain_column(A.group_nodes[0], A.group_roots[0], &key_col) && key_col >= 0 && key_col < (int)in.cols.size()) kc.dict = in.cols[key_col].dict;
+  }
   if (G) {
     int mode = 0;
     if (kf.type == DFGPU_INT32 || kf.type == DFGPU_DATE32 || kf.type == DFGPU_UINT32) mode = 3;
@@ -1926,6 +1932,7 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
     gk.nrows = G1;
     for (int g = 0; g < ngk; g++) {
       Column c = alloc_column(in.cols[small_cols[g]].field, A.group_names[g], G1);
+      c.dict = in.cols[small_cols[g]].dict;
       std::vector<uint8_t> b((size_t)(G1 ? G1 : 1));
       for (int64_t i = 0; i < G1; i++) b[(size_t)i] = (uint8_t)(A.small_keys[(size_t)i] >> (8 * g));
       if (G1) h2d_async(c.data->ptr, b.data(), (size_t)G1);

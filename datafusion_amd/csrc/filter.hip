@@ -137,7 +137,7 @@ Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_
     DFGPU_CHECK(cols[i] >= 0 && cols[i] < (int)in.cols.size(), "projection index out of range");
     const Column& c = in.cols[cols[i]];
     DFGPU_CHECK(c.field.type != DFGPU_BOOL, "filter: Boolean payload columns are not supported on the GPU path yet");
-    out.cols.push_back(alloc_column(c.field, c.name, n_out));
+    out.cols.push_back(alloc_like(c, n_out));
     if (c.validity) valid_bytes[i] = make_buf((size_t)n_out + 64);
   }
   if (n_out > 0) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(const T* __restrict__ src, con
 Column gather_column(const Column& in, const int64_t* idx, int64_t n, bool idx_may_be_null) {
   Runtime& r = rt();
   DFGPU_CHECK(in.field.type != DFGPU_BOOL, "take: Boolean columns are not supported on the GPU path yet");
-  Column out = alloc_column(in.field, in.name, n);
+  Column out = alloc_like(in, n);
   if (n == 0) return out;
   bool need_valid = idx_may_be_null || in.validity;
   BufPtr vb = need_valid ? make_buf((size_t)n + 64) : nullptr;
@@ -240,7 +240,7 @@ extern "C" int dfgpu_filter(dfgpu_table_t input, const dfgpu_expr* predicate, co
         for (int c : cols) o->cols.push_back(t->cols[c]);
       } else {
         o->nrows = 0;
-        for (int c : cols) o->cols.push_back(alloc_column(t->cols[c].field, t->cols[c].name, 0));
+        for (int c : cols) o->cols.push_back(alloc_like(t->cols[c], 0));
       }
     } else {
       *o = compact_table(*t, cols, d.col.data->as<uint64_t>(), d.col.valid_words());

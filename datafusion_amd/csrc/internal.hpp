@@ -140,6 +140,19 @@ struct ColStats {
   bool ascending = false;
 };
 
+// Values of a dictionary-encoded column (Arrow Dictionary(index type, Utf8 | LargeUtf8)): the device column holds the
+// indices as a plain integer column — every kernel treats them as integers — and the strings stay on the host,
+// attached to the column and handed on to columns derived from it by selecting / reordering rows (filter, take, join
+// payload, group keys, partitions).  This is how TPC-H's low-cardinality string columns (l_returnflag, c_mktsegment ...)
+// cross the boundary (the dictionary part: group_values/multi_group_by/dictionary.rs).
+struct DictValues {
+  std::string index_format;         // Arrow format of the indices as imported ("C", "i", "I", "l", "L")
+  std::string value_format;         // "u" (Utf8) or "U" (LargeUtf8)
+  std::vector<std::string> values;
+  std::vector<uint8_t> valid;       // per value: 1 = not NULL
+  bool sorted = false;              // values strictly ascending: index order == string order
+};
+
 struct Column {
   dfgpu_field field{};
   std::string name;
@@ -149,6 +162,7 @@ struct Column {
   size_t data_offset = 0;  // byte offset of row 0 inside `data` (partition outputs share one buffer)
   BufPtr validity;         // optional bitmap, 64-bit word padded; nullptr = all valid
   std::shared_ptr<ColStats> stats;  // filled lazily by dfgpu_column_minmax; never set on columns whose rows differ from the source
+  std::shared_ptr<const DictValues> dict;  // dictionary-encoded strings: `data` holds the indices
 
   const void* ptr() const { return data ? (const char*)data->ptr + data_offset : nullptr; }
   const uint64_t* valid_words() const { return validity ? validity->as<uint64_t>() : nullptr; }
@@ -167,6 +181,12 @@ inline Table* unwrap(dfgpu_table_t t) {
 inline dfgpu_table_t wrap(Table* t) { return reinterpret_cast<dfgpu_table_t>(t); }
 
 Column alloc_column(const dfgpu_field& f, const std::string& name, int64_t n, bool with_validity = false);
+// a fresh column for rows taken from `src` (same type and name, dictionary handed on)
+inline Column alloc_like(const Column& src, int64_t n, bool with_validity = false) {
+  Column c = alloc_column(src.field, src.name, n, with_validity);
+  c.dict = src.dict;
+  return c;
+}
 
 // ----------------------------------------------------------------- primitives (scan.hip)
 // exclusive prefix sum of popcount(mask_word & valid_word) per 64-row word -> u64 offsets

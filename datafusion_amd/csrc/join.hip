@@ -1089,7 +1089,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     int64_t bytes_in = key_bytes, bytes_per_out = 0;
     for (int c : bout) {
       const Column& sc = jt.build.cols[c];
-      out.cols.push_back(alloc_column(sc.field, sc.name, np));
+      out.cols.push_back(alloc_like(sc, np));
       jc.src[jc.n] = sc.ptr();
       jc.dst[jc.n] = out.cols.back().data->ptr;
       jc.width[jc.n] = type_width(sc.field.type);
@@ -1099,7 +1099,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     jc.n_build = jc.n;
     for (int c : pout) {
       const Column& sc = probe.cols[c];
-      out.cols.push_back(alloc_column(sc.field, sc.name, np));
+      out.cols.push_back(alloc_like(sc, np));
       jc.src[jc.n] = sc.ptr();
       jc.dst[jc.n] = out.cols.back().data->ptr;
       jc.width[jc.n] = type_width(sc.field.type);
@@ -1153,7 +1153,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       out = compact_table(probe, pout, mask->as<uint64_t>(), nullptr);
     } else if (build_side_only) {
       out.nrows = 0;  // emitted by dfgpu_join_emit_unmatched
-      for (int c : bout) out.cols.push_back(alloc_column(jt.build.cols[c].field, jt.build.cols[c].name, 0));
+      for (int c : bout) out.cols.push_back(alloc_like(jt.build.cols[c], 0));
     } else {
       BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
       scan_mask_popcounts(mask->as<uint64_t>(), nullptr, np, prefix->as<uint64_t>());
@@ -1165,7 +1165,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       int64_t bytes = 0;
       for (int c : bout) {
         const Column& sc = jt.build.cols[c];
-        out.cols.push_back(alloc_column(sc.field, sc.name, n_out));
+        out.cols.push_back(alloc_like(sc, n_out));
         jc.src[jc.n] = sc.ptr();
         jc.dst[jc.n] = out.cols.back().data->ptr;
         jc.width[jc.n] = type_width(sc.field.type);
@@ -1175,7 +1175,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       jc.n_build = jc.n;
       for (int c : pout) {
         const Column& sc = probe.cols[c];
-        out.cols.push_back(alloc_column(sc.field, sc.name, n_out));
+        out.cols.push_back(alloc_like(sc, n_out));
         jc.src[jc.n] = sc.ptr();
         jc.dst[jc.n] = out.cols.back().data->ptr;
         jc.width[jc.n] = type_width(sc.field.type);
@@ -1315,7 +1315,7 @@ static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std
   } else {
     // LeftSemi / LeftAnti / LeftMark: emitted from the visited bits by dfgpu_join_emit_unmatched
     out.nrows = 0;
-    for (int c : bout) out.cols.push_back(alloc_column(jt.build.cols[c].field, jt.build.cols[c].name, 0));
+    for (int c : bout) out.cols.push_back(alloc_like(jt.build.cols[c], 0));
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));
   jt.info.output_rows += out.nrows;

@@ -227,7 +227,7 @@ static std::vector<Table> partition_table(const Table& in, const std::vector<int
   if (n == 0) {
     for (auto& o : outs) {
       o.nrows = 0;
-      for (auto& c : in.cols) o.cols.push_back(alloc_column(c.field, c.name, 0));
+      for (auto& c : in.cols) o.cols.push_back(alloc_like(c, 0));
     }
     return outs;
   }
@@ -257,7 +257,7 @@ static std::vector<Table> partition_table(const Table& in, const std::vector<int
   for (auto& c : in.cols) simple &= !c.validity && c.field.type != DFGPU_BOOL;
   if (simple) {
     std::vector<Column> whole;
-    for (auto& c : in.cols) whole.push_back(alloc_column(c.field, c.name, n));
+    for (auto& c : in.cols) whole.push_back(alloc_like(c, n));
     for (size_t c0 = 0; c0 < in.cols.size(); c0 += PART_MAX_COLS) {
       PartCols pc{};
       int64_t bytes = n;

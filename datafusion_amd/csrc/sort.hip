@@ -417,6 +417,7 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     DFGPU_CHECK(key_cols[k] >= 0 && key_cols[k] < (int)in.cols.size(), "sort key column out of range");
     const Column& c = in.cols[key_cols[k]];
     DFGPU_CHECK(c.field.type != DFGPU_BOOL, "Boolean sort keys are not supported on the GPU path");
+    DFGPU_CHECK(!c.dict || c.dict->sorted, "ORDER BY on a dictionary-encoded string column needs a dictionary in ascending order (index order must be string order)");
     pc.c[k] = PackCol{c.ptr(), c.valid_words(), c.field.type, desc[k] != 0, nulls_first[k] != 0, c.validity != nullptr, 0, 0, 0, 0};
     key_col_bytes += n * (c.field.type == DFGPU_UINT8 ? 1 : type_width(c.field.type));
   }
@@ -425,7 +426,7 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
   Table out;
   out.nrows = n_out;
   if (n_out == 0) {
-    for (auto& c : in.cols) out.cols.push_back(alloc_column(c.field, c.name, 0));
+    for (auto& c : in.cols) out.cols.push_back(alloc_like(c, 0));
     return out;
   }
   // ---- value ranges -> field widths and positions (last key column = least significant)

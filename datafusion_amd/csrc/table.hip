@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 
 namespace dfgpu {
 
@@ -99,10 +100,44 @@ static uint64_t* shift_bitmap(const uint8_t* src, int64_t offset, int64_t n) {
   return out;
 }
 
+// strings of a Utf8 / LargeUtf8 dictionary (host side)
+static std::shared_ptr<const DictValues> import_dictionary(const ArrowArray* d, const ArrowSchema* ds, const char* index_format, const char* col_name) {
+  const std::string vf(ds->format);
+  DFGPU_CHECK(vf == "u" || vf == "U", std::string("dictionary column '") + col_name + "': only Utf8 / LargeUtf8 values are supported, got '" + vf + "'");
+  const std::string xf(index_format);
+  DFGPU_CHECK(xf == "C" || xf == "i" || xf == "I" || xf == "l" || xf == "L",
+              std::string("dictionary column '") + col_name + "': index type '" + xf + "' has no device type (cast the indices to UInt8 / Int32)");
+  DFGPU_CHECK(d && d->n_buffers == 3, "malformed dictionary array");
+  auto dv = std::make_shared<DictValues>();
+  dv->index_format = xf;
+  dv->value_format = vf;
+  const uint8_t* validity = (const uint8_t*)d->buffers[0];
+  const char* data = (const char*)d->buffers[2];
+  bool sorted = true;
+  std::map<std::string, int> seen;
+  for (int64_t i = 0; i < d->length; i++) {
+    const int64_t k = d->offset + i;
+    int64_t b, e;
+    if (vf == "u") { b = ((const int32_t*)d->buffers[1])[k]; e = ((const int32_t*)d->buffers[1])[k + 1]; }
+    else { b = ((const int64_t*)d->buffers[1])[k]; e = ((const int64_t*)d->buffers[1])[k + 1]; }
+    const bool ok = !validity || ((validity[k >> 3] >> (k & 7)) & 1);
+    dv->values.emplace_back(ok && data ? std::string(data + b, (size_t)(e - b)) : std::string());
+    dv->valid.push_back(ok ? 1 : 0);
+    if (ok) {
+      // grouping / joining on the indices is grouping on the strings only if every string has ONE index
+      DFGPU_CHECK(seen.emplace(dv->values.back(), 1).second, std::string("dictionary column '") + col_name + "': duplicate dictionary value '" + dv->values.back() + "'");
+    }
+    if (i > 0 && !(dv->values[(size_t)i - 1] < dv->values[(size_t)i])) sorted = false;
+    if (!ok) sorted = false;
+  }
+  dv->sorted = sorted;
+  return dv;
+}
+
 static Column import_column(const ArrowArray* a, const ArrowSchema* s, int64_t parent_offset, int64_t nrows, Uploader& up) {
-  DFGPU_CHECK(s->dictionary == nullptr, std::string("dictionary-encoded column '") + (s->name ? s->name : "") + "' is not supported on the GPU path");
   Column c;
   c.field = parse_format(s->format, (s->flags & 2) != 0);
+  if (s->dictionary) c.dict = import_dictionary(a->dictionary, s->dictionary, s->format, s->name ? s->name : "");
   c.name = s->name ? s->name : "";
   c.length = nrows;
   DFGPU_CHECK(a->n_buffers == 2, "expected 2 buffers for a fixed-width column");
@@ -143,6 +178,7 @@ struct ExportPrivate {
   std::vector<void*> host_buffers;
   std::vector<const void*> buffer_ptrs;
   std::vector<ArrowArray*> children;
+  ArrowArray* dictionary = nullptr;
 };
 static void release_array(ArrowArray* a) {
   if (!a || !a->release) return;
@@ -151,6 +187,10 @@ static void release_array(ArrowArray* a) {
     if (c->release) c->release(c);
     delete c;
   }
+  if (p->dictionary) {
+    if (p->dictionary->release) p->dictionary->release(p->dictionary);
+    delete p->dictionary;
+  }
   for (void* b : p->host_buffers) std::free(b);
   delete p;
   a->release = nullptr;
@@ -158,6 +198,7 @@ static void release_array(ArrowArray* a) {
 struct SchemaPrivate {
   std::string format, name;
   std::vector<ArrowSchema*> children;
+  ArrowSchema* dictionary = nullptr;
 };
 static void release_schema(ArrowSchema* s) {
   if (!s || !s->release) return;
@@ -166,17 +207,57 @@ static void release_schema(ArrowSchema* s) {
     if (c->release) c->release(c);
     delete c;
   }
+  if (p->dictionary) {
+    if (p->dictionary->release) p->dictionary->release(p->dictionary);
+    delete p->dictionary;
+  }
   delete p;
   s->release = nullptr;
 }
 static void fill_schema(ArrowSchema* s, const std::string& fmt, const std::string& name, bool nullable) {
-  auto* p = new SchemaPrivate{fmt, name, {}};
+  auto* p = new SchemaPrivate{fmt, name, {}, nullptr};
   std::memset(s, 0, sizeof(*s));
   s->format = p->format.c_str();
   s->name = p->name.c_str();
   s->flags = nullable ? 2 : 0;
   s->release = release_schema;
   s->private_data = p;
+}
+
+// the dictionary values as a Utf8 / LargeUtf8 array the consumer owns (host copies of the strings)
+static ArrowArray* export_dictionary(const DictValues& dv) {
+  auto* a = new ArrowArray();
+  std::memset(a, 0, sizeof(*a));
+  auto* p = new ExportPrivate();
+  const size_t n = dv.values.size();
+  const bool large = dv.value_format == "U";
+  size_t total = 0;
+  for (const std::string& v : dv.values) total += v.size();
+  void* offs = std::malloc((n + 1) * (large ? 8 : 4));
+  char* data = (char*)std::malloc(total ? total : 8);
+  uint8_t* vbits = nullptr;
+  int64_t nulls = 0;
+  for (size_t i = 0; i < n; i++) nulls += dv.valid[i] ? 0 : 1;
+  if (nulls) vbits = (uint8_t*)std::calloc((n + 7) / 8 + 8, 1);
+  size_t pos = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (large) ((int64_t*)offs)[i] = (int64_t)pos; else ((int32_t*)offs)[i] = (int32_t)pos;
+    std::memcpy(data + pos, dv.values[i].data(), dv.values[i].size());
+    pos += dv.values[i].size();
+    if (vbits && dv.valid[i]) vbits[i >> 3] |= (uint8_t)(1u << (i & 7));
+  }
+  if (large) ((int64_t*)offs)[n] = (int64_t)pos; else ((int32_t*)offs)[n] = (int32_t)pos;
+  if (vbits) p->host_buffers.push_back(vbits);
+  p->host_buffers.push_back(offs);
+  p->host_buffers.push_back(data);
+  p->buffer_ptrs = {vbits, offs, data};
+  a->length = (int64_t)n;
+  a->null_count = nulls;
+  a->n_buffers = 3;
+  a->buffers = p->buffer_ptrs.data();
+  a->release = release_array;
+  a->private_data = p;
+  return a;
 }
 
 }  // namespace dfgpu
@@ -239,7 +320,15 @@ int dfgpu_table_export(dfgpu_table_t th, struct ArrowArray* out_array, struct Ar
       ca->private_data = cp;
       ap->children.push_back(ca);
       auto* cs = new ArrowSchema();
-      fill_schema(cs, format_of(c.field), c.name, true);
+      fill_schema(cs, c.dict ? c.dict->index_format : format_of(c.field), c.name, true);
+      if (c.dict) {  // dictionary-encoded strings: indices from the device, values from the host
+        cp->dictionary = export_dictionary(*c.dict);
+        ca->dictionary = cp->dictionary;
+        auto* ds = new ArrowSchema();
+        fill_schema(ds, c.dict->value_format, "", true);
+        ((SchemaPrivate*)cs->private_data)->dictionary = ds;
+        cs->dictionary = ds;
+      }
       sp->children.push_back(cs);
     }
     std::memset(out_array, 0, sizeof(*out_array));
@@ -253,6 +342,22 @@ int dfgpu_table_export(dfgpu_table_t th, struct ArrowArray* out_array, struct Ar
     out_array->private_data = ap;
     out_schema->n_children = (int64_t)sp->children.size();
     out_schema->children = sp->children.data();
+  });
+}
+
+int dfgpu_table_dictionary_lookup(dfgpu_table_t th, int column, const char* utf8, int64_t len, int64_t* out_code) {
+  return guarded([&] {
+    Table* t = unwrap(th);
+    DFGPU_CHECK(column >= 0 && column < (int)t->cols.size() && utf8 && out_code, "bad argument");
+    const Column& c = t->cols[column];
+    DFGPU_CHECK(c.dict != nullptr, "column '" + c.name + "' is not dictionary-encoded");
+    const std::string want(utf8, (size_t)len);
+    *out_code = -1;
+    for (size_t i = 0; i < c.dict->values.size(); i++)
+      if (c.dict->valid[i] && c.dict->values[i] == want) {
+        *out_code = (int64_t)i;
+        break;
+      }
   });
 }
 
@@ -320,7 +425,7 @@ int dfgpu_table_slice(dfgpu_table_t th, int64_t offset, int64_t length, dfgpu_ta
     o->nrows = length;
     for (auto& c : t->cols) {
       DFGPU_CHECK(c.field.type != DFGPU_BOOL && !c.validity, "slice: Boolean / nullable columns not supported yet");
-      Column n = alloc_column(c.field, c.name, length);
+      Column n = alloc_like(c, length);
       int w = type_width(c.field.type);
       if (length)
         DFGPU_HIP(hipMemcpyAsync(n.data->ptr, (const char*)c.ptr() + (size_t)offset * w, (size_t)length * w, hipMemcpyDeviceToDevice, rt().stream));
@@ -345,7 +450,7 @@ int dfgpu_table_concat(const dfgpu_table_t* parts, int nparts, dfgpu_table_t* ou
     o->nrows = total;
     for (size_t ci = 0; ci < first->cols.size(); ci++) {
       const Column& fc = first->cols[ci];
-      Column n = alloc_column(fc.field, fc.name, total);
+      Column n = alloc_like(fc, total);
       DFGPU_CHECK(fc.field.type != DFGPU_BOOL, "concat: Boolean columns not supported yet");
       int w = type_width(fc.field.type);
       int64_t off = 0;
@@ -353,6 +458,8 @@ int dfgpu_table_concat(const dfgpu_table_t* parts, int nparts, dfgpu_table_t* ou
         Table* t = unwrap(parts[p]);
         const Column& c = t->cols[ci];
         DFGPU_CHECK(c.field.type == fc.field.type, "concat: column type mismatch");
+        DFGPU_CHECK(c.dict == fc.dict || (c.dict && fc.dict && c.dict->values == fc.dict->values && c.dict->valid == fc.dict->valid),
+                    "concat: the parts' dictionaries differ");
         DFGPU_CHECK(!c.validity, "concat: nullable columns not supported yet");
         if (t->nrows)
           DFGPU_HIP(hipMemcpyAsync((char*)n.data->ptr + (size_t)off * w, c.ptr(), (size_t)t->nrows * w, hipMemcpyDeviceToDevice, rt().stream));

@@ -135,6 +135,14 @@ class DeviceTable:
             raise KeyError(f"column {name_or_index!r} not found or ambiguous in {names}")
         return names.index(name_or_index)
 
+    def dictionary_code(self, column, value: str):
+        """index of `value` in a dictionary-encoded string column's dictionary, None if absent — what
+        `col = 'value'` is lowered to (dfgpu_table_dictionary_lookup)"""
+        b = value.encode()
+        code = C.c_int64()
+        check(_lib.load().dfgpu_table_dictionary_lookup(self.handle, self.index_of(column), b, C.c_int64(len(b)), C.byref(code)))
+        return None if code.value < 0 else code.value
+
     def nbytes(self) -> int:
         total = 0
         for i in range(self.num_columns):

@@ -146,6 +146,15 @@ int dfgpu_table_import(struct ArrowArray* array, struct ArrowSchema* schema, dfg
 /* Export to host memory as a struct array + schema owned by the caller (release
  * callbacks set).  Replaces: the RecordBatch items a SendableRecordBatchStream yields. */
 int dfgpu_table_export(dfgpu_table_t t, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+/* Dictionary-encoded string columns (Arrow Dictionary(UInt8 | Int32 | UInt32 | Int64 | UInt64, Utf8 | LargeUtf8)) are
+ * imported as their index column; the dictionary stays on the host, is handed on to every column derived from it by
+ * selecting or reordering rows (filter, take, join payload, group keys, partitions, sort output) and re-attached on
+ * export.  Dictionary values must be unique (grouping / joining on indices must mean grouping / joining on strings);
+ * ORDER BY on such a column needs a sorted dictionary.  `col = 'literal'` is lowered by the caller to a comparison with
+ * the literal's index: this returns it (-1 = the string is not in the dictionary, the predicate is constant false).
+ * Reference: group_values/multi_group_by/dictionary.rs, hash_utils.rs:401-640 (the dictionary part). */
+int dfgpu_table_dictionary_lookup(dfgpu_table_t table, int column, const char* utf8, int64_t len, int64_t* out_code);
+
 /* allocate a table of uninitialised device columns (filled by generators / exchange) */
 int dfgpu_table_alloc(int ncols, const dfgpu_field* fields, const char* const* names, int64_t nrows, dfgpu_table_t* out);
 int dfgpu_table_free(dfgpu_table_t t);

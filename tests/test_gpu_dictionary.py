@@ -1,0 +1,100 @@
+"""Dictionary-encoded string columns (Arrow Dictionary(index, Utf8)) through the boundary: indices on the device,
+dictionary on the host, handed on by every operator that selects or reorders rows, re-attached on export
+(include/dfgpu.h dfgpu_table_dictionary_lookup; reference: group_values/multi_group_by/dictionary.rs)."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+from tests.util import assert_tables_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def dict_col(codes, values, index_type=pa.int32(), mask=None):
+    return pa.DictionaryArray.from_arrays(pa.array(codes, type=index_type, mask=mask), pa.array(values, type=pa.string()))
+
+
+def decoded(t: pa.Table) -> pa.Table:
+    """dictionary columns -> plain strings (comparison form)"""
+    return pa.table({n: (c.cast(pa.string()) if pa.types.is_dictionary(c.type) else c) for n, c in zip(t.column_names, t.columns)})
+
+
+def test_import_export_round_trip_with_nulls_and_both_index_widths():
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(1)
+    n = 10_001
+    seg = dict_col(rng.integers(0, 5, n), ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"], mask=rng.random(n) < 0.1)
+    flag = dict_col(rng.integers(0, 3, n).astype(np.uint8), ["A", "N", "R"], pa.uint8())
+    t = pa.table({"seg": seg, "flag": flag, "v": pa.array(rng.integers(0, 100, n), type=pa.int64())})
+    back = DeviceTable.from_arrow(t).to_arrow()
+    assert pa.types.is_dictionary(back.schema.field("seg").type) and back.schema.field("flag").type.index_type == pa.uint8()
+    assert_tables_equal(decoded(back), decoded(t), ordered=True)
+    assert_tables_equal(decoded(DeviceTable.from_arrow(t.slice(17, 4000)).to_arrow()), decoded(t.slice(17, 4000)), ordered=True)   # non-zero offset
+
+
+def test_q1_with_string_flag_columns():
+    """TPC-H Q1 with l_returnflag / l_linestatus as strings, the reference's schema (benchmarks/src/tpch/mod.rs:93-122)"""
+    from datafusion_amd import queries, tpch
+    from datafusion_amd.table import DeviceTable
+    from tests.test_gpu_queries import oracle_q1
+    li = tpch.lineitem(0.05)
+
+    def as_strings(col):
+        codes = col.to_numpy()
+        vals = sorted(set(int(x) for x in codes))                      # ascending dictionary: ORDER BY on the column stays valid
+        return dict_col(np.searchsorted(vals, codes).astype(np.uint8), [chr(v) for v in vals], pa.uint8())
+    names = li.column_names
+    t = pa.table({n: (as_strings(li.column(n)) if n in ("l_returnflag", "l_linestatus") else li.column(n)) for n in names})
+    got = queries.q1(DeviceTable.from_arrow(t)).to_arrow()
+    assert pa.types.is_dictionary(got.schema.field("l_returnflag").type)
+    exp = oracle_q1(li)
+    exp = exp.set_column(0, "l_returnflag", pa.array([chr(v) for v in exp.column("l_returnflag").to_pylist()])) \
+             .set_column(1, "l_linestatus", pa.array([chr(v) for v in exp.column("l_linestatus").to_pylist()]))
+    assert_tables_equal(decoded(got), exp, ordered=True)
+
+
+def test_filter_on_a_dictionary_code_join_payload_group_key_sort_and_partition():
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(5)
+    segs = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"]
+    nc, no = 3000, 20_000
+    cust = pa.table({"c_custkey": pa.array(np.arange(nc), type=pa.int64()), "c_mktsegment": dict_col(rng.integers(0, 5, nc), segs)})
+    orders = pa.table({"o_custkey": pa.array(rng.integers(0, nc, no), type=pa.int64()), "o_total": pa.array(rng.integers(1, 1000, no), type=pa.int64())})
+    dc, do = DeviceTable.from_arrow(cust), DeviceTable.from_arrow(orders)
+    # FilterExec: c_mktsegment = 'BUILDING' lowered to the literal's dictionary index
+    code = dc.dictionary_code("c_mktsegment", "BUILDING")
+    assert code == 1 and dc.dictionary_code("c_mktsegment", "nope") is None
+    f = ops.filter(dc, col("c_mktsegment").eq(lit(code, pa.int32()))).to_arrow()
+    assert_tables_equal(decoded(f), decoded(cust.filter(pc.equal(cust.column("c_mktsegment").cast(pa.string()), "BUILDING"))), ordered=True)
+    # HashJoinExec with the string column as build-side payload, then AggregateExec grouped by it
+    j = ops.hash_join(dc, do, [("c_custkey", "o_custkey")], "Inner")
+    ja = j.to_arrow()
+    assert pa.types.is_dictionary(ja.schema.field("c_mktsegment").type) and ja.num_rows == no
+    want_seg = cust.column("c_mktsegment").cast(pa.string()).take(ja.column("o_custkey"))
+    assert ja.column("c_mktsegment").cast(pa.string()).to_pylist() == want_seg.to_pylist()
+    g = ops.aggregate(j, [(col("c_mktsegment"), "seg")], [("sum", col("o_total"), "s"), ("count", None, "n")], "Single").to_arrow()
+    ref = decoded(ja).group_by("c_mktsegment").aggregate([("o_total", "sum"), ("o_total", "count")])
+    assert sorted(zip(g.column("seg").cast(pa.string()).to_pylist(), g.column("s").to_pylist(), g.column("n").to_pylist())) == \
+        sorted(zip(ref.column("c_mktsegment").to_pylist(), ref.column("o_total_sum").to_pylist(), ref.column("o_total_count").to_pylist()))
+    # SortExec on another key keeps the payload's dictionary; ORDER BY the string column itself works because this dictionary is sorted
+    s = ops.sort(dc, [("c_mktsegment", False, False), ("c_custkey", True, False)]).to_arrow()
+    d = decoded(cust)
+    order = pc.sort_indices(d, sort_keys=[("c_mktsegment", "ascending"), ("c_custkey", "descending")])
+    assert_tables_equal(decoded(s), d.take(order), ordered=True)
+    parts = ops.partition(dc, ["c_custkey"], 3)
+    assert sum(p.num_rows for p in parts) == nc and all(pa.types.is_dictionary(p.to_arrow().schema.field("c_mktsegment").type) for p in parts)
+
+
+def test_rejected_dictionaries():
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.table import DeviceTable
+    dup = pa.table({"s": dict_col([0, 1, 2], ["a", "b", "a"])})
+    with pytest.raises(_lib.DfgpuError, match="duplicate dictionary value"):
+        DeviceTable.from_arrow(dup)
+    unsorted = DeviceTable.from_arrow(pa.table({"s": dict_col([0, 1, 2, 1], ["b", "a", "c"]), "v": pa.array([1, 2, 3, 4], type=pa.int64())}))
+    with pytest.raises(_lib.DfgpuError, match="dictionary in ascending order"):
+        ops.sort(unsorted, [("s", False, False)])
+    assert ops.sort(unsorted, [("v", True, False)]).to_arrow().column("s").cast(pa.string()).to_pylist() == ["a", "c", "a", "b"]
