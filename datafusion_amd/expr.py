@@ -152,8 +152,49 @@ class LoweredExpr:
         self.c = Expr(C.cast(self.nodes, C.POINTER(ExprNode)), len(nodes), len(nodes) - 1)
 
 
-def lower(expr: PhysicalExpr, column_names) -> LoweredExpr:
-    """post-order flattening; the root is the last node"""
+def bind_string_literals(expr: PhysicalExpr, table) -> PhysicalExpr:
+    """`dict_col = 'literal'` / `!=` on a dictionary-encoded string column -> comparison of the indices with the
+    literal's dictionary index (DeviceTable.dictionary_code).  A string that is not in the dictionary is compared as
+    index -1, which no row holds: `=` is then false and `!=` true for every non-NULL row, NULL rows stay NULL — SQL's answer.
+    Ordering comparisons on strings are not translated (they would compare indices)."""
+    if isinstance(expr, BinaryExpr):
+        if expr.op in ("=", "!="):
+            for a, b in ((expr.left, expr.right), (expr.right, expr.left)):
+                if isinstance(a, Column) and isinstance(b, Literal) and (pa.types.is_string(b.type) or pa.types.is_large_string(b.type)):
+                    idx = table.index_of(a.name if a.index is None else a.index)
+                    itype = table.schema.field(idx).type
+                    column = Column(a.name, idx)
+                    if b.value is None:
+                        return BinaryExpr(column, expr.op, Literal(None, itype))
+                    code = table.dictionary_code(idx, b.value)
+                    if code is not None:
+                        return BinaryExpr(column, expr.op, Literal(code, itype))
+                    # not in the dictionary: compare the (widened) index with -1, which no row holds
+                    wide = column if itype == pa.int64() else CastExpr(column, pa.int64())
+                    return BinaryExpr(wide, expr.op, Literal(-1, pa.int64()))
+        return BinaryExpr(bind_string_literals(expr.left, table), expr.op, bind_string_literals(expr.right, table))
+    if isinstance(expr, CastExpr):
+        return CastExpr(bind_string_literals(expr.expr, table), expr.cast_type)
+    if isinstance(expr, IsNullExpr):
+        return IsNullExpr(bind_string_literals(expr.arg, table))
+    if isinstance(expr, IsNotNullExpr):
+        return IsNotNullExpr(bind_string_literals(expr.arg, table))
+    if isinstance(expr, NotExpr):
+        return NotExpr(bind_string_literals(expr.arg, table))
+    return expr
+
+
+def _has_string_literal(expr) -> bool:
+    if isinstance(expr, Literal):
+        return pa.types.is_string(expr.type) or pa.types.is_large_string(expr.type)
+    return any(_has_string_literal(c) for c in expr.children())
+
+
+def lower(expr: PhysicalExpr, column_names, table=None) -> LoweredExpr:
+    """post-order flattening; the root is the last node.  With `table`, string literals compared with dictionary-encoded
+    columns are bound to dictionary indices first (bind_string_literals)."""
+    if table is not None and _has_string_literal(expr):
+        expr = bind_string_literals(expr, table)
     nodes: list[ExprNode] = []
     names = list(column_names)
 

@@ -30,7 +30,7 @@ def filter(table: DeviceTable, predicate: PhysicalExpr, projection=None) -> Devi
     """FilterExec: predicate + optional embedded projection (filter.rs:85)"""
     lib = _lib.init()
     names = table.column_names
-    le = lower(predicate, names)
+    le = lower(predicate, names, table)
     out = C.c_void_p()
     if projection is None:
         check(lib.dfgpu_filter(table.handle, C.byref(le.c), None, 0, C.byref(out)))
@@ -95,7 +95,7 @@ class JoinHashTable:
             check(lib.dfgpu_join_probe(self._h, probe.handle, _ints(pk), JOIN_TYPES[join_type], _ints(bc), len(bc), _ints(pc),
                                        len(pc), C.byref(out)))
         else:
-            le = lower(predicate, probe.column_names)
+            le = lower(predicate, probe.column_names, probe)
             check(lib.dfgpu_join_probe_filtered(self._h, probe.handle, C.byref(le.c), _ints(pk), JOIN_TYPES[join_type], _ints(bc), len(bc),
                                                 _ints(pc), len(pc), C.byref(out)))
         return DeviceTable(out)
@@ -217,7 +217,7 @@ class GroupedAggregate:
         if predicate is None:
             check(_lib.load().dfgpu_agg_update(self._h, table.handle))
         else:
-            le = lower(predicate, table.column_names)
+            le = lower(predicate, table.column_names, table)
             check(_lib.load().dfgpu_agg_update_filtered(self._h, table.handle, C.byref(le.c)))
 
     @property

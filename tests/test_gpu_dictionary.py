@@ -98,3 +98,31 @@ def test_rejected_dictionaries():
     with pytest.raises(_lib.DfgpuError, match="dictionary in ascending order"):
         ops.sort(unsorted, [("s", False, False)])
     assert ops.sort(unsorted, [("v", True, False)]).to_arrow().column("s").cast(pa.string()).to_pylist() == ["a", "c", "a", "b"]
+
+
+def test_string_literal_predicates_are_bound_to_dictionary_indices():
+    """FilterExec / fused aggregate predicate / fused probe-side predicate written with the string itself"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(9)
+    n = 30_000
+    segs = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"]
+    t = pa.table({"k": pa.array(rng.integers(0, 500, n), type=pa.int64()), "seg": dict_col(rng.integers(0, 5, n).astype(np.uint8), segs, pa.uint8(), mask=rng.random(n) < 0.1),
+                  "v": pa.array(rng.integers(0, 1000, n), type=pa.int64())})
+    dt = DeviceTable.from_arrow(t)
+    plain = decoded(t)
+    is_b = pc.equal(plain.column("seg"), "BUILDING")
+    for pred, mask in ((col("seg").eq(lit("BUILDING", pa.string())), is_b), (col("seg").ne(lit("BUILDING", pa.string())), pc.invert(is_b)),
+                       (col("seg").eq(lit("NOT THERE", pa.string())), pc.and_(is_b, pc.invert(is_b))),
+                       (col("seg").ne(lit("NOT THERE", pa.string())), pc.is_valid(plain.column("seg"))),
+                       (col("seg").eq(lit("BUILDING", pa.string())).or_(col("v") > lit(990)), pc.or_kleene(is_b, pc.greater(plain.column("v"), 990)))):
+        got = ops.filter(dt, pred).to_arrow()
+        assert_tables_equal(decoded(got), plain.filter(mask), ordered=True)          # NULL predicate rows are dropped on both sides
+    agg = ops.aggregate(dt, [], [("sum", col("v"), "s"), ("count", None, "n")], "Single", predicate=col("seg").eq(lit("MACHINERY", pa.string()))).to_arrow()
+    m = plain.filter(pc.equal(plain.column("seg"), "MACHINERY"))
+    assert agg.to_pylist() == [{"s": pc.sum(m.column("v")).as_py(), "n": m.num_rows}]
+    build = DeviceTable.from_arrow(pa.table({"bk": pa.array(np.arange(500), type=pa.int64())}))
+    ht = ops.JoinHashTable(build, ["bk"], probe_mode=3)
+    j = ht.probe(dt, ["k"], "Inner", ["bk"], ["k", "v"], predicate=col("seg").eq(lit("FURNITURE", pa.string()))).to_arrow()
+    assert j.num_rows == plain.filter(pc.equal(plain.column("seg"), "FURNITURE")).num_rows
