@@ -136,6 +136,10 @@ __global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, 
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     if (row_mask && i >= mask_offset && !bit_at(row_mask, i - mask_offset)) continue;
+    // Run compression: an input row whose key equals its (live) predecessor's never needs to claim — the predecessor
+    // or, by induction, the first row of the run does, and that row is the group's smaller row id anyway.  Clustered
+    // input (a join's output in probe order, a table stored by key) skips most of the random CAS traffic.
+    if (i > mask_offset && (!row_mask || bit_at(row_mask, i - 1 - mask_offset)) && keys_equal(c.keys, i - 1, c.keys, i, true)) continue;
     uint64_t s = group_hash(c.keys, i) & c.mask;
     const uint32_t me = (uint32_t)i + 1u;
     uint32_t steps = 0;
