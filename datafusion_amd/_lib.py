@@ -43,7 +43,7 @@ class JoinFilter(C.Structure):
 class JoinOptions(C.Structure):
     _fields_ = [("perfect_hash_join_small_build_threshold", C.c_int64),
                 ("perfect_hash_join_min_key_density", C.c_double), ("table_mode", C.c_int32),
-                ("force_hash_collisions", C.c_int32), ("probe_mode", C.c_int32), ("_pad", C.c_int32)]
+                ("force_hash_collisions", C.c_int32), ("probe_mode", C.c_int32), ("null_aware", C.c_int32)]
 
 
 class JoinInfo(C.Structure):

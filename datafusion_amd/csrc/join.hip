@@ -54,6 +54,10 @@ struct JoinTable {
   uint64_t hash_mask = 0;
   BufPtr rank_bits, rank_prefix, rank_perm;  // rank map: u64 bitmap, u64 exclusive popcount prefix per word, optional u32 perm
   BufPtr visited;  // u8 per build row, lazily allocated
+  // HashJoinExec::null_aware (NOT IN semantics, single key column): what JoinLeftData shares between the probe
+  // partitions in the reference (probe_side_has_null / probe_side_non_empty / build_side_has_null, exec.rs:195-240)
+  bool null_aware = false;
+  bool probe_side_has_null = false, probe_side_non_empty = false, build_side_has_null = false;
   dfgpu_join_info info{};
 };
 
@@ -868,6 +872,14 @@ static Column mark_column(const uint8_t* bytes, int64_t n) {
   return c;
 }
 
+static int64_t null_count_of(const Column& c) {
+  if (!c.validity) return 0;
+  if (c.null_count >= 0) return c.null_count;
+  Column tmp = c;
+  count_nulls(tmp);
+  return tmp.null_count;
+}
+
 static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts) {
   Runtime& r = rt();
   auto jt = std::make_unique<JoinTable>();
@@ -876,6 +888,13 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
   jt->null_equality = null_equality;
   jt->force_collisions = opts.force_hash_collisions != 0;
   jt->probe_mode = opts.probe_mode;
+  jt->null_aware = opts.null_aware != 0;
+  if (jt->null_aware) {
+    DFGPU_CHECK(key_cols.size() == 1,
+                "null_aware anti join only supports single column join key, got " + std::to_string(key_cols.size()) + " columns");
+    DFGPU_CHECK(key_cols[0] >= 0 && key_cols[0] < (int)build.cols.size(), "build key column out of range");
+    jt->build_side_has_null = null_count_of(build.cols[key_cols[0]]) > 0;
+  }
   if (const char* e = getenv("DFGPU_PROBE_MODE")) jt->probe_mode = atoi(e);  // experiment override
   const int64_t nb = build.nrows;
   DFGPU_CHECK(nb < 0xFFFFFFFFll, "build side has >= u32::MAX rows (the reference switches to JoinHashMapU64; not supported on GPU)");
@@ -1226,6 +1245,48 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
 
 // HashJoinExec with a JoinFilter: the general (pairs) path with the filter between pair generation and the
 // per-JoinType adjustment.  Not a tuned path: pairs and the intermediate batch are materialised.
+// null_aware anti joins (stream.rs:755-808): bookkeeping before the probe.  Returns what the probe has to do.
+enum NullAwareAction { NA_PROCEED, NA_EMPTY, NA_MASK_NULL_PROBE_KEYS };
+static NullAwareAction null_aware_before_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, bool has_filter) {
+  if (!jt.null_aware) return NA_PROCEED;
+  DFGPU_CHECK(join_type == DFGPU_JOIN_LEFT_ANTI || join_type == DFGPU_JOIN_RIGHT_ANTI,
+              "null_aware can only be true for LeftAnti joins and RightAnti joins with `CollectLeft` `PartitionMode`");
+  DFGPU_CHECK(!(join_type == DFGPU_JOIN_RIGHT_ANTI && has_filter), "null_aware RightAnti join does not support a join filter");
+  DFGPU_CHECK(pk.size() == 1 && pk[0] >= 0 && pk[0] < (int)probe.cols.size(), "probe key column out of range");
+  const Column& key = probe.cols[pk[0]];
+  if (join_type == DFGPU_JOIN_RIGHT_ANTI) {
+    if (jt.build_side_has_null) return NA_EMPTY;
+    if (jt.build.nrows == 0 || probe.nrows == 0) return NA_PROCEED;  // NOT IN (empty set) is TRUE for every probe row, NULL keys included
+    return key.has_nulls() ? NA_MASK_NULL_PROBE_KEYS : NA_PROCEED;
+  }
+  if (probe.nrows > 0) jt.probe_side_non_empty = true;
+  if (null_count_of(key) > 0) jt.probe_side_has_null = true;
+  return NA_PROCEED;  // LeftAnti emits nothing per probe table; the flags act in dfgpu_join_emit_unmatched
+}
+
+static Table empty_selection(const Table& t, const std::vector<int>& cols) {
+  BufPtr zero = make_zero_buf(bitmap_bytes(t.nrows));
+  return compact_table(t, cols, zero->as<uint64_t>(), nullptr);
+}
+
+static Table join_probe_null_aware(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
+                                   const std::vector<int>& pout) {
+  switch (null_aware_before_probe(jt, probe, pk, join_type, false)) {
+    case NA_EMPTY:
+      for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
+      jt.info.probe_rows += probe.nrows;
+      return empty_selection(probe, pout);
+    case NA_MASK_NULL_PROBE_KEYS: {
+      bool consumed = false;
+      Table res = join_probe(jt, probe, pk, join_type, bout, pout, probe.cols[pk[0]].valid_words(), &consumed);
+      DFGPU_CHECK(consumed, "internal: RightAnti probe did not take the row mask");
+      return res;
+    }
+    default:
+      return join_probe(jt, probe, pk, join_type, bout, pout);
+  }
+}
+
 static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
                                     const std::vector<int>& pout, const dfgpu_join_filter& jf) {
   Runtime& r = rt();
@@ -1386,7 +1447,7 @@ int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_
     DFGPU_CHECK(join_type >= DFGPU_JOIN_INNER && join_type <= DFGPU_JOIN_RIGHT_MARK, "bad join type");
     std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
     std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
-    auto o = std::make_unique<Table>(join_probe(*jt, *unwrap(probe), pk, join_type, bo, po));
+    auto o = std::make_unique<Table>(join_probe_null_aware(*jt, *unwrap(probe), pk, join_type, bo, po));
     *out = wrap(o.release());
   });
 }
@@ -1411,8 +1472,15 @@ int dfgpu_join_probe_filtered(dfgpu_join_t ht, dfgpu_table_t probe, const dfgpu_
       and_bitmaps(mc.data->as<uint64_t>(), mc.valid_words(), (pt.nrows + 63) / 64, mask->as<uint64_t>());
     }
     bool consumed = false;
-    Table res = join_probe(*jt, pt, pk, join_type, bo, po, mask->as<uint64_t>(), &consumed);
-    if (!consumed) {
+    Table res;
+    if (!jt->null_aware) res = join_probe(*jt, pt, pk, join_type, bo, po, mask->as<uint64_t>(), &consumed);
+    if (jt->null_aware) {
+      // NOT IN semantics look at the NULL keys of the rows that pass the filter: materialise it first
+      std::vector<int> all(pt.cols.size());
+      for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
+      Table filtered = compact_table(pt, all, mask->as<uint64_t>(), nullptr);
+      res = join_probe_null_aware(*jt, filtered, pk, join_type, bo, po);
+    } else if (!consumed) {
       // general path: FilterExec materialised, then the probe
       std::vector<int> all(pt.cols.size());
       for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
@@ -1434,6 +1502,7 @@ int dfgpu_join_probe_with_filter(dfgpu_join_t ht, dfgpu_table_t probe, const int
     DFGPU_CHECK(join_type >= DFGPU_JOIN_INNER && join_type <= DFGPU_JOIN_RIGHT_MARK, "bad join type");
     std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
     std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
+    null_aware_before_probe(*jt, *unwrap(probe), pk, join_type, true);  // LeftAnti: flags only; RightAnti: rejected
     auto o = std::make_unique<Table>(join_probe_with_filter(*jt, *unwrap(probe), pk, join_type, bo, po, *filter));
     *out = wrap(o.release());
   });
@@ -1458,7 +1527,15 @@ int dfgpu_join_emit_unmatched(dfgpu_join_t ht, int join_type, const int* build_o
       BufPtr mask = make_buf(bitmap_bytes(nb));
       int want_visited = join_type == DFGPU_JOIN_LEFT_SEMI;
       if (nb) k_visited_mask<<<grid_for((nb + 63) / 64, BLOCK / WAVE), BLOCK, 0, r.stream>>>(jt->visited->as<uint8_t>(), nb, want_visited, mask->as<uint64_t>());
-      *o = compact_table(jt->build, bo, mask->as<uint64_t>(), nullptr);
+      const uint64_t* also = nullptr;
+      if (jt->null_aware) {
+        DFGPU_CHECK(join_type == DFGPU_JOIN_LEFT_ANTI, "null_aware can only be true for LeftAnti joins and RightAnti joins with `CollectLeft` `PartitionMode`");
+        // stream.rs:1016-1076: a NULL on the probe side makes every NOT IN unknown; else NULL build keys are unknown
+        // unless the probe side was empty (NULL NOT IN (empty set) is TRUE)
+        if (jt->probe_side_has_null) DFGPU_HIP(hipMemsetAsync(mask->ptr, 0, bitmap_bytes(nb), r.stream));
+        else if (jt->probe_side_non_empty) also = jt->build.cols[jt->key_cols[0]].valid_words();
+      }
+      *o = compact_table(jt->build, bo, mask->as<uint64_t>(), also);
       if (join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_FULL) {
         // unmatched build rows carry an all-NULL probe side
         for (int i = 0; i < n_probe_out; i++) {

@@ -56,11 +56,12 @@ class JoinHashTable:
     """JoinLeftData (hash_join/exec.rs:195-240): the built side of a hash join"""
 
     def __init__(self, build: DeviceTable, on_left, null_equality="NullEqualsNothing", table_mode=0,
-                 small_build_threshold=1024, min_key_density=GPU_MIN_KEY_DENSITY, force_hash_collisions=False, probe_mode=0):
+                 small_build_threshold=1024, min_key_density=GPU_MIN_KEY_DENSITY, force_hash_collisions=False, probe_mode=0,
+                 null_aware=False):
         lib = _lib.init()
         self.build = build  # keep alive
         self.key_idx = [build.index_of(k) for k in on_left]
-        opts = JoinOptions(small_build_threshold, min_key_density, table_mode, int(force_hash_collisions), probe_mode, 0)
+        opts = JoinOptions(small_build_threshold, min_key_density, table_mode, int(force_hash_collisions), probe_mode, int(null_aware))
         self._h = C.c_void_p()
         check(lib.dfgpu_join_build(build.handle, _ints(self.key_idx), len(self.key_idx), NULL_EQUALITY[null_equality],
                                    C.byref(opts), C.byref(self._h)))

@@ -185,19 +185,21 @@ class RepartitionExec(_Unary):
 
 class HashJoinExec(ExecutionPlan):
     """HashJoinExec::try_new(left = build, right = probe, on, filter = None, join_type, projection, mode,
-    null_equality) (joins/hash_join/exec.rs:752).  `projection` = (build columns, probe columns)."""
+    null_equality, null_aware) (joins/hash_join/exec.rs:752).  `projection` = (build columns, probe columns);
+    `null_aware` = NOT IN semantics for LeftAnti / RightAnti on one key column (exec.rs:429-455)."""
 
     def __init__(self, left: ExecutionPlan, right: ExecutionPlan, on, join_type="Inner", projection=None, null_equality="NullEqualsNothing",
-                 probe_mode=0, filter=None):
+                 probe_mode=0, filter=None, null_aware=False):
         self.left, self.right, self.on, self.join_type = left, right, on, join_type
         self.projection, self.null_equality, self.probe_mode = projection, null_equality, probe_mode
         self.filter = filter   # JoinFilter: (expression over f0, f1, ..., [(column index, "Left" | "Right"), ...])
+        self.null_aware = null_aware
 
     def children(self):
         return [self.left, self.right]
 
     def with_new_children(self, c):
-        return HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode, self.filter)
+        return HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode, self.filter, self.null_aware)
 
     def _probe(self, ht, probe_table, predicate=None):
         bc, pc = self.projection if self.projection else (None, None)
@@ -210,13 +212,13 @@ class HashJoinExec(ExecutionPlan):
             b, bo = self._run_child(self.left)
             p, po = self._run_child(self.right)
             bc, pc = self.projection if self.projection else (None, None)
-            out = ops.hash_join(b, p, self.on, self.join_type, self.null_equality, bc, pc, join_filter=self.filter)
+            out = ops.hash_join(b, p, self.on, self.join_type, self.null_equality, bc, pc, join_filter=self.filter, null_aware=self.null_aware)
             for t, o in ((b, bo), (p, po)):
                 if o:
                     t.free()
             return out
         b, bo = self._run_child(self.left)
-        ht = ops.JoinHashTable(b, [l for l, _ in self.on], self.null_equality, probe_mode=self.probe_mode)
+        ht = ops.JoinHashTable(b, [l for l, _ in self.on], self.null_equality, probe_mode=self.probe_mode, null_aware=self.null_aware)
         p, po = self._run_child(self.right)
         out = self._probe(ht, p, probe_predicate)
         ht.free()
@@ -226,7 +228,8 @@ class HashJoinExec(ExecutionPlan):
         return out
 
     def detail(self):
-        return f"join_type={self.join_type}, on={self.on}" + (f", projection={self.projection}" if self.projection else "")
+        return f"join_type={self.join_type}, on={self.on}" + (f", projection={self.projection}" if self.projection else "") + \
+            (", null_aware" if self.null_aware else "")
 
 
 class AggregateExec(_Unary):
@@ -299,11 +302,11 @@ class GpuHashJoinExec(HashJoinExec):
 
     def __init__(self, join: HashJoinExec, probe_predicate: PhysicalExpr, probe_input: ExecutionPlan, probe_mode=None):
         super().__init__(join.left, probe_input, join.on, join.join_type, join.projection, join.null_equality,
-                         join.probe_mode if probe_mode is None else probe_mode)
+                         join.probe_mode if probe_mode is None else probe_mode, null_aware=join.null_aware)
         self.probe_predicate = probe_predicate
 
     def with_new_children(self, c):
-        j = HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode, self.filter)
+        j = HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode, self.filter, self.null_aware)
         return GpuHashJoinExec(j, self.probe_predicate, c[1])
 
     def execute(self, partition=0):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 4
+#define DFGPU_ABI_VERSION 5
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -258,7 +258,14 @@ typedef struct dfgpu_join_options {
    *       joins/hash_join/exec.rs:1024-1040,1352, would have to report false for the shim node).
    * Modes 2/3 allocate the output for the probe-row upper bound and fail if they are not applicable. */
   int32_t probe_mode;
-  int32_t _pad;
+  /* HashJoinExec::null_aware (hash_join/exec.rs:429-455,786): NOT IN semantics for anti joins on a single key column.
+   * LeftAnti  (stream.rs:762-808,1016-1076): a NULL probe key in any probe table empties the whole output
+   *           (dfgpu_join_emit_unmatched returns no rows); otherwise, if any probe row was seen, build rows with a NULL
+   *           key are not emitted.
+   * RightAnti (stream.rs:762-768,937-955): a NULL build key empties the output; an empty build side emits every probe
+   *           row (NULL keys included); otherwise probe rows with a NULL key are not emitted.  No JoinFilter allowed.
+   * Any other join type, or more than one key column, is an error (the reference's try_new messages). */
+  int32_t null_aware;
 } dfgpu_join_options;
 
 /* collect_left_input (physical-plan/src/joins/hash_join/exec.rs:2569-2776): build the

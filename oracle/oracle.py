@@ -137,13 +137,16 @@ def take(table: pa.Table, idx: np.ndarray) -> pa.Table:
 # ----------------------------------------------------------------------------- join
 
 def hash_join(left: pa.Table, right: pa.Table, on, join_type="Inner", null_equality="NullEqualsNothing",
-              mode=0, small_build_threshold=1024, min_key_density=0.15, return_indices=False, join_filter=None):
+              mode=0, small_build_threshold=1024, min_key_density=0.15, return_indices=False, join_filter=None, null_aware=False):
     """HashJoinExec: left = build side, right = probe side (hash_join/exec.rs:752).
     Output schema = left columns ++ right columns (Inner/Left/Right/Full), left only for
     Left{Semi,Anti}, right only for Right{Semi,Anti}, + `mark` for *Mark joins
     (joins/utils.rs:build_join_schema).
     join_filter = (expr over intermediate columns named f0, f1, ..., [(column index, "Left" | "Right"), ...]):
-    JoinFilter (joins/join_filter.rs) — see _hash_join_filtered."""
+    JoinFilter (joins/join_filter.rs) — see _hash_join_filtered.
+    null_aware = HashJoinExec::null_aware (NOT IN semantics) — see _hash_join_null_aware."""
+    if null_aware:
+        return _hash_join_null_aware(left, right, on, join_type, null_equality, mode, small_build_threshold, min_key_density, join_filter)
     if join_filter is not None:
         return _hash_join_filtered(left, right, on, join_type, null_equality, mode, small_build_threshold, min_key_density, join_filter)
     L = lib()
@@ -180,6 +183,33 @@ def hash_join(left: pa.Table, right: pa.Table, on, join_type="Inner", null_equal
     else:
         out = take(right, pi).append_column("mark", pa.array(mk))
     return out
+
+
+def _hash_join_null_aware(left, right, on, join_type, null_equality, mode, small_build_threshold, min_key_density, join_filter):
+    """null_aware anti joins = `x NOT IN (subquery)`: validation of HashJoinExec::try_new (hash_join/exec.rs:429-455), then
+    process_probe_batch / process_unmatched_build_batch (hash_join/stream.rs:755-808, 937-955, 1016-1076):
+      LeftAnti  — a NULL probe key anywhere makes every NOT IN unknown (no output); otherwise left rows with a NULL key
+                  are dropped unless the probe side is empty (NULL NOT IN (empty set) is TRUE);
+      RightAnti — a NULL build key empties the output; an empty build side emits every probe row (NULL keys
+                  included, build_batch_empty_build_side); otherwise probe rows with a NULL key are dropped."""
+    if join_type not in ("LeftAnti", "RightAnti"):
+        raise ValueError(f"null_aware can only be true for LeftAnti joins and RightAnti joins with `CollectLeft` `PartitionMode`, got {join_type}")
+    if len(on) != 1:
+        raise ValueError(f"null_aware anti join only supports single column join key, got {len(on)} columns")
+    if join_type == "RightAnti" and join_filter is not None:
+        raise ValueError("null_aware RightAnti join does not support a join filter")
+    lkey, rkey = on[0]
+    keep_valid = lambda t, key: take(t, np.flatnonzero(np.asarray(t.column(key).is_valid())).astype(np.int64))
+    plain = lambda: hash_join(left, right, on, join_type, null_equality, mode, small_build_threshold, min_key_density, join_filter=join_filter)
+    if join_type == "LeftAnti":
+        if right.column(rkey).null_count > 0:
+            return left.slice(0, 0)
+        out = plain()
+        return keep_valid(out, lkey) if right.num_rows > 0 else out
+    if left.column(lkey).null_count > 0:
+        return right.slice(0, 0)
+    out = plain()
+    return keep_valid(out, rkey) if left.num_rows > 0 else out
 
 
 def _hash_join_filtered(left, right, on, join_type, null_equality, mode, small_build_threshold, min_key_density, join_filter):
