@@ -16,6 +16,7 @@ per-operator GPU node):
   HashJoinExec(build, FilterExec(probe))             -> GpuHashJoinExec         predicate applied inside the probe kernel
   CoalesceBatchesExec / CoalescePartitionsExec       -> removed                 (whole partitions per launch)
   RepartitionExec(Hash) on one GPU                   -> removed                 (one partition per GPU)
+  SortPreservingMergeExec on one GPU                 -> removed                 (one sorted partition is the merge)
 """
 from __future__ import annotations
 
@@ -86,19 +87,28 @@ class ExecutionPlan:
 
 
 class MemoryExec(ExecutionPlan):
-    """DataSourceExec over an in-memory table (datasource/src/memory.rs:58) — here: a device-resident table"""
+    """DataSourceExec over an in-memory table (datasource/src/memory.rs:58) — here: a device-resident table.
+    `projection` = the scan's column projection (DataSourceExec: projection=[...]); a zero-copy view."""
 
-    def __init__(self, table: DeviceTable, name: str = ""):
-        self.table, self.label = table, name
+    def __init__(self, table: DeviceTable, name: str = "", projection=None):
+        self.table, self.label, self.projection = table, name, projection
+        self._view = None
+
+    def project(self, columns) -> "MemoryExec":
+        return MemoryExec(self.table, self.label, list(columns))
 
     def with_new_children(self, children):
         return self
 
     def execute(self, partition=0):
-        return self.table
+        if self.projection is None:
+            return self.table
+        if self._view is None:
+            self._view = self.table.select(self.projection)     # owned by this node, like the table by the caller
+        return self._view
 
     def detail(self):
-        return f"{self.label} rows={self.table.num_rows}"
+        return f"{self.label} rows={self.table.num_rows}" + (f", projection={self.projection}" if self.projection else "")
 
 
 class _Unary(ExecutionPlan):
@@ -181,6 +191,56 @@ class RepartitionExec(_Unary):
 
     def detail(self):
         return f"Hash({self.keys}, {self.n_partitions})"
+
+
+class CoalescePartitionsExec(_Unary):
+    """CoalescePartitionsExec::new(input) (coalesce_partitions.rs:50): all input partitions into one, in arrival
+    order.  One partition per GPU: with one GPU nothing happens, with several every rank receives the
+    concatenation of the ranks' partitions (they are partial aggregate states — a handful of rows — wherever the
+    pinned plans use it), so they travel as host objects like SortPreservingMergeExec's inputs."""
+
+    def __init__(self, input: ExecutionPlan, group=None):
+        self.input, self.group = input, group
+
+    def with_new_children(self, c):
+        return CoalescePartitionsExec(c[0], self.group)
+
+    def execute(self, partition=0):
+        from .queries import _world
+        if _world(self.group) == 1:
+            return self._pass_through(self.input)
+        import pyarrow as pa
+        import torch.distributed as dist
+        t, owned = self._run_child(self.input)
+        parts = [None] * dist.get_world_size(self.group)
+        dist.all_gather_object(parts, t.to_arrow(), group=self.group)
+        if owned:
+            t.free()
+        return DeviceTable.from_arrow(pa.concat_tables(parts))
+
+
+class SortPreservingMergeExec(_Unary):
+    """SortPreservingMergeExec::new(expr, input).with_fetch(fetch) (sorts/sort_preserving_merge.rs:91): k-way merge
+    of the sorted partitions.  One partition per GPU: a no-op on one GPU, otherwise queries._merge_sorted."""
+
+    def __init__(self, expr, input: ExecutionPlan, fetch=None, group=None):
+        self.expr, self.input, self.fetch, self.group = expr, input, fetch, group
+
+    def with_new_children(self, c):
+        return SortPreservingMergeExec(self.expr, c[0], self.fetch, self.group)
+
+    def execute(self, partition=0):
+        from .queries import _merge_sorted, _world
+        if _world(self.group) == 1:
+            return self._pass_through(self.input)
+        t, owned = self._run_child(self.input)
+        out = _merge_sorted(t, self.expr, self.fetch, self.group)
+        if owned and out is not t:
+            t.free()
+        return out
+
+    def detail(self):
+        return str([(c, "DESC" if d else "ASC") for c, d, _ in self.expr]) + (f", fetch={self.fetch}" if self.fetch is not None else "")
 
 
 class HashJoinExec(ExecutionPlan):
@@ -354,13 +414,13 @@ class GpuOffloadRule:
         # bookkeeping nodes that have no meaning for whole-partition device tables
         if isinstance(node, CoalesceBatchesExec):
             return node.input
-        if isinstance(node, RepartitionExec) and self.world_size == 1:
-            return node.input
+        if isinstance(node, (RepartitionExec, CoalescePartitionsExec, SortPreservingMergeExec)) and self.world_size == 1:
+            return node.input                                  # one partition: nothing to exchange, gather or merge
         if isinstance(node, HashJoinExec) and not isinstance(node, GpuHashJoinExec):
             probe_mode = ops.PROBE_MODES["single_pass_unordered"] if (self.unordered_probe and not parent_needs_order and
                                                                       node.join_type in ("Inner", "RightSemi", "RightAnti")) else node.probe_mode
             node = HashJoinExec(node.left, node.right, node.on, node.join_type, node.projection, node.null_equality,
-                                node.probe_mode if node.filter is not None else probe_mode, node.filter)
+                                node.probe_mode if node.filter is not None else probe_mode, node.filter, node.null_aware)
             probe = node.right
             if node.filter is None and isinstance(probe, FilterExec) and node.join_type in ("Inner", "RightSemi", "RightAnti", "Right", "RightMark"):
                 needed = set(r for _, r in node.on) | set((node.projection or (None, None))[1] or [])

@@ -118,8 +118,8 @@ def q1(lineitem: DeviceTable, group=None, fused: bool = True) -> DeviceTable:
 
 
 # ------------------------------------------------------------------------------------ Q3
-def _q3_fused_filters(customer, orders, lineitem, stats, probe_mode):
-    c = ops.filter(customer, col("c_mktsegment").eq(lit(SEGMENT_BUILDING, pa.uint8())), ["c_custkey"])
+def _q3_fused_filters(customer, orders, lineitem, stats, probe_mode, segment):
+    c = ops.filter(customer, col("c_mktsegment").eq(segment), ["c_custkey"])
     ht = ops.JoinHashTable(c, ["c_custkey"], probe_mode=probe_mode)
     # 12) FilterExec o_orderdate < 1995-03-15 + 07) HashJoinExec RightSemi on (c_custkey, o_custkey)
     semi = ht.probe(orders, ["o_custkey"], "RightSemi", probe_cols=["o_orderkey", "o_orderdate", "o_shippriority"],
@@ -147,18 +147,21 @@ Q3_SORT = [("revenue", True, True), ("o_orderdate", False, False)]  # revenue DE
 
 
 def q3(customer: DeviceTable, orders: DeviceTable, lineitem: DeviceTable, group=None, stats: dict | None = None,
-       probe_mode: int = ops.PROBE_MODES["single_pass_unordered"], fused: bool = True) -> DeviceTable:
+       probe_mode: int = ops.PROBE_MODES["single_pass_unordered"], fused: bool = True, segment_literal=None) -> DeviceTable:
     """q3.slt.part:61-76, bottom-up.  `stats` (optional) receives intermediate row counts.
 
     fused=True (what the optimizer rule substitutes on one GPU): the FilterExecs on orders and lineitem are fused
     below the probe side of their HashJoinExec (dfgpu_join_probe_filtered) — the single-pass probe applies the
     predicate's row mask in the probe kernel, so neither filtered table is materialised.  With a repartition
-    between filter and join (N > 1) the filters stay separate operators, as in the reference plan."""
+    between filter and join (N > 1) the filters stay separate operators, as in the reference plan.
+    segment_literal: what c_mktsegment is compared with — default the UInt8 code of 'BUILDING' (the device generator's
+    layout); lit("BUILDING", pa.string()) for a dictionary-encoded string column."""
+    segment = lit(SEGMENT_BUILDING, pa.uint8()) if segment_literal is None else segment_literal
     fuse_filters = fused and _world(group) == 1 and probe_mode in (ops.PROBE_MODES["single_pass_unordered"], ops.PROBE_MODES["single_pass_ordered"])
     if fuse_filters:
-        return _q3_fused_filters(customer, orders, lineitem, stats, probe_mode)
+        return _q3_fused_filters(customer, orders, lineitem, stats, probe_mode, segment)
     # 09) FilterExec: c_mktsegment = BUILDING, projection=[c_custkey]; 08) Repartition Hash(c_custkey)
-    c = ops.filter(customer, col("c_mktsegment").eq(lit(SEGMENT_BUILDING, pa.uint8())), ["c_custkey"])
+    c = ops.filter(customer, col("c_mktsegment").eq(segment), ["c_custkey"])
     c_r = _repartition(c, ["c_custkey"], group)
     # 12) FilterExec: o_orderdate < 1995-03-15; 11) Repartition Hash(o_custkey)
     o = ops.filter(orders, col("o_orderdate") < lit(DATE_Q3, pa.date32()), ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])

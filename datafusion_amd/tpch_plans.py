@@ -1,0 +1,173 @@
+"""The reference's pinned TPC-H physical plans, node for node, over this package's ExecutionPlan mirror.
+
+Source of every plan: `datafusion/sqllogictest/test_files/tpch/plans/q{N}.slt.part` (the `physical_plan` block; 4
+target partitions in the reference's files — the count only shows in RepartitionExec).  These are what a DataFusion
+session hands to a PhysicalOptimizerRule: `GpuOffloadRule.optimize(plan)` rewrites them, `physical_plan.collect` runs
+them.  String columns are compared with their string literals, as in the reference's plans; on the device they are
+dictionary-encoded (indices on the device, `expr.bind_string_literals`) or, for the device generator's layout, UInt8
+codes — `segment_literal` lets Q3 take either.
+
+The leaf tables may be DeviceTables (product) or anything with `num_rows` (plan-shape tests, the oracle's plan
+interpreter in tests/plan_oracle.py).
+"""
+from __future__ import annotations
+
+import datetime
+from decimal import Decimal
+
+import pyarrow as pa
+
+from . import physical_plan as P
+from .expr import col, lit
+
+DATE = pa.date32()
+D15_2 = pa.decimal128(15, 2)
+ONE = lit(1, pa.decimal128(20, 0))  # Int64(1) coerced to Decimal128(20,0), type_coercion/binary.rs:1257-1273
+ASC = (False, False)                # ASC NULLS LAST
+DESC = (True, True)                 # DESC (NULLS FIRST)
+
+
+def _d(y, m, d):
+    return lit(datetime.date(y, m, d), DATE)
+
+
+def _scan(table, name):
+    return P.MemoryExec(table, name)
+
+
+def _cb(x):
+    return P.CoalesceBatchesExec(x)
+
+
+def _hash(x, keys):
+    return P.RepartitionExec(x, keys, 4)
+
+
+# ------------------------------------------------------------------------------------------ Q1
+def q1_group_by():
+    return [(col("l_returnflag"), "l_returnflag"), (col("l_linestatus"), "l_linestatus")]
+
+
+def q1_aggs():
+    ce = col("__common_expr_1")
+    return [("sum", col("l_quantity"), "sum_qty"), ("sum", col("l_extendedprice"), "sum_base_price"), ("sum", ce, "sum_disc_price"),
+            ("sum", ce * (ONE + col("l_tax")), "sum_charge"), ("avg", col("l_quantity"), "avg_qty"),
+            ("avg", col("l_extendedprice"), "avg_price"), ("avg", col("l_discount"), "avg_disc"), ("count", None, "count_order")]
+
+
+def q1_plan(lineitem):
+    """q1.slt.part:50-58"""
+    f = P.FilterExec(col("l_shipdate") <= _d(1998, 9, 2), _scan(lineitem, "lineitem"),
+                     projection=["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus"])
+    proj = P.ProjectionExec([(col("l_extendedprice") * (ONE - col("l_discount")), "__common_expr_1"), (col("l_quantity"), "l_quantity"),
+                             (col("l_extendedprice"), "l_extendedprice"), (col("l_discount"), "l_discount"), (col("l_tax"), "l_tax"),
+                             (col("l_returnflag"), "l_returnflag"), (col("l_linestatus"), "l_linestatus")], _cb(f))
+    partial = P.AggregateExec("Partial", q1_group_by(), q1_aggs(), proj)
+    final = P.AggregateExec("FinalPartitioned", q1_group_by(), q1_aggs(), _cb(_hash(partial, ["l_returnflag", "l_linestatus"])))
+    keys = [("l_returnflag",) + ASC, ("l_linestatus",) + ASC]
+    return P.SortPreservingMergeExec(keys, P.SortExec(keys, final))
+
+
+# ------------------------------------------------------------------------------------------ Q3
+Q3_SORT = [("revenue",) + DESC, ("o_orderdate",) + ASC]
+
+
+def q3_plan(customer, orders, lineitem, segment_literal=None):
+    """q3.slt.part:61-76.  segment_literal: the literal `c_mktsegment` is compared with (default: the string
+    'BUILDING' for a string / dictionary column; the device generator's UInt8 code layout passes lit(1, uint8))"""
+    seg = lit("BUILDING", pa.string()) if segment_literal is None else segment_literal
+    c = _hash(_cb(P.FilterExec(col("c_mktsegment").eq(seg), _scan(customer, "customer"), projection=["c_custkey"])), ["c_custkey"])
+    o = _hash(_cb(P.FilterExec(col("o_orderdate") < _d(1995, 3, 15), _scan(orders, "orders"),
+                               projection=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])), ["o_custkey"])
+    semi = P.HashJoinExec(_cb(c), _cb(o), [("c_custkey", "o_custkey")], "RightSemi", projection=(None, ["o_orderkey", "o_orderdate", "o_shippriority"]))
+    l = _hash(_cb(P.FilterExec(col("l_shipdate") > _d(1995, 3, 15), _scan(lineitem, "lineitem"),
+                               projection=["l_orderkey", "l_extendedprice", "l_discount"])), ["l_orderkey"])
+    j = P.HashJoinExec(_cb(_hash(_cb(semi), ["o_orderkey"])), _cb(l), [("o_orderkey", "l_orderkey")], "Inner",
+                       projection=(["o_orderdate", "o_shippriority"], ["l_orderkey", "l_extendedprice", "l_discount"]))
+    gb = [(col("l_orderkey"), "l_orderkey"), (col("o_orderdate"), "o_orderdate"), (col("o_shippriority"), "o_shippriority")]
+    agg = P.AggregateExec("SinglePartitioned", gb, [("sum", col("l_extendedprice") * (ONE - col("l_discount")), "revenue")], _cb(j))
+    top = P.SortExec(Q3_SORT, agg, fetch=10)
+    proj = P.ProjectionExec([(col(n), n) for n in ["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]], top)
+    return P.SortPreservingMergeExec(Q3_SORT, proj, fetch=10)
+
+
+# ------------------------------------------------------------------------------------------ Q4
+def q4_plan(orders, lineitem):
+    """q4.slt.part:61-73: EXISTS subquery decorrelated to a LeftSemi join (build = filtered orders)"""
+    o = _hash(_cb(P.FilterExec((col("o_orderdate") >= _d(1993, 7, 1)).and_(col("o_orderdate") < _d(1993, 10, 1)), _scan(orders, "orders"),
+                               projection=["o_orderkey", "o_orderpriority"])), ["o_orderkey"])
+    l = _hash(_cb(P.FilterExec(col("l_receiptdate") > col("l_commitdate"), _scan(lineitem, "lineitem"), projection=["l_orderkey"])), ["l_orderkey"])
+    semi = P.HashJoinExec(_cb(o), _cb(l), [("o_orderkey", "l_orderkey")], "LeftSemi", projection=(["o_orderpriority"], None))
+    gb = [(col("o_orderpriority"), "o_orderpriority")]
+    aggs = [("count", None, "count(Int64(1))")]
+    partial = P.AggregateExec("Partial", gb, aggs, _cb(semi))
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["o_orderpriority"])))
+    keys = [("o_orderpriority",) + ASC]
+    proj = P.ProjectionExec([(col("o_orderpriority"), "o_orderpriority"), (col("count(Int64(1))"), "order_count")], P.SortExec(keys, final))
+    return P.SortPreservingMergeExec(keys, proj)
+
+
+# ------------------------------------------------------------------------------------------ Q5
+def q5_plan(customer, orders, lineitem, supplier, nation, region):
+    """q5.slt.part:70-99: five joins (one on two key columns), LeftSemi against the filtered region"""
+    c = _hash(_scan(customer, "customer").project(["c_custkey", "c_nationkey"]), ["c_custkey"])
+    o = _hash(_cb(P.FilterExec((col("o_orderdate") >= _d(1994, 1, 1)).and_(col("o_orderdate") < _d(1995, 1, 1)), _scan(orders, "orders"),
+                               projection=["o_orderkey", "o_custkey"])), ["o_custkey"])
+    j1 = P.HashJoinExec(_cb(c), _cb(o), [("c_custkey", "o_custkey")], "Inner", projection=(["c_nationkey"], ["o_orderkey"]))
+    l = _hash(_scan(lineitem, "lineitem").project(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]), ["l_orderkey"])
+    j2 = P.HashJoinExec(_cb(_hash(_cb(j1), ["o_orderkey"])), _cb(l), [("o_orderkey", "l_orderkey")], "Inner",
+                        projection=(["c_nationkey"], ["l_suppkey", "l_extendedprice", "l_discount"]))
+    s = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_nationkey"]), ["s_suppkey", "s_nationkey"])
+    j3 = P.HashJoinExec(_cb(_hash(_cb(j2), ["l_suppkey", "c_nationkey"])), _cb(s), [("l_suppkey", "s_suppkey"), ("c_nationkey", "s_nationkey")], "Inner",
+                        projection=(["l_extendedprice", "l_discount"], ["s_nationkey"]))
+    n = _hash(_scan(nation, "nation").project(["n_nationkey", "n_name", "n_regionkey"]), ["n_nationkey"])
+    j4 = P.HashJoinExec(_cb(_hash(_cb(j3), ["s_nationkey"])), _cb(n), [("s_nationkey", "n_nationkey")], "Inner",
+                        projection=(["l_extendedprice", "l_discount"], ["n_name", "n_regionkey"]))
+    r = _hash(_cb(P.FilterExec(col("r_name").eq(lit("ASIA", pa.string())), _scan(region, "region"), projection=["r_regionkey"])), ["r_regionkey"])
+    semi = P.HashJoinExec(_cb(_hash(_cb(j4), ["n_regionkey"])), _cb(r), [("n_regionkey", "r_regionkey")], "LeftSemi",
+                          projection=(["l_extendedprice", "l_discount", "n_name"], None))
+    gb = [(col("n_name"), "n_name")]
+    name = "sum(lineitem.l_extendedprice * Int64(1) - lineitem.l_discount)"
+    aggs = [("sum", col("l_extendedprice") * (ONE - col("l_discount")), name)]
+    partial = P.AggregateExec("Partial", gb, aggs, _cb(semi))
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["n_name"])))
+    srt = P.SortExec([(name,) + DESC], final)
+    proj = P.ProjectionExec([(col("n_name"), "n_name"), (col(name), "revenue")], srt)
+    return P.SortPreservingMergeExec([("revenue",) + DESC], proj)
+
+
+# ------------------------------------------------------------------------------------------ Q6
+def q6_plan(lineitem):
+    """q6.slt.part:38-43: one filter, one ungrouped SUM"""
+    pred = (col("l_shipdate") >= _d(1994, 1, 1)).and_(col("l_shipdate") < _d(1995, 1, 1)) \
+        .and_(col("l_discount") >= lit(Decimal("0.05"), D15_2)).and_(col("l_discount") <= lit(Decimal("0.07"), D15_2)) \
+        .and_(col("l_quantity") < lit(Decimal("24.00"), D15_2))
+    f = P.FilterExec(pred, _scan(lineitem, "lineitem"), projection=["l_extendedprice", "l_discount"])
+    name = "sum(lineitem.l_extendedprice * lineitem.l_discount)"
+    aggs = [("sum", col("l_extendedprice") * col("l_discount"), name)]
+    partial = P.AggregateExec("Partial", [], aggs, _cb(f))
+    final = P.AggregateExec("Final", [], aggs, P.CoalescePartitionsExec(partial))
+    return P.ProjectionExec([(col(name), "revenue")], final)
+
+
+# ----------------------------------------------------------------------------------------- Q18
+def q18_plan(customer, orders, lineitem):
+    """q18.slt.part:70-87: two Inner joins, a LeftSemi join against `GROUP BY l_orderkey HAVING sum(l_quantity) > 300`
+    (150 k·SF groups: the dense-integer-key aggregate node), a five-column GROUP BY, a two-key sort"""
+    c = _hash(_scan(customer, "customer").project(["c_custkey", "c_name"]), ["c_custkey"])
+    o = _hash(_scan(orders, "orders").project(["o_orderkey", "o_custkey", "o_totalprice", "o_orderdate"]), ["o_custkey"])
+    j1 = P.HashJoinExec(_cb(c), _cb(o), [("c_custkey", "o_custkey")], "Inner", projection=(["c_custkey", "c_name"], ["o_orderkey", "o_totalprice", "o_orderdate"]))
+    l = _hash(_scan(lineitem, "lineitem").project(["l_orderkey", "l_quantity"]), ["l_orderkey"])
+    j2 = P.HashJoinExec(_cb(_hash(_cb(j1), ["o_orderkey"])), _cb(l), [("o_orderkey", "l_orderkey")], "Inner",
+                        projection=(["c_custkey", "c_name", "o_orderkey", "o_totalprice", "o_orderdate"], ["l_quantity"]))
+    gb = [(col("l_orderkey"), "l_orderkey")]
+    qsum = "sum(lineitem.l_quantity)"
+    aggs = [("sum", col("l_quantity"), qsum)]
+    partial = P.AggregateExec("Partial", gb, aggs, _scan(lineitem, "lineitem").project(["l_orderkey", "l_quantity"]))
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["l_orderkey"])))
+    having = _cb(P.FilterExec(col(qsum) > lit(Decimal("300.00"), pa.decimal128(25, 2)), final, projection=["l_orderkey"]))
+    semi = P.HashJoinExec(_cb(j2), having, [("o_orderkey", "l_orderkey")], "LeftSemi")
+    gb2 = [(col(n), n) for n in ["c_name", "c_custkey", "o_orderkey", "o_orderdate", "o_totalprice"]]
+    agg = P.AggregateExec("SinglePartitioned", gb2, aggs, _cb(semi))
+    keys = [("o_totalprice",) + DESC, ("o_orderdate",) + ASC]
+    return P.SortPreservingMergeExec(keys, P.SortExec(keys, agg))

@@ -1,0 +1,232 @@
+"""TEST INFRASTRUCTURE (checker data, never on the product path): dbgen-exact TPC-H columns.
+
+The reference pins TPC-H *answers* at scale factor 0.1
+(`datafusion/sqllogictest/test_files/tpch/answers/q1.slt.part:42-45`, `q3.slt.part:44-53`) over data
+written by the TPC's `dbgen` (the reference's harness uses the `tpchgen` crate, a bit-exact Rust
+restatement of it — un-vendored, `benchmarks/src/tpch/run.rs:53-58`).  Neither generator is in this
+image, so this module restates the published dbgen v2.17 algorithm for exactly the columns Q1 and Q3
+read, vectorised with numpy:
+
+  * one Lehmer stream per column:  x' = 16807 * x mod (2^31 - 1)                (rnd.c NextRand)
+  * UnifInt(lo, hi) = lo + (long)((double)x' / 2147483647.0 * (double)(hi - lo + 1))   (rnd.c)
+  * after every row each stream is advanced to its per-row `boundary` (rnd.c row_stop), so row i
+    of a stream starts at seed * 16807^(boundary * i): that is what makes it vectorisable
+  * sparse order keys (build.c mk_sparse), retail price (rpb_routine), date offsets and the
+    returnflag / linestatus rules of build.c mk_order, market segment of mk_cust.
+
+It is pinned twice (tests/test_dbgen_golden.py): against the first rows of dbgen's SF1 output that
+the reference carries as fixtures (`datafusion/core/tests/tpch-csv/{lineitem,orders,customer}.csv`,
+copied by `tests/golden/make_tpch_answers_golden.py`), and — end to end — by the oracle's Q1 / Q3
+over `table(0.1)` reproducing the reference's pinned answers digit for digit.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pyarrow as pa
+
+M = 2147483647
+A = 16807
+# driver.c Seed[]: (initial value, per-row boundary)
+O_ODATE_SD = (1066728069, 1)
+O_CKEY_SD = (851767375, 1)
+O_LCNT_SD = (1434868289, 1)
+L_QTY_SD = (209208115, 7)
+L_DCNT_SD = (554590007, 7)
+L_TAX_SD = (721958466, 7)
+L_PKEY_SD = (1808217256, 7)
+L_SDTE_SD = (1769349045, 7)
+L_CDTE_SD = (904914315, 7)
+L_RDTE_SD = (373135028, 7)
+L_RFLG_SD = (717419739, 7)
+C_MSEG_SD = (1140279430, 1)
+O_PRIO_SD = (591449447, 1)
+C_NTRG_SD = (1489529863, 1)
+S_NTRG_SD = (110356601, 1)
+L_SHIP_SD = (1371272478, 7)
+L_SMODE_SD = (675466456, 7)
+L_SKEY_SD = (2095021727, 7)
+
+STARTDATE_EPOCH = 8035          # 1992-01-01 as days since 1970-01-01 (dss.h STARTDATE 92001)
+O_ODATE_SPAN = 2557 - (121 + 30) - 1   # O_ODATE_MAX - O_ODATE_MIN (dss.h TOTDATE, L_SDTE_MAX, L_RDTE_MAX)
+CURRENTDATE_EPOCH = 9298        # 1995-06-17 (dss.h CURRENTDATE 95168)
+CUST_MORTALITY = 3
+DBGEN_SEGMENTS = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"]   # dists.dss msegmnt
+PRIORITIES = ["1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"]                # dists.dss o_oprio
+SHIP_MODES = ["REG AIR", "AIR", "RAIL", "TRUCK", "MAIL", "FOB", "SHIP"]                   # dists.dss smode
+SHIP_INSTRUCT = ["DELIVER IN PERSON", "COLLECT COD", "TAKE BACK RETURN", "NONE"]          # dists.dss instruct
+SUPP_PER_PART = 4
+# dists.dss nations (name, region) and regions
+NATIONS = [("ALGERIA", 0), ("ARGENTINA", 1), ("BRAZIL", 1), ("CANADA", 1), ("EGYPT", 4), ("ETHIOPIA", 0), ("FRANCE", 3), ("GERMANY", 3),
+           ("INDIA", 2), ("INDONESIA", 2), ("IRAN", 4), ("IRAQ", 4), ("JAPAN", 2), ("JORDAN", 4), ("KENYA", 0), ("MOROCCO", 0),
+           ("MOZAMBIQUE", 0), ("PERU", 1), ("CHINA", 2), ("ROMANIA", 3), ("SAUDI ARABIA", 4), ("VIETNAM", 2), ("RUSSIA", 3),
+           ("UNITED KINGDOM", 3), ("UNITED STATES", 1)]
+REGIONS = ["AFRICA", "AMERICA", "ASIA", "EUROPE", "MIDDLE EAST"]
+
+
+def _powers(base: int, n: int) -> np.ndarray:
+    """[base^0, base^1, ..., base^(n-1)] mod M, built by doubling (products stay below 2^62)"""
+    out = np.empty(max(n, 1), dtype=np.uint64)
+    out[0] = 1
+    have, step = 1, base % M
+    while have < n:
+        take = min(have, n - have)
+        out[have:have + take] = out[:take] * np.uint64(step) % np.uint64(M)
+        have += take
+        step = step * step % M
+    return out[:n]
+
+
+def _row_starts(sd, n_rows: int) -> np.ndarray:
+    """stream state at the start of rows 0..n_rows-1 (row_stop advances every stream to its boundary)"""
+    seed, boundary = sd
+    return _powers(pow(A, boundary, M), n_rows) * np.uint64(seed) % np.uint64(M)
+
+
+def _unif(state: np.ndarray, lo: int, hi: int) -> np.ndarray:
+    """UnifInt on already-advanced states: the double arithmetic is the same two IEEE operations as rnd.c"""
+    return lo + (state.astype(np.float64) / 2147483647.0 * float(hi - lo + 1)).astype(np.int64)
+
+
+def _draw(sd, n_rows: int, lo: int, hi: int) -> np.ndarray:
+    """one draw per row from a boundary-1 stream"""
+    return _unif(_row_starts(sd, n_rows) * np.uint64(A) % np.uint64(M), lo, hi)
+
+
+def _draw_lines(sd, order_of_line: np.ndarray, call_in_order: np.ndarray, n_orders: int, lo: int, hi: int) -> np.ndarray:
+    """draw number `call_in_order` (0-based) of each line's order from a boundary-7 stream"""
+    starts = _row_starts(sd, n_orders)
+    apow = _powers(A, 8)
+    return _unif(starts[order_of_line] * apow[call_in_order + 1] % np.uint64(M), lo, hi)
+
+
+def counts(sf: float):
+    """dbgen scales the table bases for sf < 1 with integer arithmetic (driver.c: base * int(1000 sf) / 1000)"""
+    if sf < 1:
+        k = int(1000 * sf)
+        return dict(customer=150000 * k // 1000, orders=1500000 * k // 1000, part=200000 * k // 1000)
+    k = int(sf)
+    return dict(customer=150000 * k, orders=1500000 * k, part=200000 * k)
+
+
+def order_keys(n: int) -> np.ndarray:
+    i = np.arange(1, n + 1, dtype=np.int64)        # build.c mk_sparse: SPARSE_BITS 2, SPARSE_KEEP 3
+    return ((i >> 3) << 5) + (i & 7)
+
+
+def retail_price(partkey: np.ndarray) -> np.ndarray:
+    """build.c rpb_routine, in cents"""
+    return 90000 + (partkey // 10) % 20001 + (partkey % 1000) * 100
+
+
+def _decimal(cents: np.ndarray, precision: int = 15, scale: int = 2) -> pa.Array:
+    v = cents.astype(np.int64)
+    buf = np.empty((len(v), 2), dtype=np.int64)
+    buf[:, 0] = v
+    buf[:, 1] = v >> 63
+    return pa.Array.from_buffers(pa.decimal128(precision, scale), len(v), [None, pa.py_buffer(buf.tobytes())])
+
+
+def _strings(codes: np.ndarray, names, how: str) -> pa.Array:
+    """a pick_str column: `codes` index `names` (the distribution's own order)"""
+    if how == "utf8":
+        return pa.array(np.array(names, dtype=object)[codes], pa.string())
+    order = sorted(names)                              # ascending dictionary: ORDER BY on the indices is ORDER BY on the strings
+    remap = np.array([order.index(s) for s in names], dtype=np.uint8)
+    if how == "dictionary":
+        return pa.DictionaryArray.from_arrays(pa.array(remap[codes], pa.uint8()), pa.array(order, pa.string()))
+    return pa.array(remap[codes], pa.uint8())          # "codes": index into sorted(names)
+
+
+def _flag(ascii_codes: np.ndarray, how: str) -> pa.Array:
+    """a one-character column held as its ASCII byte"""
+    if how == "codes":
+        return pa.array(ascii_codes, pa.uint8())
+    letters = sorted(set(int(x) for x in np.unique(ascii_codes)))
+    return _strings(np.searchsorted(letters, ascii_codes), [chr(v) for v in letters], how)
+
+
+def tables(sf: float, strings: str = "codes"):
+    """(customer, orders, lineitem) restricted to the columns the pinned queries read, typed as
+    `benchmarks/src/tpch/mod.rs:93-122`.  strings: "codes" = the device generator's layout
+    (l_returnflag / l_linestatus as their ASCII byte, the other string columns as UInt8 indices into the
+    sorted value list), "dictionary" = Arrow Dictionary(UInt8, Utf8) with ascending dictionaries,
+    "utf8" = plain strings (CPU checks only)."""
+    n = counts(sf)
+    nc, no, npart = n["customer"], n["orders"], n["part"]
+    nsupp = npart // 20
+    # ---- customer (build.c mk_cust)
+    seg = _draw(C_MSEG_SD, nc, 1, 5) - 1              # pick_str over five weight-1 entries
+    names = [f"Customer#{i:09d}" for i in range(1, nc + 1)]        # build.c mk_cust: C_NAME_FMT "%s%09ld"
+    if strings == "utf8":
+        c_name = pa.array(names, pa.string())
+    elif strings == "dictionary":
+        c_name = pa.DictionaryArray.from_arrays(pa.array(np.arange(nc, dtype=np.int32)), pa.array(names, pa.string()))
+    else:
+        c_name = pa.array(np.arange(nc, dtype=np.int32))
+    customer = pa.table({"c_custkey": pa.array(np.arange(1, nc + 1, dtype=np.int64)), "c_name": c_name, "c_nationkey": pa.array(_draw(C_NTRG_SD, nc, 0, 24)),
+                         "c_mktsegment": _strings(seg, DBGEN_SEGMENTS, strings)})
+    # ---- orders (build.c mk_order)
+    okey = order_keys(no)
+    ckey = _draw(O_CKEY_SD, no, 1, nc)
+    dead = ckey % CUST_MORTALITY == 0                 # "while (custkey % 3 == 0) custkey += delta": one step of +1
+    ckey = np.where(dead, np.minimum(ckey + 1, nc), ckey)
+    dead = ckey % CUST_MORTALITY == 0                 # (only when the +1 was clamped at the maximum: delta flips to -1)
+    ckey = np.where(dead, ckey - 1, ckey)
+    odate = _draw(O_ODATE_SD, no, 0, O_ODATE_SPAN)    # days after 1992-01-01
+    prio = _draw(O_PRIO_SD, no, 1, 5) - 1
+    lines = _draw(O_LCNT_SD, no, 1, 7)
+    # ---- lineitem
+    oi = np.repeat(np.arange(no, dtype=np.int64), lines)
+    first = np.cumsum(lines) - lines
+    k = np.arange(len(oi), dtype=np.int64) - first[oi]      # line number - 1 = draw index in the order's 7-draw window
+    qty = _draw_lines(L_QTY_SD, oi, k, no, 1, 50)
+    disc = _draw_lines(L_DCNT_SD, oi, k, no, 0, 10)
+    tax = _draw_lines(L_TAX_SD, oi, k, no, 0, 8)
+    instruct = _draw_lines(L_SHIP_SD, oi, k, no, 1, 4) - 1
+    smode = _draw_lines(L_SMODE_SD, oi, k, no, 1, 7) - 1
+    pkey = _draw_lines(L_PKEY_SD, oi, k, no, 1, npart)
+    snum = _draw_lines(L_SKEY_SD, oi, k, no, 0, 3)
+    skey = (pkey + snum * (nsupp // SUPP_PER_PART + (pkey - 1) // nsupp)) % nsupp + 1     # dss.h PART_SUPP_BRIDGE
+    sdate = odate[oi] + _draw_lines(L_SDTE_SD, oi, k, no, 1, 121)
+    cdate = odate[oi] + _draw_lines(L_CDTE_SD, oi, k, no, 30, 90)
+    rdate = sdate + _draw_lines(L_RDTE_SD, oi, k, no, 1, 30)
+    returned = rdate + STARTDATE_EPOCH <= CURRENTDATE_EPOCH
+    # L_RFLG_SD is only drawn for received lines: the draw index is the count of earlier received lines of the order
+    before = np.cumsum(returned) - returned
+    r_idx = before - before[first[oi]]
+    pick = _draw_lines(L_RFLG_SD, oi, r_idx, no, 1, 2)
+    rflag = np.where(returned, np.where(pick == 1, ord("R"), ord("A")), ord("N")).astype(np.uint8)
+    lstatus = np.where(sdate + STARTDATE_EPOCH <= CURRENTDATE_EPOCH, ord("F"), ord("O")).astype(np.uint8)
+    eprice = retail_price(pkey) * qty
+    # o_totalprice += ((eprice * (100 - discount)) / PENNIES) * (100 + tax) / PENNIES, integer division (build.c mk_order)
+    per_line = (eprice * (100 - disc)) // 100 * (100 + tax) // 100
+    total = np.add.reduceat(per_line, first) if len(per_line) else np.zeros(0, dtype=np.int64)
+    orders = pa.table({"o_orderkey": pa.array(okey), "o_custkey": pa.array(ckey), "o_totalprice": _decimal(total),
+                       "o_orderdate": pa.array((odate + STARTDATE_EPOCH).astype(np.int32), pa.date32()),
+                       "o_orderpriority": _strings(prio, PRIORITIES, strings),
+                       "o_shippriority": pa.array(np.zeros(no, dtype=np.int32))})
+    lineitem = pa.table({
+        "l_orderkey": pa.array(okey[oi]), "l_partkey": pa.array(pkey), "l_suppkey": pa.array(skey), "l_linenumber": pa.array((k + 1).astype(np.int32)),
+        "l_quantity": _decimal(qty * 100), "l_extendedprice": _decimal(eprice),
+        "l_discount": _decimal(disc), "l_tax": _decimal(tax), "l_returnflag": _flag(rflag, strings), "l_linestatus": _flag(lstatus, strings),
+        "l_shipdate": pa.array((sdate + STARTDATE_EPOCH).astype(np.int32), pa.date32()),
+        "l_commitdate": pa.array((cdate + STARTDATE_EPOCH).astype(np.int32), pa.date32()),
+        "l_receiptdate": pa.array((rdate + STARTDATE_EPOCH).astype(np.int32), pa.date32()),
+        "l_shipinstruct": _strings(instruct, SHIP_INSTRUCT, strings), "l_shipmode": _strings(smode, SHIP_MODES, strings)})
+    return customer, orders, lineitem
+
+
+def supplier(sf: float) -> pa.Table:
+    """build.c mk_supp: the key and nation columns"""
+    ns = counts(sf)["part"] // 20
+    return pa.table({"s_suppkey": pa.array(np.arange(1, ns + 1, dtype=np.int64)), "s_nationkey": pa.array(_draw(S_NTRG_SD, ns, 0, 24))})
+
+
+def nation(strings: str = "codes") -> pa.Table:
+    names = [n for n, _ in NATIONS]
+    return pa.table({"n_nationkey": pa.array(np.arange(25, dtype=np.int64)), "n_name": _strings(np.arange(25), names, strings),
+                     "n_regionkey": pa.array(np.array([r for _, r in NATIONS], dtype=np.int64))})
+
+
+def region(strings: str = "codes") -> pa.Table:
+    return pa.table({"r_regionkey": pa.array(np.arange(5, dtype=np.int64)), "r_name": _strings(np.arange(5), REGIONS, strings)})

@@ -1,0 +1,152 @@
+"""TEST INFRASTRUCTURE: runs a physical plan (datafusion_amd.physical_plan node tree, used here purely as a data
+structure) with the CPU oracle's operators, so that ONE statement of a reference plan
+(datafusion_amd/tpch_plans.py) is executed twice: by the product on the GPU and by the oracle here.
+
+Leaves hold pyarrow Tables.  The oracle has no string type: dictionary-encoded string columns are carried as their
+index columns plus a {column name: dictionary} side table, string literals are bound to indices exactly as the product
+binds them (expr.bind_string_literals: `=` / `!=` only; an absent string compares as index -1), and dictionaries are
+re-attached to the same-named columns of the result.  The GPU-specific nodes are interpreted by their definition:
+GpuFusedAggregateExec = FilterExec -> AggregateExec over the inlined expressions, GpuHashJoinExec = FilterExec on the
+probe side -> HashJoinExec, which checks on the CPU that GpuOffloadRule's rewrites preserve the plan's meaning.
+"""
+from __future__ import annotations
+
+import pyarrow as pa
+
+from datafusion_amd import expr as X
+from datafusion_amd import physical_plan as P
+from oracle import oracle
+
+
+class Rel:
+    """a table of oracle-typed columns + the dictionaries of its dictionary-encoded columns"""
+
+    def __init__(self, table: pa.Table, dicts: dict):
+        self.table, self.dicts = table, {k: v for k, v in dicts.items() if k in table.column_names}
+
+
+def _encode(table: pa.Table) -> Rel:
+    cols, dicts = [], {}
+    for name, c in zip(table.column_names, table.columns):
+        if pa.types.is_dictionary(c.type):
+            arr = c.combine_chunks()
+            dicts[name] = arr.dictionary.to_pylist()
+            cols.append(arr.indices)
+        else:
+            cols.append(c)
+    return Rel(pa.Table.from_arrays(cols, names=table.column_names), dicts)
+
+
+def decode(rel: Rel) -> pa.Table:
+    cols = []
+    for name, c in zip(rel.table.column_names, rel.table.columns):
+        if name in rel.dicts:
+            c = pa.DictionaryArray.from_arrays(c.combine_chunks(), pa.array(rel.dicts[name], pa.string()))
+        cols.append(c)
+    return pa.Table.from_arrays(cols, names=rel.table.column_names)
+
+
+def _expr(e, rel: Rel):
+    """product PhysicalExpr -> oracle tuple AST, string literals bound to dictionary indices"""
+    if isinstance(e, X.Column):
+        return ("col", e.name)
+    if isinstance(e, X.Literal):
+        return ("lit", e.value, e.type)
+    if isinstance(e, X.CastExpr):
+        return ("cast", _expr(e.expr, rel), e.cast_type)
+    if isinstance(e, X.BinaryExpr):
+        if e.op in ("=", "!="):
+            for a, b in ((e.left, e.right), (e.right, e.left)):
+                if isinstance(a, X.Column) and isinstance(b, X.Literal) and pa.types.is_string(b.type):
+                    itype = rel.table.schema.field(a.name).type
+                    values = rel.dicts[a.name]
+                    if b.value in values:
+                        return ("bin", e.op, ("col", a.name), ("lit", values.index(b.value), itype))
+                    return ("bin", e.op, ("cast", ("col", a.name), pa.int64()), ("lit", -1, pa.int64()))
+        return ("bin", e.op, _expr(e.left, rel), _expr(e.right, rel))
+    if isinstance(e, X.IsNullExpr):
+        return ("is_null", _expr(e.arg, rel))
+    if isinstance(e, X.IsNotNullExpr):
+        return ("not", ("is_null", _expr(e.arg, rel)))
+    if isinstance(e, X.NotExpr):
+        return ("not", _expr(e.arg, rel))
+    raise TypeError(e)
+
+
+def _renamed_dicts(rel: Rel, pairs):
+    """dictionaries follow plain column references through (expr, name) lists"""
+    return {n: rel.dicts[e.name] for e, n in pairs if isinstance(e, X.Column) and e.name in rel.dicts}
+
+
+def _filter(rel: Rel, predicate, projection) -> Rel:
+    return Rel(oracle.filter(rel.table, _expr(predicate, rel), projection), rel.dicts)
+
+
+def _aggregate(rel: Rel, mode, group_by, aggs) -> Rel:
+    final = mode in ("Final", "FinalPartitioned")
+    gb = [(None if final else _expr(e, rel), n) for e, n in group_by]
+    ag = [(f, None if (e is None or final) else _expr(e, rel), n) for f, e, n in aggs]
+    out = oracle.aggregate(rel.table, gb, ag, mode)
+    if final:   # group columns are the first columns of the partial state, by position
+        dicts = {n: rel.dicts[rel.table.column_names[i]] for i, (_, n) in enumerate(group_by) if rel.table.column_names[i] in rel.dicts}
+    else:
+        dicts = _renamed_dicts(rel, group_by)
+    return Rel(out, dicts)
+
+
+def _join(node, left: Rel, right: Rel) -> Rel:
+    out = oracle.hash_join(left.table, right.table, node.on, node.join_type, node.null_equality, join_filter=_join_filter(node), null_aware=node.null_aware)
+    dicts = dict(right.dicts)
+    dicts.update(left.dicts)
+    rel = Rel(out, dicts)
+    if node.projection:
+        bc, pc = node.projection
+        names = []
+        if node.join_type not in ("RightSemi", "RightAnti", "RightMark"):
+            names += list(left.table.column_names if bc is None else bc)
+        if node.join_type not in ("LeftSemi", "LeftAnti", "LeftMark"):
+            names += list(right.table.column_names if pc is None else pc)
+        if node.join_type in ("LeftMark", "RightMark"):
+            names.append("mark")
+        rel = Rel(out.select(names), dicts)
+    return rel
+
+
+def _join_filter(node):
+    if node.filter is None:
+        return None
+    e, cols = node.filter
+    return (_expr(e, Rel(pa.table({}), {})), cols)
+
+
+def run(plan) -> Rel:
+    if isinstance(plan, P.MemoryExec):
+        t = plan.table if plan.projection is None else plan.table.select(plan.projection)
+        return _encode(t)
+    if isinstance(plan, (P.CoalesceBatchesExec, P.RepartitionExec, P.CoalescePartitionsExec, P.SortPreservingMergeExec)):
+        return run(plan.input)          # one partition: bookkeeping only
+    if isinstance(plan, P.FilterExec):
+        return _filter(run(plan.input), plan.predicate, plan.projection)
+    if isinstance(plan, P.ProjectionExec):
+        rel = run(plan.input)
+        return Rel(oracle.project(rel.table, [(_expr(e, rel), n) for e, n in plan.exprs]), _renamed_dicts(rel, plan.exprs))
+    if isinstance(plan, P.GpuHashJoinExec):
+        probe = _filter(run(plan.right), plan.probe_predicate, None)
+        return _join(plan, run(plan.left), probe)
+    if isinstance(plan, P.HashJoinExec):
+        return _join(plan, run(plan.left), run(plan.right))
+    if isinstance(plan, P.GpuFusedAggregateExec):
+        rel = run(plan.input)
+        if plan.predicate is not None:
+            rel = _filter(rel, plan.predicate, None)
+        return _aggregate(rel, plan.mode, plan.group_by, plan.aggr_expr)
+    if isinstance(plan, P.AggregateExec):
+        return _aggregate(run(plan.input), plan.mode, plan.group_by, plan.aggr_expr)
+    if isinstance(plan, P.SortExec):
+        rel = run(plan.input)
+        return Rel(oracle.sort(rel.table, plan.expr, plan.fetch), rel.dicts)
+    raise TypeError(f"no oracle interpretation of {plan.name()}")
+
+
+def collect(plan) -> pa.Table:
+    return decode(run(plan))

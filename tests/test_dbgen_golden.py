@@ -1,0 +1,73 @@
+"""oracle/dbgen.py against the rows of dbgen's own SF 1 output that the reference carries as test fixtures
+(datafusion/core/tests/tpch-csv/*.csv, copied into tests/golden/tpch_answers.json): every generated column of every
+sample row — keys, the sparse order keys, quantities, prices, discounts, taxes, the three dates, return flag / line
+status rules, ship mode / instructions, order priority, total price, customer / supplier nations, market segment."""
+import functools
+from decimal import Decimal
+
+import pyarrow as pa
+
+from tests.util import load_golden
+
+GOLD = load_golden("tpch_answers.json")["sf1_sample"]
+
+
+@functools.lru_cache(maxsize=None)
+def sf1():
+    from oracle import dbgen
+    c, o, l = dbgen.tables(1, "utf8")
+    return dict(customer=c, orders=o, lineitem=l, supplier=dbgen.supplier(1), nation=dbgen.nation("utf8"), region=dbgen.region("utf8"))
+
+
+def _same(v, text):
+    if isinstance(v, (int, Decimal)):
+        return Decimal(v) == Decimal(text)
+    return str(v) == text
+
+
+def _check(table_name, key_cols):
+    t = sf1()[table_name]
+    g = GOLD[table_name]
+    cols = g["columns"]
+    index = {tuple(str(t.column(k)[i].as_py()) for k in key_cols): i for i in _candidate_rows(t, key_cols, g)}
+    assert len(g["rows"]) >= 1
+    for row in g["rows"]:
+        want = dict(zip(cols, row))
+        i = index[tuple(want[k] for k in key_cols)]
+        got = {c: t.column(c)[i].as_py() for c in cols}
+        assert all(_same(got[c], want[c]) for c in cols), (table_name, got, want)
+
+
+def _candidate_rows(t, key_cols, g):
+    """row numbers of the sample's keys (the samples are the first rows of each table, except supplier 8136)"""
+    import numpy as np
+    first = t.column(key_cols[0]).to_numpy()
+    wanted = np.array(sorted({int(r[g["columns"].index(key_cols[0])]) for r in g["rows"]}))
+    return np.nonzero(np.isin(first, wanted))[0].tolist()
+
+
+def test_lineitem_rows():
+    _check("lineitem", ["l_orderkey", "l_linenumber"])
+
+
+def test_orders_rows():
+    _check("orders", ["o_orderkey"])
+
+
+def test_customer_rows():
+    _check("customer", ["c_custkey"])
+
+
+def test_supplier_nation_region_rows():
+    _check("supplier", ["s_suppkey"])
+    _check("nation", ["n_nationkey"])
+    _check("region", ["r_regionkey"])
+
+
+def test_cardinalities_and_scaling():
+    from oracle import dbgen
+    assert dbgen.counts(0.1) == dict(customer=15000, orders=150000, part=20000)
+    assert dbgen.counts(1) == dict(customer=150000, orders=1500000, part=200000)
+    t = sf1()
+    assert t["lineitem"].num_rows == 6001215 and t["orders"].num_rows == 1500000     # the TPC-H specification's SF 1 cardinalities
+    assert t["lineitem"].schema.field("l_extendedprice").type == pa.decimal128(15, 2)

@@ -13,39 +13,16 @@ pytestmark = pytest.mark.gpu
 
 
 def q1_plan(lineitem):
-    """q1.slt.part:50-58 (4 target partitions in the reference's file; the partition count only shows in RepartitionExec)"""
-    from datafusion_amd import physical_plan as P, queries as Q
-    from datafusion_amd.expr import col, lit
-    scan = P.MemoryExec(lineitem, "lineitem")
-    f = P.FilterExec(col("l_shipdate") <= lit(Q.DATE_Q1, pa.date32()), scan,
-                     projection=["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus"])
-    proj = P.ProjectionExec([(col("l_extendedprice") * (Q.ONE - col("l_discount")), "__common_expr_1"), (col("l_quantity"), "l_quantity"),
-                             (col("l_extendedprice"), "l_extendedprice"), (col("l_discount"), "l_discount"), (col("l_tax"), "l_tax"),
-                             (col("l_returnflag"), "l_returnflag"), (col("l_linestatus"), "l_linestatus")], P.CoalesceBatchesExec(f))
-    partial = P.AggregateExec("Partial", Q.Q1_GROUP_BY, Q.q1_aggs(), proj)
-    rep = P.CoalesceBatchesExec(P.RepartitionExec(partial, ["l_returnflag", "l_linestatus"], 4))
-    final = P.AggregateExec("FinalPartitioned", Q.Q1_GROUP_BY, Q.q1_aggs(), rep)
-    return P.SortExec([("l_returnflag", False, False), ("l_linestatus", False, False)], final)
+    """q1.slt.part:50-58 — one statement of the plan for the product and the oracle: datafusion_amd/tpch_plans.py"""
+    from datafusion_amd import tpch_plans as T
+    return T.q1_plan(lineitem)
 
 
 def q3_plan(customer, orders, lineitem):
-    """q3.slt.part:61-76"""
-    from datafusion_amd import physical_plan as P, queries as Q
-    from datafusion_amd.expr import col, lit
-    c = P.RepartitionExec(P.CoalesceBatchesExec(P.FilterExec(col("c_mktsegment").eq(lit(Q.SEGMENT_BUILDING, pa.uint8())), P.MemoryExec(customer, "customer"),
-                                                              projection=["c_custkey"])), ["c_custkey"], 4)
-    o = P.RepartitionExec(P.CoalesceBatchesExec(P.FilterExec(col("o_orderdate") < lit(Q.DATE_Q3, pa.date32()), P.MemoryExec(orders, "orders"),
-                                                              projection=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])), ["o_custkey"], 4)
-    semi = P.HashJoinExec(P.CoalesceBatchesExec(c), P.CoalesceBatchesExec(o), [("c_custkey", "o_custkey")], "RightSemi",
-                          projection=(None, ["o_orderkey", "o_orderdate", "o_shippriority"]))
-    l = P.RepartitionExec(P.CoalesceBatchesExec(P.FilterExec(col("l_shipdate") > lit(Q.DATE_Q3, pa.date32()), P.MemoryExec(lineitem, "lineitem"),
-                                                              projection=["l_orderkey", "l_extendedprice", "l_discount"])), ["l_orderkey"], 4)
-    j = P.HashJoinExec(P.CoalesceBatchesExec(P.RepartitionExec(P.CoalesceBatchesExec(semi), ["o_orderkey"], 4)), P.CoalesceBatchesExec(l),
-                       [("o_orderkey", "l_orderkey")], "Inner", projection=(["o_orderdate", "o_shippriority"], ["l_orderkey", "l_extendedprice", "l_discount"]))
-    gb = [(col("l_orderkey"), "l_orderkey"), (col("o_orderdate"), "o_orderdate"), (col("o_shippriority"), "o_shippriority")]
-    agg = P.AggregateExec("SinglePartitioned", gb, [("sum", col("l_extendedprice") * (Q.ONE - col("l_discount")), "revenue")], P.CoalesceBatchesExec(j))
-    top = P.SortExec(Q.Q3_SORT, agg, fetch=10)
-    return P.ProjectionExec([(col(n), n) for n in ["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]], top)
+    """q3.slt.part:61-76 over the device generator's layout (c_mktsegment as a UInt8 code)"""
+    from datafusion_amd import queries as Q, tpch_plans as T
+    from datafusion_amd.expr import lit
+    return T.q3_plan(customer, orders, lineitem, segment_literal=lit(Q.SEGMENT_BUILDING, pa.uint8()))
 
 
 def names(plan):

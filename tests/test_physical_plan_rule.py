@@ -12,8 +12,8 @@ class StubTable:
 def test_q1_plan_rewrite_shape_and_display():
     from datafusion_amd import physical_plan as P
     plan = q1_plan(StubTable(6_001_215))
-    assert names(plan) == ["SortExec", "AggregateExec", "CoalesceBatchesExec", "RepartitionExec", "AggregateExec", "ProjectionExec", "CoalesceBatchesExec",
-                           "FilterExec", "MemoryExec"]
+    assert names(plan) == ["SortPreservingMergeExec", "SortExec", "AggregateExec", "CoalesceBatchesExec", "RepartitionExec", "AggregateExec", "ProjectionExec",
+                           "CoalesceBatchesExec", "FilterExec", "MemoryExec"]
     rule = P.GpuOffloadRule()
     opt = rule.optimize(plan)
     assert names(opt) == ["SortExec", "AggregateExec", "GpuFusedAggregateExec", "MemoryExec"]
@@ -24,7 +24,8 @@ def test_q1_plan_rewrite_shape_and_display():
     assert "__common_expr_1" not in txt.split("GpuFusedAggregateExec")[1].split("\n")[0].split("aggr=")[0]
     assert "GpuFusedAggregateExec: mode=Partial, predicate=(l_shipdate@None <= " in txt
     # with more than one GPU the RepartitionExec stays (it becomes the RCCL exchange)
-    assert "RepartitionExec" in names(P.GpuOffloadRule(world_size=8).optimize(plan))
+    multi = names(P.GpuOffloadRule(world_size=8).optimize(plan))
+    assert "RepartitionExec" in multi and multi[0] == "SortPreservingMergeExec"
 
 
 def test_q3_plan_rewrite_shape():
