@@ -47,7 +47,7 @@ struct JoinTable {
   int kind = 0;  // TableKind
   bool keys_unique = true;
   bool force_collisions = false;
-  int probe_mode = 0;  // 0 auto, 1 two-pass, 2 single-pass
+  int probe_mode = 0;  // dfgpu_join_options.probe_mode
   BufPtr heads;  // u32: ArrayMap data[] or hash heads[]
   BufPtr next;   // u32 per build row (null when array_map && unique)
   uint64_t am_offset = 0, am_size = 0;
@@ -1078,8 +1078,10 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   for (int c : pout) out_row_bytes += type_width(probe.cols[c].field.type);
   const bool fused_ok = np < (1ll << 40) && !payload_nullable && (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS &&
                         bout.size() + pout.size() > 0 && (fast_inner || probe_side_only);
-  // probe_mode: 0 auto = two passes (ordered, exact allocation); 2 / 3 = single pass ordered / unordered
-  const bool use_fused = fused_ok && np > 0 && (jt.probe_mode == 2 || jt.probe_mode == 3);
+  // probe_mode: 0 auto = two passes (ordered, exact allocation); 2 / 3 = single pass ordered / unordered (an error when
+  // not applicable); 4 = a planner's hint "no ancestor needs the probe order": single pass unordered when applicable,
+  // the general path otherwise
+  const bool use_fused = fused_ok && np > 0 && (jt.probe_mode == 2 || jt.probe_mode == 3 || jt.probe_mode == 4);
   DFGPU_CHECK(!((jt.probe_mode == 2 || jt.probe_mode == 3) && !fused_ok),
               "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
   // A probe-side row mask is applied in place by the at-most-one-match probes (single pass, or lookup -> scan ->
@@ -1099,7 +1101,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   }
 
   if (use_fused_now) {
-    const bool ordered = jt.probe_mode != 3;
+    const bool ordered = jt.probe_mode == 2;
     const int64_t tile_words = (int64_t)FUSED_W * (BLOCK / WAVE);
     const int64_t n_tiles = (n_words + tile_words - 1) / tile_words;
     BufPtr state = ordered ? make_zero_buf((size_t)n_tiles * 8) : nullptr;

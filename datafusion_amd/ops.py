@@ -19,7 +19,7 @@ AGG_MODES = {"Partial": 0, "Final": 1, "FinalPartitioned": 2, "Single": 3, "Sing
 AGG_FUNCS = {"sum": 0, "min": 1, "max": 2, "count": 3, "avg": 4}
 GPU_MIN_KEY_DENSITY = 1.0 / 64.0      # DFGPU_DEFAULT_MIN_KEY_DENSITY (include/dfgpu.h); the reference's CPU default is 0.15
 TABLE_MODES = {"auto": 0, "hash_map": 1, "array_map": 2, "rank_map": 3}
-PROBE_MODES = {"auto": 0, "two_pass": 1, "single_pass_ordered": 2, "single_pass_unordered": 3}
+PROBE_MODES = {"auto": 0, "two_pass": 1, "single_pass_ordered": 2, "single_pass_unordered": 3, "order_not_needed": 4}
 
 
 def _ints(values):

@@ -382,7 +382,8 @@ class GpuOffloadRule:
     SessionStateBuilder::with_physical_optimizer_rule (core/src/execution/session_state.rs:1407-1415) so that it
     runs after the built-in rules have fixed distribution, ordering and join sides.  `unordered_probe=True` lets
     joins whose parent does not need the probe-side order (an aggregate or a repartition) take the single-pass
-    unordered probe — the rule knows the parent because it rewrites bottom-up and fixes the child when it
+    unordered probe where it applies (probe_mode "order_not_needed": at most one match per probe row, non-nullable
+    payload; the library falls back to the general path otherwise) — the rule knows the parent because it rewrites bottom-up and fixes the child when it
     visits the parent."""
 
     def __init__(self, world_size: int = 1, unordered_probe: bool = True):
@@ -417,7 +418,7 @@ class GpuOffloadRule:
         if isinstance(node, (RepartitionExec, CoalescePartitionsExec, SortPreservingMergeExec)) and self.world_size == 1:
             return node.input                                  # one partition: nothing to exchange, gather or merge
         if isinstance(node, HashJoinExec) and not isinstance(node, GpuHashJoinExec):
-            probe_mode = ops.PROBE_MODES["single_pass_unordered"] if (self.unordered_probe and not parent_needs_order and
+            probe_mode = ops.PROBE_MODES["order_not_needed"] if (self.unordered_probe and not parent_needs_order and
                                                                       node.join_type in ("Inner", "RightSemi", "RightAnti")) else node.probe_mode
             node = HashJoinExec(node.left, node.right, node.on, node.join_type, node.projection, node.null_equality,
                                 node.probe_mode if node.filter is not None else probe_mode, node.filter, node.null_aware)

@@ -256,6 +256,7 @@ typedef struct dfgpu_join_options {
    *   3 = single pass, UNORDERED: probe order inside 2048-row tiles, tiles in arbitrary order.  For
    *       plans where no ancestor needs the probe-side ordering (HashJoinExec::maintains_input_order,
    *       joins/hash_join/exec.rs:1024-1040,1352, would have to report false for the shim node).
+   *   4 = order not needed (a planner's hint): 3 when it is applicable, else the ordered / general path.
    * Modes 2/3 allocate the output for the probe-row upper bound and fail if they are not applicable. */
   int32_t probe_mode;
   /* HashJoinExec::null_aware (hash_join/exec.rs:429-455,786): NOT IN semantics for anti joins on a single key column.

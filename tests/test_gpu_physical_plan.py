@@ -56,7 +56,7 @@ def test_q3_reference_plan_through_the_rule(sf):
     assert ns.count("GpuHashJoinExec") == 2 and "RepartitionExec" not in ns and "CoalesceBatchesExec" not in ns, P.displayable(opt)
     assert ns.count("FilterExec") == 1                          # only the customer filter (a build side) stays a separate operator
     joins = [n for n in _walk(opt) if isinstance(n, P.HashJoinExec)]
-    assert all(j.probe_mode == ops.PROBE_MODES["single_pass_unordered"] for j in joins)   # both feed an aggregate / another join's build side
+    assert all(j.probe_mode == ops.PROBE_MODES["order_not_needed"] for j in joins)   # both feed an aggregate / another join's build side
     exp, _ = oracle_q3(tpch.customer(sf), tpch.orders(sf), tpch.lineitem(sf))
     assert_tables_equal(P.collect(opt).to_arrow(), exp, ordered=True)
     assert_tables_equal(P.collect(plan).to_arrow(), exp, ordered=True)

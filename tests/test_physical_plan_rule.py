@@ -37,7 +37,7 @@ def test_q3_plan_rewrite_shape():
     inner = opt.children()[0].children()[0].children()[0]
     semi = inner.children()[0]
     assert inner.join_type == "Inner" and semi.join_type == "RightSemi"
-    assert inner.probe_mode == semi.probe_mode == ops.PROBE_MODES["single_pass_unordered"]
+    assert inner.probe_mode == semi.probe_mode == ops.PROBE_MODES["order_not_needed"]
     assert repr(inner.probe_predicate).startswith("(l_shipdate@None > ") and repr(semi.probe_predicate).startswith("(o_orderdate@None < ")
     # ordered probes when the rule is told not to reorder
     keep = P.GpuOffloadRule(unordered_probe=False).optimize(plan)
