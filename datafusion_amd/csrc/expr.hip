@@ -55,6 +55,16 @@ static dfgpu_field node_type(const dfgpu_expr& e, int idx, const Table& in) {
     case DFGPU_EXPR_EQ: case DFGPU_EXPR_NE: case DFGPU_EXPR_LT: case DFGPU_EXPR_LE: case DFGPU_EXPR_GT: case DFGPU_EXPR_GE:
     case DFGPU_EXPR_AND: case DFGPU_EXPR_OR: case DFGPU_EXPR_NOT: case DFGPU_EXPR_IS_NULL: case DFGPU_EXPR_IS_NOT_NULL:
       return mkfield(DFGPU_BOOL);
+    case DFGPU_EXPR_CASE: {
+      DFGPU_CHECK(node_type(e, n.column, in).type == DFGPU_BOOL, "CASE WHEN condition must be Boolean");
+      dfgpu_field t = node_type(e, n.left, in);
+      if (n.right >= 0) {
+        dfgpu_field f = node_type(e, n.right, in);
+        DFGPU_CHECK(same_field_type(t, f), "CASE branch types differ: " + type_name(t) + " vs " + type_name(f) + " (the planner inserts casts)");
+      }
+      t.nullable = 1;
+      return t;
+    }
   }
   throw Error("unsupported expression op " + std::to_string(n.op));
 }
@@ -162,6 +172,26 @@ __global__ __launch_bounds__(BLOCK) void k_kleene(int is_or, const uint64_t* av,
 }
 
 // ------------------------------------------------------------------------------ host
+// CASE WHEN: out[i] = (cond bit i set and valid) ? a : b, values by element width
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_select(const uint64_t* __restrict__ cond, const uint64_t* __restrict__ cond_valid, Operand<T> a, Operand<T> b, int64_t n,
+                                                  T* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint64_t w = cond[i >> 6];
+    if (cond_valid) w &= cond_valid[i >> 6];
+    out[i] = ((w >> (i & 63)) & 1ull) ? a.at(i) : b.at(i);
+  }
+}
+// the same per 64-row word for bit-packed values (Boolean data, validity bitmaps); a / b null = the fill word
+__global__ __launch_bounds__(BLOCK) void k_select_bits(const uint64_t* __restrict__ cond, const uint64_t* __restrict__ cond_valid, const uint64_t* a, uint64_t afill,
+                                                       const uint64_t* b, uint64_t bfill, int64_t n_words, uint64_t* __restrict__ out) {
+  for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * BLOCK) {
+    uint64_t m = cond[w];
+    if (cond_valid) m &= cond_valid[w];
+    out[w] = (m & (a ? a[w] : afill)) | (~m & (b ? b[w] : bfill));
+  }
+}
+
 static i128 pow10_i128(int k) {
   i128 m = 1;
   for (int i = 0; i < k; i++) m *= 10;
@@ -413,11 +443,70 @@ static Datum eval_binary(const dfgpu_expr_node& n, const Datum& a, const Datum& 
   return o;
 }
 
+// CaseExpr, one WHEN (expressions/case.rs `case_when_no_expr`): THEN where the condition is TRUE, ELSE where it is
+// FALSE or NULL
+static Datum eval_case(const Datum& c, const Datum& a, const Datum& b, int64_t nrows) {
+  if (c.scalar) return (!c.scalar_null && (c.lit_lo & 1)) ? a : b;
+  const dfgpu_field f = a.col.field;
+  const uint64_t* cw = c.col.data->as<uint64_t>();
+  const uint64_t* cv = c.col.valid_words();
+  hipStream_t st = rt().stream;
+  const int64_t nw = (nrows + 63) / 64;
+  Datum o;
+  o.col = alloc_column(f, "", nrows);
+  auto bits_of = [](const Datum& d, bool validity, const uint64_t*& p, uint64_t& fill) {
+    p = nullptr;
+    if (validity) {
+      if (d.scalar) fill = d.scalar_null ? 0ull : ~0ull;
+      else { p = d.col.valid_words(); fill = ~0ull; }
+    } else {
+      if (d.scalar) fill = (d.lit_lo & 1) ? ~0ull : 0ull;
+      else p = d.col.data->as<uint64_t>();
+    }
+  };
+  if (nrows) {
+    if (f.type == DFGPU_BOOL) {
+      const uint64_t *pa, *pb;
+      uint64_t fa = 0, fb = 0;
+      bits_of(a, false, pa, fa);
+      bits_of(b, false, pb, fb);
+      k_select_bits<<<grid_for(nw, BLOCK), BLOCK, 0, st>>>(cw, cv, pa, fa, pb, fb, nw, o.col.data->as<uint64_t>());
+    } else {
+      const int g = grid_for(nrows, BLOCK);
+      switch (type_width(f.type)) {
+        case 16: k_select<i128><<<g, BLOCK, 0, st>>>(cw, cv, operand<i128>(a), operand<i128>(b), nrows, o.col.data->as<i128>()); break;
+        case 8: k_select<uint64_t><<<g, BLOCK, 0, st>>>(cw, cv, operand<uint64_t>(a), operand<uint64_t>(b), nrows, o.col.data->as<uint64_t>()); break;
+        case 4: k_select<uint32_t><<<g, BLOCK, 0, st>>>(cw, cv, operand<uint32_t>(a), operand<uint32_t>(b), nrows, o.col.data->as<uint32_t>()); break;
+        default: k_select<uint8_t><<<g, BLOCK, 0, st>>>(cw, cv, operand<uint8_t>(a), operand<uint8_t>(b), nrows, o.col.data->as<uint8_t>()); break;
+      }
+    }
+  }
+  const bool a_nulls = a.scalar ? a.scalar_null : a.col.has_nulls();
+  const bool b_nulls = b.scalar ? b.scalar_null : b.col.has_nulls();
+  if (a_nulls || b_nulls) {
+    const uint64_t *pa, *pb;
+    uint64_t fa = ~0ull, fb = ~0ull;
+    bits_of(a, true, pa, fa);
+    bits_of(b, true, pb, fb);
+    o.col.validity = make_buf(bitmap_bytes(nrows));
+    if (nw) k_select_bits<<<grid_for(nw, BLOCK), BLOCK, 0, st>>>(cw, cv, pa, fa, pb, fb, nw, o.col.validity->as<uint64_t>());
+    o.col.null_count = -1;
+  }
+  if (!a.scalar && !b.scalar && a.col.dict == b.col.dict) o.col.dict = a.col.dict;
+  return o;
+}
+
 static Datum eval_node(const dfgpu_expr& e, int idx, const Table& in) {
   DFGPU_CHECK(idx >= 0 && idx < e.n_nodes, "expression node index out of range");
   const dfgpu_expr_node& n = e.nodes[idx];
   const int64_t nrows = in.nrows;
   switch (n.op) {
+    case DFGPU_EXPR_CASE: {
+      Datum c = eval_node(e, n.column, in);
+      Datum a = eval_node(e, n.left, in);
+      Datum b = n.right >= 0 ? eval_node(e, n.right, in) : make_scalar(a.col.field, 0, true);
+      return eval_case(c, a, b, nrows);
+    }
     case DFGPU_EXPR_COLUMN: {
       DFGPU_CHECK(n.column >= 0 && n.column < (int)in.cols.size(), "Column index out of range");
       Datum d;

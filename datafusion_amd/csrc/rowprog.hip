@@ -229,6 +229,24 @@ RpValue RowProgramCompiler::lower(const dfgpu_expr& e, int idx) {
       RpValue b = lower(e, n.right);
       return lower_binary(n.op, a, b);
     }
+    case DFGPU_EXPR_CASE: {
+      // binary ops only (the register allocator and the three program forms stay two-operand):
+      //   t = c AND (c IS NOT NULL)   TRUE exactly where the WHEN condition is TRUE, never NULL
+      //   result = MERGE(GATE(then, t), GATE(else, NOT t))
+      RpValue c = lower(e, n.column);
+      DFGPU_CHECK(c.type.type == DFGPU_BOOL, "CASE WHEN condition must be Boolean");
+      RpValue a = lower(e, n.left);
+      RpValue b = n.right >= 0 ? lower(e, n.right) : literal(a.type, 0, 0, true);
+      DFGPU_CHECK(same_field_type(a.type, b.type), "CASE branch types differ: " + type_name(a.type) + " vs " + type_name(b.type) + " (the planner inserts casts)");
+      const bool wide = a.type.type == DFGPU_DECIMAL128 || a.type.type == DFGPU_UINT64;
+      const int t = emit(RP_AND, c.id, emit(RP_IS_NOT_NULL, c.id, -2, 0), 0);
+      const int nt = emit(RP_NOT, t, -2, 0);
+      const int ga = emit(RP_GATE, a.id, t, 0, -1, false, wide);
+      const int gb = emit(RP_GATE, b.id, nt, 0, -1, false, wide);
+      dfgpu_field out = a.type;
+      out.nullable = 1;
+      return RpValue{emit(RP_MERGE, ga, gb, 0, -1, false, wide), out};
+    }
   }
   throw Error("unsupported expression op " + std::to_string(n.op));
 }
@@ -526,11 +544,14 @@ bool RowProgramCompiler::finish(CompiledProgram& cp, std::string& why) {
         case RP_NOT: val = "(i128)((" + A + " & 1) ^ 1)"; nul = NA; break;
         case RP_IS_NULL: val = "(i128)(" + NA + ")"; nul = "false"; break;
         case RP_IS_NOT_NULL: val = "(i128)(!" + NA + ")"; nul = "false"; break;
+        case RP_GATE: val = "((" + B + " & 1) ? " + A + " : (i128)0)"; nul = "((" + B + " & 1) && " + NA + ")"; break;
+        case RP_MERGE: val = "(" + A + " | " + B + ")"; break;
         default: val = A; nul = NA; break;  // RP_MOV
       }
       switch (x.op) {
         case RP_LIT: maybe_null[(size_t)v] = x.lit_null; break;
         case RP_IS_NULL: case RP_IS_NOT_NULL: maybe_null[(size_t)v] = false; break;
+        case RP_GATE: maybe_null[(size_t)v] = maybe_null[(size_t)x.a]; break;
         default: maybe_null[(size_t)v] = (x.a >= 0 && maybe_null[(size_t)x.a]) || (x.b >= 0 && maybe_null[(size_t)x.b]); break;
       }
       st = "    const i128 " + V(v) + " = " + val + ";\n    const bool " + N(v) + " = " + nul + ";\n";
@@ -546,7 +567,7 @@ bool RowProgramCompiler::finish(CompiledProgram& cp, std::string& why) {
   }
   if (const char* dump = std::getenv("DFGPU_RP_DUMP"); dump && *dump == '1') {
     static const char* names[] = {"lit", "add", "sub", "mul", "sext32", "sext64", "fadd", "fsub", "fmul", "i2f", "f64ord", "cmp", "fcmp", "and", "or", "not",
-                                  "is_null", "is_not_null", "mov", "mul64", "add64", "sub64", "cmp64"};
+                                  "is_null", "is_not_null", "mov", "gate", "merge", "?", "?"};
     fprintf(stderr, "[rowprog] cols=%d regs=%d ins=%d (prologue %d, predicate end %d, pred reg %d)\n", n_cols, cp.n_regs, n_ins, n_prologue, n_pred_end, cp.pred_reg);
     for (int i = 0; i < n_ins; i++)
       fprintf(stderr, "  %2d: r%-2d = %-8s r%-2d r%-2d aux=%u\n", i, P.ins[i].dst, P.ins[i].op < 23 ? names[P.ins[i].op] : "?", P.ins[i].a, P.ins[i].b, P.ins[i].aux);

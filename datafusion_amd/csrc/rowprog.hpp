@@ -42,7 +42,10 @@ enum RpOp : uint8_t {
   RP_NOT = 15,
   RP_IS_NULL = 16,
   RP_IS_NOT_NULL = 17,
-  RP_MOV = 18
+  RP_MOV = 18,
+  // CASE WHEN c THEN x ELSE y END = MERGE(GATE(x, t), GATE(y, NOT t)) with t = c AND (c IS NOT NULL):
+  RP_GATE = 19,   // dst <- b is TRUE ? a : (0, not NULL)        (b: a non-NULL Boolean)
+  RP_MERGE = 20   // dst <- a | b bitwise, NULL if either is     (at most one side is non-zero / NULL)
 };
 // how a column is widened into a register
 enum RpLoad : uint8_t { RPL_I32 = 0, RPL_I64 = 1, RPL_U8 = 2, RPL_U32 = 3, RPL_U64 = 4, RPL_I128 = 5, RPL_F64 = 6, RPL_BOOL = 7 };
@@ -233,6 +236,8 @@ __device__ __forceinline__ void rp_exec(const RowProgram& p, int k0, int k1, RpR
       case RP_NOT: olo = (alo & 1) ^ 1ull; on = an; break;
       case RP_IS_NULL: olo = an ? 1ull : 0ull; on = false; break;
       case RP_IS_NOT_NULL: olo = an ? 0ull : 1ull; on = false; break;
+      case RP_GATE: { const bool t = (blo & 1) != 0; olo = t ? alo : 0ull; ohi = t ? ahi : 0ull; on = t && an; break; }
+      case RP_MERGE: olo = alo | blo; ohi = ahi | bhi; break;
       default: olo = alo; ohi = ahi; on = an; break;  // RP_MOV
     }
     r.set(rd, olo, ohi);
@@ -343,7 +348,7 @@ __device__ __forceinline__ void tp_exec(const TileProgram& p, int k0, int k1, Ti
     uint64_t alo, ahi, blo = 0, bhi = 0;
     bool an, bn = false;
     tp_fetch(p, t, in.a, alo, ahi, an);
-    const bool unary = in.op == RP_SEXT32 || in.op == RP_SEXT64 || in.op == RP_I2F || in.op == RP_F64ORD || in.op >= RP_NOT;
+    const bool unary = in.op == RP_SEXT32 || in.op == RP_SEXT64 || in.op == RP_I2F || in.op == RP_F64ORD || (in.op >= RP_NOT && in.op <= RP_MOV);
     if (!unary) tp_fetch(p, t, in.b, blo, bhi, bn);
     uint64_t olo = 0, ohi = 0;
     bool on = an | bn;
@@ -375,6 +380,8 @@ __device__ __forceinline__ void tp_exec(const TileProgram& p, int k0, int k1, Ti
       case RP_NOT: olo = (alo & 1) ^ 1ull; on = an; break;
       case RP_IS_NULL: olo = an ? 1ull : 0ull; on = false; break;
       case RP_IS_NOT_NULL: olo = an ? 0ull : 1ull; on = false; break;
+      case RP_GATE: { const bool g = (blo & 1) != 0; olo = g ? alo : 0ull; ohi = g ? ahi : 0ull; on = g && an; break; }
+      case RP_MERGE: olo = alo | blo; ohi = ahi | bhi; break;
       default: olo = alo; ohi = ahi; on = an; break;  // RP_MOV
     }
     tp_store(p, t, in.dst, olo, ohi, on);

@@ -1,7 +1,7 @@
 """Host-side mirror of the PhysicalExpr node kinds the GPU path evaluates
 (physical-expr-common/src/physical_expr.rs:76; concrete nodes in physical-expr/src/expressions/:
 column.rs `Column`, literal.rs `Literal`, cast.rs `CastExpr`, binary.rs `BinaryExpr`,
-is_null.rs `IsNullExpr`, is_not_null.rs `IsNotNullExpr`, not.rs `NotExpr`).
+is_null.rs `IsNullExpr`, is_not_null.rs `IsNotNullExpr`, not.rs `NotExpr`, case.rs `CaseExpr`).
 
 The trees are lowered to the flat `dfgpu_expr_node[]` IR of include/dfgpu.h; typing (decimal
 result precision/scale, operand checks) happens inside the library so a Rust shim can pass
@@ -22,6 +22,7 @@ from .table import field_of
 OP_COLUMN, OP_LITERAL, OP_CAST = 1, 2, 3
 _BINARY = {"+": 10, "-": 11, "*": 12, "=": 20, "!=": 21, "<": 22, "<=": 23, ">": 24, ">=": 25, "and": 30, "or": 31}
 OP_NOT, OP_IS_NULL, OP_IS_NOT_NULL = 32, 33, 34
+OP_CASE = 40
 
 
 class PhysicalExpr:
@@ -107,6 +108,30 @@ class NotExpr(PhysicalExpr):
     def children(self): return [self.arg]
 
 
+class CaseExpr(PhysicalExpr):
+    """CaseExpr::try_new(expr = None, when_then_expr, else_expr) (expressions/case.rs:274):
+    CASE WHEN c1 THEN v1 [WHEN c2 THEN v2 ...] [ELSE e] END.  The `CASE x WHEN v` form is written with conditions x = v."""
+
+    def __init__(self, when_then, else_expr: PhysicalExpr | None = None):
+        if not when_then:
+            raise ValueError("CASE needs at least one WHEN")
+        self.when_then = [(w, _wrap(t)) for w, t in when_then]
+        self.else_expr = None if else_expr is None else _wrap(else_expr)
+
+    def children(self):
+        return [x for wt in self.when_then for x in wt] + ([] if self.else_expr is None else [self.else_expr])
+
+    def map_children(self, f) -> "CaseExpr":
+        return CaseExpr([(f(w), f(t)) for w, t in self.when_then], None if self.else_expr is None else f(self.else_expr))
+
+    def __repr__(self):
+        return "CASE " + " ".join(f"WHEN {w!r} THEN {t!r}" for w, t in self.when_then) + (f" ELSE {self.else_expr!r}" if self.else_expr is not None else "") + " END"
+
+
+def case(when_then, else_expr=None) -> CaseExpr:
+    return CaseExpr(when_then, else_expr)
+
+
 def col(name, index=None) -> Column:
     return Column(name, index)
 
@@ -181,6 +206,8 @@ def bind_string_literals(expr: PhysicalExpr, table) -> PhysicalExpr:
         return IsNotNullExpr(bind_string_literals(expr.arg, table))
     if isinstance(expr, NotExpr):
         return NotExpr(bind_string_literals(expr.arg, table))
+    if isinstance(expr, CaseExpr):
+        return expr.map_children(lambda e: bind_string_literals(e, table))
     return expr
 
 
@@ -228,6 +255,16 @@ def lower(expr: PhysicalExpr, column_names, table=None) -> LoweredExpr:
         elif isinstance(e, (IsNullExpr, IsNotNullExpr, NotExpr)):
             n.left = emit(e.arg)
             n.op = {IsNullExpr: OP_IS_NULL, IsNotNullExpr: OP_IS_NOT_NULL, NotExpr: OP_NOT}[type(e)]
+        elif isinstance(e, CaseExpr):
+            # one DFGPU_EXPR_CASE node per WHEN, later branches nested in ELSE (include/dfgpu.h)
+            tail = -1 if e.else_expr is None else emit(e.else_expr)
+            for w, t in reversed(e.when_then[1:]):
+                m = ExprNode()
+                m.op, m.column, m.left, m.right = OP_CASE, emit(w), emit(t), tail
+                nodes.append(m)
+                tail = len(nodes) - 1
+            w, t = e.when_then[0]
+            n.op, n.column, n.left, n.right = OP_CASE, emit(w), emit(t), tail
         else:
             raise TypeError(f"{type(e).__name__} is not supported on the GPU path")
         nodes.append(n)

@@ -44,7 +44,7 @@ def project(table: DeviceTable, exprs) -> DeviceTable:
     """ProjectionExec: exprs = [(PhysicalExpr, name)] (projection.rs:439)"""
     lib = _lib.init()
     names = table.column_names
-    lowered = [lower(e, names) for e, _ in exprs]
+    lowered = [lower(e, names, table) for e, _ in exprs]
     arr = (Expr * len(exprs))(*[l.c for l in lowered])
     cnames = (C.c_char_p * len(exprs))(*[n.encode() for _, n in exprs])
     out = C.c_void_p()
@@ -183,7 +183,9 @@ def sort(table: DeviceTable, keys, fetch=None) -> DeviceTable:
 class GroupedAggregate:
     """AggregateExec state: group_by = [(expr, name)], aggs = [(func, expr|None, name)]"""
 
-    def __init__(self, mode, input_names, group_by, aggs):
+    def __init__(self, mode, input_names, group_by, aggs, dictionaries: DeviceTable | None = None):
+        """dictionaries: a table of the input's schema whose dictionary-encoded string columns bind the string
+        literals of the argument expressions (`CASE WHEN o_orderpriority = '1-URGENT' ...`)"""
         lib = _lib.init()
         self._keep = []
         final = mode in ("Final", "FinalPartitioned")
@@ -193,7 +195,9 @@ class GroupedAggregate:
             from .expr import Column
             group_by = [(Column(n, i), n) for i, (_, n) in enumerate(group_by)]
             aggs = [(f, None if f == "count" and e is None else Column("state", 0), n) for f, e, n in aggs]
-        g_low = [lower(e, input_names) for e, _ in group_by]
+        if final:
+            dictionaries = None
+        g_low = [lower(e, input_names, dictionaries) for e, _ in group_by]
         self._keep += g_low
         garr = (Expr * max(1, len(g_low)))(*[l.c for l in g_low])
         gnames = (C.c_char_p * max(1, len(group_by)))(*[n.encode() for _, n in group_by])
@@ -203,7 +207,7 @@ class GroupedAggregate:
             s.func = AGG_FUNCS[func]
             s.has_arg = 0 if e is None else 1
             if e is not None:
-                l = lower(e, input_names)
+                l = lower(e, input_names, dictionaries)
                 self._keep.append(l)
                 s.arg = l.c
             s.name = name.encode()
@@ -245,7 +249,7 @@ class GroupedAggregate:
 
 
 def aggregate(table: DeviceTable, group_by, aggs, mode="Single", predicate: PhysicalExpr | None = None, info: dict | None = None) -> DeviceTable:
-    a = GroupedAggregate(mode, table.column_names, group_by, aggs)
+    a = GroupedAggregate(mode, table.column_names, group_by, aggs, table)
     a.update(table, predicate)
     if info is not None:
         info["fused_updates"] = a.fused_updates

@@ -18,7 +18,7 @@ from decimal import Decimal
 import pyarrow as pa
 
 from . import physical_plan as P
-from .expr import col, lit
+from .expr import case, col, lit
 
 DATE = pa.date32()
 D15_2 = pa.decimal128(15, 2)
@@ -148,6 +148,30 @@ def q6_plan(lineitem):
     partial = P.AggregateExec("Partial", [], aggs, _cb(f))
     final = P.AggregateExec("Final", [], aggs, P.CoalescePartitionsExec(partial))
     return P.ProjectionExec([(col(name), "revenue")], final)
+
+
+# ----------------------------------------------------------------------------------------- Q12
+def q12_plan(orders, lineitem):
+    """q12.slt.part:62-73: build = the filtered lineitem rows (several per order), probe = orders; two SUM(CASE ...)"""
+    mode = col("l_shipmode")
+    pred = (mode.eq(lit("MAIL", pa.string())).or_(mode.eq(lit("SHIP", pa.string())))).and_(col("l_receiptdate") > col("l_commitdate")) \
+        .and_(col("l_shipdate") < col("l_commitdate")).and_(col("l_receiptdate") >= _d(1994, 1, 1)).and_(col("l_receiptdate") < _d(1995, 1, 1))
+    l = _hash(_cb(P.FilterExec(pred, _scan(lineitem, "lineitem"), projection=["l_orderkey", "l_shipmode"])), ["l_orderkey"])
+    o = _hash(_scan(orders, "orders").project(["o_orderkey", "o_orderpriority"]), ["o_orderkey"])
+    j = P.HashJoinExec(_cb(l), _cb(o), [("l_orderkey", "o_orderkey")], "Inner", projection=(["l_shipmode"], ["o_orderpriority"]))
+    prio = col("o_orderpriority")
+    urgent, high = lit("1-URGENT", pa.string()), lit("2-HIGH", pa.string())
+    one, zero = lit(1, pa.int64()), lit(0, pa.int64())
+    hi_name = 'sum(CASE WHEN orders.o_orderpriority = Utf8("1-URGENT") OR orders.o_orderpriority = Utf8("2-HIGH") THEN Int64(1) ELSE Int64(0) END)'
+    lo_name = 'sum(CASE WHEN orders.o_orderpriority != Utf8("1-URGENT") AND orders.o_orderpriority != Utf8("2-HIGH") THEN Int64(1) ELSE Int64(0) END)'
+    aggs = [("sum", case([(prio.eq(urgent).or_(prio.eq(high)), one)], zero), hi_name),
+            ("sum", case([(prio.ne(urgent).and_(prio.ne(high)), one)], zero), lo_name)]
+    gb = [(col("l_shipmode"), "l_shipmode")]
+    partial = P.AggregateExec("Partial", gb, aggs, _cb(j))
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["l_shipmode"])))
+    keys = [("l_shipmode",) + ASC]
+    proj = P.ProjectionExec([(col("l_shipmode"), "l_shipmode"), (col(hi_name), "high_line_count"), (col(lo_name), "low_line_count")], P.SortExec(keys, final))
+    return P.SortPreservingMergeExec(keys, proj)
 
 
 # ----------------------------------------------------------------------------------------- Q18

@@ -174,7 +174,7 @@ int dfgpu_table_slice(dfgpu_table_t t, int64_t offset, int64_t length, dfgpu_tab
 
 /* PhysicalExpr trees (physical-expr-common/src/physical_expr.rs:76) cross the ABI as a
  * flat node array; the Rust shim lowers Column / Literal / CastExpr / BinaryExpr /
- * IsNullExpr / NotExpr into it (anything else keeps the CPU operator). */
+ * IsNullExpr / NotExpr / CaseExpr into it (anything else keeps the CPU operator). */
 typedef enum dfgpu_expr_op {
   DFGPU_EXPR_COLUMN = 1,  /* expressions/column.rs:121 */
   DFGPU_EXPR_LITERAL = 2, /* expressions/literal.rs */
@@ -192,12 +192,18 @@ typedef enum dfgpu_expr_op {
   DFGPU_EXPR_OR = 31,
   DFGPU_EXPR_NOT = 32,
   DFGPU_EXPR_IS_NULL = 33,
-  DFGPU_EXPR_IS_NOT_NULL = 34
+  DFGPU_EXPR_IS_NOT_NULL = 34,
+  /* CaseExpr without a base expression (expressions/case.rs: `CASE WHEN c THEN a ELSE b END`), one WHEN per node:
+   * `column` = node index of the WHEN condition (Boolean), `left` = THEN, `right` = ELSE (-1 = no ELSE: NULL).
+   * The THEN value is taken where the condition is TRUE, the ELSE value where it is FALSE or NULL.  Further WHEN
+   * branches nest in ELSE; `CASE x WHEN v ...` is lowered by the caller to conditions `x = v`.  THEN and ELSE have
+   * the same type (the planner's coercion). */
+  DFGPU_EXPR_CASE = 40
 } dfgpu_expr_op;
 
 typedef struct dfgpu_expr_node {
   int32_t op;          /* dfgpu_expr_op */
-  int32_t column;      /* COLUMN: index into the input table */
+  int32_t column;      /* COLUMN: index into the input table; CASE: node index of the WHEN condition */
   int32_t left, right; /* child node indices, -1 = none */
   dfgpu_field field;   /* LITERAL: literal type; CAST: target type; else ignored */
   int32_t is_null;     /* LITERAL: SQL NULL */

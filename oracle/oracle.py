@@ -9,6 +9,7 @@ Expression trees for the oracle are plain tuples (independent of the product's I
     ("col", name) | ("lit", python_value, pa.DataType) | ("cast", expr, pa.DataType)
     ("bin", op, lhs, rhs)   op in + - * = != < <= > >= and or
     ("is_null", expr) | ("not", expr)
+    ("case", when_expr, then_expr, else_expr | None)
 """
 from __future__ import annotations
 
@@ -363,6 +364,8 @@ def evaluate(expr, table: pa.Table) -> Datum:
         return Datum(values_np(arr), arr.type, valid)
     if kind == "lit":
         _, value, typ = expr
+        if value is None and pa.types.is_boolean(typ):
+            return Datum(np.array([False]), typ, np.array([False]), scalar=True)
         if value is None:
             t = orc_type(typ)
             z = np.zeros((1, 2), np.uint64) if t == ORC_I128 else np.zeros(1, _NP[t])
@@ -401,6 +404,26 @@ def evaluate(expr, table: pa.Table) -> Datum:
     if kind == "not":
         d = evaluate(expr[1], table)
         return Datum(~d.values.astype(bool), pa.bool_(), d.valid, d.scalar)
+    if kind == "case":
+        # CaseExpr without base expression, one WHEN (physical-expr/src/expressions/case.rs:895-980 case_when_no_expr,
+        # :981-1040 expr_or_expr): THEN where the condition is TRUE; NULL conditions count as FALSE
+        # (prep_null_mask_filter) and take ELSE; no ELSE = NULL
+        _, ce, te, ee = expr
+        c, a = evaluate(ce, table), evaluate(te, table)
+        b = evaluate(ee, table) if ee is not None else evaluate(("lit", None, a.typ), table)
+        if a.typ != b.typ:
+            raise TypeError(f"oracle case: {a.typ} vs {b.typ}")
+
+        def full(d):
+            vals = np.repeat(d.values, n, axis=0) if d.scalar else d.values
+            valid = np.ones(n, bool) if d.valid is None else (np.repeat(d.valid, n) if d.scalar else d.valid)
+            return vals, valid
+        cv, cvalid = full(c)
+        take = cv.astype(bool) & cvalid
+        (av, avalid), (bv, bvalid) = full(a), full(b)
+        vals = np.where(take[:, None] if av.ndim == 2 else take, av, bv)
+        valid = np.where(take, avalid, bvalid)
+        return Datum(vals, a.typ, None if valid.all() else valid)
     if kind == "bin":
         _, op, le, re_ = expr
         a, b = evaluate(le, table), evaluate(re_, table)

@@ -108,8 +108,12 @@ def test_sort_fuzz(seed):
 def _gen_expr(rng, typ, depth):
     """random well-typed PhysicalExpr of arrow type `typ` over the columns of EXPR_SPEC (the planner's coercions are
     already applied: both operands of an arithmetic / comparison node have the same type)"""
-    from datafusion_amd.expr import col, lit
+    from datafusion_amd.expr import case, col, lit
     leaves = {"i32": ["i", "j"], "i64": ["k", "m"], "dec": ["d", "e"], "f64": ["f", "g"], "date": ["dt"]}
+    if depth > 0 and rng.integers(0, 6) == 0:   # CaseExpr of this type: one or two WHENs, ELSE optional
+        bd = 0 if typ == "dec" else depth - 1          # decimal branches stay leaves: every branch Decimal128(15,2)
+        whens = [(_gen_expr(rng, "bool", depth - 1), _gen_expr(rng, typ, bd)) for _ in range(int(rng.integers(1, 3)))]
+        return case(whens, None if rng.integers(0, 3) == 0 else _gen_expr(rng, typ, bd))
     if typ == "bool":
         kind = rng.integers(0, 6) if depth > 0 else 0
         if kind <= 2:      # comparison of two same-typed values
@@ -141,7 +145,9 @@ def _gen_expr(rng, typ, depth):
 
 
 def _is_bool(e):
-    from datafusion_amd.expr import BinaryExpr, IsNotNullExpr, IsNullExpr, NotExpr
+    from datafusion_amd.expr import BinaryExpr, CaseExpr, IsNotNullExpr, IsNullExpr, NotExpr
+    if isinstance(e, CaseExpr):
+        return _is_bool(e.when_then[0][1])
     return isinstance(e, (IsNullExpr, IsNotNullExpr, NotExpr)) or (isinstance(e, BinaryExpr) and e.op in ("=", "!=", "<", "<=", ">", ">=", "and", "or"))
 
 
