@@ -195,3 +195,31 @@ def q18_plan(customer, orders, lineitem):
     agg = P.AggregateExec("SinglePartitioned", gb2, aggs, _cb(semi))
     keys = [("o_totalprice",) + DESC, ("o_orderdate",) + ASC]
     return P.SortPreservingMergeExec(keys, P.SortExec(keys, agg))
+
+
+# ----------------------------------------------------------------------------------------- Q21
+def q21_plan(supplier, lineitem, orders, nation):
+    """q21.slt.part:92-122: EXISTS / NOT EXISTS decorrelated to LeftSemi / LeftAnti joins carrying the JoinFilter
+    `l_suppkey != l_suppkey` (joins/join_filter.rs), two more LeftSemi joins, COUNT(*) per supplier name"""
+    late = col("l_receiptdate") > col("l_commitdate")
+    s = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_name", "s_nationkey"]), ["s_suppkey"])
+    l1 = _hash(_cb(P.FilterExec(late, _scan(lineitem, "lineitem"), projection=["l_orderkey", "l_suppkey"])), ["l_suppkey"])
+    j = P.HashJoinExec(_cb(s), _cb(l1), [("s_suppkey", "l_suppkey")], "Inner", projection=(["s_name", "s_nationkey"], ["l_orderkey", "l_suppkey"]))
+    o = _hash(_cb(P.FilterExec(col("o_orderstatus").eq(lit("F", pa.string())), _scan(orders, "orders"), projection=["o_orderkey"])), ["o_orderkey"])
+    semi_o = P.HashJoinExec(_cb(_hash(_cb(j), ["l_orderkey"])), _cb(o), [("l_orderkey", "o_orderkey")], "LeftSemi")
+    n = _hash(_cb(P.FilterExec(col("n_name").eq(lit("SAUDI ARABIA", pa.string())), _scan(nation, "nation").project(["n_nationkey", "n_name"]),
+                               projection=["n_nationkey"])), ["n_nationkey"])
+    semi_n = P.HashJoinExec(_cb(_hash(_cb(semi_o), ["s_nationkey"])), _cb(n), [("s_nationkey", "n_nationkey")], "LeftSemi",
+                            projection=(["s_name", "l_orderkey", "l_suppkey"], None))
+    other_supplier = (col("f0").ne(col("f1")), [(2, "Left"), (1, "Right")])          # left.l_suppkey != right.l_suppkey
+    l2 = _hash(_scan(lineitem, "lineitem").project(["l_orderkey", "l_suppkey"]), ["l_orderkey"])
+    exists = P.HashJoinExec(_cb(_hash(_cb(semi_n), ["l_orderkey"])), _cb(l2), [("l_orderkey", "l_orderkey")], "LeftSemi", filter=other_supplier)
+    l3 = _hash(_cb(P.FilterExec(late, _scan(lineitem, "lineitem"), projection=["l_orderkey", "l_suppkey"])), ["l_orderkey"])
+    not_exists = P.HashJoinExec(_cb(exists), _cb(l3), [("l_orderkey", "l_orderkey")], "LeftAnti", projection=(["s_name"], None), filter=other_supplier)
+    gb = [(col("s_name"), "s_name")]
+    aggs = [("count", None, "count(Int64(1))")]
+    partial = P.AggregateExec("Partial", gb, aggs, _cb(not_exists))
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["s_name"])))
+    keys = [("count(Int64(1))",) + DESC, ("s_name",) + ASC]
+    proj = P.ProjectionExec([(col("s_name"), "s_name"), (col("count(Int64(1))"), "numwait")], P.SortExec(keys, final))
+    return P.SortPreservingMergeExec([("numwait",) + DESC, ("s_name",) + ASC], proj)

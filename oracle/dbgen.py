@@ -201,7 +201,11 @@ def tables(sf: float, strings: str = "codes"):
     # o_totalprice += ((eprice * (100 - discount)) / PENNIES) * (100 + tax) / PENNIES, integer division (build.c mk_order)
     per_line = (eprice * (100 - disc)) // 100 * (100 + tax) // 100
     total = np.add.reduceat(per_line, first) if len(per_line) else np.zeros(0, dtype=np.int64)
-    orders = pa.table({"o_orderkey": pa.array(okey), "o_custkey": pa.array(ckey), "o_totalprice": _decimal(total),
+    # o_orderstatus: 'F' when every line has shipped by CURRENTDATE, 'O' when none has, else 'P' (build.c mk_order)
+    shipped = (lstatus == ord("F")).astype(np.int64)
+    n_shipped = np.add.reduceat(shipped, first) if len(shipped) else np.zeros(0, dtype=np.int64)
+    ostatus = np.where(n_shipped == lines, ord("F"), np.where(n_shipped == 0, ord("O"), ord("P"))).astype(np.uint8)
+    orders = pa.table({"o_orderkey": pa.array(okey), "o_custkey": pa.array(ckey), "o_orderstatus": _flag(ostatus, strings), "o_totalprice": _decimal(total),
                        "o_orderdate": pa.array((odate + STARTDATE_EPOCH).astype(np.int32), pa.date32()),
                        "o_orderpriority": _strings(prio, PRIORITIES, strings),
                        "o_shippriority": pa.array(np.zeros(no, dtype=np.int32))})
@@ -216,10 +220,17 @@ def tables(sf: float, strings: str = "codes"):
     return customer, orders, lineitem
 
 
-def supplier(sf: float) -> pa.Table:
-    """build.c mk_supp: the key and nation columns"""
+def supplier(sf: float, strings: str = "codes") -> pa.Table:
+    """build.c mk_supp: key, name (S_NAME_FMT "%s%09ld") and nation"""
     ns = counts(sf)["part"] // 20
-    return pa.table({"s_suppkey": pa.array(np.arange(1, ns + 1, dtype=np.int64)), "s_nationkey": pa.array(_draw(S_NTRG_SD, ns, 0, 24))})
+    names = [f"Supplier#{i:09d}" for i in range(1, ns + 1)]
+    if strings == "utf8":
+        s_name = pa.array(names, pa.string())
+    elif strings == "dictionary":
+        s_name = pa.DictionaryArray.from_arrays(pa.array(np.arange(ns, dtype=np.int32)), pa.array(names, pa.string()))
+    else:
+        s_name = pa.array(np.arange(ns, dtype=np.int32))
+    return pa.table({"s_suppkey": pa.array(np.arange(1, ns + 1, dtype=np.int64)), "s_name": s_name, "s_nationkey": pa.array(_draw(S_NTRG_SD, ns, 0, 24))})
 
 
 def nation(strings: str = "codes") -> pa.Table:

@@ -16,7 +16,7 @@ GOLD = load_golden("tpch_answers.json")["sf1_sample"]
 def sf1():
     from oracle import dbgen
     c, o, l = dbgen.tables(1, "utf8")
-    return dict(customer=c, orders=o, lineitem=l, supplier=dbgen.supplier(1), nation=dbgen.nation("utf8"), region=dbgen.region("utf8"))
+    return dict(customer=c, orders=o, lineitem=l, supplier=dbgen.supplier(1, "utf8"), nation=dbgen.nation("utf8"), region=dbgen.region("utf8"))
 
 
 def _same(v, text):

@@ -1,4 +1,4 @@
-"""The reference's pinned TPC-H answers (sqllogictest/test_files/tpch/answers/q{1,3,4,5,6,12,18}.slt.part, scale factor
+"""The reference's pinned TPC-H answers (sqllogictest/test_files/tpch/answers/q{1,3,4,5,6,12,18,21}.slt.part, scale factor
 0.1) as end-to-end known-answer tests.
 
 Data: oracle/dbgen.py, a restatement of the TPC's dbgen for the columns these queries read, itself pinned against the
@@ -28,7 +28,7 @@ SF = 0.1
 def data(strings="dictionary"):
     from oracle import dbgen
     c, o, l = dbgen.tables(SF, strings)
-    return dict(customer=c, orders=o, lineitem=l, supplier=dbgen.supplier(SF), nation=dbgen.nation(strings), region=dbgen.region(strings))
+    return dict(customer=c, orders=o, lineitem=l, supplier=dbgen.supplier(SF, strings), nation=dbgen.nation(strings), region=dbgen.region(strings))
 
 
 def plans(t):
@@ -37,7 +37,8 @@ def plans(t):
     return {"q1": T.q1_plan(t["lineitem"]), "q3": T.q3_plan(t["customer"], t["orders"], t["lineitem"]),
             "q4": T.q4_plan(t["orders"], t["lineitem"]),
             "q5": T.q5_plan(t["customer"], t["orders"], t["lineitem"], t["supplier"], t["nation"], t["region"]),
-            "q6": T.q6_plan(t["lineitem"]), "q12": T.q12_plan(t["orders"], t["lineitem"]), "q18": T.q18_plan(t["customer"], t["orders"], t["lineitem"])}
+            "q6": T.q6_plan(t["lineitem"]), "q12": T.q12_plan(t["orders"], t["lineitem"]), "q18": T.q18_plan(t["customer"], t["orders"], t["lineitem"]),
+            "q21": T.q21_plan(t["supplier"], t["lineitem"], t["orders"], t["nation"])}
 
 
 # answer-file columns whose text may contain blanks (everything else is split on blanks)
@@ -72,12 +73,12 @@ def assert_answer(q, got: pa.Table):
         assert all(_cell(v, x) for v, x in zip(r, w)), f"{q} row {i}: got {r}, the reference's answer is {w} ({GOLD['answers'][q]['source']})"
 
 
-QUERIES = ["q1", "q3", "q4", "q5", "q6", "q12", "q18"]
+QUERIES = ["q1", "q3", "q4", "q5", "q6", "q12", "q18", "q21"]
 RESULT_TYPES = {   # pinned by the answer files' decimal digits and the plan files' expression types
     "q1": {"sum_qty": pa.decimal128(25, 2), "sum_disc_price": pa.decimal128(38, 4), "sum_charge": pa.decimal128(38, 6), "avg_qty": pa.decimal128(19, 6),
            "count_order": pa.int64()},
     "q3": {"revenue": pa.decimal128(38, 4)}, "q4": {"order_count": pa.int64()}, "q5": {"revenue": pa.decimal128(38, 4)},
-    "q6": {"revenue": pa.decimal128(38, 4)}, "q12": {"high_line_count": pa.int64(), "low_line_count": pa.int64()}, "q18": {"sum(lineitem.l_quantity)": pa.decimal128(25, 2)},
+    "q6": {"revenue": pa.decimal128(38, 4)}, "q12": {"high_line_count": pa.int64(), "low_line_count": pa.int64()}, "q18": {"sum(lineitem.l_quantity)": pa.decimal128(25, 2)}, "q21": {"numwait": pa.int64()},
 }
 
 
