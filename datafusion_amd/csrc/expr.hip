@@ -492,7 +492,13 @@ static Datum eval_case(const Datum& c, const Datum& a, const Datum& b, int64_t n
     if (nw) k_select_bits<<<grid_for(nw, BLOCK), BLOCK, 0, st>>>(cw, cv, pa, fa, pb, fb, nw, o.col.validity->as<uint64_t>());
     o.col.null_count = -1;
   }
-  if (!a.scalar && !b.scalar && a.col.dict == b.col.dict) o.col.dict = a.col.dict;
+  // dictionary-encoded branches: the indices are what was selected; a NULL literal on the other side keeps the encoding
+  const std::shared_ptr<const DictValues> da = a.scalar ? nullptr : a.col.dict, db = b.scalar ? nullptr : b.col.dict;
+  DFGPU_CHECK(!(da && db && da != db), "CASE over two differently encoded dictionary columns is not supported on the GPU path");
+  DFGPU_CHECK(!((da && b.scalar && !b.scalar_null) || (db && a.scalar && !a.scalar_null)),
+              "CASE mixing a dictionary-encoded column with a literal index is not supported on the GPU path");
+  DFGPU_CHECK(!((da && !b.scalar && !db) || (db && !a.scalar && !da)), "CASE mixing a dictionary-encoded column with a plain column");
+  o.col.dict = da ? da : db;
   return o;
 }
 

@@ -391,7 +391,7 @@ def evaluate(expr, table: pa.Table) -> Datum:
             return Datum(out, to, d.valid, d.scalar)
         if dst == ORC_F64 and src in (ORC_I32, ORC_I64):
             return Datum(d.values.astype(np.float64), to, d.valid, d.scalar)
-        if dst == ORC_I64 and src == ORC_I32:
+        if dst == ORC_I64 and src in (ORC_I32, ORC_U8, ORC_U32):
             return Datum(d.values.astype(np.int64), to, d.valid, d.scalar)
         if dst == src:
             return Datum(d.values, to, d.valid, d.scalar)

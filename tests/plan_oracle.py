@@ -60,6 +60,8 @@ def _expr(e, rel: Rel):
                 if isinstance(a, X.Column) and isinstance(b, X.Literal) and pa.types.is_string(b.type):
                     itype = rel.table.schema.field(a.name).type
                     values = rel.dicts[a.name]
+                    if b.value is None:
+                        return ("bin", e.op, ("col", a.name), ("lit", None, itype))
                     if b.value in values:
                         return ("bin", e.op, ("col", a.name), ("lit", values.index(b.value), itype))
                     return ("bin", e.op, ("cast", ("col", a.name), pa.int64()), ("lit", -1, pa.int64()))
@@ -78,9 +80,21 @@ def _expr(e, rel: Rel):
     raise TypeError(e)
 
 
+def _dict_of(e, rel: Rel):
+    """the dictionary an expression's values index: a dictionary-encoded column, or a CASE whose branches are such
+    columns / NULL literals"""
+    if isinstance(e, X.Column):
+        return rel.dicts.get(e.name)
+    if isinstance(e, X.CaseExpr):
+        branches = [t for _, t in e.when_then] + ([] if e.else_expr is None else [e.else_expr])
+        found = [d for d in (_dict_of(b, rel) for b in branches) if d is not None]
+        return found[0] if found else None
+    return None
+
+
 def _renamed_dicts(rel: Rel, pairs):
-    """dictionaries follow plain column references through (expr, name) lists"""
-    return {n: rel.dicts[e.name] for e, n in pairs if isinstance(e, X.Column) and e.name in rel.dicts}
+    """dictionaries follow column references (and CASE over them) through (expr, name) lists"""
+    return {n: d for e, n in pairs for d in [_dict_of(e, rel)] if d is not None}
 
 
 def _filter(rel: Rel, predicate, projection) -> Rel:
