@@ -61,6 +61,18 @@ class KernelStat(C.Structure):
                 ("algorithmic_bytes", C.c_int64)]
 
 
+class ParquetColumn(C.Structure):
+    _fields_ = [("physical_type", C.c_int32), ("type_length", C.c_int32), ("codec", C.c_int32), ("max_definition_level", C.c_int32),
+                ("max_repetition_level", C.c_int32), ("_pad", C.c_int32), ("num_values", C.c_int64), ("field", Field), ("name", C.c_char_p)]
+
+
+class ParquetChunkInfo(C.Structure):
+    _fields_ = [("n_pages", C.c_int32), ("n_dictionary_pages", C.c_int32), ("n_data_pages_v1", C.c_int32), ("n_data_pages_v2", C.c_int32),
+                ("n_plain_pages", C.c_int32), ("n_dictionary_encoded_pages", C.c_int32), ("n_runs_rle", C.c_int64), ("n_runs_bitpacked", C.c_int64),
+                ("values", C.c_int64), ("nulls", C.c_int64), ("uncompressed_bytes", C.c_int64), ("compressed_bytes", C.c_int64),
+                ("dictionary_values", C.c_int64)]
+
+
 # every symbol include/dfgpu.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
     "dfgpu_abi_version", "dfgpu_init", "dfgpu_shutdown", "dfgpu_device_count", "dfgpu_last_error", "dfgpu_sync",
@@ -71,7 +83,7 @@ SYMBOLS = [
     "dfgpu_join_get_info", "dfgpu_join_free", "dfgpu_agg_create", "dfgpu_agg_update", "dfgpu_agg_update_filtered", "dfgpu_agg_fused_updates", "dfgpu_set_fusion", "dfgpu_jit_stats", "dfgpu_agg_emit",
     "dfgpu_agg_free", "dfgpu_sort", "dfgpu_partition", "dfgpu_hash_columns", "dfgpu_tpch_orders",
     "dfgpu_tpch_lineitem", "dfgpu_tpch_customer", "dfgpu_profile_enable", "dfgpu_profile_reset",
-    "dfgpu_profile_count", "dfgpu_profile_get",
+    "dfgpu_profile_count", "dfgpu_profile_get", "dfgpu_parquet_decode_chunk", "dfgpu_parquet_inspect_chunk",
 ]
 
 _lib = None

@@ -1,0 +1,711 @@
+// parquet.hip — scan -> device: one Parquet column chunk, as the bytes the reference's reader fetches
+// from the object store (datasource-parquet; `ColumnChunkMetaData::byte_range` of the `parquet` crate), decoded straight
+// into a device column.
+//
+// Split of the work:
+//   host   page headers (Thrift compact protocol), page decompression (Snappy here, ZSTD through libzstd.so.1 —
+//          `tpchgen-cli --parquet-compression 'ZSTD(1)'` is what the reference's benchmarks read, benchmarks/bench.sh:692),
+//          definition levels -> validity bitmap (their bit-packing IS the Arrow bitmap layout), and the *run headers*
+//          of the RLE / bit-packed hybrid index streams (one varint per run) -> a run table;
+//   device one H2D copy of the value bytes per chunk, then ONE kernel decodes every page of the chunk: PLAIN values are
+//          widened / byte-swapped to the Arrow layout, dictionary indices are unpacked from their runs and gathered
+//          through the chunk's dictionary (kept in HBM, L2-resident: dictionaries are <= 1 MiB by the writers' limits).
+// Supported: flat columns (max_repetition_level 0, max_definition_level <= 1), data pages v1 and v2, encodings PLAIN /
+// PLAIN_DICTIONARY / RLE_DICTIONARY, physical types INT32 / INT64 / DOUBLE / FIXED_LEN_BYTE_ARRAY (decimals) and
+// BYTE_ARRAY when every data page is dictionary-encoded (it becomes a dictionary-encoded string column: indices on the
+// device, strings on the host, dictionary sorted ascending).  Anything else is an error: the caller keeps the CPU scan.
+#include "device.hpp"
+#include "internal.hpp"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <numeric>
+
+namespace dfgpu {
+namespace {
+
+// ------------------------------------------------------------------------------------------- Thrift compact protocol
+struct Thrift {
+  const uint8_t* p;
+  const uint8_t* end;
+  uint8_t byte() {
+    DFGPU_CHECK(p < end, "parquet: truncated page header");
+    return *p++;
+  }
+  uint64_t varint() {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      uint8_t b = byte();
+      v |= (uint64_t)(b & 0x7F) << shift;
+      if (!(b & 0x80)) return v;
+    }
+    throw Error("parquet: varint too long");
+  }
+  int64_t zigzag() {
+    uint64_t v = varint();
+    return (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
+  }
+  // field header: returns false at STOP; sets type and advances `id`
+  bool field(int& type, int& id) {
+    uint8_t b = byte();
+    if (b == 0) return false;
+    type = b & 0x0F;
+    int delta = b >> 4;
+    id = delta ? id + delta : (int)zigzag();
+    return true;
+  }
+  void skip(int type) {
+    switch (type) {
+      case 1: case 2: return;                       // BOOL true / false (in the field header)
+      case 3: (void)byte(); return;                 // BYTE
+      case 4: case 5: case 6: (void)zigzag(); return;  // I16 / I32 / I64
+      case 7: DFGPU_CHECK(end - p >= 8, "parquet: truncated double"); p += 8; return;
+      case 8: { uint64_t n = varint(); DFGPU_CHECK((uint64_t)(end - p) >= n, "parquet: truncated binary"); p += n; return; }
+      case 9: case 10: {                            // LIST / SET
+        uint8_t h = byte();
+        uint64_t n = h >> 4;
+        int et = h & 0x0F;
+        if (n == 15) n = varint();
+        for (uint64_t i = 0; i < n; i++) {
+          if (et == 1 || et == 2) (void)byte();     // bools inside a list are one byte each
+          else skip(et);
+        }
+        return;
+      }
+      case 11: {                                    // MAP
+        uint64_t n = varint();
+        if (n == 0) return;
+        uint8_t kv = byte();
+        for (uint64_t i = 0; i < n; i++) { skip(kv >> 4); skip(kv & 0x0F); }
+        return;
+      }
+      case 12: {                                    // STRUCT
+        int t, id = 0;
+        while (field(t, id)) skip(t);
+        return;
+      }
+    }
+    throw Error("parquet: unknown thrift type " + std::to_string(type));
+  }
+};
+
+enum { PAGE_DATA = 0, PAGE_INDEX = 1, PAGE_DICTIONARY = 2, PAGE_DATA_V2 = 3 };
+enum { ENC_PLAIN = 0, ENC_PLAIN_DICTIONARY = 2, ENC_RLE = 3, ENC_BIT_PACKED = 4, ENC_RLE_DICTIONARY = 8 };
+
+struct PageHeader {
+  int type = -1;
+  int32_t uncompressed = 0, compressed = 0;
+  int32_t num_values = 0, num_nulls = -1, num_rows = 0;
+  int encoding = -1, def_encoding = ENC_RLE;
+  int32_t def_bytes = 0, rep_bytes = 0;  // v2
+  bool v2_compressed = true;
+};
+
+// parquet.thrift: PageHeader {1 type, 2 uncompressed_page_size, 3 compressed_page_size, 4 crc, 5 data_page_header,
+// 6 index_page_header, 7 dictionary_page_header, 8 data_page_header_v2}
+PageHeader parse_page_header(Thrift& t) {
+  PageHeader h;
+  int ft, id = 0;
+  while (t.field(ft, id)) {
+    if (id == 1 && ft == 5) h.type = (int)t.zigzag();
+    else if (id == 2 && ft == 5) h.uncompressed = (int32_t)t.zigzag();
+    else if (id == 3 && ft == 5) h.compressed = (int32_t)t.zigzag();
+    else if ((id == 5 || id == 7 || id == 8) && ft == 12) {
+      int st, sid = 0;
+      while (t.field(st, sid)) {
+        if (id == 5) {         // DataPageHeader {1 num_values, 2 encoding, 3 definition_level_encoding, 4 repetition_level_encoding, 5 statistics}
+          if (sid == 1 && st == 5) h.num_values = (int32_t)t.zigzag();
+          else if (sid == 2 && st == 5) h.encoding = (int)t.zigzag();
+          else if (sid == 3 && st == 5) h.def_encoding = (int)t.zigzag();
+          else t.skip(st);
+        } else if (id == 7) {  // DictionaryPageHeader {1 num_values, 2 encoding, 3 is_sorted}
+          if (sid == 1 && st == 5) h.num_values = (int32_t)t.zigzag();
+          else if (sid == 2 && st == 5) h.encoding = (int)t.zigzag();
+          else t.skip(st);
+        } else {               // DataPageHeaderV2 {1 num_values, 2 num_nulls, 3 num_rows, 4 encoding, 5 definition_levels_byte_length,
+                               //                   6 repetition_levels_byte_length, 7 is_compressed, 8 statistics}
+          if (sid == 1 && st == 5) h.num_values = (int32_t)t.zigzag();
+          else if (sid == 2 && st == 5) h.num_nulls = (int32_t)t.zigzag();
+          else if (sid == 3 && st == 5) h.num_rows = (int32_t)t.zigzag();
+          else if (sid == 4 && st == 5) h.encoding = (int)t.zigzag();
+          else if (sid == 5 && st == 5) h.def_bytes = (int32_t)t.zigzag();
+          else if (sid == 6 && st == 5) h.rep_bytes = (int32_t)t.zigzag();
+          else if (sid == 7 && (st == 1 || st == 2)) h.v2_compressed = st == 1;
+          else t.skip(st);
+        }
+      }
+    } else {
+      t.skip(ft);
+    }
+  }
+  DFGPU_CHECK(h.type >= 0 && h.compressed >= 0 && h.uncompressed >= 0, "parquet: malformed page header");
+  return h;
+}
+
+// ------------------------------------------------------------------------------------------------- decompression
+// Snappy raw format (format_description.txt of google/snappy): varint length, then literal / copy elements
+void snappy_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_len) {
+  Thrift v{src, src + n};
+  uint64_t len = v.varint();
+  DFGPU_CHECK(len == dst_len, "parquet: snappy length does not match the page header");
+  const uint8_t* p = v.p;
+  const uint8_t* end = src + n;
+  size_t o = 0;
+  while (p < end) {
+    const uint8_t tag = *p++;
+    if ((tag & 3) == 0) {
+      size_t l = (tag >> 2) + 1;
+      if (l > 60) {
+        const int nb = (int)l - 60;
+        DFGPU_CHECK(end - p >= nb, "parquet: truncated snappy literal");
+        l = 0;
+        for (int i = 0; i < nb; i++) l |= (size_t)p[i] << (8 * i);
+        l += 1;
+        p += nb;
+      }
+      DFGPU_CHECK((size_t)(end - p) >= l && o + l <= dst_len, "parquet: snappy literal overruns");
+      std::memcpy(dst + o, p, l);
+      p += l;
+      o += l;
+    } else {
+      size_t l, off;
+      if ((tag & 3) == 1) {
+        DFGPU_CHECK(end - p >= 1, "parquet: truncated snappy copy");
+        l = 4 + ((tag >> 2) & 7);
+        off = ((size_t)(tag >> 5) << 8) | *p++;
+      } else if ((tag & 3) == 2) {
+        DFGPU_CHECK(end - p >= 2, "parquet: truncated snappy copy");
+        l = (tag >> 2) + 1;
+        off = (size_t)p[0] | ((size_t)p[1] << 8);
+        p += 2;
+      } else {
+        DFGPU_CHECK(end - p >= 4, "parquet: truncated snappy copy");
+        l = (tag >> 2) + 1;
+        off = (size_t)p[0] | ((size_t)p[1] << 8) | ((size_t)p[2] << 16) | ((size_t)p[3] << 24);
+        p += 4;
+      }
+      DFGPU_CHECK(off != 0 && off <= o && o + l <= dst_len, "parquet: snappy copy out of range");
+      for (size_t i = 0; i < l; i++) dst[o + i] = dst[o + i - off];  // may overlap: byte by byte
+      o += l;
+    }
+  }
+  DFGPU_CHECK(o == dst_len, "parquet: snappy output shorter than the page header says");
+}
+
+using zstd_decompress_fn = size_t (*)(void*, size_t, const void*, size_t);
+using zstd_iserror_fn = unsigned (*)(size_t);
+void zstd_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_len) {
+  static zstd_decompress_fn dec = nullptr;
+  static zstd_iserror_fn iserr = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h) {
+      dec = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
+      iserr = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
+    }
+  });
+  DFGPU_CHECK(dec && iserr, "parquet: ZSTD pages need libzstd.so.1 on this host");
+  size_t r = dec(dst, dst_len, src, n);
+  DFGPU_CHECK(!iserr(r) && r == dst_len, "parquet: ZSTD page did not decompress to the size in its header");
+}
+
+void decompress(int codec, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_len) {
+  switch (codec) {
+    case DFGPU_PARQUET_UNCOMPRESSED:
+      DFGPU_CHECK(n == dst_len, "parquet: uncompressed page with different sizes");
+      std::memcpy(dst, src, n);
+      return;
+    case DFGPU_PARQUET_SNAPPY: snappy_decompress(src, n, dst, dst_len); return;
+    case DFGPU_PARQUET_ZSTD: zstd_decompress(src, n, dst, dst_len); return;
+  }
+  throw Error("parquet: compression codec " + std::to_string(codec) + " is not supported on the GPU scan path");
+}
+
+// --------------------------------------------------------------------------------------- RLE / bit-packed hybrid runs
+// Encodings.md "Run Length Encoding / Bit-Packing Hybrid": header varint h; h & 1: (h >> 1) groups of 8 bit-packed values,
+// else an RLE run of (h >> 1) copies of one value stored in ceil(bit_width / 8) bytes.
+struct Run {            // mirrored on the device
+  int64_t start;        // first value position (chunk-wide, in the space of non-null values)
+  int64_t payload;      // RLE: the repeated value; bit-packed: byte offset of the packed bits in the staging buffer
+  int32_t count;
+  int32_t bit_width;    // bit 31 set = bit-packed
+};
+constexpr int32_t RUN_PACKED = (int32_t)0x80000000;
+
+// walks the runs of one hybrid stream holding `n` values; fn(is_packed, count, rle_value, packed_bytes_ptr)
+template <typename F>
+void walk_runs(const uint8_t* p, const uint8_t* end, int bit_width, int64_t n, F&& fn) {
+  DFGPU_CHECK(bit_width >= 0 && bit_width <= 32, "parquet: bad bit width");
+  const int vbytes = (bit_width + 7) / 8;
+  int64_t done = 0;
+  while (done < n) {
+    Thrift v{p, end};
+    uint64_t h = v.varint();
+    p = v.p;
+    if (h & 1) {
+      const int64_t groups = (int64_t)(h >> 1);
+      const int64_t bytes = groups * bit_width;
+      DFGPU_CHECK(groups > 0 && end - p >= bytes, "parquet: bit-packed run overruns its page");
+      const int64_t cnt = std::min<int64_t>(groups * 8, n - done);   // the last group may be padding
+      fn(true, cnt, 0ull, p);
+      p += bytes;
+      done += cnt;
+    } else {
+      const int64_t cnt = (int64_t)(h >> 1);
+      DFGPU_CHECK(cnt > 0 && end - p >= vbytes, "parquet: RLE run overruns its page");
+      uint64_t val = 0;
+      for (int i = 0; i < vbytes; i++) val |= (uint64_t)p[i] << (8 * i);
+      p += vbytes;
+      fn(false, std::min<int64_t>(cnt, n - done), val, nullptr);
+      done += std::min<int64_t>(cnt, n - done);
+    }
+  }
+}
+
+// a page of the chunk as the device sees it
+struct PageDesc {
+  int64_t value_start;   // first non-null value of the page, chunk-wide
+  int64_t byte_offset;   // PLAIN: offset of the values in the staging buffer
+  int32_t first_run;     // dictionary-encoded: [first_run, next page's first_run) in the run table
+  int32_t kind;          // 0 PLAIN, 1 dictionary indices
+};
+
+struct ChunkPlan {       // everything the host learns from one chunk
+  std::vector<PageDesc> pages;
+  std::vector<Run> runs;
+  std::vector<uint8_t> staging;        // value bytes of every page (PLAIN values, packed index bits)
+  std::vector<uint64_t> validity;      // one bit per row; empty = no nulls
+  std::vector<uint8_t> dict_page;      // PLAIN-encoded dictionary values (uncompressed)
+  int32_t dict_count = 0;
+  int64_t rows = 0, values = 0;        // rows incl. NULLs; non-null values
+  dfgpu_parquet_chunk_info info{};
+};
+
+void set_bits(std::vector<uint64_t>& bm, int64_t pos, int64_t n) {
+  for (int64_t i = pos; i < pos + n;) {
+    const int64_t w = i >> 6, b = i & 63;
+    const int64_t take = std::min<int64_t>(64 - b, pos + n - i);
+    const uint64_t mask = (take == 64 ? ~0ull : ((1ull << take) - 1)) << b;
+    bm[(size_t)w] |= mask;
+    i += take;
+  }
+}
+// copy n bits from an LSB-first packed byte stream to bit position pos
+void copy_bits(std::vector<uint64_t>& bm, int64_t pos, const uint8_t* src, int64_t n) {
+  for (int64_t i = 0; i < n; i++)
+    if ((src[i >> 3] >> (i & 7)) & 1) bm[(size_t)((pos + i) >> 6)] |= 1ull << ((pos + i) & 63);
+}
+
+int phys_width(const dfgpu_parquet_column& c) {
+  switch (c.physical_type) {
+    case DFGPU_PARQUET_INT32: return 4;
+    case DFGPU_PARQUET_INT64: case DFGPU_PARQUET_DOUBLE: return 8;
+    case DFGPU_PARQUET_FIXED_LEN_BYTE_ARRAY:
+      DFGPU_CHECK(c.type_length >= 1 && c.type_length <= 16, "parquet: FIXED_LEN_BYTE_ARRAY longer than 16 bytes");
+      return c.type_length;
+    case DFGPU_PARQUET_BYTE_ARRAY: return 0;
+  }
+  throw Error("parquet: physical type " + std::to_string(c.physical_type) + " is not supported on the GPU scan path");
+}
+
+void check_target(const dfgpu_parquet_column& c) {
+  const int t = c.field.type;
+  bool ok = false;
+  switch (c.physical_type) {
+    case DFGPU_PARQUET_INT32: ok = t == DFGPU_INT32 || t == DFGPU_DATE32 || t == DFGPU_UINT8 || t == DFGPU_UINT32 || t == DFGPU_DECIMAL128; break;
+    case DFGPU_PARQUET_INT64: ok = t == DFGPU_INT64 || t == DFGPU_UINT64 || t == DFGPU_DECIMAL128; break;
+    case DFGPU_PARQUET_DOUBLE: ok = t == DFGPU_FLOAT64; break;
+    case DFGPU_PARQUET_FIXED_LEN_BYTE_ARRAY: ok = t == DFGPU_DECIMAL128; break;
+    case DFGPU_PARQUET_BYTE_ARRAY: ok = t == DFGPU_INT32; break;   // dictionary indices of a string column
+  }
+  DFGPU_CHECK(ok, "parquet: physical type " + std::to_string(c.physical_type) + " cannot be read as " + type_name(c.field));
+  DFGPU_CHECK(c.max_repetition_level == 0, "parquet: repeated (nested) columns are not supported on the GPU scan path");
+  DFGPU_CHECK(c.max_definition_level == 0 || c.max_definition_level == 1, "parquet: nested optional columns are not supported on the GPU scan path");
+}
+
+// parse + decompress every page of the chunk; no device work
+ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_column& col) {
+  check_target(col);
+  const int pw = phys_width(col);
+  ChunkPlan P;
+  const bool nullable = col.max_definition_level == 1;
+  if (nullable) P.validity.assign((size_t)((col.num_values + 63) / 64) + 1, 0ull);
+  const uint8_t* p = chunk;
+  const uint8_t* end = chunk + nbytes;
+  std::vector<uint8_t> body;
+  while (P.rows < col.num_values) {
+    DFGPU_CHECK(p < end, "parquet: the chunk ends before its num_values rows");
+    Thrift t{p, end};
+    PageHeader h = parse_page_header(t);
+    p = t.p;
+    DFGPU_CHECK(end - p >= h.compressed, "parquet: page body overruns the chunk");
+    const uint8_t* raw = p;
+    p += h.compressed;
+    P.info.n_pages++;
+    P.info.compressed_bytes += h.compressed;
+    P.info.uncompressed_bytes += h.uncompressed;
+    if (h.type == PAGE_INDEX) continue;
+    if (h.type == PAGE_DICTIONARY) {
+      DFGPU_CHECK(P.dict_page.empty() && P.pages.empty(), "parquet: more than one dictionary page, or a dictionary page after data pages");
+      DFGPU_CHECK(h.encoding == ENC_PLAIN || h.encoding == ENC_PLAIN_DICTIONARY, "parquet: dictionary page encoding " + std::to_string(h.encoding));
+      P.dict_page.resize((size_t)h.uncompressed + 16);
+      decompress(col.codec, raw, (size_t)h.compressed, P.dict_page.data(), (size_t)h.uncompressed);
+      P.dict_page.resize((size_t)h.uncompressed);
+      P.dict_count = h.num_values;
+      P.info.n_dictionary_pages++;
+      continue;
+    }
+    DFGPU_CHECK(h.type == PAGE_DATA || h.type == PAGE_DATA_V2, "parquet: unknown page type " + std::to_string(h.type));
+    // ---- uncompressed page body: v1 = [def levels][values] compressed together; v2 = levels uncompressed + values
+    body.assign((size_t)h.uncompressed + 16, 0);
+    const uint8_t* levels = nullptr;
+    int64_t level_bytes = 0;
+    const uint8_t* values;
+    const uint8_t* values_end;
+    if (h.type == PAGE_DATA) {
+      decompress(col.codec, raw, (size_t)h.compressed, body.data(), (size_t)h.uncompressed);
+      const uint8_t* b = body.data();
+      if (nullable) {
+        DFGPU_CHECK(h.def_encoding == ENC_RLE, "parquet: definition levels with the deprecated BIT_PACKED encoding");
+        DFGPU_CHECK(h.uncompressed >= 4, "parquet: data page too short for its level length");
+        uint32_t lb;
+        std::memcpy(&lb, b, 4);
+        DFGPU_CHECK((int64_t)lb + 4 <= h.uncompressed, "parquet: definition levels overrun the page");
+        levels = b + 4;
+        level_bytes = lb;
+        b += 4 + lb;
+      }
+      values = b;
+      values_end = body.data() + h.uncompressed;
+      P.info.n_data_pages_v1++;
+    } else {
+      DFGPU_CHECK(h.rep_bytes == 0, "parquet: repetition levels in a flat column");
+      DFGPU_CHECK((int64_t)h.def_bytes <= h.compressed && (int64_t)h.def_bytes <= h.uncompressed, "parquet: v2 level bytes overrun the page");
+      levels = raw;
+      level_bytes = h.def_bytes;
+      const size_t vu = (size_t)(h.uncompressed - h.def_bytes), vc = (size_t)(h.compressed - h.def_bytes);
+      decompress(h.v2_compressed ? col.codec : DFGPU_PARQUET_UNCOMPRESSED, raw + h.def_bytes, vc, body.data(), vu);
+      values = body.data();
+      values_end = body.data() + vu;
+      P.info.n_data_pages_v2++;
+    }
+    // ---- definition levels -> validity bits, non-null count of the page
+    int64_t nonnull = h.num_values;
+    if (nullable) {
+      nonnull = 0;
+      int64_t row = P.rows;
+      walk_runs(levels, levels + level_bytes, 1, h.num_values, [&](bool packed, int64_t cnt, uint64_t val, const uint8_t* bits) {
+        if (packed) {
+          copy_bits(P.validity, row, bits, cnt);
+          for (int64_t i = 0; i < cnt; i++) nonnull += (bits[i >> 3] >> (i & 7)) & 1;
+        } else if (val) {
+          set_bits(P.validity, row, cnt);
+          nonnull += cnt;
+        }
+        row += cnt;
+      });
+    } else if (level_bytes) {
+      // a required column written with (empty) level data: nothing to read
+    }
+    // ---- values
+    PageDesc d{};
+    d.value_start = P.values;
+    d.first_run = (int32_t)P.runs.size();
+    const size_t base = (P.staging.size() + 15) & ~size_t(15);
+    if (h.encoding == ENC_PLAIN) {
+      DFGPU_CHECK(pw > 0, "parquet: PLAIN-encoded BYTE_ARRAY pages (strings outside a dictionary) are not supported on the GPU scan path");
+      DFGPU_CHECK(values_end - values >= nonnull * pw, "parquet: PLAIN values overrun the page");
+      P.staging.resize(base + (size_t)(nonnull * pw));
+      std::memcpy(P.staging.data() + base, values, (size_t)(nonnull * pw));
+      d.kind = 0;
+      d.byte_offset = (int64_t)base;
+      P.info.n_plain_pages++;
+    } else if (h.encoding == ENC_RLE_DICTIONARY || h.encoding == ENC_PLAIN_DICTIONARY) {
+      DFGPU_CHECK(!P.dict_page.empty() || P.dict_count == 0, "parquet: dictionary-encoded page without a dictionary page");
+      DFGPU_CHECK(values_end > values || nonnull == 0, "parquet: dictionary-encoded page without a bit width");
+      d.kind = 1;
+      if (nonnull) {
+        const int bw = values[0];
+        DFGPU_CHECK(bw <= 32, "parquet: dictionary index bit width " + std::to_string(bw));
+        const uint8_t* rp = values + 1;
+        P.staging.resize(base + (size_t)(values_end - rp) + 8);   // +8: the unpacker reads whole 64-bit windows
+        std::memcpy(P.staging.data() + base, rp, (size_t)(values_end - rp));
+        int64_t at = P.values;
+        walk_runs(rp, values_end, bw, nonnull, [&](bool packed, int64_t cnt, uint64_t val, const uint8_t* bits) {
+          Run r{};
+          r.start = at;
+          r.count = (int32_t)cnt;
+          r.bit_width = packed ? (bw | RUN_PACKED) : bw;
+          r.payload = packed ? (int64_t)base + (bits - rp) : (int64_t)val;
+          if (!packed) DFGPU_CHECK(val < (uint64_t)std::max(P.dict_count, 1), "parquet: dictionary index out of range");
+          P.runs.push_back(r);
+          (packed ? P.info.n_runs_bitpacked : P.info.n_runs_rle)++;
+          at += cnt;
+        });
+      }
+      P.info.n_dictionary_encoded_pages++;
+    } else {
+      throw Error("parquet: value encoding " + std::to_string(h.encoding) + " is not supported on the GPU scan path");
+    }
+    P.pages.push_back(d);
+    P.rows += h.num_values;
+    P.values += nonnull;
+  }
+  DFGPU_CHECK(P.rows == col.num_values, "parquet: pages hold more rows than the chunk's num_values");
+  P.info.values = P.rows;
+  P.info.nulls = P.rows - P.values;
+  if (!nullable || P.values == P.rows) P.validity.clear();
+  return P;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------- device side
+struct PqArgs {
+  const PageDesc* pages;
+  const Run* runs;
+  const uint8_t* staging;
+  const void* dict;     // dictionary values already in the TARGET representation (width out_w)
+  int32_t n_pages, n_runs, dict_count;
+  int32_t phys_w;       // bytes per PLAIN value
+  int32_t big_endian;   // PLAIN FIXED_LEN_BYTE_ARRAY decimals: big-endian two's complement
+  int32_t sign_extend;  // PLAIN INT32 / INT64 widened to a signed wider target
+};
+
+__device__ __forceinline__ uint32_t pq_unpack(const uint8_t* base, int64_t bit, int bw) {
+  // unaligned 64-bit window starting at the value's byte; bw <= 32 and bit & 7 <= 7 => 39 bits suffice
+  const uint8_t* q = base + (bit >> 3);
+  uint64_t w = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) w |= (uint64_t)q[i] << (8 * i);
+  return (uint32_t)((w >> (bit & 7)) & ((bw == 32) ? 0xFFFFFFFFull : ((1ull << bw) - 1)));
+}
+
+// one thread per non-null value: page by binary search (pages are few), run by binary search inside the page
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_pq_decode(PqArgs a, int64_t n_values, T* __restrict__ out) {
+  for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < n_values; v += (int64_t)gridDim.x * BLOCK) {
+    int lo = 0, hi = a.n_pages - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (a.pages[mid].value_start <= v) lo = mid; else hi = mid - 1;
+    }
+    const PageDesc pg = a.pages[lo];
+    T val;
+    if (pg.kind == 0) {
+      const uint8_t* src = a.staging + pg.byte_offset + (v - pg.value_start) * a.phys_w;
+      if (a.big_endian) {
+        // n-byte big-endian two's complement -> i128
+        i128 x = (int8_t)src[0];
+        for (int i = 1; i < a.phys_w; i++) x = (x << 8) | src[i];
+        val = (T)x;
+      } else if (a.phys_w == 4) {
+        uint32_t u;
+        memcpy(&u, src, 4);
+        val = a.sign_extend ? (T)(int32_t)u : (T)u;
+      } else {
+        uint64_t u;
+        memcpy(&u, src, 8);
+        val = a.sign_extend ? (T)(int64_t)u : (T)u;
+      }
+    } else {
+      int rl = pg.first_run, rh = (lo + 1 < a.n_pages ? a.pages[lo + 1].first_run : a.n_runs) - 1;
+      while (rl < rh) {
+        const int mid = (rl + rh + 1) >> 1;
+        if (a.runs[mid].start <= v) rl = mid; else rh = mid - 1;
+      }
+      const Run r = a.runs[rl];
+      uint32_t idx;
+      if (r.bit_width < 0) {
+        const int bw = r.bit_width & 0xFF;
+        idx = pq_unpack(a.staging + r.payload, (v - r.start) * bw, bw);
+      } else {
+        idx = (uint32_t)r.payload;
+      }
+      if (idx >= (uint32_t)a.dict_count) idx = 0;   // corrupt index: stay inside the dictionary (the host checked RLE runs)
+      val = reinterpret_cast<const T*>(a.dict)[idx];
+    }
+    out[v] = val;
+  }
+}
+
+// NULL expansion: out[row] = valid(row) ? dense[rank(row)] : 0, rank from the per-word popcount prefix
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_pq_expand(const T* __restrict__ dense, const uint64_t* __restrict__ valid, const uint64_t* __restrict__ prefix, int64_t n_rows,
+                                                     T* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * BLOCK) {
+    const uint64_t w = valid[i >> 6];
+    const int b = (int)(i & 63);
+    T v{};
+    if ((w >> b) & 1ull) v = dense[prefix[i >> 6] + __popcll(w & ((1ull << b) - 1ull))];
+    out[i] = v;
+  }
+}
+
+namespace {
+
+// dictionary page (PLAIN) -> host array in the target representation
+std::vector<uint8_t> convert_dictionary(const ChunkPlan& P, const dfgpu_parquet_column& col, int out_w) {
+  const int pw = phys_width(col);
+  std::vector<uint8_t> out((size_t)std::max(P.dict_count, 1) * out_w, 0);
+  DFGPU_CHECK((int64_t)P.dict_page.size() >= (int64_t)P.dict_count * pw, "parquet: dictionary page shorter than its value count");
+  for (int32_t i = 0; i < P.dict_count; i++) {
+    const uint8_t* s = P.dict_page.data() + (size_t)i * pw;
+    i128 x;
+    if (col.physical_type == DFGPU_PARQUET_FIXED_LEN_BYTE_ARRAY) {
+      x = (int8_t)s[0];
+      for (int k = 1; k < pw; k++) x = (x << 8) | s[k];
+    } else if (pw == 4) {
+      int32_t v;
+      std::memcpy(&v, s, 4);
+      x = is_signed_type(col.field.type) ? (i128)v : (i128)(uint32_t)v;
+    } else {
+      int64_t v;
+      std::memcpy(&v, s, 8);
+      x = (col.field.type == DFGPU_UINT64 || col.field.type == DFGPU_FLOAT64) ? (i128)(uint64_t)v : (i128)v;
+    }
+    std::memcpy(out.data() + (size_t)i * out_w, &x, (size_t)out_w);   // little endian: the low out_w bytes
+  }
+  return out;
+}
+
+// BYTE_ARRAY dictionary page -> strings; returns rank[old index] in the ascending order of the strings
+std::shared_ptr<DictValues> string_dictionary(const ChunkPlan& P, const std::string& name, std::vector<int32_t>& rank) {
+  std::vector<std::string> vals;
+  const uint8_t* p = P.dict_page.data();
+  const uint8_t* end = p + P.dict_page.size();
+  for (int32_t i = 0; i < P.dict_count; i++) {
+    DFGPU_CHECK(end - p >= 4, "parquet: truncated string dictionary");
+    uint32_t len;
+    std::memcpy(&len, p, 4);
+    p += 4;
+    DFGPU_CHECK((uint64_t)(end - p) >= len, "parquet: truncated string dictionary");
+    vals.emplace_back((const char*)p, (size_t)len);
+    p += len;
+  }
+  std::vector<int32_t> order((size_t)P.dict_count);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return vals[(size_t)x] < vals[(size_t)y]; });
+  auto dv = std::make_shared<DictValues>();
+  dv->index_format = "i";
+  dv->value_format = "u";
+  rank.assign((size_t)P.dict_count, 0);
+  for (int32_t k = 0; k < P.dict_count; k++) {
+    if (k > 0) DFGPU_CHECK(vals[(size_t)order[(size_t)k - 1]] != vals[(size_t)order[(size_t)k]], "parquet: column '" + name + "': duplicate dictionary value");
+    rank[(size_t)order[(size_t)k]] = k;
+    dv->values.push_back(vals[(size_t)order[(size_t)k]]);
+    dv->valid.push_back(1);
+  }
+  dv->sorted = true;
+  return dv;
+}
+
+template <typename T>
+void launch_decode(const PqArgs& a, int64_t n_values, void* out) {
+  if (n_values) k_pq_decode<T><<<grid_for(n_values, BLOCK), BLOCK, 0, rt().stream>>>(a, n_values, (T*)out);
+}
+template <typename T>
+void launch_expand(const void* dense, const uint64_t* valid, const uint64_t* prefix, int64_t n_rows, void* out) {
+  if (n_rows) k_pq_expand<T><<<grid_for(n_rows, BLOCK), BLOCK, 0, rt().stream>>>((const T*)dense, valid, prefix, n_rows, (T*)out);
+}
+
+Column decode_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_column& col) {
+  ChunkPlan P = plan_chunk(chunk, nbytes, col);
+  hipStream_t st = rt().stream;
+  dfgpu_field f = col.field;
+  f.nullable = col.max_definition_level ? 1 : 0;
+  const int out_w = type_width(f.type);
+  Column c = alloc_column(f, col.name ? col.name : "", P.rows);
+  // dictionary in the target representation
+  std::vector<uint8_t> dict_host;
+  if (col.physical_type == DFGPU_PARQUET_BYTE_ARRAY) {
+    std::vector<int32_t> rank;
+    c.dict = string_dictionary(P, c.name, rank);
+    dict_host.resize((size_t)std::max<size_t>(rank.size(), 1) * 4, 0);
+    if (!rank.empty()) std::memcpy(dict_host.data(), rank.data(), rank.size() * 4);
+  } else if (P.dict_count) {
+    dict_host = convert_dictionary(P, col, out_w);
+  }
+  BufPtr d_dict = make_buf(dict_host.size() + 16), d_stage = make_buf(P.staging.size() + 16);
+  BufPtr d_pages = make_buf(P.pages.size() * sizeof(PageDesc) + 16), d_runs = make_buf(P.runs.size() * sizeof(Run) + 16);
+  if (!dict_host.empty()) DFGPU_HIP(hipMemcpyAsync(d_dict->ptr, dict_host.data(), dict_host.size(), hipMemcpyHostToDevice, st));
+  if (!P.staging.empty()) DFGPU_HIP(hipMemcpyAsync(d_stage->ptr, P.staging.data(), P.staging.size(), hipMemcpyHostToDevice, st));
+  if (!P.pages.empty()) DFGPU_HIP(hipMemcpyAsync(d_pages->ptr, P.pages.data(), P.pages.size() * sizeof(PageDesc), hipMemcpyHostToDevice, st));
+  if (!P.runs.empty()) DFGPU_HIP(hipMemcpyAsync(d_runs->ptr, P.runs.data(), P.runs.size() * sizeof(Run), hipMemcpyHostToDevice, st));
+  PqArgs a{};
+  a.pages = d_pages->as<PageDesc>();
+  a.runs = d_runs->as<Run>();
+  a.staging = d_stage->as<uint8_t>();
+  a.dict = d_dict->ptr;
+  a.n_pages = (int32_t)P.pages.size();
+  a.n_runs = (int32_t)P.runs.size();
+  a.dict_count = std::max(P.dict_count, 1);
+  a.phys_w = std::max(phys_width(col), 1);
+  a.big_endian = col.physical_type == DFGPU_PARQUET_FIXED_LEN_BYTE_ARRAY;
+  a.sign_extend = is_signed_type(f.type) && f.type != DFGPU_FLOAT64;
+  const bool has_nulls = !P.validity.empty();
+  BufPtr dense;
+  void* target = c.data->ptr;
+  if (has_nulls) {
+    dense = make_buf((size_t)std::max<int64_t>(P.values, 1) * out_w + 16);
+    target = dense->ptr;
+  }
+  {
+    ProfileScope ps("parquet_decode", (int64_t)P.staging.size() + P.values * out_w);
+    switch (out_w) {
+      case 16: launch_decode<i128>(a, P.values, target); break;
+      case 8: launch_decode<uint64_t>(a, P.values, target); break;
+      case 4: launch_decode<uint32_t>(a, P.values, target); break;
+      default: launch_decode<uint8_t>(a, P.values, target); break;
+    }
+  }
+  if (has_nulls) {
+    const size_t bb = bitmap_bytes(P.rows);
+    c.validity = make_buf(bb);
+    c.null_count = P.rows - P.values;
+    DFGPU_HIP(hipMemcpyAsync(c.validity->ptr, P.validity.data(), bb, hipMemcpyHostToDevice, st));
+    BufPtr prefix = make_buf((size_t)((P.rows + 63) / 64 + 1) * 8);
+    scan_mask_popcounts(c.validity->as<uint64_t>(), nullptr, P.rows, prefix->as<uint64_t>());
+    switch (out_w) {
+      case 16: launch_expand<i128>(dense->ptr, c.valid_words(), prefix->as<uint64_t>(), P.rows, c.data->ptr); break;
+      case 8: launch_expand<uint64_t>(dense->ptr, c.valid_words(), prefix->as<uint64_t>(), P.rows, c.data->ptr); break;
+      case 4: launch_expand<uint32_t>(dense->ptr, c.valid_words(), prefix->as<uint64_t>(), P.rows, c.data->ptr); break;
+      default: launch_expand<uint8_t>(dense->ptr, c.valid_words(), prefix->as<uint64_t>(), P.rows, c.data->ptr); break;
+    }
+  }
+  DFGPU_HIP(hipStreamSynchronize(st));   // the host vectors above are the copies' sources
+  return c;
+}
+
+}  // namespace
+}  // namespace dfgpu
+
+using namespace dfgpu;
+
+extern "C" {
+
+int dfgpu_parquet_inspect_chunk(const uint8_t* chunk, int64_t chunk_bytes, const dfgpu_parquet_column* column, dfgpu_parquet_chunk_info* out) {
+  return guarded([&] {
+    DFGPU_CHECK(chunk && column && out && chunk_bytes >= 0, "null argument");
+    ChunkPlan P = plan_chunk(chunk, chunk_bytes, *column);
+    *out = P.info;
+    out->dictionary_values = P.dict_count;
+  });
+}
+
+int dfgpu_parquet_decode_chunk(const uint8_t* chunk, int64_t chunk_bytes, const dfgpu_parquet_column* column, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(chunk && column && out && chunk_bytes >= 0, "null argument");
+    auto t = std::make_unique<Table>();
+    t->cols.push_back(decode_chunk(chunk, chunk_bytes, *column));
+    t->nrows = t->cols[0].length;
+    *out = wrap(t.release());
+  });
+}
+
+}  // extern "C"

@@ -1,6 +1,7 @@
 // table.hip — device tables (Arrow-layout columns in HBM) and the Arrow C Data Interface
 // boundary: import (host RecordBatch -> HBM, pinned with hipHostRegister + async copies on a
 // side stream) and export (HBM -> host struct array with release callbacks).
+#include "device.hpp"
 #include "internal.hpp"
 
 #include <cstdio>
@@ -8,6 +9,34 @@
 #include <map>
 
 namespace dfgpu {
+
+// dst bits [off, off + n) |= src bits [0, n) (src null = all ones); dst starts zeroed; one thread per destination word
+__global__ __launch_bounds__(BLOCK) void k_bitmap_place(const uint64_t* __restrict__ src, int64_t off, int64_t n, unsigned long long* __restrict__ dst) {
+  const int64_t w0 = off >> 6, w1 = (off + n + 63) >> 6;
+  for (int64_t w = w0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < w1; w += (int64_t)gridDim.x * BLOCK) {
+    const int64_t first = max((w << 6), off), last = min((w << 6) + 64, off + n);   // destination bit range of this word
+    if (first >= last) continue;
+    const int64_t s = first - off;                        // source bit of `first`
+    const int len = (int)(last - first);
+    uint64_t v;
+    if (!src) {
+      v = ~0ull;
+    } else {
+      const int64_t sw = s >> 6;
+      const int sb = (int)(s & 63);
+      v = src[sw] >> sb;
+      if (sb && sb + len > 64) v |= src[sw + 1] << (64 - sb);
+    }
+    if (len < 64) v &= (1ull << len) - 1ull;
+    atomicOr(&dst[w], (unsigned long long)(v << (first & 63)));
+  }
+}
+
+// dictionary indices of one concat part rewritten into the merged dictionary: out[i] = remap[in[i]]
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_remap_indices(const T* __restrict__ in, const int32_t* __restrict__ remap, int64_t n, T* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (T)remap[(size_t)in[i]];
+}
 
 // ---------------------------------------------------------------- format strings
 static dfgpu_field parse_format(const char* fmt, bool nullable) {
@@ -454,14 +483,71 @@ int dfgpu_table_concat(const dfgpu_table_t* parts, int nparts, dfgpu_table_t* ou
       DFGPU_CHECK(fc.field.type != DFGPU_BOOL, "concat: Boolean columns not supported yet");
       int w = type_width(fc.field.type);
       int64_t off = 0;
+      bool any_nulls = false;
+      for (int p = 0; p < nparts; p++) any_nulls |= unwrap(parts[p])->cols[ci].validity != nullptr;
+      if (any_nulls) {
+        n.validity = make_zero_buf(bitmap_bytes(total));
+        n.null_count = -1;
+      }
+      // dictionary-encoded parts with different dictionaries (row groups of a Parquet file, partitions of an exchange):
+      // one merged ascending dictionary, every part's indices rewritten into it
+      std::shared_ptr<DictValues> merged;
+      std::map<std::string, int32_t> merged_index;
+      std::vector<BufPtr> keep;
+      if (fc.dict) {
+        bool same = true;
+        for (int p = 0; p < nparts; p++) {
+          const auto& d = unwrap(parts[p])->cols[ci].dict;
+          same &= d == fc.dict || (d && d->values == fc.dict->values && d->valid == fc.dict->valid);
+        }
+        if (!same) {
+          for (int p = 0; p < nparts; p++) {
+            const auto& d = unwrap(parts[p])->cols[ci].dict;
+            DFGPU_CHECK(d != nullptr, "concat: dictionary-encoded and plain columns mixed");
+            for (size_t k = 0; k < d->values.size(); k++) merged_index.emplace(d->valid[k] ? d->values[k] : std::string("\0null", 5), 0);
+          }
+          merged = std::make_shared<DictValues>();
+          merged->index_format = fc.dict->index_format;
+          merged->value_format = fc.dict->value_format;
+          int32_t next = 0;
+          bool has_null_value = false;
+          for (auto& kv : merged_index) {   // std::map iterates in ascending key order; the NULL marker sorts first
+            kv.second = next++;
+            const bool is_null = kv.first.size() == 5 && kv.first[0] == '\0';
+            has_null_value |= is_null;
+            merged->values.push_back(is_null ? std::string() : kv.first);
+            merged->valid.push_back(is_null ? 0 : 1);
+          }
+          merged->sorted = !has_null_value;
+          DFGPU_CHECK(w > 1 || next <= 256, "concat: the merged dictionary does not fit the UInt8 index type");
+          n.dict = merged;
+        }
+      }
       for (int p = 0; p < nparts; p++) {
         Table* t = unwrap(parts[p]);
         const Column& c = t->cols[ci];
         DFGPU_CHECK(c.field.type == fc.field.type, "concat: column type mismatch");
-        DFGPU_CHECK(c.dict == fc.dict || (c.dict && fc.dict && c.dict->values == fc.dict->values && c.dict->valid == fc.dict->valid),
-                    "concat: the parts' dictionaries differ");
-        DFGPU_CHECK(!c.validity, "concat: nullable columns not supported yet");
-        if (t->nrows)
+        DFGPU_CHECK((c.dict != nullptr) == (fc.dict != nullptr), "concat: dictionary-encoded and plain columns mixed");
+        if (merged && t->nrows) {
+          // this part's indices -> indices of the merged dictionary
+          std::vector<int32_t> remap(c.dict->values.size(), 0);
+          for (size_t k = 0; k < remap.size(); k++) remap[k] = merged_index.at(c.dict->valid[k] ? c.dict->values[k] : std::string("\0null", 5));
+          BufPtr d_remap = make_buf(remap.size() * 4 + 16);
+          DFGPU_HIP(hipMemcpyAsync(d_remap->ptr, remap.data(), remap.size() * 4, hipMemcpyHostToDevice, rt().stream));
+          DFGPU_HIP(hipStreamSynchronize(rt().stream));   // `remap` is a local
+          char* dst = (char*)n.data->ptr + (size_t)off * w;
+          const int g = grid_for(t->nrows, BLOCK);
+          switch (w) {
+            case 1: k_remap_indices<uint8_t><<<g, BLOCK, 0, rt().stream>>>((const uint8_t*)c.ptr(), d_remap->as<int32_t>(), t->nrows, (uint8_t*)dst); break;
+            case 4: k_remap_indices<uint32_t><<<g, BLOCK, 0, rt().stream>>>((const uint32_t*)c.ptr(), d_remap->as<int32_t>(), t->nrows, (uint32_t*)dst); break;
+            default: k_remap_indices<uint64_t><<<g, BLOCK, 0, rt().stream>>>((const uint64_t*)c.ptr(), d_remap->as<int32_t>(), t->nrows, (uint64_t*)dst); break;
+          }
+          keep.push_back(d_remap);
+        }
+        if (any_nulls && t->nrows)
+          k_bitmap_place<<<grid_for((t->nrows + 127) / 64, BLOCK), BLOCK, 0, rt().stream>>>(c.valid_words(), off, t->nrows,
+                                                                                            (unsigned long long*)n.validity->ptr);
+        if (t->nrows && !merged)
           DFGPU_HIP(hipMemcpyAsync((char*)n.data->ptr + (size_t)off * w, c.ptr(), (size_t)t->nrows * w, hipMemcpyDeviceToDevice, rt().stream));
         off += t->nrows;
       }

@@ -1,0 +1,126 @@
+"""Scan -> device: Parquet column chunks decoded on the GPU.
+
+Host side of the GPU scan node a DataFusion shim would put in place of `DataSourceExec` over a Parquet source
+(datasource/src/source.rs:366, datasource-parquet): footer metadata -> for every projected column chunk of every row group
+its byte range -> `dfgpu_parquet_decode_chunk` (include/dfgpu.h; page headers, decompression and run headers on the host,
+value decoding on the device) -> row groups assembled with dfgpu_table_hstack / dfgpu_table_concat.  The footer is read
+with pyarrow here (the shim has it from the `parquet` crate's `ParquetMetaData`); no value byte is decoded on the CPU.
+Unsupported chunks (nested columns, DELTA / BYTE_STREAM_SPLIT encodings, strings outside a dictionary, other codecs) raise
+DfgpuError: the rule keeps the CPU scan for such files.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import mmap
+
+import pyarrow as pa
+import pyarrow.parquet as pq
+
+from . import _lib
+from ._lib import ParquetChunkInfo, ParquetColumn, check
+from .table import DeviceTable, field_of
+
+PHYSICAL = {"BOOLEAN": 0, "INT32": 1, "INT64": 2, "INT96": 3, "FLOAT": 4, "DOUBLE": 5, "BYTE_ARRAY": 6, "FIXED_LEN_BYTE_ARRAY": 7}
+CODEC = {"UNCOMPRESSED": 0, "SNAPPY": 1, "GZIP": 2, "LZO": 3, "BROTLI": 4, "LZ4": 5, "ZSTD": 6, "LZ4_RAW": 7}
+
+
+def _target_field(arrow_type: pa.DataType):
+    """device type of a column: strings become the Int32 indices of a dictionary-encoded column"""
+    if pa.types.is_string(arrow_type) or pa.types.is_large_string(arrow_type) or \
+            (pa.types.is_dictionary(arrow_type) and pa.types.is_string(arrow_type.value_type)):
+        return field_of(pa.int32())
+    return field_of(arrow_type)
+
+
+class ParquetFile:
+    """one Parquet file: footer via pyarrow, bytes via mmap"""
+
+    def __init__(self, path: str):
+        self.path = path
+        self.pf = pq.ParquetFile(path)
+        self.meta = self.pf.metadata
+        self.arrow_schema = self.pf.schema_arrow
+        self._f = open(path, "rb")
+        self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+
+    def close(self):
+        self._mm.close()
+        self._f.close()
+
+    @property
+    def num_row_groups(self) -> int:
+        return self.meta.num_row_groups
+
+    @property
+    def column_names(self):
+        return self.arrow_schema.names
+
+    def _chunk(self, row_group: int, column: str):
+        """(pointer, byte length, ParquetColumn descriptor, keep-alive) of one column chunk"""
+        j = self.arrow_schema.names.index(column)
+        cc = self.meta.row_group(row_group).column(j)
+        sc = self.pf.schema.column(j)
+        start = cc.data_page_offset
+        if cc.has_dictionary_page and cc.dictionary_page_offset is not None and 0 < cc.dictionary_page_offset < start:
+            start = cc.dictionary_page_offset
+        nbytes = cc.total_compressed_size
+        raw = self._mm[start:start + nbytes]                    # a copy of the chunk's bytes (the shim: its fetched range)
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        name = column.encode()
+        d = ParquetColumn()
+        d.physical_type = PHYSICAL[cc.physical_type]
+        d.type_length = sc.length if sc.length is not None and sc.length > 0 else 0
+        d.codec = CODEC[cc.compression]
+        d.max_definition_level = sc.max_definition_level
+        d.max_repetition_level = sc.max_repetition_level
+        d.num_values = cc.num_values
+        d.field = _target_field(self.arrow_schema.field(j).type)
+        d.name = name
+        return buf, len(raw), d, (name,)
+
+    def inspect_chunk(self, row_group: int, column: str) -> dict:
+        """the host half alone (no GPU): page / run / byte counts of one chunk"""
+        buf, n, d, keep = self._chunk(row_group, column)
+        info = ParquetChunkInfo()
+        check(_lib.load().dfgpu_parquet_inspect_chunk(buf, C.c_int64(n), C.byref(d), C.byref(info)))
+        return {k: getattr(info, k) for k, _ in ParquetChunkInfo._fields_}
+
+    def read_row_group(self, row_group: int, columns=None) -> DeviceTable:
+        lib = _lib.init()
+        out = None
+        for name in (columns or self.column_names):
+            buf, n, d, keep = self._chunk(row_group, name)
+            h = C.c_void_p()
+            check(lib.dfgpu_parquet_decode_chunk(buf, C.c_int64(n), C.byref(d), C.byref(h)))
+            col = DeviceTable(h)
+            if out is None:
+                out = col
+            else:
+                both = C.c_void_p()
+                check(lib.dfgpu_table_hstack(out.handle, col.handle, C.byref(both)))
+                out.free()
+                col.free()
+                out = DeviceTable(both)
+        return out
+
+    def read(self, columns=None) -> DeviceTable:
+        parts = [self.read_row_group(g, columns) for g in range(self.num_row_groups)]
+        if not parts:   # a file without row groups: the schema alone
+            sch = self.arrow_schema if columns is None else pa.schema([self.arrow_schema.field(c) for c in columns])
+            empty = [pa.array([], pa.dictionary(pa.int32(), pa.string()) if pa.types.is_string(f.type) else f.type) for f in sch]
+            return DeviceTable.from_arrow(pa.Table.from_arrays(empty, names=sch.names))
+        if len(parts) == 1:
+            return parts[0]
+        out = DeviceTable.concat(parts)
+        for p in parts:
+            p.free()
+        return out
+
+
+def read_table(path: str, columns=None) -> DeviceTable:
+    """every row group of `path`, the given columns, as one device table"""
+    f = ParquetFile(path)
+    try:
+        return f.read(columns)
+    finally:
+        f.close()

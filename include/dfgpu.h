@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 5
+#define DFGPU_ABI_VERSION 6
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -393,6 +393,48 @@ int dfgpu_sort(dfgpu_table_t input, const int* key_cols, const uint8_t* descendi
 int dfgpu_partition(dfgpu_table_t input, const int* key_cols, int nkeys, int nparts, dfgpu_table_t* outs);
 /* create_hashes (common/src/hash_utils.rs:1239) for tests / routing checks */
 int dfgpu_hash_columns(dfgpu_table_t input, const int* key_cols, int nkeys, uint64_t seed, uint64_t* out_device);
+
+/* ----------------------------------------------------------- scan -> device */
+
+/* One Parquet column chunk decoded straight into a device column.  The reference's scan
+ * (datasource-parquet, DataSourceExec datasource/src/source.rs:366) reads each projected column chunk's byte range
+ * (ColumnChunkMetaData: dictionary_page_offset | data_page_offset, total_compressed_size) and decodes pages on the CPU;
+ * a GPU scan node hands the same bytes to dfgpu_parquet_decode_chunk instead and assembles the row group with
+ * dfgpu_table_hstack / dfgpu_table_concat.  Enum values are parquet.thrift's. */
+typedef enum dfgpu_parquet_type {
+  DFGPU_PARQUET_BOOLEAN = 0, DFGPU_PARQUET_INT32 = 1, DFGPU_PARQUET_INT64 = 2, DFGPU_PARQUET_INT96 = 3, DFGPU_PARQUET_FLOAT = 4,
+  DFGPU_PARQUET_DOUBLE = 5, DFGPU_PARQUET_BYTE_ARRAY = 6, DFGPU_PARQUET_FIXED_LEN_BYTE_ARRAY = 7
+} dfgpu_parquet_type;
+typedef enum dfgpu_parquet_codec {
+  DFGPU_PARQUET_UNCOMPRESSED = 0, DFGPU_PARQUET_SNAPPY = 1, DFGPU_PARQUET_GZIP = 2, DFGPU_PARQUET_LZO = 3, DFGPU_PARQUET_BROTLI = 4,
+  DFGPU_PARQUET_LZ4 = 5, DFGPU_PARQUET_ZSTD = 6, DFGPU_PARQUET_LZ4_RAW = 7
+} dfgpu_parquet_codec;
+typedef struct dfgpu_parquet_column {
+  int32_t physical_type;         /* dfgpu_parquet_type (SchemaElement.type) */
+  int32_t type_length;           /* FIXED_LEN_BYTE_ARRAY: bytes per value */
+  int32_t codec;                 /* dfgpu_parquet_codec (ColumnMetaData.codec) */
+  int32_t max_definition_level;  /* 0 = required, 1 = optional; deeper nesting is not supported */
+  int32_t max_repetition_level;  /* must be 0 */
+  int32_t _pad;
+  int64_t num_values;            /* ColumnMetaData.num_values = rows of the row group for a flat column */
+  dfgpu_field field;             /* Arrow type to produce.  INT32 -> Int32 / Date32 / UInt8 / UInt32 / Decimal128, INT64 -> Int64 /
+                                  * UInt64 / Decimal128, DOUBLE -> Float64, FIXED_LEN_BYTE_ARRAY -> Decimal128, BYTE_ARRAY (all pages
+                                  * dictionary-encoded) -> Int32 indices of a dictionary-encoded string column (ascending dictionary) */
+  const char* name;
+} dfgpu_parquet_column;
+/* Supported: data pages v1 / v2, PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY values, RLE definition levels, UNCOMPRESSED /
+ * SNAPPY / ZSTD (libzstd.so.1 on the host).  Anything else returns an error and the caller keeps the CPU scan.
+ * `out` = a one-column device table of num_values rows. */
+int dfgpu_parquet_decode_chunk(const uint8_t* chunk, int64_t chunk_bytes, const dfgpu_parquet_column* column, dfgpu_table_t* out);
+/* the host half alone (page headers, decompression, levels, run headers): needs no GPU and no dfgpu_init */
+typedef struct dfgpu_parquet_chunk_info {
+  int32_t n_pages, n_dictionary_pages, n_data_pages_v1, n_data_pages_v2, n_plain_pages, n_dictionary_encoded_pages;
+  int64_t n_runs_rle, n_runs_bitpacked;
+  int64_t values, nulls;                       /* rows of the chunk, NULLs among them */
+  int64_t uncompressed_bytes, compressed_bytes; /* page bodies */
+  int64_t dictionary_values;
+} dfgpu_parquet_chunk_info;
+int dfgpu_parquet_inspect_chunk(const uint8_t* chunk, int64_t chunk_bytes, const dfgpu_parquet_column* column, dfgpu_parquet_chunk_info* out);
 
 /* ------------------------------------------------------ synthetic workload */
 

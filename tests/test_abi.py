@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert _lib.load().dfgpu_abi_version() == 5
+    assert _lib.load().dfgpu_abi_version() == 6
 
 
 def test_struct_layouts_match_header(tmp_path):

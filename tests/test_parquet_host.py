@@ -1,0 +1,75 @@
+"""Scan -> device, the host half (no GPU): dfgpu_parquet_inspect_chunk parses page headers (Thrift compact protocol),
+decompresses pages (UNCOMPRESSED / SNAPPY / ZSTD), reads definition levels and walks the run headers of the dictionary
+index streams — checked against the footer pyarrow wrote (row counts, NULL counts, dictionary sizes, byte totals)."""
+import pyarrow as pa
+import pytest
+
+from tests.parquet_cases import WRITER_MATRIX, case_id, sample_table, write
+
+
+@pytest.mark.parametrize("writer", WRITER_MATRIX, ids=[case_id(w) for w in WRITER_MATRIX])
+def test_inspect_matches_the_footer(tmp_path, writer):
+    from datafusion_amd.parquet import ParquetFile
+    t = sample_table(25_000)
+    path = write(t, tmp_path, "t.parquet", data_page_size=16 * 1024, row_group_size=15_000, **writer)
+    f = ParquetFile(path)
+    assert f.num_row_groups == 2
+    for g in range(f.num_row_groups):
+        for j, name in enumerate(t.column_names):
+            cc = f.meta.row_group(g).column(j)
+            info = f.inspect_chunk(g, name)
+            assert info["values"] == cc.num_values
+            assert info["nulls"] == t.column(name).slice(g * 15_000, cc.num_values).null_count
+            assert info["n_dictionary_pages"] == (1 if cc.has_dictionary_page else 0)
+            assert info["n_data_pages_v1"] + info["n_data_pages_v2"] == info["n_plain_pages"] + info["n_dictionary_encoded_pages"] >= 1
+            assert (info["n_data_pages_v2"] > 0) == (writer["data_page_version"] == "2.0")
+            assert info["compressed_bytes"] <= cc.total_compressed_size and info["uncompressed_bytes"] <= cc.total_uncompressed_size   # footer totals include the page headers
+            if writer["compression"] == "none":
+                assert info["compressed_bytes"] == info["uncompressed_bytes"]
+            if cc.has_dictionary_page and info["n_plain_pages"] == 0:
+                want = t.column(name).slice(g * 15_000, cc.num_values).drop_null()
+                assert info["dictionary_values"] == len(want.unique())
+    assert f.inspect_chunk(0, "runs")["n_runs_rle"] >= 100 if writer["use_dictionary"] else True
+    f.close()
+
+
+def test_unsupported_chunks_are_errors_not_wrong_answers(tmp_path):
+    from datafusion_amd import _lib
+    from datafusion_amd.parquet import ParquetFile
+    import pyarrow.parquet as pq
+    t = pa.table({"s": pa.array(["a", "b", "c"] * 10), "b": pa.array([True, False, True] * 10), "i": pa.array(list(range(30)), pa.int64()),
+                  "l": pa.array([[1, 2], [3], []] * 10, pa.list_(pa.int64()))})
+    path = str(tmp_path / "u.parquet")
+    pq.write_table(t, path, use_dictionary=False, compression="gzip", column_encoding=None)
+    f = ParquetFile(path)
+    with pytest.raises(_lib.DfgpuError, match="codec"):
+        f.inspect_chunk(0, "i")
+    f.close()
+    pq.write_table(t.select(["s", "b", "i"]), path, use_dictionary=False, compression="none")
+    f = ParquetFile(path)
+    with pytest.raises(_lib.DfgpuError, match="PLAIN-encoded BYTE_ARRAY"):
+        f.inspect_chunk(0, "s")
+    with pytest.raises(_lib.DfgpuError, match="physical type 0 cannot be read as Boolean"):
+        f.inspect_chunk(0, "b")
+    f.close()
+    pq.write_table(t.select(["i"]), path, use_dictionary=False, compression="none", column_encoding={"i": "DELTA_BINARY_PACKED"})
+    f = ParquetFile(path)
+    with pytest.raises(_lib.DfgpuError, match="value encoding 5"):
+        f.inspect_chunk(0, "i")
+    f.close()
+
+
+def test_truncated_chunk_is_an_error(tmp_path):
+    import ctypes as C
+
+    from datafusion_amd import _lib
+    from datafusion_amd._lib import ParquetChunkInfo
+    from datafusion_amd.parquet import ParquetFile
+    path = write(sample_table(5000, nulls=False), tmp_path, "t.parquet", compression="snappy")
+    f = ParquetFile(path)
+    buf, n, d, keep = f._chunk(0, "d")
+    info = ParquetChunkInfo()
+    for cut in (n // 2, 10, 0):
+        assert _lib.load().dfgpu_parquet_inspect_chunk(buf, C.c_int64(cut), C.byref(d), C.byref(info)) != 0
+        assert b"parquet" in _lib.load().dfgpu_last_error()
+    f.close()
