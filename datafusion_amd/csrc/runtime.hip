@@ -119,6 +119,7 @@ ProfileScope::~ProfileScope() {
   if (!a) return;
   Runtime& r = rt();
   (void)hipEventRecord(b, r.stream);
+  std::lock_guard<std::mutex> lk(r.mu);   // scan threads decode column chunks concurrently (parquet.hip)
   r.recs.push_back({name, a, b, bytes});
 }
 

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import ctypes as C
 import mmap
+import os
+from concurrent.futures import ThreadPoolExecutor
 
 import pyarrow as pa
 import pyarrow.parquet as pq
@@ -85,30 +87,46 @@ class ParquetFile:
         check(_lib.load().dfgpu_parquet_inspect_chunk(buf, C.c_int64(n), C.byref(d), C.byref(info)))
         return {k: getattr(info, k) for k, _ in ParquetChunkInfo._fields_}
 
-    def read_row_group(self, row_group: int, columns=None) -> DeviceTable:
-        lib = _lib.init()
-        out = None
-        for name in (columns or self.column_names):
-            buf, n, d, keep = self._chunk(row_group, name)
-            h = C.c_void_p()
-            check(lib.dfgpu_parquet_decode_chunk(buf, C.c_int64(n), C.byref(d), C.byref(h)))
-            col = DeviceTable(h)
-            if out is None:
-                out = col
-            else:
-                both = C.c_void_p()
-                check(lib.dfgpu_table_hstack(out.handle, col.handle, C.byref(both)))
-                out.free()
-                col.free()
-                out = DeviceTable(both)
+    def _decode(self, row_group: int, column: str) -> DeviceTable:
+        buf, n, d, keep = self._chunk(row_group, column)
+        h = C.c_void_p()
+        check(_lib.load().dfgpu_parquet_decode_chunk(buf, C.c_int64(n), C.byref(d), C.byref(h)))
+        return DeviceTable(h)
+
+    @staticmethod
+    def _hstack(cols) -> DeviceTable:
+        out = cols[0]
+        for col in cols[1:]:
+            both = C.c_void_p()
+            check(_lib.load().dfgpu_table_hstack(out.handle, col.handle, C.byref(both)))
+            out.free()
+            col.free()
+            out = DeviceTable(both)
         return out
 
-    def read(self, columns=None) -> DeviceTable:
-        parts = [self.read_row_group(g, columns) for g in range(self.num_row_groups)]
-        if not parts:   # a file without row groups: the schema alone
-            sch = self.arrow_schema if columns is None else pa.schema([self.arrow_schema.field(c) for c in columns])
+    def read_row_group(self, row_group: int, columns=None) -> DeviceTable:
+        _lib.init()
+        return self._hstack([self._decode(row_group, name) for name in (columns or self.column_names)])
+
+    def read(self, columns=None, threads: int | None = None) -> DeviceTable:
+        """all row groups.  The host half of a chunk (decompression above all) runs on one core, so chunks are decoded from
+        `threads` host threads (default min(16, cores), DFGPU_SCAN_THREADS overrides; ctypes releases the GIL) — the way the
+        reference's scan decodes row groups on its partition threads.  All device work stays on the library's one stream."""
+        _lib.init()
+        names = list(columns or self.column_names)
+        if self.num_row_groups == 0:   # a file without row groups: the schema alone
+            sch = pa.schema([self.arrow_schema.field(c) for c in names])
             empty = [pa.array([], pa.dictionary(pa.int32(), pa.string()) if pa.types.is_string(f.type) else f.type) for f in sch]
             return DeviceTable.from_arrow(pa.Table.from_arrays(empty, names=sch.names))
+        if threads is None:
+            threads = int(os.environ.get("DFGPU_SCAN_THREADS", min(16, os.cpu_count() or 1)))
+        work = [(g, c) for g in range(self.num_row_groups) for c in names]
+        if threads > 1 and len(work) > 1:
+            with ThreadPoolExecutor(threads) as ex:
+                chunks = list(ex.map(lambda gc: self._decode(*gc), work))
+        else:
+            chunks = [self._decode(g, c) for g, c in work]
+        parts = [self._hstack(chunks[g * len(names):(g + 1) * len(names)]) for g in range(self.num_row_groups)]
         if len(parts) == 1:
             return parts[0]
         out = DeviceTable.concat(parts)
@@ -117,10 +135,10 @@ class ParquetFile:
         return out
 
 
-def read_table(path: str, columns=None) -> DeviceTable:
+def read_table(path: str, columns=None, threads: int | None = None) -> DeviceTable:
     """every row group of `path`, the given columns, as one device table"""
     f = ParquetFile(path)
     try:
-        return f.read(columns)
+        return f.read(columns, threads)
     finally:
         f.close()
