@@ -113,6 +113,28 @@ class MemoryExec(ExecutionPlan):
         return f"{self.label} rows={self.table.num_rows}" + (f", projection={self.projection}" if self.projection else "")
 
 
+class ParquetExec(ExecutionPlan):
+    """DataSourceExec over a ParquetSource (datasource/src/source.rs:366, datasource-parquet) with the scan's column
+    projection — here the GPU scan: every projected column chunk is decoded on the device (parquet.ParquetFile.read,
+    dfgpu_parquet_decode_chunk).  The decoded table is owned by the node's consumer."""
+
+    def __init__(self, path: str, projection=None, name: str = ""):
+        self.path, self.projection, self.label = path, projection, name
+
+    def project(self, columns) -> "ParquetExec":
+        return ParquetExec(self.path, list(columns), self.label)
+
+    def with_new_children(self, children):
+        return self
+
+    def execute(self, partition=0):
+        from .parquet import read_table
+        return read_table(self.path, self.projection)
+
+    def detail(self):
+        return f"{self.label or self.path}" + (f", projection={self.projection}" if self.projection else "")
+
+
 class _Unary(ExecutionPlan):
     def children(self):
         return [self.input]

@@ -142,6 +142,15 @@ def run(plan) -> Rel:
     if isinstance(plan, P.MemoryExec):
         t = plan.table if plan.projection is None else plan.table.select(plan.projection)
         return _encode(t)
+    if isinstance(plan, P.ParquetExec):     # the CPU leg reads the same file with pyarrow's reader
+        import pyarrow.parquet as pq
+        t = pq.read_table(plan.path, columns=plan.projection)
+        strings = [n for n in t.column_names if pa.types.is_string(t.schema.field(n).type)]
+        for n in strings:   # as the device scan delivers them: dictionary-encoded, ascending dictionary
+            values = sorted(set(v for v in t.column(n).to_pylist() if v is not None))
+            idx = pa.array([None if v is None else values.index(v) for v in t.column(n).to_pylist()], pa.int32())
+            t = t.set_column(t.column_names.index(n), n, pa.DictionaryArray.from_arrays(idx, pa.array(values, pa.string())))
+        return _encode(t)
     if isinstance(plan, (P.CoalesceBatchesExec, P.RepartitionExec, P.CoalescePartitionsExec, P.SortPreservingMergeExec)):
         return run(plan.input)          # one partition: bookkeeping only
     if isinstance(plan, P.FilterExec):

@@ -65,3 +65,13 @@ def test_q6_straight_from_a_parquet_file(tmp_path):
     assert li.num_rows == l.num_rows
     assert_answer("q6", P.collect(P.GpuOffloadRule().optimize(T.q6_plan(li))).to_arrow())
     assert_answer("q1", P.collect(P.GpuOffloadRule().optimize(T.q1_plan(li))).to_arrow())
+    # the same with the scan as the plan's leaf: ParquetExec = DataSourceExec over the file, owned output
+    leaf = P.ParquetExec(path, ["l_quantity", "l_extendedprice", "l_discount", "l_shipdate"], "lineitem")
+    node = T.q6_plan(li)
+    while not isinstance(node, P.FilterExec):
+        node = node.children()[0]
+    f = P.FilterExec(node.predicate, leaf, projection=["l_extendedprice", "l_discount"])
+    name = "sum(lineitem.l_extendedprice * lineitem.l_discount)"
+    from datafusion_amd.expr import col
+    plan = P.ProjectionExec([(col(name), "revenue")], P.AggregateExec("Single", [], [("sum", col("l_extendedprice") * col("l_discount"), name)], f))
+    assert_answer("q6", P.collect(P.GpuOffloadRule().optimize(plan)).to_arrow())
