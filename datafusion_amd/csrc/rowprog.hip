@@ -63,11 +63,14 @@ RpValue RowProgramCompiler::column(int idx) {
 RpValue RowProgramCompiler::literal(const dfgpu_field& f, uint64_t lo, uint64_t hi, bool is_null) {
   if (is_null) lo = hi = 0;
   if (f.type == DFGPU_FLOAT64 || f.type == DFGPU_BOOL) hi = 0;
+  // a NULL literal never shares a slot with the value literal of the same bits (zero): the LDS register-file program
+  // keeps NULL-ness per slot (TileProgram::lit_nulls)
   int slot = -1;
   for (size_t i = 0; i < lits_.size(); i++)
-    if (lits_[i].first == lo && lits_[i].second == hi) slot = (int)i;
+    if (lits_[i].first == lo && lits_[i].second == hi && lit_null_[i] == is_null) slot = (int)i;
   if (slot < 0) {
     lits_.push_back({lo, hi});
+    lit_null_.push_back(is_null);
     slot = (int)lits_.size() - 1;
     if (slot >= RP_MAX_LITS) fail("more than " + std::to_string(RP_MAX_LITS) + " distinct literals");
   }

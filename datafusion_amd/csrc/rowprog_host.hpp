@@ -71,6 +71,7 @@ class RowProgramCompiler {
   std::map<std::tuple<int, int, int, uint32_t, int>, int> cse_;
   std::vector<int> slot_col_;                             // slot -> table column
   std::vector<std::pair<uint64_t, uint64_t>> lits_;
+  std::vector<bool> lit_null_;                            // per literal slot: SQL NULL
   std::vector<RpValue> outs_;
   int pred_ = -1;
   int seg_ = 2;

@@ -44,6 +44,7 @@ class PhysicalExpr:
     def ne(self, o): return BinaryExpr(self, "!=", _wrap(o))
     def and_(self, o): return BinaryExpr(self, "and", _wrap(o))
     def or_(self, o): return BinaryExpr(self, "or", _wrap(o))
+    def in_list(self, values, negated=False): return InListExpr(self, values, negated)
     def is_null(self): return IsNullExpr(self)
     def is_not_null(self): return IsNotNullExpr(self)
     def not_(self): return NotExpr(self)
@@ -128,6 +129,33 @@ class CaseExpr(PhysicalExpr):
         return "CASE " + " ".join(f"WHEN {w!r} THEN {t!r}" for w, t in self.when_then) + (f" ELSE {self.else_expr!r}" if self.else_expr is not None else "") + " END"
 
 
+class InListExpr(PhysicalExpr):
+    """InListExpr::new(expr, list, negated) (expressions/in_list.rs): `x [NOT] IN (v1, v2, ...)`.  Lowered at the boundary to
+    the Kleene OR of `x = v_i` (NOT of it when negated), which is SQL's definition and gives the reference's NULL rules: no
+    match against a list holding a NULL is NULL, a NULL `x` is NULL (in_list.rs run_test_cases).  The shim does the same for
+    the short lists plans carry; long lists (the reference switches to a hash set) stay on the CPU."""
+
+    def __init__(self, expr: PhysicalExpr, list_, negated: bool = False):
+        if not list_:
+            raise ValueError("IN list must not be empty")
+        self.expr, self.list, self.negated = expr, [_wrap(v) for v in list_], negated
+
+    def children(self):
+        return [self.expr] + self.list
+
+    def map_children(self, f) -> "InListExpr":
+        return InListExpr(f(self.expr), [f(v) for v in self.list], self.negated)
+
+    def lowered(self) -> PhysicalExpr:
+        e = BinaryExpr(self.expr, "=", self.list[0])
+        for v in self.list[1:]:
+            e = BinaryExpr(e, "or", BinaryExpr(self.expr, "=", v))
+        return NotExpr(e) if self.negated else e
+
+    def __repr__(self):
+        return f"{self.expr!r} {'NOT ' if self.negated else ''}IN ({', '.join(repr(v) for v in self.list)})"
+
+
 def case(when_then, else_expr=None) -> CaseExpr:
     return CaseExpr(when_then, else_expr)
 
@@ -208,6 +236,8 @@ def bind_string_literals(expr: PhysicalExpr, table) -> PhysicalExpr:
         return NotExpr(bind_string_literals(expr.arg, table))
     if isinstance(expr, CaseExpr):
         return expr.map_children(lambda e: bind_string_literals(e, table))
+    if isinstance(expr, InListExpr):
+        return bind_string_literals(expr.lowered(), table)
     return expr
 
 
@@ -255,6 +285,8 @@ def lower(expr: PhysicalExpr, column_names, table=None) -> LoweredExpr:
         elif isinstance(e, (IsNullExpr, IsNotNullExpr, NotExpr)):
             n.left = emit(e.arg)
             n.op = {IsNullExpr: OP_IS_NULL, IsNotNullExpr: OP_IS_NOT_NULL, NotExpr: OP_NOT}[type(e)]
+        elif isinstance(e, InListExpr):
+            return emit(e.lowered())
         elif isinstance(e, CaseExpr):
             # one DFGPU_EXPR_CASE node per WHEN, later branches nested in ELSE (include/dfgpu.h)
             tail = -1 if e.else_expr is None else emit(e.else_expr)

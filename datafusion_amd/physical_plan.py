@@ -21,7 +21,7 @@ per-operator GPU node):
 from __future__ import annotations
 
 from . import ops
-from .expr import BinaryExpr, CaseExpr, CastExpr, Column, IsNotNullExpr, IsNullExpr, Literal, NotExpr, PhysicalExpr
+from .expr import BinaryExpr, CaseExpr, CastExpr, Column, InListExpr, IsNotNullExpr, IsNullExpr, Literal, NotExpr, PhysicalExpr
 from .table import DeviceTable
 
 
@@ -43,7 +43,7 @@ def substitute(e: PhysicalExpr, mapping: dict) -> PhysicalExpr:
         return IsNotNullExpr(substitute(e.arg, mapping))
     if isinstance(e, NotExpr):
         return NotExpr(substitute(e.arg, mapping))
-    if isinstance(e, CaseExpr):
+    if isinstance(e, (CaseExpr, InListExpr)):
         return e.map_children(lambda x: substitute(x, mapping))
     raise TypeError(f"unsupported expression node {type(e).__name__}")
 

@@ -72,6 +72,8 @@ def _expr(e, rel: Rel):
         return ("not", ("is_null", _expr(e.arg, rel)))
     if isinstance(e, X.NotExpr):
         return ("not", _expr(e.arg, rel))
+    if isinstance(e, X.InListExpr):
+        return _expr(e.lowered(), rel)
     if isinstance(e, X.CaseExpr):
         tail = None if e.else_expr is None else _expr(e.else_expr, rel)
         for w, t in reversed(e.when_then):
