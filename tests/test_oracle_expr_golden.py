@@ -81,3 +81,45 @@ def test_gpu_decimal_comparisons_match_reference(case):
     for op, expected in case["comparisons"].items():
         out = ops.project(dt, [(BinaryExpr(col("b"), op, scalar), "r")]).to_arrow().column("r")
         assert out.to_pylist() == expected, (case["source"], op)
+
+
+# ---------------------------------------------------------------------------------- Kleene logic and Int32 arithmetic
+LOGIC = load_golden("binary_expr_logic.json")
+
+
+def _logic_table(rec):
+    typ = pa.bool_() if rec["type"] == "bool" else pa.int32()
+    return pa.table({"a": pa.array(rec["a"], typ), "b": pa.array(rec["b"], typ)})
+
+
+def _logic_expr(rec):
+    from datafusion_amd.expr import BinaryExpr, col
+    return BinaryExpr(col("a"), rec["op"], col("b"))
+
+
+@pytest.mark.parametrize("rec", LOGIC, ids=[r["name"] for r in LOGIC])
+def test_oracle_binary_expr_logic_and_int_arithmetic(rec):
+    """and_with_nulls_op / or_with_nulls_op (binary.rs:3469-3765: and_kleene / or_kleene over all nine combinations),
+    plus_op / minus_op / multiply_op (binary.rs:2238-2760)"""
+    from oracle import oracle as O
+    from tests.util import to_oracle_expr
+    got = O.project(_logic_table(rec), [(to_oracle_expr(_logic_expr(rec)), "r")]).column("r")
+    assert got.to_pylist() == rec["expected"], rec["source"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rec", LOGIC, ids=[r["name"] for r in LOGIC])
+def test_gpu_binary_expr_logic_and_int_arithmetic(rec):
+    """column-at-a-time (ProjectionExec) and inside the fused aggregate node: as its predicate (Kleene) or its argument (arithmetic)"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    dev = DeviceTable.from_arrow(_logic_table(rec))
+    e = _logic_expr(rec)
+    got = ops.project(dev, [(e, "r")]).to_arrow().column("r")
+    assert got.to_pylist() == rec["expected"], rec["source"]
+    if rec["type"] == "bool":
+        n = ops.aggregate(dev, [], [("count", None, "n")], "Single", predicate=e).to_arrow().to_pylist()[0]["n"]
+        assert n == sum(1 for v in rec["expected"] if v is True)
+    else:
+        s = ops.aggregate(dev, [], [("sum", e.cast(pa.int64()), "s")], "Single").to_arrow().to_pylist()[0]["s"]
+        assert s == sum(rec["expected"])
