@@ -345,9 +345,14 @@ static dfgpu_field avg_type(const dfgpu_field& t) {
   if (t.type == DFGPU_DECIMAL128) return fld(DFGPU_DECIMAL128, std::min(38, t.precision + 4), std::min(38, t.scale + 4));
   return fld(DFGPU_FLOAT64);
 }
-// the type the AVG sum state carries
+// the type the AVG sum state carries: avg_sum_data_type (functions-aggregate/src/average.rs:131-172) — the input precision
+// plus 13 digits of headroom, never narrower than Decimal128's maximum; beyond 38 digits the reference accumulates in
+// Decimal256, which has no device representation (the sums here are i128)
 static dfgpu_field avg_sum_type(const dfgpu_field& t) {
-  if (t.type == DFGPU_DECIMAL128) return sum_type(t);
+  if (t.type == DFGPU_DECIMAL128) {
+    DFGPU_CHECK(t.precision + 13 <= 38, "AVG over " + type_name(t) + " accumulates in Decimal256 in the reference: not supported on the GPU path");
+    return fld(DFGPU_DECIMAL128, 38, t.scale);
+  }
   return fld(DFGPU_FLOAT64);
 }
 
@@ -2229,16 +2234,18 @@ static Table agg_emit(Aggregate& A) {
         out.cols.push_back(emit_column(vf, a.name + "[sum]", mode, a.lo, a.hi, a.seen, G, true));
       } else {
         // raw modes: in_type = argument type Decimal(p,s) -> AVG type Decimal(min(38,p+4), min(38,s+4))
-        // (average.rs:219-252).  final modes: in_type = the sum state Decimal(min(38,p+10), s); the
-        // planner-declared return type is used when given, else p is recovered as sum_p - 10.
+        // (average.rs:219-252).  final modes: in_type = the sum state Decimal(38, s), which no longer tells p: the
+        // planner-declared return type (AggregateFunctionExpr::return_field) is required.
         dfgpu_field base = a.in_type;
         dfgpu_field rt_;
         i128 mul = 1;
         bool dec = base.type == DFGPU_DECIMAL128;
         if (dec) {
           int s = base.scale;
-          int arg_p = fin ? std::max(1, base.precision - 10) : base.precision;
-          rt_ = a.ret.type == DFGPU_DECIMAL128 ? a.ret : fld(DFGPU_DECIMAL128, std::min(38, arg_p + 4), std::min(38, s + 4));
+          if (!fin) (void)avg_sum_type(base);   // precision check: the i128 sum must have the reference's headroom
+          DFGPU_CHECK(!fin || a.ret.type == DFGPU_DECIMAL128,
+                      "Final AVG over a Decimal128 state needs the aggregate's declared return type (dfgpu_agg_spec.return_field)");
+          rt_ = a.ret.type == DFGPU_DECIMAL128 ? a.ret : fld(DFGPU_DECIMAL128, std::min(38, base.precision + 4), std::min(38, s + 4));
           DFGPU_CHECK(rt_.scale >= s, "AVG return scale smaller than the sum scale");
           for (int i = s; i < rt_.scale; i++) mul *= 10;
         } else {

@@ -183,9 +183,12 @@ def sort(table: DeviceTable, keys, fetch=None) -> DeviceTable:
 class GroupedAggregate:
     """AggregateExec state: group_by = [(expr, name)], aggs = [(func, expr|None, name)]"""
 
-    def __init__(self, mode, input_names, group_by, aggs, dictionaries: DeviceTable | None = None):
+    def __init__(self, mode, input_names, group_by, aggs, dictionaries: DeviceTable | None = None, return_types: dict | None = None):
         """dictionaries: a table of the input's schema whose dictionary-encoded string columns bind the string
-        literals of the argument expressions (`CASE WHEN o_orderpriority = '1-URGENT' ...`)"""
+        literals of the argument expressions (`CASE WHEN o_orderpriority = '1-URGENT' ...`).
+        return_types {name: arrow type}: the aggregates' declared return types (AggregateFunctionExpr::return_field) —
+        required by Final modes for AVG over a Decimal128 state (its Decimal128(38, s) sum does not tell the argument's
+        precision); aggregate_return_types() computes them from the raw input."""
         lib = _lib.init()
         self._keep = []
         final = mode in ("Final", "FinalPartitioned")
@@ -211,6 +214,8 @@ class GroupedAggregate:
                 self._keep.append(l)
                 s.arg = l.c
             s.name = name.encode()
+            if return_types and name in return_types:
+                s.return_field = field_of(return_types[name])
             specs.append(s)
         sarr = (AggSpec * max(1, len(specs)))(*specs)
         self._h = C.c_void_p()
@@ -248,8 +253,30 @@ class GroupedAggregate:
             pass
 
 
-def aggregate(table: DeviceTable, group_by, aggs, mode="Single", predicate: PhysicalExpr | None = None, info: dict | None = None) -> DeviceTable:
-    a = GroupedAggregate(mode, table.column_names, group_by, aggs, table)
+def expr_type(table: DeviceTable, expr: PhysicalExpr) -> pa.DataType:
+    """PhysicalExpr::data_type over a table's schema (dfgpu_expr_type)"""
+    from .table import arrow_type_of
+    le = lower(expr, table.column_names, table)
+    f = _lib.Field()
+    check(_lib.load().dfgpu_expr_type(C.byref(le.c), table.handle, C.byref(f)))
+    return arrow_type_of(f)
+
+
+def aggregate_return_types(table: DeviceTable, aggs) -> dict:
+    """declared return types of the aggregates that Final modes cannot derive from the partial state: AVG over a
+    Decimal128 argument, Decimal128(min(38, p + 4), min(38, s + 4)) (functions-aggregate/src/average.rs:219-252)"""
+    out = {}
+    for func, e, name in aggs:
+        if func == "avg" and e is not None:
+            t = expr_type(table, e)
+            if pa.types.is_decimal128(t):
+                out[name] = pa.decimal128(min(38, t.precision + 4), min(38, t.scale + 4))
+    return out
+
+
+def aggregate(table: DeviceTable, group_by, aggs, mode="Single", predicate: PhysicalExpr | None = None, info: dict | None = None,
+              return_types: dict | None = None) -> DeviceTable:
+    a = GroupedAggregate(mode, table.column_names, group_by, aggs, table, return_types)
     a.update(table, predicate)
     if info is not None:
         info["fused_updates"] = a.fused_updates

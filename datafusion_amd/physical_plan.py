@@ -316,19 +316,37 @@ class HashJoinExec(ExecutionPlan):
             (", null_aware" if self.null_aware else "")
 
 
+def _partial_below(node: ExecutionPlan):
+    """the Partial aggregate feeding a Final one, through the exchange / bookkeeping nodes between them"""
+    while node is not None:
+        if isinstance(node, (AggregateExec, GpuFusedAggregateExec)):
+            return node if node.mode == "Partial" else None
+        kids = node.children()
+        node = kids[0] if len(kids) == 1 else None
+    return None
+
+
 class AggregateExec(_Unary):
     """AggregateExec::try_new(mode, group_by = [(expr, name)], aggr_expr = [(func, arg | None, name)], input)
     (aggregates/mod.rs:839)"""
 
     def __init__(self, mode: str, group_by, aggr_expr, input: ExecutionPlan):
         self.mode, self.group_by, self.aggr_expr, self.input = mode, group_by, aggr_expr, input
+        self.return_types = None    # Partial: the aggregates' declared return types, typed over the raw input when it runs
 
     def with_new_children(self, c):
         return AggregateExec(self.mode, self.group_by, self.aggr_expr, c[0])
 
     def execute(self, partition=0):
         t, owned = self._run_child(self.input)
-        out = ops.aggregate(t, self.group_by, self.aggr_expr, self.mode)
+        rt = None
+        if self.mode == "Partial":
+            self.return_types = ops.aggregate_return_types(t, self.aggr_expr)
+        elif self.mode in ("Final", "FinalPartitioned"):
+            # AggregateFunctionExpr::return_field: the reference's Final node carries the types its Partial twin was planned with
+            below = _partial_below(self.input)
+            rt = below.return_types if below is not None else None
+        out = ops.aggregate(t, self.group_by, self.aggr_expr, self.mode, return_types=rt)
         if owned:
             t.free()
         return out
@@ -366,12 +384,15 @@ class GpuFusedAggregateExec(_Unary):
 
     def __init__(self, mode, group_by, aggr_expr, predicate, input: ExecutionPlan):
         self.mode, self.group_by, self.aggr_expr, self.predicate, self.input = mode, group_by, aggr_expr, predicate, input
+        self.return_types = None
 
     def with_new_children(self, c):
         return GpuFusedAggregateExec(self.mode, self.group_by, self.aggr_expr, self.predicate, c[0])
 
     def execute(self, partition=0):
         t, owned = self._run_child(self.input)
+        if self.mode == "Partial":
+            self.return_types = ops.aggregate_return_types(t, self.aggr_expr)
         out = ops.aggregate(t, self.group_by, self.aggr_expr, self.mode, predicate=self.predicate)
         if owned:
             t.free()

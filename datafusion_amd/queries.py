@@ -93,6 +93,7 @@ def q1(lineitem: DeviceTable, group=None, fused: bool = True) -> DeviceTable:
     other, materialising the filter's and the projection's outputs."""
     pred = col("l_shipdate") <= lit(DATE_Q1, pa.date32())
     first_mode = "Single" if _world(group) == 1 else "Partial"
+    return_types = ops.aggregate_return_types(lineitem, q1_aggs_inlined())   # what the Final node is planned with (AVG types)
     if fused:
         first = ops.aggregate(lineitem, Q1_GROUP_BY, q1_aggs_inlined(), first_mode, predicate=pred)
     else:
@@ -108,7 +109,7 @@ def q1(lineitem: DeviceTable, group=None, fused: bool = True) -> DeviceTable:
         agg = first
     else:
         routed = _repartition(first, ["l_returnflag", "l_linestatus"], group)
-        agg = ops.aggregate(routed, Q1_GROUP_BY, q1_aggs(), "FinalPartitioned")
+        agg = ops.aggregate(routed, Q1_GROUP_BY, q1_aggs(), "FinalPartitioned", return_types=return_types)
         if routed is not first:
             routed.free()
         first.free()

@@ -534,7 +534,18 @@ def avg_result_type(t: pa.DataType) -> pa.DataType:
     return pa.float64()
 
 
-def aggregate(table: pa.Table, group_by, aggs, mode="Single") -> pa.Table:
+def avg_sum_type(t: pa.DataType) -> pa.DataType:
+    """the type AVG's partial `sum` state carries: avg_sum_data_type (functions-aggregate/src/average.rs:131-172) — the
+    input precision plus 13 digits of headroom, never narrower than the input type's maximum: Decimal128(38, s) while
+    p + 13 <= 38, Decimal256 beyond that (no device or oracle representation: an error here)"""
+    if pa.types.is_decimal128(t):
+        if t.precision + 13 > 38:
+            raise NotImplementedError(f"AVG({t}) accumulates in Decimal256 in the reference")
+        return pa.decimal128(38, t.scale)
+    return pa.float64()
+
+
+def aggregate(table: pa.Table, group_by, aggs, mode="Single", return_types=None) -> pa.Table:
     """AggregateExec (aggregates/mod.rs:839, aggregate_hash_table/common.rs:205-300).
     group_by = [(expr, name)], aggs = [(func, expr_or_None, name)] with func in
     sum/avg/count/min/max.  Output = group columns ++ aggregate columns, groups in first-seen
@@ -543,7 +554,10 @@ def aggregate(table: pa.Table, group_by, aggs, mode="Single") -> pa.Table:
       Partial                    : raw rows -> state columns (AVG -> `name[count]` UInt64 +
                                    `name[sum]`; others one column; average.rs:317-360, sum.rs:281-301)
       Final / FinalPartitioned   : state columns (same layout, group columns first) -> final values;
-                                   aggregate expressions are ignored (merge_batch path)."""
+                                   aggregate expressions are ignored (merge_batch path).  `return_types`
+                                   {name: type} = the aggregates' declared return types: the reference's AggregateExec
+                                   carries them (AggregateFunctionExpr::return_field); AVG over a Decimal128 state needs it,
+                                   because the state's sum type no longer tells the argument's precision."""
     L = lib()
     n = table.num_rows
     final = mode in ("Final", "FinalPartitioned")
@@ -615,7 +629,7 @@ def aggregate(table: pa.Table, group_by, aggs, mode="Single") -> pa.Table:
                 sum_t = varr.type
             else:
                 cnt, _ = acc(3, varr)
-                sum_t = sum_result_type(varr.type) if t == ORC_I128 else pa.float64()
+                sum_t = avg_sum_type(varr.type)
             if partial:
                 out_cols.append(pa.array(cnt[:ng].astype(np.uint64), type=pa.uint64()))
                 names.append(nm + "[count]")
@@ -625,8 +639,12 @@ def aggregate(table: pa.Table, group_by, aggs, mode="Single") -> pa.Table:
             valid = cnt[:ng] > 0
             if t == ORC_I128:
                 # AvgGroupsAccumulator<Decimal128> (average.rs:934-960) + DecimalAverager
-                arg_p = max(1, sum_t.precision - 10) if final else varr.type.precision
-                rt = pa.decimal128(min(38, arg_p + 4), min(38, sum_t.scale + 4))
+                if final:
+                    if not return_types or nm not in return_types:
+                        raise ValueError(f"Final AVG over the Decimal128 state of '{nm}' needs its declared return type (return_types)")
+                    rt = return_types[nm]
+                else:
+                    rt = avg_result_type(varr.type)
                 outv = np.zeros((max(ng, 1), 2), np.uint64)
                 rc = L.orc_decimal_avg(C.c_void_p(sums.ctypes.data), C.c_void_p(cnt.ctypes.data), C.c_int64(ng), sum_t.scale, rt.scale,
                                        C.c_void_p(outv.ctypes.data))

@@ -103,11 +103,22 @@ def _filter(rel: Rel, predicate, projection) -> Rel:
     return Rel(oracle.filter(rel.table, _expr(predicate, rel), projection), rel.dicts)
 
 
-def _aggregate(rel: Rel, mode, group_by, aggs) -> Rel:
+def _avg_return_types(rel: Rel, aggs) -> dict:
+    """declared AVG return types over the raw input (what the reference's Final node is planned with)"""
+    out = {}
+    for f, e, n in aggs:
+        if f == "avg" and e is not None:
+            t = oracle.evaluate(_expr(e, rel), rel.table.slice(0, 0)).typ
+            if pa.types.is_decimal128(t):
+                out[n] = oracle.avg_result_type(t)
+    return out
+
+
+def _aggregate(rel: Rel, mode, group_by, aggs, return_types=None) -> Rel:
     final = mode in ("Final", "FinalPartitioned")
     gb = [(None if final else _expr(e, rel), n) for e, n in group_by]
     ag = [(f, None if (e is None or final) else _expr(e, rel), n) for f, e, n in aggs]
-    out = oracle.aggregate(rel.table, gb, ag, mode)
+    out = oracle.aggregate(rel.table, gb, ag, mode, return_types=return_types)
     if final:   # group columns are the first columns of the partial state, by position
         dicts = {n: rel.dicts[rel.table.column_names[i]] for i, (_, n) in enumerate(group_by) if rel.table.column_names[i] in rel.dicts}
     else:
@@ -169,9 +180,18 @@ def run(plan) -> Rel:
         rel = run(plan.input)
         if plan.predicate is not None:
             rel = _filter(rel, plan.predicate, None)
+        if plan.mode == "Partial":
+            plan.return_types = _avg_return_types(rel, plan.aggr_expr)
         return _aggregate(rel, plan.mode, plan.group_by, plan.aggr_expr)
     if isinstance(plan, P.AggregateExec):
-        return _aggregate(run(plan.input), plan.mode, plan.group_by, plan.aggr_expr)
+        rel = run(plan.input)
+        rt = None
+        if plan.mode == "Partial":
+            plan.return_types = _avg_return_types(rel, plan.aggr_expr)
+        elif plan.mode in ("Final", "FinalPartitioned"):
+            below = P._partial_below(plan.input)
+            rt = below.return_types if below is not None else None
+        return _aggregate(rel, plan.mode, plan.group_by, plan.aggr_expr, rt)
     if isinstance(plan, P.SortExec):
         rel = run(plan.input)
         return Rel(oracle.sort(rel.table, plan.expr, plan.fetch), rel.dicts)

@@ -15,10 +15,10 @@ G = load_golden("aggregate_check_aggregates.json")
 REL = 1e-6  # north_star tolerance for SUM/AVG(float64)
 
 
-def gpu_agg(table, group_by, aggs, mode="Single"):
+def gpu_agg(table, group_by, aggs, mode="Single", return_types=None):
     from datafusion_amd import ops
     from datafusion_amd.table import DeviceTable
-    return ops.aggregate(DeviceTable.from_arrow(table), group_by, aggs, mode).to_arrow()
+    return ops.aggregate(DeviceTable.from_arrow(table), group_by, aggs, mode, return_types=return_types).to_arrow()
 
 
 def oracle_agg(table, group_by, aggs, mode="Single"):
@@ -114,7 +114,10 @@ def test_partial_final_composition_matches_single():
     assert parts[0].column_names == ["k", "s", "a[count]", "a[sum]", "c", "mn", "mx", "af[count]", "af[sum]"]
     exp_partial = oracle_agg(t.slice(0, 12_500), gb, aggs, "Partial")
     assert_agg_equal(parts[0], exp_partial)
-    final = gpu_agg(pa.concat_tables(parts), gb, aggs, "Final")
+    assert parts[0].schema.field("a[sum]").type == pa.decimal128(38, 2)       # avg_sum_data_type, average.rs:131-172
+    with pytest.raises(Exception, match="declared return type"):
+        gpu_agg(pa.concat_tables(parts), gb, aggs, "Final")
+    final = gpu_agg(pa.concat_tables(parts), gb, aggs, "Final", return_types={"a": pa.decimal128(19, 6)})
     single = oracle_agg(t, gb, aggs, "Single")
     assert_agg_equal(final, single, ordered=False)
 

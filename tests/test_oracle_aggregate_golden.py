@@ -4,6 +4,7 @@ against the TPC-H Q1 plan/answer files."""
 from decimal import Decimal
 
 import pyarrow as pa
+import pytest
 
 from oracle import oracle
 from tests.util import load_golden, sorted_rows
@@ -63,3 +64,76 @@ def test_decimal_typing_follows_q1_plan():
     # truncating division (DecimalAverager::avg, functions-aggregate-common/src/utils.rs:157-176)
     t3 = pa.table({"q": pa.array([D("0.01"), D("0.01"), D("0.02")], type=pa.decimal128(15, 2))})
     assert oracle.aggregate(t3, [], [("avg", ("col", "q"), "a")]).to_pylist()[0]["a"] == D("0.013333")
+
+
+# ----------------------------------------------------------------------------------------------- AVG: avg_cases
+AVG = load_golden("avg_cases.json")
+
+
+def _dec(unscaled: int, scale: int):
+    """exact Decimal (scaleb would round to the context's 28 digits)"""
+    from decimal import Decimal
+    return Decimal((0 if unscaled >= 0 else 1, tuple(int(c) for c in str(abs(unscaled))), -scale))
+
+
+def _avg_case_table(rec):
+    if rec["input_type"][0] == "Float64":
+        return pa.table({"v": pa.array(rec["values"], pa.float64())})
+    p, s = rec["input_type"][1:]
+    if "values_unscaled" in rec:
+        return pa.table({"v": pa.array([_dec(v, s) for v in rec["values_unscaled"]], pa.decimal128(p, s))})
+    return pa.table({"v": pa.array([_dec(rec["value_repeated"], s)] * 64, pa.decimal128(p, s))})   # the type decides, not the row count
+
+
+def _avg_types(rec):
+    mk = lambda t: pa.float64() if t[0] == "Float64" else pa.decimal128(t[1], t[2])   # noqa: E731
+    return mk(rec["return_type"]), (None if rec["sum_type"][0] == "Decimal256" else mk(rec["sum_type"]))
+
+
+@pytest.mark.parametrize("rec", AVG, ids=[r["name"] for r in AVG])
+def test_oracle_avg_cases_values_and_state_types(rec):
+    """avg_cases (functions-aggregate/src/average.rs:1242-1330): return type, the sum-state type of avg_sum_data_type (:131-172) and the value;
+    the Decimal128(34,0) case accumulates in Decimal256 in the reference and must be refused, not wrapped"""
+    from decimal import Decimal
+
+    from oracle import oracle
+    t = _avg_case_table(rec)
+    ret, sum_t = _avg_types(rec)
+    aggs = [("avg", ("col", "v"), "a")]
+    if sum_t is None:
+        with pytest.raises(NotImplementedError, match="Decimal256"):
+            oracle.aggregate(t, [], aggs, "Partial")
+        return
+    part = oracle.aggregate(t, [], aggs, "Partial")
+    assert part.column_names == ["a[count]", "a[sum]"] and part.schema.field("a[sum]").type == sum_t and part.schema.field("a[count]").type == pa.uint64()
+    single = oracle.aggregate(t, [], aggs, "Single")
+    final = oracle.aggregate(part, [], aggs, "Final", return_types={"a": ret})
+    want = rec["expected"] if "expected" in rec else _dec(rec["expected_unscaled"], ret.scale)
+    for got in (single, final):
+        assert got.schema.field("a").type == ret and got.column("a").to_pylist() == [want]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rec", AVG, ids=[r["name"] for r in AVG])
+def test_gpu_avg_cases_values_and_state_types(rec):
+    from decimal import Decimal
+
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    dev = DeviceTable.from_arrow(_avg_case_table(rec))
+    ret, sum_t = _avg_types(rec)
+    aggs = [("avg", col("v"), "a")]
+    if sum_t is None:
+        for mode in ("Partial", "Single"):
+            with pytest.raises(_lib.DfgpuError, match="Decimal256"):
+                ops.aggregate(dev, [], aggs, mode)
+        return
+    part = ops.aggregate(dev, [], aggs, "Partial")
+    pa_part = part.to_arrow()
+    assert pa_part.column_names == ["a[count]", "a[sum]"] and pa_part.schema.field("a[sum]").type == sum_t
+    want = rec["expected"] if "expected" in rec else _dec(rec["expected_unscaled"], ret.scale)
+    single = ops.aggregate(dev, [], aggs, "Single").to_arrow()
+    final = ops.aggregate(part, [], aggs, "Final", return_types=ops.aggregate_return_types(dev, aggs)).to_arrow()
+    for got in (single, final):
+        assert got.schema.field("a").type == ret and got.column("a").to_pylist() == [want]
