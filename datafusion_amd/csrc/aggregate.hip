@@ -2270,10 +2270,13 @@ static Table agg_emit(Aggregate& A) {
       continue;
     }
     bool nullable = a.func != DFGPU_AGG_COUNT;
+    // partial state field names: format_state_name (expr/src/utils.rs:1416) — `name[sum]` (sum.rs:293-299), `name[count]`
+    // (count.rs:317-323), `name[value]` for MIN / MAX (the default AggregateUDFImpl::state_fields, expr/src/udaf.rs:579-585)
+    const std::string out_name = !A.partial_out() ? a.name : a.name + (a.func == DFGPU_AGG_SUM ? "[sum]" : a.func == DFGPU_AGG_COUNT ? "[count]" : "[value]");
     if (vf.type == DFGPU_DECIMAL128 && p.kind != ACC_SUM_I128) {
       // widen the i64 MIN/MAX accumulator to i128: hi = sign(lo)
-      Column c = emit_column(fld(DFGPU_INT64), a.name, 0, a.lo, nullptr, a.seen, G, nullable);
-      Column w = alloc_column(vf, a.name, G);
+      Column c = emit_column(fld(DFGPU_INT64), out_name, 0, a.lo, nullptr, a.seen, G, nullable);
+      Column w = alloc_column(vf, out_name, G);
       if (G) {
         dfgpu_expr_node nodes[2]{};
         nodes[0].op = DFGPU_EXPR_COLUMN; nodes[0].column = 0; nodes[0].left = nodes[0].right = -1;
@@ -2282,14 +2285,14 @@ static Table agg_emit(Aggregate& A) {
         t1.nrows = G;
         t1.cols.push_back(c);
         dfgpu_expr e{nodes, 2, 1};
-        Column casted = datum_to_column(evaluate(e, t1), G, a.name);
+        Column casted = datum_to_column(evaluate(e, t1), G, out_name);
         casted.field = vf;
         w = casted;
       }
       out.cols.push_back(std::move(w));
       continue;
     }
-    out.cols.push_back(emit_column(vf, a.name, mode, a.lo, a.hi, a.seen, G, nullable));
+    out.cols.push_back(emit_column(vf, out_name, mode, a.lo, a.hi, a.seen, G, nullable));
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));
   return out;

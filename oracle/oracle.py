@@ -551,8 +551,9 @@ def aggregate(table: pa.Table, group_by, aggs, mode="Single", return_types=None)
     sum/avg/count/min/max.  Output = group columns ++ aggregate columns, groups in first-seen
     order.  mode (AggregateMode, aggregates/mod.rs:289-400):
       Single / SinglePartitioned : raw rows -> final values
-      Partial                    : raw rows -> state columns (AVG -> `name[count]` UInt64 +
-                                   `name[sum]`; others one column; average.rs:317-360, sum.rs:281-301)
+      Partial                    : raw rows -> state columns named by format_state_name (AVG -> `name[count]` UInt64 +
+                                   `name[sum]`; SUM `name[sum]`, COUNT `name[count]`, MIN / MAX `name[value]`;
+                                   average.rs:317-360, sum.rs:281-301, count.rs:317-323, udaf.rs:579-585)
       Final / FinalPartitioned   : state columns (same layout, group columns first) -> final values;
                                    aggregate expressions are ignored (merge_batch path).  `return_types`
                                    {name: type} = the aggregates' declared return types: the reference's AggregateExec
@@ -616,12 +617,13 @@ def aggregate(table: pa.Table, group_by, aggs, mode="Single", return_types=None)
             else:
                 vals, _ = acc(3, varr)
             out_cols.append(pa.array(vals[:ng], type=pa.int64()))
-            names.append(nm)
+            names.append(nm + "[count]" if partial else nm)          # format_state_name, count.rs:317-323
         elif func in ("sum", "min", "max"):
             vals, seen = acc({"sum": 0, "min": 1, "max": 2}[func], varr)
             rt = varr.type if (final or func != "sum") else sum_result_type(varr.type)
             out_cols.append(_from_values(vals[:ng], rt, seen))
-            names.append(nm)
+            # state names: `name[sum]` (sum.rs:293-299); MIN / MAX use the default state_fields, `name[value]` (expr/src/udaf.rs:579-585)
+            names.append((nm + ("[sum]" if func == "sum" else "[value]")) if partial else nm)
         elif func == "avg":
             sums, seen = acc(0, varr)
             if final:
