@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Scan -> device measurement: dbgen lineitem (the Q1 / Q6 columns) written as Parquet with the codecs the
+"""Scan -> device measurement: TPC-H-shaped lineitem (the Q1 / Q6 columns, datafusion_amd.tpch — the host mirror of
+the device generator; the flag columns as strings) written as Parquet with the codecs the
 reference's benchmarks use, decoded (a) by pyarrow's CPU reader on all host cores and (b) by dfgpu_parquet_decode_chunk
 (host: page headers + decompression + run headers; device: value decode).  Prints one JSON line per codec.
 usage: python scripts/bench_parquet.py [--sf 1] [--threads 1,8]"""
@@ -24,11 +25,15 @@ def main():
 
     from datafusion_amd import _lib, ops
     from datafusion_amd.parquet import ParquetFile
-    from oracle import dbgen
+    import numpy as np
+
+    from datafusion_amd import tpch
     cols = ["l_orderkey", "l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"]
     t0 = time.perf_counter()
-    _, _, l = dbgen.tables(args.sf, "utf8")
-    l = l.select(cols)
+    l = tpch.lineitem(args.sf).select(cols)
+    for name in ("l_returnflag", "l_linestatus"):   # strings, as in the reference's schema (benchmarks/src/tpch/mod.rs:93-122)
+        codes = l.column(name).to_numpy()
+        l = l.set_column(l.column_names.index(name), name, pa.array(codes.view("S1").astype("U1").astype(object), pa.string()))
     gen_s = time.perf_counter() - t0
     arrow_bytes = sum(l.column(c).nbytes for c in cols)
     _lib.init(0)
@@ -46,7 +51,7 @@ def main():
             best_cpu = dt if best_cpu is None else min(best_cpu, dt)
         line = {"what": "parquet_scan", "codec": codec, "sf": args.sf, "rows": l.num_rows, "file_bytes": size, "arrow_bytes": arrow_bytes,
                 "row_groups": pq.ParquetFile(path).metadata.num_row_groups, "pyarrow_read_s": round(best_cpu, 4),
-                "pyarrow_rows_per_s": round(l.num_rows / best_cpu), "host_cores": os.cpu_count(), "dbgen_s": round(gen_s, 2)}
+                "pyarrow_rows_per_s": round(l.num_rows / best_cpu), "host_cores": os.cpu_count(), "generate_s": round(gen_s, 2)}
         f = ParquetFile(path)
         # host half alone
         t0 = time.perf_counter()
