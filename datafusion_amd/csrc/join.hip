@@ -895,7 +895,6 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
     DFGPU_CHECK(key_cols[0] >= 0 && key_cols[0] < (int)build.cols.size(), "build key column out of range");
     jt->build_side_has_null = null_count_of(build.cols[key_cols[0]]) > 0;
   }
-  if (const char* e = getenv("DFGPU_PROBE_MODE")) jt->probe_mode = atoi(e);  // experiment override
   const int64_t nb = build.nrows;
   DFGPU_CHECK(nb < 0xFFFFFFFFll, "build side has >= u32::MAX rows (the reference switches to JoinHashMapU64; not supported on GPU)");
   KeySet ks = make_keyset(build, key_cols);

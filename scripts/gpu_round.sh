@@ -25,7 +25,3 @@ if has ops; then
   (time timeout 1200 python scripts/bench_ops.py --md $OUT/ops.md ${OPS_ARGS:-}) > $OUT/ops.jsonl 2> $OUT/ops.err
   cat $OUT/ops.md; tail -5 $OUT/ops.err
 fi
-if has bench8; then
-  (DFGPU_FUSED_WORDS=8 timeout 600 python bench.py --no-cpu) > $OUT/bench_w8.json 2> $OUT/bench_w8.err
-  tail -1 $OUT/bench_w8.json
-fi
