@@ -21,6 +21,10 @@
  *   - handles are owned by exactly one caller and freed exactly once.  A join table
  *     (dfgpu_join_t) is immutable after build and may be probed by many callers
  *     (CollectLeft: one build shared by all probe partitions, hash_join/exec.rs:1503-1523).
+ *   - threads: the allocator and the error channel are thread-safe and all device work is ordered on the one library
+ *     stream, so entry points working on different handles may be called from different host threads (the Parquet
+ *     scan decodes column chunks that way: the host half of dfgpu_parquet_decode_chunk runs in parallel); one handle is
+ *     not re-entrant — one caller at a time, as one stream per `execute(partition)` in the reference.
  *   - device columns are Arrow-layout buffers in HBM: fixed-width values, optional
  *     validity bitmap (LSB first, 1 = valid), Boolean columns bit-packed.
  */
