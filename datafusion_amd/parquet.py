@@ -108,25 +108,49 @@ class ParquetFile:
         _lib.init()
         return self._hstack([self._decode(row_group, name) for name in (columns or self.column_names)])
 
-    def read(self, columns=None, threads: int | None = None) -> DeviceTable:
+    def row_groups_overlapping(self, bounds: dict) -> list:
+        """row groups whose footer statistics admit a value inside every (column -> closed [lo, hi]) bound — the pruning the
+        reference's ParquetSource does with a pushed-down predicate (row-group statistics; here the dynamic bounds a hash join
+        publishes from its build side, hash_join/shared_bounds.rs:277-284).  An empty range (lo > hi) prunes everything; a
+        chunk without min / max statistics is kept."""
+        keep = []
+        for g in range(self.num_row_groups):
+            rg = self.meta.row_group(g)
+            ok = True
+            for name, (lo, hi) in bounds.items():
+                if lo > hi:
+                    ok = False
+                    break
+                st = rg.column(self.arrow_schema.names.index(name)).statistics
+                if st is None or not st.has_min_max:
+                    continue
+                if st.max < lo or st.min > hi:
+                    ok = False
+                    break
+            if ok:
+                keep.append(g)
+        return keep
+
+    def read(self, columns=None, threads: int | None = None, row_groups=None) -> DeviceTable:
         """all row groups.  The host half of a chunk (decompression above all) runs on one core, so chunks are decoded from
         `threads` host threads (default min(16, cores), DFGPU_SCAN_THREADS overrides; ctypes releases the GIL) — the way the
         reference's scan decodes row groups on its partition threads.  All device work stays on the library's one stream."""
         _lib.init()
         names = list(columns or self.column_names)
-        if self.num_row_groups == 0:   # a file without row groups: the schema alone
+        groups = list(range(self.num_row_groups)) if row_groups is None else list(row_groups)
+        if not groups:   # no row group (left): the schema alone
             sch = pa.schema([self.arrow_schema.field(c) for c in names])
             empty = [pa.array([], pa.dictionary(pa.int32(), pa.string()) if pa.types.is_string(f.type) else f.type) for f in sch]
             return DeviceTable.from_arrow(pa.Table.from_arrays(empty, names=sch.names))
         if threads is None:
             threads = int(os.environ.get("DFGPU_SCAN_THREADS", min(16, os.cpu_count() or 1)))
-        work = [(g, c) for g in range(self.num_row_groups) for c in names]
+        work = [(g, c) for g in groups for c in names]
         if threads > 1 and len(work) > 1:
             with ThreadPoolExecutor(threads) as ex:
                 chunks = list(ex.map(lambda gc: self._decode(*gc), work))
         else:
             chunks = [self._decode(g, c) for g, c in work]
-        parts = [self._hstack(chunks[g * len(names):(g + 1) * len(names)]) for g in range(self.num_row_groups)]
+        parts = [self._hstack(chunks[k * len(names):(k + 1) * len(names)]) for k in range(len(groups))]
         if len(parts) == 1:
             return parts[0]
         out = DeviceTable.concat(parts)
@@ -135,10 +159,14 @@ class ParquetFile:
         return out
 
 
-def read_table(path: str, columns=None, threads: int | None = None) -> DeviceTable:
-    """every row group of `path`, the given columns, as one device table"""
+def read_table(path: str, columns=None, threads: int | None = None, bounds: dict | None = None, stats: dict | None = None) -> DeviceTable:
+    """the row groups of `path` that can hold rows inside `bounds` (all of them without bounds), the given columns, as one
+    device table; `stats` receives row_groups_total / row_groups_read"""
     f = ParquetFile(path)
     try:
-        return f.read(columns, threads)
+        groups = None if not bounds else f.row_groups_overlapping(bounds)
+        if stats is not None:
+            stats.update(row_groups_total=f.num_row_groups, row_groups_read=f.num_row_groups if groups is None else len(groups))
+        return f.read(columns, threads, groups)
     finally:
         f.close()

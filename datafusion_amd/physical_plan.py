@@ -120,6 +120,8 @@ class ParquetExec(ExecutionPlan):
 
     def __init__(self, path: str, projection=None, name: str = ""):
         self.path, self.projection, self.label = path, projection, name
+        self.dynamic_bounds = {}   # column -> (lo, hi): published by a HashJoinExec above once its build side is known
+        self.metrics = {}          # row_groups_total / row_groups_read of the last execute
 
     def project(self, columns) -> "ParquetExec":
         return ParquetExec(self.path, list(columns), self.label)
@@ -129,7 +131,7 @@ class ParquetExec(ExecutionPlan):
 
     def execute(self, partition=0):
         from .parquet import read_table
-        return read_table(self.path, self.projection)
+        return read_table(self.path, self.projection, bounds=self.dynamic_bounds or None, stats=self.metrics)
 
     def detail(self):
         return f"{self.label or self.path}" + (f", projection={self.projection}" if self.projection else "")
@@ -285,6 +287,32 @@ class HashJoinExec(ExecutionPlan):
     def with_new_children(self, c):
         return HashJoinExec(c[0], c[1], self.on, self.join_type, self.projection, self.null_equality, self.probe_mode, self.filter, self.null_aware)
 
+    # probe rows without a build match are dropped by these join types (JoinType::on_lr_is_preserved, common/src/join_type.rs:115-127:
+    # the probe side accepts a pushed-down filter), so the build side's key bounds may prune the probe-side scan
+    _DYNAMIC_FILTER_JOINS = ("Inner", "Left", "LeftSemi", "RightSemi", "LeftAnti", "LeftMark")
+
+    def _publish_dynamic_bounds(self, build_table):
+        """the join's dynamic filter (HashJoinExec::create_dynamic_filter, hash_join/exec.rs:869-875; bounds accumulated in
+        hash_join/shared_bounds.rs:277-284): [min, max] of the build keys, handed to the probe-side scan, which prunes row groups
+        with it before reading them.  Single integer key, no JoinFilter-independent restrictions of the reference apply here
+        (one partition); a null-aware anti join never publishes (exec.rs:883-892)."""
+        if self.join_type not in self._DYNAMIC_FILTER_JOINS or len(self.on) != 1 or self.null_aware or self.null_equality != "NullEqualsNothing":
+            return
+        node = self.right
+        while isinstance(node, (FilterExec, CoalesceBatchesExec, RepartitionExec)):
+            node = node.input
+        if not isinstance(node, ParquetExec):
+            return
+        build_key, probe_key = self.on[0]
+        if node.projection is not None and probe_key not in node.projection:
+            return
+        import pyarrow as pa
+        ktype = build_table.schema.field(build_table.index_of(build_key)).type
+        if ktype not in (pa.int64(), pa.int32()):
+            return
+        lo, hi, n, _ = ops.column_minmax(build_table, build_key)
+        node.dynamic_bounds[probe_key] = (lo, hi) if n else (1, 0)     # an empty build side prunes the whole scan
+
     def _probe(self, ht, probe_table, predicate=None):
         bc, pc = self.projection if self.projection else (None, None)
         return ht.probe(probe_table, [r for _, r in self.on], self.join_type, bc, pc, predicate=predicate, join_filter=self.filter)
@@ -294,6 +322,7 @@ class HashJoinExec(ExecutionPlan):
             # build-side emission (Left / Full / LeftSemi / LeftAnti / LeftMark): the general path of ops.hash_join
             assert probe_predicate is None
             b, bo = self._run_child(self.left)
+            self._publish_dynamic_bounds(b)
             p, po = self._run_child(self.right)
             bc, pc = self.projection if self.projection else (None, None)
             out = ops.hash_join(b, p, self.on, self.join_type, self.null_equality, bc, pc, join_filter=self.filter, null_aware=self.null_aware)
@@ -303,6 +332,7 @@ class HashJoinExec(ExecutionPlan):
             return out
         b, bo = self._run_child(self.left)
         ht = ops.JoinHashTable(b, [l for l, _ in self.on], self.null_equality, probe_mode=self.probe_mode, null_aware=self.null_aware)
+        self._publish_dynamic_bounds(b)
         p, po = self._run_child(self.right)
         out = self._probe(ht, p, probe_predicate)
         ht.free()

@@ -75,3 +75,45 @@ def test_q6_straight_from_a_parquet_file(tmp_path):
     from datafusion_amd.expr import col
     plan = P.ProjectionExec([(col(name), "revenue")], P.AggregateExec("Single", [], [("sum", col("l_extendedprice") * col("l_discount"), name)], f))
     assert_answer("q6", P.collect(P.GpuOffloadRule().optimize(plan)).to_arrow())
+
+
+@pytest.mark.parametrize("join_type", ["Inner", "RightSemi", "Right"])
+def test_join_bounds_prune_the_probe_side_scan(tmp_path, join_type):
+    """the hash join's dynamic filter (hash_join/shared_bounds.rs:277-284): [min, max] of the build keys reaches the probe-side
+    ParquetExec, which skips row groups by their footer statistics — same join result, fewer row groups read; join types that
+    emit unmatched probe rows (Right) must not prune"""
+    from datafusion_amd import physical_plan as P
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    from tests import plan_oracle
+    rng = np.random.default_rng(5)
+    n = 60_000
+    probe = pa.table({"l_orderkey": pa.array(np.sort(rng.integers(0, 20_000, n)).astype(np.int64)), "l_qty": pa.array(rng.integers(1, 50, n).astype(np.int32))})
+    path = str(tmp_path / "probe.parquet")
+    pq.write_table(probe, path, row_group_size=5_000, compression="snappy")
+    build = pa.table({"o_orderkey": pa.array(np.arange(7_000, 7_400, dtype=np.int64)), "o_flag": pa.array(np.arange(400, dtype=np.int32) % 3)})
+
+    def plan(build_leaf):
+        scan = P.ParquetExec(path, ["l_orderkey", "l_qty"], "lineitem")
+        probe_side = P.CoalesceBatchesExec(P.FilterExec(col("l_qty") > lit(10, pa.int32()), scan))
+        return P.HashJoinExec(build_leaf, probe_side, [("o_orderkey", "l_orderkey")], join_type), scan
+    dev_build = DeviceTable.from_arrow(build)
+    j, scan = plan(P.MemoryExec(dev_build, "orders"))
+    got = P.collect(j).to_arrow()
+    exp = plan_oracle.collect(plan(P.MemoryExec(build, "orders"))[0])
+    assert_tables_equal(got, exp, ordered=False)
+    assert scan.metrics["row_groups_total"] == 12
+    if join_type == "Right":
+        assert scan.dynamic_bounds == {} and scan.metrics["row_groups_read"] == 12
+    else:
+        assert scan.dynamic_bounds == {"l_orderkey": (7_000, 7_399)} and 1 <= scan.metrics["row_groups_read"] <= 3
+    # through the rule (filter fused into the probe) the scan is still pruned
+    j2, scan2 = plan(P.MemoryExec(dev_build, "orders"))
+    opt = P.GpuOffloadRule().optimize(P.AggregateExec("Single", [], [("count", None, "n")], j2))
+    n_rows = P.collect(opt).to_arrow().to_pylist()[0]["n"]
+    assert n_rows == exp.num_rows and scan2.metrics["row_groups_read"] == scan.metrics["row_groups_read"]
+    # an empty build side reads nothing
+    j3, scan3 = plan(P.MemoryExec(DeviceTable.from_arrow(build.slice(0, 0)), "orders"))
+    out3 = P.collect(j3).to_arrow()
+    if join_type != "Right":
+        assert out3.num_rows == 0 and scan3.metrics["row_groups_read"] == 0

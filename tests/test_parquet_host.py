@@ -73,3 +73,30 @@ def test_truncated_chunk_is_an_error(tmp_path):
         assert _lib.load().dfgpu_parquet_inspect_chunk(buf, C.c_int64(cut), C.byref(d), C.byref(info)) != 0
         assert b"parquet" in _lib.load().dfgpu_last_error()
     f.close()
+
+
+def test_row_group_pruning_by_key_bounds(tmp_path):
+    """ParquetFile.row_groups_overlapping: footer min / max against closed key bounds (what a hash join's dynamic filter prunes with)"""
+    import numpy as np
+    import pyarrow.parquet as pq
+
+    from datafusion_amd.parquet import ParquetFile
+    n = 10_000
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64) * 3), "v": pa.array(np.arange(n, dtype=np.int32) % 7)})
+    path = str(tmp_path / "sorted.parquet")
+    pq.write_table(t, path, row_group_size=1000)
+    f = ParquetFile(path)
+    assert f.num_row_groups == 10
+    assert f.row_groups_overlapping({}) == list(range(10))
+    assert f.row_groups_overlapping({"k": (0, 3 * n)}) == list(range(10))
+    assert f.row_groups_overlapping({"k": (2998, 2999)}) == []                  # between row group 0 (max 2997) and row group 1 (min 3000)
+    assert f.row_groups_overlapping({"k": (2997, 3000)}) == [0, 1]              # closed bounds touch both neighbours
+    assert f.row_groups_overlapping({"k": (12_000, 12_001)}) == [4]
+    assert f.row_groups_overlapping({"k": (-50, -1)}) == [] and f.row_groups_overlapping({"k": (10**9, 10**9 + 1)}) == []
+    assert f.row_groups_overlapping({"k": (1, 0)}) == []                         # empty build side: empty range
+    assert f.row_groups_overlapping({"k": (0, 3 * n), "v": (7, 9)}) == []        # v is 0..6 everywhere
+    pq.write_table(t, path, row_group_size=1000, write_statistics=False)
+    f2 = ParquetFile(path)
+    assert f2.row_groups_overlapping({"k": (12_000, 12_001)}) == list(range(10))  # no statistics: nothing can be pruned
+    f.close()
+    f2.close()
