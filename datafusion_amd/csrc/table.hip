@@ -32,10 +32,14 @@ __global__ __launch_bounds__(BLOCK) void k_bitmap_place(const uint64_t* __restri
   }
 }
 
-// dictionary indices of one concat part rewritten into the merged dictionary: out[i] = remap[in[i]]
+// dictionary indices of one concat part rewritten into the merged dictionary: out[i] = remap[in[i]]; the slot under a NULL row
+// may hold anything (Arrow leaves it undefined): an index outside the part's dictionary becomes 0
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_remap_indices(const T* __restrict__ in, const int32_t* __restrict__ remap, int64_t n, T* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (T)remap[(size_t)in[i]];
+__global__ __launch_bounds__(BLOCK) void k_remap_indices(const T* __restrict__ in, const int32_t* __restrict__ remap, int64_t n_remap, int64_t n, T* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const uint64_t k = (uint64_t)in[i];
+    out[i] = k < (uint64_t)n_remap ? (T)remap[k] : (T)0;
+  }
 }
 
 // ---------------------------------------------------------------- format strings
@@ -538,9 +542,9 @@ int dfgpu_table_concat(const dfgpu_table_t* parts, int nparts, dfgpu_table_t* ou
           char* dst = (char*)n.data->ptr + (size_t)off * w;
           const int g = grid_for(t->nrows, BLOCK);
           switch (w) {
-            case 1: k_remap_indices<uint8_t><<<g, BLOCK, 0, rt().stream>>>((const uint8_t*)c.ptr(), d_remap->as<int32_t>(), t->nrows, (uint8_t*)dst); break;
-            case 4: k_remap_indices<uint32_t><<<g, BLOCK, 0, rt().stream>>>((const uint32_t*)c.ptr(), d_remap->as<int32_t>(), t->nrows, (uint32_t*)dst); break;
-            default: k_remap_indices<uint64_t><<<g, BLOCK, 0, rt().stream>>>((const uint64_t*)c.ptr(), d_remap->as<int32_t>(), t->nrows, (uint64_t*)dst); break;
+            case 1: k_remap_indices<uint8_t><<<g, BLOCK, 0, rt().stream>>>((const uint8_t*)c.ptr(), d_remap->as<int32_t>(), (int64_t)remap.size(), t->nrows, (uint8_t*)dst); break;
+            case 4: k_remap_indices<uint32_t><<<g, BLOCK, 0, rt().stream>>>((const uint32_t*)c.ptr(), d_remap->as<int32_t>(), (int64_t)remap.size(), t->nrows, (uint32_t*)dst); break;
+            default: k_remap_indices<uint64_t><<<g, BLOCK, 0, rt().stream>>>((const uint64_t*)c.ptr(), d_remap->as<int32_t>(), (int64_t)remap.size(), t->nrows, (uint64_t*)dst); break;
           }
           keep.push_back(d_remap);
         }
