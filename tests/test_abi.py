@@ -35,13 +35,15 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     names = {"dfgpu_field": _lib.Field, "dfgpu_expr_node": _lib.ExprNode, "dfgpu_expr": _lib.Expr, "dfgpu_join_options": _lib.JoinOptions,
              "dfgpu_join_info": _lib.JoinInfo, "dfgpu_kernel_stat": _lib.KernelStat, "dfgpu_agg_spec": _lib.AggSpec,
-             "dfgpu_column_view": _lib.ColumnView}
+             "dfgpu_column_view": _lib.ColumnView, "dfgpu_join_filter": _lib.JoinFilter, "dfgpu_parquet_column": _lib.ParquetColumn,
+             "dfgpu_parquet_chunk_info": _lib.ParquetChunkInfo}
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "dfgpu.h"\nint main(void){' +
                    "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) +
                    'printf("ArrowSchema %zu\\nArrowArray %zu\\n", sizeof(struct ArrowSchema), sizeof(struct ArrowArray));return 0;}')
     exe = tmp_path / "sizes"
-    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    # the header is plain C: it must compile as strict C99 without a single diagnostic
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
     for n, t in names.items():
         assert int(got[n]) == C.sizeof(t), (n, got[n], C.sizeof(t))
@@ -76,3 +78,62 @@ def test_expression_lowering():
     assert l.nodes[1].lit_lo == 1 and l.nodes[1].field.precision == 20
     neg = lower(lit(-5, pa.int64()), [])
     assert neg.nodes[0].lit_lo == 2**64 - 5 and neg.nodes[0].lit_hi == 2**64 - 1
+
+
+def test_c_program_links_against_the_library(tmp_path):
+    """a C translation unit (no C++, no Python) binds the boundary: links libdfgpu.so, reads the ABI version, gets a readable
+    error from an operator called before dfgpu_init, and drives the host half of the Parquet scan — what a cgo / Rust `extern "C"`
+    binding does"""
+    import subprocess
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    src = tmp_path / "bind.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "dfgpu.h"
+int main(void) {
+  if (dfgpu_abi_version() != DFGPU_ABI_VERSION) return 10;
+  dfgpu_table_t t = 0;
+  if (dfgpu_tpch_orders(0.001, 0, -1, &t) == 0) return 11;            /* not initialised: must fail */
+  if (!strstr(dfgpu_last_error(), "dfgpu_init")) return 12;
+  /* host half of the scan on a truncated chunk: an error, not a crash */
+  unsigned char junk[4] = {0x15, 0x00, 0x15, 0x02};
+  dfgpu_parquet_column col;
+  dfgpu_parquet_chunk_info info;
+  memset(&col, 0, sizeof col);
+  col.physical_type = DFGPU_PARQUET_INT64; col.codec = DFGPU_PARQUET_UNCOMPRESSED; col.num_values = 10;
+  col.field.type = DFGPU_INT64; col.name = "k";
+  if (dfgpu_parquet_inspect_chunk(junk, 4, &col, &info) == 0) return 13;
+  if (!strstr(dfgpu_last_error(), "parquet")) return 14;
+  printf("abi %d ok\n", dfgpu_abi_version());
+  return 0;
+}
+""")
+    exe = tmp_path / "bind"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-ldfgpu", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.strip() == "abi 6 ok"
+
+
+def test_case_and_in_list_lowering():
+    """CaseExpr -> one DFGPU_EXPR_CASE node per WHEN (condition in `column`, THEN left, ELSE right, later WHENs nested in ELSE);
+    InListExpr -> the OR of equalities, NOT of it when negated (include/dfgpu.h, expr.py)"""
+    import pyarrow as pa
+    from datafusion_amd.expr import OP_CASE, OP_NOT, case, col, lit, lower
+    e = case([(col("a") > lit(0), lit(1)), (col("a") < lit(0), lit(-1))], lit(0))
+    l = lower(e, ["a"])
+    root = l.nodes[l.c.root]
+    assert root.op == OP_CASE and l.nodes[root.column].op == 24 and l.nodes[root.left].lit_lo == 1     # WHEN a > 0 THEN 1
+    inner = l.nodes[root.right]
+    assert inner.op == OP_CASE and l.nodes[inner.column].op == 22 and l.nodes[inner.right].op == 2 and l.nodes[inner.right].lit_lo == 0
+    no_else = lower(case([(col("a") > lit(0), col("a"))]), ["a"])
+    assert no_else.nodes[no_else.c.root].right == -1
+    inl = lower(col("a").in_list([lit(1), lit(2), lit(3)]), ["a"])
+    ops = [inl.nodes[i].op for i in range(inl.c.n_nodes)]
+    assert ops.count(20) == 3 and ops.count(31) == 2 and inl.nodes[inl.c.root].op == 31
+    neg = lower(col("a").in_list([lit(1)], negated=True), ["a"])
+    assert neg.nodes[neg.c.root].op == OP_NOT and neg.c.n_nodes == 4
+    with pytest.raises(ValueError):
+        col("a").in_list([])
