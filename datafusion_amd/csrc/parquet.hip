@@ -360,6 +360,9 @@ ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_c
       continue;
     }
     DFGPU_CHECK(h.type == PAGE_DATA || h.type == PAGE_DATA_V2, "parquet: unknown page type " + std::to_string(h.type));
+    // a corrupt header must not walk the validity bitmap or the staging buffer out of bounds
+    DFGPU_CHECK(h.num_values >= 0 && P.rows + h.num_values <= col.num_values, "parquet: pages hold more rows than the chunk's num_values");
+    DFGPU_CHECK(h.def_bytes >= 0 && h.rep_bytes >= 0, "parquet: negative level byte length");
     // ---- uncompressed page body: v1 = [def levels][values] compressed together; v2 = levels uncompressed + values
     body.assign((size_t)h.uncompressed + 16, 0);
     const uint8_t* levels = nullptr;
