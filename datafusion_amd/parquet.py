@@ -131,6 +131,21 @@ class ParquetFile:
                 keep.append(g)
         return keep
 
+    def row_groups_for_rank(self, rank: int, world: int) -> list:
+        """this rank's share of the file when `world` GPUs scan it (one process per GPU): contiguous row groups, split where the
+        running row count crosses k/world of the total — the file-range split the reference's FileGroups make per partition
+        (DataSourceExec: file_groups), at row-group granularity.  Disjoint, covering, in file order; no collective needed."""
+        counts = [self.meta.row_group(g).num_rows for g in range(self.num_row_groups)]
+        total = sum(counts)
+        out, seen = [], 0
+        for g, c in enumerate(counts):
+            mid = seen + c / 2.0                       # a row group belongs to the rank its midpoint falls in
+            owner = min(world - 1, int(mid * world / total)) if total else 0
+            if owner == rank:
+                out.append(g)
+            seen += c
+        return out
+
     def read(self, columns=None, threads: int | None = None, row_groups=None) -> DeviceTable:
         """all row groups.  The host half of a chunk (decompression above all) runs on one core, so chunks are decoded from
         `threads` host threads (default min(16, cores), DFGPU_SCAN_THREADS overrides; ctypes releases the GIL) — the way the

@@ -151,3 +151,21 @@ def test_corrupt_page_headers_are_errors(tmp_path):
                 assert lib.dfgpu_last_error().startswith(b"parquet") or b"alloc" in lib.dfgpu_last_error().lower() or b"length" in lib.dfgpu_last_error().lower(), lib.dfgpu_last_error()
     assert outcomes["error"] > 50       # header corruption is detected; flips inside value bytes legitimately decode
     f.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_row_groups_are_shared_out_to_ranks_without_gaps_or_overlap(tmp_path, world):
+    import numpy as np
+    import pyarrow.parquet as pq
+
+    from datafusion_amd.parquet import ParquetFile
+    n = 23_456
+    path = str(tmp_path / "r.parquet")
+    pq.write_table(pa.table({"k": pa.array(np.arange(n, dtype=np.int64))}), path, row_group_size=1000)
+    f = ParquetFile(path)
+    shares = [f.row_groups_for_rank(r, world) for r in range(world)]
+    flat = [g for s in shares for g in s]
+    assert flat == list(range(f.num_row_groups))                       # covering, disjoint, in file order, contiguous per rank
+    rows = [sum(f.meta.row_group(g).num_rows for g in s) for s in shares]
+    assert sum(rows) == n and max(rows) - min(rows) <= 1000            # balanced to one row group
+    f.close()
