@@ -57,3 +57,45 @@ def test_stream_doc_example():
         assert list(bi) == [4, 5, 6, 6] and list(pi) == [3, 3, 4, 5]
     out = oracle.hash_join(build, probe, [("b1", "b2")])
     assert rows(out) == [(9, 8, 90, 8, 8, 80), (11, 8, 110, 8, 8, 80), (13, 10, 130, 10, 10, 100), (13, 10, 130, 12, 10, 120)]
+
+
+def _pairs(build_keys, probe_keys, typ, mode=0):
+    """(probe index, build index) pairs of an Inner join on one key column, in emission order, + whether the ArrayMap was used"""
+    import pyarrow as pa
+    b = pa.table({"k": pa.array(build_keys, type=typ)})
+    p = pa.table({"k": pa.array(probe_keys, type=typ)})
+    bi, pi, _, used = oracle.hash_join(b, p, [("k", "k")], return_indices=True, mode=mode)
+    return list(zip(pi.tolist(), bi.tolist())), used
+
+
+def test_array_map_known_answers():
+    """ArrayMap's own unit tests (joins/array_map.rs:428-599): matches come out in probe order, the matches of one probe row in
+    ascending build order; misses, duplicates on the build side, keys beyond the mapped range, NULL probe keys, negative keys.
+    (The tests page through `get_matched_indices_with_limit_offset`; the concatenation of their pages is what is pinned here.)"""
+    import pyarrow as pa
+    i32, i64, u64 = pa.int32(), pa.int64(), pa.uint64()
+    cases = [
+        ([1, 1, 2], [1, 2], i32, [(0, 0), (0, 1), (1, 2)]),                                   # :429 limit_offset_duplicate_elements
+        ([1, 2], [10, 1, 2], i32, [(1, 0), (2, 1)]),                                          # :460 with_limit_and_misses
+        ([1, 1], [10, 1, 20, 1], i32, [(1, 0), (1, 1), (3, 0), (3, 1)]),                      # :493 build_duplicates_and_misses (first three within its limit)
+        (list(range(11)), [3, (1 << 32) + 3, 11, None], u64, [(0, 3)]),                       # :519 rejects_large_out_of_range_probe_key
+        ([-5, 0, 5, -2, 3, 10], [0, -5, 10, -1], i64, [(0, 1), (1, 0), (2, 5)]),              # :563 i64_with_negative_and_positive_numbers
+    ]
+    for build, probe, typ, want in cases:
+        got, used = _pairs(build, probe, typ)
+        assert used and got == want, (build, probe, got)
+        got_hm, used_hm = _pairs(build, probe, typ, mode=1)                                   # the chained hash map gives the same pairs
+        assert not used_hm and sorted(got_hm) == sorted(want)
+
+
+def test_hash_map_skips_null_probe_keys():
+    """JoinHashMap's unit tests (joins/join_hash_map.rs:518-572): a probe row whose key is NULL matches nothing — not even through a
+    chain of duplicate build keys — while valid probe rows still match their whole chain.  (At map level the chain of the second test
+    is walked last-inserted-first, [3, 1]; HashJoinExec inserts the build side in reverse so that joins emit ascending build rows —
+    the pairs are compared as a set here.)"""
+    import pyarrow as pa
+    for mode in (0, 1):
+        got, _ = _pairs([10, 20, 30], [10, None, 30], pa.int64(), mode)
+        assert got == [(0, 0), (2, 2)]
+        got, _ = _pairs([10, 20, 10, 20], [None, 20], pa.int64(), mode)
+        assert sorted(got) == [(1, 1), (1, 3)]
