@@ -99,3 +99,23 @@ def test_hash_map_skips_null_probe_keys():
         assert got == [(0, 0), (2, 2)]
         got, _ = _pairs([10, 20, 10, 20], [None, 20], pa.int64(), mode)
         assert sorted(got) == [(1, 1), (1, 3)]
+
+
+def test_equal_rows_known_answers():
+    """equal_rows_arr's unit tests (joins/utils.rs:4625-4700), at join level: two-column keys (the Utf8 column as dictionary codes)
+    and NULL keys under both NullEquality settings — every candidate pair the reference test keeps is a join match here, every
+    pair it drops is not"""
+    import pyarrow as pa
+    code = {"a": 0, "b": 1, "c": 2, "d": 3}
+    left = pa.table({"a": pa.array([1, 2, 2, 3], pa.int32()), "b": pa.array([code[x] for x in "abcd"], pa.uint8())})
+    right = pa.table({"a": pa.array([2, 2, 3, 4], pa.int32()), "b": pa.array([code[x] for x in "bdda"], pa.uint8())})
+    bi, pi, _, _ = oracle.hash_join(left, right, [("a", "a"), ("b", "b")], return_indices=True)
+    assert sorted(zip(bi.tolist(), pi.tolist())) == [(1, 0), (3, 2)]            # :4625 filters_candidate_pairs: left [1, 3] / right [0, 2]
+    left = pa.table({"k": pa.array([1, None, 2, None], pa.int32())})
+    right = pa.table({"k": pa.array([None, 1, 2, None], pa.int32())})
+    bi, pi, _, _ = oracle.hash_join(left, right, [("k", "k")], null_equality="NullEqualsNothing", return_indices=True)
+    assert sorted(zip(bi.tolist(), pi.tolist())) == [(0, 1), (2, 2)]            # :4666 first half
+    bi, pi, _, _ = oracle.hash_join(left, right, [("k", "k")], null_equality="NullEqualsNull", return_indices=True)
+    got = sorted(zip(bi.tolist(), pi.tolist()))
+    assert {(0, 1), (1, 0), (2, 2), (3, 3)} <= set(got)                         # :4666 second half: all four candidate pairs survive
+    assert got == [(0, 1), (1, 0), (1, 3), (2, 2), (3, 0), (3, 3)]              # and the join also pairs the other NULLs
