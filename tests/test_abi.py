@@ -137,3 +137,48 @@ def test_case_and_in_list_lowering():
     assert neg.nodes[neg.c.root].op == OP_NOT and neg.c.n_nodes == 4
     with pytest.raises(ValueError):
         col("a").in_list([])
+
+
+class _StubTable:
+    """what bind_string_literals needs of a DeviceTable: schema (index types of dictionary columns), index_of, dictionary_code"""
+
+    def __init__(self, columns):
+        import pyarrow as pa
+        self.names = [n for n, _, _ in columns]
+        self.schema = pa.schema([pa.field(n, t) for n, t, _ in columns])
+        self.dicts = {n: d for n, _, d in columns}
+
+    def index_of(self, c):
+        return c if isinstance(c, int) else self.names.index(c)
+
+    def dictionary_code(self, column, value):
+        d = self.dicts[self.names[self.index_of(column)]]
+        return d.index(value) if value in d else None
+
+
+def test_string_literals_are_bound_to_dictionary_indices_on_the_host():
+    """expr.bind_string_literals: `dict_col = 'x'` -> index comparison; an absent string -> comparison with -1 over the widened
+    index (constant FALSE for `=`, TRUE for `!=` on non-NULL rows); a NULL string literal -> NULL index literal; binding reaches
+    into AND / OR / NOT / CASE / IN lists"""
+    import pyarrow as pa
+    from datafusion_amd.expr import BinaryExpr, CaseExpr, CastExpr, Literal, NotExpr, bind_string_literals, case, col, lit
+    t = _StubTable([("seg", pa.uint8(), ["AUTOMOBILE", "BUILDING", "FURNITURE"]), ("prio", pa.int32(), ["1-URGENT", "2-HIGH"]), ("k", pa.int64(), None)])
+    s = lambda v: lit(v, pa.string())   # noqa: E731
+    e = bind_string_literals(col("seg").eq(s("BUILDING")), t)
+    assert isinstance(e, BinaryExpr) and e.op == "=" and e.left.index == 0 and e.right.value == 1 and e.right.type == pa.uint8()
+    e = bind_string_literals(s("2-HIGH").ne(col("prio")), t)                      # literal on the left
+    assert e.op == "!=" and e.left.index == 1 and e.right.value == 1 and e.right.type == pa.int32()
+    e = bind_string_literals(col("seg").eq(s("NOT THERE")), t)
+    assert isinstance(e.left, CastExpr) and e.left.cast_type == pa.int64() and e.right.value == -1
+    e = bind_string_literals(col("prio").ne(s("NOT THERE")), t)
+    assert isinstance(e.left, CastExpr) and e.op == "!=" and e.right.value == -1
+    e = bind_string_literals(col("seg").eq(Literal(None, pa.string())), t)
+    assert e.right.value is None and e.right.type == pa.uint8()
+    e = bind_string_literals(col("seg").eq(s("BUILDING")).and_(col("k") > lit(5)).or_(col("prio").eq(s("1-URGENT")).not_()), t)
+    assert e.op == "or" and e.left.left.right.value == 1 and isinstance(e.right, NotExpr) and e.right.arg.right.value == 0
+    e = bind_string_literals(case([(col("prio").eq(s("1-URGENT")).or_(col("prio").eq(s("2-HIGH"))), lit(1))], lit(0)), t)
+    assert isinstance(e, CaseExpr) and e.when_then[0][0].left.right.value == 0 and e.when_then[0][0].right.right.value == 1
+    e = bind_string_literals(col("seg").in_list([s("FURNITURE"), s("AUTOMOBILE")], negated=True), t)
+    assert isinstance(e, NotExpr) and e.arg.op == "or" and e.arg.left.right.value == 2 and e.arg.right.right.value == 0
+    plain = bind_string_literals(col("k") > lit(5), t)           # nothing to bind: the same tree (rebuilt)
+    assert plain.op == ">" and plain.left.name == "k" and plain.right.value == 5
