@@ -58,3 +58,45 @@ def _walk(plan):
     yield plan
     for ch in plan.children():
         yield from _walk(ch)
+
+
+def test_dynamic_bounds_are_published_only_where_the_reference_allows_it(monkeypatch):
+    """HashJoinExec._publish_dynamic_bounds (the join's dynamic filter, hash_join/exec.rs:877-925 allow_join_dynamic_filter_pushdown +
+    shared_bounds.rs:277-284): only join types whose probe side is preserved, never null-aware anti joins or NullEqualsNull, one
+    integer key that the scan projects; an empty build side publishes an empty range"""
+    import pyarrow as pa
+    from datafusion_amd import ops, physical_plan as P
+    from datafusion_amd.expr import col, lit
+
+    class Build:
+        def __init__(self, typ=pa.int64()):
+            self.schema = pa.schema([pa.field("bk", typ), pa.field("v", pa.int32())])
+            self.num_rows = 10
+
+        def index_of(self, c):
+            return c if isinstance(c, int) else self.schema.names.index(c)
+    calls = []
+    monkeypatch.setattr(ops, "column_minmax", lambda t, c: (calls.append(c), (100, 200, 10, True))[1])
+
+    def scan_for(join_type, key_type=pa.int64(), projection=("pk", "w"), **kw):
+        scan = P.ParquetExec("/nonexistent.parquet", list(projection) if projection else None, "probe")
+        probe = P.CoalesceBatchesExec(P.FilterExec(col("w") > lit(1), scan))
+        j = P.HashJoinExec(P.MemoryExec(StubTable(10)), probe, [("bk", "pk")], join_type, **kw)
+        j._publish_dynamic_bounds(Build(key_type))
+        return scan
+    for jt in ("Inner", "Left", "LeftSemi", "RightSemi", "LeftAnti", "LeftMark"):
+        assert scan_for(jt).dynamic_bounds == {"pk": (100, 200)}, jt
+    for jt in ("Right", "Full", "RightAnti", "RightMark"):                       # unmatched probe rows are output: no pruning
+        assert scan_for(jt).dynamic_bounds == {}, jt
+    assert scan_for("LeftAnti", null_aware=True).dynamic_bounds == {}
+    assert scan_for("Inner", null_equality="NullEqualsNull").dynamic_bounds == {}
+    assert scan_for("Inner", key_type=pa.float64()).dynamic_bounds == {}          # bounds of integer keys only
+    assert scan_for("Inner", projection=("w",)).dynamic_bounds == {}              # the scan does not read the key column
+    assert scan_for("Inner", projection=None).dynamic_bounds == {"pk": (100, 200)}
+    monkeypatch.setattr(ops, "column_minmax", lambda t, c: (None, None, 0, False))
+    assert scan_for("Inner").dynamic_bounds == {"pk": (1, 0)}                     # empty build side: the empty range
+    # two key columns: no single-range filter
+    scan = P.ParquetExec("/nonexistent.parquet", ["pk", "pk2"], "probe")
+    j = P.HashJoinExec(P.MemoryExec(StubTable(10)), scan, [("bk", "pk"), ("v", "pk2")], "Inner")
+    j._publish_dynamic_bounds(Build())
+    assert scan.dynamic_bounds == {}
