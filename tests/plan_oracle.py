@@ -151,7 +151,54 @@ def _join_filter(node):
     return (_expr(e, Rel(pa.table({}), {})), cols)
 
 
+# --------------------------------------------------------------------------------------------- several ranks (gloo)
+# With torch.distributed initialised (world size N > 1) the interpreter runs the plan the way N GPUs do (one process per GPU):
+# a leaf is this rank's contiguous row range of its table (what N scans produce), RepartitionExec(Hash) routes rows with the
+# oracle's create_hashes (seed 0) % N and exchanges them, CoalescePartitionsExec / SortPreservingMergeExec gather every rank's
+# partition to every rank (the result is replicated, as in physical_plan.py).  The product's nodes do the same with the device
+# partition kernel + RCCL (exchange.hash_exchange; tests/test_gpu_sort_partition.py pins device routing == oracle routing).
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _all_gather_tables(t: pa.Table):
+    import torch.distributed as dist
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, t)
+    return parts
+
+
+def _hash_exchange(rel: Rel, keys) -> Rel:
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts, _ = oracle.hash_partition(rel.table, keys, world)
+    received = [None] * world
+    for dst in range(world):                      # one gather per destination: rank dst collects everybody's slice for it
+        got = [None] * world if rank == dst else None
+        dist.gather_object(parts[dst], got, dst=dst)
+        if rank == dst:
+            received = got
+    return Rel(pa.concat_tables(received), rel.dicts)
+
+
 def run(plan) -> Rel:
+    if _world() > 1:
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if isinstance(plan, P.MemoryExec):
+            t = plan.table if plan.projection is None else plan.table.select(plan.projection)
+            lo, hi = t.num_rows * rank // world, t.num_rows * (rank + 1) // world
+            return _encode(t.slice(lo, hi - lo))
+        if isinstance(plan, P.RepartitionExec):
+            return _hash_exchange(run(plan.input), plan.keys)
+        if isinstance(plan, P.CoalescePartitionsExec):
+            rel = run(plan.input)
+            return Rel(pa.concat_tables(_all_gather_tables(rel.table)), rel.dicts)
+        if isinstance(plan, P.SortPreservingMergeExec):
+            rel = run(plan.input)
+            merged = pa.concat_tables(_all_gather_tables(rel.table))
+            return Rel(oracle.sort(merged, plan.expr, plan.fetch), rel.dicts)
     if isinstance(plan, P.MemoryExec):
         t = plan.table if plan.projection is None else plan.table.select(plan.projection)
         return _encode(t)
