@@ -311,6 +311,18 @@ class HashJoinExec(ExecutionPlan):
         if ktype not in (pa.int64(), pa.int32()):
             return
         lo, hi, n, _ = ops.column_minmax(build_table, build_key)
+        from .queries import _world
+        if _world() > 1:
+            # one process per GPU: this rank's build partition holds only the keys routed to it, while its probe-side scan still
+            # holds rows bound for every rank — the filter must cover ALL partitions' build keys, as the reference's shared
+            # accumulator waits for every partition before it updates the filter (hash_join/shared_bounds.rs: SharedBuildAccumulator)
+            import torch.distributed as dist
+            parts = [None] * dist.get_world_size()
+            dist.all_gather_object(parts, (lo, hi, n))
+            seen = [(a, b) for a, b, c in parts if c]
+            n = len(seen)
+            if n:
+                lo, hi = min(a for a, _ in seen), max(b for _, b in seen)
         node.dynamic_bounds[probe_key] = (lo, hi) if n else (1, 0)     # an empty build side prunes the whole scan
 
     def _probe(self, ht, probe_table, predicate=None):

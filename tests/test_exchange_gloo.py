@@ -201,3 +201,34 @@ def test_route_is_hash_mod_world():
     from datafusion_amd.exchange import route
     h = np.array([0, 1, 7, 8, 2**64 - 1], dtype=np.uint64)
     assert route(h, 8).tolist() == [0, 1, 7, 0, 7]
+
+
+def _bounds_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from datafusion_amd import ops, physical_plan as P
+
+    class Build:     # this rank's build partition: its own key range (rank 2 of 3 holds no rows)
+        schema = pa.schema([pa.field("bk", pa.int64())])
+        num_rows = 5
+
+        def index_of(self, c):
+            return 0
+    local = {0: (100, 200, 5, True), 1: (150, 900, 5, True), 2: (None, None, 0, False)}[rank]
+    ops.column_minmax = lambda t, c: local
+    scan = P.ParquetExec("/nonexistent.parquet", ["pk"], "probe")
+    j = P.HashJoinExec(P.MemoryExec(Build()), P.RepartitionExec(scan, ["pk"], world), [("bk", "pk")], "Inner")
+    j._publish_dynamic_bounds(Build())
+    pickle.dump(scan.dynamic_bounds, open(os.path.join(outdir, f"b{rank}.pkl"), "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dynamic_join_bounds_cover_every_ranks_build_partition(tmp_path, world):
+    """Partitioned joins on N GPUs: a rank's probe-side scan feeds every rank, so the published bounds are the union over all
+    ranks' build partitions (the reference's SharedBuildAccumulator waits for all partitions, hash_join/shared_bounds.rs)"""
+    mp.spawn(_bounds_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert pickle.load(open(tmp_path / f"b{r}.pkl", "rb")) == {"pk": (100, 900)}
