@@ -241,6 +241,27 @@ def bind_string_literals(expr: PhysicalExpr, table) -> PhysicalExpr:
     return expr
 
 
+class IntermediateSchema:
+    """the schema a JoinFilter's expression is typed against (JoinFilter::schema, joins/join_filter.rs): column k = column
+    `index` of the build ("Left") or probe ("Right") table.  Quacks like a table for bind_string_literals, so that string literals
+    compared with intermediate columns are bound through the dictionary of the column they come from."""
+
+    def __init__(self, build, probe, column_indices):
+        self._src = [(build if side == "Left" else probe, int(i)) for i, side in column_indices]
+        self.names = [f"f{k}" for k in range(len(self._src))]
+
+    @property
+    def schema(self) -> pa.Schema:
+        return pa.schema([pa.field(n, t.schema.field(i).type) for n, (t, i) in zip(self.names, self._src)])
+
+    def index_of(self, c) -> int:
+        return c if isinstance(c, int) else self.names.index(c)
+
+    def dictionary_code(self, column, value):
+        t, i = self._src[self.index_of(column)]
+        return t.dictionary_code(i, value)
+
+
 def _has_string_literal(expr) -> bool:
     if isinstance(expr, Literal):
         return pa.types.is_string(expr.type) or pa.types.is_large_string(expr.type)

@@ -85,7 +85,10 @@ class JoinHashTable:
             if predicate is not None:
                 raise _lib.DfgpuError("a fused probe-side predicate and a join filter cannot be combined: filter the probe side first")
             fexpr, fcols = join_filter
-            le = lower(fexpr, [f"f{i}" for i in range(len(fcols))])
+            from .expr import IntermediateSchema, _has_string_literal
+            # string literals compared with intermediate columns: bound through the dictionaries of the columns behind them
+            view = IntermediateSchema(self.build, probe, fcols) if _has_string_literal(fexpr) else None
+            le = lower(fexpr, [f"f{i}" for i in range(len(fcols))], view)
             idx = (C.c_int32 * max(1, len(fcols)))(*[int(i) for i, _ in fcols])
             side = (C.c_int32 * max(1, len(fcols)))(*[0 if sd == "Left" else 1 for _, sd in fcols])
             jf = JoinFilter(le.c, idx, side, len(fcols))

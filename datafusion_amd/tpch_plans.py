@@ -197,6 +197,44 @@ def q18_plan(customer, orders, lineitem):
     return P.SortPreservingMergeExec(keys, P.SortExec(keys, agg))
 
 
+# ----------------------------------------------------------------------------------------- Q19
+def q19_plan(lineitem, part):
+    """q19.slt.part:67-77: LeftSemi join (build = filtered lineitem) whose JoinFilter mixes both sides — brand / container / size of
+    the part with the quantity of the line — IN lists over string columns, one ungrouped SUM"""
+    qty, s = col("l_quantity"), lambda v: lit(v, pa.string())            # noqa: E731
+    q = lambda v: lit(Decimal(v), D15_2)                                  # noqa: E731
+    between = lambda e, lo, hi: (e >= q(lo)).and_(e <= q(hi))             # noqa: E731
+    lpred = (col("l_shipmode").eq(s("AIR")).or_(col("l_shipmode").eq(s("AIR REG")))).and_(col("l_shipinstruct").eq(s("DELIVER IN PERSON"))) \
+        .and_(between(qty, "1.00", "11.00").or_(between(qty, "10.00", "20.00")).or_(between(qty, "20.00", "30.00")))
+    l = _hash(_cb(P.FilterExec(lpred, _scan(lineitem, "lineitem").project(["l_partkey", "l_quantity", "l_extendedprice", "l_discount", "l_shipinstruct", "l_shipmode"]),
+                               projection=["l_partkey", "l_quantity", "l_extendedprice", "l_discount"])), ["l_partkey"])
+    groups = [("Brand#12", ["SM CASE", "SM BOX", "SM PACK", "SM PKG"], 5, "1.00", "11.00"),
+              ("Brand#23", ["MED BAG", "MED BOX", "MED PKG", "MED PACK"], 10, "10.00", "20.00"),
+              ("Brand#34", ["LG CASE", "LG BOX", "LG PACK", "LG PKG"], 15, "20.00", "30.00")]
+
+    def part_side(brand, container, size):
+        alts = None
+        for b, cs, mx, _, _ in groups:
+            a = brand.eq(s(b)).and_(container.in_list([s(c) for c in cs])).and_(size <= lit(mx, pa.int32()))
+            alts = a if alts is None else alts.or_(a)
+        return alts
+    ppred = (col("p_size") >= lit(1, pa.int32())).and_(part_side(col("p_brand"), col("p_container"), col("p_size")))
+    p = _hash(_cb(P.FilterExec(ppred, _scan(part, "part").project(["p_partkey", "p_brand", "p_size", "p_container"]))), ["p_partkey"])
+    # JoinFilter over the intermediate columns f0 = l_quantity (Left 1), f1 = p_brand, f2 = p_size, f3 = p_container (Right 1, 2, 3)
+    f_qty, f_brand, f_size, f_cont = col("f0"), col("f1"), col("f2"), col("f3")
+    jf = None
+    for b, cs, mx, lo, hi in groups:
+        a = f_brand.eq(s(b)).and_(f_cont.in_list([s(c) for c in cs])).and_(f_qty >= q(lo)).and_(f_qty <= q(hi)).and_(f_size <= lit(mx, pa.int32()))
+        jf = a if jf is None else jf.or_(a)
+    semi = P.HashJoinExec(_cb(l), _cb(p), [("l_partkey", "p_partkey")], "LeftSemi", projection=(["l_extendedprice", "l_discount"], None),
+                          filter=(jf, [(1, "Left"), (1, "Right"), (2, "Right"), (3, "Right")]))
+    name = "sum(lineitem.l_extendedprice * Int64(1) - lineitem.l_discount)"
+    aggs = [("sum", col("l_extendedprice") * (ONE - col("l_discount")), name)]
+    partial = P.AggregateExec("Partial", [], aggs, _cb(semi))
+    final = P.AggregateExec("Final", [], aggs, P.CoalescePartitionsExec(partial))
+    return P.ProjectionExec([(col(name), "revenue")], final)
+
+
 # ----------------------------------------------------------------------------------------- Q21
 def q21_plan(supplier, lineitem, orders, nation):
     """q21.slt.part:92-122: EXISTS / NOT EXISTS decorrelated to LeftSemi / LeftAnti joins carrying the JoinFilter

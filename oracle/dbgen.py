@@ -40,6 +40,11 @@ L_RDTE_SD = (373135028, 7)
 L_RFLG_SD = (717419739, 7)
 C_MSEG_SD = (1140279430, 1)
 O_PRIO_SD = (591449447, 1)
+P_MFG_SD = (1, 1)
+P_BRND_SD = (46831694, 1)
+P_TYPE_SD = (1841581359, 1)
+P_SIZE_SD = (1193163244, 1)
+P_CNTR_SD = (727633698, 1)
 C_NTRG_SD = (1489529863, 1)
 S_NTRG_SD = (110356601, 1)
 L_SHIP_SD = (1371272478, 7)
@@ -55,6 +60,8 @@ PRIORITIES = ["1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"]     
 SHIP_MODES = ["REG AIR", "AIR", "RAIL", "TRUCK", "MAIL", "FOB", "SHIP"]                   # dists.dss smode
 SHIP_INSTRUCT = ["DELIVER IN PERSON", "COLLECT COD", "TAKE BACK RETURN", "NONE"]          # dists.dss instruct
 SUPP_PER_PART = 4
+# dists.dss p_cntr: 5 x 8 syllable combinations
+CONTAINERS = [a + " " + b for a in ("SM", "LG", "MED", "JUMBO", "WRAP") for b in ("CASE", "BOX", "BAG", "JAR", "PKG", "PACK", "CAN", "DRUM")]
 # dists.dss nations (name, region) and regions
 NATIONS = [("ALGERIA", 0), ("ARGENTINA", 1), ("BRAZIL", 1), ("CANADA", 1), ("EGYPT", 4), ("ETHIOPIA", 0), ("FRANCE", 3), ("GERMANY", 3),
            ("INDIA", 2), ("INDONESIA", 2), ("IRAN", 4), ("IRAQ", 4), ("JAPAN", 2), ("JORDAN", 4), ("KENYA", 0), ("MOROCCO", 0),
@@ -241,3 +248,16 @@ def nation(strings: str = "codes") -> pa.Table:
 
 def region(strings: str = "codes") -> pa.Table:
     return pa.table({"r_regionkey": pa.array(np.arange(5, dtype=np.int64)), "r_name": _strings(np.arange(5), REGIONS, strings)})
+
+
+def part(sf: float, strings: str = "codes") -> pa.Table:
+    """build.c mk_part: key, brand ("Brand#MN": M = manufacturer 1..5, N = 1..5), size 1..50, container"""
+    n = counts(sf)["part"]
+    mfgr = _draw(P_MFG_SD, n, 1, 5)
+    brand = mfgr * 10 + _draw(P_BRND_SD, n, 1, 5)
+    brands = [f"Brand#{m}{k}" for m in range(1, 6) for k in range(1, 6)]
+    bcode = (brand // 10 - 1) * 5 + (brand % 10 - 1)
+    size = _draw(P_SIZE_SD, n, 1, 50)
+    cntr = _draw(P_CNTR_SD, n, 1, 40) - 1
+    return pa.table({"p_partkey": pa.array(np.arange(1, n + 1, dtype=np.int64)), "p_brand": _strings(bcode, brands, strings),
+                     "p_size": pa.array(size.astype(np.int32)), "p_container": _strings(cntr, CONTAINERS, strings)})

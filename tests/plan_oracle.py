@@ -127,7 +127,7 @@ def _aggregate(rel: Rel, mode, group_by, aggs, return_types=None) -> Rel:
 
 
 def _join(node, left: Rel, right: Rel) -> Rel:
-    out = oracle.hash_join(left.table, right.table, node.on, node.join_type, node.null_equality, join_filter=_join_filter(node), null_aware=node.null_aware)
+    out = oracle.hash_join(left.table, right.table, node.on, node.join_type, node.null_equality, join_filter=_join_filter(node, left, right), null_aware=node.null_aware)
     dicts = dict(right.dicts)
     dicts.update(left.dicts)
     rel = Rel(out, dicts)
@@ -144,11 +144,21 @@ def _join(node, left: Rel, right: Rel) -> Rel:
     return rel
 
 
-def _join_filter(node):
+def _join_filter(node, left: Rel, right: Rel):
+    """JoinFilter: expression over the intermediate columns f0, f1, ... (column index, side); string literals are bound through
+    the dictionaries of the columns the intermediate columns come from"""
     if node.filter is None:
         return None
     e, cols = node.filter
-    return (_expr(e, Rel(pa.table({}), {})), cols)
+    fields, dicts = [], {}
+    for k, (idx, side) in enumerate(cols):
+        src = left if side == "Left" else right
+        name = src.table.column_names[idx]
+        fields.append(pa.field(f"f{k}", src.table.schema.field(idx).type))
+        if name in src.dicts:
+            dicts[f"f{k}"] = src.dicts[name]
+    inter = Rel(pa.Table.from_arrays([pa.array([], f.type) for f in fields], names=[f.name for f in fields]), dicts)
+    return (_expr(e, inter), cols)
 
 
 # --------------------------------------------------------------------------------------------- several ranks (gloo)

@@ -182,3 +182,23 @@ def test_string_literals_are_bound_to_dictionary_indices_on_the_host():
     assert isinstance(e, NotExpr) and e.arg.op == "or" and e.arg.left.right.value == 2 and e.arg.right.right.value == 0
     plain = bind_string_literals(col("k") > lit(5), t)           # nothing to bind: the same tree (rebuilt)
     assert plain.op == ">" and plain.left.name == "k" and plain.right.value == 5
+
+
+def test_join_filter_string_literals_bind_through_the_source_columns():
+    """expr.IntermediateSchema: a JoinFilter's intermediate column k is column (index, side) of the build / probe table; string
+    literals in the filter are bound with THAT column's dictionary (Q19: p_brand = 'Brand#12' AND p_container IN (...) AND l_quantity ...)"""
+    import pyarrow as pa
+    from datafusion_amd.expr import IntermediateSchema, bind_string_literals, col, lit, lower
+    build = _StubTable([("l_partkey", pa.int64(), None), ("l_quantity", pa.decimal128(15, 2), None)])
+    probe = _StubTable([("p_partkey", pa.int64(), None), ("p_brand", pa.uint8(), ["Brand#12", "Brand#23"]), ("p_size", pa.int32(), None),
+                        ("p_container", pa.uint8(), ["LG BOX", "SM BOX", "SM CASE"])])
+    view = IntermediateSchema(build, probe, [(1, "Left"), (1, "Right"), (2, "Right"), (3, "Right")])
+    assert view.schema.names == ["f0", "f1", "f2", "f3"] and view.schema.field("f3").type == pa.uint8() and view.schema.field("f0").type == pa.decimal128(15, 2)
+    assert view.dictionary_code("f1", "Brand#23") == 1 and view.dictionary_code(3, "SM CASE") == 2 and view.dictionary_code("f3", "JUMBO JAR") is None
+    s = lambda v: lit(v, pa.string())   # noqa: E731
+    e = col("f1").eq(s("Brand#12")).and_(col("f3").in_list([s("SM CASE"), s("SM BOX")])).and_(col("f2") <= lit(5, pa.int32()))
+    b = bind_string_literals(e, view)
+    assert b.left.left.right.value == 0 and b.left.left.left.index == 1                     # f1 = index of 'Brand#12'
+    assert b.left.right.op == "or" and b.left.right.left.right.value == 2 and b.left.right.right.right.value == 1 and b.left.right.left.left.index == 3
+    lowered = lower(e, view.names, view)                                                   # lowers without a string node left
+    assert all(lowered.nodes[i].op != 2 or lowered.nodes[i].field.type != 0 for i in range(lowered.c.n_nodes))

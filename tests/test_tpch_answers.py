@@ -1,4 +1,4 @@
-"""The reference's pinned TPC-H answers (sqllogictest/test_files/tpch/answers/q{1,3,4,5,6,12,18,21}.slt.part, scale factor
+"""The reference's pinned TPC-H answers (sqllogictest/test_files/tpch/answers/q{1,3,4,5,6,12,18,19,21}.slt.part, scale factor
 0.1) as end-to-end known-answer tests.
 
 Data: oracle/dbgen.py, a restatement of the TPC's dbgen for the columns these queries read, itself pinned against the
@@ -28,7 +28,8 @@ SF = 0.1
 def data(strings="dictionary"):
     from oracle import dbgen
     c, o, l = dbgen.tables(SF, strings)
-    return dict(customer=c, orders=o, lineitem=l, supplier=dbgen.supplier(SF, strings), nation=dbgen.nation(strings), region=dbgen.region(strings))
+    return dict(customer=c, orders=o, lineitem=l, supplier=dbgen.supplier(SF, strings), nation=dbgen.nation(strings), region=dbgen.region(strings),
+                part=dbgen.part(SF, strings))
 
 
 def plans(t):
@@ -38,6 +39,7 @@ def plans(t):
             "q4": T.q4_plan(t["orders"], t["lineitem"]),
             "q5": T.q5_plan(t["customer"], t["orders"], t["lineitem"], t["supplier"], t["nation"], t["region"]),
             "q6": T.q6_plan(t["lineitem"]), "q12": T.q12_plan(t["orders"], t["lineitem"]), "q18": T.q18_plan(t["customer"], t["orders"], t["lineitem"]),
+            "q19": T.q19_plan(t["lineitem"], t["part"]),
             "q21": T.q21_plan(t["supplier"], t["lineitem"], t["orders"], t["nation"])}
 
 
@@ -73,12 +75,16 @@ def assert_answer(q, got: pa.Table):
         assert all(_cell(v, x) for v, x in zip(r, w)), f"{q} row {i}: got {r}, the reference's answer is {w} ({GOLD['answers'][q]['source']})"
 
 
-QUERIES = ["q1", "q3", "q4", "q5", "q6", "q12", "q18", "q21"]
+QUERIES = ["q1", "q3", "q4", "q5", "q6", "q12", "q18", "q19", "q21"]
+# Q19's JoinFilter compares string columns with literals.  The host side binds them through the dictionaries of the columns behind the
+# intermediate schema (expr.IntermediateSchema, tests/test_abi.py), but that path has not run on a GPU yet (it was written after this
+# round's GPU budget was spent), so Q19 stays on the oracle legs until it has: add it here in the next round
+GPU_QUERIES = [q for q in QUERIES if q != "q19"]
 RESULT_TYPES = {   # pinned by the answer files' decimal digits and the plan files' expression types
     "q1": {"sum_qty": pa.decimal128(25, 2), "sum_disc_price": pa.decimal128(38, 4), "sum_charge": pa.decimal128(38, 6), "avg_qty": pa.decimal128(19, 6),
            "count_order": pa.int64()},
     "q3": {"revenue": pa.decimal128(38, 4)}, "q4": {"order_count": pa.int64()}, "q5": {"revenue": pa.decimal128(38, 4)},
-    "q6": {"revenue": pa.decimal128(38, 4)}, "q12": {"high_line_count": pa.int64(), "low_line_count": pa.int64()}, "q18": {"sum(lineitem.l_quantity)": pa.decimal128(25, 2)}, "q21": {"numwait": pa.int64()},
+    "q6": {"revenue": pa.decimal128(38, 4)}, "q12": {"high_line_count": pa.int64(), "low_line_count": pa.int64()}, "q18": {"sum(lineitem.l_quantity)": pa.decimal128(25, 2)}, "q19": {"revenue": pa.decimal128(38, 4)}, "q21": {"numwait": pa.int64()},
 }
 
 
@@ -142,7 +148,7 @@ def device_tables():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", QUERIES)
+@pytest.mark.parametrize("q", GPU_QUERIES)
 def test_gpu_reproduces_the_reference_answer(q, device_tables):
     from datafusion_amd import physical_plan as P
     plan = plans(device_tables)[q]
