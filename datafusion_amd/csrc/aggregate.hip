@@ -318,9 +318,29 @@ struct Aggregate {
   int64_t capacity_hint = 1 << 16;
   std::vector<uint16_t> small_keys;  // small-domain interning: host mirror of the group keys (byte g of key i = column g)
   int64_t fused_updates = 0;         // updates that took the fused (rowprog) path
+  bool touched = false;              // an update ran: the state is bound to its device
   bool final_mode() const { return mode == DFGPU_AGG_FINAL || mode == DFGPU_AGG_FINAL_PARTITIONED; }
   bool partial_out() const { return mode == DFGPU_AGG_PARTIAL; }
 };
+
+// the calling thread moves to the device the aggregate's state lives on
+static Aggregate* unwrap_agg(dfgpu_agg_t h) {
+  DFGPU_CHECK(h != nullptr, "null aggregate handle");
+  Aggregate* a = reinterpret_cast<Aggregate*>(h);
+  if (a->group_keys.device >= 0) use_device(a->group_keys.device);
+  return a;
+}
+
+// an aggregate binds to the device of its first input (it is created before any input exists)
+static const Table& agg_input(Aggregate& a, dfgpu_table_t input) {
+  const Table& in = *unwrap(input);
+  if (!a.touched) {
+    a.group_keys.device = in.device;
+    a.touched = true;
+  }
+  DFGPU_CHECK(in.device == a.group_keys.device, "the input table lives on another device than the aggregate's state");
+  return in;
+}
 
 static dfgpu_field fld(int type, int p = 0, int s = 0) {
   dfgpu_field f{};
@@ -799,6 +819,7 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
       const Column& gk = A.group_keys.cols[g];
       const Column& ik = key_cols[g];
       DFGPU_CHECK(gk.field.type == ik.field.type, "group key type changed between batches");
+      DFGPU_CHECK(same_dictionary(gk.dict, ik.dict), "group key " + gk.name + ": the dictionary changed between updates (unify the inputs' dictionaries first, e.g. dfgpu_table_concat)");
       Column cc = alloc_column(gk.field, gk.name, total, gk.validity || ik.validity);
       cc.dict = gk.dict ? gk.dict : ik.dict;
       int w = type_width(gk.field.type);
@@ -2151,6 +2172,16 @@ static void agg_update_unfused(Aggregate& A, const Table& in) {
 
 // aggregate_batch_inner over a whole table, optionally under a FilterExec predicate fused in front
 static void agg_update(Aggregate& A, const Table& in, const dfgpu_expr* pred = nullptr) {
+  // group keys that are dictionary-encoded columns are interned by their indices: every update must use the dictionary of
+  // the groups that exist already (all interning paths — LDS cells, dense ranks, hash — rely on this)
+  if (A.ngroups > 0)
+    for (size_t g = 0; g < A.group_roots.size() && g < A.group_keys.cols.size(); g++) {
+      int kc = A.final_mode() ? (int)g : -1;
+      if (!A.final_mode() && !is_plain_column(A.group_nodes[g], A.group_roots[g], &kc)) continue;
+      if (kc < 0 || kc >= (int)in.cols.size()) continue;
+      DFGPU_CHECK(same_dictionary(A.group_keys.cols[g].dict, in.cols[kc].dict),
+                  "group key " + A.group_names[g] + ": the dictionary changed between updates (unify the inputs' dictionaries first, e.g. dfgpu_table_concat)");
+    }
   std::string why;
   if (agg_update_fused(A, in, pred, why)) {
     A.fused_updates++;
@@ -2337,14 +2368,16 @@ int dfgpu_agg_create(int mode, const dfgpu_expr* group_by, const char* const* gr
 int dfgpu_agg_update(dfgpu_agg_t h, dfgpu_table_t input) {
   return guarded([&] {
     require_init();
-    agg_update(*reinterpret_cast<Aggregate*>(h), *unwrap(input));
+    Aggregate* a = unwrap_agg(h);
+    agg_update(*a, agg_input(*a, input));
   });
 }
 
 int dfgpu_agg_update_filtered(dfgpu_agg_t h, dfgpu_table_t input, const dfgpu_expr* predicate) {
   return guarded([&] {
     require_init();
-    agg_update(*reinterpret_cast<Aggregate*>(h), *unwrap(input), predicate);
+    Aggregate* a = unwrap_agg(h);
+    agg_update(*a, agg_input(*a, input), predicate);
   });
 }
 
@@ -2359,13 +2392,13 @@ int dfgpu_set_fusion(int on) {
 int dfgpu_agg_emit(dfgpu_agg_t h, dfgpu_table_t* out) {
   return guarded([&] {
     require_init();
-    auto t = std::make_unique<Table>(agg_emit(*reinterpret_cast<Aggregate*>(h)));
+    auto t = std::make_unique<Table>(agg_emit(*unwrap_agg(h)));
     *out = wrap(t.release());
   });
 }
 
 int dfgpu_agg_free(dfgpu_agg_t h) {
-  return guarded([&] { delete reinterpret_cast<Aggregate*>(h); });
+  return guarded([&] { if (h) delete unwrap_agg(h); });
 }
 
 }  // extern "C"

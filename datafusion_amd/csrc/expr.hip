@@ -336,6 +336,13 @@ static Datum eval_binary(const dfgpu_expr_node& n, const Datum& a, const Datum& 
   const dfgpu_field& lt = a.col.field;
   const dfgpu_field& rtp = b.col.field;
   const int op = n.op;
+  // dictionary-encoded strings are compared through their indices: that is only the strings' comparison when both
+  // sides share one dictionary (and, for an ordering, when it is sorted); a literal was bound to an index by the caller
+  if (!a.scalar && !b.scalar && (a.col.dict || b.col.dict) && op >= DFGPU_EXPR_EQ && op <= DFGPU_EXPR_GE) {
+    DFGPU_CHECK(a.col.dict && b.col.dict, "comparison of a dictionary-encoded column with a plain column is not supported on the GPU path");
+    DFGPU_CHECK(same_dictionary(a.col.dict, b.col.dict), "comparison of two dictionary-encoded columns with different dictionaries is not supported on the GPU path");
+    DFGPU_CHECK(op == DFGPU_EXPR_EQ || op == DFGPU_EXPR_NE || a.col.dict->sorted, "ordering comparison over an unsorted dictionary is not supported on the GPU path");
+  }
   if (op == DFGPU_EXPR_AND || op == DFGPU_EXPR_OR) {
     DFGPU_CHECK(lt.type == DFGPU_BOOL && rtp.type == DFGPU_BOOL, "AND/OR operands must be Boolean");
     Datum x = to_bool_array(a, nrows), y = to_bool_array(b, nrows);

@@ -50,7 +50,10 @@ int guarded(F&& f) noexcept {
 }
 
 // ---------------------------------------------------------------------------------------
-// Runtime: one per process (one process per GPU).
+// Runtime: one per initialised device.  A process normally drives ONE GPU (one process per GPU under torchrun); a
+// single DataFusion process that owns several GPUs (one per output partition) initialises several and selects the
+// calling thread's device with dfgpu_set_device — every entry point that takes a table / join / aggregate handle
+// switches the calling thread to the handle's device first (unwrap()).
 struct Runtime {
   int device = -1;
   hipStream_t stream = nullptr;
@@ -81,7 +84,11 @@ struct Runtime {
   void collect();
 };
 
-Runtime& rt();
+Runtime& rt();                 // the calling thread's current device runtime (hipSetDevice is kept in step, per thread)
+Runtime& rt_of(int device);    // an initialised device's runtime
+void use_device(int device);   // make `device` the calling thread's current device (must be initialised)
+int current_device();          // -1 before dfgpu_init
+const std::vector<int>& initialised_devices();
 void require_init();
 
 // RAII event pair around a kernel launch when profiling is on.
@@ -97,6 +104,7 @@ struct ProfileScope {
 struct DevBuf {
   void* ptr = nullptr;
   size_t bytes = 0;
+  Runtime* owner = nullptr;  // the pool the block goes back to (buffers may be released from any thread)
   explicit DevBuf(size_t n);
   ~DevBuf();
   DevBuf(const DevBuf&) = delete;
@@ -153,6 +161,11 @@ struct DictValues {
   bool sorted = false;              // values strictly ascending: index order == string order
 };
 
+// two dictionary-encoded columns mean the same strings by the same indices
+inline bool same_dictionary(const std::shared_ptr<const DictValues>& a, const std::shared_ptr<const DictValues>& b) {
+  return a == b || (a && b && a->values == b->values && a->valid == b->valid);
+}
+
 struct Column {
   dfgpu_field field{};
   std::string name;
@@ -172,11 +185,16 @@ struct Column {
 struct Table {
   std::vector<Column> cols;
   int64_t nrows = 0;
+  int device = current_device();  // the GPU whose HBM holds the columns
 };
 
+// every entry point reaches its input tables through unwrap(): the calling thread is switched to the table's device
+// (HIP's current device is per thread — a worker thread of the host engine starts on device 0)
 inline Table* unwrap(dfgpu_table_t t) {
   DFGPU_CHECK(t != nullptr, "null table handle");
-  return reinterpret_cast<Table*>(t);
+  Table* p = reinterpret_cast<Table*>(t);
+  if (p->device >= 0) use_device(p->device);
+  return p;
 }
 inline dfgpu_table_t wrap(Table* t) { return reinterpret_cast<dfgpu_table_t>(t); }
 
@@ -228,6 +246,12 @@ void jit_launch(hipFunction_t fn, int grid, int block, size_t lds_bytes, void* a
 hipFunction_t jit_get(const std::string& source, const char* kernel_name);
 // launches on the library stream; `args` is the kernel's single by-value argument struct
 void jit_launch(hipFunction_t fn, int grid, int block, size_t lds_bytes, void* args, size_t args_bytes);
+
+// ----------------------------------------------------------------- dictionaries (table.hip)
+// `c`'s indices rewritten so that they index `target`'s values; a value `target` does not hold gets the index
+// target->values.size() (equal to no index of a column encoded with `target`) — what joining / comparing two
+// dictionary-encoded columns with different dictionaries needs.  Errors when the index type cannot hold that value.
+Column remap_to_dictionary(const Column& c, const std::shared_ptr<const DictValues>& target);
 
 // ----------------------------------------------------------------- hashing (partition.hip)
 void hash_columns(const std::vector<const Column*>& keys, int64_t n, uint64_t seed, uint64_t* out, bool force_collisions);

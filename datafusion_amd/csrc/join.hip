@@ -1038,15 +1038,49 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
   return jt;
 }
 
+// Dictionary-encoded key columns join on their indices, which only means joining on the strings when both sides use the
+// same dictionary.  A probe side encoded differently (another Parquet file, another table) gets its key indices rewritten
+// into the build side's dictionary; probe strings the build dictionary does not hold get an index no build row carries.
+static Table with_build_dictionaries(const JoinTable& jt, const Table& probe, const std::vector<int>& pk) {
+  DFGPU_CHECK(pk.size() == jt.key_cols.size(), "probe key count differs from build key count");
+  Table fixed;
+  bool changed = false;
+  for (size_t i = 0; i < pk.size(); i++) {
+    DFGPU_CHECK(pk[i] >= 0 && pk[i] < (int)probe.cols.size(), "join key column index out of range");
+    const Column& bc = jt.build.cols[jt.key_cols[i]];
+    const Column& pc = probe.cols[pk[i]];
+    DFGPU_CHECK((bc.dict != nullptr) == (pc.dict != nullptr), "join key " + std::to_string(i) + ": one side is dictionary-encoded, the other is not (the planner inserts casts)");
+    if (!bc.dict || same_dictionary(bc.dict, pc.dict)) continue;
+    for (size_t k = 0; k < bc.dict->valid.size(); k++) DFGPU_CHECK(bc.dict->valid[k], "join keys with NULL dictionary values and different dictionaries are not supported on the GPU path");
+    for (size_t k = 0; k < pc.dict->valid.size(); k++) DFGPU_CHECK(pc.dict->valid[k], "join keys with NULL dictionary values and different dictionaries are not supported on the GPU path");
+    if (!changed) fixed = probe;  // shallow: columns share their buffers
+    changed = true;
+    fixed.cols[pk[i]] = remap_to_dictionary(pc, bc.dict);
+  }
+  return changed ? fixed : probe;
+}
+
+// the calling thread moves to the device the join table lives on (dfgpu.h: handles carry their device)
+static JoinTable* unwrap_join(dfgpu_join_t ht) {
+  DFGPU_CHECK(ht != nullptr, "null join handle");
+  JoinTable* jt = reinterpret_cast<JoinTable*>(ht);
+  if (jt->build.device >= 0) use_device(jt->build.device);
+  return jt;
+}
+
 static bool needs_visited(int join_type) {
   return join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_FULL || join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI ||
          join_type == DFGPU_JOIN_LEFT_MARK;
 }
 
-static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
+static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout_in,
                         const std::vector<int>& pout, const uint64_t* row_mask = nullptr, bool* mask_consumed = nullptr) {
   Runtime& r = rt();
+  // RightSemi / RightAnti emit probe columns only (joins/utils.rs:1628,1576): build_out_cols given by a C-ABI caller are ignored
+  // on every path — the fused kernel would otherwise gather build rows of unmatched (anti) probe rows
+  const std::vector<int> bout = (join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI) ? std::vector<int>{} : bout_in;
   DFGPU_CHECK(pk.size() == jt.key_cols.size(), "probe key count differs from build key count");
+  DFGPU_CHECK(probe.device == jt.build.device, "the probe table lives on another device than the join table (move it with dfgpu_table_copy_to_device)");
   const int64_t np = probe.nrows;
   const int64_t n_words = (np + 63) / 64;
   ProbeCtx ctx = make_ctx(jt, probe, pk);
@@ -1444,11 +1478,12 @@ int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_
   return guarded([&] {
     require_init();
     DFGPU_CHECK(ht && out, "null argument");
-    JoinTable* jt = reinterpret_cast<JoinTable*>(ht);
+    JoinTable* jt = unwrap_join(ht);
     DFGPU_CHECK(join_type >= DFGPU_JOIN_INNER && join_type <= DFGPU_JOIN_RIGHT_MARK, "bad join type");
     std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
     std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
-    auto o = std::make_unique<Table>(join_probe_null_aware(*jt, *unwrap(probe), pk, join_type, bo, po));
+    const Table pt = with_build_dictionaries(*jt, *unwrap(probe), pk);
+    auto o = std::make_unique<Table>(join_probe_null_aware(*jt, pt, pk, join_type, bo, po));
     *out = wrap(o.release());
   });
 }
@@ -1458,10 +1493,10 @@ int dfgpu_join_probe_filtered(dfgpu_join_t ht, dfgpu_table_t probe, const dfgpu_
   return guarded([&] {
     require_init();
     DFGPU_CHECK(ht && out && probe_predicate, "null argument");
-    JoinTable* jt = reinterpret_cast<JoinTable*>(ht);
+    JoinTable* jt = unwrap_join(ht);
     DFGPU_CHECK(join_type >= DFGPU_JOIN_INNER && join_type <= DFGPU_JOIN_RIGHT_MARK, "bad join type");
-    const Table& pt = *unwrap(probe);
     std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
+    const Table pt = with_build_dictionaries(*jt, *unwrap(probe), pk);
     std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
     // FilterExec predicate -> row mask (NULL => dropped, filter.rs:1396-1419)
     Datum m = evaluate(*probe_predicate, pt);
@@ -1499,12 +1534,13 @@ int dfgpu_join_probe_with_filter(dfgpu_join_t ht, dfgpu_table_t probe, const int
   return guarded([&] {
     require_init();
     DFGPU_CHECK(ht && out && filter && filter->n_columns >= 0, "null argument");
-    JoinTable* jt = reinterpret_cast<JoinTable*>(ht);
+    JoinTable* jt = unwrap_join(ht);
     DFGPU_CHECK(join_type >= DFGPU_JOIN_INNER && join_type <= DFGPU_JOIN_RIGHT_MARK, "bad join type");
     std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
     std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
-    null_aware_before_probe(*jt, *unwrap(probe), pk, join_type, true);  // LeftAnti: flags only; RightAnti: rejected
-    auto o = std::make_unique<Table>(join_probe_with_filter(*jt, *unwrap(probe), pk, join_type, bo, po, *filter));
+    const Table pt = with_build_dictionaries(*jt, *unwrap(probe), pk);
+    null_aware_before_probe(*jt, pt, pk, join_type, true);  // LeftAnti: flags only; RightAnti: rejected
+    auto o = std::make_unique<Table>(join_probe_with_filter(*jt, pt, pk, join_type, bo, po, *filter));
     *out = wrap(o.release());
   });
 }
@@ -1513,7 +1549,7 @@ int dfgpu_join_emit_unmatched(dfgpu_join_t ht, int join_type, const int* build_o
                               const char* const* probe_names, int n_probe_out, dfgpu_table_t* out) {
   return guarded([&] {
     require_init();
-    JoinTable* jt = reinterpret_cast<JoinTable*>(ht);
+    JoinTable* jt = unwrap_join(ht);
     DFGPU_CHECK(needs_visited(join_type), "join type has no build-side emission");
     Runtime& r = rt();
     const int64_t nb = jt->build.nrows;
@@ -1557,7 +1593,9 @@ int dfgpu_join_get_info(dfgpu_join_t ht, dfgpu_join_info* out) {
   return guarded([&] { *out = reinterpret_cast<JoinTable*>(ht)->info; });
 }
 int dfgpu_join_free(dfgpu_join_t ht) {
-  return guarded([&] { delete reinterpret_cast<JoinTable*>(ht); });
+  return guarded([&] {
+    if (ht) delete unwrap_join(ht);  // buffers go back to the pool of the table's device
+  });
 }
 
 }  // extern "C"

@@ -247,16 +247,21 @@ void walk_runs(const uint8_t* p, const uint8_t* end, int bit_width, int64_t n, F
     uint64_t h = v.varint();
     p = v.p;
     if (h & 1) {
-      const int64_t groups = (int64_t)(h >> 1);
+      // the varint is untrusted: bound the group count by what the page can hold BEFORE multiplying (groups * bit_width
+      // would wrap for groups >= 2^58 and pass the overrun check with bytes the page does not have)
+      const uint64_t ugroups = h >> 1;
+      DFGPU_CHECK(ugroups > 0 && ugroups <= (uint64_t)INT32_MAX && ugroups <= (uint64_t)(end - p) / (uint64_t)std::max(bit_width, 1),
+                  "parquet: bit-packed run overruns its page");
+      const int64_t groups = (int64_t)ugroups;
       const int64_t bytes = groups * bit_width;
-      DFGPU_CHECK(groups > 0 && end - p >= bytes, "parquet: bit-packed run overruns its page");
+      DFGPU_CHECK(end - p >= bytes, "parquet: bit-packed run overruns its page");
       const int64_t cnt = std::min<int64_t>(groups * 8, n - done);   // the last group may be padding
       fn(true, cnt, 0ull, p);
       p += bytes;
       done += cnt;
     } else {
+      DFGPU_CHECK((h >> 1) > 0 && (h >> 1) <= (uint64_t)INT64_MAX && end - p >= vbytes, "parquet: RLE run overruns its page");
       const int64_t cnt = (int64_t)(h >> 1);
-      DFGPU_CHECK(cnt > 0 && end - p >= vbytes, "parquet: RLE run overruns its page");
       uint64_t val = 0;
       for (int i = 0; i < vbytes; i++) val |= (uint64_t)p[i] << (8 * i);
       p += vbytes;

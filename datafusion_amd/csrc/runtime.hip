@@ -9,9 +9,42 @@ namespace dfgpu {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 
+// ------------------------------------------------------------------------------- devices
+// g_runtimes[d] exists for every visible device d once dfgpu_init ran; `initialised` says which ones the caller bound.
+static std::mutex g_devices_mu;
+static std::vector<std::unique_ptr<Runtime>> g_runtimes;
+static std::vector<int> g_initialised;         // in dfgpu_init order; [0] is the default device of new threads
+static Runtime g_uninitialised;                // what rt() answers before dfgpu_init (initialised == false)
+static thread_local int t_device = -1;         // the calling thread's current device (-1: default)
+static thread_local int t_hip_device = -1;     // what this thread last passed to hipSetDevice
+
+const std::vector<int>& initialised_devices() { return g_initialised; }
+int current_device() {
+  if (t_device >= 0) return t_device;
+  return g_initialised.empty() ? -1 : g_initialised[0];
+}
+Runtime& rt_of(int device) {
+  DFGPU_CHECK(device >= 0 && device < (int)g_runtimes.size() && g_runtimes[device] && g_runtimes[device]->initialised,
+              "device " + std::to_string(device) + " has not been initialised (dfgpu_init)");
+  return *g_runtimes[device];
+}
+void use_device(int device) {
+  if (device == t_device && device == t_hip_device) return;
+  (void)rt_of(device);
+  if (t_hip_device != device) {
+    DFGPU_HIP(hipSetDevice(device));
+    t_hip_device = device;
+  }
+  t_device = device;
+}
 Runtime& rt() {
-  static Runtime r;
-  return r;
+  const int d = current_device();
+  if (d < 0) return g_uninitialised;
+  if (t_hip_device != d) {  // HIP's current device is per thread: a fresh host thread would otherwise allocate and launch on device 0
+    if (hipSetDevice(d) == hipSuccess) t_hip_device = d;
+    else (void)hipGetLastError();
+  }
+  return *g_runtimes[d];
 }
 void require_init() { DFGPU_CHECK(rt().initialised, "dfgpu_init() has not been called"); }
 
@@ -85,8 +118,8 @@ void Runtime::trim() {
   for (auto& kv : blocks) (void)hipFree(kv.second);
 }
 
-DevBuf::DevBuf(size_t n) : ptr(rt().alloc(n)), bytes(n) {}
-DevBuf::~DevBuf() { rt().free(ptr); }
+DevBuf::DevBuf(size_t n) : bytes(n), owner(&rt()) { ptr = owner->alloc(n); }
+DevBuf::~DevBuf() { owner->free(ptr); }
 
 BufPtr make_zero_buf(size_t bytes) {
   BufPtr b = make_buf(bytes);
@@ -195,39 +228,74 @@ int dfgpu_device_count(int* out) {
   });
 }
 
-int dfgpu_init(int device) {
+int dfgpu_init(const int* device_ids, int n_devices) {
   return guarded([&] {
-    Runtime& r = rt();
-    if (r.initialised) {
-      DFGPU_CHECK(r.device == device, "dfgpu_init: already bound to device " + std::to_string(r.device));
-      return;
-    }
+    DFGPU_CHECK(device_ids != nullptr && n_devices >= 1, "dfgpu_init: give at least one device id");
+    std::lock_guard<std::mutex> lk(g_devices_mu);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) {
       (void)hipGetLastError();
       throw Error("dfgpu_init: no HIP device visible (this library has no CPU fallback)");
     }
-    DFGPU_CHECK(device >= 0 && device < n, "dfgpu_init: device index out of range");
-    DFGPU_HIP(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    DFGPU_HIP(hipGetDeviceProperties(&prop, device));
-    r.num_cus = prop.multiProcessorCount;
-    DFGPU_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
-    r.device = device;
-    r.initialised = true;
+    if ((int)g_runtimes.size() < n) g_runtimes.resize(n);
+    for (int i = 0; i < n_devices; i++) {
+      const int device = device_ids[i];
+      DFGPU_CHECK(device >= 0 && device < n, "dfgpu_init: device index out of range");
+      if (g_runtimes[device] && g_runtimes[device]->initialised) continue;  // idempotent per device
+      DFGPU_HIP(hipSetDevice(device));
+      t_hip_device = device;
+      auto r = std::make_unique<Runtime>();
+      hipDeviceProp_t prop;
+      DFGPU_HIP(hipGetDeviceProperties(&prop, device));
+      r->num_cus = prop.multiProcessorCount;
+      DFGPU_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+      r->device = device;
+      r->initialised = true;
+      g_runtimes[device] = std::move(r);
+      g_initialised.push_back(device);
+    }
+    // devices of one process reach each other's HBM directly (xGMI): dfgpu_table_copy_to_device, single-process exchanges
+    for (int a : g_initialised)
+      for (int b : g_initialised) {
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+          (void)hipSetDevice(a);
+          hipError_t pe = hipDeviceEnablePeerAccess(b, 0);
+          if (pe != hipSuccess) (void)hipGetLastError();  // already enabled
+        }
+      }
+    if (t_device < 0) t_device = g_initialised[0];
+    DFGPU_HIP(hipSetDevice(t_device));
+    t_hip_device = t_device;
+  });
+}
+
+int dfgpu_set_device(int device) {
+  return guarded([&] { use_device(device); });
+}
+int dfgpu_get_device(int* out) {
+  return guarded([&] {
+    require_init();
+    *out = current_device();
   });
 }
 
 int dfgpu_shutdown(void) {
   return guarded([&] {
-    Runtime& r = rt();
-    if (!r.initialised) return;
-    r.collect();
-    r.trim();
-    (void)hipStreamDestroy(r.stream);
-    r.stream = nullptr;
-    r.initialised = false;
+    std::lock_guard<std::mutex> lk(g_devices_mu);
+    for (int d : g_initialised) {
+      Runtime& r = *g_runtimes[d];
+      (void)hipSetDevice(d);
+      r.collect();
+      r.trim();
+      (void)hipStreamDestroy(r.stream);
+      r.stream = nullptr;
+      r.initialised = false;
+    }
+    g_initialised.clear();
+    t_device = t_hip_device = -1;
   });
 }
 

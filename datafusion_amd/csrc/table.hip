@@ -293,6 +293,46 @@ static ArrowArray* export_dictionary(const DictValues& dv) {
   return a;
 }
 
+Column remap_to_dictionary(const Column& c, const std::shared_ptr<const DictValues>& target) {
+  DFGPU_CHECK(c.dict && target, "remap_to_dictionary: both columns must be dictionary-encoded");
+  if (same_dictionary(c.dict, target)) return c;
+  std::map<std::string, int32_t> index;
+  int32_t null_index = -1;
+  for (size_t k = 0; k < target->values.size(); k++) {
+    if (target->valid[k]) index.emplace(target->values[k], (int32_t)k);
+    else null_index = (int32_t)k;
+  }
+  const int32_t missing = (int32_t)target->values.size();
+  const int w = type_width(c.field.type);
+  DFGPU_CHECK(w > 1 || missing <= 255, "the dictionary index type cannot hold the marker for values missing from the other dictionary");
+  std::vector<int32_t> remap(c.dict->values.size() + 1, missing);
+  for (size_t k = 0; k < c.dict->values.size(); k++) {
+    if (!c.dict->valid[k]) remap[k] = null_index >= 0 ? null_index : missing;
+    else {
+      auto it = index.find(c.dict->values[k]);
+      if (it != index.end()) remap[k] = it->second;
+    }
+  }
+  Column n = alloc_column(c.field, c.name, c.length);
+  n.validity = c.validity;
+  n.null_count = c.null_count;
+  n.dict = target;
+  if (c.length == 0) return n;
+  BufPtr d_remap = make_buf(remap.size() * 4 + 16);
+  DFGPU_HIP(hipMemcpyAsync(d_remap->ptr, remap.data(), remap.size() * 4, hipMemcpyHostToDevice, rt().stream));
+  DFGPU_HIP(hipStreamSynchronize(rt().stream));   // `remap` is a local
+  const int g = grid_for(c.length, BLOCK);
+  const int64_t nd = (int64_t)c.dict->values.size();
+  switch (w) {
+    case 1: k_remap_indices<uint8_t><<<g, BLOCK, 0, rt().stream>>>((const uint8_t*)c.ptr(), d_remap->as<int32_t>(), nd, c.length, (uint8_t*)n.data->ptr); break;
+    case 4: k_remap_indices<uint32_t><<<g, BLOCK, 0, rt().stream>>>((const uint32_t*)c.ptr(), d_remap->as<int32_t>(), nd, c.length, (uint32_t*)n.data->ptr); break;
+    default: k_remap_indices<uint64_t><<<g, BLOCK, 0, rt().stream>>>((const uint64_t*)c.ptr(), d_remap->as<int32_t>(), nd, c.length, (uint64_t*)n.data->ptr); break;
+  }
+  DFGPU_HIP(hipGetLastError());
+  DFGPU_HIP(hipStreamSynchronize(rt().stream));   // d_remap is released on return
+  return n;
+}
+
 }  // namespace dfgpu
 
 using namespace dfgpu;

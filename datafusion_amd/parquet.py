@@ -19,7 +19,7 @@ import pyarrow as pa
 import pyarrow.parquet as pq
 
 from . import _lib
-from ._lib import ParquetChunkInfo, ParquetColumn, check
+from ._lib import DfgpuError, ParquetChunkInfo, ParquetColumn, check
 from .table import DeviceTable, field_of
 
 PHYSICAL = {"BOOLEAN": 0, "INT32": 1, "INT64": 2, "INT96": 3, "FLOAT": 4, "DOUBLE": 5, "BYTE_ARRAY": 6, "FIXED_LEN_BYTE_ARRAY": 7}
@@ -49,6 +49,17 @@ class ParquetFile:
         self._mm.close()
         self._f.close()
 
+    def _leaf(self, column: str) -> int:
+        """Parquet leaf-column index of a flat top-level field, resolved by its path: with a nested (struct / list) column
+        ahead of it the leaf indices shift away from the Arrow field indices.  Nested fields are refused (flat columns only)."""
+        if column not in self.arrow_schema.names:
+            raise KeyError(f"{self.path}: no column {column!r}")
+        schema = self.pf.schema
+        for j in range(len(schema)):
+            if schema.column(j).path == column:
+                return j
+        raise DfgpuError(f"parquet: column {column!r} of {self.path} is not a flat leaf column (nested types are not supported on the GPU scan path)")
+
     @property
     def num_row_groups(self) -> int:
         return self.meta.num_row_groups
@@ -59,7 +70,7 @@ class ParquetFile:
 
     def _chunk(self, row_group: int, column: str):
         """(pointer, byte length, ParquetColumn descriptor, keep-alive) of one column chunk"""
-        j = self.arrow_schema.names.index(column)
+        j = self._leaf(column)
         cc = self.meta.row_group(row_group).column(j)
         sc = self.pf.schema.column(j)
         start = cc.data_page_offset
@@ -76,7 +87,7 @@ class ParquetFile:
         d.max_definition_level = sc.max_definition_level
         d.max_repetition_level = sc.max_repetition_level
         d.num_values = cc.num_values
-        d.field = _target_field(self.arrow_schema.field(j).type)
+        d.field = _target_field(self.arrow_schema.field(column).type)
         d.name = name
         return buf, len(raw), d, (name,)
 
@@ -121,7 +132,7 @@ class ParquetFile:
                 if lo > hi:
                     ok = False
                     break
-                st = rg.column(self.arrow_schema.names.index(name)).statistics
+                st = rg.column(self._leaf(name)).statistics
                 if st is None or not st.has_min_max:
                     continue
                 if st.max < lo or st.min > hi:

@@ -15,9 +15,14 @@
  * Conventions
  *   - every function returns 0 on success, non-zero on failure; the message is in
  *     dfgpu_last_error() (thread-local), mirroring `Result<_, DataFusionError>`.
- *   - one process drives one GPU (dfgpu_init(device)); all work is enqueued on the
- *     library's own HIP stream; calls are synchronous w.r.t. results they return
- *     (row counts), asynchronous otherwise.  dfgpu_sync() drains the stream.
+ *   - devices: dfgpu_init(ids, n) binds the process to one or several GPUs.  One process per GPU is
+ *     the usual deployment (torchrun-style launchers, bench.py); a single DataFusion process that owns several
+ *     GPUs — one per output partition of the plan — initialises them all and selects the calling thread's device
+ *     with dfgpu_set_device (HIP's current device is per thread; the library keeps it in step on every entry).  Every
+ *     handle (table, join table, aggregate) lives on the device that was current when it was created, and an entry
+ *     point that takes a handle switches the calling thread to that handle's device first.
+ *   - all work of a device is enqueued on that device's own library stream; calls are synchronous w.r.t. results
+ *     they return (row counts), asynchronous otherwise.  dfgpu_sync() drains the current device's stream.
  *   - handles are owned by exactly one caller and freed exactly once.  A join table
  *     (dfgpu_join_t) is immutable after build and may be probed by many callers
  *     (CollectLeft: one build shared by all probe partitions, hash_join/exec.rs:1503-1523).
@@ -38,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 6
+#define DFGPU_ABI_VERSION 7
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -123,8 +128,14 @@ typedef enum dfgpu_null_equality { DFGPU_NULL_EQUALS_NOTHING = 0, DFGPU_NULL_EQU
 /* ------------------------------------------------------- lifecycle / errors */
 
 int dfgpu_abi_version(void);
-/* bind this process to `device` and create the library stream + memory pool */
-int dfgpu_init(int device);
+/* bind this process to the listed devices (idempotent per device) and create a library stream + memory pool on
+ * each; the first device of the first call is the default device of every host thread.  Peer access between the
+ * listed devices is enabled where the hardware allows it (xGMI). */
+int dfgpu_init(const int* device_ids, int n_devices);
+/* the calling thread's current device: entry points without a handle argument (generators, dfgpu_table_import,
+ * dfgpu_table_alloc, dfgpu_parquet_decode_chunk, dfgpu_sync, dfgpu_mem_*) act on it */
+int dfgpu_set_device(int device);
+int dfgpu_get_device(int* out);
 int dfgpu_shutdown(void);
 int dfgpu_device_count(int* out);
 /* thread-local message of the last failing call ("" if none) */

@@ -9,6 +9,7 @@ import pytest
 from datafusion_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ABI = int(re.search(r"#define DFGPU_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "dfgpu.h")).read()).group(1))
 
 
 def declared_symbols():
@@ -27,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert _lib.load().dfgpu_abi_version() == 6
+    assert _lib.load().dfgpu_abi_version() == ABI
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -58,7 +59,7 @@ def test_no_cpu_fallback_without_gpu():
     lib = _lib.load()
     n = C.c_int(-1)
     assert lib.dfgpu_device_count(C.byref(n)) == 0 and n.value == 0
-    assert lib.dfgpu_init(0) != 0
+    assert lib.dfgpu_init((C.c_int * 1)(0), 1) != 0
     assert b"no HIP device" in lib.dfgpu_last_error()
     # operators refuse to run before init
     out = C.c_void_p()
@@ -114,7 +115,7 @@ int main(void) {
                            "-L", lib_dir, "-ldfgpu", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
-    assert out.stdout.strip() == "abi 6 ok"
+    assert out.stdout.strip() == f"abi {ABI} ok"
 
 
 def test_case_and_in_list_lowering():

@@ -126,3 +126,53 @@ def test_string_literal_predicates_are_bound_to_dictionary_indices():
     ht = ops.JoinHashTable(build, ["bk"], probe_mode=3)
     j = ht.probe(dt, ["k"], "Inner", ["bk"], ["k", "v"], predicate=col("seg").eq(lit("FURNITURE", pa.string()))).to_arrow()
     assert j.num_rows == plain.filter(pc.equal(plain.column("seg"), "FURNITURE")).num_rows
+
+
+@pytest.mark.parametrize("table_mode", [0, 1])
+@pytest.mark.parametrize("join_type", ["Inner", "RightAnti", "LeftSemi"])
+def test_join_on_string_keys_with_different_dictionaries(join_type, table_mode):
+    """two tables encode the same strings with different dictionaries (every Parquet file / table brings its own): the join
+    must compare strings, not raw indices — the probe side's indices are rewritten into the build side's dictionary"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(7)
+    bvals, pvals = ["pear", "apple", "fig", "kiwi"], ["apple", "banana", "cherry", "fig", "grape", "pear"]
+    nb, np_ = 50, 4000
+    b = pa.table({"k": dict_col(rng.integers(0, len(bvals), nb), bvals), "bi": pa.array(np.arange(nb), pa.int64())})
+    p = pa.table({"k2": dict_col(rng.integers(0, len(pvals), np_), pvals, mask=rng.random(np_) < 0.05), "pi": pa.array(np.arange(np_), pa.int64())})
+    got = ops.hash_join(DeviceTable.from_arrow(b), DeviceTable.from_arrow(p), [("k", "k2")], join_type, table_mode=table_mode).to_arrow()
+    # the oracle joins integer keys: one global code per distinct string stands for the string on both sides
+    code = {v: i for i, v in enumerate(sorted(set(bvals) | set(pvals)))}
+
+    def coded(t, name):
+        return t.set_column(t.schema.get_field_index(name), name, pa.array([None if v is None else code[v] for v in decoded(t).column(name).to_pylist()], pa.int32()))
+    exp = oracle.hash_join(coded(b, "k"), coded(p, "k2"), [("k", "k2")], join_type)
+    ids = [n for n in ("bi", "pi") if n in exp.column_names]
+    assert got.num_rows == exp.num_rows
+    assert_tables_equal(got.select(ids), exp.select(ids), ordered=False)
+    if "k" in got.column_names and "k2" in got.column_names:
+        assert decoded(got).column("k").to_pylist() == decoded(got).column("k2").to_pylist()
+
+
+def test_comparing_columns_of_different_dictionaries_is_refused():
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    t = pa.table({"a": dict_col([0, 1, 0], ["x", "y"]), "b": dict_col([0, 1, 1], ["y", "x"])})
+    with pytest.raises(_lib.DfgpuError, match="different dictionaries"):
+        ops.filter(DeviceTable.from_arrow(t), col("a") == col("b"))
+    same = pa.table({"a": dict_col([0, 1, 0], ["x", "y"]), "b": dict_col([0, 0, 1], ["x", "y"])})
+    assert ops.filter(DeviceTable.from_arrow(same), col("a") == col("b")).num_rows == 1
+
+
+def test_group_keys_with_a_changed_dictionary_are_refused():
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    t1 = pa.table({"k": dict_col([0, 1, 0], ["x", "y"]), "v": pa.array([1, 2, 3], pa.int64())})
+    t2 = pa.table({"k": dict_col([0, 1, 1], ["y", "z"]), "v": pa.array([1, 2, 3], pa.int64())})
+    agg = ops.GroupedAggregate("Single", ["k", "v"], [(col("k"), "k")], [("sum", col("v"), "s")])
+    agg.update(DeviceTable.from_arrow(t1))
+    with pytest.raises(_lib.DfgpuError, match="dictionary changed"):
+        agg.update(DeviceTable.from_arrow(t2))

@@ -289,3 +289,20 @@ def test_random_join_filter_vs_oracle(join_type):
         got = gpu_join(left, right, [("a", "b")], join_type, join_filter=(gpu_expr, cols), table_mode=mode)
         exp = oracle.hash_join(left, right, [("a", "b")], join_type, join_filter=(to_oracle_expr(gpu_expr), cols))
         assert_tables_equal(got, exp)
+
+
+def test_array_map_and_hash_map_known_answers_on_the_device():
+    """the map-level known answers of tests/test_oracle_join_golden.py (array_map.rs:428-599, join_hash_map.rs:518-572) as device joins"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    i32, i64, u64 = pa.int32(), pa.int64(), pa.uint64()
+    cases = [([1, 1, 2], [1, 2], i32, [(0, 0), (0, 1), (1, 2)]), ([1, 2], [10, 1, 2], i32, [(1, 0), (2, 1)]),
+             ([1, 1], [10, 1, 20, 1], i32, [(1, 0), (1, 1), (3, 0), (3, 1)]), (list(range(11)), [3, (1 << 32) + 3, 11, None], u64, [(0, 3)]),
+             ([-5, 0, 5, -2, 3, 10], [0, -5, 10, -1], i64, [(0, 1), (1, 0), (2, 5)]),
+             ([10, 20, 30], [10, None, 30], i64, [(0, 0), (2, 2)]), ([10, 20, 10, 20], [None, 20], i64, [(1, 1), (1, 3)])]
+    for build, probe, typ, want in cases:
+        b = DeviceTable.from_arrow(pa.table({"k": pa.array(build, typ), "bi": pa.array(range(len(build)), pa.int64())}))
+        p = DeviceTable.from_arrow(pa.table({"k2": pa.array(probe, typ), "pi": pa.array(range(len(probe)), pa.int64())}))
+        for table_mode in (0, 1):
+            j = ops.hash_join(b, p, [("k", "k2")], "Inner", table_mode=table_mode).to_arrow()
+            assert sorted(zip(j.column("pi").to_pylist(), j.column("bi").to_pylist())) == sorted(want), (build, probe, table_mode)

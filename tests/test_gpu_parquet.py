@@ -117,3 +117,31 @@ def test_join_bounds_prune_the_probe_side_scan(tmp_path, join_type):
     out3 = P.collect(j3).to_arrow()
     if join_type != "Right":
         assert out3.num_rows == 0 and scan3.metrics["row_groups_read"] == 0
+
+
+def test_parquet_chunk_with_dictionary_fallback_pages(tmp_path):
+    """one column chunk holding dictionary-encoded pages followed by PLAIN pages (the writer's dictionary limit was reached)"""
+    from datafusion_amd.parquet import ParquetFile, read_table
+    n = 50_000
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64) * 7), "v": pa.array((np.arange(n) % 97).astype(np.int32))})
+    path = str(tmp_path / "fallback.parquet")
+    pq.write_table(t, path, dictionary_pagesize_limit=4096, data_page_size=8192, compression="snappy")
+    f = ParquetFile(path)
+    info = f.inspect_chunk(0, "k")
+    f.close()
+    assert info["n_dictionary_encoded_pages"] >= 1 and info["n_plain_pages"] >= 1
+    assert_tables_equal(read_table(path).to_arrow(), t, ordered=True)
+
+
+def test_scan_sharded_by_rank(tmp_path):
+    """ParquetFile.row_groups_for_rank: the shares of a 3-GPU scan decode to exactly the file, in order"""
+    from datafusion_amd.parquet import ParquetFile
+    from datafusion_amd.table import DeviceTable
+    n = 20_000
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64)), "d": pa.array((np.arange(n) % 13).astype(np.int32))})
+    path = str(tmp_path / "s.parquet")
+    pq.write_table(t, path, row_group_size=1500)
+    f = ParquetFile(path)
+    parts = [f.read(row_groups=f.row_groups_for_rank(r, 3)) for r in range(3)]
+    f.close()
+    assert_tables_equal(DeviceTable.concat(parts).to_arrow(), t, ordered=True)

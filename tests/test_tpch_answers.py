@@ -76,10 +76,9 @@ def assert_answer(q, got: pa.Table):
 
 
 QUERIES = ["q1", "q3", "q4", "q5", "q6", "q12", "q18", "q19", "q21"]
-# Q19's JoinFilter compares string columns with literals.  The host side binds them through the dictionaries of the columns behind the
-# intermediate schema (expr.IntermediateSchema, tests/test_abi.py), but that path has not run on a GPU yet (it was written after this
-# round's GPU budget was spent), so Q19 stays on the oracle legs until it has: add it here in the next round
-GPU_QUERIES = [q for q in QUERIES if q != "q19"]
+# Q19's JoinFilter compares string columns with literals: the host side binds them through the dictionaries of the columns behind the
+# intermediate schema (expr.IntermediateSchema, tests/test_abi.py)
+GPU_QUERIES = list(QUERIES)
 RESULT_TYPES = {   # pinned by the answer files' decimal digits and the plan files' expression types
     "q1": {"sum_qty": pa.decimal128(25, 2), "sum_disc_price": pa.decimal128(38, 4), "sum_charge": pa.decimal128(38, 6), "avg_qty": pa.decimal128(19, 6),
            "count_order": pa.int64()},
@@ -144,7 +143,7 @@ def test_string_layouts_agree():
 @pytest.fixture(scope="module")
 def device_tables():
     from datafusion_amd.table import DeviceTable
-    return {k: DeviceTable.from_arrow(v) for k, v in data().items() if k != "part"}    # `part` is only read by Q19 (oracle legs, see GPU_QUERIES)
+    return {k: DeviceTable.from_arrow(v) for k, v in data().items()}
 
 
 @pytest.mark.gpu
