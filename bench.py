@@ -23,10 +23,13 @@ Inputs are generated on device (no dataset download possible) before the timed r
 
 Extra objects on the JSON line:
   roofline     — dominant kernel (join_probe_fused = k_join_probe_fused: lookup + output offsets +
-                 materialisation in one pass; join_probe_materialize when --probe-mode 1):
-                 algorithmic bytes per launch /
-                 average launch duration measured with HIP events on the library stream,
-                 against the 8.0 TB/s HBM3E spec peak.
+                 materialisation in one pass; join_probe_placed = the same kernel placed by pre-computed tile
+                 offsets when --probe-mode 0): algorithmic bytes per launch (probe columns read once
+                 np*40 + build payload read once nb*8 + output written once nout*48) / average launch duration
+                 measured with HIP events on the library stream, against the 8.0 TB/s HBM3E spec peak
+                 (frac) and the measured 6.29 TB/s copy ceiling (frac_vs_copy_ceiling).
+  ordered_output — the same step with the output in probe order (what the reference emits), with its own
+                 roofline object.
   cpu_baseline — the CPU restatement (oracle/, kind "port") of DataFusion's partitioned hash
                  join, timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -41,6 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: measured float4 copy ceiling (79 % of spec)
 
 BUILD_COLS = ["o_orderdate", "o_shippriority"]
 PROBE_COLS = ["l_orderkey", "l_extendedprice", "l_discount"]
@@ -202,14 +206,19 @@ def main():
     ops.profile_enable(False)
     # secondary, outside the contract's timed region: the same step with output in probe order
     # (two passes), for plans where an ancestor does need HashJoinExec's probe-side ordering
-    ordered_ms = None
+    ordered_ms, ordered_stats = None, {}
     if args.probe_mode == 3 and world == 1:
+        step(0)
+        ops.profile_enable(True)
+        ops.profile_reset()
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step(0)
         barrier()
         ordered_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        ordered_stats = ops.profile_stats()
+        ops.profile_enable(False)
 
     tot = torch.tensor([float(nb_local), float(np_local), float(n_out), dt], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -223,25 +232,35 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         rows_per_s = (nb + np_) / (dt / args.steps)
         alg = algorithmic_bytes(nb, np_, nout)
-        dom_name = "join_probe_fused" if "join_probe_fused" in stats else "join_probe_materialize"
-        dom = stats.get(dom_name, {"calls": 0, "total_ms": 0.0, "bytes": 0})
-        roof = None
-        if dom["calls"]:
-            avg_ms = dom["total_ms"] / dom["calls"]
-            per_launch = dom["bytes"] / dom["calls"]
+        def roofline_of(st):
+            """the dominant kernel of a step: algorithmic bytes per launch (probe columns once + build payload
+            once + output once, computed by the library per launch) / its average HIP-event duration on the library stream"""
+            name = next((k for k in ("join_probe_fused", "join_probe_placed", "join_probe_materialize") if k in st), None)
+            if name is None or not st[name]["calls"]:
+                return None
+            d = st[name]
+            avg_ms = d["total_ms"] / d["calls"]
+            per_launch = d["bytes"] / d["calls"]
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
-        if roof:  # HBM bytes per launch from the committed PMC passes (scripts/profile.sh), when taken on this very workload
+            return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_vs_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
+
+        def attach_traffic(roof):
+            """HBM bytes per launch from the committed PMC passes (scripts/profile.sh), when taken on this very workload and kernel"""
             try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                wl = tr["workload"]
-                if tr["kernel"] == dom_name and (wl["build_rows"], wl["probe_rows"], wl["output_rows"]) == (nb, np_, nout) and world == 1:
-                    roof["traffic"] = tr["traffic_bytes_per_launch"]
-                    roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr["source"]
-            except (OSError, KeyError, ValueError):
+                for tr in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]:
+                    wl = tr["workload"]
+                    if tr["kernel"] == roof["kernel"] and (wl["build_rows"], wl["probe_rows"], wl["output_rows"]) == (nb, np_, nout) and world == 1:
+                        roof["traffic"] = tr["traffic_bytes_per_launch"]
+                        roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr["source"]
+            except (OSError, KeyError, ValueError, TypeError):
                 pass
+            return roof
+
+        roof = roofline_of(stats)
+        if roof:
+            attach_traffic(roof)
         kernels = {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in stats.items()}
         line = {
             "metric": "tpch_q3_hash_join_rows_per_sec", "value": rows_per_s, "unit": "rows/s", "n_gpus": world,
@@ -251,7 +270,7 @@ def main():
                                    "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
                        "build_rows": nb, "probe_rows": np_, "output_rows": nout,
                        "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map"}[info.table_kind],
-                       "probe": {0: "two_pass_ordered", 1: "two_pass_ordered", 2: "single_pass_ordered", 3: "single_pass_unordered"}[args.probe_mode],
+                       "probe": {0: "placed_ordered", 1: "placed_ordered", 2: "single_pass_ordered_lookback", 3: "single_pass_unordered"}[args.probe_mode],
                        "parallelism": "single GPU" if world == 1 else
                        (f"CollectLeft x{world}: build side broadcast pruned by each rank's probe-key bounds (RCCL all-to-all(v)), probe side stays in place"
                         if exchange == "pruned" else
@@ -264,8 +283,14 @@ def main():
         if xstats:
             line["exchange_rank0"] = {**xstats, "build_row_bytes": 16}
         if ordered_ms is not None:
-            line["ordered_output_two_pass"] = {"ms_per_step": round(ordered_ms, 3), "rows_per_s": (nb + np_) / (ordered_ms * 1e-3),
-                                               "hbm_frac_whole_step": round(alg / (ordered_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4)}
+            # the same step with the output in probe order, exactly as the reference emits it (hash_join/exec.rs:3349):
+            # tile counts -> scan -> the fused kernel with known tile offsets
+            oroof = roofline_of(ordered_stats)
+            line["ordered_output"] = {"probe": "placed (tile counts -> scan -> fused materialise)", "ms_per_step": round(ordered_ms, 3),
+                                      "rows_per_s": (nb + np_) / (ordered_ms * 1e-3),
+                                      "hbm_frac_whole_step": round(alg / (ordered_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                      "roofline": attach_traffic(oroof) if oroof else None,
+                                      "kernels": {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in ordered_stats.items()}}
         if not args.no_cpu and world == 1:  # the CPU baseline is reported by the single-GPU run only
             threads = os.cpu_count() or 1
             line["cpu_baseline"] = cpu_baseline(args.cpu_sf, threads)

@@ -657,9 +657,43 @@ __device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* __restrict__ ti
   return excl;
 }
 
-template <int KIND, int KT, int W, bool ORDERED>
+// per-tile output row counts of the same tiling: pass 1 of the PLACED flavour.  Reads the probe keys (and the row mask)
+// only; the table words it touches (rank-map bitmap + directory, MALL-resident) are warm for pass 2.
+template <int KIND, int KT, int W>
+__global__ __launch_bounds__(BLOCK) void k_join_tile_counts(ProbeCtx c, int64_t np, int invert, const uint64_t* __restrict__ row_mask,
+                                                            uint32_t* __restrict__ tile_counts) {
+  __shared__ uint32_t s_wcount[BLOCK / WAVE];
+  constexpr int TILE_WORDS = W * (BLOCK / WAVE);
+  const int64_t n_words = (np + 63) >> 6;
+  const unsigned lane = lane_id();
+  const int wv = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t w0 = tile * TILE_WORDS + (int64_t)wv * W;
+  uint32_t m[W];
+  lookup_words<KIND, KT, W>(c, w0, np, m);
+  uint32_t wave_cnt = 0;
+#pragma unroll
+  for (int j = 0; j < W; j++) {
+    const int64_t p = ((w0 + j) << 6) + lane;
+    uint64_t word = ballot64(p < np && ((m[j] != 0) != (invert != 0)));
+    if (row_mask) word &= (w0 + j < n_words) ? row_mask[w0 + j] : 0ull;
+    wave_cnt += (uint32_t)__popcll(word);
+  }
+  if (lane == 0) s_wcount[wv] = wave_cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t agg = 0;
+#pragma unroll
+    for (int i = 0; i < BLOCK / WAVE; i++) agg += s_wcount[i];
+    tile_counts[tile] = agg;
+  }
+}
+
+enum FusedMode : int { FUSED_UNORDERED = 0, FUSED_LOOKBACK = 1, FUSED_PLACED = 2 };
+template <int KIND, int KT, int W, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopyCols cols, int64_t np, int invert, uint64_t* __restrict__ tile_state,
                                                             FusedCtl* __restrict__ ctl, const uint64_t* __restrict__ row_mask) {
+  constexpr bool ORDERED = MODE == FUSED_LOOKBACK;
   __shared__ unsigned s_tile;
   __shared__ uint32_t s_wcount[BLOCK / WAVE];
   __shared__ uint64_t s_prefix;
@@ -706,6 +740,8 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
       if (ORDERED) {
         excl = lookback_exclusive(tile_state, tile, agg);
         if (lane == 0 && tile == n_tiles - 1) ctl->total = excl + agg;
+      } else if (MODE == FUSED_PLACED) {
+        excl = tile_state[tile];  // exclusive prefix of k_join_tile_counts: the output is in probe order, allocation exact
       } else if (lane == 0 && agg) {
         excl = atomicAdd(&ctl->total, (unsigned long long)agg);
       }
@@ -1111,13 +1147,16 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   for (int c : pout) out_row_bytes += type_width(probe.cols[c].field.type);
   const bool fused_ok = np < (1ll << 40) && !payload_nullable && (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS &&
                         bout.size() + pout.size() > 0 && (fast_inner || probe_side_only);
-  // probe_mode: 0 auto = two passes (ordered, exact allocation); 2 / 3 = single pass ordered / unordered (an error when
-  // not applicable); 4 = a planner's hint "no ancestor needs the probe order": single pass unordered when applicable,
-  // the general path otherwise
-  const bool use_fused = fused_ok && np > 0 && (jt.probe_mode == 2 || jt.probe_mode == 3 || jt.probe_mode == 4);
+  // probe_mode: 0 / 1 = output in probe order like the reference (exec.rs:3349), exact allocation: the PLACED flavour (tile
+  // counts -> scan -> the fused kernel with known tile offsets) when it applies, else lookup -> scan -> materialise;
+  // 2 = single pass ordered by decoupled look-back, 3 = single pass unordered (errors when not applicable);
+  // 4 = a planner's hint "no ancestor needs the probe order": single pass unordered when applicable, the general path otherwise
+  const bool want_single = jt.probe_mode == 2 || jt.probe_mode == 3 || jt.probe_mode == 4;
+  const bool use_fused = fused_ok && np > 0;
   DFGPU_CHECK(!((jt.probe_mode == 2 || jt.probe_mode == 3) && !fused_ok),
               "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
-  // A probe-side row mask is applied in place by the at-most-one-match probes (single pass, or lookup -> scan ->
+  const int fused_mode = !want_single ? FUSED_PLACED : jt.probe_mode == 2 ? FUSED_LOOKBACK : FUSED_UNORDERED;
+  // A probe-side row mask is applied in place by the at-most-one-match probes (fused, or lookup -> scan ->
   // materialise); the general pairs path needs the caller to filter first.
   const bool one_match_path = np > 0 && (probe_side_only || fast_inner);
   const bool use_fused_now = use_fused;
@@ -1127,33 +1166,52 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     if (!*mask_consumed) return Table{};
     ctx.row_mask = row_mask;
   }
-  if (use_fused_now) {
+  if (use_fused_now && fused_mode != FUSED_PLACED) {
+    // single-pass flavours: output columns are allocated for the upper bound (np rows) because the row count is only
+    // known when the kernel ends; HBM is sized for that (288 GB)
     size_t free_b = 0, total_b = 0;
     DFGPU_HIP(hipMemGetInfo(&free_b, &total_b));
     DFGPU_CHECK(np * out_row_bytes <= (int64_t)free_b + r.cached, "single-pass probe: the np-row upper bound of the output does not fit in HBM");
   }
 
   if (use_fused_now) {
-    const bool ordered = jt.probe_mode == 2;
     const int64_t tile_words = (int64_t)FUSED_W * (BLOCK / WAVE);
     const int64_t n_tiles = (n_words + tile_words - 1) / tile_words;
-    BufPtr state = ordered ? make_zero_buf((size_t)n_tiles * 8) : nullptr;
+    const int invert = join_type == DFGPU_JOIN_RIGHT_ANTI;
+    ctx.row_mask = row_mask;
+    BufPtr state = fused_mode == FUSED_LOOKBACK ? make_zero_buf((size_t)n_tiles * 8) : nullptr;
     BufPtr ctl = make_zero_buf(sizeof(FusedCtl));
+    int64_t n_alloc = np;
+    if (fused_mode == FUSED_PLACED) {
+      // pass 1: output rows per tile (reads the probe keys only), then the tiles' exclusive prefix
+      BufPtr counts = make_buf((size_t)n_tiles * 4);
+      state = make_buf((size_t)(n_tiles + 1) * 8);
+      {
+        ProfileScope ps("join_probe_tile_counts", key_bytes);
+        with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
+          k_join_tile_counts<decltype(kd)::value, decltype(kt)::value, FUSED_W><<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(ctx, np, invert, row_mask, counts->as<uint32_t>());
+        });
+        DFGPU_HIP(hipGetLastError());
+      }
+      scan_u32(counts->as<uint32_t>(), n_tiles, state->as<uint64_t>());
+      n_alloc = (int64_t)read_u64(state->as<uint64_t>() + n_tiles);
+    }
     JoinCopyCols jc{};
-    int64_t bytes_in = key_bytes, bytes_per_out = 0;
+    int64_t bytes_in = key_bytes, bytes_per_out = 0, bytes_build_once = 0;
     for (int c : bout) {
       const Column& sc = jt.build.cols[c];
-      out.cols.push_back(alloc_like(sc, np));
+      out.cols.push_back(alloc_like(sc, n_alloc));
       jc.src[jc.n] = sc.ptr();
       jc.dst[jc.n] = out.cols.back().data->ptr;
       jc.width[jc.n] = type_width(sc.field.type);
-      bytes_per_out += 2 * jc.width[jc.n];
+      bytes_per_out += jc.width[jc.n];
+      bytes_build_once += jt.build.nrows * jc.width[jc.n];
       jc.n++;
     }
     jc.n_build = jc.n;
     for (int c : pout) {
       const Column& sc = probe.cols[c];
-      out.cols.push_back(alloc_like(sc, np));
+      out.cols.push_back(alloc_like(sc, n_alloc));
       jc.src[jc.n] = sc.ptr();
       jc.dst[jc.n] = out.cols.back().data->ptr;
       jc.width[jc.n] = type_width(sc.field.type);
@@ -1169,23 +1227,32 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       DFGPU_HIP(hipEventCreate(&eb));
       DFGPU_HIP(hipEventRecord(ea, r.stream));
     }
-    const int invert = join_type == DFGPU_JOIN_RIGHT_ANTI;
-    // ordered: persistent workgroups pulling tickets; unordered: one workgroup per tile
-    const unsigned g = ordered ? (unsigned)std::min<int64_t>(n_tiles, (int64_t)r.num_cus * 8) : (unsigned)n_tiles;
-    uint64_t* st = state ? state->as<uint64_t>() : nullptr;
-    ctx.row_mask = row_mask;
-    auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>(), row_mask); };
-    with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
-      constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
-      if (ordered) launch(k_join_probe_fused<K, T, FUSED_W, true>);
-      else launch(k_join_probe_fused<K, T, FUSED_W, false>);
-    });
-    DFGPU_HIP(hipGetLastError());
-    if (r.profiling) DFGPU_HIP(hipEventRecord(eb, r.stream));
-    const int64_t n_out = (int64_t)read_u64(reinterpret_cast<const uint64_t*>(&ctl->as<FusedCtl>()->total));
-    // algorithmic bytes (SURVEY 8d config 3 ii): every referenced probe column once, build payload per
-    // output row, output written once; known only now that n_out is
-    if (r.profiling) r.recs.push_back(Runtime::Rec{"join_probe_fused", ea, eb, bytes_in + n_out * bytes_per_out});
+    int64_t n_out = n_alloc;
+    if (fused_mode != FUSED_PLACED || n_alloc > 0) {
+      // look-back: persistent workgroups pulling tickets; unordered / placed: one workgroup per tile
+      const unsigned g = fused_mode == FUSED_LOOKBACK ? (unsigned)std::min<int64_t>(n_tiles, (int64_t)r.num_cus * 8) : (unsigned)n_tiles;
+      uint64_t* st = state ? state->as<uint64_t>() : nullptr;
+      auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>(), row_mask); };
+      with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
+        constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
+        if (fused_mode == FUSED_LOOKBACK) launch(k_join_probe_fused<K, T, FUSED_W, FUSED_LOOKBACK>);
+        else if (fused_mode == FUSED_PLACED) launch(k_join_probe_fused<K, T, FUSED_W, FUSED_PLACED>);
+        else launch(k_join_probe_fused<K, T, FUSED_W, FUSED_UNORDERED>);
+      });
+      DFGPU_HIP(hipGetLastError());
+      if (r.profiling) DFGPU_HIP(hipEventRecord(eb, r.stream));
+      if (fused_mode != FUSED_PLACED) n_out = (int64_t)read_u64(reinterpret_cast<const uint64_t*>(&ctl->as<FusedCtl>()->total));
+    } else if (r.profiling) {
+      DFGPU_HIP(hipEventRecord(eb, r.stream));
+    }
+    // algorithmic bytes of this launch (SURVEY 8d config 3 ii): every referenced probe column once, the build payload
+    // columns once, the output written once (re-reads of build rows matched by several probe rows, table words, tile
+    // state are overhead); known only now that n_out is
+    if (r.profiling) {
+      std::lock_guard<std::mutex> lk(r.mu);
+      r.recs.push_back(Runtime::Rec{fused_mode == FUSED_PLACED ? "join_probe_placed" : "join_probe_fused", ea, eb,
+                                    bytes_in + (n_out > 0 ? bytes_build_once : 0) + n_out * bytes_per_out});
+    }
     out.nrows = n_out;
     for (Column& c : out.cols) c.length = n_out;
   } else if (np > 0 && (probe_side_only || (build_side_only && jt.keys_unique) || fast_inner)) {

@@ -70,14 +70,22 @@ def main():
             fmt = lambda x, d=1: "" if x is None else f"{x:.{d}f}"
             f.write(f"| {r['kernel']} | {r['calls']} | {r['avg_us']:.1f} | {r['pct']:.1f} | {fmt(r['FETCH_SIZE_KB'],0)} | {fmt(r['WRITE_SIZE_KB'],0)} | "
                     f"{fmt(r['traffic_bytes']/1e9 if r['traffic_bytes'] else None,2)} | {fmt(r['traffic_GBps'],0)} |\n")
-    dom = next((r for r in rows if r["kernel"].startswith("k_join_probe_fused")), None)
-    if dom and dom["traffic_bytes"] and bench:
-        tj = os.path.join(os.path.dirname(dst) or ".", "traffic.json")
-        json.dump({"kernel": "join_probe_fused", "device_kernel": dom["kernel"], "traffic_bytes_per_launch": int(dom["traffic_bytes"]),
-                   "read_bytes_corrected": int(dom["read_bytes_corrected"] or 0), "write_bytes": int(dom["write_bytes"] or 0),
-                   "fetch_size_calibration": calib, "avg_launch_us_rocprof": dom["avg_us"], "source": os.path.basename(dst) + ".json",
-                   "workload": {k: bench["config"][k] for k in ("build_rows", "probe_rows", "output_rows", "join_table", "probe")}},
-                  open(tj, "w"), indent=1)
+    # per-launch PMC traffic of the dominant kernel, one entry per flavour (last template argument: 0 = unordered single
+    # pass -> "join_probe_fused", 2 = placed by tile offsets, probe order -> "join_probe_placed")
+    entries = []
+    for r in rows:
+        if not r["kernel"].startswith("k_join_probe_fused") or not r["traffic_bytes"] or not bench:
+            continue
+        mode = r["kernel"].rstrip(">").split(",")[-1].strip()
+        name = {"0": "join_probe_fused", "2": "join_probe_placed"}.get(mode.replace("(dfgpu::FusedMode)", ""))
+        if name is None:
+            continue
+        wl = {k: bench["config"][k] for k in ("build_rows", "probe_rows", "output_rows", "join_table")}
+        entries.append({"kernel": name, "device_kernel": r["kernel"], "traffic_bytes_per_launch": int(r["traffic_bytes"]),
+                        "read_bytes_corrected": int(r["read_bytes_corrected"] or 0), "write_bytes": int(r["write_bytes"] or 0),
+                        "fetch_size_calibration": calib, "avg_launch_us_rocprof": r["avg_us"], "source": os.path.basename(dst) + ".json", "workload": wl})
+    if entries:
+        json.dump({"kernels": entries}, open(os.path.join(os.path.dirname(dst) or ".", "traffic.json"), "w"), indent=1)
     print(open(dst + ".md").read())
 
 

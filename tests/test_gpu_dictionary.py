@@ -161,9 +161,9 @@ def test_comparing_columns_of_different_dictionaries_is_refused():
     from datafusion_amd.table import DeviceTable
     t = pa.table({"a": dict_col([0, 1, 0], ["x", "y"]), "b": dict_col([0, 1, 1], ["y", "x"])})
     with pytest.raises(_lib.DfgpuError, match="different dictionaries"):
-        ops.filter(DeviceTable.from_arrow(t), col("a") == col("b"))
+        ops.filter(DeviceTable.from_arrow(t), col("a").eq(col("b")))
     same = pa.table({"a": dict_col([0, 1, 0], ["x", "y"]), "b": dict_col([0, 0, 1], ["x", "y"])})
-    assert ops.filter(DeviceTable.from_arrow(same), col("a") == col("b")).num_rows == 1
+    assert ops.filter(DeviceTable.from_arrow(same), col("a").eq(col("b"))).num_rows == 1
 
 
 def test_group_keys_with_a_changed_dictionary_are_refused():
