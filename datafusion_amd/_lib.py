@@ -61,6 +61,20 @@ class KernelStat(C.Structure):
                 ("algorithmic_bytes", C.c_int64)]
 
 
+class ExchangeStats(C.Structure):
+    _fields_ = [("bytes_sent_to_peers", C.c_int64), ("bytes_received_from_peers", C.c_int64), ("rows_sent_to_peers", C.c_int64),
+                ("rows_received_from_peers", C.c_int64), ("messages", C.c_int64), ("collectives", C.c_int64)]
+
+
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class HostTransport(C.Structure):
+    """dfgpu_host_transport"""
+    _fields_ = [("ctx", C.c_void_p), ("alltoallv", ALLTOALLV_FN), ("allgather", ALLGATHER_FN)]
+
+
 class ParquetColumn(C.Structure):
     _fields_ = [("physical_type", C.c_int32), ("type_length", C.c_int32), ("codec", C.c_int32), ("max_definition_level", C.c_int32),
                 ("max_repetition_level", C.c_int32), ("_pad", C.c_int32), ("num_values", C.c_int64), ("field", Field), ("name", C.c_char_p)]
@@ -84,6 +98,8 @@ SYMBOLS = [
     "dfgpu_agg_free", "dfgpu_sort", "dfgpu_partition", "dfgpu_hash_columns", "dfgpu_tpch_orders",
     "dfgpu_tpch_lineitem", "dfgpu_tpch_customer", "dfgpu_profile_enable", "dfgpu_profile_reset",
     "dfgpu_profile_count", "dfgpu_profile_get", "dfgpu_parquet_decode_chunk", "dfgpu_parquet_inspect_chunk",
+    "dfgpu_comm_unique_id", "dfgpu_comm_init_rank", "dfgpu_comm_init_all", "dfgpu_comm_init_host", "dfgpu_comm_free", "dfgpu_comm_info",
+    "dfgpu_exchange_hash", "dfgpu_exchange_broadcast", "dfgpu_exchange_broadcast_pruned", "dfgpu_comm_stats",
 ]
 
 _lib = None

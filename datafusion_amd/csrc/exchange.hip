@@ -1,0 +1,743 @@
+// exchange.hip — the multi-GPU exchange below the C ABI: RepartitionExec(Partitioning::Hash) across GPUs
+// (physical-plan/src/repartition/mod.rs:1097-1150: hash(keys; seed 0) % n routes a row), the build-side collection of
+// PartitionMode::CollectLeft (hash_join/exec.rs:1325-1328) as an all-gather, and that all-gather pruned by the
+// destinations' probe-key bounds (hash_join/shared_bounds.rs:277-284 turned around).  In the reference these are
+// in-process tokio channels between partition tasks; here a partition is a GPU and the channel is RCCL over xGMI.
+//
+// Transport: RCCL point-to-point — one ncclGroup of ncclSend / ncclRecv per column, every peer pair at once.  xGMI is a
+// full mesh of point-to-point links (7 x ~153 GB/s per GPU), so an all-to-all(v) made of direct sends puts exactly one
+// peer's slice on each link and needs no ring; the all-gather of a build side is the same pattern with every peer
+// receiving the same slice.  librccl is opened with dlopen when the first communicator is created: the library loads on
+// hosts without RCCL, and a process that already carries a copy (torch's) shares it by soname.
+// Two deployments (include/dfgpu.h): one process per GPU (ncclCommInitRank, the bootstrap id travels through the host
+// engine) or one process driving several GPUs (ncclCommInitAll over the devices given to dfgpu_init; every call then
+// takes one table per local rank).  A third transport moves the same slices through host memory with collectives the
+// embedding engine supplies (dfgpu_comm_init_host): inter-node engines, and tests where two ranks share one GPU.
+//
+// What crosses: value buffers as raw bytes per (column, peer); validity bitmaps as whole 64-bit words per (column,
+// peer), re-based to the receiver's row offsets with a bit-granular placement kernel; dictionaries of dictionary-encoded
+// string columns are compared by digest first and merged (ascending, identical on every rank) only when they differ,
+// after which every rank rewrites its indices — so hash routing and later joins / group-bys on the indices mean the
+// strings on every GPU.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "device.hpp"
+#include "internal.hpp"
+
+namespace dfgpu {
+
+// ------------------------------------------------------------------------------------------------ RCCL by dlopen
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+enum { NCCL_SUCCESS = 0, NCCL_INT8 = 0, NCCL_INT64 = 4 };  // ncclDataType_t values of rccl.h (ncclInt8 = 0, ncclInt64 = 4)
+
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi& rccl() {
+  static RcclApi api;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (api.handle) return api;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (api.handle) break;
+  }
+  DFGPU_CHECK(api.handle != nullptr, std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found") +
+                                         " (multi-GPU exchanges have no fallback transport unless the host supplies one: dfgpu_comm_init_host)");
+  auto sym = [&](const char* s) {
+    void* p = dlsym(api.handle, s);
+    DFGPU_CHECK(p != nullptr, std::string("librccl lacks ") + s);
+    return p;
+  };
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+  api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+  api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+  api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+  api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  return api;
+}
+#define DFGPU_NCCL(expr)                                                                                         \
+  do {                                                                                                           \
+    int _r = (expr);                                                                                             \
+    if (_r != NCCL_SUCCESS) throw ::dfgpu::Error(std::string("RCCL error ") + rccl().GetErrorString(_r) + " at " #expr); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------ communicator
+struct Comm {
+  int world = 1;
+  int first_rank = 0;            // global rank of local rank 0
+  std::vector<int> devices;      // one per local rank
+  std::vector<ncclComm_t> nccl;  // RCCL transport: one communicator per local rank
+  bool host = false;             // host transport
+  dfgpu_host_transport ht{};
+  std::mutex mu;
+  dfgpu_exchange_stats stats{};
+  int n_local() const { return (int)devices.size(); }
+};
+// a send / receive is cut into messages of at most this many bytes (every rank derives the same cuts from the row counts)
+static int64_t max_message_bytes() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("DFGPU_EXCHANGE_MAX_MESSAGE_BYTES");
+    const long long x = e ? std::atoll(e) : 0;
+    return x > 0 ? (int64_t)x : (int64_t)1 << 30;
+  }();
+  return v;
+}
+
+// one local rank's share of an all-to-all(v): slice `send[p]` goes to global rank p, `recv[p]` receives from it
+struct Xfer {
+  std::vector<const void*> send;
+  std::vector<int64_t> send_bytes;
+  std::vector<void*> recv;
+  std::vector<int64_t> recv_bytes;
+  explicit Xfer(int world) : send(world, nullptr), send_bytes(world, 0), recv(world, nullptr), recv_bytes(world, 0) {}
+};
+
+// device buffers of every local rank exchange their slices; enqueued on each device's library stream (stream-ordered
+// after the kernels that produced the slices, before the kernels that read what arrives)
+static void alltoallv_one(Comm& c, std::vector<Xfer>& x, bool own_group);
+// several all-to-all(v)s (the columns of a table) as ONE ncclGroup: every slice of every column is in flight at once
+static void alltoallv(Comm& c, std::vector<std::vector<Xfer>>& xs) {
+  if (xs.empty()) return;
+  const bool grouped = c.world > 1 && !c.host;
+  if (grouped) DFGPU_NCCL(rccl().GroupStart());
+  for (auto& x : xs) alltoallv_one(c, x, !grouped);
+  if (grouped) DFGPU_NCCL(rccl().GroupEnd());
+  std::lock_guard<std::mutex> lk(c.mu);
+  c.stats.collectives += 1;
+}
+static void alltoallv_one(Comm& c, std::vector<Xfer>& x, bool own_group) {
+  const int L = c.n_local();
+  DFGPU_CHECK((int)x.size() == L, "internal: one transfer set per local rank");
+  int64_t sent = 0, received = 0, messages = 0;
+  // slices that stay on their GPU (or move between two GPUs of this process over the host transport) are plain copies
+  for (int l = 0; l < L; l++) {
+    const int me = c.first_rank + l;
+    if (x[l].send_bytes[me] > 0) {
+      DFGPU_CHECK(x[l].send_bytes[me] == x[l].recv_bytes[me], "internal: self slice sizes differ");
+      use_device(c.devices[l]);
+      if (x[l].send[me] != x[l].recv[me])
+        DFGPU_HIP(hipMemcpyAsync(x[l].recv[me], x[l].send[me], (size_t)x[l].send_bytes[me], hipMemcpyDeviceToDevice, rt().stream));
+    }
+    for (int p = 0; p < c.world; p++)
+      if (p != me) {
+        sent += x[l].send_bytes[p];
+        received += x[l].recv_bytes[p];
+      }
+  }
+  if (c.world > 1) {
+    if (!c.host) {
+      RcclApi& R = rccl();
+      const int64_t cut = max_message_bytes();
+      if (own_group) DFGPU_NCCL(R.GroupStart());
+      for (int l = 0; l < L; l++) {
+        const int me = c.first_rank + l;
+        hipStream_t st = rt_of(c.devices[l]).stream;
+        for (int p = 0; p < c.world; p++) {
+          if (p == me) continue;
+          for (int64_t o = 0; o < x[l].send_bytes[p]; o += cut) {
+            DFGPU_NCCL(R.Send((const char*)x[l].send[p] + o, (size_t)std::min(cut, x[l].send_bytes[p] - o), NCCL_INT8, p, c.nccl[l], st));
+            messages++;
+          }
+          for (int64_t o = 0; o < x[l].recv_bytes[p]; o += cut)
+            DFGPU_NCCL(R.Recv((char*)x[l].recv[p] + o, (size_t)std::min(cut, x[l].recv_bytes[p] - o), NCCL_INT8, p, c.nccl[l], st));
+        }
+      }
+      if (own_group) DFGPU_NCCL(R.GroupEnd());
+    } else {
+      DFGPU_CHECK(L == 1, "the host transport carries one rank per process");
+      use_device(c.devices[0]);
+      Runtime& r = rt();
+      const int me = c.first_rank;
+      int64_t st = 0, rt_ = 0;
+      for (int p = 0; p < c.world; p++)
+        if (p != me) {
+          st += x[0].send_bytes[p];
+          rt_ += x[0].recv_bytes[p];
+        }
+      char *hs = nullptr, *hr = nullptr;
+      DFGPU_HIP(hipHostMalloc((void**)&hs, (size_t)std::max<int64_t>(st, 1), hipHostMallocDefault));
+      DFGPU_HIP(hipHostMalloc((void**)&hr, (size_t)std::max<int64_t>(rt_, 1), hipHostMallocDefault));
+      std::vector<const void*> sp(c.world, nullptr);
+      std::vector<void*> rp(c.world, nullptr);
+      std::vector<int64_t> sb(x[0].send_bytes), rb(x[0].recv_bytes);
+      sb[me] = rb[me] = 0;
+      int64_t so = 0, ro = 0;
+      for (int p = 0; p < c.world; p++) {
+        if (p == me) continue;
+        sp[p] = hs + so;
+        rp[p] = hr + ro;
+        if (sb[p]) DFGPU_HIP(hipMemcpyAsync(hs + so, x[0].send[p], (size_t)sb[p], hipMemcpyDeviceToHost, r.stream));
+        so += sb[p];
+        ro += rb[p];
+        messages += sb[p] > 0;
+      }
+      DFGPU_HIP(hipStreamSynchronize(r.stream));
+      const int rc = c.ht.alltoallv(c.ht.ctx, sp.data(), sb.data(), rp.data(), rb.data());
+      if (rc == 0)
+        for (int p = 0; p < c.world; p++)
+          if (p != me && rb[p]) DFGPU_HIP(hipMemcpyAsync(x[0].recv[p], rp[p], (size_t)rb[p], hipMemcpyHostToDevice, r.stream));
+      (void)hipStreamSynchronize(r.stream);
+      (void)hipHostFree(hs);
+      (void)hipHostFree(hr);
+      DFGPU_CHECK(rc == 0, "host transport: alltoallv failed");
+    }
+  }
+  std::lock_guard<std::mutex> lk(c.mu);
+  c.stats.bytes_sent_to_peers += sent;
+  c.stats.bytes_received_from_peers += received;
+  c.stats.messages += messages;
+}
+
+// small host-side metadata: every local rank contributes `bytes` bytes, everyone learns all `world` contributions (rank order)
+static std::vector<uint8_t> allgather_meta(Comm& c, const std::vector<std::vector<uint8_t>>& mine, int64_t bytes) {
+  const int L = c.n_local();
+  std::vector<uint8_t> all((size_t)c.world * bytes);
+  if (L == c.world) {  // every rank lives in this process
+    for (int l = 0; l < L; l++) std::memcpy(all.data() + (size_t)(c.first_rank + l) * bytes, mine[l].data(), (size_t)bytes);
+    return all;
+  }
+  if (c.host) {
+    DFGPU_CHECK(c.ht.allgather(c.ht.ctx, mine[0].data(), bytes, all.data()) == 0, "host transport: allgather failed");
+    return all;
+  }
+  RcclApi& R = rccl();
+  std::vector<BufPtr> in(L), out(L);
+  for (int l = 0; l < L; l++) {
+    use_device(c.devices[l]);
+    in[l] = make_buf((size_t)bytes + 16);
+    out[l] = make_buf((size_t)c.world * bytes + 16);
+    DFGPU_HIP(hipMemcpyAsync(in[l]->ptr, mine[l].data(), (size_t)bytes, hipMemcpyHostToDevice, rt().stream));
+  }
+  DFGPU_NCCL(R.GroupStart());
+  for (int l = 0; l < L; l++) DFGPU_NCCL(R.AllGather(in[l]->ptr, out[l]->ptr, (size_t)bytes, NCCL_INT8, c.nccl[l], rt_of(c.devices[l]).stream));
+  DFGPU_NCCL(R.GroupEnd());
+  use_device(c.devices[0]);
+  d2h(all.data(), out[0]->ptr, all.size());
+  for (int l = 1; l < L; l++) {
+    use_device(c.devices[l]);
+    DFGPU_HIP(hipStreamSynchronize(rt().stream));
+  }
+  return all;
+}
+// variable-size contributions: sizes first, then the payloads padded to the largest
+static std::vector<std::vector<uint8_t>> allgather_blobs(Comm& c, const std::vector<std::vector<uint8_t>>& mine) {
+  const int L = c.n_local();
+  std::vector<std::vector<uint8_t>> sz(L, std::vector<uint8_t>(8));
+  for (int l = 0; l < L; l++) {
+    const int64_t n = (int64_t)mine[l].size();
+    std::memcpy(sz[l].data(), &n, 8);
+  }
+  const std::vector<uint8_t> all_sz = allgather_meta(c, sz, 8);
+  int64_t mx = 1;
+  std::vector<int64_t> sizes(c.world);
+  for (int r = 0; r < c.world; r++) {
+    std::memcpy(&sizes[r], all_sz.data() + (size_t)r * 8, 8);
+    mx = std::max(mx, sizes[r]);
+  }
+  std::vector<std::vector<uint8_t>> padded(L);
+  for (int l = 0; l < L; l++) {
+    padded[l] = mine[l];
+    padded[l].resize((size_t)mx, 0);
+  }
+  const std::vector<uint8_t> all = allgather_meta(c, padded, mx);
+  std::vector<std::vector<uint8_t>> out(c.world);
+  for (int r = 0; r < c.world; r++) out[r].assign(all.begin() + (size_t)r * mx, all.begin() + (size_t)r * mx + (size_t)sizes[r]);
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------ dictionaries
+static uint64_t fnv1a(const uint8_t* p, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
+  for (size_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+  return h;
+}
+static void put_u32(std::vector<uint8_t>& b, uint32_t v) { b.insert(b.end(), (uint8_t*)&v, (uint8_t*)&v + 4); }
+static std::vector<uint8_t> serialize_dict(const DictValues& d) {
+  std::vector<uint8_t> b;
+  put_u32(b, (uint32_t)d.index_format.size());
+  b.insert(b.end(), d.index_format.begin(), d.index_format.end());
+  put_u32(b, (uint32_t)d.value_format.size());
+  b.insert(b.end(), d.value_format.begin(), d.value_format.end());
+  put_u32(b, (uint32_t)d.values.size());
+  for (size_t i = 0; i < d.values.size(); i++) {
+    b.push_back(d.valid[i]);
+    put_u32(b, (uint32_t)d.values[i].size());
+    b.insert(b.end(), d.values[i].begin(), d.values[i].end());
+  }
+  return b;
+}
+static DictValues deserialize_dict(const std::vector<uint8_t>& b) {
+  DictValues d;
+  size_t o = 0;
+  auto u32 = [&] {
+    DFGPU_CHECK(o + 4 <= b.size(), "exchange: truncated dictionary");
+    uint32_t v;
+    std::memcpy(&v, b.data() + o, 4);
+    o += 4;
+    return v;
+  };
+  auto str = [&](uint32_t n) {
+    DFGPU_CHECK(o + n <= b.size(), "exchange: truncated dictionary");
+    std::string s((const char*)b.data() + o, n);
+    o += n;
+    return s;
+  };
+  d.index_format = str(u32());
+  d.value_format = str(u32());
+  const uint32_t n = u32();
+  for (uint32_t i = 0; i < n; i++) {
+    DFGPU_CHECK(o + 1 <= b.size(), "exchange: truncated dictionary");
+    d.valid.push_back(b[o++]);
+    d.values.push_back(str(u32()));
+  }
+  return d;
+}
+
+// After this every rank's column `ci` (of every local table) is encoded with one dictionary: untouched when all ranks
+// already agree (digest), else the ascending merge of all ranks' values (NULL value first), identical everywhere.
+static void unify_dictionaries(Comm& c, std::vector<Table>& t) {
+  const int L = c.n_local();
+  const size_t ncols = t[0].cols.size();
+  bool any_dict = false;
+  for (int l = 0; l < L; l++)
+    for (const Column& col : t[l].cols) any_dict |= col.dict != nullptr;
+  if (!any_dict) return;  // the schema is the same on every rank (the planner's): no rank holds an encoded column
+  // round 1: per column {encoded?, digest}
+  std::vector<std::vector<uint8_t>> meta(L, std::vector<uint8_t>(ncols * 9, 0));
+  std::vector<std::vector<std::vector<uint8_t>>> ser(L, std::vector<std::vector<uint8_t>>(ncols));
+  for (int l = 0; l < L; l++)
+    for (size_t ci = 0; ci < ncols; ci++) {
+      if (!t[l].cols[ci].dict) continue;
+      ser[l][ci] = serialize_dict(*t[l].cols[ci].dict);
+      const uint64_t h = fnv1a(ser[l][ci].data(), ser[l][ci].size());
+      meta[l][ci * 9] = 1;
+      std::memcpy(&meta[l][ci * 9 + 1], &h, 8);
+    }
+  const std::vector<uint8_t> all = allgather_meta(c, meta, (int64_t)ncols * 9);
+  for (size_t ci = 0; ci < ncols; ci++) {
+    bool any = false, every = true, same = true;
+    uint64_t h0 = 0;
+    for (int r = 0; r < c.world; r++) {
+      const uint8_t* m = all.data() + ((size_t)r * ncols + ci) * 9;
+      any |= m[0] != 0;
+      every &= m[0] != 0;
+      uint64_t h;
+      std::memcpy(&h, m + 1, 8);
+      if (r == 0) h0 = h;
+      same &= h == h0;
+    }
+    if (!any) continue;
+    DFGPU_CHECK(every, "exchange: column " + t[0].cols[ci].name + " is dictionary-encoded on some ranks only");
+    if (same) continue;
+    // round 2: everyone's dictionary -> the merged one
+    std::vector<std::vector<uint8_t>> mine(L);
+    for (int l = 0; l < L; l++) mine[l] = ser[l][ci];
+    const auto blobs = allgather_blobs(c, mine);
+    std::map<std::string, int> keys;  // ascending; the NULL value's marker sorts first
+    bool has_null = false;
+    DictValues first = deserialize_dict(blobs[0]);
+    for (int r = 0; r < c.world; r++) {
+      const DictValues d = r == 0 ? first : deserialize_dict(blobs[r]);
+      for (size_t k = 0; k < d.values.size(); k++) {
+        if (d.valid[k]) keys.emplace(d.values[k], 0);
+        else has_null = true;
+      }
+    }
+    auto merged = std::make_shared<DictValues>();
+    merged->index_format = first.index_format;
+    merged->value_format = first.value_format;
+    if (has_null) {
+      merged->values.push_back(std::string());
+      merged->valid.push_back(0);
+    }
+    for (auto& kv : keys) {
+      merged->values.push_back(kv.first);
+      merged->valid.push_back(1);
+    }
+    merged->sorted = !has_null;
+    for (int l = 0; l < L; l++) {
+      use_device(c.devices[l]);
+      t[l].cols[ci] = remap_to_dictionary(t[l].cols[ci], merged);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ the exchange proper
+__global__ __launch_bounds__(BLOCK) void k_fill_words(uint64_t* __restrict__ p, int64_t nw, uint64_t v) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < nw; i += (int64_t)gridDim.x * BLOCK) p[i] = v;
+}
+// rows whose key lies in [lo, hi] (NULL keys never): the slice of a build side one destination can match
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_range_mask(const T* __restrict__ key, const uint64_t* __restrict__ valid, int64_t n, long long lo, long long hi,
+                                                      uint64_t* __restrict__ mask) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const int64_t i = (w << 6) + lane_id();
+    bool in = false;
+    if (i < n) {
+      const long long v = (long long)key[i];
+      in = v >= lo && v <= hi;
+    }
+    uint64_t word = ballot64(in);
+    if (valid) word &= valid[w];
+    if (lane_id() == 0) mask[w] = word;
+  }
+}
+
+// parts[l][p] = the rows local rank l sends to global rank p (every part of one local rank has the schema of proto[l]);
+// returns, per local rank, the rows it receives from all ranks in rank order.
+static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<Table>>& parts, const std::vector<Table>& proto) {
+  const int L = c.n_local(), W = c.world;
+  const size_t ncols = proto[0].cols.size();
+  // what every rank must know: rows[src][dst], and per column whether any rank carries a validity bitmap + the type (a schema check)
+  const int64_t meta_bytes = (int64_t)W * 8 + (int64_t)ncols * 2;
+  std::vector<std::vector<uint8_t>> meta(L, std::vector<uint8_t>((size_t)meta_bytes, 0));
+  for (int l = 0; l < L; l++) {
+    DFGPU_CHECK(proto[l].cols.size() == ncols, "exchange: the local tables differ in their column count");
+    for (int p = 0; p < W; p++) {
+      const int64_t n = parts[l][p].nrows;
+      std::memcpy(&meta[l][(size_t)p * 8], &n, 8);
+    }
+    for (size_t ci = 0; ci < ncols; ci++) {
+      bool v = false;
+      for (int p = 0; p < W; p++) v |= parts[l][p].nrows > 0 && parts[l][p].cols[ci].validity != nullptr;
+      meta[l][(size_t)W * 8 + ci * 2] = v;
+      meta[l][(size_t)W * 8 + ci * 2 + 1] = (uint8_t)proto[l].cols[ci].field.type;
+    }
+  }
+  const std::vector<uint8_t> all = allgather_meta(c, meta, meta_bytes);
+  auto rows = [&](int src, int dst) {
+    int64_t n;
+    std::memcpy(&n, all.data() + (size_t)src * meta_bytes + (size_t)dst * 8, 8);
+    return n;
+  };
+  std::vector<uint8_t> any_valid(ncols, 0);
+  for (size_t ci = 0; ci < ncols; ci++)
+    for (int r = 0; r < W; r++) {
+      const uint8_t* m = all.data() + (size_t)r * meta_bytes + (size_t)W * 8 + ci * 2;
+      any_valid[ci] |= m[0];
+      DFGPU_CHECK(m[1] == (uint8_t)proto[0].cols[ci].field.type, "exchange: column " + proto[0].cols[ci].name + " has different types on different ranks");
+    }
+
+  std::vector<Table> out(L);
+  std::vector<std::vector<int64_t>> off(L, std::vector<int64_t>(W + 1, 0));  // receive offsets in rows
+  int64_t rows_to_peers = 0, rows_from_peers = 0;
+  for (int l = 0; l < L; l++) {
+    const int me = c.first_rank + l;
+    use_device(c.devices[l]);
+    for (int p = 0; p < W; p++) {
+      off[l][p + 1] = off[l][p] + rows(p, me);
+      if (p != me) {
+        rows_to_peers += rows(me, p);
+        rows_from_peers += rows(p, me);
+      }
+    }
+    out[l] = Table();
+    out[l].nrows = off[l][W];
+    for (size_t ci = 0; ci < ncols; ci++) {
+      Column n = alloc_like(proto[l].cols[ci], out[l].nrows);
+      if (proto[l].cols[ci].field.type == DFGPU_BOOL && out[l].nrows) DFGPU_HIP(hipMemsetAsync(n.data->ptr, 0, bitmap_bytes(out[l].nrows), rt().stream));
+      if (any_valid[ci]) {
+        n.validity = make_zero_buf(bitmap_bytes(out[l].nrows));
+        n.null_count = -1;
+      }
+      out[l].cols.push_back(std::move(n));
+    }
+  }
+  std::vector<BufPtr> keep;  // staging that must outlive the enqueued transfers
+  std::vector<std::vector<Xfer>> xs;
+  struct Placement { size_t ci; bool validity; std::vector<BufPtr> stage; std::vector<std::vector<int64_t>> soff; };
+  std::vector<Placement> placements;
+  for (size_t ci = 0; ci < ncols; ci++) {
+    const int type = proto[0].cols[ci].field.type;
+    // ---- values: byte-addressable types travel straight from the partition slices into the result column
+    if (type != DFGPU_BOOL) {
+      const int w = type_width(type);
+      std::vector<Xfer> x(L, Xfer(W));
+      for (int l = 0; l < L; l++) {
+        const int me = c.first_rank + l;
+        for (int p = 0; p < W; p++) {
+          x[l].send[p] = parts[l][p].cols[ci].ptr();
+          x[l].send_bytes[p] = parts[l][p].nrows * w;
+          x[l].recv[p] = (char*)out[l].cols[ci].data->ptr + (size_t)off[l][p] * w;
+          x[l].recv_bytes[p] = rows(p, me) * w;
+        }
+      }
+      xs.push_back(std::move(x));
+    }
+    // ---- bit-packed buffers (validity, Boolean values): whole words per peer into staging, placed at the receiver's bit offsets afterwards
+    for (int what = 0; what < 2; what++) {
+      const bool validity = what == 0;
+      if (validity ? !any_valid[ci] : type != DFGPU_BOOL) continue;
+      std::vector<Xfer> x(L, Xfer(W));
+      Placement pl{ci, validity, std::vector<BufPtr>(L), std::vector<std::vector<int64_t>>(L, std::vector<int64_t>(W + 1, 0))};
+      for (int l = 0; l < L; l++) {
+        const int me = c.first_rank + l;
+        use_device(c.devices[l]);
+        for (int p = 0; p < W; p++) pl.soff[l][p + 1] = pl.soff[l][p] + (int64_t)bitmap_bytes(rows(p, me));
+        pl.stage[l] = make_buf((size_t)pl.soff[l][W] + 16);
+        for (int p = 0; p < W; p++) {
+          const Column& pc = parts[l][p].cols[ci];
+          const int64_t n = parts[l][p].nrows;
+          const void* src = validity ? (const void*)pc.valid_words() : pc.ptr();
+          if (validity && !src && n) {  // an all-valid part still owes the receiver its bits
+            BufPtr ones = make_buf(bitmap_bytes(n));
+            k_fill_words<<<grid_for((n + 63) / 64, BLOCK), BLOCK, 0, rt().stream>>>(ones->as<uint64_t>(), (n + 63) / 64, ~0ull);
+            keep.push_back(ones);
+            src = ones->ptr;
+          }
+          x[l].send[p] = src;
+          x[l].send_bytes[p] = (int64_t)bitmap_bytes(n);
+          x[l].recv[p] = (char*)pl.stage[l]->ptr + pl.soff[l][p];
+          x[l].recv_bytes[p] = (int64_t)bitmap_bytes(rows(p, me));
+        }
+      }
+      xs.push_back(std::move(x));
+      placements.push_back(std::move(pl));
+    }
+  }
+  alltoallv(c, xs);
+  for (const Placement& pl : placements)
+    for (int l = 0; l < L; l++) {
+      const int me = c.first_rank + l;
+      use_device(c.devices[l]);
+      Column& oc = out[l].cols[pl.ci];
+      uint64_t* dst = pl.validity ? oc.validity->as<uint64_t>() : oc.data->as<uint64_t>();
+      for (int p = 0; p < W; p++)
+        if (rows(p, me)) bitmap_place((const uint64_t*)((const char*)pl.stage[l]->ptr + pl.soff[l][p]), off[l][p], rows(p, me), dst);
+    }
+  for (int l = 0; l < L; l++) {  // the caller may free the parts as soon as this returns
+    use_device(c.devices[l]);
+    DFGPU_HIP(hipStreamSynchronize(rt().stream));
+  }
+  std::lock_guard<std::mutex> lk(c.mu);
+  c.stats.rows_sent_to_peers += rows_to_peers;
+  c.stats.rows_received_from_peers += rows_from_peers;
+  return out;
+}
+
+static std::vector<Table> local_inputs(Comm& c, const dfgpu_table_t* inputs) {
+  std::vector<Table> t;
+  for (int l = 0; l < c.n_local(); l++) {
+    const Table* p = unwrap(inputs[l]);
+    DFGPU_CHECK(p->device == c.devices[l], "exchange: input table " + std::to_string(l) + " does not live on the device of local rank " + std::to_string(l));
+    t.push_back(*p);  // shallow: the columns share their buffers
+  }
+  return t;
+}
+static void hand_out(std::vector<Table>& res, dfgpu_table_t* outs) {
+  for (size_t l = 0; l < res.size(); l++) outs[l] = wrap(new Table(std::move(res[l])));
+}
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+
+extern "C" {
+
+int dfgpu_comm_unique_id(uint8_t* out_id) {
+  return guarded([&] {
+    DFGPU_CHECK(out_id != nullptr, "null argument");
+    ncclUniqueId id;
+    DFGPU_NCCL(rccl().GetUniqueId(&id));
+    std::memcpy(out_id, id.internal, DFGPU_COMM_ID_BYTES);
+  });
+}
+
+int dfgpu_comm_init_rank(const uint8_t* id, int world, int rank, dfgpu_comm_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(id && out && world >= 1 && rank >= 0 && rank < world, "dfgpu_comm_init_rank: bad arguments");
+    auto c = std::make_unique<Comm>();
+    c->world = world;
+    c->first_rank = rank;
+    c->devices = {current_device()};
+    c->nccl.resize(1);
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, DFGPU_COMM_ID_BYTES);
+    (void)rt();  // hipSetDevice on this thread: RCCL binds the communicator to the current device
+    DFGPU_NCCL(rccl().CommInitRank(&c->nccl[0], world, uid, rank));
+    *out = reinterpret_cast<dfgpu_comm_t>(c.release());
+  });
+}
+
+int dfgpu_comm_init_all(dfgpu_comm_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(out != nullptr, "null argument");
+    auto c = std::make_unique<Comm>();
+    c->devices = initialised_devices();
+    c->world = (int)c->devices.size();
+    c->first_rank = 0;
+    c->nccl.resize(c->devices.size());
+    DFGPU_NCCL(rccl().CommInitAll(c->nccl.data(), c->world, c->devices.data()));
+    *out = reinterpret_cast<dfgpu_comm_t>(c.release());
+  });
+}
+
+int dfgpu_comm_init_host(const dfgpu_host_transport* t, int world, int rank, dfgpu_comm_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(t && t->alltoallv && t->allgather && out && world >= 1 && rank >= 0 && rank < world, "dfgpu_comm_init_host: bad arguments");
+    auto c = std::make_unique<Comm>();
+    c->world = world;
+    c->first_rank = rank;
+    c->devices = {current_device()};
+    c->host = true;
+    c->ht = *t;
+    *out = reinterpret_cast<dfgpu_comm_t>(c.release());
+  });
+}
+
+int dfgpu_comm_free(dfgpu_comm_t h) {
+  return guarded([&] {
+    if (!h) return;
+    Comm* c = reinterpret_cast<Comm*>(h);
+    for (ncclComm_t n : c->nccl)
+      if (n) (void)rccl().CommDestroy(n);
+    delete c;
+  });
+}
+
+int dfgpu_comm_info(dfgpu_comm_t h, int* world, int* first_rank, int* n_local) {
+  return guarded([&] {
+    DFGPU_CHECK(h != nullptr, "null communicator");
+    Comm* c = reinterpret_cast<Comm*>(h);
+    if (world) *world = c->world;
+    if (first_rank) *first_rank = c->first_rank;
+    if (n_local) *n_local = c->n_local();
+  });
+}
+
+int dfgpu_comm_stats(dfgpu_comm_t h, dfgpu_exchange_stats* out, int reset) {
+  return guarded([&] {
+    DFGPU_CHECK(h != nullptr, "null communicator");
+    Comm* c = reinterpret_cast<Comm*>(h);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (out) *out = c->stats;
+    if (reset) c->stats = dfgpu_exchange_stats{};
+  });
+}
+
+int dfgpu_exchange_hash(dfgpu_comm_t h, const dfgpu_table_t* inputs, const int* key_cols, int nkeys, dfgpu_table_t* outs) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(h && inputs && outs && key_cols && nkeys >= 1, "dfgpu_exchange_hash: bad arguments");
+    Comm& c = *reinterpret_cast<Comm*>(h);
+    DFGPU_CHECK(c.world <= 64, "dfgpu_exchange_hash supports up to 64 ranks");
+    std::vector<Table> t = local_inputs(c, inputs);
+    unify_dictionaries(c, t);
+    std::vector<std::vector<Table>> parts(c.n_local());
+    const std::vector<int> keys(key_cols, key_cols + nkeys);
+    for (int l = 0; l < c.n_local(); l++) {
+      use_device(c.devices[l]);
+      parts[l] = partition_table(t[l], keys, c.world);
+    }
+    std::vector<Table> res = exchange_parts(c, parts, t);
+    hand_out(res, outs);
+  });
+}
+
+int dfgpu_exchange_broadcast(dfgpu_comm_t h, const dfgpu_table_t* inputs, dfgpu_table_t* outs) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(h && inputs && outs, "dfgpu_exchange_broadcast: bad arguments");
+    Comm& c = *reinterpret_cast<Comm*>(h);
+    std::vector<Table> t = local_inputs(c, inputs);
+    unify_dictionaries(c, t);
+    std::vector<std::vector<Table>> parts(c.n_local());
+    for (int l = 0; l < c.n_local(); l++) parts[l].assign(c.world, t[l]);  // every peer receives the whole local table
+    std::vector<Table> res = exchange_parts(c, parts, t);
+    hand_out(res, outs);
+  });
+}
+
+int dfgpu_exchange_broadcast_pruned(dfgpu_comm_t h, const dfgpu_table_t* builds, int build_key, const dfgpu_table_t* probes, int probe_key,
+                                    dfgpu_table_t* outs) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(h && builds && probes && outs, "dfgpu_exchange_broadcast_pruned: bad arguments");
+    Comm& c = *reinterpret_cast<Comm*>(h);
+    const int L = c.n_local(), W = c.world;
+    std::vector<Table> b = local_inputs(c, builds);
+    unify_dictionaries(c, b);
+    // every rank's closed key ranges of both sides: {probe lo, hi, any, build lo, hi, any}
+    std::vector<std::vector<uint8_t>> meta(L, std::vector<uint8_t>(48));
+    std::vector<ColStats> bstats(L);
+    for (int l = 0; l < L; l++) {
+      Table* pt = unwrap(probes[l]);
+      Table* bt = unwrap(builds[l]);
+      DFGPU_CHECK(build_key >= 0 && build_key < (int)bt->cols.size() && probe_key >= 0 && probe_key < (int)pt->cols.size(), "key column out of range");
+      DFGPU_CHECK(!bt->cols[build_key].dict && !pt->cols[probe_key].dict, "pruned broadcast: integer key columns only");
+      const ColStats ps = column_stats(pt->cols[probe_key], pt->nrows);
+      bstats[l] = column_stats(bt->cols[build_key], bt->nrows);
+      const long long v[6] = {ps.min, ps.max, ps.valid > 0, bstats[l].min, bstats[l].max, bstats[l].valid > 0};
+      std::memcpy(meta[l].data(), v, 48);
+    }
+    const std::vector<uint8_t> all = allgather_meta(c, meta, 48);
+    auto range = [&](int r, int side, long long& lo, long long& hi) {
+      long long v[6];
+      std::memcpy(v, all.data() + (size_t)r * 48, 48);
+      lo = v[side * 3];
+      hi = v[side * 3 + 1];
+      return v[side * 3 + 2] != 0;
+    };
+    std::vector<std::vector<Table>> parts(L);
+    for (int l = 0; l < L; l++) {
+      use_device(c.devices[l]);
+      const Column& kc = b[l].cols[build_key];
+      std::vector<int> allc(b[l].cols.size());
+      for (size_t i = 0; i < allc.size(); i++) allc[i] = (int)i;
+      for (int p = 0; p < W; p++) {
+        // what destination p can match lies inside [min, max] of ITS probe keys
+        long long plo, phi;
+        const bool pany = range(p, 0, plo, phi);
+        const long long lo = std::max(plo, (long long)bstats[l].min), hi = std::min(phi, (long long)bstats[l].max);
+        if (!pany || bstats[l].valid == 0 || lo > hi) {
+          BufPtr zero = make_zero_buf(bitmap_bytes(b[l].nrows));
+          parts[l].push_back(compact_table(b[l], allc, zero->as<uint64_t>(), nullptr));
+        } else if (lo == bstats[l].min && hi == bstats[l].max && !kc.validity) {
+          parts[l].push_back(b[l]);  // the bounds cover the whole shard: a view, no filter pass
+        } else {
+          BufPtr mask = make_buf(bitmap_bytes(b[l].nrows));
+          const int g = grid_for((b[l].nrows + 63) / 64, BLOCK / WAVE);
+          switch (kc.field.type) {
+            case DFGPU_INT64: k_range_mask<int64_t><<<g, BLOCK, 0, rt().stream>>>((const int64_t*)kc.ptr(), kc.valid_words(), b[l].nrows, lo, hi, mask->as<uint64_t>()); break;
+            case DFGPU_INT32: case DFGPU_DATE32: k_range_mask<int32_t><<<g, BLOCK, 0, rt().stream>>>((const int32_t*)kc.ptr(), kc.valid_words(), b[l].nrows, lo, hi, mask->as<uint64_t>()); break;
+            case DFGPU_UINT32: k_range_mask<uint32_t><<<g, BLOCK, 0, rt().stream>>>((const uint32_t*)kc.ptr(), kc.valid_words(), b[l].nrows, lo, hi, mask->as<uint64_t>()); break;
+            case DFGPU_UINT8: k_range_mask<uint8_t><<<g, BLOCK, 0, rt().stream>>>((const uint8_t*)kc.ptr(), kc.valid_words(), b[l].nrows, lo, hi, mask->as<uint64_t>()); break;
+            default: throw Error("pruned broadcast: integer key columns only");
+          }
+          DFGPU_HIP(hipGetLastError());
+          parts[l].push_back(compact_table(b[l], allc, mask->as<uint64_t>(), nullptr));
+        }
+      }
+    }
+    std::vector<Table> res = exchange_parts(c, parts, b);
+    hand_out(res, outs);
+  });
+}
+
+}  // extern "C"

@@ -75,6 +75,27 @@ __global__ __launch_bounds__(BLOCK) void k_compact(CopyCols cols, const uint64_t
   }
 }
 
+// compaction of a bit-packed (Boolean) column: the selected rows' bits (and validity bits) as one byte per output row,
+// packed to words afterwards (k_pack_bytes) — same offsets as k_compact
+__global__ __launch_bounds__(BLOCK) void k_compact_bits(const uint64_t* __restrict__ src_bits, const uint64_t* __restrict__ src_valid, const uint64_t* __restrict__ mask,
+                                                       const uint64_t* __restrict__ mask_valid, const uint64_t* __restrict__ prefix, int64_t n,
+                                                       uint8_t* __restrict__ dst_bytes, uint8_t* __restrict__ dst_valid_bytes) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  const unsigned lane = lane_id();
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    uint64_t m = mask[w];
+    if (mask_valid) m &= mask_valid[w];
+    const int64_t rem = n - (w << 6);
+    if (rem < 64) m &= (~0ull) >> (64 - rem);
+    if (!((m >> lane) & 1ull)) continue;
+    const int64_t d = (int64_t)(prefix[w] + mbcnt(m));
+    dst_bytes[d] = (uint8_t)((src_bits[w] >> lane) & 1ull);
+    if (dst_valid_bytes) dst_valid_bytes[d] = (uint8_t)((src_valid[w] >> lane) & 1ull);
+  }
+}
+
 // one byte per row -> Arrow bitmap (wave ballot = one 64-bit word per wave)
 __global__ __launch_bounds__(BLOCK) void k_pack_bytes(const uint8_t* __restrict__ bytes, int64_t n, uint64_t* __restrict__ words) {
   const int64_t n_words = (n + 63) >> 6;
@@ -136,22 +157,32 @@ Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_
   for (size_t i = 0; i < cols.size(); i++) {
     DFGPU_CHECK(cols[i] >= 0 && cols[i] < (int)in.cols.size(), "projection index out of range");
     const Column& c = in.cols[cols[i]];
-    DFGPU_CHECK(c.field.type != DFGPU_BOOL, "filter: Boolean payload columns are not supported on the GPU path yet");
     out.cols.push_back(alloc_like(c, n_out));
     if (c.validity) valid_bytes[i] = make_buf((size_t)n_out + 64);
   }
   if (n_out > 0) {
-    for (size_t c0 = 0; c0 < cols.size(); c0 += MAX_COLS) {
+    // byte-addressable columns, MAX_COLS per launch; Boolean (bit-packed) columns one by one afterwards
+    std::vector<int> wide, bits;
+    for (size_t i = 0; i < cols.size(); i++) (in.cols[cols[i]].field.type == DFGPU_BOOL ? bits : wide).push_back((int)i);
+    for (int i : bits) {
+      const Column& c = in.cols[cols[i]];
+      BufPtr vals = make_buf((size_t)n_out + 64);
+      k_compact_bits<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>((const uint64_t*)c.ptr(), c.valid_words(), mask, mask_valid, prefix->as<uint64_t>(), n,
+                                                                               vals->as<uint8_t>(), valid_bytes[i] ? valid_bytes[i]->as<uint8_t>() : nullptr);
+      DFGPU_HIP(hipGetLastError());
+      pack_bytes_to_bitmap(vals->as<uint8_t>(), n_out, out.cols[i].data->as<uint64_t>());
+    }
+    for (size_t c0 = 0; c0 < wide.size(); c0 += MAX_COLS) {
       CopyCols cc{};
       int64_t bytes = 0;
-      cc.n = (int)std::min<size_t>(MAX_COLS, cols.size() - c0);
+      cc.n = (int)std::min<size_t>(MAX_COLS, wide.size() - c0);
       for (int k = 0; k < cc.n; k++) {
-        const Column& c = in.cols[cols[c0 + k]];
+        const Column& c = in.cols[cols[wide[c0 + k]]];
         cc.src[k] = c.ptr();
-        cc.dst[k] = out.cols[c0 + k].data->ptr;
+        cc.dst[k] = out.cols[wide[c0 + k]].data->ptr;
         cc.width[k] = type_width(c.field.type);
         cc.src_valid[k] = c.valid_words();
-        cc.dst_valid_bytes[k] = valid_bytes[c0 + k] ? valid_bytes[c0 + k]->as<uint8_t>() : nullptr;
+        cc.dst_valid_bytes[k] = valid_bytes[wide[c0 + k]] ? valid_bytes[wide[c0 + k]]->as<uint8_t>() : nullptr;
         bytes += (n + n_out) * cc.width[k];
       }
       ProfileScope ps("compact", bytes + n / 8);

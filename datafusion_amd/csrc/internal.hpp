@@ -253,7 +253,16 @@ void jit_launch(hipFunction_t fn, int grid, int block, size_t lds_bytes, void* a
 // dictionary-encoded columns with different dictionaries needs.  Errors when the index type cannot hold that value.
 Column remap_to_dictionary(const Column& c, const std::shared_ptr<const DictValues>& target);
 
+// dst bits [off, off + n) |= src bits [0, n) (src null = all ones); the destination range must start zeroed
+void bitmap_place(const uint64_t* src, int64_t off, int64_t n, uint64_t* dst);
+
+// ----------------------------------------------------------------- statistics (join.hip)
+// min / max / non-null count / strictly-ascending flag of an integer column, cached on the column
+ColStats column_stats(Column& c, int64_t nrows);
+
 // ----------------------------------------------------------------- hashing (partition.hip)
+// RepartitionExec(Hash): nparts tables, row order kept inside each (slices of one buffer per column when nothing is nullable)
+std::vector<Table> partition_table(const Table& in, const std::vector<int>& key_cols, int nparts);
 void hash_columns(const std::vector<const Column*>& keys, int64_t n, uint64_t seed, uint64_t* out, bool force_collisions);
 
 }  // namespace dfgpu

@@ -1104,6 +1104,32 @@ static JoinTable* unwrap_join(dfgpu_join_t ht) {
   return jt;
 }
 
+ColStats column_stats(Column& kc, int64_t nrows) {
+  DFGPU_CHECK(is_integer_like(kc.field.type) && kc.field.type != DFGPU_UINT64, "dfgpu_column_minmax: integer columns only");
+  if (kc.stats) return *kc.stats;  // computed before for these rows (tables are immutable)
+  Runtime& r = rt();
+  MinMax res{INT64_MAX, INT64_MIN, 0, 0, 0};
+  if (nrows > 0) {
+    KeyCol k{kc.ptr(), kc.valid_words(), kc.field.type, type_width(kc.field.type)};
+    BufPtr mm = make_buf(sizeof(MinMax));
+    h2d_async(mm->ptr, &res, sizeof res);
+    {
+      ProfileScope ps("column_minmax", nrows * k.width);
+      const int g = std::min(grid_for(nrows, BLOCK * BUILD_UNROLL), 2048);
+      with_key_type(k.type, [&](auto kt) {
+        constexpr int T = decltype(kt)::value;
+        if (k.valid) k_key_minmax<T, true><<<g, BLOCK, 0, r.stream>>>(k, nrows, mm->as<MinMax>());
+        else k_key_minmax<T, false><<<g, BLOCK, 0, r.stream>>>(k, nrows, mm->as<MinMax>());
+      });
+      DFGPU_HIP(hipGetLastError());
+    }
+    d2h(&res, mm->ptr, sizeof res);
+    kc.stats = std::make_shared<ColStats>(ColStats{res.smin, res.smax, (int64_t)res.valid, res.valid > 0 && res.unsorted == 0});
+    return *kc.stats;
+  }
+  return ColStats{res.smin, res.smax, 0, false};
+}
+
 static bool needs_visited(int join_type) {
   return join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_FULL || join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI ||
          join_type == DFGPU_JOIN_LEFT_MARK;
@@ -1507,36 +1533,11 @@ int dfgpu_column_minmax(dfgpu_table_t table, int column, int64_t* out_min, int64
     require_init();
     Table& t = *unwrap(table);
     DFGPU_CHECK(column >= 0 && column < (int)t.cols.size(), "column index out of range");
-    Column& kc = t.cols[column];
-    DFGPU_CHECK(is_integer_like(kc.field.type) && kc.field.type != DFGPU_UINT64, "dfgpu_column_minmax: integer columns only");
-    Runtime& r = rt();
-    MinMax res{INT64_MAX, INT64_MIN, 0, 0, 0};
-    if (kc.stats) {  // computed before for these rows (tables are immutable)
-      res.smin = kc.stats->min;
-      res.smax = kc.stats->max;
-      res.valid = (unsigned long long)kc.stats->valid;
-      res.unsorted = kc.stats->ascending ? 0u : 1u;
-    } else if (t.nrows > 0) {
-      KeyCol k{kc.ptr(), kc.valid_words(), kc.field.type, type_width(kc.field.type)};
-      BufPtr mm = make_buf(sizeof(MinMax));
-      h2d_async(mm->ptr, &res, sizeof res);
-      {
-        ProfileScope ps("column_minmax", t.nrows * k.width);
-        const int g = std::min(grid_for(t.nrows, BLOCK * BUILD_UNROLL), 2048);
-        with_key_type(k.type, [&](auto kt) {
-          constexpr int T = decltype(kt)::value;
-          if (k.valid) k_key_minmax<T, true><<<g, BLOCK, 0, r.stream>>>(k, t.nrows, mm->as<MinMax>());
-          else k_key_minmax<T, false><<<g, BLOCK, 0, r.stream>>>(k, t.nrows, mm->as<MinMax>());
-        });
-        DFGPU_HIP(hipGetLastError());
-      }
-      d2h(&res, mm->ptr, sizeof res);
-      kc.stats = std::make_shared<ColStats>(ColStats{res.smin, res.smax, (int64_t)res.valid, res.valid > 0 && res.unsorted == 0});
-    }
-    if (out_min) *out_min = res.smin;
-    if (out_max) *out_max = res.smax;
-    if (out_valid) *out_valid = (int64_t)res.valid;
-    if (out_ascending) *out_ascending = res.valid > 0 && res.unsorted == 0;
+    const ColStats st = column_stats(t.cols[column], t.nrows);
+    if (out_min) *out_min = st.min;
+    if (out_max) *out_max = st.max;
+    if (out_valid) *out_valid = st.valid;
+    if (out_ascending) *out_ascending = st.ascending;
   });
 }
 

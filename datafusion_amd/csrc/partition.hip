@@ -212,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_mask(const uint8_t* __restrict__
   }
 }
 
-static std::vector<Table> partition_table(const Table& in, const std::vector<int>& key_cols, int nparts) {
+std::vector<Table> partition_table(const Table& in, const std::vector<int>& key_cols, int nparts) {
   Runtime& r = rt();
   DFGPU_CHECK(nparts >= 1 && nparts <= MAX_PARTS, "dfgpu_partition supports 1..64 partitions");
   const int64_t n = in.nrows;

@@ -293,6 +293,10 @@ static ArrowArray* export_dictionary(const DictValues& dv) {
   return a;
 }
 
+void bitmap_place(const uint64_t* src, int64_t off, int64_t n, uint64_t* dst) {
+  if (n > 0) k_bitmap_place<<<grid_for((n + 127) / 64, BLOCK), BLOCK, 0, rt().stream>>>(src, off, n, (unsigned long long*)dst);
+}
+
 Column remap_to_dictionary(const Column& c, const std::shared_ptr<const DictValues>& target) {
   DFGPU_CHECK(c.dict && target, "remap_to_dictionary: both columns must be dictionary-encoded");
   if (same_dictionary(c.dict, target)) return c;

@@ -1,18 +1,213 @@
-"""Multi-GPU hash-repartition exchange = RepartitionExec(Partitioning::Hash) across GPUs
-(physical-plan/src/repartition/mod.rs:1097-1150, :1626): each rank splits its rows by
-hash(keys; seed 0) % world_size with the K10 partition kernel (contiguous per-destination
-slices of one buffer per column), then one all-to-all(v) per column moves slice r of every
-rank to rank r.  In-process tokio channels of the reference become RCCL over xGMI
-(torch.distributed backend "nccl"); on CPU the same collective code runs over gloo in tests.
+"""Multi-GPU exchanges = RepartitionExec(Partitioning::Hash) across GPUs (physical-plan/src/repartition/mod.rs:1097-1150,
+:1626), the collected build side of PartitionMode::CollectLeft (hash_join/exec.rs:1325-1328) and that all-gather pruned by
+probe-key bounds — Python face of the C ABI's dfgpu_comm_* / dfgpu_exchange_* (datafusion_amd/csrc/exchange.hip), which is
+where the work happens: partition kernel, RCCL grouped ncclSend / ncclRecv over xGMI issued by the library itself on its
+own stream, validity bitmaps, Boolean columns and dictionaries carried across.  One process per GPU.
 
-One process per GPU.  torch is plumbing only: it wraps the library's HBM buffers as tensors
-(zero-copy, __cuda_array_interface__) so RCCL can send from / receive into them.
+torch.distributed is used for two things only: handing RCCL's bootstrap id from rank 0 to the other ranks, and — when the
+process group is NOT RCCL (gloo: two test ranks sharing one GPU) — as the host transport the library calls back into
+(dfgpu_comm_init_host).  The functions of the second half of this file (exchange_counts ... route) are that host transport's
+collectives plus the pruning protocol's pure functions; tests/test_exchange_gloo.py runs them with world_size 2 / 3 on CPU.
 """
 from __future__ import annotations
 
 import ctypes as C
 
 import numpy as np
+
+
+class Comm:
+    """a dfgpu_comm_t: `world` ranks, this process is `rank`"""
+
+    def __init__(self, handle, world, rank, keep=None):
+        self._h, self.world, self.rank, self._keep = handle, world, rank, keep
+
+    # ------------------------------------------------------------------ construction
+    @staticmethod
+    def single() -> "Comm":
+        """a one-rank RCCL communicator (rehearsal of the N > 1 code path on a 1-GPU box)"""
+        from . import _lib
+        lib = _lib.init()
+        uid = (C.c_uint8 * 128)()
+        _lib.check(lib.dfgpu_comm_unique_id(uid))
+        h = C.c_void_p()
+        _lib.check(lib.dfgpu_comm_init_rank(uid, 1, 0, C.byref(h)))
+        return Comm(h, 1, 0)
+
+    @staticmethod
+    def rccl(group=None) -> "Comm":
+        """RCCL communicator over the ranks of a torch.distributed group: rank 0's bootstrap id is broadcast through the group"""
+        import torch.distributed as dist
+
+        from . import _lib
+        lib = _lib.init()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(lib.dfgpu_comm_unique_id(uid))
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        _lib.check(lib.dfgpu_comm_init_rank(uid, world, rank, C.byref(h)))
+        return Comm(h, world, rank)
+
+    @staticmethod
+    def host(group=None) -> "Comm":
+        """the library's exchange protocol over collectives of `group` on host memory (dfgpu_comm_init_host)"""
+        import torch.distributed as dist
+
+        from . import _lib
+        lib = _lib.init()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def alltoallv(_ctx, send, send_bytes, recv, recv_bytes):
+            try:
+                host_alltoallv([(send[p], send_bytes[p]) for p in range(world)], [(recv[p], recv_bytes[p]) for p in range(world)], group)
+                return 0
+            except Exception as e:  # noqa: BLE001 - reported through the C ABI's error channel
+                print("host transport alltoallv failed:", e, flush=True)
+                return 1
+
+        def allgather(_ctx, mine, nbytes, out):
+            try:
+                host_allgather(mine, nbytes, out, group)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("host transport allgather failed:", e, flush=True)
+                return 1
+        t = _lib.HostTransport(None, _lib.ALLTOALLV_FN(alltoallv), _lib.ALLGATHER_FN(allgather))
+        h = C.c_void_p()
+        _lib.check(lib.dfgpu_comm_init_host(C.byref(t), world, rank, C.byref(h)))
+        return Comm(h, world, rank, keep=t)
+
+    # ------------------------------------------------------------------ collectives over device tables
+    def _call(self, fn, *args):
+        from . import _lib
+        from .table import DeviceTable
+        out = (C.c_void_p * 1)()
+        _lib.check(fn(self._h, *args, out))
+        return DeviceTable(C.c_void_p(out[0]))
+
+    def hash_exchange(self, table, keys):
+        from . import _lib
+        idx = [table.index_of(k) for k in keys]
+        return self._call(_lib.load().dfgpu_exchange_hash, (C.c_void_p * 1)(table.handle), (C.c_int * len(idx))(*idx), len(idx))
+
+    def broadcast(self, table):
+        from . import _lib
+        return self._call(_lib.load().dfgpu_exchange_broadcast, (C.c_void_p * 1)(table.handle))
+
+    def broadcast_pruned(self, build, build_key, probe, probe_key):
+        from . import _lib
+        return self._call(_lib.load().dfgpu_exchange_broadcast_pruned, (C.c_void_p * 1)(build.handle), build.index_of(build_key),
+                          (C.c_void_p * 1)(probe.handle), probe.index_of(probe_key))
+
+    def stats(self, reset=False) -> dict:
+        from . import _lib
+        st = _lib.ExchangeStats()
+        _lib.check(_lib.load().dfgpu_comm_stats(self._h, C.byref(st), int(reset)))
+        return {n: getattr(st, n) for n, _ in st._fields_}
+
+    def free(self):
+        if self._h:
+            from . import _lib
+            _lib.load().dfgpu_comm_free(self._h)
+            self._h = None
+
+
+_COMMS = {}
+
+
+def comm_for(group=None, force=False):
+    """the communicator of a torch.distributed group (cached): RCCL when the group's backend is RCCL, else the host transport
+    over the group; None when there is one rank and the caller does not insist (force = one-rank rehearsal on a 1-GPU box)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        if not force:
+            return None
+        if "single" not in _COMMS:
+            _COMMS["single"] = Comm.single()
+        return _COMMS["single"]
+    if dist.get_world_size(group) == 1 and not force:
+        return None
+    key = ("group", id(group))
+    if key not in _COMMS:
+        _COMMS[key] = Comm.rccl(group) if "nccl" in str(dist.get_backend(group)) else Comm.host(group)
+    return _COMMS[key]
+
+
+def hash_exchange(table, keys, group=None, force=False):
+    """DeviceTable -> DeviceTable holding every row (from all ranks) whose key hash routes here (dfgpu_exchange_hash).
+    force=True runs the partition + exchange path even for a single rank (exercises the plumbing on a 1-GPU box)."""
+    c = comm_for(group, force)
+    return table if c is None else c.hash_exchange(table, keys)
+
+
+def broadcast_table(table, group=None, force=False):
+    """DeviceTable -> DeviceTable holding the rows of ALL ranks in rank order: the build side of a PartitionMode::CollectLeft
+    hash join (dfgpu_exchange_broadcast).  Chosen instead of hash-repartitioning both sides when it moves fewer bytes per
+    GPU: build_bytes * N < build_bytes + probe_bytes."""
+    c = comm_for(group, force)
+    return table if c is None else c.broadcast(table)
+
+
+def pruned_broadcast_table(build, build_key, probe, probe_key, group=None, force=False, stats=None):
+    """CollectLeft with the broadcast pruned by the destinations' probe-key bounds (dfgpu_exchange_broadcast_pruned): rank r
+    receives from every rank only the build rows whose key lies inside [min, max] of r's probe keys.  `stats` (optional
+    dict) receives the rows sent / received across ranks."""
+    import pyarrow as pa
+    c = comm_for(group, force)
+    if c is None:
+        return build
+    ktype = build.schema.field(build.schema.get_field_index(build_key)).type
+    if ktype not in (pa.int64(), pa.int32()):
+        return c.broadcast(build)
+    before = c.stats()
+    out = c.broadcast_pruned(build, build_key, probe, probe_key)
+    if stats is not None:
+        after = c.stats()
+        stats.update(rows_sent_to_peers=after["rows_sent_to_peers"] - before["rows_sent_to_peers"],
+                     rows_received_from_peers=after["rows_received_from_peers"] - before["rows_received_from_peers"],
+                     bytes_sent_to_peers=after["bytes_sent_to_peers"] - before["bytes_sent_to_peers"],
+                     build_rows_local=build.num_rows, build_rows_after_exchange=out.num_rows)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host transport: the two collectives dfgpu_comm_init_host calls back into, over torch.distributed on host memory
+def _host_tensor(ptr, nbytes):
+    import torch
+    if not nbytes:
+        return torch.empty(0, dtype=torch.uint8)
+    return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(nbytes),)))
+
+
+def host_alltoallv(send, recv, group=None):
+    """send[p] = (pointer, bytes) for rank p (own entry empty), recv likewise: point-to-point isend / irecv, all in flight"""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    ops, keep = [], []
+    for p, (ptr, n) in enumerate(recv):
+        if p != rank and n:
+            t = _host_tensor(ptr, n)
+            keep.append(t)
+            ops.append(dist.P2POp(dist.irecv, t, dist.get_global_rank(group, p) if group is not None else p, group))
+    for p, (ptr, n) in enumerate(send):
+        if p != rank and n:
+            t = _host_tensor(ptr, n)
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, dist.get_global_rank(group, p) if group is not None else p, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def host_allgather(mine, nbytes, out, group=None):
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dist.all_gather_into_tensor(_host_tensor(out, nbytes * world), _host_tensor(mine, nbytes), group=group)
+
 
 _W = {1: 4, 2: 8, 3: 16, 4: 8, 5: 1, 6: 4, 7: 8, 8: 4}  # dfgpu_type -> bytes
 
@@ -92,50 +287,6 @@ def all_to_all_bytes(send, send_counts, recv, recv_counts, width, group=None, ma
             o += nb
 
 
-def hash_exchange(table, keys, group=None, force=False):
-    """DeviceTable -> DeviceTable holding every row (from all ranks) whose key hash routes here.
-    force=True runs the partition + all-to-all path even for a single rank (used to exercise the
-    RCCL plumbing on a 1-GPU box)."""
-    import torch
-    import torch.distributed as dist
-
-    from . import _lib, ops
-    from ._lib import Field, check
-    from .table import DeviceTable
-
-    world = dist.get_world_size(group)
-    if world == 1 and not force:
-        return table
-    lib = _lib.load()
-    parts = ops.partition(table, keys, world)
-    send_counts = [p.num_rows for p in parts]
-    recv_counts = exchange_counts(send_counts, group)
-    total = sum(recv_counts)
-    ncols = table.num_columns
-    views0 = [parts[0].column_view(i) for i in range(ncols)]
-    fields = (Field * ncols)(*[v.field for v in views0])
-    names = (C.c_char_p * ncols)(*[v.name for v in views0])
-    out = C.c_void_p()
-    check(lib.dfgpu_table_alloc(ncols, fields, names, C.c_int64(total), C.byref(out)))
-    result = DeviceTable(out)
-    ops.sync()  # partition kernels ran on the library stream; RCCL runs on torch's
-    n_send = sum(send_counts)
-    for i in range(ncols):
-        v = views0[i]
-        if v.validity:
-            raise _lib.DfgpuError("hash_exchange: nullable columns are not supported yet")
-        w = _W[v.field.type]
-        # partition outputs are consecutive slices of one buffer: partition 0's pointer is its start
-        send = _as_tensor(v.data, n_send * w)
-        rv = result.column_view(i)
-        recv = _as_tensor(rv.data, total * w)
-        all_to_all_bytes(send, send_counts, recv, recv_counts, w, group)
-    torch.cuda.synchronize()
-    for p in parts:
-        p.free()
-    return result
-
-
 def gather_counts(count, group=None):
     """every rank learns every rank's row count (rank order)"""
     import torch
@@ -174,44 +325,6 @@ def all_gather_bytes(send, recv, counts, width, group=None):
                 piece.copy_(send[lo * width:hi * width])
             dist.broadcast(piece.view(dtype) if (piece.data_ptr() % unit == 0) else piece, src=src, group=group)
         off += counts[r]
-
-
-def broadcast_table(table, group=None, force=False):
-    """DeviceTable -> DeviceTable holding the rows of ALL ranks in rank order: the build side of a
-    PartitionMode::CollectLeft hash join (hash_join/exec.rs:1325-1328: one side collected whole, the probe side
-    stays partitioned), as one all-gather per column over RCCL.  Chosen instead of hash-repartitioning both sides
-    when it moves fewer bytes per GPU: build_bytes * N < build_bytes + probe_bytes."""
-    import torch
-    import torch.distributed as dist
-
-    from . import _lib, ops
-    from ._lib import Field, check
-    from .table import DeviceTable
-
-    world = dist.get_world_size(group)
-    if world == 1 and not force:
-        return table
-    lib = _lib.load()
-    counts = gather_counts(table.num_rows, group)
-    total = sum(counts)
-    ncols = table.num_columns
-    views = [table.column_view(i) for i in range(ncols)]
-    fields = (Field * ncols)(*[v.field for v in views])
-    names = (C.c_char_p * ncols)(*[v.name for v in views])
-    out = C.c_void_p()
-    check(lib.dfgpu_table_alloc(ncols, fields, names, C.c_int64(total), C.byref(out)))
-    result = DeviceTable(out)
-    ops.sync()  # the producer kernels ran on the library stream; RCCL runs on torch's
-    for i in range(ncols):
-        v = views[i]
-        if v.validity:
-            raise _lib.DfgpuError("broadcast_table: nullable columns are not supported yet")
-        w = _W[v.field.type]
-        send = _as_tensor(v.data, table.num_rows * w)
-        recv = _as_tensor(result.column_view(i).data, total * w)
-        all_gather_bytes(send, recv, counts, w, group)
-    torch.cuda.synchronize()
-    return result
 
 
 def gather_key_ranges(probe_range, build_range, group=None):
@@ -256,85 +369,6 @@ def pruned_send_ranges(probe_ranges, my_build_range):
         lo, hi = max(pr[0], my_build_range[0]), min(pr[1], my_build_range[1])
         out.append((lo, hi) if lo <= hi else None)
     return out
-
-
-def _key_range(table, key):
-    """(min, max) of an integer key column of a DeviceTable, None if it has no non-null row"""
-    from . import ops
-    lo, hi, n, _ = ops.column_minmax(table, key)
-    return None if n == 0 else (lo, hi)
-
-
-def pruned_broadcast_table(build, build_key, probe, probe_key, group=None, force=False, stats=None):
-    """CollectLeft with the broadcast pruned by the destinations' probe-key bounds: rank r receives from every rank
-    only the build rows whose key lies inside [min, max] of r's probe keys (a superset of what r can match, so the
-    local join is unchanged).  Clustered inputs — TPC-H orders / lineitem in key order, any range-partitioned scan —
-    move almost nothing; uniformly spread keys degrade to the full all-gather (same bytes as broadcast_table).
-    One all-to-all(v) per column; `stats` (optional dict) receives the rows sent / received across ranks."""
-    import pyarrow as pa
-    import torch
-    import torch.distributed as dist
-
-    from . import _lib, ops
-    from ._lib import Field, check
-    from .expr import col, lit
-    from .table import DeviceTable
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if world == 1 and not force:
-        return build
-    ktype = build.schema.field(build.schema.get_field_index(build_key)).type
-    if ktype not in (pa.int64(), pa.int32()):
-        return broadcast_table(build, group, force)
-    lib = _lib.load()
-    my_range = _key_range(build, build_key)
-    probe_ranges, build_ranges = gather_key_ranges(_key_range(probe, probe_key), my_range, group=group)
-    sends = pruned_send_ranges(probe_ranges, my_range)
-
-    def part_for(sr):
-        if sr is None:
-            return build.slice(0, 0)
-        if sr == my_range:
-            return build.select(list(range(build.num_columns)))  # the bounds cover this whole shard: a zero-copy view, no filter pass
-        return ops.filter(build, (col(build_key) >= lit(sr[0], ktype)).and_(col(build_key) <= lit(sr[1], ktype)))
-
-    if nothing_crosses_ranks(probe_ranges, build_ranges):
-        own = part_for(sends[rank])                             # the local shard (pruned to the local bounds) is the build side
-        if stats is not None:
-            stats.update(rows_sent_to_peers=0, rows_received_from_peers=0, build_rows_local=build.num_rows, build_rows_after_exchange=own.num_rows)
-        return own
-    parts = [part_for(sr) for sr in sends]
-    send_counts = [p.num_rows for p in parts]
-    recv_counts = exchange_counts(send_counts, group)
-    total = sum(recv_counts)
-    if stats is not None:
-        stats.update(rows_sent_to_peers=sum(send_counts) - send_counts[rank], rows_received_from_peers=total - recv_counts[rank],
-                     build_rows_local=build.num_rows, build_rows_after_exchange=total)
-    nonempty = [p for p in parts if p.num_rows]
-    packed = nonempty[0].select(list(range(nonempty[0].num_columns))) if len(nonempty) == 1 else (DeviceTable.concat(parts) if nonempty else build.slice(0, 0))
-    ncols = build.num_columns
-    views = [packed.column_view(i) for i in range(ncols)]
-    fields = (Field * ncols)(*[v.field for v in views])
-    names = (C.c_char_p * ncols)(*[v.name for v in views])
-    out = C.c_void_p()
-    check(lib.dfgpu_table_alloc(ncols, fields, names, C.c_int64(total), C.byref(out)))
-    result = DeviceTable(out)
-    ops.sync()
-    n_send = sum(send_counts)
-    for i in range(ncols):
-        v = views[i]
-        if v.validity:
-            raise _lib.DfgpuError("pruned_broadcast_table: nullable columns are not supported yet")
-        w = _W[v.field.type]
-        send = _as_tensor(v.data, n_send * w)
-        recv = _as_tensor(result.column_view(i).data, total * w)
-        all_to_all_bytes(send, send_counts, recv, recv_counts, w, group)
-    torch.cuda.synchronize()
-    for p in parts:
-        p.free()
-    packed.free()
-    return result
 
 
 def broadcast_build_moves_fewer_bytes(build_bytes, probe_bytes, world):

@@ -222,8 +222,7 @@ class RepartitionExec(_Unary):
 class CoalescePartitionsExec(_Unary):
     """CoalescePartitionsExec::new(input) (coalesce_partitions.rs:50): all input partitions into one, in arrival
     order.  One partition per GPU: with one GPU nothing happens, with several every rank receives the
-    concatenation of the ranks' partitions (they are partial aggregate states — a handful of rows — wherever the
-    pinned plans use it), so they travel as host objects like SortPreservingMergeExec's inputs."""
+    concatenation of the ranks' partitions in rank order — a device all-gather (dfgpu_exchange_broadcast)."""
 
     def __init__(self, input: ExecutionPlan, group=None):
         self.input, self.group = input, group
@@ -235,14 +234,12 @@ class CoalescePartitionsExec(_Unary):
         from .queries import _world
         if _world(self.group) == 1:
             return self._pass_through(self.input)
-        import pyarrow as pa
-        import torch.distributed as dist
+        from .exchange import broadcast_table
         t, owned = self._run_child(self.input)
-        parts = [None] * dist.get_world_size(self.group)
-        dist.all_gather_object(parts, t.to_arrow(), group=self.group)
-        if owned:
+        out = broadcast_table(t, self.group)
+        if owned and out is not t:
             t.free()
-        return DeviceTable.from_arrow(pa.concat_tables(parts))
+        return out
 
 
 class SortPreservingMergeExec(_Unary):

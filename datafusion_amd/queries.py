@@ -48,16 +48,15 @@ def _repartition(table: DeviceTable, keys, group=None) -> DeviceTable:
 
 def _merge_sorted(table: DeviceTable, keys, fetch, group=None) -> DeviceTable:
     """SortPreservingMergeExec(fetch): every rank contributes its (already sorted, <= fetch rows)
-    partition; the merged result is replicated on all ranks.  The inputs are a handful of rows,
-    so they travel as host objects and the merge is one more device sort."""
+    partition; the merged result is replicated on all ranks: a device all-gather (dfgpu_exchange_broadcast:
+    values, validity bitmaps and dictionaries cross below the C ABI) and one more device sort."""
     if _world(group) == 1:
         return table
-    import torch.distributed as dist
-    mine = table.to_arrow()
-    parts = [None] * dist.get_world_size(group)
-    dist.all_gather_object(parts, mine, group=group)
-    merged = DeviceTable.from_arrow(pa.concat_tables(parts))
-    return ops.sort(merged, keys, fetch=fetch)
+    from .exchange import broadcast_table
+    merged = broadcast_table(table, group)
+    out = ops.sort(merged, keys, fetch=fetch)
+    merged.free()
+    return out
 
 
 # ------------------------------------------------------------------------------------ Q1

@@ -409,6 +409,60 @@ int dfgpu_partition(dfgpu_table_t input, const int* key_cols, int nkeys, int npa
 /* create_hashes (common/src/hash_utils.rs:1239) for tests / routing checks */
 int dfgpu_hash_columns(dfgpu_table_t input, const int* key_cols, int nkeys, uint64_t seed, uint64_t* out_device);
 
+/* -------------------------------------------------------- multi-GPU exchange */
+
+/* The exchange step of a distributed plan, below the C ABI (SURVEY §8b dfgpu_exchange, §8e):
+ *   RepartitionExec(Partitioning::Hash(keys, n)) across GPUs (physical-plan/src/repartition/mod.rs:1097-1150, channels
+ *   :154-360) = partition kernel + all-to-all(v); PartitionMode::CollectLeft's collected build side
+ *   (joins/hash_join/exec.rs:1325-1328) = all-gather, optionally pruned by the destinations' probe-key bounds
+ *   (hash_join/shared_bounds.rs:277-284 turned around).  In the reference these are in-process channels between partition
+ *   tasks; here a partition is a GPU and the channel is RCCL over xGMI (grouped ncclSend / ncclRecv, one slice per link).
+ * A communicator spans `world` ranks, one GPU each:
+ *   - one process per GPU: rank 0 calls dfgpu_comm_unique_id, the host engine hands the 128 bytes to the other processes,
+ *     every process calls dfgpu_comm_init_rank on its current device (a collective: returns when all ranks arrived);
+ *   - one process, several GPUs: dfgpu_comm_init_all makes the devices given to dfgpu_init ranks 0..n-1;
+ *   - dfgpu_comm_init_host: the same protocol over collectives the embedding engine supplies on host memory (an engine
+ *     that spans nodes with its own transport; tests that run two ranks on one GPU).
+ * Every exchange call is a collective over the communicator and takes / returns ONE table per local rank (arrays of
+ * dfgpu_comm_info.n_local entries: 1 unless dfgpu_comm_init_all made the communicator).  Value buffers, validity bitmaps,
+ * Boolean columns and dictionary-encoded strings cross: ranks whose dictionaries differ merge them (ascending, identical
+ * on every rank) and rewrite their indices first, so routing / joining / grouping on the indices means the strings
+ * everywhere.  Results hold the rows received from rank 0, 1, ... in that order, each sender's rows in its own order. */
+typedef struct dfgpu_comm_s* dfgpu_comm_t;
+#define DFGPU_COMM_ID_BYTES 128
+int dfgpu_comm_unique_id(uint8_t* out_id /* DFGPU_COMM_ID_BYTES */);
+int dfgpu_comm_init_rank(const uint8_t* id /* DFGPU_COMM_ID_BYTES */, int world, int rank, dfgpu_comm_t* out);
+int dfgpu_comm_init_all(dfgpu_comm_t* out);
+typedef struct dfgpu_host_transport {
+  void* ctx;
+  /* send[p] (send_bytes[p] bytes, host memory) goes to rank p, recv[p] receives recv_bytes[p] bytes from it; entries
+   * of the calling rank itself are empty.  Returns 0 on success. */
+  int (*alltoallv)(void* ctx, const void* const* send, const int64_t* send_bytes, void* const* recv, const int64_t* recv_bytes);
+  /* every rank contributes `bytes` bytes; `all` receives world * bytes in rank order */
+  int (*allgather)(void* ctx, const void* mine, int64_t bytes, void* all);
+} dfgpu_host_transport;
+int dfgpu_comm_init_host(const dfgpu_host_transport* transport, int world, int rank, dfgpu_comm_t* out);
+int dfgpu_comm_free(dfgpu_comm_t comm);
+int dfgpu_comm_info(dfgpu_comm_t comm, int* world, int* first_rank, int* n_local);
+/* RepartitionExec(Hash): outs[l] = every row (of all ranks) with hash(keys; seed 0) % world == rank of local l —
+ * routing is dfgpu_partition's, so co-partitioned inputs meet on one GPU (hash_join/exec.rs:1312-1324) */
+int dfgpu_exchange_hash(dfgpu_comm_t comm, const dfgpu_table_t* inputs, const int* key_cols, int nkeys, dfgpu_table_t* outs);
+/* all-gather: outs[l] = the rows of all ranks in rank order (CollectLeft's build side; CoalescePartitionsExec to every rank) */
+int dfgpu_exchange_broadcast(dfgpu_comm_t comm, const dfgpu_table_t* inputs, dfgpu_table_t* outs);
+/* the all-gather of a build side pruned by bounds: rank r receives only build rows whose key lies inside [min, max] of
+ * r's own probe keys — a superset of what it can match, so the local join is unchanged.  Inputs clustered by key (scans
+ * of range-partitioned data) move almost nothing; uniformly spread keys degrade to the full all-gather.  Integer keys. */
+int dfgpu_exchange_broadcast_pruned(dfgpu_comm_t comm, const dfgpu_table_t* builds, int build_key, const dfgpu_table_t* probes, int probe_key,
+                                    dfgpu_table_t* outs);
+/* what crossed GPU boundaries since the communicator was created / last reset (summed over this process's local ranks) */
+typedef struct dfgpu_exchange_stats {
+  int64_t bytes_sent_to_peers, bytes_received_from_peers;
+  int64_t rows_sent_to_peers, rows_received_from_peers;
+  int64_t messages;     /* point-to-point sends issued (a slice above DFGPU_EXCHANGE_MAX_MESSAGE_BYTES, default 1 GiB, is cut) */
+  int64_t collectives;  /* grouped all-to-all(v) rounds */
+} dfgpu_exchange_stats;
+int dfgpu_comm_stats(dfgpu_comm_t comm, dfgpu_exchange_stats* out, int reset);
+
 /* ----------------------------------------------------------- scan -> device */
 
 /* One Parquet column chunk decoded straight into a device column.  The reference's scan

@@ -1,0 +1,191 @@
+"""The multi-GPU exchange below the C ABI (dfgpu_comm_* / dfgpu_exchange_*, datafusion_amd/csrc/exchange.hip) on the GPU box.
+
+A 1-GPU box offers two ways to run the N > 1 code: a one-rank RCCL communicator (every slice is a self slice: partitioning,
+metadata all-gathers through RCCL, result assembly, validity / Boolean / dictionary handling all run, nothing crosses a
+link), and TWO processes sharing the GPU whose communicator uses the host transport over a gloo group
+(dfgpu_comm_init_host) — real two-rank exchanges of device tables: counts, offsets, bitmap re-basing and dictionary merging
+are exercised with peers, only the wire differs from RCCL.  The device plan nodes of physical_plan.py (RepartitionExec,
+CoalescePartitionsExec, SortPreservingMergeExec, Partitioned hash joins, Partial -> FinalPartitioned aggregates) run the
+reference's pinned TPC-H plans that way on 2 ranks down to the reference's answers."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from tests.util import assert_tables_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dict_col(codes, values, index_type=pa.int32(), mask=None):
+    return pa.DictionaryArray.from_arrays(pa.array(codes, type=index_type, mask=mask), pa.array(values, type=pa.string()))
+
+
+def decoded(t: pa.Table) -> pa.Table:
+    return pa.table({n: (c.cast(pa.string()) if pa.types.is_dictionary(c.type) else c) for n, c in zip(t.column_names, t.columns)})
+
+
+def mixed_table(seed, n, values=("AIR", "MAIL", "RAIL", "SHIP", "TRUCK")):
+    """integer key, Decimal128 payload, a nullable int column, a Boolean column and a dictionary-encoded string column with NULLs"""
+    rng = np.random.default_rng(seed)
+    return pa.table({
+        "k": pa.array(rng.integers(0, 10**6, n), type=pa.int64()),
+        "d": pa.array([None if x % 11 == 0 else int(x) for x in rng.integers(0, 10**9, n)], type=pa.decimal128(15, 2)),
+        "q": pa.array(rng.integers(0, 1000, n), type=pa.int32(), mask=rng.random(n) < 0.2),
+        "b": pa.array(rng.random(n) < 0.4, type=pa.bool_(), mask=rng.random(n) < 0.1),
+        "s": dict_col(rng.integers(0, len(values), n), list(values), mask=rng.random(n) < 0.15),
+    })
+
+
+# ---------------------------------------------------------------------------------------- one rank, RCCL communicator
+@pytest.mark.parametrize("n", [0, 1, 5000, 100_003])
+def test_one_rank_rccl_exchanges_carry_nulls_booleans_and_dictionaries(n):
+    from datafusion_amd.exchange import Comm
+    from datafusion_amd.table import DeviceTable
+    t = mixed_table(1, n)
+    c = Comm.single()
+    d = DeviceTable.from_arrow(t)
+    for out in (c.hash_exchange(d, ["k"]), c.hash_exchange(d, ["s", "q"]), c.broadcast(d)):
+        got = out.to_arrow()
+        assert pa.types.is_dictionary(got.schema.field("s").type)
+        assert_tables_equal(decoded(got), decoded(t), ordered=True)     # one rank: one partition, order kept
+    st = c.stats()
+    assert st["bytes_sent_to_peers"] == 0 and st["collectives"] >= 3
+    c.free()
+
+
+def test_one_rank_pruned_broadcast_keeps_rows_inside_the_probe_bounds():
+    import pyarrow.compute as pc
+
+    from datafusion_amd.exchange import Comm
+    from datafusion_amd.table import DeviceTable
+    t = mixed_table(2, 50_000)
+    probe = pa.table({"k2": pa.array(np.random.default_rng(3).integers(200_000, 600_001, 20_000), type=pa.int64())})
+    c = Comm.single()
+    got = c.broadcast_pruned(DeviceTable.from_arrow(t), "k", DeviceTable.from_arrow(probe), "k2").to_arrow()
+    lo, hi = pc.min(probe.column("k2")).as_py(), pc.max(probe.column("k2")).as_py()
+    exp = t.filter(pc.and_(pc.greater_equal(t.column("k"), lo), pc.less_equal(t.column("k"), hi)))
+    assert 0 < exp.num_rows < t.num_rows
+    assert_tables_equal(decoded(got), decoded(exp), ordered=True)
+    c.free()
+
+
+# ---------------------------------------------------------------------------------------- two ranks on one GPU (host transport)
+_WORKER = r"""
+import os, pickle, sys
+import numpy as np, pyarrow as pa
+import torch.distributed as dist
+sys.path.insert(0, os.environ["DFGPU_ROOT"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from datafusion_amd import _lib
+_lib.init(0)                                   # both ranks share GPU 0
+from datafusion_amd.table import DeviceTable
+out = {}
+mode = os.environ["DFGPU_TEST_MODE"]
+if mode == "exchange":
+    from datafusion_amd.exchange import comm_for
+    from tests.test_gpu_exchange import mixed_table, decoded
+    # every rank encodes its strings with its OWN dictionary (different value sets, different order)
+    values = [("RAIL", "AIR", "TRUCK", "FOB"), ("SHIP", "AIR", "MAIL", "REG AIR", "TRUCK")][rank % 2]
+    t = mixed_table(10 + rank, 20_000 + 777 * rank, values)
+    d = DeviceTable.from_arrow(t)
+    c = comm_for()
+    assert c.world == world and c.rank == rank
+    out["input"] = decoded(t)
+    out["hash_k"] = decoded(c.hash_exchange(d, ["k"]).to_arrow())
+    out["hash_s"] = decoded(c.hash_exchange(d, ["s"]).to_arrow())
+    out["broadcast"] = decoded(c.broadcast(d).to_arrow())
+    probe = pa.table({"k2": pa.array(np.random.default_rng(50 + rank).integers(300_000 * rank, 300_000 * rank + 400_000, 5000), type=pa.int64())})
+    out["probe"] = probe
+    out["pruned"] = decoded(c.broadcast_pruned(d, "k", DeviceTable.from_arrow(probe), "k2").to_arrow())
+    out["stats"] = c.stats()
+elif mode == "plans":
+    from datafusion_amd import physical_plan as P
+    from tests.test_tpch_answers import data, plans
+    tables = {}
+    for name, t in data().items():             # this rank's row range of every table: what `world` scans produce
+        lo, hi = t.num_rows * rank // world, t.num_rows * (rank + 1) // world
+        tables[name] = DeviceTable.from_arrow(t.slice(lo, hi - lo))
+    for q, plan in plans(tables).items():
+        opt = P.GpuOffloadRule(world_size=world).optimize(plan)
+        out[q] = P.collect(opt).to_arrow()
+        if q in ("q1", "q3"):
+            out[q + "_pinned"] = P.collect(plan).to_arrow()
+pickle.dump(out, open(os.path.join(os.environ["DFGPU_OUT"], f"r{rank}.pkl"), "wb"))
+dist.barrier()
+print("WORKER_OK", flush=True)
+os._exit(0)
+"""
+
+
+def _run_ranks(tmp_path, world, mode, port):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), DFGPU_ROOT=ROOT,
+                   DFGPU_OUT=str(tmp_path), DFGPU_TEST_MODE=mode)
+        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for r, (so, se) in enumerate(outs):
+        assert "WORKER_OK" in so, f"rank {r}:\n{so[-2000:]}\n{se[-4000:]}"
+    return [pickle.load(open(tmp_path / f"r{r}.pkl", "rb")) for r in range(world)]
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_exchange_device_tables_with_different_dictionaries_and_nulls(tmp_path):
+    import pyarrow.compute as pc
+
+    from oracle import oracle
+    world = 2
+    res = _run_ranks(tmp_path, world, "exchange", _free_port())
+    inputs = [r["input"] for r in res]
+    whole = pa.concat_tables(inputs)
+    # RepartitionExec(Hash(k)): rank r holds exactly the rows the oracle routes to r, sender by sender in sender order
+    for r in range(world):
+        exp = pa.concat_tables([oracle.hash_partition(inp.select(["k"]).append_column("row", pa.array(np.arange(inp.num_rows))), ["k"], world)[0][r]
+                                for inp in inputs])
+        got = res[r]["hash_k"]
+        assert got.column("k").to_pylist() == exp.column("k").to_pylist()
+    assert_tables_equal(pa.concat_tables([r["hash_k"] for r in res]), whole, ordered=False)
+    # routing on the string column: the ranks' dictionaries differ, yet every string (and NULL) meets on ONE rank and nothing is lost
+    assert_tables_equal(pa.concat_tables([r["hash_s"] for r in res]), whole, ordered=False)
+    homes = {}
+    for r in range(world):
+        for v in set(res[r]["hash_s"].column("s").to_pylist()):
+            assert homes.setdefault(v, r) == r, f"string {v!r} was routed to two ranks"
+    assert len(set(homes.values())) == world                      # and both ranks got something
+    # all-gather: every rank holds all rows in rank order
+    for r in range(world):
+        assert_tables_equal(res[r]["broadcast"], whole, ordered=True)
+    # pruned all-gather: rank r holds the build rows (of all ranks, rank order) inside r's own probe bounds
+    for r in range(world):
+        lo, hi = pc.min(res[r]["probe"].column("k2")).as_py(), pc.max(res[r]["probe"].column("k2")).as_py()
+        exp = whole.filter(pc.and_(pc.greater_equal(whole.column("k"), lo), pc.less_equal(whole.column("k"), hi)))
+        assert_tables_equal(res[r]["pruned"], exp, ordered=True)
+        assert res[r]["stats"]["bytes_sent_to_peers"] > 0 and res[r]["stats"]["rows_received_from_peers"] > 0
+
+
+def test_device_plans_on_two_ranks_reproduce_the_reference_answers(tmp_path):
+    """the product's plan nodes with N = 2 (device operators + C-ABI exchanges; tests/test_plans_gloo.py runs the same protocol
+    with the oracle's operators on CPU)"""
+    from tests.test_tpch_answers import QUERIES, assert_answer
+    res = _run_ranks(tmp_path, 2, "plans", _free_port())
+    for q in QUERIES:
+        for r in range(2):
+            assert_answer(q, res[r][q])
+    for q in ("q1_pinned", "q3_pinned"):
+        for r in range(2):
+            assert_answer(q[:2], res[r][q])
