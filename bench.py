@@ -7,18 +7,22 @@
 
 A step = one full pass of the hot path over device-resident inputs:
   N = 1 : HashJoinExec build (collect_left_input) + probe (whole lineitem) -> output table.
-  N > 1 : each rank holds a 1/N row range of both tables (what N scans would produce).  The exchange that
-          moves fewer bytes per GPU is used (SURVEY §8e): PartitionMode::CollectLeft = the build side is
-          broadcast (B(N-1)/N bytes received per GPU at most) when B*N < B+P — the SF100 Q3 join up to N = 8 —
-          else PartitionMode::Partitioned = K10 partition kernel + RCCL all-to-all of both sides; then the local
-          build + probe.  The broadcast is pruned by each rank's probe-key bounds (exchange.pruned_broadcast_table:
-          a rank only receives build rows inside [min, max] of its own probe keys — the reference's dynamic join
-          filter turned around); shards that arrive clustered by key, like the row ranges used here and like any
-          scan of TPC-H tables in their natural order, therefore move almost nothing, while spread keys fall back
-          to the full all-gather's volume.  `exchange_rank0` on the JSON line says how many rows crossed ranks;
-          --exchange broadcast / repartition force the unpruned exchanges.  Total work is fixed (SF100) =>
-          "strong" scaling.
-value = (build rows + probe rows summed over ranks) / max-over-ranks wall time of the K steps.
+  N > 1 : each rank holds a 1/N row range of both tables (what N scans of tables stored in key order produce; the scan
+          boundaries of the two tables do not line up exactly: --shard-skew, default 1 % of a shard).  Two exchanges
+          are timed, K steps each, and BOTH are on the JSON line under "exchanges" with the bytes that crossed per rank:
+            repartition — PartitionMode::Partitioned as the reference plans this join (hash_join/exec.rs:1312-1324):
+                          dfgpu_exchange_hash of BOTH sides (partition kernel + RCCL all-to-all(v) over xGMI), then
+                          the local build + probe.  Every row crosses with probability (N-1)/N.
+            pruned      — PartitionMode::CollectLeft with the build-side all-gather pruned by each rank's probe-key
+                          bounds (dfgpu_exchange_broadcast_pruned): inputs clustered by key move only the rows
+                          around the shard boundaries; keys spread uniformly degrade to the full all-gather.
+          `value` is the exchange a byte-counting planner picks (broadcast the build side while
+          B*N < B+P — the SF100 Q3 join up to N = 10 — pruned by bounds; else repartition), --exchange forces one.
+          Total work is fixed (SF100) => "strong" scaling.
+  --workload q1 / q3: BASELINE configs 4 and 5 — the whole TPC-H Q1 / Q3 plan per step (queries.q1 / q3: Partial
+          aggregate -> hash exchange of the states -> FinalPartitioned; Q3's four repartitions in two phases), rows of
+          the scanned tables per second.
+value = (input rows summed over ranks) / max-over-ranks wall time of the K steps.
 Inputs are generated on device (no dataset download possible) before the timed region.
 
 Extra objects on the JSON line:
@@ -98,6 +102,269 @@ def cpu_baseline(sample_sf, cores):
     return out
 
 
+def setup_dist(args):
+    """rank / world from the launcher's environment; torch.distributed (backend nccl = RCCL) carries the barrier, the
+    max-over-ranks timing and RCCL's bootstrap id for the library's own communicator — the data path is dfgpu_exchange_*"""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    from datafusion_amd import _lib
+    _lib.init(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return rank, world, local_rank, dist
+
+
+def timed(step, steps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = step()
+    barrier()
+    return time.perf_counter() - t0, last
+
+
+def max_over_ranks(dist, dt, *sums):
+    """(max dt over ranks, sums over ranks)"""
+    import torch
+    if dist is None:
+        return dt, [int(x) for x in sums]
+    mx = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(x) for x in sums], dtype=torch.float64, device="cuda")
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return float(mx[0]), [int(x) for x in tot]
+
+
+def shard_bounds(n_orders, rank, world, skew):
+    """this rank's order range for `orders`, and the (shifted) order range whose lines it holds of `lineitem`: two scans of
+    tables stored in key order cut them at row counts that do not fall on the same keys"""
+    def cut(r):
+        return n_orders * r // world
+    b, e = cut(rank), cut(rank + 1)
+    shift = int(skew * (n_orders // world)) if world > 1 else 0
+    lb = b + shift if rank > 0 else 0
+    le = e + shift if rank < world - 1 else n_orders
+    return (b, e), (lb, le)
+
+
+def run_join(args, rank, world, dist):
+    import torch
+
+    from datafusion_amd import ops, tpch
+    from datafusion_amd.exchange import broadcast_build_moves_fewer_bytes, comm_for
+    n_orders = tpch.n_orders(args.sf)
+    (b, e), (lb, le) = shard_bounds(n_orders, rank, world, args.shard_skew)
+    orders = ops.tpch_orders(args.sf, b, e).select(["o_orderkey", "o_orderdate", "o_shippriority"])
+    lineitem = ops.tpch_lineitem(args.sf, lb, le).select(["l_orderkey", "l_extendedprice", "l_discount"])
+    nb_local, np_local = orders.num_rows, lineitem.num_rows
+    ops.sync()
+    forced = world == 1 and args.exchange != "auto"   # one-rank rehearsal of the N > 1 code on a 1-GPU box
+    comm = comm_for(None, force=forced) if (world > 1 or forced) else None
+
+    def barrier():
+        ops.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def make_step(exchange, probe_mode):
+        def step():
+            o, l = orders, lineitem
+            if exchange == "pruned":
+                o = comm.broadcast_pruned(orders, "o_orderkey", lineitem, "l_orderkey")
+            elif exchange == "broadcast":
+                o = comm.broadcast(orders)
+            elif exchange == "repartition":
+                o = comm.hash_exchange(orders, ["o_orderkey"])
+                l = comm.hash_exchange(lineitem, ["l_orderkey"])
+            # join-table choice follows the library default (direct-address down to key density 1/64, see
+            # DFGPU_DEFAULT_MIN_KEY_DENSITY in include/dfgpu.h): hash routing leaves each rank 1/N of the keys over the
+            # same key range (density 0.25/N)
+            ht = ops.JoinHashTable(o, ["o_orderkey"], probe_mode=probe_mode)
+            out = ht.probe(l, ["l_orderkey"], "Inner", BUILD_COLS, PROBE_COLS)
+            res = (out.num_rows, ht.info())
+            out.free()
+            ht.free()
+            if o is not orders:
+                o.free()
+            if l is not lineitem:
+                l.free()
+            return res
+        return step
+
+    def measure(exchange, probe_mode, profile):
+        step = make_step(exchange, probe_mode)
+        for _ in range(args.warmup):
+            step()
+        if comm is not None:
+            comm.stats(reset=True)
+        if profile:
+            ops.profile_enable(True)
+            ops.profile_reset()
+        dt, (n_out, info) = timed(step, args.steps, barrier)
+        st = ops.profile_stats() if profile else {}
+        if profile:
+            ops.profile_enable(False)
+        xs = comm.stats(reset=True) if comm is not None else None
+        dt, (nb, np_, nout) = max_over_ranks(dist, dt, nb_local, np_local, n_out)
+        return {"dt": dt, "nb": nb, "np": np_, "nout": nout, "info": info, "stats": st, "xstats": xs}
+
+    if world == 1 and not forced:
+        primary = "none"
+    elif args.exchange != "auto":
+        primary = args.exchange
+    else:
+        tot = max_over_ranks(dist, 0.0, nb_local, np_local)[1]
+        primary = "pruned" if broadcast_build_moves_fewer_bytes(tot[0] * 16, tot[1] * 40, world) else "repartition"
+    m = measure(primary, args.probe_mode, True)
+    others = {}
+    if world > 1 and args.exchange == "auto":
+        for ex in ("repartition", "pruned"):
+            if ex != primary:
+                others[ex] = measure(ex, args.probe_mode, False)
+    # secondary, outside the contract's timed region: the same step with the output in probe order
+    ordered = measure(primary, 0, True) if (args.probe_mode == 3 and world == 1) else None
+    if rank != 0:
+        return None
+    nb, np_, nout, dt, stats, info = m["nb"], m["np"], m["nout"], m["dt"], m["stats"], m["info"]
+    ms_per_step = dt / args.steps * 1e3
+    rows_per_s = (nb + np_) / (dt / args.steps)
+    alg = algorithmic_bytes(nb, np_, nout)
+
+    def roofline_of(st):
+        """the dominant kernel of a step: algorithmic bytes per launch (probe columns once + build payload
+        once + output once, computed by the library per launch) / its average HIP-event duration on the library stream"""
+        name = next((k for k in ("join_probe_fused", "join_probe_placed", "join_probe_materialize") if k in st), None)
+        if name is None or not st[name]["calls"]:
+            return None
+        d = st[name]
+        avg_ms = d["total_ms"] / d["calls"]
+        per_launch = d["bytes"] / d["calls"]
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_vs_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
+                "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
+        try:  # HBM bytes per launch from the committed PMC passes (scripts/profile.sh), when taken on this very workload and kernel
+            for tr in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]:
+                wl = tr["workload"]
+                if tr["kernel"] == name and (wl["build_rows"], wl["probe_rows"], wl["output_rows"]) == (nb, np_, nout) and world == 1:
+                    roof["traffic"] = tr["traffic_bytes_per_launch"]
+                    roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr["source"]
+        except (OSError, KeyError, ValueError, TypeError):
+            pass
+        return roof
+
+    def kernel_table(st):
+        return {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in st.items()}
+
+    def exchange_summary(mm):
+        per_step = {k: v // args.steps for k, v in mm["xstats"].items()} if mm["xstats"] else None
+        return {"ms_per_step": round(mm["dt"] / args.steps * 1e3, 3), "rows_per_s": (mm["nb"] + mm["np"]) / (mm["dt"] / args.steps),
+                "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map"}[mm["info"].table_kind], "crossed_per_step_rank0": per_step}
+
+    parallelism = {"none": "single GPU",
+                   "pruned": f"CollectLeft x{world}: build-side all-gather pruned by each rank's probe-key bounds (dfgpu_exchange_broadcast_pruned, RCCL send/recv), probe side stays in place",
+                   "broadcast": f"CollectLeft x{world}: RCCL all-gather of the build side (dfgpu_exchange_broadcast), probe side stays in place",
+                   "repartition": f"Partitioned x{world}: hash repartition of both sides (dfgpu_exchange_hash: partition kernel + RCCL all-to-all(v))"}[primary]
+    line = {
+        "metric": "tpch_q3_hash_join_rows_per_sec", "value": rows_per_s, "unit": "rows/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "int64 keys / decimal128 payload", "data": "synthetic",
+        "config": {"workload": f"INNER hash-join orders⋈lineitem on o_orderkey, TPC-H SF{args.sf:g}, Q3 payload "
+                               "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
+                   "build_rows": nb, "probe_rows": np_, "output_rows": nout,
+                   "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map"}[info.table_kind],
+                   "probe": {0: "placed_ordered", 1: "placed_ordered", 2: "single_pass_ordered_lookback", 3: "single_pass_unordered"}[args.probe_mode],
+                   "parallelism": parallelism, "exchange": primary, "shard_skew": args.shard_skew if world > 1 else None},
+        "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),
+        "hbm_frac_whole_step": round(alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
+        "roofline": roofline_of(stats), "kernels": kernel_table(stats),
+    }
+    if world > 1 or forced:
+        line["exchanges"] = {primary: exchange_summary(m), **{k: exchange_summary(v) for k, v in others.items()}}
+    if ordered is not None:
+        # the same step with the output in probe order, exactly as the reference emits it (hash_join/exec.rs:3349):
+        # tile counts -> scan -> the fused kernel with known tile offsets
+        oms = ordered["dt"] / args.steps * 1e3
+        line["ordered_output"] = {"probe": "placed (tile counts -> scan -> fused materialise)", "ms_per_step": round(oms, 3),
+                                  "rows_per_s": (nb + np_) / (oms * 1e-3),
+                                  "hbm_frac_whole_step": round(alg / (oms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                  "roofline": roofline_of(ordered["stats"]), "kernels": kernel_table(ordered["stats"])}
+    if not args.no_cpu and world == 1:  # the CPU baseline is reported by the single-GPU run only
+        threads = os.cpu_count() or 1
+        line["cpu_baseline"] = cpu_baseline(args.cpu_sf, threads)
+        line["speedup_vs_cpu_port"] = round(rows_per_s / line["cpu_baseline"]["value"], 1)
+    return line
+
+
+def run_query(args, rank, world, dist):
+    """BASELINE config 4 (TPC-H Q1, grouped hash aggregate, 1 -> 8 GPUs with the hash repartition of the partial states) and
+    config 5 (TPC-H Q3 end to end: 3-way join + aggregate + top-k; four repartitions in two exchange phases at N > 1)"""
+    import torch
+
+    from datafusion_amd import ops, queries, tpch
+    n_orders = tpch.n_orders(args.sf)
+    b, e = n_orders * rank // world, n_orders * (rank + 1) // world
+    lineitem = ops.tpch_lineitem(args.sf, b, e)
+    tables = [lineitem]
+    if args.workload == "q3":
+        nc = tpch.n_customers(args.sf)
+        tables = [ops.tpch_customer(args.sf, nc * rank // world, nc * (rank + 1) // world), ops.tpch_orders(args.sf, b, e), lineitem]
+    rows_local = sum(t.num_rows for t in tables)
+    bytes_local = sum(t.nbytes() for t in tables)
+    ops.sync()
+
+    def barrier():
+        ops.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    group = None  # the default group: queries.* route their RepartitionExecs through exchange.hash_exchange -> dfgpu_exchange_hash
+
+    def step():
+        out = queries.q1(lineitem, group) if args.workload == "q1" else queries.q3(*tables, group=group)
+        n = out.num_rows
+        out.free()
+        return n
+    for _ in range(args.warmup):
+        step()
+    comm = None
+    if world > 1:
+        from datafusion_amd.exchange import comm_for
+        comm = comm_for(group)
+        comm.stats(reset=True)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    dt, n_out = timed(step, args.steps, barrier)
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    xs = comm.stats(reset=True) if comm is not None else None
+    dt, (rows, nbytes) = max_over_ranks(dist, dt, rows_local, bytes_local)
+    if rank != 0:
+        return None
+    top = sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
+    return {
+        "metric": f"tpch_{args.workload}_rows_per_sec", "value": rows / (dt / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "decimal128 / int64", "data": "synthetic",
+        "config": {"workload": ("TPC-H Q1 (FilterExec + ProjectionExec + grouped AggregateExec fused, Partial -> hash exchange -> FinalPartitioned at N > 1)" if args.workload == "q1"
+                                else "TPC-H Q3 end to end (2 hash joins + aggregate + top-k; at N > 1 four hash repartitions in two exchange phases)") + f", SF{args.sf:g}, device-resident inputs",
+                   "input_rows": rows, "output_rows": n_out, "parallelism": "single GPU" if world == 1 else f"{world} ranks, dfgpu_exchange_hash (RCCL all-to-all(v))"},
+        "scanned_table_gb_per_s": round(nbytes / (dt / args.steps) / 1e9, 1),
+        "kernels": {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in top},
+        "crossed_per_step_rank0": {k: v // args.steps for k, v in xs.items()} if xs else None,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,195 +373,22 @@ def main():
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor (BASELINE: 100)")
     ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=["join", "q1", "q3"], default="join",
+                    help="join = the BASELINE metric (config 3 ii); q1 / q3 = the whole TPC-H Q1 / Q3 plan per step (configs 4 and 5)")
     ap.add_argument("--exchange", choices=["auto", "pruned", "broadcast", "repartition"], default="auto",
-                    help="N > 1: pruned = CollectLeft with the build-side broadcast pruned by each rank's probe-key bounds; broadcast = plain "
-                         "all-gather of the build side; repartition = hash-repartition both sides (Partitioned); auto = pruned when a broadcast "
-                         "moves fewer bytes than a repartition, else repartition")
+                    help="N > 1, join workload: auto = time both repartition (Partitioned: hash exchange of both sides) and pruned (CollectLeft, "
+                         "build side pruned by probe-key bounds), `value` = the one a byte-counting planner picks; anything else forces that "
+                         "exchange (at N = 1: a one-rank rehearsal of its code path)")
+    ap.add_argument("--shard-skew", type=float, default=0.01,
+                    help="N > 1: the lineitem shards start this fraction of a shard later than the orders shards (scan boundaries of two tables "
+                         "do not fall on the same keys)")
     ap.add_argument("--probe-mode", type=int, default=3,
                     help="3 single pass, unordered output (default: in Q3 the join feeds AggregateExec, no ancestor needs the probe "
-                         "order); 0/1 two passes, output in probe order; 2 single pass ordered (look-back)")
+                         "order); 0/1 output in probe order (tile counts -> scan -> placed); 2 single pass ordered (look-back)")
     args = ap.parse_args()
-
-    import torch
-
-    from datafusion_amd import _lib, ops
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    _lib.init(local_rank)
-    dist = None
-    forced = world == 1 and args.exchange != "auto"  # one-rank rehearsal of the N > 1 exchange code on a 1-GPU box
-    if world > 1 or forced:
-        import torch.distributed as dist
-        if forced:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29544")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from datafusion_amd import tpch
-    n_orders = tpch.n_orders(args.sf)
-    b, e = n_orders * rank // world, n_orders * (rank + 1) // world
-    orders = ops.tpch_orders(args.sf, b, e).select(["o_orderkey", "o_orderdate", "o_shippriority"])
-    lineitem = ops.tpch_lineitem(args.sf, b, e).select(["l_orderkey", "l_extendedprice", "l_discount"])
-    nb_local, np_local = orders.num_rows, lineitem.num_rows
-    ops.sync()
-
-    exchange = args.exchange if forced else "none"
-    if world > 1:
-        from datafusion_amd.exchange import broadcast_build_moves_fewer_bytes
-        t4 = torch.tensor([float(nb_local), float(np_local)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t4)
-        exchange = args.exchange
-        if exchange == "auto":
-            exchange = "pruned" if broadcast_build_moves_fewer_bytes(int(t4[0]) * 16, int(t4[1]) * 40, world) else "repartition"
-
-    xstats = {}
-
-    def step(probe_mode=args.probe_mode):
-        o, l = orders, lineitem
-        if exchange == "pruned":
-            from datafusion_amd.exchange import pruned_broadcast_table
-            o = pruned_broadcast_table(orders, "o_orderkey", lineitem, "l_orderkey", force=forced, stats=xstats)
-        elif exchange == "broadcast":
-            from datafusion_amd.exchange import broadcast_table
-            o = broadcast_table(orders, force=forced)
-        elif exchange == "repartition":
-            from datafusion_amd.exchange import hash_exchange
-            o = hash_exchange(orders, ["o_orderkey"], force=forced)
-            l = hash_exchange(lineitem, ["l_orderkey"], force=forced)
-        # join-table choice follows the library default (direct-address down to key density 1/64, see
-        # DFGPU_DEFAULT_MIN_KEY_DENSITY in include/dfgpu.h): at N > 1 hash routing leaves each rank 1/N of
-        # the keys over the same key range (density 0.25/N)
-        ht = ops.JoinHashTable(o, ["o_orderkey"], probe_mode=probe_mode)
-        out = ht.probe(l, ["l_orderkey"], "Inner", BUILD_COLS, PROBE_COLS)
-        n_out = out.num_rows
-        info = ht.info()
-        out.free()
-        ht.free()
-        if exchange in ("broadcast", "pruned"):
-            o.free()
-        elif exchange == "repartition":
-            o.free()
-            l.free()
-        return n_out, info
-
-    def barrier():
-        ops.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    ops.profile_enable(True)
-    ops.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    n_out = 0
-    for _ in range(args.steps):
-        n_out, info = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    stats = ops.profile_stats()
-    ops.profile_enable(False)
-    # secondary, outside the contract's timed region: the same step with output in probe order
-    # (two passes), for plans where an ancestor does need HashJoinExec's probe-side ordering
-    ordered_ms, ordered_stats = None, {}
-    if args.probe_mode == 3 and world == 1:
-        step(0)
-        ops.profile_enable(True)
-        ops.profile_reset()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(0)
-        barrier()
-        ordered_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        ordered_stats = ops.profile_stats()
-        ops.profile_enable(False)
-
-    tot = torch.tensor([float(nb_local), float(np_local), float(n_out), dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt = float(mx[3])
-    nb, np_, nout = int(tot[0]), int(tot[1]), int(tot[2])
-
+    rank, world, _local, dist = setup_dist(args)
+    line = run_join(args, rank, world, dist) if args.workload == "join" else run_query(args, rank, world, dist)
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        rows_per_s = (nb + np_) / (dt / args.steps)
-        alg = algorithmic_bytes(nb, np_, nout)
-        def roofline_of(st):
-            """the dominant kernel of a step: algorithmic bytes per launch (probe columns once + build payload
-            once + output once, computed by the library per launch) / its average HIP-event duration on the library stream"""
-            name = next((k for k in ("join_probe_fused", "join_probe_placed", "join_probe_materialize") if k in st), None)
-            if name is None or not st[name]["calls"]:
-                return None
-            d = st[name]
-            avg_ms = d["total_ms"] / d["calls"]
-            per_launch = d["bytes"] / d["calls"]
-            achieved = per_launch / (avg_ms * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_vs_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
-
-        def attach_traffic(roof):
-            """HBM bytes per launch from the committed PMC passes (scripts/profile.sh), when taken on this very workload and kernel"""
-            try:
-                for tr in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]:
-                    wl = tr["workload"]
-                    if tr["kernel"] == roof["kernel"] and (wl["build_rows"], wl["probe_rows"], wl["output_rows"]) == (nb, np_, nout) and world == 1:
-                        roof["traffic"] = tr["traffic_bytes_per_launch"]
-                        roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr["source"]
-            except (OSError, KeyError, ValueError, TypeError):
-                pass
-            return roof
-
-        roof = roofline_of(stats)
-        if roof:
-            attach_traffic(roof)
-        kernels = {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in stats.items()}
-        line = {
-            "metric": "tpch_q3_hash_join_rows_per_sec", "value": rows_per_s, "unit": "rows/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "int64 keys / decimal128 payload", "data": "synthetic",
-            "config": {"workload": f"INNER hash-join orders⋈lineitem on o_orderkey, TPC-H SF{args.sf:g}, Q3 payload "
-                                   "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
-                       "build_rows": nb, "probe_rows": np_, "output_rows": nout,
-                       "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map"}[info.table_kind],
-                       "probe": {0: "placed_ordered", 1: "placed_ordered", 2: "single_pass_ordered_lookback", 3: "single_pass_unordered"}[args.probe_mode],
-                       "parallelism": "single GPU" if world == 1 else
-                       (f"CollectLeft x{world}: build side broadcast pruned by each rank's probe-key bounds (RCCL all-to-all(v)), probe side stays in place"
-                        if exchange == "pruned" else
-                        f"CollectLeft x{world}: RCCL all-gather of the build side, probe side stays in place" if exchange == "broadcast"
-                        else f"Partitioned: hash-repartition all-to-all of both sides x{world}")},
-            "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),
-            "hbm_frac_whole_step": round(alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
-            "roofline": roof, "kernels": kernels,
-        }
-        if xstats:
-            line["exchange_rank0"] = {**xstats, "build_row_bytes": 16}
-        if ordered_ms is not None:
-            # the same step with the output in probe order, exactly as the reference emits it (hash_join/exec.rs:3349):
-            # tile counts -> scan -> the fused kernel with known tile offsets
-            oroof = roofline_of(ordered_stats)
-            line["ordered_output"] = {"probe": "placed (tile counts -> scan -> fused materialise)", "ms_per_step": round(ordered_ms, 3),
-                                      "rows_per_s": (nb + np_) / (ordered_ms * 1e-3),
-                                      "hbm_frac_whole_step": round(alg / (ordered_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
-                                      "roofline": attach_traffic(oroof) if oroof else None,
-                                      "kernels": {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in ordered_stats.items()}}
-        if not args.no_cpu and world == 1:  # the CPU baseline is reported by the single-GPU run only
-            threads = os.cpu_count() or 1
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sf, threads)
-            line["speedup_vs_cpu_port"] = round(rows_per_s / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

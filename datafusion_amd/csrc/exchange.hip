@@ -716,8 +716,10 @@ int dfgpu_exchange_broadcast_pruned(dfgpu_comm_t h, const dfgpu_table_t* builds,
         const bool pany = range(p, 0, plo, phi);
         const long long lo = std::max(plo, (long long)bstats[l].min), hi = std::min(phi, (long long)bstats[l].max);
         if (!pany || bstats[l].valid == 0 || lo > hi) {
-          BufPtr zero = make_zero_buf(bitmap_bytes(b[l].nrows));
-          parts[l].push_back(compact_table(b[l], allc, zero->as<uint64_t>(), nullptr));
+          Table none;  // nothing of this shard can match on rank p
+          none.nrows = 0;
+          for (const Column& col : b[l].cols) none.cols.push_back(alloc_like(col, 0));
+          parts[l].push_back(std::move(none));
         } else if (lo == bstats[l].min && hi == bstats[l].max && !kc.validity) {
           parts[l].push_back(b[l]);  // the bounds cover the whole shard: a view, no filter pass
         } else {

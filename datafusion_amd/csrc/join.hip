@@ -345,7 +345,7 @@ __device__ __forceinline__ bool chain_match(const ProbeCtx& c, int64_t b, int64_
 // stage (keys -> validity -> table words -> perm) issues its N loads together; out-of-range lanes
 // load a clamped address and are masked afterwards, so there is no branch between the loads.
 template <int KIND, int KT, int N>
-__device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int64_t np, uint32_t (&m)[N]) {
+__device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int64_t np, uint32_t (&m)[N], uint64_t* raw_keys = nullptr) {
   const unsigned lane = lane_id();
   if (KIND == KIND_HASH) {
 #pragma unroll
@@ -368,7 +368,9 @@ __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int6
   for (int j = 0; j < N; j++) {
     int64_t p = ((w0 + j) << 6) + lane;
     ok[j] = p < np;
-    idx[j] = load_key<KT>(k, ok[j] ? p : np - 1) - c.am_offset;
+    idx[j] = load_key<KT>(k, ok[j] ? p : np - 1);
+    if (raw_keys) raw_keys[j] = idx[j];  // the caller writes the key column of the output from registers (no second read)
+    idx[j] -= c.am_offset;
     if (c.row_mask) ok[j] = ok[j] && ((c.row_mask[w0 + j] >> lane) & 1ull);  // filtered-out rows skip the table lookups
   }
   if (k.valid) {  // direct-address tables are never built with NULL==NULL + NULL build keys: a NULL probe key matches nothing
@@ -528,6 +530,8 @@ struct JoinCopyCols {
   int width[MAX_JOIN_COLS];
   int n_build;  // first n_build entries gather from the build side, the rest stream the probe side
   int n;
+  int key_col;  // entry that is the probe key column itself (single integer key, direct-address kinds): written from the
+                // registers the lookup loaded it into instead of being read a second time; -1 = none
 };
 template <typename T>
 __device__ __forceinline__ void jcopy(const void* src, void* dst, int64_t s, int64_t d) {
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_tile_counts(ProbeCtx c, int64_t 
 }
 
 enum FusedMode : int { FUSED_UNORDERED = 0, FUSED_LOOKBACK = 1, FUSED_PLACED = 2 };
-template <int KIND, int KT, int W, int MODE>
+template <int KIND, int KT, int W, int MODE, bool KEYREG>
 __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopyCols cols, int64_t np, int invert, uint64_t* __restrict__ tile_state,
                                                             FusedCtl* __restrict__ ctl, const uint64_t* __restrict__ row_mask) {
   constexpr bool ORDERED = MODE == FUSED_LOOKBACK;
@@ -717,7 +721,8 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
 
     // ---- lookup (every stage issues its W loads back-to-back: memory-level parallelism)
     uint32_t m[W];
-    lookup_words<KIND, KT, W>(c, w0, np, m);
+    uint64_t key[KEYREG ? W : 1];
+    lookup_words<KIND, KT, W>(c, w0, np, m, KEYREG ? key : nullptr);
     uint64_t word[W];  // wave-uniform (SGPR pairs)
     uint32_t wave_cnt = 0;
 #pragma unroll
@@ -763,6 +768,12 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
         const int64_t d = (int64_t)(ob + mbcnt(word[j]));
         ob += (uint32_t)__popcll(word[j]);
         if (!((word[j] >> lane) & 1ull)) continue;
+        if (KEYREG && cidx == cols.key_col) {  // a tile's key lines have left the L2 by now (256 tiles x ~100 KB are in flight)
+          if (KT == KT_I64) reinterpret_cast<uint64_t*>(cols.dst[cidx])[d] = key[KEYREG ? j : 0];
+          else if (KT == KT_U8) reinterpret_cast<uint8_t*>(cols.dst[cidx])[d] = (uint8_t)key[KEYREG ? j : 0];
+          else reinterpret_cast<uint32_t*>(cols.dst[cidx])[d] = (uint32_t)key[KEYREG ? j : 0];
+          continue;
+        }
         const int64_t s = from_build ? (int64_t)m[j] - 1 : ((w0 + j) << 6) + lane;
         switch (width) {
           case 16: jcopy<uint4>(cols.src[cidx], cols.dst[cidx], s, d); break;
@@ -1223,6 +1234,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       n_alloc = (int64_t)read_u64(state->as<uint64_t>() + n_tiles);
     }
     JoinCopyCols jc{};
+    jc.key_col = -1;
     int64_t bytes_in = key_bytes, bytes_per_out = 0, bytes_build_once = 0;
     for (int c : bout) {
       const Column& sc = jt.build.cols[c];
@@ -1244,6 +1256,8 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       bool is_key = false;
       for (int k : pk) is_key |= k == c;
       if (!is_key) bytes_in += np * jc.width[jc.n];  // a key column that is also payload is read once
+      static const bool keyreg = !(std::getenv("DFGPU_JOIN_KEYREG") && std::getenv("DFGPU_JOIN_KEYREG")[0] == '0');  // A/B knob
+      if (keyreg && is_key && jt.kind != KIND_HASH && pk.size() == 1 && jc.key_col < 0 && !sc.validity) jc.key_col = jc.n;
       bytes_per_out += jc.width[jc.n];
       jc.n++;
     }
@@ -1261,9 +1275,15 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>(), row_mask); };
       with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
         constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
-        if (fused_mode == FUSED_LOOKBACK) launch(k_join_probe_fused<K, T, FUSED_W, FUSED_LOOKBACK>);
-        else if (fused_mode == FUSED_PLACED) launch(k_join_probe_fused<K, T, FUSED_W, FUSED_PLACED>);
-        else launch(k_join_probe_fused<K, T, FUSED_W, FUSED_UNORDERED>);
+        constexpr bool KR = K != KIND_HASH;  // the direct-address kinds hold the one integer key in registers
+        if (fused_mode == FUSED_LOOKBACK) launch(k_join_probe_fused<K, T, FUSED_W, FUSED_LOOKBACK, false>);
+        else if (fused_mode == FUSED_PLACED) {
+          if (KR && jc.key_col >= 0) launch(k_join_probe_fused<K, T, FUSED_W, FUSED_PLACED, KR>);
+          else launch(k_join_probe_fused<K, T, FUSED_W, FUSED_PLACED, false>);
+        } else {
+          if (KR && jc.key_col >= 0) launch(k_join_probe_fused<K, T, FUSED_W, FUSED_UNORDERED, KR>);
+          else launch(k_join_probe_fused<K, T, FUSED_W, FUSED_UNORDERED, false>);
+        }
       });
       DFGPU_HIP(hipGetLastError());
       if (r.profiling) DFGPU_HIP(hipEventRecord(eb, r.stream));

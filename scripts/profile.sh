@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-(timeout 600 python bench.py "$@") > $OUT/bench.json 2> $OUT/bench.err
+(timeout 900 python bench.py "$@") > $OUT/bench.json 2> $OUT/bench.err
 export TMPDIR=/tmp
 cd /tmp
 (timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- python $R/bench.py "$@" --no-cpu) > $OUT/stats.log 2>&1
