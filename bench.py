@@ -268,7 +268,7 @@ def run_join(args, rank, world, dist):
     def exchange_summary(mm):
         per_step = {k: v // args.steps for k, v in mm["xstats"].items()} if mm["xstats"] else None
         return {"ms_per_step": round(mm["dt"] / args.steps * 1e3, 3), "rows_per_s": (mm["nb"] + mm["np"]) / (mm["dt"] / args.steps),
-                "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map"}[mm["info"].table_kind], "crossed_per_step_rank0": per_step}
+                "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map", 3: "radix_lds"}[mm["info"].table_kind], "crossed_per_step_rank0": per_step}
 
     parallelism = {"none": "single GPU",
                    "pruned": f"CollectLeft x{world}: build-side all-gather pruned by each rank's probe-key bounds (dfgpu_exchange_broadcast_pruned, RCCL send/recv), probe side stays in place",
@@ -281,7 +281,7 @@ def run_join(args, rank, world, dist):
         "config": {"workload": f"INNER hash-join orders⋈lineitem on o_orderkey, TPC-H SF{args.sf:g}, Q3 payload "
                                "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
                    "build_rows": nb, "probe_rows": np_, "output_rows": nout,
-                   "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map"}[info.table_kind],
+                   "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map", 3: "radix_lds"}[info.table_kind],
                    "probe": {0: "placed_ordered", 1: "placed_ordered", 2: "single_pass_ordered_lookback", 3: "single_pass_unordered"}[args.probe_mode],
                    "parallelism": parallelism, "exchange": primary, "shard_skew": args.shard_skew if world > 1 else None},
         "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),

@@ -260,6 +260,19 @@ void bitmap_place(const uint64_t* src, int64_t off, int64_t n, uint64_t* dst);
 // min / max / non-null count / strictly-ascending flag of an integer column, cached on the column
 ColStats column_stats(Column& c, int64_t nrows);
 
+// ----------------------------------------------------------------- radix passes (sort.hip)
+// (key u64, row id u32) pairs stably sorted by bits [lo_bit, lo_bit + nbits) of the key; `idx` null on entry = row id is the position
+void radix_sort_pairs(BufPtr& key, BufPtr& idx, int64_t n, int lo_bit, int nbits);
+
+// ----------------------------------------------------------------- LDS radix join (radix_join.hip)
+struct RadixTable;
+std::shared_ptr<RadixTable> radix_join_build(const Table& build, const std::vector<int>& key_cols, bool null_equals_null, bool force_collisions);
+int64_t radix_join_table_bytes(const RadixTable& t);
+int radix_join_bits(const RadixTable& t);
+// (build row, probe row) of every key-equal pair, in partition order; m pairs of int64
+void radix_join_pairs(const RadixTable& t, const Table& build, const std::vector<int>& build_keys, const Table& probe, const std::vector<int>& probe_keys,
+                      bool null_equals_null, bool force_collisions, BufPtr& out_b, BufPtr& out_p, int64_t& m);
+
 // ----------------------------------------------------------------- hashing (partition.hip)
 // RepartitionExec(Hash): nparts tables, row order kept inside each (slices of one buffer per column when nothing is nullable)
 std::vector<Table> partition_table(const Table& in, const std::vector<int>& key_cols, int nparts);

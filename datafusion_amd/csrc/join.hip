@@ -36,7 +36,7 @@ namespace dfgpu {
 Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_t* mask, const uint64_t* mask_valid);
 void pack_bytes_to_bitmap(const uint8_t* bytes, int64_t n, uint64_t* words);
 
-enum TableKind : int { KIND_HASH = 0, KIND_ARRAY = 1, KIND_RANK = 2 };
+enum TableKind : int { KIND_HASH = 0, KIND_ARRAY = 1, KIND_RANK = 2, KIND_RADIX = 3 };
 constexpr double RANK_MAP_MIN_KEY_DENSITY = 1.0 / 256.0;  // 64 B of bitmap + directory per build row at the limit
 
 struct JoinTable {
@@ -53,6 +53,7 @@ struct JoinTable {
   uint64_t am_offset = 0, am_size = 0;
   uint64_t hash_mask = 0;
   BufPtr rank_bits, rank_prefix, rank_perm;  // rank map: u64 bitmap, u64 exclusive popcount prefix per word, optional u32 perm
+  std::shared_ptr<RadixTable> radix;  // KIND_RADIX: build records partitioned for the LDS join (radix_join.hip)
   BufPtr visited;  // u8 per build row, lazily allocated
   // HashJoinExec::null_aware (NOT IN semantics, single key column): what JoinLeftData shares between the probe
   // partitions in the reference (probe_side_has_null / probe_side_non_empty / build_side_has_null, exec.rs:195-240)
@@ -947,6 +948,16 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
   KeySet ks = make_keyset(build, key_cols);
   jt->info.build_rows = nb;
 
+  if (opts.table_mode == 4) {
+    // LDS-staged radix-partitioned table (radix_join.hip): any key set, duplicates, NULL == NULL
+    jt->kind = KIND_RADIX;
+    jt->radix = radix_join_build(build, key_cols, null_equality == DFGPU_NULL_EQUALS_NULL, jt->force_collisions);
+    jt->keys_unique = false;  // not established: every probe takes the pairs path
+    jt->info.table_bytes = radix_join_table_bytes(*jt->radix);
+    jt->info.table_kind = KIND_RADIX;
+    jt->info.build_keys_unique = 0;
+    return jt;
+  }
   // ---- key statistics: ArrayMap::try_new bounds (array_map.rs:175-203) + ascending-order check
   bool have_stats = false, ascending = false;
   uint64_t range = 0;
@@ -1146,6 +1157,8 @@ static bool needs_visited(int join_type) {
          join_type == DFGPU_JOIN_LEFT_MARK;
 }
 
+static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
+                                    const std::vector<int>& pout, const dfgpu_join_filter* jfp);
 static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout_in,
                         const std::vector<int>& pout, const uint64_t* row_mask = nullptr, bool* mask_consumed = nullptr) {
   Runtime& r = rt();
@@ -1154,6 +1167,15 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const std::vector<int> bout = (join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI) ? std::vector<int>{} : bout_in;
   DFGPU_CHECK(pk.size() == jt.key_cols.size(), "probe key count differs from build key count");
   DFGPU_CHECK(probe.device == jt.build.device, "the probe table lives on another device than the join table (move it with dfgpu_table_copy_to_device)");
+  if (jt.kind == KIND_RADIX) {
+    // the LDS radix join produces key-equal pairs; every join type is finished from them (row masks: the caller filters first)
+    if (row_mask) {
+      DFGPU_CHECK(mask_consumed != nullptr, "probe row mask without a fallback");
+      *mask_consumed = false;
+      return Table{};
+    }
+    return join_probe_with_filter(jt, probe, pk, join_type, bout, pout, nullptr);
+  }
   const int64_t np = probe.nrows;
   const int64_t n_words = (np + 63) / 64;
   ProbeCtx ctx = make_ctx(jt, probe, pk);
@@ -1427,7 +1449,12 @@ static Table join_probe_null_aware(JoinTable& jt, const Table& probe, const std:
     case NA_MASK_NULL_PROBE_KEYS: {
       bool consumed = false;
       Table res = join_probe(jt, probe, pk, join_type, bout, pout, probe.cols[pk[0]].valid_words(), &consumed);
-      DFGPU_CHECK(consumed, "internal: RightAnti probe did not take the row mask");
+      if (!consumed) {  // table kinds without an in-place row mask (LDS radix partitions): drop the NULL-key rows first
+        std::vector<int> all(probe.cols.size());
+        for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
+        const Table filtered = compact_table(probe, all, probe.cols[pk[0]].valid_words(), nullptr);
+        res = join_probe(jt, filtered, pk, join_type, bout, pout);
+      }
       return res;
     }
     default:
@@ -1435,17 +1462,22 @@ static Table join_probe_null_aware(JoinTable& jt, const Table& probe, const std:
   }
 }
 
-static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
-                                    const std::vector<int>& pout, const dfgpu_join_filter& jf) {
+// key-equal (build row, probe row) pairs of one probe table = an Inner join on the keys; nothing is marked visited yet.
+// Chained / direct-address tables: counts -> scan -> pairs in probe order; radix table: LDS join, partition order.
+struct Pairs {
+  BufPtr ob, op;
+  int64_t m = 0;
+};
+static Pairs key_equal_pairs(JoinTable& jt, const Table& probe, const std::vector<int>& pk) {
   Runtime& r = rt();
-  DFGPU_CHECK(pk.size() == jt.key_cols.size(), "probe key count differs from build key count");
-  for (int c : bout) DFGPU_CHECK(c >= 0 && c < (int)jt.build.cols.size(), "build output column out of range");
-  for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
+  Pairs P;
+  if (jt.kind == KIND_RADIX) {
+    radix_join_pairs(*jt.radix, jt.build, jt.key_cols, probe, pk, jt.null_equality == DFGPU_NULL_EQUALS_NULL, jt.force_collisions, P.ob, P.op, P.m);
+    return P;
+  }
   const int64_t np = probe.nrows;
   const int64_t n_words = (np + 63) / 64;
   ProbeCtx ctx = make_ctx(jt, probe, pk);
-  jt.info.probe_rows += np;
-  // ---- key-equal pairs (an Inner join on the keys; nothing is marked visited yet)
   BufPtr row_counts = make_buf((size_t)(np ? np : 1) * 4), word_counts = make_buf((size_t)(n_words ? n_words : 1) * 4);
   BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
   const int g = grid_for(n_words, BLOCK / WAVE);
@@ -1453,24 +1485,45 @@ static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std
     k_probe_count<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, DFGPU_JOIN_INNER, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), nullptr);
   });
   scan_u32(word_counts->as<uint32_t>(), n_words, prefix->as<uint64_t>());
-  const int64_t m = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
-  BufPtr ob = make_buf((size_t)(m ? m : 1) * 8), op = make_buf((size_t)(m ? m : 1) * 8);
-  if (m) with_kind(jt.kind, [&](auto kt) {
-    k_probe_emit<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, DFGPU_JOIN_INNER, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), ob->as<int64_t>(), op->as<int64_t>(), nullptr);
+  P.m = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+  P.ob = make_buf((size_t)(P.m ? P.m : 1) * 8);
+  P.op = make_buf((size_t)(P.m ? P.m : 1) * 8);
+  if (P.m) with_kind(jt.kind, [&](auto kt) {
+    k_probe_emit<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, DFGPU_JOIN_INNER, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), P.ob->as<int64_t>(), P.op->as<int64_t>(), nullptr);
   });
   DFGPU_HIP(hipGetLastError());
-  // ---- intermediate batch + filter expression -> pass mask over the pairs
-  Table inter;
-  inter.nrows = m;
-  for (int i = 0; i < jf.n_columns; i++) {
-    const bool left = jf.column_side[i] == 0;
-    const Table& side = left ? jt.build : probe;
-    DFGPU_CHECK(jf.column_index[i] >= 0 && jf.column_index[i] < (int)side.cols.size(), "join filter column index out of range");
-    inter.cols.push_back(gather_column(side.cols[jf.column_index[i]], (left ? ob : op)->as<int64_t>(), m, false));
-  }
+  return P;
+}
+
+// pairs -> [JoinFilter] -> the join type's output (apply_join_filter_to_indices + adjust_indices_by_join_type, joins/utils.rs:1248-1318,1432-1488)
+static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
+                                    const std::vector<int>& pout, const dfgpu_join_filter* jfp) {
+  Runtime& r = rt();
+  DFGPU_CHECK(pk.size() == jt.key_cols.size(), "probe key count differs from build key count");
+  DFGPU_CHECK(probe.device == jt.build.device, "the probe table lives on another device than the join table (move it with dfgpu_table_copy_to_device)");
+  for (int c : bout) DFGPU_CHECK(c >= 0 && c < (int)jt.build.cols.size(), "build output column out of range");
+  for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
+  const int64_t np = probe.nrows;
+  const int64_t n_words = (np + 63) / 64;
+  const int g = grid_for(n_words, BLOCK / WAVE);
+  jt.info.probe_rows += np;
+  Pairs P = key_equal_pairs(jt, probe, pk);
+  const int64_t m = P.m;
+  BufPtr ob = P.ob, op = P.op;
+  // ---- intermediate batch + filter expression -> pass mask over the pairs (no filter: every pair passes)
   const int64_t m_words = (m + 63) / 64;
-  BufPtr pass = make_zero_buf((size_t)(m_words ? m_words : 1) * 8);
-  if (m) {
+  BufPtr pass = make_buf((size_t)(m_words ? m_words : 1) * 8);
+  DFGPU_HIP(hipMemsetAsync(pass->ptr, jfp ? 0 : 0xFF, (size_t)(m_words ? m_words : 1) * 8, r.stream));
+  if (m && jfp) {
+    const dfgpu_join_filter& jf = *jfp;
+    Table inter;
+    inter.nrows = m;
+    for (int i = 0; i < jf.n_columns; i++) {
+      const bool left = jf.column_side[i] == 0;
+      const Table& side = left ? jt.build : probe;
+      DFGPU_CHECK(jf.column_index[i] >= 0 && jf.column_index[i] < (int)side.cols.size(), "join filter column index out of range");
+      inter.cols.push_back(gather_column(side.cols[jf.column_index[i]], (left ? ob : op)->as<int64_t>(), m, false));
+    }
     Datum d = evaluate(jf.expression, inter);
     DFGPU_CHECK(d.col.field.type == DFGPU_BOOL, "join filter expression must be Boolean");
     Column mc = datum_to_column(d, m, "");
@@ -1628,7 +1681,7 @@ int dfgpu_join_probe_with_filter(dfgpu_join_t ht, dfgpu_table_t probe, const int
     std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
     const Table pt = with_build_dictionaries(*jt, *unwrap(probe), pk);
     null_aware_before_probe(*jt, pt, pk, join_type, true);  // LeftAnti: flags only; RightAnti: rejected
-    auto o = std::make_unique<Table>(join_probe_with_filter(*jt, pt, pk, join_type, bo, po, *filter));
+    auto o = std::make_unique<Table>(join_probe_with_filter(*jt, pt, pk, join_type, bo, po, filter));
     *out = wrap(o.release());
   });
 }

@@ -21,6 +21,7 @@
 //                     holding the k-th row (Q3: k = 10), then the few survivors are sorted.
 //   4. take         : output columns gathered by the sorted row ids.  Ties keep input order (stable).
 #include <algorithm>
+#include <cstdlib>
 
 #include "device.hpp"
 #include "internal.hpp"
@@ -277,6 +278,107 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter(KeyWords k, const uint32_t
   }
 }
 
+
+// stable scatter of one tile by one digit, second generation.  A wave owns a CONTIGUOUS 64 x ITEMS-row segment of the tile and
+// ranks its rows against wave-private digit counters in LDS (ballot peer masks; LDS operations of one wave are ordered, so
+// no block barrier is needed between items) — 4 block barriers per tile instead of 3 per item.  The tile is then staged in LDS
+// sorted by digit and every digit's run is written contiguously.
+template <int NW, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_t* __restrict__ idx_in, int64_t n, int dword, int shift, int bits, int64_t n_tiles,
+                                                      const uint64_t* __restrict__ offsets, SortBufs out) {
+  constexpr int TILE = BLOCK * ITEMS;
+  constexpr int NWAVE = BLOCK / WAVE;
+  __shared__ uint64_t s_key[NW][TILE];
+  __shared__ uint32_t s_idx[TILE];
+  __shared__ uint8_t s_dig[TILE];
+  __shared__ unsigned int s_cnt[NWAVE][256];   // ranking: rows of each digit seen so far by the wave; then the wave's exclusive prefix over earlier waves
+  __shared__ unsigned int s_start[256];        // exclusive scan of the tile's digit counts
+  __shared__ unsigned int s_wtot[NWAVE];
+  __shared__ unsigned long long s_goff[256];   // global output offset of each digit's run
+  const unsigned mask = (1u << bits) - 1u;
+  const int wave = threadIdx.x >> 6;
+  const unsigned lane = lane_id();
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t lo = t * TILE;
+    const int tile_rows = (int)((n - lo) < TILE ? (n - lo) : TILE);
+#pragma unroll
+    for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+    if ((int)threadIdx.x <= (int)mask) s_goff[threadIdx.x] = offsets[(int64_t)threadIdx.x * n_tiles + t];
+    __syncthreads();
+    uint64_t key[NW][ITEMS];
+    uint32_t id[ITEMS];
+    unsigned dig[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {  // all loads of the segment in flight together
+      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+      const int64_t src = lo + (j < tile_rows ? j : 0);
+#pragma unroll
+      for (int w = 0; w < NW; w++) key[w][c] = k.w[w][src];
+      id[c] = idx_in ? idx_in[src] : (uint32_t)src;
+    }
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+      const bool in = j < tile_rows;
+      uint64_t kw = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+        if (w == dword) kw = key[w][c];
+      dig[c] = in ? ((unsigned)(kw >> shift) & mask) : 0u;
+      uint64_t peers = ballot64(in);
+      for (int b = 0; b < bits; b++) {
+        const uint64_t bal = ballot64((dig[c] >> b) & 1u);
+        peers &= ((dig[c] >> b) & 1u) ? bal : ~bal;
+      }
+      const unsigned r_in_wave = mbcnt(peers);
+      const unsigned base = s_cnt[wave][dig[c]];
+      if (in && r_in_wave == 0) s_cnt[wave][dig[c]] = base + (unsigned)__popcll(peers);
+      rank[c] = base + r_in_wave;
+    }
+    __syncthreads();
+    {  // thread d: digit d's total, the waves' exclusive prefixes, and the exclusive scan over digits
+      unsigned run = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; w++) {
+        const unsigned v = s_cnt[w][threadIdx.x];
+        s_cnt[w][threadIdx.x] = run;
+        run += v;
+      }
+      const unsigned inc = wave_inclusive_sum<unsigned>(run);
+      if (lane == 63) s_wtot[wave] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; w++) base += s_wtot[w];
+      s_start[threadIdx.x] = base + inc - run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+      if (j < tile_rows) {
+        const unsigned q = s_start[dig[c]] + s_cnt[wave][dig[c]] + rank[c];
+#pragma unroll
+        for (int w = 0; w < NW; w++) s_key[w][q] = key[w][c];
+        s_idx[q] = id[c];
+        s_dig[q] = (uint8_t)dig[c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int q = c * BLOCK + threadIdx.x;
+      if (q < tile_rows) {
+        const unsigned d = s_dig[q];
+        const unsigned long long dst = s_goff[d] + (unsigned)(q - (int)s_start[d]);
+#pragma unroll
+        for (int w = 0; w < NW; w++) out.w[w][dst] = s_key[w][q];
+        out.idx[dst] = s_idx[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------ TopK narrowing
 // histogram of one digit over candidate rows
 __global__ __launch_bounds__(BLOCK) void k_select_hist(const uint64_t* __restrict__ word, const uint8_t* __restrict__ state, int64_t n, int shift, int bits,
@@ -380,20 +482,58 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
       ck.w[wd] = cur.w[wd]->as<uint64_t>();
       ob.w[wd] = alt.w[wd]->as<uint64_t>();
     }
+    if (!alt.idx) alt.idx = make_buf((size_t)n * 4);  // the input had implicit row ids (radix_sort_pairs)
     ob.idx = alt.idx->as<uint32_t>();
     const int nb = 1 << d.bits;
     ProfileScope ps("radix_sort_pass", n * 8 + n * (nwords * 8 + 4) * 2);
     k_rs_hist<<<grid, BLOCK, 0, r.stream>>>(ck.w[d.word], n, d.shift, d.bits, items, n_tiles, counts->as<uint32_t>());
     scan_u32(counts->as<uint32_t>(), (int64_t)nb * n_tiles, offsets->as<uint64_t>());
-    switch (nwords) {
-      case 1: k_rs_scatter<1><<<grid, BLOCK, 0, r.stream>>>(ck, cur.idx->as<uint32_t>(), n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-      case 2: k_rs_scatter<2><<<grid, BLOCK, 0, r.stream>>>(ck, cur.idx->as<uint32_t>(), n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-      default: k_rs_scatter<3><<<grid, BLOCK, 0, r.stream>>>(ck, cur.idx->as<uint32_t>(), n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+    static const bool gen1 = std::getenv("DFGPU_SORT_GEN1") != nullptr;  // A/B knob: the first-generation scatter
+    const uint32_t* idx_in = cur.idx ? cur.idx->as<uint32_t>() : nullptr;
+    if (gen1) {
+      switch (nwords) {
+        case 1: k_rs_scatter<1><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        case 2: k_rs_scatter<2><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        default: k_rs_scatter<3><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+      }
+    } else {
+      switch (nwords) {
+        case 1: k_rs_scatter2<1, rs_items(1)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        case 2: k_rs_scatter2<2, rs_items(2)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        default: k_rs_scatter2<3, rs_items(3)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+      }
     }
     DFGPU_HIP(hipGetLastError());
     std::swap(cur, alt);
   }
   return cur;
+}
+
+// (key, row id) pairs sorted by bits [lo_bit, lo_bit + nbits) of the key — the radix partitioning of the LDS hash join
+// (radix_join.hip): nbits / 8 stable passes.  `idx` may be null on entry: the row id of pair i is then i.
+void radix_sort_pairs(BufPtr& key, BufPtr& idx, int64_t n, int lo_bit, int nbits) {
+  if (n <= 1 || nbits <= 0) {
+    if (!idx) {
+      idx = make_buf((size_t)std::max<int64_t>(n, 1) * 4);
+      if (n) k_iota_u32<<<grid_for(n, BLOCK), BLOCK, 0, rt().stream>>>(n, idx->as<uint32_t>());
+    }
+    return;
+  }
+  std::vector<Digit> digits;
+  const int nd = (nbits + 7) / 8;
+  int pos = lo_bit;
+  for (int d = 0; d < nd; d++) {
+    const int b = (lo_bit + nbits - pos + (nd - d) - 1) / (nd - d);
+    digits.push_back({0, pos, b});
+    pos += b;
+  }
+  SortedKeys in;
+  in.nwords = 1;
+  in.w[0] = key;
+  in.idx = idx;
+  SortedKeys out = radix_sort(in, n, digits);
+  key = out.w[0];
+  idx = out.idx;
 }
 
 static int bits_for(u128 range) {

@@ -264,7 +264,11 @@ typedef struct dfgpu_join_options {
   /* 0 = auto: rank map (GPU-native compressed direct addressing: 1 bit per value of the key range +
    *     popcount directory; unique integer keys, range/rows <= 256) -> else ArrayMap by the reference's
    *     gating (hash_join/exec.rs:111-191) with the two knobs above -> else chained hash table;
-   * 1 = force chained hash table; 2 = force ArrayMap; 3 = force rank map (2/3: error if not applicable) */
+   * 1 = force chained hash table; 2 = force ArrayMap; 3 = force rank map (2/3: error if not applicable);
+   * 4 = LDS-staged radix-partitioned table: both sides are radix partitioned on the top bits of a mixed key until a build
+   *     partition fits the LDS of one workgroup, every partition pair is joined in LDS (any key set, duplicate keys, NULL ==
+   *     NULL; all join types; JoinFilter).  The output is in partition order, not probe order: for plans in which no ancestor
+   *     observes HashJoinExec's probe-side ordering (what probe_mode 4 declares). */
   int32_t table_mode;
   /* test hook = cargo feature `force_hash_collisions` (common/src/hash_utils.rs:1186-1197):
    * every key hashes to 0 so only the key re-check (K4) keeps results right */
@@ -341,7 +345,7 @@ typedef struct dfgpu_join_info {
   int32_t build_keys_unique;
   int64_t probe_rows;  /* accumulated over probe calls */
   int64_t output_rows; /* accumulated */
-  int32_t table_kind;  /* 0 = chained hash table (JoinHashMap), 1 = ArrayMap, 2 = rank map (bitmap + popcount directory) */
+  int32_t table_kind;  /* 0 = chained hash table (JoinHashMap), 1 = ArrayMap, 2 = rank map (bitmap + popcount directory), 3 = LDS radix partitions */
   int32_t build_keys_ascending; /* 1 = single integer key, strictly ascending in row order */
 } dfgpu_join_info;
 int dfgpu_join_get_info(dfgpu_join_t ht, dfgpu_join_info* out);

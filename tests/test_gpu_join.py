@@ -20,8 +20,9 @@ def gpu_join(left, right, on, join_type, null_equality="NullEqualsNothing", **op
 
 
 # the reference runs every case with PHJ on/off (exec.rs:2929-2963); plus its force_hash_collisions CI job
-@pytest.mark.parametrize("opts", [dict(table_mode=0), dict(table_mode=1), dict(table_mode=1, force_hash_collisions=True)],
-                         ids=["phj_auto", "hash_map", "forced_collisions"])
+@pytest.mark.parametrize("opts", [dict(table_mode=0), dict(table_mode=1), dict(table_mode=1, force_hash_collisions=True), dict(table_mode=4),
+                                  dict(table_mode=4, force_hash_collisions=True)],
+                         ids=["phj_auto", "hash_map", "forced_collisions", "radix_lds", "radix_lds_forced_collisions"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_reference_snapshots(case, opts):
     left = i32_table(case["left"]["columns"], case["left"]["data"], case["left"]["repeat"])
@@ -33,7 +34,7 @@ def test_reference_snapshots(case, opts):
 
 
 @pytest.mark.parametrize("join_type", ALL_TYPES)
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 4])
 def test_random_vs_oracle_all_join_types(join_type, mode):
     from oracle import oracle
     rng = np.random.default_rng(11)
@@ -111,9 +112,11 @@ def test_multi_column_and_decimal_keys():
     left = random_table(rng, 2000, {"a": (pa.int32(), 0, 30), "b": (pa.decimal128(15, 2), 0, 20), "v": (pa.int64(), 0, 10**9)}, null_frac=0.03)
     right = random_table(rng, 5000, {"a": (pa.int32(), 0, 30), "b": (pa.decimal128(15, 2), 0, 20), "w": (pa.int64(), 0, 10**9)}, null_frac=0.03)
     for jt in ("Inner", "Left", "RightSemi", "RightAnti", "Full"):
-        got = gpu_join(left, right, [("a", "a"), ("b", "b")], jt)
         exp = oracle.hash_join(left, right, [("a", "a"), ("b", "b")], jt)
-        assert_tables_equal(got, exp)
+        for mode in (0, 4):
+            for ne in ("NullEqualsNothing", "NullEqualsNull"):
+                got = gpu_join(left, right, [("a", "a"), ("b", "b")], jt, ne, table_mode=mode)
+                assert_tables_equal(got, exp if ne == "NullEqualsNothing" else oracle.hash_join(left, right, [("a", "a"), ("b", "b")], jt, ne))
 
 
 def test_empty_sides():
@@ -261,8 +264,9 @@ def _filter_of(case):
     return gpu, [(i, side) for i, side in f["columns"]]
 
 
-@pytest.mark.parametrize("opts", [dict(table_mode=0), dict(table_mode=1), dict(table_mode=1, force_hash_collisions=True)],
-                         ids=["phj_auto", "hash_map", "forced_collisions"])
+@pytest.mark.parametrize("opts", [dict(table_mode=0), dict(table_mode=1), dict(table_mode=1, force_hash_collisions=True), dict(table_mode=4),
+                                  dict(table_mode=4, force_hash_collisions=True)],
+                         ids=["phj_auto", "hash_map", "forced_collisions", "radix_lds", "radix_lds_forced_collisions"])
 @pytest.mark.parametrize("case", FILTER_CASES, ids=[c["name"] for c in FILTER_CASES])
 def test_reference_snapshots_with_join_filter(case, opts):
     """the reference's join_*_with_filter tests (hash_join/exec.rs:4422-5830) through dfgpu_join_probe_with_filter"""
@@ -285,7 +289,7 @@ def test_random_join_filter_vs_oracle(join_type):
     # residual predicate over both sides with NULLs on both: left.x > right.z AND left.y != right.w
     gpu_expr = (col("f0") > col("f1")).and_(col("f2").ne(col("f3")))
     cols = [(1, "Left"), (1, "Right"), (2, "Left"), (2, "Right")]
-    for mode in (0, 1):
+    for mode in (0, 1, 4):
         got = gpu_join(left, right, [("a", "b")], join_type, join_filter=(gpu_expr, cols), table_mode=mode)
         exp = oracle.hash_join(left, right, [("a", "b")], join_type, join_filter=(to_oracle_expr(gpu_expr), cols))
         assert_tables_equal(got, exp)
@@ -303,6 +307,31 @@ def test_array_map_and_hash_map_known_answers_on_the_device():
     for build, probe, typ, want in cases:
         b = DeviceTable.from_arrow(pa.table({"k": pa.array(build, typ), "bi": pa.array(range(len(build)), pa.int64())}))
         p = DeviceTable.from_arrow(pa.table({"k2": pa.array(probe, typ), "pi": pa.array(range(len(probe)), pa.int64())}))
-        for table_mode in (0, 1):
+        for table_mode in (0, 1, 4):
             j = ops.hash_join(b, p, [("k", "k2")], "Inner", table_mode=table_mode).to_arrow()
             assert sorted(zip(j.column("pi").to_pylist(), j.column("bi").to_pylist())) == sorted(want), (build, probe, table_mode)
+
+
+@pytest.mark.parametrize("shape", ["many_partitions", "skewed_duplicates", "no_matches"])
+def test_radix_lds_join_many_partitions_and_skew(shape):
+    """the LDS radix join over inputs large enough for several partition bits, several tasks per partition and (skew) several
+    LDS chunks per partition; M:N output compared with the oracle as a multiset"""
+    from oracle import oracle
+    rng = np.random.default_rng(31)
+    if shape == "many_partitions":
+        nb, np_, dom = 300_000, 1_000_000, 400_000
+        bk, pk = rng.integers(0, dom, nb), rng.integers(0, dom, np_)
+    elif shape == "skewed_duplicates":
+        nb, np_ = 60_000, 200_000
+        bk = np.where(rng.random(nb) < 0.1, 7, rng.integers(0, 50_000, nb))          # 10 % of the build rows share one key
+        pk = np.where(rng.random(np_) < 0.001, 7, rng.integers(0, 50_000, np_))
+    else:
+        nb, np_ = 100_000, 300_000
+        bk, pk = rng.integers(0, 10**6, nb) * 2, rng.integers(0, 10**6, np_) * 2 + 1
+    left = pa.table({"a": pa.array(bk, type=pa.int64()), "bi": pa.array(np.arange(nb), type=pa.int32())})
+    right = pa.table({"b": pa.array(pk, type=pa.int64()), "pi": pa.array(np.arange(np_), type=pa.int32())})
+    for jt in ("Inner", "RightAnti", "LeftSemi"):
+        got = gpu_join(left, right, [("a", "b")], jt, table_mode=4)
+        exp = oracle.hash_join(left, right, [("a", "b")], jt)
+        assert got.num_rows == exp.num_rows
+        assert_tables_equal(got, exp)

@@ -69,8 +69,9 @@ def gpu_join(left, right, on, join_type, null_equality="NullEqualsNothing", **op
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opts", [dict(table_mode=0), dict(table_mode=1), dict(table_mode=1, force_hash_collisions=True)],
-                         ids=["phj_auto", "hash_map", "forced_collisions"])
+@pytest.mark.parametrize("opts", [dict(table_mode=0), dict(table_mode=1), dict(table_mode=1, force_hash_collisions=True), dict(table_mode=4),
+                                  dict(table_mode=4, force_hash_collisions=True)],
+                         ids=["phj_auto", "hash_map", "forced_collisions", "radix_lds", "radix_lds_forced_collisions"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_gpu_matches_reference(case, opts):
     if case.get("force_hash_collisions"):
@@ -97,7 +98,7 @@ def test_gpu_null_aware_validation():
 @pytest.mark.gpu
 @pytest.mark.parametrize("join_type", ["LeftAnti", "RightAnti"])
 @pytest.mark.parametrize("nulls", ["none", "left", "right", "both"])
-@pytest.mark.parametrize("table_mode", [0, 1])
+@pytest.mark.parametrize("table_mode", [0, 1, 4])
 def test_gpu_null_aware_random_vs_oracle(join_type, nulls, table_mode):
     """NOT IN over a few thousand rows, NULL keys on either / both / neither side, empty sides, multi-batch probing"""
     from oracle import oracle
