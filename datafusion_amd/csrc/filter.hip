@@ -8,6 +8,9 @@
 //
 // Reference: physical-plan/src/filter.rs:1339-1362 (filter_and_project), :1396-1419;
 // arrow-select `filter_record_batch` (NULL predicate => row dropped).
+#include <algorithm>
+#include <cstdlib>
+
 #include "device.hpp"
 #include "internal.hpp"
 
@@ -245,6 +248,162 @@ Column gather_column(const Column& in, const int64_t* idx, int64_t n, bool idx_m
     out.null_count = -1;
     count_nulls(out);
   }
+  return out;
+}
+
+// ------------------------------------------------------------------------------ take of several columns
+// A random access costs a whole 128-byte line of HBM whatever the element width (profiles/r2_fetch_calib.md), so taking k
+// columns by the same row ids costs k lines per row column-by-column.  Above the Infinity Cache's size the columns are first
+// packed into row-major records with one streaming pass (16 / 32 / 48 / 64 bytes per row), then ONE line per row is touched
+// and the record is split into the output columns — arrow `take` over a whole batch (joins/utils.rs:1332-1386, sorts/sort.rs:
+// 894-914 take_arrays), laid out for HBM.
+constexpr int PACK_MAX_COLS = 8;
+struct PackLayout {
+  const void* src[PACK_MAX_COLS];
+  void* dst[PACK_MAX_COLS];
+  int width[PACK_MAX_COLS];
+  int offset[PACK_MAX_COLS];
+  int n;
+};
+// a record lives in R / 8 registers; fields are placed / extracted with constant-index selects (a runtime-indexed array would
+// live in scratch memory), the record itself moves as whole 16-byte loads / stores
+template <int NS>
+__device__ __forceinline__ uint64_t slot_get(const uint64_t (&s)[NS], int k) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int q = 0; q < NS; q++) v = k == q ? s[q] : v;
+  return v;
+}
+template <int NS>
+__device__ __forceinline__ void slot_or(uint64_t (&s)[NS], int k, uint64_t v) {
+#pragma unroll
+  for (int q = 0; q < NS; q++) s[q] |= k == q ? v : 0ull;
+}
+template <int R>
+__global__ __launch_bounds__(BLOCK) void k_pack_rows(PackLayout L, int64_t n, uint8_t* __restrict__ rec) {
+  constexpr int NS = R / 8;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint64_t s[NS];
+#pragma unroll
+    for (int q = 0; q < NS; q++) s[q] = 0;
+    for (int c = 0; c < L.n; c++) {
+      const int o = L.offset[c];
+      switch (L.width[c]) {
+        case 16: {
+          const uint4 v = reinterpret_cast<const uint4*>(L.src[c])[i];
+          slot_or<NS>(s, o >> 3, ((uint64_t)v.y << 32) | v.x);
+          slot_or<NS>(s, (o >> 3) + 1, ((uint64_t)v.w << 32) | v.z);
+          break;
+        }
+        case 8: slot_or<NS>(s, o >> 3, reinterpret_cast<const uint64_t*>(L.src[c])[i]); break;
+        case 4: slot_or<NS>(s, o >> 3, (uint64_t)reinterpret_cast<const uint32_t*>(L.src[c])[i] << ((o & 4) * 8)); break;
+        default: slot_or<NS>(s, o >> 3, (uint64_t)reinterpret_cast<const uint8_t*>(L.src[c])[i] << ((o & 7) * 8)); break;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NS / 2; q++)
+      reinterpret_cast<uint4*>(rec + i * R)[q] = uint4{(unsigned)s[2 * q], (unsigned)(s[2 * q] >> 32), (unsigned)s[2 * q + 1], (unsigned)(s[2 * q + 1] >> 32)};
+  }
+}
+template <int R>
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(PackLayout L, const uint8_t* __restrict__ rec, const int64_t* __restrict__ idx, int64_t n) {
+  constexpr int NS = R / 8;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const uint4* src = reinterpret_cast<const uint4*>(rec + idx[i] * R);
+    uint64_t s[NS];
+#pragma unroll
+    for (int q = 0; q < NS / 2; q++) {
+      const uint4 v = src[q];
+      s[2 * q] = ((uint64_t)v.y << 32) | v.x;
+      s[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+    }
+    for (int c = 0; c < L.n; c++) {
+      const int o = L.offset[c];
+      switch (L.width[c]) {
+        case 16: {
+          const uint64_t lo = slot_get<NS>(s, o >> 3), hi = slot_get<NS>(s, (o >> 3) + 1);
+          reinterpret_cast<uint4*>(L.dst[c])[i] = uint4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+          break;
+        }
+        case 8: reinterpret_cast<uint64_t*>(L.dst[c])[i] = slot_get<NS>(s, o >> 3); break;
+        case 4: reinterpret_cast<uint32_t*>(L.dst[c])[i] = (uint32_t)(slot_get<NS>(s, o >> 3) >> ((o & 4) * 8)); break;
+        default: reinterpret_cast<uint8_t*>(L.dst[c])[i] = (uint8_t)(slot_get<NS>(s, o >> 3) >> ((o & 7) * 8)); break;
+      }
+    }
+  }
+}
+
+std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols, const int64_t* idx, int64_t n, bool idx_may_be_null) {
+  Runtime& r = rt();
+  std::vector<Column> out(cols.size());
+  // what can travel as records: byte-addressable, non-nullable columns taken by non-negative ids, from a table whose columns
+  // do not sit in the Infinity Cache anyway, for enough rows to repay the packing pass
+  std::vector<int> packable;
+  int64_t in_bytes = 0;
+  for (size_t k = 0; k < cols.size(); k++) {
+    const Column& c = in.cols[cols[k]];
+    if (!idx_may_be_null && !c.validity && c.field.type != DFGPU_BOOL) {
+      packable.push_back((int)k);
+      in_bytes += in.nrows * type_width(c.field.type);
+    }
+  }
+  static const bool enabled = !(std::getenv("DFGPU_PACKED_TAKE") && std::getenv("DFGPU_PACKED_TAKE")[0] == '0');  // A/B knob
+  const bool pack = enabled && packable.size() >= 2 && in_bytes > ((int64_t)256 << 20) && n * 4 >= in.nrows;
+  std::vector<bool> done(cols.size(), false);
+  if (pack && n > 0) {
+    // widest columns first keeps every field naturally aligned inside the record
+    std::sort(packable.begin(), packable.end(), [&](int a, int b) { return type_width(in.cols[cols[a]].field.type) > type_width(in.cols[cols[b]].field.type); });
+    size_t at = 0;
+    while (at < packable.size()) {
+      PackLayout L{};
+      int bytes = 0;
+      std::vector<int> members;
+      while (at < packable.size() && L.n < PACK_MAX_COLS) {
+        const int w = type_width(in.cols[cols[packable[at]]].field.type);
+        if (bytes + w > 64) break;
+        L.width[L.n] = w;
+        L.offset[L.n] = bytes;
+        L.src[L.n] = in.cols[cols[packable[at]]].ptr();
+        bytes += w;
+        members.push_back(packable[at]);
+        L.n++;
+        at++;
+      }
+      if (members.size() < 2) {  // a lone column gains nothing from a record
+        continue;
+      }
+      const int R = (bytes + 15) / 16 * 16;
+      BufPtr rec = make_buf((size_t)in.nrows * R + 64);
+      for (int q = 0; q < L.n; q++) {
+        out[members[q]] = alloc_like(in.cols[cols[members[q]]], n);
+        L.dst[q] = out[members[q]].data->ptr;
+        done[members[q]] = true;
+      }
+      {
+        ProfileScope ps("take_pack_rows", in.nrows * (int64_t)(bytes + R));
+        const int g = grid_for(in.nrows, BLOCK);
+        switch (R) {
+          case 16: k_pack_rows<16><<<g, BLOCK, 0, r.stream>>>(L, in.nrows, rec->as<uint8_t>()); break;
+          case 32: k_pack_rows<32><<<g, BLOCK, 0, r.stream>>>(L, in.nrows, rec->as<uint8_t>()); break;
+          case 48: k_pack_rows<48><<<g, BLOCK, 0, r.stream>>>(L, in.nrows, rec->as<uint8_t>()); break;
+          default: k_pack_rows<64><<<g, BLOCK, 0, r.stream>>>(L, in.nrows, rec->as<uint8_t>()); break;
+        }
+      }
+      {
+        ProfileScope ps("take_gather_rows", n * (int64_t)(8 + R + bytes));
+        const int g = grid_for(n, BLOCK);
+        switch (R) {
+          case 16: k_gather_rows<16><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
+          case 32: k_gather_rows<32><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
+          case 48: k_gather_rows<48><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
+          default: k_gather_rows<64><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
+        }
+        DFGPU_HIP(hipGetLastError());
+      }
+    }
+  }
+  for (size_t k = 0; k < cols.size(); k++)
+    if (!done[k]) out[k] = gather_column(in.cols[cols[k]], idx, n, idx_may_be_null);
   return out;
 }
 

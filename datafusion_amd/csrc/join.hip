@@ -53,6 +53,7 @@ struct JoinTable {
   uint64_t am_offset = 0, am_size = 0;
   uint64_t hash_mask = 0;
   BufPtr rank_bits, rank_prefix, rank_perm;  // rank map: u64 bitmap, u64 exclusive popcount prefix per word, optional u32 perm
+  BufPtr rank_tab;  // the probe's view of the rank map: {bitmap word, prefix} interleaved, ONE 16-byte load per lookup
   std::shared_ptr<RadixTable> radix;  // KIND_RADIX: build records partitioned for the LDS join (radix_join.hip)
   BufPtr visited;  // u8 per build row, lazily allocated
   // HashJoinExec::null_aware (NOT IN semantics, single key column): what JoinLeftData shares between the probe
@@ -66,8 +67,7 @@ struct ProbeCtx {
   KeySet bkeys, pkeys;
   const uint32_t* heads;
   const uint32_t* next;
-  const uint64_t* rank_bits;    // KIND_RANK
-  const uint64_t* rank_prefix;
+  const ulonglong2* rank_tab;   // KIND_RANK: .x = bitmap word (one bit per key value), .y = set bits in earlier words
   const uint32_t* rank_perm;    // null when the build keys are in ascending order (row id == rank)
   uint64_t am_offset, am_size, hash_mask;
   int null_equals_null;
@@ -245,6 +245,10 @@ __global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uin
     }
   }
 }
+// rank map build: {bitmap word, prefix} side by side for the probe
+__global__ __launch_bounds__(BLOCK) void k_rank_interleave(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ prefix, int64_t n_words, ulonglong2* __restrict__ tab) {
+  for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * BLOCK) tab[w] = make_ulonglong2(bits[w], prefix[w]);
+}
 // rank map build, step 2 (keys not in ascending row order): perm[rank(key_i)] = i
 __global__ __launch_bounds__(BLOCK) void k_rank_perm(KeyCol k, int64_t n, uint64_t offset, const uint64_t* __restrict__ bits,
                                                      const uint64_t* __restrict__ prefix, uint32_t* __restrict__ perm) {
@@ -324,9 +328,10 @@ __device__ __forceinline__ uint32_t chain_head(const ProbeCtx& c, int64_t p) {
     uint64_t idx = lo - c.am_offset;
     if (idx >= c.am_size) return 0u;
     if (KIND == KIND_ARRAY) return c.heads[idx];
-    const uint64_t bits = c.rank_bits[idx >> 6];
+    const ulonglong2 e = c.rank_tab[idx >> 6];
+    const uint64_t bits = e.x;
     if (!((bits >> (idx & 63)) & 1ull)) return 0u;
-    const uint32_t rank = (uint32_t)c.rank_prefix[idx >> 6] + (uint32_t)__popcll(bits & ((1ull << (idx & 63)) - 1ull));
+    const uint32_t rank = (uint32_t)e.y + (uint32_t)__popcll(bits & ((1ull << (idx & 63)) - 1ull));
     return (c.rank_perm ? c.rank_perm[rank] : rank) + 1u;
   } else {
     bool any_null;
@@ -398,8 +403,9 @@ __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int6
     uint64_t bits[N], pre[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
-      bits[j] = c.rank_bits[idx[j] >> 6];
-      pre[j] = c.rank_prefix[idx[j] >> 6];
+      const ulonglong2 e = c.rank_tab[idx[j] >> 6];  // a random lookup costs one line, not two
+      bits[j] = e.x;
+      pre[j] = e.y;
     }
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -901,8 +907,7 @@ static ProbeCtx make_ctx(const JoinTable& jt, const Table& probe, const std::vec
   }
   c.heads = jt.heads ? jt.heads->as<uint32_t>() : nullptr;
   c.next = jt.next ? jt.next->as<uint32_t>() : nullptr;
-  c.rank_bits = jt.rank_bits ? jt.rank_bits->as<uint64_t>() : nullptr;
-  c.rank_prefix = jt.rank_prefix ? jt.rank_prefix->as<uint64_t>() : nullptr;
+  c.rank_tab = jt.rank_tab ? jt.rank_tab->as<ulonglong2>() : nullptr;
   c.rank_perm = jt.rank_perm ? jt.rank_perm->as<uint32_t>() : nullptr;
   c.am_offset = jt.am_offset;
   c.am_size = jt.am_size;
@@ -998,6 +1003,12 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
                  (range < (uint64_t)opts.perfect_hash_join_small_build_threshold || dense >= RANK_MAP_MIN_KEY_DENSITY || opts.table_mode == 3);
   DFGPU_CHECK(!(opts.table_mode == 2 && !am_ok), "direct-address join table requested but not applicable");
   DFGPU_CHECK(!(opts.table_mode == 3 && !rank_ok), "rank-map join table requested but not applicable");
+  // Build keys that do NOT arrive in ascending order need the rank -> row permutation: one more dependent random access per
+  // probe row, and once bitmap + directory + permutation outgrow the 256 MiB Infinity Cache every one of them is a 128-byte
+  // line of HBM.  ArrayMap answers with ONE access then (measured, SF100 sizes, shuffled unique keys: 22.5 ms vs 37.5 ms,
+  // profiles/r2_join_shapes_v2.md), so `auto` prefers it when the reference's own gating admits it.
+  constexpr int64_t MALL_BYTES = (int64_t)256 << 20;
+  if (opts.table_mode == 0 && rank_ok && am_ok && !ascending && (int64_t)((range >> 6) + 1) * 16 + nb * 4 > MALL_BYTES) rank_ok = false;
 
   BufPtr flag = make_zero_buf(4);
   int dup = 0;
@@ -1029,11 +1040,28 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
         k_rank_perm<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, (uint64_t)kmin, jt->rank_bits->as<uint64_t>(), jt->rank_prefix->as<uint64_t>(),
                                                                   jt->rank_perm->as<uint32_t>());
       }
+      jt->rank_tab = make_buf((size_t)n_words * 16);
+      k_rank_interleave<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(jt->rank_bits->as<uint64_t>(), jt->rank_prefix->as<uint64_t>(), n_words, jt->rank_tab->as<ulonglong2>());
+      jt->rank_bits.reset();    // enqueued work holds them until it ran (stream-ordered pool)
+      jt->rank_prefix.reset();
       jt->info.table_bytes = n_words * 16 + (ascending ? 0 : nb * 4);
     } else {
       DFGPU_CHECK(opts.table_mode != 3, "rank-map join table requested but the build keys are not unique");
       jt->rank_bits.reset();
     }
+  }
+  // Duplicate build keys at a size where the chains live in HBM: when the plan does not observe the probe order
+  // (probe_mode 4) the LDS radix join beats walking them (SF100 sizes, keys x3, M:N: 26.9 ms vs 34.1 ms ArrayMap, 59.5 ms
+  // chained table)
+  if (opts.table_mode == 0 && dup && opts.probe_mode == 4 && ks.n == 1 && nb * 8 > MALL_BYTES) {
+    jt->rank_bits.reset();
+    jt->kind = KIND_RADIX;
+    jt->radix = radix_join_build(build, key_cols, null_equality == DFGPU_NULL_EQUALS_NULL, jt->force_collisions);
+    jt->keys_unique = false;
+    jt->info.table_bytes = radix_join_table_bytes(*jt->radix);
+    jt->info.table_kind = KIND_RADIX;
+    jt->info.build_keys_unique = 0;
+    return jt;
   }
   if (jt->kind != KIND_RANK && am_ok) {
     jt->kind = KIND_ARRAY;
@@ -1057,6 +1085,18 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
     }
     if (!dup) {
       d2h(&dup, flag->ptr, 4);
+      if (dup && opts.table_mode == 0 && opts.probe_mode == 4 && ks.n == 1 && nb * 8 > MALL_BYTES) {
+        // duplicates at a size where the chains would live in HBM, and the plan does not observe the probe order: LDS radix join
+        jt->heads.reset();
+        jt->array_map = false;
+        jt->kind = KIND_RADIX;
+        jt->radix = radix_join_build(build, key_cols, null_equality == DFGPU_NULL_EQUALS_NULL, jt->force_collisions);
+        jt->keys_unique = false;
+        jt->info.table_bytes = radix_join_table_bytes(*jt->radix);
+        jt->info.table_kind = KIND_RADIX;
+        jt->info.build_keys_unique = 0;
+        return jt;
+      }
       if (dup) {  // duplicates: rebuild with chains
         DFGPU_HIP(hipMemsetAsync(jt->heads->ptr, 0, jt->am_size * 4, r.stream));
         jt->next = make_zero_buf((size_t)nb * 4);
@@ -1405,8 +1445,8 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     out.nrows = n_out;
     const bool build_null_possible = join_type == DFGPU_JOIN_RIGHT || join_type == DFGPU_JOIN_FULL;
     if (join_type != DFGPU_JOIN_RIGHT_MARK)
-      for (int c : bout) out.cols.push_back(gather_column(jt.build.cols[c], ob->as<int64_t>(), n_out, build_null_possible));
-    for (int c : pout) out.cols.push_back(gather_column(probe.cols[c], op->as<int64_t>(), n_out, false));
+      for (Column& c : gather_columns(jt.build, bout, ob->as<int64_t>(), n_out, build_null_possible)) out.cols.push_back(std::move(c));
+    for (Column& c : gather_columns(probe, pout, op->as<int64_t>(), n_out, false)) out.cols.push_back(std::move(c));
     if (join_type == DFGPU_JOIN_RIGHT_MARK) out.cols.push_back(mark_column(om->as<uint8_t>(), n_out));
   }
   jt.info.output_rows += out.nrows;
@@ -1510,6 +1550,16 @@ static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std
   Pairs P = key_equal_pairs(jt, probe, pk);
   const int64_t m = P.m;
   BufPtr ob = P.ob, op = P.op;
+  if (!jfp && join_type == DFGPU_JOIN_INNER) {
+    // Inner join without a residual filter: the pairs ARE the output rows (no visited bytes, no per-probe-row hit counts)
+    Table out;
+    out.nrows = m;
+    for (Column& c : gather_columns(jt.build, bout, ob->as<int64_t>(), m, false)) out.cols.push_back(std::move(c));
+    for (Column& c : gather_columns(probe, pout, op->as<int64_t>(), m, false)) out.cols.push_back(std::move(c));
+    DFGPU_HIP(hipStreamSynchronize(r.stream));
+    jt.info.output_rows += out.nrows;
+    return out;
+  }
   // ---- intermediate batch + filter expression -> pass mask over the pairs (no filter: every pair passes)
   const int64_t m_words = (m + 63) / 64;
   BufPtr pass = make_buf((size_t)(m_words ? m_words : 1) * 8);
@@ -1561,8 +1611,8 @@ static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std
     if (n_un) k_append_unmatched<<<g, BLOCK, 0, r.stream>>>(umask->as<uint64_t>(), uprefix->as<uint64_t>(), np, n_pass, ob2->as<int64_t>(), op2->as<int64_t>());
     DFGPU_HIP(hipGetLastError());
     out.nrows = n_out;
-    for (int c : bout) out.cols.push_back(gather_column(jt.build.cols[c], ob2->as<int64_t>(), n_out, probe_outer));
-    for (int c : pout) out.cols.push_back(gather_column(probe.cols[c], op2->as<int64_t>(), n_out, false));
+    for (Column& c : gather_columns(jt.build, bout, ob2->as<int64_t>(), n_out, probe_outer)) out.cols.push_back(std::move(c));
+    for (Column& c : gather_columns(probe, pout, op2->as<int64_t>(), n_out, false)) out.cols.push_back(std::move(c));
   } else if (join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI) {
     BufPtr mask = make_zero_buf(bitmap_bytes(np ? np : 1));
     if (np) k_hits_mask<<<g, BLOCK, 0, r.stream>>>(hits->as<uint32_t>(), np, join_type == DFGPU_JOIN_RIGHT_SEMI, mask->as<uint64_t>(), nullptr);

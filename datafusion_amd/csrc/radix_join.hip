@@ -22,6 +22,7 @@
 // so all ten join types, NullEqualsNull and residual filters work on top of it.  Output order is partition order: valid where
 // the plan does not observe HashJoinExec's probe-side order (it is chosen by table_mode 4, or by `auto` under probe_mode 4).
 #include <algorithm>
+#include <cstdlib>
 
 #include "device.hpp"
 #include "internal.hpp"
@@ -267,8 +268,11 @@ std::shared_ptr<RadixTable> radix_join_build(const Table& build, const std::vect
   bool nullable = false;
   for (int i = 0; i < ks.n; i++) nullable |= ks.c[i].valid != nullptr;
   rt_->exact = ks.n == 1 && is_integer_like(ks.c[0].type) && !(null_equals_null && nullable) && !force_collisions;
+  // ~1024 build rows per partition on average, up to three 6-bit passes (268 M build rows): a partition that needs several LDS
+  // chunks per task costs far more than a third pass over HBM (profiles/r2_radix_sweep.md)
+  static const int max_bits = std::getenv("DFGPU_RJ_MAX_BITS") ? std::atoi(std::getenv("DFGPU_RJ_MAX_BITS")) : 18;  // tuning knob
   int bits = 0;
-  while (bits < 24 && ((int64_t)1024 << bits) < build.nrows) bits++;  // ~1024 build rows per partition on average
+  while (bits < max_bits && ((int64_t)1024 << bits) < build.nrows) bits++;
   if (force_collisions) bits = 0;
   rt_->bits = bits;
   rt_->build = rj_partition(build, key_cols, bits, rt_->exact, null_equals_null, force_collisions, "build");

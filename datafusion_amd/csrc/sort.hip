@@ -445,11 +445,16 @@ struct SortedKeys {
 };
 
 // digits of a packed key of `total_bits` bits, least significant first; <= 8 bits each, none straddles a word
+static int max_digit_bits() {
+  static const int v = std::getenv("DFGPU_RS_DIGIT_BITS") ? std::max(1, std::min(8, std::atoi(std::getenv("DFGPU_RS_DIGIT_BITS")))) : 8;  // tuning knob
+  return v;
+}
 static std::vector<Digit> key_digits(int total_bits) {
   std::vector<Digit> ds;
+  const int mb = max_digit_bits();
   for (int w = 0; w * 64 < total_bits; w++) {
     const int wbits = std::min(64, total_bits - w * 64);
-    const int nd = (wbits + 7) / 8;
+    const int nd = (wbits + mb - 1) / mb;
     int pos = 0;
     for (int d = 0; d < nd; d++) {
       const int b = (wbits - pos + (nd - d) - 1) / (nd - d);  // spread the bits evenly over the passes
@@ -465,7 +470,8 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
   Runtime& r = rt();
   if (n <= 1 || digits.empty()) return in;
   const int nwords = in.nwords;
-  const int items = rs_items(nwords);
+  static const int items1 = std::getenv("DFGPU_RS_ITEMS") ? std::atoi(std::getenv("DFGPU_RS_ITEMS")) : 16;  // tuning knob: 8 or 16 rows per thread (one key word); measured profiles/r2_radix_sweep.md
+  const int items = (nwords == 1 && items1 == 16 && !std::getenv("DFGPU_SORT_GEN1")) ? 16 : rs_items(nwords);
   const int64_t tile = (int64_t)BLOCK * items;
   const int64_t n_tiles = (n + tile - 1) / tile;
   SortedKeys cur = in, alt;
@@ -498,7 +504,10 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
       }
     } else {
       switch (nwords) {
-        case 1: k_rs_scatter2<1, rs_items(1)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        case 1:
+          if (items == 16) k_rs_scatter2<1, 16><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob);
+          else k_rs_scatter2<1, rs_items(1)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob);
+          break;
         case 2: k_rs_scatter2<2, rs_items(2)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
         default: k_rs_scatter2<3, rs_items(3)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
       }
@@ -520,7 +529,9 @@ void radix_sort_pairs(BufPtr& key, BufPtr& idx, int64_t n, int lo_bit, int nbits
     return;
   }
   std::vector<Digit> digits;
-  const int nd = (nbits + 7) / 8;
+  // 6-bit digits: a 64-way scatter of a 4096-row tile writes 64-row runs; 256-way passes cost 2x per pass (profiles/r2_radix_sweep.md)
+  const int mb = std::getenv("DFGPU_RS_DIGIT_BITS") ? max_digit_bits() : 6;
+  const int nd = (nbits + mb - 1) / mb;
   int pos = lo_bit;
   for (int d = 0; d < nd; d++) {
     const int b = (lo_bit + nbits - pos + (nd - d) - 1) / (nd - d);
@@ -665,7 +676,9 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     BufPtr take_idx = make_buf((size_t)n_out * 8);
     k_idx_to_i64<<<grid_for(n_out, BLOCK), BLOCK, 0, r.stream>>>(sorted.idx->as<uint32_t>(), remap ? remap->as<int64_t>() : nullptr, n_out, take_idx->as<int64_t>());
     DFGPU_HIP(hipGetLastError());
-    for (auto& c : in.cols) out.cols.push_back(gather_column(c, take_idx->as<int64_t>(), n_out, false));
+    std::vector<int> allc(in.cols.size());
+    for (size_t i = 0; i < allc.size(); i++) allc[i] = (int)i;
+    out.cols = gather_columns(in, allc, take_idx->as<int64_t>(), n_out, false);
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));
   return out;
