@@ -1651,6 +1651,108 @@ int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int nu
   });
 }
 
+// ---- streaming build side: collect_left_input (hash_join/exec.rs:2569-2705) accumulates the build child's batches, charging
+// a MemoryReservation per batch (exec.rs:2608 try_grow), then concat_batches + the table build.
+struct JoinBuilder {
+  std::vector<int> key_cols;
+  int null_equality = 0;
+  dfgpu_join_options opts{};
+  std::vector<std::unique_ptr<Table>> batches;  // shallow copies: the pushed tables' buffers stay alive through them
+  int64_t rows = 0, bytes = 0;
+  dfgpu_reservation_t reservation = nullptr;
+};
+static int64_t table_bytes(const Table& t) {
+  int64_t b = 0;
+  for (const Column& c : t.cols) b += (int64_t)data_bytes(c.field.type, c.length) + (c.validity ? (int64_t)bitmap_bytes(c.length) : 0);
+  return b;
+}
+
+int dfgpu_join_builder_create(const int* key_cols, int nkeys, int null_equality, const dfgpu_join_options* opts, dfgpu_join_builder_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(nkeys >= 1 && key_cols && out, "join needs at least one key column");
+    auto b = std::make_unique<JoinBuilder>();
+    b->key_cols.assign(key_cols, key_cols + nkeys);
+    b->null_equality = null_equality;
+    b->opts = dfgpu_join_options{1024, DFGPU_DEFAULT_MIN_KEY_DENSITY, 0, 0, 0, 0};
+    if (opts) b->opts = *opts;
+    *out = reinterpret_cast<dfgpu_join_builder_t>(b.release());
+  });
+}
+int dfgpu_join_builder_push(dfgpu_join_builder_t h, dfgpu_table_t batch) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(h != nullptr, "null join builder");
+    JoinBuilder* b = reinterpret_cast<JoinBuilder*>(h);
+    const Table& t = *unwrap(batch);
+    DFGPU_CHECK(b->batches.empty() || t.cols.size() == b->batches[0]->cols.size(), "join builder: batches differ in their column count");
+    // the concatenated copy + the join table are still to come: grow the reservation by this batch's share of them
+    // (2 x its bytes bounds copy + table for every table kind); refusal = the reference's ResourcesExhausted
+    const int64_t tb = table_bytes(t);
+    dfgpu_reservation_t more = nullptr;
+    if (dfgpu_mem_try_reserve(2 * tb, &more) != 0) throw Error(dfgpu_last_error());
+    if (b->reservation) {
+      int64_t held = 0;
+      (void)dfgpu_mem_reservation_size(b->reservation, &held);
+      (void)dfgpu_mem_release(b->reservation);
+      (void)dfgpu_mem_release(more);
+      b->reservation = nullptr;
+      if (dfgpu_mem_try_reserve(held + 2 * tb, &b->reservation) != 0) throw Error(dfgpu_last_error());
+    } else {
+      b->reservation = more;
+    }
+    b->batches.push_back(std::make_unique<Table>(t));
+    b->rows += t.nrows;
+    b->bytes += tb;
+  });
+}
+int dfgpu_join_builder_finish(dfgpu_join_builder_t h, dfgpu_join_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(h != nullptr && out != nullptr, "null argument");
+    std::unique_ptr<JoinBuilder> b(reinterpret_cast<JoinBuilder*>(h));
+    struct Release {
+      dfgpu_reservation_t r;
+      ~Release() { if (r) (void)dfgpu_mem_release(r); }
+    } rel{b->reservation};
+    DFGPU_CHECK(!b->batches.empty(), "join builder: no batch was pushed (push an empty batch for an empty build side)");
+    std::unique_ptr<Table> whole;
+    if (b->batches.size() == 1) {
+      whole = std::make_unique<Table>(*b->batches[0]);
+    } else {
+      std::vector<dfgpu_table_t> hs;
+      for (auto& t : b->batches) hs.push_back(wrap(t.get()));
+      dfgpu_table_t cat = nullptr;
+      if (dfgpu_table_concat(hs.data(), (int)hs.size(), &cat) != 0) throw Error(dfgpu_last_error());  // concat_batches (exec.rs:2705)
+      whole.reset(unwrap(cat));
+    }
+    b->batches.clear();
+    auto jt = join_build(*whole, b->key_cols, b->null_equality, b->opts);
+    *out = reinterpret_cast<dfgpu_join_t>(jt.release());
+  });
+}
+int dfgpu_join_builder_free(dfgpu_join_builder_t h) {
+  return guarded([&] {
+    if (!h) return;
+    std::unique_ptr<JoinBuilder> b(reinterpret_cast<JoinBuilder*>(h));
+    if (b->reservation) (void)dfgpu_mem_release(b->reservation);
+  });
+}
+
+// what a hash join of these sizes will hold on the device at its peak, for admission control (the optimizer rule declines —
+// keeps the CPU operator, which can spill — when dfgpu_mem_try_reserve refuses this much)
+int dfgpu_join_estimate_bytes(int64_t build_rows, int64_t build_row_bytes, int64_t probe_rows, int64_t output_rows, int64_t output_row_bytes, int64_t* out) {
+  return guarded([&] {
+    DFGPU_CHECK(out != nullptr && build_rows >= 0 && probe_rows >= 0, "bad argument");
+    // join table: the widest kind (ArrayMap over a sparse range / chained table: ~2 x 4 B x max(rows, range)) is bounded by 16 B per
+    // build row for the reference's own density gate; the LDS radix join holds 12 B records of both sides twice (ping-pong) + pairs
+    const int64_t table = build_rows * 16;
+    const int64_t radix = (build_rows + probe_rows) * 24 + (output_rows < 0 ? probe_rows : output_rows) * 16;
+    const int64_t outb = (output_rows < 0 ? probe_rows : output_rows) * output_row_bytes;
+    *out = build_rows * build_row_bytes /* concat_batches copy */ + std::max(table, radix) + outb + probe_rows * 5 /* match ids, masks */;
+  });
+}
+
 int dfgpu_column_minmax(dfgpu_table_t table, int column, int64_t* out_min, int64_t* out_max, int64_t* out_valid, int* out_ascending) {
   return guarded([&] {
     require_init();

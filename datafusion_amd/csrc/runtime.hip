@@ -321,6 +321,76 @@ int dfgpu_mem_trim(void) {
   return guarded([&] { rt().trim(); });
 }
 
+// ---- admission control: MemoryPool / MemoryReservation (execution/src/memory_pool/mod.rs:188 try_grow) for the device pool
+namespace {
+struct Reservation {
+  int device;
+  int64_t bytes;
+};
+std::mutex g_res_mu;
+std::map<int, int64_t> g_reserved;  // device -> outstanding reservations
+std::map<int, int64_t> g_limit;     // device -> limit (0 / absent: 92 % of the device's memory)
+int64_t limit_of(int device) {
+  auto it = g_limit.find(device);
+  if (it != g_limit.end() && it->second > 0) return it->second;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return INT64_MAX;
+  }
+  return (int64_t)((double)total_b * 0.92);
+}
+}  // namespace
+
+int dfgpu_mem_set_limit(int64_t bytes) {
+  return guarded([&] {
+    require_init();
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    g_limit[current_device()] = bytes;
+  });
+}
+int dfgpu_mem_limit(int64_t* limit, int64_t* reserved) {
+  return guarded([&] {
+    require_init();
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    if (limit) *limit = limit_of(current_device());
+    if (reserved) *reserved = g_reserved[current_device()];
+  });
+}
+int dfgpu_mem_try_reserve(int64_t bytes, dfgpu_reservation_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(out != nullptr && bytes >= 0, "bad argument");
+    Runtime& r = rt();
+    int64_t in_use = 0;
+    {
+      std::lock_guard<std::mutex> lk(r.mu);
+      in_use = r.in_use;
+    }
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    const int64_t lim = limit_of(r.device), held = g_reserved[r.device];
+    if (in_use + held + bytes > lim)
+      throw Error("Resources exhausted: Failed to allocate additional " + std::to_string(bytes) + " bytes of HBM with " + std::to_string(in_use) +
+                  " bytes in tables and " + std::to_string(held) + " bytes already reserved - maximum available is " + std::to_string(lim));
+    g_reserved[r.device] = held + bytes;
+    *out = reinterpret_cast<dfgpu_reservation_t>(new Reservation{r.device, bytes});
+  });
+}
+int dfgpu_mem_reservation_size(dfgpu_reservation_t h, int64_t* out) {
+  return guarded([&] {
+    DFGPU_CHECK(h && out, "null argument");
+    *out = reinterpret_cast<Reservation*>(h)->bytes;
+  });
+}
+int dfgpu_mem_release(dfgpu_reservation_t h) {
+  return guarded([&] {
+    if (!h) return;
+    std::unique_ptr<Reservation> res(reinterpret_cast<Reservation*>(h));
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    g_reserved[res->device] -= res->bytes;
+  });
+}
+
 int dfgpu_profile_enable(int on) {
   return guarded([&] {
     require_init();

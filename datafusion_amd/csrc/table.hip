@@ -207,8 +207,66 @@ static Column import_column(const ArrowArray* a, const ArrowSchema* s, int64_t p
 }
 
 // ---------------------------------------------------------------- export
+// Exported buffers are PINNED host memory from a process-wide pool: a device-to-host copy into pageable memory goes through
+// the driver's bounce buffers (measured 6.7 GB/s, profiles/r1_ops_v5.md); into pinned memory it is one DMA at PCIe rate.
+// hipHostMalloc is slow (it pins pages), so blocks are cached by size and come back when the consumer releases the batch —
+// a stream of equally sized output batches (LimitedBatchCoalescer's fixed target, coalesce/mod.rs:27-120) reuses them.
+struct PinnedPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;
+  std::map<void*, size_t> live;
+  size_t cached = 0;
+  static size_t cap() {
+    static const size_t v = std::getenv("DFGPU_PINNED_CACHE_BYTES") ? (size_t)std::atoll(std::getenv("DFGPU_PINNED_CACHE_BYTES")) : ((size_t)8 << 30);
+    return v;
+  }
+  void* alloc(size_t n) {
+    size_t c = 4096;
+    while (c < n) c <<= 1;
+    if (c > ((size_t)64 << 20)) c = (n + ((size_t)16 << 20) - 1) / ((size_t)16 << 20) * ((size_t)16 << 20);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_blocks.lower_bound(c);
+      if (it != free_blocks.end() && it->first <= c + c / 4) {
+        void* p = it->second;
+        cached -= it->first;
+        live[p] = it->first;
+        free_blocks.erase(it);
+        return p;
+      }
+    }
+    void* p = nullptr;
+    DFGPU_HIP(hipHostMalloc(&p, c, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lk(mu);
+    live[p] = c;
+    return p;
+  }
+  void release(void* p) {
+    if (!p) return;
+    size_t c = 0;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = live.find(p);
+      if (it == live.end()) return;
+      c = it->second;
+      live.erase(it);
+      if (cached + c <= cap()) {
+        free_blocks.emplace(c, p);
+        cached += c;
+        return;
+      }
+    }
+    (void)hipHostFree(p);
+  }
+};
+static PinnedPool& pinned() {
+  static PinnedPool* p = new PinnedPool();  // never destroyed: release callbacks may run at interpreter exit
+  return *p;
+}
+
 struct ExportPrivate {
   std::vector<void*> host_buffers;
+  std::vector<void*> pinned_buffers;
   std::vector<const void*> buffer_ptrs;
   std::vector<ArrowArray*> children;
   ArrowArray* dictionary = nullptr;
@@ -225,6 +283,7 @@ static void release_array(ArrowArray* a) {
     delete p->dictionary;
   }
   for (void* b : p->host_buffers) std::free(b);
+  for (void* b : p->pinned_buffers) pinned().release(b);
   delete p;
   a->release = nullptr;
 }
@@ -363,62 +422,128 @@ int dfgpu_table_import(struct ArrowArray* array, struct ArrowSchema* schema, dfg
   return rc;
 }
 
+// rows [offset, offset + length) of `t` as a struct array in pinned host memory.  Bit-packed buffers (validity, Boolean values)
+// start at a word boundary: the exported child carries the Arrow `offset` (< 64) of its first row.
+static void export_rows(Table* t, int64_t offset, int64_t length, struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+  Runtime& r = rt();
+  DFGPU_CHECK(out_array && out_schema, "null argument");
+  DFGPU_CHECK(offset >= 0 && length >= 0 && offset + length <= t->nrows, "export: row range out of bounds");
+  auto* ap = new ExportPrivate();
+  fill_schema(out_schema, "+s", "", false);
+  auto* sp = (SchemaPrivate*)out_schema->private_data;
+  const int64_t lead = offset & 63;          // rows ahead of `offset` inside its 64-row word
+  const int64_t row0 = offset - lead;
+  for (Column& c : t->cols) {
+    if (c.validity && c.null_count < 0) count_nulls(c);
+    auto* ca = new ArrowArray();
+    std::memset(ca, 0, sizeof(*ca));
+    auto* cp = new ExportPrivate();
+    const bool bits = c.field.type == DFGPU_BOOL;
+    const bool with_valid = c.validity && c.null_count != 0;
+    const bool shifted = (bits || with_valid) && lead != 0;   // every buffer of the child starts `lead` rows early
+    const int64_t first = shifted ? row0 : offset, rows = shifted ? length + lead : length;
+    const size_t db = bits ? bitmap_bytes(rows) : (size_t)rows * type_width(c.field.type);
+    void* hd = pinned().alloc(db ? db : 8);
+    cp->pinned_buffers.push_back(hd);
+    if (db) {
+      const char* src = (const char*)c.ptr() + (bits ? (size_t)(first >> 6) * 8 : (size_t)first * type_width(c.field.type));
+      DFGPU_HIP(hipMemcpyAsync(hd, src, db, hipMemcpyDeviceToHost, r.stream));
+    }
+    void* hv = nullptr;
+    int64_t nulls = 0;
+    if (with_valid) {
+      const size_t vb = bitmap_bytes(rows);
+      hv = pinned().alloc(vb ? vb : 8);
+      cp->pinned_buffers.push_back(hv);
+      if (vb) DFGPU_HIP(hipMemcpyAsync(hv, (const char*)c.validity->ptr + (size_t)(first >> 6) * 8, vb, hipMemcpyDeviceToHost, r.stream));
+      nulls = (offset == 0 && length == c.length) ? c.null_count : -1;  // a slice's count is left to the consumer
+    }
+    cp->buffer_ptrs = {hv, hd};
+    ca->length = length;
+    ca->offset = shifted ? lead : 0;
+    ca->null_count = nulls;
+    ca->n_buffers = 2;
+    ca->buffers = cp->buffer_ptrs.data();
+    ca->release = release_array;
+    ca->private_data = cp;
+    ap->children.push_back(ca);
+    auto* cs = new ArrowSchema();
+    fill_schema(cs, c.dict ? c.dict->index_format : format_of(c.field), c.name, true);
+    if (c.dict) {  // dictionary-encoded strings: indices from the device, values from the host
+      cp->dictionary = export_dictionary(*c.dict);
+      ca->dictionary = cp->dictionary;
+      auto* ds = new ArrowSchema();
+      fill_schema(ds, c.dict->value_format, "", true);
+      ((SchemaPrivate*)cs->private_data)->dictionary = ds;
+      cs->dictionary = ds;
+    }
+    sp->children.push_back(cs);
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  std::memset(out_array, 0, sizeof(*out_array));
+  ap->buffer_ptrs = {nullptr};
+  out_array->length = length;
+  out_array->n_buffers = 1;
+  out_array->buffers = ap->buffer_ptrs.data();
+  out_array->n_children = (int64_t)ap->children.size();
+  out_array->children = ap->children.data();
+  out_array->release = release_array;
+  out_array->private_data = ap;
+  out_schema->n_children = (int64_t)sp->children.size();
+  out_schema->children = sp->children.data();
+}
+
 int dfgpu_table_export(dfgpu_table_t th, struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
   return guarded([&] {
     require_init();
     Table* t = unwrap(th);
-    DFGPU_CHECK(out_array && out_schema, "null argument");
-    DFGPU_HIP(hipStreamSynchronize(rt().stream));
-    auto* ap = new ExportPrivate();
-    fill_schema(out_schema, "+s", "", false);
-    auto* sp = (SchemaPrivate*)out_schema->private_data;
-    for (Column& c : t->cols) {
-      if (c.validity && c.null_count < 0) count_nulls(c);
-      auto* ca = new ArrowArray();
-      std::memset(ca, 0, sizeof(*ca));
-      auto* cp = new ExportPrivate();
-      size_t db = data_bytes(c.field.type, c.length);
-      void* hd = std::malloc(db ? db : 8);
-      if (db) DFGPU_HIP(hipMemcpy(hd, c.ptr(), db, hipMemcpyDeviceToHost));
-      void* hv = nullptr;
-      if (c.validity && c.null_count != 0) {
-        size_t vb = bitmap_bytes(c.length);
-        hv = std::malloc(vb ? vb : 8);
-        if (vb) DFGPU_HIP(hipMemcpy(hv, c.validity->ptr, vb, hipMemcpyDeviceToHost));
-        cp->host_buffers.push_back(hv);
+    export_rows(t, 0, t->nrows, out_array, out_schema);
+  });
+}
+
+int dfgpu_table_export_batch(dfgpu_table_t th, int64_t offset, int64_t length, struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+  return guarded([&] {
+    require_init();
+    export_rows(unwrap(th), offset, length, out_array, out_schema);
+  });
+}
+
+int dfgpu_host_register(void* ptr, size_t bytes) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(ptr != nullptr && bytes > 0, "dfgpu_host_register: empty range");
+    DFGPU_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  });
+}
+int dfgpu_host_unregister(void* ptr) {
+  return guarded([&] {
+    require_init();
+    DFGPU_HIP(hipHostUnregister(ptr));
+  });
+}
+
+int dfgpu_table_export_into(dfgpu_table_t th, int64_t offset, int64_t length, void* const* data_buffers, void* const* validity_buffers) {
+  return guarded([&] {
+    require_init();
+    Table* t = unwrap(th);
+    Runtime& r = rt();
+    DFGPU_CHECK(data_buffers != nullptr, "null argument");
+    DFGPU_CHECK(offset >= 0 && length >= 0 && offset + length <= t->nrows, "export: row range out of bounds");
+    DFGPU_CHECK((offset & 63) == 0 || validity_buffers == nullptr, "dfgpu_table_export_into: bitmaps are copied as whole words, the row offset must be a multiple of 64");
+    for (size_t i = 0; i < t->cols.size(); i++) {
+      Column& c = t->cols[i];
+      const bool bits = c.field.type == DFGPU_BOOL;
+      DFGPU_CHECK(!bits || (offset & 63) == 0, "dfgpu_table_export_into: Boolean columns need a row offset that is a multiple of 64");
+      const size_t db = bits ? bitmap_bytes(length) : (size_t)length * type_width(c.field.type);
+      const char* src = (const char*)c.ptr() + (bits ? (size_t)(offset >> 6) * 8 : (size_t)offset * type_width(c.field.type));
+      if (db && data_buffers[i]) DFGPU_HIP(hipMemcpyAsync(data_buffers[i], src, db, hipMemcpyDeviceToHost, r.stream));
+      if (validity_buffers && validity_buffers[i]) {
+        const size_t vb = bitmap_bytes(length);
+        if (c.validity) DFGPU_HIP(hipMemcpyAsync(validity_buffers[i], (const char*)c.validity->ptr + (size_t)(offset >> 6) * 8, vb, hipMemcpyDeviceToHost, r.stream));
+        else std::memset(validity_buffers[i], 0xFF, vb);
       }
-      cp->host_buffers.push_back(hd);
-      cp->buffer_ptrs = {hv, hd};
-      ca->length = c.length;
-      ca->null_count = hv ? c.null_count : 0;
-      ca->n_buffers = 2;
-      ca->buffers = cp->buffer_ptrs.data();
-      ca->release = release_array;
-      ca->private_data = cp;
-      ap->children.push_back(ca);
-      auto* cs = new ArrowSchema();
-      fill_schema(cs, c.dict ? c.dict->index_format : format_of(c.field), c.name, true);
-      if (c.dict) {  // dictionary-encoded strings: indices from the device, values from the host
-        cp->dictionary = export_dictionary(*c.dict);
-        ca->dictionary = cp->dictionary;
-        auto* ds = new ArrowSchema();
-        fill_schema(ds, c.dict->value_format, "", true);
-        ((SchemaPrivate*)cs->private_data)->dictionary = ds;
-        cs->dictionary = ds;
-      }
-      sp->children.push_back(cs);
     }
-    std::memset(out_array, 0, sizeof(*out_array));
-    ap->buffer_ptrs = {nullptr};
-    out_array->length = t->nrows;
-    out_array->n_buffers = 1;
-    out_array->buffers = ap->buffer_ptrs.data();
-    out_array->n_children = (int64_t)ap->children.size();
-    out_array->children = ap->children.data();
-    out_array->release = release_array;
-    out_array->private_data = ap;
-    out_schema->n_children = (int64_t)sp->children.size();
-    out_schema->children = sp->children.data();
+    DFGPU_HIP(hipStreamSynchronize(r.stream));
   });
 }
 

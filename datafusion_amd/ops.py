@@ -328,6 +328,89 @@ def tpch_customer(sf: float, begin=0, end=-1) -> DeviceTable:
     return DeviceTable(out)
 
 
+# ----------------------------------------------------------------------------- streaming boundary, admission control
+class JoinBuilder:
+    """the build side as a stream of batches (dfgpu_join_builder_*: CollectBuildSide over collect_left_input): push every batch,
+    finish() -> JoinHashTable.  A push fails with "Resources exhausted" when the device pool cannot admit the build."""
+
+    def __init__(self, on_left_idx, null_equality="NullEqualsNothing", small_build_threshold=1024, min_key_density=1.0 / 64.0, table_mode=0,
+                 force_hash_collisions=False, probe_mode=0, null_aware=False):
+        lib = _lib.init()
+        self.key_idx = list(on_left_idx)
+        opts = JoinOptions(small_build_threshold, min_key_density, table_mode, int(force_hash_collisions), probe_mode, int(null_aware))
+        self._h = C.c_void_p()
+        check(lib.dfgpu_join_builder_create(_ints(self.key_idx), len(self.key_idx), NULL_EQUALITY[null_equality], C.byref(opts), C.byref(self._h)))
+        self._first = None
+
+    def push(self, batch: DeviceTable):
+        check(_lib.load().dfgpu_join_builder_push(self._h, batch.handle))
+        if self._first is None:
+            self._first = batch.select(list(range(batch.num_columns)))   # schema carrier for probe()'s column lookups
+
+    def finish(self) -> "JoinHashTable":
+        h = C.c_void_p()
+        check(_lib.load().dfgpu_join_builder_finish(self._h, C.byref(h)))
+        self._h = None
+        ht = JoinHashTable.__new__(JoinHashTable)
+        ht.build, ht.key_idx, ht._h = self._first, self.key_idx, h
+        return ht
+
+    def free(self):
+        if self._h:
+            _lib.load().dfgpu_join_builder_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def mem_set_limit(nbytes: int):
+    check(_lib.init().dfgpu_mem_set_limit(C.c_int64(nbytes)))
+
+
+def mem_limit():
+    """(limit, bytes reserved by operators in flight) of the current device's pool"""
+    lim, res = C.c_int64(), C.c_int64()
+    check(_lib.init().dfgpu_mem_limit(C.byref(lim), C.byref(res)))
+    return lim.value, res.value
+
+
+class Reservation:
+    """MemoryReservation: dfgpu_mem_try_reserve / dfgpu_mem_release"""
+
+    def __init__(self, nbytes: int):
+        self._h = C.c_void_p()
+        check(_lib.init().dfgpu_mem_try_reserve(C.c_int64(nbytes), C.byref(self._h)))
+        self.nbytes = nbytes
+
+    def release(self):
+        if self._h:
+            _lib.load().dfgpu_mem_release(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.release()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def join_estimate_bytes(build_rows, build_row_bytes, probe_rows, output_rows, output_row_bytes) -> int:
+    out = C.c_int64()
+    check(_lib.load().dfgpu_join_estimate_bytes(C.c_int64(build_rows), C.c_int64(build_row_bytes), C.c_int64(probe_rows), C.c_int64(output_rows),
+                                                C.c_int64(output_row_bytes), C.byref(out)))
+    return out.value
+
+
 # ----------------------------------------------------------------------------- metrics
 def sync():
     check(_lib.load().dfgpu_sync())

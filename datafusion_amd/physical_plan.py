@@ -20,7 +20,7 @@ per-operator GPU node):
 """
 from __future__ import annotations
 
-from . import ops
+from . import _lib, ops
 from .expr import BinaryExpr, CaseExpr, CastExpr, Column, InListExpr, IsNotNullExpr, IsNullExpr, Literal, NotExpr, PhysicalExpr
 from .table import DeviceTable
 
@@ -472,6 +472,27 @@ class GpuOffloadRule:
 
     def __init__(self, world_size: int = 1, unordered_probe: bool = True):
         self.world_size, self.unordered_probe = world_size, unordered_probe
+        self.declined = []    # (node, reason) of operators the rule left to the CPU
+
+    def _admits(self, node) -> bool:
+        """spill-aware fallback: a hash join whose device footprint the pool cannot admit stays the reference's CPU
+        operator, which can spill (MemoryReservation::try_grow failing is how the reference itself learns it, hash_join/exec.rs:2608).
+        The estimate uses row-count upper bounds of the children (their statistics) and dfgpu_join_estimate_bytes."""
+        if _lib._initialised_device is None:
+            return True       # planning without a device (tests of the rewrite shapes): nothing to admit against
+        try:
+            b_rows, b_bytes = _row_bound(node.left)
+            p_rows, p_bytes = _row_bound(node.right)
+        except (TypeError, AttributeError):
+            return True       # no statistics: decided at run time by the build's own reservation
+        out_row = (b_bytes + p_bytes)
+        need = ops.join_estimate_bytes(b_rows, b_bytes, p_rows, -1, out_row)
+        try:
+            ops.Reservation(need).release()
+            return True
+        except _lib.DfgpuError as e:
+            self.declined.append((node, str(e)))
+            return False
 
     def name(self) -> str:
         return "gpu_offload_amd"
@@ -501,6 +522,9 @@ class GpuOffloadRule:
             return node.input
         if isinstance(node, (RepartitionExec, CoalescePartitionsExec, SortPreservingMergeExec)) and self.world_size == 1:
             return node.input                                  # one partition: nothing to exchange, gather or merge
+        if isinstance(node, HashJoinExec) and not isinstance(node, GpuHashJoinExec) and not self._admits(node):
+            node.kept_on_cpu = True
+            return node
         if isinstance(node, HashJoinExec) and not isinstance(node, GpuHashJoinExec):
             probe_mode = ops.PROBE_MODES["order_not_needed"] if (self.unordered_probe and not parent_needs_order and
                                                                       node.join_type in ("Inner", "RightSemi", "RightAnti")) else node.probe_mode
@@ -526,6 +550,20 @@ class GpuOffloadRule:
                 aggs = [(f, None if e is None else substitute(e, mapping), n) for f, e, n in node.aggr_expr]
                 return GpuFusedAggregateExec(node.mode, gb, aggs, predicate, child)
         return node
+
+
+def _row_bound(node):
+    """(upper bound of the output rows, bytes per row) of a subtree from its leaves' statistics"""
+    if isinstance(node, MemoryExec):
+        t = node.execute()
+        return t.num_rows, (t.nbytes() // max(1, t.num_rows))
+    if isinstance(node, (FilterExec, ProjectionExec, CoalesceBatchesExec, RepartitionExec, CoalescePartitionsExec, SortExec, SortPreservingMergeExec,
+                         AggregateExec, GpuFusedAggregateExec)):
+        return _row_bound(node.children()[0])
+    if isinstance(node, HashJoinExec):
+        (br, bb), (pr, pb) = _row_bound(node.left), _row_bound(node.right)
+        return max(br, pr), bb + pb
+    raise TypeError(node.name())
 
 
 def displayable(plan: ExecutionPlan, indent: int = 0) -> str:

@@ -94,6 +94,16 @@ class DeviceTable:
         batch = pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
         return pa.Table.from_batches([batch])
 
+    def to_batches(self, batch_rows: int = 8192):
+        """the table as a stream of RecordBatches of `batch_rows` rows (the last one may be shorter): what the shim's
+        poll_next yields (dfgpu_table_export_batch; LimitedBatchCoalescer's target batch size, coalesce/mod.rs:27-120)"""
+        lib = _lib.load()
+        n = self.num_rows
+        for off in range(0, max(n, 1), batch_rows):
+            arr, sch = ArrowArray(), ArrowSchema()
+            check(lib.dfgpu_table_export_batch(self._h, C.c_int64(off), C.c_int64(min(batch_rows, n - off)), C.byref(arr), C.byref(sch)))
+            yield pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+
     # ------------------------------------------------------------------ inspection
     @property
     def handle(self) -> C.c_void_p:

@@ -149,6 +149,17 @@ void* dfgpu_stream(void);
  * Counterpart of MemoryReservation accounting (execution/src/memory_pool/mod.rs:188). */
 int dfgpu_mem_stats(int64_t* in_use, int64_t* cached, int64_t* peak);
 int dfgpu_mem_trim(void);
+/* Admission control = MemoryPool::try_grow / MemoryReservation (execution/src/memory_pool/mod.rs:188; the hash join's
+ * build side charges one per batch, hash_join/exec.rs:2608).  An operator reserves what it is about to hold on the current
+ * device; the call fails with the reference's "Resources exhausted: ..." message when tables + reservations + the request
+ * exceed the limit (default 92 % of the device's memory) — the optimizer rule then keeps the CPU operator, which can spill
+ * (the spill-aware fallback of SURVEY §8f N4).  A reservation does not allocate; release it when the operator is done. */
+typedef struct dfgpu_reservation_s* dfgpu_reservation_t;
+int dfgpu_mem_set_limit(int64_t bytes); /* 0 = back to the default */
+int dfgpu_mem_limit(int64_t* limit, int64_t* reserved);
+int dfgpu_mem_try_reserve(int64_t bytes, dfgpu_reservation_t* out);
+int dfgpu_mem_reservation_size(dfgpu_reservation_t r, int64_t* out);
+int dfgpu_mem_release(dfgpu_reservation_t r);
 
 /* ------------------------------------------------------------------ tables */
 
@@ -161,6 +172,17 @@ int dfgpu_table_import(struct ArrowArray* array, struct ArrowSchema* schema, dfg
 /* Export to host memory as a struct array + schema owned by the caller (release
  * callbacks set).  Replaces: the RecordBatch items a SendableRecordBatchStream yields. */
 int dfgpu_table_export(dfgpu_table_t t, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+/* Rows [offset, offset + length) as one RecordBatch: the output batching of the stream contract (LimitedBatchCoalescer's
+ * fixed target batch size, physical-plan/src/coalesce/mod.rs:27-120; batch_size 8192 by default) — the shim's poll_next
+ * exports the next slice.  Buffers are pinned host memory from a cached pool (one DMA at PCIe rate; they return to the pool
+ * when the consumer releases the batch); a child whose bitmaps do not start at a word boundary carries an Arrow `offset`. */
+int dfgpu_table_export_batch(dfgpu_table_t t, int64_t offset, int64_t length, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+/* The same into buffers the caller owns (e.g. arrow-rs MutableBuffers it registered once with dfgpu_host_register =
+ * hipHostRegister): data_buffers[i] / validity_buffers[i] per column, NULL entries are skipped; bitmaps are copied as whole
+ * 64-bit words, so `offset` must be a multiple of 64 when a validity or Boolean buffer is requested. */
+int dfgpu_host_register(void* ptr, size_t bytes);
+int dfgpu_host_unregister(void* ptr);
+int dfgpu_table_export_into(dfgpu_table_t t, int64_t offset, int64_t length, void* const* data_buffers, void* const* validity_buffers);
 /* Dictionary-encoded string columns (Arrow Dictionary(UInt8 | Int32 | UInt32 | Int64 | UInt64, Utf8 | LargeUtf8)) are
  * imported as their index column; the dictionary stays on the host, is handed on to every column derived from it by
  * selecting or reordering rows (filter, take, join payload, group keys, partitions, sort output) and re-attached on
@@ -299,6 +321,20 @@ typedef struct dfgpu_join_options {
  * (the handle holds a reference).  key_cols index into `build`. */
 int dfgpu_join_build(dfgpu_table_t build, const int* key_cols, int nkeys, int null_equality,
                      const dfgpu_join_options* opts, dfgpu_join_t* out);
+/* The build side as a stream of batches = HashJoinStream's CollectBuildSide state (hash_join/stream.rs:127-140,591-640) over
+ * collect_left_input (exec.rs:2569-2705): push every batch of the build child (each push grows a memory reservation and fails
+ * with "Resources exhausted" like try_grow, exec.rs:2608), then finish = concat_batches + table build.  finish consumes the
+ * builder; free abandons it.  The probe side is a stream already: dfgpu_join_probe per probe batch, then
+ * dfgpu_join_emit_unmatched (ExhaustedProbeSide). */
+typedef struct dfgpu_join_builder_s* dfgpu_join_builder_t;
+int dfgpu_join_builder_create(const int* key_cols, int nkeys, int null_equality, const dfgpu_join_options* opts, dfgpu_join_builder_t* out);
+int dfgpu_join_builder_push(dfgpu_join_builder_t b, dfgpu_table_t batch);
+int dfgpu_join_builder_finish(dfgpu_join_builder_t b, dfgpu_join_t* out);
+int dfgpu_join_builder_free(dfgpu_join_builder_t b);
+/* peak device bytes of a hash join of these sizes (output_rows < 0: assume one output row per probe row), for
+ * dfgpu_mem_try_reserve: what the optimizer rule checks before it substitutes the GPU operator */
+int dfgpu_join_estimate_bytes(int64_t build_rows, int64_t build_row_bytes, int64_t probe_rows, int64_t output_rows, int64_t output_row_bytes, int64_t* out);
+
 /* HashJoinStream::process_probe_batch (hash_join/stream.rs:740-1000): probe one probe
  * table (any size — the whole partition, not 8192-row batches) and materialise the output
  * for `join_type`.  Output columns = build_out_cols of the build table followed by
