@@ -1636,6 +1636,424 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   return true;
 }
 
+// ---------------------------------------------------------------- specialised node: group key arrives in order
+// GROUP BY <integer column> whose values are non-decreasing in row order (TPC-H: lineitem by l_orderkey, orders by
+// o_orderkey — the clustering dbgen produces and a sorted scan declares): equal keys are adjacent, so groups are RUNS of
+// rows and the group number of a row is the number of run heads before it — the reference's fully-ordered aggregation
+// (aggregates/order/full.rs GroupOrderingFull: the current group is the last one, earlier groups are complete), without
+// any table: no bitmap over the key range, no hash, no renumbering (run order IS first-seen order).
+//   heads      : head[i] = key[i] != key[i-1]                 (one pass over the key column; wave ballot = one word)
+//   scan       : exclusive popcount prefix per 64-row word     (scan.hip)
+//   accumulate : one wave per word; a segmented wave scan gives every run's total at its last lane.  A run that starts in
+//                this word and ends before the end of the NEXT word is finished by this wave (it evaluates the run's first
+//                rows of the next word itself) and leaves as plain stores — no atomics, no initialised accumulators; only
+//                pieces of longer runs (> 64 rows) fall back to atomics on identity-filled cells.
+// Whether the column is ordered comes from its cached statistics (column_stats: min / max / ascending / non-decreasing,
+// one pass, shared with the join's map gating) — the scan-statistics twin of the reference's `output_ordering`.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_run_heads(const T* __restrict__ key, int64_t n, uint64_t* __restrict__ heads) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  const unsigned lane = lane_id();
+  constexpr int U = 4;
+  for (int64_t w0 = wave * U; w0 < n_words; w0 += n_waves * U) {
+    T k[U], kp[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {  // a wave's U words are consecutive: lane 0 of word j takes its predecessor from lane 63 of word j - 1
+      const int64_t i = ((w0 + j) << 6) + lane;
+      const int64_t ic = i < n ? i : n - 1;
+      k[j] = key[ic];
+    }
+    const int64_t first = w0 << 6;
+    const T before = key[first > 0 ? (first < n ? first : n) - 1 : 0];  // one extra element per wave iteration (same line as k[0])
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const T up = (T)__shfl_up((unsigned long long)k[j], 1, 64);
+      const T carry = j == 0 ? before : (T)__shfl((unsigned long long)k[j > 0 ? j - 1 : 0], 63, 64);
+      kp[j] = lane == 0 ? carry : up;
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const int64_t i = ((w0 + j) << 6) + lane;
+      const uint64_t h = ballot64(i < n && (i == 0 || k[j] != kp[j]));
+      if (lane == 0 && w0 + j < n_words) heads[w0 + j] = h;
+    }
+  }
+}
+// flag[0] |= 1 when some run spans more than "the rest of its first word + the leading rows of the next word"
+__global__ __launch_bounds__(BLOCK) void k_run_long_flag(const uint64_t* __restrict__ heads, int64_t n_words, uint32_t* __restrict__ flag) {
+  bool any = false;
+  for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x + 1; w < n_words; w += (int64_t)gridDim.x * BLOCK) {
+    const uint64_t hw = heads[w];
+    if (hw & 1ull) continue;                                  // a run starts at the word's first row: nothing is carried in
+    const bool short_run = heads[w - 1] != 0ull && (hw != 0ull || w == n_words - 1);
+    any |= !short_run;
+  }
+  if (ballot64(any) != 0 && lane_id() == 0) atomicOr(flag, 1u);
+}
+
+constexpr int RUNS_MAX_ACCS = 16;
+struct RunsNodeArgs {
+  const void* col[RP_MAX_COLS];
+  const uint64_t* valid[RP_MAX_COLS];
+  const uint64_t* heads;
+  const uint64_t* prefix;
+  unsigned long long* cell[2 * RUNS_MAX_ACCS];  // per accumulator: [2k] = value / low word, [2k + 1] = high word of an i128 sum
+  uint32_t* seen[RUNS_MAX_ACCS];                // per accumulator, null = none kept (the count of an AVG)
+  void* key_out;
+  long long n;
+};
+struct RunsAcc {
+  int kind;     // AccKind
+  int val;      // value id in the generated source, -1 = none (COUNT(*))
+  bool narrow;  // ACC_SUM_I128 over values of at most 16 decimal digits: the sum of 128 rows fits 64 bits
+};
+
+static std::string agg_runs_node_source(const CompiledProgram& cp, int key_val, int key_type, const std::vector<RunsAcc>& accs) {
+  auto S = [](long long v) { return std::to_string(v); };
+  const int K = (int)accs.size();
+  std::string src = R"SRC(
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+typedef unsigned long long U64;
+typedef long long I64;
+typedef unsigned int U32;
+typedef int I32;
+typedef unsigned char U8;
+#define BLOCK 256
+struct Args {
+  const void* col[10];
+  const U64* valid[10];
+  const U64* heads;
+  const U64* prefix;
+  U64* cell[32];
+  U32* seen[16];
+  void* key_out;
+  long long n;
+};
+__device__ __forceinline__ double v2f(i128 x) { return __longlong_as_double((long long)(U64)x); }
+__device__ __forceinline__ i128 f2v(double d) { return (i128)(u128)(U64)__double_as_longlong(d); }
+__device__ __forceinline__ long long f64ord(U64 bits) { long long b = (long long)bits; return b ^ (long long)((U64)(b >> 63) >> 1); }
+__device__ __forceinline__ bool kt(i128 v, bool n) { return !n && ((int)v & 1); }
+__device__ __forceinline__ bool kf(i128 v, bool n) { return !n && !((int)v & 1); }
+#define SEG_SCAN(STEP)                                        \
+  bool f = head;                                              \
+  const int lane = threadIdx.x & 63;                          \
+  _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) {        \
+    const int fo = __shfl_up((int)f, d, 64);                  \
+    STEP                                                      \
+    if (lane >= d && !f) f = fo != 0;                         \
+  }
+__device__ __forceinline__ U64 seg_add_u64(U64 v, bool head) {
+  SEG_SCAN(const U64 o = __shfl_up(v, d, 64); if (lane >= d && !f) v += o;)
+  return v;
+}
+__device__ __forceinline__ u128 seg_add_u128(u128 v, bool head) {
+  SEG_SCAN(const U64 ol = __shfl_up((U64)v, d, 64); const U64 oh = __shfl_up((U64)(v >> 64), d, 64); if (lane >= d && !f) v += ((u128)oh << 64) | ol;)
+  return v;
+}
+__device__ __forceinline__ double seg_add_f64(double v, bool head) {
+  SEG_SCAN(const double o = __shfl_up(v, d, 64); if (lane >= d && !f) v += o;)
+  return v;
+}
+__device__ __forceinline__ long long seg_min_i64(long long v, bool head) {
+  SEG_SCAN(const long long o = __shfl_up(v, d, 64); if (lane >= d && !f) v = o < v ? o : v;)
+  return v;
+}
+__device__ __forceinline__ long long seg_max_i64(long long v, bool head) {
+  SEG_SCAN(const long long o = __shfl_up(v, d, 64); if (lane >= d && !f) v = o > v ? o : v;)
+  return v;
+}
+// Unsegmented inclusive wave prefix sums in 6 DPP steps (VALU only — the segmented scans above cost 3-5 LDS-crossbar
+// permutes per step): a run's total is P[last lane] - P[lane before its first lane], exact in wrapping integer arithmetic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ U64 dpp_u64(U64 v) {
+  const U32 lo = (U32)__builtin_amdgcn_update_dpp(0, (int)(U32)v, CTRL, ROW_MASK, 0xF, true);
+  const U32 hi = (U32)__builtin_amdgcn_update_dpp(0, (int)(U32)(v >> 32), CTRL, ROW_MASK, 0xF, true);
+  return ((U64)hi << 32) | lo;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u128 dpp_u128(u128 v) { return ((u128)dpp_u64<CTRL, ROW_MASK>((U64)(v >> 64)) << 64) | dpp_u64<CTRL, ROW_MASK>((U64)v); }
+__device__ __forceinline__ U64 scan_u64(U64 v) {
+  v += dpp_u64<0x111, 0xF>(v); v += dpp_u64<0x112, 0xF>(v); v += dpp_u64<0x114, 0xF>(v); v += dpp_u64<0x118, 0xF>(v);
+  v += dpp_u64<0x142, 0xA>(v); v += dpp_u64<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ u128 scan_u128(u128 v) {
+  v += dpp_u128<0x111, 0xF>(v); v += dpp_u128<0x112, 0xF>(v); v += dpp_u128<0x114, 0xF>(v); v += dpp_u128<0x118, 0xF>(v);
+  v += dpp_u128<0x142, 0xA>(v); v += dpp_u128<0x143, 0xC>(v);
+  return v;
+}
+// value of lane `src` (all lanes execute)
+__device__ __forceinline__ U64 lane_u64(U64 v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ u128 lane_u128(u128 v, int src) { return ((u128)__shfl((U64)(v >> 64), src, 64) << 64) | __shfl((U64)v, src, 64); }
+// whole-wave reductions (the rows of the next word that finish this word's last run)
+__device__ __forceinline__ double all_add_f64(double v) {
+  _Pragma("unroll") for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ long long all_min_i64(long long v) {
+  _Pragma("unroll") for (int d = 32; d >= 1; d >>= 1) { const long long o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ long long all_max_i64(long long v) {
+  _Pragma("unroll") for (int d = 32; d >= 1; d >>= 1) { const long long o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+  return v;
+}
+)SRC";
+  const int KK = std::max(K, 1);
+  src += "#define NACC " + S(KK) + "\n";
+  src += "__device__ __forceinline__ void eval_row(const Args& a, const long long i, long long& key, U64 (&Xlo)[NACC], U64 (&Xhi)[NACC], bool (&Xok)[NACC]) {\n";
+  src += cp.src_loads;
+  src += cp.src_pred;
+  src += cp.src_outs;
+  src += "    key = (long long)(U64)V" + S(key_val) + ";\n";
+  for (int k = 0; k < K; k++) {
+    const RunsAcc& c = accs[(size_t)k];
+    if (c.val >= 0)
+      src += "    Xok[" + S(k) + "] = !N" + S(c.val) + "; Xlo[" + S(k) + "] = (U64)V" + S(c.val) + "; Xhi[" + S(k) + "] = (U64)((u128)V" + S(c.val) + " >> 64);\n";
+    else
+      src += "    Xok[" + S(k) + "] = true;\n";
+  }
+  src += "}\n";
+  std::string key_store;
+  switch (key_type) {
+    case DFGPU_INT64: key_store = "((long long*)a.key_out)[g] = key;"; break;
+    case DFGPU_UINT8: key_store = "((U8*)a.key_out)[g] = (U8)key;"; break;
+    default: key_store = "((U32*)a.key_out)[g] = (U32)key;"; break;  // INT32 / DATE32 / UINT32
+  }
+  src += R"SRC(
+extern "C" __global__ __launch_bounds__(BLOCK) void runs_accumulate(Args a) {
+  const int lane_ = threadIdx.x & 63;
+  const long long n_words = (a.n + 63) >> 6;
+  const long long n_waves = ((long long)gridDim.x * BLOCK) >> 6;
+  for (long long w = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 6; w < n_words; w += n_waves) {
+    const U64 hw = a.heads[w];
+    const bool has_next = w + 1 < n_words;
+    const U64 hprev = w > 0 ? a.heads[w - 1] : 1ull;
+    const U64 hnext = has_next ? a.heads[w + 1] : 1ull;
+    const int lead = hw ? __builtin_ctzll(hw) : 64;                  // leading rows that continue a run of an earlier word
+    const bool lead_short = hprev != 0ull && (hw != 0ull || !has_next);  // ... which the previous word's wave finishes itself
+    int ext = 0;                                                      // rows of the next word that finish this word's last run
+    if (has_next && !(hnext & 1ull) && hw != 0ull && (hnext != 0ull || w + 2 == n_words)) {
+      const long long rem = a.n - ((w + 1) << 6);
+      ext = hnext ? __builtin_ctzll(hnext) : (int)(rem < 64 ? rem : 64);
+    }
+    const long long i = (w << 6) + lane_;
+    const bool active = i < a.n && (lane_ >= lead || !lead_short);
+    U64 Xlo[NACC], Xhi[NACC], Elo[NACC], Ehi[NACC];
+    bool Xok[NACC], Eok[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) { Xlo[k] = Xhi[k] = Elo[k] = Ehi[k] = 0ull; Xok[k] = Eok[k] = false; }
+    long long key = 0, key2 = 0;
+    if (active) eval_row(a, i, key, Xlo, Xhi, Xok);
+    if (lane_ < ext) eval_row(a, ((w + 1) << 6) + lane_, key2, Elo, Ehi, Eok);
+    const long long g = (long long)a.prefix[w] + __popcll(hw & ((2ull << lane_) - 1ull)) - 1;
+    const bool is_head = (hw >> lane_) & 1ull;
+    const bool head = lane_ == 0 || is_head;
+    const bool tail = lane_ == 63 || ((hw >> (lane_ + 1)) & 1ull);
+    const bool cont = lane_ < lead;
+    const bool ends = lane_ < 63 || !has_next || (hnext & 1ull) || ext > 0;
+    const bool plain = tail && !cont && ends;                    // the whole run is in this wave's hands: plain stores
+    const bool atom = tail && !plain && !(cont && lead_short);   // a piece of a long run: atomics on identity-filled cells
+    if (is_head) { )SRC" + key_store + R"SRC( }
+    // the segment (piece of a run) this lane belongs to starts at lane h; rows and non-NULL values are counted on ballots
+    const int h = 63 - __builtin_clzll((hw | 1ull) & ((2ull << lane_) - 1ull));
+    const U64 seg_mask = ((2ull << lane_) - 1ull) & ~((1ull << h) - 1ull);
+    const U64 ext_mask = ext >= 64 ? ~0ull : ((1ull << ext) - 1ull);
+    const int hp = (h + 63) & 63;  // the lane before the segment (its prefix is subtracted; none for h == 0)
+    const U64 run_rows = (U64)__popcll(__ballot(active) & seg_mask) + (lane_ == 63 ? (U64)ext : 0ull);
+)SRC";
+  for (int k = 0; k < K; k++) {
+    const RunsAcc& c = accs[(size_t)k];
+    const std::string ks = "[" + S(k) + "]";
+    const bool maybe_null = c.val >= 0 && cp.src_maybe_null[(size_t)c.val];
+    const std::string cell = "a.cell[" + S(2 * k) + "]", cellhi = "a.cell[" + S(2 * k + 1) + "]", seen = "a.seen[" + S(k) + "]";
+    src += "    {\n";
+    if (maybe_null)  // the ballots are taken by the whole wave, outside any lane-dependent expression
+      src += "      const U64 okm = __ballot(Xok" + ks + "), eokm = __ballot(Eok" + ks + ");\n"
+             "      const U64 cnt = (U64)__popcll(okm & seg_mask) + (lane_ == 63 ? (U64)__popcll(eokm & ext_mask) : 0ull);\n";
+    else src += "      const U64 cnt = run_rows;\n";
+    const std::string seen_plain = "if (" + seen + ") " + seen + "[g] = cnt ? 1u : 0u;";
+    const std::string seen_atom = "if (" + seen + " && !" + seen + "[g]) atomicOr(" + seen + " + g, 1u);";
+    const std::string add128 = "const U64 lo = (U64)t, hi = (U64)(t >> 64); const U64 old = atomicAdd(" + cell + " + g, lo); atomicAdd(" + cellhi +
+                               " + g, hi + ((old + lo) < old ? 1ull : 0ull));";
+    switch (c.kind) {
+      case ACC_SUM_I128:
+        if (c.narrow) {
+          src += "      const U64 P = scan_u64(Xok" + ks + " ? Xlo" + ks + " : 0ull);\n"
+                 "      const U64 Pp = lane_u64(P, hp);\n"
+                 "      U64 t64 = P - (h ? Pp : 0ull);\n"
+                 "      if (ext) { const U64 E = scan_u64(Eok" + ks + " ? Elo" + ks + " : 0ull); if (lane_ == 63) t64 += E; }\n"
+                 "      const u128 t = (u128)(i128)(long long)t64;\n";
+        } else {
+          src += "      const u128 P = scan_u128(Xok" + ks + " ? (((u128)Xhi" + ks + " << 64) | Xlo" + ks + ") : (u128)0);\n"
+                 "      const u128 Pp = lane_u128(P, hp);\n"
+                 "      u128 t = P - (h ? Pp : (u128)0);\n"
+                 "      if (ext) { const u128 E = scan_u128(Eok" + ks + " ? (((u128)Ehi" + ks + " << 64) | Elo" + ks + ") : (u128)0); if (lane_ == 63) t += E; }\n";
+        }
+        src += "      if (plain) { " + cell + "[g] = (U64)t; " + cellhi + "[g] = (U64)(t >> 64); " + seen_plain + " }\n"
+               "      else if (atom && cnt) { " + add128 + " " + seen_atom + " }\n";
+        break;
+      case ACC_SUM_I64:
+        src += "      const U64 P = scan_u64(Xok" + ks + " ? Xlo" + ks + " : 0ull);\n"
+               "      const U64 Pp = lane_u64(P, hp);\n"
+               "      U64 t = P - (h ? Pp : 0ull);\n"
+               "      if (ext) { const U64 E = scan_u64(Eok" + ks + " ? Elo" + ks + " : 0ull); if (lane_ == 63) t += E; }\n"
+               "      if (plain) { " + cell + "[g] = t; " + seen_plain + " }\n"
+               "      else if (atom && cnt) { atomicAdd(" + cell + " + g, t); " + seen_atom + " }\n";
+        break;
+      case ACC_SUM_F64:  // floating point: a difference of prefixes would cancel, so the run is summed by a segmented scan
+        src += "      double t = seg_add_f64(Xok" + ks + " ? __longlong_as_double((long long)Xlo" + ks + ") : 0.0, head);\n"
+               "      if (ext) { const double e = all_add_f64(Eok" + ks + " ? __longlong_as_double((long long)Elo" + ks + ") : 0.0); if (lane_ == 63) t += e; }\n"
+               "      if (plain) { " + cell + "[g] = (U64)__double_as_longlong(t); " + seen_plain + " }\n"
+               "      else if (atom && cnt) { atomicAdd(reinterpret_cast<double*>(" + cell + " + g), t); " + seen_atom + " }\n";
+        break;
+      case ACC_MIN_I64:
+        src += "      long long t = seg_min_i64(Xok" + ks + " ? (long long)Xlo" + ks + " : 0x7fffffffffffffffll, head);\n"
+               "      if (ext) { const long long e = all_min_i64(Eok" + ks + " ? (long long)Elo" + ks + " : 0x7fffffffffffffffll); if (lane_ == 63) t = e < t ? e : t; }\n"
+               "      if (plain) { " + cell + "[g] = (U64)t; " + seen_plain + " }\n"
+               "      else if (atom && cnt) { atomicMin(reinterpret_cast<long long*>(" + cell + " + g), t); " + seen_atom + " }\n";
+        break;
+      case ACC_MAX_I64:
+        src += "      long long t = seg_max_i64(Xok" + ks + " ? (long long)Xlo" + ks + " : (-0x7fffffffffffffffll - 1), head);\n"
+               "      if (ext) { const long long e = all_max_i64(Eok" + ks + " ? (long long)Elo" + ks + " : (-0x7fffffffffffffffll - 1)); if (lane_ == 63) t = e > t ? e : t; }\n"
+               "      if (plain) { " + cell + "[g] = (U64)t; " + seen_plain + " }\n"
+               "      else if (atom && cnt) { atomicMax(reinterpret_cast<long long*>(" + cell + " + g), t); " + seen_atom + " }\n";
+        break;
+      default:  // ACC_COUNT / ACC_COUNT_STAR
+        src += "      if (plain) { " + cell + "[g] = cnt; " + seen_plain + " }\n"
+               "      else if (atom && cnt) { atomicAdd(" + cell + " + g, cnt); " + seen_atom + " }\n";
+        break;
+    }
+    src += "    }\n";
+  }
+  src += "  }\n}\n";
+  return src;
+}
+
+// The ordered-input node.  Returns false (state untouched) when it does not apply.
+static bool agg_update_sorted_runs_jit(Aggregate& A, const Table& in, const dfgpu_expr* pred) {
+  Runtime& r = rt();
+  const int64_t n = in.nrows;
+  if (pred || env_int("DFGPU_JIT", 1) == 0 || env_int("DFGPU_AGG_RUNS", 1) == 0 || A.group_roots.size() != 1 || A.ngroups != 0) return false;
+  if (n < env_int("DFGPU_JIT_MIN_ROWS", 1 << 22) || n >= 0xFFFFFFFFll) return false;
+  int key_col = -1;
+  if (!is_plain_column(A.group_nodes[0], A.group_roots[0], &key_col) || key_col < 0 || key_col >= (int)in.cols.size()) return false;
+  const Column& kcol = in.cols[(size_t)key_col];
+  const dfgpu_field kf = kcol.field;
+  if (kcol.validity || !(kf.type == DFGPU_INT32 || kf.type == DFGPU_INT64 || kf.type == DFGPU_DATE32 || kf.type == DFGPU_UINT32 || kf.type == DFGPU_UINT8)) return false;
+  if (!column_stats(const_cast<Column&>(kcol), n).nondecreasing) return false;  // cached on the (immutable) column
+  // ---- compile: key + aggregate arguments
+  std::string why;
+  RowProgramCompiler comp(in);
+  dfgpu_expr ke{A.group_nodes[0].data(), (int)A.group_nodes[0].size(), A.group_roots[0]};
+  const int key_out = comp.add_output(ke);
+  std::vector<int> arg_out(A.aggs.size(), -1);
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    if (!a.has_arg) continue;
+    dfgpu_expr e{a.nodes.data(), (int)a.nodes.size(), a.root};
+    arg_out[k] = comp.add_output(e);
+    dfgpu_field t = comp.output_type(arg_out[k]);
+    if (a.typed) DFGPU_CHECK(a.in_type.type == t.type, "aggregate argument type changed between batches");
+    AccPlan p = plan_for(a.func, t, false);
+    if (p.val == VAL_I32_TO_F64 || p.val == VAL_I64_TO_F64) comp.convert_output(arg_out[k], RP_I2F, t);
+    else if (p.val == VAL_F64_ORDERED) comp.convert_output(arg_out[k], RP_F64ORD, t);
+  }
+  CompiledProgram cp;
+  if (!comp.finish(cp, why)) return false;
+  // ---- accumulators: one per aggregate (+ the row count of an AVG); every run writes its own cells, nothing is shared
+  struct Ent { int agg; bool is_avg_count; int kind; };
+  std::vector<Ent> entries;
+  std::vector<RunsAcc> accs;
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    dfgpu_field t = a.typed ? a.in_type : (a.has_arg ? cp.out_types[(size_t)arg_out[k]] : fld(DFGPU_INT64));
+    AccPlan pl = plan_for(a.func, t, false);
+    const int kind = (a.func == DFGPU_AGG_COUNT && !a.has_arg) ? ACC_COUNT_STAR : pl.kind;
+    const int val = a.has_arg ? cp.src_out_vals[(size_t)arg_out[k]] : -1;
+    entries.push_back({(int)k, false, kind});
+    accs.push_back({kind, val, kind == ACC_SUM_I128 && t.type == DFGPU_DECIMAL128 && t.precision > 0 && t.precision <= 16});
+    if (a.func == DFGPU_AGG_AVG) {
+      entries.push_back({(int)k, true, ACC_COUNT});
+      accs.push_back({ACC_COUNT, val, false});
+    }
+  }
+  if (accs.size() > (size_t)RUNS_MAX_ACCS) return false;
+  const std::string source = agg_runs_node_source(cp, cp.src_out_vals[(size_t)key_out], kf.type, accs);
+  hipFunction_t f_acc = nullptr;
+  try {
+    f_acc = jit_get(source, "runs_accumulate");
+  } catch (const Error& e) {
+    if (env_int("DFGPU_JIT_STRICT", 0)) throw;
+    fprintf(stderr, "[dfgpu] node specialisation failed, using the interpreter: %s\n", e.what());
+    return false;
+  }
+  // ---- run heads -> group numbers
+  const int64_t n_words = (n + 63) / 64;
+  BufPtr heads = make_buf((size_t)n_words * 8);
+  {
+    ProfileScope ps("agg_runs_heads", n * type_width(kf.type));
+    const int g = grid_for(n_words, (BLOCK / WAVE) * 4);
+    switch (type_width(kf.type)) {
+      case 8: k_run_heads<uint64_t><<<g, BLOCK, 0, r.stream>>>((const uint64_t*)kcol.ptr(), n, heads->as<uint64_t>()); break;
+      case 4: k_run_heads<uint32_t><<<g, BLOCK, 0, r.stream>>>((const uint32_t*)kcol.ptr(), n, heads->as<uint64_t>()); break;
+      default: k_run_heads<uint8_t><<<g, BLOCK, 0, r.stream>>>((const uint8_t*)kcol.ptr(), n, heads->as<uint64_t>()); break;
+    }
+    DFGPU_HIP(hipGetLastError());
+  }
+  BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
+  scan_mask_popcounts(heads->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
+  BufPtr long_flag = make_zero_buf(4);
+  k_run_long_flag<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(heads->as<uint64_t>(), n_words, long_flag->as<uint32_t>());
+  const int64_t G = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+  uint32_t has_long = 0;
+  d2h(&has_long, long_flag->ptr, 4);
+  // ---- from here on state is modified
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    if (!a.typed) {
+      a.in_type = a.has_arg ? cp.out_types[(size_t)arg_out[k]] : fld(DFGPU_INT64);
+      a.typed = true;
+    }
+  }
+  grow_accumulators(A, 0, G, /*init=*/has_long != 0);  // plain stores cover every cell unless some run needs the atomics
+  Column kc = alloc_like(kcol, G);
+  kc.name = A.group_names[0];
+  RunsNodeArgs args{};
+  for (int c = 0; c < cp.prog.n_cols; c++) {
+    args.col[c] = cp.prog.col_data[c];
+    args.valid[c] = cp.prog.col_valid[c];
+  }
+  args.heads = heads->as<uint64_t>();
+  args.prefix = prefix->as<uint64_t>();
+  args.key_out = kc.data->ptr;
+  args.n = n;
+  for (size_t e = 0; e < entries.size(); e++) {
+    AggState& a = A.aggs[(size_t)entries[e].agg];
+    if (entries[e].is_avg_count) {
+      args.cell[2 * e] = a.cnt->as<unsigned long long>();
+    } else {
+      args.cell[2 * e] = a.lo->as<unsigned long long>();
+      if (entries[e].kind == ACC_SUM_I128) args.cell[2 * e + 1] = a.hi->as<unsigned long long>();
+      args.seen[e] = a.seen->as<uint32_t>();
+    }
+  }
+  {
+    ProfileScope ps("agg_runs_accumulate", n * cp.input_bytes_per_row);
+    jit_launch(f_acc, grid_for(n_words, BLOCK / WAVE), BLOCK, 0, &args, sizeof(args));
+  }
+  Table gk;
+  gk.nrows = G;
+  gk.cols.push_back(std::move(kc));
+  A.group_keys = std::move(gk);
+  A.ngroups = G;
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  return true;
+}
+
 // The single-pass small-domain node (k_agg_fused_tile).  `cp` = predicate + key bytes + arguments.
 // Returns false (state untouched) when the forest has no tile form or the LDS budget does not fit.
 constexpr size_t TILE_LDS_BUDGET = 64 * 1024;  // per workgroup: at least two workgroups per CU (160 KiB LDS)
@@ -1859,6 +2277,7 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
   std::vector<int> small_cols;
   const bool small = small_domain_applicable(A, in, small_cols);
   const int gid_mode = ngk == 0 ? GID_NONE : small ? GID_SMALL : GID_HASH;
+  if (gid_mode == GID_HASH && A.ngroups == 0 && agg_update_sorted_runs_jit(A, in, pred)) return true;
   if (gid_mode == GID_HASH && A.ngroups == 0 && agg_update_dense_key_jit(A, in, pred)) return true;
 
   // ---- compile: predicate, (small mode) key bytes, aggregate arguments

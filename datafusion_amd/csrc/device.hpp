@@ -155,6 +155,28 @@ __device__ __forceinline__ bool keys_equal(const KeySet& a, int64_t ia, const Ke
   return true;
 }
 
+// h % n for a small runtime n (partition counts): the compiler expands a 64-bit remainder by a runtime value into a
+// ~150-instruction loop, which made the partition passes compute-bound.  Exact: h = hi * 2^32 + lo, so
+// h mod n = ((hi mod n) * (2^32 mod n) + (lo mod n)) mod n, each 32-bit remainder by Lemire's fastmod
+// (M = floor((2^64 - 1) / n) + 1; x mod n = mulhi64(M * x, n) for every 32-bit x).
+struct FastMod {
+  uint64_t M;
+  uint32_t n, c;  // c = 2^32 mod n
+};
+inline FastMod fastmod_for(uint32_t n) { return FastMod{~0ull / n + 1ull, n, (uint32_t)((1ull << 32) % n)}; }
+__host__ __device__ __forceinline__ uint32_t fastmod_u32(uint32_t x, const FastMod& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__umul64hi(f.M * x, (uint64_t)f.n);
+#else
+  return (uint32_t)(((unsigned __int128)(f.M * x) * f.n) >> 64);
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t fastmod_u64(uint64_t h, const FastMod& f) {
+  if ((f.n & (f.n - 1)) == 0) return (uint32_t)h & (f.n - 1);
+  const uint32_t a = fastmod_u32((uint32_t)(h >> 32), f), b = fastmod_u32((uint32_t)h, f);
+  return fastmod_u32(a * f.c + b, f);
+}
+
 // grid sizing for HBM-bound grid-stride kernels: enough workgroups to fill 256 CUs x 8
 inline int grid_for(int64_t work_items, int per_block) {
   int64_t b = (work_items + per_block - 1) / per_block;

@@ -5,6 +5,11 @@
 // is prefix[word] + popcount(mask & lanes_below(l)) (v_mbcnt), so selected lanes store to
 // consecutive addresses and no LDS or workgroup barrier is needed.  HBM traffic per row:
 // N/8 B mask (x3: written once, read by scan and by compaction) + the columns themselves.
+// Measured (profiles/r2_ops_v1.md): k_compact moves 5.7-5.8 TB/s of algorithmic bytes = 91-92 % of the 6.29 TB/s copy
+// ceiling.  A variant that packs a wave's 256 / 512 rows through wave-private LDS so that every store is a full 64-lane
+// store was tried in round 2 and ran 1.7-2.3x SLOWER (LDS round trip + the occupancy lost to 16-32 KB of LDS per
+// workgroup buy nothing: L2 already merges the per-word pieces) — what is left of FilterExec's gap is the predicate
+// pass, the scan and one host round trip for the output size, a fixed ~0.17 ms that weighs on a 1 ms SF10 operator.
 //
 // Reference: physical-plan/src/filter.rs:1339-1362 (filter_and_project), :1396-1419;
 // arrow-select `filter_record_batch` (NULL predicate => row dropped).

@@ -145,7 +145,8 @@ std::string type_name(const dfgpu_field& f);
 struct ColStats {
   long long min = 0, max = 0;
   int64_t valid = 0;
-  bool ascending = false;
+  bool ascending = false;      // strictly ascending in row order, no NULLs
+  bool nondecreasing = false;  // key[i-1] <= key[i] for every row, no NULLs: equal keys are adjacent (ordered input of an aggregate)
 };
 
 // Values of a dictionary-encoded column (Arrow Dictionary(index type, Utf8 | LargeUtf8)): the device column holds the

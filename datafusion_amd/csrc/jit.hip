@@ -10,6 +10,8 @@
 #include <hip/hiprtc.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <unordered_map>
 
 #include "internal.hpp"
@@ -44,6 +46,13 @@ hipFunction_t jit_get(const std::string& source, const char* kernel_name) {
   auto it = g_jit_cache.find(source);
   if (it != g_jit_cache.end()) return function_of(it->second);
   auto t0 = std::chrono::steady_clock::now();
+  if (const char* dump = std::getenv("DFGPU_JIT_DUMP")) {  // debugging aid: the generated sources, one file per node
+    const std::string path = std::string(dump) + "/node_" + std::to_string(g_jit_compiles) + "_" + kernel_name + ".hip";
+    if (FILE* f = fopen(path.c_str(), "w")) {
+      fwrite(source.data(), 1, source.size(), f);
+      fclose(f);
+    }
+  }
   hiprtcProgram prog;
   DFGPU_RTC(hiprtcCreateProgram(&prog, source.c_str(), "dfgpu_node.hip", 0, nullptr, nullptr));
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};

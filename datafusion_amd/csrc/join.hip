@@ -109,7 +109,7 @@ struct MinMax {
   long long smin, smax;
   unsigned long long valid;
   unsigned unsorted;  // set when some key is <= its predecessor (or a NULL key exists): keys are not strictly ascending
-  unsigned _pad;
+  unsigned descends;  // set when some key is < its predecessor (or a NULL key exists): keys are not in non-decreasing order
 };
 constexpr int BUILD_UNROLL = 4;  // independent key loads in flight per thread
 // min / max / valid count of the build key (ArrayMap::try_new bounds, array_map.rs:175-203) and whether
@@ -120,7 +120,7 @@ template <int KT, bool HASV>
 __global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMax* out) {
   long long mn = INT64_MAX, mx = INT64_MIN;
   unsigned long long cnt = 0;
-  bool unsorted = false;
+  bool unsorted = false, descends = false;
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += stride * BUILD_UNROLL) {
     uint64_t lo[BUILD_UNROLL], plo[BUILD_UNROLL];
@@ -145,13 +145,14 @@ __global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMa
 #pragma unroll
     for (int j = 0; j < BUILD_UNROLL; j++) {
       int64_t i = i0 + j * stride;
-      if (i < n && !ok[j]) unsorted = true;  // NULL key
+      if (i < n && !ok[j]) unsorted = descends = true;  // NULL key
       if (!ok[j]) continue;
       long long v = (long long)lo[j];
       mn = v < mn ? v : mn;
       mx = v > mx ? v : mx;
       cnt++;
       if (pok[j] && (long long)plo[j] >= v) unsorted = true;
+      if (pok[j] && (long long)plo[j] > v) descends = true;
     }
   }
 #pragma unroll
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMa
     mx = omx > mx ? omx : mx;
     cnt += __shfl_xor(cnt, d, 64);
   }
-  const bool wave_unsorted = ballot64(unsorted) != 0;
+  const unsigned wave_unsorted = (ballot64(unsorted) != 0 ? 1u : 0u) | (ballot64(descends) != 0 ? 2u : 0u);
   __shared__ long long s_mn[BLOCK / WAVE], s_mx[BLOCK / WAVE];
   __shared__ unsigned long long s_cnt[BLOCK / WAVE];
   __shared__ unsigned s_uns[BLOCK / WAVE];
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMa
       atomicMax(&out->smax, mx);
       atomicAdd(&out->valid, cnt);
     }
-    if (uns) atomicOr(&out->unsorted, 1u);
+    if (uns & 1u) atomicOr(&out->unsorted, 1u);
+    if (uns & 2u) atomicOr(&out->descends, 1u);
   }
 }
 
@@ -1186,10 +1188,10 @@ ColStats column_stats(Column& kc, int64_t nrows) {
       DFGPU_HIP(hipGetLastError());
     }
     d2h(&res, mm->ptr, sizeof res);
-    kc.stats = std::make_shared<ColStats>(ColStats{res.smin, res.smax, (int64_t)res.valid, res.valid > 0 && res.unsorted == 0});
+    kc.stats = std::make_shared<ColStats>(ColStats{res.smin, res.smax, (int64_t)res.valid, res.valid > 0 && res.unsorted == 0, res.valid > 0 && res.descends == 0});
     return *kc.stats;
   }
-  return ColStats{res.smin, res.smax, 0, false};
+  return ColStats{res.smin, res.smax, 0, false, false};
 }
 
 static bool needs_visited(int join_type) {

@@ -180,3 +180,94 @@ def test_errors_match_the_unfused_path():
         gpu(t, [], [("sum", col("a") + col("b"), "s")], col("a") > lit(0))
     with pytest.raises(_lib.DfgpuError, match="non-boolean predicate"):
         gpu(t, [], [("sum", col("a"), "s")], col("a") + lit(1))
+
+
+# ------------------------------------------------------------------ ordered input: groups are runs (aggregates/order/full.rs)
+def _runs_table(rng, run_lengths, key_type=pa.int64(), null_frac=0.0, start=-5, gaps=True):
+    """a key column in non-decreasing order whose runs have the given lengths, plus value columns"""
+    keys, k = [], start
+    for ln in run_lengths:
+        keys += [k] * int(ln)
+        k += int(rng.integers(1, 4)) if gaps else 1
+    n = len(keys)
+    t = random_table(rng, n, {"d": (pa.decimal128(15, 2), -10**9, 10**9), "i": (pa.int32(), -1000, 1000), "f": (pa.float64(), -10**6, 10**6),
+                              "j": (pa.int64(), -10**12, 10**12)}, null_frac=null_frac)
+    return t.append_column("k", pa.array(keys, type=key_type))
+
+
+RUN_AGGS = lambda col: [("sum", col("d"), "sd"), ("avg", col("d"), "ad"), ("count", col("i"), "ci"), ("count", None, "n"), ("min", col("j"), "mn"),
+                        ("max", col("i"), "mx"), ("sum", col("f"), "sf"), ("avg", col("i"), "ai"), ("sum", col("d") * col("d"), "sdd")]
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.2])
+@pytest.mark.parametrize("shape", ["short", "word_edges", "long", "mixed", "single", "all_distinct"])
+def test_ordered_group_key_runs_node(shape, null_frac):
+    """GROUP BY a key that arrives in order: the runs node (k_run_heads -> scan -> runs_accumulate).  Run shapes cover runs inside
+    one 64-row word, runs ending exactly at word edges, runs finished by the previous word's wave, runs longer than two words
+    (the atomic path) and the partial last word"""
+    import os
+
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    rng = np.random.default_rng(len(shape) * 7 + int(null_frac * 10))
+    lengths = {"short": rng.integers(1, 8, size=700), "word_edges": [64, 64, 1, 63, 128, 32, 32, 1, 127, 5, 59, 64, 3],
+               "long": [300, 2, 129, 1, 1, 640, 7, 65, 64, 200], "mixed": np.concatenate([rng.integers(1, 8, size=300), [500], rng.integers(1, 90, size=60), [1, 1, 1]]),
+               "single": [1000], "all_distinct": [1] * 777}[shape]
+    t = _runs_table(rng, lengths, null_frac=null_frac)
+    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT", "DFGPU_AGG_RUNS")}
+    try:
+        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1", "DFGPU_AGG_RUNS": "1"})
+        ops.profile_enable(True)
+        ops.profile_reset()
+        got, fused = gpu(t, [(col("k"), "k")], RUN_AGGS(col))
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert "agg_runs_accumulate" in stats, sorted(stats)   # the node under test ran
+    assert_agg_equal(got, oracle(t, [(col("k"), "k")], RUN_AGGS(col)), ordered=True)
+
+
+@pytest.mark.parametrize("key_type", [pa.int32(), pa.date32(), pa.uint32(), pa.uint8()])
+def test_ordered_group_key_runs_node_key_types(key_type):
+    import os
+
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    rng = np.random.default_rng(5)
+    t = _runs_table(rng, rng.integers(1, 40, size=120), key_type=key_type, start=3, gaps=False)
+    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
+    try:
+        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+        got, _ = gpu(t, [(col("k"), "k")], [("sum", col("d"), "sd"), ("count", None, "n")])
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert got.schema.field("k").type == key_type
+    assert_agg_equal(got, oracle(t, [(col("k"), "k")], [("sum", col("d"), "sd"), ("count", None, "n")]), ordered=True)
+
+
+def test_unordered_group_key_does_not_take_the_runs_node():
+    import os
+
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    rng = np.random.default_rng(9)
+    t = _runs_table(rng, rng.integers(1, 9, size=200))
+    k = t.column("k").to_numpy().copy()
+    k[[50, 51]] = k[[51, 50]] if k[50] != k[51] else (k[51] + 1000, k[51])      # one descent
+    t = t.set_column(t.schema.get_field_index("k"), "k", pa.array(k, type=pa.int64()))
+    saved = {k_: os.environ.get(k_) for k_ in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
+    try:
+        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+        ops.profile_enable(True)
+        ops.profile_reset()
+        got, _ = gpu(t, [(col("k"), "k")], [("sum", col("d"), "sd"), ("count", None, "n")])
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+    finally:
+        for k_, v in saved.items():
+            os.environ.pop(k_, None) if v is None else os.environ.__setitem__(k_, v)
+    assert "agg_runs_accumulate" not in stats
+    assert_agg_equal(got, oracle(t, [(col("k"), "k")], [("sum", col("d"), "sd"), ("count", None, "n")]), ordered=True)
