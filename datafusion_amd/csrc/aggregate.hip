@@ -997,6 +997,12 @@ enum { SUM_I64 = 0, SUM_I128 = 1, SUM_F64 = 2, MIN_I64 = 3, MAX_I64 = 4, COUNT =
 __device__ __forceinline__ double v2f(i128 x) { return __longlong_as_double((long long)(U64)x); }
 __device__ __forceinline__ i128 f2v(double d) { return (i128)(u128)(U64)__double_as_longlong(d); }
 __device__ __forceinline__ long long f64ord(U64 bits) { long long b = (long long)bits; return b ^ (long long)((U64)(b >> 63) >> 1); }
+__device__ __forceinline__ I32 date32_part(I32 days, int part) {  // device.hpp date32_part
+  const I64 z = (I64)days + 719468, era = (z >= 0 ? z : z - 146096) / 146097, doe = z - era * 146097;
+  const I64 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365, doy = doe - (365 * yoe + yoe / 4 - yoe / 100), mp = (5 * doy + 2) / 153;
+  const I64 d = doy - (153 * mp + 2) / 5 + 1, m = mp < 10 ? mp + 3 : mp - 9, y = yoe + era * 400 + (m <= 2 ? 1 : 0);
+  return (I32)(part == 0 ? y : part == 1 ? m : d);
+}
 __device__ __forceinline__ bool kt(i128 v, bool n) { return !n && ((int)v & 1); }
 __device__ __forceinline__ bool kf(i128 v, bool n) { return !n && !((int)v & 1); }
 __device__ __forceinline__ U64 identity_of(int kind) {
@@ -1216,6 +1222,12 @@ struct Args {
 __device__ __forceinline__ double v2f(i128 x) { return __longlong_as_double((long long)(U64)x); }
 __device__ __forceinline__ i128 f2v(double d) { return (i128)(u128)(U64)__double_as_longlong(d); }
 __device__ __forceinline__ long long f64ord(U64 bits) { long long b = (long long)bits; return b ^ (long long)((U64)(b >> 63) >> 1); }
+__device__ __forceinline__ I32 date32_part(I32 days, int part) {  // device.hpp date32_part
+  const I64 z = (I64)days + 719468, era = (z >= 0 ? z : z - 146096) / 146097, doe = z - era * 146097;
+  const I64 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365, doy = doe - (365 * yoe + yoe / 4 - yoe / 100), mp = (5 * doy + 2) / 153;
+  const I64 d = doy - (153 * mp + 2) / 5 + 1, m = mp < 10 ? mp + 3 : mp - 9, y = yoe + era * 400 + (m <= 2 ? 1 : 0);
+  return (I32)(part == 0 ? y : part == 1 ? m : d);
+}
 __device__ __forceinline__ bool kt(i128 v, bool n) { return !n && ((int)v & 1); }
 __device__ __forceinline__ bool kf(i128 v, bool n) { return !n && !((int)v & 1); }
 // Segmented inclusive scans over the lanes of a wave: a run = adjacent lanes holding the same group (`head` marks
@@ -1735,6 +1747,12 @@ struct Args {
 __device__ __forceinline__ double v2f(i128 x) { return __longlong_as_double((long long)(U64)x); }
 __device__ __forceinline__ i128 f2v(double d) { return (i128)(u128)(U64)__double_as_longlong(d); }
 __device__ __forceinline__ long long f64ord(U64 bits) { long long b = (long long)bits; return b ^ (long long)((U64)(b >> 63) >> 1); }
+__device__ __forceinline__ I32 date32_part(I32 days, int part) {  // device.hpp date32_part
+  const I64 z = (I64)days + 719468, era = (z >= 0 ? z : z - 146096) / 146097, doe = z - era * 146097;
+  const I64 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365, doy = doe - (365 * yoe + yoe / 4 - yoe / 100), mp = (5 * doy + 2) / 153;
+  const I64 d = doy - (153 * mp + 2) / 5 + 1, m = mp < 10 ? mp + 3 : mp - 9, y = yoe + era * 400 + (m <= 2 ? 1 : 0);
+  return (I32)(part == 0 ? y : part == 1 ? m : d);
+}
 __device__ __forceinline__ bool kt(i128 v, bool n) { return !n && ((int)v & 1); }
 __device__ __forceinline__ bool kf(i128 v, bool n) { return !n && !((int)v & 1); }
 #define SEG_SCAN(STEP)                                        \

@@ -155,6 +155,21 @@ __device__ __forceinline__ bool keys_equal(const KeySet& a, int64_t ia, const Ke
   return true;
 }
 
+// date_part(YEAR | MONTH | DAY, Date32): days since 1970-01-01 -> proleptic Gregorian civil date (the algorithm chrono's
+// NaiveDate::from_num_days_from_ce restates; era = 400-year cycle of 146097 days starting on 0000-03-01)
+__host__ __device__ __forceinline__ int32_t date32_part(int32_t days, int part) {
+  const int64_t z = (int64_t)days + 719468;
+  const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+  const int64_t doe = z - era * 146097;                                   // [0, 146096]
+  const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;  // [0, 399]
+  const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);            // [0, 365], year starts on March 1
+  const int64_t mp = (5 * doy + 2) / 153;                                 // [0, 11]
+  const int64_t d = doy - (153 * mp + 2) / 5 + 1;
+  const int64_t m = mp < 10 ? mp + 3 : mp - 9;
+  const int64_t y = yoe + era * 400 + (m <= 2 ? 1 : 0);
+  return (int32_t)(part == 0 ? y : part == 1 ? m : d);
+}
+
 // h % n for a small runtime n (partition counts): the compiler expands a 64-bit remainder by a runtime value into a
 // ~150-instruction loop, which made the partition passes compute-bound.  Exact: h = hi * 2^32 + lo, so
 // h mod n = ((hi mod n) * (2^32 mod n) + (lo mod n)) mod n, each 32-bit remainder by Lemire's fastmod

@@ -8,6 +8,8 @@
 // arrays via one wave64 ballot per 64 rows; AND/OR follow Kleene logic (:543-603).
 // Decimal128 result types follow arrow-rs (clamped to precision 38, never an error):
 // add/sub -> scale max(s1,s2), mul -> scale s1+s2 (expr-common/src/type_coercion/binary.rs:168-186).
+#include <cmath>
+
 #include "device.hpp"
 #include "internal.hpp"
 
@@ -30,6 +32,14 @@ bool same_field_type(const dfgpu_field& a, const dfgpu_field& b) {
 dfgpu_field arith_result_type(int op, const dfgpu_field& l, const dfgpu_field& r) {
   if (l.type == DFGPU_DECIMAL128 && r.type == DFGPU_DECIMAL128) {
     int p1 = l.precision, s1 = l.scale, p2 = r.precision, s2 = r.scale;
+    if (op == DFGPU_EXPR_DIV) {  // arrow-arith decimal_op Op::Div: "follow postgres and MySQL adding a fixed scale increment of 4"
+      const int s = std::min(38, s1 + 4);
+      return mkfield(DFGPU_DECIMAL128, std::min(38, s - s1 + s2 + p1), s);
+    }
+    if (op == DFGPU_EXPR_MOD) {
+      const int s = std::max(s1, s2);
+      return mkfield(DFGPU_DECIMAL128, std::min(38, s + std::min(p1 - s1, p2 - s2)), s);
+    }
     if (op == DFGPU_EXPR_MUL) return mkfield(DFGPU_DECIMAL128, std::min(38, p1 + p2 + 1), std::min(38, s1 + s2));
     int s = std::max(s1, s2);
     return mkfield(DFGPU_DECIMAL128, std::min(38, s + std::max(p1 - s1, p2 - s2) + 1), s);
@@ -50,8 +60,12 @@ static dfgpu_field node_type(const dfgpu_expr& e, int idx, const Table& in) {
     case DFGPU_EXPR_LITERAL:
     case DFGPU_EXPR_CAST:
       return n.field;
-    case DFGPU_EXPR_ADD: case DFGPU_EXPR_SUB: case DFGPU_EXPR_MUL:
+    case DFGPU_EXPR_ADD: case DFGPU_EXPR_SUB: case DFGPU_EXPR_MUL: case DFGPU_EXPR_DIV: case DFGPU_EXPR_MOD:
       return arith_result_type(n.op, node_type(e, n.left, in), node_type(e, n.right, in));
+    case DFGPU_EXPR_DATE_PART:
+      DFGPU_CHECK(node_type(e, n.left, in).type == DFGPU_DATE32, "date_part: the GPU path takes a Date32 argument");
+      DFGPU_CHECK(n.column >= DFGPU_DATE_PART_YEAR && n.column <= DFGPU_DATE_PART_DAY, "date_part: the GPU path extracts YEAR, MONTH or DAY");
+      return mkfield(DFGPU_INT32);
     case DFGPU_EXPR_EQ: case DFGPU_EXPR_NE: case DFGPU_EXPR_LT: case DFGPU_EXPR_LE: case DFGPU_EXPR_GT: case DFGPU_EXPR_GE:
     case DFGPU_EXPR_AND: case DFGPU_EXPR_OR: case DFGPU_EXPR_NOT: case DFGPU_EXPR_IS_NULL: case DFGPU_EXPR_IS_NOT_NULL:
       return mkfield(DFGPU_BOOL);
@@ -137,6 +151,37 @@ __global__ __launch_bounds__(BLOCK) void k_arith_f64(int op, Operand<double> a, 
     double x = a.at(i), y = b.at(i);
     out[i] = op == DFGPU_EXPR_ADD ? x + y : op == DFGPU_EXPR_SUB ? x - y : x * y;
   }
+}
+
+// arrow-arith div / rem over the rows that are valid on both sides (try_binary visits no others).  flags[0] |= 1: a zero
+// divisor, |= 2: an overflow (MIN / -1, or a decimal operand times its power of ten leaving 128 bits: mul_checked)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_divmod(int is_mod, Operand<T> a, Operand<T> b, T ma, T mb, const uint64_t* __restrict__ valid, int64_t n,
+                                                  T* __restrict__ out, unsigned* __restrict__ flags) {
+  unsigned bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    T v = 0;
+    if (!valid || bit_at(valid, i)) {
+      T x, y;
+      const bool ox = __builtin_mul_overflow(a.at(i), ma, &x), oy = __builtin_mul_overflow(b.at(i), mb, &y);
+      const bool ovf = ox || oy;
+      if (ovf) bad |= 2u;
+      else if (y == 0) bad |= 1u;
+      else if (y == (T)-1 && x == (T)((T)1 << (sizeof(T) * 8 - 1))) bad |= 2u;
+      else v = is_mod ? (T)(x % y) : (T)(x / y);
+    }
+    out[i] = v;
+  }
+  if (bad) atomicOr(flags, bad);
+}
+__global__ __launch_bounds__(BLOCK) void k_divmod_f64(int is_mod, Operand<double> a, Operand<double> b, int64_t n, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const double x = a.at(i), y = b.at(i);
+    out[i] = is_mod ? fmod(x, y) : x / y;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_date_part(const int32_t* __restrict__ days, int part, int64_t n, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = date32_part(days[i], part);
 }
 
 template <typename S, typename D>
@@ -331,8 +376,80 @@ static Datum to_bool_array(const Datum& d, int64_t n) {
   return o;
 }
 
+static void throw_divmod(unsigned flags) {
+  if (flags & 1u) throw Error("Arrow error: Divide by zero error");
+  if (flags & 2u) throw Error("Arrow error: Arithmetic overflow: Overflow happened on a division");
+}
+// BinaryExpr Divide / Modulo (binary.rs:636-637 -> arrow-arith div / rem)
+static Datum eval_divmod(int op, const Datum& a, const Datum& b, int64_t nrows) {
+  Runtime& r = rt();
+  const dfgpu_field& lt = a.col.field;
+  const dfgpu_field& rtp = b.col.field;
+  const bool is_mod = op == DFGPU_EXPR_MOD;
+  const dfgpu_field out_field = arith_result_type(op, lt, rtp);
+  i128 ma = 1, mb = 1;
+  if (out_field.type == DFGPU_DECIMAL128) {
+    if (is_mod) {
+      ma = pow10_i128(out_field.scale - lt.scale);
+      mb = pow10_i128(out_field.scale - rtp.scale);
+    } else {
+      const int mul_pow = out_field.scale - lt.scale + rtp.scale;  // >= 0 unless the result scale was capped at 38
+      if (mul_pow >= 0) ma = pow10_i128(mul_pow);
+      else mb = pow10_i128(-mul_pow);
+    }
+  }
+  if (a.scalar && b.scalar) {
+    const bool isnull = a.scalar_null || b.scalar_null;
+    if (isnull) return make_scalar(out_field, 0, true);
+    if (lt.type == DFGPU_FLOAT64) {
+      double x, y;
+      std::memcpy(&x, &a.lit_lo, 8);
+      std::memcpy(&y, &b.lit_lo, 8);
+      const double v = is_mod ? std::fmod(x, y) : x / y;
+      Datum d = make_scalar(out_field, 0, false);
+      std::memcpy(&d.lit_lo, &v, 8);
+      return d;
+    }
+    i128 x, y;
+    const bool ox = __builtin_mul_overflow(scalar_i128(a), ma, &x), oy = __builtin_mul_overflow(scalar_i128(b), mb, &y);
+    unsigned flags = (ox || oy) ? 2u : 0u;
+    if (!flags && y == 0) flags = 1u;
+    const i128 lowest = out_field.type == DFGPU_INT32 ? (i128)INT32_MIN : out_field.type == DFGPU_INT64 ? (i128)INT64_MIN : (i128)((u128)1 << 127);
+    if (!flags && y == -1 && x == lowest) flags = 2u;
+    throw_divmod(flags);
+    return make_scalar(out_field, is_mod ? x % y : x / y, false);
+  }
+  Datum o;
+  o.col = alloc_column(out_field, "", nrows);
+  bool all_null = false;
+  o.col.validity = combine_validity(a, b, nrows, all_null);
+  o.col.null_count = o.col.validity ? -1 : 0;
+  if (nrows == 0) return o;
+  const int g = grid_for(nrows, BLOCK);
+  const uint64_t* valid = o.col.valid_words();
+  BufPtr flags = make_zero_buf(4);
+  {
+    ProfileScope ps("arith", nrows * type_width(out_field.type) * ((a.scalar ? 0 : 1) + (b.scalar ? 0 : 1) + 1));
+    switch (out_field.type) {
+      case DFGPU_INT32: k_divmod<int32_t><<<g, BLOCK, 0, r.stream>>>(is_mod, operand<int32_t>(a), operand<int32_t>(b), 1, 1, valid, nrows, o.col.data->as<int32_t>(), flags->as<unsigned>()); break;
+      case DFGPU_INT64: k_divmod<int64_t><<<g, BLOCK, 0, r.stream>>>(is_mod, operand<int64_t>(a), operand<int64_t>(b), 1, 1, valid, nrows, o.col.data->as<int64_t>(), flags->as<unsigned>()); break;
+      case DFGPU_DECIMAL128: k_divmod<i128><<<g, BLOCK, 0, r.stream>>>(is_mod, operand<i128>(a), operand<i128>(b), ma, mb, valid, nrows, o.col.data->as<i128>(), flags->as<unsigned>()); break;
+      case DFGPU_FLOAT64: k_divmod_f64<<<g, BLOCK, 0, r.stream>>>(is_mod, operand<double>(a), operand<double>(b), nrows, o.col.data->as<double>()); break;
+      default: throw Error("arithmetic result type not supported");
+    }
+    DFGPU_HIP(hipGetLastError());
+  }
+  if (out_field.type != DFGPU_FLOAT64) {
+    unsigned hf = 0;
+    d2h(&hf, flags->ptr, 4);
+    throw_divmod(hf);
+  }
+  return o;
+}
+
 static Datum eval_binary(const dfgpu_expr_node& n, const Datum& a, const Datum& b, int64_t nrows) {
   Runtime& r = rt();
+  if (n.op == DFGPU_EXPR_DIV || n.op == DFGPU_EXPR_MOD) return eval_divmod(n.op, a, b, nrows);
   const dfgpu_field& lt = a.col.field;
   const dfgpu_field& rtp = b.col.field;
   const int op = n.op;
@@ -537,6 +654,20 @@ static Datum eval_node(const dfgpu_expr& e, int idx, const Table& in) {
     }
     case DFGPU_EXPR_CAST:
       return eval_cast(n, eval_node(e, n.left, in));
+    case DFGPU_EXPR_DATE_PART: {
+      Datum a = eval_node(e, n.left, in);
+      if (a.scalar) return make_scalar(mkfield(DFGPU_INT32), a.scalar_null ? 0 : (i128)date32_part((int32_t)scalar_i128(a), n.column), a.scalar_null);
+      Datum o;
+      o.col = alloc_column(mkfield(DFGPU_INT32), "", nrows);
+      o.col.validity = a.col.validity;
+      o.col.null_count = a.col.null_count;
+      if (nrows) {
+        ProfileScope ps("date_part", nrows * 8);
+        k_date_part<<<grid_for(nrows, BLOCK), BLOCK, 0, rt().stream>>>((const int32_t*)a.col.ptr(), n.column, nrows, o.col.data->as<int32_t>());
+        DFGPU_HIP(hipGetLastError());
+      }
+      return o;
+    }
     case DFGPU_EXPR_NOT: {
       Datum a = to_bool_array(eval_node(e, n.left, in), nrows);
       DFGPU_CHECK(a.col.field.type == DFGPU_BOOL, "NOT operand must be Boolean");

@@ -225,6 +225,19 @@ RpValue RowProgramCompiler::lower(const dfgpu_expr& e, int idx) {
       RpValue a = lower(e, n.left);
       return RpValue{emit(n.op == DFGPU_EXPR_IS_NULL ? RP_IS_NULL : RP_IS_NOT_NULL, a.id, -2, 0), mk(DFGPU_BOOL)};
     }
+    case DFGPU_EXPR_DATE_PART: {
+      RpValue a = lower(e, n.left);
+      DFGPU_CHECK(a.type.type == DFGPU_DATE32, "date_part: the GPU path takes a Date32 argument");
+      DFGPU_CHECK(n.column >= DFGPU_DATE_PART_YEAR && n.column <= DFGPU_DATE_PART_DAY, "date_part: the GPU path extracts YEAR, MONTH or DAY");
+      return RpValue{emit(RP_DATE_PART, a.id, -2, (uint32_t)n.column), mk(DFGPU_INT32)};
+    }
+    case DFGPU_EXPR_DIV: case DFGPU_EXPR_MOD: {
+      // a zero divisor is an error the row programs cannot raise: division stays column-at-a-time (expr.hip eval_divmod)
+      RpValue a = lower(e, n.left);
+      RpValue b = lower(e, n.right);
+      fail("division is evaluated column-at-a-time");
+      return literal(arith_result_type(n.op, a.type, b.type), 0, 0, true);
+    }
     case DFGPU_EXPR_ADD: case DFGPU_EXPR_SUB: case DFGPU_EXPR_MUL:
     case DFGPU_EXPR_EQ: case DFGPU_EXPR_NE: case DFGPU_EXPR_LT: case DFGPU_EXPR_LE: case DFGPU_EXPR_GT: case DFGPU_EXPR_GE:
     case DFGPU_EXPR_AND: case DFGPU_EXPR_OR: {
@@ -534,6 +547,7 @@ bool RowProgramCompiler::finish(CompiledProgram& cp, std::string& why) {
         case RP_FMUL: val = "f2v(v2f(" + A + ") * v2f(" + B + "))"; break;
         case RP_I2F: val = "f2v((double)(I64)(U64)" + A + ")"; nul = NA; break;
         case RP_F64ORD: val = "(i128)f64ord((U64)" + A + ")"; nul = NA; break;
+        case RP_DATE_PART: val = "(i128)date32_part((I32)(U32)(U64)" + A + ", " + std::to_string(x.aux) + ")"; nul = NA; break;
         case RP_CMP: val = "(i128)(" + A + " " + cmp_str(x.aux) + " " + B + ")"; break;
         case RP_FCMP: val = "(i128)(f64ord((U64)" + A + ") " + cmp_str(x.aux) + " f64ord((U64)" + B + "))"; break;
         case RP_AND:

@@ -45,7 +45,8 @@ enum RpOp : uint8_t {
   RP_MOV = 18,
   // CASE WHEN c THEN x ELSE y END = MERGE(GATE(x, t), GATE(y, NOT t)) with t = c AND (c IS NOT NULL):
   RP_GATE = 19,   // dst <- b is TRUE ? a : (0, not NULL)        (b: a non-NULL Boolean)
-  RP_MERGE = 20   // dst <- a | b bitwise, NULL if either is     (at most one side is non-zero / NULL)
+  RP_MERGE = 20,  // dst <- a | b bitwise, NULL if either is     (at most one side is non-zero / NULL)
+  RP_DATE_PART = 21  // dst <- date_part(aux: 0 YEAR / 1 MONTH / 2 DAY, Date32 a) as Int32
 };
 // how a column is widened into a register
 enum RpLoad : uint8_t { RPL_I32 = 0, RPL_I64 = 1, RPL_U8 = 2, RPL_U32 = 3, RPL_U64 = 4, RPL_I128 = 5, RPL_F64 = 6, RPL_BOOL = 7 };
@@ -219,6 +220,7 @@ __device__ __forceinline__ void rp_exec(const RowProgram& p, int k0, int k1, RpR
       case RP_FMUL: olo = (uint64_t)__double_as_longlong(__longlong_as_double((long long)alo) * __longlong_as_double((long long)blo)); break;
       case RP_I2F: olo = (uint64_t)__double_as_longlong((double)(int64_t)alo); on = an; break;
       case RP_F64ORD: { int64_t s = rp_f64_ordered(alo); olo = (uint64_t)s; ohi = (uint64_t)(s >> 63); on = an; break; }
+      case RP_DATE_PART: { int64_t s = (int64_t)date32_part((int32_t)(uint32_t)alo, (int)in.aux); olo = (uint64_t)s; ohi = (uint64_t)(s >> 63); on = an; break; }
       case RP_CMP: olo = rp_cmp128(in.aux, (i128)(((u128)ahi << 64) | alo), (i128)(((u128)bhi << 64) | blo)) ? 1ull : 0ull; break;
       case RP_FCMP: olo = rp_cmp128(in.aux, (i128)rp_f64_ordered(alo), (i128)rp_f64_ordered(blo)) ? 1ull : 0ull; break;
       case RP_AND: {  // and_kleene: false AND x = false
@@ -348,7 +350,7 @@ __device__ __forceinline__ void tp_exec(const TileProgram& p, int k0, int k1, Ti
     uint64_t alo, ahi, blo = 0, bhi = 0;
     bool an, bn = false;
     tp_fetch(p, t, in.a, alo, ahi, an);
-    const bool unary = in.op == RP_SEXT32 || in.op == RP_SEXT64 || in.op == RP_I2F || in.op == RP_F64ORD || (in.op >= RP_NOT && in.op <= RP_MOV);
+    const bool unary = in.op == RP_SEXT32 || in.op == RP_SEXT64 || in.op == RP_I2F || in.op == RP_F64ORD || in.op == RP_DATE_PART || (in.op >= RP_NOT && in.op <= RP_MOV);
     if (!unary) tp_fetch(p, t, in.b, blo, bhi, bn);
     uint64_t olo = 0, ohi = 0;
     bool on = an | bn;
@@ -363,6 +365,7 @@ __device__ __forceinline__ void tp_exec(const TileProgram& p, int k0, int k1, Ti
       case RP_FMUL: olo = (uint64_t)__double_as_longlong(__longlong_as_double((long long)alo) * __longlong_as_double((long long)blo)); break;
       case RP_I2F: olo = (uint64_t)__double_as_longlong((double)(int64_t)alo); on = an; break;
       case RP_F64ORD: { int64_t s = rp_f64_ordered(alo); olo = (uint64_t)s; ohi = (uint64_t)(s >> 63); on = an; break; }
+      case RP_DATE_PART: { int64_t s = (int64_t)date32_part((int32_t)(uint32_t)alo, (int)in.aux); olo = (uint64_t)s; ohi = (uint64_t)(s >> 63); on = an; break; }
       case RP_CMP: olo = rp_cmp128(in.aux, (i128)(((u128)ahi << 64) | alo), (i128)(((u128)bhi << 64) | blo)) ? 1ull : 0ull; break;
       case RP_FCMP: olo = rp_cmp128(in.aux, (i128)rp_f64_ordered(alo), (i128)rp_f64_ordered(blo)) ? 1ull : 0ull; break;
       case RP_AND: {

@@ -1,6 +1,8 @@
 // table.hip — device tables (Arrow-layout columns in HBM) and the Arrow C Data Interface
 // boundary: import (host RecordBatch -> HBM, pinned with hipHostRegister + async copies on a
 // side stream) and export (HBM -> host struct array with release callbacks).
+#include <algorithm>
+
 #include "device.hpp"
 #include "internal.hpp"
 
@@ -560,6 +562,63 @@ int dfgpu_table_dictionary_lookup(dfgpu_table_t th, int column, const char* utf8
         *out_code = (int64_t)i;
         break;
       }
+  });
+}
+
+// SQL LIKE over one string (arrow-string like.rs: `%` = any run of characters incl. none, `_` = exactly one character — a
+// Unicode scalar, not a byte —, `\\` makes the next pattern character literal; ILIKE folds ASCII case).  Iterative with
+// backtracking to the last `%`.
+static size_t utf8_len(unsigned char c) { return c < 0x80 ? 1 : (c >> 5) == 0x6 ? 2 : (c >> 4) == 0xE ? 3 : (c >> 3) == 0x1E ? 4 : 1; }
+static bool like_match(const std::string& s, const std::string& pat, bool fold_case) {
+  auto lower = [&](unsigned char c) { return fold_case && c >= 'A' && c <= 'Z' ? (unsigned char)(c + 32) : c; };
+  size_t si = 0, pi = 0, star_p = std::string::npos, star_s = 0;
+  while (si < s.size()) {
+    bool step = false;
+    if (pi < pat.size()) {
+      const unsigned char pc = (unsigned char)pat[pi];
+      if (pc == '%') {
+        star_p = ++pi;
+        star_s = si;
+        continue;
+      }
+      if (pc == '_') {
+        si += std::min(utf8_len((unsigned char)s[si]), s.size() - si);
+        pi++;
+        step = true;
+      } else {
+        const size_t lit = (pc == '\\' && pi + 1 < pat.size()) ? pi + 1 : pi;
+        if (lower((unsigned char)pat[lit]) == lower((unsigned char)s[si])) {
+          si++;
+          pi = lit + 1;
+          step = true;
+        }
+      }
+    }
+    if (step) continue;
+    if (star_p == std::string::npos) return false;
+    star_s += std::min(utf8_len((unsigned char)s[star_s]), s.size() - star_s);  // let the last % swallow one more character
+    si = star_s;
+    pi = star_p;
+  }
+  while (pi < pat.size() && pat[pi] == '%') pi++;
+  return pi == pat.size();
+}
+
+int dfgpu_table_dictionary_like(dfgpu_table_t th, int column, const char* pattern, int64_t len, int case_insensitive, int64_t* out_codes, int64_t capacity,
+                                int64_t* out_n) {
+  return guarded([&] {
+    Table* t = unwrap(th);
+    DFGPU_CHECK(column >= 0 && column < (int)t->cols.size() && pattern && out_n, "bad argument");
+    const Column& c = t->cols[column];
+    DFGPU_CHECK(c.dict != nullptr, "column '" + c.name + "' is not dictionary-encoded");
+    const std::string pat(pattern, (size_t)len);
+    int64_t n = 0;
+    for (size_t i = 0; i < c.dict->values.size(); i++)
+      if (c.dict->valid[i] && like_match(c.dict->values[i], pat, case_insensitive != 0)) {
+        if (out_codes && n < capacity) out_codes[n] = (int64_t)i;
+        n++;
+      }
+    *out_n = n;
   });
 }
 

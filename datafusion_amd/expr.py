@@ -20,9 +20,11 @@ from .table import field_of
 
 # dfgpu_expr_op
 OP_COLUMN, OP_LITERAL, OP_CAST = 1, 2, 3
-_BINARY = {"+": 10, "-": 11, "*": 12, "=": 20, "!=": 21, "<": 22, "<=": 23, ">": 24, ">=": 25, "and": 30, "or": 31}
+_BINARY = {"+": 10, "-": 11, "*": 12, "/": 13, "%": 14, "=": 20, "!=": 21, "<": 22, "<=": 23, ">": 24, ">=": 25, "and": 30, "or": 31}
 OP_NOT, OP_IS_NULL, OP_IS_NOT_NULL = 32, 33, 34
 OP_CASE = 40
+OP_DATE_PART = 50
+_DATE_PARTS = {"year": 0, "month": 1, "day": 2}
 
 
 class PhysicalExpr:
@@ -33,6 +35,9 @@ class PhysicalExpr:
     def __add__(self, o): return BinaryExpr(self, "+", _wrap(o))
     def __sub__(self, o): return BinaryExpr(self, "-", _wrap(o))
     def __mul__(self, o): return BinaryExpr(self, "*", _wrap(o))
+    def __truediv__(self, o): return BinaryExpr(self, "/", _wrap(o))
+    def __mod__(self, o): return BinaryExpr(self, "%", _wrap(o))
+    def __rtruediv__(self, o): return BinaryExpr(_wrap(o), "/", self)
     def __rsub__(self, o): return BinaryExpr(_wrap(o), "-", self)
     def __radd__(self, o): return BinaryExpr(_wrap(o), "+", self)
     def __rmul__(self, o): return BinaryExpr(_wrap(o), "*", self)
@@ -45,6 +50,7 @@ class PhysicalExpr:
     def and_(self, o): return BinaryExpr(self, "and", _wrap(o))
     def or_(self, o): return BinaryExpr(self, "or", _wrap(o))
     def in_list(self, values, negated=False): return InListExpr(self, values, negated)
+    def like(self, pattern, negated=False, case_insensitive=False): return LikeExpr(self, pattern, negated, case_insensitive)
     def is_null(self): return IsNullExpr(self)
     def is_not_null(self): return IsNotNullExpr(self)
     def not_(self): return NotExpr(self)
@@ -156,6 +162,78 @@ class InListExpr(PhysicalExpr):
         return f"{self.expr!r} {'NOT ' if self.negated else ''}IN ({', '.join(repr(v) for v in self.list)})"
 
 
+class DatePartExpr(PhysicalExpr):
+    """ScalarFunctionExpr date_part(part, expr) (functions/src/datetime/date_part.rs; `EXTRACT(YEAR FROM d)` plans to it):
+    YEAR / MONTH / DAY of a Date32 as Int32"""
+
+    def __init__(self, part: str, arg: PhysicalExpr):
+        if part.lower() not in _DATE_PARTS:
+            raise ValueError(f"date_part({part!r}) is not supported on the GPU path")
+        self.part, self.arg = part.lower(), arg
+
+    def children(self):
+        return [self.arg]
+
+    def map_children(self, f) -> "DatePartExpr":
+        return DatePartExpr(self.part, f(self.arg))
+
+    def __repr__(self):
+        return f"date_part({self.part.upper()}, {self.arg!r})"
+
+
+class LikeExpr(PhysicalExpr):
+    """LikeExpr::new(negated, case_insensitive, expr, pattern) (expressions/like.rs): `col [NOT] LIKE 'pattern'` over a
+    dictionary-encoded string column.  Bound at the boundary (bind_string_literals): the pattern is matched against the
+    column's dictionary by the library (dfgpu_table_dictionary_like) and the predicate becomes comparisons of the index
+    column with the matching indices — one `lo <= index <= hi` per contiguous run (a prefix pattern over an ascending
+    dictionary is ONE run).  NULL rows stay NULL; patterns that match more than MAX_RUNS separate runs stay on the CPU."""
+    MAX_RUNS = 16
+
+    def __init__(self, expr: PhysicalExpr, pattern: str, negated: bool = False, case_insensitive: bool = False):
+        self.expr, self.pattern, self.negated, self.case_insensitive = expr, pattern, negated, case_insensitive
+
+    def children(self):
+        return [self.expr]
+
+    def __repr__(self):
+        return f"{self.expr!r} {'NOT ' if self.negated else ''}{'ILIKE' if self.case_insensitive else 'LIKE'} {self.pattern}"
+
+    @staticmethod
+    def runs(codes):
+        """[(lo, hi)] of the maximal runs of consecutive integers in ascending `codes`"""
+        out = []
+        for c in codes:
+            if out and out[-1][1] + 1 == c:
+                out[-1][1] = c
+            else:
+                out.append([c, c])
+        return [tuple(r) for r in out]
+
+    def bound(self, table) -> PhysicalExpr:
+        a = self.expr
+        if not isinstance(a, Column):
+            raise TypeError("LIKE on the GPU path takes a dictionary-encoded string column")
+        idx = table.index_of(a.name if a.index is None else a.index)
+        itype = table.schema.field(idx).type
+        column = Column(a.name, idx)
+        runs = LikeExpr.runs(table.dictionary_like(idx, self.pattern, self.case_insensitive))
+        if len(runs) > self.MAX_RUNS:
+            raise ValueError(f"LIKE {self.pattern!r} matches {len(runs)} separate runs of dictionary indices: kept on the CPU")
+        e = None
+        for lo, hi in runs:
+            r = BinaryExpr(column, "=", Literal(lo, itype)) if lo == hi else \
+                BinaryExpr(BinaryExpr(column, ">=", Literal(lo, itype)), "and", BinaryExpr(column, "<=", Literal(hi, itype)))
+            e = r if e is None else BinaryExpr(e, "or", r)
+        if e is None:   # nothing matches: FALSE for every non-NULL row (index -1 is held by no row), NULL rows stay NULL
+            wide = column if itype == pa.int64() else CastExpr(column, pa.int64())
+            e = BinaryExpr(wide, "=", Literal(-1, pa.int64()))
+        return NotExpr(e) if self.negated else e
+
+
+def date_part(part: str, arg: PhysicalExpr) -> DatePartExpr:
+    return DatePartExpr(part, arg)
+
+
 def case(when_then, else_expr=None) -> CaseExpr:
     return CaseExpr(when_then, else_expr)
 
@@ -238,6 +316,10 @@ def bind_string_literals(expr: PhysicalExpr, table) -> PhysicalExpr:
         return expr.map_children(lambda e: bind_string_literals(e, table))
     if isinstance(expr, InListExpr):
         return bind_string_literals(expr.lowered(), table)
+    if isinstance(expr, LikeExpr):
+        return expr.bound(table)
+    if isinstance(expr, DatePartExpr):
+        return expr.map_children(lambda e: bind_string_literals(e, table))
     return expr
 
 
@@ -261,8 +343,14 @@ class IntermediateSchema:
         t, i = self._src[self.index_of(column)]
         return t.dictionary_code(i, value)
 
+    def dictionary_like(self, column, pattern, case_insensitive=False):
+        t, i = self._src[self.index_of(column)]
+        return t.dictionary_like(i, pattern, case_insensitive)
+
 
 def _has_string_literal(expr) -> bool:
+    if isinstance(expr, LikeExpr):
+        return True
     if isinstance(expr, Literal):
         return pa.types.is_string(expr.type) or pa.types.is_large_string(expr.type)
     return any(_has_string_literal(c) for c in expr.children())
@@ -308,6 +396,12 @@ def lower(expr: PhysicalExpr, column_names, table=None) -> LoweredExpr:
             n.op = {IsNullExpr: OP_IS_NULL, IsNotNullExpr: OP_IS_NOT_NULL, NotExpr: OP_NOT}[type(e)]
         elif isinstance(e, InListExpr):
             return emit(e.lowered())
+        elif isinstance(e, DatePartExpr):
+            n.left = emit(e.arg)
+            n.op = OP_DATE_PART
+            n.column = _DATE_PARTS[e.part]
+        elif isinstance(e, LikeExpr):
+            raise TypeError("LIKE must be bound to the column's dictionary first: lower(expr, names, table=...)")
         elif isinstance(e, CaseExpr):
             # one DFGPU_EXPR_CASE node per WHEN, later branches nested in ELSE (include/dfgpu.h)
             tail = -1 if e.else_expr is None else emit(e.else_expr)

@@ -153,6 +153,15 @@ class DeviceTable:
         check(_lib.load().dfgpu_table_dictionary_lookup(self.handle, self.index_of(column), b, C.c_int64(len(b)), C.byref(code)))
         return None if code.value < 0 else code.value
 
+    def dictionary_like(self, column, pattern: str, case_insensitive: bool = False):
+        """ascending indices of the dictionary values of a dictionary-encoded string column that match the SQL LIKE
+        `pattern` (dfgpu_table_dictionary_like) — what `col LIKE 'pattern'` is lowered to (expr.LikeExpr)"""
+        lib, b, n = _lib.load(), pattern.encode(), C.c_int64(0)
+        check(lib.dfgpu_table_dictionary_like(self.handle, self.index_of(column), b, C.c_int64(len(b)), int(case_insensitive), None, C.c_int64(0), C.byref(n)))
+        codes = (C.c_int64 * max(1, n.value))()
+        check(lib.dfgpu_table_dictionary_like(self.handle, self.index_of(column), b, C.c_int64(len(b)), int(case_insensitive), codes, C.c_int64(n.value), C.byref(n)))
+        return list(codes[:n.value])
+
     def nbytes(self) -> int:
         total = 0
         for i in range(self.num_columns):

@@ -191,6 +191,13 @@ int dfgpu_table_export_into(dfgpu_table_t t, int64_t offset, int64_t length, voi
  * the literal's index: this returns it (-1 = the string is not in the dictionary, the predicate is constant false).
  * Reference: group_values/multi_group_by/dictionary.rs, hash_utils.rs:401-640 (the dictionary part). */
 int dfgpu_table_dictionary_lookup(dfgpu_table_t table, int column, const char* utf8, int64_t len, int64_t* out_code);
+/* `col LIKE 'pattern'` / ILIKE on a dictionary-encoded string column (BinaryExpr LikeMatch / ILikeMatch, binary.rs:640-650 ->
+ * arrow-string like.rs: `%`, `_`, backslash escape): the indices of the dictionary values that match, ascending.  The caller
+ * lowers the predicate to comparisons of the index column with them — index ranges when the dictionary is in ascending
+ * order, where a prefix pattern matches one contiguous range.  *out_n = number of matches (may exceed `capacity`: call again
+ * with a larger buffer); NOT LIKE is NOT(...) of the same, NULL rows stay NULL. */
+int dfgpu_table_dictionary_like(dfgpu_table_t table, int column, const char* pattern, int64_t len, int case_insensitive, int64_t* out_codes,
+                                int64_t capacity, int64_t* out_n);
 
 /* allocate a table of uninitialised device columns (filled by generators / exchange) */
 int dfgpu_table_alloc(int ncols, const dfgpu_field* fields, const char* const* names, int64_t nrows, dfgpu_table_t* out);
@@ -219,6 +226,13 @@ typedef enum dfgpu_expr_op {
   DFGPU_EXPR_ADD = 10,    /* BinaryExpr, expressions/binary.rs:536-656 */
   DFGPU_EXPR_SUB = 11,
   DFGPU_EXPR_MUL = 12,
+  /* arrow-arith `div` / `rem` (binary.rs:636-637): integers truncate toward zero; a zero divisor in a non-NULL row is the
+   * error "Arrow error: Divide by zero error" (Float64 follows IEEE: inf / NaN); Decimal128(p1,s1) / Decimal128(p2,s2) has
+   * scale min(38, s1 + 4) and precision min(38, p1 - s1 + s2 + scale), the quotient truncated (arrow-arith numeric.rs
+   * decimal_op Op::Div, pinned by binary.rs:3042-3075,4800-4817); % has scale max(s1, s2) and precision
+   * min(p1 - s1, p2 - s2) + scale (binary.rs:4819-4836) */
+  DFGPU_EXPR_DIV = 13,
+  DFGPU_EXPR_MOD = 14,
   DFGPU_EXPR_EQ = 20,
   DFGPU_EXPR_NE = 21,
   DFGPU_EXPR_LT = 22,
@@ -235,12 +249,16 @@ typedef enum dfgpu_expr_op {
    * The THEN value is taken where the condition is TRUE, the ELSE value where it is FALSE or NULL.  Further WHEN
    * branches nest in ELSE; `CASE x WHEN v ...` is lowered by the caller to conditions `x = v`.  THEN and ELSE have
    * the same type (the planner's coercion). */
-  DFGPU_EXPR_CASE = 40
+  DFGPU_EXPR_CASE = 40,
+  /* date_part(part, Date32) -> Int32 (functions/src/datetime/date_part.rs:165-187; the form `EXTRACT(YEAR FROM d)` plans
+   * to): `column` = dfgpu_date_part, `left` = the Date32 argument */
+  DFGPU_EXPR_DATE_PART = 50
 } dfgpu_expr_op;
+typedef enum dfgpu_date_part { DFGPU_DATE_PART_YEAR = 0, DFGPU_DATE_PART_MONTH = 1, DFGPU_DATE_PART_DAY = 2 } dfgpu_date_part;
 
 typedef struct dfgpu_expr_node {
   int32_t op;          /* dfgpu_expr_op */
-  int32_t column;      /* COLUMN: index into the input table; CASE: node index of the WHEN condition */
+  int32_t column;      /* COLUMN: index into the input table; CASE: node index of the WHEN condition; DATE_PART: the part */
   int32_t left, right; /* child node indices, -1 = none */
   dfgpu_field field;   /* LITERAL: literal type; CAST: target type; else ignored */
   int32_t is_null;     /* LITERAL: SQL NULL */

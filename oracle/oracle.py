@@ -311,6 +311,14 @@ def arith_result_type(op: str, lt: pa.DataType, rt: pa.DataType) -> pa.DataType:
             return _clamp_dec(s + max(p1 - s1, p2 - s2) + 1, s)
         if op == "*":
             return _clamp_dec(p1 + p2 + 1, s1 + s2)
+        if op == "/":
+            # arrow-arith numeric.rs decimal_op Op::Div ("a fixed scale increment of 4"); pinned by binary.rs:3042-3075
+            # (Decimal(10,0) / Decimal(10,0) -> Decimal(14,4)) and :4800-4817 (Decimal(10,0) / Decimal(10,2) -> Decimal(16,4))
+            s = min(38, s1 + 4)
+            return _clamp_dec(s - s1 + s2 + p1, s)
+        if op == "%":
+            s = max(s1, s2)   # binary.rs:4819-4836: Decimal(10,0) % Decimal(10,2) -> Decimal(10,2)
+            return _clamp_dec(s + min(p1 - s1, p2 - s2), s)
     if lt != rt:
         raise TypeError(f"oracle arith: operand types differ {lt} vs {rt} (planner inserts casts)")
     return lt
@@ -396,6 +404,23 @@ def evaluate(expr, table: pa.Table) -> Datum:
         if dst == src:
             return Datum(d.values, to, d.valid, d.scalar)
         raise NotImplementedError(f"oracle cast {d.typ} -> {to}")
+    if kind == "date_part":
+        # date_part(YEAR | MONTH | DAY, Date32) -> Int32 (functions/src/datetime/date_part.rs:165-187), through numpy's calendar
+        _, part, arg = expr
+        d = evaluate(arg, table)
+        if not pa.types.is_date32(d.typ):
+            raise TypeError(f"oracle date_part over {d.typ}")
+        days = d.values.astype("int64").astype("datetime64[D]")
+        months = days.astype("datetime64[M]")
+        if part == "year":
+            v = days.astype("datetime64[Y]").astype(np.int64) + 1970
+        elif part == "month":
+            v = months.astype(np.int64) % 12 + 1
+        elif part == "day":
+            v = (days - months.astype("datetime64[D]")).astype(np.int64) + 1
+        else:
+            raise NotImplementedError(part)
+        return Datum(v.astype(np.int32), pa.int32(), d.valid, d.scalar)
     if kind == "is_null":
         d = evaluate(expr[1], table)
         m = 1 if d.scalar else n
@@ -458,6 +483,8 @@ def evaluate(expr, table: pa.Table) -> Datum:
                              C.c_void_p(y.ctypes.data), int(bv.scalar and not scalar), C.c_int64(m), C.c_void_p(out.ctypes.data))
             assert rc == 0
             return Datum(out, rt, valid, scalar)
+        if op in ("/", "%"):
+            return _divmod(op, a, b, m, valid, scalar)
         ops = {"=": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5}
         if op in ops:
             av, bv = a, b
@@ -474,6 +501,60 @@ def evaluate(expr, table: pa.Table) -> Datum:
             vals = np.unpackbits(bits, bitorder="little")[:m].astype(bool)
             return Datum(vals, pa.bool_(), valid, scalar)
     raise NotImplementedError(f"oracle expr {expr!r}")
+
+
+def _py_ints(d: Datum) -> list:
+    """the values as Python integers (Decimal128: unscaled)"""
+    if orc_type(d.typ) == ORC_I128:
+        out = []
+        for lo, hi in d.values.tolist():
+            v = (int(hi) << 64) | int(lo)
+            out.append(v - (1 << 128) if v >> 127 else v)
+        return out
+    return [int(v) for v in d.values.tolist()]
+
+
+def _divmod(op, a: Datum, b: Datum, m: int, valid, scalar: bool) -> Datum:
+    """BinaryExpr Divide / Modulo = arrow-arith `div` / `rem` (binary.rs:636-637): integers and decimals truncate toward zero
+    (Rust `/`, `%`: the remainder takes the dividend's sign), a zero divisor in a valid row is the error the reference tests
+    pin (arithmetic_divide_zero, binary.rs:4955-5003); Float64 follows IEEE.  Exact integer arithmetic on Python ints."""
+    rt = arith_result_type(op, a.typ, b.typ)
+    if pa.types.is_float64(rt):
+        x = np.repeat(a.values, m) if (a.scalar and not scalar) else a.values
+        y = np.repeat(b.values, m) if (b.scalar and not scalar) else b.values
+        with np.errstate(all="ignore"):
+            out = np.divide(x, y) if op == "/" else np.fmod(x, y)
+        return Datum(out.astype(np.float64), rt, valid, scalar)
+    la, lb = 1, 1
+    if pa.types.is_decimal128(rt):
+        if op == "/":
+            k = rt.scale - a.typ.scale + b.typ.scale
+            la, lb = (10 ** k, 1) if k >= 0 else (1, 10 ** -k)
+        else:
+            la, lb = 10 ** (rt.scale - a.typ.scale), 10 ** (rt.scale - b.typ.scale)
+    xs, ys = _py_ints(a), _py_ints(b)
+    if a.scalar and not scalar:
+        xs = xs * m
+    if b.scalar and not scalar:
+        ys = ys * m
+    bits = {ORC_I32: 32, ORC_I64: 64, ORC_I128: 128}[orc_type(rt)]
+    out = []
+    for i in range(m):
+        if valid is not None and not valid[i]:
+            out.append(0)
+            continue
+        x, y = xs[i] * la, ys[i] * lb
+        if y == 0:
+            raise ZeroDivisionError("Arrow error: Divide by zero error")
+        q = abs(x) // abs(y)
+        q = -q if (x < 0) != (y < 0) else q
+        v = q if op == "/" else x - q * y
+        if not -(1 << (bits - 1)) <= v < (1 << (bits - 1)) or abs(x) >= 1 << (bits - 1) and bits == 128:
+            raise OverflowError("Arrow error: Arithmetic overflow")
+        out.append(v)
+    t = orc_type(rt)
+    vals = _i128_np(out) if t == ORC_I128 else np.array(out, dtype=_NP[t])
+    return Datum(vals, rt, valid, scalar)
 
 
 def _rescale(d: Datum, scale: int) -> Datum:

@@ -74,6 +74,23 @@ def _expr(e, rel: Rel):
         return ("not", _expr(e.arg, rel))
     if isinstance(e, X.InListExpr):
         return _expr(e.lowered(), rel)
+    if isinstance(e, X.DatePartExpr):
+        return ("date_part", e.part, _expr(e.arg, rel))
+    if isinstance(e, X.LikeExpr):
+        # the checker's own LIKE: pyarrow's match_like over the dictionary, then membership of the index
+        import pyarrow.compute as pc
+        values = rel.dicts[e.expr.name]
+        hit = pc.match_like(pa.array(values, pa.string()), e.pattern, ignore_case=e.case_insensitive).to_pylist()
+        itype = rel.table.schema.field(e.expr.name).type
+        codes = [i for i, h in enumerate(hit) if h]
+        if codes:
+            out = None
+            for c in codes:
+                t = ("bin", "=", ("col", e.expr.name), ("lit", c, itype))
+                out = t if out is None else ("bin", "or", out, t)
+        else:
+            out = ("bin", "=", ("cast", ("col", e.expr.name), pa.int64()), ("lit", -1, pa.int64()))
+        return ("not", out) if e.negated else out
     if isinstance(e, X.CaseExpr):
         tail = None if e.else_expr is None else _expr(e.else_expr, rel)
         for w, t in reversed(e.when_then):

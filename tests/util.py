@@ -64,6 +64,8 @@ def to_oracle_expr(e):
         return ("not", to_oracle_expr(e.arg))
     if isinstance(e, X.InListExpr):
         return to_oracle_expr(e.lowered())
+    if isinstance(e, X.DatePartExpr):
+        return ("date_part", e.part, to_oracle_expr(e.arg))
     if isinstance(e, X.CaseExpr):
         tail = None if e.else_expr is None else to_oracle_expr(e.else_expr)
         for w, t in reversed(e.when_then):
