@@ -190,6 +190,9 @@ __global__ __launch_bounds__(BLOCK) void k_cast(const S* __restrict__ in, int64_
 }
 
 // word-wise bitmap kernels. mode: 0 and, 1 or, 2 not(a), 3 copy-not-valid (is_null), 4 fill(v)
+__global__ __launch_bounds__(BLOCK) void k_cast_div(const i128* __restrict__ in, int64_t n, double div, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (double)in[i] / div;
+}
 __global__ __launch_bounds__(BLOCK) void k_bitmap(int mode, const uint64_t* a, const uint64_t* b, uint64_t fill, int64_t n_words, uint64_t* out) {
   for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * BLOCK) {
     uint64_t r;
@@ -304,6 +307,7 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
     }
     if (to.type == DFGPU_FLOAT64) {
       double v = from.type == DFGPU_FLOAT64 ? 0 : (double)scalar_i128(src);
+      if (from.type == DFGPU_DECIMAL128) v /= std::pow(10.0, from.scale);
       Datum d = make_scalar(to, 0, false);
       if (from.type == DFGPU_FLOAT64) return src;
       std::memcpy(&d.lit_lo, &v, 8);
@@ -349,6 +353,8 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
     switch (ft) {
       case DFGPU_INT32: k_cast<int32_t, double><<<g, BLOCK, 0, st>>>((const int32_t*)src.col.ptr(), len, 1.0, o); break;
       case DFGPU_INT64: k_cast<int64_t, double><<<g, BLOCK, 0, st>>>((const int64_t*)src.col.ptr(), len, 1.0, o); break;
+      // arrow-cast cast_decimal_to_float: x as f64 / 10_f64.powi(scale)
+      case DFGPU_DECIMAL128: k_cast_div<<<g, BLOCK, 0, st>>>((const i128*)src.col.ptr(), len, std::pow(10.0, from.scale), o); break;
       default: unsupported();
     }
   } else if ((to.type == DFGPU_INT32 || to.type == DFGPU_DATE32) && ft == DFGPU_INT32) {

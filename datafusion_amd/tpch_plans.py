@@ -18,7 +18,7 @@ from decimal import Decimal
 import pyarrow as pa
 
 from . import physical_plan as P
-from .expr import case, col, lit
+from .expr import case, col, date_part, lit
 
 DATE = pa.date32()
 D15_2 = pa.decimal128(15, 2)
@@ -134,6 +134,67 @@ def q5_plan(customer, orders, lineitem, supplier, nation, region):
     srt = P.SortExec([(name,) + DESC], final)
     proj = P.ProjectionExec([(col("n_name"), "n_name"), (col(name), "revenue")], srt)
     return P.SortPreservingMergeExec([("revenue",) + DESC], proj)
+
+
+# ------------------------------------------------------------------------------------------ Q7
+def q7_plan(supplier, lineitem, orders, customer, nation):
+    """q7.slt.part:87-119: five Inner joins, the last one with a JoinFilter over the two nation names
+    (n_name@0 = FRANCE AND n_name@1 = GERMANY OR n_name@0 = GERMANY AND n_name@1 = FRANCE), date_part(YEAR, l_shipdate) as a group key.
+    This mirror addresses columns by name where the reference's plan uses indices, so the second nation scan carries an aliasing
+    ProjectionExec (n_nationkey / n_name -> n2_nationkey / n2_name) that the index-addressed plan does not need."""
+    s_ = lambda v: lit(v, pa.string())                                     # noqa: E731
+    sup = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_nationkey"]), ["s_suppkey"])
+    li = _hash(_cb(P.FilterExec((col("l_shipdate") >= _d(1995, 1, 1)).and_(col("l_shipdate") <= _d(1996, 12, 31)),
+                                _scan(lineitem, "lineitem").project(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate"]))), ["l_suppkey"])
+    j1 = P.HashJoinExec(_cb(sup), _cb(li), [("s_suppkey", "l_suppkey")], "Inner",
+                        projection=(["s_nationkey"], ["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"]))
+    o = _hash(_scan(orders, "orders").project(["o_orderkey", "o_custkey"]), ["o_orderkey"])
+    j2 = P.HashJoinExec(_cb(_hash(_cb(j1), ["l_orderkey"])), _cb(o), [("l_orderkey", "o_orderkey")], "Inner",
+                        projection=(["s_nationkey", "l_extendedprice", "l_discount", "l_shipdate"], ["o_custkey"]))
+    c = _hash(_scan(customer, "customer").project(["c_custkey", "c_nationkey"]), ["c_custkey"])
+    j3 = P.HashJoinExec(_cb(_hash(_cb(j2), ["o_custkey"])), _cb(c), [("o_custkey", "c_custkey")], "Inner",
+                        projection=(["s_nationkey", "l_extendedprice", "l_discount", "l_shipdate"], ["c_nationkey"]))
+    n1 = _hash(_cb(P.FilterExec(col("n_name").eq(s_("FRANCE")).or_(col("n_name").eq(s_("GERMANY"))), _scan(nation, "nation").project(["n_nationkey", "n_name"]))),
+               ["n_nationkey"])
+    j4 = P.HashJoinExec(_cb(_hash(_cb(j3), ["s_nationkey"])), _cb(n1), [("s_nationkey", "n_nationkey")], "Inner",
+                        projection=(["l_extendedprice", "l_discount", "l_shipdate", "c_nationkey"], ["n_name"]))
+    n2scan = P.ProjectionExec([(col("n_nationkey"), "n2_nationkey"), (col("n_name"), "n2_name")], _scan(nation, "nation").project(["n_nationkey", "n_name"]))
+    n2 = _hash(_cb(P.FilterExec(col("n2_name").eq(s_("GERMANY")).or_(col("n2_name").eq(s_("FRANCE"))), n2scan)), ["n2_nationkey"])
+    # JoinFilter over the intermediate columns f0 = n_name (Left 4), f1 = n2_name (Right 1)
+    f0, f1 = col("f0"), col("f1")
+    jf = (f0.eq(s_("FRANCE")).and_(f1.eq(s_("GERMANY")))).or_(f0.eq(s_("GERMANY")).and_(f1.eq(s_("FRANCE"))))
+    j5 = P.HashJoinExec(_cb(_hash(_cb(j4), ["c_nationkey"])), _cb(n2), [("c_nationkey", "n2_nationkey")], "Inner",
+                        projection=(["n_name", "l_shipdate", "l_extendedprice", "l_discount"], ["n2_name"]), filter=(jf, [(4, "Left"), (1, "Right")]))
+    proj = P.ProjectionExec([(col("n_name"), "supp_nation"), (col("n2_name"), "cust_nation"), (date_part("year", col("l_shipdate")), "l_year"),
+                             (col("l_extendedprice") * (ONE - col("l_discount")), "volume")], _cb(j5))
+    gb = [(col("supp_nation"), "supp_nation"), (col("cust_nation"), "cust_nation"), (col("l_year"), "l_year")]
+    aggs = [("sum", col("volume"), "sum(shipping.volume)")]
+    partial = P.AggregateExec("Partial", gb, aggs, proj)
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["supp_nation", "cust_nation", "l_year"])))
+    keys = [("supp_nation",) + ASC, ("cust_nation",) + ASC, ("l_year",) + ASC]
+    out = P.ProjectionExec([(col("supp_nation"), "supp_nation"), (col("cust_nation"), "cust_nation"), (col("l_year"), "l_year"), (col("sum(shipping.volume)"), "revenue")],
+                           P.SortExec(keys, final))
+    return P.SortPreservingMergeExec(keys, out)
+
+
+# ----------------------------------------------------------------------------------------- Q14
+def q14_plan(lineitem, part):
+    """q14.slt.part:39-49: Inner join lineitem x part, SUM(CASE WHEN p_type LIKE 'PROMO%' THEN ... ELSE 0.0000 END) and the final
+    Float64 division 100 * CAST(a AS Float64) / CAST(b AS Float64)"""
+    li = _hash(_cb(P.FilterExec((col("l_shipdate") >= _d(1995, 9, 1)).and_(col("l_shipdate") < _d(1995, 10, 1)),
+                                _scan(lineitem, "lineitem").project(["l_partkey", "l_extendedprice", "l_discount", "l_shipdate"]),
+                                projection=["l_partkey", "l_extendedprice", "l_discount"])), ["l_partkey"])
+    p = _hash(_scan(part, "part").project(["p_partkey", "p_type"]), ["p_partkey"])
+    j = P.HashJoinExec(_cb(li), _cb(p), [("l_partkey", "p_partkey")], "Inner", projection=(["l_extendedprice", "l_discount"], ["p_type"]))
+    proj = P.ProjectionExec([(col("l_extendedprice") * (ONE - col("l_discount")), "__common_expr_1"), (col("p_type"), "p_type")], _cb(j))
+    a_name = 'sum(CASE WHEN part.p_type LIKE Utf8("PROMO%") THEN lineitem.l_extendedprice * Int64(1) - lineitem.l_discount ELSE Int64(0) END)'
+    b_name = "sum(lineitem.l_extendedprice * Int64(1) - lineitem.l_discount)"
+    zero = lit(Decimal("0.0000"), pa.decimal128(38, 4))
+    aggs = [("sum", case([(col("p_type").like("PROMO%"), col("__common_expr_1"))], zero), a_name), ("sum", col("__common_expr_1"), b_name)]
+    partial = P.AggregateExec("Partial", [], aggs, proj)
+    final = P.AggregateExec("Final", [], aggs, P.CoalescePartitionsExec(partial))
+    f64 = pa.float64()
+    return P.ProjectionExec([(lit(100.0, f64) * col(a_name).cast(f64) / col(b_name).cast(f64), "promo_revenue")], final)
 
 
 # ------------------------------------------------------------------------------------------ Q6

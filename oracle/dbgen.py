@@ -250,8 +250,13 @@ def region(strings: str = "codes") -> pa.Table:
     return pa.table({"r_regionkey": pa.array(np.arange(5, dtype=np.int64)), "r_name": _strings(np.arange(5), REGIONS, strings)})
 
 
+# dists.dss p_types: 6 x 5 x 5 syllable combinations, weight 1 each, in this order (pick_str over the cumulative weights)
+PART_TYPES = [a + " " + b + " " + c for a in ("STANDARD", "SMALL", "MEDIUM", "LARGE", "ECONOMY", "PROMO")
+              for b in ("ANODIZED", "BURNISHED", "PLATED", "POLISHED", "BRUSHED") for c in ("TIN", "NICKEL", "BRASS", "STEEL", "COPPER")]
+
+
 def part(sf: float, strings: str = "codes") -> pa.Table:
-    """build.c mk_part: key, brand ("Brand#MN": M = manufacturer 1..5, N = 1..5), size 1..50, container"""
+    """build.c mk_part: key, brand ("Brand#MN": M = manufacturer 1..5, N = 1..5), type, size 1..50, container"""
     n = counts(sf)["part"]
     mfgr = _draw(P_MFG_SD, n, 1, 5)
     brand = mfgr * 10 + _draw(P_BRND_SD, n, 1, 5)
@@ -259,5 +264,7 @@ def part(sf: float, strings: str = "codes") -> pa.Table:
     bcode = (brand // 10 - 1) * 5 + (brand % 10 - 1)
     size = _draw(P_SIZE_SD, n, 1, 50)
     cntr = _draw(P_CNTR_SD, n, 1, 40) - 1
+    ptype = _draw(P_TYPE_SD, n, 1, len(PART_TYPES)) - 1
     return pa.table({"p_partkey": pa.array(np.arange(1, n + 1, dtype=np.int64)), "p_brand": _strings(bcode, brands, strings),
+                     "p_type": _strings(ptype, PART_TYPES, strings),
                      "p_size": pa.array(size.astype(np.int32)), "p_container": _strings(cntr, CONTAINERS, strings)})

@@ -399,6 +399,8 @@ def evaluate(expr, table: pa.Table) -> Datum:
             return Datum(out, to, d.valid, d.scalar)
         if dst == ORC_F64 and src in (ORC_I32, ORC_I64):
             return Datum(d.values.astype(np.float64), to, d.valid, d.scalar)
+        if dst == ORC_F64 and src == ORC_I128:   # arrow-cast cast_decimal_to_float: x as f64 / 10_f64.powi(scale)
+            return Datum(np.array([float(v) / float(10 ** d.typ.scale) for v in _py_ints(d)], dtype=np.float64), to, d.valid, d.scalar)
         if dst == ORC_I64 and src in (ORC_I32, ORC_U8, ORC_U32):
             return Datum(d.values.astype(np.int64), to, d.valid, d.scalar)
         if dst == src:

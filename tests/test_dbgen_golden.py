@@ -64,6 +64,15 @@ def test_supplier_nation_region_rows():
     _check("region", ["r_regionkey"])
 
 
+def test_the_reference_part_fixture_is_not_dbgen_output():
+    """core/tests/tpch-csv/part.csv holds one row (p_partkey 63700, p_retailprice 901.00) that dbgen cannot have written: its
+    retail price is a function of the key alone (build.c rpb_routine: 1663.70 for 63700).  The part columns are therefore pinned
+    end to end instead: Q19 (brand, size, container) and Q14 (type) reproduce the reference's answers only with the right draws."""
+    from oracle import dbgen
+    import numpy as np
+    assert int(dbgen.retail_price(np.array([63700]))[0]) == 166370
+
+
 def test_cardinalities_and_scaling():
     from oracle import dbgen
     assert dbgen.counts(0.1) == dict(customer=15000, orders=150000, part=20000)

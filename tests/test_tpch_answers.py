@@ -38,13 +38,15 @@ def plans(t):
     return {"q1": T.q1_plan(t["lineitem"]), "q3": T.q3_plan(t["customer"], t["orders"], t["lineitem"]),
             "q4": T.q4_plan(t["orders"], t["lineitem"]),
             "q5": T.q5_plan(t["customer"], t["orders"], t["lineitem"], t["supplier"], t["nation"], t["region"]),
-            "q6": T.q6_plan(t["lineitem"]), "q12": T.q12_plan(t["orders"], t["lineitem"]), "q18": T.q18_plan(t["customer"], t["orders"], t["lineitem"]),
+            "q6": T.q6_plan(t["lineitem"]), "q7": T.q7_plan(t["supplier"], t["lineitem"], t["orders"], t["customer"], t["nation"]),
+            "q14": T.q14_plan(t["lineitem"], t.get("part")), "q12": T.q12_plan(t["orders"], t["lineitem"]), "q18": T.q18_plan(t["customer"], t["orders"], t["lineitem"]),
             "q19": T.q19_plan(t["lineitem"], t.get("part")),
             "q21": T.q21_plan(t["supplier"], t["lineitem"], t["orders"], t["nation"])}
 
 
 # answer-file columns whose text may contain blanks (everything else is split on blanks)
 _TEXT_FIRST = {"q4": 1, "q5": 1}
+# (q7's nation names FRANCE / GERMANY hold no blanks)
 
 
 def expected_rows(q):
@@ -60,6 +62,8 @@ def _cell(v, want: str):
     trims trailing zeros), dates and strings as text"""
     if isinstance(v, (Decimal, int)) and not isinstance(v, bool):
         return Decimal(v) == Decimal(want)
+    if isinstance(v, float):   # sqllogictest prints Float64 rounded to 12 decimal places (sqllogictest/src/engines/conversion.rs f64_to_str)
+        return Decimal(repr(v)).quantize(Decimal(1).scaleb(-12)) == Decimal(want).quantize(Decimal(1).scaleb(-12))
     if isinstance(v, datetime.date):
         return v.isoformat() == want
     return str(v) == want
@@ -75,7 +79,7 @@ def assert_answer(q, got: pa.Table):
         assert all(_cell(v, x) for v, x in zip(r, w)), f"{q} row {i}: got {r}, the reference's answer is {w} ({GOLD['answers'][q]['source']})"
 
 
-QUERIES = ["q1", "q3", "q4", "q5", "q6", "q12", "q18", "q19", "q21"]
+QUERIES = ["q1", "q3", "q4", "q5", "q6", "q7", "q12", "q14", "q18", "q19", "q21"]
 # Q19's JoinFilter compares string columns with literals: the host side binds them through the dictionaries of the columns behind the
 # intermediate schema (expr.IntermediateSchema, tests/test_abi.py)
 GPU_QUERIES = list(QUERIES)
@@ -84,6 +88,7 @@ RESULT_TYPES = {   # pinned by the answer files' decimal digits and the plan fil
            "count_order": pa.int64()},
     "q3": {"revenue": pa.decimal128(38, 4)}, "q4": {"order_count": pa.int64()}, "q5": {"revenue": pa.decimal128(38, 4)},
     "q6": {"revenue": pa.decimal128(38, 4)}, "q12": {"high_line_count": pa.int64(), "low_line_count": pa.int64()}, "q18": {"sum(lineitem.l_quantity)": pa.decimal128(25, 2)}, "q19": {"revenue": pa.decimal128(38, 4)}, "q21": {"numwait": pa.int64()},
+    "q7": {"l_year": pa.int32(), "revenue": pa.decimal128(38, 4)}, "q14": {"promo_revenue": pa.float64()},
 }
 
 
