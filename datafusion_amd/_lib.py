@@ -22,7 +22,7 @@ class Field(C.Structure):
 
 class ColumnView(C.Structure):
     _fields_ = [("field", Field), ("length", C.c_int64), ("null_count", C.c_int64), ("data", C.c_void_p),
-                ("validity", C.c_void_p), ("name", C.c_char_p)]
+                ("validity", C.c_void_p), ("name", C.c_char_p), ("offsets", C.c_void_p)]
 
 
 class ExprNode(C.Structure):
@@ -32,7 +32,7 @@ class ExprNode(C.Structure):
 
 
 class Expr(C.Structure):
-    _fields_ = [("nodes", C.POINTER(ExprNode)), ("n_nodes", C.c_int32), ("root", C.c_int32)]
+    _fields_ = [("nodes", C.POINTER(ExprNode)), ("n_nodes", C.c_int32), ("root", C.c_int32), ("string_pool", C.c_char_p)]
 
 
 class JoinFilter(C.Structure):
@@ -102,7 +102,7 @@ SYMBOLS = [
     "dfgpu_exchange_hash", "dfgpu_exchange_broadcast", "dfgpu_exchange_broadcast_pruned", "dfgpu_comm_stats",
     "dfgpu_mem_set_limit", "dfgpu_mem_limit", "dfgpu_mem_try_reserve", "dfgpu_mem_reservation_size", "dfgpu_mem_release",
     "dfgpu_table_export_batch", "dfgpu_host_register", "dfgpu_host_unregister", "dfgpu_table_export_into",
-    "dfgpu_table_dictionary_like", "dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_estimate_bytes",
+    "dfgpu_table_dictionary_like", "dfgpu_table_dictionary_encode", "dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_estimate_bytes",
 ]
 
 _lib = None

@@ -68,6 +68,7 @@ static dfgpu_field node_type(const dfgpu_expr& e, int idx, const Table& in) {
       return mkfield(DFGPU_INT32);
     case DFGPU_EXPR_EQ: case DFGPU_EXPR_NE: case DFGPU_EXPR_LT: case DFGPU_EXPR_LE: case DFGPU_EXPR_GT: case DFGPU_EXPR_GE:
     case DFGPU_EXPR_AND: case DFGPU_EXPR_OR: case DFGPU_EXPR_NOT: case DFGPU_EXPR_IS_NULL: case DFGPU_EXPR_IS_NOT_NULL:
+    case DFGPU_EXPR_LIKE: case DFGPU_EXPR_ILIKE:
       return mkfield(DFGPU_BOOL);
     case DFGPU_EXPR_CASE: {
       DFGPU_CHECK(node_type(e, n.column, in).type == DFGPU_BOOL, "CASE WHEN condition must be Boolean");
@@ -656,6 +657,10 @@ static Datum eval_node(const dfgpu_expr& e, int idx, const Table& in) {
       d.col.field = n.field;
       d.lit_lo = n.lit_lo;
       d.lit_hi = n.lit_hi;
+      if (n.field.type == DFGPU_UTF8 && !d.scalar_null) {
+        DFGPU_CHECK(e.string_pool != nullptr, "a string literal without dfgpu_expr.string_pool");
+        d.str.assign(e.string_pool + n.lit_lo, (size_t)n.lit_hi);
+      }
       return d;
     }
     case DFGPU_EXPR_CAST:
@@ -703,6 +708,8 @@ static Datum eval_node(const dfgpu_expr& e, int idx, const Table& in) {
     default: {
       Datum a = eval_node(e, n.left, in);
       Datum b = eval_node(e, n.right, in);
+      if (n.op == DFGPU_EXPR_LIKE || n.op == DFGPU_EXPR_ILIKE || a.col.field.type == DFGPU_UTF8 || b.col.field.type == DFGPU_UTF8)
+        return string_binary(n.op, a, b, nrows);
       return eval_binary(n, a, b, nrows);
     }
   }

@@ -165,13 +165,20 @@ Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_
   for (size_t i = 0; i < cols.size(); i++) {
     DFGPU_CHECK(cols[i] >= 0 && cols[i] < (int)in.cols.size(), "projection index out of range");
     const Column& c = in.cols[cols[i]];
+    if (c.field.type == DFGPU_UTF8) {  // strings: lengths -> scan -> byte copy (strings.hip); done here, skipped below
+      out.cols.push_back(compact_strings(c, mask, mask_valid, prefix->as<uint64_t>(), n, n_out));
+      continue;
+    }
     out.cols.push_back(alloc_like(c, n_out));
     if (c.validity) valid_bytes[i] = make_buf((size_t)n_out + 64);
   }
   if (n_out > 0) {
     // byte-addressable columns, MAX_COLS per launch; Boolean (bit-packed) columns one by one afterwards
     std::vector<int> wide, bits;
-    for (size_t i = 0; i < cols.size(); i++) (in.cols[cols[i]].field.type == DFGPU_BOOL ? bits : wide).push_back((int)i);
+    for (size_t i = 0; i < cols.size(); i++) {
+      if (in.cols[cols[i]].field.type == DFGPU_UTF8) continue;
+      (in.cols[cols[i]].field.type == DFGPU_BOOL ? bits : wide).push_back((int)i);
+    }
     for (int i : bits) {
       const Column& c = in.cols[cols[i]];
       BufPtr vals = make_buf((size_t)n_out + 64);
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(const T* __restrict__ src, con
 // arrow `take` (joins/utils.rs:1371,1379 build_batch_from_indices): idx < 0 => NULL
 Column gather_column(const Column& in, const int64_t* idx, int64_t n, bool idx_may_be_null) {
   Runtime& r = rt();
+  if (in.field.type == DFGPU_UTF8) return gather_strings(in, idx, n, idx_may_be_null);
   DFGPU_CHECK(in.field.type != DFGPU_BOOL, "take: Boolean columns are not supported on the GPU path yet");
   Column out = alloc_like(in, n);
   if (n == 0) return out;
@@ -347,7 +355,7 @@ std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols
   int64_t in_bytes = 0;
   for (size_t k = 0; k < cols.size(); k++) {
     const Column& c = in.cols[cols[k]];
-    if (!idx_may_be_null && !c.validity && c.field.type != DFGPU_BOOL) {
+    if (!idx_may_be_null && !c.validity && c.field.type != DFGPU_BOOL && c.field.type != DFGPU_UTF8) {
       packable.push_back((int)k);
       in_bytes += in.nrows * type_width(c.field.type);
     }

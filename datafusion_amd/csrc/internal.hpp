@@ -128,6 +128,8 @@ inline int type_width(int t) {
     case DFGPU_DECIMAL128: return 16;
     case DFGPU_UINT8: return 1;
     case DFGPU_BOOL: return 0;  // bit-packed
+    case DFGPU_UTF8:
+      throw Error("a Utf8 column reached an operator that works on fixed-width columns: dictionary-encode it first (dfgpu_table_dictionary_encode)");
   }
   throw Error("unknown dfgpu_type " + std::to_string(t));
 }
@@ -175,6 +177,7 @@ struct Column {
   BufPtr data;             // values (or bit-packed booleans), 64-bit word padded
   size_t data_offset = 0;  // byte offset of row 0 inside `data` (partition outputs share one buffer)
   BufPtr validity;         // optional bitmap, 64-bit word padded; nullptr = all valid
+  BufPtr offsets;          // DFGPU_UTF8: int64 [length + 1] byte offsets into `data` (offsets[0] == 0)
   std::shared_ptr<ColStats> stats;  // filled lazily by dfgpu_column_minmax; never set on columns whose rows differ from the source
   std::shared_ptr<const DictValues> dict;  // dictionary-encoded strings: `data` holds the indices
 
@@ -230,6 +233,7 @@ void count_nulls(Column& c);
 // ----------------------------------------------------------------- expressions (expr.hip)
 struct Datum {  // ColumnarValue: array or scalar
   Column col;   // for scalars: length-1 column resident on device? no: host literal below
+  std::string str;  // scalar of type DFGPU_UTF8: the literal's bytes
   bool scalar = false;
   bool scalar_null = false;
   uint64_t lit_lo = 0, lit_hi = 0;  // scalar bits (sign-extended ints / f64 bits)
@@ -237,6 +241,21 @@ struct Datum {  // ColumnarValue: array or scalar
 dfgpu_field expr_type(const dfgpu_expr& e, const Table& input);
 Datum evaluate(const dfgpu_expr& e, const Table& input);
 Column datum_to_column(const Datum& d, int64_t n, const std::string& name);
+
+// ----------------------------------------------------------------- strings (strings.hip)
+inline const int64_t* str_offsets(const Column& c) { return c.offsets ? c.offsets->as<int64_t>() : nullptr; }
+// a fresh DFGPU_UTF8 column: offsets allocated (n + 1), bytes allocated by the caller once their total is known
+Column alloc_string_column(const Column& like, int64_t n);
+// take: out[i] = in[idx[i]]; idx < 0 -> NULL
+Column gather_strings(const Column& in, const int64_t* idx, int64_t n, bool idx_may_be_null);
+// rows of `in` whose mask bit is set (prefix = exclusive popcount prefix per mask word, n_out = total)
+Column compact_strings(const Column& in, const uint64_t* mask, const uint64_t* mask_valid, const uint64_t* prefix, int64_t nrows, int64_t n_out);
+// vertical concatenation of string columns (all DFGPU_UTF8)
+Column concat_strings(const std::vector<const Column*>& parts, int64_t total);
+// Int32 indices + host dictionary (first-seen order, or ascending when `sorted`)
+Column dictionary_encode(const Column& in, bool sorted);
+// BinaryExpr comparison / LikeExpr over string operands (a Boolean column; NULL where an operand is NULL)
+Datum string_binary(int op, const Datum& a, const Datum& b, int64_t nrows);
 
 // ----------------------------------------------------------------- runtime specialisation (jit.hip)
 // compiles `source` with hiprtc for gfx950 (cached per process by source text) and returns `kernel_name`

@@ -1236,16 +1236,19 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const bool probe_side_only = join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI;
   const bool build_side_only = join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI || join_type == DFGPU_JOIN_LEFT_MARK;
   bool payload_nullable = false;
-  for (int c : bout) payload_nullable |= jt.build.cols[c].has_nulls();
-  for (int c : pout) payload_nullable |= probe.cols[c].has_nulls();
+  // (a Utf8 payload column takes the same route as a nullable one: pairs, then take — strings.hip gather_strings)
+  for (int c : bout) payload_nullable |= jt.build.cols[c].has_nulls() || jt.build.cols[c].field.type == DFGPU_UTF8;
+  for (int c : pout) payload_nullable |= probe.cols[c].has_nulls() || probe.cols[c].field.type == DFGPU_UTF8;
   const bool fast_inner = join_type == DFGPU_JOIN_INNER && jt.keys_unique && !payload_nullable &&
                           (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS;
 
   // single-pass flavour: output columns are allocated for the upper bound (np rows) because the
   // row count is only known when the kernel ends; HBM is sized for that (288 GB)
   int64_t out_row_bytes = 0;
-  for (int c : bout) out_row_bytes += type_width(jt.build.cols[c].field.type);
-  for (int c : pout) out_row_bytes += type_width(probe.cols[c].field.type);
+  if (!payload_nullable) {
+    for (int c : bout) out_row_bytes += type_width(jt.build.cols[c].field.type);
+    for (int c : pout) out_row_bytes += type_width(probe.cols[c].field.type);
+  }
   const bool fused_ok = np < (1ll << 40) && !payload_nullable && (int)(bout.size() + pout.size()) <= MAX_JOIN_COLS &&
                         bout.size() + pout.size() > 0 && (fast_inner || probe_side_only);
   // probe_mode: 0 / 1 = output in probe order like the reference (exec.rs:3349), exact allocation: the PLACED flavour (tile

@@ -297,7 +297,7 @@ std::vector<Table> partition_table(const Table& in, const std::vector<int>& key_
   int nbits = 0;
   while ((1 << nbits) < nparts) nbits++;
   bool simple = true;
-  for (auto& c : in.cols) simple &= !c.validity && c.field.type != DFGPU_BOOL;
+  for (auto& c : in.cols) simple &= !c.validity && c.field.type != DFGPU_BOOL && c.field.type != DFGPU_UTF8;
   static const bool gen1 = std::getenv("DFGPU_PART_GEN1") != nullptr;  // A/B knob: the first-generation count pass
   const bool gen2 = !gen1 && nparts <= 16;
   const FastMod fm = fastmod_for((uint32_t)nparts);

@@ -57,6 +57,7 @@ RpValue RowProgramCompiler::column(int idx) {
     if (slot >= RP_MAX_COLS) fail("more than " + std::to_string(RP_MAX_COLS) + " input columns");
   }
   const int ct = in_.cols[idx].field.type;
+  if (ct == DFGPU_UTF8) fail("string columns are evaluated column-at-a-time");
   return RpValue{emit(0xFF, -1, -1, 0, slot, false, ct == DFGPU_DECIMAL128 || ct == DFGPU_UINT64), in_.cols[idx].field};
 }
 
@@ -151,6 +152,10 @@ RpValue RowProgramCompiler::lower_binary(int op, RpValue a, RpValue b) {
     return RpValue{emit(op == DFGPU_EXPR_AND ? RP_AND : RP_OR, a.id, b.id, 0), mk(DFGPU_BOOL)};
   }
   const bool is_cmp = op >= DFGPU_EXPR_EQ && op <= DFGPU_EXPR_GE;
+  if (lt.type == DFGPU_UTF8 || rtp.type == DFGPU_UTF8) {  // already failed in column() / literal: keep lowering harmless
+    fail("string operands are evaluated column-at-a-time");
+    return literal(mk(DFGPU_BOOL), 0, 0, true);
+  }
   if (is_literal(a) && is_literal(b)) {
     std::vector<dfgpu_expr_node> nodes(3);
     const RpValue* side[2] = {&a, &b};
@@ -213,7 +218,14 @@ RpValue RowProgramCompiler::lower(const dfgpu_expr& e, int idx) {
   const dfgpu_expr_node& n = e.nodes[idx];
   switch (n.op) {
     case DFGPU_EXPR_COLUMN: return column(n.column);
-    case DFGPU_EXPR_LITERAL: return literal(n.field, n.lit_lo, n.lit_hi, n.is_null != 0);
+    case DFGPU_EXPR_LITERAL:
+      if (n.field.type == DFGPU_UTF8) fail("string literals are evaluated column-at-a-time");
+      return literal(n.field, n.lit_lo, n.lit_hi, n.is_null != 0);
+    case DFGPU_EXPR_LIKE: case DFGPU_EXPR_ILIKE: {
+      lower(e, n.left);
+      fail("LIKE is evaluated column-at-a-time");
+      return literal(mk(DFGPU_BOOL), 0, 0, true);
+    }
     case DFGPU_EXPR_CAST: return lower_cast(n.field, lower(e, n.left));
     case DFGPU_EXPR_NOT: {
       RpValue a = lower(e, n.left);

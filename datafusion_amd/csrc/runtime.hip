@@ -198,7 +198,12 @@ Column alloc_column(const dfgpu_field& f, const std::string& name, int64_t n, bo
   c.field = f;
   c.name = name;
   c.length = n;
-  c.data = make_buf(data_bytes(f.type, n) + 16);
+  if (f.type == DFGPU_UTF8) {  // n empty strings (row-selecting operators build string columns themselves, strings.hip)
+    c.data = make_buf(16);
+    c.offsets = make_zero_buf((size_t)(n + 1) * 8);
+  } else {
+    c.data = make_buf(data_bytes(f.type, n) + 16);
+  }
   if (with_validity) {
     c.validity = make_buf(bitmap_bytes(n));
     c.null_count = -1;

@@ -1,0 +1,519 @@
+// strings.hip — variable-length strings in HBM (DFGPU_UTF8: 64-bit offsets + bytes).
+//
+// What the reference does with string keys and predicates on the CPU, restated for HBM:
+//   * interning (ArrowBytesMap::insert_if_new, physical-expr-common/src/binary_map.rs:215-420; GroupValuesByes,
+//     aggregates/group_values/single_group_by/bytes.rs; ByteGroupValueBuilder equal_to / append, multi_group_by/bytes.rs):
+//     hash the bytes (hash_utils.rs:401-640 hashes the same bytes), look the hash up, compare bytes with the stored
+//     value, hand out group numbers in first-seen order.  Here: ONE pass in which every row claims or joins a slot of an
+//     open-addressing table in HBM (the representative of a slot converges to the string's first row by atomicMin), then
+//     representatives -> row bitmask -> popcount prefix -> dense numbers, exactly the aggregate's interning (aggregate.hip).
+//     The result is a dictionary-encoded column; joins / GROUP BY / ORDER BY / repartition then run on 4-byte indices,
+//     which is what makes string keys an HBM-friendly workload (a 25-byte key becomes a 4-byte one).
+//   * comparisons and LIKE against a literal (arrow-ord cmp, arrow-string like.rs): one thread per string, the literal in
+//     the kernel's argument block, a wave's 64 results leave as one ballot word.
+//   * take / filter of a string column (arrow-select take_bytes / filter_bytes): lengths -> exclusive scan (= the new
+//     offsets) -> byte copy.
+// Strings are short (TPC-H: 10-40 bytes), so the unit of work is a thread per string moving 8 bytes at a time (unaligned
+// 64-bit accesses through a packed struct: global memory takes them), not a wave per string.
+#include <algorithm>
+#include <cstdlib>
+#include <numeric>
+
+#include "device.hpp"
+#include "internal.hpp"
+
+namespace dfgpu {
+
+void pack_bytes_to_bitmap(const uint8_t* bytes, int64_t n, uint64_t* words);
+
+struct __attribute__((packed)) Unaligned64 {
+  uint64_t v;
+};
+__device__ __forceinline__ uint64_t load_u64(const uint8_t* p) { return reinterpret_cast<const Unaligned64*>(p)->v; }
+__device__ __forceinline__ void store_u64(uint8_t* p, uint64_t v) { reinterpret_cast<Unaligned64*>(p)->v = v; }
+
+// bytes [0, len) of a string as a little-endian prefix: the last (partial) word zero-padded
+__device__ __forceinline__ uint64_t tail_u64(const uint8_t* p, int64_t len) {
+  uint64_t v = 0;
+  for (int64_t k = 0; k < len; k++) v |= (uint64_t)p[k] << (8 * k);
+  return v;
+}
+__device__ __forceinline__ uint64_t hash_bytes(const uint8_t* p, int64_t len) {
+  uint64_t h = fmix64((uint64_t)len ^ SEED_AGG);
+  int64_t k = 0;
+  for (; k + 8 <= len; k += 8) h = fmix64(h ^ load_u64(p + k));
+  if (k < len) h = fmix64(h ^ tail_u64(p + k, len - k) ^ 0x9E3779B97F4A7C15ULL);
+  return h;
+}
+__device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, int64_t len) {
+  int64_t k = 0;
+  for (; k + 8 <= len; k += 8)
+    if (load_u64(a + k) != load_u64(b + k)) return false;
+  for (; k < len; k++)
+    if (a[k] != b[k]) return false;
+  return true;
+}
+// memcmp order = code point order of UTF-8 (Rust's str Ord, arrow-ord's byte-wise comparison)
+__device__ __forceinline__ int bytes_compare(const uint8_t* a, int64_t la, const uint8_t* b, int64_t lb) {
+  const int64_t m = la < lb ? la : lb;
+  for (int64_t k = 0; k < m; k++)
+    if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
+  return la < lb ? -1 : (la > lb ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------ take / filter
+__global__ __launch_bounds__(BLOCK) void k_str_lengths(const int64_t* __restrict__ off, const uint64_t* __restrict__ valid, const int64_t* __restrict__ idx, int64_t n,
+                                                       uint32_t* __restrict__ len, uint8_t* __restrict__ valid_bytes) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t s = idx ? idx[i] : i;
+    const bool ok = s >= 0 && (!valid || bit_at(valid, s));
+    len[i] = ok ? (uint32_t)(off[s + 1] - off[s]) : 0u;
+    if (valid_bytes) valid_bytes[i] = ok ? 1 : 0;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_str_copy(const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, const int64_t* __restrict__ idx, int64_t n,
+                                                    const uint64_t* __restrict__ new_off, uint8_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t len = (int64_t)(new_off[i + 1] - new_off[i]);
+    if (len == 0) continue;
+    const int64_t s = idx ? idx[i] : i;
+    const uint8_t* src = bytes + off[s];
+    uint8_t* dst = out + new_off[i];
+    int64_t k = 0;
+    for (; k + 8 <= len; k += 8) store_u64(dst + k, load_u64(src + k));
+    for (; k < len; k++) dst[k] = src[k];
+  }
+}
+// row ids of the set bits of a mask, in order
+__global__ __launch_bounds__(BLOCK) void k_str_mask_ids(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ mask_valid, const uint64_t* __restrict__ prefix,
+                                                        int64_t n, int64_t* __restrict__ ids) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    uint64_t m = mask[w];
+    if (mask_valid) m &= mask_valid[w];
+    const int64_t rem = n - (w << 6);
+    if (rem < 64) m &= (~0ull) >> (64 - rem);
+    if ((m >> lane_id()) & 1ull) ids[prefix[w] + mbcnt(m)] = (w << 6) + lane_id();
+  }
+}
+
+Column alloc_string_column(const Column& like, int64_t n) {
+  Column c;
+  c.field = like.field;
+  c.field.type = DFGPU_UTF8;
+  c.name = like.name;
+  c.length = n;
+  c.offsets = make_buf((size_t)(n + 1) * 8 + 16);
+  return c;
+}
+
+Column gather_strings(const Column& in, const int64_t* idx, int64_t n, bool idx_may_be_null) {
+  Runtime& r = rt();
+  DFGPU_CHECK(in.field.type == DFGPU_UTF8 && (in.offsets || in.length == 0), "gather_strings: not a string column");
+  Column out = alloc_string_column(in, n);
+  if (n == 0) {
+    DFGPU_HIP(hipMemsetAsync(out.offsets->ptr, 0, 8, r.stream));
+    out.data = make_buf(16);
+    return out;
+  }
+  const bool need_valid = idx_may_be_null || in.validity;
+  BufPtr len = make_buf((size_t)n * 4 + 16);
+  BufPtr vb = need_valid ? make_buf((size_t)n + 64) : nullptr;
+  const int g = grid_for(n, BLOCK);
+  {
+    ProfileScope ps("take_string_lengths", n * 24);
+    k_str_lengths<<<g, BLOCK, 0, r.stream>>>(str_offsets(in), in.valid_words(), idx, n, len->as<uint32_t>(), vb ? vb->as<uint8_t>() : nullptr);
+  }
+  scan_u32(len->as<uint32_t>(), n, out.offsets->as<uint64_t>());
+  const int64_t total = (int64_t)read_u64(out.offsets->as<uint64_t>() + n);
+  out.data = make_buf((size_t)total + 16);
+  {
+    ProfileScope ps("take_string_bytes", 2 * total + n * 24);
+    k_str_copy<<<g, BLOCK, 0, r.stream>>>(str_offsets(in), (const uint8_t*)in.ptr(), idx, n, out.offsets->as<uint64_t>(), (uint8_t*)out.data->ptr);
+    DFGPU_HIP(hipGetLastError());
+  }
+  if (need_valid) {
+    out.validity = make_buf(bitmap_bytes(n));
+    pack_bytes_to_bitmap(vb->as<uint8_t>(), n, out.validity->as<uint64_t>());
+    out.null_count = -1;
+    count_nulls(out);
+  }
+  return out;
+}
+
+Column compact_strings(const Column& in, const uint64_t* mask, const uint64_t* mask_valid, const uint64_t* prefix, int64_t nrows, int64_t n_out) {
+  BufPtr ids = make_buf((size_t)std::max<int64_t>(n_out, 1) * 8);
+  if (n_out) {
+    const int64_t n_words = (nrows + 63) / 64;
+    k_str_mask_ids<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, rt().stream>>>(mask, mask_valid, prefix, nrows, ids->as<int64_t>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  return gather_strings(in, ids->as<int64_t>(), n_out, false);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_str_rebase(const int64_t* __restrict__ off, int64_t n, int64_t base, int64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = off[i] + base;
+}
+Column concat_strings(const std::vector<const Column*>& parts, int64_t total_rows) {
+  Runtime& r = rt();
+  DFGPU_CHECK(!parts.empty(), "concat of zero columns");
+  Column out = alloc_string_column(*parts[0], total_rows);
+  // byte totals of the parts (their last offsets)
+  std::vector<int64_t> bytes(parts.size(), 0);
+  for (size_t p = 0; p < parts.size(); p++)
+    if (parts[p]->length) bytes[p] = (int64_t)read_u64((const uint64_t*)str_offsets(*parts[p]) + parts[p]->length);
+  const int64_t total_bytes = std::accumulate(bytes.begin(), bytes.end(), (int64_t)0);
+  out.data = make_buf((size_t)total_bytes + 16);
+  bool any_nulls = false;
+  for (const Column* c : parts) any_nulls |= c->validity != nullptr;
+  if (any_nulls) {
+    out.validity = make_zero_buf(bitmap_bytes(total_rows));
+    out.null_count = -1;
+  }
+  int64_t row = 0, base = 0;
+  for (size_t p = 0; p < parts.size(); p++) {
+    const Column& c = *parts[p];
+    DFGPU_CHECK(c.field.type == DFGPU_UTF8, "concat: column type mismatch");
+    if (c.length) {
+      k_str_rebase<<<grid_for(c.length, BLOCK), BLOCK, 0, r.stream>>>(str_offsets(c), c.length, base, out.offsets->as<int64_t>() + row);
+      if (bytes[p]) DFGPU_HIP(hipMemcpyAsync((char*)out.data->ptr + base, c.ptr(), (size_t)bytes[p], hipMemcpyDeviceToDevice, r.stream));
+      if (any_nulls) bitmap_place(c.valid_words(), row, c.length, out.validity->as<uint64_t>());
+    }
+    row += c.length;
+    base += bytes[p];
+  }
+  DFGPU_HIP(hipMemcpyAsync(out.offsets->as<int64_t>() + total_rows, &base, 8, hipMemcpyHostToDevice, r.stream));
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // `base` is a local
+  return out;
+}
+
+// ------------------------------------------------------------------------------ interning
+// slots[s] = (first row holding the slot's string) + 1, 0 = empty.  A row either claims an empty slot or finds a slot whose
+// representative has the same bytes; in that case it lowers the representative to itself when it comes earlier in the
+// table (atomicMin): after the pass every slot holds the FIRST row of its string, whatever order the waves ran in.
+__global__ __launch_bounds__(BLOCK) void k_str_intern(const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ valid, int64_t n,
+                                                      unsigned* __restrict__ slots, uint64_t mask, uint32_t* __restrict__ row_slot) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (valid && !bit_at(valid, i)) {
+      row_slot[i] = 0xFFFFFFFFu;
+      continue;
+    }
+    const uint8_t* p = bytes + off[i];
+    const int64_t len = off[i + 1] - off[i];
+    uint64_t s = hash_bytes(p, len) & mask;
+    const unsigned me = (unsigned)i + 1u;
+    for (;;) {
+      unsigned cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == 0u) {
+        cur = atomicCAS(&slots[s], 0u, me);
+        if (cur == 0u) break;  // claimed
+      }
+      const int64_t rep = (int64_t)cur - 1;
+      if (off[rep + 1] - off[rep] == len && bytes_equal(bytes + off[rep], p, len)) {
+        if (me < cur) atomicMin(&slots[s], me);
+        break;
+      }
+      s = (s + 1) & mask;
+    }
+    row_slot[i] = (unsigned)s;
+  }
+}
+// representatives -> bitmask over row numbers (scan.hip turns it into first-seen numbers)
+__global__ __launch_bounds__(BLOCK) void k_str_mark_reps(const unsigned* __restrict__ slots, uint64_t capacity, unsigned long long* __restrict__ rep_mask) {
+  for (uint64_t s = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; s < capacity; s += (uint64_t)gridDim.x * BLOCK) {
+    const unsigned v = slots[s];
+    if (v) atomicOr(&rep_mask[(v - 1) >> 6], 1ull << ((v - 1) & 63));
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_str_codes(const unsigned* __restrict__ slots, const uint32_t* __restrict__ row_slot, const uint64_t* __restrict__ rep_mask,
+                                                     const uint64_t* __restrict__ prefix, const int32_t* __restrict__ renumber, int64_t n, int32_t* __restrict__ codes) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const uint32_t s = row_slot[i];
+    int32_t c = 0;
+    if (s != 0xFFFFFFFFu) {
+      const unsigned rep = slots[s] - 1u;
+      c = (int32_t)(prefix[rep >> 6] + __popcll(rep_mask[rep >> 6] & ((1ull << (rep & 63)) - 1ull)));
+      if (renumber) c = renumber[c];
+    }
+    codes[i] = c;
+  }
+}
+
+Column dictionary_encode(const Column& in, bool sorted) {
+  Runtime& r = rt();
+  DFGPU_CHECK(in.field.type == DFGPU_UTF8, "dictionary_encode: column '" + in.name + "' is not a Utf8 column");
+  const int64_t n = in.length;
+  DFGPU_CHECK(n < 0x7FFFFFFFll, "dictionary_encode: more than 2^31 rows");
+  dfgpu_field f{};
+  f.type = DFGPU_INT32;
+  f.nullable = 1;
+  Column out = alloc_column(f, in.name, n);
+  out.validity = in.validity;
+  out.null_count = in.null_count;
+  auto dv = std::make_shared<DictValues>();
+  dv->index_format = "i";
+  dv->value_format = "u";
+  if (n == 0) {
+    dv->sorted = true;
+    out.dict = dv;
+    return out;
+  }
+  uint64_t capacity = 1024;
+  while (capacity < (uint64_t)n * 2) capacity <<= 1;
+  BufPtr slots = make_zero_buf((size_t)capacity * 4);
+  BufPtr row_slot = make_buf((size_t)n * 4 + 16);
+  const int64_t row_words = (n + 63) / 64;
+  BufPtr rep_mask = make_zero_buf((size_t)row_words * 8);
+  BufPtr prefix = make_buf((size_t)(row_words + 1) * 8);
+  {
+    ProfileScope ps("string_intern", n * 12);
+    k_str_intern<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(str_offsets(in), (const uint8_t*)in.ptr(), in.valid_words(), n, slots->as<unsigned>(), capacity - 1,
+                                                             row_slot->as<uint32_t>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  k_str_mark_reps<<<grid_for((int64_t)capacity, BLOCK), BLOCK, 0, r.stream>>>(slots->as<unsigned>(), capacity, rep_mask->as<unsigned long long>());
+  scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
+  const int64_t G = (int64_t)read_u64(prefix->as<uint64_t>() + row_words);
+  // the distinct strings in first-seen order -> host
+  BufPtr ids = make_buf((size_t)std::max<int64_t>(G, 1) * 8);
+  if (G) k_str_mask_ids<<<grid_for(row_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(rep_mask->as<uint64_t>(), nullptr, prefix->as<uint64_t>(), n, ids->as<int64_t>());
+  Column plain = in;
+  plain.validity.reset();  // representatives are valid rows
+  Column values = gather_strings(plain, ids->as<int64_t>(), G, false);
+  std::vector<int64_t> hoff((size_t)G + 1, 0);
+  d2h(hoff.data(), values.offsets->ptr, (size_t)(G + 1) * 8);
+  std::vector<char> hbytes((size_t)hoff[(size_t)G] + 1);
+  if (hoff[(size_t)G]) d2h(hbytes.data(), values.data->ptr, (size_t)hoff[(size_t)G]);
+  dv->values.resize((size_t)G);
+  dv->valid.assign((size_t)G, 1);
+  for (int64_t k = 0; k < G; k++) dv->values[(size_t)k].assign(hbytes.data() + hoff[(size_t)k], (size_t)(hoff[(size_t)k + 1] - hoff[(size_t)k]));
+  BufPtr renumber;
+  if (sorted && G > 1) {
+    std::vector<int32_t> order((size_t)G);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dv->values[(size_t)a] < dv->values[(size_t)b]; });
+    std::vector<int32_t> rank((size_t)G);
+    std::vector<std::string> sorted_values((size_t)G);
+    for (int64_t k = 0; k < G; k++) {
+      rank[(size_t)order[(size_t)k]] = (int32_t)k;
+      sorted_values[(size_t)k] = std::move(dv->values[(size_t)order[(size_t)k]]);
+    }
+    dv->values = std::move(sorted_values);
+    renumber = make_buf((size_t)G * 4);
+    DFGPU_HIP(hipMemcpyAsync(renumber->ptr, rank.data(), (size_t)G * 4, hipMemcpyHostToDevice, r.stream));
+    DFGPU_HIP(hipStreamSynchronize(r.stream));  // `rank` is a local
+  }
+  dv->sorted = sorted || G <= 1;
+  {
+    ProfileScope ps("string_codes", n * 16);
+    k_str_codes<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(slots->as<unsigned>(), row_slot->as<uint32_t>(), rep_mask->as<uint64_t>(), prefix->as<uint64_t>(),
+                                                            renumber ? renumber->as<int32_t>() : nullptr, n, out.data->as<int32_t>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  out.dict = dv;
+  return out;
+}
+
+// ------------------------------------------------------------------------------ comparisons / LIKE
+constexpr int STR_LIT_MAX = 256;
+struct StrLit {
+  uint8_t p[STR_LIT_MAX];
+  int len;
+};
+__device__ __forceinline__ bool cmp_result(int op, int c) {
+  switch (op) {
+    case DFGPU_EXPR_EQ: return c == 0;
+    case DFGPU_EXPR_NE: return c != 0;
+    case DFGPU_EXPR_LT: return c < 0;
+    case DFGPU_EXPR_LE: return c <= 0;
+    case DFGPU_EXPR_GT: return c > 0;
+    default: return c >= 0;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_str_cmp_lit(int op, const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, StrLit lit,
+                                                       uint64_t* __restrict__ out) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const int64_t i = (w << 6) + lane_id();
+    bool rr = false;
+    if (i < n) {
+      const int64_t len = off[i + 1] - off[i];
+      if (op == DFGPU_EXPR_EQ || op == DFGPU_EXPR_NE) {
+        bool eq = len == lit.len;
+        if (eq) {
+          const uint8_t* p = bytes + off[i];
+          for (int k = 0; k < lit.len; k++) eq &= p[k] == lit.p[k];
+        }
+        rr = (op == DFGPU_EXPR_EQ) == eq;
+      } else {
+        rr = cmp_result(op, bytes_compare(bytes + off[i], len, lit.p, lit.len));
+      }
+    }
+    const uint64_t word = ballot64(rr);
+    if (lane_id() == 0) out[w] = word;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_str_cmp_cols(int op, const int64_t* __restrict__ aoff, const uint8_t* __restrict__ ab, const int64_t* __restrict__ boff,
+                                                        const uint8_t* __restrict__ bb, int64_t n, uint64_t* __restrict__ out) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const int64_t i = (w << 6) + lane_id();
+    bool rr = false;
+    if (i < n) rr = cmp_result(op, bytes_compare(ab + aoff[i], aoff[i + 1] - aoff[i], bb + boff[i], boff[i + 1] - boff[i]));
+    const uint64_t word = ballot64(rr);
+    if (lane_id() == 0) out[w] = word;
+  }
+}
+__device__ __forceinline__ int utf8_char_len(uint8_t c) { return c < 0x80 ? 1 : (c >> 5) == 0x6 ? 2 : (c >> 4) == 0xE ? 3 : (c >> 3) == 0x1E ? 4 : 1; }
+__device__ __forceinline__ uint8_t fold(uint8_t c, bool ci) { return ci && c >= 'A' && c <= 'Z' ? (uint8_t)(c + 32) : c; }
+// the matcher of table.hip like_match (arrow-string like.rs semantics), one thread per string
+__device__ __forceinline__ bool like_device(const uint8_t* s, int64_t slen, const StrLit& pat, bool ci) {
+  int64_t si = 0, star_s = 0;
+  int pi = 0, star_p = -1;
+  while (si < slen) {
+    bool step = false;
+    if (pi < pat.len) {
+      const uint8_t pc = pat.p[pi];
+      if (pc == '%') {
+        star_p = ++pi;
+        star_s = si;
+        continue;
+      }
+      if (pc == '_') {
+        const int64_t cl = utf8_char_len(s[si]);
+        si += cl < slen - si ? cl : slen - si;
+        pi++;
+        step = true;
+      } else {
+        const int lit = (pc == '\\' && pi + 1 < pat.len) ? pi + 1 : pi;
+        if (fold(pat.p[lit], ci) == fold(s[si], ci)) {
+          si++;
+          pi = lit + 1;
+          step = true;
+        }
+      }
+    }
+    if (step) continue;
+    if (star_p < 0) return false;
+    const int64_t cl = utf8_char_len(s[star_s]);
+    star_s += cl < slen - star_s ? cl : slen - star_s;
+    si = star_s;
+    pi = star_p;
+  }
+  while (pi < pat.len && pat.p[pi] == '%') pi++;
+  return pi == pat.len;
+}
+__global__ __launch_bounds__(BLOCK) void k_str_like(const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, StrLit pat, int ci,
+                                                    uint64_t* __restrict__ out) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const int64_t i = (w << 6) + lane_id();
+    const bool rr = i < n && like_device(bytes + off[i], off[i + 1] - off[i], pat, ci != 0);
+    const uint64_t word = ballot64(rr);
+    if (lane_id() == 0) out[w] = word;
+  }
+}
+
+static StrLit make_lit(const std::string& s, const char* what) {
+  DFGPU_CHECK(s.size() <= (size_t)STR_LIT_MAX, std::string(what) + " longer than 256 bytes is not supported on the GPU path");
+  StrLit l{};
+  std::memcpy(l.p, s.data(), s.size());
+  l.len = (int)s.size();
+  return l;
+}
+static int mirrored(int op) {
+  switch (op) {
+    case DFGPU_EXPR_LT: return DFGPU_EXPR_GT;
+    case DFGPU_EXPR_LE: return DFGPU_EXPR_GE;
+    case DFGPU_EXPR_GT: return DFGPU_EXPR_LT;
+    case DFGPU_EXPR_GE: return DFGPU_EXPR_LE;
+    default: return op;
+  }
+}
+
+Datum string_binary(int op, const Datum& a, const Datum& b, int64_t nrows) {
+  Runtime& r = rt();
+  dfgpu_field bf{};
+  bf.type = DFGPU_BOOL;
+  bf.nullable = 1;
+  const bool like = op == DFGPU_EXPR_LIKE || op == DFGPU_EXPR_ILIKE;
+  DFGPU_CHECK(like || (op >= DFGPU_EXPR_EQ && op <= DFGPU_EXPR_GE), "operator not supported on string operands");
+  DFGPU_CHECK(a.col.field.type == DFGPU_UTF8 && b.col.field.type == DFGPU_UTF8,
+              "string comparison: both operands must be Utf8 (a dictionary-encoded column is compared through its indices: bind the literal with dfgpu_table_dictionary_lookup)");
+  if (a.scalar && !b.scalar) {
+    DFGPU_CHECK(!like, "LIKE takes the column on the left and the pattern on the right");
+    return string_binary(mirrored(op), b, a, nrows);
+  }
+  Datum o;
+  if (a.scalar && b.scalar) {  // two literals: fold on the host
+    o.scalar = true;
+    o.col.field = bf;
+    o.scalar_null = a.scalar_null || b.scalar_null;
+    if (!o.scalar_null) {
+      DFGPU_CHECK(!like, "LIKE between two literals is folded by the planner");
+      const int c = a.str.compare(b.str);
+      const bool rr = op == DFGPU_EXPR_EQ ? c == 0 : op == DFGPU_EXPR_NE ? c != 0 : op == DFGPU_EXPR_LT ? c < 0 : op == DFGPU_EXPR_LE ? c <= 0 : op == DFGPU_EXPR_GT ? c > 0 : c >= 0;
+      o.lit_lo = rr ? 1 : 0;
+    }
+    return o;
+  }
+  o.col = alloc_column(bf, "", nrows);
+  const int64_t nw = (nrows + 63) / 64;
+  if (b.scalar) {
+    if (b.scalar_null) {  // comparison with NULL: NULL everywhere
+      o.col.validity = make_zero_buf(bitmap_bytes(nrows));
+      o.col.null_count = nrows;
+      if (nw) DFGPU_HIP(hipMemsetAsync(o.col.data->ptr, 0, (size_t)nw * 8, r.stream));
+      return o;
+    }
+    o.col.validity = a.col.validity;
+    o.col.null_count = a.col.null_count;
+    if (nrows == 0) return o;
+    const StrLit lit = make_lit(b.str, like ? "a LIKE pattern" : "a string literal");
+    const int g = grid_for(nw, BLOCK / WAVE);
+    ProfileScope ps(like ? "string_like" : "string_cmp", nrows * 9);
+    if (like) k_str_like<<<g, BLOCK, 0, r.stream>>>(str_offsets(a.col), (const uint8_t*)a.col.ptr(), nrows, lit, op == DFGPU_EXPR_ILIKE, o.col.data->as<uint64_t>());
+    else k_str_cmp_lit<<<g, BLOCK, 0, r.stream>>>(op, str_offsets(a.col), (const uint8_t*)a.col.ptr(), nrows, lit, o.col.data->as<uint64_t>());
+    DFGPU_HIP(hipGetLastError());
+    return o;
+  }
+  DFGPU_CHECK(!like, "LIKE with a column as the pattern is not supported on the GPU path");
+  if (a.col.validity && b.col.validity) {
+    o.col.validity = make_buf(bitmap_bytes(nrows));
+    and_bitmaps(a.col.valid_words(), b.col.valid_words(), nw, o.col.validity->as<uint64_t>());
+    o.col.null_count = -1;
+  } else {
+    o.col.validity = a.col.validity ? a.col.validity : b.col.validity;
+    o.col.null_count = o.col.validity ? -1 : 0;
+  }
+  if (nrows == 0) return o;
+  ProfileScope ps("string_cmp", nrows * 18);
+  k_str_cmp_cols<<<grid_for(nw, BLOCK / WAVE), BLOCK, 0, r.stream>>>(op, str_offsets(a.col), (const uint8_t*)a.col.ptr(), str_offsets(b.col), (const uint8_t*)b.col.ptr(),
+                                                                     nrows, o.col.data->as<uint64_t>());
+  DFGPU_HIP(hipGetLastError());
+  return o;
+}
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+
+extern "C" int dfgpu_table_dictionary_encode(dfgpu_table_t th, int column, int sorted, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    Table* t = unwrap(th);
+    DFGPU_CHECK(out && column >= 0 && column < (int)t->cols.size(), "bad argument");
+    auto o = std::make_unique<Table>(*t);
+    o->cols[(size_t)column] = dictionary_encode(t->cols[(size_t)column], sorted != 0);
+    *out = wrap(o.release());
+  });
+}

@@ -57,6 +57,7 @@ static dfgpu_field parse_format(const char* fmt, bool nullable) {
   else if (s == "L") f.type = DFGPU_UINT64;
   else if (s == "tdD") f.type = DFGPU_DATE32;
   else if (s == "b") f.type = DFGPU_BOOL;
+  else if (s == "u" || s == "U" || s == "vu") f.type = DFGPU_UTF8;  // Utf8 / LargeUtf8 / Utf8View: offsets + bytes in HBM (strings.hip)
   else if (s.rfind("d:", 0) == 0) {
     int p = 0, sc = 0, bits = 128;
     int n = std::sscanf(s.c_str(), "d:%d,%d,%d", &p, &sc, &bits);
@@ -65,7 +66,7 @@ static dfgpu_field parse_format(const char* fmt, bool nullable) {
     f.precision = p;
     f.scale = sc;
   } else {
-    // Utf8/Utf8View/Dictionary/nested: the GPU rule leaves such operators on the CPU
+    // nested / binary / temporal types other than Date32: the GPU rule leaves such operators on the CPU
     throw Error("unsupported Arrow type format '" + s + "' for GPU execution");
   }
   return f;
@@ -81,6 +82,7 @@ static std::string format_of(const dfgpu_field& f) {
     case DFGPU_DATE32: return "tdD";
     case DFGPU_BOOL: return "b";
     case DFGPU_DECIMAL128: return "d:" + std::to_string(f.precision) + "," + std::to_string(f.scale);
+    case DFGPU_UTF8: return "u";
   }
   throw Error("format_of: bad type");
 }
@@ -169,12 +171,86 @@ static std::shared_ptr<const DictValues> import_dictionary(const ArrowArray* d, 
   return dv;
 }
 
+static void import_validity(Column& c, const uint8_t* validity, int64_t null_count, int64_t off, int64_t nrows, Uploader& up) {
+  if (!(validity && null_count != 0 && nrows)) return;
+  uint64_t* h = shift_bitmap(validity, off, nrows);
+  int64_t valid = 0;
+  for (size_t wd = 0; wd < bitmap_bytes(nrows) / 8; wd++) valid += __builtin_popcountll(h[wd]);
+  if (valid != nrows) {
+    c.validity = make_buf(bitmap_bytes(nrows));
+    c.null_count = nrows - valid;
+    up.staged.push_back(h);
+    up.upload(c.validity->ptr, h, bitmap_bytes(nrows));
+  } else {
+    std::free(h);
+  }
+}
+// Utf8 ("u": 32-bit offsets), LargeUtf8 ("U": 64-bit offsets), Utf8View ("vu": 16-byte views over variadic buffers) ->
+// 64-bit offsets starting at 0 + contiguous bytes.  Contiguous layouts upload their byte range as it is; views are first
+// laid out contiguously on the host (the CPU-side half of a scan: arrow-rs would `gc()` them the same way).
+static Column import_string_column(const ArrowArray* a, const ArrowSchema* s, Column c, int64_t parent_offset, int64_t nrows, Uploader& up) {
+  const std::string fmt(s->format);
+  const int64_t off = a->offset + parent_offset;
+  int64_t* ho = (int64_t*)std::malloc((size_t)(nrows + 1) * 8);
+  up.staged.push_back(ho);
+  const uint8_t* validity = (const uint8_t*)a->buffers[0];
+  const char* bytes = nullptr;
+  int64_t total = 0;
+  if (fmt == "vu") {
+    DFGPU_CHECK(a->n_buffers >= 3, "Utf8View: expected views + variadic buffers + sizes");
+    struct View { int32_t len; char inl[12]; };
+    const View* v = (const View*)a->buffers[1] + off;
+    ho[0] = 0;
+    for (int64_t i = 0; i < nrows; i++) {
+      const bool ok = !validity || ((validity[(off + i) >> 3] >> ((off + i) & 7)) & 1);
+      ho[i + 1] = ho[i] + (ok ? v[i].len : 0);
+    }
+    total = ho[nrows];
+    char* hb = (char*)std::malloc((size_t)total + 8);
+    up.staged.push_back(hb);
+    for (int64_t i = 0; i < nrows; i++) {
+      const int64_t len = ho[i + 1] - ho[i];
+      if (len == 0) continue;
+      if (len <= 12) std::memcpy(hb + ho[i], v[i].inl, (size_t)len);
+      else {
+        int32_t buf, boff;
+        std::memcpy(&buf, v[i].inl + 4, 4);
+        std::memcpy(&boff, v[i].inl + 8, 4);
+        std::memcpy(hb + ho[i], (const char*)a->buffers[2 + buf] + boff, (size_t)len);
+      }
+    }
+    bytes = hb;
+  } else {
+    DFGPU_CHECK(a->n_buffers == 3, "Utf8: expected validity + offsets + data buffers");
+    int64_t first = 0;
+    ho[0] = 0;
+    if (nrows && fmt == "u") {
+      const int32_t* o = (const int32_t*)a->buffers[1] + off;
+      first = o[0];
+      for (int64_t i = 0; i <= nrows; i++) ho[i] = (int64_t)o[i] - first;
+    } else if (nrows) {
+      const int64_t* o = (const int64_t*)a->buffers[1] + off;
+      first = o[0];
+      for (int64_t i = 0; i <= nrows; i++) ho[i] = o[i] - first;
+    }
+    total = ho[nrows];
+    bytes = (const char*)a->buffers[2] + first;
+  }
+  c.offsets = make_buf((size_t)(nrows + 1) * 8 + 16);
+  up.upload(c.offsets->ptr, ho, (size_t)(nrows + 1) * 8);
+  c.data = make_buf((size_t)total + 16);
+  if (total) up.upload(c.data->ptr, bytes, (size_t)total);
+  import_validity(c, validity, a->null_count, off, nrows, up);
+  return c;
+}
+
 static Column import_column(const ArrowArray* a, const ArrowSchema* s, int64_t parent_offset, int64_t nrows, Uploader& up) {
   Column c;
   c.field = parse_format(s->format, (s->flags & 2) != 0);
   if (s->dictionary) c.dict = import_dictionary(a->dictionary, s->dictionary, s->format, s->name ? s->name : "");
   c.name = s->name ? s->name : "";
   c.length = nrows;
+  if (c.field.type == DFGPU_UTF8 && !s->dictionary) return import_string_column(a, s, c, parent_offset, nrows, up);
   DFGPU_CHECK(a->n_buffers == 2, "expected 2 buffers for a fixed-width column");
   int64_t off = a->offset + parent_offset;
   DFGPU_CHECK(a->length >= nrows + parent_offset || a->length == nrows, "child array shorter than struct");
@@ -444,6 +520,45 @@ static void export_rows(Table* t, int64_t offset, int64_t length, struct ArrowAr
     const bool with_valid = c.validity && c.null_count != 0;
     const bool shifted = (bits || with_valid) && lead != 0;   // every buffer of the child starts `lead` rows early
     const int64_t first = shifted ? row0 : offset, rows = shifted ? length + lead : length;
+    if (c.field.type == DFGPU_UTF8) {
+      // strings: offsets first (their ends give the byte range), rebased to the slice; Utf8 while the bytes fit 32-bit
+      // offsets, LargeUtf8 beyond
+      std::vector<int64_t> ho((size_t)rows + 1, 0);
+      if (rows) d2h(ho.data(), (const char*)c.offsets->ptr + (size_t)first * 8, (size_t)(rows + 1) * 8);
+      const int64_t b0 = ho[0], nbytes = ho[(size_t)rows] - b0;
+      const bool large = nbytes > 0x7FFFFFFFll;
+      void* hoff = pinned().alloc((size_t)(rows + 1) * (large ? 8 : 4) + 8);
+      cp->pinned_buffers.push_back(hoff);
+      for (int64_t i = 0; i <= rows; i++) {
+        if (large) ((int64_t*)hoff)[i] = ho[(size_t)i] - b0;
+        else ((int32_t*)hoff)[i] = (int32_t)(ho[(size_t)i] - b0);
+      }
+      void* hb = pinned().alloc((size_t)nbytes + 8);
+      cp->pinned_buffers.push_back(hb);
+      if (nbytes) DFGPU_HIP(hipMemcpyAsync(hb, (const char*)c.ptr() + b0, (size_t)nbytes, hipMemcpyDeviceToHost, r.stream));
+      void* hv = nullptr;
+      int64_t nulls = 0;
+      if (with_valid) {
+        const size_t vb = bitmap_bytes(rows);
+        hv = pinned().alloc(vb ? vb : 8);
+        cp->pinned_buffers.push_back(hv);
+        if (vb) DFGPU_HIP(hipMemcpyAsync(hv, (const char*)c.validity->ptr + (size_t)(first >> 6) * 8, vb, hipMemcpyDeviceToHost, r.stream));
+        nulls = (offset == 0 && length == c.length) ? c.null_count : -1;
+      }
+      cp->buffer_ptrs = {hv, hoff, hb};
+      ca->length = length;
+      ca->offset = shifted ? lead : 0;
+      ca->null_count = nulls;
+      ca->n_buffers = 3;
+      ca->buffers = cp->buffer_ptrs.data();
+      ca->release = release_array;
+      ca->private_data = cp;
+      ap->children.push_back(ca);
+      auto* cs = new ArrowSchema();
+      fill_schema(cs, large ? "U" : "u", c.name, true);
+      sp->children.push_back(cs);
+      continue;
+    }
     const size_t db = bits ? bitmap_bytes(rows) : (size_t)rows * type_width(c.field.type);
     void* hd = pinned().alloc(db ? db : 8);
     cp->pinned_buffers.push_back(hd);
@@ -535,6 +650,7 @@ int dfgpu_table_export_into(dfgpu_table_t th, int64_t offset, int64_t length, vo
     for (size_t i = 0; i < t->cols.size(); i++) {
       Column& c = t->cols[i];
       const bool bits = c.field.type == DFGPU_BOOL;
+      DFGPU_CHECK(c.field.type != DFGPU_UTF8, "dfgpu_table_export_into: Utf8 columns have no fixed size per row (use dfgpu_table_export_batch)");
       DFGPU_CHECK(!bits || (offset & 63) == 0, "dfgpu_table_export_into: Boolean columns need a row offset that is a multiple of 64");
       const size_t db = bits ? bitmap_bytes(length) : (size_t)length * type_width(c.field.type);
       const char* src = (const char*)c.ptr() + (bits ? (size_t)(offset >> 6) * 8 : (size_t)offset * type_width(c.field.type));
@@ -653,6 +769,7 @@ int dfgpu_table_column(dfgpu_table_t th, int i, dfgpu_column_view* out) {
     out->data = c.ptr();
     out->validity = c.validity ? (const uint8_t*)c.validity->ptr : nullptr;
     out->name = c.name.c_str();
+    out->offsets = c.offsets ? c.offsets->as<int64_t>() : nullptr;
   });
 }
 int dfgpu_table_select(dfgpu_table_t th, const int* cols, int ncols, dfgpu_table_t* out) {
@@ -685,7 +802,7 @@ int dfgpu_table_slice(dfgpu_table_t th, int64_t offset, int64_t length, dfgpu_ta
     auto o = std::make_unique<Table>();
     o->nrows = length;
     for (auto& c : t->cols) {
-      DFGPU_CHECK(c.field.type != DFGPU_BOOL && !c.validity, "slice: Boolean / nullable columns not supported yet");
+      DFGPU_CHECK(c.field.type != DFGPU_BOOL && c.field.type != DFGPU_UTF8 && !c.validity, "slice: Boolean / Utf8 / nullable columns not supported yet");
       Column n = alloc_like(c, length);
       int w = type_width(c.field.type);
       if (length)
@@ -711,6 +828,12 @@ int dfgpu_table_concat(const dfgpu_table_t* parts, int nparts, dfgpu_table_t* ou
     o->nrows = total;
     for (size_t ci = 0; ci < first->cols.size(); ci++) {
       const Column& fc = first->cols[ci];
+      if (fc.field.type == DFGPU_UTF8) {
+        std::vector<const Column*> cs;
+        for (int p = 0; p < nparts; p++) cs.push_back(&unwrap(parts[p])->cols[ci]);
+        o->cols.push_back(concat_strings(cs, total));
+        continue;
+      }
       Column n = alloc_like(fc, total);
       DFGPU_CHECK(fc.field.type != DFGPU_BOOL, "concat: Boolean columns not supported yet");
       int w = type_width(fc.field.type);

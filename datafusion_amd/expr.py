@@ -23,6 +23,7 @@ OP_COLUMN, OP_LITERAL, OP_CAST = 1, 2, 3
 _BINARY = {"+": 10, "-": 11, "*": 12, "/": 13, "%": 14, "=": 20, "!=": 21, "<": 22, "<=": 23, ">": 24, ">=": 25, "and": 30, "or": 31}
 OP_NOT, OP_IS_NULL, OP_IS_NOT_NULL = 32, 33, 34
 OP_CASE = 40
+OP_LIKE, OP_ILIKE = 41, 42
 OP_DATE_PART = 50
 _DATE_PARTS = {"year": 0, "month": 1, "day": 2}
 
@@ -215,6 +216,8 @@ class LikeExpr(PhysicalExpr):
             raise TypeError("LIKE on the GPU path takes a dictionary-encoded string column")
         idx = table.index_of(a.name if a.index is None else a.index)
         itype = table.schema.field(idx).type
+        if pa.types.is_string(itype) or pa.types.is_large_string(itype):
+            return self        # a Utf8 column in HBM: matched on its bytes by the device (DFGPU_EXPR_LIKE)
         column = Column(a.name, idx)
         runs = LikeExpr.runs(table.dictionary_like(idx, self.pattern, self.case_insensitive))
         if len(runs) > self.MAX_RUNS:
@@ -276,11 +279,12 @@ def _literal_bits(value, t: pa.DataType):
 
 
 class LoweredExpr:
-    """keeps the node array alive while the C struct points at it"""
+    """keeps the node array (and the pool of string literals) alive while the C struct points at them"""
 
-    def __init__(self, nodes):
+    def __init__(self, nodes, pool: bytes = b""):
         self.nodes = (ExprNode * len(nodes))(*nodes)
-        self.c = Expr(C.cast(self.nodes, C.POINTER(ExprNode)), len(nodes), len(nodes) - 1)
+        self.pool = pool
+        self.c = Expr(C.cast(self.nodes, C.POINTER(ExprNode)), len(nodes), len(nodes) - 1, pool if pool else None)
 
 
 def bind_string_literals(expr: PhysicalExpr, table) -> PhysicalExpr:
@@ -294,6 +298,8 @@ def bind_string_literals(expr: PhysicalExpr, table) -> PhysicalExpr:
                 if isinstance(a, Column) and isinstance(b, Literal) and (pa.types.is_string(b.type) or pa.types.is_large_string(b.type)):
                     idx = table.index_of(a.name if a.index is None else a.index)
                     itype = table.schema.field(idx).type
+                    if pa.types.is_string(itype) or pa.types.is_large_string(itype):
+                        return expr     # a Utf8 column in HBM: compared on its bytes (DFGPU_UTF8), nothing to bind
                     column = Column(a.name, idx)
                     if b.value is None:
                         return BinaryExpr(column, expr.op, Literal(None, itype))
@@ -363,6 +369,17 @@ def lower(expr: PhysicalExpr, column_names, table=None) -> LoweredExpr:
         expr = bind_string_literals(expr, table)
     nodes: list[ExprNode] = []
     names = list(column_names)
+    pool = bytearray()
+
+    def string_literal(n, value):
+        n.op = OP_LITERAL
+        n.field = field_of(pa.string())
+        if value is None:
+            n.is_null = 1
+        else:
+            b = value.encode()
+            n.lit_lo, n.lit_hi = len(pool), len(b)
+            pool.extend(b)
 
     def emit(e) -> int:
         n = ExprNode()
@@ -376,6 +393,8 @@ def lower(expr: PhysicalExpr, column_names, table=None) -> LoweredExpr:
                 if names.count(e.name) != 1:
                     raise KeyError(f"column {e.name!r} not found or ambiguous in {names}")
                 n.column = names.index(e.name)
+        elif isinstance(e, Literal) and (pa.types.is_string(e.type) or pa.types.is_large_string(e.type)):
+            string_literal(n, e.value)
         elif isinstance(e, Literal):
             n.op = OP_LITERAL
             n.field = field_of(e.type)
@@ -401,7 +420,20 @@ def lower(expr: PhysicalExpr, column_names, table=None) -> LoweredExpr:
             n.op = OP_DATE_PART
             n.column = _DATE_PARTS[e.part]
         elif isinstance(e, LikeExpr):
-            raise TypeError("LIKE must be bound to the column's dictionary first: lower(expr, names, table=...)")
+            # over a Utf8 column in HBM (a dictionary-encoded column was rewritten by LikeExpr.bound before this point)
+            n.left = emit(e.expr)
+            m = ExprNode()
+            m.left = m.right = m.column = -1
+            string_literal(m, e.pattern)
+            nodes.append(m)
+            n.right = len(nodes) - 1
+            n.op = OP_ILIKE if e.case_insensitive else OP_LIKE
+            if e.negated:
+                nodes.append(n)
+                n = ExprNode()
+                n.right = n.column = -1
+                n.left = len(nodes) - 1
+                n.op = OP_NOT
         elif isinstance(e, CaseExpr):
             # one DFGPU_EXPR_CASE node per WHEN, later branches nested in ELSE (include/dfgpu.h)
             tail = -1 if e.else_expr is None else emit(e.else_expr)
@@ -418,4 +450,4 @@ def lower(expr: PhysicalExpr, column_names, table=None) -> LoweredExpr:
         return len(nodes) - 1
 
     emit(expr)
-    return LoweredExpr(nodes)
+    return LoweredExpr(nodes, bytes(pool) + b"\0")

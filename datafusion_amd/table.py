@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import ColumnView, Field, check
 
 # dfgpu_type
-INT32, INT64, DECIMAL128, FLOAT64, UINT8, UINT32, UINT64, DATE32, BOOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
+INT32, INT64, DECIMAL128, FLOAT64, UINT8, UINT32, UINT64, DATE32, BOOL, UTF8 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 class ArrowSchema(C.Structure):
@@ -53,12 +53,14 @@ def field_of(t: pa.DataType) -> Field:
         return Field(DATE32, 0, 0, 1)
     if pa.types.is_boolean(t):
         return Field(BOOL, 0, 0, 1)
+    if pa.types.is_string(t) or pa.types.is_large_string(t) or t == pa.string_view():
+        return Field(UTF8, 0, 0, 1)
     raise TypeError(f"type {t} is not supported on the GPU path")
 
 
 def arrow_type_of(f: Field) -> pa.DataType:
     return {INT32: pa.int32(), INT64: pa.int64(), FLOAT64: pa.float64(), UINT8: pa.uint8(), UINT32: pa.uint32(),
-            UINT64: pa.uint64(), DATE32: pa.date32(), BOOL: pa.bool_()}.get(f.type) or pa.decimal128(f.precision, f.scale)
+            UINT64: pa.uint64(), DATE32: pa.date32(), BOOL: pa.bool_(), UTF8: pa.string()}.get(f.type) or pa.decimal128(f.precision, f.scale)
 
 
 class DeviceTable:
@@ -152,6 +154,23 @@ class DeviceTable:
         code = C.c_int64()
         check(_lib.load().dfgpu_table_dictionary_lookup(self.handle, self.index_of(column), b, C.c_int64(len(b)), C.byref(code)))
         return None if code.value < 0 else code.value
+
+    def dictionary_encode(self, columns=None, sorted: bool = True) -> "DeviceTable":
+        """the table with its Utf8 columns (all of them, or the named ones) dictionary-encoded on the device
+        (dfgpu_table_dictionary_encode): Int32 indices in HBM, the dictionary on the host in ascending order (`sorted`) or in
+        first-seen order — the form joins, GROUP BY, ORDER BY and repartition take string keys in"""
+        lib = _lib.load()
+        names = self.column_names
+        todo = [i for i in range(self.num_columns) if self.column_view(i).field.type == UTF8] if columns is None else [self.index_of(c) for c in columns]
+        cur, owned = self, False
+        for i in todo:
+            out = C.c_void_p()
+            check(lib.dfgpu_table_dictionary_encode(cur.handle, i, int(sorted), C.byref(out)))
+            nxt = DeviceTable(out)
+            if owned:
+                cur.free()
+            cur, owned = nxt, True
+        return cur if owned else self.select(names)
 
     def dictionary_like(self, column, pattern: str, case_insensitive: bool = False):
         """ascending indices of the dictionary values of a dictionary-encoded string column that match the SQL LIKE

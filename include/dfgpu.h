@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 7
+#define DFGPU_ABI_VERSION 8
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -84,7 +84,14 @@ typedef enum dfgpu_type {
   DFGPU_UINT32 = 6,
   DFGPU_UINT64 = 7,
   DFGPU_DATE32 = 8, /* days since epoch, int32 */
-  DFGPU_BOOL = 9    /* bit-packed */
+  DFGPU_BOOL = 9,   /* bit-packed */
+  /* variable-length strings in HBM (Arrow Utf8 / LargeUtf8 / Utf8View on import): `data` = the bytes, 64-bit offsets
+   * [length + 1] beside them.  Row-selecting operators (filter, take, join payload, sort output, partitions, concat) move
+   * such columns; `=`, `!=`, `<` ..., LIKE / ILIKE against a literal or another string column are evaluated on the bytes;
+   * operators that hash or order by a string key (joins, GROUP BY, ORDER BY, repartition) take the column dictionary-encoded:
+   * dfgpu_table_dictionary_encode interns it on the device (hash + byte comparison, first-seen order — ArrowBytesMap,
+   * physical-expr-common/src/binary_map.rs; group_values/{single,multi}_group_by/bytes*.rs) and they then run on the indices. */
+  DFGPU_UTF8 = 10
 } dfgpu_type;
 
 typedef struct dfgpu_field {
@@ -102,6 +109,7 @@ typedef struct dfgpu_column_view {
   const void* data;        /* device pointer */
   const uint8_t* validity; /* device pointer or NULL */
   const char* name;        /* owned by the table */
+  const int64_t* offsets;  /* DFGPU_UTF8: device pointer to length + 1 byte offsets into `data`; NULL otherwise */
 } dfgpu_column_view;
 
 typedef struct dfgpu_table_s* dfgpu_table_t;
@@ -196,6 +204,13 @@ int dfgpu_table_dictionary_lookup(dfgpu_table_t table, int column, const char* u
  * lowers the predicate to comparisons of the index column with them — index ranges when the dictionary is in ascending
  * order, where a prefix pattern matches one contiguous range.  *out_n = number of matches (may exceed `capacity`: call again
  * with a larger buffer); NOT LIKE is NOT(...) of the same, NULL rows stay NULL. */
+/* A DFGPU_UTF8 column -> the same rows dictionary-encoded (Int32 indices in HBM, dictionary on the host), interned on the
+ * device: one pass hashes every string and claims a slot of an open-addressing table, comparing bytes with the slot's
+ * representative; representatives converge to each string's first row, so dictionary order = first-seen order exactly as
+ * ArrowBytesMap::insert_if_new hands out payloads (binary_map.rs:877-960); NULL rows keep a NULL index.  `sorted` != 0
+ * re-numbers the dictionary in ascending string order (what ORDER BY and range predicates over the indices need).  `out` = a
+ * copy of `table` with column `column` replaced (the other columns are shared, not copied). */
+int dfgpu_table_dictionary_encode(dfgpu_table_t table, int column, int sorted, dfgpu_table_t* out);
 int dfgpu_table_dictionary_like(dfgpu_table_t table, int column, const char* pattern, int64_t len, int case_insensitive, int64_t* out_codes,
                                 int64_t capacity, int64_t* out_n);
 
@@ -250,6 +265,10 @@ typedef enum dfgpu_expr_op {
    * branches nest in ELSE; `CASE x WHEN v ...` is lowered by the caller to conditions `x = v`.  THEN and ELSE have
    * the same type (the planner's coercion). */
   DFGPU_EXPR_CASE = 40,
+  /* LikeExpr (expressions/like.rs -> arrow-string like / ilike): left = a DFGPU_UTF8 column, right = the pattern (a DFGPU_UTF8
+   * literal): `%` any run of characters, `_` one character, backslash escapes; NOT LIKE = NOT of it */
+  DFGPU_EXPR_LIKE = 41,
+  DFGPU_EXPR_ILIKE = 42,
   /* date_part(part, Date32) -> Int32 (functions/src/datetime/date_part.rs:165-187; the form `EXTRACT(YEAR FROM d)` plans
    * to): `column` = dfgpu_date_part, `left` = the Date32 argument */
   DFGPU_EXPR_DATE_PART = 50
@@ -270,6 +289,9 @@ typedef struct dfgpu_expr {
   const dfgpu_expr_node* nodes;
   int32_t n_nodes;
   int32_t root;
+  /* bytes of the string literals: a LITERAL node of type DFGPU_UTF8 holds (lit_lo = byte offset, lit_hi = byte length) into
+   * this pool; NULL when the expression has none */
+  const char* string_pool;
 } dfgpu_expr;
 
 /* result type of an expression over a table (PhysicalExpr::data_type, :80) */

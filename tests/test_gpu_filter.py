@@ -117,4 +117,4 @@ def test_unsupported_type_is_an_error_not_a_fallback():
     from datafusion_amd import DfgpuError
     from datafusion_amd.table import DeviceTable
     with pytest.raises(DfgpuError, match="unsupported Arrow type"):
-        DeviceTable.from_arrow(pa.table({"s": pa.array(["a", "b"])}))
+        DeviceTable.from_arrow(pa.table({"s": pa.array([[1], [2, 3]], pa.list_(pa.int32()))}))      # (strings are imported since ABI 8: tests/test_gpu_strings.py)

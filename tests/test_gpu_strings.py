@@ -1,0 +1,177 @@
+"""Variable-length strings in HBM (DFGPU_UTF8): import / export of Utf8, LargeUtf8 and Utf8View, comparisons and LIKE on the bytes,
+row-selecting operators (filter, take through joins / sort), concatenation, and device-side interning
+(dfgpu_table_dictionary_encode) against the reference's ArrowBytesMap known answers (physical-expr-common/src/binary_map.rs:649-697
+test_string_set_basic, :877-893 test_map: distinct values in first-seen order, a NULL kept apart, re-inserting changes nothing) and
+against pyarrow on random data.  String keys of joins / GROUP BY / ORDER BY run on the interned indices and are compared with the
+oracle over pyarrow-encoded inputs."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WORDS = ["", "a", "b", "ab", "abc", "cbcxx", "AAAAAAAA", "BBBBBQBBB", "CXCCCCCCCC", "bcdefghijklmnop", "qrstuvqxyzhjwya", "✨🔥", "🔥", "🔥🔥🔥🔥🔥🔥",
+         "PROMO BURNISHED COPPER", "STANDARD ANODIZED TIN", "furiously special requests haggle", "50% off_", "naïve café", "x" * 100, "y" * 257]
+
+
+def random_strings(rng, n, null_frac=0.0, pool=None):
+    pool = WORDS if pool is None else pool
+    idx = rng.integers(0, len(pool), size=n)
+    mask = rng.random(n) < null_frac if null_frac else None
+    return pa.array([pool[i] for i in idx], pa.string(), mask=mask)
+
+
+@pytest.mark.parametrize("typ", [pa.string(), pa.large_string(), pa.string_view()])
+@pytest.mark.parametrize("null_frac", [0.0, 0.2])
+def test_import_export_round_trip(typ, null_frac):
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 63, 64, 1000):
+        s = random_strings(rng, n, null_frac).cast(typ)
+        t = pa.table({"i": pa.array(np.arange(n, dtype=np.int64)), "s": s})
+        got = DeviceTable.from_arrow(t).to_arrow()
+        assert got.column("s").cast(pa.string()).to_pylist() == s.cast(pa.string()).to_pylist()
+        assert got.column("i").to_pylist() == list(range(n))
+    sliced = pa.table({"s": random_strings(rng, 500, null_frac).cast(typ)}).slice(37, 201)       # an Arrow offset on the way in
+    assert DeviceTable.from_arrow(sliced).to_arrow().column("s").cast(pa.string()).to_pylist() == sliced.column("s").cast(pa.string()).to_pylist()
+
+
+def test_batched_export_of_strings():
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(2)
+    s = random_strings(rng, 1000, 0.1)
+    dev = DeviceTable.from_arrow(pa.table({"s": s}))
+    out = pa.Table.from_batches(list(dev.to_batches(130)))
+    assert out.column("s").to_pylist() == s.to_pylist()
+
+
+def test_reference_string_set_basic_and_test_map():
+    """binary_map.rs:655-697 and :877-893"""
+    from datafusion_amd.table import DeviceTable
+    values = ["a", "b", "CXCCCCCCCC", "", "cbcxx", None, "AAAAAAAA", "BBBBBQBBB", "a", "cbcxx", "b", "cbcxx", "", None, "BBBBBQBBB", "BBBBBQBBB", "AAAAAAAA", "CXCCCCCCCC"]
+    enc = DeviceTable.from_arrow(pa.table({"s": pa.array(values, pa.string())})).dictionary_encode(sorted=False).to_arrow().column("s").combine_chunks()
+    # "values must appear in the order they were inserted"; the set keeps ONE NULL entry, the dictionary array keeps NULL indices
+    assert enc.dictionary.to_pylist() == ["a", "b", "CXCCCCCCCC", "", "cbcxx", "AAAAAAAA", "BBBBBQBBB"]
+    assert enc.to_pylist() == values
+    seq = ["A", "bcdefghijklmnop", "X", "Y", None, "qrstuvqxyzhjwya", "✨🔥", "🔥", "🔥🔥🔥🔥🔥🔥"]
+    enc = DeviceTable.from_arrow(pa.table({"s": pa.array(seq + seq, pa.string())})).dictionary_encode(sorted=False).to_arrow().column("s").combine_chunks()
+    assert enc.dictionary.to_pylist() == [v for v in seq if v is not None]             # "put it in twice": no new entries
+    assert enc.indices.to_pylist() == [0, 1, 2, 3, None, 4, 5, 6, 7] * 2                # payload = index of first insertion
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.15])
+@pytest.mark.parametrize("sorted_", [False, True])
+def test_dictionary_encode_matches_pyarrow(null_frac, sorted_):
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(3)
+    pool = WORDS + [f"Customer#{i:09d}" for i in range(5000)]
+    s = random_strings(rng, 40000, null_frac, pool)
+    enc = DeviceTable.from_arrow(pa.table({"s": s})).dictionary_encode(sorted=sorted_).to_arrow().column("s").combine_chunks()
+    assert enc.to_pylist() == s.to_pylist()
+    want = pc.dictionary_encode(s).dictionary.to_pylist()                               # pyarrow: first-seen order too
+    assert enc.dictionary.to_pylist() == (sorted(want) if sorted_ else want)
+    assert enc.indices.null_count == s.null_count
+
+
+def test_dictionary_encode_edge_shapes():
+    from datafusion_amd.table import DeviceTable
+    for vals in ([], [None], [None] * 11, ["same"] * 1000, [""] * 3 + [None], [str(i) for i in range(3000)]):
+        enc = DeviceTable.from_arrow(pa.table({"s": pa.array(vals, pa.string())})).dictionary_encode(sorted=False).to_arrow().column("s").combine_chunks()
+        assert enc.to_pylist() == vals
+        assert enc.dictionary.to_pylist() == list(dict.fromkeys(v for v in vals if v is not None))
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.2])
+def test_comparisons_and_like_on_bytes(null_frac):
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(4)
+    n = 6000
+    a, b = random_strings(rng, n, null_frac), random_strings(rng, n, null_frac)
+    t = pa.table({"a": a, "b": b, "i": pa.array(np.arange(n, dtype=np.int64))})
+    dev = DeviceTable.from_arrow(t)
+    fns = {"=": pc.equal, "!=": pc.not_equal, "<": pc.less, "<=": pc.less_equal, ">": pc.greater, ">=": pc.greater_equal}
+    from datafusion_amd.expr import BinaryExpr
+    for op, f in fns.items():
+        for literal in ("cbcxx", "", "zzz", "naïve café", "🔥"):
+            want = t.filter(pc.fill_null(f(a, pa.scalar(literal)), False)).column("i").to_pylist()
+            assert ops.filter(dev, BinaryExpr(col("a"), op, lit(literal, pa.string())), ["i"]).to_arrow().column("i").to_pylist() == want, (op, literal)
+            wantr = t.filter(pc.fill_null(f(pa.scalar(literal), a), False)).column("i").to_pylist()
+            assert ops.filter(dev, BinaryExpr(lit(literal, pa.string()), op, col("a")), ["i"]).to_arrow().column("i").to_pylist() == wantr, (op, literal, "literal first")
+        want = t.filter(pc.fill_null(f(a, b), False)).column("i").to_pylist()
+        assert ops.filter(dev, BinaryExpr(col("a"), op, col("b")), ["i"]).to_arrow().column("i").to_pylist() == want, op
+    for pattern, ci in (("PROMO%", False), ("%requests%", False), ("%special%requests%", False), ("_b%", False), ("%", False), ("", False), ("a", False), ("%\\%%", False),
+                        ("50\\% off\\_", False), ("%CAFÉ", False), ("promo%copper", True), ("🔥%", False), ("_", False), ("%x", False), ("__", False)):
+        for negated in (False, True):
+            keep = pc.match_like(a, pattern, ignore_case=ci)
+            keep = pc.invert(keep) if negated else keep
+            want = t.filter(pc.fill_null(keep, False)).column("i").to_pylist()
+            got = ops.filter(dev, col("a").like(pattern, negated=negated, case_insensitive=ci), ["i"]).to_arrow().column("i").to_pylist()
+            assert got == want, (pattern, ci, negated)
+    # NULL literal: NULL everywhere -> no row passes
+    assert ops.filter(dev, col("a").eq(lit(None, pa.string())), ["i"]).num_rows == 0
+
+
+def test_filter_take_and_concat_move_strings():
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(5)
+    n = 20000
+    t = pa.table({"k": pa.array(rng.integers(0, 500, size=n)), "s": random_strings(rng, n, 0.1), "v": pa.array(rng.integers(0, 10**6, size=n))})
+    dev = DeviceTable.from_arrow(t)
+    got = ops.filter(dev, col("v") < lit(300000, pa.int64())).to_arrow()
+    want = t.filter(pc.less(t.column("v"), 300000))
+    assert got.column("s").to_pylist() == want.column("s").to_pylist() and got.column("v").to_pylist() == want.column("v").to_pylist()
+    # strings as join payload on both sides + sort output (take)
+    build = pa.table({"bk": pa.array(np.arange(500, dtype=np.int64)), "name": pa.array([f"Supplier#{i:09d}" if i % 7 else None for i in range(500)], pa.string())})
+    j = ops.hash_join(DeviceTable.from_arrow(build), dev, [("bk", "k")], "Inner").to_arrow()
+    names = build.column("name").to_pylist()
+    assert j.num_rows == n
+    rows = sorted(zip(j.column("v").to_pylist(), j.column("k").to_pylist(), j.column("name").to_pylist(), j.column("s").to_pylist()), key=lambda r: (r[0], r[1], str(r[3])))
+    exp = sorted(zip(t.column("v").to_pylist(), t.column("k").to_pylist(), [names[k] for k in t.column("k").to_pylist()], t.column("s").to_pylist()), key=lambda r: (r[0], r[1], str(r[3])))
+    assert rows == exp
+    srt = ops.sort(dev, [("v", False, False), ("k", False, False)]).to_arrow()
+    order = np.lexsort((t.column("k").to_numpy(), t.column("v").to_numpy()))
+    assert srt.column("s").to_pylist() == t.column("s").take(pa.array(order)).to_pylist()
+    cat = DeviceTable.concat([dev, dev.select(["k", "s", "v"]), DeviceTable.from_arrow(t.slice(0, 5))]).to_arrow()
+    assert cat.column("s").to_pylist() == t.column("s").to_pylist() * 2 + t.column("s").slice(0, 5).to_pylist()
+
+
+def test_string_keys_run_on_interned_indices():
+    """GROUP BY / join / ORDER BY on string keys: encode on the device, run on the indices; oracle over pyarrow-encoded input"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(6)
+    n = 30000
+    pool = [f"Customer#{i:09d}" for i in range(700)] + WORDS
+    t = pa.table({"name": random_strings(rng, n, 0.05, pool), "v": pa.array(rng.integers(0, 1000, size=n))})
+    dev = DeviceTable.from_arrow(t).dictionary_encode(["name"])
+    g = ops.aggregate(dev, [(col("name"), "name")], [("sum", col("v"), "s"), ("count", None, "n")], "Single").to_arrow()
+    got = {r["name"]: (r["s"], r["n"]) for r in pa.table({"name": g.column("name").cast(pa.string()), "s": g.column("s"), "n": g.column("n")}).to_pylist()}
+    want = {}
+    for name, v in zip(t.column("name").to_pylist(), t.column("v").to_pylist()):
+        s, c = want.get(name, (0, 0))
+        want[name] = (s + v, c + 1)
+    assert got == want
+    srt = ops.sort(dev, [("name", False, False), ("v", True, False)]).to_arrow()
+    keys = [(x is None, x or "", -v) for x, v in zip(srt.column("name").cast(pa.string()).to_pylist(), srt.column("v").to_pylist())]
+    assert keys == sorted(keys)
+    other = pa.table({"name2": pa.array(pool[::3] + ["not there"], pa.string()), "w": pa.array(np.arange(len(pool[::3]) + 1, dtype=np.int64))})
+    odev = DeviceTable.from_arrow(other).dictionary_encode(["name2"])                  # a different dictionary: the join unifies them
+    j = ops.hash_join(odev, dev, [("name2", "name")], "Inner").to_arrow()
+    w_of = dict(zip(other.column("name2").to_pylist(), other.column("w").to_pylist()))
+    exp = sorted((nm, w_of[nm], v) for nm, v in zip(t.column("name").to_pylist(), t.column("v").to_pylist()) if nm in w_of)
+    assert sorted(zip(j.column("name").cast(pa.string()).to_pylist(), j.column("w").to_pylist(), j.column("v").to_pylist())) == exp
+
+
+def test_utf8_key_without_encoding_is_a_clear_error():
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    dev = DeviceTable.from_arrow(pa.table({"s": pa.array(["a", "b"], pa.string()), "v": pa.array([1, 2])}))
+    with pytest.raises(_lib.DfgpuError, match="dictionary"):
+        ops.aggregate(dev, [(col("s"), "s")], [("sum", col("v"), "t")], "Single")
