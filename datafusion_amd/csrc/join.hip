@@ -1771,6 +1771,46 @@ int dfgpu_column_minmax(dfgpu_table_t table, int column, int64_t* out_min, int64
   });
 }
 
+int dfgpu_column_inlist(dfgpu_table_t th, int column, int64_t max_size, int64_t max_distinct_values, int64_t* out_values, int64_t capacity, int64_t* out_n) {
+  return guarded([&] {
+    require_init();
+    Table& t = *unwrap(th);
+    DFGPU_CHECK(out_n && column >= 0 && column < (int)t.cols.size(), "bad argument");
+    const Column& c = t.cols[(size_t)column];
+    DFGPU_CHECK(is_integer_like(c.field.type) && c.field.type != DFGPU_UINT64, "dfgpu_column_inlist: integer columns only");
+    const int w = type_width(c.field.type);
+    *out_n = -1;
+    if (t.nrows == 0) {
+      *out_n = 0;
+      return;
+    }
+    if (max_distinct_values <= 0 || t.nrows * w > max_size) return;  // PushdownStrategy::Map
+    std::vector<uint8_t> raw((size_t)t.nrows * w);
+    d2h(raw.data(), c.ptr(), raw.size());
+    std::vector<uint64_t> valid;
+    if (c.validity) {
+      valid.resize(bitmap_bytes(t.nrows) / 8);
+      d2h(valid.data(), c.validity->ptr, valid.size() * 8);
+    }
+    std::vector<int64_t> v;
+    v.reserve((size_t)t.nrows);
+    for (int64_t i = 0; i < t.nrows; i++) {
+      if (c.validity && !((valid[(size_t)(i >> 6)] >> (i & 63)) & 1)) continue;
+      switch (c.field.type) {
+        case DFGPU_INT32: case DFGPU_DATE32: v.push_back(((const int32_t*)raw.data())[i]); break;
+        case DFGPU_UINT32: v.push_back(((const uint32_t*)raw.data())[i]); break;
+        case DFGPU_UINT8: v.push_back(raw[(size_t)i]); break;
+        default: v.push_back(((const int64_t*)raw.data())[i]); break;
+      }
+    }
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    if ((int64_t)v.size() > max_distinct_values) return;
+    *out_n = (int64_t)v.size();
+    for (int64_t k = 0; k < (int64_t)v.size() && k < capacity && out_values; k++) out_values[k] = v[(size_t)k];
+  });
+}
+
 int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type, const int* build_out_cols, int n_build_out,
                      const int* probe_out_cols, int n_probe_out, dfgpu_table_t* out) {
   return guarded([&] {

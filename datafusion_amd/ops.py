@@ -297,6 +297,17 @@ def column_minmax(table: DeviceTable, column):
     return lo.value, hi.value, n.value, bool(asc.value)
 
 
+def column_inlist(table: DeviceTable, column, max_size: int = 128 * 1024, max_distinct_values: int = 150):
+    """the distinct non-NULL values (ascending) of a small integer column for the join's `IN (...)` dynamic filter, or None when the
+    build side is beyond the reference's limits (optimizer.hash_join_inlist_pushdown_max_size / _max_distinct_values): the Map
+    strategy, bounds only (dfgpu_column_inlist)"""
+    n = C.c_int64()
+    vals = (C.c_int64 * max(1, max_distinct_values))()
+    check(_lib.init().dfgpu_column_inlist(table.handle, table.index_of(column), C.c_int64(max_size), C.c_int64(max_distinct_values), vals,
+                                          C.c_int64(max_distinct_values), C.byref(n)))
+    return None if n.value < 0 else list(vals[:n.value])
+
+
 def jit_stats():
     """(distinct nodes compiled with hiprtc, total compile ms) of this process"""
     n, ms = C.c_int64(), C.c_double()

@@ -119,11 +119,14 @@ class ParquetFile:
         _lib.init()
         return self._hstack([self._decode(row_group, name) for name in (columns or self.column_names)])
 
-    def row_groups_overlapping(self, bounds: dict) -> list:
+    def row_groups_overlapping(self, bounds: dict, in_lists: dict | None = None) -> list:
         """row groups whose footer statistics admit a value inside every (column -> closed [lo, hi]) bound — the pruning the
         reference's ParquetSource does with a pushed-down predicate (row-group statistics; here the dynamic bounds a hash join
-        publishes from its build side, hash_join/shared_bounds.rs:277-284).  An empty range (lo > hi) prunes everything; a
-        chunk without min / max statistics is kept."""
+        publishes from its build side, hash_join/shared_bounds.rs:277-284) — and, for a small build side, at least one value of
+        the join's `IN (...)` list (column -> ascending values; PushdownStrategy::InList, shared_bounds.rs:275-284: a row group
+        between two build keys is skipped although it lies inside their bounds).  An empty range (lo > hi) or an empty list
+        prunes everything; a chunk without min / max statistics is kept."""
+        import bisect
         keep = []
         for g in range(self.num_row_groups):
             rg = self.meta.row_group(g)
@@ -138,6 +141,18 @@ class ParquetFile:
                 if st.max < lo or st.min > hi:
                     ok = False
                     break
+            for name, values in (in_lists or {}).items():
+                if not ok:
+                    break
+                if not values:
+                    ok = False
+                    break
+                st = rg.column(self._leaf(name)).statistics
+                if st is None or not st.has_min_max or not isinstance(st.min, int):
+                    continue
+                k = bisect.bisect_left(values, st.min)          # first list value >= the chunk's minimum
+                if k == len(values) or values[k] > st.max:
+                    ok = False
             if ok:
                 keep.append(g)
         return keep
@@ -185,12 +200,12 @@ class ParquetFile:
         return out
 
 
-def read_table(path: str, columns=None, threads: int | None = None, bounds: dict | None = None, stats: dict | None = None) -> DeviceTable:
-    """the row groups of `path` that can hold rows inside `bounds` (all of them without bounds), the given columns, as one
-    device table; `stats` receives row_groups_total / row_groups_read"""
+def read_table(path: str, columns=None, threads: int | None = None, bounds: dict | None = None, stats: dict | None = None, in_lists: dict | None = None) -> DeviceTable:
+    """the row groups of `path` that can hold rows inside `bounds` and one of `in_lists`' values (all of them without either), the
+    given columns, as one device table; `stats` receives row_groups_total / row_groups_read"""
     f = ParquetFile(path)
     try:
-        groups = None if not bounds else f.row_groups_overlapping(bounds)
+        groups = None if not (bounds or in_lists) else f.row_groups_overlapping(bounds or {}, in_lists)
         if stats is not None:
             stats.update(row_groups_total=f.num_row_groups, row_groups_read=f.num_row_groups if groups is None else len(groups))
         return f.read(columns, threads, groups)

@@ -123,6 +123,7 @@ class ParquetExec(ExecutionPlan):
     def __init__(self, path: str, projection=None, name: str = ""):
         self.path, self.projection, self.label = path, projection, name
         self.dynamic_bounds = {}   # column -> (lo, hi): published by a HashJoinExec above once its build side is known
+        self.dynamic_in_lists = {} # column -> ascending distinct build keys of a small build side (PushdownStrategy::InList)
         self.metrics = {}          # row_groups_total / row_groups_read of the last execute
 
     def project(self, columns) -> "ParquetExec":
@@ -133,7 +134,7 @@ class ParquetExec(ExecutionPlan):
 
     def execute(self, partition=0):
         from .parquet import read_table
-        return read_table(self.path, self.projection, bounds=self.dynamic_bounds or None, stats=self.metrics)
+        return read_table(self.path, self.projection, bounds=self.dynamic_bounds or None, stats=self.metrics, in_lists=self.dynamic_in_lists or None)
 
     def detail(self):
         return f"{self.label or self.path}" + (f", projection={self.projection}" if self.projection else "")
@@ -323,6 +324,12 @@ class HashJoinExec(ExecutionPlan):
             if n:
                 lo, hi = min(a for a, _ in seen), max(b for _, b in seen)
         node.dynamic_bounds[probe_key] = (lo, hi) if n else (1, 0)     # an empty build side prunes the whole scan
+        if _world() == 1:
+            # the membership half (PushdownStrategy::InList for small build sides, else Map = bounds only); with several ranks the
+            # lists of all partitions would have to be merged like the bounds — they stay on bounds
+            values = ops.column_inlist(build_table, build_key)
+            if values is not None:
+                node.dynamic_in_lists[probe_key] = values
 
     def _probe(self, ht, probe_table, predicate=None):
         bc, pc = self.projection if self.projection else (None, None)

@@ -404,6 +404,14 @@ int dfgpu_join_probe_with_filter(dfgpu_join_t ht, dfgpu_table_t probe, const int
  * exchange prunes the build-side broadcast with — hash_join/shared_bounds.rs:277-284 turned around).  One pass, one
  * device-to-host copy.  *out_valid == 0: no non-null value, min / max are INT64_MAX / INT64_MIN. */
 int dfgpu_column_minmax(dfgpu_table_t table, int column, int64_t* out_min, int64_t* out_max, int64_t* out_valid, int* out_ascending);
+/* The membership half of the join's dynamic filter (PushdownStrategy, hash_join/shared_bounds.rs:275-284, chosen in
+ * collect_left_input, hash_join/exec.rs:2727-2751): a build-side key column that is small — at most `max_size` bytes
+ * (optimizer.hash_join_inlist_pushdown_max_size, default 128 KiB) and at most `max_distinct_values` distinct values
+ * (hash_join_inlist_pushdown_max_distinct_values, default 150; 0 = never) — is pushed to the probe-side scan as
+ * `key IN (v1, v2, ...)`: *out_n = the number of distinct non-NULL values, written ascending to out_values (up to `capacity`).
+ * Larger build sides use the Map strategy (the hash table itself is the membership test — here: the probe kernel), and only
+ * their bounds are pushed: *out_n = -1.  An empty column gives *out_n = 0 (PushdownStrategy::Empty: nothing can match). */
+int dfgpu_column_inlist(dfgpu_table_t table, int column, int64_t max_size, int64_t max_distinct_values, int64_t* out_values, int64_t capacity, int64_t* out_n);
 /* The same with a FilterExec fused below the probe side (filter.rs:1396-1419 -> hash_join/stream.rs:687-1000):
  * probe rows whose predicate is false or NULL do not exist for the join.  With the single-pass probe the predicate's
  * row mask is applied inside the probe kernel and the filtered probe table is never materialised; every other

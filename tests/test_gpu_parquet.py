@@ -119,6 +119,34 @@ def test_join_bounds_prune_the_probe_side_scan(tmp_path, join_type):
         assert out3.num_rows == 0 and scan3.metrics["row_groups_read"] == 0
 
 
+def test_small_build_side_pushes_an_in_list_that_prunes_between_the_bounds(tmp_path):
+    """PushdownStrategy::InList (hash_join/shared_bounds.rs:275-284; limits of exec.rs:2727-2751: 128 KiB and 150 distinct keys):
+    three far-apart build keys have bounds that cover every row group, the IN list keeps only the groups that hold one of them;
+    a build side beyond the limits pushes bounds only (Map strategy)"""
+    from datafusion_amd import ops, physical_plan as P
+    from datafusion_amd.table import DeviceTable
+    from tests import plan_oracle
+    n = 60_000
+    probe = pa.table({"l_orderkey": pa.array(np.arange(n, dtype=np.int64) // 3), "l_qty": pa.array((np.arange(n) % 50).astype(np.int32))})
+    path = str(tmp_path / "probe.parquet")
+    pq.write_table(probe, path, row_group_size=5_000, compression="snappy")
+    for keys, want_list, groups in (([10, 9_999, 19_990, 10, None], [10, 9_999, 19_990], 3), (list(range(0, 20_000, 100)), None, 12), ([], [], 0)):
+        build = pa.table({"o_orderkey": pa.array(keys, pa.int64()), "o_flag": pa.array(np.arange(len(keys), dtype=np.int32))})
+        dev_build = DeviceTable.from_arrow(build)
+        assert ops.column_inlist(dev_build, "o_orderkey") == want_list
+        scan = P.ParquetExec(path, ["l_orderkey", "l_qty"], "lineitem")
+        j = P.HashJoinExec(P.MemoryExec(dev_build, "orders"), scan, [("o_orderkey", "l_orderkey")], "Inner")
+        got = P.collect(j).to_arrow()
+        exp = plan_oracle.collect(P.HashJoinExec(P.MemoryExec(build, "orders"), P.MemoryExec(probe, "lineitem"), [("o_orderkey", "l_orderkey")], "Inner"))
+        assert_tables_equal(got, exp, ordered=False)
+        assert scan.metrics["row_groups_total"] == 12 and scan.metrics["row_groups_read"] == groups, (keys[:3], scan.metrics)
+        assert scan.dynamic_in_lists == ({} if want_list is None else {"l_orderkey": want_list})
+    # the reference's knobs
+    small = DeviceTable.from_arrow(pa.table({"k": pa.array(np.arange(200, dtype=np.int64))}))
+    assert ops.column_inlist(small, "k") is None and ops.column_inlist(small, "k", max_distinct_values=200) == list(range(200))
+    assert ops.column_inlist(small, "k", max_size=1000, max_distinct_values=1000) is None and ops.column_inlist(small, "k", max_distinct_values=0) is None
+
+
 def test_parquet_chunk_with_dictionary_fallback_pages(tmp_path):
     """one column chunk holding dictionary-encoded pages followed by PLAIN pages (the writer's dictionary limit was reached)"""
     from datafusion_amd.parquet import ParquetFile, read_table
