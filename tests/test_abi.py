@@ -203,3 +203,11 @@ def test_join_filter_string_literals_bind_through_the_source_columns():
     assert b.left.right.op == "or" and b.left.right.left.right.value == 2 and b.left.right.right.right.value == 1 and b.left.right.left.left.index == 3
     lowered = lower(e, view.names, view)                                                   # lowers without a string node left
     assert all(lowered.nodes[i].op != 2 or lowered.nodes[i].field.type != 0 for i in range(lowered.c.n_nodes))
+
+
+def test_rust_shim_sys_rs_matches_the_header():
+    """shim/src/sys.rs (the Rust `extern "C"` block) is generated from include/dfgpu.h: a change of the C ABI that is not carried over fails here"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_shim_sys.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
