@@ -147,6 +147,42 @@ def test_small_build_side_pushes_an_in_list_that_prunes_between_the_bounds(tmp_p
     assert ops.column_inlist(small, "k", max_size=1000, max_distinct_values=1000) is None and ops.column_inlist(small, "k", max_distinct_values=0) is None
 
 
+def test_device_chunk_cache_serves_repeated_scans(tmp_path):
+    """a second scan of the same file takes its column chunks from HBM (no decode); a rewritten file is a new identity; the
+    byte budget evicts least recently used chunks"""
+    from datafusion_amd import parquet as P
+    from datafusion_amd.parquet import ChunkCache, read_table
+    n = 40_000
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64)), "v": pa.array((np.arange(n) % 97).astype(np.int32)),
+                  "s": pa.array([["x", "yy", "zzz"][i % 3] for i in range(n)], pa.string())})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, row_group_size=10_000, compression="snappy")
+    saved = P.CACHE
+    try:
+        P.CACHE = ChunkCache(budget=1 << 30)
+        a = read_table(path).to_arrow()
+        assert P.CACHE.stats()["misses"] == 12 and P.CACHE.stats()["hits"] == 0 and P.CACHE.stats()["chunks"] == 12
+        b = read_table(path, ["v", "k"]).to_arrow()
+        assert P.CACHE.stats()["hits"] == 8 and P.CACHE.stats()["misses"] == 12
+        assert_tables_equal(a, pa.table({"k": t.column("k"), "v": t.column("v"), "s": t.column("s").dictionary_encode().cast(pa.dictionary(pa.int32(), pa.string()))}), ordered=True)
+        assert b.column("v").to_pylist() == t.column("v").to_pylist() and b.column("k").to_pylist() == t.column("k").to_pylist()
+        t2 = t.set_column(1, "v", pa.array(np.zeros(n, dtype=np.int32)))
+        import time
+        time.sleep(0.01)
+        pq.write_table(t2, path, row_group_size=10_000, compression="snappy")
+        assert read_table(path, ["v"]).to_arrow().column("v").to_pylist() == [0] * n          # not the stale chunks
+        P.CACHE = ChunkCache(budget=200_000)                                                     # ~ two 80 KB chunks of `k`
+        read_table(path, ["k"])
+        st = P.CACHE.stats()
+        assert 1 <= st["chunks"] < 4 and st["bytes"] <= 200_000
+        P.CACHE = ChunkCache(budget=0)
+        read_table(path, ["k"])
+        assert P.CACHE.stats()["chunks"] == 0
+    finally:
+        P.CACHE.clear()
+        P.CACHE = saved
+
+
 def test_parquet_chunk_with_dictionary_fallback_pages(tmp_path):
     """one column chunk holding dictionary-encoded pages followed by PLAIN pages (the writer's dictionary limit was reached)"""
     from datafusion_amd.parquet import ParquetFile, read_table
