@@ -76,7 +76,8 @@ def main():
     for r in rows:
         if not r["kernel"].startswith("k_join_probe_fused") or not r["traffic_bytes"] or not bench:
             continue
-        mode = r["kernel"].rstrip(">").split(",")[-1].strip()
+        targs = [a.strip() for a in r["kernel"][r["kernel"].index("<") + 1:].rstrip(">").split(",")]   # <KIND, KT, W, MODE, KEYREG>
+        mode = targs[3] if len(targs) >= 4 else ""
         name = {"0": "join_probe_fused", "2": "join_probe_placed"}.get(mode.replace("(dfgpu::FusedMode)", ""))
         if name is None:
             continue
