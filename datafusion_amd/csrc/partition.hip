@@ -49,8 +49,9 @@ void hash_columns(const std::vector<const Column*>& keys, int64_t n, uint64_t se
 }
 
 constexpr int MAX_PARTS = 64;
-constexpr int PT_ITEMS = 8;                 // rows per thread
-constexpr int PT_TILE = BLOCK * PT_ITEMS;   // 2048 rows per workgroup tile
+constexpr int PT_ITEMS = 4;                 // rows per thread (a multiple of 4).  Measured in one run, 600 M rows into 8 partitions: 4 -> 11.0 ms,
+                                            // 8 -> 12.0 ms, 16 -> 17.5 ms: the 16 KB of LDS a 1024-row tile stages leave room for 8 workgroups per CU
+constexpr int PT_TILE = BLOCK * PT_ITEMS;   // 1024 rows per workgroup tile
 
 // pass 1: part[i] = partition of row i; counts[p * n_tiles + t] = rows of tile t routed to partition p.
 // Per 64 rows the membership of a partition is one ballot; lane q keeps partition q's running count.
@@ -207,7 +208,10 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter(PartCols cols, const uin
 // remainder h % nparts is Lemire's fastmod (device.hpp; the compiler's 64-bit remainder by a runtime value is a ~150-instruction
 // loop): 2.47 -> 1.25 ms for 600 M rows.  (A second-generation scatter with wave-private ranking that recomputes the partition
 // from the key instead of reading `part` was measured too: 10.6 ms against 10.2 ms — the scatter sits at 84 % of the copy
-// ceiling and is not bound by its barriers; with its 8 loads per thread batched it dropped to 15.3 ms.)
+// ceiling and is not bound by its barriers; with its 8 loads per thread batched it dropped to 15.3 ms.  A SINGLE-PASS placement
+// — no count pass, the tile hashes its keys and claims its range in every partition's slack-sized region with one atomic — was
+// measured as well: 11.4-12.0 ms against 11.9-13.0 ms for the two passes in the same runs: the scatter with the hash folded in
+// costs what both passes cost, so the deterministic two-pass placement stays.)
 template <int NPK>  // nparts <= 4 * NPK
 __global__ __launch_bounds__(BLOCK) void k_part_count2(KeySet ks, int64_t n, int nparts, FastMod fm, int64_t n_tiles, uint8_t* __restrict__ part,
                                                        uint32_t* __restrict__ counts) {
