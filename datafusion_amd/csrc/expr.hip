@@ -191,6 +191,10 @@ __global__ __launch_bounds__(BLOCK) void k_cast(const S* __restrict__ in, int64_
 }
 
 // word-wise bitmap kernels. mode: 0 and, 1 or, 2 not(a), 3 copy-not-valid (is_null), 4 fill(v)
+// arrow-cast cast_floating_point_to_decimal128: (v * 10^scale).round() as i128 (f64::round: half away from zero)
+__global__ __launch_bounds__(BLOCK) void k_cast_f64_dec(const double* __restrict__ in, int64_t n, double mul, i128* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (i128)round(in[i] * mul);
+}
 __global__ __launch_bounds__(BLOCK) void k_cast_div(const i128* __restrict__ in, int64_t n, double div, double* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (double)in[i] / div;
 }
@@ -300,8 +304,12 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
   if (src.scalar) {
     // constant folding on the host
     if (src.scalar_null) return make_scalar(to, 0, true);
+    if (to.type == DFGPU_DECIMAL128 && from.type == DFGPU_FLOAT64) {
+      double v;
+      std::memcpy(&v, &src.lit_lo, 8);
+      return make_scalar(to, (i128)std::round(v * std::pow(10.0, to.scale)), false);
+    }
     if (to.type == DFGPU_DECIMAL128) {
-      DFGPU_CHECK(from.type != DFGPU_FLOAT64, "cast Float64 -> Decimal128 literal not supported");
       int fs = from.type == DFGPU_DECIMAL128 ? from.scale : 0;
       DFGPU_CHECK(to.scale >= fs, "decimal scale-down cast not supported");
       return make_scalar(to, (i128)((u128)scalar_i128(src) * (u128)pow10_i128(to.scale - fs)), false);
@@ -329,7 +337,9 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
   int ft = from.type == DFGPU_DATE32 ? DFGPU_INT32 : from.type;
   if (same_field_type(from, to)) return src;
   ProfileScope ps("cast", len * (type_width(from.type) + type_width(to.type)));
-  if (to.type == DFGPU_DECIMAL128) {
+  if (to.type == DFGPU_DECIMAL128 && ft == DFGPU_FLOAT64) {
+    k_cast_f64_dec<<<g, BLOCK, 0, st>>>((const double*)src.col.ptr(), len, std::pow(10.0, to.scale), out.col.data->as<i128>());
+  } else if (to.type == DFGPU_DECIMAL128) {
     int fs = from.type == DFGPU_DECIMAL128 ? from.scale : 0;
     DFGPU_CHECK(to.scale >= fs, "decimal scale-down cast not supported on the GPU path");
     i128 mul = pow10_i128(to.scale - fs);

@@ -197,6 +197,30 @@ def q14_plan(lineitem, part):
     return P.ProjectionExec([(lit(100.0, f64) * col(a_name).cast(f64) / col(b_name).cast(f64), "promo_revenue")], final)
 
 
+# ----------------------------------------------------------------------------------------- Q17
+def q17_plan(lineitem, part):
+    """q17.slt.part:54-69: the correlated scalar subquery decorrelated to a LeftSemi join whose JoinFilter compares
+    CAST(l_quantity AS Decimal128(30, 15)) with CAST(0.2 * CAST(avg(l_quantity) AS Float64) AS Decimal128(30, 15)) per part.
+    (The subquery's key column is aliased l_partkey2: this mirror addresses columns by name, the reference's plan by index.)"""
+    f64, d30 = pa.float64(), pa.decimal128(30, 15)
+    li = _hash(_scan(lineitem, "lineitem").project(["l_partkey", "l_quantity", "l_extendedprice"]), ["l_partkey"])
+    p = _hash(_cb(P.FilterExec(col("p_brand").eq(lit("Brand#23", pa.string())).and_(col("p_container").eq(lit("MED BOX", pa.string()))),
+                               _scan(part, "part").project(["p_partkey", "p_brand", "p_container"]), projection=["p_partkey"])), ["p_partkey"])
+    j1 = P.HashJoinExec(_cb(li), _cb(p), [("l_partkey", "p_partkey")], "Inner", projection=(["l_quantity", "l_extendedprice"], ["p_partkey"]))
+    gb = [(col("l_partkey"), "l_partkey")]
+    aggs = [("avg", col("l_quantity"), "avg(lineitem.l_quantity)")]
+    partial = P.AggregateExec("Partial", gb, aggs, _scan(lineitem, "lineitem").project(["l_partkey", "l_quantity"]))
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["l_partkey"])))
+    name = "Float64(0.2) * avg(lineitem.l_quantity)"
+    thr = P.ProjectionExec([((lit(0.2, f64) * col("avg(lineitem.l_quantity)").cast(f64)).cast(d30), name), (col("l_partkey"), "l_partkey2")], final)
+    # JoinFilter over the intermediate columns f0 = l_quantity (Left 0), f1 = the threshold (Right 0)
+    jf = (col("f0").cast(d30) < col("f1"), [(0, "Left"), (0, "Right")])
+    semi = P.HashJoinExec(_cb(j1), _cb(thr), [("p_partkey", "l_partkey2")], "LeftSemi", projection=(["l_extendedprice"], None), filter=jf)
+    a = [("sum", col("l_extendedprice"), "sum(lineitem.l_extendedprice)")]
+    fin = P.AggregateExec("Final", [], a, P.CoalescePartitionsExec(P.AggregateExec("Partial", [], a, _cb(semi))))
+    return P.ProjectionExec([(col("sum(lineitem.l_extendedprice)").cast(f64) / lit(7.0, f64), "avg_yearly")], fin)
+
+
 # ------------------------------------------------------------------------------------------ Q6
 def q6_plan(lineitem):
     """q6.slt.part:38-43: one filter, one ungrouped SUM"""

@@ -386,6 +386,10 @@ def evaluate(expr, table: pa.Table) -> Datum:
         to = expr[2]
         src, dst = orc_type(d.typ), orc_type(to)
         m = d.values.shape[0]
+        if dst == ORC_I128 and src == ORC_F64:   # arrow-cast cast_floating_point_to_decimal128: (v * 10^scale).round() as i128
+            mv = d.values.astype(np.float64) * float(10 ** to.scale)
+            r = np.where(np.abs(mv) < 2.0 ** 52, np.copysign(np.floor(np.abs(mv) + 0.5), mv), mv)
+            return Datum(_i128_np([int(x) for x in r.tolist()]), to, d.valid, d.scalar)
         if dst == ORC_I128:
             out = np.zeros((m, 2), np.uint64)
             L.orc_cast_to_i128(src, C.c_void_p(np.ascontiguousarray(d.values).ctypes.data), C.c_int64(m), C.c_void_p(out.ctypes.data))
