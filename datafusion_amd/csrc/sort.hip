@@ -41,6 +41,10 @@ struct PackCol {
   uint64_t base_lo, base_hi;  // min (ASC) or max (DESC) of the transformed value
   int bits;                   // value field width
   int shift;                  // bit offset of the value field in the packed key; the null bit sits at shift + bits
+  // one-word keys are packed in MIXED RADIX instead (k_pack_keys64): key = sum(digit_k * mult_k), digit_k = value - base (or
+  // base - value) [+ range_k when the NULL flag is set], mult_k = product of the later columns' digit ranges.  No holes: a
+  // date column spanning 2406 days costs log2(2406) bits, not 12, and keys spread evenly over [0, P) when the columns do.
+  uint64_t mult, range;
 };
 struct PackCols {
   PackCol c[MAX_SORT_KEYS];
@@ -164,16 +168,35 @@ __global__ __launch_bounds__(BLOCK) void k_pack_keys64(PackCols pc, int64_t n, u
       for (int c = 0; c < pc.n; c++) {
         const PackCol& k = pc.c[c];
         const bool ok = !k.valid || bit_at(k.valid, i);
-        if (ok && k.bits > 0) {
+        uint64_t digit = 0;
+        if (ok && k.range > 1) {
           const uint64_t t = key_transform64(k.type, k.data, i);
-          w[u] |= (k.desc ? k.base_lo - t : t - k.base_lo) << k.shift;
+          digit = k.desc ? k.base_lo - t : t - k.base_lo;
         }
-        if (k.has_null_bit && (ok == (k.nulls_first != 0))) w[u] |= 1ull << (k.shift + k.bits);
+        // NULL flag as the column's top digit: NULLS FIRST => nulls 0 / values 1; NULLS LAST => values 0 / nulls 1
+        if (k.has_null_bit && (ok == (k.nulls_first != 0))) digit += k.range;
+        w[u] += digit * k.mult;
       }
     }
     o0[i0] = w[0];
     if (i0 + stride < n) o0[i0 + stride] = w[1];
   }
+}
+
+// floor(x / div) for a divisor fixed per sort: magic = floor(2^64 / div) underestimates the quotient by at most 2
+struct DivBy {
+  uint64_t div, magic;  // div == 0: no division (x itself)
+};
+static DivBy div_by(uint64_t d) { return DivBy{d, d > 1 ? (uint64_t)(((u128)1 << 64) / d) : 0ull}; }
+__device__ __forceinline__ uint64_t div_apply(uint64_t x, const DivBy& d) {
+  if (d.div <= 1) return x;
+  uint64_t q = __umul64hi(x, d.magic);
+  uint64_t r = x - q * d.div;
+  while (r >= d.div) {
+    q++;
+    r -= d.div;
+  }
+  return q;
 }
 
 // ------------------------------------------------------------------------------ LSD radix pass
@@ -189,7 +212,7 @@ struct SortBufs {
 };
 
 // per-tile digit histogram: counts[digit * n_tiles + tile]
-__global__ __launch_bounds__(BLOCK) void k_rs_hist(const uint64_t* __restrict__ word, int64_t n, int shift, int bits, int items, int64_t n_tiles,
+__global__ __launch_bounds__(BLOCK) void k_rs_hist(const uint64_t* __restrict__ word, int64_t n, DivBy dv, int shift, int bits, int items, int64_t n_tiles,
                                                    uint32_t* __restrict__ counts) {
   __shared__ unsigned int sh[256];
   const unsigned mask = (1u << bits) - 1u;
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_hist(const uint64_t* __restrict__ 
     const int64_t lo = t * (int64_t)(BLOCK * items);
     for (int c = 0; c < items; c++) {
       const int64_t i = lo + c * BLOCK + threadIdx.x;
-      if (i < n) atomicAdd(&sh[(unsigned)(word[i] >> shift) & mask], 1u);
+      if (i < n) atomicAdd(&sh[(unsigned)(div_apply(word[i], dv) >> shift) & mask], 1u);
     }
     __syncthreads();
     if ((int)threadIdx.x <= (int)mask) counts[(int64_t)threadIdx.x * n_tiles + t] = sh[threadIdx.x];
@@ -209,7 +232,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_hist(const uint64_t* __restrict__ 
 
 // stable scatter of one tile by one digit, staged through LDS so that every digit's run is written contiguously
 template <int NW>
-__global__ __launch_bounds__(BLOCK) void k_rs_scatter(KeyWords k, const uint32_t* __restrict__ idx_in, int64_t n, int dword, int shift, int bits, int64_t n_tiles,
+__global__ __launch_bounds__(BLOCK) void k_rs_scatter(KeyWords k, const uint32_t* __restrict__ idx_in, int64_t n, DivBy dv, int dword, int shift, int bits, int64_t n_tiles,
                                                      const uint64_t* __restrict__ offsets, SortBufs out) {
   constexpr int RS_ITEMS = rs_items(NW);
   constexpr int RS_TILE = BLOCK * RS_ITEMS;
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter(KeyWords k, const uint32_t
 #pragma unroll
       for (int w = 0; w < NW; w++)
         if (w == dword) kw = key[w][c];
-      dig[c] = in ? ((unsigned)(kw >> shift) & mask) : 0u;
+      dig[c] = in ? ((unsigned)(div_apply(kw, dv) >> shift) & mask) : 0u;
       uint64_t peers = ballot64(in);
       for (int b = 0; b < bits; b++) {
         const uint64_t bal = ballot64((dig[c] >> b) & 1u);
@@ -322,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter(KeyWords k, const uint32_t
 // no block barrier is needed between items) — 4 block barriers per tile instead of 3 per item.  The tile is then staged in LDS
 // sorted by digit and every digit's run is written contiguously.
 template <int NW, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_t* __restrict__ idx_in, int64_t n, int dword, int shift, int bits, int64_t n_tiles,
+__global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_t* __restrict__ idx_in, int64_t n, DivBy dv, int dword, int shift, int bits, int64_t n_tiles,
                                                       const uint64_t* __restrict__ offsets, SortBufs out) {
   constexpr int TILE = BLOCK * ITEMS;
   constexpr int NWAVE = BLOCK / WAVE;
@@ -362,7 +385,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_
 #pragma unroll
       for (int w = 0; w < NW; w++)
         if (w == dword) kw = key[w][c];
-      dig[c] = in ? ((unsigned)(kw >> shift) & mask) : 0u;
+      dig[c] = in ? ((unsigned)(div_apply(kw, dv) >> shift) & mask) : 0u;
       uint64_t peers = ballot64(in);
       for (int b = 0; b < bits; b++) {
         const uint64_t bal = ballot64((dig[c] >> b) & 1u);
@@ -475,6 +498,7 @@ __global__ void k_iota_u32(int64_t n, uint32_t* out) {
 // ------------------------------------------------------------------------------- host
 struct Digit {
   int word, shift, bits;
+  uint64_t div = 0;  // the digit is taken from key / div instead of the key (one-word keys; the top digits of the two-level sort)
 };
 struct SortedKeys {
   BufPtr w[MAX_KEY_WORDS];
@@ -530,30 +554,210 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
     ob.idx = alt.idx->as<uint32_t>();
     const int nb = 1 << d.bits;
     ProfileScope ps("radix_sort_pass", n * 8 + n * (nwords * 8 + 4) * 2);
-    k_rs_hist<<<grid, BLOCK, 0, r.stream>>>(ck.w[d.word], n, d.shift, d.bits, items, n_tiles, counts->as<uint32_t>());
+    const DivBy dv = div_by(d.div);
+    k_rs_hist<<<grid, BLOCK, 0, r.stream>>>(ck.w[d.word], n, dv, d.shift, d.bits, items, n_tiles, counts->as<uint32_t>());
     scan_u32(counts->as<uint32_t>(), (int64_t)nb * n_tiles, offsets->as<uint64_t>());
     static const bool gen1 = std::getenv("DFGPU_SORT_GEN1") != nullptr;  // A/B knob: the first-generation scatter
     const uint32_t* idx_in = cur.idx ? cur.idx->as<uint32_t>() : nullptr;
     if (gen1) {
       switch (nwords) {
-        case 1: k_rs_scatter<1><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-        case 2: k_rs_scatter<2><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-        default: k_rs_scatter<3><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        case 1: k_rs_scatter<1><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        case 2: k_rs_scatter<2><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        default: k_rs_scatter<3><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
       }
     } else {
       switch (nwords) {
         case 1:
-          if (items == 16) k_rs_scatter2<1, 16><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob);
-          else k_rs_scatter2<1, rs_items(1)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob);
+          if (items == 16) k_rs_scatter2<1, 16><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob);
+          else k_rs_scatter2<1, rs_items(1)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob);
           break;
-        case 2: k_rs_scatter2<2, rs_items(2)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-        default: k_rs_scatter2<3, rs_items(3)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        case 2: k_rs_scatter2<2, rs_items(2)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+        default: k_rs_scatter2<3, rs_items(3)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
       }
     }
     DFGPU_HIP(hipGetLastError());
     std::swap(cur, alt);
   }
   return cur;
+}
+
+// ------------------------------------------------------------------------------ top digits in HBM, the rest in LDS
+// A one-word key of T bits over n rows: the stable passes above run over the TOP bits only — as many 8-bit digits as it takes
+// for a bucket (= rows sharing those bits) to hold ~2300 rows on average: 2 passes for 150 M rows instead of 6 — and every
+// bucket, now contiguous and in stable order, is finished by ONE workgroup inside LDS (stable LSD passes over the remaining
+// low bits with the same wave-private ranking; elements live in registers between passes, LDS holds one copy).  Whether every
+// bucket fits is known exactly before the buckets are sorted (bucket bounds are read off the top-sorted keys); keys whose top
+// bits are skewed beyond that take the all-HBM passes instead.
+constexpr int LS_ITEMS = 16;
+constexpr int LS_CAP = BLOCK * LS_ITEMS;  // 4096 elements per bucket in LDS
+
+// bounds of the buckets of keys sorted by (key >> shift): starts / ends (both zero for an empty bucket) and the largest size
+__global__ __launch_bounds__(BLOCK) void k_bucket_bounds(const uint64_t* __restrict__ key, int64_t n, DivBy width, uint32_t* __restrict__ starts,
+                                                         uint32_t* __restrict__ ends) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const uint64_t b = div_apply(key[i], width);
+    if (i == 0 || div_apply(key[i - 1], width) != b) starts[b] = (uint32_t)i;
+    if (i == n - 1 || div_apply(key[i + 1], width) != b) ends[b] = (uint32_t)(i + 1);
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_bucket_max(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends, int64_t n_buckets, unsigned* __restrict__ max_size) {
+  unsigned mx = 0;
+  for (int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x; b < n_buckets; b += (int64_t)gridDim.x * BLOCK) {
+    const unsigned sz = ends[b] - starts[b];
+    mx = sz > mx ? sz : mx;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned o = __shfl_xor(mx, d, 64);
+    mx = o > mx ? o : mx;
+  }
+  if (lane_id() == 0 && mx) atomicMax(max_size, mx);
+}
+
+// one workgroup per bucket: stable LSD sort of the bucket's (key, id) elements by the key's low `low_bits` bits, in LDS
+__global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ starts,
+                                                      const uint32_t* __restrict__ ends, int64_t n_buckets, uint64_t width, int low_bits, uint32_t* __restrict__ idx_out) {
+  constexpr int NWAVE = BLOCK / WAVE;
+  __shared__ uint64_t s_key[LS_CAP];
+  __shared__ uint32_t s_idx[LS_CAP];
+  __shared__ unsigned int s_cnt[NWAVE][256];
+  __shared__ unsigned int s_start[256];
+  __shared__ unsigned int s_wtot[NWAVE];
+  const int wave = threadIdx.x >> 6;
+  const unsigned lane = lane_id();
+  const int n_pass = (low_bits + 7) / 8;
+  for (int64_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+    const uint32_t lo = starts[b];
+    const int m = (int)(ends[b] - lo);
+    if (m == 0) continue;
+    uint64_t k[LS_ITEMS];
+    uint32_t id[LS_ITEMS];
+    // position of item c of this lane: a wave owns a contiguous segment, so position order = (wave, item, lane) order; the
+    // segments are sized for THIS bucket (items = ceil(m / 256) rows per thread), so the four waves share its rows evenly
+    const int items = (m + BLOCK - 1) / BLOCK;
+#pragma unroll
+    for (int c = 0; c < LS_ITEMS; c++) {
+      if (c >= items) continue;
+      const int j = (wave * items + c) * WAVE + (int)lane;
+      const int64_t src = (int64_t)lo + (j < m ? j : 0);
+      k[c] = key[src] - (uint64_t)b * width;  // the key inside its bucket: < width <= 2^low_bits
+      id[c] = idx_in ? idx_in[src] : (uint32_t)src;
+    }
+    if (m > 1) {
+      int pos = 0;
+      for (int p = 0; p < n_pass; p++) {
+        const int bits = (low_bits - pos + (n_pass - p) - 1) / (n_pass - p);  // spread the bits evenly over the passes
+        const unsigned dmask = (1u << bits) - 1u;
+#pragma unroll
+        for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+        __syncthreads();
+        unsigned dig[LS_ITEMS], rank[LS_ITEMS];
+#pragma unroll
+        for (int c = 0; c < LS_ITEMS; c++) {
+          if (c >= items) continue;
+          const int j = (wave * items + c) * WAVE + (int)lane;
+          const bool in = j < m;
+          dig[c] = in ? ((unsigned)(k[c] >> pos) & dmask) : 0u;
+          uint64_t peers = ballot64(in);
+          for (int q = 0; q < bits; q++) {
+            const uint64_t bal = ballot64((dig[c] >> q) & 1u);
+            peers &= ((dig[c] >> q) & 1u) ? bal : ~bal;
+          }
+          const unsigned r_in_wave = mbcnt(peers);
+          const unsigned base = s_cnt[wave][dig[c]];
+          if (in && r_in_wave == 0) s_cnt[wave][dig[c]] = base + (unsigned)__popcll(peers);
+          rank[c] = base + r_in_wave;
+        }
+        __syncthreads();
+        {  // thread d: digit d's total, the waves' exclusive prefixes, and the exclusive scan over digits
+          unsigned run = 0;
+#pragma unroll
+          for (int w = 0; w < NWAVE; w++) {
+            const unsigned v = s_cnt[w][threadIdx.x];
+            s_cnt[w][threadIdx.x] = run;
+            run += v;
+          }
+          const unsigned inc = wave_inclusive_sum<unsigned>(run);
+          if (lane == 63) s_wtot[wave] = inc;
+          __syncthreads();
+          unsigned base = 0;
+          for (int w = 0; w < wave; w++) base += s_wtot[w];
+          s_start[threadIdx.x] = base + inc - run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < LS_ITEMS; c++) {
+          if (c >= items) continue;
+          const int j = (wave * items + c) * WAVE + (int)lane;
+          if (j < m) {
+            const unsigned q = s_start[dig[c]] + s_cnt[wave][dig[c]] + rank[c];
+            s_key[q] = k[c];
+            s_idx[q] = id[c];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < LS_ITEMS; c++) {  // back into registers in position order
+          if (c >= items) continue;
+          const int j = (wave * items + c) * WAVE + (int)lane;
+          if (j < m) {
+            k[c] = s_key[j];
+            id[c] = s_idx[j];
+          }
+        }
+        __syncthreads();
+        pos += bits;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < LS_ITEMS; c++) {
+      if (c >= items) continue;
+      const int j = (wave * items + c) * WAVE + (int)lane;
+      if (j < m) idx_out[(int64_t)lo + j] = id[c];
+    }
+  }
+}
+
+static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>& digits);
+
+// row ids of a one-word key in sorted order by "top digits in HBM + buckets in LDS"; null when that does not apply (then
+// `clobbered` tells whether the key buffer was used as scratch by the top passes and has to be packed again)
+static BufPtr sorted_ids_local(const SortedKeys& sk, int64_t n, uint64_t key_space, bool& clobbered) {
+  Runtime& r = rt();
+  clobbered = false;
+  static const bool enabled = !(std::getenv("DFGPU_SORT_LOCAL") && std::getenv("DFGPU_SORT_LOCAL")[0] == '0');  // A/B knob
+  // key_space = number of values the mixed-radix key can take (0: the key is not of that kind).  Buckets are key / width with
+  // width = ceil(key_space / 2^top_bits): equal slices of the key space whatever its size, ~2300 rows each when keys spread evenly
+  int top_bits = 0;
+  while (top_bits < 32 && (n >> top_bits) > 2304) top_bits += 8;
+  if (!enabled || sk.nwords != 1 || n < 2 || n >= 0xFFFFFFFFll || key_space < 2 || (key_space >> top_bits) < 2) return nullptr;
+  const int64_t n_buckets = (int64_t)1 << top_bits;
+  const uint64_t width = (key_space + (uint64_t)n_buckets - 1) / (uint64_t)n_buckets;
+  int low_bits = 0;
+  while (low_bits < 64 && ((width - 1) >> low_bits)) low_bits++;
+  if (low_bits == 0) return nullptr;
+  SortedKeys cur = sk;
+  if (top_bits) {
+    std::vector<Digit> top;
+    for (int pos = 0; pos < top_bits; pos += 8) top.push_back({0, pos, std::min(8, top_bits - pos), width});
+    cur = radix_sort(sk, n, top);
+    clobbered = true;
+  }
+  BufPtr starts = make_zero_buf((size_t)n_buckets * 4), ends = make_zero_buf((size_t)n_buckets * 4), mx = make_zero_buf(4);
+  {
+    ProfileScope ps("sort_bucket_bounds", n * 8);
+    k_bucket_bounds<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(cur.w[0]->as<uint64_t>(), n, div_by(width), starts->as<uint32_t>(), ends->as<uint32_t>());
+    k_bucket_max<<<grid_for(n_buckets, BLOCK), BLOCK, 0, r.stream>>>(starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, mx->as<unsigned>());
+  }
+  unsigned largest = 0;
+  d2h(&largest, mx->ptr, 4);
+  if (largest > (unsigned)LS_CAP) return nullptr;  // skewed keys: the caller finishes with the all-HBM passes
+  BufPtr out = make_buf((size_t)n * 4);
+  ProfileScope ps("sort_local_buckets", n * 16);
+  k_local_sort<<<(unsigned)std::min<int64_t>(n_buckets, (int64_t)r.num_cus * 16), BLOCK, 0, r.stream>>>(
+      cur.w[0]->as<uint64_t>(), cur.idx ? cur.idx->as<uint32_t>() : nullptr, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, out->as<uint32_t>());
+  DFGPU_HIP(hipGetLastError());
+  return out;
 }
 
 // (key, row id) pairs sorted by bits [lo_bit, lo_bit + nbits) of the key — the radix partitioning of the LDS hash join
@@ -650,6 +854,7 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       d2h(h.data(), rb->ptr, h.size() * sizeof(u128));
     }
     int pos = 0;
+    u128 product = 1;
     for (int k = pc.n - 1; k >= 0; k--) {
       u128 mn = ~(u128)0, mx = 0;
       for (int b = 0; b < grid; b++) {
@@ -664,16 +869,25 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       c.bits = bits_for(mx - mn);
       c.shift = pos;
       pos += c.bits + (c.has_null_bit ? 1 : 0);
+      // mixed radix (one-word keys): this column's digit range and the product of the ranges behind it
+      const u128 span = mx - mn + 1;
+      c.range = span > (u128)0x7FFFFFFFFFFFFFFFull ? 0 : (uint64_t)span;
+      c.mult = product > (u128)0x7FFFFFFFFFFFFFFFull ? 0 : (uint64_t)product;
+      if (c.range == 0 || c.type == DFGPU_DECIMAL128) product = ~(u128)0;
+      else if (product <= ((u128)1 << 63)) product *= (u128)c.range * (c.has_null_bit ? 2 : 1);
     }
     DFGPU_CHECK(pos <= 64 * MAX_KEY_WORDS, "packed sort key longer than 192 bits is not supported on the GPU path");
-    const int total_bits = pos;
+    // `product` = number of distinct key values the mixed-radix packing can produce; it is used when that fits 63 bits
+    const bool narrow = product <= ((u128)1 << 63);
+    const uint64_t key_space = narrow ? (uint64_t)product : 0;
+    const int total_bits = narrow ? bits_for(product - 1) : pos;
     const int nwords = std::max(1, (total_bits + 63) / 64);
     SortedKeys sk;
     sk.nwords = nwords;
     for (int wd = 0; wd < nwords; wd++) sk.w[wd] = make_buf((size_t)n * 8);
-    bool narrow = nwords == 1;
-    for (int k = 0; k < pc.n; k++) narrow &= pc.c[k].type != DFGPU_DECIMAL128;
     const bool topk = fetch >= 0 && n > 4096 && n_out < n / 4 && total_bits > 0;
+    auto pack_keys = [&]() {
+    sk.idx.reset();
     if (narrow) {
       // row ids stay implicit until the first radix pass (radix_sort: idx_in == null means id = position); the TopK narrowing
       // reads the key words only and numbers its survivors afresh
@@ -687,6 +901,8 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
                                                              nwords > 2 ? sk.w[2]->as<uint64_t>() : nullptr, sk.idx->as<uint32_t>());
       DFGPU_HIP(hipGetLastError());
     }
+    };
+    pack_keys();
     const std::vector<Digit> digits = key_digits(total_bits);  // least significant first
     BufPtr remap;                                               // survivor position -> original row id (TopK path)
     int64_t m = n;
@@ -739,13 +955,19 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       if (m) k_iota_u32<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(m, sv.idx->as<uint32_t>());
       sk = sv;
     }
-    SortedKeys sorted = radix_sort(sk, m, digits);
-    if (!sorted.idx) {  // nothing to sort by (one row, or every key column constant): ids are the positions
-      sorted.idx = make_buf((size_t)std::max<int64_t>(m, 1) * 4);
-      if (m) k_iota_u32<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(m, sorted.idx->as<uint32_t>());
+    bool clobbered = false;
+    BufPtr sorted_idx = remap ? nullptr : sorted_ids_local(sk, m, key_space, clobbered);  // (TopK survivors are few: all-HBM passes)
+    if (!sorted_idx) {
+      if (clobbered) pack_keys();
+      SortedKeys sorted = radix_sort(sk, m, digits);
+      if (!sorted.idx) {  // nothing to sort by (one row, or every key column constant): ids are the positions
+        sorted.idx = make_buf((size_t)std::max<int64_t>(m, 1) * 4);
+        if (m) k_iota_u32<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(m, sorted.idx->as<uint32_t>());
+      }
+      sorted_idx = sorted.idx;
     }
     BufPtr take_idx = make_buf((size_t)n_out * 8);
-    k_idx_to_i64<<<grid_for(n_out, BLOCK), BLOCK, 0, r.stream>>>(sorted.idx->as<uint32_t>(), remap ? remap->as<int64_t>() : nullptr, n_out, take_idx->as<int64_t>());
+    k_idx_to_i64<<<grid_for(n_out, BLOCK), BLOCK, 0, r.stream>>>(sorted_idx->as<uint32_t>(), remap ? remap->as<int64_t>() : nullptr, n_out, take_idx->as<int64_t>());
     DFGPU_HIP(hipGetLastError());
     std::vector<int> allc(in.cols.size());
     for (size_t i = 0; i < allc.size(); i++) allc[i] = (int)i;

@@ -44,6 +44,34 @@ def test_topk(k):
     run_sort(t, [("q", False, True)], fetch=k)     # heavy ties
 
 
+@pytest.mark.parametrize("shape", ["wide_uniform", "skewed_top_bits", "heavy_ties", "two_keys_wide", "tiny_buckets"])
+@pytest.mark.parametrize("n", [3000, 70_000, 700_000])
+def test_sort_top_digits_in_hbm_buckets_in_lds(shape, n):
+    """the two-level sort (sort.hip sorted_ids_local): stable passes over the top digits, every bucket finished in LDS.  Shapes: keys
+    that spread over their range (buckets of ~n / 2^top rows), top bits held by three values only (buckets beyond the LDS capacity:
+    the all-HBM fallback after the key buffer was used as scratch), few distinct keys (stability inside long runs of ties), two wide
+    key columns with NULLs and DESC, and far more buckets than rows"""
+    rng = np.random.default_rng(n % 1000 + len(shape))
+    v = pa.array(np.arange(n, dtype=np.int64))
+    if shape == "wide_uniform":
+        t = pa.table({"a": pa.array(rng.integers(-2**40, 2**40, size=n)), "v": v})
+        keys = [("a", False, False)]
+    elif shape == "skewed_top_bits":
+        t = pa.table({"a": pa.array((rng.integers(0, 3, size=n) << 40) + rng.integers(0, 2**20, size=n)), "v": v})
+        keys = [("a", True, False)]
+    elif shape == "heavy_ties":
+        t = pa.table({"a": pa.array(rng.integers(0, 7, size=n) * 10**9), "v": v})
+        keys = [("a", False, False)]
+    elif shape == "two_keys_wide":
+        a = pa.array(rng.integers(8000, 11000, size=n).astype(np.int32), pa.int32(), mask=rng.random(n) < 0.05).cast(pa.date32())
+        t = pa.table({"a": a, "b": pa.array(rng.integers(0, 2**33, size=n)), "v": v})
+        keys = [("a", False, True), ("b", True, False)]
+    else:
+        t = pa.table({"a": pa.array(rng.integers(0, 2**62, size=n)), "v": v})
+        keys = [("a", False, False)]
+    run_sort(t, keys)
+
+
 def test_sort_special_floats():
     t = pa.table({"f": pa.array([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1.5, None, -1.5]), "i": pa.array(range(8), type=pa.int32())})
     run_sort(t, [("f", False, False)])
