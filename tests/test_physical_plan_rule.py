@@ -77,6 +77,7 @@ def test_dynamic_bounds_are_published_only_where_the_reference_allows_it(monkeyp
             return c if isinstance(c, int) else self.schema.names.index(c)
     calls = []
     monkeypatch.setattr(ops, "column_minmax", lambda t, c: (calls.append(c), (100, 200, 10, True))[1])
+    monkeypatch.setattr(ops, "column_inlist", lambda t, c, **kw: None)      # a large build side: the Map strategy, bounds only
 
     def scan_for(join_type, key_type=pa.int64(), projection=("pk", "w"), **kw):
         scan = P.ParquetExec("/nonexistent.parquet", list(projection) if projection else None, "probe")
