@@ -250,6 +250,8 @@ Column alloc_string_column(const Column& like, int64_t n);
 Column gather_strings(const Column& in, const int64_t* idx, int64_t n, bool idx_may_be_null);
 // rows of `in` whose mask bit is set (prefix = exclusive popcount prefix per mask word, n_out = total)
 Column compact_strings(const Column& in, const uint64_t* mask, const uint64_t* mask_valid, const uint64_t* prefix, int64_t nrows, int64_t n_out);
+// rows [offset, offset + length) of a string column (offsets rebased to 0)
+Column slice_strings(const Column& in, int64_t offset, int64_t length);
 // vertical concatenation of string columns (all DFGPU_UTF8)
 Column concat_strings(const std::vector<const Column*>& parts, int64_t total);
 // Int32 indices + host dictionary (first-seen order, or ascending when `sorted`)

@@ -189,6 +189,23 @@ Column concat_strings(const std::vector<const Column*>& parts, int64_t total_row
   return out;
 }
 
+Column slice_strings(const Column& in, int64_t offset, int64_t length) {
+  Runtime& r = rt();
+  Column out = alloc_string_column(in, length);
+  if (length == 0) {
+    DFGPU_HIP(hipMemsetAsync(out.offsets->ptr, 0, 8, r.stream));
+    out.data = make_buf(16);
+    return out;
+  }
+  int64_t ends[2];
+  d2h(&ends[0], str_offsets(in) + offset, 8);
+  d2h(&ends[1], str_offsets(in) + offset + length, 8);
+  k_str_rebase<<<grid_for(length + 1, BLOCK), BLOCK, 0, r.stream>>>(str_offsets(in) + offset, length + 1, -ends[0], out.offsets->as<int64_t>());
+  out.data = make_buf((size_t)(ends[1] - ends[0]) + 16);
+  if (ends[1] > ends[0]) DFGPU_HIP(hipMemcpyAsync(out.data->ptr, (const char*)in.ptr() + ends[0], (size_t)(ends[1] - ends[0]), hipMemcpyDeviceToDevice, r.stream));
+  return out;
+}
+
 // ------------------------------------------------------------------------------ interning
 // slots[s] = (first row holding the slot's string) + 1, 0 = empty.  A row either claims an empty slot or finds a slot whose
 // representative has the same bytes; in that case it lowers the representative to itself when it comes earlier in the

@@ -34,6 +34,21 @@ __global__ __launch_bounds__(BLOCK) void k_bitmap_place(const uint64_t* __restri
   }
 }
 
+// dst bits [0, n) = src bits [off, off + n); one thread per destination word, padding bits of the last word cleared
+__global__ __launch_bounds__(BLOCK) void k_bitmap_extract(const uint64_t* __restrict__ src, int64_t off, int64_t n, uint64_t* __restrict__ dst) {
+  const int64_t nw = (n + 63) >> 6;
+  for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < nw; w += (int64_t)gridDim.x * BLOCK) {
+    const int64_t s = off + (w << 6);
+    const int sb = (int)(s & 63);
+    const int64_t last_src_word = (off + n - 1) >> 6;
+    uint64_t v = src[s >> 6] >> sb;
+    if (sb && (s >> 6) + 1 <= last_src_word) v |= src[(s >> 6) + 1] << (64 - sb);
+    const int64_t rem = n - (w << 6);
+    if (rem < 64) v &= (1ull << rem) - 1ull;
+    dst[w] = v;
+  }
+}
+
 // dictionary indices of one concat part rewritten into the merged dictionary: out[i] = remap[in[i]]; the slot under a NULL row
 // may hold anything (Arrow leaves it undefined): an index outside the part's dictionary becomes 0
 template <typename T>
@@ -801,12 +816,26 @@ int dfgpu_table_slice(dfgpu_table_t th, int64_t offset, int64_t length, dfgpu_ta
     DFGPU_CHECK(offset >= 0 && length >= 0 && offset + length <= t->nrows, "slice out of range");
     auto o = std::make_unique<Table>();
     o->nrows = length;
+    const int64_t nw = (length + 63) / 64;
     for (auto& c : t->cols) {
-      DFGPU_CHECK(c.field.type != DFGPU_BOOL && c.field.type != DFGPU_UTF8 && !c.validity, "slice: Boolean / Utf8 / nullable columns not supported yet");
-      Column n = alloc_like(c, length);
-      int w = type_width(c.field.type);
-      if (length)
-        DFGPU_HIP(hipMemcpyAsync(n.data->ptr, (const char*)c.ptr() + (size_t)offset * w, (size_t)length * w, hipMemcpyDeviceToDevice, rt().stream));
+      Column n;
+      if (c.field.type == DFGPU_UTF8) {
+        n = slice_strings(c, offset, length);
+      } else {
+        n = alloc_like(c, length);
+        if (length && c.field.type == DFGPU_BOOL) {
+          k_bitmap_extract<<<grid_for(nw, BLOCK), BLOCK, 0, rt().stream>>>((const uint64_t*)c.ptr(), offset, length, n.data->as<uint64_t>());
+        } else if (length) {
+          const int w = type_width(c.field.type);
+          DFGPU_HIP(hipMemcpyAsync(n.data->ptr, (const char*)c.ptr() + (size_t)offset * w, (size_t)length * w, hipMemcpyDeviceToDevice, rt().stream));
+        }
+      }
+      if (c.validity && length) {  // the slice's validity bits start at bit 0 of a fresh word-padded bitmap
+        n.validity = make_buf(bitmap_bytes(length));
+        k_bitmap_extract<<<grid_for(nw, BLOCK), BLOCK, 0, rt().stream>>>(c.valid_words(), offset, length, n.validity->as<uint64_t>());
+        n.null_count = -1;
+      }
+      DFGPU_HIP(hipGetLastError());
       o->cols.push_back(std::move(n));
     }
     *out = wrap(o.release());

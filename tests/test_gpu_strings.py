@@ -175,3 +175,19 @@ def test_utf8_key_without_encoding_is_a_clear_error():
     dev = DeviceTable.from_arrow(pa.table({"s": pa.array(["a", "b"], pa.string()), "v": pa.array([1, 2])}))
     with pytest.raises(_lib.DfgpuError, match="dictionary"):
         ops.aggregate(dev, [(col("s"), "s")], [("sum", col("v"), "t")], "Single")
+
+
+def test_slice_of_nullable_boolean_and_string_columns():
+    """RecordBatch::slice on the device (dfgpu_table_slice): validity bits, bit-packed Booleans and strings at offsets that are not
+    multiples of 64"""
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(7)
+    n = 5000
+    t = pa.table({"i": pa.array(rng.integers(0, 1000, size=n), mask=rng.random(n) < 0.2), "b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.1),
+                  "s": random_strings(rng, n, 0.15), "d": pa.array(rng.integers(0, 10**6, size=n).astype(np.int32)).cast(pa.decimal128(15, 2))})
+    dev = DeviceTable.from_arrow(t)
+    for off, ln in ((0, n), (1, 63), (63, 130), (64, 64), (1000, 3999), (4999, 1), (77, 0)):
+        got = dev.slice(off, ln).to_arrow()
+        want = t.slice(off, ln)
+        for c in t.column_names:
+            assert got.column(c).to_pylist() == want.column(c).to_pylist(), (off, ln, c)
