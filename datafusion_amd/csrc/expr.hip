@@ -191,6 +191,21 @@ __global__ __launch_bounds__(BLOCK) void k_cast(const S* __restrict__ in, int64_
 }
 
 // word-wise bitmap kernels. mode: 0 and, 1 or, 2 not(a), 3 copy-not-valid (is_null), 4 fill(v)
+// arrow-cast cast_decimal_to_decimal, scale reduction: x / 10^k rounded half away from zero; a result of more than `limit` - 1
+// (= 10^precision - 1) in magnitude does not fit the target precision: flag (the reference's cast is not `safe`: an error)
+__global__ __launch_bounds__(BLOCK) void k_cast_dec_down(const i128* __restrict__ in, const uint64_t* __restrict__ valid, int64_t n, i128 div, i128 limit,
+                                                         i128* __restrict__ out, unsigned* __restrict__ flags) {
+  unsigned bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const i128 x = in[i];
+    i128 d = x / div;
+    const i128 r = x % div, half = div / 2;
+    if (x >= 0 ? r >= half : -r >= half) d += x >= 0 ? 1 : -1;
+    if ((!valid || bit_at(valid, i)) && (d >= limit || d <= -limit)) bad = 1;
+    out[i] = d;
+  }
+  if (bad) atomicOr(flags, 1u);
+}
 // arrow-cast cast_floating_point_to_decimal128: (v * 10^scale).round() as i128 (f64::round: half away from zero)
 __global__ __launch_bounds__(BLOCK) void k_cast_f64_dec(const double* __restrict__ in, int64_t n, double mul, i128* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (i128)round(in[i] * mul);
@@ -311,7 +326,12 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
     }
     if (to.type == DFGPU_DECIMAL128) {
       int fs = from.type == DFGPU_DECIMAL128 ? from.scale : 0;
-      DFGPU_CHECK(to.scale >= fs, "decimal scale-down cast not supported");
+      if (to.scale < fs) {
+        const i128 x = scalar_i128(src), div = pow10_i128(fs - to.scale), half = div / 2, r = x % div;
+        i128 d = x / div;
+        if (x >= 0 ? r >= half : -r >= half) d += x >= 0 ? 1 : -1;
+        return make_scalar(to, d, false);
+      }
       return make_scalar(to, (i128)((u128)scalar_i128(src) * (u128)pow10_i128(to.scale - fs)), false);
     }
     if (to.type == DFGPU_FLOAT64) {
@@ -339,6 +359,14 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
   ProfileScope ps("cast", len * (type_width(from.type) + type_width(to.type)));
   if (to.type == DFGPU_DECIMAL128 && ft == DFGPU_FLOAT64) {
     k_cast_f64_dec<<<g, BLOCK, 0, st>>>((const double*)src.col.ptr(), len, std::pow(10.0, to.scale), out.col.data->as<i128>());
+  } else if (to.type == DFGPU_DECIMAL128 && from.type == DFGPU_DECIMAL128 && to.scale < from.scale) {
+    BufPtr flags = make_zero_buf(4);
+    k_cast_dec_down<<<g, BLOCK, 0, st>>>((const i128*)src.col.ptr(), src.col.valid_words(), len, pow10_i128(from.scale - to.scale), pow10_i128(to.precision),
+                                         out.col.data->as<i128>(), flags->as<unsigned>());
+    DFGPU_HIP(hipGetLastError());
+    unsigned hf = 0;
+    d2h(&hf, flags->ptr, 4);
+    DFGPU_CHECK(hf == 0, "Arrow error: Invalid argument error: a value is too large to store in a " + type_name(to));
   } else if (to.type == DFGPU_DECIMAL128) {
     int fs = from.type == DFGPU_DECIMAL128 ? from.scale : 0;
     DFGPU_CHECK(to.scale >= fs, "decimal scale-down cast not supported on the GPU path");

@@ -177,6 +177,49 @@ def q7_plan(supplier, lineitem, orders, customer, nation):
     return P.SortPreservingMergeExec(keys, out)
 
 
+# ------------------------------------------------------------------------------------------ Q8
+def q8_plan(part, supplier, lineitem, orders, customer, nation, region):
+    """q8.slt.part:93-132: RightSemi against the filtered part, five Inner joins, LeftSemi against the filtered region,
+    date_part(YEAR, o_orderdate) as the group key, SUM(CASE WHEN nation = 'BRAZIL' ...) and the final
+    CAST(CAST(a AS Decimal128(12, 2)) / CAST(b AS Decimal128(12, 2)) AS Decimal128(15, 2)): two scale-down casts around arrow-arith's
+    decimal division (Decimal128(12,2) / Decimal128(12,2) -> Decimal128(18,6))"""
+    s_ = lambda v: lit(v, pa.string())                                     # noqa: E731
+    p = _hash(_cb(P.FilterExec(col("p_type").eq(s_("ECONOMY ANODIZED STEEL")), _scan(part, "part").project(["p_partkey", "p_type"]), projection=["p_partkey"])), ["p_partkey"])
+    li = _hash(_scan(lineitem, "lineitem").project(["l_orderkey", "l_partkey", "l_suppkey", "l_extendedprice", "l_discount"]), ["l_partkey"])
+    j1 = P.HashJoinExec(_cb(p), _cb(li), [("p_partkey", "l_partkey")], "RightSemi", projection=(None, ["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]))
+    sup = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_nationkey"]), ["s_suppkey"])
+    j2 = P.HashJoinExec(_cb(_hash(_cb(j1), ["l_suppkey"])), _cb(sup), [("l_suppkey", "s_suppkey")], "Inner",
+                        projection=(["l_orderkey", "l_extendedprice", "l_discount"], ["s_nationkey"]))
+    o = _hash(_cb(P.FilterExec((col("o_orderdate") >= _d(1995, 1, 1)).and_(col("o_orderdate") <= _d(1996, 12, 31)),
+                               _scan(orders, "orders").project(["o_orderkey", "o_custkey", "o_orderdate"]))), ["o_orderkey"])
+    j3 = P.HashJoinExec(_cb(_hash(_cb(j2), ["l_orderkey"])), _cb(o), [("l_orderkey", "o_orderkey")], "Inner",
+                        projection=(["l_extendedprice", "l_discount", "s_nationkey"], ["o_custkey", "o_orderdate"]))
+    c = _hash(_scan(customer, "customer").project(["c_custkey", "c_nationkey"]), ["c_custkey"])
+    j4 = P.HashJoinExec(_cb(_hash(_cb(j3), ["o_custkey"])), _cb(c), [("o_custkey", "c_custkey")], "Inner",
+                        projection=(["l_extendedprice", "l_discount", "s_nationkey", "o_orderdate"], ["c_nationkey"]))
+    n1 = _hash(_scan(nation, "nation").project(["n_nationkey", "n_regionkey"]), ["n_nationkey"])
+    j5 = P.HashJoinExec(_cb(_hash(_cb(j4), ["c_nationkey"])), _cb(n1), [("c_nationkey", "n_nationkey")], "Inner",
+                        projection=(["l_extendedprice", "l_discount", "s_nationkey", "o_orderdate"], ["n_regionkey"]))
+    n2 = _hash(_scan(nation, "nation").project(["n_nationkey", "n_name"]), ["n_nationkey"])
+    j6 = P.HashJoinExec(_cb(_hash(_cb(j5), ["s_nationkey"])), _cb(n2), [("s_nationkey", "n_nationkey")], "Inner",
+                        projection=(["l_extendedprice", "l_discount", "o_orderdate", "n_regionkey"], ["n_name"]))
+    r = _hash(_cb(P.FilterExec(col("r_name").eq(s_("AMERICA")), _scan(region, "region"), projection=["r_regionkey"])), ["r_regionkey"])
+    semi = P.HashJoinExec(_cb(_hash(_cb(j6), ["n_regionkey"])), _cb(r), [("n_regionkey", "r_regionkey")], "LeftSemi",
+                          projection=(["o_orderdate", "l_extendedprice", "l_discount", "n_name"], None))
+    proj = P.ProjectionExec([(date_part("year", col("o_orderdate")), "o_year"), (col("l_extendedprice") * (ONE - col("l_discount")), "volume"), (col("n_name"), "nation")], _cb(semi))
+    a_name = 'sum(CASE WHEN all_nations.nation = Utf8("BRAZIL") THEN all_nations.volume ELSE Int64(0) END)'
+    b_name = "sum(all_nations.volume)"
+    zero = lit(Decimal("0.0000"), pa.decimal128(38, 4))
+    gb = [(col("o_year"), "o_year")]
+    aggs = [("sum", case([(col("nation").eq(s_("BRAZIL")), col("volume"))], zero), a_name), ("sum", col("volume"), b_name)]
+    partial = P.AggregateExec("Partial", gb, aggs, proj)
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["o_year"])))
+    d12, d15 = pa.decimal128(12, 2), pa.decimal128(15, 2)
+    share = P.ProjectionExec([(col("o_year"), "o_year"), ((col(a_name).cast(d12) / col(b_name).cast(d12)).cast(d15), "mkt_share")], final)
+    keys = [("o_year",) + ASC]
+    return P.SortPreservingMergeExec(keys, P.SortExec(keys, share))
+
+
 # ----------------------------------------------------------------------------------------- Q14
 def q14_plan(lineitem, part):
     """q14.slt.part:39-49: Inner join lineitem x part, SUM(CASE WHEN p_type LIKE 'PROMO%' THEN ... ELSE 0.0000 END) and the final

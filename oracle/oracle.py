@@ -399,7 +399,18 @@ def evaluate(expr, table: pa.Table) -> Datum:
                 L.orc_decimal_rescale_up(C.c_void_p(out.ctypes.data), C.c_int64(m), to.scale - from_scale, C.c_void_p(out2.ctypes.data))
                 out = out2
             elif to.scale < from_scale:
-                raise NotImplementedError("oracle: decimal scale-down cast")
+                # arrow-cast cast_decimal_to_decimal, scale reduction: divide by 10^k, round half away from zero; a value beyond the
+                # target precision is an error (the reference's CastExpr is not `safe`)
+                div = 10 ** (from_scale - to.scale)
+                vals = []
+                for i, x in enumerate(_py_ints(Datum(out, d.typ, None, d.scalar))):
+                    q, r = divmod(abs(x), div)
+                    q = q + 1 if 2 * r >= div else q
+                    v = -q if x < 0 else q
+                    if (d.valid is None or d.valid[i]) and abs(v) >= 10 ** to.precision:
+                        raise OverflowError(f"Arrow error: Invalid argument error: {v} is too large to store in a {to}")
+                    vals.append(v)
+                out = _i128_np(vals)
             return Datum(out, to, d.valid, d.scalar)
         if dst == ORC_F64 and src in (ORC_I32, ORC_I64):
             return Datum(d.values.astype(np.float64), to, d.valid, d.scalar)
