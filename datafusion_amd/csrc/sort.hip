@@ -615,10 +615,11 @@ __global__ __launch_bounds__(BLOCK) void k_bucket_max(const uint32_t* __restrict
 }
 
 // one workgroup per bucket: stable LSD sort of the bucket's (key, id) elements by the key's low `low_bits` bits, in LDS
+template <typename LK>  // the key inside its bucket: 32 bits when `width` allows (less LDS and registers: more buckets in flight per CU)
 __global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ starts,
                                                       const uint32_t* __restrict__ ends, int64_t n_buckets, uint64_t width, int low_bits, uint32_t* __restrict__ idx_out) {
   constexpr int NWAVE = BLOCK / WAVE;
-  __shared__ uint64_t s_key[LS_CAP];
+  __shared__ LK s_key[LS_CAP];
   __shared__ uint32_t s_idx[LS_CAP];
   __shared__ unsigned int s_cnt[NWAVE][256];
   __shared__ unsigned int s_start[256];
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict
     const uint32_t lo = starts[b];
     const int m = (int)(ends[b] - lo);
     if (m == 0) continue;
-    uint64_t k[LS_ITEMS];
+    LK k[LS_ITEMS];
     uint32_t id[LS_ITEMS];
     // position of item c of this lane: a wave owns a contiguous segment, so position order = (wave, item, lane) order; the
     // segments are sized for THIS bucket (items = ceil(m / 256) rows per thread), so the four waves share its rows evenly
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict
       if (c >= items) continue;
       const int j = (wave * items + c) * WAVE + (int)lane;
       const int64_t src = (int64_t)lo + (j < m ? j : 0);
-      k[c] = key[src] - (uint64_t)b * width;  // the key inside its bucket: < width <= 2^low_bits
+      k[c] = (LK)(key[src] - (uint64_t)b * width);  // the key inside its bucket: < width <= 2^low_bits
       id[c] = idx_in ? idx_in[src] : (uint32_t)src;
     }
     if (m > 1) {
@@ -754,8 +755,10 @@ static BufPtr sorted_ids_local(const SortedKeys& sk, int64_t n, uint64_t key_spa
   if (largest > (unsigned)LS_CAP) return nullptr;  // skewed keys: the caller finishes with the all-HBM passes
   BufPtr out = make_buf((size_t)n * 4);
   ProfileScope ps("sort_local_buckets", n * 16);
-  k_local_sort<<<(unsigned)std::min<int64_t>(n_buckets, (int64_t)r.num_cus * 16), BLOCK, 0, r.stream>>>(
-      cur.w[0]->as<uint64_t>(), cur.idx ? cur.idx->as<uint32_t>() : nullptr, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, out->as<uint32_t>());
+  const unsigned lg = (unsigned)std::min<int64_t>(n_buckets, (int64_t)r.num_cus * 16);
+  const uint32_t* idp = cur.idx ? cur.idx->as<uint32_t>() : nullptr;
+  if (low_bits <= 32) k_local_sort<uint32_t><<<lg, BLOCK, 0, r.stream>>>(cur.w[0]->as<uint64_t>(), idp, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, out->as<uint32_t>());
+  else k_local_sort<uint64_t><<<lg, BLOCK, 0, r.stream>>>(cur.w[0]->as<uint64_t>(), idp, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, out->as<uint32_t>());
   DFGPU_HIP(hipGetLastError());
   return out;
 }
