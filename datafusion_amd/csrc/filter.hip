@@ -318,11 +318,11 @@ __global__ __launch_bounds__(BLOCK) void k_pack_rows(PackLayout L, int64_t n, ui
       reinterpret_cast<uint4*>(rec + i * R)[q] = uint4{(unsigned)s[2 * q], (unsigned)(s[2 * q] >> 32), (unsigned)s[2 * q + 1], (unsigned)(s[2 * q + 1] >> 32)};
   }
 }
-template <int R>
-__global__ __launch_bounds__(BLOCK) void k_gather_rows(PackLayout L, const uint8_t* __restrict__ rec, const int64_t* __restrict__ idx, int64_t n) {
+template <int R, typename IT>  // IT: row ids as int64 (take) or uint32 (the sort's ids, taken as they are)
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(PackLayout L, const uint8_t* __restrict__ rec, const IT* __restrict__ idx, int64_t n) {
   constexpr int NS = R / 8;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    const uint4* src = reinterpret_cast<const uint4*>(rec + idx[i] * R);
+    const uint4* src = reinterpret_cast<const uint4*>(rec + (int64_t)idx[i] * R);
     uint64_t s[NS];
 #pragma unroll
     for (int q = 0; q < NS / 2; q++) {
@@ -346,8 +346,20 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(PackLayout L, const uint8
   }
 }
 
-std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols, const int64_t* idx, int64_t n, bool idx_may_be_null) {
+__global__ __launch_bounds__(BLOCK) void k_widen_ids(const uint32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (int64_t)in[i];
+}
+std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols, const int64_t* idx, int64_t n, bool idx_may_be_null, const uint32_t* idx32) {
   Runtime& r = rt();
+  BufPtr widened;
+  auto ids64 = [&]() -> const int64_t* {  // columns that go one by one take 64-bit ids: widened on first use
+    if (idx || !idx32) return idx;
+    if (!widened) {
+      widened = make_buf((size_t)std::max<int64_t>(n, 1) * 8);
+      if (n) k_widen_ids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(idx32, n, widened->as<int64_t>());
+    }
+    return widened->as<int64_t>();
+  };
   std::vector<Column> out(cols.size());
   // what can travel as records: byte-addressable, non-nullable columns taken by non-negative ids, from a table whose columns
   // do not sit in the Infinity Cache anyway, for enough rows to repay the packing pass
@@ -406,17 +418,17 @@ std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols
         ProfileScope ps("take_gather_rows", n * (int64_t)(8 + R + bytes));
         const int g = grid_for(n, BLOCK);
         switch (R) {
-          case 16: k_gather_rows<16><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
-          case 32: k_gather_rows<32><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
-          case 48: k_gather_rows<48><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
-          default: k_gather_rows<64><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
+          case 16: if (idx32) k_gather_rows<16, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx32, n); else k_gather_rows<16, int64_t><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
+          case 32: if (idx32) k_gather_rows<32, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx32, n); else k_gather_rows<32, int64_t><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
+          case 48: if (idx32) k_gather_rows<48, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx32, n); else k_gather_rows<48, int64_t><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
+          default: if (idx32) k_gather_rows<64, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx32, n); else k_gather_rows<64, int64_t><<<g, BLOCK, 0, r.stream>>>(L, rec->as<uint8_t>(), idx, n); break;
         }
         DFGPU_HIP(hipGetLastError());
       }
     }
   }
   for (size_t k = 0; k < cols.size(); k++)
-    if (!done[k]) out[k] = gather_column(in.cols[cols[k]], idx, n, idx_may_be_null);
+    if (!done[k]) out[k] = gather_column(in.cols[cols[k]], ids64(), n, idx_may_be_null);
   return out;
 }
 

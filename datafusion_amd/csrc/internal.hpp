@@ -224,7 +224,8 @@ Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_
 // take: out[i] = in[idx[i]] ; idx < 0 -> NULL.  idx is a device array of int64.
 Column gather_column(const Column& in, const int64_t* idx, int64_t n, bool idx_may_be_null);
 // take of several columns of one table by the same ids: row-major records + ONE random access per row when that pays
-std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols, const int64_t* idx, int64_t n, bool idx_may_be_null);
+// (idx32: the same ids as 32-bit values instead of `idx` — the sort hands its row ids over without widening them)
+std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols, const int64_t* idx, int64_t n, bool idx_may_be_null, const uint32_t* idx32 = nullptr);
 // out[w] = a[w] & b[w] over nw 64-bit words (aggregate.hip)
 void and_bitmaps(const uint64_t* a, const uint64_t* b, int64_t nw, uint64_t* out);
 // clear bits beyond n in the last word of a bitmap (keeps padding deterministic)

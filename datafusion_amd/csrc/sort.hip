@@ -594,10 +594,19 @@ constexpr int LS_CAP = BLOCK * LS_ITEMS;  // 4096 elements per bucket in LDS
 // bounds of the buckets of keys sorted by (key >> shift): starts / ends (both zero for an empty bucket) and the largest size
 __global__ __launch_bounds__(BLOCK) void k_bucket_bounds(const uint64_t* __restrict__ key, int64_t n, DivBy width, uint32_t* __restrict__ starts,
                                                          uint32_t* __restrict__ ends) {
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    const uint64_t b = div_apply(key[i], width);
-    if (i == 0 || div_apply(key[i - 1], width) != b) starts[b] = (uint32_t)i;
-    if (i == n - 1 || div_apply(key[i + 1], width) != b) ends[b] = (uint32_t)(i + 1);
+  // one load and one division per row: the neighbours' bucket numbers come from the adjacent lanes (the wave's first / last
+  // lane divides the element before / after the wave's 64 rows itself)
+  const unsigned lane = lane_id();
+  const int64_t n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
+    const bool in = i < n;
+    const uint64_t b = in ? div_apply(key[i], width) : ~0ull;
+    uint64_t prev = __shfl_up(b, 1, 64), next = __shfl_down(b, 1, 64);
+    if (lane == 0) prev = (in && i > 0) ? div_apply(key[i - 1], width) : ~0ull;
+    if (lane == 63) next = (i + 1 < n) ? div_apply(key[i + 1], width) : ~0ull;
+    if (!in) continue;
+    if (i == 0 || prev != b) starts[b] = (uint32_t)i;
+    if (i == n - 1 || next != b) ends[b] = (uint32_t)(i + 1);
   }
 }
 __global__ __launch_bounds__(BLOCK) void k_bucket_max(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends, int64_t n_buckets, unsigned* __restrict__ max_size) {
@@ -969,12 +978,16 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       }
       sorted_idx = sorted.idx;
     }
-    BufPtr take_idx = make_buf((size_t)n_out * 8);
-    k_idx_to_i64<<<grid_for(n_out, BLOCK), BLOCK, 0, r.stream>>>(sorted_idx->as<uint32_t>(), remap ? remap->as<int64_t>() : nullptr, n_out, take_idx->as<int64_t>());
-    DFGPU_HIP(hipGetLastError());
     std::vector<int> allc(in.cols.size());
     for (size_t i = 0; i < allc.size(); i++) allc[i] = (int)i;
-    out.cols = gather_columns(in, allc, take_idx->as<int64_t>(), n_out, false);
+    if (remap) {  // TopK survivors: positions among the survivors -> row ids of the input
+      BufPtr take_idx = make_buf((size_t)n_out * 8);
+      k_idx_to_i64<<<grid_for(n_out, BLOCK), BLOCK, 0, r.stream>>>(sorted_idx->as<uint32_t>(), remap->as<int64_t>(), n_out, take_idx->as<int64_t>());
+      DFGPU_HIP(hipGetLastError());
+      out.cols = gather_columns(in, allc, take_idx->as<int64_t>(), n_out, false);
+    } else {
+      out.cols = gather_columns(in, allc, nullptr, n_out, false, sorted_idx->as<uint32_t>());
+    }
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));
   return out;
