@@ -35,6 +35,11 @@ class Expr(C.Structure):
     _fields_ = [("nodes", C.POINTER(ExprNode)), ("n_nodes", C.c_int32), ("root", C.c_int32), ("string_pool", C.c_char_p)]
 
 
+class Metrics(C.Structure):
+    """dfgpu_metrics"""
+    _fields_ = [(n, C.c_int64) for n in ("calls", "elapsed_ns", "kernel_ns", "h2d_bytes", "d2h_bytes", "hbm_bytes_algorithmic", "rows_in", "rows_out")]
+
+
 class JoinFilter(C.Structure):
     """dfgpu_join_filter"""
     _fields_ = [("expression", Expr), ("column_index", C.POINTER(C.c_int32)), ("column_side", C.POINTER(C.c_int32)), ("n_columns", C.c_int32)]
@@ -102,7 +107,7 @@ SYMBOLS = [
     "dfgpu_exchange_hash", "dfgpu_exchange_broadcast", "dfgpu_exchange_broadcast_pruned", "dfgpu_comm_stats",
     "dfgpu_mem_set_limit", "dfgpu_mem_limit", "dfgpu_mem_try_reserve", "dfgpu_mem_reservation_size", "dfgpu_mem_release",
     "dfgpu_table_export_batch", "dfgpu_host_register", "dfgpu_host_unregister", "dfgpu_table_export_into",
-    "dfgpu_column_inlist", "dfgpu_table_dictionary_like", "dfgpu_table_dictionary_encode", "dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_estimate_bytes",
+    "dfgpu_column_inlist", "dfgpu_metrics_reset", "dfgpu_metrics_get", "dfgpu_table_dictionary_like", "dfgpu_table_dictionary_encode", "dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_estimate_bytes",
 ]
 
 _lib = None

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -10,6 +11,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dfgpu.h"
@@ -34,9 +36,21 @@ void set_last_error(const std::string& msg);
     if (!(cond)) throw ::dfgpu::Error(std::string(msg)); \
   } while (0)
 
+// the calling thread's operator metrics (dfgpu_metrics)
+dfgpu_metrics& thread_metrics();
+struct MetricsTimer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~MetricsTimer() {
+    dfgpu_metrics& m = thread_metrics();
+    m.calls++;
+    m.elapsed_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
+
 // Wraps a C-ABI entry point body: exceptions -> error code + thread-local message.
 template <typename F>
 int guarded(F&& f) noexcept {
+  MetricsTimer timer;
   try {
     f();
     return 0;
@@ -78,7 +92,9 @@ struct Runtime {
     std::string name;
     hipEvent_t a, b;
     int64_t bytes;
+    std::thread::id thread;  // who launched it (dfgpu_metrics.kernel_ns is per thread)
   };
+  std::map<std::thread::id, int64_t> kernel_ns_by_thread;  // filled by collect(), drained by dfgpu_metrics_get
   std::vector<Rec> recs;
   std::vector<dfgpu_kernel_stat> stats;  // aggregated by collect()
   void collect();
@@ -198,9 +214,19 @@ inline Table* unwrap(dfgpu_table_t t) {
   DFGPU_CHECK(t != nullptr, "null table handle");
   Table* p = reinterpret_cast<Table*>(t);
   if (p->device >= 0) use_device(p->device);
+  thread_metrics().rows_in += p->nrows;
   return p;
 }
-inline dfgpu_table_t wrap(Table* t) { return reinterpret_cast<dfgpu_table_t>(t); }
+// the same for entry points that only look at a table (row counts, column views, zero-copy selections): no rows are consumed
+inline Table* unwrap_quiet(dfgpu_table_t t) {
+  Table* p = unwrap(t);
+  thread_metrics().rows_in -= p->nrows;
+  return p;
+}
+inline dfgpu_table_t wrap(Table* t) {
+  thread_metrics().rows_out += t->nrows;
+  return reinterpret_cast<dfgpu_table_t>(t);
+}
 
 Column alloc_column(const dfgpu_field& f, const std::string& name, int64_t n, bool with_validity = false);
 // a fresh column for rows taken from `src` (same type and name, dictionary handed on)
@@ -209,6 +235,8 @@ inline Column alloc_like(const Column& src, int64_t n, bool with_validity = fals
   c.dict = src.dict;
   return c;
 }
+
+inline dfgpu_table_t wrap_quiet(Table* t) { return reinterpret_cast<dfgpu_table_t>(t); }  // zero-copy views: no rows produced
 
 // ----------------------------------------------------------------- primitives (scan.hip)
 // exclusive prefix sum of popcount(mask_word & valid_word) per 64-row word -> u64 offsets

@@ -141,8 +141,14 @@ uint64_t read_u64(const uint64_t* dev) {
 }
 
 // -------------------------------------------------------------------------- profiling
+dfgpu_metrics& thread_metrics() {
+  static thread_local dfgpu_metrics m{};
+  return m;
+}
+
 ProfileScope::ProfileScope(const char* n, int64_t algorithmic_bytes) : name(n), bytes(algorithmic_bytes) {
   Runtime& r = rt();
+  thread_metrics().hbm_bytes_algorithmic += algorithmic_bytes;
   if (!r.profiling) return;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
@@ -153,7 +159,7 @@ ProfileScope::~ProfileScope() {
   Runtime& r = rt();
   (void)hipEventRecord(b, r.stream);
   std::lock_guard<std::mutex> lk(r.mu);   // scan threads decode column chunks concurrently (parquet.hip)
-  r.recs.push_back({name, a, b, bytes});
+  r.recs.push_back({name, a, b, bytes, std::this_thread::get_id()});
 }
 
 void Runtime::collect() {
@@ -174,6 +180,7 @@ void Runtime::collect() {
     it->calls += 1;
     it->total_ms += ms;
     it->algorithmic_bytes += rec.bytes;
+    kernel_ns_by_thread[rec.thread] += (int64_t)((double)ms * 1e6);
   }
   recs.clear();
 }
@@ -218,6 +225,26 @@ using namespace dfgpu;
 extern "C" {
 
 int dfgpu_abi_version(void) { return DFGPU_ABI_VERSION; }
+
+int dfgpu_metrics_reset(void) {
+  thread_metrics() = dfgpu_metrics{};
+  return 0;
+}
+int dfgpu_metrics_get(dfgpu_metrics* out) {
+  if (!out) return 1;
+  if (current_device() >= 0) {  // device time of this thread's profiled launches (drains the stream: events must have completed)
+    Runtime& r = rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.profiling) r.collect();
+    auto it = r.kernel_ns_by_thread.find(std::this_thread::get_id());
+    if (it != r.kernel_ns_by_thread.end()) {
+      thread_metrics().kernel_ns += it->second;
+      r.kernel_ns_by_thread.erase(it);
+    }
+  }
+  *out = thread_metrics();
+  return 0;
+}
 
 const char* dfgpu_last_error(void) { return g_last_error.c_str(); }
 

@@ -110,6 +110,7 @@ struct Uploader {
   Uploader() { DFGPU_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); }
   void upload(void* dst, const void* src, size_t n) {
     if (n == 0) return;
+    thread_metrics().h2d_bytes += (int64_t)n;
     // pin large host buffers so the copy engine streams at PCIe rate without a bounce buffer
     if (n >= (size_t(8) << 20)) {
       if (hipHostRegister(const_cast<void*>(src), n, hipHostRegisterDefault) == hipSuccess) registered.push_back(const_cast<void*>(src));
@@ -297,6 +298,12 @@ static Column import_column(const ArrowArray* a, const ArrowSchema* s, int64_t p
     }
   }
   return c;
+}
+
+// device -> host copy of an export on the library stream, counted in the calling thread's metrics
+static void export_copy(void* dst, const void* src, size_t n) {
+  thread_metrics().d2h_bytes += (int64_t)n;
+  DFGPU_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, rt().stream));
 }
 
 // ---------------------------------------------------------------- export
@@ -550,14 +557,14 @@ static void export_rows(Table* t, int64_t offset, int64_t length, struct ArrowAr
       }
       void* hb = pinned().alloc((size_t)nbytes + 8);
       cp->pinned_buffers.push_back(hb);
-      if (nbytes) DFGPU_HIP(hipMemcpyAsync(hb, (const char*)c.ptr() + b0, (size_t)nbytes, hipMemcpyDeviceToHost, r.stream));
+      if (nbytes) export_copy(hb, (const char*)c.ptr() + b0, (size_t)nbytes);
       void* hv = nullptr;
       int64_t nulls = 0;
       if (with_valid) {
         const size_t vb = bitmap_bytes(rows);
         hv = pinned().alloc(vb ? vb : 8);
         cp->pinned_buffers.push_back(hv);
-        if (vb) DFGPU_HIP(hipMemcpyAsync(hv, (const char*)c.validity->ptr + (size_t)(first >> 6) * 8, vb, hipMemcpyDeviceToHost, r.stream));
+        if (vb) export_copy(hv, (const char*)c.validity->ptr + (size_t)(first >> 6) * 8, vb);
         nulls = (offset == 0 && length == c.length) ? c.null_count : -1;
       }
       cp->buffer_ptrs = {hv, hoff, hb};
@@ -579,7 +586,7 @@ static void export_rows(Table* t, int64_t offset, int64_t length, struct ArrowAr
     cp->pinned_buffers.push_back(hd);
     if (db) {
       const char* src = (const char*)c.ptr() + (bits ? (size_t)(first >> 6) * 8 : (size_t)first * type_width(c.field.type));
-      DFGPU_HIP(hipMemcpyAsync(hd, src, db, hipMemcpyDeviceToHost, r.stream));
+      export_copy(hd, src, db);
     }
     void* hv = nullptr;
     int64_t nulls = 0;
@@ -587,7 +594,7 @@ static void export_rows(Table* t, int64_t offset, int64_t length, struct ArrowAr
       const size_t vb = bitmap_bytes(rows);
       hv = pinned().alloc(vb ? vb : 8);
       cp->pinned_buffers.push_back(hv);
-      if (vb) DFGPU_HIP(hipMemcpyAsync(hv, (const char*)c.validity->ptr + (size_t)(first >> 6) * 8, vb, hipMemcpyDeviceToHost, r.stream));
+      if (vb) export_copy(hv, (const char*)c.validity->ptr + (size_t)(first >> 6) * 8, vb);
       nulls = (offset == 0 && length == c.length) ? c.null_count : -1;  // a slice's count is left to the consumer
     }
     cp->buffer_ptrs = {hv, hd};
@@ -669,10 +676,10 @@ int dfgpu_table_export_into(dfgpu_table_t th, int64_t offset, int64_t length, vo
       DFGPU_CHECK(!bits || (offset & 63) == 0, "dfgpu_table_export_into: Boolean columns need a row offset that is a multiple of 64");
       const size_t db = bits ? bitmap_bytes(length) : (size_t)length * type_width(c.field.type);
       const char* src = (const char*)c.ptr() + (bits ? (size_t)(offset >> 6) * 8 : (size_t)offset * type_width(c.field.type));
-      if (db && data_buffers[i]) DFGPU_HIP(hipMemcpyAsync(data_buffers[i], src, db, hipMemcpyDeviceToHost, r.stream));
+      if (db && data_buffers[i]) export_copy(data_buffers[i], src, db);
       if (validity_buffers && validity_buffers[i]) {
         const size_t vb = bitmap_bytes(length);
-        if (c.validity) DFGPU_HIP(hipMemcpyAsync(validity_buffers[i], (const char*)c.validity->ptr + (size_t)(offset >> 6) * 8, vb, hipMemcpyDeviceToHost, r.stream));
+        if (c.validity) export_copy(validity_buffers[i], (const char*)c.validity->ptr + (size_t)(offset >> 6) * 8, vb);
         else std::memset(validity_buffers[i], 0xFF, vb);
       }
     }
@@ -682,7 +689,7 @@ int dfgpu_table_export_into(dfgpu_table_t th, int64_t offset, int64_t length, vo
 
 int dfgpu_table_dictionary_lookup(dfgpu_table_t th, int column, const char* utf8, int64_t len, int64_t* out_code) {
   return guarded([&] {
-    Table* t = unwrap(th);
+    Table* t = unwrap_quiet(th);
     DFGPU_CHECK(column >= 0 && column < (int)t->cols.size() && utf8 && out_code, "bad argument");
     const Column& c = t->cols[column];
     DFGPU_CHECK(c.dict != nullptr, "column '" + c.name + "' is not dictionary-encoded");
@@ -738,7 +745,7 @@ static bool like_match(const std::string& s, const std::string& pat, bool fold_c
 int dfgpu_table_dictionary_like(dfgpu_table_t th, int column, const char* pattern, int64_t len, int case_insensitive, int64_t* out_codes, int64_t capacity,
                                 int64_t* out_n) {
   return guarded([&] {
-    Table* t = unwrap(th);
+    Table* t = unwrap_quiet(th);
     DFGPU_CHECK(column >= 0 && column < (int)t->cols.size() && pattern && out_n, "bad argument");
     const Column& c = t->cols[column];
     DFGPU_CHECK(c.dict != nullptr, "column '" + c.name + "' is not dictionary-encoded");
@@ -767,14 +774,14 @@ int dfgpu_table_free(dfgpu_table_t t) {
   return guarded([&] { delete reinterpret_cast<Table*>(t); });
 }
 int dfgpu_table_num_rows(dfgpu_table_t t, int64_t* out) {
-  return guarded([&] { *out = unwrap(t)->nrows; });
+  return guarded([&] { *out = unwrap_quiet(t)->nrows; });
 }
 int dfgpu_table_num_columns(dfgpu_table_t t, int* out) {
-  return guarded([&] { *out = (int)unwrap(t)->cols.size(); });
+  return guarded([&] { *out = (int)unwrap_quiet(t)->cols.size(); });
 }
 int dfgpu_table_column(dfgpu_table_t th, int i, dfgpu_column_view* out) {
   return guarded([&] {
-    Table* t = unwrap(th);
+    Table* t = unwrap_quiet(th);
     DFGPU_CHECK(i >= 0 && i < (int)t->cols.size(), "column index out of range");
     Column& c = t->cols[i];
     if (c.validity && c.null_count < 0) count_nulls(c);
@@ -789,23 +796,23 @@ int dfgpu_table_column(dfgpu_table_t th, int i, dfgpu_column_view* out) {
 }
 int dfgpu_table_select(dfgpu_table_t th, const int* cols, int ncols, dfgpu_table_t* out) {
   return guarded([&] {
-    Table* t = unwrap(th);
+    Table* t = unwrap_quiet(th);
     auto o = std::make_unique<Table>();
     o->nrows = t->nrows;
     for (int i = 0; i < ncols; i++) {
       DFGPU_CHECK(cols[i] >= 0 && cols[i] < (int)t->cols.size(), "column index out of range");
       o->cols.push_back(t->cols[cols[i]]);
     }
-    *out = wrap(o.release());
+    *out = wrap_quiet(o.release());
   });
 }
 int dfgpu_table_hstack(dfgpu_table_t a, dfgpu_table_t b, dfgpu_table_t* out) {
   return guarded([&] {
-    Table *ta = unwrap(a), *tb = unwrap(b);
+    Table *ta = unwrap_quiet(a), *tb = unwrap_quiet(b);
     DFGPU_CHECK(ta->nrows == tb->nrows, "hstack: row counts differ");
     auto o = std::make_unique<Table>(*ta);
     for (auto& c : tb->cols) o->cols.push_back(c);
-    *out = wrap(o.release());
+    *out = wrap_quiet(o.release());
   });
 }
 

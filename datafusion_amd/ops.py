@@ -308,6 +308,18 @@ def column_inlist(table: DeviceTable, column, max_size: int = 128 * 1024, max_di
     return None if n.value < 0 else list(vals[:n.value])
 
 
+def metrics_reset():
+    """zero the calling thread's operator metrics (dfgpu_metrics_reset)"""
+    check(_lib.load().dfgpu_metrics_reset())
+
+
+def metrics() -> dict:
+    """the calling thread's operator metrics since its last reset (dfgpu_metrics: what a GPU node's ExecutionPlan::metrics() reports)"""
+    m = _lib.Metrics()
+    check(_lib.load().dfgpu_metrics_get(C.byref(m)))
+    return {n: getattr(m, n) for n, _ in _lib.Metrics._fields_}
+
+
 def jit_stats():
     """(distinct nodes compiled with hiprtc, total compile ms) of this process"""
     n, ms = C.c_int64(), C.c_double()

@@ -606,6 +606,21 @@ int dfgpu_tpch_customer(double scale_factor, int64_t begin, int64_t end, dfgpu_t
 
 /* ----------------------------------------------------------------- metrics */
 
+/* Operator metrics (MetricsSet / BaselineMetrics: output_rows, elapsed_compute — physical-expr-common/src/metrics/baseline.rs:53-75;
+ * what `ExecutionPlan::metrics()` of a GPU node reports): counters of the CALLING THREAD since its last dfgpu_metrics_reset.
+ * A shim resets them on the blocking thread that runs `execute(partition)`'s device work and reads them when the partition's
+ * stream ends; nothing is shared between threads, so concurrent partitions do not mix. */
+typedef struct dfgpu_metrics {
+  int64_t calls;                 /* entry points entered */
+  int64_t elapsed_ns;            /* host time spent inside entry points (launches, waits for results, copies) = elapsed_compute */
+  int64_t kernel_ns;             /* device time of the launches this thread profiled (0 unless dfgpu_profile_enable(1)) */
+  int64_t h2d_bytes, d2h_bytes;  /* bytes that crossed PCIe in dfgpu_table_import / dfgpu_table_export* */
+  int64_t hbm_bytes_algorithmic; /* SURVEY 8(d) bytes of the launches: inputs read once + outputs written once */
+  int64_t rows_in, rows_out;     /* rows of the table handles passed in / handed out */
+} dfgpu_metrics;
+int dfgpu_metrics_reset(void);
+int dfgpu_metrics_get(dfgpu_metrics* out);
+
 /* per-kernel HIP-event timing on the library stream (BaselineMetrics.elapsed_compute
  * analogue, physical-expr-common/src/metrics/baseline.rs:53-75) */
 int dfgpu_profile_enable(int on);

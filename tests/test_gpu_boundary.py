@@ -110,3 +110,41 @@ def test_reservations_and_the_rule_declining_a_join_that_does_not_fit():
         assert P.collect(opt).num_rows == ops.hash_join(b, p, [("a", "b")], "Inner").num_rows
     finally:
         ops.mem_set_limit(0)
+
+
+def test_operator_metrics_are_per_thread():
+    """dfgpu_metrics (MetricsSet / BaselineMetrics of a GPU node): rows, PCIe bytes, algorithmic HBM bytes, host and device time of the
+    calling thread; another thread's work does not show up"""
+    import threading
+
+    import numpy as np
+    import pyarrow as pa
+
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    n = 200_000
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64)), "v": pa.array(np.arange(n, dtype=np.int32) % 7)})
+    ops.profile_enable(True)
+    ops.metrics_reset()
+    dev = DeviceTable.from_arrow(t)
+    out = ops.filter(dev, col("v") < lit(3, pa.int32()))
+    got = out.to_arrow()
+    m = ops.metrics()
+    assert m["h2d_bytes"] == n * 12 and m["d2h_bytes"] == got.num_rows * 12
+    assert m["rows_out"] == n + got.num_rows and m["rows_in"] == n + got.num_rows   # out: the imported table + the filter's output; in: the filter's input + the exported table
+    assert m["hbm_bytes_algorithmic"] >= n * 4 + (n + got.num_rows) * 12 and m["elapsed_ns"] > 0 and m["kernel_ns"] > 0 and m["calls"] >= 3
+    seen = {}
+
+    def other():
+        ops.metrics_reset()
+        ops.filter(dev, col("v") < lit(1, pa.int32())).free()
+        seen.update(ops.metrics())
+    before = ops.metrics()
+    th = threading.Thread(target=other)
+    th.start()
+    th.join()
+    after = ops.metrics()
+    assert seen["rows_in"] == n and seen["h2d_bytes"] == 0
+    assert after["rows_in"] == before["rows_in"] and after["hbm_bytes_algorithmic"] == before["hbm_bytes_algorithmic"]
+    ops.profile_enable(False)
