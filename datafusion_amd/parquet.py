@@ -59,13 +59,30 @@ class ChunkCache:
                 return None
             self._chunks.move_to_end(key)
             self.hits += 1
-            return e[0].select([0])
+            return e[0].select(list(range(e[0].num_columns)))
 
     def put(self, key, table: DeviceTable):
         nbytes = table.nbytes()
         if self.budget <= 0 or nbytes > self.budget:
             return
         keep = table.select([0])
+        with self._lock:
+            if key in self._chunks:
+                keep.free()
+                return
+            self._chunks[key] = (keep, nbytes)
+            self.bytes += nbytes
+            while self.bytes > self.budget:
+                _, (old, b) = self._chunks.popitem(last=False)
+                old.free()
+                self.bytes -= b
+
+    def put_table(self, key, table: DeviceTable):
+        """the same for a whole multi-column table (one record batch of an IPC file)"""
+        nbytes = table.nbytes()
+        if self.budget <= 0 or nbytes > self.budget:
+            return
+        keep = table.select(list(range(table.num_columns)))
         with self._lock:
             if key in self._chunks:
                 keep.free()

@@ -140,6 +140,31 @@ class ParquetExec(ExecutionPlan):
         return f"{self.label or self.path}" + (f", projection={self.projection}" if self.projection else "")
 
 
+class ArrowIpcExec(ExecutionPlan):
+    """DataSourceExec over an ArrowSource (datasource-arrow/src/source.rs:260): an Arrow IPC file or stream scanned straight into
+    HBM (ipc.read_table: no decoding, one H2D copy per buffer, batches concatenated on the device)"""
+
+    def __init__(self, path: str, projection=None, name: str = ""):
+        self.path, self.projection, self.label = path, projection, name
+        self.metrics = {}
+
+    def project(self, columns) -> "ArrowIpcExec":
+        return ArrowIpcExec(self.path, list(columns), self.label)
+
+    def children(self):
+        return []
+
+    def with_new_children(self, children):
+        return self
+
+    def execute(self, partition=0):
+        from .ipc import read_table
+        return read_table(self.path, self.projection, stats=self.metrics)
+
+    def detail(self):
+        return f"{self.label or self.path}" + (f", projection={self.projection}" if self.projection else "")
+
+
 class _Unary(ExecutionPlan):
     def children(self):
         return [self.input]

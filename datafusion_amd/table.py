@@ -186,7 +186,10 @@ class DeviceTable:
         for i in range(self.num_columns):
             v = self.column_view(i)
             w = {INT32: 4, INT64: 8, DECIMAL128: 16, FLOAT64: 8, UINT8: 1, UINT32: 4, UINT64: 8, DATE32: 4}.get(v.field.type)
-            total += (v.length + 7) // 8 if w is None else v.length * w
+            if v.field.type == UTF8:
+                total += v.length * 24            # 64-bit offsets + an estimate of 16 bytes per string (the exact byte count lives on the device)
+            else:
+                total += (v.length + 7) // 8 if w is None else v.length * w
         return total
 
     # ------------------------------------------------------------------ zero-copy ops

@@ -183,6 +183,48 @@ def test_device_chunk_cache_serves_repeated_scans(tmp_path):
         P.CACHE = saved
 
 
+@pytest.mark.parametrize("fmt", ["file", "stream", "file_zstd"])
+def test_arrow_ipc_scan(tmp_path, fmt):
+    """ArrowSource (datasource-arrow/src/source.rs:260): IPC file / stream -> device, projection, several record batches, strings and
+    dictionaries, buffer compression; the second scan is served from the device cache; a plan over the scan gives the oracle's answer"""
+    import pyarrow.ipc as ipc
+
+    from datafusion_amd import parquet as P, physical_plan as PP
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.ipc import read_table
+    from tests import plan_oracle
+    rng = np.random.default_rng(3)
+    n = 25_000
+    t = pa.table({"k": pa.array(rng.integers(0, 1000, n)), "v": pa.array(rng.integers(0, 10**6, n).astype(np.int32), mask=rng.random(n) < 0.1),
+                  "s": pa.array([["x", "yy", None, "zzz"][i % 4] for i in range(n)], pa.string()),
+                  "d": pa.array([["a", "b", "c"][i % 3] for i in range(n)], pa.string()).dictionary_encode()})
+    path = str(tmp_path / "t.arrow")
+    opts = ipc.IpcWriteOptions(compression="zstd") if fmt == "file_zstd" else None
+    with (ipc.new_stream(path, t.schema) if fmt == "stream" else ipc.new_file(path, t.schema, options=opts)) as w:
+        for b in t.to_batches(max_chunksize=6000):
+            w.write_batch(b)
+    saved = P.CACHE
+    try:
+        P.CACHE = P.ChunkCache(budget=1 << 30)
+        stats = {}
+        got = read_table(path, ["k", "s", "v", "d"], stats=stats).to_arrow()
+        assert stats == {"record_batches": 5, "record_batches_from_cache": 0}
+        for c in ("k", "s", "v"):
+            assert got.column(c).to_pylist() == t.column(c).to_pylist(), c
+        assert got.column("d").cast(pa.string()).to_pylist() == t.column("d").cast(pa.string()).to_pylist()
+        read_table(path, ["k", "s", "v", "d"], stats=stats)
+        assert stats["record_batches_from_cache"] == 5
+        scan = PP.ArrowIpcExec(path, ["k", "v"], "t")
+        plan = PP.AggregateExec("Single", [(col("k"), "k")], [("sum", col("v"), "s"), ("count", None, "n")], PP.FilterExec(col("v") > lit(1000, pa.int32()), scan))
+        got = PP.collect(PP.GpuOffloadRule().optimize(plan)).to_arrow()
+        exp = plan_oracle.collect(PP.AggregateExec("Single", [(col("k"), "k")], [("sum", col("v"), "s"), ("count", None, "n")],
+                                                   PP.FilterExec(col("v") > lit(1000, pa.int32()), PP.MemoryExec(t.select(["k", "v"]), "t"))))
+        assert_tables_equal(got, exp, ordered=False)
+    finally:
+        P.CACHE.clear()
+        P.CACHE = saved
+
+
 def test_parquet_chunk_with_dictionary_fallback_pages(tmp_path):
     """one column chunk holding dictionary-encoded pages followed by PLAIN pages (the writer's dictionary limit was reached)"""
     from datafusion_amd.parquet import ParquetFile, read_table
