@@ -118,11 +118,18 @@ class ParquetFile:
         self.arrow_schema = self.pf.schema_arrow
         self._f = open(path, "rb")
         self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+        import numpy as np
+        self._view = np.frombuffer(self._mm, dtype=np.uint8)    # keeps the mapping's address (and the mapping) alive
+        self._base = self._view.ctypes.data
         st = os.fstat(self._f.fileno())
         self._identity = (os.path.realpath(path), st.st_mtime_ns, st.st_size)
 
     def close(self):
-        self._mm.close()
+        self._view = None
+        try:
+            self._mm.close()
+        except BufferError:      # a view of the mapping is still referenced somewhere: the mapping goes with its last reference
+            pass
         self._f.close()
 
     def _leaf(self, column: str) -> int:
@@ -153,8 +160,9 @@ class ParquetFile:
         if cc.has_dictionary_page and cc.dictionary_page_offset is not None and 0 < cc.dictionary_page_offset < start:
             start = cc.dictionary_page_offset
         nbytes = cc.total_compressed_size
-        raw = self._mm[start:start + nbytes]                    # a copy of the chunk's bytes (the shim: its fetched range)
-        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        if start < 0 or start + nbytes > len(self._mm):
+            raise DfgpuError(f"parquet: column chunk {column!r} of row group {row_group} lies outside {self.path}")
+        buf = C.c_void_p(self._base + start)                    # the chunk's bytes where the page cache maps them: no host copy
         name = column.encode()
         d = ParquetColumn()
         d.physical_type = PHYSICAL[cc.physical_type]
@@ -165,7 +173,7 @@ class ParquetFile:
         d.num_values = cc.num_values
         d.field = _target_field(self.arrow_schema.field(column).type)
         d.name = name
-        return buf, len(raw), d, (name,)
+        return buf, nbytes, d, (name,)
 
     def inspect_chunk(self, row_group: int, column: str) -> dict:
         """the host half alone (no GPU): page / run / byte counts of one chunk"""

@@ -138,7 +138,7 @@ def test_corrupt_page_headers_are_errors(tmp_path):
     outcomes = {"ok": 0, "error": 0}
     for name in ("nul", "lowcard", "d", "s"):
         buf, n, d, keep = f._chunk(0, name)
-        raw = bytes(buf)
+        raw = C.string_at(buf, n)
         positions = list(range(min(64, n))) + [int(x) for x in rng.integers(0, n, 200)]
         for pos in positions:
             mutated = bytearray(raw)
