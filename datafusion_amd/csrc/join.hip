@@ -425,6 +425,51 @@ __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int6
   }
 }
 
+// Which rows of a wave's N probe words have a match (bit `lane` of word[j]) — all that the tile counts ask.  The rank map answers
+// from the bitmap half of its entries alone (8 of 16 bytes, no prefix, no rank -> row step): two dependent loads instead of three
+// and 50 VGPRs instead of 76, and occupancy is what a latency-bound lookup is paid in (both SF100 Q3 probes: 1.48 ms against
+// 2.95 ms through lookup_words; profiles/r2_selective_probe.md).
+template <int KIND, int KT, int N>
+__device__ __forceinline__ void hit_words(const ProbeCtx& c, int64_t w0, int64_t np, uint64_t (&word)[N]) {
+  if (KIND != KIND_RANK) {
+    uint32_t m[N];
+    lookup_words<KIND, KT, N>(c, w0, np, m);
+#pragma unroll
+    for (int j = 0; j < N; j++) word[j] = ballot64(m[j] != 0);
+    return;
+  }
+  const unsigned lane = lane_id();
+  const KeyCol& k = c.pkeys.c[0];
+  uint64_t idx[N];
+  bool ok[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const int64_t p = ((w0 + j) << 6) + lane;
+    ok[j] = p < np;
+    idx[j] = load_key<KT>(k, ok[j] ? p : np - 1) - c.am_offset;
+    if (c.row_mask) ok[j] = ok[j] && ((c.row_mask[w0 + j] >> lane) & 1ull);  // filtered-out rows skip the table
+  }
+  if (k.valid) {
+    uint64_t vw[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const int64_t p = ((w0 + j) << 6) + lane;
+      vw[j] = k.valid[(p < np ? p : np - 1) >> 6];
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) ok[j] = ok[j] && ((vw[j] >> lane) & 1ull);
+  }
+  const uint64_t* tab = reinterpret_cast<const uint64_t*>(c.rank_tab);
+  uint64_t bits[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    ok[j] = ok[j] && idx[j] < c.am_size;
+    bits[j] = tab[ok[j] ? (idx[j] >> 6) * 2 : 0];
+  }
+#pragma unroll
+  for (int j = 0; j < N; j++) word[j] = ballot64(ok[j] && ((bits[j] >> (idx[j] & 63)) & 1ull));
+}
+
 // per-row output multiplicity for the probe-side part of each JoinType
 // (adjust_indices_by_join_type, joins/utils.rs:1432-1488)
 __device__ __forceinline__ uint32_t out_count(int join_type, uint32_t nmatch) {
@@ -672,24 +717,26 @@ __device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* __restrict__ ti
 
 // per-tile output row counts of the same tiling: pass 1 of the PLACED flavour.  Reads the probe keys (and the row mask)
 // only; the table words it touches (rank-map bitmap + directory, MALL-resident) are warm for pass 2.
+// `out_words` (optional): the output rows themselves, one bit per probe row — what k_join_emit_listed materialises from.
 template <int KIND, int KT, int W>
 __global__ __launch_bounds__(BLOCK) void k_join_tile_counts(ProbeCtx c, int64_t np, int invert, const uint64_t* __restrict__ row_mask,
-                                                            uint32_t* __restrict__ tile_counts) {
+                                                            uint32_t* __restrict__ tile_counts, uint64_t* __restrict__ out_words) {
   __shared__ uint32_t s_wcount[BLOCK / WAVE];
   constexpr int TILE_WORDS = W * (BLOCK / WAVE);
   const int64_t n_words = (np + 63) >> 6;
   const unsigned lane = lane_id();
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: the row mask words load as scalars
   const int64_t tile = blockIdx.x;
   const int64_t w0 = tile * TILE_WORDS + (int64_t)wv * W;
-  uint32_t m[W];
-  lookup_words<KIND, KT, W>(c, w0, np, m);
+  uint64_t hit[W];
+  hit_words<KIND, KT, W>(c, w0, np, hit);
   uint32_t wave_cnt = 0;
 #pragma unroll
   for (int j = 0; j < W; j++) {
     const int64_t p = ((w0 + j) << 6) + lane;
-    uint64_t word = ballot64(p < np && ((m[j] != 0) != (invert != 0)));
+    uint64_t word = ballot64(p < np) & (invert ? ~hit[j] : hit[j]);
     if (row_mask) word &= (w0 + j < n_words) ? row_mask[w0 + j] : 0ull;
+    if (out_words && lane == 0 && w0 + j < n_words) out_words[w0 + j] = word;
     wave_cnt += (uint32_t)__popcll(word);
   }
   if (lane == 0) s_wcount[wv] = wave_cnt;
@@ -794,6 +841,110 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
     }
     if (!ORDERED) return;
     __syncthreads();  // s_tile / s_wcount / s_prefix are reused by the next tile
+  }
+}
+
+// ---------------------------------------------------------------- the selective probe (direct-address kinds)
+// A probe that emits few of its rows is made of latency, not of bytes: in the fused kernel every tile walks key -> table ->
+// (rank -> row) -> barrier -> offset -> a load/store round trip per column with a few lanes alive, at the 5 waves per SIMD
+// that the materialising half of the kernel leaves (SF100 Q3 under its row masks: 5.4 ms for 6 GB of keys).  Split where
+// the work changes shape: k_join_tile_counts looks every key up at 50 VGPRs (key -> bitmap word) and leaves the output rows
+// as one bit per probe row next to its tile counts; after the scan, this kernel lists the set bits of 8192 probe rows in
+// LDS and gives every OUTPUT row one thread that takes the whole chain (key, rank, build row, all columns' loads in flight
+// together) and writes consecutive output rows.  The output is in probe order and allocated exactly.
+constexpr int EL_WORDS = 128;  // probe words per workgroup: 4 tiles of the counts pass
+template <int KIND, int KT>
+__global__ __launch_bounds__(BLOCK) void k_join_emit_listed(ProbeCtx c, JoinCopyCols cols, int64_t np, const uint64_t* __restrict__ out_words,
+                                                            const uint64_t* __restrict__ tile_prefix, int tiles_per_group) {
+  static_assert(EL_WORDS <= BLOCK && EL_WORDS % WAVE == 0, "one thread per word of the group");
+  __shared__ uint64_t s_word[EL_WORDS];
+  __shared__ uint32_t s_off[EL_WORDS];
+  __shared__ uint32_t s_wsum[BLOCK / WAVE];
+  __shared__ uint16_t s_row[EL_WORDS * 64];
+  const int64_t n_words = (np + 63) >> 6;
+  const int64_t w_base = (int64_t)blockIdx.x * EL_WORDS;
+  const unsigned lane = lane_id();
+  const int wv = threadIdx.x >> 6;
+  uint64_t w = 0;
+  if (threadIdx.x < EL_WORDS && w_base + threadIdx.x < n_words) w = out_words[w_base + threadIdx.x];
+  const uint32_t cnt = (uint32_t)__popcll(w);
+  const uint32_t inc = wave_inclusive_sum(cnt);
+  if (lane == 63) s_wsum[wv] = inc;
+  if (threadIdx.x < EL_WORDS) s_word[threadIdx.x] = w;
+  __syncthreads();
+  uint32_t before = 0, agg = 0;
+#pragma unroll
+  for (int i = 0; i < BLOCK / WAVE; i++) {
+    if (i < wv) before += s_wsum[i];
+    agg += s_wsum[i];
+  }
+  if (agg == 0) return;
+  if (threadIdx.x < EL_WORDS) s_off[threadIdx.x] = before + inc - cnt;
+  __syncthreads();
+  for (int i = wv; i < EL_WORDS; i += BLOCK / WAVE) {  // the listed rows, in probe order
+    const uint64_t ww = s_word[i];
+    if ((ww >> lane) & 1ull) s_row[s_off[i] + mbcnt(ww)] = (uint16_t)((i << 6) | lane);
+  }
+  __syncthreads();
+  const uint64_t out0 = tile_prefix[(int64_t)blockIdx.x * tiles_per_group];
+  const KeyCol& k = c.pkeys.c[0];
+  for (uint32_t q = threadIdx.x; q < agg; q += BLOCK) {
+    const int64_t prow = (w_base << 6) + s_row[q];
+    int64_t brow = 0;
+    uint64_t key = 0;
+    if (cols.n_build > 0 || cols.key_col >= 0) {  // (a RightAnti probe lists the rows WITHOUT a match and has no build columns)
+      key = load_key<KT>(k, prow);
+      if (cols.n_build > 0) {
+        const uint64_t idx = key - c.am_offset;
+        if (KIND == KIND_ARRAY) {
+          brow = (int64_t)c.heads[idx] - 1;
+        } else {
+          const ulonglong2 e = c.rank_tab[idx >> 6];
+          const uint32_t rank = (uint32_t)e.y + (uint32_t)__popcll(e.x & ((1ull << (idx & 63)) - 1ull));
+          brow = c.rank_perm ? (int64_t)c.rank_perm[rank] : (int64_t)rank;
+        }
+      }
+    }
+    const int64_t d = (int64_t)(out0 + q);
+#pragma unroll
+    for (int c0 = 0; c0 < MAX_JOIN_COLS; c0 += 4) {
+      if (c0 >= cols.n) continue;
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (c0 + u >= cols.n) continue;
+        int ci = c0 + u + cols.n_build;  // the probe side's columns first: their loads do not wait for the build row
+        if (ci >= cols.n) ci -= cols.n;
+        if (ci == cols.key_col) {
+          v[u].x = (uint32_t)key;
+          v[u].y = (uint32_t)(key >> 32);
+          continue;
+        }
+        const int64_t sr = ci < cols.n_build ? brow : prow;
+        switch (cols.width[ci]) {
+          case 16: v[u] = reinterpret_cast<const uint4*>(cols.src[ci])[sr]; break;
+          case 8: {
+            const uint2 t = reinterpret_cast<const uint2*>(cols.src[ci])[sr];
+            v[u].x = t.x;
+            v[u].y = t.y;
+          } break;
+          case 4: v[u].x = reinterpret_cast<const uint32_t*>(cols.src[ci])[sr]; break;
+          case 1: v[u].x = reinterpret_cast<const uint8_t*>(cols.src[ci])[sr]; break;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (c0 + u >= cols.n) continue;
+        int ci = c0 + u + cols.n_build;
+        if (ci >= cols.n) ci -= cols.n;
+        switch (cols.width[ci]) {
+          case 16: reinterpret_cast<uint4*>(cols.dst[ci])[d] = v[u]; break;
+          case 8: reinterpret_cast<uint2*>(cols.dst[ci])[d] = make_uint2(v[u].x, v[u].y); break;
+          case 4: reinterpret_cast<uint32_t*>(cols.dst[ci])[d] = v[u].x; break;
+          case 1: reinterpret_cast<uint8_t*>(cols.dst[ci])[d] = (uint8_t)v[u].x; break;
+        }
+      }
+    }
   }
 }
 
@@ -1259,7 +1410,16 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const bool use_fused = fused_ok && np > 0;
   DFGPU_CHECK(!((jt.probe_mode == 2 || jt.probe_mode == 3) && !fused_ok),
               "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
-  const int fused_mode = !want_single ? FUSED_PLACED : jt.probe_mode == 2 ? FUSED_LOOKBACK : FUSED_UNORDERED;
+  int fused_mode = !want_single ? FUSED_PLACED : jt.probe_mode == 2 ? FUSED_LOOKBACK : FUSED_UNORDERED;
+  // Few output rows expected — a FilterExec fused below the probe side, or a build side that covers little of its key range
+  // (the hit rate of foreign keys drawn from that range): counts + hit words, then k_join_emit_listed.  The counts pass
+  // knows the answer before the second kernel is chosen, so a wrong guess costs the counts pass, not the result; the
+  // output is in probe order, which every probe_mode accepts.
+  static const char* listed_env = std::getenv("DFGPU_JOIN_LISTED");  // A/B knob: 0 / 1 force the guess
+  bool listed = fused_ok && fused_mode != FUSED_LOOKBACK && (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY) &&
+                (row_mask != nullptr || (double)jt.build.nrows < 0.15 * (double)jt.am_size);
+  if (listed_env && fused_ok && fused_mode != FUSED_LOOKBACK && (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY)) listed = listed_env[0] == '1';
+  if (listed) fused_mode = FUSED_PLACED;
   // A probe-side row mask is applied in place by the at-most-one-match probes (fused, or lookup -> scan ->
   // materialise); the general pairs path needs the caller to filter first.
   const bool one_match_path = np > 0 && (probe_side_only || fast_inner);
@@ -1285,20 +1445,24 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     ctx.row_mask = row_mask;
     BufPtr state = fused_mode == FUSED_LOOKBACK ? make_zero_buf((size_t)n_tiles * 8) : nullptr;
     BufPtr ctl = make_zero_buf(sizeof(FusedCtl));
+    BufPtr out_words;
     int64_t n_alloc = np;
     if (fused_mode == FUSED_PLACED) {
       // pass 1: output rows per tile (reads the probe keys only), then the tiles' exclusive prefix
       BufPtr counts = make_buf((size_t)n_tiles * 4);
       state = make_buf((size_t)(n_tiles + 1) * 8);
+      if (listed) out_words = make_buf((size_t)n_words * 8);
       {
         ProfileScope ps("join_probe_tile_counts", key_bytes);
         with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
-          k_join_tile_counts<decltype(kd)::value, decltype(kt)::value, FUSED_W><<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(ctx, np, invert, row_mask, counts->as<uint32_t>());
+          k_join_tile_counts<decltype(kd)::value, decltype(kt)::value, FUSED_W><<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(
+              ctx, np, invert, row_mask, counts->as<uint32_t>(), out_words ? out_words->as<uint64_t>() : nullptr);
         });
         DFGPU_HIP(hipGetLastError());
       }
       scan_u32(counts->as<uint32_t>(), n_tiles, state->as<uint64_t>());
       n_alloc = (int64_t)read_u64(state->as<uint64_t>() + n_tiles);
+      listed = listed && n_alloc * 4 <= np;  // denser than guessed: the placed kernel streams better than it lists
     }
     JoinCopyCols jc{};
     jc.key_col = -1;
@@ -1343,6 +1507,13 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
         constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
         constexpr bool KR = K != KIND_HASH;  // the direct-address kinds hold the one integer key in registers
+        if constexpr (KR) {
+          if (listed) {
+            const int64_t groups = (n_words + EL_WORDS - 1) / EL_WORDS;
+            k_join_emit_listed<K, T><<<(unsigned)groups, BLOCK, 0, r.stream>>>(ctx, jc, np, out_words->as<uint64_t>(), st, (int)(EL_WORDS / tile_words));
+            return;
+          }
+        }
         if (fused_mode == FUSED_LOOKBACK) launch(k_join_probe_fused<K, T, FUSED_W, FUSED_LOOKBACK, false>);
         else if (fused_mode == FUSED_PLACED) {
           if (KR && jc.key_col >= 0) launch(k_join_probe_fused<K, T, FUSED_W, FUSED_PLACED, KR>);
@@ -1363,7 +1534,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     // state are overhead); known only now that n_out is
     if (r.profiling) {
       std::lock_guard<std::mutex> lk(r.mu);
-      r.recs.push_back(Runtime::Rec{fused_mode == FUSED_PLACED ? "join_probe_placed" : "join_probe_fused", ea, eb,
+      r.recs.push_back(Runtime::Rec{listed ? "join_probe_listed" : fused_mode == FUSED_PLACED ? "join_probe_placed" : "join_probe_fused", ea, eb,
                                     bytes_in + (n_out > 0 ? bytes_build_once : 0) + n_out * bytes_per_out});
     }
     out.nrows = n_out;

@@ -335,3 +335,74 @@ def test_radix_lds_join_many_partitions_and_skew(shape):
         exp = oracle.hash_join(left, right, [("a", "b")], jt)
         assert got.num_rows == exp.num_rows
         assert_tables_equal(got, exp)
+
+
+def _probe_paths(fn):
+    """run fn() with the library's profile on; returns (result, names of the profiled scopes that ran)"""
+    from datafusion_amd import ops
+    ops.profile_enable(True)
+    ops.profile_reset()
+    try:
+        out = fn()
+        names = set(ops.profile_stats())
+    finally:
+        ops.profile_enable(False)
+    return out, names
+
+
+@pytest.mark.parametrize("np_rows", [1, 63, 64, 65, 2047, 2049, 8191, 8192, 8193, 50_003])
+@pytest.mark.parametrize("join_type", ["Inner", "RightSemi", "RightAnti"])
+def test_selective_probe_lists_its_output_rows(np_rows, join_type):
+    """few output rows expected (a build side that covers little of its key range): counts + hit words, then one thread per listed
+    output row (join.hip k_join_emit_listed).  Sizes around the 64-row word, the 2048-row tile and the 8192-row group; output in
+    probe order under every probe_mode; the key column written from the reloaded key"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(np_rows)
+    build = pa.table({"k": pa.array(rng.permutation(100_000)[:4000] * 3 - 50_000, type=pa.int64()), "v": pa.array(np.arange(4000), type=pa.int32()),
+                      "w": pa.array(rng.integers(0, 10**9, 4000), type=pa.int64())})
+    probe = pa.table({"k2": pa.array(rng.integers(-60_000, 260_000, np_rows), type=pa.int64()),
+                      "p": pa.array(rng.integers(0, 10**9, np_rows), type=pa.int32()).cast(pa.decimal128(15, 2)),
+                      "q": pa.array(rng.integers(0, 100, np_rows).astype(np.uint8))})
+    for probe_mode in (0, 3):
+        ht = ops.JoinHashTable(DeviceTable.from_arrow(build), ["k"], probe_mode=probe_mode)
+        got, names = _probe_paths(lambda: ht.probe(DeviceTable.from_arrow(probe), ["k2"], join_type, ["w", "v"], ["q", "k2", "p"]).to_arrow())
+        exp = oracle.hash_join(build, probe, [("k", "k2")], join_type)
+        keep = ["w", "v", "q", "k2", "p"] if join_type == "Inner" else ["q", "k2", "p"]
+        assert_tables_equal(got, exp.select(keep), ordered=True)
+        if join_type != "RightAnti" and exp.num_rows:       # (the anti join emits most rows here: the counts pass sends it to the placed kernel)
+            assert "join_probe_listed" in names, names
+        ht.free()
+
+
+@pytest.mark.parametrize("table_mode", ["array_map", "rank_map"])
+@pytest.mark.parametrize("key_type", [pa.int32(), pa.int64()], ids=["i32", "i64"])
+def test_selective_probe_clustered_hits_nullable_keys_and_masks(table_mode, key_type):
+    """the listed path where a whole 8192-row group is output (ascending probe keys: the hits sit in one cluster, 32 rounds of one
+    thread per row), NULL probe keys (never a match; emitted by RightAnti), a fused FilterExec, an all-false mask, and a mask so
+    permissive that the counts pass sends the probe to the placed kernel instead"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    from tests.util import to_oracle_expr
+    rng = np.random.default_rng(5)
+    n = 120_000
+    build = pa.table({"k": pa.array(np.concatenate([np.arange(0, 9000), [99_999]]), type=key_type), "v": pa.array(rng.integers(0, 10**6, 9001), type=pa.int32())})
+    keys = np.sort(rng.integers(0, 100_000, n))          # ~9 % of the probe rows match, all of them at the front
+    probe = pa.table({"k2": pa.array(keys, type=key_type, mask=rng.random(n) < 0.03), "p": pa.array(rng.integers(0, 10**9, n), type=pa.int64()),
+                      "f": pa.array(rng.integers(0, 100, n), type=pa.int32())})
+    tm = ops.TABLE_MODES[table_mode]
+    for join_type in ("Inner", "RightSemi", "RightAnti"):
+        keep = ["v", "f", "p"] if join_type == "Inner" else ["f", "p"]     # (a nullable payload column would take the general path)
+        for pred, expect_listed in ((None, join_type != "RightAnti"), (col("f") < lit(20, pa.int32()), True), (col("f") < lit(0, pa.int32()), None),
+                                    (col("f") < lit(99, pa.int32()), None)):
+            ht = ops.JoinHashTable(DeviceTable.from_arrow(build), ["k"], probe_mode=3, table_mode=tm)
+            got, names = _probe_paths(lambda: ht.probe(DeviceTable.from_arrow(probe), ["k2"], join_type, ["v"], ["f", "p"], predicate=pred).to_arrow())
+            src = probe if pred is None else oracle.filter(probe, to_oracle_expr(pred), probe.column_names)
+            exp = oracle.hash_join(build, src, [("k", "k2")], join_type).select(keep)
+            assert_tables_equal(got, exp, ordered="join_probe_fused" not in names)    # (probe_mode 3 leaves the order to the flavour that runs)
+            if expect_listed is True:
+                assert "join_probe_listed" in names, (join_type, names)
+            ht.free()
