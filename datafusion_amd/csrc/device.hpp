@@ -13,6 +13,50 @@ constexpr int BLOCK = 256;  // 4 waves: one per SIMD
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
+// Streamed-once data: non-temporal loads and stores (`global_load / global_store ... nt`) keep it out of the caches'
+// replacement order.  What was measured (profiles/r2_streaming_nt.md): they pay where a wave writes whole lines that nobody
+// else touches (the fused probe's all-match tiles: 9.93 -> 9.69 ms per SF100 step; the partition scatter's runs: 11.0 ->
+// 8.7 ms) and cost where neighbouring waves share output lines (FilterExec's compaction +10-15 %).  DFGPU_STREAM_NT: bit 0
+// loads, bit 1 stores (A/B builds).
+#ifndef DFGPU_STREAM_NT
+#define DFGPU_STREAM_NT 3
+#endif
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if DFGPU_STREAM_NT & 1
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void stream_store(T* p, T v) {
+#if DFGPU_STREAM_NT & 2
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+typedef unsigned stream_v4 __attribute__((ext_vector_type(4)));
+template <>
+__device__ __forceinline__ uint4 stream_load<uint4>(const uint4* p) {
+#if DFGPU_STREAM_NT & 1
+  const stream_v4 t = __builtin_nontemporal_load(reinterpret_cast<const stream_v4*>(p));
+  return make_uint4(t.x, t.y, t.z, t.w);
+#else
+  return *p;
+#endif
+}
+template <>
+__device__ __forceinline__ void stream_store<uint4>(uint4* p, uint4 v) {
+#if DFGPU_STREAM_NT & 2
+  const stream_v4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<stream_v4*>(p));
+#else
+  *p = v;
+#endif
+}
+
 // number of set bits of `mask` strictly below this lane (v_mbcnt_lo/hi)
 __device__ __forceinline__ unsigned mbcnt(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));

@@ -591,6 +591,18 @@ template <typename T>
 __device__ __forceinline__ void jcopy(const void* src, void* dst, int64_t s, int64_t d) {
   reinterpret_cast<T*>(dst)[d] = reinterpret_cast<const T*>(src)[s];
 }
+// A tile of the fused probe whose rows ALL come out writes whole, aligned lines and reads its probe columns exactly once:
+// non-temporal loads and stores (device.hpp stream_load / stream_store; bench.py's SF100 probe 9.93 -> 9.69 ms).  A tile that
+// emits part of its rows shares output lines with its neighbours — L2 merges those pieces, a non-temporal store would send
+// each piece to HBM on its own (the same stores made FilterExec's compaction 10-15 % slower) — and keeps the plain forms.
+template <typename T>
+__device__ __forceinline__ void jcopy_stream(const void* src, void* dst, int64_t s, int64_t d, bool stream_ld, bool stream_st) {
+  T v;
+  if (stream_ld) v = stream_load(reinterpret_cast<const T*>(src) + s);
+  else v = reinterpret_cast<const T*>(src)[s];
+  if (stream_st) stream_store(reinterpret_cast<T*>(dst) + d, v);
+  else reinterpret_cast<T*>(dst)[d] = v;
+}
 __global__ __launch_bounds__(BLOCK) void k_join_materialize(JoinCopyCols cols, const uint64_t* __restrict__ mask,
                                                             const uint64_t* __restrict__ prefix,
                                                             const uint32_t* __restrict__ first_match, int64_t np) {
@@ -757,6 +769,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
   __shared__ unsigned s_tile;
   __shared__ uint32_t s_wcount[BLOCK / WAVE];
   __shared__ uint64_t s_prefix;
+  __shared__ bool s_full;  // every row of the tile comes out
   constexpr int TILE_WORDS = W * (BLOCK / WAVE);
   const int64_t n_words = (np + 63) >> 6;
   const int64_t n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
@@ -806,7 +819,10 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
       } else if (lane == 0 && agg) {
         excl = atomicAdd(&ctl->total, (unsigned long long)agg);
       }
-      if (lane == 0) s_prefix = excl;
+      if (lane == 0) {
+        s_prefix = excl;
+        s_full = agg == (uint64_t)TILE_WORDS * 64;
+      }
     }
     __syncthreads();
     uint64_t wave_base = s_prefix;
@@ -815,9 +831,11 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
       if (i < wv) wave_base += s_wcount[i];
 
     // ---- materialise: probe columns stream, build columns gather; probe order inside the tile
+    const bool full = s_full;  // uniform: the two forms of a copy differ in their cache-policy bits only
     for (int cidx = 0; cidx < cols.n; cidx++) {
       const int width = cols.width[cidx];
       const bool from_build = cidx < cols.n_build;
+      const bool stream = full && !from_build;
       uint64_t ob = wave_base;
 #pragma unroll
       for (int j = 0; j < W; j++) {
@@ -832,10 +850,10 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
         }
         const int64_t s = from_build ? (int64_t)m[j] - 1 : ((w0 + j) << 6) + lane;
         switch (width) {
-          case 16: jcopy<uint4>(cols.src[cidx], cols.dst[cidx], s, d); break;
-          case 8: jcopy<uint64_t>(cols.src[cidx], cols.dst[cidx], s, d); break;
-          case 4: jcopy<uint32_t>(cols.src[cidx], cols.dst[cidx], s, d); break;
-          case 1: jcopy<uint8_t>(cols.src[cidx], cols.dst[cidx], s, d); break;
+          case 16: jcopy_stream<uint4>(cols.src[cidx], cols.dst[cidx], s, d, stream, full); break;
+          case 8: jcopy_stream<uint64_t>(cols.src[cidx], cols.dst[cidx], s, d, stream, full); break;
+          case 4: jcopy_stream<uint32_t>(cols.src[cidx], cols.dst[cidx], s, d, stream, full); break;
+          case 1: jcopy_stream<uint8_t>(cols.src[cidx], cols.dst[cidx], s, d, stream, full); break;
         }
       }
     }
