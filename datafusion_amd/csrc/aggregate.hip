@@ -162,6 +162,21 @@ __global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, 
     }
   }
 }
+// table sizing from a sample: out[0] = occupied slots, out[1] = those whose representative row lies before `early`
+__global__ __launch_bounds__(BLOCK) void k_count_slots(const uint32_t* __restrict__ slots, uint64_t capacity, uint32_t early, unsigned long long* __restrict__ out) {
+  unsigned long long a = 0, b = 0;
+  for (uint64_t s = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; s < capacity; s += (uint64_t)gridDim.x * BLOCK) {
+    const uint32_t v = slots[s];
+    a += v != 0u;
+    b += v != 0u && v - 1u < early;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (lane_id() == 0) {
+    if (a) atomicAdd(&out[0], a);
+    if (b) atomicAdd(&out[1], b);
+  }
+}
 // representatives -> row bitmask
 __global__ __launch_bounds__(BLOCK) void k_mark_reps(const uint32_t* __restrict__ slots, uint64_t capacity, unsigned long long* __restrict__ rep_mask) {
   for (uint64_t s = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; s < capacity; s += (uint64_t)gridDim.x * BLOCK) {
@@ -841,6 +856,38 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   BufPtr flag = make_zero_buf(4);
   uint64_t cap = (uint64_t)A.capacity_hint;
   const uint64_t cap_max = [&] { uint64_t c = 64; while (c < (uint64_t)total * 2) c <<= 1; return c; }();
+  // First batch: size the table before the first attempt.  An attempt at too small a capacity is the expensive way to find
+  // out — every row walks PROBE_LIMIT slots before the overflow flag stops the launch, and the table then grows 16x at a time
+  // (SF100 Q3's 3 M joined rows / 1.1 M groups: 64 K -> 1 M -> 8 M slots, 1.6 ms; sized first: one attempt).  Small inputs
+  // take the 2-slots-per-row bound (its zero-fill is microseconds); large ones intern a 1 M-row prefix into a table of their
+  // own and extrapolate: distinct keys still growing with the sample => groups ~ rows x (distinct / sample); flat between
+  // the first quarter and the whole sample => the sample has seen them all.
+  constexpr int64_t SAMPLE = 1 << 20;
+  if (G0 == 0) {
+    if (total <= 4 * SAMPLE) {
+      cap = cap_max;
+    } else if (!row_mask) {
+      BufPtr sslots = make_zero_buf((size_t)(2 * SAMPLE) * 4);
+      BufPtr cnt = make_zero_buf(16);
+      InternCtx sc = ictx;
+      sc.slots = sslots->as<uint32_t>();
+      sc.mask = 2 * SAMPLE - 1;
+      {
+        ProfileScope ps("agg_intern_sample", key_bytes / total * SAMPLE);
+        k_intern_claim<<<grid_for(SAMPLE, BLOCK), BLOCK, 0, r.stream>>>(sc, SAMPLE, flag->as<int>(), nullptr, 0);
+        k_count_slots<<<grid_for(2 * SAMPLE, BLOCK), BLOCK, 0, r.stream>>>(sc.slots, (uint64_t)(2 * SAMPLE), (uint32_t)(SAMPLE / 4), cnt->as<unsigned long long>());
+        DFGPU_HIP(hipGetLastError());
+      }
+      unsigned long long c2[2] = {0, 0};
+      d2h(c2, cnt->ptr, 16);
+      DFGPU_HIP(hipMemsetAsync(flag->ptr, 0, 4, r.stream));  // (a 2x table cannot overflow; the flag is shared with the real attempts)
+      const double d_all = (double)c2[0], d_early = (double)c2[1];
+      const double est = d_all < 1.25 * d_early ? 2.0 * d_all : d_all / (double)SAMPLE * (double)total;
+      uint64_t want = 1 << 16;
+      while ((double)want < 3.0 * est && want < cap_max) want <<= 1;
+      cap = std::max<uint64_t>(cap, want);
+    }
+  }
   if (cap > cap_max) cap = cap_max;
   for (;;) {
     R.slots = make_zero_buf(cap * 4);
@@ -1693,6 +1740,22 @@ __global__ __launch_bounds__(BLOCK) void k_run_heads(const T* __restrict__ key, 
     }
   }
 }
+// Further group keys of an ordered-input aggregation: flag[0] |= 1 when the column changes INSIDE a run of the first key —
+// then the first key does not determine it and the runs are not the groups.  (GROUP BY l_orderkey, o_orderdate, o_shippriority
+// over a join's output in probe order: the order key determines the other two, one run = one group, no hash table.)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_run_dependent(const T* __restrict__ col, const uint64_t* __restrict__ heads, int64_t n, uint32_t* __restrict__ flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (i == 0) continue;
+    const T a = col[i - 1], b = col[i];
+    bool differ;
+    if constexpr (sizeof(T) == 16) differ = a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w;
+    else differ = a != b;
+    bad |= differ && !((heads[i >> 6] >> (i & 63)) & 1ull);
+  }
+  if (__any(bad) && lane_id() == 0) atomicOr(flag, 1u);
+}
 // flag[0] |= 1 when some run spans more than "the rest of its first word + the leading rows of the next word"
 __global__ __launch_bounds__(BLOCK) void k_run_long_flag(const uint64_t* __restrict__ heads, int64_t n_words, uint32_t* __restrict__ flag) {
   bool any = false;
@@ -1955,13 +2018,22 @@ extern "C" __global__ __launch_bounds__(BLOCK) void runs_accumulate(Args a) {
 static bool agg_update_sorted_runs_jit(Aggregate& A, const Table& in, const dfgpu_expr* pred) {
   Runtime& r = rt();
   const int64_t n = in.nrows;
-  if (pred || env_int("DFGPU_JIT", 1) == 0 || env_int("DFGPU_AGG_RUNS", 1) == 0 || A.group_roots.size() != 1 || A.ngroups != 0) return false;
+  if (pred || env_int("DFGPU_JIT", 1) == 0 || env_int("DFGPU_AGG_RUNS", 1) == 0 || A.group_roots.empty() || A.ngroups != 0) return false;
   if (n < env_int("DFGPU_JIT_MIN_ROWS", 1 << 22) || n >= 0xFFFFFFFFll) return false;
   int key_col = -1;
   if (!is_plain_column(A.group_nodes[0], A.group_roots[0], &key_col) || key_col < 0 || key_col >= (int)in.cols.size()) return false;
   const Column& kcol = in.cols[(size_t)key_col];
   const dfgpu_field kf = kcol.field;
   if (kcol.validity || !(kf.type == DFGPU_INT32 || kf.type == DFGPU_INT64 || kf.type == DFGPU_DATE32 || kf.type == DFGPU_UINT32 || kf.type == DFGPU_UINT8)) return false;
+  // further group keys: plain non-NULL fixed-width columns that the first key determines (checked against the run heads below)
+  std::vector<int> more_keys;
+  for (size_t g = 1; g < A.group_roots.size(); g++) {
+    int c = -1;
+    if (!is_plain_column(A.group_nodes[g], A.group_roots[g], &c) || c < 0 || c >= (int)in.cols.size()) return false;
+    const Column& mc = in.cols[(size_t)c];
+    if (mc.validity || mc.field.type == DFGPU_BOOL || mc.field.type == DFGPU_UTF8) return false;
+    more_keys.push_back(c);
+  }
   if (!column_stats(const_cast<Column&>(kcol), n).nondecreasing) return false;  // cached on the (immutable) column
   // ---- compile: key + aggregate arguments
   std::string why;
@@ -2024,11 +2096,30 @@ static bool agg_update_sorted_runs_jit(Aggregate& A, const Table& in, const dfgp
   }
   BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
   scan_mask_popcounts(heads->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
-  BufPtr long_flag = make_zero_buf(4);
+  BufPtr long_flag = make_zero_buf(8);  // [0] some run needs the atomics, [1] a further key changes inside a run
   k_run_long_flag<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(heads->as<uint64_t>(), n_words, long_flag->as<uint32_t>());
+  if (!more_keys.empty()) {
+    int64_t bytes = 0;
+    for (int c : more_keys) bytes += n * type_width(in.cols[(size_t)c].field.type);
+    ProfileScope ps("agg_runs_dependent_keys", bytes);
+    const int g = grid_for(n, BLOCK * 4);
+    for (int c : more_keys) {
+      const Column& mc = in.cols[(size_t)c];
+      uint32_t* fl = long_flag->as<uint32_t>() + 1;
+      switch (type_width(mc.field.type)) {
+        case 16: k_run_dependent<uint4><<<g, BLOCK, 0, r.stream>>>((const uint4*)mc.ptr(), heads->as<uint64_t>(), n, fl); break;
+        case 8: k_run_dependent<uint64_t><<<g, BLOCK, 0, r.stream>>>((const uint64_t*)mc.ptr(), heads->as<uint64_t>(), n, fl); break;
+        case 4: k_run_dependent<uint32_t><<<g, BLOCK, 0, r.stream>>>((const uint32_t*)mc.ptr(), heads->as<uint64_t>(), n, fl); break;
+        default: k_run_dependent<uint8_t><<<g, BLOCK, 0, r.stream>>>((const uint8_t*)mc.ptr(), heads->as<uint64_t>(), n, fl); break;
+      }
+    }
+    DFGPU_HIP(hipGetLastError());
+  }
   const int64_t G = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
-  uint32_t has_long = 0;
-  d2h(&has_long, long_flag->ptr, 4);
+  uint32_t flags[2] = {0, 0};
+  d2h(flags, long_flag->ptr, 8);
+  if (flags[1]) return false;  // the runs of the first key are not the groups: the hash path
+  const uint32_t has_long = flags[0];
   // ---- from here on state is modified
   for (size_t k = 0; k < A.aggs.size(); k++) {
     AggState& a = A.aggs[k];
@@ -2066,6 +2157,13 @@ static bool agg_update_sorted_runs_jit(Aggregate& A, const Table& in, const dfgp
   Table gk;
   gk.nrows = G;
   gk.cols.push_back(std::move(kc));
+  if (!more_keys.empty()) {  // the further keys of a group = their values at its run head
+    Table heads_rows = compact_table(in, more_keys, heads->as<uint64_t>(), nullptr);
+    for (size_t g = 0; g < more_keys.size(); g++) {
+      heads_rows.cols[g].name = A.group_names[g + 1];
+      gk.cols.push_back(std::move(heads_rows.cols[g]));
+    }
+  }
   A.group_keys = std::move(gk);
   A.ngroups = G;
   DFGPU_HIP(hipStreamSynchronize(r.stream));

@@ -271,3 +271,48 @@ def test_unordered_group_key_does_not_take_the_runs_node():
             os.environ.pop(k_, None) if v is None else os.environ.__setitem__(k_, v)
     assert "agg_runs_accumulate" not in stats
     assert_agg_equal(got, oracle(t, [(col("k"), "k")], [("sum", col("d"), "sd"), ("count", None, "n")]), ordered=True)
+
+
+def _with_jit_env(fn):
+    import os
+    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT", "DFGPU_AGG_RUNS")}
+    from datafusion_amd import ops
+    try:
+        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1", "DFGPU_AGG_RUNS": "1"})
+        ops.profile_enable(True)
+        ops.profile_reset()
+        out = fn()
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return out, stats
+
+
+@pytest.mark.parametrize("dependent", [True, False], ids=["determined_by_first_key", "changes_inside_a_run"])
+def test_ordered_first_key_with_further_group_keys(dependent):
+    """GROUP BY k, a, b, c where k arrives in order (TPC-H Q3's l_orderkey, o_orderdate, o_shippriority over a join's output in
+    probe order).  When k determines the further keys, a run of k is a group and the runs node serves all of them (the further keys
+    are read at the run heads; Decimal128 / Date32 / UInt8 / Int64 columns); when a further key changes inside a run of k, the
+    dependency check sends the aggregation to the hash path.  Same groups, same first-seen order either way."""
+    from datafusion_amd.expr import col
+    rng = np.random.default_rng(11 + int(dependent))
+    lengths = np.concatenate([rng.integers(1, 9, size=400), [64, 64, 1, 300, 2, 127], rng.integers(1, 70, size=50)])
+    t = _runs_table(rng, lengths)
+    k = t.column("k").to_numpy()
+    a = (k * 7 + 3).astype(np.int32)                       # functions of k
+    b = (np.abs(k) % 5).astype(np.uint8)
+    c = k * 1000 + 17
+    if not dependent:
+        pos = int(np.flatnonzero(np.diff(k) == 0)[len(k) // 7])   # a row inside a run
+        b = b.copy()
+        b[pos + 1] = (b[pos + 1] + 1) % 5
+    t = t.append_column("a", pa.array(a, type=pa.int32()).cast(pa.date32())).append_column("b", pa.array(b)).append_column(
+        "c", pa.array(c, type=pa.int64())).append_column("e", pa.array(a, type=pa.int32()).cast(pa.decimal128(15, 2)))
+    gb = [(col("k"), "k"), (col("a"), "a"), (col("b"), "b"), (col("c"), "c"), (col("e"), "e")]
+    aggs = [("sum", col("d") * col("d"), "sdd"), ("count", None, "n"), ("min", col("j"), "mn"), ("avg", col("i"), "ai")]
+    (got, _), stats = _with_jit_env(lambda: gpu(t, gb, aggs))
+    assert ("agg_runs_accumulate" in stats) == dependent, sorted(stats)
+    assert "agg_runs_dependent_keys" in stats
+    assert_agg_equal(got, oracle(t, gb, aggs), ordered=True)
