@@ -388,8 +388,15 @@ def main():
     args = ap.parse_args()
     rank, world, _local, dist = setup_dist(args)
     line = run_join(args, rank, world, dist) if args.workload == "join" else run_query(args, rank, world, dist)
+    # the JSON line is the LAST thing on stdout: whatever native libraries buffered in C stdio (RCCL prints its version banner
+    # there) leaves every rank's buffer first
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if dist is not None:
+        dist.barrier()
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         sys.stdout.flush()

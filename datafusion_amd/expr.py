@@ -78,6 +78,34 @@ class Literal(PhysicalExpr):
         return f"{self.value}:{self.type}"
 
 
+class ScalarSubqueryResults(list):
+    """the container a ScalarSubqueryExec fills and the ScalarSubqueryExprs of its main plan read by index
+    (expr/src/physical_planning_context.rs ScalarSubqueryResults)"""
+    PENDING = object()
+
+    def __init__(self, n: int = 1):
+        super().__init__([ScalarSubqueryResults.PENDING] * n)
+
+
+class ScalarSubqueryExpr(Literal):
+    """physical-expr/src/scalar_subquery.rs ScalarSubqueryExpr: the value of an uncorrelated scalar subquery — a literal whose
+    value arrives when the ScalarSubqueryExec above the plan has run the subquery (reading it earlier is an error, as in the
+    reference)."""
+
+    def __init__(self, results: ScalarSubqueryResults, index: int, type_: pa.DataType):
+        self.results, self.index, self.type = results, index, type_
+
+    @property
+    def value(self):
+        v = self.results[self.index]
+        if v is ScalarSubqueryResults.PENDING:
+            raise RuntimeError(f"scalar subquery {self.index} has not been executed yet (no ScalarSubqueryExec above this plan?)")
+        return v
+
+    def __repr__(self):
+        return f"scalar_subquery(<{'pending' if self.results[self.index] is ScalarSubqueryResults.PENDING else self.results[self.index]}>)"
+
+
 class CastExpr(PhysicalExpr):
     def __init__(self, expr: PhysicalExpr, cast_type: pa.DataType):
         self.expr, self.cast_type = expr, cast_type

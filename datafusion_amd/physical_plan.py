@@ -450,6 +450,34 @@ class SortExec(_Unary):
 
 
 # ------------------------------------------------------------------------------ fused GPU nodes
+class ScalarSubqueryExec(ExecutionPlan):
+    """physical-plan/src/scalar_subquery.rs:85 — a pass-through over its main input that first runs every (uncorrelated) scalar
+    subquery exactly once and stores its value where the ScalarSubqueryExprs of the main plan read it.  A subquery returns zero
+    rows (NULL) or one; more is the reference's "Scalar subquery returned more than one row" error."""
+
+    def __init__(self, input: ExecutionPlan, subqueries, results):
+        self.input, self.subqueries, self.results = input, list(subqueries), results   # subqueries: [(plan, index)]
+
+    def children(self):
+        return [self.input] + [p for p, _ in self.subqueries]
+
+    def with_new_children(self, c):
+        return ScalarSubqueryExec(c[0], [(p, i) for p, (_, i) in zip(c[1:], self.subqueries)], self.results)
+
+    def execute(self, partition=0):
+        for plan, index in self.subqueries:
+            t, owned = self._run_child(plan)
+            if t.num_rows > 1:
+                raise _lib.DfgpuError("Scalar subquery returned more than one row")
+            self.results[index] = None if t.num_rows == 0 else t.select([0]).to_arrow().column(0)[0].as_py()
+            if owned:
+                t.free()
+        return self._pass_through(self.input)
+
+    def detail(self):
+        return f"subqueries={len(self.subqueries)}"
+
+
 class GpuFusedAggregateExec(_Unary):
     """FilterExec + ProjectionExec + AggregateExec as one node: predicate, inlined argument expressions and
     accumulation in a single pass over the input's referenced columns (dfgpu_agg_update_filtered; the kernel is

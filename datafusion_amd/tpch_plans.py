@@ -264,6 +264,40 @@ def q17_plan(lineitem, part):
     return P.ProjectionExec([(col("sum(lineitem.l_extendedprice)").cast(f64) / lit(7.0, f64), "avg_yearly")], fin)
 
 
+# ----------------------------------------------------------------------------------------- Q11
+def q11_plan(partsupp, supplier, nation):
+    """q11.slt.part:75-108: partsupp (build) x supplier, LeftSemi against the GERMANY row of nation, SUM(ps_supplycost *
+    CAST(ps_availqty AS Decimal128(10, 0))) per part, HAVING it above 0.0001 of the same sum over all parts — an uncorrelated scalar
+    subquery: ScalarSubqueryExec runs it first, the FilterExec reads it as CAST(CAST(sum AS Float64) * 0.0001 AS Decimal128(38, 15))"""
+    from .expr import ScalarSubqueryExpr, ScalarSubqueryResults
+    f64, d38 = pa.float64(), pa.decimal128(38, 15)
+    name = "sum(partsupp.ps_supplycost * partsupp.ps_availqty)"
+    value = col("ps_supplycost") * col("ps_availqty").cast(pa.decimal128(10, 0))
+
+    def german_parts(with_partkey):
+        pcols = (["ps_partkey"] if with_partkey else []) + ["ps_availqty", "ps_supplycost"]
+        ps = _hash(_scan(partsupp, "partsupp").project((["ps_partkey"] if with_partkey else []) + ["ps_suppkey", "ps_availqty", "ps_supplycost"]), ["ps_suppkey"])
+        su = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_nationkey"]), ["s_suppkey"])
+        j = P.HashJoinExec(_cb(ps), _cb(su), [("ps_suppkey", "s_suppkey")], "Inner", projection=(pcols, ["s_nationkey"]))
+        n = _hash(_cb(P.FilterExec(col("n_name").eq(lit("GERMANY", pa.string())), _scan(nation, "nation").project(["n_nationkey", "n_name"]),
+                                   projection=["n_nationkey"])), ["n_nationkey"])
+        return P.HashJoinExec(_cb(_hash(_cb(j), ["s_nationkey"])), _cb(n), [("s_nationkey", "n_nationkey")], "LeftSemi", projection=(pcols, None))
+
+    aggs = [("sum", value, name)]
+    # the subquery: the ungrouped sum, scaled
+    sub = P.AggregateExec("Final", [], aggs, P.CoalescePartitionsExec(P.AggregateExec("Partial", [], aggs, _cb(german_parts(False)))))
+    sub = P.ProjectionExec([((col(name).cast(f64) * lit(0.0001, f64)).cast(d38), name + " * Float64(0.0001)")], sub)
+    results = ScalarSubqueryResults(1)
+    # the main plan
+    gb = [(col("ps_partkey"), "ps_partkey")]
+    partial = P.AggregateExec("Partial", gb, aggs, _cb(german_parts(True)))
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["ps_partkey"])))
+    having = P.FilterExec(col(name).cast(d38) > ScalarSubqueryExpr(results, 0, d38), final)
+    keys = [(name,) + DESC]
+    top = P.ProjectionExec([(col("ps_partkey"), "ps_partkey"), (col(name), "value")], P.SortExec(keys, _cb(having), fetch=10))
+    return P.ScalarSubqueryExec(P.SortPreservingMergeExec([("value",) + DESC], top, fetch=10), [(sub, 0)], results)
+
+
 # ------------------------------------------------------------------------------------------ Q6
 def q6_plan(lineitem):
     """q6.slt.part:38-43: one filter, one ungrouped SUM"""

@@ -50,6 +50,8 @@ S_NTRG_SD = (110356601, 1)
 L_SHIP_SD = (1371272478, 7)
 L_SMODE_SD = (675466456, 7)
 L_SKEY_SD = (2095021727, 7)
+PS_QTY_SD = (1671059989, 4)     # driver.c seed table: PSUPP streams advance SUPP_PER_PART draws per part row
+PS_SCST_SD = (1051288424, 4)
 
 STARTDATE_EPOCH = 8035          # 1992-01-01 as days since 1970-01-01 (dss.h STARTDATE 92001)
 O_ODATE_SPAN = 2557 - (121 + 30) - 1   # O_ODATE_MAX - O_ODATE_MIN (dss.h TOTDATE, L_SDTE_MAX, L_RDTE_MAX)
@@ -268,3 +270,21 @@ def part(sf: float, strings: str = "codes") -> pa.Table:
     return pa.table({"p_partkey": pa.array(np.arange(1, n + 1, dtype=np.int64)), "p_brand": _strings(bcode, brands, strings),
                      "p_type": _strings(ptype, PART_TYPES, strings),
                      "p_size": pa.array(size.astype(np.int32)), "p_container": _strings(cntr, CONTAINERS, strings)})
+
+
+def partsupp(sf: float) -> pa.Table:
+    """build.c mk_part, the SUPP_PER_PART = 4 partsupp rows of every part: ps_suppkey by PART_SUPP_BRIDGE (dss.h), ps_availqty =
+    RANDOM(1, 9999, PS_QTY_SD), ps_supplycost = RANDOM(100, 100000, PS_SCST_SD) cents.  (ps_comment is text and not generated.)
+    Pinned by the SF0.1 answer of Q11 (sqllogictest/test_files/tpch/answers/q11.slt.part: all ten rows, to the cent).  The one
+    row of core/tests/tpch-csv/partsupp.csv (`67310,7311,100,993.49`) agrees in its supplier key only — like the part.csv row it
+    does not come from this dbgen (tests/test_dbgen_golden.py)."""
+    n = counts(sf)["part"]
+    tot_scnt = n // 20                                   # suppliers: tdefs[SUPP].base * scale
+    part_of = np.repeat(np.arange(n, dtype=np.int64), SUPP_PER_PART)
+    s_idx = np.tile(np.arange(SUPP_PER_PART, dtype=np.int64), n)
+    p = part_of + 1
+    suppkey = (p + s_idx * (tot_scnt // SUPP_PER_PART + (p - 1) // tot_scnt)) % tot_scnt + 1
+    qty = _draw_lines(PS_QTY_SD, part_of, s_idx, n, 1, 9999)
+    cost = _draw_lines(PS_SCST_SD, part_of, s_idx, n, 100, 100000)
+    return pa.table({"ps_partkey": pa.array(p), "ps_suppkey": pa.array(suppkey), "ps_availqty": pa.array(qty.astype(np.int32)),
+                     "ps_supplycost": _decimal(cost)})

@@ -269,6 +269,12 @@ def run(plan) -> Rel:
     if isinstance(plan, P.SortExec):
         rel = run(plan.input)
         return Rel(oracle.sort(rel.table, plan.expr, plan.fetch), rel.dicts)
+    if isinstance(plan, P.ScalarSubqueryExec):   # scalar_subquery.rs:85: the subqueries first, each exactly once
+        for sub, index in plan.subqueries:
+            t = decode(run(sub))
+            assert t.num_rows <= 1, "Scalar subquery returned more than one row"
+            plan.results[index] = None if t.num_rows == 0 else t.column(0)[0].as_py()
+        return run(plan.input)
     raise TypeError(f"no oracle interpretation of {plan.name()}")
 
 

@@ -73,6 +73,19 @@ def test_the_reference_part_fixture_is_not_dbgen_output():
     assert int(dbgen.retail_price(np.array([63700]))[0]) == 166370
 
 
+def test_partsupp_bridge_and_the_fixture_row():
+    """PART_SUPP_BRIDGE (dss.h): the four suppliers of part 67310 at SF1 start with 7311, the supplier key of the reference's one
+    partsupp.csv row (`67310,7311,100,993.49`); that row's quantity and cost are not this dbgen's draws (the generated ones are
+    pinned by Q11's answer, tests/test_tpch_answers.py) — like the part.csv row above"""
+    from oracle import dbgen
+    import pyarrow.compute as pc
+    t = dbgen.partsupp(1.0)
+    assert t.num_rows == 800_000
+    rows = t.filter(pc.equal(t.column("ps_partkey"), 67310)).to_pylist()
+    assert [r["ps_suppkey"] for r in rows] == [7311, 9817, 2323, 4829]
+    assert all(1 <= r["ps_availqty"] <= 9999 and 1 <= r["ps_supplycost"] <= 1000 for r in rows)
+
+
 def test_cardinalities_and_scaling():
     from oracle import dbgen
     assert dbgen.counts(0.1) == dict(customer=15000, orders=150000, part=20000)
