@@ -66,6 +66,13 @@ static dfgpu_field node_type(const dfgpu_expr& e, int idx, const Table& in) {
       DFGPU_CHECK(node_type(e, n.left, in).type == DFGPU_DATE32, "date_part: the GPU path takes a Date32 argument");
       DFGPU_CHECK(n.column >= DFGPU_DATE_PART_YEAR && n.column <= DFGPU_DATE_PART_DAY, "date_part: the GPU path extracts YEAR, MONTH or DAY");
       return mkfield(DFGPU_INT32);
+    case DFGPU_EXPR_SUBSTR: {
+      // a Utf8 column stays Utf8; a dictionary-encoded column keeps its index type (eval_node checks that it IS one)
+      dfgpu_field t = node_type(e, n.left, in);
+      DFGPU_CHECK(t.type == DFGPU_UTF8 || t.type == DFGPU_INT32 || t.type == DFGPU_UINT32 || t.type == DFGPU_UINT8 || t.type == DFGPU_INT64 || t.type == DFGPU_UINT64,
+                  "substr: the argument must be a string column (Utf8 or dictionary-encoded)");
+      return t;
+    }
     case DFGPU_EXPR_EQ: case DFGPU_EXPR_NE: case DFGPU_EXPR_LT: case DFGPU_EXPR_LE: case DFGPU_EXPR_GT: case DFGPU_EXPR_GE:
     case DFGPU_EXPR_AND: case DFGPU_EXPR_OR: case DFGPU_EXPR_NOT: case DFGPU_EXPR_IS_NULL: case DFGPU_EXPR_IS_NOT_NULL:
     case DFGPU_EXPR_LIKE: case DFGPU_EXPR_ILIKE:
@@ -717,6 +724,15 @@ static Datum eval_node(const dfgpu_expr& e, int idx, const Table& in) {
       }
       return o;
     }
+    case DFGPU_EXPR_SUBSTR: {
+      Datum a = eval_node(e, n.left, in);
+      DFGPU_CHECK(!a.scalar, "substr of a literal is folded by the planner");
+      DFGPU_CHECK(a.col.dict || a.col.field.type == DFGPU_UTF8, "substr: the argument must be a string column (Utf8 or dictionary-encoded)");
+      Datum o;
+      o.col = substr_column(a.col, (int64_t)n.column, n.is_null == 0, (int64_t)n.lit_lo);
+      o.col.name.clear();
+      return o;
+    }
     case DFGPU_EXPR_NOT: {
       Datum a = to_bool_array(eval_node(e, n.left, in), nrows);
       DFGPU_CHECK(a.col.field.type == DFGPU_BOOL, "NOT operand must be Boolean");
@@ -746,6 +762,25 @@ static Datum eval_node(const dfgpu_expr& e, int idx, const Table& in) {
     default: {
       Datum a = eval_node(e, n.left, in);
       Datum b = eval_node(e, n.right, in);
+      // `dictionary-encoded column = 'literal'`: the literal becomes the index of that string in the column's dictionary (an
+      // index no row holds when the string is absent) — what a caller does beforehand for a plain column reference
+      // (dfgpu_table_dictionary_lookup) and cannot do for a computed column such as substr(c_phone, 1, 2)
+      if (n.op == DFGPU_EXPR_EQ || n.op == DFGPU_EXPR_NE) {
+        Datum* colside = (!a.scalar && a.col.dict && b.scalar && b.col.field.type == DFGPU_UTF8) ? &a : (!b.scalar && b.col.dict && a.scalar && a.col.field.type == DFGPU_UTF8) ? &b : nullptr;
+        if (colside) {
+          Datum& lit = colside == &a ? b : a;
+          const DictValues& dv = *colside->col.dict;
+          i128 code = (i128)dv.values.size();
+          for (size_t k = 0; k < dv.values.size() && !lit.scalar_null; k++)
+            if (dv.valid[k] && dv.values[k] == lit.str) {
+              code = (i128)k;
+              break;
+            }
+          DFGPU_CHECK(type_width(colside->col.field.type) > 1 || code <= 255, "the dictionary index type cannot hold the marker of an absent string");
+          Datum bound = make_scalar(colside->col.field, code, lit.scalar_null);
+          return colside == &a ? eval_binary(n, a, bound, nrows) : eval_binary(n, bound, b, nrows);
+        }
+      }
       if (n.op == DFGPU_EXPR_LIKE || n.op == DFGPU_EXPR_ILIKE || a.col.field.type == DFGPU_UTF8 || b.col.field.type == DFGPU_UTF8)
         return string_binary(n.op, a, b, nrows);
       return eval_binary(n, a, b, nrows);

@@ -277,6 +277,8 @@ inline const int64_t* str_offsets(const Column& c) { return c.offsets ? c.offset
 Column alloc_string_column(const Column& like, int64_t n);
 // take: out[i] = in[idx[i]]; idx < 0 -> NULL
 Column gather_strings(const Column& in, const int64_t* idx, int64_t n, bool idx_may_be_null);
+// substr(column, start, count) over a Utf8 column (device) or a dictionary-encoded one (its dictionary values, on the host)
+Column substr_column(const Column& in, int64_t start, bool has_count, int64_t count);
 // rows of `in` whose mask bit is set (prefix = exclusive popcount prefix per mask word, n_out = total)
 Column compact_strings(const Column& in, const uint64_t* mask, const uint64_t* mask_valid, const uint64_t* prefix, int64_t nrows, int64_t n_out);
 // rows [offset, offset + length) of a string column (offsets rebased to 0)

@@ -229,6 +229,11 @@ RpValue RowProgramCompiler::lower(const dfgpu_expr& e, int idx) {
       fail("LIKE is evaluated column-at-a-time");
       return literal(mk(DFGPU_BOOL), 0, 0, true);
     }
+    case DFGPU_EXPR_SUBSTR: {
+      lower(e, n.left);
+      fail("substr is evaluated column-at-a-time");
+      return literal(mk(DFGPU_INT32), 0, 0, true);
+    }
     case DFGPU_EXPR_CAST: return lower_cast(n.field, lower(e, n.left));
     case DFGPU_EXPR_NOT: {
       RpValue a = lower(e, n.left);

@@ -334,6 +334,130 @@ Column dictionary_encode(const Column& in, bool sorted) {
   return out;
 }
 
+// ------------------------------------------------------------------------------ substr
+// Characters [first, last) of a string, 0-based, in UTF-8 code points (SQL SUBSTRING / functions/src/unicode/substr.rs): start
+// is 1-based and may lie below 1, in which case the positions before the string eat into the count.
+struct SubstrSpec {
+  int64_t first;  // first character kept (0-based, >= 0)
+  int64_t last;   // one past the last character kept; INT64_MAX = to the end
+};
+static SubstrSpec substr_spec(int64_t start, bool has_count, int64_t count) {
+  DFGPU_CHECK(!has_count || count >= 0, "negative substring length not allowed: substr(<str>, " + std::to_string(start) + ", " + std::to_string(count) + ")");
+  SubstrSpec sp;
+  sp.first = start > 1 ? start - 1 : 0;
+  sp.last = INT64_MAX;
+  if (has_count) {
+    const __int128 end = (__int128)start - 1 + count;  // exclusive, 0-based
+    sp.last = end < 0 ? 0 : end > (__int128)INT64_MAX ? INT64_MAX : (int64_t)end;
+  }
+  if (sp.last < sp.first) sp.last = sp.first;
+  return sp;
+}
+// byte range of the characters [first, last) of the `len` bytes at p
+__host__ __device__ inline void substr_bytes(const uint8_t* p, int64_t len, SubstrSpec sp, int64_t& b0, int64_t& b1) {
+  int64_t ch = 0, k = 0;
+  b0 = len;
+  b1 = len;
+  bool have0 = false;
+  for (; k < len; k++) {
+    if ((p[k] & 0xC0) != 0x80) {  // a character starts here
+      if (!have0 && ch == sp.first) { b0 = k; have0 = true; }
+      if (ch == sp.last) { b1 = k; break; }
+      ch++;
+    }
+  }
+  if (!have0) b0 = b1 = len;  // the string is shorter than `first` characters
+  if (b1 < b0) b1 = b0;
+}
+__global__ __launch_bounds__(BLOCK) void k_substr_lengths(const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ valid, int64_t n,
+                                                          SubstrSpec sp, uint32_t* __restrict__ len, uint32_t* __restrict__ begin) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    int64_t b0 = 0, b1 = 0;
+    if (!valid || bit_at(valid, i)) substr_bytes(bytes + off[i], off[i + 1] - off[i], sp, b0, b1);
+    len[i] = (uint32_t)(b1 - b0);
+    begin[i] = (uint32_t)b0;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_substr_copy(const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ begin, int64_t n,
+                                                       const uint64_t* __restrict__ new_off, uint8_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t len = (int64_t)(new_off[i + 1] - new_off[i]);
+    const uint8_t* src = bytes + off[i] + begin[i];
+    uint8_t* dst = out + new_off[i];
+    for (int64_t k = 0; k < len; k++) dst[k] = src[k];
+  }
+}
+
+Column substr_column(const Column& in, int64_t start, bool has_count, int64_t count) {
+  Runtime& r = rt();
+  const SubstrSpec sp = substr_spec(start, has_count, count);
+  if (in.dict) {
+    // dictionary-encoded: the function runs over the dictionary's values on the host; the indices are re-pointed at the
+    // ascending dictionary of the distinct results
+    auto mapped = std::make_shared<DictValues>(*in.dict);
+    std::vector<std::string> distinct;
+    bool any_null = false;
+    for (size_t k = 0; k < mapped->values.size(); k++) {
+      if (!mapped->valid[k]) {
+        any_null = true;
+        continue;
+      }
+      const std::string& v = in.dict->values[k];
+      int64_t b0, b1;
+      substr_bytes(reinterpret_cast<const uint8_t*>(v.data()), (int64_t)v.size(), sp, b0, b1);
+      mapped->values[k] = v.substr((size_t)b0, (size_t)(b1 - b0));
+      distinct.push_back(mapped->values[k]);
+    }
+    mapped->sorted = false;
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    auto target = std::make_shared<DictValues>();
+    target->index_format = in.dict->index_format;
+    target->value_format = in.dict->value_format;
+    target->values = std::move(distinct);
+    target->valid.assign(target->values.size(), 1);
+    if (any_null) {
+      target->values.push_back(std::string());
+      target->valid.push_back(0);
+    }
+    target->sorted = !any_null;
+    Column tmp = in;
+    tmp.dict = mapped;
+    if (same_dictionary(mapped, target)) {
+      tmp.dict = target;
+      return tmp;
+    }
+    return remap_to_dictionary(tmp, target);
+  }
+  DFGPU_CHECK(in.field.type == DFGPU_UTF8 && (in.offsets || in.length == 0), "substr: the argument is neither a Utf8 column nor a dictionary-encoded string column");
+  const int64_t n = in.length;
+  Column out = alloc_string_column(in, n);
+  out.validity = in.validity;
+  out.null_count = in.null_count;
+  if (n == 0) {
+    DFGPU_HIP(hipMemsetAsync(out.offsets->ptr, 0, 8, r.stream));
+    out.data = make_buf(16);
+    return out;
+  }
+  BufPtr len = make_buf((size_t)n * 4 + 16), begin = make_buf((size_t)n * 4 + 16);
+  const int g = grid_for(n, BLOCK);
+  {
+    ProfileScope ps("substr_lengths", n * 24);
+    k_substr_lengths<<<g, BLOCK, 0, r.stream>>>(str_offsets(in), (const uint8_t*)in.ptr(), in.valid_words(), n, sp, len->as<uint32_t>(), begin->as<uint32_t>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  scan_u32(len->as<uint32_t>(), n, out.offsets->as<uint64_t>());
+  const int64_t total = (int64_t)read_u64(out.offsets->as<uint64_t>() + n);
+  out.data = make_buf((size_t)total + 16);
+  {
+    ProfileScope ps("substr_bytes", 2 * total + n * 20);
+    k_substr_copy<<<g, BLOCK, 0, r.stream>>>(str_offsets(in), (const uint8_t*)in.ptr(), begin->as<uint32_t>(), n, out.offsets->as<uint64_t>(), (uint8_t*)out.data->ptr);
+    DFGPU_HIP(hipGetLastError());
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // `len` / `begin` are released on return
+  return out;
+}
+
 // ------------------------------------------------------------------------------ comparisons / LIKE
 constexpr int STR_LIT_MAX = 256;
 struct StrLit {

@@ -25,6 +25,7 @@ OP_NOT, OP_IS_NULL, OP_IS_NOT_NULL = 32, 33, 34
 OP_CASE = 40
 OP_LIKE, OP_ILIKE = 41, 42
 OP_DATE_PART = 50
+OP_SUBSTR = 51
 _DATE_PARTS = {"year": 0, "month": 1, "day": 2}
 
 
@@ -210,6 +211,24 @@ class DatePartExpr(PhysicalExpr):
         return f"date_part({self.part.upper()}, {self.arg!r})"
 
 
+class SubstrExpr(PhysicalExpr):
+    """ScalarFunctionExpr substr(str, start[, count]) (functions/src/unicode/substr.rs; SQL SUBSTRING): characters from the 1-based
+    position `start` for `count` characters (to the end without a count) of a Utf8 or dictionary-encoded string column; the result
+    is a string column of the same kind (include/dfgpu.h DFGPU_EXPR_SUBSTR)"""
+
+    def __init__(self, arg: PhysicalExpr, start: int, count: int | None = None):
+        self.arg, self.start, self.count = arg, int(start), None if count is None else int(count)
+
+    def children(self):
+        return [self.arg]
+
+    def map_children(self, f) -> "SubstrExpr":
+        return SubstrExpr(f(self.arg), self.start, self.count)
+
+    def __repr__(self):
+        return f"substr({self.arg!r}, {self.start}" + ("" if self.count is None else f", {self.count}") + ")"
+
+
 class LikeExpr(PhysicalExpr):
     """LikeExpr::new(negated, case_insensitive, expr, pattern) (expressions/like.rs): `col [NOT] LIKE 'pattern'` over a
     dictionary-encoded string column.  Bound at the boundary (bind_string_literals): the pattern is matched against the
@@ -263,6 +282,10 @@ class LikeExpr(PhysicalExpr):
 
 def date_part(part: str, arg: PhysicalExpr) -> DatePartExpr:
     return DatePartExpr(part, arg)
+
+
+def substr(arg: PhysicalExpr, start: int, count: int | None = None) -> SubstrExpr:
+    return SubstrExpr(arg, start, count)
 
 
 def case(when_then, else_expr=None) -> CaseExpr:
@@ -352,7 +375,7 @@ def bind_string_literals(expr: PhysicalExpr, table) -> PhysicalExpr:
         return bind_string_literals(expr.lowered(), table)
     if isinstance(expr, LikeExpr):
         return expr.bound(table)
-    if isinstance(expr, DatePartExpr):
+    if isinstance(expr, (DatePartExpr, SubstrExpr)):
         return expr.map_children(lambda e: bind_string_literals(e, table))
     return expr
 
@@ -447,6 +470,15 @@ def lower(expr: PhysicalExpr, column_names, table=None) -> LoweredExpr:
             n.left = emit(e.arg)
             n.op = OP_DATE_PART
             n.column = _DATE_PARTS[e.part]
+        elif isinstance(e, SubstrExpr):
+            n.left = emit(e.arg)
+            n.op = OP_SUBSTR
+            n.column = e.start
+            if e.count is None:
+                n.is_null = 1
+            else:
+                n.lit_lo = e.count & 0xFFFFFFFFFFFFFFFF
+                n.lit_hi = 0xFFFFFFFFFFFFFFFF if e.count < 0 else 0
         elif isinstance(e, LikeExpr):
             # over a Utf8 column in HBM (a dictionary-encoded column was rewritten by LikeExpr.bound before this point)
             n.left = emit(e.expr)

@@ -21,7 +21,7 @@ per-operator GPU node):
 from __future__ import annotations
 
 from . import _lib, ops
-from .expr import BinaryExpr, CaseExpr, CastExpr, Column, DatePartExpr, InListExpr, IsNotNullExpr, IsNullExpr, LikeExpr, Literal, NotExpr, PhysicalExpr
+from .expr import BinaryExpr, CaseExpr, CastExpr, Column, DatePartExpr, InListExpr, IsNotNullExpr, IsNullExpr, LikeExpr, Literal, NotExpr, PhysicalExpr, SubstrExpr
 from .table import DeviceTable
 
 
@@ -43,7 +43,7 @@ def substitute(e: PhysicalExpr, mapping: dict) -> PhysicalExpr:
         return IsNotNullExpr(substitute(e.arg, mapping))
     if isinstance(e, NotExpr):
         return NotExpr(substitute(e.arg, mapping))
-    if isinstance(e, (CaseExpr, InListExpr, DatePartExpr)):
+    if isinstance(e, (CaseExpr, InListExpr, DatePartExpr, SubstrExpr)):
         return e.map_children(lambda x: substitute(x, mapping))
     if isinstance(e, LikeExpr):
         return LikeExpr(substitute(e.expr, mapping), e.pattern, e.negated, e.case_insensitive)

@@ -298,6 +298,37 @@ def q11_plan(partsupp, supplier, nation):
     return P.ScalarSubqueryExec(P.SortPreservingMergeExec([("value",) + DESC], top, fetch=10), [(sub, 0)], results)
 
 
+# ----------------------------------------------------------------------------------------- Q22
+def q22_plan(customer, orders):
+    """q22.slt.part:76-95: customers of seven country codes (substr(c_phone, 1, 2)) whose balance is above the average positive
+    balance of those countries (uncorrelated scalar subquery) and who have no orders (LeftAnti: the filtered customers are the
+    build side), counted and summed per country code"""
+    from .expr import ScalarSubqueryExpr, ScalarSubqueryResults, substr
+    codes = [lit(c, pa.string()) for c in ("13", "31", "23", "29", "30", "18", "17")]
+    cc = substr(col("c_phone"), 1, 2)
+    d19 = pa.decimal128(19, 6)
+    # the subquery: avg(c_acctbal) over the positive balances of those countries
+    avg_name = "avg(customer.c_acctbal)"
+    a = [("avg", col("c_acctbal"), avg_name)]
+    sub_f = P.FilterExec((col("c_acctbal") > lit(Decimal("0.00"), D15_2)).and_(cc.in_list(codes)), _scan(customer, "customer").project(["c_phone", "c_acctbal"]),
+                         projection=["c_acctbal"])
+    sub = P.AggregateExec("Final", [], a, P.CoalescePartitionsExec(P.AggregateExec("Partial", [], a, _cb(sub_f))))
+    results = ScalarSubqueryResults(1)
+    # the main plan
+    f = P.FilterExec(cc.in_list(codes).and_(col("c_acctbal").cast(d19) > ScalarSubqueryExpr(results, 0, d19)),
+                     _scan(customer, "customer").project(["c_custkey", "c_phone", "c_acctbal"]))
+    anti = P.HashJoinExec(_cb(_hash(_cb(f), ["c_custkey"])), _cb(_hash(_scan(orders, "orders").project(["o_custkey"]), ["o_custkey"])),
+                          [("c_custkey", "o_custkey")], "LeftAnti", projection=(["c_phone", "c_acctbal"], None))
+    proj = P.ProjectionExec([(substr(col("c_phone"), 1, 2), "cntrycode"), (col("c_acctbal"), "c_acctbal")], _cb(anti))
+    gb = [(col("cntrycode"), "cntrycode")]
+    aggs = [("count", None, "count(Int64(1))"), ("sum", col("c_acctbal"), "sum(custsale.c_acctbal)")]
+    partial = P.AggregateExec("Partial", gb, aggs, proj)
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["cntrycode"])))
+    keys = [("cntrycode",) + ASC]
+    out = P.ProjectionExec([(col("cntrycode"), "cntrycode"), (col("count(Int64(1))"), "numcust"), (col("sum(custsale.c_acctbal)"), "totacctbal")], P.SortExec(keys, final))
+    return P.ScalarSubqueryExec(P.SortPreservingMergeExec(keys, out), [(sub, 0)], results)
+
+
 # ------------------------------------------------------------------------------------------ Q6
 def q6_plan(lineitem):
     """q6.slt.part:38-43: one filter, one ungrouped SUM"""

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 8
+#define DFGPU_ABI_VERSION 9
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -271,13 +271,19 @@ typedef enum dfgpu_expr_op {
   DFGPU_EXPR_ILIKE = 42,
   /* date_part(part, Date32) -> Int32 (functions/src/datetime/date_part.rs:165-187; the form `EXTRACT(YEAR FROM d)` plans
    * to): `column` = dfgpu_date_part, `left` = the Date32 argument */
-  DFGPU_EXPR_DATE_PART = 50
+  DFGPU_EXPR_DATE_PART = 50,
+  /* substr(string, start[, count]) (functions/src/unicode/substr.rs; SQL SUBSTRING): `left` = a DFGPU_UTF8 column or a
+   * dictionary-encoded string column, `column` = start (1-based, in characters; values below 1 eat into count as in SQL),
+   * `lit_lo` = count in characters, `is_null` != 0 = no count (to the end).  The result is a string column of the argument's
+   * kind: Utf8 bytes in HBM, or the argument's indices re-pointed at the dictionary of the substrings (ascending, distinct) —
+   * TPC-H Q22's `substr(c_phone, 1, 2)` over 15 M phone numbers becomes a 25-entry dictionary.  A negative count is an error. */
+  DFGPU_EXPR_SUBSTR = 51
 } dfgpu_expr_op;
 typedef enum dfgpu_date_part { DFGPU_DATE_PART_YEAR = 0, DFGPU_DATE_PART_MONTH = 1, DFGPU_DATE_PART_DAY = 2 } dfgpu_date_part;
 
 typedef struct dfgpu_expr_node {
   int32_t op;          /* dfgpu_expr_op */
-  int32_t column;      /* COLUMN: index into the input table; CASE: node index of the WHEN condition; DATE_PART: the part */
+  int32_t column;      /* COLUMN: index into the input table; CASE: node index of the WHEN condition; DATE_PART: the part; SUBSTR: start */
   int32_t left, right; /* child node indices, -1 = none */
   dfgpu_field field;   /* LITERAL: literal type; CAST: target type; else ignored */
   int32_t is_null;     /* LITERAL: SQL NULL */

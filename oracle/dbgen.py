@@ -50,6 +50,8 @@ S_NTRG_SD = (110356601, 1)
 L_SHIP_SD = (1371272478, 7)
 L_SMODE_SD = (675466456, 7)
 L_SKEY_SD = (2095021727, 7)
+C_PHNE_SD = (1521138112, 3)     # three draws per customer: area code, exchange, number (bm_utils.c gen_phone)
+C_ABAL_SD = (298370230, 1)
 PS_QTY_SD = (1671059989, 4)     # driver.c seed table: PSUPP streams advance SUPP_PER_PART draws per part row
 PS_SCST_SD = (1051288424, 4)
 
@@ -172,8 +174,26 @@ def tables(sf: float, strings: str = "codes"):
         c_name = pa.DictionaryArray.from_arrays(pa.array(np.arange(nc, dtype=np.int32)), pa.array(names, pa.string()))
     else:
         c_name = pa.array(np.arange(nc, dtype=np.int32))
-    customer = pa.table({"c_custkey": pa.array(np.arange(1, nc + 1, dtype=np.int64)), "c_name": c_name, "c_nationkey": pa.array(_draw(C_NTRG_SD, nc, 0, 24)),
+    c_nation = _draw(C_NTRG_SD, nc, 0, 24)
+    customer = pa.table({"c_custkey": pa.array(np.arange(1, nc + 1, dtype=np.int64)), "c_name": c_name, "c_nationkey": pa.array(c_nation),
                          "c_mktsegment": _strings(seg, DBGEN_SEGMENTS, strings)})
+    if strings != "codes":
+        # bm_utils.c gen_phone: PHONE_FMT "%02d-%03d-%03d-%04d" = country code 10 + nation, then three draws of C_PHNE_SD;
+        # build.c mk_cust: c_acctbal = RANDOM(-99999, 999999) cents.  (Q22 reads the country code and the balance; its answer pins
+        # the balance stream to the cent.)
+        row = np.arange(nc)
+        zero = np.zeros(nc, dtype=np.int64)
+        area = _draw_lines(C_PHNE_SD, row, zero, nc, 100, 999)
+        exch = _draw_lines(C_PHNE_SD, row, zero + 1, nc, 100, 999)
+        numb = _draw_lines(C_PHNE_SD, row, zero + 2, nc, 1000, 9999)
+        phones = [f"{10 + int(c):02d}-{int(a):03d}-{int(e):03d}-{int(u):04d}" for c, a, e, u in zip(c_nation, area, exch, numb)]
+        if strings == "utf8":
+            c_phone = pa.array(phones, pa.string())
+        else:
+            order = sorted(set(phones))
+            at = {v: i for i, v in enumerate(order)}
+            c_phone = pa.DictionaryArray.from_arrays(pa.array(np.array([at[v] for v in phones], dtype=np.int32)), pa.array(order, pa.string()))
+        customer = customer.append_column("c_phone", c_phone).append_column("c_acctbal", _decimal(_draw(C_ABAL_SD, nc, -99999, 999999)))
     # ---- orders (build.c mk_order)
     okey = order_keys(no)
     ckey = _draw(O_CKEY_SD, no, 1, nc)

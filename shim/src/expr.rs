@@ -101,6 +101,22 @@ pub fn lower(e: &Arc<dyn PhysicalExpr>, schema: &Schema, out: &mut Lowered) -> O
             n.left = out.nodes.len() as i32 - 1;
         }
     } else if let Some(f) = any.downcast_ref::<ScalarFunctionExpr>() {
+        if f.name() == "substr" {
+            // substr(string column, Int64 start [, Int64 count]) with literal positions (functions/src/unicode/substr.rs)
+            let int = |e: &Arc<dyn PhysicalExpr>| -> Option<i64> {
+                match e.as_any().downcast_ref::<Literal>()?.value() { ScalarValue::Int64(Some(v)) => Some(*v), _ => None }
+            };
+            if f.args().len() < 2 || f.args().len() > 3 { return None; }
+            n = node(DFGPU_EXPR_SUBSTR);
+            n.left = lower(&f.args()[0], schema, out)?;
+            n.column = i32::try_from(int(&f.args()[1])?).ok()?;
+            match f.args().get(2) {
+                Some(c) => { let v = int(c)?; n.lit_lo = v as u64; n.lit_hi = if v < 0 { u64::MAX } else { 0 }; }
+                None => n.is_null = 1,
+            }
+            out.nodes.push(n);
+            return Some(out.nodes.len() as i32 - 1);
+        }
         // date_part('year' | 'month' | 'day', Date32)
         if f.name() != "date_part" { return None; }
         let part = f.args()[0].as_any().downcast_ref::<Literal>()?.value().to_string().to_lowercase();

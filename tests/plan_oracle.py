@@ -116,8 +116,60 @@ def _renamed_dicts(rel: Rel, pairs):
     return {n: d for e, n in pairs for d in [_dict_of(e, rel)] if d is not None}
 
 
+def _substr(v: str, start: int, count):
+    """SQL SUBSTRING over code points (functions/src/unicode/substr.rs): 1-based start, positions below 1 eat into the count"""
+    first = max(start - 1, 0)
+    if count is None:
+        return v[first:]
+    assert count >= 0, "negative substring length not allowed"
+    return v[first:max(start - 1 + count, first)]
+
+
+def _lower_substr(rel: Rel, exprs):
+    """substr over a dictionary-encoded column, the checker's way: the function runs over the dictionary, the rows get the indices of
+    the ascending dictionary of the distinct results as a new column, and the expression becomes a reference to it"""
+    table, dicts = rel.table, dict(rel.dicts)
+
+    def lower(e):
+        nonlocal table
+        if isinstance(e, X.SubstrExpr):
+            assert isinstance(e.arg, X.Column) and e.arg.name in dicts, "the oracle's substr takes a dictionary-encoded column"
+            name = f"__substr_{e.arg.name}_{e.start}_{e.count}"
+            if name not in table.column_names:
+                values = dicts[e.arg.name]
+                mapped = [None if v is None else _substr(v, e.start, e.count) for v in values]
+                order = sorted(set(v for v in mapped if v is not None))
+                at = {v: i for i, v in enumerate(order)}
+                codes = table.column(e.arg.name).to_pylist()
+                itype = table.schema.field(e.arg.name).type
+                table = table.append_column(name, pa.array([None if c is None or mapped[c] is None else at[mapped[c]] for c in codes], itype))
+                dicts[name] = order
+            return X.Column(name)
+        if isinstance(e, (X.Column, X.Literal)):
+            return e
+        if isinstance(e, X.CastExpr):
+            return X.CastExpr(lower(e.expr), e.cast_type)
+        if isinstance(e, X.BinaryExpr):
+            return X.BinaryExpr(lower(e.left), e.op, lower(e.right))
+        if isinstance(e, X.IsNullExpr):
+            return X.IsNullExpr(lower(e.arg))
+        if isinstance(e, X.IsNotNullExpr):
+            return X.IsNotNullExpr(lower(e.arg))
+        if isinstance(e, X.NotExpr):
+            return X.NotExpr(lower(e.arg))
+        if isinstance(e, (X.CaseExpr, X.InListExpr, X.DatePartExpr)):
+            return e.map_children(lower)
+        return e
+
+    out = [lower(e) for e in exprs]
+    rel2 = Rel(table, dicts)
+    return rel2, out
+
+
 def _filter(rel: Rel, predicate, projection) -> Rel:
-    return Rel(oracle.filter(rel.table, _expr(predicate, rel), projection), rel.dicts)
+    keep = projection if projection is not None else rel.table.column_names
+    rel, (predicate,) = _lower_substr(rel, [predicate])
+    return Rel(oracle.filter(rel.table, _expr(predicate, rel), keep), rel.dicts)
 
 
 def _avg_return_types(rel: Rel, aggs) -> dict:
@@ -133,6 +185,11 @@ def _avg_return_types(rel: Rel, aggs) -> dict:
 
 def _aggregate(rel: Rel, mode, group_by, aggs, return_types=None) -> Rel:
     final = mode in ("Final", "FinalPartitioned")
+    if not final:   # (a fused node carries the projection's expressions: substr over dictionary columns is lowered first)
+        rel, low = _lower_substr(rel, [e for e, _ in group_by] + [e for _, e, _ in aggs if e is not None])
+        group_by = [(low[i], n) for i, (_, n) in enumerate(group_by)]
+        it = iter(low[len(group_by):])
+        aggs = [(f, None if e is None else next(it), n) for f, e, n in aggs]
     gb = [(None if final else _expr(e, rel), n) for e, n in group_by]
     ag = [(f, None if (e is None or final) else _expr(e, rel), n) for f, e, n in aggs]
     out = oracle.aggregate(rel.table, gb, ag, mode, return_types=return_types)
@@ -244,7 +301,9 @@ def run(plan) -> Rel:
         return _filter(run(plan.input), plan.predicate, plan.projection)
     if isinstance(plan, P.ProjectionExec):
         rel = run(plan.input)
-        return Rel(oracle.project(rel.table, [(_expr(e, rel), n) for e, n in plan.exprs]), _renamed_dicts(rel, plan.exprs))
+        rel, lowered = _lower_substr(rel, [e for e, _ in plan.exprs])
+        pairs = [(e, n) for e, (_, n) in zip(lowered, plan.exprs)]
+        return Rel(oracle.project(rel.table, [(_expr(e, rel), n) for e, n in pairs]), _renamed_dicts(rel, pairs))
     if isinstance(plan, P.GpuHashJoinExec):
         probe = _filter(run(plan.right), plan.probe_predicate, None)
         return _join(plan, run(plan.left), probe)

@@ -191,3 +191,60 @@ def test_slice_of_nullable_boolean_and_string_columns():
         want = t.slice(off, ln)
         for c in t.column_names:
             assert got.column(c).to_pylist() == want.column(c).to_pylist(), (off, ln, c)
+
+
+@pytest.mark.parametrize("start,count", [(1, 2), (1, None), (3, 4), (0, 3), (-2, 5), (-5, 2), (4, 0), (50, 3), (2, 1000)])
+def test_substr_utf8_and_dictionary_columns(start, count):
+    """substr(string, start[, count]) (functions/src/unicode/substr.rs): 1-based start in characters, positions below 1 eat into the
+    count; over a Utf8 column (device kernels, multi-byte characters, NULLs, empty strings) and over a dictionary-encoded column (the
+    dictionary of the distinct substrings, ascending), both against Python's slicing of the code points"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, substr
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(3)
+    pool = ["", "a", "ab", "13-989-741-2988", "31-768-687-3665", "żółć-gęślą", "日本語のテキスト", "x" * 70, "naïve café", "🙂🙃 ok"] + WORDS
+    s = random_strings(rng, 4000, 0.1, pool)
+    t = pa.table({"s": s, "v": pa.array(np.arange(4000))})
+
+    def want(v):
+        if v is None:
+            return None
+        first = max(start - 1, 0)
+        return v[first:] if count is None else v[first:max(start - 1 + count, first)]
+    exp = [want(v) for v in s.to_pylist()]
+    got = ops.project(DeviceTable.from_arrow(t), [(substr(col("s"), start, count), "p"), (col("v"), "v")]).to_arrow()
+    assert got.column("p").to_pylist() == exp
+    enc = ops.project(DeviceTable.from_arrow(t).dictionary_encode(["s"]), [(substr(col("s"), start, count), "p")]).to_arrow()
+    assert pa.types.is_dictionary(enc.schema.field("p").type)
+    assert enc.column("p").cast(pa.string()).to_pylist() == exp
+    d = enc.column("p").combine_chunks().dictionary.to_pylist()
+    live = [x for x in d if x is not None]
+    assert live == sorted(set(live))                              # distinct, ascending
+
+
+def test_substr_results_compare_with_string_literals_and_group():
+    """`substr(c_phone, 1, 2) IN ('13', '31', ...)` and GROUP BY on it (TPC-H Q22): a string literal compared with a computed
+    dictionary column is bound to that column's dictionary inside the library; an absent string matches no row"""
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.expr import col, lit, substr
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(4)
+    phones = [f"{int(c):02d}-{int(a):03d}-{int(b):04d}" for c, a, b in zip(rng.integers(10, 35, 6000), rng.integers(100, 999, 6000), rng.integers(1000, 9999, 6000))]
+    t = pa.table({"phone": pa.array(phones, pa.string()), "bal": pa.array(rng.integers(-999, 9999, 6000))})
+    dev = DeviceTable.from_arrow(t).dictionary_encode(["phone"])
+    cc = substr(col("phone"), 1, 2)
+    codes = ["13", "31", "23", "99"]                                # "99" is in no row
+    f = ops.filter(dev, cc.in_list([lit(c, pa.string()) for c in codes]))
+    keep = [p[:2] in codes for p in phones]
+    assert f.num_rows == sum(keep)
+    g = ops.aggregate(ops.project(f, [(cc, "cc"), (col("bal"), "bal")]), [(col("cc"), "cc")], [("count", None, "n"), ("sum", col("bal"), "s")], "Single").to_arrow()
+    got = {r["cc"]: (r["n"], r["s"]) for r in pa.table({"cc": g.column("cc").cast(pa.string()), "n": g.column("n"), "s": g.column("s")}).to_pylist()}
+    want = {}
+    for p, b, k in zip(phones, t.column("bal").to_pylist(), keep):
+        if k:
+            n, s = want.get(p[:2], (0, 0))
+            want[p[:2]] = (n + 1, s + b)
+    assert got == want
+    assert ops.filter(dev, cc.ne(lit("99", pa.string()))).num_rows == 6000
+    with pytest.raises(_lib.DfgpuError, match="negative substring length"):
+        ops.project(dev, [(substr(col("phone"), 1, -1), "p")])
