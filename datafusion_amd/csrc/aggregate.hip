@@ -438,14 +438,38 @@ static AccPlan plan_for(int func, const dfgpu_field& t, bool merging_counts) {
         case DFGPU_UINT32: return {k, VAL_U32, false};
         case DFGPU_FLOAT64: return {k, VAL_F64_ORDERED, false};
         case DFGPU_DECIMAL128:
-          // 64-bit atomics only: exact for precision <= 18 (every TPC-H money column is Decimal128(15,2))
-          DFGPU_CHECK(t.precision <= 18, "MIN/MAX over Decimal128 with precision > 18 is not supported on the GPU path");
+          // 64-bit atomics: exact whenever the values fit in 64 bits — by type for precision <= 18 (every TPC-H money column is
+          // Decimal128(15,2)); for wider types (MAX over a SUM's Decimal128(38,4), TPC-H Q15) the update checks the values
+          // themselves on the device first (wide_minmax_values_fit) and is an error otherwise
           return {k, VAL_I128, false};  // low word sign-carrying: values fit in i64
       }
       break;
     }
   }
   throw Error("aggregate over " + type_name(t) + " is not supported on the GPU path");
+}
+
+// MIN / MAX over Decimal128 wider than 18 digits: is every (valid) value representable in 64 bits?
+static bool wide_minmax(int func, const dfgpu_field& t) {
+  return (func == DFGPU_AGG_MIN || func == DFGPU_AGG_MAX) && t.type == DFGPU_DECIMAL128 && t.precision > 18;
+}
+__global__ __launch_bounds__(BLOCK) void k_i128_fits_i64(const uint64_t* __restrict__ words, const uint64_t* __restrict__ valid, int64_t n, uint32_t* __restrict__ flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (valid && !bit_at(valid, i)) continue;
+    const int64_t lo = (int64_t)words[2 * i], hi = (int64_t)words[2 * i + 1];
+    bad |= hi != (lo >> 63);
+  }
+  if (__any(bad) && lane_id() == 0) atomicOr(flag, 1u);
+}
+static void wide_minmax_values_fit(const Column& v, const std::string& name) {
+  if (v.length == 0) return;
+  BufPtr flag = make_zero_buf(4);
+  k_i128_fits_i64<<<grid_for(v.length, BLOCK), BLOCK, 0, rt().stream>>>((const uint64_t*)v.ptr(), v.valid_words(), v.length, flag->as<uint32_t>());
+  DFGPU_HIP(hipGetLastError());
+  uint32_t bad = 0;
+  d2h(&bad, flag->ptr, 4);
+  DFGPU_CHECK(!bad, "MIN/MAX(" + name + ") over Decimal128 with precision > 18: a value does not fit in 64 bits (not supported on the GPU path)");
 }
 
 // ------------------------------------------------------------------ fused update (rowprog)
@@ -2390,6 +2414,14 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
     why = "not a raw-input update";
     return false;
   }
+  for (const AggState& a : A.aggs)
+    if (a.has_arg && (a.func == DFGPU_AGG_MIN || a.func == DFGPU_AGG_MAX)) {
+      dfgpu_expr e{a.nodes.data(), (int)a.nodes.size(), a.root};
+      if (wide_minmax(a.func, expr_type(e, in))) {
+        why = "MIN/MAX over a Decimal128 wider than 18 digits checks its values column-at-a-time";
+        return false;
+      }
+    }
   std::vector<int> small_cols;
   const bool small = small_domain_applicable(A, in, small_cols);
   const int gid_mode = ngk == 0 ? GID_NONE : small ? GID_SMALL : GID_HASH;
@@ -2630,6 +2662,7 @@ static void agg_update_unfused(Aggregate& A, const Table& in) {
       else a.in_type = fld(DFGPU_INT64);
       a.typed = true;
     }
+    if (inputs[k].has_v && wide_minmax(a.func, inputs[k].v.field)) wide_minmax_values_fit(inputs[k].v, a.name);
   }
 
   // ---- intern (GroupValues::intern)

@@ -298,6 +298,32 @@ def q11_plan(partsupp, supplier, nation):
     return P.ScalarSubqueryExec(P.SortPreservingMergeExec([("value",) + DESC], top, fetch=10), [(sub, 0)], results)
 
 
+# ----------------------------------------------------------------------------------------- Q15
+def q15_plan(supplier, lineitem):
+    """q15.slt.part:73-94: the revenue0 view (revenue per supplier over one quarter) twice — once under MAX as an uncorrelated scalar
+    subquery, once filtered to the suppliers whose revenue EQUALS it — joined to supplier (build side, string payload)"""
+    from .expr import ScalarSubqueryExpr, ScalarSubqueryResults
+    name = "sum(lineitem.l_extendedprice * Int64(1) - lineitem.l_discount)"
+    d38 = pa.decimal128(38, 4)
+
+    def revenue0():
+        pred = (col("l_shipdate") >= _d(1996, 1, 1)).and_(col("l_shipdate") < _d(1996, 4, 1))
+        f = P.FilterExec(pred, _scan(lineitem, "lineitem"), projection=["l_suppkey", "l_extendedprice", "l_discount"])
+        gb = [(col("l_suppkey"), "l_suppkey")]
+        aggs = [("sum", col("l_extendedprice") * (ONE - col("l_discount")), name)]
+        return P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(P.AggregateExec("Partial", gb, aggs, _cb(f)), ["l_suppkey"])))
+
+    mx = [("max", col("total_revenue"), "max(revenue0.total_revenue)")]
+    sub = P.AggregateExec("Final", [], mx, P.CoalescePartitionsExec(P.AggregateExec("Partial", [], mx, P.ProjectionExec([(col(name), "total_revenue")], revenue0()))))
+    results = ScalarSubqueryResults(1)
+    best = P.ProjectionExec([(col("l_suppkey"), "supplier_no"), (col(name), "total_revenue")],
+                            _cb(P.FilterExec(col(name).eq(ScalarSubqueryExpr(results, 0, d38)), revenue0())))
+    su = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_name", "s_address", "s_phone"]), ["s_suppkey"])
+    j = P.HashJoinExec(_cb(su), _cb(best), [("s_suppkey", "supplier_no")], "Inner", projection=(["s_suppkey", "s_name", "s_address", "s_phone"], ["total_revenue"]))
+    keys = [("s_suppkey",) + ASC]
+    return P.ScalarSubqueryExec(P.SortPreservingMergeExec(keys, P.SortExec(keys, _cb(j))), [(sub, 0)], results)
+
+
 # ----------------------------------------------------------------------------------------- Q22
 def q22_plan(customer, orders):
     """q22.slt.part:76-95: customers of seven country codes (substr(c_phone, 1, 2)) whose balance is above the average positive

@@ -50,6 +50,9 @@ S_NTRG_SD = (110356601, 1)
 L_SHIP_SD = (1371272478, 7)
 L_SMODE_SD = (675466456, 7)
 L_SKEY_SD = (2095021727, 7)
+S_ADDR_SD = (706178559, 9)      # one length draw + up to eight character draws (a_rnd: a draw per five characters)
+S_PHNE_SD = (884434366, 3)
+C_ADDR_SD = (881155353, 9)
 C_PHNE_SD = (1521138112, 3)     # three draws per customer: area code, exchange, number (bm_utils.c gen_phone)
 C_ABAL_SD = (298370230, 1)
 PS_QTY_SD = (1671059989, 4)     # driver.c seed table: PSUPP streams advance SUPP_PER_PART draws per part row
@@ -181,18 +184,8 @@ def tables(sf: float, strings: str = "codes"):
         # bm_utils.c gen_phone: PHONE_FMT "%02d-%03d-%03d-%04d" = country code 10 + nation, then three draws of C_PHNE_SD;
         # build.c mk_cust: c_acctbal = RANDOM(-99999, 999999) cents.  (Q22 reads the country code and the balance; its answer pins
         # the balance stream to the cent.)
-        row = np.arange(nc)
-        zero = np.zeros(nc, dtype=np.int64)
-        area = _draw_lines(C_PHNE_SD, row, zero, nc, 100, 999)
-        exch = _draw_lines(C_PHNE_SD, row, zero + 1, nc, 100, 999)
-        numb = _draw_lines(C_PHNE_SD, row, zero + 2, nc, 1000, 9999)
-        phones = [f"{10 + int(c):02d}-{int(a):03d}-{int(e):03d}-{int(u):04d}" for c, a, e, u in zip(c_nation, area, exch, numb)]
-        if strings == "utf8":
-            c_phone = pa.array(phones, pa.string())
-        else:
-            order = sorted(set(phones))
-            at = {v: i for i, v in enumerate(order)}
-            c_phone = pa.DictionaryArray.from_arrays(pa.array(np.array([at[v] for v in phones], dtype=np.int32)), pa.array(order, pa.string()))
+        c_phone = _string_column(_phones(C_PHNE_SD, c_nation), strings)
+        customer = customer.append_column("c_address", _string_column(_v_strings(C_ADDR_SD, nc, 25), strings))
         customer = customer.append_column("c_phone", c_phone).append_column("c_acctbal", _decimal(_draw(C_ABAL_SD, nc, -99999, 999999)))
     # ---- orders (build.c mk_order)
     okey = order_keys(no)
@@ -249,6 +242,51 @@ def tables(sf: float, strings: str = "codes"):
     return customer, orders, lineitem
 
 
+ALPHA_NUM = "0123456789abcdefghijklmnopqrstuvwxyz ABCDEFGHIJKLMNOPQRSTUVWXYZ,"   # bm_utils.c alpha_num (64 characters)
+
+
+def _v_strings(sd, n_rows: int, avg_len: int) -> list:
+    """bm_utils.c a_rnd behind V_STR(avg, sd): length = RANDOM(0.4 avg, 1.6 avg), then one RANDOM(0, MAX_LONG) per five
+    characters, six bits per character from the low end.  MAX_LONG - 0 + 1 overflows dbgen's 32-bit range to -2^31, so the value
+    the bits are taken from is the NEGATED draw — pinned by the five addresses the reference carries (core/tests/tpch-csv
+    customer.csv rows 2 and 3, supplier.csv rows 1 and 8136, answers/q15.slt.part supplier 677): 129 characters."""
+    lo, hi = int(avg_len * 0.4), int(avg_len * 1.6)
+    rows = np.arange(n_rows)
+    zero = np.zeros(n_rows, dtype=np.int64)
+    length = _draw_lines(sd, rows, zero, n_rows, lo, hi)
+    starts = _row_starts(sd, n_rows)
+    apow = _powers(A, 10)
+    groups = (hi + 4) // 5
+    codes = np.zeros((n_rows, groups * 5), dtype=np.int64)
+    for g in range(groups):
+        state = (starts * apow[g + 2] % np.uint64(M)).astype(np.int64)       # draw g + 1 of the row (draw 0 is the length)
+        v = (np.int64(1) << 31) - state
+        for k in range(5):
+            codes[:, g * 5 + k] = (v >> (6 * k)) & 63
+    table = np.frombuffer(ALPHA_NUM.encode(), dtype=np.uint8)
+    chars = table[codes]
+    return [bytes(chars[i, :length[i]]).decode() for i in range(n_rows)]
+
+
+def _phones(sd, nation: np.ndarray) -> list:
+    """bm_utils.c gen_phone: PHONE_FMT "%02d-%03d-%03d-%04d" = country code 10 + nation, then three draws"""
+    n = len(nation)
+    rows, zero = np.arange(n), np.zeros(n, dtype=np.int64)
+    area = _draw_lines(sd, rows, zero, n, 100, 999)
+    exch = _draw_lines(sd, rows, zero + 1, n, 100, 999)
+    numb = _draw_lines(sd, rows, zero + 2, n, 1000, 9999)
+    return [f"{10 + int(c):02d}-{int(a):03d}-{int(e):03d}-{int(u):04d}" for c, a, e, u in zip(nation, area, exch, numb)]
+
+
+def _string_column(values: list, how: str) -> pa.Array:
+    """a free-text column: plain Utf8, or dictionary-encoded over the ascending distinct values"""
+    if how == "utf8":
+        return pa.array(values, pa.string())
+    order = sorted(set(values))
+    at = {v: i for i, v in enumerate(order)}
+    return pa.DictionaryArray.from_arrays(pa.array(np.array([at[v] for v in values], dtype=np.int32)), pa.array(order, pa.string()))
+
+
 def supplier(sf: float, strings: str = "codes") -> pa.Table:
     """build.c mk_supp: key, name (S_NAME_FMT "%s%09ld") and nation"""
     ns = counts(sf)["part"] // 20
@@ -259,7 +297,11 @@ def supplier(sf: float, strings: str = "codes") -> pa.Table:
         s_name = pa.DictionaryArray.from_arrays(pa.array(np.arange(ns, dtype=np.int32)), pa.array(names, pa.string()))
     else:
         s_name = pa.array(np.arange(ns, dtype=np.int32))
-    return pa.table({"s_suppkey": pa.array(np.arange(1, ns + 1, dtype=np.int64)), "s_name": s_name, "s_nationkey": pa.array(_draw(S_NTRG_SD, ns, 0, 24))})
+    s_nation = _draw(S_NTRG_SD, ns, 0, 24)
+    t = pa.table({"s_suppkey": pa.array(np.arange(1, ns + 1, dtype=np.int64)), "s_name": s_name, "s_nationkey": pa.array(s_nation)})
+    if strings != "codes":     # mk_supp: V_STR(S_ADDR_LEN = 25, S_ADDR_SD), gen_phone(nation, S_PHNE_SD) — Q15 prints both
+        t = t.append_column("s_address", _string_column(_v_strings(S_ADDR_SD, ns, 25), strings)).append_column("s_phone", _string_column(_phones(S_PHNE_SD, s_nation), strings))
+    return t
 
 
 def nation(strings: str = "codes") -> pa.Table:

@@ -14,13 +14,13 @@ import os
 
 REF = "/root/reference/datafusion"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tpch_answers.json")
-QUERIES = [1, 3, 4, 5, 6, 7, 8, 11, 12, 14, 17, 18, 19, 21, 22]
+QUERIES = [1, 3, 4, 5, 6, 7, 8, 11, 12, 14, 15, 17, 18, 19, 21, 22]
 SAMPLE_COLUMNS = {
-    "customer": ["c_custkey", "c_nationkey", "c_phone", "c_acctbal", "c_mktsegment"],
+    "customer": ["c_custkey", "c_address", "c_nationkey", "c_phone", "c_acctbal", "c_mktsegment"],
     "orders": ["o_orderkey", "o_custkey", "o_orderstatus", "o_totalprice", "o_orderdate", "o_orderpriority", "o_shippriority"],
     "lineitem": ["l_orderkey", "l_partkey", "l_suppkey", "l_linenumber", "l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag",
                  "l_linestatus", "l_shipdate", "l_commitdate", "l_receiptdate", "l_shipinstruct", "l_shipmode"],
-    "supplier": ["s_suppkey", "s_name", "s_nationkey"],
+    "supplier": ["s_suppkey", "s_name", "s_address", "s_nationkey", "s_phone"],
     "nation": ["n_nationkey", "n_name", "n_regionkey"],
     "region": ["r_regionkey", "r_name"],
 }

@@ -141,3 +141,28 @@ def test_wrapping_i128_sum_is_order_independent():
     got, exp = gpu_agg(t, [(col("k"), "k")], aggs), oracle_agg(t, [(col("k"), "k")], aggs)
     from oracle import oracle
     assert (oracle.values_np(got.column("s")) == oracle.values_np(exp.column("s"))).all()
+
+
+def test_min_max_over_wide_decimals_check_that_values_fit():
+    """MIN / MAX over Decimal128(38, 4) (TPC-H Q15: MAX over a SUM's type): 64-bit atomics after a device-side check that every
+    value is representable in 64 bits; a value beyond that is an error, never a wrong answer"""
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    from decimal import Decimal
+    rng = np.random.default_rng(8)
+    n = 5000
+    vals = [Decimal(int(x)).scaleb(-4) for x in rng.integers(-10**17, 10**17, n)]
+    t = pa.table({"g": pa.array(rng.integers(0, 40, n)), "d": pa.array(vals, pa.decimal128(38, 4))})
+    got = ops.aggregate(DeviceTable.from_arrow(t), [(col("g"), "g")], [("max", col("d"), "mx"), ("min", col("d"), "mn")], "Single").to_arrow()
+    want = {}
+    for g, v in zip(t.column("g").to_pylist(), vals):
+        a, b = want.get(g, (v, v))
+        want[g] = (max(a, v), min(b, v))
+    assert got.schema.field("mx").type == pa.decimal128(38, 4)
+    assert {r["g"]: (r["mx"], r["mn"]) for r in got.to_pylist()} == want
+    one = ops.aggregate(DeviceTable.from_arrow(t), [], [("max", col("d"), "mx")], "Single").to_arrow()
+    assert one.column("mx")[0].as_py() == max(vals)
+    big = pa.table({"d": pa.array([Decimal(1), Decimal(2**70)], pa.decimal128(38, 4))})
+    with pytest.raises(_lib.DfgpuError, match="does not fit in 64 bits"):
+        ops.aggregate(DeviceTable.from_arrow(big), [], [("max", col("d"), "mx")], "Single")
