@@ -781,6 +781,12 @@ static Datum eval_node(const dfgpu_expr& e, int idx, const Table& in) {
           return colside == &a ? eval_binary(n, a, bound, nrows) : eval_binary(n, bound, b, nrows);
         }
       }
+      if ((n.op == DFGPU_EXPR_LIKE || n.op == DFGPU_EXPR_ILIKE) && !a.scalar && a.col.dict && b.scalar && b.col.field.type == DFGPU_UTF8) {
+        DFGPU_CHECK(!b.scalar_null, "LIKE NULL is folded by the planner");
+        Datum o;
+        o.col = dictionary_like_column(a.col, b.str, n.op == DFGPU_EXPR_ILIKE);
+        return o;
+      }
       if (n.op == DFGPU_EXPR_LIKE || n.op == DFGPU_EXPR_ILIKE || a.col.field.type == DFGPU_UTF8 || b.col.field.type == DFGPU_UTF8)
         return string_binary(n.op, a, b, nrows);
       return eval_binary(n, a, b, nrows);

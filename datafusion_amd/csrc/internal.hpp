@@ -307,6 +307,7 @@ void jit_launch(hipFunction_t fn, int grid, int block, size_t lds_bytes, void* a
 // target->values.size() (equal to no index of a column encoded with `target`) — what joining / comparing two
 // dictionary-encoded columns with different dictionaries needs.  Errors when the index type cannot hold that value.
 Column remap_to_dictionary(const Column& c, const std::shared_ptr<const DictValues>& target);
+Column dictionary_like_column(const Column& c, const std::string& pattern, bool case_insensitive);  // Boolean column: value LIKE pattern
 
 // dst bits [off, off + n) |= src bits [0, n) (src null = all ones); the destination range must start zeroed
 void bitmap_place(const uint64_t* src, int64_t off, int64_t n, uint64_t* dst);

@@ -742,6 +742,56 @@ static bool like_match(const std::string& s, const std::string& pat, bool fold_c
   return pi == pat.size();
 }
 
+}  // extern "C"
+namespace dfgpu {
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_dict_match(const T* __restrict__ codes, const uint8_t* __restrict__ match, int64_t n_match, int64_t n, uint64_t* __restrict__ out) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const int64_t i = (w << 6) + lane_id();
+    bool hit = false;
+    if (i < n) {
+      const uint64_t k = (uint64_t)codes[i];
+      hit = k < (uint64_t)n_match && match[k] != 0;
+    }
+    const uint64_t word = ballot64(hit);
+    if (lane_id() == 0) out[w] = word;
+  }
+}
+// `dictionary-encoded column LIKE pattern` when the matching indices do not form a few runs (a dictionary with one value per
+// row, TPC-H's p_name LIKE '%green%'): the pattern is matched against the dictionary's values on the host, the rows look their
+// index up in the resulting table.  NULL rows stay NULL (the column's validity).
+Column dictionary_like_column(const Column& c, const std::string& pattern, bool case_insensitive) {
+  DFGPU_CHECK(c.dict != nullptr, "LIKE: the column is not dictionary-encoded");
+  dfgpu_field bf{};
+  bf.type = DFGPU_BOOL;
+  bf.nullable = 1;
+  Column o = alloc_column(bf, "", c.length);
+  o.validity = c.validity;
+  o.null_count = c.null_count;
+  if (c.length == 0) return o;
+  std::vector<uint8_t> match(c.dict->values.size() + 1, 0);
+  for (size_t i = 0; i < c.dict->values.size(); i++) match[i] = c.dict->valid[i] && like_match(c.dict->values[i], pattern, case_insensitive) ? 1 : 0;
+  BufPtr d_match = make_buf(match.size() + 16);
+  DFGPU_HIP(hipMemcpyAsync(d_match->ptr, match.data(), match.size(), hipMemcpyHostToDevice, rt().stream));
+  DFGPU_HIP(hipStreamSynchronize(rt().stream));  // `match` is a local
+  const int64_t nd = (int64_t)c.dict->values.size();
+  const int g = grid_for((c.length + 63) / 64, BLOCK / WAVE);
+  ProfileScope ps("dictionary_like", c.length * type_width(c.field.type));
+  switch (type_width(c.field.type)) {
+    case 1: k_dict_match<uint8_t><<<g, BLOCK, 0, rt().stream>>>((const uint8_t*)c.ptr(), d_match->as<uint8_t>(), nd, c.length, o.data->as<uint64_t>()); break;
+    case 4: k_dict_match<uint32_t><<<g, BLOCK, 0, rt().stream>>>((const uint32_t*)c.ptr(), d_match->as<uint8_t>(), nd, c.length, o.data->as<uint64_t>()); break;
+    default: k_dict_match<uint64_t><<<g, BLOCK, 0, rt().stream>>>((const uint64_t*)c.ptr(), d_match->as<uint8_t>(), nd, c.length, o.data->as<uint64_t>()); break;
+  }
+  DFGPU_HIP(hipGetLastError());
+  DFGPU_HIP(hipStreamSynchronize(rt().stream));  // d_match is released on return
+  return o;
+}
+}  // namespace dfgpu
+extern "C" {
+
 int dfgpu_table_dictionary_like(dfgpu_table_t th, int column, const char* pattern, int64_t len, int case_insensitive, int64_t* out_codes, int64_t capacity,
                                 int64_t* out_n) {
   return guarded([&] {

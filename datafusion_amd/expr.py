@@ -234,7 +234,8 @@ class LikeExpr(PhysicalExpr):
     dictionary-encoded string column.  Bound at the boundary (bind_string_literals): the pattern is matched against the
     column's dictionary by the library (dfgpu_table_dictionary_like) and the predicate becomes comparisons of the index
     column with the matching indices — one `lo <= index <= hi` per contiguous run (a prefix pattern over an ascending
-    dictionary is ONE run).  NULL rows stay NULL; patterns that match more than MAX_RUNS separate runs stay on the CPU."""
+    dictionary is ONE run); a pattern that matches more than MAX_RUNS separate runs goes to the library as it is, which matches it
+    against the dictionary and lets the rows look their index up.  NULL rows stay NULL."""
     MAX_RUNS = 16
 
     def __init__(self, expr: PhysicalExpr, pattern: str, negated: bool = False, case_insensitive: bool = False):
@@ -268,7 +269,9 @@ class LikeExpr(PhysicalExpr):
         column = Column(a.name, idx)
         runs = LikeExpr.runs(table.dictionary_like(idx, self.pattern, self.case_insensitive))
         if len(runs) > self.MAX_RUNS:
-            raise ValueError(f"LIKE {self.pattern!r} matches {len(runs)} separate runs of dictionary indices: kept on the CPU")
+            # many separate runs (a dictionary with one value per row: p_name LIKE '%green%'): the library matches the pattern against
+            # the dictionary and the rows look their index up (DFGPU_EXPR_LIKE with a dictionary-encoded left operand)
+            return LikeExpr(column, self.pattern, self.negated, self.case_insensitive)
         e = None
         for lo, hi in runs:
             r = BinaryExpr(column, "=", Literal(lo, itype)) if lo == hi else \

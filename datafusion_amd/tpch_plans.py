@@ -298,6 +298,67 @@ def q11_plan(partsupp, supplier, nation):
     return P.ScalarSubqueryExec(P.SortPreservingMergeExec([("value",) + DESC], top, fetch=10), [(sub, 0)], results)
 
 
+# ------------------------------------------------------------------------------------------ Q9
+def q9_plan(part, supplier, lineitem, partsupp, orders, nation):
+    """q9.slt.part:77-104: RightSemi against the parts named LIKE '%green%', then four Inner joins in which the running result is
+    always the BUILD side (duplicate keys: l_suppkey, then the two-column (l_suppkey, l_partkey), l_orderkey, s_nationkey), profit =
+    l_extendedprice * (1 - l_discount) - ps_supplycost * l_quantity per nation and date_part(YEAR, o_orderdate), top 10"""
+    p = _hash(_cb(P.FilterExec(col("p_name").like("%green%"), _scan(part, "part").project(["p_partkey", "p_name"]), projection=["p_partkey"])), ["p_partkey"])
+    lcols = ["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount"]
+    li = _hash(_scan(lineitem, "lineitem").project(lcols), ["l_partkey"])
+    j1 = P.HashJoinExec(_cb(p), _cb(li), [("p_partkey", "l_partkey")], "RightSemi", projection=(None, lcols))
+    su = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_nationkey"]), ["s_suppkey"])
+    j2 = P.HashJoinExec(_cb(_hash(_cb(j1), ["l_suppkey"])), _cb(su), [("l_suppkey", "s_suppkey")], "Inner", projection=(lcols, ["s_nationkey"]))
+    ps = _hash(_scan(partsupp, "partsupp").project(["ps_partkey", "ps_suppkey", "ps_supplycost"]), ["ps_suppkey", "ps_partkey"])
+    j3 = P.HashJoinExec(_cb(_hash(_cb(j2), ["l_suppkey", "l_partkey"])), _cb(ps), [("l_suppkey", "ps_suppkey"), ("l_partkey", "ps_partkey")], "Inner",
+                        projection=(["l_orderkey", "l_quantity", "l_extendedprice", "l_discount", "s_nationkey"], ["ps_supplycost"]))
+    o = _hash(_scan(orders, "orders").project(["o_orderkey", "o_orderdate"]), ["o_orderkey"])
+    j4 = P.HashJoinExec(_cb(_hash(_cb(j3), ["l_orderkey"])), _cb(o), [("l_orderkey", "o_orderkey")], "Inner",
+                        projection=(["l_quantity", "l_extendedprice", "l_discount", "s_nationkey", "ps_supplycost"], ["o_orderdate"]))
+    n = _hash(_scan(nation, "nation").project(["n_nationkey", "n_name"]), ["n_nationkey"])
+    j5 = P.HashJoinExec(_cb(_hash(_cb(j4), ["s_nationkey"])), _cb(n), [("s_nationkey", "n_nationkey")], "Inner",
+                        projection=(["l_quantity", "l_extendedprice", "l_discount", "ps_supplycost", "o_orderdate"], ["n_name"]))
+    amount = col("l_extendedprice") * (ONE - col("l_discount")) - col("ps_supplycost") * col("l_quantity")
+    proj = P.ProjectionExec([(col("n_name"), "nation"), (date_part("year", col("o_orderdate")), "o_year"), (amount, "amount")], _cb(j5))
+    gb = [(col("nation"), "nation"), (col("o_year"), "o_year")]
+    aggs = [("sum", col("amount"), "sum(profit.amount)")]
+    partial = P.AggregateExec("Partial", gb, aggs, proj)
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(partial, ["nation", "o_year"])))
+    keys = [("nation",) + ASC, ("o_year",) + DESC]
+    top = P.ProjectionExec([(col("nation"), "nation"), (col("o_year"), "o_year"), (col("sum(profit.amount)"), "sum_profit")], P.SortExec(keys, final, fetch=10))
+    return P.SortPreservingMergeExec(keys, top, fetch=10)
+
+
+# ----------------------------------------------------------------------------------------- Q20
+def q20_plan(supplier, nation, partsupp, part, lineitem):
+    """q20.slt.part:84-111: suppliers of CANADA (LeftSemi against nation) that supply (LeftSemi) a part named LIKE 'forest%' whose
+    ps_availqty exceeds half of what was shipped of it by that supplier in 1994 — a LeftSemi join on (partkey, suppkey) with the
+    JoinFilter CAST(ps_availqty AS Float64) > 0.5 * sum(l_quantity)"""
+    f64 = pa.float64()
+    su = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_name", "s_address", "s_nationkey"]), ["s_nationkey"])
+    n = _hash(_cb(P.FilterExec(col("n_name").eq(lit("CANADA", pa.string())), _scan(nation, "nation").project(["n_nationkey", "n_name"]), projection=["n_nationkey"])),
+              ["n_nationkey"])
+    canada = P.HashJoinExec(_cb(su), _cb(n), [("s_nationkey", "n_nationkey")], "LeftSemi", projection=(["s_suppkey", "s_name", "s_address"], None))
+    ps = _hash(_scan(partsupp, "partsupp").project(["ps_partkey", "ps_suppkey", "ps_availqty"]), ["ps_partkey"])
+    p = _hash(_cb(P.FilterExec(col("p_name").like("forest%"), _scan(part, "part").project(["p_partkey", "p_name"]), projection=["p_partkey"])), ["p_partkey"])
+    forest = P.HashJoinExec(_cb(ps), _cb(p), [("ps_partkey", "p_partkey")], "LeftSemi")
+    pred = (col("l_shipdate") >= _d(1994, 1, 1)).and_(col("l_shipdate") < _d(1995, 1, 1))
+    lf = P.FilterExec(pred, _scan(lineitem, "lineitem").project(["l_partkey", "l_suppkey", "l_quantity", "l_shipdate"]), projection=["l_partkey", "l_suppkey", "l_quantity"])
+    gb = [(col("l_partkey"), "l_partkey"), (col("l_suppkey"), "l_suppkey")]
+    aggs = [("sum", col("l_quantity"), "sum(lineitem.l_quantity)")]
+    shipped = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(P.AggregateExec("Partial", gb, aggs, _cb(lf)), ["l_partkey", "l_suppkey"])))
+    half_name = "Float64(0.5) * sum(lineitem.l_quantity)"
+    half = P.ProjectionExec([(lit(0.5, f64) * col("sum(lineitem.l_quantity)").cast(f64), half_name), (col("l_partkey"), "l_partkey"), (col("l_suppkey"), "l_suppkey")], shipped)
+    # JoinFilter over the intermediate columns f0 = ps_availqty (Left 2), f1 = the half of the shipped quantity (Right 0)
+    jf = (col("f0").cast(f64) > col("f1"), [(2, "Left"), (0, "Right")])
+    excess = P.HashJoinExec(_cb(_hash(_cb(forest), ["ps_partkey", "ps_suppkey"])), _cb(half), [("ps_partkey", "l_partkey"), ("ps_suppkey", "l_suppkey")], "LeftSemi",
+                            projection=(["ps_suppkey"], None), filter=jf)
+    out = P.HashJoinExec(_cb(_hash(_cb(canada), ["s_suppkey"])), _cb(_hash(_cb(excess), ["ps_suppkey"])), [("s_suppkey", "ps_suppkey")], "LeftSemi",
+                         projection=(["s_name", "s_address"], None))
+    keys = [("s_name",) + ASC]
+    return P.SortPreservingMergeExec(keys, P.SortExec(keys, _cb(out)))
+
+
 # ----------------------------------------------------------------------------------------- Q15
 def q15_plan(supplier, lineitem):
     """q15.slt.part:73-94: the revenue0 view (revenue per supplier over one quarter) twice — once under MAX as an uncorrelated scalar

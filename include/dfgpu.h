@@ -265,8 +265,9 @@ typedef enum dfgpu_expr_op {
    * branches nest in ELSE; `CASE x WHEN v ...` is lowered by the caller to conditions `x = v`.  THEN and ELSE have
    * the same type (the planner's coercion). */
   DFGPU_EXPR_CASE = 40,
-  /* LikeExpr (expressions/like.rs -> arrow-string like / ilike): left = a DFGPU_UTF8 column, right = the pattern (a DFGPU_UTF8
-   * literal): `%` any run of characters, `_` one character, backslash escapes; NOT LIKE = NOT of it */
+  /* LikeExpr (expressions/like.rs -> arrow-string like / ilike): left = a DFGPU_UTF8 column or a dictionary-encoded string column
+   * (the pattern is then matched against the dictionary's values once and the rows look their index up), right = the pattern (a
+   * DFGPU_UTF8 literal): `%` any run of characters, `_` one character, backslash escapes; NOT LIKE = NOT of it */
   DFGPU_EXPR_LIKE = 41,
   DFGPU_EXPR_ILIKE = 42,
   /* date_part(part, Date32) -> Int32 (functions/src/datetime/date_part.rs:165-187; the form `EXTRACT(YEAR FROM d)` plans

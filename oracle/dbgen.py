@@ -55,6 +55,7 @@ S_PHNE_SD = (884434366, 3)
 C_ADDR_SD = (881155353, 9)
 C_PHNE_SD = (1521138112, 3)     # three draws per customer: area code, exchange, number (bm_utils.c gen_phone)
 C_ABAL_SD = (298370230, 1)
+P_NAME_SD = (709314158, 92)     # a permutation of the 92 colours per part (permute.c: one draw per position)
 PS_QTY_SD = (1671059989, 4)     # driver.c seed table: PSUPP streams advance SUPP_PER_PART draws per part row
 PS_SCST_SD = (1051288424, 4)
 
@@ -319,6 +320,35 @@ PART_TYPES = [a + " " + b + " " + c for a in ("STANDARD", "SMALL", "MEDIUM", "LA
               for b in ("ANODIZED", "BURNISHED", "PLATED", "POLISHED", "BRUSHED") for c in ("TIN", "NICKEL", "BRASS", "STEEL", "COPPER")]
 
 
+# dists.dss colors: the 92 words p_name is made of
+COLORS = ("almond antique aquamarine azure beige bisque black blanched blue blush brown burlywood burnished chartreuse chiffon chocolate coral "
+          "cornflower cornsilk cream cyan dark deep dim dodger drab firebrick floral forest frosted gainsboro ghost goldenrod green grey honeydew "
+          "hot indian ivory khaki lace lavender lawn lemon light lime linen magenta maroon medium metallic midnight mint misty moccasin navajo "
+          "navy olive orange orchid pale papaya peach peru pink plum powder puff purple red rose rosy royal saddle salmon sandy seashell sienna "
+          "sky slate smoke snow spring steel tan thistle tomato turquoise violet wheat white yellow").split()
+
+
+def part_names(n: int) -> list:
+    """build.c mk_part agg_str(&colors, 5, P_NAME_SD): the colour list is permuted afresh for every part (permute.c: position i
+    swaps with a position drawn from [i, 91]) and the first five words make the name — only the first five swaps matter.  Pinned by
+    the name the reference's part.csv row carries (part 1: "goldenrod lavender spring chocolate lace") and by Q9 / Q20."""
+    nc = len(COLORS)
+    rows = np.arange(n)
+    perm = np.tile(np.arange(nc, dtype=np.int64), (n, 1))
+    for i in range(5):
+        src = _draw_lines_wide(P_NAME_SD, rows, i, n, i, nc - 1)
+        a, b = perm[rows, i].copy(), perm[rows, src].copy()
+        perm[rows, i], perm[rows, src] = b, a
+    words = np.array(COLORS, dtype=object)
+    return [" ".join(words[perm[r, :5]]) for r in range(n)]
+
+
+def _draw_lines_wide(sd, rows: np.ndarray, call: int, n_rows: int, lo: int, hi: int) -> np.ndarray:
+    """draw number `call` (0-based) of every row from a stream with any boundary"""
+    starts = _row_starts(sd, n_rows)
+    return _unif(starts[rows] * np.uint64(pow(A, call + 1, M)) % np.uint64(M), lo, hi)
+
+
 def part(sf: float, strings: str = "codes") -> pa.Table:
     """build.c mk_part: key, brand ("Brand#MN": M = manufacturer 1..5, N = 1..5), type, size 1..50, container"""
     n = counts(sf)["part"]
@@ -329,9 +359,12 @@ def part(sf: float, strings: str = "codes") -> pa.Table:
     size = _draw(P_SIZE_SD, n, 1, 50)
     cntr = _draw(P_CNTR_SD, n, 1, 40) - 1
     ptype = _draw(P_TYPE_SD, n, 1, len(PART_TYPES)) - 1
-    return pa.table({"p_partkey": pa.array(np.arange(1, n + 1, dtype=np.int64)), "p_brand": _strings(bcode, brands, strings),
-                     "p_type": _strings(ptype, PART_TYPES, strings),
-                     "p_size": pa.array(size.astype(np.int32)), "p_container": _strings(cntr, CONTAINERS, strings)})
+    t = pa.table({"p_partkey": pa.array(np.arange(1, n + 1, dtype=np.int64)), "p_brand": _strings(bcode, brands, strings),
+                  "p_type": _strings(ptype, PART_TYPES, strings),
+                  "p_size": pa.array(size.astype(np.int32)), "p_container": _strings(cntr, CONTAINERS, strings)})
+    if strings != "codes":
+        t = t.append_column("p_name", _string_column(part_names(n), strings))
+    return t
 
 
 def partsupp(sf: float) -> pa.Table:

@@ -145,6 +145,19 @@ def _lower_substr(rel: Rel, exprs):
                 table = table.append_column(name, pa.array([None if c is None or mapped[c] is None else at[mapped[c]] for c in codes], itype))
                 dicts[name] = order
             return X.Column(name)
+        if isinstance(e, X.LikeExpr) and isinstance(e.expr, X.Column) and e.expr.name in dicts and len(dicts[e.expr.name]) > 64:
+            # a large dictionary (p_name: one value per part): the checker's LIKE runs over the dictionary with pyarrow and the rows
+            # get a Boolean column (a chain of `=` per matching index would nest thousands deep)
+            import numpy as np
+            import pyarrow.compute as pc
+            name = f"__like_{e.expr.name}_{len(table.column_names)}"
+            hit = np.array(pc.match_like(pa.array(dicts[e.expr.name], pa.string()), e.pattern, ignore_case=e.case_insensitive).fill_null(False).to_pylist(), dtype=bool)
+            codes = table.column(e.expr.name).combine_chunks()
+            vals = hit[np.asarray(codes.fill_null(0).to_numpy(zero_copy_only=False), dtype=np.int64)]
+            if e.negated:
+                vals = ~vals
+            table = table.append_column(name, pa.array(vals, pa.bool_(), mask=np.asarray(codes.is_null().to_numpy(zero_copy_only=False))))
+            return X.Column(name)
         if isinstance(e, (X.Column, X.Literal)):
             return e
         if isinstance(e, X.CastExpr):

@@ -176,3 +176,26 @@ def test_group_keys_with_a_changed_dictionary_are_refused():
     agg.update(DeviceTable.from_arrow(t1))
     with pytest.raises(_lib.DfgpuError, match="dictionary changed"):
         agg.update(DeviceTable.from_arrow(t2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pattern,negated,ci", [("%green%", False, False), ("forest%", False, False), ("%e_ %", True, False), ("%GREEN%", False, True), ("%nothing%", False, False)])
+def test_like_over_a_dictionary_with_one_value_per_row(pattern, negated, ci):
+    """LIKE over a dictionary-encoded column whose matching indices do not form a few runs (TPC-H p_name: one value per part): the
+    library matches the pattern against the dictionary and the rows look their index up; NULL rows stay NULL"""
+    import numpy as np
+    import pyarrow.compute as pc
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    from oracle import dbgen
+    names = dbgen.part_names(6000)
+    rng = np.random.default_rng(2)
+    arr = pa.array(names, pa.string(), mask=rng.random(6000) < 0.05)
+    t = pa.table({"p_name": arr.dictionary_encode(), "k": pa.array(np.arange(6000))})
+    got = ops.filter(DeviceTable.from_arrow(t), col("p_name").like(pattern, negated=negated, case_insensitive=ci)).to_arrow()
+    hit = pc.match_like(arr, pattern, ignore_case=ci)
+    if negated:
+        hit = pc.invert(hit)
+    want = [k for k, h in zip(range(6000), hit.to_pylist()) if h]
+    assert got.column("k").to_pylist() == want

@@ -42,6 +42,8 @@ def plans(t):
             "q8": T.q8_plan(t.get("part"), t["supplier"], t["lineitem"], t["orders"], t["customer"], t["nation"], t["region"]),
             "q11": T.q11_plan(t.get("partsupp"), t["supplier"], t["nation"]),
             "q15": T.q15_plan(t["supplier"], t["lineitem"]),
+            "q9": T.q9_plan(t.get("part"), t["supplier"], t["lineitem"], t.get("partsupp"), t["orders"], t["nation"]),
+            "q20": T.q20_plan(t["supplier"], t["nation"], t.get("partsupp"), t.get("part"), t["lineitem"]),
             "q14": T.q14_plan(t["lineitem"], t.get("part")), "q17": T.q17_plan(t["lineitem"], t.get("part")), "q12": T.q12_plan(t["orders"], t["lineitem"]), "q18": T.q18_plan(t["customer"], t["orders"], t["lineitem"]),
             "q19": T.q19_plan(t["lineitem"], t.get("part")),
             "q21": T.q21_plan(t["supplier"], t["lineitem"], t["orders"], t["nation"]),
@@ -50,6 +52,7 @@ def plans(t):
 
 # answer-file columns whose text may contain blanks (everything else is split on blanks)
 _TEXT_FIRST = {"q4": 1, "q5": 1}
+_TEXT_LAST = {"q20"}      # s_name (no blank), then s_address (blanks are part of it)
 # (q15's one supplier address, 8mhrffG7D2WJBSQbOGstQ, holds no blank)
 # (q7's nation names FRANCE / GERMANY hold no blanks)
 
@@ -57,7 +60,7 @@ _TEXT_FIRST = {"q4": 1, "q5": 1}
 def expected_rows(q):
     rows = []
     for line in GOLD["answers"][q]["rows"]:
-        toks = line.rsplit(" ", 1) if q in _TEXT_FIRST else line.split(" ")
+        toks = line.rsplit(" ", 1) if q in _TEXT_FIRST else line.split(" ", 1) if q in _TEXT_LAST else line.split(" ")
         rows.append(toks)
     return rows
 
@@ -84,7 +87,7 @@ def assert_answer(q, got: pa.Table):
         assert all(_cell(v, x) for v, x in zip(r, w)), f"{q} row {i}: got {r}, the reference's answer is {w} ({GOLD['answers'][q]['source']})"
 
 
-QUERIES = ["q1", "q3", "q4", "q5", "q6", "q7", "q8", "q11", "q12", "q14", "q15", "q17", "q18", "q19", "q21", "q22"]
+QUERIES = ["q1", "q3", "q4", "q5", "q6", "q7", "q8", "q9", "q11", "q12", "q14", "q15", "q17", "q18", "q19", "q20", "q21", "q22"]
 # Q19's JoinFilter compares string columns with literals: the host side binds them through the dictionaries of the columns behind the
 # intermediate schema (expr.IntermediateSchema, tests/test_abi.py)
 GPU_QUERIES = list(QUERIES)
@@ -93,7 +96,7 @@ RESULT_TYPES = {   # pinned by the answer files' decimal digits and the plan fil
            "count_order": pa.int64()},
     "q3": {"revenue": pa.decimal128(38, 4)}, "q4": {"order_count": pa.int64()}, "q5": {"revenue": pa.decimal128(38, 4)},
     "q6": {"revenue": pa.decimal128(38, 4)}, "q12": {"high_line_count": pa.int64(), "low_line_count": pa.int64()}, "q18": {"sum(lineitem.l_quantity)": pa.decimal128(25, 2)}, "q19": {"revenue": pa.decimal128(38, 4)}, "q21": {"numwait": pa.int64()},
-    "q11": {"value": pa.decimal128(36, 2)}, "q15": {"total_revenue": pa.decimal128(38, 4)}, "q22": {"numcust": pa.int64(), "totacctbal": pa.decimal128(25, 2)},
+    "q9": {"o_year": pa.int32(), "sum_profit": pa.decimal128(38, 4)}, "q20": {}, "q11": {"value": pa.decimal128(36, 2)}, "q15": {"total_revenue": pa.decimal128(38, 4)}, "q22": {"numcust": pa.int64(), "totacctbal": pa.decimal128(25, 2)},
     "q7": {"l_year": pa.int32(), "revenue": pa.decimal128(38, 4)}, "q8": {"o_year": pa.int32(), "mkt_share": pa.decimal128(15, 2)}, "q14": {"promo_revenue": pa.float64()}, "q17": {"avg_yearly": pa.float64()},
 }
 
