@@ -316,3 +316,20 @@ def test_ordered_first_key_with_further_group_keys(dependent):
     assert ("agg_runs_accumulate" in stats) == dependent, sorted(stats)
     assert "agg_runs_dependent_keys" in stats
     assert_agg_equal(got, oracle(t, gb, aggs), ordered=True)
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.3])
+@pytest.mark.parametrize("batches", [1, 3])
+def test_runs_node_sum_cells_are_the_decimal_column_and_split_for_the_next_batch(batches, null_frac):
+    """SUM(Decimal128) from the ordered-input node lives as interleaved {lo, hi} cells — the emitted column itself.  One batch: emit
+    hands them out (validity from the seen flags: groups whose values are all NULL).  Further batches (hash path) first split them
+    back into the lo / hi arrays; the totals must be those of the whole input either way."""
+    from datafusion_amd.expr import col
+    rng = np.random.default_rng(17 + batches)
+    lengths = np.concatenate([rng.integers(1, 9, size=500), [64, 200, 1, 63], rng.integers(1, 70, size=40)])
+    t = _runs_table(rng, lengths, null_frac=null_frac)
+    gb = [(col("k"), "k")]
+    aggs = [("sum", col("d"), "sd"), ("sum", col("d") * col("d"), "sdd"), ("avg", col("d"), "ad"), ("count", col("d"), "cd"), ("sum", col("j"), "sj")]
+    (got, _), stats = _with_jit_env(lambda: gpu(t, gb, aggs, batches=batches))
+    assert "agg_runs_accumulate" in stats
+    assert_agg_equal(got, oracle(t, gb, aggs), ordered=batches == 1)
