@@ -157,6 +157,23 @@ __device__ __forceinline__ uint64_t key_transform64(int type, const void* data, 
     default: return (uint64_t)((const uint8_t*)data)[i];
   }
 }
+// the mixed-radix key of row i
+__device__ __forceinline__ uint64_t pack_key64(const PackCols& pc, int64_t i) {
+  uint64_t w = 0;
+  for (int c = 0; c < pc.n; c++) {
+    const PackCol& k = pc.c[c];
+    const bool ok = !k.valid || bit_at(k.valid, i);
+    uint64_t digit = 0;
+    if (ok && k.range > 1) {
+      const uint64_t t = key_transform64(k.type, k.data, i);
+      digit = k.desc ? k.base_lo - t : t - k.base_lo;
+    }
+    // NULL flag as the column's top digit: NULLS FIRST => nulls 0 / values 1; NULLS LAST => values 0 / nulls 1
+    if (k.has_null_bit && (ok == (k.nulls_first != 0))) digit += k.range;
+    w += digit * k.mult;
+  }
+  return w;
+}
 __global__ __launch_bounds__(BLOCK) void k_pack_keys64(PackCols pc, int64_t n, uint64_t* __restrict__ o0) {
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += 2 * stride) {
@@ -165,21 +182,25 @@ __global__ __launch_bounds__(BLOCK) void k_pack_keys64(PackCols pc, int64_t n, u
     for (int u = 0; u < 2; u++) {
       const int64_t i = i0 + u * stride;
       if (i >= n) continue;
-      for (int c = 0; c < pc.n; c++) {
-        const PackCol& k = pc.c[c];
-        const bool ok = !k.valid || bit_at(k.valid, i);
-        uint64_t digit = 0;
-        if (ok && k.range > 1) {
-          const uint64_t t = key_transform64(k.type, k.data, i);
-          digit = k.desc ? k.base_lo - t : t - k.base_lo;
-        }
-        // NULL flag as the column's top digit: NULLS FIRST => nulls 0 / values 1; NULLS LAST => values 0 / nulls 1
-        if (k.has_null_bit && (ok == (k.nulls_first != 0))) digit += k.range;
-        w[u] += digit * k.mult;
-      }
+      w[u] = pack_key64(pc, i);
     }
     o0[i0] = w[0];
     if (i0 + stride < n) o0[i0 + stride] = w[1];
+  }
+}
+// keys of listed rows (ids), or of every `every`-th row (ids == null): the TopK sample and the TopK survivors
+__global__ __launch_bounds__(BLOCK) void k_pack_keys64_rows(PackCols pc, const int64_t* __restrict__ ids, int64_t every, int64_t m, uint64_t* __restrict__ out) {
+  for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < m; j += (int64_t)gridDim.x * BLOCK) out[j] = pack_key64(pc, ids ? ids[j] : j * every);
+}
+// mask of the rows whose key is <= limit, computed from the key columns (no packed key array)
+__global__ __launch_bounds__(BLOCK) void k_key_limit_mask(PackCols pc, int64_t n, uint64_t limit, uint64_t* __restrict__ mask) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const int64_t i = (w << 6) + lane_id();
+    const uint64_t m = ballot64(i < n && pack_key64(pc, i) <= limit);
+    if (lane_id() == 0) mask[w] = m;
   }
 }
 
@@ -914,11 +935,58 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       DFGPU_HIP(hipGetLastError());
     }
     };
-    pack_keys();
     const std::vector<Digit> digits = key_digits(total_bits);  // least significant first
     BufPtr remap;                                               // survivor position -> original row id (TopK path)
     int64_t m = n;
-    if (topk) {
+    // ---- TopK by a sampled limit (one-word keys): the keys of 64 K evenly spaced rows give a limit that a few thousand rows
+    // stay under; ONE pass over the key columns marks them (no packed key array is ever written), and the rest of the sort
+    // sees only those.  The k-th smallest key lies under the c-th smallest of S samples unless fewer than k of the n keys do —
+    // c is chosen so that ~c n / S >> k rows are expected there; if the marked rows are fewer than k (never seen) or too many
+    // (a few distinct keys: ties), the radix select below takes over.
+    bool limited = false;
+    static const bool topk_limit = !(std::getenv("DFGPU_TOPK_LIMIT") && std::getenv("DFGPU_TOPK_LIMIT")[0] == '0');  // A/B knob
+    if (topk && narrow && topk_limit && n >= (1 << 20)) {
+      const int64_t S = 1 << 16, every = n / S;
+      const int64_t c = std::min<int64_t>(S, (n_out * S + n - 1) / n * 2 + 16);
+      if (c < S / 4) {
+        BufPtr d_sample = make_buf((size_t)S * 8);
+        const int64_t n_words = (n + 63) / 64;
+        BufPtr mask = make_buf(bitmap_bytes(n));
+        BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
+        std::vector<uint64_t> sample((size_t)S);
+        {
+          ProfileScope ps("topk_limit_sample", S * 16);
+          k_pack_keys64_rows<<<grid_for(S, BLOCK), BLOCK, 0, r.stream>>>(pc, nullptr, every, S, d_sample->as<uint64_t>());
+          DFGPU_HIP(hipGetLastError());
+        }
+        d2h(sample.data(), d_sample->ptr, (size_t)S * 8);
+        std::nth_element(sample.begin(), sample.begin() + (c - 1), sample.end());
+        const uint64_t limit = sample[(size_t)(c - 1)];
+        {
+          ProfileScope ps("topk_limit_pass", key_col_bytes + n / 8);
+          k_key_limit_mask<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(pc, n, limit, mask->as<uint64_t>());
+          DFGPU_HIP(hipGetLastError());
+        }
+        scan_mask_popcounts(mask->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
+        const int64_t under = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
+        if (under >= n_out && under <= std::max<int64_t>(1 << 22, 64 * n_out)) {
+          m = under;
+          remap = make_buf((size_t)m * 8);
+          k_mask_to_ids<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(mask->as<uint64_t>(), prefix->as<uint64_t>(), n, remap->as<int64_t>());
+          SortedKeys sv;
+          sv.nwords = 1;
+          sv.w[0] = make_buf((size_t)m * 8);
+          k_pack_keys64_rows<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(pc, remap->as<int64_t>(), 0, m, sv.w[0]->as<uint64_t>());
+          sv.idx = make_buf((size_t)m * 4);
+          k_iota_u32<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(m, sv.idx->as<uint32_t>());
+          DFGPU_HIP(hipGetLastError());
+          sk = sv;
+          limited = true;
+        }
+      }
+    }
+    if (!limited) pack_keys();
+    if (topk && !limited) {
       // ---- TopK: MSD radix select narrows to the rows that can still be among the first k
       BufPtr state = make_buf((size_t)n + 64);
       k_fill_bytes<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(1, n, state->as<uint8_t>());

@@ -157,3 +157,28 @@ def test_exchange_plumbing_single_rank_rccl():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", DFGPU_ROOT=root)
     r = subprocess.run([sys.executable, "-c", _RCCL_WORKER], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert "EXCHANGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("shape", ["spread", "two_keys_desc_nulls", "few_distinct", "all_equal"])
+@pytest.mark.parametrize("k", [1, 10, 5000])
+def test_topk_by_sampled_limit(shape, k):
+    """TopK of >= 1 Mi rows with a one-word key (sort.hip: a limit from 64 K sampled keys, one pass over the key columns, the sort of
+    the rows under it): keys that spread, two key columns with DESC and NULLs, few distinct values and one value only (ties: the rows
+    under the limit are too many and the radix select takes over) — always the first k rows of the stable sort"""
+    n = 1_300_003
+    rng = np.random.default_rng(k + len(shape))
+    v = pa.array(np.arange(n, dtype=np.int64))
+    if shape == "spread":
+        t = pa.table({"a": pa.array(rng.integers(-2**40, 2**40, size=n)), "v": v})
+        keys = [("a", False, False)]
+    elif shape == "two_keys_desc_nulls":
+        a = pa.array(rng.integers(8000, 11000, size=n).astype(np.int32), pa.int32(), mask=rng.random(n) < 0.01).cast(pa.date32())
+        t = pa.table({"a": a, "b": pa.array(rng.integers(0, 2**31, size=n)), "v": v})
+        keys = [("a", True, False), ("b", False, False)]
+    elif shape == "few_distinct":
+        t = pa.table({"a": pa.array(rng.integers(0, 5, size=n)), "v": v})
+        keys = [("a", False, False)]
+    else:
+        t = pa.table({"a": pa.array(np.full(n, 7, dtype=np.int64)), "v": v})
+        keys = [("a", True, True)]
+    run_sort(t, keys, fetch=k)
