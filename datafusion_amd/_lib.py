@@ -107,7 +107,7 @@ SYMBOLS = [
     "dfgpu_exchange_hash", "dfgpu_exchange_broadcast", "dfgpu_exchange_broadcast_pruned", "dfgpu_comm_stats",
     "dfgpu_mem_set_limit", "dfgpu_mem_limit", "dfgpu_mem_try_reserve", "dfgpu_mem_reservation_size", "dfgpu_mem_release",
     "dfgpu_table_export_batch", "dfgpu_host_register", "dfgpu_host_unregister", "dfgpu_table_export_into",
-    "dfgpu_column_inlist", "dfgpu_metrics_reset", "dfgpu_metrics_get", "dfgpu_table_dictionary_like", "dfgpu_table_dictionary_encode", "dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_estimate_bytes",
+    "dfgpu_column_inlist", "dfgpu_metrics_reset", "dfgpu_metrics_get", "dfgpu_table_dictionary_like", "dfgpu_table_dictionary_encode", "dfgpu_table_dictionary_decode", "dfgpu_table_dictionary_size", "dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_estimate_bytes",
 ]
 
 _lib = None

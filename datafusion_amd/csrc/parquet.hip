@@ -12,7 +12,8 @@
 //          through the chunk's dictionary (kept in HBM, L2-resident: dictionaries are <= 1 MiB by the writers' limits).
 // Supported: flat columns (max_repetition_level 0, max_definition_level <= 1), data pages v1 and v2, encodings PLAIN /
 // PLAIN_DICTIONARY / RLE_DICTIONARY, physical types INT32 / INT64 / DOUBLE / FIXED_LEN_BYTE_ARRAY (decimals) and
-// BYTE_ARRAY when every data page is dictionary-encoded (it becomes a dictionary-encoded string column: indices on the
+// BYTE_ARRAY — read as field.type DFGPU_UTF8 it becomes a Utf8 column whatever its pages' encodings (decode_string_chunk); read
+// as Int32 it must have every data page dictionary-encoded (it becomes a dictionary-encoded string column: indices on the
 // device, strings on the host, dictionary sorted ascending).  Anything else is an error: the caller keeps the CPU scan.
 #include "device.hpp"
 #include "internal.hpp"
@@ -288,6 +289,13 @@ struct ChunkPlan {       // everything the host learns from one chunk
   int32_t dict_count = 0;
   int64_t rows = 0, values = 0;        // rows incl. NULLs; non-null values
   dfgpu_parquet_chunk_info info{};
+  // BYTE_ARRAY read as Utf8 (field.type DFGPU_UTF8): every non-null value as (offset, length) into str_bytes — a PLAIN page's
+  // body goes there as it is (the offsets skip its 4-byte length prefixes), the dictionary's strings once
+  std::vector<int64_t> str_src;
+  std::vector<uint32_t> str_len;
+  std::vector<uint8_t> str_bytes;
+  std::vector<int64_t> dict_src;       // the dictionary's strings in str_bytes
+  std::vector<uint32_t> dict_len;
 };
 
 void set_bits(std::vector<uint64_t>& bm, int64_t pos, int64_t n) {
@@ -325,7 +333,7 @@ void check_target(const dfgpu_parquet_column& c) {
     case DFGPU_PARQUET_INT64: ok = t == DFGPU_INT64 || t == DFGPU_UINT64 || t == DFGPU_DECIMAL128; break;
     case DFGPU_PARQUET_DOUBLE: ok = t == DFGPU_FLOAT64; break;
     case DFGPU_PARQUET_FIXED_LEN_BYTE_ARRAY: ok = t == DFGPU_DECIMAL128; break;
-    case DFGPU_PARQUET_BYTE_ARRAY: ok = t == DFGPU_INT32; break;   // dictionary indices of a string column
+    case DFGPU_PARQUET_BYTE_ARRAY: ok = t == DFGPU_INT32 || t == DFGPU_UTF8; break;   // dictionary indices of a string column, or the strings
   }
   DFGPU_CHECK(ok, "parquet: physical type " + std::to_string(c.physical_type) + " cannot be read as " + type_name(c.field));
   DFGPU_CHECK(c.max_repetition_level == 0, "parquet: repeated (nested) columns are not supported on the GPU scan path");
@@ -424,8 +432,77 @@ ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_c
     d.value_start = P.values;
     d.first_run = (int32_t)P.runs.size();
     const size_t base = (P.staging.size() + 15) & ~size_t(15);
+    if (col.field.type == DFGPU_UTF8) {
+      // ---- strings: every value's (offset, length); the bytes move once, on the device
+      if (h.encoding == ENC_PLAIN) {
+        const int64_t at = (int64_t)P.str_bytes.size();
+        const uint8_t* q = values;
+        for (int64_t j = 0; j < nonnull; j++) {
+          DFGPU_CHECK(values_end - q >= 4, "parquet: PLAIN string values overrun the page");
+          uint32_t len;
+          std::memcpy(&len, q, 4);
+          q += 4;
+          DFGPU_CHECK((uint64_t)(values_end - q) >= len, "parquet: PLAIN string values overrun the page");
+          P.str_src.push_back(at + (q - values));
+          P.str_len.push_back(len);
+          q += len;
+        }
+        P.str_bytes.insert(P.str_bytes.end(), values, q);
+        P.info.n_plain_pages++;
+      } else if (h.encoding == ENC_RLE_DICTIONARY || h.encoding == ENC_PLAIN_DICTIONARY) {
+        DFGPU_CHECK(!P.dict_page.empty() || P.dict_count == 0, "parquet: dictionary-encoded page without a dictionary page");
+        if (P.dict_src.empty() && P.dict_count) {  // the dictionary's strings, once
+          const uint8_t* q = P.dict_page.data();
+          const uint8_t* qe = q + P.dict_page.size();
+          const int64_t at = (int64_t)P.str_bytes.size();
+          for (int32_t i = 0; i < P.dict_count; i++) {
+            DFGPU_CHECK(qe - q >= 4, "parquet: truncated string dictionary");
+            uint32_t len;
+            std::memcpy(&len, q, 4);
+            q += 4;
+            DFGPU_CHECK((uint64_t)(qe - q) >= len, "parquet: truncated string dictionary");
+            P.dict_src.push_back(at + (q - P.dict_page.data()));
+            P.dict_len.push_back(len);
+            q += len;
+          }
+          P.str_bytes.insert(P.str_bytes.end(), P.dict_page.begin(), P.dict_page.end());
+        }
+        DFGPU_CHECK(values_end > values || nonnull == 0, "parquet: dictionary-encoded page without a bit width");
+        if (nonnull) {
+          const int bw = values[0];
+          DFGPU_CHECK(bw <= 32, "parquet: dictionary index bit width " + std::to_string(bw));
+          auto put = [&](uint64_t idx) {
+            DFGPU_CHECK(idx < (uint64_t)P.dict_count, "parquet: dictionary index out of range");
+            P.str_src.push_back(P.dict_src[(size_t)idx]);
+            P.str_len.push_back(P.dict_len[(size_t)idx]);
+          };
+          walk_runs(values + 1, values_end, bw, nonnull, [&](bool packed, int64_t cnt, uint64_t val, const uint8_t* bits) {
+            if (!packed) {
+              for (int64_t i = 0; i < cnt; i++) put(val);
+              (void)P.info.n_runs_rle++;
+              return;
+            }
+            P.info.n_runs_bitpacked++;
+            for (int64_t i = 0; i < cnt; i++) {  // bit-packed, LSB first
+              const int64_t bit = i * bw;
+              uint64_t v = 0;
+              for (int b = 0; b < bw; b++) v |= (uint64_t)((bits[(bit + b) >> 3] >> ((bit + b) & 7)) & 1) << b;
+              put(v);
+            }
+          });
+        }
+        P.info.n_dictionary_encoded_pages++;
+      } else {
+        throw Error("parquet: value encoding " + std::to_string(h.encoding) + " is not supported on the GPU scan path");
+      }
+      d.kind = 2;
+      P.pages.push_back(d);
+      P.rows += h.num_values;
+      P.values += nonnull;
+      continue;
+    }
     if (h.encoding == ENC_PLAIN) {
-      DFGPU_CHECK(pw > 0, "parquet: PLAIN-encoded BYTE_ARRAY pages (strings outside a dictionary) are not supported on the GPU scan path");
+      DFGPU_CHECK(pw > 0, "parquet: PLAIN-encoded BYTE_ARRAY pages (strings outside a dictionary): read the column as Utf8 (field.type DFGPU_UTF8) instead of dictionary indices");
       DFGPU_CHECK(values_end - values >= nonnull * pw, "parquet: PLAIN values overrun the page");
       P.staging.resize(base + (size_t)(nonnull * pw));
       std::memcpy(P.staging.data() + base, values, (size_t)(nonnull * pw));
@@ -621,8 +698,67 @@ void launch_expand(const void* dense, const uint64_t* valid, const uint64_t* pre
   if (n_rows) k_pq_expand<T><<<grid_for(n_rows, BLOCK), BLOCK, 0, rt().stream>>>((const T*)dense, valid, prefix, n_rows, (T*)out);
 }
 
+// out[new_off[i] ...) = src_bytes[src[i] ...) for every row (a NULL row has length 0)
+__global__ __launch_bounds__(BLOCK) void k_pq_string_copy(const int64_t* __restrict__ src, const uint64_t* __restrict__ new_off, const uint8_t* __restrict__ src_bytes, int64_t n,
+                                                          uint8_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t len = (int64_t)(new_off[i + 1] - new_off[i]);
+    const uint8_t* s = src_bytes + src[i];
+    uint8_t* d = out + new_off[i];
+    for (int64_t k = 0; k < len; k++) d[k] = s[k];
+  }
+}
+
+// BYTE_ARRAY -> a Utf8 column: the host found every value's (offset, length); the device spreads them over the NULL rows, scans
+// the lengths into Arrow offsets and copies the bytes
+Column decode_string_chunk(ChunkPlan& P, const dfgpu_parquet_column& col) {
+  hipStream_t st = rt().stream;
+  Column like;
+  like.field = col.field;
+  like.field.nullable = col.max_definition_level ? 1 : 0;
+  like.name = col.name ? col.name : "";
+  Column c = alloc_string_column(like, P.rows);
+  if (P.rows == 0) {
+    DFGPU_HIP(hipMemsetAsync(c.offsets->ptr, 0, 8, st));
+    c.data = make_buf(16);
+    return c;
+  }
+  DFGPU_CHECK((int64_t)P.str_src.size() == P.values && (int64_t)P.str_len.size() == P.values, "parquet: string value count mismatch");
+  BufPtr d_bytes = make_buf(P.str_bytes.size() + 16), d_src = make_buf((size_t)std::max<int64_t>(P.values, 1) * 8 + 16),
+         d_len = make_buf((size_t)std::max<int64_t>(P.values, 1) * 4 + 16);
+  if (!P.str_bytes.empty()) DFGPU_HIP(hipMemcpyAsync(d_bytes->ptr, P.str_bytes.data(), P.str_bytes.size(), hipMemcpyHostToDevice, st));
+  if (P.values) {
+    DFGPU_HIP(hipMemcpyAsync(d_src->ptr, P.str_src.data(), (size_t)P.values * 8, hipMemcpyHostToDevice, st));
+    DFGPU_HIP(hipMemcpyAsync(d_len->ptr, P.str_len.data(), (size_t)P.values * 4, hipMemcpyHostToDevice, st));
+  }
+  BufPtr src_rows = d_src, len_rows = d_len;
+  if (!P.validity.empty()) {
+    const size_t bb = bitmap_bytes(P.rows);
+    c.validity = make_buf(bb);
+    c.null_count = P.rows - P.values;
+    DFGPU_HIP(hipMemcpyAsync(c.validity->ptr, P.validity.data(), bb, hipMemcpyHostToDevice, st));
+    BufPtr prefix = make_buf((size_t)((P.rows + 63) / 64 + 1) * 8);
+    scan_mask_popcounts(c.validity->as<uint64_t>(), nullptr, P.rows, prefix->as<uint64_t>());
+    src_rows = make_buf((size_t)P.rows * 8 + 16);
+    len_rows = make_buf((size_t)P.rows * 4 + 16);
+    launch_expand<uint64_t>(d_src->ptr, c.valid_words(), prefix->as<uint64_t>(), P.rows, src_rows->ptr);
+    launch_expand<uint32_t>(d_len->ptr, c.valid_words(), prefix->as<uint64_t>(), P.rows, len_rows->ptr);
+  }
+  scan_u32(len_rows->as<uint32_t>(), P.rows, c.offsets->as<uint64_t>());
+  const int64_t total = (int64_t)read_u64(c.offsets->as<uint64_t>() + P.rows);
+  c.data = make_buf((size_t)total + 16);
+  {
+    ProfileScope ps("parquet_decode_strings", (int64_t)P.str_bytes.size() + total + P.rows * 20);
+    k_pq_string_copy<<<grid_for(P.rows, BLOCK), BLOCK, 0, st>>>(src_rows->as<int64_t>(), c.offsets->as<uint64_t>(), d_bytes->as<uint8_t>(), P.rows, (uint8_t*)c.data->ptr);
+    DFGPU_HIP(hipGetLastError());
+  }
+  DFGPU_HIP(hipStreamSynchronize(st));   // the host vectors are the copies' sources
+  return c;
+}
+
 Column decode_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_column& col) {
   ChunkPlan P = plan_chunk(chunk, nbytes, col);
+  if (col.field.type == DFGPU_UTF8) return decode_string_chunk(P, col);
   hipStream_t st = rt().stream;
   dfgpu_field f = col.field;
   f.nullable = col.max_definition_level ? 1 : 0;

@@ -17,6 +17,7 @@
 // 64-bit accesses through a packed struct: global memory takes them), not a wave per string.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 
 #include "device.hpp"
@@ -647,6 +648,77 @@ Datum string_binary(int op, const Datum& a, const Datum& b, int64_t nrows) {
 }  // namespace dfgpu
 
 using namespace dfgpu;
+
+namespace dfgpu {
+// indices (any width) -> 64-bit row ids into the dictionary; a NULL row, a NULL dictionary value or an index beyond it -> -1
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_dict_ids(const T* __restrict__ codes, const uint64_t* __restrict__ valid, const uint8_t* __restrict__ value_valid, int64_t n_values, int64_t n,
+                                                    int64_t* __restrict__ ids) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const uint64_t k = (uint64_t)codes[i];
+    const bool ok = (!valid || bit_at(valid, i)) && k < (uint64_t)n_values && value_valid[k] != 0;
+    ids[i] = ok ? (int64_t)k : -1;
+  }
+}
+// dictionary-encoded -> Utf8: the dictionary's values go to HBM as a string column once, every row takes its value (the same
+// take that filters and joins move strings with)
+Column dictionary_decode(const Column& in) {
+  Runtime& r = rt();
+  DFGPU_CHECK(in.dict != nullptr, "dictionary_decode: column '" + in.name + "' is not dictionary-encoded");
+  const DictValues& dv = *in.dict;
+  const int64_t nv = (int64_t)dv.values.size();
+  std::vector<int64_t> off((size_t)nv + 1, 0);
+  for (int64_t k = 0; k < nv; k++) off[(size_t)k + 1] = off[(size_t)k] + (int64_t)dv.values[(size_t)k].size();
+  std::vector<char> bytes((size_t)off[(size_t)nv] + 1);
+  for (int64_t k = 0; k < nv; k++) std::memcpy(bytes.data() + off[(size_t)k], dv.values[(size_t)k].data(), dv.values[(size_t)k].size());
+  Column values;
+  values.field.type = DFGPU_UTF8;
+  values.field.nullable = 1;
+  values.length = nv;
+  values.offsets = make_buf((size_t)(nv + 1) * 8 + 16);
+  values.data = make_buf((size_t)off[(size_t)nv] + 16);
+  BufPtr vvalid = make_buf((size_t)nv + 16);
+  h2d_async(values.offsets->ptr, off.data(), (size_t)(nv + 1) * 8);
+  if (off[(size_t)nv]) h2d_async(values.data->ptr, bytes.data(), (size_t)off[(size_t)nv]);
+  if (nv) h2d_async(vvalid->ptr, dv.valid.data(), (size_t)nv);
+  const int64_t n = in.length;
+  BufPtr ids = make_buf((size_t)std::max<int64_t>(n, 1) * 8);
+  if (n) {
+    const int g = grid_for(n, BLOCK);
+    switch (type_width(in.field.type)) {
+      case 1: k_dict_ids<uint8_t><<<g, BLOCK, 0, r.stream>>>((const uint8_t*)in.ptr(), in.valid_words(), vvalid->as<uint8_t>(), nv, n, ids->as<int64_t>()); break;
+      case 4: k_dict_ids<uint32_t><<<g, BLOCK, 0, r.stream>>>((const uint32_t*)in.ptr(), in.valid_words(), vvalid->as<uint8_t>(), nv, n, ids->as<int64_t>()); break;
+      default: k_dict_ids<uint64_t><<<g, BLOCK, 0, r.stream>>>((const uint64_t*)in.ptr(), in.valid_words(), vvalid->as<uint8_t>(), nv, n, ids->as<int64_t>()); break;
+    }
+    DFGPU_HIP(hipGetLastError());
+  }
+  Column out = gather_strings(values, ids->as<int64_t>(), n, true);
+  out.name = in.name;
+  out.field.nullable = in.field.nullable;
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // the host vectors are the copies' sources
+  return out;
+}
+}  // namespace dfgpu
+
+extern "C" int dfgpu_table_dictionary_size(dfgpu_table_t th, int column, int64_t* out_n) {
+  return guarded([&] {
+    Table* t = unwrap_quiet(th);
+    DFGPU_CHECK(out_n && column >= 0 && column < (int)t->cols.size(), "bad argument");
+    const Column& c = t->cols[(size_t)column];
+    *out_n = c.dict ? (int64_t)c.dict->values.size() : -1;
+  });
+}
+
+extern "C" int dfgpu_table_dictionary_decode(dfgpu_table_t th, int column, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    Table* t = unwrap(th);
+    DFGPU_CHECK(out && column >= 0 && column < (int)t->cols.size(), "bad argument");
+    auto o = std::make_unique<Table>(*t);
+    o->cols[(size_t)column] = dictionary_decode(t->cols[(size_t)column]);
+    *out = wrap(o.release());
+  });
+}
 
 extern "C" int dfgpu_table_dictionary_encode(dfgpu_table_t th, int column, int sorted, dfgpu_table_t* out) {
   return guarded([&] {

@@ -179,17 +179,32 @@ class ParquetFile:
         """the host half alone (no GPU): page / run / byte counts of one chunk"""
         buf, n, d, keep = self._chunk(row_group, column)
         info = ParquetChunkInfo()
-        check(_lib.load().dfgpu_parquet_inspect_chunk(buf, C.c_int64(n), C.byref(d), C.byref(info)))
+        lib = _lib.load()
+        rc = lib.dfgpu_parquet_inspect_chunk(buf, C.c_int64(n), C.byref(d), C.byref(info))
+        if rc != 0 and d.physical_type == PHYSICAL["BYTE_ARRAY"] and b"read the column as Utf8" in lib.dfgpu_last_error():
+            from .table import UTF8
+            d.field.type = UTF8         # a string chunk with PLAIN pages: inspected the way it will be decoded
+            rc = lib.dfgpu_parquet_inspect_chunk(buf, C.c_int64(n), C.byref(d), C.byref(info))
+        check(rc)
         return {k: getattr(info, k) for k, _ in ParquetChunkInfo._fields_}
 
     def _decode(self, row_group: int, column: str) -> DeviceTable:
+        """one column chunk on the device.  A string column is read as dictionary indices when every data page of the chunk is
+        dictionary-encoded, and as Utf8 bytes when the writer fell back to PLAIN pages in it (high-cardinality text: TPC-H's
+        comment columns) — `read` brings the chunks of a column to one kind."""
         key = self._identity + (row_group, column)
         hit = CACHE.get(key)
         if hit is not None:
             return hit
         buf, n, d, keep = self._chunk(row_group, column)
         h = C.c_void_p()
-        check(_lib.load().dfgpu_parquet_decode_chunk(buf, C.c_int64(n), C.byref(d), C.byref(h)))
+        lib = _lib.load()
+        rc = lib.dfgpu_parquet_decode_chunk(buf, C.c_int64(n), C.byref(d), C.byref(h))
+        if rc != 0 and d.physical_type == PHYSICAL["BYTE_ARRAY"] and b"read the column as Utf8" in lib.dfgpu_last_error():
+            from .table import UTF8
+            d.field.type = UTF8
+            rc = lib.dfgpu_parquet_decode_chunk(buf, C.c_int64(n), C.byref(d), C.byref(h))
+        check(rc)
         out = DeviceTable(h)
         CACHE.put(key, out)
         return out
@@ -281,6 +296,17 @@ class ParquetFile:
                 chunks = list(ex.map(lambda gc: self._decode(*gc), work))
         else:
             chunks = [self._decode(g, c) for g, c in work]
+        # a string column whose chunks came out in both kinds (dictionary indices here, Utf8 bytes there) becomes Utf8 everywhere
+        from .table import UTF8
+        for j, name in enumerate(names):
+            col_chunks = [chunks[k * len(names) + j] for k in range(len(groups))]
+            kinds = {t.column_view(0).field.type == UTF8 for t in col_chunks}
+            if kinds == {True, False}:
+                for k in range(len(groups)):
+                    t = chunks[k * len(names) + j]
+                    if t.column_view(0).field.type != UTF8:
+                        chunks[k * len(names) + j] = t.dictionary_decode()
+                        t.free()
         parts = [self._hstack(chunks[k * len(names):(k + 1) * len(names)]) for k in range(len(groups))]
         if len(parts) == 1:
             return parts[0]

@@ -172,6 +172,28 @@ class DeviceTable:
             cur, owned = nxt, True
         return cur if owned else self.select(names)
 
+    def dictionary_size(self, column):
+        """number of values in the dictionary of a dictionary-encoded column, None for any other column"""
+        n = C.c_int64(0)
+        check(_lib.load().dfgpu_table_dictionary_size(self.handle, self.index_of(column), C.byref(n)))
+        return None if n.value < 0 else n.value
+
+    def dictionary_decode(self, columns=None) -> "DeviceTable":
+        """the table with its dictionary-encoded string columns (all of them, or the named ones) as Utf8 columns in HBM
+        (dfgpu_table_dictionary_decode)"""
+        lib = _lib.load()
+        names = self.column_names
+        todo = [i for i in range(self.num_columns) if self.dictionary_size(i) is not None] if columns is None else [self.index_of(c) for c in columns]
+        cur, owned = self, False
+        for i in todo:
+            out = C.c_void_p()
+            check(lib.dfgpu_table_dictionary_decode(cur.handle, i, C.byref(out)))
+            nxt = DeviceTable(out)
+            if owned:
+                cur.free()
+            cur, owned = nxt, True
+        return cur if owned else self.select(names)
+
     def dictionary_like(self, column, pattern: str, case_insensitive: bool = False):
         """ascending indices of the dictionary values of a dictionary-encoded string column that match the SQL LIKE
         `pattern` (dfgpu_table_dictionary_like) — what `col LIKE 'pattern'` is lowered to (expr.LikeExpr)"""

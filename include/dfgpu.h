@@ -211,6 +211,13 @@ int dfgpu_table_dictionary_lookup(dfgpu_table_t table, int column, const char* u
  * re-numbers the dictionary in ascending string order (what ORDER BY and range predicates over the indices need).  `out` = a
  * copy of `table` with column `column` replaced (the other columns are shared, not copied). */
 int dfgpu_table_dictionary_encode(dfgpu_table_t table, int column, int sorted, dfgpu_table_t* out);
+/* the inverse: a dictionary-encoded string column becomes a DFGPU_UTF8 column (its dictionary's values go to HBM once, every row
+ * takes its value; NULL rows and NULL dictionary values are NULL) — e.g. to unify a Parquet column whose row groups are partly
+ * dictionary-encoded and partly PLAIN strings */
+int dfgpu_table_dictionary_decode(dfgpu_table_t table, int column, dfgpu_table_t* out);
+/* number of values in the column's dictionary, -1 when the column is not dictionary-encoded (introspection: a dictionary-encoded
+ * column's dfgpu_field is that of its indices) */
+int dfgpu_table_dictionary_size(dfgpu_table_t table, int column, int64_t* out_n);
 int dfgpu_table_dictionary_like(dfgpu_table_t table, int column, const char* pattern, int64_t len, int case_insensitive, int64_t* out_codes,
                                 int64_t capacity, int64_t* out_n);
 

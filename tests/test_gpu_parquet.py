@@ -251,3 +251,52 @@ def test_scan_sharded_by_rank(tmp_path):
     parts = [f.read(row_groups=f.row_groups_for_rank(r, 3)) for r in range(3)]
     f.close()
     assert_tables_equal(DeviceTable.concat(parts).to_arrow(), t, ordered=True)
+
+
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+@pytest.mark.parametrize("compression", ["none", "snappy", "zstd"])
+def test_plain_string_pages_and_dictionary_fallback(tmp_path, compression, version):
+    """BYTE_ARRAY columns outside a dictionary: written PLAIN (use_dictionary off), or dictionary-encoded until the writer's
+    dictionary page limit and PLAIN from there (TPC-H's comment columns).  Such a chunk arrives as a Utf8 column (the host finds
+    every value's offset and length, the device spreads them over the NULL rows, scans and copies); a column whose row groups came
+    out in both kinds is Utf8 throughout (dfgpu_table_dictionary_decode on the dictionary-encoded ones); a low-cardinality column
+    stays dictionary-encoded."""
+    from datafusion_amd.parquet import ParquetFile, read_table
+    rng = np.random.default_rng(5)
+    n = 30_000
+    words = ["final", "deposits", "slyly", "żółw", "日本", "", "carefully ironic requests", "x" * 90]
+    comment = [" ".join(words[int(j)] for j in rng.integers(0, len(words), int(rng.integers(1, 5)))) + f" #{i}" for i in range(n)]
+    low = [words[int(j)] for j in rng.integers(0, 4, n)]
+    mixed = [words[int(j)] for j in rng.integers(0, 3, 8000)] + comment[8000:]
+    t = pa.table({"k": pa.array(np.arange(n)), "comment": pa.array(comment, pa.string(), mask=rng.random(n) < 0.1), "low": pa.array(low, pa.string()),
+                  "mixed": pa.array(mixed, pa.string(), mask=rng.random(n) < 0.05), "plain_low": pa.array(low, pa.string(), mask=rng.random(n) < 0.5)})
+    path = str(tmp_path / "strings.parquet")
+    pq.write_table(t, path, use_dictionary=["comment", "low", "mixed"], dictionary_pagesize_limit=4096, data_page_size=4096, row_group_size=8000,
+                   compression=compression, data_page_version=version)
+    f = ParquetFile(path)
+    kinds = [f.inspect_chunk(g, "mixed") for g in range(f.num_row_groups)]
+    f.close()
+    assert kinds[0]["n_plain_pages"] == 0 and kinds[-1]["n_plain_pages"] > 0       # dictionary-only first, fallback later
+    got = read_table(path).to_arrow()
+    assert pa.types.is_dictionary(got.schema.field("low").type)
+    for name in ("comment", "mixed", "plain_low"):
+        assert pa.types.is_string(got.schema.field(name).type) or pa.types.is_large_string(got.schema.field(name).type), got.schema.field(name)
+    assert_tables_equal(plain(got), pq.read_table(path), ordered=True)
+    # the columns of interest alone, and a filter over the Utf8 column on the device
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    dev = read_table(path, columns=["k", "comment"])
+    hit = ops.filter(dev, col("comment").like("%slyly%")).to_arrow()
+    want = [i for i, c in enumerate(t.column("comment").to_pylist()) if c is not None and "slyly" in c]
+    assert hit.column("k").to_pylist() == want
+
+
+def test_dictionary_decode_round_trip():
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(6)
+    vals = ["a", "", "żółć", "longer string " * 3, "b"]
+    s = pa.array([vals[int(j)] for j in rng.integers(0, len(vals), 5000)], pa.string(), mask=rng.random(5000) < 0.2)
+    t = pa.table({"s": s.dictionary_encode(), "v": pa.array(np.arange(5000))})
+    got = DeviceTable.from_arrow(t).dictionary_decode().to_arrow()
+    assert pa.types.is_string(got.schema.field("s").type) or pa.types.is_large_string(got.schema.field("s").type)
+    assert got.column("s").to_pylist() == s.to_pylist() and got.column("v").to_pylist() == list(range(5000))

@@ -47,8 +47,12 @@ def test_unsupported_chunks_are_errors_not_wrong_answers(tmp_path):
     f.close()
     pq.write_table(t.select(["s", "b", "i"]), path, use_dictionary=False, compression="none")
     f = ParquetFile(path)
-    with pytest.raises(_lib.DfgpuError, match="PLAIN-encoded BYTE_ARRAY"):
-        f.inspect_chunk(0, "s")
+    assert f.inspect_chunk(0, "s")["n_plain_pages"] == 1      # PLAIN strings are read as Utf8 since round 2 (the dictionary-index reading of the same chunk is refused)
+    import ctypes as C
+    from datafusion_amd._lib import ParquetChunkInfo
+    buf, nb, d, keep = f._chunk(0, "s")
+    assert _lib.load().dfgpu_parquet_inspect_chunk(buf, C.c_int64(nb), C.byref(d), C.byref(ParquetChunkInfo())) != 0
+    assert b"PLAIN-encoded BYTE_ARRAY" in _lib.load().dfgpu_last_error()
     with pytest.raises(_lib.DfgpuError, match="physical type 0 cannot be read as Boolean"):
         f.inspect_chunk(0, "b")
     f.close()
@@ -168,4 +172,43 @@ def test_row_groups_are_shared_out_to_ranks_without_gaps_or_overlap(tmp_path, wo
     assert flat == list(range(f.num_row_groups))                       # covering, disjoint, in file order, contiguous per rank
     rows = [sum(f.meta.row_group(g).num_rows for g in s) for s in shares]
     assert sum(rows) == n and max(rows) - min(rows) <= 1000            # balanced to one row group
+    f.close()
+
+
+def test_plain_string_chunks_host_half_and_corruption(tmp_path):
+    """BYTE_ARRAY chunks with PLAIN pages (read as Utf8): the host half counts the pages, and flipped bytes in the length prefixes /
+    page headers end in an error message or a clean parse, never in a crash"""
+    import ctypes as C
+
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    from datafusion_amd import _lib
+    from datafusion_amd._lib import ParquetChunkInfo
+    from datafusion_amd.parquet import ParquetFile
+    rng = np.random.default_rng(1)
+    n = 6000
+    t = pa.table({"c": pa.array([f"comment {i} " + "x" * int(rng.integers(0, 30)) for i in range(n)], pa.string(), mask=rng.random(n) < 0.1)})
+    path = str(tmp_path / "plain.parquet")
+    pq.write_table(t, path, use_dictionary=False, data_page_size=2048, compression="none")
+    f = ParquetFile(path)
+    info = f.inspect_chunk(0, "c")
+    assert info["n_plain_pages"] >= 2 and info["values"] == n and info["nulls"] == t.column("c").null_count
+    from datafusion_amd.table import UTF8
+    buf, nb, d, keep = f._chunk(0, "c")
+    d.field.type = UTF8
+    raw = C.string_at(buf, nb)
+    lib = _lib.load()
+    outcomes = {"ok": 0, "error": 0}
+    for pos in list(range(min(96, nb))) + [int(x) for x in rng.integers(0, nb, 300)]:
+        mutated = bytearray(raw)
+        mutated[pos] ^= 0xFF
+        mb = (C.c_uint8 * nb).from_buffer_copy(bytes(mutated))
+        out = ParquetChunkInfo()
+        rc = lib.dfgpu_parquet_inspect_chunk(mb, C.c_int64(nb), C.byref(d), C.byref(out))
+        outcomes["ok" if rc == 0 else "error"] += 1
+        if rc != 0:
+            assert b"parquet" in lib.dfgpu_last_error()
+    assert outcomes["error"] > 0
     f.close()
