@@ -1438,6 +1438,19 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
                 (row_mask != nullptr || (double)jt.build.nrows < 0.15 * (double)jt.am_size);
   if (listed_env && fused_ok && fused_mode != FUSED_LOOKBACK && (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY)) listed = listed_env[0] == '1';
   if (listed) fused_mode = FUSED_PLACED;
+  // The unordered flavour claims every 2048-row tile's output range with one returning atomicAdd on ONE cursor, and a contended
+  // agent-scope atomic retires one claim per ~12 ns (scripts/microbench/tile_atomics.hip): 3.5 ms for an SF100 probe's 293 K
+  // tiles.  A tile of narrow rows streams in less than that — a key-only join moves 16 B per probe row: 5 ns per tile — so the
+  // cursor, not HBM, would set the pace (3.64 ms); counts + placed have no cursor (0.92 + 1.62 ms) and give probe order besides.
+  if (fused_ok && fused_mode == FUSED_UNORDERED && np > (1 << 22)) {
+    int64_t row_bytes = key_bytes / std::max<int64_t>(np, 1) + out_row_bytes;
+    for (int c : pout) {
+      bool is_key = false;
+      for (int k : pk) is_key |= k == c;
+      if (!is_key) row_bytes += type_width(probe.cols[c].field.type);
+    }
+    if (row_bytes * (FUSED_W * BLOCK) < 24 * 6000) fused_mode = FUSED_PLACED;  // tile bytes / (6000 B per ns) < 2 claims' worth
+  }
   // A probe-side row mask is applied in place by the at-most-one-match probes (fused, or lookup -> scan ->
   // materialise); the general pairs path needs the caller to filter first.
   const bool one_match_path = np > 0 && (probe_side_only || fast_inner);

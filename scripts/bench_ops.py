@@ -153,6 +153,47 @@ def main():
         o.free()
         ops.sync()
 
+    # ------------------------------------------------------------------ config 3's other shapes: key-only output, in-query shape
+    if want("join"):
+        import datetime
+        o, li = ops.tpch_orders(args.sf), ops.tpch_lineitem(args.sf)
+        ok = o.select(["o_orderkey"])
+        lk = li.select(["l_orderkey"])
+        nb, np_ = o.num_rows, li.num_rows
+
+        def key_only(mode):
+            ht = ops.JoinHashTable(ok, ["o_orderkey"], probe_mode=ops.PROBE_MODES[mode])
+            out = ht.probe(lk, ["l_orderkey"], "Inner", [], ["l_orderkey"])
+            ht.free()
+            return out
+        for mode in ("order_not_needed", "auto"):
+            measure(f"config 3 (i): INNER join orders x lineitem SF{args.sf:g}, key-only output, probe_mode {mode}", lambda: key_only(mode), nb + np_,
+                    nb * 8 + np_ * 8 + np_ * 8, note="bytes = build keys + probe keys + 8 B per output row (the key; SURVEY's (u32, u32) index pair is 8 B as well)")
+        # the in-query shape: Q3's filters applied first (build = the semi-join's output, probe = lineitem after l_shipdate > 1995-03-15)
+        c = ops.tpch_customer(args.sf)
+        d = lit(datetime.date(1995, 3, 15), pa.date32())
+        cb = ops.filter(c, col("c_mktsegment").eq(lit(queries.SEGMENT_BUILDING, pa.uint8())), ["c_custkey"])
+        of = ops.filter(o, col("o_orderdate") < d, ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+        h0 = ops.JoinHashTable(cb, ["c_custkey"])
+        build = h0.probe(of, ["o_custkey"], "RightSemi", probe_cols=["o_orderkey", "o_orderdate", "o_shippriority"])
+        h0.free()
+        probe = ops.filter(li, col("l_shipdate") > d, ["l_orderkey", "l_extendedprice", "l_discount"])
+        nb2, np2 = build.num_rows, probe.num_rows
+        outn = {}
+
+        def in_query():
+            ht = ops.JoinHashTable(build, ["o_orderkey"], probe_mode=ops.PROBE_MODES["order_not_needed"])
+            out = ht.probe(probe, ["l_orderkey"], "Inner", ["o_orderdate", "o_shippriority"], ["l_orderkey", "l_extendedprice", "l_discount"])
+            ht.free()
+            outn["n"] = out.num_rows
+            return out
+        in_query().free()
+        measure(f"config 3 in-query shape: {nb2} build rows (after the semi-join) x {np2} probe rows (after the shipdate filter), Q3 payload", in_query,
+                nb2 + np2, lambda: nb2 * 16 + np2 * 40 + outn["n"] * 48, note="bytes = build 16 B/row + probe 40 B/row + output 48 B/row")
+        for t in (c, cb, of, build, probe, ok, lk, o, li):
+            t.free()
+        ops.sync()
+
     # ------------------------------------------------------------------ strings in HBM (DFGPU_UTF8)
     if want("strings"):
         import numpy as np
