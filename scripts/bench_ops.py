@@ -155,7 +155,6 @@ def main():
 
     # ------------------------------------------------------------------ config 3's other shapes: key-only output, in-query shape
     if want("join"):
-        import datetime
         o, li = ops.tpch_orders(args.sf), ops.tpch_lineitem(args.sf)
         ok = o.select(["o_orderkey"])
         lk = li.select(["l_orderkey"])
