@@ -1449,7 +1449,9 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       for (int k : pk) is_key |= k == c;
       if (!is_key) row_bytes += type_width(probe.cols[c].field.type);
     }
-    if (row_bytes * (FUSED_W * BLOCK) < 24 * 6000) fused_mode = FUSED_PLACED;  // tile bytes / (6000 B per ns) < 2 claims' worth
+    // tile bytes / (6000 B per ns) below one claim's 12 ns: < 35 B per probe row.  (At two claims' worth the counts pass cost more
+    // than the cursor did: a 40-byte semi-join probe of 72 M rows went from 0.35 to 0.8 ms.)
+    if (row_bytes * (FUSED_W * BLOCK) < 12 * 6000) fused_mode = FUSED_PLACED;
   }
   // A probe-side row mask is applied in place by the at-most-one-match probes (fused, or lookup -> scan ->
   // materialise); the general pairs path needs the caller to filter first.
