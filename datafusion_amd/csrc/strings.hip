@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <string_view>
+#include <thread>
 
 #include "device.hpp"
 #include "internal.hpp"
@@ -306,22 +308,71 @@ Column dictionary_encode(const Column& in, bool sorted) {
   if (hoff[(size_t)G]) d2h(hbytes.data(), values.data->ptr, (size_t)hoff[(size_t)G]);
   dv->values.resize((size_t)G);
   dv->valid.assign((size_t)G, 1);
-  for (int64_t k = 0; k < G; k++) dv->values[(size_t)k].assign(hbytes.data() + hoff[(size_t)k], (size_t)(hoff[(size_t)k + 1] - hoff[(size_t)k]));
+  auto value_at = [&](int32_t k) { return std::string_view(hbytes.data() + hoff[(size_t)k], (size_t)(hoff[(size_t)k + 1] - hoff[(size_t)k])); };
   BufPtr renumber;
   if (sorted && G > 1) {
-    std::vector<int32_t> order((size_t)G);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dv->values[(size_t)a] < dv->values[(size_t)b]; });
-    std::vector<int32_t> rank((size_t)G);
-    std::vector<std::string> sorted_values((size_t)G);
+    // ascending order of the distinct strings (byte order = code point order): views into the one downloaded buffer, sorted in
+    // chunks on host threads and merged pairwise — the 150 K distinct names of 30 M rows took 25 ms of std::string compares on
+    // one core, which was ten times the device side of the call
+    // every string's first 24 bytes as three big-endian words (zero-padded): integer compares decide almost every pair; equal
+    // words mean equal prefixes, then the shorter string is the smaller one unless both run past 24 bytes (full compare)
+    struct SortKey {
+      uint64_t w[3];
+      uint32_t len;
+      int32_t idx;
+    };
+    std::vector<SortKey> order((size_t)G);
     for (int64_t k = 0; k < G; k++) {
-      rank[(size_t)order[(size_t)k]] = (int32_t)k;
-      sorted_values[(size_t)k] = std::move(dv->values[(size_t)order[(size_t)k]]);
+      const std::string_view v = value_at((int32_t)k);
+      SortKey& o = order[(size_t)k];
+      o.len = (uint32_t)v.size();
+      o.idx = (int32_t)k;
+      for (int q = 0; q < 3; q++) {
+        uint64_t x = 0;
+        for (int b = 0; b < 8; b++) {
+          const size_t at = (size_t)q * 8 + (size_t)b;
+          x = (x << 8) | (at < v.size() ? (uint8_t)v[at] : 0u);
+        }
+        o.w[q] = x;
+      }
     }
-    dv->values = std::move(sorted_values);
+    auto less = [&](const SortKey& a, const SortKey& b) {
+      if (a.w[0] != b.w[0]) return a.w[0] < b.w[0];
+      if (a.w[1] != b.w[1]) return a.w[1] < b.w[1];
+      if (a.w[2] != b.w[2]) return a.w[2] < b.w[2];
+      if (a.len <= 24 || b.len <= 24) return a.len < b.len;
+      return value_at(a.idx) < value_at(b.idx);
+    };
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>({16, (int64_t)std::thread::hardware_concurrency(), G / 4096}));
+    if (T <= 1) {
+      std::sort(order.begin(), order.end(), less);
+    } else {
+      std::vector<int64_t> cut((size_t)T + 1);
+      for (int t = 0; t <= T; t++) cut[(size_t)t] = G * t / T;
+      {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back([&, t] { std::sort(order.begin() + cut[(size_t)t], order.begin() + cut[(size_t)t + 1], less); });
+        for (auto& x : th) x.join();
+      }
+      for (int width = 1; width < T; width *= 2) {  // merge runs [t, t + width) and [t + width, t + 2 width)
+        std::vector<std::thread> th;
+        for (int t = 0; t + width < T; t += 2 * width)
+          th.emplace_back([&, t, width] {
+            std::inplace_merge(order.begin() + cut[(size_t)t], order.begin() + cut[(size_t)(t + width)], order.begin() + cut[(size_t)std::min(T, t + 2 * width)], less);
+          });
+        for (auto& x : th) x.join();
+      }
+    }
+    std::vector<int32_t> rank((size_t)G);
+    for (int64_t k = 0; k < G; k++) {
+      rank[(size_t)order[(size_t)k].idx] = (int32_t)k;
+      dv->values[(size_t)k] = std::string(value_at(order[(size_t)k].idx));
+    }
     renumber = make_buf((size_t)G * 4);
     DFGPU_HIP(hipMemcpyAsync(renumber->ptr, rank.data(), (size_t)G * 4, hipMemcpyHostToDevice, r.stream));
     DFGPU_HIP(hipStreamSynchronize(r.stream));  // `rank` is a local
+  } else {
+    for (int64_t k = 0; k < G; k++) dv->values[(size_t)k] = std::string(value_at((int32_t)k));  // first-seen order
   }
   dv->sorted = sorted || G <= 1;
   {

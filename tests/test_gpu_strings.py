@@ -248,3 +248,21 @@ def test_substr_results_compare_with_string_literals_and_group():
     assert ops.filter(dev, cc.ne(lit("99", pa.string()))).num_rows == 6000
     with pytest.raises(_lib.DfgpuError, match="negative substring length"):
         ops.project(dev, [(substr(col("phone"), 1, -1), "p")])
+
+
+def test_sorted_dictionary_order_long_and_prefix_strings():
+    """dictionary_encode(sorted=True): the dictionary is in byte order (= code point order) also for strings that agree in their
+    first 24 bytes, that are prefixes of one another, that hold NUL or non-ASCII bytes — the host sort decides on three big-endian
+    words first and must fall back correctly"""
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(12)
+    base = "a fairly long common prefix, 30+"   # 32 bytes
+    pool = [base + suffix for suffix in ("", "a", "b", "aa", "\x00", "\x00\x00", "z", "é", "zz")] + ["", "a", "a\x00", "a\x00b", "ab", "b", "é", "éa", "日本", "日本語", "x" * 24, "x" * 25, "x" * 23]
+    pool += [f"Customer#{i:09d}" for i in rng.integers(0, 10**6, 9000)]
+    pool = list(dict.fromkeys(pool))
+    rows = [pool[int(j)] for j in rng.integers(0, len(pool), 50_000)]
+    enc = DeviceTable.from_arrow(pa.table({"s": pa.array(rows, pa.string())})).dictionary_encode(["s"], sorted=True).to_arrow()
+    d = enc.column("s").combine_chunks()
+    values = d.dictionary.to_pylist()
+    assert values == sorted(set(rows), key=lambda v: v.encode())
+    assert d.cast(pa.string()).to_pylist() == rows
