@@ -47,20 +47,26 @@ struct MetricsTimer {
   }
 };
 
+// end of every C-ABI call (runtime.hip): when several host threads drive the library, the calling thread's streams are drained
+// and the blocks it freed become everybody's
+void call_epilogue() noexcept;
+
 // Wraps a C-ABI entry point body: exceptions -> error code + thread-local message.
 template <typename F>
 int guarded(F&& f) noexcept {
   MetricsTimer timer;
+  int rc = 0;
   try {
     f();
-    return 0;
   } catch (const std::exception& e) {
     set_last_error(e.what());
-    return 1;
+    rc = 1;
   } catch (...) {
     set_last_error("unknown error");
-    return 1;
+    rc = 1;
   }
+  call_epilogue();
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -68,15 +74,30 @@ int guarded(F&& f) noexcept {
 // single DataFusion process that owns several GPUs (one per output partition) initialises several and selects the
 // calling thread's device with dfgpu_set_device — every entry point that takes a table / join / aggregate handle
 // switches the calling thread to the handle's device first (unwrap()).
+struct Runtime;
+// `r.stream` = the CALLING THREAD's stream on device r (handles usable concurrently from different threads).  The thread
+// that initialised the device works on the device's first stream; every other host thread gets a stream of its own on first use
+// (taken from / returned to a per-device list when threads come and go: a scan's decode threads, a plan's partition threads), so
+// their kernels and copies overlap.  What keeps that safe is the rule of call_epilogue(): once a second thread has appeared,
+// every C-ABI call drains its thread's stream before it returns — whatever a handle holds is complete when another thread
+// gets to see it — and the blocks a thread frees stay its own until then.  A process with one thread keeps the old behaviour:
+// calls return with their work enqueued, freed blocks are reusable at once in stream order.
+struct StreamRef {
+  Runtime* r = nullptr;
+  operator hipStream_t() const;
+};
 struct Runtime {
   int device = -1;
-  hipStream_t stream = nullptr;
+  StreamRef stream;                 // the calling thread's stream (see above)
+  hipStream_t first_stream = nullptr;
+  uint64_t generation = 0;          // bumped by dfgpu_init / dfgpu_shutdown: threads re-resolve the streams they remembered
   bool initialised = false;
   int num_cus = 256;
+  hipStream_t thread_stream();      // what `stream` converts to
 
-  // pool allocator: size-bucketed free lists; blocks are reused in stream order (all work is
-  // enqueued on `stream`, so a block freed by the host after its last kernel was enqueued can
-  // be handed to the next kernel safely).
+  // pool allocator: size-bucketed free lists; blocks are reused in stream order (a block freed by the host after its last kernel was
+  // enqueued can be handed to the next kernel of the SAME stream safely; with several threads a freed block waits in its thread's
+  // pending list until the end of the call).
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks;
   std::map<void*, size_t> live;  // ptr -> capacity

@@ -3,6 +3,7 @@
 #include "internal.hpp"
 
 #include <algorithm>
+#include <atomic>
 
 namespace dfgpu {
 
@@ -48,6 +49,99 @@ Runtime& rt() {
 }
 void require_init() { DFGPU_CHECK(rt().initialised, "dfgpu_init() has not been called"); }
 
+// ------------------------------------------------------------------------------- threads and streams
+// per (host thread, device): the thread's stream and the blocks it freed during the current call
+struct ThreadDevice {
+  hipStream_t stream = nullptr;
+  uint64_t generation = 0;                            // of the runtime the stream was resolved against
+  bool borrowed = false;                              // taken from the device's spare list (goes back when the thread ends)
+  std::vector<std::pair<size_t, void*>> pending;      // freed by this thread, reusable by it, by everyone after the call's drain
+};
+struct SpareStreams {                                  // process lifetime (never destroyed: threads may end after static destructors ran)
+  std::mutex mu;
+  std::map<int, std::vector<hipStream_t>> by_device;
+};
+static SpareStreams& spare_streams() {
+  static SpareStreams* s = new SpareStreams();
+  return *s;
+}
+static std::atomic<bool> g_multi_thread{false};        // a second host thread has driven the library
+static std::atomic<std::thread::id> g_first_thread{};
+struct ThreadState {
+  std::vector<ThreadDevice> dev;                       // indexed by device id
+  ~ThreadState() {
+    for (size_t d = 0; d < dev.size(); d++) {
+      ThreadDevice& td = dev[d];
+      if (!td.pending.empty() && d < g_runtimes.size() && g_runtimes[d]) {   // (a thread that ends outside a call: its blocks go home)
+        if (td.stream) (void)hipStreamSynchronize(td.stream);
+        std::lock_guard<std::mutex> lk(g_runtimes[d]->mu);
+        for (auto& b : td.pending) {
+          g_runtimes[d]->free_blocks.emplace(b.first, b.second);
+          g_runtimes[d]->cached += (int64_t)b.first;
+        }
+      }
+      if (td.stream && td.borrowed) {
+        std::lock_guard<std::mutex> lk(spare_streams().mu);
+        spare_streams().by_device[(int)d].push_back(td.stream);
+      }
+    }
+  }
+};
+static thread_local ThreadState t_state;
+static ThreadDevice& thread_device(int device) {
+  if ((int)t_state.dev.size() <= device) t_state.dev.resize((size_t)device + 1);
+  return t_state.dev[(size_t)device];
+}
+
+StreamRef::operator hipStream_t() const { return r ? r->thread_stream() : nullptr; }
+
+hipStream_t Runtime::thread_stream() {
+  if (!initialised) return nullptr;
+  ThreadDevice& td = thread_device(device);
+  if (td.stream && td.generation == generation) return td.stream;
+  if (td.stream && !td.borrowed) td.stream = nullptr;   // the first stream of an earlier dfgpu_init: gone with its dfgpu_shutdown
+  td.generation = generation;
+  if (td.stream) return td.stream;                      // (a borrowed stream outlives shutdown / init)
+  const std::thread::id me = std::this_thread::get_id();
+  std::thread::id none{};
+  if (g_first_thread.compare_exchange_strong(none, me) || g_first_thread.load() == me) {
+    td.stream = first_stream;   // the thread that came first keeps the device's first stream
+    return td.stream;
+  }
+  // a further thread: from now on calls drain their streams before they return.  Whatever the other threads had in flight when
+  // this one arrived — including work on blocks that already went back to the pool — is waited for once, here.
+  if (!g_multi_thread.exchange(true)) (void)hipDeviceSynchronize();
+  {
+    std::lock_guard<std::mutex> lk(spare_streams().mu);
+    auto& spare = spare_streams().by_device[device];
+    if (!spare.empty()) {
+      td.stream = spare.back();
+      spare.pop_back();
+    }
+  }
+  if (!td.stream) DFGPU_HIP(hipStreamCreateWithFlags(&td.stream, hipStreamNonBlocking));
+  td.borrowed = true;
+  return td.stream;
+}
+
+void call_epilogue() noexcept {
+  if (!g_multi_thread.load(std::memory_order_relaxed)) return;
+  for (size_t d = 0; d < t_state.dev.size(); d++) {
+    ThreadDevice& td = t_state.dev[d];
+    if (!td.stream) continue;
+    if (d >= g_runtimes.size() || !g_runtimes[d]) continue;
+    if (hipStreamSynchronize(td.stream) != hipSuccess) (void)hipGetLastError();
+    if (td.pending.empty()) continue;
+    Runtime& r = *g_runtimes[d];
+    std::lock_guard<std::mutex> lk(r.mu);
+    for (auto& b : td.pending) {
+      r.free_blocks.emplace(b.first, b.second);
+      r.cached += (int64_t)b.first;
+    }
+    td.pending.clear();
+  }
+}
+
 // ------------------------------------------------------------------------------- pool
 // Blocks are rounded to 512 B (small) or 2 MiB (large) so that the large, repeated
 // allocations of a query pipeline (column buffers of equal row counts) hit the cache.
@@ -59,6 +153,23 @@ static size_t round_size(size_t n) {
 
 void* Runtime::alloc(size_t bytes) {
   size_t cap = round_size(bytes ? bytes : 1);
+  if (g_multi_thread.load(std::memory_order_relaxed)) {
+    // a block this thread freed earlier in the call: reusable in its own stream's order
+    ThreadDevice& td = thread_device(device);
+    size_t best = td.pending.size();
+    for (size_t i = 0; i < td.pending.size(); i++)
+      if (td.pending[i].first >= cap && td.pending[i].first <= cap + cap / 4 && (best == td.pending.size() || td.pending[i].first < td.pending[best].first)) best = i;
+    if (best < td.pending.size()) {
+      const size_t c = td.pending[best].first;
+      void* p = td.pending[best].second;
+      td.pending.erase(td.pending.begin() + (long)best);
+      std::lock_guard<std::mutex> lk(mu);
+      live[p] = c;
+      in_use += (int64_t)c;
+      peak = std::max(peak, in_use);
+      return p;
+    }
+  }
   {
     std::lock_guard<std::mutex> lk(mu);
     auto it = free_blocks.lower_bound(cap);
@@ -96,14 +207,21 @@ void* Runtime::alloc(size_t bytes) {
 
 void Runtime::free(void* p) {
   if (!p) return;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = live.find(p);
-  if (it == live.end()) return;
-  size_t cap = it->second;
-  live.erase(it);
-  in_use -= (int64_t)cap;
-  free_blocks.emplace(cap, p);
-  cached += (int64_t)cap;
+  size_t cap;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = live.find(p);
+    if (it == live.end()) return;
+    cap = it->second;
+    live.erase(it);
+    in_use -= (int64_t)cap;
+    if (!g_multi_thread.load(std::memory_order_seq_cst)) {
+      free_blocks.emplace(cap, p);
+      cached += (int64_t)cap;
+      return;
+    }
+  }
+  thread_device(device).pending.emplace_back(cap, p);   // everybody's after this thread's call has drained its stream
 }
 
 void Runtime::trim() {
@@ -114,7 +232,7 @@ void Runtime::trim() {
     cached = 0;
   }
   if (blocks.empty()) return;
-  (void)hipStreamSynchronize(stream);
+  (void)hipDeviceSynchronize();   // every thread's stream: a cached block may have been freed on any of them
   for (auto& kv : blocks) (void)hipFree(kv.second);
 }
 
@@ -164,7 +282,7 @@ ProfileScope::~ProfileScope() {
 
 void Runtime::collect() {
   if (recs.empty()) return;
-  (void)hipStreamSynchronize(stream);
+  (void)hipDeviceSynchronize();   // the events were recorded on their threads' streams
   for (auto& rec : recs) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, rec.a, rec.b);
@@ -281,7 +399,10 @@ int dfgpu_init(const int* device_ids, int n_devices) {
       hipDeviceProp_t prop;
       DFGPU_HIP(hipGetDeviceProperties(&prop, device));
       r->num_cus = prop.multiProcessorCount;
-      DFGPU_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+      DFGPU_HIP(hipStreamCreateWithFlags(&r->first_stream, hipStreamNonBlocking));
+      r->stream.r = r.get();
+      static std::atomic<uint64_t> generations{0};
+      r->generation = ++generations;
       r->device = device;
       r->initialised = true;
       g_runtimes[device] = std::move(r);
@@ -322,9 +443,14 @@ int dfgpu_shutdown(void) {
       (void)hipSetDevice(d);
       r.collect();
       r.trim();
-      (void)hipStreamDestroy(r.stream);
-      r.stream = nullptr;
-      r.initialised = false;
+      r.initialised = false;   // (thread_stream() answers null from here on)
+      (void)hipStreamDestroy(r.first_stream);
+      r.first_stream = nullptr;
+      {
+        std::lock_guard<std::mutex> sl(spare_streams().mu);
+        for (hipStream_t s : spare_streams().by_device[d]) (void)hipStreamDestroy(s);
+        spare_streams().by_device[d].clear();
+      }
     }
     g_initialised.clear();
     t_device = t_hip_device = -1;
@@ -334,11 +460,12 @@ int dfgpu_shutdown(void) {
 int dfgpu_sync(void) {
   return guarded([&] {
     require_init();
-    DFGPU_HIP(hipStreamSynchronize(rt().stream));
+    if (g_multi_thread.load()) DFGPU_HIP(hipDeviceSynchronize());   // every thread's stream
+    else DFGPU_HIP(hipStreamSynchronize(rt().stream));
   });
 }
 
-void* dfgpu_stream(void) { return (void*)rt().stream; }
+void* dfgpu_stream(void) { return (void*)(hipStream_t)rt().stream; }
 
 int dfgpu_mem_stats(int64_t* in_use, int64_t* cached, int64_t* peak) {
   return guarded([&] {

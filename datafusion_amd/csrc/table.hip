@@ -107,7 +107,12 @@ struct Uploader {
   hipStream_t copy_stream = nullptr;
   std::vector<void*> registered;
   std::vector<void*> staged;  // host temporaries to free after the copies
-  Uploader() { DFGPU_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); }
+  Uploader() {
+    // the destination blocks come from the pool in the calling thread's stream order: whatever that stream still has in flight on a
+    // recycled block must be done before the side stream writes into it
+    DFGPU_HIP(hipStreamSynchronize(rt().stream));
+    DFGPU_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  }
   void upload(void* dst, const void* src, size_t n) {
     if (n == 0) return;
     thread_metrics().h2d_bytes += (int64_t)n;

@@ -21,15 +21,16 @@
  *     with dfgpu_set_device (HIP's current device is per thread; the library keeps it in step on every entry).  Every
  *     handle (table, join table, aggregate) lives on the device that was current when it was created, and an entry
  *     point that takes a handle switches the calling thread to that handle's device first.
- *   - all work of a device is enqueued on that device's own library stream; calls are synchronous w.r.t. results
- *     they return (row counts), asynchronous otherwise.  dfgpu_sync() drains the current device's stream.
- *   - handles are owned by exactly one caller and freed exactly once.  A join table
- *     (dfgpu_join_t) is immutable after build and may be probed by many callers
- *     (CollectLeft: one build shared by all probe partitions, hash_join/exec.rs:1503-1523).
- *   - threads: the allocator and the error channel are thread-safe and all device work is ordered on the one library
- *     stream, so entry points working on different handles may be called from different host threads (the Parquet
- *     scan decodes column chunks that way: the host half of dfgpu_parquet_decode_chunk runs in parallel); one handle is
- *     not re-entrant — one caller at a time, as one stream per `execute(partition)` in the reference.
+ *   - streams: every host thread works on a HIP stream of its own per device (the thread that called dfgpu_init on the device's
+ *     first stream), so entry points working on different handles from different threads run concurrently on the device —
+ *     `execute(partition)` of several partitions, the column chunks of a scan.  With ONE calling thread, calls are synchronous
+ *     w.r.t. the results they return (row counts) and asynchronous otherwise; dfgpu_sync() drains the device.  Once a SECOND
+ *     thread has called into the library, every call drains its thread's stream before it returns: what a handle holds is
+ *     complete when another thread gets to see it, and the HBM blocks a call freed become reusable by other threads only then.
+ *   - handles are owned by exactly one caller and freed exactly once (from any thread).  A join table (dfgpu_join_t) is
+ *     immutable after build and may be probed by many callers at once (CollectLeft: one build shared by all probe partitions,
+ *     hash_join/exec.rs:1503-1523); any other handle is not re-entrant — one caller at a time, as one stream per
+ *     `execute(partition)` in the reference.  The allocator, the error channel (thread-local) and the metrics are thread-safe.
  *   - device columns are Arrow-layout buffers in HBM: fixed-width values, optional
  *     validity bitmap (LSB first, 1 = valid), Boolean columns bit-packed.
  */

@@ -148,3 +148,60 @@ def test_operator_metrics_are_per_thread():
     assert seen["rows_in"] == n and seen["h2d_bytes"] == 0
     assert after["rows_in"] == before["rows_in"] and after["hbm_bytes_algorithmic"] == before["hbm_bytes_algorithmic"]
     ops.profile_enable(False)
+
+
+def test_handles_are_usable_concurrently_from_different_threads():
+    """different handles usable concurrently from different host threads.  Every thread works on a stream of its own
+    (dfgpu_stream differs per thread), builds / probes / aggregates its own tables while the others do the same, shares one join
+    table built by the main thread (CollectLeft: one build, many probers), and frees its handles itself; every result equals the
+    oracle's.  The pool must never hand a block that one thread's stream still works on to another thread."""
+    import threading
+
+    import numpy as np
+    import pyarrow as pa
+
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    from tests.util import assert_tables_equal, random_table, to_oracle_expr
+    lib = _lib.init()
+    lib.dfgpu_stream.restype = __import__("ctypes").c_void_p
+    rng = np.random.default_rng(1)
+    shared_build = random_table(rng, 20_000, {"bk": (pa.int64(), 0, 30_000), "bv": (pa.int32(), 0, 1000)})
+    shared_build = shared_build.group_by("bk").aggregate([("bv", "min")]).rename_columns(["bk", "bv"])     # unique keys
+    ht = ops.JoinHashTable(DeviceTable.from_arrow(shared_build), ["bk"])
+    streams, errors, results = {}, [], {}
+
+    def work(tid):
+        try:
+            streams[tid] = lib.dfgpu_stream()
+            r = np.random.default_rng(100 + tid)
+            for it in range(6):
+                t = random_table(r, 60_000 + 1000 * tid, {"k": (pa.int64(), 0, 30_000), "d": (pa.decimal128(15, 2), -10**6, 10**6), "g": (pa.int32(), 0, 50)}, null_frac=0.05)
+                dev = DeviceTable.from_arrow(t)
+                pred = col("g") < lit(25 + tid, pa.int32())
+                f = ops.filter(dev, pred)
+                agg = ops.aggregate(f, [(col("g"), "g")], [("sum", col("d"), "s"), ("count", None, "n")], "Single").to_arrow()
+                j = ht.probe(f, ["k"], "Inner", ["bv"], ["k", "d"]).to_arrow()
+                srt = ops.sort(f, [("d", True, False), ("k", False, False)], fetch=50).to_arrow()
+                ft = oracle.filter(t, to_oracle_expr(pred), t.column_names)
+                results[(tid, it)] = (agg, j, srt, ft)
+                f.free()
+                dev.free()
+        except Exception as e:   # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert len(set(streams.values())) == len(streams) and lib.dfgpu_stream() not in streams.values()   # a stream per thread, none is the main thread's
+    from tests.test_gpu_aggregate import assert_agg_equal, oracle_agg
+    for (tid, it), (agg, j, srt, ft) in results.items():
+        assert_agg_equal(agg, oracle_agg(ft, [(col("g"), "g")], [("sum", col("d"), "s"), ("count", None, "n")], "Single"))
+        assert_tables_equal(j, oracle.hash_join(shared_build, ft, [("bk", "k")], "Inner").select(["bv", "k", "d"]))
+        assert_tables_equal(srt, oracle.sort(ft, [("d", True, False), ("k", False, False)], 50), ordered=True)
+    ht.free()
