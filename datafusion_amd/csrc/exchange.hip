@@ -383,6 +383,9 @@ static void unify_dictionaries(Comm& c, std::vector<Table>& t) {
 }
 
 // ------------------------------------------------------------------------------------------------ the exchange proper
+__global__ __launch_bounds__(BLOCK) void k_offsets_to_lengths(const int64_t* __restrict__ off, int64_t n, uint32_t* __restrict__ len) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) len[i] = (uint32_t)(off[i + 1] - off[i]);
+}
 __global__ __launch_bounds__(BLOCK) void k_fill_words(uint64_t* __restrict__ p, int64_t nw, uint64_t v) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < nw; i += (int64_t)gridDim.x * BLOCK) p[i] = v;
 }
@@ -411,9 +414,32 @@ __global__ __launch_bounds__(BLOCK) void k_range_mask(const T* __restrict__ key,
 static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<Table>>& parts, const std::vector<Table>& proto) {
   const int L = c.n_local(), W = c.world;
   const size_t ncols = proto[0].cols.size();
-  // what every rank must know: rows[src][dst], and per column whether any rank carries a validity bitmap + the type (a schema check)
-  const int64_t meta_bytes = (int64_t)W * 8 + (int64_t)ncols * 2;
+  // Utf8 columns travel as two buffers: one 32-bit length per row (scanned into Arrow offsets at the receiver) and the bytes; the
+  // receiver must know how many bytes every source sends it
+  std::vector<size_t> utf8_cols;
+  for (size_t ci = 0; ci < ncols; ci++)
+    if (proto[0].cols[ci].field.type == DFGPU_UTF8) utf8_cols.push_back(ci);
+  const size_t NU = utf8_cols.size();
+  // what every rank must know: rows[src][dst], per column whether any rank carries a validity bitmap + the type (a schema check),
+  // and string bytes[src][dst] per Utf8 column
+  const int64_t meta_strings = (int64_t)W * 8 + (int64_t)ncols * 2;
+  const int64_t meta_bytes = meta_strings + (int64_t)NU * W * 8;
   std::vector<std::vector<uint8_t>> meta(L, std::vector<uint8_t>((size_t)meta_bytes, 0));
+  // string bytes of part (l, p), column utf8_cols[u]: [first, last) of its data buffer
+  std::vector<std::vector<std::vector<std::pair<int64_t, int64_t>>>> str_range(L, std::vector<std::vector<std::pair<int64_t, int64_t>>>(W, std::vector<std::pair<int64_t, int64_t>>(NU, {0, 0})));
+  for (int l = 0; l < L && NU; l++) {
+    use_device(c.devices[l]);
+    for (int p = 0; p < W; p++)
+      for (size_t u = 0; u < NU; u++) {
+        const Column& pc = parts[l][p].cols[utf8_cols[u]];
+        const int64_t n = parts[l][p].nrows;
+        if (n == 0 || !pc.offsets) continue;
+        const uint64_t first = read_u64(reinterpret_cast<const uint64_t*>(str_offsets(pc))), last = read_u64(reinterpret_cast<const uint64_t*>(str_offsets(pc)) + n);
+        str_range[l][p][u] = {(int64_t)first, (int64_t)last};
+        const int64_t nb = (int64_t)(last - first);
+        std::memcpy(&meta[l][(size_t)meta_strings + (u * W + (size_t)p) * 8], &nb, 8);
+      }
+  }
   for (int l = 0; l < L; l++) {
     DFGPU_CHECK(proto[l].cols.size() == ncols, "exchange: the local tables differ in their column count");
     for (int p = 0; p < W; p++) {
@@ -431,6 +457,11 @@ static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<
   auto rows = [&](int src, int dst) {
     int64_t n;
     std::memcpy(&n, all.data() + (size_t)src * meta_bytes + (size_t)dst * 8, 8);
+    return n;
+  };
+  auto str_bytes = [&](int src, int dst, size_t u) {
+    int64_t n;
+    std::memcpy(&n, all.data() + (size_t)src * meta_bytes + (size_t)meta_strings + (u * W + (size_t)dst) * 8, 8);
     return n;
   };
   std::vector<uint8_t> any_valid(ncols, 0);
@@ -457,6 +488,17 @@ static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<
     out[l] = Table();
     out[l].nrows = off[l][W];
     for (size_t ci = 0; ci < ncols; ci++) {
+      if (proto[l].cols[ci].field.type == DFGPU_UTF8) {  // offsets and bytes are made after the lengths arrived
+        Column n = alloc_string_column(proto[l].cols[ci], out[l].nrows);
+        n.validity.reset();
+        n.null_count = 0;
+        if (any_valid[ci]) {
+          n.validity = make_zero_buf(bitmap_bytes(out[l].nrows));
+          n.null_count = -1;
+        }
+        out[l].cols.push_back(std::move(n));
+        continue;
+      }
       Column n = alloc_like(proto[l].cols[ci], out[l].nrows);
       if (proto[l].cols[ci].field.type == DFGPU_BOOL && out[l].nrows) DFGPU_HIP(hipMemsetAsync(n.data->ptr, 0, bitmap_bytes(out[l].nrows), rt().stream));
       if (any_valid[ci]) {
@@ -466,14 +508,51 @@ static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<
       out[l].cols.push_back(std::move(n));
     }
   }
-  std::vector<BufPtr> keep;  // staging that must outlive the enqueued transfers
-  std::vector<std::vector<Xfer>> xs;
+
   struct Placement { size_t ci; bool validity; std::vector<BufPtr> stage; std::vector<std::vector<int64_t>> soff; };
   std::vector<Placement> placements;
+  std::vector<BufPtr> keep;  // staging that must outlive the enqueued transfers
+  std::vector<std::vector<Xfer>> xs;
+  // per local rank and Utf8 column: the received lengths (rows of the result), the byte offsets of every source's share
+  std::vector<std::vector<BufPtr>> str_len(L, std::vector<BufPtr>(NU));
+  for (size_t u = 0; u < NU; u++) {
+    const size_t ci = utf8_cols[u];
+    std::vector<Xfer> xl(L, Xfer(W)), xb(L, Xfer(W));
+    for (int l = 0; l < L; l++) {
+      const int me = c.first_rank + l;
+      use_device(c.devices[l]);
+      str_len[l][u] = make_buf((size_t)std::max<int64_t>(out[l].nrows, 1) * 4 + 16);
+      int64_t total = 0;
+      for (int p = 0; p < W; p++) total += str_bytes(p, me, u);
+      out[l].cols[ci].data = make_buf((size_t)total + 16);
+      int64_t at = 0;
+      for (int p = 0; p < W; p++) {
+        const Column& pc = parts[l][p].cols[ci];
+        const int64_t n = parts[l][p].nrows;
+        if (n) {  // this part's lengths, from its offsets
+          BufPtr lens = make_buf((size_t)n * 4 + 16);
+          k_offsets_to_lengths<<<grid_for(n, BLOCK), BLOCK, 0, rt().stream>>>(str_offsets(pc), n, lens->as<uint32_t>());
+          DFGPU_HIP(hipGetLastError());
+          keep.push_back(lens);
+          xl[l].send[p] = lens->ptr;
+          xb[l].send[p] = (const char*)pc.ptr() + str_range[l][p][u].first;
+        }
+        xl[l].send_bytes[p] = n * 4;
+        xb[l].send_bytes[p] = str_range[l][p][u].second - str_range[l][p][u].first;
+        xl[l].recv[p] = (char*)str_len[l][u]->ptr + (size_t)off[l][p] * 4;
+        xl[l].recv_bytes[p] = rows(p, me) * 4;
+        xb[l].recv[p] = (char*)out[l].cols[ci].data->ptr + at;
+        xb[l].recv_bytes[p] = str_bytes(p, me, u);
+        at += str_bytes(p, me, u);
+      }
+    }
+    xs.push_back(std::move(xl));
+    xs.push_back(std::move(xb));
+  }
   for (size_t ci = 0; ci < ncols; ci++) {
     const int type = proto[0].cols[ci].field.type;
     // ---- values: byte-addressable types travel straight from the partition slices into the result column
-    if (type != DFGPU_BOOL) {
+    if (type != DFGPU_BOOL && type != DFGPU_UTF8) {
       const int w = type_width(type);
       std::vector<Xfer> x(L, Xfer(W));
       for (int l = 0; l < L; l++) {
@@ -527,6 +606,13 @@ static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<
       uint64_t* dst = pl.validity ? oc.validity->as<uint64_t>() : oc.data->as<uint64_t>();
       for (int p = 0; p < W; p++)
         if (rows(p, me)) bitmap_place((const uint64_t*)((const char*)pl.stage[l]->ptr + pl.soff[l][p]), off[l][p], rows(p, me), dst);
+    }
+  for (size_t u = 0; u < NU; u++)
+    for (int l = 0; l < L; l++) {  // the received lengths, in row order, become the Arrow offsets
+      use_device(c.devices[l]);
+      Column& oc = out[l].cols[utf8_cols[u]];
+      if (out[l].nrows) scan_u32(str_len[l][u]->as<uint32_t>(), out[l].nrows, oc.offsets->as<uint64_t>());
+      else DFGPU_HIP(hipMemsetAsync(oc.offsets->ptr, 0, 8, rt().stream));
     }
   for (int l = 0; l < L; l++) {  // the caller may free the parts as soon as this returns
     use_device(c.devices[l]);

@@ -31,7 +31,8 @@ def decoded(t: pa.Table) -> pa.Table:
 
 
 def mixed_table(seed, n, values=("AIR", "MAIL", "RAIL", "SHIP", "TRUCK")):
-    """integer key, Decimal128 payload, a nullable int column, a Boolean column and a dictionary-encoded string column with NULLs"""
+    """integer key, Decimal128 payload, a nullable int column, a Boolean column, a dictionary-encoded string column with NULLs and a plain Utf8
+    column with NULLs"""
     rng = np.random.default_rng(seed)
     return pa.table({
         "k": pa.array(rng.integers(0, 10**6, n), type=pa.int64()),
@@ -39,6 +40,8 @@ def mixed_table(seed, n, values=("AIR", "MAIL", "RAIL", "SHIP", "TRUCK")):
         "q": pa.array(rng.integers(0, 1000, n), type=pa.int32(), mask=rng.random(n) < 0.2),
         "b": pa.array(rng.random(n) < 0.4, type=pa.bool_(), mask=rng.random(n) < 0.1),
         "s": dict_col(rng.integers(0, len(values), n), list(values), mask=rng.random(n) < 0.15),
+        # a plain Utf8 column (bytes in HBM: a Parquet comment column): lengths and bytes cross the exchange, offsets are rebuilt
+        "u": pa.array([None if x % 13 == 0 else ("żółw " * int(x % 4) + f"comment {x}") for x in rng.integers(0, 10**6, n)], type=pa.string()),
     })
 
 
