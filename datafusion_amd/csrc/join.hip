@@ -56,6 +56,7 @@ struct JoinTable {
   BufPtr rank_tab;  // the probe's view of the rank map: {bitmap word, prefix} interleaved, ONE 16-byte load per lookup
   std::shared_ptr<RadixTable> radix;  // KIND_RADIX: build records partitioned for the LDS join (radix_join.hip)
   BufPtr visited;  // u8 per build row, lazily allocated
+  std::mutex mu;   // a join table is probed by several threads at once (CollectLeft): `visited` is made once, `info` counts under it
   // HashJoinExec::null_aware (NOT IN semantics, single key column): what JoinLeftData shares between the probe
   // partitions in the reference (probe_side_has_null / probe_side_non_empty / build_side_has_null, exec.rs:195-240)
   bool null_aware = false;
@@ -1339,7 +1340,9 @@ static JoinTable* unwrap_join(dfgpu_join_t ht) {
 
 ColStats column_stats(Column& kc, int64_t nrows) {
   DFGPU_CHECK(is_integer_like(kc.field.type) && kc.field.type != DFGPU_UINT64, "dfgpu_column_minmax: integer columns only");
-  if (kc.stats) return *kc.stats;  // computed before for these rows (tables are immutable)
+  // computed before for these rows (tables are immutable).  The cache slot is read and written atomically: two threads that read
+  // the same table at once (the same statistics, computed twice at worst) must not tear it.
+  if (auto cached = std::atomic_load(&kc.stats)) return *cached;
   Runtime& r = rt();
   MinMax res{INT64_MAX, INT64_MIN, 0, 0, 0};
   if (nrows > 0) {
@@ -1357,8 +1360,9 @@ ColStats column_stats(Column& kc, int64_t nrows) {
       DFGPU_HIP(hipGetLastError());
     }
     d2h(&res, mm->ptr, sizeof res);
-    kc.stats = std::make_shared<ColStats>(ColStats{res.smin, res.smax, (int64_t)res.valid, res.valid > 0 && res.unsorted == 0, res.valid > 0 && res.descends == 0});
-    return *kc.stats;
+    auto fresh = std::make_shared<ColStats>(ColStats{res.smin, res.smax, (int64_t)res.valid, res.valid > 0 && res.unsorted == 0, res.valid > 0 && res.descends == 0});
+    std::atomic_store(&kc.stats, fresh);
+    return *fresh;
   }
   return ColStats{res.smin, res.smax, 0, false, false};
 }
@@ -1394,10 +1398,19 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
   uint8_t* visited = nullptr;
   if (needs_visited(join_type)) {
-    if (!jt.visited) jt.visited = make_zero_buf((size_t)jt.build.nrows + 64);
+    {
+      std::lock_guard<std::mutex> lk(jt.mu);
+      if (!jt.visited) {
+        jt.visited = make_zero_buf((size_t)jt.build.nrows + 64);
+        DFGPU_HIP(hipStreamSynchronize(rt().stream));  // zeroed before any other thread's stream marks rows in it
+      }
+    }
     visited = jt.visited->as<uint8_t>();
   }
-  jt.info.probe_rows += np;
+  {
+    std::lock_guard<std::mutex> lk(jt.mu);
+    jt.info.probe_rows += np;
+  }
   int64_t key_bytes = 0;
   for (int i = 0; i < ctx.pkeys.n; i++) key_bytes += np * ctx.pkeys.c[i].width;
   Table out;
@@ -1693,7 +1706,10 @@ static Table join_probe_null_aware(JoinTable& jt, const Table& probe, const std:
   switch (null_aware_before_probe(jt, probe, pk, join_type, false)) {
     case NA_EMPTY:
       for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
-      jt.info.probe_rows += probe.nrows;
+      {
+        std::lock_guard<std::mutex> lk(jt.mu);
+        jt.info.probe_rows += probe.nrows;
+      }
       return empty_selection(probe, pout);
     case NA_MASK_NULL_PROBE_KEYS: {
       bool consumed = false;
@@ -1755,7 +1771,10 @@ static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std
   const int64_t np = probe.nrows;
   const int64_t n_words = (np + 63) / 64;
   const int g = grid_for(n_words, BLOCK / WAVE);
-  jt.info.probe_rows += np;
+  {
+    std::lock_guard<std::mutex> lk(jt.mu);
+    jt.info.probe_rows += np;
+  }
   Pairs P = key_equal_pairs(jt, probe, pk);
   const int64_t m = P.m;
   BufPtr ob = P.ob, op = P.op;
@@ -1793,7 +1812,13 @@ static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std
   BufPtr hits = make_zero_buf((size_t)(np ? np : 1) * 4);
   uint8_t* visited = nullptr;
   if (needs_visited(join_type)) {
-    if (!jt.visited) jt.visited = make_zero_buf((size_t)jt.build.nrows + 64);
+    {
+      std::lock_guard<std::mutex> lk(jt.mu);
+      if (!jt.visited) {
+        jt.visited = make_zero_buf((size_t)jt.build.nrows + 64);
+        DFGPU_HIP(hipStreamSynchronize(rt().stream));  // zeroed before any other thread's stream marks rows in it
+      }
+    }
     visited = jt.visited->as<uint8_t>();
   }
   if (m) k_pair_tally<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(ob->as<int64_t>(), op->as<int64_t>(), pass->as<uint64_t>(), m, hits->as<uint32_t>(), visited);

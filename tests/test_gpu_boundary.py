@@ -171,7 +171,8 @@ def test_handles_are_usable_concurrently_from_different_threads():
     shared_build = random_table(rng, 20_000, {"bk": (pa.int64(), 0, 30_000), "bv": (pa.int32(), 0, 1000)})
     shared_build = shared_build.group_by("bk").aggregate([("bv", "min")]).rename_columns(["bk", "bv"])     # unique keys
     ht = ops.JoinHashTable(DeviceTable.from_arrow(shared_build), ["bk"])
-    streams, errors, results = {}, [], {}
+    ht_semi = ops.JoinHashTable(DeviceTable.from_arrow(shared_build), ["bk"])   # its visited bytes are marked by all threads at once
+    streams, errors, results, probed_keys = {}, [], {}, []
 
     def work(tid):
         try:
@@ -184,9 +185,11 @@ def test_handles_are_usable_concurrently_from_different_threads():
                 f = ops.filter(dev, pred)
                 agg = ops.aggregate(f, [(col("g"), "g")], [("sum", col("d"), "s"), ("count", None, "n")], "Single").to_arrow()
                 j = ht.probe(f, ["k"], "Inner", ["bv"], ["k", "d"]).to_arrow()
+                ht_semi.probe(f, ["k"], "LeftSemi").free()
                 srt = ops.sort(f, [("d", True, False), ("k", False, False)], fetch=50).to_arrow()
                 ft = oracle.filter(t, to_oracle_expr(pred), t.column_names)
                 results[(tid, it)] = (agg, j, srt, ft)
+                probed_keys.append(ft.column("k"))
                 f.free()
                 dev.free()
         except Exception as e:   # noqa: BLE001
@@ -204,4 +207,10 @@ def test_handles_are_usable_concurrently_from_different_threads():
         assert_agg_equal(agg, oracle_agg(ft, [(col("g"), "g")], [("sum", col("d"), "s"), ("count", None, "n")], "Single"))
         assert_tables_equal(j, oracle.hash_join(shared_build, ft, [("bk", "k")], "Inner").select(["bv", "k", "d"]))
         assert_tables_equal(srt, oracle.sort(ft, [("d", True, False), ("k", False, False)], 50), ordered=True)
+    # LeftSemi: the build rows that ANY thread's probe matched (the shared visited bytes, created once, marked concurrently)
+    import pyarrow.compute as pc
+    seen = pc.unique(pa.chunked_array([c for col_ in probed_keys for c in col_.chunks]))
+    want = shared_build.filter(pc.is_in(shared_build.column("bk"), value_set=seen))
+    assert_tables_equal(ht_semi.emit_unmatched("LeftSemi", ["bk", "bv"]).to_arrow(), want)
+    ht_semi.free()
     ht.free()
