@@ -111,13 +111,22 @@ def setup_dist(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # DFGPU_BENCH_REHEARSAL=1: every rank on GPU 0, a gloo group and the host transport under dfgpu_exchange_* — the N > 1 control
+    # flow (shards, both exchanges, max-over-ranks timing, the JSON line) on a box with one GPU.  Its numbers mean nothing.
+    rehearsal = os.environ.get("DFGPU_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"   # (what the library binds to when nothing else is said)
     torch.cuda.set_device(local_rank)
     from datafusion_amd import _lib
     _lib.init(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     return rank, world, local_rank, dist
 
 
@@ -136,8 +145,9 @@ def max_over_ranks(dist, dt, *sums):
     import torch
     if dist is None:
         return dt, [int(x) for x in sums]
-    mx = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(x) for x in sums], dtype=torch.float64, device="cuda")
+    where = "cpu" if "gloo" in str(dist.get_backend()) else "cuda"
+    mx = torch.tensor([dt], dtype=torch.float64, device=where)
+    tot = torch.tensor([float(x) for x in sums], dtype=torch.float64, device=where)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     return float(mx[0]), [int(x) for x in tot]
