@@ -193,3 +193,44 @@ def test_expression_fuzz_projection_filter_and_fused_arguments(seed):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_single_match_probe_flavours_fuzz(seed):
+    """the at-most-one-match probes (unique build keys; Inner / RightSemi / RightAnti) under random sizes, build densities, fused
+    FilterExec selectivities, key types and probe modes: whichever flavour the library picks — single pass with a cursor, tile counts
+    + placed, tile counts + hit words + listed rows — the rows are the oracle's (in probe order whenever the order is promised)"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    from tests.util import to_oracle_expr
+    rng = np.random.default_rng(7000 + seed)
+    kt = [pa.int32(), pa.int64()][int(rng.integers(2))]
+    span = int(rng.integers(10, 400_000))
+    nb = int(rng.integers(1, max(2, int(span * float(rng.choice([0.02, 0.1, 0.5, 1.0]))))))
+    npr = int(rng.integers(1, 300_000))
+    bkeys = rng.permutation(span)[:nb] if rng.integers(2) else np.sort(rng.permutation(span)[:nb])
+    build = pa.table({"a": pa.array(bkeys, type=kt), "x": pa.array(rng.integers(0, 10**6, nb), type=pa.int64()), "y": pa.array(rng.integers(0, 99, nb).astype(np.int32))})
+    pk = rng.integers(-5, span + 5, npr)
+    if rng.integers(2):
+        pk = np.sort(pk)                                   # clustered hits
+    null_keys = bool(rng.integers(0, 3) == 0)
+    probe = pa.table({"b": pa.array(pk, type=kt, mask=(rng.random(npr) < 0.05) if null_keys else None), "p": pa.array(rng.integers(0, 10**9, npr), type=pa.int64()),
+                      "f": pa.array(rng.integers(0, 100, npr).astype(np.int32))})
+    pred = None if rng.integers(3) == 0 else col("f") < lit(int(rng.integers(0, 101)), pa.int32())
+    jt = ["Inner", "RightSemi", "RightAnti"][int(rng.integers(3))]
+    mode = [0, 3, 4][int(rng.integers(3))]
+    pcols = ["p", "f"] if null_keys else ["b", "p"]        # (a nullable payload column would take the general path)
+    ht = ops.JoinHashTable(DeviceTable.from_arrow(build), ["a"], probe_mode=mode)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    try:
+        got = ht.probe(DeviceTable.from_arrow(probe), ["b"], jt, ["y", "x"], pcols, predicate=pred).to_arrow()
+        names = set(ops.profile_stats())
+    finally:
+        ops.profile_enable(False)
+    src = probe if pred is None else oracle.filter(probe, to_oracle_expr(pred), probe.column_names)
+    exp = oracle.hash_join(build, src, [("a", "b")], jt).select((["y", "x"] if jt == "Inner" else []) + pcols)
+    assert_tables_equal(got, exp, ordered="join_probe_fused" not in names)
+    ht.free()
