@@ -266,3 +266,21 @@ def test_sorted_dictionary_order_long_and_prefix_strings():
     values = d.dictionary.to_pylist()
     assert values == sorted(set(rows), key=lambda v: v.encode())
     assert d.cast(pa.string()).to_pylist() == rows
+
+
+@pytest.mark.parametrize("pattern", ["Customer#00001%", "%45", "%er#0000%", "%", "%%", "a%", "%a", "%ż%", "żółw%", "%日本", "x%y", "_b%", "100\\%%", "%requests%", "%slyly ironic%"])
+def test_like_affix_fast_paths_match_the_general_matcher(pattern):
+    """LIKE 'lit%' / '%lit' / '%lit%' take a prefix / suffix compare or a literal search; every other shape takes the general
+    matcher; both are checked against pyarrow's match_like on strings with multi-byte characters, empty strings and NULLs"""
+    import pyarrow.compute as pc
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(21)
+    pool = ["", "a", "ab", "xay", "x%y", "100%", "100% sure", "żółw", "żółw w wodzie", "日本", "東京と日本", "slyly ironic requests", "carefully ironic requests sleep"] + \
+           [f"Customer#{i:09d}" for i in rng.integers(0, 10**5, 300)]
+    s = random_strings(rng, 20_000, 0.1, pool)
+    t = pa.table({"s": s, "k": pa.array(np.arange(20_000))})
+    got = ops.filter(DeviceTable.from_arrow(t), col("s").like(pattern)).to_arrow()
+    want = [i for i, h in enumerate(pc.match_like(s, pattern).to_pylist()) if h]
+    assert got.column("k").to_pylist() == want
