@@ -2448,6 +2448,10 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
     why = "not a raw-input update";
     return false;
   }
+  if (A.aggs.empty()) {   // gby=[...], aggr=[] (the inner level of COUNT(DISTINCT), q16.slt.part:75-77): the keys are interned, nothing accumulates
+    why = "no aggregates";
+    return false;
+  }
   for (const AggState& a : A.aggs)
     if (a.has_arg && (a.func == DFGPU_AGG_MIN || a.func == DFGPU_AGG_MAX)) {
       dfgpu_expr e{a.nodes.data(), (int)a.nodes.size(), a.root};

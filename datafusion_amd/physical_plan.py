@@ -315,6 +315,7 @@ class HashJoinExec(ExecutionPlan):
     # probe rows without a build match are dropped by these join types (JoinType::on_lr_is_preserved, common/src/join_type.rs:115-127:
     # the probe side accepts a pushed-down filter), so the build side's key bounds may prune the probe-side scan
     _DYNAMIC_FILTER_JOINS = ("Inner", "Left", "LeftSemi", "RightSemi", "LeftAnti", "LeftMark")
+    _BUILD_EMITTING = ("Left", "Full", "LeftSemi", "LeftAnti", "LeftMark")      # join types that report build rows by their visited marks
 
     def _publish_dynamic_bounds(self, build_table):
         """the join's dynamic filter (HashJoinExec::create_dynamic_filter, hash_join/exec.rs:869-875; bounds accumulated in
@@ -368,10 +369,29 @@ class HashJoinExec(ExecutionPlan):
             self._publish_dynamic_bounds(b)
             p, po = self._run_child(self.right)
             bc, pc = self.projection if self.projection else (None, None)
+            shared_build = self.join_type in self._BUILD_EMITTING and replicated_build(self.left)
+            if shared_build:
+                # PartitionMode::CollectLeft with build-side emission: the reference's probe partitions mark ONE shared visited bitmap
+                # and the last of them reports the unmatched build rows (hash_join/exec.rs:1312-1330, stream.rs ProcessUnmatchedBuild).
+                # Here the probe partitions sit on different GPUs and the build side is replicated: the probe side is gathered as
+                # well, every rank computes the same join and keeps its slice of the rows — without this every rank would report the
+                # build rows unmatched by ITS probe rows
+                from .exchange import broadcast_table
+                pg = broadcast_table(p)
+                if pg is not p:
+                    if po:
+                        p.free()
+                    p, po = pg, True
             out = ops.hash_join(b, p, self.on, self.join_type, self.null_equality, bc, pc, join_filter=self.filter, null_aware=self.null_aware)
             for t, o in ((b, bo), (p, po)):
                 if o:
                     t.free()
+            if shared_build:
+                import torch.distributed as dist
+                n, world, rank = out.num_rows, dist.get_world_size(), dist.get_rank()
+                mine = out.slice(n * rank // world, n * (rank + 1) // world - n * rank // world)
+                out.free()
+                out = mine
             return out
         b, bo = self._run_child(self.left)
         ht = ops.JoinHashTable(b, [l for l, _ in self.on], self.null_equality, probe_mode=self.probe_mode, null_aware=self.null_aware)
@@ -387,6 +407,16 @@ class HashJoinExec(ExecutionPlan):
     def detail(self):
         return f"join_type={self.join_type}, on={self.on}" + (f", projection={self.projection}" if self.projection else "") + \
             (", null_aware" if self.null_aware else "")
+
+
+def replicated_build(node: ExecutionPlan) -> bool:
+    """several ranks and the build side is a CoalescePartitionsExec (every rank holds ALL build rows: PartitionMode::CollectLeft)"""
+    from .queries import _world
+    if _world() == 1:
+        return False
+    while isinstance(node, CoalesceBatchesExec):
+        node = node.input
+    return isinstance(node, CoalescePartitionsExec)
 
 
 def _partial_below(node: ExecutionPlan):

@@ -416,6 +416,98 @@ def q22_plan(customer, orders):
     return P.ScalarSubqueryExec(P.SortPreservingMergeExec(keys, out), [(sub, 0)], results)
 
 
+# ------------------------------------------------------------------------------------------ Q2
+def q2_plan(part, supplier, partsupp, nation, region):
+    """q2.slt.part:101-144: the BRASS parts of size 15 with their suppliers of EUROPE (three Inner joins, the running result the
+    build side, then LeftSemi against the EUROPE row of region), kept where the supply cost EQUALS the minimum over EUROPE's suppliers
+    of that part: a LeftSemi join on the two columns (p_partkey, ps_supplycost) = (ps_partkey, min(ps_supplycost)) against the
+    decorrelated subquery (partsupp x supplier x nation, LeftSemi region, MIN per part); top 10"""
+    def europe():
+        f = P.FilterExec(col("r_name").eq(lit("EUROPE", pa.string())), _scan(region, "region").project(["r_regionkey", "r_name"]), projection=["r_regionkey"])
+        return _hash(_cb(f), ["r_regionkey"])
+
+    p = _hash(_cb(P.FilterExec(col("p_size").eq(lit(15, pa.int32())).and_(col("p_type").like("%BRASS")),
+                               _scan(part, "part").project(["p_partkey", "p_mfgr", "p_type", "p_size"]), projection=["p_partkey", "p_mfgr"])), ["p_partkey"])
+    ps = _hash(_scan(partsupp, "partsupp").project(["ps_partkey", "ps_suppkey", "ps_supplycost"]), ["ps_partkey"])
+    j1 = P.HashJoinExec(_cb(p), _cb(ps), [("p_partkey", "ps_partkey")], "Inner", projection=(["p_partkey", "p_mfgr"], ["ps_suppkey", "ps_supplycost"]))
+    su = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_name", "s_address", "s_nationkey", "s_phone", "s_acctbal", "s_comment"]), ["s_suppkey"])
+    j2 = P.HashJoinExec(_cb(_hash(_cb(j1), ["ps_suppkey"])), _cb(su), [("ps_suppkey", "s_suppkey")], "Inner",
+                        projection=(["p_partkey", "p_mfgr", "ps_supplycost"], ["s_name", "s_address", "s_nationkey", "s_phone", "s_acctbal", "s_comment"]))
+    n = _hash(_scan(nation, "nation").project(["n_nationkey", "n_name", "n_regionkey"]), ["n_nationkey"])
+    j3 = P.HashJoinExec(_cb(_hash(_cb(j2), ["s_nationkey"])), _cb(n), [("s_nationkey", "n_nationkey")], "Inner",
+                        projection=(["p_partkey", "p_mfgr", "s_name", "s_address", "s_phone", "s_acctbal", "s_comment", "ps_supplycost"], ["n_name", "n_regionkey"]))
+    cols = ["p_partkey", "p_mfgr", "s_name", "s_address", "s_phone", "s_acctbal", "s_comment", "ps_supplycost", "n_name"]
+    j4 = P.HashJoinExec(_cb(_hash(_cb(j3), ["n_regionkey"])), _cb(europe()), [("n_regionkey", "r_regionkey")], "LeftSemi", projection=(cols, None))
+    # the subquery: the cheapest supply cost of every part among EUROPE's suppliers
+    ps2 = _hash(_scan(partsupp, "partsupp").project(["ps_partkey", "ps_suppkey", "ps_supplycost"]), ["ps_suppkey"])
+    su2 = _hash(_scan(supplier, "supplier").project(["s_suppkey", "s_nationkey"]), ["s_suppkey"])
+    k1 = P.HashJoinExec(_cb(ps2), _cb(su2), [("ps_suppkey", "s_suppkey")], "Inner", projection=(["ps_partkey", "ps_supplycost"], ["s_nationkey"]))
+    n2 = _hash(_scan(nation, "nation").project(["n_nationkey", "n_regionkey"]), ["n_nationkey"])
+    k2 = P.HashJoinExec(_cb(_hash(_cb(k1), ["s_nationkey"])), _cb(n2), [("s_nationkey", "n_nationkey")], "Inner", projection=(["ps_partkey", "ps_supplycost"], ["n_regionkey"]))
+    k3 = P.HashJoinExec(_cb(_hash(_cb(k2), ["n_regionkey"])), _cb(europe()), [("n_regionkey", "r_regionkey")], "LeftSemi", projection=(["ps_partkey", "ps_supplycost"], None))
+    gb = [(col("ps_partkey"), "ps_partkey")]
+    mn = "min(partsupp.ps_supplycost)"
+    aggs = [("min", col("ps_supplycost"), mn)]
+    cheapest = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(P.AggregateExec("Partial", gb, aggs, _cb(k3)), ["ps_partkey"])))
+    cheapest = P.ProjectionExec([(col(mn), mn), (col("ps_partkey"), "ps_partkey")], cheapest)
+    out_cols = ["s_acctbal", "s_name", "n_name", "p_partkey", "p_mfgr", "s_address", "s_phone", "s_comment"]
+    j5 = P.HashJoinExec(_cb(_hash(_cb(j4), ["p_partkey", "ps_supplycost"])), _cb(_hash(cheapest, ["ps_partkey", mn])),
+                        [("p_partkey", "ps_partkey"), ("ps_supplycost", mn)], "LeftSemi", projection=(out_cols, None))
+    keys = [("s_acctbal",) + DESC, ("n_name",) + ASC, ("s_name",) + ASC, ("p_partkey",) + ASC]
+    return P.SortPreservingMergeExec(keys, P.SortExec(keys, _cb(j5), fetch=10), fetch=10)
+
+
+# ----------------------------------------------------------------------------------------- Q10
+def q10_plan(customer, orders, lineitem, nation):
+    """q10.slt.part:70-91: customer (build) x the orders of 1993 Q4 x the returned lines x nation, the lost revenue per customer —
+    grouped by SEVEN columns (the key, the name, the balance and four more strings), top 10 by revenue"""
+    ccols = ["c_custkey", "c_name", "c_address", "c_nationkey", "c_phone", "c_acctbal", "c_comment"]
+    c = _hash(_scan(customer, "customer").project(ccols), ["c_custkey"])
+    of = P.FilterExec((col("o_orderdate") >= _d(1993, 10, 1)).and_(col("o_orderdate") < _d(1994, 1, 1)),
+                      _scan(orders, "orders").project(["o_orderkey", "o_custkey", "o_orderdate"]), projection=["o_orderkey", "o_custkey"])
+    j1 = P.HashJoinExec(_cb(c), _cb(_hash(_cb(of), ["o_custkey"])), [("c_custkey", "o_custkey")], "Inner", projection=(ccols, ["o_orderkey"]))
+    lf = P.FilterExec(col("l_returnflag").eq(lit("R", pa.string())), _scan(lineitem, "lineitem").project(["l_orderkey", "l_extendedprice", "l_discount", "l_returnflag"]),
+                      projection=["l_orderkey", "l_extendedprice", "l_discount"])
+    j2 = P.HashJoinExec(_cb(_hash(_cb(j1), ["o_orderkey"])), _cb(_hash(_cb(lf), ["l_orderkey"])), [("o_orderkey", "l_orderkey")], "Inner",
+                        projection=(ccols, ["l_extendedprice", "l_discount"]))
+    n = _hash(_scan(nation, "nation").project(["n_nationkey", "n_name"]), ["n_nationkey"])
+    j3 = P.HashJoinExec(_cb(_hash(_cb(j2), ["c_nationkey"])), _cb(n), [("c_nationkey", "n_nationkey")], "Inner",
+                        projection=(["c_custkey", "c_name", "c_address", "c_phone", "c_acctbal", "c_comment", "l_extendedprice", "l_discount"], ["n_name"]))
+    gcols = ["c_custkey", "c_name", "c_acctbal", "c_phone", "n_name", "c_address", "c_comment"]
+    gb = [(col(g), g) for g in gcols]
+    name = "sum(lineitem.l_extendedprice * Int64(1) - lineitem.l_discount)"
+    aggs = [("sum", col("l_extendedprice") * (ONE - col("l_discount")), name)]
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(P.AggregateExec("Partial", gb, aggs, _cb(j3)), gcols)))
+    top = P.SortExec([(name,) + DESC], final, fetch=10)
+    out = P.ProjectionExec([(col("c_custkey"), "c_custkey"), (col("c_name"), "c_name"), (col(name), "revenue"), (col("c_acctbal"), "c_acctbal"), (col("n_name"), "n_name"),
+                            (col("c_address"), "c_address"), (col("c_phone"), "c_phone"), (col("c_comment"), "c_comment")], top)
+    return P.SortPreservingMergeExec([("revenue",) + DESC], out, fetch=10)
+
+
+# ----------------------------------------------------------------------------------------- Q16
+def q16_plan(partsupp, part, supplier):
+    """q16.slt.part:69-88: partsupp x the parts kept by three predicates (<> on a string, IN over eight sizes, NOT LIKE), a null-aware
+    LeftAnti join (NOT IN) against the suppliers whose comment is LIKE '%Customer%Complaints%', then COUNT(DISTINCT ps_suppkey) as two
+    aggregate levels: the distinct (brand, type, size, supplier) groups with no aggregate, counted per (brand, type, size); top 10"""
+    sizes = [lit(v, pa.int32()) for v in (49, 14, 23, 45, 19, 3, 36, 9)]
+    pf = P.FilterExec(col("p_brand").ne(lit("Brand#45", pa.string())).and_(col("p_size").in_list(sizes)).and_(col("p_type").like("MEDIUM POLISHED%", negated=True)),
+                      _scan(part, "part").project(["p_partkey", "p_brand", "p_type", "p_size"]))
+    ps = _hash(_scan(partsupp, "partsupp").project(["ps_partkey", "ps_suppkey"]), ["ps_partkey"])
+    j = P.HashJoinExec(_cb(ps), _cb(_hash(_cb(pf), ["p_partkey"])), [("ps_partkey", "p_partkey")], "Inner", projection=(["ps_suppkey"], ["p_brand", "p_type", "p_size"]))
+    bad = P.FilterExec(col("s_comment").like("%Customer%Complaints%"), _scan(supplier, "supplier").project(["s_suppkey", "s_comment"]), projection=["s_suppkey"])
+    anti = P.HashJoinExec(P.CoalescePartitionsExec(_cb(j)), _cb(bad), [("ps_suppkey", "s_suppkey")], "LeftAnti", null_aware=True)
+    g4 = [(col("p_brand"), "p_brand"), (col("p_type"), "p_type"), (col("p_size"), "p_size"), (col("ps_suppkey"), "alias1")]
+    d_partial = P.AggregateExec("Partial", g4, [], _cb(anti))
+    g4f = [(col("p_brand"), "p_brand"), (col("p_type"), "p_type"), (col("p_size"), "p_size"), (col("alias1"), "alias1")]
+    distinct = P.AggregateExec("FinalPartitioned", g4f, [], _cb(_hash(d_partial, ["p_brand", "p_type", "p_size", "alias1"])))
+    g3 = [(col("p_brand"), "p_brand"), (col("p_type"), "p_type"), (col("p_size"), "p_size")]
+    aggs = [("count", col("alias1"), "count(alias1)")]
+    final = P.AggregateExec("FinalPartitioned", g3, aggs, _cb(_hash(P.AggregateExec("Partial", g3, aggs, distinct), ["p_brand", "p_type", "p_size"])))
+    keys = [("count(alias1)",) + DESC, ("p_brand",) + ASC, ("p_type",) + ASC, ("p_size",) + ASC]
+    top = P.ProjectionExec([(col("p_brand"), "p_brand"), (col("p_type"), "p_type"), (col("p_size"), "p_size"), (col("count(alias1)"), "supplier_cnt")], P.SortExec(keys, final, fetch=10))
+    return P.SortPreservingMergeExec([("supplier_cnt",) + DESC, ("p_brand",) + ASC, ("p_type",) + ASC, ("p_size",) + ASC], top, fetch=10)
+
+
 # ------------------------------------------------------------------------------------------ Q6
 def q6_plan(lineitem):
     """q6.slt.part:38-43: one filter, one ungrouped SUM"""

@@ -58,6 +58,9 @@ C_ABAL_SD = (298370230, 1)
 P_NAME_SD = (709314158, 92)     # a permutation of the 92 colours per part (permute.c: one draw per position)
 PS_QTY_SD = (1671059989, 4)     # driver.c seed table: PSUPP streams advance SUPP_PER_PART draws per part row
 PS_SCST_SD = (1051288424, 4)
+S_ABAL_SD = (962338209, 1)
+BBB_TYPE_SD = (753643799, 1)    # driver.c seed table, streams 45 / 46: mk_supp draws both for EVERY supplier (one draw per row)
+BBB_CMNT_SD = (202794285, 1)
 
 STARTDATE_EPOCH = 8035          # 1992-01-01 as days since 1970-01-01 (dss.h STARTDATE 92001)
 O_ODATE_SPAN = 2557 - (121 + 30) - 1   # O_ODATE_MAX - O_ODATE_MIN (dss.h TOTDATE, L_SDTE_MAX, L_RDTE_MAX)
@@ -188,6 +191,8 @@ def tables(sf: float, strings: str = "codes"):
         c_phone = _string_column(_phones(C_PHNE_SD, c_nation), strings)
         customer = customer.append_column("c_address", _string_column(_v_strings(C_ADDR_SD, nc, 25), strings))
         customer = customer.append_column("c_phone", c_phone).append_column("c_acctbal", _decimal(_draw(C_ABAL_SD, nc, -99999, 999999)))
+        # (c_comment is dbgen text: a stand-in, see supplier_comments — Q10 groups by it beside c_custkey and prints it)
+        customer = customer.append_column("c_comment", _string_column([f"(text {i})" for i in range(1, nc + 1)], strings))
     # ---- orders (build.c mk_order)
     okey = order_keys(no)
     ckey = _draw(O_CKEY_SD, no, 1, nc)
@@ -302,7 +307,29 @@ def supplier(sf: float, strings: str = "codes") -> pa.Table:
     t = pa.table({"s_suppkey": pa.array(np.arange(1, ns + 1, dtype=np.int64)), "s_name": s_name, "s_nationkey": pa.array(s_nation)})
     if strings != "codes":     # mk_supp: V_STR(S_ADDR_LEN = 25, S_ADDR_SD), gen_phone(nation, S_PHNE_SD) — Q15 prints both
         t = t.append_column("s_address", _string_column(_v_strings(S_ADDR_SD, ns, 25), strings)).append_column("s_phone", _string_column(_phones(S_PHNE_SD, s_nation), strings))
+        # s_acctbal = RANDOM(-99999, 999999) cents (Q2 prints it: pinned to the cent by its answer)
+        t = t.append_column("s_acctbal", _decimal(_draw(S_ABAL_SD, ns, -99999, 999999)))
+        t = t.append_column("s_comment", _string_column(supplier_comments(ns), strings))
     return t
+
+
+def supplier_complaints(ns: int):
+    """mk_supp's Better Business Bureau marks: every supplier draws bad_press = RANDOM(1, 10000, BBB_CMNT_SD) and type =
+    RANDOM(0, 100, BBB_TYPE_SD); bad_press <= S_CMNT_BBB (10) overwrites part of the comment with "Customer " … "Complaints"
+    (type < BBB_DEADBEATS = 50) or "Customer " … "Recommends".  -> (complaints, recommends) Boolean arrays"""
+    marked = _draw(BBB_CMNT_SD, ns, 1, 10000) <= 10
+    deadbeat = _draw(BBB_TYPE_SD, ns, 0, 100) < 50
+    return marked & deadbeat, marked & ~deadbeat
+
+
+def supplier_comments(ns: int) -> list:
+    """NOT dbgen's s_comment: the comment columns are cut out of dbgen's grammar-generated text pool (dists.dss weights, not in the
+    reference), which this restatement does not generate.  What the pinned queries READ of s_comment is restated: the
+    "Customer … Complaints" / "Customer … Recommends" marks (Q16's LIKE '%Customer%Complaints%'; the grammar has no capitalised
+    "Customer", so only marked suppliers match).  Queries that PRINT a comment (Q2, Q10) are compared on their other columns."""
+    bad, good = supplier_complaints(ns)
+    return [f"(text {i}) Customer (text) Complaints (text)" if bad[i - 1] else f"(text {i}) Customer (text) Recommends (text)" if good[i - 1] else f"(text {i})"
+            for i in range(1, ns + 1)]
 
 
 def nation(strings: str = "codes") -> pa.Table:
@@ -359,7 +386,8 @@ def part(sf: float, strings: str = "codes") -> pa.Table:
     size = _draw(P_SIZE_SD, n, 1, 50)
     cntr = _draw(P_CNTR_SD, n, 1, 40) - 1
     ptype = _draw(P_TYPE_SD, n, 1, len(PART_TYPES)) - 1
-    t = pa.table({"p_partkey": pa.array(np.arange(1, n + 1, dtype=np.int64)), "p_brand": _strings(bcode, brands, strings),
+    mfgrs = [f"Manufacturer#{m}" for m in range(1, 6)]      # build.c mk_part: P_MFG_FMT "%s%d" over RANDOM(1, 5, P_MFG_SD)
+    t = pa.table({"p_partkey": pa.array(np.arange(1, n + 1, dtype=np.int64)), "p_mfgr": _strings(mfgr - 1, mfgrs, strings), "p_brand": _strings(bcode, brands, strings),
                   "p_type": _strings(ptype, PART_TYPES, strings),
                   "p_size": pa.array(size.astype(np.int32)), "p_container": _strings(cntr, CONTAINERS, strings)})
     if strings != "codes":

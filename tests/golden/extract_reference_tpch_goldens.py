@@ -14,7 +14,7 @@ import os
 
 REF = "/root/reference/datafusion"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tpch_answers.json")
-QUERIES = [1, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 15, 17, 18, 19, 20, 21, 22]
+QUERIES = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17, 18, 19, 20, 21, 22]
 SAMPLE_COLUMNS = {
     "customer": ["c_custkey", "c_address", "c_nationkey", "c_phone", "c_acctbal", "c_mktsegment"],
     "orders": ["o_orderkey", "o_custkey", "o_orderstatus", "o_totalprice", "o_orderdate", "o_orderpriority", "o_shippriority"],

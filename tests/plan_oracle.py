@@ -214,7 +214,14 @@ def _aggregate(rel: Rel, mode, group_by, aggs, return_types=None) -> Rel:
 
 
 def _join(node, left: Rel, right: Rel) -> Rel:
+    shared_build = node.join_type in P.HashJoinExec._BUILD_EMITTING and P.replicated_build(node.left)
+    if shared_build:    # CollectLeft with build-side emission on several ranks: physical_plan.HashJoinExec.execute
+        right = Rel(pa.concat_tables(_all_gather_tables(right.table)), right.dicts)
     out = oracle.hash_join(left.table, right.table, node.on, node.join_type, node.null_equality, join_filter=_join_filter(node, left, right), null_aware=node.null_aware)
+    if shared_build:
+        import torch.distributed as dist
+        n, world, rank = out.num_rows, dist.get_world_size(), dist.get_rank()
+        out = out.slice(n * rank // world, n * (rank + 1) // world - n * rank // world)
     dicts = dict(right.dicts)
     dicts.update(left.dicts)
     rel = Rel(out, dicts)

@@ -132,6 +132,25 @@ def test_no_group_by_and_empty_input():
     assert gpu_agg(empty, [(col("i"), "i")], aggs).num_rows == 0
 
 
+def test_group_by_without_aggregates_is_distinct():
+    """gby=[...], aggr=[] — the inner level of COUNT(DISTINCT x) (q16.slt.part:75-77: Partial and FinalPartitioned with no
+    aggregate): the distinct key rows in first-seen order, then COUNT(column) over them per outer group"""
+    from datafusion_amd.expr import col
+    rng = np.random.default_rng(16)
+    t = random_table(rng, 40_000, {"a": (pa.int32(), 0, 40), "b": (pa.int64(), 0, 300), "d": (pa.decimal128(15, 2), 0, 5)}, null_frac=0.03)
+    gb = [(col("a"), "a"), (col("d"), "d"), (col("b"), "alias1")]
+    for mode in ("Single", "Partial"):
+        assert_agg_equal(gpu_agg(t, gb, [], mode), oracle_agg(t, gb, [], mode))
+    parts = [gpu_agg(t.slice(o, 10_000), gb, [], "Partial") for o in range(0, 40_000, 10_000)]
+    distinct = gpu_agg(pa.concat_tables(parts), gb, [], "FinalPartitioned")
+    assert_agg_equal(distinct, oracle_agg(t, gb, [], "Single"))
+    assert distinct.num_rows == len({(r["a"], r["d"], r["b"]) for r in t.to_pylist()})
+    outer = [(col("a"), "a"), (col("d"), "d")]
+    cnt = [("count", col("alias1"), "count(alias1)")]
+    assert_agg_equal(gpu_agg(distinct, outer, cnt), oracle_agg(distinct, outer, cnt))
+    assert gpu_agg(t.slice(0, 0), gb, [], "Single").num_rows == 0
+
+
 def test_wrapping_i128_sum_is_order_independent():
     """SUM(Decimal128) uses add_wrapping (sum.rs:308-320): overflow wraps identically on GPU and CPU"""
     from datafusion_amd.expr import col

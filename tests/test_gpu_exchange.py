@@ -115,11 +115,16 @@ elif mode == "plans":
     for name, t in data().items():             # this rank's row range of every table: what `world` scans produce
         lo, hi = t.num_rows * rank // world, t.num_rows * (rank + 1) // world
         tables[name] = DeviceTable.from_arrow(t.slice(lo, hi - lo))
+    from tests.test_tpch_answers import GPU_QUERIES, q16_with_many_complaints
     for q, plan in plans(tables).items():
+        if q not in GPU_QUERIES:
+            continue
         opt = P.GpuOffloadRule(world_size=world).optimize(plan)
         out[q] = P.collect(opt).to_arrow()
         if q in ("q1", "q3"):
             out[q + "_pinned"] = P.collect(plan).to_arrow()
+    if "q16" in GPU_QUERIES:     # CollectLeft + build-side emission with a build side that really loses rows (HashJoinExec.execute)
+        out["q16_many"] = P.collect(P.GpuOffloadRule(world_size=world).optimize(q16_with_many_complaints(tables))).to_arrow()
 pickle.dump(out, open(os.path.join(os.environ["DFGPU_OUT"], f"r{rank}.pkl"), "wb"))
 dist.barrier()
 print("WORKER_OK", flush=True)
@@ -184,11 +189,19 @@ def test_two_ranks_exchange_device_tables_with_different_dictionaries_and_nulls(
 def test_device_plans_on_two_ranks_reproduce_the_reference_answers(tmp_path):
     """the product's plan nodes with N = 2 (device operators + C-ABI exchanges; tests/test_plans_gloo.py runs the same protocol
     with the oracle's operators on CPU)"""
-    from tests.test_tpch_answers import QUERIES, assert_answer
+    from tests.test_tpch_answers import GPU_QUERIES, assert_answer
     res = _run_ranks(tmp_path, 2, "plans", _free_port())
-    for q in QUERIES:
+    for q in GPU_QUERIES:
         for r in range(2):
             assert_answer(q, res[r][q])
+    if "q16" in GPU_QUERIES:
+        from tests import plan_oracle
+        from tests.test_tpch_answers import data, q16_with_many_complaints
+        want = plan_oracle.collect(q16_with_many_complaints(data()))
+        for r in range(2):
+            got = res[r]["q16_many"]
+            got = pa.table({n: (c.cast(pa.string()) if pa.types.is_dictionary(c.type) else c) for n, c in zip(got.column_names, got.columns)})
+            assert got.to_pylist() == want.to_pylist()
     for q in ("q1_pinned", "q3_pinned"):
         for r in range(2):
             assert_answer(q[:2], res[r][q])

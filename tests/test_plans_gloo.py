@@ -14,7 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-QUERIES = ["q1", "q3", "q4", "q5", "q6", "q7", "q8", "q9", "q11", "q12", "q14", "q15", "q17", "q18", "q19", "q20", "q21", "q22"]
+QUERIES = ["q1", "q2", "q3", "q4", "q5", "q6", "q7", "q8", "q9", "q10", "q11", "q12", "q14", "q15", "q16", "q17", "q18", "q19", "q20", "q21", "q22"]
 
 
 def _free_port():
@@ -31,8 +31,10 @@ def _worker(rank, world, port, optimized, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from datafusion_amd import physical_plan as P
     from tests import plan_oracle
-    from tests.test_tpch_answers import data, plans
+    from tests.test_tpch_answers import data, plans, q16_with_many_complaints
     out = {}
+    many = q16_with_many_complaints(data())
+    out["q16_many"] = plan_oracle.collect(P.GpuOffloadRule(world_size=world).optimize(many) if optimized else many)
     for q, plan in plans(data()).items():
         if optimized:
             plan = P.GpuOffloadRule(world_size=world).optimize(plan)
@@ -55,3 +57,10 @@ def test_reference_plans_on_several_ranks_reproduce_the_answers(tmp_path, world,
     for q in QUERIES:
         for r in range(world):          # the root SortPreservingMergeExec / CoalescePartitionsExec replicates the result on every rank
             assert_answer(q, res[r][q])
+    # CollectLeft with build-side emission (Q16's null-aware LeftAnti) where the build side really loses rows
+    from tests import plan_oracle
+    from tests.test_tpch_answers import data, q16_with_many_complaints
+    want = plan_oracle.collect(q16_with_many_complaints(data()))
+    assert want.to_pylist() != res[0]["q16"].to_pylist()
+    for r in range(world):
+        assert res[r]["q16_many"].to_pylist() == want.to_pylist()

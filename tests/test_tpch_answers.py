@@ -13,6 +13,7 @@ GPU legs: the same plans through the C ABI on the device, same answers.
 """
 import datetime
 import functools
+import re
 from decimal import Decimal
 
 import pyarrow as pa
@@ -47,7 +48,29 @@ def plans(t):
             "q14": T.q14_plan(t["lineitem"], t.get("part")), "q17": T.q17_plan(t["lineitem"], t.get("part")), "q12": T.q12_plan(t["orders"], t["lineitem"]), "q18": T.q18_plan(t["customer"], t["orders"], t["lineitem"]),
             "q19": T.q19_plan(t["lineitem"], t.get("part")),
             "q21": T.q21_plan(t["supplier"], t["lineitem"], t["orders"], t["nation"]),
-            "q22": T.q22_plan(t["customer"], t["orders"])}
+            "q22": T.q22_plan(t["customer"], t["orders"]),
+            "q2": T.q2_plan(t.get("part"), t["supplier"], t.get("partsupp"), t["nation"], t["region"]),
+            "q10": T.q10_plan(t["customer"], t["orders"], t["lineitem"], t["nation"]),
+            "q16": T.q16_plan(t.get("partsupp"), t.get("part"), t["supplier"])}
+
+
+def q16_with_many_complaints(t):
+    """Q16 over a supplier table in which every 7th supplier carries the "Customer … Complaints" mark: at SF0.1 dbgen marks ONE
+    supplier and the pinned answer does not depend on it, so the null-aware anti join of the plan is exercised with a build side
+    that really loses rows (the multi-rank tests compare with the single-process oracle)"""
+    from datafusion_amd import tpch_plans as T
+    from oracle import dbgen
+    s = t["supplier"]
+    if not isinstance(s, pa.Table):
+        s = s.to_arrow()
+    n = s.num_rows
+    keys = s.column("s_suppkey").to_pylist()
+    com = dbgen._string_column([f"(text {k}) Customer (text) Complaints" if k % 7 == 0 else f"(text {k})" for k in keys], "dictionary")
+    s = s.set_column(s.schema.get_field_index("s_comment"), "s_comment", com)
+    if not isinstance(t["supplier"], pa.Table):
+        from datafusion_amd.table import DeviceTable
+        s = DeviceTable.from_arrow(s)
+    return T.q16_plan(t["partsupp"], t["part"], s)
 
 
 # answer-file columns whose text may contain blanks (everything else is split on blanks)
@@ -57,9 +80,32 @@ _TEXT_LAST = {"q20"}      # s_name (no blank), then s_address (blanks are part o
 # (q7's nation names FRANCE / GERMANY hold no blanks)
 
 
+# answer lines with several free-text columns: one pattern per query.  The last column of Q2 / Q10 is a dbgen comment — text cut
+# out of dbgen's grammar-generated pool, which oracle/dbgen.py does not restate (its docstrings): those queries are compared on
+# every other column (the key, name, balance, nation, address and phone of every printed row, in the printed order)
+_PHONE = r"\d\d-\d{3}-\d{3}-\d{4}"
+_PATTERNS = {
+    "q2": re.compile(r"^(\S+) (Supplier#\d{9}) (.+?) (\d+) (Manufacturer#\d) (.*) (" + _PHONE + r") (.*)$"),
+    "q10": re.compile(r"^(\d+) (Customer#\d{9}) (\S+) (\S+) (.+?) (\S.*) (" + _PHONE + r") (.*)$"),
+    "q16": re.compile(r"^(Brand#\d\d) (.+) (\d+) (\d+)$"),
+}
+UNCOMPARED = {"q2": {"s_comment"}, "q10": {"c_comment"}}
+_NATION_WORDS = {"UNITED", "SAUDI"}      # the two-word nation names start with one of these
+
+
 def expected_rows(q):
     rows = []
     for line in GOLD["answers"][q]["rows"]:
+        if q in _PATTERNS:
+            m = _PATTERNS[q].match(line)
+            assert m, (q, line)
+            toks = list(m.groups())
+            if q == "q10":      # n_name (one or two words) then c_address (may hold blanks): split where the nation name ends
+                words = (toks[4] + " " + toks[5]).split(" ")
+                k = 2 if words[0] in _NATION_WORDS else 1
+                toks[4], toks[5] = " ".join(words[:k]), " ".join(words[k:])
+            rows.append(toks)
+            continue
         toks = line.rsplit(" ", 1) if q in _TEXT_FIRST else line.split(" ", 1) if q in _TEXT_LAST else line.split(" ")
         rows.append(toks)
     return rows
@@ -80,14 +126,16 @@ def _cell(v, want: str):
 def assert_answer(q, got: pa.Table):
     want = expected_rows(q)
     t = pa.table({n: (c.cast(pa.string()) if pa.types.is_dictionary(c.type) else c) for n, c in zip(got.column_names, got.columns)})
-    rows = [list(r.values()) for r in t.to_pylist()]
+    skip = [i for i, n in enumerate(t.column_names) if n in UNCOMPARED.get(q, ())]
+    rows = [[v for i, v in enumerate(r.values()) if i not in skip] for r in t.to_pylist()]
+    want = [[v for i, v in enumerate(w) if i not in skip] for w in want]
     assert len(rows) == len(want), (q, len(rows), len(want))
     for i, (r, w) in enumerate(zip(rows, want)):
         assert len(r) == len(w), (q, r, w)
         assert all(_cell(v, x) for v, x in zip(r, w)), f"{q} row {i}: got {r}, the reference's answer is {w} ({GOLD['answers'][q]['source']})"
 
 
-QUERIES = ["q1", "q3", "q4", "q5", "q6", "q7", "q8", "q9", "q11", "q12", "q14", "q15", "q17", "q18", "q19", "q20", "q21", "q22"]
+QUERIES = ["q1", "q2", "q3", "q4", "q5", "q6", "q7", "q8", "q9", "q10", "q11", "q12", "q14", "q15", "q16", "q17", "q18", "q19", "q20", "q21", "q22"]
 # Q19's JoinFilter compares string columns with literals: the host side binds them through the dictionaries of the columns behind the
 # intermediate schema (expr.IntermediateSchema, tests/test_abi.py)
 GPU_QUERIES = list(QUERIES)
@@ -97,6 +145,7 @@ RESULT_TYPES = {   # pinned by the answer files' decimal digits and the plan fil
     "q3": {"revenue": pa.decimal128(38, 4)}, "q4": {"order_count": pa.int64()}, "q5": {"revenue": pa.decimal128(38, 4)},
     "q6": {"revenue": pa.decimal128(38, 4)}, "q12": {"high_line_count": pa.int64(), "low_line_count": pa.int64()}, "q18": {"sum(lineitem.l_quantity)": pa.decimal128(25, 2)}, "q19": {"revenue": pa.decimal128(38, 4)}, "q21": {"numwait": pa.int64()},
     "q9": {"o_year": pa.int32(), "sum_profit": pa.decimal128(38, 4)}, "q20": {}, "q11": {"value": pa.decimal128(36, 2)}, "q15": {"total_revenue": pa.decimal128(38, 4)}, "q22": {"numcust": pa.int64(), "totacctbal": pa.decimal128(25, 2)},
+    "q2": {"s_acctbal": pa.decimal128(15, 2)}, "q10": {"revenue": pa.decimal128(38, 4), "c_acctbal": pa.decimal128(15, 2)}, "q16": {"supplier_cnt": pa.int64()},
     "q7": {"l_year": pa.int32(), "revenue": pa.decimal128(38, 4)}, "q8": {"o_year": pa.int32(), "mkt_share": pa.decimal128(15, 2)}, "q14": {"promo_revenue": pa.float64()}, "q17": {"avg_yearly": pa.float64()},
 }
 
@@ -172,6 +221,20 @@ def test_gpu_reproduces_the_reference_answer(q, device_tables):
     assert_answer(q, got)
     assert_answer(q, P.collect(plan).to_arrow())               # the plan as pinned, operator by operator
     assert all(t.num_rows for t in device_tables.values())      # leaf tables are never freed by a plan
+
+
+@pytest.mark.gpu
+def test_gpu_q16_null_aware_anti_join_that_loses_rows(device_tables):
+    """the pinned Q16 answer does not depend on dbgen's one marked supplier: the same plan over a supplier table with 142 marked
+    suppliers (LIKE over the dictionary in 142 runs, the null-aware LeftAnti join drops their partsupp rows), against the oracle"""
+    from datafusion_amd import physical_plan as P
+    from tests import plan_oracle
+    want = plan_oracle.collect(q16_with_many_complaints(data()))
+    plan = q16_with_many_complaints(device_tables)
+    for p in (plan, P.GpuOffloadRule().optimize(plan)):
+        got = P.collect(p).to_arrow()
+        got = pa.table({n: (c.cast(pa.string()) if pa.types.is_dictionary(c.type) else c) for n, c in zip(got.column_names, got.columns)})
+        assert got.to_pylist() == want.to_pylist()
 
 
 @pytest.mark.gpu
