@@ -484,6 +484,25 @@ def q10_plan(customer, orders, lineitem, nation):
     return P.SortPreservingMergeExec([("revenue",) + DESC], out, fetch=10)
 
 
+# ----------------------------------------------------------------------------------------- Q13
+def q13_plan(customer, orders):
+    """q13.slt.part:55-68: customer LEFT JOIN the orders whose comment is NOT LIKE '%special%requests%' (customer is the build side:
+    its unmatched rows come out with a NULL o_orderkey), COUNT(o_orderkey) per customer (SinglePartitioned: the join output is
+    already partitioned on c_custkey), then the distribution of those counts; top 10"""
+    c = _hash(_scan(customer, "customer").project(["c_custkey"]), ["c_custkey"])
+    of = P.FilterExec(col("o_comment").like("%special%requests%", negated=True), _scan(orders, "orders").project(["o_orderkey", "o_custkey", "o_comment"]),
+                      projection=["o_orderkey", "o_custkey"])
+    j = P.HashJoinExec(_cb(c), _cb(_hash(_cb(of), ["o_custkey"])), [("c_custkey", "o_custkey")], "Left", projection=(["c_custkey"], ["o_orderkey"]))
+    per_customer = P.AggregateExec("SinglePartitioned", [(col("c_custkey"), "c_custkey")], [("count", col("o_orderkey"), "count(orders.o_orderkey)")], _cb(j))
+    counts = P.ProjectionExec([(col("count(orders.o_orderkey)"), "c_count")], per_customer)
+    gb = [(col("c_count"), "c_count")]
+    aggs = [("count", None, "count(Int64(1))")]
+    final = P.AggregateExec("FinalPartitioned", gb, aggs, _cb(_hash(P.AggregateExec("Partial", gb, aggs, counts), ["c_count"])))
+    keys = [("count(Int64(1))",) + DESC, ("c_count",) + DESC]
+    top = P.ProjectionExec([(col("c_count"), "c_count"), (col("count(Int64(1))"), "custdist")], P.SortExec(keys, final, fetch=10))
+    return P.SortPreservingMergeExec([("custdist",) + DESC, ("c_count",) + DESC], top, fetch=10)
+
+
 # ----------------------------------------------------------------------------------------- Q16
 def q16_plan(partsupp, part, supplier):
     """q16.slt.part:69-88: partsupp x the parts kept by three predicates (<> on a string, IN over eight sizes, NOT LIKE), a null-aware

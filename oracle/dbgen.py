@@ -21,6 +21,10 @@ over `table(0.1)` reproducing the reference's pinned answers digit for digit.
 """
 from __future__ import annotations
 
+import ctypes
+import functools
+import os
+
 import numpy as np
 import pyarrow as pa
 
@@ -113,7 +117,7 @@ def _draw(sd, n_rows: int, lo: int, hi: int) -> np.ndarray:
 def _draw_lines(sd, order_of_line: np.ndarray, call_in_order: np.ndarray, n_orders: int, lo: int, hi: int) -> np.ndarray:
     """draw number `call_in_order` (0-based) of each line's order from a boundary-7 stream"""
     starts = _row_starts(sd, n_orders)
-    apow = _powers(A, 8)
+    apow = _powers(A, max(8, sd[1] + 1))
     return _unif(starts[order_of_line] * apow[call_in_order + 1] % np.uint64(M), lo, hi)
 
 
@@ -191,8 +195,7 @@ def tables(sf: float, strings: str = "codes"):
         c_phone = _string_column(_phones(C_PHNE_SD, c_nation), strings)
         customer = customer.append_column("c_address", _string_column(_v_strings(C_ADDR_SD, nc, 25), strings))
         customer = customer.append_column("c_phone", c_phone).append_column("c_acctbal", _decimal(_draw(C_ABAL_SD, nc, -99999, 999999)))
-        # (c_comment is dbgen text: a stand-in, see supplier_comments — Q10 groups by it beside c_custkey and prints it)
-        customer = customer.append_column("c_comment", _string_column([f"(text {i})" for i in range(1, nc + 1)], strings))
+        customer = customer.append_column("c_comment", _string_column(text_column(C_CMNT_SD, nc, 73), strings))     # mk_cust: TEXT(C_CMNT_LEN = 73)
     # ---- orders (build.c mk_order)
     okey = order_keys(no)
     ckey = _draw(O_CKEY_SD, no, 1, nc)
@@ -237,6 +240,8 @@ def tables(sf: float, strings: str = "codes"):
                        "o_orderdate": pa.array((odate + STARTDATE_EPOCH).astype(np.int32), pa.date32()),
                        "o_orderpriority": _strings(prio, PRIORITIES, strings),
                        "o_shippriority": pa.array(np.zeros(no, dtype=np.int32))})
+    if strings != "codes":
+        orders = orders.append_column("o_comment", _string_column(text_column(O_CMNT_SD, no, 49), strings))    # mk_order: TEXT(O_CMNT_LEN = 49)
     lineitem = pa.table({
         "l_orderkey": pa.array(okey[oi]), "l_partkey": pa.array(pkey), "l_suppkey": pa.array(skey), "l_linenumber": pa.array((k + 1).astype(np.int32)),
         "l_quantity": _decimal(qty * 100), "l_extendedprice": _decimal(eprice),
@@ -313,6 +318,294 @@ def supplier(sf: float, strings: str = "codes") -> pa.Table:
     return t
 
 
+# ------------------------------------------------------------------------------------------------------------ comment text
+# dists.dss, the distributions of dbgen's text grammar (TPC-H specification clause 4.2.2.14): sentence forms, noun and verb
+# phrases, and the weighted word lists — in dists.dss's own "word|weight" lines, including its misspelt "whithout".  Restated
+# from the published file; pinned, together with oracle/dbgen_text.c, by every comment string the reference carries (165 strings
+# at offsets spread over the whole pool: tests/test_dbgen_golden.py).
+DISTS = """\
+BEGIN grammar
+N V T|3
+N V P T|3
+N V N T|3
+N P V N T|1
+N P V P T|1
+END
+BEGIN np
+N|10
+J N|20
+J, J N|10
+D J N|50
+END
+BEGIN vp
+V|30
+X V|1
+V D|40
+X V D|1
+END
+BEGIN nouns
+packages|40
+requests|40
+accounts|40
+deposits|40
+foxes|20
+ideas|20
+theodolites|20
+pinto beans|20
+instructions|20
+dependencies|10
+excuses|10
+platelets|10
+asymptotes|10
+courts|5
+dolphins|5
+multipliers|1
+sauternes|1
+warthogs|1
+frets|1
+dinos|1
+attainments|1
+somas|1
+Tiresias|1
+patterns|1
+forges|1
+braids|1
+frays|1
+warhorses|1
+dugouts|1
+notornis|1
+epitaphs|1
+pearls|1
+tithes|1
+waters|1
+orbits|1
+gifts|1
+sheaves|1
+depths|1
+sentiments|1
+decoys|1
+realms|1
+pains|1
+grouches|1
+escapades|1
+hockey players|1
+END
+BEGIN verbs
+sleep|20
+wake|20
+are|20
+cajole|20
+haggle|20
+nag|10
+use|10
+boost|10
+affix|5
+detect|5
+integrate|5
+maintain|1
+nod|1
+was|1
+lose|1
+sublate|1
+solve|1
+thrash|1
+promise|1
+engage|1
+hinder|1
+print|1
+x-ray|1
+breach|1
+eat|1
+grow|1
+impress|1
+mold|1
+poach|1
+serve|1
+run|1
+dazzle|1
+snooze|1
+doze|1
+unwind|1
+kindle|1
+play|1
+hang|1
+believe|1
+doubt|1
+END
+BEGIN adjectives
+special|20
+pending|20
+unusual|20
+express|20
+furious|1
+sly|1
+careful|1
+blithe|1
+quick|1
+fluffy|1
+slow|1
+quiet|1
+ruthless|1
+thin|1
+close|1
+dogged|1
+daring|1
+brave|1
+stealthy|1
+permanent|1
+enticing|1
+idle|1
+busy|1
+regular|50
+final|40
+ironic|40
+even|30
+bold|20
+silent|10
+END
+BEGIN adverbs
+sometimes|1
+always|1
+never|1
+furiously|50
+slyly|50
+carefully|50
+blithely|40
+quickly|30
+fluffily|20
+slowly|1
+quietly|1
+ruthlessly|1
+thinly|1
+closely|1
+doggedly|1
+daringly|1
+bravely|1
+stealthily|1
+permanently|1
+enticingly|1
+idly|1
+busily|1
+regularly|1
+finally|1
+ironically|1
+evenly|1
+boldly|1
+silently|1
+END
+BEGIN prepositions
+about|50
+above|50
+according to|50
+across|50
+after|50
+against|40
+along|40
+alongside of|30
+among|30
+around|20
+at|10
+atop|1
+before|1
+behind|1
+beneath|1
+beside|1
+besides|1
+between|1
+beyond|1
+by|1
+despite|1
+during|1
+except|1
+for|1
+from|1
+in place of|1
+inside|1
+instead of|1
+into|1
+near|1
+of|1
+on|1
+outside|1
+over|1
+past|1
+since|1
+through|1
+throughout|1
+to|1
+toward|1
+under|1
+until|1
+up|1
+upon|1
+whithout|1
+with|1
+within|1
+END
+BEGIN auxillaries
+do|1
+may|1
+might|1
+shall|1
+will|1
+would|1
+can|1
+could|1
+should|1
+ought to|1
+must|1
+will have to|1
+shall have to|1
+could have to|1
+should have to|1
+must have to|1
+need to|1
+try to|1
+END
+BEGIN terminators
+.|50
+;|1
+:|1
+?|1
+!|1
+--|1
+END
+"""
+TEXT_POOL_SIZE = 300 * 1024 * 1024     # dss.h TEXT_POOL_SIZE
+N_CMNT_SD = (606179079, 2)             # driver.c seed table: text columns draw twice per row (offset into the pool, then length)
+R_CMNT_SD = (1500869201, 2)
+S_CMNT_SD = (1341315363, 2)
+C_CMNT_SD = (1335826707, 2)
+O_CMNT_SD = (276090261, 2)
+P_CMNT_SD = (804159733, 2)
+PS_CMNT_SD = (1961692154, 8)            # SUPP_PER_PART rows x 2 draws per part
+BBB_JNK_SD = (263032577, 1)
+BBB_OFFSET_SD = (715851524, 1)
+
+
+@functools.lru_cache(maxsize=1)
+def text_pool() -> bytes:
+    """dbgen's 300 MiB text pool (text.c init_text_pool; restated in oracle/dbgen_text.c, ≈ 2 s)"""
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdforacle.so"))
+    out = ctypes.create_string_buffer(TEXT_POOL_SIZE + 4096)
+    rc = lib.dbgen_text_pool(ctypes.create_string_buffer(DISTS.encode()), out, ctypes.c_int64(TEXT_POOL_SIZE))
+    assert rc == 0, rc
+    return out.raw[:TEXT_POOL_SIZE]
+
+
+def text_column(sd, n_rows: int, avg_len: int, rows=None, call: int = 0) -> list:
+    """dss.h TEXT(avg, sd, tgt) = text.c dbg_text(tgt, 0.4 avg, 1.6 avg, sd): offset = RANDOM(0, TEXT_POOL_SIZE - max), then
+    length = RANDOM(min, max); the comment is that slice of the pool.  `rows` (default: all n_rows) selects rows of the table;
+    `call` = the TEXT call's number within its row (partsupp: four rows of one part share a stream boundary)"""
+    lo, hi = int(avg_len * 0.4), int(avg_len * 1.6)
+    rows = np.arange(n_rows) if rows is None else np.asarray(rows, dtype=np.int64)
+    calls = np.zeros(len(rows), dtype=np.int64) + 2 * np.asarray(call, dtype=np.int64)
+    off = _draw_lines(sd, rows, calls, n_rows, 0, TEXT_POOL_SIZE - hi)
+    length = _draw_lines(sd, rows, calls + 1, n_rows, lo, hi)
+    pool = text_pool()
+    return [pool[o:o + n].decode() for o, n in zip(off.tolist(), length.tolist())]
+
+
 def supplier_complaints(ns: int):
     """mk_supp's Better Business Bureau marks: every supplier draws bad_press = RANDOM(1, 10000, BBB_CMNT_SD) and type =
     RANDOM(0, 100, BBB_TYPE_SD); bad_press <= S_CMNT_BBB (10) overwrites part of the comment with "Customer " … "Complaints"
@@ -323,13 +616,24 @@ def supplier_complaints(ns: int):
 
 
 def supplier_comments(ns: int) -> list:
-    """NOT dbgen's s_comment: the comment columns are cut out of dbgen's grammar-generated text pool (dists.dss weights, not in the
-    reference), which this restatement does not generate.  What the pinned queries READ of s_comment is restated: the
-    "Customer … Complaints" / "Customer … Recommends" marks (Q16's LIKE '%Customer%Complaints%'; the grammar has no capitalised
-    "Customer", so only marked suppliers match).  Queries that PRINT a comment (Q2, Q10) are compared on their other columns."""
+    """mk_supp: TEXT(S_CMNT_LEN = 63, S_CMNT_SD), then the Better Business Bureau marks of the suppliers supplier_complaints()
+    selects: noise = RANDOM(0, len - 19, BBB_JNK_SD), offset = RANDOM(0, len - (19 + noise), BBB_OFFSET_SD) — drawn for every
+    supplier — and "Customer " is written at `offset`, "Complaints" / "Recommends" `noise` characters after it.  (The text is
+    pinned by the reference's supplier rows and Q2's answer; none of those carries a mark: the marks follow build.c as published.)"""
+    text = text_column(S_CMNT_SD, ns, 63)
     bad, good = supplier_complaints(ns)
-    return [f"(text {i}) Customer (text) Complaints (text)" if bad[i - 1] else f"(text {i}) Customer (text) Recommends (text)" if good[i - 1] else f"(text {i})"
-            for i in range(1, ns + 1)]
+    length = np.array([len(t) for t in text], dtype=np.int64)
+    state = lambda sd: _row_starts(sd, ns) * np.uint64(A) % np.uint64(M)      # noqa: E731 - one draw per row
+    junk = state(BBB_JNK_SD).astype(np.float64) / 2147483647.0
+    offs = state(BBB_OFFSET_SD).astype(np.float64) / 2147483647.0
+    for i in np.nonzero(bad | good)[0]:
+        noise = int(junk[i] * float(length[i] - 19 + 1))
+        offset = int(offs[i] * float(length[i] - (19 + noise) + 1))
+        t = bytearray(text[i].encode())
+        t[offset:offset + 9] = b"Customer "
+        t[offset + 9 + noise:offset + 9 + noise + 10] = b"Complaints" if bad[i] else b"Recommends"
+        text[i] = t.decode()
+    return text
 
 
 def nation(strings: str = "codes") -> pa.Table:

@@ -93,3 +93,56 @@ def test_cardinalities_and_scaling():
     t = sf1()
     assert t["lineitem"].num_rows == 6001215 and t["orders"].num_rows == 1500000     # the TPC-H specification's SF 1 cardinalities
     assert t["lineitem"].schema.field("l_extendedprice").type == pa.decimal128(15, 2)
+
+
+def test_comment_text_pool_is_pinned_by_every_comment_the_reference_carries():
+    """dbgen's text pool (oracle/dbgen_text.c + dbgen.DISTS): every comment string of the reference's SF1 fixtures — nation,
+    region, supplier, customer, orders, part, partsupp rows of core/tests/data/tpch_*_small.parquet and core/tests/tpch-csv — is
+    the slice of the pool its row's stream selects.  The offsets are uniform over the 300 MiB, so a single wrong weight, word or
+    blank anywhere in the grammar would move every string after it."""
+    import numpy as np
+
+    from oracle import dbgen
+    com = load_golden("tpch_answers.json")["comments"]
+    n = dbgen.counts(1.0)
+    checked = 0
+
+    def check(table, rows, got, skip=()):
+        nonlocal checked
+        for (key, want), have in zip(com[table]["rows"], got):
+            if tuple(key) in skip:
+                continue
+            assert have == want, (table, key, have, want)
+            checked += 1
+
+    keys = lambda t: np.array([k[0] for k, _ in com[t]["rows"]], dtype=np.int64)       # noqa: E731
+    check("nation", None, dbgen.text_column(dbgen.N_CMNT_SD, 25, 72, rows=keys("nation")))
+    check("region", None, dbgen.text_column(dbgen.R_CMNT_SD, 5, 72, rows=keys("region")))
+    check("supplier", None, dbgen.text_column(dbgen.S_CMNT_SD, n["part"] // 20, 63, rows=keys("supplier") - 1))
+    check("customer", None, dbgen.text_column(dbgen.C_CMNT_SD, n["customer"], 73, rows=keys("customer") - 1))
+    ok = keys("orders")
+    check("orders", None, dbgen.text_column(dbgen.O_CMNT_SD, n["orders"], 49, rows=((ok >> 5) << 3 | (ok & 7)) - 1))     # mk_sparse inverted
+    # the one part.csv / partsupp.csv row is not dbgen output (test_the_reference_part_fixture_is_not_dbgen_output): skipped
+    check("part", None, dbgen.text_column(dbgen.P_CMNT_SD, n["part"], 14, rows=keys("part") - 1), skip={(63700,)})
+    ps = dbgen.partsupp(1.0)
+    at = {(p, s): i for i, (p, s) in enumerate(zip(ps.column("ps_partkey").to_pylist()[:400], ps.column("ps_suppkey").to_pylist()[:400]))}
+    rows = [(k, v) for k, v in com["partsupp"]["rows"] if tuple(k) in at]
+    got = dbgen.text_column(dbgen.PS_CMNT_SD, n["part"], 124, rows=[at[tuple(k)] // 4 for k, _ in rows], call=[at[tuple(k)] % 4 for k, _ in rows])
+    for (k, want), have in zip(rows, got):
+        assert have == want, ("partsupp", k, have, want)
+        checked += 1
+    assert checked >= 120
+
+
+def test_supplier_complaint_marks():
+    """mk_supp's "Customer … Complaints" / "Customer … Recommends" marks sit inside the comment text and are found by Q16's pattern"""
+    import re
+
+    from oracle import dbgen
+    text = dbgen.supplier_comments(10000)
+    bad, good = dbgen.supplier_complaints(10000)
+    assert 0 < bad.sum() < 20 and 0 < good.sum() < 20
+    for i, t in enumerate(text):
+        assert bool(re.search("Customer.*Complaints", t)) == bool(bad[i]), (i, t)
+        assert bool(re.search("Customer.*Recommends", t)) == bool(good[i]), (i, t)
+        assert 25 <= len(t) <= 100
