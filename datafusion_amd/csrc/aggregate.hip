@@ -341,6 +341,7 @@ struct Aggregate {
   int64_t capacity_hint = 1 << 16;
   std::vector<uint16_t> small_keys;  // small-domain interning: host mirror of the group keys (byte g of key i = column g)
   int64_t fused_updates = 0;         // updates that took the fused (rowprog) path
+  std::vector<uint8_t> utf8_key;     // group key g arrived as a Utf8 column: interned on entry, decoded again on emit
   bool touched = false;              // an update ran: the state is bound to its device
   bool final_mode() const { return mode == DFGPU_AGG_FINAL || mode == DFGPU_AGG_FINAL_PARTITIONED; }
   bool partial_out() const { return mode == DFGPU_AGG_PARTIAL; }
@@ -2777,7 +2778,27 @@ static void agg_update_unfused(Aggregate& A, const Table& in) {
 }
 
 // aggregate_batch_inner over a whole table, optionally under a FilterExec predicate fused in front
+static void agg_update_keys_fixed(Aggregate& A, const Table& in, const dfgpu_expr* pred);
+// Utf8 group keys (plain column references; in Final modes the leading columns): interned on entry with an ascending dictionary —
+// grouping on the indices is grouping on the strings — and decoded again when the groups are emitted, so the node's schema keeps
+// Utf8.  One update per aggregate: a second batch would arrive with another dictionary (the check below says so).
 static void agg_update(Aggregate& A, const Table& in, const dfgpu_expr* pred = nullptr) {
+  const int ngk = (int)A.group_roots.size();
+  Table coded;
+  bool any = false;
+  for (int g = 0; g < ngk; g++) {
+    int kc = A.final_mode() ? g : -1;
+    if (!A.final_mode() && !is_plain_column(A.group_nodes[(size_t)g], A.group_roots[(size_t)g], &kc)) continue;
+    if (kc < 0 || kc >= (int)in.cols.size() || in.cols[(size_t)kc].field.type != DFGPU_UTF8 || in.cols[(size_t)kc].dict) continue;
+    if (!any) coded = in;
+    any = true;
+    if (coded.cols[(size_t)kc].field.type == DFGPU_UTF8) coded.cols[(size_t)kc] = dictionary_encode(in.cols[(size_t)kc], true);
+    A.utf8_key.resize((size_t)ngk, 0);
+    A.utf8_key[(size_t)g] = 1;
+  }
+  agg_update_keys_fixed(A, any ? coded : in, pred);
+}
+static void agg_update_keys_fixed(Aggregate& A, const Table& in, const dfgpu_expr* pred) {
   // group keys that are dictionary-encoded columns are interned by their indices: every update must use the dictionary of
   // the groups that exist already (all interning paths — LDS cells, dense ranks, hash — rely on this)
   if (A.ngroups > 0)
@@ -2840,6 +2861,10 @@ static Table agg_emit(Aggregate& A) {
   for (int g = 0; g < ngk; g++) {
     if (G == 0 && (int)A.group_keys.cols.size() <= g) throw Error("aggregate emitted before any input: group key types unknown");
     out.cols.push_back(A.group_keys.cols[g]);
+    if ((size_t)g < A.utf8_key.size() && A.utf8_key[(size_t)g] && out.cols.back().dict) {
+      out.cols.back() = dictionary_decode(out.cols.back());
+      out.cols.back().name = A.group_names[(size_t)g];
+    }
   }
   for (AggState& a : A.aggs) {
     DFGPU_CHECK(a.typed || G == 0, "aggregate emitted before any input");

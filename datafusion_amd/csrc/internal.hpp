@@ -308,6 +308,7 @@ Column slice_strings(const Column& in, int64_t offset, int64_t length);
 Column concat_strings(const std::vector<const Column*>& parts, int64_t total);
 // Int32 indices + host dictionary (first-seen order, or ascending when `sorted`)
 Column dictionary_encode(const Column& in, bool sorted);
+Column dictionary_decode(const Column& in);
 // BinaryExpr comparison / LikeExpr over string operands (a Boolean column; NULL where an operand is NULL)
 Datum string_binary(int op, const Datum& a, const Datum& b, int64_t nrows);
 

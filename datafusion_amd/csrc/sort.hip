@@ -1069,7 +1069,23 @@ extern "C" int dfgpu_sort(dfgpu_table_t input, const int* key_cols, const uint8_
                           dfgpu_table_t* out) {
   return guarded([&] {
     require_init();
-    auto t = std::make_unique<Table>(sort_table(*unwrap(input), std::vector<int>(key_cols, key_cols + nkeys), descending, nulls_first, fetch));
+    const Table& in = *unwrap(input);
+    std::vector<int> keys(key_cols, key_cols + nkeys);
+    // Utf8 sort keys: interned with an ascending dictionary (index order = byte order of the strings = arrow's order for Utf8), the
+    // indices are the key; the strings themselves travel as payload (the take of strings, strings.hip)
+    Table work;
+    bool interned = false;
+    for (int k = 0; k < nkeys; k++) {
+      DFGPU_CHECK(keys[(size_t)k] >= 0 && keys[(size_t)k] < (int)in.cols.size(), "sort key column out of range");
+      const Column& c = in.cols[(size_t)keys[(size_t)k]];
+      if (c.field.type != DFGPU_UTF8 || c.dict) continue;
+      if (!interned) work = in;
+      interned = true;
+      work.cols.push_back(dictionary_encode(c, true));
+      keys[(size_t)k] = (int)work.cols.size() - 1;
+    }
+    auto t = std::make_unique<Table>(sort_table(interned ? work : in, keys, descending, nulls_first, fetch));
+    if (interned) t->cols.resize(in.cols.size());
     *out = wrap(t.release());
   });
 }

@@ -89,9 +89,10 @@ typedef enum dfgpu_type {
   /* variable-length strings in HBM (Arrow Utf8 / LargeUtf8 / Utf8View on import): `data` = the bytes, 64-bit offsets
    * [length + 1] beside them.  Row-selecting operators (filter, take, join payload, sort output, partitions, concat) move
    * such columns; `=`, `!=`, `<` ..., LIKE / ILIKE against a literal or another string column are evaluated on the bytes;
-   * operators that hash or order by a string key (joins, GROUP BY, ORDER BY, repartition) take the column dictionary-encoded:
-   * dfgpu_table_dictionary_encode interns it on the device (hash + byte comparison, first-seen order — ArrowBytesMap,
-   * physical-expr-common/src/binary_map.rs; group_values/{single,multi}_group_by/bytes*.rs) and they then run on the indices. */
+   * operators that hash or order by a string key run on interned indices (hash + byte comparison on the device — ArrowBytesMap,
+   * physical-expr-common/src/binary_map.rs; group_values/{single,multi}_group_by/bytes*.rs): GROUP BY (dfgpu_agg_update; one
+   * update per aggregate) and ORDER BY (dfgpu_sort) intern a DFGPU_UTF8 key themselves and hand DFGPU_UTF8 back; joins and
+   * repartition take the key column dictionary-encoded (dfgpu_table_dictionary_encode) and refuse plain DFGPU_UTF8 keys. */
   DFGPU_UTF8 = 10
 } dfgpu_type;
 

@@ -168,13 +168,54 @@ def test_string_keys_run_on_interned_indices():
     assert sorted(zip(j.column("name").cast(pa.string()).to_pylist(), j.column("w").to_pylist(), j.column("v").to_pylist())) == exp
 
 
-def test_utf8_key_without_encoding_is_a_clear_error():
+def test_utf8_join_key_without_encoding_is_a_clear_error():
     from datafusion_amd import _lib, ops
-    from datafusion_amd.expr import col
     from datafusion_amd.table import DeviceTable
     dev = DeviceTable.from_arrow(pa.table({"s": pa.array(["a", "b"], pa.string()), "v": pa.array([1, 2])}))
     with pytest.raises(_lib.DfgpuError, match="dictionary"):
-        ops.aggregate(dev, [(col("s"), "s")], [("sum", col("v"), "t")], "Single")
+        ops.hash_join(dev, dev, [("s", "s")], "Inner")
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.1])
+def test_group_by_and_order_by_on_utf8_columns_intern_them_inside_the_operator(null_frac):
+    """GROUP BY / ORDER BY keys that arrive as plain Utf8 columns: the operator interns them (ascending dictionary), works on the
+    indices and hands Utf8 back — Single, Partial -> Final over concatenated partitions, several keys, TopK"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(8)
+    n = 20000
+    pool = [f"Brand#{i}" for i in range(40)] + WORDS
+    t = pa.table({"s": random_strings(rng, n, null_frac, pool), "k": pa.array(rng.integers(0, 5, size=n), pa.int32()), "u": random_strings(rng, n, null_frac, WORDS[:6]),
+                  "v": pa.array(rng.integers(0, 1000, size=n))})
+    dev = DeviceTable.from_arrow(t)
+
+    def expected(keys):
+        want = {}
+        for row in t.to_pylist():
+            kk = tuple(row[c] for c in keys)
+            s, c = want.get(kk, (0, 0))
+            want[kk] = (s + row["v"], c + 1)
+        return want
+
+    aggs = [("sum", col("v"), "t"), ("count", None, "n")]
+    for keys in (["s"], ["s", "k", "u"]):
+        gb = [(col(c), c) for c in keys]
+        g = ops.aggregate(dev, gb, aggs, "Single").to_arrow()
+        assert all(g.schema.field(c).type == t.schema.field(c).type for c in keys)            # Utf8 in, Utf8 out
+        assert {tuple(r[c] for c in keys): (r["t"], r["n"]) for r in g.to_pylist()} == expected(keys)
+        parts = [ops.aggregate(DeviceTable.from_arrow(t.slice(o, n // 4)), gb, aggs, "Partial") for o in range(0, n, n // 4)]
+        f = ops.aggregate(DeviceTable.concat(parts), gb, aggs, "Final").to_arrow()
+        assert {tuple(r[c] for c in keys): (r["t"], r["n"]) for r in f.to_pylist()} == expected(keys)
+    # ORDER BY s ASC NULLS LAST, v DESC; then s DESC NULLS FIRST with a fetch
+    srt = ops.sort(dev, [("s", False, False), ("v", True, False)]).to_arrow()
+    assert srt.schema.field("s").type == pa.string()
+    ks = [(x is None, (x or "").encode(), -v) for x, v in zip(srt.column("s").to_pylist(), srt.column("v").to_pylist())]
+    assert ks == sorted(ks)
+    assert sorted(map(str, srt.to_pylist())) == sorted(map(str, t.to_pylist()))
+    top = ops.sort(dev, [("s", True, True), ("u", False, False), ("v", False, False)], fetch=50).to_arrow()
+    allr = sorted(t.to_pylist(), key=lambda r: (r["s"] is not None, [-b for b in (r["s"] or "").encode()] + [1], r["u"] is None, (r["u"] or "").encode(), r["v"]))
+    assert [(r["s"], r["u"], r["v"]) for r in top.to_pylist()] == [(r["s"], r["u"], r["v"]) for r in allr[:50]]
 
 
 def test_slice_of_nullable_boolean_and_string_columns():

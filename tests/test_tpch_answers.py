@@ -224,6 +224,23 @@ def test_gpu_reproduces_the_reference_answer(q, device_tables):
 
 
 @pytest.mark.gpu
+def test_gpu_text_queries_over_utf8_columns_in_hbm():
+    """Q13 (o_comment NOT LIKE '%special%requests%'), Q16 (s_comment LIKE '%Customer%Complaints%', p_type NOT LIKE 'MEDIUM POLISHED%',
+    p_brand <> 'Brand#45') and Q2 (p_type LIKE '%BRASS', strings through three joins into the top-k) with every string column as plain
+    Utf8 bytes on the device instead of dictionary indices: the patterns are matched on the bytes by the LIKE kernels"""
+    from datafusion_amd import physical_plan as P
+    from datafusion_amd.table import DeviceTable
+    t = {k: DeviceTable.from_arrow(v) for k, v in data("utf8").items() if k in ("customer", "orders", "supplier", "part", "partsupp", "nation", "region")}
+    t["lineitem"] = None
+    from datafusion_amd import tpch_plans as T
+    todo = {"q13": T.q13_plan(t["customer"], t["orders"]), "q16": T.q16_plan(t["partsupp"], t["part"], t["supplier"]),
+            "q2": T.q2_plan(t["part"], t["supplier"], t["partsupp"], t["nation"], t["region"])}
+    for q, plan in todo.items():
+        assert_answer(q, P.collect(plan).to_arrow())
+        assert_answer(q, P.collect(P.GpuOffloadRule().optimize(plan)).to_arrow())
+
+
+@pytest.mark.gpu
 def test_gpu_q16_null_aware_anti_join_that_loses_rows(device_tables):
     """the pinned Q16 answer does not depend on dbgen's one marked supplier: the same plan over a supplier table with 142 marked
     suppliers (LIKE over the dictionary in 142 runs, the null-aware LeftAnti join drops their partsupp rows), against the oracle"""
