@@ -309,6 +309,7 @@ Column concat_strings(const std::vector<const Column*>& parts, int64_t total);
 // Int32 indices + host dictionary (first-seen order, or ascending when `sorted`)
 Column dictionary_encode(const Column& in, bool sorted);
 Column dictionary_decode(const Column& in);
+Column string_hash_column(const Column& in);
 // BinaryExpr comparison / LikeExpr over string operands (a Boolean column; NULL where an operand is NULL)
 Datum string_binary(int op, const Datum& a, const Datum& b, int64_t nrows);
 

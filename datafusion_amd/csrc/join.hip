@@ -1105,7 +1105,26 @@ static int64_t null_count_of(const Column& c) {
   return tmp.null_count;
 }
 
+static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts);
+// Utf8 key columns: interned on entry (ascending dictionary) into an extra column behind the caller's columns, which becomes the key —
+// the string column itself stays where it is and travels as payload.  The probe side is interned the same way and its indices are
+// rewritten into the build side's dictionary (with_build_dictionaries).
 static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts) {
+  Table coded;
+  std::vector<int> kc = key_cols;
+  bool any = false;
+  for (size_t i = 0; i < kc.size(); i++) {
+    DFGPU_CHECK(kc[i] >= 0 && kc[i] < (int)build.cols.size(), "join key column index out of range");
+    const Column& c = build.cols[(size_t)kc[i]];
+    if (c.field.type != DFGPU_UTF8 || c.dict) continue;
+    if (!any) coded = build;
+    any = true;
+    coded.cols.push_back(dictionary_encode(c, true));
+    kc[i] = (int)coded.cols.size() - 1;
+  }
+  return join_build_fixed_keys(any ? coded : build, kc, null_equality, opts);
+}
+static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts) {
   Runtime& r = rt();
   auto jt = std::make_unique<JoinTable>();
   jt->build = build;
@@ -1311,13 +1330,27 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
 // Dictionary-encoded key columns join on their indices, which only means joining on the strings when both sides use the
 // same dictionary.  A probe side encoded differently (another Parquet file, another table) gets its key indices rewritten
 // into the build side's dictionary; probe strings the build dictionary does not hold get an index no build row carries.
-static Table with_build_dictionaries(const JoinTable& jt, const Table& probe, const std::vector<int>& pk) {
+// A Utf8 probe key (the build key was interned by join_build, or arrived dictionary-encoded) is interned into an extra column behind the
+// caller's columns and `pk` is pointed at it: the string column keeps its place for the output.
+static Table with_build_dictionaries(const JoinTable& jt, const Table& probe, std::vector<int>& pk) {
   DFGPU_CHECK(pk.size() == jt.key_cols.size(), "probe key count differs from build key count");
   Table fixed;
   bool changed = false;
   for (size_t i = 0; i < pk.size(); i++) {
     DFGPU_CHECK(pk[i] >= 0 && pk[i] < (int)probe.cols.size(), "join key column index out of range");
     const Column& bc = jt.build.cols[jt.key_cols[i]];
+    if (bc.dict && probe.cols[pk[i]].field.type == DFGPU_UTF8 && !probe.cols[pk[i]].dict) {
+      Column enc = dictionary_encode(probe.cols[pk[i]], true);
+      if (!same_dictionary(bc.dict, enc.dict)) {
+        for (size_t k = 0; k < bc.dict->valid.size(); k++) DFGPU_CHECK(bc.dict->valid[k], "join keys with NULL dictionary values and different dictionaries are not supported on the GPU path");
+        enc = remap_to_dictionary(enc, bc.dict);
+      }
+      if (!changed) fixed = probe;
+      changed = true;
+      fixed.cols.push_back(enc);
+      pk[i] = (int)fixed.cols.size() - 1;
+      continue;
+    }
     const Column& pc = probe.cols[pk[i]];
     DFGPU_CHECK((bc.dict != nullptr) == (pc.dict != nullptr), "join key " + std::to_string(i) + ": one side is dictionary-encoded, the other is not (the planner inserts casts)");
     if (!bc.dict || same_dictionary(bc.dict, pc.dict)) continue;
@@ -2143,6 +2176,19 @@ int dfgpu_join_emit_unmatched(dfgpu_join_t ht, int join_type, const int* build_o
       if (join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_FULL) {
         // unmatched build rows carry an all-NULL probe side
         for (int i = 0; i < n_probe_out; i++) {
+          if (probe_fields[i].type == DFGPU_UTF8) {   // all-NULL strings: zero offsets, no bytes
+            Column c;
+            c.field = probe_fields[i];
+            c.field.nullable = 1;
+            c.name = probe_names && probe_names[i] ? probe_names[i] : "";
+            c.length = o->nrows;
+            c.offsets = make_zero_buf((size_t)(o->nrows + 1) * 8 + 16);
+            c.data = make_buf(16);
+            c.validity = make_zero_buf(bitmap_bytes(o->nrows));
+            c.null_count = o->nrows;
+            o->cols.push_back(std::move(c));
+            continue;
+          }
           Column c = alloc_column(probe_fields[i], probe_names && probe_names[i] ? probe_names[i] : "", o->nrows);
           if (o->nrows) DFGPU_HIP(hipMemsetAsync(c.data->ptr, 0, data_bytes(c.field.type, o->nrows), r.stream));
           c.validity = make_zero_buf(bitmap_bytes(o->nrows));

@@ -279,7 +279,29 @@ __global__ __launch_bounds__(BLOCK) void k_part_mask(const uint8_t* __restrict__
   }
 }
 
+static std::vector<Table> partition_table_fixed_keys(const Table& in, const std::vector<int>& key_cols, int nparts);
+// String keys (Utf8 bytes or dictionary-encoded) are routed on a hash of their BYTES (strings.hip string_hash_column), carried as an
+// extra column behind the caller's columns through the partitioning and dropped from the partitions: indices of a dictionary mean
+// nothing across tables, calls or ranks.
 std::vector<Table> partition_table(const Table& in, const std::vector<int>& key_cols, int nparts) {
+  Table work;
+  std::vector<int> kc = key_cols;
+  bool any = false;
+  for (size_t i = 0; i < kc.size(); i++) {
+    DFGPU_CHECK(kc[i] >= 0 && kc[i] < (int)in.cols.size(), "partition key column out of range");
+    const Column& c = in.cols[(size_t)kc[i]];
+    if (c.field.type != DFGPU_UTF8 && !c.dict) continue;
+    if (!any) work = in;
+    any = true;
+    work.cols.push_back(string_hash_column(c));
+    kc[i] = (int)work.cols.size() - 1;
+  }
+  if (!any) return partition_table_fixed_keys(in, key_cols, nparts);
+  std::vector<Table> parts = partition_table_fixed_keys(work, kc, nparts);
+  for (Table& p : parts) p.cols.resize(in.cols.size());
+  return parts;
+}
+static std::vector<Table> partition_table_fixed_keys(const Table& in, const std::vector<int>& key_cols, int nparts) {
   Runtime& r = rt();
   DFGPU_CHECK(nparts >= 1 && nparts <= MAX_PARTS, "dfgpu_partition supports 1..64 partitions");
   const int64_t n = in.nrows;

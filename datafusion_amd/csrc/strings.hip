@@ -765,6 +765,77 @@ __global__ __launch_bounds__(BLOCK) void k_dict_ids(const T* __restrict__ codes,
     ids[i] = ok ? (int64_t)k : -1;
   }
 }
+// ------------------------------------------------------------------------------ content hash (routing on a string key)
+__global__ __launch_bounds__(BLOCK) void k_str_hash(const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, uint64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = hash_bytes(bytes + off[i], off[i + 1] - off[i]);
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_dict_hash(const T* __restrict__ codes, const uint64_t* __restrict__ value_hash, int64_t n_values, int64_t n, uint64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const uint64_t k = (uint64_t)codes[i];
+    out[i] = k < (uint64_t)n_values ? value_hash[k] : 0;   // (NULL rows may hold any index: their validity bit says so)
+  }
+}
+static Column dictionary_values_column(const DictValues& dv, BufPtr* value_valid);
+// A UInt64 column holding a hash of every row's string BYTES (NULL rows stay NULL): equal strings give equal values whatever
+// table, dictionary or rank they come from.  Hash repartitioning routes string keys on it — the two sides of a Partitioned join
+// arrive in separate calls with dictionaries of their own, and equal strings must still meet on one rank.
+Column string_hash_column(const Column& in) {
+  Runtime& r = rt();
+  dfgpu_field f{};
+  f.type = DFGPU_UINT64;
+  f.nullable = in.field.nullable;
+  Column out = alloc_column(f, in.name, in.length);
+  out.validity = in.validity;
+  out.null_count = in.null_count;
+  const int64_t n = in.length;
+  if (in.dict) {
+    Column values = dictionary_values_column(*in.dict, nullptr);
+    const int64_t nv = values.length;
+    BufPtr vh = make_buf((size_t)std::max<int64_t>(nv, 1) * 8);
+    if (nv) k_str_hash<<<grid_for(nv, BLOCK), BLOCK, 0, r.stream>>>(str_offsets(values), (const uint8_t*)values.ptr(), nv, vh->as<uint64_t>());
+    if (n) {
+      const int g = grid_for(n, BLOCK);
+      switch (type_width(in.field.type)) {
+        case 1: k_dict_hash<uint8_t><<<g, BLOCK, 0, r.stream>>>((const uint8_t*)in.ptr(), vh->as<uint64_t>(), nv, n, out.data->as<uint64_t>()); break;
+        case 4: k_dict_hash<uint32_t><<<g, BLOCK, 0, r.stream>>>((const uint32_t*)in.ptr(), vh->as<uint64_t>(), nv, n, out.data->as<uint64_t>()); break;
+        default: k_dict_hash<uint64_t><<<g, BLOCK, 0, r.stream>>>((const uint64_t*)in.ptr(), vh->as<uint64_t>(), nv, n, out.data->as<uint64_t>()); break;
+      }
+    }
+    DFGPU_HIP(hipGetLastError());
+    DFGPU_HIP(hipStreamSynchronize(r.stream));  // `values` / `vh` are released on return
+    return out;
+  }
+  DFGPU_CHECK(in.field.type == DFGPU_UTF8, "string_hash_column: not a string column");
+  if (n) k_str_hash<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(str_offsets(in), (const uint8_t*)in.ptr(), n, out.data->as<uint64_t>());
+  DFGPU_HIP(hipGetLastError());
+  return out;
+}
+
+// the dictionary's values as a Utf8 column in HBM (value_valid: one byte per value, optional)
+static Column dictionary_values_column(const DictValues& dv, BufPtr* value_valid) {
+  Runtime& r = rt();
+  const int64_t nv = (int64_t)dv.values.size();
+  std::vector<int64_t> off((size_t)nv + 1, 0);
+  for (int64_t k = 0; k < nv; k++) off[(size_t)k + 1] = off[(size_t)k] + (int64_t)dv.values[(size_t)k].size();
+  std::vector<char> bytes((size_t)off[(size_t)nv] + 1);
+  for (int64_t k = 0; k < nv; k++) std::memcpy(bytes.data() + off[(size_t)k], dv.values[(size_t)k].data(), dv.values[(size_t)k].size());
+  Column values;
+  values.field.type = DFGPU_UTF8;
+  values.field.nullable = 1;
+  values.length = nv;
+  values.offsets = make_buf((size_t)(nv + 1) * 8 + 16);
+  values.data = make_buf((size_t)off[(size_t)nv] + 16);
+  h2d_async(values.offsets->ptr, off.data(), (size_t)(nv + 1) * 8);
+  if (off[(size_t)nv]) h2d_async(values.data->ptr, bytes.data(), (size_t)off[(size_t)nv]);
+  if (value_valid) {
+    *value_valid = make_buf((size_t)nv + 16);
+    if (nv) h2d_async((*value_valid)->ptr, dv.valid.data(), (size_t)nv);
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // the host vectors are the copies' sources
+  return values;
+}
+
 // dictionary-encoded -> Utf8: the dictionary's values go to HBM as a string column once, every row takes its value (the same
 // take that filters and joins move strings with)
 Column dictionary_decode(const Column& in) {

@@ -91,8 +91,10 @@ typedef enum dfgpu_type {
    * such columns; `=`, `!=`, `<` ..., LIKE / ILIKE against a literal or another string column are evaluated on the bytes;
    * operators that hash or order by a string key run on interned indices (hash + byte comparison on the device — ArrowBytesMap,
    * physical-expr-common/src/binary_map.rs; group_values/{single,multi}_group_by/bytes*.rs): GROUP BY (dfgpu_agg_update; one
-   * update per aggregate) and ORDER BY (dfgpu_sort) intern a DFGPU_UTF8 key themselves and hand DFGPU_UTF8 back; joins and
-   * repartition take the key column dictionary-encoded (dfgpu_table_dictionary_encode) and refuse plain DFGPU_UTF8 keys. */
+   * update per aggregate), ORDER BY (dfgpu_sort) and the joins (build and probe side, each against the other's dictionary) intern a
+   * DFGPU_UTF8 key themselves and hand DFGPU_UTF8 back; dfgpu_table_dictionary_encode does it once for a column used many times.
+   * Hash repartitioning (dfgpu_partition, dfgpu_exchange_hash) routes string keys — DFGPU_UTF8 or dictionary-encoded — on a hash
+   * of their BYTES, so equal strings meet in one partition whatever table, dictionary, call or rank they come from. */
   DFGPU_UTF8 = 10
 } dfgpu_type;
 

@@ -108,6 +108,17 @@ if mode == "exchange":
     out["probe"] = probe
     out["pruned"] = decoded(c.broadcast_pruned(d, "k", DeviceTable.from_arrow(probe), "k2").to_arrow())
     out["stats"] = c.stats()
+    # PartitionMode::Partitioned on a STRING key: the two sides cross in separate exchanges — one dictionary-encoded with this rank's own
+    # dictionary, the other as plain Utf8 bytes — and equal strings must still meet on one rank (routing hashes the bytes)
+    from datafusion_amd import ops
+    rng = np.random.default_rng(70 + rank)
+    words = [f"w{i}" for i in range(40)] + list(values)
+    left = pa.table({"s": pa.array([words[i] for i in rng.integers(0, len(words), 3000)], pa.string()).dictionary_encode(), "a": pa.array(rng.integers(0, 10**6, 3000))})
+    right = pa.table({"s2": pa.array([words[i] for i in rng.integers(0, len(words), 4000)], pa.string()), "b": pa.array(rng.integers(0, 10**6, 4000))})
+    lx = c.hash_exchange(DeviceTable.from_arrow(left), ["s"])
+    rx = c.hash_exchange(DeviceTable.from_arrow(right), ["s2"])
+    out["pjoin"] = decoded(ops.hash_join(lx, rx, [("s", "s2")], "Inner").to_arrow())
+    out["pjoin_inputs"] = (decoded(left), right)
 elif mode == "plans":
     from datafusion_amd import physical_plan as P
     from tests.test_tpch_answers import data, plans
@@ -184,6 +195,15 @@ def test_two_ranks_exchange_device_tables_with_different_dictionaries_and_nulls(
         exp = whole.filter(pc.and_(pc.greater_equal(whole.column("k"), lo), pc.less_equal(whole.column("k"), hi)))
         assert_tables_equal(res[r]["pruned"], exp, ordered=True)
         assert res[r]["stats"]["bytes_sent_to_peers"] > 0 and res[r]["stats"]["rows_received_from_peers"] > 0
+    # the partitioned join on the string key: the ranks' results together are the global join
+    lefts = pa.concat_tables([r["pjoin_inputs"][0] for r in res])
+    rights = pa.concat_tables([r["pjoin_inputs"][1] for r in res])
+    by_s = {}
+    for s_, b in zip(rights.column("s2").to_pylist(), rights.column("b").to_pylist()):
+        by_s.setdefault(s_, []).append(b)
+    want = sorted((s_, a, b) for s_, a in zip(lefts.column("s").to_pylist(), lefts.column("a").to_pylist()) for b in by_s.get(s_, []))
+    got = sorted((x["s"], x["a"], x["b"]) for r in res for x in r["pjoin"].to_pylist())
+    assert len(want) > 100_000 and got == want
 
 
 def test_device_plans_on_two_ranks_reproduce_the_reference_answers(tmp_path):

@@ -168,12 +168,58 @@ def test_string_keys_run_on_interned_indices():
     assert sorted(zip(j.column("name").cast(pa.string()).to_pylist(), j.column("w").to_pylist(), j.column("v").to_pylist())) == exp
 
 
-def test_utf8_join_key_without_encoding_is_a_clear_error():
-    from datafusion_amd import _lib, ops
+def test_partition_on_string_keys_routes_on_the_bytes():
+    """RepartitionExec Hash on a string key: Utf8 bytes and dictionary-encoded columns (whatever their dictionaries) send equal strings
+    to the same partition — the partition contents are identical for the three encodings of one column, NULLs travel together"""
+    from datafusion_amd import ops
     from datafusion_amd.table import DeviceTable
-    dev = DeviceTable.from_arrow(pa.table({"s": pa.array(["a", "b"], pa.string()), "v": pa.array([1, 2])}))
-    with pytest.raises(_lib.DfgpuError, match="dictionary"):
-        ops.hash_join(dev, dev, [("s", "s")], "Inner")
+    rng = np.random.default_rng(31)
+    n = 20000
+    s = random_strings(rng, n, 0.05, [f"Customer#{i:09d}" for i in range(500)] + WORDS)
+    t = pa.table({"s": s, "v": pa.array(np.arange(n, dtype=np.int64))})
+    plain = DeviceTable.from_arrow(t)
+    views = [plain, plain.dictionary_encode(["s"], sorted=True), plain.dictionary_encode(["s"], sorted=False)]
+    results = []
+    for d in views:
+        parts = [p.to_arrow() for p in ops.partition(d, ["s"], 8)]
+        assert [p.column_names for p in parts] == [["s", "v"]] * 8
+        results.append([p.column("v").to_pylist() for p in parts])
+        home = {}
+        for q, p in enumerate(parts):
+            for x in set(p.column("s").cast(pa.string()).to_pylist()):
+                assert home.setdefault(x, q) == q
+        assert sum(len(r) for r in results[-1]) == n and sum(1 for r in results[-1] if r) >= 6
+    assert results[0] == results[1] == results[2]
+
+
+@pytest.mark.parametrize("join_type", ["Inner", "Left", "LeftAnti", "RightSemi", "Full"])
+def test_joins_on_utf8_keys_intern_them_inside_the_operator(join_type):
+    """join keys that arrive as plain Utf8 columns on both sides (and Utf8 against dictionary-encoded): interned inside the join, the
+    string columns come out as Utf8; duplicates on both sides, NULL keys, strings only one side holds; a second (integer) key"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(21)
+    pool = [f"Supplier#{i:09d}" for i in range(300)] + WORDS
+    b = pa.table({"name": random_strings(rng, 2000, 0.05, pool[:250]), "k": pa.array(rng.integers(0, 3, size=2000), pa.int32()), "w": pa.array(np.arange(2000, dtype=np.int64))})
+    p = pa.table({"name2": random_strings(rng, 9000, 0.05, pool[100:]), "k2": pa.array(rng.integers(0, 3, size=9000), pa.int32()), "v": pa.array(np.arange(9000, dtype=np.int64))})
+
+    def codes(t, c):      # the oracle joins on integer codes of one shared dictionary (NULL stays NULL)
+        at = {v: i for i, v in enumerate(pool)}
+        return t.set_column(t.column_names.index(c), c, pa.array([None if v is None else at[v] for v in t.column(c).to_pylist()], pa.int32()))
+
+    def decoded(t):
+        cols = {n: (pa.array([None if v is None else pool[v] for v in t.column(n).to_pylist()], pa.string()) if n in ("name", "name2") else t.column(n)) for n in t.column_names}
+        return pa.table(cols)
+    for on in ([("name", "name2")], [("name", "name2"), ("k", "k2")]):
+        want = decoded(oracle.hash_join(codes(b, "name"), codes(p, "name2"), on, join_type))
+        for bd, pd in ((DeviceTable.from_arrow(b), DeviceTable.from_arrow(p)), (DeviceTable.from_arrow(b).dictionary_encode(["name"]), DeviceTable.from_arrow(p))):
+            got = ops.hash_join(bd, pd, on, join_type).to_arrow()
+            got = pa.table({n: (c.cast(pa.string()) if pa.types.is_dictionary(c.type) else c) for n, c in zip(got.column_names, got.columns)})
+            assert got.column_names == want.column_names
+            assert sorted(map(str, got.to_pylist())) == sorted(map(str, want.to_pylist()))
+        if "name2" in want.column_names:
+            assert ops.hash_join(DeviceTable.from_arrow(b), DeviceTable.from_arrow(p), on, join_type).schema.field("name2").type == pa.string()
 
 
 @pytest.mark.parametrize("null_frac", [0.0, 0.1])
