@@ -6,10 +6,12 @@
 //! (datafusion/core/src/execution/session_state.rs:1407-1415).  Everything the rule does not recognise stays on the CPU.
 //!
 //! This crate is source only in this repository (no Rust toolchain in the build image): `sys.rs` is generated from the header
-//! and drift-checked (scripts/gen_shim_sys.py --check, tests/test_abi.py); the other modules mirror, call for call,
+//! and drift-checked (scripts/gen_shim_sys.py --check, tests/test_abi.py); the other modules (`hash_join.rs`: GpuHashJoinExec,
+//! `operators.rs`: filter / projection / aggregate incl. the fused filter / sort and TopK / hash repartition) mirror, call for call,
 //! `datafusion_amd/{table,expr,physical_plan}.py`, which the parity tests drive through the same entry points.
 pub mod expr;
 pub mod hash_join;
+pub mod operators;
 pub mod rule;
 pub mod sys;
 pub mod table;

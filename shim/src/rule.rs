@@ -4,12 +4,18 @@
 //! nodes only copy PlanProperties.  Python twin (tested against the reference's pinned TPC-H plans): datafusion_amd/physical_plan.py.
 use crate::expr::{field_of, lower, Lowered};
 use crate::hash_join::GpuHashJoinExec;
+use crate::operators::GpuUnaryExec;
 use crate::{check, sys};
 use datafusion::common::tree_node::{Transformed, TreeNode};
 use datafusion::config::ConfigOptions;
 use datafusion::error::Result;
 use datafusion::physical_optimizer::PhysicalOptimizerRule;
+use datafusion::physical_plan::aggregates::AggregateExec;
+use datafusion::physical_plan::filter::FilterExec;
 use datafusion::physical_plan::joins::HashJoinExec;
+use datafusion::physical_plan::projection::ProjectionExec;
+use datafusion::physical_plan::repartition::RepartitionExec;
+use datafusion::physical_plan::sorts::sort::SortExec;
 use datafusion::physical_plan::ExecutionPlan;
 use std::sync::Arc;
 
@@ -44,13 +50,27 @@ impl PhysicalOptimizerRule for GpuOffloadRule {
                     return Ok(Transformed::yes(Arc::new(GpuHashJoinExec::try_from_cpu(j, /*order_insensitive=*/ false)?) as _));
                 }
             }
-            // FilterExec (filter.rs:85) -> GpuFilterExec{dfgpu_filter}; AggregateExec (aggregates/mod.rs:839) -> GpuAggregateExec
-            // {dfgpu_agg_create / update / emit}; SortExec (sorts/sort.rs:1366) -> dfgpu_sort; ProjectionExec -> dfgpu_project;
-            // RepartitionExec Hash (repartition/mod.rs:1626) -> dfgpu_partition / dfgpu_exchange_hash.  Fused patterns, matched on
-            // the way up (children are Gpu* nodes already):
-            //   GpuAggregateExec(GpuProjectionExec?(GpuFilterExec?(x))) => dfgpu_agg_update_filtered: one pass over x's columns
-            //   GpuHashJoinExec(build, GpuFilterExec(probe))            => dfgpu_join_probe_filtered: row mask inside the probe kernel
-            // The Python twin implements all of them; they follow the pattern above.
+            // the single-input operators (operators.rs).  Children were visited first: an AggregateExec directly over a GpuFilterExec
+            // absorbs it (dfgpu_agg_update_filtered: filter, argument expressions and accumulation in ONE pass over the input columns —
+            // the shape of TPC-H Q1 and Q6).  The probe-side twin (GpuHashJoinExec over a GpuFilterExec -> dfgpu_join_probe_filtered)
+            // is implemented by the Python twin (physical_plan.py GpuHashJoinExec.probe_predicate) and follows the same pattern.
+            let any = node.as_any();
+            let replaced: Option<GpuUnaryExec> = if let Some(f) = any.downcast_ref::<FilterExec>() {
+                GpuUnaryExec::try_from_filter(f)
+            } else if let Some(p) = any.downcast_ref::<ProjectionExec>() {
+                GpuUnaryExec::try_from_projection(p)
+            } else if let Some(a) = any.downcast_ref::<AggregateExec>() {
+                GpuUnaryExec::try_from_aggregate(a, a.input().as_any().downcast_ref::<GpuUnaryExec>())
+            } else if let Some(so) = any.downcast_ref::<SortExec>() {
+                GpuUnaryExec::try_from_sort(so)
+            } else if let Some(r) = any.downcast_ref::<RepartitionExec>() {
+                GpuUnaryExec::try_from_repartition(r)
+            } else {
+                None
+            };
+            if let Some(g) = replaced {
+                return Ok(Transformed::yes(Arc::new(g) as _));
+            }
             Ok(Transformed::no(node))
         }).map(|t| t.data)
     }
