@@ -102,9 +102,20 @@ def main():
         ops.sync()
 
     # ------------------------------------------------------------------ config 4: Q1
-    if want("q1") or want("agg_highcard") or want("partition"):
+    if want("q1") or want("agg_highcard") or want("partition") or want("filter"):
         li = ops.tpch_lineitem(args.sf)
         n = li.num_rows
+        if want("filter"):
+            # the same FilterExec at the scale of configs 3-5 (config 2 at SF10 is a 1 ms operator: its fixed costs are a tenth of it)
+            q3p = ["l_orderkey", "l_extendedprice", "l_discount"]
+            holder = {}
+
+            def run_big():
+                o = ops.filter(li, col("l_shipdate") > lit(datetime.date(1995, 3, 15), pa.date32()), q3p)
+                holder["n"] = o.num_rows
+                return o
+            measure(f"filter[shipdate>1995-03-15,q3proj] SF{args.sf:g}", run_big, n, lambda: n * 4 + n * 40 + holder["n"] * 40,
+                    note="bytes = N*4 (predicate col) + N*W (projected cols read) + sel*N*W (written)")
         if want("q1"):
             measure(f"Q1 SF{args.sf:g} fused node (filter+project+aggregate in one pass, 8 aggs/4 groups) + sort", lambda: queries.q1(li), n, n * 70,
                     note="bytes = 7 referenced columns: l_shipdate 4 + 4 x Decimal128 64 + 2 x u8 flags = 70 B/row; output 4 rows")
