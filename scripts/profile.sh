@@ -14,9 +14,11 @@ cd /tmp
 (timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python $R/bench.py "$@" --no-cpu --steps 2 --warmup 1) > $OUT/pmc_fetch.log 2>&1
 (timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python $R/bench.py "$@" --no-cpu --steps 2 --warmup 1) > $OUT/pmc_write.log 2>&1
 # per-operator kernel trace (Q1 fused node, dense-key group-by, sort, Q3): the specialised kernels show up by name
+if [ -z "${SKIP_OPS:-}" ]; then
 (timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats_ops -o trace -- python $R/scripts/bench_ops.py --only q1,agg_highcard,sort,q3 --iters 3) > $OUT/stats_ops.log 2>&1
+fi
 cd $R
-python - <<PY > $OUT/ops_kernels.md 2>&1
+[ -z "${SKIP_OPS:-}" ] && python - <<PY > $OUT/ops_kernels.md 2>&1
 import sqlite3
 con = sqlite3.connect("$OUT/stats_ops/trace_results.db")
 print("| kernel | calls | avg ms | total ms | % |\n|---|---:|---:|---:|---:|")
