@@ -66,6 +66,11 @@ class KernelStat(C.Structure):
                 ("algorithmic_bytes", C.c_int64)]
 
 
+class CacheStats(C.Structure):
+    """dfgpu_cache_stats"""
+    _fields_ = [(n, C.c_int64) for n in ("entries", "bytes", "budget_bytes", "hits", "misses", "insertions", "evictions")]
+
+
 class ExchangeStats(C.Structure):
     _fields_ = [("bytes_sent_to_peers", C.c_int64), ("bytes_received_from_peers", C.c_int64), ("rows_sent_to_peers", C.c_int64),
                 ("rows_received_from_peers", C.c_int64), ("messages", C.c_int64), ("collectives", C.c_int64)]
@@ -108,6 +113,8 @@ SYMBOLS = [
     "dfgpu_mem_set_limit", "dfgpu_mem_limit", "dfgpu_mem_try_reserve", "dfgpu_mem_reservation_size", "dfgpu_mem_release",
     "dfgpu_table_export_batch", "dfgpu_host_register", "dfgpu_host_unregister", "dfgpu_table_export_into",
     "dfgpu_column_inlist", "dfgpu_metrics_reset", "dfgpu_metrics_get", "dfgpu_table_dictionary_like", "dfgpu_table_dictionary_encode", "dfgpu_table_dictionary_decode", "dfgpu_table_dictionary_size", "dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_estimate_bytes",
+    "dfgpu_table_retain", "dfgpu_table_export_device", "dfgpu_table_import_device",
+    "dfgpu_cache_create", "dfgpu_cache_free", "dfgpu_cache_get", "dfgpu_cache_put", "dfgpu_cache_clear", "dfgpu_cache_get_stats",
 ]
 
 _lib = None

@@ -142,7 +142,9 @@ struct DevBuf {
   void* ptr = nullptr;
   size_t bytes = 0;
   Runtime* owner = nullptr;  // the pool the block goes back to (buffers may be released from any thread)
+  std::shared_ptr<void> foreign;  // device memory somebody else owns (an imported ArrowDeviceArray): released with the last buffer that refers to it
   explicit DevBuf(size_t n);
+  DevBuf(void* p, size_t n, std::shared_ptr<void> keep_alive) : ptr(p), bytes(n), foreign(std::move(keep_alive)) {}
   ~DevBuf();
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -324,6 +326,12 @@ void jit_launch(hipFunction_t fn, int grid, int block, size_t lds_bytes, void* a
 hipFunction_t jit_get(const std::string& source, const char* kernel_name);
 // launches on the library stream; `args` is the kernel's single by-value argument struct
 void jit_launch(hipFunction_t fn, int grid, int block, size_t lds_bytes, void* args, size_t args_bytes);
+
+// ----------------------------------------------------------------- Arrow format strings (table.hip)
+dfgpu_field parse_format(const char* fmt, bool nullable);
+std::string format_of(const dfgpu_field& f);
+// bytes of HBM a table's columns occupy (values, validity, offsets)
+int64_t table_device_bytes(const Table& t);
 
 // ----------------------------------------------------------------- dictionaries (table.hip)
 // `c`'s indices rewritten so that they index `target`'s values; a value `target` does not hold gets the index

@@ -237,7 +237,9 @@ void Runtime::trim() {
 }
 
 DevBuf::DevBuf(size_t n) : bytes(n), owner(&rt()) { ptr = owner->alloc(n); }
-DevBuf::~DevBuf() { owner->free(ptr); }
+DevBuf::~DevBuf() {
+  if (owner) owner->free(ptr);  // foreign memory (owner == nullptr) goes with `foreign`
+}
 
 BufPtr make_zero_buf(size_t bytes) {
   BufPtr b = make_buf(bytes);

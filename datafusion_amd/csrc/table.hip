@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BLOCK) void k_remap_indices(const T* __restrict__ i
 }
 
 // ---------------------------------------------------------------- format strings
-static dfgpu_field parse_format(const char* fmt, bool nullable) {
+dfgpu_field parse_format(const char* fmt, bool nullable) {
   dfgpu_field f{};
   f.nullable = nullable ? 1 : 0;
   std::string s(fmt);
@@ -86,7 +86,7 @@ static dfgpu_field parse_format(const char* fmt, bool nullable) {
   }
   return f;
 }
-static std::string format_of(const dfgpu_field& f) {
+std::string format_of(const dfgpu_field& f) {
   switch (f.type) {
     case DFGPU_INT32: return "i";
     case DFGPU_INT64: return "l";

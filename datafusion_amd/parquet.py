@@ -37,72 +37,67 @@ def _target_field(arrow_type: pa.DataType):
 class ChunkCache:
     """Device-resident column chunks of files that were scanned before: the HBM twin of the reference's keeping hot inputs in
     memory (MemorySourceConfig over cached RecordBatches, datasource/src/memory.rs:58; the file-metadata / statistics caches of
-    execution/src/cache).  Keyed by (file identity = real path + mtime + size, row group, column); a hit hands out a zero-copy
-    view of the cached column (dfgpu_table_select), so a repeated scan — the same query again, or another query over the same
-    lineitem columns — costs no host read, no decompression and no PCIe transfer.  Least recently used chunks leave when the
-    byte budget (DFGPU_TABLE_CACHE_BYTES, default 16 GiB, 0 = off; 288 GB of HBM hold TPC-H SF100's hot columns) is exceeded;
-    a file that changed on disk has a new identity and its old chunks age out."""
+    execution/src/cache).  The cache itself lives BELOW the C ABI (dfgpu_cache_*: LRU under a byte budget, thread-safe, zero-copy
+    views on a hit) so that the Rust shim's scan node uses the very same one; this class only spells the keys: (file identity = real
+    path + mtime + size, row group, column).  A repeated scan — the same query again, or another query over the same lineitem
+    columns — costs no host read, no decompression and no PCIe transfer.  Budget: DFGPU_TABLE_CACHE_BYTES (default 16 GiB, 0 = off;
+    288 GB of HBM hold TPC-H SF100's hot columns); a file that changed on disk has a new identity and its old chunks age out."""
 
     def __init__(self, budget: int | None = None):
-        import collections
-        import threading
         self.budget = int(os.environ.get("DFGPU_TABLE_CACHE_BYTES", 16 << 30)) if budget is None else budget
-        self._lock = threading.Lock()
-        self._chunks = collections.OrderedDict()   # key -> (DeviceTable, bytes)
-        self.bytes = self.hits = self.misses = 0
+        self._h = None
+
+    def _handle(self):
+        if self._h is None:
+            h = C.c_void_p()
+            check(_lib.load().dfgpu_cache_create(C.c_int64(self.budget), C.byref(h)))
+            self._h = h
+        return self._h
+
+    @staticmethod
+    def _key(key) -> bytes:
+        return repr(key).encode()
 
     def get(self, key):
-        with self._lock:
-            e = self._chunks.get(key)
-            if e is None:
-                self.misses += 1
-                return None
-            self._chunks.move_to_end(key)
-            self.hits += 1
-            return e[0].select(list(range(e[0].num_columns)))
+        k = self._key(key)
+        out = C.c_void_p()
+        check(_lib.load().dfgpu_cache_get(self._handle(), k, C.c_int64(len(k)), C.byref(out)))
+        return DeviceTable(out) if out.value else None
 
     def put(self, key, table: DeviceTable):
-        nbytes = table.nbytes()
-        if self.budget <= 0 or nbytes > self.budget:
-            return
-        keep = table.select([0])
-        with self._lock:
-            if key in self._chunks:
-                keep.free()
-                return
-            self._chunks[key] = (keep, nbytes)
-            self.bytes += nbytes
-            while self.bytes > self.budget:
-                _, (old, b) = self._chunks.popitem(last=False)
-                old.free()
-                self.bytes -= b
+        k = self._key(key)
+        check(_lib.load().dfgpu_cache_put(self._handle(), k, C.c_int64(len(k)), table.handle))
 
-    def put_table(self, key, table: DeviceTable):
-        """the same for a whole multi-column table (one record batch of an IPC file)"""
-        nbytes = table.nbytes()
-        if self.budget <= 0 or nbytes > self.budget:
-            return
-        keep = table.select(list(range(table.num_columns)))
-        with self._lock:
-            if key in self._chunks:
-                keep.free()
-                return
-            self._chunks[key] = (keep, nbytes)
-            self.bytes += nbytes
-            while self.bytes > self.budget:
-                _, (old, b) = self._chunks.popitem(last=False)
-                old.free()
-                self.bytes -= b
+    put_table = put     # a whole multi-column table (one record batch of an IPC file) is kept the same way
 
     def clear(self):
-        with self._lock:
-            for t, _ in self._chunks.values():
-                t.free()
-            self._chunks.clear()
-            self.bytes = 0
+        if self._h is not None:
+            check(_lib.load().dfgpu_cache_clear(self._h))
 
     def stats(self) -> dict:
-        return dict(chunks=len(self._chunks), bytes=self.bytes, hits=self.hits, misses=self.misses)
+        st = _lib.CacheStats()
+        check(_lib.load().dfgpu_cache_get_stats(self._handle(), C.byref(st)))
+        return dict(chunks=st.entries, bytes=st.bytes, hits=st.hits, misses=st.misses, evictions=st.evictions, budget=st.budget_bytes)
+
+    @property
+    def bytes(self) -> int:
+        return self.stats()["bytes"]
+
+    @property
+    def hits(self) -> int:
+        return self.stats()["hits"]
+
+    @property
+    def misses(self) -> int:
+        return self.stats()["misses"]
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.load().dfgpu_cache_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 CACHE = ChunkCache()

@@ -34,6 +34,14 @@ ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offse
                        ("release", C.c_void_p), ("private_data", C.c_void_p)]
 
 
+class ArrowDeviceArray(C.Structure):
+    """Arrow C Device Data Interface: an ArrowArray whose buffers are device pointers (ARROW_DEVICE_ROCM = 10)"""
+    _fields_ = [("array", ArrowArray), ("device_id", C.c_int64), ("device_type", C.c_int32), ("sync_event", C.c_void_p), ("reserved", C.c_int64 * 3)]
+
+
+ARROW_DEVICE_ROCM = 10
+
+
 def field_of(t: pa.DataType) -> Field:
     if pa.types.is_int32(t):
         return Field(INT32, 0, 0, 1)
@@ -105,6 +113,28 @@ class DeviceTable:
             arr, sch = ArrowArray(), ArrowSchema()
             check(lib.dfgpu_table_export_batch(self._h, C.c_int64(off), C.c_int64(min(batch_rows, n - off)), C.byref(arr), C.byref(sch)))
             yield pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+
+    # ------------------------------------------------------------------ device-resident hand-off
+    def retain(self) -> "DeviceTable":
+        """a second owner of the same HBM buffers (dfgpu_table_retain)"""
+        out = C.c_void_p()
+        check(_lib.load().dfgpu_table_retain(self.handle, C.byref(out)))
+        return DeviceTable(out)
+
+    def export_device(self):
+        """(ArrowDeviceArray, ArrowSchema): the table as an Arrow C Device array over its own HBM buffers — what a GPU node hands the
+        next GPU node (or any other ROCm component) instead of a host RecordBatch.  The array keeps the buffers alive until its release
+        callback runs (DeviceTable.from_device consumes it)."""
+        arr, sch = ArrowDeviceArray(), ArrowSchema()
+        check(_lib.load().dfgpu_table_export_device(self.handle, C.byref(arr), C.byref(sch)))
+        return arr, sch
+
+    @staticmethod
+    def from_device(arr: ArrowDeviceArray, sch: ArrowSchema) -> "DeviceTable":
+        """dfgpu_table_import_device: zero-copy; consumes both structs"""
+        out = C.c_void_p()
+        check(_lib.init().dfgpu_table_import_device(C.byref(arr), C.byref(sch), C.byref(out)))
+        return DeviceTable(out)
 
     # ------------------------------------------------------------------ inspection
     @property

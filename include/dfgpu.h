@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 9
+#define DFGPU_ABI_VERSION 10
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -71,6 +71,35 @@ struct ArrowArray {
   struct ArrowArray* dictionary;
   void (*release)(struct ArrowArray*);
   void* private_data;
+};
+#endif
+
+/* Arrow C Device Data Interface (https://arrow.apache.org/docs/format/CDeviceDataInterface.html): an ArrowArray whose buffers are
+ * DEVICE pointers, tagged with the device that holds them.  This is how a device table crosses to (or from) another component of the
+ * process WITHOUT touching the host: dfgpu_table_export_device / dfgpu_table_import_device below. */
+#ifndef ARROW_C_DEVICE_DATA_INTERFACE
+#define ARROW_C_DEVICE_DATA_INTERFACE
+typedef int32_t ArrowDeviceType;
+#define ARROW_DEVICE_CPU 1
+#define ARROW_DEVICE_CUDA 2
+#define ARROW_DEVICE_CUDA_HOST 3
+#define ARROW_DEVICE_OPENCL 4
+#define ARROW_DEVICE_VULKAN 7
+#define ARROW_DEVICE_METAL 8
+#define ARROW_DEVICE_VPI 9
+#define ARROW_DEVICE_ROCM 10
+#define ARROW_DEVICE_ROCM_HOST 11
+#define ARROW_DEVICE_EXT_DEV 12
+#define ARROW_DEVICE_CUDA_MANAGED 13
+#define ARROW_DEVICE_ONEAPI 14
+#define ARROW_DEVICE_WEBGPU 15
+#define ARROW_DEVICE_HEXAGON 16
+struct ArrowDeviceArray {
+  struct ArrowArray array;
+  int64_t device_id;
+  ArrowDeviceType device_type;
+  void* sync_event; /* ROCm: hipEvent_t* the consumer waits on before reading, or NULL = the data is ready */
+  int64_t reserved[3];
 };
 #endif
 
@@ -239,6 +268,50 @@ int dfgpu_table_hstack(dfgpu_table_t a, dfgpu_table_t b, dfgpu_table_t* out);
 int dfgpu_table_concat(const dfgpu_table_t* parts, int nparts, dfgpu_table_t* out);
 /* contiguous row range copy (RecordBatch::slice) */
 int dfgpu_table_slice(dfgpu_table_t t, int64_t offset, int64_t length, dfgpu_table_t* out);
+
+/* A second owner of the same device table: *out shares every buffer of `t` (no copy) and is freed on its own with
+ * dfgpu_table_free.  What a plan node keeps when it hands its output to more than one consumer (CollectLeft's build side shared
+ * by all probe partitions, hash_join/exec.rs:772,1503; a cached scan handed to several queries). */
+int dfgpu_table_retain(dfgpu_table_t t, dfgpu_table_t* out);
+
+/* Device-resident hand-off between adjacent GPU nodes (and to / from any other ROCm component of the process) as an
+ * ArrowDeviceArray: the RecordBatch a GPU node's stream yields when its consumer is another GPU node
+ * (physical-plan/src/execution_plan.rs:696-700 `execute` -> SendableRecordBatchStream; the reference's FFI streams carry the same
+ * ArrowArray structs, ffi/src/record_batch_stream.rs:105-114).  No byte crosses PCIe:
+ *   - dfgpu_table_export_device: a struct array whose children point INTO the table's HBM buffers (device_type ARROW_DEVICE_ROCM,
+ *     device_id = the HIP device; validity / Boolean bitmaps as stored; Utf8 columns as LargeUtf8 = the 64-bit offsets as stored;
+ *     dictionary-encoded columns as Arrow dictionaries whose values are uploaded once).  The array holds a reference on the
+ *     buffers: `t` may be freed at once, the memory lives until the consumer calls array.release.  The calling thread's stream is
+ *     drained first, so sync_event is NULL.
+ *   - dfgpu_table_import_device: the inverse.  An array this library exported is recognised by its release callback and comes
+ *     back as the SAME buffers with dictionaries, cached column statistics and names intact; any other producer's array
+ *     (ARROW_DEVICE_ROCM on an initialised device; Int32 / Int64 / UInt8 / UInt32 / UInt64 / Float64 / Date32 / Decimal128 /
+ *     Boolean / LargeUtf8 children with offset 0) is wrapped zero-copy — its release callback runs when the last column that
+ *     refers to it is freed — after the calling thread's stream has been made to wait on sync_event.  Consumes `array` and
+ *     `schema` like dfgpu_table_import. */
+int dfgpu_table_export_device(dfgpu_table_t t, struct ArrowDeviceArray* out_array, struct ArrowSchema* out_schema);
+int dfgpu_table_import_device(struct ArrowDeviceArray* array, struct ArrowSchema* schema, dfgpu_table_t* out);
+
+/* Device-resident scan cache = the HBM twin of the reference keeping hot inputs in memory (MemorySourceConfig over cached
+ * RecordBatches, datasource/src/memory.rs:58; the file-metadata / statistics caches of execution/src/cache): decoded column
+ * chunks / record batches stay in HBM under a caller-chosen key (file identity + row group + column ...), least recently used
+ * entries leave when `budget_bytes` is exceeded.  A hit is a zero-copy view: no host read, no decompression, no PCIe.  One cache may
+ * be used from many threads (the column chunks of a scan are decoded in parallel).  Entries live on the device their table
+ * lives on; the budget is per cache. */
+typedef struct dfgpu_cache_s* dfgpu_cache_t;
+typedef struct dfgpu_cache_stats {
+  int64_t entries, bytes, budget_bytes;
+  int64_t hits, misses, insertions, evictions;
+} dfgpu_cache_stats;
+int dfgpu_cache_create(int64_t budget_bytes, dfgpu_cache_t* out);
+int dfgpu_cache_free(dfgpu_cache_t cache);
+/* *out = a view of the cached table (the caller frees it), or NULL when the key is not cached */
+int dfgpu_cache_get(dfgpu_cache_t cache, const void* key, int64_t key_bytes, dfgpu_table_t* out);
+/* keeps a view of `table` (the caller still owns its handle); a table larger than the whole budget is not kept; an existing key
+ * keeps its first table */
+int dfgpu_cache_put(dfgpu_cache_t cache, const void* key, int64_t key_bytes, dfgpu_table_t table);
+int dfgpu_cache_clear(dfgpu_cache_t cache);
+int dfgpu_cache_get_stats(dfgpu_cache_t cache, dfgpu_cache_stats* out);
 
 /* ------------------------------------------------------------- expressions */
 

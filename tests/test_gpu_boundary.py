@@ -214,3 +214,163 @@ def test_handles_are_usable_concurrently_from_different_threads():
     assert_tables_equal(ht_semi.emit_unmatched("LeftSemi", ["bk", "bv"]).to_arrow(), want)
     ht_semi.free()
     ht.free()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Device-resident hand-off (ABI 10): dfgpu_table_retain, Arrow C Device Data Interface export / import, the scan cache under the C ABI
+
+def _mixed_table(rng, n):
+    return pa.table({"k": pa.array(rng.integers(0, 10**9, n), type=pa.int64()),
+                     "q": pa.array(rng.integers(0, 100, n), type=pa.int32(), mask=rng.random(n) < 0.2),
+                     "b": pa.array(rng.random(n) < 0.5, type=pa.bool_(), mask=rng.random(n) < 0.1),
+                     "d": random_table(rng, n, {"d": (pa.decimal128(15, 2), 0, 10**9)}).column("d"),
+                     "s": dict_col(rng.integers(0, 3, n), ["a", "bb", "ccc"], mask=rng.random(n) < 0.1),
+                     "u": pa.array([None if i % 11 == 0 else "row-%d" % (i % 977) for i in range(n)], type=pa.string())})
+
+
+def test_device_array_round_trip_shares_the_buffers_and_moves_nothing_over_pcie():
+    from datafusion_amd import ops
+    from datafusion_amd.table import ARROW_DEVICE_ROCM, DeviceTable
+    rng = np.random.default_rng(21)
+    t = _mixed_table(rng, 70_001)
+    d = DeviceTable.from_arrow(t)
+    ptrs = [d.column_view(i).data for i in range(d.num_columns)]
+    ops.metrics_reset()
+    arr, sch = d.export_device()
+    assert arr.device_type == ARROW_DEVICE_ROCM and arr.sync_event is None and arr.array.length == t.num_rows and arr.array.n_children == t.num_columns
+    assert sch.children[5].contents.format == b"U" and sch.children[4].contents.dictionary        # strings: LargeUtf8 over the stored 64-bit offsets
+    for i in range(d.num_columns):
+        assert arr.array.children[i].contents.buffers[1 if i != 5 else 2] == ptrs[i]             # pointers INTO the table's HBM
+    d.free()                                                                                       # the array keeps the buffers alive
+    back = DeviceTable.from_device(arr, sch)
+    assert not arr.array.release and not sch.release                                               # consumed
+    assert [back.column_view(i).data for i in range(back.num_columns)] == ptrs                     # the same buffers
+    m = ops.metrics()
+    assert m["h2d_bytes"] == 0 and m["d2h_bytes"] == 0
+    assert_tables_equal(decoded(back.to_arrow()), decoded(t), ordered=True)                        # dictionary + names + NULLs intact
+    twin = back.retain()
+    back.free()
+    assert_tables_equal(decoded(twin.to_arrow()), decoded(t), ordered=True)
+
+
+def test_foreign_device_array_from_torch_tensors_is_wrapped_zero_copy():
+    """a producer that is not this library: torch tensors in HBM described by a hand-made ArrowDeviceArray (Int64, Float64, a validity
+    bitmap, a Boolean column).  The library wraps the pointers, operators run on them, and the producer's release callback runs when
+    the last table that refers to the memory is freed — not before."""
+    import ctypes as C
+
+    import torch
+
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import ARROW_DEVICE_ROCM, ArrowArray, ArrowDeviceArray, ArrowSchema, DeviceTable
+    n = 100_003
+    g = torch.Generator(device="cpu").manual_seed(5)
+    k = torch.randint(0, 1000, (n,), generator=g, dtype=torch.int64)
+    f = torch.rand((n,), generator=g, dtype=torch.float64)
+    valid = torch.rand((n,), generator=g) < 0.8
+    flag = torch.rand((n,), generator=g) < 0.3
+    pack = lambda bits: torch.from_numpy(np.packbits(np.concatenate([bits.numpy(), np.zeros((-n) % 64 + 64, bool)]), bitorder="little").copy())
+    dev = [x.to("cuda:0") for x in (k, f, pack(valid), pack(flag))]
+    torch.cuda.synchronize()
+    released = []
+    RELEASE = C.CFUNCTYPE(None, C.POINTER(ArrowArray))
+
+    @RELEASE
+    def release(a):
+        released.append(1)
+        a.contents.release = None
+    names = [b"k", b"f", b"flag"]
+    fmts = [b"l", b"g", b"b"]
+    bufs = [(C.c_void_p * 2)(None, dev[0].data_ptr()), (C.c_void_p * 2)(dev[2].data_ptr(), dev[1].data_ptr()), (C.c_void_p * 2)(None, dev[3].data_ptr())]
+    kids = [ArrowArray(length=n, null_count=(0, int((~valid).sum()), 0)[i], offset=0, n_buffers=2, n_children=0, buffers=bufs[i]) for i in range(3)]
+    skids = [ArrowSchema(format=fmts[i], name=names[i], flags=2) for i in range(3)]
+    kid_ptrs = (C.POINTER(ArrowArray) * 3)(*[C.pointer(x) for x in kids])
+    skid_ptrs = (C.POINTER(ArrowSchema) * 3)(*[C.pointer(x) for x in skids])
+    root_bufs = (C.c_void_p * 1)(None)
+    arr = ArrowDeviceArray(device_id=0, device_type=ARROW_DEVICE_ROCM, sync_event=None)
+    arr.array = ArrowArray(length=n, null_count=0, offset=0, n_buffers=1, n_children=3, buffers=root_bufs, children=kid_ptrs, release=C.cast(release, C.c_void_p))
+    sch = ArrowSchema(format=b"+s", name=b"", flags=0, n_children=3, children=skid_ptrs)
+    t = DeviceTable.from_device(arr, sch)
+    assert t.column_view(0).data == dev[0].data_ptr() and t.column_view(1).validity == dev[2].data_ptr()      # wrapped, not copied
+    out = ops.filter(t, (col("k") < lit(500, pa.int64())).and_(col("flag")), ["k", "f"]).to_arrow()
+    keep = (k.numpy() < 500) & flag.numpy()
+    assert out.column("k").to_pylist() == k.numpy()[keep].tolist()
+    exp_f = pa.array(f.numpy()[keep], mask=~valid.numpy()[keep])
+    assert out.column("f").combine_chunks().equals(exp_f)
+    agg = ops.aggregate(t, [(col("flag"), "flag")], [("sum", col("f"), "s"), ("count", col("f"), "c")], "Single").to_arrow().to_pylist()
+    for row in agg:
+        sel = (flag.numpy() == row["flag"]) & valid.numpy()
+        assert row["c"] == int(sel.sum()) and abs(row["s"] - float(f.numpy()[sel].sum())) <= 1e-6 * abs(row["s"])
+    view = t.select(["k"])
+    t.free()
+    assert released == []                  # `view` still points into the producer's memory
+    view.free()
+    assert released == [1]
+
+
+def test_device_import_rejects_what_it_cannot_wrap():
+    import ctypes as C
+
+    from datafusion_amd import _lib
+    from datafusion_amd.table import ARROW_DEVICE_ROCM, ArrowArray, ArrowDeviceArray, ArrowSchema, DeviceTable
+    _lib.init()
+    root_bufs = (C.c_void_p * 1)(None)
+    for device_type, device_id, msg in ((1, 0, "not in ROCm device memory"), (ARROW_DEVICE_ROCM, 77, "was not given to dfgpu_init")):
+        arr = ArrowDeviceArray(device_id=device_id, device_type=device_type)
+        arr.array = ArrowArray(length=0, n_buffers=1, buffers=root_bufs)
+        with pytest.raises(_lib.DfgpuError, match=msg):
+            DeviceTable.from_device(arr, ArrowSchema(format=b"+s", name=b""))
+
+
+def test_scan_cache_below_the_c_abi_lru_budget_and_threads():
+    """dfgpu_cache_*: hits are zero-copy views, least recently used entries leave under the byte budget, many threads at once"""
+    import threading
+
+    from datafusion_amd.parquet import ChunkCache
+    from datafusion_amd.table import DeviceTable
+    mk = lambda i, n=10_000: DeviceTable.from_arrow(pa.table({"v": pa.array(np.full(n, i, dtype=np.int64))}))
+    cache = ChunkCache(budget=250_000)                       # three 80 KB tables
+    tables = [mk(i) for i in range(5)]
+    for i in range(3):
+        cache.put(("f", i), tables[i])
+    assert cache.stats()["chunks"] == 3 and cache.stats()["bytes"] == 240_000
+    hit = cache.get(("f", 0))                                # touches entry 0: entry 1 is now the oldest
+    assert hit.column_view(0).data == tables[0].column_view(0).data
+    cache.put(("f", 3), tables[3])
+    assert cache.get(("f", 1)) is None and cache.get(("f", 0)) is not None and cache.get(("f", 3)) is not None
+    st = cache.stats()
+    assert st["chunks"] == 3 and st["evictions"] == 1 and st["hits"] == 3 and st["misses"] == 1
+    cache.put(("f", 0), tables[4])                           # an existing key keeps its first table
+    assert cache.get(("f", 0)).to_arrow().column("v")[0].as_py() == 0
+    big = mk(9, 100_000)
+    cache.put(("big",), big)                                 # larger than the whole budget: not kept
+    assert cache.get(("big",)) is None
+    for t in tables:
+        t.free()                                             # the cache holds its own references
+    assert cache.get(("f", 3)).to_arrow().column("v").to_pylist() == [3] * 10_000
+    shared = ChunkCache(budget=1 << 30)
+    errors = []
+
+    def worker(w):
+        try:
+            for i in range(40):
+                key = ("t", i % 8)
+                got = shared.get(key)
+                if got is None:
+                    t = mk(i % 8, 2_000)
+                    shared.put(key, t)
+                    t.free()
+                else:
+                    assert got.to_arrow().column("v")[0].as_py() == i % 8
+                    got.free()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors and shared.stats()["chunks"] == 8
+    cache.clear()
+    assert cache.stats()["chunks"] == 0 and cache.stats()["bytes"] == 0
