@@ -327,6 +327,13 @@ def jit_stats():
     return n.value, ms.value
 
 
+def jit_cache_stats() -> dict:
+    """the on-disk code-object cache and the per-device module loads of this process (dfgpu_jit_cache_stats)"""
+    h, w, m = C.c_int64(), C.c_int64(), C.c_int64()
+    check(_lib.init().dfgpu_jit_cache_stats(C.byref(h), C.byref(w), C.byref(m)))
+    return dict(disk_hits=h.value, disk_writes=w.value, modules_loaded=m.value)
+
+
 def set_fusion(on: bool):
     """expression fusion (rowprog) on/off, process-wide; off = column-at-a-time evaluation everywhere"""
     check(_lib.init().dfgpu_set_fusion(int(on)))

@@ -572,6 +572,11 @@ int dfgpu_set_fusion(int on);
  * aggregate node is compiled for its expression forest with hiprtc (cached per process by source text); this reports
  * how many distinct nodes were compiled and the total compile time.  DFGPU_JIT=0 keeps the interpreter. */
 int dfgpu_jit_stats(int64_t* compiles, double* compile_ms);
+/* Compiled nodes are kept as code objects on disk ($DFGPU_JIT_CACHE_DIR, else $XDG_CACHE_HOME/dfgpu/jit, else ~/.cache/dfgpu/jit;
+ * DFGPU_JIT_CACHE=0 = off) keyed by target + hiprtc version + source: a plan seen before by ANY process of the machine costs a file
+ * read instead of a 150 ms compile.  Modules are loaded once per (device, source) — a process that drives several GPUs loads the
+ * same code object on each.  Any out pointer may be NULL. */
+int dfgpu_jit_cache_stats(int64_t* disk_hits, int64_t* disk_writes, int64_t* modules_loaded);
 /* next_output_batch_inner (common.rs:247-300): emit all groups */
 int dfgpu_agg_emit(dfgpu_agg_t h, dfgpu_table_t* out);
 int dfgpu_agg_free(dfgpu_agg_t h);

@@ -298,10 +298,11 @@ def test_foreign_device_array_from_torch_tensors_is_wrapped_zero_copy():
     assert out.column("k").to_pylist() == k.numpy()[keep].tolist()
     exp_f = pa.array(f.numpy()[keep], mask=~valid.numpy()[keep])
     assert out.column("f").combine_chunks().equals(exp_f)
-    agg = ops.aggregate(t, [(col("flag"), "flag")], [("sum", col("f"), "s"), ("count", col("f"), "c")], "Single").to_arrow().to_pylist()
-    for row in agg:
-        sel = (flag.numpy() == row["flag"]) & valid.numpy()
-        assert row["c"] == int(sel.sum()) and abs(row["s"] - float(f.numpy()[sel].sum())) <= 1e-6 * abs(row["s"])
+    agg = ops.aggregate(t, [(col("k"), "k")], [("sum", col("f"), "s"), ("count", col("f"), "c")], "Single", predicate=col("flag")).to_arrow()
+    assert agg.num_rows == len(set(k.numpy()[flag.numpy()].tolist()))
+    for row in agg.slice(0, 50).to_pylist():
+        sel = (k.numpy() == row["k"]) & flag.numpy() & valid.numpy()
+        assert row["c"] == int(sel.sum()) and abs((row["s"] or 0.0) - float(f.numpy()[sel].sum())) <= 1e-6 * max(1.0, abs(row["s"] or 0.0))
     view = t.select(["k"])
     t.free()
     assert released == []                  # `view` still points into the producer's memory

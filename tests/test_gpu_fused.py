@@ -333,3 +333,38 @@ def test_runs_node_sum_cells_are_the_decimal_column_and_split_for_the_next_batch
     (got, _), stats = _with_jit_env(lambda: gpu(t, gb, aggs, batches=batches))
     assert "agg_runs_accumulate" in stats
     assert_agg_equal(got, oracle(t, gb, aggs), ordered=batches == 1)
+
+
+def test_specialised_nodes_are_kept_as_code_objects_on_disk(tmp_path):
+    """the second PROCESS that plans the same forest reads the code object instead of compiling it (dfgpu_jit_cache_stats);
+    a truncated cache file is a miss, never a wrong kernel"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import json, sys; sys.path.insert(0, %r)\n"
+        "import pyarrow as pa\n"
+        "from datafusion_amd import ops, queries\n"
+        "from datafusion_amd.expr import col, lit\n"
+        "t = ops.tpch_lineitem(0.01)\n"
+        "out = ops.aggregate(t, queries.Q1_GROUP_BY, queries.q1_aggs_inlined(), 'Single', predicate=col('l_shipdate') <= lit(queries.DATE_Q1, pa.date32())).to_arrow()\n"
+        "print(json.dumps(dict(jit=ops.jit_stats()[0], **ops.jit_cache_stats(), rows=[[str(v) for v in r.values()] for r in out.to_pylist()])))\n" % root)
+    env = dict(os.environ, DFGPU_JIT="1", DFGPU_JIT_MIN_ROWS="0", DFGPU_JIT_STRICT="1", DFGPU_JIT_CACHE_DIR=str(tmp_path / "jit"))
+    env.pop("DFGPU_JIT_CACHE", None)
+    run = lambda e=env: json.loads(subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, check=True, timeout=300).stdout.splitlines()[-1])
+    first = run()
+    assert first["jit"] >= 1 and first["disk_writes"] == first["jit"] and first["disk_hits"] == 0
+    files = sorted(os.listdir(tmp_path / "jit"))
+    assert len(files) == first["jit"] and all(f.endswith(".hsaco") for f in files)
+    second = run()
+    assert second["jit"] == 0 and second["disk_hits"] == first["jit"] and second["modules_loaded"] == first["modules_loaded"]
+    assert second["rows"] == first["rows"]
+    victim = tmp_path / "jit" / files[0]
+    data = victim.read_bytes()
+    victim.write_bytes(data[: len(data) // 2])                   # a torn file
+    third = run()
+    assert third["jit"] == 1 and third["rows"] == first["rows"]
+    off = run(dict(env, DFGPU_JIT_CACHE="0"))
+    assert off["jit"] == first["jit"] and off["disk_hits"] == 0 and off["disk_writes"] == 0
