@@ -214,8 +214,22 @@ __global__ __launch_bounds__(BLOCK) void k_cast_dec_down(const i128* __restrict_
   if (bad) atomicOr(flags, 1u);
 }
 // arrow-cast cast_floating_point_to_decimal128: (v * 10^scale).round() as i128 (f64::round: half away from zero)
-__global__ __launch_bounds__(BLOCK) void k_cast_f64_dec(const double* __restrict__ in, int64_t n, double mul, i128* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (i128)round(in[i] * mul);
+// With safe = false (the CastExpr default) a non-NULL row whose product is not finite or leaves the i128 range is the error "Cannot cast to
+// Decimal128(p, s). Overflowing on v" (flags |= 1), one beyond the declared precision "v is too large to store in a Decimal128 of precision p"
+// (flags |= 2); try_unary visits no NULL row.
+__global__ __launch_bounds__(BLOCK) void k_cast_f64_dec(const double* __restrict__ in, const uint64_t* __restrict__ valid, int64_t n, double mul, i128 limit,
+                                                        i128* __restrict__ out, unsigned* __restrict__ flags) {
+  unsigned bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const double r = round(in[i] * mul);
+    const bool live = !valid || bit_at(valid, i);
+    const bool fits = r >= -0x1p127 && r < 0x1p127;   // false for NaN
+    const i128 d = fits ? (i128)r : (i128)0;
+    if (live && !fits) bad |= 1u;
+    if (live && fits && (d >= limit || d <= -limit)) bad |= 2u;
+    out[i] = d;
+  }
+  if (bad) atomicOr(flags, bad);
 }
 __global__ __launch_bounds__(BLOCK) void k_cast_div(const i128* __restrict__ in, int64_t n, double div, double* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (double)in[i] / div;
@@ -329,7 +343,11 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
     if (to.type == DFGPU_DECIMAL128 && from.type == DFGPU_FLOAT64) {
       double v;
       std::memcpy(&v, &src.lit_lo, 8);
-      return make_scalar(to, (i128)std::round(v * std::pow(10.0, to.scale)), false);
+      const double r = std::round(v * std::pow(10.0, to.scale));
+      DFGPU_CHECK(r >= -0x1p127 && r < 0x1p127, "Arrow error: Cast error: Cannot cast to " + type_name(to) + ". Overflowing on " + std::to_string(v));
+      const i128 d = (i128)r, limit = pow10_i128(to.precision);
+      DFGPU_CHECK(d < limit && d > -limit, "Arrow error: Invalid argument error: a value is too large to store in a " + type_name(to));
+      return make_scalar(to, d, false);
     }
     if (to.type == DFGPU_DECIMAL128) {
       int fs = from.type == DFGPU_DECIMAL128 ? from.scale : 0;
@@ -337,6 +355,8 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
         const i128 x = scalar_i128(src), div = pow10_i128(fs - to.scale), half = div / 2, r = x % div;
         i128 d = x / div;
         if (x >= 0 ? r >= half : -r >= half) d += x >= 0 ? 1 : -1;
+        const i128 limit = pow10_i128(to.precision);   // the same precision check the column path makes (k_cast_dec_down)
+        DFGPU_CHECK(d < limit && d > -limit, "Arrow error: Invalid argument error: a value is too large to store in a " + type_name(to));
         return make_scalar(to, d, false);
       }
       return make_scalar(to, (i128)((u128)scalar_i128(src) * (u128)pow10_i128(to.scale - fs)), false);
@@ -365,7 +385,14 @@ static Datum eval_cast(const dfgpu_expr_node& n, const Datum& src) {
   if (same_field_type(from, to)) return src;
   ProfileScope ps("cast", len * (type_width(from.type) + type_width(to.type)));
   if (to.type == DFGPU_DECIMAL128 && ft == DFGPU_FLOAT64) {
-    k_cast_f64_dec<<<g, BLOCK, 0, st>>>((const double*)src.col.ptr(), len, std::pow(10.0, to.scale), out.col.data->as<i128>());
+    BufPtr flags = make_zero_buf(4);
+    k_cast_f64_dec<<<g, BLOCK, 0, st>>>((const double*)src.col.ptr(), src.col.valid_words(), len, std::pow(10.0, to.scale), pow10_i128(to.precision),
+                                        out.col.data->as<i128>(), flags->as<unsigned>());
+    DFGPU_HIP(hipGetLastError());
+    unsigned hf = 0;
+    d2h(&hf, flags->ptr, 4);
+    DFGPU_CHECK(!(hf & 1u), "Arrow error: Cast error: Cannot cast to " + type_name(to) + ". Overflowing on a value of the Float64 input");
+    DFGPU_CHECK(!(hf & 2u), "Arrow error: Invalid argument error: a value is too large to store in a " + type_name(to));
   } else if (to.type == DFGPU_DECIMAL128 && from.type == DFGPU_DECIMAL128 && to.scale < from.scale) {
     BufPtr flags = make_zero_buf(4);
     k_cast_dec_down<<<g, BLOCK, 0, st>>>((const i128*)src.col.ptr(), src.col.valid_words(), len, pow10_i128(from.scale - to.scale), pow10_i128(to.precision),

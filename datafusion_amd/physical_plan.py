@@ -356,6 +356,8 @@ class HashJoinExec(ExecutionPlan):
             values = ops.column_inlist(build_table, build_key)
             if values is not None:
                 node.dynamic_in_lists[probe_key] = values
+            else:
+                node.dynamic_in_lists.pop(probe_key, None)     # a larger build side this time (Map strategy): a list of an earlier run must not prune
 
     def _probe(self, ht, probe_table, predicate=None):
         bc, pc = self.projection if self.projection else (None, None)

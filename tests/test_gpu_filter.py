@@ -118,3 +118,30 @@ def test_unsupported_type_is_an_error_not_a_fallback():
     from datafusion_amd.table import DeviceTable
     with pytest.raises(DfgpuError, match="unsupported Arrow type"):
         DeviceTable.from_arrow(pa.table({"s": pa.array([[1], [2, 3]], pa.list_(pa.int32()))}))      # (strings are imported since ABI 8: tests/test_gpu_strings.py)
+
+
+def test_float64_to_decimal_cast_values_and_errors():
+    """CastExpr Float64 -> Decimal128 with safe = false (arrow-cast cast_floating_point_to_decimal128): (v * 10^scale).round(), an error —
+    not garbage — for NaN / inf / beyond i128 and for values beyond the declared precision; NULL rows are never looked at.  Values are
+    checked against pyarrow's cast of the same column."""
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(8)
+    v = np.round(rng.uniform(-1e6, 1e6, 50_000), 3)
+    t = pa.table({"f": pa.array(v, mask=rng.random(len(v)) < 0.1)})
+    got = ops.project(DeviceTable.from_arrow(t), [(col("f").cast(pa.decimal128(15, 2)), "d")]).to_arrow()
+    exp = pa.array([None if x is None else round(x * 100) for x in t.column("f").to_pylist()], pa.int64())
+    unscaled = pa.array([None if x is None else int(x.scaleb(2)) for x in got.column("d").to_pylist()], pa.int64())
+    assert unscaled.equals(exp)
+    for bad, msg in ((float("nan"), "Cannot cast to Decimal128"), (float("inf"), "Cannot cast to Decimal128"), (1e40, "Cannot cast to Decimal128"),
+                     (1e14, "too large to store in a Decimal128")):
+        tb = pa.table({"f": pa.array([1.0, bad, 2.0])})
+        with pytest.raises(_lib.DfgpuError, match=msg):
+            ops.project(DeviceTable.from_arrow(tb), [(col("f").cast(pa.decimal128(15, 2)), "d")])
+        with pytest.raises(_lib.DfgpuError, match=msg):                                                      # the literal is folded on the host
+            ops.project(DeviceTable.from_arrow(tb), [(lit(bad, pa.float64()).cast(pa.decimal128(15, 2)), "d")])
+        masked = pa.table({"f": pa.array([1.0, bad, 2.0], mask=np.array([False, True, False]))})             # the offending slot is NULL: no error
+        assert ops.project(DeviceTable.from_arrow(masked), [(col("f").cast(pa.decimal128(15, 2)), "d")]).to_arrow().column("d").null_count == 1
+    with pytest.raises(_lib.DfgpuError, match="too large to store"):                                         # scalar scale-down beyond the precision
+        ops.project(DeviceTable.from_arrow(pa.table({"f": pa.array([1.0])})), [(lit("999.99", pa.decimal128(7, 2)).cast(pa.decimal128(2, 0)), "d")])
