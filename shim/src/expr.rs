@@ -13,8 +13,14 @@ pub struct Lowered {
     pub nodes: Vec<dfgpu_expr_node>,
     pub pool: Vec<u8>,
 }
+impl std::fmt::Debug for Lowered {
+    fn fmt(&self, f: &mut std::fmt::Formatter) -> std::fmt::Result {
+        write!(f, "Lowered({} nodes: {:?})", self.nodes.len(), self.nodes.iter().map(|n| n.op).collect::<Vec<_>>())
+    }
+}
 impl Lowered {
     pub fn as_c(&self) -> dfgpu_expr {
+        // the root is the last node (post-order flattening below); the pool pointer is only read when a node refers into it
         dfgpu_expr { nodes: self.nodes.as_ptr(), n_nodes: self.nodes.len() as i32, root: self.nodes.len() as i32 - 1, string_pool: self.pool.as_ptr() as *const _ }
     }
 }
@@ -43,7 +49,7 @@ fn node(op: dfgpu_expr_op) -> dfgpu_expr_node {
 
 /// post-order flattening; the root is the last node
 pub fn lower(e: &Arc<dyn PhysicalExpr>, schema: &Schema, out: &mut Lowered) -> Option<i32> {
-    let any = e.as_any();
+    let any = e.as_ref(); // `dyn PhysicalExpr`: downcast_ref is the trait object's own helper in 55 (physical_expr.rs:814)
     let mut n;
     if let Some(c) = any.downcast_ref::<Column>() {
         field_of(schema.field(c.index()).data_type())?;
@@ -104,7 +110,7 @@ pub fn lower(e: &Arc<dyn PhysicalExpr>, schema: &Schema, out: &mut Lowered) -> O
         if f.name() == "substr" {
             // substr(string column, Int64 start [, Int64 count]) with literal positions (functions/src/unicode/substr.rs)
             let int = |e: &Arc<dyn PhysicalExpr>| -> Option<i64> {
-                match e.as_any().downcast_ref::<Literal>()?.value() { ScalarValue::Int64(Some(v)) => Some(*v), _ => None }
+                match e.downcast_ref::<Literal>()?.value() { ScalarValue::Int64(Some(v)) => Some(*v), _ => None }
             };
             if f.args().len() < 2 || f.args().len() > 3 { return None; }
             n = node(DFGPU_EXPR_SUBSTR);
@@ -119,7 +125,7 @@ pub fn lower(e: &Arc<dyn PhysicalExpr>, schema: &Schema, out: &mut Lowered) -> O
         }
         // date_part('year' | 'month' | 'day', Date32)
         if f.name() != "date_part" { return None; }
-        let part = f.args()[0].as_any().downcast_ref::<Literal>()?.value().to_string().to_lowercase();
+        let part = f.args()[0].downcast_ref::<Literal>()?.value().to_string().to_lowercase();
         n = node(DFGPU_EXPR_DATE_PART);
         n.column = match part.as_str() { "year" => DFGPU_DATE_PART_YEAR, "month" => DFGPU_DATE_PART_MONTH, "day" => DFGPU_DATE_PART_DAY, _ => return None };
         n.left = lower(&f.args()[1], schema, out)?;

@@ -1,28 +1,32 @@
 //! The single-input GPU nodes: FilterExec (filter.rs:85), ProjectionExec (projection.rs:721-746), AggregateExec
 //! (aggregates/mod.rs:839), SortExec / TopK (sorts/sort.rs:1366) and RepartitionExec with Partitioning::Hash
-//! (repartition/mod.rs:1626) over `libdfgpu.so`.  All of them share one shape — `GpuUnaryExec`: the child's partition is uploaded
-//! batch by batch and concatenated (a launch wants >= 10^6 rows: an 8192-row batch would be launch-bound), ONE call sequence of
-//! the C ABI runs on a blocking thread (HIP waits never block the executor, execution_plan.rs:549-565), the result leaves
-//! `batch_size` rows at a time (LimitedBatchCoalescer, coalesce/mod.rs:27-120).  Dropping the stream frees the device tables
+//! (repartition/mod.rs:1626) over `libdfgpu.so`.  All of them share one shape — `GpuUnaryExec`: the child's partition arrives as
+//! ONE device table (device.rs: handed over by a GPU child, or uploaded batch by batch from a CPU child and concatenated — a launch
+//! wants >= 10^6 rows, an 8192-row batch would be launch-bound), ONE call sequence of the C ABI runs on a blocking thread (HIP waits
+//! never block the executor, execution_plan.rs:549-565), the result stays on the device for a GPU parent or leaves `batch_size`
+//! rows at a time (LimitedBatchCoalescer, coalesce/mod.rs:27-120).  A hash repartition executes every input partition exactly
+//! once and shares the slices between its output partitions (`RepartitionState`).  Dropping the stream frees the device tables
 //! (drop = cancel, execution_plan.rs:539-547).  Python twins, driven by the parity tests through the same entry points:
 //! datafusion_amd/physical_plan.py {FilterExec, ProjectionExec, AggregateExec, GpuFusedAggregateExec, SortExec, RepartitionExec}.
+use crate::device::{device_input, host_stream, DeviceFuture, GpuNode};
 use crate::expr::{field_of, lower, Lowered};
 use crate::table::DeviceTable;
-use crate::{check, sys};
+use crate::{blocking, check, sys};
 use arrow::datatypes::SchemaRef;
+use datafusion::common::tree_node::TreeNodeRecursion;
 use datafusion::error::{DataFusionError, Result};
 use datafusion::execution::{SendableRecordBatchStream, TaskContext};
-use datafusion::physical_expr::expressions::Column;
+use datafusion::physical_expr::expressions::{Column, Literal};
+use datafusion::physical_expr::PhysicalExpr;
 use datafusion::physical_plan::aggregates::{AggregateExec, AggregateMode};
 use datafusion::physical_plan::filter::FilterExec;
 use datafusion::physical_plan::projection::ProjectionExec;
 use datafusion::physical_plan::repartition::RepartitionExec;
 use datafusion::physical_plan::sorts::sort::SortExec;
-use datafusion::physical_plan::stream::RecordBatchStreamAdapter;
-use datafusion::physical_plan::{DisplayAs, DisplayFormatType, ExecutionPlan, Partitioning, PlanProperties};
-use futures::{StreamExt, TryStreamExt};
+use datafusion::physical_plan::{ChildrenPropertiesMode, DisplayAs, DisplayFormatType, ExecutionPlan, Partitioning, PlanProperties, ReplaceChildrenOptions};
+use futures::FutureExt;
 use std::ffi::CString;
-use std::sync::Arc;
+use std::sync::{Arc, Mutex};
 
 /// what one node does with its input table
 #[derive(Debug, Clone)]
@@ -53,7 +57,21 @@ pub struct GpuUnaryExec {
     name: &'static str,
     input: Arc<dyn ExecutionPlan>,
     op: GpuOp,
+    /// HashRepartition only: the slices of ALL input partitions, computed once and shared by the output partitions
+    /// (RepartitionExec's shared state: every input partition is executed exactly once, repartition/mod.rs:154-360)
+    exchange: Arc<RepartitionState>,
     cache: Arc<PlanProperties>, // copied verbatim from the CPU operator this node replaces: same schema, partitioning, ordering
+}
+
+/// output partition p of a hash repartition = slice p of every input partition, concatenated in input-partition order
+#[derive(Default)]
+pub struct RepartitionState {
+    outputs: tokio::sync::OnceCell<Vec<Mutex<Option<DeviceTable>>>>,
+}
+impl std::fmt::Debug for RepartitionState {
+    fn fmt(&self, f: &mut std::fmt::Formatter) -> std::fmt::Result {
+        write!(f, "RepartitionState(computed: {})", self.outputs.initialized())
+    }
 }
 
 fn lowered(e: &Arc<dyn datafusion::physical_expr::PhysicalExpr>, schema: &arrow::datatypes::Schema) -> Option<Arc<Lowered>> {
@@ -75,10 +93,10 @@ impl GpuUnaryExec {
         if !types_ok(&in_schema) {
             return None;
         }
-        let projection = f.projection().cloned().unwrap_or_else(|| (0..in_schema.fields().len()).collect());
+        let projection: Vec<usize> = match f.projection() { Some(p) => p.iter().copied().collect(), None => (0..in_schema.fields().len()).collect() };
         Some(Self { name: "GpuFilterExec", input: Arc::clone(f.input()),
                     op: GpuOp::Filter { predicate: lowered(f.predicate(), &in_schema)?, projection: projection.iter().map(|c| *c as i32).collect() },
-                    cache: Arc::clone(f.properties()) })
+                    exchange: Default::default(), cache: Arc::clone(f.properties()) })
     }
 
     pub fn try_from_projection(p: &ProjectionExec) -> Option<Self> {
@@ -92,7 +110,7 @@ impl GpuUnaryExec {
             exprs.push(lowered(&pe.expr, &in_schema)?);
             names.push(cname(&pe.alias));
         }
-        Some(Self { name: "GpuProjectionExec", input: Arc::clone(p.input()), op: GpuOp::Project { exprs, names }, cache: Arc::clone(p.properties()) })
+        Some(Self { name: "GpuProjectionExec", input: Arc::clone(p.input()), op: GpuOp::Project { exprs, names }, exchange: Default::default(), cache: Arc::clone(p.properties()) })
     }
 
     /// AggregateExec with SUM / AVG / COUNT / MIN / MAX, plain (single) grouping sets and no per-aggregate FILTER / DISTINCT /
@@ -135,16 +153,17 @@ impl GpuUnaryExec {
             if f.is_distinct() || !f.order_bys().is_empty() || f.expressions().len() > 1 {
                 return None;
             }
-            // COUNT(*) arrives as count(Int64(1)): a literal argument counts rows
-            let arg = f.expressions().first().filter(|e| e.as_any().downcast_ref::<datafusion::physical_expr::expressions::Literal>().is_none());
-            let arg = match arg {
+            // COUNT(*) arrives as count(Int64(1)): a (non-NULL) literal argument counts rows
+            let exprs = f.expressions();
+            let arg = match exprs.first() {
+                Some(e) if e.downcast_ref::<Literal>().is_some_and(|l| !l.value().is_null()) && func == sys::DFGPU_AGG_COUNT => None,
                 Some(e) => Some(lowered(e, &in_schema)?),
                 None => None,
             };
             // Final modes cannot derive AVG(Decimal128)'s declared type from its state: AggregateFunctionExpr::return_field carries it
             aggs.push(AggSpec { func, arg, name: cname(f.name()), return_field: field_of(f.field().data_type())? });
         }
-        Some(Self { name: "GpuAggregateExec", input, op: GpuOp::Aggregate { mode, group_by, group_names, aggs, predicate }, cache: Arc::clone(a.properties()) })
+        Some(Self { name: "GpuAggregateExec", input, op: GpuOp::Aggregate { mode, group_by, group_names, aggs, predicate }, exchange: Default::default(), cache: Arc::clone(a.properties()) })
     }
 
     /// SortExec over column keys (expressions are projected below it by the planner); preserve_partitioning = true sorts every
@@ -155,23 +174,23 @@ impl GpuUnaryExec {
         }
         let (mut keys, mut descending, mut nulls_first) = (vec![], vec![], vec![]);
         for e in s.expr().iter() {
-            keys.push(e.expr.as_any().downcast_ref::<Column>()?.index() as i32);
+            keys.push(e.expr.downcast_ref::<Column>()?.index() as i32);
             descending.push(e.options.descending as u8);
             nulls_first.push(e.options.nulls_first as u8);
         }
         Some(Self { name: "GpuSortExec", input: Arc::clone(s.input()), op: GpuOp::Sort { keys, descending, nulls_first, fetch: s.fetch().map_or(-1, |f| f as i64) },
-                    cache: Arc::clone(s.properties()) })
+                    exchange: Default::default(), cache: Arc::clone(s.properties()) })
     }
 
     /// RepartitionExec(Hash(columns, n)) inside ONE process (several processes = dfgpu_exchange_hash over RCCL, driven by the
     /// distributed runtime that owns the ranks).  RoundRobin / UnknownPartitioning stay on the CPU: they only regroup batches.
     pub fn try_from_repartition(r: &RepartitionExec) -> Option<Self> {
         let Partitioning::Hash(exprs, n) = r.partitioning() else { return None };
-        if !types_ok(&r.input().schema()) || *n > 64 {
-            return None;
+        if !types_ok(&r.input().schema()) || *n > 64 || r.preserve_order() {
+            return None; // a sort-preserving repartition merges sorted streams: it stays the CPU operator
         }
-        let keys = exprs.iter().map(|e| e.as_any().downcast_ref::<Column>().map(|c| c.index() as i32)).collect::<Option<Vec<_>>>()?;
-        Some(Self { name: "GpuRepartitionExec", input: Arc::clone(r.input()), op: GpuOp::HashRepartition { keys, n: *n as i32 }, cache: Arc::clone(r.properties()) })
+        let keys = exprs.iter().map(|e| e.downcast_ref::<Column>().map(|c| c.index() as i32)).collect::<Option<Vec<_>>>()?;
+        Some(Self { name: "GpuRepartitionExec", input: Arc::clone(r.input()), op: GpuOp::HashRepartition { keys, n: *n as i32 }, exchange: Default::default(), cache: Arc::clone(r.properties()) })
     }
 
     pub fn op(&self) -> &GpuOp {
@@ -180,7 +199,7 @@ impl GpuUnaryExec {
 }
 
 /// the call sequence of one node over one device table
-fn run(op: &GpuOp, input: &DeviceTable, out_partition: usize) -> Result<DeviceTable> {
+fn run(op: &GpuOp, input: &DeviceTable) -> Result<DeviceTable> {
     let mut out = std::ptr::null_mut();
     match op {
         GpuOp::Filter { predicate, projection } => {
@@ -211,20 +230,18 @@ fn run(op: &GpuOp, input: &DeviceTable, out_partition: usize) -> Result<DeviceTa
         GpuOp::Sort { keys, descending, nulls_first, fetch } => {
             check(unsafe { sys::dfgpu_sort(input.0, keys.as_ptr(), descending.as_ptr(), nulls_first.as_ptr(), keys.len() as i32, *fetch, &mut out) })?;
         }
-        GpuOp::HashRepartition { keys, n } => {
-            let mut parts = vec![std::ptr::null_mut(); *n as usize];
-            check(unsafe { sys::dfgpu_partition(input.0, keys.as_ptr(), keys.len() as i32, *n, parts.as_mut_ptr()) })?;
-            let mut kept = None;
-            for (p, h) in parts.into_iter().enumerate() {
-                let t = DeviceTable(h); // every slice is owned: the ones this output partition does not take are freed here
-                if p == out_partition {
-                    kept = Some(t);
-                }
-            }
-            return kept.ok_or_else(|| DataFusionError::Internal("output partition out of range".into()));
+        GpuOp::HashRepartition { .. } => {
+            return Err(DataFusionError::Internal("a hash repartition runs through RepartitionState, not through run()".into()));
         }
     }
     Ok(DeviceTable(out))
+}
+
+/// dfgpu_partition of one input partition: `n` owned slices (partition = hash(keys; seed 0) % n, row order kept inside each)
+fn partition_slices(input: &DeviceTable, keys: &[i32], n: i32) -> Result<Vec<DeviceTable>> {
+    let mut parts = vec![std::ptr::null_mut(); n as usize];
+    check(unsafe { sys::dfgpu_partition(input.0, keys.as_ptr(), keys.len() as i32, n, parts.as_mut_ptr()) })?;
+    Ok(parts.into_iter().map(DeviceTable).collect())
 }
 
 impl DisplayAs for GpuUnaryExec {
@@ -238,41 +255,69 @@ impl DisplayAs for GpuUnaryExec {
     }
 }
 
+impl GpuNode for GpuUnaryExec {
+    fn execute_device(&self, partition: usize, ctx: Arc<TaskContext>) -> Result<DeviceFuture> {
+        if let GpuOp::HashRepartition { keys, n } = &self.op {
+            // every input partition is executed ONCE, by whichever output partition is polled first; the others wait on the cell
+            let n_inputs = self.input.output_partitioning().partition_count();
+            let inputs = (0..n_inputs).map(|p| device_input(&self.input, p, Arc::clone(&ctx))).collect::<Result<Vec<_>>>()?;
+            let (state, keys, n) = (Arc::clone(&self.exchange), keys.clone(), *n);
+            return Ok(async move {
+                let outputs = state.outputs.get_or_try_init(|| async move {
+                    let tables = futures::future::try_join_all(inputs).await?; // the input partitions run concurrently, each on its own stream
+                    blocking(move || {
+                        let mut per_output: Vec<Vec<DeviceTable>> = (0..n).map(|_| vec![]).collect();
+                        for t in &tables {
+                            for (p, slice) in partition_slices(t, &keys, n)?.into_iter().enumerate() {
+                                per_output[p].push(slice);
+                            }
+                        }
+                        per_output.into_iter().map(|slices| Ok(Mutex::new(Some(if slices.len() == 1 { slices.into_iter().next().unwrap() } else { DeviceTable::concat(&slices)? }))))
+                            .collect::<Result<Vec<_>>>()
+                    }).await
+                }).await?;
+                outputs.get(partition).and_then(|m| m.lock().unwrap().take())
+                    .ok_or_else(|| DataFusionError::Internal(format!("GpuRepartitionExec: output partition {partition} out of range or executed twice")))
+            }
+            .boxed());
+        }
+        let input = device_input(&self.input, partition, ctx)?; // a GPU child hands its device table over: no PCIe in between
+        let op = self.op.clone();
+        Ok(async move {
+            let input = input.await?;
+            blocking(move || run(&op, &input)).await
+        }
+        .boxed())
+    }
+}
+
 impl ExecutionPlan for GpuUnaryExec {
     fn name(&self) -> &str { self.name }
-    fn as_any(&self) -> &dyn std::any::Any { self }
     fn properties(&self) -> &Arc<PlanProperties> { &self.cache }
     fn children(&self) -> Vec<&Arc<dyn ExecutionPlan>> { vec![&self.input] }
-    fn with_new_children(self: Arc<Self>, c: Vec<Arc<dyn ExecutionPlan>>) -> Result<Arc<dyn ExecutionPlan>> {
-        Ok(Arc::new(Self { name: self.name, input: Arc::clone(&c[0]), op: self.op.clone(), cache: Arc::clone(&self.cache) }))
+    fn apply_expressions(&self, _f: &mut dyn FnMut(&Arc<dyn PhysicalExpr>) -> Result<TreeNodeRecursion>) -> Result<TreeNodeRecursion> {
+        Ok(TreeNodeRecursion::Continue) // every expression was lowered to the flat IR at plan time: no PhysicalExpr is evaluated here
     }
-
+    fn maintains_input_order(&self) -> Vec<bool> {
+        vec![matches!(self.op, GpuOp::Filter { .. } | GpuOp::Project { .. })] // FilterExec / ProjectionExec keep their input's order
+    }
+    fn replace_children(self: Arc<Self>, c: Vec<Arc<dyn ExecutionPlan>>, _options: ReplaceChildrenOptions) -> Result<Arc<dyn ExecutionPlan>> {
+        if c.len() != 1 {
+            return Err(DataFusionError::Internal(format!("{} takes one child", self.name)));
+        }
+        Ok(Arc::new(Self { name: self.name, input: Arc::clone(&c[0]), op: self.op.clone(), exchange: Default::default(), cache: Arc::clone(&self.cache) }))
+    }
+    #[allow(deprecated)]
+    fn with_new_children(self: Arc<Self>, c: Vec<Arc<dyn ExecutionPlan>>) -> Result<Arc<dyn ExecutionPlan>> {
+        self.replace_children(c, ReplaceChildrenOptions::new(ChildrenPropertiesMode::Recompute))
+    }
+    fn reset_state(self: Arc<Self>) -> Result<Arc<dyn ExecutionPlan>> {
+        let children = vec![Arc::clone(&self.input)];
+        self.replace_children(children, ReplaceChildrenOptions::new(ChildrenPropertiesMode::Keep))
+    }
     fn execute(&self, partition: usize, ctx: Arc<TaskContext>) -> Result<SendableRecordBatchStream> {
-        // which input partitions feed this output partition: all of them for a repartition (and for Final over a coalesced
-        // input the planner already put a CoalescePartitionsExec below), the same-numbered one otherwise
-        let inputs: Vec<usize> = match &self.op {
-            GpuOp::HashRepartition { .. } => (0..self.input.output_partitioning().partition_count()).collect(),
-            _ => vec![partition],
-        };
-        let mut streams = inputs.iter().map(|p| self.input.execute(*p, Arc::clone(&ctx))).collect::<Result<Vec<_>>>()?; // lazy (execution_plan.rs:514-516)
-        let op = self.op.clone();
+        let batch_size = ctx.session_config().batch_size();
         let schema: SchemaRef = self.schema();
-        let out_schema = Arc::clone(&schema);
-        let batch_size = ctx.session_config().batch_size() as i64;
-        let fut = async move {
-            let mut parts = vec![];
-            for s in streams.iter_mut() {
-                while let Some(batch) = s.next().await {
-                    parts.push(DeviceTable::from_batch(&batch?)?);
-                }
-            }
-            let input = DeviceTable::concat(&parts)?;
-            drop(parts);
-            let out = tokio::task::spawn_blocking(move || run(&op, &input, partition)).await.map_err(|e| DataFusionError::External(Box::new(e)))??;
-            let n = out.num_rows()?;
-            let batches: Vec<_> = (0..n).step_by(batch_size as usize).map(|off| out.export_batch(off, batch_size.min(n - off), &out_schema)).collect();
-            Ok::<_, DataFusionError>(futures::stream::iter(batches))
-        };
-        Ok(Box::pin(RecordBatchStreamAdapter::new(schema, futures::stream::once(fut).try_flatten())))
+        Ok(host_stream(schema, self.execute_device(partition, ctx)?, batch_size))
     }
 }

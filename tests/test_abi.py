@@ -211,3 +211,52 @@ def test_rust_shim_sys_rs_matches_the_header():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_shim_sys.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def _shim(name):
+    return open(os.path.join(ROOT, "shim", "src", name)).read()
+
+
+def test_rust_shim_binds_only_declared_entry_points_and_the_join_sequence_the_c_driver_runs():
+    """No rustc in this image, so the shim is kept right by inspection: every `sys::dfgpu_*` it calls exists in the generated binding
+    (= in the header), `hash_join.rs` performs the sequence tests/c/plan_driver.c executes on the GPU (builder push -> finish once ->
+    probe / probe_with_filter per partition -> emit_unmatched once), and the round-2 review's defects stay fixed."""
+    sys_rs = _shim("sys.rs")
+    declared = set(re.findall(r"pub fn (dfgpu_\w+)\(", sys_rs))
+    used = {}
+    for f in ("lib.rs", "table.rs", "device.rs", "expr.rs", "hash_join.rs", "operators.rs", "rule.rs", "ffi.rs"):
+        used[f] = set(re.findall(r"sys::(dfgpu_[a-z0-9_]+)\(", _shim(f)))
+        assert used[f] <= declared, (f, used[f] - declared)
+    hj = _shim("hash_join.rs")
+    assert {"dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_probe",
+            "dfgpu_join_probe_with_filter", "dfgpu_join_emit_unmatched", "dfgpu_join_free", "dfgpu_column_minmax"} <= used["hash_join.rs"]
+    driver = open(os.path.join(ROOT, "tests", "c", "plan_driver.c")).read()
+    for fn in ("dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_probe_with_filter", "dfgpu_join_emit_unmatched", "dfgpu_table_export_batch",
+               "dfgpu_table_export_device", "dfgpu_table_import_device"):
+        assert fn + "(" in driver, fn
+    # the defects of the round-2 review (VERDICT weak 2 / ADVICE high) by their fingerprints
+    assert "null_aware: self.null_aware as i32" in hj and "null_aware: 0" not in hj
+    assert "OnceCell" in hj and "remaining.fetch_sub" in hj                       # ONE shared build, the last partition emits
+    assert "build_join_schema" in hj and "reorder" in hj                           # per-join-type column mapping, interleaved projections
+    assert ".expect(\"the rule admits column keys only\")" not in hj             # expression keys decline instead of panicking
+    ops_rs = _shim("operators.rs")
+    assert "RepartitionState" in ops_rs and "get_or_try_init" in ops_rs            # every input partition executed once
+    rule = _shim("rule.rs")
+    assert "all_hash_repartitions_offloadable" in rule and "!needs_order" in rule  # co-partitioning stays consistent; order_insensitive from the ancestors
+    for f in ("hash_join.rs", "operators.rs", "rule.rs", "expr.rs"):
+        assert ".as_any()" not in _shim(f), f                                      # DataFusion 55: `dyn ExecutionPlan` / `dyn PhysicalExpr` downcast_ref
+    ffi = _shim("ffi.rs")
+    assert "FFI_PhysicalOptimizerRule::new(" in ffi and "FFI_QueryPlanner::new_with_ffi_codecs(" in ffi and "datafusion_gpu_amd_get_module" in ffi
+
+
+def test_rust_shim_targets_the_reference_workspace_versions():
+    """shim/Cargo.toml pins the datafusion / arrow versions of the reference workspace (skipped on the GPU box, where /root/reference does not exist)"""
+    ref = "/root/reference/Cargo.toml"
+    if not os.path.exists(ref):
+        pytest.skip("no reference checkout here")
+    text = open(ref).read()
+    df = re.search(r'^version = "([0-9.]+)"', text[text.index("[workspace.package]"):], flags=re.M).group(1)
+    arrow = re.search(r'^arrow = \{ version = "([0-9.]+)"', text, flags=re.M).group(1)
+    cargo = open(os.path.join(ROOT, "shim", "Cargo.toml")).read()
+    assert f'datafusion = "{df}"' in cargo and f'datafusion-ffi = "{df}"' in cargo, df
+    assert f'arrow = {{ version = "{arrow}"' in cargo, arrow
