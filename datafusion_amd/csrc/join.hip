@@ -54,6 +54,10 @@ struct JoinTable {
   uint64_t hash_mask = 0;
   BufPtr rank_bits, rank_prefix, rank_perm;  // rank map: u64 bitmap, u64 exclusive popcount prefix per word, optional u32 perm
   BufPtr rank_tab;  // the probe's view of the rank map: {bitmap word, prefix} interleaved, ONE 16-byte load per lookup
+  // build keys not in ascending row order: rank != row id, a probe that needs BUILD ROWS (payload columns, visited marks, pairs)
+  // goes through the rank -> row permutation — built on the first such probe (ensure_rank_perm), because a probe that only asks
+  // "is the key there" (no build column in the output: SELECT l.k ... JOIN, semi / anti joins) never touches it
+  bool rank_needs_perm = false;
   std::shared_ptr<RadixTable> radix;  // KIND_RADIX: build records partitioned for the LDS join (radix_join.hip)
   BufPtr visited;  // u8 per build row, lazily allocated
   std::mutex mu;   // a join table is probed by several threads at once (CollectLeft): `visited` is made once, `info` counts under it
@@ -252,16 +256,15 @@ __global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uin
 __global__ __launch_bounds__(BLOCK) void k_rank_interleave(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ prefix, int64_t n_words, ulonglong2* __restrict__ tab) {
   for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * BLOCK) tab[w] = make_ulonglong2(bits[w], prefix[w]);
 }
-// rank map build, step 2 (keys not in ascending row order): perm[rank(key_i)] = i
-__global__ __launch_bounds__(BLOCK) void k_rank_perm(KeyCol k, int64_t n, uint64_t offset, const uint64_t* __restrict__ bits,
-                                                     const uint64_t* __restrict__ prefix, uint32_t* __restrict__ perm) {
+// rank map build, step 2 (keys not in ascending row order): perm[rank(key_i)] = i, read off the interleaved table
+__global__ __launch_bounds__(BLOCK) void k_rank_perm_tab(KeyCol k, int64_t n, uint64_t offset, const ulonglong2* __restrict__ tab, uint32_t* __restrict__ perm) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     if (k.valid && !bit_at(k.valid, i)) continue;
     uint64_t lo, hi;
     load_words(k, i, lo, hi);
     const uint64_t idx = lo - offset;
-    const uint64_t w = bits[idx >> 6];
-    perm[(uint32_t)prefix[idx >> 6] + (uint32_t)__popcll(w & ((1ull << (idx & 63)) - 1ull))] = (uint32_t)i;
+    const ulonglong2 e = tab[idx >> 6];
+    perm[(uint32_t)e.y + (uint32_t)__popcll(e.x & ((1ull << (idx & 63)) - 1ull))] = (uint32_t)i;
   }
 }
 
@@ -1068,7 +1071,28 @@ static void with_kind_and_key(int kind, int probe_key_type, F&& f) {
   });
 }
 
-static ProbeCtx make_ctx(const JoinTable& jt, const Table& probe, const std::vector<int>& pk) {
+// rank map over keys that are not in ascending row order: the rank -> row permutation, made once, by the first probe that needs
+// build rows (several probe partitions may arrive together: CollectLeft)
+static void ensure_rank_perm(JoinTable& jt) {
+  if (jt.kind != KIND_RANK || !jt.rank_needs_perm) return;
+  std::lock_guard<std::mutex> lk(jt.mu);
+  if (jt.rank_perm) return;
+  Runtime& r = rt();
+  const int64_t nb = jt.build.nrows;
+  const KeySet ks = make_keyset(jt.build, jt.key_cols);
+  BufPtr perm = make_buf((size_t)std::max<int64_t>(nb, 1) * 4);
+  {
+    ProfileScope ps("join_build_rank_perm", nb * (ks.c[0].width + 4));
+    k_rank_perm_tab<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, jt.am_offset, jt.rank_tab->as<ulonglong2>(), perm->as<uint32_t>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // complete before another thread's stream reads it
+  jt.rank_perm = perm;
+  jt.info.table_bytes += nb * 4;
+}
+
+static ProbeCtx make_ctx(JoinTable& jt, const Table& probe, const std::vector<int>& pk, bool need_build_rows = true) {
+  if (need_build_rows) ensure_rank_perm(jt);
   ProbeCtx c{};
   c.bkeys = make_keyset(jt.build, jt.key_cols);
   c.pkeys = make_keyset(probe, pk);
@@ -1080,7 +1104,7 @@ static ProbeCtx make_ctx(const JoinTable& jt, const Table& probe, const std::vec
   c.heads = jt.heads ? jt.heads->as<uint32_t>() : nullptr;
   c.next = jt.next ? jt.next->as<uint32_t>() : nullptr;
   c.rank_tab = jt.rank_tab ? jt.rank_tab->as<ulonglong2>() : nullptr;
-  c.rank_perm = jt.rank_perm ? jt.rank_perm->as<uint32_t>() : nullptr;
+  c.rank_perm = need_build_rows && jt.rank_perm ? jt.rank_perm->as<uint32_t>() : nullptr;
   c.am_offset = jt.am_offset;
   c.am_size = jt.am_size;
   c.hash_mask = jt.hash_mask;
@@ -1198,8 +1222,12 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
   // probe row, and once bitmap + directory + permutation outgrow the 256 MiB Infinity Cache every one of them is a 128-byte
   // line of HBM.  ArrayMap answers with ONE access then (measured, SF100 sizes, shuffled unique keys: 22.5 ms vs 37.5 ms,
   // profiles/r2_join_shapes_v2.md), so `auto` prefers it when the reference's own gating admits it.
+  // (round 3: the permutation is built lazily, so the choice no longer has to be made blind — a key-only probe of the rank map
+  // needs neither it nor ArrayMap's 4 bytes per VALUE of the range: 150 M shuffled keys x 600 M probes, key-only: 23.7 ms -> see
+  // profiles/r3_join_shapes.md; probes that do gather build rows pay rank -> perm -> row, within 10 % of ArrayMap's two accesses.)
   constexpr int64_t MALL_BYTES = (int64_t)256 << 20;
-  if (opts.table_mode == 0 && rank_ok && am_ok && !ascending && (int64_t)((range >> 6) + 1) * 16 + nb * 4 > MALL_BYTES) rank_ok = false;
+  static const bool eager_array_map = std::getenv("DFGPU_JOIN_SHUFFLED_ARRAY_MAP") && std::getenv("DFGPU_JOIN_SHUFFLED_ARRAY_MAP")[0] == '1';  // A/B knob: round 2's choice
+  if (eager_array_map && opts.table_mode == 0 && rank_ok && am_ok && !ascending && (int64_t)((range >> 6) + 1) * 16 + nb * 4 > MALL_BYTES) rank_ok = false;
 
   BufPtr flag = make_zero_buf(4);
   int dup = 0;
@@ -1225,17 +1253,12 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       jt->am_size = range + 1;
       jt->rank_prefix = make_buf((size_t)(n_words + 1) * 8);
       scan_mask_popcounts(jt->rank_bits->as<uint64_t>(), nullptr, n_words * 64, jt->rank_prefix->as<uint64_t>());
-      if (!ascending) {
-        jt->rank_perm = make_buf((size_t)nb * 4);
-        ProfileScope ps("join_build_rank_perm", nb * (ks.c[0].width + 4));
-        k_rank_perm<<<grid_for(nb, BLOCK), BLOCK, 0, r.stream>>>(ks.c[0], nb, (uint64_t)kmin, jt->rank_bits->as<uint64_t>(), jt->rank_prefix->as<uint64_t>(),
-                                                                  jt->rank_perm->as<uint32_t>());
-      }
+      jt->rank_needs_perm = !ascending;  // the permutation itself waits for a probe that needs build rows (ensure_rank_perm)
       jt->rank_tab = make_buf((size_t)n_words * 16);
       k_rank_interleave<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(jt->rank_bits->as<uint64_t>(), jt->rank_prefix->as<uint64_t>(), n_words, jt->rank_tab->as<ulonglong2>());
       jt->rank_bits.reset();    // enqueued work holds them until it ran (stream-ordered pool)
       jt->rank_prefix.reset();
-      jt->info.table_bytes = n_words * 16 + (ascending ? 0 : nb * 4);
+      jt->info.table_bytes = n_words * 16;
     } else {
       DFGPU_CHECK(opts.table_mode != 3, "rank-map join table requested but the build keys are not unique");
       jt->rank_bits.reset();
@@ -1426,7 +1449,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   }
   const int64_t np = probe.nrows;
   const int64_t n_words = (np + 63) / 64;
-  ProbeCtx ctx = make_ctx(jt, probe, pk);
+  ProbeCtx ctx = make_ctx(jt, probe, pk, /*need_build_rows=*/false);  // decided below, once the probe flavour is known
   for (int c : bout) DFGPU_CHECK(c >= 0 && c < (int)jt.build.cols.size(), "build output column out of range");
   for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
   uint8_t* visited = nullptr;
@@ -1472,6 +1495,14 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   // 4 = a planner's hint "no ancestor needs the probe order": single pass unordered when applicable, the general path otherwise
   const bool want_single = jt.probe_mode == 2 || jt.probe_mode == 3 || jt.probe_mode == 4;
   const bool use_fused = fused_ok && np > 0;
+  // A probe whose output holds no build column and that marks no build row only asks whether the key is THERE: over a rank map of
+  // keys in no particular order it needs the bitmap alone, not the rank -> row permutation (which is built by the first probe
+  // that does need rows)
+  const bool rows_unused = bout.empty() && !needs_visited(join_type) && (use_fused || probe_side_only);
+  if (!rows_unused && jt.kind == KIND_RANK && jt.rank_needs_perm) {
+    ensure_rank_perm(jt);
+    ctx.rank_perm = jt.rank_perm->as<uint32_t>();
+  }
   DFGPU_CHECK(!((jt.probe_mode == 2 || jt.probe_mode == 3) && !fused_ok),
               "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
   int fused_mode = !want_single ? FUSED_PLACED : jt.probe_mode == 2 ? FUSED_LOOKBACK : FUSED_UNORDERED;

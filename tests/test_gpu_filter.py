@@ -131,7 +131,9 @@ def test_float64_to_decimal_cast_values_and_errors():
     v = np.round(rng.uniform(-1e6, 1e6, 50_000), 3)
     t = pa.table({"f": pa.array(v, mask=rng.random(len(v)) < 0.1)})
     got = ops.project(DeviceTable.from_arrow(t), [(col("f").cast(pa.decimal128(15, 2)), "d")]).to_arrow()
-    exp = pa.array([None if x is None else round(x * 100) for x in t.column("f").to_pylist()], pa.int64())
+    import decimal
+    half_away = lambda y: int(decimal.Decimal(y).quantize(decimal.Decimal(1), rounding=decimal.ROUND_HALF_UP))    # f64::round on the exact value of the double
+    exp = pa.array([None if x is None else half_away(x * 100.0) for x in t.column("f").to_pylist()], pa.int64())
     unscaled = pa.array([None if x is None else int(x.scaleb(2)) for x in got.column("d").to_pylist()], pa.int64())
     assert unscaled.equals(exp)
     for bad, msg in ((float("nan"), "Cannot cast to Decimal128"), (float("inf"), "Cannot cast to Decimal128"), (1e40, "Cannot cast to Decimal128"),

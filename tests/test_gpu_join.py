@@ -406,3 +406,53 @@ def test_selective_probe_clustered_hits_nullable_keys_and_masks(table_mode, key_
             if expect_listed is True:
                 assert "join_probe_listed" in names, (join_type, names)
             ht.free()
+
+
+def test_rank_map_over_unordered_keys_builds_its_permutation_on_the_first_probe_that_needs_build_rows():
+    """build keys in no particular order: a probe that only asks whether the key is there (SELECT l.k, RightSemi / RightAnti)
+    runs on the bitmap alone; the rank -> row permutation appears with the first probe that gathers build columns or marks
+    build rows — also when several probe partitions arrive at once"""
+    import threading
+
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(12)
+    nb, npr = 200_000, 1_000_003
+    keys = rng.permutation(nb).astype(np.int64) * 4 + 1                      # unique, shuffled, density 1/4
+    build = pa.table({"k": pa.array(keys), "pay": pa.array(rng.integers(0, 10**6, nb), type=pa.int32())})
+    pk = rng.integers(0, nb * 5, npr).astype(np.int64)                       # ~ 1/5 of the probe keys exist
+    probe = pa.table({"k2": pa.array(pk), "v": pa.array(rng.integers(0, 100, npr), type=pa.int64())})
+    b, p = DeviceTable.from_arrow(build), DeviceTable.from_arrow(probe)
+    ht = ops.JoinHashTable(b, ["k"], probe_mode=4)
+    i0 = ht.info()
+    assert (i0.table_kind, i0.build_keys_ascending, i0.build_keys_unique) == (2, 0, 1)
+    bitmap_only = i0.table_bytes
+    for jt in ("Inner", "RightSemi", "RightAnti"):
+        got = ht.probe(p, ["k2"], jt, [], ["k2", "v"]).to_arrow()
+        exp = oracle.hash_join(build, probe, [("k", "k2")], jt).select(["k2", "v"])
+        assert sorted_rows(got) == sorted_rows(exp), jt
+    assert ht.info().table_bytes == bitmap_only                              # no permutation was needed
+    results, errors = {}, []
+
+    def worker(w, jt):
+        try:
+            results[w] = ht.probe(p, ["k2"], jt, ["pay"] if jt != "LeftSemi" else ["k", "pay"], ["k2"] if jt != "LeftSemi" else []).to_arrow()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=worker, args=(w, "Inner")) for w in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    assert ht.info().table_bytes == bitmap_only + nb * 4                     # built once
+    exp = oracle.hash_join(build, probe, [("k", "k2")], "Inner").select(["pay", "k2"])
+    for w in range(4):
+        assert sorted_rows(results[w]) == sorted_rows(exp)
+    ht.free()
+    ht2 = ops.JoinHashTable(b, ["k"])
+    ht2.probe(p, ["k2"], "LeftSemi", ["k", "pay"], [])
+    got = ht2.emit_unmatched("LeftSemi", ["k", "pay"]).to_arrow()            # visited marks are per build ROW: the permutation is there
+    assert sorted_rows(got) == sorted_rows(oracle.hash_join(build, probe, [("k", "k2")], "LeftSemi"))
+    ht2.free()
