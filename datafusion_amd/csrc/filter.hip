@@ -18,6 +18,7 @@
 
 #include "device.hpp"
 #include "internal.hpp"
+#include "records.hpp"
 
 namespace dfgpu {
 
@@ -272,80 +273,74 @@ Column gather_column(const Column& in, const int64_t* idx, int64_t n, bool idx_m
 // packed into row-major records with one streaming pass (16 / 32 / 48 / 64 bytes per row), then ONE line per row is touched
 // and the record is split into the output columns — arrow `take` over a whole batch (joins/utils.rs:1332-1386, sorts/sort.rs:
 // 894-914 take_arrays), laid out for HBM.
-constexpr int PACK_MAX_COLS = 8;
-struct PackLayout {
-  const void* src[PACK_MAX_COLS];
-  void* dst[PACK_MAX_COLS];
-  int width[PACK_MAX_COLS];
-  int offset[PACK_MAX_COLS];
-  int n;
-};
-// a record lives in R / 8 registers; fields are placed / extracted with constant-index selects (a runtime-indexed array would
-// live in scratch memory), the record itself moves as whole 16-byte loads / stores
-template <int NS>
-__device__ __forceinline__ uint64_t slot_get(const uint64_t (&s)[NS], int k) {
-  uint64_t v = 0;
-#pragma unroll
-  for (int q = 0; q < NS; q++) v = k == q ? s[q] : v;
-  return v;
-}
-template <int NS>
-__device__ __forceinline__ void slot_or(uint64_t (&s)[NS], int k, uint64_t v) {
-#pragma unroll
-  for (int q = 0; q < NS; q++) s[q] |= k == q ? v : 0ull;
-}
 template <int R>
 __global__ __launch_bounds__(BLOCK) void k_pack_rows(PackLayout L, int64_t n, uint8_t* __restrict__ rec) {
   constexpr int NS = R / 8;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     uint64_t s[NS];
-#pragma unroll
-    for (int q = 0; q < NS; q++) s[q] = 0;
-    for (int c = 0; c < L.n; c++) {
-      const int o = L.offset[c];
-      switch (L.width[c]) {
-        case 16: {
-          const uint4 v = reinterpret_cast<const uint4*>(L.src[c])[i];
-          slot_or<NS>(s, o >> 3, ((uint64_t)v.y << 32) | v.x);
-          slot_or<NS>(s, (o >> 3) + 1, ((uint64_t)v.w << 32) | v.z);
-          break;
-        }
-        case 8: slot_or<NS>(s, o >> 3, reinterpret_cast<const uint64_t*>(L.src[c])[i]); break;
-        case 4: slot_or<NS>(s, o >> 3, (uint64_t)reinterpret_cast<const uint32_t*>(L.src[c])[i] << ((o & 4) * 8)); break;
-        default: slot_or<NS>(s, o >> 3, (uint64_t)reinterpret_cast<const uint8_t*>(L.src[c])[i] << ((o & 7) * 8)); break;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NS / 2; q++)
-      reinterpret_cast<uint4*>(rec + i * R)[q] = uint4{(unsigned)s[2 * q], (unsigned)(s[2 * q] >> 32), (unsigned)s[2 * q + 1], (unsigned)(s[2 * q + 1] >> 32)};
+    record_build<NS>(L, i, s);
+    record_store<NS>(rec, i, s);
   }
 }
 template <int R, typename IT>  // IT: row ids as int64 (take) or uint32 (the sort's ids, taken as they are)
 __global__ __launch_bounds__(BLOCK) void k_gather_rows(PackLayout L, const uint8_t* __restrict__ rec, const IT* __restrict__ idx, int64_t n) {
   constexpr int NS = R / 8;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    const uint4* src = reinterpret_cast<const uint4*>(rec + (int64_t)idx[i] * R);
     uint64_t s[NS];
-#pragma unroll
-    for (int q = 0; q < NS / 2; q++) {
-      const uint4 v = src[q];
-      s[2 * q] = ((uint64_t)v.y << 32) | v.x;
-      s[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
-    }
-    for (int c = 0; c < L.n; c++) {
-      const int o = L.offset[c];
-      switch (L.width[c]) {
-        case 16: {
-          const uint64_t lo = slot_get<NS>(s, o >> 3), hi = slot_get<NS>(s, (o >> 3) + 1);
-          reinterpret_cast<uint4*>(L.dst[c])[i] = uint4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-          break;
-        }
-        case 8: reinterpret_cast<uint64_t*>(L.dst[c])[i] = slot_get<NS>(s, o >> 3); break;
-        case 4: reinterpret_cast<uint32_t*>(L.dst[c])[i] = (uint32_t)(slot_get<NS>(s, o >> 3) >> ((o & 4) * 8)); break;
-        default: reinterpret_cast<uint8_t*>(L.dst[c])[i] = (uint8_t)(slot_get<NS>(s, o >> 3) >> ((o & 7) * 8)); break;
-      }
-    }
+    record_load<NS>(rec, (int64_t)idx[i], s);
+    record_split<NS>(L, i, s);
   }
+}
+
+// ---- records laid out by somebody else (sort.hip's clustered take): can every column of `cols` travel in ONE record?
+bool plan_record_layout(const Table& in, const std::vector<int>& cols, PackLayout& L, int& R, std::vector<int>& order) {
+  L = PackLayout{};
+  order.clear();
+  if (cols.empty() || (int)cols.size() > PACK_MAX_COLS) return false;
+  for (int c : cols) {
+    const Column& col = in.cols[(size_t)c];
+    if (col.validity || col.field.type == DFGPU_BOOL || col.field.type == DFGPU_UTF8) return false;
+  }
+  for (size_t k = 0; k < cols.size(); k++) order.push_back((int)k);
+  // widest columns first keeps every field naturally aligned inside the record
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return type_width(in.cols[(size_t)cols[(size_t)a]].field.type) > type_width(in.cols[(size_t)cols[(size_t)b]].field.type); });
+  int bytes = 0;
+  for (int k : order) {
+    const Column& col = in.cols[(size_t)cols[(size_t)k]];
+    const int w = type_width(col.field.type);
+    if (bytes + w > 64) return false;
+    L.width[L.n] = w;
+    L.offset[L.n] = bytes;
+    L.src[L.n] = col.ptr();
+    bytes += w;
+    L.n++;
+  }
+  R = (bytes + 15) / 16 * 16;
+  return true;
+}
+// out[k][i] = field k of rec[idx[i]] (the layout's fields are in `order`)
+std::vector<Column> gather_records(const Table& in, const std::vector<int>& cols, PackLayout L, int R, const std::vector<int>& order, const uint8_t* rec,
+                                   const uint32_t* idx, int64_t n) {
+  Runtime& r = rt();
+  std::vector<Column> out(cols.size());
+  int bytes = 0;
+  for (int q = 0; q < L.n; q++) {
+    const int k = order[(size_t)q];
+    out[(size_t)k] = alloc_like(in.cols[(size_t)cols[(size_t)k]], n);
+    L.dst[q] = out[(size_t)k].data->ptr;
+    bytes += L.width[q];
+  }
+  if (n == 0) return out;
+  ProfileScope ps("take_gather_rows", n * (int64_t)(4 + R + bytes));
+  const int g = grid_for(n, BLOCK);
+  switch (R) {
+    case 16: k_gather_rows<16, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec, idx, n); break;
+    case 32: k_gather_rows<32, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec, idx, n); break;
+    case 48: k_gather_rows<48, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec, idx, n); break;
+    default: k_gather_rows<64, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec, idx, n); break;
+  }
+  DFGPU_HIP(hipGetLastError());
+  return out;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_widen_ids(const uint32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {

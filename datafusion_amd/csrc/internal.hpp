@@ -277,6 +277,12 @@ Column gather_column(const Column& in, const int64_t* idx, int64_t n, bool idx_m
 // take of several columns of one table by the same ids: row-major records + ONE random access per row when that pays
 // (idx32: the same ids as 32-bit values instead of `idx` — the sort hands its row ids over without widening them)
 std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols, const int64_t* idx, int64_t n, bool idx_may_be_null, const uint32_t* idx32 = nullptr);
+// one row-major record per row holding every column of `cols` (records.hpp): layout planning and the take from records laid
+// out by the caller (sort.hip's clustered take)
+struct PackLayout;
+bool plan_record_layout(const Table& in, const std::vector<int>& cols, PackLayout& L, int& R, std::vector<int>& order);
+std::vector<Column> gather_records(const Table& in, const std::vector<int>& cols, PackLayout L, int R, const std::vector<int>& order, const uint8_t* rec,
+                                   const uint32_t* idx, int64_t n);
 // out[w] = a[w] & b[w] over nw 64-bit words (aggregate.hip)
 void and_bitmaps(const uint64_t* a, const uint64_t* b, int64_t nw, uint64_t* out);
 // clear bits beyond n in the last word of a bitmap (keeps padding deterministic)

@@ -1428,6 +1428,31 @@ static bool needs_visited(int join_type) {
          join_type == DFGPU_JOIN_LEFT_MARK;
 }
 
+// Do neighbouring probe rows look up neighbouring keys?  A direct-address table bigger than the caches answers a CLUSTERED probe
+// (foreign keys in the parent's order: lineitem -> orders) from lines it has just fetched, and a random one with one 128-byte line
+// of Infinity Cache / HBM traffic per row — which decides between probe flavours below.  From the column's cached statistics when
+// they exist, else from 4096 evenly spaced neighbour pairs (random keys ascend half of the time).
+template <int KT>
+__global__ void k_sample_ascents(KeyCol k, int64_t n, int64_t every, int samples, int* __restrict__ ascents) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= samples) return;
+  const int64_t r = (int64_t)i * every;
+  if (r + 1 >= n) return;
+  const uint64_t a = load_key<KT>(k, r), b = load_key<KT>(k, r + 1);
+  if ((int64_t)b >= (int64_t)a) atomicAdd(ascents, 1);
+}
+static bool probe_keys_clustered(const Column& kc, int64_t n) {
+  if (auto cached = std::atomic_load(&kc.stats)) return cached->nondecreasing;
+  if (n < (1 << 16) || kc.validity || !is_integer_like(kc.field.type) || kc.field.type == DFGPU_UINT64) return true;
+  constexpr int S = 4096;
+  BufPtr cnt = make_zero_buf(4);
+  const KeyCol k{kc.ptr(), nullptr, kc.field.type, type_width(kc.field.type)};
+  with_key_type(k.type, [&](auto kt) { k_sample_ascents<decltype(kt)::value><<<S / BLOCK, BLOCK, 0, rt().stream>>>(k, n, n / S, S, cnt->as<int>()); });
+  int ascents = 0;
+  d2h(&ascents, cnt->ptr, 4);
+  return ascents * 10 >= S * 9;
+}
+
 static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
                                     const std::vector<int>& pout, const dfgpu_join_filter* jfp);
 static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout_in,
@@ -1519,7 +1544,53 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   // agent-scope atomic retires one claim per ~12 ns (scripts/microbench/tile_atomics.hip): 3.5 ms for an SF100 probe's 293 K
   // tiles.  A tile of narrow rows streams in less than that — a key-only join moves 16 B per probe row: 5 ns per tile — so the
   // cursor, not HBM, would set the pace (3.64 ms); counts + placed have no cursor (0.92 + 1.62 ms) and give probe order besides.
-  if (fused_ok && fused_mode == FUSED_UNORDERED && np > (1 << 22)) {
+  // Probe keys in NO order against a direct-address table beyond the caches: every lookup is a line of its own, and counts +
+  // placed would make every lookup twice (150 M shuffled keys x 600 M random probes, key-only: 11.2 + 11.9 ms).  Two answers:
+  //  * the probe reads nothing but its key and nobody observes its order (SELECT l.k ... JOIN, the reference's hj.rs shapes;
+  //    semi / anti joins on the key alone): ONE stable radix pass groups the probe keys by the top bits of their range
+  //    (sort.hip's pass, 64 groups: a group's slice of the table is ~1/64 of it and sits in L2), then the ordinary probe runs
+  //    over the grouped keys — lookups hit lines their neighbours fetched;
+  //  * otherwise the single-pass probe: one lookup per row.
+  const char* big_env = std::getenv("DFGPU_JOIN_BIG_TABLE_BYTES");  // test knob: what counts as "beyond the caches" (default 16 MiB)
+  const int64_t big_bytes = big_env ? std::atoll(big_env) : ((int64_t)16 << 20);
+  const bool big_table = (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY) && (int64_t)(jt.kind == KIND_RANK ? (jt.am_size >> 6) * 16 : jt.am_size * 4) > big_bytes;
+  static thread_local bool in_grouped_probe = false;  // the probe over keys this function grouped itself: clustered by construction
+  const bool unclustered = fused_ok && big_table && np > (1 << 22) && pk.size() == 1 && !in_grouped_probe && !probe_keys_clustered(probe.cols[(size_t)pk[0]], np);
+  const bool group_env = !(std::getenv("DFGPU_JOIN_GROUPED_PROBE") && std::getenv("DFGPU_JOIN_GROUPED_PROBE")[0] == '0');  // A/B knob
+  if (unclustered && group_env && !in_grouped_probe && jt.probe_mode == 4 && rows_unused && !row_mask && pout.size() == 1 && pout[0] == pk[0] &&
+      ctx.pkeys.c[0].width == 8 && !probe.cols[(size_t)pk[0]].validity) {
+    const Column& kc = probe.cols[(size_t)pk[0]];
+    BufPtr keys = kc.data, ids;
+    if (kc.data_offset != 0) {  // a slice of a larger buffer: the pass wants its own
+      keys = make_buf((size_t)np * 8);
+      DFGPU_HIP(hipMemcpyAsync(keys->ptr, kc.ptr(), (size_t)np * 8, hipMemcpyDeviceToDevice, r.stream));
+    }
+    int range_bits = 0;
+    while (range_bits < 64 && (jt.am_size >> range_bits)) range_bits++;
+    // groups = keys sharing bits [range_bits - 6, range_bits) of their value: at most two stretches of the key range each
+    radix_sort_pairs(keys, ids, np, std::max(0, range_bits - 6), 6);
+    Table grouped;
+    grouped.nrows = np;
+    grouped.device = probe.device;
+    Column gk = kc;
+    gk.data = keys;
+    gk.data_offset = 0;
+    gk.stats.reset();
+    grouped.cols.push_back(std::move(gk));
+    in_grouped_probe = true;
+    Table res;
+    try {
+      res = join_probe(jt, grouped, {0}, join_type, bout_in, {0}, nullptr, nullptr);
+    } catch (...) {
+      in_grouped_probe = false;
+      throw;
+    }
+    in_grouped_probe = false;
+    std::lock_guard<std::mutex> lk(jt.mu);
+    jt.info.probe_rows -= np;  // counted by the inner call as well
+    return res;
+  }
+  if (fused_ok && fused_mode == FUSED_UNORDERED && np > (1 << 22) && !unclustered) {
     int64_t row_bytes = key_bytes / std::max<int64_t>(np, 1) + out_row_bytes;
     for (int c : pout) {
       bool is_key = false;

@@ -456,3 +456,40 @@ def test_rank_map_over_unordered_keys_builds_its_permutation_on_the_first_probe_
     got = ht2.emit_unmatched("LeftSemi", ["k", "pay"]).to_arrow()            # visited marks are per build ROW: the permutation is there
     assert sorted_rows(got) == sorted_rows(oracle.hash_join(build, probe, [("k", "k2")], "LeftSemi"))
     ht2.free()
+
+
+@pytest.mark.parametrize("join_type", ["Inner", "RightSemi", "RightAnti"])
+def test_key_only_probe_of_unordered_keys_is_grouped_by_key_range(join_type):
+    """probe keys in no order against a table beyond the caches, nothing read but the key, order unobserved (probe_mode 4): the
+    keys are grouped by the top bits of their range before the lookup — the same rows come out (as a multiset), whichever way"""
+    import os
+
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(14)
+    nb, npr = 3_000_000, 6_000_011
+    bkeys = (rng.permutation(nb).astype(np.int64) // 8) * 32 + rng.permutation(nb) % 8 + 1          # sparse, shuffled; duplicates possible -> made unique
+    bkeys = np.unique(bkeys)
+    rng.shuffle(bkeys)
+    pk = rng.integers(0, int(bkeys.max()) + 1000, npr).astype(np.int64)
+    b = DeviceTable.from_arrow(pa.table({"k": pa.array(bkeys)}))
+    p = DeviceTable.from_arrow(pa.table({"k2": pa.array(pk)}))
+    member = np.isin(pk, bkeys)
+    exp = np.sort(pk[member if join_type != "RightAnti" else ~member])
+    outs = {}
+    for grouped in ("1", "0"):
+        os.environ["DFGPU_JOIN_GROUPED_PROBE"] = grouped
+        os.environ["DFGPU_JOIN_BIG_TABLE_BYTES"] = "1000000"      # this test's 3 MB table counts as beyond the caches
+        try:
+            ht = ops.JoinHashTable(b, ["k"], probe_mode=4)
+            assert ht.info().table_kind == 2
+            out = ht.probe(p, ["k2"], join_type, [], ["k2"])
+            outs[grouped] = out.to_arrow().column("k2").to_numpy()
+            assert out.column_names == ["k2"]
+            ht.free()
+        finally:
+            os.environ.pop("DFGPU_JOIN_GROUPED_PROBE", None)
+            os.environ.pop("DFGPU_JOIN_BIG_TABLE_BYTES", None)
+        assert np.array_equal(np.sort(outs[grouped]), exp), grouped
+    if join_type == "Inner":
+        assert not np.array_equal(outs["1"], outs["0"])       # the grouped flavour really ran: its rows come out in group order
