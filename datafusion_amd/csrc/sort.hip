@@ -25,6 +25,7 @@
 
 #include "device.hpp"
 #include "internal.hpp"
+#include "records.hpp"
 
 namespace dfgpu {
 
@@ -455,6 +456,101 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_
 #pragma unroll
         for (int w = 0; w < NW; w++) out.w[w][dst] = s_key[w][q];
         out.idx[dst] = s_idx[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The clustered take's pass (sort_table): one stable scatter of the packed keys by the TOP digit of their bucket number that also
+// carries every row's payload as ONE row-major record (records.hpp).  Afterwards rows whose keys are close sit close together
+// in `rec`, the row id of a key is its position in this order, and the take that ends the sort reads records from a window of
+// n / 2^bits rows at a time (tens of MB: Infinity-Cache resident) instead of random 128-byte lines of the whole table.  Same
+// ranking as k_rs_scatter2; the keys are staged through LDS, a record goes from its source row (inside the tile's own 4096-row
+// window of the source columns: cache hits) straight to its destination (32-64 contiguous bytes per row, whole runs per digit).
+template <int ITEMS, int R>
+__global__ __launch_bounds__(BLOCK) void k_rs_scatter_rec(const uint64_t* __restrict__ key_in, int64_t n, DivBy dv, int shift, int bits, int64_t n_tiles,
+                                                         const uint64_t* __restrict__ offsets, uint64_t* __restrict__ key_out, PackLayout L, uint8_t* __restrict__ rec) {
+  constexpr int TILE = BLOCK * ITEMS;
+  constexpr int NWAVE = BLOCK / WAVE;
+  constexpr int NS = R / 8;
+  __shared__ uint64_t s_key[TILE];
+  __shared__ uint16_t s_src[TILE];   // source row inside the tile
+  __shared__ uint8_t s_dig[TILE];
+  __shared__ unsigned int s_cnt[NWAVE][256];
+  __shared__ unsigned int s_start[256];
+  __shared__ unsigned int s_wtot[NWAVE];
+  __shared__ unsigned long long s_goff[256];
+  const unsigned mask = (1u << bits) - 1u;
+  const int wave = threadIdx.x >> 6;
+  const unsigned lane = lane_id();
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t lo = t * TILE;
+    const int tile_rows = (int)((n - lo) < TILE ? (n - lo) : TILE);
+#pragma unroll
+    for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+    if ((int)threadIdx.x <= (int)mask) s_goff[threadIdx.x] = offsets[(int64_t)threadIdx.x * n_tiles + t];
+    __syncthreads();
+    uint64_t key[ITEMS];
+    unsigned dig[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+      key[c] = key_in[lo + (j < tile_rows ? j : 0)];
+    }
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+      const bool in = j < tile_rows;
+      dig[c] = in ? ((unsigned)(div_apply(key[c], dv) >> shift) & mask) : 0u;
+      uint64_t peers = ballot64(in);
+      for (int b = 0; b < bits; b++) {
+        const uint64_t bal = ballot64((dig[c] >> b) & 1u);
+        peers &= ((dig[c] >> b) & 1u) ? bal : ~bal;
+      }
+      const unsigned r_in_wave = mbcnt(peers);
+      const unsigned base = s_cnt[wave][dig[c]];
+      if (in && r_in_wave == 0) s_cnt[wave][dig[c]] = base + (unsigned)__popcll(peers);
+      rank[c] = base + r_in_wave;
+    }
+    __syncthreads();
+    {
+      unsigned run = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; w++) {
+        const unsigned v = s_cnt[w][threadIdx.x];
+        s_cnt[w][threadIdx.x] = run;
+        run += v;
+      }
+      const unsigned inc = wave_inclusive_sum<unsigned>(run);
+      if (lane == 63) s_wtot[wave] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; w++) base += s_wtot[w];
+      s_start[threadIdx.x] = base + inc - run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+      if (j < tile_rows) {
+        const unsigned q = s_start[dig[c]] + s_cnt[wave][dig[c]] + rank[c];
+        s_key[q] = key[c];
+        s_src[q] = (uint16_t)j;
+        s_dig[q] = (uint8_t)dig[c];
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int c = 0; c < ITEMS; c++) {
+      const int q = c * BLOCK + threadIdx.x;
+      if (q < tile_rows) {
+        const unsigned d = s_dig[q];
+        const int64_t dst = (int64_t)(s_goff[d] + (unsigned)(q - (int)s_start[d]));
+        key_out[dst] = s_key[q];
+        uint64_t srec[NS];
+        record_build<NS>(L, lo + s_src[q], srec);
+        record_store<NS>(rec, dst, srec);
       }
     }
     __syncthreads();
@@ -1035,8 +1131,68 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       if (m) k_iota_u32<<<grid_for(m, BLOCK), BLOCK, 0, r.stream>>>(m, sv.idx->as<uint32_t>());
       sk = sv;
     }
+    std::vector<int> allc(in.cols.size());
+    for (size_t i = 0; i < allc.size(); i++) allc[i] = (int)i;
+    // ---- clustered take: a full sort of a table far beyond the Infinity Cache whose columns fit ONE record.  Sorting row ids and
+    // taking the rows afterwards reads a random 128-byte line per row and column group (150 M orders: 19.9 GB for 4.8 GB of
+    // records, profiles/r2_ops_v3_traffic.md).  Instead ONE extra stable pass (k_rs_scatter_rec) moves keys AND records into the
+    // order of the top digit of the bucket number; the sort then runs over THAT order (row id = position in it), and the final
+    // take reads records from one top-digit group at a time — n / 256 rows, tens of MB, cache resident.
+    BufPtr rec;
+    PackLayout L{};
+    int R = 0;
+    std::vector<int> rec_order;
+    SortedKeys sk_sorted_from = sk;
+    {
+      static const bool enabled = !(std::getenv("DFGPU_SORT_CLUSTERED_TAKE") && std::getenv("DFGPU_SORT_CLUSTERED_TAKE")[0] == '0');  // A/B knob
+      const char* min_env = std::getenv("DFGPU_SORT_CLUSTERED_MIN_BYTES");  // test knob (default: 256 MiB of input columns)
+      const int64_t min_bytes = min_env ? std::atoll(min_env) : ((int64_t)256 << 20);
+      int64_t in_bytes = 0;
+      for (const Column& c : in.cols) in_bytes += (c.field.type == DFGPU_UTF8 || c.field.type == DFGPU_BOOL) ? 0 : n * type_width(c.field.type);
+      int top_bits = 0;
+      while (top_bits < 32 && (n >> top_bits) > 2304) top_bits += 8;
+      if (enabled && !remap && narrow && nwords == 1 && !sk.idx && n_out * 4 >= n && in_bytes > min_bytes && top_bits >= 8 && key_space >= 2 && (key_space >> top_bits) >= 2 &&
+          n < 0xFFFFFFFFll && plan_record_layout(in, allc, L, R, rec_order)) {
+        const int64_t n_buckets = (int64_t)1 << top_bits;
+        const uint64_t width = (key_space + (uint64_t)n_buckets - 1) / (uint64_t)n_buckets;
+        constexpr int ITEMS = 16;
+        const int64_t tile = (int64_t)BLOCK * ITEMS, n_tiles = (n + tile - 1) / tile;
+        const int hbits = 8, shift = top_bits - hbits;
+        BufPtr counts = make_buf((size_t)256 * n_tiles * 4), offsets = make_buf((size_t)(256 * n_tiles + 1) * 8);
+        BufPtr key_r = make_buf((size_t)n * 8);
+        rec = make_buf((size_t)n * R + 64);
+        const int grid = (int)std::min<int64_t>(n_tiles, 256 * 8);
+        const DivBy dv = div_by(width);
+        int payload = 0;
+        for (int q = 0; q < L.n; q++) payload += L.width[q];
+        {
+          ProfileScope ps("sort_cluster_records", n * (int64_t)(8 + 8 + payload + 8 + R));
+          k_rs_hist<<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, ITEMS, n_tiles, counts->as<uint32_t>());
+          scan_u32(counts->as<uint32_t>(), (int64_t)256 * n_tiles, offsets->as<uint64_t>());
+          switch (R) {
+            case 16: k_rs_scatter_rec<ITEMS, 16><<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, n_tiles, offsets->as<uint64_t>(), key_r->as<uint64_t>(), L, rec->as<uint8_t>()); break;
+            case 32: k_rs_scatter_rec<ITEMS, 32><<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, n_tiles, offsets->as<uint64_t>(), key_r->as<uint64_t>(), L, rec->as<uint8_t>()); break;
+            case 48: k_rs_scatter_rec<ITEMS, 48><<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, n_tiles, offsets->as<uint64_t>(), key_r->as<uint64_t>(), L, rec->as<uint8_t>()); break;
+            default: k_rs_scatter_rec<ITEMS, 64><<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, n_tiles, offsets->as<uint64_t>(), key_r->as<uint64_t>(), L, rec->as<uint8_t>()); break;
+          }
+          DFGPU_HIP(hipGetLastError());
+        }
+        sk_sorted_from = SortedKeys{};
+        sk_sorted_from.nwords = 1;
+        sk_sorted_from.w[0] = key_r;   // row ids implicit: positions in the clustered order
+      }
+    }
     bool clobbered = false;
-    BufPtr sorted_idx = remap ? nullptr : sorted_ids_local(sk, m, key_space, clobbered);  // (TopK survivors are few: all-HBM passes)
+    BufPtr sorted_idx = remap ? nullptr : sorted_ids_local(sk_sorted_from, m, key_space, clobbered);  // (TopK survivors are few: all-HBM passes)
+    if (rec && sorted_idx) {
+      out.cols = gather_records(in, allc, L, R, rec_order, rec->as<uint8_t>(), sorted_idx->as<uint32_t>(), n_out);
+      DFGPU_HIP(hipStreamSynchronize(r.stream));
+      return out;
+    }
+    if (rec) {  // skewed keys (a bucket beyond the LDS capacity): the plain path over the keys in their original order, which are intact
+      rec.reset();
+      clobbered = false;   // sorted_idx stays null: the all-HBM passes below (the same skew would stop the local sort again)
+    }
     if (!sorted_idx) {
       if (clobbered) pack_keys();
       SortedKeys sorted = radix_sort(sk, m, digits);
@@ -1046,8 +1202,6 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       }
       sorted_idx = sorted.idx;
     }
-    std::vector<int> allc(in.cols.size());
-    for (size_t i = 0; i < allc.size(); i++) allc[i] = (int)i;
     if (remap) {  // TopK survivors: positions among the survivors -> row ids of the input
       BufPtr take_idx = make_buf((size_t)n_out * 8);
       k_idx_to_i64<<<grid_for(n_out, BLOCK), BLOCK, 0, r.stream>>>(sorted_idx->as<uint32_t>(), remap->as<int64_t>(), n_out, take_idx->as<int64_t>());
