@@ -356,6 +356,8 @@ ColStats column_stats(Column& c, int64_t nrows);
 // ----------------------------------------------------------------- radix passes (sort.hip)
 // (key u64, row id u32) pairs stably sorted by bits [lo_bit, lo_bit + nbits) of the key; `idx` null on entry = row id is the position
 void radix_sort_pairs(BufPtr& key, BufPtr& idx, int64_t n, int lo_bit, int nbits);
+// keys alone, grouped stably by bits [lo_bit, lo_bit + nbits) of their value (no row ids are made)
+void radix_group_keys(BufPtr& key, int64_t n, int lo_bit, int nbits);
 
 // ----------------------------------------------------------------- LDS radix join (radix_join.hip)
 struct RadixTable;

@@ -248,7 +248,9 @@ __global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uin
       if (!ok[j]) continue;
       const uint64_t idx = lo[j] - offset;
       const unsigned long long bit = 1ull << (idx & 63);
-      if (atomicOr(&bits[idx >> 6], bit) & bit) *dup_flag = 1;  // the old word detects duplicate keys
+      // fire-and-forget: nothing waits for the old word (a returning atomic per key was what 150 M keys in no order spent their
+      // 5.7 ms on); duplicate keys show afterwards as fewer set bits than non-NULL keys (join_build_fixed_keys)
+      (void)__hip_atomic_fetch_or(&bits[idx >> 6], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1182,6 +1184,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
   bool have_stats = false, ascending = false;
   uint64_t range = 0;
   long long kmin = 0;
+  int64_t n_valid_keys = 0;
   if (opts.table_mode != 1 && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64) {
     const Column& kc = build.cols[key_cols[0]];
     bool null_block = null_equality == DFGPU_NULL_EQUALS_NULL && kc.has_nulls();
@@ -1200,6 +1203,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       }
       MinMax res;
       d2h(&res, mm->ptr, sizeof res);
+      n_valid_keys = (int64_t)res.valid;
       if (res.valid > 0) {
         range = (uint64_t)res.smax - (uint64_t)res.smin;  // ArrayMap::calculate_range (wrapping)
         have_stats = range != UINT64_MAX;
@@ -1242,7 +1246,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       // stable radix pass groups the keys by the top bits of their range first (sort.hip: 64 groups), the bits of a group
       // then land in ~1/64 of the bitmap
       KeyCol kc0 = ks.c[0];
-      BufPtr grouped_keys, grouped_ids;
+      BufPtr grouped_keys;
       if (!ascending && !kc0.valid && kc0.width == 8 && nb > (1 << 22) && n_words * 8 > ((int64_t)16 << 20) &&
           !(std::getenv("DFGPU_JOIN_GROUPED_BUILD") && std::getenv("DFGPU_JOIN_GROUPED_BUILD")[0] == '0')) {
         const Column& kcol = build.cols[(size_t)key_cols[0]];
@@ -1253,7 +1257,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
         }
         int range_bits = 0;
         while (range_bits < 64 && ((range + 1) >> range_bits)) range_bits++;
-        radix_sort_pairs(grouped_keys, grouped_ids, nb, std::max(0, range_bits - 6), 6);
+        radix_group_keys(grouped_keys, nb, std::max(0, range_bits - 6), 6);
         kc0.data = grouped_keys->ptr;
       }
       with_key_type(kc0.type, [&](auto kt) {
@@ -1264,13 +1268,14 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
         else k_rank_setbits<T, false, false><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>());
       });
     }
-    if (!ascending) d2h(&dup, flag->ptr, 4);
+    jt->rank_prefix = make_buf((size_t)(n_words + 1) * 8);
+    scan_mask_popcounts(jt->rank_bits->as<uint64_t>(), nullptr, n_words * 64, jt->rank_prefix->as<uint64_t>());
+    // keys in no order set their bits without looking: two rows with one key set one bit
+    if (!ascending) dup = (int64_t)read_u64(jt->rank_prefix->as<uint64_t>() + n_words) != n_valid_keys;
     if (!dup) {
       jt->kind = KIND_RANK;
       jt->am_offset = (uint64_t)kmin;
       jt->am_size = range + 1;
-      jt->rank_prefix = make_buf((size_t)(n_words + 1) * 8);
-      scan_mask_popcounts(jt->rank_bits->as<uint64_t>(), nullptr, n_words * 64, jt->rank_prefix->as<uint64_t>());
       jt->rank_needs_perm = !ascending;  // the permutation itself waits for a probe that needs build rows (ensure_rank_perm)
       jt->rank_tab = make_buf((size_t)n_words * 16);
       k_rank_interleave<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(jt->rank_bits->as<uint64_t>(), jt->rank_prefix->as<uint64_t>(), n_words, jt->rank_tab->as<ulonglong2>());
@@ -1280,6 +1285,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
     } else {
       DFGPU_CHECK(opts.table_mode != 3, "rank-map join table requested but the build keys are not unique");
       jt->rank_bits.reset();
+      jt->rank_prefix.reset();
     }
   }
   // Duplicate build keys at a size where the chains live in HBM: when the plan does not observe the probe order
@@ -1578,7 +1584,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   if (unclustered && group_env && !in_grouped_probe && jt.probe_mode == 4 && rows_unused && !row_mask && pout.size() == 1 && pout[0] == pk[0] &&
       ctx.pkeys.c[0].width == 8 && !probe.cols[(size_t)pk[0]].validity) {
     const Column& kc = probe.cols[(size_t)pk[0]];
-    BufPtr keys = kc.data, ids;
+    BufPtr keys = kc.data;
     if (kc.data_offset != 0) {  // a slice of a larger buffer: the pass wants its own
       keys = make_buf((size_t)np * 8);
       DFGPU_HIP(hipMemcpyAsync(keys->ptr, kc.ptr(), (size_t)np * 8, hipMemcpyDeviceToDevice, r.stream));
@@ -1586,7 +1592,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     int range_bits = 0;
     while (range_bits < 64 && (jt.am_size >> range_bits)) range_bits++;
     // groups = keys sharing bits [range_bits - 6, range_bits) of their value: at most two stretches of the key range each
-    radix_sort_pairs(keys, ids, np, std::max(0, range_bits - 6), 6);
+    radix_group_keys(keys, np, std::max(0, range_bits - 6), 6);
     Table grouped;
     grouped.nrows = np;
     grouped.device = probe.device;
@@ -1608,7 +1614,8 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     jt.info.probe_rows -= np;  // counted by the inner call as well
     return res;
   }
-  if (fused_ok && fused_mode == FUSED_UNORDERED && np > (1 << 22) && !unclustered) {
+  // (the probe over keys grouped above: its lookups hit L2 but are still one line request per row — one pass, not two)
+  if (fused_ok && fused_mode == FUSED_UNORDERED && np > (1 << 22) && !unclustered && !in_grouped_probe) {
     int64_t row_bytes = key_bytes / std::max<int64_t>(np, 1) + out_row_bytes;
     for (int c : pout) {
       bool is_key = false;
@@ -2318,6 +2325,39 @@ int dfgpu_join_emit_unmatched(dfgpu_join_t ht, int join_type, const int* build_o
       }
     }
     jt->info.output_rows += o->nrows;
+    *out = wrap(o.release());
+  });
+}
+
+// HashTableLookupExpr (hash_join/partitioned_hash_eval.rs:278): the Map strategy of the join's dynamic filter — is the row's key in the
+// build side's table?  One Boolean per probe row (never NULL; a NULL key is FALSE unless NULL == NULL and the build side holds one).
+int dfgpu_join_contains(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, dfgpu_table_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(ht && probe_key_cols && out, "null argument");
+    JoinTable* jt = unwrap_join(ht);
+    DFGPU_CHECK(jt->kind != KIND_RADIX, "dfgpu_join_contains: the LDS radix table answers pairs, not membership (build with table_mode 0-3)");
+    std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
+    const Table pt = with_build_dictionaries(*jt, *unwrap(probe), pk);
+    DFGPU_CHECK(pt.device == jt->build.device, "the probe table lives on another device than the join table");
+    const int64_t np = pt.nrows, n_words = (np + 63) / 64;
+    // membership needs no build row: over a rank map of keys in no order the bitmap alone answers (no permutation is built)
+    ProbeCtx ctx = make_ctx(*jt, pt, pk, /*need_build_rows=*/false);
+    dfgpu_field f{};
+    f.type = DFGPU_BOOL;
+    auto o = std::make_unique<Table>();
+    o->nrows = np;
+    o->cols.push_back(alloc_column(f, "contains", np));
+    if (np > 0) {
+      int64_t key_bytes = 0;
+      for (int i = 0; i < ctx.pkeys.n; i++) key_bytes += np * ctx.pkeys.c[i].width;
+      ProfileScope ps("join_contains", key_bytes + np / 8);
+      const int g = grid_for(n_words, (BLOCK / WAVE) * PROBE_UNROLL);
+      with_kind_and_key(jt->kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
+        k_probe_first<decltype(kd)::value, decltype(kt)::value><<<g, BLOCK, 0, rt().stream>>>(ctx, np, 0, nullptr, o->cols[0].data->as<uint64_t>(), nullptr);
+      });
+      DFGPU_HIP(hipGetLastError());
+    }
     *out = wrap(o.release());
   });
 }

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_
         const unsigned long long dst = s_goff[d] + (unsigned)(q - (int)s_start[d]);
 #pragma unroll
         for (int w = 0; w < NW; w++) out.w[w][dst] = s_key[w][q];
-        out.idx[dst] = s_idx[q];
+        if (out.idx) out.idx[dst] = s_idx[q];   // (null: the caller groups keys and wants no row ids)
       }
     }
     __syncthreads();
@@ -645,7 +645,7 @@ static std::vector<Digit> key_digits(int total_bits) {
 }
 
 // stable LSD radix sort of n (key, idx) elements over the given digits; returns the buffers holding the result
-static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>& digits) {
+static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>& digits, bool want_ids) {
   Runtime& r = rt();
   if (n <= 1 || digits.empty()) return in;
   const int nwords = in.nwords;
@@ -656,7 +656,7 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
   SortedKeys cur = in, alt;
   alt.nwords = nwords;
   for (int wd = 0; wd < nwords; wd++) alt.w[wd] = make_buf((size_t)n * 8);
-  alt.idx = make_buf((size_t)n * 4);
+  if (want_ids) alt.idx = make_buf((size_t)n * 4);
   BufPtr counts = make_buf((size_t)256 * n_tiles * 4);
   BufPtr offsets = make_buf((size_t)(256 * n_tiles + 1) * 8);
   const int grid = (int)std::min<int64_t>(n_tiles, 256 * 8);
@@ -667,8 +667,8 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
       ck.w[wd] = cur.w[wd]->as<uint64_t>();
       ob.w[wd] = alt.w[wd]->as<uint64_t>();
     }
-    if (!alt.idx) alt.idx = make_buf((size_t)n * 4);  // the input had implicit row ids (radix_sort_pairs)
-    ob.idx = alt.idx->as<uint32_t>();
+    if (!alt.idx && want_ids) alt.idx = make_buf((size_t)n * 4);  // the input had implicit row ids (radix_sort_pairs)
+    ob.idx = alt.idx ? alt.idx->as<uint32_t>() : nullptr;
     const int nb = 1 << d.bits;
     ProfileScope ps("radix_sort_pass", n * 8 + n * (nwords * 8 + 4) * 2);
     const DivBy dv = div_by(d.div);
@@ -676,7 +676,7 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
     scan_u32(counts->as<uint32_t>(), (int64_t)nb * n_tiles, offsets->as<uint64_t>());
     static const bool gen1 = std::getenv("DFGPU_SORT_GEN1") != nullptr;  // A/B knob: the first-generation scatter
     const uint32_t* idx_in = cur.idx ? cur.idx->as<uint32_t>() : nullptr;
-    if (gen1) {
+    if (gen1 && want_ids) {
       switch (nwords) {
         case 1: k_rs_scatter<1><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
         case 2: k_rs_scatter<2><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict
   }
 }
 
-static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>& digits);
+static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>& digits, bool want_ids = true);
 
 // row ids of a one-word key in sorted order by "top digits in HBM + buckets in LDS"; null when that does not apply (then
 // `clobbered` tells whether the key buffer was used as scratch by the top passes and has to be packed again)
@@ -916,6 +916,24 @@ void radix_sort_pairs(BufPtr& key, BufPtr& idx, int64_t n, int lo_bit, int nbits
   SortedKeys out = radix_sort(in, n, digits);
   key = out.w[0];
   idx = out.idx;
+}
+
+// keys alone grouped (stably) by bits [lo_bit, lo_bit + nbits) of their value, ONE pass per <= 6 bits, no row ids: what the hash join
+// does to keys that arrive in no order before it looks them up / sets their bits (join.hip)
+void radix_group_keys(BufPtr& key, int64_t n, int lo_bit, int nbits) {
+  if (n <= 1 || nbits <= 0) return;
+  std::vector<Digit> digits;
+  const int mb = 6, nd = (nbits + mb - 1) / mb;
+  int pos = lo_bit;
+  for (int d = 0; d < nd; d++) {
+    const int b = (lo_bit + nbits - pos + (nd - d) - 1) / (nd - d);
+    digits.push_back({0, pos, b});
+    pos += b;
+  }
+  SortedKeys in;
+  in.nwords = 1;
+  in.w[0] = key;
+  key = radix_sort(in, n, digits, /*want_ids=*/false).w[0];
 }
 
 static int bits_for(u128 range) {
@@ -1144,7 +1162,10 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     std::vector<int> rec_order;
     SortedKeys sk_sorted_from = sk;
     {
-      static const bool enabled = !(std::getenv("DFGPU_SORT_CLUSTERED_TAKE") && std::getenv("DFGPU_SORT_CLUSTERED_TAKE")[0] == '0');  // A/B knob
+      // MEASURED AND NOT KEPT as the default (profiles/r3_sort_clustered.md): 150 M orders 12.6 -> 17.9 ms.  The record-carrying pass
+      // costs 7.1 ms (its per-row record build is 4 dependent gathers inside the tile: line-request bound), and the take from 18 MB
+      // groups runs at the Infinity Cache's random-line rate, which is barely above HBM's (3.5 vs 4.3 ms).  Opt-in for experiments.
+      const bool enabled = std::getenv("DFGPU_SORT_CLUSTERED_TAKE") && std::getenv("DFGPU_SORT_CLUSTERED_TAKE")[0] == '1';
       const char* min_env = std::getenv("DFGPU_SORT_CLUSTERED_MIN_BYTES");  // test knob (default: 256 MiB of input columns)
       const int64_t min_bytes = min_env ? std::atoll(min_env) : ((int64_t)256 << 20);
       int64_t in_bytes = 0;

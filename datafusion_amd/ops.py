@@ -104,6 +104,14 @@ class JoinHashTable:
                                                 _ints(pc), len(pc), C.byref(out)))
         return DeviceTable(out)
 
+    def contains(self, probe: DeviceTable, on_right) -> DeviceTable:
+        """HashTableLookupExpr (hash_join/partitioned_hash_eval.rs:278), the Map strategy of the join's dynamic filter: a one-column
+        Boolean table `contains` of `probe`'s rows — is the row's key in the build side?  (dfgpu_join_contains)"""
+        pk = [probe.index_of(k) for k in on_right]
+        out = C.c_void_p()
+        check(_lib.load().dfgpu_join_contains(self._h, probe.handle, _ints(pk), C.byref(out)))
+        return DeviceTable(out)
+
     def emit_unmatched(self, join_type, build_cols=None, probe_schema: pa.Schema | None = None) -> DeviceTable:
         """process_unmatched_build_batch (stream.rs:1002-): build rows by visited state"""
         lib = _lib.load()

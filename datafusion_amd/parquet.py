@@ -311,14 +311,68 @@ class ParquetFile:
         return out
 
 
-def read_table(path: str, columns=None, threads: int | None = None, bounds: dict | None = None, stats: dict | None = None, in_lists: dict | None = None) -> DeviceTable:
+def read_table(path: str, columns=None, threads: int | None = None, bounds: dict | None = None, stats: dict | None = None, in_lists: dict | None = None,
+               membership: dict | None = None) -> DeviceTable:
     """the row groups of `path` that can hold rows inside `bounds` and one of `in_lists`' values (all of them without either), the
-    given columns, as one device table; `stats` receives row_groups_total / row_groups_read"""
+    given columns, as one device table; `stats` receives row_groups_total / row_groups_read.
+
+    `membership` = {key column: a join's built table (ops.JoinHashTable)}: the Map strategy of the join's dynamic filter
+    (PushdownStrategy::Map, hash_join/shared_bounds.rs:275-284 — the reference pushes `HashTableLookupExpr`, partitioned_hash_eval.rs:278,
+    to the probe-side scan, where it runs as a row filter).  After the statistics have pruned what they can, every surviving row group's
+    KEY chunk is decoded first and asked `contains`; a row group without a single key of the build side is dropped before its other
+    column chunks are read, decompressed or sent over PCIe, and the rows of the others are filtered on the device.  `stats` additionally
+    receives row_groups_skipped_by_membership / rows_scanned / rows_passed."""
     f = ParquetFile(path)
     try:
         groups = None if not (bounds or in_lists) else f.row_groups_overlapping(bounds or {}, in_lists)
         if stats is not None:
             stats.update(row_groups_total=f.num_row_groups, row_groups_read=f.num_row_groups if groups is None else len(groups))
-        return f.read(columns, threads, groups)
+        if not membership:
+            return f.read(columns, threads, groups)
+        return _read_with_membership(f, columns, threads, groups, membership, stats)
     finally:
         f.close()
+
+
+def _read_with_membership(f: "ParquetFile", columns, threads, groups, membership: dict, stats) -> DeviceTable:
+    from . import ops
+    from .expr import col
+    names = list(columns or f.column_names)
+    (key, table), = membership.items()           # one pushed-down join per scan (a second one filters what the first lets through)
+    if key not in names:
+        return f.read(names, threads, groups)
+    groups = list(range(f.num_row_groups)) if groups is None else list(groups)
+    parts, skipped, scanned, passed = [], 0, 0, 0
+    for g in groups:
+        keys = f._decode(g, key)
+        scanned += keys.num_rows
+        mask = table.contains(keys, [key])
+        hit = ops.filter(mask, col("contains"), [])      # the count of passing rows without moving a column
+        n_hit = hit.num_rows
+        hit.free()
+        if n_hit == 0:
+            skipped += 1
+            keys.free()
+            mask.free()
+            continue
+        keys.free()                                       # cached: read() below takes the chunk from the device cache
+        rg = f.read(names, threads, [g])
+        if n_hit < rg.num_rows:
+            both = ParquetFile._hstack([rg.select(list(range(rg.num_columns))), mask])
+            rg.free()
+            rg = ops.filter(both, col("contains"), names)
+            both.free()
+        else:
+            mask.free()
+        passed += rg.num_rows
+        parts.append(rg)
+    if stats is not None:
+        stats.update(row_groups_skipped_by_membership=skipped, rows_scanned=scanned, rows_passed=passed)
+    if not parts:
+        return f.read(names, threads, [])
+    if len(parts) == 1:
+        return parts[0]
+    out = DeviceTable.concat(parts)
+    for p in parts:
+        p.free()
+    return out

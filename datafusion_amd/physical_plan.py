@@ -124,6 +124,7 @@ class ParquetExec(ExecutionPlan):
         self.path, self.projection, self.label = path, projection, name
         self.dynamic_bounds = {}   # column -> (lo, hi): published by a HashJoinExec above once its build side is known
         self.dynamic_in_lists = {} # column -> ascending distinct build keys of a small build side (PushdownStrategy::InList)
+        self.dynamic_membership = {}  # column -> the built join table of a LARGE build side (PushdownStrategy::Map): asked `contains` per row group
         self.metrics = {}          # row_groups_total / row_groups_read of the last execute
 
     def project(self, columns) -> "ParquetExec":
@@ -134,7 +135,8 @@ class ParquetExec(ExecutionPlan):
 
     def execute(self, partition=0):
         from .parquet import read_table
-        return read_table(self.path, self.projection, bounds=self.dynamic_bounds or None, stats=self.metrics, in_lists=self.dynamic_in_lists or None)
+        return read_table(self.path, self.projection, bounds=self.dynamic_bounds or None, stats=self.metrics, in_lists=self.dynamic_in_lists or None,
+                          membership=self.dynamic_membership or None)
 
     def detail(self):
         return f"{self.label or self.path}" + (f", projection={self.projection}" if self.projection else "")
@@ -317,6 +319,22 @@ class HashJoinExec(ExecutionPlan):
     _DYNAMIC_FILTER_JOINS = ("Inner", "Left", "LeftSemi", "RightSemi", "LeftAnti", "LeftMark")
     _BUILD_EMITTING = ("Left", "Full", "LeftSemi", "LeftAnti", "LeftMark")      # join types that report build rows by their visited marks
 
+    def _publish_membership(self, ht):
+        """the Map strategy (hash_join/exec.rs:2727-2751: a build side beyond the IN-list limits pushes the hash table itself):
+        the probe-side ParquetExec asks the built table `contains` for every row group's key chunk before it reads anything else.
+        Only where the bounds were published (same join types / key restrictions) and no IN list was (that is the small-build case)."""
+        node = self.right
+        while isinstance(node, (FilterExec, CoalesceBatchesExec, RepartitionExec)):
+            node = node.input
+        if not isinstance(node, ParquetExec):
+            return
+        probe_key = self.on[0][1]
+        from .queries import _world
+        if probe_key in node.dynamic_bounds and probe_key not in node.dynamic_in_lists and _world() == 1 and self.filter is None:
+            node.dynamic_membership[probe_key] = ht
+        else:
+            node.dynamic_membership.pop(probe_key, None)
+
     def _publish_dynamic_bounds(self, build_table):
         """the join's dynamic filter (HashJoinExec::create_dynamic_filter, hash_join/exec.rs:869-875; bounds accumulated in
         hash_join/shared_bounds.rs:277-284): [min, max] of the build keys, handed to the probe-side scan, which prunes row groups
@@ -398,6 +416,8 @@ class HashJoinExec(ExecutionPlan):
         b, bo = self._run_child(self.left)
         ht = ops.JoinHashTable(b, [l for l, _ in self.on], self.null_equality, probe_mode=self.probe_mode, null_aware=self.null_aware)
         self._publish_dynamic_bounds(b)
+        if self.join_type in ("Inner", "RightSemi") and len(self.on) == 1:
+            self._publish_membership(ht)
         p, po = self._run_child(self.right)
         out = self._probe(ht, p, probe_predicate)
         ht.free()

@@ -503,6 +503,13 @@ int dfgpu_column_minmax(dfgpu_table_t table, int column, int64_t* out_min, int64
  * Larger build sides use the Map strategy (the hash table itself is the membership test — here: the probe kernel), and only
  * their bounds are pushed: *out_n = -1.  An empty column gives *out_n = 0 (PushdownStrategy::Empty: nothing can match). */
 int dfgpu_column_inlist(dfgpu_table_t table, int column, int64_t max_size, int64_t max_distinct_values, int64_t* out_values, int64_t capacity, int64_t* out_n);
+/* The Map strategy of the join's dynamic filter (PushdownStrategy::Map, hash_join/shared_bounds.rs:275-284; HashTableLookupExpr,
+ * hash_join/partitioned_hash_eval.rs:278): a build side too large for an IN list pushes the TABLE ITSELF to the probe-side scan as the
+ * membership test.  *out = a one-column Boolean table `contains` of `probe`'s rows: TRUE where the row's key is in the build side
+ * (never NULL: a NULL key is FALSE under NullEqualsNothing).  Needs no build row — over a rank map of keys in no particular order the
+ * bitmap alone answers.  The scan evaluates it on the key column of a row group FIRST and decodes the other columns only when a row
+ * passes (datafusion_amd/parquet.py read_table(membership=...)). */
+int dfgpu_join_contains(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, dfgpu_table_t* out);
 /* The same with a FilterExec fused below the probe side (filter.rs:1396-1419 -> hash_join/stream.rs:687-1000):
  * probe rows whose predicate is false or NULL do not exist for the join.  With the single-pass probe the predicate's
  * row mask is applied inside the probe kernel and the filtered probe table is never materialised; every other
