@@ -147,6 +147,49 @@ def test_small_build_side_pushes_an_in_list_that_prunes_between_the_bounds(tmp_p
     assert ops.column_inlist(small, "k", max_size=1000, max_distinct_values=1000) is None and ops.column_inlist(small, "k", max_distinct_values=0) is None
 
 
+@pytest.mark.parametrize("join_type", ["Inner", "RightSemi"])
+def test_large_build_side_pushes_its_table_as_a_membership_filter(tmp_path, join_type):
+    """PushdownStrategy::Map (hash_join/shared_bounds.rs:275-284, exec.rs:2727-2751; HashTableLookupExpr, partitioned_hash_eval.rs:278):
+    a build side beyond the IN-list limits pushes the built table itself.  300 keys in two far-apart clusters: their bounds cover
+    nearly every row group, the membership test — asked on each row group's key chunk before anything else is decoded — keeps the two
+    that hold them, and only the matching rows of those leave the scan.  Same join result."""
+    from datafusion_amd import physical_plan as P
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    from tests import plan_oracle
+    n = 60_000
+    probe = pa.table({"l_orderkey": pa.array(np.arange(n, dtype=np.int64) // 3), "l_qty": pa.array((np.arange(n) % 50).astype(np.int32)),
+                      "l_tag": pa.array([["a", "bb", "ccc"][i % 3] for i in range(n)], pa.string())})
+    path = str(tmp_path / "probe.parquet")
+    pq.write_table(probe, path, row_group_size=5_000, compression="snappy")
+    keys = list(range(1_000, 1_150)) + list(range(18_000, 18_150))
+    build = pa.table({"o_orderkey": pa.array(keys, pa.int64()), "o_flag": pa.array(np.arange(len(keys), dtype=np.int32))})
+    dev_build = DeviceTable.from_arrow(build)
+    scan = P.ParquetExec(path, ["l_orderkey", "l_qty", "l_tag"], "lineitem")
+    j = P.HashJoinExec(P.MemoryExec(dev_build, "orders"), scan, [("o_orderkey", "l_orderkey")], join_type)
+    got = P.collect(j).to_arrow()
+    exp = plan_oracle.collect(P.HashJoinExec(P.MemoryExec(build, "orders"), P.MemoryExec(probe, "lineitem"), [("o_orderkey", "l_orderkey")], join_type))
+    strings = lambda t: pa.table({c: (t.column(c).cast(pa.string()) if c == "l_tag" else t.column(c)) for c in t.column_names})
+    assert_tables_equal(strings(got), strings(exp), ordered=False)
+    m = scan.metrics
+    assert scan.dynamic_in_lists == {} and scan.dynamic_bounds == {"l_orderkey": (1_000, 18_149)} and "l_orderkey" in scan.dynamic_membership
+    assert m["row_groups_total"] == 12 and m["row_groups_read"] == 11            # the statistics drop one row group (keys >= 18 333)
+    assert m["row_groups_skipped_by_membership"] == 9 and m["rows_passed"] == 900 and m["rows_scanned"] == 55_000
+    # a FilterExec between the join and the scan, fused into the probe by the rule: still pushed down
+    scan2 = P.ParquetExec(path, ["l_orderkey", "l_qty", "l_tag"], "lineitem")
+    j2 = P.HashJoinExec(P.MemoryExec(dev_build, "orders"), P.FilterExec(col("l_qty") > lit(10, pa.int32()), scan2), [("o_orderkey", "l_orderkey")], join_type)
+    opt = P.GpuOffloadRule().optimize(P.AggregateExec("Single", [], [("count", None, "n")], j2))
+    n_rows = P.collect(opt).to_arrow().to_pylist()[0]["n"]
+    exp2 = plan_oracle.collect(P.HashJoinExec(P.MemoryExec(build, "orders"), P.FilterExec(col("l_qty") > lit(10, pa.int32()), P.MemoryExec(probe, "lineitem")),
+                                              [("o_orderkey", "l_orderkey")], join_type))
+    assert n_rows == exp2.num_rows and scan2.metrics["row_groups_skipped_by_membership"] == 9
+    # a second run of the same plan over a SMALL build side: the IN list takes over and the stale table is gone
+    small = DeviceTable.from_arrow(build.slice(0, 5))
+    j.left = P.MemoryExec(small, "orders")
+    P.collect(j)
+    assert scan.dynamic_membership == {} and scan.dynamic_in_lists == {"l_orderkey": list(range(1_000, 1_005))}
+
+
 def test_device_chunk_cache_serves_repeated_scans(tmp_path):
     """a second scan of the same file takes its column chunks from HBM (no decode); a rewritten file is a new identity; the
     byte budget evicts least recently used chunks"""
