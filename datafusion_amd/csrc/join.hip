@@ -254,6 +254,28 @@ __global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uin
     }
   }
 }
+// rank map build over keys in no order, without atomics: one BYTE per value of the range is set by a plain store (racing stores all
+// write 1; an agent-scope atomic per key — even fire-and-forget — retires at ~27 G/s on this part: 150 M keys = 5.6 ms), then the
+// bytes are packed to the bitmap (pack_bytes_to_bitmap: one ballot per 64 values)
+template <int KT, bool HASV>
+__global__ __launch_bounds__(BLOCK) void k_rank_setbytes(KeyCol k, int64_t n, uint64_t offset, uint8_t* __restrict__ bytes) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += stride * BUILD_UNROLL) {
+    uint64_t lo[BUILD_UNROLL];
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      const int64_t i = i0 + j * stride;
+      lo[j] = load_key<KT>(k, i < n ? i : n - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < BUILD_UNROLL; j++) {
+      const int64_t i = i0 + j * stride;
+      if (i >= n) continue;
+      if (HASV && !bit_at(k.valid, i)) continue;
+      bytes[lo[j] - offset] = 1;
+    }
+  }
+}
 // rank map build: {bitmap word, prefix} side by side for the probe
 __global__ __launch_bounds__(BLOCK) void k_rank_interleave(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ prefix, int64_t n_words, ulonglong2* __restrict__ tab) {
   for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * BLOCK) tab[w] = make_ulonglong2(bits[w], prefix[w]);
@@ -821,7 +843,17 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
         excl = lookback_exclusive(tile_state, tile, agg);
         if (lane == 0 && tile == n_tiles - 1) ctl->total = excl + agg;
       } else if (MODE == FUSED_PLACED) {
-        excl = tile_state[tile];  // exclusive prefix of k_join_tile_counts: the output is in probe order, allocation exact
+        if (tile_state) {
+          excl = tile_state[tile];  // exclusive prefix of k_join_tile_counts: the output is in probe order, allocation exact
+        } else {
+          // SPECULATION (join_probe): every probe row finds its key — a foreign key against its primary key — so row i of the
+          // output is probe row i and no counts pass is needed.  A tile that disagrees raises the flag; its rows stay inside its own
+          // range of the output, and the host starts over with the counts.
+          excl = (uint64_t)tile * (uint64_t)(TILE_WORDS * 64);
+          const int64_t left = np - tile * (int64_t)(TILE_WORDS * 64);
+          const uint64_t rows_here = (uint64_t)(left < (int64_t)(TILE_WORDS * 64) ? left : (int64_t)(TILE_WORDS * 64));
+          if (lane == 0 && agg != rows_here) ctl->ticket = 1u;
+        }
       } else if (lane == 0 && agg) {
         excl = atomicAdd(&ctl->total, (unsigned long long)agg);
       }
@@ -1260,6 +1292,20 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
         radix_group_keys(grouped_keys, nb, std::max(0, range_bits - 6), 6);
         kc0.data = grouped_keys->ptr;
       }
+      // many keys in no order: byte map + pack instead of one atomic per key (the byte map is a temporary of one byte per VALUE of
+      // the range: up to 4 GiB of it)
+      const bool byte_map = !ascending && nb > (1 << 20) && range < (1ull << 32) &&
+                            !(std::getenv("DFGPU_JOIN_BYTE_MAP") && std::getenv("DFGPU_JOIN_BYTE_MAP")[0] == '0');
+      if (byte_map) {
+        BufPtr bytes = make_zero_buf((size_t)n_words * 64);
+        with_key_type(kc0.type, [&](auto kt) {
+          constexpr int T = decltype(kt)::value;
+          if (kc0.valid) k_rank_setbytes<T, true><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bytes->as<uint8_t>());
+          else k_rank_setbytes<T, false><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bytes->as<uint8_t>());
+        });
+        DFGPU_HIP(hipGetLastError());
+        pack_bytes_to_bitmap(bytes->as<uint8_t>(), n_words * 64, jt->rank_bits->as<uint64_t>());
+      } else {
       with_key_type(kc0.type, [&](auto kt) {
         constexpr int T = decltype(kt)::value;
         // ascending implies no NULL keys
@@ -1267,6 +1313,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
         else if (kc0.valid) k_rank_setbits<T, true, false><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>());
         else k_rank_setbits<T, false, false><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>());
       });
+      }
     }
     jt->rank_prefix = make_buf((size_t)(n_words + 1) * 8);
     scan_mask_popcounts(jt->rank_bits->as<uint64_t>(), nullptr, n_words * 64, jt->rank_prefix->as<uint64_t>());
@@ -1477,6 +1524,21 @@ static bool probe_keys_clustered(const Column& kc, int64_t n) {
   return ascents * 10 >= S * 9;
 }
 
+// do 64 K evenly spaced probe rows ALL find their key?  (the speculation of the placed probe is only worth trying then)
+template <int KIND, int KT>
+__global__ __launch_bounds__(BLOCK) void k_sample_all_hit(ProbeCtx c, int64_t np, int64_t every_words, int samples, int* __restrict__ misses) {
+  const int64_t n_words = (np + 63) >> 6;
+  const int i = (int)(((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6);
+  if (i >= samples) return;
+  const int64_t w = (int64_t)i * every_words;
+  if (w >= n_words) return;
+  uint64_t word[1];
+  hit_words<KIND, KT, 1>(c, w, np, word);
+  const int64_t rem = np - (w << 6);
+  const uint64_t want = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+  if (lane_id() == 0 && (word[0] & want) != want) atomicAdd(misses, 1);
+}
+
 static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
                                     const std::vector<int>& pout, const dfgpu_join_filter* jfp);
 static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout_in,
@@ -1653,7 +1715,24 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     BufPtr ctl = make_zero_buf(sizeof(FusedCtl));
     BufPtr out_words;
     int64_t n_alloc = np;
-    if (fused_mode == FUSED_PLACED) {
+    // ---- speculation for the probe-order output: a foreign-key probe (every row finds its key) needs no counts pass — row i of
+    // the output IS probe row i.  64 K sampled rows that all hit make it worth trying; the kernel verifies every tile and the
+    // host starts over with the counts when one disagrees (the reference's order, exec.rs:3349, at the unordered flavour's cost)
+    static thread_local bool no_speculation = false;
+    bool speculate = false;
+    if (fused_mode == FUSED_PLACED && !listed && !row_mask && !invert && !no_speculation && np >= (1 << 22) && (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY) &&
+        !(std::getenv("DFGPU_JOIN_SPECULATE") && std::getenv("DFGPU_JOIN_SPECULATE")[0] == '0')) {
+      constexpr int S = 1024;  // sampled words
+      BufPtr miss = make_zero_buf(4);
+      with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
+        k_sample_all_hit<decltype(kd)::value, decltype(kt)::value><<<S * WAVE / BLOCK, BLOCK, 0, r.stream>>>(ctx, np, std::max<int64_t>(1, n_words / S), S, miss->as<int>());
+      });
+      DFGPU_HIP(hipGetLastError());
+      int m = 0;
+      d2h(&m, miss->ptr, 4);
+      speculate = m == 0;
+    }
+    if (fused_mode == FUSED_PLACED && !speculate) {
       // pass 1: output rows per tile (reads the probe keys only), then the tiles' exclusive prefix
       BufPtr counts = make_buf((size_t)n_tiles * 4);
       state = make_buf((size_t)(n_tiles + 1) * 8);
@@ -1732,6 +1811,31 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       DFGPU_HIP(hipGetLastError());
       if (r.profiling) DFGPU_HIP(hipEventRecord(eb, r.stream));
       if (fused_mode != FUSED_PLACED) n_out = (int64_t)read_u64(reinterpret_cast<const uint64_t*>(&ctl->as<FusedCtl>()->total));
+      if (speculate) {
+        unsigned missed = 0;
+        d2h(&missed, &ctl->as<FusedCtl>()->ticket, 4);
+        if (missed) {  // some probe row has no partner after all: the same probe again, counted
+          if (r.profiling) {
+            std::lock_guard<std::mutex> lk(r.mu);
+            r.recs.push_back(Runtime::Rec{"join_probe_speculation_missed", ea, eb, 0});
+          }
+          {
+            std::lock_guard<std::mutex> lk(jt.mu);
+            jt.info.probe_rows -= np;
+          }
+          out = Table{};
+          no_speculation = true;
+          Table again;
+          try {
+            again = join_probe(jt, probe, pk, join_type, bout_in, pout, row_mask, mask_consumed);
+          } catch (...) {
+            no_speculation = false;
+            throw;
+          }
+          no_speculation = false;
+          return again;
+        }
+      }
     } else if (r.profiling) {
       DFGPU_HIP(hipEventRecord(eb, r.stream));
     }

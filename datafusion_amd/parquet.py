@@ -44,14 +44,18 @@ class ChunkCache:
     288 GB of HBM hold TPC-H SF100's hot columns); a file that changed on disk has a new identity and its old chunks age out."""
 
     def __init__(self, budget: int | None = None):
+        import threading
         self.budget = int(os.environ.get("DFGPU_TABLE_CACHE_BYTES", 16 << 30)) if budget is None else budget
         self._h = None
+        self._make = threading.Lock()      # the scan's decode threads arrive together: ONE cache is made
 
     def _handle(self):
         if self._h is None:
-            h = C.c_void_p()
-            check(_lib.load().dfgpu_cache_create(C.c_int64(self.budget), C.byref(h)))
-            self._h = h
+            with self._make:
+                if self._h is None:
+                    h = C.c_void_p()
+                    check(_lib.load().dfgpu_cache_create(C.c_int64(self.budget), C.byref(h)))
+                    self._h = h
         return self._h
 
     @staticmethod

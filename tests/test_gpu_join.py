@@ -493,3 +493,36 @@ def test_key_only_probe_of_unordered_keys_is_grouped_by_key_range(join_type):
         assert np.array_equal(np.sort(outs[grouped]), exp), grouped
     if join_type == "Inner":
         assert not np.array_equal(outs["1"], outs["0"])       # the grouped flavour really ran: its rows come out in group order
+
+
+@pytest.mark.parametrize("dangling", [0, 3])
+def test_probe_order_speculation_every_row_finds_its_key(dangling):
+    """the probe-order (placed) flavour skips its counts pass when 64 K sampled probe rows all find their key and verifies the
+    assumption tile by tile while it writes: a foreign-key probe comes out in one pass; three dangling keys between the samples make
+    the kernel raise its flag and the host run the counted probe — same rows, same order, either way"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(31)
+    nb, npr = 500_000, 5_000_000
+    okeys = (np.arange(nb, dtype=np.int64) // 8) * 32 + np.arange(nb) % 8 + 1
+    fk = np.sort(rng.integers(0, nb, npr))
+    pk = okeys[fk].copy()
+    pay = rng.integers(0, 10**6, npr).astype(np.int64)
+    if dangling:
+        for pos in (70_001, 2_345_679, 4_999_998):       # none of them on a sampled word
+            pk[pos] = -5
+    build = DeviceTable.from_arrow(pa.table({"o_orderkey": pa.array(okeys), "o_flag": pa.array((np.arange(nb) % 7).astype(np.int32))}))
+    probe = DeviceTable.from_arrow(pa.table({"l_orderkey": pa.array(pk), "l_pay": pa.array(pay)}))
+    ops.profile_enable(True)
+    ops.profile_reset()
+    ht = ops.JoinHashTable(build, ["o_orderkey"], probe_mode=0)
+    out = ht.probe(probe, ["l_orderkey"], "Inner", ["o_flag"], ["l_orderkey", "l_pay"]).to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    ht.free()
+    keep = pk > 0
+    assert out.num_rows == int(keep.sum())
+    assert np.array_equal(out.column("l_orderkey").to_numpy(), pk[keep]) and np.array_equal(out.column("l_pay").to_numpy(), pay[keep])      # probe order
+    assert np.array_equal(out.column("o_flag").to_numpy(), (fk[keep] % 7).astype(np.int32))
+    assert ("join_probe_speculation_missed" in stats) == bool(dangling), sorted(stats)
+    assert ("join_probe_tile_counts" in stats) == bool(dangling)                                  # no counts pass when the speculation holds
