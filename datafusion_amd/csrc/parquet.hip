@@ -93,7 +93,7 @@ struct Thrift {
 };
 
 enum { PAGE_DATA = 0, PAGE_INDEX = 1, PAGE_DICTIONARY = 2, PAGE_DATA_V2 = 3 };
-enum { ENC_PLAIN = 0, ENC_PLAIN_DICTIONARY = 2, ENC_RLE = 3, ENC_BIT_PACKED = 4, ENC_RLE_DICTIONARY = 8 };
+enum { ENC_PLAIN = 0, ENC_PLAIN_DICTIONARY = 2, ENC_RLE = 3, ENC_BIT_PACKED = 4, ENC_DELTA_BINARY_PACKED = 5, ENC_RLE_DICTIONARY = 8, ENC_BYTE_STREAM_SPLIT = 9 };
 
 struct PageHeader {
   int type = -1;
@@ -272,6 +272,49 @@ void walk_runs(const uint8_t* p, const uint8_t* end, int bit_width, int64_t n, F
   }
 }
 
+// DELTA_BINARY_PACKED (Encodings.md "Delta Encoding"): <block size> <miniblocks per block> <total count> <first value (zigzag)>, then
+// per block <min delta (zigzag)> <one bit width per miniblock> <miniblocks: deltas - min delta, bit-packed LSB first>.  A value is
+// the running sum of the deltas, wrapping in the PHYSICAL type's width.  Decoded on the host into PLAIN little-endian values of
+// `pw` bytes (the value of a page depends on all before it: a scan per page; files that carry it are rare — pyarrow writes it only
+// on request) and staged like a PLAIN page.
+void decode_delta_binary_packed(const uint8_t* p, const uint8_t* end, int pw, int64_t n, uint8_t* out) {
+  Thrift t{p, end};
+  const uint64_t block = t.varint(), minis = t.varint(), total = t.varint();
+  DFGPU_CHECK(block > 0 && block % 128 == 0 && minis > 0 && block % minis == 0 && (block / minis) % 32 == 0, "parquet: malformed DELTA_BINARY_PACKED header");
+  DFGPU_CHECK((int64_t)total >= n, "parquet: DELTA_BINARY_PACKED page holds fewer values than its header says");
+  const uint64_t per_mini = block / minis;
+  uint64_t cur = (uint64_t)t.zigzag();
+  auto put = [&](int64_t i, uint64_t v) { std::memcpy(out + (size_t)i * pw, &v, (size_t)pw); };  // little endian: the low pw bytes (wraps)
+  int64_t done = 0;
+  if (n > 0) put(done++, cur);
+  while (done < n) {
+    const uint64_t min_delta = (uint64_t)t.zigzag();
+    DFGPU_CHECK((uint64_t)(t.end - t.p) >= minis, "parquet: DELTA_BINARY_PACKED block overruns its page");
+    const uint8_t* widths = t.p;
+    t.p += minis;
+    for (uint64_t m = 0; m < minis && done < n; m++) {
+      const int bw = widths[m];
+      DFGPU_CHECK(bw <= 64, "parquet: DELTA_BINARY_PACKED bit width");
+      const uint64_t bytes = per_mini * (uint64_t)bw / 8;
+      DFGPU_CHECK((uint64_t)(t.end - t.p) >= bytes, "parquet: DELTA_BINARY_PACKED miniblock overruns its page");
+      for (uint64_t i = 0; i < per_mini && done < n; i++) {
+        uint64_t d = 0;
+        const uint64_t bit = i * (uint64_t)bw;
+        for (int b = 0; b < bw; b++) d |= (uint64_t)((t.p[(bit + b) >> 3] >> ((bit + b) & 7)) & 1) << b;
+        cur += min_delta + d;
+        put(done++, cur);
+      }
+      t.p += bytes;
+    }
+  }
+}
+// BYTE_STREAM_SPLIT: byte k of value i at stream k * n + i
+void decode_byte_stream_split(const uint8_t* p, const uint8_t* end, int pw, int64_t n, uint8_t* out) {
+  DFGPU_CHECK(end - p >= n * pw, "parquet: BYTE_STREAM_SPLIT values overrun the page");
+  for (int k = 0; k < pw; k++)
+    for (int64_t i = 0; i < n; i++) out[(size_t)i * pw + k] = p[(size_t)k * n + i];
+}
+
 // a page of the chunk as the device sees it
 struct PageDesc {
   int64_t value_start;   // first non-null value of the page, chunk-wide
@@ -296,6 +339,7 @@ struct ChunkPlan {       // everything the host learns from one chunk
   std::vector<uint8_t> str_bytes;
   std::vector<int64_t> dict_src;       // the dictionary's strings in str_bytes
   std::vector<uint32_t> dict_len;
+  std::vector<uint8_t> bool_values;    // BOOLEAN: one byte per non-null value
 };
 
 void set_bits(std::vector<uint64_t>& bm, int64_t pos, int64_t n) {
@@ -321,6 +365,7 @@ int phys_width(const dfgpu_parquet_column& c) {
       DFGPU_CHECK(c.type_length >= 1 && c.type_length <= 16, "parquet: FIXED_LEN_BYTE_ARRAY longer than 16 bytes");
       return c.type_length;
     case DFGPU_PARQUET_BYTE_ARRAY: return 0;
+    case DFGPU_PARQUET_BOOLEAN: return 0;   // bit-packed
   }
   throw Error("parquet: physical type " + std::to_string(c.physical_type) + " is not supported on the GPU scan path");
 }
@@ -332,6 +377,7 @@ void check_target(const dfgpu_parquet_column& c) {
     case DFGPU_PARQUET_INT32: ok = t == DFGPU_INT32 || t == DFGPU_DATE32 || t == DFGPU_UINT8 || t == DFGPU_UINT32 || t == DFGPU_DECIMAL128; break;
     case DFGPU_PARQUET_INT64: ok = t == DFGPU_INT64 || t == DFGPU_UINT64 || t == DFGPU_DECIMAL128; break;
     case DFGPU_PARQUET_DOUBLE: ok = t == DFGPU_FLOAT64; break;
+    case DFGPU_PARQUET_BOOLEAN: ok = t == DFGPU_BOOL; break;
     case DFGPU_PARQUET_FIXED_LEN_BYTE_ARRAY: ok = t == DFGPU_DECIMAL128; break;
     case DFGPU_PARQUET_BYTE_ARRAY: ok = t == DFGPU_INT32 || t == DFGPU_UTF8; break;   // dictionary indices of a string column, or the strings
   }
@@ -496,6 +542,50 @@ ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_c
         throw Error("parquet: value encoding " + std::to_string(h.encoding) + " is not supported on the GPU scan path");
       }
       d.kind = 2;
+      P.pages.push_back(d);
+      P.rows += h.num_values;
+      P.values += nonnull;
+      continue;
+    }
+    if (col.physical_type == DFGPU_PARQUET_BOOLEAN) {
+      // BOOLEAN: PLAIN = one bit per value, LSB first; RLE (data page v2, and v1 of newer writers) = <4-byte length> hybrid runs of
+      // bit width 1.  Kept as one byte per non-null value here; the column's bitmap is assembled once all pages are in.
+      const size_t at = P.bool_values.size();
+      P.bool_values.resize(at + (size_t)nonnull);
+      if (h.encoding == ENC_PLAIN) {
+        DFGPU_CHECK((values_end - values) * 8 >= nonnull, "parquet: PLAIN BOOLEAN values overrun the page");
+        for (int64_t i = 0; i < nonnull; i++) P.bool_values[at + (size_t)i] = (values[i >> 3] >> (i & 7)) & 1;
+        P.info.n_plain_pages++;
+      } else if (h.encoding == ENC_RLE) {
+        DFGPU_CHECK(values_end - values >= 4, "parquet: RLE BOOLEAN page without its length");
+        uint32_t lb;
+        std::memcpy(&lb, values, 4);
+        DFGPU_CHECK((int64_t)lb <= values_end - values - 4, "parquet: RLE BOOLEAN values overrun the page");
+        int64_t i = 0;
+        walk_runs(values + 4, values + 4 + lb, 1, nonnull, [&](bool packed, int64_t cnt, uint64_t val, const uint8_t* bits) {
+          for (int64_t k = 0; k < cnt; k++) P.bool_values[at + (size_t)(i + k)] = packed ? ((bits[k >> 3] >> (k & 7)) & 1) : (uint8_t)(val & 1);
+          i += cnt;
+          (packed ? P.info.n_runs_bitpacked : P.info.n_runs_rle)++;
+        });
+      } else {
+        throw Error("parquet: BOOLEAN value encoding " + std::to_string(h.encoding) + " is not supported on the GPU scan path");
+      }
+      d.kind = 3;
+      P.pages.push_back(d);
+      P.rows += h.num_values;
+      P.values += nonnull;
+      continue;
+    }
+    if (h.encoding == ENC_DELTA_BINARY_PACKED || h.encoding == ENC_BYTE_STREAM_SPLIT) {
+      DFGPU_CHECK(pw == 4 || pw == 8 || (h.encoding == ENC_BYTE_STREAM_SPLIT && pw > 0), "parquet: value encoding " + std::to_string(h.encoding) + " on this physical type");
+      DFGPU_CHECK(h.encoding == ENC_BYTE_STREAM_SPLIT || col.physical_type == DFGPU_PARQUET_INT32 || col.physical_type == DFGPU_PARQUET_INT64,
+                  "parquet: DELTA_BINARY_PACKED on a non-integer column");
+      P.staging.resize(base + (size_t)(nonnull * pw));
+      if (h.encoding == ENC_DELTA_BINARY_PACKED) decode_delta_binary_packed(values, values_end, pw, nonnull, P.staging.data() + base);
+      else decode_byte_stream_split(values, values_end, pw, nonnull, P.staging.data() + base);
+      d.kind = 0;   // staged as PLAIN
+      d.byte_offset = (int64_t)base;
+      P.info.n_plain_pages++;
       P.pages.push_back(d);
       P.rows += h.num_values;
       P.values += nonnull;
@@ -756,9 +846,35 @@ Column decode_string_chunk(ChunkPlan& P, const dfgpu_parquet_column& col) {
   return c;
 }
 
+// BOOLEAN chunk -> bit-packed column: the dense values are spread over the NULL rows on the host (a bit per row: the whole column
+// is rows / 8 bytes)
+Column decode_bool_chunk(const ChunkPlan& P, const dfgpu_parquet_column& col) {
+  hipStream_t st = rt().stream;
+  dfgpu_field f = col.field;
+  f.nullable = col.max_definition_level ? 1 : 0;
+  Column c = alloc_column(f, col.name ? col.name : "", P.rows);
+  DFGPU_CHECK((int64_t)P.bool_values.size() == P.values, "parquet: BOOLEAN value count mismatch");
+  std::vector<uint64_t> bits((size_t)((P.rows + 63) / 64) + 1, 0ull);
+  int64_t v = 0;
+  for (int64_t r = 0; r < P.rows; r++) {
+    if (!P.validity.empty() && !((P.validity[(size_t)r >> 6] >> (r & 63)) & 1)) continue;
+    if (P.bool_values[(size_t)v++]) bits[(size_t)r >> 6] |= 1ull << (r & 63);
+  }
+  const size_t bb = bitmap_bytes(P.rows);
+  if (bb) DFGPU_HIP(hipMemcpyAsync(c.data->ptr, bits.data(), bb, hipMemcpyHostToDevice, st));
+  if (!P.validity.empty()) {
+    c.validity = make_buf(bb);
+    c.null_count = P.rows - P.values;
+    DFGPU_HIP(hipMemcpyAsync(c.validity->ptr, P.validity.data(), bb, hipMemcpyHostToDevice, st));
+  }
+  DFGPU_HIP(hipStreamSynchronize(st));
+  return c;
+}
+
 Column decode_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_column& col) {
   ChunkPlan P = plan_chunk(chunk, nbytes, col);
   if (col.field.type == DFGPU_UTF8) return decode_string_chunk(P, col);
+  if (col.physical_type == DFGPU_PARQUET_BOOLEAN) return decode_bool_chunk(P, col);
   hipStream_t st = rt().stream;
   dfgpu_field f = col.field;
   f.nullable = col.max_definition_level ? 1 : 0;

@@ -52,6 +52,30 @@ def test_decimals_stored_as_integers_and_column_projection(tmp_path):
     assert_tables_equal(read_table(path, ["k", "d9"]).to_arrow(), t.select(["k", "d9"]), ordered=True)
 
 
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+@pytest.mark.parametrize("compression", ["none", "snappy", "zstd"])
+def test_delta_byte_stream_split_and_boolean_pages(tmp_path, compression, version):
+    """the encodings beyond PLAIN / dictionary: DELTA_BINARY_PACKED (Int32 / Int64 / Date32 incl. wrapping deltas and NULLs),
+    BYTE_STREAM_SPLIT (Float64), BOOLEAN columns (PLAIN bits in v1 pages, RLE runs in v2) — against pyarrow's reader"""
+    from datafusion_amd.parquet import read_table
+    rng = np.random.default_rng(11)
+    n = 50_003
+    wide = rng.integers(-2**62, 2**62, n)
+    wide[:4] = [np.iinfo(np.int64).max, np.iinfo(np.int64).min, 0, -1]                            # deltas that wrap
+    t = pa.table({"d64": pa.array(np.cumsum(rng.integers(-3, 50, n)).astype(np.int64)), "wide": pa.array(wide),
+                  "d32": pa.array(rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)), "d32n": pa.array(rng.integers(0, 1000, n).astype(np.int32), mask=rng.random(n) < 0.3),
+                  "dt": pa.array(np.sort(rng.integers(8000, 10000, n)).astype(np.int32), pa.int32()).cast(pa.date32()),
+                  "f": pa.array(rng.normal(size=n)), "fn": pa.array(rng.random(n), mask=rng.random(n) < 0.2),
+                  "b": pa.array(rng.random(n) < 0.5), "bn": pa.array(rng.random(n) < 0.1, mask=rng.random(n) < 0.25), "runs": pa.array(np.repeat([True, False, True], [20_000, 20_000, 10_003]))})
+    path = str(tmp_path / "e.parquet")
+    pq.write_table(t, path, compression=compression, data_page_version=version, use_dictionary=False, data_page_size=16 * 1024, row_group_size=21_000,
+                   column_encoding={"d64": "DELTA_BINARY_PACKED", "wide": "DELTA_BINARY_PACKED", "d32": "DELTA_BINARY_PACKED", "d32n": "DELTA_BINARY_PACKED", "dt": "DELTA_BINARY_PACKED",
+                                    "f": "BYTE_STREAM_SPLIT", "fn": "BYTE_STREAM_SPLIT", "b": "PLAIN", "bn": "PLAIN", "runs": "PLAIN" if version == "1.0" else "RLE"})
+    got = read_table(path).to_arrow()
+    assert_tables_equal(got, pq.read_table(path), ordered=True)
+    assert got.column("bn").null_count == t.column("bn").null_count and got.schema.field("b").type == pa.bool_()
+
+
 def test_q6_straight_from_a_parquet_file(tmp_path):
     """dbgen lineitem -> Parquet (ZSTD, the reference's benchmark setting) -> device -> the reference's Q6 plan -> the reference's answer"""
     from datafusion_amd import physical_plan as P, tpch_plans as T
