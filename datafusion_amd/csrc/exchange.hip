@@ -760,6 +760,30 @@ int dfgpu_exchange_broadcast(dfgpu_comm_t h, const dfgpu_table_t* inputs, dfgpu_
   });
 }
 
+// CollectLeft with build-side emission across ranks: OR of the visited marks (and null-aware flags) of the replicated join tables
+int dfgpu_exchange_join_visited(dfgpu_comm_t h, const dfgpu_join_t* joins) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(h && joins, "null argument");
+    Comm& c = *reinterpret_cast<Comm*>(h);
+    const int L = c.n_local();
+    std::vector<std::vector<uint8_t>> mine((size_t)L);
+    for (int l = 0; l < L; l++) {
+      DFGPU_CHECK(joins[l] != nullptr, "null join table");
+      mine[(size_t)l] = join_visited_export(joins[l]);
+    }
+    const std::vector<std::vector<uint8_t>> all = allgather_blobs(c, mine);
+    std::vector<uint8_t> merged = all[0];
+    for (int r = 1; r < c.world; r++) {
+      DFGPU_CHECK(all[(size_t)r].size() == merged.size(), "join visited merge: the ranks' build sides differ in size (the build side must be replicated)");
+      for (size_t i = 0; i < merged.size(); i++) merged[i] |= all[(size_t)r][i];
+    }
+    for (int l = 0; l < L; l++) join_visited_merge(joins[l], merged.data(), merged.size());
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.stats.collectives += 1;
+  });
+}
+
 int dfgpu_exchange_broadcast_pruned(dfgpu_comm_t h, const dfgpu_table_t* builds, int build_key, const dfgpu_table_t* probes, int probe_key,
                                     dfgpu_table_t* outs) {
   return guarded([&] {

@@ -353,6 +353,10 @@ void bitmap_place(const uint64_t* src, int64_t off, int64_t n, uint64_t* dst);
 // min / max / non-null count / strictly-ascending flag of an integer column, cached on the column
 ColStats column_stats(Column& c, int64_t nrows);
 
+// ----------------------------------------------------------------- visited marks of a replicated build side (join.hip)
+std::vector<uint8_t> join_visited_export(dfgpu_join_t h);                       // one bit per build row + 8 bytes of null-aware flags
+void join_visited_merge(dfgpu_join_t h, const uint8_t* merged, size_t nbytes);  // OR into the table's marks
+
 // ----------------------------------------------------------------- radix passes (sort.hip)
 // (key u64, row id u32) pairs stably sorted by bits [lo_bit, lo_bit + nbits) of the key; `idx` null on entry = row id is the position
 void radix_sort_pairs(BufPtr& key, BufPtr& idx, int64_t n, int lo_bit, int nbits);

@@ -2466,6 +2466,54 @@ int dfgpu_join_contains(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_k
   });
 }
 
+}  // extern "C"
+
+// ---- the visited marks of a REPLICATED build side across ranks (exchange.hip dfgpu_exchange_join_visited): CollectLeft with
+// build-side emission, the probe partitions on different GPUs.  In the reference all probe partitions mark ONE bitmap
+// (hash_join/exec.rs:1312-1330); here every rank marks its copy, the copies are OR-ed, and the last step — reporting build rows by
+// their marks — sees the union everywhere.  One bit per build row, then the null-aware flags (probe_side_has_null, non_empty).
+namespace dfgpu {
+__global__ __launch_bounds__(BLOCK) void k_visited_or_bits(const uint64_t* __restrict__ bits, int64_t n, uint8_t* __restrict__ visited) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+    if ((bits[i >> 6] >> (i & 63)) & 1ull) visited[i] = 1;
+}
+std::vector<uint8_t> join_visited_export(dfgpu_join_t h) {
+  JoinTable* jt = unwrap_join(h);
+  const int64_t nb = jt->build.nrows;
+  const size_t bb = bitmap_bytes(nb);
+  std::vector<uint8_t> out(bb + 8, 0);
+  {
+    std::lock_guard<std::mutex> lk(jt->mu);
+    if (!jt->visited) jt->visited = make_zero_buf((size_t)nb + 64);
+  }
+  if (nb) {
+    BufPtr bits = make_buf(bb);
+    pack_bytes_to_bitmap(jt->visited->as<uint8_t>(), nb, bits->as<uint64_t>());
+    d2h(out.data(), bits->ptr, bb);
+  }
+  out[bb] = jt->probe_side_has_null ? 1 : 0;
+  out[bb + 1] = jt->probe_side_non_empty ? 1 : 0;
+  return out;
+}
+void join_visited_merge(dfgpu_join_t h, const uint8_t* merged, size_t nbytes) {
+  JoinTable* jt = unwrap_join(h);
+  const int64_t nb = jt->build.nrows;
+  const size_t bb = bitmap_bytes(nb);
+  DFGPU_CHECK(nbytes == bb + 8, "join visited merge: the ranks' build sides differ in size (the build side must be replicated)");
+  if (nb) {
+    BufPtr bits = make_buf(bb);
+    h2d_async(bits->ptr, merged, bb);
+    k_visited_or_bits<<<grid_for(nb, BLOCK), BLOCK, 0, rt().stream>>>(bits->as<uint64_t>(), nb, jt->visited->as<uint8_t>());
+    DFGPU_HIP(hipGetLastError());
+    DFGPU_HIP(hipStreamSynchronize(rt().stream));  // `merged` is the caller's
+  }
+  jt->probe_side_has_null = jt->probe_side_has_null || merged[bb] != 0;
+  jt->probe_side_non_empty = jt->probe_side_non_empty || merged[bb + 1] != 0;
+}
+}  // namespace dfgpu
+
+extern "C" {
+
 int dfgpu_join_get_info(dfgpu_join_t ht, dfgpu_join_info* out) {
   return guarded([&] { *out = reinterpret_cast<JoinTable*>(ht)->info; });
 }

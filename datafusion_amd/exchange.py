@@ -103,6 +103,12 @@ class Comm:
         return self._call(_lib.load().dfgpu_exchange_broadcast_pruned, (C.c_void_p * 1)(build.handle), build.index_of(build_key),
                           (C.c_void_p * 1)(probe.handle), probe.index_of(probe_key))
 
+    def merge_join_visited(self, ht):
+        """OR of the visited marks (and null-aware flags) of a replicated build side's join tables across the ranks
+        (dfgpu_exchange_join_visited): after it, emit_unmatched reports the same rows everywhere"""
+        from . import _lib
+        _lib.check(_lib.load().dfgpu_exchange_join_visited(self._h, (C.c_void_p * 1)(ht._h)))
+
     def stats(self, reset=False) -> dict:
         from . import _lib
         st = _lib.ExchangeStats()

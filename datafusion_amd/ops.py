@@ -147,12 +147,7 @@ def hash_join(left: DeviceTable, right: DeviceTable, on, join_type="Inner", null
     ht = JoinHashTable(left, [l for l, _ in on], null_equality, **build_opts)
     out = ht.probe(right, [r for _, r in on], join_type, build_cols, probe_cols, join_filter=join_filter)
     if join_type in ("Left", "Full", "LeftSemi", "LeftAnti", "LeftMark"):
-        psch = None
-        if join_type in ("Left", "Full"):
-            rs = right.schema
-            pnames = rs.names if probe_cols is None else [right.column_names[right.index_of(c)] for c in probe_cols]
-            psch = pa.schema([rs.field(rs.get_field_index(n)) if rs.names.count(n) == 1 else rs.field(right.index_of(n)) for n in pnames])
-        tail = ht.emit_unmatched(join_type, build_cols, psch)
+        tail = ht.emit_unmatched(join_type, build_cols, tail_probe_schema(right, join_type, probe_cols))
         if join_type in ("Left", "Full"):
             # concat needs equal nullability handling: go through the generic concat
             out = concat_tables([out, tail])
@@ -160,6 +155,15 @@ def hash_join(left: DeviceTable, right: DeviceTable, on, join_type="Inner", null
             out = tail
     ht.free()
     return out
+
+
+def tail_probe_schema(right: DeviceTable, join_type, probe_cols=None):
+    """the NULL-filled probe columns of the unmatched build rows of Left / Full joins (dfgpu_join_emit_unmatched's probe_fields)"""
+    if join_type not in ("Left", "Full"):
+        return None
+    rs = right.schema
+    pnames = rs.names if probe_cols is None else [right.column_names[right.index_of(c)] for c in probe_cols]
+    return pa.schema([rs.field(rs.get_field_index(n)) if rs.names.count(n) == 1 else rs.field(right.index_of(n)) for n in pnames])
 
 
 def concat_tables(parts) -> DeviceTable:

@@ -392,26 +392,33 @@ class HashJoinExec(ExecutionPlan):
             shared_build = self.join_type in self._BUILD_EMITTING and replicated_build(self.left)
             if shared_build:
                 # PartitionMode::CollectLeft with build-side emission: the reference's probe partitions mark ONE shared visited bitmap
-                # and the last of them reports the unmatched build rows (hash_join/exec.rs:1312-1330, stream.rs ProcessUnmatchedBuild).
-                # Here the probe partitions sit on different GPUs and the build side is replicated: the probe side is gathered as
-                # well, every rank computes the same join and keeps its slice of the rows — without this every rank would report the
-                # build rows unmatched by ITS probe rows
-                from .exchange import broadcast_table
-                pg = broadcast_table(p)
-                if pg is not p:
-                    if po:
-                        p.free()
-                    p, po = pg, True
-            out = ops.hash_join(b, p, self.on, self.join_type, self.null_equality, bc, pc, join_filter=self.filter, null_aware=self.null_aware)
+                # and the last of them reports the build rows (hash_join/exec.rs:1312-1330, stream.rs ProcessUnmatchedBuild).  Here the
+                # probe partitions sit on different GPUs and the build side is replicated: every rank probes ITS probe rows, the copies'
+                # visited marks (and null-aware flags) are OR-ed across the ranks (dfgpu_exchange_join_visited), and the build rows the
+                # marks select — the same on every rank, in build-row order — are split by position.  Nothing is computed twice, and
+                # no rank depends on the order another rank's atomics built its chains in.
+                import torch.distributed as dist
+
+                from .exchange import comm_for
+                ht = ops.JoinHashTable(b, [l for l, _ in self.on], self.null_equality, null_aware=self.null_aware)
+                matched = ht.probe(p, [r for _, r in self.on], self.join_type, bc, pc, join_filter=self.filter)
+                comm_for().merge_join_visited(ht)
+                tail = ht.emit_unmatched(self.join_type, bc, ops.tail_probe_schema(p, self.join_type, pc))
+                n, world, rank = tail.num_rows, dist.get_world_size(), dist.get_rank()
+                mine = tail.slice(n * rank // world, n * (rank + 1) // world - n * rank // world)
+                tail.free()
+                if self.join_type in ("Left", "Full"):
+                    out = ops.concat_tables([matched, mine])
+                    mine.free()
+                else:
+                    out = mine
+                matched.free()
+                ht.free()
+            else:
+                out = ops.hash_join(b, p, self.on, self.join_type, self.null_equality, bc, pc, join_filter=self.filter, null_aware=self.null_aware)
             for t, o in ((b, bo), (p, po)):
                 if o:
                     t.free()
-            if shared_build:
-                import torch.distributed as dist
-                n, world, rank = out.num_rows, dist.get_world_size(), dist.get_rank()
-                mine = out.slice(n * rank // world, n * (rank + 1) // world - n * rank // world)
-                out.free()
-                out = mine
             return out
         b, bo = self._run_child(self.left)
         ht = ops.JoinHashTable(b, [l for l, _ in self.on], self.null_equality, probe_mode=self.probe_mode, null_aware=self.null_aware)

@@ -645,6 +645,13 @@ int dfgpu_exchange_broadcast(dfgpu_comm_t comm, const dfgpu_table_t* inputs, dfg
  * of range-partitioned data) move almost nothing; uniformly spread keys degrade to the full all-gather.  Integer keys. */
 int dfgpu_exchange_broadcast_pruned(dfgpu_comm_t comm, const dfgpu_table_t* builds, int build_key, const dfgpu_table_t* probes, int probe_key,
                                     dfgpu_table_t* outs);
+/* PartitionMode::CollectLeft with build-side emission (Left / Full / LeftSemi / LeftAnti / LeftMark) when the probe partitions sit on
+ * different GPUs: in the reference they all mark ONE visited bitmap and the last of them reports the build rows
+ * (hash_join/exec.rs:1312-1330).  Here every rank probes ITS probe partition against its copy of the replicated build side
+ * (dfgpu_exchange_broadcast), then this collective ORs the copies' visited marks (and the null-aware flags) so that
+ * dfgpu_join_emit_unmatched sees the union — the same rows on every rank, of which rank r keeps its share by build-row position.
+ * joins[l] = the table of local rank l; all build sides must hold the same rows. */
+int dfgpu_exchange_join_visited(dfgpu_comm_t comm, const dfgpu_join_t* joins);
 /* what crossed GPU boundaries since the communicator was created / last reset (summed over this process's local ranks) */
 typedef struct dfgpu_exchange_stats {
   int64_t bytes_sent_to_peers, bytes_received_from_peers;
