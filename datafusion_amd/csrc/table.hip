@@ -926,7 +926,31 @@ int dfgpu_table_concat(const dfgpu_table_t* parts, int nparts, dfgpu_table_t* ou
         continue;
       }
       Column n = alloc_like(fc, total);
-      DFGPU_CHECK(fc.field.type != DFGPU_BOOL, "concat: Boolean columns not supported yet");
+      if (fc.field.type == DFGPU_BOOL) {
+        // bit-packed values: every part's bits are placed at its bit offset, exactly as the validity bitmaps are
+        DFGPU_HIP(hipMemsetAsync(n.data->ptr, 0, bitmap_bytes(total) ? bitmap_bytes(total) : 1, rt().stream));
+        bool nulls = false;
+        for (int p = 0; p < nparts; p++) nulls |= unwrap(parts[p])->cols[ci].validity != nullptr;
+        if (nulls) {
+          n.validity = make_zero_buf(bitmap_bytes(total));
+          n.null_count = -1;
+        }
+        int64_t at = 0;
+        for (int p = 0; p < nparts; p++) {
+          Table* t = unwrap(parts[p]);
+          const Column& c = t->cols[ci];
+          DFGPU_CHECK(c.field.type == DFGPU_BOOL, "concat: column type mismatch");
+          if (t->nrows) {
+            const int g = grid_for((t->nrows + 127) / 64, BLOCK);
+            k_bitmap_place<<<g, BLOCK, 0, rt().stream>>>((const uint64_t*)c.ptr(), at, t->nrows, (unsigned long long*)n.data->ptr);
+            if (nulls) k_bitmap_place<<<g, BLOCK, 0, rt().stream>>>(c.valid_words(), at, t->nrows, (unsigned long long*)n.validity->ptr);
+          }
+          at += t->nrows;
+        }
+        DFGPU_HIP(hipGetLastError());
+        o->cols.push_back(std::move(n));
+        continue;
+      }
       int w = type_width(fc.field.type);
       int64_t off = 0;
       bool any_nulls = false;

@@ -703,6 +703,22 @@ typedef struct dfgpu_parquet_chunk_info {
 } dfgpu_parquet_chunk_info;
 int dfgpu_parquet_inspect_chunk(const uint8_t* chunk, int64_t chunk_bytes, const dfgpu_parquet_column* column, dfgpu_parquet_chunk_info* out);
 
+/* Arrow IPC files and streams (DataSourceExec over an ArrowSource, datasource-arrow/src/source.rs:260-330: arrow-ipc FileReader /
+ * StreamReader) scanned straight into HBM.  The file already holds Arrow buffers: dfgpu_ipc_open walks the encapsulated messages of
+ * the bytes it is given (a memory-mapped file; they must stay valid until dfgpu_ipc_close) — schema, dictionary batches, record
+ * batches — without copying anything and without a GPU; dfgpu_ipc_read_batch lays Arrow C Data structs over the bytes of batch `i`,
+ * the projected columns only (columns == NULL: all), undoes per-buffer compression (ZSTD; LZ4_FRAME when liblz4 is present) and
+ * imports them like dfgpu_table_import (pinned side-stream copies).  Flat columns of the device's types, Utf8 / LargeUtf8 /
+ * Utf8View and dictionary-encoded strings; nested columns, delta dictionaries, big-endian files are errors (the rule keeps the CPU
+ * scan).  dfgpu_ipc_column: `format` is the Arrow C Data format string of the column's VALUE type ("l", "d:15,2", "u" ...). */
+typedef struct dfgpu_ipc_s* dfgpu_ipc_t;
+int dfgpu_ipc_open(const uint8_t* data, int64_t nbytes, dfgpu_ipc_t* out);
+int dfgpu_ipc_close(dfgpu_ipc_t f);
+int dfgpu_ipc_info(dfgpu_ipc_t f, int64_t* n_batches, int32_t* n_columns, int32_t* is_file_format);
+int dfgpu_ipc_column(dfgpu_ipc_t f, int32_t i, const char** name, const char** format, int32_t* nullable, int32_t* dictionary_encoded);
+int dfgpu_ipc_batch_rows(dfgpu_ipc_t f, int64_t i, int64_t* rows);
+int dfgpu_ipc_read_batch(dfgpu_ipc_t f, int64_t i, const int* columns, int ncols, dfgpu_table_t* out);
+
 /* ------------------------------------------------------ synthetic workload */
 
 /* Deterministic TPC-H-shaped generator (counter-based PRNG, any slice

@@ -1,6 +1,8 @@
 """Scan -> device on the GPU: every column chunk of files written by pyarrow — three codecs x data page
 v1 / v2 x dictionary on / off, small pages, several row groups, NULLs — decoded by dfgpu_parquet_decode_chunk and compared
 with pyarrow's own reader (an independent production decoder of the same bytes), bit for bit."""
+import ctypes.util  # noqa: F401
+
 import numpy as np
 import pyarrow as pa
 import pyarrow.parquet as pq
@@ -290,6 +292,35 @@ def test_arrow_ipc_scan(tmp_path, fmt):
     finally:
         P.CACHE.clear()
         P.CACHE = saved
+
+
+@pytest.mark.parametrize("compression", [None, "zstd", "lz4"])
+@pytest.mark.parametrize("fmt", ["file", "stream"])
+def test_arrow_ipc_reader_below_the_c_abi_every_type(tmp_path, fmt, compression):
+    """dfgpu_ipc_open / dfgpu_ipc_read_batch (csrc/ipc.hip) over every column type the device knows — integers, Float64, Date32, Decimal128,
+    Boolean, Utf8 / LargeUtf8 / Utf8View, dictionary-encoded strings, NULLs — in both framings and with compressed buffers, batch by
+    batch and with a projection, against the table pyarrow wrote"""
+    import ctypes as C
+
+    from datafusion_amd import _lib
+    from datafusion_amd.ipc import IpcFile, read_table
+    from tests.test_ipc_host import sample, write
+    t = sample(10_001)
+    path = str(tmp_path / "t.arrow")
+    write(t, path, fmt, compression)
+    import ctypes.util
+    if compression == "lz4" and not ctypes.util.find_library("lz4"):
+        with pytest.raises(_lib.DfgpuError, match="liblz4"):
+            read_table(path)
+        return
+    norm = lambda x: pa.table({n: (c.cast(pa.string()) if (pa.types.is_dictionary(c.type) or c.type in (pa.large_string(), pa.string_view())) else c)
+                               for n, c in zip(x.column_names, x.columns)})
+    got = read_table(path).to_arrow()
+    assert_tables_equal(norm(got), norm(t), ordered=True)
+    f = IpcFile(path)
+    b1 = f.read_batch(1, ["dec", "sv", "b", "dict"]).to_arrow()
+    assert_tables_equal(norm(b1), norm(t.slice(4000, 4000).select(["dec", "sv", "b", "dict"])), ordered=True)
+    f.close()
 
 
 def test_parquet_chunk_with_dictionary_fallback_pages(tmp_path):
