@@ -343,6 +343,10 @@ struct Aggregate {
   int64_t fused_updates = 0;         // updates that took the fused (rowprog) path
   std::vector<uint8_t> utf8_key;     // group key g arrived as a Utf8 column: interned on entry, decoded again on emit
   bool touched = false;              // an update ran: the state is bound to its device
+  // grouping sets (PhysicalGroupBy::groups, aggregates/mod.rs:400-520): one aggregate per set — the set's NULLed-out key
+  // expressions replaced by the typed NULL literals, `__grouping_id` appended as a literal key — updated together, emitted
+  // one after the other.  Empty for a plain GROUP BY.
+  std::vector<std::unique_ptr<Aggregate>> sets;
   bool final_mode() const { return mode == DFGPU_AGG_FINAL || mode == DFGPU_AGG_FINAL_PARTITIONED; }
   bool partial_out() const { return mode == DFGPU_AGG_PARTIAL; }
 };
@@ -3013,10 +3017,59 @@ int dfgpu_agg_create(int mode, const dfgpu_expr* group_by, const char* const* gr
   });
 }
 
+// GROUPING SETS / CUBE / ROLLUP (PhysicalGroupBy with several groups, aggregates/mod.rs:400-520; merge_expressions / group_schema
+// :700-760): the reference evaluates every grouping set's keys — expr where the set keeps the column, the typed NULL of `null_expr`
+// where it does not, plus `__grouping_id` (bit n-1-i set = column i is NULLed out; UInt8 / 16 / 32 / 64 by the number of
+// columns) — and interns them into ONE table.  Here every set is an aggregate of its own over the same input (their group spaces are
+// disjoint: the grouping id differs), updated together and emitted set after set; output columns and types are the reference's.
+int dfgpu_agg_create_grouping_sets(int mode, const dfgpu_expr* group_by, const dfgpu_expr* null_by, const char* const* group_names, int n_group,
+                                   const uint8_t* groups, int n_sets, const dfgpu_agg_spec* aggs, int n_aggs, dfgpu_agg_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(mode == DFGPU_AGG_PARTIAL || mode == DFGPU_AGG_SINGLE || mode == DFGPU_AGG_SINGLE_PARTITIONED,
+                "grouping sets: Final modes group by the partial state's key columns (the n_group keys and __grouping_id): use dfgpu_agg_create");
+    DFGPU_CHECK(group_by && null_by && groups && n_group >= 1 && n_group <= 63 && n_sets >= 1 && out, "grouping sets: bad argument");
+    auto top = std::make_unique<Aggregate>();
+    top->mode = mode;
+    const int id_type = n_group <= 8 ? DFGPU_UINT8 : n_group <= 32 ? DFGPU_UINT32 : DFGPU_UINT64;  // Aggregate::grouping_id_type (no UInt16 on the device: widened)
+    for (int s = 0; s < n_sets; s++) {
+      std::vector<dfgpu_expr> keys((size_t)n_group + 1);
+      std::vector<const char*> names((size_t)n_group + 1);
+      uint64_t id = 0;
+      for (int g = 0; g < n_group; g++) {
+        const bool nulled = groups[(size_t)s * n_group + g] != 0;
+        keys[(size_t)g] = nulled ? null_by[g] : group_by[g];
+        if (nulled) {
+          DFGPU_CHECK(null_by[g].n_nodes >= 1 && null_by[g].nodes[null_by[g].root].op == DFGPU_EXPR_LITERAL && null_by[g].nodes[null_by[g].root].is_null,
+                      "grouping sets: null_by must hold typed NULL literals");
+          id |= 1ull << (n_group - 1 - g);
+        }
+        names[(size_t)g] = group_names && group_names[g] ? group_names[g] : "";
+      }
+      dfgpu_expr_node idn{};
+      idn.op = DFGPU_EXPR_LITERAL;
+      idn.column = -1;
+      idn.left = idn.right = -1;
+      idn.field.type = id_type;
+      idn.lit_lo = id;
+      keys[(size_t)n_group] = dfgpu_expr{&idn, 1, 0, nullptr};
+      names[(size_t)n_group] = "__grouping_id";
+      dfgpu_agg_t sub = nullptr;
+      if (dfgpu_agg_create(mode, keys.data(), names.data(), n_group + 1, aggs, n_aggs, &sub) != 0) throw Error(dfgpu_last_error());
+      top->sets.emplace_back(reinterpret_cast<Aggregate*>(sub));
+    }
+    *out = reinterpret_cast<dfgpu_agg_t>(top.release());
+  });
+}
+
 int dfgpu_agg_update(dfgpu_agg_t h, dfgpu_table_t input) {
   return guarded([&] {
     require_init();
     Aggregate* a = unwrap_agg(h);
+    if (!a->sets.empty()) {
+      for (auto& s : a->sets) agg_update(*s, agg_input(*s, input));
+      return;
+    }
     agg_update(*a, agg_input(*a, input));
   });
 }
@@ -3025,6 +3078,10 @@ int dfgpu_agg_update_filtered(dfgpu_agg_t h, dfgpu_table_t input, const dfgpu_ex
   return guarded([&] {
     require_init();
     Aggregate* a = unwrap_agg(h);
+    if (!a->sets.empty()) {
+      for (auto& s : a->sets) agg_update(*s, agg_input(*s, input), predicate);
+      return;
+    }
     agg_update(*a, agg_input(*a, input), predicate);
   });
 }
@@ -3040,7 +3097,23 @@ int dfgpu_set_fusion(int on) {
 int dfgpu_agg_emit(dfgpu_agg_t h, dfgpu_table_t* out) {
   return guarded([&] {
     require_init();
-    auto t = std::make_unique<Table>(agg_emit(*unwrap_agg(h)));
+    Aggregate* a = unwrap_agg(h);
+    if (!a->sets.empty()) {
+      std::vector<std::unique_ptr<Table>> parts;
+      std::vector<dfgpu_table_t> hs;
+      for (auto& s : a->sets) {
+        if (s->group_keys.device >= 0) use_device(s->group_keys.device);
+        parts.push_back(std::make_unique<Table>(agg_emit(*s)));
+        hs.push_back(wrap_quiet(parts.back().get()));
+      }
+      if (hs.size() == 1) {
+        *out = wrap(parts[0].release());
+        return;
+      }
+      if (dfgpu_table_concat(hs.data(), (int)hs.size(), out) != 0) throw Error(dfgpu_last_error());
+      return;
+    }
+    auto t = std::make_unique<Table>(agg_emit(*a));
     *out = wrap(t.release());
   });
 }

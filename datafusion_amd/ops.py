@@ -198,7 +198,7 @@ def sort(table: DeviceTable, keys, fetch=None) -> DeviceTable:
 class GroupedAggregate:
     """AggregateExec state: group_by = [(expr, name)], aggs = [(func, expr|None, name)]"""
 
-    def __init__(self, mode, input_names, group_by, aggs, dictionaries: DeviceTable | None = None, return_types: dict | None = None):
+    def __init__(self, mode, input_names, group_by, aggs, dictionaries: DeviceTable | None = None, return_types: dict | None = None, grouping_sets=None):
         """dictionaries: a table of the input's schema whose dictionary-encoded string columns bind the string
         literals of the argument expressions (`CASE WHEN o_orderpriority = '1-URGENT' ...`).
         return_types {name: arrow type}: the aggregates' declared return types (AggregateFunctionExpr::return_field) —
@@ -234,6 +234,15 @@ class GroupedAggregate:
             specs.append(s)
         sarr = (AggSpec * max(1, len(specs)))(*specs)
         self._h = C.c_void_p()
+        if grouping_sets is not None:
+            # PhysicalGroupBy with several groups: grouping_sets = ([typed NULL Literal per key], [[column g is NULL in set s] ...])
+            null_exprs, groups = grouping_sets
+            n_low = [lower(e, input_names, dictionaries) for e in null_exprs]
+            self._keep += n_low
+            narr = (Expr * max(1, len(n_low)))(*[l.c for l in n_low])
+            flat = (C.c_uint8 * max(1, len(groups) * len(group_by)))(*[int(bool(x)) for g in groups for x in g])
+            check(lib.dfgpu_agg_create_grouping_sets(AGG_MODES[mode], garr, narr, gnames, len(group_by), flat, len(groups), sarr, len(specs), C.byref(self._h)))
+            return
         check(lib.dfgpu_agg_create(AGG_MODES[mode], garr, gnames, len(group_by), sarr, len(specs), C.byref(self._h)))
 
     def update(self, table: DeviceTable, predicate: PhysicalExpr | None = None):
@@ -286,6 +295,16 @@ def aggregate_return_types(table: DeviceTable, aggs) -> dict:
             t = expr_type(table, e)
             if pa.types.is_decimal128(t):
                 out[name] = pa.decimal128(min(38, t.precision + 4), min(38, t.scale + 4))
+    return out
+
+
+def aggregate_grouping_sets(table: DeviceTable, group_by, null_exprs, groups, aggs, mode="Single", predicate: PhysicalExpr | None = None) -> DeviceTable:
+    """AggregateExec over a PhysicalGroupBy with grouping sets (GROUPING SETS / CUBE / ROLLUP, aggregates/mod.rs:400-520): the key
+    columns, `__grouping_id`, the aggregates — one row per (grouping set, group)"""
+    a = GroupedAggregate(mode, table.column_names, group_by, aggs, dictionaries=table, grouping_sets=(null_exprs, groups))
+    a.update(table, predicate)
+    out = a.emit()
+    a.free()
     return out
 
 

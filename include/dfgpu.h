@@ -561,6 +561,14 @@ typedef struct dfgpu_agg_spec {
  * `arg`/`group_by` expressions are ignored beyond their count. */
 int dfgpu_agg_create(int mode, const dfgpu_expr* group_by, const char* const* group_names, int n_group,
                      const dfgpu_agg_spec* aggs, int n_aggs, dfgpu_agg_t* out);
+/* GROUPING SETS / CUBE / ROLLUP = PhysicalGroupBy with several groups (aggregates/mod.rs:400-520: expr, null_expr, groups; pinned by
+ * check_grouping_sets, :3428-3590).  group_by[g] / null_by[g] = the key expression and its typed NULL literal, groups[s * n_group + g]
+ * != 0 = column g is NULL in grouping set s.  Output: the n_group key columns, `__grouping_id` (bit n_group-1-g set = column g is
+ * NULLed out; UInt8 up to 8 columns, UInt32 up to 32, else UInt64), then the aggregates (Partial: their state columns).  Raw modes
+ * only (Partial / Single / SinglePartitioned): the Final node of such a plan groups by the partial state's n_group + 1 key columns
+ * and is a plain dfgpu_agg_create.  update / update_filtered / emit / free as for any aggregate. */
+int dfgpu_agg_create_grouping_sets(int mode, const dfgpu_expr* group_by, const dfgpu_expr* null_by, const char* const* group_names, int n_group,
+                                   const uint8_t* groups, int n_sets, const dfgpu_agg_spec* aggs, int n_aggs, dfgpu_agg_t* out);
 /* aggregate_batch_inner (aggregate_hash_table/common.rs:205-236) over a whole table */
 int dfgpu_agg_update(dfgpu_agg_t h, dfgpu_table_t input);
 /* The same with a FilterExec predicate fused in front (filter.rs:1396-1419 -> common.rs:205-236): rows whose
