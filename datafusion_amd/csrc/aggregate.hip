@@ -347,8 +347,9 @@ struct Aggregate {
   // expressions replaced by the typed NULL literals, `__grouping_id` appended as a literal key — updated together, emitted
   // one after the other.  Empty for a plain GROUP BY.
   std::vector<std::unique_ptr<Aggregate>> sets;
-  bool final_mode() const { return mode == DFGPU_AGG_FINAL || mode == DFGPU_AGG_FINAL_PARTITIONED; }
-  bool partial_out() const { return mode == DFGPU_AGG_PARTIAL; }
+  // PartialReduce (aggregates/mod.rs:340-361): partial states in, partial states out — the merge of Final with the output of Partial
+  bool final_mode() const { return mode == DFGPU_AGG_FINAL || mode == DFGPU_AGG_FINAL_PARTITIONED || mode == DFGPU_AGG_PARTIAL_REDUCE; }
+  bool partial_out() const { return mode == DFGPU_AGG_PARTIAL || mode == DFGPU_AGG_PARTIAL_REDUCE; }
 };
 
 // the calling thread moves to the device the aggregate's state lives on
@@ -2991,7 +2992,7 @@ int dfgpu_agg_create(int mode, const dfgpu_expr* group_by, const char* const* gr
                      dfgpu_agg_t* out) {
   return guarded([&] {
     require_init();
-    DFGPU_CHECK(mode >= DFGPU_AGG_PARTIAL && mode <= DFGPU_AGG_SINGLE_PARTITIONED, "bad aggregate mode");
+    DFGPU_CHECK(mode >= DFGPU_AGG_PARTIAL && mode <= DFGPU_AGG_PARTIAL_REDUCE, "bad aggregate mode");
     auto A = std::make_unique<Aggregate>();
     A->mode = mode;
     for (int g = 0; g < n_group; g++) {

@@ -15,7 +15,7 @@ from .table import DeviceTable, field_of
 JOIN_TYPES = {"Inner": 0, "Left": 1, "Right": 2, "Full": 3, "LeftSemi": 4, "RightSemi": 5, "LeftAnti": 6,
               "RightAnti": 7, "LeftMark": 8, "RightMark": 9}
 NULL_EQUALITY = {"NullEqualsNothing": 0, "NullEqualsNull": 1}
-AGG_MODES = {"Partial": 0, "Final": 1, "FinalPartitioned": 2, "Single": 3, "SinglePartitioned": 4}
+AGG_MODES = {"Partial": 0, "Final": 1, "FinalPartitioned": 2, "Single": 3, "SinglePartitioned": 4, "PartialReduce": 5}
 AGG_FUNCS = {"sum": 0, "min": 1, "max": 2, "count": 3, "avg": 4}
 GPU_MIN_KEY_DENSITY = 1.0 / 64.0      # DFGPU_DEFAULT_MIN_KEY_DENSITY (include/dfgpu.h); the reference's CPU default is 0.15
 TABLE_MODES = {"auto": 0, "hash_map": 1, "array_map": 2, "rank_map": 3}
@@ -206,9 +206,9 @@ class GroupedAggregate:
         precision); aggregate_return_types() computes them from the raw input."""
         lib = _lib.init()
         self._keep = []
-        final = mode in ("Final", "FinalPartitioned")
+        final = mode in ("Final", "FinalPartitioned", "PartialReduce")
         if final:
-            # Final modes read the partial-state schema positionally (group columns first); the
+            # Final modes (and PartialReduce) read the partial-state schema positionally (group columns first); the
             # original argument expressions do not exist in that schema and are not evaluated
             from .expr import Column
             group_by = [(Column(n, i), n) for i, (_, n) in enumerate(group_by)]

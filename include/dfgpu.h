@@ -539,7 +539,8 @@ typedef enum dfgpu_agg_mode {
   DFGPU_AGG_FINAL = 1,            /* partial state -> final values */
   DFGPU_AGG_FINAL_PARTITIONED = 2,
   DFGPU_AGG_SINGLE = 3,           /* raw input -> final values */
-  DFGPU_AGG_SINGLE_PARTITIONED = 4
+  DFGPU_AGG_SINGLE_PARTITIONED = 4,
+  DFGPU_AGG_PARTIAL_REDUCE = 5    /* partial state -> partial state: merges like Final, emits like Partial (mod.rs:340-361) */
 } dfgpu_agg_mode;
 typedef enum dfgpu_agg_func { DFGPU_AGG_SUM = 0, DFGPU_AGG_MIN = 1, DFGPU_AGG_MAX = 2, DFGPU_AGG_COUNT = 3, DFGPU_AGG_AVG = 4 } dfgpu_agg_func;
 typedef struct dfgpu_agg_spec {

@@ -260,3 +260,24 @@ def test_grouping_sets_vs_oracle(shape):
         host = oracle.filter(t, to_oracle_expr(pred), t.column_names)
     exp = _oracle_grouping_sets(host, gb, types, groups, aggs, "Single")
     assert_agg_equal(got, exp, ordered=False)
+
+
+def test_partial_reduce_merges_states_into_states():
+    """AggregateMode::PartialReduce (aggregates/mod.rs:340-361): partial states in, partial states out — a tree of
+    Partial -> PartialReduce -> Final gives what Single gives, and PartialReduce's output has Partial's schema"""
+    from datafusion_amd.expr import col
+    rng = np.random.default_rng(41)
+    t = random_table(rng, 40_000, {"k": (pa.int64(), 0, 300), "d": (pa.decimal128(15, 2), -10**6, 10**6), "f": (pa.float64(), -100, 100), "q": (pa.int32(), -50, 50)}, null_frac=0.1)
+    gb = [(col("k"), "k")]
+    aggs = [("sum", col("d"), "s"), ("avg", col("d"), "ad"), ("avg", col("f"), "af"), ("count", col("q"), "c"), ("count", None, "n"), ("min", col("q"), "mn"), ("max", col("f"), "mx")]
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    rt = ops.aggregate_return_types(DeviceTable.from_arrow(t), aggs)
+    leaves = [gpu_agg(t.slice(lo, 10_000), gb, aggs, "Partial") for lo in range(0, 40_000, 10_000)]
+    mids = [gpu_agg(pa.concat_tables(leaves[i:i + 2]), gb, aggs, "PartialReduce") for i in (0, 2)]
+    for m in mids:
+        assert m.schema == leaves[0].schema                       # states in, states out
+    final = gpu_agg(pa.concat_tables(mids), gb, aggs, "Final", return_types=rt)
+    single = gpu_agg(t, gb, aggs, "Single")
+    assert_agg_equal(final, single, ordered=False)
+    assert_agg_equal(single, oracle_agg(t, gb, aggs, "Single"), ordered=False)
