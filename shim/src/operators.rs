@@ -37,7 +37,10 @@ pub enum GpuOp {
     Project { exprs: Vec<Arc<Lowered>>, names: Vec<CString> },
     /// dfgpu_agg_create / update(_filtered) / emit.  `predicate` = a FilterExec the rule fused below the aggregate: filter,
     /// projection and accumulation then run as ONE pass over the input columns (aggregate.hip's fused node)
-    Aggregate { mode: i32, group_by: Vec<Arc<Lowered>>, group_names: Vec<CString>, aggs: Vec<AggSpec>, predicate: Option<Arc<Lowered>> },
+    /// `grouping_sets` = PhysicalGroupBy with several groups (GROUPING SETS / CUBE / ROLLUP): the typed NULL literal per key and, per set,
+    /// which keys are NULLed out (dfgpu_agg_create_grouping_sets; raw modes only — a Final node groups by the keys + __grouping_id)
+    Aggregate { mode: i32, group_by: Vec<Arc<Lowered>>, group_names: Vec<CString>, aggs: Vec<AggSpec>, predicate: Option<Arc<Lowered>>,
+                grouping_sets: Option<(Vec<Arc<Lowered>>, Vec<u8>, i32)> },
     /// dfgpu_sort; fetch >= 0 = TopK
     Sort { keys: Vec<i32>, descending: Vec<u8>, nulls_first: Vec<u8>, fetch: i64 },
     /// dfgpu_partition: hash(keys; seed 0) % n — output partition p of this node is slice p of every input partition
@@ -123,7 +126,7 @@ impl GpuUnaryExec {
             _ => (Arc::clone(a.input()), None),
         };
         let in_schema = input.schema();
-        if !types_ok(&in_schema) || !types_ok(&a.schema()) || !a.group_expr().is_single() || a.filter_expr().iter().any(|f| f.is_some()) {
+        if !types_ok(&in_schema) || !types_ok(&a.schema()) || a.filter_expr().iter().any(|f| f.is_some()) {
             return None;
         }
         let mode = match a.mode() {
@@ -132,8 +135,23 @@ impl GpuUnaryExec {
             AggregateMode::FinalPartitioned => sys::DFGPU_AGG_FINAL_PARTITIONED,
             AggregateMode::Single => sys::DFGPU_AGG_SINGLE,
             AggregateMode::SinglePartitioned => sys::DFGPU_AGG_SINGLE_PARTITIONED,
-            _ => return None, // PartialReduce: state in, state out — not offered by the library
+            AggregateMode::PartialReduce => sys::DFGPU_AGG_PARTIAL_REDUCE, // states in, states out
         };
+        // GROUPING SETS: the typed NULL per key + the sets' masks; state-reading modes see __grouping_id as one more key column
+        let raw = matches!(a.mode(), AggregateMode::Partial | AggregateMode::Single | AggregateMode::SinglePartitioned);
+        let grouping_sets = if a.group_expr().is_single() {
+            None
+        } else if raw {
+            let nulls = a.group_expr().null_expr().iter().map(|(e, _)| lowered(e, &in_schema)).collect::<Option<Vec<_>>>()?;
+            let n = a.group_expr().expr().len();
+            let masks: Vec<u8> = a.group_expr().groups().iter().flat_map(|g| g.iter().map(|b| *b as u8)).collect();
+            Some((nulls, masks, (a.group_expr().groups().len()) as i32)).filter(|_| n >= 1 && n <= 63)
+        } else {
+            return None; // a Final over grouping sets reads (keys, __grouping_id) positionally: planned as single-set by as_final()
+        };
+        if !a.group_expr().is_single() && grouping_sets.is_none() {
+            return None;
+        }
         let mut group_by = vec![];
         let mut group_names = vec![];
         for (e, name) in a.group_expr().expr() {
@@ -163,7 +181,8 @@ impl GpuUnaryExec {
             // Final modes cannot derive AVG(Decimal128)'s declared type from its state: AggregateFunctionExpr::return_field carries it
             aggs.push(AggSpec { func, arg, name: cname(f.name()), return_field: field_of(f.field().data_type())? });
         }
-        Some(Self { name: "GpuAggregateExec", input, op: GpuOp::Aggregate { mode, group_by, group_names, aggs, predicate }, exchange: Default::default(), cache: Arc::clone(a.properties()) })
+        Some(Self { name: "GpuAggregateExec", input, op: GpuOp::Aggregate { mode, group_by, group_names, aggs, predicate, grouping_sets }, exchange: Default::default(),
+                    cache: Arc::clone(a.properties()) })
     }
 
     /// SortExec over column keys (expressions are projected below it by the planner); preserve_partitioning = true sorts every
@@ -211,14 +230,21 @@ fn run(op: &GpuOp, input: &DeviceTable) -> Result<DeviceTable> {
             let n: Vec<_> = names.iter().map(|s| s.as_ptr()).collect();
             check(unsafe { sys::dfgpu_project(input.0, e.as_ptr(), n.as_ptr(), e.len() as i32, &mut out) })?;
         }
-        GpuOp::Aggregate { mode, group_by, group_names, aggs, predicate } => {
+        GpuOp::Aggregate { mode, group_by, group_names, aggs, predicate, grouping_sets } => {
             let g: Vec<_> = group_by.iter().map(|l| l.as_c()).collect();
             let gn: Vec<_> = group_names.iter().map(|s| s.as_ptr()).collect();
             let empty = Lowered::default();
             let specs: Vec<_> = aggs.iter().map(|a| sys::dfgpu_agg_spec { func: a.func, has_arg: a.arg.is_some() as i32, arg: a.arg.as_deref().unwrap_or(&empty).as_c(),
                                                                          name: a.name.as_ptr(), return_field: a.return_field }).collect();
             let mut h = std::ptr::null_mut();
-            check(unsafe { sys::dfgpu_agg_create(*mode, g.as_ptr(), gn.as_ptr(), g.len() as i32, specs.as_ptr(), specs.len() as i32, &mut h) })?;
+            match grouping_sets {
+                None => check(unsafe { sys::dfgpu_agg_create(*mode, g.as_ptr(), gn.as_ptr(), g.len() as i32, specs.as_ptr(), specs.len() as i32, &mut h) })?,
+                Some((nulls, masks, n_sets)) => {
+                    let nb: Vec<_> = nulls.iter().map(|l| l.as_c()).collect();
+                    check(unsafe { sys::dfgpu_agg_create_grouping_sets(*mode, g.as_ptr(), nb.as_ptr(), gn.as_ptr(), g.len() as i32, masks.as_ptr(), *n_sets, specs.as_ptr(),
+                                                                       specs.len() as i32, &mut h) })?
+                }
+            }
             let rc = match predicate {
                 Some(p) => unsafe { sys::dfgpu_agg_update_filtered(h, input.0, &p.as_c()) },
                 None => unsafe { sys::dfgpu_agg_update(h, input.0) },
@@ -248,6 +274,7 @@ impl DisplayAs for GpuUnaryExec {
     fn fmt_as(&self, _t: DisplayFormatType, f: &mut std::fmt::Formatter) -> std::fmt::Result {
         match &self.op {
             GpuOp::Aggregate { predicate: Some(_), .. } => write!(f, "{}: FilterExec fused", self.name),
+            GpuOp::Aggregate { grouping_sets: Some((_, _, n)), .. } => write!(f, "{}: {} grouping sets", self.name, n),
             GpuOp::Sort { fetch, .. } if *fetch >= 0 => write!(f, "{}: TopK(fetch={})", self.name, fetch),
             GpuOp::HashRepartition { keys, n } => write!(f, "{}: Hash({:?}, {})", self.name, keys, n),
             _ => write!(f, "{}", self.name),
