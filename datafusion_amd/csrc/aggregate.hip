@@ -342,6 +342,7 @@ struct Aggregate {
   std::vector<uint16_t> small_keys;  // small-domain interning: host mirror of the group keys (byte g of key i = column g)
   int64_t fused_updates = 0;         // updates that took the fused (rowprog) path
   std::vector<uint8_t> utf8_key;     // group key g arrived as a Utf8 column: interned on entry, decoded again on emit
+  std::vector<uint8_t> bool_key;     // group key g arrived as a Boolean column: one byte per row on entry, bit-packed again on emit
   bool touched = false;              // an update ran: the state is bound to its device
   // grouping sets (PhysicalGroupBy::groups, aggregates/mod.rs:400-520): one aggregate per set — the set's NULLed-out key
   // expressions replaced by the typed NULL literals, `__grouping_id` appended as a literal key — updated together, emitted
@@ -2783,6 +2784,9 @@ static void agg_update_unfused(Aggregate& A, const Table& in) {
 }
 
 // aggregate_batch_inner over a whole table, optionally under a FilterExec predicate fused in front
+__global__ __launch_bounds__(BLOCK) void k_bits_to_u8(const uint64_t* __restrict__ bits, int64_t n, uint8_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (uint8_t)((bits[i >> 6] >> (i & 63)) & 1ull);
+}
 static void agg_update_keys_fixed(Aggregate& A, const Table& in, const dfgpu_expr* pred);
 // Utf8 group keys (plain column references; in Final modes the leading columns): interned on entry with an ascending dictionary —
 // grouping on the indices is grouping on the strings — and decoded again when the groups are emitted, so the node's schema keeps
@@ -2794,6 +2798,23 @@ static void agg_update(Aggregate& A, const Table& in, const dfgpu_expr* pred = n
   for (int g = 0; g < ngk; g++) {
     int kc = A.final_mode() ? g : -1;
     if (!A.final_mode() && !is_plain_column(A.group_nodes[(size_t)g], A.group_roots[(size_t)g], &kc)) continue;
+    if (kc >= 0 && kc < (int)in.cols.size() && in.cols[(size_t)kc].field.type == DFGPU_BOOL) {
+      // Boolean group keys (plain column references): one byte per row on entry, a Boolean column again on emit
+      if (!any) coded = in;
+      any = true;
+      const Column& bc = in.cols[(size_t)kc];
+      if (coded.cols[(size_t)kc].field.type == DFGPU_BOOL) {
+        Column u = alloc_column(fld(DFGPU_UINT8), bc.name, in.nrows);
+        if (in.nrows) k_bits_to_u8<<<grid_for(in.nrows, BLOCK), BLOCK, 0, rt().stream>>>((const uint64_t*)bc.ptr(), in.nrows, u.data->as<uint8_t>());
+        DFGPU_HIP(hipGetLastError());
+        u.validity = bc.validity;
+        u.null_count = bc.null_count;
+        coded.cols[(size_t)kc] = std::move(u);
+      }
+      A.bool_key.resize((size_t)ngk, 0);
+      A.bool_key[(size_t)g] = 1;
+      continue;
+    }
     if (kc < 0 || kc >= (int)in.cols.size() || in.cols[(size_t)kc].field.type != DFGPU_UTF8 || in.cols[(size_t)kc].dict) continue;
     if (!any) coded = in;
     any = true;
@@ -2869,6 +2890,14 @@ static Table agg_emit(Aggregate& A) {
     if ((size_t)g < A.utf8_key.size() && A.utf8_key[(size_t)g] && out.cols.back().dict) {
       out.cols.back() = dictionary_decode(out.cols.back());
       out.cols.back().name = A.group_names[(size_t)g];
+    }
+    if ((size_t)g < A.bool_key.size() && A.bool_key[(size_t)g] && out.cols.back().field.type == DFGPU_UINT8) {
+      const Column& u = out.cols.back();
+      Column b = alloc_column(fld(DFGPU_BOOL), A.group_names[(size_t)g], G);
+      if (G) pack_bytes_to_bitmap((const uint8_t*)u.ptr(), G, b.data->as<uint64_t>());
+      b.validity = u.validity;
+      b.null_count = u.null_count;
+      out.cols.back() = std::move(b);
     }
   }
   for (AggState& a : A.aggs) {

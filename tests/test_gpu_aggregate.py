@@ -281,3 +281,21 @@ def test_partial_reduce_merges_states_into_states():
     single = gpu_agg(t, gb, aggs, "Single")
     assert_agg_equal(final, single, ordered=False)
     assert_agg_equal(single, oracle_agg(t, gb, aggs, "Single"), ordered=False)
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.2])
+def test_boolean_group_keys(null_frac):
+    """GROUP BY over Boolean columns (alone, with another key, through Partial -> Final): TRUE / FALSE / NULL groups in first-seen order"""
+    from datafusion_amd.expr import col
+    rng = np.random.default_rng(5)
+    n = 30_000
+    t = pa.table({"b": pa.array(rng.random(n) < 0.3, mask=(rng.random(n) < null_frac) if null_frac else None), "c": pa.array(rng.random(n) < 0.5),
+                  "k": pa.array(rng.integers(0, 4, n)), "v": pa.array(rng.integers(-100, 100, n).astype(np.int32), mask=rng.random(n) < 0.1)})
+    aggs = [("sum", col("v"), "s"), ("count", None, "n"), ("avg", col("v"), "a")]
+    for gb in ([(col("b"), "b")], [(col("b"), "b"), (col("k"), "k")], [(col("c"), "c"), (col("b"), "b")]):
+        got = gpu_agg(t, gb, aggs, "Single")
+        assert got.schema.field("b").type == pa.bool_()
+        assert_agg_equal(got, oracle_agg(t, gb, aggs, "Single"), ordered=True)
+    gb = [(col("b"), "b"), (col("k"), "k")]
+    parts = [gpu_agg(t.slice(lo, 10_000), gb, aggs, "Partial") for lo in range(0, n, 10_000)]
+    assert_agg_equal(gpu_agg(pa.concat_tables(parts), gb, aggs, "Final"), oracle_agg(t, gb, aggs, "Single"), ordered=False)
