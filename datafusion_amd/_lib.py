@@ -114,7 +114,7 @@ SYMBOLS = [
     "dfgpu_table_export_batch", "dfgpu_host_register", "dfgpu_host_unregister", "dfgpu_table_export_into",
     "dfgpu_column_inlist", "dfgpu_metrics_reset", "dfgpu_metrics_get", "dfgpu_table_dictionary_like", "dfgpu_table_dictionary_encode", "dfgpu_table_dictionary_decode", "dfgpu_table_dictionary_size", "dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_estimate_bytes",
     "dfgpu_table_retain", "dfgpu_table_export_device", "dfgpu_table_import_device",
-    "dfgpu_cache_create", "dfgpu_cache_free", "dfgpu_cache_get", "dfgpu_cache_put", "dfgpu_cache_clear", "dfgpu_cache_get_stats", "dfgpu_jit_cache_stats", "dfgpu_join_contains", "dfgpu_exchange_join_visited",
+    "dfgpu_cache_create", "dfgpu_cache_free", "dfgpu_cache_get", "dfgpu_cache_put", "dfgpu_cache_clear", "dfgpu_cache_get_stats", "dfgpu_jit_cache_stats", "dfgpu_join_contains", "dfgpu_exchange_join_visited", "dfgpu_exchange_range",
     "dfgpu_agg_create_grouping_sets", "dfgpu_ipc_open", "dfgpu_ipc_close", "dfgpu_ipc_info", "dfgpu_ipc_column", "dfgpu_ipc_batch_rows", "dfgpu_ipc_read_batch",
 ]
 

@@ -633,6 +633,47 @@ static std::vector<Table> local_inputs(Comm& c, const dfgpu_table_t* inputs) {
   }
   return t;
 }
+// ---- range exchange (the distributed ORDER BY): destination of a row = number of splitters <= its key
+constexpr int MAX_RANGE_RANKS = 64;
+struct Splitters {
+  long long s[MAX_RANGE_RANKS];
+  int n;  // world - 1
+};
+__global__ __launch_bounds__(BLOCK) void k_range_masks(KeyCol k, int64_t n, Splitters sp, int world, int descending, int null_dest, uint64_t* __restrict__ masks,
+                                                       int64_t n_words) {
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const int64_t i = (w << 6) + lane_id();
+    int dest = -1;
+    if (i < n) {
+      if (k.valid && !bit_at(k.valid, i)) {
+        dest = null_dest;
+      } else {
+        uint64_t lo, hi;
+        load_words(k, i, lo, hi);
+        const long long v = (long long)lo;
+        int d = 0;
+        for (int q = 0; q < sp.n; q++) d += sp.s[q] <= v ? 1 : 0;
+        dest = descending ? world - 1 - d : d;
+      }
+    }
+    for (int d = 0; d < world; d++) {
+      const uint64_t b = ballot64(dest == d);
+      if (lane_id() == 0) masks[(int64_t)d * n_words + w] = b;
+    }
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_sample_keys(KeyCol k, int64_t n, int64_t every, int samples, long long* __restrict__ out, int* __restrict__ n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= samples) return;
+  const int64_t r = (int64_t)i * every;
+  if (r >= n || (k.valid && !bit_at(k.valid, r))) return;
+  uint64_t lo, hi;
+  load_words(k, r, lo, hi);
+  out[atomicAdd(n_out, 1)] = (long long)lo;
+}
+
 static void hand_out(std::vector<Table>& res, dfgpu_table_t* outs) {
   for (size_t l = 0; l < res.size(); l++) outs[l] = wrap(new Table(std::move(res[l])));
 }
@@ -755,6 +796,78 @@ int dfgpu_exchange_broadcast(dfgpu_comm_t h, const dfgpu_table_t* inputs, dfgpu_
     unify_dictionaries(c, t);
     std::vector<std::vector<Table>> parts(c.n_local());
     for (int l = 0; l < c.n_local(); l++) parts[l].assign(c.world, t[l]);  // every peer receives the whole local table
+    std::vector<Table> res = exchange_parts(c, parts, t);
+    hand_out(res, outs);
+  });
+}
+
+// The exchange of a distributed ORDER BY (SURVEY §8e "all-to-all for sample-sort"; SortPreservingMergeExec over partitions that sit
+// on different GPUs, sorts/sort_preserving_merge.rs:91): every rank samples its rows' FIRST sort key, the samples of all ranks give
+// world - 1 splitters (quantiles), and a row goes to the rank whose key range holds its key — rank 0 the smallest keys (the largest
+// under DESC), NULL keys first or last as the sort options say.  Rows with equal first keys land on ONE rank, so after a local sort
+// by the full key list the ranks' outputs, read in rank order, are the globally sorted result: no rank ever holds or re-sorts
+// everything.  Integer-like first key (Int32 / Int64 / Date32 / UInt8 / UInt32).
+int dfgpu_exchange_range(dfgpu_comm_t h, const dfgpu_table_t* inputs, int key_col, int descending, int nulls_first, dfgpu_table_t* outs) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(h && inputs && outs, "dfgpu_exchange_range: bad arguments");
+    Comm& c = *reinterpret_cast<Comm*>(h);
+    DFGPU_CHECK(c.world <= MAX_RANGE_RANKS, "dfgpu_exchange_range: too many ranks");
+    std::vector<Table> t = local_inputs(c, inputs);
+    unify_dictionaries(c, t);
+    const int L = c.n_local();
+    constexpr int S = 1024;
+    std::vector<std::vector<uint8_t>> mine((size_t)L);
+    for (int l = 0; l < L; l++) {
+      use_device(c.devices[l]);
+      DFGPU_CHECK(key_col >= 0 && key_col < (int)t[l].cols.size(), "dfgpu_exchange_range: key column out of range");
+      const Column& kc = t[l].cols[(size_t)key_col];
+      DFGPU_CHECK(is_integer_like(kc.field.type) && kc.field.type != DFGPU_UINT64 && !kc.dict, "dfgpu_exchange_range: the first sort key must be an integer-like column");
+      const int64_t n = t[l].nrows;
+      std::vector<long long> samples;
+      if (n > 0) {
+        BufPtr d = make_buf((size_t)S * 8), cnt = make_zero_buf(4);
+        const KeyCol k{kc.ptr(), kc.valid_words(), kc.field.type, type_width(kc.field.type)};
+        k_sample_keys<<<S / BLOCK, BLOCK, 0, rt().stream>>>(k, n, std::max<int64_t>(1, n / S), S, d->as<long long>(), cnt->as<int>());
+        DFGPU_HIP(hipGetLastError());
+        int got = 0;
+        d2h(&got, cnt->ptr, 4);
+        samples.resize((size_t)got);
+        if (got) d2h(samples.data(), d->ptr, (size_t)got * 8);
+      }
+      mine[(size_t)l].assign((const uint8_t*)samples.data(), (const uint8_t*)samples.data() + samples.size() * 8);
+    }
+    const std::vector<std::vector<uint8_t>> all = allgather_blobs(c, mine);
+    std::vector<long long> pool;
+    for (const auto& b : all) {
+      const size_t m = b.size() / 8;
+      const size_t at = pool.size();
+      pool.resize(at + m);
+      if (m) std::memcpy(pool.data() + at, b.data(), m * 8);
+    }
+    std::sort(pool.begin(), pool.end());
+    Splitters sp{};
+    sp.n = c.world - 1;
+    for (int q = 0; q < sp.n; q++) sp.s[q] = pool.empty() ? 0 : pool[std::min(pool.size() - 1, (size_t)((q + 1) * pool.size() / (size_t)c.world))];
+    // ---- every local table split by destination
+    std::vector<std::vector<Table>> parts((size_t)L);
+    for (int l = 0; l < L; l++) {
+      use_device(c.devices[l]);
+      const int64_t n = t[l].nrows, n_words = (n + 63) / 64;
+      std::vector<int> allc(t[l].cols.size());
+      for (size_t i = 0; i < allc.size(); i++) allc[i] = (int)i;
+      BufPtr masks = make_buf((size_t)std::max<int64_t>(1, n_words * c.world) * 8);
+      if (n) {
+        const Column& kc = t[l].cols[(size_t)key_col];
+        const KeyCol k{kc.ptr(), kc.valid_words(), kc.field.type, type_width(kc.field.type)};
+        // NULLs: first in the output -> the rank that comes first; the key order among ranks is reversed under DESC
+        const int null_dest = nulls_first ? 0 : c.world - 1;
+        ProfileScope ps("exchange_range_masks", n * k.width);
+        k_range_masks<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, rt().stream>>>(k, n, sp, c.world, descending, null_dest, masks->as<uint64_t>(), n_words);
+        DFGPU_HIP(hipGetLastError());
+      }
+      for (int d = 0; d < c.world; d++) parts[(size_t)l].push_back(compact_table(t[l], allc, masks->as<uint64_t>() + (int64_t)d * n_words, nullptr));
+    }
     std::vector<Table> res = exchange_parts(c, parts, t);
     hand_out(res, outs);
   });

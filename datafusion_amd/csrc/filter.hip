@@ -236,11 +236,44 @@ __global__ __launch_bounds__(BLOCK) void k_gather(const T* __restrict__ src, con
   }
 }
 
+// take of a bit-packed (Boolean) column: the taken bits as one byte per output row, packed afterwards
+__global__ __launch_bounds__(BLOCK) void k_gather_bits(const uint64_t* __restrict__ src, const uint64_t* __restrict__ src_valid, const int64_t* __restrict__ idx, int64_t n,
+                                                      uint8_t* __restrict__ dst_bytes, uint8_t* __restrict__ dst_valid_bytes) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t s = idx[i];
+    bool ok = s >= 0, v = false;
+    if (ok) {
+      v = (src[s >> 6] >> (s & 63)) & 1ull;
+      if (src_valid) ok = bit_at(src_valid, s);
+    }
+    dst_bytes[i] = v ? 1 : 0;
+    if (dst_valid_bytes) dst_valid_bytes[i] = ok ? 1 : 0;
+  }
+}
+
 // arrow `take` (joins/utils.rs:1371,1379 build_batch_from_indices): idx < 0 => NULL
 Column gather_column(const Column& in, const int64_t* idx, int64_t n, bool idx_may_be_null) {
   Runtime& r = rt();
   if (in.field.type == DFGPU_UTF8) return gather_strings(in, idx, n, idx_may_be_null);
-  DFGPU_CHECK(in.field.type != DFGPU_BOOL, "take: Boolean columns are not supported on the GPU path yet");
+  if (in.field.type == DFGPU_BOOL) {
+    Column out = alloc_like(in, n);
+    if (n == 0) return out;
+    const bool need_valid = idx_may_be_null || in.validity;
+    BufPtr vals = make_buf((size_t)n + 64), vb = need_valid ? make_buf((size_t)n + 64) : nullptr;
+    {
+      ProfileScope ps("gather", n * 10);
+      k_gather_bits<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>((const uint64_t*)in.ptr(), in.valid_words(), idx, n, vals->as<uint8_t>(), vb ? vb->as<uint8_t>() : nullptr);
+      DFGPU_HIP(hipGetLastError());
+    }
+    pack_bytes_to_bitmap(vals->as<uint8_t>(), n, out.data->as<uint64_t>());
+    if (need_valid) {
+      out.validity = make_buf(bitmap_bytes(n));
+      pack_bytes_to_bitmap(vb->as<uint8_t>(), n, out.validity->as<uint64_t>());
+      out.null_count = -1;
+      count_nulls(out);
+    }
+    return out;
+  }
   Column out = alloc_like(in, n);
   if (n == 0) return out;
   bool need_valid = idx_may_be_null || in.validity;

@@ -103,6 +103,11 @@ class Comm:
         return self._call(_lib.load().dfgpu_exchange_broadcast_pruned, (C.c_void_p * 1)(build.handle), build.index_of(build_key),
                           (C.c_void_p * 1)(probe.handle), probe.index_of(probe_key))
 
+    def range_exchange(self, table, key, descending=False, nulls_first=False):
+        """the exchange of a distributed ORDER BY (dfgpu_exchange_range): this rank's share of the key range, unsorted"""
+        from . import _lib
+        return self._call(_lib.load().dfgpu_exchange_range, (C.c_void_p * 1)(table.handle), table.index_of(key), int(descending), int(nulls_first))
+
     def merge_join_visited(self, ht):
         """OR of the visited marks (and null-aware flags) of a replicated build side's join tables across the ranks
         (dfgpu_exchange_join_visited): after it, emit_unmatched reports the same rows everywhere"""

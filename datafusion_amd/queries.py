@@ -52,8 +52,24 @@ def _merge_sorted(table: DeviceTable, keys, fetch, group=None) -> DeviceTable:
     values, validity bitmaps and dictionaries cross below the C ABI) and one more device sort."""
     if _world(group) == 1:
         return table
-    from .exchange import broadcast_table
-    merged = broadcast_table(table, group)
+    from .exchange import broadcast_table, comm_for
+    import pyarrow as pa
+    first = table.schema.field(table.index_of(keys[0][0])).type if keys else None
+    int_like = first is not None and (pa.types.is_integer(first) or pa.types.is_date32(first)) and first not in (pa.uint64(), pa.int8(), pa.int16(), pa.uint16())
+    if fetch is None and int_like:
+        # an unbounded ORDER BY: sample sort.  Rows move to the rank that owns their first key's range (dfgpu_exchange_range:
+        # splitters from all ranks' samples, all-to-all(v)), every rank sorts ITS range, and the ranges read in rank order are the
+        # result — no rank sorts everything.  SortPreservingMergeExec has ONE output partition: the sorted ranges are gathered to
+        # every rank (a concatenation in rank order, no second sort); an engine that streams the result from rank 0 keeps them apart.
+        comm = comm_for(group)
+        mine = comm.range_exchange(table, keys[0][0], bool(keys[0][1]), bool(keys[0][2]))
+        ranged = ops.sort(mine, keys)
+        mine.free()
+        out = broadcast_table(ranged, group)
+        if out is not ranged:
+            ranged.free()
+        return out
+    merged = broadcast_table(table, group)          # TopK: at most `fetch` rows per rank
     out = ops.sort(merged, keys, fetch=fetch)
     merged.free()
     return out

@@ -654,6 +654,13 @@ int dfgpu_exchange_broadcast(dfgpu_comm_t comm, const dfgpu_table_t* inputs, dfg
  * of range-partitioned data) move almost nothing; uniformly spread keys degrade to the full all-gather.  Integer keys. */
 int dfgpu_exchange_broadcast_pruned(dfgpu_comm_t comm, const dfgpu_table_t* builds, int build_key, const dfgpu_table_t* probes, int probe_key,
                                     dfgpu_table_t* outs);
+/* The exchange of a distributed ORDER BY (SortPreservingMergeExec over partitions on different GPUs, sorts/sort_preserving_merge.rs:91;
+ * SURVEY §8e "all-to-all for sample-sort"): every rank samples its rows' first sort key (`key_col`, integer-like), the samples of all
+ * ranks give world - 1 splitters, a row goes to the rank whose key range holds its key — rank 0 the smallest keys (the largest when
+ * `descending`), NULL keys to the first or the last rank as `nulls_first` says.  Rows with equal first keys land on one rank, so after a
+ * local dfgpu_sort by the full key list the ranks' outputs read in rank order are the globally sorted result: no rank holds or
+ * re-sorts everything.  outs[l] = the rows rank l owns (in no particular order yet). */
+int dfgpu_exchange_range(dfgpu_comm_t comm, const dfgpu_table_t* inputs, int key_col, int descending, int nulls_first, dfgpu_table_t* outs);
 /* PartitionMode::CollectLeft with build-side emission (Left / Full / LeftSemi / LeftAnti / LeftMark) when the probe partitions sit on
  * different GPUs: in the reference they all mark ONE visited bitmap and the last of them reports the build rows
  * (hash_join/exec.rs:1312-1330).  Here every rank probes ITS probe partition against its copy of the replicated build side

@@ -108,6 +108,12 @@ if mode == "exchange":
     out["probe"] = probe
     out["pruned"] = decoded(c.broadcast_pruned(d, "k", DeviceTable.from_arrow(probe), "k2").to_arrow())
     out["stats"] = c.stats()
+    # the exchange of a distributed ORDER BY (dfgpu_exchange_range) + the local sort: rank order = sort order
+    from datafusion_amd import ops as _ops
+    out["range_asc"] = decoded(_ops.sort(c.range_exchange(d, "k", False, False), [("k", False, False), ("d", True, False)]).to_arrow())
+    out["range_desc_nulls_first"] = decoded(_ops.sort(c.range_exchange(d, "q", True, True), [("q", True, True), ("k", False, False)]).to_arrow())
+    from datafusion_amd import queries as _Q
+    out["merge_sorted"] = decoded(_Q._merge_sorted(_ops.sort(d, [("k", False, False), ("d", True, False)]), [("k", False, False), ("d", True, False)], None).to_arrow())
     # PartitionMode::Partitioned on a STRING key: the two sides cross in separate exchanges — one dictionary-encoded with this rank's own
     # dictionary, the other as plain Utf8 bytes — and equal strings must still meet on one rank (routing hashes the bytes)
     from datafusion_amd import ops
@@ -195,6 +201,18 @@ def test_two_ranks_exchange_device_tables_with_different_dictionaries_and_nulls(
         exp = whole.filter(pc.and_(pc.greater_equal(whole.column("k"), lo), pc.less_equal(whole.column("k"), hi)))
         assert_tables_equal(res[r]["pruned"], exp, ordered=True)
         assert res[r]["stats"]["bytes_sent_to_peers"] > 0 and res[r]["stats"]["rows_received_from_peers"] > 0
+    # distributed ORDER BY: every rank owns one key range; read in rank order the sorted ranges are the oracle's sort of everything
+    exp = oracle.sort(whole, [("k", False, False), ("d", True, False)])
+    got = pa.concat_tables([r["range_asc"] for r in res])
+    assert got.column("k").to_pylist() == exp.column("k").to_pylist() and got.column("d").to_pylist() == exp.column("d").to_pylist()
+    assert all(r["range_asc"].num_rows > 0.2 * whole.num_rows for r in res)        # the sampled splitters balance the ranks
+    exp = oracle.sort(whole, [("q", True, True), ("k", False, False)])
+    got = pa.concat_tables([r["range_desc_nulls_first"] for r in res])
+    assert got.column("q").to_pylist() == exp.column("q").to_pylist() and got.column("k").to_pylist() == exp.column("k").to_pylist()
+    assert res[0]["range_desc_nulls_first"].column("q").null_count == whole.column("q").null_count      # NULLS FIRST: all on the first rank
+    exp = oracle.sort(whole, [("k", False, False), ("d", True, False)])
+    for r in res:                                                                  # SortPreservingMergeExec: ONE output, on every rank
+        assert r["merge_sorted"].column("k").to_pylist() == exp.column("k").to_pylist() and r["merge_sorted"].column("d").to_pylist() == exp.column("d").to_pylist()
     # the partitioned join on the string key: the ranks' results together are the global join
     lefts = pa.concat_tables([r["pjoin_inputs"][0] for r in res])
     rights = pa.concat_tables([r["pjoin_inputs"][1] for r in res])

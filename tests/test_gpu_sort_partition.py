@@ -230,3 +230,21 @@ def test_sort_clustered_take_carries_records_through_the_top_digit_pass(shape):
     finally:
         os.environ.pop("DFGPU_SORT_CLUSTERED_MIN_BYTES", None)
         os.environ.pop("DFGPU_SORT_CLUSTERED_TAKE", None)
+
+
+def test_sort_and_joins_move_boolean_payload_columns():
+    """take of a bit-packed column (SortExec's output, the general join path's gathers): Boolean payload with NULLs"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(19)
+    n = 50_000
+    t = pa.table({"k": pa.array(rng.integers(0, 5000, n)), "b": pa.array(rng.random(n) < 0.4, mask=rng.random(n) < 0.1), "c": pa.array(rng.random(n) < 0.5)})
+    got = ops.sort(DeviceTable.from_arrow(t), [("k", False, False)]).to_arrow()
+    order = np.argsort(t.column("k").to_numpy(), kind="stable")
+    assert got.column("b").to_pylist() == t.column("b").take(pa.array(order)).to_pylist() and got.column("c").to_pylist() == t.column("c").take(pa.array(order)).to_pylist()
+    build = pa.table({"bk": pa.array(np.arange(5000, dtype=np.int64)), "flag": pa.array(np.arange(5000) % 3 == 0, mask=np.arange(5000) % 7 == 0)})
+    j = ops.hash_join(DeviceTable.from_arrow(build), DeviceTable.from_arrow(t), [("bk", "k")], "Right").to_arrow()
+    as_u8 = lambda x: pa.table({c: (x.column(c).cast(pa.uint8()) if pa.types.is_boolean(x.schema.field(c).type) else x.column(c)) for c in x.column_names})
+    exp = oracle.hash_join(as_u8(build), as_u8(t), [("bk", "k")], "Right")
+    assert_tables_equal(as_u8(j), exp, ordered=False)
