@@ -22,6 +22,9 @@
 #include <string_view>
 #include <thread>
 
+#include <chrono>
+#include <cstdio>
+
 #include "device.hpp"
 #include "internal.hpp"
 
@@ -280,6 +283,16 @@ Column dictionary_encode(const Column& in, bool sorted) {
     out.dict = dv;
     return out;
   }
+  // DFGPU_TRACE_DICT=1: the phases of this call on stderr (where its host time goes: profiles/r3_strings.md)
+  const bool trace = std::getenv("DFGPU_TRACE_DICT") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto phase = [&](const char* what) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(r.stream);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[dict] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   uint64_t capacity = 1024;
   while (capacity < (uint64_t)n * 2) capacity <<= 1;
   BufPtr slots = make_zero_buf((size_t)capacity * 4);
@@ -293,6 +306,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
                                                              row_slot->as<uint32_t>());
     DFGPU_HIP(hipGetLastError());
   }
+  phase("alloc + intern kernel");
   k_str_mark_reps<<<grid_for((int64_t)capacity, BLOCK), BLOCK, 0, r.stream>>>(slots->as<unsigned>(), capacity, rep_mask->as<unsigned long long>());
   scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
   const int64_t G = (int64_t)read_u64(prefix->as<uint64_t>() + row_words);
@@ -301,11 +315,14 @@ Column dictionary_encode(const Column& in, bool sorted) {
   if (G) k_str_mask_ids<<<grid_for(row_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(rep_mask->as<uint64_t>(), nullptr, prefix->as<uint64_t>(), n, ids->as<int64_t>());
   Column plain = in;
   plain.validity.reset();  // representatives are valid rows
+  phase("mark reps + scan + count");
   Column values = gather_strings(plain, ids->as<int64_t>(), G, false);
+  phase("gather distinct strings");
   std::vector<int64_t> hoff((size_t)G + 1, 0);
   d2h(hoff.data(), values.offsets->ptr, (size_t)(G + 1) * 8);
   std::vector<char> hbytes((size_t)hoff[(size_t)G] + 1);
   if (hoff[(size_t)G]) d2h(hbytes.data(), values.data->ptr, (size_t)hoff[(size_t)G]);
+  phase("download offsets + bytes");
   dv->values.resize((size_t)G);
   dv->valid.assign((size_t)G, 1);
   auto value_at = [&](int32_t k) { return std::string_view(hbytes.data() + hoff[(size_t)k], (size_t)(hoff[(size_t)k + 1] - hoff[(size_t)k])); };
@@ -336,6 +353,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
         o.w[q] = x;
       }
     }
+    phase("sort keys (prefix words)");
     auto less = [&](const SortKey& a, const SortKey& b) {
       if (a.w[0] != b.w[0]) return a.w[0] < b.w[0];
       if (a.w[1] != b.w[1]) return a.w[1] < b.w[1];
@@ -363,6 +381,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
         for (auto& x : th) x.join();
       }
     }
+    phase("host sort (threads)");
     std::vector<int32_t> rank((size_t)G);
     for (int64_t k = 0; k < G; k++) {
       rank[(size_t)order[(size_t)k].idx] = (int32_t)k;
@@ -375,6 +394,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
     for (int64_t k = 0; k < G; k++) dv->values[(size_t)k] = std::string(value_at((int32_t)k));  // first-seen order
   }
   dv->sorted = sorted || G <= 1;
+  phase("dictionary strings + ranks");
   {
     ProfileScope ps("string_codes", n * 16);
     k_str_codes<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(slots->as<unsigned>(), row_slot->as<uint32_t>(), rep_mask->as<uint64_t>(), prefix->as<uint64_t>(),
@@ -382,6 +402,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
     DFGPU_HIP(hipGetLastError());
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));
+  phase("codes kernel");
   out.dict = dv;
   return out;
 }
