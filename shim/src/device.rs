@@ -32,6 +32,9 @@ pub fn as_gpu_node(plan: &Arc<dyn ExecutionPlan>) -> Option<&dyn GpuNode> {
     if let Some(n) = plan.downcast_ref::<GpuHashJoinExec>() {
         return Some(n);
     }
+    if let Some(n) = plan.downcast_ref::<crate::scan::GpuIpcScanExec>() {
+        return Some(n);
+    }
     None
 }
 

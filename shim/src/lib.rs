@@ -19,6 +19,7 @@ pub mod ffi;
 pub mod hash_join;
 pub mod operators;
 pub mod rule;
+pub mod scan;
 pub mod sys;
 pub mod table;
 

@@ -1,0 +1,134 @@
+//! Scan -> device below the C ABI, from the Rust side: the Arrow IPC reader (`dfgpu_ipc_*`, csrc/ipc.hip) and the device-resident scan
+//! cache (`dfgpu_cache_*`, csrc/interop.hip) as a leaf `ExecutionPlan` — the GPU twin of `DataSourceExec` over an `ArrowSource`
+//! (datasource-arrow/src/source.rs:260-330) whose output partition is ONE device table handed to the GPU node above it (device.rs),
+//! or exported `batch_size` rows at a time to a CPU parent.  A file scanned before costs no host read and no PCIe transfer: its
+//! batches are views of HBM (`MemorySourceConfig`'s role, datasource/src/memory.rs:58).  Python twin: datafusion_amd/ipc.py.
+//! (The Parquet twin drives `dfgpu_parquet_decode_chunk` per projected column chunk the same way: INTEGRATION.md §3.1.)
+use crate::device::{host_stream, DeviceFuture, GpuNode};
+use crate::table::DeviceTable;
+use crate::{blocking, check, sys};
+use arrow::datatypes::SchemaRef;
+use datafusion::common::tree_node::TreeNodeRecursion;
+use datafusion::error::{DataFusionError, Result};
+use datafusion::execution::{SendableRecordBatchStream, TaskContext};
+use datafusion::physical_expr::{EquivalenceProperties, PhysicalExpr};
+use datafusion::physical_plan::execution_plan::{Boundedness, EmissionType};
+use datafusion::physical_plan::{DisplayAs, DisplayFormatType, ExecutionPlan, Partitioning, PlanProperties, ReplaceChildrenOptions};
+use futures::FutureExt;
+use std::sync::{Arc, OnceLock};
+
+/// process-wide device cache (budget: DFGPU_TABLE_CACHE_BYTES, default 16 GiB)
+pub struct ScanCache(sys::dfgpu_cache_t);
+unsafe impl Send for ScanCache {}
+unsafe impl Sync for ScanCache {}
+impl ScanCache {
+    pub fn global() -> &'static ScanCache {
+        static CACHE: OnceLock<ScanCache> = OnceLock::new();
+        CACHE.get_or_init(|| {
+            let budget = std::env::var("DFGPU_TABLE_CACHE_BYTES").ok().and_then(|v| v.parse::<i64>().ok()).unwrap_or(16 << 30);
+            let mut h = std::ptr::null_mut();
+            check(unsafe { sys::dfgpu_cache_create(budget, &mut h) }).expect("dfgpu_cache_create");
+            ScanCache(h)
+        })
+    }
+    pub fn get(&self, key: &[u8]) -> Result<Option<DeviceTable>> {
+        let mut out = std::ptr::null_mut();
+        check(unsafe { sys::dfgpu_cache_get(self.0, key.as_ptr() as *const _, key.len() as i64, &mut out) })?;
+        Ok(if out.is_null() { None } else { Some(DeviceTable(out)) })
+    }
+    pub fn put(&self, key: &[u8], table: &DeviceTable) -> Result<()> {
+        check(unsafe { sys::dfgpu_cache_put(self.0, key.as_ptr() as *const _, key.len() as i64, table.0) })
+    }
+}
+
+/// one memory-mapped Arrow IPC file; the library has walked its messages (`dfgpu_ipc_open` needs no GPU)
+struct IpcFile {
+    handle: sys::dfgpu_ipc_t,
+    _map: memmap2::Mmap, // the bytes must outlive the handle
+    identity: Vec<u8>,   // path + mtime + size: the cache key prefix
+    n_batches: i64,
+}
+unsafe impl Send for IpcFile {}
+unsafe impl Sync for IpcFile {}
+impl Drop for IpcFile {
+    fn drop(&mut self) {
+        unsafe { sys::dfgpu_ipc_close(self.handle) };
+    }
+}
+
+#[derive(Debug)]
+pub struct GpuIpcScanExec {
+    path: String,
+    /// indices into the file's schema (the scan's projection), in output order
+    projection: Vec<i32>,
+    schema: SchemaRef,
+    cache: Arc<PlanProperties>,
+}
+
+impl GpuIpcScanExec {
+    pub fn new(path: String, projection: Vec<i32>, schema: SchemaRef) -> Self {
+        let props = PlanProperties::new(EquivalenceProperties::new(Arc::clone(&schema)), Partitioning::UnknownPartitioning(1), EmissionType::Final, Boundedness::Bounded);
+        Self { path, projection, schema, cache: Arc::new(props) }
+    }
+
+    fn open(&self) -> Result<IpcFile> {
+        let file = std::fs::File::open(&self.path)?;
+        let meta = file.metadata()?;
+        let map = unsafe { memmap2::Mmap::map(&file) }.map_err(|e| DataFusionError::External(Box::new(e)))?;
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { sys::dfgpu_ipc_open(map.as_ptr(), map.len() as i64, &mut handle) })?;
+        let (mut n_batches, mut n_cols, mut is_file) = (0i64, 0i32, 0i32);
+        check(unsafe { sys::dfgpu_ipc_info(handle, &mut n_batches, &mut n_cols, &mut is_file) })?;
+        let mtime = meta.modified().ok().and_then(|t| t.duration_since(std::time::UNIX_EPOCH).ok()).map_or(0, |d| d.as_nanos());
+        let identity = format!("{}|{}|{}", self.path, mtime, meta.len()).into_bytes();
+        Ok(IpcFile { handle, _map: map, identity, n_batches })
+    }
+}
+
+impl DisplayAs for GpuIpcScanExec {
+    fn fmt_as(&self, _t: DisplayFormatType, f: &mut std::fmt::Formatter) -> std::fmt::Result {
+        write!(f, "GpuIpcScanExec: {}, projection={:?}", self.path, self.projection)
+    }
+}
+
+impl GpuNode for GpuIpcScanExec {
+    fn execute_device(&self, _partition: usize, _ctx: Arc<TaskContext>) -> Result<DeviceFuture> {
+        let file = self.open()?;
+        let projection = self.projection.clone();
+        Ok(async move {
+            blocking(move || {
+                let mut parts = vec![];
+                for i in 0..file.n_batches {
+                    let key = [file.identity.as_slice(), format!("|ipc|{i}|{projection:?}").as_bytes()].concat();
+                    if let Some(hit) = ScanCache::global().get(&key)? {
+                        parts.push(hit); // a zero-copy view of HBM: no host read, no PCIe
+                        continue;
+                    }
+                    let mut out = std::ptr::null_mut();
+                    check(unsafe { sys::dfgpu_ipc_read_batch(file.handle, i, projection.as_ptr(), projection.len() as i32, &mut out) })?;
+                    let t = DeviceTable(out);
+                    ScanCache::global().put(&key, &t)?;
+                    parts.push(t);
+                }
+                if parts.len() == 1 { Ok(parts.pop().unwrap()) } else { DeviceTable::concat(&parts) }
+            }).await
+        }
+        .boxed())
+    }
+}
+
+impl ExecutionPlan for GpuIpcScanExec {
+    fn name(&self) -> &str { "GpuIpcScanExec" }
+    fn properties(&self) -> &Arc<PlanProperties> { &self.cache }
+    fn children(&self) -> Vec<&Arc<dyn ExecutionPlan>> { vec![] }
+    fn apply_expressions(&self, _f: &mut dyn FnMut(&Arc<dyn PhysicalExpr>) -> Result<TreeNodeRecursion>) -> Result<TreeNodeRecursion> {
+        Ok(TreeNodeRecursion::Continue)
+    }
+    fn replace_children(self: Arc<Self>, _c: Vec<Arc<dyn ExecutionPlan>>, _o: ReplaceChildrenOptions) -> Result<Arc<dyn ExecutionPlan>> { Ok(self) }
+    #[allow(deprecated)]
+    fn with_new_children(self: Arc<Self>, _c: Vec<Arc<dyn ExecutionPlan>>) -> Result<Arc<dyn ExecutionPlan>> { Ok(self) }
+    fn execute(&self, partition: usize, ctx: Arc<TaskContext>) -> Result<SendableRecordBatchStream> {
+        let batch_size = ctx.session_config().batch_size();
+        Ok(host_stream(Arc::clone(&self.schema), self.execute_device(partition, ctx)?, batch_size))
+    }
+}

@@ -224,7 +224,7 @@ def test_rust_shim_binds_only_declared_entry_points_and_the_join_sequence_the_c_
     sys_rs = _shim("sys.rs")
     declared = set(re.findall(r"pub fn (dfgpu_\w+)\(", sys_rs))
     used = {}
-    for f in ("lib.rs", "table.rs", "device.rs", "expr.rs", "hash_join.rs", "operators.rs", "rule.rs", "ffi.rs"):
+    for f in ("lib.rs", "table.rs", "device.rs", "expr.rs", "hash_join.rs", "operators.rs", "rule.rs", "ffi.rs", "scan.rs"):
         used[f] = set(re.findall(r"sys::(dfgpu_[a-z0-9_]+)\(", _shim(f)))
         assert used[f] <= declared, (f, used[f] - declared)
     hj = _shim("hash_join.rs")
