@@ -216,9 +216,13 @@ Column slice_strings(const Column& in, int64_t offset, int64_t length) {
 // slots[s] = (first row holding the slot's string) + 1, 0 = empty.  A row either claims an empty slot or finds a slot whose
 // representative has the same bytes; in that case it lowers the representative to itself when it comes earlier in the
 // table (atomicMin): after the pass every slot holds the FIRST row of its string, whatever order the waves ran in.
+// `claims` (optional): a table tried at a fraction of the worst-case size — claimed slots are counted, and once they pass `max_claims`
+// the table is declared too small (claims[1] = 1) and every row gives up at once; the host then interns into the full-size table.
 __global__ __launch_bounds__(BLOCK) void k_str_intern(const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ valid, int64_t n,
-                                                      unsigned* __restrict__ slots, uint64_t mask, uint32_t* __restrict__ row_slot) {
+                                                      unsigned* __restrict__ slots, uint64_t mask, uint32_t* __restrict__ row_slot, unsigned* __restrict__ claims = nullptr,
+                                                      unsigned max_claims = 0) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (claims && __hip_atomic_load(&claims[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     if (valid && !bit_at(valid, i)) {
       row_slot[i] = 0xFFFFFFFFu;
       continue;
@@ -231,7 +235,10 @@ __global__ __launch_bounds__(BLOCK) void k_str_intern(const int64_t* __restrict_
       unsigned cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (cur == 0u) {
         cur = atomicCAS(&slots[s], 0u, me);
-        if (cur == 0u) break;  // claimed
+        if (cur == 0u) {  // claimed
+          if (claims && atomicAdd(&claims[0], 1u) >= max_claims) __hip_atomic_store(&claims[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
       }
       const int64_t rep = (int64_t)cur - 1;
       if (off[rep + 1] - off[rep] == len && bytes_equal(bytes + off[rep], p, len)) {
@@ -293,8 +300,12 @@ Column dictionary_encode(const Column& in, bool sorted) {
     fprintf(stderr, "[dict] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
-  uint64_t capacity = 1024;
-  while (capacity < (uint64_t)n * 2) capacity <<= 1;
+  // A table for the worst case (every row its own string) has 2 n slots: 256 MB for 30 M rows, every probe of it a line of HBM /
+  // Infinity Cache.  Columns worth a dictionary have far fewer distinct strings, so a table of at most 1 Mi slots (4 MB: L2) is
+  // tried first; the kernel counts its claims and gives up when half of it is taken (then: the full-size table).
+  uint64_t full = 1024;
+  while (full < (uint64_t)n * 2) full <<= 1;
+  uint64_t capacity = std::min<uint64_t>(full, (uint64_t)1 << 20);
   BufPtr slots = make_zero_buf((size_t)capacity * 4);
   BufPtr row_slot = make_buf((size_t)n * 4 + 16);
   const int64_t row_words = (n + 63) / 64;
@@ -302,9 +313,21 @@ Column dictionary_encode(const Column& in, bool sorted) {
   BufPtr prefix = make_buf((size_t)(row_words + 1) * 8);
   {
     ProfileScope ps("string_intern", n * 12);
+    BufPtr claims = capacity < full ? make_zero_buf(8) : nullptr;
     k_str_intern<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(str_offsets(in), (const uint8_t*)in.ptr(), in.valid_words(), n, slots->as<unsigned>(), capacity - 1,
-                                                             row_slot->as<uint32_t>());
+                                                             row_slot->as<uint32_t>(), claims ? claims->as<unsigned>() : nullptr, (unsigned)(capacity / 2));
     DFGPU_HIP(hipGetLastError());
+    if (claims) {
+      unsigned c2[2] = {0, 0};
+      d2h(c2, claims->ptr, 8);
+      if (c2[1]) {  // more distinct strings than the small table takes
+        capacity = full;
+        slots = make_zero_buf((size_t)capacity * 4);
+        k_str_intern<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(str_offsets(in), (const uint8_t*)in.ptr(), in.valid_words(), n, slots->as<unsigned>(), capacity - 1,
+                                                                 row_slot->as<uint32_t>());
+        DFGPU_HIP(hipGetLastError());
+      }
+    }
   }
   phase("alloc + intern kernel");
   k_str_mark_reps<<<grid_for((int64_t)capacity, BLOCK), BLOCK, 0, r.stream>>>(slots->as<unsigned>(), capacity, rep_mask->as<unsigned long long>());
@@ -339,7 +362,17 @@ Column dictionary_encode(const Column& in, bool sorted) {
       int32_t idx;
     };
     std::vector<SortKey> order((size_t)G);
-    for (int64_t k = 0; k < G; k++) {
+    const int TP = (int)std::max<int64_t>(1, std::min<int64_t>({16, (int64_t)std::thread::hardware_concurrency(), G / 8192}));
+    auto parallel_for = [&](auto&& body) {  // body(k) for k in [0, G), in TP contiguous chunks
+      if (TP <= 1) {
+        for (int64_t k = 0; k < G; k++) body(k);
+        return;
+      }
+      std::vector<std::thread> th;
+      for (int t = 0; t < TP; t++) th.emplace_back([&, t] { for (int64_t k = G * t / TP; k < G * (t + 1) / TP; k++) body(k); });
+      for (auto& x : th) x.join();
+    };
+    parallel_for([&](int64_t k) {
       const std::string_view v = value_at((int32_t)k);
       SortKey& o = order[(size_t)k];
       o.len = (uint32_t)v.size();
@@ -352,7 +385,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
         }
         o.w[q] = x;
       }
-    }
+    });
     phase("sort keys (prefix words)");
     auto less = [&](const SortKey& a, const SortKey& b) {
       if (a.w[0] != b.w[0]) return a.w[0] < b.w[0];
@@ -383,10 +416,10 @@ Column dictionary_encode(const Column& in, bool sorted) {
     }
     phase("host sort (threads)");
     std::vector<int32_t> rank((size_t)G);
-    for (int64_t k = 0; k < G; k++) {
+    parallel_for([&](int64_t k) {
       rank[(size_t)order[(size_t)k].idx] = (int32_t)k;
       dv->values[(size_t)k] = std::string(value_at(order[(size_t)k].idx));
-    }
+    });
     renumber = make_buf((size_t)G * 4);
     DFGPU_HIP(hipMemcpyAsync(renumber->ptr, rank.data(), (size_t)G * 4, hipMemcpyHostToDevice, r.stream));
     DFGPU_HIP(hipStreamSynchronize(r.stream));  // `rank` is a local

@@ -56,7 +56,7 @@ def _merge_sorted(table: DeviceTable, keys, fetch, group=None) -> DeviceTable:
     import pyarrow as pa
     first = table.schema.field(table.index_of(keys[0][0])).type if keys else None
     int_like = first is not None and (pa.types.is_integer(first) or pa.types.is_date32(first)) and first not in (pa.uint64(), pa.int8(), pa.int16(), pa.uint16()) and \
-        table.dictionary_size(keys[0][0]) < 0       # (a dictionary-encoded string key is ordered by its strings, not by its indices on every rank)
+        table.dictionary_size(keys[0][0]) is None       # (a dictionary-encoded string key is ordered by its strings, not by its indices on every rank)
     if fetch is None and int_like:
         # an unbounded ORDER BY: sample sort.  Rows move to the rank that owns their first key's range (dfgpu_exchange_range:
         # splitters from all ranks' samples, all-to-all(v)), every rank sorts ITS range, and the ranges read in rank order are the
