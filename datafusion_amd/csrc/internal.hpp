@@ -1,6 +1,7 @@
 // internal.hpp — host-side plumbing shared by every translation unit of libdfgpu.so:
 // error channel, HBM pool allocator, stream, launch/profiling helpers, Column/Table.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -102,6 +103,7 @@ struct Runtime {
   std::multimap<size_t, void*> free_blocks;
   std::map<void*, size_t> live;  // ptr -> capacity
   int64_t in_use = 0, cached = 0, peak = 0;
+  std::atomic<int64_t> driver_allocs{0}, driver_alloc_ns{0};   // pool misses: hipMalloc calls and the host time they took
 
   void* alloc(size_t bytes);
   void free(void* p);
@@ -157,6 +159,34 @@ BufPtr make_zero_buf(size_t bytes);
 
 // scratch helper for small host<->device scalars
 void d2h(void* dst, const void* src, size_t n);  // synchronous w.r.t. the library stream
+// Pinned host memory from the process-wide pool of the export path (table.hip).  A copy between HBM and PAGEABLE memory beyond a
+// few hundred KB makes the driver pin the caller's pages for the copy; freeing such memory afterwards invalidates a range the kernel
+// driver still tracks, which evicts the process's queues until a worker restores them — measured as 14-23 ms of dead time at the
+// start of the NEXT call (profiles/r3_strings.md).  Downloads the library itself consumes go through these blocks instead.
+void* pinned_alloc(size_t n);
+void pinned_release(void* p);
+// std::vector over such blocks for host-side staging that is uploaded and dropped (the Parquet chunk plans); plain memory in a
+// process without a GPU
+void* stage_alloc(size_t n);
+template <class T> struct StageAllocator {
+  using value_type = T;
+  StageAllocator() = default;
+  template <class U> StageAllocator(const StageAllocator<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(stage_alloc(n * sizeof(T))); }
+  void deallocate(T* p, size_t) { pinned_release(p); }
+  template <class U> bool operator==(const StageAllocator<U>&) const { return true; }
+  template <class U> bool operator!=(const StageAllocator<U>&) const { return false; }
+};
+template <class T> using StageVec = std::vector<T, StageAllocator<T>>;
+struct PinnedBuf {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  explicit PinnedBuf(size_t n) : ptr(pinned_alloc(n ? n : 1)), bytes(n) {}
+  ~PinnedBuf() { pinned_release(ptr); }
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
+};
 void h2d_async(void* dst, const void* src, size_t n);
 
 // ---------------------------------------------------------------------------------------

@@ -21,8 +21,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <mutex>
 #include <numeric>
+#include <thread>
 
 namespace dfgpu {
 namespace {
@@ -326,7 +329,7 @@ struct PageDesc {
 struct ChunkPlan {       // everything the host learns from one chunk
   std::vector<PageDesc> pages;
   std::vector<Run> runs;
-  std::vector<uint8_t> staging;        // value bytes of every page (PLAIN values, packed index bits)
+  StageVec<uint8_t> staging;           // value bytes of every page (PLAIN values, packed index bits)
   std::vector<uint64_t> validity;      // one bit per row; empty = no nulls
   std::vector<uint8_t> dict_page;      // PLAIN-encoded dictionary values (uncompressed)
   int32_t dict_count = 0;
@@ -334,9 +337,9 @@ struct ChunkPlan {       // everything the host learns from one chunk
   dfgpu_parquet_chunk_info info{};
   // BYTE_ARRAY read as Utf8 (field.type DFGPU_UTF8): every non-null value as (offset, length) into str_bytes — a PLAIN page's
   // body goes there as it is (the offsets skip its 4-byte length prefixes), the dictionary's strings once
-  std::vector<int64_t> str_src;
-  std::vector<uint32_t> str_len;
-  std::vector<uint8_t> str_bytes;
+  StageVec<int64_t> str_src;           // (pinned staging: uploaded once and dropped, see internal.hpp PinnedBuf)
+  StageVec<uint32_t> str_len;
+  StageVec<uint8_t> str_bytes;
   std::vector<int64_t> dict_src;       // the dictionary's strings in str_bytes
   std::vector<uint32_t> dict_len;
   std::vector<uint8_t> bool_values;    // BOOLEAN: one byte per non-null value
@@ -969,3 +972,152 @@ int dfgpu_parquet_decode_chunk(const uint8_t* chunk, int64_t chunk_bytes, const 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------ a scan's chunks in one call
+// One worker per host thread asked for: a chunk's host half (page headers, decompression, levels, run headers) runs on that
+// thread, its device half on that thread's stream — the same shape as a scan node decoding from its partition threads, without
+// a call through the boundary (and, for the Python face, without the interpreter) per chunk.
+struct ScanShared {
+  const dfgpu_parquet_chunk* chunks;
+  int64_t n;
+  dfgpu_cache_t cache;
+  std::vector<std::unique_ptr<Table>>* out;
+  std::atomic<int64_t> next{0};
+  std::mutex mu;
+  std::string error;
+  dfgpu_metrics metrics{};   // the workers' metrics, folded into the caller's
+  int64_t from_cache = 0;
+};
+static std::unique_ptr<Table> scan_one_chunk(const dfgpu_parquet_chunk& ch, dfgpu_cache_t cache, bool& hit) {
+  hit = false;
+  if (cache && ch.cache_key && ch.cache_key_bytes > 0) {
+    dfgpu_table_t got = nullptr;
+    if (dfgpu_cache_get(cache, ch.cache_key, ch.cache_key_bytes, &got) != 0) throw Error(dfgpu_last_error());
+    if (got) {
+      hit = true;
+      return std::unique_ptr<Table>(unwrap_quiet(got));
+    }
+  }
+  DFGPU_CHECK(ch.bytes && ch.n_bytes >= 0, "parquet: null chunk");
+  auto t = std::make_unique<Table>();
+  dfgpu_parquet_column col = ch.column;
+  try {
+    t->cols.push_back(decode_chunk(ch.bytes, ch.n_bytes, col));
+  } catch (const Error& e) {
+    // a string chunk whose writer fell back to PLAIN pages: Utf8 bytes instead of dictionary indices (the caller brings the
+    // chunks of the column to one kind)
+    if (col.physical_type != DFGPU_PARQUET_BYTE_ARRAY || col.field.type == DFGPU_UTF8 || std::string(e.what()).find("read the column as Utf8") == std::string::npos) throw;
+    col.field.type = DFGPU_UTF8;
+    t->cols.push_back(decode_chunk(ch.bytes, ch.n_bytes, col));
+  }
+  t->nrows = t->cols[0].length;
+  t->device = current_device();
+  if (cache && ch.cache_key && ch.cache_key_bytes > 0) {
+    DFGPU_HIP(hipStreamSynchronize(rt().stream));   // other threads may take it from the cache at once
+    if (dfgpu_cache_put(cache, ch.cache_key, ch.cache_key_bytes, wrap_quiet(t.get())) != 0) throw Error(dfgpu_last_error());
+  }
+  return t;
+}
+static void scan_worker(ScanShared& sh, int device, bool own_thread) {
+  if (own_thread) {
+    use_device(device);
+    thread_metrics() = dfgpu_metrics{};
+  }
+  for (;;) {
+    const int64_t k = sh.next.fetch_add(1);
+    if (k >= sh.n) break;
+    {
+      std::lock_guard<std::mutex> lk(sh.mu);
+      if (!sh.error.empty()) break;
+    }
+    try {
+      bool hit = false;
+      (*sh.out)[(size_t)k] = scan_one_chunk(sh.chunks[k], sh.cache, hit);
+      if (hit) {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        sh.from_cache++;
+      }
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> lk(sh.mu);
+      if (sh.error.empty()) sh.error = e.what();
+    }
+  }
+  if (own_thread) {
+    call_epilogue();   // drains this thread's stream; the blocks it freed join the pool
+    std::lock_guard<std::mutex> lk(sh.mu);
+    const dfgpu_metrics& m = thread_metrics();
+    sh.metrics.h2d_bytes += m.h2d_bytes;
+    sh.metrics.d2h_bytes += m.d2h_bytes;
+    sh.metrics.hbm_bytes_algorithmic += m.hbm_bytes_algorithmic;
+  }
+}
+
+extern "C" int dfgpu_parquet_read_chunks(const dfgpu_parquet_chunk* chunks, int32_t n_row_groups, int32_t n_columns, int32_t threads, dfgpu_cache_t cache,
+                                         dfgpu_table_t* out, int64_t* chunks_from_cache) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(chunks && out && n_row_groups >= 1 && n_columns >= 1, "bad argument");
+    const int64_t n = (int64_t)n_row_groups * n_columns;
+    std::vector<std::unique_ptr<Table>> parts((size_t)n);
+    ScanShared sh;
+    sh.chunks = chunks;
+    sh.n = n;
+    sh.cache = cache;
+    sh.out = &parts;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
+    const int device = current_device();
+    if (T <= 1) {
+      scan_worker(sh, device, false);
+    } else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; t++) th.emplace_back([&] { scan_worker(sh, device, true); });
+      for (auto& x : th) x.join();
+      dfgpu_metrics& m = thread_metrics();
+      m.h2d_bytes += sh.metrics.h2d_bytes;
+      m.d2h_bytes += sh.metrics.d2h_bytes;
+      m.hbm_bytes_algorithmic += sh.metrics.hbm_bytes_algorithmic;
+    }
+    if (!sh.error.empty()) throw Error(sh.error);
+    if (chunks_from_cache) *chunks_from_cache = sh.from_cache;
+    DFGPU_HIP(hipStreamSynchronize(rt().stream));
+    // a string column whose chunks came out in both kinds (dictionary indices here, Utf8 bytes there) becomes Utf8 everywhere
+    for (int j = 0; j < n_columns; j++) {
+      bool any_utf8 = false, any_dict = false;
+      for (int g = 0; g < n_row_groups; g++) {
+        const Column& c = parts[(size_t)g * n_columns + j]->cols[0];
+        (c.field.type == DFGPU_UTF8 ? any_utf8 : any_dict) = true;
+      }
+      if (!(any_utf8 && any_dict)) continue;
+      for (int g = 0; g < n_row_groups; g++) {
+        Column& c = parts[(size_t)g * n_columns + j]->cols[0];
+        if (c.field.type != DFGPU_UTF8) {
+          auto fresh = std::make_unique<Table>(*parts[(size_t)g * n_columns + j]);   // (the cached chunk keeps its own form)
+          fresh->cols[0] = dictionary_decode(c);
+          parts[(size_t)g * n_columns + j] = std::move(fresh);
+        }
+      }
+    }
+    // row groups side by side, then one below the other
+    std::vector<std::unique_ptr<Table>> groups;
+    for (int g = 0; g < n_row_groups; g++) {
+      auto t = std::make_unique<Table>();
+      t->device = device;
+      t->nrows = parts[(size_t)g * n_columns]->nrows;
+      for (int j = 0; j < n_columns; j++) {
+        Table& p = *parts[(size_t)g * n_columns + j];
+        DFGPU_CHECK(p.nrows == t->nrows, "parquet: the column chunks of a row group differ in row count");
+        t->cols.push_back(p.cols[0]);
+      }
+      groups.push_back(std::move(t));
+    }
+    if (n_row_groups == 1) {
+      *out = wrap(groups[0].release());
+      return;
+    }
+    std::vector<dfgpu_table_t> hs;
+    for (auto& g : groups) hs.push_back(wrap_quiet(g.get()));
+    dfgpu_table_t whole = nullptr;
+    if (dfgpu_table_concat(hs.data(), (int)hs.size(), &whole) != 0) throw Error(dfgpu_last_error());
+    *out = whole;
+  });
+}

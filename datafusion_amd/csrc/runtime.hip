@@ -2,6 +2,7 @@
 // HBM pool allocator, the thread-local error channel and per-kernel HIP-event profiling.
 #include "internal.hpp"
 
+#include <chrono>
 #include <algorithm>
 #include <atomic>
 
@@ -186,7 +187,10 @@ void* Runtime::alloc(size_t bytes) {
     }
   }
   void* p = nullptr;
+  const auto t_driver = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&p, cap);
+  driver_allocs.fetch_add(1, std::memory_order_relaxed);
+  driver_alloc_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_driver).count(), std::memory_order_relaxed);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     trim();  // give cached blocks back to the driver and retry once

@@ -216,13 +216,9 @@ Column slice_strings(const Column& in, int64_t offset, int64_t length) {
 // slots[s] = (first row holding the slot's string) + 1, 0 = empty.  A row either claims an empty slot or finds a slot whose
 // representative has the same bytes; in that case it lowers the representative to itself when it comes earlier in the
 // table (atomicMin): after the pass every slot holds the FIRST row of its string, whatever order the waves ran in.
-// `claims` (optional): a table tried at a fraction of the worst-case size — claimed slots are counted, and once they pass `max_claims`
-// the table is declared too small (claims[1] = 1) and every row gives up at once; the host then interns into the full-size table.
 __global__ __launch_bounds__(BLOCK) void k_str_intern(const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ valid, int64_t n,
-                                                      unsigned* __restrict__ slots, uint64_t mask, uint32_t* __restrict__ row_slot, unsigned* __restrict__ claims = nullptr,
-                                                      unsigned max_claims = 0) {
+                                                      unsigned* __restrict__ slots, uint64_t mask, uint32_t* __restrict__ row_slot) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    if (claims && __hip_atomic_load(&claims[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     if (valid && !bit_at(valid, i)) {
       row_slot[i] = 0xFFFFFFFFu;
       continue;
@@ -235,10 +231,7 @@ __global__ __launch_bounds__(BLOCK) void k_str_intern(const int64_t* __restrict_
       unsigned cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (cur == 0u) {
         cur = atomicCAS(&slots[s], 0u, me);
-        if (cur == 0u) {  // claimed
-          if (claims && atomicAdd(&claims[0], 1u) >= max_claims) __hip_atomic_store(&claims[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
+        if (cur == 0u) break;  // claimed
       }
       const int64_t rep = (int64_t)cur - 1;
       if (off[rep + 1] - off[rep] == len && bytes_equal(bytes + off[rep], p, len)) {
@@ -297,39 +290,28 @@ Column dictionary_encode(const Column& in, bool sorted) {
     if (!trace) return;
     (void)hipStreamSynchronize(r.stream);
     const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[dict] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    fprintf(stderr, "[dict] %-28s %8.3f ms   (pool misses so far: %lld hipMalloc calls, %.3f ms)\n", what, std::chrono::duration<double, std::milli>(now - t_last).count(),
+            (long long)r.driver_allocs.load(), (double)r.driver_alloc_ns.load() * 1e-6);
     t_last = now;
   };
-  // A table for the worst case (every row its own string) has 2 n slots: 256 MB for 30 M rows, every probe of it a line of HBM /
-  // Infinity Cache.  Columns worth a dictionary have far fewer distinct strings, so a table of at most 1 Mi slots (4 MB: L2) is
-  // tried first; the kernel counts its claims and gives up when half of it is taken (then: the full-size table).
-  uint64_t full = 1024;
-  while (full < (uint64_t)n * 2) full <<= 1;
-  uint64_t capacity = std::min<uint64_t>(full, (uint64_t)1 << 20);
+  // 2 slots per row: every row its own string is the worst case.  (A cache-sized table tried first — 1 Mi slots, claims counted,
+  // the full-size table on overflow — was measured and dropped: at 150 K distinct strings the intern kernel went 1.81 -> 2.39 ms,
+  // every collision being a byte compare with somebody else's string; profiles/r3_strings.md.)
+  uint64_t capacity = 1024;
+  while (capacity < (uint64_t)n * 2) capacity <<= 1;
   BufPtr slots = make_zero_buf((size_t)capacity * 4);
   BufPtr row_slot = make_buf((size_t)n * 4 + 16);
   const int64_t row_words = (n + 63) / 64;
   BufPtr rep_mask = make_zero_buf((size_t)row_words * 8);
   BufPtr prefix = make_buf((size_t)(row_words + 1) * 8);
+  phase("allocations");
   {
     ProfileScope ps("string_intern", n * 12);
-    BufPtr claims = capacity < full ? make_zero_buf(8) : nullptr;
     k_str_intern<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(str_offsets(in), (const uint8_t*)in.ptr(), in.valid_words(), n, slots->as<unsigned>(), capacity - 1,
-                                                             row_slot->as<uint32_t>(), claims ? claims->as<unsigned>() : nullptr, (unsigned)(capacity / 2));
+                                                             row_slot->as<uint32_t>());
     DFGPU_HIP(hipGetLastError());
-    if (claims) {
-      unsigned c2[2] = {0, 0};
-      d2h(c2, claims->ptr, 8);
-      if (c2[1]) {  // more distinct strings than the small table takes
-        capacity = full;
-        slots = make_zero_buf((size_t)capacity * 4);
-        k_str_intern<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(str_offsets(in), (const uint8_t*)in.ptr(), in.valid_words(), n, slots->as<unsigned>(), capacity - 1,
-                                                                 row_slot->as<uint32_t>());
-        DFGPU_HIP(hipGetLastError());
-      }
-    }
   }
-  phase("alloc + intern kernel");
+  phase("intern kernel");
   k_str_mark_reps<<<grid_for((int64_t)capacity, BLOCK), BLOCK, 0, r.stream>>>(slots->as<unsigned>(), capacity, rep_mask->as<unsigned long long>());
   scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
   const int64_t G = (int64_t)read_u64(prefix->as<uint64_t>() + row_words);
@@ -341,14 +323,16 @@ Column dictionary_encode(const Column& in, bool sorted) {
   phase("mark reps + scan + count");
   Column values = gather_strings(plain, ids->as<int64_t>(), G, false);
   phase("gather distinct strings");
-  std::vector<int64_t> hoff((size_t)G + 1, 0);
-  d2h(hoff.data(), values.offsets->ptr, (size_t)(G + 1) * 8);
-  std::vector<char> hbytes((size_t)hoff[(size_t)G] + 1);
-  if (hoff[(size_t)G]) d2h(hbytes.data(), values.data->ptr, (size_t)hoff[(size_t)G]);
+  PinnedBuf hoff_buf((size_t)(G + 1) * 8);   // pinned: see internal.hpp PinnedBuf
+  int64_t* const hoff = hoff_buf.as<int64_t>();
+  d2h(hoff, values.offsets->ptr, (size_t)(G + 1) * 8);
+  PinnedBuf hbytes_buf((size_t)hoff[(size_t)G] + 1);
+  char* const hbytes = hbytes_buf.as<char>();
+  if (hoff[(size_t)G]) d2h(hbytes, values.data->ptr, (size_t)hoff[(size_t)G]);
   phase("download offsets + bytes");
   dv->values.resize((size_t)G);
   dv->valid.assign((size_t)G, 1);
-  auto value_at = [&](int32_t k) { return std::string_view(hbytes.data() + hoff[(size_t)k], (size_t)(hoff[(size_t)k + 1] - hoff[(size_t)k])); };
+  auto value_at = [&](int32_t k) { return std::string_view(hbytes + hoff[(size_t)k], (size_t)(hoff[(size_t)k + 1] - hoff[(size_t)k])); };
   BufPtr renumber;
   if (sorted && G > 1) {
     // ascending order of the distinct strings (byte order = code point order): views into the one downloaded buffer, sorted in
@@ -415,14 +399,15 @@ Column dictionary_encode(const Column& in, bool sorted) {
       }
     }
     phase("host sort (threads)");
-    std::vector<int32_t> rank((size_t)G);
+    PinnedBuf rank_buf((size_t)G * 4);
+    int32_t* const rank = rank_buf.as<int32_t>();
     parallel_for([&](int64_t k) {
       rank[(size_t)order[(size_t)k].idx] = (int32_t)k;
       dv->values[(size_t)k] = std::string(value_at(order[(size_t)k].idx));
     });
     renumber = make_buf((size_t)G * 4);
-    DFGPU_HIP(hipMemcpyAsync(renumber->ptr, rank.data(), (size_t)G * 4, hipMemcpyHostToDevice, r.stream));
-    DFGPU_HIP(hipStreamSynchronize(r.stream));  // `rank` is a local
+    DFGPU_HIP(hipMemcpyAsync(renumber->ptr, rank, (size_t)G * 4, hipMemcpyHostToDevice, r.stream));
+    DFGPU_HIP(hipStreamSynchronize(r.stream));  // `rank_buf` is a local
   } else {
     for (int64_t k = 0; k < G; k++) dv->values[(size_t)k] = std::string(value_at((int32_t)k));  // first-seen order
   }

@@ -117,7 +117,7 @@ struct Uploader {
     if (n == 0) return;
     thread_metrics().h2d_bytes += (int64_t)n;
     // pin large host buffers so the copy engine streams at PCIe rate without a bounce buffer
-    if (n >= (size_t(8) << 20)) {
+    if (n >= (size_t(1) << 20)) {   // (from 1 MiB: a pageable copy of that size makes the driver pin the pages itself, and it keeps track of them afterwards)
       if (hipHostRegister(const_cast<void*>(src), n, hipHostRegisterDefault) == hipSuccess) registered.push_back(const_cast<void*>(src));
       else (void)hipGetLastError();
     }
@@ -346,6 +346,23 @@ struct PinnedPool {
     live[p] = c;
     return p;
   }
+  // for staging vectors (internal.hpp StageVec): plain memory where nothing can be pinned — the host halves of the scan run
+  // without a GPU (dfgpu_parquet_inspect_chunk, dfgpu_ipc_open) — or with DFGPU_PINNED_STAGING=0
+  void* alloc_or_plain(size_t n) {
+    static const bool off = std::getenv("DFGPU_PINNED_STAGING") && std::atoi(std::getenv("DFGPU_PINNED_STAGING")) == 0;
+    if (!off && current_device() >= 0) {
+      try {
+        return alloc(n);
+      } catch (const Error&) {
+        (void)hipGetLastError();
+      }
+    }
+    void* p = std::malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    std::lock_guard<std::mutex> lk(mu);
+    live[p] = 0;   // 0 = not ours to cache
+    return p;
+  }
   void release(void* p) {
     if (!p) return;
     size_t c = 0;
@@ -355,6 +372,10 @@ struct PinnedPool {
       if (it == live.end()) return;
       c = it->second;
       live.erase(it);
+      if (c == 0) {
+        std::free(p);
+        return;
+      }
       if (cached + c <= cap()) {
         free_blocks.emplace(c, p);
         cached += c;
@@ -368,6 +389,10 @@ static PinnedPool& pinned() {
   static PinnedPool* p = new PinnedPool();  // never destroyed: release callbacks may run at interpreter exit
   return *p;
 }
+
+void* pinned_alloc(size_t n) { return pinned().alloc(n); }
+void* stage_alloc(size_t n) { return pinned().alloc_or_plain(n); }
+void pinned_release(void* p) { pinned().release(p); }
 
 struct ExportPrivate {
   std::vector<void*> host_buffers;
@@ -550,8 +575,10 @@ static void export_rows(Table* t, int64_t offset, int64_t length, struct ArrowAr
     if (c.field.type == DFGPU_UTF8) {
       // strings: offsets first (their ends give the byte range), rebased to the slice; Utf8 while the bytes fit 32-bit
       // offsets, LargeUtf8 beyond
-      std::vector<int64_t> ho((size_t)rows + 1, 0);
-      if (rows) d2h(ho.data(), (const char*)c.offsets->ptr + (size_t)first * 8, (size_t)(rows + 1) * 8);
+      PinnedBuf ho_buf((size_t)(rows + 1) * 8);   // (pinned: internal.hpp PinnedBuf)
+      int64_t* const ho = ho_buf.as<int64_t>();
+      ho[0] = 0;
+      if (rows) d2h(ho, (const char*)c.offsets->ptr + (size_t)first * 8, (size_t)(rows + 1) * 8);
       const int64_t b0 = ho[0], nbytes = ho[(size_t)rows] - b0;
       const bool large = nbytes > 0x7FFFFFFFll;
       void* hoff = pinned().alloc((size_t)(rows + 1) * (large ? 8 : 4) + 8);

@@ -277,9 +277,10 @@ class ParquetFile:
         return out
 
     def read(self, columns=None, threads: int | None = None, row_groups=None) -> DeviceTable:
-        """all row groups.  The host half of a chunk (decompression above all) runs on one core, so chunks are decoded from
-        `threads` host threads (default min(16, cores), DFGPU_SCAN_THREADS overrides; ctypes releases the GIL) — the way the
-        reference's scan decodes row groups on its partition threads.  All device work stays on the library's one stream."""
+        """all row groups (or the given ones), through dfgpu_parquet_read_chunks: the host half of a chunk (decompression above
+        all) runs on one core, so the library decodes the chunks from `threads` host threads of its own (default min(16, cores),
+        DFGPU_SCAN_THREADS overrides), each on a stream of its own — the way the reference's scan decodes row groups on its
+        partition threads."""
         _lib.init()
         names = list(columns or self.column_names)
         groups = list(range(self.num_row_groups)) if row_groups is None else list(row_groups)
@@ -289,30 +290,22 @@ class ParquetFile:
             return DeviceTable.from_arrow(pa.Table.from_arrays(empty, names=sch.names))
         if threads is None:
             threads = int(os.environ.get("DFGPU_SCAN_THREADS", min(16, os.cpu_count() or 1)))
+        # ONE call: the library's own host threads take the chunks off the list (dfgpu_parquet_read_chunks), look them up in the
+        # chunk cache, decode the others and put the row groups together on the device
         work = [(g, c) for g in groups for c in names]
-        if threads > 1 and len(work) > 1:
-            with ThreadPoolExecutor(threads) as ex:
-                chunks = list(ex.map(lambda gc: self._decode(*gc), work))
-        else:
-            chunks = [self._decode(g, c) for g, c in work]
-        # a string column whose chunks came out in both kinds (dictionary indices here, Utf8 bytes there) becomes Utf8 everywhere
-        from .table import UTF8
-        for j, name in enumerate(names):
-            col_chunks = [chunks[k * len(names) + j] for k in range(len(groups))]
-            kinds = {t.column_view(0).field.type == UTF8 for t in col_chunks}
-            if kinds == {True, False}:
-                for k in range(len(groups)):
-                    t = chunks[k * len(names) + j]
-                    if t.column_view(0).field.type != UTF8:
-                        chunks[k * len(names) + j] = t.dictionary_decode()
-                        t.free()
-        parts = [self._hstack(chunks[k * len(names):(k + 1) * len(names)]) for k in range(len(groups))]
-        if len(parts) == 1:
-            return parts[0]
-        out = DeviceTable.concat(parts)
-        for p in parts:
-            p.free()
-        return out
+        arr = (_lib.ParquetChunk * len(work))()
+        keep = []
+        for k, (g, c) in enumerate(work):
+            buf, n, d, names_alive = self._chunk(g, c)
+            key = CACHE._key(self._identity + (g, c))
+            keep.append((names_alive, key))
+            arr[k].bytes, arr[k].n_bytes, arr[k].column = buf, n, d
+            arr[k].cache_key, arr[k].cache_key_bytes = key, len(key)
+        out, hits = C.c_void_p(), C.c_int64()
+        check(_lib.load().dfgpu_parquet_read_chunks(arr, len(groups), len(names), threads, CACHE._handle() if CACHE.budget > 0 else None, C.byref(out),
+                                                    C.byref(hits)))
+        self.chunks_from_cache = hits.value
+        return DeviceTable(out)
 
 
 def read_table(path: str, columns=None, threads: int | None = None, bounds: dict | None = None, stats: dict | None = None, in_lists: dict | None = None,

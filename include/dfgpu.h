@@ -719,6 +719,23 @@ typedef struct dfgpu_parquet_chunk_info {
 } dfgpu_parquet_chunk_info;
 int dfgpu_parquet_inspect_chunk(const uint8_t* chunk, int64_t chunk_bytes, const dfgpu_parquet_column* column, dfgpu_parquet_chunk_info* out);
 
+/* The projected column chunks of a scan in ONE call: chunks[g * n_columns + j] = column j of the g-th row group read (file order).
+ * `threads` host threads inside the library each take chunks off the list — a chunk's host half on that thread, its device half on
+ * that thread's stream — as the reference's scan decodes row groups on its partition threads (DataSourceExec,
+ * datasource/src/source.rs:366); the row groups are then put side by side and below each other on the device.  A BYTE_ARRAY
+ * column asked for as dictionary indices comes back as Utf8 when any of its chunks holds PLAIN pages.  `cache` (may be NULL) +
+ * per-chunk keys: decoded chunks are taken from / left in the device chunk cache (dfgpu_cache_*), `chunks_from_cache` (may be NULL)
+ * counts the hits.  `out` = n_columns columns, the row groups' rows in order. */
+typedef struct dfgpu_parquet_chunk {
+  const uint8_t* bytes;          /* the chunk's byte range (dictionary page first), e.g. where the page cache maps the file */
+  int64_t n_bytes;
+  dfgpu_parquet_column column;
+  const void* cache_key;         /* NULL = not cached */
+  int64_t cache_key_bytes;
+} dfgpu_parquet_chunk;
+int dfgpu_parquet_read_chunks(const dfgpu_parquet_chunk* chunks, int32_t n_row_groups, int32_t n_columns, int32_t threads, dfgpu_cache_t cache,
+                              dfgpu_table_t* out, int64_t* chunks_from_cache);
+
 /* Arrow IPC files and streams (DataSourceExec over an ArrowSource, datasource-arrow/src/source.rs:260-330: arrow-ipc FileReader /
  * StreamReader) scanned straight into HBM.  The file already holds Arrow buffers: dfgpu_ipc_open walks the encapsulated messages of
  * the bytes it is given (a memory-mapped file; they must stay valid until dfgpu_ipc_close) — schema, dictionary batches, record

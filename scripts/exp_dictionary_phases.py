@@ -30,6 +30,23 @@ def run(label):
 
 
 run("fresh process")
+# exactly what bench_ops.py's strings block holds: the host table stays alive, a second column
+pool = np.array([f"Customer#{i:09d}" for i in range(distinct)])
+rng0 = np.random.default_rng(0)
+host = pa.table({"name": pa.array(pool[rng0.integers(0, distinct, size=n)], pa.string()), "v": pa.array(rng0.integers(0, 1000, size=n))})
+t_keep, t = t, DeviceTable.from_arrow(host)
+run("bench_ops.py's table (host table alive, two columns)")
+del host
+run("the same after dropping the host table")
+t.free()
+t = t_keep
+run("first table again")
+ops.profile_enable(True)
+ops.profile_reset()
+run("fresh process, per-kernel profiling on (what bench_ops.py's measure() does)")
+ops.profile_stats()
+ops.profile_enable(False)
+run("fresh process, profiling off again")
 big = [ops.tpch_lineitem(100.0), ops.tpch_orders(100.0)]        # what bench_ops.py holds before its strings cases
 j = ops.hash_join(big[1], big[0], [("o_orderkey", "l_orderkey")], "Inner", build_cols=["o_orderdate"], probe_cols=["l_orderkey", "l_extendedprice"], probe_mode=3)
 j.free()
