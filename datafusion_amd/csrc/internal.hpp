@@ -163,6 +163,7 @@ void d2h(void* dst, const void* src, size_t n);  // synchronous w.r.t. the libra
 // few hundred KB makes the driver pin the caller's pages for the copy; freeing such memory afterwards invalidates a range the kernel
 // driver still tracks, which evicts the process's queues until a worker restores them — measured as 14-23 ms of dead time at the
 // start of the NEXT call (profiles/r3_strings.md).  Downloads the library itself consumes go through these blocks instead.
+extern std::atomic<int64_t> g_pinned_driver_allocs, g_pinned_driver_ns;   // hipHostMalloc calls of the pinned pool and their host time
 void* pinned_alloc(size_t n);
 void pinned_release(void* p);
 // std::vector over such blocks for host-side staging that is uploaded and dropped (the Parquet chunk plans); plain memory in a
@@ -174,6 +175,10 @@ template <class T> struct StageAllocator {
   template <class U> StageAllocator(const StageAllocator<U>&) {}
   T* allocate(size_t n) { return static_cast<T*>(stage_alloc(n * sizeof(T))); }
   void deallocate(T* p, size_t) { pinned_release(p); }
+  // resize() leaves new elements uninitialised (they are about to be overwritten by a page body; zero-filling a staging buffer
+  // first doubles the host's memory traffic)
+  template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
   template <class U> bool operator==(const StageAllocator<U>&) const { return true; }
   template <class U> bool operator!=(const StageAllocator<U>&) const { return false; }
 };

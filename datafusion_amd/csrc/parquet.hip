@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <mutex>
 #include <numeric>
@@ -327,10 +328,10 @@ struct PageDesc {
 };
 
 struct ChunkPlan {       // everything the host learns from one chunk
-  std::vector<PageDesc> pages;
-  std::vector<Run> runs;
+  StageVec<PageDesc> pages;            // (everything uploaded lives in pinned staging: internal.hpp PinnedBuf)
+  StageVec<Run> runs;
   StageVec<uint8_t> staging;           // value bytes of every page (PLAIN values, packed index bits)
-  std::vector<uint64_t> validity;      // one bit per row; empty = no nulls
+  StageVec<uint64_t> validity;         // one bit per row; empty = no nulls
   std::vector<uint8_t> dict_page;      // PLAIN-encoded dictionary values (uncompressed)
   int32_t dict_count = 0;
   int64_t rows = 0, values = 0;        // rows incl. NULLs; non-null values
@@ -345,7 +346,7 @@ struct ChunkPlan {       // everything the host learns from one chunk
   std::vector<uint8_t> bool_values;    // BOOLEAN: one byte per non-null value
 };
 
-void set_bits(std::vector<uint64_t>& bm, int64_t pos, int64_t n) {
+void set_bits(StageVec<uint64_t>& bm, int64_t pos, int64_t n) {
   for (int64_t i = pos; i < pos + n;) {
     const int64_t w = i >> 6, b = i & 63;
     const int64_t take = std::min<int64_t>(64 - b, pos + n - i);
@@ -355,7 +356,7 @@ void set_bits(std::vector<uint64_t>& bm, int64_t pos, int64_t n) {
   }
 }
 // copy n bits from an LSB-first packed byte stream to bit position pos
-void copy_bits(std::vector<uint64_t>& bm, int64_t pos, const uint8_t* src, int64_t n) {
+void copy_bits(StageVec<uint64_t>& bm, int64_t pos, const uint8_t* src, int64_t n) {
   for (int64_t i = 0; i < n; i++)
     if ((src[i >> 3] >> (i & 7)) & 1) bm[(size_t)((pos + i) >> 6)] |= 1ull << ((pos + i) & 63);
 }
@@ -399,6 +400,24 @@ ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_c
   const uint8_t* p = chunk;
   const uint8_t* end = chunk + nbytes;
   std::vector<uint8_t> body;
+  {
+    // the staging buffer is sized once, from a walk over the page headers alone: growing it page by page re-copies what is
+    // already there (a 38 MB chunk: three times the memory traffic of the copy itself)
+    size_t need = 0;
+    int64_t rows = 0;
+    const uint8_t* q = chunk;
+    while (rows < col.num_values && q < end) {
+      Thrift t{q, end};
+      PageHeader h = parse_page_header(t);
+      if (h.compressed < 0 || h.uncompressed < 0 || end - t.p < h.compressed) break;   // (reported by the walk below)
+      q = t.p + h.compressed;
+      if (h.type == PAGE_DATA || h.type == PAGE_DATA_V2) {
+        need += (size_t)h.uncompressed + 32;
+        rows += h.num_values > 0 ? h.num_values : 0;
+      }
+    }
+    if (col.field.type != DFGPU_UTF8 && col.physical_type != DFGPU_PARQUET_BOOLEAN) P.staging.reserve(need);
+  }
   while (P.rows < col.num_values) {
     DFGPU_CHECK(p < end, "parquet: the chunk ends before its num_values rows");
     Thrift t{p, end};
@@ -426,14 +445,27 @@ ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_c
     DFGPU_CHECK(h.num_values >= 0 && P.rows + h.num_values <= col.num_values, "parquet: pages hold more rows than the chunk's num_values");
     DFGPU_CHECK(h.def_bytes >= 0 && h.rep_bytes >= 0, "parquet: negative level byte length");
     // ---- uncompressed page body: v1 = [def levels][values] compressed together; v2 = levels uncompressed + values
-    body.assign((size_t)h.uncompressed + 16, 0);
+    // Fixed-width values and dictionary indices are decoded on the device from the page body as it is, so the body is decompressed
+    // straight into the staging buffer that is uploaded (pinned; the few level bytes in front of the values ride along); strings,
+    // BOOLEAN and the host-decoded encodings go through a scratch body
+    const bool direct = col.field.type != DFGPU_UTF8 && col.physical_type != DFGPU_PARQUET_BOOLEAN &&
+                        (h.encoding == ENC_PLAIN || h.encoding == ENC_RLE_DICTIONARY || h.encoding == ENC_PLAIN_DICTIONARY);
+    uint8_t* body_at;
+    if (direct) {
+      const size_t body_base = (P.staging.size() + 15) & ~size_t(15);
+      P.staging.resize(body_base + (size_t)h.uncompressed + 16);   // +16: the unpacker reads whole 64-bit windows
+      body_at = P.staging.data() + body_base;
+    } else {
+      if (body.size() < (size_t)h.uncompressed + 16) body.resize((size_t)h.uncompressed + 16);
+      body_at = body.data();
+    }
     const uint8_t* levels = nullptr;
     int64_t level_bytes = 0;
     const uint8_t* values;
     const uint8_t* values_end;
     if (h.type == PAGE_DATA) {
-      decompress(col.codec, raw, (size_t)h.compressed, body.data(), (size_t)h.uncompressed);
-      const uint8_t* b = body.data();
+      decompress(col.codec, raw, (size_t)h.compressed, body_at, (size_t)h.uncompressed);
+      const uint8_t* b = body_at;
       if (nullable) {
         DFGPU_CHECK(h.def_encoding == ENC_RLE, "parquet: definition levels with the deprecated BIT_PACKED encoding");
         DFGPU_CHECK(h.uncompressed >= 4, "parquet: data page too short for its level length");
@@ -445,7 +477,7 @@ ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_c
         b += 4 + lb;
       }
       values = b;
-      values_end = body.data() + h.uncompressed;
+      values_end = body_at + h.uncompressed;
       P.info.n_data_pages_v1++;
     } else {
       DFGPU_CHECK(h.rep_bytes == 0, "parquet: repetition levels in a flat column");
@@ -453,9 +485,9 @@ ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_c
       levels = raw;
       level_bytes = h.def_bytes;
       const size_t vu = (size_t)(h.uncompressed - h.def_bytes), vc = (size_t)(h.compressed - h.def_bytes);
-      decompress(h.v2_compressed ? col.codec : DFGPU_PARQUET_UNCOMPRESSED, raw + h.def_bytes, vc, body.data(), vu);
-      values = body.data();
-      values_end = body.data() + vu;
+      decompress(h.v2_compressed ? col.codec : DFGPU_PARQUET_UNCOMPRESSED, raw + h.def_bytes, vc, body_at, vu);
+      values = body_at;
+      values_end = body_at + vu;
       P.info.n_data_pages_v2++;
     }
     // ---- definition levels -> validity bits, non-null count of the page
@@ -597,10 +629,8 @@ ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_c
     if (h.encoding == ENC_PLAIN) {
       DFGPU_CHECK(pw > 0, "parquet: PLAIN-encoded BYTE_ARRAY pages (strings outside a dictionary): read the column as Utf8 (field.type DFGPU_UTF8) instead of dictionary indices");
       DFGPU_CHECK(values_end - values >= nonnull * pw, "parquet: PLAIN values overrun the page");
-      P.staging.resize(base + (size_t)(nonnull * pw));
-      std::memcpy(P.staging.data() + base, values, (size_t)(nonnull * pw));
       d.kind = 0;
-      d.byte_offset = (int64_t)base;
+      d.byte_offset = (int64_t)(values - P.staging.data());   // (direct: the values lie in the staging buffer already)
       P.info.n_plain_pages++;
     } else if (h.encoding == ENC_RLE_DICTIONARY || h.encoding == ENC_PLAIN_DICTIONARY) {
       DFGPU_CHECK(!P.dict_page.empty() || P.dict_count == 0, "parquet: dictionary-encoded page without a dictionary page");
@@ -610,15 +640,14 @@ ChunkPlan plan_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_c
         const int bw = values[0];
         DFGPU_CHECK(bw <= 32, "parquet: dictionary index bit width " + std::to_string(bw));
         const uint8_t* rp = values + 1;
-        P.staging.resize(base + (size_t)(values_end - rp) + 8);   // +8: the unpacker reads whole 64-bit windows
-        std::memcpy(P.staging.data() + base, rp, (size_t)(values_end - rp));
+        const uint8_t* staged = P.staging.data();   // (direct: the runs lie in the staging buffer already)
         int64_t at = P.values;
         walk_runs(rp, values_end, bw, nonnull, [&](bool packed, int64_t cnt, uint64_t val, const uint8_t* bits) {
           Run r{};
           r.start = at;
           r.count = (int32_t)cnt;
           r.bit_width = packed ? (bw | RUN_PACKED) : bw;
-          r.payload = packed ? (int64_t)base + (bits - rp) : (int64_t)val;
+          r.payload = packed ? (int64_t)(bits - staged) : (int64_t)val;
           if (!packed) DFGPU_CHECK(val < (uint64_t)std::max(P.dict_count, 1), "parquet: dictionary index out of range");
           P.runs.push_back(r);
           (packed ? P.info.n_runs_bitpacked : P.info.n_runs_rle)++;
@@ -727,9 +756,9 @@ __global__ __launch_bounds__(BLOCK) void k_pq_expand(const T* __restrict__ dense
 namespace {
 
 // dictionary page (PLAIN) -> host array in the target representation
-std::vector<uint8_t> convert_dictionary(const ChunkPlan& P, const dfgpu_parquet_column& col, int out_w) {
+StageVec<uint8_t> convert_dictionary(const ChunkPlan& P, const dfgpu_parquet_column& col, int out_w) {
   const int pw = phys_width(col);
-  std::vector<uint8_t> out((size_t)std::max(P.dict_count, 1) * out_w, 0);
+  StageVec<uint8_t> out((size_t)std::max(P.dict_count, 1) * out_w, 0);
   DFGPU_CHECK((int64_t)P.dict_page.size() >= (int64_t)P.dict_count * pw, "parquet: dictionary page shorter than its value count");
   for (int32_t i = 0; i < P.dict_count; i++) {
     const uint8_t* s = P.dict_page.data() + (size_t)i * pw;
@@ -874,8 +903,20 @@ Column decode_bool_chunk(const ChunkPlan& P, const dfgpu_parquet_column& col) {
   return c;
 }
 
-Column decode_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_column& col) {
-  ChunkPlan P = plan_chunk(chunk, nbytes, col);
+thread_local double t_plan_ms = 0;   // host halves of this thread's chunks (DFGPU_TRACE_SCAN)
+thread_local double t_upload_ms[6] = {0, 0, 0, 0, 0, 0};
+// `keep` (optional): instead of waiting for the uploads, the host buffers they read from are handed to the caller, who lets go of
+// them once the stream has passed this point — a scan worker plans its next chunk while this one crosses PCIe
+struct ChunkSources {
+  ChunkPlan P;
+  StageVec<uint8_t> dict_host;
+};
+Column decode_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_column& col, std::shared_ptr<void>* keep = nullptr) {
+  const auto t_plan0 = std::chrono::steady_clock::now();
+  auto sources = std::make_shared<ChunkSources>();
+  ChunkPlan& P = sources->P;
+  P = plan_chunk(chunk, nbytes, col);
+  t_plan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
   if (col.field.type == DFGPU_UTF8) return decode_string_chunk(P, col);
   if (col.physical_type == DFGPU_PARQUET_BOOLEAN) return decode_bool_chunk(P, col);
   hipStream_t st = rt().stream;
@@ -884,7 +925,7 @@ Column decode_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_co
   const int out_w = type_width(f.type);
   Column c = alloc_column(f, col.name ? col.name : "", P.rows);
   // dictionary in the target representation
-  std::vector<uint8_t> dict_host;
+  StageVec<uint8_t>& dict_host = sources->dict_host;
   if (col.physical_type == DFGPU_PARQUET_BYTE_ARRAY) {
     std::vector<int32_t> rank;
     c.dict = string_dictionary(P, c.name, rank);
@@ -895,10 +936,20 @@ Column decode_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_co
   }
   BufPtr d_dict = make_buf(dict_host.size() + 16), d_stage = make_buf(P.staging.size() + 16);
   BufPtr d_pages = make_buf(P.pages.size() * sizeof(PageDesc) + 16), d_runs = make_buf(P.runs.size() * sizeof(Run) + 16);
+  auto tk = std::chrono::steady_clock::now();
+  auto lap = [&](int i) {
+    const auto now = std::chrono::steady_clock::now();
+    t_upload_ms[i] += std::chrono::duration<double, std::milli>(now - tk).count();
+    tk = now;
+  };
   if (!dict_host.empty()) DFGPU_HIP(hipMemcpyAsync(d_dict->ptr, dict_host.data(), dict_host.size(), hipMemcpyHostToDevice, st));
+  lap(0);
   if (!P.staging.empty()) DFGPU_HIP(hipMemcpyAsync(d_stage->ptr, P.staging.data(), P.staging.size(), hipMemcpyHostToDevice, st));
+  lap(1);
   if (!P.pages.empty()) DFGPU_HIP(hipMemcpyAsync(d_pages->ptr, P.pages.data(), P.pages.size() * sizeof(PageDesc), hipMemcpyHostToDevice, st));
+  lap(2);
   if (!P.runs.empty()) DFGPU_HIP(hipMemcpyAsync(d_runs->ptr, P.runs.data(), P.runs.size() * sizeof(Run), hipMemcpyHostToDevice, st));
+  lap(3);
   PqArgs a{};
   a.pages = d_pages->as<PageDesc>();
   a.runs = d_runs->as<Run>();
@@ -940,7 +991,9 @@ Column decode_chunk(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet_co
       default: launch_expand<uint8_t>(dense->ptr, c.valid_words(), prefix->as<uint64_t>(), P.rows, c.data->ptr); break;
     }
   }
-  DFGPU_HIP(hipStreamSynchronize(st));   // the host vectors above are the copies' sources
+  lap(4);
+  if (keep) *keep = sources;   // the copies' sources: the caller's until the stream has passed them
+  else DFGPU_HIP(hipStreamSynchronize(st));
   return c;
 }
 
@@ -982,14 +1035,20 @@ struct ScanShared {
   int64_t n;
   dfgpu_cache_t cache;
   std::vector<std::unique_ptr<Table>>* out;
+  std::vector<int64_t> order;   // largest chunk first: the slowest worker ends as early as a greedy schedule lets it
   std::atomic<int64_t> next{0};
   std::mutex mu;
   std::string error;
   dfgpu_metrics metrics{};   // the workers' metrics, folded into the caller's
   int64_t from_cache = 0;
+  double plan_ms = 0, worker_ms_max = 0, drain_ms_max = 0, settle_ms = 0, upload_ms[6] = {0, 0, 0, 0, 0, 0};   // DFGPU_TRACE_SCAN
 };
-static std::unique_ptr<Table> scan_one_chunk(const dfgpu_parquet_chunk& ch, dfgpu_cache_t cache, bool& hit) {
+// one chunk, launched: `keep` holds what its uploads read from (null when the chunk came from the cache or was decoded with a
+// wait inside), `to_cache` says whether it is to be put into the cache once complete
+static std::unique_ptr<Table> scan_one_chunk(const dfgpu_parquet_chunk& ch, dfgpu_cache_t cache, bool& hit, std::shared_ptr<void>& keep, bool& to_cache) {
   hit = false;
+  to_cache = false;
+  keep.reset();
   if (cache && ch.cache_key && ch.cache_key_bytes > 0) {
     dfgpu_table_t got = nullptr;
     if (dfgpu_cache_get(cache, ch.cache_key, ch.cache_key_bytes, &got) != 0) throw Error(dfgpu_last_error());
@@ -1002,48 +1061,92 @@ static std::unique_ptr<Table> scan_one_chunk(const dfgpu_parquet_chunk& ch, dfgp
   auto t = std::make_unique<Table>();
   dfgpu_parquet_column col = ch.column;
   try {
-    t->cols.push_back(decode_chunk(ch.bytes, ch.n_bytes, col));
+    t->cols.push_back(decode_chunk(ch.bytes, ch.n_bytes, col, &keep));
   } catch (const Error& e) {
     // a string chunk whose writer fell back to PLAIN pages: Utf8 bytes instead of dictionary indices (the caller brings the
     // chunks of the column to one kind)
     if (col.physical_type != DFGPU_PARQUET_BYTE_ARRAY || col.field.type == DFGPU_UTF8 || std::string(e.what()).find("read the column as Utf8") == std::string::npos) throw;
     col.field.type = DFGPU_UTF8;
-    t->cols.push_back(decode_chunk(ch.bytes, ch.n_bytes, col));
+    t->cols.push_back(decode_chunk(ch.bytes, ch.n_bytes, col, &keep));
   }
   t->nrows = t->cols[0].length;
   t->device = current_device();
-  if (cache && ch.cache_key && ch.cache_key_bytes > 0) {
-    DFGPU_HIP(hipStreamSynchronize(rt().stream));   // other threads may take it from the cache at once
-    if (dfgpu_cache_put(cache, ch.cache_key, ch.cache_key_bytes, wrap_quiet(t.get())) != 0) throw Error(dfgpu_last_error());
-  }
+  to_cache = cache && ch.cache_key && ch.cache_key_bytes > 0;
   return t;
 }
 static void scan_worker(ScanShared& sh, int device, bool own_thread) {
+  const auto t_w0 = std::chrono::steady_clock::now();
+  t_plan_ms = 0;
   if (own_thread) {
     use_device(device);
     thread_metrics() = dfgpu_metrics{};
   }
-  for (;;) {
-    const int64_t k = sh.next.fetch_add(1);
-    if (k >= sh.n) break;
-    {
-      std::lock_guard<std::mutex> lk(sh.mu);
-      if (!sh.error.empty()) break;
+  // two chunks in flight per worker: while chunk i crosses PCIe and is decoded, the host half of chunk i + 1 runs; chunk i's
+  // host buffers go (and the chunk enters the cache: complete, other threads may take it at once) when its event has passed
+  struct InFlight {
+    std::shared_ptr<void> keep;
+    int64_t k = -1;
+    bool to_cache = false;
+    hipEvent_t ev = nullptr;
+  } fl[2];
+  int cur = 0;
+  double settle_ms = 0;
+  for (double& x : t_upload_ms) x = 0;
+  auto settle = [&](InFlight& f) {
+    if (f.k < 0) return;
+    const auto ts = std::chrono::steady_clock::now();
+    if (f.ev) (void)hipEventSynchronize(f.ev);
+    settle_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
+    f.keep.reset();
+    if (f.to_cache) {
+      const dfgpu_parquet_chunk& ch = sh.chunks[f.k];
+      if (dfgpu_cache_put(sh.cache, ch.cache_key, ch.cache_key_bytes, wrap_quiet((*sh.out)[(size_t)f.k].get())) != 0) throw Error(dfgpu_last_error());
     }
-    try {
+    f.k = -1;
+  };
+  try {
+    for (int i = 0; i < 2; i++) DFGPU_HIP(hipEventCreateWithFlags(&fl[i].ev, hipEventDisableTiming));
+    for (;;) {
+      const int64_t at = sh.next.fetch_add(1);
+      if (at >= sh.n) break;
+      const int64_t k = sh.order[(size_t)at];
+      {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        if (!sh.error.empty()) break;
+      }
+      InFlight& f = fl[cur];
+      settle(f);   // (the chunk before the previous one)
       bool hit = false;
-      (*sh.out)[(size_t)k] = scan_one_chunk(sh.chunks[k], sh.cache, hit);
+      (*sh.out)[(size_t)k] = scan_one_chunk(sh.chunks[k], sh.cache, hit, f.keep, f.to_cache);
+      f.k = k;
+      DFGPU_HIP(hipEventRecord(f.ev, rt().stream));
+      cur ^= 1;
       if (hit) {
         std::lock_guard<std::mutex> lk(sh.mu);
         sh.from_cache++;
       }
-    } catch (const std::exception& e) {
-      std::lock_guard<std::mutex> lk(sh.mu);
-      if (sh.error.empty()) sh.error = e.what();
     }
+    settle(fl[cur]);
+    settle(fl[cur ^ 1]);
+  } catch (const std::exception& e) {
+    (void)hipStreamSynchronize(rt().stream);   // nothing may still read the host buffers that go with `fl`
+    std::lock_guard<std::mutex> lk(sh.mu);
+    if (sh.error.empty()) sh.error = e.what();
+  }
+  for (int i = 0; i < 2; i++)
+    if (fl[i].ev) (void)hipEventDestroy(fl[i].ev);
+  const auto t_w1 = std::chrono::steady_clock::now();
+  if (own_thread) call_epilogue();   // drains this thread's stream; the blocks it freed join the pool
+  {
+    const auto t_w2 = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> lk(sh.mu);
+    sh.plan_ms += t_plan_ms;
+    sh.settle_ms += settle_ms;
+    for (int i = 0; i < 6; i++) sh.upload_ms[i] += t_upload_ms[i];
+    sh.worker_ms_max = std::max(sh.worker_ms_max, std::chrono::duration<double, std::milli>(t_w1 - t_w0).count());
+    sh.drain_ms_max = std::max(sh.drain_ms_max, std::chrono::duration<double, std::milli>(t_w2 - t_w1).count());
   }
   if (own_thread) {
-    call_epilogue();   // drains this thread's stream; the blocks it freed join the pool
     std::lock_guard<std::mutex> lk(sh.mu);
     const dfgpu_metrics& m = thread_metrics();
     sh.metrics.h2d_bytes += m.h2d_bytes;
@@ -1064,8 +1167,15 @@ extern "C" int dfgpu_parquet_read_chunks(const dfgpu_parquet_chunk* chunks, int3
     sh.n = n;
     sh.cache = cache;
     sh.out = &parts;
+    sh.order.resize((size_t)n);
+    std::iota(sh.order.begin(), sh.order.end(), (int64_t)0);
+    std::stable_sort(sh.order.begin(), sh.order.end(), [&](int64_t a, int64_t b) { return chunks[a].n_bytes > chunks[b].n_bytes; });
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
     const int device = current_device();
+    const bool trace = std::getenv("DFGPU_TRACE_SCAN") != nullptr;
+    const int64_t dev_allocs0 = rt().driver_allocs.load(), dev_ns0 = rt().driver_alloc_ns.load(), pin_allocs0 = g_pinned_driver_allocs.load(), pin_ns0 = g_pinned_driver_ns.load();
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     if (T <= 1) {
       scan_worker(sh, device, false);
     } else {
@@ -1080,6 +1190,8 @@ extern "C" int dfgpu_parquet_read_chunks(const dfgpu_parquet_chunk* chunks, int3
     if (!sh.error.empty()) throw Error(sh.error);
     if (chunks_from_cache) *chunks_from_cache = sh.from_cache;
     DFGPU_HIP(hipStreamSynchronize(rt().stream));
+    const double workers_ms = since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
     // a string column whose chunks came out in both kinds (dictionary indices here, Utf8 bytes there) becomes Utf8 everywhere
     for (int j = 0; j < n_columns; j++) {
       bool any_utf8 = false, any_dict = false;
@@ -1119,5 +1231,14 @@ extern "C" int dfgpu_parquet_read_chunks(const dfgpu_parquet_chunk* chunks, int3
     dfgpu_table_t whole = nullptr;
     if (dfgpu_table_concat(hs.data(), (int)hs.size(), &whole) != 0) throw Error(dfgpu_last_error());
     *out = whole;
+    if (trace) {
+      DFGPU_HIP(hipStreamSynchronize(rt().stream));
+      fprintf(stderr, "[scan] %lld chunks on %d threads: workers %.3f ms (slowest %.3f + drain %.3f; host halves %.3f ms in total), assembly %.3f ms\n", (long long)n, T,
+              workers_ms, sh.worker_ms_max, sh.drain_ms_max, sh.plan_ms, since(t1));
+      fprintf(stderr, "[scan]   summed over workers: waits for chunks in flight %.3f ms; uploads: dictionary %.3f, staging %.3f, pages %.3f, runs %.3f, kernels + validity %.3f ms\n",
+              sh.settle_ms, sh.upload_ms[0], sh.upload_ms[1], sh.upload_ms[2], sh.upload_ms[3], sh.upload_ms[4]);
+      fprintf(stderr, "[scan]   pool misses: %lld hipMalloc (%.3f ms), %lld hipHostMalloc (%.3f ms)\n", (long long)(rt().driver_allocs.load() - dev_allocs0),
+              (double)(rt().driver_alloc_ns.load() - dev_ns0) * 1e-6, (long long)(g_pinned_driver_allocs.load() - pin_allocs0), (double)(g_pinned_driver_ns.load() - pin_ns0) * 1e-6);
+    }
   });
 }

@@ -1,6 +1,7 @@
 // table.hip — device tables (Arrow-layout columns in HBM) and the Arrow C Data Interface
 // boundary: import (host RecordBatch -> HBM, pinned with hipHostRegister + async copies on a
 // side stream) and export (HBM -> host struct array with release callbacks).
+#include <chrono>
 #include <algorithm>
 
 #include "device.hpp"
@@ -316,6 +317,7 @@ static void export_copy(void* dst, const void* src, size_t n) {
 // the driver's bounce buffers (measured 6.7 GB/s, profiles/r1_ops_v5.md); into pinned memory it is one DMA at PCIe rate.
 // hipHostMalloc is slow (it pins pages), so blocks are cached by size and come back when the consumer releases the batch —
 // a stream of equally sized output batches (LimitedBatchCoalescer's fixed target, coalesce/mod.rs:27-120) reuses them.
+std::atomic<int64_t> g_pinned_driver_allocs{0}, g_pinned_driver_ns{0};   // pool misses: hipHostMalloc calls and their host time
 struct PinnedPool {
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks;
@@ -341,7 +343,10 @@ struct PinnedPool {
       }
     }
     void* p = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     DFGPU_HIP(hipHostMalloc(&p, c, hipHostMallocDefault));
+    g_pinned_driver_allocs.fetch_add(1, std::memory_order_relaxed);
+    g_pinned_driver_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
     std::lock_guard<std::mutex> lk(mu);
     live[p] = c;
     return p;
@@ -357,25 +362,51 @@ struct PinnedPool {
         (void)hipGetLastError();
       }
     }
-    void* p = std::malloc(n ? n : 1);
+    // plain blocks are kept too: a fresh block of this size is page-faulted in 4 KB at a time (38 MB: 9 ms against 2.7 ms for
+    // the copy into a block that was touched before)
+    size_t c = 4096;
+    while (c < n) c <<= 1;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_plain.lower_bound(c);
+      if (it != free_plain.end() && it->first <= c + c / 4) {
+        void* p = it->second;
+        cached_plain -= it->first;
+        plain[p] = it->first;
+        free_plain.erase(it);
+        return p;
+      }
+    }
+    void* p = std::malloc(c);
     if (!p) throw std::bad_alloc();
     std::lock_guard<std::mutex> lk(mu);
-    live[p] = 0;   // 0 = not ours to cache
+    plain[p] = c;
     return p;
   }
+  std::multimap<size_t, void*> free_plain;
+  std::map<void*, size_t> plain;
+  size_t cached_plain = 0;
   void release(void* p) {
     if (!p) return;
     size_t c = 0;
     {
       std::lock_guard<std::mutex> lk(mu);
+      auto pl = plain.find(p);
+      if (pl != plain.end()) {
+        const size_t pc = pl->second;
+        plain.erase(pl);
+        if (cached_plain + pc <= ((size_t)1 << 30)) {
+          free_plain.emplace(pc, p);
+          cached_plain += pc;
+        } else {
+          std::free(p);
+        }
+        return;
+      }
       auto it = live.find(p);
       if (it == live.end()) return;
       c = it->second;
       live.erase(it);
-      if (c == 0) {
-        std::free(p);
-        return;
-      }
       if (cached + c <= cap()) {
         free_blocks.emplace(c, p);
         cached += c;
