@@ -192,10 +192,27 @@ __global__ __launch_bounds__(BLOCK) void k_key_minmax(KeyCol k, int64_t n, MinMa
   }
 }
 
+// first key, last key, and whether `samples` evenly spaced neighbour pairs all ascend strictly: what the build speculates on
+template <int KT>
+__global__ void k_key_ends(KeyCol k, int64_t n, int64_t every, int samples, long long* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    out[0] = (long long)load_key<KT>(k, 0);
+    out[1] = (long long)load_key<KT>(k, n - 1);
+  }
+  if (i >= samples) return;
+  const int64_t r = (int64_t)i * every;
+  if (r + 1 >= n) return;
+  if ((long long)load_key<KT>(k, r + 1) <= (long long)load_key<KT>(k, r)) atomicOr((unsigned long long*)&out[2], 1ull);
+}
+
 // rank map build, step 1: one bit per present key value.  Strictly ascending keys are unique by
 // construction; otherwise the returned old word detects duplicates.
-template <int KT, bool HASV, bool ASCENDING>
-__global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uint64_t offset, unsigned long long* __restrict__ bits, int* dup_flag) {
+// VERIFY (ASCENDING only): min / max / order are the caller's GUESS (first key, last key, a sample of neighbours) — every key is
+// checked against its predecessor and the guessed range on the way, a violation raises dup_flag (and sets no bit out of range);
+// the caller then throws the table away and builds from measured statistics
+template <int KT, bool HASV, bool ASCENDING, bool VERIFY = false>
+__global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uint64_t offset, unsigned long long* __restrict__ bits, int* dup_flag, uint64_t range = 0) {
   if (ASCENDING) {
     // a wave holds 64 consecutive rows => ascending keys: the lanes that share a bitmap word are
     // contiguous and carry distinct bits, so the word a segment sets is the SUM of its lanes' bits =
@@ -214,7 +231,15 @@ __global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uin
 #pragma unroll
       for (int j = 0; j < BUILD_UNROLL; j++) {
         const int64_t i = base + j * stride + lane;
-        const bool ok = i < n;
+        bool ok = i < n;
+        if (VERIFY) {
+          // lane l's predecessor is lane l - 1's key; lane 0 reads the row before the wave's (the previous wave's line: a cache hit)
+          uint64_t prev = __shfl_up(idx[j], 1, 64);
+          if (lane == 0) prev = i > 0 && ok ? load_key<KT>(k, i - 1) - offset : 0;
+          const bool bad = ok && (idx[j] > range || (i > 0 && idx[j] <= prev));
+          if (ballot64(bad) != 0 && lane == 0) atomicOr(dup_flag, 1);
+          ok = ok && idx[j] <= range;
+        }
         const uint64_t w = ok ? (idx[j] >> 6) : ~0ull;  // the ragged tail forms its own (ignored) segment
         const uint64_t v = ok ? 1ull << (idx[j] & 63) : 0ull;
         const uint64_t inc = wave_inclusive_sum_dpp(v);
@@ -1163,7 +1188,8 @@ static int64_t null_count_of(const Column& c) {
   return tmp.null_count;
 }
 
-static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts);
+static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts,
+                                                        bool speculate = true);
 // Utf8 key columns: interned on entry (ascending dictionary) into an extra column behind the caller's columns, which becomes the key —
 // the string column itself stays where it is and travels as payload.  The probe side is interned the same way and its indices are
 // rewritten into the build side's dictionary (with_build_dictionaries).
@@ -1182,7 +1208,8 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
   }
   return join_build_fixed_keys(any ? coded : build, kc, null_equality, opts);
 }
-static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts) {
+static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts,
+                                                        bool speculate) {
   Runtime& r = rt();
   auto jt = std::make_unique<JoinTable>();
   jt->build = build;
@@ -1217,7 +1244,34 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
   uint64_t range = 0;
   long long kmin = 0;
   int64_t n_valid_keys = 0;
-  if (opts.table_mode != 1 && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64) {
+  // Large builds guess their statistics instead of measuring them first: keys that arrive in ascending order (a primary key in
+  // table order: what dbgen, a sorted file or an ordered scan hands over) have min = the first key, max = the last, and a sample of
+  // neighbours says whether that is plausible.  The rank map is then built in ONE pass over the keys that verifies the guess on the
+  // way (k_rank_setbits<.., VERIFY>): 150 M keys, 0.31 ms of the step's 9.8.  A wrong guess costs the verifying pass and is
+  // repaired by the measured path below (`speculate` = false).
+  bool speculated = false;
+  static const bool spec_off = std::getenv("DFGPU_JOIN_SPECULATE") && std::getenv("DFGPU_JOIN_SPECULATE")[0] == '0';
+  if (speculate && !spec_off && (opts.table_mode == 0 || opts.table_mode == 3) && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64 &&
+      !ks.c[0].valid && nb >= (1 << 22)) {
+    constexpr int S = 4096;
+    BufPtr ends = make_zero_buf(24);
+    with_key_type(ks.c[0].type, [&](auto kt) { k_key_ends<decltype(kt)::value><<<S / BLOCK, BLOCK, 0, r.stream>>>(ks.c[0], nb, nb / S, S, ends->as<long long>()); });
+    long long e[3] = {0, 0, 1};
+    d2h(e, ends->ptr, 24);
+    const uint64_t grange = (uint64_t)e[1] - (uint64_t)e[0];
+    if (e[2] == 0 && e[1] > e[0] && grange != UINT64_MAX && grange + 1 >= (uint64_t)nb && grange < (1ull << 40)) {
+      const double gdense = (double)nb / ((double)grange + 1.0);
+      if (grange < (uint64_t)opts.perfect_hash_join_small_build_threshold || gdense >= RANK_MAP_MIN_KEY_DENSITY || opts.table_mode == 3) {
+        speculated = true;
+        have_stats = true;
+        ascending = true;
+        range = grange;
+        kmin = e[0];
+        n_valid_keys = nb;
+      }
+    }
+  }
+  if (!speculated && opts.table_mode != 1 && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64) {
     const Column& kc = build.cols[key_cols[0]];
     bool null_block = null_equality == DFGPU_NULL_EQUALS_NULL && kc.has_nulls();
     if (!null_block && nb > 0) {
@@ -1252,6 +1306,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
   // rank map: 1/4 byte per value of the range, so it pays far below ArrayMap's density gate
   bool rank_ok = have_stats && (opts.table_mode == 0 || opts.table_mode == 3) && range < (1ull << 40) &&
                  (range < (uint64_t)opts.perfect_hash_join_small_build_threshold || dense >= RANK_MAP_MIN_KEY_DENSITY || opts.table_mode == 3);
+  DFGPU_CHECK(!speculated || rank_ok, "internal: speculative build statistics outside the rank map's gate");
   DFGPU_CHECK(!(opts.table_mode == 2 && !am_ok), "direct-address join table requested but not applicable");
   DFGPU_CHECK(!(opts.table_mode == 3 && !rank_ok), "rank-map join table requested but not applicable");
   // Build keys that do NOT arrive in ascending order need the rank -> row permutation: one more dependent random access per
@@ -1309,7 +1364,8 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       with_key_type(kc0.type, [&](auto kt) {
         constexpr int T = decltype(kt)::value;
         // ascending implies no NULL keys
-        if (ascending) k_rank_setbits<T, false, true><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>());
+        if (speculated) k_rank_setbits<T, false, true, true><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>(), range);
+        else if (ascending) k_rank_setbits<T, false, true><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>());
         else if (kc0.valid) k_rank_setbits<T, true, false><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>());
         else k_rank_setbits<T, false, false><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>());
       });
@@ -1319,6 +1375,15 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
     scan_mask_popcounts(jt->rank_bits->as<uint64_t>(), nullptr, n_words * 64, jt->rank_prefix->as<uint64_t>());
     // keys in no order set their bits without looking: two rows with one key set one bit
     if (!ascending) dup = (int64_t)read_u64(jt->rank_prefix->as<uint64_t>() + n_words) != n_valid_keys;
+    if (speculated) {
+      int wrong = 0;
+      d2h(&wrong, flag->ptr, 4);
+      if (wrong) {  // not ascending after all (or a key outside [first, last]): measure, then build
+        ProfileScope ps("join_build_speculation_missed", 0);
+        jt.reset();
+        return join_build_fixed_keys(build, key_cols, null_equality, opts, false);
+      }
+    }
     if (!dup) {
       jt->kind = KIND_RANK;
       jt->am_offset = (uint64_t)kmin;

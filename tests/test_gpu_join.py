@@ -526,3 +526,44 @@ def test_probe_order_speculation_every_row_finds_its_key(dangling):
     assert np.array_equal(out.column("o_flag").to_numpy(), (fk[keep] % 7).astype(np.int32))
     assert ("join_probe_speculation_missed" in stats) == bool(dangling), sorted(stats)
     assert ("join_probe_tile_counts" in stats) == bool(dangling)                                  # no counts pass when the speculation holds
+
+
+@pytest.mark.parametrize("flaw", ["none", "swap", "duplicate", "out_of_range"])
+def test_build_speculates_on_ascending_keys_and_verifies_while_it_builds(flaw):
+    """a large build guesses min / max / order from its first key, its last key and a sample of neighbours and builds the rank map in
+    one pass that checks every key against its predecessor and the guessed range; keys in table order take that pass alone (no
+    statistics pass), a single swapped pair, a repeated key or a key beyond the last one — none of them on a sampled position — raise
+    the flag and the build starts over from measured statistics: the same join either way"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(44)
+    nb, npr = 5_000_000, 3_000_000
+    keys = np.arange(nb, dtype=np.int64) * 3 + 7
+    if flaw == "swap":
+        keys[[1_234_567, 1_234_568]] = keys[[1_234_568, 1_234_567]]
+    elif flaw == "duplicate":
+        keys[3_000_001] = keys[3_000_000]
+    elif flaw == "out_of_range":
+        keys[2_222_223] = keys[-1] + 1_000_003
+    pay = rng.integers(0, 10**6, nb).astype(np.int64)
+    pk = rng.integers(0, nb * 3 + 50, npr).astype(np.int64)
+    build = DeviceTable.from_arrow(pa.table({"k": pa.array(keys), "v": pa.array(pay)}))
+    probe = DeviceTable.from_arrow(pa.table({"pk": pa.array(pk), "row": pa.array(np.arange(npr, dtype=np.int64))}))
+    ops.profile_enable(True)
+    ops.profile_reset()
+    ht = ops.JoinHashTable(build, ["k"], probe_mode=0)
+    out = ht.probe(probe, ["pk"], "Inner", ["v"], ["pk", "row"]).to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    info = ht.info()
+    ht.free()
+    assert ("join_build_speculation_missed" in stats) == (flaw != "none"), sorted(stats)
+    assert ("join_build_key_stats" in stats) == (flaw != "none")                      # no statistics pass when the guess holds
+    # expected pairs from a host dictionary (the duplicate key matches twice)
+    order = np.argsort(keys, kind="stable")
+    sk = keys[order]
+    lo, hi = np.searchsorted(sk, pk, "left"), np.searchsorted(sk, pk, "right")
+    exp = sorted((int(r), int(pay[order[j]])) for r in np.nonzero(hi > lo)[0] for j in range(lo[r], hi[r]))
+    got = sorted(zip(out.column("row").to_pylist(), out.column("v").to_pylist()))
+    assert got == exp
+    assert bool(info.build_keys_unique) == (flaw != "duplicate")

@@ -398,3 +398,51 @@ def test_dictionary_decode_round_trip():
     got = DeviceTable.from_arrow(t).dictionary_decode().to_arrow()
     assert pa.types.is_string(got.schema.field("s").type) or pa.types.is_large_string(got.schema.field("s").type)
     assert got.column("s").to_pylist() == s.to_pylist() and got.column("v").to_pylist() == list(range(5000))
+
+
+def test_scan_in_one_call_thread_counts_cache_hits_and_a_corrupt_chunk(tmp_path):
+    """dfgpu_parquet_read_chunks: the chunks of a scan in one call, decoded by host threads inside the library (two chunks in flight
+    per worker, largest chunk first) — the same table for every thread count; chunks found in the device chunk cache are counted;
+    an error on a worker thread (a chunk cut short) comes back as the call's error, not as a crash or a partial table"""
+    import ctypes as C
+
+    from datafusion_amd import _lib
+    from datafusion_amd import parquet as P
+    from datafusion_amd.parquet import ChunkCache, ParquetFile
+    rng = np.random.default_rng(21)
+    n = 300_000
+    t = pa.table({"k": pa.array(rng.integers(0, 1 << 40, n)), "d": pa.array(rng.integers(0, 50, n).astype(np.int32)),
+                  "f": pa.array(rng.random(n), mask=rng.random(n) < 0.2), "s": pa.array([f"v{i % 97}" for i in range(n)])})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, row_group_size=50_000, compression="zstd")
+    want = pq.read_table(path)
+    saved = P.CACHE
+    try:
+        P.CACHE = ChunkCache(budget=0)
+        f = ParquetFile(path)
+        for threads in (1, 3, 16):
+            got = f.read(threads=threads).to_arrow()
+            for c in want.column_names:
+                col = got.column(c)
+                assert (col.cast(pa.string()) if pa.types.is_dictionary(col.type) else col).equals(want.column(c)), (threads, c)
+        P.CACHE = ChunkCache(budget=1 << 30)
+        f.read(["k", "d"], threads=4).free()
+        assert f.chunks_from_cache == 0
+        f.read(["d", "f"], threads=4).free()
+        assert f.chunks_from_cache == 6          # the six row groups' `d` chunks
+        # one chunk cut short, on a worker thread
+        arr = (_lib.ParquetChunk * 12)()
+        keep = []
+        for g in range(6):
+            for j, c in enumerate(("k", "f")):
+                buf, nb, d, alive = f._chunk(g, c)
+                keep.append(alive)
+                a = arr[g * 2 + j]
+                a.bytes, a.n_bytes, a.column = buf, (nb // 2 if (g, c) == (4, "f") else nb), d
+        out = C.c_void_p()
+        rc = _lib.load().dfgpu_parquet_read_chunks(arr, 6, 2, 4, None, C.byref(out), None)
+        assert rc != 0 and b"parquet" in _lib.load().dfgpu_last_error() and not out.value
+        f.close()
+    finally:
+        P.CACHE.clear()
+        P.CACHE = saved
