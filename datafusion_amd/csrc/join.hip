@@ -222,21 +222,19 @@ __global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uin
     const unsigned lane = lane_id();
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
     for (int64_t base = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < n; base += stride * BUILD_UNROLL) {
-      uint64_t idx[BUILD_UNROLL];
+      uint64_t idx[BUILD_UNROLL], pidx[BUILD_UNROLL];
 #pragma unroll
       for (int j = 0; j < BUILD_UNROLL; j++) {
         int64_t i = base + j * stride + lane;
         idx[j] = load_key<KT>(k, i < n ? i : n - 1) - offset;
+        if (VERIFY) pidx[j] = load_key<KT>(k, i < n ? (i > 0 ? i - 1 : 0) : n - 1) - offset;   // the neighbour's line: a cache hit, in flight with the rest
       }
 #pragma unroll
       for (int j = 0; j < BUILD_UNROLL; j++) {
         const int64_t i = base + j * stride + lane;
         bool ok = i < n;
         if (VERIFY) {
-          // lane l's predecessor is lane l - 1's key; lane 0 reads the row before the wave's (the previous wave's line: a cache hit)
-          uint64_t prev = __shfl_up(idx[j], 1, 64);
-          if (lane == 0) prev = i > 0 && ok ? load_key<KT>(k, i - 1) - offset : 0;
-          const bool bad = ok && (idx[j] > range || (i > 0 && idx[j] <= prev));
+          const bool bad = ok && (idx[j] > range || (i > 0 && idx[j] <= pidx[j]));
           if (ballot64(bad) != 0 && lane == 0) atomicOr(dup_flag, 1);
           ok = ok && idx[j] <= range;
         }
