@@ -64,6 +64,49 @@ def test_sf100_join_properties(tables, probe_mode):
     out.free()
 
 
+def test_sf100_join_over_keys_in_no_order(tables):
+    """the same join with both sides in NO key order (orders sorted by o_orderdate with ties broken by a hash-like key, lineitem by
+    l_extendedprice): the build guesses nothing (its sample does not ascend), marks bytes instead of bits, leaves the row permutation
+    unbuilt until a probe wants build rows; a key-only probe whose order nobody observes is grouped by key range first.  Properties:
+    every probe row still finds its order; key checksums survive; the build payload is still the function of the key it was
+    generated as; the grouped and the ungrouped probe hold the same rows."""
+    import os
+
+    from datafusion_amd import ops, tpch
+    orders, lineitem = tables
+    so = ops.sort(orders, [("o_orderdate", False, False), ("o_orderkey", True, False)])
+    sl = ops.sort(lineitem.select(["l_orderkey", "l_extendedprice"]), [("l_extendedprice", False, False)])
+    k_sum = _sums(lineitem, ["l_orderkey"])
+    ops.profile_enable(True)
+    ops.profile_reset()
+    ht = ops.JoinHashTable(so, ["o_orderkey"], probe_mode=4)
+    keys = ht.probe(sl, ["l_orderkey"], "Inner", [], ["l_orderkey"])
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert ht.info().table_kind == 2 and "join_build_key_stats" in stats and "join_build_speculation_missed" not in stats   # rank map, measured statistics
+    assert "radix_sort_pass" in stats                                      # probe keys grouped by key range
+    assert keys.num_rows == lineitem.num_rows and _sums(keys, ["l_orderkey"]) == k_sum
+    keys.free()
+    os.environ["DFGPU_JOIN_GROUPED_PROBE"] = "0"
+    try:
+        plain = ht.probe(sl, ["l_orderkey"], "Inner", [], ["l_orderkey"])
+    finally:
+        del os.environ["DFGPU_JOIN_GROUPED_PROBE"]
+    assert plain.num_rows == lineitem.num_rows and _sums(plain, ["l_orderkey"]) == k_sum
+    plain.free()
+    # a probe that gathers build payload: the permutation is built now; payload = f(key) on a sample
+    out = ht.probe(sl, ["l_orderkey"], "Inner", ["o_orderdate"], ["l_orderkey", "l_extendedprice"])
+    ht.free()
+    assert out.num_rows == lineitem.num_rows
+    assert _sums(out, ["l_orderkey", "l_extendedprice"]) == _sums(lineitem, ["l_orderkey", "l_extendedprice"])
+    sample = pa.concat_tables([out.slice(o, 1000).to_arrow() for o in range(0, out.num_rows - 1000, out.num_rows // 200)])
+    key = sample.column("l_orderkey").to_numpy() - 1
+    idx = (key >> 5) * 8 + (key & 31)
+    assert (sample.column("o_orderdate").cast(pa.int32()).to_numpy() == tpch.order_date(idx.astype(np.int64))).all()
+    for t in (out, so, sl):
+        t.free()
+
+
 def test_sf100_filter_fused_into_probe_equals_filter_then_join(tables):
     from datafusion_amd import ops, queries
     from datafusion_amd.expr import col, lit
