@@ -397,6 +397,7 @@ void join_visited_merge(dfgpu_join_t h, const uint8_t* merged, size_t nbytes);  
 void radix_sort_pairs(BufPtr& key, BufPtr& idx, int64_t n, int lo_bit, int nbits);
 // keys alone, grouped stably by bits [lo_bit, lo_bit + nbits) of their value (no row ids are made)
 void radix_group_keys(BufPtr& key, int64_t n, int lo_bit, int nbits);
+Table sort_table_ascending(const Table& in, const std::vector<int>& key_cols);   // sort.hip; stable
 
 // ----------------------------------------------------------------- LDS radix join (radix_join.hip)
 struct RadixTable;

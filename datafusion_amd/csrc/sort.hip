@@ -945,6 +945,13 @@ static int bits_for(u128 range) {
   return b;
 }
 
+static Table sort_table(const Table& in, const std::vector<int>& key_cols, const uint8_t* desc, const uint8_t* nulls_first, int64_t fetch);
+// the rows of `in` in ascending order of the given key columns (stable); for the library's own use (strings.hip orders the distinct
+// strings of a dictionary by their prefix words)
+Table sort_table_ascending(const Table& in, const std::vector<int>& key_cols) {
+  const std::vector<uint8_t> zeros(key_cols.size(), 0);
+  return sort_table(in, key_cols, zeros.data(), zeros.data(), -1);
+}
 static Table sort_table(const Table& in, const std::vector<int>& key_cols, const uint8_t* desc, const uint8_t* nulls_first, int64_t fetch) {
   Runtime& r = rt();
   const int64_t n = in.nrows;

@@ -264,6 +264,60 @@ __global__ __launch_bounds__(BLOCK) void k_str_codes(const unsigned* __restrict_
   }
 }
 
+
+// the first 24 bytes of every string as three big-endian words (zero-padded): integer order of (w0, w1, w2) = byte order of the
+// prefixes; what the distinct strings of a dictionary are sorted by on the device
+__global__ __launch_bounds__(BLOCK) void k_str_prefix_words(const int64_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, uint64_t* __restrict__ w0,
+                                                            uint64_t* __restrict__ w1, uint64_t* __restrict__ w2, uint32_t* __restrict__ id) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const uint8_t* p = bytes + off[i];
+    const int64_t len = off[i + 1] - off[i];
+    uint64_t w[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const int at = q * 8 + b;
+        w[q] = (w[q] << 8) | (at < len ? (uint64_t)p[at] : 0ull);
+      }
+    w0[i] = w[0];
+    w1[i] = w[1];
+    w2[i] = w[2];
+    id[i] = (uint32_t)i;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_count_equal_neighbours(const uint64_t* __restrict__ w0, const uint64_t* __restrict__ w1, const uint64_t* __restrict__ w2, int64_t n,
+                                                                  unsigned* __restrict__ count) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * BLOCK)
+    if (w0[i] == w0[i - 1] && w1[i] == w1[i - 1] && w2[i] == w2[i - 1]) atomicAdd(count, 1u);
+}
+// row numbers of `strings` (no NULLs) in ascending order of their first 24 bytes, ties in first-to-last row order; `ties` = pairs of
+// neighbours in that order whose first 24 bytes agree (their order is the caller's to settle)
+static BufPtr string_prefix_order(const Column& strings, int64_t n, int64_t& ties) {
+  Table keys;
+  keys.nrows = n;
+  dfgpu_field f{};
+  f.type = DFGPU_UINT64;
+  for (int q = 0; q < 3; q++) keys.cols.push_back(alloc_column(f, "w" + std::to_string(q), n));
+  f.type = DFGPU_UINT32;
+  keys.cols.push_back(alloc_column(f, "id", n));
+  k_str_prefix_words<<<grid_for(n, BLOCK), BLOCK, 0, rt().stream>>>(str_offsets(strings), (const uint8_t*)strings.ptr(), n, keys.cols[0].data->as<uint64_t>(),
+                                                                     keys.cols[1].data->as<uint64_t>(), keys.cols[2].data->as<uint64_t>(), keys.cols[3].data->as<uint32_t>());
+  DFGPU_HIP(hipGetLastError());
+  Table sorted = sort_table_ascending(keys, {0, 1, 2});
+  BufPtr cnt = make_zero_buf(4);
+  k_count_equal_neighbours<<<grid_for(n, BLOCK), BLOCK, 0, rt().stream>>>((const uint64_t*)sorted.cols[0].ptr(), (const uint64_t*)sorted.cols[1].ptr(),
+                                                                           (const uint64_t*)sorted.cols[2].ptr(), n, cnt->as<unsigned>());
+  unsigned c = 0;
+  d2h(&c, cnt->ptr, 4);
+  ties = c;
+  const Column& ids = sorted.cols[3];
+  if (ids.data_offset == 0) return ids.data;
+  BufPtr out = make_buf((size_t)n * 4);
+  DFGPU_HIP(hipMemcpyAsync(out->ptr, ids.ptr(), (size_t)n * 4, hipMemcpyDeviceToDevice, rt().stream));
+  return out;
+}
+
 Column dictionary_encode(const Column& in, bool sorted) {
   Runtime& r = rt();
   DFGPU_CHECK(in.field.type == DFGPU_UTF8, "dictionary_encode: column '" + in.name + "' is not a Utf8 column");
@@ -356,11 +410,10 @@ Column dictionary_encode(const Column& in, bool sorted) {
       for (int t = 0; t < TP; t++) th.emplace_back([&, t] { for (int64_t k = G * t / TP; k < G * (t + 1) / TP; k++) body(k); });
       for (auto& x : th) x.join();
     };
-    parallel_for([&](int64_t k) {
-      const std::string_view v = value_at((int32_t)k);
-      SortKey& o = order[(size_t)k];
+    auto prefix_words = [&](int32_t idx, SortKey& o) {
+      const std::string_view v = value_at(idx);
       o.len = (uint32_t)v.size();
-      o.idx = (int32_t)k;
+      o.idx = idx;
       for (int q = 0; q < 3; q++) {
         uint64_t x = 0;
         for (int b = 0; b < 8; b++) {
@@ -369,8 +422,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
         }
         o.w[q] = x;
       }
-    });
-    phase("sort keys (prefix words)");
+    };
     auto less = [&](const SortKey& a, const SortKey& b) {
       if (a.w[0] != b.w[0]) return a.w[0] < b.w[0];
       if (a.w[1] != b.w[1]) return a.w[1] < b.w[1];
@@ -378,6 +430,31 @@ Column dictionary_encode(const Column& in, bool sorted) {
       if (a.len <= 24 || b.len <= 24) return a.len < b.len;
       return value_at(a.idx) < value_at(b.idx);
     };
+    static const bool device_sort_off = std::getenv("DFGPU_STRING_DEVICE_SORT") && std::getenv("DFGPU_STRING_DEVICE_SORT")[0] == '0';
+    if (G >= 16384 && !device_sort_off) {
+      // many distinct strings: the device orders them by their first 24 bytes (three prefix words through the sort operator's
+      // radix passes: 150 K strings in a few launches, where 16 host threads sorting and merging took 3.3-4 ms); the host only
+      // settles runs of equal prefixes with the full comparison — none for keys and names, a few for long common prefixes
+      int64_t ties = 0;
+      BufPtr d_order = string_prefix_order(values, G, ties);
+      PinnedBuf ids_buf((size_t)G * 4);
+      d2h(ids_buf.ptr, d_order->ptr, (size_t)G * 4);
+      const uint32_t* ids = ids_buf.as<uint32_t>();
+      phase("device sort of the prefix words");
+      if (ties == 0) {
+        for (int64_t k = 0; k < G; k++) order[(size_t)k].idx = (int32_t)ids[k];
+      } else {
+        parallel_for([&](int64_t k) { prefix_words((int32_t)ids[k], order[(size_t)k]); });
+        for (int64_t k = 0; k < G;) {
+          int64_t e = k + 1;
+          while (e < G && order[(size_t)e].w[0] == order[(size_t)k].w[0] && order[(size_t)e].w[1] == order[(size_t)k].w[1] && order[(size_t)e].w[2] == order[(size_t)k].w[2]) e++;
+          if (e - k > 1) std::stable_sort(order.begin() + k, order.begin() + e, less);
+          k = e;
+        }
+      }
+    } else {
+    parallel_for([&](int64_t k) { prefix_words((int32_t)k, order[(size_t)k]); });
+    phase("sort keys (prefix words)");
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>({16, (int64_t)std::thread::hardware_concurrency(), G / 4096}));
     if (T <= 1) {
       std::sort(order.begin(), order.end(), less);
@@ -397,6 +474,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
           });
         for (auto& x : th) x.join();
       }
+    }
     }
     phase("host sort (threads)");
     PinnedBuf rank_buf((size_t)G * 4);

@@ -388,3 +388,28 @@ def test_dictionary_encode_first_seen_order_from_few_to_many_distinct_strings(di
     want = pc.dictionary_encode(s)
     assert enc.dictionary.to_pylist() == want.dictionary.to_pylist()
     assert enc.indices.to_numpy().tolist() == want.indices.to_numpy().tolist()
+
+
+@pytest.mark.parametrize("shape", ["short_keys", "long_common_prefixes", "prefix_of_each_other"])
+def test_ascending_dictionary_of_many_distinct_strings_is_ordered_on_the_device(shape):
+    """from 16 Ki distinct strings on, the ascending dictionary is ordered by the device (three big-endian prefix words through the
+    sort operator) and the host only settles runs that agree in their first 24 bytes: byte order (= pyarrow's sort of the distinct
+    strings) for short keys, for URLs that share 30 bytes, and for strings that are prefixes of each other around the 24-byte mark"""
+    import pyarrow.compute as pc
+
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(5)
+    distinct = 40_000
+    if shape == "short_keys":
+        pool = [f"k{int(x):09d}" for x in rng.permutation(10**9)[:distinct] % 10**9]
+    elif shape == "long_common_prefixes":
+        pool = [f"https://www.example.com/catalog/item/{int(x):07d}/{'z' * int(x % 5)}" for x in rng.permutation(distinct * 3)[:distinct]]
+    else:
+        base = "abcdefghijklmnopqrstuvw"                                      # 23 bytes
+        pool = list({base[: int(a)] + "x" * int(b) + str(int(c)) for a, b, c in zip(rng.integers(20, 24, distinct * 2), rng.integers(0, 6, distinct * 2), rng.integers(0, 3000, distinct * 2))})[:distinct]
+    pool = sorted(set(pool), key=lambda s: rng.random())                      # first-seen order is not the sorted order
+    s = pa.array(pool, pa.string()).take(pa.array(rng.integers(0, len(pool), 400_000)))
+    enc = DeviceTable.from_arrow(pa.table({"s": s})).dictionary_encode(sorted=True).to_arrow().column("s").combine_chunks()
+    want = pc.sort_indices(pc.unique(s))
+    assert enc.dictionary.to_pylist() == pc.unique(s).take(want).to_pylist()
+    assert enc.dictionary.take(enc.indices).to_pylist() == s.to_pylist()
