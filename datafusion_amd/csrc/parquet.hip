@@ -23,7 +23,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <functional>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -1030,33 +1032,80 @@ int dfgpu_parquet_decode_chunk(const uint8_t* chunk, int64_t chunk_bytes, const 
 // One worker per host thread asked for: a chunk's host half (page headers, decompression, levels, run headers) runs on that
 // thread, its device half on that thread's stream — the same shape as a scan node decoding from its partition threads, without
 // a call through the boundary (and, for the Python face, without the interpreter) per chunk.
+// A unit of host work = a column chunk.  (Groups of about 1 MiB of a big chunk's data pages as the unit — the dictionary page riding
+// along where needed, the groups' columns put together afterwards — were measured: 10.5-22 ms against 8.7-8.8 ms for ZSTD at SF1
+// on 16 threads, 10.4 against 6.9-7.5 uncompressed: more launches, more concatenation, the dictionary parsed per group.  Dropped.)
+struct ScanTask {
+  int64_t chunk = 0;            // index into the caller's chunk list
+};
 struct ScanShared {
   const dfgpu_parquet_chunk* chunks;
-  int64_t n;
+  std::vector<ScanTask> tasks;
   dfgpu_cache_t cache;
-  std::vector<std::unique_ptr<Table>>* out;
-  std::vector<int64_t> order;   // largest chunk first: the slowest worker ends as early as a greedy schedule lets it
+  std::vector<std::unique_ptr<Table>>* out;   // per task
+  std::vector<int64_t> order;   // largest task first: the slowest worker ends as early as a greedy schedule lets it
   std::atomic<int64_t> next{0};
   std::mutex mu;
   std::string error;
   dfgpu_metrics metrics{};   // the workers' metrics, folded into the caller's
-  int64_t from_cache = 0;
   double plan_ms = 0, worker_ms_max = 0, drain_ms_max = 0, settle_ms = 0, upload_ms[6] = {0, 0, 0, 0, 0, 0};   // DFGPU_TRACE_SCAN
 };
-// one chunk, launched: `keep` holds what its uploads read from (null when the chunk came from the cache or was decoded with a
-// wait inside), `to_cache` says whether it is to be put into the cache once complete
-static std::unique_ptr<Table> scan_one_chunk(const dfgpu_parquet_chunk& ch, dfgpu_cache_t cache, bool& hit, std::shared_ptr<void>& keep, bool& to_cache) {
-  hit = false;
-  to_cache = false;
-  keep.reset();
-  if (cache && ch.cache_key && ch.cache_key_bytes > 0) {
-    dfgpu_table_t got = nullptr;
-    if (dfgpu_cache_get(cache, ch.cache_key, ch.cache_key_bytes, &got) != 0) throw Error(dfgpu_last_error());
-    if (got) {
-      hit = true;
-      return std::unique_ptr<Table>(unwrap_quiet(got));
+// The scan's host threads live as long as the process: a thread made for one scan starts with a cold allocator arena and a cold
+// stack — its first megabytes of page buffers are page-faulted in, 16-32 threads at a time on one address space — and a HIP stream
+// to find; measured as host halves that took 3-7 times their single-threaded time.  Workers sleep on a condition variable between
+// scans.
+struct ScanPool {
+  std::mutex mu;
+  std::condition_variable wake, done_cv;
+  std::vector<std::thread> workers;
+  std::function<void()> job;
+  int64_t generation = 0;
+  int to_start = 0, running = 0;
+  void loop() {
+    int64_t seen = 0;
+    for (;;) {
+      std::function<void()> mine;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        wake.wait(lk, [&] { return generation != seen && to_start > 0; });
+        seen = generation;
+        to_start--;
+        mine = job;
+      }
+      mine();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--running == 0) done_cv.notify_all();
+      }
     }
   }
+  // fn() on `n` pool threads at once; returns when all of them have returned.  One scan at a time uses the pool.
+  void run(int n, std::function<void()> fn) {
+    std::unique_lock<std::mutex> lk(mu);
+    done_cv.wait(lk, [&] { return running == 0; });
+    while ((int)workers.size() < n) {
+      workers.emplace_back([this] { loop(); });
+      workers.back().detach();
+    }
+    job = std::move(fn);
+    generation++;
+    to_start = n;
+    running = n;
+    wake.notify_all();
+    done_cv.wait(lk, [&] { return running == 0; });
+  }
+};
+static ScanPool& scan_pool() {
+  static ScanPool* p = new ScanPool();   // never destroyed: its threads outlive static destructors
+  return *p;
+}
+
+// one chunk, launched: `keep` holds what its uploads read from (null when decoded with a wait inside), `to_cache` says whether the
+// result is to be put into the cache once complete
+static std::unique_ptr<Table> scan_one_task(const ScanShared& sh, const ScanTask& task, std::shared_ptr<void>& keep, bool& to_cache) {
+  to_cache = false;
+  keep.reset();
+  const dfgpu_parquet_chunk& ch = sh.chunks[task.chunk];
   DFGPU_CHECK(ch.bytes && ch.n_bytes >= 0, "parquet: null chunk");
   auto t = std::make_unique<Table>();
   dfgpu_parquet_column col = ch.column;
@@ -1071,7 +1120,7 @@ static std::unique_ptr<Table> scan_one_chunk(const dfgpu_parquet_chunk& ch, dfgp
   }
   t->nrows = t->cols[0].length;
   t->device = current_device();
-  to_cache = cache && ch.cache_key && ch.cache_key_bytes > 0;
+  to_cache = sh.cache && ch.cache_key && ch.cache_key_bytes > 0;
   return t;
 }
 static void scan_worker(ScanShared& sh, int device, bool own_thread) {
@@ -1081,8 +1130,8 @@ static void scan_worker(ScanShared& sh, int device, bool own_thread) {
     use_device(device);
     thread_metrics() = dfgpu_metrics{};
   }
-  // two chunks in flight per worker: while chunk i crosses PCIe and is decoded, the host half of chunk i + 1 runs; chunk i's
-  // host buffers go (and the chunk enters the cache: complete, other threads may take it at once) when its event has passed
+  // two tasks in flight per worker: while task i crosses PCIe and is decoded, the host half of task i + 1 runs; task i's host
+  // buffers go (and a whole chunk enters the cache: complete, other threads may take it at once) when its event has passed
   struct InFlight {
     std::shared_ptr<void> keep;
     int64_t k = -1;
@@ -1099,32 +1148,29 @@ static void scan_worker(ScanShared& sh, int device, bool own_thread) {
     settle_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
     f.keep.reset();
     if (f.to_cache) {
-      const dfgpu_parquet_chunk& ch = sh.chunks[f.k];
+      const dfgpu_parquet_chunk& ch = sh.chunks[sh.tasks[(size_t)f.k].chunk];
       if (dfgpu_cache_put(sh.cache, ch.cache_key, ch.cache_key_bytes, wrap_quiet((*sh.out)[(size_t)f.k].get())) != 0) throw Error(dfgpu_last_error());
     }
     f.k = -1;
   };
   try {
-    for (int i = 0; i < 2; i++) DFGPU_HIP(hipEventCreateWithFlags(&fl[i].ev, hipEventDisableTiming));
+    // blocking events: a worker that waits for its chunk to cross PCIe sleeps instead of spinning — the host cores (16 CPUs' worth
+    // of quota on the benchmark boxes) belong to the workers that are decompressing
+    for (int i = 0; i < 2; i++) DFGPU_HIP(hipEventCreateWithFlags(&fl[i].ev, hipEventDisableTiming | hipEventBlockingSync));
     for (;;) {
       const int64_t at = sh.next.fetch_add(1);
-      if (at >= sh.n) break;
+      if (at >= (int64_t)sh.tasks.size()) break;
       const int64_t k = sh.order[(size_t)at];
       {
         std::lock_guard<std::mutex> lk(sh.mu);
         if (!sh.error.empty()) break;
       }
       InFlight& f = fl[cur];
-      settle(f);   // (the chunk before the previous one)
-      bool hit = false;
-      (*sh.out)[(size_t)k] = scan_one_chunk(sh.chunks[k], sh.cache, hit, f.keep, f.to_cache);
+      settle(f);   // (the task before the previous one)
+      (*sh.out)[(size_t)k] = scan_one_task(sh, sh.tasks[(size_t)k], f.keep, f.to_cache);
       f.k = k;
       DFGPU_HIP(hipEventRecord(f.ev, rt().stream));
       cur ^= 1;
-      if (hit) {
-        std::lock_guard<std::mutex> lk(sh.mu);
-        sh.from_cache++;
-      }
     }
     settle(fl[cur]);
     settle(fl[cur ^ 1]);
@@ -1164,32 +1210,51 @@ extern "C" int dfgpu_parquet_read_chunks(const dfgpu_parquet_chunk* chunks, int3
     std::vector<std::unique_ptr<Table>> parts((size_t)n);
     ScanShared sh;
     sh.chunks = chunks;
-    sh.n = n;
     sh.cache = cache;
-    sh.out = &parts;
-    sh.order.resize((size_t)n);
-    std::iota(sh.order.begin(), sh.order.end(), (int64_t)0);
-    std::stable_sort(sh.order.begin(), sh.order.end(), [&](int64_t a, int64_t b) { return chunks[a].n_bytes > chunks[b].n_bytes; });
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
     const int device = current_device();
     const bool trace = std::getenv("DFGPU_TRACE_SCAN") != nullptr;
     const int64_t dev_allocs0 = rt().driver_allocs.load(), dev_ns0 = rt().driver_alloc_ns.load(), pin_allocs0 = g_pinned_driver_allocs.load(), pin_ns0 = g_pinned_driver_ns.load();
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
-    if (T <= 1) {
+    // chunks the cache holds are taken from it; the others become tasks
+    int64_t from_cache = 0;
+    for (int64_t k = 0; k < n; k++) {
+      const dfgpu_parquet_chunk& ch = chunks[k];
+      if (cache && ch.cache_key && ch.cache_key_bytes > 0) {
+        dfgpu_table_t got = nullptr;
+        if (dfgpu_cache_get(cache, ch.cache_key, ch.cache_key_bytes, &got) != 0) throw Error(dfgpu_last_error());
+        if (got) {
+          parts[(size_t)k].reset(unwrap_quiet(got));
+          from_cache++;
+          continue;
+        }
+      }
+      ScanTask task;
+      task.chunk = k;
+      sh.tasks.push_back(task);
+    }
+    const int64_t n_tasks = (int64_t)sh.tasks.size();
+    std::vector<std::unique_ptr<Table>> done((size_t)n_tasks);
+    sh.out = &done;
+    sh.order.resize((size_t)n_tasks);
+    std::iota(sh.order.begin(), sh.order.end(), (int64_t)0);
+    std::stable_sort(sh.order.begin(), sh.order.end(), [&](int64_t a, int64_t b) { return chunks[sh.tasks[(size_t)a].chunk].n_bytes > chunks[sh.tasks[(size_t)b].chunk].n_bytes; });
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n_tasks));
+    if (n_tasks == 0) {
+      // everything came from the cache
+    } else if (T <= 1) {
       scan_worker(sh, device, false);
     } else {
-      std::vector<std::thread> th;
-      for (int t = 0; t < T; t++) th.emplace_back([&] { scan_worker(sh, device, true); });
-      for (auto& x : th) x.join();
+      scan_pool().run(T, [&] { scan_worker(sh, device, true); });
       dfgpu_metrics& m = thread_metrics();
       m.h2d_bytes += sh.metrics.h2d_bytes;
       m.d2h_bytes += sh.metrics.d2h_bytes;
       m.hbm_bytes_algorithmic += sh.metrics.hbm_bytes_algorithmic;
     }
     if (!sh.error.empty()) throw Error(sh.error);
-    if (chunks_from_cache) *chunks_from_cache = sh.from_cache;
+    if (chunks_from_cache) *chunks_from_cache = from_cache;
     DFGPU_HIP(hipStreamSynchronize(rt().stream));
+    for (int64_t t = 0; t < n_tasks; t++) parts[(size_t)sh.tasks[(size_t)t].chunk] = std::move(done[(size_t)t]);
     const double workers_ms = since(t0);
     const auto t1 = std::chrono::steady_clock::now();
     // a string column whose chunks came out in both kinds (dictionary indices here, Utf8 bytes there) becomes Utf8 everywhere
@@ -1233,8 +1298,8 @@ extern "C" int dfgpu_parquet_read_chunks(const dfgpu_parquet_chunk* chunks, int3
     *out = whole;
     if (trace) {
       DFGPU_HIP(hipStreamSynchronize(rt().stream));
-      fprintf(stderr, "[scan] %lld chunks on %d threads: workers %.3f ms (slowest %.3f + drain %.3f; host halves %.3f ms in total), assembly %.3f ms\n", (long long)n, T,
-              workers_ms, sh.worker_ms_max, sh.drain_ms_max, sh.plan_ms, since(t1));
+      fprintf(stderr, "[scan] %lld chunks (%lld to decode) on %d threads: workers %.3f ms (slowest %.3f + drain %.3f; host halves %.3f ms in total), assembly %.3f ms\n",
+              (long long)n, (long long)n_tasks, T, workers_ms, sh.worker_ms_max, sh.drain_ms_max, sh.plan_ms, since(t1));
       fprintf(stderr, "[scan]   summed over workers: waits for chunks in flight %.3f ms; uploads: dictionary %.3f, staging %.3f, pages %.3f, runs %.3f, kernels + validity %.3f ms\n",
               sh.settle_ms, sh.upload_ms[0], sh.upload_ms[1], sh.upload_ms[2], sh.upload_ms[3], sh.upload_ms[4]);
       fprintf(stderr, "[scan]   pool misses: %lld hipMalloc (%.3f ms), %lld hipHostMalloc (%.3f ms)\n", (long long)(rt().driver_allocs.load() - dev_allocs0),
