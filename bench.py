@@ -62,6 +62,16 @@ def algorithmic_bytes(nb, np_, nout):
     return nb * 16 + np_ * 40 + nout * 48
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max: "<quota> <period>"), None when unlimited or unknown: a
+    256-thread host behind a 16-CPU quota runs 16 threads at a time whatever os.cpu_count() says"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(sample_sf, cores):
     """oracle leg: RepartitionExec(Hash) x2 -> HashJoinExec(Partitioned), one thread per partition
     (target_partitions); the best of a few partition counts up to the core count is reported, since one
@@ -84,7 +94,8 @@ def cpu_baseline(sample_sf, cores):
             best, best_t = dt, threads
     out = {"value": (len(bk) + len(pk)) / best, "unit": "rows/s", "cores": best_t, "kind": "port",
            "sample": f"orders x lineitem keys at SF{sample_sf:g} ({len(bk)} build + {len(pk)} probe rows), "
-                     f"{best_t} partitions/threads (best of {tried} rows/s; host has {cores} cores), 8192-row probe batches, key-only pairs (no payload gather)"}
+                     f"{best_t} partitions/threads (best of {tried} rows/s; host has {cores} hardware threads, cgroup CPU quota {cpu_quota()}), "
+                     f"8192-row probe batches, key-only pairs (no payload gather)", "cpu_quota": cpu_quota()}
     try:  # independent production CPU engine on the same sample: Arrow Acero hash join
         import pyarrow as pa
         pa.set_cpu_count(cores)
