@@ -3,7 +3,8 @@
 //! (datasource-arrow/src/source.rs:260-330) whose output partition is ONE device table handed to the GPU node above it (device.rs),
 //! or exported `batch_size` rows at a time to a CPU parent.  A file scanned before costs no host read and no PCIe transfer: its
 //! batches are views of HBM (`MemorySourceConfig`'s role, datasource/src/memory.rs:58).  Python twin: datafusion_amd/ipc.py.
-//! (The Parquet twin drives `dfgpu_parquet_decode_chunk` per projected column chunk the same way: INTEGRATION.md §3.1.)
+//! `GpuParquetScanExec` below is the Parquet twin: the footer through the `parquet` crate, the projected column chunks through ONE
+//! `dfgpu_parquet_read_chunks` call.
 use crate::device::{host_stream, DeviceFuture, GpuNode};
 use crate::table::DeviceTable;
 use crate::{blocking, check, sys};
@@ -119,6 +120,132 @@ impl GpuNode for GpuIpcScanExec {
 
 impl ExecutionPlan for GpuIpcScanExec {
     fn name(&self) -> &str { "GpuIpcScanExec" }
+    fn properties(&self) -> &Arc<PlanProperties> { &self.cache }
+    fn children(&self) -> Vec<&Arc<dyn ExecutionPlan>> { vec![] }
+    fn apply_expressions(&self, _f: &mut dyn FnMut(&Arc<dyn PhysicalExpr>) -> Result<TreeNodeRecursion>) -> Result<TreeNodeRecursion> {
+        Ok(TreeNodeRecursion::Continue)
+    }
+    fn replace_children(self: Arc<Self>, _c: Vec<Arc<dyn ExecutionPlan>>, _o: ReplaceChildrenOptions) -> Result<Arc<dyn ExecutionPlan>> { Ok(self) }
+    #[allow(deprecated)]
+    fn with_new_children(self: Arc<Self>, _c: Vec<Arc<dyn ExecutionPlan>>) -> Result<Arc<dyn ExecutionPlan>> { Ok(self) }
+    fn execute(&self, partition: usize, ctx: Arc<TaskContext>) -> Result<SendableRecordBatchStream> {
+        let batch_size = ctx.session_config().batch_size();
+        Ok(host_stream(Arc::clone(&self.schema), self.execute_device(partition, ctx)?, batch_size))
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------- Parquet
+/// A local Parquet file scanned straight into HBM: the footer is read with the `parquet` crate (as the CPU reader does,
+/// datasource-parquet/src/metadata.rs), every projected column chunk's byte range is described to the library, and ONE call —
+/// `dfgpu_parquet_read_chunks` — decodes them on the library's own host threads (host half: page headers, decompression, levels,
+/// run headers; device half: value decode), consults and fills the device chunk cache and puts the row groups together on the
+/// device.  Python twin: datafusion_amd/parquet.py `ParquetFile.read`.  A chunk the library rejects (an encoding or codec outside
+/// include/dfgpu.h's list, nested columns) fails the call with the library's message; the rule keeps the CPU `DataSourceExec` for files
+/// whose footer shows such chunks.
+#[derive(Debug)]
+pub struct GpuParquetScanExec {
+    path: String,
+    /// leaf-column indices of the file's schema (the scan's projection), in output order
+    projection: Vec<usize>,
+    /// row groups to read (after statistics pruning by the rule / the dynamic filter), in file order
+    row_groups: Vec<usize>,
+    schema: SchemaRef,
+    cache: Arc<PlanProperties>,
+}
+
+fn thrift_codec(c: datafusion::parquet::basic::Compression) -> i32 {
+    use datafusion::parquet::basic::Compression::*;
+    match c {
+        UNCOMPRESSED => 0,
+        SNAPPY => 1,
+        GZIP(_) => 2,
+        LZO => 3,
+        BROTLI(_) => 4,
+        LZ4 => 5,
+        ZSTD(_) => 6,
+        LZ4_RAW => 7,
+    }
+}
+
+impl GpuParquetScanExec {
+    pub fn new(path: String, projection: Vec<usize>, row_groups: Vec<usize>, schema: SchemaRef) -> Self {
+        let props = PlanProperties::new(EquivalenceProperties::new(Arc::clone(&schema)), Partitioning::UnknownPartitioning(1), EmissionType::Final, Boundedness::Bounded);
+        Self { path, projection, row_groups, schema, cache: Arc::new(props) }
+    }
+}
+
+impl DisplayAs for GpuParquetScanExec {
+    fn fmt_as(&self, _t: DisplayFormatType, f: &mut std::fmt::Formatter) -> std::fmt::Result {
+        write!(f, "GpuParquetScanExec: {}, projection={:?}, row_groups={:?}", self.path, self.projection, self.row_groups)
+    }
+}
+
+impl GpuNode for GpuParquetScanExec {
+    fn execute_device(&self, _partition: usize, ctx: Arc<TaskContext>) -> Result<DeviceFuture> {
+        use datafusion::parquet::file::metadata::ParquetMetaDataReader;
+        let file = std::fs::File::open(&self.path)?;
+        let meta = file.metadata()?;
+        let map = unsafe { memmap2::Mmap::map(&file) }.map_err(|e| DataFusionError::External(Box::new(e)))?;
+        let footer = ParquetMetaDataReader::new().parse_and_finish(&file).map_err(|e| DataFusionError::External(Box::new(e)))?;
+        let mtime = meta.modified().ok().and_then(|t| t.duration_since(std::time::UNIX_EPOCH).ok()).map_or(0, |d| d.as_nanos());
+        let identity = format!("{}|{}|{}", self.path, mtime, meta.len());
+        let threads = ctx.session_config().target_partitions().clamp(1, 16) as i32;
+        let (projection, row_groups, schema) = (self.projection.clone(), self.row_groups.clone(), Arc::clone(&self.schema));
+        Ok(async move {
+            blocking(move || {
+                if row_groups.is_empty() {
+                    return DeviceTable::empty(&schema);
+                }
+                // everything the chunk descriptors point at (names, cache keys) lives until the call returns
+                let names: Vec<std::ffi::CString> = schema.fields().iter().map(|f| std::ffi::CString::new(f.name().as_str()).unwrap()).collect();
+                let mut keys: Vec<Vec<u8>> = vec![];
+                let mut chunks: Vec<sys::dfgpu_parquet_chunk> = vec![];
+                for &g in &row_groups {
+                    let rg = footer.row_group(g);
+                    for (j, &leaf) in projection.iter().enumerate() {
+                        let cc = rg.column(leaf);
+                        let (start, len) = cc.byte_range(); // dictionary page first, then the data pages
+                        let descr = cc.column_descr();
+                        let field = crate::expr::field_of(schema.field(j).data_type())
+                            .ok_or_else(|| DataFusionError::NotImplemented(format!("GPU scan of {:?}", schema.field(j).data_type())))?;
+                        keys.push(format!("{identity}|{g}|{}", schema.field(j).name()).into_bytes());
+                        chunks.push(sys::dfgpu_parquet_chunk {
+                            bytes: unsafe { map.as_ptr().add(start as usize) },
+                            n_bytes: len as i64,
+                            column: sys::dfgpu_parquet_column {
+                                physical_type: cc.column_type() as i32,
+                                type_length: descr.type_length().max(0),
+                                codec: thrift_codec(cc.compression()),
+                                max_definition_level: descr.max_def_level() as i32,
+                                max_repetition_level: descr.max_rep_level() as i32,
+                                _pad: 0,
+                                num_values: cc.num_values(),
+                                field,
+                                name: names[j].as_ptr(),
+                            },
+                            cache_key: std::ptr::null(),
+                            cache_key_bytes: 0,
+                        });
+                    }
+                }
+                for (c, k) in chunks.iter_mut().zip(&keys) {
+                    c.cache_key = k.as_ptr() as *const _;
+                    c.cache_key_bytes = k.len() as i64;
+                }
+                let (mut out, mut hits) = (std::ptr::null_mut(), 0i64);
+                check(unsafe {
+                    sys::dfgpu_parquet_read_chunks(chunks.as_ptr(), row_groups.len() as i32, projection.len() as i32, threads, ScanCache::global().0, &mut out, &mut hits)
+                })?;
+                Ok(DeviceTable(out))
+            })
+            .await
+        }
+        .boxed())
+    }
+}
+
+impl ExecutionPlan for GpuParquetScanExec {
+    fn name(&self) -> &str { "GpuParquetScanExec" }
     fn properties(&self) -> &Arc<PlanProperties> { &self.cache }
     fn children(&self) -> Vec<&Arc<dyn ExecutionPlan>> { vec![] }
     fn apply_expressions(&self, _f: &mut dyn FnMut(&Arc<dyn PhysicalExpr>) -> Result<TreeNodeRecursion>) -> Result<TreeNodeRecursion> {

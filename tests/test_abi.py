@@ -258,5 +258,5 @@ def test_rust_shim_targets_the_reference_workspace_versions():
     df = re.search(r'^version = "([0-9.]+)"', text[text.index("[workspace.package]"):], flags=re.M).group(1)
     arrow = re.search(r'^arrow = \{ version = "([0-9.]+)"', text, flags=re.M).group(1)
     cargo = open(os.path.join(ROOT, "shim", "Cargo.toml")).read()
-    assert f'datafusion = "{df}"' in cargo and f'datafusion-ffi = "{df}"' in cargo, df
+    assert re.search(rf'^datafusion = (\{{ version = )?"{re.escape(df)}"', cargo, flags=re.M) and f'datafusion-ffi = "{df}"' in cargo, df
     assert f'arrow = {{ version = "{arrow}"' in cargo, arrow
