@@ -45,7 +45,8 @@ def main():
     nb = bench["config"]["build_rows"] if bench else None
     # calibration kernel: k_rank_setbits (ascending variant) reads exactly the 8-byte build keys, nothing else
     calib = None
-    cal_k = next((k for k in fetch if k.startswith("k_rank_setbits")), None) or next((k for k in fetch if k.startswith("k_key_minmax")), None)
+    # (the VERIFY variant — 4 template arguments — also reads every key's predecessor: not a known-bytes kernel)
+    cal_k = next((k for k in fetch if k.startswith("k_rank_setbits") and k.count(",") < 3), None) or next((k for k in fetch if k.startswith("k_key_minmax")), None)
     if nb and cal_k:
         calib = nb * 8 / (fetch[cal_k] * 1024)
     rows = []
@@ -64,7 +65,11 @@ def main():
         if bench:
             f.write("bench line: `" + json.dumps({k: bench[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step")}) + "`\n\n")
             f.write("roofline: `" + json.dumps(bench.get("roofline")) + "`\n\n")
-        f.write(f"FETCH_SIZE calibration (bytes {cal_k} must read / FETCH_SIZE*1024): {calib}\n\n")
+        if calib is not None:
+            f.write(f"FETCH_SIZE calibration (bytes {cal_k} must read / FETCH_SIZE*1024): {calib}\n\n")
+        else:
+            f.write("FETCH_SIZE calibration: no kernel with known read bytes in this run (the build's one pass reads each key and its predecessor); "
+                    "the x2 factor for coalesced reads is the one measured in profiles/r2_fetch_calib.md (2.000) and in profiles/r3_sf100_v1.md (1.99990)\n\n")
         f.write("| kernel | calls | avg µs | % | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | HBM traffic GB/launch (read x2 corrected) | GB/s |\n|---|---:|---:|---:|---:|---:|---:|---:|\n")
         for r in rows:
             fmt = lambda x, d=1: "" if x is None else f"{x:.{d}f}"
