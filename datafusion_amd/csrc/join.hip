@@ -26,6 +26,7 @@
 //           output rows in probe order.  General M:N path: (build_idx, probe_idx) pairs, then
 //           arrow-`take`-style gathers (build_batch_from_indices, joins/utils.rs:1332-1386).
 // Output order = probe order, then chain order (unordered by contract for duplicates).
+#include <thread>
 #include <cstdlib>
 
 #include "device.hpp"
@@ -1882,7 +1883,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
         if (missed) {  // some probe row has no partner after all: the same probe again, counted
           if (r.profiling) {
             std::lock_guard<std::mutex> lk(r.mu);
-            r.recs.push_back(Runtime::Rec{"join_probe_speculation_missed", ea, eb, 0});
+            r.recs.push_back(Runtime::Rec{"join_probe_speculation_missed", ea, eb, 0, std::this_thread::get_id()});
           }
           {
             std::lock_guard<std::mutex> lk(jt.mu);
@@ -1910,7 +1911,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     if (r.profiling) {
       std::lock_guard<std::mutex> lk(r.mu);
       r.recs.push_back(Runtime::Rec{listed ? "join_probe_listed" : fused_mode == FUSED_PLACED ? "join_probe_placed" : "join_probe_fused", ea, eb,
-                                    bytes_in + (n_out > 0 ? bytes_build_once : 0) + n_out * bytes_per_out});
+                                    bytes_in + (n_out > 0 ? bytes_build_once : 0) + n_out * bytes_per_out, std::this_thread::get_id()});
     }
     out.nrows = n_out;
     for (Column& c : out.cols) c.length = n_out;
