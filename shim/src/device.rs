@@ -35,6 +35,9 @@ pub fn as_gpu_node(plan: &Arc<dyn ExecutionPlan>) -> Option<&dyn GpuNode> {
     if let Some(n) = plan.downcast_ref::<crate::scan::GpuIpcScanExec>() {
         return Some(n);
     }
+    if let Some(n) = plan.downcast_ref::<crate::scan::GpuParquetScanExec>() {
+        return Some(n);
+    }
     None
 }
 

@@ -95,10 +95,16 @@ impl GpuOffloadRule {
         } else {
             None
         };
-        Ok(match replaced {
-            Some(g) => Arc::new(g),
-            None => node,
-        })
+        if let Some(g) = replaced {
+            return Ok(Arc::new(g));
+        }
+        // a leaf scan of one local Arrow IPC / Parquet file: straight into HBM (scan.rs), the device chunk cache in front
+        if let Some(d) = node.downcast_ref::<datafusion::datasource::source::DataSourceExec>() {
+            if let Some(scan) = crate::scan::try_from_data_source(d) {
+                return Ok(scan);
+            }
+        }
+        Ok(node)
     }
 }
 

@@ -259,3 +259,41 @@ impl ExecutionPlan for GpuParquetScanExec {
         Ok(host_stream(Arc::clone(&self.schema), self.execute_device(partition, ctx)?, batch_size))
     }
 }
+
+// ------------------------------------------------------------------------------------------ rule-side conversions
+/// `DataSourceExec` over ONE local, unfiltered file -> the GPU scan node that reads it, or None (the CPU scan stays): an Arrow IPC file
+/// (`ArrowSource`) or a Parquet file (`ParquetSource` without a pushed-down predicate; every projected column of a type the library
+/// decodes).  A scan with several files / partitions, partition columns, a limit or a byte range per file keeps the CPU reader —
+/// the node above it then uploads its batches (device.rs `device_input`).
+pub fn try_from_data_source(d: &datafusion::datasource::source::DataSourceExec) -> Option<Arc<dyn ExecutionPlan>> {
+    use datafusion::datasource::physical_plan::{ArrowSource, FileScanConfig, ParquetSource};
+    let conf = d.data_source().downcast_ref::<FileScanConfig>()?;
+    if conf.file_groups.len() != 1 || conf.file_groups[0].len() != 1 || conf.limit.is_some() || !conf.table_partition_cols().is_empty() {
+        return None;
+    }
+    let file = &conf.file_groups[0].files()[0];
+    if file.range.is_some() || conf.object_store_url.as_str() != "file:///" {
+        return None;
+    }
+    let path = format!("/{}", file.object_meta.location);
+    let schema = conf.projected_schema().ok()?;
+    if !schema.fields().iter().all(|f| crate::expr::field_of(f.data_type()).is_some()) {
+        return None;
+    }
+    let projection: Vec<usize> = conf.file_column_projection_indices().unwrap_or_else(|| (0..conf.file_schema().fields().len()).collect());
+    if conf.file_source().downcast_ref::<ArrowSource>().is_some() {
+        return Some(Arc::new(GpuIpcScanExec::new(path, projection.iter().map(|&i| i as i32).collect(), schema)));
+    }
+    let pq = conf.file_source().downcast_ref::<ParquetSource>()?;
+    if pq.predicate().is_some() {
+        return None; // row-group / page pruning by a pushed-down predicate stays with the CPU reader (a dynamic join filter arrives this way)
+    }
+    // all row groups: the footer is read when the node executes (flat schema: leaf index = field index)
+    let file_handle = std::fs::File::open(&path).ok()?;
+    let footer = datafusion::parquet::file::metadata::ParquetMetaDataReader::new().parse_and_finish(&file_handle).ok()?;
+    if footer.file_metadata().schema_descr().num_columns() != conf.file_schema().fields().len() {
+        return None; // nested columns: leaves and fields do not line up
+    }
+    let row_groups: Vec<usize> = (0..footer.num_row_groups()).collect();
+    Some(Arc::new(GpuParquetScanExec::new(path, projection, row_groups, schema)))
+}
