@@ -1634,14 +1634,37 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   args.minmax = mm->as<long long>();
   args.flags = flags->as<uint32_t>();
   int64_t key_bytes = n * (kf.type == DFGPU_INT64 ? 8 : kf.type == DFGPU_UINT8 ? 1 : 4);
-  {
-    ProfileScope ps("agg_dense_key_range", key_bytes);
-    jit_launch(f_minmax, grid, BLOCK, 0, &args, sizeof(args));
-  }
   long long hmm[2];
   uint32_t hflags[2];
-  d2h(hmm, mm->ptr, 16);
-  d2h(hflags, flags->ptr, 8);
+  // the key's range is known without a pass when the key is a column as it stands, without NULLs, under no predicate, and the column
+  // is dictionary-encoded (its codes lie in [0, dictionary size)) or carries cached statistics (internal.hpp ColStats)
+  bool range_known = false;
+  int key_col = -1;
+  if (!pred && n > 0 && is_plain_column(A.group_nodes[0], A.group_roots[0], &key_col) && key_col >= 0 && key_col < (int)in.cols.size() && !in.cols[(size_t)key_col].validity) {
+    const Column& kc = in.cols[(size_t)key_col];
+    if (kc.dict && !kc.dict->values.empty()) {
+      hmm[0] = 0;
+      hmm[1] = (long long)kc.dict->values.size() - 1;
+      range_known = true;
+    } else if (auto cached = std::atomic_load(&kc.stats)) {
+      if (cached->valid == n) {
+        hmm[0] = cached->min;
+        hmm[1] = cached->max;
+        range_known = true;
+      }
+    }
+  }
+  if (range_known) {
+    hflags[0] = 0;   // no NULL group
+    hflags[1] = 1;   // rows exist
+  } else {
+    {
+      ProfileScope ps("agg_dense_key_range", key_bytes);
+      jit_launch(f_minmax, grid, BLOCK, 0, &args, sizeof(args));
+    }
+    d2h(hmm, mm->ptr, 16);
+    d2h(hflags, flags->ptr, 8);
+  }
   const bool any_rows = hflags[1] != 0, null_group = hflags[0] != 0;
   uint64_t range = any_rows ? (uint64_t)hmm[1] - (uint64_t)hmm[0] + 1 : 0;
   // dense enough: at most 64 bitmap bits per input row (the join's rank-map gate), and a bounded bitmap

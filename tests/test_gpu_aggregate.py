@@ -304,3 +304,35 @@ def test_boolean_group_keys(null_frac):
     gb = [(col("b"), "b"), (col("k"), "k")]
     parts = [gpu_agg(t.slice(lo, 10_000), gb, aggs, "Partial") for lo in range(0, n, 10_000)]
     assert_agg_equal(gpu_agg(pa.concat_tables(parts), gb, aggs, "Final"), expected(gb), ordered=False)
+
+
+@pytest.mark.gpu
+def test_dense_key_node_takes_a_known_key_range_without_a_pass():
+    """GROUP BY on a dictionary-encoded column (codes lie in [0, dictionary size)) or on a column whose min / max are cached needs
+    no pass over the keys for their range: the dense-key node goes straight to its bitmap — same groups, same sums, in first-seen order"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(77)
+    n, distinct = 5_000_000, 40_000
+    codes = rng.integers(0, distinct, n)
+    names = pa.array([f"name{i:06d}" for i in range(distinct)])
+    v = rng.integers(-1000, 1000, n)
+    t = DeviceTable.from_arrow(pa.table({"s": pa.DictionaryArray.from_arrays(pa.array(codes.astype(np.int32)), names), "k": pa.array(codes * 3 + 11), "v": pa.array(v)}))
+    want = {}
+    first = {}
+    for i, (c, x) in enumerate(zip(codes.tolist(), v.tolist())):
+        want[c] = want.get(c, 0) + x
+        first.setdefault(c, i)
+    order = sorted(want, key=lambda c: first[c])
+    for key, label, convert in (("s", "dictionary", lambda c: f"name{c:06d}"), ("k", "cached statistics", lambda c: c * 3 + 11)):
+        if key == "k":
+            assert ops.column_minmax(t, "k")[:2] == (11, (distinct - 1) * 3 + 11)       # fills the column's cached statistics
+        ops.profile_enable(True)
+        ops.profile_reset()
+        got = ops.aggregate(t, [(col(key), key)], [("sum", col("v"), "sv")], "Single").to_arrow()
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+        assert "agg_dense_accumulate" in stats and "agg_dense_key_range" not in stats, (label, sorted(stats))
+        assert got.column(key).to_pylist() == [convert(c) for c in order], label
+        assert got.column("sv").to_pylist() == [want[c] for c in order], label
