@@ -1553,6 +1553,243 @@ __global__ __launch_bounds__(BLOCK) void k_dense_keys(const uint64_t* __restrict
   }
 }
 
+// ---------------------------------------------------------------- dense-key node, medium cardinality: partition, then LDS
+// One global atomic per (row, aggregate) is what dense_accumulate costs when neighbouring rows carry different keys — ~27 G
+// atomics/s on this part, 30 M rows x SUM = 1.36 ms where the bytes are worth 0.07 ms.  When key and arguments are columns as they
+// stand, the rows are first moved into <= 64 groups by the RANGE their key falls in (partition.hip: count + one stable scatter at
+// copy rate); a group's distinct values then fit one workgroup's LDS, where the rows are accumulated with LDS atomics, and only
+// the per-workgroup totals go to the global cells (groups x workgroups-per-partition atomics instead of rows).
+constexpr int PART_ACC_MAX = 8;
+struct PartAcc {
+  int kind;          // AccKind
+  int cell;          // first cell word among the node's global cells
+  int lcell;         // first cell word among this launch's LDS cells
+  int val;           // ValKind of the moved argument column (unused for the counts)
+  const void* data;  // the moved argument column (partition-major), null for COUNT / COUNT(*)
+};
+struct PartAccSet {   // the accumulators of ONE launch: as many as fit LDS beside the window's first rows
+  PartAcc a[PART_ACC_MAX];
+  int n;
+  int ncw;            // LDS cell words per value in this launch
+  int track_first;    // this launch also tracks first rows / seen flags (the first one does)
+};
+struct PartBlock {
+  int64_t begin, end;  // rows of the partition-major order
+  int32_t part, _pad;
+};
+template <typename KT>
+__global__ __launch_bounds__(BLOCK) void k_dense_accumulate_parts(const PartBlock* __restrict__ blocks, const KT* __restrict__ key, const uint32_t* __restrict__ row_id,
+                                                                 PartAccSet accs, long long kmin, int wshift, const uint64_t* __restrict__ bits,
+                                                                 const uint64_t* __restrict__ prefix, unsigned long long* __restrict__ cells, int64_t G,
+                                                                 uint32_t* __restrict__ first_row, uint32_t* __restrict__ seen, uint32_t seen_mask) {
+  extern __shared__ unsigned long long s_mem[];
+  const int W = 1 << wshift;
+  unsigned long long* s_cell = s_mem;                                   // [ncw][W]
+  uint32_t* s_first = reinterpret_cast<uint32_t*>(s_mem + (size_t)accs.ncw * W);  // [W]
+  const PartBlock b = blocks[blockIdx.x];
+  for (int x = threadIdx.x; x < W; x += BLOCK) s_first[x] = 0xFFFFFFFFu;
+  for (int k = 0; k < accs.n; k++) {
+    const unsigned long long id = acc_identity(accs.a[k].kind);
+    for (int x = threadIdx.x; x < W; x += BLOCK) {
+      s_cell[(size_t)accs.a[k].lcell * W + x] = id;
+      if (accs.a[k].kind == ACC_SUM_I128) s_cell[(size_t)(accs.a[k].lcell + 1) * W + x] = 0ull;
+    }
+  }
+  __syncthreads();
+  const unsigned long long base = (unsigned long long)b.part << wshift;
+  for (int64_t i = b.begin + threadIdx.x; i < b.end; i += BLOCK) {
+    const int x = (int)((unsigned long long)((long long)key[i] - kmin) - base);   // value index inside the partition's window
+    atomicMin(&s_first[x], row_id[i]);
+    for (int k = 0; k < accs.n; k++) {
+      const PartAcc& a = accs.a[k];
+      unsigned long long* c = s_cell + (size_t)a.lcell * W + x;
+      switch (a.kind) {
+        case ACC_COUNT:
+        case ACC_COUNT_STAR: atomicAdd(c, 1ull); break;
+        case ACC_SUM_I128: {
+          const unsigned long long* p = (const unsigned long long*)a.data + 2 * i;
+          const unsigned long long lo = p[0], hi = p[1];
+          const unsigned long long old = atomicAdd(c, lo);
+          atomicAdd(c + W, hi + ((old + lo) < old ? 1ull : 0ull));
+          break;
+        }
+        case ACC_SUM_F64: atomicAdd(reinterpret_cast<double*>(c), ((const double*)a.data)[i]); break;
+        default: {
+          long long v;
+          switch (a.val) {
+            case VAL_I32: v = ((const int32_t*)a.data)[i]; break;
+            case VAL_U32: v = ((const uint32_t*)a.data)[i]; break;
+            case VAL_U8: v = ((const uint8_t*)a.data)[i]; break;
+            case VAL_I128: v = ((const long long*)a.data)[2 * i]; break;   // MIN / MAX over decimals that fit 64 bits (plan_for)
+            default: v = ((const long long*)a.data)[i]; break;
+          }
+          if (a.kind == ACC_SUM_I64) atomicAdd(c, (unsigned long long)v);
+          else if (a.kind == ACC_MIN_I64) atomicMin(reinterpret_cast<long long*>(c), v);
+          else atomicMax(reinterpret_cast<long long*>(c), v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // the workgroup's totals -> the global cells of the values it saw (group number = rank of the value in the key bitmap)
+  for (int x = threadIdx.x; x < W; x += BLOCK) {
+    const uint32_t fr = s_first[x];
+    if (fr == 0xFFFFFFFFu) continue;
+    const unsigned long long idx = base + (unsigned)x;
+    const int64_t g = (int64_t)(prefix[idx >> 6] + __popcll(bits[idx >> 6] & ((1ull << (idx & 63)) - 1ull)));
+    if (accs.track_first && fr < first_row[g]) atomicMin(first_row + g, fr);
+    for (int k = 0; k < accs.n; k++) {
+      const PartAcc& a = accs.a[k];
+      const unsigned long long v = s_cell[(size_t)a.lcell * W + x];
+      unsigned long long* c = cells + (int64_t)a.cell * G + g;
+      switch (a.kind) {
+        case ACC_SUM_I128: {
+          const unsigned long long old = atomicAdd(c, v);
+          atomicAdd(c + G, s_cell[(size_t)(a.lcell + 1) * W + x] + ((old + v) < old ? 1ull : 0ull));
+          break;
+        }
+        case ACC_SUM_F64: atomicAdd(reinterpret_cast<double*>(c), __longlong_as_double((long long)v)); break;
+        case ACC_MIN_I64: atomicMin(reinterpret_cast<long long*>(c), (long long)v); break;
+        case ACC_MAX_I64: atomicMax(reinterpret_cast<long long*>(c), (long long)v); break;
+        default: atomicAdd(c, v); break;
+      }
+    }
+    if (accs.track_first && (seen_mask & ~seen[g])) atomicOr(seen + g, seen_mask);
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_row_ids(int64_t n, uint32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (uint32_t)i;
+}
+// applies when: no predicate, the key and every aggregate argument are columns as they stand without NULLs, the value range splits
+// into <= 64 windows that fit LDS, enough rows to pay for the move.  Fills the same cells / first_row / seen as dense_accumulate.
+// acc_col[u]: input column of accumulator u's argument (-1 = none: the counts; -2 = an expression), acc_val[u]: its ValKind.
+static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, const dfgpu_expr* pred, const std::vector<DenseAcc>& accs, const std::vector<int>& acc_col,
+                                         const std::vector<int>& acc_val, int ncw, long long kmin, uint64_t range, const uint64_t* bits, const uint64_t* prefix,
+                                         unsigned long long* cells, int64_t G, uint32_t* first_row, uint32_t* seen) {
+  static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
+  const int64_t n = in.nrows;
+  const int64_t min_rows = env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23);
+  if (off || pred || n < min_rows || G < 4096 || accs.empty() || accs.size() > (size_t)PART_ACC_MAX || range == 0) return false;
+  int kc = -1;
+  if (!is_plain_column(A.group_nodes[0], A.group_roots[0], &kc) || kc < 0 || kc >= (int)in.cols.size()) return false;
+  const Column& key = in.cols[(size_t)kc];
+  if (key.validity) return false;
+  const int kt = key.field.type;
+  if (!(kt == DFGPU_INT32 || kt == DFGPU_DATE32 || kt == DFGPU_INT64 || kt == DFGPU_UINT32 || kt == DFGPU_UINT8)) return false;
+  // windows of 2^wshift values: at most 64 of them, each with ncw cell words + a first row per value in <= 64 KB of LDS
+  int wshift = 0;
+  while (((range - 1) >> wshift) >= 64) wshift++;
+  const int nparts = (int)((range - 1) >> wshift) + 1;
+  // LDS per launch: a first row (4 B) and the launch's cell words per value; accumulators are spread over as many launches as it
+  // takes (the move is the cost, a launch over the moved rows is cheap), an accumulator needs its 1-2 words beside the first rows
+  const size_t W = (size_t)1 << wshift;
+  constexpr size_t LDS_BUDGET = (size_t)128 << 10;   // of the CU's 160 KB: one workgroup per CU at the widest windows
+  if (W * 12 > LDS_BUDGET) return false;
+  const int words_per_launch = (int)std::min<size_t>((LDS_BUDGET / W - 4) / 8, 64);
+  for (const DenseAcc& a : accs)
+    if (a.kind == ACC_SUM_I128 && words_per_launch < 2) return false;
+  (void)ncw;
+  // more than 64 KB of dynamic LDS has to be asked for, per kernel
+  {
+    const void* fn = nullptr;
+    switch (kt) {
+      case DFGPU_INT64: fn = (const void*)k_dense_accumulate_parts<int64_t>; break;
+      case DFGPU_UINT32: fn = (const void*)k_dense_accumulate_parts<uint32_t>; break;
+      case DFGPU_UINT8: fn = (const void*)k_dense_accumulate_parts<uint8_t>; break;
+      default: fn = (const void*)k_dense_accumulate_parts<int32_t>; break;
+    }
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess) {
+      (void)hipGetLastError();
+      if (W * 12 > ((size_t)64 << 10)) return false;
+    }
+  }
+  std::vector<PartAcc> all(accs.size());
+  std::vector<const void*> src;
+  std::vector<int> widths;
+  src.push_back(key.ptr());
+  widths.push_back(type_width(kt));
+  std::vector<int> moved_of_col;   // input column -> index in `src`
+  moved_of_col.assign(in.cols.size(), -1);
+  std::vector<int> acc_src(accs.size(), -1);
+  for (size_t u = 0; u < accs.size(); u++) {
+    const int kind = accs[u].kind;
+    all[u] = PartAcc{kind, accs[u].cell, 0, acc_val[u], nullptr};
+    if (kind == ACC_COUNT_STAR) continue;
+    const int c = acc_col[u];
+    if (c < 0 || c >= (int)in.cols.size()) return false;   // an expression: the specialised kernel evaluates it, this path moves columns
+    const Column& col = in.cols[(size_t)c];
+    if (col.validity || col.dict) return false;
+    if (kind == ACC_COUNT) continue;                        // non-NULL argument: counts rows
+    const int v = acc_val[u];
+    const bool ok = (kind == ACC_SUM_I128 && v == VAL_I128) || (kind == ACC_SUM_F64 && v == VAL_F64) ||
+                    ((kind == ACC_SUM_I64 || kind == ACC_MIN_I64 || kind == ACC_MAX_I64) && (v == VAL_I32 || v == VAL_I64 || v == VAL_U32 || v == VAL_U8)) ||
+                    ((kind == ACC_MIN_I64 || kind == ACC_MAX_I64) && v == VAL_I128);
+    if (!ok) return false;
+    if (moved_of_col[(size_t)c] < 0) {
+      moved_of_col[(size_t)c] = (int)src.size();
+      src.push_back(col.ptr());
+      widths.push_back(type_width(col.field.type));
+    }
+    acc_src[u] = moved_of_col[(size_t)c];
+  }
+  Runtime& r = rt();
+  BufPtr ids = make_buf((size_t)n * 4);
+  k_row_ids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(n, ids->as<uint32_t>());
+  const int ids_at = (int)src.size();
+  src.push_back(ids->ptr);
+  widths.push_back(4);
+  RangePartition rp = partition_by_key_range(key.ptr(), kt, n, kmin, wshift, nparts, src, widths);
+  for (size_t u = 0; u < accs.size(); u++)
+    if (acc_src[u] >= 0) all[u].data = rp.cols[(size_t)acc_src[u]]->ptr;
+  // workgroups: a partition's rows in chunks (at most ~16 per partition: every chunk ends with one global atomic per value it saw)
+  std::vector<PartBlock> blocks;
+  for (int p = 0; p < nparts; p++) {
+    const int64_t b0 = (int64_t)rp.bounds[(size_t)p], b1 = (int64_t)rp.bounds[(size_t)p + 1];
+    if (b1 <= b0) continue;
+    const int64_t chunk = std::max<int64_t>(32768, (b1 - b0 + 15) / 16);
+    for (int64_t at = b0; at < b1; at += chunk) blocks.push_back(PartBlock{at, std::min(at + chunk, b1), p, 0});
+  }
+  BufPtr d_blocks = make_buf(blocks.size() * sizeof(PartBlock) + 16);
+  DFGPU_HIP(hipMemcpyAsync(d_blocks->ptr, blocks.data(), blocks.size() * sizeof(PartBlock), hipMemcpyHostToDevice, r.stream));
+  const uint32_t seen_mask = (uint32_t)((1ull << accs.size()) - 1ull);
+  {
+    int64_t bytes = 0;
+    for (int w : widths) bytes += n * w;
+    ProfileScope psc("agg_dense_accumulate_partitioned", bytes);
+    const PartBlock* db = d_blocks->as<PartBlock>();
+    const uint32_t* rid = rp.cols[(size_t)ids_at]->as<uint32_t>();
+    const void* mk = rp.cols[0]->ptr;
+    const int nb = (int)blocks.size();
+    size_t u = 0;
+    bool first_launch = true;
+    while (u < all.size()) {
+      PartAccSet ps{};
+      ps.track_first = first_launch ? 1 : 0;
+      while (u < all.size() && ps.n < PART_ACC_MAX) {
+        const int need = all[u].kind == ACC_SUM_I128 ? 2 : 1;
+        if (ps.ncw + need > words_per_launch) break;
+        ps.a[ps.n] = all[u];
+        ps.a[ps.n].lcell = ps.ncw;
+        ps.ncw += need;
+        ps.n++;
+        u++;
+      }
+      const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4);
+      switch (kt) {
+        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
+        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
+        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
+        default: k_dense_accumulate_parts<int32_t><<<nb, BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
+      }
+      DFGPU_HIP(hipGetLastError());
+      first_launch = false;
+    }
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));   // `blocks` and the moved columns are locals
+  return true;
+}
+
 // The specialised dense-key node.  Returns false (state untouched) when it does not apply.
 static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_expr* pred) {
   Runtime& r = rt();
@@ -1585,17 +1822,21 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   struct Ent { int agg; bool is_avg_count; int kind; int cell; int seen_bit; };
   std::vector<Ent> entries;
   std::vector<DenseAcc> accs;
-  std::vector<int> cell_kind;
+  std::vector<int> cell_kind, acc_col, acc_val;   // per accumulator: its argument's input column (-1 none, -2 an expression) and ValKind
   for (size_t k = 0; k < A.aggs.size(); k++) {
     AggState& a = A.aggs[k];
     dfgpu_field t = a.typed ? a.in_type : (a.has_arg ? cp.out_types[(size_t)arg_out[k]] : fld(DFGPU_INT64));
     AccPlan pl = plan_for(a.func, t, false);
     const int kind = (a.func == DFGPU_AGG_COUNT && !a.has_arg) ? ACC_COUNT_STAR : pl.kind;
     const int val = a.has_arg ? cp.src_out_vals[(size_t)arg_out[k]] : -1;
+    int arg_col = -1;
+    const int acc_column = !a.has_arg ? -1 : (is_plain_column(a.nodes, a.root, &arg_col) ? arg_col : -2);
     auto unique = [&](int kd) {
       for (size_t u = 0; u < accs.size(); u++)
         if (accs[u].kind == kd && accs[u].val == val) return (int)u;
       accs.push_back({kd, val, (int)cell_kind.size()});
+      acc_col.push_back(acc_column);
+      acc_val.push_back(pl.val);
       cell_kind.push_back(kd == ACC_SUM_I128 ? ACC_SUM_I64 : kd);
       if (kd == ACC_SUM_I128) cell_kind.push_back(ACC_SUM_I64);
       return (int)accs.size() - 1;
@@ -1702,7 +1943,8 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   args.seen = seen->as<uint32_t>();
   args.G = G;
   args.null_group = null_group ? Gk : -1;
-  if (G) {
+  if (G && !(null_group == false && dense_accumulate_partitioned(A, in, pred, accs, acc_col, acc_val, ncw, args.kmin, range, bits->as<uint64_t>(), prefix->as<uint64_t>(),
+                                                                cells->as<unsigned long long>(), G, first_row->as<uint32_t>(), seen->as<uint32_t>()))) {
     ProfileScope ps("agg_dense_accumulate", n * cp.input_bytes_per_row);
     jit_launch(f_acc, grid, BLOCK, 0, &args, sizeof(args));
   }

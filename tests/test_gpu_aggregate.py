@@ -336,3 +336,67 @@ def test_dense_key_node_takes_a_known_key_range_without_a_pass():
         assert "agg_dense_accumulate" in stats and "agg_dense_key_range" not in stats, (label, sorted(stats))
         assert got.column(key).to_pylist() == [convert(c) for c in order], label
         assert got.column("sv").to_pylist() == [want[c] for c in order], label
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key_type", ["int64", "int32_dictionary_codes"])
+def test_medium_cardinality_group_by_partitions_rows_then_accumulates_in_lds(key_type):
+    """GROUP BY over tens of thousands of groups whose key and arguments are columns as they stand: the rows are moved into <= 64
+    key-range partitions first and accumulated in LDS per partition (one global atomic per value and workgroup instead of one per row
+    and aggregate).  Same groups in first-seen order, same SUM / COUNT / MIN / MAX / AVG as the specialised kernel with its global
+    atomics (DFGPU_AGG_PARTITIONED=0 is read once per process, so the comparison is against values computed on the host)."""
+    from decimal import Decimal
+
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(123)
+    n, distinct = 9_000_000, 50_000
+    codes = rng.integers(0, distinct, n)
+    i64 = rng.integers(-10**9, 10**9, n)
+    i32 = rng.integers(-1000, 1000, n).astype(np.int32)
+    f64 = rng.random(n) * 100.0
+    dec = rng.integers(-10**8, 10**8, n)
+    cols = {"v": pa.array(i64), "w": pa.array(i32), "f": pa.array(f64), "d": pa.array([Decimal(int(x)).scaleb(-2) for x in dec[:0]], pa.decimal128(15, 2))}
+    # Decimal128(15, 2) column from unscaled int64 values without 9 M Python objects: low word = value, high word = sign
+    raw = np.empty((n, 2), dtype=np.int64)
+    raw[:, 0] = dec
+    raw[:, 1] = dec >> 63
+    cols["d"] = pa.Array.from_buffers(pa.decimal128(15, 2), n, [None, pa.py_buffer(raw.tobytes())])
+    if key_type == "int64":
+        keys = codes * 3 + 1000
+        cols["k"] = pa.array(keys)
+        label = lambda c: c * 3 + 1000
+    else:
+        names = pa.array([f"n{i:06d}" for i in range(distinct)])
+        cols["k"] = pa.DictionaryArray.from_arrays(pa.array(codes.astype(np.int32)), names)
+        label = lambda c: f"n{c:06d}"
+    t = DeviceTable.from_arrow(pa.table(cols))
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = ops.aggregate(t, [(col("k"), "k")], [("sum", col("v"), "sv"), ("count", None, "n"), ("count", col("w"), "nw"), ("min", col("w"), "lo"), ("max", col("v"), "hi"),
+                                              ("sum", col("d"), "sd"), ("avg", col("d"), "ad"), ("sum", col("f"), "sf")], "Single").to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert "agg_dense_accumulate_partitioned" in stats and "agg_dense_accumulate" not in stats, sorted(stats)
+    first = np.full(distinct, n, dtype=np.int64)
+    np.minimum.at(first, codes, np.arange(n))
+    present = np.nonzero(first < n)[0]
+    order = present[np.argsort(first[present], kind="stable")]
+    assert got.column("k").to_pylist() == [label(int(c)) for c in order]
+    sv = np.zeros(distinct, dtype=np.int64); np.add.at(sv, codes, i64)
+    cnt = np.bincount(codes, minlength=distinct)
+    lo = np.full(distinct, 2**31, dtype=np.int64); np.minimum.at(lo, codes, i32)
+    hi = np.full(distinct, -2**62, dtype=np.int64); np.maximum.at(hi, codes, i64)
+    sd = np.zeros(distinct, dtype=np.int64); np.add.at(sd, codes, dec)
+    sf = np.bincount(codes, weights=f64, minlength=distinct)
+    assert got.column("sv").to_pylist() == sv[order].tolist()
+    assert got.column("n").to_pylist() == cnt[order].tolist() == got.column("nw").to_pylist()
+    assert got.column("lo").to_pylist() == lo[order].tolist() and got.column("hi").to_pylist() == hi[order].tolist()
+    assert [int(x.scaleb(2)) for x in got.column("sd").to_pylist()] == sd[order].tolist()
+    # AVG(Decimal128(15, 2)) -> Decimal128(19, 6): sum * 10^4 / count in i128, truncating (DecimalAverager::avg, functions-aggregate-common/src/utils.rs)
+    def avg(s, c):
+        q = abs(int(s)) * 10**4 // int(c)
+        return q if s >= 0 else -q
+    assert [int(x.scaleb(6)) for x in got.column("ad").to_pylist()] == [avg(sd[c], cnt[c]) for c in order]
+    assert np.allclose(got.column("sf").to_numpy(), sf[order], rtol=1e-9)
