@@ -1574,11 +1574,13 @@ struct PartAccSet {   // the accumulators of ONE launch: as many as fit LDS besi
   int track_first;    // this launch also tracks first rows / seen flags (the first one does)
 };
 struct PartBlock {
-  int64_t begin, end;  // rows of the partition-major order
-  int32_t part, _pad;
+  int64_t begin, end;  // rows of the window order
+  int32_t part;        // window number
+  int32_t alone;       // no other workgroup works on this window
 };
+constexpr int PART_BLOCK = 1024;   // threads per workgroup: the windows' LDS leaves room for one or two workgroups per CU, so they are big
 template <typename KT>
-__global__ __launch_bounds__(BLOCK) void k_dense_accumulate_parts(const PartBlock* __restrict__ blocks, const KT* __restrict__ key, const uint32_t* __restrict__ row_id,
+__global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const PartBlock* __restrict__ blocks, const KT* __restrict__ key, const uint32_t* __restrict__ row_id,
                                                                  PartAccSet accs, long long kmin, int wshift, const uint64_t* __restrict__ bits,
                                                                  const uint64_t* __restrict__ prefix, unsigned long long* __restrict__ cells, int64_t G,
                                                                  uint32_t* __restrict__ first_row, uint32_t* __restrict__ seen, uint32_t seen_mask) {
@@ -1587,17 +1589,17 @@ __global__ __launch_bounds__(BLOCK) void k_dense_accumulate_parts(const PartBloc
   unsigned long long* s_cell = s_mem;                                   // [ncw][W]
   uint32_t* s_first = reinterpret_cast<uint32_t*>(s_mem + (size_t)accs.ncw * W);  // [W]
   const PartBlock b = blocks[blockIdx.x];
-  for (int x = threadIdx.x; x < W; x += BLOCK) s_first[x] = 0xFFFFFFFFu;
+  for (int x = threadIdx.x; x < W; x += PART_BLOCK) s_first[x] = 0xFFFFFFFFu;
   for (int k = 0; k < accs.n; k++) {
     const unsigned long long id = acc_identity(accs.a[k].kind);
-    for (int x = threadIdx.x; x < W; x += BLOCK) {
+    for (int x = threadIdx.x; x < W; x += PART_BLOCK) {
       s_cell[(size_t)accs.a[k].lcell * W + x] = id;
       if (accs.a[k].kind == ACC_SUM_I128) s_cell[(size_t)(accs.a[k].lcell + 1) * W + x] = 0ull;
     }
   }
   __syncthreads();
   const unsigned long long base = (unsigned long long)b.part << wshift;
-  for (int64_t i = b.begin + threadIdx.x; i < b.end; i += BLOCK) {
+  for (int64_t i = b.begin + threadIdx.x; i < b.end; i += PART_BLOCK) {
     const int x = (int)((unsigned long long)((long long)key[i] - kmin) - base);   // value index inside the partition's window
     atomicMin(&s_first[x], row_id[i]);
     for (int k = 0; k < accs.n; k++) {
@@ -1632,11 +1634,23 @@ __global__ __launch_bounds__(BLOCK) void k_dense_accumulate_parts(const PartBloc
   }
   __syncthreads();
   // the workgroup's totals -> the global cells of the values it saw (group number = rank of the value in the key bitmap)
-  for (int x = threadIdx.x; x < W; x += BLOCK) {
+  for (int x = threadIdx.x; x < W; x += PART_BLOCK) {
     const uint32_t fr = s_first[x];
     if (fr == 0xFFFFFFFFu) continue;
     const unsigned long long idx = base + (unsigned)x;
     const int64_t g = (int64_t)(prefix[idx >> 6] + __popcll(bits[idx >> 6] & ((1ull << (idx & 63)) - 1ull)));
+    if (b.alone) {   // the window's only workgroup: its groups belong to nobody else — plain stores, consecutive values = consecutive groups
+      if (accs.track_first) {
+        first_row[g] = fr;
+        seen[g] = seen_mask;
+      }
+      for (int k = 0; k < accs.n; k++) {
+        const PartAcc& a = accs.a[k];
+        cells[(int64_t)a.cell * G + g] = s_cell[(size_t)a.lcell * W + x];
+        if (a.kind == ACC_SUM_I128) cells[(int64_t)(a.cell + 1) * G + g] = s_cell[(size_t)(a.lcell + 1) * W + x];
+      }
+      continue;
+    }
     if (accs.track_first && fr < first_row[g]) atomicMin(first_row + g, fr);
     for (int k = 0; k < accs.n; k++) {
       const PartAcc& a = accs.a[k];
@@ -1658,6 +1672,15 @@ __global__ __launch_bounds__(BLOCK) void k_dense_accumulate_parts(const PartBloc
   }
 }
 
+// first row of every window in the window-ordered keys (-1 stays where a window has no row)
+template <typename KT>
+__global__ __launch_bounds__(BLOCK) void k_window_begins(const KT* __restrict__ key, int64_t n, long long kmin, int wshift, long long* __restrict__ begins) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const long long w = (long long)(((unsigned long long)((long long)key[i] - kmin)) >> wshift);
+    const long long wp = i ? (long long)(((unsigned long long)((long long)key[i - 1] - kmin)) >> wshift) : -1;
+    if (w != wp) begins[w] = i;
+  }
+}
 __global__ __launch_bounds__(BLOCK) void k_row_ids(int64_t n, uint32_t* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (uint32_t)i;
 }
@@ -1677,18 +1700,26 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
   if (key.validity) return false;
   const int kt = key.field.type;
   if (!(kt == DFGPU_INT32 || kt == DFGPU_DATE32 || kt == DFGPU_INT64 || kt == DFGPU_UINT32 || kt == DFGPU_UINT8)) return false;
-  // windows of 2^wshift values: at most 64 of them, each with ncw cell words + a first row per value in <= 64 KB of LDS
+  // windows of 2^wshift values whose first rows (4 B) and at least one accumulator (8 B, 16 for a 128-bit sum) fit the LDS budget:
+  // at most 64 of them after ONE move of the rows, at most 4096 after two (low 6 bits of the window number first, then the high 6)
+  constexpr size_t LDS_BUDGET = (size_t)128 << 10;   // of the CU's 160 KB: one workgroup per CU at the widest windows
+  int min_words = 1;
+  for (const DenseAcc& a : accs)
+    if (a.kind == ACC_SUM_I128) min_words = 2;
+  int wcap = 0;
+  while (((size_t)2 << wcap) * (4 + 8 * (size_t)min_words) <= LDS_BUDGET) wcap++;
   int wshift = 0;
   while (((range - 1) >> wshift) >= 64) wshift++;
-  const int nparts = (int)((range - 1) >> wshift) + 1;
-  // LDS per launch: a first row (4 B) and the launch's cell words per value; accumulators are spread over as many launches as it
-  // takes (the move is the cost, a launch over the moved rows is cheap), an accumulator needs its 1-2 words beside the first rows
+  int levels = 1;
+  if (wshift > wcap) {
+    wshift = wcap;
+    if (((range - 1) >> wshift) >= 4096) return false;
+    levels = 2;
+    if (n < 4 * min_rows) return false;   // two moves: only for inputs where the atomics are long
+  }
+  const int64_t n_windows = (int64_t)((range - 1) >> wshift) + 1;
   const size_t W = (size_t)1 << wshift;
-  constexpr size_t LDS_BUDGET = (size_t)128 << 10;   // of the CU's 160 KB: one workgroup per CU at the widest windows
-  if (W * 12 > LDS_BUDGET) return false;
   const int words_per_launch = (int)std::min<size_t>((LDS_BUDGET / W - 4) / 8, 64);
-  for (const DenseAcc& a : accs)
-    if (a.kind == ACC_SUM_I128 && words_per_launch < 2) return false;
   (void)ncw;
   // more than 64 KB of dynamic LDS has to be asked for, per kernel
   {
@@ -1739,16 +1770,41 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
   const int ids_at = (int)src.size();
   src.push_back(ids->ptr);
   widths.push_back(4);
-  RangePartition rp = partition_by_key_range(key.ptr(), kt, n, kmin, wshift, nparts, src, widths);
+  RangePartition rp = partition_by_key_range(key.ptr(), kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths);
+  if (levels == 2) {   // stable second move by the high digit: the rows end up in window order
+    std::vector<const void*> src2;
+    for (const BufPtr& b : rp.cols) src2.push_back(b->ptr);
+    RangePartition rp2 = partition_by_key_range(rp.cols[0]->ptr, kt, n, kmin, wshift + 6, 63u, (int)((n_windows + 63) / 64), src2, widths);
+    rp = std::move(rp2);
+  }
   for (size_t u = 0; u < accs.size(); u++)
     if (acc_src[u] >= 0) all[u].data = rp.cols[(size_t)acc_src[u]]->ptr;
-  // workgroups: a partition's rows in chunks (at most ~16 per partition: every chunk ends with one global atomic per value it saw)
+  // where every window's rows begin (read off the moved keys), then the workgroups: a window's rows in chunks (at most ~16 per
+  // window at one level: every chunk ends with one global atomic per value it saw)
+  BufPtr d_begins = make_buf((size_t)n_windows * 8);
+  DFGPU_HIP(hipMemsetAsync(d_begins->ptr, 0xFF, (size_t)n_windows * 8, r.stream));
+  switch (kt) {
+    case DFGPU_INT64: k_window_begins<int64_t><<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(rp.cols[0]->as<int64_t>(), n, kmin, wshift, d_begins->as<long long>()); break;
+    case DFGPU_UINT32: k_window_begins<uint32_t><<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(rp.cols[0]->as<uint32_t>(), n, kmin, wshift, d_begins->as<long long>()); break;
+    case DFGPU_UINT8: k_window_begins<uint8_t><<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(rp.cols[0]->as<uint8_t>(), n, kmin, wshift, d_begins->as<long long>()); break;
+    default: k_window_begins<int32_t><<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(rp.cols[0]->as<int32_t>(), n, kmin, wshift, d_begins->as<long long>()); break;
+  }
+  std::vector<long long> begins((size_t)n_windows);
+  d2h(begins.data(), d_begins->ptr, (size_t)n_windows * 8);
   std::vector<PartBlock> blocks;
-  for (int p = 0; p < nparts; p++) {
-    const int64_t b0 = (int64_t)rp.bounds[(size_t)p], b1 = (int64_t)rp.bounds[(size_t)p + 1];
-    if (b1 <= b0) continue;
-    const int64_t chunk = std::max<int64_t>(32768, (b1 - b0 + 15) / 16);
-    for (int64_t at = b0; at < b1; at += chunk) blocks.push_back(PartBlock{at, std::min(at + chunk, b1), p, 0});
+  {
+    int64_t end = n;
+    std::vector<PartBlock> rev;
+    for (int64_t w = n_windows - 1; w >= 0; w--) {
+      const int64_t b0 = begins[(size_t)w];
+      if (b0 < 0) continue;
+      // one workgroup per window while its rows are few (its totals then leave as plain stores); else chunks, merged by atomics
+      const int64_t rows = end - b0;
+      const int64_t chunk = rows <= ((int64_t)1 << 18) ? rows : std::max<int64_t>((int64_t)1 << 17, (rows + 15) / 16);
+      for (int64_t at = b0; at < end; at += chunk) rev.push_back(PartBlock{at, std::min(at + chunk, end), (int32_t)w, chunk >= rows ? 1 : 0});
+      end = b0;
+    }
+    blocks.assign(rev.rbegin(), rev.rend());
   }
   BufPtr d_blocks = make_buf(blocks.size() * sizeof(PartBlock) + 16);
   DFGPU_HIP(hipMemcpyAsync(d_blocks->ptr, blocks.data(), blocks.size() * sizeof(PartBlock), hipMemcpyHostToDevice, r.stream));
@@ -1777,10 +1833,10 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
       }
       const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4);
       switch (kt) {
-        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
-        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
-        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
-        default: k_dense_accumulate_parts<int32_t><<<nb, BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
+        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
+        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
+        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
+        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
       }
       DFGPU_HIP(hipGetLastError());
       first_launch = false;

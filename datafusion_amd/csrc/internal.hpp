@@ -398,14 +398,15 @@ void radix_sort_pairs(BufPtr& key, BufPtr& idx, int64_t n, int lo_bit, int nbits
 // keys alone, grouped stably by bits [lo_bit, lo_bit + nbits) of their value (no row ids are made)
 void radix_group_keys(BufPtr& key, int64_t n, int lo_bit, int nbits);
 Table sort_table_ascending(const Table& in, const std::vector<int>& key_cols);   // sort.hip; stable
-// partition.hip: the rows of fixed-width columns (no validity) moved into `nparts` (<= 64) contiguous groups by (key - kmin) >> shift,
-// row order kept inside a group; bounds[p] .. bounds[p + 1] = group p's rows in every moved column
+// partition.hip: the rows of fixed-width columns (no validity) moved into `nparts` (<= 64) contiguous groups by
+// ((key - kmin) >> shift) & mask, row order kept inside a group (two calls, low digit first, order the rows by 12 bits);
+// bounds[p] .. bounds[p + 1] = group p's rows in every moved column
 struct RangePartition {
   std::vector<BufPtr> cols;
   std::vector<uint64_t> bounds;
 };
-RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, long long kmin, int shift, int nparts, const std::vector<const void*>& src,
-                                      const std::vector<int>& widths);
+RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, long long kmin, int shift, unsigned mask, int nparts,
+                                      const std::vector<const void*>& src, const std::vector<int>& widths);
 
 // ----------------------------------------------------------------- LDS radix join (radix_join.hip)
 struct RadixTable;

@@ -268,11 +268,11 @@ __global__ __launch_bounds__(BLOCK) void k_part_count2(KeySet ks, int64_t n, int
 }
 
 // ---------------------------------------------------------------- rows grouped by the RANGE their key falls in
-// part[i] = (key[i] - kmin) >> shift (the caller guarantees < nparts <= 64) + the per-(partition, tile) counts k_part_scatter
+// part[i] = ((key[i] - kmin) >> shift) & mask (the caller guarantees < nparts <= 64) + the per-(partition, tile) counts k_part_scatter
 // places rows by.  What the aggregate does to rows whose groups are too many for one workgroup's LDS: afterwards every
 // partition's groups fit (aggregate.hip dense_accumulate_partitioned).
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_part_count_range(const T* __restrict__ key, int64_t n, long long kmin, int shift, int nparts, int64_t n_tiles,
+__global__ __launch_bounds__(BLOCK) void k_part_count_range(const T* __restrict__ key, int64_t n, long long kmin, int shift, unsigned mask, int nparts, int64_t n_tiles,
                                                             uint8_t* __restrict__ part, uint32_t* __restrict__ counts) {
   __shared__ unsigned int sh[MAX_PARTS];
   for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_count_range(const T* __restrict_
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (i0 + k < n) {
-          const unsigned p = (unsigned)(((unsigned long long)((long long)key[i0 + k] - kmin)) >> shift);
+          const unsigned p = (unsigned)(((unsigned long long)((long long)key[i0 + k] - kmin)) >> shift) & mask;
           packed |= (p & 0xFFu) << (8 * k);
           atomicAdd(&sh[p & (MAX_PARTS - 1)], 1u);
         }
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_count_range(const T* __restrict_
   }
 }
 
-RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, long long kmin, int shift, int nparts, const std::vector<const void*>& src,
-                                      const std::vector<int>& widths) {
+RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, long long kmin, int shift, unsigned mask, int nparts,
+                                      const std::vector<const void*>& src, const std::vector<int>& widths) {
   Runtime& r = rt();
   DFGPU_CHECK(nparts >= 1 && nparts <= MAX_PARTS && src.size() == widths.size() && n > 0, "partition_by_key_range: bad arguments");
   const int64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
@@ -319,10 +319,10 @@ RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, 
   {
     ProfileScope ps("partition_count_range", n * type_width(key_type) + n);
     switch (key_type) {
-      case DFGPU_INT64: k_part_count_range<int64_t><<<tile_grid, BLOCK, 0, r.stream>>>((const int64_t*)key, n, kmin, shift, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
-      case DFGPU_UINT32: k_part_count_range<uint32_t><<<tile_grid, BLOCK, 0, r.stream>>>((const uint32_t*)key, n, kmin, shift, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
-      case DFGPU_UINT8: k_part_count_range<uint8_t><<<tile_grid, BLOCK, 0, r.stream>>>((const uint8_t*)key, n, kmin, shift, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
-      default: k_part_count_range<int32_t><<<tile_grid, BLOCK, 0, r.stream>>>((const int32_t*)key, n, kmin, shift, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
+      case DFGPU_INT64: k_part_count_range<int64_t><<<tile_grid, BLOCK, 0, r.stream>>>((const int64_t*)key, n, kmin, shift, mask, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
+      case DFGPU_UINT32: k_part_count_range<uint32_t><<<tile_grid, BLOCK, 0, r.stream>>>((const uint32_t*)key, n, kmin, shift, mask, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
+      case DFGPU_UINT8: k_part_count_range<uint8_t><<<tile_grid, BLOCK, 0, r.stream>>>((const uint8_t*)key, n, kmin, shift, mask, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
+      default: k_part_count_range<int32_t><<<tile_grid, BLOCK, 0, r.stream>>>((const int32_t*)key, n, kmin, shift, mask, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
     }
     DFGPU_HIP(hipGetLastError());
   }

@@ -102,7 +102,7 @@ def main():
         ops.sync()
 
     # ------------------------------------------------------------------ config 4: Q1
-    if want("q1") or want("agg_highcard") or want("partition") or want("filter"):
+    if want("q1") or want("agg_highcard") or want("agg_mediumcard") or want("partition") or want("filter"):
         li = ops.tpch_lineitem(args.sf)
         n = li.num_rows
         if want("filter"):
@@ -144,6 +144,20 @@ def main():
                     note="bytes = N*(8+16) in + groups*(8+16) out")
             results[-1]["groups"] = holder["g"]
             t.free()
+        if want("agg_mediumcard"):
+            # Q13's shape: orders per customer — 150 M rows, 10 M groups over a key range of 15 M values at SF100 (two-level partitioned
+            # LDS aggregation: aggregate.hip dense_accumulate_partitioned)
+            oc = ops.tpch_orders(args.sf).select(["o_custkey", "o_orderdate"])
+            holder = {}
+
+            def run_mc():
+                o = ops.aggregate(oc, [(col("o_custkey"), "o_custkey")], [("count", None, "n"), ("min", col("o_orderdate"), "first_order")], "Single")
+                holder["g"] = o.num_rows
+                return o
+            measure(f"GROUP BY o_custkey COUNT(*), MIN(o_orderdate) SF{args.sf:g}", run_mc, oc.num_rows, lambda: oc.num_rows * 12 + holder["g"] * 20,
+                    note="bytes = N*(8+4) in + groups*(8+8+4) out")
+            results[-1]["groups"] = holder["g"]
+            oc.free()
         if want("partition"):
             t = li.select(["l_orderkey", "l_extendedprice", "l_discount"])
             measure(f"RepartitionExec Hash(l_orderkey) -> 8 partitions SF{args.sf:g}", lambda: ops.partition(t, ["l_orderkey"], 8), n, 2 * n * 40,

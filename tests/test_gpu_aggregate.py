@@ -400,3 +400,36 @@ def test_medium_cardinality_group_by_partitions_rows_then_accumulates_in_lds(key
         return q if s >= 0 else -q
     assert [int(x.scaleb(6)) for x in got.column("ad").to_pylist()] == [avg(sd[c], cnt[c]) for c in order]
     assert np.allclose(got.column("sf").to_numpy(), sf[order], rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_medium_cardinality_group_by_over_a_wide_key_range_moves_the_rows_twice(monkeypatch):
+    """a key range too wide for 64 LDS-sized windows: the rows are moved twice (low 6 bits of the window number, then the high 6: up to
+    4096 windows) before the LDS accumulation — 600 K groups over a range of 1.8 M values here, COUNT(*) / SUM / MIN in first-seen order"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    monkeypatch.setenv("DFGPU_AGG_PARTITIONED_MIN_ROWS", "1000000")
+    rng = np.random.default_rng(9)
+    n, distinct = 6_000_000, 600_000
+    codes = rng.integers(0, distinct, n)
+    keys = codes * 3 + 5
+    v = rng.integers(-10**6, 10**6, n)
+    d = rng.integers(0, 3000, n).astype(np.int32)
+    t = DeviceTable.from_arrow(pa.table({"k": pa.array(keys), "v": pa.array(v), "d": pa.array(d, pa.date32())}))
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = ops.aggregate(t, [(col("k"), "k")], [("count", None, "n"), ("sum", col("v"), "sv"), ("min", col("d"), "first_day")], "Single").to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert stats["partition_scatter"]["calls"] == 2 and "agg_dense_accumulate_partitioned" in stats and "agg_dense_accumulate" not in stats, sorted(stats)
+    first = np.full(distinct, n, dtype=np.int64)
+    np.minimum.at(first, codes, np.arange(n))
+    present = np.nonzero(first < n)[0]
+    order = present[np.argsort(first[present], kind="stable")]
+    sv = np.zeros(distinct, dtype=np.int64); np.add.at(sv, codes, v)
+    lo = np.full(distinct, 10**6, dtype=np.int64); np.minimum.at(lo, codes, d)
+    assert got.column("k").to_pylist() == (order * 3 + 5).tolist()
+    assert got.column("n").to_pylist() == np.bincount(codes, minlength=distinct)[order].tolist()
+    assert got.column("sv").to_pylist() == sv[order].tolist()
+    assert got.column("first_day").cast(pa.int32()).to_pylist() == lo[order].tolist()
