@@ -1581,9 +1581,8 @@ struct PartBlock {
 constexpr int PART_BLOCK = 1024;   // threads per workgroup: the windows' LDS leaves room for one or two workgroups per CU, so they are big
 template <typename KT>
 __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const PartBlock* __restrict__ blocks, const KT* __restrict__ key, const uint32_t* __restrict__ row_id,
-                                                                 PartAccSet accs, long long kmin, int wshift, const uint64_t* __restrict__ bits,
-                                                                 const uint64_t* __restrict__ prefix, unsigned long long* __restrict__ cells, int64_t G,
-                                                                 uint32_t* __restrict__ first_row, uint32_t* __restrict__ seen, uint32_t seen_mask) {
+                                                                 PartAccSet accs, long long kmin, int wshift, unsigned long long* __restrict__ cells_v,
+                                                                 int64_t vstride, uint64_t vrange, uint32_t* __restrict__ first_row_v) {
   extern __shared__ unsigned long long s_mem[];
   const int W = 1 << wshift;
   unsigned long long* s_cell = s_mem;                                   // [ncw][W]
@@ -1633,33 +1632,32 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
     }
   }
   __syncthreads();
-  // the workgroup's totals -> the global cells of the values it saw (group number = rank of the value in the key bitmap)
+  // the workgroup's totals -> the per-VALUE arrays (value index = key - kmin); which values exist, and their group numbers in
+  // first-seen order, are worked out afterwards from the first rows (k_presence_bits, k_values_to_groups)
   for (int x = threadIdx.x; x < W; x += PART_BLOCK) {
-    const uint32_t fr = s_first[x];
-    if (fr == 0xFFFFFFFFu) continue;
     const unsigned long long idx = base + (unsigned)x;
-    const int64_t g = (int64_t)(prefix[idx >> 6] + __popcll(bits[idx >> 6] & ((1ull << (idx & 63)) - 1ull)));
-    if (b.alone) {   // the window's only workgroup: its groups belong to nobody else — plain stores, consecutive values = consecutive groups
-      if (accs.track_first) {
-        first_row[g] = fr;
-        seen[g] = seen_mask;
-      }
-      for (int k = 0; k < accs.n; k++) {
-        const PartAcc& a = accs.a[k];
-        cells[(int64_t)a.cell * G + g] = s_cell[(size_t)a.lcell * W + x];
-        if (a.kind == ACC_SUM_I128) cells[(int64_t)(a.cell + 1) * G + g] = s_cell[(size_t)(a.lcell + 1) * W + x];
-      }
+    if (idx >= vrange) continue;
+    const uint32_t fr = s_first[x];
+    if (b.alone) {   // the window's only workgroup: its values belong to nobody else — plain, coalesced stores
+      if (accs.track_first) first_row_v[idx] = fr;
+      if (fr != 0xFFFFFFFFu)
+        for (int k = 0; k < accs.n; k++) {
+          const PartAcc& a = accs.a[k];
+          cells_v[(int64_t)a.cell * vstride + (int64_t)idx] = s_cell[(size_t)a.lcell * W + x];
+          if (a.kind == ACC_SUM_I128) cells_v[(int64_t)(a.cell + 1) * vstride + (int64_t)idx] = s_cell[(size_t)(a.lcell + 1) * W + x];
+        }
       continue;
     }
-    if (accs.track_first && fr < first_row[g]) atomicMin(first_row + g, fr);
+    if (fr == 0xFFFFFFFFu) continue;
+    if (accs.track_first && fr < first_row_v[idx]) atomicMin(first_row_v + idx, fr);
     for (int k = 0; k < accs.n; k++) {
       const PartAcc& a = accs.a[k];
       const unsigned long long v = s_cell[(size_t)a.lcell * W + x];
-      unsigned long long* c = cells + (int64_t)a.cell * G + g;
+      unsigned long long* c = cells_v + (int64_t)a.cell * vstride + (int64_t)idx;
       switch (a.kind) {
         case ACC_SUM_I128: {
           const unsigned long long old = atomicAdd(c, v);
-          atomicAdd(c + G, s_cell[(size_t)(a.lcell + 1) * W + x] + ((old + v) < old ? 1ull : 0ull));
+          atomicAdd(c + vstride, s_cell[(size_t)(a.lcell + 1) * W + x] + ((old + v) < old ? 1ull : 0ull));
           break;
         }
         case ACC_SUM_F64: atomicAdd(reinterpret_cast<double*>(c), __longlong_as_double((long long)v)); break;
@@ -1668,7 +1666,31 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
         default: atomicAdd(c, v); break;
       }
     }
-    if (accs.track_first && (seen_mask & ~seen[g])) atomicOr(seen + g, seen_mask);
+  }
+}
+
+// which values have a row: one bit per value of the key range, from the first rows the partitioned accumulation left
+__global__ __launch_bounds__(BLOCK) void k_presence_bits(const uint32_t* __restrict__ first_row_v, uint64_t vrange, int64_t n_words, uint64_t* __restrict__ bits) {
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < n_words; w += n_waves) {
+    const uint64_t v = ((uint64_t)w << 6) + lane_id();
+    const uint64_t m = ballot64(v < vrange && first_row_v[v] != 0xFFFFFFFFu);
+    if (lane_id() == 0) bits[w] = m;
+  }
+}
+// per-value totals -> per-group cells (group = rank of the value among the present ones), first rows and seen flags
+__global__ __launch_bounds__(BLOCK) void k_values_to_groups(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ prefix, const uint32_t* __restrict__ first_row_v,
+                                                           const unsigned long long* __restrict__ cells_v, int64_t vstride, uint64_t vrange, int ncw, int64_t G,
+                                                           uint32_t* __restrict__ first_row, unsigned long long* __restrict__ cells, uint32_t* __restrict__ seen,
+                                                           uint32_t seen_mask) {
+  for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < vrange; v += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t m = bits[v >> 6];
+    if (!((m >> (v & 63)) & 1ull)) continue;
+    const int64_t g = (int64_t)(prefix[v >> 6] + __popcll(m & ((1ull << (v & 63)) - 1ull)));
+    first_row[g] = first_row_v[v];
+    seen[g] = seen_mask;
+    for (int w = 0; w < ncw; w++) cells[(int64_t)w * G + g] = cells_v[(int64_t)w * vstride + (int64_t)v];
   }
 }
 
@@ -1687,13 +1709,17 @@ __global__ __launch_bounds__(BLOCK) void k_row_ids(int64_t n, uint32_t* __restri
 // applies when: no predicate, the key and every aggregate argument are columns as they stand without NULLs, the value range splits
 // into <= 64 windows that fit LDS, enough rows to pay for the move.  Fills the same cells / first_row / seen as dense_accumulate.
 // acc_col[u]: input column of accumulator u's argument (-1 = none: the counts; -2 = an expression), acc_val[u]: its ValKind.
+struct PartValues {     // what the partitioned accumulation leaves: totals and first rows per VALUE of the key range
+  BufPtr first_row_v;   // u32 [vstride], 0xFFFFFFFF = no row has this value
+  BufPtr cells_v;       // u64 [ncw][vstride]
+  int64_t vstride = 0;
+};
 static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, const dfgpu_expr* pred, const std::vector<DenseAcc>& accs, const std::vector<int>& acc_col,
-                                         const std::vector<int>& acc_val, int ncw, long long kmin, uint64_t range, const uint64_t* bits, const uint64_t* prefix,
-                                         unsigned long long* cells, int64_t G, uint32_t* first_row, uint32_t* seen) {
+                                         const std::vector<int>& acc_val, int ncw, long long kmin, uint64_t range, PartValues& out) {
   static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
   const int64_t n = in.nrows;
   const int64_t min_rows = env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23);
-  if (off || pred || n < min_rows || G < 4096 || accs.empty() || accs.size() > (size_t)PART_ACC_MAX || range == 0) return false;
+  if (off || pred || n < min_rows || range < 4096 || accs.empty() || accs.size() > (size_t)PART_ACC_MAX) return false;
   int kc = -1;
   if (!is_plain_column(A.group_nodes[0], A.group_roots[0], &kc) || kc < 0 || kc >= (int)in.cols.size()) return false;
   const Column& key = in.cols[(size_t)kc];
@@ -1720,7 +1746,6 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
   const int64_t n_windows = (int64_t)((range - 1) >> wshift) + 1;
   const size_t W = (size_t)1 << wshift;
   const int words_per_launch = (int)std::min<size_t>((LDS_BUDGET / W - 4) / 8, 64);
-  (void)ncw;
   // more than 64 KB of dynamic LDS has to be asked for, per kernel
   {
     const void* fn = nullptr;
@@ -1806,9 +1831,20 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
     }
     blocks.assign(rev.rbegin(), rev.rend());
   }
+  out.vstride = ((int64_t)range + 63) / 64 * 64;
+  out.first_row_v = make_buf((size_t)out.vstride * 4);
+  DFGPU_HIP(hipMemsetAsync(out.first_row_v->ptr, 0xFF, (size_t)out.vstride * 4, r.stream));   // (windows without a row have no workgroup)
+  out.cells_v = make_buf((size_t)std::max(1, ncw) * (size_t)out.vstride * 8);
+  bool any_chunked = false;
+  for (const PartBlock& b : blocks) any_chunked |= !b.alone;
+  if (any_chunked)   // chunks of one window merge through atomics: their cells start from the identities
+    for (size_t u = 0; u < accs.size(); u++) {
+      k_fill_u64<<<grid_for(out.vstride, BLOCK), BLOCK, 0, r.stream>>>(acc_identity(accs[u].kind), out.vstride, out.cells_v->as<unsigned long long>() + (int64_t)accs[u].cell * out.vstride);
+      if (accs[u].kind == ACC_SUM_I128)
+        k_fill_u64<<<grid_for(out.vstride, BLOCK), BLOCK, 0, r.stream>>>(0ull, out.vstride, out.cells_v->as<unsigned long long>() + (int64_t)(accs[u].cell + 1) * out.vstride);
+    }
   BufPtr d_blocks = make_buf(blocks.size() * sizeof(PartBlock) + 16);
   DFGPU_HIP(hipMemcpyAsync(d_blocks->ptr, blocks.data(), blocks.size() * sizeof(PartBlock), hipMemcpyHostToDevice, r.stream));
-  const uint32_t seen_mask = (uint32_t)((1ull << accs.size()) - 1ull);
   {
     int64_t bytes = 0;
     for (int w : widths) bytes += n * w;
@@ -1833,10 +1869,10 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
       }
       const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4);
       switch (kt) {
-        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
-        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
-        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
-        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, bits, prefix, cells, G, first_row, seen, seen_mask); break;
+        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, out.cells_v->as<unsigned long long>(), out.vstride, range, out.first_row_v->as<uint32_t>()); break;
+        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, out.cells_v->as<unsigned long long>(), out.vstride, range, out.first_row_v->as<uint32_t>()); break;
+        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, out.cells_v->as<unsigned long long>(), out.vstride, range, out.first_row_v->as<uint32_t>()); break;
+        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, out.cells_v->as<unsigned long long>(), out.vstride, range, out.first_row_v->as<uint32_t>()); break;
       }
       DFGPU_HIP(hipGetLastError());
       first_launch = false;
@@ -1979,30 +2015,47 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
   args.bits = bits->as<unsigned long long>();
   args.kmin = any_rows ? hmm[0] : 0;
-  if (any_rows) {
+  const int ncw = (int)cell_kind.size();
+  // medium cardinalities over plain columns: the rows are moved into LDS-sized key windows and accumulated there FIRST
+  // (dense_accumulate_partitioned: totals and first rows per value of the range); which values exist then falls out of the first
+  // rows, and the per-value totals are compacted into the groups' cells — no pass that sets bits, no accumulation by global atomics
+  PartValues pv;
+  const bool by_parts = any_rows && !null_group && dense_accumulate_partitioned(A, in, pred, accs, acc_col, acc_val, ncw, args.kmin, range, pv);
+  if (by_parts) {
+    k_presence_bits<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(pv.first_row_v->as<uint32_t>(), range, n_words, bits->as<uint64_t>());
+    DFGPU_HIP(hipGetLastError());
+  } else if (any_rows) {
     ProfileScope ps("agg_dense_setbits", key_bytes);
     jit_launch(f_setbits, grid, BLOCK, 0, &args, sizeof(args));
   }
   scan_mask_popcounts(bits->as<uint64_t>(), nullptr, n_words * 64, prefix->as<uint64_t>());
   const int64_t Gk = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
   const int64_t G = Gk + (null_group ? 1 : 0);
-  const int ncw = (int)cell_kind.size();
   BufPtr first_row = make_buf((size_t)std::max<int64_t>(G, 1) * 4);
-  DFGPU_HIP(hipMemsetAsync(first_row->ptr, 0xFF, (size_t)std::max<int64_t>(G, 1) * 4, r.stream));
-  BufPtr seen = make_zero_buf((size_t)std::max<int64_t>(G, 1) * 4);
+  BufPtr seen = by_parts ? make_buf((size_t)std::max<int64_t>(G, 1) * 4) : make_zero_buf((size_t)std::max<int64_t>(G, 1) * 4);
   BufPtr cells = make_buf((size_t)std::max(1, ncw) * std::max<int64_t>(G, 1) * 8);
-  for (int w = 0; w < ncw && G; w++)
-    k_fill_u64<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(acc_identity(cell_kind[(size_t)w]), G, cells->as<unsigned long long>() + (int64_t)w * G);
   args.prefix = prefix->as<uint64_t>();
   args.first_row = first_row->as<uint32_t>();
   args.cells = cells->as<unsigned long long>();
   args.seen = seen->as<uint32_t>();
   args.G = G;
   args.null_group = null_group ? Gk : -1;
-  if (G && !(null_group == false && dense_accumulate_partitioned(A, in, pred, accs, acc_col, acc_val, ncw, args.kmin, range, bits->as<uint64_t>(), prefix->as<uint64_t>(),
-                                                                cells->as<unsigned long long>(), G, first_row->as<uint32_t>(), seen->as<uint32_t>()))) {
-    ProfileScope ps("agg_dense_accumulate", n * cp.input_bytes_per_row);
-    jit_launch(f_acc, grid, BLOCK, 0, &args, sizeof(args));
+  if (by_parts) {
+    if (G) {
+      ProfileScope ps("agg_dense_values_to_groups", (int64_t)range * (4 + 8 * ncw) + G * (8 + 8 * ncw));
+      k_values_to_groups<<<grid_for((int64_t)range, BLOCK), BLOCK, 0, r.stream>>>(bits->as<uint64_t>(), prefix->as<uint64_t>(), pv.first_row_v->as<uint32_t>(),
+                                                                                 pv.cells_v->as<unsigned long long>(), pv.vstride, range, ncw, G, first_row->as<uint32_t>(),
+                                                                                 cells->as<unsigned long long>(), seen->as<uint32_t>(), (uint32_t)((1ull << accs.size()) - 1ull));
+      DFGPU_HIP(hipGetLastError());
+    }
+  } else {
+    DFGPU_HIP(hipMemsetAsync(first_row->ptr, 0xFF, (size_t)std::max<int64_t>(G, 1) * 4, r.stream));
+    for (int w = 0; w < ncw && G; w++)
+      k_fill_u64<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(acc_identity(cell_kind[(size_t)w]), G, cells->as<unsigned long long>() + (int64_t)w * G);
+    if (G) {
+      ProfileScope ps("agg_dense_accumulate", n * cp.input_bytes_per_row);
+      jit_launch(f_acc, grid, BLOCK, 0, &args, sizeof(args));
+    }
   }
   // ---- first-seen order (group_values/mod.rs:88-92), keys rebuilt from the bit positions
   const int64_t row_words = (n + 63) / 64;
