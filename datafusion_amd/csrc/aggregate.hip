@@ -1599,36 +1599,19 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
   __syncthreads();
   const unsigned long long base = (unsigned long long)b.part << wshift;
   for (int64_t i = b.begin + threadIdx.x; i < b.end; i += PART_BLOCK) {
-    const int x = (int)((unsigned long long)((long long)key[i] - kmin) - base);   // value index inside the partition's window
-    atomicMin(&s_first[x], row_id[i]);
+    const int x = (int)((unsigned long long)((long long)key[i] - kmin) - base);   // value index inside the window
+    atomicMin(&s_first[x], row_id ? row_id[i] : 0u);
     for (int k = 0; k < accs.n; k++) {
       const PartAcc& a = accs.a[k];
       unsigned long long* c = s_cell + (size_t)a.lcell * W + x;
-      switch (a.kind) {
-        case ACC_COUNT:
-        case ACC_COUNT_STAR: atomicAdd(c, 1ull); break;
-        case ACC_SUM_I128: {
-          const unsigned long long* p = (const unsigned long long*)a.data + 2 * i;
-          const unsigned long long lo = p[0], hi = p[1];
-          const unsigned long long old = atomicAdd(c, lo);
-          atomicAdd(c + W, hi + ((old + lo) < old ? 1ull : 0ull));
-          break;
-        }
-        case ACC_SUM_F64: atomicAdd(reinterpret_cast<double*>(c), ((const double*)a.data)[i]); break;
-        default: {
-          long long v;
-          switch (a.val) {
-            case VAL_I32: v = ((const int32_t*)a.data)[i]; break;
-            case VAL_U32: v = ((const uint32_t*)a.data)[i]; break;
-            case VAL_U8: v = ((const uint8_t*)a.data)[i]; break;
-            case VAL_I128: v = ((const long long*)a.data)[2 * i]; break;   // MIN / MAX over decimals that fit 64 bits (plan_for)
-            default: v = ((const long long*)a.data)[i]; break;
-          }
-          if (a.kind == ACC_SUM_I64) atomicAdd(c, (unsigned long long)v);
-          else if (a.kind == ACC_MIN_I64) atomicMin(reinterpret_cast<long long*>(c), v);
-          else atomicMax(reinterpret_cast<long long*>(c), v);
-        }
+      uint64_t lo = 0, hi = 0;
+      if (a.data && a.kind != ACC_COUNT) {
+        AccDesc d{};
+        d.values = a.data;
+        d.val = a.val;
+        load_value(d, i, lo, hi);
       }
+      accumulate_cell(a.kind, c, c + W, lo, hi);   // (LDS cells)
     }
   }
   __syncthreads();
@@ -1714,23 +1697,28 @@ struct PartValues {     // what the partitioned accumulation leaves: totals and 
   BufPtr cells_v;       // u64 [ncw][vstride]
   int64_t vstride = 0;
 };
-static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, const dfgpu_expr* pred, const std::vector<DenseAcc>& accs, const std::vector<int>& acc_col,
-                                         const std::vector<int>& acc_val, int ncw, long long kmin, uint64_t range, PartValues& out) {
+static int part_val_width(int val) {
+  switch (val) {
+    case VAL_I32: case VAL_U32: case VAL_I32_TO_F64: return 4;
+    case VAL_U8: return 1;
+    case VAL_I128: return 16;
+    default: return 8;
+  }
+}
+// The core: `key` (type kt, no NULLs) takes values in [kmin, kmin + range); accumulator u reads its argument from all[u].data (a
+// source column without NULLs, null for the counts) and owns the cell words all[u].cell (.. + 1 for a 128-bit sum) of `ncw`.
+// Moves key, arguments (and row numbers, when first rows are wanted) into window order and leaves totals per value in `out`.
+static bool partitioned_accumulate(const void* key, int kt, int64_t n, long long kmin, uint64_t range, std::vector<PartAcc> all, int ncw, bool want_first_rows,
+                                   PartValues& out) {
   static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
-  const int64_t n = in.nrows;
   const int64_t min_rows = env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23);
-  if (off || pred || n < min_rows || range < 4096 || accs.empty() || accs.size() > (size_t)PART_ACC_MAX) return false;
-  int kc = -1;
-  if (!is_plain_column(A.group_nodes[0], A.group_roots[0], &kc) || kc < 0 || kc >= (int)in.cols.size()) return false;
-  const Column& key = in.cols[(size_t)kc];
-  if (key.validity) return false;
-  const int kt = key.field.type;
+  if (off || n < min_rows || range < 4096 || all.empty() || all.size() > (size_t)PART_ACC_MAX) return false;
   if (!(kt == DFGPU_INT32 || kt == DFGPU_DATE32 || kt == DFGPU_INT64 || kt == DFGPU_UINT32 || kt == DFGPU_UINT8)) return false;
   // windows of 2^wshift values whose first rows (4 B) and at least one accumulator (8 B, 16 for a 128-bit sum) fit the LDS budget:
   // at most 64 of them after ONE move of the rows, at most 4096 after two (low 6 bits of the window number first, then the high 6)
   constexpr size_t LDS_BUDGET = (size_t)128 << 10;   // of the CU's 160 KB: one workgroup per CU at the widest windows
   int min_words = 1;
-  for (const DenseAcc& a : accs)
+  for (const PartAcc& a : all)
     if (a.kind == ACC_SUM_I128) min_words = 2;
   int wcap = 0;
   while (((size_t)2 << wcap) * (4 + 8 * (size_t)min_words) <= LDS_BUDGET) wcap++;
@@ -1760,52 +1748,46 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
       if (W * 12 > ((size_t)64 << 10)) return false;
     }
   }
-  std::vector<PartAcc> all(accs.size());
+  Runtime& r = rt();
+  // what moves: the key, every distinct argument column, the row numbers
   std::vector<const void*> src;
   std::vector<int> widths;
-  src.push_back(key.ptr());
+  src.push_back(key);
   widths.push_back(type_width(kt));
-  std::vector<int> moved_of_col;   // input column -> index in `src`
-  moved_of_col.assign(in.cols.size(), -1);
-  std::vector<int> acc_src(accs.size(), -1);
-  for (size_t u = 0; u < accs.size(); u++) {
-    const int kind = accs[u].kind;
-    all[u] = PartAcc{kind, accs[u].cell, 0, acc_val[u], nullptr};
-    if (kind == ACC_COUNT_STAR) continue;
-    const int c = acc_col[u];
-    if (c < 0 || c >= (int)in.cols.size()) return false;   // an expression: the specialised kernel evaluates it, this path moves columns
-    const Column& col = in.cols[(size_t)c];
-    if (col.validity || col.dict) return false;
-    if (kind == ACC_COUNT) continue;                        // non-NULL argument: counts rows
-    const int v = acc_val[u];
-    const bool ok = (kind == ACC_SUM_I128 && v == VAL_I128) || (kind == ACC_SUM_F64 && v == VAL_F64) ||
-                    ((kind == ACC_SUM_I64 || kind == ACC_MIN_I64 || kind == ACC_MAX_I64) && (v == VAL_I32 || v == VAL_I64 || v == VAL_U32 || v == VAL_U8)) ||
-                    ((kind == ACC_MIN_I64 || kind == ACC_MAX_I64) && v == VAL_I128);
-    if (!ok) return false;
-    if (moved_of_col[(size_t)c] < 0) {
-      moved_of_col[(size_t)c] = (int)src.size();
-      src.push_back(col.ptr());
-      widths.push_back(type_width(col.field.type));
+  std::vector<int> acc_src(all.size(), -1);
+  for (size_t u = 0; u < all.size(); u++) {
+    if (!all[u].data || all[u].kind == ACC_COUNT || all[u].kind == ACC_COUNT_STAR) {
+      all[u].data = nullptr;
+      continue;
     }
-    acc_src[u] = moved_of_col[(size_t)c];
+    for (size_t q = 1; q < src.size(); q++)
+      if (src[q] == all[u].data) acc_src[u] = (int)q;
+    if (acc_src[u] < 0) {
+      acc_src[u] = (int)src.size();
+      src.push_back(all[u].data);
+      widths.push_back(part_val_width(all[u].val));
+    }
   }
-  Runtime& r = rt();
-  BufPtr ids = make_buf((size_t)n * 4);
-  k_row_ids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(n, ids->as<uint32_t>());
-  const int ids_at = (int)src.size();
-  src.push_back(ids->ptr);
-  widths.push_back(4);
-  RangePartition rp = partition_by_key_range(key.ptr(), kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths);
+  BufPtr ids;
+  int ids_at = -1;
+  if (want_first_rows) {
+    ids = make_buf((size_t)n * 4);
+    k_row_ids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(n, ids->as<uint32_t>());
+    ids_at = (int)src.size();
+    src.push_back(ids->ptr);
+    widths.push_back(4);
+  }
+  RangePartition rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths);
   if (levels == 2) {   // stable second move by the high digit: the rows end up in window order
     std::vector<const void*> src2;
     for (const BufPtr& b : rp.cols) src2.push_back(b->ptr);
     RangePartition rp2 = partition_by_key_range(rp.cols[0]->ptr, kt, n, kmin, wshift + 6, 63u, (int)((n_windows + 63) / 64), src2, widths);
     rp = std::move(rp2);
   }
-  for (size_t u = 0; u < accs.size(); u++)
+  for (size_t u = 0; u < all.size(); u++)
     if (acc_src[u] >= 0) all[u].data = rp.cols[(size_t)acc_src[u]]->ptr;
-  // where every window's rows begin (read off the moved keys), then the workgroups: a window's rows in chunks (at most ~16 per
-  // window at one level: every chunk ends with one global atomic per value it saw)
+  // where every window's rows begin (read off the moved keys), then the workgroups: one per window while its rows are few (its
+  // totals then leave as plain stores); else chunks, merged by atomics
   BufPtr d_begins = make_buf((size_t)n_windows * 8);
   DFGPU_HIP(hipMemsetAsync(d_begins->ptr, 0xFF, (size_t)n_windows * 8, r.stream));
   switch (kt) {
@@ -1823,7 +1805,6 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
     for (int64_t w = n_windows - 1; w >= 0; w--) {
       const int64_t b0 = begins[(size_t)w];
       if (b0 < 0) continue;
-      // one workgroup per window while its rows are few (its totals then leave as plain stores); else chunks, merged by atomics
       const int64_t rows = end - b0;
       const int64_t chunk = rows <= ((int64_t)1 << 18) ? rows : std::max<int64_t>((int64_t)1 << 17, (rows + 15) / 16);
       for (int64_t at = b0; at < end; at += chunk) rev.push_back(PartBlock{at, std::min(at + chunk, end), (int32_t)w, chunk >= rows ? 1 : 0});
@@ -1838,10 +1819,10 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
   bool any_chunked = false;
   for (const PartBlock& b : blocks) any_chunked |= !b.alone;
   if (any_chunked)   // chunks of one window merge through atomics: their cells start from the identities
-    for (size_t u = 0; u < accs.size(); u++) {
-      k_fill_u64<<<grid_for(out.vstride, BLOCK), BLOCK, 0, r.stream>>>(acc_identity(accs[u].kind), out.vstride, out.cells_v->as<unsigned long long>() + (int64_t)accs[u].cell * out.vstride);
-      if (accs[u].kind == ACC_SUM_I128)
-        k_fill_u64<<<grid_for(out.vstride, BLOCK), BLOCK, 0, r.stream>>>(0ull, out.vstride, out.cells_v->as<unsigned long long>() + (int64_t)(accs[u].cell + 1) * out.vstride);
+    for (size_t u = 0; u < all.size(); u++) {
+      k_fill_u64<<<grid_for(out.vstride, BLOCK), BLOCK, 0, r.stream>>>(acc_identity(all[u].kind), out.vstride, out.cells_v->as<unsigned long long>() + (int64_t)all[u].cell * out.vstride);
+      if (all[u].kind == ACC_SUM_I128)
+        k_fill_u64<<<grid_for(out.vstride, BLOCK), BLOCK, 0, r.stream>>>(0ull, out.vstride, out.cells_v->as<unsigned long long>() + (int64_t)(all[u].cell + 1) * out.vstride);
     }
   BufPtr d_blocks = make_buf(blocks.size() * sizeof(PartBlock) + 16);
   DFGPU_HIP(hipMemcpyAsync(d_blocks->ptr, blocks.data(), blocks.size() * sizeof(PartBlock), hipMemcpyHostToDevice, r.stream));
@@ -1850,9 +1831,11 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
     for (int w : widths) bytes += n * w;
     ProfileScope psc("agg_dense_accumulate_partitioned", bytes);
     const PartBlock* db = d_blocks->as<PartBlock>();
-    const uint32_t* rid = rp.cols[(size_t)ids_at]->as<uint32_t>();
+    const uint32_t* rid = ids_at >= 0 ? rp.cols[(size_t)ids_at]->as<uint32_t>() : nullptr;
     const void* mk = rp.cols[0]->ptr;
     const int nb = (int)blocks.size();
+    unsigned long long* cv = out.cells_v->as<unsigned long long>();
+    uint32_t* fv = out.first_row_v->as<uint32_t>();
     size_t u = 0;
     bool first_launch = true;
     while (u < all.size()) {
@@ -1869,16 +1852,109 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
       }
       const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4);
       switch (kt) {
-        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, out.cells_v->as<unsigned long long>(), out.vstride, range, out.first_row_v->as<uint32_t>()); break;
-        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, out.cells_v->as<unsigned long long>(), out.vstride, range, out.first_row_v->as<uint32_t>()); break;
-        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, out.cells_v->as<unsigned long long>(), out.vstride, range, out.first_row_v->as<uint32_t>()); break;
-        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, out.cells_v->as<unsigned long long>(), out.vstride, range, out.first_row_v->as<uint32_t>()); break;
+        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv); break;
+        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv); break;
+        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv); break;
+        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv); break;
       }
       DFGPU_HIP(hipGetLastError());
       first_launch = false;
     }
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));   // `blocks` and the moved columns are locals
+  return true;
+}
+// the dense-key node's face of it: applies when there is no predicate and the key and every aggregate argument are columns as they
+// stand, without NULLs.  acc_col[u]: input column of accumulator u's argument (-1 = none: the counts; -2 = an expression),
+// acc_val[u]: its ValKind.
+static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, const dfgpu_expr* pred, const std::vector<DenseAcc>& accs, const std::vector<int>& acc_col,
+                                         const std::vector<int>& acc_val, int ncw, long long kmin, uint64_t range, PartValues& out) {
+  if (pred) return false;
+  int kc = -1;
+  if (!is_plain_column(A.group_nodes[0], A.group_roots[0], &kc) || kc < 0 || kc >= (int)in.cols.size()) return false;
+  const Column& key = in.cols[(size_t)kc];
+  if (key.validity) return false;
+  std::vector<PartAcc> all(accs.size());
+  for (size_t u = 0; u < accs.size(); u++) {
+    const int kind = accs[u].kind;
+    all[u] = PartAcc{kind, accs[u].cell, 0, acc_val[u], nullptr};
+    if (kind == ACC_COUNT_STAR) continue;
+    const int c = acc_col[u];
+    if (c < 0 || c >= (int)in.cols.size()) return false;   // an expression: the specialised kernel evaluates it, this path moves columns
+    const Column& col = in.cols[(size_t)c];
+    if (col.validity || col.dict) return false;
+    all[u].data = col.ptr();
+  }
+  return partitioned_accumulate(key.ptr(), key.field.type, in.nrows, kmin, range, std::move(all), ncw, /*want_first_rows=*/true, out);
+}
+
+// ---- the same for groups that were interned by hash (agg_update_unfused: evaluated key / argument columns, Final-mode merges of
+// partial states): the key that is moved is the row's group number, the per-value totals ARE per-group totals
+__global__ __launch_bounds__(BLOCK) void k_row_gids(InternCtx c, const uint32_t* __restrict__ slot_gid, int64_t row_offset, int64_t n, uint32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = lookup_gid(c, slot_gid, row_offset + i);
+}
+struct MergeAcc {
+  unsigned long long* acc_lo;
+  unsigned long long* acc_hi;
+  uint32_t* seen;
+  int kind, cell;
+};
+struct MergeSet {
+  MergeAcc a[MAX_AGGS];
+  int n;
+};
+// per-group totals of this batch -> the node's accumulators (which may hold earlier batches); one thread per group, no atomics
+__global__ __launch_bounds__(BLOCK) void k_merge_group_totals(const uint32_t* __restrict__ first_row_v, const unsigned long long* __restrict__ cells_v, int64_t vstride, int64_t G,
+                                                             MergeSet m) {
+  for (int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x; g < G; g += (int64_t)gridDim.x * BLOCK) {
+    if (first_row_v[g] == 0xFFFFFFFFu) continue;   // no row of this batch in the group
+    for (int k = 0; k < m.n; k++) {
+      const MergeAcc& a = m.a[k];
+      const unsigned long long v = cells_v[(int64_t)a.cell * vstride + g];
+      switch (a.kind) {
+        case ACC_SUM_I128: {
+          const unsigned long long hi = cells_v[(int64_t)(a.cell + 1) * vstride + g];
+          const unsigned long long old = a.acc_lo[g];
+          a.acc_lo[g] = old + v;
+          a.acc_hi[g] += hi + ((old + v) < old ? 1ull : 0ull);
+          break;
+        }
+        case ACC_SUM_F64: a.acc_lo[g] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)a.acc_lo[g]) + __longlong_as_double((long long)v)); break;
+        case ACC_MIN_I64: if ((long long)v < (long long)a.acc_lo[g]) a.acc_lo[g] = v; break;
+        case ACC_MAX_I64: if ((long long)v > (long long)a.acc_lo[g]) a.acc_lo[g] = v; break;
+        default: a.acc_lo[g] += v; break;   // SUM_I64 and the counts
+      }
+      if (a.seen) a.seen[g] = 1u;
+    }
+  }
+}
+static bool general_accumulate_partitioned(const InternCtx& ictx, const uint32_t* slot_gid, int64_t G0, int64_t n, const AccSet& accs, int64_t G1) {
+  if (accs.n <= 0 || accs.n > PART_ACC_MAX || G1 >= 0xFFFFFFFFll) return false;
+  std::vector<PartAcc> all((size_t)accs.n);
+  MergeSet m{};
+  int ncw = 0;
+  for (int k = 0; k < accs.n; k++) {
+    const AccDesc& d = accs.a[k];
+    if (d.valid && d.kind != ACC_COUNT_STAR) return false;   // NULL arguments: the row-at-a-time kernels
+    all[(size_t)k] = PartAcc{d.kind, ncw, 0, d.val, d.kind == ACC_COUNT_STAR ? nullptr : d.values};
+    m.a[m.n++] = MergeAcc{d.acc_lo, d.acc_hi, d.seen, d.kind, ncw};
+    ncw += d.kind == ACC_SUM_I128 ? 2 : 1;
+  }
+  // cheap refusals first (the row -> group pass below is a random lookup per row)
+  static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
+  if (off || n < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || G1 < 4096) return false;
+  Runtime& r = rt();
+  BufPtr gids = make_buf((size_t)n * 4);
+  {
+    ProfileScope ps("agg_row_gids", n * 4);
+    k_row_gids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(ictx, slot_gid, G0, n, gids->as<uint32_t>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  PartValues pv;
+  if (!partitioned_accumulate(gids->ptr, DFGPU_UINT32, n, 0, (uint64_t)G1, std::move(all), ncw, /*want_first_rows=*/false, pv)) return false;
+  k_merge_group_totals<<<grid_for(G1, BLOCK), BLOCK, 0, r.stream>>>(pv.first_row_v->as<uint32_t>(), pv.cells_v->as<unsigned long long>(), pv.vstride, G1, m);
+  DFGPU_HIP(hipGetLastError());
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
   return true;
 }
 
@@ -3148,6 +3224,8 @@ static void agg_update_unfused(Aggregate& A, const Table& in) {
     while (p2 * 2 <= nrep) p2 *= 2;
     ProfileScope ps("agg_accumulate_lds", bytes);
     k_accumulate_lds<<<grid_for(n, BLOCK * 8), BLOCK, 0, r.stream>>>(ictx, sg, ngk > 0, G0, n, accs, (int)G1, p2);
+  } else if (ngk > 0 && general_accumulate_partitioned(ictx, sg, G0, n, accs, G1)) {
+    // (rows moved into LDS-sized windows of group numbers, accumulated there, merged per group)
   } else {
     ProfileScope ps("agg_accumulate_global", bytes);
     k_accumulate_global<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(ictx, sg, ngk > 0, G0, n, accs);

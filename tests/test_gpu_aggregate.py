@@ -433,3 +433,44 @@ def test_medium_cardinality_group_by_over_a_wide_key_range_moves_the_rows_twice(
     assert got.column("n").to_pylist() == np.bincount(codes, minlength=distinct)[order].tolist()
     assert got.column("sv").to_pylist() == sv[order].tolist()
     assert got.column("first_day").cast(pa.int32()).to_pylist() == lo[order].tolist()
+
+
+@pytest.mark.gpu
+def test_final_merge_of_many_partial_states_moves_rows_by_group_number():
+    """Final over millions of partial-state rows with a two-column key (hash-interned groups): every row's group number is looked up
+    once, the rows are moved into LDS-sized windows of group numbers, accumulated there and merged per group — SUM / AVG / COUNT / MIN
+    states of 40 K groups come out as the sums / minima of the partial rows"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    rng = np.random.default_rng(31)
+    n, g1, g2 = 9_000_000, 200, 200
+    k1 = rng.integers(0, g1, n)
+    k2 = rng.integers(0, g2, n).astype(np.int32)
+    s = rng.integers(-10**6, 10**6, n)                 # SUM(int64) state
+    c = rng.integers(0, 50, n).astype(np.uint64)       # COUNT state
+    mn = rng.integers(-10**9, 10**9, n)                # MIN(int64) state
+    ac = rng.integers(1, 9, n).astype(np.uint64)       # AVG(float64) state: count, sum
+    asum = rng.random(n) * 10.0
+    t = pa.table({"k1": pa.array(k1), "k2": pa.array(k2), "s[sum]": pa.array(s), "c[count]": pa.array(c.astype(np.int64)), "m[value]": pa.array(mn),
+                  "a[count]": pa.array(ac), "a[sum]": pa.array(asum)})
+    gb = [(col("k1"), "k1"), (col("k2"), "k2")]
+    aggs = [("sum", col("v"), "s"), ("count", col("v"), "c"), ("min", col("v"), "m"), ("avg", col("f"), "a")]
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = gpu_agg(t, gb, aggs, "Final")
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert "agg_dense_accumulate_partitioned" in stats and "agg_row_gids" in stats and "agg_accumulate_global" not in stats, sorted(stats)
+    gid = k1 * g2 + k2
+    ss = np.zeros(g1 * g2, dtype=np.int64); np.add.at(ss, gid, s)
+    cc = np.bincount(gid, weights=c.astype(np.float64), minlength=g1 * g2).astype(np.int64)
+    mm = np.full(g1 * g2, 2**62, dtype=np.int64); np.minimum.at(mm, gid, mn)
+    an = np.bincount(gid, weights=ac.astype(np.float64), minlength=g1 * g2)
+    asm = np.bincount(gid, weights=asum, minlength=g1 * g2)
+    rows = {(a, b): (x, y, z, w) for a, b, x, y, z, w in zip(got.column("k1").to_pylist(), got.column("k2").to_pylist(), got.column("s").to_pylist(),
+                                                        got.column("c").to_pylist(), got.column("m").to_pylist(), got.column("a").to_pylist())}
+    assert len(rows) == got.num_rows == int((np.bincount(gid, minlength=g1 * g2) > 0).sum())
+    for (a, b), (x, y, z, w) in list(rows.items())[::37]:
+        g = a * g2 + b
+        assert (x, y, z) == (int(ss[g]), int(cc[g]), int(mm[g]))
+        assert abs(w - asm[g] / an[g]) <= 1e-9 * abs(asm[g] / an[g])
