@@ -1559,7 +1559,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_keys(const uint64_t* __restrict
 // stand, the rows are first moved into <= 64 groups by the RANGE their key falls in (partition.hip: count + one stable scatter at
 // copy rate); a group's distinct values then fit one workgroup's LDS, where the rows are accumulated with LDS atomics, and only
 // the per-workgroup totals go to the global cells (groups x workgroups-per-partition atomics instead of rows).
-constexpr int PART_ACC_MAX = 8;
+constexpr int PART_ACC_MAX = 16;
 struct PartAcc {
   int kind;          // AccKind
   int cell;          // first cell word among the node's global cells
@@ -1868,22 +1868,43 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n, long long
 // stand, without NULLs.  acc_col[u]: input column of accumulator u's argument (-1 = none: the counts; -2 = an expression),
 // acc_val[u]: its ValKind.
 static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, const dfgpu_expr* pred, const std::vector<DenseAcc>& accs, const std::vector<int>& acc_col,
-                                         const std::vector<int>& acc_val, int ncw, long long kmin, uint64_t range, PartValues& out) {
+                                         const std::vector<int>& acc_val, const std::vector<int>& acc_agg, int ncw, long long kmin, uint64_t range, PartValues& out) {
   if (pred) return false;
+  // cheap refusals before any argument expression is evaluated
+  if (in.nrows < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || range < 4096) return false;
   int kc = -1;
   if (!is_plain_column(A.group_nodes[0], A.group_roots[0], &kc) || kc < 0 || kc >= (int)in.cols.size()) return false;
   const Column& key = in.cols[(size_t)kc];
   if (key.validity) return false;
   std::vector<PartAcc> all(accs.size());
+  std::vector<Column> evaluated;   // argument expressions evaluated for this call (alive until the rows have been moved)
   for (size_t u = 0; u < accs.size(); u++) {
     const int kind = accs[u].kind;
     all[u] = PartAcc{kind, accs[u].cell, 0, acc_val[u], nullptr};
     if (kind == ACC_COUNT_STAR) continue;
     const int c = acc_col[u];
-    if (c < 0 || c >= (int)in.cols.size()) return false;   // an expression: the specialised kernel evaluates it, this path moves columns
-    const Column& col = in.cols[(size_t)c];
-    if (col.validity || col.dict) return false;
-    all[u].data = col.ptr();
+    if (c >= 0 && c < (int)in.cols.size()) {
+      const Column& col = in.cols[(size_t)c];
+      if (col.validity || col.dict) return false;
+      all[u].data = col.ptr();
+      continue;
+    }
+    // an expression (Q15's l_extendedprice * (1 - l_discount)): evaluated column-at-a-time first — a streaming pass, where the
+    // specialised kernel would pay a global atomic per row for it
+    const AggState& a = A.aggs[(size_t)acc_agg[u]];
+    if (!a.has_arg) return false;
+    int found = -1;
+    for (size_t q = 0; q < u; q++)
+      if (acc_agg[q] == acc_agg[u] && acc_col[q] == c && all[q].data) found = (int)q;   // (AVG: sum and count share the argument)
+    if (found >= 0) {
+      all[u].data = all[(size_t)found].data;
+      continue;
+    }
+    dfgpu_expr e{a.nodes.data(), (int)a.nodes.size(), a.root};
+    Column v = datum_to_column(evaluate(e, in), in.nrows, a.name);
+    if (v.validity || v.dict || v.field.type == DFGPU_BOOL || v.field.type == DFGPU_UTF8) return false;
+    all[u].data = v.ptr();
+    evaluated.push_back(std::move(v));
   }
   return partitioned_accumulate(key.ptr(), key.field.type, in.nrows, kmin, range, std::move(all), ncw, /*want_first_rows=*/true, out);
 }
@@ -1990,7 +2011,7 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   struct Ent { int agg; bool is_avg_count; int kind; int cell; int seen_bit; };
   std::vector<Ent> entries;
   std::vector<DenseAcc> accs;
-  std::vector<int> cell_kind, acc_col, acc_val;   // per accumulator: its argument's input column (-1 none, -2 an expression) and ValKind
+  std::vector<int> cell_kind, acc_col, acc_val, acc_agg;   // per accumulator: its argument's input column (-1 none, -2 an expression), ValKind, aggregate
   for (size_t k = 0; k < A.aggs.size(); k++) {
     AggState& a = A.aggs[k];
     dfgpu_field t = a.typed ? a.in_type : (a.has_arg ? cp.out_types[(size_t)arg_out[k]] : fld(DFGPU_INT64));
@@ -2005,6 +2026,7 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
       accs.push_back({kd, val, (int)cell_kind.size()});
       acc_col.push_back(acc_column);
       acc_val.push_back(pl.val);
+      acc_agg.push_back((int)k);
       cell_kind.push_back(kd == ACC_SUM_I128 ? ACC_SUM_I64 : kd);
       if (kd == ACC_SUM_I128) cell_kind.push_back(ACC_SUM_I64);
       return (int)accs.size() - 1;
@@ -2096,7 +2118,7 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   // (dense_accumulate_partitioned: totals and first rows per value of the range); which values exist then falls out of the first
   // rows, and the per-value totals are compacted into the groups' cells — no pass that sets bits, no accumulation by global atomics
   PartValues pv;
-  const bool by_parts = any_rows && !null_group && dense_accumulate_partitioned(A, in, pred, accs, acc_col, acc_val, ncw, args.kmin, range, pv);
+  const bool by_parts = any_rows && !null_group && dense_accumulate_partitioned(A, in, pred, accs, acc_col, acc_val, acc_agg, ncw, args.kmin, range, pv);
   if (by_parts) {
     k_presence_bits<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(pv.first_row_v->as<uint32_t>(), range, n_words, bits->as<uint64_t>());
     DFGPU_HIP(hipGetLastError());

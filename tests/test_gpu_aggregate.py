@@ -375,7 +375,8 @@ def test_medium_cardinality_group_by_partitions_rows_then_accumulates_in_lds(key
     ops.profile_enable(True)
     ops.profile_reset()
     got = ops.aggregate(t, [(col("k"), "k")], [("sum", col("v"), "sv"), ("count", None, "n"), ("count", col("w"), "nw"), ("min", col("w"), "lo"), ("max", col("v"), "hi"),
-                                              ("sum", col("d"), "sd"), ("avg", col("d"), "ad"), ("sum", col("f"), "sf")], "Single").to_arrow()
+                                              ("sum", col("d"), "sd"), ("avg", col("d"), "ad"), ("sum", col("f"), "sf"),
+                                              ("sum", col("v") + col("v"), "s2"), ("avg", col("w"), "aw")], "Single").to_arrow()      # an expression; AVG(Int32) sums doubles
     stats = ops.profile_stats()
     ops.profile_enable(False)
     assert "agg_dense_accumulate_partitioned" in stats and "agg_dense_accumulate" not in stats, sorted(stats)
@@ -400,6 +401,9 @@ def test_medium_cardinality_group_by_partitions_rows_then_accumulates_in_lds(key
         return q if s >= 0 else -q
     assert [int(x.scaleb(6)) for x in got.column("ad").to_pylist()] == [avg(sd[c], cnt[c]) for c in order]
     assert np.allclose(got.column("sf").to_numpy(), sf[order], rtol=1e-9)
+    assert got.column("s2").to_pylist() == (2 * sv[order]).tolist()
+    sw = np.zeros(distinct, dtype=np.int64); np.add.at(sw, codes, i32)
+    assert np.allclose(got.column("aw").to_numpy(), sw[order] / cnt[order], rtol=1e-12)
 
 
 @pytest.mark.gpu
