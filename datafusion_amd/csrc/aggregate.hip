@@ -1777,11 +1777,11 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n, long long
     src.push_back(ids->ptr);
     widths.push_back(4);
   }
-  RangePartition rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths);
+  RangePartition rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths, /*want_bounds=*/false);
   if (levels == 2) {   // stable second move by the high digit: the rows end up in window order
     std::vector<const void*> src2;
     for (const BufPtr& b : rp.cols) src2.push_back(b->ptr);
-    RangePartition rp2 = partition_by_key_range(rp.cols[0]->ptr, kt, n, kmin, wshift + 6, 63u, (int)((n_windows + 63) / 64), src2, widths);
+    RangePartition rp2 = partition_by_key_range(rp.cols[0]->ptr, kt, n, kmin, wshift + 6, 63u, (int)((n_windows + 63) / 64), src2, widths, /*want_bounds=*/false);
     rp = std::move(rp2);
   }
   for (size_t u = 0; u < all.size(); u++)

@@ -406,7 +406,7 @@ struct RangePartition {
   std::vector<uint64_t> bounds;
 };
 RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, long long kmin, int shift, unsigned mask, int nparts,
-                                      const std::vector<const void*>& src, const std::vector<int>& widths);
+                                      const std::vector<const void*>& src, const std::vector<int>& widths, bool want_bounds = true);
 
 // ----------------------------------------------------------------- LDS radix join (radix_join.hip)
 struct RadixTable;

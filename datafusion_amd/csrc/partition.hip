@@ -306,7 +306,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_count_range(const T* __restrict_
 }
 
 RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, long long kmin, int shift, unsigned mask, int nparts,
-                                      const std::vector<const void*>& src, const std::vector<int>& widths) {
+                                      const std::vector<const void*>& src, const std::vector<int>& widths, bool want_bounds) {
   Runtime& r = rt();
   DFGPU_CHECK(nparts >= 1 && nparts <= MAX_PARTS && src.size() == widths.size() && n > 0, "partition_by_key_range: bad arguments");
   const int64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
@@ -329,10 +329,14 @@ RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, 
   scan_u32(counts->as<uint32_t>(), (int64_t)nparts * n_tiles, prefix->as<uint64_t>());
   RangePartition out;
   out.bounds.resize((size_t)nparts + 1);
-  // the partitions' first offsets = every n_tiles-th entry of the prefix: ONE strided copy (64 separate 8-byte copies cost 0.6 ms)
-  DFGPU_HIP(hipMemcpy2DAsync(out.bounds.data(), 8, prefix->ptr, (size_t)n_tiles * 8, 8, (size_t)nparts, hipMemcpyDeviceToHost, r.stream));
-  DFGPU_HIP(hipStreamSynchronize(r.stream));
-  out.bounds[(size_t)nparts] = (uint64_t)n;
+  if (want_bounds) {
+    // the partitions' first offsets = every n_tiles-th entry of the prefix: ONE strided copy (64 separate 8-byte copies cost 0.6 ms)
+    DFGPU_HIP(hipMemcpy2DAsync(out.bounds.data(), 8, prefix->ptr, (size_t)n_tiles * 8, 8, (size_t)nparts, hipMemcpyDeviceToHost, r.stream));
+    DFGPU_HIP(hipStreamSynchronize(r.stream));
+    out.bounds[(size_t)nparts] = (uint64_t)n;
+  } else {
+    out.bounds.clear();
+  }
   for (size_t c = 0; c < src.size(); c++) out.cols.push_back(make_buf((size_t)n * widths[c] + 64));
   for (size_t c0 = 0; c0 < src.size(); c0 += PART_MAX_COLS) {
     PartCols pc{};
