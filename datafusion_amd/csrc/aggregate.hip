@@ -1708,10 +1708,11 @@ static int part_val_width(int val) {
 // The core: `key` (type kt, no NULLs) takes values in [kmin, kmin + range); accumulator u reads its argument from all[u].data (a
 // source column without NULLs, null for the counts) and owns the cell words all[u].cell (.. + 1 for a 128-bit sum) of `ncw`.
 // Moves key, arguments (and row numbers, when first rows are wanted) into window order and leaves totals per value in `out`.
-static bool partitioned_accumulate(const void* key, int kt, int64_t n, long long kmin, uint64_t range, std::vector<PartAcc> all, int ncw, bool want_first_rows,
-                                   PartValues& out) {
+static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long long kmin, uint64_t range, std::vector<PartAcc> all, int ncw, bool want_first_rows,
+                                   PartValues& out, const uint64_t* row_mask = nullptr, const uint64_t* row_mask_valid = nullptr) {
   static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
   const int64_t min_rows = env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23);
+  int64_t n = n_in;
   if (off || n < min_rows || range < 4096 || all.empty() || all.size() > (size_t)PART_ACC_MAX) return false;
   if (!(kt == DFGPU_INT32 || kt == DFGPU_DATE32 || kt == DFGPU_INT64 || kt == DFGPU_UINT32 || kt == DFGPU_UINT8)) return false;
   // windows of 2^wshift values whose first rows (4 B) and at least one accumulator (8 B, 16 for a 128-bit sum) fit the LDS budget:
@@ -1777,7 +1778,17 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n, long long
     src.push_back(ids->ptr);
     widths.push_back(4);
   }
-  RangePartition rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths, /*want_bounds=*/false);
+  // (under a predicate only the rows it lets through are moved: `n` is their number from here on)
+  RangePartition rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths, /*want_bounds=*/false, row_mask, row_mask_valid);
+  n = rp.rows;
+  if (n == 0) {   // the predicate dropped every row
+    out.vstride = ((int64_t)range + 63) / 64 * 64;
+    out.first_row_v = make_buf((size_t)out.vstride * 4);
+    DFGPU_HIP(hipMemsetAsync(out.first_row_v->ptr, 0xFF, (size_t)out.vstride * 4, r.stream));
+    out.cells_v = make_buf((size_t)std::max(1, ncw) * (size_t)out.vstride * 8);
+    DFGPU_HIP(hipStreamSynchronize(r.stream));
+    return true;
+  }
   if (levels == 2) {   // stable second move by the high digit: the rows end up in window order
     std::vector<const void*> src2;
     for (const BufPtr& b : rp.cols) src2.push_back(b->ptr);
@@ -1869,7 +1880,6 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n, long long
 // acc_val[u]: its ValKind.
 static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, const dfgpu_expr* pred, const std::vector<DenseAcc>& accs, const std::vector<int>& acc_col,
                                          const std::vector<int>& acc_val, const std::vector<int>& acc_agg, int ncw, long long kmin, uint64_t range, PartValues& out) {
-  if (pred) return false;
   // cheap refusals before any argument expression is evaluated
   if (in.nrows < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || range < 4096) return false;
   int kc = -1;
@@ -1890,9 +1900,10 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
       continue;
     }
     // an expression (Q15's l_extendedprice * (1 - l_discount)): evaluated column-at-a-time first — a streaming pass, where the
-    // specialised kernel would pay a global atomic per row for it
+    // specialised kernel would pay a global atomic per row for it.  Not under a predicate: the reference evaluates arguments on the
+    // rows the FilterExec lets through, and an expression may fail (divide by zero) on the others
     const AggState& a = A.aggs[(size_t)acc_agg[u]];
-    if (!a.has_arg) return false;
+    if (!a.has_arg || pred) return false;
     int found = -1;
     for (size_t q = 0; q < u; q++)
       if (acc_agg[q] == acc_agg[u] && acc_col[q] == c && all[q].data) found = (int)q;   // (AVG: sum and count share the argument)
@@ -1906,7 +1917,15 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
     all[u].data = v.ptr();
     evaluated.push_back(std::move(v));
   }
-  return partitioned_accumulate(key.ptr(), key.field.type, in.nrows, kmin, range, std::move(all), ncw, /*want_first_rows=*/true, out);
+  // a FilterExec fused below the aggregate: its mask (false and NULL drop the row) decides which rows are moved at all
+  Column mask;
+  if (pred) {
+    Datum m = evaluate(*pred, in);
+    DFGPU_CHECK(m.col.field.type == DFGPU_BOOL, "Cannot create filter with non-boolean predicate");
+    mask = datum_to_column(m, in.nrows, "");
+  }
+  return partitioned_accumulate(key.ptr(), key.field.type, in.nrows, kmin, range, std::move(all), ncw, /*want_first_rows=*/true, out,
+                                pred ? (const uint64_t*)mask.ptr() : nullptr, pred ? mask.valid_words() : nullptr);
 }
 
 // ---- the same for groups that were interned by hash (agg_update_unfused: evaluated key / argument columns, Final-mode merges of

@@ -404,9 +404,11 @@ Table sort_table_ascending(const Table& in, const std::vector<int>& key_cols);  
 struct RangePartition {
   std::vector<BufPtr> cols;
   std::vector<uint64_t> bounds;
+  int64_t rows = 0;   // rows moved (fewer than the input's under a row mask)
 };
 RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, long long kmin, int shift, unsigned mask, int nparts,
-                                      const std::vector<const void*>& src, const std::vector<int>& widths, bool want_bounds = true);
+                                      const std::vector<const void*>& src, const std::vector<int>& widths, bool want_bounds = true,
+                                      const uint64_t* row_mask = nullptr, const uint64_t* row_mask_valid = nullptr);   // (mask: one bit per row, 1 = takes part)
 
 // ----------------------------------------------------------------- LDS radix join (radix_join.hip)
 struct RadixTable;

@@ -113,7 +113,7 @@ __device__ __forceinline__ void stage_column(const void* __restrict__ src, void*
 #pragma unroll
   for (int c = 0; c < PT_ITEMS; c++) {
     const int j = c * BLOCK + threadIdx.x;
-    if (j < tile_rows) sv[q[c]] = reinterpret_cast<const T*>(src)[lo + j];
+    if (q[c] != 0xFFFFFFFFu) sv[q[c]] = reinterpret_cast<const T*>(src)[lo + j];
   }
   __syncthreads();
 #pragma unroll
@@ -132,6 +132,8 @@ __device__ __forceinline__ void stage_column(const void* __restrict__ src, void*
 // (wave64 ballot peer masks + a cross-wave prefix in LDS, as sort.hip's radix pass); each column is then staged
 // through LDS in that order and every partition's run is written contiguously — 2048 / nparts rows per run
 // instead of the ~8-row runs a 64-row wave scatters on its own (measured 33 % of HBM peak).
+// MASKED: rows whose part id is 0xFF take no part (a predicate dropped them: partition_by_key_range under a row mask)
+template <bool MASKED = false>
 __global__ __launch_bounds__(BLOCK) void k_part_scatter(PartCols cols, const uint8_t* __restrict__ part, const uint64_t* __restrict__ prefix, int64_t n,
                                                         int nparts, int nbits, int64_t n_tiles) {
   __shared__ uint4 s_val[PT_TILE];
@@ -150,11 +152,17 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter(PartCols cols, const uin
     }
     __syncthreads();
     unsigned dig[PT_ITEMS], rank[PT_ITEMS], q[PT_ITEMS];
+    bool inr[PT_ITEMS];
 #pragma unroll
     for (int c = 0; c < PT_ITEMS; c++) {
       const int j = c * BLOCK + threadIdx.x;
-      const bool in = j < tile_rows;
+      bool in = j < tile_rows;
       dig[c] = in ? part[lo + j] : 0u;
+      if (MASKED && dig[c] == 0xFFu) {
+        in = false;
+        dig[c] = 0u;
+      }
+      inr[c] = in;
       uint64_t peers = ballot64(in);
       for (int b = 0; b < nbits; b++) {
         const uint64_t bal = ballot64((dig[c] >> b) & 1u);
@@ -187,20 +195,21 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter(PartCols cols, const uin
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < PT_ITEMS; c++) {
-      const int j = c * BLOCK + threadIdx.x;
-      q[c] = 0;
-      if (j < tile_rows) {
+      q[c] = 0xFFFFFFFFu;   // (a row that takes no part)
+      if (inr[c]) {
         q[c] = s_start[dig[c]] + rank[c];
         s_dig[q[c]] = (uint8_t)dig[c];
       }
     }
     __syncthreads();
+    // rows that leave the tile: all of them, or — MASKED — those that take part
+    const int out_rows = MASKED ? (int)(s_start[nparts - 1] + s_run[nparts - 1]) : tile_rows;
     for (int c = 0; c < cols.n; c++) {
       switch (cols.width[c]) {
-        case 16: stage_column<uint4>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, tile_rows, q); break;
-        case 8: stage_column<uint64_t>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, tile_rows, q); break;
-        case 4: stage_column<uint32_t>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, tile_rows, q); break;
-        case 1: stage_column<uint8_t>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, tile_rows, q); break;
+        case 16: stage_column<uint4>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, out_rows, q); break;
+        case 8: stage_column<uint64_t>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, out_rows, q); break;
+        case 4: stage_column<uint32_t>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, out_rows, q); break;
+        case 1: stage_column<uint8_t>(cols.src[c], cols.dst[c], s_val, s_dig, s_start, s_goff, lo, out_rows, q); break;
       }
     }
   }
@@ -273,6 +282,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_count2(KeySet ks, int64_t n, int
 // partition's groups fit (aggregate.hip dense_accumulate_partitioned).
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_part_count_range(const T* __restrict__ key, int64_t n, long long kmin, int shift, unsigned mask, int nparts, int64_t n_tiles,
+                                                            const uint64_t* __restrict__ row_mask, const uint64_t* __restrict__ row_mask_valid,
                                                             uint8_t* __restrict__ part, uint32_t* __restrict__ counts) {
   __shared__ unsigned int sh[MAX_PARTS];
   for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -286,7 +296,13 @@ __global__ __launch_bounds__(BLOCK) void k_part_count_range(const T* __restrict_
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (i0 + k < n) {
-          const unsigned p = (unsigned)(((unsigned long long)((long long)key[i0 + k] - kmin)) >> shift) & mask;
+          const int64_t i = i0 + k;
+          // a row the predicate dropped (false or NULL) takes no part: id 0xFF
+          if (row_mask && !(((row_mask[i >> 6] & (row_mask_valid ? row_mask_valid[i >> 6] : ~0ull)) >> (i & 63)) & 1ull)) {
+            packed |= 0xFFu << (8 * k);
+            continue;
+          }
+          const unsigned p = (unsigned)(((unsigned long long)((long long)key[i] - kmin)) >> shift) & mask;
           packed |= (p & 0xFFu) << (8 * k);
           atomicAdd(&sh[p & (MAX_PARTS - 1)], 1u);
         }
@@ -306,7 +322,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_count_range(const T* __restrict_
 }
 
 RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, long long kmin, int shift, unsigned mask, int nparts,
-                                      const std::vector<const void*>& src, const std::vector<int>& widths, bool want_bounds) {
+                                      const std::vector<const void*>& src, const std::vector<int>& widths, bool want_bounds, const uint64_t* row_mask,
+                                      const uint64_t* row_mask_valid) {
   Runtime& r = rt();
   DFGPU_CHECK(nparts >= 1 && nparts <= MAX_PARTS && src.size() == widths.size() && n > 0, "partition_by_key_range: bad arguments");
   const int64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
@@ -319,10 +336,10 @@ RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, 
   {
     ProfileScope ps("partition_count_range", n * type_width(key_type) + n);
     switch (key_type) {
-      case DFGPU_INT64: k_part_count_range<int64_t><<<tile_grid, BLOCK, 0, r.stream>>>((const int64_t*)key, n, kmin, shift, mask, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
-      case DFGPU_UINT32: k_part_count_range<uint32_t><<<tile_grid, BLOCK, 0, r.stream>>>((const uint32_t*)key, n, kmin, shift, mask, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
-      case DFGPU_UINT8: k_part_count_range<uint8_t><<<tile_grid, BLOCK, 0, r.stream>>>((const uint8_t*)key, n, kmin, shift, mask, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
-      default: k_part_count_range<int32_t><<<tile_grid, BLOCK, 0, r.stream>>>((const int32_t*)key, n, kmin, shift, mask, nparts, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); break;
+      case DFGPU_INT64: k_part_count_range<int64_t><<<tile_grid, BLOCK, 0, r.stream>>>((const int64_t*)key, n, kmin, shift, mask, nparts, n_tiles, row_mask, row_mask_valid, part->as<uint8_t>(), counts->as<uint32_t>()); break;
+      case DFGPU_UINT32: k_part_count_range<uint32_t><<<tile_grid, BLOCK, 0, r.stream>>>((const uint32_t*)key, n, kmin, shift, mask, nparts, n_tiles, row_mask, row_mask_valid, part->as<uint8_t>(), counts->as<uint32_t>()); break;
+      case DFGPU_UINT8: k_part_count_range<uint8_t><<<tile_grid, BLOCK, 0, r.stream>>>((const uint8_t*)key, n, kmin, shift, mask, nparts, n_tiles, row_mask, row_mask_valid, part->as<uint8_t>(), counts->as<uint32_t>()); break;
+      default: k_part_count_range<int32_t><<<tile_grid, BLOCK, 0, r.stream>>>((const int32_t*)key, n, kmin, shift, mask, nparts, n_tiles, row_mask, row_mask_valid, part->as<uint8_t>(), counts->as<uint32_t>()); break;
     }
     DFGPU_HIP(hipGetLastError());
   }
@@ -337,6 +354,8 @@ RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, 
   } else {
     out.bounds.clear();
   }
+  out.rows = n;
+  if (row_mask) out.rows = (int64_t)read_u64(prefix->as<uint64_t>() + (int64_t)nparts * n_tiles);   // rows that take part
   for (size_t c = 0; c < src.size(); c++) out.cols.push_back(make_buf((size_t)n * widths[c] + 64));
   for (size_t c0 = 0; c0 < src.size(); c0 += PART_MAX_COLS) {
     PartCols pc{};
@@ -350,7 +369,8 @@ RangePartition partition_by_key_range(const void* key, int key_type, int64_t n, 
       bytes += 2 * n * pc.width[k];
     }
     ProfileScope ps("partition_scatter", bytes);
-    k_part_scatter<<<tile_grid, BLOCK, 0, r.stream>>>(pc, part->as<uint8_t>(), prefix->as<uint64_t>(), n, nparts, nbits, n_tiles);
+    if (row_mask) k_part_scatter<true><<<tile_grid, BLOCK, 0, r.stream>>>(pc, part->as<uint8_t>(), prefix->as<uint64_t>(), n, nparts, nbits, n_tiles);
+    else k_part_scatter<false><<<tile_grid, BLOCK, 0, r.stream>>>(pc, part->as<uint8_t>(), prefix->as<uint64_t>(), n, nparts, nbits, n_tiles);
     DFGPU_HIP(hipGetLastError());
   }
   return out;
@@ -452,7 +472,7 @@ static std::vector<Table> partition_table_fixed_keys(const Table& in, const std:
         bytes += 2 * n * pc.width[k];
       }
       ProfileScope ps("partition_scatter", bytes);
-      k_part_scatter<<<tile_grid, BLOCK, 0, r.stream>>>(pc, part->as<uint8_t>(), prefix->as<uint64_t>(), n, nparts, nbits, n_tiles);
+      k_part_scatter<false><<<tile_grid, BLOCK, 0, r.stream>>>(pc, part->as<uint8_t>(), prefix->as<uint64_t>(), n, nparts, nbits, n_tiles);
       DFGPU_HIP(hipGetLastError());
     }
     for (int p = 0; p < nparts; p++) {

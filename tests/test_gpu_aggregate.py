@@ -478,3 +478,37 @@ def test_final_merge_of_many_partial_states_moves_rows_by_group_number():
         g = a * g2 + b
         assert (x, y, z) == (int(ss[g]), int(cc[g]), int(mm[g]))
         assert abs(w - asm[g] / an[g]) <= 1e-9 * abs(asm[g] / an[g])
+
+
+@pytest.mark.gpu
+def test_medium_cardinality_group_by_under_a_fused_filter_moves_only_the_rows_that_pass():
+    """a FilterExec fused below the aggregate (predicate with NULLs in its column): the rows it drops are not moved at all — the
+    partitions hold the passing rows, the groups are those with a passing row, in the order their first passing rows come"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(55)
+    n, distinct = 9_000_000, 30_000
+    codes = rng.integers(0, distinct, n)
+    v = rng.integers(-10**6, 10**6, n)
+    w = rng.integers(-100, 100, n).astype(np.int32)
+    wnull = rng.random(n) < 0.1
+    t = DeviceTable.from_arrow(pa.table({"k": pa.array(codes * 2 + 1), "v": pa.array(v), "w": pa.array(w, mask=wnull), "x": pa.array(rng.integers(0, 9, n))}))
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = ops.aggregate(t, [(col("k"), "k")], [("sum", col("v"), "sv"), ("count", None, "n"), ("max", col("x"), "mx")], "Single", predicate=col("w") > lit(10, pa.int32())).to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert "agg_dense_accumulate_partitioned" in stats and "agg_dense_accumulate" not in stats, sorted(stats)
+    keep = (w > 10) & ~wnull
+    kc, kv, kx = codes[keep], v[keep], t.to_arrow().column("x").to_numpy()[keep]
+    first = np.full(distinct, n, dtype=np.int64)
+    np.minimum.at(first, kc, np.nonzero(keep)[0])
+    present = np.nonzero(first < n)[0]
+    order = present[np.argsort(first[present], kind="stable")]
+    sv = np.zeros(distinct, dtype=np.int64); np.add.at(sv, kc, kv)
+    mx = np.full(distinct, -1, dtype=np.int64); np.maximum.at(mx, kc, kx)
+    assert got.column("k").to_pylist() == (order * 2 + 1).tolist()
+    assert got.column("sv").to_pylist() == sv[order].tolist()
+    assert got.column("n").to_pylist() == np.bincount(kc, minlength=distinct)[order].tolist()
+    assert got.column("mx").to_pylist() == mx[order].tolist()
