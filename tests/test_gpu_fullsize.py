@@ -171,3 +171,34 @@ def test_sf100_sort_is_an_ordered_permutation():
         assert ((np.diff(d) > 0) | ((np.diff(d) == 0) & (np.diff(k) < 0))).all()
     s.free()
     o.free()
+
+
+def test_sf100_group_by_custkey_partitioned_equals_global_atomics(monkeypatch):
+    """Q13's shape at SF100 (150 M orders, 10 M customers with orders): the dense-key node with its rows moved into LDS-sized key
+    windows (two moves) gives exactly what the same node gives with one global atomic per row — groups in the same first-seen order,
+    same counts, same first order dates — and the counts add up to the orders"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    orders = ops.tpch_orders(SF).select(["o_custkey", "o_orderdate"])
+    aggs = [("count", None, "cnt"), ("min", col("o_orderdate"), "first_order")]
+
+    def run():
+        ops.profile_enable(True)
+        ops.profile_reset()
+        out = ops.aggregate(orders, [(col("o_custkey"), "o_custkey")], aggs, "Single")
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+        return out, stats
+    moved, s1 = run()
+    assert "agg_dense_accumulate_partitioned" in s1 and s1["partition_scatter"]["calls"] == 2
+    monkeypatch.setenv("DFGPU_AGG_PARTITIONED_MIN_ROWS", str(2**31 - 1))
+    plain, s2 = run()
+    assert "agg_dense_accumulate" in s2 and "agg_dense_accumulate_partitioned" not in s2
+    assert moved.num_rows == plain.num_rows
+    cols = ["o_custkey", "cnt", "first_order"]
+    assert _sums(moved, cols) == _sums(plain, cols)
+    assert _sums(moved, ["cnt"])["cnt"] == orders.num_rows
+    for off in range(0, moved.num_rows - 1000, moved.num_rows // 50):          # the same rows in the same (first-seen) order
+        assert moved.slice(off, 1000).to_arrow().equals(plain.slice(off, 1000).to_arrow())
+    for t in (moved, plain, orders):
+        t.free()
