@@ -132,9 +132,13 @@ __device__ __forceinline__ uint64_t group_hash(const KeySet& ks, int64_t i) {
 // up holding the smallest row id of the key (first-seen representative).
 // `row_mask` (optional): bit r covers concatenated row mask_offset + r; rows below mask_offset (the existing
 // groups) are always interned.
-__global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, int* overflow, const uint64_t* __restrict__ row_mask, int64_t mask_offset) {
+// `row_slot` (optional): the slot every row ended at (0xFFFFFFFF: masked out, or skipped by the run compression below) — a later
+// row -> group pass then reads slot_gid[row_slot[i]] instead of hashing and comparing the keys again (k_row_gids).
+__global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, int* overflow, const uint64_t* __restrict__ row_mask, int64_t mask_offset,
+                                                       uint32_t* __restrict__ row_slot = nullptr) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (row_slot) row_slot[i] = 0xFFFFFFFFu;
     if (row_mask && i >= mask_offset && !bit_at(row_mask, i - mask_offset)) continue;
     // Run compression: an input row whose key equals its (live) predecessor's never needs to claim — the predecessor
     // or, by induction, the first row of the run does, and that row is the group's smaller row id anyway.  Clustered
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, 
         return;
       }
     }
+    if (row_slot) row_slot[i] = (uint32_t)s;
   }
 }
 // table sizing from a sample: out[0] = occupied slots, out[1] = those whose representative row lies before `early`
@@ -856,10 +861,11 @@ bool fusion_enabled() { return g_fusion_enabled; }
 struct InternResult {
   InternCtx ictx{};
   BufPtr slots, slot_gid;
+  BufPtr row_slot;               // (on request) the slot of every concatenated row, 0xFFFFFFFF where the claim pass skipped it
   std::vector<Column> cat_keys;  // [existing group keys ; input keys] — referenced by ictx
   int64_t G1 = 0;
 };
-static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_cols, int64_t n, const uint64_t* row_mask) {
+static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_cols, int64_t n, const uint64_t* row_mask, bool want_row_slots = false) {
   Runtime& r = rt();
   InternResult R;
   const int ngk = (int)key_cols.size();
@@ -934,7 +940,8 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
     ictx.mask = cap - 1;
     if (total) {
       ProfileScope ps("agg_intern_claim", key_bytes);
-      k_intern_claim<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx, total, flag->as<int>(), row_mask, G0);
+      if (want_row_slots && !R.row_slot) R.row_slot = make_buf((size_t)total * 4);
+      k_intern_claim<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx, total, flag->as<int>(), row_mask, G0, R.row_slot ? R.row_slot->as<uint32_t>() : nullptr);
       DFGPU_HIP(hipGetLastError());
     }
     int ovf = 0;
@@ -1713,7 +1720,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
   const int64_t min_rows = env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23);
   int64_t n = n_in;
-  if (off || n < min_rows || range < 4096 || all.empty() || all.size() > (size_t)PART_ACC_MAX) return false;
+  if (off || n < min_rows || range < 256 || all.empty() || all.size() > (size_t)PART_ACC_MAX) return false;
   if (!(kt == DFGPU_INT32 || kt == DFGPU_DATE32 || kt == DFGPU_INT64 || kt == DFGPU_UINT32 || kt == DFGPU_UINT8)) return false;
   // windows of 2^wshift values whose first rows (4 B) and at least one accumulator (8 B, 16 for a 128-bit sum) fit the LDS budget:
   // at most 64 of them after ONE move of the rows, at most 4096 after two (low 6 bits of the window number first, then the high 6)
@@ -1930,8 +1937,16 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
 
 // ---- the same for groups that were interned by hash (agg_update_unfused: evaluated key / argument columns, Final-mode merges of
 // partial states): the key that is moved is the row's group number, the per-value totals ARE per-group totals
-__global__ __launch_bounds__(BLOCK) void k_row_gids(InternCtx c, const uint32_t* __restrict__ slot_gid, int64_t row_offset, int64_t n, uint32_t* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = lookup_gid(c, slot_gid, row_offset + i);
+__global__ __launch_bounds__(BLOCK) void k_row_gids(InternCtx c, const uint32_t* __restrict__ slot_gid, int64_t row_offset, int64_t n, const uint64_t* __restrict__ row_mask,
+                                                   const uint32_t* __restrict__ row_slot, uint32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (row_mask && !bit_at(row_mask, i)) {   // (rows a predicate dropped were never interned)
+      out[i] = 0u;
+      continue;
+    }
+    const uint32_t rs = row_slot ? row_slot[row_offset + i] : 0xFFFFFFFFu;
+    out[i] = rs != 0xFFFFFFFFu ? slot_gid[rs] : lookup_gid(c, slot_gid, row_offset + i);
+  }
 }
 struct MergeAcc {
   unsigned long long* acc_lo;
@@ -1968,7 +1983,8 @@ __global__ __launch_bounds__(BLOCK) void k_merge_group_totals(const uint32_t* __
     }
   }
 }
-static bool general_accumulate_partitioned(const InternCtx& ictx, const uint32_t* slot_gid, int64_t G0, int64_t n, const AccSet& accs, int64_t G1) {
+static bool general_accumulate_partitioned(const InternCtx& ictx, const uint32_t* slot_gid, int64_t G0, int64_t n, const AccSet& accs, int64_t G1,
+                                           const uint64_t* row_mask = nullptr, const uint32_t* row_slot = nullptr) {
   if (accs.n <= 0 || accs.n > PART_ACC_MAX || G1 >= 0xFFFFFFFFll) return false;
   std::vector<PartAcc> all((size_t)accs.n);
   MergeSet m{};
@@ -1982,20 +1998,68 @@ static bool general_accumulate_partitioned(const InternCtx& ictx, const uint32_t
   }
   // cheap refusals first (the row -> group pass below is a random lookup per row)
   static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
-  if (off || n < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || G1 < 4096) return false;
+  if (off || n < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || G1 < 256) return false;
   Runtime& r = rt();
   BufPtr gids = make_buf((size_t)n * 4);
   {
     ProfileScope ps("agg_row_gids", n * 4);
-    k_row_gids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(ictx, slot_gid, G0, n, gids->as<uint32_t>());
+    k_row_gids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(ictx, slot_gid, G0, n, row_mask, row_slot, gids->as<uint32_t>());
     DFGPU_HIP(hipGetLastError());
   }
   PartValues pv;
-  if (!partitioned_accumulate(gids->ptr, DFGPU_UINT32, n, 0, (uint64_t)G1, std::move(all), ncw, /*want_first_rows=*/false, pv)) return false;
+  if (!partitioned_accumulate(gids->ptr, DFGPU_UINT32, n, 0, (uint64_t)G1, std::move(all), ncw, /*want_first_rows=*/false, pv, row_mask, nullptr)) return false;
   k_merge_group_totals<<<grid_for(G1, BLOCK), BLOCK, 0, r.stream>>>(pv.first_row_v->as<uint32_t>(), pv.cells_v->as<unsigned long long>(), pv.vstride, G1, m);
   DFGPU_HIP(hipGetLastError());
   DFGPU_HIP(hipStreamSynchronize(r.stream));
   return true;
+}
+
+// the fused node's face of it (hash-interned groups, the keys are interned already): the aggregate arguments are evaluated
+// column-at-a-time — plain columns in place; expressions only without a predicate (see dense_accumulate_partitioned) — and the rows
+// are moved by group number.  `plans`: plan_for of every aggregate; `row_mask`: the fused FilterExec's mask (null: none).
+static bool fused_general_partitioned(Aggregate& A, const Table& in, const std::vector<AccPlan>& plans, const InternCtx& ictx, const uint32_t* slot_gid, int64_t G0,
+                                      int64_t G1, const uint64_t* row_mask, const uint32_t* row_slot) {
+  const int64_t n = in.nrows;
+  static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
+  if (std::getenv("DFGPU_TRACE_AGG")) fprintf(stderr, "[agg] fused_general_partitioned: n %lld, G0 %lld, G1 %lld, off %d\n", (long long)n, (long long)G0, (long long)G1, (int)off);
+  if (off || n < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || G1 < 256) return false;   // (fewer groups: the LDS-replicated cells of the fused kernel)
+  AccSet accs{};
+  std::vector<Column> keep;
+  for (size_t k = 0; k < A.aggs.size(); k++) {
+    AggState& a = A.aggs[k];
+    AccDesc d{};
+    d.kind = (a.func == DFGPU_AGG_COUNT && !a.has_arg) ? ACC_COUNT_STAR : plans[k].kind;
+    d.val = plans[k].val;
+    if (a.has_arg) {
+      int c = -1;
+      Column v;
+      if (is_plain_column(a.nodes, a.root, &c) && c >= 0 && c < (int)in.cols.size()) {
+        v = in.cols[(size_t)c];
+      } else {
+        if (row_mask) return false;
+        dfgpu_expr e{a.nodes.data(), (int)a.nodes.size(), a.root};
+        v = datum_to_column(evaluate(e, in), n, a.name);
+      }
+      if (v.validity || v.dict || v.field.type == DFGPU_BOOL || v.field.type == DFGPU_UTF8) return false;
+      d.values = v.ptr();
+      keep.push_back(std::move(v));
+    }
+    d.acc_lo = a.lo->as<unsigned long long>();
+    d.acc_hi = a.hi ? a.hi->as<unsigned long long>() : nullptr;
+    d.seen = a.seen->as<uint32_t>();
+    if (accs.n >= MAX_AGGS) return false;
+    accs.a[accs.n++] = d;
+    if (a.func == DFGPU_AGG_AVG) {   // companion count of the non-null arguments (there are no NULLs here: the rows)
+      AccDesc c2{};
+      c2.kind = ACC_COUNT;
+      c2.val = VAL_I64;
+      c2.values = d.values;
+      c2.acc_lo = a.cnt->as<unsigned long long>();
+      if (accs.n >= MAX_AGGS) return false;
+      accs.a[accs.n++] = c2;
+    }
+  }
+  return general_accumulate_partitioned(ictx, slot_gid, G0, n, accs, G1, row_mask, row_slot);
 }
 
 // The specialised dense-key node.  Returns false (state untouched) when it does not apply.
@@ -3105,7 +3169,9 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
       }
       row_mask = pred_mask_keepalive->as<uint64_t>();
     }
-    IR = intern_keys(A, key_cols_keepalive, n, row_mask);
+    // (large inputs may take the partitioned accumulation below: it wants every row's slot from the claim pass)
+    const bool maybe_partitioned = n >= env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) && !(std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0');
+    IR = intern_keys(A, key_cols_keepalive, n, row_mask, maybe_partitioned);
     G1 = IR.G1;
     gs.ictx = IR.ictx;
     gs.slot_gid = IR.slot_gid->as<uint32_t>();
@@ -3142,6 +3208,8 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
       ProfileScope ps("agg_fused_lds", bytes);
       auto kern = cp.n_regs <= 16 ? k_agg_fused<true, 16> : k_agg_fused<true, 32>;
       kern<<<grid_for(n, BLOCK * 8), BLOCK, 0, r.stream>>>(cp.prog, cp.n_prologue, cp.n_pred_end, cp.pred_reg, gs, accs, n, (int)G1, nrep);
+    } else if (gid_mode == GID_HASH && fused_general_partitioned(A, in, plans, gs.ictx, gs.slot_gid, G0, G1, pred ? pred_mask_keepalive->as<uint64_t>() : nullptr, IR.row_slot ? IR.row_slot->as<uint32_t>() : nullptr)) {
+      // (medium cardinalities: rows moved by group number into LDS-sized windows instead of one global atomic per row and aggregate)
     } else {
       ProfileScope ps("agg_fused_global", bytes);
       auto kern = cp.n_regs <= 16 ? k_agg_fused<false, 16> : k_agg_fused<false, 32>;

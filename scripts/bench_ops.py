@@ -102,7 +102,7 @@ def main():
         ops.sync()
 
     # ------------------------------------------------------------------ config 4: Q1
-    if want("q1") or want("agg_highcard") or want("agg_mediumcard") or want("partition") or want("filter"):
+    if want("q1") or want("agg_highcard") or want("agg_mediumcard") or want("agg_multikey") or want("partition") or want("filter"):
         li = ops.tpch_lineitem(args.sf)
         n = li.num_rows
         if want("filter"):
@@ -158,6 +158,20 @@ def main():
                     note="bytes = N*(8+4) in + groups*(8+8+4) out")
             results[-1]["groups"] = holder["g"]
             oc.free()
+        if want("agg_multikey"):
+            # a daily report: three key columns (hash-interned groups: ~10 K), three aggregates over 600 M rows
+            t = li.select(["l_returnflag", "l_linestatus", "l_shipdate", "l_quantity", "l_extendedprice"])
+            holder = {}
+
+            def run_mk():
+                o = ops.aggregate(t, [(col("l_returnflag"), "l_returnflag"), (col("l_linestatus"), "l_linestatus"), (col("l_shipdate"), "l_shipdate")],
+                                  [("sum", col("l_quantity"), "q"), ("sum", col("l_extendedprice"), "p"), ("count", None, "n")], "Single")
+                holder["g"] = o.num_rows
+                return o
+            measure(f"GROUP BY l_returnflag, l_linestatus, l_shipdate SUM(l_quantity), SUM(l_extendedprice), COUNT(*) SF{args.sf:g}", run_mk, n,
+                    lambda: n * 38 + holder["g"] * 46, note="bytes = N*(1+1+4+16+16) in + groups*(6+16+16+8) out")
+            results[-1]["groups"] = holder["g"]
+            t.free()
         if want("partition"):
             t = li.select(["l_orderkey", "l_extendedprice", "l_discount"])
             measure(f"RepartitionExec Hash(l_orderkey) -> 8 partitions SF{args.sf:g}", lambda: ops.partition(t, ["l_orderkey"], 8), n, 2 * n * 40,

@@ -512,3 +512,47 @@ def test_medium_cardinality_group_by_under_a_fused_filter_moves_only_the_rows_th
     assert got.column("sv").to_pylist() == sv[order].tolist()
     assert got.column("n").to_pylist() == np.bincount(kc, minlength=distinct)[order].tolist()
     assert got.column("mx").to_pylist() == mx[order].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filtered", [False, True], ids=["no_predicate", "fused_filter"])
+def test_two_column_key_medium_cardinality_moves_rows_by_group_number(filtered):
+    """GROUP BY (k1, k2) — hash-interned groups, 40 K of them over 9 M rows — in Single mode: after the keys are interned, every row's
+    group number is looked up once, the rows are moved by group number into LDS-sized windows and accumulated there; under a fused
+    FilterExec only the passing rows are interned, looked up and moved.  Against sums computed on the host."""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(77 + filtered)
+    n, g1, g2 = 9_000_000, 200, 200
+    k1 = rng.integers(0, g1, n)
+    k2 = rng.integers(0, g2, n).astype(np.int32)
+    v = rng.integers(-10**6, 10**6, n)
+    w = rng.integers(-100, 100, n).astype(np.int32)
+    t = DeviceTable.from_arrow(pa.table({"k1": pa.array(k1), "k2": pa.array(k2), "v": pa.array(v), "w": pa.array(w)}))
+    aggs = [("sum", col("v"), "sv"), ("count", None, "n"), ("avg", col("w"), "aw"), ("min", col("v"), "lo")]
+    if not filtered:
+        aggs.append(("sum", col("v") + col("v"), "s2"))       # an expression: evaluated column-at-a-time first
+    pred = (col("w") >= lit(0, pa.int32())) if filtered else None
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = ops.aggregate(t, [(col("k1"), "k1"), (col("k2"), "k2")], aggs, "Single", predicate=pred).to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert "agg_dense_accumulate_partitioned" in stats and "agg_row_gids" in stats and "agg_fused_global" not in stats, sorted(stats)
+    keep = (w >= 0) if filtered else np.ones(n, dtype=bool)
+    gid = (k1 * g2 + k2)[keep]
+    first = np.full(g1 * g2, n, dtype=np.int64)
+    np.minimum.at(first, gid, np.nonzero(keep)[0])
+    present = np.nonzero(first < n)[0]
+    order = present[np.argsort(first[present], kind="stable")]                      # first-seen order, like the reference
+    assert got.column("k1").to_pylist() == (order // g2).tolist() and got.column("k2").to_pylist() == (order % g2).tolist()
+    sv = np.zeros(g1 * g2, dtype=np.int64); np.add.at(sv, gid, v[keep])
+    cnt = np.bincount(gid, minlength=g1 * g2)
+    sw = np.zeros(g1 * g2, dtype=np.int64); np.add.at(sw, gid, w[keep])
+    lo = np.full(g1 * g2, 2**62, dtype=np.int64); np.minimum.at(lo, gid, v[keep])
+    assert got.column("sv").to_pylist() == sv[order].tolist() and got.column("n").to_pylist() == cnt[order].tolist()
+    assert got.column("lo").to_pylist() == lo[order].tolist()
+    assert np.allclose(got.column("aw").to_numpy(), sw[order] / cnt[order], rtol=1e-12)
+    if not filtered:
+        assert got.column("s2").to_pylist() == (2 * sv[order]).tolist()
