@@ -858,10 +858,27 @@ bool fusion_enabled() { return g_fusion_enabled; }
 
 // ------------------------------------------------------------------------------ host
 // GroupValues::intern over materialised key columns (hash table of representative rows)
+// several narrow key columns (no NULLs, <= 64 bits together) as ONE 64-bit key: the raw bits side by side.  Equal rows <=> equal
+// packed keys, so interning hashes one word and compares one word with the representative's instead of one per column
+__global__ __launch_bounds__(BLOCK) void k_pack_key_bits(KeySet ks, int64_t n, uint64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint64_t v = 0;
+    int shift = 0;
+    for (int c = 0; c < ks.n; c++) {
+      uint64_t lo, hi;
+      load_words(ks.c[c], i, lo, hi);
+      const int bits = ks.c[c].width * 8;
+      v |= (bits >= 64 ? lo : (lo & ((1ull << bits) - 1ull))) << shift;
+      shift += bits;
+    }
+    out[i] = v;
+  }
+}
 struct InternResult {
   InternCtx ictx{};
   BufPtr slots, slot_gid;
   BufPtr row_slot;               // (on request) the slot of every concatenated row, 0xFFFFFFFF where the claim pass skipped it
+  BufPtr packed;                 // the keys packed into one word per row, when that is what ictx refers to
   std::vector<Column> cat_keys;  // [existing group keys ; input keys] — referenced by ictx
   int64_t G1 = 0;
 };
@@ -898,6 +915,27 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   }
   int64_t key_bytes = 0;
   for (int g = 0; g < ngk; g++) key_bytes += total * type_width(R.cat_keys[g].field.type);
+  // 2+ narrow keys without NULLs: interned through their packed form
+  {
+    int bits = 0;
+    bool packable = ngk >= 2 && total >= (1 << 20) && !(std::getenv("DFGPU_AGG_PACK_KEYS") && std::getenv("DFGPU_AGG_PACK_KEYS")[0] == '0');
+    for (int g = 0; g < ngk && packable; g++) {
+      const Column& c = R.cat_keys[g];
+      packable = !c.validity && c.field.type != DFGPU_DECIMAL128 && c.field.type != DFGPU_FLOAT64 && c.field.type != DFGPU_UTF8;
+      bits += type_width(c.field.type) * 8;
+    }
+    if (packable && bits <= 64) {
+      R.packed = make_buf((size_t)total * 8);
+      {
+        ProfileScope ps("agg_pack_keys", key_bytes + total * 8);
+        k_pack_key_bits<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx.keys, total, R.packed->as<uint64_t>());
+        DFGPU_HIP(hipGetLastError());
+      }
+      ictx.keys.n = 1;
+      ictx.keys.c[0] = KeyCol{R.packed->ptr, nullptr, DFGPU_UINT64, 8};
+      key_bytes = total * 8;
+    }
+  }
   BufPtr flag = make_zero_buf(4);
   uint64_t cap = (uint64_t)A.capacity_hint;
   const uint64_t cap_max = [&] { uint64_t c = 64; while (c < (uint64_t)total * 2) c <<= 1; return c; }();
