@@ -1627,7 +1627,8 @@ constexpr int PART_BLOCK = 1024;   // threads per workgroup: the windows' LDS le
 template <typename KT>
 __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const PartBlock* __restrict__ blocks, const KT* __restrict__ key, const uint32_t* __restrict__ row_id,
                                                                  PartAccSet accs, long long kmin, int wshift, unsigned long long* __restrict__ cells_v,
-                                                                 int64_t vstride, uint64_t vrange, uint32_t* __restrict__ first_row_v) {
+                                                                 int64_t vstride, uint64_t vrange, uint32_t* __restrict__ first_row_v,
+                                                                 const uint64_t* __restrict__ row_mask, const uint64_t* __restrict__ row_mask_valid, int rows_in_place) {
   extern __shared__ unsigned long long s_mem[];
   const int W = 1 << wshift;
   unsigned long long* s_cell = s_mem;                                   // [ncw][W]
@@ -1644,8 +1645,11 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
   __syncthreads();
   const unsigned long long base = (unsigned long long)b.part << wshift;
   for (int64_t i = b.begin + threadIdx.x; i < b.end; i += PART_BLOCK) {
+    // (rows in place — the one-window form: the predicate's mask is looked at here instead of on the move)
+    if (row_mask && !((row_mask[i >> 6] >> (i & 63)) & 1ull)) continue;
+    if (row_mask_valid && !((row_mask_valid[i >> 6] >> (i & 63)) & 1ull)) continue;
     const int x = (int)((unsigned long long)((long long)key[i] - kmin) - base);   // value index inside the window
-    atomicMin(&s_first[x], row_id ? row_id[i] : 0u);
+    atomicMin(&s_first[x], row_id ? row_id[i] : rows_in_place ? (uint32_t)i : 0u);
     for (int k = 0; k < accs.n; k++) {
       const PartAcc& a = accs.a[k];
       unsigned long long* c = s_cell + (size_t)a.lcell * W + x;
@@ -1771,7 +1775,15 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   int wshift = 0;
   while (((range - 1) >> wshift) >= 64) wshift++;
   int levels = 1;
-  if (wshift > wcap) {
+  // the whole range fits ONE workgroup's LDS: nothing is moved.  Every workgroup takes a slice of the rows where they lie (the
+  // predicate's mask looked at row by row) and accumulates into its own copy of the one window; the copies merge through atomics
+  // — range x workgroups of them, against the 2 x (key + arguments) bytes per row the move costs
+  static const bool in_place_off = std::getenv("DFGPU_AGG_IN_PLACE") && std::getenv("DFGPU_AGG_IN_PLACE")[0] == '0';
+  const bool in_place = !in_place_off && ((range - 1) >> wcap) == 0;
+  if (in_place) {
+    wshift = 6;
+    while (((range - 1) >> wshift) >= 1) wshift++;
+  } else if (wshift > wcap) {
     wshift = wcap;
     if (((range - 1) >> wshift) >= 4096) return false;
     levels = 2;
@@ -1816,15 +1828,21 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   }
   BufPtr ids;
   int ids_at = -1;
-  if (want_first_rows) {
+  if (want_first_rows && !in_place) {
     ids = make_buf((size_t)n * 4);
     k_row_ids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(n, ids->as<uint32_t>());
     ids_at = (int)src.size();
     src.push_back(ids->ptr);
     widths.push_back(4);
   }
+  std::vector<PartBlock> blocks;
+  RangePartition rp;
+  if (in_place) {
+    const int64_t nb = std::min<int64_t>(std::max<int64_t>((n + (1 << 16) - 1) >> 16, 1), 2048);
+    for (int64_t b = 0; b < nb; b++) blocks.push_back(PartBlock{n * b / nb, n * (b + 1) / nb, 0, nb == 1 ? 1 : 0});
+  } else {
   // (under a predicate only the rows it lets through are moved: `n` is their number from here on)
-  RangePartition rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths, /*want_bounds=*/false, row_mask, row_mask_valid);
+  rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths, /*want_bounds=*/false, row_mask, row_mask_valid);
   n = rp.rows;
   if (n == 0) {   // the predicate dropped every row
     out.vstride = ((int64_t)range + 63) / 64 * 64;
@@ -1854,7 +1872,6 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   }
   std::vector<long long> begins((size_t)n_windows);
   d2h(begins.data(), d_begins->ptr, (size_t)n_windows * 8);
-  std::vector<PartBlock> blocks;
   {
     int64_t end = n;
     std::vector<PartBlock> rev;
@@ -1867,6 +1884,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
       end = b0;
     }
     blocks.assign(rev.rbegin(), rev.rend());
+  }
   }
   out.vstride = ((int64_t)range + 63) / 64 * 64;
   out.first_row_v = make_buf((size_t)out.vstride * 4);
@@ -1888,7 +1906,10 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     ProfileScope psc("agg_dense_accumulate_partitioned", bytes);
     const PartBlock* db = d_blocks->as<PartBlock>();
     const uint32_t* rid = ids_at >= 0 ? rp.cols[(size_t)ids_at]->as<uint32_t>() : nullptr;
-    const void* mk = rp.cols[0]->ptr;
+    const void* mk = in_place ? key : rp.cols[0]->ptr;
+    const uint64_t* km = in_place ? row_mask : nullptr;
+    const uint64_t* kmv = in_place ? row_mask_valid : nullptr;
+    const int ip = in_place && want_first_rows ? 1 : 0;
     const int nb = (int)blocks.size();
     unsigned long long* cv = out.cells_v->as<unsigned long long>();
     uint32_t* fv = out.first_row_v->as<uint32_t>();
@@ -1908,10 +1929,10 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
       }
       const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4);
       switch (kt) {
-        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv); break;
-        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv); break;
-        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv); break;
-        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv); break;
+        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip); break;
+        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip); break;
+        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip); break;
+        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip); break;
       }
       DFGPU_HIP(hipGetLastError());
       first_launch = false;

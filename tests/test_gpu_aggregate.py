@@ -556,3 +556,61 @@ def test_two_column_key_medium_cardinality_moves_rows_by_group_number(filtered):
     assert np.allclose(got.column("aw").to_numpy(), sw[order] / cnt[order], rtol=1e-12)
     if not filtered:
         assert got.column("s2").to_pylist() == (2 * sv[order]).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["u8_u8_date32", "i32_i32_with_negatives"])
+@pytest.mark.parametrize("filtered", [False, True], ids=["no_predicate", "fused_filter"])
+def test_narrow_key_columns_are_interned_through_one_packed_word(shape, filtered):
+    """2+ key columns without NULLs that fit 64 bits together are interned through their packed form (one hash and one comparison per
+    row instead of one per column) — the groups, their first-seen order and the key VALUES that come out (taken from the original
+    columns, negative ones included) are those of the column-by-column path; four updates, so the later ones intern against
+    existing groups, and the last two (small ones) go column by column against groups found through packed keys"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(5 + filtered)
+    n = 3_500_000
+    if shape == "u8_u8_date32":
+        dom = [4, 50, 60]
+        cols = {"a": pa.array(rng.integers(0, dom[0], n).astype(np.uint8) + 250), "b": pa.array((rng.integers(0, dom[1], n) * 5).astype(np.uint8)),
+                "c": pa.array((rng.integers(0, dom[2], n) + 9000).astype(np.int32), pa.date32())}
+        raw = [cols["a"].to_numpy().astype(np.int64), cols["b"].to_numpy().astype(np.int64), cols["c"].cast(pa.int32()).to_numpy().astype(np.int64)]
+    else:
+        dom = [300, 40]
+        cols = {"a": pa.array((rng.integers(0, dom[0], n) - 150).astype(np.int32) * 7_000_000), "b": pa.array((rng.integers(0, dom[1], n) - 39).astype(np.int32))}
+        raw = [cols["a"].to_numpy().astype(np.int64), cols["b"].to_numpy().astype(np.int64)]
+    names = list(cols)
+    v = rng.integers(-10**6, 10**6, n)
+    w = rng.integers(-100, 100, n).astype(np.int32)
+    table = pa.table({**cols, "v": pa.array(v), "w": pa.array(w)})
+    gb = [(col(c), c) for c in names]
+    aggs = [("sum", col("v"), "sv"), ("count", None, "cnt"), ("max", col("w"), "hi")]
+    pred = (col("w") < lit(20, pa.int32())) if filtered else None
+    a = ops.GroupedAggregate("Single", table.column_names, gb, aggs)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    for lo, hi in ((0, 1_300_000), (1_300_000, 2_500_000), (2_500_000, 3_400_000), (3_400_000, n)):      # the last two are below the packing threshold
+        a.update(DeviceTable.from_arrow(table.slice(lo, hi - lo)), pred)                                # (existing groups + rows < 2^20): column by column
+    got = a.emit().to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert stats["agg_pack_keys"]["calls"] == 2, sorted(stats)
+    keep = (w < 20) if filtered else np.ones(n, dtype=bool)
+    _, dense = np.unique(np.stack(raw, axis=1), axis=0, return_inverse=True)
+    dense = dense.reshape(-1)
+    G = int(dense.max()) + 1
+    gid = dense[keep]
+    first = np.full(G, n, dtype=np.int64)
+    np.minimum.at(first, gid, np.nonzero(keep)[0])
+    present = np.nonzero(first < n)[0]
+    order = present[np.argsort(first[present], kind="stable")]
+    rows = first[order]
+    assert got.num_rows == len(order)
+    for c in names:
+        assert got.column(c).to_pylist() == table.column(c).take(pa.array(rows)).to_pylist(), c
+    sv = np.zeros(G, dtype=np.int64); np.add.at(sv, gid, v[keep])
+    hi = np.full(G, -1000, dtype=np.int64); np.maximum.at(hi, gid, w[keep])
+    assert got.column("sv").to_pylist() == sv[order].tolist()
+    assert got.column("cnt").to_pylist() == np.bincount(gid, minlength=G)[order].tolist()
+    assert got.column("hi").to_pylist() == hi[order].tolist()
