@@ -114,10 +114,31 @@ __host__ __device__ __forceinline__ unsigned long long acc_identity(int kind) {
 
 // ------------------------------------------------------------------------------ intern
 struct InternCtx {
-  KeySet keys;       // concatenated [existing group keys ; input keys]
-  uint32_t* slots;   // representative row + 1, 0 = empty
-  uint64_t mask;     // capacity - 1
+  KeySet keys;          // concatenated [existing group keys ; input keys]
+  uint32_t* slots;      // representative row + 1, 0 = empty
+  uint64_t mask;        // capacity - 1
+  uint64_t* slot_keys;  // keyed table (below): the packed key every slot holds, KEY_EMPTY = none; null = slots are compared through their rows
 };
+
+// Keyed table: key columns without NULLs that are <= 64 bits wide TOGETHER are interned as one word — their raw bits side by side,
+// put together in registers — and the table keeps that word in the slot: a row hashes one word and compares it with the slot's,
+// without going to the representative row's columns (one dependent random load less per row, and per key column).  Equal rows <=>
+// equal words.  The one word that cannot be told from an empty slot (all ones: possible when the columns fill all 64 bits) has
+// a slot of its own past the table's end (index capacity).
+constexpr uint64_t KEY_EMPTY = ~0ull;
+__device__ __forceinline__ uint64_t packed_key(const KeySet& ks, int64_t i) {
+  uint64_t v = 0;
+  int shift = 0;
+  for (int c = 0; c < ks.n; c++) {
+    uint64_t lo, hi;
+    load_words(ks.c[c], i, lo, hi);
+    const int bits = ks.c[c].width * 8;
+    v |= (bits >= 64 ? lo : (lo & ((1ull << bits) - 1ull))) << shift;
+    shift += bits;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t packed_key_slot(uint64_t k, uint64_t mask) { return fmix64(k ^ SEED_AGG) & mask; }
 
 __device__ __forceinline__ uint64_t group_hash(const KeySet& ks, int64_t i) {
   uint64_t h = SEED_AGG;
@@ -167,6 +188,45 @@ __global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, 
     if (row_slot) row_slot[i] = (uint32_t)s;
   }
 }
+// the same over a keyed table: find or claim the slot of the row's packed key, leave the smallest row there; every live row
+// gets its slot into row_slot
+__global__ __launch_bounds__(BLOCK) void k_intern_claim_keyed(InternCtx c, int64_t n, int* overflow, const uint64_t* __restrict__ row_mask, int64_t mask_offset,
+                                                             uint32_t* __restrict__ row_slot) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (row_mask && i >= mask_offset && !bit_at(row_mask, i - mask_offset)) {
+      if (row_slot) row_slot[i] = 0xFFFFFFFFu;
+      continue;
+    }
+    const uint64_t k = packed_key(c.keys, i);
+    uint64_t s = c.mask + 1;
+    if (k != KEY_EMPTY) {
+      s = packed_key_slot(k, c.mask);
+      uint32_t steps = 0;
+      for (;;) {
+        unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&c.slot_keys[s]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == KEY_EMPTY) {
+          cur = atomicCAS(reinterpret_cast<unsigned long long*>(&c.slot_keys[s]), (unsigned long long)KEY_EMPTY, (unsigned long long)k);
+          if (cur == KEY_EMPTY) break;   // claimed
+        }
+        if (cur == k) break;
+        s = (s + 1) & c.mask;
+        if (++steps > PROBE_LIMIT) {
+          __hip_atomic_store(overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+      }
+    }
+    const uint32_t me = (uint32_t)i + 1u;
+    uint32_t old = __hip_atomic_load(&c.slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (old == 0u || me < old) {   // (0 = no row yet)
+      const uint32_t prev = atomicCAS(&c.slots[s], old, me);
+      if (prev == old) break;
+      old = prev;
+    }
+    if (row_slot) row_slot[i] = (uint32_t)s;
+  }
+}
 // table sizing from a sample: out[0] = occupied slots, out[1] = those whose representative row lies before `early`
 __global__ __launch_bounds__(BLOCK) void k_count_slots(const uint32_t* __restrict__ slots, uint64_t capacity, uint32_t early, unsigned long long* __restrict__ out) {
   unsigned long long a = 0, b = 0;
@@ -204,6 +264,13 @@ __global__ __launch_bounds__(BLOCK) void k_slot_gids(const uint32_t* __restrict_
 }
 
 __device__ __forceinline__ uint32_t lookup_gid(const InternCtx& c, const uint32_t* __restrict__ slot_gid, int64_t i) {
+  if (c.slot_keys) {
+    const uint64_t k = packed_key(c.keys, i);
+    if (k == KEY_EMPTY) return slot_gid[c.mask + 1];
+    uint64_t s = packed_key_slot(k, c.mask);
+    while (c.slot_keys[s] != k) s = (s + 1) & c.mask;
+    return slot_gid[s];
+  }
   uint64_t s = group_hash(c.keys, i) & c.mask;
   for (;;) {
     uint32_t cur = c.slots[s];
@@ -858,27 +925,11 @@ bool fusion_enabled() { return g_fusion_enabled; }
 
 // ------------------------------------------------------------------------------ host
 // GroupValues::intern over materialised key columns (hash table of representative rows)
-// several narrow key columns (no NULLs, <= 64 bits together) as ONE 64-bit key: the raw bits side by side.  Equal rows <=> equal
-// packed keys, so interning hashes one word and compares one word with the representative's instead of one per column
-__global__ __launch_bounds__(BLOCK) void k_pack_key_bits(KeySet ks, int64_t n, uint64_t* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    uint64_t v = 0;
-    int shift = 0;
-    for (int c = 0; c < ks.n; c++) {
-      uint64_t lo, hi;
-      load_words(ks.c[c], i, lo, hi);
-      const int bits = ks.c[c].width * 8;
-      v |= (bits >= 64 ? lo : (lo & ((1ull << bits) - 1ull))) << shift;
-      shift += bits;
-    }
-    out[i] = v;
-  }
-}
 struct InternResult {
   InternCtx ictx{};
   BufPtr slots, slot_gid;
   BufPtr row_slot;               // (on request) the slot of every concatenated row, 0xFFFFFFFF where the claim pass skipped it
-  BufPtr packed;                 // the keys packed into one word per row, when that is what ictx refers to
+  BufPtr slot_keys;              // keyed table: the packed key of every slot
   std::vector<Column> cat_keys;  // [existing group keys ; input keys] — referenced by ictx
   int64_t G1 = 0;
 };
@@ -915,26 +966,16 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   }
   int64_t key_bytes = 0;
   for (int g = 0; g < ngk; g++) key_bytes += total * type_width(R.cat_keys[g].field.type);
-  // 2+ narrow keys without NULLs: interned through their packed form
+  // key columns without NULLs that fit 64 bits together: a keyed table (k_intern_claim_keyed)
+  bool keyed = total >= (1 << 16) && !(std::getenv("DFGPU_AGG_PACK_KEYS") && std::getenv("DFGPU_AGG_PACK_KEYS")[0] == '0');
   {
     int bits = 0;
-    bool packable = ngk >= 2 && total >= (1 << 20) && !(std::getenv("DFGPU_AGG_PACK_KEYS") && std::getenv("DFGPU_AGG_PACK_KEYS")[0] == '0');
-    for (int g = 0; g < ngk && packable; g++) {
+    for (int g = 0; g < ngk && keyed; g++) {
       const Column& c = R.cat_keys[g];
-      packable = !c.validity && c.field.type != DFGPU_DECIMAL128 && c.field.type != DFGPU_FLOAT64 && c.field.type != DFGPU_UTF8;
+      keyed = !c.validity && c.field.type != DFGPU_DECIMAL128 && c.field.type != DFGPU_FLOAT64 && c.field.type != DFGPU_UTF8;
       bits += type_width(c.field.type) * 8;
     }
-    if (packable && bits <= 64) {
-      R.packed = make_buf((size_t)total * 8);
-      {
-        ProfileScope ps("agg_pack_keys", key_bytes + total * 8);
-        k_pack_key_bits<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx.keys, total, R.packed->as<uint64_t>());
-        DFGPU_HIP(hipGetLastError());
-      }
-      ictx.keys.n = 1;
-      ictx.keys.c[0] = KeyCol{R.packed->ptr, nullptr, DFGPU_UINT64, 8};
-      key_bytes = total * 8;
-    }
+    keyed = keyed && bits <= 64;
   }
   BufPtr flag = make_zero_buf(4);
   uint64_t cap = (uint64_t)A.capacity_hint;
@@ -952,7 +993,7 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
     } else if (!row_mask) {
       BufPtr sslots = make_zero_buf((size_t)(2 * SAMPLE) * 4);
       BufPtr cnt = make_zero_buf(16);
-      InternCtx sc = ictx;
+      InternCtx sc = ictx;   // (the sample goes through the column-by-column table whatever the real attempts use)
       sc.slots = sslots->as<uint32_t>();
       sc.mask = 2 * SAMPLE - 1;
       {
@@ -973,13 +1014,20 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   }
   if (cap > cap_max) cap = cap_max;
   for (;;) {
-    R.slots = make_zero_buf(cap * 4);
+    R.slots = make_zero_buf((cap + 1) * 4);   // (+ 1: the keyed table's slot for the all-ones key)
     ictx.slots = R.slots->as<uint32_t>();
     ictx.mask = cap - 1;
+    if (keyed) {
+      R.slot_keys = make_buf((cap + 1) * 8);
+      DFGPU_HIP(hipMemsetAsync(R.slot_keys->ptr, 0xFF, (cap + 1) * 8, r.stream));
+      ictx.slot_keys = R.slot_keys->as<uint64_t>();
+    }
     if (total) {
-      ProfileScope ps("agg_intern_claim", key_bytes);
+      ProfileScope ps(keyed ? "agg_intern_claim_keyed" : "agg_intern_claim", key_bytes);
       if (want_row_slots && !R.row_slot) R.row_slot = make_buf((size_t)total * 4);
-      k_intern_claim<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx, total, flag->as<int>(), row_mask, G0, R.row_slot ? R.row_slot->as<uint32_t>() : nullptr);
+      uint32_t* rs = R.row_slot ? R.row_slot->as<uint32_t>() : nullptr;
+      if (keyed) k_intern_claim_keyed<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx, total, flag->as<int>(), row_mask, G0, rs);
+      else k_intern_claim<<<grid_for(total, BLOCK), BLOCK, 0, r.stream>>>(ictx, total, flag->as<int>(), row_mask, G0, rs);
       DFGPU_HIP(hipGetLastError());
     }
     int ovf = 0;
@@ -993,12 +1041,13 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   const int64_t n_words = (total + 63) / 64;
   BufPtr rep_mask = make_zero_buf((size_t)(n_words ? n_words : 1) * 8);
   BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
-  k_mark_reps<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(R.slots->as<uint32_t>(), cap, rep_mask->as<unsigned long long>());
+  const uint64_t n_slots = cap + (keyed ? 1 : 0);
+  k_mark_reps<<<grid_for((int64_t)n_slots, BLOCK), BLOCK, 0, r.stream>>>(R.slots->as<uint32_t>(), n_slots, rep_mask->as<unsigned long long>());
   scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, total, prefix->as<uint64_t>());
   R.G1 = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
-  R.slot_gid = make_buf(cap * 4);
+  R.slot_gid = make_buf((cap + 1) * 4);
   BufPtr rep_row = make_buf((size_t)(R.G1 ? R.G1 : 1) * 8);
-  k_slot_gids<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(R.slots->as<uint32_t>(), cap, rep_mask->as<uint64_t>(), prefix->as<uint64_t>(),
+  k_slot_gids<<<grid_for((int64_t)n_slots, BLOCK), BLOCK, 0, r.stream>>>(R.slots->as<uint32_t>(), n_slots, rep_mask->as<uint64_t>(), prefix->as<uint64_t>(),
                                                                       R.slot_gid->as<uint32_t>(), rep_row->as<int64_t>());
   DFGPU_HIP(hipGetLastError());
   // new dense group key columns = representative rows (first-seen order)

@@ -562,15 +562,15 @@ def test_two_column_key_medium_cardinality_moves_rows_by_group_number(filtered):
 @pytest.mark.parametrize("shape", ["u8_u8_date32", "i32_i32_with_negatives"])
 @pytest.mark.parametrize("filtered", [False, True], ids=["no_predicate", "fused_filter"])
 def test_narrow_key_columns_are_interned_through_one_packed_word(shape, filtered):
-    """2+ key columns without NULLs that fit 64 bits together are interned through their packed form (one hash and one comparison per
-    row instead of one per column) — the groups, their first-seen order and the key VALUES that come out (taken from the original
-    columns, negative ones included) are those of the column-by-column path; four updates, so the later ones intern against
-    existing groups, and the last two (small ones) go column by column against groups found through packed keys"""
+    """key columns without NULLs that fit 64 bits together are interned through their packed form, which the table keeps in its slots
+    (one hash and one comparison per row, no trip to the representative row's columns) — the groups, their first-seen order and the key
+    VALUES that come out (taken from the original columns, negative ones included) are those of the column-by-column path; four updates, so the later ones intern against
+    existing groups, and the last (small) one goes column by column against groups found through packed keys"""
     from datafusion_amd import ops
     from datafusion_amd.expr import col, lit
     from datafusion_amd.table import DeviceTable
     rng = np.random.default_rng(5 + filtered)
-    n = 3_500_000
+    n = 3_430_000
     if shape == "u8_u8_date32":
         dom = [4, 50, 60]
         cols = {"a": pa.array(rng.integers(0, dom[0], n).astype(np.uint8) + 250), "b": pa.array((rng.integers(0, dom[1], n) * 5).astype(np.uint8)),
@@ -590,12 +590,12 @@ def test_narrow_key_columns_are_interned_through_one_packed_word(shape, filtered
     a = ops.GroupedAggregate("Single", table.column_names, gb, aggs)
     ops.profile_enable(True)
     ops.profile_reset()
-    for lo, hi in ((0, 1_300_000), (1_300_000, 2_500_000), (2_500_000, 3_400_000), (3_400_000, n)):      # the last two are below the packing threshold
-        a.update(DeviceTable.from_arrow(table.slice(lo, hi - lo)), pred)                                # (existing groups + rows < 2^20): column by column
+    for lo, hi in ((0, 1_300_000), (1_300_000, 2_500_000), (2_500_000, 3_400_000), (3_400_000, n)):      # the last one is below the threshold
+        a.update(DeviceTable.from_arrow(table.slice(lo, hi - lo)), pred)                                # (existing groups + rows < 2^16): column by column
     got = a.emit().to_arrow()
     stats = ops.profile_stats()
     ops.profile_enable(False)
-    assert stats["agg_pack_keys"]["calls"] == 2, sorted(stats)
+    assert stats["agg_intern_claim_keyed"]["calls"] == 3 and stats["agg_intern_claim"]["calls"] == 1, sorted(stats)
     keep = (w < 20) if filtered else np.ones(n, dtype=bool)
     _, dense = np.unique(np.stack(raw, axis=1), axis=0, return_inverse=True)
     dense = dense.reshape(-1)
@@ -614,3 +614,102 @@ def test_narrow_key_columns_are_interned_through_one_packed_word(shape, filtered
     assert got.column("sv").to_pylist() == sv[order].tolist()
     assert got.column("cnt").to_pylist() == np.bincount(gid, minlength=G)[order].tolist()
     assert got.column("hi").to_pylist() == hi[order].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filtered", [False, True], ids=["no_predicate", "fused_filter"])
+@pytest.mark.parametrize("keys", ["dense_int64", "two_columns"])
+def test_a_few_thousand_groups_are_accumulated_in_lds_where_the_rows_lie(keys, filtered):
+    """a key range (or a number of hash-interned groups) small enough for ONE workgroup's LDS: no row is moved — every workgroup
+    accumulates a slice of the rows in place (the fused predicate's mask read row by row, NULL predicate values dropping the row)
+    and the copies merge; groups in first-seen order, SUM / COUNT / MIN / AVG / SUM(Decimal128) as computed on the host"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(1234 + filtered)
+    n = 9_000_000
+    if keys == "dense_int64":
+        G = 5000
+        gid_all = rng.integers(0, G, n)
+        cols = {"k": pa.array(gid_all * 1 + 77)}
+        gb = [(col("k"), "k")]
+    else:
+        g2 = 60
+        G = 50 * g2
+        k1 = rng.integers(0, 50, n)
+        k2 = rng.integers(0, g2, n).astype(np.int32)
+        gid_all = k1 * g2 + k2
+        cols = {"k1": pa.array(k1 - 25), "k2": pa.array(k2)}
+        gb = [(col("k1"), "k1"), (col("k2"), "k2")]
+    v = rng.integers(-10**6, 10**6, n)
+    w = rng.integers(-100, 100, n).astype(np.int32)
+    wnull = rng.random(n) < 0.05
+    dec = rng.integers(-10**8, 10**8, n)
+    raw = np.empty((n, 2), dtype=np.int64)
+    raw[:, 0] = dec
+    raw[:, 1] = dec >> 63
+    table = pa.table({**cols, "v": pa.array(v), "w": pa.array(w, mask=wnull if filtered else None),
+                      "d": pa.Array.from_buffers(pa.decimal128(15, 2), n, [None, pa.py_buffer(raw.tobytes())])})
+    aggs = [("sum", col("v"), "sv"), ("count", None, "cnt"), ("min", col("v"), "lo"), ("avg", col("v"), "av")]
+    if keys == "two_columns":
+        aggs.append(("sum", col("d"), "sd"))           # a 128-bit sum: two cell words, its own launch beside the others
+    pred = (col("w") >= lit(-20, pa.int32())) if filtered else None
+    t = DeviceTable.from_arrow(table)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = ops.aggregate(t, gb, aggs, "Single", predicate=pred).to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert "agg_dense_accumulate_partitioned" in stats and "partition_scatter" not in stats and "agg_fused_global" not in stats, sorted(stats)
+    keep = ((w >= -20) & ~wnull) if filtered else np.ones(n, dtype=bool)
+    gid = gid_all[keep]
+    first = np.full(G, n, dtype=np.int64)
+    np.minimum.at(first, gid, np.nonzero(keep)[0])
+    present = np.nonzero(first < n)[0]
+    order = present[np.argsort(first[present], kind="stable")]
+    for c in cols:
+        assert got.column(c).to_pylist() == table.column(c).take(pa.array(first[order])).to_pylist(), c
+    sv = np.zeros(G, dtype=np.int64); np.add.at(sv, gid, v[keep])
+    cnt = np.bincount(gid, minlength=G)
+    lo = np.full(G, 2**62, dtype=np.int64); np.minimum.at(lo, gid, v[keep])
+    assert got.column("sv").to_pylist() == sv[order].tolist() and got.column("cnt").to_pylist() == cnt[order].tolist()
+    assert got.column("lo").to_pylist() == lo[order].tolist()
+    assert np.allclose(got.column("av").to_numpy(), sv[order] / cnt[order], rtol=1e-12)
+    if keys == "two_columns":
+        sd = np.zeros(G, dtype=np.int64); np.add.at(sd, gid, dec[keep])
+        assert [int(x.scaleb(2)) for x in got.column("sd").to_pylist()] == sd[order].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streamed", [False, True], ids=["one_update", "three_updates"])
+def test_the_packed_key_of_all_ones_has_a_slot_of_its_own(streamed):
+    """(Int32 -1, Int32 -1) packs to the one 64-bit word an empty slot of the keyed table holds: its group lives in a slot past the
+    table's end — it is found, counted once, and keeps its place in the first-seen order"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(2)
+    n = 300_000
+    a = rng.integers(-1, 2, n).astype(np.int32)
+    b = (rng.integers(-1, 3, n) * np.where(rng.random(n) < 0.5, 1, 7)).astype(np.int32)
+    a[:5] = [3, 3, -1, 3, -1]
+    b[:5] = [3, 3, -1, 3, -1]               # (-1, -1) is the second group seen
+    v = rng.integers(-1000, 1000, n)
+    table = pa.table({"a": pa.array(a), "b": pa.array(b), "v": pa.array(v)})
+    agg = ops.GroupedAggregate("Single", table.column_names, [(col("a"), "a"), (col("b"), "b")], [("sum", col("v"), "sv"), ("count", None, "cnt")])
+    ops.profile_enable(True)
+    ops.profile_reset()
+    for lo, hi in (((0, 100_000), (100_000, 200_000), (200_000, n)) if streamed else ((0, n),)):
+        agg.update(DeviceTable.from_arrow(table.slice(lo, hi - lo)))
+    got = agg.emit().to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert "agg_intern_claim_keyed" in stats and "agg_intern_claim" not in stats, sorted(stats)
+    want = {}
+    for x, y, z in zip(a.tolist(), b.tolist(), v.tolist()):
+        e = want.setdefault((x, y), [0, 0])
+        e[0] += z
+        e[1] += 1
+    assert list(zip(got.column("a").to_pylist(), got.column("b").to_pylist())) == list(want)           # dict order = first-seen order
+    assert list(want)[1] == (-1, -1)
+    assert got.column("sv").to_pylist() == [e[0] for e in want.values()] and got.column("cnt").to_pylist() == [e[1] for e in want.values()]
