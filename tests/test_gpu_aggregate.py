@@ -713,3 +713,33 @@ def test_the_packed_key_of_all_ones_has_a_slot_of_its_own(streamed):
     assert list(zip(got.column("a").to_pylist(), got.column("b").to_pylist())) == list(want)           # dict order = first-seen order
     assert list(want)[1] == (-1, -1)
     assert got.column("sv").to_pylist() == [e[0] for e in want.values()] and got.column("cnt").to_pylist() == [e[1] for e in want.values()]
+
+
+@pytest.mark.gpu
+def test_keyed_table_sized_from_a_misleading_sample_overflows_and_is_rebuilt_larger():
+    """the first million rows carry 1000 distinct (a, b) keys — the table is sized for a few thousand groups — and the rows after them
+    300 K more: the claim pass reports the table too full, it is rebuilt 16 x larger, and the groups, their first-seen order and
+    their counts / sums are those computed on the host"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(99)
+    n, head = 6_000_000, 2_000_000
+    a = np.concatenate([rng.integers(0, 50, head), rng.integers(0, 600, n - head)]).astype(np.int32)
+    b = np.concatenate([rng.integers(0, 20, head), rng.integers(0, 500, n - head)]).astype(np.int32) - 3
+    v = rng.integers(-1000, 1000, n)
+    t = DeviceTable.from_arrow(pa.table({"a": pa.array(a), "b": pa.array(b), "v": pa.array(v)}))
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = ops.aggregate(t, [(col("a"), "a"), (col("b"), "b")], [("sum", col("v"), "sv"), ("count", None, "cnt")], "Single").to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert stats["agg_intern_claim_keyed"]["calls"] >= 2, sorted(stats)
+    key = a.astype(np.int64) * 1000 + (b + 3)
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")
+    assert got.num_rows == len(uniq) > 250_000
+    assert got.column("a").to_pylist() == a[first[order]].tolist() and got.column("b").to_pylist() == b[first[order]].tolist()
+    sv = np.zeros(len(uniq), dtype=np.int64); np.add.at(sv, inv.reshape(-1), v)
+    assert got.column("sv").to_pylist() == sv[order].tolist()
+    assert got.column("cnt").to_pylist() == np.bincount(inv.reshape(-1), minlength=len(uniq))[order].tolist()
