@@ -52,6 +52,7 @@ struct AccDesc {
   uint32_t* seen;              // [ngroups] non-null value seen (NullState)
   int kind;                    // AccKind
   int val;                     // ValKind
+  int narrow;                  // the values fit 64 bits (their high word is the sign): a partial 128-bit sum may keep a 32-bit high word
 };
 struct AccSet {
   AccDesc a[MAX_AGGS];
@@ -1730,16 +1731,20 @@ constexpr int PART_ACC_MAX = 16;
 struct PartAcc {
   int kind;          // AccKind
   int cell;          // first cell word among the node's global cells
-  int lcell;         // first cell word among this launch's LDS cells
+  int lcell;         // first 64-bit cell word among this launch's LDS cells
   int val;           // ValKind of the moved argument column (unused for the counts)
   const void* data;  // the moved argument column (partition-major), null for COUNT / COUNT(*)
+  int lcell32;       // 32-bit LDS word: a count (a workgroup sees < 2^32 rows), the high word of a 128-bit sum of `narrow` values
+  int narrow;        // 128-bit sum of values that fit 64 bits: LDS keeps {64-bit low word, 32-bit high word = negative rows and carries}
 };
 struct PartAccSet {   // the accumulators of ONE launch: as many as fit LDS beside the window's first rows
   PartAcc a[PART_ACC_MAX];
   int n;
-  int ncw;            // LDS cell words per value in this launch
+  int ncw;            // 64-bit LDS cell words per value in this launch
+  int n32;            // 32-bit LDS words per value
   int track_first;    // this launch also tracks first rows / seen flags (the first one does)
 };
+__host__ __device__ __forceinline__ bool part_acc_is_count(int kind) { return kind == ACC_COUNT || kind == ACC_COUNT_STAR; }
 struct PartBlock {
   int64_t begin, end;  // rows of the window order
   int32_t part;        // window number
@@ -1755,14 +1760,17 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
   extern __shared__ unsigned long long s_mem[];
   const int W = 1 << wshift;
   unsigned long long* s_cell = s_mem;                                   // [ncw][W]
-  uint32_t* s_first = reinterpret_cast<uint32_t*>(s_mem + (size_t)accs.ncw * W);  // [W]
+  uint32_t* s_c32 = reinterpret_cast<uint32_t*>(s_mem + (size_t)accs.ncw * W);   // [n32][W]
+  uint32_t* s_first = s_c32 + (size_t)accs.n32 * W;                      // [W]
   const PartBlock b = blocks[blockIdx.x];
   for (int x = threadIdx.x; x < W; x += PART_BLOCK) s_first[x] = 0xFFFFFFFFu;
   for (int k = 0; k < accs.n; k++) {
-    const unsigned long long id = acc_identity(accs.a[k].kind);
+    const PartAcc& a = accs.a[k];
+    const unsigned long long id = acc_identity(a.kind);
     for (int x = threadIdx.x; x < W; x += PART_BLOCK) {
-      s_cell[(size_t)accs.a[k].lcell * W + x] = id;
-      if (accs.a[k].kind == ACC_SUM_I128) s_cell[(size_t)(accs.a[k].lcell + 1) * W + x] = 0ull;
+      if (!part_acc_is_count(a.kind)) s_cell[(size_t)a.lcell * W + x] = id;
+      if (part_acc_is_count(a.kind) || (a.kind == ACC_SUM_I128 && a.narrow)) s_c32[(size_t)a.lcell32 * W + x] = 0u;
+      else if (a.kind == ACC_SUM_I128) s_cell[(size_t)(a.lcell + 1) * W + x] = 0ull;
     }
   }
   __syncthreads();
@@ -1778,13 +1786,23 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
     else s_first[x] = 0u;   // (no first rows wanted: a mark that the value has a row — a plain store, every writer's the same)
     for (int k = 0; k < accs.n; k++) {
       const PartAcc& a = accs.a[k];
+      if (part_acc_is_count(a.kind)) {
+        atomicAdd(&s_c32[(size_t)a.lcell32 * W + x], 1u);
+        continue;
+      }
       unsigned long long* c = s_cell + (size_t)a.lcell * W + x;
       uint64_t lo = 0, hi = 0;
-      if (a.data && a.kind != ACC_COUNT) {
+      if (a.data) {
         AccDesc d{};
         d.values = a.data;
         d.val = a.val;
         load_value(d, i, lo, hi);
+      }
+      if (a.kind == ACC_SUM_I128 && a.narrow) {   // the high word is 0 or -1: what the LDS keeps of it is 32 bits wide
+        const unsigned long long old = atomicAdd(c, (unsigned long long)lo);
+        const int32_t h = (int32_t)(uint32_t)hi + ((old + lo) < old ? 1 : 0);
+        if (h) atomicAdd(&s_c32[(size_t)a.lcell32 * W + x], (uint32_t)h);
+        continue;
       }
       accumulate_cell(a.kind, c, c + W, lo, hi);   // (LDS cells)
     }
@@ -1796,13 +1814,20 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
     const unsigned long long idx = base + (unsigned)x;
     if (idx >= vrange) continue;
     const uint32_t fr = s_first[x];
+    // the workgroup's total of accumulator k for this value as 64-bit words (the 32-bit LDS words widened)
+    auto total_lo = [&](const PartAcc& a) -> unsigned long long {
+      return part_acc_is_count(a.kind) ? (unsigned long long)s_c32[(size_t)a.lcell32 * W + x] : s_cell[(size_t)a.lcell * W + x];
+    };
+    auto total_hi = [&](const PartAcc& a) -> unsigned long long {
+      return a.narrow ? (unsigned long long)(long long)(int32_t)s_c32[(size_t)a.lcell32 * W + x] : s_cell[(size_t)(a.lcell + 1) * W + x];
+    };
     if (b.alone) {   // the window's only workgroup: its values belong to nobody else — plain, coalesced stores
       if (accs.track_first) first_row_v[idx] = fr;
       if (fr != 0xFFFFFFFFu)
         for (int k = 0; k < accs.n; k++) {
           const PartAcc& a = accs.a[k];
-          cells_v[(int64_t)a.cell * vstride + (int64_t)idx] = s_cell[(size_t)a.lcell * W + x];
-          if (a.kind == ACC_SUM_I128) cells_v[(int64_t)(a.cell + 1) * vstride + (int64_t)idx] = s_cell[(size_t)(a.lcell + 1) * W + x];
+          cells_v[(int64_t)a.cell * vstride + (int64_t)idx] = total_lo(a);
+          if (a.kind == ACC_SUM_I128) cells_v[(int64_t)(a.cell + 1) * vstride + (int64_t)idx] = total_hi(a);
         }
       continue;
     }
@@ -1810,12 +1835,13 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
     if (accs.track_first && fr < first_row_v[idx]) atomicMin(first_row_v + idx, fr);
     for (int k = 0; k < accs.n; k++) {
       const PartAcc& a = accs.a[k];
-      const unsigned long long v = s_cell[(size_t)a.lcell * W + x];
+      const unsigned long long v = total_lo(a);
       unsigned long long* c = cells_v + (int64_t)a.cell * vstride + (int64_t)idx;
       switch (a.kind) {
         case ACC_SUM_I128: {
           const unsigned long long old = atomicAdd(c, v);
-          atomicAdd(c + vstride, s_cell[(size_t)(a.lcell + 1) * W + x] + ((old + v) < old ? 1ull : 0ull));
+          const unsigned long long h = total_hi(a) + ((old + v) < old ? 1ull : 0ull);
+          if (h) atomicAdd(c + vstride, h);
           break;
         }
         case ACC_SUM_F64: atomicAdd(reinterpret_cast<double*>(c), __longlong_as_double((long long)v)); break;
@@ -1928,7 +1954,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   }
   const int64_t n_windows = (int64_t)((range - 1) >> wshift) + 1;
   const size_t W = (size_t)1 << wshift;
-  const int words_per_launch = (int)std::min<size_t>((LDS_BUDGET / W - 4) / 8, 64);
+  const size_t bytes_per_value = LDS_BUDGET / W - 4;   // of LDS, beside the first row
   // more than 64 KB of dynamic LDS has to be asked for, per kernel
   {
     const void* fn = nullptr;
@@ -2056,15 +2082,20 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
       PartAccSet ps{};
       ps.track_first = first_launch ? 1 : 0;
       while (u < all.size() && ps.n < PART_ACC_MAX) {
-        const int need = all[u].kind == ACC_SUM_I128 ? 2 : 1;
-        if (ps.ncw + need > words_per_launch) break;
+        const bool count = part_acc_is_count(all[u].kind), wide = all[u].kind == ACC_SUM_I128;
+        const int need64 = count ? 0 : (wide && !all[u].narrow) ? 2 : 1;
+        const int need32 = count || (wide && all[u].narrow) ? 1 : 0;
+        if (8 * (size_t)(ps.ncw + need64) + 4 * (size_t)(ps.n32 + need32) > bytes_per_value) break;
         ps.a[ps.n] = all[u];
         ps.a[ps.n].lcell = ps.ncw;
-        ps.ncw += need;
+        ps.a[ps.n].lcell32 = ps.n32;
+        ps.ncw += need64;
+        ps.n32 += need32;
         ps.n++;
         u++;
       }
-      const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4);
+      DFGPU_CHECK(ps.n > 0, "partitioned aggregation: an accumulator does not fit the window");
+      const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4 * (size_t)ps.n32 + 4);
       switch (kt) {
         case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
         case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
@@ -2093,13 +2124,15 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
   std::vector<Column> evaluated;   // argument expressions evaluated for this call (alive until the rows have been moved)
   for (size_t u = 0; u < accs.size(); u++) {
     const int kind = accs[u].kind;
-    all[u] = PartAcc{kind, accs[u].cell, 0, acc_val[u], nullptr};
+    all[u] = PartAcc{kind, accs[u].cell, 0, acc_val[u], nullptr, 0, 0};
     if (kind == ACC_COUNT_STAR) continue;
     const int c = acc_col[u];
+    auto narrow = [&](const Column& v) { return acc_val[u] != VAL_I128 || (v.field.type == DFGPU_DECIMAL128 && v.field.precision <= 18) ? 1 : 0; };
     if (c >= 0 && c < (int)in.cols.size()) {
       const Column& col = in.cols[(size_t)c];
       if (col.validity || col.dict) return false;
       all[u].data = col.ptr();
+      all[u].narrow = narrow(col);
       continue;
     }
     // an expression (Q15's l_extendedprice * (1 - l_discount)): evaluated column-at-a-time first — a streaming pass, where the
@@ -2112,12 +2145,14 @@ static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, co
       if (acc_agg[q] == acc_agg[u] && acc_col[q] == c && all[q].data) found = (int)q;   // (AVG: sum and count share the argument)
     if (found >= 0) {
       all[u].data = all[(size_t)found].data;
+      all[u].narrow = all[(size_t)found].narrow;
       continue;
     }
     dfgpu_expr e{a.nodes.data(), (int)a.nodes.size(), a.root};
     Column v = datum_to_column(evaluate(e, in), in.nrows, a.name);
     if (v.validity || v.dict || v.field.type == DFGPU_BOOL || v.field.type == DFGPU_UTF8) return false;
     all[u].data = v.ptr();
+    all[u].narrow = narrow(v);
     evaluated.push_back(std::move(v));
   }
   // a FilterExec fused below the aggregate: its mask (false and NULL drop the row) decides which rows are moved at all
@@ -2188,7 +2223,7 @@ static bool general_accumulate_partitioned(const InternCtx& ictx, const uint32_t
   for (int k = 0; k < accs.n; k++) {
     const AccDesc& d = accs.a[k];
     if (d.valid && d.kind != ACC_COUNT_STAR) return false;   // NULL arguments: the row-at-a-time kernels
-    all[(size_t)k] = PartAcc{d.kind, ncw, 0, d.val, d.kind == ACC_COUNT_STAR ? nullptr : d.values};
+    all[(size_t)k] = PartAcc{d.kind, ncw, 0, d.val, d.kind == ACC_COUNT_STAR ? nullptr : d.values, 0, d.narrow};
     m.a[m.n++] = MergeAcc{d.acc_lo, d.acc_hi, d.seen, d.kind, ncw};
     ncw += d.kind == ACC_SUM_I128 ? 2 : 1;
   }
@@ -2244,6 +2279,7 @@ static bool fused_general_partitioned(Aggregate& A, const Table& in, const std::
       }
       if (v.validity || v.dict || v.field.type == DFGPU_BOOL || v.field.type == DFGPU_UTF8) return false;
       d.values = v.ptr();
+      d.narrow = d.val != VAL_I128 || (v.field.type == DFGPU_DECIMAL128 && v.field.precision <= 18) ? 1 : 0;
       keep.push_back(std::move(v));
     }
     d.acc_lo = a.lo->as<unsigned long long>();
@@ -3494,6 +3530,7 @@ static void agg_update_unfused(Aggregate& A, const Table& in) {
     d.val = p.val;
     d.values = inputs[k].has_v ? inputs[k].v.ptr() : nullptr;
     d.valid = inputs[k].has_v ? inputs[k].v.valid_words() : nullptr;
+    d.narrow = inputs[k].has_v && (p.val != VAL_I128 || (inputs[k].v.field.type == DFGPU_DECIMAL128 && inputs[k].v.field.precision <= 18)) ? 1 : 0;
     d.acc_lo = a.lo->as<unsigned long long>();
     d.acc_hi = a.hi ? a.hi->as<unsigned long long>() : nullptr;
     d.seen = a.seen->as<uint32_t>();
