@@ -219,7 +219,10 @@ __global__ __launch_bounds__(BLOCK) void k_intern_claim(InternCtx c, int64_t n, 
 // both are settled by the compare-and-swap that follows), and a thread works on U rows whose keys, then whose slots, are in flight
 // together.  Measured over 600 M rows x (u8, u8, date32), 3817 groups: key and row in separate arrays read by atomic loads, one row
 // at a time 7.1 ms; the same four rows at a time with their loads one after the other 9.2 ms; a table of the met keys in every
-// workgroup's LDS (a row then costs LDS probes only) 7.1 - 8.1 ms — random LDS accesses cost ~55 clocks per wave and CU.
+// workgroup's LDS (a row then costs LDS probes only) 7.1 - 8.1 ms — slow for its structure (one 1024-thread workgroup per CU, three
+// barriers per 8 K rows), not for LDS: a random LDS read costs 10 - 27 clocks per wave and CU, a random L2 hit ~120
+// (scripts/microbench/random_access.hip, profiles/r3_random_access.md).  By those numbers this pass's random read is worth 2.3 ms of
+// its 6.5: the rest is the chain of dependent round trips a thread waits for (the key columns one after the other, then the slot).
 __device__ __forceinline__ void keyed_load(const KeyedSlot* t, uint64_t s, uint64_t& key, uint32_t& row) {
   const uint4 e = *reinterpret_cast<const uint4*>(t + s);
   key = (uint64_t)e.x | ((uint64_t)e.y << 32);
@@ -1077,7 +1080,9 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
       const double d_all = (double)c2[0], d_early = (double)c2[1];
       const double est = d_all < 1.25 * d_early ? 2.0 * d_all : d_all / (double)SAMPLE * (double)total;
       // (a table sized down to ~4 slots per key when the sample has seen them all — 16 K slots instead of 64 K for 3817 groups — was
-      // tried for the sake of cache hits on the rows' random accesses: the claim pass got slower, 6.6 -> 8.0 ms over 600 M rows)
+      // tried for the sake of cache hits on the rows' random accesses: 6.6 -> 8.0 ms over 600 M rows, but measured on a box whose
+      // whole test run was 3 x slower than the others'; by profiles/r3_random_access.md a 256 KB table should cost no more than a
+      // 1 MB one — to be measured again)
       uint64_t want = 1 << 16;
       while ((double)want < 3.0 * est && want < cap_max) want <<= 1;
       cap = std::max<uint64_t>(cap, want);
