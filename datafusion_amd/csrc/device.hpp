@@ -182,8 +182,10 @@ __device__ __forceinline__ uint64_t hash_row(const KeySet& ks, int64_t i, uint64
   }
   return h;
 }
-// equal_rows_arr (joins/utils.rs:2191-2260)
-__device__ __forceinline__ bool keys_equal(const KeySet& a, int64_t ia, const KeySet& b, int64_t ib, bool null_equals_null) {
+// equal_rows_arr (joins/utils.rs:2191-2260).  `float_total_order`: the join compares Float64 keys with arrow-ord's eq — IEEE 754
+// totalOrder equality, i.e. equality of the bit patterns: -0.0 and +0.0 are different keys (they still hash alike) —
+// which is what the oracle restates (dforacle.c keys_equal)
+__device__ __forceinline__ bool keys_equal(const KeySet& a, int64_t ia, const KeySet& b, int64_t ib, bool null_equals_null, bool float_total_order = false) {
   for (int c = 0; c < a.n; c++) {
     bool va = !a.c[c].valid || bit_at(a.c[c].valid, ia);
     bool vb = !b.c[c].valid || bit_at(b.c[c].valid, ib);
@@ -194,6 +196,10 @@ __device__ __forceinline__ bool keys_equal(const KeySet& a, int64_t ia, const Ke
     uint64_t alo, ahi, blo, bhi;
     load_words(a.c[c], ia, alo, ahi);
     load_words(b.c[c], ib, blo, bhi);
+    if (float_total_order && a.c[c].type == 4) {
+      alo = ((const uint64_t*)a.c[c].data)[ia];
+      blo = ((const uint64_t*)b.c[c].data)[ib];
+    }
     if (alo != blo || ahi != bhi) return false;
   }
   return true;

@@ -37,7 +37,25 @@ namespace dfgpu {
 Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_t* mask, const uint64_t* mask_valid);
 void pack_bytes_to_bitmap(const uint8_t* bytes, int64_t n, uint64_t* words);
 
-enum TableKind : int { KIND_HASH = 0, KIND_ARRAY = 1, KIND_RANK = 2, KIND_RADIX = 3 };
+enum TableKind : int { KIND_HASH = 0, KIND_ARRAY = 1, KIND_RANK = 2, KIND_RADIX = 3, KIND_FLAT = 4, KIND_FLAT16 = 5 };
+template <int KIND> constexpr bool kind_is_flat() { return KIND == KIND_FLAT || KIND == KIND_FLAT16; }
+template <int KIND> constexpr bool kind_is_direct() { return KIND == KIND_ARRAY || KIND == KIND_RANK; }
+
+// Flat table (round 4): the general hash table with the KEYS INLINE.  JoinHashMap (joins/join_hash_map.rs:144-338) keeps
+// (hash, first row) per slot and re-checks candidates on the key columns (equal_rows_arr, joins/utils.rs:2191-2260): on the GPU
+// that is a chain of dependent random accesses per probe row — slot, next[], then one line per key column of the build side
+// (profiles/r3_join_shapes_v2.md: two-column key, 1 M x 60 M rows: 5.5 ms per pass, 1.6 % of peak).  When the key columns of a row
+// pack into 16 bytes (any mix of integer / date / Float64 / Decimal128 columns, plus one bit per nullable column under NULL == NULL)
+// a slot holds the packed key itself and the first build row with that key: ONE 16- or 32-byte access answers "is the key there,
+// and which row", equal packed keys ARE equal keys (no re-check), rows with the same key chain through next[] exactly as in
+// JoinHashMap.  Open addressing, linear probing, load <= 0.5, slot = top bits of the hash (so that a range of hashes is a range
+// of slots: what a grouped probe wants).
+struct FlatLayout {
+  int n;                       // key columns
+  uint8_t off[MAX_KEYS];       // byte offset of column i inside the packed key
+  uint8_t width[MAX_KEYS];     // its bytes
+  int8_t null_bit[MAX_KEYS];   // bit of the packed key that says "column i is NULL" (NULL == NULL over a nullable build column), -1 = none
+};
 constexpr double RANK_MAP_MIN_KEY_DENSITY = 1.0 / 256.0;  // 64 B of bitmap + directory per build row at the limit
 
 struct JoinTable {
@@ -60,6 +78,10 @@ struct JoinTable {
   // "is the key there" (no build column in the output: SELECT l.k ... JOIN, semi / anti joins) never touches it
   bool rank_needs_perm = false;
   std::shared_ptr<RadixTable> radix;  // KIND_RADIX: build records partitioned for the LDS join (radix_join.hip)
+  BufPtr flat;                        // KIND_FLAT / KIND_FLAT16: uint4 {key, first row + 1, 0} per slot (two uint4 for 16-byte keys)
+  FlatLayout flat_layout{};
+  int flat_shift = 0;                 // slot = hash >> flat_shift
+  uint64_t flat_mask = 0;
   BufPtr visited;  // u8 per build row, lazily allocated
   std::mutex mu;   // a join table is probed by several threads at once (CollectLeft): `visited` is made once, `info` counts under it
   // HashJoinExec::null_aware (NOT IN semantics, single key column): what JoinLeftData shares between the probe
@@ -79,6 +101,10 @@ struct ProbeCtx {
   int null_equals_null;
   int force_collisions;
   const uint64_t* row_mask;     // optional: probe rows whose bit is 0 do not exist (FilterExec fused below the probe side)
+  const uint4* flat;            // KIND_FLAT / KIND_FLAT16
+  FlatLayout flat_layout;
+  int flat_shift;
+  uint64_t flat_mask;
 };
 
 static KeySet make_keyset(const Table& t, const std::vector<int>& cols) {
@@ -369,8 +395,104 @@ __global__ __launch_bounds__(BLOCK) void k_hm_check_unique(KeySet ks, int64_t n,
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     uint32_t cur = next[i];
     while (cur) {
-      if (keys_equal(ks, i, ks, (int64_t)cur - 1, null_equals_null)) { *dup_flag = 1; break; }
+      if (keys_equal(ks, i, ks, (int64_t)cur - 1, null_equals_null, true)) { *dup_flag = 1; break; }
       cur = next[cur - 1];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------ flat table (keys inline)
+// the key columns of row i as one packed key of <= 16 bytes; false = the row has a NULL key that matches nothing
+__device__ __forceinline__ bool flat_pack(const KeySet& ks, const FlatLayout& L, int64_t i, bool null_equals_null, uint64_t& k0, uint64_t& k1) {
+  u128 k = 0;
+  for (int c = 0; c < ks.n; c++) {
+    const KeyCol& kc = ks.c[c];
+    if (kc.valid && !bit_at(kc.valid, i)) {
+      if (!null_equals_null || L.null_bit[c] < 0) return false;  // (no NULL on the build side of this column: nothing to equal)
+      k |= (u128)1 << L.null_bit[c];
+      continue;
+    }
+    uint64_t lo, hi;
+    load_words(kc, i, lo, hi);
+    if (kc.type == 4) lo = ((const uint64_t*)kc.data)[i];   // Float64 keys are equal when their bits are (arrow-ord eq = totalOrder: -0.0 != +0.0)
+    u128 v = ((u128)hi << 64) | lo;
+    if (L.width[c] < 16) v &= ((u128)1 << (8 * L.width[c])) - 1;   // sign extension of the narrow types: both sides drop it alike
+    k |= v << (8 * L.off[c]);
+  }
+  k0 = (uint64_t)k;
+  k1 = (uint64_t)(k >> 64);
+  return true;
+}
+template <bool WIDE>
+__device__ __forceinline__ uint64_t flat_hash(uint64_t k0, uint64_t k1, bool force_collisions) {
+  if (force_collisions) return 0;
+  uint64_t h = hash_u64(k0, SEED_JOIN);
+  if (WIDE) h = fmix64(k1 ^ h);
+  return h;
+}
+template <bool WIDE>
+__device__ __forceinline__ bool flat_slot_is(const uint4* __restrict__ tab, uint64_t s, uint64_t k0, uint64_t k1, uint32_t& head) {
+  if (!WIDE) {
+    const uint4 e = tab[s];
+    head = e.z;
+    return e.x == (uint32_t)k0 && e.y == (uint32_t)(k0 >> 32);
+  }
+  const uint4 a = tab[2 * s], b = tab[2 * s + 1];
+  head = b.x;
+  return a.x == (uint32_t)k0 && a.y == (uint32_t)(k0 >> 32) && a.z == (uint32_t)k1 && a.w == (uint32_t)(k1 >> 32);
+}
+// first build row + 1 with this key, 0 = none
+template <bool WIDE>
+__device__ __forceinline__ uint32_t flat_find(const uint4* __restrict__ tab, int shift, uint64_t mask, uint64_t k0, uint64_t k1, bool force_collisions) {
+  uint64_t s = flat_hash<WIDE>(k0, k1, force_collisions) >> shift;
+  for (;;) {
+    uint32_t head;
+    const bool same = flat_slot_is<WIDE>(tab, s, k0, k1, head);
+    if (head == 0) return 0u;  // an empty slot ends the run of its hash neighbourhood
+    if (same) return head;
+    s = (s + 1) & mask;
+  }
+}
+// build, pass 1: every key claims ONE slot with the row that gets there first (a 4-byte CAS; the slot's key is read from that
+// row's key columns — immutable input — so nobody ever waits for another thread's stores); later rows with the same key push
+// themselves behind the owner: next[owner] -> newest -> ... -> 0 (LIFO like JoinHashMap's chains; order among equal keys is
+// unobserved by contract)
+template <bool WIDE>
+__global__ __launch_bounds__(BLOCK) void k_flat_claim(KeySet ks, FlatLayout L, int64_t n, int null_equals_null, int force_collisions, int shift, uint64_t mask,
+                                                      uint32_t* __restrict__ owner, uint32_t* __restrict__ next, int* __restrict__ dup_flag) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint64_t k0, k1;
+    if (!flat_pack(ks, L, i, null_equals_null != 0, k0, k1)) continue;
+    uint64_t s = flat_hash<WIDE>(k0, k1, force_collisions != 0) >> shift;
+    for (;;) {
+      uint32_t o = __hip_atomic_load(&owner[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (o == 0) {
+        o = atomicCAS(&owner[s], 0u, (uint32_t)i + 1u);
+        if (o == 0) break;  // ours
+      }
+      uint64_t q0, q1;
+      flat_pack(ks, L, (int64_t)o - 1, null_equals_null != 0, q0, q1);
+      if (q0 == k0 && (!WIDE || q1 == k1)) {
+        next[i] = atomicExch(&next[o - 1], (uint32_t)i + 1u);
+        *dup_flag = 1;
+        break;
+      }
+      s = (s + 1) & mask;
+    }
+  }
+}
+// build, pass 2: the owners' keys move into the slots
+template <bool WIDE>
+__global__ __launch_bounds__(BLOCK) void k_flat_fill(KeySet ks, FlatLayout L, int64_t cap, int null_equals_null, const uint32_t* __restrict__ owner, uint4* __restrict__ tab) {
+  for (int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x; s < cap; s += (int64_t)gridDim.x * BLOCK) {
+    const uint32_t o = owner[s];
+    uint64_t k0 = 0, k1 = 0;
+    if (o) flat_pack(ks, L, (int64_t)o - 1, null_equals_null != 0, k0, k1);
+    if (!WIDE) {
+      tab[s] = make_uint4((uint32_t)k0, (uint32_t)(k0 >> 32), o, 0u);
+    } else {
+      tab[2 * s] = make_uint4((uint32_t)k0, (uint32_t)(k0 >> 32), (uint32_t)k1, (uint32_t)(k1 >> 32));
+      tab[2 * s + 1] = make_uint4(o, 0u, 0u, 0u);
     }
   }
 }
@@ -378,7 +500,11 @@ __global__ __launch_bounds__(BLOCK) void k_hm_check_unique(KeySet ks, int64_t n,
 // ------------------------------------------------------------------------ probe kernels
 template <int KIND>
 __device__ __forceinline__ uint32_t chain_head(const ProbeCtx& c, int64_t p) {
-  if (KIND != KIND_HASH) {
+  if (kind_is_flat<KIND>()) {
+    uint64_t k0, k1;
+    if (!flat_pack(c.pkeys, c.flat_layout, p, c.null_equals_null != 0, k0, k1)) return 0u;
+    return flat_find<KIND == KIND_FLAT16>(c.flat, c.flat_shift, c.flat_mask, k0, k1, c.force_collisions != 0);
+  } else if (KIND != KIND_HASH) {
     const KeyCol& k = c.pkeys.c[0];
     if (k.valid && !bit_at(k.valid, p)) return 0;  // direct-address tables are never built with NULL==NULL + NULL build keys
     uint64_t lo, hi;
@@ -401,8 +527,8 @@ __device__ __forceinline__ uint32_t chain_head(const ProbeCtx& c, int64_t p) {
 }
 template <int KIND>
 __device__ __forceinline__ bool chain_match(const ProbeCtx& c, int64_t b, int64_t p) {
-  if (KIND != KIND_HASH) return true;  // direct addressing: same slot <=> same key
-  return keys_equal(c.bkeys, b, c.pkeys, p, c.null_equals_null);
+  if (KIND != KIND_HASH) return true;  // direct addressing / inline keys: same slot <=> same key
+  return keys_equal(c.bkeys, b, c.pkeys, p, c.null_equals_null, true);
 }
 
 // match ids (build row + 1, 0 = none) of N consecutive 64-row probe words for this lane.  Every
@@ -411,6 +537,37 @@ __device__ __forceinline__ bool chain_match(const ProbeCtx& c, int64_t b, int64_
 template <int KIND, int KT, int N>
 __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int64_t np, uint32_t (&m)[N], uint64_t* raw_keys = nullptr) {
   const unsigned lane = lane_id();
+  if (kind_is_flat<KIND>()) {
+    // the packed keys of all N words first (their column loads in flight together), then the N first slots, then whoever did not
+    // settle on its first slot walks on
+    constexpr bool WIDE = KIND == KIND_FLAT16;
+    uint64_t k0[N], k1[N], s[N];
+    bool live[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const int64_t p = ((w0 + j) << 6) + lane;
+      live[j] = p < np && (!c.row_mask || ((c.row_mask[w0 + j] >> lane) & 1ull));
+      k0[j] = k1[j] = 0;
+      live[j] = live[j] && flat_pack(c.pkeys, c.flat_layout, p, c.null_equals_null != 0, k0[j], k1[j]);
+      s[j] = flat_hash<WIDE>(k0[j], k1[j], c.force_collisions != 0) >> c.flat_shift;
+    }
+    uint32_t head[N];
+    bool same[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) same[j] = flat_slot_is<WIDE>(c.flat, s[j], k0[j], k1[j], head[j]);
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      uint64_t ss = s[j];
+      uint32_t hd = head[j];
+      bool sm = same[j];
+      while (live[j] && hd != 0 && !sm) {
+        ss = (ss + 1) & c.flat_mask;
+        sm = flat_slot_is<WIDE>(c.flat, ss, k0[j], k1[j], hd);
+      }
+      m[j] = live[j] && sm ? hd : 0u;   // (hd == 0 with sm: an empty slot compared equal to an all-zero key)
+    }
+    return;
+  }
   if (KIND == KIND_HASH) {
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -567,9 +724,11 @@ __global__ __launch_bounds__(BLOCK) void k_probe_first(ProbeCtx c, int64_t np, i
 }
 
 // pass 1, general M:N flavour: row_counts[p] = output rows of probe row p, word_counts[w] = sum
+// `row_first` (optional): the first MATCHING build row + 1 of every probe row (0 = none) — pass 2 starts its walk there instead of
+// looking the key up a second time (the lookup is the expensive part: a random line of the table per probe row)
 template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, int join_type, uint32_t* __restrict__ row_counts,
-                                                       uint32_t* __restrict__ word_counts, uint8_t* __restrict__ visited) {
+                                                       uint32_t* __restrict__ word_counts, uint8_t* __restrict__ visited, uint32_t* __restrict__ row_first = nullptr) {
   const int64_t n_words = (np + 63) >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
@@ -577,11 +736,12 @@ __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, i
     int64_t p = (w << 6) + lane_id();
     uint32_t cnt = 0;
     if (p < np) {
-      uint32_t nmatch = 0;
+      uint32_t nmatch = 0, first = 0;
       uint32_t cur = chain_head<KIND>(c, p);
       while (cur) {
         int64_t b = (int64_t)cur - 1;
         if (chain_match<KIND>(c, b, p)) {
+          if (!nmatch) first = cur;
           nmatch++;
           if (visited) visited[b] = 1;
         }
@@ -589,6 +749,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, i
       }
       cnt = out_count(join_type, nmatch);
       row_counts[p] = cnt;
+      if (row_first) row_first[p] = first;
     }
     uint32_t tot = wave_sum(cnt);
     if (lane_id() == 0) word_counts[w] = tot;
@@ -599,7 +760,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, i
 template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_probe_emit(ProbeCtx c, int64_t np, int join_type, const uint32_t* __restrict__ row_counts,
                                                       const uint64_t* __restrict__ prefix, int64_t* __restrict__ out_build,
-                                                      int64_t* __restrict__ out_probe, uint8_t* __restrict__ out_mark) {
+                                                      int64_t* __restrict__ out_probe, uint8_t* __restrict__ out_mark, const uint32_t* __restrict__ row_first = nullptr) {
   const int64_t n_words = (np + 63) >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
@@ -612,7 +773,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_emit(ProbeCtx c, int64_t np, in
     if (cnt == 0) continue;
     uint32_t nmatch = 0;
     if (emit_pairs || join_type == DFGPU_JOIN_RIGHT_MARK) {
-      uint32_t cur = chain_head<KIND>(c, p);
+      uint32_t cur = row_first ? row_first[p] : chain_head<KIND>(c, p);
       while (cur) {
         int64_t b = (int64_t)cur - 1;
         if (chain_match<KIND>(c, b, p)) {
@@ -1107,6 +1268,8 @@ static void with_kind(int kind, F&& f) {
   switch (kind) {
     case KIND_ARRAY: f(std::integral_constant<int, KIND_ARRAY>{}); break;
     case KIND_RANK: f(std::integral_constant<int, KIND_RANK>{}); break;
+    case KIND_FLAT: f(std::integral_constant<int, KIND_FLAT>{}); break;
+    case KIND_FLAT16: f(std::integral_constant<int, KIND_FLAT16>{}); break;
     default: f(std::integral_constant<int, KIND_HASH>{}); break;
   }
 }
@@ -1125,6 +1288,14 @@ template <typename F>
 static void with_kind_and_key(int kind, int probe_key_type, F&& f) {
   if (kind == KIND_HASH) {
     f(std::integral_constant<int, KIND_HASH>{}, std::integral_constant<int, KT_ANY>{});
+    return;
+  }
+  if (kind == KIND_FLAT) {
+    f(std::integral_constant<int, KIND_FLAT>{}, std::integral_constant<int, KT_ANY>{});
+    return;
+  }
+  if (kind == KIND_FLAT16) {
+    f(std::integral_constant<int, KIND_FLAT16>{}, std::integral_constant<int, KT_ANY>{});
     return;
   }
   with_key_type(probe_key_type, [&](auto kt) {
@@ -1170,6 +1341,10 @@ static ProbeCtx make_ctx(JoinTable& jt, const Table& probe, const std::vector<in
   c.am_offset = jt.am_offset;
   c.am_size = jt.am_size;
   c.hash_mask = jt.hash_mask;
+  c.flat = jt.flat ? jt.flat->as<uint4>() : nullptr;
+  c.flat_layout = jt.flat_layout;
+  c.flat_shift = jt.flat_shift;
+  c.flat_mask = jt.flat_mask;
   c.null_equals_null = jt.null_equality == DFGPU_NULL_EQUALS_NULL;
   c.force_collisions = jt.force_collisions;
   return c;
@@ -1191,6 +1366,28 @@ static int64_t null_count_of(const Column& c) {
   return tmp.null_count;
 }
 
+// do the key columns of a row pack into 16 bytes (plus one bit per nullable column when NULL == NULL)?
+static bool flat_layout_for(const KeySet& ks, bool null_equals_null, FlatLayout& L, bool& wide) {
+  L = FlatLayout{};
+  L.n = ks.n;
+  int bytes = 0, null_bits = 0;
+  for (int i = 0; i < ks.n; i++) {
+    const int w = ks.c[i].width;
+    if (w != 1 && w != 4 && w != 8 && w != 16) return false;
+    if (bytes + w > 16) return false;
+    L.off[i] = (uint8_t)bytes;
+    L.width[i] = (uint8_t)w;
+    L.null_bit[i] = -1;
+    bytes += w;
+    if (null_equals_null && ks.c[i].valid) null_bits++;
+  }
+  if (bytes * 8 + null_bits > 128) return false;
+  int bit = bytes * 8;
+  for (int i = 0; i < ks.n; i++)
+    if (null_equals_null && ks.c[i].valid) L.null_bit[i] = (int8_t)bit++;
+  wide = bit > 64;
+  return true;
+}
 static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, const std::vector<int>& key_cols, int null_equality, const dfgpu_join_options& opts,
                                                         bool speculate = true);
 // Utf8 key columns: interned on entry (ascending dictionary) into an extra column behind the caller's columns, which becomes the key —
@@ -1274,7 +1471,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       }
     }
   }
-  if (!speculated && opts.table_mode != 1 && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64) {
+  if (!speculated && opts.table_mode != 1 && opts.table_mode != 5 && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64) {
     const Column& kc = build.cols[key_cols[0]];
     bool null_block = null_equality == DFGPU_NULL_EQUALS_NULL && kc.has_nulls();
     if (!null_block && nb > 0) {
@@ -1325,6 +1522,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
 
   BufPtr flag = make_zero_buf(4);
   int dup = 0;
+  bool flat_wide = false;
   if (rank_ok) {
     const int64_t n_words = (int64_t)(range >> 6) + 1;
     jt->rank_bits = make_zero_buf((size_t)n_words * 8);
@@ -1458,7 +1656,40 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       }
     }
     jt->info.table_bytes = (int64_t)jt->am_size * 4 + (dup ? nb * 4 : 0);
+  } else if (jt->kind != KIND_RANK && opts.table_mode != 1 && flat_layout_for(ks, null_equality == DFGPU_NULL_EQUALS_NULL, jt->flat_layout, flat_wide)) {
+    // the key columns pack into 16 bytes: hash table with the keys inline (one access per probe row, no re-check)
+    jt->kind = flat_wide ? KIND_FLAT16 : KIND_FLAT;
+    dup = 0;
+    uint64_t cap = 64;
+    int log2cap = 6;
+    while (cap < (uint64_t)nb * 2) {
+      cap <<= 1;
+      log2cap++;
+    }
+    jt->flat_mask = cap - 1;
+    jt->flat_shift = 64 - log2cap;
+    jt->next = make_zero_buf((size_t)(nb ? nb : 1) * 4);
+    jt->flat = make_buf((size_t)cap * (flat_wide ? 32 : 16));
+    BufPtr owner = make_zero_buf((size_t)cap * 4);
+    int64_t kb = 0;
+    for (int i = 0; i < ks.n; i++) kb += nb * ks.c[i].width;
+    const int nen = null_equality == DFGPU_NULL_EQUALS_NULL;
+    {
+      ProfileScope ps("join_build_flat_table", kb + nb * 4 + (int64_t)cap * (flat_wide ? 32 : 16));
+      if (nb) {
+        const int g = grid_for(nb, BLOCK);
+        if (flat_wide) k_flat_claim<true><<<g, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, nb, nen, jt->force_collisions, jt->flat_shift, jt->flat_mask, owner->as<uint32_t>(), jt->next->as<uint32_t>(), flag->as<int>());
+        else k_flat_claim<false><<<g, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, nb, nen, jt->force_collisions, jt->flat_shift, jt->flat_mask, owner->as<uint32_t>(), jt->next->as<uint32_t>(), flag->as<int>());
+      }
+      const int gf = grid_for((int64_t)cap, BLOCK);
+      if (flat_wide) k_flat_fill<true><<<gf, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, (int64_t)cap, nen, owner->as<uint32_t>(), jt->flat->as<uint4>());
+      else k_flat_fill<false><<<gf, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, (int64_t)cap, nen, owner->as<uint32_t>(), jt->flat->as<uint4>());
+      DFGPU_HIP(hipGetLastError());
+    }
+    d2h(&dup, flag->ptr, 4);
+    jt->info.table_bytes = (int64_t)cap * (flat_wide ? 32 : 16) + nb * 4;
   } else if (jt->kind != KIND_RANK) {
+    DFGPU_CHECK(opts.table_mode != 5, "flat (inline-key) join table requested but the key columns do not pack into 16 bytes");
     jt->kind = KIND_HASH;
     dup = 0;
     uint64_t cap = 64;
@@ -1841,7 +2072,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       for (int k : pk) is_key |= k == c;
       if (!is_key) bytes_in += np * jc.width[jc.n];  // a key column that is also payload is read once
       static const bool keyreg = !(std::getenv("DFGPU_JOIN_KEYREG") && std::getenv("DFGPU_JOIN_KEYREG")[0] == '0');  // A/B knob
-      if (keyreg && is_key && jt.kind != KIND_HASH && pk.size() == 1 && jc.key_col < 0 && !sc.validity) jc.key_col = jc.n;
+      if (keyreg && is_key && (jt.kind == KIND_ARRAY || jt.kind == KIND_RANK) && pk.size() == 1 && jc.key_col < 0 && !sc.validity) jc.key_col = jc.n;
       bytes_per_out += jc.width[jc.n];
       jc.n++;
     }
@@ -1859,7 +2090,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>(), row_mask); };
       with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
         constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
-        constexpr bool KR = K != KIND_HASH;  // the direct-address kinds hold the one integer key in registers
+        constexpr bool KR = kind_is_direct<K>();  // the direct-address kinds hold the one integer key in registers
         if constexpr (KR) {
           if (listed) {
             const int64_t groups = (n_words + EL_WORDS - 1) / EL_WORDS;
@@ -1975,13 +2206,14 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   } else {
     // ---- general M:N path: counts -> scan -> pairs -> gathers
     BufPtr row_counts = make_buf((size_t)(np ? np : 1) * 4);
+    BufPtr row_first = make_buf((size_t)(np ? np : 1) * 4);
     BufPtr word_counts = make_buf((size_t)(n_words ? n_words : 1) * 4);
     BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
     int g = grid_for(n_words, BLOCK / WAVE);
     if (np) {
       ProfileScope ps("join_probe_count", key_bytes + np * 4);
       with_kind(jt.kind, [&](auto kt) {
-        k_probe_count<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), visited);
+        k_probe_count<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), visited, row_first->as<uint32_t>());
       });
       DFGPU_HIP(hipGetLastError());
     }
@@ -1992,7 +2224,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     if (n_out) {
       ProfileScope ps("join_probe_emit", key_bytes + np * 4 + n_out * 16);
       with_kind(jt.kind, [&](auto kt) {
-        k_probe_emit<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), ob->as<int64_t>(), op->as<int64_t>(), om ? om->as<uint8_t>() : nullptr);
+        k_probe_emit<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, join_type, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), ob->as<int64_t>(), op->as<int64_t>(), om ? om->as<uint8_t>() : nullptr, row_first->as<uint32_t>());
       });
       DFGPU_HIP(hipGetLastError());
     }
@@ -2076,17 +2308,18 @@ static Pairs key_equal_pairs(JoinTable& jt, const Table& probe, const std::vecto
   const int64_t n_words = (np + 63) / 64;
   ProbeCtx ctx = make_ctx(jt, probe, pk);
   BufPtr row_counts = make_buf((size_t)(np ? np : 1) * 4), word_counts = make_buf((size_t)(n_words ? n_words : 1) * 4);
+  BufPtr row_first = make_buf((size_t)(np ? np : 1) * 4);
   BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
   const int g = grid_for(n_words, BLOCK / WAVE);
   if (np) with_kind(jt.kind, [&](auto kt) {
-    k_probe_count<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, DFGPU_JOIN_INNER, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), nullptr);
+    k_probe_count<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, DFGPU_JOIN_INNER, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), nullptr, row_first->as<uint32_t>());
   });
   scan_u32(word_counts->as<uint32_t>(), n_words, prefix->as<uint64_t>());
   P.m = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
   P.ob = make_buf((size_t)(P.m ? P.m : 1) * 8);
   P.op = make_buf((size_t)(P.m ? P.m : 1) * 8);
   if (P.m) with_kind(jt.kind, [&](auto kt) {
-    k_probe_emit<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, DFGPU_JOIN_INNER, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), P.ob->as<int64_t>(), P.op->as<int64_t>(), nullptr);
+    k_probe_emit<decltype(kt)::value><<<g, BLOCK, 0, r.stream>>>(ctx, np, DFGPU_JOIN_INNER, row_counts->as<uint32_t>(), prefix->as<uint64_t>(), P.ob->as<int64_t>(), P.op->as<int64_t>(), nullptr, row_first->as<uint32_t>());
   });
   DFGPU_HIP(hipGetLastError());
   return P;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void k_rj_join(const uint64_t* __restrict__ 
         if (in) {
           uint32_t cur = s_head[(uint32_t)k & (RJ_HEADS - 1)];
           while (cur) {
-            if (s_key[cur - 1] == k && (EXACT || keys_equal(v.bkeys, (int64_t)s_rid[cur - 1], v.pkeys, (int64_t)pr, v.null_equals_null != 0))) cnt++;
+            if (s_key[cur - 1] == k && (EXACT || keys_equal(v.bkeys, (int64_t)s_rid[cur - 1], v.pkeys, (int64_t)pr, v.null_equals_null != 0, true))) cnt++;
             cur = s_next[cur - 1];
           }
         }
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(BLOCK) void k_rj_join(const uint64_t* __restrict__ 
         if (cnt) {
           uint32_t cur = s_head[(uint32_t)k & (RJ_HEADS - 1)];
           while (cur) {
-            if (s_key[cur - 1] == k && (EXACT || keys_equal(v.bkeys, (int64_t)s_rid[cur - 1], v.pkeys, (int64_t)pr, v.null_equals_null != 0))) {
+            if (s_key[cur - 1] == k && (EXACT || keys_equal(v.bkeys, (int64_t)s_rid[cur - 1], v.pkeys, (int64_t)pr, v.null_equals_null != 0, true))) {
               out_b[o] = (int64_t)s_rid[cur - 1];
               out_p[o] = (int64_t)pr;
               o++;

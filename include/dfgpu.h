@@ -421,7 +421,11 @@ typedef struct dfgpu_join_options {
    * 4 = LDS-staged radix-partitioned table: both sides are radix partitioned on the top bits of a mixed key until a build
    *     partition fits the LDS of one workgroup, every partition pair is joined in LDS (any key set, duplicate keys, NULL ==
    *     NULL; all join types; JoinFilter).  The output is in partition order, not probe order: for plans in which no ancestor
-   *     observes HashJoinExec's probe-side ordering (what probe_mode 4 declares). */
+   *     observes HashJoinExec's probe-side ordering (what probe_mode 4 declares);
+   * 5 = force the flat table: open addressing with the KEYS INLINE — the packed key columns (<= 16 bytes: any mix of integer /
+   *     date / Float64 / Decimal128 columns) and the first build row per slot, rows with equal keys chained behind it; one
+   *     access per probe row and no key re-check.  Error if the key columns do not pack.  `auto` takes it wherever it used
+   *     to take the chained table and the keys pack. */
   int32_t table_mode;
   /* test hook = cargo feature `force_hash_collisions` (common/src/hash_utils.rs:1186-1197):
    * every key hashes to 0 so only the key re-check (K4) keeps results right */
@@ -527,7 +531,8 @@ typedef struct dfgpu_join_info {
   int32_t build_keys_unique;
   int64_t probe_rows;  /* accumulated over probe calls */
   int64_t output_rows; /* accumulated */
-  int32_t table_kind;  /* 0 = chained hash table (JoinHashMap), 1 = ArrayMap, 2 = rank map (bitmap + popcount directory), 3 = LDS radix partitions */
+  int32_t table_kind;  /* 0 = chained hash table (JoinHashMap), 1 = ArrayMap, 2 = rank map (bitmap + popcount directory), 3 = LDS radix partitions,
+                        * 4 / 5 = flat hash table with inline keys of <= 8 / <= 16 bytes */
   int32_t build_keys_ascending; /* 1 = single integer key, strictly ascending in row order */
 } dfgpu_join_info;
 int dfgpu_join_get_info(dfgpu_join_t ht, dfgpu_join_info* out);

@@ -111,13 +111,13 @@ def main():
             best = min(times)
             b = (nb + np_ + m) * w
             kern = {k: round(v["total_ms"] / args.iters, 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
-            rec = {"case": name, "table": label, "table_kind": {0: "chained", 1: "array_map", 2: "rank_map", 3: "radix_lds"}[kind], "build_rows": nb, "probe_rows": np_,
+            rec = {"case": name, "table": label, "table_kind": {0: "chained", 1: "array_map", 2: "rank_map", 3: "radix_lds", 4: "flat8", 5: "flat16"}[kind], "build_rows": nb, "probe_rows": np_,
                    "output_rows": m, "ms": round(best * 1e3, 3), "rows_per_s": (nb + np_) / best, "algorithmic_bytes": b,
                    "algorithmic_gb_per_s": round(b / best / 1e9, 1), "hbm_frac": round(b / best / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms_per_iter": kern, "note": note}
             results.append(rec)
             print(json.dumps(rec), flush=True)
 
-    ALL = [("auto", {}), ("chained", {"table_mode": 1}), ("radix", {"table_mode": 4})]
+    ALL = [("auto", {}), ("chained", {"table_mode": 1}), ("radix", {"table_mode": 4}), ("flat", {"table_mode": 5})]
     # ---- hj.rs shapes at SF10: supplier-sized build side (100 K keys) x lineitem-sized probe side (60 M rows)
     nb, np_ = 100_000, 59_986_052
     for mult in (1, 2, 5, 10, 100):
@@ -144,11 +144,11 @@ def main():
     a, c = randint(0, 1000, 1_000_000), randint(0, 1000, 1_000_000)
     pa_, pc = randint(0, 1000, np_), randint(0, 1000, np_)
     b, p = table({"a": (a, "i32"), "c": c}), table({"a2": (pa_, "i32"), "c2": pc})
-    run_shape("two-column key (Int32, Int64) build 1M (duplicates) probe 60M", b, p, [("a", "a2"), ("c", "c2")], ALL[1:], 12)
+    run_shape("two-column key (Int32, Int64) build 1M (duplicates) probe 60M", b, p, [("a", "a2"), ("c", "c2")], ALL, 12)
     b.free()
     p.free()
     b, p = table({"k": (torch.randperm(1_000_000, generator=gen, device="cuda") * 7, "d128")}), table({"k2": (randint(0, 1_000_000, np_) * 7, "d128")})
-    run_shape("Decimal128 key build 1M probe 60M", b, p, [("k", "k2")], ALL[1:], 16)
+    run_shape("Decimal128 key build 1M probe 60M", b, p, [("k", "k2")], ALL, 16)
     b.free()
     p.free()
     if args.big:

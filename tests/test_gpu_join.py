@@ -21,8 +21,8 @@ def gpu_join(left, right, on, join_type, null_equality="NullEqualsNothing", **op
 
 # the reference runs every case with PHJ on/off (exec.rs:2929-2963); plus its force_hash_collisions CI job
 @pytest.mark.parametrize("opts", [dict(table_mode=0), dict(table_mode=1), dict(table_mode=1, force_hash_collisions=True), dict(table_mode=4),
-                                  dict(table_mode=4, force_hash_collisions=True)],
-                         ids=["phj_auto", "hash_map", "forced_collisions", "radix_lds", "radix_lds_forced_collisions"])
+                                  dict(table_mode=4, force_hash_collisions=True), dict(table_mode=5), dict(table_mode=5, force_hash_collisions=True)],
+                         ids=["phj_auto", "hash_map", "forced_collisions", "radix_lds", "radix_lds_forced_collisions", "flat", "flat_forced_collisions"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_reference_snapshots(case, opts):
     left = i32_table(case["left"]["columns"], case["left"]["data"], case["left"]["repeat"])
@@ -34,7 +34,7 @@ def test_reference_snapshots(case, opts):
 
 
 @pytest.mark.parametrize("join_type", ALL_TYPES)
-@pytest.mark.parametrize("mode", [0, 1, 4])
+@pytest.mark.parametrize("mode", [0, 1, 4, 5])
 def test_random_vs_oracle_all_join_types(join_type, mode):
     from oracle import oracle
     rng = np.random.default_rng(11)
@@ -113,10 +113,61 @@ def test_multi_column_and_decimal_keys():
     right = random_table(rng, 5000, {"a": (pa.int32(), 0, 30), "b": (pa.decimal128(15, 2), 0, 20), "w": (pa.int64(), 0, 10**9)}, null_frac=0.03)
     for jt in ("Inner", "Left", "RightSemi", "RightAnti", "Full"):
         exp = oracle.hash_join(left, right, [("a", "a"), ("b", "b")], jt)
-        for mode in (0, 4):
+        for mode in (0, 1, 4):   # (Int32, Decimal128) = 20 bytes: beyond what the flat table packs, auto = chained
             for ne in ("NullEqualsNothing", "NullEqualsNull"):
                 got = gpu_join(left, right, [("a", "a"), ("b", "b")], jt, ne, table_mode=mode)
                 assert_tables_equal(got, exp if ne == "NullEqualsNothing" else oracle.hash_join(left, right, [("a", "a"), ("b", "b")], jt, ne))
+
+
+@pytest.mark.parametrize("keys", ["i32_i64", "i32_i32", "d128", "date_u8ish_f64", "i64_i64"])
+@pytest.mark.parametrize("join_type", ALL_TYPES)
+def test_flat_table_packed_keys(keys, join_type):
+    """hash table with the keys inline (round 4): every key set that packs into 16 bytes — one or several columns, NULLs on both
+    sides under both NullEquality settings (a NULL flag per nullable column rides in the packed key), duplicates on both sides —
+    gives the oracle's rows for every JoinType, also with every hash forced to 0 (one long run of slots)"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(len(keys) * 31 + len(join_type))
+    spec = {"i32_i64": [(pa.int32(), -20, 20), (pa.int64(), -(2**40), -(2**40) + 25)], "i32_i32": [(pa.int32(), -5, 40), (pa.int32(), 0, 12)],
+            "d128": [(pa.decimal128(20, 2), -300, 300)], "date_u8ish_f64": [(pa.date32(), 9000, 9020), (pa.float64(), 0, 1)],
+            "i64_i64": [(pa.int64(), -9, 9), (pa.int64(), 2**62, 2**62 + 30)]}[keys]
+    lcols = {f"k{i}": t for i, t in enumerate(spec)}
+    rcols = {f"j{i}": t for i, t in enumerate(spec)}
+    left = random_table(rng, 2500, {**lcols, "v": (pa.int64(), 0, 10**9)}, null_frac=0.04)
+    right = random_table(rng, 6000, {**rcols, "w": (pa.decimal128(15, 2), 0, 10**6)}, null_frac=0.04)
+    if keys == "date_u8ish_f64":   # few distinct doubles, -0.0 among them (hash_utils.rs:258-276: -0.0 and +0.0 are one key)
+        vals = np.array([0.0, -0.0, 1.5, -2.25, 1e300])
+        for t, name, n in ((left, "k1", 2500), (right, "j1", 6000)):
+            arr = pa.array(vals[rng.integers(0, 5, n)], mask=rng.random(n) < 0.04)
+            t = t.set_column(t.schema.get_field_index(name), name, arr)
+            if name == "k1":
+                left = t
+            else:
+                right = t
+    on = [(f"k{i}", f"j{i}") for i in range(len(spec))]
+    assert ops.JoinHashTable(DeviceTable.from_arrow(left), [a for a, _ in on], table_mode=5).info().table_kind == (5 if keys in ("i32_i64", "d128", "i64_i64", "date_u8ish_f64") else 4)
+    for ne in ("NullEqualsNothing", "NullEqualsNull"):
+        exp = oracle.hash_join(left, right, on, join_type, ne)
+        assert_tables_equal(gpu_join(left, right, on, join_type, ne, table_mode=5), exp)
+        assert_tables_equal(gpu_join(left, right, on, join_type, ne), exp)   # auto takes the same table for these keys
+        assert_tables_equal(gpu_join(left, right, on, join_type, ne, table_mode=5, force_hash_collisions=True), exp)
+
+
+def test_flat_table_selection():
+    """auto: key columns that pack into 16 bytes get the hash table with inline keys (kinds 4 / 5), wider key sets the chained one"""
+    from datafusion_amd import _lib, ops
+    from datafusion_amd.table import DeviceTable
+    t = DeviceTable.from_arrow(pa.table({"a": pa.array([1, 2, 3, 2], type=pa.int32()), "b": pa.array([5, 6, 7, 6], type=pa.int64()),
+                                         "d": pa.array([1, 2, 3, 4], type=pa.decimal128(15, 2))}))
+    i = ops.JoinHashTable(t, ["a", "b"]).info()
+    assert (i.table_kind, i.build_keys_unique) == (5, 0)
+    assert ops.JoinHashTable(t, ["d"]).info().table_kind == 5
+    assert ops.JoinHashTable(t, ["a", "a"]).info().table_kind == 4
+    assert ops.JoinHashTable(t, ["a", "d"]).info().table_kind == 0            # 20 bytes
+    assert ops.JoinHashTable(t, ["a", "b"], table_mode=1).info().table_kind == 0
+    with pytest.raises(_lib.DfgpuError):
+        ops.JoinHashTable(t, ["a", "d"], table_mode=5)
 
 
 def test_empty_sides():
@@ -144,7 +195,7 @@ def test_array_map_gating_matches_reference_rules():
     assert ops.JoinHashTable(sparse, ["k"], min_key_density=0.001).info().used_array_map == 1
     assert ops.JoinHashTable(sparse, ["k"]).info().used_array_map == 0             # GPU default 1/64 still rejects 0.005
     neg = DeviceTable.from_arrow(pa.table({"k": pa.array([-(2**63), 2**63 - 1], type=pa.int64())}))
-    assert ops.JoinHashTable(neg, ["k"], **ref).info().table_kind == 0  # full-range overflow guard, exec.rs:6907
+    assert ops.JoinHashTable(neg, ["k"], **ref).info().table_kind == 4  # full-range overflow guard, exec.rs:6907: the hash table (keys inline)
 
 
 def test_rank_map_selection():
@@ -165,8 +216,9 @@ def test_rank_map_selection():
     with pytest.raises(_lib.DfgpuError):
         ops.JoinHashTable(dups, ["k"], table_mode=3)
     very_sparse = DeviceTable.from_arrow(pa.table({"k": pa.array(range(0, 3_000_000, 1000), type=pa.int64())}))   # density 1/1000 < 1/256
-    assert ops.JoinHashTable(very_sparse, ["k"]).info().table_kind == 0
+    assert ops.JoinHashTable(very_sparse, ["k"]).info().table_kind == 4    # hash table, keys inline
     assert ops.JoinHashTable(asc, ["k"], table_mode=1).info().table_kind == 0
+    assert ops.JoinHashTable(asc, ["k"], table_mode=5).info().table_kind == 4
     assert ops.JoinHashTable(asc, ["k"], table_mode=2).info().table_kind == 1
 
 
@@ -184,7 +236,7 @@ def test_unique_build_keys_all_table_kinds_agree(join_type, order):
     left = pa.table({"a": pa.array(keys, type=pa.int64(), mask=mask), "x": pa.array(np.arange(nb), type=pa.int32())})
     right = random_table(rng, 20_000, {"b": (pa.int64(), -900, 3 * nb), "z": (pa.float64(), 0, 1000)}, null_frac=0.05)
     exp = oracle.hash_join(left, right, [("a", "b")], join_type)
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 5):
         assert_tables_equal(gpu_join(left, right, [("a", "b")], join_type, table_mode=mode), exp)
 
 
@@ -265,8 +317,8 @@ def _filter_of(case):
 
 
 @pytest.mark.parametrize("opts", [dict(table_mode=0), dict(table_mode=1), dict(table_mode=1, force_hash_collisions=True), dict(table_mode=4),
-                                  dict(table_mode=4, force_hash_collisions=True)],
-                         ids=["phj_auto", "hash_map", "forced_collisions", "radix_lds", "radix_lds_forced_collisions"])
+                                  dict(table_mode=4, force_hash_collisions=True), dict(table_mode=5), dict(table_mode=5, force_hash_collisions=True)],
+                         ids=["phj_auto", "hash_map", "forced_collisions", "radix_lds", "radix_lds_forced_collisions", "flat", "flat_forced_collisions"])
 @pytest.mark.parametrize("case", FILTER_CASES, ids=[c["name"] for c in FILTER_CASES])
 def test_reference_snapshots_with_join_filter(case, opts):
     """the reference's join_*_with_filter tests (hash_join/exec.rs:4422-5830) through dfgpu_join_probe_with_filter"""
@@ -289,7 +341,7 @@ def test_random_join_filter_vs_oracle(join_type):
     # residual predicate over both sides with NULLs on both: left.x > right.z AND left.y != right.w
     gpu_expr = (col("f0") > col("f1")).and_(col("f2").ne(col("f3")))
     cols = [(1, "Left"), (1, "Right"), (2, "Left"), (2, "Right")]
-    for mode in (0, 1, 4):
+    for mode in (0, 1, 4, 5):
         got = gpu_join(left, right, [("a", "b")], join_type, join_filter=(gpu_expr, cols), table_mode=mode)
         exp = oracle.hash_join(left, right, [("a", "b")], join_type, join_filter=(to_oracle_expr(gpu_expr), cols))
         assert_tables_equal(got, exp)
