@@ -171,6 +171,21 @@ __device__ __forceinline__ uint64_t hash_value(const KeyCol& k, int64_t i, uint6
   if (k.type == 3) h = fmix64(hi ^ h);
   return h;
 }
+// ---- typed key access.  The generic load_words() switches on the column type per element; the
+// compiler then cannot hoist loads out of the switch arms and waits on every single one
+// (s_waitcnt vmcnt(0) after each global_load in the ISA).  Hot kernels are therefore instantiated
+// per key type so that N independent loads are issued back-to-back.
+enum KeyT : int { KT_I32 = 0, KT_U32 = 1, KT_I64 = 2, KT_U8 = 3, KT_ANY = 4 };
+template <int KT>
+__device__ __forceinline__ uint64_t load_key(const KeyCol& k, int64_t i) {
+  if (KT == KT_I32) return (uint64_t)(int64_t)((const int32_t*)k.data)[i];
+  if (KT == KT_U32) return ((const uint32_t*)k.data)[i];
+  if (KT == KT_I64) return ((const uint64_t*)k.data)[i];
+  if (KT == KT_U8) return ((const uint8_t*)k.data)[i];
+  uint64_t lo, hi;
+  load_words(k, i, lo, hi);
+  return lo;
+}
 // create_hashes semantics (hash_utils.rs:1239-1252): col 0 seeds with `seed`, col i>=1
 // re-seeds with the running hash; NULL leaves the running hash (initially 0) untouched.
 __device__ __forceinline__ uint64_t hash_row(const KeySet& ks, int64_t i, uint64_t seed, bool& any_null) {

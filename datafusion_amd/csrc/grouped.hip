@@ -1,0 +1,280 @@
+// grouped.hip — rows moved into groups of their key (round 4): the pass under every operator that has to turn random accesses
+// into cache-resident ones.
+//
+// Where it is used: a hash-join probe whose keys arrive in no order against a table beyond the caches (join.hip: the grouped
+// probe with positional return — the probe KEYS travel to the table, group by group, and what they found comes back to the
+// probe rows through `dest`), the rank-ordered copy of a shuffled build side's payload, and the key-only grouped probe.
+// The reference has no counterpart: its probe walks one table with dependent random loads (joins/join_hash_map.rs:389-484),
+// which on MI355X costs a 64-byte unit of HBM per row once the table outgrows the 4 MiB L2 of an XCD (profiles/r2_fetch_calib.md,
+// profiles/r3_random_access.md: ~50 G random lines/s against 270 G/s for L2 hits).
+//
+// Shape of the pass (two kernels, both one workgroup per CHUNK of consecutive tiles):
+//   k_gp_hist     keys -> group (LDS atomics) -> counts[group][chunk]
+//   scan          exclusive prefix over the group-major count matrix: every (group, chunk) gets its output range
+//   k_gp_scatter  per tile: keys -> group, rank inside (tile, group) by a returning LDS atomic, exclusive scan of the tile's
+//                 counts, the tile staged in LDS in group order, every group's run written contiguously (TILE / groups rows
+//                 per run: 128 bytes of keys at 8192 rows and 512 groups); `dest[row]` = where the row went; carried columns
+//                 take the same route one after the other.  The chunk keeps its running output cursors in LDS, so the count
+//                 matrix has one column per chunk (thousands), not per tile.
+// Rows whose key is NULL, masked out, or outside the table's key range take no part (dest = ~0): they can match nothing.
+// Order inside a group is arbitrary (the ranks come from atomics): callers that need the probe order get it back through `dest`.
+#include <algorithm>
+#include <cstdlib>
+
+#include "device.hpp"
+#include "internal.hpp"
+#include "grouped.hpp"
+
+namespace dfgpu {
+
+constexpr int GP_RANK_BITS = 13;   // rank inside (tile, group) < 8192
+
+__device__ __forceinline__ bool gp_row_takes_part(const KeyCol& key, const uint64_t* __restrict__ row_mask, int64_t i) {
+  bool ok = true;
+  if (key.valid) ok = (key.valid[i >> 6] >> (i & 63)) & 1ull;
+  if (row_mask) ok = ok && ((row_mask[i >> 6] >> (i & 63)) & 1ull);
+  return ok;
+}
+
+template <int KT, int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_gp_hist(KeyCol key, int64_t n, GroupSpec gs, int P, const uint64_t* __restrict__ row_mask, int tiles_per_chunk,
+                                                     int64_t n_chunks, uint32_t* __restrict__ counts) {
+  __shared__ unsigned s_cnt[GP_MAX_GROUPS];
+  constexpr int TILE = THREADS * ITEMS;
+  for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    for (int i = threadIdx.x; i < P; i += THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    const int64_t lo = chunk * (int64_t)tiles_per_chunk * TILE;
+    const int64_t hi = (lo + (int64_t)tiles_per_chunk * TILE) < n ? (lo + (int64_t)tiles_per_chunk * TILE) : n;
+    for (int64_t base = lo; base < hi; base += TILE) {
+      uint64_t k[ITEMS];
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {  // all loads of the tile in flight together
+        const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+        k[c] = load_key<KT>(key, i < hi ? i : hi - 1);
+      }
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {
+        const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+        const uint64_t idx = k[c] - gs.offset;
+        if (i < hi && idx < gs.size && gp_row_takes_part(key, row_mask, i)) atomicAdd(&s_cnt[idx >> gs.shift], 1u);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += THREADS) counts[(int64_t)i * n_chunks + chunk] = s_cnt[i];
+    __syncthreads();
+  }
+}
+
+// dynamic LDS: stage [TILE * stage_width] | group of every staged row u16 [TILE] | cnt, start, goff u32 [P each] | wave totals
+template <int KT, int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_gp_scatter(KeyCol key, int64_t n, GroupSpec gs, int P, const uint64_t* __restrict__ row_mask, int tiles_per_chunk,
+                                                        int64_t n_chunks, const uint64_t* __restrict__ offsets, uint64_t* __restrict__ out_keys,
+                                                        uint32_t* __restrict__ dest, GroupCols cols, int stage_width) {
+  extern __shared__ __align__(16) unsigned char gp_smem[];
+  constexpr int TILE = THREADS * ITEMS;
+  constexpr int NWAVE = THREADS / WAVE;
+  static_assert(TILE <= (1 << GP_RANK_BITS), "rank field too narrow");
+  unsigned char* s_stage = gp_smem;
+  uint16_t* s_g = reinterpret_cast<uint16_t*>(gp_smem + (size_t)TILE * stage_width);
+  unsigned* s_cnt = reinterpret_cast<unsigned*>(s_g + TILE);
+  unsigned* s_start = s_cnt + P;
+  unsigned* s_goff = s_start + P;
+  unsigned* s_wtot = s_goff + P;
+  const unsigned lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const int64_t lo = chunk * (int64_t)tiles_per_chunk * TILE;
+    const int64_t hi = (lo + (int64_t)tiles_per_chunk * TILE) < n ? (lo + (int64_t)tiles_per_chunk * TILE) : n;
+    for (int i = threadIdx.x; i < P; i += THREADS) {
+      s_goff[i] = (unsigned)offsets[(int64_t)i * n_chunks + chunk];
+      s_cnt[i] = 0;
+    }
+    __syncthreads();
+    uint64_t k[ITEMS], knext[ITEMS];
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int64_t i = lo + (int64_t)c * THREADS + threadIdx.x;
+      knext[c] = lo < hi ? load_key<KT>(key, i < hi ? i : hi - 1) : 0ull;
+    }
+    for (int64_t base = lo; base < hi; base += TILE) {
+      unsigned gr[ITEMS];
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) k[c] = knext[c];
+      // ---- group and rank of every row of the tile
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {
+        const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+        const uint64_t idx = k[c] - gs.offset;
+        gr[c] = 0xFFFFFFFFu;
+        if (i < hi && idx < gs.size && gp_row_takes_part(key, row_mask, i)) {
+          const unsigned g = (unsigned)(idx >> gs.shift);
+          gr[c] = (g << GP_RANK_BITS) | atomicAdd(&s_cnt[g], 1u);
+        }
+      }
+      __syncthreads();
+      // ---- exclusive scan of the tile's group counts (P <= THREADS: one group per thread)
+      {
+        const unsigned v = (int)threadIdx.x < P ? s_cnt[threadIdx.x] : 0u;
+        const unsigned inc = wave_inclusive_sum<unsigned>(v);
+        if (lane == 63) s_wtot[wave] = inc;
+        __syncthreads();
+        unsigned before = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; w++) before += w < wave ? s_wtot[w] : 0u;
+        if ((int)threadIdx.x < P) s_start[threadIdx.x] = before + inc - v;
+      }
+      __syncthreads();
+      unsigned total = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; w++) total += s_wtot[w];
+      // ---- the tile in group order: keys into LDS, every row told where it goes
+      unsigned pos[ITEMS];
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {
+        const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+        pos[c] = 0xFFFFFFFFu;
+        if (gr[c] != 0xFFFFFFFFu) {
+          const unsigned g = gr[c] >> GP_RANK_BITS, r = gr[c] & ((1u << GP_RANK_BITS) - 1u);
+          pos[c] = s_start[g] + r;
+          reinterpret_cast<uint64_t*>(s_stage)[pos[c]] = k[c];
+          s_g[pos[c]] = (uint16_t)g;
+          if (dest) dest[i] = s_goff[g] + r;
+        } else if (dest && i < hi) {
+          dest[i] = 0xFFFFFFFFu;
+        }
+      }
+      // the next tile's keys are on their way while this one is written out
+      {
+        const int64_t nb = base + TILE;
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) {
+          const int64_t i = nb + (int64_t)c * THREADS + threadIdx.x;
+          knext[c] = nb < hi ? load_key<KT>(key, i < hi ? i : hi - 1) : 0ull;
+        }
+      }
+      __syncthreads();
+      if (out_keys) {
+        for (unsigned q = threadIdx.x; q < total; q += THREADS) {
+          const unsigned g = s_g[q];
+          out_keys[(uint64_t)s_goff[g] + (q - s_start[g])] = reinterpret_cast<const uint64_t*>(s_stage)[q];
+        }
+      }
+      // ---- carried columns: the same route, one after the other through the same staging buffer
+      for (int cc = 0; cc < cols.n; cc++) {
+        __syncthreads();
+        const int w = cols.width[cc];
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) {
+          if (pos[c] == 0xFFFFFFFFu) continue;
+          const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+          switch (w) {
+            case 16: reinterpret_cast<uint4*>(s_stage)[pos[c]] = reinterpret_cast<const uint4*>(cols.src[cc])[i]; break;
+            case 8: reinterpret_cast<uint64_t*>(s_stage)[pos[c]] = reinterpret_cast<const uint64_t*>(cols.src[cc])[i]; break;
+            case 4: reinterpret_cast<uint32_t*>(s_stage)[pos[c]] = reinterpret_cast<const uint32_t*>(cols.src[cc])[i]; break;
+            default: s_stage[pos[c]] = reinterpret_cast<const uint8_t*>(cols.src[cc])[i]; break;
+          }
+        }
+        __syncthreads();
+        for (unsigned q = threadIdx.x; q < total; q += THREADS) {
+          const unsigned g = s_g[q];
+          const uint64_t d = (uint64_t)s_goff[g] + (q - s_start[g]);
+          switch (w) {
+            case 16: reinterpret_cast<uint4*>(cols.dst[cc])[d] = reinterpret_cast<const uint4*>(s_stage)[q]; break;
+            case 8: reinterpret_cast<uint64_t*>(cols.dst[cc])[d] = reinterpret_cast<const uint64_t*>(s_stage)[q]; break;
+            case 4: reinterpret_cast<uint32_t*>(cols.dst[cc])[d] = reinterpret_cast<const uint32_t*>(s_stage)[q]; break;
+            default: reinterpret_cast<uint8_t*>(cols.dst[cc])[d] = s_stage[q]; break;
+          }
+        }
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < P; i += THREADS) {
+        s_goff[i] += s_cnt[i];
+        s_cnt[i] = 0;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void k_gp_bounds(const uint64_t* __restrict__ offsets, int P, int64_t n_chunks, uint64_t* __restrict__ bounds) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= P) bounds[g] = offsets[(int64_t)g * n_chunks];
+}
+
+template <typename F>
+static void gp_with_key_type(int dfgpu_type, F&& f) {
+  switch (dfgpu_type) {
+    case DFGPU_INT32: case DFGPU_DATE32: f(std::integral_constant<int, KT_I32>{}); break;
+    case DFGPU_UINT32: f(std::integral_constant<int, KT_U32>{}); break;
+    case DFGPU_INT64: case DFGPU_UINT64: f(std::integral_constant<int, KT_I64>{}); break;
+    case DFGPU_UINT8: f(std::integral_constant<int, KT_U8>{}); break;
+    default: throw Error("group_rows_by_key: the key column is not an integer column");
+  }
+}
+
+GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs, int nbits, const uint64_t* row_mask, bool want_keys, bool want_dest,
+                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what) {
+  Runtime& r = rt();
+  DFGPU_CHECK(n > 0 && n < 0xFFFFFFFFll, "group_rows_by_key: row count out of range");
+  DFGPU_CHECK(nbits >= 1 && (1 << nbits) <= GP_MAX_GROUPS, "group_rows_by_key: bad number of groups");
+  DFGPU_CHECK(carry_src.size() == carry_width.size() && (int)carry_src.size() <= GP_MAX_COLS, "group_rows_by_key: bad carried columns");
+  DFGPU_CHECK(gs.size > 0 && ((gs.size - 1) >> gs.shift) < (1ull << nbits), "group_rows_by_key: the key range does not fit the groups");
+  const int P = 1 << nbits;
+  GroupedRows out;
+  out.P = P;
+  int stage_width = 8;
+  for (int w : carry_width) {
+    DFGPU_CHECK(w == 1 || w == 4 || w == 8 || w == 16, "group_rows_by_key: carried columns are 1, 4, 8 or 16 bytes wide");
+    stage_width = std::max(stage_width, w);
+  }
+  // 1024 threads x 8 rows: 8192-row tiles (runs of 8192 / P rows).  A 16-byte carried column needs 128 KB of staging: still one
+  // workgroup per CU, like the 8-byte case (92 KB)
+  constexpr int THREADS = 1024, ITEMS = 8, TILE = THREADS * ITEMS;
+  const int64_t n_tiles = (n + TILE - 1) / TILE;
+  // chunks: enough of them to fill the chip a few times over, few enough to keep the count matrix small
+  int tiles_per_chunk = (int)std::min<int64_t>(32, std::max<int64_t>(1, n_tiles / 2048));
+  const int64_t n_chunks = (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
+  BufPtr counts = make_buf((size_t)P * n_chunks * 4);
+  BufPtr offsets = make_buf(((size_t)P * n_chunks + 1) * 8);
+  const int grid = (int)std::min<int64_t>(n_chunks, (int64_t)r.num_cus * 4);
+  const int64_t key_bytes = n * key.width;
+  {
+    ProfileScope ps("group_rows_count", key_bytes);
+    gp_with_key_type(key.type, [&](auto kt) {
+      k_gp_hist<decltype(kt)::value, THREADS, ITEMS><<<grid, THREADS, 0, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, counts->as<uint32_t>());
+    });
+    DFGPU_HIP(hipGetLastError());
+  }
+  scan_u32(counts->as<uint32_t>(), (int64_t)P * n_chunks, offsets->as<uint64_t>());
+  out.bounds = make_buf((size_t)(P + 1) * 8);
+  k_gp_bounds<<<(P + 1 + 255) / 256, 256, 0, r.stream>>>(offsets->as<uint64_t>(), P, n_chunks, out.bounds->as<uint64_t>());
+  out.rows = (int64_t)read_u64(offsets->as<uint64_t>() + (int64_t)P * n_chunks);
+  const size_t out_rows = (size_t)std::max<int64_t>(out.rows, 1);
+  if (want_keys) out.keys = make_buf(out_rows * 8);
+  if (want_dest) out.dest = make_buf((size_t)n * 4);
+  GroupCols gc{};
+  gc.n = (int)carry_src.size();
+  int64_t moved = (want_keys ? out.rows * 8 : 0) + (want_dest ? n * 4 : 0);
+  for (int c = 0; c < gc.n; c++) {
+    out.cols.push_back(make_buf(out_rows * (size_t)carry_width[c]));
+    gc.src[c] = carry_src[c];
+    gc.dst[c] = out.cols.back()->ptr;
+    gc.width[c] = carry_width[c];
+    moved += n * carry_width[c] + out.rows * carry_width[c];
+  }
+  const size_t lds = (size_t)TILE * stage_width + (size_t)TILE * 2 + (size_t)P * 12 + (THREADS / WAVE) * 4;
+  {
+    ProfileScope ps(what ? what : "group_rows_scatter", key_bytes + moved);
+    gp_with_key_type(key.type, [&](auto kt) {
+      auto kern = k_gp_scatter<decltype(kt)::value, THREADS, ITEMS>;
+      DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      kern<<<grid, THREADS, lds, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, offsets->as<uint64_t>(),
+                                             want_keys ? out.keys->as<uint64_t>() : nullptr, want_dest ? out.dest->as<uint32_t>() : nullptr, gc, stage_width);
+    });
+    DFGPU_HIP(hipGetLastError());
+  }
+  return out;
+}
+
+}  // namespace dfgpu

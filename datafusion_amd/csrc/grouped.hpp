@@ -1,0 +1,36 @@
+// grouped.hpp — rows moved into groups of their key (grouped.hip)
+#pragma once
+#include <vector>
+
+#include "device.hpp"
+#include "internal.hpp"
+
+namespace dfgpu {
+
+// group of a key: idx = key - offset (wrapping) must be < size; group = idx >> shift
+struct GroupSpec {
+  uint64_t offset, size;
+  int shift;
+};
+constexpr int GP_MAX_GROUPS = 1024;
+constexpr int GP_MAX_COLS = 8;
+struct GroupCols {
+  const void* src[GP_MAX_COLS];
+  void* dst[GP_MAX_COLS];
+  int width[GP_MAX_COLS];
+  int n;
+};
+struct GroupedRows {
+  int P = 0;
+  int64_t rows = 0;            // rows that took part
+  BufPtr keys;                 // u64 per grouped row: the key, widened (want_keys)
+  BufPtr dest;                 // u32 per INPUT row: its position in group order, ~0 = takes no part (want_dest)
+  BufPtr bounds;               // u64 [P + 1] on the device: group g = positions bounds[g] .. bounds[g + 1]
+  std::vector<BufPtr> cols;    // carried columns in group order
+};
+// Rows of an integer key column moved into 2^nbits groups of their key's range (NULL keys, rows masked out by `row_mask` and keys
+// outside [offset, offset + size) take no part).  Order inside a group is arbitrary.
+GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs, int nbits, const uint64_t* row_mask, bool want_keys, bool want_dest,
+                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what = nullptr);
+
+}  // namespace dfgpu

@@ -31,13 +31,15 @@
 
 #include "device.hpp"
 #include "internal.hpp"
+#include "grouped.hpp"
 
 namespace dfgpu {
 
 Table compact_table(const Table& in, const std::vector<int>& cols, const uint64_t* mask, const uint64_t* mask_valid);
 void pack_bytes_to_bitmap(const uint8_t* bytes, int64_t n, uint64_t* words);
 
-enum TableKind : int { KIND_HASH = 0, KIND_ARRAY = 1, KIND_RANK = 2, KIND_RADIX = 3, KIND_FLAT = 4, KIND_FLAT16 = 5 };
+enum TableKind : int { KIND_HASH = 0, KIND_ARRAY = 1, KIND_RANK = 2, KIND_RADIX = 3, KIND_FLAT = 4, KIND_FLAT16 = 5,
+                       KIND_RETURNED = 6 };   // (6 is not a table: the probe reads what a grouped lookup found for every probe row — join_probe)
 template <int KIND> constexpr bool kind_is_flat() { return KIND == KIND_FLAT || KIND == KIND_FLAT16; }
 template <int KIND> constexpr bool kind_is_direct() { return KIND == KIND_ARRAY || KIND == KIND_RANK; }
 
@@ -78,6 +80,7 @@ struct JoinTable {
   // "is the key there" (no build column in the output: SELECT l.k ... JOIN, semi / anti joins) never touches it
   bool rank_needs_perm = false;
   std::shared_ptr<RadixTable> radix;  // KIND_RADIX: build records partitioned for the LDS join (radix_join.hip)
+  std::map<int, BufPtr> rank_payload;  // rank map over keys in no order: build column -> its copy in RANK order (ensure_rank_payload)
   BufPtr flat;                        // KIND_FLAT / KIND_FLAT16: uint4 {key, first row + 1, 0} per slot (two uint4 for 16-byte keys)
   FlatLayout flat_layout{};
   int flat_shift = 0;                 // slot = hash >> flat_shift
@@ -105,6 +108,10 @@ struct ProbeCtx {
   FlatLayout flat_layout;
   int flat_shift;
   uint64_t flat_mask;
+  // KIND_RETURNED: probe row p -> ret_dest[p] (~0: nothing looked up) -> a record of ret_R bytes whose first word is the match id
+  const uint32_t* ret_dest;
+  const uint8_t* ret_rec;
+  int ret_R;
 };
 
 static KeySet make_keyset(const Table& t, const std::vector<int>& cols) {
@@ -120,21 +127,6 @@ static KeySet make_keyset(const Table& t, const std::vector<int>& cols) {
   return ks;
 }
 
-// ---- typed key access.  The generic load_words() switches on the column type per element; the
-// compiler then cannot hoist loads out of the switch arms and waits on every single one
-// (s_waitcnt vmcnt(0) after each global_load in the ISA).  Hot kernels are therefore instantiated
-// per key type so that N independent loads are issued back-to-back.
-enum KeyT : int { KT_I32 = 0, KT_U32 = 1, KT_I64 = 2, KT_U8 = 3, KT_ANY = 4 };
-template <int KT>
-__device__ __forceinline__ uint64_t load_key(const KeyCol& k, int64_t i) {
-  if (KT == KT_I32) return (uint64_t)(int64_t)((const int32_t*)k.data)[i];
-  if (KT == KT_U32) return ((const uint32_t*)k.data)[i];
-  if (KT == KT_I64) return ((const uint64_t*)k.data)[i];
-  if (KT == KT_U8) return ((const uint8_t*)k.data)[i];
-  uint64_t lo, hi;
-  load_words(k, i, lo, hi);
-  return lo;
-}
 
 // ------------------------------------------------------------------------ build kernels
 struct MinMax {
@@ -537,6 +529,25 @@ __device__ __forceinline__ bool chain_match(const ProbeCtx& c, int64_t b, int64_
 template <int KIND, int KT, int N>
 __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int64_t np, uint32_t (&m)[N], uint64_t* raw_keys = nullptr) {
   const unsigned lane = lane_id();
+  if (KIND == KIND_RETURNED) {
+    uint32_t d[N];
+    bool ok[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const int64_t p = ((w0 + j) << 6) + lane;
+      ok[j] = p < np;
+      d[j] = c.ret_dest[ok[j] ? p : np - 1];
+      if (c.row_mask) ok[j] = ok[j] && ((c.row_mask[w0 + j] >> lane) & 1ull);
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      ok[j] = ok[j] && d[j] != 0xFFFFFFFFu;
+      m[j] = *reinterpret_cast<const uint32_t*>(c.ret_rec + (uint64_t)(ok[j] ? d[j] : 0u) * (uint64_t)c.ret_R);
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) m[j] = ok[j] ? m[j] : 0u;
+    return;
+  }
   if (kind_is_flat<KIND>()) {
     // the packed keys of all N words first (their column loads in flight together), then the N first slots, then whoever did not
     // settle on its first slot walks on
@@ -803,6 +814,8 @@ struct JoinCopyCols {
   int n;
   int key_col;  // entry that is the probe key column itself (single integer key, direct-address kinds): written from the
                 // registers the lookup loaded it into instead of being read a second time; -1 = none
+  // KIND_RETURNED: a build column is a field of the returned records — element ret_dest[p] * ret_mul + ret_add of `src` (= the records)
+  int ret_mul[MAX_JOIN_COLS], ret_add[MAX_JOIN_COLS];
 };
 template <typename T>
 __device__ __forceinline__ void jcopy(const void* src, void* dst, int64_t s, int64_t d) {
@@ -1075,7 +1088,8 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
           else reinterpret_cast<uint32_t*>(cols.dst[cidx])[d] = (uint32_t)key[KEYREG ? j : 0];
           continue;
         }
-        const int64_t s = from_build ? (int64_t)m[j] - 1 : ((w0 + j) << 6) + lane;
+        int64_t s = from_build ? (int64_t)m[j] - 1 : ((w0 + j) << 6) + lane;
+        if (KIND == KIND_RETURNED && from_build) s = (int64_t)c.ret_dest[((w0 + j) << 6) + lane] * cols.ret_mul[cidx] + cols.ret_add[cidx];
         switch (width) {
           case 16: jcopy_stream<uint4>(cols.src[cidx], cols.dst[cidx], s, d, stream, full); break;
           case 8: jcopy_stream<uint64_t>(cols.src[cidx], cols.dst[cidx], s, d, stream, full); break;
@@ -1193,6 +1207,132 @@ __global__ __launch_bounds__(BLOCK) void k_join_emit_listed(ProbeCtx c, JoinCopy
   }
 }
 
+// ---------------------------------------------------------------- grouped probe with positional return (round 4)
+// Probe keys in NO order against a rank map beyond the caches: every lookup is a 64-byte unit of HBM / Infinity Cache of its own
+// (~50 G/s), and so is every build-payload gather behind it (150 M shuffled x 600 M rows with the Q3 payload: ~24 ms).  Moving the
+// probe ROWS to the table (radix partitioning keys and payload together, the textbook GPU join) costs two passes over 40 bytes
+// per row; moving only the KEYS costs 8:
+//   1. group_rows_by_key (grouped.hip): the probe keys grouped by the top bits of their position in the table's key range, 2^9
+//      groups or so, every probe row told where its key went (`dest`);
+//   2. k_gp_lookup: group by group — a group's slice of the table and of the build payload is a few MB, and all workgroups of
+//      an XCD walk the groups in the same order, so the slice is fetched into that XCD's L2 once — every key is looked up and what
+//      it found (match id + the build columns of the output) is left as one record per key, in group order;
+//   3. the ordinary fused probe in PROBE order with KIND_RETURNED as its "table": row p reads record dest[p].  Rows of one
+//      (tile, group) run share lines, so these reads are L2 hits, not HBM lines.  Output in probe order: every probe_mode is served.
+// The build payload has to be read at rank positions: as it is when the build keys ascend (row == rank), else from a rank-ordered
+// copy made once per join table (ensure_rank_payload: the build rows grouped the same way, then placed inside L2-sized ranges).
+constexpr int GP_U = 4;  // keys per thread and step
+struct RetLayout {
+  const void* src[MAX_JOIN_COLS];   // the build columns, readable at RANK positions
+  int width[MAX_JOIN_COLS], off[MAX_JOIN_COLS];
+  int n, R;
+};
+// this workgroup's share [lo, hi) of group g's rows: all workgroups of an XCD (blockIdx % 8, MI355X_MICROARCH.md) split each of
+// that XCD's groups among themselves
+__device__ __forceinline__ void gp_share(const uint64_t* __restrict__ bounds, int g, int64_t& lo, int64_t& hi) {
+  const int64_t r0 = (int64_t)bounds[g], r1 = (int64_t)bounds[g + 1];
+  const int slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  int64_t per = (r1 - r0 + nslots - 1) / nslots;
+  per = (per + BLOCK * GP_U - 1) / (BLOCK * GP_U) * (BLOCK * GP_U);
+  lo = r0 + (int64_t)slot * per;
+  hi = lo + per < r1 ? lo + per : r1;
+}
+__global__ __launch_bounds__(BLOCK) void k_gp_lookup(const ulonglong2* __restrict__ rank_tab, uint64_t am_offset, uint64_t am_size, const uint64_t* __restrict__ gkeys,
+                                                     const uint64_t* __restrict__ bounds, int P, RetLayout L, uint8_t* __restrict__ rec,
+                                                     unsigned long long* __restrict__ total_hits) {
+  __shared__ unsigned long long s_hits[BLOCK / WAVE];
+  unsigned long long hits = 0;
+  for (int g = blockIdx.x & 7; g < P; g += 8) {
+    int64_t lo, hi;
+    gp_share(bounds, g, lo, hi);
+    for (int64_t base = lo; base < hi; base += BLOCK * GP_U) {
+      uint64_t idx[GP_U];
+      bool in[GP_U];
+#pragma unroll
+      for (int u = 0; u < GP_U; u++) {
+        const int64_t i = base + u * BLOCK + threadIdx.x;
+        in[u] = i < hi;
+        idx[u] = gkeys[in[u] ? i : hi - 1] - am_offset;   // in range by construction (group_rows_by_key drops the others)
+      }
+      ulonglong2 e[GP_U];
+#pragma unroll
+      for (int u = 0; u < GP_U; u++) e[u] = rank_tab[idx[u] >> 6];
+      uint32_t m[GP_U];
+#pragma unroll
+      for (int u = 0; u < GP_U; u++) {
+        const bool hit = in[u] && ((e[u].x >> (idx[u] & 63)) & 1ull);
+        const uint32_t rank = (uint32_t)e[u].y + (uint32_t)__popcll(e[u].x & ((1ull << (idx[u] & 63)) - 1ull));
+        m[u] = hit ? rank + 1u : 0u;
+        hits += hit ? 1u : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < GP_U; u++) {
+        const int64_t i = base + u * BLOCK + threadIdx.x;
+        if (in[u]) *reinterpret_cast<uint32_t*>(rec + (uint64_t)i * L.R) = m[u];
+      }
+      for (int c = 0; c < L.n; c++) {
+        const int w = L.width[c];
+#pragma unroll
+        for (int u = 0; u < GP_U; u++) {
+          if (!m[u]) continue;
+          const int64_t i = base + u * BLOCK + threadIdx.x;
+          const int64_t r = (int64_t)m[u] - 1;
+          uint8_t* d = rec + (uint64_t)i * L.R + L.off[c];
+          switch (w) {
+            case 16: *reinterpret_cast<uint4*>(d) = reinterpret_cast<const uint4*>(L.src[c])[r]; break;
+            case 8: *reinterpret_cast<uint64_t*>(d) = reinterpret_cast<const uint64_t*>(L.src[c])[r]; break;
+            case 4: *reinterpret_cast<uint32_t*>(d) = reinterpret_cast<const uint32_t*>(L.src[c])[r]; break;
+            default: *d = reinterpret_cast<const uint8_t*>(L.src[c])[r]; break;
+          }
+        }
+      }
+    }
+  }
+  hits = wave_sum<unsigned long long>(hits);
+  if (lane_id() == 0) s_hits[threadIdx.x >> 6] = hits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < BLOCK / WAVE; w++) t += s_hits[w];
+    if (t) atomicAdd(total_hits, t);
+  }
+}
+// build rows in group order (every key is in the table): their columns to the RANK position of their key
+__global__ __launch_bounds__(BLOCK) void k_gp_place(const ulonglong2* __restrict__ rank_tab, uint64_t am_offset, const uint64_t* __restrict__ gkeys,
+                                                    const uint64_t* __restrict__ bounds, int P, GroupCols cols) {
+  for (int g = blockIdx.x & 7; g < P; g += 8) {
+    int64_t lo, hi;
+    gp_share(bounds, g, lo, hi);
+    for (int64_t base = lo; base < hi; base += BLOCK * GP_U) {
+      uint64_t idx[GP_U];
+      bool in[GP_U];
+#pragma unroll
+      for (int u = 0; u < GP_U; u++) {
+        const int64_t i = base + u * BLOCK + threadIdx.x;
+        in[u] = i < hi;
+        idx[u] = gkeys[in[u] ? i : hi - 1] - am_offset;
+      }
+      ulonglong2 e[GP_U];
+#pragma unroll
+      for (int u = 0; u < GP_U; u++) e[u] = rank_tab[idx[u] >> 6];
+      for (int c = 0; c < cols.n; c++) {
+#pragma unroll
+        for (int u = 0; u < GP_U; u++) {
+          if (!in[u]) continue;
+          const int64_t i = base + u * BLOCK + threadIdx.x;
+          const int64_t r = (int64_t)((uint32_t)e[u].y + (uint32_t)__popcll(e[u].x & ((1ull << (idx[u] & 63)) - 1ull)));
+          switch (cols.width[c]) {
+            case 16: reinterpret_cast<uint4*>(cols.dst[c])[r] = reinterpret_cast<const uint4*>(cols.src[c])[i]; break;
+            case 8: reinterpret_cast<uint64_t*>(cols.dst[c])[r] = reinterpret_cast<const uint64_t*>(cols.src[c])[i]; break;
+            case 4: reinterpret_cast<uint32_t*>(cols.dst[c])[r] = reinterpret_cast<const uint32_t*>(cols.src[c])[i]; break;
+            default: reinterpret_cast<uint8_t*>(cols.dst[c])[r] = reinterpret_cast<const uint8_t*>(cols.src[c])[i]; break;
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- JoinFilter (joins/join_filter.rs)
 // apply_join_filter_to_indices (joins/utils.rs:1248-1318): key-equal pairs -> intermediate batch -> filter
 // expression -> pairs whose value is TRUE.  Only passing pairs count as matches (visited bits, probe hits).
@@ -1296,6 +1436,10 @@ static void with_kind_and_key(int kind, int probe_key_type, F&& f) {
   }
   if (kind == KIND_FLAT16) {
     f(std::integral_constant<int, KIND_FLAT16>{}, std::integral_constant<int, KT_ANY>{});
+    return;
+  }
+  if (kind == KIND_RETURNED) {
+    f(std::integral_constant<int, KIND_RETURNED>{}, std::integral_constant<int, KT_ANY>{});
     return;
   }
   with_key_type(probe_key_type, [&](auto kt) {
@@ -1838,6 +1982,119 @@ __global__ __launch_bounds__(BLOCK) void k_sample_all_hit(ProbeCtx c, int64_t np
   if (lane_id() == 0 && (word[0] & want) != want) atomicAdd(misses, 1);
 }
 
+// ---- grouped probe with positional return: host side
+// groups of a rank map's key range: enough of them that a group's slice of the table plus of the build payload stays inside an
+// XCD's 4 MiB L2 with room for the streams passing through (2.5 MB aimed at), at most 2^10 (a run of a tile is 8192 / groups rows)
+static int gp_bits_for(const JoinTable& jt, int64_t payload_bytes_per_row) {
+  if (const char* e = std::getenv("DFGPU_JOIN_GP_BITS")) return std::min(10, std::max(1, std::atoi(e)));  // tuning knob
+  const double slice = (double)((jt.am_size >> 6) + 1) * 16.0 + (double)jt.build.nrows * (double)payload_bytes_per_row;
+  int bits = 6;
+  while (bits < 10 && slice / (double)(1 << bits) > 2.5 * 1048576.0) bits++;
+  return bits;
+}
+static GroupSpec gp_spec_for(const JoinTable& jt, int nbits) {
+  int shift = 0;
+  while (((jt.am_size - 1) >> shift) >= (1ull << nbits)) shift++;
+  return GroupSpec{jt.am_offset, jt.am_size, shift};
+}
+// rank map over build keys in no order: the build columns `cols` copied into RANK order, once per join table and column (a probe
+// in group order reads build payload at rank positions; through rank -> row -> column it would be a random line per row)
+static void ensure_rank_payload(JoinTable& jt, const std::vector<int>& cols) {
+  std::lock_guard<std::mutex> lk(jt.mu);
+  std::vector<int> missing;
+  for (int c : cols)
+    if (!jt.rank_payload.count(c) && std::find(missing.begin(), missing.end(), c) == missing.end()) missing.push_back(c);
+  if (missing.empty()) return;
+  Runtime& r = rt();
+  const int64_t nb = jt.build.nrows;
+  const KeySet ks = make_keyset(jt.build, jt.key_cols);
+  for (size_t a = 0; a < missing.size(); a += GP_MAX_COLS) {
+    std::vector<const void*> src;
+    std::vector<int> width;
+    int64_t bytes = 0;
+    for (size_t q = a; q < std::min(missing.size(), a + GP_MAX_COLS); q++) {
+      const Column& c = jt.build.cols[(size_t)missing[q]];
+      src.push_back(c.ptr());
+      width.push_back(type_width(c.field.type));
+      bytes += width.back();
+    }
+    const int nbits = gp_bits_for(jt, bytes);
+    GroupedRows gr = group_rows_by_key(ks.c[0], nb, gp_spec_for(jt, nbits), nbits, nullptr, true, false, src, width, "join_build_group_payload");
+    GroupCols gc{};
+    gc.n = (int)src.size();
+    for (int q = 0; q < gc.n; q++) {
+      BufPtr dst = make_buf((size_t)std::max<int64_t>(nb, 1) * width[(size_t)q]);
+      gc.src[q] = gr.cols[(size_t)q]->ptr;
+      gc.dst[q] = dst->ptr;
+      gc.width[q] = width[(size_t)q];
+      jt.rank_payload[missing[a + (size_t)q]] = dst;
+      jt.info.table_bytes += nb * width[(size_t)q];
+    }
+    ProfileScope ps("join_build_rank_payload", gr.rows * (8 + 2 * bytes));
+    k_gp_place<<<r.num_cus * 8, BLOCK, 0, r.stream>>>(jt.rank_tab->as<ulonglong2>(), jt.am_offset, gr.keys->as<uint64_t>(), gr.bounds->as<uint64_t>(), gr.P, gc);
+    DFGPU_HIP(hipGetLastError());
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // complete before another thread's stream reads the copies
+}
+struct ReturnedProbe {
+  BufPtr dest, rec;
+  int R = 0;
+  int64_t hits = 0;
+  std::vector<int> mul, add;  // per build output column: element index = dest * mul + add
+};
+// steps 1 and 2 of the grouped probe; false = not applicable (the records would be wider than 64 bytes)
+static bool grouped_probe_lookup(JoinTable& jt, const Table& probe, int pk0, const std::vector<int>& bout, const uint64_t* row_mask, ReturnedProbe& rp) {
+  Runtime& r = rt();
+  const int64_t np = probe.nrows;
+  // record layout: the match id in the first word (KIND_RETURNED reads it there), then the 4-byte build columns, the 8-byte ones,
+  // the 16-byte ones — every field aligned to its own width — and the single bytes at the end
+  RetLayout L{};
+  std::vector<int> field_off(bout.size(), 0);
+  rp.mul.assign(bout.size(), 0);
+  rp.add.assign(bout.size(), 0);
+  int off = 4;
+  int64_t payload = 0;
+  for (int w : {4, 8, 16, 1})
+    for (size_t i = 0; i < bout.size(); i++)
+      if (type_width(jt.build.cols[(size_t)bout[i]].field.type) == w) {
+        off = (off + w - 1) / w * w;
+        field_off[i] = off;
+        off += w;
+        payload += w;
+      }
+  L.R = off <= 4 ? 4 : off <= 8 ? 8 : (off + 15) / 16 * 16;
+  if (L.R > 64 || (int)bout.size() > MAX_JOIN_COLS) return false;
+  L.n = (int)bout.size();
+  if (jt.rank_needs_perm && !bout.empty()) ensure_rank_payload(jt, bout);
+  std::unique_lock<std::mutex> lk(jt.mu);
+  for (size_t i = 0; i < bout.size(); i++) {
+    const Column& c = jt.build.cols[(size_t)bout[i]];
+    const int w = type_width(c.field.type);
+    L.src[i] = jt.rank_needs_perm ? jt.rank_payload.at(bout[i])->ptr : c.ptr();
+    L.width[i] = w;
+    L.off[i] = field_off[i];
+    rp.mul[i] = L.R / w;
+    rp.add[i] = field_off[i] / w;
+  }
+  lk.unlock();
+  rp.R = L.R;
+  const Column& kc = probe.cols[(size_t)pk0];
+  const KeyCol key{kc.ptr(), kc.valid_words(), kc.field.type, type_width(kc.field.type)};
+  const int nbits = gp_bits_for(jt, payload);
+  GroupedRows gr = group_rows_by_key(key, np, gp_spec_for(jt, nbits), nbits, row_mask, true, true, {}, {}, "join_probe_group_keys");
+  rp.dest = gr.dest;
+  rp.rec = make_buf((size_t)std::max<int64_t>(gr.rows, 1) * (size_t)L.R);
+  BufPtr total = make_zero_buf(8);
+  if (gr.rows) {
+    ProfileScope ps("join_probe_grouped_lookup", gr.rows * (8 + L.R + payload));
+    k_gp_lookup<<<r.num_cus * 8, BLOCK, 0, r.stream>>>(jt.rank_tab->as<ulonglong2>(), jt.am_offset, jt.am_size, gr.keys->as<uint64_t>(), gr.bounds->as<uint64_t>(), gr.P, L,
+                                                       rp.rec->as<uint8_t>(), total->as<unsigned long long>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  rp.hits = (int64_t)read_u64(total->as<uint64_t>());
+  return true;
+}
+
 static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
                                     const std::vector<int>& pout, const dfgpu_join_filter* jfp);
 static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout_in,
@@ -1859,6 +2116,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   }
   const int64_t np = probe.nrows;
   const int64_t n_words = (np + 63) / 64;
+  int kind = jt.kind;  // what the probe kernels look the keys up in: the table, or (KIND_RETURNED) what a grouped lookup left per probe row
   ProbeCtx ctx = make_ctx(jt, probe, pk, /*need_build_rows=*/false);  // decided below, once the probe flavour is known
   for (int c : bout) DFGPU_CHECK(c >= 0 && c < (int)jt.build.cols.size(), "build output column out of range");
   for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
@@ -1909,7 +2167,31 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   // keys in no particular order it needs the bitmap alone, not the rank -> row permutation (which is built by the first probe
   // that does need rows)
   const bool rows_unused = bout.empty() && !needs_visited(join_type) && (use_fused || probe_side_only);
-  if (!rows_unused && jt.kind == KIND_RANK && jt.rank_needs_perm) {
+  const char* big_env = std::getenv("DFGPU_JOIN_BIG_TABLE_BYTES");  // test knob: what counts as "beyond the caches" (default 16 MiB)
+  const int64_t big_bytes = big_env ? std::atoll(big_env) : ((int64_t)16 << 20);
+  const bool big_table = (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY) && (int64_t)(jt.kind == KIND_RANK ? (jt.am_size >> 6) * 16 : jt.am_size * 4) > big_bytes;
+  static thread_local bool in_grouped_probe = false;  // the probe over keys this function grouped itself: clustered by construction
+  const char* min_env = std::getenv("DFGPU_JOIN_GROUPED_MIN_ROWS");  // test knob: from how many probe rows grouping is considered (default 4 Mi)
+  const int64_t grouped_min_rows = min_env ? std::atoll(min_env) : ((int64_t)1 << 22);
+  const bool unclustered = fused_ok && big_table && np > grouped_min_rows && pk.size() == 1 && !in_grouped_probe && !probe_keys_clustered(probe.cols[(size_t)pk[0]], np);
+  const bool group_env = !(std::getenv("DFGPU_JOIN_GROUPED_PROBE") && std::getenv("DFGPU_JOIN_GROUPED_PROBE")[0] == '0');  // A/B knob
+  // the key-only probe whose order nobody observes: its keys are grouped and probed in group order (below)
+  const bool grouped_keys_only = unclustered && group_env && jt.probe_mode == 4 && rows_unused && !row_mask && pout.size() == 1 && pout[0] == pk[0] &&
+                                 ctx.pkeys.c[0].width == 8 && !probe.cols[(size_t)pk[0]].validity;
+  // every other unclustered probe of a big rank map: the keys travel to the table group by group and what they found comes back
+  // to the probe rows (k_gp_lookup above); the build rows are read at rank positions, so no rank -> row permutation is needed
+  const bool returned_env = !(std::getenv("DFGPU_JOIN_RETURNED_PROBE") && std::getenv("DFGPU_JOIN_RETURNED_PROBE")[0] == '0');  // A/B knob
+  bool returned = use_fused && unclustered && group_env && returned_env && !grouped_keys_only && jt.kind == KIND_RANK && jt.probe_mode != 2 &&
+                  is_integer_like(probe.cols[(size_t)pk[0]].field.type);
+  ReturnedProbe rp;
+  if (returned) returned = grouped_probe_lookup(jt, probe, pk[0], bout, row_mask, rp);
+  if (returned) {
+    kind = KIND_RETURNED;
+    ctx.ret_dest = rp.dest->as<uint32_t>();
+    ctx.ret_rec = rp.rec->as<uint8_t>();
+    ctx.ret_R = rp.R;
+  }
+  if (!returned && !rows_unused && jt.kind == KIND_RANK && jt.rank_needs_perm) {
     ensure_rank_perm(jt);
     ctx.rank_perm = jt.rank_perm->as<uint32_t>();
   }
@@ -1921,9 +2203,14 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   // knows the answer before the second kernel is chosen, so a wrong guess costs the counts pass, not the result; the
   // output is in probe order, which every probe_mode accepts.
   static const char* listed_env = std::getenv("DFGPU_JOIN_LISTED");  // A/B knob: 0 / 1 force the guess
-  bool listed = fused_ok && fused_mode != FUSED_LOOKBACK && (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY) &&
+  bool listed = fused_ok && fused_mode != FUSED_LOOKBACK && (kind == KIND_RANK || kind == KIND_ARRAY) &&
                 (row_mask != nullptr || (double)jt.build.nrows < 0.15 * (double)jt.am_size);
-  if (listed_env && fused_ok && fused_mode != FUSED_LOOKBACK && (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY)) listed = listed_env[0] == '1';
+  if (listed_env && fused_ok && fused_mode != FUSED_LOOKBACK && (kind == KIND_RANK || kind == KIND_ARRAY)) listed = listed_env[0] == '1';
+  // what the grouped lookup found decides the placement: every probe row matched — row i of the output is probe row i, no counts
+  // pass; else the cursor when nobody observes the order, else counts + placed
+  const bool returned_all_hit = returned && rp.hits == np && !row_mask && join_type != DFGPU_JOIN_RIGHT_ANTI;
+  if (returned && !returned_all_hit && fused_mode != FUSED_LOOKBACK) fused_mode = want_single ? FUSED_UNORDERED : FUSED_PLACED;
+  if (returned_all_hit) fused_mode = FUSED_PLACED;
   if (listed) fused_mode = FUSED_PLACED;
   // The unordered flavour claims every 2048-row tile's output range with one returning atomicAdd on ONE cursor, and a contended
   // agent-scope atomic retires one claim per ~12 ns (scripts/microbench/tile_atomics.hip): 3.5 ms for an SF100 probe's 293 K
@@ -1936,30 +2223,36 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   //    (sort.hip's pass, 64 groups: a group's slice of the table is ~1/64 of it and sits in L2), then the ordinary probe runs
   //    over the grouped keys — lookups hit lines their neighbours fetched;
   //  * otherwise the single-pass probe: one lookup per row.
-  const char* big_env = std::getenv("DFGPU_JOIN_BIG_TABLE_BYTES");  // test knob: what counts as "beyond the caches" (default 16 MiB)
-  const int64_t big_bytes = big_env ? std::atoll(big_env) : ((int64_t)16 << 20);
-  const bool big_table = (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY) && (int64_t)(jt.kind == KIND_RANK ? (jt.am_size >> 6) * 16 : jt.am_size * 4) > big_bytes;
-  static thread_local bool in_grouped_probe = false;  // the probe over keys this function grouped itself: clustered by construction
-  const bool unclustered = fused_ok && big_table && np > (1 << 22) && pk.size() == 1 && !in_grouped_probe && !probe_keys_clustered(probe.cols[(size_t)pk[0]], np);
-  const bool group_env = !(std::getenv("DFGPU_JOIN_GROUPED_PROBE") && std::getenv("DFGPU_JOIN_GROUPED_PROBE")[0] == '0');  // A/B knob
-  if (unclustered && group_env && !in_grouped_probe && jt.probe_mode == 4 && rows_unused && !row_mask && pout.size() == 1 && pout[0] == pk[0] &&
-      ctx.pkeys.c[0].width == 8 && !probe.cols[(size_t)pk[0]].validity) {
+  if (grouped_keys_only) {
     const Column& kc = probe.cols[(size_t)pk[0]];
     BufPtr keys = kc.data;
     if (kc.data_offset != 0) {  // a slice of a larger buffer: the pass wants its own
       keys = make_buf((size_t)np * 8);
       DFGPU_HIP(hipMemcpyAsync(keys->ptr, kc.ptr(), (size_t)np * 8, hipMemcpyDeviceToDevice, r.stream));
     }
+    static const bool gp_keys = !(std::getenv("DFGPU_JOIN_GP_KEYS") && std::getenv("DFGPU_JOIN_GP_KEYS")[0] == '0');  // A/B knob: round 3's radix pass
+    int64_t n_grouped = np;
+    if (gp_keys && jt.kind == KIND_RANK && join_type != DFGPU_JOIN_RIGHT_ANTI) {
+      // round 4: grouped by their position in the table's key range (grouped.hip: one pass, 2^9 groups or so); keys outside the
+      // range — they match nothing, and an Inner / RightSemi probe emits nothing for them — drop out here
+      const KeyCol key{kc.ptr(), nullptr, kc.field.type, 8};
+      const int nbits = gp_bits_for(jt, 0);
+      GroupedRows gr = group_rows_by_key(key, np, gp_spec_for(jt, nbits), nbits, nullptr, true, false, {}, {}, "join_probe_group_keys");
+      keys = gr.keys;
+      n_grouped = gr.rows;
+    } else {
     int range_bits = 0;
     while (range_bits < 64 && (jt.am_size >> range_bits)) range_bits++;
     // groups = keys sharing bits [range_bits - 6, range_bits) of their value: at most two stretches of the key range each
     radix_group_keys(keys, np, std::max(0, range_bits - 6), 6);
+    }
     Table grouped;
-    grouped.nrows = np;
+    grouped.nrows = n_grouped;
     grouped.device = probe.device;
     Column gk = kc;
     gk.data = keys;
     gk.data_offset = 0;
+    gk.length = n_grouped;
     gk.stats.reset();
     grouped.cols.push_back(std::move(gk));
     in_grouped_probe = true;
@@ -1972,11 +2265,11 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     }
     in_grouped_probe = false;
     std::lock_guard<std::mutex> lk(jt.mu);
-    jt.info.probe_rows -= np;  // counted by the inner call as well
+    jt.info.probe_rows -= n_grouped;  // counted by the inner call as well
     return res;
   }
   // (the probe over keys grouped above: its lookups hit L2 but are still one line request per row — one pass, not two)
-  if (fused_ok && fused_mode == FUSED_UNORDERED && np > (1 << 22) && !unclustered && !in_grouped_probe) {
+  if (fused_ok && fused_mode == FUSED_UNORDERED && np > (1 << 22) && !unclustered && !in_grouped_probe && !returned) {
     int64_t row_bytes = key_bytes / std::max<int64_t>(np, 1) + out_row_bytes;
     for (int c : pout) {
       bool is_key = false;
@@ -2019,11 +2312,13 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     // host starts over with the counts when one disagrees (the reference's order, exec.rs:3349, at the unordered flavour's cost)
     static thread_local bool no_speculation = false;
     bool speculate = false;
-    if (fused_mode == FUSED_PLACED && !listed && !row_mask && !invert && !no_speculation && np >= (1 << 22) && (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY) &&
+    if (returned_all_hit && !no_speculation) {
+      speculate = true;   // (not a guess here: the grouped lookup counted its hits; the kernel's per-tile check stays as the safety net)
+    } else if (fused_mode == FUSED_PLACED && !listed && !row_mask && !invert && !no_speculation && np >= (1 << 22) && (kind == KIND_RANK || kind == KIND_ARRAY) &&
         !(std::getenv("DFGPU_JOIN_SPECULATE") && std::getenv("DFGPU_JOIN_SPECULATE")[0] == '0')) {
       constexpr int S = 1024;  // sampled words
       BufPtr miss = make_zero_buf(4);
-      with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
+      with_kind_and_key(kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
         k_sample_all_hit<decltype(kd)::value, decltype(kt)::value><<<S * WAVE / BLOCK, BLOCK, 0, r.stream>>>(ctx, np, std::max<int64_t>(1, n_words / S), S, miss->as<int>());
       });
       DFGPU_HIP(hipGetLastError());
@@ -2038,7 +2333,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       if (listed) out_words = make_buf((size_t)n_words * 8);
       {
         ProfileScope ps("join_probe_tile_counts", key_bytes);
-        with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
+        with_kind_and_key(kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
           k_join_tile_counts<decltype(kd)::value, decltype(kt)::value, FUSED_W><<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(
               ctx, np, invert, row_mask, counts->as<uint32_t>(), out_words ? out_words->as<uint64_t>() : nullptr);
         });
@@ -2057,6 +2352,11 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       jc.src[jc.n] = sc.ptr();
       jc.dst[jc.n] = out.cols.back().data->ptr;
       jc.width[jc.n] = type_width(sc.field.type);
+      if (returned) {  // the column's values came back inside the records
+        jc.src[jc.n] = rp.rec->ptr;
+        jc.ret_mul[jc.n] = rp.mul[(size_t)jc.n];
+        jc.ret_add[jc.n] = rp.add[(size_t)jc.n];
+      }
       bytes_per_out += jc.width[jc.n];
       bytes_build_once += jt.build.nrows * jc.width[jc.n];
       jc.n++;
@@ -2072,7 +2372,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       for (int k : pk) is_key |= k == c;
       if (!is_key) bytes_in += np * jc.width[jc.n];  // a key column that is also payload is read once
       static const bool keyreg = !(std::getenv("DFGPU_JOIN_KEYREG") && std::getenv("DFGPU_JOIN_KEYREG")[0] == '0');  // A/B knob
-      if (keyreg && is_key && (jt.kind == KIND_ARRAY || jt.kind == KIND_RANK) && pk.size() == 1 && jc.key_col < 0 && !sc.validity) jc.key_col = jc.n;
+      if (keyreg && is_key && (kind == KIND_ARRAY || kind == KIND_RANK) && pk.size() == 1 && jc.key_col < 0 && !sc.validity) jc.key_col = jc.n;
       bytes_per_out += jc.width[jc.n];
       jc.n++;
     }
@@ -2088,7 +2388,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       const unsigned g = fused_mode == FUSED_LOOKBACK ? (unsigned)std::min<int64_t>(n_tiles, (int64_t)r.num_cus * 8) : (unsigned)n_tiles;
       uint64_t* st = state ? state->as<uint64_t>() : nullptr;
       auto launch = [&](auto kern) { kern<<<g, BLOCK, 0, r.stream>>>(ctx, jc, np, invert, st, ctl->as<FusedCtl>(), row_mask); };
-      with_kind_and_key(jt.kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
+      with_kind_and_key(kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
         constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
         constexpr bool KR = kind_is_direct<K>();  // the direct-address kinds hold the one integer key in registers
         if constexpr (KR) {

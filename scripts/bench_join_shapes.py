@@ -75,7 +75,8 @@ def main():
 
     results = []
 
-    def run_shape(name, build, probe, on, modes, w, note=""):
+    def run_shape(name, build, probe, on, modes, w, note="", build_out=(), probe_out=None, row_bytes=None):
+        """row_bytes = (build row, probe row, output row) bytes of the referenced columns when the output carries payload"""
         if only and not any(o in name for o in only):
             return
         nb, np_ = build.num_rows, probe.num_rows
@@ -83,9 +84,13 @@ def main():
             if args.tables and label not in args.tables.split(","):
                 continue
 
+            opts = dict(opts)
+            env = opts.pop("env", {})
+            os.environ.update(env)
+
             def step():
                 ht = ops.JoinHashTable(build, [l for l, _ in on], probe_mode=4, **opts)
-                out = ht.probe(probe, [r for _, r in on], "Inner", [], [on[0][1]])
+                out = ht.probe(probe, [r for _, r in on], "Inner", list(build_out), [on[0][1]] if probe_out is None else list(probe_out))
                 n = out.num_rows
                 kind = ht.info().table_kind
                 out.free()
@@ -95,6 +100,8 @@ def main():
                 step()
             except _lib.DfgpuError as e:
                 print(json.dumps({"case": name, "table": label, "error": str(e)[:200]}), flush=True)
+                for k in env:
+                    os.environ.pop(k, None)
                 continue
             ops.sync()
             ops.profile_enable(True)
@@ -109,13 +116,15 @@ def main():
             stats = ops.profile_stats()
             ops.profile_enable(False)
             best = min(times)
-            b = (nb + np_ + m) * w
+            b = (nb + np_ + m) * w if row_bytes is None else nb * row_bytes[0] + np_ * row_bytes[1] + m * row_bytes[2]
             kern = {k: round(v["total_ms"] / args.iters, 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
             rec = {"case": name, "table": label, "table_kind": {0: "chained", 1: "array_map", 2: "rank_map", 3: "radix_lds", 4: "flat8", 5: "flat16"}[kind], "build_rows": nb, "probe_rows": np_,
                    "output_rows": m, "ms": round(best * 1e3, 3), "rows_per_s": (nb + np_) / best, "algorithmic_bytes": b,
                    "algorithmic_gb_per_s": round(b / best / 1e9, 1), "hbm_frac": round(b / best / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms_per_iter": kern, "note": note}
             results.append(rec)
             print(json.dumps(rec), flush=True)
+            for k in env:
+                os.environ.pop(k, None)
 
     ALL = [("auto", {}), ("chained", {"table_mode": 1}), ("radix", {"table_mode": 4}), ("flat", {"table_mode": 5})]
     # ---- hj.rs shapes at SF10: supplier-sized build side (100 K keys) x lineitem-sized probe side (60 M rows)
@@ -164,6 +173,23 @@ def main():
         torch.cuda.empty_cache()
         run_shape("SF100 sizes: 150M unique shuffled build keys, 600M random foreign keys", b, p, [("k", "k2")], ALL + [("array_map", {"table_mode": 2})], 8,
                   note="auto = rank map + permutation (the build keys are not in ascending row order)")
+        b.free()
+        p.free()
+        # the same keys WITH TPC-H Q3's payload (SURVEY 8d config 3 ii: 16 B build rows, 40 B probe rows, 48 B output rows = 55.2 GB):
+        # what a join of tables that are not clustered on the key looks like
+        perm = torch.randperm(nb, generator=gen, device="cuda")
+        bk = (perm // 8) * 32 + perm % 8 + 1
+        fk = randint(0, nb, np_)
+        pk = (fk // 8) * 32 + fk % 8 + 1
+        del fk
+        b = table({"k": bk, "o_orderdate": (perm % 2406 + 8035, "i32"), "o_shippriority": (perm * 0, "i32")})
+        del perm, bk
+        p = table({"k2": pk, "l_extendedprice": (randint(90000, 10_000_000, np_), "d128"), "l_discount": (randint(0, 11, np_), "d128")})
+        del pk
+        torch.cuda.empty_cache()
+        run_shape("SF100 sizes with the Q3 payload: 150M unique shuffled build rows x 600M random foreign keys", b, p, [("k", "k2")],
+                  [("auto", {}), ("auto, no grouped lookup", {"env": {"DFGPU_JOIN_RETURNED_PROBE": "0"}}), ("array_map", {"table_mode": 2})], 8,
+                  build_out=["o_orderdate", "o_shippriority"], probe_out=["k2", "l_extendedprice", "l_discount"], row_bytes=(16, 40, 48))
         b.free()
         p.free()
         bk = randint(0, 50_000_000, nb) * 3                      # every key ~3 times on the build side: M:N, ~3 matches per hit

@@ -31,6 +31,65 @@ def _sums(table, cols):
     return row
 
 
+def _col_tensor(table, name, dtype):
+    """zero-copy torch view of a fixed-width, non-nullable device column (test plumbing: the checker below is plain torch)"""
+    import torch
+
+    from datafusion_amd.exchange import _as_tensor
+    v = table.column_view(table.index_of(name))
+    width = {torch.int64: 8, torch.int32: 4}[dtype]
+    per_row = 16 if str(table.schema.field(table.index_of(name)).type).startswith("decimal128") else width
+    return _as_tensor(v.data, table.num_rows * per_row).view(dtype)
+
+
+def _order_date_torch(idx):
+    """tpch.order_date (datafusion_amd/tpch.py; csrc/tpch.hip) over an int64 CUDA tensor of order indices, in wrapping int64
+    arithmetic: fmix64((i * 16 + 1) ^ seed ^ golden) % 2406 + DATE_START — an independent restatement of the generator, so every
+    output row's o_orderdate can be recomputed from its l_orderkey"""
+    import torch
+
+    from datafusion_amd import tpch
+
+    def c(v):   # 64-bit constant as the int64 with the same bits
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr33(x):
+        return (x >> 33) & 0x7FFFFFFF
+    x = (idx * 16 + 1) ^ c((tpch.SEED_BASE + tpch.T_ORDERS) ^ 0x9E3779B97F4A7C15)
+    x = x ^ lsr33(x)
+    x = x * c(0xff51afd7ed558ccd)
+    x = x ^ lsr33(x)
+    x = x * c(0xc4ceb9fe1a85ec53)
+    x = x ^ lsr33(x)
+    m = tpch.DATE_END - tpch.DATE_START + 1
+    # unsigned x mod m: x = 2 * (x >>> 1) + (x & 1)
+    hi = (x >> 1) & 0x7FFFFFFFFFFFFFFF
+    r = ((hi % m) * 2 + (x & 1)) % m
+    return (r + tpch.DATE_START).to(torch.int32)
+
+
+def _assert_every_joined_row(out, lineitem=None):
+    """EVERY output row of the orders x lineitem join, on the device: the build payload is the generator's function of the key
+    (o_orderdate = order_date(index of l_orderkey), o_shippriority = 0); with `lineitem`: the output is the probe side row for row"""
+    import torch
+    key = _col_tensor(out, "l_orderkey", torch.int64) - 1
+    assert bool(((key & 31) < 8).all())
+    idx = (key >> 5) * 8 + (key & 31)
+    got = _col_tensor(out, "o_orderdate", torch.int32)
+    step = 1 << 27   # bounded temporaries
+    for lo in range(0, out.num_rows, step):
+        assert bool((got[lo:lo + step] == _order_date_torch(idx[lo:lo + step])).all()), lo
+    assert bool((_col_tensor(out, "o_shippriority", torch.int32) == 0).all())
+    del key, idx
+    if lineitem is not None:
+        assert out.num_rows == lineitem.num_rows
+        for name in ("l_orderkey", "l_extendedprice", "l_discount"):
+            a, b = _col_tensor(out, name, torch.int64), _col_tensor(lineitem, name, torch.int64)
+            for lo in range(0, a.numel(), 1 << 28):
+                assert torch.equal(a[lo:lo + (1 << 28)], b[lo:lo + (1 << 28)]), (name, lo)
+    torch.cuda.empty_cache()
+
+
 @pytest.fixture(scope="module")
 def tables():
     from datafusion_amd import ops
@@ -61,6 +120,8 @@ def test_sf100_join_properties(tables, probe_mode):
     if probe_mode == 0:   # probe order preserved: l_orderkey ascending like the input
         k = sample.slice(0, 1000).column("l_orderkey").to_numpy()
         assert (np.diff(k) >= 0).all()
+    # all 600 M rows, not a sample: the build payload recomputed from the key; in probe-order mode the output IS the probe side
+    _assert_every_joined_row(out, lineitem if probe_mode == 0 else None)
     out.free()
 
 
@@ -84,7 +145,7 @@ def test_sf100_join_over_keys_in_no_order(tables):
     stats = ops.profile_stats()
     ops.profile_enable(False)
     assert ht.info().table_kind == 2 and "join_build_key_stats" in stats and "join_build_speculation_missed" not in stats   # rank map, measured statistics
-    assert "radix_sort_pass" in stats                                      # probe keys grouped by key range
+    assert "join_probe_group_keys" in stats or "radix_sort_pass" in stats   # probe keys grouped by key range (grouped.hip; round 3: a radix pass)
     assert keys.num_rows == lineitem.num_rows and _sums(keys, ["l_orderkey"]) == k_sum
     keys.free()
     os.environ["DFGPU_JOIN_GROUPED_PROBE"] = "0"
@@ -94,8 +155,12 @@ def test_sf100_join_over_keys_in_no_order(tables):
         del os.environ["DFGPU_JOIN_GROUPED_PROBE"]
     assert plain.num_rows == lineitem.num_rows and _sums(plain, ["l_orderkey"]) == k_sum
     plain.free()
-    # a probe that gathers build payload: the permutation is built now; payload = f(key) on a sample
+    # a probe that gathers build payload: payload = f(key)
+    ops.profile_enable(True)
+    ops.profile_reset()
     out = ht.probe(sl, ["l_orderkey"], "Inner", ["o_orderdate"], ["l_orderkey", "l_extendedprice"])
+    stats2 = ops.profile_stats()
+    ops.profile_enable(False)
     ht.free()
     assert out.num_rows == lineitem.num_rows
     assert _sums(out, ["l_orderkey", "l_extendedprice"]) == _sums(lineitem, ["l_orderkey", "l_extendedprice"])
@@ -103,6 +168,19 @@ def test_sf100_join_over_keys_in_no_order(tables):
     key = sample.column("l_orderkey").to_numpy() - 1
     idx = (key >> 5) * 8 + (key & 31)
     assert (sample.column("o_orderdate").cast(pa.int32()).to_numpy() == tpch.order_date(idx.astype(np.int64))).all()
+    # (round 4) this probe — payload on both sides, keys in no order, a table beyond the caches — goes through the grouped lookup
+    # and comes back in probe order: every row checked on the device, build payload recomputed from the key, probe side row for row
+    import torch
+    assert "join_probe_grouped_lookup" in stats2 and "join_build_rank_payload" in stats2 and "join_build_rank_perm" not in stats2, sorted(stats2)
+    okey = _col_tensor(out, "l_orderkey", torch.int64) - 1
+    oidx = (okey >> 5) * 8 + (okey & 31)
+    got = _col_tensor(out, "o_orderdate", torch.int32)
+    for lo in range(0, out.num_rows, 1 << 27):
+        assert bool((got[lo:lo + (1 << 27)] == _order_date_torch(oidx[lo:lo + (1 << 27)])).all()), lo
+    del okey, oidx
+    for name in ("l_orderkey", "l_extendedprice"):
+        a, b = _col_tensor(out, name, torch.int64), _col_tensor(sl, name, torch.int64)
+        assert torch.equal(a, b), name
     for t in (out, so, sl):
         t.free()
 
@@ -201,4 +279,38 @@ def test_sf100_group_by_custkey_partitioned_equals_global_atomics(monkeypatch):
     for off in range(0, moved.num_rows - 1000, moved.num_rows // 50):          # the same rows in the same (first-seen) order
         assert moved.slice(off, 1000).to_arrow().equals(plain.slice(off, 1000).to_arrow())
     for t in (moved, plain, orders):
+        t.free()
+
+
+def test_sf300_q3_on_one_gpu():
+    """BASELINE config 5's N = 1 anchor: TPC-H Q3 at SF300 (45 M customers, 450 M orders, 1.8 G lineitem rows; ~91 GB of referenced
+    columns) on ONE MI355X, as the plan of tpch/plans/q3.slt.part:60-76.  No oracle finishes this: the two executions of the plan —
+    FilterExecs fused into the probes vs operator by operator (different kernels: row-masked probes vs compaction + plain probes) —
+    must agree row for row on the ten result rows and on every intermediate row count; the group count SURVEY §8 a9 asks to be
+    measured is asserted against the SF100 measurement scaled (1.1 groups per 100 lineitem rows surviving both joins' filters is a
+    property of the date predicates, not of the scale); the revenue of the top row is re-derived from lineitem with a filter on its
+    l_orderkey alone (a third path: FilterExec + ungrouped aggregate)"""
+    from datafusion_amd import ops, queries
+    from datafusion_amd.expr import col, lit
+    sf = 300.0
+    customer = ops.tpch_customer(sf)
+    orders = ops.tpch_orders(sf).select(["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+    lineitem = ops.tpch_lineitem(sf).select(["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
+    assert (customer.num_rows, orders.num_rows) == (45_000_000, 450_000_000) and 1_795_000_000 < lineitem.num_rows < 1_805_000_000
+    s1, s2 = {}, {}
+    fused = queries.q3(customer, orders, lineitem, stats=s1, fused=True).to_arrow()
+    plain = queries.q3(customer, orders, lineitem, stats=s2, fused=False).to_arrow()
+    assert fused.num_rows == 10 and fused.equals(plain), (fused.to_pylist(), plain.to_pylist())
+    for k in ("customer_filtered", "semi_join", "join", "groups"):
+        assert s1[k] == s2[k], (k, s1, s2)
+    print("Q3 SF300 on one GPU:", {**s2, **s1})
+    # measured at SF100: 3.0 M joined rows in 1.13 M groups; the ratios are scale-free
+    assert 0.30 < s1["groups"] / s1["join"] < 0.45 and 9_000 * sf < s1["groups"] < 13_000 * sf, s1
+    rev = fused.column("revenue").to_pylist()
+    assert rev == sorted(rev, reverse=True)
+    top_key = fused.column("l_orderkey").to_pylist()[0]
+    pred = col("l_orderkey").eq(lit(top_key, pa.int64())).and_(col("l_shipdate") > lit(queries.DATE_Q3, pa.date32()))
+    again = ops.aggregate(lineitem, [], [("sum", col("l_extendedprice") * (queries.ONE - col("l_discount")), "revenue")], "Single", predicate=pred).to_arrow()
+    assert again.column("revenue").to_pylist()[0] == rev[0]
+    for t in (customer, orders, lineitem):
         t.free()

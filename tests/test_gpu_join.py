@@ -547,6 +547,75 @@ def test_key_only_probe_of_unordered_keys_is_grouped_by_key_range(join_type):
         assert not np.array_equal(outs["1"], outs["0"])       # the grouped flavour really ran: its rows come out in group order
 
 
+@pytest.mark.parametrize("gp_bits", ["3", "9", "10"])
+@pytest.mark.parametrize("build_order", ["shuffled", "ascending"])
+def test_unclustered_probe_with_payload_goes_through_groups_and_comes_back_in_probe_order(build_order, gp_bits):
+    """round 4: a probe whose keys arrive in no order against a rank map beyond the caches, WITH payload on both sides: the probe keys
+    are grouped by their position in the table's key range, looked up group by group (build payload read at rank positions — from a
+    rank-ordered copy when the build keys are shuffled), and what they found returns to the probe rows through `dest`.  The output
+    is in probe order like the reference's (exec.rs:3349) under every probe_mode; NULL keys, keys outside the range, misses, a fused
+    probe-side predicate, RightSemi / RightAnti all take the same route"""
+    import os
+
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(91 + len(build_order))
+    nb, npr = 200_000, 1_000_003
+    bkeys = np.unique((rng.permutation(4 * nb)[:nb].astype(np.int64)) * 3 - 1000)
+    if build_order == "shuffled":
+        rng.shuffle(bkeys)
+    nb = len(bkeys)
+    build = pa.table({"k": pa.array(bkeys), "d": pa.array((bkeys % 9000).astype(np.int32), type=pa.int32()).cast(pa.date32()),
+                      "p": pa.array((bkeys % 7).astype(np.int32), type=pa.int32()), "w": pa.array(bkeys * 11, type=pa.int64()),
+                      "x": random_table(rng, nb, {"x": (pa.decimal128(15, 2), -10**6, 10**6)}).column("x"),
+                      "u": pa.array((np.arange(nb) % 251).astype(np.uint8), type=pa.uint8())})
+    probe = random_table(rng, npr, {"k2": (pa.int64(), -5000, 12 * nb + 5000), "e": (pa.decimal128(15, 2), 0, 10**7), "q": (pa.int32(), 0, 50)})
+    probe = probe.set_column(0, "k2", pa.array(probe.column("k2").to_numpy(), mask=rng.random(npr) < 0.02))   # NULL keys; the payload stays non-nullable
+    b, p = DeviceTable.from_arrow(build), DeviceTable.from_arrow(probe)
+    os.environ.update({"DFGPU_JOIN_BIG_TABLE_BYTES": "0", "DFGPU_JOIN_GROUPED_MIN_ROWS": "0", "DFGPU_JOIN_GP_BITS": gp_bits})
+    try:
+        for payload in (["d", "p"], ["x", "u", "w", "p", "d"], ["w"], []):
+            exp = oracle.hash_join(build, probe, [("k", "k2")], "Inner").select(payload + ["k2", "e", "q"])
+            for probe_mode in (0, 3, 4):
+                ht = ops.JoinHashTable(b, ["k"], probe_mode=probe_mode)
+                assert ht.info().table_kind == 2
+                ops.profile_enable(True)
+                ops.profile_reset()
+                got = ht.probe(p, ["k2"], "Inner", payload, ["k2", "e", "q"]).to_arrow()
+                stats = ops.profile_stats()
+                ops.profile_enable(False)
+                assert "join_probe_grouped_lookup" in stats and "join_build_rank_perm" not in stats, sorted(stats)
+                assert ("join_build_rank_payload" in stats) == (build_order == "shuffled" and bool(payload)), sorted(stats)
+                assert_tables_equal(got, exp, ordered=probe_mode == 0)
+                ht.free()
+        ht = ops.JoinHashTable(b, ["k"])
+        for jt in ("RightSemi", "RightAnti"):
+            got = ht.probe(p, ["k2"], jt, [], ["k2", "q"]).to_arrow()
+            assert_tables_equal(got, oracle.hash_join(build, probe, [("k", "k2")], jt).select(["k2", "q"]), ordered=True)
+        # a FilterExec fused below the probe side (its row mask rides through the grouping)
+        pred = col("q") < lit(20, pa.int32())
+        got = ht.probe(p, ["k2"], "Inner", ["d", "w"], ["k2", "e"], predicate=pred).to_arrow()
+        kept = probe.filter(pa.compute.less(probe.column("q"), 20))
+        assert_tables_equal(got, oracle.hash_join(build, kept, [("k", "k2")], "Inner").select(["d", "w", "k2", "e"]), ordered=True)
+        ht.free()
+        # every probe row finds its key (a foreign key): the lookup's hit count lets the placed probe run without a counts pass
+        fk = pa.table({"k2": pa.array(bkeys[rng.integers(0, nb, npr)]), "e": probe.column("e")})
+        ht = ops.JoinHashTable(b, ["k"])
+        ops.profile_enable(True)
+        ops.profile_reset()
+        got = ht.probe(DeviceTable.from_arrow(fk), ["k2"], "Inner", ["d", "p"], ["k2", "e"]).to_arrow()
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+        assert "join_probe_grouped_lookup" in stats and "join_probe_tile_counts" not in stats and "join_probe_speculation_missed" not in stats, sorted(stats)
+        assert_tables_equal(got, oracle.hash_join(build, fk, [("k", "k2")], "Inner").select(["d", "p", "k2", "e"]), ordered=True)
+        ht.free()
+    finally:
+        for k in ("DFGPU_JOIN_BIG_TABLE_BYTES", "DFGPU_JOIN_GROUPED_MIN_ROWS", "DFGPU_JOIN_GP_BITS"):
+            os.environ.pop(k, None)
+
+
 @pytest.mark.parametrize("dangling", [0, 3])
 def test_probe_order_speculation_every_row_finds_its_key(dangling):
     """the probe-order (placed) flavour skips its counts pass when 64 K sampled probe rows all find their key and verifies the
