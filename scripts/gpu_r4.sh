@@ -1,0 +1,30 @@
+#!/bin/bash
+# usage (on the GPU box, via gpurun): scripts/gpu_r4.sh <tag> [tests] [sf300] [shapes] [ops] [bench] — writes gpurun_out/<tag>/
+set -u
+TAG=$1; shift
+WHAT=${*:-tests sf300 shapes}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+if has tests; then
+  (time timeout ${TESTS_TIMEOUT:-1200} python -m pytest tests -m gpu -q --maxfail=${MAXFAIL:-25} -p no:cacheprovider -k "not sf300 ${TESTS_K:-}") > $OUT/pytest.log 2>&1
+  tail -40 $OUT/pytest.log
+fi
+if has sf300; then
+  (time timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -s -p no:cacheprovider -k sf300) > $OUT/pytest_sf300.log 2>&1
+  tail -15 $OUT/pytest_sf300.log
+fi
+if has shapes; then
+  (time timeout 1200 python scripts/bench_join_shapes.py --md $OUT/join_shapes.md ${SHAPES_ARGS:-}) > $OUT/join_shapes.jsonl 2> $OUT/join_shapes.err
+  cat $OUT/join_shapes.md; tail -5 $OUT/join_shapes.err
+fi
+if has ops; then
+  (time timeout 1200 python scripts/bench_ops.py --md $OUT/ops.md ${OPS_ARGS:-}) > $OUT/ops.jsonl 2> $OUT/ops.err
+  cat $OUT/ops.md; tail -5 $OUT/ops.err
+fi
+if has bench; then
+  (time timeout 600 python bench.py) > $OUT/bench.json 2> $OUT/bench.err
+  tail -2 $OUT/bench.json; tail -3 $OUT/bench.err
+fi
