@@ -35,8 +35,10 @@ Extra objects on the JSON line:
                  (frac) and the measured 6.29 TB/s copy ceiling (frac_vs_copy_ceiling).
   ordered_output — the same step with the output in probe order (what the reference emits), with its own
                  roofline object.
-  cpu_baseline — the CPU restatement (oracle/, kind "port") of DataFusion's partitioned hash
-                 join, timed on this box's host cores on a bounded sample of the same workload.
+  cpu_baseline — the CPU restatement (oracle/, kind "port") of DataFusion's plan for the same join — RepartitionExec(Hash) of
+                 both sides, HashJoinExec(Partitioned), build_batch_from_indices of the five Q3 payload columns — timed on this
+                 box's host cores on the GPU leg's own tables at the GPU leg's scale factor when host RAM allows (the SF is
+                 stated; `speedup_vs_cpu_port` is only reported between equal workloads).
 """
 import argparse
 import json
@@ -72,43 +74,113 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(sample_sf, cores):
-    """oracle leg: RepartitionExec(Hash) x2 -> HashJoinExec(Partitioned), one thread per partition
-    (target_partitions); the best of a few partition counts up to the core count is reported, since one
-    partition per core is not the fastest setting on a many-core NUMA host"""
+def host_memory_available():
+    """bytes of host RAM this process may still take: MemAvailable, capped by the cgroup's memory.max minus memory.current"""
+    avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    try:
+        mx = open("/sys/fs/cgroup/memory.max").read().strip()
+        if mx != "max":
+            room = int(mx) - int(open("/sys/fs/cgroup/memory.current").read())
+            avail = room if avail is None else min(avail, room)
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
+def _host_q3_columns(orders, lineitem):
+    """the Q3 join's referenced columns of two device tables as host numpy arrays (Decimal128 as (n, 2) uint64, low word first)"""
+    import numpy as np
+    o = orders.select(["o_orderkey", "o_orderdate", "o_shippriority"]).to_arrow()
+    l = lineitem.select(["l_orderkey", "l_extendedprice", "l_discount"]).to_arrow()
+
+    def dec(c):
+        a = c.combine_chunks()
+        return np.frombuffer(a.buffers()[1], dtype=np.uint64)[2 * a.offset:2 * (a.offset + len(a))].reshape(-1, 2)
+    import pyarrow as pa
+    return (o.column("o_orderkey").to_numpy(), o.column("o_orderdate").cast(pa.int32()).to_numpy(), o.column("o_shippriority").to_numpy(),
+            l.column("l_orderkey").to_numpy(), dec(l.column("l_extendedprice")), dec(l.column("l_discount"))), (o, l)
+
+
+def cpu_baseline(gpu_sf, max_sf, hw_threads, orders_dev=None, lineitem_dev=None):
+    """oracle leg (kind "port"): the SAME join as the GPU leg, as the reference plans it on a CPU — RepartitionExec(Hash) of every
+    column of both sides -> HashJoinExec(Partitioned), one thread per partition, 8192-row probe batches, build_batch_from_indices of
+    the five Q3 payload columns per batch (oracle/dforacle.c orc_partitioned_q3_join) — on the GPU leg's own tables copied to the
+    host, at the GPU leg's scale factor when host RAM allows (inputs + their repartitioned copies: 2 x 26.4 GB at SF100), else at the
+    largest of SF50 / 30 / 10 that fits.  The partition count is chosen on an SF10 sample first (one partition per core is not the
+    fastest setting on a many-core NUMA host behind a CPU quota); the big run uses that count once."""
     import numpy as np
 
-    from datafusion_amd import tpch
+    from datafusion_amd import ops
     from oracle import oracle
-    i = np.arange(tpch.n_orders(sample_sf), dtype=np.int64)
-    bk = tpch.order_key(i)
-    pk = np.repeat(bk, tpch.line_count(i))
-    best, best_t, tried = None, None, {}
-    for threads in sorted({max(1, cores), max(1, cores // 2), max(1, cores // 4), min(cores, 32)}, reverse=True):
+    quota = cpu_quota()
+    cores = max(1, int(min(hw_threads, quota) if quota else hw_threads))   # threads that can actually run at a time
+    avail = host_memory_available()
+    need = lambda sf: int(sf * 1.0e6 * (1.5 * 16 + 6.0 * 40) * 2.6)   # inputs + repartitioned copies + Arrow export buffers, 30 % slack
+    sample_sf = next((sf for sf in (gpu_sf, 50.0, 30.0, 10.0) if sf <= min(gpu_sf, max_sf) and (avail is None or need(sf) < avail)), min(gpu_sf, 1.0))
+    small_sf = min(10.0, sample_sf)
+
+    def tables(sf):
+        if sf == gpu_sf and orders_dev is not None:
+            return orders_dev, lineitem_dev, False
+        return ops.tpch_orders(sf), ops.tpch_lineitem(sf), True
+    o, l, own = tables(small_sf)
+    cols, keep = _host_q3_columns(o, l)
+    if own:
+        o.free()
+        l.free()
+    tried, best_t, best = {}, None, None
+    for threads in sorted({cores, 2 * cores, max(1, cores // 2), min(hw_threads, 32)}, reverse=True):
         t0 = time.perf_counter()
-        pairs, _chk = oracle.partitioned_inner_join_i64(bk, pk, threads)
+        rows, chk_small = oracle.partitioned_q3_join(*cols, threads)
         dt = time.perf_counter() - t0
-        assert pairs == len(pk)
-        tried[threads] = round((len(bk) + len(pk)) / dt)
+        assert rows == len(cols[3])
+        tried[threads] = round((len(cols[0]) + len(cols[3])) / dt)
         if best is None or dt < best:
             best, best_t = dt, threads
-    out = {"value": (len(bk) + len(pk)) / best, "unit": "rows/s", "cores": best_t, "kind": "port",
-           "sample": f"orders x lineitem keys at SF{sample_sf:g} ({len(bk)} build + {len(pk)} probe rows), "
-                     f"{best_t} partitions/threads (best of {tried} rows/s; host has {cores} hardware threads, cgroup CPU quota {cpu_quota()}), "
-                     f"8192-row probe batches, key-only pairs (no payload gather)", "cpu_quota": cpu_quota()}
-    try:  # independent production CPU engine on the same sample (BASELINE.md §2 B): Arrow Acero hash join
+    nb, np_, dt_big = len(cols[0]), len(cols[3]), best
+    if sample_sf > small_sf:
+        del cols, keep
+        o, l, own = tables(sample_sf)
+        cols, keep = _host_q3_columns(o, l)
+        if own:
+            o.free()
+            l.free()
+        t0 = time.perf_counter()
+        rows, _chk = oracle.partitioned_q3_join(*cols, best_t)
+        dt_big = time.perf_counter() - t0
+        nb, np_ = len(cols[0]), len(cols[3])
+        assert rows == np_
+    out = {"value": (nb + np_) / dt_big, "unit": "rows/s", "cores": min(best_t, cores), "threads": best_t, "kind": "port", "sf": sample_sf,
+           "same_workload_as_gpu_leg": bool(sample_sf == gpu_sf),
+           "sample": f"orders x lineitem at SF{sample_sf:g} with the Q3 payload ({nb} build rows x 16 B, {np_} probe rows x 40 B, {np_} output rows x 48 B): "
+                     f"RepartitionExec(Hash) of all columns of both sides -> HashJoinExec(Partitioned) -> build_batch_from_indices per 8192-row "
+                     f"probe batch (output batches produced, checksummed and dropped like the reference's stream), {best_t} partitions/threads "
+                     f"chosen on SF{small_sf:g} (rows/s by thread count: {tried}); host has {hw_threads} hardware threads, cgroup CPU quota {quota}, "
+                     f"{'unknown' if avail is None else round(avail / 2**30)} GiB of host RAM available", "cpu_quota": quota}
+    try:  # independent production CPU engine (BASELINE.md §2 B): Arrow Acero hash join WITH the payload, on the SF10-sized sample
         import pyarrow as pa
         pa.set_cpu_count(cores)
-        b = pa.table({"k": bk, "bi": np.arange(len(bk), dtype=np.int64)})
-        p = pa.table({"k": pk, "pi": np.arange(len(pk), dtype=np.int64)})
+        so, sl, sown = tables(small_sf)
+        bt = so.select(["o_orderkey", "o_orderdate", "o_shippriority"]).to_arrow()
+        pt = sl.select(["l_orderkey", "l_extendedprice", "l_discount"]).to_arrow()
+        if sown:
+            so.free()
+            sl.free()
         t_best = None
         for _ in range(2):
             t0 = time.perf_counter()
-            j = p.join(b, keys="k", join_type="inner")
+            j = pt.join(bt, keys="l_orderkey", right_keys="o_orderkey", join_type="inner")
             dt = time.perf_counter() - t0
-            assert j.num_rows == len(pk)
+            assert j.num_rows == pt.num_rows
             t_best = dt if t_best is None else min(t_best, dt)
-        out["acero_rows_per_s"] = (len(bk) + len(pk)) / t_best
+        out["acero_rows_per_s"] = (bt.num_rows + pt.num_rows) / t_best
+        out["acero_sample"] = f"SF{small_sf:g}, the same five payload columns, {cores} threads"
     except Exception as e:  # noqa: BLE001 - the Acero leg is a sanity bound, never required
         out["acero_error"] = str(e)[:200]
     return out
@@ -329,8 +401,9 @@ def run_join(args, rank, world, dist):
                                   "roofline": roofline_of(ordered["stats"]), "kernels": kernel_table(ordered["stats"])}
     if not args.no_cpu and world == 1:  # the CPU baseline is reported by the single-GPU run only
         threads = os.cpu_count() or 1
-        line["cpu_baseline"] = cpu_baseline(args.cpu_sf, threads)
-        line["speedup_vs_cpu_port"] = round(rows_per_s / line["cpu_baseline"]["value"], 1)
+        line["cpu_baseline"] = cpu_baseline(args.sf, args.cpu_sf, threads, orders, lineitem)
+        # a ratio only between equal workloads: the same tables, the same payload, the same scale factor
+        line["speedup_vs_cpu_port"] = round(rows_per_s / line["cpu_baseline"]["value"], 1) if line["cpu_baseline"]["same_workload_as_gpu_leg"] else None
     return line
 
 
@@ -400,7 +473,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor (BASELINE: 100)")
-    ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the CPU-baseline sample")
+    ap.add_argument("--cpu-sf", type=float, default=100.0, help="largest scale factor the CPU-baseline leg may run at (it takes the GPU leg's when host RAM allows)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", choices=["join", "q1", "q3"], default="join",
                     help="join = the BASELINE metric (config 3 ii); q1 / q3 = the whole TPC-H Q1 / Q3 plan per step (configs 4 and 5)")

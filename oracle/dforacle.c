@@ -405,6 +405,112 @@ int orc_partitioned_inner_join_i64(const int64_t* bkeys, int64_t nb, const int64
   return 0;
 }
 
+/* The same plan with TPC-H Q3's payload (bench.py's cpu_baseline leg, SURVEY 8d "CPU path timed beside it"): what the GPU leg
+ * of the benchmark does, as the reference does it.
+ *   RepartitionExec(Hash) moves EVERY column of both inputs (BatchPartitioner::partition_iter -> take of each column,
+ *   repartition/mod.rs:1111-1150,1237): build {o_orderkey i64, o_orderdate i32, o_shippriority i32}, probe {l_orderkey i64,
+ *   l_extendedprice i128, l_discount i128};
+ *   HashJoinExec(Partitioned) per partition: JoinHashMap over the partition's build keys (update_from_iter), probe in
+ *   8192-row batches (lookup_join_hashmap -> equal_rows_arr), and build_batch_from_indices (joins/utils.rs:1332-1386) = arrow
+ *   `take` of the two build payload columns by the matched build indices and of the three probe columns by the probe indices
+ *   into a fresh output batch (48 bytes per row).  The reference hands each output batch to the next operator and drops it; here
+ *   the batch is folded into a checksum (one pass over a cache-resident batch) and its buffers are reused.
+ * out_rows = joined rows; out_checksum = wrapping sum over output rows of
+ *   (o_orderdate + 3 * o_shippriority + 5 * l_orderkey + 7 * low64(l_extendedprice) + 11 * low64(l_discount)) — order independent. */
+int orc_partitioned_q3_join(const int64_t* bkeys, const int32_t* bdate, const int32_t* bprio, int64_t nb, const int64_t* pkeys,
+                            const i128* pprice, const i128* pdisc, int64_t np, int nthreads, int64_t* out_rows, uint64_t* out_checksum) {
+  if (nthreads < 1) nthreads = 1;
+  const int T = nthreads;
+  const int64_t BATCH = 8192;
+  int64_t* bcount = (int64_t*)calloc((size_t)T * T + T, 8);
+  int64_t* pcount = (int64_t*)calloc((size_t)T * T + T, 8);
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+  for (int t = 0; t < T; t++) {
+    int64_t lo = nb * t / T, hi = nb * (t + 1) / T;
+    for (int64_t i = lo; i < hi; i++) bcount[(size_t)t * T + hash_u64((uint64_t)bkeys[i], ORC_SEED_REPARTITION) % (uint64_t)T]++;
+    lo = np * t / T; hi = np * (t + 1) / T;
+    for (int64_t i = lo; i < hi; i++) pcount[(size_t)t * T + hash_u64((uint64_t)pkeys[i], ORC_SEED_REPARTITION) % (uint64_t)T]++;
+  }
+  int64_t* boff = (int64_t*)malloc((size_t)T * T * 8), *poff = (int64_t*)malloc((size_t)T * T * 8);
+  int64_t* bstart = (int64_t*)malloc((T + 1) * 8), *pstart = (int64_t*)malloc((T + 1) * 8);
+  int64_t accb = 0, accp = 0;
+  for (int part = 0; part < T; part++) {
+    bstart[part] = accb; pstart[part] = accp;
+    for (int t = 0; t < T; t++) { boff[(size_t)t * T + part] = accb; accb += bcount[(size_t)t * T + part]; poff[(size_t)t * T + part] = accp; accp += pcount[(size_t)t * T + part]; }
+  }
+  bstart[T] = accb; pstart[T] = accp;
+  const size_t nb1 = (size_t)(nb > 0 ? nb : 1), np1 = (size_t)(np > 0 ? np : 1);
+  int64_t* bk2 = (int64_t*)malloc(nb1 * 8); int32_t* bd2 = (int32_t*)malloc(nb1 * 4); int32_t* bp2 = (int32_t*)malloc(nb1 * 4);
+  int64_t* pk2 = (int64_t*)malloc(np1 * 8); i128* pp2 = (i128*)malloc(np1 * 16); i128* pd2 = (i128*)malloc(np1 * 16);
+  if (!bk2 || !bd2 || !bp2 || !pk2 || !pp2 || !pd2) return -1;
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+  for (int t = 0; t < T; t++) {
+    int64_t lo = nb * t / T, hi = nb * (t + 1) / T;
+    for (int64_t i = lo; i < hi; i++) {
+      int part = (int)(hash_u64((uint64_t)bkeys[i], ORC_SEED_REPARTITION) % (uint64_t)T);
+      int64_t o = boff[(size_t)t * T + part]++;
+      bk2[o] = bkeys[i]; bd2[o] = bdate[i]; bp2[o] = bprio[i];
+    }
+    lo = np * t / T; hi = np * (t + 1) / T;
+    for (int64_t i = lo; i < hi; i++) {
+      int part = (int)(hash_u64((uint64_t)pkeys[i], ORC_SEED_REPARTITION) % (uint64_t)T);
+      int64_t o = poff[(size_t)t * T + part]++;
+      pk2[o] = pkeys[i]; pp2[o] = pprice[i]; pd2[o] = pdisc[i];
+    }
+  }
+  int64_t total = 0; uint64_t checksum = 0;
+#pragma omp parallel for num_threads(T) schedule(static, 1) reduction(+ : total, checksum)
+  for (int part = 0; part < T; part++) {
+    int64_t b0 = bstart[part], nbp = bstart[part + 1] - b0;
+    int64_t p0 = pstart[part], npp = pstart[part + 1] - p0;
+    join_hash_map hm; jhm_init(&hm, nbp);
+    for (int64_t i = nbp - 1; i >= 0; i--) jhm_insert(&hm, hash_u64((uint64_t)bk2[b0 + i], ORC_SEED_JOIN), i);
+    uint64_t* hashes = (uint64_t*)malloc(BATCH * 8);
+    /* pairs of one probe batch; an FK -> PK probe has one match per row, M:N batches grow */
+    int64_t cap = BATCH * 2, *ib = (int64_t*)malloc(cap * 8), *ip = (int64_t*)malloc(cap * 8);
+    int32_t* o_date = (int32_t*)malloc(cap * 4), *o_prio = (int32_t*)malloc(cap * 4);
+    int64_t* o_key = (int64_t*)malloc(cap * 8); i128* o_price = (i128*)malloc(cap * 16), *o_disc = (i128*)malloc(cap * 16);
+    for (int64_t s0 = 0; s0 < npp; s0 += BATCH) {
+      int64_t e = s0 + BATCH < npp ? s0 + BATCH : npp, m = 0;
+      for (int64_t i = s0; i < e; i++) hashes[i - s0] = hash_u64((uint64_t)pk2[p0 + i], ORC_SEED_JOIN);
+      for (int64_t i = s0; i < e; i++) {
+        uint64_t cur = jhm_find(&hm, hashes[i - s0]);
+        while (cur) {
+          int64_t b = (int64_t)cur - 1;
+          if (bk2[b0 + b] == pk2[p0 + i]) {
+            if (m == cap) {
+              cap *= 2;
+              ib = (int64_t*)realloc(ib, cap * 8); ip = (int64_t*)realloc(ip, cap * 8);
+              o_date = (int32_t*)realloc(o_date, cap * 4); o_prio = (int32_t*)realloc(o_prio, cap * 4);
+              o_key = (int64_t*)realloc(o_key, cap * 8); o_price = (i128*)realloc(o_price, cap * 16); o_disc = (i128*)realloc(o_disc, cap * 16);
+            }
+            ib[m] = b; ip[m] = i; m++;
+          }
+          cur = hm.next[b];
+        }
+      }
+      /* build_batch_from_indices: one take per output column */
+      for (int64_t j = 0; j < m; j++) o_date[j] = bd2[b0 + ib[j]];
+      for (int64_t j = 0; j < m; j++) o_prio[j] = bp2[b0 + ib[j]];
+      for (int64_t j = 0; j < m; j++) o_key[j] = pk2[p0 + ip[j]];
+      for (int64_t j = 0; j < m; j++) o_price[j] = pp2[p0 + ip[j]];
+      for (int64_t j = 0; j < m; j++) o_disc[j] = pd2[p0 + ip[j]];
+      uint64_t c = 0;
+      for (int64_t j = 0; j < m; j++)
+        c += (uint64_t)(int64_t)o_date[j] + 3u * (uint64_t)(int64_t)o_prio[j] + 5u * (uint64_t)o_key[j] + 7u * (uint64_t)o_price[j] + 11u * (uint64_t)o_disc[j];
+      checksum += c;
+      total += m;
+    }
+    free(hashes); free(ib); free(ip); free(o_date); free(o_prio); free(o_key); free(o_price); free(o_disc);
+    jhm_free(&hm);
+  }
+  free(bcount); free(pcount); free(boff); free(poff); free(bstart); free(pstart);
+  free(bk2); free(bd2); free(bp2); free(pk2); free(pp2); free(pd2);
+  if (out_rows) *out_rows = total;
+  if (out_checksum) *out_checksum = checksum;
+  return 0;
+}
+
 /* ------------------------------------------------------------------ filter (K8) */
 
 /* filter_record_batch with a BooleanArray predicate (filter.rs:1339-1362; arrow-select

@@ -97,6 +97,10 @@ void orc_free(void* p);
 int orc_partitioned_inner_join_i64(const int64_t* build_keys, int64_t nb,
                                    const int64_t* probe_keys, int64_t np, int nthreads,
                                    int64_t* out_pairs, uint64_t* out_checksum);
+/* the same plan carrying TPC-H Q3's payload through RepartitionExec and build_batch_from_indices (bench.py cpu_baseline) */
+int orc_partitioned_q3_join(const int64_t* bkeys, const int32_t* bdate, const int32_t* bprio, int64_t nb, const int64_t* pkeys,
+                            const __int128* pprice, const __int128* pdisc, int64_t np, int nthreads, int64_t* out_rows, uint64_t* out_checksum);
+
 
 /* K8: filter (physical-plan/src/filter.rs:1339-1362; arrow `filter` treats a NULL
  * predicate as false).  mask/mask_valid are bit-packed; writes selected row ids. */

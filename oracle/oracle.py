@@ -271,6 +271,24 @@ def partitioned_inner_join_i64(build_keys: np.ndarray, probe_keys: np.ndarray, n
     return pairs.value, chk.value
 
 
+def partitioned_q3_join(bkeys, bdate, bprio, pkeys, pprice, pdisc, nthreads: int):
+    """CPU-baseline leg with TPC-H Q3's payload: RepartitionExec(Hash) of every column of both sides -> HashJoinExec(Partitioned) ->
+    build_batch_from_indices per 8192-row probe batch (dforacle.c orc_partitioned_q3_join).  Keys int64, o_orderdate / o_shippriority
+    int32, the two Decimal128 columns as (n, 2) uint64 / int64 arrays (low word first).  Returns (rows, checksum)."""
+    L = lib()
+    arrs = [np.ascontiguousarray(bkeys, dtype=np.int64), np.ascontiguousarray(bdate, dtype=np.int32), np.ascontiguousarray(bprio, dtype=np.int32),
+            np.ascontiguousarray(pkeys, dtype=np.int64), np.ascontiguousarray(pprice), np.ascontiguousarray(pdisc)]
+    assert arrs[4].nbytes == 16 * len(arrs[3]) and arrs[5].nbytes == 16 * len(arrs[3]) and len(arrs[1]) == len(arrs[0]) == len(arrs[2])
+    rows, chk = C.c_int64(), C.c_uint64()
+    L.orc_partitioned_q3_join.restype = C.c_int
+    rc = L.orc_partitioned_q3_join(C.c_void_p(arrs[0].ctypes.data), C.c_void_p(arrs[1].ctypes.data), C.c_void_p(arrs[2].ctypes.data), C.c_int64(len(arrs[0])),
+                                   C.c_void_p(arrs[3].ctypes.data), C.c_void_p(arrs[4].ctypes.data), C.c_void_p(arrs[5].ctypes.data), C.c_int64(len(arrs[3])),
+                                   int(nthreads), C.byref(rows), C.byref(chk))
+    if rc != 0:
+        raise MemoryError("orc_partitioned_q3_join: allocation failed")
+    return rows.value, chk.value
+
+
 # ---------------------------------------------------------------------- expressions
 
 def _decimal_unscaled(v, scale: int) -> int:
