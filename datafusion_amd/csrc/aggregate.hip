@@ -1193,7 +1193,7 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
       // tried for the sake of cache hits on the rows' random accesses: 6.6 -> 8.0 ms over 600 M rows, but measured on a box whose
       // whole test run was 3 x slower than the others'; by profiles/r3_random_access.md a 256 KB table should cost no more than a
       // 1 MB one — to be measured again)
-      static const bool small_table = std::getenv("DFGPU_AGG_SMALL_TABLE") && std::getenv("DFGPU_AGG_SMALL_TABLE")[0] == '1';
+      const bool small_table = std::getenv("DFGPU_AGG_SMALL_TABLE") && std::getenv("DFGPU_AGG_SMALL_TABLE")[0] == '1';
       if (small_table && d_all < 1.25 * d_early) {   // (opt-in: ~4 slots per key when the sample has seen them all, from 4 K slots)
         uint64_t want = 1 << 12;
         while ((double)want < 2.0 * est && want < cap_max) want <<= 1;
@@ -1220,7 +1220,7 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
       if (want_row_slots && !R.row_slot) R.row_slot = make_buf((size_t)total * 4);
       uint32_t* rs = R.row_slot ? R.row_slot->as<uint32_t>() : nullptr;
       // (opt-in, not yet run on the GPU: see k_intern_claim_keyed_lds)
-      static const bool lds_claim = std::getenv("DFGPU_AGG_LDS_CLAIM") && std::getenv("DFGPU_AGG_LDS_CLAIM")[0] == '1';
+      const bool lds_claim = std::getenv("DFGPU_AGG_LDS_CLAIM") && std::getenv("DFGPU_AGG_LDS_CLAIM")[0] == '1';
       constexpr int LBITS = 13;
       constexpr size_t LDS_CLAIM_BYTES = (size_t)16 << LBITS;
       if (keyed && lds_claim && sample_saw_all_keys && cap < (1ull << 31) &&
@@ -2108,7 +2108,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
       if (W * 12 > ((size_t)64 << 10)) return false;
     }
     // (opt-in: the slot -> group table in LDS beside the cells — up to 16 K + 1 slots as 16-bit words on top of the budget)
-    static const bool small_table = std::getenv("DFGPU_AGG_SMALL_TABLE") && std::getenv("DFGPU_AGG_SMALL_TABLE")[0] == '1';
+    const bool small_table = std::getenv("DFGPU_AGG_SMALL_TABLE") && std::getenv("DFGPU_AGG_SMALL_TABLE")[0] == '1';
     if (small_table && in_place && key_map && key_map_n > 0 && key_map_n <= (1 << 14) + 1 && range <= 65535 &&
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET + (((size_t)key_map_n * 2 + 15) & ~(size_t)15))) == hipSuccess)
       map_n = (int)key_map_n;

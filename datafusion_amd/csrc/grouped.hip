@@ -57,7 +57,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_hist(KeyCol key, int64_t n, Grou
       for (int c = 0; c < ITEMS; c++) {
         const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
         const uint64_t idx = k[c] - gs.offset;
-        if (i < hi && idx < gs.size && gp_row_takes_part(key, row_mask, i)) atomicAdd(&s_cnt[idx >> gs.shift], 1u);
+        if (i < hi && idx < gs.size && gp_row_takes_part(key, row_mask, i)) atomicAdd(&s_cnt[__umul64hi(idx, gs.mul)], 1u);
       }
     }
     __syncthreads();
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_scatter(KeyCol key, int64_t n, G
         const uint64_t idx = k[c] - gs.offset;
         gr[c] = 0xFFFFFFFFu;
         if (i < hi && idx < gs.size && gp_row_takes_part(key, row_mask, i)) {
-          const unsigned g = (unsigned)(idx >> gs.shift);
+          const unsigned g = (unsigned)__umul64hi(idx, gs.mul);
           gr[c] = (g << GP_RANK_BITS) | atomicAdd(&s_cnt[g], 1u);
         }
       }
@@ -219,7 +219,7 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
   DFGPU_CHECK(n > 0 && n < 0xFFFFFFFFll, "group_rows_by_key: row count out of range");
   DFGPU_CHECK(nbits >= 1 && (1 << nbits) <= GP_MAX_GROUPS, "group_rows_by_key: bad number of groups");
   DFGPU_CHECK(carry_src.size() == carry_width.size() && (int)carry_src.size() <= GP_MAX_COLS, "group_rows_by_key: bad carried columns");
-  DFGPU_CHECK(gs.size > 0 && ((gs.size - 1) >> gs.shift) < (1ull << nbits), "group_rows_by_key: the key range does not fit the groups");
+  DFGPU_CHECK(gs.size > 0 && (uint64_t)(((unsigned __int128)(gs.size - 1) * gs.mul) >> 64) < (1ull << nbits), "group_rows_by_key: the key range does not fit the groups");
   const int P = 1 << nbits;
   GroupedRows out;
   out.P = P;

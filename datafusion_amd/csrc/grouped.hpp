@@ -7,11 +7,15 @@
 
 namespace dfgpu {
 
-// group of a key: idx = key - offset (wrapping) must be < size; group = idx >> shift
+// group of a key: idx = key - offset (wrapping) must be < size; group = floor(idx * mul / 2^64) — `groups` equal stretches of the
+// key range whatever its size (a shift would leave up to half of a power-of-two number of groups empty and the others twice as wide)
 struct GroupSpec {
-  uint64_t offset, size;
-  int shift;
+  uint64_t offset, size, mul;
 };
+inline GroupSpec group_spec(uint64_t offset, uint64_t size, int groups) {
+  const unsigned __int128 m = (((unsigned __int128)(unsigned)groups) << 64) / (size ? size : 1);
+  return GroupSpec{offset, size, m > (unsigned __int128)~0ull ? ~0ull : (uint64_t)m};
+}
 constexpr int GP_MAX_GROUPS = 1024;
 constexpr int GP_MAX_COLS = 8;
 struct GroupCols {

@@ -323,6 +323,41 @@ __global__ __launch_bounds__(BLOCK) void k_rank_setbytes(KeyCol k, int64_t n, ui
   }
 }
 // rank map build: {bitmap word, prefix} side by side for the probe
+// Rank map over MANY keys in no order (round 4): the build keys are grouped by their position in the key range first
+// (grouped.hip: 1024 groups), then ONE workgroup per group sets the group's bits in an LDS bitmap — a group spans at most 2^20
+// key values = 128 KB of bits — and writes the words out: interior words with plain coalesced stores, the two words it may share
+// with its neighbour groups with an atomicOr.  No byte map (one byte per VALUE of the range), no random global atomics; a bit
+// that was already set is a duplicate key (150 M shuffled keys: 5.4 + 0.7 ms of byte map + pack -> see profiles/r4_join_shapes.md).
+constexpr int RB_THREADS = 1024;
+__global__ __launch_bounds__(RB_THREADS) void k_rank_bits_grouped(const uint64_t* __restrict__ gkeys, const uint64_t* __restrict__ bounds, const uint64_t* __restrict__ gfirst,
+                                                                  uint64_t offset, unsigned long long* __restrict__ bits, int* __restrict__ dup_flag) {
+  extern __shared__ unsigned long long rb_words[];
+  const int g = blockIdx.x;
+  const uint64_t v0 = gfirst[g], v1 = gfirst[g + 1];   // the group's values [v0, v1) of the key range
+  if (v1 <= v0) return;
+  const uint64_t w0 = v0 >> 6, w1 = (v1 - 1) >> 6;      // its bitmap words [w0, w1]
+  const int nw = (int)(w1 - w0 + 1);
+  for (int i = threadIdx.x; i < nw; i += RB_THREADS) rb_words[i] = 0ull;
+  __syncthreads();
+  const int64_t r0 = (int64_t)bounds[g], r1 = (int64_t)bounds[g + 1];
+  bool dup = false;
+  for (int64_t i = r0 + threadIdx.x; i < r1; i += RB_THREADS) {
+    const uint64_t idx = gkeys[i] - offset;
+    const unsigned long long bit = 1ull << (idx & 63);
+    const unsigned long long old = atomicOr(&rb_words[(idx >> 6) - w0], bit);
+    dup |= (old & bit) != 0;
+  }
+  if (dup) *dup_flag = 1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nw; i += RB_THREADS) {
+    const unsigned long long w = rb_words[i];
+    if (i == 0 || i == nw - 1) {
+      if (w) atomicOr(&bits[w0 + i], w);   // may be shared with the neighbouring group
+    } else {
+      bits[w0 + i] = w;
+    }
+  }
+}
 __global__ __launch_bounds__(BLOCK) void k_rank_interleave(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ prefix, int64_t n_words, ulonglong2* __restrict__ tab) {
   for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * BLOCK) tab[w] = make_ulonglong2(bits[w], prefix[w]);
 }
@@ -396,6 +431,11 @@ __global__ __launch_bounds__(BLOCK) void k_hm_check_unique(KeySet ks, int64_t n,
 // ------------------------------------------------------------------------ flat table (keys inline)
 // the key columns of row i as one packed key of <= 16 bytes; false = the row has a NULL key that matches nothing
 __device__ __forceinline__ bool flat_pack(const KeySet& ks, const FlatLayout& L, int64_t i, bool null_equals_null, uint64_t& k0, uint64_t& k1) {
+  if (ks.n == 1 && ks.c[0].width == 8 && !ks.c[0].valid) {   // the common single Int64 / Float64 key: its bits are the packed key
+    k0 = ((const uint64_t*)ks.c[0].data)[i];
+    k1 = 0;
+    return true;
+  }
   u128 k = 0;
   for (int c = 0; c < ks.n; c++) {
     const KeyCol& kc = ks.c[c];
@@ -527,7 +567,7 @@ __device__ __forceinline__ bool chain_match(const ProbeCtx& c, int64_t b, int64_
 // stage (keys -> validity -> table words -> perm) issues its N loads together; out-of-range lanes
 // load a clamped address and are masked afterwards, so there is no branch between the loads.
 template <int KIND, int KT, int N>
-__device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int64_t np, uint32_t (&m)[N], uint64_t* raw_keys = nullptr) {
+__device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int64_t np, uint32_t (&m)[N], uint64_t* raw_keys = nullptr, uint4* rec16 = nullptr) {
   const unsigned lane = lane_id();
   if (KIND == KIND_RETURNED) {
     uint32_t d[N];
@@ -538,6 +578,16 @@ __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int6
       ok[j] = p < np;
       d[j] = c.ret_dest[ok[j] ? p : np - 1];
       if (c.row_mask) ok[j] = ok[j] && ((c.row_mask[w0 + j] >> lane) & 1ull);
+    }
+    if (rec16) {  // 16-byte records: match id and build columns in ONE access, kept in registers until the row is written
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        ok[j] = ok[j] && d[j] != 0xFFFFFFFFu;
+        rec16[j] = reinterpret_cast<const uint4*>(c.ret_rec)[ok[j] ? d[j] : 0u];
+      }
+#pragma unroll
+      for (int j = 0; j < N; j++) m[j] = ok[j] ? rec16[j].x : 0u;
+      return;
     }
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -783,6 +833,9 @@ __global__ __launch_bounds__(BLOCK) void k_probe_emit(ProbeCtx c, int64_t np, in
     int64_t o = (int64_t)prefix[w] + (inc - cnt);
     if (cnt == 0) continue;
     uint32_t nmatch = 0;
+    // Inner / Left: a row's output rows ARE its matches, so the walk ends with the last one — a probe row with one match (all of
+    // them, over unique build keys) never reads next[]
+    const uint32_t stop_at = (join_type == DFGPU_JOIN_INNER || join_type == DFGPU_JOIN_LEFT) ? cnt : 0xFFFFFFFFu;
     if (emit_pairs || join_type == DFGPU_JOIN_RIGHT_MARK) {
       uint32_t cur = row_first ? row_first[p] : chain_head<KIND>(c, p);
       while (cur) {
@@ -790,6 +843,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_emit(ProbeCtx c, int64_t np, in
         if (chain_match<KIND>(c, b, p)) {
           if (emit_pairs) { out_build[o] = b; out_probe[o] = p; o++; }
           nmatch++;
+          if (nmatch == stop_at) break;
         }
         cur = c.next ? c.next[b] : 0u;
       }
@@ -957,6 +1011,13 @@ __device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* __restrict__ ti
   return excl;
 }
 
+// KIND_RETURNED: consecutive tiles read neighbouring records (the rows of one (grouping tile, group) run lie in a few fused tiles),
+// and workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) — so every XCD takes a CONTIGUOUS eighth of the tiles, in order, and the
+// lines one of its tiles fetched serve the next ones out of the same L2.  A bijection of [0, n_tiles) for any n_tiles; speed only.
+__device__ __forceinline__ int64_t xcd_contiguous_tile(int64_t b, int64_t n_tiles) {
+  const int64_t q = n_tiles >> 3, r = n_tiles & 7, x = b & 7, j = b >> 3;
+  return x * q + (x < r ? x : r) + j;
+}
 // per-tile output row counts of the same tiling: pass 1 of the PLACED flavour.  Reads the probe keys (and the row mask)
 // only; the table words it touches (rank-map bitmap + directory, MALL-resident) are warm for pass 2.
 // `out_words` (optional): the output rows themselves, one bit per probe row — what k_join_emit_listed materialises from.
@@ -968,7 +1029,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_tile_counts(ProbeCtx c, int64_t 
   const int64_t n_words = (np + 63) >> 6;
   const unsigned lane = lane_id();
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: the row mask words load as scalars
-  const int64_t tile = blockIdx.x;
+  const int64_t tile = KIND == KIND_RETURNED ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
   const int64_t w0 = tile * TILE_WORDS + (int64_t)wv * W;
   uint64_t hit[W];
   hit_words<KIND, KT, W>(c, w0, np, hit);
@@ -1006,7 +1067,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
   const unsigned lane = lane_id();
   const int wv = threadIdx.x >> 6;
   for (;;) {
-    int64_t tile = blockIdx.x;
+    int64_t tile = KIND == KIND_RETURNED && !ORDERED ? xcd_contiguous_tile(blockIdx.x, n_tiles) : (int64_t)blockIdx.x;
     if (ORDERED) {
       // every tile takes its OWN ticket: handing one workgroup several consecutive tiles would make
       // tile 4k wait on the AGG of tile 4k-1, which its owner only reaches after finishing
@@ -1021,7 +1082,9 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
     // ---- lookup (every stage issues its W loads back-to-back: memory-level parallelism)
     uint32_t m[W];
     uint64_t key[KEYREG ? W : 1];
-    lookup_words<KIND, KT, W>(c, w0, np, m, KEYREG ? key : nullptr);
+    uint4 rec16[KIND == KIND_RETURNED ? W : 1];
+    const bool rec_in_regs = KIND == KIND_RETURNED && c.ret_R == 16;
+    lookup_words<KIND, KT, W>(c, w0, np, m, KEYREG ? key : nullptr, rec_in_regs ? rec16 : nullptr);
     uint64_t word[W];  // wave-uniform (SGPR pairs)
     uint32_t wave_cnt = 0;
 #pragma unroll
@@ -1089,7 +1152,18 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
           continue;
         }
         int64_t s = from_build ? (int64_t)m[j] - 1 : ((w0 + j) << 6) + lane;
-        if (KIND == KIND_RETURNED && from_build) s = (int64_t)c.ret_dest[((w0 + j) << 6) + lane] * cols.ret_mul[cidx] + cols.ret_add[cidx];
+        if (KIND == KIND_RETURNED && from_build) {
+          if (rec_in_regs) {  // a 4- or 8-byte field of the record the lookup loaded
+            const uint4 rv = rec16[KIND == KIND_RETURNED ? j : 0];
+            const int bo = cols.ret_add[cidx] * width;   // byte offset inside the record (word 0 is the match id)
+            const uint32_t w32 = (bo >> 2) == 1 ? rv.y : (bo >> 2) == 2 ? rv.z : rv.w;
+            if (width == 4) reinterpret_cast<uint32_t*>(cols.dst[cidx])[d] = w32;
+            else if (width == 8) reinterpret_cast<uint64_t*>(cols.dst[cidx])[d] = ((uint64_t)rv.w << 32) | rv.z;   // an 8-byte field is the upper half
+            else reinterpret_cast<uint8_t*>(cols.dst[cidx])[d] = (uint8_t)(w32 >> ((bo & 3) * 8));
+            continue;
+          }
+          s = (int64_t)c.ret_dest[((w0 + j) << 6) + lane] * cols.ret_mul[cidx] + cols.ret_add[cidx];
+        }
         switch (width) {
           case 16: jcopy_stream<uint4>(cols.src[cidx], cols.dst[cidx], s, d, stream, full); break;
           case 8: jcopy_stream<uint64_t>(cols.src[cidx], cols.dst[cidx], s, d, stream, full); break;
@@ -1252,7 +1326,7 @@ __global__ __launch_bounds__(BLOCK) void k_gp_lookup(const ulonglong2* __restric
       for (int u = 0; u < GP_U; u++) {
         const int64_t i = base + u * BLOCK + threadIdx.x;
         in[u] = i < hi;
-        idx[u] = gkeys[in[u] ? i : hi - 1] - am_offset;   // in range by construction (group_rows_by_key drops the others)
+        idx[u] = stream_load(gkeys + (in[u] ? i : hi - 1)) - am_offset;   // in range by construction (group_rows_by_key drops the others)
       }
       ulonglong2 e[GP_U];
 #pragma unroll
@@ -1264,6 +1338,36 @@ __global__ __launch_bounds__(BLOCK) void k_gp_lookup(const ulonglong2* __restric
         const uint32_t rank = (uint32_t)e[u].y + (uint32_t)__popcll(e[u].x & ((1ull << (idx[u] & 63)) - 1ull));
         m[u] = hit ? rank + 1u : 0u;
         hits += hit ? 1u : 0u;
+      }
+      if (L.R == 16) {
+        // the whole record in registers, ONE 16-byte store per row (streamed: the records are read back much later, and must not
+        // push the group's slice of the table out of the L2)
+        uint4 rv[GP_U];
+#pragma unroll
+        for (int u = 0; u < GP_U; u++) rv[u] = make_uint4(m[u], 0u, 0u, 0u);
+        for (int c = 0; c < L.n; c++) {
+          const int w = L.width[c], bo = L.off[c];
+#pragma unroll
+          for (int u = 0; u < GP_U; u++) {
+            const int64_t r = m[u] ? (int64_t)m[u] - 1 : 0;   // (a miss reads rank 0: harmless, nobody looks at its fields)
+            if (w == 8) {
+              const uint64_t v = reinterpret_cast<const uint64_t*>(L.src[c])[r];
+              rv[u].z = (uint32_t)v;
+              rv[u].w = (uint32_t)(v >> 32);
+            } else {
+              const uint32_t v = w == 4 ? reinterpret_cast<const uint32_t*>(L.src[c])[r] : (uint32_t)reinterpret_cast<const uint8_t*>(L.src[c])[r] << ((bo & 3) * 8);
+              rv[u].y |= (bo >> 2) == 1 ? v : 0u;
+              rv[u].z |= (bo >> 2) == 2 ? v : 0u;
+              rv[u].w |= (bo >> 2) == 3 ? v : 0u;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GP_U; u++) {
+          const int64_t i = base + u * BLOCK + threadIdx.x;
+          if (in[u]) stream_store(reinterpret_cast<uint4*>(rec) + i, rv[u]);
+        }
+        continue;
       }
 #pragma unroll
       for (int u = 0; u < GP_U; u++) {
@@ -1310,7 +1414,7 @@ __global__ __launch_bounds__(BLOCK) void k_gp_place(const ulonglong2* __restrict
       for (int u = 0; u < GP_U; u++) {
         const int64_t i = base + u * BLOCK + threadIdx.x;
         in[u] = i < hi;
-        idx[u] = gkeys[in[u] ? i : hi - 1] - am_offset;
+        idx[u] = stream_load(gkeys + (in[u] ? i : hi - 1)) - am_offset;
       }
       ulonglong2 e[GP_U];
 #pragma unroll
@@ -1679,6 +1783,29 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       // then land in ~1/64 of the bitmap
       KeyCol kc0 = ks.c[0];
       BufPtr grouped_keys;
+      // (round 4) many keys in no order over a bitmap beyond the caches: grouped by key range, bits set in LDS
+      constexpr int RB_BITS = 10;
+      const bool lds_bits = !ascending && nb > (1 << 22) && n_words * 8 > ((int64_t)16 << 20) && (range >> RB_BITS) < (1ull << 20) - 64 &&
+                            !(std::getenv("DFGPU_JOIN_LDS_BITMAP") && std::getenv("DFGPU_JOIN_LDS_BITMAP")[0] == '0');   // A/B knob
+      if (lds_bits) {
+        const GroupSpec gs = group_spec((uint64_t)kmin, range + 1, 1 << RB_BITS);
+        GroupedRows gr = group_rows_by_key(kc0, nb, gs, RB_BITS, nullptr, true, false, {}, {}, "join_build_group_keys");
+        const int P = 1 << RB_BITS;
+        std::vector<uint64_t> gfirst((size_t)P + 1);
+        uint64_t max_span = 0;
+        for (int q = 0; q <= P; q++) {   // first value of group q: the smallest idx with floor(idx * mul / 2^64) >= q
+          const unsigned __int128 v = ((((unsigned __int128)(unsigned)q) << 64) + gs.mul - 1) / gs.mul;
+          gfirst[(size_t)q] = v > (unsigned __int128)(range + 1) || q == P ? range + 1 : (uint64_t)v;
+          if (q) max_span = std::max(max_span, gfirst[(size_t)q] - gfirst[(size_t)q - 1]);
+        }
+        BufPtr d_first = make_buf(gfirst.size() * 8);
+        h2d_async(d_first->ptr, gfirst.data(), gfirst.size() * 8);
+        const size_t lds = (size_t)((max_span >> 6) + 2) * 8;
+        DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_bits_grouped), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_rank_bits_grouped<<<P, RB_THREADS, lds, r.stream>>>(gr.keys->as<uint64_t>(), gr.bounds->as<uint64_t>(), d_first->as<uint64_t>(), (uint64_t)kmin, bits, flag->as<int>());
+        DFGPU_HIP(hipGetLastError());
+        DFGPU_HIP(hipStreamSynchronize(r.stream));   // gfirst is a local the copy reads
+      } else {
       if (!ascending && !kc0.valid && kc0.width == 8 && nb > (1 << 22) && n_words * 8 > ((int64_t)16 << 20) &&
           !(std::getenv("DFGPU_JOIN_GROUPED_BUILD") && std::getenv("DFGPU_JOIN_GROUPED_BUILD")[0] == '0')) {
         const Column& kcol = build.cols[(size_t)key_cols[0]];
@@ -1714,6 +1841,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
         else if (kc0.valid) k_rank_setbits<T, true, false><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>());
         else k_rank_setbits<T, false, false><<<g, BLOCK, 0, r.stream>>>(kc0, nb, (uint64_t)kmin, bits, flag->as<int>());
       });
+      }
       }
     }
     jt->rank_prefix = make_buf((size_t)(n_words + 1) * 8);
@@ -1943,28 +2071,33 @@ static bool needs_visited(int join_type) {
 }
 
 // Do neighbouring probe rows look up neighbouring keys?  A direct-address table bigger than the caches answers a CLUSTERED probe
-// (foreign keys in the parent's order: lineitem -> orders) from lines it has just fetched, and a random one with one 128-byte line
+// (foreign keys in the parent's order: lineitem -> orders) from lines it has just fetched, and a random one with one 64-byte unit
 // of Infinity Cache / HBM traffic per row — which decides between probe flavours below.  From the column's cached statistics when
-// they exist, else from 4096 evenly spaced neighbour pairs (random keys ascend half of the time).
+// they exist (a nondecreasing column is clustered), else from 4096 evenly spaced neighbour pairs: clustered = nine in ten of them
+// lie within `window` key values of each other (the stretch of the table an L2 keeps without effort).  Round 3 asked whether
+// the neighbours ASCEND, which rows sorted by another column with many ties do — runs of a few hundred ascending keys that jump
+// all over the table (SF100 lineitem ordered by l_extendedprice: 99 % ascents, no locality).
 template <int KT>
-__global__ void k_sample_ascents(KeyCol k, int64_t n, int64_t every, int samples, int* __restrict__ ascents) {
+__global__ void k_sample_near(KeyCol k, int64_t n, int64_t every, int samples, uint64_t window, int* __restrict__ near) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= samples) return;
   const int64_t r = (int64_t)i * every;
   if (r + 1 >= n) return;
   const uint64_t a = load_key<KT>(k, r), b = load_key<KT>(k, r + 1);
-  if ((int64_t)b >= (int64_t)a) atomicAdd(ascents, 1);
+  const uint64_t d = (int64_t)b >= (int64_t)a ? b - a : a - b;
+  if (d <= window) atomicAdd(near, 1);
 }
-static bool probe_keys_clustered(const Column& kc, int64_t n) {
-  if (auto cached = std::atomic_load(&kc.stats)) return cached->nondecreasing;
+static bool probe_keys_clustered(const Column& kc, int64_t n, uint64_t window) {
+  if (auto cached = std::atomic_load(&kc.stats))
+    if (cached->nondecreasing) return true;
   if (n < (1 << 16) || kc.validity || !is_integer_like(kc.field.type) || kc.field.type == DFGPU_UINT64) return true;
   constexpr int S = 4096;
   BufPtr cnt = make_zero_buf(4);
   const KeyCol k{kc.ptr(), nullptr, kc.field.type, type_width(kc.field.type)};
-  with_key_type(k.type, [&](auto kt) { k_sample_ascents<decltype(kt)::value><<<S / BLOCK, BLOCK, 0, rt().stream>>>(k, n, n / S, S, cnt->as<int>()); });
-  int ascents = 0;
-  d2h(&ascents, cnt->ptr, 4);
-  return ascents * 10 >= S * 9;
+  with_key_type(k.type, [&](auto kt) { k_sample_near<decltype(kt)::value><<<S / BLOCK, BLOCK, 0, rt().stream>>>(k, n, n / S, S, window, cnt->as<int>()); });
+  int near = 0;
+  d2h(&near, cnt->ptr, 4);
+  return near * 10 >= S * 9;
 }
 
 // do 64 K evenly spaced probe rows ALL find their key?  (the speculation of the placed probe is only worth trying then)
@@ -1992,11 +2125,7 @@ static int gp_bits_for(const JoinTable& jt, int64_t payload_bytes_per_row) {
   while (bits < 10 && slice / (double)(1 << bits) > 2.5 * 1048576.0) bits++;
   return bits;
 }
-static GroupSpec gp_spec_for(const JoinTable& jt, int nbits) {
-  int shift = 0;
-  while (((jt.am_size - 1) >> shift) >= (1ull << nbits)) shift++;
-  return GroupSpec{jt.am_offset, jt.am_size, shift};
-}
+static GroupSpec gp_spec_for(const JoinTable& jt, int nbits) { return group_spec(jt.am_offset, jt.am_size, 1 << nbits); }
 // rank map over build keys in no order: the build columns `cols` copied into RANK order, once per join table and column (a probe
 // in group order reads build payload at rank positions; through rank -> row -> column it would be a random line per row)
 static void ensure_rank_payload(JoinTable& jt, const std::vector<int>& cols) {
@@ -2173,7 +2302,8 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   static thread_local bool in_grouped_probe = false;  // the probe over keys this function grouped itself: clustered by construction
   const char* min_env = std::getenv("DFGPU_JOIN_GROUPED_MIN_ROWS");  // test knob: from how many probe rows grouping is considered (default 4 Mi)
   const int64_t grouped_min_rows = min_env ? std::atoll(min_env) : ((int64_t)1 << 22);
-  const bool unclustered = fused_ok && big_table && np > grouped_min_rows && pk.size() == 1 && !in_grouped_probe && !probe_keys_clustered(probe.cols[(size_t)pk[0]], np);
+  const bool unclustered = fused_ok && big_table && np > grouped_min_rows && pk.size() == 1 && !in_grouped_probe &&
+                           !probe_keys_clustered(probe.cols[(size_t)pk[0]], np, jt.kind == KIND_RANK ? ((uint64_t)512 << 10) / 16 * 64 : ((uint64_t)512 << 10) / 4);
   const bool group_env = !(std::getenv("DFGPU_JOIN_GROUPED_PROBE") && std::getenv("DFGPU_JOIN_GROUPED_PROBE")[0] == '0');  // A/B knob
   // the key-only probe whose order nobody observes: its keys are grouped and probed in group order (below)
   const bool grouped_keys_only = unclustered && group_env && jt.probe_mode == 4 && rows_unused && !row_mask && pout.size() == 1 && pout[0] == pk[0] &&
@@ -2183,6 +2313,9 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const bool returned_env = !(std::getenv("DFGPU_JOIN_RETURNED_PROBE") && std::getenv("DFGPU_JOIN_RETURNED_PROBE")[0] == '0');  // A/B knob
   bool returned = use_fused && unclustered && group_env && returned_env && !grouped_keys_only && jt.kind == KIND_RANK && jt.probe_mode != 2 &&
                   is_integer_like(probe.cols[(size_t)pk[0]].field.type);
+  if (std::getenv("DFGPU_TRACE_JOIN"))   // one line per probe on stderr: what decided the probe flavour
+    fprintf(stderr, "[dfgpu join_probe] np=%lld kind=%d probe_mode=%d fused_ok=%d big_table=%d unclustered=%d grouped_keys_only=%d returned=%d rows_unused=%d row_mask=%d\n",
+            (long long)np, jt.kind, jt.probe_mode, (int)fused_ok, (int)big_table, (int)unclustered, (int)grouped_keys_only, (int)returned, (int)rows_unused, row_mask != nullptr);
   ReturnedProbe rp;
   if (returned) returned = grouped_probe_lookup(jt, probe, pk[0], bout, row_mask, rp);
   if (returned) {
@@ -2314,7 +2447,8 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     bool speculate = false;
     if (returned_all_hit && !no_speculation) {
       speculate = true;   // (not a guess here: the grouped lookup counted its hits; the kernel's per-tile check stays as the safety net)
-    } else if (fused_mode == FUSED_PLACED && !listed && !row_mask && !invert && !no_speculation && np >= (1 << 22) && (kind == KIND_RANK || kind == KIND_ARRAY) &&
+    } else if (fused_mode == FUSED_PLACED && !listed && !row_mask && !invert && !no_speculation && np >= (1 << 22) &&
+               (kind == KIND_RANK || kind == KIND_ARRAY || kind == KIND_FLAT || kind == KIND_FLAT16) &&
         !(std::getenv("DFGPU_JOIN_SPECULATE") && std::getenv("DFGPU_JOIN_SPECULATE")[0] == '0')) {
       constexpr int S = 1024;  // sampled words
       BufPtr miss = make_zero_buf(4);

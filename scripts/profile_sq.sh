@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box, via gpurun): CASES=<bench_ops cases> scripts/profile_sq.sh <tag> [kernel-name filter]
+#        CMD="python scripts/bench_join_shapes.py --only ... --iters 1" scripts/profile_sq.sh <tag> [filter]   (any command; it runs from /tmp: absolute paths)
 # Where the waves of the per-operator kernels spend their cycles: SQ counters in separate rocprofv3 --pmc passes (counters only, as
 # the pool requires), summed over each kernel's largest launch.  Writes gpurun_out/<tag>/sq.md
 set -u
@@ -11,10 +12,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 CASES=${CASES:-agg_multikey}
+CMD=${CMD:-python $R/scripts/bench_ops.py --only $CASES --iters 2}
 i=0
-for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  (timeout 300 rocprofv3 --pmc $SET -d /tmp/sq_$i -o pmc -- python $R/scripts/bench_ops.py --only $CASES --iters 2) > $OUT/sq_$i.log 2>&1
+  (timeout ${PASS_TIMEOUT:-300} rocprofv3 --pmc $SET -d /tmp/sq_$i -o pmc -- $CMD) > $OUT/sq_$i.log 2>&1
 done
 cd $R
 python - <<PY > $OUT/sq.md 2>&1
