@@ -20,6 +20,29 @@ if has shapes; then
   (time timeout 1200 python scripts/bench_join_shapes.py --md $OUT/join_shapes.md ${SHAPES_ARGS:-}) > $OUT/join_shapes.jsonl 2> $OUT/join_shapes.err
   cat $OUT/join_shapes.md; tail -5 $OUT/join_shapes.err
 fi
+if has gpbits; then   # the grouped probe's group count: 2^8 .. 2^10 groups on the Q3-payload shape
+  for B in 8 9 10; do
+    (DFGPU_JOIN_GP_BITS=$B timeout 600 python scripts/bench_join_shapes.py --only payload --tables auto --iters 2) > $OUT/gpbits_$B.jsonl 2> $OUT/gpbits_$B.err
+    echo "GP_BITS=$B"; python - <<PY
+import json
+for ln in open("$OUT/gpbits_$B.jsonl"):
+    r = json.loads(ln); print(r.get("ms"), r.get("kernel_ms_per_iter"))
+PY
+  done
+fi
+if has aggknobs; then   # round 3's opt-in aggregate paths on the three-key aggregate
+  for K in "" "DFGPU_AGG_LDS_CLAIM=1" "DFGPU_AGG_SMALL_TABLE=1" "DFGPU_AGG_LDS_CLAIM=1 DFGPU_AGG_SMALL_TABLE=1"; do
+    (env $K timeout 600 python scripts/bench_ops.py --only agg_multikey --iters 3) > "$OUT/agg_${K// /_}.jsonl" 2> $OUT/agg.err
+    echo "knobs: [$K]"; python - <<PY
+import json
+for ln in open("$OUT/agg_${K// /_}.jsonl"):
+    r = json.loads(ln); print(r.get("ms"), r.get("kernel_ms_per_iter") or r.get("kernels"))
+PY
+  done
+fi
+if has pmc; then   # counters of the shape named by PMC_SHAPE / PMC_TABLES (scripts/profile_sq.sh)
+  CMD="python $R/scripts/bench_join_shapes.py --only ${PMC_SHAPE:-payload} --tables ${PMC_TABLES:-auto} --iters 1" scripts/profile_sq.sh $TAG/pmc ${PMC_FILTER:-}
+fi
 if has ops; then
   (time timeout 1200 python scripts/bench_ops.py --md $OUT/ops.md ${OPS_ARGS:-}) > $OUT/ops.jsonl 2> $OUT/ops.err
   cat $OUT/ops.md; tail -5 $OUT/ops.err
