@@ -1133,7 +1133,14 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
       int w = type_width(gk.field.type);
       DFGPU_HIP(hipMemcpyAsync(cc.data->ptr, gk.ptr(), (size_t)G0 * w, hipMemcpyDeviceToDevice, r.stream));
       if (n) DFGPU_HIP(hipMemcpyAsync((char*)cc.data->ptr + (size_t)G0 * w, ik.ptr(), (size_t)n * w, hipMemcpyDeviceToDevice, r.stream));
-      DFGPU_CHECK(!cc.validity, "incremental aggregation over nullable group keys is not supported on the GPU path yet");
+      if (cc.validity) {
+        // nullable group keys across updates (group_values/multi_group_by/mod.rs:595-745: NULL is a key value like any other): the
+        // validity of [existing groups ; input rows] — a side without a bitmap is all valid
+        DFGPU_HIP(hipMemsetAsync(cc.validity->ptr, 0, bitmap_bytes(total), r.stream));
+        bitmap_place(gk.valid_words(), 0, G0, cc.validity->as<uint64_t>());
+        if (n) bitmap_place(ik.valid_words(), G0, n, cc.validity->as<uint64_t>());
+        cc.null_count = -1;
+      }
       R.cat_keys.push_back(std::move(cc));
     }
   }
@@ -3733,6 +3740,19 @@ static void agg_update_unfused(Aggregate& A, const Table& in) {
 __global__ __launch_bounds__(BLOCK) void k_bits_to_u8(const uint64_t* __restrict__ bits, int64_t n, uint8_t* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (uint8_t)((bits[i >> 6] >> (i & 63)) & 1ull);
 }
+// a Boolean column (bit-packed) as one UInt8 per row, validity kept: how Boolean KEY columns enter the hashing / ordering kernels
+// (group keys here; join, repartition and sort keys in their files) — hash_utils.rs:306-345 hashes a BooleanArray value by value too
+Column bool_as_u8(const Column& c, int64_t n) {
+  dfgpu_field f{};
+  f.type = DFGPU_UINT8;
+  f.nullable = c.field.nullable;
+  Column u = alloc_column(f, c.name, n);
+  if (n) k_bits_to_u8<<<grid_for(n, BLOCK), BLOCK, 0, rt().stream>>>((const uint64_t*)c.ptr(), n, u.data->as<uint8_t>());
+  DFGPU_HIP(hipGetLastError());
+  u.validity = c.validity;
+  u.null_count = c.null_count;
+  return u;
+}
 static void agg_update_keys_fixed(Aggregate& A, const Table& in, const dfgpu_expr* pred);
 // Utf8 group keys (plain column references; in Final modes the leading columns): interned on entry with an ascending dictionary —
 // grouping on the indices is grouping on the strings — and decoded again when the groups are emitted, so the node's schema keeps
@@ -3749,14 +3769,7 @@ static void agg_update(Aggregate& A, const Table& in, const dfgpu_expr* pred = n
       if (!any) coded = in;
       any = true;
       const Column& bc = in.cols[(size_t)kc];
-      if (coded.cols[(size_t)kc].field.type == DFGPU_BOOL) {
-        Column u = alloc_column(fld(DFGPU_UINT8), bc.name, in.nrows);
-        if (in.nrows) k_bits_to_u8<<<grid_for(in.nrows, BLOCK), BLOCK, 0, rt().stream>>>((const uint64_t*)bc.ptr(), in.nrows, u.data->as<uint8_t>());
-        DFGPU_HIP(hipGetLastError());
-        u.validity = bc.validity;
-        u.null_count = bc.null_count;
-        coded.cols[(size_t)kc] = std::move(u);
-      }
+      if (coded.cols[(size_t)kc].field.type == DFGPU_BOOL) coded.cols[(size_t)kc] = bool_as_u8(bc, in.nrows);
       A.bool_key.resize((size_t)ngk, 0);
       A.bool_key[(size_t)g] = 1;
       continue;

@@ -318,6 +318,8 @@ struct PackLayout;
 bool plan_record_layout(const Table& in, const std::vector<int>& cols, PackLayout& L, int& R, std::vector<int>& order);
 std::vector<Column> gather_records(const Table& in, const std::vector<int>& cols, PackLayout L, int R, const std::vector<int>& order, const uint8_t* rec,
                                    const uint32_t* idx, int64_t n);
+// a Boolean column as one UInt8 per row (validity kept): Boolean key columns of joins, repartitions, sorts and aggregates (aggregate.hip)
+Column bool_as_u8(const Column& c, int64_t n);
 // out[w] = a[w] & b[w] over nw 64-bit words (aggregate.hip)
 void and_bitmaps(const uint64_t* a, const uint64_t* b, int64_t nw, uint64_t* out);
 // clear bits beyond n in the last word of a bitmap (keeps padding deterministic)

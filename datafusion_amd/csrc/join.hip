@@ -1648,6 +1648,13 @@ static std::unique_ptr<JoinTable> join_build(const Table& build, const std::vect
   for (size_t i = 0; i < kc.size(); i++) {
     DFGPU_CHECK(kc[i] >= 0 && kc[i] < (int)build.cols.size(), "join key column index out of range");
     const Column& c = build.cols[(size_t)kc[i]];
+    if (c.field.type == DFGPU_BOOL) {   // a Boolean key: one byte per row behind the caller's columns (the Boolean column travels as payload)
+      if (!any) coded = build;
+      any = true;
+      coded.cols.push_back(bool_as_u8(c, build.nrows));
+      kc[i] = (int)coded.cols.size() - 1;
+      continue;
+    }
     if (c.field.type != DFGPU_UTF8 || c.dict) continue;
     if (!any) coded = build;
     any = true;
@@ -2004,6 +2011,14 @@ static Table with_build_dictionaries(const JoinTable& jt, const Table& probe, st
   for (size_t i = 0; i < pk.size(); i++) {
     DFGPU_CHECK(pk[i] >= 0 && pk[i] < (int)probe.cols.size(), "join key column index out of range");
     const Column& bc = jt.build.cols[jt.key_cols[i]];
+    if (probe.cols[pk[i]].field.type == DFGPU_BOOL) {   // the build side's Boolean key was widened to bytes by join_build: so is this one
+      DFGPU_CHECK(bc.field.type == DFGPU_UINT8 && !bc.dict, "join key types differ between build and probe side (the planner inserts casts)");
+      if (!changed) fixed = probe;
+      changed = true;
+      fixed.cols.push_back(bool_as_u8(probe.cols[pk[i]], probe.nrows));
+      pk[i] = (int)fixed.cols.size() - 1;
+      continue;
+    }
     if (bc.dict && probe.cols[pk[i]].field.type == DFGPU_UTF8 && !probe.cols[pk[i]].dict) {
       Column enc = dictionary_encode(probe.cols[pk[i]], true);
       if (!same_dictionary(bc.dict, enc.dict)) {

@@ -399,6 +399,13 @@ std::vector<Table> partition_table(const Table& in, const std::vector<int>& key_
   for (size_t i = 0; i < kc.size(); i++) {
     DFGPU_CHECK(kc[i] >= 0 && kc[i] < (int)in.cols.size(), "partition key column out of range");
     const Column& c = in.cols[(size_t)kc[i]];
+    if (c.field.type == DFGPU_BOOL) {   // Boolean keys are hashed as one byte per row (hash_utils.rs:306-345: value by value)
+      if (!any) work = in;
+      any = true;
+      work.cols.push_back(bool_as_u8(c, in.nrows));
+      kc[i] = (int)work.cols.size() - 1;
+      continue;
+    }
     if (c.field.type != DFGPU_UTF8 && !c.dict) continue;
     if (!any) work = in;
     any = true;

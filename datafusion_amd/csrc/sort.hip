@@ -1260,6 +1260,13 @@ extern "C" int dfgpu_sort(dfgpu_table_t input, const int* key_cols, const uint8_
     for (int k = 0; k < nkeys; k++) {
       DFGPU_CHECK(keys[(size_t)k] >= 0 && keys[(size_t)k] < (int)in.cols.size(), "sort key column out of range");
       const Column& c = in.cols[(size_t)keys[(size_t)k]];
+      if (c.field.type == DFGPU_BOOL) {   // a Boolean sort key orders false < true: one byte per row, the Boolean column travels as payload
+        if (!interned) work = in;
+        interned = true;
+        work.cols.push_back(bool_as_u8(c, in.nrows));
+        keys[(size_t)k] = (int)work.cols.size() - 1;
+        continue;
+      }
       if (c.field.type != DFGPU_UTF8 || c.dict) continue;
       if (!interned) work = in;
       interned = true;
