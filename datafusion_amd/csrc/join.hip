@@ -1301,24 +1301,61 @@ struct RetLayout {
   int width[MAX_JOIN_COLS], off[MAX_JOIN_COLS];
   int n, R;
 };
-// this workgroup's share [lo, hi) of group g's rows: all workgroups of an XCD (blockIdx % 8, MI355X_MICROARCH.md) split each of
-// that XCD's groups among themselves
-__device__ __forceinline__ void gp_share(const uint64_t* __restrict__ bounds, int g, int64_t& lo, int64_t& hi) {
-  const int64_t r0 = (int64_t)bounds[g], r1 = (int64_t)bounds[g + 1];
-  const int slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  int64_t per = (r1 - r0 + nslots - 1) / nslots;
-  per = (per + BLOCK * GP_U - 1) / (BLOCK * GP_U) * (BLOCK * GP_U);
-  lo = r0 + (int64_t)slot * per;
-  hi = lo + per < r1 ? lo + per : r1;
+// Which rows a workgroup takes next.  All workgroups of an XCD (blockIdx % 8, MI355X_MICROARCH.md: a placement that only speed
+// depends on) walk that XCD's groups — g = xcd, xcd + 8, ... — in order, GP_CHUNK rows at a time, handed out by ONE counter per XCD:
+// whatever pace the workgroups keep, the chunks in flight on an XCD are consecutive — 256 workgroups x 2048 rows = less than one
+// group — so its L2 holds the slice of the table of one or two groups at a time.  (Round 4's first form gave every workgroup a
+// fixed share of every group: the workgroups drifted apart over the 128 groups, the XCD worked on many slices at once and 44 %
+// of the lookups missed the L2, profiles/r4_join_grouped_pmc.md.)
+constexpr int GP_CHUNK = 2048;
+struct GpWalk {
+  uint32_t pref[GP_MAX_GROUPS / 8 + 2];   // chunks of this XCD's groups before its k-th group
+  unsigned ticket;
+  int ng;
+};
+__device__ __forceinline__ void gp_walk_init(GpWalk& w, const uint64_t* __restrict__ bounds, int P) {
+  const int xcd = blockIdx.x & 7;
+  const int ng = xcd < P ? (P - xcd + 7) / 8 : 0;
+  for (int k = threadIdx.x; k < ng; k += BLOCK) {
+    const int g = xcd + 8 * k;
+    w.pref[k + 1] = (uint32_t)((bounds[g + 1] - bounds[g] + GP_CHUNK - 1) / GP_CHUNK);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    w.pref[0] = 0;
+    for (int k = 0; k < ng; k++) w.pref[k + 1] += w.pref[k];
+    w.ng = ng;
+  }
+  __syncthreads();
+}
+// false = no chunk left.  Every thread of the workgroup calls it (barriers inside).
+__device__ __forceinline__ bool gp_walk_next(GpWalk& w, const uint64_t* __restrict__ bounds, unsigned* __restrict__ tickets, int64_t& lo, int64_t& hi) {
+  const int xcd = blockIdx.x & 7;
+  __syncthreads();   // the previous chunk's readers of w.ticket are done
+  if (threadIdx.x == 0) w.ticket = atomicAdd(&tickets[xcd * 32], 1u);
+  __syncthreads();
+  const unsigned t = w.ticket;
+  if (t >= w.pref[w.ng]) return false;
+  int a = 0, b = w.ng - 1;   // the last k with pref[k] <= t
+  while (a < b) {
+    const int m = (a + b + 1) >> 1;
+    if (w.pref[m] <= t) a = m;
+    else b = m - 1;
+  }
+  const int g = xcd + 8 * a;
+  lo = (int64_t)bounds[g] + (int64_t)(t - w.pref[a]) * GP_CHUNK;
+  const int64_t end = (int64_t)bounds[g + 1];
+  hi = lo + GP_CHUNK < end ? lo + GP_CHUNK : end;
+  return true;
 }
 __global__ __launch_bounds__(BLOCK) void k_gp_lookup(const ulonglong2* __restrict__ rank_tab, uint64_t am_offset, uint64_t am_size, const uint64_t* __restrict__ gkeys,
                                                      const uint64_t* __restrict__ bounds, int P, RetLayout L, uint8_t* __restrict__ rec,
-                                                     unsigned long long* __restrict__ total_hits) {
+                                                     unsigned long long* __restrict__ total_hits, unsigned* __restrict__ tickets) {
   __shared__ unsigned long long s_hits[BLOCK / WAVE];
+  __shared__ GpWalk walk;
   unsigned long long hits = 0;
-  for (int g = blockIdx.x & 7; g < P; g += 8) {
-    int64_t lo, hi;
-    gp_share(bounds, g, lo, hi);
+  gp_walk_init(walk, bounds, P);
+  for (int64_t lo, hi; gp_walk_next(walk, bounds, tickets, lo, hi);) {
     for (int64_t base = lo; base < hi; base += BLOCK * GP_U) {
       uint64_t idx[GP_U];
       bool in[GP_U];
@@ -1403,10 +1440,10 @@ __global__ __launch_bounds__(BLOCK) void k_gp_lookup(const ulonglong2* __restric
 }
 // build rows in group order (every key is in the table): their columns to the RANK position of their key
 __global__ __launch_bounds__(BLOCK) void k_gp_place(const ulonglong2* __restrict__ rank_tab, uint64_t am_offset, const uint64_t* __restrict__ gkeys,
-                                                    const uint64_t* __restrict__ bounds, int P, GroupCols cols) {
-  for (int g = blockIdx.x & 7; g < P; g += 8) {
-    int64_t lo, hi;
-    gp_share(bounds, g, lo, hi);
+                                                    const uint64_t* __restrict__ bounds, int P, GroupCols cols, unsigned* __restrict__ tickets) {
+  __shared__ GpWalk walk;
+  gp_walk_init(walk, bounds, P);
+  for (int64_t lo, hi; gp_walk_next(walk, bounds, tickets, lo, hi);) {
     for (int64_t base = lo; base < hi; base += BLOCK * GP_U) {
       uint64_t idx[GP_U];
       bool in[GP_U];
@@ -2175,7 +2212,9 @@ static void ensure_rank_payload(JoinTable& jt, const std::vector<int>& cols) {
       jt.info.table_bytes += nb * width[(size_t)q];
     }
     ProfileScope ps("join_build_rank_payload", gr.rows * (8 + 2 * bytes));
-    k_gp_place<<<r.num_cus * 8, BLOCK, 0, r.stream>>>(jt.rank_tab->as<ulonglong2>(), jt.am_offset, gr.keys->as<uint64_t>(), gr.bounds->as<uint64_t>(), gr.P, gc);
+    BufPtr tickets = make_zero_buf(8 * 32 * 4);
+    k_gp_place<<<r.num_cus * 8, BLOCK, 0, r.stream>>>(jt.rank_tab->as<ulonglong2>(), jt.am_offset, gr.keys->as<uint64_t>(), gr.bounds->as<uint64_t>(), gr.P, gc,
+                                                      tickets->as<unsigned>());
     DFGPU_HIP(hipGetLastError());
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));  // complete before another thread's stream reads the copies
@@ -2231,8 +2270,9 @@ static bool grouped_probe_lookup(JoinTable& jt, const Table& probe, int pk0, con
   BufPtr total = make_zero_buf(8);
   if (gr.rows) {
     ProfileScope ps("join_probe_grouped_lookup", gr.rows * (8 + L.R + payload));
+    BufPtr tickets = make_zero_buf(8 * 32 * 4);
     k_gp_lookup<<<r.num_cus * 8, BLOCK, 0, r.stream>>>(jt.rank_tab->as<ulonglong2>(), jt.am_offset, jt.am_size, gr.keys->as<uint64_t>(), gr.bounds->as<uint64_t>(), gr.P, L,
-                                                       rp.rec->as<uint8_t>(), total->as<unsigned long long>());
+                                                       rp.rec->as<uint8_t>(), total->as<unsigned long long>(), tickets->as<unsigned>());
     DFGPU_HIP(hipGetLastError());
   }
   rp.hits = (int64_t)read_u64(total->as<uint64_t>());

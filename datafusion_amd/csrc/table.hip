@@ -126,7 +126,10 @@ struct Uploader {
   }
   void finish() {
     DFGPU_HIP(hipStreamSynchronize(copy_stream));
-    for (void* p : registered) (void)hipHostUnregister(p);
+    // (two columns may share pages of one host allocation: the second unregister of such a page fails, harmlessly — but HIP keeps
+    // the error as the thread's LAST error, and the next launch check of an unrelated operator would report it)
+    for (void* p : registered)
+      if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
     for (void* p : staged) std::free(p);
     registered.clear();
     staged.clear();
@@ -134,7 +137,8 @@ struct Uploader {
   ~Uploader() {
     if (copy_stream) {
       (void)hipStreamSynchronize(copy_stream);
-      for (void* p : registered) (void)hipHostUnregister(p);
+      for (void* p : registered)
+        if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
       for (void* p : staged) std::free(p);
       (void)hipStreamDestroy(copy_stream);
     }

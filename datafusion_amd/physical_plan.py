@@ -643,6 +643,12 @@ class GpuOffloadRule:
             return node.input
         if isinstance(node, (RepartitionExec, CoalescePartitionsExec, SortPreservingMergeExec)) and self.world_size == 1:
             return node.input                                  # one partition: nothing to exchange, gather or merge
+        if not isinstance(node, (GpuHashJoinExec, GpuFusedAggregateExec)) and not getattr(node, "kept_on_cpu", False):
+            reason = unsupported_reason(node)
+            if reason is not None:                             # the reference's operator stays (it runs these inputs)
+                node.kept_on_cpu = True
+                self.declined.append((node, reason))
+                return node
         if isinstance(node, HashJoinExec) and not isinstance(node, GpuHashJoinExec) and not self._admits(node):
             node.kept_on_cpu = True
             return node
@@ -685,6 +691,157 @@ def _row_bound(node):
         (br, bb), (pr, pb) = _row_bound(node.left), _row_bound(node.right)
         return max(br, pr), bb + pb
     raise TypeError(node.name())
+
+
+# ------------------------------------------------------------------------------ plan-time schemas and declines
+def plan_schema(node):
+    """Output schema of a plan node (pa.Schema), or None when it cannot be told at plan time (a scan that has not opened its file,
+    a node below one that could not be typed).  What ExecutionPlan::schema() is in the reference; here it only serves the rule's
+    decisions — expression types come from the library (dfgpu_expr_type over an empty table of the input schema)."""
+    import pyarrow as pa
+    if isinstance(node, MemoryExec):
+        sch = node.table.schema
+        if node.projection is None:
+            return sch
+        idx = [node.table.index_of(c) for c in node.projection]
+        return pa.schema([sch.field(i) for i in idx])
+    if isinstance(node, GpuHashJoinExec) or isinstance(node, HashJoinExec):
+        l, r = plan_schema(node.left), plan_schema(node.right)
+        if l is None or r is None:
+            return None
+        bc, pc = node.projection if node.projection is not None else (None, None)
+        lf = list(l) if bc is None else [l.field(l.get_field_index(c)) if isinstance(c, str) else l.field(c) for c in bc]
+        rf = list(r) if pc is None else [r.field(r.get_field_index(c)) if isinstance(c, str) else r.field(c) for c in pc]
+        jt = node.join_type
+        if jt in ("LeftSemi", "LeftAnti"):
+            return pa.schema(lf)
+        if jt in ("RightSemi", "RightAnti"):
+            return pa.schema(rf)
+        if jt == "LeftMark":
+            return pa.schema(lf + [pa.field("mark", pa.bool_())])
+        if jt == "RightMark":
+            return pa.schema(rf + [pa.field("mark", pa.bool_())])
+        return pa.schema(lf + rf)
+    kids = node.children()
+    if len(kids) != 1:
+        return None
+    inp = plan_schema(kids[0])
+    if inp is None:
+        return None
+    if isinstance(node, FilterExec):
+        if node.projection is None:
+            return inp
+        return pa.schema([inp.field(inp.get_field_index(c)) if isinstance(c, str) else inp.field(c) for c in node.projection])
+    if isinstance(node, (CoalesceBatchesExec, RepartitionExec, CoalescePartitionsExec, SortPreservingMergeExec, SortExec)):
+        return inp
+    try:
+        empty = DeviceTable.from_arrow(inp.empty_table())
+    except Exception:  # noqa: BLE001 - no device (planning-only tests): nothing can be typed
+        return None
+    try:
+        if isinstance(node, ProjectionExec):
+            return pa.schema([pa.field(n, ops.expr_type(empty, e)) for e, n in node.exprs])
+        if isinstance(node, (AggregateExec, GpuFusedAggregateExec)):
+            fields = [pa.field(n, ops.expr_type(empty, e)) for e, n in node.group_by]
+            for func, e, n in node.aggr_expr:
+                t = None if e is None else ops.expr_type(empty, e)
+                if node.mode == "Partial":      # state fields (sum.rs:281-301, average.rs:317-360, count.rs): AVG = count + sum
+                    if func == "avg":
+                        fields.append(pa.field(n + "[count]", pa.uint64()))
+                        # avg_sum_data_type (average.rs:131-172): the input precision + 13 digits, never narrower than Decimal128's 38
+                        fields.append(pa.field(n + "[sum]", pa.decimal128(38, t.scale) if pa.types.is_decimal128(t) else pa.float64()))
+                    else:
+                        fields.append(pa.field(n, _agg_type(func, t)))
+                else:
+                    fields.append(pa.field(n, _agg_type(func, t)))
+            return pa.schema(fields)
+    except _lib.DfgpuError:
+        return None
+    finally:
+        empty.free()
+    return None
+
+
+def _sum_type(t):
+    import pyarrow as pa
+    if pa.types.is_decimal128(t):
+        return pa.decimal128(min(38, t.precision + 10), t.scale)      # sum.rs:232-260
+    if pa.types.is_floating(t):
+        return pa.float64()
+    return pa.uint64() if pa.types.is_unsigned_integer(t) and t != pa.uint8() else pa.int64()
+
+
+def _agg_type(func, t):
+    import pyarrow as pa
+    if func == "count":
+        return pa.int64()
+    if func == "sum":
+        return _sum_type(t)
+    if func == "avg":
+        return pa.decimal128(min(38, t.precision + 4), min(38, t.scale + 4)) if pa.types.is_decimal128(t) else pa.float64()   # average.rs:219-252
+    return t    # min / max
+
+
+def _key_bits(t):
+    """upper bound of the bits a sort key column of this type takes in the packed key (sort.hip packs value ranges; the type is
+    what is known at plan time), plus one bit for NULL placement"""
+    import pyarrow as pa
+    if pa.types.is_boolean(t):
+        return 2
+    if pa.types.is_string(t) or pa.types.is_large_string(t) or pa.types.is_dictionary(t):
+        return 33
+    return t.bit_width + 1
+
+
+def unsupported_reason(node):
+    """Why an operator the reference can run has no device form (None = it has one).  The library refuses these inputs when it
+    meets them at run time (the DFGPU_CHECKs named below); the rule asks first, so that such an operator STAYS the reference's CPU
+    operator instead of failing the query — every entry here has a test that feeds a plan through GpuOffloadRule."""
+    import pyarrow as pa
+    if isinstance(node, (AggregateExec, GpuFusedAggregateExec)) and node.mode in ("Single", "SinglePartitioned", "Partial"):
+        inp = plan_schema(node.input)
+        if inp is None:
+            return None
+        try:
+            empty = DeviceTable.from_arrow(inp.empty_table())
+        except Exception:  # noqa: BLE001
+            return None
+        try:
+            for func, e, n in node.aggr_expr:
+                if e is None:
+                    continue
+                try:
+                    t = ops.expr_type(empty, e)
+                except _lib.DfgpuError as err:
+                    return f"{func}({e!r}): {err}"
+                if func == "avg" and pa.types.is_decimal128(t) and t.precision + 13 > 38:
+                    # aggregate.hip avg_sum_type: avg_sum_data_type (average.rs:131-172) widens to Decimal256 beyond 38 digits
+                    return f"AVG({n}) over {t} accumulates in Decimal256 in the reference (no device representation)"
+                if func in ("min", "max") and pa.types.is_decimal128(t) and t.precision > 18:
+                    # aggregate.hip wide_minmax_values_fit: the device compares 64-bit words; values beyond them are only found at run time
+                    return f"{func.upper()}({n}) over {t}: values of more than 18 digits do not fit the device's 64-bit comparison"
+                if func in ("sum", "avg", "min", "max") and (pa.types.is_boolean(t) or pa.types.is_string(t) or pa.types.is_large_string(t)):
+                    return f"{func.upper()}({n}) over {t} is not supported on the GPU path"
+        finally:
+            empty.free()
+        return None
+    if isinstance(node, SortExec):
+        inp = plan_schema(node.input)
+        if inp is None:
+            return None
+        bits = sum(_key_bits(inp.field(inp.get_field_index(c) if isinstance(c, str) else c).type) for c, _, _ in node.expr)
+        if bits > 192:   # sort.hip: "packed sort key longer than 192 bits"
+            return f"sort key of up to {bits} bits: the device packs at most 192"
+        return None
+    if isinstance(node, HashJoinExec):
+        try:
+            b_rows, _ = _row_bound(node.left)
+        except (TypeError, AttributeError):
+            return None
+        if b_rows >= 0xFFFFFFFF:   # join.hip: the reference switches to JoinHashMapU64 (joins/join_hash_map.rs:224); row ids here are 32 bits
+            return f"build side of up to {b_rows} rows: the device addresses build rows with 32 bits (JoinHashMapU64 is not built)"
+        return None
+    return None
 
 
 def displayable(plan: ExecutionPlan, indent: int = 0) -> str:
