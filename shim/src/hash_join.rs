@@ -71,6 +71,7 @@ struct LoweredJoinFilter {
 /// (SharedBuildAccumulator, hash_join/shared_bounds.rs:277-284)
 struct BoundsAccumulator {
     filter: Arc<DynamicFilterPhysicalExpr>,
+    key_type: arrow::datatypes::DataType,      // the probe-side key expression's type: the bounds are published as scalars of it
     state: Mutex<(usize, Option<(i64, i64)>)>, // (partitions still to report, bounds so far)
 }
 
@@ -165,7 +166,8 @@ impl GpuHashJoinExec {
             e.downcast::<DynamicFilterPhysicalExpr>().ok()
         }).filter(|_| on.len() == 1 && !j.null_aware).map(|filter| {
             let parts = if *j.partition_mode() == PartitionMode::CollectLeft { 1 } else { j.right().output_partitioning().partition_count() };
-            Arc::new(BoundsAccumulator { filter, state: Mutex::new((parts, None)) })
+            let key_type = j.right().schema().field(on[0].1 as usize).data_type().clone();
+            Arc::new(BoundsAccumulator { filter, key_type, state: Mutex::new((parts, None)) })
         });
         Some(Self {
             left: Arc::clone(j.left()),
@@ -213,11 +215,26 @@ async fn collect_build(left: Arc<dyn ExecutionPlan>, partition: usize, ctx: Arc<
     }
     let mut b = Builder(std::ptr::null_mut());
     check(unsafe { sys::dfgpu_join_builder_create(on_l.as_ptr(), on_l.len() as i32, null_equality, &opts, &mut b.0) })?;
-    let mut stats_source: Option<DeviceTable> = None; // single-batch builds: the key statistics come from the pushed table's cache
+    // the dynamic filter's bounds half (PushdownStrategy::Map = bounds only for large build sides, shared_bounds.rs:277-284): the key's
+    // min / max over EVERY pushed batch (dfgpu_column_minmax reduces one table and caches the answer on its column), folded as the
+    // batches go by — a build partition fed several CPU batches reports like one fed a single device table
+    let key = on_l[0];
+    let want_bounds = bounds.is_some();
+    let mut key_bounds: Option<(i64, i64)> = None;
+    let mut fold = |t: &DeviceTable| -> Result<()> {
+        if want_bounds {
+            let (mut lo, mut hi, mut valid, mut asc) = (0i64, 0i64, 0i64, 0i32);
+            check(unsafe { sys::dfgpu_column_minmax(t.0, key, &mut lo, &mut hi, &mut valid, &mut asc) })?;
+            if valid > 0 {
+                key_bounds = Some(match key_bounds { Some((a, b)) => (a.min(lo), b.max(hi)), None => (lo, hi) });
+            }
+        }
+        Ok(())
+    };
     if crate::device::as_gpu_node(&left).is_some() {
         let t = device_input(&left, partition, ctx)?.await?;
         check(unsafe { sys::dfgpu_join_builder_push(b.0, t.0) })?;
-        stats_source = Some(t);
+        fold(&t)?;
     } else {
         let schema = left.schema();
         let mut stream = left.execute(partition, ctx)?;
@@ -225,15 +242,14 @@ async fn collect_build(left: Arc<dyn ExecutionPlan>, partition: usize, ctx: Arc<
         while let Some(batch) = stream.next().await {
             let t = DeviceTable::from_batch(&batch?)?;
             check(unsafe { sys::dfgpu_join_builder_push(b.0, t.0) })?; // "Resources exhausted" here = try_grow failing (exec.rs:2608)
+            fold(&t)?;
             pushed += 1;
-            stats_source = if pushed == 1 { Some(t) } else { None };
         }
         if pushed == 0 {
             let t = DeviceTable::empty(&schema)?; // the builder wants at least one (possibly empty) batch
             check(unsafe { sys::dfgpu_join_builder_push(b.0, t.0) })?;
         }
     }
-    let key = on_l[0];
     blocking(move || {
         let mut b = b;
         let mut ht = std::ptr::null_mut();
@@ -241,12 +257,8 @@ async fn collect_build(left: Arc<dyn ExecutionPlan>, partition: usize, ctx: Arc<
         b.0 = std::ptr::null_mut();
         check(rc)?;
         let ht = Arc::new(GpuJoinTable(ht));
-        if let (Some(acc), Some(t)) = (bounds, stats_source) {
-            // the dynamic filter's bounds half (PushdownStrategy::Map = bounds only for large build sides, shared_bounds.rs:277-284)
-            let (mut lo, mut hi, mut valid, mut asc) = (0i64, 0i64, 0i64, 0i32);
-            if unsafe { sys::dfgpu_column_minmax(t.0, key, &mut lo, &mut hi, &mut valid, &mut asc) } == 0 {
-                acc.report(if valid > 0 { Some((lo, hi)) } else { None })?;
-            }
+        if let Some(acc) = bounds {
+            acc.report(key_bounds)?; // ALWAYS once per build partition: the filter completes when the last one has reported
         }
         Ok(ht)
     }).await
@@ -271,9 +283,12 @@ impl BoundsAccumulator {
             // an empty build side matches nothing: the probe-side scan may skip everything
             None => Arc::new(Literal::new(ScalarValue::Boolean(Some(false)))),
             Some((lo, hi)) => {
-                let lit = |v: i64| -> Arc<dyn PhysicalExpr> { Arc::new(Literal::new(ScalarValue::Int64(Some(v)))) };
-                let ge: Arc<dyn PhysicalExpr> = Arc::new(BinaryExpr::new(Arc::clone(&key), Operator::GtEq, lit(lo)));
-                let le: Arc<dyn PhysicalExpr> = Arc::new(BinaryExpr::new(key, Operator::LtEq, lit(hi)));
+                // scalars of the key column's OWN type, as the reference builds them (shared_bounds.rs: the bounds are ScalarValues
+                // taken from the key arrays): `key >= Int64(lo)` over an Int32 / Date32 / UInt8 / UInt32 key would be an ill-typed
+                // BinaryExpr — lost pruning, or an error once it runs as a row filter (pushdown_filters = true)
+                let lit = |v: i64| -> Result<Arc<dyn PhysicalExpr>> { Ok(Arc::new(Literal::new(ScalarValue::Int64(Some(v)).cast_to(&self.key_type)?))) };
+                let ge: Arc<dyn PhysicalExpr> = Arc::new(BinaryExpr::new(Arc::clone(&key), Operator::GtEq, lit(lo)?));
+                let le: Arc<dyn PhysicalExpr> = Arc::new(BinaryExpr::new(key, Operator::LtEq, lit(hi)?));
                 Arc::new(BinaryExpr::new(ge, Operator::And, le))
             }
         };
