@@ -326,8 +326,86 @@ const void* next_buffer(BatchCursor& c, Owned& own, int64_t* out_len = nullptr) 
   return own.decompressed.back().data();
 }
 
-// one column of the batch as an ArrowArray over host bytes; `take` = false skips its buffers (a column outside the projection)
-ArrowArray* column_array(BatchCursor& c, const IpcField& f, Owned& own, bool take) {
+// bytes per value of a fixed-width Arrow C format string; 0 = bit-packed (Boolean); -1 = not fixed width
+int format_width(const std::string& fmt) {
+  if (fmt == "b") return 0;
+  if (fmt == "c" || fmt == "C") return 1;
+  if (fmt == "s" || fmt == "S" || fmt == "e") return 2;
+  if (fmt == "i" || fmt == "I" || fmt == "f" || fmt == "tdD") return 4;
+  if (fmt == "l" || fmt == "L" || fmt == "g" || fmt == "tdm" || fmt.rfind("ts", 0) == 0 || fmt.rfind("tt", 0) == 0 || fmt.rfind("tD", 0) == 0) return 8;
+  if (fmt.rfind("d:", 0) == 0) return fmt.find(",256") != std::string::npos ? 32 : 16;
+  return -1;
+}
+// Everything dfgpu_table_import is about to read through these pointers must lie INSIDE the buffers the file really holds: the node's
+// row count against every buffer's (decompressed) length, the last string offset against the data buffer, view references against
+// their data buffers, dictionary indices against the dictionary.  arrow-ipc's reader validates the same (ArrayData::validate_full
+// for untrusted input); a truncated or corrupt file must fail here, not read beyond a host mapping.
+void validate_column(const IpcField& f, int64_t length, int64_t nulls, const std::vector<const void*>& bl, const std::vector<int64_t>& lens, int64_t dict_len) {
+  DFGPU_CHECK(length >= 0 && nulls >= 0 && nulls <= length, "arrow ipc: column '" + f.name + "': bad field node (length / null count)");
+  const std::string what = "arrow ipc: column '" + f.name + "': ";
+  if (nulls > 0) DFGPU_CHECK(lens[0] >= (length + 7) / 8, what + "validity buffer shorter than its rows");
+  const uint8_t* valid = nulls > 0 ? static_cast<const uint8_t*>(bl[0]) : nullptr;
+  auto is_valid = [&](int64_t i) { return !valid || ((valid[i >> 3] >> (i & 7)) & 1); };
+  if (length == 0) return;
+  const std::string& fmt = f.format;
+  if (f.view && f.dict_id < 0) {
+    DFGPU_CHECK(lens.size() >= 2 && lens[1] >= length * 16, what + "view buffer shorter than its rows");
+    const uint8_t* v = static_cast<const uint8_t*>(bl[1]);
+    for (int64_t i = 0; i < length; i++) {
+      if (!is_valid(i)) continue;
+      int32_t n, bi, off;
+      std::memcpy(&n, v + i * 16, 4);
+      DFGPU_CHECK(n >= 0, what + "negative view length");
+      if (n <= 12) continue;
+      std::memcpy(&bi, v + i * 16 + 8, 4);
+      std::memcpy(&off, v + i * 16 + 12, 4);
+      DFGPU_CHECK(bi >= 0 && (size_t)bi + 2 < lens.size() && off >= 0 && (int64_t)off + n <= lens[(size_t)bi + 2], what + "a view points outside its data buffers");
+    }
+    return;
+  }
+  if (fmt == "u" || fmt == "z" || fmt == "U" || fmt == "Z") {
+    const int ow = (fmt == "u" || fmt == "z") ? 4 : 8;
+    DFGPU_CHECK(lens.size() >= 3 && lens[1] >= (length + 1) * ow, what + "offsets buffer shorter than its rows");
+    const uint8_t* o = static_cast<const uint8_t*>(bl[1]);
+    int64_t prev = 0;
+    for (int64_t i = 0; i <= length; i++) {
+      int64_t cur;
+      if (ow == 4) {
+        int32_t t;
+        std::memcpy(&t, o + i * 4, 4);
+        cur = t;
+      } else {
+        std::memcpy(&cur, o + i * 8, 8);
+      }
+      DFGPU_CHECK(cur >= prev && (i > 0 || cur >= 0), what + "string offsets are not non-decreasing");
+      prev = cur;
+    }
+    DFGPU_CHECK(prev <= lens[2], what + "the last string offset lies beyond the data buffer");
+    return;
+  }
+  const int w = format_width(fmt);
+  if (w < 0) return;   // (a layout this reader does not import: dfgpu_table_import names it)
+  DFGPU_CHECK(lens.size() >= 2 && lens[1] >= (w == 0 ? (length + 7) / 8 : length * w), what + "values buffer shorter than its rows");
+  if (f.dict_id >= 0) {   // the values are indices into the dictionary
+    const uint8_t* p = static_cast<const uint8_t*>(bl[1]);
+    const bool is_unsigned = fmt == "C" || fmt == "S" || fmt == "I" || fmt == "L";
+    for (int64_t i = 0; i < length; i++) {
+      if (!is_valid(i)) continue;
+      int64_t idx = 0;
+      switch (w) {
+        case 1: idx = is_unsigned ? (int64_t)p[i] : (int64_t)(int8_t)p[i]; break;
+        case 2: { uint16_t t; std::memcpy(&t, p + i * 2, 2); idx = is_unsigned ? (int64_t)t : (int64_t)(int16_t)t; } break;
+        case 4: { uint32_t t; std::memcpy(&t, p + i * 4, 4); idx = is_unsigned ? (int64_t)t : (int64_t)(int32_t)t; } break;
+        default: std::memcpy(&idx, p + i * 8, 8); break;
+      }
+      DFGPU_CHECK(idx >= 0 && idx < dict_len, what + "a dictionary index lies outside its dictionary");
+    }
+  }
+}
+
+// one column of the batch as an ArrowArray over host bytes; `take` = false skips its buffers (a column outside the projection).
+// `rows` = the batch's declared row count the node must agree with (-1: a dictionary batch); `dict_len` = length of the column's dictionary
+ArrowArray* column_array(BatchCursor& c, const IpcField& f, Owned& own, bool take, int64_t rows = -1, int64_t dict_len = 0) {
   DFGPU_CHECK(c.node_at < c.n_nodes, "arrow ipc: a record batch lists fewer field nodes than its schema has columns");
   const uint8_t* node = c.nodes + (size_t)c.node_at * 16;
   c.node_at++;
@@ -346,12 +424,15 @@ ArrowArray* column_array(BatchCursor& c, const IpcField& f, Owned& own, bool tak
   }
   own.buffer_lists.emplace_back();
   std::vector<const void*>& bl = own.buffer_lists.back();
-  std::vector<int64_t> data_lens;
+  std::vector<int64_t> data_lens, lens;
   for (int i = 0; i < n_buf; i++) {
     int64_t len = 0;
     bl.push_back(next_buffer(c, own, &len));
+    lens.push_back(len);
     if (i >= 2) data_lens.push_back(len);
   }
+  DFGPU_CHECK(rows < 0 || length == rows, "arrow ipc: column '" + f.name + "': its field node's length differs from the record batch's");
+  validate_column(f, length, nulls, bl, lens, dict_len);
   if (nulls == 0) bl[0] = nullptr;
   if (f.view && f.dict_id < 0) {
     // the C Data Interface carries a view array's data-buffer lengths as one more (last) buffer of int64
@@ -470,7 +551,7 @@ int dfgpu_ipc_read_batch(dfgpu_ipc_t h, int64_t i, const int* columns, int ncols
     std::vector<ArrowSchema*> skids(want.size(), nullptr);
     for (size_t c = 0; c < f.fields.size(); c++) {
       const IpcField& fld = f.fields[c];
-      ArrowArray* a = column_array(bc, fld, *own, slot[c] >= 0);
+      ArrowArray* a = column_array(bc, fld, *own, slot[c] >= 0, f.batches[(size_t)i].rows, fld.dict_id >= 0 && slot[c] >= 0 ? dict_arrays[fld.dict_id]->length : 0);
       if (slot[c] < 0) continue;
       ArrowSchema* s = plain_schema(*own, fld.format, fld.name, fld.nullable);
       if (fld.dict_id >= 0) {

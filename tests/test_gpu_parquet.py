@@ -323,6 +323,55 @@ def test_arrow_ipc_reader_below_the_c_abi_every_type(tmp_path, fmt, compression)
     f.close()
 
 
+@pytest.mark.parametrize("damage", ["node_longer_than_its_buffers", "node_differs_from_batch", "string_offsets_beyond_data", "dictionary_index_out_of_range"])
+def test_arrow_ipc_reader_rejects_files_whose_metadata_overruns_their_buffers(tmp_path, damage):
+    """a truncated / corrupt IPC file must fail in dfgpu_ipc_read_batch — the field node's row count is checked against every
+    buffer's length, the last string offset against the data buffer, dictionary indices against the dictionary — instead of
+    letting dfgpu_table_import read beyond the host mapping (arrow-ipc validates the same for untrusted input)"""
+    import struct
+
+    import pyarrow.ipc as ipc
+
+    from datafusion_amd import _lib
+    from datafusion_amd.ipc import IpcFile
+    n = 12_345   # a row count whose 8 little-endian bytes appear nowhere else in the file
+    t = pa.table({"a": pa.array(np.arange(n, dtype=np.int64) * 3), "s": pa.array(["v%d" % (i % 50) for i in range(n)], pa.string()),
+                  "d": pa.array([["x", "yy", "zzz"][i % 3] for i in range(n)], pa.string()).dictionary_encode()})
+    path = str(tmp_path / "t.arrow")
+    with ipc.new_stream(path, t.schema) as w:
+        w.write_batch(t.to_batches()[0])
+    raw = bytearray(open(path, "rb").read())
+    IpcFile(path).read_batch(0).free()       # intact: reads
+    pat = struct.pack("<q", n)
+    hits = [i for i in range(len(raw) - 8) if raw[i:i + 8] == pat]
+    assert len(hits) >= 4                    # RecordBatch.length + one FieldNode.length per column
+    if damage == "node_longer_than_its_buffers":
+        for h in hits:                        # batch and nodes agree on a row count the buffers do not hold
+            raw[h:h + 8] = struct.pack("<q", n * 1000)
+        needle = "shorter than its rows"
+    elif damage == "node_differs_from_batch":
+        raw[hits[1]:hits[1] + 8] = struct.pack("<q", n - 1)
+        needle = "differs from the record batch"
+    elif damage == "string_offsets_beyond_data":
+        last = struct.pack("<i", sum(len("v%d" % (i % 50)) for i in range(n)))     # the final offset of column s
+        at = raw.rfind(last)
+        assert at > 0
+        raw[at:at + 4] = struct.pack("<i", 2**30)
+        needle = "last string offset"
+    else:
+        idx = np.frombuffer(t.column("d").chunk(0).indices.buffers()[1], dtype=np.int32).tobytes()
+        at = raw.find(idx[:64])
+        assert at > 0
+        raw[at:at + 4] = struct.pack("<i", 77)
+        needle = "dictionary index"
+    bad = str(tmp_path / "bad.arrow")
+    open(bad, "wb").write(bytes(raw))
+    f = IpcFile(bad)
+    with pytest.raises(_lib.DfgpuError, match=needle):
+        f.read_batch(0)
+    f.close()
+
+
 def test_parquet_chunk_with_dictionary_fallback_pages(tmp_path):
     """one column chunk holding dictionary-encoded pages followed by PLAIN pages (the writer's dictionary limit was reached)"""
     from datafusion_amd.parquet import ParquetFile, read_table
