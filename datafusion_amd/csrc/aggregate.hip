@@ -2111,8 +2111,10 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
       default: fn = (const void*)k_dense_accumulate_parts<int32_t>; break;
     }
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess) {
+      // the windows and the accumulators per value above were sized for LDS_BUDGET: a device that does not grant it (none of the
+      // CDNA parts this is built for) takes the global-atomic path instead of launching with more LDS than it has
       (void)hipGetLastError();
-      if (W * 12 > ((size_t)64 << 10)) return false;
+      return false;
     }
     // (opt-in: the slot -> group table in LDS beside the cells — up to 16 K + 1 slots as 16-bit words on top of the budget)
     const bool small_table = std::getenv("DFGPU_AGG_SMALL_TABLE") && std::getenv("DFGPU_AGG_SMALL_TABLE")[0] == '1';
@@ -4020,7 +4022,11 @@ int dfgpu_agg_create_grouping_sets(int mode, const dfgpu_expr* group_by, const d
     DFGPU_CHECK(group_by && null_by && groups && n_group >= 1 && n_group <= 63 && n_sets >= 1 && out, "grouping sets: bad argument");
     auto top = std::make_unique<Aggregate>();
     top->mode = mode;
-    const int id_type = n_group <= 8 ? DFGPU_UINT8 : n_group <= 32 ? DFGPU_UINT32 : DFGPU_UINT64;  // Aggregate::grouping_id_type (no UInt16 on the device: widened)
+    // Aggregate::grouping_id_type: UInt8 / UInt16 / UInt32 / UInt64 by the number of grouping columns.  The device has no UInt16
+    // column: 9..16 grouping columns would come out as UInt32 and a CPU Final node fed by this Partial one would see another schema
+    // than the reference's — refused, the planner keeps the CPU operator (shim/src/operators.rs try_from_aggregate)
+    DFGPU_CHECK(!(n_group >= 9 && n_group <= 16), "grouping sets over 9..16 columns: __grouping_id is UInt16 in the reference, which has no device type");
+    const int id_type = n_group <= 8 ? DFGPU_UINT8 : n_group <= 32 ? DFGPU_UINT32 : DFGPU_UINT64;
     for (int s = 0; s < n_sets; s++) {
       std::vector<dfgpu_expr> keys((size_t)n_group + 1);
       std::vector<const char*> names((size_t)n_group + 1);

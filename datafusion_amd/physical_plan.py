@@ -327,13 +327,14 @@ class HashJoinExec(ExecutionPlan):
         while isinstance(node, (FilterExec, CoalesceBatchesExec, RepartitionExec)):
             node = node.input
         if not isinstance(node, ParquetExec):
-            return
+            return None
         probe_key = self.on[0][1]
         from .queries import _world
         if probe_key in node.dynamic_bounds and probe_key not in node.dynamic_in_lists and _world() == 1 and self.filter is None:
             node.dynamic_membership[probe_key] = ht
-        else:
-            node.dynamic_membership.pop(probe_key, None)
+            return node, probe_key        # the caller withdraws the entry before it frees the table (the scan does not own it)
+        node.dynamic_membership.pop(probe_key, None)
+        return None
 
     def _publish_dynamic_bounds(self, build_table):
         """the join's dynamic filter (HashJoinExec::create_dynamic_filter, hash_join/exec.rs:869-875; bounds accumulated in
@@ -423,9 +424,14 @@ class HashJoinExec(ExecutionPlan):
         b, bo = self._run_child(self.left)
         ht = ops.JoinHashTable(b, [l for l, _ in self.on], self.null_equality, probe_mode=self.probe_mode, null_aware=self.null_aware)
         self._publish_dynamic_bounds(b)
-        if self.join_type in ("Inner", "RightSemi") and len(self.on) == 1:
-            self._publish_membership(ht)
-        p, po = self._run_child(self.right)
+        published = self._publish_membership(ht) if self.join_type in ("Inner", "RightSemi") and len(self.on) == 1 else None
+        try:
+            p, po = self._run_child(self.right)
+        finally:
+            # the membership entry is the live join table: it leaves the scan node once the probe child has run — a later execution of
+            # that scan (on its own, or through a re-used node) must not ask a freed table
+            if published is not None:
+                published[0].dynamic_membership.pop(published[1], None)
         out = self._probe(ht, p, probe_predicate)
         ht.free()
         for t, o in ((b, bo), (p, po)):

@@ -145,7 +145,8 @@ impl GpuUnaryExec {
             let nulls = a.group_expr().null_expr().iter().map(|(e, _)| lowered(e, &in_schema)).collect::<Option<Vec<_>>>()?;
             let n = a.group_expr().expr().len();
             let masks: Vec<u8> = a.group_expr().groups().iter().flat_map(|g| g.iter().map(|b| *b as u8)).collect();
-            Some((nulls, masks, (a.group_expr().groups().len()) as i32)).filter(|_| n >= 1 && n <= 63)
+            // (9..16 grouping columns: __grouping_id is UInt16 in the reference — no device type — so the CPU operator stays)
+            Some((nulls, masks, (a.group_expr().groups().len()) as i32)).filter(|_| n >= 1 && n <= 63 && !(9..=16).contains(&n))
         } else {
             return None; // a Final over grouping sets reads (keys, __grouping_id) positionally: planned as single-set by as_final()
         };
