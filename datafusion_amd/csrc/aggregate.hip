@@ -291,114 +291,6 @@ __global__ __launch_bounds__(BLOCK) void k_intern_claim_keyed(InternCtx c, int64
     }
   }
 }
-// NOT YET RUN ON THE GPU — opt-in with DFGPU_AGG_LDS_CLAIM=1 (written at the end of round 3, after the GPU budget: the round's
-// microbenchmark prices a random LDS access at a tenth of a random L2 hit, profiles/r3_random_access.md; tests to run with the knob on:
-// tests/test_gpu_aggregate.py -k "lie or narrow or all_ones or misleading").
-// A few thousand distinct keys: every workgroup keeps the keys IT has met in LDS — entry {packed key, device-wide slot, smallest row of
-// the workgroup's slice} — so a row costs its key bytes, LDS probes and its row_slot store.  No barrier between rows: the thread that
-// enters a key finds or claims it in the device-wide table at once and publishes the slot in the entry; a thread that meets an entry
-// whose slot is not published yet goes to the device-wide table itself (no waiting: the publisher may be a lane of the same wave);
-// every row lowers the entry's smallest row when its own is smaller; after ONE barrier at the end of the slice the entries offer
-// their rows to their slots.  Entries stop being made at 3/4 of the LDS table (many more keys than the caller expected): the rows
-// of other keys then go to the device-wide table directly.
-constexpr int LC2_BLOCK = 1024;
-constexpr int LC2_ROWS = 8;
-constexpr int LC2_PROBES = 512;   // (a bound only)
-constexpr uint64_t SEED_LOCAL = 0x9E6C63D0876A9A35ULL;
-__global__ __launch_bounds__(LC2_BLOCK) void k_intern_claim_keyed_lds(InternCtx c, int64_t n, int* overflow, const uint64_t* __restrict__ row_mask, int64_t mask_offset,
-                                                                     uint32_t* __restrict__ row_slot, int lbits, int64_t rows_per_block) {
-  extern __shared__ unsigned long long lc_mem[];
-  const uint32_t L = 1u << lbits;
-  unsigned long long* lkey = lc_mem;                              // [L]
-  uint32_t* lslot = reinterpret_cast<uint32_t*>(lc_mem + L);      // [L] device-wide slot, 0xFFFFFFFF = not published yet
-  uint32_t* lrow = lslot + L;                                     // [L] smallest row + 1 of this workgroup's slice
-  __shared__ uint32_t s_entries, s_stop;
-  for (uint32_t x = threadIdx.x; x < L; x += LC2_BLOCK) {
-    lkey[x] = KEY_EMPTY;
-    lslot[x] = 0xFFFFFFFFu;
-    lrow[x] = 0xFFFFFFFFu;
-  }
-  if (threadIdx.x == 0) {
-    s_entries = 0;
-    s_stop = 0;
-  }
-  __syncthreads();
-  const int64_t b0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t b1 = b0 + rows_per_block < n ? b0 + rows_per_block : n;
-  for (int64_t t0 = b0 + threadIdx.x; t0 < b1 && !s_stop; t0 += (int64_t)LC2_BLOCK * LC2_ROWS) {
-    int64_t rows[LC2_ROWS];
-    uint64_t keys[LC2_ROWS];
-    uint32_t live = 0;
-#pragma unroll
-    for (int r = 0; r < LC2_ROWS; r++) {
-      rows[r] = t0 + (int64_t)r * LC2_BLOCK;
-      if (rows[r] < b1 && !(row_mask && rows[r] >= mask_offset && !bit_at(row_mask, rows[r] - mask_offset))) live |= 1u << r;
-    }
-    packed_keys<LC2_ROWS>(c.keys, rows, live, keys);
-    const bool enter = s_entries <= (L / 4u) * 3u;
-#pragma unroll
-    for (int r = 0; r < LC2_ROWS; r++) {
-      const int64_t i = rows[r];
-      if (i >= b1) continue;
-      if (!((live >> r) & 1u)) {
-        if (row_slot) row_slot[i] = 0xFFFFFFFFu;
-        continue;
-      }
-      const uint64_t k = keys[r];
-      const uint32_t me = (uint32_t)i + 1u;
-      uint32_t slot = 0xFFFFFFFFu;
-      bool owner = false, local = false;
-      uint32_t h = (uint32_t)(fmix64(k ^ SEED_LOCAL) >> 32) & (L - 1u);
-      if (k != KEY_EMPTY) {
-        for (int steps = 0; steps <= LC2_PROBES; steps++) {
-          unsigned long long cur = lkey[h];
-          if (cur == KEY_EMPTY) {
-            if (!enter) break;
-            cur = atomicCAS(&lkey[h], (unsigned long long)KEY_EMPTY, (unsigned long long)k);
-            if (cur == KEY_EMPTY) {
-              owner = true;
-              cur = k;
-              atomicAdd(&s_entries, 1u);
-            }
-          }
-          if (cur == k) {
-            local = true;
-            break;
-          }
-          h = (h + 1u) & (L - 1u);
-        }
-      }
-      if (local) {
-        if (me < lrow[h]) atomicMin(&lrow[h], me);
-        if (!owner) slot = lslot[h];
-      }
-      if (slot == 0xFFFFFFFFu) {   // the owner of a new entry, an entry not published yet, or no entry: the device-wide table
-        uint64_t s = k == KEY_EMPTY ? c.mask + 1 : packed_key_slot(k, c.mask);
-        uint64_t key;
-        uint32_t row;
-        keyed_load(c.keyed, s, key, row);
-        if (!keyed_find_or_claim(c, k, s, key, row)) {
-          __hip_atomic_store(overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_stop = 1u;
-          continue;
-        }
-        slot = (uint32_t)s;
-        if (owner) lslot[h] = slot;
-        if (!local) keyed_offer_row(c, s, me, row);   // (rows with an entry are offered through it at the end)
-      }
-      if (row_slot) row_slot[i] = slot;
-    }
-  }
-  __syncthreads();
-  // the entries' smallest rows -> their slots (an entry whose owner ran into a full table has no slot: the launch is repeated anyway)
-  for (uint32_t x = threadIdx.x; x < L; x += LC2_BLOCK) {
-    if (lkey[x] == KEY_EMPTY || lslot[x] == 0xFFFFFFFFu || lrow[x] == 0xFFFFFFFFu) continue;
-    uint64_t key;
-    uint32_t row;
-    keyed_load(c.keyed, lslot[x], key, row);
-    keyed_offer_row(c, lslot[x], lrow[x], row);
-  }
-}
 __global__ __launch_bounds__(BLOCK) void k_keyed_clear(KeyedSlot* t, uint64_t n_slots) {
   for (uint64_t s = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; s < n_slots; s += (uint64_t)gridDim.x * BLOCK)
     *reinterpret_cast<uint4*>(t + s) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
@@ -1174,7 +1066,6 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   // own and extrapolate: distinct keys still growing with the sample => groups ~ rows x (distinct / sample); flat between
   // the first quarter and the whole sample => the sample has seen them all.
   constexpr int64_t SAMPLE = 1 << 20;
-  bool sample_saw_all_keys = false;   // ... and they are a few thousand (what the opt-in LDS claim pass asks for)
   if (G0 == 0) {
     if (total <= 4 * SAMPLE) {
       cap = cap_max;
@@ -1195,21 +1086,12 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
       DFGPU_HIP(hipMemsetAsync(flag->ptr, 0, 4, r.stream));  // (a 2x table cannot overflow; the flag is shared with the real attempts)
       const double d_all = (double)c2[0], d_early = (double)c2[1];
       const double est = d_all < 1.25 * d_early ? 2.0 * d_all : d_all / (double)SAMPLE * (double)total;
-      sample_saw_all_keys = d_all < 1.25 * d_early && d_all <= 5500.0;
-      // (a table sized down to ~4 slots per key when the sample has seen them all — 16 K slots instead of 64 K for 3817 groups — was
-      // tried for the sake of cache hits on the rows' random accesses: 6.6 -> 8.0 ms over 600 M rows, but measured on a box whose
-      // whole test run was 3 x slower than the others'; by profiles/r3_random_access.md a 256 KB table should cost no more than a
-      // 1 MB one — to be measured again)
-      const bool small_table = std::getenv("DFGPU_AGG_SMALL_TABLE") && std::getenv("DFGPU_AGG_SMALL_TABLE")[0] == '1';
-      if (small_table && d_all < 1.25 * d_early) {   // (opt-in: ~4 slots per key when the sample has seen them all, from 4 K slots)
-        uint64_t want = 1 << 12;
-        while ((double)want < 2.0 * est && want < cap_max) want <<= 1;
-        cap = want;
-      } else {
-        uint64_t want = 1 << 16;
-        while ((double)want < 3.0 * est && want < cap_max) want <<= 1;
-        cap = std::max<uint64_t>(cap, want);
-      }
+      // (round 3 left two opt-in variants here — a table sized down to ~4 slots per key, and a barrier-free claim pass that kept the met
+      // keys in LDS — for the three-key aggregate over 600 M rows; measured in round 4 (profiles/r4_agg_knobs.md): 15.1 ms either way
+      // against 13.6 ms without them, so they are gone)
+      uint64_t want = 1 << 16;
+      while ((double)want < 3.0 * est && want < cap_max) want <<= 1;
+      cap = std::max<uint64_t>(cap, want);
     }
   }
   if (cap > cap_max) cap = cap_max;
@@ -1226,18 +1108,7 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
       ProfileScope ps(keyed ? "agg_intern_claim_keyed" : "agg_intern_claim", key_bytes);
       if (want_row_slots && !R.row_slot) R.row_slot = make_buf((size_t)total * 4);
       uint32_t* rs = R.row_slot ? R.row_slot->as<uint32_t>() : nullptr;
-      // (opt-in, not yet run on the GPU: see k_intern_claim_keyed_lds)
-      const bool lds_claim = std::getenv("DFGPU_AGG_LDS_CLAIM") && std::getenv("DFGPU_AGG_LDS_CLAIM")[0] == '1';
-      constexpr int LBITS = 13;
-      constexpr size_t LDS_CLAIM_BYTES = (size_t)16 << LBITS;
-      if (keyed && lds_claim && sample_saw_all_keys && cap < (1ull << 31) &&
-          hipFuncSetAttribute((const void*)k_intern_claim_keyed_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CLAIM_BYTES) == hipSuccess) {
-        const int64_t tile = (int64_t)LC2_BLOCK * LC2_ROWS;
-        const int64_t nb = std::min<int64_t>(512, (total + tile - 1) / tile);
-        const int64_t per = ((total + nb - 1) / nb + tile - 1) / tile * tile;
-        k_intern_claim_keyed_lds<<<(int)((total + per - 1) / per), LC2_BLOCK, LDS_CLAIM_BYTES, r.stream>>>(ictx, total, flag->as<int>(), row_mask, G0, rs, LBITS, per);
-        k_keyed_rows<<<grid_for((int64_t)cap + 1, BLOCK), BLOCK, 0, r.stream>>>(ictx.keyed, cap + 1, ictx.slots);
-      } else if (keyed) {
+      if (keyed) {
         k_intern_claim_keyed<<<grid_for((total + KEYED_ROWS - 1) / KEYED_ROWS, BLOCK), BLOCK, 0, r.stream>>>(ictx, total, flag->as<int>(), row_mask, G0, rs);
         k_keyed_rows<<<grid_for((int64_t)cap + 1, BLOCK), BLOCK, 0, r.stream>>>(ictx.keyed, cap + 1, ictx.slots);
       }
@@ -1896,17 +1767,13 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
                                                                  PartAccSet accs, long long kmin, int wshift, unsigned long long* __restrict__ cells_v,
                                                                  int64_t vstride, uint64_t vrange, uint32_t* __restrict__ first_row_v,
                                                                  const uint64_t* __restrict__ row_mask, const uint64_t* __restrict__ row_mask_valid, int rows_in_place,
-                                                                 const uint32_t* __restrict__ key_map, int map_n) {
+                                                                 const uint32_t* __restrict__ key_map) {
   extern __shared__ unsigned long long s_mem[];
   const int W = 1 << wshift;
   unsigned long long* s_cell = s_mem;                                   // [ncw][W]
   uint32_t* s_c32 = reinterpret_cast<uint32_t*>(s_mem + (size_t)accs.ncw * W);   // [n32][W]
   uint32_t* s_first = s_c32 + (size_t)accs.n32 * W;                      // [W]
-  // (opt-in DFGPU_AGG_SMALL_TABLE=1, not yet run on the GPU: the slot -> group table as 16-bit words in LDS — a random LDS read
-  // per row, a tenth of the L2 hit the lookup in key_map costs, profiles/r3_random_access.md)
-  uint16_t* s_map = reinterpret_cast<uint16_t*>(s_first + W);             // [map_n]
   const PartBlock b = blocks[blockIdx.x];
-  for (int x = threadIdx.x; x < map_n; x += PART_BLOCK) s_map[x] = (uint16_t)key_map[x];
   for (int x = threadIdx.x; x < W; x += PART_BLOCK) s_first[x] = 0xFFFFFFFFu;
   for (int k = 0; k < accs.n; k++) {
     const PartAcc& a = accs.a[k];
@@ -1924,7 +1791,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
     if (row_mask && !((row_mask[i >> 6] >> (i & 63)) & 1ull)) continue;
     if (row_mask_valid && !((row_mask_valid[i >> 6] >> (i & 63)) & 1ull)) continue;
     // (key_map: the key column holds table slots, the value is the slot's group number — hash-interned groups in place)
-    const long long kv = map_n ? (long long)s_map[(size_t)key[i]] : key_map ? (long long)key_map[(size_t)key[i]] : (long long)key[i];
+    const long long kv = key_map ? (long long)key_map[(size_t)key[i]] : (long long)key[i];
     const int x = (int)((unsigned long long)(kv - kmin) - base);   // value index inside the window
     if (row_id || rows_in_place) atomicMin(&s_first[x], row_id ? row_id[i] : (uint32_t)i);
     else s_first[x] = 0u;   // (no first rows wanted: a mark that the value has a row — a plain store, every writer's the same)
@@ -2100,7 +1967,6 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   const int64_t n_windows = (int64_t)((range - 1) >> wshift) + 1;
   const size_t W = (size_t)1 << wshift;
   const size_t bytes_per_value = LDS_BUDGET / W - 4;   // of LDS, beside the first row
-  int map_n = 0;   // entries of key_map kept in LDS (opt-in, below)
   // more than 64 KB of dynamic LDS has to be asked for, per kernel
   {
     const void* fn = nullptr;
@@ -2116,13 +1982,6 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
       (void)hipGetLastError();
       return false;
     }
-    // (opt-in: the slot -> group table in LDS beside the cells — up to 16 K + 1 slots as 16-bit words on top of the budget)
-    const bool small_table = std::getenv("DFGPU_AGG_SMALL_TABLE") && std::getenv("DFGPU_AGG_SMALL_TABLE")[0] == '1';
-    if (small_table && in_place && key_map && key_map_n > 0 && key_map_n <= (1 << 14) + 1 && range <= 65535 &&
-        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET + (((size_t)key_map_n * 2 + 15) & ~(size_t)15))) == hipSuccess)
-      map_n = (int)key_map_n;
-    else
-      (void)hipGetLastError();
   }
   Runtime& r = rt();
   // what moves: the key, every distinct argument column, the row numbers
@@ -2250,12 +2109,12 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
         u++;
       }
       DFGPU_CHECK(ps.n > 0, "partitioned aggregation: an accumulator does not fit the window");
-      const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4 * (size_t)ps.n32 + 4) + (((size_t)map_n * 2 + 15) & ~(size_t)15);
+      const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4 * (size_t)ps.n32 + 4);
       switch (kt) {
-        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_n); break;
-        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_n); break;
-        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_n); break;
-        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_n); break;
+        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
+        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
+        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
+        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
       }
       DFGPU_HIP(hipGetLastError());
       first_launch = false;

@@ -558,15 +558,10 @@ def test_two_column_key_medium_cardinality_moves_rows_by_group_number(filtered):
         assert got.column("s2").to_pylist() == (2 * sv[order]).tolist()
 
 
-AGG_KNOBS = [{}, {"DFGPU_AGG_LDS_CLAIM": "1"}, {"DFGPU_AGG_SMALL_TABLE": "1"}, {"DFGPU_AGG_LDS_CLAIM": "1", "DFGPU_AGG_SMALL_TABLE": "1"}]
-AGG_KNOB_IDS = ["default", "lds_claim", "small_table", "lds_claim_small_table"]
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("knobs", AGG_KNOBS, ids=AGG_KNOB_IDS)
 @pytest.mark.parametrize("shape", ["u8_u8_date32", "i32_i32_with_negatives"])
 @pytest.mark.parametrize("filtered", [False, True], ids=["no_predicate", "fused_filter"])
-def test_narrow_key_columns_are_interned_through_one_packed_word(shape, filtered, knobs, monkeypatch):
+def test_narrow_key_columns_are_interned_through_one_packed_word(shape, filtered):
     """key columns without NULLs that fit 64 bits together are interned through their packed form, which the table keeps in its slots
     (one hash and one comparison per row, no trip to the representative row's columns) — the groups, their first-seen order and the key
     VALUES that come out (taken from the original columns, negative ones included) are those of the column-by-column path; four updates, so the later ones intern against
@@ -574,8 +569,6 @@ def test_narrow_key_columns_are_interned_through_one_packed_word(shape, filtered
     from datafusion_amd import ops
     from datafusion_amd.expr import col, lit
     from datafusion_amd.table import DeviceTable
-    for k, v in knobs.items():   # (round 3's opt-in paths: the barrier-free LDS claim pass, the slot -> group table in LDS)
-        monkeypatch.setenv(k, v)
     rng = np.random.default_rng(5 + filtered)
     n = 3_430_000
     if shape == "u8_u8_date32":
@@ -602,8 +595,7 @@ def test_narrow_key_columns_are_interned_through_one_packed_word(shape, filtered
     got = a.emit().to_arrow()
     stats = ops.profile_stats()
     ops.profile_enable(False)
-    keyed = sum(stats.get(k, {"calls": 0})["calls"] for k in ("agg_intern_claim_keyed", "agg_intern_claim_keyed_lds"))
-    assert keyed == 3 and stats["agg_intern_claim"]["calls"] == 1, sorted(stats)
+    assert stats["agg_intern_claim_keyed"]["calls"] == 3 and stats["agg_intern_claim"]["calls"] == 1, sorted(stats)
     keep = (w < 20) if filtered else np.ones(n, dtype=bool)
     _, dense = np.unique(np.stack(raw, axis=1), axis=0, return_inverse=True)
     dense = dense.reshape(-1)
@@ -625,18 +617,15 @@ def test_narrow_key_columns_are_interned_through_one_packed_word(shape, filtered
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knobs", AGG_KNOBS, ids=AGG_KNOB_IDS)
 @pytest.mark.parametrize("filtered", [False, True], ids=["no_predicate", "fused_filter"])
 @pytest.mark.parametrize("keys", ["dense_int64", "two_columns"])
-def test_a_few_thousand_groups_are_accumulated_in_lds_where_the_rows_lie(keys, filtered, knobs, monkeypatch):
+def test_a_few_thousand_groups_are_accumulated_in_lds_where_the_rows_lie(keys, filtered):
     """a key range (or a number of hash-interned groups) small enough for ONE workgroup's LDS: no row is moved — every workgroup
     accumulates a slice of the rows in place (the fused predicate's mask read row by row, NULL predicate values dropping the row)
     and the copies merge; groups in first-seen order, SUM / COUNT / MIN / AVG / SUM(Decimal128) as computed on the host"""
     from datafusion_amd import ops
     from datafusion_amd.expr import col, lit
     from datafusion_amd.table import DeviceTable
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
     rng = np.random.default_rng(1234 + filtered)
     n = 9_000_000
     if keys == "dense_int64":
