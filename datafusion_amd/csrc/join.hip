@@ -2358,7 +2358,9 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const char* min_env = std::getenv("DFGPU_JOIN_GROUPED_MIN_ROWS");  // test knob: from how many probe rows grouping is considered (default 4 Mi)
   const int64_t grouped_min_rows = min_env ? std::atoll(min_env) : ((int64_t)1 << 22);
   const bool unclustered = fused_ok && big_table && np > grouped_min_rows && pk.size() == 1 && !in_grouped_probe &&
-                           !probe_keys_clustered(probe.cols[(size_t)pk[0]], np, jt.kind == KIND_RANK ? ((uint64_t)512 << 10) / 16 * 64 : ((uint64_t)512 << 10) / 4);
+                           !probe_keys_clustered(probe.cols[(size_t)pk[0]], np,
+                                                 std::getenv("DFGPU_JOIN_NEAR_WINDOW") ? (uint64_t)std::atoll(std::getenv("DFGPU_JOIN_NEAR_WINDOW"))   // test knob
+                                                 : jt.kind == KIND_RANK ? ((uint64_t)512 << 10) / 16 * 64 : ((uint64_t)512 << 10) / 4);
   const bool group_env = !(std::getenv("DFGPU_JOIN_GROUPED_PROBE") && std::getenv("DFGPU_JOIN_GROUPED_PROBE")[0] == '0');  // A/B knob
   // the key-only probe whose order nobody observes: its keys are grouped and probed in group order (below)
   const bool grouped_keys_only = unclustered && group_env && jt.probe_mode == 4 && rows_unused && !row_mask && pout.size() == 1 && pout[0] == pk[0] &&

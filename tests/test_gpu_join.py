@@ -580,7 +580,8 @@ def test_unclustered_probe_with_payload_goes_through_groups_and_comes_back_in_pr
     # NULL keys; the payload stays non-nullable (a nullable output column takes the pairs path): the key travels as the copy "kk"
     probe = probe.append_column("kk", probe.column("k2")).set_column(0, "k2", pa.array(probe.column("k2").to_numpy(), mask=rng.random(npr) < 0.02))
     b, p = DeviceTable.from_arrow(build), DeviceTable.from_arrow(probe)
-    os.environ.update({"DFGPU_JOIN_BIG_TABLE_BYTES": "0", "DFGPU_JOIN_GROUPED_MIN_ROWS": "0", "DFGPU_JOIN_GP_BITS": gp_bits})
+    # (test knobs: this table counts as beyond the caches, grouping from the first row on, "near" = within 1000 key values)
+    os.environ.update({"DFGPU_JOIN_BIG_TABLE_BYTES": "0", "DFGPU_JOIN_GROUPED_MIN_ROWS": "0", "DFGPU_JOIN_GP_BITS": gp_bits, "DFGPU_JOIN_NEAR_WINDOW": "1000"})
     try:
         for payload in (["d", "p"], ["x", "u", "w", "p", "d"], ["w"], []):
             exp = oracle.hash_join(build, probe, [("k", "k2")], "Inner").select(payload + ["kk", "e", "q"])
@@ -619,7 +620,7 @@ def test_unclustered_probe_with_payload_goes_through_groups_and_comes_back_in_pr
         assert_tables_equal(got, oracle.hash_join(build, fk, [("k", "k2")], "Inner").select(["d", "p", "k2", "e"]), ordered=True)
         ht.free()
     finally:
-        for k in ("DFGPU_JOIN_BIG_TABLE_BYTES", "DFGPU_JOIN_GROUPED_MIN_ROWS", "DFGPU_JOIN_GP_BITS"):
+        for k in ("DFGPU_JOIN_BIG_TABLE_BYTES", "DFGPU_JOIN_GROUPED_MIN_ROWS", "DFGPU_JOIN_GP_BITS", "DFGPU_JOIN_NEAR_WINDOW"):
             os.environ.pop(k, None)
 
 

@@ -63,13 +63,13 @@ def test_a_sort_key_wider_than_the_packed_key_stays_on_the_cpu():
     """sort.hip packs the key columns into at most 192 bits; two Decimal128 columns (2 x 129 bits by type) may not fit"""
     from datafusion_amd import physical_plan as P
     t = pa.table({"a": pa.array([Decimal("3"), Decimal("1")], type=pa.decimal128(38, 0)), "b": pa.array([Decimal("2"), Decimal("2")], type=pa.decimal128(38, 0)),
-                  "c": pa.array([5, 6], type=pa.int64())})
+                  "c": pa.array([5, 6], type=pa.int32())})
     leaf = _leaf(t)
     rule = P.GpuOffloadRule()
     out = rule.optimize(P.SortExec([("a", False, False), ("b", True, False)], leaf))
     assert getattr(out, "kept_on_cpu", False) and "192" in rule.declined[0][1]
     rule2 = P.GpuOffloadRule()
-    ok = rule2.optimize(P.SortExec([("a", False, False), ("c", True, False)], leaf))     # 129 + 65 bits: fits, as it is
+    ok = rule2.optimize(P.SortExec([("a", False, False), ("c", True, False)], leaf))     # 129 + 33 bits: fits, as it is
     assert not getattr(ok, "kept_on_cpu", False) and not rule2.declined
     assert P.collect(ok).to_arrow().column("c").to_pylist() == [6, 5]
 
