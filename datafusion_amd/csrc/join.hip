@@ -81,6 +81,7 @@ struct JoinTable {
   bool rank_needs_perm = false;
   std::shared_ptr<RadixTable> radix;  // KIND_RADIX: build records partitioned for the LDS join (radix_join.hip)
   std::map<int, BufPtr> rank_payload;  // rank map over keys in no order: build column -> its copy in RANK order (ensure_rank_payload)
+  std::map<std::vector<int>, BufPtr> rank_records;  // ... and, for a payload of <= 12 bytes, those columns as ONE 16-byte record per rank
   BufPtr flat;                        // KIND_FLAT / KIND_FLAT16: uint4 {key, first row + 1, 0} per slot (two uint4 for 16-byte keys)
   FlatLayout flat_layout{};
   int flat_shift = 0;                 // slot = hash >> flat_shift
@@ -1300,6 +1301,7 @@ struct RetLayout {
   const void* src[MAX_JOIN_COLS];   // the build columns, readable at RANK positions
   int width[MAX_JOIN_COLS], off[MAX_JOIN_COLS];
   int n, R;
+  const uint4* packed16;            // R == 16 only: the build columns of rank r already laid out as the record (word 0 free): one access
 };
 // Which rows a workgroup takes next.  All workgroups of an XCD (blockIdx % 8, MI355X_MICROARCH.md: a placement that only speed
 // depends on) walk that XCD's groups — g = xcd, xcd + 8, ... — in order, GP_CHUNK rows at a time, handed out by ONE counter per XCD:
@@ -1380,6 +1382,12 @@ __global__ __launch_bounds__(BLOCK) void k_gp_lookup(const ulonglong2* __restric
         // the whole record in registers, ONE 16-byte store per row (streamed: the records are read back much later, and must not
         // push the group's slice of the table out of the L2)
         uint4 rv[GP_U];
+        if (L.packed16) {   // the payload of a rank is one 16-byte record already: one L2 access per row beside the table's
+#pragma unroll
+          for (int u = 0; u < GP_U; u++) rv[u] = L.packed16[m[u] ? m[u] - 1u : 0u];
+#pragma unroll
+          for (int u = 0; u < GP_U; u++) rv[u].x = m[u];
+        } else {
 #pragma unroll
         for (int u = 0; u < GP_U; u++) rv[u] = make_uint4(m[u], 0u, 0u, 0u);
         for (int c = 0; c < L.n; c++) {
@@ -1398,6 +1406,7 @@ __global__ __launch_bounds__(BLOCK) void k_gp_lookup(const ulonglong2* __restric
               rv[u].w |= (bo >> 2) == 3 ? v : 0u;
             }
           }
+        }
         }
 #pragma unroll
         for (int u = 0; u < GP_U; u++) {
@@ -1439,8 +1448,15 @@ __global__ __launch_bounds__(BLOCK) void k_gp_lookup(const ulonglong2* __restric
   }
 }
 // build rows in group order (every key is in the table): their columns to the RANK position of their key
+// `out16` (optional): the columns of a row as ONE 16-byte record at its rank — field c at byte rec_off[c], word 0 left free — instead
+// of one store per column (a store of a few bytes leaves the L2 as a whole fabric write: 4-byte stores made this kernel write
+// 13 GB for 1.2 GB of payload, profiles/r4_join_grouped_pmc.md)
+struct PlaceRec {
+  uint4* out16;
+  int off[GP_MAX_COLS];
+};
 __global__ __launch_bounds__(BLOCK) void k_gp_place(const ulonglong2* __restrict__ rank_tab, uint64_t am_offset, const uint64_t* __restrict__ gkeys,
-                                                    const uint64_t* __restrict__ bounds, int P, GroupCols cols, unsigned* __restrict__ tickets) {
+                                                    const uint64_t* __restrict__ bounds, int P, GroupCols cols, unsigned* __restrict__ tickets, PlaceRec pr) {
   __shared__ GpWalk walk;
   gp_walk_init(walk, bounds, P);
   for (int64_t lo, hi; gp_walk_next(walk, bounds, tickets, lo, hi);) {
@@ -1456,6 +1472,35 @@ __global__ __launch_bounds__(BLOCK) void k_gp_place(const ulonglong2* __restrict
       ulonglong2 e[GP_U];
 #pragma unroll
       for (int u = 0; u < GP_U; u++) e[u] = rank_tab[idx[u] >> 6];
+      if (pr.out16) {
+        uint4 rv[GP_U];
+#pragma unroll
+        for (int u = 0; u < GP_U; u++) rv[u] = make_uint4(0u, 0u, 0u, 0u);
+        for (int c = 0; c < cols.n; c++) {
+          const int w = cols.width[c], bo = pr.off[c];
+#pragma unroll
+          for (int u = 0; u < GP_U; u++) {
+            const int64_t i = in[u] ? base + u * BLOCK + threadIdx.x : lo;
+            if (w == 8) {
+              const uint64_t v = reinterpret_cast<const uint64_t*>(cols.src[c])[i];
+              rv[u].z = (uint32_t)v;
+              rv[u].w = (uint32_t)(v >> 32);
+            } else {
+              const uint32_t v = w == 4 ? reinterpret_cast<const uint32_t*>(cols.src[c])[i] : (uint32_t)reinterpret_cast<const uint8_t*>(cols.src[c])[i] << ((bo & 3) * 8);
+              rv[u].y |= (bo >> 2) == 1 ? v : 0u;
+              rv[u].z |= (bo >> 2) == 2 ? v : 0u;
+              rv[u].w |= (bo >> 2) == 3 ? v : 0u;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GP_U; u++) {
+          if (!in[u]) continue;
+          const int64_t r = (int64_t)((uint32_t)e[u].y + (uint32_t)__popcll(e[u].x & ((1ull << (idx[u] & 63)) - 1ull)));
+          pr.out16[r] = rv[u];
+        }
+        continue;
+      }
       for (int c = 0; c < cols.n; c++) {
 #pragma unroll
         for (int u = 0; u < GP_U; u++) {
@@ -2180,6 +2225,48 @@ static int gp_bits_for(const JoinTable& jt, int64_t payload_bytes_per_row) {
 static GroupSpec gp_spec_for(const JoinTable& jt, int nbits) { return group_spec(jt.am_offset, jt.am_size, 1 << nbits); }
 // rank map over build keys in no order: the build columns `cols` copied into RANK order, once per join table and column (a probe
 // in group order reads build payload at rank positions; through rank -> row -> column it would be a random line per row)
+// the packed form: `cols` (<= 12 bytes together) as one 16-byte record per rank, field i at byte rec_off[i] (word 0 free)
+static BufPtr ensure_rank_records(JoinTable& jt, const std::vector<int>& cols, const std::vector<int>& rec_off) {
+  std::lock_guard<std::mutex> lk(jt.mu);
+  auto it = jt.rank_records.find(cols);
+  if (it != jt.rank_records.end()) return it->second;
+  Runtime& r = rt();
+  const int64_t nb = jt.build.nrows;
+  const KeySet ks = make_keyset(jt.build, jt.key_cols);
+  std::vector<const void*> src;
+  std::vector<int> width;
+  int64_t bytes = 0;
+  for (int c : cols) {
+    const Column& col = jt.build.cols[(size_t)c];
+    src.push_back(col.ptr());
+    width.push_back(type_width(col.field.type));
+    bytes += width.back();
+  }
+  const int nbits = gp_bits_for(jt, 16);
+  GroupedRows gr = group_rows_by_key(ks.c[0], nb, gp_spec_for(jt, nbits), nbits, nullptr, true, false, src, width, "join_build_group_payload");
+  BufPtr recs = make_buf((size_t)std::max<int64_t>(nb, 1) * 16);
+  GroupCols gc{};
+  PlaceRec pr{};
+  gc.n = (int)src.size();
+  for (int q = 0; q < gc.n; q++) {
+    gc.src[q] = gr.cols[(size_t)q]->ptr;
+    gc.dst[q] = nullptr;
+    gc.width[q] = width[(size_t)q];
+    pr.off[q] = rec_off[(size_t)q];
+  }
+  pr.out16 = recs->as<uint4>();
+  {
+    ProfileScope ps("join_build_rank_payload", gr.rows * (8 + bytes + 16));
+    BufPtr tickets = make_zero_buf(8 * 32 * 4);
+    k_gp_place<<<r.num_cus * 8, BLOCK, 0, r.stream>>>(jt.rank_tab->as<ulonglong2>(), jt.am_offset, gr.keys->as<uint64_t>(), gr.bounds->as<uint64_t>(), gr.P, gc,
+                                                      tickets->as<unsigned>(), pr);
+    DFGPU_HIP(hipGetLastError());
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // complete before another thread's stream reads the records
+  jt.rank_records[cols] = recs;
+  jt.info.table_bytes += nb * 16;
+  return recs;
+}
 static void ensure_rank_payload(JoinTable& jt, const std::vector<int>& cols) {
   std::lock_guard<std::mutex> lk(jt.mu);
   std::vector<int> missing;
@@ -2214,7 +2301,7 @@ static void ensure_rank_payload(JoinTable& jt, const std::vector<int>& cols) {
     ProfileScope ps("join_build_rank_payload", gr.rows * (8 + 2 * bytes));
     BufPtr tickets = make_zero_buf(8 * 32 * 4);
     k_gp_place<<<r.num_cus * 8, BLOCK, 0, r.stream>>>(jt.rank_tab->as<ulonglong2>(), jt.am_offset, gr.keys->as<uint64_t>(), gr.bounds->as<uint64_t>(), gr.P, gc,
-                                                      tickets->as<unsigned>());
+                                                      tickets->as<unsigned>(), PlaceRec{});
     DFGPU_HIP(hipGetLastError());
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));  // complete before another thread's stream reads the copies
@@ -2248,12 +2335,18 @@ static bool grouped_probe_lookup(JoinTable& jt, const Table& probe, int pk0, con
   L.R = off <= 4 ? 4 : off <= 8 ? 8 : (off + 15) / 16 * 16;
   if (L.R > 64 || (int)bout.size() > MAX_JOIN_COLS) return false;
   L.n = (int)bout.size();
-  if (jt.rank_needs_perm && !bout.empty()) ensure_rank_payload(jt, bout);
+  // build keys in no order: the payload is read at rank positions from a rank-ordered copy — ONE 16-byte record per rank when the
+  // returned record is 16 bytes (the build columns then cost the lookup one L2 access, not one per column), else column by column
+  const bool packed = jt.rank_needs_perm && !bout.empty() && L.R == 16 && !(std::getenv("DFGPU_JOIN_RANK_RECORDS") && std::getenv("DFGPU_JOIN_RANK_RECORDS")[0] == '0');
+  BufPtr packed_recs;
+  if (packed) packed_recs = ensure_rank_records(jt, bout, field_off);
+  else if (jt.rank_needs_perm && !bout.empty()) ensure_rank_payload(jt, bout);
+  L.packed16 = packed ? packed_recs->as<uint4>() : nullptr;
   std::unique_lock<std::mutex> lk(jt.mu);
   for (size_t i = 0; i < bout.size(); i++) {
     const Column& c = jt.build.cols[(size_t)bout[i]];
     const int w = type_width(c.field.type);
-    L.src[i] = jt.rank_needs_perm ? jt.rank_payload.at(bout[i])->ptr : c.ptr();
+    L.src[i] = packed ? nullptr : jt.rank_needs_perm ? jt.rank_payload.at(bout[i])->ptr : c.ptr();
     L.width[i] = w;
     L.off[i] = field_off[i];
     rp.mul[i] = L.R / w;
