@@ -52,6 +52,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: measured float4 copy ceiling (79 % of spec)
+TABLE_KINDS = {0: "hash_map", 1: "array_map", 2: "rank_map", 3: "radix_lds", 4: "flat_hash_map", 5: "flat_hash_map_16"}
 
 BUILD_COLS = ["o_orderdate", "o_shippriority"]
 PROBE_COLS = ["l_orderkey", "l_extendedprice", "l_discount"]
@@ -367,9 +368,24 @@ def run_join(args, rank, world, dist):
         return {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in st.items()}
 
     def exchange_summary(mm):
+        """one exchange flavour: its step time, what crossed per step (rank 0's view), and — so that a first run on real multi-GPU
+        hardware diagnoses itself — what the transport reports and what the wires allow: xGMI is point-to-point, 7 links x ~153 GB/s
+        per GPU (MI355X_MICROARCH.md / SURVEY 8e), so an all-to-all(v) in which rank 0 sends B bytes to its N - 1 peers cannot
+        finish before max(bytes to one peer) / 153 GB/s; the same bound for what it receives"""
         per_step = {k: v // args.steps for k, v in mm["xstats"].items()} if mm["xstats"] else None
-        return {"ms_per_step": round(mm["dt"] / args.steps * 1e3, 3), "rows_per_s": (mm["nb"] + mm["np"]) / (mm["dt"] / args.steps),
-                "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map", 3: "radix_lds"}[mm["info"].table_kind], "crossed_per_step_rank0": per_step}
+        out = {"ms_per_step": round(mm["dt"] / args.steps * 1e3, 3), "rows_per_s": (mm["nb"] + mm["np"]) / (mm["dt"] / args.steps),
+               "join_table": TABLE_KINDS[mm["info"].table_kind], "crossed_per_step_rank0": per_step}
+        if comm is not None:
+            out.update(comm.transport_info())
+        if per_step and world > 1:
+            link_gbs = 153.0
+            sent, recv = per_step.get("bytes_sent_to_peers", 0), per_step.get("bytes_received_from_peers", 0)
+            per_link = max(sent, recv) / (world - 1)          # an even all-to-all spreads a rank's bytes over its N - 1 links
+            out["bytes_per_link_per_step_rank0"] = int(per_link)
+            out["predicted_exchange_ms_at_153_GBps_per_link"] = round(per_link / (link_gbs * 1e9) * 1e3, 3)
+            ex_ms = sum(v["total_ms"] for k, v in mm["stats"].items() if k.startswith("exchange")) / args.steps if mm["stats"] else None
+            out["measured_exchange_ms"] = round(ex_ms, 3) if ex_ms else None
+        return out
 
     parallelism = {"none": "single GPU",
                    "pruned": f"CollectLeft x{world}: build-side all-gather pruned by each rank's probe-key bounds (dfgpu_exchange_broadcast_pruned, RCCL send/recv), probe side stays in place",
@@ -382,7 +398,7 @@ def run_join(args, rank, world, dist):
         "config": {"workload": f"INNER hash-join orders⋈lineitem on o_orderkey, TPC-H SF{args.sf:g}, Q3 payload "
                                "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
                    "build_rows": nb, "probe_rows": np_, "output_rows": nout,
-                   "join_table": {0: "hash_map", 1: "array_map", 2: "rank_map", 3: "radix_lds"}[info.table_kind],
+                   "join_table": TABLE_KINDS[info.table_kind],
                    "probe": {0: "placed_ordered", 1: "placed_ordered", 2: "single_pass_ordered_lookback", 3: "single_pass_unordered"}[args.probe_mode],
                    "parallelism": parallelism, "exchange": primary, "planner_choice": planner_choice, "shard_skew": args.shard_skew if world > 1 else None},
         "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),

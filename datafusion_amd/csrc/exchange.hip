@@ -40,6 +40,8 @@ struct RcclApi {
   int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommCount)(const ncclComm_t, int*) = nullptr;
+  int (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -68,6 +70,8 @@ static RcclApi& rccl() {
   api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
   api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+  api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
   api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
   api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
   api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
@@ -120,6 +124,11 @@ static void alltoallv_one(Comm& c, std::vector<Xfer>& x, bool own_group);
 static void alltoallv(Comm& c, std::vector<std::vector<Xfer>>& xs) {
   if (xs.empty()) return;
   const bool grouped = c.world > 1 && !c.host;
+  int64_t moved = 0;   // bytes this process sends (the profile's "exchange_alltoall" row: HIP events on the library stream around the sends / receives)
+  for (auto& x : xs)
+    for (auto& xf : x)
+      for (int64_t b : xf.send_bytes) moved += b;
+  ProfileScope ps("exchange_alltoall", moved);
   if (grouped) DFGPU_NCCL(rccl().GroupStart());
   for (auto& x : xs) alltoallv_one(c, x, !grouped);
   if (grouped) DFGPU_NCCL(rccl().GroupEnd());
@@ -755,6 +764,25 @@ int dfgpu_comm_info(dfgpu_comm_t h, int* world, int* first_rank, int* n_local) {
     if (world) *world = c->world;
     if (first_rank) *first_rank = c->first_rank;
     if (n_local) *n_local = c->n_local();
+  });
+}
+
+// what the TRANSPORT itself says about the communicator (a first run on real multi-GPU hardware diagnoses itself with it):
+// is_rccl = 1 RCCL / 0 host transport; rccl_ranks = ncclCommCount of local rank 0's communicator (= world when every rank joined
+// the same communicator), rccl_rank = its ncclCommUserRank; -1 where the transport is not RCCL
+int dfgpu_comm_transport_info(dfgpu_comm_t h, int* is_rccl, int* rccl_ranks, int* rccl_rank) {
+  return guarded([&] {
+    DFGPU_CHECK(h != nullptr, "null communicator");
+    Comm* c = reinterpret_cast<Comm*>(h);
+    const bool r = !c->host && !c->nccl.empty();
+    if (is_rccl) *is_rccl = r ? 1 : 0;
+    int n = -1, me = -1;
+    if (r) {
+      DFGPU_NCCL(rccl().CommCount(c->nccl[0], &n));
+      DFGPU_NCCL(rccl().CommUserRank(c->nccl[0], &me));
+    }
+    if (rccl_ranks) *rccl_ranks = n;
+    if (rccl_rank) *rccl_rank = me;
   });
 }
 

@@ -464,24 +464,30 @@ __device__ __forceinline__ uint64_t flat_hash(uint64_t k0, uint64_t k1, bool for
   return h;
 }
 template <bool WIDE>
-__device__ __forceinline__ bool flat_slot_is(const uint4* __restrict__ tab, uint64_t s, uint64_t k0, uint64_t k1, uint32_t& head) {
+__device__ __forceinline__ bool flat_slot_is(const uint4* __restrict__ tab, uint64_t s, uint64_t k0, uint64_t k1, uint32_t& head, uint32_t* rows = nullptr) {
   if (!WIDE) {
     const uint4 e = tab[s];
     head = e.z;
+    if (rows) *rows = e.w;
     return e.x == (uint32_t)k0 && e.y == (uint32_t)(k0 >> 32);
   }
   const uint4 a = tab[2 * s], b = tab[2 * s + 1];
   head = b.x;
+  if (rows) *rows = b.y;
   return a.x == (uint32_t)k0 && a.y == (uint32_t)(k0 >> 32) && a.z == (uint32_t)k1 && a.w == (uint32_t)(k1 >> 32);
 }
-// first build row + 1 with this key, 0 = none
+// first build row + 1 with this key, 0 = none; `rows` (optional) = how many build rows carry the key (the slot keeps the count,
+// so a pass that only COUNTS matches never walks next[])
 template <bool WIDE>
-__device__ __forceinline__ uint32_t flat_find(const uint4* __restrict__ tab, int shift, uint64_t mask, uint64_t k0, uint64_t k1, bool force_collisions) {
+__device__ __forceinline__ uint32_t flat_find(const uint4* __restrict__ tab, int shift, uint64_t mask, uint64_t k0, uint64_t k1, bool force_collisions, uint32_t* rows = nullptr) {
   uint64_t s = flat_hash<WIDE>(k0, k1, force_collisions) >> shift;
   for (;;) {
     uint32_t head;
-    const bool same = flat_slot_is<WIDE>(tab, s, k0, k1, head);
-    if (head == 0) return 0u;  // an empty slot ends the run of its hash neighbourhood
+    const bool same = flat_slot_is<WIDE>(tab, s, k0, k1, head, rows);
+    if (head == 0) {   // an empty slot ends the run of its hash neighbourhood
+      if (rows) *rows = 0;
+      return 0u;
+    }
     if (same) return head;
     s = (s + 1) & mask;
   }
@@ -492,7 +498,7 @@ __device__ __forceinline__ uint32_t flat_find(const uint4* __restrict__ tab, int
 // unobserved by contract)
 template <bool WIDE>
 __global__ __launch_bounds__(BLOCK) void k_flat_claim(KeySet ks, FlatLayout L, int64_t n, int null_equals_null, int force_collisions, int shift, uint64_t mask,
-                                                      uint32_t* __restrict__ owner, uint32_t* __restrict__ next, int* __restrict__ dup_flag) {
+                                                      uint32_t* __restrict__ owner, uint32_t* __restrict__ next, int* __restrict__ dup_flag, uint32_t* __restrict__ more) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     uint64_t k0, k1;
     if (!flat_pack(ks, L, i, null_equals_null != 0, k0, k1)) continue;
@@ -507,6 +513,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat_claim(KeySet ks, FlatLayout L, i
       flat_pack(ks, L, (int64_t)o - 1, null_equals_null != 0, q0, q1);
       if (q0 == k0 && (!WIDE || q1 == k1)) {
         next[i] = atomicExch(&next[o - 1], (uint32_t)i + 1u);
+        atomicAdd(&more[o - 1], 1u);   // rows behind the owner
         *dup_flag = 1;
         break;
       }
@@ -516,16 +523,18 @@ __global__ __launch_bounds__(BLOCK) void k_flat_claim(KeySet ks, FlatLayout L, i
 }
 // build, pass 2: the owners' keys move into the slots
 template <bool WIDE>
-__global__ __launch_bounds__(BLOCK) void k_flat_fill(KeySet ks, FlatLayout L, int64_t cap, int null_equals_null, const uint32_t* __restrict__ owner, uint4* __restrict__ tab) {
+__global__ __launch_bounds__(BLOCK) void k_flat_fill(KeySet ks, FlatLayout L, int64_t cap, int null_equals_null, const uint32_t* __restrict__ owner,
+                                                     const uint32_t* __restrict__ more, uint4* __restrict__ tab) {
   for (int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x; s < cap; s += (int64_t)gridDim.x * BLOCK) {
     const uint32_t o = owner[s];
     uint64_t k0 = 0, k1 = 0;
     if (o) flat_pack(ks, L, (int64_t)o - 1, null_equals_null != 0, k0, k1);
+    const uint32_t rows = o ? more[o - 1] + 1u : 0u;   // build rows with this key
     if (!WIDE) {
-      tab[s] = make_uint4((uint32_t)k0, (uint32_t)(k0 >> 32), o, 0u);
+      tab[s] = make_uint4((uint32_t)k0, (uint32_t)(k0 >> 32), o, rows);
     } else {
       tab[2 * s] = make_uint4((uint32_t)k0, (uint32_t)(k0 >> 32), (uint32_t)k1, (uint32_t)(k1 >> 32));
-      tab[2 * s + 1] = make_uint4(o, 0u, 0u, 0u);
+      tab[2 * s + 1] = make_uint4(o, rows, 0u, 0u);
     }
   }
 }
@@ -799,6 +808,12 @@ __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, i
     uint32_t cnt = 0;
     if (p < np) {
       uint32_t nmatch = 0, first = 0;
+      if (kind_is_flat<KIND>() && !visited) {
+        // the slot holds how many build rows carry the key: counting needs no walk (next[] is read by the pass that emits pairs)
+        uint64_t k0, k1;
+        if (flat_pack(c.pkeys, c.flat_layout, p, c.null_equals_null != 0, k0, k1))
+          first = flat_find<KIND == KIND_FLAT16>(c.flat, c.flat_shift, c.flat_mask, k0, k1, c.force_collisions != 0, &nmatch);
+      } else {
       uint32_t cur = chain_head<KIND>(c, p);
       while (cur) {
         int64_t b = (int64_t)cur - 1;
@@ -808,6 +823,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, i
           if (visited) visited[b] = 1;
         }
         cur = c.next ? c.next[b] : 0u;
+      }
       }
       cnt = out_count(join_type, nmatch);
       row_counts[p] = cnt;
@@ -2032,6 +2048,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
     jt->next = make_zero_buf((size_t)(nb ? nb : 1) * 4);
     jt->flat = make_buf((size_t)cap * (flat_wide ? 32 : 16));
     BufPtr owner = make_zero_buf((size_t)cap * 4);
+    BufPtr more = make_zero_buf((size_t)(nb ? nb : 1) * 4);   // per owner row: rows with the same key behind it
     int64_t kb = 0;
     for (int i = 0; i < ks.n; i++) kb += nb * ks.c[i].width;
     const int nen = null_equality == DFGPU_NULL_EQUALS_NULL;
@@ -2039,12 +2056,12 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       ProfileScope ps("join_build_flat_table", kb + nb * 4 + (int64_t)cap * (flat_wide ? 32 : 16));
       if (nb) {
         const int g = grid_for(nb, BLOCK);
-        if (flat_wide) k_flat_claim<true><<<g, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, nb, nen, jt->force_collisions, jt->flat_shift, jt->flat_mask, owner->as<uint32_t>(), jt->next->as<uint32_t>(), flag->as<int>());
-        else k_flat_claim<false><<<g, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, nb, nen, jt->force_collisions, jt->flat_shift, jt->flat_mask, owner->as<uint32_t>(), jt->next->as<uint32_t>(), flag->as<int>());
+        if (flat_wide) k_flat_claim<true><<<g, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, nb, nen, jt->force_collisions, jt->flat_shift, jt->flat_mask, owner->as<uint32_t>(), jt->next->as<uint32_t>(), flag->as<int>(), more->as<uint32_t>());
+        else k_flat_claim<false><<<g, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, nb, nen, jt->force_collisions, jt->flat_shift, jt->flat_mask, owner->as<uint32_t>(), jt->next->as<uint32_t>(), flag->as<int>(), more->as<uint32_t>());
       }
       const int gf = grid_for((int64_t)cap, BLOCK);
-      if (flat_wide) k_flat_fill<true><<<gf, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, (int64_t)cap, nen, owner->as<uint32_t>(), jt->flat->as<uint4>());
-      else k_flat_fill<false><<<gf, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, (int64_t)cap, nen, owner->as<uint32_t>(), jt->flat->as<uint4>());
+      if (flat_wide) k_flat_fill<true><<<gf, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, (int64_t)cap, nen, owner->as<uint32_t>(), more->as<uint32_t>(), jt->flat->as<uint4>());
+      else k_flat_fill<false><<<gf, BLOCK, 0, r.stream>>>(ks, jt->flat_layout, (int64_t)cap, nen, owner->as<uint32_t>(), more->as<uint32_t>(), jt->flat->as<uint4>());
       DFGPU_HIP(hipGetLastError());
     }
     d2h(&dup, flag->ptr, 4);

@@ -114,6 +114,14 @@ class Comm:
         from . import _lib
         _lib.check(_lib.load().dfgpu_exchange_join_visited(self._h, (C.c_void_p * 1)(ht._h)))
 
+    def transport_info(self) -> dict:
+        """what the transport itself reports (dfgpu_comm_transport_info): RCCL or the host transport, and — under RCCL — how many
+        ranks ncclCommCount sees and which one this is"""
+        from . import _lib
+        a, n, r = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(_lib.load().dfgpu_comm_transport_info(self._h, C.byref(a), C.byref(n), C.byref(r)))
+        return {"transport": "rccl" if a.value else "host", "n_ranks_seen_by_rccl": n.value if a.value else None, "rccl_rank": r.value if a.value else None}
+
     def stats(self, reset=False) -> dict:
         from . import _lib
         st = _lib.ExchangeStats()

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 10
+#define DFGPU_ABI_VERSION 11
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -649,6 +649,10 @@ typedef struct dfgpu_host_transport {
 int dfgpu_comm_init_host(const dfgpu_host_transport* transport, int world, int rank, dfgpu_comm_t* out);
 int dfgpu_comm_free(dfgpu_comm_t comm);
 int dfgpu_comm_info(dfgpu_comm_t comm, int* world, int* first_rank, int* n_local);
+/* What the transport itself reports: is_rccl = 1 (RCCL) / 0 (host transport); rccl_ranks = ncclCommCount and rccl_rank =
+ * ncclCommUserRank of the first local rank's communicator, -1 under the host transport.  A first run on a multi-GPU node checks
+ * rccl_ranks == world before it trusts a scaling number (bench.py prints it as n_ranks_seen_by_rccl). */
+int dfgpu_comm_transport_info(dfgpu_comm_t comm, int* is_rccl, int* rccl_ranks, int* rccl_rank);
 /* RepartitionExec(Hash): outs[l] = every row (of all ranks) with hash(keys; seed 0) % world == rank of local l —
  * routing is dfgpu_partition's, so co-partitioned inputs meet on one GPU (hash_join/exec.rs:1312-1324) */
 int dfgpu_exchange_hash(dfgpu_comm_t comm, const dfgpu_table_t* inputs, const int* key_cols, int nkeys, dfgpu_table_t* outs);
