@@ -18,6 +18,15 @@
  *       dfgpu_table_import_device; dfgpu_metrics must report zero PCIe bytes for the whole chain.  A foreign producer is played
  *       too: a hand-made ArrowDeviceArray (release callback of this program) over device pointers, wrapped zero-copy.
  *
+ *   plan_driver partial_final <scale factor> <partitions>
+ *       the two-phase aggregate as shim/src/operators.rs runs it (aggregates/mod.rs:28-47): per input partition AggregateExec(Partial)
+ *       [dfgpu_agg_create PARTIAL, one dfgpu_agg_update per batch, dfgpu_agg_emit = the state schema: keys, SUM -> sum, AVG -> count + sum,
+ *       COUNT -> count, MIN -> value], RepartitionExec(Hash(keys, P)) of every partial output [dfgpu_partition], and per output
+ *       partition AggregateExec(FinalPartitioned) fed partition p of every input [dfgpu_agg_create FINAL_PARTITIONED with the declared
+ *       AVG type, one dfgpu_agg_update per input, dfgpu_agg_emit].  Then the same with GROUPING SETS ((flag), (status), (flag, status)):
+ *       dfgpu_agg_create_grouping_sets PARTIAL -> dfgpu_partition on (keys, __grouping_id) -> a plain FINAL_PARTITIONED over them.
+ *       Prints both results; the Python side compares them with the oracle's Single aggregates.
+ *
  * Case file (text, whitespace separated):
  *   join_type N   null_equality N   null_aware N   table_mode N   build_batches K   probe_partitions P   batch_size B
  *   on NKEYS  l0 r0  l1 r1 ...
@@ -530,8 +539,100 @@ static void run_chain(double sf) {
   CHECK(dfgpu_table_free(sorted));
   CHECK(dfgpu_table_free(lineitem));
 }
+/* ------------------------------------------------------------------ mode: partial_final */
+static dfgpu_expr expr_of(dfgpu_expr_node* n) {
+  dfgpu_expr e;
+  e.nodes = n; e.n_nodes = 1; e.root = 0; e.string_pool = NULL;
+  return e;
+}
+/* Partial aggregates of `n_in` input partitions -> hash repartition on the first n_key output columns -> FinalPartitioned per output
+ * partition; prints the rows of all output partitions under `title` */
+static void two_phase(const char* title, dfgpu_agg_t* partials, int n_in, int n_key, int nparts, const dfgpu_expr* group_by, const char* const* key_names,
+                      const dfgpu_agg_spec* final_aggs, int n_aggs) {
+  dfgpu_table_t* parts = (dfgpu_table_t*)calloc((size_t)n_in * nparts, sizeof(dfgpu_table_t));
+  int key_cols[8];
+  for (int k = 0; k < n_key; k++) key_cols[k] = k;
+  for (int i = 0; i < n_in; i++) {
+    dfgpu_table_t state = NULL;
+    CHECK(dfgpu_agg_emit(partials[i], &state));          /* AggregateExec(Partial)'s output: keys + state columns */
+    CHECK(dfgpu_agg_free(partials[i]));
+    CHECK(dfgpu_partition(state, key_cols, n_key, nparts, parts + (size_t)i * nparts));   /* RepartitionExec(Hash(keys, nparts)) */
+    CHECK(dfgpu_table_free(state));
+  }
+  printf("%s\n", title);
+  int64_t printed = 0;
+  for (int p = 0; p < nparts; p++) {
+    dfgpu_agg_t fin = NULL;
+    CHECK(dfgpu_agg_create(DFGPU_AGG_FINAL_PARTITIONED, group_by, key_names, n_key, final_aggs, n_aggs, &fin));
+    for (int i = 0; i < n_in; i++) {                      /* partition p of every input partition arrives at output partition p */
+      CHECK(dfgpu_agg_update(fin, parts[(size_t)i * nparts + p]));
+      CHECK(dfgpu_table_free(parts[(size_t)i * nparts + p]));
+    }
+    dfgpu_table_t out = NULL;
+    CHECK(dfgpu_agg_emit(fin, &out));
+    CHECK(dfgpu_agg_free(fin));
+    printed += export_and_print(out, 8192, p == 0);
+    CHECK(dfgpu_table_free(out));
+  }
+  printf("rows %" PRId64 "\n", printed);
+  free(parts);
+}
+static void run_partial_final(double sf, int nparts) {
+  REQUIRE(nparts >= 1 && nparts <= 8, "1..8 partitions");
+  dfgpu_table_t lineitem = NULL;
+  CHECK(dfgpu_tpch_lineitem(sf, 0, -1, 0, &lineitem));
+  int64_t n = 0;
+  CHECK(dfgpu_table_num_rows(lineitem, &n));
+  const int n_in = 3;                                     /* three input partitions, each fed in two batches */
+  dfgpu_expr_node gn[2], an[2], nulls[2];
+  gn[0] = col_node(find_column(lineitem, "l_returnflag"));
+  gn[1] = col_node(find_column(lineitem, "l_linestatus"));
+  an[0] = col_node(find_column(lineitem, "l_quantity"));
+  an[1] = col_node(find_column(lineitem, "l_extendedprice"));
+  dfgpu_expr group_by[2] = {expr_of(&gn[0]), expr_of(&gn[1])};
+  const char* key_names[3] = {"l_returnflag", "l_linestatus", "__grouping_id"};
+  dfgpu_agg_spec aggs[4];
+  memset(aggs, 0, sizeof aggs);
+  aggs[0].func = DFGPU_AGG_SUM; aggs[0].has_arg = 1; aggs[0].arg = expr_of(&an[0]); aggs[0].name = "sum_qty";
+  aggs[1].func = DFGPU_AGG_AVG; aggs[1].has_arg = 1; aggs[1].arg = expr_of(&an[1]); aggs[1].name = "avg_price";
+  aggs[2].func = DFGPU_AGG_COUNT; aggs[2].has_arg = 0; aggs[2].name = "count_order";
+  aggs[3].func = DFGPU_AGG_MIN; aggs[3].has_arg = 1; aggs[3].arg = expr_of(&an[0]); aggs[3].name = "min_qty";
+  /* what AggregateFunctionExpr::return_field carries to the Final node: AVG(Decimal128(15,2)) -> Decimal128(19,6) (average.rs:219-252) */
+  dfgpu_agg_spec final_aggs[4];
+  memcpy(final_aggs, aggs, sizeof aggs);
+  final_aggs[1].return_field.type = DFGPU_DECIMAL128; final_aggs[1].return_field.precision = 19; final_aggs[1].return_field.scale = 6; final_aggs[1].return_field.nullable = 1;
+
+  dfgpu_agg_t partials[3];
+  for (int pass = 0; pass < 2; pass++) {
+    for (int i = 0; i < n_in; i++) {
+      if (pass == 0) {
+        CHECK(dfgpu_agg_create(DFGPU_AGG_PARTIAL, group_by, key_names, 2, aggs, 4, &partials[i]));
+      } else {
+        memset(nulls, 0, sizeof nulls);
+        for (int g = 0; g < 2; g++) {                      /* the typed NULL literal of each key (PhysicalGroupBy::null_expr) */
+          nulls[g].op = DFGPU_EXPR_LITERAL; nulls[g].column = -1; nulls[g].left = nulls[g].right = -1;
+          nulls[g].field.type = DFGPU_UINT8; nulls[g].field.nullable = 1; nulls[g].is_null = 1;
+        }
+        dfgpu_expr null_by[2] = {expr_of(&nulls[0]), expr_of(&nulls[1])};
+        const uint8_t sets[3 * 2] = {0, 1, /* (flag) */ 1, 0, /* (status) */ 0, 0 /* (flag, status) */};
+        CHECK(dfgpu_agg_create_grouping_sets(DFGPU_AGG_PARTIAL, group_by, null_by, key_names, 2, sets, 3, aggs, 4, &partials[i]));
+      }
+      const int64_t lo = n * i / n_in, hi = n * (i + 1) / n_in, mid = lo + (hi - lo) / 2;
+      const int64_t cut[3] = {lo, mid, hi};
+      for (int b = 0; b < 2; b++) {                        /* the partition's input stream: two batches */
+        dfgpu_table_t batch = NULL;
+        CHECK(dfgpu_table_slice(lineitem, cut[b], cut[b + 1] - cut[b], &batch));
+        CHECK(dfgpu_agg_update(partials[i], batch));
+        CHECK(dfgpu_table_free(batch));
+      }
+    }
+    if (pass == 0) two_phase("two_phase", partials, n_in, 2, nparts, group_by, key_names, final_aggs, 4);
+    else two_phase("grouping_sets", partials, n_in, 3, nparts, group_by, key_names, final_aggs, 4);   /* the Final groups by keys + __grouping_id */
+  }
+  CHECK(dfgpu_table_free(lineitem));
+}
 int main(int argc, char** argv) {
-  REQUIRE(argc >= 3, "usage: plan_driver join <case>... | plan_driver chain <sf>");
+  REQUIRE(argc >= 3, "usage: plan_driver join <case>... | plan_driver chain <sf> | plan_driver partial_final <sf> <partitions>");
   REQUIRE(dfgpu_abi_version() == DFGPU_ABI_VERSION, "libdfgpu.so was built from another header");
   const int device = 0;
   CHECK(dfgpu_init(&device, 1));
@@ -543,6 +644,9 @@ int main(int argc, char** argv) {
     }
   } else if (strcmp(argv[1], "chain") == 0) {
     run_chain(strtod(argv[2], NULL));
+  } else if (strcmp(argv[1], "partial_final") == 0) {
+    REQUIRE(argc >= 4, "usage: plan_driver partial_final <sf> <partitions>");
+    run_partial_final(strtod(argv[2], NULL), atoi(argv[3]));
   } else {
     REQUIRE(0, "unknown mode");
   }

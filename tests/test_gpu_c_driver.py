@@ -153,3 +153,49 @@ def test_three_node_chain_from_plain_c_moves_no_table_bytes_over_pcie(tmp_path):
     unscaled = lambda d: int(d.scaleb(2))
     want = [(r["l_returnflag"], r["l_linestatus"], unscaled(r["sum_qty"]), unscaled(r["sum_base_price"]), r["count_order"]) for r in exp.to_pylist()]
     assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nparts", [1, 4])
+def test_partial_repartition_final_and_grouping_sets_from_plain_c(tmp_path, nparts):
+    """the two-phase aggregate's call sequence (shim/src/operators.rs; aggregates/mod.rs:28-47) from plain C: three input partitions of two
+    batches each -> AggregateExec(Partial) -> RepartitionExec(Hash(keys, P)) -> AggregateExec(FinalPartitioned) per output partition,
+    with SUM / AVG(Decimal128) / COUNT(*) / MIN — and the same under GROUPING SETS ((flag), (status), (flag, status)), whose Final node
+    groups by (keys, __grouping_id).  The printed rows equal the oracle's Single aggregates over the same generated lineitem."""
+    from datafusion_amd import tpch
+    from oracle import oracle
+    exe = build_driver(tmp_path)
+    sf = 0.03
+    run = subprocess.run([exe, "partial_final", str(sf), str(nparts)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    sections, cur = {}, None
+    for ln in run.stdout.splitlines():
+        w = ln.split()
+        if ln in ("two_phase", "grouping_sets"):
+            cur = sections.setdefault(ln, {"columns": None, "rows": []})
+        elif w and w[0] == "columns":
+            cur["columns"] = w[1:]
+        elif w and w[0] == "row":
+            cur["rows"].append(tuple(None if v == "NULL" else int(v) for v in w[1:]))
+        elif w and w[0] == "rows":
+            assert int(w[1]) == len(cur["rows"])
+    li = tpch.lineitem(sf)
+    gb = [(("col", "l_returnflag"), "l_returnflag"), (("col", "l_linestatus"), "l_linestatus")]
+    aggs = [("sum", ("col", "l_quantity"), "sum_qty"), ("avg", ("col", "l_extendedprice"), "avg_price"), ("count", None, "count_order"), ("min", ("col", "l_quantity"), "min_qty")]
+    exp = oracle.aggregate(li, gb, aggs, "Single")
+    unscaled = lambda d, s: int(d.scaleb(s))
+    want = sorted((r["l_returnflag"], r["l_linestatus"], unscaled(r["sum_qty"], 2), unscaled(r["avg_price"], 6), r["count_order"], unscaled(r["min_qty"], 2)) for r in exp.to_pylist())
+    two = sections["two_phase"]
+    assert two["columns"] == ["l_returnflag", "l_linestatus", "sum_qty", "avg_price", "count_order", "min_qty"]
+    assert sorted(two["rows"]) == want
+    # grouping sets: every set is the Single aggregate over its own keys, the other key NULL, __grouping_id = the NULLed columns' bits
+    gs = sections["grouping_sets"]
+    assert gs["columns"] == ["l_returnflag", "l_linestatus", "__grouping_id", "sum_qty", "avg_price", "count_order", "min_qty"]
+    want_gs = [(a, b, 0) + rest for (a, b, *rest) in [tuple(r) for r in want]]
+    for keep, gid in ((0, 1), (1, 2)):   # (flag): linestatus NULLed -> bit 0; (status): returnflag NULLed -> bit 1
+        e = oracle.aggregate(li, [gb[keep]], aggs, "Single")
+        for r in e.to_pylist():
+            key = (r["l_returnflag"], None) if keep == 0 else (None, r["l_linestatus"])
+            want_gs.append(key + (gid, unscaled(r["sum_qty"], 2), unscaled(r["avg_price"], 6), r["count_order"], unscaled(r["min_qty"], 2)))
+    norm = lambda rows: sorted(rows, key=lambda t: tuple((v is None, 0 if v is None else v) for v in t))
+    assert norm(gs["rows"]) == norm([tuple(x) for x in want_gs])
