@@ -2204,7 +2204,8 @@ __global__ void k_sample_near(KeyCol k, int64_t n, int64_t every, int samples, u
 static bool probe_keys_clustered(const Column& kc, int64_t n, uint64_t window) {
   if (auto cached = std::atomic_load(&kc.stats))
     if (cached->nondecreasing) return true;
-  if (n < (1 << 16) || kc.validity || !is_integer_like(kc.field.type) || kc.field.type == DFGPU_UINT64) return true;
+  // (a column with NULLs is sampled like any other: the values under its NULLs are few and say nothing either way)
+  if (n < (1 << 16) || !is_integer_like(kc.field.type) || kc.field.type == DFGPU_UINT64) return true;
   constexpr int S = 4096;
   BufPtr cnt = make_zero_buf(4);
   const KeyCol k{kc.ptr(), nullptr, kc.field.type, type_width(kc.field.type)};
