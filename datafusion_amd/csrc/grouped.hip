@@ -66,21 +66,26 @@ __global__ __launch_bounds__(THREADS) void k_gp_hist(KeyCol key, int64_t n, Grou
   }
 }
 
-// dynamic LDS: stage [TILE * stage_width] | group of every staged row u16 [TILE] | cnt, start, goff u32 [P each] | wave totals
-template <int KT, int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void k_gp_scatter(KeyCol key, int64_t n, GroupSpec gs, int P, const uint64_t* __restrict__ row_mask, int tiles_per_chunk,
-                                                        int64_t n_chunks, const uint64_t* __restrict__ offsets, uint64_t* __restrict__ out_keys,
-                                                        uint32_t* __restrict__ dest, GroupCols cols, int stage_width) {
+// dynamic LDS: stage [TILE * stage_width] | cnt, goff, delta u32 [P each] | wave totals | start u16 [P] | group of every staged row
+// u16 [TILE] (only when columns are carried: a key says its own group).  WPS = workgroups the launch bounds make room for per
+// CU-quarter (waves per SIMD); PREFETCH = the next tile's keys are loaded while this one is written out.
+template <int KT, int THREADS, int ITEMS, int WPS, bool PREFETCH>
+__global__ __launch_bounds__(THREADS, WPS) void k_gp_scatter(KeyCol key, int64_t n, GroupSpec gs, int P, const uint64_t* __restrict__ row_mask, int tiles_per_chunk,
+                                                             int64_t n_chunks, const uint64_t* __restrict__ offsets, uint64_t* __restrict__ out_keys,
+                                                             uint32_t* __restrict__ dest, GroupCols cols, int stage_width) {
   extern __shared__ __align__(16) unsigned char gp_smem[];
   constexpr int TILE = THREADS * ITEMS;
   constexpr int NWAVE = THREADS / WAVE;
+  constexpr int GPT = (GP_MAX_GROUPS + THREADS - 1) / THREADS;   // groups per thread in the tile's scan
   static_assert(TILE <= (1 << GP_RANK_BITS), "rank field too narrow");
+  const bool carry = cols.n > 0;
   unsigned char* s_stage = gp_smem;
-  uint16_t* s_g = reinterpret_cast<uint16_t*>(gp_smem + (size_t)TILE * stage_width);
-  unsigned* s_cnt = reinterpret_cast<unsigned*>(s_g + TILE);
-  unsigned* s_start = s_cnt + P;
-  unsigned* s_goff = s_start + P;
-  unsigned* s_wtot = s_goff + P;
+  unsigned* s_cnt = reinterpret_cast<unsigned*>(gp_smem + (size_t)TILE * stage_width);
+  unsigned* s_goff = s_cnt + P;
+  unsigned* s_delta = s_goff + P;     // goff - start of the current tile: where a staged position goes
+  unsigned* s_wtot = s_delta + P;
+  uint16_t* s_start = reinterpret_cast<uint16_t*>(s_wtot + NWAVE);
+  uint16_t* s_g = s_start + P;
   const unsigned lane = lane_id();
   const int wave = threadIdx.x >> 6;
   for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -91,16 +96,26 @@ __global__ __launch_bounds__(THREADS) void k_gp_scatter(KeyCol key, int64_t n, G
       s_cnt[i] = 0;
     }
     __syncthreads();
-    uint64_t k[ITEMS], knext[ITEMS];
+    uint64_t k[ITEMS], knext[PREFETCH ? ITEMS : 1];
+    if (PREFETCH) {
 #pragma unroll
-    for (int c = 0; c < ITEMS; c++) {
-      const int64_t i = lo + (int64_t)c * THREADS + threadIdx.x;
-      knext[c] = lo < hi ? load_key<KT>(key, i < hi ? i : hi - 1) : 0ull;
+      for (int c = 0; c < ITEMS; c++) {
+        const int64_t i = lo + (int64_t)c * THREADS + threadIdx.x;
+        knext[PREFETCH ? c : 0] = lo < hi ? load_key<KT>(key, i < hi ? i : hi - 1) : 0ull;
+      }
     }
     for (int64_t base = lo; base < hi; base += TILE) {
       unsigned gr[ITEMS];
+      if (PREFETCH) {
 #pragma unroll
-      for (int c = 0; c < ITEMS; c++) k[c] = knext[c];
+        for (int c = 0; c < ITEMS; c++) k[c] = knext[PREFETCH ? c : 0];
+      } else {
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) {
+          const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+          k[c] = load_key<KT>(key, i < hi ? i : hi - 1);
+        }
+      }
       // ---- group and rank of every row of the tile
 #pragma unroll
       for (int c = 0; c < ITEMS; c++) {
@@ -113,16 +128,30 @@ __global__ __launch_bounds__(THREADS) void k_gp_scatter(KeyCol key, int64_t n, G
         }
       }
       __syncthreads();
-      // ---- exclusive scan of the tile's group counts (P <= THREADS: one group per thread)
+      // ---- exclusive scan of the tile's group counts: thread t owns groups [t * GPT, (t + 1) * GPT)
       {
-        const unsigned v = (int)threadIdx.x < P ? s_cnt[threadIdx.x] : 0u;
+        unsigned c_[GPT], v = 0;
+#pragma unroll
+        for (int q = 0; q < GPT; q++) {
+          const int g = (int)threadIdx.x * GPT + q;
+          c_[q] = g < P ? s_cnt[g] : 0u;
+          v += c_[q];
+        }
         const unsigned inc = wave_inclusive_sum<unsigned>(v);
         if (lane == 63) s_wtot[wave] = inc;
         __syncthreads();
-        unsigned before = 0;
+        unsigned run = inc - v;
 #pragma unroll
-        for (int w = 0; w < NWAVE; w++) before += w < wave ? s_wtot[w] : 0u;
-        if ((int)threadIdx.x < P) s_start[threadIdx.x] = before + inc - v;
+        for (int w = 0; w < NWAVE; w++) run += w < wave ? s_wtot[w] : 0u;
+#pragma unroll
+        for (int q = 0; q < GPT; q++) {
+          const int g = (int)threadIdx.x * GPT + q;
+          if (g < P) {
+            s_start[g] = (uint16_t)run;
+            s_delta[g] = s_goff[g] - run;
+          }
+          run += c_[q];
+        }
       }
       __syncthreads();
       unsigned total = 0;
@@ -136,28 +165,29 @@ __global__ __launch_bounds__(THREADS) void k_gp_scatter(KeyCol key, int64_t n, G
         pos[c] = 0xFFFFFFFFu;
         if (gr[c] != 0xFFFFFFFFu) {
           const unsigned g = gr[c] >> GP_RANK_BITS, r = gr[c] & ((1u << GP_RANK_BITS) - 1u);
-          pos[c] = s_start[g] + r;
+          pos[c] = (unsigned)s_start[g] + r;
           reinterpret_cast<uint64_t*>(s_stage)[pos[c]] = k[c];
-          s_g[pos[c]] = (uint16_t)g;
-          if (dest) dest[i] = s_goff[g] + r;
+          if (carry) s_g[pos[c]] = (uint16_t)g;
+          if (dest) dest[i] = pos[c] + s_delta[g];
         } else if (dest && i < hi) {
           dest[i] = 0xFFFFFFFFu;
         }
       }
       // the next tile's keys are on their way while this one is written out
-      {
+      if (PREFETCH) {
         const int64_t nb = base + TILE;
 #pragma unroll
         for (int c = 0; c < ITEMS; c++) {
           const int64_t i = nb + (int64_t)c * THREADS + threadIdx.x;
-          knext[c] = nb < hi ? load_key<KT>(key, i < hi ? i : hi - 1) : 0ull;
+          knext[PREFETCH ? c : 0] = nb < hi ? load_key<KT>(key, i < hi ? i : hi - 1) : 0ull;
         }
       }
       __syncthreads();
       if (out_keys) {
         for (unsigned q = threadIdx.x; q < total; q += THREADS) {
-          const unsigned g = s_g[q];
-          out_keys[(uint64_t)s_goff[g] + (q - s_start[g])] = reinterpret_cast<const uint64_t*>(s_stage)[q];
+          const uint64_t kq = reinterpret_cast<const uint64_t*>(s_stage)[q];
+          const unsigned g = (unsigned)__umul64hi(kq - gs.offset, gs.mul);   // (a key says its own group: no table of groups per staged row)
+          out_keys[(uint64_t)(q + s_delta[g])] = kq;
         }
       }
       // ---- carried columns: the same route, one after the other through the same staging buffer
@@ -178,7 +208,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_scatter(KeyCol key, int64_t n, G
         __syncthreads();
         for (unsigned q = threadIdx.x; q < total; q += THREADS) {
           const unsigned g = s_g[q];
-          const uint64_t d = (uint64_t)s_goff[g] + (q - s_start[g]);
+          const uint64_t d = (uint64_t)(q + s_delta[g]);
           switch (w) {
             case 16: reinterpret_cast<uint4*>(cols.dst[cc])[d] = reinterpret_cast<const uint4*>(s_stage)[q]; break;
             case 8: reinterpret_cast<uint64_t*>(cols.dst[cc])[d] = reinterpret_cast<const uint64_t*>(s_stage)[q]; break;
@@ -228,21 +258,28 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
     DFGPU_CHECK(w == 1 || w == 4 || w == 8 || w == 16, "group_rows_by_key: carried columns are 1, 4, 8 or 16 bytes wide");
     stage_width = std::max(stage_width, w);
   }
-  // 1024 threads x 8 rows: 8192-row tiles (runs of 8192 / P rows).  A 16-byte carried column needs 128 KB of staging: still one
-  // workgroup per CU, like the 8-byte case (92 KB)
-  constexpr int THREADS = 1024, ITEMS = 8, TILE = THREADS * ITEMS;
+  // Tile shapes (DFGPU_GP_VARIANT, A/B knob; measured in profiles/r4_group_rows.md):
+  //   A  1024 threads x 8 rows = 8192-row tiles (runs of 8192 / P rows), the next tile's keys prefetched, one workgroup per CU
+  //   B  the same tile without the prefetch and registers capped for TWO workgroups per CU (key-only: 80 KB of LDS each)
+  //   C  512 threads x 8 rows = 4096-row tiles, three workgroups per CU, half the run length
+  const char* venv = std::getenv("DFGPU_GP_VARIANT");
+  const char variant = venv ? venv[0] : 'A';
+  const int THREADS = variant == 'C' ? 512 : 1024;
+  constexpr int ITEMS = 8;
+  const int TILE = THREADS * ITEMS;
   const int64_t n_tiles = (n + TILE - 1) / TILE;
   // chunks: enough of them to fill the chip a few times over, few enough to keep the count matrix small
   int tiles_per_chunk = (int)std::min<int64_t>(32, std::max<int64_t>(1, n_tiles / 2048));
   const int64_t n_chunks = (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
   BufPtr counts = make_buf((size_t)P * n_chunks * 4);
   BufPtr offsets = make_buf(((size_t)P * n_chunks + 1) * 8);
-  const int grid = (int)std::min<int64_t>(n_chunks, (int64_t)r.num_cus * 4);
+  const int grid = (int)std::min<int64_t>(n_chunks, (int64_t)r.num_cus * 6);
   const int64_t key_bytes = n * key.width;
   {
     ProfileScope ps("group_rows_count", key_bytes);
     gp_with_key_type(key.type, [&](auto kt) {
-      k_gp_hist<decltype(kt)::value, THREADS, ITEMS><<<grid, THREADS, 0, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, counts->as<uint32_t>());
+      if (THREADS == 512) k_gp_hist<decltype(kt)::value, 512, ITEMS><<<grid, 512, 0, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, counts->as<uint32_t>());
+      else k_gp_hist<decltype(kt)::value, 1024, ITEMS><<<grid, 1024, 0, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, counts->as<uint32_t>());
     });
     DFGPU_HIP(hipGetLastError());
   }
@@ -263,14 +300,19 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
     gc.width[c] = carry_width[c];
     moved += n * carry_width[c] + out.rows * carry_width[c];
   }
-  const size_t lds = (size_t)TILE * stage_width + (size_t)TILE * 2 + (size_t)P * 12 + (THREADS / WAVE) * 4;
+  const size_t lds = (size_t)TILE * stage_width + (size_t)P * 12 + (size_t)(THREADS / WAVE) * 4 + (size_t)P * 2 + (gc.n > 0 ? (size_t)TILE * 2 : 0);
   {
     ProfileScope ps(what ? what : "group_rows_scatter", key_bytes + moved);
     gp_with_key_type(key.type, [&](auto kt) {
-      auto kern = k_gp_scatter<decltype(kt)::value, THREADS, ITEMS>;
-      DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      kern<<<grid, THREADS, lds, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, offsets->as<uint64_t>(),
-                                             want_keys ? out.keys->as<uint64_t>() : nullptr, want_dest ? out.dest->as<uint32_t>() : nullptr, gc, stage_width);
+      constexpr int T = decltype(kt)::value;
+      auto launch = [&](auto kern, int threads) {
+        DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, threads, lds, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, offsets->as<uint64_t>(), want_keys ? out.keys->as<uint64_t>() : nullptr,
+                                               want_dest ? out.dest->as<uint32_t>() : nullptr, gc, stage_width);
+      };
+      if (variant == 'C') launch(k_gp_scatter<T, 512, ITEMS, 6, true>, 512);
+      else if (variant == 'B') launch(k_gp_scatter<T, 1024, ITEMS, 8, false>, 1024);
+      else launch(k_gp_scatter<T, 1024, ITEMS, 4, true>, 1024);
     });
     DFGPU_HIP(hipGetLastError());
   }
