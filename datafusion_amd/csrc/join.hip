@@ -577,7 +577,8 @@ __device__ __forceinline__ bool chain_match(const ProbeCtx& c, int64_t b, int64_
 // stage (keys -> validity -> table words -> perm) issues its N loads together; out-of-range lanes
 // load a clamped address and are masked afterwards, so there is no branch between the loads.
 template <int KIND, int KT, int N>
-__device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int64_t np, uint32_t (&m)[N], uint64_t* raw_keys = nullptr, uint4* rec16 = nullptr) {
+__device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int64_t np, uint32_t (&m)[N], uint64_t* raw_keys = nullptr, uint4* rec16 = nullptr,
+                                             uint32_t* key_rows = nullptr /* flat kinds: build rows per matched key */) {
   const unsigned lane = lane_id();
   if (KIND == KIND_RETURNED) {
     uint32_t d[N];
@@ -622,20 +623,21 @@ __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int6
       live[j] = live[j] && flat_pack(c.pkeys, c.flat_layout, p, c.null_equals_null != 0, k0[j], k1[j]);
       s[j] = flat_hash<WIDE>(k0[j], k1[j], c.force_collisions != 0) >> c.flat_shift;
     }
-    uint32_t head[N];
+    uint32_t head[N], rws[N];
     bool same[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) same[j] = flat_slot_is<WIDE>(c.flat, s[j], k0[j], k1[j], head[j]);
+    for (int j = 0; j < N; j++) same[j] = flat_slot_is<WIDE>(c.flat, s[j], k0[j], k1[j], head[j], &rws[j]);
 #pragma unroll
     for (int j = 0; j < N; j++) {
       uint64_t ss = s[j];
-      uint32_t hd = head[j];
+      uint32_t hd = head[j], rw = rws[j];
       bool sm = same[j];
       while (live[j] && hd != 0 && !sm) {
         ss = (ss + 1) & c.flat_mask;
-        sm = flat_slot_is<WIDE>(c.flat, ss, k0[j], k1[j], hd);
+        sm = flat_slot_is<WIDE>(c.flat, ss, k0[j], k1[j], hd, &rw);
       }
       m[j] = live[j] && sm ? hd : 0u;   // (hd == 0 with sm: an empty slot compared equal to an all-zero key)
+      if (key_rows) key_rows[j] = m[j] ? rw : 0u;
     }
     return;
   }
@@ -803,6 +805,28 @@ __global__ __launch_bounds__(BLOCK) void k_probe_count(ProbeCtx c, int64_t np, i
   const int64_t n_words = (np + 63) >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  if (kind_is_flat<KIND>() && !visited) {
+    // the flat table answers "which row first, and how many" from the slot: PROBE_UNROLL words per step, their slot loads in flight
+    // together (one word at a time this pass waited on every load: 1.8 ms for 60 M probe rows against a 64 MB table, now the
+    // table's random-access rate sets the pace)
+    for (int64_t w0 = wave * PROBE_UNROLL; w0 < n_words; w0 += n_waves * PROBE_UNROLL) {
+      uint32_t m[PROBE_UNROLL], rws[PROBE_UNROLL];
+      lookup_words<KIND, KT_ANY, PROBE_UNROLL>(c, w0, np, m, nullptr, nullptr, rws);
+#pragma unroll
+      for (int j = 0; j < PROBE_UNROLL; j++) {
+        const int64_t p = ((w0 + j) << 6) + lane_id();
+        uint32_t cnt = 0;
+        if (p < np) {
+          cnt = out_count(join_type, rws[j]);
+          row_counts[p] = cnt;
+          if (row_first) row_first[p] = m[j];
+        }
+        const uint32_t tot = wave_sum(cnt);
+        if (lane_id() == 0 && w0 + j < n_words) word_counts[w0 + j] = tot;
+      }
+    }
+    return;
+  }
   for (int64_t w = wave; w < n_words; w += n_waves) {
     int64_t p = (w << 6) + lane_id();
     uint32_t cnt = 0;

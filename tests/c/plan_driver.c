@@ -626,8 +626,11 @@ static void run_partial_final(double sf, int nparts) {
         CHECK(dfgpu_table_free(batch));
       }
     }
-    if (pass == 0) two_phase("two_phase", partials, n_in, 2, nparts, group_by, key_names, final_aggs, 4);
-    else two_phase("grouping_sets", partials, n_in, 3, nparts, group_by, key_names, final_aggs, 4);   /* the Final groups by keys + __grouping_id */
+    /* a Final node's group expressions are the leading columns of the partial state: Column(0), Column(1) [, Column(2) = __grouping_id] */
+    dfgpu_expr_node fk[3] = {col_node(0), col_node(1), col_node(2)};
+    dfgpu_expr final_keys[3] = {expr_of(&fk[0]), expr_of(&fk[1]), expr_of(&fk[2])};
+    if (pass == 0) two_phase("two_phase", partials, n_in, 2, nparts, final_keys, key_names, final_aggs, 4);
+    else two_phase("grouping_sets", partials, n_in, 3, nparts, final_keys, key_names, final_aggs, 4);   /* the Final groups by keys + __grouping_id */
   }
   CHECK(dfgpu_table_free(lineitem));
 }
