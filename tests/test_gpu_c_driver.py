@@ -191,7 +191,7 @@ def test_partial_repartition_final_and_grouping_sets_from_plain_c(tmp_path, npar
     # grouping sets: every set is the Single aggregate over its own keys, the other key NULL, __grouping_id = the NULLed columns' bits
     gs = sections["grouping_sets"]
     assert gs["columns"] == ["l_returnflag", "l_linestatus", "__grouping_id", "sum_qty", "avg_price", "count_order", "min_qty"]
-    want_gs = [(a, b, 0) + rest for (a, b, *rest) in [tuple(r) for r in want]]
+    want_gs = [(a, b, 0) + tuple(rest) for (a, b, *rest) in [tuple(r) for r in want]]
     for keep, gid in ((0, 1), (1, 2)):   # (flag): linestatus NULLed -> bit 0; (status): returnflag NULLed -> bit 1
         e = oracle.aggregate(li, [gb[keep]], aggs, "Single")
         for r in e.to_pylist():
