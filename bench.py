@@ -354,12 +354,20 @@ def run_join(args, rank, world, dist):
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_vs_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
                 "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
-        try:  # HBM bytes per launch from the committed PMC passes (scripts/profile.sh), when taken on this very workload and kernel
+        try:  # HBM bytes per launch from the committed PMC passes (scripts/profile.sh): this workload, this device kernel, and the
+            # kernel's SOURCE as it was when the passes were taken (a kernel edit without a fresh PMC pass reports no traffic)
+            import hashlib
             for tr in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]:
                 wl = tr["workload"]
-                if tr["kernel"] == name and (wl["build_rows"], wl["probe_rows"], wl["output_rows"]) == (nb, np_, nout) and world == 1:
-                    roof["traffic"] = tr["traffic_bytes_per_launch"]
-                    roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr["source"]
+                if tr["kernel"] != name or (wl["build_rows"], wl["probe_rows"], wl["output_rows"]) != (nb, np_, nout) or world != 1:
+                    continue
+                cur = hashlib.sha256(open(os.path.join(ROOT, tr.get("kernel_source", "datafusion_amd/csrc/join.hip")), "rb").read()).hexdigest()[:16]
+                if tr.get("kernel_source_sha16") != cur:
+                    roof["traffic_note"] = f"the PMC passes in profiles/{tr['source']} (commit {tr.get('commit')}) predate the kernel's source: not attached"
+                    continue
+                roof["traffic"] = tr["traffic_bytes_per_launch"]
+                roof["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {tr['device_kernel']} at commit {tr.get('commit')}, "
+                                          f"profiles/{tr['source']}")
         except (OSError, KeyError, ValueError, TypeError):
             pass
         return roof

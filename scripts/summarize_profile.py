@@ -78,6 +78,17 @@ def main():
     # per-launch PMC traffic of the dominant kernel, one entry per flavour (last template argument: 0 = unordered single
     # pass -> "join_probe_fused", 2 = placed by tile offsets, probe order -> "join_probe_placed")
     entries = []
+    # what the passes were taken on: the commit checked out when this summary is made (the run's snapshot) and a hash of the file
+    # that defines the kernel — bench.py attaches the traffic only while that file is unchanged (a kernel edit without a fresh PMC
+    # pass must not report the old bytes)
+    import hashlib
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:  # noqa: BLE001
+        commit = None
+    src_sha = hashlib.sha256(open(os.path.join(root, "datafusion_amd", "csrc", "join.hip"), "rb").read()).hexdigest()[:16]
     for r in rows:
         if not r["kernel"].startswith("k_join_probe_fused") or not r["traffic_bytes"] or not bench:
             continue
@@ -89,7 +100,8 @@ def main():
         wl = {k: bench["config"][k] for k in ("build_rows", "probe_rows", "output_rows", "join_table")}
         entries.append({"kernel": name, "device_kernel": r["kernel"], "traffic_bytes_per_launch": int(r["traffic_bytes"]),
                         "read_bytes_corrected": int(r["read_bytes_corrected"] or 0), "write_bytes": int(r["write_bytes"] or 0),
-                        "fetch_size_calibration": calib, "avg_launch_us_rocprof": r["avg_us"], "source": os.path.basename(dst) + ".json", "workload": wl})
+                        "fetch_size_calibration": calib, "avg_launch_us_rocprof": r["avg_us"], "source": os.path.basename(dst) + ".json", "workload": wl,
+                        "commit": commit, "kernel_source": "datafusion_amd/csrc/join.hip", "kernel_source_sha16": src_sha})
     if entries:
         json.dump({"kernels": entries}, open(os.path.join(os.path.dirname(dst) or ".", "traffic.json"), "w"), indent=1)
     print(open(dst + ".md").read())
