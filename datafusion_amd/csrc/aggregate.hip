@@ -31,6 +31,7 @@
 #include "device.hpp"
 #include "internal.hpp"
 #include "rowprog_host.hpp"
+#include "grouped.hpp"
 
 namespace dfgpu {
 
@@ -119,6 +120,12 @@ struct InternCtx {
   uint32_t* slots;      // representative row + 1, 0 = empty
   uint64_t mask;        // capacity - 1
   struct KeyedSlot* keyed;  // keyed table (below): packed key and smallest row of every slot; null = slots are compared through their rows
+  // direct table (round 4): the key columns' value ranges multiply to a few thousand — the slot of a row IS its mixed-radix number
+  // sum((value_c - dmin[c]) * dstride[c]); nothing is hashed, compared or probed (k_intern_claim_direct)
+  int direct;
+  long long dmin[MAX_KEYS];
+  uint32_t dstride[MAX_KEYS];
+  const uint8_t* dcode[MAX_KEYS];   // UInt8 columns: value -> its rank among the values that occur (256 bytes; null: value - dmin)
 };
 struct KeyedSlot {   // 16 bytes: one L2 request brings a slot's key and its row
   uint64_t key;      // KEY_EMPTY = none
@@ -335,7 +342,133 @@ __global__ __launch_bounds__(BLOCK) void k_slot_gids(const uint32_t* __restrict_
   }
 }
 
+// ---- direct table: mixed-radix slot numbers from the key columns' value ranges
+template <int R>
+__device__ __forceinline__ void direct_slots(const InternCtx& c, const int64_t (&i)[R], uint32_t live, uint32_t (&v)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; r++) v[r] = 0;
+  for (int k = 0; k < c.keys.n; k++) {
+    const void* p = c.keys.c[k].data;
+    uint64_t x[R];
+    switch (c.keys.c[k].type) {   // (all R loads of a column in flight together)
+      case DFGPU_UINT8:
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = (live >> r) & 1u ? (uint64_t)((const uint8_t*)p)[i[r]] : (uint64_t)c.dmin[k];
+        if (c.dcode[k]) {
+#pragma unroll
+          for (int r = 0; r < R; r++) x[r] = (uint64_t)c.dmin[k] + c.dcode[k][x[r]];
+        }
+        break;
+      case DFGPU_UINT32:
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = (live >> r) & 1u ? (uint64_t)((const uint32_t*)p)[i[r]] : (uint64_t)c.dmin[k];
+        break;
+      case DFGPU_INT64:
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = (live >> r) & 1u ? ((const uint64_t*)p)[i[r]] : (uint64_t)c.dmin[k];
+        break;
+      default:   // Int32, Date32
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = (live >> r) & 1u ? (uint64_t)(int64_t)((const int32_t*)p)[i[r]] : (uint64_t)c.dmin[k];
+        break;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] += (uint32_t)(x[r] - (uint64_t)c.dmin[k]) * c.dstride[k];
+  }
+}
+__device__ __forceinline__ uint32_t direct_slot(const InternCtx& c, int64_t i) {
+  const int64_t ii[1] = {i};
+  uint32_t v[1];
+  direct_slots<1>(c, ii, 1u, v);
+  return v[0];
+}
+// claim pass over a direct table: a workgroup takes a contiguous slice of the rows and keeps the smallest row of every slot it
+// meets in LDS (a read per row, an atomic only when the row is smaller than what is there — rows arrive in ascending order, so
+// after a slot's first rows hardly ever); what it met goes to the device-wide array at the end, one atomic per slot and workgroup.
+// first_row: u32 [n_slots], 0xFFFFFFFF = no row.  Reads the key columns, writes the rows' slots: no random access beyond LDS.
+constexpr int DIRECT_BLOCK = 1024;
+constexpr int DIRECT_ROWS = 4;
+constexpr uint32_t DIRECT_MAX_SLOTS = 32768;   // x 4 bytes of LDS
+__global__ __launch_bounds__(DIRECT_BLOCK) void k_intern_claim_direct(InternCtx c, int64_t n, uint32_t n_slots, const uint64_t* __restrict__ row_mask,
+                                                                     uint32_t* __restrict__ row_slot, uint32_t* __restrict__ first_row) {
+  extern __shared__ uint32_t s_first[];
+  for (uint32_t x = threadIdx.x; x < n_slots; x += DIRECT_BLOCK) s_first[x] = 0xFFFFFFFFu;
+  __syncthreads();
+  constexpr int U = DIRECT_ROWS;
+  const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 63) & ~(int64_t)63;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)U * DIRECT_BLOCK) {
+    int64_t rows[U];
+    uint32_t slot[U];
+    uint32_t live = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      rows[u] = i0 + (int64_t)u * DIRECT_BLOCK;
+      if (rows[u] < hi && !(row_mask && !bit_at(row_mask, rows[u]))) live |= 1u << u;
+    }
+    direct_slots<U>(c, rows, live, slot);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (rows[u] >= hi) continue;
+      if (!((live >> u) & 1u)) {
+        if (row_slot) row_slot[rows[u]] = 0xFFFFFFFFu;
+        continue;
+      }
+      if ((uint32_t)rows[u] < s_first[slot[u]]) atomicMin(&s_first[slot[u]], (uint32_t)rows[u]);
+      if (row_slot) row_slot[rows[u]] = slot[u];
+    }
+  }
+  __syncthreads();
+  for (uint32_t x = threadIdx.x; x < n_slots; x += DIRECT_BLOCK) {
+    const uint32_t v = s_first[x];
+    if (v != 0xFFFFFFFFu) atomicMin(&first_row[x], v);
+  }
+}
+// first rows (0xFFFFFFFF = none) -> the slot array's convention (row + 1, 0 = empty)
+__global__ __launch_bounds__(BLOCK) void k_direct_slots_from_rows(const uint32_t* __restrict__ first_row, uint64_t n_slots, uint32_t* __restrict__ slots) {
+  for (uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; x < n_slots; x += (uint64_t)gridDim.x * BLOCK) slots[x] = first_row[x] + 1u;
+}
+// which of the 256 values a UInt8 column takes (a key column like l_returnflag holds 'A', 'N', 'R': 3 codes instead of a span of 18)
+__global__ __launch_bounds__(BLOCK) void k_u8_presence(const uint8_t* __restrict__ col, int64_t n, unsigned long long* __restrict__ out) {
+  __shared__ unsigned s_bits[8];
+  if (threadIdx.x < 8) s_bits[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * BLOCK) {
+    const uint32_t w = reinterpret_cast<const uint32_t*>(col)[i];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const unsigned v = (w >> (8 * b)) & 255u;
+      mine[v >> 5] |= 1u << (v & 31);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {
+    const unsigned v = col[n4 * 4 + threadIdx.x];
+    mine[v >> 5] |= 1u << (v & 31);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++)
+    if (mine[q]) atomicOr(&s_bits[q], mine[q]);
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const unsigned long long w = (unsigned long long)s_bits[2 * threadIdx.x] | ((unsigned long long)s_bits[2 * threadIdx.x + 1] << 32);
+    if (w) atomicOr(&out[threadIdx.x], w);
+  }
+}
+// min / max of 4096 evenly spaced rows: tells a key column whose values span too much for a direct table without a pass over it
+template <typename T>
+__global__ void k_sample_minmax(const T* __restrict__ col, int64_t n, long long* __restrict__ out) {
+  const int64_t step = n / 4096 > 0 ? n / 4096 : 1;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * step;
+  if (i >= n) return;
+  const long long v = (long long)col[i];
+  atomicMin(&out[0], v);
+  atomicMax(&out[1], v);
+}
+
 __device__ __forceinline__ uint32_t lookup_gid(const InternCtx& c, const uint32_t* __restrict__ slot_gid, int64_t i) {
+  if (c.direct) return slot_gid[direct_slot(c, i)];
   if (c.keyed) {
     const uint64_t k = packed_key(c.keys, i);
     if (k == KEY_EMPTY) return slot_gid[c.mask + 1];
@@ -1002,9 +1135,82 @@ struct InternResult {
   BufPtr slots, slot_gid;
   BufPtr row_slot;               // (on request) the slot of every concatenated row, 0xFFFFFFFF where the claim pass skipped it
   BufPtr keyed;                  // keyed table: packed key and row of every slot
+  std::vector<BufPtr> direct_codes;   // direct table: the UInt8 key columns' value -> code tables
   std::vector<Column> cat_keys;  // [existing group keys ; input keys] — referenced by ictx
   int64_t G1 = 0;
 };
+// Do the key columns' value ranges multiply to a table of <= DIRECT_MAX_SLOTS slots?  Fills ictx.dmin / dstride and returns the number
+// of slots (0: no).  Ranges come from the columns' cached statistics (column_stats: a pass over a column that has none yet — a
+// 4096-row sample first says whether it can be worth it).
+static ColStats u8_presence(Column& c, int64_t n) {
+  ColStats st = column_stats(c, n);
+  if (st.has_present) return st;
+  Runtime& r = rt();
+  BufPtr d = make_zero_buf(32);
+  {
+    ProfileScope ps("column_u8_presence", n);
+    k_u8_presence<<<std::min(grid_for(n / 4 + 1, BLOCK * 8), 2048), BLOCK, 0, r.stream>>>((const uint8_t*)c.ptr(), n, d->as<unsigned long long>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  d2h(st.present, d->ptr, 32);
+  st.has_present = true;
+  std::atomic_store(&c.stats, std::make_shared<ColStats>(st));
+  return st;
+}
+static uint32_t direct_table_spec(std::vector<Column>& keys, int64_t n, InternCtx& ictx, std::vector<BufPtr>& keep) {
+  Runtime& r = rt();
+  const int ngk = (int)keys.size();
+  std::vector<int> order((size_t)ngk);
+  for (int g = 0; g < ngk; g++) order[(size_t)g] = g;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return type_width(keys[(size_t)a].field.type) < type_width(keys[(size_t)b].field.type); });
+  uint64_t ranges[MAX_KEYS];
+  uint64_t prod = 1;
+  for (int g : order) {   // (narrow columns first: their statistics are the cheap ones)
+    Column& c = keys[(size_t)g];
+    const int t = c.field.type;
+    if (c.validity || !(t == DFGPU_UINT8 || t == DFGPU_INT32 || t == DFGPU_DATE32 || t == DFGPU_UINT32 || t == DFGPU_INT64)) return 0;
+    if (!std::atomic_load(&c.stats) && t != DFGPU_UINT8) {
+      long long mm[2] = {INT64_MAX, INT64_MIN};
+      BufPtr d = make_buf(16);
+      h2d_async(d->ptr, mm, 16);
+      switch (t) {
+        case DFGPU_INT64: k_sample_minmax<int64_t><<<16, 256, 0, r.stream>>>((const int64_t*)c.ptr(), n, d->as<long long>()); break;
+        case DFGPU_UINT32: k_sample_minmax<uint32_t><<<16, 256, 0, r.stream>>>((const uint32_t*)c.ptr(), n, d->as<long long>()); break;
+        default: k_sample_minmax<int32_t><<<16, 256, 0, r.stream>>>((const int32_t*)c.ptr(), n, d->as<long long>()); break;
+      }
+      d2h(mm, d->ptr, 16);
+      if ((unsigned long long)(mm[1] - mm[0]) >= DIRECT_MAX_SLOTS / prod) return 0;
+    }
+    const ColStats st = t == DFGPU_UINT8 ? u8_presence(c, n) : column_stats(c, n);
+    if (st.valid != n) return 0;
+    unsigned long long span = (unsigned long long)(st.max - st.min);
+    ictx.dmin[g] = st.min;
+    ictx.dcode[g] = nullptr;
+    if (t == DFGPU_UINT8) {   // the values that occur, numbered: 'A', 'N', 'R' -> 0, 1, 2
+      uint8_t code[256];
+      unsigned next = 0;
+      for (int v = 0; v < 256; v++) code[v] = (uint8_t)((st.present[v >> 6] >> (v & 63)) & 1ull ? next++ : 0u);
+      if (next >= 1 && next - 1 < span) {
+        span = next - 1;
+        BufPtr d = make_buf(256);
+        h2d_async(d->ptr, code, 256);
+        DFGPU_HIP(hipStreamSynchronize(r.stream));   // (`code` is a local)
+        ictx.dcode[g] = d->as<uint8_t>();
+        ictx.dmin[g] = 0;
+        keep.push_back(d);
+      }
+    }
+    if (span >= DIRECT_MAX_SLOTS / prod) return 0;
+    ranges[g] = span + 1;
+    prod *= span + 1;
+  }
+  uint32_t stride = 1;
+  for (int g = ngk - 1; g >= 0; g--) {
+    ictx.dstride[g] = stride;
+    stride *= (uint32_t)ranges[g];
+  }
+  return (uint32_t)prod;
+}
 static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_cols, int64_t n, const uint64_t* row_mask, bool want_row_slots = false) {
   Runtime& r = rt();
   InternResult R;
@@ -1056,6 +1262,12 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
     }
     keyed = keyed && bits <= 64;
   }
+  // key columns whose value ranges multiply to a few thousand: a direct table (first batch of a large input only: the concatenation
+  // with earlier groups' keys has no statistics)
+  uint32_t direct_n = 0;
+  if (G0 == 0 && total >= (1 << 22) && ngk >= 1 && !(std::getenv("DFGPU_AGG_DIRECT_TABLE") && std::getenv("DFGPU_AGG_DIRECT_TABLE")[0] == '0'))   // A/B knob
+    direct_n = direct_table_spec(R.cat_keys, total, ictx, R.direct_codes);
+  if (direct_n) keyed = false;
   BufPtr flag = make_zero_buf(4);
   uint64_t cap = (uint64_t)A.capacity_hint;
   const uint64_t cap_max = [&] { uint64_t c = 64; while (c < (uint64_t)total * 2) c <<= 1; return c; }();
@@ -1066,7 +1278,29 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   // own and extrapolate: distinct keys still growing with the sample => groups ~ rows x (distinct / sample); flat between
   // the first quarter and the whole sample => the sample has seen them all.
   constexpr int64_t SAMPLE = 1 << 20;
-  if (G0 == 0) {
+  if (direct_n) {
+    cap = 64;
+    while (cap < direct_n) cap <<= 1;
+    R.slots = make_zero_buf((cap + 1) * 4);
+    ictx.slots = R.slots->as<uint32_t>();
+    ictx.mask = cap - 1;
+    ictx.direct = 1;
+    BufPtr first = make_buf(cap * 4);
+    DFGPU_HIP(hipMemsetAsync(first->ptr, 0xFF, cap * 4, r.stream));
+    if (want_row_slots) R.row_slot = make_buf((size_t)total * 4);
+    const size_t lds = (size_t)direct_n * 4;
+    DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_intern_claim_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int per_cu = lds * 2 <= ((size_t)150 << 10) ? 2 : 1;   // (1024-thread workgroups: two per CU at most)
+    const int grid = (int)std::min<int64_t>((int64_t)r.num_cus * per_cu, (total + 8191) / 8192);
+    {
+      ProfileScope ps("agg_intern_claim_direct", key_bytes + (R.row_slot ? total * 4 : 0));
+      k_intern_claim_direct<<<grid, DIRECT_BLOCK, lds, r.stream>>>(ictx, total, direct_n, row_mask, R.row_slot ? R.row_slot->as<uint32_t>() : nullptr, first->as<uint32_t>());
+      k_direct_slots_from_rows<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(first->as<uint32_t>(), cap, ictx.slots);
+      DFGPU_HIP(hipGetLastError());
+    }
+    DFGPU_HIP(hipStreamSynchronize(r.stream));   // (`first` is a local)
+  }
+  if (G0 == 0 && !direct_n) {
     if (total <= 4 * SAMPLE) {
       cap = cap_max;
     } else if (!row_mask) {
@@ -1094,8 +1328,8 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
       cap = std::max<uint64_t>(cap, want);
     }
   }
-  if (cap > cap_max) cap = cap_max;
-  for (;;) {
+  if (cap > cap_max && !direct_n) cap = cap_max;
+  while (!direct_n) {
     R.slots = make_zero_buf((cap + 1) * 4);   // (+ 1: the keyed table's slot for the all-ones key)
     ictx.slots = R.slots->as<uint32_t>();
     ictx.mask = cap - 1;
@@ -1950,6 +2184,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   int wshift = 0;
   while (((range - 1) >> wshift) >= 64) wshift++;
   int levels = 1;
+  bool grouped_move = false;
   // the whole range fits ONE workgroup's LDS: nothing is moved.  Every workgroup takes a slice of the rows where they lie (the
   // predicate's mask looked at row by row) and accumulates into its own copy of the one window; the copies merge through atomics
   // — range x workgroups of them, against the 2 x (key + arguments) bytes per row the move costs
@@ -1961,8 +2196,13 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   } else if (wshift > wcap) {
     wshift = wcap;
     if (((range - 1) >> wshift) >= 4096) return false;
-    levels = 2;
-    if (n < 4 * min_rows) return false;   // two moves: only for inputs where the atomics are long
+    // up to 2048 windows: ONE move by grouped.hip's pass (round 4: the two 64-way moves cost 4.6 ms for 150 M orders, this one 1.2)
+    const bool grouped_off = std::getenv("DFGPU_AGG_GROUPED_MOVE") && std::getenv("DFGPU_AGG_GROUPED_MOVE")[0] == '0';   // A/B knob
+    grouped_move = !grouped_off && ((range - 1) >> wshift) < (uint64_t)GP_MAX_GROUPS && !row_mask_valid && n < 0xFFFFFFFFll;
+    if (!grouped_move) {
+      levels = 2;
+      if (n < 4 * min_rows) return false;   // two moves: only for inputs where the atomics are long
+    }
   }
   const int64_t n_windows = (int64_t)((range - 1) >> wshift) + 1;
   const size_t W = (size_t)1 << wshift;
@@ -1970,7 +2210,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   // more than 64 KB of dynamic LDS has to be asked for, per kernel
   {
     const void* fn = nullptr;
-    switch (kt) {
+    switch (grouped_move ? (int)DFGPU_INT64 : kt) {
       case DFGPU_INT64: fn = (const void*)k_dense_accumulate_parts<int64_t>; break;
       case DFGPU_UINT32: fn = (const void*)k_dense_accumulate_parts<uint32_t>; break;
       case DFGPU_UINT8: fn = (const void*)k_dense_accumulate_parts<uint8_t>; break;
@@ -2012,6 +2252,15 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     src.push_back(ids->ptr);
     widths.push_back(4);
   }
+  if (grouped_move) {   // what grouped.hip's pass carries: <= GP_MAX_COLS columns, and its LDS holds a tile of the widest one beside the groups' words
+    bool wide = false;
+    for (size_t q = 1; q < widths.size(); q++) wide |= widths[q] == 16;
+    if ((int)src.size() - 1 > GP_MAX_COLS || (wide && n_windows > 1024)) {
+      grouped_move = false;
+      levels = 2;
+      if (n < 4 * min_rows) return false;
+    }
+  }
   std::vector<PartBlock> blocks;
   RangePartition rp;
   if (in_place) {
@@ -2019,7 +2268,26 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     for (int64_t b = 0; b < nb; b++) blocks.push_back(PartBlock{n * b / nb, n * (b + 1) / nb, 0, nb == 1 ? 1 : 0});
   } else {
   // (under a predicate only the rows it lets through are moved: `n` is their number from here on)
-  rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths, /*want_bounds=*/false, row_mask, row_mask_valid);
+  std::vector<uint64_t> group_bounds;
+  if (grouped_move) {
+    // group = window: floor(idx * 2^(64 - wshift) / 2^64) = idx >> wshift.  The keys arrive widened to 64 bits (cols[0]), the
+    // arguments and row numbers as carried columns; where every window's rows begin comes with them
+    int nbits = 1;
+    while (((int64_t)1 << nbits) < n_windows) nbits++;
+    const KeyCol kc{key, nullptr, kt, type_width(kt)};
+    const GroupSpec gs{(uint64_t)kmin, range, 1ull << (64 - wshift)};
+    GroupedRows gr = group_rows_by_key(kc, n, gs, nbits, row_mask, /*want_keys=*/true, /*want_dest=*/false, std::vector<const void*>(src.begin() + 1, src.end()),
+                                       std::vector<int>(widths.begin() + 1, widths.end()), "agg_group_rows");
+    rp.rows = gr.rows;
+    rp.cols.push_back(gr.keys);
+    for (BufPtr& b : gr.cols) rp.cols.push_back(b);
+    group_bounds.resize((size_t)gr.P + 1);
+    d2h(group_bounds.data(), gr.bounds->ptr, group_bounds.size() * 8);
+    widths[0] = 8;
+    kt = DFGPU_INT64;
+  } else {
+    rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths, /*want_bounds=*/false, row_mask, row_mask_valid);
+  }
   n = rp.rows;
   if (n == 0) {   // the predicate dropped every row
     out.vstride = ((int64_t)range + 63) / 64 * 64;
@@ -2039,6 +2307,10 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     if (acc_src[u] >= 0) all[u].data = rp.cols[(size_t)acc_src[u]]->ptr;
   // where every window's rows begin (read off the moved keys), then the workgroups: one per window while its rows are few (its
   // totals then leave as plain stores); else chunks, merged by atomics
+  std::vector<long long> begins((size_t)n_windows);
+  if (grouped_move) {
+    for (int64_t w = 0; w < n_windows; w++) begins[(size_t)w] = group_bounds[(size_t)w + 1] > group_bounds[(size_t)w] ? (long long)group_bounds[(size_t)w] : -1ll;
+  } else {
   BufPtr d_begins = make_buf((size_t)n_windows * 8);
   DFGPU_HIP(hipMemsetAsync(d_begins->ptr, 0xFF, (size_t)n_windows * 8, r.stream));
   switch (kt) {
@@ -2047,8 +2319,8 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     case DFGPU_UINT8: k_window_begins<uint8_t><<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(rp.cols[0]->as<uint8_t>(), n, kmin, wshift, d_begins->as<long long>()); break;
     default: k_window_begins<int32_t><<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(rp.cols[0]->as<int32_t>(), n, kmin, wshift, d_begins->as<long long>()); break;
   }
-  std::vector<long long> begins((size_t)n_windows);
   d2h(begins.data(), d_begins->ptr, (size_t)n_windows * 8);
+  }
   {
     int64_t end = n;
     std::vector<PartBlock> rev;
@@ -2246,7 +2518,7 @@ static bool general_accumulate_partitioned(const InternCtx& ictx, const uint32_t
   if (off || n < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || G1 < 256) return false;
   Runtime& r = rt();
   PartValues pv;
-  if (row_slot && ictx.keyed && partitioned_in_place((uint64_t)G1, all)) {
+  if (row_slot && (ictx.keyed || ictx.direct) && partitioned_in_place((uint64_t)G1, all)) {
     // few enough groups to accumulate the rows where they lie: the slot the claim pass left for every row (a keyed table leaves one for
     // every live row) stands in for the key, its group number is looked up on the way (the slot -> group table is cache-sized)
     if (!partitioned_accumulate(row_slot + G0, DFGPU_UINT32, n, 0, (uint64_t)G1, std::move(all), ncw, /*want_first_rows=*/false, pv, row_mask, nullptr, slot_gid, (int64_t)ictx.mask + 2)) return false;
@@ -3424,6 +3696,16 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
     // (large inputs may take the partitioned accumulation below: it wants every row's slot from the claim pass)
     const bool maybe_partitioned = n >= env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) && !(std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0');
     IR = intern_keys(A, key_cols_keepalive, n, row_mask, maybe_partitioned);
+    if (G0 == 0)   // statistics the interning took of plain key columns belong to the table's columns (the same rows): the next query finds them
+      for (int g = 0; g < ngk; g++) {
+        int c = -1;
+        if (!is_plain_column(A.group_nodes[g], A.group_roots[g], &c) || c < 0 || c >= (int)in.cols.size()) continue;
+        Column& home = const_cast<Column&>(in.cols[(size_t)c]);
+        if (auto st = std::atomic_load(&IR.cat_keys[(size_t)g].stats)) {
+          auto had = std::atomic_load(&home.stats);
+          if (!had || (st->has_present && !had->has_present)) std::atomic_store(&home.stats, st);
+        }
+      }
     G1 = IR.G1;
     gs.ictx = IR.ictx;
     gs.slot_gid = IR.slot_gid->as<uint32_t>();

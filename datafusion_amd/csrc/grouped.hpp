@@ -16,7 +16,7 @@ inline GroupSpec group_spec(uint64_t offset, uint64_t size, int groups) {
   const unsigned __int128 m = (((unsigned __int128)(unsigned)groups) << 64) / (size ? size : 1);
   return GroupSpec{offset, size, m > (unsigned __int128)~0ull ? ~0ull : (uint64_t)m};
 }
-constexpr int GP_MAX_GROUPS = 1024;
+constexpr int GP_MAX_GROUPS = 2048;
 constexpr int GP_MAX_COLS = 8;
 struct GroupCols {
   const void* src[GP_MAX_COLS];
@@ -32,7 +32,7 @@ struct GroupedRows {
   BufPtr bounds;               // u64 [P + 1] on the device: group g = positions bounds[g] .. bounds[g + 1]
   std::vector<BufPtr> cols;    // carried columns in group order
 };
-// Rows of an integer key column moved into 2^nbits groups of their key's range (NULL keys, rows masked out by `row_mask` and keys
+// Rows of an integer key column moved into 2^nbits (<= GP_MAX_GROUPS) groups of their key's range (NULL keys, rows masked out by `row_mask` and keys
 // outside [offset, offset + size) take no part).  Order inside a group is arbitrary.
 GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs, int nbits, const uint64_t* row_mask, bool want_keys, bool want_dest,
                               const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what = nullptr);

@@ -223,6 +223,8 @@ struct ColStats {
   int64_t valid = 0;
   bool ascending = false;      // strictly ascending in row order, no NULLs
   bool nondecreasing = false;  // key[i-1] <= key[i] for every row, no NULLs: equal keys are adjacent (ordered input of an aggregate)
+  bool has_present = false;    // UInt8 columns, on request (aggregate.hip u8_presence): which of the 256 values occur
+  uint64_t present[4] = {0, 0, 0, 0};
 };
 
 // Values of a dictionary-encoded column (Arrow Dictionary(index type, Utf8 | LargeUtf8)): the device column holds the

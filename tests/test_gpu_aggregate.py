@@ -407,13 +407,17 @@ def test_medium_cardinality_group_by_partitions_rows_then_accumulates_in_lds(key
 
 
 @pytest.mark.gpu
-def test_medium_cardinality_group_by_over_a_wide_key_range_moves_the_rows_twice(monkeypatch):
-    """a key range too wide for 64 LDS-sized windows: the rows are moved twice (low 6 bits of the window number, then the high 6: up to
-    4096 windows) before the LDS accumulation — 600 K groups over a range of 1.8 M values here, COUNT(*) / SUM / MIN in first-seen order"""
+@pytest.mark.parametrize("move", ["grouped", "two_level"])
+def test_medium_cardinality_group_by_over_a_wide_key_range_moves_the_rows_twice(monkeypatch, move):
+    """a key range too wide for 64 LDS-sized windows: up to 2048 windows are reached by ONE move of the rows (grouped.hip's pass,
+    round 4), up to 4096 by two 64-way moves (low 6 bits of the window number, then the high 6; DFGPU_AGG_GROUPED_MOVE=0 forces them
+    here) before the LDS accumulation — 600 K groups over a range of 1.8 M values here, COUNT(*) / SUM / MIN in first-seen order"""
     from datafusion_amd import ops
     from datafusion_amd.expr import col
     from datafusion_amd.table import DeviceTable
     monkeypatch.setenv("DFGPU_AGG_PARTITIONED_MIN_ROWS", "1000000")
+    if move == "two_level":
+        monkeypatch.setenv("DFGPU_AGG_GROUPED_MOVE", "0")
     rng = np.random.default_rng(9)
     n, distinct = 6_000_000, 600_000
     codes = rng.integers(0, distinct, n)
@@ -426,7 +430,11 @@ def test_medium_cardinality_group_by_over_a_wide_key_range_moves_the_rows_twice(
     got = ops.aggregate(t, [(col("k"), "k")], [("count", None, "n"), ("sum", col("v"), "sv"), ("min", col("d"), "first_day")], "Single").to_arrow()
     stats = ops.profile_stats()
     ops.profile_enable(False)
-    assert stats["partition_scatter"]["calls"] == 2 and "agg_dense_accumulate_partitioned" in stats and "agg_dense_accumulate" not in stats, sorted(stats)
+    assert "agg_dense_accumulate_partitioned" in stats and "agg_dense_accumulate" not in stats, sorted(stats)
+    if move == "grouped":
+        assert stats["agg_group_rows"]["calls"] == 1 and "partition_scatter" not in stats, sorted(stats)
+    else:
+        assert stats["partition_scatter"]["calls"] == 2 and "agg_group_rows" not in stats, sorted(stats)
     first = np.full(distinct, n, dtype=np.int64)
     np.minimum.at(first, codes, np.arange(n))
     present = np.nonzero(first < n)[0]
@@ -510,6 +518,46 @@ def test_medium_cardinality_group_by_under_a_fused_filter_moves_only_the_rows_th
     mx = np.full(distinct, -1, dtype=np.int64); np.maximum.at(mx, kc, kx)
     assert got.column("k").to_pylist() == (order * 2 + 1).tolist()
     assert got.column("sv").to_pylist() == sv[order].tolist()
+    assert got.column("n").to_pylist() == np.bincount(kc, minlength=distinct)[order].tolist()
+    assert got.column("mx").to_pylist() == mx[order].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key_type", ["int32", "int64"])
+def test_one_grouped_move_under_a_fused_filter_with_a_decimal_sum(monkeypatch, key_type):
+    """the single move into up to 2048 windows (grouped.hip) under a fused predicate: only passing rows move; Int32 and Int64 keys
+    (the moved keys are widened), a 128-bit SUM(Decimal128) beside COUNT(*) and MAX — groups in the order of their first passing row"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    monkeypatch.setenv("DFGPU_AGG_PARTITIONED_MIN_ROWS", "1000000")
+    rng = np.random.default_rng(77)
+    n, distinct = 5_000_000, 400_000
+    codes = rng.integers(0, distinct, n)
+    keys = (codes * 5 - 700_000).astype(np.int32 if key_type == "int32" else np.int64)     # negative keys too: range 2 M values
+    cents = rng.integers(-10**9, 10**9, n)
+    x = rng.integers(0, 1000, n).astype(np.int32)
+    w = rng.integers(0, 100, n).astype(np.int32)
+    import pyarrow.compute as pc
+    dcol = pc.cast(pa.array(cents), pa.decimal128(15, 0))
+    dcol = pa.Array.from_buffers(pa.decimal128(15, 2), n, dcol.buffers())                   # the same unscaled values at scale 2
+    t = DeviceTable.from_arrow(pa.table({"k": pa.array(keys), "p": dcol, "x": pa.array(x), "w": pa.array(w)}))
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = ops.aggregate(t, [(col("k"), "k")], [("sum", col("p"), "sp"), ("count", None, "n"), ("max", col("x"), "mx")], "Single", predicate=col("w") < lit(60, pa.int32())).to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert "agg_dense_accumulate_partitioned" in stats and stats["agg_group_rows"]["calls"] == 1 and "partition_scatter" not in stats, sorted(stats)
+    keep = w < 60
+    kc = codes[keep]
+    first = np.full(distinct, n, dtype=np.int64)
+    np.minimum.at(first, kc, np.nonzero(keep)[0])
+    present = np.nonzero(first < n)[0]
+    order = present[np.argsort(first[present], kind="stable")]
+    sp = np.zeros(distinct, dtype=np.int64); np.add.at(sp, kc, cents[keep])
+    mx = np.full(distinct, -1, dtype=np.int64); np.maximum.at(mx, kc, x[keep])
+    assert got.column("k").to_pylist() == (order * 5 - 700_000).tolist()
+    assert [int(v.scaleb(2)) for v in got.column("sp").to_pylist()] == sp[order].tolist()
     assert got.column("n").to_pylist() == np.bincount(kc, minlength=distinct)[order].tolist()
     assert got.column("mx").to_pylist() == mx[order].tolist()
 
@@ -661,6 +709,8 @@ def test_a_few_thousand_groups_are_accumulated_in_lds_where_the_rows_lie(keys, f
     stats = ops.profile_stats()
     ops.profile_enable(False)
     assert "agg_dense_accumulate_partitioned" in stats and "partition_scatter" not in stats and "agg_fused_global" not in stats, sorted(stats)
+    if keys == "two_columns":   # (k1: 50 values) x (k2: 60 values): a direct table of 3000 slots (round 4), no hash table
+        assert "agg_intern_claim_direct" in stats and "agg_intern_claim_keyed" not in stats, sorted(stats)
     keep = ((w >= -20) & ~wnull) if filtered else np.ones(n, dtype=bool)
     gid = gid_all[keep]
     first = np.full(G, n, dtype=np.int64)
@@ -678,6 +728,72 @@ def test_a_few_thousand_groups_are_accumulated_in_lds_where_the_rows_lie(keys, f
     if keys == "two_columns":
         sd = np.zeros(G, dtype=np.int64); np.add.at(sd, gid, dec[keep])
         assert [int(x.scaleb(2)) for x in got.column("sd").to_pylist()] == sd[order].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("table", ["direct", "keyed_by_knob"])
+@pytest.mark.parametrize("filtered", [False, True], ids=["no_predicate", "fused_filter"])
+def test_key_columns_with_small_value_ranges_take_a_direct_table(monkeypatch, table, filtered):
+    """round 4: key columns whose value ranges multiply to a few thousand slots — two UInt8 flags holding a few letters each (numbered by
+    the values that occur: 'A', 'N', 'R' -> 0, 1, 2), a Date32 over ~1500 days, an Int64 with negative values — are interned without a
+    hash table: a row's slot is its mixed-radix number, the smallest row per slot is kept in LDS.  Groups, first-seen order, key values
+    and totals equal the host's and those of the keyed table (DFGPU_AGG_DIRECT_TABLE=0); a second update interns against the groups
+    of the first through the hash table again"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    if table == "keyed_by_knob":
+        monkeypatch.setenv("DFGPU_AGG_DIRECT_TABLE", "0")
+    rng = np.random.default_rng(41 + filtered)
+    n, n2 = 4_600_000, 300_000
+    flag = np.frombuffer(b"ANR", dtype=np.uint8)[rng.integers(0, 3, n + n2)]
+    status = np.frombuffer(b"FO", dtype=np.uint8)[rng.integers(0, 2, n + n2)]
+    day = (np.sort(rng.integers(0, 1500, n + n2)) + rng.integers(0, 60, n + n2) + 8000).astype(np.int32)     # clustered like l_shipdate
+    small = rng.integers(-2, 1, n + n2)                                                                       # Int64: -2, -1, 0
+    v = rng.integers(-10**6, 10**6, n + n2)
+    w = rng.integers(-100, 100, n + n2).astype(np.int32)
+    cents = rng.integers(-10**8, 10**8, n + n2)
+    raw = np.empty((n + n2, 2), dtype=np.int64)
+    raw[:, 0] = cents
+    raw[:, 1] = cents >> 63
+    full = pa.table({"f": pa.array(flag), "s": pa.array(status), "d": pa.array(day, pa.date32()), "z": pa.array(small), "v": pa.array(v), "w": pa.array(w),
+                     "p": pa.Array.from_buffers(pa.decimal128(15, 2), n + n2, [None, pa.py_buffer(raw.tobytes())])})
+    gb = [(col(c), c) for c in ("f", "s", "d", "z")]
+    aggs = [("sum", col("p"), "sp"), ("sum", col("v"), "sv"), ("count", None, "cnt"), ("max", col("w"), "hi")]
+    pred = (col("w") < lit(30, pa.int32())) if filtered else None
+    a = ops.GroupedAggregate("Single", full.column_names, gb, aggs)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    a.update(DeviceTable.from_arrow(full.slice(0, n)), pred)
+    a.update(DeviceTable.from_arrow(full.slice(n, n2)), pred)
+    got = a.emit().to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    if table == "direct":
+        assert stats["agg_intern_claim_direct"]["calls"] == 1 and "column_u8_presence" in stats, sorted(stats)
+    else:
+        assert "agg_intern_claim_direct" not in stats and "agg_intern_claim_keyed" in stats, sorted(stats)
+    keep = (w < 30) if filtered else np.ones(n + n2, dtype=bool)
+    key = ((flag.astype(np.int64) * 256 + status) * 100_000 + day) * 8 + (small + 2)
+    uniq, inv = np.unique(key, return_inverse=True)
+    inv = inv.reshape(-1)
+    G = len(uniq)
+    gid = inv[keep]
+    first = np.full(G, n + n2, dtype=np.int64)
+    np.minimum.at(first, gid, np.nonzero(keep)[0])
+    present = np.nonzero(first < n + n2)[0]
+    order = present[np.argsort(first[present], kind="stable")]
+    rows = first[order]
+    assert got.num_rows == len(order) > 10_000
+    for c in ("f", "s", "d", "z"):
+        assert got.column(c).to_pylist() == full.column(c).take(pa.array(rows)).to_pylist(), c
+    sv = np.zeros(G, dtype=np.int64); np.add.at(sv, gid, v[keep])
+    sp = np.zeros(G, dtype=np.int64); np.add.at(sp, gid, cents[keep])
+    hi = np.full(G, -1000, dtype=np.int64); np.maximum.at(hi, gid, w[keep])
+    assert got.column("sv").to_pylist() == sv[order].tolist()
+    assert [int(x.scaleb(2)) for x in got.column("sp").to_pylist()] == sp[order].tolist()
+    assert got.column("cnt").to_pylist() == np.bincount(gid, minlength=G)[order].tolist()
+    assert got.column("hi").to_pylist() == hi[order].tolist()
 
 
 @pytest.mark.gpu
