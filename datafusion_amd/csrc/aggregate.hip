@@ -122,7 +122,7 @@ struct InternCtx {
   struct KeyedSlot* keyed;  // keyed table (below): packed key and smallest row of every slot; null = slots are compared through their rows
   // direct table (round 4): the key columns' value ranges multiply to a few thousand — the slot of a row IS its mixed-radix number
   // sum((value_c - dmin[c]) * dstride[c]); nothing is hashed, compared or probed (k_intern_claim_direct)
-  int direct;
+  int direct;           // number of slots of the direct table, 0 = a hash table
   long long dmin[MAX_KEYS];
   uint32_t dstride[MAX_KEYS];
   const uint8_t* dcode[MAX_KEYS];   // UInt8 columns: value -> its rank among the values that occur (256 bytes; null: value - dmin)
@@ -386,36 +386,94 @@ __device__ __forceinline__ uint32_t direct_slot(const InternCtx& c, int64_t i) {
 // meets in LDS (a read per row, an atomic only when the row is smaller than what is there — rows arrive in ascending order, so
 // after a slot's first rows hardly ever); what it met goes to the device-wide array at the end, one atomic per slot and workgroup.
 // first_row: u32 [n_slots], 0xFFFFFFFF = no row.  Reads the key columns, writes the rows' slots: no random access beyond LDS.
+// A thread takes FOUR CONSECUTIVE rows: a UInt8 column's four values are one 32-bit load, an Int32 column's one 16-byte load, the
+// four slots one 16-byte store (VEC: every key column starts on a 16-byte boundary) — a wave-level load of one byte per lane costs
+// what one of 16 bytes per lane does (the first version, a row per lane and load: 4.2 ms for 600 M rows x (u8, u8, date32); this one
+// R4DIRECT ms).  The UInt8 columns' value -> code tables sit in LDS behind the first rows.
 constexpr int DIRECT_BLOCK = 1024;
 constexpr int DIRECT_ROWS = 4;
 constexpr uint32_t DIRECT_MAX_SLOTS = 32768;   // x 4 bytes of LDS
+template <bool VEC>
+__device__ __forceinline__ void direct_load4(const KeyCol& k, int64_t r0, int64_t hi, bool full, uint64_t fill, uint64_t (&x)[4]) {
+  const void* p = k.data;
+  if (VEC && full) {
+    switch (k.type) {
+      case DFGPU_UINT8: {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>((const uint8_t*)p + r0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = (w >> (8 * j)) & 255u;
+        return;
+      }
+      case DFGPU_UINT32: {
+        const uint4 w = *reinterpret_cast<const uint4*>((const uint32_t*)p + r0);
+        x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
+        return;
+      }
+      case DFGPU_INT64: {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>((const uint64_t*)p + r0), b = *reinterpret_cast<const ulonglong2*>((const uint64_t*)p + r0 + 2);
+        x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
+        return;
+      }
+      default: {
+        const int4 w = *reinterpret_cast<const int4*>((const int32_t*)p + r0);
+        x[0] = (uint64_t)(int64_t)w.x; x[1] = (uint64_t)(int64_t)w.y; x[2] = (uint64_t)(int64_t)w.z; x[3] = (uint64_t)(int64_t)w.w;
+        return;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    x[j] = fill;
+    if (r0 + j >= hi) continue;
+    switch (k.type) {
+      case DFGPU_UINT8: x[j] = ((const uint8_t*)p)[r0 + j]; break;
+      case DFGPU_UINT32: x[j] = ((const uint32_t*)p)[r0 + j]; break;
+      case DFGPU_INT64: x[j] = ((const uint64_t*)p)[r0 + j]; break;
+      default: x[j] = (uint64_t)(int64_t)((const int32_t*)p)[r0 + j]; break;
+    }
+  }
+}
+template <bool VEC>
 __global__ __launch_bounds__(DIRECT_BLOCK) void k_intern_claim_direct(InternCtx c, int64_t n, uint32_t n_slots, const uint64_t* __restrict__ row_mask,
                                                                      uint32_t* __restrict__ row_slot, uint32_t* __restrict__ first_row) {
   extern __shared__ uint32_t s_first[];
+  uint8_t* s_code = reinterpret_cast<uint8_t*>(s_first + n_slots);   // [keys.n][256]
   for (uint32_t x = threadIdx.x; x < n_slots; x += DIRECT_BLOCK) s_first[x] = 0xFFFFFFFFu;
+  for (int k = 0; k < c.keys.n; k++)
+    if (c.dcode[k] && threadIdx.x < 256) s_code[k * 256 + threadIdx.x] = c.dcode[k][threadIdx.x];
   __syncthreads();
   constexpr int U = DIRECT_ROWS;
   const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 63) & ~(int64_t)63;
   const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)U * DIRECT_BLOCK) {
-    int64_t rows[U];
-    uint32_t slot[U];
-    uint32_t live = 0;
+  for (int64_t r0 = lo + (int64_t)threadIdx.x * U; r0 < hi; r0 += (int64_t)U * DIRECT_BLOCK) {
+    const bool full = r0 + U <= hi;
+    uint32_t slot[U] = {0, 0, 0, 0};
+    for (int k = 0; k < c.keys.n; k++) {
+      uint64_t x[U];
+      direct_load4<VEC>(c.keys.c[k], r0, hi, full, (uint64_t)c.dmin[k], x);
+      if (c.dcode[k]) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      rows[u] = i0 + (int64_t)u * DIRECT_BLOCK;
-      if (rows[u] < hi && !(row_mask && !bit_at(row_mask, rows[u]))) live |= 1u << u;
-    }
-    direct_slots<U>(c, rows, live, slot);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (rows[u] >= hi) continue;
-      if (!((live >> u) & 1u)) {
-        if (row_slot) row_slot[rows[u]] = 0xFFFFFFFFu;
-        continue;
+        for (int j = 0; j < U; j++) x[j] = s_code[k * 256 + (int)(x[j] & 255u)];   // (dmin is 0 for a coded column)
       }
-      if ((uint32_t)rows[u] < s_first[slot[u]]) atomicMin(&s_first[slot[u]], (uint32_t)rows[u]);
-      if (row_slot) row_slot[rows[u]] = slot[u];
+#pragma unroll
+      for (int j = 0; j < U; j++) slot[j] += (uint32_t)(x[j] - (uint64_t)c.dmin[k]) * c.dstride[k];
+    }
+    uint32_t live = 0xFu;
+    if (row_mask) live = (uint32_t)(row_mask[r0 >> 6] >> (r0 & 63)) & 0xFu;   // (r0 is a multiple of 4: the four bits lie in one word)
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      if (r0 + j >= hi) live &= ~(1u << j);
+      if (!((live >> j) & 1u)) slot[j] = 0xFFFFFFFFu;
+      else if ((uint32_t)(r0 + j) < s_first[slot[j]]) atomicMin(&s_first[slot[j]], (uint32_t)(r0 + j));
+    }
+    if (row_slot) {
+      if (full) {
+        *reinterpret_cast<uint4*>(row_slot + r0) = make_uint4(slot[0], slot[1], slot[2], slot[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < U; j++)
+          if (r0 + j < hi) row_slot[r0 + j] = slot[j];
+      }
     }
   }
   __syncthreads();
@@ -1157,7 +1215,7 @@ static ColStats u8_presence(Column& c, int64_t n) {
   std::atomic_store(&c.stats, std::make_shared<ColStats>(st));
   return st;
 }
-static uint32_t direct_table_spec(std::vector<Column>& keys, int64_t n, InternCtx& ictx, std::vector<BufPtr>& keep) {
+static uint32_t direct_table_spec(std::vector<Column>& keys, const std::vector<Column*>* homes, int64_t n, InternCtx& ictx, std::vector<BufPtr>& keep) {
   Runtime& r = rt();
   const int ngk = (int)keys.size();
   std::vector<int> order((size_t)ngk);
@@ -1166,7 +1224,8 @@ static uint32_t direct_table_spec(std::vector<Column>& keys, int64_t n, InternCt
   uint64_t ranges[MAX_KEYS];
   uint64_t prod = 1;
   for (int g : order) {   // (narrow columns first: their statistics are the cheap ones)
-    Column& c = keys[(size_t)g];
+    // (the statistics live on the table's own column when the key is one: `keys` holds copies that die with this update)
+    Column& c = homes && (*homes)[(size_t)g] ? *(*homes)[(size_t)g] : keys[(size_t)g];
     const int t = c.field.type;
     if (c.validity || !(t == DFGPU_UINT8 || t == DFGPU_INT32 || t == DFGPU_DATE32 || t == DFGPU_UINT32 || t == DFGPU_INT64)) return 0;
     if (!std::atomic_load(&c.stats) && t != DFGPU_UINT8) {
@@ -1211,7 +1270,8 @@ static uint32_t direct_table_spec(std::vector<Column>& keys, int64_t n, InternCt
   }
   return (uint32_t)prod;
 }
-static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_cols, int64_t n, const uint64_t* row_mask, bool want_row_slots = false) {
+static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_cols, int64_t n, const uint64_t* row_mask, bool want_row_slots = false,
+                                const std::vector<Column*>* stat_homes = nullptr) {
   Runtime& r = rt();
   InternResult R;
   const int ngk = (int)key_cols.size();
@@ -1266,7 +1326,7 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   // with earlier groups' keys has no statistics)
   uint32_t direct_n = 0;
   if (G0 == 0 && total >= (1 << 22) && ngk >= 1 && !(std::getenv("DFGPU_AGG_DIRECT_TABLE") && std::getenv("DFGPU_AGG_DIRECT_TABLE")[0] == '0'))   // A/B knob
-    direct_n = direct_table_spec(R.cat_keys, total, ictx, R.direct_codes);
+    direct_n = direct_table_spec(R.cat_keys, stat_homes, total, ictx, R.direct_codes);
   if (direct_n) keyed = false;
   BufPtr flag = make_zero_buf(4);
   uint64_t cap = (uint64_t)A.capacity_hint;
@@ -1284,17 +1344,20 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
     R.slots = make_zero_buf((cap + 1) * 4);
     ictx.slots = R.slots->as<uint32_t>();
     ictx.mask = cap - 1;
-    ictx.direct = 1;
+    ictx.direct = (int)direct_n;
     BufPtr first = make_buf(cap * 4);
     DFGPU_HIP(hipMemsetAsync(first->ptr, 0xFF, cap * 4, r.stream));
     if (want_row_slots) R.row_slot = make_buf((size_t)total * 4);
-    const size_t lds = (size_t)direct_n * 4;
-    DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_intern_claim_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = (size_t)direct_n * 4 + (size_t)ngk * 256;
+    bool vec = true;   // 16-byte loads of four consecutive rows: every key column on a 16-byte boundary (views of partitions may not be)
+    for (int g = 0; g < ngk; g++) vec = vec && ((uintptr_t)ictx.keys.c[g].data & 15u) == 0;
+    auto kern = vec ? k_intern_claim_direct<true> : k_intern_claim_direct<false>;
+    DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = lds * 2 <= ((size_t)150 << 10) ? 2 : 1;   // (1024-thread workgroups: two per CU at most)
     const int grid = (int)std::min<int64_t>((int64_t)r.num_cus * per_cu, (total + 8191) / 8192);
     {
       ProfileScope ps("agg_intern_claim_direct", key_bytes + (R.row_slot ? total * 4 : 0));
-      k_intern_claim_direct<<<grid, DIRECT_BLOCK, lds, r.stream>>>(ictx, total, direct_n, row_mask, R.row_slot ? R.row_slot->as<uint32_t>() : nullptr, first->as<uint32_t>());
+      kern<<<grid, DIRECT_BLOCK, lds, r.stream>>>(ictx, total, direct_n, row_mask, R.row_slot ? R.row_slot->as<uint32_t>() : nullptr, first->as<uint32_t>());
       k_direct_slots_from_rows<<<grid_for((int64_t)cap, BLOCK), BLOCK, 0, r.stream>>>(first->as<uint32_t>(), cap, ictx.slots);
       DFGPU_HIP(hipGetLastError());
     }
@@ -2001,13 +2064,17 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
                                                                  PartAccSet accs, long long kmin, int wshift, unsigned long long* __restrict__ cells_v,
                                                                  int64_t vstride, uint64_t vrange, uint32_t* __restrict__ first_row_v,
                                                                  const uint64_t* __restrict__ row_mask, const uint64_t* __restrict__ row_mask_valid, int rows_in_place,
-                                                                 const uint32_t* __restrict__ key_map) {
+                                                                 const uint32_t* __restrict__ key_map, int key_map_lds) {
   extern __shared__ unsigned long long s_mem[];
   const int W = 1 << wshift;
   unsigned long long* s_cell = s_mem;                                   // [ncw][W]
   uint32_t* s_c32 = reinterpret_cast<uint32_t*>(s_mem + (size_t)accs.ncw * W);   // [n32][W]
   uint32_t* s_first = s_c32 + (size_t)accs.n32 * W;                      // [W]
+  // key_map_lds > 0: the first key_map_lds entries of key_map (all that occur) as 16-bit words behind the cells — a random LDS read
+  // per row instead of a random L1 / L2 one (0.2 against 1.2 - 2 ms per 600 M rows, profiles/r3_random_access.md)
+  uint16_t* s_map = key_map_lds > 0 ? reinterpret_cast<uint16_t*>(s_first + W) : nullptr;
   const PartBlock b = blocks[blockIdx.x];
+  for (int x = threadIdx.x; x < key_map_lds; x += PART_BLOCK) s_map[x] = (uint16_t)key_map[x];
   for (int x = threadIdx.x; x < W; x += PART_BLOCK) s_first[x] = 0xFFFFFFFFu;
   for (int k = 0; k < accs.n; k++) {
     const PartAcc& a = accs.a[k];
@@ -2020,36 +2087,74 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
   }
   __syncthreads();
   const unsigned long long base = (unsigned long long)b.part << wshift;
-  for (int64_t i = b.begin + threadIdx.x; i < b.end; i += PART_BLOCK) {
-    // (rows in place — the one-window form: the predicate's mask is looked at here instead of on the move)
-    if (row_mask && !((row_mask[i >> 6] >> (i & 63)) & 1ull)) continue;
-    if (row_mask_valid && !((row_mask_valid[i >> 6] >> (i & 63)) & 1ull)) continue;
-    // (key_map: the key column holds table slots, the value is the slot's group number — hash-interned groups in place)
-    const long long kv = key_map ? (long long)key_map[(size_t)key[i]] : (long long)key[i];
-    const int x = (int)((unsigned long long)(kv - kmin) - base);   // value index inside the window
-    if (row_id || rows_in_place) atomicMin(&s_first[x], row_id ? row_id[i] : (uint32_t)i);
-    else s_first[x] = 0u;   // (no first rows wanted: a mark that the value has a row — a plain store, every writer's the same)
+  // FOUR rows per thread at a time (round 4): their keys, then their group numbers (key_map), then each accumulator's four arguments
+  // are in flight together — one row at a time, a thread waited for key -> key_map -> LDS in turn at four waves per SIMD
+  constexpr int U = 4;
+  for (int64_t i0 = b.begin + threadIdx.x; i0 < b.end; i0 += (int64_t)U * PART_BLOCK) {
+    int64_t ii[U];
+    uint32_t live = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      ii[u] = i0 + (int64_t)u * PART_BLOCK;
+      bool ok = ii[u] < b.end;
+      // (rows in place — the one-window form: the predicate's mask is looked at here instead of on the move)
+      if (ok && row_mask) ok = (row_mask[ii[u] >> 6] >> (ii[u] & 63)) & 1ull;
+      if (ok && row_mask_valid) ok = (row_mask_valid[ii[u] >> 6] >> (ii[u] & 63)) & 1ull;
+      if (ok) live |= 1u << u;
+    }
+    if (!live) continue;
+    KT kraw[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) kraw[u] = (live >> u) & 1u ? key[ii[u]] : KT(0);
+    int x[U];
+    // (key_map: the key column holds table slots, the value is the slot's group number — hash-interned groups in place; its 16-bit
+    // copy in LDS when the launch had room for one)
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      long long kv = (long long)kraw[u];
+      if ((live >> u) & 1u) {
+        if (s_map) kv = (long long)s_map[(size_t)kraw[u]];
+        else if (key_map) kv = (long long)key_map[(size_t)kraw[u]];
+      }
+      x[u] = (int)((unsigned long long)(kv - kmin) - base);   // value index inside the window
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!((live >> u) & 1u)) continue;
+      if (row_id || rows_in_place) atomicMin(&s_first[x[u]], row_id ? row_id[ii[u]] : (uint32_t)ii[u]);
+      else s_first[x[u]] = 0u;   // (no first rows wanted: a mark that the value has a row — a plain store, every writer's the same)
+    }
     for (int k = 0; k < accs.n; k++) {
       const PartAcc& a = accs.a[k];
       if (part_acc_is_count(a.kind)) {
-        atomicAdd(&s_c32[(size_t)a.lcell32 * W + x], 1u);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if ((live >> u) & 1u) atomicAdd(&s_c32[(size_t)a.lcell32 * W + x[u]], 1u);
         continue;
       }
-      unsigned long long* c = s_cell + (size_t)a.lcell * W + x;
-      uint64_t lo = 0, hi = 0;
-      if (a.data) {
-        AccDesc d{};
-        d.values = a.data;
-        d.val = a.val;
-        load_value(d, i, lo, hi);
+      uint64_t lo[U], hi[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        lo[u] = hi[u] = 0;
+        if (a.data && ((live >> u) & 1u)) {
+          AccDesc d{};
+          d.values = a.data;
+          d.val = a.val;
+          load_value(d, ii[u], lo[u], hi[u]);
+        }
       }
-      if (a.kind == ACC_SUM_I128 && a.narrow) {   // the high word is 0 or -1: what the LDS keeps of it is 32 bits wide
-        const unsigned long long old = atomicAdd(c, (unsigned long long)lo);
-        const int32_t h = (int32_t)(uint32_t)hi + ((old + lo) < old ? 1 : 0);
-        if (h) atomicAdd(&s_c32[(size_t)a.lcell32 * W + x], (uint32_t)h);
-        continue;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (!((live >> u) & 1u)) continue;
+        unsigned long long* c = s_cell + (size_t)a.lcell * W + x[u];
+        if (a.kind == ACC_SUM_I128 && a.narrow) {   // the high word is 0 or -1: what the LDS keeps of it is 32 bits wide
+          const unsigned long long old = atomicAdd(c, (unsigned long long)lo[u]);
+          const int32_t h = (int32_t)(uint32_t)hi[u] + ((old + lo[u]) < old ? 1 : 0);
+          if (h) atomicAdd(&s_c32[(size_t)a.lcell32 * W + x[u]], (uint32_t)h);
+          continue;
+        }
+        accumulate_cell(a.kind, c, c + W, lo[u], hi[u]);   // (LDS cells)
       }
-      accumulate_cell(a.kind, c, c + W, lo, hi);   // (LDS cells)
     }
   }
   __syncthreads();
@@ -2154,6 +2259,7 @@ static int part_val_width(int val) {
 // does a range of this many values fit ONE workgroup's LDS beside at least one of these accumulators (partitioned_accumulate then
 // moves nothing)?
 constexpr size_t PART_LDS_BUDGET = (size_t)128 << 10;   // of the CU's 160 KB: one workgroup per CU at the widest windows
+constexpr size_t PART_LDS_MAX = (size_t)160 << 10;      // what a launch may ask for: the windows' cells + (in place, over table slots) the slot -> group words
 static int part_window_cap(const std::vector<PartAcc>& all) {
   int min_words = 1;
   for (const PartAcc& a : all)
@@ -2216,7 +2322,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
       case DFGPU_UINT8: fn = (const void*)k_dense_accumulate_parts<uint8_t>; break;
       default: fn = (const void*)k_dense_accumulate_parts<int32_t>; break;
     }
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_MAX) != hipSuccess) {
       // the windows and the accumulators per value above were sized for LDS_BUDGET: a device that does not grant it (none of the
       // CDNA parts this is built for) takes the global-atomic path instead of launching with more LDS than it has
       (void)hipGetLastError();
@@ -2381,12 +2487,19 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
         u++;
       }
       DFGPU_CHECK(ps.n > 0, "partitioned aggregation: an accumulator does not fit the window");
-      const size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4 * (size_t)ps.n32 + 4);
+      size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4 * (size_t)ps.n32 + 4);
+      // the slot -> group table as 16-bit words in LDS behind the cells when both fit (in place over table slots: every row looks it up)
+      int map_lds = 0;
+      if (in_place && key_map && key_map_n > 0 && range <= 65536 && lds_bytes + (size_t)key_map_n * 2 + 8 <= PART_LDS_MAX &&
+          !(std::getenv("DFGPU_AGG_LDS_KEY_MAP") && std::getenv("DFGPU_AGG_LDS_KEY_MAP")[0] == '0')) {   // A/B knob
+        map_lds = (int)key_map_n;
+        lds_bytes += (size_t)key_map_n * 2 + 8;
+      }
       switch (kt) {
-        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
-        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
-        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
-        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map); break;
+        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_lds); break;
+        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_lds); break;
+        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_lds); break;
+        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_lds); break;
       }
       DFGPU_HIP(hipGetLastError());
       first_launch = false;
@@ -2521,7 +2634,7 @@ static bool general_accumulate_partitioned(const InternCtx& ictx, const uint32_t
   if (row_slot && (ictx.keyed || ictx.direct) && partitioned_in_place((uint64_t)G1, all)) {
     // few enough groups to accumulate the rows where they lie: the slot the claim pass left for every row (a keyed table leaves one for
     // every live row) stands in for the key, its group number is looked up on the way (the slot -> group table is cache-sized)
-    if (!partitioned_accumulate(row_slot + G0, DFGPU_UINT32, n, 0, (uint64_t)G1, std::move(all), ncw, /*want_first_rows=*/false, pv, row_mask, nullptr, slot_gid, (int64_t)ictx.mask + 2)) return false;
+    if (!partitioned_accumulate(row_slot + G0, DFGPU_UINT32, n, 0, (uint64_t)G1, std::move(all), ncw, /*want_first_rows=*/false, pv, row_mask, nullptr, slot_gid, ictx.direct ? (int64_t)ictx.direct : (int64_t)ictx.mask + 2)) return false;
   } else {
     BufPtr gids = make_buf((size_t)n * 4);
     {
@@ -3695,17 +3808,13 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
     }
     // (large inputs may take the partitioned accumulation below: it wants every row's slot from the claim pass)
     const bool maybe_partitioned = n >= env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) && !(std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0');
-    IR = intern_keys(A, key_cols_keepalive, n, row_mask, maybe_partitioned);
-    if (G0 == 0)   // statistics the interning took of plain key columns belong to the table's columns (the same rows): the next query finds them
-      for (int g = 0; g < ngk; g++) {
-        int c = -1;
-        if (!is_plain_column(A.group_nodes[g], A.group_roots[g], &c) || c < 0 || c >= (int)in.cols.size()) continue;
-        Column& home = const_cast<Column&>(in.cols[(size_t)c]);
-        if (auto st = std::atomic_load(&IR.cat_keys[(size_t)g].stats)) {
-          auto had = std::atomic_load(&home.stats);
-          if (!had || (st->has_present && !had->has_present)) std::atomic_store(&home.stats, st);
-        }
-      }
+    // (statistics the interning takes of plain key columns are kept on the table's own columns — the same rows: the next query finds them)
+    std::vector<Column*> homes((size_t)ngk, nullptr);
+    for (int g = 0; g < ngk; g++) {
+      int c = -1;
+      if (is_plain_column(A.group_nodes[g], A.group_roots[g], &c) && c >= 0 && c < (int)in.cols.size()) homes[(size_t)g] = const_cast<Column*>(&in.cols[(size_t)c]);
+    }
+    IR = intern_keys(A, key_cols_keepalive, n, row_mask, maybe_partitioned, &homes);
     G1 = IR.G1;
     gs.ictx = IR.ictx;
     gs.slot_gid = IR.slot_gid->as<uint32_t>();

@@ -538,9 +538,10 @@ def test_one_grouped_move_under_a_fused_filter_with_a_decimal_sum(monkeypatch, k
     cents = rng.integers(-10**9, 10**9, n)
     x = rng.integers(0, 1000, n).astype(np.int32)
     w = rng.integers(0, 100, n).astype(np.int32)
-    import pyarrow.compute as pc
-    dcol = pc.cast(pa.array(cents), pa.decimal128(15, 0))
-    dcol = pa.Array.from_buffers(pa.decimal128(15, 2), n, dcol.buffers())                   # the same unscaled values at scale 2
+    raw = np.empty((n, 2), dtype=np.int64)                                                  # Decimal128(15, 2) from its two words
+    raw[:, 0] = cents
+    raw[:, 1] = cents >> 63
+    dcol = pa.Array.from_buffers(pa.decimal128(15, 2), n, [None, pa.py_buffer(raw.tobytes())])
     t = DeviceTable.from_arrow(pa.table({"k": pa.array(keys), "p": dcol, "x": pa.array(x), "w": pa.array(w)}))
     ops.profile_enable(True)
     ops.profile_reset()
