@@ -462,6 +462,106 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_
   }
 }
 
+// The carried sort's pass (round 4, sort_table): k_rs_scatter2 with a 16-BYTE RECORD per row in the place of the row id — the
+// columns of the output that the packed key does not hold (orders sorted by (o_orderdate, o_orderkey): o_custkey and
+// o_shippriority), so that no take by row id ends the sort.  BUILD: the first pass reads the record's fields from the source
+// columns (row = position); later passes read the records the pass before wrote.  Same ranking, same stability.
+template <int ITEMS, bool BUILD>
+__global__ __launch_bounds__(BLOCK) void k_rs_scatter_kv(const uint64_t* __restrict__ key_in, const uint4* __restrict__ rec_in, PackLayout L, int64_t n, DivBy dv, int shift,
+                                                        int bits, int64_t n_tiles, const uint64_t* __restrict__ offsets, uint64_t* __restrict__ key_out,
+                                                        uint4* __restrict__ rec_out) {
+  constexpr int TILE = BLOCK * ITEMS;
+  constexpr int NWAVE = BLOCK / WAVE;
+  __shared__ uint64_t s_key[TILE];
+  __shared__ uint4 s_rec[TILE];
+  __shared__ uint8_t s_dig[TILE];
+  __shared__ unsigned int s_cnt[NWAVE][256];
+  __shared__ unsigned int s_start[256];
+  __shared__ unsigned int s_wtot[NWAVE];
+  __shared__ unsigned long long s_goff[256];
+  const unsigned mask = (1u << bits) - 1u;
+  const int wave = threadIdx.x >> 6;
+  const unsigned lane = lane_id();
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t lo = t * TILE;
+    const int tile_rows = (int)((n - lo) < TILE ? (n - lo) : TILE);
+#pragma unroll
+    for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+    if ((int)threadIdx.x <= (int)mask) s_goff[threadIdx.x] = offsets[(int64_t)threadIdx.x * n_tiles + t];
+    __syncthreads();
+    uint64_t key[ITEMS];
+    uint4 rec[ITEMS];
+    unsigned dig[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {  // all loads of the segment in flight together
+      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+      const int64_t src = lo + (j < tile_rows ? j : 0);
+      key[c] = key_in[src];
+      if (BUILD) {
+        uint64_t sl[2];
+        record_build<2>(L, src, sl);
+        rec[c] = uint4{(unsigned)sl[0], (unsigned)(sl[0] >> 32), (unsigned)sl[1], (unsigned)(sl[1] >> 32)};
+      } else {
+        rec[c] = rec_in[src];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+      const bool in = j < tile_rows;
+      dig[c] = in ? ((unsigned)(div_apply(key[c], dv) >> shift) & mask) : 0u;
+      uint64_t peers = ballot64(in);
+      for (int b = 0; b < bits; b++) {
+        const uint64_t bal = ballot64((dig[c] >> b) & 1u);
+        peers &= ((dig[c] >> b) & 1u) ? bal : ~bal;
+      }
+      const unsigned r_in_wave = mbcnt(peers);
+      const unsigned base = s_cnt[wave][dig[c]];
+      if (in && r_in_wave == 0) s_cnt[wave][dig[c]] = base + (unsigned)__popcll(peers);
+      rank[c] = base + r_in_wave;
+    }
+    __syncthreads();
+    {
+      unsigned run = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; w++) {
+        const unsigned v = s_cnt[w][threadIdx.x];
+        s_cnt[w][threadIdx.x] = run;
+        run += v;
+      }
+      const unsigned inc = wave_inclusive_sum<unsigned>(run);
+      if (lane == 63) s_wtot[wave] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; w++) base += s_wtot[w];
+      s_start[threadIdx.x] = base + inc - run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+      if (j < tile_rows) {
+        const unsigned q = s_start[dig[c]] + s_cnt[wave][dig[c]] + rank[c];
+        s_key[q] = key[c];
+        s_rec[q] = rec[c];
+        s_dig[q] = (uint8_t)dig[c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int q = c * BLOCK + threadIdx.x;
+      if (q < tile_rows) {
+        const unsigned d = s_dig[q];
+        const unsigned long long dst = s_goff[d] + (unsigned)(q - (int)s_start[d]);
+        key_out[dst] = s_key[q];
+        rec_out[dst] = s_rec[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // The clustered take's pass (sort_table): one stable scatter of the packed keys by the TOP digit of their bucket number that also
 // carries every row's payload as ONE row-major record (records.hpp).  Afterwards rows whose keys are close sit close together
 // in `rec`, the row id of a key is its position in this order, and the take that ends the sort reads records from a window of
@@ -740,10 +840,44 @@ __global__ __launch_bounds__(BLOCK) void k_bucket_max(const uint32_t* __restrict
   if (lane_id() == 0 && mx) atomicMax(max_size, mx);
 }
 
+// What the carried sort's last step writes instead of row ids: the key columns DECODED from the sorted packed key (mixed radix:
+// digit_c = key / mult_c mod range_c, value = base +- digit — pack_key64 read backwards; integer / date columns without NULLs) and
+// the record's fields.
+struct SortEmit {
+  int n_keys;
+  void* key_dst[MAX_SORT_KEYS];
+  int key_type[MAX_SORT_KEYS];
+  int key_desc[MAX_SORT_KEYS];
+  uint64_t key_base[MAX_SORT_KEYS], key_mult[MAX_SORT_KEYS];
+  DivBy key_div[MAX_SORT_KEYS];
+  const uint4* rec;     // records in the order the top passes left (id = position there)
+  PackLayout fields;    // the record's fields and their output columns (dst)
+};
+__device__ __forceinline__ void sort_emit_row(const SortEmit& e, uint64_t full_key, uint32_t id, int64_t pos) {
+  uint64_t rem = full_key;
+  for (int c = 0; c < e.n_keys; c++) {   // most significant column first
+    const uint64_t digit = div_apply(rem, e.key_div[c]);
+    rem -= digit * e.key_mult[c];
+    const uint64_t t = e.key_desc[c] ? e.key_base[c] - digit : e.key_base[c] + digit;
+    switch (e.key_type[c]) {
+      case DFGPU_INT32: case DFGPU_DATE32: reinterpret_cast<int32_t*>(e.key_dst[c])[pos] = (int32_t)((uint32_t)t ^ 0x80000000u); break;
+      case DFGPU_UINT32: reinterpret_cast<uint32_t*>(e.key_dst[c])[pos] = (uint32_t)t; break;
+      case DFGPU_INT64: reinterpret_cast<uint64_t*>(e.key_dst[c])[pos] = t ^ 0x8000000000000000ull; break;
+      case DFGPU_UINT64: reinterpret_cast<uint64_t*>(e.key_dst[c])[pos] = t; break;
+      default: reinterpret_cast<uint8_t*>(e.key_dst[c])[pos] = (uint8_t)t; break;
+    }
+  }
+  if (e.fields.n > 0) {
+    const uint4 v = e.rec[id];   // (inside the bucket's few tens of KB of records: cache hits)
+    const uint64_t sl[2] = {((uint64_t)v.y << 32) | v.x, ((uint64_t)v.w << 32) | v.z};
+    record_split<2>(e.fields, pos, sl);
+  }
+}
 // one workgroup per bucket: stable LSD sort of the bucket's (key, id) elements by the key's low `low_bits` bits, in LDS
-template <typename LK>  // the key inside its bucket: 32 bits when `width` allows (less LDS and registers: more buckets in flight per CU)
+template <typename LK, bool EMIT = false>  // the key inside its bucket: 32 bits when `width` allows (less LDS and registers: more buckets in flight per CU)
 __global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ starts,
-                                                      const uint32_t* __restrict__ ends, int64_t n_buckets, uint64_t width, int low_bits, uint32_t* __restrict__ idx_out) {
+                                                      const uint32_t* __restrict__ ends, int64_t n_buckets, uint64_t width, int low_bits, uint32_t* __restrict__ idx_out,
+                                                      SortEmit emit = SortEmit{}) {
   constexpr int NWAVE = BLOCK / WAVE;
   __shared__ LK s_key[LS_CAP];
   __shared__ uint32_t s_idx[LS_CAP];
@@ -840,7 +974,9 @@ __global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict
     for (int c = 0; c < LS_ITEMS; c++) {
       if (c >= items) continue;
       const int j = (wave * items + c) * WAVE + (int)lane;
-      if (j < m) idx_out[(int64_t)lo + j] = id[c];
+      if (j >= m) continue;
+      if (EMIT) sort_emit_row(emit, (uint64_t)b * width + (uint64_t)k[c], id[c], (int64_t)lo + j);
+      else idx_out[(int64_t)lo + j] = id[c];
     }
   }
 }
@@ -952,6 +1088,120 @@ Table sort_table_ascending(const Table& in, const std::vector<int>& key_cols) {
   const std::vector<uint8_t> zeros(key_cols.size(), 0);
   return sort_table(in, key_cols, zeros.data(), zeros.data(), -1);
 }
+__global__ __launch_bounds__(BLOCK) void k_build_records16(PackLayout L, int64_t n, uint4* __restrict__ rec) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint64_t sl[2];
+    record_build<2>(L, i, sl);
+    rec[i] = uint4{(unsigned)sl[0], (unsigned)(sl[0] >> 32), (unsigned)sl[1], (unsigned)(sl[1] >> 32)};
+  }
+}
+// the carried sort (see sort_table); false = does not apply (nothing was touched: `keys` are intact)
+static bool sort_carried(const Table& in, const std::vector<int>& key_cols, const PackCols& pc, const BufPtr& keys, int64_t n, uint64_t key_space, Table& out) {
+  Runtime& r = rt();
+  static const bool off = std::getenv("DFGPU_SORT_CARRIED") && std::getenv("DFGPU_SORT_CARRIED")[0] == '0';   // A/B knob
+  const char* min_env = std::getenv("DFGPU_SORT_CARRIED_MIN_ROWS");   // test knob (default: 4 Mi rows — below that the take's lines are cache hits)
+  const int64_t min_rows = min_env ? std::atoll(min_env) : ((int64_t)1 << 22);
+  if (off || n < min_rows || n < 2 || n >= 0xFFFFFFFFll || key_space < 2) return false;
+  // every key column can be read back from the packed key
+  for (int k = 0; k < pc.n; k++) {
+    const PackCol& c = pc.c[k];
+    const bool int_like = c.type == DFGPU_INT32 || c.type == DFGPU_DATE32 || c.type == DFGPU_UINT32 || c.type == DFGPU_INT64 || c.type == DFGPU_UINT64 || c.type == DFGPU_UINT8;
+    if (c.valid || c.has_null_bit || !int_like || c.range == 0 || c.mult == 0) return false;
+  }
+  // the other columns: one 16-byte record
+  std::vector<int> payload;
+  for (int c = 0; c < (int)in.cols.size(); c++)
+    if (std::find(key_cols.begin(), key_cols.end(), c) == key_cols.end()) payload.push_back(c);
+  PackLayout L{};
+  int R = 0;
+  std::vector<int> order;
+  if (payload.empty() || !plan_record_layout(in, payload, L, R, order) || R != 16) return false;
+  // buckets as sorted_ids_local cuts them
+  int top_bits = 0;
+  while (top_bits < 32 && (n >> top_bits) > 2304) top_bits += 8;
+  if ((key_space >> top_bits) < 2) return false;
+  const int64_t n_buckets = (int64_t)1 << top_bits;
+  const uint64_t width = (key_space + (uint64_t)n_buckets - 1) / (uint64_t)n_buckets;
+  int low_bits = 0;
+  while (low_bits < 64 && ((width - 1) >> low_bits)) low_bits++;
+  if (low_bits == 0) return false;
+  constexpr int ITEMS = 8;
+  const int64_t tile = (int64_t)BLOCK * ITEMS, n_tiles = (n + tile - 1) / tile;
+  BufPtr cur_key = keys, cur_rec;
+  if (top_bits) {
+    BufPtr counts = make_buf((size_t)256 * n_tiles * 4), offsets = make_buf((size_t)(256 * n_tiles + 1) * 8);
+    BufPtr key_a = make_buf((size_t)n * 8), key_b = top_bits > 8 ? make_buf((size_t)n * 8) : nullptr;
+    BufPtr rec_a = make_buf((size_t)n * 16), rec_b = top_bits > 8 ? make_buf((size_t)n * 16) : nullptr;
+    const int grid = (int)std::min<int64_t>(n_tiles, 256 * 8);
+    const DivBy dv = div_by(width);
+    int payload_bytes = 0;
+    for (int q = 0; q < L.n; q++) payload_bytes += L.width[q];
+    bool first = true;
+    for (int pos = 0; pos < top_bits; pos += 8) {
+      const int bits = std::min(8, top_bits - pos);
+      BufPtr& dst_key = first || cur_key == key_b ? key_a : key_b;
+      BufPtr& dst_rec = first || cur_rec == rec_b ? rec_a : rec_b;
+      ProfileScope ps("sort_carried_pass", n * 8 + n * (int64_t)(8 + (first ? payload_bytes : 16) + 8 + 16));
+      k_rs_hist<<<grid, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), n, dv, pos, bits, ITEMS, n_tiles, counts->as<uint32_t>());
+      scan_u32(counts->as<uint32_t>(), (int64_t)(1 << bits) * n_tiles, offsets->as<uint64_t>());
+      if (first)
+        k_rs_scatter_kv<ITEMS, true><<<grid, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), nullptr, L, n, dv, pos, bits, n_tiles, offsets->as<uint64_t>(), dst_key->as<uint64_t>(), dst_rec->as<uint4>());
+      else
+        k_rs_scatter_kv<ITEMS, false><<<grid, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), cur_rec->as<uint4>(), L, n, dv, pos, bits, n_tiles, offsets->as<uint64_t>(), dst_key->as<uint64_t>(), dst_rec->as<uint4>());
+      DFGPU_HIP(hipGetLastError());
+      cur_key = dst_key;
+      cur_rec = dst_rec;
+      first = false;
+    }
+  } else {
+    cur_rec = make_buf((size_t)n * 16 + 64);   // (a table of one bucket: no top pass to build the records on the way)
+    k_build_records16<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(L, n, cur_rec->as<uint4>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  BufPtr starts = make_zero_buf((size_t)n_buckets * 4), ends = make_zero_buf((size_t)n_buckets * 4), mx = make_zero_buf(4);
+  {
+    ProfileScope ps("sort_bucket_bounds", n * 8);
+    k_bucket_bounds<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), n, div_by(width), starts->as<uint32_t>(), ends->as<uint32_t>());
+    k_bucket_max<<<grid_for(n_buckets, BLOCK), BLOCK, 0, r.stream>>>(starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, mx->as<unsigned>());
+  }
+  unsigned largest = 0;
+  d2h(&largest, mx->ptr, 4);
+  if (largest > (unsigned)LS_CAP) return false;  // skewed keys: the caller's paths (the packed keys are intact)
+  // the output columns and who writes them
+  out.cols.assign(in.cols.size(), Column{});
+  SortEmit e{};
+  e.n_keys = pc.n;
+  int out_bytes = 0;
+  for (int k = 0; k < pc.n; k++) {
+    const int c = key_cols[(size_t)k];
+    if (!out.cols[(size_t)c].data) out.cols[(size_t)c] = alloc_like(in.cols[(size_t)c], n);
+    e.key_dst[k] = out.cols[(size_t)c].data->ptr;
+    e.key_type[k] = pc.c[k].type;
+    e.key_desc[k] = pc.c[k].desc;
+    e.key_base[k] = pc.c[k].base_lo;
+    e.key_mult[k] = pc.c[k].mult;
+    e.key_div[k] = div_by(pc.c[k].mult);
+    out_bytes += type_width(in.cols[(size_t)c].field.type);
+  }
+  e.rec = cur_rec->as<uint4>();
+  e.fields = L;
+  for (int q = 0; q < L.n; q++) {
+    const int c = payload[(size_t)order[(size_t)q]];
+    out.cols[(size_t)c] = alloc_like(in.cols[(size_t)c], n);
+    e.fields.dst[q] = out.cols[(size_t)c].data->ptr;
+    out_bytes += L.width[q];
+  }
+  {
+    ProfileScope ps("sort_local_emit", n * (int64_t)(8 + 16 + out_bytes));
+    const unsigned lg = (unsigned)std::min<int64_t>(n_buckets, (int64_t)r.num_cus * 16);
+    if (low_bits <= 32) k_local_sort<uint32_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), nullptr, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
+    else k_local_sort<uint64_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), nullptr, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
+    DFGPU_HIP(hipGetLastError());
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  return true;
+}
+
 static Table sort_table(const Table& in, const std::vector<int>& key_cols, const uint8_t* desc, const uint8_t* nulls_first, int64_t fetch) {
   Runtime& r = rt();
   const int64_t n = in.nrows;
@@ -1158,6 +1408,14 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     }
     std::vector<int> allc(in.cols.size());
     for (size_t i = 0; i < allc.size(); i++) allc[i] = (int)i;
+    // ---- carried sort (round 4): a full sort whose key is one mixed-radix word over integer / date columns without NULLs and whose
+    // OTHER columns fit a 16-byte record.  The record travels with the key through the top passes (the first pass reads it from the
+    // source columns), the bucket sort in LDS writes the OUTPUT: key columns decoded from the sorted key, the record's fields from
+    // the bucket's records.  No row ids, no take: orders by (o_orderdate, o_orderkey DESC) R4SORT ms against 11.9 (the take alone was
+    // 5.7: a random line per row, profiles/r3_sort_clustered.md).
+    if (!remap && narrow && nwords == 1 && !sk.idx && n_out == n && m == n &&
+        sort_carried(in, key_cols, pc, sk.w[0], n, key_space, out))
+      return out;
     // ---- clustered take: a full sort of a table far beyond the Infinity Cache whose columns fit ONE record.  Sorting row ids and
     // taking the rows afterwards reads a random 128-byte line per row and column group (150 M orders: 19.9 GB for 4.8 GB of
     // records, profiles/r2_ops_v3_traffic.md).  Instead ONE extra stable pass (k_rs_scatter_rec) moves keys AND records into the

@@ -232,6 +232,63 @@ def test_sort_clustered_take_carries_records_through_the_top_digit_pass(shape):
         os.environ.pop("DFGPU_SORT_CLUSTERED_TAKE", None)
 
 
+@pytest.mark.parametrize("shape", ["orders_shape", "one_bucket", "three_keys_u8_date_desc", "payload_of_exactly_16_bytes", "skewed_top_bits", "heavy_ties",
+                                   "payload_too_wide", "nullable_key", "uint32_and_negative_keys"])
+def test_sort_carried_records_and_keys_decoded_from_the_packed_key(monkeypatch, shape):
+    """round 4, the carried sort (sort.hip sort_carried; forced here for tables of a few MB): the columns the packed key does not hold
+    travel with it as a 16-byte record through the top passes, the LDS bucket sort writes the output — key columns DECODED from the
+    sorted mixed-radix key (ASC and DESC, dates, negative and unsigned values, UInt8), payload fields from the records — and no take
+    by row id runs.  Same stable order as the oracle position by position (ties keep their input order: the payload tells).  Shapes
+    it must decline and leave to the other paths: a payload beyond 16 bytes, a nullable key column, buckets beyond the LDS capacity"""
+    from datafusion_amd import ops
+    rng = np.random.default_rng(len(shape) * 7)
+    n = 700_000
+    carried = True
+    if shape == "orders_shape":
+        t = pa.table({"o_orderkey": pa.array(rng.permutation(n).astype(np.int64) * 4 + 1), "o_custkey": pa.array(rng.integers(1, 10**6, n)),
+                      "o_orderdate": pa.array(rng.integers(8035, 10441, n).astype(np.int32), pa.int32()).cast(pa.date32()),
+                      "o_shippriority": pa.array(rng.integers(0, 3, n).astype(np.int32))})
+        keys = [("o_orderdate", False, False), ("o_orderkey", True, False)]
+    elif shape == "one_bucket":
+        n = 1500                                                                                    # fewer rows than one bucket holds: no top pass, records built on their own
+        t = pa.table({"a": pa.array(rng.integers(-50, 50, n)), "v": pa.array(np.arange(n, dtype=np.int64)), "w": pa.array(rng.integers(0, 255, n).astype(np.uint8))})
+        keys = [("a", True, False)]
+    elif shape == "three_keys_u8_date_desc":
+        t = pa.table({"c": pa.array(rng.integers(3, 9, n).astype(np.uint8)), "d": pa.array(rng.integers(9000, 9400, n).astype(np.int32), pa.int32()).cast(pa.date32()),
+                      "k": pa.array(rng.integers(-10**6, 10**6, n)), "v": pa.array(np.arange(n, dtype=np.int32)), "x": pa.array(rng.integers(0, 2**40, n))})
+        keys = [("c", True, False), ("d", False, False), ("k", True, False)]
+    elif shape == "payload_of_exactly_16_bytes":
+        t = pa.table({"a": pa.array(rng.integers(-2**40, 2**40, size=n)), "v": pa.array(np.arange(n, dtype=np.int64)), "w": pa.array(rng.integers(-2**62, 2**62, n))})
+        keys = [("a", False, False)]
+    elif shape == "skewed_top_bits":                                                                # three values hold the top bits: buckets beyond the LDS capacity
+        t = pa.table({"a": pa.array((rng.integers(0, 3, size=n) << 40) + rng.integers(0, 2**20, size=n)), "v": pa.array(np.arange(n, dtype=np.int64))})
+        keys, carried = [("a", True, False)], False
+    elif shape == "heavy_ties":                                                                     # seven distinct keys: a bucket holds a seventh of the rows
+        t = pa.table({"a": pa.array(rng.integers(0, 7, size=n) * 10**9), "v": pa.array(np.arange(n, dtype=np.int64)), "w": pa.array(rng.integers(0, 255, n).astype(np.uint8))})
+        keys, carried = [("a", False, False)], False
+    elif shape == "payload_too_wide":
+        t = pa.table({"a": pa.array(rng.integers(-2**40, 2**40, size=n)), "v": pa.array(np.arange(n, dtype=np.int64)), "w": pa.array(rng.integers(0, 9, n)), "x": pa.array(rng.integers(0, 9, n).astype(np.int32))})
+        keys, carried = [("a", False, False)], False
+    elif shape == "nullable_key":
+        t = pa.table({"a": pa.array(rng.integers(-2**40, 2**40, size=n), mask=rng.random(n) < 0.01), "v": pa.array(np.arange(n, dtype=np.int64))})
+        keys, carried = [("a", False, True)], False
+    else:
+        t = pa.table({"u": pa.array(rng.integers(2**31, 2**32 - 1, n).astype(np.uint32)), "s": pa.array(rng.integers(-2**31, -2**30, n).astype(np.int32)),
+                      "v": pa.array(np.arange(n, dtype=np.int64))})
+        keys = [("s", False, False), ("u", True, False)]
+    monkeypatch.setenv("DFGPU_SORT_CARRIED_MIN_ROWS", "0")
+    ops.profile_enable(True)
+    ops.profile_reset()
+    run_sort(t, keys)
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    if carried:
+        assert "sort_local_emit" in stats and "take_gather_rows" not in stats and "gather" not in stats, sorted(stats)
+        assert ("sort_carried_pass" in stats) == (shape != "one_bucket"), sorted(stats)
+    else:
+        assert "sort_local_emit" not in stats, sorted(stats)
+
+
 def test_sort_and_joins_move_boolean_payload_columns():
     """take of a bit-packed column (SortExec's output, the general join path's gathers): Boolean payload with NULLs"""
     from datafusion_amd import ops
