@@ -472,9 +472,10 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter_kv(const uint64_t* __restr
                                                         uint4* __restrict__ rec_out) {
   constexpr int TILE = BLOCK * ITEMS;
   constexpr int NWAVE = BLOCK / WAVE;
-  __shared__ uint64_t s_key[TILE];
-  __shared__ uint4 s_rec[TILE];
-  __shared__ uint8_t s_dig[TILE];
+  extern __shared__ __align__(16) unsigned char kv_smem[];   // records | keys | digits of the staged tile (beyond the 64 KB static LDS allows at 16 rows per thread)
+  uint4* s_rec = reinterpret_cast<uint4*>(kv_smem);
+  uint64_t* s_key = reinterpret_cast<uint64_t*>(kv_smem + (size_t)TILE * 16);
+  uint8_t* s_dig = kv_smem + (size_t)TILE * 24;
   __shared__ unsigned int s_cnt[NWAVE][256];
   __shared__ unsigned int s_start[256];
   __shared__ unsigned int s_wtot[NWAVE];
@@ -853,7 +854,7 @@ struct SortEmit {
   const uint4* rec;     // records in the order the top passes left (id = position there)
   PackLayout fields;    // the record's fields and their output columns (dst)
 };
-__device__ __forceinline__ void sort_emit_row(const SortEmit& e, uint64_t full_key, uint32_t id, int64_t pos) {
+__device__ __forceinline__ void sort_emit_row(const SortEmit& e, uint64_t full_key, const uint4& v, int64_t pos) {
   uint64_t rem = full_key;
   for (int c = 0; c < e.n_keys; c++) {   // most significant column first
     const uint64_t digit = div_apply(rem, e.key_div[c]);
@@ -868,7 +869,6 @@ __device__ __forceinline__ void sort_emit_row(const SortEmit& e, uint64_t full_k
     }
   }
   if (e.fields.n > 0) {
-    const uint4 v = e.rec[id];   // (inside the bucket's few tens of KB of records: cache hits)
     const uint64_t sl[2] = {((uint64_t)v.y << 32) | v.x, ((uint64_t)v.w << 32) | v.z};
     record_split<2>(e.fields, pos, sl);
   }
@@ -904,6 +904,8 @@ __global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict
       k[c] = (LK)(key[src] - (uint64_t)b * width);  // the key inside its bucket: < width <= 2^low_bits
       id[c] = idx_in ? idx_in[src] : (uint32_t)src;
     }
+    // (EMIT: asking for the records' lines here, ahead of the LDS passes — one word of each kept in a register until the end — was
+    // measured and lost: sort_local_emit 5.4 -> 6.8 ms; the early loads are waited for at the first barrier)
     if (m > 1) {
       int pos = 0;
       for (int p = 0; p < n_pass; p++) {
@@ -970,13 +972,25 @@ __global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict
         pos += bits;
       }
     }
+    if (EMIT) {
+      // (the records are fetched row by row between the stores.  Fetching a thread's sixteen first took the kernel to 256 VGPRs and one
+      // wave per SIMD: 10.4 ms; four at a time: 5.6 ms against 5.4 — what bounds this step is a random line of HBM per row)
+#pragma unroll
+      for (int c = 0; c < LS_ITEMS; c++) {
+        if (c >= items) continue;
+        const int j = (wave * items + c) * WAVE + (int)lane;
+        if (j >= m) continue;
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (emit.fields.n > 0) v = emit.rec[id[c]];
+        sort_emit_row(emit, (uint64_t)b * width + (uint64_t)k[c], v, (int64_t)lo + j);
+      }
+      continue;
+    }
 #pragma unroll
     for (int c = 0; c < LS_ITEMS; c++) {
       if (c >= items) continue;
       const int j = (wave * items + c) * WAVE + (int)lane;
-      if (j >= m) continue;
-      if (EMIT) sort_emit_row(emit, (uint64_t)b * width + (uint64_t)k[c], id[c], (int64_t)lo + j);
-      else idx_out[(int64_t)lo + j] = id[c];
+      if (j < m) idx_out[(int64_t)lo + j] = id[c];
     }
   }
 }
@@ -1096,9 +1110,15 @@ __global__ __launch_bounds__(BLOCK) void k_build_records16(PackLayout L, int64_t
   }
 }
 // the carried sort (see sort_table); false = does not apply (nothing was touched: `keys` are intact)
-static bool sort_carried(const Table& in, const std::vector<int>& key_cols, const PackCols& pc, const BufPtr& keys, int64_t n, uint64_t key_space, Table& out) {
+static bool sort_carried(const Table& in, const std::vector<int>& key_cols, const PackCols& pc, const BufPtr& keys, int64_t n, uint64_t key_space, Table& out,
+                         bool& clobbered) {
   Runtime& r = rt();
-  static const bool off = std::getenv("DFGPU_SORT_CARRIED") && std::getenv("DFGPU_SORT_CARRIED")[0] == '0';   // A/B knob
+  clobbered = false;
+  // DFGPU_SORT_CARRIED: 0 = off; passes = the records travel through the top passes (measured: what the take saves the passes lose,
+  // 12.0 ms either way for 150 M orders); default = row ids through the passes as before, records taken by row id INSIDE the bucket sort
+  const char* mode_env = std::getenv("DFGPU_SORT_CARRIED");
+  const bool off = mode_env && mode_env[0] == '0';
+  const bool through_passes = mode_env && mode_env[0] == 'p';
   const char* min_env = std::getenv("DFGPU_SORT_CARRIED_MIN_ROWS");   // test knob (default: 4 Mi rows — below that the take's lines are cache hits)
   const int64_t min_rows = min_env ? std::atoll(min_env) : ((int64_t)1 << 22);
   if (off || n < min_rows || n < 2 || n >= 0xFFFFFFFFll || key_space < 2) return false;
@@ -1125,10 +1145,32 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
   int low_bits = 0;
   while (low_bits < 64 && ((width - 1) >> low_bits)) low_bits++;
   if (low_bits == 0) return false;
-  constexpr int ITEMS = 8;
+  const int ITEMS = std::getenv("DFGPU_SORT_CARRIED_ITEMS") ? std::atoi(std::getenv("DFGPU_SORT_CARRIED_ITEMS")) : 8;   // tuning knob: 4, 8 or 16 rows per thread
+  DFGPU_CHECK(ITEMS == 4 || ITEMS == 8 || ITEMS == 16, "DFGPU_SORT_CARRIED_ITEMS: 4, 8 or 16");
   const int64_t tile = (int64_t)BLOCK * ITEMS, n_tiles = (n + tile - 1) / tile;
-  BufPtr cur_key = keys, cur_rec;
-  if (top_bits) {
+  BufPtr cur_key = keys, cur_rec, cur_idx;
+  if (!through_passes) {
+    // records in the input's row order (one streaming pass), row ids through the top passes
+    cur_rec = make_buf((size_t)n * 16 + 64);
+    {
+      int payload_bytes = 0;
+      for (int q = 0; q < L.n; q++) payload_bytes += L.width[q];
+      ProfileScope ps("sort_build_records", n * (int64_t)(payload_bytes + 16));
+      k_build_records16<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(L, n, cur_rec->as<uint4>());
+      DFGPU_HIP(hipGetLastError());
+    }
+    if (top_bits) {
+      SortedKeys sk0;
+      sk0.nwords = 1;
+      sk0.w[0] = keys;
+      std::vector<Digit> top;
+      for (int pos = 0; pos < top_bits; pos += 8) top.push_back({0, pos, std::min(8, top_bits - pos), width});
+      SortedKeys cur = radix_sort(sk0, n, top);
+      clobbered = true;   // (the key buffer was scratch of the passes)
+      cur_key = cur.w[0];
+      cur_idx = cur.idx;
+    }
+  } else if (top_bits) {
     BufPtr counts = make_buf((size_t)256 * n_tiles * 4), offsets = make_buf((size_t)(256 * n_tiles + 1) * 8);
     BufPtr key_a = make_buf((size_t)n * 8), key_b = top_bits > 8 ? make_buf((size_t)n * 8) : nullptr;
     BufPtr rec_a = make_buf((size_t)n * 16), rec_b = top_bits > 8 ? make_buf((size_t)n * 16) : nullptr;
@@ -1144,10 +1186,21 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
       ProfileScope ps("sort_carried_pass", n * 8 + n * (int64_t)(8 + (first ? payload_bytes : 16) + 8 + 16));
       k_rs_hist<<<grid, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), n, dv, pos, bits, ITEMS, n_tiles, counts->as<uint32_t>());
       scan_u32(counts->as<uint32_t>(), (int64_t)(1 << bits) * n_tiles, offsets->as<uint64_t>());
-      if (first)
-        k_rs_scatter_kv<ITEMS, true><<<grid, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), nullptr, L, n, dv, pos, bits, n_tiles, offsets->as<uint64_t>(), dst_key->as<uint64_t>(), dst_rec->as<uint4>());
-      else
-        k_rs_scatter_kv<ITEMS, false><<<grid, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), cur_rec->as<uint4>(), L, n, dv, pos, bits, n_tiles, offsets->as<uint64_t>(), dst_key->as<uint64_t>(), dst_rec->as<uint4>());
+      auto launch = [&](auto kern) {
+        const size_t lds = (size_t)tile * (8 + 16 + 1);
+        DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, BLOCK, lds, r.stream>>>(cur_key->as<uint64_t>(), first ? nullptr : cur_rec->as<uint4>(), L, n, dv, pos, bits, n_tiles, offsets->as<uint64_t>(),
+                                           dst_key->as<uint64_t>(), dst_rec->as<uint4>());
+      };
+      if (first) {
+        if (ITEMS == 4) launch(k_rs_scatter_kv<4, true>);
+        else if (ITEMS == 8) launch(k_rs_scatter_kv<8, true>);
+        else launch(k_rs_scatter_kv<16, true>);
+      } else {
+        if (ITEMS == 4) launch(k_rs_scatter_kv<4, false>);
+        else if (ITEMS == 8) launch(k_rs_scatter_kv<8, false>);
+        else launch(k_rs_scatter_kv<16, false>);
+      }
       DFGPU_HIP(hipGetLastError());
       cur_key = dst_key;
       cur_rec = dst_rec;
@@ -1194,8 +1247,9 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
   {
     ProfileScope ps("sort_local_emit", n * (int64_t)(8 + 16 + out_bytes));
     const unsigned lg = (unsigned)std::min<int64_t>(n_buckets, (int64_t)r.num_cus * 16);
-    if (low_bits <= 32) k_local_sort<uint32_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), nullptr, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
-    else k_local_sort<uint64_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), nullptr, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
+    const uint32_t* idp = cur_idx ? cur_idx->as<uint32_t>() : nullptr;   // (null: a row's id is its position — in the top passes' order, or of a one-bucket input)
+    if (low_bits <= 32) k_local_sort<uint32_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), idp, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
+    else k_local_sort<uint64_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), idp, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
     DFGPU_HIP(hipGetLastError());
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));
@@ -1410,12 +1464,14 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     for (size_t i = 0; i < allc.size(); i++) allc[i] = (int)i;
     // ---- carried sort (round 4): a full sort whose key is one mixed-radix word over integer / date columns without NULLs and whose
     // OTHER columns fit a 16-byte record.  The record travels with the key through the top passes (the first pass reads it from the
-    // source columns), the bucket sort in LDS writes the OUTPUT: key columns decoded from the sorted key, the record's fields from
-    // the bucket's records.  No row ids, no take: orders by (o_orderdate, o_orderkey DESC) R4SORT ms against 11.9 (the take alone was
-    // 5.7: a random line per row, profiles/r3_sort_clustered.md).
-    if (!remap && narrow && nwords == 1 && !sk.idx && n_out == n && m == n &&
-        sort_carried(in, key_cols, pc, sk.w[0], n, key_space, out))
-      return out;
+    // source columns — or, the default, row ids travel and the records are fetched by row id), the bucket sort in LDS writes the OUTPUT: key
+    // columns decoded from the sorted key, the record's fields from the records.  No separate take: orders by (o_orderdate, o_orderkey DESC)
+    // 10.5 ms against 11.9 (the take alone was 5.7: a random line per row, profiles/r3_sort_clustered.md).
+    if (!remap && narrow && nwords == 1 && !sk.idx && n_out == n && m == n) {
+      bool keys_clobbered = false;
+      if (sort_carried(in, key_cols, pc, sk.w[0], n, key_space, out, keys_clobbered)) return out;
+      if (keys_clobbered) pack_keys();   // (skewed keys: the paths below start from the packed keys again)
+    }
     // ---- clustered take: a full sort of a table far beyond the Infinity Cache whose columns fit ONE record.  Sorting row ids and
     // taking the rows afterwards reads a random 128-byte line per row and column group (150 M orders: 19.9 GB for 4.8 GB of
     // records, profiles/r2_ops_v3_traffic.md).  Instead ONE extra stable pass (k_rs_scatter_rec) moves keys AND records into the

@@ -234,11 +234,12 @@ def test_sort_clustered_take_carries_records_through_the_top_digit_pass(shape):
 
 @pytest.mark.parametrize("shape", ["orders_shape", "one_bucket", "three_keys_u8_date_desc", "payload_of_exactly_16_bytes", "skewed_top_bits", "heavy_ties",
                                    "payload_too_wide", "nullable_key", "uint32_and_negative_keys"])
-def test_sort_carried_records_and_keys_decoded_from_the_packed_key(monkeypatch, shape):
+@pytest.mark.parametrize("mode", ["records_by_row_id", "records_through_the_passes"])
+def test_sort_carried_records_and_keys_decoded_from_the_packed_key(monkeypatch, shape, mode):
     """round 4, the carried sort (sort.hip sort_carried; forced here for tables of a few MB): the columns the packed key does not hold
-    travel with it as a 16-byte record through the top passes, the LDS bucket sort writes the output — key columns DECODED from the
-    sorted mixed-radix key (ASC and DESC, dates, negative and unsigned values, UInt8), payload fields from the records — and no take
-    by row id runs.  Same stable order as the oracle position by position (ties keep their input order: the payload tells).  Shapes
+    become ONE 16-byte record per row — fetched by row id inside the LDS bucket sort (the default) or travelling with the key through
+    the top passes (DFGPU_SORT_CARRIED=passes) — and the bucket sort writes the output: key columns DECODED from the sorted mixed-radix
+    key (ASC and DESC, dates, negative and unsigned values, UInt8), payload fields from the records.  No separate take runs.  Same stable order as the oracle position by position (ties keep their input order: the payload tells).  Shapes
     it must decline and leave to the other paths: a payload beyond 16 bytes, a nullable key column, buckets beyond the LDS capacity"""
     from datafusion_amd import ops
     rng = np.random.default_rng(len(shape) * 7)
@@ -277,6 +278,8 @@ def test_sort_carried_records_and_keys_decoded_from_the_packed_key(monkeypatch, 
                       "v": pa.array(np.arange(n, dtype=np.int64))})
         keys = [("s", False, False), ("u", True, False)]
     monkeypatch.setenv("DFGPU_SORT_CARRIED_MIN_ROWS", "0")
+    if mode == "records_through_the_passes":
+        monkeypatch.setenv("DFGPU_SORT_CARRIED", "passes")
     ops.profile_enable(True)
     ops.profile_reset()
     run_sort(t, keys)
@@ -284,7 +287,10 @@ def test_sort_carried_records_and_keys_decoded_from_the_packed_key(monkeypatch, 
     ops.profile_enable(False)
     if carried:
         assert "sort_local_emit" in stats and "take_gather_rows" not in stats and "gather" not in stats, sorted(stats)
-        assert ("sort_carried_pass" in stats) == (shape != "one_bucket"), sorted(stats)
+        if mode == "records_through_the_passes":
+            assert ("sort_carried_pass" in stats) == (shape != "one_bucket") and "radix_sort_pass" not in stats, sorted(stats)
+        else:
+            assert "sort_build_records" in stats and ("radix_sort_pass" in stats) == (shape != "one_bucket"), sorted(stats)
     else:
         assert "sort_local_emit" not in stats, sorted(stats)
 
