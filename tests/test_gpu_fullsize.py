@@ -253,8 +253,9 @@ def test_sf100_sort_is_an_ordered_permutation():
 
 def test_sf100_group_by_custkey_partitioned_equals_global_atomics(monkeypatch):
     """Q13's shape at SF100 (150 M orders, 10 M customers with orders): the dense-key node with its rows moved into LDS-sized key
-    windows (two moves) gives exactly what the same node gives with one global atomic per row — groups in the same first-seen order,
-    same counts, same first order dates — and the counts add up to the orders"""
+    windows — by ONE grouped move into 1831 windows (round 4), or by round 3's two 64-way moves (DFGPU_AGG_GROUPED_MOVE=0) — gives exactly
+    what the same node gives with one global atomic per row: groups in the same first-seen order, same counts, same first order dates,
+    and the counts add up to the orders"""
     from datafusion_amd import ops
     from datafusion_amd.expr import col
     orders = ops.tpch_orders(SF).select(["o_custkey", "o_orderdate"])
@@ -268,17 +269,21 @@ def test_sf100_group_by_custkey_partitioned_equals_global_atomics(monkeypatch):
         ops.profile_enable(False)
         return out, stats
     moved, s1 = run()
-    assert "agg_dense_accumulate_partitioned" in s1 and s1["partition_scatter"]["calls"] == 2
+    assert "agg_dense_accumulate_partitioned" in s1 and s1["agg_group_rows"]["calls"] == 1 and "partition_scatter" not in s1, sorted(s1)
+    monkeypatch.setenv("DFGPU_AGG_GROUPED_MOVE", "0")
+    twice, s3 = run()
+    assert "agg_dense_accumulate_partitioned" in s3 and s3["partition_scatter"]["calls"] == 2 and "agg_group_rows" not in s3, sorted(s3)
     monkeypatch.setenv("DFGPU_AGG_PARTITIONED_MIN_ROWS", str(2**31 - 1))
     plain, s2 = run()
     assert "agg_dense_accumulate" in s2 and "agg_dense_accumulate_partitioned" not in s2
-    assert moved.num_rows == plain.num_rows
+    assert moved.num_rows == plain.num_rows == twice.num_rows
     cols = ["o_custkey", "cnt", "first_order"]
-    assert _sums(moved, cols) == _sums(plain, cols)
+    assert _sums(moved, cols) == _sums(plain, cols) == _sums(twice, cols)
     assert _sums(moved, ["cnt"])["cnt"] == orders.num_rows
     for off in range(0, moved.num_rows - 1000, moved.num_rows // 50):          # the same rows in the same (first-seen) order
-        assert moved.slice(off, 1000).to_arrow().equals(plain.slice(off, 1000).to_arrow())
-    for t in (moved, plain, orders):
+        want = plain.slice(off, 1000).to_arrow()
+        assert moved.slice(off, 1000).to_arrow().equals(want) and twice.slice(off, 1000).to_arrow().equals(want)
+    for t in (moved, twice, plain, orders):
         t.free()
 
 
