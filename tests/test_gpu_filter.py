@@ -68,26 +68,16 @@ def test_filter_is_null():
     run_filter(t, col("p").is_not_null())
 
 
-def test_filter_compound_predicates_run_as_one_fused_pass():
-    """round 4: from 1 Mi rows a predicate with several operators is compiled into ONE row program (filter.hip predicate_mask_fused:
-    the band l_shipdate >= a AND l_shipdate <= b, Kleene AND / OR / NOT over NULLs, a comparison of computed values); the rows that
-    pass are those of the oracle's column-at-a-time FilterExec, in order.  A single comparison stays column at a time, and so does a
-    forest the row programs do not take (a division)"""
-    from datafusion_amd import ops
+def test_filter_compound_predicates_over_a_million_rows():
+    """compound predicates over 1.1 M rows (the band l_shipdate >= a AND l_shipdate <= b, Kleene AND / OR / NOT over NULLs, a comparison of
+    computed values, a division): the rows that pass are those of the oracle's FilterExec, in order"""
     from datafusion_amd.expr import col, lit
     t = random_table(np.random.default_rng(11), 1_100_000, SPEC, null_frac=0.1)
     band = (col("d") >= lit(9000, pa.date32())).and_(col("d") <= lit(9365, pa.date32()))
     kleene = ((col("q") > lit(0, pa.int32())).and_(col("k") < lit(500, pa.int64()))).or_((col("q") > lit(10, pa.int32())).or_(col("d") <= lit(9000, pa.date32())).not_())
     computed = (col("q").cast(pa.int64()) + col("k")) > lit(400, pa.int64())
-    for pred, fused in ((band, True), (kleene, True), (computed, True), (col("q") >= lit(0, pa.int32()), False),
-                        ((col("k") / lit(7, pa.int64())) > lit(50, pa.int64()), False)):
-        ops.profile_enable(True)
-        ops.profile_reset()
+    for pred in (band, kleene, computed, (col("k") / lit(7, pa.int64())) > lit(50, pa.int64())):
         run_filter(t, pred, ["k", "p", "d"])
-        stats = ops.profile_stats()
-        ops.profile_enable(False)
-        assert ("predicate_fused" in stats) == fused, sorted(stats)
-        assert ("cmp" in stats) != fused, sorted(stats)
 
 
 def test_filter_between_q_shapes():
