@@ -2316,7 +2316,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   // more than 64 KB of dynamic LDS has to be asked for, per kernel
   {
     const void* fn = nullptr;
-    switch (grouped_move ? (int)DFGPU_INT64 : kt) {
+    switch (grouped_move ? (range <= (1ull << 32) ? (int)DFGPU_UINT32 : (int)DFGPU_INT64) : kt) {
       case DFGPU_INT64: fn = (const void*)k_dense_accumulate_parts<int64_t>; break;
       case DFGPU_UINT32: fn = (const void*)k_dense_accumulate_parts<uint32_t>; break;
       case DFGPU_UINT8: fn = (const void*)k_dense_accumulate_parts<uint8_t>; break;
@@ -2349,23 +2349,27 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
       widths.push_back(part_val_width(all[u].val));
     }
   }
-  BufPtr ids;
-  int ids_at = -1;
-  if (want_first_rows && !in_place) {
-    ids = make_buf((size_t)n * 4);
-    k_row_ids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(n, ids->as<uint32_t>());
-    ids_at = (int)src.size();
-    src.push_back(ids->ptr);
-    widths.push_back(4);
-  }
   if (grouped_move) {   // what grouped.hip's pass carries: <= GP_MAX_COLS columns, and its LDS holds a tile of the widest one beside the groups' words
     bool wide = false;
     for (size_t q = 1; q < widths.size(); q++) wide |= widths[q] == 16;
-    if ((int)src.size() - 1 > GP_MAX_COLS || (wide && n_windows > 1024)) {
+    if ((int)src.size() - 1 + (want_first_rows ? 1 : 0) > GP_MAX_COLS || (wide && n_windows > 1024)) {
       grouped_move = false;
       levels = 2;
       if (n < 4 * min_rows) return false;
     }
+  }
+  BufPtr ids;
+  int ids_at = -1;
+  if (want_first_rows && !in_place) {
+    ids_at = (int)src.size();
+    if (grouped_move) {
+      src.push_back(nullptr);   // (grouped.hip carries the rows' numbers without a column of them)
+    } else {
+      ids = make_buf((size_t)n * 4);
+      k_row_ids<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(n, ids->as<uint32_t>());
+      src.push_back(ids->ptr);
+    }
+    widths.push_back(4);
   }
   std::vector<PartBlock> blocks;
   RangePartition rp;
@@ -2382,15 +2386,18 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     while (((int64_t)1 << nbits) < n_windows) nbits++;
     const KeyCol kc{key, nullptr, kt, type_width(kt)};
     const GroupSpec gs{(uint64_t)kmin, range, 1ull << (64 - wshift)};
+    // (the keys leave as key - kmin in 32 bits when the range allows: half the key bytes of the widened form)
+    const bool narrow = range <= (1ull << 32);
     GroupedRows gr = group_rows_by_key(kc, n, gs, nbits, row_mask, /*want_keys=*/true, /*want_dest=*/false, std::vector<const void*>(src.begin() + 1, src.end()),
-                                       std::vector<int>(widths.begin() + 1, widths.end()), "agg_group_rows");
+                                       std::vector<int>(widths.begin() + 1, widths.end()), "agg_group_rows", narrow);
     rp.rows = gr.rows;
     rp.cols.push_back(gr.keys);
     for (BufPtr& b : gr.cols) rp.cols.push_back(b);
     group_bounds.resize((size_t)gr.P + 1);
     d2h(group_bounds.data(), gr.bounds->ptr, group_bounds.size() * 8);
-    widths[0] = 8;
-    kt = DFGPU_INT64;
+    widths[0] = gr.key_width;
+    kt = narrow ? DFGPU_UINT32 : DFGPU_INT64;
+    if (narrow) kmin = 0;   // (the moved keys are offsets from the range's start)
   } else {
     rp = partition_by_key_range(key, kt, n, kmin, wshift, 63u, (int)std::min<int64_t>(n_windows, 64), src, widths, /*want_bounds=*/false, row_mask, row_mask_valid);
   }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_hist(KeyCol key, int64_t n, Grou
 template <int KT, int THREADS, int ITEMS, int WPS, bool PREFETCH>
 __global__ __launch_bounds__(THREADS, WPS) void k_gp_scatter(KeyCol key, int64_t n, GroupSpec gs, int P, const uint64_t* __restrict__ row_mask, int tiles_per_chunk,
                                                              int64_t n_chunks, const uint64_t* __restrict__ offsets, uint64_t* __restrict__ out_keys,
-                                                             uint32_t* __restrict__ dest, GroupCols cols, int stage_width) {
+                                                             uint32_t* __restrict__ dest, GroupCols cols, int stage_width, int narrow_keys) {
   extern __shared__ __align__(16) unsigned char gp_smem[];
   constexpr int TILE = THREADS * ITEMS;
   constexpr int NWAVE = THREADS / WAVE;
@@ -187,7 +187,9 @@ __global__ __launch_bounds__(THREADS, WPS) void k_gp_scatter(KeyCol key, int64_t
         for (unsigned q = threadIdx.x; q < total; q += THREADS) {
           const uint64_t kq = reinterpret_cast<const uint64_t*>(s_stage)[q];
           const unsigned g = (unsigned)__umul64hi(kq - gs.offset, gs.mul);   // (a key says its own group: no table of groups per staged row)
-          out_keys[(uint64_t)(q + s_delta[g])] = kq;
+          // (narrow_keys: key - offset as 32 bits — a range below 2^32 moves half the key bytes)
+          if (narrow_keys) reinterpret_cast<uint32_t*>(out_keys)[(uint64_t)(q + s_delta[g])] = (uint32_t)(kq - gs.offset);
+          else out_keys[(uint64_t)(q + s_delta[g])] = kq;
         }
       }
       // ---- carried columns: the same route, one after the other through the same staging buffer
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_gp_scatter(KeyCol key, int64_t
           switch (w) {
             case 16: reinterpret_cast<uint4*>(s_stage)[pos[c]] = reinterpret_cast<const uint4*>(cols.src[cc])[i]; break;
             case 8: reinterpret_cast<uint64_t*>(s_stage)[pos[c]] = reinterpret_cast<const uint64_t*>(cols.src[cc])[i]; break;
-            case 4: reinterpret_cast<uint32_t*>(s_stage)[pos[c]] = reinterpret_cast<const uint32_t*>(cols.src[cc])[i]; break;
+            case 4: reinterpret_cast<uint32_t*>(s_stage)[pos[c]] = cols.src[cc] ? reinterpret_cast<const uint32_t*>(cols.src[cc])[i] : (uint32_t)i; break;   // (no source: the row's number)
             default: s_stage[pos[c]] = reinterpret_cast<const uint8_t*>(cols.src[cc])[i]; break;
           }
         }
@@ -244,7 +246,7 @@ static void gp_with_key_type(int dfgpu_type, F&& f) {
 }
 
 GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs, int nbits, const uint64_t* row_mask, bool want_keys, bool want_dest,
-                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what) {
+                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what, bool narrow_keys) {
   Runtime& r = rt();
   DFGPU_CHECK(n > 0 && n < 0xFFFFFFFFll, "group_rows_by_key: row count out of range");
   DFGPU_CHECK(nbits >= 1 && (1 << nbits) <= GP_MAX_GROUPS, "group_rows_by_key: bad number of groups");
@@ -288,17 +290,20 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
   k_gp_bounds<<<(P + 1 + 255) / 256, 256, 0, r.stream>>>(offsets->as<uint64_t>(), P, n_chunks, out.bounds->as<uint64_t>());
   out.rows = (int64_t)read_u64(offsets->as<uint64_t>() + (int64_t)P * n_chunks);
   const size_t out_rows = (size_t)std::max<int64_t>(out.rows, 1);
-  if (want_keys) out.keys = make_buf(out_rows * 8);
+  DFGPU_CHECK(!narrow_keys || gs.size <= (1ull << 32), "group_rows_by_key: 32-bit keys need a key range below 2^32");
+  out.key_width = narrow_keys ? 4 : 8;
+  if (want_keys) out.keys = make_buf(out_rows * (size_t)out.key_width + 8);
   if (want_dest) out.dest = make_buf((size_t)n * 4);
   GroupCols gc{};
   gc.n = (int)carry_src.size();
-  int64_t moved = (want_keys ? out.rows * 8 : 0) + (want_dest ? n * 4 : 0);
+  int64_t moved = (want_keys ? out.rows * out.key_width : 0) + (want_dest ? n * 4 : 0);
   for (int c = 0; c < gc.n; c++) {
     out.cols.push_back(make_buf(out_rows * (size_t)carry_width[c]));
     gc.src[c] = carry_src[c];
     gc.dst[c] = out.cols.back()->ptr;
     gc.width[c] = carry_width[c];
-    moved += n * carry_width[c] + out.rows * carry_width[c];
+    DFGPU_CHECK(carry_src[c] || carry_width[c] == 4, "group_rows_by_key: a carried column without a source is the 32-bit row number");
+    moved += (carry_src[c] ? n * carry_width[c] : 0) + out.rows * carry_width[c];
   }
   const size_t lds = (size_t)TILE * stage_width + (size_t)P * 12 + (size_t)(THREADS / WAVE) * 4 + (size_t)P * 2 + (gc.n > 0 ? (size_t)TILE * 2 : 0);
   {
@@ -308,7 +313,7 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
       auto launch = [&](auto kern, int threads) {
         DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, threads, lds, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, offsets->as<uint64_t>(), want_keys ? out.keys->as<uint64_t>() : nullptr,
-                                               want_dest ? out.dest->as<uint32_t>() : nullptr, gc, stage_width);
+                                               want_dest ? out.dest->as<uint32_t>() : nullptr, gc, stage_width, narrow_keys ? 1 : 0);
       };
       if (variant == 'C') launch(k_gp_scatter<T, 512, ITEMS, 6, true>, 512);
       else if (variant == 'B') launch(k_gp_scatter<T, 1024, ITEMS, 8, false>, 1024);

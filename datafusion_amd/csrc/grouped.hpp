@@ -27,7 +27,8 @@ struct GroupCols {
 struct GroupedRows {
   int P = 0;
   int64_t rows = 0;            // rows that took part
-  BufPtr keys;                 // u64 per grouped row: the key, widened (want_keys)
+  BufPtr keys;                 // per grouped row (want_keys): the key widened to u64 — or, narrow_keys, key - offset as u32
+  int key_width = 8;
   BufPtr dest;                 // u32 per INPUT row: its position in group order, ~0 = takes no part (want_dest)
   BufPtr bounds;               // u64 [P + 1] on the device: group g = positions bounds[g] .. bounds[g + 1]
   std::vector<BufPtr> cols;    // carried columns in group order
@@ -35,6 +36,7 @@ struct GroupedRows {
 // Rows of an integer key column moved into 2^nbits (<= GP_MAX_GROUPS) groups of their key's range (NULL keys, rows masked out by `row_mask` and keys
 // outside [offset, offset + size) take no part).  Order inside a group is arbitrary.
 GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs, int nbits, const uint64_t* row_mask, bool want_keys, bool want_dest,
-                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what = nullptr);
+                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what = nullptr, bool narrow_keys = false);
+// (a carried column of width 4 whose source is null carries the rows' numbers)
 
 }  // namespace dfgpu
