@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: runs a physical plan (datafusion_amd.physical_plan node tree, used here purely as a data
 structure) with the CPU oracle's operators, so that ONE statement of a reference plan
-(datafusion_amd/tpch_plans.py) is executed twice: by the product on the GPU and by the oracle here.
+(tests/tpch_plans.py) is executed twice: by the product on the GPU and by the oracle here.
 
 Leaves hold pyarrow Tables.  The oracle has no string type: dictionary-encoded string columns are carried as their
 index columns plus a {column name: dictionary} side table, string literals are bound to indices exactly as the product

@@ -80,7 +80,8 @@ def test_delta_byte_stream_split_and_boolean_pages(tmp_path, compression, versio
 
 def test_q6_straight_from_a_parquet_file(tmp_path):
     """dbgen lineitem -> Parquet (ZSTD, the reference's benchmark setting) -> device -> the reference's Q6 plan -> the reference's answer"""
-    from datafusion_amd import physical_plan as P, tpch_plans as T
+    from datafusion_amd import physical_plan as P
+    from tests import tpch_plans as T
     from datafusion_amd.parquet import read_table
     from oracle import dbgen
     from tests.test_tpch_answers import assert_answer

@@ -13,14 +13,15 @@ pytestmark = pytest.mark.gpu
 
 
 def q1_plan(lineitem):
-    """q1.slt.part:50-58 — one statement of the plan for the product and the oracle: datafusion_amd/tpch_plans.py"""
-    from datafusion_amd import tpch_plans as T
+    """q1.slt.part:50-58 — one statement of the plan for the product and the oracle: tests/tpch_plans.py"""
+    from tests import tpch_plans as T
     return T.q1_plan(lineitem)
 
 
 def q3_plan(customer, orders, lineitem):
     """q3.slt.part:61-76 over the device generator's layout (c_mktsegment as a UInt8 code)"""
-    from datafusion_amd import queries as Q, tpch_plans as T
+    from datafusion_amd import queries as Q
+    from tests import tpch_plans as T
     from datafusion_amd.expr import lit
     return T.q3_plan(customer, orders, lineitem, segment_literal=lit(Q.SEGMENT_BUILDING, pa.uint8()))
 

@@ -85,7 +85,8 @@ def test_sf10_join_unordered_flavours_hold_the_same_rows(sf10, flavour):
 @pytest.mark.parametrize("fused", [True, False])
 def test_sf10_q3_equals_the_oracle(sf10, fused):
     """the reference's pinned Q3 plan over the same 15 M / 60 M-row tables: the oracle's operators on the host vs the device"""
-    from datafusion_amd import queries, tpch_plans as T
+    from datafusion_amd import queries
+    from tests import tpch_plans as T
     from datafusion_amd.expr import lit
     from tests import plan_oracle
     if "q3" not in sf10:

@@ -4,7 +4,7 @@
 Data: oracle/dbgen.py, a restatement of the TPC's dbgen for the columns these queries read, itself pinned against the
 first rows of dbgen's SF 1 output that the reference carries (core/tests/tpch-csv/*.csv) — both copied into
 tests/golden/tpch_answers.json by tests/golden/extract_reference_tpch_goldens.py.
-Plans: the reference's pinned physical plans (datafusion_amd/tpch_plans.py).
+Plans: the reference's pinned physical plans (tests/tpch_plans.py).
 
 CPU legs (no GPU): the oracle's operators run each plan — as pinned and as rewritten by GpuOffloadRule — and must print
 the reference's answers digit for digit; that pins the oracle (joins of all shapes used, Decimal128 arithmetic and
@@ -35,7 +35,7 @@ def data(strings="dictionary"):
 
 def plans(t):
     """query -> plan over the leaf tables `t` (a dict of tables: Arrow for the oracle, device tables for the product)"""
-    from datafusion_amd import tpch_plans as T
+    from tests import tpch_plans as T
     return {"q1": T.q1_plan(t["lineitem"]), "q3": T.q3_plan(t["customer"], t["orders"], t["lineitem"]),
             "q4": T.q4_plan(t["orders"], t["lineitem"]),
             "q5": T.q5_plan(t["customer"], t["orders"], t["lineitem"], t["supplier"], t["nation"], t["region"]),
@@ -59,7 +59,7 @@ def q16_with_many_complaints(t):
     """Q16 over a supplier table in which every 7th supplier carries the "Customer … Complaints" mark: at SF0.1 dbgen marks ONE
     supplier and the pinned answer does not depend on it, so the null-aware anti join of the plan is exercised with a build side
     that really loses rows (the multi-rank tests compare with the single-process oracle)"""
-    from datafusion_amd import tpch_plans as T
+    from tests import tpch_plans as T
     from oracle import dbgen
     s = t["supplier"]
     if not isinstance(s, pa.Table):
@@ -192,7 +192,7 @@ def names(plan):
 
 def test_string_layouts_agree():
     """UInt8 codes (the device generator's layout) and dictionary-encoded strings give the same Q1 / Q3 answers"""
-    from datafusion_amd import tpch_plans as T
+    from tests import tpch_plans as T
     from datafusion_amd.expr import lit
     from tests import plan_oracle
     t = data("codes")
@@ -232,7 +232,7 @@ def test_gpu_text_queries_over_utf8_columns_in_hbm():
     from datafusion_amd.table import DeviceTable
     t = {k: DeviceTable.from_arrow(v) for k, v in data("utf8").items() if k in ("customer", "orders", "supplier", "part", "partsupp", "nation", "region")}
     t["lineitem"] = None
-    from datafusion_amd import tpch_plans as T
+    from tests import tpch_plans as T
     todo = {"q13": T.q13_plan(t["customer"], t["orders"]), "q16": T.q16_plan(t["partsupp"], t["part"], t["supplier"]),
             "q2": T.q2_plan(t["part"], t["supplier"], t["partsupp"], t["nation"], t["region"])}
     for q, plan in todo.items():

@@ -17,8 +17,8 @@ from decimal import Decimal
 
 import pyarrow as pa
 
-from . import physical_plan as P
-from .expr import case, col, date_part, lit
+from datafusion_amd import physical_plan as P
+from datafusion_amd.expr import case, col, date_part, lit
 
 DATE = pa.date32()
 D15_2 = pa.decimal128(15, 2)
@@ -269,7 +269,7 @@ def q11_plan(partsupp, supplier, nation):
     """q11.slt.part:75-108: partsupp (build) x supplier, LeftSemi against the GERMANY row of nation, SUM(ps_supplycost *
     CAST(ps_availqty AS Decimal128(10, 0))) per part, HAVING it above 0.0001 of the same sum over all parts — an uncorrelated scalar
     subquery: ScalarSubqueryExec runs it first, the FilterExec reads it as CAST(CAST(sum AS Float64) * 0.0001 AS Decimal128(38, 15))"""
-    from .expr import ScalarSubqueryExpr, ScalarSubqueryResults
+    from datafusion_amd.expr import ScalarSubqueryExpr, ScalarSubqueryResults
     f64, d38 = pa.float64(), pa.decimal128(38, 15)
     name = "sum(partsupp.ps_supplycost * partsupp.ps_availqty)"
     value = col("ps_supplycost") * col("ps_availqty").cast(pa.decimal128(10, 0))
@@ -363,7 +363,7 @@ def q20_plan(supplier, nation, partsupp, part, lineitem):
 def q15_plan(supplier, lineitem):
     """q15.slt.part:73-94: the revenue0 view (revenue per supplier over one quarter) twice — once under MAX as an uncorrelated scalar
     subquery, once filtered to the suppliers whose revenue EQUALS it — joined to supplier (build side, string payload)"""
-    from .expr import ScalarSubqueryExpr, ScalarSubqueryResults
+    from datafusion_amd.expr import ScalarSubqueryExpr, ScalarSubqueryResults
     name = "sum(lineitem.l_extendedprice * Int64(1) - lineitem.l_discount)"
     d38 = pa.decimal128(38, 4)
 
@@ -390,7 +390,7 @@ def q22_plan(customer, orders):
     """q22.slt.part:76-95: customers of seven country codes (substr(c_phone, 1, 2)) whose balance is above the average positive
     balance of those countries (uncorrelated scalar subquery) and who have no orders (LeftAnti: the filtered customers are the
     build side), counted and summed per country code"""
-    from .expr import ScalarSubqueryExpr, ScalarSubqueryResults, substr
+    from datafusion_amd.expr import ScalarSubqueryExpr, ScalarSubqueryResults, substr
     codes = [lit(c, pa.string()) for c in ("13", "31", "23", "29", "30", "18", "17")]
     cc = substr(col("c_phone"), 1, 2)
     d19 = pa.decimal128(19, 6)
