@@ -1312,7 +1312,7 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   int64_t key_bytes = 0;
   for (int g = 0; g < ngk; g++) key_bytes += total * type_width(R.cat_keys[g].field.type);
   // key columns without NULLs that fit 64 bits together: a keyed table (k_intern_claim_keyed)
-  bool keyed = total >= (1 << 16) && !(std::getenv("DFGPU_AGG_PACK_KEYS") && std::getenv("DFGPU_AGG_PACK_KEYS")[0] == '0');
+  bool keyed = total >= (1 << 16);
   {
     int bits = 0;
     for (int g = 0; g < ngk && keyed; g++) {
@@ -2269,8 +2269,7 @@ static int part_window_cap(const std::vector<PartAcc>& all) {
   return wcap;
 }
 static bool partitioned_in_place(uint64_t range, const std::vector<PartAcc>& all) {
-  static const bool in_place_off = std::getenv("DFGPU_AGG_IN_PLACE") && std::getenv("DFGPU_AGG_IN_PLACE")[0] == '0';
-  return !in_place_off && range > 0 && ((range - 1) >> part_window_cap(all)) == 0;
+  return range > 0 && ((range - 1) >> part_window_cap(all)) == 0;
 }
 // The core: `key` (type kt, no NULLs) takes values in [kmin, kmin + range); accumulator u reads its argument from all[u].data (a
 // source column without NULLs, null for the counts) and owns the cell words all[u].cell (.. + 1 for a 128-bit sum) of `ncw`.
@@ -2497,8 +2496,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
       size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4 * (size_t)ps.n32 + 4);
       // the slot -> group table as 16-bit words in LDS behind the cells when both fit (in place over table slots: every row looks it up)
       int map_lds = 0;
-      if (in_place && key_map && key_map_n > 0 && range <= 65536 && lds_bytes + (size_t)key_map_n * 2 + 8 <= PART_LDS_MAX &&
-          !(std::getenv("DFGPU_AGG_LDS_KEY_MAP") && std::getenv("DFGPU_AGG_LDS_KEY_MAP")[0] == '0')) {   // A/B knob
+      if (in_place && key_map && key_map_n > 0 && range <= 65536 && lds_bytes + (size_t)key_map_n * 2 + 8 <= PART_LDS_MAX) {
         map_lds = (int)key_map_n;
         lds_bytes += (size_t)key_map_n * 2 + 8;
       }
@@ -3510,7 +3508,7 @@ static bool agg_update_small_single_pass(Aggregate& A, const Table& in, const Co
   BufPtr g_first = make_buf((size_t)D * 4);
   BufPtr g_seen = make_buf((size_t)D * 4);
   const int ko0 = ngk > 0 ? cp.tile_outs[key_out[0]] : -1, ko1 = ngk > 1 ? cp.tile_outs[key_out[1]] : -1;
-  const bool prefetch = env_int("DFGPU_AGG_PREFETCH", 1) != 0;
+  const bool prefetch = true;
   DFGPU_HIP(hipFuncSetAttribute((const void*)k_agg_fused_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_BUDGET));
   DFGPU_HIP(hipFuncSetAttribute((const void*)k_agg_fused_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_BUDGET));
 
@@ -3717,7 +3715,7 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
       a.typed = true;
     }
   }
-  if (gid_mode != GID_HASH && env_int("DFGPU_AGG_SINGLE_PASS", 1) != 0 &&
+  if (gid_mode != GID_HASH &&
       agg_update_small_single_pass(A, in, cp, small_cols, key_out, arg_out))
     return true;
   const int64_t G0 = A.ngroups;

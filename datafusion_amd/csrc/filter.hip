@@ -325,7 +325,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(PackLayout L, const uint8
   }
 }
 
-// ---- records laid out by somebody else (sort.hip's clustered take): can every column of `cols` travel in ONE record?
+// ---- records laid out by somebody else (sort.hip's carried sort): can every column of `cols` travel in ONE record?
 bool plan_record_layout(const Table& in, const std::vector<int>& cols, PackLayout& L, int& R, std::vector<int>& order) {
   L = PackLayout{};
   order.clear();
@@ -351,31 +351,6 @@ bool plan_record_layout(const Table& in, const std::vector<int>& cols, PackLayou
   R = (bytes + 15) / 16 * 16;
   return true;
 }
-// out[k][i] = field k of rec[idx[i]] (the layout's fields are in `order`)
-std::vector<Column> gather_records(const Table& in, const std::vector<int>& cols, PackLayout L, int R, const std::vector<int>& order, const uint8_t* rec,
-                                   const uint32_t* idx, int64_t n) {
-  Runtime& r = rt();
-  std::vector<Column> out(cols.size());
-  int bytes = 0;
-  for (int q = 0; q < L.n; q++) {
-    const int k = order[(size_t)q];
-    out[(size_t)k] = alloc_like(in.cols[(size_t)cols[(size_t)k]], n);
-    L.dst[q] = out[(size_t)k].data->ptr;
-    bytes += L.width[q];
-  }
-  if (n == 0) return out;
-  ProfileScope ps("take_gather_rows", n * (int64_t)(4 + R + bytes));
-  const int g = grid_for(n, BLOCK);
-  switch (R) {
-    case 16: k_gather_rows<16, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec, idx, n); break;
-    case 32: k_gather_rows<32, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec, idx, n); break;
-    case 48: k_gather_rows<48, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec, idx, n); break;
-    default: k_gather_rows<64, uint32_t><<<g, BLOCK, 0, r.stream>>>(L, rec, idx, n); break;
-  }
-  DFGPU_HIP(hipGetLastError());
-  return out;
-}
-
 __global__ __launch_bounds__(BLOCK) void k_widen_ids(const uint32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (int64_t)in[i];
 }
@@ -402,8 +377,7 @@ std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols
       in_bytes += in.nrows * type_width(c.field.type);
     }
   }
-  static const bool enabled = !(std::getenv("DFGPU_PACKED_TAKE") && std::getenv("DFGPU_PACKED_TAKE")[0] == '0');  // A/B knob
-  const bool pack = enabled && packable.size() >= 2 && in_bytes > ((int64_t)256 << 20) && n * 4 >= in.nrows;
+  const bool pack = packable.size() >= 2 && in_bytes > ((int64_t)256 << 20) && n * 4 >= in.nrows;
   std::vector<bool> done(cols.size(), false);
   if (pack && n > 0) {
     // widest columns first keeps every field naturally aligned inside the record

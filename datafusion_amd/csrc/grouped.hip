@@ -260,13 +260,10 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
     DFGPU_CHECK(w == 1 || w == 4 || w == 8 || w == 16, "group_rows_by_key: carried columns are 1, 4, 8 or 16 bytes wide");
     stage_width = std::max(stage_width, w);
   }
-  // Tile shapes (DFGPU_GP_VARIANT, A/B knob; measured in profiles/r4_group_rows.md):
-  //   A  1024 threads x 8 rows = 8192-row tiles (runs of 8192 / P rows), the next tile's keys prefetched, one workgroup per CU
-  //   B  the same tile without the prefetch and registers capped for TWO workgroups per CU (key-only: 80 KB of LDS each)
-  //   C  512 threads x 8 rows = 4096-row tiles, three workgroups per CU, half the run length
-  const char* venv = std::getenv("DFGPU_GP_VARIANT");
-  const char variant = venv ? venv[0] : 'A';
-  const int THREADS = variant == 'C' ? 512 : 1024;
+  // Tile shape: 1024 threads x 8 rows = 8192-row tiles (runs of 8192 / P rows), the next tile's keys prefetched, one workgroup per CU.
+  // Measured against it (profiles/r4_group_rows.md) and dropped: the same tile without the prefetch at two workgroups per CU (+ 5 %),
+  // 512 threads x 8 rows at three per CU (half the run length: + 13 %) — the pass is bound by its LDS work, not by latency.
+  constexpr int THREADS = 1024;
   constexpr int ITEMS = 8;
   const int TILE = THREADS * ITEMS;
   const int64_t n_tiles = (n + TILE - 1) / TILE;
@@ -280,8 +277,7 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
   {
     ProfileScope ps("group_rows_count", key_bytes);
     gp_with_key_type(key.type, [&](auto kt) {
-      if (THREADS == 512) k_gp_hist<decltype(kt)::value, 512, ITEMS><<<grid, 512, 0, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, counts->as<uint32_t>());
-      else k_gp_hist<decltype(kt)::value, 1024, ITEMS><<<grid, 1024, 0, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, counts->as<uint32_t>());
+      k_gp_hist<decltype(kt)::value, THREADS, ITEMS><<<grid, THREADS, 0, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, counts->as<uint32_t>());
     });
     DFGPU_HIP(hipGetLastError());
   }
@@ -315,9 +311,7 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
         kern<<<grid, threads, lds, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, offsets->as<uint64_t>(), want_keys ? out.keys->as<uint64_t>() : nullptr,
                                                want_dest ? out.dest->as<uint32_t>() : nullptr, gc, stage_width, narrow_keys ? 1 : 0);
       };
-      if (variant == 'C') launch(k_gp_scatter<T, 512, ITEMS, 6, true>, 512);
-      else if (variant == 'B') launch(k_gp_scatter<T, 1024, ITEMS, 8, false>, 1024);
-      else launch(k_gp_scatter<T, 1024, ITEMS, 4, true>, 1024);
+      launch(k_gp_scatter<T, THREADS, ITEMS, 4, true>, THREADS);
     });
     DFGPU_HIP(hipGetLastError());
   }

@@ -315,11 +315,9 @@ Column gather_column(const Column& in, const int64_t* idx, int64_t n, bool idx_m
 // (idx32: the same ids as 32-bit values instead of `idx` — the sort hands its row ids over without widening them)
 std::vector<Column> gather_columns(const Table& in, const std::vector<int>& cols, const int64_t* idx, int64_t n, bool idx_may_be_null, const uint32_t* idx32 = nullptr);
 // one row-major record per row holding every column of `cols` (records.hpp): layout planning and the take from records laid
-// out by the caller (sort.hip's clustered take)
+// out by the caller (sort.hip's carried sort)
 struct PackLayout;
 bool plan_record_layout(const Table& in, const std::vector<int>& cols, PackLayout& L, int& R, std::vector<int>& order);
-std::vector<Column> gather_records(const Table& in, const std::vector<int>& cols, PackLayout L, int R, const std::vector<int>& order, const uint8_t* rec,
-                                   const uint32_t* idx, int64_t n);
 // a Boolean column as one UInt8 per row (validity kept): Boolean key columns of joins, repartitions, sorts and aggregates (aggregate.hip)
 Column bool_as_u8(const Column& c, int64_t n);
 // out[w] = a[w] & b[w] over nw 64-bit words (aggregate.hip)

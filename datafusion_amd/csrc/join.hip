@@ -1894,8 +1894,6 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
   // needs neither it nor ArrayMap's 4 bytes per VALUE of the range: 150 M shuffled keys x 600 M probes, key-only: 23.7 ms -> see
   // profiles/r3_join_shapes.md; probes that do gather build rows pay rank -> perm -> row, within 10 % of ArrayMap's two accesses.)
   constexpr int64_t MALL_BYTES = (int64_t)256 << 20;
-  static const bool eager_array_map = std::getenv("DFGPU_JOIN_SHUFFLED_ARRAY_MAP") && std::getenv("DFGPU_JOIN_SHUFFLED_ARRAY_MAP")[0] == '1';  // A/B knob: round 2's choice
-  if (eager_array_map && opts.table_mode == 0 && rank_ok && am_ok && !ascending && (int64_t)((range >> 6) + 1) * 16 + nb * 4 > MALL_BYTES) rank_ok = false;
 
   BufPtr flag = make_zero_buf(4);
   int dup = 0;
@@ -1914,8 +1912,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       BufPtr grouped_keys;
       // (round 4) many keys in no order over a bitmap beyond the caches: grouped by key range, bits set in LDS
       constexpr int RB_BITS = 10;
-      const bool lds_bits = !ascending && nb > (1 << 22) && n_words * 8 > ((int64_t)16 << 20) && (range >> RB_BITS) < (1ull << 20) - 64 &&
-                            !(std::getenv("DFGPU_JOIN_LDS_BITMAP") && std::getenv("DFGPU_JOIN_LDS_BITMAP")[0] == '0');   // A/B knob
+      const bool lds_bits = !ascending && nb > (1 << 22) && n_words * 8 > ((int64_t)16 << 20) && (range >> RB_BITS) < (1ull << 20) - 64;
       if (lds_bits) {
         const GroupSpec gs = group_spec((uint64_t)kmin, range + 1, 1 << RB_BITS);
         GroupedRows gr = group_rows_by_key(kc0, nb, gs, RB_BITS, nullptr, true, false, {}, {}, "join_build_group_keys");
@@ -1935,8 +1932,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
         DFGPU_HIP(hipGetLastError());
         DFGPU_HIP(hipStreamSynchronize(r.stream));   // gfirst is a local the copy reads
       } else {
-      if (!ascending && !kc0.valid && kc0.width == 8 && nb > (1 << 22) && n_words * 8 > ((int64_t)16 << 20) &&
-          !(std::getenv("DFGPU_JOIN_GROUPED_BUILD") && std::getenv("DFGPU_JOIN_GROUPED_BUILD")[0] == '0')) {
+      if (!ascending && !kc0.valid && kc0.width == 8 && nb > (1 << 22) && n_words * 8 > ((int64_t)16 << 20)) {
         const Column& kcol = build.cols[(size_t)key_cols[0]];
         grouped_keys = kcol.data;
         if (kcol.data_offset != 0) {
@@ -1950,8 +1946,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       }
       // many keys in no order: byte map + pack instead of one atomic per key (the byte map is a temporary of one byte per VALUE of
       // the range: up to 4 GiB of it)
-      const bool byte_map = !ascending && nb > (1 << 20) && range < (1ull << 32) &&
-                            !(std::getenv("DFGPU_JOIN_BYTE_MAP") && std::getenv("DFGPU_JOIN_BYTE_MAP")[0] == '0');
+      const bool byte_map = !ascending && nb > (1 << 20) && range < (1ull << 32);
       if (byte_map) {
         BufPtr bytes = make_zero_buf((size_t)n_words * 64);
         with_key_type(kc0.type, [&](auto kt) {
@@ -2379,7 +2374,7 @@ static bool grouped_probe_lookup(JoinTable& jt, const Table& probe, int pk0, con
   L.n = (int)bout.size();
   // build keys in no order: the payload is read at rank positions from a rank-ordered copy — ONE 16-byte record per rank when the
   // returned record is 16 bytes (the build columns then cost the lookup one L2 access, not one per column), else column by column
-  const bool packed = jt.rank_needs_perm && !bout.empty() && L.R == 16 && !(std::getenv("DFGPU_JOIN_RANK_RECORDS") && std::getenv("DFGPU_JOIN_RANK_RECORDS")[0] == '0');
+  const bool packed = jt.rank_needs_perm && !bout.empty() && L.R == 16;
   BufPtr packed_recs;
   if (packed) packed_recs = ensure_rank_records(jt, bout, field_off);
   else if (jt.rank_needs_perm && !bout.empty()) ensure_rank_payload(jt, bout);
@@ -2527,10 +2522,8 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   // (the hit rate of foreign keys drawn from that range): counts + hit words, then k_join_emit_listed.  The counts pass
   // knows the answer before the second kernel is chosen, so a wrong guess costs the counts pass, not the result; the
   // output is in probe order, which every probe_mode accepts.
-  static const char* listed_env = std::getenv("DFGPU_JOIN_LISTED");  // A/B knob: 0 / 1 force the guess
   bool listed = fused_ok && fused_mode != FUSED_LOOKBACK && (kind == KIND_RANK || kind == KIND_ARRAY) &&
                 (row_mask != nullptr || (double)jt.build.nrows < 0.15 * (double)jt.am_size);
-  if (listed_env && fused_ok && fused_mode != FUSED_LOOKBACK && (kind == KIND_RANK || kind == KIND_ARRAY)) listed = listed_env[0] == '1';
   // what the grouped lookup found decides the placement: every probe row matched — row i of the output is probe row i, no counts
   // pass; else the cursor when nobody observes the order, else counts + placed
   const bool returned_all_hit = returned && rp.hits == np && !row_mask && join_type != DFGPU_JOIN_RIGHT_ANTI;
@@ -2555,9 +2548,8 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       keys = make_buf((size_t)np * 8);
       DFGPU_HIP(hipMemcpyAsync(keys->ptr, kc.ptr(), (size_t)np * 8, hipMemcpyDeviceToDevice, r.stream));
     }
-    static const bool gp_keys = !(std::getenv("DFGPU_JOIN_GP_KEYS") && std::getenv("DFGPU_JOIN_GP_KEYS")[0] == '0');  // A/B knob: round 3's radix pass
     int64_t n_grouped = np;
-    if (gp_keys && jt.kind == KIND_RANK && join_type != DFGPU_JOIN_RIGHT_ANTI) {
+    if (jt.kind == KIND_RANK && join_type != DFGPU_JOIN_RIGHT_ANTI) {
       // round 4: grouped by their position in the table's key range (grouped.hip: one pass, 2^9 groups or so); keys outside the
       // range — they match nothing, and an Inner / RightSemi probe emits nothing for them — drop out here
       const KeyCol key{kc.ptr(), nullptr, kc.field.type, 8};
@@ -2697,8 +2689,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       bool is_key = false;
       for (int k : pk) is_key |= k == c;
       if (!is_key) bytes_in += np * jc.width[jc.n];  // a key column that is also payload is read once
-      static const bool keyreg = !(std::getenv("DFGPU_JOIN_KEYREG") && std::getenv("DFGPU_JOIN_KEYREG")[0] == '0');  // A/B knob
-      if (keyreg && is_key && (kind == KIND_ARRAY || kind == KIND_RANK) && pk.size() == 1 && jc.key_col < 0 && !sc.validity) jc.key_col = jc.n;
+      if (is_key && (kind == KIND_ARRAY || kind == KIND_RANK) && pk.size() == 1 && jc.key_col < 0 && !sc.validity) jc.key_col = jc.n;
       bytes_per_out += jc.width[jc.n];
       jc.n++;
     }

@@ -442,8 +442,7 @@ static std::vector<Table> partition_table_fixed_keys(const Table& in, const std:
   while ((1 << nbits) < nparts) nbits++;
   bool simple = true;
   for (auto& c : in.cols) simple &= !c.validity && c.field.type != DFGPU_BOOL && c.field.type != DFGPU_UTF8;
-  static const bool gen1 = std::getenv("DFGPU_PART_GEN1") != nullptr;  // A/B knob: the first-generation count pass
-  const bool gen2 = !gen1 && nparts <= 16;
+  const bool gen2 = nparts <= 16;   // (packed 16-bit counters in registers; more partitions take the ballot-counting pass)
   const FastMod fm = fastmod_for((uint32_t)nparts);
   BufPtr part = make_buf((size_t)n + 64);
   BufPtr counts = make_buf((size_t)nparts * n_tiles * 4);

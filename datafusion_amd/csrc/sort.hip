@@ -252,116 +252,6 @@ __global__ __launch_bounds__(BLOCK) void k_rs_hist(const uint64_t* __restrict__ 
   }
 }
 
-// stable scatter of one tile by one digit, staged through LDS so that every digit's run is written contiguously
-template <int NW>
-__global__ __launch_bounds__(BLOCK) void k_rs_scatter(KeyWords k, const uint32_t* __restrict__ idx_in, int64_t n, DivBy dv, int dword, int shift, int bits, int64_t n_tiles,
-                                                     const uint64_t* __restrict__ offsets, SortBufs out) {
-  constexpr int RS_ITEMS = rs_items(NW);
-  constexpr int RS_TILE = BLOCK * RS_ITEMS;
-  __shared__ uint64_t s_key[NW][RS_TILE];
-  __shared__ uint32_t s_idx[RS_TILE];
-  __shared__ uint8_t s_dig[RS_TILE];
-  __shared__ unsigned int s_wave[BLOCK / WAVE][256];  // per-wave digit counts of the current chunk
-  __shared__ unsigned int s_run[256];                 // rows of each digit seen in earlier chunks of the tile
-  __shared__ unsigned int s_start[256];               // exclusive scan of the tile's digit counts
-  __shared__ unsigned long long s_goff[256];          // global output offset of each digit's run
-  const unsigned mask = (1u << bits) - 1u;
-  const int wave = threadIdx.x >> 6;
-  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const int64_t lo = t * RS_TILE;
-    const int tile_rows = (int)((n - lo) < RS_TILE ? (n - lo) : RS_TILE);
-    s_run[threadIdx.x] = 0;
-    for (int w = 0; w < BLOCK / WAVE; w++) s_wave[w][threadIdx.x] = 0;
-    if ((int)threadIdx.x <= (int)mask) s_goff[threadIdx.x] = offsets[(int64_t)threadIdx.x * n_tiles + t];
-    __syncthreads();
-    uint64_t key[NW][RS_ITEMS];
-    uint32_t id[RS_ITEMS];
-    unsigned dig[RS_ITEMS], rank[RS_ITEMS];
-    // ---- pass 1: stable rank of every row among the tile's rows with the same digit
-#pragma unroll
-    for (int c = 0; c < RS_ITEMS; c++) {
-      const int j = c * BLOCK + threadIdx.x;
-      const bool in = j < tile_rows;
-      if (in) {
-#pragma unroll
-        for (int w = 0; w < NW; w++) key[w][c] = k.w[w][lo + j];
-        id[c] = idx_in ? idx_in[lo + j] : (uint32_t)(lo + j);
-      } else {
-#pragma unroll
-        for (int w = 0; w < NW; w++) key[w][c] = 0;
-        id[c] = 0;
-      }
-      uint64_t kw = 0;
-#pragma unroll
-      for (int w = 0; w < NW; w++)
-        if (w == dword) kw = key[w][c];
-      dig[c] = in ? ((unsigned)(div_apply(kw, dv) >> shift) & mask) : 0u;
-      uint64_t peers = ballot64(in);
-      for (int b = 0; b < bits; b++) {
-        const uint64_t bal = ballot64((dig[c] >> b) & 1u);
-        peers &= ((dig[c] >> b) & 1u) ? bal : ~bal;
-      }
-      const unsigned r_in_wave = mbcnt(peers);
-      if (in && r_in_wave == 0) s_wave[wave][dig[c]] = (unsigned)__popcll(peers);
-      __syncthreads();
-      if (in) {
-        unsigned r = s_run[dig[c]] + r_in_wave;
-        for (int w = 0; w < wave; w++) r += s_wave[w][dig[c]];
-        rank[c] = r;
-      }
-      __syncthreads();
-      {
-        unsigned tot = 0;
-        for (int w = 0; w < BLOCK / WAVE; w++) {
-          tot += s_wave[w][threadIdx.x];
-          s_wave[w][threadIdx.x] = 0;
-        }
-        s_run[threadIdx.x] += tot;
-      }
-      __syncthreads();
-    }
-    // ---- exclusive scan of the digit counts (256 threads, wave scan + wave totals)
-    {
-      const unsigned cnt = s_run[threadIdx.x];
-      const unsigned inc = wave_inclusive_sum<unsigned>(cnt);
-      if (lane_id() == 63) s_wave[0][wave] = inc;
-      __syncthreads();
-      unsigned base = 0;
-      for (int w = 0; w < wave; w++) base += s_wave[0][w];
-      s_start[threadIdx.x] = base + inc - cnt;
-      __syncthreads();
-      if (threadIdx.x < BLOCK / WAVE) s_wave[0][threadIdx.x] = 0;
-    }
-    // ---- pass 2: stage the tile sorted by digit
-#pragma unroll
-    for (int c = 0; c < RS_ITEMS; c++) {
-      const int j = c * BLOCK + threadIdx.x;
-      if (j < tile_rows) {
-        const unsigned q = s_start[dig[c]] + rank[c];
-#pragma unroll
-        for (int w = 0; w < NW; w++) s_key[w][q] = key[w][c];
-        s_idx[q] = id[c];
-        s_dig[q] = (uint8_t)dig[c];
-      }
-    }
-    __syncthreads();
-    // ---- pass 3: contiguous runs out
-#pragma unroll
-    for (int c = 0; c < RS_ITEMS; c++) {
-      const int q = c * BLOCK + threadIdx.x;
-      if (q < tile_rows) {
-        const unsigned d = s_dig[q];
-        const unsigned long long dst = s_goff[d] + (unsigned)(q - (int)s_start[d]);
-#pragma unroll
-        for (int w = 0; w < NW; w++) out.w[w][dst] = s_key[w][q];
-        out.idx[dst] = s_idx[q];
-      }
-    }
-    __syncthreads();
-  }
-}
-
-
 // stable scatter of one tile by one digit, second generation.  A wave owns a CONTIGUOUS 64 x ITEMS-row segment of the tile and
 // ranks its rows against wave-private digit counters in LDS (ballot peer masks; LDS operations of one wave are ordered, so
 // no block barrier is needed between items) — 4 block barriers per tile instead of 3 per item.  The tile is then staged in LDS
@@ -563,101 +453,6 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter_kv(const uint64_t* __restr
   }
 }
 
-// The clustered take's pass (sort_table): one stable scatter of the packed keys by the TOP digit of their bucket number that also
-// carries every row's payload as ONE row-major record (records.hpp).  Afterwards rows whose keys are close sit close together
-// in `rec`, the row id of a key is its position in this order, and the take that ends the sort reads records from a window of
-// n / 2^bits rows at a time (tens of MB: Infinity-Cache resident) instead of random 128-byte lines of the whole table.  Same
-// ranking as k_rs_scatter2; the keys are staged through LDS, a record goes from its source row (inside the tile's own 4096-row
-// window of the source columns: cache hits) straight to its destination (32-64 contiguous bytes per row, whole runs per digit).
-template <int ITEMS, int R>
-__global__ __launch_bounds__(BLOCK) void k_rs_scatter_rec(const uint64_t* __restrict__ key_in, int64_t n, DivBy dv, int shift, int bits, int64_t n_tiles,
-                                                         const uint64_t* __restrict__ offsets, uint64_t* __restrict__ key_out, PackLayout L, uint8_t* __restrict__ rec) {
-  constexpr int TILE = BLOCK * ITEMS;
-  constexpr int NWAVE = BLOCK / WAVE;
-  constexpr int NS = R / 8;
-  __shared__ uint64_t s_key[TILE];
-  __shared__ uint16_t s_src[TILE];   // source row inside the tile
-  __shared__ uint8_t s_dig[TILE];
-  __shared__ unsigned int s_cnt[NWAVE][256];
-  __shared__ unsigned int s_start[256];
-  __shared__ unsigned int s_wtot[NWAVE];
-  __shared__ unsigned long long s_goff[256];
-  const unsigned mask = (1u << bits) - 1u;
-  const int wave = threadIdx.x >> 6;
-  const unsigned lane = lane_id();
-  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const int64_t lo = t * TILE;
-    const int tile_rows = (int)((n - lo) < TILE ? (n - lo) : TILE);
-#pragma unroll
-    for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
-    if ((int)threadIdx.x <= (int)mask) s_goff[threadIdx.x] = offsets[(int64_t)threadIdx.x * n_tiles + t];
-    __syncthreads();
-    uint64_t key[ITEMS];
-    unsigned dig[ITEMS], rank[ITEMS];
-#pragma unroll
-    for (int c = 0; c < ITEMS; c++) {
-      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
-      key[c] = key_in[lo + (j < tile_rows ? j : 0)];
-    }
-#pragma unroll
-    for (int c = 0; c < ITEMS; c++) {
-      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
-      const bool in = j < tile_rows;
-      dig[c] = in ? ((unsigned)(div_apply(key[c], dv) >> shift) & mask) : 0u;
-      uint64_t peers = ballot64(in);
-      for (int b = 0; b < bits; b++) {
-        const uint64_t bal = ballot64((dig[c] >> b) & 1u);
-        peers &= ((dig[c] >> b) & 1u) ? bal : ~bal;
-      }
-      const unsigned r_in_wave = mbcnt(peers);
-      const unsigned base = s_cnt[wave][dig[c]];
-      if (in && r_in_wave == 0) s_cnt[wave][dig[c]] = base + (unsigned)__popcll(peers);
-      rank[c] = base + r_in_wave;
-    }
-    __syncthreads();
-    {
-      unsigned run = 0;
-#pragma unroll
-      for (int w = 0; w < NWAVE; w++) {
-        const unsigned v = s_cnt[w][threadIdx.x];
-        s_cnt[w][threadIdx.x] = run;
-        run += v;
-      }
-      const unsigned inc = wave_inclusive_sum<unsigned>(run);
-      if (lane == 63) s_wtot[wave] = inc;
-      __syncthreads();
-      unsigned base = 0;
-      for (int w = 0; w < wave; w++) base += s_wtot[w];
-      s_start[threadIdx.x] = base + inc - run;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < ITEMS; c++) {
-      const int j = (wave * ITEMS + c) * WAVE + (int)lane;
-      if (j < tile_rows) {
-        const unsigned q = s_start[dig[c]] + s_cnt[wave][dig[c]] + rank[c];
-        s_key[q] = key[c];
-        s_src[q] = (uint16_t)j;
-        s_dig[q] = (uint8_t)dig[c];
-      }
-    }
-    __syncthreads();
-#pragma unroll 2
-    for (int c = 0; c < ITEMS; c++) {
-      const int q = c * BLOCK + threadIdx.x;
-      if (q < tile_rows) {
-        const unsigned d = s_dig[q];
-        const int64_t dst = (int64_t)(s_goff[d] + (unsigned)(q - (int)s_start[d]));
-        key_out[dst] = s_key[q];
-        uint64_t srec[NS];
-        record_build<NS>(L, lo + s_src[q], srec);
-        record_store<NS>(rec, dst, srec);
-      }
-    }
-    __syncthreads();
-  }
-}
-
 // ------------------------------------------------------------------------------ TopK narrowing
 // histogram of one digit over candidate rows
 __global__ __launch_bounds__(BLOCK) void k_select_hist(const uint64_t* __restrict__ word, const uint8_t* __restrict__ state, int64_t n, int shift, int bits,
@@ -725,10 +520,7 @@ struct SortedKeys {
 };
 
 // digits of a packed key of `total_bits` bits, least significant first; <= 8 bits each, none straddles a word
-static int max_digit_bits() {
-  static const int v = std::getenv("DFGPU_RS_DIGIT_BITS") ? std::max(1, std::min(8, std::atoi(std::getenv("DFGPU_RS_DIGIT_BITS")))) : 8;  // tuning knob
-  return v;
-}
+static int max_digit_bits() { return 8; }   // (digit widths and tile sizes were swept in round 2: profiles/r2_radix_sweep.md)
 static std::vector<Digit> key_digits(int total_bits) {
   std::vector<Digit> ds;
   const int mb = max_digit_bits();
@@ -750,8 +542,7 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
   Runtime& r = rt();
   if (n <= 1 || digits.empty()) return in;
   const int nwords = in.nwords;
-  static const int items1 = std::getenv("DFGPU_RS_ITEMS") ? std::atoi(std::getenv("DFGPU_RS_ITEMS")) : 16;  // tuning knob: 8 or 16 rows per thread (one key word); measured profiles/r2_radix_sweep.md
-  const int items = (nwords == 1 && items1 == 16 && !std::getenv("DFGPU_SORT_GEN1")) ? 16 : rs_items(nwords);
+  const int items = nwords == 1 ? 16 : rs_items(nwords);   // rows per thread (one key word: 16; measured profiles/r2_radix_sweep.md)
   const int64_t tile = (int64_t)BLOCK * items;
   const int64_t n_tiles = (n + tile - 1) / tile;
   SortedKeys cur = in, alt;
@@ -775,23 +566,11 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
     const DivBy dv = div_by(d.div);
     k_rs_hist<<<grid, BLOCK, 0, r.stream>>>(ck.w[d.word], n, dv, d.shift, d.bits, items, n_tiles, counts->as<uint32_t>());
     scan_u32(counts->as<uint32_t>(), (int64_t)nb * n_tiles, offsets->as<uint64_t>());
-    static const bool gen1 = std::getenv("DFGPU_SORT_GEN1") != nullptr;  // A/B knob: the first-generation scatter
     const uint32_t* idx_in = cur.idx ? cur.idx->as<uint32_t>() : nullptr;
-    if (gen1 && want_ids) {
-      switch (nwords) {
-        case 1: k_rs_scatter<1><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-        case 2: k_rs_scatter<2><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-        default: k_rs_scatter<3><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-      }
-    } else {
-      switch (nwords) {
-        case 1:
-          if (items == 16) k_rs_scatter2<1, 16><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob);
-          else k_rs_scatter2<1, rs_items(1)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob);
-          break;
-        case 2: k_rs_scatter2<2, rs_items(2)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-        default: k_rs_scatter2<3, rs_items(3)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-      }
+    switch (nwords) {
+      case 1: k_rs_scatter2<1, 16><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+      case 2: k_rs_scatter2<2, rs_items(2)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+      default: k_rs_scatter2<3, rs_items(3)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
     }
     DFGPU_HIP(hipGetLastError());
     std::swap(cur, alt);
@@ -1002,12 +781,11 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
 static BufPtr sorted_ids_local(const SortedKeys& sk, int64_t n, uint64_t key_space, bool& clobbered) {
   Runtime& r = rt();
   clobbered = false;
-  static const bool enabled = !(std::getenv("DFGPU_SORT_LOCAL") && std::getenv("DFGPU_SORT_LOCAL")[0] == '0');  // A/B knob
   // key_space = number of values the mixed-radix key can take (0: the key is not of that kind).  Buckets are key / width with
   // width = ceil(key_space / 2^top_bits): equal slices of the key space whatever its size, ~2300 rows each when keys spread evenly
   int top_bits = 0;
   while (top_bits < 32 && (n >> top_bits) > 2304) top_bits += 8;
-  if (!enabled || sk.nwords != 1 || n < 2 || n >= 0xFFFFFFFFll || key_space < 2 || (key_space >> top_bits) < 2) return nullptr;
+  if (sk.nwords != 1 || n < 2 || n >= 0xFFFFFFFFll || key_space < 2 || (key_space >> top_bits) < 2) return nullptr;
   const int64_t n_buckets = (int64_t)1 << top_bits;
   const uint64_t width = (key_space + (uint64_t)n_buckets - 1) / (uint64_t)n_buckets;
   int low_bits = 0;
@@ -1051,7 +829,7 @@ void radix_sort_pairs(BufPtr& key, BufPtr& idx, int64_t n, int lo_bit, int nbits
   }
   std::vector<Digit> digits;
   // 6-bit digits: a 64-way scatter of a 4096-row tile writes 64-row runs; 256-way passes cost 2x per pass (profiles/r2_radix_sweep.md)
-  const int mb = std::getenv("DFGPU_RS_DIGIT_BITS") ? max_digit_bits() : 6;
+  const int mb = 6;
   const int nd = (nbits + mb - 1) / mb;
   int pos = lo_bit;
   for (int d = 0; d < nd; d++) {
@@ -1145,8 +923,7 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
   int low_bits = 0;
   while (low_bits < 64 && ((width - 1) >> low_bits)) low_bits++;
   if (low_bits == 0) return false;
-  const int ITEMS = std::getenv("DFGPU_SORT_CARRIED_ITEMS") ? std::atoi(std::getenv("DFGPU_SORT_CARRIED_ITEMS")) : 8;   // tuning knob: 4, 8 or 16 rows per thread
-  DFGPU_CHECK(ITEMS == 4 || ITEMS == 8 || ITEMS == 16, "DFGPU_SORT_CARRIED_ITEMS: 4, 8 or 16");
+  constexpr int ITEMS = 8;   // rows per thread of the record-carrying pass (4: 7.06 ms, 8: 6.75 ms, 16: 9.03 ms for the two passes over 150 M orders)
   const int64_t tile = (int64_t)BLOCK * ITEMS, n_tiles = (n + tile - 1) / tile;
   BufPtr cur_key = keys, cur_rec, cur_idx;
   if (!through_passes) {
@@ -1192,15 +969,8 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
         kern<<<grid, BLOCK, lds, r.stream>>>(cur_key->as<uint64_t>(), first ? nullptr : cur_rec->as<uint4>(), L, n, dv, pos, bits, n_tiles, offsets->as<uint64_t>(),
                                            dst_key->as<uint64_t>(), dst_rec->as<uint4>());
       };
-      if (first) {
-        if (ITEMS == 4) launch(k_rs_scatter_kv<4, true>);
-        else if (ITEMS == 8) launch(k_rs_scatter_kv<8, true>);
-        else launch(k_rs_scatter_kv<16, true>);
-      } else {
-        if (ITEMS == 4) launch(k_rs_scatter_kv<4, false>);
-        else if (ITEMS == 8) launch(k_rs_scatter_kv<8, false>);
-        else launch(k_rs_scatter_kv<16, false>);
-      }
+      if (first) launch(k_rs_scatter_kv<ITEMS, true>);
+      else launch(k_rs_scatter_kv<ITEMS, false>);
       DFGPU_HIP(hipGetLastError());
       cur_key = dst_key;
       cur_rec = dst_rec;
@@ -1369,8 +1139,7 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     // c is chosen so that ~c n / S >> k rows are expected there; if the marked rows are fewer than k (never seen) or too many
     // (a few distinct keys: ties), the radix select below takes over.
     bool limited = false;
-    static const bool topk_limit = !(std::getenv("DFGPU_TOPK_LIMIT") && std::getenv("DFGPU_TOPK_LIMIT")[0] == '0');  // A/B knob
-    if (topk && narrow && topk_limit && n >= (1 << 20)) {
+    if (topk && narrow && n >= (1 << 20)) {
       const int64_t S = 1 << 16, every = n / S;
       const int64_t c = std::min<int64_t>(S, (n_out * S + n - 1) / n * 2 + 16);
       if (c < S / 4) {
@@ -1472,69 +1241,11 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       if (sort_carried(in, key_cols, pc, sk.w[0], n, key_space, out, keys_clobbered)) return out;
       if (keys_clobbered) pack_keys();   // (skewed keys: the paths below start from the packed keys again)
     }
-    // ---- clustered take: a full sort of a table far beyond the Infinity Cache whose columns fit ONE record.  Sorting row ids and
-    // taking the rows afterwards reads a random 128-byte line per row and column group (150 M orders: 19.9 GB for 4.8 GB of
-    // records, profiles/r2_ops_v3_traffic.md).  Instead ONE extra stable pass (k_rs_scatter_rec) moves keys AND records into the
-    // order of the top digit of the bucket number; the sort then runs over THAT order (row id = position in it), and the final
-    // take reads records from one top-digit group at a time — n / 256 rows, tens of MB, cache resident.
-    BufPtr rec;
-    PackLayout L{};
-    int R = 0;
-    std::vector<int> rec_order;
-    SortedKeys sk_sorted_from = sk;
-    {
-      // MEASURED AND NOT KEPT as the default (profiles/r3_sort_clustered.md): 150 M orders 12.6 -> 17.9 ms.  The record-carrying pass
-      // costs 7.1 ms (its per-row record build is 4 dependent gathers inside the tile: line-request bound), and the take from 18 MB
-      // groups runs at the Infinity Cache's random-line rate, which is barely above HBM's (3.5 vs 4.3 ms).  Opt-in for experiments.
-      const bool enabled = std::getenv("DFGPU_SORT_CLUSTERED_TAKE") && std::getenv("DFGPU_SORT_CLUSTERED_TAKE")[0] == '1';
-      const char* min_env = std::getenv("DFGPU_SORT_CLUSTERED_MIN_BYTES");  // test knob (default: 256 MiB of input columns)
-      const int64_t min_bytes = min_env ? std::atoll(min_env) : ((int64_t)256 << 20);
-      int64_t in_bytes = 0;
-      for (const Column& c : in.cols) in_bytes += (c.field.type == DFGPU_UTF8 || c.field.type == DFGPU_BOOL) ? 0 : n * type_width(c.field.type);
-      int top_bits = 0;
-      while (top_bits < 32 && (n >> top_bits) > 2304) top_bits += 8;
-      if (enabled && !remap && narrow && nwords == 1 && !sk.idx && n_out * 4 >= n && in_bytes > min_bytes && top_bits >= 8 && key_space >= 2 && (key_space >> top_bits) >= 2 &&
-          n < 0xFFFFFFFFll && plan_record_layout(in, allc, L, R, rec_order)) {
-        const int64_t n_buckets = (int64_t)1 << top_bits;
-        const uint64_t width = (key_space + (uint64_t)n_buckets - 1) / (uint64_t)n_buckets;
-        constexpr int ITEMS = 16;
-        const int64_t tile = (int64_t)BLOCK * ITEMS, n_tiles = (n + tile - 1) / tile;
-        const int hbits = 8, shift = top_bits - hbits;
-        BufPtr counts = make_buf((size_t)256 * n_tiles * 4), offsets = make_buf((size_t)(256 * n_tiles + 1) * 8);
-        BufPtr key_r = make_buf((size_t)n * 8);
-        rec = make_buf((size_t)n * R + 64);
-        const int grid = (int)std::min<int64_t>(n_tiles, 256 * 8);
-        const DivBy dv = div_by(width);
-        int payload = 0;
-        for (int q = 0; q < L.n; q++) payload += L.width[q];
-        {
-          ProfileScope ps("sort_cluster_records", n * (int64_t)(8 + 8 + payload + 8 + R));
-          k_rs_hist<<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, ITEMS, n_tiles, counts->as<uint32_t>());
-          scan_u32(counts->as<uint32_t>(), (int64_t)256 * n_tiles, offsets->as<uint64_t>());
-          switch (R) {
-            case 16: k_rs_scatter_rec<ITEMS, 16><<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, n_tiles, offsets->as<uint64_t>(), key_r->as<uint64_t>(), L, rec->as<uint8_t>()); break;
-            case 32: k_rs_scatter_rec<ITEMS, 32><<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, n_tiles, offsets->as<uint64_t>(), key_r->as<uint64_t>(), L, rec->as<uint8_t>()); break;
-            case 48: k_rs_scatter_rec<ITEMS, 48><<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, n_tiles, offsets->as<uint64_t>(), key_r->as<uint64_t>(), L, rec->as<uint8_t>()); break;
-            default: k_rs_scatter_rec<ITEMS, 64><<<grid, BLOCK, 0, r.stream>>>(sk.w[0]->as<uint64_t>(), n, dv, shift, hbits, n_tiles, offsets->as<uint64_t>(), key_r->as<uint64_t>(), L, rec->as<uint8_t>()); break;
-          }
-          DFGPU_HIP(hipGetLastError());
-        }
-        sk_sorted_from = SortedKeys{};
-        sk_sorted_from.nwords = 1;
-        sk_sorted_from.w[0] = key_r;   // row ids implicit: positions in the clustered order
-      }
-    }
+    // (round 3's 'clustered take' — one more stable pass that moved keys AND a 32-byte record per row into the order of the bucket
+    // number's top digit, so that the final take read records from 18 MB groups — measured 17.9 ms against 12.4-13.2 and stayed
+    // opt-in for a round (profiles/r3_sort_clustered.md); round 4 removed it: the carried sort above is what became of the idea)
     bool clobbered = false;
-    BufPtr sorted_idx = remap ? nullptr : sorted_ids_local(sk_sorted_from, m, key_space, clobbered);  // (TopK survivors are few: all-HBM passes)
-    if (rec && sorted_idx) {
-      out.cols = gather_records(in, allc, L, R, rec_order, rec->as<uint8_t>(), sorted_idx->as<uint32_t>(), n_out);
-      DFGPU_HIP(hipStreamSynchronize(r.stream));
-      return out;
-    }
-    if (rec) {  // skewed keys (a bucket beyond the LDS capacity): the plain path over the keys in their original order, which are intact
-      rec.reset();
-      clobbered = false;   // sorted_idx stays null: the all-HBM passes below (the same skew would stop the local sort again)
-    }
+    BufPtr sorted_idx = remap ? nullptr : sorted_ids_local(sk, m, key_space, clobbered);  // (TopK survivors are few: all-HBM passes)
     if (!sorted_idx) {
       if (clobbered) pack_keys();
       SortedKeys sorted = radix_sort(sk, m, digits);

@@ -430,8 +430,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
       if (a.len <= 24 || b.len <= 24) return a.len < b.len;
       return value_at(a.idx) < value_at(b.idx);
     };
-    static const bool device_sort_off = std::getenv("DFGPU_STRING_DEVICE_SORT") && std::getenv("DFGPU_STRING_DEVICE_SORT")[0] == '0';
-    if (G >= 16384 && !device_sort_off) {
+    if (G >= 16384) {
       // many distinct strings: the device orders them by their first 24 bytes (three prefix words through the sort operator's
       // radix passes: 150 K strings in a few launches, where 16 host threads sorting and merging took 3.3-4 ms); the host only
       // settles runs of equal prefixes with the full comparison — none for keys and names, a few for long common prefixes

@@ -51,14 +51,5 @@ if has bench; then
   (time timeout 600 python bench.py) > $OUT/bench.json 2> $OUT/bench.err
   tail -2 $OUT/bench.json; tail -3 $OUT/bench.err
 fi
-if has gpvariants; then   # grouped.hip tile variants on the shuffled key-only shape (group_rows kernels timed inside the join) + correctness of each
-  for V in A B C; do
-    (DFGPU_GP_VARIANT=$V timeout 600 python scripts/bench_join_shapes.py --only "unique shuffled build keys" --tables auto --iters 3) > $OUT/gpvariant_$V.jsonl 2> $OUT/gpvariant_$V.err
-    echo "GP_VARIANT=$V"; python - <<PY
-import json
-for ln in open("$OUT/gpvariant_$V.jsonl"):
-    r = json.loads(ln); print(r.get("ms"), r.get("kernel_ms_per_iter"))
-PY
-    (DFGPU_GP_VARIANT=$V timeout 600 python -m pytest tests/test_gpu_join.py -q -p no:cacheprovider -k "unclustered or key_only_probe") 2>&1 | tail -3
-  done
-fi
+# (gpvariants: the A/B/C tile shapes of grouped.hip were measured with DFGPU_GP_VARIANT — profiles/r4_group_rows.md — and the losing two
+# were removed together with the knob)

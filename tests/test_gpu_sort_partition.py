@@ -184,54 +184,6 @@ def test_topk_by_sampled_limit(shape, k):
     run_sort(t, keys, fetch=k)
 
 
-@pytest.mark.parametrize("shape", ["orders_shape", "skewed_top_bits", "heavy_ties", "wide_record_64_bytes", "partial_fetch"])
-def test_sort_clustered_take_carries_records_through_the_top_digit_pass(shape):
-    """the clustered take (sort.hip k_rs_scatter_rec; forced here for a table of a few MB): keys and ONE row-major record per row move
-    into top-digit order first, the sort runs over that order and the final take reads records group by group.  Same stable order as the
-    oracle, position by position: TPC-H orders' shape (two keys, one DESC, 24-byte payload), keys whose buckets overflow LDS (the
-    fallback after the records were made), long runs of ties, a 64-byte record of seven columns, and fetch = n / 2"""
-    import os
-    n = 700_000
-    rng = np.random.default_rng(len(shape))
-    fetch = None
-    if shape == "orders_shape":
-        t = pa.table({"o_orderkey": pa.array(rng.permutation(n).astype(np.int64) * 4 + 1), "o_custkey": pa.array(rng.integers(1, 10**6, n)),
-                      "o_orderdate": pa.array(rng.integers(8035, 10441, n).astype(np.int32), pa.int32()).cast(pa.date32()),
-                      "o_shippriority": pa.array(np.zeros(n, np.int32))})
-        keys = [("o_orderdate", False, False), ("o_orderkey", True, False)]
-    elif shape == "skewed_top_bits":
-        t = pa.table({"a": pa.array((rng.integers(0, 3, size=n) << 40) + rng.integers(0, 2**20, size=n)), "v": pa.array(np.arange(n, dtype=np.int64))})
-        keys = [("a", True, False)]
-    elif shape == "heavy_ties":
-        t = pa.table({"a": pa.array(rng.integers(0, 7, size=n) * 10**9), "v": pa.array(np.arange(n, dtype=np.int64)), "w": pa.array(rng.integers(0, 255, n).astype(np.uint8))})
-        keys = [("a", False, False)]
-    elif shape == "wide_record_64_bytes":
-        t = random_table(rng, n, {"d1": (pa.decimal128(15, 2), -10**9, 10**9), "d2": (pa.decimal128(15, 2), 0, 10**6), "k": (pa.int64(), -2**40, 2**40), "j": (pa.int64(), 0, 100),
-                                  "f": (pa.float64(), -100, 100), "i": (pa.int32(), -5, 5), "c": (pa.uint8(), 0, 200)})
-        t = t.append_column("x", pa.array(rng.integers(0, 2**31 - 1, n).astype(np.int32)))       # 16+16+8+8+8+4+1+4 = 65 bytes: does NOT fit -> plain path
-        run_sort(t, [("k", False, False)])
-        t = t.drop_columns(["c"])                                                                   # 64 bytes, seven columns: fits
-        keys = [("k", False, False), ("i", True, False)]
-    else:
-        t = pa.table({"a": pa.array(rng.integers(-2**40, 2**40, size=n)), "v": pa.array(np.arange(n, dtype=np.int64))})
-        keys, fetch = [("a", False, False)], n // 2
-    os.environ["DFGPU_SORT_CLUSTERED_MIN_BYTES"] = "0"
-    os.environ["DFGPU_SORT_CLUSTERED_TAKE"] = "1"                 # opt-in: measured slower than the plain take on MI355X (profiles/r3_sort_clustered.md)
-    try:
-        from datafusion_amd import ops
-        ops.profile_enable(True)
-        ops.profile_reset()
-        run_sort(t, keys, fetch)
-        stats = ops.profile_stats()
-        ops.profile_enable(False)
-        assert "sort_cluster_records" in stats, sorted(stats)                                       # the clustered pass really ran
-        if shape not in ("skewed_top_bits", "heavy_ties"):         # (those two overflow the LDS buckets: the fallback after the records were made)
-            assert "take_gather_rows" in stats and "take_pack_rows" not in stats
-    finally:
-        os.environ.pop("DFGPU_SORT_CLUSTERED_MIN_BYTES", None)
-        os.environ.pop("DFGPU_SORT_CLUSTERED_TAKE", None)
-
-
 @pytest.mark.parametrize("shape", ["orders_shape", "one_bucket", "three_keys_u8_date_desc", "payload_of_exactly_16_bytes", "skewed_top_bits", "heavy_ties",
                                    "payload_too_wide", "nullable_key", "uint32_and_negative_keys"])
 @pytest.mark.parametrize("mode", ["records_by_row_id", "records_through_the_passes"])
