@@ -395,11 +395,16 @@ def test_medium_cardinality_group_by_partitions_rows_then_accumulates_in_lds(key
     assert got.column("n").to_pylist() == cnt[order].tolist() == got.column("nw").to_pylist()
     assert got.column("lo").to_pylist() == lo[order].tolist() and got.column("hi").to_pylist() == hi[order].tolist()
     assert [int(x.scaleb(2)) for x in got.column("sd").to_pylist()] == sd[order].tolist()
-    # AVG(Decimal128(15, 2)) -> Decimal128(19, 6): sum * 10^4 / count in i128, truncating (DecimalAverager::avg, functions-aggregate-common/src/utils.rs)
-    def avg(s, c):
-        q = abs(int(s)) * 10**4 // int(c)
-        return q if s >= 0 else -q
-    assert [int(x.scaleb(6)) for x in got.column("ad").to_pylist()] == [avg(sd[c], cnt[c]) for c in order]
+    # AVG(Decimal128(15, 2)) -> Decimal128(19, 6) (DecimalAverager::avg, functions-aggregate-common/src/utils.rs): the rule is the
+    # ORACLE's, pinned by the reference's avg_cases — its Final mode turns the host's per-group (count, sum) state into the averages
+    from oracle import oracle
+    praw = np.empty((len(order), 2), dtype=np.int64)
+    praw[:, 0] = sd[order]
+    praw[:, 1] = sd[order] >> 63
+    state = pa.table({"k": pa.array(np.arange(len(order))), "ad[count]": pa.array(cnt[order].astype(np.uint64)),
+                      "ad[sum]": pa.Array.from_buffers(pa.decimal128(25, 2), len(order), [None, pa.py_buffer(praw.tobytes())])})
+    want = oracle.aggregate(state, [(to_oracle_expr(col("k")), "k")], [("avg", to_oracle_expr(col("k")), "ad")], "Final", return_types={"ad": pa.decimal128(19, 6)})
+    assert got.column("ad").to_pylist() == want.column("ad").to_pylist()
     assert np.allclose(got.column("sf").to_numpy(), sf[order], rtol=1e-9)
     assert got.column("s2").to_pylist() == (2 * sv[order]).tolist()
     sw = np.zeros(distinct, dtype=np.int64); np.add.at(sw, codes, i32)
