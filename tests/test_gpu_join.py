@@ -159,6 +159,41 @@ def test_flat_table_packed_keys(keys, join_type):
         assert_tables_equal(gpu_join(left, right, on, join_type, ne, table_mode=5, force_hash_collisions=True), exp)
 
 
+@pytest.mark.parametrize("shape", ["uniform_duplicates", "sample_sees_no_match", "nulls_both_equalities"])
+def test_flat_table_many_to_many_pairs_in_one_pass(shape):
+    """round 4: an INNER join over a flat table whose order nobody observes (probe_mode 4) makes its pairs in ONE pass — every tile of
+    probe rows reserves its pairs at a device-wide cursor (join.hip k_probe_pairs_single).  Same rows as the oracle (as multisets) over
+    duplicate keys on both sides and a two-column key; a probe side whose SAMPLED rows (every 2nd here) match nothing while the others
+    match three build rows each makes the first pair buffer too small: the cursor has counted the exact size and a second pass fits;
+    NULL keys under both NullEquality settings"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(len(shape))
+    nb, npr = 3000, 140_000                                              # np >= 65536: the single pass applies
+    bk = rng.integers(0, 1000, nb)
+    left = pa.table({"a": pa.array(bk.astype(np.int32)), "b": pa.array(bk * 7 - 2**40), "v": pa.array(np.arange(nb, dtype=np.int64))})
+    pk = rng.integers(0, 1400, npr)
+    if shape == "sample_sees_no_match":
+        pk = np.where(np.arange(npr) % 2 == 0, 5000 + pk, pk % 1000)     # even rows (the sampled ones) miss, odd rows hit ~3 build rows
+    nulls = (rng.random(npr) < 0.03) if shape == "nulls_both_equalities" else None
+    right = pa.table({"c": pa.array(pk.astype(np.int32), mask=nulls), "d": pa.array(pk * 7 - 2**40), "w": pa.array(rng.integers(0, 10**6, npr))})
+    if shape == "nulls_both_equalities":
+        lm = rng.random(nb) < 0.05
+        left = left.set_column(0, "a", pa.array(bk.astype(np.int32), mask=lm))
+    on = [("a", "c"), ("b", "d")]
+    for ne in (("NullEqualsNothing", "NullEqualsNull") if shape == "nulls_both_equalities" else ("NullEqualsNothing",)):
+        exp = oracle.hash_join(left, right, on, "Inner", ne)
+        ops.profile_enable(True)
+        ops.profile_reset()
+        got = gpu_join(left, right, on, "Inner", ne, probe_mode=4)
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+        assert stats["join_probe_pairs_single"]["calls"] == (2 if shape == "sample_sees_no_match" else 1) and "join_probe_count" not in stats, sorted(stats)
+        assert_tables_equal(got, exp)                                      # (multisets: the order is the tiles' arrival order)
+        assert_tables_equal(gpu_join(left, right, on, "Inner", ne, probe_mode=0), exp)   # the ordered two-pass path beside it
+
+
 def test_flat_table_selection():
     """auto: key columns that pack into 16 bytes get the hash table with inline keys (kinds 4 / 5), wider key sets the chained one"""
     from datafusion_amd import _lib, ops
