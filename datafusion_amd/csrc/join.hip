@@ -590,7 +590,7 @@ __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int6
       d[j] = c.ret_dest[ok[j] ? p : np - 1];
       if (c.row_mask) ok[j] = ok[j] && ((c.row_mask[w0 + j] >> lane) & 1ull);
     }
-    if (rec16) {  // 16-byte records: match id and build columns in ONE access, kept in registers until the row is written
+    if (rec16 && c.ret_R == 16) {  // 16-byte records: match id and build columns in ONE access, kept in registers until the row is written
 #pragma unroll
       for (int j = 0; j < N; j++) {
         ok[j] = ok[j] && d[j] != 0xFFFFFFFFu;
@@ -1202,7 +1202,9 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopy
     uint64_t key[KEYREG ? W : 1];
     uint4 rec16[KIND == KIND_RETURNED ? W : 1];
     const bool rec_in_regs = KIND == KIND_RETURNED && c.ret_R == 16;
-    lookup_words<KIND, KT, W>(c, w0, np, m, KEYREG ? key : nullptr, rec_in_regs ? rec16 : nullptr);
+    // (the array is handed over whenever the kind has records — a pointer chosen at run time kept it in scratch memory: 144 bytes per
+    // lane written and read back in the kernel that moves 65 GB; whether the records are 16 bytes wide is asked inside)
+    lookup_words<KIND, KT, W>(c, w0, np, m, KEYREG ? key : nullptr, KIND == KIND_RETURNED ? rec16 : nullptr);
     uint64_t word[W];  // wave-uniform (SGPR pairs)
     uint32_t wave_cnt = 0;
 #pragma unroll

@@ -393,7 +393,8 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter_kv(const uint64_t* __restr
         record_build<2>(L, src, sl);
         rec[c] = uint4{(unsigned)sl[0], (unsigned)(sl[0] >> 32), (unsigned)sl[1], (unsigned)(sl[1] >> 32)};
       } else {
-        rec[c] = rec_in[src];
+        const uint4 v = rec_in[src];   // (component by component: the 16-byte struct copy kept the whole array in scratch memory)
+        rec[c] = uint4{v.x, v.y, v.z, v.w};
       }
     }
 #pragma unroll
