@@ -655,7 +655,7 @@ __device__ __forceinline__ void sort_emit_row(const SortEmit& e, uint64_t full_k
 }
 // one workgroup per bucket: stable LSD sort of the bucket's (key, id) elements by the key's low `low_bits` bits, in LDS
 template <typename LK, bool EMIT = false>  // the key inside its bucket: 32 bits when `width` allows (less LDS and registers: more buckets in flight per CU)
-__global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ starts,
+__global__ __launch_bounds__(BLOCK, (sizeof(LK) == 4 ? 4 : 3)) void k_local_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ starts,
                                                       const uint32_t* __restrict__ ends, int64_t n_buckets, uint64_t width, int low_bits, uint32_t* __restrict__ idx_out,
                                                       SortEmit emit = SortEmit{}) {
   constexpr int NWAVE = BLOCK / WAVE;
