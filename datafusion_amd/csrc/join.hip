@@ -1172,7 +1172,9 @@ __global__ __launch_bounds__(BLOCK) void k_join_tile_counts(ProbeCtx c, int64_t 
 
 enum FusedMode : int { FUSED_UNORDERED = 0, FUSED_LOOKBACK = 1, FUSED_PLACED = 2 };
 template <int KIND, int KT, int W, int MODE, bool KEYREG>
-__global__ __launch_bounds__(BLOCK) void k_join_probe_fused(ProbeCtx c, JoinCopyCols cols, int64_t np, int invert, uint64_t* __restrict__ tile_state,
+// (flat tables: the lookup is a random line per row, a fourth wave per SIMD buys 0.2 ms of 2.0 on the Decimal128 shape.  The other kinds
+// keep the compiler's own choice: the same bound took the rank-map instance of the SF100 probe from 9.1 to 11.4 ms)
+__global__ __launch_bounds__(BLOCK, ((KIND == KIND_FLAT || KIND == KIND_FLAT16) ? 4 : 1)) void k_join_probe_fused(ProbeCtx c, JoinCopyCols cols, int64_t np, int invert, uint64_t* __restrict__ tile_state,
                                                             FusedCtl* __restrict__ ctl, const uint64_t* __restrict__ row_mask) {
   constexpr bool ORDERED = MODE == FUSED_LOOKBACK;
   __shared__ unsigned s_tile;
