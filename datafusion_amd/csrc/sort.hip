@@ -893,8 +893,8 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
                          bool& clobbered) {
   Runtime& r = rt();
   clobbered = false;
-  // DFGPU_SORT_CARRIED: 0 = off; passes = the records travel through the top passes (measured: what the take saves the passes lose,
-  // 12.0 ms either way for 150 M orders); default = row ids through the passes as before, records taken by row id INSIDE the bucket sort
+  // DFGPU_SORT_CARRIED: 0 = off; passes = the records travel through the top passes (measured: the passes lose more than the take
+  // they save, 11.1 ms against 9.9 for 150 M orders); default = row ids through the passes as before, records taken by row id INSIDE the bucket sort
   const char* mode_env = std::getenv("DFGPU_SORT_CARRIED");
   const bool off = mode_env && mode_env[0] == '0';
   const bool through_passes = mode_env && mode_env[0] == 'p';
@@ -1236,7 +1236,7 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     // OTHER columns fit a 16-byte record.  The record travels with the key through the top passes (the first pass reads it from the
     // source columns — or, the default, row ids travel and the records are fetched by row id), the bucket sort in LDS writes the OUTPUT: key
     // columns decoded from the sorted key, the record's fields from the records.  No separate take: orders by (o_orderdate, o_orderkey DESC)
-    // 10.5 ms against 11.9 (the take alone was 5.7: a random line per row, profiles/r3_sort_clustered.md).
+    // 9.9 ms against 11.9 (the take alone was 5.7: a random line per row, profiles/r3_sort_clustered.md).
     if (!remap && narrow && nwords == 1 && !sk.idx && n_out == n && m == n) {
       bool keys_clobbered = false;
       if (sort_carried(in, key_cols, pc, sk.w[0], n, key_space, out, keys_clobbered)) return out;
