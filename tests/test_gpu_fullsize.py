@@ -287,6 +287,50 @@ def test_sf100_group_by_custkey_partitioned_equals_global_atomics(monkeypatch):
         t.free()
 
 
+def test_two_column_many_to_many_join_at_60m_probe_rows_one_pass_equals_two_passes():
+    """the benchmark's two-column shape (1 M build rows with duplicate (Int32, Int64) keys x 60 M probe rows, flat table) at its size:
+    the pairs made in ONE pass under probe_mode 4 (round 4, k_probe_pairs_single) and the counts + pairs passes of the ordered probe
+    give the same number of rows and the same wrapping sums of every output column — and both equal what the host derives from the
+    key counts: rows = sum over probe rows of the build rows carrying their key, and sum(v * w) over the joined rows = sum over probe rows
+    of w x (the sum of v over the key's build rows), which a wrong pairing of build and probe rows cannot reproduce"""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(2024)
+    nb, npr, nkeys, nprobe_keys = 1_000_000, 60_000_000, 400_000, 500_000
+    bk = rng.integers(0, nkeys, nb)
+    v = rng.integers(0, 10**6, nb)
+    build = DeviceTable.from_arrow(pa.table({"a": pa.array(bk.astype(np.int32)), "b": pa.array(bk * 7 - 2**40), "v": pa.array(v)}))
+    pk = rng.integers(0, nprobe_keys, npr)
+    w = rng.integers(0, 1000, npr)
+    probe = DeviceTable.from_arrow(pa.table({"c": pa.array(pk.astype(np.int32)), "d": pa.array(pk * 7 - 2**40), "w": pa.array(w)}))
+    rows_per_key = np.bincount(bk, minlength=nprobe_keys)
+    v_per_key = np.zeros(nprobe_keys, dtype=np.int64)
+    np.add.at(v_per_key, bk, v)
+    want_rows = int(rows_per_key[pk].sum())
+    want_vw = int((v_per_key[pk] * w).sum())
+    assert 100_000_000 < want_rows < 200_000_000
+    on = [("a", "c"), ("b", "d")]
+    seen = {}
+    for mode in (4, 0):
+        ops.profile_enable(True)
+        ops.profile_reset()
+        out = ops.hash_join(build, probe, on, "Inner", probe_mode=mode)
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+        assert ("join_probe_pairs_single" in stats) == (mode == 4) and ("join_probe_count" in stats) == (mode == 0), sorted(stats)
+        sums = _sums(out, ["a", "b", "v", "c", "d", "w"])
+        vw = ops.project(out, [(col("v") * col("w"), "vw")])
+        sums["vw"] = _sums(vw, ["vw"])["vw"]
+        vw.free()
+        out.free()
+        assert sums["n"] == want_rows and sums["vw"] == want_vw, (mode, sums, want_rows, want_vw)
+        seen[mode] = sums
+    assert seen[4] == seen[0]
+    build.free()
+    probe.free()
+
+
 def test_sf300_q3_on_one_gpu():
     """BASELINE config 5's N = 1 anchor: TPC-H Q3 at SF300 (45 M customers, 450 M orders, 1.8 G lineitem rows; ~91 GB of referenced
     columns) on ONE MI355X, as the plan of tpch/plans/q3.slt.part:60-76.  No oracle finishes this: the two executions of the plan —
