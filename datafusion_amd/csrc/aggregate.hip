@@ -492,18 +492,28 @@ __global__ __launch_bounds__(BLOCK) void k_u8_presence(const uint8_t* __restrict
   if (threadIdx.x < 8) s_bits[threadIdx.x] = 0;
   __syncthreads();
   unsigned mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t n4 = n / 4;
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * BLOCK) {
-    const uint32_t w = reinterpret_cast<const uint32_t*>(col)[i];
+  auto mark = [&](unsigned v) {   // (constant indices: the eight words stay in registers)
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const unsigned v = (w >> (8 * b)) & 255u;
-      mine[v >> 5] |= 1u << (v & 31);
+    for (int q = 0; q < 8; q++) mine[q] |= (v >> 5) == (unsigned)q ? 1u << (v & 31) : 0u;
+  };
+  // 16 bytes per lane and load; the column's start is 16-byte aligned or the head is done bytewise.  (0.43 ms per 600 M rows either way,
+  // with 4-byte loads as well: the pass is bound by its ~26 VALU operations per byte — eight compare / select / or per value —, not by
+  // its loads.  It runs once per column and table: the set is kept with the column's statistics.)
+  const int64_t head = std::min<int64_t>(n, (16 - ((uintptr_t)col & 15)) & 15);
+  const int64_t n16 = (n - head) / 16;
+  const uint4* v16 = reinterpret_cast<const uint4*>(col + head);
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (int64_t)gridDim.x * BLOCK) {
+    const uint4 w = v16[i];
+    const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+      for (int b = 0; b < 4; b++) mark((ws[k] >> (8 * b)) & 255u);
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {
-    const unsigned v = col[n4 * 4 + threadIdx.x];
-    mine[v >> 5] |= 1u << (v & 31);
+  if (blockIdx.x == 0) {   // the unaligned head and the tail
+    for (int64_t i = threadIdx.x; i < head; i += BLOCK) mark(col[i]);
+    for (int64_t i = head + n16 * 16 + threadIdx.x; i < n; i += BLOCK) mark(col[i]);
   }
 #pragma unroll
   for (int q = 0; q < 8; q++)
@@ -1207,7 +1217,7 @@ static ColStats u8_presence(Column& c, int64_t n) {
   BufPtr d = make_zero_buf(32);
   {
     ProfileScope ps("column_u8_presence", n);
-    k_u8_presence<<<std::min(grid_for(n / 4 + 1, BLOCK * 8), 2048), BLOCK, 0, r.stream>>>((const uint8_t*)c.ptr(), n, d->as<unsigned long long>());
+    k_u8_presence<<<std::min(grid_for(n / 16 + 1, BLOCK * 4), 2048), BLOCK, 0, r.stream>>>((const uint8_t*)c.ptr(), n, d->as<unsigned long long>());
     DFGPU_HIP(hipGetLastError());
   }
   d2h(st.present, d->ptr, 32);
