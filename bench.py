@@ -354,22 +354,7 @@ def run_join(args, rank, world, dist):
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_vs_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
                 "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
-        try:  # HBM bytes per launch from the committed PMC passes (scripts/profile.sh): this workload, this device kernel, and the
-            # kernel's SOURCE as it was when the passes were taken (a kernel edit without a fresh PMC pass reports no traffic)
-            import hashlib
-            for tr in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]:
-                wl = tr["workload"]
-                if tr["kernel"] != name or (wl["build_rows"], wl["probe_rows"], wl["output_rows"]) != (nb, np_, nout) or world != 1:
-                    continue
-                cur = hashlib.sha256(open(os.path.join(ROOT, tr.get("kernel_source", "datafusion_amd/csrc/join.hip")), "rb").read()).hexdigest()[:16]
-                if tr.get("kernel_source_sha16") != cur:
-                    roof["traffic_note"] = f"the PMC passes in profiles/{tr['source']} (commit {tr.get('commit')}) predate the kernel's source: not attached"
-                    continue
-                roof["traffic"] = tr["traffic_bytes_per_launch"]
-                roof["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {tr['device_kernel']} at commit {tr.get('commit')}, "
-                                          f"profiles/{tr['source']}")
-        except (OSError, KeyError, ValueError, TypeError):
-            pass
+        attach_traffic(roof, name, {"build_rows": nb, "probe_rows": np_, "output_rows": nout}, world)
         return roof
 
     def kernel_table(st):
@@ -431,6 +416,149 @@ def run_join(args, rank, world, dist):
     return line
 
 
+# ProfileScope name (the library's HIP-event table) -> the device kernel's name as rocprofv3 prints it (prefix match)
+DEVICE_KERNEL_OF = {"agg_fused_jit": "agg_node", "agg_fused_tile": "k_agg_fused_tile", "join_probe_tile_counts": "k_join_tile_counts",
+                    "join_probe_listed": "k_join_emit_listed", "join_probe_fused": "k_join_probe_fused", "join_probe_placed": "k_join_probe_fused",
+                    "cmp": "k_cmp", "compact": "k_compact", "agg_fused_global": "k_agg_fused", "agg_fused_lds": "k_agg_fused"}
+
+
+def attach_traffic(roof, name, workload_key, world):
+    """HBM bytes per launch from the committed PMC passes (scripts/profile.sh -> profiles/traffic.json): this workload, this device
+    kernel, and the kernel's SOURCE as it was when the passes were taken (a kernel edit without a fresh PMC pass reports no traffic)"""
+    try:
+        import hashlib
+        for tr in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]:
+            if tr["kernel"] != name or tr["workload"] != workload_key or world != 1:
+                continue
+            cur = hashlib.sha256(open(os.path.join(ROOT, tr.get("kernel_source", "datafusion_amd/csrc/join.hip")), "rb").read()).hexdigest()[:16]
+            if tr.get("kernel_source_sha16") != cur:
+                roof["traffic_note"] = f"the PMC passes in profiles/{tr['source']} (commit {tr.get('commit')}) predate the kernel's source: not attached"
+                continue
+            roof["traffic"] = tr["traffic_bytes_per_launch"]
+            roof["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {tr['device_kernel']} at commit {tr.get('commit')}, "
+                                      f"profiles/{tr['source']}")
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    return roof
+
+
+def q3_algorithmic_table(n_customer, n_orders, n_lineitem, st):
+    """sum over the plan's operators of (referenced input column bytes + output bytes), intermediate row counts
+    as measured (queries.q3's `stats`).  c_mktsegment is a 1-byte dictionary code here (the string layout in use)."""
+    c, semi, j, g = st["customer_filtered"], st["semi_join"], st["join"], st["groups"]
+    rows = [("FilterExec customer (c_mktsegment = BUILDING) -> [c_custkey]", n_customer * (8 + 1), c * 8),
+            ("FilterExec orders (o_orderdate < 1995-03-15) + HashJoinExec RightSemi (c_custkey = o_custkey) -> [o_orderkey, o_orderdate, o_shippriority]",
+             c * 8 + n_orders * (8 + 8 + 4 + 4), semi * 16),
+            ("FilterExec lineitem (l_shipdate > 1995-03-15) + HashJoinExec Inner (o_orderkey = l_orderkey) -> Q3 payload",
+             semi * 16 + n_lineitem * (8 + 16 + 16 + 4), j * 48),
+            ("AggregateExec gby [l_orderkey, o_orderdate, o_shippriority] SUM(l_extendedprice * (1 - l_discount))", j * 48, g * (8 + 4 + 4 + 16)),
+            ("SortExec TopK(10) [revenue DESC, o_orderdate]", g * (16 + 4), 10 * 32)]
+    return [{"operator": o, "input_bytes": int(i), "output_bytes": int(w)} for o, i, w in rows]
+
+
+def cpu_baseline_query(workload, gpu_sf, hw_threads, budget_s=20.0):
+    """oracle leg (kind "port") of configs 4 / 5: the reference's pinned plan (q1.slt.part:42-58 / q3.slt.part:44-76) run with the CPU
+    restatement's operators (oracle/oracle.py over oracle/dforacle.c) on this box's host cores, the way DataFusion runs it: the scan cut
+    into `target_partitions` row ranges, one thread per partition — Partial aggregate / filter per partition, RepartitionExec(Hash) between
+    the stages, FinalPartitioned aggregate / partitioned joins per hash partition, a merge of the per-partition sorted runs.  The scale
+    factor is a BOUNDED sample: SF1 is timed first and the largest of SF 1 / 3 / 10 / 30 whose projected time fits ~budget_s is run."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+    import pyarrow as pa
+
+    from datafusion_amd import queries
+    from oracle import oracle
+    quota = cpu_quota()
+    cores = max(1, int(min(hw_threads, quota) if quota else hw_threads))
+    P = cores
+    D1, D3 = queries.DATE_Q1, queries.DATE_Q3
+    ce = ("bin", "*", ("col", "l_extendedprice"), ("bin", "-", ("lit", 1, pa.decimal128(20, 0)), ("col", "l_discount")))
+
+    def slices(t):
+        n = t.num_rows
+        return [t.slice(n * k // P, n * (k + 1) // P - n * k // P) for k in range(P)]
+
+    def by_hash(parts, key):
+        """RepartitionExec(Hash([key], P)): every input partition splits its rows by the reference's hash routing; output partition q
+        is the concatenation of the q-th pieces"""
+        def split(t):
+            if t.num_rows == 0:
+                return [t] * P
+            return oracle.hash_partition(t, [key], P)[0]
+        with ThreadPoolExecutor(P) as ex:
+            pieces = list(ex.map(split, parts))
+        return [pa.concat_tables([pieces[i][q] for i in range(len(parts))]) for q in range(P)]
+
+    def run_q1(li):
+        gb = [(("col", "l_returnflag"), "l_returnflag"), (("col", "l_linestatus"), "l_linestatus")]
+        one_plus_tax = ("bin", "+", ("lit", 1, pa.decimal128(20, 0)), ("col", "l_tax"))
+        aggs = [("sum", ("col", "l_quantity"), "sum_qty"), ("sum", ("col", "l_extendedprice"), "sum_base_price"), ("sum", ce, "sum_disc_price"),
+                ("sum", ("bin", "*", ce, one_plus_tax), "sum_charge"), ("avg", ("col", "l_quantity"), "avg_qty"),
+                ("avg", ("col", "l_extendedprice"), "avg_price"), ("avg", ("col", "l_discount"), "avg_disc"), ("count", None, "count_order")]
+
+        def partial(t):
+            f = oracle.filter(t, ("bin", "<=", ("col", "l_shipdate"), ("lit", D1, pa.date32())),
+                              ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus"])
+            return oracle.aggregate(f, gb, aggs, "Partial")
+        with ThreadPoolExecutor(P) as ex:
+            parts = list(ex.map(partial, slices(li)))
+        rt = {"avg_qty": pa.decimal128(19, 6), "avg_price": pa.decimal128(19, 6), "avg_disc": pa.decimal128(19, 6)}
+        fin = oracle.aggregate(pa.concat_tables(parts), gb, aggs, "FinalPartitioned", return_types=rt)
+        return oracle.sort(fin, [("l_returnflag", False, False), ("l_linestatus", False, False)])
+
+    def run_q3(cu, od, li):
+        with ThreadPoolExecutor(P) as ex:
+            c = list(ex.map(lambda t: oracle.filter(t, ("bin", "=", ("col", "c_mktsegment"), ("lit", queries.SEGMENT_BUILDING, pa.uint8())), ["c_custkey"]), slices(cu)))
+            o = list(ex.map(lambda t: oracle.filter(t, ("bin", "<", ("col", "o_orderdate"), ("lit", D3, pa.date32())),
+                                                    ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"]), slices(od)))
+            l = list(ex.map(lambda t: oracle.filter(t, ("bin", ">", ("col", "l_shipdate"), ("lit", D3, pa.date32())),
+                                                    ["l_orderkey", "l_extendedprice", "l_discount"]), slices(li)))
+        c_r, o_r = by_hash(c, "c_custkey"), by_hash(o, "o_custkey")
+        with ThreadPoolExecutor(P) as ex:
+            semi = list(ex.map(lambda ab: oracle.hash_join(ab[0], ab[1], [("c_custkey", "o_custkey")], "RightSemi").select(["o_orderkey", "o_orderdate", "o_shippriority"]),
+                               zip(c_r, o_r)))
+        s_r, l_r = by_hash(semi, "o_orderkey"), by_hash(l, "l_orderkey")
+        gb = [(("col", "l_orderkey"), "l_orderkey"), (("col", "o_orderdate"), "o_orderdate"), (("col", "o_shippriority"), "o_shippriority")]
+
+        def tail(ab):
+            j = oracle.hash_join(ab[0], ab[1], [("o_orderkey", "l_orderkey")], "Inner").select(["o_orderdate", "o_shippriority", "l_orderkey", "l_extendedprice", "l_discount"])
+            a = oracle.aggregate(j, gb, [("sum", ce, "revenue")], "SinglePartitioned")
+            return oracle.sort(a, queries.Q3_SORT, fetch=10)
+        with ThreadPoolExecutor(P) as ex:
+            tops = list(ex.map(tail, zip(s_r, l_r)))
+        return oracle.sort(pa.concat_tables(tops), queries.Q3_SORT, fetch=10)
+
+    def tables(sf):
+        """the sample's tables from the DEVICE generator (the GPU leg's own, seconds instead of the numpy mirror's minute), copied to the host"""
+        from datafusion_amd import ops
+        gens = (ops.tpch_lineitem,) if workload == "q1" else (ops.tpch_customer, ops.tpch_orders, ops.tpch_lineitem)
+        out = []
+        for g in gens:
+            t = g(sf)
+            out.append(t.to_arrow())
+            t.free()
+        return tuple(out)
+
+    def once(sf):
+        ts = tables(sf)
+        t0 = time.perf_counter()
+        out = run_q1(*ts) if workload == "q1" else run_q3(*ts)
+        return time.perf_counter() - t0, sum(t.num_rows for t in ts), out.num_rows
+    dt, rows, n_out = once(1.0)
+    sf = 1.0
+    for cand in (30.0, 10.0, 3.0):
+        if cand <= gpu_sf and dt * cand <= budget_s:
+            sf = cand
+            dt, rows, n_out = once(sf)
+            break
+    return {"value": rows / dt, "unit": "rows/s", "cores": cores, "threads": P, "kind": "port", "sf": sf, "seconds": round(dt, 2),
+            "same_workload_as_gpu_leg": bool(sf == gpu_sf), "cpu_quota": quota,
+            "sample": f"TPC-H {workload.upper()} at SF{sf:g} ({rows} scanned rows, {n_out} output rows), tables from the GPU leg's own generator copied to "
+                      f"the host: the reference's pinned plan on the oracle's operators, "
+                      f"{P} partitions / threads (host has {hw_threads} hardware threads, cgroup CPU quota {quota})"}
+
+
 def run_query(args, rank, world, dist):
     """BASELINE config 4 (TPC-H Q1, grouped hash aggregate, 1 -> 8 GPUs with the hash repartition of the partial states) and
     config 5 (TPC-H Q3 end to end: 3-way join + aggregate + top-k; four repartitions in two exchange phases at N > 1)"""
@@ -455,6 +583,7 @@ def run_query(args, rank, world, dist):
             dist.barrier()
 
     group = None  # the default group: queries.* route their RepartitionExecs through exchange.hash_exchange -> dfgpu_exchange_hash
+    q3_stats = {}
 
     def step():
         out = queries.q1(lineitem, group) if args.workload == "q1" else queries.q3(*tables, group=group)
@@ -463,6 +592,8 @@ def run_query(args, rank, world, dist):
         return n
     for _ in range(args.warmup):
         step()
+    if args.workload == "q3":   # the intermediate row counts of the algorithmic-bytes table (8d config 5), outside the timed region
+        queries.q3(*tables, group=group, stats=q3_stats).free()
     comm = None
     if world > 1:
         from datafusion_amd.exchange import comm_for
@@ -470,25 +601,62 @@ def run_query(args, rank, world, dist):
         comm.stats(reset=True)
     ops.profile_enable(True)
     ops.profile_reset()
+    ops.metrics_reset()
     dt, n_out = timed(step, args.steps, barrier)
     stats = ops.profile_stats()
+    alg_local = ops.metrics()["hbm_bytes_algorithmic"] // args.steps   # sum of the kernels' algorithmic bytes of one step, as the library counts them
     ops.profile_enable(False)
     xs = comm.stats(reset=True) if comm is not None else None
-    dt, (rows, nbytes) = max_over_ranks(dist, dt, rows_local, bytes_local)
+    dt, (rows, nbytes, alg_kernels) = max_over_ranks(dist, dt, rows_local, bytes_local, alg_local)
+    counts = None
+    if args.workload == "q3":
+        counts = max_over_ranks(dist, 0.0, *(q3_stats.get(k, 0) for k in ("customer_filtered", "semi_join", "join", "groups")), *(t.num_rows for t in tables))[1]
     if rank != 0:
         return None
+    step_s = dt / args.steps
     top = sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
-    return {
-        "metric": f"tpch_{args.workload}_rows_per_sec", "value": rows / (dt / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+    # config 4 = the Arrow buffer bytes of the 7 referenced columns (l_shipdate 4 + 4 x Decimal128 64 + 2 flags as 1-byte
+    # codes = 70 B/row; the 4 x 10 output values are noise); config 5 = the operator table with the measured intermediate row counts
+    if args.workload == "q1":
+        alg_table = [{"operator": "FilterExec + ProjectionExec + AggregateExec (fused node) over [l_shipdate, l_quantity, l_extendedprice, l_discount, l_tax, "
+                                  "l_returnflag (u8), l_linestatus (u8)]", "input_bytes": rows * 70, "output_bytes": n_out * 10 * 16}]
+    else:
+        alg_table = q3_algorithmic_table(counts[4], counts[5], counts[6], dict(zip(("customer_filtered", "semi_join", "join", "groups"), counts[:4])))
+    alg = sum(r["input_bytes"] + r["output_bytes"] for r in alg_table)
+    roof = None
+    if top and top[0][1]["calls"]:
+        name, d = top[0]
+        avg_ms, per_launch = d["total_ms"] / d["calls"], d["bytes"] / d["calls"]
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": name, "device_kernel": DEVICE_KERNEL_OF.get(name), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_vs_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": d["calls"] / args.steps, "algorithmic_bytes_per_launch": int(per_launch),
+                "share_of_step": round(d["total_ms"] / args.steps / (step_s * 1e3), 3)}
+        attach_traffic(roof, name, {"query": args.workload, "sf": args.sf, "input_rows": rows}, world)
+    line = {
+        "metric": f"tpch_{args.workload}_rows_per_sec", "value": rows / step_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "decimal128 / int64", "data": "synthetic",
         "config": {"workload": ("TPC-H Q1 (FilterExec + ProjectionExec + grouped AggregateExec fused, Partial -> hash exchange -> FinalPartitioned at N > 1)" if args.workload == "q1"
                                 else "TPC-H Q3 end to end (2 hash joins + aggregate + top-k; at N > 1 four hash repartitions in two exchange phases)") + f", SF{args.sf:g}, device-resident inputs",
                    "input_rows": rows, "output_rows": n_out, "parallelism": "single GPU" if world == 1 else f"{world} ranks, dfgpu_exchange_hash (RCCL all-to-all(v))"},
-        "scanned_table_gb_per_s": round(nbytes / (dt / args.steps) / 1e9, 1),
+        "scanned_table_gb_per_s": round(nbytes / step_s / 1e9, 1),
+        "algorithmic_bytes_per_step": int(alg), "algorithmic_bytes_table": alg_table,
+        "algorithmic_gb_per_s": round(alg / step_s / 1e9, 1), "hbm_frac_whole_step": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 4),
+        "kernel_algorithmic_bytes_per_step": int(alg_kernels),
+        "roofline": roof,
         "kernels": {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in top},
+        "kernel_ms_per_step": round(sum(v["total_ms"] for v in stats.values()) / args.steps, 4),
         "crossed_per_step_rank0": {k: v // args.steps for k, v in xs.items()} if xs else None,
     }
+    if counts is not None:
+        line["config"]["intermediate_rows"] = dict(zip(("customer_filtered", "semi_join", "join", "groups"), counts[:4]))
+    if not args.no_cpu and world == 1:
+        for t in tables:
+            t.free()
+        line["cpu_baseline"] = cpu_baseline_query(args.workload, args.sf, os.cpu_count() or 1)
+        line["speedup_vs_cpu_port"] = round(line["value"] / line["cpu_baseline"]["value"], 1) if line["cpu_baseline"]["same_workload_as_gpu_leg"] else None
+    return line
 
 
 def main():

@@ -2322,21 +2322,23 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   const int64_t n_windows = (int64_t)((range - 1) >> wshift) + 1;
   const size_t W = (size_t)1 << wshift;
   const size_t bytes_per_value = LDS_BUDGET / W - 4;   // of LDS, beside the first row
-  // more than 64 KB of dynamic LDS has to be asked for, per kernel
+  // more than 64 KB of dynamic LDS has to be asked for, per kernel (and per device: not cached) — on EVERY key-type instantiation:
+  // which one is launched is only final further down (grouped_move can still fall back to the two-level move of the original key type)
   {
-    const void* fn = nullptr;
-    switch (grouped_move ? (range <= (1ull << 32) ? (int)DFGPU_UINT32 : (int)DFGPU_INT64) : kt) {
-      case DFGPU_INT64: fn = (const void*)k_dense_accumulate_parts<int64_t>; break;
-      case DFGPU_UINT32: fn = (const void*)k_dense_accumulate_parts<uint32_t>; break;
-      case DFGPU_UINT8: fn = (const void*)k_dense_accumulate_parts<uint8_t>; break;
-      default: fn = (const void*)k_dense_accumulate_parts<int32_t>; break;
-    }
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_MAX) != hipSuccess) {
-      // the windows and the accumulators per value above were sized for LDS_BUDGET: a device that does not grant it (none of the
-      // CDNA parts this is built for) takes the global-atomic path instead of launching with more LDS than it has
-      (void)hipGetLastError();
-      return false;
-    }
+    const bool granted = [] {
+      const void* fns[] = {(const void*)k_dense_accumulate_parts<int64_t>, (const void*)k_dense_accumulate_parts<uint32_t>,
+                           (const void*)k_dense_accumulate_parts<uint8_t>, (const void*)k_dense_accumulate_parts<int32_t>};
+      bool ok = true;
+      for (const void* fn : fns)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_MAX) != hipSuccess) {
+          (void)hipGetLastError();
+          ok = false;
+        }
+      return ok;
+    }();
+    // the windows and the accumulators per value above were sized for LDS_BUDGET: a device that does not grant it (none of the
+    // CDNA parts this is built for) takes the global-atomic path instead of launching with more LDS than it has
+    if (!granted) return false;
   }
   Runtime& r = rt();
   // what moves: the key, every distinct argument column, the row numbers

@@ -341,7 +341,8 @@ int format_width(const std::string& fmt) {
 // their data buffers, dictionary indices against the dictionary.  arrow-ipc's reader validates the same (ArrayData::validate_full
 // for untrusted input); a truncated or corrupt file must fail here, not read beyond a host mapping.
 void validate_column(const IpcField& f, int64_t length, int64_t nulls, const std::vector<const void*>& bl, const std::vector<int64_t>& lens, int64_t dict_len) {
-  DFGPU_CHECK(length >= 0 && nulls >= 0 && nulls <= length, "arrow ipc: column '" + f.name + "': bad field node (length / null count)");
+  // (length is untrusted: bounded before any size product below, so that no `length * width` can wrap past a buffer-length check)
+  DFGPU_CHECK(length >= 0 && length < ((int64_t)1 << 48) && nulls >= 0 && nulls <= length, "arrow ipc: column '" + f.name + "': bad field node (length / null count)");
   const std::string what = "arrow ipc: column '" + f.name + "': ";
   if (nulls > 0) DFGPU_CHECK(lens[0] >= (length + 7) / 8, what + "validity buffer shorter than its rows");
   const uint8_t* valid = nulls > 0 ? static_cast<const uint8_t*>(bl[0]) : nullptr;

@@ -920,12 +920,13 @@ __global__ __launch_bounds__(BLOCK) void k_probe_pairs_single(ProbeCtx c, int64_
     const int64_t w0 = tile * TILE_WORDS + (int64_t)wv * W;
     uint32_t m[W], rws[W];
     lookup_words<KIND, KT_ANY, W>(c, w0, np, m, nullptr, nullptr, rws);
-    uint32_t inc[W];
+    // pair counts are summed in 64 bits: one 64-row word over heavily duplicated build keys can hold >= 2^31 pairs
+    uint64_t inc[W];
     unsigned long long wave_total = 0;
 #pragma unroll
     for (int j = 0; j < W; j++) {
-      inc[j] = wave_inclusive_sum(rws[j]);
-      wave_total += (unsigned long long)__shfl((int)inc[j], 63, 64);
+      inc[j] = wave_inclusive_sum_dpp((uint64_t)rws[j]);
+      wave_total += (unsigned long long)__shfl(inc[j], 63, 64);
     }
     if (lane == 0) s_wtot[wv] = wave_total;
     __syncthreads();
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_pairs_single(ProbeCtx c, int64_
           o++;
           if (q + 1 < rws[j]) cur = c.next[cur - 1];
         }
-        off += (unsigned long long)__shfl((int)inc[j], 63, 64);
+        off += (unsigned long long)__shfl(inc[j], 63, 64);
       }
     }
     __syncthreads();   // s_wtot / s_base are reused by the next tile

@@ -9,7 +9,7 @@ import pyarrow as pa
 
 from . import _lib
 from ._lib import AggSpec, Expr, Field, JoinFilter, JoinInfo, JoinOptions, KernelStat, check
-from .expr import PhysicalExpr, lower
+from .expr import LoweredExpr, PhysicalExpr, lower
 from .table import DeviceTable, field_of
 
 JOIN_TYPES = {"Inner": 0, "Left": 1, "Right": 2, "Full": 3, "LeftSemi": 4, "RightSemi": 5, "LeftAnti": 6,
@@ -195,16 +195,11 @@ def sort(table: DeviceTable, keys, fetch=None) -> DeviceTable:
     return DeviceTable(out)
 
 
-class GroupedAggregate:
-    """AggregateExec state: group_by = [(expr, name)], aggs = [(func, expr|None, name)]"""
+class _LoweredAggregate:
+    """the C-ABI form of an AggregateExec's expressions (group keys, aggregate arguments, grouping sets): what
+    dfgpu_agg_create reads.  Built once per planned node; every execution of the node creates its state from it."""
 
-    def __init__(self, mode, input_names, group_by, aggs, dictionaries: DeviceTable | None = None, return_types: dict | None = None, grouping_sets=None):
-        """dictionaries: a table of the input's schema whose dictionary-encoded string columns bind the string
-        literals of the argument expressions (`CASE WHEN o_orderpriority = '1-URGENT' ...`).
-        return_types {name: arrow type}: the aggregates' declared return types (AggregateFunctionExpr::return_field) —
-        required by Final modes for AVG over a Decimal128 state (its Decimal128(38, s) sum does not tell the argument's
-        precision); aggregate_return_types() computes them from the raw input."""
-        lib = _lib.init()
+    def __init__(self, mode, input_names, group_by, aggs, dictionaries=None, return_types=None, grouping_sets=None):
         self._keep = []
         final = mode in ("Final", "FinalPartitioned", "PartialReduce")
         if final:
@@ -213,12 +208,12 @@ class GroupedAggregate:
             from .expr import Column
             group_by = [(Column(n, i), n) for i, (_, n) in enumerate(group_by)]
             aggs = [(f, None if f == "count" and e is None else Column("state", 0), n) for f, e, n in aggs]
-        if final:
             dictionaries = None
         g_low = [lower(e, input_names, dictionaries) for e, _ in group_by]
         self._keep += g_low
-        garr = (Expr * max(1, len(g_low)))(*[l.c for l in g_low])
-        gnames = (C.c_char_p * max(1, len(group_by)))(*[n.encode() for _, n in group_by])
+        self.n_group = len(group_by)
+        self.garr = (Expr * max(1, len(g_low)))(*[l.c for l in g_low])
+        self.gnames = (C.c_char_p * max(1, len(group_by)))(*[n.encode() for _, n in group_by])
         specs = []
         for func, e, name in aggs:
             s = AggSpec()
@@ -232,8 +227,9 @@ class GroupedAggregate:
             if return_types and name in return_types:
                 s.return_field = field_of(return_types[name])
             specs.append(s)
-        sarr = (AggSpec * max(1, len(specs)))(*specs)
-        self._h = C.c_void_p()
+        self.n_aggs = len(specs)
+        self.sarr = (AggSpec * max(1, len(specs)))(*specs)
+        self.grouping = None
         if grouping_sets is not None:
             # PhysicalGroupBy with several groups: grouping_sets = ([typed NULL Literal per key], [[column g is NULL in set s] ...])
             null_exprs, groups = grouping_sets
@@ -241,9 +237,48 @@ class GroupedAggregate:
             self._keep += n_low
             narr = (Expr * max(1, len(n_low)))(*[l.c for l in n_low])
             flat = (C.c_uint8 * max(1, len(groups) * len(group_by)))(*[int(bool(x)) for g in groups for x in g])
-            check(lib.dfgpu_agg_create_grouping_sets(AGG_MODES[mode], garr, narr, gnames, len(group_by), flat, len(groups), sarr, len(specs), C.byref(self._h)))
+            self.grouping = (narr, flat, len(groups))
+
+
+class AggregatePlan:
+    """A PLANNED AggregateExec (optionally with the FilterExec below it fused in as `predicate`): the expressions are lowered to
+    the C ABI's form once, at planning time, and `execute(table)` runs the node — dfgpu_agg_create -> update[_filtered] -> emit —
+    any number of times, the way one ExecutionPlan is `execute()`d repeatedly (physical-plan/src/execution_plan.rs:696).  The
+    table given here fixes the input schema (and binds string literals to its dictionaries)."""
+
+    def __init__(self, table: DeviceTable, group_by, aggs, mode="Single", predicate: PhysicalExpr | None = None, return_types: dict | None = None):
+        self.mode, self.column_names = mode, list(table.column_names)
+        self._lowered = _LoweredAggregate(mode, self.column_names, group_by, aggs, table, return_types)
+        self._predicate = None if predicate is None else lower(predicate, self.column_names, table)
+
+    def execute(self, table: DeviceTable) -> DeviceTable:
+        a = GroupedAggregate(self.mode, None, None, None, _lowered=self._lowered)
+        try:
+            a.update(table, self._predicate)
+            return a.emit()
+        finally:
+            a.free()
+
+
+class GroupedAggregate:
+    """AggregateExec state: group_by = [(expr, name)], aggs = [(func, expr|None, name)]"""
+
+    def __init__(self, mode, input_names, group_by, aggs, dictionaries: DeviceTable | None = None, return_types: dict | None = None, grouping_sets=None,
+                 _lowered: "_LoweredAggregate | None" = None):
+        """dictionaries: a table of the input's schema whose dictionary-encoded string columns bind the string
+        literals of the argument expressions (`CASE WHEN o_orderpriority = '1-URGENT' ...`).
+        return_types {name: arrow type}: the aggregates' declared return types (AggregateFunctionExpr::return_field) —
+        required by Final modes for AVG over a Decimal128 state (its Decimal128(38, s) sum does not tell the argument's
+        precision); aggregate_return_types() computes them from the raw input."""
+        lib = _lib.init()
+        low = _lowered if _lowered is not None else _LoweredAggregate(mode, input_names, group_by, aggs, dictionaries, return_types, grouping_sets)
+        self._keep = low           # the C structs the library copied from stay alive with the plan that owns them
+        self._h = C.c_void_p()
+        if low.grouping is not None:
+            narr, flat, n_sets = low.grouping
+            check(lib.dfgpu_agg_create_grouping_sets(AGG_MODES[mode], low.garr, narr, low.gnames, low.n_group, flat, n_sets, low.sarr, low.n_aggs, C.byref(self._h)))
             return
-        check(lib.dfgpu_agg_create(AGG_MODES[mode], garr, gnames, len(group_by), sarr, len(specs), C.byref(self._h)))
+        check(lib.dfgpu_agg_create(AGG_MODES[mode], low.garr, low.gnames, low.n_group, low.sarr, low.n_aggs, C.byref(self._h)))
 
     def update(self, table: DeviceTable, predicate: PhysicalExpr | None = None):
         """aggregate_batch_inner over a whole table; `predicate` = a FilterExec fused in front of this node
@@ -251,7 +286,7 @@ class GroupedAggregate:
         if predicate is None:
             check(_lib.load().dfgpu_agg_update(self._h, table.handle))
         else:
-            le = lower(predicate, table.column_names, table)
+            le = predicate if isinstance(predicate, LoweredExpr) else lower(predicate, table.column_names, table)
             check(_lib.load().dfgpu_agg_update_filtered(self._h, table.handle, C.byref(le.c)))
 
     @property

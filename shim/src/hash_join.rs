@@ -219,12 +219,19 @@ async fn collect_build(left: Arc<dyn ExecutionPlan>, partition: usize, ctx: Arc<
     // min / max over EVERY pushed batch (dfgpu_column_minmax reduces one table and caches the answer on its column), folded as the
     // batches go by — a build partition fed several CPU batches reports like one fed a single device table
     let key = on_l[0];
-    let want_bounds = bounds.is_some();
+    // dfgpu_column_minmax reduces integer-like columns only (Int8..Int64, UInt8..UInt32, Date32).  A key of any other type (Utf8,
+    // dictionary, Float64, Decimal128, UInt64, Boolean) makes it return non-zero: that is "no bounds for this join" — the fold stops and
+    // the filter's bounds half stays unpublished — never a failed query (the reference's bounds are best effort too, shared_bounds.rs:277)
+    let mut want_bounds = bounds.is_some();
     let mut key_bounds: Option<(i64, i64)> = None;
     let mut fold = |t: &DeviceTable| -> Result<()> {
         if want_bounds {
             let (mut lo, mut hi, mut valid, mut asc) = (0i64, 0i64, 0i64, 0i32);
-            check(unsafe { sys::dfgpu_column_minmax(t.0, key, &mut lo, &mut hi, &mut valid, &mut asc) })?;
+            if unsafe { sys::dfgpu_column_minmax(t.0, key, &mut lo, &mut hi, &mut valid, &mut asc) } != 0 {
+                want_bounds = false;
+                key_bounds = None;
+                return Ok(());
+            }
             if valid > 0 {
                 key_bounds = Some(match key_bounds { Some((a, b)) => (a.min(lo), b.max(hi)), None => (lo, hi) });
             }
