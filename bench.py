@@ -428,7 +428,7 @@ def attach_traffic(roof, name, workload_key, world):
     try:
         import hashlib
         for tr in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]:
-            if tr["kernel"] != name or tr["workload"] != workload_key or world != 1:
+            if tr["kernel"] != name or any(tr["workload"].get(k) != v for k, v in workload_key.items()) or world != 1:
                 continue
             cur = hashlib.sha256(open(os.path.join(ROOT, tr.get("kernel_source", "datafusion_amd/csrc/join.hip")), "rb").read()).hexdigest()[:16]
             if tr.get("kernel_source_sha16") != cur:
@@ -567,11 +567,16 @@ def run_query(args, rank, world, dist):
     from datafusion_amd import ops, queries, tpch
     n_orders = tpch.n_orders(args.sf)
     b, e = n_orders * rank // world, n_orders * (rank + 1) // world
-    lineitem = ops.tpch_lineitem(args.sf, b, e)
-    tables = [lineitem]
-    if args.workload == "q3":
+    # only the columns the plan references stay resident (the generator's other columns are dropped with the full table: SF300's full
+    # lineitem alone is ~200 GB)
+    if args.workload == "q1":
+        lineitem = ops.tpch_lineitem(args.sf, b, e).select(["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"])
+        tables = [lineitem]
+    else:
         nc = tpch.n_customers(args.sf)
-        tables = [ops.tpch_customer(args.sf, nc * rank // world, nc * (rank + 1) // world), ops.tpch_orders(args.sf, b, e), lineitem]
+        lineitem = ops.tpch_lineitem(args.sf, b, e).select(["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
+        tables = [ops.tpch_customer(args.sf, nc * rank // world, nc * (rank + 1) // world).select(["c_custkey", "c_mktsegment"]),
+                  ops.tpch_orders(args.sf, b, e).select(["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"]), lineitem]
     rows_local = sum(t.num_rows for t in tables)
     bytes_local = sum(t.nbytes() for t in tables)
     ops.sync()

@@ -655,6 +655,66 @@ __global__ __launch_bounds__(BLOCK) void k_emit_avg(int is_decimal, const unsign
   }
 }
 
+// Every output column of an aggregate in ONE launch (blockIdx.y = column): the value (k_emit_values / k_emit_avg), its validity
+// WORD (a wave's ballot: no byte-per-row detour) and the column's count of valid rows — read back once for all columns, together
+// with the AVG overflow flags.  stats[2 e] = valid rows of entry e, stats[2 e + 1] = overflow seen.
+struct EmitEntry {
+  int kind;                         // 0 = accumulator value (mode as k_emit_values), 1 = AVG (mode = is_decimal)
+  int mode;
+  const unsigned long long *lo, *hi, *cnt;
+  const uint32_t* seen;             // null: every row is valid
+  unsigned long long mul_lo, mul_hi;   // AVG over decimals: 10^(return scale - sum scale)
+  void* dst;
+  uint64_t* valid_words;            // null: the column is not nullable
+};
+constexpr int EMIT_MAX = 2 * MAX_AGGS;
+struct EmitSet {
+  int n;
+  EmitEntry e[EMIT_MAX];
+};
+__global__ __launch_bounds__(BLOCK) void k_emit_set(EmitSet s, int64_t n, unsigned long long* __restrict__ stats) {
+  const EmitEntry& e = s.e[blockIdx.y];
+  const int64_t n_round = (n + WAVE - 1) / WAVE * WAVE;
+  unsigned long long valid_rows = 0;
+  bool overflow = false;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {   // (whole waves: the ballot)
+    const bool in = i < n;
+    bool ok = false;
+    if (in) {
+      if (e.kind == 0) {
+        ok = !e.seen || e.seen[i] != 0;
+        switch (e.mode) {
+          case 0: ((unsigned long long*)e.dst)[i] = ok ? e.lo[i] : 0ull; break;
+          case 1: ((unsigned long long*)e.dst)[2 * i] = ok ? e.lo[i] : 0ull; ((unsigned long long*)e.dst)[2 * i + 1] = ok ? e.hi[i] : 0ull; break;
+          case 2: ((double*)e.dst)[i] = ok ? f64_from_ordered((int64_t)e.lo[i]) : 0.0; break;
+          case 3: ((int32_t*)e.dst)[i] = ok ? (int32_t)(int64_t)e.lo[i] : 0; break;
+          case 4: ((uint8_t*)e.dst)[i] = ok ? (uint8_t)e.lo[i] : 0; break;
+        }
+      } else {
+        const unsigned long long c = e.cnt[i];
+        ok = c != 0;
+        if (e.mode) {
+          i128 r = 0;
+          if (ok) {
+            const i128 sum = (i128)(((u128)e.hi[i] << 64) | (u128)e.lo[i]);
+            const i128 mul = (i128)(((u128)e.mul_hi << 64) | (u128)e.mul_lo);
+            if (__builtin_mul_overflow(sum, mul, &r)) overflow = true;  // sum.mul_checked
+            r = r / (i128)c;
+          }
+          ((i128*)e.dst)[i] = r;
+        } else {
+          ((double*)e.dst)[i] = ok ? __longlong_as_double((long long)e.lo[i]) / (double)c : 0.0;
+        }
+      }
+    }
+    const uint64_t word = ballot64(ok);
+    if (e.valid_words && lane_id() == 0 && in) e.valid_words[i >> 6] = word;
+    if (lane_id() == 0) valid_rows += (unsigned long long)__popcll(word);
+  }
+  if (lane_id() == 0 && valid_rows) atomicAdd(&stats[2 * blockIdx.y], valid_rows);
+  if (overflow) stats[2 * blockIdx.y + 1] = 1ull;
+}
+
 // ------------------------------------------------------------------------------- host
 struct AggState {
   int func;               // dfgpu_agg_func
@@ -757,6 +817,7 @@ static BufPtr filled(int64_t n, unsigned long long v) {
   return b;
 }
 static BufPtr grown(const BufPtr& old, int64_t old_n, int64_t new_n, unsigned long long fill, int elem = 8, bool init = true) {
+  if (old && old_n == new_n && old_n > 0 && old->bytes >= (size_t)new_n * elem) return old;   // no new group: nothing to allocate, fill or copy
   BufPtr b;
   if (!init) b = make_buf((size_t)(new_n ? new_n : 1) * elem);  // the caller overwrites every element
   else if (elem == 8) b = filled(new_n, fill);
@@ -1170,19 +1231,39 @@ struct MergeDst {
   int src[MAX_AGGS];  // index into SmallAccSet::a
   int n;
 };
-__global__ __launch_bounds__(BLOCK) void k_small_merge(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ gids, int n_keys, SmallAccSet accs,
-                                                      MergeDst dst, const uint32_t* __restrict__ g_seen) {
-  const int x = blockIdx.x * BLOCK + threadIdx.x;
-  if (x >= n_keys * dst.n) return;
-  const int t = x / dst.n, e = x % dst.n;
+__device__ __forceinline__ void small_merge_one(int e, uint32_t key, uint32_t gid, const SmallAccSet& accs, const MergeDst& dst, const uint32_t* __restrict__ g_seen) {
   const int k = dst.src[e];
-  const uint32_t key = keys[t], gid = gids[t];
   if (!((g_seen[key] >> k) & 1u)) return;
   const SmallAcc& d = accs.a[k];
   int kind = d.kind;
   if (kind == ACC_COUNT || kind == ACC_COUNT_STAR) kind = ACC_SUM_I64;
   accumulate_cell(kind, dst.lo[e] + gid, dst.hi[e] ? dst.hi[e] + gid : nullptr, d.tmp_lo[key], d.tmp_hi ? d.tmp_hi[key] : 0ull);
   if (dst.seen[e]) dst.seen[e][gid] = 1u;
+}
+__global__ __launch_bounds__(BLOCK) void k_small_merge(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ gids, int n_keys, SmallAccSet accs,
+                                                      MergeDst dst, const uint32_t* __restrict__ g_seen) {
+  const int x = blockIdx.x * BLOCK + threadIdx.x;
+  if (x >= n_keys * dst.n) return;
+  const int t = x / dst.n, e = x % dst.n;
+  small_merge_one(e, keys[t], gids[t], accs, dst, g_seen);
+}
+// the same with the touched keys and their group numbers in the kernel's ARGUMENTS (a handful of groups: no upload, no host
+// buffer to keep alive, nothing to wait for)
+constexpr int SMALL_KG_MAX = 64;
+struct SmallKG {
+  uint32_t key[SMALL_KG_MAX], gid[SMALL_KG_MAX];
+};
+__global__ __launch_bounds__(BLOCK) void k_small_merge_v(SmallKG kg, int n_keys, SmallAccSet accs, MergeDst dst, const uint32_t* __restrict__ g_seen) {
+  const int x = blockIdx.x * BLOCK + threadIdx.x;
+  if (x >= n_keys * dst.n) return;
+  const int t = x / dst.n, e = x % dst.n;
+  small_merge_one(e, kg.key[t], kg.gid[t], accs, dst, g_seen);
+}
+struct SmallBytes {
+  uint8_t v[SMALL_KG_MAX];
+};
+__global__ void k_set_bytes_v(SmallBytes b, int n, uint8_t* __restrict__ dst) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = b.v[threadIdx.x];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_and_words(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, int64_t nw, uint64_t* __restrict__ out) {
@@ -1524,6 +1605,14 @@ static void small_rebuild_group_keys(Aggregate& A, const Table& in, const std::v
   for (int g = 0; g < ngk; g++) {
     Column c = alloc_column(in.cols[small_cols[g]].field, A.group_names[g], G1);
     c.dict = in.cols[small_cols[g]].dict;
+    if (G1 > 0 && G1 <= SMALL_KG_MAX) {   // a handful of groups: the key bytes travel as kernel arguments (no upload to wait for)
+      SmallBytes sb{};
+      for (int64_t i = 0; i < G1; i++) sb.v[(size_t)i] = (uint8_t)(A.small_keys[(size_t)i] >> (8 * g));
+      k_set_bytes_v<<<1, SMALL_KG_MAX, 0, r.stream>>>(sb, (int)G1, c.data->as<uint8_t>());
+      DFGPU_HIP(hipGetLastError());
+      gk.cols.push_back(std::move(c));
+      continue;
+    }
     std::vector<uint8_t> b((size_t)(G1 ? G1 : 1));
     for (int64_t i = 0; i < G1; i++) b[(size_t)i] = (uint8_t)(A.small_keys[(size_t)i] >> (8 * g));
     if (G1) h2d_async(c.data->ptr, b.data(), (size_t)G1);
@@ -3444,6 +3533,21 @@ static bool agg_update_sorted_runs_jit(Aggregate& A, const Table& in, const dfgp
   return true;
 }
 
+// identities of every key-indexed partial of a range, its first-row words (no row yet) and seen words: one launch
+__global__ __launch_bounds__(BLOCK) void k_small_reset(SmallAccSet accs, int D, uint32_t* __restrict__ g_first, uint32_t* __restrict__ g_seen) {
+  const int64_t total = (int64_t)D * (accs.n + 1);
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+    const int k = (int)(i / D), j = (int)(i % D);
+    if (k == accs.n) {
+      g_first[j] = 0xFFFFFFFFu;
+      g_seen[j] = 0u;
+    } else {
+      accs.a[k].tmp_lo[j] = acc_identity(accs.a[k].kind);
+      if (accs.a[k].tmp_hi) accs.a[k].tmp_hi[j] = 0ull;
+    }
+  }
+}
+
 // The single-pass small-domain node (k_agg_fused_tile).  `cp` = predicate + key bytes + arguments.
 // Returns false (state untouched) when the forest has no tile form or the LDS budget does not fit.
 constexpr size_t TILE_LDS_BUDGET = 64 * 1024;  // per workgroup: at least two workgroups per CU (160 KiB LDS)
@@ -3504,21 +3608,34 @@ static bool agg_update_small_single_pass(Aggregate& A, const Table& in, const Co
   };
   if (D > 1 && slots_for(std::max<int64_t>(A.ngroups, 1)) > plane_max) return false;  // too many groups for LDS: two-pass node
 
-  // ---- key-indexed partials (reset per range)
-  std::vector<BufPtr> keep;
-  for (int k = 0; k < accs.n; k++) {
-    SmallAcc& d = accs.a[k];
-    BufPtr lo = make_buf((size_t)D * 8);
-    keep.push_back(lo);
-    d.tmp_lo = lo->as<unsigned long long>();
-    if (d.kind == ACC_SUM_I128) {
-      BufPtr hi = make_buf((size_t)D * 8);
-      keep.push_back(hi);
-      d.tmp_hi = hi->as<unsigned long long>();
+  // ---- key-indexed partials: one set of buffers per range, so that the second range can be launched before the first range's
+  // bookkeeping (group numbering, merge) is done on the host
+  struct RangeState {
+    SmallAccSet accs;
+    std::vector<BufPtr> keep;
+    BufPtr g_first, g_seen;
+    int64_t begin = 0, end = 0;
+  };
+  auto make_range = [&](int64_t begin, int64_t end) {
+    RangeState st;
+    st.accs = accs;
+    st.begin = begin;
+    st.end = end;
+    for (int k = 0; k < accs.n; k++) {
+      SmallAcc& d = st.accs.a[k];
+      BufPtr lo = make_buf((size_t)D * 8);
+      st.keep.push_back(lo);
+      d.tmp_lo = lo->as<unsigned long long>();
+      if (d.kind == ACC_SUM_I128) {
+        BufPtr hi = make_buf((size_t)D * 8);
+        st.keep.push_back(hi);
+        d.tmp_hi = hi->as<unsigned long long>();
+      }
     }
-  }
-  BufPtr g_first = make_buf((size_t)D * 4);
-  BufPtr g_seen = make_buf((size_t)D * 4);
+    st.g_first = make_buf((size_t)D * 4);
+    st.g_seen = make_buf((size_t)D * 4);
+    return st;
+  };
   const int ko0 = ngk > 0 ? cp.tile_outs[key_out[0]] : -1, ko1 = ngk > 1 ? cp.tile_outs[key_out[1]] : -1;
   const bool prefetch = true;
   DFGPU_HIP(hipFuncSetAttribute((const void*)k_agg_fused_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_BUDGET));
@@ -3537,58 +3654,60 @@ static bool agg_update_small_single_pass(Aggregate& A, const Table& in, const Co
     }
   }
 
-  auto run_range = [&](int64_t begin, int64_t end) {
-    const int64_t m = end - begin;
-    for (int k = 0; k < accs.n; k++) {
-      SmallAcc& d = accs.a[k];
-      k_fill_u64<<<grid_for(D, BLOCK), BLOCK, 0, r.stream>>>(acc_identity(d.kind), D, d.tmp_lo);
-      if (d.tmp_hi) DFGPU_HIP(hipMemsetAsync(d.tmp_hi, 0, (size_t)D * 8, r.stream));
-    }
-    DFGPU_HIP(hipMemsetAsync(g_first->ptr, 0xFF, (size_t)D * 4, r.stream));
-    DFGPU_HIP(hipMemsetAsync(g_seen->ptr, 0, (size_t)D * 4, r.stream));
+  // launch half: ONE reset kernel (identities of every partial, first-row and seen words) and the node's kernel over [begin, end).
+  // `groups_known` = the number of groups the local tables are sized for (0: unknown, 16 slots)
+  auto launch_range = [&](RangeState& st, int64_t groups_known) {
+    const int64_t begin = st.begin, end = st.end, m = end - begin;
+    k_small_reset<<<grid_for((int64_t)D * (st.accs.n + 1), BLOCK), BLOCK, 0, r.stream>>>(st.accs, D, st.g_first->as<uint32_t>(), st.g_seen->as<uint32_t>());
+    DFGPU_HIP(hipGetLastError());
     // local slots: the groups known so far (unknown: 16), replicas: what the LDS budget leaves, up to one per lane
     const bool use_jit = jit_fn != nullptr && m >= jit_min_rows;
     const int pmax = use_jit ? plane_max_jit : plane_max;
-    int L = D == 1 ? 1 : slots_for(A.ngroups > 0 ? A.ngroups : 16);
+    int L = D == 1 ? 1 : slots_for(groups_known > 0 ? groups_known : 16);
     while (L > 1 && L > pmax) L /= 2;
     int nrep = 1;
     while (nrep * 2 <= WAVE && L * nrep * 2 <= pmax) nrep *= 2;
-    if (m > 0) {
-      const int plane = L * nrep;
-      const size_t cell_bytes = (size_t)ncell * plane * 8 + (size_t)plane * 4 + (size_t)L * 8;
-      int grid = grid_for(m, BLOCK * 4);
-      const int64_t min_grid = (m >> 20) + 1;  // < 2^20 rows per workgroup: limb sums cannot wrap (see kernel header)
-      if (grid < min_grid) grid = (int)min_grid;
-      if (use_jit) {
-        ProfileScope ps("agg_fused_jit", m * cp.input_bytes_per_row);
-        AggNodeArgs args{};
-        for (int c = 0; c < T.n_cols; c++) {
-          args.col[c] = T.col_data[c];
-          args.valid[c] = T.col_valid[c];
-        }
-        for (int k = 0; k < accs.n; k++) {
-          args.tmp_lo[k] = accs.a[k].tmp_lo;
-          args.tmp_hi[k] = accs.a[k].tmp_hi;
-        }
-        args.g_first = g_first->as<uint32_t>();
-        args.g_seen = g_seen->as<uint32_t>();
-        args.begin = begin;
-        args.end = end;
-        args.L = L;
-        args.nrep = nrep;
-        jit_launch(jit_fn, grid, BLOCK, cell_bytes, &args, sizeof(args));
-      } else {
-        ProfileScope ps("agg_fused_tile", m * cp.input_bytes_per_row);
-        const size_t lds = regfile + cell_bytes;
-        if (prefetch) k_agg_fused_tile<true><<<grid, BLOCK, lds, r.stream>>>(T, cp.tile_pred, ko0, ko1, accs, begin, end, L, nrep, g_first->as<uint32_t>(), g_seen->as<uint32_t>());
-        else k_agg_fused_tile<false><<<grid, BLOCK, lds, r.stream>>>(T, cp.tile_pred, ko0, ko1, accs, begin, end, L, nrep, g_first->as<uint32_t>(), g_seen->as<uint32_t>());
-        DFGPU_HIP(hipGetLastError());
+    if (m <= 0) return;
+    const int plane = L * nrep;
+    const size_t cell_bytes = (size_t)ncell * plane * 8 + (size_t)plane * 4 + (size_t)L * 8;
+    int grid = grid_for(m, BLOCK * 4);
+    const int64_t min_grid = (m >> 20) + 1;  // < 2^20 rows per workgroup: limb sums cannot wrap (see kernel header)
+    if (grid < min_grid) grid = (int)min_grid;
+    if (use_jit) {
+      ProfileScope ps("agg_fused_jit", m * cp.input_bytes_per_row);
+      AggNodeArgs args{};
+      for (int c = 0; c < T.n_cols; c++) {
+        args.col[c] = T.col_data[c];
+        args.valid[c] = T.col_valid[c];
       }
+      for (int k = 0; k < st.accs.n; k++) {
+        args.tmp_lo[k] = st.accs.a[k].tmp_lo;
+        args.tmp_hi[k] = st.accs.a[k].tmp_hi;
+      }
+      args.g_first = st.g_first->as<uint32_t>();
+      args.g_seen = st.g_seen->as<uint32_t>();
+      args.begin = begin;
+      args.end = end;
+      args.L = L;
+      args.nrep = nrep;
+      jit_launch(jit_fn, grid, BLOCK, cell_bytes, &args, sizeof(args));
+    } else {
+      ProfileScope ps("agg_fused_tile", m * cp.input_bytes_per_row);
+      const size_t lds = regfile + cell_bytes;
+      if (prefetch) k_agg_fused_tile<true><<<grid, BLOCK, lds, r.stream>>>(T, cp.tile_pred, ko0, ko1, st.accs, begin, end, L, nrep, st.g_first->as<uint32_t>(), st.g_seen->as<uint32_t>());
+      else k_agg_fused_tile<false><<<grid, BLOCK, lds, r.stream>>>(T, cp.tile_pred, ko0, ko1, st.accs, begin, end, L, nrep, st.g_first->as<uint32_t>(), st.g_seen->as<uint32_t>());
+      DFGPU_HIP(hipGetLastError());
     }
-    // ---- number the new groups in first-seen order
-    const int64_t G0 = A.ngroups;
+  };
+  // the keys a range touched, as the host sees them (waits for the range's kernel)
+  auto read_first = [&](RangeState& st) {
     std::vector<uint32_t> hfirst((size_t)D);
-    d2h(hfirst.data(), g_first->ptr, (size_t)D * 4);
+    d2h(hfirst.data(), st.g_first->ptr, (size_t)D * 4);
+    return hfirst;
+  };
+  // finish half: number the new groups in first-seen order, grow the accumulators, merge the range's key-indexed partials
+  auto finish_range = [&](RangeState& st, const std::vector<uint32_t>& hfirst) {
+    const int64_t G0 = A.ngroups;
     std::vector<uint32_t> touched_keys, touched_gids;
     if (ngk == 0) {
       touched_keys.push_back(0);
@@ -3633,24 +3752,47 @@ static bool agg_update_small_single_pass(Aggregate& A, const Table& in, const Co
           dst.seen[ei] = a.seen->as<uint32_t>();
         }
       }
-      BufPtr dk = make_buf((size_t)K * 4), dg = make_buf((size_t)K * 4);
-      h2d_async(dk->ptr, touched_keys.data(), (size_t)K * 4);
-      h2d_async(dg->ptr, touched_gids.data(), (size_t)K * 4);
-      k_small_merge<<<grid_for((int64_t)K * dst.n, BLOCK), BLOCK, 0, r.stream>>>(dk->as<uint32_t>(), dg->as<uint32_t>(), K, accs, dst, g_seen->as<uint32_t>());
+      if (K <= SMALL_KG_MAX) {
+        SmallKG kgv{};
+        for (int i = 0; i < K; i++) {
+          kgv.key[i] = touched_keys[(size_t)i];
+          kgv.gid[i] = touched_gids[(size_t)i];
+        }
+        k_small_merge_v<<<grid_for((int64_t)K * dst.n, BLOCK), BLOCK, 0, r.stream>>>(kgv, K, st.accs, dst, st.g_seen->as<uint32_t>());
+        DFGPU_HIP(hipGetLastError());
+        return;   // (asynchronous: the range's buffers stay alive until the update's last synchronise)
+      }
+      // (keys and group numbers in ONE upload)
+      std::vector<uint32_t> kg(touched_keys);
+      kg.insert(kg.end(), touched_gids.begin(), touched_gids.end());
+      BufPtr dkg = make_buf((size_t)K * 8);
+      h2d_async(dkg->ptr, kg.data(), (size_t)K * 8);
+      k_small_merge<<<grid_for((int64_t)K * dst.n, BLOCK), BLOCK, 0, r.stream>>>(dkg->as<uint32_t>(), dkg->as<uint32_t>() + K, K, st.accs, dst, st.g_seen->as<uint32_t>());
       DFGPU_HIP(hipGetLastError());
       DFGPU_HIP(hipStreamSynchronize(r.stream));  // host vectors are released on return
     }
   };
   // The first update of a large input learns the number of groups from a short prefix, so the bulk runs with
-  // exactly-sized local tables and as many accumulator replicas as LDS allows.
+  // exactly-sized local tables and as many accumulator replicas as LDS allows.  The bulk's kernel is LAUNCHED as soon as the
+  // prefix's keys are on the host (their count sizes its local tables); the prefix's bookkeeping — numbering the groups,
+  // growing the accumulators, merging its partials — is issued behind it and overlaps the bulk's run instead of delaying it.
   const int64_t prefix = 1 << 18;
   if (A.ngroups == 0 && D > 1 && n > 4 * prefix) {
-    run_range(0, prefix);
-    run_range(prefix, n);
+    RangeState head = make_range(0, prefix), bulk = make_range(prefix, n);
+    launch_range(head, 0);
+    const std::vector<uint32_t> first_head = read_first(head);
+    int64_t seen_keys = 0;
+    for (uint32_t v : first_head) seen_keys += v != 0xFFFFFFFFu;
+    launch_range(bulk, seen_keys);
+    finish_range(head, first_head);
+    finish_range(bulk, read_first(bulk));
+    DFGPU_HIP(hipStreamSynchronize(r.stream));   // (the ranges' buffers are still referenced by queued kernels until here)
   } else {
-    run_range(0, n);
+    RangeState all = make_range(0, n);
+    launch_range(all, A.ngroups);
+    finish_range(all, read_first(all));
+    DFGPU_HIP(hipStreamSynchronize(r.stream));
   }
-  DFGPU_HIP(hipStreamSynchronize(r.stream));
   return true;
 }
 
@@ -4112,6 +4254,33 @@ static Table agg_emit(Aggregate& A) {
   const int64_t G = A.ngroups;
   Table out;
   out.nrows = G;
+  // the aggregates' columns are written by ONE kernel (k_emit_set) launched after this loop; `pending[e]` = the column entry e fills
+  EmitSet eset{};
+  std::vector<size_t> pending;
+  auto emit_later = [&](const dfgpu_field& f, const std::string& name, int kind, int mode, const BufPtr& lo, const BufPtr& hi, const BufPtr& seen,
+                        const BufPtr& cnt, i128 mul, bool nullable) {
+    Column c = alloc_column(f, name, G);
+    if (G > 0) {
+      DFGPU_CHECK(eset.n < EMIT_MAX, "too many aggregate output columns for one GPU aggregate node");
+      EmitEntry& e = eset.e[eset.n++];
+      e.kind = kind;
+      e.mode = mode;
+      e.lo = lo ? lo->as<unsigned long long>() : nullptr;
+      e.hi = hi ? hi->as<unsigned long long>() : nullptr;
+      e.cnt = cnt ? cnt->as<unsigned long long>() : nullptr;
+      e.seen = (nullable && seen) ? seen->as<uint32_t>() : nullptr;
+      e.mul_lo = (unsigned long long)(u128)mul;
+      e.mul_hi = (unsigned long long)((u128)mul >> 64);
+      e.dst = c.data->ptr;
+      if (nullable) {
+        c.validity = make_buf(bitmap_bytes(G));
+        c.null_count = -1;
+        e.valid_words = c.validity->as<uint64_t>();
+      }
+      pending.push_back(out.cols.size());
+    }
+    out.cols.push_back(std::move(c));
+  };
   for (int g = 0; g < ngk; g++) {
     if (G == 0 && (int)A.group_keys.cols.size() <= g) throw Error("aggregate emitted before any input: group key types unknown");
     out.cols.push_back(A.group_keys.cols[g]);
@@ -4154,8 +4323,8 @@ static Table agg_emit(Aggregate& A) {
     if (a.func == DFGPU_AGG_AVG) {
       if (A.partial_out()) {
         // state_fields of AVG: [count: UInt64, sum] (average.rs:317-360)
-        out.cols.push_back(emit_column(fld(DFGPU_UINT64), a.name + "[count]", 0, a.cnt, nullptr, nullptr, G, false));
-        out.cols.push_back(emit_column(vf, a.name + "[sum]", mode, a.lo, a.hi, a.seen, G, true));
+        emit_later(fld(DFGPU_UINT64), a.name + "[count]", 0, 0, a.cnt, nullptr, nullptr, nullptr, 1, false);
+        emit_later(vf, a.name + "[sum]", 0, mode, a.lo, a.hi, a.seen, nullptr, 1, true);
       } else {
         // raw modes: in_type = argument type Decimal(p,s) -> AVG type Decimal(min(38,p+4), min(38,s+4))
         // (average.rs:219-252).  final modes: in_type = the sum state Decimal(38, s), which no longer tells p: the
@@ -4175,21 +4344,7 @@ static Table agg_emit(Aggregate& A) {
         } else {
           rt_ = fld(DFGPU_FLOAT64);
         }
-        Column c = alloc_column(rt_, a.name, G);
-        if (G) {
-          BufPtr vb = make_buf((size_t)G + 64);
-          BufPtr ovf = make_zero_buf(4);
-          k_emit_avg<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(dec, a.lo->as<unsigned long long>(), a.hi ? a.hi->as<unsigned long long>() : nullptr,
-                                                                 a.cnt->as<unsigned long long>(), mul, G, c.data->ptr, vb->as<uint8_t>(), ovf->as<int>());
-          int o = 0;
-          d2h(&o, ovf->ptr, 4);
-          DFGPU_CHECK(!o, "Arithmetic Overflow in AvgAccumulator");
-          c.validity = make_buf(bitmap_bytes(G));
-          pack_bytes_to_bitmap(vb->as<uint8_t>(), G, c.validity->as<uint64_t>());
-          c.null_count = -1;
-          count_nulls(c);
-        }
-        out.cols.push_back(std::move(c));
+        emit_later(rt_, a.name, 1, dec ? 1 : 0, a.lo, a.hi, nullptr, a.cnt, mul, true);
       }
       continue;
     }
@@ -4233,9 +4388,24 @@ static Table agg_emit(Aggregate& A) {
       out.cols.push_back(std::move(c));
       continue;
     }
-    out.cols.push_back(emit_column(vf, out_name, mode, a.lo, a.hi, a.seen, G, nullable));
+    emit_later(vf, out_name, 0, mode, a.lo, a.hi, a.seen, nullptr, 1, nullable);
   }
-  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  if (eset.n > 0) {
+    BufPtr stats = make_zero_buf((size_t)eset.n * 16);
+    k_emit_set<<<dim3((unsigned)grid_for(G, BLOCK), (unsigned)eset.n), BLOCK, 0, r.stream>>>(eset, G, stats->as<unsigned long long>());
+    DFGPU_HIP(hipGetLastError());
+    std::vector<unsigned long long> h((size_t)eset.n * 2);
+    d2h(h.data(), stats->ptr, h.size() * 8);   // (waits for the stream: the columns are complete)
+    for (int e = 0; e < eset.n; e++) {
+      DFGPU_CHECK(!h[(size_t)e * 2 + 1], "Arithmetic Overflow in AvgAccumulator");
+      Column& c = out.cols[pending[(size_t)e]];
+      if (!c.validity) continue;
+      c.null_count = G - (int64_t)h[(size_t)e * 2];
+      if (c.null_count == 0) c.validity.reset();
+    }
+  } else {
+    DFGPU_HIP(hipStreamSynchronize(r.stream));
+  }
   return out;
 }
 

@@ -111,6 +111,14 @@ __device__ __forceinline__ uint64_t wave_seg_or(uint64_t v, bool head) {
   return v;
 }
 
+// Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md): tile = xcd_tile(b + k * gridDim.x, n_tiles) (gridDim.x a multiple of 8) gives every
+// XCD a CONTIGUOUS eighth of the tiles, walked in order — the lines neighbouring tiles read or append to meet in ONE L2 instead of
+// being split across eight (a partially written line leaves each L2 as a masked write).  A bijection of [0, n_tiles); speed only.
+__device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t n_tiles) {
+  const int64_t q = n_tiles >> 3, r = n_tiles & 7, x = b & 7, j = b >> 3;
+  return x * q + (x < r ? x : r) + j;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_hist(const uint64_t* __restrict__ 
 // sorted by digit and every digit's run is written contiguously.
 template <int NW, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_t* __restrict__ idx_in, int64_t n, DivBy dv, int dword, int shift, int bits, int64_t n_tiles,
-                                                      const uint64_t* __restrict__ offsets, SortBufs out) {
+                                                      const uint64_t* __restrict__ offsets, SortBufs out, int xcd_map) {
   constexpr int TILE = BLOCK * ITEMS;
   constexpr int NWAVE = BLOCK / WAVE;
   __shared__ uint64_t s_key[NW][TILE];
@@ -271,7 +271,8 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_
   const unsigned mask = (1u << bits) - 1u;
   const int wave = threadIdx.x >> 6;
   const unsigned lane = lane_id();
-  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const int64_t t = xcd_map ? xcd_tile(tl, n_tiles) : tl;
     const int64_t lo = t * TILE;
     const int tile_rows = (int)((n - lo) < TILE ? (n - lo) : TILE);
 #pragma unroll
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter2(KeyWords k, const uint32_
 template <int ITEMS, bool BUILD>
 __global__ __launch_bounds__(BLOCK) void k_rs_scatter_kv(const uint64_t* __restrict__ key_in, const uint4* __restrict__ rec_in, PackLayout L, int64_t n, DivBy dv, int shift,
                                                         int bits, int64_t n_tiles, const uint64_t* __restrict__ offsets, uint64_t* __restrict__ key_out,
-                                                        uint4* __restrict__ rec_out) {
+                                                        uint4* __restrict__ rec_out, int xcd_map) {
   constexpr int TILE = BLOCK * ITEMS;
   constexpr int NWAVE = BLOCK / WAVE;
   extern __shared__ __align__(16) unsigned char kv_smem[];   // records | keys | digits of the staged tile (beyond the 64 KB static LDS allows at 16 rows per thread)
@@ -373,7 +374,8 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter_kv(const uint64_t* __restr
   const unsigned mask = (1u << bits) - 1u;
   const int wave = threadIdx.x >> 6;
   const unsigned lane = lane_id();
-  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const int64_t t = xcd_map ? xcd_tile(tl, n_tiles) : tl;
     const int64_t lo = t * TILE;
     const int tile_rows = (int)((n - lo) < TILE ? (n - lo) : TILE);
 #pragma unroll
@@ -521,6 +523,11 @@ struct SortedKeys {
 };
 
 // digits of a packed key of `total_bits` bits, least significant first; <= 8 bits each, none straddles a word
+// A/B knob of the XCD-contiguous tile order of the scatter passes (device.hpp xcd_tile); default on
+static int sort_xcd_map() {
+  const char* e = std::getenv("DFGPU_SORT_XCD");
+  return e ? std::atoi(e) : 1;
+}
 static int max_digit_bits() { return 8; }   // (digit widths and tile sizes were swept in round 2: profiles/r2_radix_sweep.md)
 static std::vector<Digit> key_digits(int total_bits) {
   std::vector<Digit> ds;
@@ -540,6 +547,7 @@ static std::vector<Digit> key_digits(int total_bits) {
 
 // stable LSD radix sort of n (key, idx) elements over the given digits; returns the buffers holding the result
 static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>& digits, bool want_ids) {
+  const int xcd_map = sort_xcd_map();   // A/B knob of the XCD-contiguous tile order (device.hpp xcd_tile)
   Runtime& r = rt();
   if (n <= 1 || digits.empty()) return in;
   const int nwords = in.nwords;
@@ -569,9 +577,9 @@ static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>&
     scan_u32(counts->as<uint32_t>(), (int64_t)nb * n_tiles, offsets->as<uint64_t>());
     const uint32_t* idx_in = cur.idx ? cur.idx->as<uint32_t>() : nullptr;
     switch (nwords) {
-      case 1: k_rs_scatter2<1, 16><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-      case 2: k_rs_scatter2<2, rs_items(2)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
-      default: k_rs_scatter2<3, rs_items(3)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob); break;
+      case 1: k_rs_scatter2<1, 16><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob, xcd_map); break;
+      case 2: k_rs_scatter2<2, rs_items(2)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob, xcd_map); break;
+      default: k_rs_scatter2<3, rs_items(3)><<<grid, BLOCK, 0, r.stream>>>(ck, idx_in, n, dv, d.word, d.shift, d.bits, n_tiles, offsets->as<uint64_t>(), ob, xcd_map); break;
     }
     DFGPU_HIP(hipGetLastError());
     std::swap(cur, alt);
@@ -968,7 +976,7 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
         const size_t lds = (size_t)tile * (8 + 16 + 1);
         DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, BLOCK, lds, r.stream>>>(cur_key->as<uint64_t>(), first ? nullptr : cur_rec->as<uint4>(), L, n, dv, pos, bits, n_tiles, offsets->as<uint64_t>(),
-                                           dst_key->as<uint64_t>(), dst_rec->as<uint4>());
+                                           dst_key->as<uint64_t>(), dst_rec->as<uint4>(), sort_xcd_map());
       };
       if (first) launch(k_rs_scatter_kv<ITEMS, true>);
       else launch(k_rs_scatter_kv<ITEMS, false>);

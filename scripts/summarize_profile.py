@@ -42,7 +42,7 @@ def main():
         return {short(r[0]): r[1] for r in q(os.path.join(src, sub, "pmc_results.db"),
                 "select kernel_name, avg(value) from counters_collection group by 1")}
     fetch, write = pmc("pmc_fetch"), pmc("pmc_write")
-    nb = bench["config"]["build_rows"] if bench else None
+    nb = bench["config"].get("build_rows") if bench else None
     # calibration kernel: k_rank_setbits (ascending variant) reads exactly the 8-byte build keys, nothing else
     calib = None
     # (the VERIFY variant — 4 template arguments — also reads every key's predecessor: not a known-bytes kernel)
@@ -75,35 +75,90 @@ def main():
             fmt = lambda x, d=1: "" if x is None else f"{x:.{d}f}"
             f.write(f"| {r['kernel']} | {r['calls']} | {r['avg_us']:.1f} | {r['pct']:.1f} | {fmt(r['FETCH_SIZE_KB'],0)} | {fmt(r['WRITE_SIZE_KB'],0)} | "
                     f"{fmt(r['traffic_bytes']/1e9 if r['traffic_bytes'] else None,2)} | {fmt(r['traffic_GBps'],0)} |\n")
-    # per-launch PMC traffic of the dominant kernel, one entry per flavour (last template argument: 0 = unordered single
-    # pass -> "join_probe_fused", 2 = placed by tile offsets, probe order -> "join_probe_placed")
-    entries = []
-    # what the passes were taken on: the commit checked out when this summary is made (the run's snapshot) and a hash of the file
-    # that defines the kernel — bench.py attaches the traffic only while that file is unchanged (a kernel edit without a fresh PMC
-    # pass must not report the old bytes)
+    # ---- agreement of the two clocks and the clock state of the passes (scripts/profile_run.py)
+    try:
+        agree = json.load(open(os.path.join(src, "agreement.json")))["tries"]
+        with open(dst + ".md", "a") as f:
+            f.write("\nHIP-event average vs rocprofv3 average of the dominant kernel, SAME process (the kernel-trace pass prints its own bench line):\n\n"
+                    "| try | scope | device kernel | HIP events ms | rocprofv3 ms | difference | step ms (under the profiler) |\n|---:|---|---|---:|---:|---:|---:|\n")
+            for t in agree:
+                if "error" in t:
+                    f.write(f"| {t['try']} | error: {t['error']} | | | | | |\n")
+                else:
+                    f.write(f"| {t['try']} | {t['scope']} | {t['device_kernel']} | {t['hip_event_avg_ms']} | {t['rocprof_avg_ms']} | "
+                            f"{'' if t['relative_difference'] is None else format(t['relative_difference'] * 100, '.2f') + ' %'} | {t['ms_per_step']:.3f} |\n")
+        out["agreement"] = agree
+    except (OSError, KeyError, ValueError):
+        pass
+    try:
+        clocks = json.load(open(os.path.join(src, "clocks.json")))
+        out["clocks"] = clocks
+        with open(dst + ".md", "a") as f:
+            f.write("\nclock state (rocm-smi) before -> after each pass:\n\n")
+            for c in clocks:
+                def brief(x):
+                    if not isinstance(x, dict):
+                        return str(x)
+                    card = x.get("card0", x)
+                    keep = {k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk", "mclk", "power", "performance", "temperature (sensor junction)", "temperature (sensor memory)"))} if isinstance(card, dict) else card
+                    return json.dumps(keep)[:600]
+                f.write(f"- `{c['pass']}` ({c['seconds']} s, rc {c['rc']}): {brief(c['before'])} -> {brief(c['after'])}\n")
+    except (OSError, KeyError, ValueError):
+        pass
+    json.dump(out, open(dst + ".json", "w"), indent=1)
+    # per-launch PMC traffic of the line's dominant kernel -> profiles/traffic.json (entries of OTHER workloads / kernels are kept).
+    # What the passes were taken on: the commit checked out when this summary is made (the run's snapshot) and a hash of the file that
+    # defines the kernel — bench.py attaches the traffic only while that file is unchanged (a kernel edit without a fresh PMC pass must
+    # not report the old bytes)
     import hashlib
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import DEVICE_KERNEL_OF
     try:
         commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
     except Exception:  # noqa: BLE001
         commit = None
-    src_sha = hashlib.sha256(open(os.path.join(root, "datafusion_amd", "csrc", "join.hip"), "rb").read()).hexdigest()[:16]
+    entries = []
+    is_join = bool(bench) and "build_rows" in bench.get("config", {})
     for r in rows:
-        if not r["kernel"].startswith("k_join_probe_fused") or not r["traffic_bytes"] or not bench:
+        if not r["traffic_bytes"] or not bench:
             continue
-        targs = [a.strip() for a in r["kernel"][r["kernel"].index("<") + 1:].rstrip(">").split(",")]   # <KIND, KT, W, MODE, KEYREG>
-        mode = targs[3] if len(targs) >= 4 else ""
-        name = {"0": "join_probe_fused", "2": "join_probe_placed"}.get(mode.replace("(dfgpu::FusedMode)", ""))
-        if name is None:
-            continue
-        wl = {k: bench["config"][k] for k in ("build_rows", "probe_rows", "output_rows", "join_table")}
+        if is_join:
+            if not r["kernel"].startswith("k_join_probe_fused"):
+                continue
+            targs = [a.strip() for a in r["kernel"][r["kernel"].index("<") + 1:].rstrip(">").split(",")]   # <KIND, KT, W, MODE, KEYREG>
+            mode = targs[3] if len(targs) >= 4 else ""
+            name = {"0": "join_probe_fused", "2": "join_probe_placed"}.get(mode.replace("(dfgpu::FusedMode)", ""))
+            if name is None:
+                continue
+            wl = {k: bench["config"][k] for k in ("build_rows", "probe_rows", "output_rows", "join_table")}
+            ksrc = "datafusion_amd/csrc/join.hip"
+        else:
+            scope = (bench.get("roofline") or {}).get("kernel")
+            prefix = DEVICE_KERNEL_OF.get(scope)
+            if prefix is None or not r["kernel"].startswith(prefix):
+                continue
+            if any(e["kernel"] == scope for e in entries):     # (rows are sorted by total time: the first match is the dominant instantiation)
+                continue
+            name = scope
+            wl = {"query": bench["metric"].split("_")[1], "sf": float(bench["config"]["workload"].split(", SF")[1].split(",")[0]), "input_rows": bench["config"]["input_rows"]}
+            ksrc = "datafusion_amd/csrc/aggregate.hip" if scope.startswith("agg") else "datafusion_amd/csrc/join.hip"
+        src_sha = hashlib.sha256(open(os.path.join(root, ksrc), "rb").read()).hexdigest()[:16]
         entries.append({"kernel": name, "device_kernel": r["kernel"], "traffic_bytes_per_launch": int(r["traffic_bytes"]),
                         "read_bytes_corrected": int(r["read_bytes_corrected"] or 0), "write_bytes": int(r["write_bytes"] or 0),
                         "fetch_size_calibration": calib, "avg_launch_us_rocprof": r["avg_us"], "source": os.path.basename(dst) + ".json", "workload": wl,
-                        "commit": commit, "kernel_source": "datafusion_amd/csrc/join.hip", "kernel_source_sha16": src_sha})
+                        "commit": commit, "kernel_source": ksrc, "kernel_source_sha16": src_sha})
     if entries:
-        json.dump({"kernels": entries}, open(os.path.join(os.path.dirname(dst) or ".", "traffic.json"), "w"), indent=1)
+        tpath = os.path.join(os.path.dirname(dst) or ".", "traffic.json")
+        try:
+            old = json.load(open(tpath))["kernels"]
+        except (OSError, KeyError, ValueError):
+            old = []
+        def same(a, b):
+            return a["kernel"] == b["kernel"] and {k: v for k, v in a["workload"].items() if k != "join_table"} == {k: v for k, v in b["workload"].items() if k != "join_table"}
+        kept = [o for o in old if not any(same(o, e) for e in entries)]
+        json.dump({"kernels": kept + entries}, open(tpath, "w"), indent=1)
     print(open(dst + ".md").read())
 
 
