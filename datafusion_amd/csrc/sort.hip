@@ -456,6 +456,189 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter_kv(const uint64_t* __restr
   }
 }
 
+// ------------------------------------------------------------------------------ onesweep pass (round 5)
+// The carried sort's top passes as ONE kernel per pass: no per-tile histogram kernel (a second read of the keys), no scan of a
+// (digit x tile) matrix, no strided load of a tile's 256 offsets.  The digit totals of ALL passes come from one read of the key
+// columns up front (k_os_hist); a tile then finds where its run of every digit starts with a decoupled look-back over the tiles
+// before it — per digit, by the thread that owns the digit: {status, count} words of 32 bits, published AGG(regate) as soon as the
+// tile's counts are known and PFX (inclusive prefix) once its own look-back is done.  Tiles are handed out by an atomic ticket, so a tile
+// only ever waits on tiles whose workgroup is already resident.  While its predecessors publish, the tile stages its keys in LDS in digit
+// order (that needs local positions only); the look-back's answer is needed for the write-out alone.  Keys and records go through the
+// SAME 32 KB staging buffer one after the other: 38 KB of LDS per workgroup, four workgroups per CU.
+// Measured with the phases switched off one by one (150 M orders, two passes, profiles/r5_sort_phases.md): the tiles copied where they lie
+// 3.3 ms (this launch geometry streams at 4.3 TB/s), + ranking / staging / scattered write-out 4.0, + the look-back 5.1 (a look-back per
+// CHUNK of 8 tiles, counted in a sweep of its own, was slower: 6.1).
+// Stable (wave-private ballot ranking, as k_rs_scatter_kv).  Row counts below 2^30 (the status words hold 30-bit prefixes).
+constexpr int OS_ITEMS = 8;
+constexpr int OS_TILE = BLOCK * OS_ITEMS;
+constexpr int OS_MAX_PASSES = 4;
+constexpr uint32_t OS_AGG = 1u << 30, OS_PFX = 2u << 30, OS_VAL = (1u << 30) - 1u;
+struct OsDigits {
+  int shift[OS_MAX_PASSES], bits[OS_MAX_PASSES];
+  int n;
+};
+__device__ __forceinline__ uint32_t os_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void os_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// digit totals of every pass: hist[pass * 256 + digit].  BUILD: the keys are computed from the key columns (no packed key array exists)
+template <bool BUILD>
+__global__ __launch_bounds__(BLOCK) void k_os_hist(const uint64_t* __restrict__ key_in, PackCols pc, int64_t n, DivBy dv, OsDigits dg, unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int s_h[OS_MAX_PASSES][256];
+#pragma unroll
+  for (int p = 0; p < OS_MAX_PASSES; p++) s_h[p][threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    uint64_t k[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t i = i0 + u * stride;
+      k[u] = i < n ? (BUILD ? pack_key64(pc, i) : key_in[i]) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (i0 + u * stride >= n) continue;
+      const uint64_t b = div_apply(k[u], dv);
+      for (int p = 0; p < dg.n; p++) atomicAdd(&s_h[p][(unsigned)(b >> dg.shift[p]) & ((1u << dg.bits[p]) - 1u)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < dg.n; p++)
+    if (s_h[p][threadIdx.x]) atomicAdd(&hist[p * 256 + threadIdx.x], (unsigned long long)s_h[p][threadIdx.x]);
+}
+// exclusive scan of every pass's 256 totals (one workgroup of 256 threads per pass)
+__global__ __launch_bounds__(BLOCK) void k_os_bases(const unsigned long long* __restrict__ hist, unsigned long long* __restrict__ base) {
+  __shared__ unsigned long long s_w[BLOCK / WAVE];
+  const unsigned long long v = hist[blockIdx.x * 256 + threadIdx.x];
+  const unsigned long long inc = wave_inclusive_sum_dpp(v);
+  if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  unsigned long long b = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) b += s_w[w];
+  base[blockIdx.x * 256 + threadIdx.x] = b + inc - v;
+}
+
+template <bool BUILD>
+__global__ __launch_bounds__(BLOCK, 4) void k_os_pass(const uint64_t* __restrict__ key_in, const uint4* __restrict__ rec_in, PackCols pc, PackLayout L, int64_t n, DivBy dv, int shift,
+                                                     int bits, int64_t n_tiles, const unsigned long long* __restrict__ bin_base, uint32_t* __restrict__ tile_state,
+                                                     unsigned* __restrict__ ticket, uint64_t* __restrict__ key_out, uint4* __restrict__ rec_out) {
+  constexpr int NWAVE = BLOCK / WAVE;
+  __shared__ __align__(16) unsigned char s_stage[OS_TILE * 16];   // the tile in digit order: its keys, then its records
+  __shared__ uint8_t s_dig[OS_TILE];
+  __shared__ uint16_t s_cnt[NWAVE][256];   // ranking: rows of each digit seen so far by the wave; then the wave's exclusive prefix over earlier waves
+  __shared__ uint16_t s_start[256];        // exclusive scan of the tile's digit counts
+  __shared__ unsigned int s_goff[256];     // staged slot q of digit d goes to output position q + s_goff[d] (32-bit wrap-around arithmetic: n < 2^30)
+  __shared__ unsigned int s_wtot[NWAVE];
+  __shared__ unsigned int s_tile;
+  uint64_t* s_key = reinterpret_cast<uint64_t*>(s_stage);
+  uint4* s_rec = reinterpret_cast<uint4*>(s_stage);
+  const unsigned mask = (1u << bits) - 1u;
+  const int wave = threadIdx.x >> 6;
+  const unsigned lane = lane_id();
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t t = (int64_t)s_tile;
+    if (t >= n_tiles) return;
+    const int64_t lo = t * OS_TILE;
+    const int tile_rows = (int)((n - lo) < OS_TILE ? (n - lo) : OS_TILE);
+    uint64_t key[OS_ITEMS];
+    uint4 rec[OS_ITEMS];
+    unsigned dig[OS_ITEMS], rank[OS_ITEMS];
+#pragma unroll
+    for (int c = 0; c < OS_ITEMS; c++) {  // all loads of the wave's segment in flight together
+      const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
+      const int64_t src = lo + (j < tile_rows ? j : 0);
+      if (BUILD) {
+        key[c] = pack_key64(pc, src);
+        uint64_t sl[2];
+        record_build<2>(L, src, sl);
+        rec[c] = uint4{(unsigned)sl[0], (unsigned)(sl[0] >> 32), (unsigned)sl[1], (unsigned)(sl[1] >> 32)};
+      } else {
+        key[c] = key_in[src];
+        const uint4 v = rec_in[src];   // (component by component: the 16-byte struct copy kept the whole array in scratch memory)
+        rec[c] = uint4{v.x, v.y, v.z, v.w};
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < OS_ITEMS; c++) {
+      const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
+      const bool in = j < tile_rows;
+      dig[c] = in ? ((unsigned)(div_apply(key[c], dv) >> shift) & mask) : 0u;
+      uint64_t peers = ballot64(in);
+      for (int b = 0; b < bits; b++) {
+        const uint64_t bal = ballot64((dig[c] >> b) & 1u);
+        peers &= ((dig[c] >> b) & 1u) ? bal : ~bal;
+      }
+      const unsigned r_in_wave = mbcnt(peers);
+      const unsigned base = s_cnt[wave][dig[c]];
+      if (in && r_in_wave == 0) s_cnt[wave][dig[c]] = (uint16_t)(base + (unsigned)__popcll(peers));
+      rank[c] = base + r_in_wave;
+    }
+    __syncthreads();
+    unsigned run = 0;   // thread d: digit d's rows in this tile
+    {
+#pragma unroll
+      for (int w = 0; w < NWAVE; w++) {
+        const unsigned v = s_cnt[w][threadIdx.x];
+        s_cnt[w][threadIdx.x] = (uint16_t)run;
+        run += v;
+      }
+      // the tile's count of this digit is public from here on: the tiles behind it can add it up while this one stages its rows
+      if (t > 0 && threadIdx.x <= mask) os_store(&tile_state[t * 256 + threadIdx.x], OS_AGG | run);
+      const unsigned inc = wave_inclusive_sum<unsigned>(run);
+      if (lane == 63) s_wtot[wave] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; w++) base += s_wtot[w];
+      s_start[threadIdx.x] = (uint16_t)(base + inc - run);
+    }
+    __syncthreads();
+    unsigned q[OS_ITEMS];
+#pragma unroll
+    for (int c = 0; c < OS_ITEMS; c++) {
+      const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
+      q[c] = 0xFFFFFFFFu;
+      if (j < tile_rows) {
+        q[c] = (unsigned)s_start[dig[c]] + (unsigned)s_cnt[wave][dig[c]] + rank[c];
+        s_key[q[c]] = key[c];
+        s_dig[q[c]] = (uint8_t)dig[c];
+      }
+    }
+    // ---- look-back: thread d adds up digit d's counts over the tiles before this one, nearest first, until it meets an inclusive prefix
+    if (threadIdx.x <= mask) {
+      unsigned excl = 0;
+      if (t > 0) {
+        int64_t p = t - 1;
+        for (;;) {
+          const uint32_t st = os_load(&tile_state[p * 256 + threadIdx.x]);
+          const uint32_t status = st >> 30;
+          if (status == 0) {
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+          }
+          excl += st & OS_VAL;
+          if (status == 2) break;
+          p--;
+        }
+      }
+      os_store(&tile_state[t * 256 + threadIdx.x], OS_PFX | (excl + run));
+      s_goff[threadIdx.x] = (unsigned)bin_base[threadIdx.x] + excl - (unsigned)s_start[threadIdx.x];
+    }
+    __syncthreads();
+    for (int qq = threadIdx.x; qq < tile_rows; qq += BLOCK) key_out[qq + s_goff[s_dig[qq]]] = s_key[qq];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < OS_ITEMS; c++)
+      if (q[c] != 0xFFFFFFFFu) s_rec[q[c]] = rec[c];
+    __syncthreads();
+    for (int qq = threadIdx.x; qq < tile_rows; qq += BLOCK) rec_out[qq + s_goff[s_dig[qq]]] = s_rec[qq];
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------ TopK narrowing
 // histogram of one digit over candidate rows
 __global__ __launch_bounds__(BLOCK) void k_select_hist(const uint64_t* __restrict__ word, const uint8_t* __restrict__ state, int64_t n, int shift, int bits,
@@ -896,6 +1079,57 @@ __global__ __launch_bounds__(BLOCK) void k_build_records16(PackLayout L, int64_t
     rec[i] = uint4{(unsigned)sl[0], (unsigned)(sl[0] >> 32), (unsigned)sl[1], (unsigned)(sl[1] >> 32)};
   }
 }
+// the carried sort's last step: bucket bounds off the top-sorted keys, then one workgroup per bucket sorts it in LDS and writes the OUTPUT
+// (key columns decoded from the sorted key, the record's fields from the records).  false = a bucket is too large for LDS (skewed keys).
+static bool carried_emit(const Table& in, const std::vector<int>& key_cols, const PackCols& pc, const std::vector<int>& payload, const std::vector<int>& order,
+                         const PackLayout& L, const BufPtr& cur_key, const BufPtr& cur_rec, const BufPtr& cur_idx, int64_t n, int64_t n_buckets, uint64_t width,
+                         int low_bits, Table& out) {
+  Runtime& r = rt();
+  BufPtr starts = make_zero_buf((size_t)n_buckets * 4), ends = make_zero_buf((size_t)n_buckets * 4), mx = make_zero_buf(4);
+  {
+    ProfileScope ps("sort_bucket_bounds", n * 8);
+    k_bucket_bounds<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), n, div_by(width), starts->as<uint32_t>(), ends->as<uint32_t>());
+    k_bucket_max<<<grid_for(n_buckets, BLOCK), BLOCK, 0, r.stream>>>(starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, mx->as<unsigned>());
+  }
+  unsigned largest = 0;
+  d2h(&largest, mx->ptr, 4);
+  if (largest > (unsigned)LS_CAP) return false;  // skewed keys: the caller's paths (the packed keys are intact)
+  // the output columns and who writes them
+  out.cols.assign(in.cols.size(), Column{});
+  SortEmit e{};
+  e.n_keys = pc.n;
+  int out_bytes = 0;
+  for (int k = 0; k < pc.n; k++) {
+    const int c = key_cols[(size_t)k];
+    if (!out.cols[(size_t)c].data) out.cols[(size_t)c] = alloc_like(in.cols[(size_t)c], n);
+    e.key_dst[k] = out.cols[(size_t)c].data->ptr;
+    e.key_type[k] = pc.c[k].type;
+    e.key_desc[k] = pc.c[k].desc;
+    e.key_base[k] = pc.c[k].base_lo;
+    e.key_mult[k] = pc.c[k].mult;
+    e.key_div[k] = div_by(pc.c[k].mult);
+    out_bytes += type_width(in.cols[(size_t)c].field.type);
+  }
+  e.rec = cur_rec->as<uint4>();
+  e.fields = L;
+  for (int q = 0; q < L.n; q++) {
+    const int c = payload[(size_t)order[(size_t)q]];
+    out.cols[(size_t)c] = alloc_like(in.cols[(size_t)c], n);
+    e.fields.dst[q] = out.cols[(size_t)c].data->ptr;
+    out_bytes += L.width[q];
+  }
+  {
+    ProfileScope ps("sort_local_emit", n * (int64_t)(8 + 16 + out_bytes));
+    const unsigned lg = (unsigned)std::min<int64_t>(n_buckets, (int64_t)r.num_cus * 16);
+    const uint32_t* idp = cur_idx ? cur_idx->as<uint32_t>() : nullptr;   // (null: a row's id is its position — in the top passes' order, or of a one-bucket input)
+    if (low_bits <= 32) k_local_sort<uint32_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), idp, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
+    else k_local_sort<uint64_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), idp, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
+    DFGPU_HIP(hipGetLastError());
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  return true;
+}
+
 // the carried sort (see sort_table); false = does not apply (nothing was touched: `keys` are intact)
 static bool sort_carried(const Table& in, const std::vector<int>& key_cols, const PackCols& pc, const BufPtr& keys, int64_t n, uint64_t key_space, Table& out,
                          bool& clobbered) {
@@ -990,49 +1224,82 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
     k_build_records16<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(L, n, cur_rec->as<uint4>());
     DFGPU_HIP(hipGetLastError());
   }
-  BufPtr starts = make_zero_buf((size_t)n_buckets * 4), ends = make_zero_buf((size_t)n_buckets * 4), mx = make_zero_buf(4);
+  return carried_emit(in, key_cols, pc, payload, order, L, cur_key, cur_rec, cur_idx, n, n_buckets, width, low_bits, out);
+}
+
+// The carried sort with onesweep top passes (round 5; the default form).  The first pass reads the SOURCE columns — the key is packed and
+// the 16-byte record built on the fly — so no packed key array and no record array in input order are ever written: per row the sort
+// moves 12 B (histogram of the key columns) + 24 + 24 B per top pass + 24 + 24 B for the bucket sort that writes the output.
+// false = does not apply, or the keys are skewed beyond what a bucket holds (nothing was touched; the caller's older paths take over).
+static bool sort_carried_onesweep(const Table& in, const std::vector<int>& key_cols, const PackCols& pc, int64_t n, uint64_t key_space, Table& out) {
+  Runtime& r = rt();
+  const char* mode_env = std::getenv("DFGPU_SORT_CARRIED");   // A/B knob: unset / "o" = this form; "0", "p", "i" = the round-4 forms
+  if (mode_env && mode_env[0] != 'o') return false;
+  const char* min_env = std::getenv("DFGPU_SORT_CARRIED_MIN_ROWS");
+  const int64_t min_rows = min_env ? std::atoll(min_env) : ((int64_t)1 << 22);
+  if (n < min_rows || n < 2 || n >= ((int64_t)1 << 30) || key_space < 2) return false;
+  for (int k = 0; k < pc.n; k++) {   // every key column can be read back from the packed key
+    const PackCol& c = pc.c[k];
+    const bool int_like = c.type == DFGPU_INT32 || c.type == DFGPU_DATE32 || c.type == DFGPU_UINT32 || c.type == DFGPU_INT64 || c.type == DFGPU_UINT64 || c.type == DFGPU_UINT8;
+    if (c.valid || c.has_null_bit || !int_like || c.range == 0 || c.mult == 0) return false;
+  }
+  std::vector<int> payload;
+  for (int c = 0; c < (int)in.cols.size(); c++)
+    if (std::find(key_cols.begin(), key_cols.end(), c) == key_cols.end()) payload.push_back(c);
+  PackLayout L{};
+  int R = 0;
+  std::vector<int> order;
+  if (payload.empty() || !plan_record_layout(in, payload, L, R, order) || R != 16) return false;
+  int top_bits = 0;
+  while (top_bits < 32 && (n >> top_bits) > 2304) top_bits += 8;
+  if (top_bits == 0 || top_bits > 8 * OS_MAX_PASSES || (key_space >> top_bits) < 2) return false;
+  const int64_t n_buckets = (int64_t)1 << top_bits;
+  const uint64_t width = (key_space + (uint64_t)n_buckets - 1) / (uint64_t)n_buckets;
+  int low_bits = 0;
+  while (low_bits < 64 && ((width - 1) >> low_bits)) low_bits++;
+  if (low_bits == 0) return false;
+  const DivBy dv = div_by(width);
+  OsDigits dg{};
+  for (int pos = 0; pos < top_bits; pos += 8) {
+    dg.shift[dg.n] = pos;
+    dg.bits[dg.n] = std::min(8, top_bits - pos);
+    dg.n++;
+  }
+  const int64_t n_tiles = (n + OS_TILE - 1) / OS_TILE;
+  BufPtr hist = make_zero_buf((size_t)OS_MAX_PASSES * 256 * 8), bases = make_buf((size_t)OS_MAX_PASSES * 256 * 8);
+  BufPtr tickets = make_zero_buf((size_t)OS_MAX_PASSES * 4);
+  BufPtr state = make_buf((size_t)n_tiles * 256 * 4);
+  int64_t key_col_bytes = 0, payload_bytes = 0;
+  for (int k = 0; k < pc.n; k++) key_col_bytes += n * (pc.c[k].type == DFGPU_UINT8 ? 1 : type_width(pc.c[k].type));
+  for (int q = 0; q < L.n; q++) payload_bytes += L.width[q];
   {
-    ProfileScope ps("sort_bucket_bounds", n * 8);
-    k_bucket_bounds<<<grid_for(n, BLOCK), BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), n, div_by(width), starts->as<uint32_t>(), ends->as<uint32_t>());
-    k_bucket_max<<<grid_for(n_buckets, BLOCK), BLOCK, 0, r.stream>>>(starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, mx->as<unsigned>());
-  }
-  unsigned largest = 0;
-  d2h(&largest, mx->ptr, 4);
-  if (largest > (unsigned)LS_CAP) return false;  // skewed keys: the caller's paths (the packed keys are intact)
-  // the output columns and who writes them
-  out.cols.assign(in.cols.size(), Column{});
-  SortEmit e{};
-  e.n_keys = pc.n;
-  int out_bytes = 0;
-  for (int k = 0; k < pc.n; k++) {
-    const int c = key_cols[(size_t)k];
-    if (!out.cols[(size_t)c].data) out.cols[(size_t)c] = alloc_like(in.cols[(size_t)c], n);
-    e.key_dst[k] = out.cols[(size_t)c].data->ptr;
-    e.key_type[k] = pc.c[k].type;
-    e.key_desc[k] = pc.c[k].desc;
-    e.key_base[k] = pc.c[k].base_lo;
-    e.key_mult[k] = pc.c[k].mult;
-    e.key_div[k] = div_by(pc.c[k].mult);
-    out_bytes += type_width(in.cols[(size_t)c].field.type);
-  }
-  e.rec = cur_rec->as<uint4>();
-  e.fields = L;
-  for (int q = 0; q < L.n; q++) {
-    const int c = payload[(size_t)order[(size_t)q]];
-    out.cols[(size_t)c] = alloc_like(in.cols[(size_t)c], n);
-    e.fields.dst[q] = out.cols[(size_t)c].data->ptr;
-    out_bytes += L.width[q];
-  }
-  {
-    ProfileScope ps("sort_local_emit", n * (int64_t)(8 + 16 + out_bytes));
-    const unsigned lg = (unsigned)std::min<int64_t>(n_buckets, (int64_t)r.num_cus * 16);
-    const uint32_t* idp = cur_idx ? cur_idx->as<uint32_t>() : nullptr;   // (null: a row's id is its position — in the top passes' order, or of a one-bucket input)
-    if (low_bits <= 32) k_local_sort<uint32_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), idp, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
-    else k_local_sort<uint64_t, true><<<lg, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), idp, starts->as<uint32_t>(), ends->as<uint32_t>(), n_buckets, width, low_bits, nullptr, e);
+    ProfileScope ps("sort_digit_totals", key_col_bytes);
+    k_os_hist<true><<<r.num_cus * 8, BLOCK, 0, r.stream>>>(nullptr, pc, n, dv, dg, hist->as<unsigned long long>());
+    k_os_bases<<<dg.n, BLOCK, 0, r.stream>>>(hist->as<unsigned long long>(), bases->as<unsigned long long>());
     DFGPU_HIP(hipGetLastError());
   }
-  DFGPU_HIP(hipStreamSynchronize(r.stream));
-  return true;
+  BufPtr key_a = make_buf((size_t)n * 8), rec_a = make_buf((size_t)n * 16 + 64);
+  BufPtr key_b = dg.n > 1 ? make_buf((size_t)n * 8) : nullptr, rec_b = dg.n > 1 ? make_buf((size_t)n * 16 + 64) : nullptr;
+  BufPtr cur_key, cur_rec;
+  const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)r.num_cus * 4);
+  for (int p = 0; p < dg.n; p++) {
+    const bool first = p == 0;
+    BufPtr& dst_key = (first || cur_key == key_b) ? key_a : key_b;
+    BufPtr& dst_rec = (first || cur_rec == rec_b) ? rec_a : rec_b;
+    ProfileScope ps("sort_onesweep_pass", first ? key_col_bytes + n * (payload_bytes + 24) : n * 48);
+    DFGPU_HIP(hipMemsetAsync(state->ptr, 0, (size_t)n_tiles * 256 * 4, r.stream));
+    if (first)
+      k_os_pass<true><<<grid, BLOCK, 0, r.stream>>>(nullptr, nullptr, pc, L, n, dv, dg.shift[p], dg.bits[p], n_tiles, bases->as<unsigned long long>() + p * 256,
+                                                    state->as<uint32_t>(), tickets->as<unsigned>() + p, dst_key->as<uint64_t>(), dst_rec->as<uint4>());
+    else
+      k_os_pass<false><<<grid, BLOCK, 0, r.stream>>>(cur_key->as<uint64_t>(), cur_rec->as<uint4>(), pc, L, n, dv, dg.shift[p], dg.bits[p], n_tiles,
+                                                     bases->as<unsigned long long>() + p * 256, state->as<uint32_t>(), tickets->as<unsigned>() + p, dst_key->as<uint64_t>(),
+                                                     dst_rec->as<uint4>());
+    DFGPU_HIP(hipGetLastError());
+    cur_key = dst_key;
+    cur_rec = dst_rec;
+  }
+  return carried_emit(in, key_cols, pc, payload, order, L, cur_key, cur_rec, nullptr, n, n_buckets, width, low_bits, out);
 }
 
 static Table sort_table(const Table& in, const std::vector<int>& key_cols, const uint8_t* desc, const uint8_t* nulls_first, int64_t fetch) {
@@ -1188,6 +1455,8 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
         }
       }
     }
+    // a full sort by one mixed-radix word whose other columns fit a 16-byte record: the onesweep carried sort reads the source columns itself
+    if (!topk && !limited && narrow && nwords == 1 && n_out == n && sort_carried_onesweep(in, key_cols, pc, n, key_space, out)) return out;
     if (!limited) pack_keys();
     if (topk && !limited) {
       // ---- TopK: MSD radix select narrows to the rows that can still be among the first k
