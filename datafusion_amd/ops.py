@@ -40,6 +40,22 @@ def filter(table: DeviceTable, predicate: PhysicalExpr, projection=None) -> Devi
     return DeviceTable(out)
 
 
+class FilterPlan:
+    """A PLANNED FilterExec (predicate + embedded projection, filter.rs:85): the predicate is lowered to the C ABI's form and the projected
+    columns are resolved once; `execute(table)` runs dfgpu_filter on any table of the planning table's schema (whose dictionaries bound
+    the predicate's string literals)."""
+
+    def __init__(self, table: DeviceTable, predicate: PhysicalExpr, projection=None):
+        self._pred = lower(predicate, table.column_names, table)
+        self._idx = None if projection is None else [table.index_of(c) for c in projection]
+        self._arr = None if self._idx is None else _ints(self._idx)
+
+    def execute(self, table: DeviceTable) -> DeviceTable:
+        out = C.c_void_p()
+        check(_lib.load().dfgpu_filter(table.handle, C.byref(self._pred.c), self._arr, 0 if self._idx is None else len(self._idx), C.byref(out)))
+        return DeviceTable(out)
+
+
 def project(table: DeviceTable, exprs) -> DeviceTable:
     """ProjectionExec: exprs = [(PhysicalExpr, name)] (projection.rs:439)"""
     lib = _lib.init()

@@ -162,7 +162,11 @@ class DeviceTable:
 
     @property
     def column_names(self):
-        return [self.column_view(i).name.decode() for i in range(self.num_columns)]
+        # a table is immutable: its names are read through the C ABI once (an operator call looks several columns up by name)
+        names = self.__dict__.get("_names")
+        if names is None:
+            names = self.__dict__["_names"] = tuple(self.column_view(i).name.decode() for i in range(self.num_columns))
+        return list(names)
 
     @property
     def schema(self) -> pa.Schema:
@@ -172,10 +176,14 @@ class DeviceTable:
     def index_of(self, name_or_index) -> int:
         if isinstance(name_or_index, int):
             return name_or_index
-        names = self.column_names
-        if names.count(name_or_index) != 1:
-            raise KeyError(f"column {name_or_index!r} not found or ambiguous in {names}")
-        return names.index(name_or_index)
+        index = self.__dict__.get("_name_index")
+        if index is None:
+            names = self.column_names
+            index = self.__dict__["_name_index"] = {n: (i if names.count(n) == 1 else -1) for i, n in enumerate(names)}
+        i = index.get(name_or_index, -1)
+        if i < 0:
+            raise KeyError(f"column {name_or_index!r} not found or ambiguous in {self.column_names}")
+        return i
 
     def dictionary_code(self, column, value: str):
         """index of `value` in a dictionary-encoded string column's dictionary, None if absent — what

