@@ -280,6 +280,24 @@ def run_join(args, rank, world, dist):
             elif exchange == "repartition":
                 o = comm.hash_exchange(orders, ["o_orderkey"])
                 l = comm.hash_exchange(lineitem, ["l_orderkey"])
+            elif exchange == "repartition_stream":
+                # the same exchange, streamed (dfgpu_exchange_hash_stream_*): the build side's chunks go into the join builder as they
+                # land, the probe side's chunks are probed as they land — partition kernel, all-to-all(v) and build / probe of
+                # neighbouring chunks overlap on the library's own threads and streams
+                builder = ops.JoinBuilder([0], probe_mode=probe_mode)
+                for chunk in comm.hash_exchange_stream(orders, ["o_orderkey"], args.exchange_chunks):
+                    builder.push(chunk)
+                    chunk.free()
+                ht = builder.finish()
+                n_out = 0
+                for chunk in comm.hash_exchange_stream(lineitem, ["l_orderkey"], args.exchange_chunks):
+                    out = ht.probe(chunk, ["l_orderkey"], "Inner", BUILD_COLS, PROBE_COLS)
+                    n_out += out.num_rows
+                    out.free()
+                    chunk.free()
+                res = (n_out, ht.info())
+                ht.free()
+                return res
             # join-table choice follows the library default (direct-address down to key density 1/64, see
             # DFGPU_DEFAULT_MIN_KEY_DENSITY in include/dfgpu.h): hash routing leaves each rank 1/N of the keys over the
             # same key range (density 0.25/N)
@@ -321,17 +339,17 @@ def run_join(args, rank, world, dist):
         # The exchange a byte-counting planner would pick instead for these sizes (broadcast the build side while
         # B*N < B+P, pruned by the destinations' probe-key bounds) is timed as the secondary entry of "exchanges" and named in
         # config.planner_choice — on clustered shards it moves almost nothing, which is not what the scaling curve is about.
-        primary = "repartition"
+        primary = "repartition_stream" if args.exchange_chunks > 1 else "repartition"
     planner_choice = None
     if world > 1:
         tot = max_over_ranks(dist, 0.0, nb_local, np_local)[1]
         planner_choice = "pruned" if broadcast_build_moves_fewer_bytes(tot[0] * 16, tot[1] * 40, world) else "repartition"
     m = measure(primary, args.probe_mode, True)
     others = {}
-    if world > 1 and args.exchange == "auto":
-        for ex in ("repartition", "pruned"):
+    if (world > 1 and args.exchange == "auto") or (forced and primary == "repartition_stream"):
+        for ex in (("repartition", "pruned") if world > 1 else ("repartition",)):
             if ex != primary:
-                others[ex] = measure(ex, args.probe_mode, False)
+                others[ex] = measure(ex, args.probe_mode, True)
     # secondary, outside the contract's timed region: the same step with the output in probe order
     ordered = measure(primary, 0, True) if (args.probe_mode == 3 and world == 1) else None
     if rank != 0:
@@ -368,6 +386,17 @@ def run_join(args, rank, world, dist):
         per_step = {k: v // args.steps for k, v in mm["xstats"].items()} if mm["xstats"] else None
         out = {"ms_per_step": round(mm["dt"] / args.steps * 1e3, 3), "rows_per_s": (mm["nb"] + mm["np"]) / (mm["dt"] / args.steps),
                "join_table": TABLE_KINDS[mm["info"].table_kind], "crossed_per_step_rank0": per_step}
+        if mm["stats"]:
+            # the step's three phases as the library's HIP events saw them on rank 0 (summed kernel time per step; under the streamed
+            # exchange they run on three streams at once, so their sum may exceed the step): partition kernels, the all-to-all(v), the join
+            def phase(pred):
+                return round(sum(v["total_ms"] for k, v in mm["stats"].items() if pred(k)) / args.steps, 3)
+            ph = {"partition_ms": phase(lambda k: k.startswith("partition") or k == "scan_u32"), "exchange_ms": phase(lambda k: k.startswith("exchange")),
+                  "join_ms": phase(lambda k: k.startswith("join") or k in ("scan_mask_popcounts", "column_minmax", "gather", "concat"))}
+            out["phases_ms_rank0"] = ph
+            out["phases_sum_ms"] = round(sum(ph.values()), 3)
+            out["longest_phase_ms"] = max(ph.values())
+            out["step_over_longest_phase"] = round(out["ms_per_step"] / max(ph.values()), 3) if max(ph.values()) > 0 else None
         if comm is not None:
             out.update(comm.transport_info())
         if per_step and world > 1:
@@ -381,6 +410,8 @@ def run_join(args, rank, world, dist):
         return out
 
     parallelism = {"none": "single GPU",
+                   "repartition_stream": f"Partitioned x{world}: hash repartition of both sides STREAMED in {args.exchange_chunks} chunks (dfgpu_exchange_hash_stream: partition "
+                                         "kernel, RCCL all-to-all(v) and the join's build / probe of neighbouring chunks overlap)",
                    "pruned": f"CollectLeft x{world}: build-side all-gather pruned by each rank's probe-key bounds (dfgpu_exchange_broadcast_pruned, RCCL send/recv), probe side stays in place",
                    "broadcast": f"CollectLeft x{world}: RCCL all-gather of the build side (dfgpu_exchange_broadcast), probe side stays in place",
                    "repartition": f"Partitioned x{world}: hash repartition of both sides (dfgpu_exchange_hash: partition kernel + RCCL all-to-all(v))"}[primary]
@@ -674,7 +705,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", choices=["join", "q1", "q3"], default="join",
                     help="join = the BASELINE metric (config 3 ii); q1 / q3 = the whole TPC-H Q1 / Q3 plan per step (configs 4 and 5)")
-    ap.add_argument("--exchange", choices=["auto", "pruned", "broadcast", "repartition"], default="auto",
+    ap.add_argument("--exchange-chunks", type=int, default=4,
+                    help="N > 1: row ranges the streamed hash repartition cuts every input into (1 = the blocking exchange: partition, all-to-all(v), join one after the other)")
+    ap.add_argument("--exchange", choices=["auto", "pruned", "broadcast", "repartition", "repartition_stream"], default="auto",
                     help="N > 1, join workload: auto = time both repartition (Partitioned: hash exchange of both sides) and pruned (CollectLeft, "
                          "build side pruned by probe-key bounds), `value` = the one a byte-counting planner picks; anything else forces that "
                          "exchange (at N = 1: a one-rank rehearsal of its code path)")

@@ -113,7 +113,7 @@ SYMBOLS = [
     "dfgpu_tpch_lineitem", "dfgpu_tpch_customer", "dfgpu_profile_enable", "dfgpu_profile_reset",
     "dfgpu_profile_count", "dfgpu_profile_get", "dfgpu_parquet_decode_chunk", "dfgpu_parquet_inspect_chunk", "dfgpu_parquet_read_chunks",
     "dfgpu_comm_unique_id", "dfgpu_comm_init_rank", "dfgpu_comm_init_all", "dfgpu_comm_init_host", "dfgpu_comm_free", "dfgpu_comm_info", "dfgpu_comm_transport_info",
-    "dfgpu_exchange_hash", "dfgpu_exchange_broadcast", "dfgpu_exchange_broadcast_pruned", "dfgpu_comm_stats",
+    "dfgpu_exchange_hash", "dfgpu_exchange_hash_stream_open", "dfgpu_exchange_hash_stream_next", "dfgpu_exchange_hash_stream_free", "dfgpu_exchange_broadcast", "dfgpu_exchange_broadcast_pruned", "dfgpu_comm_stats",
     "dfgpu_mem_set_limit", "dfgpu_mem_limit", "dfgpu_mem_try_reserve", "dfgpu_mem_reservation_size", "dfgpu_mem_release",
     "dfgpu_table_export_batch", "dfgpu_host_register", "dfgpu_host_unregister", "dfgpu_table_export_into",
     "dfgpu_column_inlist", "dfgpu_metrics_reset", "dfgpu_metrics_get", "dfgpu_table_dictionary_like", "dfgpu_table_dictionary_encode", "dfgpu_table_dictionary_decode", "dfgpu_table_dictionary_size", "dfgpu_join_builder_create", "dfgpu_join_builder_push", "dfgpu_join_builder_finish", "dfgpu_join_builder_free", "dfgpu_join_estimate_bytes",

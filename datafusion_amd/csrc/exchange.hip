@@ -22,7 +22,10 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <thread>
 
 #include "device.hpp"
 #include "internal.hpp"
@@ -683,6 +686,114 @@ __global__ __launch_bounds__(BLOCK) void k_sample_keys(KeyCol k, int64_t n, int6
   out[atomicAdd(n_out, 1)] = (long long)lo;
 }
 
+// ------------------------------------------------------------------------------------------------ the streaming exchange
+// rows [begin, end) of a table as a zero-copy view (begin a multiple of 64, so validity words and bit-packed values start on a word);
+// Utf8 columns cannot be viewed this way (their offsets start at 0 by contract): the caller keeps such tables whole
+static bool sliceable(const Table& t) {
+  for (const Column& c : t.cols)
+    if (c.field.type == DFGPU_UTF8) return false;
+  return true;
+}
+static Table slice_rows(const Table& t, int64_t begin, int64_t end) {
+  Table out;
+  out.device = t.device;
+  out.nrows = end - begin;
+  for (const Column& c : t.cols) {
+    Column v = c;
+    v.length = end - begin;
+    v.stats.reset();   // (the view's rows are not the source's)
+    v.data_offset = c.data_offset + (c.field.type == DFGPU_BOOL ? (size_t)(begin / 8) : (size_t)begin * type_width(c.field.type));
+    if (c.validity) {
+      v.validity = std::make_shared<DevBuf>((char*)c.validity->ptr + begin / 8, bitmap_bytes(end - begin), std::static_pointer_cast<void>(c.validity));
+      v.null_count = -1;
+    }
+    out.cols.push_back(std::move(v));
+  }
+  return out;
+}
+
+// RepartitionExec streams: every input partition hashes a batch, hands the pieces to the output partitions' channels and goes on with
+// the next batch while the consumers work (repartition/mod.rs:154-360, 1097-1150).  Here the three stages of a chunk — partition
+// kernel, all-to-all(v), the consumer — run on three host threads with a stream each: while chunk k is being consumed (a join
+// builder's push, a probe), chunk k + 1 crosses the links and chunk k + 2 is being partitioned.  Every rank cuts its input into the
+// SAME number of row ranges (the all-to-all(v)s of the ranks must pair up); a rank with fewer rows sends empty pieces.
+struct HashStream {
+  Comm* c = nullptr;
+  std::vector<Table> inputs;   // shallow copies, dictionaries unified
+  std::vector<int> keys;
+  int n_chunks = 1;
+  std::vector<int> devices;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::vector<std::vector<Table>>> parted;   // partitioner -> exchanger
+  std::deque<std::vector<Table>> received;               // exchanger -> consumer
+  bool parted_done = false, received_done = false, cancel = false;
+  std::string error;
+  std::thread partitioner, exchanger;
+  int handed = 0;
+  static constexpr size_t DEPTH = 1;   // chunks waiting between two stages (each stage also holds the one it works on)
+};
+static void hash_stream_partition(HashStream* s) {
+  try {
+    for (int k = 0; k < s->n_chunks; k++) {
+      {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->cancel || s->parted.size() < HashStream::DEPTH; });
+        if (s->cancel) break;
+      }
+      std::vector<std::vector<Table>> parts(s->inputs.size());
+      for (size_t l = 0; l < s->inputs.size(); l++) {
+        use_device(s->devices[l]);
+        const Table& t = s->inputs[l];
+        const int64_t n = t.nrows;
+        auto cut = [&](int q) { return q >= s->n_chunks ? n : (n * q / s->n_chunks) / 64 * 64; };
+        parts[l] = partition_table(s->n_chunks == 1 ? t : slice_rows(t, cut(k), cut(k + 1)), s->keys, s->c->world);
+      }
+      call_epilogue();   // this thread's streams drained: the pieces are complete before another thread sees them
+      std::lock_guard<std::mutex> lk(s->mu);
+      s->parted.push_back(std::move(parts));
+      s->cv.notify_all();
+    }
+  } catch (const std::exception& e) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->error.empty()) s->error = e.what();
+  }
+  call_epilogue();
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->parted_done = true;
+  s->cv.notify_all();
+}
+static void hash_stream_exchange(HashStream* s) {
+  try {
+    for (;;) {
+      std::vector<std::vector<Table>> parts;
+      {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->cancel || !s->parted.empty() || s->parted_done; });
+        if (s->cancel || (s->parted.empty() && s->parted_done)) break;
+        parts = std::move(s->parted.front());
+        s->parted.pop_front();
+        s->cv.notify_all();
+      }
+      std::vector<Table> res = exchange_parts(*s->c, parts, s->inputs);
+      parts.clear();
+      call_epilogue();
+      std::unique_lock<std::mutex> lk(s->mu);
+      s->cv.wait(lk, [&] { return s->cancel || s->received.size() < HashStream::DEPTH; });
+      if (s->cancel) break;
+      s->received.push_back(std::move(res));
+      s->cv.notify_all();
+    }
+  } catch (const std::exception& e) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->error.empty()) s->error = e.what();
+  }
+  call_epilogue();
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->received_done = true;
+  s->cv.notify_all();
+}
+
 static void hand_out(std::vector<Table>& res, dfgpu_table_t* outs) {
   for (size_t l = 0; l < res.size(); l++) outs[l] = wrap(new Table(std::move(res[l])));
 }
@@ -812,6 +923,66 @@ int dfgpu_exchange_hash(dfgpu_comm_t h, const dfgpu_table_t* inputs, const int* 
     }
     std::vector<Table> res = exchange_parts(c, parts, t);
     hand_out(res, outs);
+  });
+}
+
+int dfgpu_exchange_hash_stream_open(dfgpu_comm_t h, const dfgpu_table_t* inputs, const int* key_cols, int nkeys, int n_chunks, dfgpu_exchange_stream_t* out) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(h && inputs && out && key_cols && nkeys >= 1 && n_chunks >= 1, "dfgpu_exchange_hash_stream_open: bad arguments");
+    Comm& c = *reinterpret_cast<Comm*>(h);
+    DFGPU_CHECK(c.world <= 64, "dfgpu_exchange_hash supports up to 64 ranks");
+    auto s = std::make_unique<HashStream>();
+    s->c = &c;
+    s->inputs = local_inputs(c, inputs);
+    unify_dictionaries(c, s->inputs);
+    s->keys.assign(key_cols, key_cols + nkeys);
+    s->devices = c.devices;
+    // Utf8 columns travel whole (no zero-copy row ranges of them): ONE chunk.  Every rank sees the same schema, so every rank decides the same.
+    bool can_cut = true;
+    for (const Table& t : s->inputs) can_cut = can_cut && sliceable(t);
+    s->n_chunks = can_cut ? n_chunks : 1;
+    (void)rt().stream;   // (the calling thread keeps the device's first stream: the workers get streams of their own)
+    HashStream* raw = s.get();
+    s->partitioner = std::thread(hash_stream_partition, raw);
+    s->exchanger = std::thread(hash_stream_exchange, raw);
+    *out = reinterpret_cast<dfgpu_exchange_stream_t>(s.release());
+  });
+}
+int dfgpu_exchange_hash_stream_next(dfgpu_exchange_stream_t sh, dfgpu_table_t* outs, int* done) {
+  return guarded([&] {
+    DFGPU_CHECK(sh && outs && done, "dfgpu_exchange_hash_stream_next: bad arguments");
+    HashStream& s = *reinterpret_cast<HashStream*>(sh);
+    std::vector<Table> res;
+    {
+      std::unique_lock<std::mutex> lk(s.mu);
+      s.cv.wait(lk, [&] { return !s.received.empty() || s.received_done; });
+      if (s.received.empty()) {
+        DFGPU_CHECK(s.error.empty(), "exchange stream: " + s.error);
+        *done = 1;
+        return;
+      }
+      res = std::move(s.received.front());
+      s.received.pop_front();
+      s.cv.notify_all();
+    }
+    *done = 0;
+    s.handed++;
+    hand_out(res, outs);
+  });
+}
+int dfgpu_exchange_hash_stream_free(dfgpu_exchange_stream_t sh) {
+  return guarded([&] {
+    if (!sh) return;
+    HashStream* s = reinterpret_cast<HashStream*>(sh);
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      s->cancel = true;
+      s->cv.notify_all();
+    }
+    if (s->partitioner.joinable()) s->partitioner.join();
+    if (s->exchanger.joinable()) s->exchanger.join();
+    delete s;
   });
 }
 

@@ -94,6 +94,26 @@ class Comm:
         idx = [table.index_of(k) for k in keys]
         return self._call(_lib.load().dfgpu_exchange_hash, (C.c_void_p * 1)(table.handle), (C.c_int * len(idx))(*idx), len(idx))
 
+    def hash_exchange_stream(self, table, keys, n_chunks):
+        """the same exchange as a stream of `n_chunks` tables (dfgpu_exchange_hash_stream_*): chunk k holds the rows of every rank's k-th
+        row range that route here and is handed over while chunk k + 1 crosses the links and chunk k + 2 is being partitioned — the
+        consumer (a join builder's push, a probe) overlaps both.  Every rank must pass the same n_chunks and drain the stream."""
+        from . import _lib
+        from .table import DeviceTable
+        lib = _lib.load()
+        idx = [table.index_of(k) for k in keys]
+        h = C.c_void_p()
+        _lib.check(lib.dfgpu_exchange_hash_stream_open(self._h, (C.c_void_p * 1)(table.handle), (C.c_int * len(idx))(*idx), len(idx), int(n_chunks), C.byref(h)))
+        try:
+            while True:
+                out, done = (C.c_void_p * 1)(), C.c_int()
+                _lib.check(lib.dfgpu_exchange_hash_stream_next(h, out, C.byref(done)))
+                if done.value:
+                    break
+                yield DeviceTable(C.c_void_p(out[0]))
+        finally:
+            lib.dfgpu_exchange_hash_stream_free(h)
+
     def broadcast(self, table):
         from . import _lib
         return self._call(_lib.load().dfgpu_exchange_broadcast, (C.c_void_p * 1)(table.handle))

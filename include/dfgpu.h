@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 11
+#define DFGPU_ABI_VERSION 12
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -656,6 +656,18 @@ int dfgpu_comm_transport_info(dfgpu_comm_t comm, int* is_rccl, int* rccl_ranks, 
 /* RepartitionExec(Hash): outs[l] = every row (of all ranks) with hash(keys; seed 0) % world == rank of local l —
  * routing is dfgpu_partition's, so co-partitioned inputs meet on one GPU (hash_join/exec.rs:1312-1324) */
 int dfgpu_exchange_hash(dfgpu_comm_t comm, const dfgpu_table_t* inputs, const int* key_cols, int nkeys, dfgpu_table_t* outs);
+/* The same exchange as a STREAM (ABI 12): RepartitionExec hands batches to its output partitions' channels while their consumers run
+ * (physical-plan/src/repartition/mod.rs:154-360, 1097-1150).  Every rank cuts its input into `n_chunks` row ranges (the same number on
+ * every rank: the chunks' all-to-all(v)s pair up; a rank with fewer rows sends empty pieces); _next hands over chunk k — the rows of
+ * every rank's k-th range that route here — while chunk k + 1 crosses the links and chunk k + 2 is being partitioned, on threads and
+ * streams of the library's own.  The union of the chunks is dfgpu_exchange_hash's result (row order differs: chunk by chunk, rank order
+ * inside a chunk).  *done = 1 (and no table) after the last chunk.  Tables with Utf8 columns arrive as ONE chunk.  While a stream is
+ * open its communicator belongs to it: no other collective of the same communicator may be called, and every rank must take (or
+ * _free) the same chunks.  _free joins the workers; it may be called before the stream is drained once every rank does so. */
+typedef struct dfgpu_exchange_stream_s* dfgpu_exchange_stream_t;
+int dfgpu_exchange_hash_stream_open(dfgpu_comm_t comm, const dfgpu_table_t* inputs, const int* key_cols, int nkeys, int n_chunks, dfgpu_exchange_stream_t* out);
+int dfgpu_exchange_hash_stream_next(dfgpu_exchange_stream_t stream, dfgpu_table_t* outs, int* done);
+int dfgpu_exchange_hash_stream_free(dfgpu_exchange_stream_t stream);
 /* all-gather: outs[l] = the rows of all ranks in rank order (CollectLeft's build side; CoalescePartitionsExec to every rank) */
 int dfgpu_exchange_broadcast(dfgpu_comm_t comm, const dfgpu_table_t* inputs, dfgpu_table_t* outs);
 /* the all-gather of a build side pruned by bounds: rank r receives only build rows whose key lies inside [min, max] of

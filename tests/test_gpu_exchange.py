@@ -62,6 +62,22 @@ def test_one_rank_rccl_exchanges_carry_nulls_booleans_and_dictionaries(n):
     c.free()
 
 
+@pytest.mark.parametrize("n,chunks", [(0, 3), (1, 2), (100_003, 1), (100_003, 5), (4096, 64)])
+def test_one_rank_streaming_exchange_hands_over_every_row_chunk_by_chunk(n, chunks):
+    """dfgpu_exchange_hash_stream_* with one rank: the chunks, concatenated, are the blocking exchange's rows in order (one partition: the
+    row ranges in input order); a table with a Utf8 column arrives as ONE chunk, a table without as `chunks` of them (empty ranges included)"""
+    from datafusion_amd.exchange import Comm
+    from datafusion_amd.table import DeviceTable
+    t = mixed_table(5, n)
+    c = Comm.single()
+    for cols in (t.column_names, ["k", "d", "q", "b", "s"]):
+        d = DeviceTable.from_arrow(t.select(cols))
+        parts = [x.to_arrow() for x in c.hash_exchange_stream(d, ["k"], chunks)]
+        assert len(parts) == (1 if "u" in cols else chunks)
+        assert_tables_equal(decoded(pa.concat_tables(parts)), decoded(t.select(cols)), ordered=True)
+    c.free()
+
+
 def test_one_rank_pruned_broadcast_keeps_rows_inside_the_probe_bounds():
     import pyarrow.compute as pc
 
@@ -108,6 +124,18 @@ if mode == "exchange":
     out["probe"] = probe
     out["pruned"] = decoded(c.broadcast_pruned(d, "k", DeviceTable.from_arrow(probe), "k2").to_arrow())
     out["stats"] = c.stats()
+    # the streaming exchange: a join builder consumes the chunks of one side as they land, the probe takes the other side's chunk by chunk
+    nk = d.select(["k", "d", "q", "b", "s"])
+    out["stream_k"] = [decoded(x.to_arrow()) for x in c.hash_exchange_stream(nk, ["k"], 4)]
+    out["stream_s"] = [decoded(x.to_arrow()) for x in c.hash_exchange_stream(nk, ["s", "q"], 3)]
+    from datafusion_amd import ops as _o
+    bt = DeviceTable.from_arrow(pa.table({"bk": pa.array(np.arange(0, 10**6, 7, dtype=np.int64)[rank::world]), "bv": pa.array(np.arange(0, 10**6, 7, dtype=np.int64)[rank::world] * 3)}))
+    builder = _o.JoinBuilder([0])
+    for chunk in c.hash_exchange_stream(bt, ["bk"], 3):
+        builder.push(chunk)
+    ht = builder.finish()
+    joined = [ht.probe(chunk, ["k"], "Inner", ["bv"], ["k", "q"]).to_arrow() for chunk in c.hash_exchange_stream(d.select(["k", "q"]), ["k"], 4)]
+    out["stream_join"] = pa.concat_tables(joined)
     # the exchange of a distributed ORDER BY (dfgpu_exchange_range) + the local sort: rank order = sort order
     from datafusion_amd import ops as _ops
     out["range_asc"] = decoded(_ops.sort(c.range_exchange(d, "k", False, False), [("k", False, False), ("d", True, False)]).to_arrow())
@@ -170,6 +198,11 @@ def _free_port():
     return p
 
 
+def cut(n, q, chunks):
+    """row range boundaries of the streaming exchange (exchange.hip hash_stream_partition): multiples of 64, the last one the row count"""
+    return n if q >= chunks else (n * q // chunks) // 64 * 64
+
+
 def test_two_ranks_exchange_device_tables_with_different_dictionaries_and_nulls(tmp_path):
     import pyarrow.compute as pc
 
@@ -185,6 +218,20 @@ def test_two_ranks_exchange_device_tables_with_different_dictionaries_and_nulls(
         got = res[r]["hash_k"]
         assert got.column("k").to_pylist() == exp.column("k").to_pylist()
     assert_tables_equal(pa.concat_tables([r["hash_k"] for r in res]), whole, ordered=False)
+    # the streaming exchange: chunk k of rank r = the rows of every sender's k-th row range that route to r, sender by sender — the chunks of a
+    # rank together are exactly the blocking exchange's rows (another order), and a join fed chunk by chunk finds every match once
+    for r in range(world):
+        assert len(res[r]["stream_k"]) == 4 and len(res[r]["stream_s"]) == 3
+        five = ["k", "d", "q", "b", "s"]
+        for k_, chunk in enumerate(res[r]["stream_k"]):
+            exp = pa.concat_tables([oracle.hash_partition(inp.select(["k"]).slice(cut(inp.num_rows, k_, 4), cut(inp.num_rows, k_ + 1, 4) - cut(inp.num_rows, k_, 4)), ["k"], world)[0][r]
+                                    for inp in inputs])
+            assert chunk.column("k").to_pylist() == exp.column("k").to_pylist()
+        assert_tables_equal(pa.concat_tables(res[r]["stream_k"]), res[r]["hash_k"].select(five), ordered=False)
+    assert_tables_equal(pa.concat_tables([x for r in res for x in r["stream_s"]]), whole.select(["k", "d", "q", "b", "s"]), ordered=False)
+    got = sorted(zip(*[pa.concat_tables([r["stream_join"] for r in res]).column(c_).to_pylist() for c_ in ("bv", "k", "q")]), key=lambda x: (x[1], x[0], -1 if x[2] is None else x[2]))
+    want = sorted(((k_ * 3, k_, q_) for k_, q_ in zip(whole.column("k").to_pylist(), whole.column("q").to_pylist()) if k_ % 7 == 0), key=lambda x: (x[1], x[0], -1 if x[2] is None else x[2]))
+    assert len(want) > 1000 and got == want
     # routing on the string column: the ranks' dictionaries differ, yet every string (and NULL) meets on ONE rank and nothing is lost
     assert_tables_equal(pa.concat_tables([r["hash_s"] for r in res]), whole, ordered=False)
     homes = {}
