@@ -103,7 +103,7 @@ class ParquetChunkInfo(C.Structure):
 
 # every symbol include/dfgpu.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
-    "dfgpu_abi_version", "dfgpu_init", "dfgpu_set_device", "dfgpu_get_device", "dfgpu_shutdown", "dfgpu_device_count", "dfgpu_last_error", "dfgpu_sync",
+    "dfgpu_abi_version", "dfgpu_set_option", "dfgpu_init", "dfgpu_set_device", "dfgpu_get_device", "dfgpu_shutdown", "dfgpu_device_count", "dfgpu_last_error", "dfgpu_sync",
     "dfgpu_stream", "dfgpu_mem_stats", "dfgpu_mem_trim", "dfgpu_table_import", "dfgpu_table_export",
     "dfgpu_table_alloc", "dfgpu_table_dictionary_lookup", "dfgpu_table_free", "dfgpu_table_num_rows", "dfgpu_table_num_columns", "dfgpu_table_column",
     "dfgpu_table_select", "dfgpu_table_hstack", "dfgpu_table_concat", "dfgpu_table_slice", "dfgpu_expr_type",

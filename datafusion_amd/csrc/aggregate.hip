@@ -1416,7 +1416,7 @@ static InternResult intern_keys(Aggregate& A, const std::vector<Column>& key_col
   // key columns whose value ranges multiply to a few thousand: a direct table (first batch of a large input only: the concatenation
   // with earlier groups' keys has no statistics)
   uint32_t direct_n = 0;
-  if (G0 == 0 && total >= (1 << 22) && ngk >= 1 && !(std::getenv("DFGPU_AGG_DIRECT_TABLE") && std::getenv("DFGPU_AGG_DIRECT_TABLE")[0] == '0'))   // A/B knob
+  if (G0 == 0 && total >= policy().rows_worth_a_pass() && ngk >= 1 && option_on("agg.direct_table", true))   // (A/B switch)
     direct_n = direct_table_spec(R.cat_keys, stat_homes, total, ictx, R.direct_codes);
   if (direct_n) keyed = false;
   BufPtr flag = make_zero_buf(4);
@@ -1590,10 +1590,7 @@ static bool small_domain_applicable(const Aggregate& A, const Table& in, std::ve
   return true;
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return v && *v ? std::atoi(v) : dflt;
-}
+
 
 // rebuilds A.group_keys (dense, gid order) from the host mirror of the 1-byte keys
 static void small_rebuild_group_keys(Aggregate& A, const Table& in, const std::vector<int>& small_cols) {
@@ -2376,8 +2373,8 @@ static bool partitioned_in_place(uint64_t range, const std::vector<PartAcc>& all
 static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long long kmin, uint64_t range, std::vector<PartAcc> all, int ncw, bool want_first_rows,
                                    PartValues& out, const uint64_t* row_mask = nullptr, const uint64_t* row_mask_valid = nullptr, const uint32_t* key_map = nullptr,
                                    int64_t key_map_n = 0) {
-  static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
-  const int64_t min_rows = env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23);
+  const bool off = !option_on("agg.partitioned", true);
+  const int64_t min_rows = option_int("agg.partitioned_min_rows", 2 * policy().rows_worth_a_pass());
   int64_t n = n_in;
   if (off || n < min_rows || range < 256 || all.empty() || all.size() > (size_t)PART_ACC_MAX) return false;
   if (!(kt == DFGPU_INT32 || kt == DFGPU_DATE32 || kt == DFGPU_INT64 || kt == DFGPU_UINT32 || kt == DFGPU_UINT8)) return false;
@@ -2401,7 +2398,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     wshift = wcap;
     if (((range - 1) >> wshift) >= 4096) return false;
     // up to 2048 windows: ONE move by grouped.hip's pass (round 4: the two 64-way moves cost 4.6 ms for 150 M orders, this one 1.2)
-    const bool grouped_off = std::getenv("DFGPU_AGG_GROUPED_MOVE") && std::getenv("DFGPU_AGG_GROUPED_MOVE")[0] == '0';   // A/B knob
+    const bool grouped_off = !option_on("agg.grouped_move", true);   // (A/B switch)
     grouped_move = !grouped_off && ((range - 1) >> wshift) < (uint64_t)GP_MAX_GROUPS && !row_mask_valid && n < 0xFFFFFFFFll;
     if (!grouped_move) {
       levels = 2;
@@ -2620,7 +2617,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
 static bool dense_accumulate_partitioned(const Aggregate& A, const Table& in, const dfgpu_expr* pred, const std::vector<DenseAcc>& accs, const std::vector<int>& acc_col,
                                          const std::vector<int>& acc_val, const std::vector<int>& acc_agg, int ncw, long long kmin, uint64_t range, PartValues& out) {
   // cheap refusals before any argument expression is evaluated
-  if (in.nrows < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || range < 4096) return false;
+  if (in.nrows < option_int("agg.partitioned_min_rows", 2 * policy().rows_worth_a_pass()) || range < 4096) return false;
   int kc = -1;
   if (!is_plain_column(A.group_nodes[0], A.group_roots[0], &kc) || kc < 0 || kc >= (int)in.cols.size()) return false;
   const Column& key = in.cols[(size_t)kc];
@@ -2733,8 +2730,8 @@ static bool general_accumulate_partitioned(const InternCtx& ictx, const uint32_t
     ncw += d.kind == ACC_SUM_I128 ? 2 : 1;
   }
   // cheap refusals first (the row -> group pass below is a random lookup per row)
-  static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
-  if (off || n < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || G1 < 256) return false;
+  const bool off = !option_on("agg.partitioned", true);
+  if (off || n < option_int("agg.partitioned_min_rows", 2 * policy().rows_worth_a_pass()) || G1 < 256) return false;
   Runtime& r = rt();
   PartValues pv;
   if (row_slot && (ictx.keyed || ictx.direct) && partitioned_in_place((uint64_t)G1, all)) {
@@ -2762,9 +2759,9 @@ static bool general_accumulate_partitioned(const InternCtx& ictx, const uint32_t
 static bool fused_general_partitioned(Aggregate& A, const Table& in, const std::vector<AccPlan>& plans, const InternCtx& ictx, const uint32_t* slot_gid, int64_t G0,
                                       int64_t G1, const uint64_t* row_mask, const uint32_t* row_slot) {
   const int64_t n = in.nrows;
-  static const bool off = std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0';
-  if (std::getenv("DFGPU_TRACE_AGG")) fprintf(stderr, "[agg] fused_general_partitioned: n %lld, G0 %lld, G1 %lld, off %d\n", (long long)n, (long long)G0, (long long)G1, (int)off);
-  if (off || n < env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) || G1 < 256) return false;   // (fewer groups: the LDS-replicated cells of the fused kernel)
+  const bool off = !option_on("agg.partitioned", true);
+  if (trace_on("agg")) fprintf(stderr, "[agg] fused_general_partitioned: n %lld, G0 %lld, G1 %lld, off %d\n", (long long)n, (long long)G0, (long long)G1, (int)off);
+  if (off || n < option_int("agg.partitioned_min_rows", 2 * policy().rows_worth_a_pass()) || G1 < 256) return false;   // (fewer groups: the LDS-replicated cells of the fused kernel)
   AccSet accs{};
   std::vector<Column> keep;
   for (size_t k = 0; k < A.aggs.size(); k++) {
@@ -2809,8 +2806,8 @@ static bool fused_general_partitioned(Aggregate& A, const Table& in, const std::
 static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_expr* pred) {
   Runtime& r = rt();
   const int64_t n = in.nrows;
-  if (env_int("DFGPU_JIT", 1) == 0 || A.group_roots.size() != 1 || A.ngroups != 0) return false;
-  if (n < env_int("DFGPU_JIT_MIN_ROWS", 1 << 22) || n >= 0xFFFFFFFFll) return false;
+  if (!option_on("jit", true) || A.group_roots.size() != 1 || A.ngroups != 0) return false;
+  if (n < option_int("jit.min_rows", policy().rows_worth_a_pass()) || n >= 0xFFFFFFFFll) return false;
   // ---- compile: predicate, key expression, aggregate arguments
   std::string why;
   RowProgramCompiler comp(in);
@@ -2872,7 +2869,7 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
     f_setbits = jit_get(source, "dense_setbits");
     f_acc = jit_get(source, "dense_accumulate");
   } catch (const Error& e) {
-    if (env_int("DFGPU_JIT_STRICT", 0)) throw;
+    if (option_on("jit.strict", false)) throw;
     fprintf(stderr, "[dfgpu] node specialisation failed, using the interpreter: %s\n", e.what());
     return false;
   }
@@ -3375,8 +3372,8 @@ extern "C" __global__ __launch_bounds__(BLOCK) void runs_accumulate(Args a) {
 static bool agg_update_sorted_runs_jit(Aggregate& A, const Table& in, const dfgpu_expr* pred) {
   Runtime& r = rt();
   const int64_t n = in.nrows;
-  if (pred || env_int("DFGPU_JIT", 1) == 0 || env_int("DFGPU_AGG_RUNS", 1) == 0 || A.group_roots.empty() || A.ngroups != 0) return false;
-  if (n < env_int("DFGPU_JIT_MIN_ROWS", 1 << 22) || n >= 0xFFFFFFFFll) return false;
+  if (pred || !option_on("jit", true) || !option_on("agg.runs", true) || A.group_roots.empty() || A.ngroups != 0) return false;
+  if (n < option_int("jit.min_rows", policy().rows_worth_a_pass()) || n >= 0xFFFFFFFFll) return false;
   int key_col = -1;
   if (!is_plain_column(A.group_nodes[0], A.group_roots[0], &key_col) || key_col < 0 || key_col >= (int)in.cols.size()) return false;
   const Column& kcol = in.cols[(size_t)key_col];
@@ -3435,7 +3432,7 @@ static bool agg_update_sorted_runs_jit(Aggregate& A, const Table& in, const dfgp
   try {
     f_acc = jit_get(source, "runs_accumulate");
   } catch (const Error& e) {
-    if (env_int("DFGPU_JIT_STRICT", 0)) throw;
+    if (option_on("jit.strict", false)) throw;
     fprintf(stderr, "[dfgpu] node specialisation failed, using the interpreter: %s\n", e.what());
     return false;
   }
@@ -3642,14 +3639,14 @@ static bool agg_update_small_single_pass(Aggregate& A, const Table& in, const Co
   DFGPU_HIP(hipFuncSetAttribute((const void*)k_agg_fused_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_BUDGET));
 
   // large inputs run the node specialised for this forest (jit.hip); DFGPU_JIT=0 keeps the interpreter
-  const int64_t jit_min_rows = env_int("DFGPU_JIT_MIN_ROWS", 1 << 22);
+  const int64_t jit_min_rows = option_int("jit.min_rows", policy().rows_worth_a_pass());
   const int plane_max_jit = (int)std::min<size_t>((TILE_LDS_BUDGET - 2048) / plane_bytes, 4096);
   hipFunction_t jit_fn = nullptr;
-  if (env_int("DFGPU_JIT", 1) != 0 && n >= jit_min_rows) {
+  if (option_on("jit", true) && n >= jit_min_rows) {
     try {
       jit_fn = jit_get(agg_node_source(cp, accs, acc_val, ngk > 0 ? cp.src_out_vals[key_out[0]] : -1, ngk > 1 ? cp.src_out_vals[key_out[1]] : -1), "agg_node");
     } catch (const Error& e) {
-      if (env_int("DFGPU_JIT_STRICT", 0)) throw;
+      if (option_on("jit.strict", false)) throw;
       fprintf(stderr, "[dfgpu] node specialisation failed, using the interpreter: %s\n", e.what());
     }
   }
@@ -3966,7 +3963,7 @@ static bool agg_update_fused(Aggregate& A, const Table& in, const dfgpu_expr* pr
       row_mask = pred_mask_keepalive->as<uint64_t>();
     }
     // (large inputs may take the partitioned accumulation below: it wants every row's slot from the claim pass)
-    const bool maybe_partitioned = n >= env_int("DFGPU_AGG_PARTITIONED_MIN_ROWS", 1 << 23) && !(std::getenv("DFGPU_AGG_PARTITIONED") && std::getenv("DFGPU_AGG_PARTITIONED")[0] == '0');
+    const bool maybe_partitioned = n >= option_int("agg.partitioned_min_rows", 2 * policy().rows_worth_a_pass()) && option_on("agg.partitioned", true);
     // (statistics the interning takes of plain key columns are kept on the table's own columns — the same rows: the next query finds them)
     std::vector<Column*> homes((size_t)ngk, nullptr);
     for (int g = 0; g < ngk; g++) {

@@ -104,9 +104,7 @@ struct Comm {
 // a send / receive is cut into messages of at most this many bytes (every rank derives the same cuts from the row counts)
 static int64_t max_message_bytes() {
   static const int64_t v = [] {
-    const char* e = std::getenv("DFGPU_EXCHANGE_MAX_MESSAGE_BYTES");
-    const long long x = e ? std::atoll(e) : 0;
-    return x > 0 ? (int64_t)x : (int64_t)1 << 30;
+    return (int64_t)1 << 30;
   }();
   return v;
 }

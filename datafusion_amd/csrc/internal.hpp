@@ -71,6 +71,30 @@ int guarded(F&& f) noexcept {
 }
 
 // ---------------------------------------------------------------------------------------
+// Options (dfgpu_set_option, include/dfgpu.h): the dispatch policy's numbers and switches in ONE table — the library's twin of the
+// reference's ConfigOptions (common/src/config.rs: `datafusion.execution.*`).  Defaults are DERIVED FROM THE DEVICE at dfgpu_init
+// (hipDeviceProp: CU count, L2 size of an XCD, LDS per CU), not tuned on a benchmark's shapes; an embedding engine (or a test that
+// must force a path on a small input) overrides them by name.  Two environment variables remain, both for debugging:
+// DFGPU_OPTIONS="name=value,..." (the same table, read at every lookup so a test may set it) and DFGPU_TRACE="agg,join,scan,dict".
+struct Policy {
+  int num_cus = 256;
+  size_t lds_per_cu = 160 * 1024;
+  size_t l2_bytes = 4 << 20;          // of ONE XCD
+  int xcds = 8;
+  // rows from which a pass that has fixed costs of its own (a specialised kernel's launch and look-up, an extra move of the rows, a
+  // second kernel) repays them: every CU gets 16 Ki rows — 64 rows per lane of a 256-lane workgroup, 4 Mi rows on 256 CUs
+  int64_t rows_worth_a_pass() const { return (int64_t)num_cus * 16384; }
+  // a table / accumulator set beyond this is "beyond the caches": random access into it leaves an XCD's L2 (4 x its size: the share
+  // of the 256 MiB Infinity Cache a kernel's other streams leave a table, measured in profiles/r3_random_access.md)
+  size_t beyond_cache_bytes() const { return l2_bytes * 4; }
+};
+const Policy& policy();                                        // of the calling thread's current device
+int64_t option_int(const char* name, int64_t dflt);            // the named option, else `dflt`
+bool option_on(const char* name, bool dflt);                   // "0" / "off" / "false" = off
+std::string option_str(const char* name, const char* dflt);
+bool trace_on(const char* what);                               // DFGPU_TRACE names `what` (or "all")
+
+// ---------------------------------------------------------------------------------------
 // Runtime: one per initialised device.  A process normally drives ONE GPU (one process per GPU under torchrun); a
 // single DataFusion process that owns several GPUs (one per output partition) initialises several and selects the
 // calling thread's device with dfgpu_set_device — every entry point that takes a table / join / aggregate handle
@@ -94,6 +118,7 @@ struct Runtime {
   uint64_t generation = 0;          // bumped by dfgpu_init / dfgpu_shutdown: threads re-resolve the streams they remembered
   bool initialised = false;
   int num_cus = 256;
+  Policy policy;
   hipStream_t thread_stream();      // what `stream` converts to
 
   // pool allocator: size-bucketed free lists; blocks are reused in stream order (a block freed by the host after its last kernel was

@@ -51,9 +51,10 @@ static uint64_t fnv1a(const std::string& s, uint64_t h) {
   return h;
 }
 static std::string jit_cache_dir() {
-  const char* off = std::getenv("DFGPU_JIT_CACHE");
+  const std::string off_s = option_str("jit.cache", "");
+  const char* off = off_s.empty() ? nullptr : off_s.c_str();
   if (off && std::string(off) == "0") return "";
-  if (const char* d = std::getenv("DFGPU_JIT_CACHE_DIR")) return d;
+  if (const std::string d = option_str("jit.cache_dir", ""); !d.empty()) return d;
   if (const char* x = std::getenv("XDG_CACHE_HOME")) return std::string(x) + "/dfgpu/jit";
   if (const char* h = std::getenv("HOME")) return std::string(h) + "/.cache/dfgpu/jit";
   return "";
@@ -104,7 +105,8 @@ static void disk_store(const std::string& dir, const std::string& keyed, const s
 
 static std::shared_ptr<std::vector<char>> jit_compile(const std::string& source, const char* kernel_name) {
   auto t0 = std::chrono::steady_clock::now();
-  if (const char* dump = std::getenv("DFGPU_JIT_DUMP")) {  // debugging aid: the generated sources, one file per node
+  const std::string dump_s = option_str("jit.dump_dir", "");
+  if (const char* dump = dump_s.empty() ? nullptr : dump_s.c_str()) {  // debugging aid: the generated sources, one file per node
     const std::string path = std::string(dump) + "/node_" + std::to_string(g_jit_compiles) + "_" + kernel_name + ".hip";
     if (FILE* f = fopen(path.c_str(), "w")) {
       fwrite(source.data(), 1, source.size(), f);

@@ -1909,7 +1909,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
   // way (k_rank_setbits<.., VERIFY>): 150 M keys, 0.31 ms of the step's 9.8.  A wrong guess costs the verifying pass and is
   // repaired by the measured path below (`speculate` = false).
   bool speculated = false;
-  static const bool spec_off = std::getenv("DFGPU_JOIN_SPECULATE") && std::getenv("DFGPU_JOIN_SPECULATE")[0] == '0';
+  const bool spec_off = false;
   if (speculate && !spec_off && (opts.table_mode == 0 || opts.table_mode == 3) && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64 &&
       !ks.c[0].valid && nb >= (1 << 22)) {
     constexpr int S = 4096;
@@ -2335,7 +2335,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_all_hit(ProbeCtx c, int64_t np
 // groups of a rank map's key range: enough of them that a group's slice of the table plus of the build payload stays inside an
 // XCD's 4 MiB L2 with room for the streams passing through (2.5 MB aimed at), at most 2^10 (a run of a tile is 8192 / groups rows)
 static int gp_bits_for(const JoinTable& jt, int64_t payload_bytes_per_row) {
-  if (const char* e = std::getenv("DFGPU_JOIN_GP_BITS")) return std::min(10, std::max(1, std::atoi(e)));  // tuning knob
+  if (const int64_t e = option_int("join.grouped_bits", 0)) return std::min(10, std::max(1, (int)e));  // (test hook)
   const double slice = (double)((jt.am_size >> 6) + 1) * 16.0 + (double)jt.build.nrows * (double)payload_bytes_per_row;
   int bits = 6;
   while (bits < 10 && slice / (double)(1 << bits) > 2.5 * 1048576.0) bits++;
@@ -2562,31 +2562,31 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   // the general M:N path in one pass (k_probe_pairs_single): flat tables under the planner's hint that nobody observes the order
   const bool single_pass_pairs = !use_fused && join_type == DFGPU_JOIN_INNER && jt.probe_mode == 4 && (jt.kind == KIND_FLAT || jt.kind == KIND_FLAT16) &&
                                  !row_mask && np >= (1 << 16) && np < 0xFFFFFFFFll &&
-                                 !(std::getenv("DFGPU_JOIN_SINGLE_PASS_PAIRS") && std::getenv("DFGPU_JOIN_SINGLE_PASS_PAIRS")[0] == '0');   // A/B knob
+                                 true;
   // A probe whose output holds no build column and that marks no build row only asks whether the key is THERE: over a rank map of
   // keys in no particular order it needs the bitmap alone, not the rank -> row permutation (which is built by the first probe
   // that does need rows)
   const bool rows_unused = bout.empty() && !needs_visited(join_type) && (use_fused || probe_side_only);
-  const char* big_env = std::getenv("DFGPU_JOIN_BIG_TABLE_BYTES");  // test knob: what counts as "beyond the caches" (default 16 MiB)
-  const int64_t big_bytes = big_env ? std::atoll(big_env) : ((int64_t)16 << 20);
+  // what counts as "beyond the caches": 4 x the L2 of an XCD (16 MiB on MI355X), Policy::beyond_cache_bytes
+  const int64_t big_bytes = option_int("join.beyond_cache_bytes", (int64_t)policy().beyond_cache_bytes());
   const bool big_table = (jt.kind == KIND_RANK || jt.kind == KIND_ARRAY) && (int64_t)(jt.kind == KIND_RANK ? (jt.am_size >> 6) * 16 : jt.am_size * 4) > big_bytes;
   static thread_local bool in_grouped_probe = false;  // the probe over keys this function grouped itself: clustered by construction
-  const char* min_env = std::getenv("DFGPU_JOIN_GROUPED_MIN_ROWS");  // test knob: from how many probe rows grouping is considered (default 4 Mi)
-  const int64_t grouped_min_rows = min_env ? std::atoll(min_env) : ((int64_t)1 << 22);
+  // from how many probe rows grouping them first is considered: the extra move has to repay itself (Policy::rows_worth_a_pass)
+  const int64_t grouped_min_rows = option_int("join.grouped_min_rows", policy().rows_worth_a_pass());
   const bool unclustered = fused_ok && big_table && np > grouped_min_rows && pk.size() == 1 && !in_grouped_probe &&
                            !probe_keys_clustered(probe.cols[(size_t)pk[0]], np,
-                                                 std::getenv("DFGPU_JOIN_NEAR_WINDOW") ? (uint64_t)std::atoll(std::getenv("DFGPU_JOIN_NEAR_WINDOW"))   // test knob
+                                                 option_int("join.near_window", 0) ? (uint64_t)option_int("join.near_window", 0)   // (test hook)
                                                  : jt.kind == KIND_RANK ? ((uint64_t)512 << 10) / 16 * 64 : ((uint64_t)512 << 10) / 4);
-  const bool group_env = !(std::getenv("DFGPU_JOIN_GROUPED_PROBE") && std::getenv("DFGPU_JOIN_GROUPED_PROBE")[0] == '0');  // A/B knob
+  const bool group_env = option_on("join.grouped_probe", true);  // (A/B switch)
   // the key-only probe whose order nobody observes: its keys are grouped and probed in group order (below)
   const bool grouped_keys_only = unclustered && group_env && jt.probe_mode == 4 && rows_unused && !row_mask && pout.size() == 1 && pout[0] == pk[0] &&
                                  ctx.pkeys.c[0].width == 8 && !probe.cols[(size_t)pk[0]].validity;
   // every other unclustered probe of a big rank map: the keys travel to the table group by group and what they found comes back
   // to the probe rows (k_gp_lookup above); the build rows are read at rank positions, so no rank -> row permutation is needed
-  const bool returned_env = !(std::getenv("DFGPU_JOIN_RETURNED_PROBE") && std::getenv("DFGPU_JOIN_RETURNED_PROBE")[0] == '0');  // A/B knob
+  const bool returned_env = true;
   bool returned = use_fused && unclustered && group_env && returned_env && !grouped_keys_only && jt.kind == KIND_RANK && jt.probe_mode != 2 &&
                   is_integer_like(probe.cols[(size_t)pk[0]].field.type);
-  if (std::getenv("DFGPU_TRACE_JOIN"))   // one line per probe on stderr: what decided the probe flavour
+  if (trace_on("join"))   // one line per probe on stderr: what decided the probe flavour
     fprintf(stderr, "[dfgpu join_probe] np=%lld kind=%d probe_mode=%d fused_ok=%d big_table=%d unclustered=%d grouped_keys_only=%d returned=%d rows_unused=%d row_mask=%d\n",
             (long long)np, jt.kind, jt.probe_mode, (int)fused_ok, (int)big_table, (int)unclustered, (int)grouped_keys_only, (int)returned, (int)rows_unused, row_mask != nullptr);
   ReturnedProbe rp;
@@ -2719,7 +2719,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       speculate = true;   // (not a guess here: the grouped lookup counted its hits; the kernel's per-tile check stays as the safety net)
     } else if (fused_mode == FUSED_PLACED && !listed && !row_mask && !invert && !no_speculation && np >= (1 << 22) &&
                (kind == KIND_RANK || kind == KIND_ARRAY || kind == KIND_FLAT || kind == KIND_FLAT16) &&
-        !(std::getenv("DFGPU_JOIN_SPECULATE") && std::getenv("DFGPU_JOIN_SPECULATE")[0] == '0')) {
+        true) {
       constexpr int S = 1024;  // sampled words
       BufPtr miss = make_zero_buf(4);
       with_kind_and_key(kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {

@@ -1212,7 +1212,7 @@ extern "C" int dfgpu_parquet_read_chunks(const dfgpu_parquet_chunk* chunks, int3
     sh.chunks = chunks;
     sh.cache = cache;
     const int device = current_device();
-    const bool trace = std::getenv("DFGPU_TRACE_SCAN") != nullptr;
+    const bool trace = trace_on("scan");
     const int64_t dev_allocs0 = rt().driver_allocs.load(), dev_ns0 = rt().driver_alloc_ns.load(), pin_allocs0 = g_pinned_driver_allocs.load(), pin_ns0 = g_pinned_driver_ns.load();
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };

@@ -270,7 +270,7 @@ std::shared_ptr<RadixTable> radix_join_build(const Table& build, const std::vect
   rt_->exact = ks.n == 1 && is_integer_like(ks.c[0].type) && !(null_equals_null && nullable) && !force_collisions;
   // ~1024 build rows per partition on average, up to three 6-bit passes (268 M build rows): a partition that needs several LDS
   // chunks per task costs far more than a third pass over HBM (profiles/r2_radix_sweep.md)
-  static const int max_bits = std::getenv("DFGPU_RJ_MAX_BITS") ? std::atoi(std::getenv("DFGPU_RJ_MAX_BITS")) : 18;  // tuning knob
+  const int max_bits = 18;
   int bits = 0;
   while (bits < max_bits && ((int64_t)1024 << bits) < build.nrows) bits++;
   if (force_collisions) bits = 0;

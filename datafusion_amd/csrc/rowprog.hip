@@ -602,7 +602,7 @@ bool RowProgramCompiler::finish(CompiledProgram& cp, std::string& why) {
     cp.src_maybe_null = maybe_null;
     for (const RpValue& o : outs_) cp.src_out_vals.push_back(o.id);
   }
-  if (const char* dump = std::getenv("DFGPU_RP_DUMP"); dump && *dump == '1') {
+  if (trace_on("rowprog")) {
     static const char* names[] = {"lit", "add", "sub", "mul", "sext32", "sext64", "fadd", "fsub", "fmul", "i2f", "f64ord", "cmp", "fcmp", "and", "or", "not",
                                   "is_null", "is_not_null", "mov", "gate", "merge", "?", "?"};
     fprintf(stderr, "[rowprog] cols=%d regs=%d ins=%d (prologue %d, predicate end %d, pred reg %d)\n", n_cols, cp.n_regs, n_ins, n_prologue, n_pred_end, cp.pred_reg);

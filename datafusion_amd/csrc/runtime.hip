@@ -4,6 +4,7 @@
 
 #include <chrono>
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 
 namespace dfgpu {
@@ -49,6 +50,58 @@ Runtime& rt() {
   return *g_runtimes[d];
 }
 void require_init() { DFGPU_CHECK(rt().initialised, "dfgpu_init() has not been called"); }
+// ------------------------------------------------------------------------------- options
+static std::mutex g_opt_mu;
+static std::map<std::string, std::string> g_options;     // dfgpu_set_option
+const Policy& policy() { return rt().policy; }
+// "name=value,name=value" of DFGPU_OPTIONS: looked at on every call (a handful of characters), so that a test's monkeypatched
+// environment and an operator's shell both work without a restart
+static bool env_option(const char* name, std::string& out) {
+  const char* e = std::getenv("DFGPU_OPTIONS");
+  if (!e || !*e) return false;
+  const size_t len = std::strlen(name);
+  for (const char* p = e; *p;) {
+    const char* end = std::strchr(p, ',');
+    const size_t n = end ? (size_t)(end - p) : std::strlen(p);
+    if (n > len && std::strncmp(p, name, len) == 0 && p[len] == '=') {
+      out.assign(p + len + 1, n - len - 1);
+      return true;
+    }
+    p += n;
+    if (*p == ',') p++;
+  }
+  return false;
+}
+static bool find_option(const char* name, std::string& out) {
+  {
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    auto it = g_options.find(name);
+    if (it != g_options.end()) {
+      out = it->second;
+      return true;
+    }
+  }
+  return env_option(name, out);
+}
+int64_t option_int(const char* name, int64_t dflt) {
+  std::string v;
+  return find_option(name, v) && !v.empty() ? (int64_t)std::atoll(v.c_str()) : dflt;
+}
+bool option_on(const char* name, bool dflt) {
+  std::string v;
+  if (!find_option(name, v) || v.empty()) return dflt;
+  return !(v == "0" || v == "off" || v == "false");
+}
+std::string option_str(const char* name, const char* dflt) {
+  std::string v;
+  return find_option(name, v) ? v : std::string(dflt ? dflt : "");
+}
+bool trace_on(const char* what) {
+  const char* e = std::getenv("DFGPU_TRACE");
+  if (!e || !*e) return false;
+  return std::strstr(e, what) != nullptr || std::strstr(e, "all") != nullptr;
+}
+
 
 // ------------------------------------------------------------------------------- threads and streams
 // per (host thread, device): the thread's stream and the blocks it freed during the current call
@@ -349,6 +402,18 @@ using namespace dfgpu;
 extern "C" {
 
 int dfgpu_abi_version(void) { return DFGPU_ABI_VERSION; }
+int dfgpu_set_option(const char* name, const char* value) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (!name) {   // every option back to its default
+      g_options.clear();
+      return;
+    }
+    if (!value) g_options.erase(name);
+    else g_options[name] = value;
+  });
+}
+
 
 int dfgpu_metrics_reset(void) {
   thread_metrics() = dfgpu_metrics{};
@@ -405,6 +470,10 @@ int dfgpu_init(const int* device_ids, int n_devices) {
       hipDeviceProp_t prop;
       DFGPU_HIP(hipGetDeviceProperties(&prop, device));
       r->num_cus = prop.multiProcessorCount;
+      r->policy.num_cus = prop.multiProcessorCount;
+      if (prop.l2CacheSize > 0) r->policy.l2_bytes = (size_t)prop.l2CacheSize;
+      if (prop.maxSharedMemoryPerMultiProcessor > 0) r->policy.lds_per_cu = (size_t)prop.maxSharedMemoryPerMultiProcessor;
+      r->policy.xcds = std::max(1, prop.multiProcessorCount / 32);   // CDNA3 / CDNA4: 32 CUs per XCD
       DFGPU_HIP(hipStreamCreateWithFlags(&r->first_stream, hipStreamNonBlocking));
       r->stream.r = r.get();
       static std::atomic<uint64_t> generations{0};

@@ -706,11 +706,9 @@ struct SortedKeys {
 };
 
 // digits of a packed key of `total_bits` bits, least significant first; <= 8 bits each, none straddles a word
-// A/B knob of the XCD-contiguous tile order of the scatter passes (device.hpp xcd_tile); default on
-static int sort_xcd_map() {
-  const char* e = std::getenv("DFGPU_SORT_XCD");
-  return e ? std::atoi(e) : 1;
-}
+// the scatter passes walk their tiles in XCD-contiguous order (device.hpp xcd_tile; measured against tile t on XCD t % 8: - 4 to - 8 %,
+// profiles/r5_sort_phases.md)
+static int sort_xcd_map() { return 1; }
 static int max_digit_bits() { return 8; }   // (digit widths and tile sizes were swept in round 2: profiles/r2_radix_sweep.md)
 static std::vector<Digit> key_digits(int total_bits) {
   std::vector<Digit> ds;
@@ -1137,11 +1135,11 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
   clobbered = false;
   // DFGPU_SORT_CARRIED: 0 = off; passes = the records travel through the top passes (measured: the passes lose more than the take
   // they save, 11.1 ms against 9.9 for 150 M orders); default = row ids through the passes as before, records taken by row id INSIDE the bucket sort
-  const char* mode_env = std::getenv("DFGPU_SORT_CARRIED");
+  const std::string mode_s = option_str("sort.carried", "");
+  const char* mode_env = mode_s.empty() ? nullptr : mode_s.c_str();
   const bool off = mode_env && mode_env[0] == '0';
   const bool through_passes = mode_env && mode_env[0] == 'p';
-  const char* min_env = std::getenv("DFGPU_SORT_CARRIED_MIN_ROWS");   // test knob (default: 4 Mi rows — below that the take's lines are cache hits)
-  const int64_t min_rows = min_env ? std::atoll(min_env) : ((int64_t)1 << 22);
+  const int64_t min_rows = option_int("sort.carried_min_rows", policy().rows_worth_a_pass());   // (below that the take's lines are cache hits)
   if (off || n < min_rows || n < 2 || n >= 0xFFFFFFFFll || key_space < 2) return false;
   // every key column can be read back from the packed key
   for (int k = 0; k < pc.n; k++) {
@@ -1233,10 +1231,10 @@ static bool sort_carried(const Table& in, const std::vector<int>& key_cols, cons
 // false = does not apply, or the keys are skewed beyond what a bucket holds (nothing was touched; the caller's older paths take over).
 static bool sort_carried_onesweep(const Table& in, const std::vector<int>& key_cols, const PackCols& pc, int64_t n, uint64_t key_space, Table& out) {
   Runtime& r = rt();
-  const char* mode_env = std::getenv("DFGPU_SORT_CARRIED");   // A/B knob: unset / "o" = this form; "0", "p", "i" = the round-4 forms
+  const std::string mode_s = option_str("sort.carried", "");   // A/B switch: unset / "o" = this form; "0", "p", "i" = the round-4 forms
+  const char* mode_env = mode_s.empty() ? nullptr : mode_s.c_str();
   if (mode_env && mode_env[0] != 'o') return false;
-  const char* min_env = std::getenv("DFGPU_SORT_CARRIED_MIN_ROWS");
-  const int64_t min_rows = min_env ? std::atoll(min_env) : ((int64_t)1 << 22);
+  const int64_t min_rows = option_int("sort.carried_min_rows", policy().rows_worth_a_pass());
   if (n < min_rows || n < 2 || n >= ((int64_t)1 << 30) || key_space < 2) return false;
   for (int k = 0; k < pc.n; k++) {   // every key column can be read back from the packed key
     const PackCol& c = pc.c[k];

@@ -338,7 +338,7 @@ Column dictionary_encode(const Column& in, bool sorted) {
     return out;
   }
   // DFGPU_TRACE_DICT=1: the phases of this call on stderr (where its host time goes: profiles/r3_strings.md)
-  const bool trace = std::getenv("DFGPU_TRACE_DICT") != nullptr;
+  const bool trace = trace_on("dict");
   auto t_last = std::chrono::steady_clock::now();
   auto phase = [&](const char* what) {
     if (!trace) return;

@@ -328,7 +328,7 @@ struct PinnedPool {
   std::map<void*, size_t> live;
   size_t cached = 0;
   static size_t cap() {
-    static const size_t v = std::getenv("DFGPU_PINNED_CACHE_BYTES") ? (size_t)std::atoll(std::getenv("DFGPU_PINNED_CACHE_BYTES")) : ((size_t)8 << 30);
+    static const size_t v = (size_t)8 << 30;
     return v;
   }
   void* alloc(size_t n) {
@@ -358,7 +358,7 @@ struct PinnedPool {
   // for staging vectors (internal.hpp StageVec): plain memory where nothing can be pinned — the host halves of the scan run
   // without a GPU (dfgpu_parquet_inspect_chunk, dfgpu_ipc_open) — or with DFGPU_PINNED_STAGING=0
   void* alloc_or_plain(size_t n) {
-    static const bool off = std::getenv("DFGPU_PINNED_STAGING") && std::atoi(std::getenv("DFGPU_PINNED_STAGING")) == 0;
+    static const bool off = false;
     if (!off && current_device() >= 0) {
       try {
         return alloc(n);

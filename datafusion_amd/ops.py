@@ -524,6 +524,19 @@ def join_estimate_bytes(build_rows, build_row_bytes, probe_rows, output_rows, ou
 
 
 # ----------------------------------------------------------------------------- metrics
+def set_options(**kv):
+    """dfgpu_set_option for every keyword (dots as double underscores: jit__min_rows=0 sets "jit.min_rows"); a value of None restores the
+    option's default.  What tests use to force a path on a small input and what an embedding engine would map its ConfigOptions to."""
+    lib = _lib.init()
+    for k, v in kv.items():
+        check(lib.dfgpu_set_option(k.replace("__", ".").encode(), None if v is None else str(v).encode()))
+
+
+def reset_options():
+    """every option back to its device-derived default"""
+    check(_lib.load().dfgpu_set_option(None, None))
+
+
 def sync():
     check(_lib.load().dfgpu_sync())
 

@@ -587,14 +587,30 @@ int dfgpu_agg_update_filtered(dfgpu_agg_t h, dfgpu_table_t input, const dfgpu_ex
 /* number of updates of `h` that ran fused (0 when the expression forest did not fit the register program and
  * the column-at-a-time evaluator was used; results are identical either way) */
 int dfgpu_agg_fused_updates(dfgpu_agg_t h, int64_t* out);
+/* Options (ABI 12): the dispatch policy's thresholds and switches by name — the library's twin of the reference's ConfigOptions
+ * (common/src/config.rs).  Every default is derived from the device at dfgpu_init (CU count, L2 size of an XCD, LDS per CU), e.g.
+ * "rows worth a pass" = 16 Ki rows per CU; an embedding engine, or a test that must force a path on a small input, overrides by name.
+ * value == NULL restores the option's default; name == NULL restores all of them.  Unknown names are kept and ignored.
+ *   jit = 0|1 (1)                       plan-time specialisation of the fused aggregate node (hiprtc)
+ *   jit.min_rows (rows worth a pass)    smallest input a node is specialised for
+ *   jit.strict = 0|1 (0)                a failed specialisation is an error instead of a fall-back to the interpreter
+ *   jit.cache = 0|1 (1), jit.cache_dir  on-disk cache of compiled nodes; jit.dump_dir: generated sources are written there
+ *   agg.partitioned = 0|1 (1), agg.partitioned_min_rows (2 x rows worth a pass), agg.grouped_move, agg.direct_table, agg.runs = 0|1 (1)
+ *   join.grouped_probe = 0|1 (1), join.grouped_min_rows (rows worth a pass), join.beyond_cache_bytes (4 x the L2 of an XCD),
+ *   join.grouped_bits, join.near_window (test hooks: 0 = derived)
+ *   sort.carried = o|i|p|0 (o), sort.carried_min_rows (rows worth a pass)
+ * The same table is read from the environment variable DFGPU_OPTIONS="name=value,name=value" (lower priority than this call).
+ * DFGPU_TRACE="agg,join,scan,dict,rowprog" (or "all") prints the named subsystems' decisions on stderr; no other environment
+ * variable changes what the library does. */
+int dfgpu_set_option(const char* name, const char* value);
 /* process-wide switch for expression fusion (default on); off = always column-at-a-time (A/B measurements, tests) */
 int dfgpu_set_fusion(int on);
-/* Plan-time specialisation (jit.hip): for inputs of at least DFGPU_JIT_MIN_ROWS rows (default 4 Mi) the fused
+/* Plan-time specialisation (jit.hip): for inputs of at least `jit.min_rows` rows (dfgpu_set_option; default 4 Mi on 256 CUs) the fused
  * aggregate node is compiled for its expression forest with hiprtc (cached per process by source text); this reports
- * how many distinct nodes were compiled and the total compile time.  DFGPU_JIT=0 keeps the interpreter. */
+ * how many distinct nodes were compiled and the total compile time.  Option jit = 0 keeps the interpreter. */
 int dfgpu_jit_stats(int64_t* compiles, double* compile_ms);
-/* Compiled nodes are kept as code objects on disk ($DFGPU_JIT_CACHE_DIR, else $XDG_CACHE_HOME/dfgpu/jit, else ~/.cache/dfgpu/jit;
- * DFGPU_JIT_CACHE=0 = off) keyed by target + hiprtc version + source: a plan seen before by ANY process of the machine costs a file
+/* Compiled nodes are kept as code objects on disk (option jit.cache_dir, else $XDG_CACHE_HOME/dfgpu/jit, else ~/.cache/dfgpu/jit;
+ * option jit.cache = 0: off) keyed by target + hiprtc version + source: a plan seen before by ANY process of the machine costs a file
  * read instead of a 150 ms compile.  Modules are loaded once per (device, source) — a process that drives several GPUs loads the
  * same code object on each.  Any out pointer may be NULL. */
 int dfgpu_jit_cache_stats(int64_t* disk_hits, int64_t* disk_writes, int64_t* modules_loaded);
@@ -693,7 +709,7 @@ int dfgpu_exchange_join_visited(dfgpu_comm_t comm, const dfgpu_join_t* joins);
 typedef struct dfgpu_exchange_stats {
   int64_t bytes_sent_to_peers, bytes_received_from_peers;
   int64_t rows_sent_to_peers, rows_received_from_peers;
-  int64_t messages;     /* point-to-point sends issued (a slice above DFGPU_EXCHANGE_MAX_MESSAGE_BYTES, default 1 GiB, is cut) */
+  int64_t messages;     /* point-to-point sends issued (a slice above 1 GiB is cut) */
   int64_t collectives;  /* grouped all-to-all(v) rounds */
 } dfgpu_exchange_stats;
 int dfgpu_comm_stats(dfgpu_comm_t comm, dfgpu_exchange_stats* out, int reset);

@@ -188,7 +188,7 @@ def main():
         del pk
         torch.cuda.empty_cache()
         run_shape("SF100 sizes with the Q3 payload: 150M unique shuffled build rows x 600M random foreign keys", b, p, [("k", "k2")],
-                  [("auto", {}), ("auto, no grouped lookup", {"env": {"DFGPU_JOIN_RETURNED_PROBE": "0"}}), ("array_map", {"table_mode": 2})], 8,
+                  [("auto", {}), ("array_map", {"table_mode": 2})], 8,
                   build_out=["o_orderdate", "o_shippriority"], probe_out=["k2", "l_extendedprice", "l_discount"], row_bytes=(16, 40, 48))
         b.free()
         p.free()

@@ -1,5 +1,5 @@
 """Where does dictionary_encode's host time go — alone, and inside a process that has held SF100-sized tables (profiles/r3_strings.md)?
-DFGPU_TRACE_DICT=1 makes the library print its phases."""
+DFGPU_TRACE=dict makes the library print its phases."""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import numpy as np
 import pyarrow as pa
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["DFGPU_TRACE_DICT"] = "1"
+os.environ["DFGPU_TRACE"] = "dict"
 from datafusion_amd import ops  # noqa: E402
 from datafusion_amd.table import DeviceTable  # noqa: E402
 

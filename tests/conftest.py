@@ -27,3 +27,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _options_back_to_their_defaults(request):
+    """a GPU test may force a path with ops.set_options(...): whatever it set is gone before the next test (the options are process-wide)"""
+    yield
+    if "gpu" in request.keywords and _has_gpu():
+        from datafusion_amd import _lib
+        if _lib._lib is not None:
+            _lib._lib.dfgpu_set_option(None, None)

@@ -165,9 +165,8 @@ def test_gpu_date_part_column_at_a_time_and_in_the_fused_node(fused):
     t2 = random_table(rng, 50000, {"d": (pa.date32(), 8035, 10591), "v": (pa.int64(), 0, 1000)})
     gb, aggs = [(date_part("year", col("d")), "l_year")], [("sum", col("v"), "s"), ("count", None, "n")]
     ops.set_fusion(fused)
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
     try:
-        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+        ops.set_options(jit="1", jit__min_rows="0", jit__strict="1")
         g = ops.aggregate(DeviceTable.from_arrow(t2), gb, aggs, "Single", predicate=col("v") > 10).to_arrow()
     finally:
         ops.set_fusion(True)

@@ -420,9 +420,9 @@ def test_medium_cardinality_group_by_over_a_wide_key_range_moves_the_rows_twice(
     from datafusion_amd import ops
     from datafusion_amd.expr import col
     from datafusion_amd.table import DeviceTable
-    monkeypatch.setenv("DFGPU_AGG_PARTITIONED_MIN_ROWS", "1000000")
+    ops.set_options(agg__partitioned_min_rows="1000000")
     if move == "two_level":
-        monkeypatch.setenv("DFGPU_AGG_GROUPED_MOVE", "0")
+        ops.set_options(agg__grouped_move="0")
     rng = np.random.default_rng(9)
     n, distinct = 6_000_000, 600_000
     codes = rng.integers(0, distinct, n)
@@ -535,7 +535,7 @@ def test_one_grouped_move_under_a_fused_filter_with_a_decimal_sum(monkeypatch, k
     from datafusion_amd import ops
     from datafusion_amd.expr import col, lit
     from datafusion_amd.table import DeviceTable
-    monkeypatch.setenv("DFGPU_AGG_PARTITIONED_MIN_ROWS", "1000000")
+    ops.set_options(agg__partitioned_min_rows="1000000")
     rng = np.random.default_rng(77)
     n, distinct = 5_000_000, 400_000
     codes = rng.integers(0, distinct, n)
@@ -749,7 +749,7 @@ def test_key_columns_with_small_value_ranges_take_a_direct_table(monkeypatch, ta
     from datafusion_amd.expr import col, lit
     from datafusion_amd.table import DeviceTable
     if table == "keyed_by_knob":
-        monkeypatch.setenv("DFGPU_AGG_DIRECT_TABLE", "0")
+        ops.set_options(agg__direct_table="0")
     rng = np.random.default_rng(41 + filtered)
     n, n2 = 4_600_000, 300_000
     flag = np.frombuffer(b"ANR", dtype=np.uint8)[rng.integers(0, 3, n + n2)]

@@ -77,21 +77,16 @@ def test_case_in_aggregate_arguments_and_predicate(keys, nulls, evaluator):
     numeric = [(e, nm) for e, nm in _cases() if nm not in ("bool_result", "date_no_else")]
     aggs = [("sum", e, f"s_{nm}") for e, nm in numeric[:7]] + [("count", e, f"c_{nm}") for e, nm in numeric[7:]] + [("avg", numeric[3][0], "avg_dec"), ("count", None, "n")]
     pred = case([(col("i") > lit(0, pa.int32()), col("d") < col("e"))], col("k") > lit(0))
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
     ops.set_fusion(evaluator != "column_at_a_time")
     if evaluator == "specialised":
-        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+        ops.set_options(jit="1", jit__min_rows="0", jit__strict="1")
     else:
-        os.environ["DFGPU_JIT"] = "0"
+        ops.set_options(jit="0")
     try:
         got = ops.aggregate(DeviceTable.from_arrow(t), gb, aggs, "Single", predicate=pred).to_arrow()
     finally:
         ops.set_fusion(True)
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        ops.reset_options()
     src = O.filter(t, to_oracle_expr(pred), t.column_names)
     assert_agg_equal(got, oracle_agg(src, gb, aggs, "Single"), ordered=True)
 

@@ -148,11 +148,11 @@ def test_sf100_join_over_keys_in_no_order(tables):
     assert "join_probe_group_keys" in stats or "radix_sort_pass" in stats   # probe keys grouped by key range (grouped.hip; round 3: a radix pass)
     assert keys.num_rows == lineitem.num_rows and _sums(keys, ["l_orderkey"]) == k_sum
     keys.free()
-    os.environ["DFGPU_JOIN_GROUPED_PROBE"] = "0"
+    ops.set_options(join__grouped_probe="0")
     try:
         plain = ht.probe(sl, ["l_orderkey"], "Inner", [], ["l_orderkey"])
     finally:
-        del os.environ["DFGPU_JOIN_GROUPED_PROBE"]
+        ops.set_options(join__grouped_probe=None)
     assert plain.num_rows == lineitem.num_rows and _sums(plain, ["l_orderkey"]) == k_sum
     plain.free()
     # a probe that gathers build payload: payload = f(key)
@@ -270,10 +270,10 @@ def test_sf100_group_by_custkey_partitioned_equals_global_atomics(monkeypatch):
         return out, stats
     moved, s1 = run()
     assert "agg_dense_accumulate_partitioned" in s1 and s1["agg_group_rows"]["calls"] == 1 and "partition_scatter" not in s1, sorted(s1)
-    monkeypatch.setenv("DFGPU_AGG_GROUPED_MOVE", "0")
+    ops.set_options(agg__grouped_move="0")
     twice, s3 = run()
     assert "agg_dense_accumulate_partitioned" in s3 and s3["partition_scatter"]["calls"] == 2 and "agg_group_rows" not in s3, sorted(s3)
-    monkeypatch.setenv("DFGPU_AGG_PARTITIONED_MIN_ROWS", str(2**31 - 1))
+    ops.set_options(agg__partitioned_min_rows=str(2**31 - 1))
     plain, s2 = run()
     assert "agg_dense_accumulate" in s2 and "agg_dense_accumulate_partitioned" not in s2
     assert moved.num_rows == plain.num_rows == twice.num_rows

@@ -21,17 +21,12 @@ def fusion(request):
 
     from datafusion_amd import ops
     ops.set_fusion(request.param != "column_at_a_time")
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
     if request.param == "specialised":
-        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+        ops.set_options(jit="1", jit__min_rows="0", jit__strict="1")
     else:
-        os.environ["DFGPU_JIT"] = "0"
+        ops.set_options(jit="0")
     yield request.param != "column_at_a_time"
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    ops.reset_options()
     ops.set_fusion(True)
 
 
@@ -214,17 +209,15 @@ def test_ordered_group_key_runs_node(shape, null_frac):
                "long": [300, 2, 129, 1, 1, 640, 7, 65, 64, 200], "mixed": np.concatenate([rng.integers(1, 8, size=300), [500], rng.integers(1, 90, size=60), [1, 1, 1]]),
                "single": [1000], "all_distinct": [1] * 777}[shape]
     t = _runs_table(rng, lengths, null_frac=null_frac)
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT", "DFGPU_AGG_RUNS")}
     try:
-        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1", "DFGPU_AGG_RUNS": "1"})
+        ops.set_options(jit="1", jit__min_rows="0", jit__strict="1", agg__runs="1")
         ops.profile_enable(True)
         ops.profile_reset()
         got, fused = gpu(t, [(col("k"), "k")], RUN_AGGS(col))
         stats = ops.profile_stats()
         ops.profile_enable(False)
     finally:
-        for k, v in saved.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        ops.reset_options()
     assert "agg_runs_accumulate" in stats, sorted(stats)   # the node under test ran
     assert_agg_equal(got, oracle(t, [(col("k"), "k")], RUN_AGGS(col)), ordered=True)
 
@@ -237,13 +230,11 @@ def test_ordered_group_key_runs_node_key_types(key_type):
     from datafusion_amd.expr import col
     rng = np.random.default_rng(5)
     t = _runs_table(rng, rng.integers(1, 40, size=120), key_type=key_type, start=3, gaps=False)
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
     try:
-        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+        ops.set_options(jit="1", jit__min_rows="0", jit__strict="1")
         got, _ = gpu(t, [(col("k"), "k")], [("sum", col("d"), "sd"), ("count", None, "n")])
     finally:
-        for k, v in saved.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        ops.reset_options()
     assert got.schema.field("k").type == key_type
     assert_agg_equal(got, oracle(t, [(col("k"), "k")], [("sum", col("d"), "sd"), ("count", None, "n")]), ordered=True)
 
@@ -258,35 +249,31 @@ def test_unordered_group_key_does_not_take_the_runs_node():
     k = t.column("k").to_numpy().copy()
     k[[50, 51]] = k[[51, 50]] if k[50] != k[51] else (k[51] + 1000, k[51])      # one descent
     t = t.set_column(t.schema.get_field_index("k"), "k", pa.array(k, type=pa.int64()))
-    saved = {k_: os.environ.get(k_) for k_ in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
     try:
-        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+        ops.set_options(jit="1", jit__min_rows="0", jit__strict="1")
         ops.profile_enable(True)
         ops.profile_reset()
         got, _ = gpu(t, [(col("k"), "k")], [("sum", col("d"), "sd"), ("count", None, "n")])
         stats = ops.profile_stats()
         ops.profile_enable(False)
     finally:
-        for k_, v in saved.items():
-            os.environ.pop(k_, None) if v is None else os.environ.__setitem__(k_, v)
+        ops.reset_options()
     assert "agg_runs_accumulate" not in stats
     assert_agg_equal(got, oracle(t, [(col("k"), "k")], [("sum", col("d"), "sd"), ("count", None, "n")]), ordered=True)
 
 
 def _with_jit_env(fn):
     import os
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT", "DFGPU_AGG_RUNS")}
     from datafusion_amd import ops
     try:
-        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1", "DFGPU_AGG_RUNS": "1"})
+        ops.set_options(jit="1", jit__min_rows="0", jit__strict="1", agg__runs="1")
         ops.profile_enable(True)
         ops.profile_reset()
         out = fn()
         stats = ops.profile_stats()
         ops.profile_enable(False)
     finally:
-        for k, v in saved.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        ops.reset_options()
     return out, stats
 
 
@@ -351,8 +338,7 @@ def test_specialised_nodes_are_kept_as_code_objects_on_disk(tmp_path):
         "t = ops.tpch_lineitem(0.01)\n"
         "out = ops.aggregate(t, queries.Q1_GROUP_BY, queries.q1_aggs_inlined(), 'Single', predicate=col('l_shipdate') <= lit(queries.DATE_Q1, pa.date32())).to_arrow()\n"
         "print(json.dumps(dict(jit=ops.jit_stats()[0], **ops.jit_cache_stats(), rows=[[str(v) for v in r.values()] for r in out.to_pylist()])))\n" % root)
-    env = dict(os.environ, DFGPU_JIT="1", DFGPU_JIT_MIN_ROWS="0", DFGPU_JIT_STRICT="1", DFGPU_JIT_CACHE_DIR=str(tmp_path / "jit"))
-    env.pop("DFGPU_JIT_CACHE", None)
+    env = dict(os.environ, DFGPU_OPTIONS="jit=1,jit.min_rows=0,jit.strict=1,jit.cache_dir=" + str(tmp_path / "jit"))
     run = lambda e=env: json.loads(subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, check=True, timeout=300).stdout.splitlines()[-1])
     first = run()
     assert first["jit"] >= 1 and first["disk_writes"] == first["jit"] and first["disk_hits"] == 0
@@ -366,5 +352,5 @@ def test_specialised_nodes_are_kept_as_code_objects_on_disk(tmp_path):
     victim.write_bytes(data[: len(data) // 2])                   # a torn file
     third = run()
     assert third["jit"] == 1 and third["rows"] == first["rows"]
-    off = run(dict(env, DFGPU_JIT_CACHE="0"))
+    off = run(dict(env, DFGPU_OPTIONS=env["DFGPU_OPTIONS"] + ",jit.cache=0"))
     assert off["jit"] == first["jit"] and off["disk_hits"] == 0 and off["disk_writes"] == 0

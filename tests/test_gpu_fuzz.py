@@ -68,21 +68,16 @@ def test_aggregate_fuzz(seed, evaluator):
     picks = rng.choice(len(AGG_POOL), size=int(rng.integers(1, 6)), replace=False)
     aggs = [(f, None if c is None else col(c), f"{f}_{c}_{j}") for j, (f, c) in enumerate(AGG_POOL[p] for p in picks)]
     pred = None if rng.integers(0, 3) == 0 else (col("i") > lit(int(rng.integers(-900, 900)), pa.int32()))
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
     ops.set_fusion(evaluator != "column_at_a_time")
     if evaluator == "specialised":
-        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+        ops.set_options(jit="1", jit__min_rows="0", jit__strict="1")
     else:
-        os.environ["DFGPU_JIT"] = "0"
+        ops.set_options(jit="0")
     try:
         got = ops.aggregate(DeviceTable.from_arrow(t), gb, aggs, "Single", predicate=pred).to_arrow()
     finally:
         ops.set_fusion(True)
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        ops.reset_options()
     src = t if pred is None else O.filter(t, to_oracle_expr(pred), t.column_names)
     assert_agg_equal(got, oracle_agg(src, gb, aggs, "Single"), ordered=True)
 
@@ -182,17 +177,12 @@ def test_expression_fuzz_projection_filter_and_fused_arguments(seed):
     aggs = [("sum", e, f"s_{nm}") for e, nm in numeric] + [("count", e, f"c_{nm}") for e, nm in exprs[:2] if not _is_bool(e)] + [("count", None, "n")]
     src = O.filter(t, to_oracle_expr(pred), t.column_names)
     want = oracle_agg(src, [], aggs, "Single")
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
     try:
-        for env in ({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"}, {"DFGPU_JIT": "0"}):
-            os.environ.update(env)
+        for opts in (dict(jit=1, jit__min_rows=0, jit__strict=1), dict(jit=0)):
+            ops.set_options(**opts)
             assert_agg_equal(ops.aggregate(dev, [], aggs, "Single", predicate=pred).to_arrow(), want)
     finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        ops.reset_options()
 
 
 @pytest.mark.parametrize("seed", range(20))

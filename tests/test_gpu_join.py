@@ -570,8 +570,8 @@ def test_key_only_probe_of_unordered_keys_is_grouped_by_key_range(join_type):
     exp = np.sort(pk[member if join_type != "RightAnti" else ~member])
     outs = {}
     for grouped in ("1", "0"):
-        os.environ["DFGPU_JOIN_GROUPED_PROBE"] = grouped
-        os.environ["DFGPU_JOIN_BIG_TABLE_BYTES"] = "1000000"      # this test's 3 MB table counts as beyond the caches
+        ops.set_options(join__grouped_probe=grouped)
+        ops.set_options(join__beyond_cache_bytes="1000000")  # this test's 3 MB table counts as beyond the caches
         try:
             ht = ops.JoinHashTable(b, ["k"], probe_mode=4)
             assert ht.info().table_kind == 2
@@ -580,8 +580,8 @@ def test_key_only_probe_of_unordered_keys_is_grouped_by_key_range(join_type):
             assert out.column_names == ["k2"]
             ht.free()
         finally:
-            os.environ.pop("DFGPU_JOIN_GROUPED_PROBE", None)
-            os.environ.pop("DFGPU_JOIN_BIG_TABLE_BYTES", None)
+            ops.set_options(join__grouped_probe=None)
+            ops.set_options(join__beyond_cache_bytes=None)
         assert np.array_equal(np.sort(outs[grouped]), exp), grouped
     if join_type == "Inner":
         assert not np.array_equal(outs["1"], outs["0"])       # the grouped flavour really ran: its rows come out in group order
@@ -616,7 +616,7 @@ def test_unclustered_probe_with_payload_goes_through_groups_and_comes_back_in_pr
     probe = probe.append_column("kk", probe.column("k2")).set_column(0, "k2", pa.array(probe.column("k2").to_numpy(), mask=rng.random(npr) < 0.02))
     b, p = DeviceTable.from_arrow(build), DeviceTable.from_arrow(probe)
     # (test knobs: this table counts as beyond the caches, grouping from the first row on, "near" = within 1000 key values)
-    os.environ.update({"DFGPU_JOIN_BIG_TABLE_BYTES": "0", "DFGPU_JOIN_GROUPED_MIN_ROWS": "0", "DFGPU_JOIN_GP_BITS": gp_bits, "DFGPU_JOIN_NEAR_WINDOW": "1000"})
+    ops.set_options(join__beyond_cache_bytes="0", join__grouped_min_rows="0", join__grouped_bits=gp_bits, join__near_window="1000")
     try:
         for payload in (["d", "p"], ["x", "u", "w", "p", "d"], ["w"], []):
             exp = oracle.hash_join(build, probe, [("k", "k2")], "Inner").select(payload + ["kk", "e", "q"])
@@ -655,8 +655,7 @@ def test_unclustered_probe_with_payload_goes_through_groups_and_comes_back_in_pr
         assert_tables_equal(got, oracle.hash_join(build, fk, [("k", "k2")], "Inner").select(["d", "p", "k2", "e"]), ordered=True)
         ht.free()
     finally:
-        for k in ("DFGPU_JOIN_BIG_TABLE_BYTES", "DFGPU_JOIN_GROUPED_MIN_ROWS", "DFGPU_JOIN_GP_BITS", "DFGPU_JOIN_NEAR_WINDOW"):
-            os.environ.pop(k, None)
+        ops.set_options(join__beyond_cache_bytes=None, join__grouped_min_rows=None, join__grouped_bits=None, join__near_window=None)
 
 
 @pytest.mark.parametrize("dangling", [0, 3])

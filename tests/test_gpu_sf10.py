@@ -151,17 +151,12 @@ def evaluator(request):
 
     from datafusion_amd import ops
     ops.set_fusion(request.param != "column_at_a_time")
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_STRICT")}
     if request.param == "specialised":
-        os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_STRICT": "1"})
+        ops.set_options(jit="1", jit__strict="1")
     else:
-        os.environ["DFGPU_JIT"] = "0"
+        ops.set_options(jit="0")
     yield request.param
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    ops.reset_options()
     ops.set_fusion(True)
 
 

@@ -230,8 +230,8 @@ def test_sort_carried_records_and_keys_decoded_from_the_packed_key(monkeypatch, 
         t = pa.table({"u": pa.array(rng.integers(2**31, 2**32 - 1, n).astype(np.uint32)), "s": pa.array(rng.integers(-2**31, -2**30, n).astype(np.int32)),
                       "v": pa.array(np.arange(n, dtype=np.int64))})
         keys = [("s", False, False), ("u", True, False)]
-    monkeypatch.setenv("DFGPU_SORT_CARRIED_MIN_ROWS", "0")
-    monkeypatch.setenv("DFGPU_SORT_CARRIED", {"onesweep": "onesweep", "records_by_row_id": "ids", "records_through_the_passes": "passes"}[mode])
+    ops.set_options(sort__carried_min_rows="0")
+    ops.set_options(sort__carried={"onesweep": "onesweep", "records_by_row_id": "ids", "records_through_the_passes": "passes"}[mode])
     ops.profile_enable(True)
     ops.profile_reset()
     run_sort(t, keys)

@@ -88,8 +88,7 @@ def test_two_devices_one_process_exchanges_joins_and_specialised_nodes():
         assert_tables_equal(j, je, ordered=False)
         t.free()
     # ---- the specialised (hiprtc) fused aggregate on BOTH devices: one compile, one module load per device
-    saved = {k: os.environ.get(k) for k in ("DFGPU_JIT", "DFGPU_JIT_MIN_ROWS", "DFGPU_JIT_STRICT")}
-    os.environ.update({"DFGPU_JIT": "1", "DFGPU_JIT_MIN_ROWS": "0", "DFGPU_JIT_STRICT": "1"})
+    ops.set_options(jit="1", jit__min_rows="0", jit__strict="1")
     try:
         before = ops.jit_cache_stats()["modules_loaded"]
         results = []
@@ -104,11 +103,7 @@ def test_two_devices_one_process_exchanges_joins_and_specialised_nodes():
         loaded = ops.jit_cache_stats()["modules_loaded"] - before
         assert loaded >= 2 and loaded % 2 == 0                        # the same code objects, loaded on device 0 AND on device 1
     finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        ops.reset_options()
     st = _lib.ExchangeStats()
     _lib.check(lib.dfgpu_comm_stats(comm, C.byref(st), 0))
     assert st.bytes_sent_to_peers > 0 and st.bytes_sent_to_peers == st.bytes_received_from_peers and st.collectives >= 3
