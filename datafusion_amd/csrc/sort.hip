@@ -842,6 +842,203 @@ __device__ __forceinline__ void sort_emit_row(const SortEmit& e, uint64_t full_k
     record_split<2>(e.fields, pos, sl);
   }
 }
+// ------------------------------------------------------------------------------ LSD carried sort: narrow keys (round 5)
+// A sort whose packed key is NARROW (<= 32 bits: a date, a few small codes, dictionary indices ...) needs no bucket sort at all: a few
+// stable onesweep passes over the ROWS finish it, the first reading the SOURCE columns and the last writing the OUTPUT columns.  A row
+// travels as one record of 16, 24 or 32 bytes: every column the key does not cover, plus the 32-bit key itself in the record's last
+// word (so no key array exists either; the key columns are decoded from that word at the end).  The record moves as a 16-byte slice and,
+// beyond 16 bytes, a second slice of 8 or 16 bytes in an array of its own, staged through LDS one slice after the other.
+// `reverse`: the first pass reads the input back to front — how a trailing key column that is strictly ascending IN INPUT ORDER and
+// wanted DESC is honoured without being part of the key (sort_lsd_carried).  Same ranking, look-back and ticket as k_os_pass.
+struct LsdIo {
+  const uint4* in0;
+  const void* in1;
+  uint4* out0;
+  void* out1;
+};
+__device__ __forceinline__ void lsd_emit_fields(const PackLayout& L, int slice, const uint4& v, int64_t pos) {
+  for (int c = 0; c < L.n; c++) {
+    const int o = L.offset[c];
+    if ((o >> 4) != slice) continue;
+    const int oo = o & 15;
+    const uint32_t w32 = (oo >> 2) == 0 ? v.x : (oo >> 2) == 1 ? v.y : (oo >> 2) == 2 ? v.z : v.w;
+    switch (L.width[c]) {
+      case 16: reinterpret_cast<uint4*>(L.dst[c])[pos] = v; break;
+      case 8: reinterpret_cast<uint2*>(L.dst[c])[pos] = oo ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y); break;
+      case 4: reinterpret_cast<uint32_t*>(L.dst[c])[pos] = w32; break;
+      default: reinterpret_cast<uint8_t*>(L.dst[c])[pos] = (uint8_t)(w32 >> ((oo & 3) * 8)); break;
+    }
+  }
+}
+__device__ __forceinline__ void lsd_emit_keys(const SortEmit& emit, uint32_t key, int64_t pos) {
+  uint64_t rem = key;
+  for (int c = 0; c < emit.n_keys; c++) {   // most significant column first (sort_emit_row)
+    const uint64_t digit = div_apply(rem, emit.key_div[c]);
+    rem -= digit * emit.key_mult[c];
+    const uint64_t v = emit.key_desc[c] ? emit.key_base[c] - digit : emit.key_base[c] + digit;
+    switch (emit.key_type[c]) {
+      case DFGPU_INT32: case DFGPU_DATE32: reinterpret_cast<int32_t*>(emit.key_dst[c])[pos] = (int32_t)((uint32_t)v ^ 0x80000000u); break;
+      case DFGPU_UINT32: reinterpret_cast<uint32_t*>(emit.key_dst[c])[pos] = (uint32_t)v; break;
+      case DFGPU_INT64: reinterpret_cast<uint64_t*>(emit.key_dst[c])[pos] = v ^ 0x8000000000000000ull; break;
+      case DFGPU_UINT64: reinterpret_cast<uint64_t*>(emit.key_dst[c])[pos] = v; break;
+      default: reinterpret_cast<uint8_t*>(emit.key_dst[c])[pos] = (uint8_t)v; break;
+    }
+  }
+}
+__device__ __forceinline__ uint32_t word_of(const uint4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+// W2: bytes of the record's second slice (0, 8 or 16); key_off: byte offset of the key word inside the record
+template <bool BUILD, bool EMIT, int W2>
+__global__ __launch_bounds__(BLOCK, (W2 == 0 ? 4 : 3)) void k_lsd_pass(LsdIo io, PackCols pc, PackLayout L, int key_off, int64_t n, int reverse, int shift, int bits,
+                                                                       int64_t n_tiles, const unsigned long long* __restrict__ bin_base, uint32_t* __restrict__ tile_state,
+                                                                       unsigned* __restrict__ ticket, SortEmit emit) {
+  constexpr int NWAVE = BLOCK / WAVE;
+  constexpr int NS = W2 == 0 ? 2 : 4;
+  __shared__ __align__(16) uint4 s_rec[OS_TILE];   // the tile in digit order, one slice of its records at a time
+  __shared__ uint8_t s_dig[OS_TILE];
+  __shared__ uint16_t s_cnt[NWAVE][256];
+  __shared__ uint16_t s_start[256];
+  __shared__ unsigned int s_goff[256];
+  __shared__ unsigned int s_wtot[NWAVE];
+  __shared__ unsigned int s_tile;
+  const unsigned mask = (1u << bits) - 1u;
+  const int wave = threadIdx.x >> 6;
+  const unsigned lane = lane_id();
+  const int key_slice = key_off >> 4, key_word = (key_off & 15) >> 2;
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t t = (int64_t)s_tile;
+    if (t >= n_tiles) return;
+    const int64_t lo = t * OS_TILE;
+    const int tile_rows = (int)((n - lo) < OS_TILE ? (n - lo) : OS_TILE);
+    uint4 rec0[OS_ITEMS], rec1[OS_ITEMS];
+    unsigned dig[OS_ITEMS], rank[OS_ITEMS];
+#pragma unroll
+    for (int c = 0; c < OS_ITEMS; c++) {   // all loads of the wave's segment in flight together
+      const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
+      const int64_t row = lo + (j < tile_rows ? j : 0);
+      rec1[c] = uint4{0u, 0u, 0u, 0u};
+      if (BUILD) {
+        const int64_t src = reverse ? n - 1 - row : row;   // (position `row` of the order the stable passes see)
+        uint64_t sl[NS];
+        record_build<NS>(L, src, sl);
+        slot_or<NS>(sl, key_off >> 3, (uint64_t)(uint32_t)pack_key64(pc, src) << ((key_off & 4) * 8));
+        rec0[c] = uint4{(unsigned)sl[0], (unsigned)(sl[0] >> 32), (unsigned)sl[1], (unsigned)(sl[1] >> 32)};
+        if (W2) rec1[c] = uint4{(unsigned)sl[NS - 2], (unsigned)(sl[NS - 2] >> 32), (unsigned)sl[NS - 1], (unsigned)(sl[NS - 1] >> 32)};
+      } else {
+        const uint4 v = io.in0[row];   // (component by component: a 16-byte struct copy kept the whole array in scratch memory)
+        rec0[c] = uint4{v.x, v.y, v.z, v.w};
+        if (W2 == 16) {
+          const uint4 u = reinterpret_cast<const uint4*>(io.in1)[row];
+          rec1[c] = uint4{u.x, u.y, u.z, u.w};
+        } else if (W2 == 8) {
+          const uint2 u = reinterpret_cast<const uint2*>(io.in1)[row];
+          rec1[c] = uint4{u.x, u.y, 0u, 0u};
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < OS_ITEMS; c++) {
+      const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
+      const bool in = j < tile_rows;
+      const uint32_t key0 = word_of(rec0[c], key_word), key1 = word_of(rec1[c], key_word);
+      const uint32_t key = key_slice ? key1 : key0;
+      dig[c] = in ? ((key >> shift) & mask) : 0u;
+      uint64_t peers = ballot64(in);
+      for (int b = 0; b < bits; b++) {
+        const uint64_t bal = ballot64((dig[c] >> b) & 1u);
+        peers &= ((dig[c] >> b) & 1u) ? bal : ~bal;
+      }
+      const unsigned r_in_wave = mbcnt(peers);
+      const unsigned base = s_cnt[wave][dig[c]];
+      if (in && r_in_wave == 0) s_cnt[wave][dig[c]] = (uint16_t)(base + (unsigned)__popcll(peers));
+      rank[c] = base + r_in_wave;
+    }
+    __syncthreads();
+    unsigned run = 0;   // thread d: digit d's rows in this tile
+    {
+#pragma unroll
+      for (int w = 0; w < NWAVE; w++) {
+        const unsigned v = s_cnt[w][threadIdx.x];
+        s_cnt[w][threadIdx.x] = (uint16_t)run;
+        run += v;
+      }
+      if (t > 0 && threadIdx.x <= mask) os_store(&tile_state[t * 256 + threadIdx.x], OS_AGG | run);
+      const unsigned inc = wave_inclusive_sum<unsigned>(run);
+      if (lane == 63) s_wtot[wave] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; w++) base += s_wtot[w];
+      s_start[threadIdx.x] = (uint16_t)(base + inc - run);
+    }
+    __syncthreads();
+    unsigned q[OS_ITEMS];
+#pragma unroll
+    for (int c = 0; c < OS_ITEMS; c++) {
+      const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
+      q[c] = 0xFFFFFFFFu;
+      if (j < tile_rows) {
+        q[c] = (unsigned)s_start[dig[c]] + (unsigned)s_cnt[wave][dig[c]] + rank[c];
+        s_rec[q[c]] = rec0[c];
+        s_dig[q[c]] = (uint8_t)dig[c];
+      }
+    }
+    // ---- look-back (k_os_pass): thread d adds up digit d's counts over the tiles before this one until it meets an inclusive prefix
+    if (threadIdx.x <= mask) {
+      unsigned excl = 0;
+      if (t > 0) {
+        int64_t p = t - 1;
+        for (;;) {
+          const uint32_t st = os_load(&tile_state[p * 256 + threadIdx.x]);
+          const uint32_t status = st >> 30;
+          if (status == 0) {
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+          }
+          excl += st & OS_VAL;
+          if (status == 2) break;
+          p--;
+        }
+      }
+      os_store(&tile_state[t * 256 + threadIdx.x], OS_PFX | (excl + run));
+      s_goff[threadIdx.x] = (unsigned)bin_base[threadIdx.x] + excl - (unsigned)s_start[threadIdx.x];
+    }
+    __syncthreads();
+    // ---- write-out, one slice after the other (EMIT: the slice's fields to their columns; the key columns decoded from the key word)
+    for (int qq = threadIdx.x; qq < tile_rows; qq += BLOCK) {
+      const unsigned pos = qq + s_goff[s_dig[qq]];
+      const uint4 v = s_rec[qq];
+      if (!EMIT) {
+        io.out0[pos] = v;
+      } else {
+        lsd_emit_fields(emit.fields, 0, v, (int64_t)pos);
+        if (key_slice == 0) lsd_emit_keys(emit, word_of(v, key_word), (int64_t)pos);
+      }
+    }
+    if (W2) {
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < OS_ITEMS; c++)
+        if (q[c] != 0xFFFFFFFFu) s_rec[q[c]] = rec1[c];
+      __syncthreads();
+      for (int qq = threadIdx.x; qq < tile_rows; qq += BLOCK) {
+        const unsigned pos = qq + s_goff[s_dig[qq]];
+        const uint4 v = s_rec[qq];
+        if (!EMIT) {
+          if (W2 == 16) reinterpret_cast<uint4*>(io.out1)[pos] = v;
+          else reinterpret_cast<uint2*>(io.out1)[pos] = make_uint2(v.x, v.y);
+        } else {
+          lsd_emit_fields(emit.fields, 1, v, (int64_t)pos);
+          if (key_slice == 1) lsd_emit_keys(emit, word_of(v, key_word), (int64_t)pos);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // one workgroup per bucket: stable LSD sort of the bucket's (key, id) elements by the key's low `low_bits` bits, in LDS
 template <typename LK, bool EMIT = false>  // the key inside its bucket: 32 bits when `width` allows (less LDS and registers: more buckets in flight per CU)
 __global__ __launch_bounds__(BLOCK, (sizeof(LK) == 4 ? 4 : 3)) void k_local_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ starts,
@@ -1300,6 +1497,148 @@ static bool sort_carried_onesweep(const Table& in, const std::vector<int>& key_c
   return carried_emit(in, key_cols, pc, payload, order, L, cur_key, cur_rec, nullptr, n, n_buckets, width, low_bits, out);
 }
 
+// The LSD carried sort (round 5): the packed key — after dropping what the input's own order already settles — fits 32 bits, so two to
+// four stable passes over 16-32-byte records sort the table, the last one writing the output columns; no bucket sort, no key array.
+// What the input's order settles: a key column that is STRICTLY ASCENDING in row order (a primary key the table was loaded by, a row
+// number) decides every tie among the columns before it exactly as the input order does (ASC) or as the reversed input order does (DESC),
+// and no column after it matters — so it and everything behind it leave the key, and the first pass reads the rows back to front for DESC.
+// `ORDER BY o_orderdate, o_orderkey DESC` over orders is then a 12-bit sort.  false = does not apply (nothing was touched).
+static bool sort_lsd_carried(const Table& in, const std::vector<int>& key_cols, const PackCols& pc, int64_t n, Table& out) {
+  Runtime& r = rt();
+  if (!option_on("sort.lsd", true)) return false;
+  const int64_t min_rows = option_int("sort.carried_min_rows", policy().rows_worth_a_pass());
+  if (n < min_rows || n < 2 || n >= ((int64_t)1 << 30)) return false;
+  // the key columns that stay
+  int kept = pc.n, reverse = 0;
+  for (int k = 0; k < pc.n; k++) {
+    const Column& c = in.cols[(size_t)key_cols[(size_t)k]];
+    const bool stats_cheap = !c.validity && (c.field.type == DFGPU_INT32 || c.field.type == DFGPU_DATE32 || c.field.type == DFGPU_INT64);
+    if (stats_cheap && column_stats(const_cast<Column&>(c), n).ascending) {
+      kept = k;
+      reverse = pc.c[k].desc ? 1 : 0;
+      break;
+    }
+  }
+  if (kept == 0) return false;   // (already in order, or its reverse: not this path's business)
+  PackCols kc = pc;
+  kc.n = kept;
+  u128 product = 1;
+  for (int k = kept - 1; k >= 0; k--) {
+    PackCol& c = kc.c[k];
+    const bool int_like = c.type == DFGPU_INT32 || c.type == DFGPU_DATE32 || c.type == DFGPU_UINT32 || c.type == DFGPU_INT64 || c.type == DFGPU_UINT64 || c.type == DFGPU_UINT8;
+    if (c.valid || c.has_null_bit || !int_like || c.range == 0) return false;   // (the key columns are read back from the key)
+    c.mult = (uint64_t)product;
+    product *= (u128)c.range;
+    if (product > ((u128)1 << 32)) return false;
+  }
+  if (product < 2) return false;
+  const int total_bits = bits_for(product - 1);
+  const int n_pass = (total_bits + 7) / 8;
+  if (n_pass > OS_MAX_PASSES) return false;
+  OsDigits dg{};
+  for (int p = 0, pos = 0; p < n_pass; p++) {   // digits of (nearly) equal width: 12 bits = 6 + 6
+    const int b = (total_bits - pos + (n_pass - p) - 1) / (n_pass - p);
+    dg.shift[p] = pos;
+    dg.bits[p] = b;
+    pos += b;
+    dg.n++;
+  }
+  // the record: every other column (the dropped key columns among them) + the key word
+  std::vector<int> kept_cols(key_cols.begin(), key_cols.begin() + kept), payload;
+  for (int c = 0; c < (int)in.cols.size(); c++)
+    if (std::find(kept_cols.begin(), kept_cols.end(), c) == kept_cols.end()) payload.push_back(c);
+  PackLayout L{};
+  int R = 0, key_off = 0;
+  std::vector<int> order;
+  if (!payload.empty()) {
+    if (!plan_record_layout(in, payload, L, R, order)) return false;
+    int bytes = 0;
+    for (int q = 0; q < L.n; q++) bytes = std::max(bytes, L.offset[q] + L.width[q]);
+    key_off = (bytes + 3) / 4 * 4;
+  }
+  const int rec_bytes = (key_off + 4 + 7) / 8 * 8;
+  if (rec_bytes > 32) return false;
+  const int w2 = rec_bytes <= 16 ? 0 : rec_bytes - 16;
+  for (int k = 0; k < kept; k++)   // a key column listed twice, or kept and dropped: leave it to the general paths
+    for (int j = k + 1; j < pc.n; j++)
+      if (key_cols[(size_t)k] == key_cols[(size_t)j]) return false;
+  // output columns and who writes them
+  out.cols.assign(in.cols.size(), Column{});
+  SortEmit e{};
+  e.n_keys = kept;
+  int64_t key_col_bytes = 0, row_bytes = 0;
+  for (int k = 0; k < kept; k++) {
+    const int c = key_cols[(size_t)k];
+    out.cols[(size_t)c] = alloc_like(in.cols[(size_t)c], n);
+    e.key_dst[k] = out.cols[(size_t)c].data->ptr;
+    e.key_type[k] = kc.c[k].type;
+    e.key_desc[k] = kc.c[k].desc;
+    e.key_base[k] = kc.c[k].base_lo;
+    e.key_mult[k] = kc.c[k].mult;
+    e.key_div[k] = div_by(kc.c[k].mult);
+    const int w = kc.c[k].type == DFGPU_UINT8 ? 1 : type_width(kc.c[k].type);
+    key_col_bytes += n * w;
+    row_bytes += w;
+  }
+  e.fields = L;
+  for (int q = 0; q < L.n; q++) {
+    const int c = payload[(size_t)order[(size_t)q]];
+    out.cols[(size_t)c] = alloc_like(in.cols[(size_t)c], n);
+    e.fields.dst[q] = out.cols[(size_t)c].data->ptr;
+    row_bytes += L.width[q];
+  }
+  const int64_t n_tiles = (n + OS_TILE - 1) / OS_TILE;
+  BufPtr hist = make_zero_buf((size_t)OS_MAX_PASSES * 256 * 8), bases = make_buf((size_t)OS_MAX_PASSES * 256 * 8);
+  BufPtr tickets = make_zero_buf((size_t)OS_MAX_PASSES * 4);
+  BufPtr state = make_buf((size_t)n_tiles * 256 * 4);
+  {
+    ProfileScope ps("sort_digit_totals", key_col_bytes);
+    k_os_hist<true><<<r.num_cus * 8, BLOCK, 0, r.stream>>>(nullptr, kc, n, div_by(1), dg, hist->as<unsigned long long>());
+    k_os_bases<<<dg.n, BLOCK, 0, r.stream>>>(hist->as<unsigned long long>(), bases->as<unsigned long long>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  BufPtr a0, a1, b0, b1;
+  if (dg.n > 1) {
+    a0 = make_buf((size_t)n * 16 + 64);
+    if (w2) a1 = make_buf((size_t)n * w2 + 64);
+  }
+  if (dg.n > 2) {
+    b0 = make_buf((size_t)n * 16 + 64);
+    if (w2) b1 = make_buf((size_t)n * w2 + 64);
+  }
+  const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)r.num_cus * 4);
+  LsdIo io{};
+  for (int p = 0; p < dg.n; p++) {
+    const bool first = p == 0, last = p == dg.n - 1;
+    if (!last) {
+      const bool to_a = first || io.in0 == b0->as<uint4>();
+      io.out0 = (to_a ? a0 : b0)->as<uint4>();
+      io.out1 = w2 ? (to_a ? a1 : b1)->ptr : nullptr;
+    }
+    ProfileScope ps("sort_lsd_pass", n * (int64_t)((first ? row_bytes : rec_bytes) + (last ? row_bytes : rec_bytes)));
+    DFGPU_HIP(hipMemsetAsync(state->ptr, 0, (size_t)n_tiles * 256 * 4, r.stream));
+    auto launch = [&](auto kern) {
+      kern<<<grid, BLOCK, 0, r.stream>>>(io, kc, L, key_off, n, reverse, dg.shift[p], dg.bits[p], n_tiles, bases->as<unsigned long long>() + p * 256, state->as<uint32_t>(),
+                                         tickets->as<unsigned>() + p, e);
+    };
+    auto pick = [&](auto w2c) {
+      constexpr int W2 = decltype(w2c)::value;
+      if (first && last) launch(k_lsd_pass<true, true, W2>);
+      else if (first) launch(k_lsd_pass<true, false, W2>);
+      else if (last) launch(k_lsd_pass<false, true, W2>);
+      else launch(k_lsd_pass<false, false, W2>);
+    };
+    if (w2 == 0) pick(std::integral_constant<int, 0>{});
+    else if (w2 == 8) pick(std::integral_constant<int, 8>{});
+    else pick(std::integral_constant<int, 16>{});
+    DFGPU_HIP(hipGetLastError());
+    io.in0 = io.out0;
+    io.in1 = io.out1;
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));
+  return true;
+}
+
 static Table sort_table(const Table& in, const std::vector<int>& key_cols, const uint8_t* desc, const uint8_t* nulls_first, int64_t fetch) {
   Runtime& r = rt();
   const int64_t n = in.nrows;
@@ -1454,6 +1793,7 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       }
     }
     // a full sort by one mixed-radix word whose other columns fit a 16-byte record: the onesweep carried sort reads the source columns itself
+    if (!topk && !limited && n_out == n && sort_lsd_carried(in, key_cols, pc, n, out)) return out;
     if (!topk && !limited && narrow && nwords == 1 && n_out == n && sort_carried_onesweep(in, key_cols, pc, n, key_space, out)) return out;
     if (!limited) pack_keys();
     if (topk && !limited) {

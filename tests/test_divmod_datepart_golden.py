@@ -170,8 +170,7 @@ def test_gpu_date_part_column_at_a_time_and_in_the_fused_node(fused):
         g = ops.aggregate(DeviceTable.from_arrow(t2), gb, aggs, "Single", predicate=col("v") > 10).to_arrow()
     finally:
         ops.set_fusion(True)
-        for k, v in saved.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        ops.set_options(jit=None, jit__min_rows=None, jit__strict=None)
     src = oracle.filter(t2, to_oracle_expr(col("v") > 10), t2.column_names)
     assert_agg_equal(g, oracle_agg(src, gb, aggs), ordered=True)
 

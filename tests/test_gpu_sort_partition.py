@@ -230,7 +230,7 @@ def test_sort_carried_records_and_keys_decoded_from_the_packed_key(monkeypatch, 
         t = pa.table({"u": pa.array(rng.integers(2**31, 2**32 - 1, n).astype(np.uint32)), "s": pa.array(rng.integers(-2**31, -2**30, n).astype(np.int32)),
                       "v": pa.array(np.arange(n, dtype=np.int64))})
         keys = [("s", False, False), ("u", True, False)]
-    ops.set_options(sort__carried_min_rows="0")
+    ops.set_options(sort__carried_min_rows="0", sort__lsd="0")   # (narrow keys would take the record passes of the next test)
     ops.set_options(sort__carried={"onesweep": "onesweep", "records_by_row_id": "ids", "records_through_the_passes": "passes"}[mode])
     ops.profile_enable(True)
     ops.profile_reset()
@@ -247,6 +247,60 @@ def test_sort_carried_records_and_keys_decoded_from_the_packed_key(monkeypatch, 
             assert "sort_build_records" in stats and ("radix_sort_pass" in stats) == (shape != "one_bucket"), sorted(stats)
     else:
         assert "sort_local_emit" not in stats, sorted(stats)
+
+
+@pytest.mark.parametrize("shape", ["orders_by_date_then_ascending_key_desc", "orders_by_date_then_ascending_key_asc", "one_pass_u8_key_16_byte_record",
+                                   "three_passes_two_keys_32_byte_record", "key_only_table", "record_too_wide", "key_beyond_32_bits", "nullable_key",
+                                   "ragged_tail_and_ties"])
+def test_sort_narrow_keys_by_record_passes(shape):
+    """the LSD carried sort (sort.hip sort_lsd_carried / k_lsd_pass, round 5): a packed key of at most 32 bits — after dropping a key column that
+    is strictly ascending in input order and everything behind it (ASC: the stable passes keep the input order of ties; DESC: the first
+    pass reads the rows back to front) — is sorted by two to four stable passes over 16 / 24 / 32-byte records that carry the key in
+    their last word; the last pass writes the output columns, key columns decoded from that word.  No bucket sort, no key array, no
+    take.  Same stable order as the oracle position by position; wider records, wider keys and nullable keys are left to the other paths"""
+    from datafusion_amd import ops
+    rng = np.random.default_rng(len(shape) * 11)
+    n = 300_001
+    lsd = True
+    if shape.startswith("orders_by_date"):
+        t = pa.table({"o_orderkey": pa.array(np.cumsum(rng.integers(1, 9, n)).astype(np.int64)), "o_custkey": pa.array(rng.integers(1, 10**6, n)),
+                      "o_orderdate": pa.array(rng.integers(8035, 10441, n).astype(np.int32), pa.int32()).cast(pa.date32()),
+                      "o_shippriority": pa.array(rng.integers(0, 3, n).astype(np.int32))})
+        keys = [("o_orderdate", False, False), ("o_orderkey", shape.endswith("desc"), False)]
+    elif shape == "one_pass_u8_key_16_byte_record":
+        t = pa.table({"c": pa.array(rng.integers(3, 200, n).astype(np.uint8)), "v": pa.array(np.arange(n, dtype=np.int64)), "w": pa.array(rng.integers(0, 2**31, n).astype(np.int32))})
+        keys = [("c", True, False)]
+    elif shape == "three_passes_two_keys_32_byte_record":
+        t = pa.table({"d": pa.array(rng.integers(-3000, 3000, n).astype(np.int32)), "e": pa.array(rng.integers(0, 1500, n)), "x": pa.array(rng.integers(-2**62, 2**62, n)),
+                      "y": pa.array(rng.integers(0, 255, n).astype(np.uint8)), "dec": pa.array([int(v) for v in rng.integers(-10**15, 10**15, n)], pa.decimal128(30, 2))})
+        keys = [("e", False, False), ("d", True, False)]
+    elif shape == "key_only_table":
+        t = pa.table({"a": pa.array(rng.integers(-40000, 40000, n).astype(np.int32)), "b": pa.array(rng.integers(0, 50, n).astype(np.uint8))})
+        keys = [("b", False, False), ("a", False, False)]
+    elif shape == "record_too_wide":
+        t = pa.table({"a": pa.array(rng.integers(0, 4000, n)), "v": pa.array(np.arange(n, dtype=np.int64)), "w": pa.array(rng.integers(0, 9, n)), "x": pa.array(rng.integers(0, 9, n)),
+                      "y": pa.array(rng.integers(0, 9, n))})
+        keys, lsd = [("a", False, False)], False
+    elif shape == "key_beyond_32_bits":
+        t = pa.table({"a": pa.array(rng.integers(0, 2**33, n)), "v": pa.array(np.arange(n, dtype=np.int64))})
+        keys, lsd = [("a", False, False)], False
+    elif shape == "nullable_key":
+        t = pa.table({"a": pa.array(rng.integers(0, 4000, n), mask=rng.random(n) < 0.01), "v": pa.array(np.arange(n, dtype=np.int64))})
+        keys, lsd = [("a", False, True)], False
+    else:
+        n = 2048 * 5 + 3
+        t = pa.table({"a": pa.array(rng.integers(0, 5, n)), "v": pa.array(np.arange(n, dtype=np.int64)), "row": pa.array(np.arange(n, dtype=np.int64) * 3)})
+        keys = [("a", True, False), ("row", True, False), ("v", False, False)]
+    ops.set_options(sort__carried_min_rows="0")
+    ops.profile_enable(True)
+    ops.profile_reset()
+    run_sort(t, keys)
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    if lsd:
+        assert "sort_lsd_pass" in stats and not {"sort_local_emit", "sort_onesweep_pass", "radix_sort_pass", "sort_pack_keys", "gather", "take_gather_rows"} & set(stats), sorted(stats)
+    else:
+        assert "sort_lsd_pass" not in stats, sorted(stats)
 
 
 def test_sort_and_joins_move_boolean_payload_columns():
