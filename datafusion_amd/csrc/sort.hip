@@ -480,6 +480,130 @@ struct OsDigits {
 __device__ __forceinline__ uint32_t os_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void os_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// A tile's keys and records read off the SOURCE columns, column by column: the loads of all of a lane's rows from one column are in
+// flight together (the row-by-row form — pack_key64 / record_build per row — walks the column list once per row, every load behind a
+// uniform branch of its own: the first pass of the carried sorts spent 2.5 ms there for 3.6 GB).  Key columns without NULLs only (what
+// the carried sorts take).
+template <int ITEMS, typename K>   // (K = uint32_t where the whole key fits 32 bits: half the registers)
+__device__ __forceinline__ void tile_keys(const PackCols& pc, const uint32_t (&src)[ITEMS], K (&key)[ITEMS]) {
+#pragma unroll
+  for (int c = 0; c < ITEMS; c++) key[c] = 0;
+  for (int k = 0; k < pc.n; k++) {
+    const PackCol& col = pc.c[k];
+    uint64_t t[ITEMS];
+    switch (col.type) {
+      case DFGPU_INT32: case DFGPU_DATE32:
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) t[c] = (uint64_t)(reinterpret_cast<const uint32_t*>(col.data)[src[c]] ^ 0x80000000u);
+        break;
+      case DFGPU_UINT32:
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) t[c] = (uint64_t)reinterpret_cast<const uint32_t*>(col.data)[src[c]];
+        break;
+      case DFGPU_INT64:
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) t[c] = reinterpret_cast<const uint64_t*>(col.data)[src[c]] ^ 0x8000000000000000ull;
+        break;
+      case DFGPU_UINT64:
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) t[c] = reinterpret_cast<const uint64_t*>(col.data)[src[c]];
+        break;
+      default:
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) t[c] = (uint64_t)reinterpret_cast<const uint8_t*>(col.data)[src[c]];
+        break;
+    }
+    const uint64_t base = col.base_lo, mult = col.mult;
+    const bool desc = col.desc != 0;
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) key[c] += (K)((desc ? base - t[c] : t[c] - base) * mult);
+  }
+}
+template <int ITEMS, int NS>
+__device__ __forceinline__ void tile_records(const PackLayout& L, const uint32_t (&src)[ITEMS], uint64_t (&sl)[ITEMS][NS]) {
+#pragma unroll
+  for (int c = 0; c < ITEMS; c++)
+#pragma unroll
+    for (int q = 0; q < NS; q++) sl[c][q] = 0;
+  for (int f = 0; f < L.n; f++) {
+    const int o = L.offset[f];
+    switch (L.width[f]) {
+      case 16: {
+        uint4 v[ITEMS];
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) {
+          const uint4 u = reinterpret_cast<const uint4*>(L.src[f])[src[c]];
+          v[c] = uint4{u.x, u.y, u.z, u.w};
+        }
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) {
+          slot_or<NS>(sl[c], o >> 3, ((uint64_t)v[c].y << 32) | v[c].x);
+          slot_or<NS>(sl[c], (o >> 3) + 1, ((uint64_t)v[c].w << 32) | v[c].z);
+        }
+        break;
+      }
+      case 8: {
+        uint64_t v[ITEMS];
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) v[c] = reinterpret_cast<const uint64_t*>(L.src[f])[src[c]];
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) slot_or<NS>(sl[c], o >> 3, v[c]);
+        break;
+      }
+      case 4: {
+        uint32_t v[ITEMS];
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) v[c] = reinterpret_cast<const uint32_t*>(L.src[f])[src[c]];
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) slot_or<NS>(sl[c], o >> 3, (uint64_t)v[c] << ((o & 4) * 8));
+        break;
+      }
+      default: {
+        uint8_t v[ITEMS];
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) v[c] = reinterpret_cast<const uint8_t*>(L.src[f])[src[c]];
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) slot_or<NS>(sl[c], o >> 3, (uint64_t)v[c] << ((o & 7) * 8));
+        break;
+      }
+    }
+  }
+}
+
+// The look-back of digit `d` for tile t: the sum of the digit's counts over the tiles before t — nearest first, AGG words added up until
+// an inclusive prefix (PFX) is met.  OS_LB predecessors are read at once: an agent-scope load is a round trip to the memory side of the
+// fabric (no XCD's L2 may answer it), a microsecond, and tiles retire every few tens of nanoseconds — one word per round trip cannot keep
+// up with that and the tiles queue behind their look-backs (measured: 0.6-0.9 ms of a 2-2.6 ms pass; profiles/r5_sort_phases.md).
+constexpr int OS_LB = 8;
+__device__ __forceinline__ unsigned os_look_back(const uint32_t* tile_state, int64_t t, unsigned d) {
+  unsigned excl = 0;
+  int64_t p = t - 1;
+  bool done = t == 0;
+  while (!done) {
+    uint32_t st[OS_LB];
+#pragma unroll
+    for (int u = 0; u < OS_LB; u++) st[u] = p - u >= 0 ? os_load(&tile_state[(p - u) * 256 + d]) : OS_PFX;
+    int adv = 0;
+    bool stop = false;
+#pragma unroll
+    for (int u = 0; u < OS_LB; u++) {
+      const uint32_t status = st[u] >> 30;
+      if (!stop) {
+        if (status == 0) {
+          stop = true;   // not published yet: read again from here
+        } else {
+          excl += st[u] & OS_VAL;
+          adv++;
+          if (status == 2) done = stop = true;
+        }
+      }
+    }
+    p -= adv;
+    if (!done && adv == 0) __builtin_amdgcn_s_sleep(1);
+  }
+  return excl;
+}
+
 // digit totals of every pass: hist[pass * 256 + digit].  BUILD: the keys are computed from the key columns (no packed key array exists)
 template <bool BUILD>
 __global__ __launch_bounds__(BLOCK) void k_os_hist(const uint64_t* __restrict__ key_in, PackCols pc, int64_t n, DivBy dv, OsDigits dg, unsigned long long* __restrict__ hist) {
@@ -519,7 +643,7 @@ __global__ __launch_bounds__(BLOCK) void k_os_bases(const unsigned long long* __
 }
 
 template <bool BUILD>
-__global__ __launch_bounds__(BLOCK, 4) void k_os_pass(const uint64_t* __restrict__ key_in, const uint4* __restrict__ rec_in, PackCols pc, PackLayout L, int64_t n, DivBy dv, int shift,
+__global__ __launch_bounds__(BLOCK, (BUILD ? 3 : 4)) void k_os_pass(const uint64_t* __restrict__ key_in, const uint4* __restrict__ rec_in, PackCols pc, PackLayout L, int64_t n, DivBy dv, int shift,
                                                      int bits, int64_t n_tiles, const unsigned long long* __restrict__ bin_base, uint32_t* __restrict__ tile_state,
                                                      unsigned* __restrict__ ticket, uint64_t* __restrict__ key_out, uint4* __restrict__ rec_out) {
   constexpr int NWAVE = BLOCK / WAVE;
@@ -547,16 +671,23 @@ __global__ __launch_bounds__(BLOCK, 4) void k_os_pass(const uint64_t* __restrict
     uint64_t key[OS_ITEMS];
     uint4 rec[OS_ITEMS];
     unsigned dig[OS_ITEMS], rank[OS_ITEMS];
+    if (BUILD) {   // (column by column: tile_keys)
+      uint32_t src[OS_ITEMS];   // (row numbers below 2^30)
 #pragma unroll
-    for (int c = 0; c < OS_ITEMS; c++) {  // all loads of the wave's segment in flight together
-      const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
-      const int64_t src = lo + (j < tile_rows ? j : 0);
-      if (BUILD) {
-        key[c] = pack_key64(pc, src);
-        uint64_t sl[2];
-        record_build<2>(L, src, sl);
-        rec[c] = uint4{(unsigned)sl[0], (unsigned)(sl[0] >> 32), (unsigned)sl[1], (unsigned)(sl[1] >> 32)};
-      } else {
+      for (int c = 0; c < OS_ITEMS; c++) {
+        const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
+        src[c] = (uint32_t)(lo + (j < tile_rows ? j : 0));
+      }
+      tile_keys<OS_ITEMS, uint64_t>(pc, src, key);
+      uint64_t sl[OS_ITEMS][2];
+      tile_records<OS_ITEMS, 2>(L, src, sl);
+#pragma unroll
+      for (int c = 0; c < OS_ITEMS; c++) rec[c] = uint4{(unsigned)sl[c][0], (unsigned)(sl[c][0] >> 32), (unsigned)sl[c][1], (unsigned)(sl[c][1] >> 32)};
+    } else {
+#pragma unroll
+      for (int c = 0; c < OS_ITEMS; c++) {  // all loads of the wave's segment in flight together
+        const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
+        const int64_t src = lo + (j < tile_rows ? j : 0);
         key[c] = key_in[src];
         const uint4 v = rec_in[src];   // (component by component: the 16-byte struct copy kept the whole array in scratch memory)
         rec[c] = uint4{v.x, v.y, v.z, v.w};
@@ -609,21 +740,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_os_pass(const uint64_t* __restrict
     }
     // ---- look-back: thread d adds up digit d's counts over the tiles before this one, nearest first, until it meets an inclusive prefix
     if (threadIdx.x <= mask) {
-      unsigned excl = 0;
-      if (t > 0) {
-        int64_t p = t - 1;
-        for (;;) {
-          const uint32_t st = os_load(&tile_state[p * 256 + threadIdx.x]);
-          const uint32_t status = st >> 30;
-          if (status == 0) {
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-          }
-          excl += st & OS_VAL;
-          if (status == 2) break;
-          p--;
-        }
-      }
+      const unsigned excl = os_look_back(tile_state, t, threadIdx.x);
       os_store(&tile_state[t * 256 + threadIdx.x], OS_PFX | (excl + run));
       s_goff[threadIdx.x] = (unsigned)bin_base[threadIdx.x] + excl - (unsigned)s_start[threadIdx.x];
     }
@@ -888,7 +1005,7 @@ __device__ __forceinline__ void lsd_emit_keys(const SortEmit& emit, uint32_t key
 __device__ __forceinline__ uint32_t word_of(const uint4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 // W2: bytes of the record's second slice (0, 8 or 16); key_off: byte offset of the key word inside the record
 template <bool BUILD, bool EMIT, int W2>
-__global__ __launch_bounds__(BLOCK, (W2 == 0 ? 4 : 3)) void k_lsd_pass(LsdIo io, PackCols pc, PackLayout L, int key_off, int64_t n, int reverse, int shift, int bits,
+__global__ __launch_bounds__(BLOCK, (BUILD ? (W2 == 0 ? 3 : 2) : (W2 == 0 ? 4 : 3))) void k_lsd_pass(LsdIo io, PackCols pc, PackLayout L, int key_off, int64_t n, int reverse, int shift, int bits,
                                                                        int64_t n_tiles, const unsigned long long* __restrict__ bin_base, uint32_t* __restrict__ tile_state,
                                                                        unsigned* __restrict__ ticket, SortEmit emit) {
   constexpr int NWAVE = BLOCK / WAVE;
@@ -915,19 +1032,32 @@ __global__ __launch_bounds__(BLOCK, (W2 == 0 ? 4 : 3)) void k_lsd_pass(LsdIo io,
     const int tile_rows = (int)((n - lo) < OS_TILE ? (n - lo) : OS_TILE);
     uint4 rec0[OS_ITEMS], rec1[OS_ITEMS];
     unsigned dig[OS_ITEMS], rank[OS_ITEMS];
+    if (BUILD) {   // (column by column: tile_keys)
+      uint32_t src[OS_ITEMS];   // (row numbers below 2^30)
+#pragma unroll
+      for (int c = 0; c < OS_ITEMS; c++) {
+        const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
+        const int64_t row = lo + (j < tile_rows ? j : 0);
+        src[c] = (uint32_t)(reverse ? n - 1 - row : row);   // (position `row` of the order the stable passes see)
+      }
+      uint32_t key[OS_ITEMS];
+      tile_keys<OS_ITEMS, uint32_t>(pc, src, key);
+      uint64_t sl[OS_ITEMS][NS];
+      tile_records<OS_ITEMS, NS>(L, src, sl);
+#pragma unroll
+      for (int c = 0; c < OS_ITEMS; c++) {
+        slot_or<NS>(sl[c], key_off >> 3, (uint64_t)key[c] << ((key_off & 4) * 8));
+        rec0[c] = uint4{(unsigned)sl[c][0], (unsigned)(sl[c][0] >> 32), (unsigned)sl[c][1], (unsigned)(sl[c][1] >> 32)};
+        rec1[c] = uint4{0u, 0u, 0u, 0u};
+        if (W2) rec1[c] = uint4{(unsigned)sl[c][NS - 2], (unsigned)(sl[c][NS - 2] >> 32), (unsigned)sl[c][NS - 1], (unsigned)(sl[c][NS - 1] >> 32)};
+      }
+    }
 #pragma unroll
     for (int c = 0; c < OS_ITEMS; c++) {   // all loads of the wave's segment in flight together
       const int j = (wave * OS_ITEMS + c) * WAVE + (int)lane;
       const int64_t row = lo + (j < tile_rows ? j : 0);
-      rec1[c] = uint4{0u, 0u, 0u, 0u};
-      if (BUILD) {
-        const int64_t src = reverse ? n - 1 - row : row;   // (position `row` of the order the stable passes see)
-        uint64_t sl[NS];
-        record_build<NS>(L, src, sl);
-        slot_or<NS>(sl, key_off >> 3, (uint64_t)(uint32_t)pack_key64(pc, src) << ((key_off & 4) * 8));
-        rec0[c] = uint4{(unsigned)sl[0], (unsigned)(sl[0] >> 32), (unsigned)sl[1], (unsigned)(sl[1] >> 32)};
-        if (W2) rec1[c] = uint4{(unsigned)sl[NS - 2], (unsigned)(sl[NS - 2] >> 32), (unsigned)sl[NS - 1], (unsigned)(sl[NS - 1] >> 32)};
-      } else {
+      if (!BUILD) {
+        rec1[c] = uint4{0u, 0u, 0u, 0u};
         const uint4 v = io.in0[row];   // (component by component: a 16-byte struct copy kept the whole array in scratch memory)
         rec0[c] = uint4{v.x, v.y, v.z, v.w};
         if (W2 == 16) {
@@ -987,21 +1117,7 @@ __global__ __launch_bounds__(BLOCK, (W2 == 0 ? 4 : 3)) void k_lsd_pass(LsdIo io,
     }
     // ---- look-back (k_os_pass): thread d adds up digit d's counts over the tiles before this one until it meets an inclusive prefix
     if (threadIdx.x <= mask) {
-      unsigned excl = 0;
-      if (t > 0) {
-        int64_t p = t - 1;
-        for (;;) {
-          const uint32_t st = os_load(&tile_state[p * 256 + threadIdx.x]);
-          const uint32_t status = st >> 30;
-          if (status == 0) {
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-          }
-          excl += st & OS_VAL;
-          if (status == 2) break;
-          p--;
-        }
-      }
+      const unsigned excl = os_look_back(tile_state, t, threadIdx.x);
       os_store(&tile_state[t * 256 + threadIdx.x], OS_PFX | (excl + run));
       s_goff[threadIdx.x] = (unsigned)bin_base[threadIdx.x] + excl - (unsigned)s_start[threadIdx.x];
     }
@@ -1536,7 +1652,7 @@ static bool sort_lsd_carried(const Table& in, const std::vector<int>& key_cols, 
   const int n_pass = (total_bits + 7) / 8;
   if (n_pass > OS_MAX_PASSES) return false;
   OsDigits dg{};
-  for (int p = 0, pos = 0; p < n_pass; p++) {   // digits of (nearly) equal width: 12 bits = 6 + 6
+  for (int p = 0, pos = 0; p < n_pass; p++) {   // digits of (nearly) equal width: 12 bits = 6 + 6 (8 + 4, 4 + 8, 7 + 5 measured within 5 % of it)
     const int b = (total_bits - pos + (n_pass - p) - 1) / (n_pass - p);
     dg.shift[p] = pos;
     dg.bits[p] = b;
@@ -1615,7 +1731,7 @@ static bool sort_lsd_carried(const Table& in, const std::vector<int>& key_cols, 
       io.out0 = (to_a ? a0 : b0)->as<uint4>();
       io.out1 = w2 ? (to_a ? a1 : b1)->ptr : nullptr;
     }
-    ProfileScope ps("sort_lsd_pass", n * (int64_t)((first ? row_bytes : rec_bytes) + (last ? row_bytes : rec_bytes)));
+    ProfileScope ps(last ? "sort_lsd_pass_out" : "sort_lsd_pass", n * (int64_t)((first ? row_bytes : rec_bytes) + (last ? row_bytes : rec_bytes)));
     DFGPU_HIP(hipMemsetAsync(state->ptr, 0, (size_t)n_tiles * 256 * 4, r.stream));
     auto launch = [&](auto kern) {
       kern<<<grid, BLOCK, 0, r.stream>>>(io, kc, L, key_off, n, reverse, dg.shift[p], dg.bits[p], n_tiles, bases->as<unsigned long long>() + p * 256, state->as<uint32_t>(),

@@ -298,9 +298,9 @@ def test_sort_narrow_keys_by_record_passes(shape):
     stats = ops.profile_stats()
     ops.profile_enable(False)
     if lsd:
-        assert "sort_lsd_pass" in stats and not {"sort_local_emit", "sort_onesweep_pass", "radix_sort_pass", "sort_pack_keys", "gather", "take_gather_rows"} & set(stats), sorted(stats)
+        assert "sort_lsd_pass_out" in stats and not {"sort_local_emit", "sort_onesweep_pass", "radix_sort_pass", "sort_pack_keys", "gather", "take_gather_rows"} & set(stats), sorted(stats)
     else:
-        assert "sort_lsd_pass" not in stats, sorted(stats)
+        assert "sort_lsd_pass_out" not in stats, sorted(stats)
 
 
 def test_sort_and_joins_move_boolean_payload_columns():
