@@ -496,3 +496,94 @@ def test_scan_in_one_call_thread_counts_cache_hits_and_a_corrupt_chunk(tmp_path)
     finally:
         P.CACHE.clear()
         P.CACHE = saved
+
+
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+@pytest.mark.parametrize("compression", ["none", "snappy", "snappy_on_the_device", "zstd"])
+def test_pages_decoded_on_the_device(tmp_path, compression, version):
+    """the device half of the scan (parquet.hip k_pq_decompress / k_pq_levels / k_pq_decode_pages, round 5): for fixed-width targets the host
+    reads the page headers and — for ZSTD, and for Snappy by default — undoes the compression straight into the upload buffer; the definition
+    levels' runs, the dictionary indices' runs, DELTA_BINARY_PACKED and BYTE_STREAM_SPLIT are decoded by kernels, and with
+    parquet.snappy=device the file's bytes cross PCIe as they are and Snappy is decoded by a wave per page as well — 1 MiB pages with the
+    shapes a Snappy stream takes: long literals (random data), short and OVERLAPPING copies (constant and periodic columns), copies
+    reaching back further than the 32 KB ring the decoder keeps in LDS (a 40 KB period), NULLs in runs and scattered.  Bit for bit
+    pyarrow's reading of the same file; the same table through the host path (parquet.device_decode = 0); the profile shows which kernels ran"""
+    from datafusion_amd import ops
+    from datafusion_amd.parquet import read_table
+    rng = np.random.default_rng(5)
+    n = 400_000
+    period = rng.integers(0, 2**60, 5000)                                 # 40 KB of int64: a copy source behind the ring
+    runs = np.repeat(rng.integers(0, 50, n // 1000 + 1), 1000)[:n]
+    null_runs = np.repeat(rng.random(n // 700 + 1) < 0.3, 700)[:n]
+    t = pa.table({
+        "random64": pa.array(rng.integers(-2**62, 2**62, n)),
+        "constant": pa.array(np.full(n, 123456789, dtype=np.int64)),
+        "periodic": pa.array(period[np.arange(n) % 5000]),
+        "short_period": pa.array((np.arange(n) % 7).astype(np.int32)),
+        "runs_dict": pa.array(runs.astype(np.int32)),
+        "date": pa.array((8000 + np.arange(n) // 97).astype(np.int32), pa.int32()).cast(pa.date32()),
+        "f64": pa.array(np.round(rng.random(n) * 100, 2)),
+        "null_runs": pa.array(rng.integers(0, 1000, n), mask=null_runs),
+        "null_scattered": pa.array(rng.integers(0, 10**9, n).astype(np.int32), mask=rng.random(n) < 0.2),
+        "delta": pa.array(np.cumsum(rng.integers(-5, 1000, n))),
+        "bss": pa.array(rng.random(n)),
+        "s": pa.array(np.array(["alpha", "beta", "gamma", "delta", None], dtype=object)[rng.integers(0, 5, n)], pa.string()),
+    })
+    path = str(tmp_path / "p.parquet")
+    on_device = compression == "snappy_on_the_device"
+    compression = "snappy" if on_device else compression
+    if on_device:
+        ops.set_options(parquet__snappy="device")
+    pq.write_table(t, path, compression=compression, data_page_version=version, row_group_size=250_000, data_page_size=1 << 20,
+                   use_dictionary=["runs_dict", "short_period", "s", "null_runs", "date"], column_encoding={"delta": "DELTA_BINARY_PACKED", "bss": "BYTE_STREAM_SPLIT"})
+    exp = pq.read_table(path)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = read_table(path).to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert_tables_equal(plain(got), exp, ordered=True)
+    assert "parquet_levels" in stats and "parquet_decode_pages" in stats and "parquet_decode" not in stats, sorted(stats)
+    assert ("parquet_decompress_pages" in stats) == on_device, sorted(stats)
+    ops.set_options(parquet__device_decode="0")
+    from datafusion_amd import parquet as P
+    P.CACHE.clear()   # (the second scan is to decode, not to be served from the device chunk cache)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    host = read_table(path).to_arrow()
+    stats = ops.profile_stats()
+    ops.profile_enable(False)
+    assert_tables_equal(plain(host), exp, ordered=True)
+    assert "parquet_decompress_pages" not in stats and "parquet_decode" in stats, sorted(stats)
+
+
+@pytest.mark.parametrize("compression", ["none", "snappy"])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_device_page_decode_survives_corrupt_pages(tmp_path, compression, seed):
+    """a column chunk with a stretch of its bytes overwritten — Snappy elements that copy from before the start of the output or end early,
+    level lengths and run headers that overrun their page, indices beyond the dictionary: the device path either reports an error or
+    decodes what the bytes now say (Parquet pages carry no checksum the readers verify); it never hangs and never writes out of bounds"""
+    from datafusion_amd.parquet import ParquetFile
+    rng = np.random.default_rng(seed)
+    n = 60_000
+    t = pa.table({"a": pa.array(np.repeat(rng.integers(0, 9, n // 50), 50).astype(np.int64), mask=np.repeat(rng.random(n // 50) < 0.2, 50)),
+                  "b": pa.array(rng.integers(0, 1000, n))})
+    path = str(tmp_path / "c.parquet")
+    if compression == "snappy":
+        from datafusion_amd import ops
+        ops.set_options(parquet__snappy="device")   # (the Snappy stream is decoded by the kernel: its bounds checks are what is tested)
+    pq.write_table(t, path, compression=compression, use_dictionary=["a"], data_page_size=64 * 1024, data_page_version="2.0" if seed % 2 else "1.0")
+    raw = bytearray(open(path, "rb").read())
+    for ci in range(2):
+        md = pq.ParquetFile(path).metadata.row_group(0).column(ci)
+        start = md.dictionary_page_offset if md.dictionary_page_offset else md.data_page_offset
+        at = start + 30 + int(rng.integers(0, max(1, md.total_compressed_size - 120)))   # (behind the first page header)
+        raw[at: at + 40] = bytes(rng.choice([0xFF, 0xFE, 0x7F, 0x01, 0xF3], 40).astype(np.uint8))
+    open(path, "wb").write(bytes(raw))
+    try:
+        f = ParquetFile(path)
+        got = f.read(["a", "b"]).to_arrow()
+    except Exception as e:   # noqa: BLE001
+        assert "parquet" in str(e) or "Parquet" in str(e), str(e)
+    else:
+        assert got.num_rows == n
