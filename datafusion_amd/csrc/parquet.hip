@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(BLOCK) void k_pq_decode_pages(PqDevArgs a, T* __res
           const int64_t left = n - d;
           if (h & 1) {
             const uint64_t groups = h >> 1;
-            if (groups == 0 || groups > (uint64_t)INT32_MAX || (bw && groups > (uint64_t)(vbytes - wbase - pos) / (uint64_t)bw)) { err = PQE_RUNS; break; }
+            if (groups == 0 || groups > (uint64_t)INT32_MAX || groups * (uint64_t)bw > (uint64_t)(vbytes - wbase - pos)) { err = PQE_RUNS; break; }   // (no overflow: 2^31 x 32)
             s_start[nr] = d;
             s_pay[nr] = wbase + pos;
             s_bw[nr] = bw | RUN_PACKED;
@@ -1395,16 +1395,41 @@ __global__ __launch_bounds__(BLOCK) void k_pq_decode_pages(PqDevArgs a, T* __res
       const int nr = s_n;
       const int64_t batch_end = s_batch_end;
       if (!s_err) {
-        for (int64_t v = done + tid; v < batch_end; v += BLOCK) {
+        // eight consecutive values per thread: one search for the run, one 64-bit window of packed bits (a group of eight indices of up to
+        // 7 bits), eight look-ups, 8 x sizeof(T) contiguous bytes stored
+        const uint64_t mask = bw == 32 ? 0xFFFFFFFFull : ((1ull << bw) - 1);
+        for (int64_t v0 = done + (int64_t)tid * 8; v0 < batch_end; v0 += (int64_t)BLOCK * 8) {
           int lo = 0, hi = nr - 1;
           while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (s_start[mid] <= v) lo = mid; else hi = mid - 1;
+            if (s_start[mid] <= v0) lo = mid; else hi = mid - 1;
           }
-          uint32_t idx;
-          if (s_bw[lo] < 0) idx = (uint32_t)pq_unpack64(vals + s_pay[lo], (uint64_t)(v - s_start[lo]) * (uint64_t)bw, bw);
-          else idx = (uint32_t)s_pay[lo];
-          o[v] = dict_value(idx);
+          const int64_t vend = v0 + 8 < batch_end ? v0 + 8 : batch_end;
+          for (int64_t v = v0; v < vend;) {
+            while (lo + 1 < nr && s_start[lo + 1] <= v) lo++;
+            const int64_t rend = lo + 1 < nr ? s_start[lo + 1] : batch_end;
+            const int take = (int)((vend < rend ? vend : rend) - v);
+            if (s_bw[lo] < 0) {
+              const uint64_t bit = (uint64_t)(v - s_start[lo]) * (uint64_t)bw;
+              if (take * bw + (int)(bit & 7) <= 64) {
+                const uint8_t* q = vals + s_pay[lo] + (bit >> 3);
+                uint64_t w = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) w |= (uint64_t)q[i] << (8 * i);
+                w >>= (bit & 7);
+                for (int j = 0; j < take; j++) {
+                  o[v + j] = dict_value((uint32_t)(w & mask));
+                  w >>= bw;
+                }
+              } else {
+                for (int j = 0; j < take; j++) o[v + j] = dict_value((uint32_t)pq_unpack64(vals + s_pay[lo], bit + (uint64_t)j * (uint64_t)bw, bw));
+              }
+            } else {
+              const T val = dict_value((uint32_t)s_pay[lo]);
+              for (int j = 0; j < take; j++) o[v + j] = val;
+            }
+            v += take;
+          }
         }
       }
       done = batch_end;
