@@ -223,7 +223,9 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter(PartCols cols, const uin
 // — no count pass, the tile hashes its keys and claims its range in every partition's slack-sized region with one atomic — was
 // measured as well: 11.4-12.0 ms against 11.9-13.0 ms for the two passes in the same runs: the scatter with the hash folded in
 // costs what both passes cost, so the deterministic two-pass placement stays.)
-template <int NPK>  // nparts <= 4 * NPK
+// KT: one key column of that type without NULLs — the 4 x (PT_ITEMS / 4) keys of a thread are loaded before any is hashed (hash_row
+// walks the column list per row and waits on every load: device.hpp; 1.44 -> ms for 600 M Int64 keys); KT_ANY = any key set
+template <int NPK, int KT = KT_ANY>  // nparts <= 4 * NPK
 __global__ __launch_bounds__(BLOCK) void k_part_count2(KeySet ks, int64_t n, int nparts, FastMod fm, int64_t n_tiles, uint8_t* __restrict__ part,
                                                        uint32_t* __restrict__ counts) {
   __shared__ unsigned int s_cnt[BLOCK / WAVE][4 * NPK];
@@ -234,6 +236,15 @@ __global__ __launch_bounds__(BLOCK) void k_part_count2(KeySet ks, int64_t n, int
     uint64_t acc[NPK];
 #pragma unroll
     for (int q = 0; q < NPK; q++) acc[q] = 0;
+    uint64_t kv[PT_ITEMS];
+    if (KT != KT_ANY) {
+#pragma unroll
+      for (int c = 0; c < PT_ITEMS / 4; c++) {
+        const int64_t i0 = lo + ((int64_t)c * BLOCK + threadIdx.x) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) kv[c * 4 + k] = load_key<KT>(ks.c[0], i0 + k < n ? i0 + k : n - 1);
+      }
+    }
 #pragma unroll
     for (int c = 0; c < PT_ITEMS / 4; c++) {
       const int64_t i0 = lo + ((int64_t)c * BLOCK + threadIdx.x) * 4;
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_count2(KeySet ks, int64_t n, int
       for (int k = 0; k < 4; k++) {
         if (i0 + k < n) {
           bool any_null;
-          const unsigned p = fastmod_u64(hash_row(ks, i0 + k, SEED_REPARTITION, any_null), fm);
+          const unsigned p = fastmod_u64(KT != KT_ANY ? hash_u64(kv[c * 4 + k], SEED_REPARTITION) : hash_row(ks, i0 + k, SEED_REPARTITION, any_null), fm);
           packed |= p << (8 * k);
           const uint64_t inc = 1ull << ((p & 3u) * 16);
 #pragma unroll
@@ -452,8 +463,21 @@ static std::vector<Table> partition_table_fixed_keys(const Table& in, const std:
   {
     ProfileScope ps("partition_count", key_bytes + n);
     if (!gen2) k_part_count<<<tile_grid, BLOCK, 0, r.stream>>>(ks, n, nparts, fm, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>());
-    else if (nparts <= 8) k_part_count2<2><<<tile_grid, BLOCK, 0, r.stream>>>(ks, n, nparts, fm, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>());
-    else k_part_count2<4><<<tile_grid, BLOCK, 0, r.stream>>>(ks, n, nparts, fm, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>());
+    else {
+      // one integer key column without NULLs: the typed kernel
+      int kt = KT_ANY;
+      if (ks.n == 1 && !ks.c[0].valid) kt = ks.c[0].type == DFGPU_INT64 || ks.c[0].type == DFGPU_UINT64 ? KT_I64 : ks.c[0].type == DFGPU_INT32 || ks.c[0].type == DFGPU_DATE32 ? KT_I32 : KT_ANY;
+      auto launch = [&](auto kern) { kern<<<tile_grid, BLOCK, 0, r.stream>>>(ks, n, nparts, fm, n_tiles, part->as<uint8_t>(), counts->as<uint32_t>()); };
+      if (nparts <= 8) {
+        if (kt == KT_I64) launch(k_part_count2<2, KT_I64>);
+        else if (kt == KT_I32) launch(k_part_count2<2, KT_I32>);
+        else launch(k_part_count2<2, KT_ANY>);
+      } else {
+        if (kt == KT_I64) launch(k_part_count2<4, KT_I64>);
+        else if (kt == KT_I32) launch(k_part_count2<4, KT_I32>);
+        else launch(k_part_count2<4, KT_ANY>);
+      }
+    }
     DFGPU_HIP(hipGetLastError());
   }
   scan_u32(counts->as<uint32_t>(), (int64_t)nparts * n_tiles, prefix->as<uint64_t>());

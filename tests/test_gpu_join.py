@@ -730,3 +730,55 @@ def test_build_speculates_on_ascending_keys_and_verifies_while_it_builds(flaw):
     got = sorted(zip(out.column("row").to_pylist(), out.column("v").to_pylist()))
     assert got == exp
     assert bool(info.build_keys_unique) == (flaw != "duplicate")
+
+
+@pytest.mark.parametrize("shape", ["dense_unique_int64", "two_column_duplicates", "sparse_int64_with_duplicates"])
+def test_auto_takes_a_table_kind_within_reach_of_the_fastest(shape):
+    """`auto` (table_mode 0) against every table kind that applies to the shape — chained (1), ArrayMap (2), rank map (3), LDS radix (4),
+    flat (5) — build + probe timed on the device, best of five after a warm-up: what `auto` takes may not be more than 25 % (and 0.3 ms)
+    slower than the fastest forced kind.  4 M-row builds against 16 M-row probes: tables beyond an XCD's L2, where the kinds differ.
+    The dispatch thresholds were tuned on the benchmark shapes (profiles/r4_join_shapes_final.md); this is what keeps them honest"""
+    import time
+
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(len(shape))
+    nb, npr = 4_000_000, 16_000_000
+    if shape == "dense_unique_int64":
+        build = pa.table({"k": pa.array(rng.permutation(nb).astype(np.int64)), "v": pa.array(np.arange(nb, dtype=np.int64))})
+        probe = pa.table({"k": pa.array(rng.integers(0, nb, npr)), "w": pa.array(np.arange(npr, dtype=np.int64))})
+        on, kinds = ["k"], [1, 2, 3, 5]
+    elif shape == "two_column_duplicates":
+        build = pa.table({"a": pa.array(rng.integers(0, 2000, nb).astype(np.int32)), "b": pa.array(rng.integers(0, 1000, nb)), "v": pa.array(np.arange(nb, dtype=np.int64))})
+        probe = pa.table({"a": pa.array(rng.integers(0, 2000, npr).astype(np.int32)), "b": pa.array(rng.integers(0, 1000, npr)), "w": pa.array(np.arange(npr, dtype=np.int64))})
+        on, kinds = ["a", "b"], [1, 4, 5]
+    else:
+        build = pa.table({"k": pa.array(rng.integers(0, 2**40, nb // 2).repeat(2)), "v": pa.array(np.arange(nb, dtype=np.int64))})
+        probe = pa.table({"k": pa.array(np.concatenate([build.column("k").to_numpy()[rng.integers(0, nb, npr // 2)], rng.integers(0, 2**40, npr // 2)])),
+                          "w": pa.array(np.arange(npr, dtype=np.int64))})
+        on, kinds = ["k"], [1, 4, 5]
+    b, p = DeviceTable.from_arrow(build), DeviceTable.from_arrow(probe)
+
+    def run(mode):
+        best, rows = None, None
+        for it in range(6):
+            ops.sync()
+            t0 = time.perf_counter()
+            jt = ops.JoinHashTable(b, on, table_mode=mode, probe_mode=4)
+            out = jt.probe(p, on, "Inner", build_cols=["v"], probe_cols=["w"])
+            ops.sync()
+            dt = time.perf_counter() - t0
+            rows = out.num_rows
+            out.free()
+            jt.free() if hasattr(jt, "free") else None
+            if it and (best is None or dt < best):
+                best = dt
+        return best, rows
+
+    t_auto, rows_auto = run(0)
+    forced = {}
+    for m in kinds:
+        forced[m], rows = run(m)
+        assert rows == rows_auto, (shape, m, rows, rows_auto)
+    fastest = min(forced.values())
+    assert t_auto <= fastest * 1.25 + 0.3e-3, {"shape": shape, "auto_ms": round(t_auto * 1e3, 3), "forced_ms": {m: round(t * 1e3, 3) for m, t in forced.items()}}
