@@ -400,6 +400,9 @@ __global__ __launch_bounds__(BLOCK) void k_part_mask(const uint8_t* __restrict__
 }
 
 static std::vector<Table> partition_table_fixed_keys(const Table& in, const std::vector<int>& key_cols, int nparts);
+__global__ void k_part_bounds(const uint64_t* __restrict__ prefix, int64_t n_tiles, int nparts, uint64_t* __restrict__ bounds) {
+  if ((int)threadIdx.x < nparts) bounds[threadIdx.x] = prefix[(int64_t)threadIdx.x * n_tiles];
+}
 // String keys (Utf8 bytes or dictionary-encoded) are routed on a hash of their BYTES (strings.hip string_hash_column), carried as an
 // extra column behind the caller's columns through the partitioning and dropped from the partitions: indices of a dictionary mean
 // nothing across tables, calls or ranks.
@@ -481,12 +484,16 @@ static std::vector<Table> partition_table_fixed_keys(const Table& in, const std:
     DFGPU_HIP(hipGetLastError());
   }
   scan_u32(counts->as<uint32_t>(), (int64_t)nparts * n_tiles, prefix->as<uint64_t>());
-  // partition boundaries = prefix at the start of each partition's row of the matrix
+  // partition boundaries = prefix at the start of each partition's row of the matrix.  The scatter does not need them on the host:
+  // it is launched first, they are read while it runs (the device idled for the read-back's round trip before)
   std::vector<uint64_t> bounds(nparts + 1);
-  for (int p = 0; p < nparts; p++)
-    DFGPU_HIP(hipMemcpyAsync(&bounds[p], prefix->as<uint64_t>() + (int64_t)p * n_tiles, 8, hipMemcpyDeviceToHost, r.stream));
-  DFGPU_HIP(hipStreamSynchronize(r.stream));
-  bounds[nparts] = (uint64_t)n;
+  auto read_bounds = [&]() {
+    BufPtr d_bounds = make_buf((size_t)nparts * 8);
+    k_part_bounds<<<1, MAX_PARTS, 0, r.stream>>>(prefix->as<uint64_t>(), n_tiles, nparts, d_bounds->as<uint64_t>());
+    DFGPU_HIP(hipGetLastError());
+    d2h(bounds.data(), d_bounds->ptr, (size_t)nparts * 8);
+    bounds[nparts] = (uint64_t)n;
+  };
 
   if (simple) {
     std::vector<Column> whole;
@@ -505,6 +512,7 @@ static std::vector<Table> partition_table_fixed_keys(const Table& in, const std:
       k_part_scatter<false><<<tile_grid, BLOCK, 0, r.stream>>>(pc, part->as<uint8_t>(), prefix->as<uint64_t>(), n, nparts, nbits, n_tiles);
       DFGPU_HIP(hipGetLastError());
     }
+    read_bounds();
     for (int p = 0; p < nparts; p++) {
       outs[p].nrows = (int64_t)(bounds[p + 1] - bounds[p]);
       for (size_t ci = 0; ci < in.cols.size(); ci++) {
@@ -518,6 +526,7 @@ static std::vector<Table> partition_table_fixed_keys(const Table& in, const std:
     std::vector<int> all;
     for (int i = 0; i < (int)in.cols.size(); i++) all.push_back(i);
     BufPtr mask = make_buf(bitmap_bytes(n));
+    read_bounds();
     for (int p = 0; p < nparts; p++) {
       k_part_mask<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(part->as<uint8_t>(), n, p, mask->as<uint64_t>());
       outs[p] = compact_table(in, all, mask->as<uint64_t>(), nullptr);
