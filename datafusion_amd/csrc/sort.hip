@@ -1004,10 +1004,21 @@ __device__ __forceinline__ void lsd_emit_keys(const SortEmit& emit, uint32_t key
 }
 __device__ __forceinline__ uint32_t word_of(const uint4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 // W2: bytes of the record's second slice (0, 8 or 16); key_off: byte offset of the key word inside the record
-template <bool BUILD, bool EMIT, int W2>
+// AHEAD: the offsets of every unit of work are known before the pass starts (sort_lsd_carried: two passes over keys of at most 13
+// bits — the digit-totals pass counts per input segment, jointly over both digits): a workgroup takes a UNIT — a stretch of consecutive
+// rows [unit_lo, unit_hi) whose run of every digit starts at ahead_off[digit * ahead_stride + unit] — walks its tiles in order with the
+// cursors in LDS, and waits for nobody: no tile states, no look-back (0.6-0.9 ms of a pass, profiles/r5_sort_phases.md).
+struct LsdAhead {
+  const int64_t* unit_lo;
+  const int64_t* unit_hi;
+  const unsigned long long* off;
+  int64_t stride;
+  int64_t n_units;
+};
+template <bool BUILD, bool EMIT, int W2, bool AHEAD = false>
 __global__ __launch_bounds__(BLOCK, (BUILD ? (W2 == 0 ? 3 : 2) : (W2 == 0 ? 4 : 3))) void k_lsd_pass(LsdIo io, PackCols pc, PackLayout L, int key_off, int64_t n, int reverse, int shift, int bits,
                                                                        int64_t n_tiles, const unsigned long long* __restrict__ bin_base, uint32_t* __restrict__ tile_state,
-                                                                       unsigned* __restrict__ ticket, SortEmit emit) {
+                                                                       unsigned* __restrict__ ticket, SortEmit emit, LsdAhead ahead) {
   constexpr int NWAVE = BLOCK / WAVE;
   constexpr int NS = W2 == 0 ? 2 : 4;
   __shared__ __align__(16) uint4 s_rec[OS_TILE];   // the tile in digit order, one slice of its records at a time
@@ -1021,15 +1032,39 @@ __global__ __launch_bounds__(BLOCK, (BUILD ? (W2 == 0 ? 3 : 2) : (W2 == 0 ? 4 : 
   const int wave = threadIdx.x >> 6;
   const unsigned lane = lane_id();
   const int key_slice = key_off >> 4, key_word = (key_off & 15) >> 2;
+  __shared__ unsigned int s_cur[256];   // AHEAD: where the unit's next row of every digit goes
+  int64_t u_lo = 0, u_hi = 0;           // AHEAD: what is left of the current unit
   for (;;) {
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    int64_t t = 0, lo;
+    int tile_rows;
+    if (AHEAD) {
+      if (u_lo >= u_hi) {   // the next unit
+        if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const int64_t u = (int64_t)s_tile;
+        if (u >= ahead.n_units) return;
+        u_lo = ahead.unit_lo[u];
+        u_hi = ahead.unit_hi[u];
+        if (threadIdx.x <= mask) s_cur[threadIdx.x] = (unsigned)ahead.off[(int64_t)threadIdx.x * ahead.stride + u];
+        __syncthreads();   // (s_tile is read before the next unit's ticket overwrites it)
+        if (u_lo >= u_hi) continue;
+      }
+      lo = u_lo;
+      tile_rows = (int)((u_hi - u_lo) < OS_TILE ? (u_hi - u_lo) : OS_TILE);
+      u_lo += OS_TILE;
 #pragma unroll
-    for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t t = (int64_t)s_tile;
-    if (t >= n_tiles) return;
-    const int64_t lo = t * OS_TILE;
-    const int tile_rows = (int)((n - lo) < OS_TILE ? (n - lo) : OS_TILE);
+      for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+      __syncthreads();
+    } else {
+      if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+      for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+      __syncthreads();
+      t = (int64_t)s_tile;
+      if (t >= n_tiles) return;
+      lo = t * OS_TILE;
+      tile_rows = (int)((n - lo) < OS_TILE ? (n - lo) : OS_TILE);
+    }
     uint4 rec0[OS_ITEMS], rec1[OS_ITEMS];
     unsigned dig[OS_ITEMS], rank[OS_ITEMS];
     if (BUILD) {   // (column by column: tile_keys)
@@ -1095,7 +1130,7 @@ __global__ __launch_bounds__(BLOCK, (BUILD ? (W2 == 0 ? 3 : 2) : (W2 == 0 ? 4 : 
         s_cnt[w][threadIdx.x] = (uint16_t)run;
         run += v;
       }
-      if (t > 0 && threadIdx.x <= mask) os_store(&tile_state[t * 256 + threadIdx.x], OS_AGG | run);
+      if (!AHEAD && t > 0 && threadIdx.x <= mask) os_store(&tile_state[t * 256 + threadIdx.x], OS_AGG | run);
       const unsigned inc = wave_inclusive_sum<unsigned>(run);
       if (lane == 63) s_wtot[wave] = inc;
       __syncthreads();
@@ -1117,9 +1152,14 @@ __global__ __launch_bounds__(BLOCK, (BUILD ? (W2 == 0 ? 3 : 2) : (W2 == 0 ? 4 : 
     }
     // ---- look-back (k_os_pass): thread d adds up digit d's counts over the tiles before this one until it meets an inclusive prefix
     if (threadIdx.x <= mask) {
-      const unsigned excl = os_look_back(tile_state, t, threadIdx.x);
-      os_store(&tile_state[t * 256 + threadIdx.x], OS_PFX | (excl + run));
-      s_goff[threadIdx.x] = (unsigned)bin_base[threadIdx.x] + excl - (unsigned)s_start[threadIdx.x];
+      if (AHEAD) {
+        s_goff[threadIdx.x] = s_cur[threadIdx.x] - (unsigned)s_start[threadIdx.x];
+        s_cur[threadIdx.x] += run;
+      } else {
+        const unsigned excl = os_look_back(tile_state, t, threadIdx.x);
+        os_store(&tile_state[t * 256 + threadIdx.x], OS_PFX | (excl + run));
+        s_goff[threadIdx.x] = (unsigned)bin_base[threadIdx.x] + excl - (unsigned)s_start[threadIdx.x];
+      }
     }
     __syncthreads();
     // ---- write-out, one slice after the other (EMIT: the slice's fields to their columns; the key columns decoded from the key word)
@@ -1613,6 +1653,64 @@ static bool sort_carried_onesweep(const Table& in, const std::vector<int>& key_c
   return carried_emit(in, key_cols, pc, payload, order, L, cur_key, cur_rec, nullptr, n, n_buckets, width, low_bits, out);
 }
 
+// The digit-totals pass of the AHEAD form: the input in COARSE segments of `cf` FINE segments of `fine` rows; per fine segment the counts
+// of digit 1 (c1f[d1 * n_fine + f]: pass 1's units), per coarse segment the JOINT counts of both digits (joint[(d2 * B1 + d1) * n_coarse + g]:
+// the rows of coarse segment g with digit 1 = d1 lie together in pass 1's output — stable passes — and are pass 2's units).  Exclusive
+// scans of the two arrays as they lie ARE the output offsets of the two passes.  One workgroup of 1024 threads per coarse segment.
+constexpr int LSD_JOINT_MAX = 8192;
+__global__ __launch_bounds__(1024) void k_lsd_joint(PackCols pc, int64_t n, int reverse, int bits1, int bits2, int64_t fine, int cf, int64_t n_fine, int64_t n_coarse,
+                                                     uint32_t* __restrict__ c1f, uint32_t* __restrict__ joint) {
+  __shared__ unsigned s_joint[LSD_JOINT_MAX];
+  __shared__ unsigned s_fine[256];
+  const int B1 = 1 << bits1, B2 = 1 << bits2;
+  const int64_t g = blockIdx.x;
+  for (int i = threadIdx.x; i < B1 * B2; i += 1024) s_joint[i] = 0;
+  for (int k = 0; k < cf; k++) {
+    const int64_t f = g * cf + k;
+    if (f >= n_fine) break;
+    if ((int)threadIdx.x < B1) s_fine[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t lo = f * fine, hi = (lo + fine) < n ? (lo + fine) : n;
+    for (int64_t base = lo; base < hi; base += 1024 * 4) {
+      uint32_t src[4], key[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int64_t row = base + (int64_t)c * 1024 + threadIdx.x;
+        const int64_t r = row < hi ? row : hi - 1;
+        src[c] = (uint32_t)(reverse ? n - 1 - r : r);
+      }
+      tile_keys<4, uint32_t>(pc, src, key);
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        if (base + (int64_t)c * 1024 + threadIdx.x < hi) {
+          const unsigned d1 = key[c] & (unsigned)(B1 - 1), d2 = (key[c] >> bits1) & (unsigned)(B2 - 1);
+          atomicAdd(&s_fine[d1], 1u);
+          atomicAdd(&s_joint[d2 * B1 + d1], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < B1) c1f[(int64_t)threadIdx.x * n_fine + f] = s_fine[threadIdx.x];
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B1 * B2; i += 1024) joint[(int64_t)i * n_coarse + g] = s_joint[i];
+}
+// units of the two passes: pass 1 = the fine segments; pass 2 = (digit 1, coarse segment) cells, where pass 1 put them
+__global__ void k_lsd_units(const unsigned long long* __restrict__ off1, int64_t n, int64_t fine, int cf, int64_t n_fine, int64_t n_coarse, int B1,
+                            int64_t* __restrict__ lo1, int64_t* __restrict__ hi1, int64_t* __restrict__ lo2, int64_t* __restrict__ hi2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_fine) {
+    lo1[i] = i * fine;
+    hi1[i] = (i + 1) * fine < n ? (i + 1) * fine : n;
+  }
+  if (i < (int64_t)B1 * n_coarse) {
+    const int64_t d1 = i / n_coarse, g = i % n_coarse;
+    lo2[i] = (int64_t)off1[d1 * n_fine + g * cf];
+    hi2[i] = (g + 1) * cf < n_fine ? (int64_t)off1[d1 * n_fine + (g + 1) * cf] : (int64_t)off1[(d1 + 1) * n_fine];
+  }
+}
+
 // The LSD carried sort (round 5): the packed key — after dropping what the input's own order already settles — fits 32 bits, so two to
 // four stable passes over 16-32-byte records sort the table, the last one writing the output columns; no bucket sort, no key array.
 // What the input's order settles: a key column that is STRICTLY ASCENDING in row order (a primary key the table was loaded by, a row
@@ -1704,10 +1802,47 @@ static bool sort_lsd_carried(const Table& in, const std::vector<int>& key_cols, 
     row_bytes += L.width[q];
   }
   const int64_t n_tiles = (n + OS_TILE - 1) / OS_TILE;
-  BufPtr hist = make_zero_buf((size_t)OS_MAX_PASSES * 256 * 8), bases = make_buf((size_t)OS_MAX_PASSES * 256 * 8);
   BufPtr tickets = make_zero_buf((size_t)OS_MAX_PASSES * 4);
-  BufPtr state = make_buf((size_t)n_tiles * 256 * 4);
-  {
+  // two passes over at most 13 bits: every unit's offsets ahead of time (k_lsd_joint), no look-back
+  const bool ahead = dg.n == 2 && (1 << total_bits) <= LSD_JOINT_MAX && option_on("sort.lsd_ahead", true);
+  BufPtr hist, bases, state, c1f, joint, off1, off2, units;
+  LsdAhead ah[2] = {};
+  if (ahead) {
+    // fine segments of 4 tiles (pass 1's units: small enough that the workgroups' reads and writes stay near each other, 16 and 64 tiles
+    // measured 0.1 / 0.5 ms slower), coarse segments of 30 of them (pass 2's units hold about cf * fine / B1 rows — 3840 at 64 digits —
+    // and the joint histogram stays a few MB); a unit that would end right at a whole number of tiles is made a little smaller (8192 +- 90
+    // rows is a fifth, nearly empty tile more than every third time)
+    const int64_t fine = (int64_t)OS_TILE * 4;
+    int cf = 30;
+    {
+      const int64_t mean = (int64_t)cf * fine / ((int64_t)1 << dg.bits[0]);
+      if (mean % OS_TILE == 0 || mean % OS_TILE > OS_TILE - 256) cf -= 1;
+    }
+    const int64_t n_fine = (n + fine - 1) / fine, n_coarse = (n_fine + cf - 1) / cf;
+    const int B1 = 1 << dg.bits[0], B2 = 1 << dg.bits[1];
+    c1f = make_buf((size_t)B1 * n_fine * 4);
+    joint = make_buf((size_t)B1 * B2 * n_coarse * 4);
+    off1 = make_buf(((size_t)B1 * n_fine + 1) * 8);
+    off2 = make_buf(((size_t)B1 * B2 * n_coarse + 1) * 8);
+    units = make_buf((size_t)(2 * n_fine + 2 * B1 * n_coarse) * 8);
+    {
+      ProfileScope ps("sort_digit_totals", key_col_bytes);
+      k_lsd_joint<<<(unsigned)n_coarse, 1024, 0, r.stream>>>(kc, n, reverse, dg.bits[0], dg.bits[1], fine, cf, n_fine, n_coarse, c1f->as<uint32_t>(), joint->as<uint32_t>());
+      DFGPU_HIP(hipGetLastError());
+    }
+    scan_u32(c1f->as<uint32_t>(), (int64_t)B1 * n_fine, off1->as<uint64_t>());
+    scan_u32(joint->as<uint32_t>(), (int64_t)B1 * B2 * n_coarse, off2->as<uint64_t>());
+    int64_t* up = units->as<int64_t>();
+    const int64_t nu = std::max<int64_t>(n_fine, (int64_t)B1 * n_coarse);
+    k_lsd_units<<<(unsigned)((nu + 255) / 256), 256, 0, r.stream>>>(off1->as<unsigned long long>(), n, fine, cf, n_fine, n_coarse, B1, up, up + n_fine, up + 2 * n_fine,
+                                                                    up + 2 * n_fine + (int64_t)B1 * n_coarse);
+    DFGPU_HIP(hipGetLastError());
+    ah[0] = LsdAhead{up, up + n_fine, off1->as<unsigned long long>(), n_fine, n_fine};
+    ah[1] = LsdAhead{up + 2 * n_fine, up + 2 * n_fine + (int64_t)B1 * n_coarse, off2->as<unsigned long long>(), (int64_t)B1 * n_coarse, (int64_t)B1 * n_coarse};
+  } else {
+    hist = make_zero_buf((size_t)OS_MAX_PASSES * 256 * 8);
+    bases = make_buf((size_t)OS_MAX_PASSES * 256 * 8);
+    state = make_buf((size_t)n_tiles * 256 * 4);
     ProfileScope ps("sort_digit_totals", key_col_bytes);
     k_os_hist<true><<<r.num_cus * 8, BLOCK, 0, r.stream>>>(nullptr, kc, n, div_by(1), dg, hist->as<unsigned long long>());
     k_os_bases<<<dg.n, BLOCK, 0, r.stream>>>(hist->as<unsigned long long>(), bases->as<unsigned long long>());
@@ -1732,14 +1867,17 @@ static bool sort_lsd_carried(const Table& in, const std::vector<int>& key_cols, 
       io.out1 = w2 ? (to_a ? a1 : b1)->ptr : nullptr;
     }
     ProfileScope ps(last ? "sort_lsd_pass_out" : "sort_lsd_pass", n * (int64_t)((first ? row_bytes : rec_bytes) + (last ? row_bytes : rec_bytes)));
-    DFGPU_HIP(hipMemsetAsync(state->ptr, 0, (size_t)n_tiles * 256 * 4, r.stream));
+    if (!ahead) DFGPU_HIP(hipMemsetAsync(state->ptr, 0, (size_t)n_tiles * 256 * 4, r.stream));
     auto launch = [&](auto kern) {
-      kern<<<grid, BLOCK, 0, r.stream>>>(io, kc, L, key_off, n, reverse, dg.shift[p], dg.bits[p], n_tiles, bases->as<unsigned long long>() + p * 256, state->as<uint32_t>(),
-                                         tickets->as<unsigned>() + p, e);
+      kern<<<grid, BLOCK, 0, r.stream>>>(io, kc, L, key_off, n, reverse, dg.shift[p], dg.bits[p], n_tiles, ahead ? nullptr : bases->as<unsigned long long>() + p * 256,
+                                         ahead ? nullptr : state->as<uint32_t>(), tickets->as<unsigned>() + p, e, ah[ahead ? p : 0]);
     };
     auto pick = [&](auto w2c) {
       constexpr int W2 = decltype(w2c)::value;
-      if (first && last) launch(k_lsd_pass<true, true, W2>);
+      if (ahead) {   // (two passes: the first builds, the last emits)
+        if (first) launch(k_lsd_pass<true, false, W2, true>);
+        else launch(k_lsd_pass<false, true, W2, true>);
+      } else if (first && last) launch(k_lsd_pass<true, true, W2>);
       else if (first) launch(k_lsd_pass<true, false, W2>);
       else if (last) launch(k_lsd_pass<false, true, W2>);
       else launch(k_lsd_pass<false, false, W2>);

@@ -249,7 +249,8 @@ def test_sort_carried_records_and_keys_decoded_from_the_packed_key(monkeypatch, 
         assert "sort_local_emit" not in stats, sorted(stats)
 
 
-@pytest.mark.parametrize("shape", ["orders_by_date_then_ascending_key_desc", "orders_by_date_then_ascending_key_asc", "one_pass_u8_key_16_byte_record",
+@pytest.mark.parametrize("shape", ["orders_by_date_then_ascending_key_desc", "orders_by_date_then_ascending_key_asc", "orders_by_date_then_ascending_key_desc_with_look_back",
+                                   "two_passes_skewed_digits_16_byte_record", "one_pass_u8_key_16_byte_record",
                                    "three_passes_two_keys_32_byte_record", "key_only_table", "record_too_wide", "key_beyond_32_bits", "nullable_key",
                                    "ragged_tail_and_ties"])
 def test_sort_narrow_keys_by_record_passes(shape):
@@ -266,7 +267,15 @@ def test_sort_narrow_keys_by_record_passes(shape):
         t = pa.table({"o_orderkey": pa.array(np.cumsum(rng.integers(1, 9, n)).astype(np.int64)), "o_custkey": pa.array(rng.integers(1, 10**6, n)),
                       "o_orderdate": pa.array(rng.integers(8035, 10441, n).astype(np.int32), pa.int32()).cast(pa.date32()),
                       "o_shippriority": pa.array(rng.integers(0, 3, n).astype(np.int32))})
-        keys = [("o_orderdate", False, False), ("o_orderkey", shape.endswith("desc"), False)]
+        keys = [("o_orderdate", False, False), ("o_orderkey", "_desc" in shape, False)]
+        if shape.endswith("with_look_back"):   # (two passes over 12 bits take the offsets-ahead-of-time form by default: this is the other leg)
+            ops.set_options(sort__lsd_ahead="0")
+    elif shape == "two_passes_skewed_digits_16_byte_record":
+        # 10 bits in two passes, most rows on three key values (units of very different sizes, empty ones), more than one coarse segment
+        n = 1_200_003
+        a = np.where(rng.random(n) < 0.9, rng.choice([5, 700, 701], n), rng.integers(0, 1000, n)).astype(np.int32)
+        t = pa.table({"a": pa.array(a), "v": pa.array(np.arange(n, dtype=np.int64)), "w": pa.array(rng.integers(0, 2**31, n).astype(np.int32))})
+        keys = [("a", False, False)]
     elif shape == "one_pass_u8_key_16_byte_record":
         t = pa.table({"c": pa.array(rng.integers(3, 200, n).astype(np.uint8)), "v": pa.array(np.arange(n, dtype=np.int64)), "w": pa.array(rng.integers(0, 2**31, n).astype(np.int32))})
         keys = [("c", True, False)]
