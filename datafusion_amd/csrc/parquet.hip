@@ -24,6 +24,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <functional>
 #include <mutex>
@@ -1636,13 +1637,6 @@ bool plan_chunk_device(const uint8_t* chunk, int64_t nbytes, const dfgpu_parquet
   return !D.pages.empty() && D.pages.size() <= 65535;
 }
 
-// the pages' states and the decode error word into pinned host memory the device can write (a hipMemcpyAsync of a few bytes back to the
-// host returns only once the stream has reached it: the worker's next chunk would wait for this one's kernels)
-__global__ void k_pq_report(const DevPageState* __restrict__ states, int n, const int32_t* __restrict__ err, DevPageState* host_states, int32_t* host_err) {
-  for (int q = threadIdx.x; q < n; q += blockDim.x) host_states[q] = states[q];
-  if (threadIdx.x == 0) *host_err = *err;
-  __threadfence_system();
-}
 template <typename T>
 void launch_decode_pages(const PqDevArgs& a, void* out) {
   k_pq_decode_pages<T><<<dim3((unsigned)a.n_pages, 8), BLOCK, 0, rt().stream>>>(a, (T*)out);
@@ -1651,12 +1645,44 @@ void launch_decode_pages(const PqDevArgs& a, void* out) {
 // Everything a chunk needs is enqueued in one go — upload, decompression, levels, values, NULL expansion, the pages' states and the
 // decode error word on their way back to pinned memory — and nothing waits: `fin` (run by the caller once the stream has passed this
 // point: a scan worker has several chunks in flight) reads what came back, raises a corrupt page's error and settles the NULL count.
+extern thread_local double t_upload_ms[6];   // (defined below: where a worker's host time went, DFGPU_TRACE=scan)
+// Device buffers the uploads land in, kept per host thread and handed out again only after the chunk that used one has been settled (its
+// event has passed: no kernel reads it any more).  That is what lets the upload stream run WITHOUT waiting for the kernel stream — a block
+// from the general pool may still be read by kernels this thread enqueued earlier, and an upload that has to wait for them is not handed
+// to the copy engine by hipMemcpyAsync: the call itself waits (measured: 1-4 ms per chunk, 2-9 ms with an event wait in front of it).
+struct UploadCache {
+  std::vector<BufPtr> free;
+  BufPtr take(size_t n, hipStream_t kernel_stream) {
+    size_t best = free.size();
+    for (size_t i = 0; i < free.size(); i++)
+      if (free[i]->bytes >= n && free[i]->bytes <= 2 * n + (1 << 20) && (best == free.size() || free[i]->bytes < free[best]->bytes)) best = i;
+    if (best < free.size()) {
+      BufPtr b = std::move(free[best]);
+      free.erase(free.begin() + (long)best);
+      return b;
+    }
+    BufPtr b = make_buf(n + n / 8);                   // (a little room: the next chunk of the column is about this size)
+    DFGPU_HIP(hipStreamSynchronize(kernel_stream));   // a pool block: whatever this thread's kernels still read of it is done after this
+    return b;
+  }
+  void give(BufPtr b) {
+    if (free.size() < 12) free.push_back(std::move(b));
+  }
+};
+// (never destroyed: a thread's cache would otherwise give its blocks back to a pool that static destruction may already have taken down)
+static UploadCache& upload_cache() {
+  static thread_local UploadCache* c = new UploadCache();
+  return *c;
+}
 struct DeviceChunkKeep {
+  ~DeviceChunkKeep() {
+    if (d_chunk) upload_cache().give(std::move(d_chunk));
+  }
   StageVec<uint8_t> staged, dict_host;
   StageVec<DevPage> pages;
   StageVec<DevPageState> states;
   StageVec<int32_t> err;
-  BufPtr d_chunk, d_body, d_pages, d_states, d_err, d_dict, dense, prefix;
+  BufPtr d_chunk, d_body, d_states, d_err, d_dict, dense, prefix;
   std::vector<int32_t> page_type, page_rows;
   int64_t rows = 0;
 };
@@ -1678,10 +1704,12 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
   // compression, the pages' bodies decompressed straight into the staging buffer, each page then reading as an uncompressed one
   K->pages = D.pages;
   int64_t padded;
+  const auto t_fill0 = std::chrono::steady_clock::now();
   if (D.host_decompress) {
     padded = (D.upload_bytes + 64 + 3) & ~(int64_t)3;
     K->staged.resize((size_t)padded);
     int64_t at = 0;
+    // (the pages of a big chunk as jobs for whichever worker is free were measured: SF1 medians 15 ms against 10.6 — removed)
     for (DevPage& g : K->pages) {
       uint8_t* to = K->staged.data() + at;
       const uint8_t* raw = chunk + g.src_off;
@@ -1698,24 +1726,45 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
     K->staged.resize((size_t)padded);   // (uninitialised: StageAllocator)
     std::memcpy(K->staged.data(), chunk, (size_t)nbytes);
   }
-  K->d_chunk = make_buf((size_t)padded);
+  auto tk = std::chrono::steady_clock::now();
+  auto lap = [&](int i) {
+    const auto now = std::chrono::steady_clock::now();
+    t_upload_ms[i] += std::chrono::duration<double, std::milli>(now - tk).count();
+    tk = now;
+  };
+  t_upload_ms[0] += std::chrono::duration<double, std::milli>(tk - t_fill0).count();   // the upload buffer filled (copy or decompression)
+  // The uploads go on a stream of their own (per thread), into a buffer no kernel reads any more (UploadCache): the page table rides
+  // behind the chunk's bytes in the same buffer.  The kernel stream waits for the upload's event on the device.
+  static thread_local hipStream_t up = nullptr;
+  static thread_local hipEvent_t ev_up = nullptr;
+  if (!up) {
+    DFGPU_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    DFGPU_HIP(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
+  }
+  const size_t pages_at = ((size_t)padded + 63) & ~(size_t)63, pages_bytes = (size_t)n_pages * sizeof(DevPage);
+  K->d_chunk = upload_cache().take(pages_at + pages_bytes + 64, st);
   K->d_body = make_buf((size_t)D.body_bytes + 64);
-  K->d_pages = make_buf((size_t)n_pages * sizeof(DevPage));
   K->d_states = make_buf((size_t)n_pages * sizeof(DevPageState));
+  lap(2);
+  DFGPU_HIP(hipMemcpyAsync(K->d_chunk->ptr, K->staged.data(), (size_t)padded, hipMemcpyHostToDevice, up));
+  DFGPU_HIP(hipMemcpyAsync((uint8_t*)K->d_chunk->ptr + pages_at, K->pages.data(), pages_bytes, hipMemcpyHostToDevice, up));
+  DFGPU_HIP(hipEventRecord(ev_up, up));
+  DFGPU_HIP(hipStreamWaitEvent(st, ev_up, 0));
+  lap(3);   // the uploads enqueued
+  const DevPage* d_pages = reinterpret_cast<const DevPage*>((const uint8_t*)K->d_chunk->ptr + pages_at);
   K->d_err = make_zero_buf(4);
-  DFGPU_HIP(hipMemcpyAsync(K->d_chunk->ptr, K->staged.data(), (size_t)padded, hipMemcpyHostToDevice, st));
-  DFGPU_HIP(hipMemcpyAsync(K->d_pages->ptr, K->pages.data(), (size_t)n_pages * sizeof(DevPage), hipMemcpyHostToDevice, st));
   thread_metrics().h2d_bytes += padded;
+  lap(1);   // buffers + the upload enqueued
   {
     ProfileScope ps(D.body_bytes ? "parquet_decompress_pages" : "parquet_page_states", nbytes + D.body_bytes);
-    k_pq_decompress<<<n_pages, 64, 0, st>>>(K->d_pages->as<DevPage>(), K->d_chunk->as<uint8_t>(), padded, K->d_body->as<uint8_t>(), K->d_states->as<DevPageState>());
+    k_pq_decompress<<<n_pages, 64, 0, st>>>(d_pages, K->d_chunk->as<uint8_t>(), padded, K->d_body->as<uint8_t>(), K->d_states->as<DevPageState>());
     DFGPU_HIP(hipGetLastError());
   }
   const bool nullable = col.max_definition_level == 1;
   if (nullable) {
     c.validity = make_zero_buf(bitmap_bytes(D.rows) + 8);
     ProfileScope ps("parquet_levels", D.rows / 8);
-    k_pq_levels<<<n_pages, 64, 0, st>>>(K->d_pages->as<DevPage>(), K->d_chunk->as<uint8_t>(), K->d_body->as<uint8_t>(), K->d_states->as<DevPageState>(),
+    k_pq_levels<<<n_pages, 64, 0, st>>>(d_pages, K->d_chunk->as<uint8_t>(), K->d_body->as<uint8_t>(), K->d_states->as<DevPageState>(),
                                         reinterpret_cast<unsigned long long*>(c.validity->ptr));
     DFGPU_HIP(hipGetLastError());
   }
@@ -1746,7 +1795,7 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
     std::vector<int32_t> rank;
     c.dict = string_dictionary(P, c.name, rank);
   }
-  a.pages = K->d_pages->as<DevPage>();
+  a.pages = d_pages;
   a.states = K->d_states->as<DevPageState>();
   a.chunk = K->d_chunk->as<uint8_t>();
   a.body = K->d_body->as<uint8_t>();
@@ -1784,12 +1833,20 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
     }
     c.null_count = -1;   // (settled by `fin`)
   }
+  lap(4);   // kernels enqueued
   K->states.assign((size_t)n_pages, DevPageState{});
   K->err.assign(1, 0);
-  k_pq_report<<<1, BLOCK, 0, st>>>(K->d_states->as<DevPageState>(), n_pages, K->d_err->as<int32_t>(), K->states.data(), K->err.data());
-  DFGPU_HIP(hipGetLastError());
   thread_metrics().d2h_bytes += (int64_t)n_pages * (int64_t)sizeof(DevPageState) + 4;
-  std::function<void(Column&)> finish = [K, nullable](Column& col_out) {
+  // `finish` runs once the stream is past this chunk: the pages' states and the error word come back on a stream of their own (on the
+  // worker's stream the read-back would queue behind the chunks enqueued since; a kernel writing them into pinned host memory and a
+  // hipMemcpyAsync issued here were both measured: the first makes later uploads on the stream wait on the host, the second returns only
+  // when the stream has reached it)
+  std::function<void(Column&)> finish = [K, nullable, n_pages](Column& col_out) {
+    static thread_local hipStream_t readback = nullptr;
+    if (!readback) DFGPU_HIP(hipStreamCreateWithFlags(&readback, hipStreamNonBlocking));
+    DFGPU_HIP(hipMemcpyAsync(K->states.data(), K->d_states->ptr, (size_t)n_pages * sizeof(DevPageState), hipMemcpyDeviceToHost, readback));
+    DFGPU_HIP(hipMemcpyAsync(K->err.data(), K->d_err->ptr, 4, hipMemcpyDeviceToHost, readback));
+    DFGPU_HIP(hipStreamSynchronize(readback));
     int64_t values = 0;
     for (size_t q = 0; q < K->states.size(); q++) {
       const DevPageState& s = K->states[q];
@@ -1820,7 +1877,7 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
 namespace {
 
 thread_local double t_plan_ms = 0;   // host halves of this thread's chunks (DFGPU_TRACE_SCAN)
-thread_local double t_upload_ms[6] = {0, 0, 0, 0, 0, 0};
+thread_local double t_upload_ms[6] = {0, 0, 0, 0, 0, 0};   // (device path: [0] upload buffer filled, [1] buffers + upload enqueued, [4] kernels enqueued)
 // `keep` (optional): instead of waiting for the uploads, the host buffers they read from are handed to the caller, who lets go of
 // them once the stream has passed this point — a scan worker plans its next chunk while this one crosses PCIe
 struct ChunkSources {

@@ -11,6 +11,8 @@ def main():
     ap.add_argument("--sf", type=float, default=1.0)
     ap.add_argument("--codec", default="snappy")
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=12, help="cold scans per line (the first few warm the pools up: best and median are printed)")
+    ap.add_argument("--all-only", action="store_true", help="only the all-columns line of each path")
     args = ap.parse_args()
     import pyarrow as pa, pyarrow.parquet as pq
     from datafusion_amd import _lib, ops, tpch
@@ -29,11 +31,11 @@ def main():
     f = P.ParquetFile(path)
     for dev in ("1", "0"):
         ops.set_options(parquet__device_decode=dev)
-        for single in (cols, None):
+        for single in ((None,) if args.all_only else (cols, None)):
             for c in (single or [None]):
                 use = [c] if c else cols
-                best, cpu = None, None
-                for _ in range(3):
+                best, cpu, all_ms = None, None, []
+                for _ in range(args.iters):
                     ops.sync()
                     c0 = time.process_time()
                     t0 = time.perf_counter()
@@ -41,6 +43,7 @@ def main():
                     ops.sync()
                     dt = time.perf_counter() - t0
                     dc = time.process_time() - c0
+                    all_ms.append(dt * 1e3)
                     if best is None or dt < best:
                         best, cpu = dt, dc
                     tab.free()
@@ -51,7 +54,7 @@ def main():
                 st = ops.profile_stats()
                 ops.profile_enable(False)
                 tab.free()
-                print(json.dumps({"device_decode": dev, "columns": c or "all", "ms": round(best * 1e3, 2), "host_cpu_ms": round(cpu * 1e3, 2),
+                print(json.dumps({"device_decode": dev, "columns": c or "all", "ms": round(best * 1e3, 2), "ms_median": round(sorted(all_ms)[len(all_ms) // 2], 2), "host_cpu_ms": round(cpu * 1e3, 2),
                                   "kernels_ms": {k: round(v["total_ms"], 3) for k, v in st.items() if k.startswith("parquet")},
                                   "calls": {k: v["calls"] for k, v in st.items() if k.startswith("parquet")}}), flush=True)
 
