@@ -614,10 +614,17 @@ __global__ __launch_bounds__(BLOCK) void k_os_hist(const uint64_t* __restrict__ 
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += 4 * stride) {
     uint64_t k[4];
+    if (BUILD) {   // (column by column: tile_keys)
+      uint32_t src[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int64_t i = i0 + u * stride;
-      k[u] = i < n ? (BUILD ? pack_key64(pc, i) : key_in[i]) : 0ull;
+      for (int u = 0; u < 4; u++) src[u] = (uint32_t)(i0 + u * stride < n ? i0 + u * stride : n - 1);
+      tile_keys<4, uint64_t>(pc, src, k);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int64_t i = i0 + u * stride;
+        k[u] = i < n ? key_in[i] : 0ull;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -629,6 +636,29 @@ __global__ __launch_bounds__(BLOCK) void k_os_hist(const uint64_t* __restrict__ 
   __syncthreads();
   for (int p = 0; p < dg.n; p++)
     if (s_h[p][threadIdx.x]) atomicAdd(&hist[p * 256 + threadIdx.x], (unsigned long long)s_h[p][threadIdx.x]);
+}
+// k_key_limit_mask for key columns without NULLs (integer / date types): four mask words per wave iteration, the keys of a lane's four rows
+// loaded column by column before any is packed (tile_keys)
+__global__ __launch_bounds__(BLOCK) void k_key_limit_mask_plain(PackCols pc, int64_t n, uint64_t limit, uint64_t* __restrict__ mask) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w0 = wave * 4; w0 < n_words; w0 += n_waves * 4) {
+    uint32_t src[4];
+    uint64_t k[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t i = ((w0 + u) << 6) + lane_id();
+      src[u] = (uint32_t)(i < n ? i : n - 1);
+    }
+    tile_keys<4, uint64_t>(pc, src, k);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t i = ((w0 + u) << 6) + lane_id();
+      const uint64_t m = ballot64(i < n && k[u] <= limit);
+      if (lane_id() == 0 && w0 + u < n_words) mask[w0 + u] = m;
+    }
+  }
 }
 // exclusive scan of every pass's 256 totals (one workgroup of 256 threads per pass)
 __global__ __launch_bounds__(BLOCK) void k_os_bases(const unsigned long long* __restrict__ hist, unsigned long long* __restrict__ base) {
@@ -2025,7 +2055,14 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
         const uint64_t limit = sample[(size_t)(c - 1)];
         {
           ProfileScope ps("topk_limit_pass", key_col_bytes + n / 8);
-          k_key_limit_mask<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(pc, n, limit, mask->as<uint64_t>());
+          bool plain_keys = n < ((int64_t)1 << 32);
+          for (int k = 0; k < pc.n; k++) {
+            const PackCol& c = pc.c[k];
+            plain_keys = plain_keys && !c.valid && !c.has_null_bit && c.range > 0 &&
+                         (c.type == DFGPU_INT32 || c.type == DFGPU_DATE32 || c.type == DFGPU_UINT32 || c.type == DFGPU_INT64 || c.type == DFGPU_UINT64 || c.type == DFGPU_UINT8);
+          }
+          if (plain_keys) k_key_limit_mask_plain<<<grid_for(n_words, (BLOCK / WAVE) * 4), BLOCK, 0, r.stream>>>(pc, n, limit, mask->as<uint64_t>());
+          else k_key_limit_mask<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(pc, n, limit, mask->as<uint64_t>());
           DFGPU_HIP(hipGetLastError());
         }
         scan_mask_popcounts(mask->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
