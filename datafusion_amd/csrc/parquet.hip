@@ -1652,21 +1652,29 @@ extern thread_local double t_upload_ms[6];   // (defined below: where a worker's
 // to the copy engine by hipMemcpyAsync: the call itself waits (measured: 1-4 ms per chunk, 2-9 ms with an event wait in front of it).
 struct UploadCache {
   std::vector<BufPtr> free;
+  // sizes in classes (powers of two from 256 KB): the chunks of a scan's columns come in a handful of sizes, and a miss costs a drain of
+  // the kernel stream
+  static size_t size_class(size_t n) {
+    size_t c = (size_t)256 << 10;
+    while (c < n) c <<= 1;
+    return c;
+  }
   BufPtr take(size_t n, hipStream_t kernel_stream) {
-    size_t best = free.size();
+    const size_t c = size_class(n);
     for (size_t i = 0; i < free.size(); i++)
-      if (free[i]->bytes >= n && free[i]->bytes <= 2 * n + (1 << 20) && (best == free.size() || free[i]->bytes < free[best]->bytes)) best = i;
-    if (best < free.size()) {
-      BufPtr b = std::move(free[best]);
-      free.erase(free.begin() + (long)best);
-      return b;
-    }
-    BufPtr b = make_buf(n + n / 8);                   // (a little room: the next chunk of the column is about this size)
+      if (free[i]->bytes == c) {
+        BufPtr b = std::move(free[i]);
+        free.erase(free.begin() + (long)i);
+        return b;
+      }
+    BufPtr b = make_buf(c);
     DFGPU_HIP(hipStreamSynchronize(kernel_stream));   // a pool block: whatever this thread's kernels still read of it is done after this
     return b;
   }
   void give(BufPtr b) {
-    if (free.size() < 12) free.push_back(std::move(b));
+    size_t same = 0;
+    for (const BufPtr& f : free) same += f->bytes == b->bytes;
+    if (same < 6 && free.size() < 48) free.push_back(std::move(b));   // (a few per class: the chunks in flight plus one)
   }
 };
 // (never destroyed: a thread's cache would otherwise give its blocks back to a pool that static destruction may already have taken down)
