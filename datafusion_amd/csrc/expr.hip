@@ -135,15 +135,18 @@ __global__ __launch_bounds__(BLOCK) void k_cmp(int op, Operand<T> a, Operand<T> 
       x[j] = in ? a.at(i) : T{};
       y[j] = in ? b.at(i) : T{};
     }
+    // the iteration's mask words leave in ONE store (lane j holds word j: 32 contiguous bytes) instead of one 8-byte store each
+    uint64_t mine = 0;
 #pragma unroll
     for (int j = 0; j < CMP_UNROLL; j++) {
       int64_t i = ((w0 + j) << 6) + lane_id();
       bool r;
       if constexpr (IS_F64) r = cmp_op<int64_t>(op, f64_total_key((double)x[j]), f64_total_key((double)y[j]));
       else r = cmp_op<T>(op, (T)(x[j] * ma), (T)(y[j] * mb));
-      uint64_t word = ballot64(i < n && r);
-      if (lane_id() == 0 && w0 + j < n_words) out[w0 + j] = word;
+      const uint64_t word = ballot64(i < n && r);
+      mine = (int)lane_id() == j ? word : mine;
     }
+    if ((int)lane_id() < CMP_UNROLL && w0 + (int64_t)lane_id() < n_words) out[w0 + lane_id()] = mine;
   }
 }
 
