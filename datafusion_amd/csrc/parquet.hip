@@ -27,6 +27,7 @@
 #include <deque>
 #include <cstdio>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -1300,9 +1301,20 @@ __global__ __launch_bounds__(BLOCK) void k_pq_decode_pages(PqDevArgs a, T* __res
   const DevPage pg = a.pages[p];
   if (pg.type == PAGE_DICTIONARY) return;
   const DevPageState st = a.states[p];
+  // first non-null value of the page, chunk-wide: the sum of the earlier data pages' counts (the workgroup's threads share the pages out:
+  // a chunk written with small pages has thousands of them)
+  __shared__ unsigned long long s_vs[BLOCK / WAVE];
+  {
+    unsigned long long part = 0;
+    for (int q = threadIdx.x; q < p; q += BLOCK)
+      if (a.pages[q].type != PAGE_DICTIONARY) part += (unsigned long long)a.states[q].nonnull;
+    part = wave_sum<unsigned long long>(part);
+    if (lane_id() == 0) s_vs[threadIdx.x >> 6] = part;
+    __syncthreads();
+  }
   int64_t value_start = 0;
-  for (int q = 0; q < p; q++)
-    if (a.pages[q].type != PAGE_DICTIONARY) value_start += a.states[q].nonnull;
+#pragma unroll
+  for (int w = 0; w < BLOCK / WAVE; w++) value_start += (int64_t)s_vs[w];
   const uint8_t* vals = pq_page_body(pg, a.chunk, a.body) + st.values_off;
   const int64_t vbytes = st.values_end - st.values_off;
   const int64_t n = st.nonnull;
@@ -1677,14 +1689,24 @@ struct UploadCache {
     if (same < 6 && free.size() < 48) free.push_back(std::move(b));   // (a few per class: the chunks in flight plus one)
   }
 };
-// (never destroyed: a thread's cache would otherwise give its blocks back to a pool that static destruction may already have taken down)
-static UploadCache& upload_cache() {
-  static thread_local UploadCache* c = new UploadCache();
-  return *c;
+// What a host thread keeps per DEVICE for the scan (a library thread may serve scans on different GPUs of the process): the upload stream
+// and its event, the stream the pages' states come back on, the upload buffers.  Never destroyed: a thread's cache would otherwise give
+// its blocks back to a pool that static destruction may already have taken down.
+struct ScanThreadDevice {
+  hipStream_t up = nullptr, readback = nullptr;
+  hipEvent_t ev_up = nullptr;
+  UploadCache cache;
+};
+static ScanThreadDevice& scan_thread_device(int device) {
+  static thread_local std::map<int, ScanThreadDevice*>* per_device = new std::map<int, ScanThreadDevice*>();
+  ScanThreadDevice*& p = (*per_device)[device];
+  if (!p) p = new ScanThreadDevice();
+  return *p;
 }
 struct DeviceChunkKeep {
+  int device = -1;
   ~DeviceChunkKeep() {
-    if (d_chunk) upload_cache().give(std::move(d_chunk));
+    if (d_chunk && device >= 0) scan_thread_device(device).cache.give(std::move(d_chunk));
   }
   StageVec<uint8_t> staged, dict_host;
   StageVec<DevPage> pages;
@@ -1743,14 +1765,16 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
   t_upload_ms[0] += std::chrono::duration<double, std::milli>(tk - t_fill0).count();   // the upload buffer filled (copy or decompression)
   // The uploads go on a stream of their own (per thread), into a buffer no kernel reads any more (UploadCache): the page table rides
   // behind the chunk's bytes in the same buffer.  The kernel stream waits for the upload's event on the device.
-  static thread_local hipStream_t up = nullptr;
-  static thread_local hipEvent_t ev_up = nullptr;
-  if (!up) {
-    DFGPU_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
-    DFGPU_HIP(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
+  ScanThreadDevice& tdv = scan_thread_device(current_device());
+  K->device = current_device();
+  if (!tdv.up) {
+    DFGPU_HIP(hipStreamCreateWithFlags(&tdv.up, hipStreamNonBlocking));
+    DFGPU_HIP(hipEventCreateWithFlags(&tdv.ev_up, hipEventDisableTiming));
   }
+  hipStream_t up = tdv.up;
+  hipEvent_t ev_up = tdv.ev_up;
   const size_t pages_at = ((size_t)padded + 63) & ~(size_t)63, pages_bytes = (size_t)n_pages * sizeof(DevPage);
-  K->d_chunk = upload_cache().take(pages_at + pages_bytes + 64, st);
+  K->d_chunk = tdv.cache.take(pages_at + pages_bytes + 64, st);
   K->d_body = make_buf((size_t)D.body_bytes + 64);
   K->d_states = make_buf((size_t)n_pages * sizeof(DevPageState));
   lap(2);
@@ -1850,7 +1874,7 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
   // hipMemcpyAsync issued here were both measured: the first makes later uploads on the stream wait on the host, the second returns only
   // when the stream has reached it)
   std::function<void(Column&)> finish = [K, nullable, n_pages](Column& col_out) {
-    static thread_local hipStream_t readback = nullptr;
+    hipStream_t& readback = scan_thread_device(K->device).readback;   // (`finish` runs on a thread whose current device is the chunk's)
     if (!readback) DFGPU_HIP(hipStreamCreateWithFlags(&readback, hipStreamNonBlocking));
     DFGPU_HIP(hipMemcpyAsync(K->states.data(), K->d_states->ptr, (size_t)n_pages * sizeof(DevPageState), hipMemcpyDeviceToHost, readback));
     DFGPU_HIP(hipMemcpyAsync(K->err.data(), K->d_err->ptr, 4, hipMemcpyDeviceToHost, readback));

@@ -587,3 +587,16 @@ def test_device_page_decode_survives_corrupt_pages(tmp_path, compression, seed):
         assert "parquet" in str(e) or "Parquet" in str(e), str(e)
     else:
         assert got.num_rows == n
+
+
+def test_device_page_decode_of_a_chunk_with_hundreds_of_pages(tmp_path):
+    """a chunk written with small pages (8 KB: ~400 data pages of 1000 values in one chunk): every page's first value is the sum of the
+    earlier pages' non-null counts, which the decode workgroups add up among their threads — more pages than a workgroup has threads"""
+    from datafusion_amd.parquet import read_table
+    rng = np.random.default_rng(23)
+    n = 400_000
+    t = pa.table({"a": pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.1), "b": pa.array(rng.integers(0, 40, n).astype(np.int32))})
+    path = str(tmp_path / "m.parquet")
+    pq.write_table(t, path, compression="snappy", data_page_size=8 * 1024, row_group_size=n, use_dictionary=["b"])
+    assert pq.ParquetFile(path).metadata.row_group(0).column(0).total_uncompressed_size > 300 * 8 * 1024
+    assert_tables_equal(plain(read_table(path).to_arrow()), pq.read_table(path), ordered=True)
