@@ -598,7 +598,10 @@ int dfgpu_agg_fused_updates(dfgpu_agg_t h, int64_t* out);
  *   agg.partitioned = 0|1 (1), agg.partitioned_min_rows (2 x rows worth a pass), agg.grouped_move, agg.direct_table, agg.runs = 0|1 (1)
  *   join.grouped_probe = 0|1 (1), join.grouped_min_rows (rows worth a pass), join.beyond_cache_bytes (4 x the L2 of an XCD),
  *   join.grouped_bits, join.near_window (test hooks: 0 = derived)
- *   sort.carried = o|i|p|0 (o), sort.carried_min_rows (rows worth a pass), sort.lsd = 0|1 (1: narrow keys sorted by record passes alone)
+ *   sort.carried = o|i|p|0 (o), sort.carried_min_rows (rows worth a pass), sort.lsd = 0|1 (1: narrow keys sorted by record passes alone),
+ *   sort.lsd_ahead = 0|1 (1: two-pass narrow-key sorts take their offsets from the digit-totals pass instead of a look-back)
+ *   parquet.device_decode = 0|1 (1: page headers on the host, levels / runs / values decoded by kernels), parquet.snappy = host|device (host),
+ *   parquet.in_flight (4: chunks a scan worker keeps in flight)
  * The same table is read from the environment variable DFGPU_OPTIONS="name=value,name=value" (lower priority than this call).
  * DFGPU_TRACE="agg,join,scan,dict,rowprog" (or "all") prints the named subsystems' decisions on stderr; no other environment
  * variable changes what the library does. */
