@@ -290,3 +290,26 @@ def test_device_plans_on_two_ranks_reproduce_the_reference_answers(tmp_path):
     for q in ("q1_pinned", "q3_pinned"):
         for r in range(2):
             assert_answer(q[:2], res[r][q])
+
+
+def test_bench_two_ranks_rehearsal_prints_its_line(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE GPU: both ranks on device 0,
+    a gloo group for the barriers and the host transport under dfgpu_exchange_* (DFGPU_BENCH_REHEARSAL=1).  Rank 0 prints ONE JSON line:
+    the blocking hash exchange is measured first, the streamed form and the pruned broadcast beside it, none of them reports an error,
+    and every exchange joins the same number of rows"""
+    import json
+    env = dict(os.environ, DFGPU_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sf", "1", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["metric"] == "tpch_q3_hash_join_rows_per_sec" and line["value"] > 0 and line["scaling"] == "strong"
+    assert "exchange_errors" not in line, line.get("exchange_errors")
+    ex = line["exchanges"]
+    assert {"repartition", "repartition_stream", "pruned"} <= set(ex), sorted(ex)
+    assert line["config"]["exchange"] in ("repartition", "repartition_stream")
+    assert line["config"]["output_rows"] == line["config"]["probe_rows"] > 5_900_000
+    for k, v in ex.items():
+        assert v["ms_per_step"] > 0 and v["transport"] == "host", (k, v)
