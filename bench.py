@@ -54,6 +54,50 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: measured float4 copy ceiling (79 % of spec)
 TABLE_KINDS = {0: "hash_map", 1: "array_map", 2: "rank_map", 3: "radix_lds", 4: "flat_hash_map", 5: "flat_hash_map_16"}
 
+# what the watchdog thread prints if a collective never returns (N > 1): the line as of the last finished measurement, the phase
+# that was running and since when.  run_join / run_query update it through checkpoint().
+WATCHDOG = {"line": None, "phase": "setup", "since": time.monotonic()}
+
+
+def start_watchdog(args, rank, world):
+    """N > 1 only: a rank stuck inside a collective (a peer died, RCCL never connected) cannot be helped from Python — but the run can
+    still leave a record.  Every rank runs a timer thread (the main thread is inside a C call with the GIL released); when one phase
+    has taken longer than --watchdog-s, rank 0 prints ONE JSON line — the line of the measurements that DID finish, or a line with
+    value null — carrying `watchdog: {phase, seconds}`, and every rank leaves with os._exit (rank 0 first, the others 5 s later)."""
+    if world == 1 or args.watchdog_s <= 0:
+        return
+    import threading
+
+    def watch():
+        while True:
+            time.sleep(1.0)
+            if WATCHDOG["phase"] == "done":
+                return
+            waited = time.monotonic() - WATCHDOG["since"]
+            if waited > args.watchdog_s + (0 if rank == 0 else 5):
+                line = WATCHDOG["line"]
+                if rank == 0:
+                    measured = line is not None
+                    if line is None:
+                        line = {"metric": "tpch_q3_hash_join_rows_per_sec" if args.workload == "join" else f"tpch_{args.workload}_rows_per_sec", "value": None,
+                                "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                                "scaling": "strong", "vs_baseline": None, "data": "synthetic", "config": {"workload": args.workload, "sf": args.sf}}
+                    line["watchdog"] = {"fired_in_phase": WATCHDOG["phase"], "after_s": round(waited, 1), "limit_s": args.watchdog_s,
+                                        "measured_before_it_fired": measured}
+                    sys.stdout.flush()
+                    print(json.dumps(line), flush=True)
+                    os._exit(0 if measured else 3)
+                os._exit(3)
+    threading.Thread(target=watch, daemon=True, name="bench-watchdog").start()
+
+
+def checkpoint_phase(phase, line=None):
+    WATCHDOG["phase"] = phase
+    WATCHDOG["since"] = time.monotonic()
+    if line is not None:
+        WATCHDOG["line"] = line
+
+
 BUILD_COLS = ["o_orderdate", "o_shippriority"]
 PROBE_COLS = ["l_orderkey", "l_extendedprice", "l_discount"]
 
@@ -195,7 +239,7 @@ def setup_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit("--gpus N needs N ranks: main() starts them itself when no launcher did")
     # DFGPU_BENCH_REHEARSAL=1: every rank on GPU 0, a gloo group and the host transport under dfgpu_exchange_* — the N > 1 control
     # flow (shards, both exchanges, max-over-ranks timing, the JSON line) on a box with one GPU.  Its numbers mean nothing.
     rehearsal = os.environ.get("DFGPU_BENCH_REHEARSAL", "0") == "1"
@@ -345,14 +389,120 @@ def run_join(args, rank, world, dist):
         tot = max_over_ranks(dist, 0.0, nb_local, np_local)[1]
         planner_choice = "pruned" if broadcast_build_moves_fewer_bytes(tot[0] * 16, tot[1] * 40, world) else "repartition"
     others, exchange_errors = {}, {}
+
+    def make_line(m, primary, ordered, final):
+        """the JSON line from what has been measured so far (final=False: the watchdog's partial line, no CPU leg)"""
+        nb, np_, nout, dt, stats, info = m["nb"], m["np"], m["nout"], m["dt"], m["stats"], m["info"]
+        ms_per_step = dt / args.steps * 1e3
+        rows_per_s = (nb + np_) / (dt / args.steps)
+        alg = algorithmic_bytes(nb, np_, nout)
+
+        def roofline_of(st):
+            """the dominant kernel of a step: algorithmic bytes per launch (probe columns once + build payload
+            once + output once, computed by the library per launch) / its average HIP-event duration on the library stream"""
+            name = next((k for k in ("join_probe_fused", "join_probe_placed", "join_probe_materialize") if k in st), None)
+            if name is None or not st[name]["calls"]:
+                return None
+            d = st[name]
+            avg_ms = d["total_ms"] / d["calls"]
+            per_launch = d["bytes"] / d["calls"]
+            achieved = per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_vs_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
+            attach_traffic(roof, name, {"build_rows": nb, "probe_rows": np_, "output_rows": nout}, world)
+            return roof
+
+        def kernel_table(st):
+            return {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in st.items()}
+
+        def exchange_summary(mm):
+            """one exchange flavour: its step time, what crossed per step (rank 0's view), and — so that a first run on real multi-GPU
+            hardware diagnoses itself — what the transport reports and what the wires allow: xGMI is point-to-point, 7 links x ~153 GB/s
+            per GPU (MI355X_MICROARCH.md / SURVEY 8e), so an all-to-all(v) in which rank 0 sends B bytes to its N - 1 peers cannot
+            finish before max(bytes to one peer) / 153 GB/s; the same bound for what it receives"""
+            per_step = {k: v // args.steps for k, v in mm["xstats"].items()} if mm["xstats"] else None
+            out = {"ms_per_step": round(mm["dt"] / args.steps * 1e3, 3), "rows_per_s": (mm["nb"] + mm["np"]) / (mm["dt"] / args.steps),
+                   "join_table": TABLE_KINDS[mm["info"].table_kind], "crossed_per_step_rank0": per_step}
+            if mm["stats"]:
+                # the step's three phases as the library's HIP events saw them on rank 0 (summed kernel time per step; under the streamed
+                # exchange they run on three streams at once, so their sum may exceed the step): partition kernels, the all-to-all(v), the join
+                def phase(pred):
+                    return round(sum(v["total_ms"] for k, v in mm["stats"].items() if pred(k)) / args.steps, 3)
+                ph = {"partition_ms": phase(lambda k: k.startswith("partition") or k == "scan_u32"), "exchange_ms": phase(lambda k: k.startswith("exchange")),
+                      "join_ms": phase(lambda k: k.startswith("join") or k in ("scan_mask_popcounts", "column_minmax", "gather", "concat"))}
+                out["phases_ms_rank0"] = ph
+                out["phases_sum_ms"] = round(sum(ph.values()), 3)
+                out["longest_phase_ms"] = max(ph.values())
+                out["step_over_longest_phase"] = round(out["ms_per_step"] / max(ph.values()), 3) if max(ph.values()) > 0 else None
+            if comm is not None:
+                out.update(comm.transport_info())
+            if per_step and world > 1:
+                link_gbs = 153.0
+                sent, recv = per_step.get("bytes_sent_to_peers", 0), per_step.get("bytes_received_from_peers", 0)
+                per_link = max(sent, recv) / (world - 1)          # an even all-to-all spreads a rank's bytes over its N - 1 links
+                out["bytes_per_link_per_step_rank0"] = int(per_link)
+                out["predicted_exchange_ms_at_153_GBps_per_link"] = round(per_link / (link_gbs * 1e9) * 1e3, 3)
+                ex_ms = sum(v["total_ms"] for k, v in mm["stats"].items() if k.startswith("exchange")) / args.steps if mm["stats"] else None
+                out["measured_exchange_ms"] = round(ex_ms, 3) if ex_ms else None
+            return out
+
+        parallelism = {"none": "single GPU",
+                       "repartition_stream": f"Partitioned x{world}: hash repartition of both sides STREAMED in {args.exchange_chunks} chunks (dfgpu_exchange_hash_stream: partition "
+                                             "kernel, RCCL all-to-all(v) and the join's build / probe of neighbouring chunks overlap)",
+                       "pruned": f"CollectLeft x{world}: build-side all-gather pruned by each rank's probe-key bounds (dfgpu_exchange_broadcast_pruned, RCCL send/recv), probe side stays in place",
+                       "broadcast": f"CollectLeft x{world}: RCCL all-gather of the build side (dfgpu_exchange_broadcast), probe side stays in place",
+                       "repartition": f"Partitioned x{world}: hash repartition of both sides (dfgpu_exchange_hash: partition kernel + RCCL all-to-all(v))"}[primary]
+        line = {
+            "metric": "tpch_q3_hash_join_rows_per_sec", "value": rows_per_s, "unit": "rows/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int64 keys / decimal128 payload", "data": "synthetic",
+            "config": {"workload": f"INNER hash-join orders⋈lineitem on o_orderkey, TPC-H SF{args.sf:g}, Q3 payload "
+                                   "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
+                       "build_rows": nb, "probe_rows": np_, "output_rows": nout,
+                       "join_table": TABLE_KINDS[info.table_kind],
+                       "probe": {0: "placed_ordered", 1: "placed_ordered", 2: "single_pass_ordered_lookback", 3: "single_pass_unordered"}[args.probe_mode],
+                       "parallelism": parallelism, "exchange": primary, "planner_choice": planner_choice, "shard_skew": args.shard_skew if world > 1 else None},
+            "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),
+            "hbm_frac_whole_step": round(alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "roofline": roofline_of(stats), "kernels": kernel_table(stats),
+        }
+        if world > 1 or forced:
+            line["exchanges"] = {primary: exchange_summary(m), **{k: exchange_summary(v) for k, v in others.items()}}
+            if exchange_errors:
+                line["exchange_errors"] = exchange_errors
+        if ordered is not None:
+            # the same step with the output in probe order, exactly as the reference emits it (hash_join/exec.rs:3349):
+            # tile counts -> scan -> the fused kernel with known tile offsets
+            oms = ordered["dt"] / args.steps * 1e3
+            line["ordered_output"] = {"probe": "placed (tile counts -> scan -> fused materialise)", "ms_per_step": round(oms, 3),
+                                      "rows_per_s": (nb + np_) / (oms * 1e-3),
+                                      "hbm_frac_whole_step": round(alg / (oms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                      "roofline": roofline_of(ordered["stats"]), "kernels": kernel_table(ordered["stats"])}
+        if final and not args.no_cpu and world == 1:  # the CPU baseline is reported by the single-GPU run only
+            threads = os.cpu_count() or 1
+            line["cpu_baseline"] = cpu_baseline(args.sf, args.sf if args.cpu_sf is None else args.cpu_sf, threads, orders, lineitem)
+            # a ratio only between equal workloads: the same tables, the same payload, the same scale factor
+            line["speedup_vs_cpu_port"] = round(rows_per_s / line["cpu_baseline"]["value"], 1) if line["cpu_baseline"]["same_workload_as_gpu_leg"] else None
+        return line
+
+    def checkpoint(m, primary, phase):
+        """rank 0 keeps the line as it would be printed NOW: if a later exchange hangs, the watchdog prints this one"""
+        checkpoint_phase(phase, make_line(m, primary, None, False) if (rank == 0 and m is not None) else None)
     if world > 1 and args.exchange == "auto":
         # First the blocking exchange — the shortest code path through RCCL, so that a first run on a real multi-GPU node has a result in
         # hand — then the streamed form of the same exchange and the planner's alternative, each allowed to fail with an error (the same
-        # error on every rank: a rank that hangs inside a collective cannot be helped from here).  `value` = north_star's hash repartition
+        # error on every rank: a rank that hangs inside a collective is the watchdog's case).  `value` = north_star's hash repartition
         # at its best: the streamed form when it ran and was faster (dt is the maximum over ranks, so every rank decides alike).
+        checkpoint(None, None, "repartition")
         m = measure("repartition", args.probe_mode, True)
         primary = "repartition"
         for ex in (("repartition_stream",) if args.exchange_chunks > 1 else ()) + ("pruned",):
+            checkpoint(m, primary, ex)
+            if exchange_errors:
+                # an exchange that failed part-way may have left the ranks out of step inside the communicator: nothing more runs on it
+                exchange_errors[ex] = "skipped: an earlier exchange failed on this communicator"
+                continue
             try:
                 others[ex] = measure(ex, args.probe_mode, True)
             except Exception as e:  # noqa: BLE001
@@ -360,105 +510,18 @@ def run_join(args, rank, world, dist):
         if "repartition_stream" in others and others["repartition_stream"]["dt"] < m["dt"]:
             others["repartition"], m, primary = m, others.pop("repartition_stream"), "repartition_stream"
     else:
+        checkpoint(None, None, primary)
         m = measure(primary, args.probe_mode, True)
         if forced and primary == "repartition_stream":
+            checkpoint(m, primary, "repartition")
             others["repartition"] = measure("repartition", args.probe_mode, True)
     # secondary, outside the contract's timed region: the same step with the output in probe order
+    checkpoint(m, primary, "ordered_output")
     ordered = measure(primary, 0, True) if (args.probe_mode == 3 and world == 1) else None
-    if rank != 0:
-        return None
-    nb, np_, nout, dt, stats, info = m["nb"], m["np"], m["nout"], m["dt"], m["stats"], m["info"]
-    ms_per_step = dt / args.steps * 1e3
-    rows_per_s = (nb + np_) / (dt / args.steps)
-    alg = algorithmic_bytes(nb, np_, nout)
-
-    def roofline_of(st):
-        """the dominant kernel of a step: algorithmic bytes per launch (probe columns once + build payload
-        once + output once, computed by the library per launch) / its average HIP-event duration on the library stream"""
-        name = next((k for k in ("join_probe_fused", "join_probe_placed", "join_probe_materialize") if k in st), None)
-        if name is None or not st[name]["calls"]:
-            return None
-        d = st[name]
-        avg_ms = d["total_ms"] / d["calls"]
-        per_launch = d["bytes"] / d["calls"]
-        achieved = per_launch / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_vs_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
-                "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch)}
-        attach_traffic(roof, name, {"build_rows": nb, "probe_rows": np_, "output_rows": nout}, world)
-        return roof
-
-    def kernel_table(st):
-        return {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in st.items()}
-
-    def exchange_summary(mm):
-        """one exchange flavour: its step time, what crossed per step (rank 0's view), and — so that a first run on real multi-GPU
-        hardware diagnoses itself — what the transport reports and what the wires allow: xGMI is point-to-point, 7 links x ~153 GB/s
-        per GPU (MI355X_MICROARCH.md / SURVEY 8e), so an all-to-all(v) in which rank 0 sends B bytes to its N - 1 peers cannot
-        finish before max(bytes to one peer) / 153 GB/s; the same bound for what it receives"""
-        per_step = {k: v // args.steps for k, v in mm["xstats"].items()} if mm["xstats"] else None
-        out = {"ms_per_step": round(mm["dt"] / args.steps * 1e3, 3), "rows_per_s": (mm["nb"] + mm["np"]) / (mm["dt"] / args.steps),
-               "join_table": TABLE_KINDS[mm["info"].table_kind], "crossed_per_step_rank0": per_step}
-        if mm["stats"]:
-            # the step's three phases as the library's HIP events saw them on rank 0 (summed kernel time per step; under the streamed
-            # exchange they run on three streams at once, so their sum may exceed the step): partition kernels, the all-to-all(v), the join
-            def phase(pred):
-                return round(sum(v["total_ms"] for k, v in mm["stats"].items() if pred(k)) / args.steps, 3)
-            ph = {"partition_ms": phase(lambda k: k.startswith("partition") or k == "scan_u32"), "exchange_ms": phase(lambda k: k.startswith("exchange")),
-                  "join_ms": phase(lambda k: k.startswith("join") or k in ("scan_mask_popcounts", "column_minmax", "gather", "concat"))}
-            out["phases_ms_rank0"] = ph
-            out["phases_sum_ms"] = round(sum(ph.values()), 3)
-            out["longest_phase_ms"] = max(ph.values())
-            out["step_over_longest_phase"] = round(out["ms_per_step"] / max(ph.values()), 3) if max(ph.values()) > 0 else None
-        if comm is not None:
-            out.update(comm.transport_info())
-        if per_step and world > 1:
-            link_gbs = 153.0
-            sent, recv = per_step.get("bytes_sent_to_peers", 0), per_step.get("bytes_received_from_peers", 0)
-            per_link = max(sent, recv) / (world - 1)          # an even all-to-all spreads a rank's bytes over its N - 1 links
-            out["bytes_per_link_per_step_rank0"] = int(per_link)
-            out["predicted_exchange_ms_at_153_GBps_per_link"] = round(per_link / (link_gbs * 1e9) * 1e3, 3)
-            ex_ms = sum(v["total_ms"] for k, v in mm["stats"].items() if k.startswith("exchange")) / args.steps if mm["stats"] else None
-            out["measured_exchange_ms"] = round(ex_ms, 3) if ex_ms else None
-        return out
-
-    parallelism = {"none": "single GPU",
-                   "repartition_stream": f"Partitioned x{world}: hash repartition of both sides STREAMED in {args.exchange_chunks} chunks (dfgpu_exchange_hash_stream: partition "
-                                         "kernel, RCCL all-to-all(v) and the join's build / probe of neighbouring chunks overlap)",
-                   "pruned": f"CollectLeft x{world}: build-side all-gather pruned by each rank's probe-key bounds (dfgpu_exchange_broadcast_pruned, RCCL send/recv), probe side stays in place",
-                   "broadcast": f"CollectLeft x{world}: RCCL all-gather of the build side (dfgpu_exchange_broadcast), probe side stays in place",
-                   "repartition": f"Partitioned x{world}: hash repartition of both sides (dfgpu_exchange_hash: partition kernel + RCCL all-to-all(v))"}[primary]
-    line = {
-        "metric": "tpch_q3_hash_join_rows_per_sec", "value": rows_per_s, "unit": "rows/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "int64 keys / decimal128 payload", "data": "synthetic",
-        "config": {"workload": f"INNER hash-join orders⋈lineitem on o_orderkey, TPC-H SF{args.sf:g}, Q3 payload "
-                               "(o_orderdate,o_shippriority,l_orderkey,l_extendedprice,l_discount), device-resident inputs",
-                   "build_rows": nb, "probe_rows": np_, "output_rows": nout,
-                   "join_table": TABLE_KINDS[info.table_kind],
-                   "probe": {0: "placed_ordered", 1: "placed_ordered", 2: "single_pass_ordered_lookback", 3: "single_pass_unordered"}[args.probe_mode],
-                   "parallelism": parallelism, "exchange": primary, "planner_choice": planner_choice, "shard_skew": args.shard_skew if world > 1 else None},
-        "algorithmic_gb_per_s": round(alg / (dt / args.steps) / 1e9, 1),
-        "hbm_frac_whole_step": round(alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
-        "roofline": roofline_of(stats), "kernels": kernel_table(stats),
-    }
-    if world > 1 or forced:
-        line["exchanges"] = {primary: exchange_summary(m), **{k: exchange_summary(v) for k, v in others.items()}}
-        if exchange_errors:
-            line["exchange_errors"] = exchange_errors
-    if ordered is not None:
-        # the same step with the output in probe order, exactly as the reference emits it (hash_join/exec.rs:3349):
-        # tile counts -> scan -> the fused kernel with known tile offsets
-        oms = ordered["dt"] / args.steps * 1e3
-        line["ordered_output"] = {"probe": "placed (tile counts -> scan -> fused materialise)", "ms_per_step": round(oms, 3),
-                                  "rows_per_s": (nb + np_) / (oms * 1e-3),
-                                  "hbm_frac_whole_step": round(alg / (oms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
-                                  "roofline": roofline_of(ordered["stats"]), "kernels": kernel_table(ordered["stats"])}
-    if not args.no_cpu and world == 1:  # the CPU baseline is reported by the single-GPU run only
-        threads = os.cpu_count() or 1
-        line["cpu_baseline"] = cpu_baseline(args.sf, args.cpu_sf, threads, orders, lineitem)
-        # a ratio only between equal workloads: the same tables, the same payload, the same scale factor
-        line["speedup_vs_cpu_port"] = round(rows_per_s / line["cpu_baseline"]["value"], 1) if line["cpu_baseline"]["same_workload_as_gpu_leg"] else None
+    checkpoint_phase("done")
+    line = make_line(m, primary, ordered, True) if rank == 0 else None
+    orders.free()
+    lineitem.free()
     return line
 
 
@@ -502,107 +565,66 @@ def q3_algorithmic_table(n_customer, n_orders, n_lineitem, st):
     return [{"operator": o, "input_bytes": int(i), "output_bytes": int(w)} for o, i, w in rows]
 
 
-def cpu_baseline_query(workload, gpu_sf, hw_threads, budget_s=20.0):
+def cpu_baseline_query(workload, gpu_sf, hw_threads, device_tables=None, max_sf=None, budget_s=60.0):
     """oracle leg (kind "port") of configs 4 / 5: the reference's pinned plan (q1.slt.part:42-58 / q3.slt.part:44-76) run with the CPU
-    restatement's operators (oracle/oracle.py over oracle/dforacle.c) on this box's host cores, the way DataFusion runs it: the scan cut
-    into `target_partitions` row ranges, one thread per partition — Partial aggregate / filter per partition, RepartitionExec(Hash) between
-    the stages, FinalPartitioned aggregate / partitioned joins per hash partition, a merge of the per-partition sorted runs.  The scale
-    factor is a BOUNDED sample: SF1 is timed first and the largest of SF 1 / 3 / 10 / 30 whose projected time fits ~budget_s is run."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    import numpy as np
-    import pyarrow as pa
-
-    from datafusion_amd import queries
-    from oracle import oracle
+    restatement's operators (oracle/plans.py over oracle/oracle.py, oracle/dforacle.c) on this box's host cores, the way DataFusion runs
+    it: the scan cut into `target_partitions` row ranges, one thread per partition — Partial aggregate / filter per partition,
+    RepartitionExec(Hash) between the stages, FinalPartitioned aggregate / partitioned joins per hash partition, a merge of the
+    per-partition sorted runs.  It runs on the GPU leg's OWN tables copied to the host, at the GPU leg's scale factor, when host RAM
+    holds them and their intermediates (Q1 SF100: 42 GB + 39 GB; Q3 SF300: 91 GB + 2 x 39 GB) and SF1's time projects to less than
+    `budget_s`; else on the largest of SF 100 / 30 / 10 / 3 / 1 that does (same_workload_as_gpu_leg says which)."""
+    from datafusion_amd import ops
+    from oracle import plans
     quota = cpu_quota()
     cores = max(1, int(min(hw_threads, quota) if quota else hw_threads))
     P = cores
-    D1, D3 = queries.DATE_Q1, queries.DATE_Q3
-    ce = ("bin", "*", ("col", "l_extendedprice"), ("bin", "-", ("lit", 1, pa.decimal128(20, 0)), ("col", "l_discount")))
+    avail = host_memory_available()
+    per_sf = (70 * 6.0e6 * 2.2) if workload == "q1" else ((9 * 0.15e6 + 24 * 1.5e6 + 44 * 6.0e6) * 2.4)   # tables + filtered + repartitioned copies
 
-    def slices(t):
-        n = t.num_rows
-        return [t.slice(n * k // P, n * (k + 1) // P - n * k // P) for k in range(P)]
+    q1_cols = ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"]
 
-    def by_hash(parts, key):
-        """RepartitionExec(Hash([key], P)): every input partition splits its rows by the reference's hash routing; output partition q
-        is the concatenation of the q-th pieces"""
-        def split(t):
-            if t.num_rows == 0:
-                return [t] * P
-            return oracle.hash_partition(t, [key], P)[0]
-        with ThreadPoolExecutor(P) as ex:
-            pieces = list(ex.map(split, parts))
-        return [pa.concat_tables([pieces[i][q] for i in range(len(parts))]) for q in range(P)]
+    def fits(sf):
+        return avail is None or sf * per_sf < 0.8 * avail
 
-    def run_q1(li):
-        gb = [(("col", "l_returnflag"), "l_returnflag"), (("col", "l_linestatus"), "l_linestatus")]
-        one_plus_tax = ("bin", "+", ("lit", 1, pa.decimal128(20, 0)), ("col", "l_tax"))
-        aggs = [("sum", ("col", "l_quantity"), "sum_qty"), ("sum", ("col", "l_extendedprice"), "sum_base_price"), ("sum", ce, "sum_disc_price"),
-                ("sum", ("bin", "*", ce, one_plus_tax), "sum_charge"), ("avg", ("col", "l_quantity"), "avg_qty"),
-                ("avg", ("col", "l_extendedprice"), "avg_price"), ("avg", ("col", "l_discount"), "avg_disc"), ("count", None, "count_order")]
-
-        def partial(t):
-            f = oracle.filter(t, ("bin", "<=", ("col", "l_shipdate"), ("lit", D1, pa.date32())),
-                              ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus"])
-            return oracle.aggregate(f, gb, aggs, "Partial")
-        with ThreadPoolExecutor(P) as ex:
-            parts = list(ex.map(partial, slices(li)))
-        rt = {"avg_qty": pa.decimal128(19, 6), "avg_price": pa.decimal128(19, 6), "avg_disc": pa.decimal128(19, 6)}
-        fin = oracle.aggregate(pa.concat_tables(parts), gb, aggs, "FinalPartitioned", return_types=rt)
-        return oracle.sort(fin, [("l_returnflag", False, False), ("l_linestatus", False, False)])
-
-    def run_q3(cu, od, li):
-        with ThreadPoolExecutor(P) as ex:
-            c = list(ex.map(lambda t: oracle.filter(t, ("bin", "=", ("col", "c_mktsegment"), ("lit", queries.SEGMENT_BUILDING, pa.uint8())), ["c_custkey"]), slices(cu)))
-            o = list(ex.map(lambda t: oracle.filter(t, ("bin", "<", ("col", "o_orderdate"), ("lit", D3, pa.date32())),
-                                                    ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"]), slices(od)))
-            l = list(ex.map(lambda t: oracle.filter(t, ("bin", ">", ("col", "l_shipdate"), ("lit", D3, pa.date32())),
-                                                    ["l_orderkey", "l_extendedprice", "l_discount"]), slices(li)))
-        c_r, o_r = by_hash(c, "c_custkey"), by_hash(o, "o_custkey")
-        with ThreadPoolExecutor(P) as ex:
-            semi = list(ex.map(lambda ab: oracle.hash_join(ab[0], ab[1], [("c_custkey", "o_custkey")], "RightSemi").select(["o_orderkey", "o_orderdate", "o_shippriority"]),
-                               zip(c_r, o_r)))
-        s_r, l_r = by_hash(semi, "o_orderkey"), by_hash(l, "l_orderkey")
-        gb = [(("col", "l_orderkey"), "l_orderkey"), (("col", "o_orderdate"), "o_orderdate"), (("col", "o_shippriority"), "o_shippriority")]
-
-        def tail(ab):
-            j = oracle.hash_join(ab[0], ab[1], [("o_orderkey", "l_orderkey")], "Inner").select(["o_orderdate", "o_shippriority", "l_orderkey", "l_extendedprice", "l_discount"])
-            a = oracle.aggregate(j, gb, [("sum", ce, "revenue")], "SinglePartitioned")
-            return oracle.sort(a, queries.Q3_SORT, fetch=10)
-        with ThreadPoolExecutor(P) as ex:
-            tops = list(ex.map(tail, zip(s_r, l_r)))
-        return oracle.sort(pa.concat_tables(tops), queries.Q3_SORT, fetch=10)
-
-    def tables(sf):
-        """the sample's tables from the DEVICE generator (the GPU leg's own, seconds instead of the numpy mirror's minute), copied to the host"""
-        from datafusion_amd import ops
-        gens = (ops.tpch_lineitem,) if workload == "q1" else (ops.tpch_customer, ops.tpch_orders, ops.tpch_lineitem)
+    def host_tables(sf):
+        """the sample's tables: the GPU leg's own when the scale factors agree, else from the same DEVICE generator, copied to the host"""
+        if device_tables is not None and sf == gpu_sf:
+            return tuple(t.to_arrow() for t in device_tables)
+        gens = ((ops.tpch_lineitem, q1_cols),) if workload == "q1" else ((ops.tpch_customer, ["c_custkey", "c_mktsegment"]),
+                (ops.tpch_orders, ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"]), (ops.tpch_lineitem, ["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"]))
         out = []
-        for g in gens:
+        for g, cols in gens:
             t = g(sf)
-            out.append(t.to_arrow())
+            s = t.select(cols)
             t.free()
+            out.append(s.to_arrow())
+            s.free()
         return tuple(out)
 
     def once(sf):
-        ts = tables(sf)
+        ts = host_tables(sf)
+        st = {}
         t0 = time.perf_counter()
-        out = run_q1(*ts) if workload == "q1" else run_q3(*ts)
-        return time.perf_counter() - t0, sum(t.num_rows for t in ts), out.num_rows
-    dt, rows, n_out = once(1.0)
-    sf = 1.0
-    for cand in (30.0, 10.0, 3.0):
-        if cand <= gpu_sf and dt * cand <= budget_s:
+        out = plans.run_q1(*ts, P, st) if workload == "q1" else plans.run_q3(*ts, P, st)
+        dt = time.perf_counter() - t0
+        return dt, sum(t.num_rows for t in ts), out, st
+    dt, rows, out, st = once(min(1.0, gpu_sf))
+    sf = min(1.0, gpu_sf)
+    cap = gpu_sf if max_sf is None else min(gpu_sf, max_sf)
+    for cand in (gpu_sf, 100.0, 30.0, 10.0, 3.0):
+        if 1.0 < cand <= cap and dt * cand <= budget_s and fits(cand):
             sf = cand
-            dt, rows, n_out = once(sf)
+            dt, rows, out, st = once(sf)
             break
+    origin = "the GPU leg's own tables" if (device_tables is not None and sf == gpu_sf) else "tables from the GPU leg's generator"
     return {"value": rows / dt, "unit": "rows/s", "cores": cores, "threads": P, "kind": "port", "sf": sf, "seconds": round(dt, 2),
-            "same_workload_as_gpu_leg": bool(sf == gpu_sf), "cpu_quota": quota,
-            "sample": f"TPC-H {workload.upper()} at SF{sf:g} ({rows} scanned rows, {n_out} output rows), tables from the GPU leg's own generator copied to "
-                      f"the host: the reference's pinned plan on the oracle's operators, "
-                      f"{P} partitions / threads (host has {hw_threads} hardware threads, cgroup CPU quota {quota})"}
+            "same_workload_as_gpu_leg": bool(sf == gpu_sf), "cpu_quota": quota, "intermediate_rows": st,
+            "result": out,
+            "sample": f"TPC-H {workload.upper()} at SF{sf:g} ({rows} scanned rows, {out.num_rows} output rows), "
+                      f"{origin} copied to "
+                      f"the host: the reference's pinned plan on the oracle's operators (oracle/plans.py), "
+                      f"{P} partitions / threads (host has {hw_threads} hardware threads, cgroup CPU quota {quota}, "
+                      f"{'unknown' if avail is None else round(avail / 2**30)} GiB of host RAM available)"}
 
 
 def run_query(args, rank, world, dist):
@@ -641,10 +663,16 @@ def run_query(args, rank, world, dist):
         n = out.num_rows
         out.free()
         return n
+    checkpoint_phase(f"{args.workload} warm-up")
     for _ in range(args.warmup):
         step()
+    checkpoint_phase(f"{args.workload} timed steps")
     if args.workload == "q3":   # the intermediate row counts of the algorithmic-bytes table (8d config 5), outside the timed region
-        queries.q3(*tables, group=group, stats=q3_stats).free()
+        res = queries.q3(*tables, group=group, stats=q3_stats)
+    else:
+        res = queries.q1(lineitem, group)
+    gpu_result = res.to_arrow()      # what the CPU leg's result is compared with (outside the timed region)
+    res.free()
     comm = None
     if world > 1:
         from datafusion_amd.exchange import comm_for
@@ -662,6 +690,7 @@ def run_query(args, rank, world, dist):
     counts = None
     if args.workload == "q3":
         counts = max_over_ranks(dist, 0.0, *(q3_stats.get(k, 0) for k in ("customer_filtered", "semi_join", "join", "groups")), *(t.num_rows for t in tables))[1]
+    checkpoint_phase("done")
     if rank != 0:
         return None
     step_s = dt / args.steps
@@ -692,9 +721,13 @@ def run_query(args, rank, world, dist):
                                 else "TPC-H Q3 end to end (2 hash joins + aggregate + top-k; at N > 1 four hash repartitions in two exchange phases)") + f", SF{args.sf:g}, device-resident inputs",
                    "input_rows": rows, "output_rows": n_out, "parallelism": "single GPU" if world == 1 else f"{world} ranks, dfgpu_exchange_hash (RCCL all-to-all(v))"},
         "scanned_table_gb_per_s": round(nbytes / step_s / 1e9, 1),
-        "algorithmic_bytes_per_step": int(alg), "algorithmic_bytes_table": alg_table,
-        "algorithmic_gb_per_s": round(alg / step_s / 1e9, 1), "hbm_frac_whole_step": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 4),
+        # whole-step fraction of peak by the bytes the step's kernels have to move (each kernel's own algorithmic bytes, summed by the
+        # library): a late-materialising plan never reads the columns of rows it drops, so SURVEY 8(d)'s operator-table formula (every
+        # referenced column read once) is kept beside it under its own name and is NOT a roofline fraction
         "kernel_algorithmic_bytes_per_step": int(alg_kernels),
+        "algorithmic_gb_per_s": round(alg_kernels / step_s / 1e9, 1), "hbm_frac_whole_step": round(alg_kernels / step_s / 1e9 / (HBM_PEAK_GBS * world), 4),
+        "survey_8d_formula": {"bytes_per_step": int(alg), "table": alg_table, "gb_per_s": round(alg / step_s / 1e9, 1),
+                              "note": "referenced input column bytes + output bytes per operator; not a roofline fraction when the plan skips columns of dropped rows"},
         "roofline": roof,
         "kernels": {k: {"calls": v["calls"], "avg_ms": round(v["total_ms"] / max(1, v["calls"]), 4)} for k, v in top},
         "kernel_ms_per_step": round(sum(v["total_ms"] for v in stats.values()) / args.steps, 4),
@@ -703,11 +736,70 @@ def run_query(args, rank, world, dist):
     if counts is not None:
         line["config"]["intermediate_rows"] = dict(zip(("customer_filtered", "semi_join", "join", "groups"), counts[:4]))
     if not args.no_cpu and world == 1:
-        for t in tables:
-            t.free()
-        line["cpu_baseline"] = cpu_baseline_query(args.workload, args.sf, os.cpu_count() or 1)
-        line["speedup_vs_cpu_port"] = round(line["value"] / line["cpu_baseline"]["value"], 1) if line["cpu_baseline"]["same_workload_as_gpu_leg"] else None
+        cb = cpu_baseline_query(args.workload, args.sf, os.cpu_count() or 1, device_tables=tables, max_sf=args.cpu_sf)
+        cpu_result = cb.pop("result")
+        if cb["same_workload_as_gpu_leg"]:
+            # the oracle as the CHECKER of the GPU leg at the benchmark's own size: the same tables, so the same rows (bit-exact)
+            cb["result_equals_gpu_leg"] = bool(cpu_result.to_pylist() == gpu_result.to_pylist())
+            if counts is not None:
+                cb["intermediate_rows_equal_gpu_leg"] = bool(all(cb["intermediate_rows"].get(k) == v for k, v in line["config"]["intermediate_rows"].items()))
+        line["cpu_baseline"] = cb
+        line["speedup_vs_cpu_port"] = round(line["value"] / cb["value"], 1) if cb["same_workload_as_gpu_leg"] else None
+    for t in tables:
+        t.free()
     return line
+
+
+ALSO_DEFAULT = "q1:100,q3:300"   # BASELINE config 4 (TPC-H Q1 SF100) and config 5 (TPC-H Q3 SF300: the one-GPU anchor of the 8-GPU configuration)
+
+
+def also_legs(args, spec, deadline_s=900.0):
+    """BASELINE configs 4 and 5 beside the headline, on the default single-GPU line: each runs as its own process (`bench.py --workload q1 /
+    q3` at the configuration's scale factor, the same --steps / --warmup, its CPU leg included) AFTER the headline's timed region and after
+    its tables are freed, and its line is folded into `also` — ms_per_step, rows/s, the dominant kernel's roofline, the whole-step
+    fraction, the CPU leg on the same tables and whether the oracle's result equals the GPU leg's.  A leg that fails or runs out of time
+    leaves an `error` entry; the headline line is printed whatever happens here."""
+    import subprocess
+    out = {}
+    t_start = time.perf_counter()
+    for item in spec.split(","):
+        workload, sf = item.split(":")[0], float(item.split(":")[1])
+        what = f"BASELINE config {4 if workload == 'q1' else 5}: TPC-H {workload.upper()} at SF{sf:g} on one GPU"
+        left = deadline_s - (time.perf_counter() - t_start)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--sf", str(sf), "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--no-also"] + (["--no-cpu"] if args.no_cpu else []) + ([] if args.cpu_sf is None else ["--cpu-sf", str(args.cpu_sf)])
+        try:
+            if left < 30:
+                raise TimeoutError("no time left for this leg")
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=left)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                raise RuntimeError(f"rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}")
+            d = json.loads(lines[-1])
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernel_algorithmic_bytes_per_step", "algorithmic_gb_per_s",
+                    "hbm_frac_whole_step", "roofline", "kernels", "kernel_ms_per_step", "cpu_baseline", "speedup_vs_cpu_port")
+            out[workload] = {"what": what, **{k: d[k] for k in keep if k in d}, "survey_8d_formula_gb_per_s": d.get("survey_8d_formula", {}).get("gb_per_s"),
+                             "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:  # noqa: BLE001 - the headline must not depend on a secondary leg
+            out[workload] = {"what": what, "error": repr(e)[:400]}
+    return out
+
+
+def self_spawn(args):
+    """`bench.py --gpus N` started WITHOUT a launcher (no RANK / WORLD_SIZE in the environment): start the N ranks ourselves — the
+    command line the driver documents, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` — and pass
+    their output through, so the run produces its line either way."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -716,7 +808,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor (BASELINE: 100)")
-    ap.add_argument("--cpu-sf", type=float, default=100.0, help="largest scale factor the CPU-baseline leg may run at (it takes the GPU leg's when host RAM allows)")
+    ap.add_argument("--cpu-sf", type=float, default=None, help="largest scale factor the CPU-baseline leg may run at (default: the GPU leg's, taken when host RAM allows)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", choices=["join", "q1", "q3"], default="join",
                     help="join = the BASELINE metric (config 3 ii); q1 / q3 = the whole TPC-H Q1 / Q3 plan per step (configs 4 and 5)")
@@ -732,9 +824,26 @@ def main():
     ap.add_argument("--probe-mode", type=int, default=3,
                     help="3 single pass, unordered output (default: in Q3 the join feeds AggregateExec, no ancestor needs the probe "
                          "order); 0/1 output in probe order (tile counts -> scan -> placed); 2 single pass ordered (look-back)")
+    ap.add_argument("--watchdog-s", type=float, default=300.0,
+                    help="N > 1: seconds one phase (RCCL bootstrap, table generation, one exchange flavour's warm-up + timed steps) may take before rank 0 "
+                         "prints the line of what HAS been measured with a `watchdog` object and every rank exits (0 = no watchdog)")
+    ap.add_argument("--also", default=None,
+                    help=f"workload:SF pairs run after the headline and folded into `also` (default {ALSO_DEFAULT} when --sf is 100, nothing otherwise)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="the default single-GPU join line also carries BASELINE configs 4 and 5 (Q1 SF100, Q3 SF300, each run as its own process after "
+                         "the headline's timed region) under `also`; this leaves them out")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(args))
+    start_watchdog(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
     rank, world, _local, dist = setup_dist(args)
+    checkpoint_phase("generate tables")
     line = run_join(args, rank, world, dist) if args.workload == "join" else run_query(args, rank, world, dist)
+    also = "" if args.no_also else (args.also if args.also is not None else (ALSO_DEFAULT if args.sf == 100.0 else ""))
+    if world == 1 and args.workload == "join" and args.exchange == "auto" and also:
+        from datafusion_amd import _lib
+        _lib.load().dfgpu_mem_trim()    # the headline's HBM goes back to the driver before the other configurations take theirs
+        line["also"] = also_legs(args, also)
     # the JSON line is the LAST thing on stdout: whatever native libraries buffered in C stdio (RCCL prints its version banner
     # there) leaves every rank's buffer first
     import ctypes

@@ -313,3 +313,18 @@ def test_bench_two_ranks_rehearsal_prints_its_line(tmp_path):
     assert line["config"]["output_rows"] == line["config"]["probe_rows"] > 5_900_000
     for k, v in ex.items():
         assert v["ms_per_step"] > 0 and v["transport"] == "host", (k, v)
+
+
+def test_bench_two_ranks_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (no RANK / WORLD_SIZE in the environment — how the driver starts N = 1) starts the two ranks
+    itself (torch.distributed.run on 127.0.0.1) instead of exiting: one line, three exchanges (rehearsed on one GPU over the host transport)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DFGPU_BENCH_REHEARSAL"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sf", "1", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "watchdog" not in line and "exchange_errors" not in line
+    assert {"repartition", "repartition_stream", "pruned"} <= set(line["exchanges"])

