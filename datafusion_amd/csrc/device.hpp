@@ -184,8 +184,16 @@ __device__ __forceinline__ uint64_t hash_value(const KeyCol& k, int64_t i, uint6
 // (s_waitcnt vmcnt(0) after each global_load in the ISA).  Hot kernels are therefore instantiated
 // per key type so that N independent loads are issued back-to-back.
 enum KeyT : int { KT_I32 = 0, KT_U32 = 1, KT_I64 = 2, KT_U8 = 3, KT_ANY = 4 };
-template <int KT>
+// NT: a non-temporal load (global_load ... nt) — the key column streams by once; read that way it does not push a table the same
+// kernel looks up out of the L2 (scripts/microbench/stream_width.hip: +9 % on the read side alone, +17 % with a 5.6 MB bitmap beside it)
+template <int KT, bool NT = false>
 __device__ __forceinline__ uint64_t load_key(const KeyCol& k, int64_t i) {
+  if (NT) {
+    if (KT == KT_I32) return (uint64_t)(int64_t)__builtin_nontemporal_load((const int32_t*)k.data + i);
+    if (KT == KT_U32) return __builtin_nontemporal_load((const uint32_t*)k.data + i);
+    if (KT == KT_I64) return __builtin_nontemporal_load((const uint64_t*)k.data + i);
+    if (KT == KT_U8) return __builtin_nontemporal_load((const uint8_t*)k.data + i);
+  }
   if (KT == KT_I32) return (uint64_t)(int64_t)((const int32_t*)k.data)[i];
   if (KT == KT_U32) return ((const uint32_t*)k.data)[i];
   if (KT == KT_I64) return ((const uint64_t*)k.data)[i];

@@ -27,6 +27,7 @@
 //           arrow-`take`-style gathers (build_batch_from_indices, joins/utils.rs:1332-1386).
 // Output order = probe order, then chain order (unordered by contract for duplicates).
 #include <thread>
+#include <functional>
 #include <cstdlib>
 
 #include "device.hpp"
@@ -100,6 +101,7 @@ struct ProbeCtx {
   const uint32_t* heads;
   const uint32_t* next;
   const ulonglong2* rank_tab;   // KIND_RANK: .x = bitmap word (one bit per key value), .y = set bits in earlier words
+  const uint64_t* rank_bits;    // KIND_RANK: the bitmap words alone (what "is the key there" asks: half the bytes of rank_tab per line)
   const uint32_t* rank_perm;    // null when the build keys are in ascending order (row id == rank)
   uint64_t am_offset, am_size, hash_mask;
   int null_equals_null;
@@ -114,6 +116,66 @@ struct ProbeCtx {
   const uint8_t* ret_rec;
   int ret_R;
 };
+
+// A FilterExec fused below the probe side whose predicate is an AND of `column <op> literal` over fixed-width integer-like columns
+// (Int32 / Date32 / Int64 / UInt8 / UInt32 — TPC-H's date and code filters): the counts pass of the selective probe evaluates it
+// per row from the column itself instead of reading a mask that k_cmp wrote a moment ago (one launch, one 1-bit-per-row write and
+// one read less; filter.rs:1339-1444 semantics: a NULL operand drops the row).
+constexpr int ROWPRED_MAX = 2;
+struct RowPred {
+  const void* data[ROWPRED_MAX];
+  const uint64_t* valid[ROWPRED_MAX];
+  long long lit[ROWPRED_MAX];
+  uint8_t width[ROWPRED_MAX], is_unsigned[ROWPRED_MAX], op[ROWPRED_MAX];   // op: rowpred_sel(DFGPU_EXPR_EQ .. DFGPU_EXPR_GE)
+  int n;
+};
+// All W rows of one conjunct at once: the width is asked ONCE, outside the unrolled loop, so the W loads leave back to back (a switch
+// per load put every load in a basic block of its own and an s_waitcnt vmcnt(0) behind it: the fused counts pass ran slower than k_cmp
+// plus the mask-reading counts pass, 4.82 vs 4.66 ms on SF300's lineitem).  The comparison is branch-free: `sel` holds what the
+// predicate says for v < lit, v == lit, v > lit (bits 0, 1, 2), made on the host from the operator.
+template <bool NT, int W>
+__device__ __forceinline__ void rowpred_load_words(const RowPred& q, int i, int64_t w0, int64_t np, unsigned lane, long long (&v)[W]) {
+  const int width = q.width[i];
+  if (width == 8) {
+    const long long* d = reinterpret_cast<const long long*>(q.data[i]);
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+      const int64_t p = ((w0 + j) << 6) + lane;
+      v[j] = NT ? __builtin_nontemporal_load(d + (p < np ? p : np - 1)) : d[p < np ? p : np - 1];
+    }
+  } else if (width == 4) {
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(q.data[i]);
+    uint32_t u[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+      const int64_t p = ((w0 + j) << 6) + lane;
+      u[j] = NT ? __builtin_nontemporal_load(d + (p < np ? p : np - 1)) : d[p < np ? p : np - 1];
+    }
+    const long long keep = q.is_unsigned[i] ? 0xFFFFFFFFll : -1ll;   // uniform: zero- or sign-extension
+#pragma unroll
+    for (int j = 0; j < W; j++) v[j] = (long long)(int32_t)u[j] & keep;
+  } else {
+    const uint8_t* d = reinterpret_cast<const uint8_t*>(q.data[i]);
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+      const int64_t p = ((w0 + j) << 6) + lane;
+      v[j] = (long long)(NT ? __builtin_nontemporal_load(d + (p < np ? p : np - 1)) : d[p < np ? p : np - 1]);
+    }
+  }
+}
+__device__ __forceinline__ bool rowpred_cmp(unsigned sel, long long v, long long lit) {
+  return ((v < lit ? sel : v == lit ? sel >> 1 : sel >> 2) & 1u) != 0;
+}
+static unsigned rowpred_sel(int op) {   // bit 0: holds for v < lit, bit 1: v == lit, bit 2: v > lit
+  switch (op) {
+    case DFGPU_EXPR_EQ: return 2u;
+    case DFGPU_EXPR_NE: return 5u;
+    case DFGPU_EXPR_LT: return 1u;
+    case DFGPU_EXPR_LE: return 3u;
+    case DFGPU_EXPR_GT: return 4u;
+    default: return 6u;   // GE
+  }
+}
 
 static KeySet make_keyset(const Table& t, const std::vector<int>& cols) {
   KeySet ks{};
@@ -740,8 +802,11 @@ __device__ __forceinline__ void lookup_words(const ProbeCtx& c, int64_t w0, int6
 // from the bitmap half of its entries alone (8 of 16 bytes, no prefix, no rank -> row step): two dependent loads instead of three
 // and 50 VGPRs instead of 76, and occupancy is what a latency-bound lookup is paid in (both SF100 Q3 probes: 1.48 ms against
 // 2.95 ms through lookup_words; profiles/r2_selective_probe.md).
-template <int KIND, int KT, int N>
-__device__ __forceinline__ void hit_words(const ProbeCtx& c, int64_t w0, int64_t np, uint64_t (&word)[N]) {
+// `pre` (optional): lane-private "this row exists" flags of the N words (a predicate evaluated by the caller); rows without it skip the
+// table like rows outside the row mask do.
+// `keys_in` (optional, KIND_RANK): the N raw key values, loaded by the caller ahead of its own work.
+template <int KIND, int KT, int N, bool NT = false>
+__device__ __forceinline__ void hit_words(const ProbeCtx& c, int64_t w0, int64_t np, uint64_t (&word)[N], const bool* pre = nullptr, const uint64_t* keys_in = nullptr) {
   if (KIND != KIND_RANK) {
     uint32_t m[N];
     lookup_words<KIND, KT, N>(c, w0, np, m);
@@ -757,8 +822,9 @@ __device__ __forceinline__ void hit_words(const ProbeCtx& c, int64_t w0, int64_t
   for (int j = 0; j < N; j++) {
     const int64_t p = ((w0 + j) << 6) + lane;
     ok[j] = p < np;
-    idx[j] = load_key<KT>(k, ok[j] ? p : np - 1) - c.am_offset;
-    if (c.row_mask) ok[j] = ok[j] && ((c.row_mask[w0 + j] >> lane) & 1ull);  // filtered-out rows skip the table
+    idx[j] = (keys_in ? keys_in[j] : load_key<KT, NT>(k, ok[j] ? p : np - 1)) - c.am_offset;
+    if (pre) ok[j] = ok[j] && pre[j];
+    else if (c.row_mask) ok[j] = ok[j] && ((c.row_mask[w0 + j] >> lane) & 1ull);  // filtered-out rows skip the table
   }
   if (k.valid) {
     uint64_t vw[N];
@@ -770,12 +836,14 @@ __device__ __forceinline__ void hit_words(const ProbeCtx& c, int64_t w0, int64_t
 #pragma unroll
     for (int j = 0; j < N; j++) ok[j] = ok[j] && ((vw[j] >> lane) & 1ull);
   }
-  const uint64_t* tab = reinterpret_cast<const uint64_t*>(c.rank_tab);
+  // the bitmap words alone: 8 useful bytes per 8-byte stride (through rank_tab's {bits, prefix} pairs the same question touched
+  // twice the lines — SF300's orders: 450 MB, outside the 256 MB Infinity Cache, against 225 MB inside it)
+  const uint64_t* tab = c.rank_bits;
   uint64_t bits[N];
 #pragma unroll
   for (int j = 0; j < N; j++) {
     ok[j] = ok[j] && idx[j] < c.am_size;
-    bits[j] = tab[ok[j] ? (idx[j] >> 6) * 2 : 0];
+    bits[j] = tab[ok[j] ? (idx[j] >> 6) : 0];
   }
 #pragma unroll
   for (int j = 0; j < N; j++) word[j] = ballot64(ok[j] && ((bits[j] >> (idx[j] & 63)) & 1ull));
@@ -1165,29 +1233,76 @@ __device__ __forceinline__ int64_t xcd_contiguous_tile(int64_t b, int64_t n_tile
 // per-tile output row counts of the same tiling: pass 1 of the PLACED flavour.  Reads the probe keys (and the row mask)
 // only; the table words it touches (rank-map bitmap + directory, MALL-resident) are warm for pass 2.
 // `out_words` (optional): the output rows themselves, one bit per probe row — what k_join_emit_listed materialises from.
-template <int KIND, int KT, int W>
+// PRED: a FilterExec's predicate (RowPred) evaluated here, per row, instead of a row mask: its columns' loads go out first, all W of
+// them, then the keys'; rows it drops skip the table.
+template <int KIND, int KT, int W, bool PRED = false, bool NT = false>
 __global__ __launch_bounds__(BLOCK) void k_join_tile_counts(ProbeCtx c, int64_t np, int invert, const uint64_t* __restrict__ row_mask,
-                                                            uint32_t* __restrict__ tile_counts, uint64_t* __restrict__ out_words) {
+                                                            uint32_t* __restrict__ tile_counts, uint64_t* __restrict__ out_words, RowPred pred = RowPred{}) {
   __shared__ uint32_t s_wcount[BLOCK / WAVE];
   constexpr int TILE_WORDS = W * (BLOCK / WAVE);
+  static_assert(TILE_WORDS <= BLOCK, "one thread per output word of the tile");
+  __shared__ uint64_t s_words[TILE_WORDS];
   const int64_t n_words = (np + 63) >> 6;
   const unsigned lane = lane_id();
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: the row mask words load as scalars
   const int64_t tile = KIND == KIND_RETURNED ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
   const int64_t w0 = tile * TILE_WORDS + (int64_t)wv * W;
   uint64_t hit[W];
-  hit_words<KIND, KT, W>(c, w0, np, hit);
+  bool pre[PRED ? W : 1];
+  if (PRED) {
+    // the keys' loads first, then the predicate columns': everything is in flight before the first comparison waits
+    uint64_t keyv[KIND == KIND_RANK ? W : 1];
+    if (KIND == KIND_RANK) {
+#pragma unroll
+      for (int j = 0; j < W; j++) {
+        const int64_t p = ((w0 + j) << 6) + lane;
+        keyv[KIND == KIND_RANK ? j : 0] = load_key<KT, NT>(c.pkeys.c[0], p < np ? p : np - 1);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < W; j++) pre[PRED ? j : 0] = (((w0 + j) << 6) + lane) < np;
+#pragma unroll
+    for (int i = 0; i < ROWPRED_MAX; i++) {
+      if (i >= pred.n) continue;     // (uniform: one branch per conjunct, none per load)
+      long long v[W];
+      rowpred_load_words<NT, W>(pred, i, w0, np, lane, v);
+      const unsigned sel = pred.op[i];
+      const long long lit = pred.lit[i];
+#pragma unroll
+      for (int j = 0; j < W; j++) pre[PRED ? j : 0] = pre[PRED ? j : 0] & rowpred_cmp(sel, v[j], lit);
+      if (pred.valid[i]) {
+        uint64_t vw[W];
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+          const int64_t p = ((w0 + j) << 6) + lane;
+          vw[j] = pred.valid[i][(p < np ? p : np - 1) >> 6];
+        }
+#pragma unroll
+        for (int j = 0; j < W; j++) pre[PRED ? j : 0] = pre[PRED ? j : 0] & (bool)((vw[j] >> lane) & 1ull);
+      }
+    }
+    hit_words<KIND, KT, W, NT>(c, w0, np, hit, pre, KIND == KIND_RANK ? keyv : nullptr);
+  } else {
+    hit_words<KIND, KT, W, NT>(c, w0, np, hit);
+  }
   uint32_t wave_cnt = 0;
 #pragma unroll
   for (int j = 0; j < W; j++) {
     const int64_t p = ((w0 + j) << 6) + lane;
     uint64_t word = ballot64(p < np) & (invert ? ~hit[j] : hit[j]);
-    if (row_mask) word &= (w0 + j < n_words) ? row_mask[w0 + j] : 0ull;
-    if (out_words && lane == 0 && w0 + j < n_words) out_words[w0 + j] = word;
+    if (PRED) word &= ballot64(pre[PRED ? j : 0]);
+    else if (row_mask) word &= (w0 + j < n_words) ? row_mask[w0 + j] : 0ull;
+    // the tile's output words leave together, below (one 8-byte store per wave and word — 28 M partial-line stores for SF300's
+    // lineitem — cost 0.7 ms of 4.0: scripts/microbench/stream_width.hip G vs E)
+    if (lane == 0) s_words[wv * W + j] = word;
     wave_cnt += (uint32_t)__popcll(word);
   }
   if (lane == 0) s_wcount[wv] = wave_cnt;
   __syncthreads();
+  if (out_words && threadIdx.x < TILE_WORDS) {
+    const int64_t w = tile * TILE_WORDS + threadIdx.x;
+    if (w < n_words) out_words[w] = s_words[threadIdx.x];   // TILE_WORDS x 8 bytes, contiguous: whole lines
+  }
   if (threadIdx.x == 0) {
     uint32_t agg = 0;
 #pragma unroll
@@ -1814,6 +1929,7 @@ static ProbeCtx make_ctx(JoinTable& jt, const Table& probe, const std::vector<in
   c.heads = jt.heads ? jt.heads->as<uint32_t>() : nullptr;
   c.next = jt.next ? jt.next->as<uint32_t>() : nullptr;
   c.rank_tab = jt.rank_tab ? jt.rank_tab->as<ulonglong2>() : nullptr;
+  c.rank_bits = jt.rank_bits ? jt.rank_bits->as<uint64_t>() : nullptr;
   c.rank_perm = need_build_rows && jt.rank_perm ? jt.rank_perm->as<uint32_t>() : nullptr;
   c.am_offset = jt.am_offset;
   c.am_size = jt.am_size;
@@ -2116,9 +2232,9 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       jt->rank_needs_perm = !ascending;  // the permutation itself waits for a probe that needs build rows (ensure_rank_perm)
       jt->rank_tab = make_buf((size_t)n_words * 16);
       k_rank_interleave<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(jt->rank_bits->as<uint64_t>(), jt->rank_prefix->as<uint64_t>(), n_words, jt->rank_tab->as<ulonglong2>());
-      jt->rank_bits.reset();    // enqueued work holds them until it ran (stream-ordered pool)
-      jt->rank_prefix.reset();
-      jt->info.table_bytes = n_words * 16;
+      // (the bitmap stays: the membership-only passes — tile counts, semi / anti probes — read it instead of the interleaved pairs)
+      jt->rank_prefix.reset();    // enqueued work holds it until it ran (stream-ordered pool)
+      jt->info.table_bytes = n_words * 24;
     } else {
       DFGPU_CHECK(opts.table_mode != 3, "rank-map join table requested but the build keys are not unique");
       jt->rank_bits.reset();
@@ -2539,9 +2655,23 @@ static bool grouped_probe_lookup(JoinTable& jt, const Table& probe, int pk0, con
 
 static Table join_probe_with_filter(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout,
                                     const std::vector<int>& pout, const dfgpu_join_filter* jfp);
+// `lazy` (optional, with row_mask == nullptr): a FilterExec below the probe side that has NOT been evaluated yet — `pred` is its
+// predicate in the form the counts pass can evaluate per row, `mask()` evaluates it into a row mask for every other flavour.
+struct LazyRowFilter {
+  RowPred pred;
+  int64_t pred_bytes_per_row;
+  std::function<const uint64_t*()> mask;
+};
 static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int>& pk, int join_type, const std::vector<int>& bout_in,
-                        const std::vector<int>& pout, const uint64_t* row_mask = nullptr, bool* mask_consumed = nullptr) {
+                        const std::vector<int>& pout, const uint64_t* row_mask = nullptr, bool* mask_consumed = nullptr, const LazyRowFilter* lazy = nullptr) {
   Runtime& r = rt();
+  if (row_mask) lazy = nullptr;
+  auto need_mask = [&]() {   // a flavour that cannot evaluate the predicate itself: the mask after all
+    if (lazy) {
+      row_mask = lazy->mask();
+      lazy = nullptr;
+    }
+  };
   // RightSemi / RightAnti emit probe columns only (joins/utils.rs:1628,1576): build_out_cols given by a C-ABI caller are ignored
   // on every path — the fused kernel would otherwise gather build rows of unmatched (anti) probe rows
   const std::vector<int> bout = (join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI) ? std::vector<int>{} : bout_in;
@@ -2549,7 +2679,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   DFGPU_CHECK(probe.device == jt.build.device, "the probe table lives on another device than the join table (move it with dfgpu_table_copy_to_device)");
   if (jt.kind == KIND_RADIX) {
     // the LDS radix join produces key-equal pairs; every join type is finished from them (row masks: the caller filters first)
-    if (row_mask) {
+    if (row_mask || lazy) {
       DFGPU_CHECK(mask_consumed != nullptr, "probe row mask without a fallback");
       *mask_consumed = false;
       return Table{};
@@ -2607,7 +2737,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const bool use_fused = fused_ok && np > 0;
   // the general M:N path in one pass (k_probe_pairs_single): flat tables under the planner's hint that nobody observes the order
   const bool single_pass_pairs = !use_fused && join_type == DFGPU_JOIN_INNER && jt.probe_mode == 4 && (jt.kind == KIND_FLAT || jt.kind == KIND_FLAT16) &&
-                                 !row_mask && np >= (1 << 16) && np < 0xFFFFFFFFll &&
+                                 !row_mask && !lazy && np >= (1 << 16) && np < 0xFFFFFFFFll &&
                                  true;
   // A probe whose output holds no build column and that marks no build row only asks whether the key is THERE: over a rank map of
   // keys in no particular order it needs the bitmap alone, not the rank -> row permutation (which is built by the first probe
@@ -2625,7 +2755,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
                                                  : jt.kind == KIND_RANK ? ((uint64_t)512 << 10) / 16 * 64 : ((uint64_t)512 << 10) / 4);
   const bool group_env = option_on("join.grouped_probe", true);  // (A/B switch)
   // the key-only probe whose order nobody observes: its keys are grouped and probed in group order (below)
-  const bool grouped_keys_only = unclustered && group_env && jt.probe_mode == 4 && rows_unused && !row_mask && pout.size() == 1 && pout[0] == pk[0] &&
+  const bool grouped_keys_only = unclustered && group_env && jt.probe_mode == 4 && rows_unused && !row_mask && !lazy && pout.size() == 1 && pout[0] == pk[0] &&
                                  ctx.pkeys.c[0].width == 8 && !probe.cols[(size_t)pk[0]].validity;
   // every other unclustered probe of a big rank map: the keys travel to the table group by group and what they found comes back
   // to the probe rows (k_gp_lookup above); the build rows are read at rank positions, so no rank -> row permutation is needed
@@ -2636,6 +2766,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     fprintf(stderr, "[dfgpu join_probe] np=%lld kind=%d probe_mode=%d fused_ok=%d big_table=%d unclustered=%d grouped_keys_only=%d returned=%d rows_unused=%d row_mask=%d\n",
             (long long)np, jt.kind, jt.probe_mode, (int)fused_ok, (int)big_table, (int)unclustered, (int)grouped_keys_only, (int)returned, (int)rows_unused, row_mask != nullptr);
   ReturnedProbe rp;
+  if (returned) need_mask();
   if (returned) returned = grouped_probe_lookup(jt, probe, pk[0], bout, row_mask, rp);
   if (returned) {
     kind = KIND_RETURNED;
@@ -2655,7 +2786,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   // knows the answer before the second kernel is chosen, so a wrong guess costs the counts pass, not the result; the
   // output is in probe order, which every probe_mode accepts.
   bool listed = fused_ok && fused_mode != FUSED_LOOKBACK && (kind == KIND_RANK || kind == KIND_ARRAY) &&
-                (row_mask != nullptr || (double)jt.build.nrows < 0.15 * (double)jt.am_size);
+                (row_mask != nullptr || lazy != nullptr || (double)jt.build.nrows < 0.15 * (double)jt.am_size);
   // what the grouped lookup found decides the placement: every probe row matched — row i of the output is probe row i, no counts
   // pass; else the cursor when nobody observes the order, else counts + placed
   const bool returned_all_hit = returned && rp.hits == np && !row_mask && join_type != DFGPU_JOIN_RIGHT_ANTI;
@@ -2733,7 +2864,10 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   // materialise); the general pairs path needs the caller to filter first.
   const bool one_match_path = np > 0 && (probe_side_only || fast_inner);
   const bool use_fused_now = use_fused;
-  if (row_mask) {
+  // the counts pass of the listed flavour evaluates the predicate itself; everything else reads a mask
+  const bool pred_in_counts = lazy != nullptr && use_fused && listed && fused_mode == FUSED_PLACED && !returned && (kind == KIND_RANK || kind == KIND_ARRAY);
+  if (!pred_in_counts) need_mask();
+  if (row_mask || pred_in_counts) {
     DFGPU_CHECK(mask_consumed != nullptr, "probe row mask without a fallback");
     *mask_consumed = use_fused || one_match_path;
     if (!*mask_consumed) return Table{};
@@ -2782,9 +2916,22 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       state = make_buf((size_t)(n_tiles + 1) * 8);
       if (listed) out_words = make_buf((size_t)n_words * 8);
       {
-        ProfileScope ps("join_probe_tile_counts", key_bytes);
+        ProfileScope ps("join_probe_tile_counts", key_bytes + (pred_in_counts ? np * lazy->pred_bytes_per_row : 0));
         with_kind_and_key(kind, ctx.pkeys.c[0].type, [&](auto kd, auto kt) {
-          k_join_tile_counts<decltype(kd)::value, decltype(kt)::value, FUSED_W><<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(
+          constexpr int K = decltype(kd)::value, T = decltype(kt)::value;
+          if constexpr (kind_is_direct<K>()) {
+            const bool nt = option_on("join.counts_nt", true);
+            if (pred_in_counts) {
+              if (nt) k_join_tile_counts<K, T, FUSED_W, true, true><<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(ctx, np, invert, nullptr, counts->as<uint32_t>(), out_words->as<uint64_t>(), lazy->pred);
+              else k_join_tile_counts<K, T, FUSED_W, true><<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(ctx, np, invert, nullptr, counts->as<uint32_t>(), out_words->as<uint64_t>(), lazy->pred);
+              return;
+            }
+            if (nt) {
+              k_join_tile_counts<K, T, FUSED_W, false, true><<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(ctx, np, invert, row_mask, counts->as<uint32_t>(), out_words ? out_words->as<uint64_t>() : nullptr);
+              return;
+            }
+          }
+          k_join_tile_counts<K, T, FUSED_W><<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(
               ctx, np, invert, row_mask, counts->as<uint32_t>(), out_words ? out_words->as<uint64_t>() : nullptr);
         });
         DFGPU_HIP(hipGetLastError());
@@ -2792,6 +2939,12 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       scan_u32(counts->as<uint32_t>(), n_tiles, state->as<uint64_t>());
       n_alloc = (int64_t)read_u64(state->as<uint64_t>() + n_tiles);
       listed = listed && n_alloc * 4 <= np;  // denser than guessed: the placed kernel streams better than it lists
+      if (pred_in_counts && !listed) {
+        // the placed kernel wants a row mask: the counts pass's output words ARE one — (hit & predicate) read as "rows that exist"
+        // selects exactly the rows that come out, for the inverted (anti) probe as well
+        row_mask = out_words->as<uint64_t>();
+        ctx.row_mask = row_mask;
+      }
     }
     JoinCopyCols jc{};
     jc.key_col = -1;
@@ -3406,6 +3559,62 @@ int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_
   });
 }
 
+// AND of `column <op> literal` / `literal <op> column` comparisons over fixed-width integer-like columns of `t` -> RowPred.
+// false: the predicate has another shape (k_cmp and a row mask serve it).
+static bool simple_row_pred(const dfgpu_expr& e, const Table& t, RowPred& out, int64_t& bytes_per_row) {
+  out = RowPred{};
+  bytes_per_row = 0;
+  if (!e.nodes || e.root < 0 || e.root >= e.n_nodes) return false;
+  std::vector<int> todo{e.root};
+  while (!todo.empty()) {
+    const int i = todo.back();
+    todo.pop_back();
+    if (i < 0 || i >= e.n_nodes) return false;
+    const dfgpu_expr_node& nd = e.nodes[i];
+    if (nd.op == DFGPU_EXPR_AND) {
+      todo.push_back(nd.right);
+      todo.push_back(nd.left);
+      continue;
+    }
+    if (nd.op < DFGPU_EXPR_EQ || nd.op > DFGPU_EXPR_GE || nd.left < 0 || nd.right < 0 || nd.left >= e.n_nodes || nd.right >= e.n_nodes) return false;
+    const dfgpu_expr_node *a = &e.nodes[nd.left], *b = &e.nodes[nd.right];
+    int op = nd.op;
+    if (a->op == DFGPU_EXPR_LITERAL && b->op == DFGPU_EXPR_COLUMN) {   // literal <op> column == column <mirrored op> literal
+      std::swap(a, b);
+      op = op == DFGPU_EXPR_LT ? DFGPU_EXPR_GT : op == DFGPU_EXPR_LE ? DFGPU_EXPR_GE : op == DFGPU_EXPR_GT ? DFGPU_EXPR_LT : op == DFGPU_EXPR_GE ? DFGPU_EXPR_LE : op;
+    }
+    auto int_like = [](int ty) { return ty == DFGPU_INT32 || ty == DFGPU_DATE32 || ty == DFGPU_INT64 || ty == DFGPU_UINT8 || ty == DFGPU_UINT32; };
+    int lit_type = b->field.type;
+    if (b->op == DFGPU_EXPR_CAST && b->left >= 0 && b->left < e.n_nodes && e.nodes[b->left].op == DFGPU_EXPR_LITERAL) {
+      // CAST(integer literal AS the column's type) where the value is representable: the literal itself (expressions/cast.rs; the
+      // planner usually folds it, a hand-built plan may not)
+      const dfgpu_expr_node* l = &e.nodes[b->left];
+      const long long v = (long long)l->lit_lo;
+      const int to = b->field.type;
+      const bool fits = to == DFGPU_INT64 || ((to == DFGPU_INT32 || to == DFGPU_DATE32) && v >= INT32_MIN && v <= INT32_MAX) || (to == DFGPU_UINT8 && v >= 0 && v <= 255) ||
+                        (to == DFGPU_UINT32 && v >= 0 && v <= (long long)UINT32_MAX);
+      if (!int_like(l->field.type) || !int_like(to) || !fits) return false;
+      lit_type = to;
+      b = l;
+    }
+    if (a->op != DFGPU_EXPR_COLUMN || b->op != DFGPU_EXPR_LITERAL || b->is_null || out.n >= ROWPRED_MAX) return false;
+    if (a->column < 0 || a->column >= (int)t.cols.size()) return false;
+    const Column& c = t.cols[(size_t)a->column];
+    const int ty = c.field.type;
+    if (c.dict || lit_type != ty) return false;    // (dictionary codes compare through their strings: evaluate() binds those)
+    if (!int_like(ty)) return false;
+    const int k = out.n++;
+    out.data[k] = c.ptr();
+    out.valid[k] = c.has_nulls() ? c.valid_words() : nullptr;
+    out.lit[k] = (long long)b->lit_lo;    // sign-extended (signed types) / zero-extended (unsigned) to 128 bits by the caller: the low word is the value
+    out.width[k] = (uint8_t)type_width(ty);
+    out.is_unsigned[k] = ty == DFGPU_UINT8 || ty == DFGPU_UINT32;
+    out.op[k] = (uint8_t)rowpred_sel(op);
+    bytes_per_row += type_width(ty);
+  }
+  return out.n > 0;
+}
+
 int dfgpu_join_probe_filtered(dfgpu_join_t ht, dfgpu_table_t probe, const dfgpu_expr* probe_predicate, const int* probe_key_cols, int join_type,
                               const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out, dfgpu_table_t* out) {
   return guarded([&] {
@@ -3416,18 +3625,30 @@ int dfgpu_join_probe_filtered(dfgpu_join_t ht, dfgpu_table_t probe, const dfgpu_
     std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
     const Table pt = with_build_dictionaries(*jt, *unwrap(probe), pk);
     std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
-    // FilterExec predicate -> row mask (NULL => dropped, filter.rs:1396-1419)
-    Datum m = evaluate(*probe_predicate, pt);
-    DFGPU_CHECK(m.col.field.type == DFGPU_BOOL, "Cannot create filter with non-boolean predicate");
-    Column mc = datum_to_column(m, pt.nrows, "");
-    BufPtr mask = mc.data;
-    if (mc.validity) {
-      mask = make_buf(bitmap_bytes(pt.nrows));
-      and_bitmaps(mc.data->as<uint64_t>(), mc.valid_words(), (pt.nrows + 63) / 64, mask->as<uint64_t>());
-    }
+    // FilterExec predicate -> row mask (NULL => dropped, filter.rs:1396-1419) — evaluated only when somebody asks for the mask: a
+    // predicate the selective probe's counts pass can evaluate per row (simple_row_pred) never becomes one
+    BufPtr mask;
+    auto make_mask = [&]() -> const uint64_t* {
+      if (!mask) {
+        Datum m = evaluate(*probe_predicate, pt);
+        DFGPU_CHECK(m.col.field.type == DFGPU_BOOL, "Cannot create filter with non-boolean predicate");
+        Column mc = datum_to_column(m, pt.nrows, "");
+        mask = mc.data;
+        if (mc.validity) {
+          mask = make_buf(bitmap_bytes(pt.nrows));
+          and_bitmaps(mc.data->as<uint64_t>(), mc.valid_words(), (pt.nrows + 63) / 64, mask->as<uint64_t>());
+        }
+      }
+      return mask->as<uint64_t>();
+    };
+    LazyRowFilter lazy;
+    lazy.mask = make_mask;
+    const bool simple = !jt->null_aware && pt.nrows > 0 && option_on("join.pred_in_counts", true) && simple_row_pred(*probe_predicate, pt, lazy.pred, lazy.pred_bytes_per_row);
+    if (!simple) make_mask();
     bool consumed = false;
     Table res;
-    if (!jt->null_aware) res = join_probe(*jt, pt, pk, join_type, bo, po, mask->as<uint64_t>(), &consumed);
+    if (!jt->null_aware) res = join_probe(*jt, pt, pk, join_type, bo, po, simple ? nullptr : mask->as<uint64_t>(), &consumed, simple ? &lazy : nullptr);
+    if (!consumed) make_mask();
     if (jt->null_aware) {
       // NOT IN semantics look at the NULL keys of the rows that pass the filter: materialise it first
       std::vector<int> all(pt.cols.size());

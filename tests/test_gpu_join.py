@@ -1,6 +1,8 @@
 """K1-K5 parity: HashJoinExec on the GPU vs (a) the reference's own snapshot tests and (b) the
 CPU oracle on random inputs — every JoinType, both table kinds (direct-address / chained hash),
 NULL keys under both NullEquality settings, duplicates, forced hash collisions."""
+import datetime
+
 import numpy as np
 import pyarrow as pa
 import pytest
@@ -788,3 +790,53 @@ def test_auto_takes_a_table_kind_within_reach_of_the_fastest(shape):
             break
     else:
         raise AssertionError({"shape": shape, "attempts": seen})
+
+
+@pytest.mark.parametrize("table_mode", ["array_map", "rank_map"])
+def test_simple_predicates_are_evaluated_inside_the_counts_pass(table_mode):
+    """round 6: a FilterExec below the probe side whose predicate is an AND of `column <op> literal` over fixed-width integer-like columns
+    is evaluated per row by the selective probe's counts pass (RowPred) — no k_cmp launch, no row mask — for every comparison, either
+    operand order, every supported column type, nullable predicate columns, the inverted (anti) probe, and a predicate so permissive
+    that the counts pass hands its output words to the placed kernel as the row mask.  Same rows as filter-then-join by the oracle, and
+    as the mask path (join.pred_in_counts=0)."""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    from tests.util import to_oracle_expr
+    rng = np.random.default_rng(606)
+    n = 150_001
+    build = pa.table({"k": pa.array(np.sort(rng.permutation(400_000)[:50_000]), type=pa.int64()), "v": pa.array(rng.integers(0, 10**6, 50_000), type=pa.int32())})
+    probe = pa.table({"k2": pa.array(rng.integers(-3, 400_010, n), type=pa.int64()), "p": pa.array(rng.integers(0, 10**9, n), type=pa.int64()),
+                      "d": pa.array(rng.integers(8000, 9000, n).astype(np.int32), type=pa.date32()), "i": pa.array(rng.integers(-50, 50, n), type=pa.int32()),
+                      "b": pa.array(rng.integers(0, 256, n).astype(np.uint8)), "u": pa.array(rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)),
+                      "w": pa.array(rng.integers(-2**40, 2**40, n), type=pa.int64()),
+                      "dn": pa.array(rng.integers(0, 100, n), type=pa.int32(), mask=rng.random(n) < 0.2)})
+    d = lambda v: lit(v, pa.int32()).cast(pa.date32())
+    preds = {"date_gt": col("d") > d(8500), "date_le_and_i_ne": (col("d") <= lit(datetime.date(1970, 1, 1) + datetime.timedelta(days=8300), pa.date32())).and_(col("i").ne(lit(7, pa.int32()))), "lit_on_the_left": lit(10, pa.int32()) >= col("i"),
+             "u8_eq": col("b").eq(lit(17, pa.uint8())), "u32_ge": col("u") >= lit(3_000_000_000, pa.uint32()), "i64_lt_negative": col("w") < lit(-2**39, pa.int64()),
+             "nullable": (col("dn") < lit(30, pa.int32())).and_(col("d") >= d(8100)), "permissive": col("i") >= lit(-49, pa.int32())}
+    dev_b, dev_p = DeviceTable.from_arrow(build), DeviceTable.from_arrow(probe)
+    ht = ops.JoinHashTable(dev_b, ["k"], probe_mode=3, table_mode=ops.TABLE_MODES[table_mode])
+    for name, pred in preds.items():
+        filtered = oracle.filter(probe, to_oracle_expr(pred), probe.column_names)
+        for join_type in ("Inner", "RightSemi", "RightAnti"):
+            keep = ["v", "k2", "p"] if join_type == "Inner" else ["k2", "p"]
+            exp = oracle.hash_join(build, filtered, [("k", "k2")], join_type).select(keep)
+            got, names = _probe_paths(lambda: ht.probe(dev_p, ["k2"], join_type, ["v"], ["k2", "p"], predicate=pred).to_arrow())
+            assert "cmp" not in names and "join_probe_tile_counts" in names, (name, join_type, names)
+            assert ("join_probe_placed" in names) == (exp.num_rows * 4 > n), (name, join_type, names, exp.num_rows)
+            assert_tables_equal(got, exp, ordered=True)
+            ops.set_options(join__pred_in_counts="0")
+            try:
+                old, old_names = _probe_paths(lambda: ht.probe(dev_p, ["k2"], join_type, ["v"], ["k2", "p"], predicate=pred).to_arrow())
+            finally:
+                ops.set_options(join__pred_in_counts=None)
+            assert "cmp" in old_names and old.equals(got), (name, join_type)
+    # a predicate of another shape (a comparison of two columns) still takes the mask
+    other = col("i") < col("dn")
+    got, names = _probe_paths(lambda: ht.probe(dev_p, ["k2"], "Inner", ["v"], ["k2", "p"], predicate=other).to_arrow())
+    assert "cmp" in names
+    exp = oracle.hash_join(build, oracle.filter(probe, to_oracle_expr(other), probe.column_names), [("k", "k2")], "Inner").select(["v", "k2", "p"])
+    assert_tables_equal(got, exp, ordered=True)
+    ht.free()
