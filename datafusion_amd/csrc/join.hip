@@ -75,7 +75,10 @@ struct JoinTable {
   uint64_t am_offset = 0, am_size = 0;
   uint64_t hash_mask = 0;
   BufPtr rank_bits, rank_prefix, rank_perm;  // rank map: u64 bitmap, u64 exclusive popcount prefix per word, optional u32 perm
-  BufPtr rank_tab;  // the probe's view of the rank map: {bitmap word, prefix} interleaved, ONE 16-byte load per lookup
+  BufPtr rank_tab;  // the probe's view of the rank map: {bitmap word, prefix} interleaved, ONE 16-byte load per lookup; made by the
+                    // first probe that looks ranks up row by row (ensure_rank_tab): membership passes and the listed emit read
+                    // rank_bits / rank_prefix
+  std::mutex tab_mu;
   // build keys not in ascending row order: rank != row id, a probe that needs BUILD ROWS (payload columns, visited marks, pairs)
   // goes through the rank -> row permutation — built on the first such probe (ensure_rank_perm), because a probe that only asks
   // "is the key there" (no build column in the output: SELECT l.k ... JOIN, semi / anti joins) never touches it
@@ -102,6 +105,7 @@ struct ProbeCtx {
   const uint32_t* next;
   const ulonglong2* rank_tab;   // KIND_RANK: .x = bitmap word (one bit per key value), .y = set bits in earlier words
   const uint64_t* rank_bits;    // KIND_RANK: the bitmap words alone (what "is the key there" asks: half the bytes of rank_tab per line)
+  const uint64_t* rank_prefix;  // KIND_RANK: set bits in earlier words, one u64 per word (what rank_tab interleaves with the bits)
   const uint32_t* rank_perm;    // null when the build keys are in ascending order (row id == rank)
   uint64_t am_offset, am_size, hash_mask;
   int null_equals_null;
@@ -1449,24 +1453,41 @@ __global__ __launch_bounds__(BLOCK, ((KIND == KIND_FLAT || KIND == KIND_FLAT16) 
 // LDS and gives every OUTPUT row one thread that takes the whole chain (key, rank, build row, all columns' loads in flight
 // together) and writes consecutive output rows.  The output is in probe order and allocated exactly.
 constexpr int EL_WORDS = 128;  // probe words per workgroup: 4 tiles of the counts pass
-template <int KIND, int KT>
+// A very selective probe (SF300's lineitem under Q3's filters: 9 M of 1.8 G rows) leaves ~40 listed rows per 8192-row group: 40 of 256
+// threads walk the key -> rank -> build row -> columns chain and the workgroup is gone, 220 K times over (1.05 ms).  EL_WORDS_SPARSE
+// gives a workgroup 65536 probe rows (the most a 16-bit row index addresses): ~330 rows per chain at that density, an eighth of
+// the workgroups.  The listed rows are taken EL_CAP at a time, so any density stays correct.
+constexpr int EL_WORDS_SPARSE = 1024;
+constexpr int EL_CAP = 8192;   // listed rows per round (16 KB of LDS)
+template <int KIND, int KT, int EW>
 __global__ __launch_bounds__(BLOCK) void k_join_emit_listed(ProbeCtx c, JoinCopyCols cols, int64_t np, const uint64_t* __restrict__ out_words,
                                                             const uint64_t* __restrict__ tile_prefix, int tiles_per_group) {
-  static_assert(EL_WORDS <= BLOCK && EL_WORDS % WAVE == 0, "one thread per word of the group");
-  __shared__ uint64_t s_word[EL_WORDS];
-  __shared__ uint32_t s_off[EL_WORDS];
+  static_assert(EW % BLOCK == 0 || BLOCK % EW == 0, "whole words per thread");
+  static_assert(EW * 64 <= 65536, "a listed row is a 16-bit index into the group");
+  constexpr int WPT = EW >= BLOCK ? EW / BLOCK : 1;   // words per thread (contiguous)
+  __shared__ uint64_t s_word[EW];
+  __shared__ uint32_t s_off[EW];
   __shared__ uint32_t s_wsum[BLOCK / WAVE];
-  __shared__ uint16_t s_row[EL_WORDS * 64];
+  __shared__ uint16_t s_row[EL_CAP];
   const int64_t n_words = (np + 63) >> 6;
-  const int64_t w_base = (int64_t)blockIdx.x * EL_WORDS;
+  const int64_t w_base = (int64_t)blockIdx.x * EW;
   const unsigned lane = lane_id();
   const int wv = threadIdx.x >> 6;
-  uint64_t w = 0;
-  if (threadIdx.x < EL_WORDS && w_base + threadIdx.x < n_words) w = out_words[w_base + threadIdx.x];
-  const uint32_t cnt = (uint32_t)__popcll(w);
+  uint64_t w[WPT];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int t = 0; t < WPT; t++) {
+    const int i = (int)threadIdx.x * WPT + t;
+    w[t] = (i < EW && w_base + i < n_words) ? out_words[w_base + i] : 0ull;
+    cnt += (uint32_t)__popcll(w[t]);
+  }
   const uint32_t inc = wave_inclusive_sum(cnt);
   if (lane == 63) s_wsum[wv] = inc;
-  if (threadIdx.x < EL_WORDS) s_word[threadIdx.x] = w;
+#pragma unroll
+  for (int t = 0; t < WPT; t++) {
+    const int i = (int)threadIdx.x * WPT + t;
+    if (i < EW) s_word[i] = w[t];
+  }
   __syncthreads();
   uint32_t before = 0, agg = 0;
 #pragma unroll
@@ -1475,17 +1496,30 @@ __global__ __launch_bounds__(BLOCK) void k_join_emit_listed(ProbeCtx c, JoinCopy
     agg += s_wsum[i];
   }
   if (agg == 0) return;
-  if (threadIdx.x < EL_WORDS) s_off[threadIdx.x] = before + inc - cnt;
-  __syncthreads();
-  for (int i = wv; i < EL_WORDS; i += BLOCK / WAVE) {  // the listed rows, in probe order
-    const uint64_t ww = s_word[i];
-    if ((ww >> lane) & 1ull) s_row[s_off[i] + mbcnt(ww)] = (uint16_t)((i << 6) | lane);
+  {
+    uint32_t off = before + inc - cnt;
+#pragma unroll
+    for (int t = 0; t < WPT; t++) {
+      const int i = (int)threadIdx.x * WPT + t;
+      if (i < EW) s_off[i] = off;
+      off += (uint32_t)__popcll(w[t]);
+    }
   }
   __syncthreads();
   const uint64_t out0 = tile_prefix[(int64_t)blockIdx.x * tiles_per_group];
   const KeyCol& k = c.pkeys.c[0];
-  for (uint32_t q = threadIdx.x; q < agg; q += BLOCK) {
-    const int64_t prow = (w_base << 6) + s_row[q];
+  for (uint32_t base = 0; base < agg; base += EL_CAP) {
+  if (base) __syncthreads();   // the previous round's readers of s_row are done
+  for (int i = wv; i < EW; i += BLOCK / WAVE) {  // the listed rows of this round, in probe order
+    const uint64_t ww = s_word[i];
+    const uint32_t pos = s_off[i] + mbcnt(ww) - base;
+    if (((ww >> lane) & 1ull) && pos < (uint32_t)EL_CAP) s_row[pos] = (uint16_t)((i << 6) | lane);   // (pos wraps for rows of earlier rounds)
+  }
+  __syncthreads();
+  const uint32_t round_rows = agg - base < (uint32_t)EL_CAP ? agg - base : (uint32_t)EL_CAP;
+  for (uint32_t q0 = threadIdx.x; q0 < round_rows; q0 += BLOCK) {
+    const uint32_t q = base + q0;
+    const int64_t prow = (w_base << 6) + s_row[q0];
     int64_t brow = 0;
     uint64_t key = 0;
     if (cols.n_build > 0 || cols.key_col >= 0) {  // (a RightAnti probe lists the rows WITHOUT a match and has no build columns)
@@ -1495,8 +1529,16 @@ __global__ __launch_bounds__(BLOCK) void k_join_emit_listed(ProbeCtx c, JoinCopy
         if (KIND == KIND_ARRAY) {
           brow = (int64_t)c.heads[idx] - 1;
         } else {
-          const ulonglong2 e = c.rank_tab[idx >> 6];
-          const uint32_t rank = (uint32_t)e.y + (uint32_t)__popcll(e.x & ((1ull << (idx & 63)) - 1ull));
+          uint64_t bw, pre;
+          if (c.rank_tab) {   // (uniform)
+            const ulonglong2 e = c.rank_tab[idx >> 6];
+            bw = e.x;
+            pre = e.y;
+          } else {
+            bw = c.rank_bits[idx >> 6];
+            pre = c.rank_prefix[idx >> 6];
+          }
+          const uint32_t rank = (uint32_t)pre + (uint32_t)__popcll(bw & ((1ull << (idx & 63)) - 1ull));
           brow = c.rank_perm ? (int64_t)c.rank_perm[rank] : (int64_t)rank;
         }
       }
@@ -1541,6 +1583,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_emit_listed(ProbeCtx c, JoinCopy
         }
       }
     }
+  }
   }
 }
 
@@ -1896,10 +1939,32 @@ static void with_kind_and_key(int kind, int probe_key_type, F&& f) {
   });
 }
 
+// The interleaved {bits, prefix} view of the rank map, made once by the first probe that asks every row for its rank (the fused probe
+// kernel, the pairs paths, the grouped lookup): one 16-byte load per lookup there.  A selective probe — membership in the counts pass,
+// ranks for the few listed rows — never builds it (SF300's Q3: 450 MB written and 0.18 ms per join table).
+static void ensure_rank_tab(JoinTable& jt) {
+  if (jt.kind != KIND_RANK) return;
+  std::lock_guard<std::mutex> lk(jt.tab_mu);
+  if (jt.rank_tab) return;
+  Runtime& r = rt();
+  const int64_t n_words = (int64_t)((jt.am_size - 1) >> 6) + 1;
+  BufPtr tab = make_buf((size_t)n_words * 16);
+  {
+    ProfileScope ps("join_build_rank_interleave", n_words * 16);
+    k_rank_interleave<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(jt.rank_bits->as<uint64_t>(), jt.rank_prefix->as<uint64_t>(), n_words, tab->as<ulonglong2>());
+    DFGPU_HIP(hipGetLastError());
+  }
+  DFGPU_HIP(hipStreamSynchronize(r.stream));  // complete before another thread's stream reads it
+  jt.rank_tab = tab;
+  std::lock_guard<std::mutex> lk2(jt.mu);
+  jt.info.table_bytes += n_words * 16;
+}
+
 // rank map over keys that are not in ascending row order: the rank -> row permutation, made once, by the first probe that needs
 // build rows (several probe partitions may arrive together: CollectLeft)
 static void ensure_rank_perm(JoinTable& jt) {
   if (jt.kind != KIND_RANK || !jt.rank_needs_perm) return;
+  ensure_rank_tab(jt);
   std::lock_guard<std::mutex> lk(jt.mu);
   if (jt.rank_perm) return;
   Runtime& r = rt();
@@ -1916,7 +1981,8 @@ static void ensure_rank_perm(JoinTable& jt) {
   jt.info.table_bytes += nb * 4;
 }
 
-static ProbeCtx make_ctx(JoinTable& jt, const Table& probe, const std::vector<int>& pk, bool need_build_rows = true) {
+static ProbeCtx make_ctx(JoinTable& jt, const Table& probe, const std::vector<int>& pk, bool need_build_rows = true, bool want_tab = true) {
+  if (want_tab) ensure_rank_tab(jt);
   if (need_build_rows) ensure_rank_perm(jt);
   ProbeCtx c{};
   c.bkeys = make_keyset(jt.build, jt.key_cols);
@@ -1930,6 +1996,7 @@ static ProbeCtx make_ctx(JoinTable& jt, const Table& probe, const std::vector<in
   c.next = jt.next ? jt.next->as<uint32_t>() : nullptr;
   c.rank_tab = jt.rank_tab ? jt.rank_tab->as<ulonglong2>() : nullptr;
   c.rank_bits = jt.rank_bits ? jt.rank_bits->as<uint64_t>() : nullptr;
+  c.rank_prefix = jt.rank_prefix ? jt.rank_prefix->as<uint64_t>() : nullptr;
   c.rank_perm = need_build_rows && jt.rank_perm ? jt.rank_perm->as<uint32_t>() : nullptr;
   c.am_offset = jt.am_offset;
   c.am_size = jt.am_size;
@@ -2230,11 +2297,9 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       jt->am_offset = (uint64_t)kmin;
       jt->am_size = range + 1;
       jt->rank_needs_perm = !ascending;  // the permutation itself waits for a probe that needs build rows (ensure_rank_perm)
-      jt->rank_tab = make_buf((size_t)n_words * 16);
-      k_rank_interleave<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(jt->rank_bits->as<uint64_t>(), jt->rank_prefix->as<uint64_t>(), n_words, jt->rank_tab->as<ulonglong2>());
-      // (the bitmap stays: the membership-only passes — tile counts, semi / anti probes — read it instead of the interleaved pairs)
-      jt->rank_prefix.reset();    // enqueued work holds it until it ran (stream-ordered pool)
-      jt->info.table_bytes = n_words * 24;
+      // (bitmap and prefix stay as they are: the membership-only passes read the bitmap, the listed emit both; the interleaved view
+      // waits for a probe that wants it — ensure_rank_tab)
+      jt->info.table_bytes = n_words * 16;
     } else {
       DFGPU_CHECK(opts.table_mode != 3, "rank-map join table requested but the build keys are not unique");
       jt->rank_bits.reset();
@@ -2508,6 +2573,7 @@ static GroupSpec gp_spec_for(const JoinTable& jt, int nbits) { return group_spec
 // in group order reads build payload at rank positions; through rank -> row -> column it would be a random line per row)
 // the packed form: `cols` (<= 12 bytes together) as one 16-byte record per rank, field i at byte rec_off[i] (word 0 free)
 static BufPtr ensure_rank_records(JoinTable& jt, const std::vector<int>& cols, const std::vector<int>& rec_off) {
+  ensure_rank_tab(jt);   // (before jt.mu is taken: it takes its own lock, then jt.mu)
   std::lock_guard<std::mutex> lk(jt.mu);
   auto it = jt.rank_records.find(cols);
   if (it != jt.rank_records.end()) return it->second;
@@ -2549,6 +2615,7 @@ static BufPtr ensure_rank_records(JoinTable& jt, const std::vector<int>& cols, c
   return recs;
 }
 static void ensure_rank_payload(JoinTable& jt, const std::vector<int>& cols) {
+  ensure_rank_tab(jt);   // (before jt.mu is taken: it takes its own lock, then jt.mu)
   std::lock_guard<std::mutex> lk(jt.mu);
   std::vector<int> missing;
   for (int c : cols)
@@ -2595,6 +2662,7 @@ struct ReturnedProbe {
 };
 // steps 1 and 2 of the grouped probe; false = not applicable (the records would be wider than 64 bytes)
 static bool grouped_probe_lookup(JoinTable& jt, const Table& probe, int pk0, const std::vector<int>& bout, const uint64_t* row_mask, ReturnedProbe& rp) {
+  ensure_rank_tab(jt);   // (before jt.mu is taken: it takes its own lock, then jt.mu)
   Runtime& r = rt();
   const int64_t np = probe.nrows;
   // record layout: the match id in the first word (KIND_RETURNED reads it there), then the 4-byte build columns, the 8-byte ones,
@@ -2689,7 +2757,13 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   const int64_t np = probe.nrows;
   const int64_t n_words = (np + 63) / 64;
   int kind = jt.kind;  // what the probe kernels look the keys up in: the table, or (KIND_RETURNED) what a grouped lookup left per probe row
-  ProbeCtx ctx = make_ctx(jt, probe, pk, /*need_build_rows=*/false);  // decided below, once the probe flavour is known
+  ProbeCtx ctx = make_ctx(jt, probe, pk, /*need_build_rows=*/false, /*want_tab=*/false);  // both decided below, once the probe flavour is known
+  auto need_tab = [&]() {
+    if (jt.kind == KIND_RANK) {
+      ensure_rank_tab(jt);
+      ctx.rank_tab = jt.rank_tab->as<ulonglong2>();
+    }
+  };
   for (int c : bout) DFGPU_CHECK(c >= 0 && c < (int)jt.build.cols.size(), "build output column out of range");
   for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
   uint8_t* visited = nullptr;
@@ -2777,6 +2851,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
   if (!returned && !rows_unused && jt.kind == KIND_RANK && jt.rank_needs_perm) {
     ensure_rank_perm(jt);
     ctx.rank_perm = jt.rank_perm->as<uint32_t>();
+    ctx.rank_tab = jt.rank_tab->as<ulonglong2>();
   }
   DFGPU_CHECK(!((jt.probe_mode == 2 || jt.probe_mode == 3) && !fused_ok),
               "single-pass probe requested but not applicable (needs <=1 match per probe row and non-nullable payload)");
@@ -2873,6 +2948,10 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
     if (!*mask_consumed) return Table{};
     ctx.row_mask = row_mask;
   }
+  // the interleaved rank table: every flavour but the listed one (membership from the bitmap in the counts pass, ranks of the few
+  // listed rows from bitmap + prefix) looks every row's rank up through it
+  const bool listed_flavour = use_fused_now && listed && fused_mode == FUSED_PLACED && kind == KIND_RANK;
+  if (!listed_flavour) need_tab();
   if (use_fused_now && fused_mode != FUSED_PLACED) {
     // single-pass flavours: output columns are allocated for the upper bound (np rows) because the row count is only
     // known when the kernel ends; HBM is sized for that (288 GB)
@@ -2939,6 +3018,7 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       scan_u32(counts->as<uint32_t>(), n_tiles, state->as<uint64_t>());
       n_alloc = (int64_t)read_u64(state->as<uint64_t>() + n_tiles);
       listed = listed && n_alloc * 4 <= np;  // denser than guessed: the placed kernel streams better than it lists
+      if (!listed) need_tab();
       if (pred_in_counts && !listed) {
         // the placed kernel wants a row mask: the counts pass's output words ARE one — (hit & predicate) read as "rows that exist"
         // selects exactly the rows that come out, for the inverted (anti) probe as well
@@ -2995,8 +3075,15 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
         constexpr bool KR = kind_is_direct<K>();  // the direct-address kinds hold the one integer key in registers
         if constexpr (KR) {
           if (listed) {
-            const int64_t groups = (n_words + EL_WORDS - 1) / EL_WORDS;
-            k_join_emit_listed<K, T><<<(unsigned)groups, BLOCK, 0, r.stream>>>(ctx, jc, np, out_words->as<uint64_t>(), st, (int)(EL_WORDS / tile_words));
+            // (sparse: fewer than one row in `join.listed_sparse_den` comes out)
+            const int64_t den = option_int("join.listed_sparse_den", 32);   // (0: never)
+            if (den > 0 && n_alloc * den <= np) {
+              const int64_t groups = (n_words + EL_WORDS_SPARSE - 1) / EL_WORDS_SPARSE;
+              k_join_emit_listed<K, T, EL_WORDS_SPARSE><<<(unsigned)groups, BLOCK, 0, r.stream>>>(ctx, jc, np, out_words->as<uint64_t>(), st, (int)(EL_WORDS_SPARSE / tile_words));
+            } else {
+              const int64_t groups = (n_words + EL_WORDS - 1) / EL_WORDS;
+              k_join_emit_listed<K, T, EL_WORDS><<<(unsigned)groups, BLOCK, 0, r.stream>>>(ctx, jc, np, out_words->as<uint64_t>(), st, (int)(EL_WORDS / tile_words));
+            }
             return;
           }
         }

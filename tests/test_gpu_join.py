@@ -526,7 +526,9 @@ def test_rank_map_over_unordered_keys_builds_its_permutation_on_the_first_probe_
         got = ht.probe(p, ["k2"], jt, [], ["k2", "v"]).to_arrow()
         exp = oracle.hash_join(build, probe, [("k", "k2")], jt).select(["k2", "v"])
         assert sorted_rows(got) == sorted_rows(exp), jt
-    assert ht.info().table_bytes == bitmap_only                              # no permutation was needed
+    # no permutation was needed — only the interleaved {bits, prefix} view of the same 16 bytes per word, which the first probe that
+    # asks every row for its rank builds (round 6: it used to be built with the table)
+    assert ht.info().table_bytes == 2 * bitmap_only
     results, errors = {}, []
 
     def worker(w, jt):
@@ -540,7 +542,7 @@ def test_rank_map_over_unordered_keys_builds_its_permutation_on_the_first_probe_
     for t in threads:
         t.join()
     assert not errors
-    assert ht.info().table_bytes == bitmap_only + nb * 4                     # built once
+    assert ht.info().table_bytes == 2 * bitmap_only + nb * 4                 # built once
     exp = oracle.hash_join(build, probe, [("k", "k2")], "Inner").select(["pay", "k2"])
     for w in range(4):
         assert sorted_rows(results[w]) == sorted_rows(exp)
@@ -839,4 +841,41 @@ def test_simple_predicates_are_evaluated_inside_the_counts_pass(table_mode):
     assert "cmp" in names
     exp = oracle.hash_join(build, oracle.filter(probe, to_oracle_expr(other), probe.column_names), [("k", "k2")], "Inner").select(["v", "k2", "p"])
     assert_tables_equal(got, exp, ordered=True)
+    ht.free()
+
+
+@pytest.mark.parametrize("table_mode", ["array_map", "rank_map"])
+def test_sparse_listed_emit_takes_its_rows_in_rounds(table_mode):
+    """round 6: a probe that emits fewer than 1 row in 32 gives every workgroup of the listed emit 65536 probe rows (k_join_emit_listed<..,
+    EL_WORDS_SPARSE>) and takes a group's listed rows 8192 at a time.  Ascending probe keys put ALL ~12 K hits into the first group (two
+    rounds), a second cluster straddles a group boundary, a fused FilterExec thins them; the 8192-row-group variant (join.listed_sparse_den=0)
+    and the oracle give the same rows in the same (probe) order."""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    from tests.util import to_oracle_expr
+    rng = np.random.default_rng(61)
+    n = 3_000_000
+    bk = np.concatenate([np.arange(0, 20_000), np.arange(109_000, 110_500), [4_999_999]])
+    build = pa.table({"k": pa.array(bk, type=pa.int64()), "v": pa.array(rng.integers(0, 10**6, len(bk)), type=pa.int32())})
+    keys = np.sort(rng.integers(0, 5_000_000, n))
+    probe = pa.table({"k2": pa.array(keys, type=pa.int64()), "p": pa.array(rng.integers(0, 10**9, n), type=pa.int64()), "f": pa.array(rng.integers(0, 100, n), type=pa.int32())})
+    dev_p = DeviceTable.from_arrow(probe)
+    ht = ops.JoinHashTable(DeviceTable.from_arrow(build), ["k"], probe_mode=3, table_mode=ops.TABLE_MODES[table_mode])
+    for pred in (None, col("f") < lit(90, pa.int32())):
+        src = probe if pred is None else oracle.filter(probe, to_oracle_expr(pred), probe.column_names)
+        for join_type in ("Inner", "RightSemi"):
+            keep = ["v", "k2", "p"] if join_type == "Inner" else ["k2", "p"]
+            exp = oracle.hash_join(build, src, [("k", "k2")], join_type).select(keep)
+            assert 8192 < exp.num_rows < n // 32
+            got, names = _probe_paths(lambda: ht.probe(dev_p, ["k2"], join_type, ["v"], ["k2", "p"], predicate=pred).to_arrow())
+            assert "join_probe_listed" in names, names
+            assert_tables_equal(got, exp, ordered=True)
+            ops.set_options(join__listed_sparse_den="0")
+            try:
+                small = ht.probe(dev_p, ["k2"], join_type, ["v"], ["k2", "p"], predicate=pred).to_arrow()
+            finally:
+                ops.set_options(join__listed_sparse_den=None)
+            assert small.equals(got)
     ht.free()
