@@ -145,6 +145,8 @@ struct Runtime {
   std::map<std::thread::id, int64_t> kernel_ns_by_thread;  // filled by collect(), drained by dfgpu_metrics_get
   std::vector<Rec> recs;
   std::vector<dfgpu_kernel_stat> stats;  // aggregated by collect()
+  struct Launch { int stat; float ms; int64_t bytes; };
+  std::vector<Launch> launches;          // every collected launch, in order (dfgpu_profile_launches); bounded
   void collect();
 };
 

@@ -357,6 +357,8 @@ void Runtime::collect() {
     it->calls += 1;
     it->total_ms += ms;
     it->algorithmic_bytes += rec.bytes;
+    if (launches.size() >= 65536) launches.erase(launches.begin(), launches.begin() + 32768);
+    launches.push_back(Launch{(int)(it - stats.begin()), ms, rec.bytes});
     kernel_ns_by_thread[rec.thread] += (int64_t)((double)ms * 1e6);
   }
   recs.clear();
@@ -636,6 +638,7 @@ int dfgpu_profile_reset(void) {
   return guarded([&] {
     rt().collect();
     rt().stats.clear();
+    rt().launches.clear();
   });
 }
 int dfgpu_profile_count(int* out) {
@@ -649,6 +652,24 @@ int dfgpu_profile_get(int i, dfgpu_kernel_stat* out) {
     rt().collect();
     DFGPU_CHECK(i >= 0 && i < (int)rt().stats.size(), "profile index out of range");
     *out = rt().stats[i];
+  });
+}
+
+int dfgpu_profile_launches(const char* name, int64_t capacity, double* ms, int64_t* bytes, int64_t* out_n) {
+  return guarded([&] {
+    DFGPU_CHECK(name && out_n && capacity >= 0 && (capacity == 0 || (ms && bytes)), "null argument");
+    Runtime& r = rt();
+    r.collect();
+    int64_t n = 0;
+    for (const Runtime::Launch& l : r.launches) {
+      if (std::strcmp(r.stats[(size_t)l.stat].name, name) != 0) continue;
+      if (n < capacity) {
+        ms[n] = l.ms;
+        bytes[n] = l.bytes;
+      }
+      n++;
+    }
+    *out_n = n;
   });
 }
 

@@ -1349,6 +1349,82 @@ __global__ __launch_bounds__(BLOCK, (sizeof(LK) == 4 ? 4 : 3)) void k_local_sort
 
 static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>& digits, bool want_ids = true);
 
+// ------------------------------------------------------------------------------ a few thousand rows: one workgroup, in LDS
+// The rows a TopK narrows down to, Q1's four groups, any ORDER BY over a small result: the radix passes above are 5 launches per
+// 8-bit digit (histogram, three scan kernels, scatter) whatever n is — 25 launches and 0.25 ms for the ~3000 survivors of Q3's TopK.
+// One workgroup sorts up to SMALL_SORT_CAP (key words, position) elements in LDS with a bitonic network; the position breaks ties,
+// which makes the order total and the sort stable (sorts/sort.rs:894-914: lexsort_to_indices over the batch; ties by input order
+// is what the LSD passes gave).
+constexpr int SMALL_SORT_CAP = 4096;
+constexpr int SMALL_SORT_THREADS = 1024;
+template <int NW>
+__global__ __launch_bounds__(SMALL_SORT_THREADS) void k_small_sort(KeyWords in, const uint32_t* __restrict__ idx_in, int n, int padded, uint32_t* __restrict__ idx_out) {
+  extern __shared__ uint64_t s_mem[];
+  uint64_t* s_key = s_mem;                                            // [NW][padded]
+  uint32_t* s_pos = reinterpret_cast<uint32_t*>(s_mem + (size_t)NW * padded);   // [padded]
+  for (int i = threadIdx.x; i < padded; i += SMALL_SORT_THREADS) {
+#pragma unroll
+    for (int w = 0; w < NW; w++) s_key[w * padded + i] = i < n ? in.w[w][i] : ~0ull;
+    s_pos[i] = i < n ? (uint32_t)i : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  for (int k = 2; k <= padded; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (padded >> 1); t += SMALL_SORT_THREADS) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // the t-th index with bit j clear
+        const int q = i | j;
+        const bool up = (i & k) == 0;
+        bool gt = false, decided = false;                       // element i > element q ?
+#pragma unroll
+        for (int w = NW - 1; w >= 0; w--) {
+          const uint64_t a = s_key[w * padded + i], b = s_key[w * padded + q];
+          if (!decided && a != b) {
+            gt = a > b;
+            decided = true;
+          }
+        }
+        if (!decided) gt = s_pos[i] > s_pos[q];
+        if (gt == up) {
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            const uint64_t a = s_key[w * padded + i];
+            s_key[w * padded + i] = s_key[w * padded + q];
+            s_key[w * padded + q] = a;
+          }
+          const uint32_t pa = s_pos[i];
+          s_pos[i] = s_pos[q];
+          s_pos[q] = pa;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += SMALL_SORT_THREADS) idx_out[i] = idx_in ? idx_in[s_pos[i]] : s_pos[i];
+}
+// row ids of up to SMALL_SORT_CAP packed keys in sorted order (stable)
+static BufPtr small_sort_ids(const SortedKeys& sk, int64_t n) {
+  Runtime& r = rt();
+  int padded = 2;
+  while (padded < n) padded <<= 1;
+  BufPtr out = make_buf((size_t)std::max<int64_t>(n, 1) * 4);
+  KeyWords kw{};
+  for (int w = 0; w < sk.nwords; w++) kw.w[w] = sk.w[w]->as<uint64_t>();
+  const uint32_t* idp = sk.idx ? sk.idx->as<uint32_t>() : nullptr;
+  const size_t lds = (size_t)padded * (sk.nwords * 8 + 4);
+  ProfileScope ps("sort_small", n * (sk.nwords * 8 + 8));
+  auto launch = [&](auto kern) {
+    DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<1, SMALL_SORT_THREADS, lds, r.stream>>>(kw, idp, (int)n, padded, out->as<uint32_t>());
+  };
+  switch (sk.nwords) {
+    case 1: launch(k_small_sort<1>); break;
+    case 2: launch(k_small_sort<2>); break;
+    default: launch(k_small_sort<3>); break;
+  }
+  DFGPU_HIP(hipGetLastError());
+  return out;
+}
+
 // row ids of a one-word key in sorted order by "top digits in HBM + buckets in LDS"; null when that does not apply (then
 // `clobbered` tells whether the key buffer was used as scratch by the top passes and has to be packed again)
 static BufPtr sorted_ids_local(const SortedKeys& sk, int64_t n, uint64_t key_space, bool& clobbered) {
@@ -2086,8 +2162,10 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
       }
     }
     // a full sort by one mixed-radix word whose other columns fit a 16-byte record: the onesweep carried sort reads the source columns itself
-    if (!topk && !limited && n_out == n && sort_lsd_carried(in, key_cols, pc, n, out)) return out;
-    if (!topk && !limited && narrow && nwords == 1 && n_out == n && sort_carried_onesweep(in, key_cols, pc, n, key_space, out)) return out;
+    // one workgroup sorts it in LDS (below) — unless the carried sorts are forced onto small tables (sort.carried_min_rows=0: their tests)
+    const bool small_input = n <= SMALL_SORT_CAP && option_on("sort.small", true) && option_int("sort.carried_min_rows", 1) != 0;
+    if (!small_input && !topk && !limited && n_out == n && sort_lsd_carried(in, key_cols, pc, n, out)) return out;
+    if (!small_input && !topk && !limited && narrow && nwords == 1 && n_out == n && sort_carried_onesweep(in, key_cols, pc, n, key_space, out)) return out;
     if (!limited) pack_keys();
     if (topk && !limited) {
       // ---- TopK: MSD radix select narrows to the rows that can still be among the first k
@@ -2145,7 +2223,7 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     // source columns — or, the default, row ids travel and the records are fetched by row id), the bucket sort in LDS writes the OUTPUT: key
     // columns decoded from the sorted key, the record's fields from the records.  No separate take: orders by (o_orderdate, o_orderkey DESC)
     // 9.9 ms against 11.9 (the take alone was 5.7: a random line per row, profiles/r3_sort_clustered.md).
-    if (!remap && narrow && nwords == 1 && !sk.idx && n_out == n && m == n) {
+    if (!small_input && !remap && narrow && nwords == 1 && !sk.idx && n_out == n && m == n) {
       bool keys_clobbered = false;
       if (sort_carried(in, key_cols, pc, sk.w[0], n, key_space, out, keys_clobbered)) return out;
       if (keys_clobbered) pack_keys();   // (skewed keys: the paths below start from the packed keys again)
@@ -2154,7 +2232,9 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
     // number's top digit, so that the final take read records from 18 MB groups — measured 17.9 ms against 12.4-13.2 and stayed
     // opt-in for a round (profiles/r3_sort_clustered.md); round 4 removed it: the carried sort above is what became of the idea)
     bool clobbered = false;
-    BufPtr sorted_idx = remap ? nullptr : sorted_ids_local(sk, m, key_space, clobbered);  // (TopK survivors are few: all-HBM passes)
+    BufPtr sorted_idx;
+    if (m <= SMALL_SORT_CAP && total_bits > 0 && (small_input || m < n) && option_on("sort.small", true)) sorted_idx = small_sort_ids(sk, m);   // the whole input, or a TopK's survivors
+    else if (!remap) sorted_idx = sorted_ids_local(sk, m, key_space, clobbered);
     if (!sorted_idx) {
       if (clobbered) pack_keys();
       SortedKeys sorted = radix_sort(sk, m, digits);

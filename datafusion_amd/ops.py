@@ -561,6 +561,16 @@ def profile_stats():
     return out
 
 
+def profile_launches(name: str, capacity: int = 4096):
+    """[(ms, algorithmic bytes)] of every launch recorded under `name` since the last reset, in launch order (dfgpu_profile_launches)"""
+    ms = (C.c_double * capacity)()
+    nb = (C.c_int64 * capacity)()
+    n = C.c_int64()
+    check(_lib.load().dfgpu_profile_launches(name.encode(), C.c_int64(capacity), ms, nb, C.byref(n)))
+    k = min(n.value, capacity)
+    return [(ms[i], nb[i]) for i in range(k)]
+
+
 def mem_stats():
     a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
     check(_lib.load().dfgpu_mem_stats(C.byref(a), C.byref(b), C.byref(c)))

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFGPU_ABI_VERSION 12
+#define DFGPU_ABI_VERSION 13
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
 #ifndef ARROW_C_DATA_INTERFACE
@@ -833,6 +833,11 @@ typedef struct dfgpu_kernel_stat {
   int64_t algorithmic_bytes; /* bytes the launch had to move (inputs read once + outputs written once) */
 } dfgpu_kernel_stat;
 int dfgpu_profile_get(int i, dfgpu_kernel_stat* out);
+/* (ABI 13) the launches recorded under one name since the last reset, in launch order: duration and algorithmic bytes of EACH — a plan
+ * that runs the same kernel over unlike inputs (Q3: the counts pass over 450 M orders rows, then over 1.8 G lineitem rows) reports a
+ * roofline per launch instead of the average of two different things.  Fills at most `capacity` entries of `ms` / `bytes`;
+ * *out_n = how many launches there were (the 65536 most recent are kept). */
+int dfgpu_profile_launches(const char* name, int64_t capacity, double* ms, int64_t* bytes, int64_t* out_n);
 
 #ifdef __cplusplus
 }

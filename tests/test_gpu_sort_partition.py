@@ -328,3 +328,55 @@ def test_sort_and_joins_move_boolean_payload_columns():
     as_u8 = lambda x: pa.table({c: (x.column(c).cast(pa.uint8()) if pa.types.is_boolean(x.schema.field(c).type) else x.column(c)) for c in x.column_names})
     exp = oracle.hash_join(as_u8(build), as_u8(t), [("bk", "k")], "Right")
     assert_tables_equal(as_u8(j), exp, ordered=False)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 100, 1025, 4095, 4096, 4097])
+@pytest.mark.parametrize("keys", [[("q", False, False)], [("d", True, False), ("dt", False, False)], [("c", True, True), ("dt", False, False), ("q", True, True)],
+                                  [("f", False, True), ("k", True, False)], [("d", True, False), ("k", False, True), ("d", False, False)]],
+                         ids=["heavy_ties_one_word", "q3_order_two_words", "3keys_nulls", "f64_then_i64", "three_words"])
+def test_small_inputs_are_sorted_by_one_workgroup_in_lds(n, keys):
+    """round 6: up to 4096 rows — a small result, a TopK's survivors — are sorted by ONE workgroup in LDS (k_small_sort: a bitonic network over
+    (key words, position); the position makes the sort stable) instead of 5 launches per 8-bit digit.  Same rows in the same order as the
+    oracle's stable sort and as the radix passes (sort.small=0), with and without fetch; 4097 rows take the old path."""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    t = random_table(np.random.default_rng(n), n, SPEC, null_frac=0.1)
+    dev = DeviceTable.from_arrow(t)
+    for fetch in (None, 1, 10):
+        ops.profile_enable(True)
+        ops.profile_reset()
+        got = ops.sort(dev, keys, fetch).to_arrow()
+        names = set(ops.profile_stats())
+        ops.profile_enable(False)
+        if 100 <= n <= 4096:
+            assert "sort_small" in names and "radix_sort_pass" not in names, (n, names)
+        elif n > 4096 and fetch is None:   # (with a fetch the TopK narrows 4097 rows down first: its survivors are sorted in LDS)
+            assert "sort_small" not in names, (n, names)
+        assert_tables_equal(got, oracle.sort(t, keys, fetch), ordered=True)
+        ops.set_options(sort__small="0")
+        try:
+            old = ops.sort(dev, keys, fetch).to_arrow()
+        finally:
+            ops.set_options(sort__small=None)
+        assert old.equals(got)
+
+
+def test_topk_survivors_are_sorted_in_lds():
+    """Q3's shape: TopK(10) by (Decimal128 DESC, Date32) over 3 M groups — the MSD select narrows to a few thousand survivors, one workgroup
+    sorts them"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(33)
+    n = 3_000_000
+    t = pa.table({"revenue": pa.array(rng.integers(0, 10**9, n) * 10**4, type=pa.int64()).cast(pa.decimal128(38, 4)), "o_orderdate": pa.array(rng.integers(8000, 9000, n).astype(np.int32), type=pa.date32()),
+                  "l_orderkey": pa.array(np.arange(n), type=pa.int64())})
+    keys = [("revenue", True, True), ("o_orderdate", False, False)]
+    ops.profile_enable(True)
+    ops.profile_reset()
+    got = ops.sort(DeviceTable.from_arrow(t), keys, 10).to_arrow()
+    names = set(ops.profile_stats())
+    ops.profile_enable(False)
+    assert "sort_small" in names and "radix_sort_pass" not in names, names
+    assert_tables_equal(got, oracle.sort(t, keys, 10), ordered=True)
