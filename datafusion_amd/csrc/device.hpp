@@ -281,4 +281,62 @@ inline int grid_for(int64_t work_items, int per_block) {
   return (int)b;
 }
 
+// ---- decoupled look-back over per-tile states (one 8-byte agent-scope atomic granule per tile: status in the top two bits — 0 not
+// published, TS_AGG the tile's own aggregate, TS_PFX its inclusive prefix — the value below).  Tiles are handed out in order by an
+// atomic ticket, so a tile only ever waits on tiles whose workgroup is already resident.
+constexpr uint64_t TS_AGG = 1ull << 62, TS_PFX = 2ull << 62, TS_VAL = (1ull << 62) - 1;
+
+__device__ __forceinline__ uint64_t ts_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ts_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// wave 0 of a tile in ordered mode: exclusive prefix of `agg` over all earlier tiles
+__device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* __restrict__ tile_state, int64_t tile, uint64_t agg) {
+  const unsigned lane = lane_id();
+  uint64_t excl = 0;
+  if (tile > 0) {
+    if (lane == 0) ts_store(&tile_state[tile], TS_AGG | agg);
+    // each lane polls LB consecutive predecessors, nearest first => a 64*LB-tile window per round
+    constexpr int LB = 4;
+    int64_t base = tile - 1;
+    for (;;) {
+      uint64_t sum, pfx_lanes;
+      for (;;) {
+        uint64_t st[LB];
+#pragma unroll
+        for (int q = 0; q < LB; q++) {
+          const int64_t idx = base - ((int64_t)lane * LB + q);
+          st[q] = idx >= 0 ? ts_load(&tile_state[idx]) : TS_PFX;  // virtual inclusive prefix 0 before tile 0
+        }
+        sum = 0;
+        bool lane_pfx = false, lane_block = false;  // block = an unpublished tile sits before this lane's first prefix
+#pragma unroll
+        for (int q = 0; q < LB; q++) {
+          const unsigned status = (unsigned)(st[q] >> 62);
+          if (!lane_pfx && !lane_block) {
+            if (status == 0) lane_block = true;
+            else {
+              sum += st[q] & TS_VAL;
+              lane_pfx = status == 2;
+            }
+          }
+        }
+        pfx_lanes = ballot64(lane_pfx);
+        const uint64_t block_lanes = ballot64(lane_block);
+        const int first_pfx = pfx_lanes ? __builtin_ctzll(pfx_lanes) : 64;
+        const int first_block = block_lanes ? __builtin_ctzll(block_lanes) : 64;
+        // lanes before the nearest prefix lane must be fully published (a blocked lane never
+        // reports a prefix, so first_block != first_pfx)
+        if (first_block > first_pfx || !block_lanes) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const int first_pfx = pfx_lanes ? __builtin_ctzll(pfx_lanes) : 64;
+      excl += wave_sum((int)lane <= first_pfx ? sum : 0ull);
+      if (first_pfx < 64) break;
+      base -= 64 * LB;
+    }
+  }
+  if (lane == 0) ts_store(&tile_state[tile], TS_PFX | (excl + agg));
+  return excl;
+}
+
 }  // namespace dfgpu

@@ -1165,67 +1165,13 @@ __global__ __launch_bounds__(BLOCK) void k_join_materialize(JoinCopyCols cols, c
 //    look-back round is an agent-scope load queued behind the CU's own streaming loads, 3-5 us,
 //    with the whole workgroup parked on it), so `auto` keeps two passes for ordered output.
 constexpr int FUSED_W = 8;  // 64-row words per wave per tile: 2048-row tiles (4 and 8 measured equal, 16 slower: 142 VGPRs)
-constexpr uint64_t TS_AGG = 1ull << 62, TS_PFX = 2ull << 62, TS_VAL = (1ull << 62) - 1;
-
-__device__ __forceinline__ uint64_t ts_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ts_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
+// (tile states and the look-back itself: device.hpp — scan.hip's single-pass scan walks the same chain)
 struct alignas(128) FusedCtl {
   unsigned long long total;  // out: number of output rows (ordered: last tile's inclusive prefix; unordered: the cursor)
   char _pad0[120];           // the ticket lives on its own cache line: both words are hot atomics
   unsigned ticket;           // ordered mode: next tile to hand out
   char _pad1[124];
 };
-
-// wave 0 of a tile in ordered mode: exclusive prefix of `agg` over all earlier tiles
-__device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* __restrict__ tile_state, int64_t tile, uint64_t agg) {
-  const unsigned lane = lane_id();
-  uint64_t excl = 0;
-  if (tile > 0) {
-    if (lane == 0) ts_store(&tile_state[tile], TS_AGG | agg);
-    // each lane polls LB consecutive predecessors, nearest first => a 64*LB-tile window per round
-    constexpr int LB = 4;
-    int64_t base = tile - 1;
-    for (;;) {
-      uint64_t sum, pfx_lanes;
-      for (;;) {
-        uint64_t st[LB];
-#pragma unroll
-        for (int q = 0; q < LB; q++) {
-          const int64_t idx = base - ((int64_t)lane * LB + q);
-          st[q] = idx >= 0 ? ts_load(&tile_state[idx]) : TS_PFX;  // virtual inclusive prefix 0 before tile 0
-        }
-        sum = 0;
-        bool lane_pfx = false, lane_block = false;  // block = an unpublished tile sits before this lane's first prefix
-#pragma unroll
-        for (int q = 0; q < LB; q++) {
-          const unsigned status = (unsigned)(st[q] >> 62);
-          if (!lane_pfx && !lane_block) {
-            if (status == 0) lane_block = true;
-            else {
-              sum += st[q] & TS_VAL;
-              lane_pfx = status == 2;
-            }
-          }
-        }
-        pfx_lanes = ballot64(lane_pfx);
-        const uint64_t block_lanes = ballot64(lane_block);
-        const int first_pfx = pfx_lanes ? __builtin_ctzll(pfx_lanes) : 64;
-        const int first_block = block_lanes ? __builtin_ctzll(block_lanes) : 64;
-        // lanes before the nearest prefix lane must be fully published (a blocked lane never
-        // reports a prefix, so first_block != first_pfx)
-        if (first_block > first_pfx || !block_lanes) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      const int first_pfx = pfx_lanes ? __builtin_ctzll(pfx_lanes) : 64;
-      excl += wave_sum((int)lane <= first_pfx ? sum : 0ull);
-      if (first_pfx < 64) break;
-      base -= 64 * LB;
-    }
-  }
-  if (lane == 0) ts_store(&tile_state[tile], TS_PFX | (excl + agg));
-  return excl;
-}
 
 // KIND_RETURNED: consecutive tiles read neighbouring records (the rows of one (grouping tile, group) run lie in a few fused tiles),
 // and workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) — so every XCD takes a CONTIGUOUS eighth of the tiles, in order, and the

@@ -89,11 +89,62 @@ __global__ __launch_bounds__(BLOCK) void k_scan_down(In in, int64_t n, const uin
   }
 }
 
+// ---- one launch (round 6): chained scan with decoupled look-back.  Every workgroup takes the next chunk by ticket, reduces it,
+// publishes the aggregate, wave 0 sums its predecessors' states back to the nearest published prefix (device.hpp lookback_exclusive)
+// and the chunk is written — the input is read ONCE and there is one launch instead of three.
+constexpr int CH_ITEMS = 16;
+constexpr int CH_CHUNK = BLOCK * CH_ITEMS;  // 4096 elements per workgroup
+template <typename In>
+__global__ __launch_bounds__(BLOCK) void k_scan_chained(In in, int64_t n, uint64_t* __restrict__ state, unsigned* __restrict__ ticket, uint64_t* __restrict__ out) {
+  __shared__ unsigned s_tile;
+  __shared__ uint64_t s_excl;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int64_t tile = s_tile;
+  const int64_t n_tiles = (n + CH_CHUNK - 1) / CH_CHUNK;
+  const int64_t base = tile * CH_CHUNK + (int64_t)threadIdx.x * CH_ITEMS;
+  uint32_t v[CH_ITEMS];
+  uint64_t s = 0;
+#pragma unroll
+  for (int j = 0; j < CH_ITEMS; j++) {
+    v[j] = base + j < n ? in(base + j) : 0;
+    s += v[j];
+  }
+  uint64_t tot;
+  uint64_t ex = block_exclusive_scan(s, &tot);
+  if (threadIdx.x < WAVE) {
+    const uint64_t excl = lookback_exclusive(state, tile, tot);
+    if (threadIdx.x == 0) {
+      s_excl = excl;
+      if (tile == n_tiles - 1) out[n] = excl + tot;
+    }
+  }
+  __syncthreads();
+  ex += s_excl;
+#pragma unroll
+  for (int j = 0; j < CH_ITEMS; j++) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+}
+
 template <typename In>
 static void run_scan(In in, int64_t n, uint64_t* out, const char* name) {
   Runtime& r = rt();
   if (n == 0) {
     DFGPU_HIP(hipMemsetAsync(out, 0, 8, r.stream));
+    return;
+  }
+  // (measured, profiles/r6_ops.md: over SF300's 28 M bitmap words the chained form takes 0.46 ms against 0.28 — every workgroup parks on
+  // agent-scope loads of its predecessors' states behind its own streaming loads, as the look-back probe did in round 2 — so it serves the
+  // SHORT scans, where one launch instead of three is the whole difference; scan.chained_max_tiles=0 turns it off, a large value forces it)
+  const int64_t n_tiles_ch = (n + CH_CHUNK - 1) / CH_CHUNK;
+  if (n_tiles_ch <= option_int("scan.chained_max_tiles", 8)) {
+    const int64_t n_tiles = n_tiles_ch;
+    BufPtr state = make_zero_buf((size_t)(n_tiles + 2) * 8);   // [n_tiles] states, then the ticket
+    ProfileScope ps(name, 0);
+    k_scan_chained<<<(unsigned)n_tiles, BLOCK, 0, r.stream>>>(in, n, state->as<uint64_t>(), reinterpret_cast<unsigned*>(state->as<uint64_t>() + n_tiles), out);
+    DFGPU_HIP(hipGetLastError());
     return;
   }
   int64_t n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(BLOCK) void k_pack_keys64_rows(PackCols pc, const i
   for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < m; j += (int64_t)gridDim.x * BLOCK) out[j] = pack_key64(pc, ids ? ids[j] : j * every);
 }
 // mask of the rows whose key is <= limit, computed from the key columns (no packed key array)
-__global__ __launch_bounds__(BLOCK) void k_key_limit_mask(PackCols pc, int64_t n, uint64_t limit, uint64_t* __restrict__ mask) {
+__global__ __launch_bounds__(BLOCK) void k_key_limit_mask(PackCols pc, int64_t n, const uint64_t* __restrict__ limit_p, uint64_t* __restrict__ mask) {
+  const uint64_t limit = *limit_p;   // (left on the device by k_select_kth: no host round trip between the sample and this pass)
   const int64_t n_words = (n + 63) >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
@@ -639,7 +640,8 @@ __global__ __launch_bounds__(BLOCK) void k_os_hist(const uint64_t* __restrict__ 
 }
 // k_key_limit_mask for key columns without NULLs (integer / date types): four mask words per wave iteration, the keys of a lane's four rows
 // loaded column by column before any is packed (tile_keys)
-__global__ __launch_bounds__(BLOCK) void k_key_limit_mask_plain(PackCols pc, int64_t n, uint64_t limit, uint64_t* __restrict__ mask) {
+__global__ __launch_bounds__(BLOCK) void k_key_limit_mask_plain(PackCols pc, int64_t n, const uint64_t* __restrict__ limit_p, uint64_t* __restrict__ mask) {
+  const uint64_t limit = *limit_p;
   const int64_t n_words = (n + 63) >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
@@ -1349,10 +1351,98 @@ __global__ __launch_bounds__(BLOCK, (sizeof(LK) == 4 ? 4 : 3)) void k_local_sort
 
 static SortedKeys radix_sort(SortedKeys in, int64_t n, const std::vector<Digit>& digits, bool want_ids = true);
 
+// ------------------------------------------------------------------------------ the k-th smallest of m one-word keys, on the device
+// MSD radix select by ONE workgroup: eight 8-bit digits from the top, a 256-bin histogram in LDS per digit over the keys that still
+// share the chosen prefix.  The TopK uses it twice: the c-th smallest of its 16 K samples is the limit of the marking pass (round 5
+// copied the samples to the host and ran std::nth_element between two kernels), and the n_out-th smallest of the rows that pass
+// narrows them again — exactly — to what one workgroup sorts in LDS.  m up to a few hundred thousand: the keys stay in L2.
+constexpr int SELECT_THREADS = 1024;
+__global__ __launch_bounds__(SELECT_THREADS) void k_select_kth(const uint64_t* __restrict__ keys, int64_t m, int64_t k /* 1-based */, int top_shift, uint64_t* __restrict__ out) {
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_wtot[4];
+  __shared__ uint64_t s_prefix, s_mask;
+  __shared__ long long s_k;
+  if (threadIdx.x == 0) {
+    s_prefix = 0;
+    s_mask = 0;
+    s_k = k < 1 ? 1 : (k > m ? m : k);
+  }
+  // (digits above `top_shift` are zero in every key: the packed key has total_bits bits)
+  const int64_t m_round = (m + SELECT_THREADS - 1) / SELECT_THREADS * SELECT_THREADS;
+  for (int shift = top_shift; shift >= 0; shift -= 8) {
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t prefix = s_prefix, mask = s_mask;
+    for (int64_t i = threadIdx.x; i < m_round; i += SELECT_THREADS) {
+      const uint64_t v = i < m ? keys[i] : 0;
+      bool act = i < m && (v & mask) == prefix;
+      const unsigned bin = (unsigned)(v >> shift) & 255u;
+      // the smallest keys of a table share their top digits: 150 K atomics on ONE LDS word took 0.3 ms a digit.  Two rounds of "the first
+      // active lane's bin, counted once for the wave", then whoever is left adds its own
+#pragma unroll
+      for (int round = 0; round < 2; round++) {
+        const uint64_t am = ballot64(act);
+        if (am == 0) break;
+        const int leader = __builtin_ctzll(am);
+        const unsigned lb = __shfl(bin, leader, 64);
+        const uint64_t same = ballot64(act && bin == lb);
+        if ((int)lane_id() == leader) atomicAdd(&s_hist[lb], (unsigned)__popcll(same));
+        act = act && bin != lb;
+      }
+      if (act) atomicAdd(&s_hist[bin], 1u);
+    }
+    __syncthreads();
+    // the bin that holds the k-th key: an inclusive scan over the 256 bins by 256 threads (one thread walking the bins cost 8 us a digit)
+    const long long need = s_k;
+    __syncthreads();   // (everybody has read s_k / s_prefix / s_mask before the one thread below rewrites them)
+    if (threadIdx.x < 256) {
+      const unsigned h = s_hist[threadIdx.x];
+      const unsigned inc_w = wave_inclusive_sum(h);
+      if (lane_id() == 63) s_wtot[threadIdx.x >> 6] = inc_w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const unsigned h = s_hist[threadIdx.x];
+      unsigned before = 0;
+      for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += s_wtot[w];
+      const unsigned inc_w = wave_inclusive_sum(h);
+      const long long inc = (long long)before + inc_w, excl = inc - h;
+      const bool last = threadIdx.x == 255;
+      if ((excl < need && inc >= need) || (last && inc < need)) {   // (the second form cannot happen for 1 <= k <= m: a guard, not a case)
+        s_k = need - excl;
+        s_prefix = prefix | ((uint64_t)threadIdx.x << shift);
+        s_mask = mask | (255ull << shift);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = s_prefix;
+}
+__global__ __launch_bounds__(BLOCK) void k_strided_u64(const uint64_t* __restrict__ in, int64_t every, int64_t m, uint64_t* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (j < m) out[j] = in[j * every];
+}
+// (key, id) of the rows whose key is <= *limit, appended at a cursor (in no order: the LDS sort orders ties by id); the cursor counts
+// every such row, also those beyond `cap`
+__global__ __launch_bounds__(BLOCK) void k_take_le(const uint64_t* __restrict__ keys, int64_t m, const uint64_t* __restrict__ limit_p, unsigned* __restrict__ cursor, int cap,
+                                                   uint64_t* __restrict__ out_keys, uint32_t* __restrict__ out_ids) {
+  const uint64_t limit = *limit_p;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < m; i += (int64_t)gridDim.x * BLOCK) {
+    const uint64_t v = keys[i];
+    if (v <= limit) {
+      const unsigned at = atomicAdd(cursor, 1u);
+      if (at < (unsigned)cap) {
+        out_keys[at] = v;
+        out_ids[at] = (uint32_t)i;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ a few thousand rows: one workgroup, in LDS
 // The rows a TopK narrows down to, Q1's four groups, any ORDER BY over a small result: the radix passes above are 5 launches per
 // 8-bit digit (histogram, three scan kernels, scatter) whatever n is — 25 launches and 0.25 ms for the ~3000 survivors of Q3's TopK.
-// One workgroup sorts up to SMALL_SORT_CAP (key words, position) elements in LDS with a bitonic network; the position breaks ties,
+// One workgroup sorts up to SMALL_SORT_CAP (key words, row id) elements in LDS with a bitonic network; the id breaks ties,
 // which makes the order total and the sort stable (sorts/sort.rs:894-914: lexsort_to_indices over the batch; ties by input order
 // is what the LSD passes gave).
 constexpr int SMALL_SORT_CAP = 4096;
@@ -1365,7 +1455,8 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void k_small_sort(KeyWords in, 
   for (int i = threadIdx.x; i < padded; i += SMALL_SORT_THREADS) {
 #pragma unroll
     for (int w = 0; w < NW; w++) s_key[w * padded + i] = i < n ? in.w[w][i] : ~0ull;
-    s_pos[i] = i < n ? (uint32_t)i : 0xFFFFFFFFu;
+    // the element's id — its row's position in the sort's input, unique — orders equal keys, whatever order the elements arrive in
+    s_pos[i] = i < n ? (idx_in ? idx_in[i] : (uint32_t)i) : 0xFFFFFFFFu;
   }
   __syncthreads();
   for (int k = 2; k <= padded; k <<= 1) {
@@ -1399,7 +1490,7 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void k_small_sort(KeyWords in, 
       __syncthreads();
     }
   }
-  for (int i = threadIdx.x; i < n; i += SMALL_SORT_THREADS) idx_out[i] = idx_in ? idx_in[s_pos[i]] : s_pos[i];
+  for (int i = threadIdx.x; i < n; i += SMALL_SORT_THREADS) idx_out[i] = s_pos[i];
 }
 // row ids of up to SMALL_SORT_CAP packed keys in sorted order (stable)
 static BufPtr small_sort_ids(const SortedKeys& sk, int64_t n) {
@@ -2122,15 +2213,16 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
         const int64_t n_words = (n + 63) / 64;
         BufPtr mask = make_buf(bitmap_bytes(n));
         BufPtr prefix = make_buf((size_t)(n_words + 1) * 8);
-        std::vector<uint64_t> sample((size_t)S);
+        const int top_shift = total_bits > 0 ? ((std::min(total_bits, 64) - 1) / 8) * 8 : 0;
+        BufPtr d_limit = make_buf(16);   // [0] the c-th smallest sample, [1] the n_out-th smallest survivor
+        uint64_t* limit = d_limit->as<uint64_t>();
         {
+          // the c-th smallest of the samples, selected on the device (k_select_kth): nothing crosses PCIe before the marking pass
           ProfileScope ps("topk_limit_sample", S * 16);
           k_pack_keys64_rows<<<grid_for(S, BLOCK), BLOCK, 0, r.stream>>>(pc, nullptr, every, S, d_sample->as<uint64_t>());
+          k_select_kth<<<1, SELECT_THREADS, 0, r.stream>>>(d_sample->as<uint64_t>(), S, c, top_shift, limit);
           DFGPU_HIP(hipGetLastError());
         }
-        d2h(sample.data(), d_sample->ptr, (size_t)S * 8);
-        std::nth_element(sample.begin(), sample.begin() + (c - 1), sample.end());
-        const uint64_t limit = sample[(size_t)(c - 1)];
         {
           ProfileScope ps("topk_limit_pass", key_col_bytes + n / 8);
           bool plain_keys = n < ((int64_t)1 << 32);
@@ -2158,6 +2250,33 @@ static Table sort_table(const Table& in, const std::vector<int>& key_cols, const
           DFGPU_HIP(hipGetLastError());
           sk = sv;
           limited = true;
+          // ---- second narrowing: the rows that passed are narrowed once more, by a limit sampled among THEM, down to what one workgroup
+          // sorts in LDS (a few hundred rows); too few (never seen) or too many (ties) and the radix passes sort all who passed the first
+          if (m > SMALL_SORT_CAP && m <= ((int64_t)1 << 22) && option_on("sort.topk_second_narrowing", true)) {
+            BufPtr cursor = make_zero_buf(4);
+            SortedKeys s2;
+            s2.nwords = 1;
+            s2.w[0] = make_buf((size_t)SMALL_SORT_CAP * 8);
+            s2.idx = make_buf((size_t)SMALL_SORT_CAP * 4);
+            {
+              // (the limit: the c2-th smallest of up to 16 K evenly spaced survivors, as for the first pass — the exact n_out-th smallest of
+              // all 150 K survivors would be six passes of one workgroup over them, 0.4 ms)
+              ProfileScope ps("topk_second_narrowing", m * 8 * 2);
+              const int64_t S2 = std::min<int64_t>(S, m), every2 = m / S2;
+              const int64_t c2 = std::min<int64_t>(S2, (n_out * S2 + m - 1) / m * 2 + 16);
+              k_strided_u64<<<grid_for(S2, BLOCK), BLOCK, 0, r.stream>>>(sv.w[0]->as<uint64_t>(), every2, S2, d_sample->as<uint64_t>());
+              k_select_kth<<<1, SELECT_THREADS, 0, r.stream>>>(d_sample->as<uint64_t>(), S2, c2, top_shift, limit + 1);
+              k_take_le<<<grid_for(m, BLOCK * 4), BLOCK, 0, r.stream>>>(sv.w[0]->as<uint64_t>(), m, limit + 1, cursor->as<unsigned>(), SMALL_SORT_CAP, s2.w[0]->as<uint64_t>(),
+                                                                         s2.idx->as<uint32_t>());
+              DFGPU_HIP(hipGetLastError());
+            }
+            unsigned taken = 0;
+            d2h(&taken, cursor->ptr, 4);
+            if ((int64_t)taken >= n_out && taken <= (unsigned)SMALL_SORT_CAP) {   // (else: ties beyond the LDS sort's capacity — the radix passes sort all survivors)
+              sk = s2;
+              m = taken;
+            }
+          }
         }
       }
     }

@@ -159,3 +159,23 @@ def test_float64_to_decimal_cast_values_and_errors():
         assert ops.project(DeviceTable.from_arrow(masked), [(col("f").cast(pa.decimal128(15, 2)), "d")]).to_arrow().column("d").null_count == 1
     with pytest.raises(_lib.DfgpuError, match="too large to store"):                                         # scalar scale-down beyond the precision
         ops.project(DeviceTable.from_arrow(pa.table({"f": pa.array([1.0])})), [(lit("999.99", pa.decimal128(7, 2)).cast(pa.decimal128(2, 0)), "d")])
+
+
+def test_short_scans_take_one_launch_and_long_ones_three_with_the_same_result():
+    """round 6: prefix sums of up to 8 x 4096 elements run as ONE chained kernel (decoupled look-back over the tiles), longer ones as reduce /
+    sums / down; forcing either form on a 3 M-row filter gives the same rows (the scan places every compacted row)"""
+    import numpy as np
+    import pyarrow as pa
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(8)
+    n = 3_000_017
+    t = pa.table({"a": pa.array(rng.integers(0, 100, n), type=pa.int32()), "b": pa.array(np.arange(n), type=pa.int64())})
+    dev = DeviceTable.from_arrow(t)
+    want = t.filter(pa.compute.less(t.column("a"), 37))
+    for tiles in ("0", "1000000", None):
+        ops.set_options(scan__chained_max_tiles=tiles)
+        got = ops.filter(dev, col("a") < lit(37, pa.int32())).to_arrow()
+        assert got.equals(want), tiles
+    ops.set_options(scan__chained_max_tiles=None)
