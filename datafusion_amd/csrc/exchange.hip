@@ -99,8 +99,17 @@ struct Comm {
   dfgpu_host_transport ht{};
   std::mutex mu;
   dfgpu_exchange_stats stats{};
+  // streamed exchanges open on this communicator: their collectives run on library threads, so while one is open the communicator
+  // takes no other collective and cannot be freed (a HashStream holds a plain pointer to it)
+  std::atomic<int> open_streams{0};
   int n_local() const { return (int)devices.size(); }
 };
+// the communicator behind a handle, free to start a collective of its own
+static Comm& idle_comm(dfgpu_comm_t h, const char* who) {
+  Comm& c = *reinterpret_cast<Comm*>(h);
+  DFGPU_CHECK(c.open_streams.load() == 0, std::string(who) + ": a streamed exchange is open on this communicator (dfgpu_exchange_hash_stream_free it first)");
+  return c;
+}
 // a send / receive is cut into messages of at most this many bytes (every rank derives the same cuts from the row counts)
 static int64_t max_message_bytes() {
   static const int64_t v = [] {
@@ -421,7 +430,12 @@ __global__ __launch_bounds__(BLOCK) void k_range_mask(const T* __restrict__ key,
 
 // parts[l][p] = the rows local rank l sends to global rank p (every part of one local rank has the schema of proto[l]);
 // returns, per local rank, the rows it receives from all ranks in rank order.
-static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<Table>>& parts, const std::vector<Table>& proto) {
+// `poisoned`: this rank takes part in the metadata all-gather only to tell the others that it has FAILED (row counts of -1): every
+// rank — this one included — then abandons the exchange with the same error instead of waiting for rows that never come.
+struct ExchangeAbandoned : Error {
+  using Error::Error;
+};
+static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<Table>>& parts, const std::vector<Table>& proto, bool poisoned = false) {
   const int L = c.n_local(), W = c.world;
   const size_t ncols = proto[0].cols.size();
   // Utf8 columns travel as two buffers: one 32-bit length per row (scanned into Arrow offsets at the receiver) and the bytes; the
@@ -453,7 +467,7 @@ static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<
   for (int l = 0; l < L; l++) {
     DFGPU_CHECK(proto[l].cols.size() == ncols, "exchange: the local tables differ in their column count");
     for (int p = 0; p < W; p++) {
-      const int64_t n = parts[l][p].nrows;
+      const int64_t n = poisoned ? -1 : parts[l][p].nrows;
       std::memcpy(&meta[l][(size_t)p * 8], &n, 8);
     }
     for (size_t ci = 0; ci < ncols; ci++) {
@@ -474,6 +488,8 @@ static std::vector<Table> exchange_parts(Comm& c, const std::vector<std::vector<
     std::memcpy(&n, all.data() + (size_t)src * meta_bytes + (size_t)meta_strings + (u * W + (size_t)dst) * 8, 8);
     return n;
   };
+  for (int r = 0; r < W; r++)
+    if (rows(r, 0) < 0) throw ExchangeAbandoned("exchange abandoned on every rank: rank " + std::to_string(r) + " reported an error (or its consumer left the stream early)");
   std::vector<uint8_t> any_valid(ncols, 0);
   for (size_t ci = 0; ci < ncols; ci++)
     for (int r = 0; r < W; r++) {
@@ -762,6 +778,8 @@ static void hash_stream_partition(HashStream* s) {
   s->cv.notify_all();
 }
 static void hash_stream_exchange(HashStream* s) {
+  int exchanged = 0;         // collectives this rank has completed: its peers are about to enter number `exchanged`
+  bool abandoned = false;    // the error came out of a collective every rank abandoned together: nobody waits for another one
   try {
     for (;;) {
       std::vector<std::vector<Table>> parts;
@@ -774,6 +792,7 @@ static void hash_stream_exchange(HashStream* s) {
         s->cv.notify_all();
       }
       std::vector<Table> res = exchange_parts(*s->c, parts, s->inputs);
+      exchanged++;
       parts.clear();
       call_epilogue();
       std::unique_lock<std::mutex> lk(s->mu);
@@ -782,9 +801,43 @@ static void hash_stream_exchange(HashStream* s) {
       s->received.push_back(std::move(res));
       s->cv.notify_all();
     }
+  } catch (const ExchangeAbandoned& e) {
+    abandoned = true;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->error.empty()) s->error = e.what();
   } catch (const std::exception& e) {
     std::lock_guard<std::mutex> lk(s->mu);
     if (s->error.empty()) s->error = e.what();
+  }
+  // This rank stops before the last chunk — an error on one of its threads, or a consumer that left early — while its peers are about to
+  // enter the next chunk's collective: it enters that one too, poisoned, so that every rank abandons the stream with an error at the
+  // same chunk instead of waiting forever (round-5 advice).  Not after an abandoned collective: there everybody has left already.
+  bool stopped_early;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    stopped_early = (s->cancel || !s->error.empty()) && exchanged < s->n_chunks;
+  }
+  if (stopped_early && !abandoned && s->c->world > 1) {
+    try {
+      std::vector<std::vector<Table>> none(s->inputs.size());
+      for (size_t l = 0; l < s->inputs.size(); l++) {   // (pieces of no rows with the input's columns: only the metadata round runs)
+        Table empty;
+        empty.device = s->inputs[l].device;
+        empty.nrows = 0;
+        for (const Column& col : s->inputs[l].cols) {
+          Column v = col;
+          v.length = 0;
+          v.validity = nullptr;
+          v.stats.reset();
+          empty.cols.push_back(std::move(v));
+        }
+        none[l].assign((size_t)s->c->world, empty);
+      }
+      (void)exchange_parts(*s->c, none, s->inputs, /*poisoned=*/true);
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> lk(s->mu);
+      if (s->error.empty()) s->error = e.what();
+    }
   }
   call_epilogue();
   std::lock_guard<std::mutex> lk(s->mu);
@@ -860,6 +913,7 @@ int dfgpu_comm_free(dfgpu_comm_t h) {
   return guarded([&] {
     if (!h) return;
     Comm* c = reinterpret_cast<Comm*>(h);
+    DFGPU_CHECK(c->open_streams.load() == 0, "dfgpu_comm_free: a streamed exchange is still open on this communicator (its threads hold it)");
     for (ncclComm_t n : c->nccl)
       if (n) (void)rccl().CommDestroy(n);
     delete c;
@@ -909,7 +963,7 @@ int dfgpu_exchange_hash(dfgpu_comm_t h, const dfgpu_table_t* inputs, const int* 
   return guarded([&] {
     require_init();
     DFGPU_CHECK(h && inputs && outs && key_cols && nkeys >= 1, "dfgpu_exchange_hash: bad arguments");
-    Comm& c = *reinterpret_cast<Comm*>(h);
+    Comm& c = idle_comm(h, "dfgpu_exchange_hash");
     DFGPU_CHECK(c.world <= 64, "dfgpu_exchange_hash supports up to 64 ranks");
     std::vector<Table> t = local_inputs(c, inputs);
     unify_dictionaries(c, t);
@@ -928,7 +982,7 @@ int dfgpu_exchange_hash_stream_open(dfgpu_comm_t h, const dfgpu_table_t* inputs,
   return guarded([&] {
     require_init();
     DFGPU_CHECK(h && inputs && out && key_cols && nkeys >= 1 && n_chunks >= 1, "dfgpu_exchange_hash_stream_open: bad arguments");
-    Comm& c = *reinterpret_cast<Comm*>(h);
+    Comm& c = idle_comm(h, "dfgpu_exchange_hash_stream_open");
     DFGPU_CHECK(c.world <= 64, "dfgpu_exchange_hash supports up to 64 ranks");
     auto s = std::make_unique<HashStream>();
     s->c = &c;
@@ -942,6 +996,7 @@ int dfgpu_exchange_hash_stream_open(dfgpu_comm_t h, const dfgpu_table_t* inputs,
     s->n_chunks = can_cut ? n_chunks : 1;
     (void)rt().stream;   // (the calling thread keeps the device's first stream: the workers get streams of their own)
     HashStream* raw = s.get();
+    c.open_streams++;
     s->partitioner = std::thread(hash_stream_partition, raw);
     s->exchanger = std::thread(hash_stream_exchange, raw);
     *out = reinterpret_cast<dfgpu_exchange_stream_t>(s.release());
@@ -980,6 +1035,7 @@ int dfgpu_exchange_hash_stream_free(dfgpu_exchange_stream_t sh) {
     }
     if (s->partitioner.joinable()) s->partitioner.join();
     if (s->exchanger.joinable()) s->exchanger.join();
+    s->c->open_streams--;
     delete s;
   });
 }
@@ -988,7 +1044,7 @@ int dfgpu_exchange_broadcast(dfgpu_comm_t h, const dfgpu_table_t* inputs, dfgpu_
   return guarded([&] {
     require_init();
     DFGPU_CHECK(h && inputs && outs, "dfgpu_exchange_broadcast: bad arguments");
-    Comm& c = *reinterpret_cast<Comm*>(h);
+    Comm& c = idle_comm(h, "dfgpu_exchange_broadcast");
     std::vector<Table> t = local_inputs(c, inputs);
     unify_dictionaries(c, t);
     std::vector<std::vector<Table>> parts(c.n_local());
@@ -1008,7 +1064,7 @@ int dfgpu_exchange_range(dfgpu_comm_t h, const dfgpu_table_t* inputs, int key_co
   return guarded([&] {
     require_init();
     DFGPU_CHECK(h && inputs && outs, "dfgpu_exchange_range: bad arguments");
-    Comm& c = *reinterpret_cast<Comm*>(h);
+    Comm& c = idle_comm(h, "dfgpu_exchange_range");
     DFGPU_CHECK(c.world <= MAX_RANGE_RANKS, "dfgpu_exchange_range: too many ranks");
     std::vector<Table> t = local_inputs(c, inputs);
     unify_dictionaries(c, t);
@@ -1099,7 +1155,7 @@ int dfgpu_exchange_broadcast_pruned(dfgpu_comm_t h, const dfgpu_table_t* builds,
   return guarded([&] {
     require_init();
     DFGPU_CHECK(h && builds && probes && outs, "dfgpu_exchange_broadcast_pruned: bad arguments");
-    Comm& c = *reinterpret_cast<Comm*>(h);
+    Comm& c = idle_comm(h, "dfgpu_exchange_broadcast_pruned");
     const int L = c.n_local(), W = c.world;
     std::vector<Table> b = local_inputs(c, builds);
     unify_dictionaries(c, b);

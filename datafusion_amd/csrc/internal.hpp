@@ -151,6 +151,8 @@ struct Runtime {
 };
 
 Runtime& rt();                 // the calling thread's current device runtime (hipSetDevice is kept in step, per thread)
+void scan_upload_caches_drop(int device);      // parquet.hip: the scan workers' cached upload blocks of `device` (-1: all) go back to the pool
+int64_t scan_upload_caches_bytes(int device);  // what they hold right now
 Runtime& rt_of(int device);    // an initialised device's runtime
 void use_device(int device);   // make `device` the calling thread's current device (must be initialised)
 int current_device();          // -1 before dfgpu_init
@@ -447,6 +449,10 @@ int radix_join_bits(const RadixTable& t);
 // (build row, probe row) of every key-equal pair, in partition order; m pairs of int64
 void radix_join_pairs(const RadixTable& t, const Table& build, const std::vector<int>& build_keys, const Table& probe, const std::vector<int>& probe_keys,
                       bool null_equals_null, bool force_collisions, BufPtr& out_b, BufPtr& out_p, int64_t& m);
+
+// INNER join with the output columns written by the emit walk (fixed-width, non-nullable payload; exact record keys); false = not applicable
+bool radix_join_inner_columns(const RadixTable& t, const Table& build, const std::vector<int>& build_keys, const Table& probe, const std::vector<int>& probe_keys,
+                              const std::vector<int>& bout, const std::vector<int>& pout, Table& out);
 
 // ----------------------------------------------------------------- hashing (partition.hip)
 // RepartitionExec(Hash): nparts tables, row order kept inside each (slices of one buffer per column when nothing is nullable)

@@ -2698,6 +2698,18 @@ static Table join_probe(JoinTable& jt, const Table& probe, const std::vector<int
       *mask_consumed = false;
       return Table{};
     }
+    if (join_type == DFGPU_JOIN_INNER && !jt.null_aware && pk.size() == 1) {
+      // INNER, fixed-width payload without NULLs: the emit walk writes the output columns itself (radix_join.hip, round 6)
+      for (int c : bout) DFGPU_CHECK(c >= 0 && c < (int)jt.build.cols.size(), "build output column out of range");
+      for (int c : pout) DFGPU_CHECK(c >= 0 && c < (int)probe.cols.size(), "probe output column out of range");
+      Table fused;
+      if (radix_join_inner_columns(*jt.radix, jt.build, jt.key_cols, probe, pk, bout, pout, fused)) {
+        std::lock_guard<std::mutex> lk(jt.mu);
+        jt.info.probe_rows += probe.nrows;
+        jt.info.output_rows += fused.nrows;
+        return fused;
+      }
+    }
     return join_probe_with_filter(jt, probe, pk, join_type, bout, pout, nullptr);
   }
   const int64_t np = probe.nrows;

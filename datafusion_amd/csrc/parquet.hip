@@ -1664,6 +1664,8 @@ extern thread_local double t_upload_ms[6];   // (defined below: where a worker's
 // to the copy engine by hipMemcpyAsync: the call itself waits (measured: 1-4 ms per chunk, 2-9 ms with an event wait in front of it).
 struct UploadCache {
   std::vector<BufPtr> free;
+  size_t cached_bytes = 0;
+  std::mutex mu;   // the owner thread takes and gives; dfgpu_mem_trim / dfgpu_shutdown drop the blocks from another thread
   // sizes in classes (powers of two from 256 KB): the chunks of a scan's columns come in a handful of sizes, and a miss costs a drain of
   // the kernel stream
   static size_t size_class(size_t n) {
@@ -1673,34 +1675,67 @@ struct UploadCache {
   }
   BufPtr take(size_t n, hipStream_t kernel_stream) {
     const size_t c = size_class(n);
-    for (size_t i = 0; i < free.size(); i++)
-      if (free[i]->bytes == c) {
-        BufPtr b = std::move(free[i]);
-        free.erase(free.begin() + (long)i);
-        return b;
-      }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < free.size(); i++)
+        if (free[i]->bytes == c) {
+          BufPtr b = std::move(free[i]);
+          free.erase(free.begin() + (long)i);
+          cached_bytes -= c;
+          return b;
+        }
+    }
     BufPtr b = make_buf(c);
     DFGPU_HIP(hipStreamSynchronize(kernel_stream));   // a pool block: whatever this thread's kernels still read of it is done after this
     return b;
   }
+  // A few blocks per size class (the chunks in flight plus one), and no more than `parquet.upload_cache_bytes` (256 MiB) per thread and
+  // device in all: with 16 scan workers that bounds what the caches hold at 4 GiB whatever the chunk sizes; what does not fit goes
+  // back to the pool.
   void give(BufPtr b) {
+    const size_t cap = (size_t)option_int("parquet.upload_cache_bytes", (int64_t)256 << 20);
+    std::lock_guard<std::mutex> lk(mu);
     size_t same = 0;
     for (const BufPtr& f : free) same += f->bytes == b->bytes;
-    if (same < 6 && free.size() < 48) free.push_back(std::move(b));   // (a few per class: the chunks in flight plus one)
+    if (same < 6 && free.size() < 48 && cached_bytes + b->bytes <= cap) {
+      cached_bytes += b->bytes;
+      free.push_back(std::move(b));
+    }
   }
+  void drop_all() {
+    std::vector<BufPtr> gone;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      gone.swap(free);
+      cached_bytes = 0;
+    }
+  }   // (the blocks go back to the pool here, outside the lock)
 };
 // What a host thread keeps per DEVICE for the scan (a library thread may serve scans on different GPUs of the process): the upload stream
-// and its event, the stream the pages' states come back on, the upload buffers.  Never destroyed: a thread's cache would otherwise give
-// its blocks back to a pool that static destruction may already have taken down.
+// and its event, the stream the pages' states come back on, the upload buffers.  The object itself is never destroyed (a thread's cache
+// would otherwise give its blocks back to a pool that static destruction may already have taken down), but its BLOCKS belong to the
+// runtime: every instance is registered, and dfgpu_mem_trim / dfgpu_shutdown (Runtime::trim -> scan_upload_caches_drop) hand all cached
+// upload blocks of the device back before the pool itself is trimmed — so they count as reclaimable, and nothing survives a shutdown.
 struct ScanThreadDevice {
   hipStream_t up = nullptr, readback = nullptr;
   hipEvent_t ev_up = nullptr;
   UploadCache cache;
+  int device = -1;
 };
+static std::mutex g_scan_devs_mu;
+static std::vector<ScanThreadDevice*>& scan_devs() {
+  static std::vector<ScanThreadDevice*>* v = new std::vector<ScanThreadDevice*>();
+  return *v;
+}
 static ScanThreadDevice& scan_thread_device(int device) {
   static thread_local std::map<int, ScanThreadDevice*>* per_device = new std::map<int, ScanThreadDevice*>();
   ScanThreadDevice*& p = (*per_device)[device];
-  if (!p) p = new ScanThreadDevice();
+  if (!p) {
+    p = new ScanThreadDevice();
+    p->device = device;
+    std::lock_guard<std::mutex> lk(g_scan_devs_mu);
+    scan_devs().push_back(p);
+  }
   return *p;
 }
 struct DeviceChunkKeep {
@@ -1905,6 +1940,27 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
 }
 
 }  // namespace
+
+// (declared in internal.hpp: Runtime::trim calls them)
+void scan_upload_caches_drop(int device) {
+  std::vector<ScanThreadDevice*> mine;
+  {
+    std::lock_guard<std::mutex> lk(g_scan_devs_mu);
+    for (ScanThreadDevice* s : scan_devs())
+      if (device < 0 || s->device == device) mine.push_back(s);
+  }
+  for (ScanThreadDevice* s : mine) s->cache.drop_all();
+}
+int64_t scan_upload_caches_bytes(int device) {
+  std::lock_guard<std::mutex> lk(g_scan_devs_mu);
+  int64_t n = 0;
+  for (ScanThreadDevice* s : scan_devs())
+    if (device < 0 || s->device == device) {
+      std::lock_guard<std::mutex> cl(s->cache.mu);
+      n += (int64_t)s->cache.cached_bytes;
+    }
+  return n;
+}
 
 namespace {
 

@@ -23,15 +23,18 @@
 // the plan does not observe HashJoinExec's probe-side order (it is chosen by table_mode 4, or by `auto` under probe_mode 4).
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 
 #include "device.hpp"
 #include "internal.hpp"
 
 namespace dfgpu {
 
+static bool force_fused_off() { return !option_on("join.radix_fused_emit", true); }   // (A/B switch: the pairs + gathers of round 5)
 constexpr int RJ_CAP = 2048;     // build rows per LDS chunk
 constexpr int RJ_HEADS = 4096;   // chain heads (power of two, 2 x RJ_CAP)
 constexpr int RJ_TASK_ROWS = 8192;
+constexpr int RJ_STAGE = 512;    // matches of one 256-row probe tile staged in LDS before they are written (8 KB: 3 workgroups per CU still fit)
 
 struct RadixTask {
   uint32_t part;
@@ -170,16 +173,57 @@ struct RjVerify {
   KeySet bkeys, pkeys;
   int null_equals_null;
 };
-template <bool EXACT, bool EMIT>
+// The output columns of an INNER join written by the emit walk itself (round 6): a pair's build row and probe row are in registers the
+// moment the pair is found — its columns are gathered and written right there, and the (build row, probe row) list — 16 bytes a pair
+// written, then read back by one gather per column — never exists (M:N at SF100 sizes, 300 M pairs: 4.8 GB of pairs each way).  A column
+// that IS the join key (EXACT records: mixed key = fmix64(value), a bijection) comes out of the record's key by unfmix64: no access at all.
+constexpr int RJ_MAX_COLS = 12;
+struct RjCols {
+  const void* src[RJ_MAX_COLS];
+  void* dst[RJ_MAX_COLS];
+  int width[RJ_MAX_COLS];
+  int n_build;   // the first n_build entries read the build row, the others the probe row
+  int n;
+  unsigned key_cols;   // bit c: entry c is the join key column (EXACT): the value is unfmix64(record key)
+};
+__device__ __forceinline__ uint64_t unfmix64(uint64_t x) {   // fmix64's inverse (the multipliers' inverses mod 2^64; x ^= x >> 33 undoes itself)
+  x ^= x >> 33; x *= 0x9cb4b2f8129337dbULL;
+  x ^= x >> 33; x *= 0x4f74430c22a54005ULL;
+  x ^= x >> 33;
+  return x;
+}
+__device__ __forceinline__ void rj_emit_row(const RjCols& cols, uint64_t key, uint32_t brow, uint32_t prow, unsigned long long o) {
+  for (int c = 0; c < cols.n; c++) {
+    const int w = cols.width[c];
+    if ((cols.key_cols >> c) & 1u) {
+      const uint64_t v = unfmix64(key);
+      if (w == 8) reinterpret_cast<uint64_t*>(cols.dst[c])[o] = v;
+      else if (w == 4) reinterpret_cast<uint32_t*>(cols.dst[c])[o] = (uint32_t)v;
+      else reinterpret_cast<uint8_t*>(cols.dst[c])[o] = (uint8_t)v;
+      continue;
+    }
+    const int64_t s = c < cols.n_build ? (int64_t)brow : (int64_t)prow;
+    switch (w) {
+      case 16: reinterpret_cast<uint4*>(cols.dst[c])[o] = reinterpret_cast<const uint4*>(cols.src[c])[s]; break;
+      case 8: reinterpret_cast<uint64_t*>(cols.dst[c])[o] = reinterpret_cast<const uint64_t*>(cols.src[c])[s]; break;
+      case 4: reinterpret_cast<uint32_t*>(cols.dst[c])[o] = reinterpret_cast<const uint32_t*>(cols.src[c])[s]; break;
+      default: reinterpret_cast<uint8_t*>(cols.dst[c])[o] = reinterpret_cast<const uint8_t*>(cols.src[c])[s]; break;
+    }
+  }
+}
+// EMIT: 0 = count the task's matches, 1 = write (build row, probe row) pairs, 2 = write the output columns (RjCols)
+template <bool EXACT, int EMIT>
 __global__ __launch_bounds__(BLOCK) void k_rj_join(const uint64_t* __restrict__ bkey, const uint32_t* __restrict__ brid, const uint64_t* __restrict__ bstart,
                                                   const uint64_t* __restrict__ pkey, const uint32_t* __restrict__ prid, const RadixTask* __restrict__ tasks,
                                                   int64_t n_tasks, RjVerify v, unsigned long long* __restrict__ task_counts,
-                                                  const uint64_t* __restrict__ task_off, int64_t* __restrict__ out_b, int64_t* __restrict__ out_p) {
+                                                  const uint64_t* __restrict__ task_off, int64_t* __restrict__ out_b, int64_t* __restrict__ out_p, RjCols cols = RjCols{}) {
   __shared__ uint64_t s_key[RJ_CAP];
   __shared__ uint32_t s_rid[RJ_CAP];
   __shared__ uint32_t s_head[RJ_HEADS];
   __shared__ uint16_t s_next[RJ_CAP];
   __shared__ unsigned long long s_wtot[BLOCK / WAVE];
+  __shared__ uint64_t s_ok[EMIT ? RJ_STAGE : 1];   // the emit walks' stage: a tile's matches (record key, build row, probe row)
+  __shared__ uint32_t s_ob[EMIT ? RJ_STAGE : 1], s_op[EMIT ? RJ_STAGE : 1];
   const unsigned lane = lane_id();
   const int wave = threadIdx.x >> 6;
   for (int64_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
@@ -231,19 +275,49 @@ __global__ __launch_bounds__(BLOCK) void k_rj_join(const uint64_t* __restrict__ 
           tot += s_wtot[w];
         }
         unsigned long long o = base + inc - cnt;
-        if (cnt) {
+        if (tot <= (unsigned long long)RJ_STAGE) {
+          // the tile's matches are listed in LDS first, then every OUTPUT row gets a thread: consecutive threads write consecutive rows
+          // (a thread writing its own two or three matches one after the other left 8-byte stores 16-24 bytes apart: 5.6 ms for 300 M
+          // pairs against 3.x staged) and the gathers of a row's columns are issued by as many threads as there are rows
+          if (cnt) {
+            uint32_t lo = (uint32_t)(o - run);
+            uint32_t cur = s_head[(uint32_t)k & (RJ_HEADS - 1)];
+            while (cur) {
+              if (s_key[cur - 1] == k && (EXACT || keys_equal(v.bkeys, (int64_t)s_rid[cur - 1], v.pkeys, (int64_t)pr, v.null_equals_null != 0, true))) {
+                s_ok[lo] = k;
+                s_ob[lo] = s_rid[cur - 1];
+                s_op[lo] = pr;
+                lo++;
+              }
+              cur = s_next[cur - 1];
+            }
+          }
+          __syncthreads();
+          for (uint32_t q = threadIdx.x; q < (uint32_t)tot; q += BLOCK) {
+            if (EMIT == 2) {
+              rj_emit_row(cols, s_ok[q], s_ob[q], s_op[q], run + q);
+            } else {
+              out_b[run + q] = (int64_t)s_ob[q];
+              out_p[run + q] = (int64_t)s_op[q];
+            }
+          }
+        } else if (cnt) {   // (more matches than the stage holds — heavy duplicates: every thread writes its own)
           uint32_t cur = s_head[(uint32_t)k & (RJ_HEADS - 1)];
           while (cur) {
             if (s_key[cur - 1] == k && (EXACT || keys_equal(v.bkeys, (int64_t)s_rid[cur - 1], v.pkeys, (int64_t)pr, v.null_equals_null != 0, true))) {
-              out_b[o] = (int64_t)s_rid[cur - 1];
-              out_p[o] = (int64_t)pr;
+              if (EMIT == 2) {
+                rj_emit_row(cols, k, s_rid[cur - 1], pr, o);
+              } else {
+                out_b[o] = (int64_t)s_rid[cur - 1];
+                out_p[o] = (int64_t)pr;
+              }
               o++;
             }
             cur = s_next[cur - 1];
           }
         }
         run += tot;
-        __syncthreads();  // s_wtot is reused by the next tile
+        __syncthreads();  // s_wtot and the stage are reused by the next tile
       }
       __syncthreads();  // the next chunk overwrites the table
     }
@@ -282,9 +356,10 @@ std::shared_ptr<RadixTable> radix_join_build(const Table& build, const std::vect
 int64_t radix_join_table_bytes(const RadixTable& t) { return t.build.n * 12 + (((int64_t)1 << t.bits) + 1) * 8; }
 int radix_join_bits(const RadixTable& t) { return t.bits; }
 
-// inner pairs (build row, probe row) of all key-equal rows, in partition order
-void radix_join_pairs(const RadixTable& t, const Table& build, const std::vector<int>& build_keys, const Table& probe, const std::vector<int>& probe_keys,
-                      bool null_equals_null, bool force_collisions, BufPtr& out_b, BufPtr& out_p, int64_t& m) {
+// inner pairs (build row, probe row) of all key-equal rows, in partition order — or, with `columns` (an INNER join's output columns: a
+// callback that allocates them for m rows and fills in the destinations), the joined rows themselves
+static void radix_join_run(const RadixTable& t, const Table& build, const std::vector<int>& build_keys, const Table& probe, const std::vector<int>& probe_keys,
+                           bool null_equals_null, bool force_collisions, BufPtr& out_b, BufPtr& out_p, int64_t& m, const std::function<RjCols(int64_t)>* columns) {
   Runtime& r = rt();
   m = 0;
   out_b = make_buf(8);
@@ -313,10 +388,10 @@ void radix_join_pairs(const RadixTable& t, const Table& build, const std::vector
   {
     ProfileScope psc("radix_join_count", rec_bytes);
     if (t.exact)
-      k_rj_join<true, false><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
+      k_rj_join<true, 0><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
                                                            ps.rid->as<uint32_t>(), d_tasks->as<RadixTask>(), nt, v, d_counts->as<unsigned long long>(), nullptr, nullptr, nullptr);
     else
-      k_rj_join<false, false><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
+      k_rj_join<false, 0><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
                                                             ps.rid->as<uint32_t>(), d_tasks->as<RadixTask>(), nt, v, d_counts->as<unsigned long long>(), nullptr, nullptr, nullptr);
     DFGPU_HIP(hipGetLastError());
   }
@@ -330,19 +405,85 @@ void radix_join_pairs(const RadixTable& t, const Table& build, const std::vector
   m = (int64_t)tot;
   if (m == 0) return;
   DFGPU_HIP(hipMemcpyAsync(d_off->ptr, off.data(), (size_t)nt * 8, hipMemcpyHostToDevice, r.stream));
+  if (columns) {
+    const RjCols cols = (*columns)(m);
+    int64_t row_bytes = 0;
+    for (int c = 0; c < cols.n; c++) row_bytes += cols.width[c];
+    ProfileScope pse("radix_join_emit_columns", rec_bytes + m * row_bytes * 2);
+    DFGPU_CHECK(t.exact, "internal: the fused column emit needs exact record keys");
+    k_rj_join<true, 2><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
+                                                     ps.rid->as<uint32_t>(), d_tasks->as<RadixTask>(), nt, v, nullptr, d_off->as<uint64_t>(), nullptr, nullptr, cols);
+    DFGPU_HIP(hipGetLastError());
+    DFGPU_HIP(hipStreamSynchronize(r.stream));  // `off` and `tasks` are locals the copies read
+    return;
+  }
   out_b = make_buf((size_t)m * 8);
   out_p = make_buf((size_t)m * 8);
   {
     ProfileScope pse("radix_join_emit", rec_bytes + m * 16);
     if (t.exact)
-      k_rj_join<true, true><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
+      k_rj_join<true, 1><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
                                                           ps.rid->as<uint32_t>(), d_tasks->as<RadixTask>(), nt, v, nullptr, d_off->as<uint64_t>(), out_b->as<int64_t>(), out_p->as<int64_t>());
     else
-      k_rj_join<false, true><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
+      k_rj_join<false, 1><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
                                                            ps.rid->as<uint32_t>(), d_tasks->as<RadixTask>(), nt, v, nullptr, d_off->as<uint64_t>(), out_b->as<int64_t>(), out_p->as<int64_t>());
     DFGPU_HIP(hipGetLastError());
   }
   DFGPU_HIP(hipStreamSynchronize(r.stream));  // `off` and `tasks` are locals the copies read
+}
+
+void radix_join_pairs(const RadixTable& t, const Table& build, const std::vector<int>& build_keys, const Table& probe, const std::vector<int>& probe_keys,
+                      bool null_equals_null, bool force_collisions, BufPtr& out_b, BufPtr& out_p, int64_t& m) {
+  radix_join_run(t, build, build_keys, probe, probe_keys, null_equals_null, force_collisions, out_b, out_p, m, nullptr);
+}
+
+// INNER join, output columns written by the emit walk (no pair list, no gathers).  false: this table / these columns do not qualify
+// (record keys that are hashes, nullable or variable-width payload, too many columns) — the caller takes the pairs.
+bool radix_join_inner_columns(const RadixTable& t, const Table& build, const std::vector<int>& build_keys, const Table& probe, const std::vector<int>& probe_keys,
+                              const std::vector<int>& bout, const std::vector<int>& pout, Table& out) {
+  if (!t.exact || force_fused_off() || (int)(bout.size() + pout.size()) > RJ_MAX_COLS || bout.size() + pout.size() == 0) return false;
+  auto fixed = [](const Column& c) { return !c.has_nulls() && c.field.type != DFGPU_UTF8 && c.field.type != DFGPU_BOOL; };
+  for (int c : bout)
+    if (!fixed(build.cols[(size_t)c])) return false;
+  for (int c : pout)
+    if (!fixed(probe.cols[(size_t)c])) return false;
+  if (probe.cols[(size_t)probe_keys[0]].has_nulls() || build.cols[(size_t)build_keys[0]].has_nulls()) return false;   // (NULL keys are dropped from the records: fine, but keep it simple)
+  out = Table{};
+  out.device = probe.device;
+  std::function<RjCols(int64_t)> columns = [&](int64_t m) {
+    RjCols rc{};
+    out.nrows = m;
+    for (int c : bout) {
+      const Column& sc = build.cols[(size_t)c];
+      out.cols.push_back(alloc_like(sc, m));
+      rc.src[rc.n] = sc.ptr();
+      rc.dst[rc.n] = out.cols.back().data->ptr;
+      rc.width[rc.n] = type_width(sc.field.type);
+      if (c == build_keys[0]) rc.key_cols |= 1u << rc.n;
+      rc.n++;
+    }
+    rc.n_build = rc.n;
+    for (int c : pout) {
+      const Column& sc = probe.cols[(size_t)c];
+      out.cols.push_back(alloc_like(sc, m));
+      rc.src[rc.n] = sc.ptr();
+      rc.dst[rc.n] = out.cols.back().data->ptr;
+      rc.width[rc.n] = type_width(sc.field.type);
+      if (c == probe_keys[0]) rc.key_cols |= 1u << rc.n;
+      rc.n++;
+    }
+    return rc;
+  };
+  BufPtr ob, op;
+  int64_t m = 0;
+  radix_join_run(t, build, build_keys, probe, probe_keys, false, false, ob, op, m, &columns);
+  if (m == 0) {   // no pair: the callback never ran
+    out.nrows = 0;
+    out.cols.clear();
+    for (int c : bout) out.cols.push_back(alloc_like(build.cols[(size_t)c], 0));
+    for (int c : pout) out.cols.push_back(alloc_like(probe.cols[(size_t)c], 0));
+  }
+  return true;
 }
 
 }  // namespace dfgpu

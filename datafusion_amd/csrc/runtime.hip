@@ -282,6 +282,8 @@ void Runtime::free(void* p) {
 }
 
 void Runtime::trim() {
+  scan_upload_caches_drop(device);   // the Parquet scan workers' upload blocks are pool blocks on loan: back first, then the pool itself
+  call_epilogue();                   // (several threads: what this thread just freed waits on its pending list until its stream has drained)
   std::multimap<size_t, void*> blocks;
   {
     std::lock_guard<std::mutex> lk(mu);

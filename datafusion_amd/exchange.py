@@ -149,9 +149,10 @@ class Comm:
         return {n: getattr(st, n) for n, _ in st._fields_}
 
     def free(self):
+        """dfgpu_comm_free; refused (DfgpuError, the communicator stays usable) while a streamed exchange is open on it"""
         if self._h:
             from . import _lib
-            _lib.load().dfgpu_comm_free(self._h)
+            _lib.check(_lib.load().dfgpu_comm_free(self._h))
             self._h = None
 
 

@@ -153,6 +153,37 @@ if mode == "exchange":
     rx = c.hash_exchange(DeviceTable.from_arrow(right), ["s2"])
     out["pjoin"] = decoded(ops.hash_join(lx, rx, [("s", "s2")], "Inner").to_arrow())
     out["pjoin_inputs"] = (decoded(left), right)
+elif mode == "stream_abandoned":
+    # rank 0's consumer leaves the stream after its first chunk; rank 1 drains.  Nobody hangs: rank 0 enters the next chunk's collective
+    # poisoned, rank 1 gets an error at that chunk — and the communicator is still in step: a blocking exchange afterwards works
+    from datafusion_amd.exchange import comm_for
+    from tests.test_gpu_exchange import mixed_table, decoded
+    t = mixed_table(20 + rank, 30_000)
+    d = DeviceTable.from_arrow(t).select(["k", "d", "q"])
+    c = comm_for()
+    got, err = [], None
+    try:
+        for i, chunk in enumerate(c.hash_exchange_stream(d, ["k"], 6)):
+            got.append(chunk.num_rows)
+            if rank == 0 and i == 0:
+                break
+    except Exception as e:
+        err = str(e)
+    out["chunks"], out["error"] = got, err
+    # a collective while a stream is open, and freeing the communicator under it, are refused
+    gen = c.hash_exchange_stream(d, ["k"], 2)
+    first = next(gen)
+    refused = []
+    for what in (lambda: c.hash_exchange(d, ["k"]), lambda: c.free()):
+        try:
+            what()
+            refused.append(None)
+        except Exception as e:
+            refused.append(str(e))
+    rest = [first.num_rows] + [x.num_rows for x in gen]
+    out["refused"], out["second_stream_rows"] = refused, sum(rest)
+    out["after"] = decoded(c.hash_exchange(d, ["k"]).to_arrow())
+    out["input"] = decoded(d.to_arrow())
 elif mode == "plans":
     from datafusion_amd import physical_plan as P
     from tests.test_tpch_answers import data, plans
@@ -328,3 +359,19 @@ def test_bench_two_ranks_without_a_launcher_starts_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and "watchdog" not in line and "exchange_errors" not in line
     assert {"repartition", "repartition_stream", "pruned"} <= set(line["exchanges"])
+
+
+def test_a_rank_that_leaves_a_streamed_exchange_early_takes_every_rank_out_with_an_error(tmp_path):
+    """round-5 advice: a consumer that leaves the stream early (or an error on one rank's threads) used to stop that rank's all-to-all(v)s
+    while its peers waited in theirs forever.  Now the leaving rank enters the next chunk's collective poisoned: every rank abandons the
+    stream at the same chunk with an error, the communicator stays in step (a blocking exchange right after works), and while a stream
+    is open the communicator refuses other collectives and dfgpu_comm_free"""
+    world = 2
+    res = _run_ranks(tmp_path, world, "stream_abandoned", _free_port())
+    assert res[0]["error"] is None and len(res[0]["chunks"]) == 1                      # rank 0 left after its first chunk
+    assert res[1]["error"] is not None and "abandoned" in res[1]["error"] and 1 <= len(res[1]["chunks"]) <= 4, res[1]   # (rank 0 runs up to two chunks ahead of its consumer)
+    for r in range(world):
+        assert all(x is not None and "streamed exchange" in x for x in res[r]["refused"]), res[r]["refused"]
+    whole = pa.concat_tables([r["input"] for r in res])
+    assert sum(r["second_stream_rows"] for r in res) == whole.num_rows
+    assert_tables_equal(pa.concat_tables([r["after"] for r in res]), whole, ordered=False)

@@ -600,3 +600,46 @@ def test_device_page_decode_of_a_chunk_with_hundreds_of_pages(tmp_path):
     pq.write_table(t, path, compression="snappy", data_page_size=8 * 1024, row_group_size=n, use_dictionary=["b"])
     assert pq.ParquetFile(path).metadata.row_group(0).column(0).total_uncompressed_size > 300 * 8 * 1024
     assert_tables_equal(plain(read_table(path).to_arrow()), pq.read_table(path), ordered=True)
+
+
+def test_scan_workers_upload_blocks_go_back_on_trim(tmp_path):
+    """round 5 advice: the scan workers keep the device blocks their uploads land in per thread, between chunks and between calls.  They are
+    pool blocks on loan: dfgpu_mem_trim (and dfgpu_shutdown) takes them back — after a scan whose tables are freed and a trim, the pool holds
+    nothing — and a thread keeps at most parquet.upload_cache_bytes of them"""
+    from datafusion_amd import _lib, ops
+    from datafusion_amd import parquet as P
+    from datafusion_amd.parquet import ChunkCache, ParquetFile
+    rng = np.random.default_rng(4)
+    n = 2_000_000
+    t = pa.table({"a": pa.array(rng.integers(0, 1 << 40, n)), "b": pa.array(rng.integers(0, 1 << 40, n)), "c": pa.array(rng.random(n))})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, row_group_size=500_000, compression="none", use_dictionary=False)
+    saved = P.CACHE
+    try:
+        P.CACHE = ChunkCache(budget=0)
+        ops.sync()
+        _lib.load().dfgpu_mem_trim()
+        base = ops.mem_stats()["in_use"]
+        f = ParquetFile(path)
+        for _ in range(2):
+            got = f.read(threads=4)
+            assert got.num_rows == n
+            got.free()
+        f.close()
+        ops.sync()
+        held = ops.mem_stats()["in_use"] - base
+        assert held > 0                                    # the workers' upload blocks (4 MB chunks -> 4 MiB blocks)
+        _lib.load().dfgpu_mem_trim()
+        after = ops.mem_stats()
+        assert after["in_use"] == base and after["cached"] == 0, (base, held, after)
+        # the byte cap: with a cap below one block nothing is kept at all
+        ops.set_options(parquet__upload_cache_bytes="1024")
+        f = ParquetFile(path)
+        f.read(threads=4).free()
+        f.close()
+        ops.sync()
+        assert ops.mem_stats()["in_use"] == base
+    finally:
+        ops.set_options(parquet__upload_cache_bytes=None)
+        P.CACHE.clear()
+        P.CACHE = saved
