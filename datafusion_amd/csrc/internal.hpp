@@ -174,6 +174,10 @@ struct DevBuf {
   size_t bytes = 0;
   Runtime* owner = nullptr;  // the pool the block goes back to (buffers may be released from any thread)
   std::shared_ptr<void> foreign;  // device memory somebody else owns (an imported ArrowDeviceArray): released with the last buffer that refers to it
+  // One remembered answer about the (immutable) contents, shared by every column that views this buffer: bits 63..2 = a tag of the
+  // question (what was asked, of which rows), bits 1..0 = 2 | answer.  The join's "are these probe keys clustered?" sample lives here:
+  // asked once per table instead of once per probe (a kernel and a blocking read-back each time).
+  std::atomic<uint64_t> hint{0};
   explicit DevBuf(size_t n);
   DevBuf(void* p, size_t n, std::shared_ptr<void> keep_alive) : ptr(p), bytes(n), foreign(std::move(keep_alive)) {}
   ~DevBuf();
@@ -333,6 +337,7 @@ inline dfgpu_table_t wrap_quiet(Table* t) { return reinterpret_cast<dfgpu_table_
 void scan_mask_popcounts(const uint64_t* mask, const uint64_t* valid, int64_t nrows, uint64_t* out_prefix);
 // exclusive prefix sum of u32 counts -> u64 (n + 1 entries)
 void scan_u32(const uint32_t* in, int64_t n, uint64_t* out_prefix);
+void scan_bitmap_words_tab(const uint64_t* words, int64_t n_words, uint64_t* out_prefix, void* out_tab);   // + the rank map's interleaved {word, prefix} pairs
 uint64_t read_u64(const uint64_t* dev);
 
 // ----------------------------------------------------------------- compaction (filter.hip)

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_rank_setbits(KeyCol k, int64_t n, uin
 #pragma unroll
       for (int j = 0; j < BUILD_UNROLL; j++) {
         int64_t i = base + j * stride + lane;
-        idx[j] = load_key<KT>(k, i < n ? i : n - 1) - offset;
+        idx[j] = load_key<KT, true>(k, i < n ? i : n - 1) - offset;   // (the keys stream by once: non-temporal)
         if (VERIFY) pidx[j] = load_key<KT>(k, i < n ? (i > 0 ? i - 1 : 0) : n - 1) - offset;   // the neighbour's line: a cache hit, in flight with the rest
       }
 #pragma unroll
@@ -1900,7 +1900,7 @@ static void ensure_rank_tab(JoinTable& jt) {
     k_rank_interleave<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(jt.rank_bits->as<uint64_t>(), jt.rank_prefix->as<uint64_t>(), n_words, tab->as<ulonglong2>());
     DFGPU_HIP(hipGetLastError());
   }
-  DFGPU_HIP(hipStreamSynchronize(r.stream));  // complete before another thread's stream reads it
+  call_epilogue();  // several host threads: complete before another thread's stream reads it (one thread: its stream orders it, no wait)
   jt.rank_tab = tab;
   std::lock_guard<std::mutex> lk2(jt.mu);
   jt.info.table_bytes += n_words * 16;
@@ -2064,7 +2064,25 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
   // repaired by the measured path below (`speculate` = false).
   bool speculated = false;
   const bool spec_off = false;
-  if (speculate && !spec_off && (opts.table_mode == 0 || opts.table_mode == 3) && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64 &&
+  // Statistics this (immutable) key column already carries — measured by an earlier build over the same table, by dfgpu_column_minmax,
+  // by a sort — are taken as they are: no sample, no verifying pass, no read-back (the reference's planner reads a table's column
+  // statistics the same way, common/src/stats.rs; a build that has to measure or guess leaves what it learned on the column, below)
+  std::shared_ptr<ColStats> known;
+  if (ks.n == 1 && opts.table_mode != 1 && opts.table_mode != 5 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64 && option_on("join.cached_key_stats", true)) {
+    const Column& kc = build.cols[key_cols[0]];
+    known = std::atomic_load(&kc.stats);
+    const bool null_block = null_equality == DFGPU_NULL_EQUALS_NULL && kc.has_nulls();
+    if (known && !null_block && nb > 0 && known->valid > 0) {
+      range = (uint64_t)known->max - (uint64_t)known->min;
+      have_stats = range != UINT64_MAX;
+      kmin = known->min;
+      ascending = known->ascending;
+      n_valid_keys = known->valid;
+    } else {
+      known.reset();
+    }
+  }
+  if (!known && speculate && !spec_off && (opts.table_mode == 0 || opts.table_mode == 3) && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64 &&
       !ks.c[0].valid && nb >= (1 << 22)) {
     constexpr int S = 4096;
     BufPtr ends = make_zero_buf(24);
@@ -2084,7 +2102,7 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       }
     }
   }
-  if (!speculated && opts.table_mode != 1 && opts.table_mode != 5 && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64) {
+  if (!known && !speculated && opts.table_mode != 1 && opts.table_mode != 5 && ks.n == 1 && is_integer_like(ks.c[0].type) && ks.c[0].type != DFGPU_UINT64) {
     const Column& kc = build.cols[key_cols[0]];
     bool null_block = null_equality == DFGPU_NULL_EQUALS_NULL && kc.has_nulls();
     if (!null_block && nb > 0) {
@@ -2108,6 +2126,8 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
         have_stats = range != UINT64_MAX;
         kmin = res.smin;
         ascending = res.unsorted == 0;
+        // (what was measured stays with the column: the next build over this table reads it)
+        std::atomic_store(&const_cast<Column&>(kc).stats, std::make_shared<ColStats>(ColStats{res.smin, res.smax, (int64_t)res.valid, res.unsorted == 0, res.descends == 0}));
       }
     }
   }
@@ -2226,6 +2246,14 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       }
     }
     jt->rank_prefix = make_buf((size_t)(n_words + 1) * 8);
+    // A build side that fills its key range densely enough for the probes to look every row's rank up (below 0.15 the selective flavour
+    // takes over: membership from the bitmap, ranks of the few listed rows from bitmap + prefix) gets the interleaved table from the
+    // prefix scan's own down-sweep; the others leave it to the first probe that asks (ensure_rank_tab).
+    BufPtr eager_tab;
+    if (ascending && (double)nb >= 0.15 * ((double)range + 1.0) && option_on("join.eager_rank_tab", true)) {
+      eager_tab = make_buf((size_t)n_words * 16);
+      scan_bitmap_words_tab(jt->rank_bits->as<uint64_t>(), n_words, jt->rank_prefix->as<uint64_t>(), eager_tab->ptr);
+    } else
     scan_mask_popcounts(jt->rank_bits->as<uint64_t>(), nullptr, n_words * 64, jt->rank_prefix->as<uint64_t>());
     // keys in no order set their bits without looking: two rows with one key set one bit
     if (!ascending) dup = (int64_t)read_u64(jt->rank_prefix->as<uint64_t>() + n_words) != n_valid_keys;
@@ -2237,6 +2265,9 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
         jt.reset();
         return join_build_fixed_keys(build, key_cols, null_equality, opts, false);
       }
+      // the guess held for every key: first = min, last = max, strictly ascending, no NULLs — the column's statistics from now on
+      std::atomic_store(&const_cast<Column&>(build.cols[key_cols[0]]).stats,
+                        std::make_shared<ColStats>(ColStats{kmin, (long long)((uint64_t)kmin + range), nb, true, true}));
     }
     if (!dup) {
       jt->kind = KIND_RANK;
@@ -2244,8 +2275,12 @@ static std::unique_ptr<JoinTable> join_build_fixed_keys(const Table& build, cons
       jt->am_size = range + 1;
       jt->rank_needs_perm = !ascending;  // the permutation itself waits for a probe that needs build rows (ensure_rank_perm)
       // (bitmap and prefix stay as they are: the membership-only passes read the bitmap, the listed emit both; the interleaved view
-      // waits for a probe that wants it — ensure_rank_tab)
+      // waits for a probe that wants it — ensure_rank_tab — unless the scan above already left it)
       jt->info.table_bytes = n_words * 16;
+      if (eager_tab) {
+        jt->rank_tab = eager_tab;
+        jt->info.table_bytes += n_words * 16;
+      }
     } else {
       DFGPU_CHECK(opts.table_mode != 3, "rank-map join table requested but the build keys are not unique");
       jt->rank_bits.reset();
@@ -2480,13 +2515,21 @@ static bool probe_keys_clustered(const Column& kc, int64_t n, uint64_t window) {
     if (cached->nondecreasing) return true;
   // (a column with NULLs is sampled like any other: the values under its NULLs are few and say nothing either way)
   if (n < (1 << 16) || !is_integer_like(kc.field.type) || kc.field.type == DFGPU_UINT64) return true;
+  // asked before of these rows with this window?  (the buffer remembers one answer: DevBuf::hint)
+  const uint64_t tag = (fmix64((uint64_t)kc.data_offset * 0x9E3779B97F4A7C15ull ^ (uint64_t)n ^ (window << 20)) & ~3ull) | 2ull;
+  if (kc.data) {
+    const uint64_t h = kc.data->hint.load(std::memory_order_relaxed);
+    if ((h & ~1ull) == tag) return (h & 1ull) != 0;
+  }
   constexpr int S = 4096;
   BufPtr cnt = make_zero_buf(4);
   const KeyCol k{kc.ptr(), nullptr, kc.field.type, type_width(kc.field.type)};
   with_key_type(k.type, [&](auto kt) { k_sample_near<decltype(kt)::value><<<S / BLOCK, BLOCK, 0, rt().stream>>>(k, n, n / S, S, window, cnt->as<int>()); });
   int near = 0;
   d2h(&near, cnt->ptr, 4);
-  return near * 10 >= S * 9;
+  const bool clustered = near * 10 >= S * 9;
+  if (kc.data) kc.data->hint.store(tag | (clustered ? 1ull : 0ull), std::memory_order_relaxed);
+  return clustered;
 }
 
 // do 64 K evenly spaced probe rows ALL find their key?  (the speculation of the placed probe is only worth trying then)

@@ -128,6 +128,29 @@ __global__ __launch_bounds__(BLOCK) void k_scan_chained(In in, int64_t n, uint64
   }
 }
 
+// the down-sweep over bitmap words that also leaves the rank map's interleaved {word, prefix} pairs (join.hip rank_tab): the words
+// and their prefixes are in registers here — writing the pairs now saves the separate interleave pass its read of both arrays
+__global__ __launch_bounds__(BLOCK) void k_scan_down_tab(InMaskPopc in, int64_t n, const uint64_t* chunk_base, uint64_t* out, ulonglong2* __restrict__ tab) {
+  int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint64_t w[SCAN_ITEMS];
+  uint64_t s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    w[j] = base + j < n ? in.mask[base + j] : 0ull;
+    s += (uint32_t)__popcll(w[j]);
+  }
+  uint64_t tot;
+  uint64_t ex = block_exclusive_scan(s, &tot) + chunk_base[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    if (base + j < n) {
+      out[base + j] = ex;
+      tab[base + j] = make_ulonglong2(w[j], ex);
+    }
+    ex += (uint32_t)__popcll(w[j]);
+  }
+}
+
 template <typename In>
 static void run_scan(In in, int64_t n, uint64_t* out, const char* name) {
   Runtime& r = rt();
@@ -161,5 +184,18 @@ void scan_mask_popcounts(const uint64_t* mask, const uint64_t* valid, int64_t nr
   run_scan(InMaskPopc{mask, valid, nrows}, n_words, out_prefix, "scan_mask_popcounts");
 }
 void scan_u32(const uint32_t* in, int64_t n, uint64_t* out_prefix) { run_scan(InU32{in}, n, out_prefix, "scan_u32"); }
+// prefix popcounts of `n_words` whole bitmap words (no ragged tail, no validity) + the interleaved {word, prefix} table
+void scan_bitmap_words_tab(const uint64_t* words, int64_t n_words, uint64_t* out_prefix, void* out_tab) {
+  Runtime& r = rt();
+  DFGPU_CHECK(n_words > 0, "scan_bitmap_words_tab: empty bitmap");
+  const InMaskPopc in{words, nullptr, n_words * 64};
+  const int64_t n_chunks = (n_words + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  BufPtr sums = make_buf((size_t)n_chunks * 8);
+  ProfileScope ps("scan_mask_popcounts", 0);
+  k_scan_reduce<<<(unsigned)n_chunks, BLOCK, 0, r.stream>>>(in, n_words, sums->as<uint64_t>());
+  k_scan_sums<<<1, BLOCK, 0, r.stream>>>(sums->as<uint64_t>(), n_chunks, out_prefix + n_words);
+  k_scan_down_tab<<<(unsigned)n_chunks, BLOCK, 0, r.stream>>>(in, n_words, sums->as<uint64_t>(), out_prefix, reinterpret_cast<ulonglong2*>(out_tab));
+  DFGPU_HIP(hipGetLastError());
+}
 
 }  // namespace dfgpu
