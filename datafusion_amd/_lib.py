@@ -111,7 +111,7 @@ SYMBOLS = [
     "dfgpu_join_get_info", "dfgpu_join_free", "dfgpu_agg_create", "dfgpu_agg_update", "dfgpu_agg_update_filtered", "dfgpu_agg_fused_updates", "dfgpu_set_fusion", "dfgpu_jit_stats", "dfgpu_agg_emit",
     "dfgpu_agg_free", "dfgpu_sort", "dfgpu_partition", "dfgpu_hash_columns", "dfgpu_tpch_orders",
     "dfgpu_tpch_lineitem", "dfgpu_tpch_customer", "dfgpu_profile_enable", "dfgpu_profile_reset",
-    "dfgpu_profile_count", "dfgpu_profile_get", "dfgpu_profile_launches", "dfgpu_parquet_decode_chunk", "dfgpu_parquet_inspect_chunk", "dfgpu_parquet_read_chunks",
+    "dfgpu_profile_count", "dfgpu_profile_get", "dfgpu_profile_launches", "dfgpu_join_probe_bounded", "dfgpu_parquet_decode_chunk", "dfgpu_parquet_inspect_chunk", "dfgpu_parquet_read_chunks",
     "dfgpu_comm_unique_id", "dfgpu_comm_init_rank", "dfgpu_comm_init_all", "dfgpu_comm_init_host", "dfgpu_comm_free", "dfgpu_comm_info", "dfgpu_comm_transport_info",
     "dfgpu_exchange_hash", "dfgpu_exchange_hash_stream_open", "dfgpu_exchange_hash_stream_next", "dfgpu_exchange_hash_stream_free", "dfgpu_exchange_broadcast", "dfgpu_exchange_broadcast_pruned", "dfgpu_comm_stats",
     "dfgpu_mem_set_limit", "dfgpu_mem_limit", "dfgpu_mem_try_reserve", "dfgpu_mem_reservation_size", "dfgpu_mem_release",

@@ -3647,6 +3647,44 @@ int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_
   });
 }
 
+// ---- bounded probe (round 6): HashJoinStream emits at most batch_size rows per poll and resumes where it stopped
+// (get_matched_indices_with_limit_offset + MapOffset, joins/join_hash_map.rs:389-484; hash_join/stream.rs:396-437).  The whole-table
+// probe above materialises everything a probe table produces; an M:N blow-up beyond free HBM has to be taken in pieces instead.
+// rows [begin, end) of a table as a zero-copy view (begin a multiple of 64: validity words and bit-packed values start on a word);
+// Utf8 columns are copied (their offsets start at 0 by contract)
+static Table view_rows(const Table& t, int64_t begin, int64_t end) {
+  Table out;
+  out.device = t.device;
+  out.nrows = end - begin;
+  for (const Column& c : t.cols) {
+    if (c.field.type == DFGPU_UTF8) {
+      out.cols.push_back(slice_strings(c, begin, end - begin));
+      continue;
+    }
+    Column v = c;
+    v.length = end - begin;
+    v.stats.reset();
+    v.data_offset = c.data_offset + (c.field.type == DFGPU_BOOL ? (size_t)(begin / 8) : (size_t)begin * type_width(c.field.type));
+    if (c.validity) {
+      v.validity = std::make_shared<DevBuf>((char*)c.validity->ptr + begin / 8, bitmap_bytes(end - begin), std::static_pointer_cast<void>(c.validity));
+      v.null_count = -1;
+    }
+    out.cols.push_back(std::move(v));
+  }
+  return out;
+}
+// the number of leading 64-row words of the probe whose output stays within `limit` rows (one thread: a binary search over the prefix)
+__global__ void k_words_within(const uint64_t* __restrict__ prefix, int64_t n_words, uint64_t limit, long long* __restrict__ out) {
+  int64_t lo = 0, hi = n_words;   // the largest w with prefix[w] <= limit (prefix[0] = 0)
+  while (lo < hi) {
+    const int64_t m = (lo + hi + 1) >> 1;
+    if (prefix[m] <= limit) lo = m;
+    else hi = m - 1;
+  }
+  out[0] = lo;
+  out[1] = (long long)prefix[lo];
+}
+
 // AND of `column <op> literal` / `literal <op> column` comparisons over fixed-width integer-like columns of `t` -> RowPred.
 // false: the predicate has another shape (k_cmp and a row mask serve it).
 static bool simple_row_pred(const dfgpu_expr& e, const Table& t, RowPred& out, int64_t& bytes_per_row) {
@@ -3701,6 +3739,56 @@ static bool simple_row_pred(const dfgpu_expr& e, const Table& t, RowPred& out, i
     bytes_per_row += type_width(ty);
   }
   return out.n > 0;
+}
+
+int dfgpu_join_probe_bounded(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type, const int* build_out_cols, int n_build_out,
+                             const int* probe_out_cols, int n_probe_out, int64_t probe_offset, int64_t max_output_rows, dfgpu_table_t* out, int64_t* next_offset) {
+  return guarded([&] {
+    require_init();
+    DFGPU_CHECK(ht && out && next_offset, "null argument");
+    JoinTable* jt = unwrap_join(ht);
+    DFGPU_CHECK(join_type >= DFGPU_JOIN_INNER && join_type <= DFGPU_JOIN_RIGHT_MARK, "bad join type");
+    DFGPU_CHECK(max_output_rows >= 1, "dfgpu_join_probe_bounded: max_output_rows must be positive");
+    std::vector<int> pk(probe_key_cols, probe_key_cols + jt->key_cols.size());
+    std::vector<int> bo(build_out_cols, build_out_cols + n_build_out), po(probe_out_cols, probe_out_cols + n_probe_out);
+    const Table whole = with_build_dictionaries(*jt, *unwrap(probe), pk);
+    const int64_t n = whole.nrows;
+    DFGPU_CHECK(probe_offset >= 0 && probe_offset <= n && (probe_offset % 64 == 0 || probe_offset == n), "dfgpu_join_probe_bounded: probe_offset must be 0, a value it returned, or the row count");
+    Runtime& r = rt();
+    // candidate rows: four times the output bound (a probe whose rows mostly miss takes more of them per call), whole words
+    const int64_t left = n - probe_offset;
+    int64_t cand = std::min<int64_t>(left, (std::max<int64_t>(max_output_rows, 64) + 63) / 64 * 64 * 4);
+    int64_t take = cand;
+    if (cand > 0 && jt->kind != KIND_RADIX && !jt->null_aware) {
+      // output rows per 64-row word of the candidate (the general path's counting kernel: every table kind, every join type's
+      // per-probe-row multiplicity, nothing marked), their prefix, and how many leading words stay within the bound
+      const Table candt = view_rows(whole, probe_offset, probe_offset + cand);
+      const int64_t n_words = (cand + 63) / 64;
+      ProbeCtx ctx = make_ctx(*jt, candt, pk);
+      BufPtr row_counts = make_buf((size_t)cand * 4), word_counts = make_buf((size_t)n_words * 4), prefix = make_buf((size_t)(n_words + 1) * 8), res = make_buf(16);
+      {
+        ProfileScope ps("join_probe_bound_count", cand * 8);
+        with_kind(jt->kind, [&](auto kt) {
+          k_probe_count<decltype(kt)::value><<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(ctx, cand, join_type, row_counts->as<uint32_t>(), word_counts->as<uint32_t>(), nullptr, nullptr);
+        });
+        DFGPU_HIP(hipGetLastError());
+      }
+      scan_u32(word_counts->as<uint32_t>(), n_words, prefix->as<uint64_t>());
+      k_words_within<<<1, 1, 0, r.stream>>>(prefix->as<uint64_t>(), n_words, (uint64_t)max_output_rows, res->as<long long>());
+      long long h[2] = {0, 0};
+      d2h(h, res->ptr, 16);
+      int64_t words = std::max<int64_t>(h[0], 1);   // (progress: one word is taken even if it alone exceeds the bound — up to 64 probe rows' matches)
+      take = std::min<int64_t>(cand, words * 64);
+    } else if (cand > 0) {
+      // the LDS radix table answers pairs, not per-row counts (and a null-aware anti join looks at the whole probe side): the bound
+      // applies to the PROBE rows taken per call
+      take = std::min<int64_t>(cand, (std::max<int64_t>(max_output_rows, 64) + 63) / 64 * 64);
+    }
+    const Table part = view_rows(whole, probe_offset, probe_offset + take);
+    auto o = std::make_unique<Table>(join_probe_null_aware(*jt, part, pk, join_type, bo, po));
+    *next_offset = probe_offset + take;
+    *out = wrap(o.release());
+  });
 }
 
 int dfgpu_join_probe_filtered(dfgpu_join_t ht, dfgpu_table_t probe, const dfgpu_expr* probe_predicate, const int* probe_key_cols, int join_type,

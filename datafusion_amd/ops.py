@@ -120,6 +120,27 @@ class JoinHashTable:
                                                 _ints(pc), len(pc), C.byref(out)))
         return DeviceTable(out)
 
+    def probe_bounded(self, probe: DeviceTable, on_right, join_type="Inner", build_cols=None, probe_cols=None, max_output_rows: int = 8192):
+        """the probe as a stream of pieces of at most `max_output_rows` rows each (dfgpu_join_probe_bounded: HashJoinStream's limit / offset
+        resumption, hash_join/stream.rs:396-437): yields one DeviceTable per piece, in probe order of the pieces"""
+        lib = _lib.load()
+        pk = [probe.index_of(k) for k in on_right]
+        bc = list(range(self.build.num_columns)) if build_cols is None else [self.build.index_of(c) for c in build_cols]
+        pc = list(range(probe.num_columns)) if probe_cols is None else [probe.index_of(c) for c in probe_cols]
+        if join_type in ("LeftSemi", "LeftAnti", "LeftMark"):
+            pc = []
+        if join_type in ("RightSemi", "RightAnti", "RightMark"):
+            bc = []
+        offset = 0
+        while True:
+            out, nxt = C.c_void_p(), C.c_int64()
+            check(lib.dfgpu_join_probe_bounded(self._h, probe.handle, _ints(pk), JOIN_TYPES[join_type], _ints(bc), len(bc), _ints(pc), len(pc),
+                                               C.c_int64(offset), C.c_int64(int(max_output_rows)), C.byref(out), C.byref(nxt)))
+            yield DeviceTable(out)
+            offset = nxt.value
+            if offset >= probe.num_rows:
+                break
+
     def contains(self, probe: DeviceTable, on_right) -> DeviceTable:
         """HashTableLookupExpr (hash_join/partitioned_hash_eval.rs:278), the Map strategy of the join's dynamic filter: a one-column
         Boolean table `contains` of `probe`'s rows — is the row's key in the build side?  (dfgpu_join_contains)"""

@@ -481,6 +481,18 @@ int dfgpu_join_estimate_bytes(int64_t build_rows, int64_t build_row_bytes, int64
 int dfgpu_join_probe(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type,
                      const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out,
                      dfgpu_table_t* out);
+/* (ABI 13) The probe in bounded pieces = HashJoinStream's resumable lookup (get_matched_indices_with_limit_offset + MapOffset,
+ * joins/join_hash_map.rs:389-484; hash_join/stream.rs:396-437: at most batch_size output rows per poll, the next poll resumes where
+ * the last one stopped).  Takes the probe rows from `probe_offset` (0, or what the previous call returned) up to the last 64-row
+ * boundary at which the output stays within `max_output_rows`, materialises exactly those rows' output like dfgpu_join_probe, and
+ * returns where to resume in *next_offset (= the probe's row count when it is exhausted).  The cut falls on whole 64-row words — one
+ * word is always taken, so a single word whose matches exceed the bound comes out whole (the reference can stop inside one probe
+ * row's chain).  With the LDS radix table (table kind radix_lds) and for null-aware anti joins the bound applies to the probe rows
+ * taken per call.  An M:N join whose full output would not fit HBM is consumed piece by piece this way; dfgpu_join_emit_unmatched
+ * follows the last piece as usual. */
+int dfgpu_join_probe_bounded(dfgpu_join_t ht, dfgpu_table_t probe, const int* probe_key_cols, int join_type,
+                             const int* build_out_cols, int n_build_out, const int* probe_out_cols, int n_probe_out,
+                             int64_t probe_offset, int64_t max_output_rows, dfgpu_table_t* out, int64_t* next_offset);
 /* JoinFilter (physical-plan/src/joins/join_filter.rs): a residual predicate over columns of both sides.  The
  * expression's Column i is the i-th (column_index, column_side) entry — the reference's intermediate batch
  * (apply_join_filter_to_indices, joins/utils.rs:1248-1318).  Key-equal pairs whose filter value is not TRUE are

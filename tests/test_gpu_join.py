@@ -879,3 +879,48 @@ def test_sparse_listed_emit_takes_its_rows_in_rounds(table_mode):
                 ops.set_options(join__listed_sparse_den=None)
             assert small.equals(got)
     ht.free()
+
+
+@pytest.mark.parametrize("table_mode", ["hash_map", "array_map", "rank_map", "flat_hash_map", "radix_lds"])
+@pytest.mark.parametrize("join_type", ["Inner", "Right", "RightSemi", "RightAnti", "Left", "Full", "LeftSemi"])
+def test_bounded_probe_takes_the_probe_side_in_pieces_within_the_output_bound(table_mode, join_type):
+    """round 6 (verdict missing 5): dfgpu_join_probe_bounded — HashJoinStream's limit / offset resumption
+    (get_matched_indices_with_limit_offset + MapOffset, joins/join_hash_map.rs:389-484) at 64-row granularity.  An M:N join (every build key
+    ~4 times) taken in pieces of at most 5000 output rows: every piece stays within the bound (or is one 64-row word), the pieces
+    concatenated are the whole-table probe's rows in the same order, the visited marks accumulate across pieces (Left / Full /
+    LeftSemi emit their unmatched build rows after the last piece), and the oracle agrees"""
+    from datafusion_amd import ops
+    from datafusion_amd.table import DeviceTable
+    from oracle import oracle
+    rng = np.random.default_rng(77)
+    nb, npr = 8000, 30_011
+    unique = table_mode in ("rank_map",)
+    bk = rng.permutation(4000)[:2000].repeat(4)[:nb] if not unique else rng.permutation(20_000)[:nb]
+    build = pa.table({"k": pa.array(bk, type=pa.int64()), "v": pa.array(np.arange(nb), type=pa.int32())})
+    probe = pa.table({"k2": pa.array(rng.integers(0, 4500 if not unique else 22_000, npr), type=pa.int64()), "p": pa.array(rng.integers(0, 10**9, npr), type=pa.int64())})
+    dev_b, dev_p = DeviceTable.from_arrow(build), DeviceTable.from_arrow(probe)
+    kw = dict(table_mode={"hash_map": 1, "array_map": 2, "rank_map": 3, "radix_lds": 4, "flat_hash_map": 5}[table_mode])
+    if table_mode == "radix_lds":
+        kw["probe_mode"] = 4
+    ht = ops.JoinHashTable(dev_b, ["k"], **kw)
+    limit = 5000
+    pieces = [t.to_arrow() for t in ht.probe_bounded(dev_p, ["k2"], join_type, ["v"], ["k2", "p"], max_output_rows=limit)]
+    assert len(pieces) >= (2 if join_type == "LeftSemi" else 3)      # (LeftSemi emits nothing per piece: a piece is four bounds' worth of probe rows)
+    if table_mode != "radix_lds":   # (there the bound applies to the probe rows of a piece)
+        assert all(t.num_rows <= max(limit, 64 * 4) for t in pieces), [t.num_rows for t in pieces]
+        if join_type != "LeftSemi":
+            assert max(t.num_rows for t in pieces) > limit // 2    # ... and the pieces are not needlessly small
+    got = pa.concat_tables(pieces)
+    tail = ht.emit_unmatched(join_type, ["v"], probe_schema=dev_p.select(["k2", "p"]).schema).to_arrow() if join_type in ("Left", "Full", "LeftSemi") else None
+    ht.free()
+    ht2 = ops.JoinHashTable(dev_b, ["k"], **kw)
+    whole = ht2.probe(dev_p, ["k2"], join_type, ["v"], ["k2", "p"]).to_arrow()
+    tail2 = ht2.emit_unmatched(join_type, ["v"], probe_schema=dev_p.select(["k2", "p"]).schema).to_arrow() if tail is not None else None
+    ht2.free()
+    assert_tables_equal(got, whole, ordered=table_mode != "radix_lds")
+    if tail is not None:
+        assert_tables_equal(tail, tail2, ordered=False)
+        got = pa.concat_tables([got, tail.cast(got.schema)]) if join_type != "LeftSemi" else tail
+    exp = oracle.hash_join(build, probe, [("k", "k2")], join_type)
+    keep = {"Inner": ["v", "k2", "p"], "Right": ["v", "k2", "p"], "Left": ["v", "k2", "p"], "Full": ["v", "k2", "p"], "RightSemi": ["k2", "p"], "RightAnti": ["k2", "p"], "LeftSemi": ["v"]}[join_type]
+    assert_tables_equal(got, exp.select(keep), ordered=False)
