@@ -13,6 +13,7 @@ usage: python scripts/profile_run.py <tag> [--skip-pmc] [--skip-plain] -- <bench
 then (in the container): python scripts/summarize_profile.py gpurun_out/<tag> profiles/<tag>"""
 import json
 import os
+import re
 import sqlite3
 import subprocess
 import sys
@@ -73,6 +74,24 @@ def rocprof_avg_ms(db, line):
     if not cand:
         return None, None
     best = max(cand, key=lambda r: r[2])
+    # a roofline quoted on "launch k of n in a step" (one kernel over unlike inputs): compare with rocprofv3's average of THAT grid size —
+    # launch positions matched to grid sizes by duration order, as scripts/summarize_profile.py does
+    m = re.match(r"launch (\d+) of (\d+)", str(roof.get("launch") or ""))
+    if m and int(m.group(2)) > 1:
+        con = sqlite3.connect(db)
+        per = [(g, c, avg) for n, g, c, avg in con.execute("select name, grid_x, count(*), avg(duration) from kernels group by 1, 2")
+               if short(n) == best[0] and c > 1]
+        con.close()
+        per_launch = roof.get("per_launch_avg_ms")
+        if len(per) == int(m.group(2)):
+            per.sort(key=lambda r: r[2])
+            if per_launch and len(per_launch) == len(per):
+                order = sorted(range(len(per_launch)), key=lambda i: per_launch[i])
+                rank = order.index(int(m.group(1)) - 1)
+            else:
+                rank = len(per) - 1      # the quoted launch is the dominant (longest) one
+            g, c, avg = per[rank]
+            return avg / 1e6, f"{best[0]} [grid {g}]"      # the kernels table's durations are nanoseconds
     return best[3] / 1e3, best[0]     # the top_kernels view's durations are microseconds (traffic.json: avg_launch_us_rocprof)
 
 
