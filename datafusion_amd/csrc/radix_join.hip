@@ -27,14 +27,16 @@
 
 #include "device.hpp"
 #include "internal.hpp"
+#include "onesweep.hpp"
 
 namespace dfgpu {
 
 static bool force_fused_off() { return !option_on("join.radix_fused_emit", true); }   // (A/B switch: the pairs + gathers of round 5)
-constexpr int RJ_CAP = 2048;     // build rows per LDS chunk
+constexpr int RJ_CAP = 3072;     // build rows per LDS chunk (round 6: partitions average ~2300 rows, so two 8-bit passes reach them up to 157 M build rows)
 constexpr int RJ_HEADS = 4096;   // chain heads (power of two, 2 x RJ_CAP)
 constexpr int RJ_TASK_ROWS = 8192;
-constexpr int RJ_STAGE = 512;    // matches of one 256-row probe tile staged in LDS before they are written (8 KB: 3 workgroups per CU still fit)
+constexpr int RJ_STAGE = 1024;   // matches of one 256-row probe tile listed in LDS before they are written ({build position u16, probe row u32}: 6 KB; keys 24 + heads 16 + chains 6:
+                                 // 52 KB, 3 workgroups per CU).  The M:N benchmark shape averages 384 matches per tile: a stage of 384 overflowed every other tile
 
 struct RadixTask {
   uint32_t part;
@@ -81,13 +83,240 @@ __global__ __launch_bounds__(BLOCK) void k_rj_valid_mask(KeySet ks, int64_t n_wo
     mask[w] = m;
   }
 }
-// first position of every non-empty partition of a sorted record array (empty ones are filled in on the host)
-__global__ __launch_bounds__(BLOCK) void k_rj_starts(const uint64_t* __restrict__ key, int64_t n, int shift, unsigned long long* __restrict__ starts) {
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    const uint64_t p = shift >= 64 ? 0ull : key[i] >> shift;
-    const uint64_t q = i == 0 ? ~0ull : (shift >= 64 ? 0ull : key[i - 1] >> shift);
-    if (p != q) starts[p] = (unsigned long long)i;
+// ---------------------------------------------------------------------------------------------- the partitioner (round 6)
+// Records partitioned on the top B bits of the mixed key by TWO stable 8-bit passes (three beyond 2^16 partitions) — round 5 ran three
+// 6-bit passes of three kernels each over a record array made by a kernel of its own (116 bytes moved per row; this: 52):
+//   k_rp_hist   one read of the key column: per-tile counts of the first digit (-> a scan gives every tile's offsets: the first pass waits
+//               for nobody) and the totals of the later digits (-> their passes' bin bases);
+//   k_rp_pass   BUILD: reads the KEY COLUMN, mixes, ranks (wave-private ballot ranking), stages the tile in LDS in digit order and writes
+//               (key, row id) runs — no record array exists before the first scatter; later passes read records and find their offsets by
+//               the decoupled look-back of onesweep.hpp.
+//   k_rp_starts the partitions' first positions by binary search over the partitioned keys (65 K threads x 28 probes; the pass over
+//               all keys that marked boundaries cost a read of the whole array).
+constexpr int RP_MAX_PASSES = 3;
+constexpr int RP_HIST_GROUP = 4;   // tiles a workgroup counts between two barriers
+struct RpDigits {
+  int shift[RP_MAX_PASSES], bits[RP_MAX_PASSES];
+  int n;
+};
+template <bool EXACT>
+__device__ __forceinline__ uint64_t rp_mixed_key(const KeySet& ks, int64_t i) {
+  if (EXACT) {
+    uint64_t lo, hi;
+    load_words(ks.c[0], i, lo, hi);
+    return fmix64(lo);
   }
+  bool any_null;
+  return hash_row(ks, i, SEED_JOIN, any_null);
+}
+// the keys of a lane's ITEMS rows, all loads in flight together where the key is one 64- or 32-bit integer column
+template <bool EXACT, int ITEMS>
+__device__ __forceinline__ void rp_tile_keys(const KeySet& ks, int64_t base, const int (&off)[ITEMS], uint64_t (&key)[ITEMS]) {
+  if (EXACT && (ks.c[0].type == 2 || ks.c[0].type == 7)) {
+    const uint64_t* col = reinterpret_cast<const uint64_t*>(ks.c[0].data) + base;
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) key[c] = col[off[c]];
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) key[c] = fmix64(key[c]);
+  } else if (EXACT && (ks.c[0].type == 1 || ks.c[0].type == 8)) {
+    int32_t v[ITEMS];
+    const int32_t* col = reinterpret_cast<const int32_t*>(ks.c[0].data) + base;
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) v[c] = col[off[c]];
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) key[c] = fmix64((uint64_t)(int64_t)v[c]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) key[c] = rp_mixed_key<EXACT>(ks, base + off[c]);
+  }
+}
+template <bool EXACT, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_rp_hist(KeySet ks, const uint64_t* __restrict__ mask, int64_t n, int64_t n_tiles, RpDigits dg, uint32_t* __restrict__ counts,
+                                                  unsigned long long* __restrict__ totals) {
+  constexpr int TILE = BLOCK * ITEMS;
+  __shared__ unsigned int s_h0[RP_HIST_GROUP][256];
+  __shared__ unsigned int s_h[RP_MAX_PASSES - 1][256];
+#pragma unroll
+  for (int p = 0; p < RP_MAX_PASSES - 1; p++) s_h[p][threadIdx.x] = 0;
+  const int64_t n_groups = (n_tiles + RP_HIST_GROUP - 1) / RP_HIST_GROUP;
+  const unsigned m0 = (1u << dg.bits[0]) - 1u, m1 = (1u << dg.bits[1]) - 1u, m2 = (1u << dg.bits[2]) - 1u;
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < RP_HIST_GROUP; u++) s_h0[u][threadIdx.x] = 0;
+    __syncthreads();
+    for (int u = 0; u < RP_HIST_GROUP; u++) {
+      const int64_t t = g * RP_HIST_GROUP + u;
+      if (t >= n_tiles) break;
+      const int64_t lo = t * TILE;
+      int off[ITEMS];
+      uint64_t key[ITEMS];
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {
+        const int64_t i = lo + c * BLOCK + threadIdx.x;
+        off[c] = (int)((i < n ? i : n - 1) - lo);
+      }
+      rp_tile_keys<EXACT, ITEMS>(ks, lo, off, key);
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {
+        const int64_t i = lo + c * BLOCK + threadIdx.x;
+        if (i >= n || (mask && !bit_at(mask, i))) continue;
+        atomicAdd(&s_h0[u][(unsigned)(key[c] >> dg.shift[0]) & m0], 1u);
+        if (dg.n > 1) atomicAdd(&s_h[0][(unsigned)(key[c] >> dg.shift[1]) & m1], 1u);
+        if (dg.n > 2) atomicAdd(&s_h[1][(unsigned)(key[c] >> dg.shift[2]) & m2], 1u);
+      }
+    }
+    __syncthreads();
+    for (int u = 0; u < RP_HIST_GROUP; u++) {
+      const int64_t t = g * RP_HIST_GROUP + u;
+      if (t < n_tiles) counts[(int64_t)threadIdx.x * n_tiles + t] = s_h0[u][threadIdx.x];
+    }
+    __syncthreads();
+  }
+  for (int p = 1; p < dg.n; p++)
+    if (s_h[p - 1][threadIdx.x]) atomicAdd(&totals[p * 256 + threadIdx.x], (unsigned long long)s_h[p - 1][threadIdx.x]);
+}
+// BUILD: tile t = source rows [t * TILE, ...), `offsets` (digit-major, scanned) holds every run's start; else: records in, look-back.
+template <bool BUILD, bool EXACT, int ITEMS>
+__global__ __launch_bounds__(BLOCK, (ITEMS > 8 ? 2 : 4)) void k_rp_pass(KeySet ks, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ key_in, const uint32_t* __restrict__ rid_in,
+                                                     int64_t n, int shift, int bits, int64_t n_tiles, const uint64_t* __restrict__ offsets,
+                                                     const unsigned long long* __restrict__ totals, uint32_t* __restrict__ tile_state, unsigned* __restrict__ ticket,
+                                                     uint64_t* __restrict__ key_out, uint32_t* __restrict__ rid_out, int xcd_static) {
+  constexpr int NWAVE = BLOCK / WAVE;
+  constexpr int TILE = BLOCK * ITEMS;
+  __shared__ uint64_t s_key[TILE];
+  __shared__ uint32_t s_rid[TILE];
+  __shared__ uint8_t s_dig[TILE];
+  __shared__ uint16_t s_cnt[NWAVE][256];
+  __shared__ uint16_t s_start[256];
+  __shared__ unsigned int s_goff[256];
+  __shared__ unsigned int s_base[256];
+  __shared__ unsigned int s_wtot[NWAVE];
+  __shared__ unsigned int s_tile, s_nst;
+  const unsigned mask_d = (1u << bits) - 1u;
+  const int wave = threadIdx.x >> 6;
+  const unsigned lane = lane_id();
+  if (!BUILD) {   // bin bases of this pass: exclusive scan of the digit totals
+    const unsigned v = (unsigned)totals[threadIdx.x];
+    const unsigned inc = wave_inclusive_sum<unsigned>(v);
+    if (lane == 63) s_wtot[wave] = inc;
+    __syncthreads();
+    unsigned b = 0;
+    for (int w = 0; w < wave; w++) b += s_wtot[w];
+    s_base[threadIdx.x] = b + inc - v;
+    __syncthreads();
+  }
+  for (int64_t round = 0;; round++) {
+    if (!(BUILD && xcd_static) && threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    int64_t t;
+    if (BUILD && xcd_static) {   // every XCD walks a contiguous eighth of the tiles: the runs neighbouring tiles append to a digit meet in ONE L2
+      const int64_t b = (int64_t)blockIdx.x + round * (int64_t)gridDim.x;
+      if (b >= n_tiles) return;
+      t = xcd_tile(b, n_tiles);
+    } else {
+      t = (int64_t)s_tile;
+      if (t >= n_tiles) return;
+    }
+    const int64_t lo = t * TILE;
+    const int tile_rows = (int)((n - lo) < TILE ? (n - lo) : TILE);
+    uint64_t key[ITEMS];
+    uint32_t rid[BUILD ? 1 : ITEMS];   // (BUILD: a row's id is its position)
+    unsigned dr[ITEMS];                // digit | rank << 8
+    unsigned take = 0;                 // bit c: the lane's c-th row takes part
+    if (BUILD) {
+      int off[ITEMS];
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {
+        const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+        off[c] = j < tile_rows ? j : 0;
+        if (j < tile_rows && (!mask || bit_at(mask, lo + off[c]))) take |= 1u << c;
+      }
+      rp_tile_keys<EXACT, ITEMS>(ks, lo, off, key);
+    } else {
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {
+        const int j = (wave * ITEMS + c) * WAVE + (int)lane;
+        const int64_t src = lo + (j < tile_rows ? j : 0);
+        key[c] = key_in[src];
+        rid[BUILD ? 0 : c] = rid_in[src];
+        if (j < tile_rows) take |= 1u << c;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const bool in = (take >> c) & 1u;
+      const unsigned dig = in ? ((unsigned)(key[c] >> shift) & mask_d) : 0u;
+      uint64_t peers = ballot64(in);
+      for (int b = 0; b < bits; b++) {
+        const uint64_t bal = ballot64((dig >> b) & 1u);
+        peers &= ((dig >> b) & 1u) ? bal : ~bal;
+      }
+      const unsigned r_in_wave = mbcnt(peers);
+      const unsigned base = s_cnt[wave][dig];
+      if (in && r_in_wave == 0) s_cnt[wave][dig] = (uint16_t)(base + (unsigned)__popcll(peers));
+      dr[c] = dig | ((base + r_in_wave) << 8);
+    }
+    __syncthreads();
+    unsigned run = 0;   // thread d: digit d's rows in this tile
+#pragma unroll
+    for (int w = 0; w < NWAVE; w++) {
+      const unsigned v = s_cnt[w][threadIdx.x];
+      s_cnt[w][threadIdx.x] = (uint16_t)run;
+      run += v;
+    }
+    if (!BUILD && t > 0 && threadIdx.x <= mask_d) os_store(&tile_state[t * 256 + threadIdx.x], OS_AGG | run);
+    {
+      const unsigned inc = wave_inclusive_sum<unsigned>(run);
+      if (lane == 63) s_wtot[wave] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; w++) base += s_wtot[w];
+      s_start[threadIdx.x] = (uint16_t)(base + inc - run);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      if ((take >> c) & 1u) {
+        const unsigned dig = dr[c] & 255u;
+        const unsigned q = (unsigned)s_start[dig] + (unsigned)s_cnt[wave][dig] + (dr[c] >> 8);
+        s_key[q] = key[c];
+        s_rid[q] = BUILD ? (uint32_t)(lo + (wave * ITEMS + c) * WAVE + (int)lane) : rid[BUILD ? 0 : c];
+        s_dig[q] = (uint8_t)dig;
+      }
+    }
+    if (threadIdx.x <= mask_d) {
+      if (BUILD) {
+        s_goff[threadIdx.x] = (unsigned)offsets[(int64_t)threadIdx.x * n_tiles + t] - (unsigned)s_start[threadIdx.x];
+      } else {
+        const unsigned excl = os_look_back(tile_state, t, threadIdx.x);
+        os_store(&tile_state[t * 256 + threadIdx.x], OS_PFX | (excl + run));
+        s_goff[threadIdx.x] = s_base[threadIdx.x] + excl - (unsigned)s_start[threadIdx.x];
+      }
+    }
+    if (threadIdx.x == 255) s_nst = (unsigned)s_start[255] + run;   // rows of the tile that take part (digit 255's run is the last)
+    __syncthreads();
+    const int n_staged = (int)s_nst;
+    for (int qq = threadIdx.x; qq < n_staged; qq += BLOCK) {
+      const unsigned dst = (unsigned)qq + s_goff[s_dig[qq]];
+      key_out[dst] = s_key[qq];   // (plain stores: neighbouring tiles' runs of a digit meet in the L2 — non-temporal ones cost + 30 % at 4096-row
+      rid_out[dst] = s_rid[qq];   //  tiles and + 90 % at 2048-row tiles)
+    }
+    __syncthreads();
+  }
+}
+// starts[p] = first position whose partition id (key >> shift) is >= p, p in [0, P]
+__global__ __launch_bounds__(BLOCK) void k_rp_starts(const uint64_t* __restrict__ key, int64_t n, int shift, int64_t P, unsigned long long* __restrict__ starts) {
+  const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (p > P) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)(shift >= 64 ? 0ull : key[mid] >> shift) < p) lo = mid + 1;
+    else hi = mid;
+  }
+  starts[p] = (unsigned long long)lo;
 }
 
 struct RadixSide {
@@ -131,39 +360,114 @@ static RadixSide rj_partition(const Table& t, const std::vector<int>& key_cols, 
   // (no NULL build key), so NULL probe keys are dropped there too (the value under a NULL is arbitrary)
   if (nullable && (!null_equals_null || exact) && n) {
     mask = make_buf(bitmap_bytes(n));
-    prefix = make_buf((size_t)(n_words + 1) * 8);
     k_rj_valid_mask<<<grid_for(n_words, BLOCK), BLOCK, 0, r.stream>>>(ks, n_words, mask->as<uint64_t>());
+  }
+  int64_t key_bytes = 0;
+  for (int i = 0; i < ks.n; i++) key_bytes += n * ks.c[i].width;
+  const uint64_t* mk = mask ? mask->as<uint64_t>() : nullptr;
+  const bool two_pass = bits > 0 && n > 1 && n < ((int64_t)1 << 30) && option_on("join.radix_onesweep", true);
+  if (two_pass) {
+    // (round 6) the partitioner above: digits of at most 8 bits over the top `bits` bits, least significant first
+    RpDigits dg{};
+    dg.n = (bits + 7) / 8;
+    for (int p = 0, pos = 64 - bits; p < dg.n; p++) {
+      const int b = (64 - pos + (dg.n - p) - 1) / (dg.n - p);
+      dg.shift[p] = pos;
+      dg.bits[p] = b;
+      pos += b;
+    }
+    const int items = option_int("join.radix_tile_items", 16) > 8 ? 16 : 8;   // rows per thread of a tile: 4096-row tiles write 16-row runs (128 B of keys)
+    const int64_t tile = (int64_t)BLOCK * items;
+    const int64_t n_tiles = (n + tile - 1) / tile;
+    BufPtr counts = make_buf((size_t)256 * n_tiles * 4), offsets = make_buf(((size_t)256 * n_tiles + 1) * 8);
+    BufPtr totals = make_zero_buf((size_t)RP_MAX_PASSES * 256 * 8 + 64);   // + the passes' tickets
+    unsigned* tickets = reinterpret_cast<unsigned*>(totals->as<unsigned long long>() + RP_MAX_PASSES * 256);
+    const int wg_per_cu = items > 8 ? 2 : 4;
+    auto with_shape = [&](auto f) {
+      if (items > 8) {
+        if (exact) f(std::true_type{}, std::integral_constant<int, 16>{});
+        else f(std::false_type{}, std::integral_constant<int, 16>{});
+      } else {
+        if (exact) f(std::true_type{}, std::integral_constant<int, 8>{});
+        else f(std::false_type{}, std::integral_constant<int, 8>{});
+      }
+    };
+    {
+      ProfileScope ps(what[0] == 'b' ? "radix_join_build_hist" : "radix_join_probe_hist", key_bytes);
+      const int64_t n_groups = (n_tiles + RP_HIST_GROUP - 1) / RP_HIST_GROUP;
+      const int hgrid = (int)std::min<int64_t>(n_groups, (int64_t)r.num_cus * 64);
+      with_shape([&](auto ex, auto it) {
+        k_rp_hist<decltype(ex)::value, decltype(it)::value><<<hgrid, BLOCK, 0, r.stream>>>(ks, mk, n, n_tiles, dg, counts->as<uint32_t>(), totals->as<unsigned long long>());
+      });
+      DFGPU_HIP(hipGetLastError());
+      scan_u32(counts->as<uint32_t>(), (int64_t)256 * n_tiles, offsets->as<uint64_t>());
+    }
+    if (mask) s.n = (int64_t)read_u64(offsets->as<uint64_t>() + (int64_t)256 * n_tiles);
+    const int64_t cap = std::max<int64_t>(mask ? s.n : n, 1);
+    BufPtr k0 = make_buf((size_t)cap * 8), r0 = make_buf((size_t)cap * 4), k1, r1, state;
+    if (dg.n > 1 && s.n > 0) {
+      k1 = make_buf((size_t)cap * 8);
+      r1 = make_buf((size_t)cap * 4);
+    }
+    if (s.n > 0) {
+      {
+        ProfileScope ps("radix_join_partition_pass", key_bytes + s.n * 12);
+        const int xcd_static = option_on("join.radix_xcd", true) ? 1 : 0;
+        const int grid = (int)std::min<int64_t>((n_tiles + 7) / 8 * 8, (int64_t)r.num_cus * wg_per_cu);
+        with_shape([&](auto ex, auto it) {
+          k_rp_pass<true, decltype(ex)::value, decltype(it)::value><<<grid, BLOCK, 0, r.stream>>>(ks, mk, nullptr, nullptr, n, dg.shift[0], dg.bits[0], n_tiles, offsets->as<uint64_t>(),
+                                                                                                   nullptr, nullptr, tickets, k0->as<uint64_t>(), r0->as<uint32_t>(), xcd_static);
+        });
+        DFGPU_HIP(hipGetLastError());
+      }
+      const int64_t rec_tiles = (s.n + tile - 1) / tile;
+      const int rgrid = (int)std::min<int64_t>(rec_tiles, (int64_t)r.num_cus * wg_per_cu);
+      for (int p = 1; p < dg.n; p++) {
+        ProfileScope ps("radix_join_partition_pass", s.n * 24);
+        if (!state) state = make_buf((size_t)rec_tiles * 256 * 4);
+        DFGPU_HIP(hipMemsetAsync(state->ptr, 0, (size_t)rec_tiles * 256 * 4, r.stream));
+        with_shape([&](auto ex, auto it) {
+          (void)ex;
+          k_rp_pass<false, true, decltype(it)::value><<<rgrid, BLOCK, 0, r.stream>>>(ks, nullptr, k0->as<uint64_t>(), r0->as<uint32_t>(), s.n, dg.shift[p], dg.bits[p], rec_tiles, nullptr,
+                                                                                      totals->as<unsigned long long>() + p * 256, state->as<uint32_t>(), tickets + p, k1->as<uint64_t>(),
+                                                                                      r1->as<uint32_t>(), 0);
+        });
+        DFGPU_HIP(hipGetLastError());
+        std::swap(k0, k1);
+        std::swap(r0, r1);
+      }
+    }
+    s.key = k0;
+    s.rid = r0;
+  } else {
+  s.key = make_buf((size_t)std::max<int64_t>(s.n, 1) * 8);
+  s.rid = make_buf((size_t)std::max<int64_t>(s.n, 1) * 4);
+  if (nullable && (!null_equals_null || exact) && n) {   // (the record kernel wants the rows' dense positions)
+    prefix = make_buf((size_t)(n_words + 1) * 8);
     scan_mask_popcounts(mask->as<uint64_t>(), nullptr, n, prefix->as<uint64_t>());
     s.n = (int64_t)read_u64(prefix->as<uint64_t>() + n_words);
   }
-  s.key = make_buf((size_t)std::max<int64_t>(s.n, 1) * 8);
-  s.rid = make_buf((size_t)std::max<int64_t>(s.n, 1) * 4);
-  int64_t key_bytes = 0;
-  for (int i = 0; i < ks.n; i++) key_bytes += n * ks.c[i].width;
   if (n) {
     ProfileScope ps(what[0] == 'b' ? "radix_join_build_records" : "radix_join_probe_records", key_bytes + s.n * 12);
     const int g = grid_for(n_words, BLOCK / WAVE);
-    const uint64_t* mk = mask ? mask->as<uint64_t>() : nullptr;
     const uint64_t* pf = prefix ? prefix->as<uint64_t>() : nullptr;
     if (exact) k_rj_records<true><<<g, BLOCK, 0, r.stream>>>(ks, n, force_collisions, mk, pf, s.key->as<uint64_t>(), s.rid->as<uint32_t>());
     else k_rj_records<false><<<g, BLOCK, 0, r.stream>>>(ks, n, force_collisions, mk, pf, s.key->as<uint64_t>(), s.rid->as<uint32_t>());
     DFGPU_HIP(hipGetLastError());
   }
   if (bits > 0 && s.n > 1) radix_sort_pairs(s.key, s.rid, s.n, 64 - bits, bits);
+  }
   // partition boundaries
-  s.h_starts.assign((size_t)P + 1, ~0ull);
+  s.h_starts.assign((size_t)P + 1, 0);
   if (s.n) {
     BufPtr st = make_buf((size_t)(P + 1) * 8);
-    DFGPU_HIP(hipMemsetAsync(st->ptr, 0xFF, (size_t)(P + 1) * 8, r.stream));
-    k_rj_starts<<<grid_for(s.n, BLOCK), BLOCK, 0, r.stream>>>(s.key->as<uint64_t>(), s.n, 64 - bits, st->as<unsigned long long>());
+    k_rp_starts<<<grid_for(P + 1, BLOCK), BLOCK, 0, r.stream>>>(s.key->as<uint64_t>(), s.n, 64 - bits, P, st->as<unsigned long long>());
     DFGPU_HIP(hipGetLastError());
     d2h(s.h_starts.data(), st->ptr, (size_t)(P + 1) * 8);
+    s.starts = st;
+  } else {
+    s.starts = make_zero_buf((size_t)(P + 1) * 8);
   }
-  s.h_starts[(size_t)P] = (uint64_t)s.n;
-  for (int64_t p = P - 1; p >= 0; p--)
-    if (s.h_starts[(size_t)p] == ~0ull) s.h_starts[(size_t)p] = s.h_starts[(size_t)p + 1];
-  s.starts = make_buf((size_t)(P + 1) * 8);
-  DFGPU_HIP(hipMemcpyAsync(s.starts->ptr, s.h_starts.data(), (size_t)(P + 1) * 8, hipMemcpyHostToDevice, r.stream));
   DFGPU_HIP(hipStreamSynchronize(r.stream));
   return s;
 }
@@ -185,6 +489,7 @@ struct RjCols {
   int n_build;   // the first n_build entries read the build row, the others the probe row
   int n;
   unsigned key_cols;   // bit c: entry c is the join key column (EXACT): the value is unfmix64(record key)
+  int need_brow;       // some build column is not the key: the build row id is needed
 };
 __device__ __forceinline__ uint64_t unfmix64(uint64_t x) {   // fmix64's inverse (the multipliers' inverses mod 2^64; x ^= x >> 33 undoes itself)
   x ^= x >> 33; x *= 0x9cb4b2f8129337dbULL;
@@ -211,26 +516,35 @@ __device__ __forceinline__ void rj_emit_row(const RjCols& cols, uint64_t key, ui
     }
   }
 }
-// EMIT: 0 = count the task's matches, 1 = write (build row, probe row) pairs, 2 = write the output columns (RjCols)
+// EMIT: 0 = count the task's matches, 1 = write (build row, probe row) pairs, 2 = write the output columns (RjCols).
+// ONE chain walk per probe row in either mode, and no workgroup barrier inside a task's probe loop (round 6; round 5's emit counted a
+// tile's matches, scanned the counts across the workgroup and walked again): the walk is wave-uniform — a step's matches are ranked by
+// ballot and listed in the WAVE's own stage in LDS ({build position, probe row}, RJ_WSTAGE entries) — and a wave that has finished its 64
+// probe rows (or filled its stage) takes its output range from the task's cursor (one LDS atomic) and writes its list out, consecutive
+// lanes to consecutive rows.  The order of a task's output rows is therefore arbitrary within the task (the radix join's output order is
+// not the probe's anyway).
+constexpr int RJ_WSTAGE = RJ_STAGE / (BLOCK / WAVE);
 template <bool EXACT, int EMIT>
 __global__ __launch_bounds__(BLOCK) void k_rj_join(const uint64_t* __restrict__ bkey, const uint32_t* __restrict__ brid, const uint64_t* __restrict__ bstart,
                                                   const uint64_t* __restrict__ pkey, const uint32_t* __restrict__ prid, const RadixTask* __restrict__ tasks,
                                                   int64_t n_tasks, RjVerify v, unsigned long long* __restrict__ task_counts,
                                                   const uint64_t* __restrict__ task_off, int64_t* __restrict__ out_b, int64_t* __restrict__ out_p, RjCols cols = RjCols{}) {
   __shared__ uint64_t s_key[RJ_CAP];
-  __shared__ uint32_t s_rid[RJ_CAP];
   __shared__ uint32_t s_head[RJ_HEADS];
   __shared__ uint16_t s_next[RJ_CAP];
   __shared__ unsigned long long s_wtot[BLOCK / WAVE];
-  __shared__ uint64_t s_ok[EMIT ? RJ_STAGE : 1];   // the emit walks' stage: a tile's matches (record key, build row, probe row)
-  __shared__ uint32_t s_ob[EMIT ? RJ_STAGE : 1], s_op[EMIT ? RJ_STAGE : 1];
+  __shared__ uint16_t s_ob[EMIT ? RJ_STAGE : 1];   // the emit walks' stages, one per wave: a match = (build row's position in the chunk, probe row)
+  __shared__ uint32_t s_op[EMIT ? RJ_STAGE : 1];
+  __shared__ unsigned long long s_run;             // EMIT: next free output position of the task
   const unsigned lane = lane_id();
   const int wave = threadIdx.x >> 6;
+  uint16_t* w_ob = s_ob + (EMIT ? wave * RJ_WSTAGE : 0);
+  uint32_t* w_op = s_op + (EMIT ? wave * RJ_WSTAGE : 0);
   for (int64_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
     const RadixTask task = tasks[t];
     const uint64_t b0 = bstart[task.part], b1 = bstart[task.part + 1];
     unsigned long long mine = 0;                                   // COUNT: this thread's matches over the whole task
-    unsigned long long run = EMIT ? task_off[t] : 0ull;             // EMIT: next free output position of the task (uniform)
+    if (EMIT && threadIdx.x == 0) s_run = task_off[t];
     for (uint64_t c0 = b0; c0 < b1; c0 += RJ_CAP) {
       const int nbk = (int)((b1 - c0) < (uint64_t)RJ_CAP ? (b1 - c0) : (uint64_t)RJ_CAP);
       for (int i = threadIdx.x; i < RJ_HEADS; i += BLOCK) s_head[i] = 0;
@@ -238,86 +552,73 @@ __global__ __launch_bounds__(BLOCK) void k_rj_join(const uint64_t* __restrict__ 
       for (int i = threadIdx.x; i < nbk; i += BLOCK) {
         const uint64_t k = bkey[c0 + i];
         s_key[i] = k;
-        s_rid[i] = brid[c0 + i];
         const uint32_t old = atomicExch(&s_head[(uint32_t)k & (RJ_HEADS - 1)], (uint32_t)i + 1u);
         s_next[i] = (uint16_t)old;
       }
       __syncthreads();
+      // the NEXT tile's probe records are requested before the current tile is walked: one HBM latency per 256-row tile, exposed, was
+      // 1.5 ms of each walk (781 K tiles over 768 resident workgroups, ~1.5 us each)
+      uint64_t k_nx = 0;
+      uint32_t pr_nx = 0;
+      if (threadIdx.x < task.rows) {
+        k_nx = pkey[task.q0 + threadIdx.x];
+        pr_nx = prid[task.q0 + threadIdx.x];
+      }
       for (uint32_t r0 = 0; r0 < task.rows; r0 += BLOCK) {
         const uint32_t j = r0 + threadIdx.x;
         const bool in = j < task.rows;
-        uint64_t k = 0;
-        uint32_t pr = 0;
-        if (in) {
-          k = pkey[task.q0 + j];
-          pr = prid[task.q0 + j];
+        const uint64_t k = k_nx;
+        const uint32_t pr = pr_nx;
+        if (j + BLOCK < task.rows) {
+          k_nx = pkey[task.q0 + j + BLOCK];
+          pr_nx = prid[task.q0 + j + BLOCK];
         }
-        uint32_t cnt = 0;
-        if (in) {
-          uint32_t cur = s_head[(uint32_t)k & (RJ_HEADS - 1)];
-          while (cur) {
-            if (s_key[cur - 1] == k && (EXACT || keys_equal(v.bkeys, (int64_t)s_rid[cur - 1], v.pkeys, (int64_t)pr, v.null_equals_null != 0, true))) cnt++;
-            cur = s_next[cur - 1];
-          }
-        }
+        uint32_t cur = in ? s_head[(uint32_t)k & (RJ_HEADS - 1)] : 0u;
         if (!EMIT) {
-          mine += cnt;
+          while (cur) {
+            const uint32_t bi = cur - 1;
+            if (s_key[bi] == k && (EXACT || keys_equal(v.bkeys, (int64_t)brid[c0 + bi], v.pkeys, (int64_t)pr, v.null_equals_null != 0, true))) mine++;
+            cur = s_next[bi];
+          }
           continue;
         }
-        // exclusive offsets of this tile's matches: wave scan + wave totals
-        const unsigned long long inc = wave_inclusive_sum<unsigned long long>((unsigned long long)cnt);
-        if (lane == 63) s_wtot[wave] = inc;
-        __syncthreads();
-        unsigned long long base = run, tot = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / WAVE; w++) {
-          if (w < wave) base += s_wtot[w];
-          tot += s_wtot[w];
-        }
-        unsigned long long o = base + inc - cnt;
-        if (tot <= (unsigned long long)RJ_STAGE) {
-          // the tile's matches are listed in LDS first, then every OUTPUT row gets a thread: consecutive threads write consecutive rows
-          // (a thread writing its own two or three matches one after the other left 8-byte stores 16-24 bytes apart: 5.6 ms for 300 M
-          // pairs against 3.x staged) and the gathers of a row's columns are issued by as many threads as there are rows
-          if (cnt) {
-            uint32_t lo = (uint32_t)(o - run);
-            uint32_t cur = s_head[(uint32_t)k & (RJ_HEADS - 1)];
-            while (cur) {
-              if (s_key[cur - 1] == k && (EXACT || keys_equal(v.bkeys, (int64_t)s_rid[cur - 1], v.pkeys, (int64_t)pr, v.null_equals_null != 0, true))) {
-                s_ok[lo] = k;
-                s_ob[lo] = s_rid[cur - 1];
-                s_op[lo] = pr;
-                lo++;
-              }
-              cur = s_next[cur - 1];
-            }
-          }
-          __syncthreads();
-          for (uint32_t q = threadIdx.x; q < (uint32_t)tot; q += BLOCK) {
-            if (EMIT == 2) {
-              rj_emit_row(cols, s_ok[q], s_ob[q], s_op[q], run + q);
+        unsigned listed = 0;   // matches in the wave's stage (uniform)
+        auto flush = [&]() {
+          unsigned long long base = 0;
+          if (lane == 0) base = atomicAdd(&s_run, (unsigned long long)listed);
+          base = __shfl(base, 0, 64);
+          for (unsigned q = lane; q < listed; q += WAVE) {
+            const uint32_t bi = w_ob[q], prow = w_op[q];
+            if (EMIT == 2) {   // (EXACT: the record key of a match is the build row's)
+              const uint32_t brow = cols.need_brow ? brid[c0 + bi] : 0u;
+              rj_emit_row(cols, s_key[bi], brow, prow, base + q);
             } else {
-              out_b[run + q] = (int64_t)s_ob[q];
-              out_p[run + q] = (int64_t)s_op[q];
+              out_b[base + q] = (int64_t)brid[c0 + bi];
+              out_p[base + q] = (int64_t)prow;
             }
           }
-        } else if (cnt) {   // (more matches than the stage holds — heavy duplicates: every thread writes its own)
-          uint32_t cur = s_head[(uint32_t)k & (RJ_HEADS - 1)];
-          while (cur) {
-            if (s_key[cur - 1] == k && (EXACT || keys_equal(v.bkeys, (int64_t)s_rid[cur - 1], v.pkeys, (int64_t)pr, v.null_equals_null != 0, true))) {
-              if (EMIT == 2) {
-                rj_emit_row(cols, k, s_rid[cur - 1], pr, o);
-              } else {
-                out_b[o] = (int64_t)s_rid[cur - 1];
-                out_p[o] = (int64_t)pr;
-              }
-              o++;
-            }
-            cur = s_next[cur - 1];
+          listed = 0;
+        };
+        while (ballot64(cur != 0)) {   // (wave-uniform)
+          bool hit = false;
+          uint32_t bi = 0;
+          if (cur) {
+            bi = cur - 1;
+            hit = s_key[bi] == k && (EXACT || keys_equal(v.bkeys, (int64_t)brid[c0 + bi], v.pkeys, (int64_t)pr, v.null_equals_null != 0, true));
+            cur = s_next[bi];
           }
+          const uint64_t hm = ballot64(hit);
+          if (hm == 0) continue;
+          const unsigned nh = (unsigned)__popcll(hm);
+          if (listed + nh > (unsigned)RJ_WSTAGE) flush();
+          if (hit) {
+            const unsigned slot = listed + mbcnt(hm);
+            w_ob[slot] = (uint16_t)bi;
+            w_op[slot] = pr;
+          }
+          listed += nh;
         }
-        run += tot;
-        __syncthreads();  // s_wtot and the stage are reused by the next tile
+        if (listed) flush();
       }
       __syncthreads();  // the next chunk overwrites the table
     }
@@ -342,11 +643,11 @@ std::shared_ptr<RadixTable> radix_join_build(const Table& build, const std::vect
   bool nullable = false;
   for (int i = 0; i < ks.n; i++) nullable |= ks.c[i].valid != nullptr;
   rt_->exact = ks.n == 1 && is_integer_like(ks.c[0].type) && !(null_equals_null && nullable) && !force_collisions;
-  // ~1024 build rows per partition on average, up to three 6-bit passes (268 M build rows): a partition that needs several LDS
-  // chunks per task costs far more than a third pass over HBM (profiles/r2_radix_sweep.md)
-  const int max_bits = 18;
+  // ~2300 build rows per partition on average at most (RJ_CAP less five standard deviations of a partition's size when every key comes
+  // three times): a partition that needs several LDS chunks per task costs far more than another pass over HBM (profiles/r2_radix_sweep.md)
+  const int max_bits = 24;
   int bits = 0;
-  while (bits < max_bits && ((int64_t)1024 << bits) < build.nrows) bits++;
+  while (bits < max_bits && ((int64_t)2400 << bits) < build.nrows) bits++;
   if (force_collisions) bits = 0;
   rt_->bits = bits;
   rt_->build = rj_partition(build, key_cols, bits, rt_->exact, null_equals_null, force_collisions, "build");
@@ -463,6 +764,8 @@ bool radix_join_inner_columns(const RadixTable& t, const Table& build, const std
       rc.n++;
     }
     rc.n_build = rc.n;
+    for (int c = 0; c < rc.n_build; c++)
+      if (!((rc.key_cols >> c) & 1u)) rc.need_brow = 1;
     for (int c : pout) {
       const Column& sc = probe.cols[(size_t)c];
       out.cols.push_back(alloc_like(sc, m));

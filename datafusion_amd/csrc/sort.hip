@@ -25,6 +25,7 @@
 
 #include "device.hpp"
 #include "internal.hpp"
+#include "onesweep.hpp"
 #include "records.hpp"
 
 namespace dfgpu {
@@ -473,13 +474,10 @@ __global__ __launch_bounds__(BLOCK) void k_rs_scatter_kv(const uint64_t* __restr
 constexpr int OS_ITEMS = 8;
 constexpr int OS_TILE = BLOCK * OS_ITEMS;
 constexpr int OS_MAX_PASSES = 4;
-constexpr uint32_t OS_AGG = 1u << 30, OS_PFX = 2u << 30, OS_VAL = (1u << 30) - 1u;
 struct OsDigits {
   int shift[OS_MAX_PASSES], bits[OS_MAX_PASSES];
   int n;
 };
-__device__ __forceinline__ uint32_t os_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void os_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // A tile's keys and records read off the SOURCE columns, column by column: the loads of all of a lane's rows from one column are in
 // flight together (the row-by-row form — pack_key64 / record_build per row — walks the column list once per row, every load behind a
@@ -569,40 +567,6 @@ __device__ __forceinline__ void tile_records(const PackLayout& L, const uint32_t
       }
     }
   }
-}
-
-// The look-back of digit `d` for tile t: the sum of the digit's counts over the tiles before t — nearest first, AGG words added up until
-// an inclusive prefix (PFX) is met.  OS_LB predecessors are read at once: an agent-scope load is a round trip to the memory side of the
-// fabric (no XCD's L2 may answer it), a microsecond, and tiles retire every few tens of nanoseconds — one word per round trip cannot keep
-// up with that and the tiles queue behind their look-backs (measured: 0.6-0.9 ms of a 2-2.6 ms pass; profiles/r5_sort_phases.md).
-constexpr int OS_LB = 8;
-__device__ __forceinline__ unsigned os_look_back(const uint32_t* tile_state, int64_t t, unsigned d) {
-  unsigned excl = 0;
-  int64_t p = t - 1;
-  bool done = t == 0;
-  while (!done) {
-    uint32_t st[OS_LB];
-#pragma unroll
-    for (int u = 0; u < OS_LB; u++) st[u] = p - u >= 0 ? os_load(&tile_state[(p - u) * 256 + d]) : OS_PFX;
-    int adv = 0;
-    bool stop = false;
-#pragma unroll
-    for (int u = 0; u < OS_LB; u++) {
-      const uint32_t status = st[u] >> 30;
-      if (!stop) {
-        if (status == 0) {
-          stop = true;   // not published yet: read again from here
-        } else {
-          excl += st[u] & OS_VAL;
-          adv++;
-          if (status == 2) done = stop = true;
-        }
-      }
-    }
-    p -= adv;
-    if (!done && adv == 0) __builtin_amdgcn_s_sleep(1);
-  }
-  return excl;
 }
 
 // digit totals of every pass: hist[pass * 256 + digit].  BUILD: the keys are computed from the key columns (no packed key array exists)

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--big", type=int, default=1, help="include the SF100-sized shapes (150 M build / 600 M probe rows)")
     ap.add_argument("--md", default="")
     ap.add_argument("--tables", default="", help="comma-separated subset of auto,chained,radix,array_map")
+    ap.add_argument("--launches", default="", help="comma-separated profile scopes whose launches are listed one by one (ms, last iteration)")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
 
@@ -114,13 +115,18 @@ def main():
                 ops.sync()
                 times.append(time.perf_counter() - t0)
             stats = ops.profile_stats()
+            launches = {}
+            for scope in [x for x in args.launches.split(",") if x]:
+                ls = ops.profile_launches(scope)
+                per = len(ls) // args.iters if args.iters else 0
+                launches[scope] = [round(ms, 3) for ms, _ in ls[-per:]] if per else []
             ops.profile_enable(False)
             best = min(times)
             b = (nb + np_ + m) * w if row_bytes is None else nb * row_bytes[0] + np_ * row_bytes[1] + m * row_bytes[2]
             kern = {k: round(v["total_ms"] / args.iters, 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
             rec = {"case": name, "table": label, "table_kind": {0: "chained", 1: "array_map", 2: "rank_map", 3: "radix_lds", 4: "flat8", 5: "flat16"}[kind], "build_rows": nb, "probe_rows": np_,
                    "output_rows": m, "ms": round(best * 1e3, 3), "rows_per_s": (nb + np_) / best, "algorithmic_bytes": b,
-                   "algorithmic_gb_per_s": round(b / best / 1e9, 1), "hbm_frac": round(b / best / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms_per_iter": kern, "note": note}
+                   "algorithmic_gb_per_s": round(b / best / 1e9, 1), "hbm_frac": round(b / best / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms_per_iter": kern, "note": note, **({"launches_ms": launches} if launches else {})}
             results.append(rec)
             print(json.dumps(rec), flush=True)
             for k in env:
