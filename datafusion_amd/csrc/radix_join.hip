@@ -308,15 +308,15 @@ __global__ __launch_bounds__(BLOCK, (ITEMS > 8 ? 2 : 4)) void k_rp_pass(KeySet k
 }
 // starts[p] = first position whose partition id (key >> shift) is >= p, p in [0, P]
 __global__ __launch_bounds__(BLOCK) void k_rp_starts(const uint64_t* __restrict__ key, int64_t n, int shift, int64_t P, unsigned long long* __restrict__ starts) {
-  const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (p > P) return;
-  int64_t lo = 0, hi = n;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)(shift >= 64 ? 0ull : key[mid] >> shift) < p) lo = mid + 1;
-    else hi = mid;
+  for (int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x; p <= P; p += (int64_t)gridDim.x * BLOCK) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)(shift >= 64 ? 0ull : key[mid] >> shift) < p) lo = mid + 1;
+      else hi = mid;
+    }
+    starts[p] = (unsigned long long)lo;
   }
-  starts[p] = (unsigned long long)lo;
 }
 
 struct RadixSide {
@@ -647,7 +647,8 @@ std::shared_ptr<RadixTable> radix_join_build(const Table& build, const std::vect
   // three times): a partition that needs several LDS chunks per task costs far more than another pass over HBM (profiles/r2_radix_sweep.md)
   const int max_bits = 24;
   int bits = 0;
-  while (bits < max_bits && ((int64_t)2400 << bits) < build.nrows) bits++;
+  const int64_t part_rows = std::max<int64_t>(1, option_int("join.radix_partition_rows", 2400));   // (test hook: several passes over a small input)
+  while (bits < max_bits && (part_rows << bits) < build.nrows) bits++;
   if (force_collisions) bits = 0;
   rt_->bits = bits;
   rt_->build = rj_partition(build, key_cols, bits, rt_->exact, null_equals_null, force_collisions, "build");

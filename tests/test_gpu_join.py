@@ -431,6 +431,42 @@ def test_radix_lds_join_many_partitions_and_skew(shape):
         assert_tables_equal(got, exp)
 
 
+@pytest.mark.parametrize("keys", ["int64_nullable", "int32", "two_columns", "decimal128"])
+@pytest.mark.parametrize("opts", [dict(join__radix_partition_rows=8), dict(join__radix_partition_rows=1), dict(join__radix_partition_rows=8, join__radix_tile_items=8),
+                                  dict(join__radix_partition_rows=8, join__radix_onesweep=0)], ids=["two_passes", "three_passes", "tiles_of_2048", "six_bit_passes"])
+def test_radix_partitioner_passes_masks_and_key_kinds(keys, opts):
+    """the radix join's partitioner (round 6: 8-bit passes straight off the key column, look-back from the second pass on) forced to two and to
+    three passes on a 70 K-row build side, over NULL keys (the validity mask decides which rows become records), 32-bit keys, and keys that
+    are hashed (two columns, Decimal128: records carry the row hash and matches are re-checked); every join type's pairs against the oracle"""
+    from oracle import oracle
+    from datafusion_amd import ops
+    rng = np.random.default_rng(77)
+    nb, np_ = 70_000, 120_000
+    if keys == "int64_nullable":
+        left = random_table(rng, nb, {"a": (pa.int64(), -40_000, 40_000), "x": (pa.int32(), 0, 100)}, null_frac=0.07)
+        right = random_table(rng, np_, {"b": (pa.int64(), -50_000, 50_000), "z": (pa.int32(), 0, 100)}, null_frac=0.07)
+        on = [("a", "b")]
+    elif keys == "int32":
+        left = random_table(rng, nb, {"a": (pa.int32(), 0, 90_000), "x": (pa.int64(), 0, 100)}, null_frac=0.0)
+        right = random_table(rng, np_, {"b": (pa.int32(), 0, 120_000), "z": (pa.int32(), 0, 100)}, null_frac=0.0)
+        on = [("a", "b")]
+    elif keys == "two_columns":
+        left = random_table(rng, nb, {"a": (pa.int32(), 0, 300), "a2": (pa.int64(), 0, 300), "x": (pa.int32(), 0, 100)}, null_frac=0.03)
+        right = random_table(rng, np_, {"b": (pa.int32(), 0, 320), "b2": (pa.int64(), 0, 320), "z": (pa.int32(), 0, 100)}, null_frac=0.03)
+        on = [("a", "b"), ("a2", "b2")]
+    else:
+        left = random_table(rng, nb, {"a": (pa.decimal128(20, 2), 0, 80_000), "x": (pa.int32(), 0, 100)}, null_frac=0.02)
+        right = random_table(rng, np_, {"b": (pa.decimal128(20, 2), 0, 100_000), "z": (pa.int32(), 0, 100)}, null_frac=0.02)
+        on = [("a", "b")]
+    ops.set_options(**opts)
+    for jt, ne in (("Inner", "NullEqualsNothing"), ("Full", "NullEqualsNothing"), ("LeftAnti", "NullEqualsNothing"), ("Inner", "NullEqualsNull")):
+        got, names = _probe_paths(lambda: gpu_join(left, right, on, jt, ne, table_mode=4))
+        assert ("radix_join_partition_pass" in names) == (opts.get("join__radix_onesweep", 1) == 1), names
+        exp = oracle.hash_join(left, right, on, jt, ne)
+        assert got.num_rows == exp.num_rows
+        assert_tables_equal(got, exp)
+
+
 def _probe_paths(fn):
     """run fn() with the library's profile on; returns (result, names of the profiled scopes that ran)"""
     from datafusion_amd import ops
