@@ -1550,10 +1550,49 @@ static void split_interleaved(Aggregate& A, int64_t G) {
   }
 }
 
+// the fresh accumulators of a FEW groups (a first batch's: nothing to copy) filled by ONE launch — blockIdx.y is the array.  Q1's eight
+// aggregates were 28 fill launches a step, 0.13 ms behind a kernel of 7.4
+constexpr int FM_MAX = 4 * MAX_AGGS;
+struct FillMany {
+  void* p[FM_MAX];
+  unsigned long long v[FM_MAX];
+  int elem[FM_MAX];
+};
+__global__ __launch_bounds__(BLOCK) void k_fill_many(FillMany f, int64_t n) {
+  const int c = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (f.elem[c] == 8) reinterpret_cast<unsigned long long*>(f.p[c])[i] = f.v[c];
+    else reinterpret_cast<uint32_t*>(f.p[c])[i] = (uint32_t)f.v[c];
+  }
+}
 static std::vector<AccPlan> grow_accumulators(Aggregate& A, int64_t G0, int64_t G1, bool init = true) {
   std::vector<AccPlan> plans;
   const bool final_mode = A.final_mode();
   split_interleaved(A, G0);
+  if (init && G0 == 0 && G1 > 0 && G1 <= 65536 && (int)A.aggs.size() <= MAX_AGGS) {
+    FillMany fm{};
+    int m = 0;
+    auto fresh = [&](BufPtr& b, unsigned long long fill, int elem) {
+      b = make_buf((size_t)G1 * elem);
+      fm.p[m] = b->ptr;
+      fm.v[m] = fill;
+      fm.elem[m] = elem;
+      m++;
+    };
+    for (AggState& a : A.aggs) {
+      AccPlan p = plan_for(a.func, a.in_type, final_mode);
+      fresh(a.lo, acc_identity(p.kind), 8);
+      if (p.needs_hi) fresh(a.hi, 0ull, 8);
+      fresh(a.seen, 0ull, 4);
+      if (a.func == DFGPU_AGG_AVG) fresh(a.cnt, 0ull, 8);
+      plans.push_back(p);
+    }
+    if (m) {
+      k_fill_many<<<dim3((unsigned)grid_for(G1, BLOCK), (unsigned)m), BLOCK, 0, rt().stream>>>(fm, G1);
+      DFGPU_HIP(hipGetLastError());
+    }
+    return plans;
+  }
   for (AggState& a : A.aggs) {
     AccPlan p = plan_for(a.func, a.in_type, final_mode);
     a.lo = grown(a.lo, G0, G1, acc_identity(p.kind), 8, init);
