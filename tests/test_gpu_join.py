@@ -467,6 +467,29 @@ def test_radix_partitioner_passes_masks_and_key_kinds(keys, opts):
         assert_tables_equal(got, exp)
 
 
+@pytest.mark.parametrize("part_rows", [2400, 16], ids=["one_partition_level", "two_passes"])
+def test_radix_inner_join_writes_payload_columns_of_every_width_from_the_emit_walk(part_rows):
+    """INNER radix join whose output columns are written by the emit walk itself (no pair list, no gathers): payload of 16, 8, 4 and 1 bytes on
+    both sides without NULLs, the key column of either side among the outputs (rebuilt from the record key), duplicates on both sides"""
+    from oracle import oracle
+    from datafusion_amd import ops
+    rng = np.random.default_rng(5)
+    nb, np_ = 90_000, 200_000
+    left = random_table(rng, nb, {"a": (pa.int64(), -30_000, 30_000), "x": (pa.decimal128(15, 2), 0, 10**6), "y": (pa.int32(), 0, 1000), "u": (pa.uint8(), 0, 255), "v": (pa.int64(), 0, 10**12)})
+    right = random_table(rng, np_, {"b": (pa.int64(), -40_000, 40_000), "z": (pa.decimal128(15, 2), 0, 10**6), "w": (pa.date32(), 8000, 9000), "t": (pa.uint8(), 0, 255), "s": (pa.int64(), 0, 10**12)})
+    ops.set_options(join__radix_partition_rows=part_rows)
+    got, names = _probe_paths(lambda: gpu_join(left, right, [("a", "b")], "Inner", table_mode=4))
+    assert "radix_join_emit_columns" in names, names
+    exp = oracle.hash_join(left, right, [("a", "b")], "Inner")
+    assert got.num_rows == exp.num_rows and got.num_rows > 200_000
+    assert_tables_equal(got, exp)
+    # the pairs + gathers of round 5 (join.radix_fused_emit = 0) give the same rows
+    ops.set_options(join__radix_fused_emit=0)
+    got2, names2 = _probe_paths(lambda: gpu_join(left, right, [("a", "b")], "Inner", table_mode=4))
+    assert "radix_join_emit_columns" not in names2 and "radix_join_emit" in names2, names2
+    assert_tables_equal(got2, exp)
+
+
 def _probe_paths(fn):
     """run fn() with the library's profile on; returns (result, names of the profiled scopes that ran)"""
     from datafusion_amd import ops
