@@ -1250,7 +1250,29 @@ struct PqDevArgs {
   int32_t n_pages, dict_count;
   int32_t phys_w, big_endian, sign_extend;
   int32_t* error;
+  const int64_t* value_starts;   // per page: first non-null value of the page, chunk-wide (k_pq_value_starts)
 };
+// the exclusive prefix of the data pages' non-null counts, once per chunk (one workgroup; round 5 had every decode workgroup re-sum the
+// earlier pages' counts — O(pages^2) loads, billions for a chunk written with tiny pages)
+__global__ __launch_bounds__(BLOCK) void k_pq_value_starts(const DevPage* __restrict__ pages, const DevPageState* __restrict__ states, int n_pages, int64_t* __restrict__ starts) {
+  __shared__ unsigned long long s_w[BLOCK / WAVE];
+  __shared__ unsigned long long s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_pages; base += BLOCK) {
+    const int q = base + (int)threadIdx.x;
+    const unsigned long long v = q < n_pages && pages[q].type != PAGE_DICTIONARY ? (unsigned long long)states[q].nonnull : 0ull;
+    const unsigned long long inc = wave_inclusive_sum<unsigned long long>(v);
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned long long before = s_carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += s_w[w];
+    if (q < n_pages) starts[q] = (int64_t)(before + inc - v);
+    __syncthreads();
+    if (threadIdx.x == BLOCK - 1) s_carry = before + inc;
+    __syncthreads();
+  }
+}
 template <typename T>
 __device__ __forceinline__ T pq_plain_value(const uint8_t* src, int phys_w, int big_endian, int sign_extend) {
   if (big_endian) {   // n-byte big-endian two's complement -> i128
@@ -1301,20 +1323,7 @@ __global__ __launch_bounds__(BLOCK) void k_pq_decode_pages(PqDevArgs a, T* __res
   const DevPage pg = a.pages[p];
   if (pg.type == PAGE_DICTIONARY) return;
   const DevPageState st = a.states[p];
-  // first non-null value of the page, chunk-wide: the sum of the earlier data pages' counts (the workgroup's threads share the pages out:
-  // a chunk written with small pages has thousands of them)
-  __shared__ unsigned long long s_vs[BLOCK / WAVE];
-  {
-    unsigned long long part = 0;
-    for (int q = threadIdx.x; q < p; q += BLOCK)
-      if (a.pages[q].type != PAGE_DICTIONARY) part += (unsigned long long)a.states[q].nonnull;
-    part = wave_sum<unsigned long long>(part);
-    if (lane_id() == 0) s_vs[threadIdx.x >> 6] = part;
-    __syncthreads();
-  }
-  int64_t value_start = 0;
-#pragma unroll
-  for (int w = 0; w < BLOCK / WAVE; w++) value_start += (int64_t)s_vs[w];
+  const int64_t value_start = a.value_starts[p];   // first non-null value of the page, chunk-wide
   const uint8_t* vals = pq_page_body(pg, a.chunk, a.body) + st.values_off;
   const int64_t vbytes = st.values_end - st.values_off;
   const int64_t n = st.nonnull;
@@ -1747,7 +1756,7 @@ struct DeviceChunkKeep {
   StageVec<DevPage> pages;
   StageVec<DevPageState> states;
   StageVec<int32_t> err;
-  BufPtr d_chunk, d_body, d_states, d_err, d_dict, dense, prefix;
+  BufPtr d_chunk, d_body, d_states, d_err, d_dict, dense, prefix, d_value_starts;
   std::vector<int32_t> page_type, page_rows;
   int64_t rows = 0;
 };
@@ -1813,6 +1822,18 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
   K->d_body = make_buf((size_t)D.body_bytes + 64);
   K->d_states = make_buf((size_t)n_pages * sizeof(DevPageState));
   lap(2);
+  // From here on copies out of K's pinned staging and kernels on K's buffers are in flight: should anything below throw (a malformed string
+  // dictionary, a decompression error), both streams are drained BEFORE K unwinds — its staging block must not return to the pinned pool, nor
+  // its chunk buffer to the upload cache, while the copy engine still reads them
+  struct InFlightGuard {
+    hipStream_t a, b;
+    bool armed = true;
+    ~InFlightGuard() {
+      if (!armed) return;
+      (void)hipStreamSynchronize(a);
+      (void)hipStreamSynchronize(b);
+    }
+  } in_flight{up, st};
   DFGPU_HIP(hipMemcpyAsync(K->d_chunk->ptr, K->staged.data(), (size_t)padded, hipMemcpyHostToDevice, up));
   DFGPU_HIP(hipMemcpyAsync((uint8_t*)K->d_chunk->ptr + pages_at, K->pages.data(), pages_bytes, hipMemcpyHostToDevice, up));
   DFGPU_HIP(hipEventRecord(ev_up, up));
@@ -1879,6 +1900,9 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
     K->dense = make_buf((size_t)std::max<int64_t>(D.rows, 1) * out_w + 16);
     target = K->dense->ptr;
   }
+  K->d_value_starts = make_buf((size_t)n_pages * 8);
+  k_pq_value_starts<<<1, BLOCK, 0, st>>>(d_pages, K->d_states->as<DevPageState>(), n_pages, K->d_value_starts->as<int64_t>());
+  a.value_starts = K->d_value_starts->as<int64_t>();
   {
     ProfileScope ps("parquet_decode_pages", D.body_bytes + D.rows * out_w);
     switch (out_w) {
@@ -1932,8 +1956,10 @@ Column decode_chunk_device(const DevPlan& D, const uint8_t* chunk, int64_t nbyte
   if (keep && fin) {
     *keep = K;
     *fin = std::move(finish);
+    in_flight.armed = false;   // (the caller holds K until the stream has passed this chunk)
   } else {
     DFGPU_HIP(hipStreamSynchronize(st));
+    in_flight.armed = false;
     finish(c);
   }
   return c;

@@ -107,24 +107,14 @@ class _Q1Planned:
         self.node = ops.AggregatePlan(lineitem, Q1_GROUP_BY, q1_aggs_inlined(), mode, predicate=pred)
 
 
-_Q1_PLANS: dict = {}
+def plan_q1(lineitem: DeviceTable, group=None) -> _Q1Planned:
+    """Q1's fused node planned for `lineitem`'s schema — what a caller that runs the query more than once holds on to and hands to q1()
+    (bench.py plans once, outside its timed region, and says so on its line; q1() without a plan plans per call).  No cache is kept
+    anywhere: the plan lives as long as the caller keeps it."""
+    return _Q1Planned(lineitem, "Single" if _world(group) == 1 else "Partial")
 
 
-def _q1_plan(lineitem: DeviceTable, mode: str) -> _Q1Planned:
-    """plan cache: on the table object first (no schema walk on the hot path), then by input schema (names + types) and the aggregate
-    mode; Q1's expressions bind no dictionaries, so a plan serves every table of that schema"""
-    mine = lineitem.__dict__.setdefault("_q1_plans", {})
-    plan = mine.get(mode)
-    if plan is None:
-        key = (mode, str(lineitem.schema))
-        plan = _Q1_PLANS.get(key)
-        if plan is None:
-            plan = _Q1_PLANS[key] = _Q1Planned(lineitem, mode)
-        mine[mode] = plan
-    return plan
-
-
-def q1(lineitem: DeviceTable, group=None, fused: bool = True) -> DeviceTable:
+def q1(lineitem: DeviceTable, group=None, fused: bool = True, plan: _Q1Planned = None) -> DeviceTable:
     """q1.slt.part:50-58, bottom-up: FilterExec(l_shipdate <= 1998-09-02, projection) ->
     ProjectionExec(__common_expr_1 = l_extendedprice * (1 - l_discount), ...) ->
     AggregateExec(Partial) -> RepartitionExec(Hash(flag, status)) -> AggregateExec(FinalPartitioned)
@@ -137,7 +127,8 @@ def q1(lineitem: DeviceTable, group=None, fused: bool = True) -> DeviceTable:
     other, materialising the filter's and the projection's outputs."""
     first_mode = "Single" if _world(group) == 1 else "Partial"
     if fused:
-        plan = _q1_plan(lineitem, first_mode)
+        if plan is None:
+            plan = _Q1Planned(lineitem, first_mode)
         return_types = plan.return_types
         first = plan.node.execute(lineitem)
     else:

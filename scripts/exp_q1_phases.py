@@ -28,7 +28,7 @@ def main():
     ph = {"plan_lookup": 0.0, "node_execute": 0.0, "sort": 0.0, "free": 0.0}
     for _ in range(a.steps):
         t0 = time.perf_counter()
-        plan = queries._q1_plan(li, "Single")
+        plan = queries.plan_q1(li)
         t1 = time.perf_counter()
         agg = plan.node.execute(li)
         ops.sync()
