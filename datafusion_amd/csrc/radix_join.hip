@@ -176,13 +176,16 @@ __global__ __launch_bounds__(BLOCK) void k_rp_hist(KeySet ks, const uint64_t* __
     if (s_h[p - 1][threadIdx.x]) atomicAdd(&totals[p * 256 + threadIdx.x], (unsigned long long)s_h[p - 1][threadIdx.x]);
 }
 // BUILD: tile t = source rows [t * TILE, ...), `offsets` (digit-major, scanned) holds every run's start; else: records in, look-back.
-template <bool BUILD, bool EXACT, int ITEMS>
-__global__ __launch_bounds__(BLOCK, (ITEMS > 8 ? 2 : 4)) void k_rp_pass(KeySet ks, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ key_in, const uint32_t* __restrict__ rid_in,
-                                                     int64_t n, int shift, int bits, int64_t n_tiles, const uint64_t* __restrict__ offsets,
+// THREADS x ITEMS rows per tile: 256 x 8 (2048 rows), 256 x 16 (4096 rows: 16-row runs, but ~200 VGPRs = 8 waves per CU) or 512 x 8 (the same
+// tile at half the registers per thread: 16 waves per CU).  The digits' bookkeeping (counts, scan, offsets, look-back) belongs to the first
+// 256 threads = waves 0-3; every wave ranks and stages its own 64 x ITEMS-row segment.
+template <bool BUILD, bool EXACT, int ITEMS, int THREADS>
+__global__ __launch_bounds__(THREADS, (THREADS == 512 ? 1 : ITEMS > 8 ? 2 : 4)) void k_rp_pass(KeySet ks, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ key_in,
+                                                     const uint32_t* __restrict__ rid_in, int64_t n, int shift, int bits, int64_t n_tiles, const uint64_t* __restrict__ offsets,
                                                      const unsigned long long* __restrict__ totals, uint32_t* __restrict__ tile_state, unsigned* __restrict__ ticket,
                                                      uint64_t* __restrict__ key_out, uint32_t* __restrict__ rid_out, int xcd_static) {
-  constexpr int NWAVE = BLOCK / WAVE;
-  constexpr int TILE = BLOCK * ITEMS;
+  constexpr int NWAVE = THREADS / WAVE;
+  constexpr int TILE = THREADS * ITEMS;
   __shared__ uint64_t s_key[TILE];
   __shared__ uint32_t s_rid[TILE];
   __shared__ uint8_t s_dig[TILE];
@@ -190,25 +193,30 @@ __global__ __launch_bounds__(BLOCK, (ITEMS > 8 ? 2 : 4)) void k_rp_pass(KeySet k
   __shared__ uint16_t s_start[256];
   __shared__ unsigned int s_goff[256];
   __shared__ unsigned int s_base[256];
-  __shared__ unsigned int s_wtot[NWAVE];
+  __shared__ unsigned int s_wtot[4];
   __shared__ unsigned int s_tile, s_nst;
   const unsigned mask_d = (1u << bits) - 1u;
   const int wave = threadIdx.x >> 6;
   const unsigned lane = lane_id();
+  const bool dig_thread = threadIdx.x < 256;   // (wave-uniform: waves 0-3)
   if (!BUILD) {   // bin bases of this pass: exclusive scan of the digit totals
-    const unsigned v = (unsigned)totals[threadIdx.x];
-    const unsigned inc = wave_inclusive_sum<unsigned>(v);
-    if (lane == 63) s_wtot[wave] = inc;
+    unsigned v = 0, inc = 0;
+    if (dig_thread) {
+      v = (unsigned)totals[threadIdx.x];
+      inc = wave_inclusive_sum<unsigned>(v);
+      if (lane == 63) s_wtot[wave] = inc;
+    }
     __syncthreads();
-    unsigned b = 0;
-    for (int w = 0; w < wave; w++) b += s_wtot[w];
-    s_base[threadIdx.x] = b + inc - v;
+    if (dig_thread) {
+      unsigned b = 0;
+      for (int w = 0; w < wave; w++) b += s_wtot[w];
+      s_base[threadIdx.x] = b + inc - v;
+    }
     __syncthreads();
   }
   for (int64_t round = 0;; round++) {
     if (!(BUILD && xcd_static) && threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-    for (int w = 0; w < NWAVE; w++) s_cnt[w][threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < NWAVE * 256; i += THREADS) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     int64_t t;
     if (BUILD && xcd_static) {   // every XCD walks a contiguous eighth of the tiles: the runs neighbouring tiles append to a digit meet in ONE L2
@@ -259,18 +267,20 @@ __global__ __launch_bounds__(BLOCK, (ITEMS > 8 ? 2 : 4)) void k_rp_pass(KeySet k
       dr[c] = dig | ((base + r_in_wave) << 8);
     }
     __syncthreads();
-    unsigned run = 0;   // thread d: digit d's rows in this tile
+    unsigned run = 0, inc = 0;   // thread d: digit d's rows in this tile
+    if (dig_thread) {
 #pragma unroll
-    for (int w = 0; w < NWAVE; w++) {
-      const unsigned v = s_cnt[w][threadIdx.x];
-      s_cnt[w][threadIdx.x] = (uint16_t)run;
-      run += v;
-    }
-    if (!BUILD && t > 0 && threadIdx.x <= mask_d) os_store(&tile_state[t * 256 + threadIdx.x], OS_AGG | run);
-    {
-      const unsigned inc = wave_inclusive_sum<unsigned>(run);
+      for (int w = 0; w < NWAVE; w++) {
+        const unsigned v = s_cnt[w][threadIdx.x];
+        s_cnt[w][threadIdx.x] = (uint16_t)run;
+        run += v;
+      }
+      if (!BUILD && t > 0 && threadIdx.x <= mask_d) os_store(&tile_state[t * 256 + threadIdx.x], OS_AGG | run);
+      inc = wave_inclusive_sum<unsigned>(run);
       if (lane == 63) s_wtot[wave] = inc;
-      __syncthreads();
+    }
+    __syncthreads();
+    if (dig_thread) {
       unsigned base = 0;
       for (int w = 0; w < wave; w++) base += s_wtot[w];
       s_start[threadIdx.x] = (uint16_t)(base + inc - run);
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(BLOCK, (ITEMS > 8 ? 2 : 4)) void k_rp_pass(KeySet k
     if (threadIdx.x == 255) s_nst = (unsigned)s_start[255] + run;   // rows of the tile that take part (digit 255's run is the last)
     __syncthreads();
     const int n_staged = (int)s_nst;
-    for (int qq = threadIdx.x; qq < n_staged; qq += BLOCK) {
+    for (int qq = threadIdx.x; qq < n_staged; qq += THREADS) {
       const unsigned dst = (unsigned)qq + s_goff[s_dig[qq]];
       key_out[dst] = s_key[qq];   // (plain stores: neighbouring tiles' runs of a digit meet in the L2 — non-temporal ones cost + 30 % at 4096-row
       rid_out[dst] = s_rid[qq];   //  tiles and + 90 % at 2048-row tiles)
@@ -376,29 +386,39 @@ static RadixSide rj_partition(const Table& t, const std::vector<int>& key_cols, 
       dg.bits[p] = b;
       pos += b;
     }
-    const int items = option_int("join.radix_tile_items", 16) > 8 ? 16 : 8;   // rows per thread of a tile: 4096-row tiles write 16-row runs (128 B of keys)
-    const int64_t tile = (int64_t)BLOCK * items;
+    // tile shape: 512 threads x 8 rows (default), 256 x 16, or 256 x 8 — k_rp_pass
+    const int threads = option_int("join.radix_tile_threads", 512) >= 512 ? 512 : 256;
+    const int items = threads == 512 ? 8 : (option_int("join.radix_tile_items", 16) > 8 ? 16 : 8);
+    const int64_t tile = (int64_t)threads * items;
+    const int hist_items = (int)(tile / BLOCK);   // (the counting pass walks the same tiles with 256 threads)
     const int64_t n_tiles = (n + tile - 1) / tile;
     BufPtr counts = make_buf((size_t)256 * n_tiles * 4), offsets = make_buf(((size_t)256 * n_tiles + 1) * 8);
     BufPtr totals = make_zero_buf((size_t)RP_MAX_PASSES * 256 * 8 + 64);   // + the passes' tickets
     unsigned* tickets = reinterpret_cast<unsigned*>(totals->as<unsigned long long>() + RP_MAX_PASSES * 256);
-    const int wg_per_cu = items > 8 ? 2 : 4;
-    auto with_shape = [&](auto f) {
-      if (items > 8) {
-        if (exact) f(std::true_type{}, std::integral_constant<int, 16>{});
-        else f(std::false_type{}, std::integral_constant<int, 16>{});
+    const int wg_per_cu = threads == 512 ? 2 : items > 8 ? 2 : 4;
+    auto with_shape = [&](auto f) {   // f(exact, items, threads)
+      if (threads == 512) {
+        if (exact) f(std::true_type{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 512>{});
+        else f(std::false_type{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 512>{});
+      } else if (items > 8) {
+        if (exact) f(std::true_type{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 256>{});
+        else f(std::false_type{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 256>{});
       } else {
-        if (exact) f(std::true_type{}, std::integral_constant<int, 8>{});
-        else f(std::false_type{}, std::integral_constant<int, 8>{});
+        if (exact) f(std::true_type{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 256>{});
+        else f(std::false_type{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 256>{});
       }
     };
     {
       ProfileScope ps(what[0] == 'b' ? "radix_join_build_hist" : "radix_join_probe_hist", key_bytes);
       const int64_t n_groups = (n_tiles + RP_HIST_GROUP - 1) / RP_HIST_GROUP;
       const int hgrid = (int)std::min<int64_t>(n_groups, (int64_t)r.num_cus * 64);
-      with_shape([&](auto ex, auto it) {
-        k_rp_hist<decltype(ex)::value, decltype(it)::value><<<hgrid, BLOCK, 0, r.stream>>>(ks, mk, n, n_tiles, dg, counts->as<uint32_t>(), totals->as<unsigned long long>());
-      });
+      if (hist_items > 8) {
+        if (exact) k_rp_hist<true, 16><<<hgrid, BLOCK, 0, r.stream>>>(ks, mk, n, n_tiles, dg, counts->as<uint32_t>(), totals->as<unsigned long long>());
+        else k_rp_hist<false, 16><<<hgrid, BLOCK, 0, r.stream>>>(ks, mk, n, n_tiles, dg, counts->as<uint32_t>(), totals->as<unsigned long long>());
+      } else {
+        if (exact) k_rp_hist<true, 8><<<hgrid, BLOCK, 0, r.stream>>>(ks, mk, n, n_tiles, dg, counts->as<uint32_t>(), totals->as<unsigned long long>());
+        else k_rp_hist<false, 8><<<hgrid, BLOCK, 0, r.stream>>>(ks, mk, n, n_tiles, dg, counts->as<uint32_t>(), totals->as<unsigned long long>());
+      }
       DFGPU_HIP(hipGetLastError());
       scan_u32(counts->as<uint32_t>(), (int64_t)256 * n_tiles, offsets->as<uint64_t>());
     }
@@ -414,8 +434,8 @@ static RadixSide rj_partition(const Table& t, const std::vector<int>& key_cols, 
         ProfileScope ps("radix_join_partition_pass", key_bytes + s.n * 12);
         const int xcd_static = option_on("join.radix_xcd", true) ? 1 : 0;
         const int grid = (int)std::min<int64_t>((n_tiles + 7) / 8 * 8, (int64_t)r.num_cus * wg_per_cu);
-        with_shape([&](auto ex, auto it) {
-          k_rp_pass<true, decltype(ex)::value, decltype(it)::value><<<grid, BLOCK, 0, r.stream>>>(ks, mk, nullptr, nullptr, n, dg.shift[0], dg.bits[0], n_tiles, offsets->as<uint64_t>(),
+        with_shape([&](auto ex, auto it, auto th) {
+          k_rp_pass<true, decltype(ex)::value, decltype(it)::value, decltype(th)::value><<<grid, threads, 0, r.stream>>>(ks, mk, nullptr, nullptr, n, dg.shift[0], dg.bits[0], n_tiles, offsets->as<uint64_t>(),
                                                                                                    nullptr, nullptr, tickets, k0->as<uint64_t>(), r0->as<uint32_t>(), xcd_static);
         });
         DFGPU_HIP(hipGetLastError());
@@ -426,9 +446,9 @@ static RadixSide rj_partition(const Table& t, const std::vector<int>& key_cols, 
         ProfileScope ps("radix_join_partition_pass", s.n * 24);
         if (!state) state = make_buf((size_t)rec_tiles * 256 * 4);
         DFGPU_HIP(hipMemsetAsync(state->ptr, 0, (size_t)rec_tiles * 256 * 4, r.stream));
-        with_shape([&](auto ex, auto it) {
+        with_shape([&](auto ex, auto it, auto th) {
           (void)ex;
-          k_rp_pass<false, true, decltype(it)::value><<<rgrid, BLOCK, 0, r.stream>>>(ks, nullptr, k0->as<uint64_t>(), r0->as<uint32_t>(), s.n, dg.shift[p], dg.bits[p], rec_tiles, nullptr,
+          k_rp_pass<false, true, decltype(it)::value, decltype(th)::value><<<rgrid, threads, 0, r.stream>>>(ks, nullptr, k0->as<uint64_t>(), r0->as<uint32_t>(), s.n, dg.shift[p], dg.bits[p], rec_tiles, nullptr,
                                                                                       totals->as<unsigned long long>() + p * 256, state->as<uint32_t>(), tickets + p, k1->as<uint64_t>(),
                                                                                       r1->as<uint32_t>(), 0);
         });

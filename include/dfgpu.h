@@ -611,7 +611,7 @@ int dfgpu_agg_fused_updates(dfgpu_agg_t h, int64_t* out);
  *   join.grouped_probe = 0|1 (1), join.grouped_min_rows (rows worth a pass), join.beyond_cache_bytes (4 x the L2 of an XCD),
  *   join.grouped_bits, join.near_window (test hooks: 0 = derived)
  *   join.radix_onesweep = 0|1 (1: the LDS radix join partitions by two or three 8-bit passes straight off the key column; 0: round 5's
- *   record kernel + 6-bit passes), join.radix_tile_items = 8|16 (16: rows per thread of a partitioning tile), join.radix_fused_emit = 0|1 (1),
+ *   record kernel + 6-bit passes), join.radix_tile_threads = 256|512 (512) and join.radix_tile_items = 8|16 (with 256 threads; 16): the partitioning tile, 512 x 8 = 4096 rows by default, join.radix_fused_emit = 0|1 (1),
  *   join.radix_partition_rows (2400: build rows per LDS partition on average; test hook: small values give several passes on small inputs)
  *   sort.carried = o|i|p|0 (o), sort.carried_min_rows (rows worth a pass), sort.lsd = 0|1 (1: narrow keys sorted by record passes alone),
  *   sort.lsd_ahead = 0|1 (1: two-pass narrow-key sorts take their offsets from the digit-totals pass instead of a look-back)

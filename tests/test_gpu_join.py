@@ -432,8 +432,8 @@ def test_radix_lds_join_many_partitions_and_skew(shape):
 
 
 @pytest.mark.parametrize("keys", ["int64_nullable", "int32", "two_columns", "decimal128"])
-@pytest.mark.parametrize("opts", [dict(join__radix_partition_rows=8), dict(join__radix_partition_rows=1), dict(join__radix_partition_rows=8, join__radix_tile_items=8),
-                                  dict(join__radix_partition_rows=8, join__radix_onesweep=0)], ids=["two_passes", "three_passes", "tiles_of_2048", "six_bit_passes"])
+@pytest.mark.parametrize("opts", [dict(join__radix_partition_rows=8), dict(join__radix_partition_rows=1), dict(join__radix_partition_rows=8, join__radix_tile_threads=256, join__radix_tile_items=8), dict(join__radix_partition_rows=8, join__radix_tile_threads=256),
+                                  dict(join__radix_partition_rows=8, join__radix_onesweep=0)], ids=["two_passes", "three_passes", "tiles_256x8", "tiles_256x16", "six_bit_passes"])
 def test_radix_partitioner_passes_masks_and_key_kinds(keys, opts):
     """the radix join's partitioner (round 6: 8-bit passes straight off the key column, look-back from the second pass on) forced to two and to
     three passes on a 70 K-row build side, over NULL keys (the validity mask decides which rows become records), 32-bit keys, and keys that
