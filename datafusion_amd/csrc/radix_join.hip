@@ -544,7 +544,10 @@ __device__ __forceinline__ void rj_emit_row(const RjCols& cols, uint64_t key, ui
 // lanes to consecutive rows.  The order of a task's output rows is therefore arbitrary within the task (the radix join's output order is
 // not the probe's anyway).
 constexpr int RJ_WSTAGE = RJ_STAGE / (BLOCK / WAVE);
-template <bool EXACT, int EMIT>
+// BROW (EMIT == 2): some output column reads the build ROW (a payload column): its id is fetched in the write-out.  A compile-time switch: as a
+// run-time one the compiler guarded the unused load's register with s_waitcnt vmcnt(0) — every write-out round then waited for the stores of
+// the round before and for the prefetched probe tile (3.7 ms for the walk that costs the count pass 1.4).
+template <bool EXACT, int EMIT, bool BROW = true>
 __global__ __launch_bounds__(BLOCK) void k_rj_join(const uint64_t* __restrict__ bkey, const uint32_t* __restrict__ brid, const uint64_t* __restrict__ bstart,
                                                   const uint64_t* __restrict__ pkey, const uint32_t* __restrict__ prid, const RadixTask* __restrict__ tasks,
                                                   int64_t n_tasks, RjVerify v, unsigned long long* __restrict__ task_counts,
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(BLOCK) void k_rj_join(const uint64_t* __restrict__ 
           for (unsigned q = lane; q < listed; q += WAVE) {
             const uint32_t bi = w_ob[q], prow = w_op[q];
             if (EMIT == 2) {   // (EXACT: the record key of a match is the build row's)
-              const uint32_t brow = cols.need_brow ? brid[c0 + bi] : 0u;
+              const uint32_t brow = BROW ? brid[c0 + bi] : 0u;
               rj_emit_row(cols, s_key[bi], brow, prow, base + q);
             } else {
               out_b[base + q] = (int64_t)brid[c0 + bi];
@@ -733,8 +736,12 @@ static void radix_join_run(const RadixTable& t, const Table& build, const std::v
     for (int c = 0; c < cols.n; c++) row_bytes += cols.width[c];
     ProfileScope pse("radix_join_emit_columns", rec_bytes + m * row_bytes * 2);
     DFGPU_CHECK(t.exact, "internal: the fused column emit needs exact record keys");
-    k_rj_join<true, 2><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
-                                                     ps.rid->as<uint32_t>(), d_tasks->as<RadixTask>(), nt, v, nullptr, d_off->as<uint64_t>(), nullptr, nullptr, cols);
+    if (cols.need_brow)
+      k_rj_join<true, 2, true><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
+                                                             ps.rid->as<uint32_t>(), d_tasks->as<RadixTask>(), nt, v, nullptr, d_off->as<uint64_t>(), nullptr, nullptr, cols);
+    else
+      k_rj_join<true, 2, false><<<grid, BLOCK, 0, r.stream>>>(t.build.key->as<uint64_t>(), t.build.rid->as<uint32_t>(), t.build.starts->as<uint64_t>(), ps.key->as<uint64_t>(),
+                                                              ps.rid->as<uint32_t>(), d_tasks->as<RadixTask>(), nt, v, nullptr, d_off->as<uint64_t>(), nullptr, nullptr, cols);
     DFGPU_HIP(hipGetLastError());
     DFGPU_HIP(hipStreamSynchronize(r.stream));  // `off` and `tasks` are locals the copies read
     return;
