@@ -92,6 +92,59 @@ __device__ __forceinline__ void load_value(const AccDesc& d, int64_t i, uint64_t
   }
 }
 
+// the values of U rows of one argument column at once: the ValKind is asked ONCE, outside the unrolled loop, so the U loads leave back to
+// back (a switch per load puts every load in a basic block of its own with a wait behind it)
+template <int U>
+__device__ __forceinline__ void load_values_batch(int val, const void* values, const int64_t (&ii)[U], uint32_t live, uint64_t (&lo)[U], uint64_t (&hi)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; u++) lo[u] = hi[u] = 0;
+  switch (val) {
+    case VAL_I32:
+    case VAL_I32_TO_F64: {
+      int32_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = (live >> u) & 1u ? ((const int32_t*)values)[ii[u]] : 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (val == VAL_I32) { lo[u] = (uint64_t)(int64_t)v[u]; hi[u] = (uint64_t)((int64_t)v[u] >> 63); }
+        else lo[u] = (uint64_t)__double_as_longlong((double)v[u]);
+      }
+      break;
+    }
+    case VAL_U32:
+#pragma unroll
+      for (int u = 0; u < U; u++) lo[u] = (live >> u) & 1u ? ((const uint32_t*)values)[ii[u]] : 0u;
+      break;
+    case VAL_U8:
+#pragma unroll
+      for (int u = 0; u < U; u++) lo[u] = (live >> u) & 1u ? ((const uint8_t*)values)[ii[u]] : 0u;
+      break;
+    case VAL_I128: {
+      ulonglong2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = (live >> u) & 1u ? ((const ulonglong2*)values)[ii[u]] : make_ulonglong2(0ull, 0ull);
+#pragma unroll
+      for (int u = 0; u < U; u++) { lo[u] = v[u].x; hi[u] = v[u].y; }
+      break;
+    }
+    default: {   // the 64-bit kinds
+      uint64_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = (live >> u) & 1u ? ((const uint64_t*)values)[ii[u]] : 0ull;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        switch (val) {
+          case VAL_I64: lo[u] = v[u]; hi[u] = (uint64_t)((int64_t)v[u] >> 63); break;
+          case VAL_F64_ORDERED: lo[u] = (uint64_t)f64_ordered(__longlong_as_double((long long)v[u])); break;
+          case VAL_I64_TO_F64: lo[u] = (uint64_t)__double_as_longlong((double)(int64_t)v[u]); break;
+          default: lo[u] = v[u]; break;   // VAL_U64, VAL_F64
+        }
+      }
+      break;
+    }
+  }
+}
+
 // one accumulation into (lo, hi) cells that may live in LDS or HBM
 __device__ __forceinline__ void accumulate_cell(int kind, unsigned long long* lo_cell, unsigned long long* hi_cell, uint64_t lo, uint64_t hi) {
   switch (kind) {
@@ -689,6 +742,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit_set(EmitSet s, int64_t n, unsign
           case 2: ((double*)e.dst)[i] = ok ? f64_from_ordered((int64_t)e.lo[i]) : 0.0; break;
           case 3: ((int32_t*)e.dst)[i] = ok ? (int32_t)(int64_t)e.lo[i] : 0; break;
           case 4: ((uint8_t*)e.dst)[i] = ok ? (uint8_t)e.lo[i] : 0; break;
+          default: break;   // 5: the values are in place already (the runs node's interleaved cells), only the validity is made
         }
       } else {
         const unsigned long long c = e.cnt[i];
@@ -2164,6 +2218,75 @@ __global__ __launch_bounds__(BLOCK) void k_dense_keys(const uint64_t* __restrict
   }
 }
 
+// The partitioned accumulation's emit (round 6): the first row of every group is marked in `rep_mask` (one bit per INPUT row), so the
+// groups in first-seen order are the set bits in row order — group number = popcount prefix.  One thread per 64-row word walks its set
+// bits: the row's key comes from the key column where it lies (neighbouring bits share lines: all but a stream of the column), the
+// group's totals from the value-major cells (one line per group), and keys, accumulators and seen flags leave at consecutive group
+// numbers.  No per-value presence bitmap, no per-group first rows, no renumbering scatter (k_values_to_groups + k_mark_first_rows +
+// k_dense_permute + k_dense_keys + k_emit_values: 1.64 ms for 10 M groups of 150 M orders; this: one pass).
+constexpr int GE_TILE_WORDS = BLOCK;   // 64-row words per tile: 16384 rows, whose first-row marks become a list of at most that many 16-bit row numbers
+template <typename KT>
+__global__ __launch_bounds__(BLOCK) void k_dense_gather_emit(const uint64_t* __restrict__ rep_mask, const uint64_t* __restrict__ rprefix, int64_t row_words,
+                                                            const KT* __restrict__ key, long long kmin, const unsigned long long* __restrict__ cells_v, int ncw,
+                                                            DenseEmit e, KT* __restrict__ key_out) {
+  // (a thread per word that wrote its own groups kept one open line per lane and array — 2 M partly written lines on the chip, evicted
+  // before they filled: 0.94 ms.  The tile's marked rows go through a list in LDS instead: the groups of a tile leave in group order,
+  // whole lines per wave, four groups per thread in flight)
+  __shared__ uint16_t s_list[GE_TILE_WORDS * 64];
+  const int64_t n_tiles = (row_words + GE_TILE_WORDS - 1) / GE_TILE_WORDS;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t w0 = tile * GE_TILE_WORDS, w = w0 + threadIdx.x;
+    const int64_t w_end = w0 + GE_TILE_WORDS < row_words ? w0 + GE_TILE_WORDS : row_words;
+    const int64_t g0 = (int64_t)rprefix[w0], g1 = (int64_t)rprefix[w_end];
+    if (g1 == g0) continue;   // (uniform: no group's first row lies in this tile)
+    if (w < row_words) {
+      uint64_t m = rep_mask[w];
+      unsigned off = (unsigned)((int64_t)rprefix[w] - g0);
+      while (m) {
+        s_list[off++] = (uint16_t)((threadIdx.x << 6) | (unsigned)__builtin_ctzll(m));
+        m &= m - 1;
+      }
+    }
+    __syncthreads();
+    const unsigned cnt = (unsigned)(g1 - g0);
+    const int64_t row0 = w0 << 6;
+    constexpr int U = 4;
+    for (unsigned q0 = threadIdx.x; q0 < cnt; q0 += BLOCK * U) {
+      KT k[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const unsigned q = q0 + (unsigned)u * BLOCK;
+        ok[u] = q < cnt;
+        k[u] = key[row0 + s_list[ok[u] ? q : q0]];
+      }
+      const unsigned long long* c[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) c[u] = cells_v + (int64_t)((long long)k[u] - kmin) * ncw;
+      for (int d = 0; d < e.n_dst; d++) {
+        const int sw = e.src_word[d];
+        unsigned long long* dst = e.dst[d] + g0;
+        unsigned long long a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] = c[u][sw];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (ok[u]) dst[q0 + (unsigned)u * BLOCK] = a[u];
+      }
+      for (int d = 0; d < e.n_seen; d++) {
+        uint32_t* dst = e.seen_dst[d] + g0;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (ok[u]) dst[q0 + (unsigned)u * BLOCK] = 1u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (ok[u]) key_out[g0 + q0 + (unsigned)u * BLOCK] = k[u];
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- dense-key node, medium cardinality: partition, then LDS
 // One global atomic per (row, aggregate) is what dense_accumulate costs when neighbouring rows carry different keys — ~27 G
 // atomics/s on this part, 30 M rows x SUM = 1.36 ms where the bytes are worth 0.07 ms.  When key and arguments are columns as they
@@ -2193,13 +2316,18 @@ struct PartBlock {
   int32_t part;        // window number
   int32_t alone;       // no other workgroup works on this window
 };
+constexpr int PART_PRELOAD = 3;   // accumulators whose arguments are loaded together with the keys
 constexpr int PART_BLOCK = 1024;   // threads per workgroup: the windows' LDS leaves room for one or two workgroups per CU, so they are big
 template <typename KT>
 __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const PartBlock* __restrict__ blocks, const KT* __restrict__ key, const uint32_t* __restrict__ row_id,
                                                                  PartAccSet accs, long long kmin, int wshift, unsigned long long* __restrict__ cells_v,
                                                                  int64_t vstride, uint64_t vrange, uint32_t* __restrict__ first_row_v,
                                                                  const uint64_t* __restrict__ row_mask, const uint64_t* __restrict__ row_mask_valid, int rows_in_place,
-                                                                 const uint32_t* __restrict__ key_map, int key_map_lds) {
+                                                                 const uint32_t* __restrict__ key_map, int key_map_lds, int64_t istride,
+                                                                 unsigned long long* __restrict__ rep_mask) {
+  // cell word w of value v lives at cells_v[w * vstride + v * istride]: word-major (vstride = values, istride = 1) or value-major
+  // (vstride = 1, istride = words: what the gathering emit reads — one line per group).  rep_mask (every window has ONE workgroup):
+  // the first row of every value that has one is marked here, one bit per input row — the first-seen order falls out of its popcounts
   extern __shared__ unsigned long long s_mem[];
   const int W = 1 << wshift;
   unsigned long long* s_cell = s_mem;                                   // [ncw][W]
@@ -2238,9 +2366,24 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
       if (ok) live |= 1u << u;
     }
     if (!live) continue;
+    // EVERYTHING the iteration reads from HBM leaves now: the keys, the rows' numbers and the first PART_PRELOAD accumulators' arguments
+    // (round 6: keys -> row numbers -> one accumulator's arguments after the other were three and more memory round trips per iteration
+    // at four waves per SIMD — 7.5 us per 4096 rows, 1.08 ms for 150 M orders whose bytes are worth 0.35)
     KT kraw[U];
 #pragma unroll
     for (int u = 0; u < U; u++) kraw[u] = (live >> u) & 1u ? key[ii[u]] : KT(0);
+    uint32_t rid[U];
+    if (row_id) {
+#pragma unroll
+      for (int u = 0; u < U; u++) rid[u] = (live >> u) & 1u ? row_id[ii[u]] : 0u;
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) rid[u] = (uint32_t)ii[u];
+    }
+    uint64_t plo[PART_PRELOAD][U], phi[PART_PRELOAD][U];
+#pragma unroll
+    for (int k = 0; k < PART_PRELOAD; k++)
+      if (k < accs.n && accs.a[k].data && !part_acc_is_count(accs.a[k].kind)) load_values_batch<U>(accs.a[k].val, accs.a[k].data, ii, live, plo[k], phi[k]);
     int x[U];
     // (key_map: the key column holds table slots, the value is the slot's group number — hash-interned groups in place; its 16-bit
     // copy in LDS when the launch had room for one)
@@ -2256,28 +2399,10 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
 #pragma unroll
     for (int u = 0; u < U; u++) {
       if (!((live >> u) & 1u)) continue;
-      if (row_id || rows_in_place) atomicMin(&s_first[x[u]], row_id ? row_id[ii[u]] : (uint32_t)ii[u]);
+      if (row_id || rows_in_place) atomicMin(&s_first[x[u]], rid[u]);
       else s_first[x[u]] = 0u;   // (no first rows wanted: a mark that the value has a row — a plain store, every writer's the same)
     }
-    for (int k = 0; k < accs.n; k++) {
-      const PartAcc& a = accs.a[k];
-      if (part_acc_is_count(a.kind)) {
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          if ((live >> u) & 1u) atomicAdd(&s_c32[(size_t)a.lcell32 * W + x[u]], 1u);
-        continue;
-      }
-      uint64_t lo[U], hi[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        lo[u] = hi[u] = 0;
-        if (a.data && ((live >> u) & 1u)) {
-          AccDesc d{};
-          d.values = a.data;
-          d.val = a.val;
-          load_value(d, ii[u], lo[u], hi[u]);
-        }
-      }
+    auto accumulate_rows = [&](const PartAcc& a, const uint64_t (&lo)[U], const uint64_t (&hi)[U]) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (!((live >> u) & 1u)) continue;
@@ -2290,6 +2415,38 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
         }
         accumulate_cell(a.kind, c, c + W, lo[u], hi[u]);   // (LDS cells)
       }
+    };
+#pragma unroll
+    for (int k = 0; k < PART_PRELOAD; k++) {
+      if (k >= accs.n) continue;
+      const PartAcc& a = accs.a[k];
+      if (part_acc_is_count(a.kind)) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if ((live >> u) & 1u) atomicAdd(&s_c32[(size_t)a.lcell32 * W + x[u]], 1u);
+        continue;
+      }
+      if (!a.data) {
+#pragma unroll
+        for (int u = 0; u < U; u++) plo[k][u] = phi[k][u] = 0;
+      }
+      accumulate_rows(a, plo[k], phi[k]);
+    }
+    for (int k = PART_PRELOAD; k < accs.n; k++) {   // further accumulators: one batch of loads each
+      const PartAcc& a = accs.a[k];
+      if (part_acc_is_count(a.kind)) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if ((live >> u) & 1u) atomicAdd(&s_c32[(size_t)a.lcell32 * W + x[u]], 1u);
+        continue;
+      }
+      uint64_t lo[U], hi[U];
+      if (a.data) load_values_batch<U>(a.val, a.data, ii, live, lo, hi);
+      else {
+#pragma unroll
+        for (int u = 0; u < U; u++) lo[u] = hi[u] = 0;
+      }
+      accumulate_rows(a, lo, hi);
     }
   }
   __syncthreads();
@@ -2307,12 +2464,18 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
       return a.narrow ? (unsigned long long)(long long)(int32_t)s_c32[(size_t)a.lcell32 * W + x] : s_cell[(size_t)(a.lcell + 1) * W + x];
     };
     if (b.alone) {   // the window's only workgroup: its values belong to nobody else — plain, coalesced stores
-      if (accs.track_first) first_row_v[idx] = fr;
+      if (accs.track_first) {
+        if (rep_mask) {
+          if (fr != 0xFFFFFFFFu) atomicOr(&rep_mask[fr >> 6], 1ull << (fr & 63));
+        } else {
+          first_row_v[idx] = fr;
+        }
+      }
       if (fr != 0xFFFFFFFFu)
         for (int k = 0; k < accs.n; k++) {
           const PartAcc& a = accs.a[k];
-          cells_v[(int64_t)a.cell * vstride + (int64_t)idx] = total_lo(a);
-          if (a.kind == ACC_SUM_I128) cells_v[(int64_t)(a.cell + 1) * vstride + (int64_t)idx] = total_hi(a);
+          cells_v[(int64_t)a.cell * vstride + (int64_t)idx * istride] = total_lo(a);
+          if (a.kind == ACC_SUM_I128) cells_v[(int64_t)(a.cell + 1) * vstride + (int64_t)idx * istride] = total_hi(a);
         }
       continue;
     }
@@ -2321,7 +2484,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
     for (int k = 0; k < accs.n; k++) {
       const PartAcc& a = accs.a[k];
       const unsigned long long v = total_lo(a);
-      unsigned long long* c = cells_v + (int64_t)a.cell * vstride + (int64_t)idx;
+      unsigned long long* c = cells_v + (int64_t)a.cell * vstride + (int64_t)idx * istride;
       switch (a.kind) {
         case ACC_SUM_I128: {
           const unsigned long long old = atomicAdd(c, v);
@@ -2380,8 +2543,13 @@ __global__ __launch_bounds__(BLOCK) void k_row_ids(int64_t n, uint32_t* __restri
 // acc_col[u]: input column of accumulator u's argument (-1 = none: the counts; -2 = an expression), acc_val[u]: its ValKind.
 struct PartValues {     // what the partitioned accumulation leaves: totals and first rows per VALUE of the key range
   BufPtr first_row_v;   // u32 [vstride], 0xFFFFFFFF = no row has this value
-  BufPtr cells_v;       // u64 [ncw][vstride]
+  BufPtr cells_v;       // u64 [ncw][vstride] — or, value_major, [vstride][ncw]
   int64_t vstride = 0;
+  // asked for by the caller (want_rep_mask) and granted when every window had ONE workgroup: the first rows were marked straight into
+  // a bitmap over the input rows (no first_row_v), the cells lie value-major
+  bool want_rep_mask = false;
+  BufPtr rep_mask;      // u64 [(n_in + 63) / 64]
+  bool value_major = false;
 };
 static int part_val_width(int val) {
   switch (val) {
@@ -2585,11 +2753,17 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   }
   }
   out.vstride = ((int64_t)range + 63) / 64 * 64;
-  out.first_row_v = make_buf((size_t)out.vstride * 4);
-  DFGPU_HIP(hipMemsetAsync(out.first_row_v->ptr, 0xFF, (size_t)out.vstride * 4, r.stream));   // (windows without a row have no workgroup)
-  out.cells_v = make_buf((size_t)std::max(1, ncw) * (size_t)out.vstride * 8);
   bool any_chunked = false;
   for (const PartBlock& b : blocks) any_chunked |= !b.alone;
+  const bool mark = out.want_rep_mask && want_first_rows && !in_place && !any_chunked;
+  if (mark) {
+    out.rep_mask = make_zero_buf((size_t)((n_in + 63) / 64 + 1) * 8);
+    out.value_major = true;
+  } else {
+    out.first_row_v = make_buf((size_t)out.vstride * 4);
+    DFGPU_HIP(hipMemsetAsync(out.first_row_v->ptr, 0xFF, (size_t)out.vstride * 4, r.stream));   // (windows without a row have no workgroup)
+  }
+  out.cells_v = make_buf((size_t)std::max(1, ncw) * (size_t)out.vstride * 8);
   if (any_chunked)   // chunks of one window merge through atomics: their cells start from the identities
     for (size_t u = 0; u < all.size(); u++) {
       k_fill_u64<<<grid_for(out.vstride, BLOCK), BLOCK, 0, r.stream>>>(acc_identity(all[u].kind), out.vstride, out.cells_v->as<unsigned long long>() + (int64_t)all[u].cell * out.vstride);
@@ -2610,7 +2784,9 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     const int ip = in_place && want_first_rows ? 1 : 0;
     const int nb = (int)blocks.size();
     unsigned long long* cv = out.cells_v->as<unsigned long long>();
-    uint32_t* fv = out.first_row_v->as<uint32_t>();
+    uint32_t* fv = mark ? nullptr : out.first_row_v->as<uint32_t>();
+    unsigned long long* rm = mark ? out.rep_mask->as<unsigned long long>() : nullptr;
+    const int64_t wstride = out.value_major ? 1 : out.vstride, istride = out.value_major ? (int64_t)std::max(1, ncw) : 1;
     size_t u = 0;
     bool first_launch = true;
     while (u < all.size()) {
@@ -2638,10 +2814,10 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
         lds_bytes += (size_t)key_map_n * 2 + 8;
       }
       switch (kt) {
-        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_lds); break;
-        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_lds); break;
-        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_lds); break;
-        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, out.vstride, range, fv, km, kmv, ip, key_map, map_lds); break;
+        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm); break;
+        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm); break;
+        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm); break;
+        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm); break;
       }
       DFGPU_HIP(hipGetLastError());
       first_launch = false;
@@ -2980,7 +3156,67 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   // (dense_accumulate_partitioned: totals and first rows per value of the range); which values exist then falls out of the first
   // rows, and the per-value totals are compacted into the groups' cells — no pass that sets bits, no accumulation by global atomics
   PartValues pv;
+  pv.want_rep_mask = option_on("agg.gather_emit", true);   // (A/B switch)
   const bool by_parts = any_rows && !null_group && dense_accumulate_partitioned(A, in, pred, accs, acc_col, acc_val, acc_agg, ncw, args.kmin, range, pv);
+  // the emit of both forms: where every aggregate's words go (the accumulators exist once the group count is known)
+  auto dense_emit_of = [&]() {
+    DenseEmit e{};
+    for (const Ent& en : entries) {
+      AggState& a = A.aggs[(size_t)en.agg];
+      if (en.is_avg_count) {
+        e.dst[e.n_dst] = a.cnt->as<unsigned long long>();
+        e.src_word[e.n_dst++] = en.cell;
+      } else {
+        e.dst[e.n_dst] = a.lo->as<unsigned long long>();
+        e.src_word[e.n_dst++] = en.cell;
+        if (en.kind == ACC_SUM_I128) {
+          e.dst[e.n_dst] = a.hi->as<unsigned long long>();
+          e.src_word[e.n_dst++] = en.cell + 1;
+        }
+        e.seen_dst[e.n_seen] = a.seen->as<uint32_t>();
+        e.seen_bit[e.n_seen++] = en.seen_bit;
+      }
+    }
+    return e;
+  };
+  if (by_parts && pv.rep_mask) {
+    // every window had one workgroup: the first rows are marked over the input rows, the totals lie value-major — the groups in
+    // first-seen order (group_values/mod.rs:88-92) are gathered in one pass (k_dense_gather_emit)
+    const int64_t row_words = (n + 63) / 64;
+    BufPtr rprefix = make_buf((size_t)(row_words + 1) * 8);
+    scan_mask_popcounts(pv.rep_mask->as<uint64_t>(), nullptr, n, rprefix->as<uint64_t>());
+    const int64_t G = (int64_t)read_u64(rprefix->as<uint64_t>() + row_words);
+    grow_accumulators(A, 0, G, /*init=*/false);   // every cell of every group is written by the gather
+    const DenseEmit e = dense_emit_of();
+    int kci = -1;   // (dense_accumulate_partitioned: the key is a column as it stands, without NULLs)
+    DFGPU_CHECK(is_plain_column(A.group_nodes[0], A.group_roots[0], &kci) && kci >= 0 && kci < (int)in.cols.size(), "internal: the partitioned node's key is not a column");
+    const Column& kin = in.cols[(size_t)kci];
+    Column kc = alloc_column(kf, A.group_names[0], G);
+    kc.dict = kin.dict;
+    if (G) {
+      ProfileScope ps("agg_dense_gather_emit", n * type_width(kf.type) + G * (type_width(kf.type) + 16 * (int64_t)e.n_dst + 4 * (int64_t)e.n_seen));
+      const int g = (int)std::min<int64_t>((row_words + GE_TILE_WORDS - 1) / GE_TILE_WORDS, 2048);
+      const uint64_t* rm = pv.rep_mask->as<uint64_t>();
+      const uint64_t* rp = rprefix->as<uint64_t>();
+      const unsigned long long* cv = pv.cells_v->as<unsigned long long>();
+      switch (type_width(kf.type)) {
+        case 8: k_dense_gather_emit<int64_t><<<g, BLOCK, 0, r.stream>>>(rm, rp, row_words, (const int64_t*)kin.ptr(), args.kmin, cv, std::max(1, ncw), e, (int64_t*)kc.data->ptr); break;
+        case 1: k_dense_gather_emit<uint8_t><<<g, BLOCK, 0, r.stream>>>(rm, rp, row_words, (const uint8_t*)kin.ptr(), args.kmin, cv, std::max(1, ncw), e, (uint8_t*)kc.data->ptr); break;
+        default:
+          if (kf.type == DFGPU_UINT32) k_dense_gather_emit<uint32_t><<<g, BLOCK, 0, r.stream>>>(rm, rp, row_words, (const uint32_t*)kin.ptr(), args.kmin, cv, std::max(1, ncw), e, (uint32_t*)kc.data->ptr);
+          else k_dense_gather_emit<int32_t><<<g, BLOCK, 0, r.stream>>>(rm, rp, row_words, (const int32_t*)kin.ptr(), args.kmin, cv, std::max(1, ncw), e, (int32_t*)kc.data->ptr);
+          break;
+      }
+      DFGPU_HIP(hipGetLastError());
+    }
+    Table gk;
+    gk.nrows = G;
+    gk.cols.push_back(std::move(kc));
+    A.group_keys = std::move(gk);
+    A.ngroups = G;
+    DFGPU_HIP(hipStreamSynchronize(r.stream));   // (the moved cells and the marks are locals)
+    return true;
+  }
   if (by_parts) {
     k_presence_bits<<<grid_for(n_words, BLOCK / WAVE), BLOCK, 0, r.stream>>>(pv.first_row_v->as<uint32_t>(), range, n_words, bits->as<uint64_t>());
     DFGPU_HIP(hipGetLastError());
@@ -3025,23 +3261,7 @@ static bool agg_update_dense_key_jit(Aggregate& A, const Table& in, const dfgpu_
   scan_mask_popcounts(rep_mask->as<uint64_t>(), nullptr, n, rprefix->as<uint64_t>());
   DFGPU_CHECK((int64_t)read_u64(rprefix->as<uint64_t>() + row_words) == G, "dense-key node: first-row marks do not match the group count");
   grow_accumulators(A, 0, G, /*init=*/false);  // new_gid is a permutation of 0..G-1: k_dense_permute writes every cell
-  DenseEmit e{};
-  for (const Ent& en : entries) {
-    AggState& a = A.aggs[(size_t)en.agg];
-    if (en.is_avg_count) {
-      e.dst[e.n_dst] = a.cnt->as<unsigned long long>();
-      e.src_word[e.n_dst++] = en.cell;
-    } else {
-      e.dst[e.n_dst] = a.lo->as<unsigned long long>();
-      e.src_word[e.n_dst++] = en.cell;
-      if (en.kind == ACC_SUM_I128) {
-        e.dst[e.n_dst] = a.hi->as<unsigned long long>();
-        e.src_word[e.n_dst++] = en.cell + 1;
-      }
-      e.seen_dst[e.n_seen] = a.seen->as<uint32_t>();
-      e.seen_bit[e.n_seen++] = en.seen_bit;
-    }
-  }
+  const DenseEmit e = dense_emit_of();
   BufPtr new_gid = make_buf((size_t)std::max<int64_t>(G, 1) * 4);
   BufPtr key_i64 = make_zero_buf((size_t)std::max<int64_t>(G, 1) * 8);
   if (G) {
@@ -4414,13 +4634,18 @@ static Table agg_emit(Aggregate& A) {
       c.name = out_name;
       c.length = G;
       c.data = a.inter;
-      BufPtr vb = make_buf((size_t)G + 64);
-      k_seen_bytes<<<grid_for(G, BLOCK), BLOCK, 0, r.stream>>>(a.seen->as<uint32_t>(), G, vb->as<uint8_t>());
-      DFGPU_HIP(hipGetLastError());
+      // the validity words and the count of valid groups come from the seen flags in k_emit_set's pass (mode 5: no value is written) —
+      // a byte per group, the packing of the bytes and a count over the words were three passes over 150 M groups (0.40 of 5.8 ms)
+      DFGPU_CHECK(eset.n < EMIT_MAX, "too many aggregate output columns for one GPU aggregate node");
       c.validity = make_buf(bitmap_bytes(G));
-      pack_bytes_to_bitmap(vb->as<uint8_t>(), G, c.validity->as<uint64_t>());
       c.null_count = -1;
-      count_nulls(c);
+      EmitEntry& e = eset.e[eset.n++];
+      e = EmitEntry{};
+      e.kind = 0;
+      e.mode = 5;
+      e.seen = a.seen->as<uint32_t>();
+      e.valid_words = c.validity->as<uint64_t>();
+      pending.push_back(out.cols.size());
       out.cols.push_back(std::move(c));
       continue;
     }

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_gp_scatter(KeyCol key, int64_t
           const unsigned g = gr[c] >> GP_RANK_BITS, r = gr[c] & ((1u << GP_RANK_BITS) - 1u);
           pos[c] = (unsigned)s_start[g] + r;
           reinterpret_cast<uint64_t*>(s_stage)[pos[c]] = k[c];
-          if (carry) s_g[pos[c]] = (uint16_t)g;
+          if (carry && !out_keys) s_g[pos[c]] = (uint16_t)g;   // (a staged key says its own group)
           if (dest) dest[i] = pos[c] + s_delta[g];
         } else if (dest && i < hi) {
           dest[i] = 0xFFFFFFFFu;
@@ -183,40 +183,84 @@ __global__ __launch_bounds__(THREADS, WPS) void k_gp_scatter(KeyCol key, int64_t
         }
       }
       __syncthreads();
-      if (out_keys) {
-        for (unsigned q = threadIdx.x; q < total; q += THREADS) {
-          const uint64_t kq = reinterpret_cast<const uint64_t*>(s_stage)[q];
-          const unsigned g = (unsigned)__umul64hi(kq - gs.offset, gs.mul);   // (a key says its own group: no table of groups per staged row)
-          // (narrow_keys: key - offset as 32 bits — a range below 2^32 moves half the key bytes)
-          if (narrow_keys) reinterpret_cast<uint32_t*>(out_keys)[(uint64_t)(q + s_delta[g])] = (uint32_t)(kq - gs.offset);
-          else out_keys[(uint64_t)(q + s_delta[g])] = kq;
+      // where every staged position goes — worked out ONCE per tile and kept in registers for the carried columns (round 6: every column's
+      // write-out used to look its rows' groups and the groups' deltas up again: two LDS reads per row and column of a pass that is bound
+      // by its LDS work).  A staged key says its own group; without staged keys the group comes from s_g.
+      unsigned dq[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; j++) {
+        const unsigned q = threadIdx.x + (unsigned)j * THREADS;
+        dq[j] = 0xFFFFFFFFu;
+        if (q < total) {
+          if (out_keys) {
+            const uint64_t kq = reinterpret_cast<const uint64_t*>(s_stage)[q];
+            const unsigned d = q + s_delta[(unsigned)__umul64hi(kq - gs.offset, gs.mul)];
+            dq[j] = d;
+            // (narrow_keys: key - offset as 32 bits — a range below 2^32 moves half the key bytes)
+            if (narrow_keys) reinterpret_cast<uint32_t*>(out_keys)[d] = (uint32_t)(kq - gs.offset);
+            else out_keys[d] = kq;
+          } else if (carry) {
+            dq[j] = q + s_delta[s_g[q]];
+          }
         }
       }
-      // ---- carried columns: the same route, one after the other through the same staging buffer
+      // ---- carried columns: the same route, one after the other through the same staging buffer (the width is asked once per column,
+      // outside the unrolled loops: the tile's loads leave back to back)
       for (int cc = 0; cc < cols.n; cc++) {
         __syncthreads();
         const int w = cols.width[cc];
+        const void* csrc = cols.src[cc];
+        void* cdst = cols.dst[cc];
+        if (w == 16) {
 #pragma unroll
-        for (int c = 0; c < ITEMS; c++) {
-          if (pos[c] == 0xFFFFFFFFu) continue;
-          const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
-          switch (w) {
-            case 16: reinterpret_cast<uint4*>(s_stage)[pos[c]] = reinterpret_cast<const uint4*>(cols.src[cc])[i]; break;
-            case 8: reinterpret_cast<uint64_t*>(s_stage)[pos[c]] = reinterpret_cast<const uint64_t*>(cols.src[cc])[i]; break;
-            case 4: reinterpret_cast<uint32_t*>(s_stage)[pos[c]] = cols.src[cc] ? reinterpret_cast<const uint32_t*>(cols.src[cc])[i] : (uint32_t)i; break;   // (no source: the row's number)
-            default: s_stage[pos[c]] = reinterpret_cast<const uint8_t*>(cols.src[cc])[i]; break;
+          for (int c = 0; c < ITEMS; c++) {
+            const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+            if (pos[c] != 0xFFFFFFFFu) reinterpret_cast<uint4*>(s_stage)[pos[c]] = reinterpret_cast<const uint4*>(csrc)[i];
           }
+        } else if (w == 8) {
+#pragma unroll
+          for (int c = 0; c < ITEMS; c++) {
+            const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+            if (pos[c] != 0xFFFFFFFFu) reinterpret_cast<uint64_t*>(s_stage)[pos[c]] = reinterpret_cast<const uint64_t*>(csrc)[i];
+          }
+        } else if (w == 4) {
+          uint32_t v[ITEMS];
+#pragma unroll
+          for (int c = 0; c < ITEMS; c++) {
+            const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+            if (pos[c] != 0xFFFFFFFFu) v[c] = csrc ? reinterpret_cast<const uint32_t*>(csrc)[i] : (uint32_t)i;   // (no source: the row's number)
+          }
+#pragma unroll
+          for (int c = 0; c < ITEMS; c++)
+            if (pos[c] != 0xFFFFFFFFu) reinterpret_cast<uint32_t*>(s_stage)[pos[c]] = v[c];
+        } else {
+          uint8_t v[ITEMS];
+#pragma unroll
+          for (int c = 0; c < ITEMS; c++) {
+            const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+            if (pos[c] != 0xFFFFFFFFu) v[c] = reinterpret_cast<const uint8_t*>(csrc)[i];
+          }
+#pragma unroll
+          for (int c = 0; c < ITEMS; c++)
+            if (pos[c] != 0xFFFFFFFFu) s_stage[pos[c]] = v[c];
         }
         __syncthreads();
-        for (unsigned q = threadIdx.x; q < total; q += THREADS) {
-          const unsigned g = s_g[q];
-          const uint64_t d = (uint64_t)(q + s_delta[g]);
-          switch (w) {
-            case 16: reinterpret_cast<uint4*>(cols.dst[cc])[d] = reinterpret_cast<const uint4*>(s_stage)[q]; break;
-            case 8: reinterpret_cast<uint64_t*>(cols.dst[cc])[d] = reinterpret_cast<const uint64_t*>(s_stage)[q]; break;
-            case 4: reinterpret_cast<uint32_t*>(cols.dst[cc])[d] = reinterpret_cast<const uint32_t*>(s_stage)[q]; break;
-            default: reinterpret_cast<uint8_t*>(cols.dst[cc])[d] = s_stage[q]; break;
-          }
+        if (w == 16) {
+#pragma unroll
+          for (int j = 0; j < ITEMS; j++)
+            if (dq[j] != 0xFFFFFFFFu) reinterpret_cast<uint4*>(cdst)[dq[j]] = reinterpret_cast<const uint4*>(s_stage)[threadIdx.x + (unsigned)j * THREADS];
+        } else if (w == 8) {
+#pragma unroll
+          for (int j = 0; j < ITEMS; j++)
+            if (dq[j] != 0xFFFFFFFFu) reinterpret_cast<uint64_t*>(cdst)[dq[j]] = reinterpret_cast<const uint64_t*>(s_stage)[threadIdx.x + (unsigned)j * THREADS];
+        } else if (w == 4) {
+#pragma unroll
+          for (int j = 0; j < ITEMS; j++)
+            if (dq[j] != 0xFFFFFFFFu) reinterpret_cast<uint32_t*>(cdst)[dq[j]] = reinterpret_cast<const uint32_t*>(s_stage)[threadIdx.x + (unsigned)j * THREADS];
+        } else {
+#pragma unroll
+          for (int j = 0; j < ITEMS; j++)
+            if (dq[j] != 0xFFFFFFFFu) reinterpret_cast<uint8_t*>(cdst)[dq[j]] = s_stage[threadIdx.x + (unsigned)j * THREADS];
         }
       }
       __syncthreads();
