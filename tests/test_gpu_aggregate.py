@@ -453,6 +453,52 @@ def test_medium_cardinality_group_by_over_a_wide_key_range_moves_the_rows_twice(
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["gather", "renumber_forced", "skewed_windows"])
+def test_partitioned_group_by_emits_groups_in_first_seen_order_by_either_form(case):
+    """the two emits of the partitioned dense-key node: when every key window had ONE workgroup, the first rows are marked over the
+    input rows by the accumulation itself and the groups are gathered in first-seen order by one pass over the marks (round 6); when
+    a window's rows were split over several workgroups (skew: half of the rows in the first two thousand keys) or agg.gather_emit=0,
+    per-value first rows are merged and the groups renumbered (rounds 3-5).  Same groups, order and values either way."""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(61)
+    n, distinct = 6_000_000, 300_000
+    codes = rng.integers(0, distinct, n)
+    if case == "skewed_windows":
+        codes[: n // 2] = rng.integers(0, 2000, n // 2)
+        rng.shuffle(codes)
+    v = rng.integers(-10**6, 10**6, n)
+    d = rng.integers(0, 3000, n).astype(np.int32)
+    t = DeviceTable.from_arrow(pa.table({"k": pa.array(codes * 3 + 5), "v": pa.array(v), "d": pa.array(d, pa.date32())}))
+    try:
+        ops.set_options(agg__partitioned_min_rows="1000000")
+        if case == "renumber_forced":
+            ops.set_options(agg__gather_emit="0")
+        ops.profile_enable(True)
+        ops.profile_reset()
+        got = ops.aggregate(t, [(col("k"), "k")], [("count", None, "n"), ("sum", col("v"), "sv"), ("min", col("d"), "first_day"), ("avg", col("v"), "av")], "Single").to_arrow()
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+    finally:
+        ops.reset_options()
+    assert "agg_dense_accumulate_partitioned" in stats and "agg_dense_accumulate" not in stats, sorted(stats)
+    assert ("agg_dense_gather_emit" in stats) == (case == "gather") and ("agg_dense_emit" in stats) == (case != "gather"), sorted(stats)
+    first = np.full(distinct, n, dtype=np.int64)
+    np.minimum.at(first, codes, np.arange(n))
+    present = np.nonzero(first < n)[0]
+    order = present[np.argsort(first[present], kind="stable")]
+    cnt = np.bincount(codes, minlength=distinct)
+    sv = np.zeros(distinct, dtype=np.int64); np.add.at(sv, codes, v)
+    lo = np.full(distinct, 10**6, dtype=np.int64); np.minimum.at(lo, codes, d)
+    assert got.column("k").to_pylist() == (order * 3 + 5).tolist()
+    assert got.column("n").to_pylist() == cnt[order].tolist()
+    assert got.column("sv").to_pylist() == sv[order].tolist()
+    assert got.column("first_day").cast(pa.int32()).to_pylist() == lo[order].tolist()
+    assert np.allclose(got.column("av").to_numpy(), sv[order] / cnt[order], rtol=1e-12)
+
+
+@pytest.mark.gpu
 def test_final_merge_of_many_partial_states_moves_rows_by_group_number():
     """Final over millions of partial-state rows with a two-column key (hash-interned groups): every row's group number is looked up
     once, the rows are moved into LDS-sized windows of group numbers, accumulated there and merged per group — SUM / AVG / COUNT / MIN

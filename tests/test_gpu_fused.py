@@ -194,12 +194,14 @@ RUN_AGGS = lambda col: [("sum", col("d"), "sd"), ("avg", col("d"), "ad"), ("coun
                         ("max", col("i"), "mx"), ("sum", col("f"), "sf"), ("avg", col("i"), "ai"), ("sum", col("d") * col("d"), "sdd")]
 
 
+@pytest.mark.parametrize("max_blocks", [None, 1, 3], ids=["a_wave_per_word", "four_waves_walk_all_words", "twelve_waves"])
 @pytest.mark.parametrize("null_frac", [0.0, 0.2])
 @pytest.mark.parametrize("shape", ["short", "word_edges", "long", "mixed", "single", "all_distinct"])
-def test_ordered_group_key_runs_node(shape, null_frac):
+def test_ordered_group_key_runs_node(shape, null_frac, max_blocks):
     """GROUP BY a key that arrives in order: the runs node (k_run_heads -> scan -> runs_accumulate).  Run shapes cover runs inside
     one 64-row word, runs ending exactly at word edges, runs finished by the previous word's wave, runs longer than two words
-    (the atomic path) and the partial last word"""
+    (the atomic path) and the partial last word.  max_blocks: the launch held to a few waves, so that every wave walks many words
+    of the table one after the other (what a wave does over 600 M rows)"""
     import os
 
     from datafusion_amd import ops
@@ -211,6 +213,8 @@ def test_ordered_group_key_runs_node(shape, null_frac):
     t = _runs_table(rng, lengths, null_frac=null_frac)
     try:
         ops.set_options(jit="1", jit__min_rows="0", jit__strict="1", agg__runs="1")
+        if max_blocks:
+            ops.set_options(agg__runs_max_blocks=max_blocks)
         ops.profile_enable(True)
         ops.profile_reset()
         got, fused = gpu(t, [(col("k"), "k")], RUN_AGGS(col))
