@@ -307,6 +307,8 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
   // Tile shape: 1024 threads x 8 rows = 8192-row tiles (runs of 8192 / P rows), the next tile's keys prefetched, one workgroup per CU.
   // Measured against it (profiles/r4_group_rows.md) and dropped: the same tile without the prefetch at two workgroups per CU (+ 5 %),
   // 512 threads x 8 rows at three per CU (half the run length: + 13 %) — the pass is bound by its LDS work, not by latency.
+  // Round 6, also dropped: 16384-row tiles with 32-bit key registers (runs of twice the length): 16 rows per thread spill (148-620 bytes of
+  // scratch per lane at the 128 VGPRs four waves per SIMD leave) — 2.55 against 2.25 ms for 150 M orders into 1831 windows.
   constexpr int THREADS = 1024;
   constexpr int ITEMS = 8;
   const int TILE = THREADS * ITEMS;
