@@ -2224,7 +2224,10 @@ __global__ __launch_bounds__(BLOCK) void k_dense_keys(const uint64_t* __restrict
 // group's totals from the value-major cells (one line per group), and keys, accumulators and seen flags leave at consecutive group
 // numbers.  No per-value presence bitmap, no per-group first rows, no renumbering scatter (k_values_to_groups + k_mark_first_rows +
 // k_dense_permute + k_dense_keys + k_emit_values: 1.64 ms for 10 M groups of 150 M orders; this: one pass).
-constexpr int GE_TILE_WORDS = BLOCK;   // 64-row words per tile: 16384 rows, whose first-row marks become a list of at most that many 16-bit row numbers
+// 64-row words per tile: 4096 rows, whose first-row marks become a list of at most that many 16-bit row numbers.  (16384-row tiles: the
+// tiles dense with first rows — the table's beginning — fell to a third of the workgroups, whose random cell reads then ran at 36 G/s:
+// 0.47 ms for 10 M groups, 0.28 of it those reads)
+constexpr int GE_TILE_WORDS = 64;
 template <typename KT>
 __global__ __launch_bounds__(BLOCK) void k_dense_gather_emit(const uint64_t* __restrict__ rep_mask, const uint64_t* __restrict__ rprefix, int64_t row_words,
                                                             const KT* __restrict__ key, long long kmin, const unsigned long long* __restrict__ cells_v, int ncw,
@@ -2239,7 +2242,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_gather_emit(const uint64_t* __r
     const int64_t w_end = w0 + GE_TILE_WORDS < row_words ? w0 + GE_TILE_WORDS : row_words;
     const int64_t g0 = (int64_t)rprefix[w0], g1 = (int64_t)rprefix[w_end];
     if (g1 == g0) continue;   // (uniform: no group's first row lies in this tile)
-    if (w < row_words) {
+    if (threadIdx.x < GE_TILE_WORDS && w < row_words) {
       uint64_t m = rep_mask[w];
       unsigned off = (unsigned)((int64_t)rprefix[w] - g0);
       while (m) {
