@@ -2224,9 +2224,9 @@ __global__ __launch_bounds__(BLOCK) void k_dense_keys(const uint64_t* __restrict
 // group's totals from the value-major cells (one line per group), and keys, accumulators and seen flags leave at consecutive group
 // numbers.  No per-value presence bitmap, no per-group first rows, no renumbering scatter (k_values_to_groups + k_mark_first_rows +
 // k_dense_permute + k_dense_keys + k_emit_values: 1.64 ms for 10 M groups of 150 M orders; this: one pass).
-// 64-row words per tile: 4096 rows, whose first-row marks become a list of at most that many 16-bit row numbers.  (16384-row tiles: the
-// tiles dense with first rows — the table's beginning — fell to a third of the workgroups, whose random cell reads then ran at 36 G/s:
-// 0.47 ms for 10 M groups, 0.28 of it those reads)
+// 64-row words per tile: 4096 rows, whose first-row marks become a list of at most that many 16-bit row numbers.  (16384-row tiles take
+// the same time.  Of 0.47 ms for 10 M groups of 150 M orders, 0.28 are the groups' cell reads — a random 64-byte line each, 36 G/s, the
+// chip's random-line rate — measured by reading the cells in order instead; the stores are 0.06.)
 constexpr int GE_TILE_WORDS = 64;
 template <typename KT>
 __global__ __launch_bounds__(BLOCK) void k_dense_gather_emit(const uint64_t* __restrict__ rep_mask, const uint64_t* __restrict__ rprefix, int64_t row_words,
