@@ -2327,7 +2327,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
                                                                  int64_t vstride, uint64_t vrange, uint32_t* __restrict__ first_row_v,
                                                                  const uint64_t* __restrict__ row_mask, const uint64_t* __restrict__ row_mask_valid, int rows_in_place,
                                                                  const uint32_t* __restrict__ key_map, int key_map_lds, int64_t istride,
-                                                                 unsigned long long* __restrict__ rep_mask) {
+                                                                 unsigned long long* __restrict__ rep_mask, int estride) {
   // cell word w of value v lives at cells_v[w * vstride + v * istride]: word-major (vstride = values, istride = 1) or value-major
   // (vstride = 1, istride = words: what the gathering emit reads — one line per group).  rep_mask (every window has ONE workgroup):
   // the first row of every value that has one is marked here, one bit per input row — the first-seen order falls out of its popcounts
@@ -2372,13 +2372,18 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
     // EVERYTHING the iteration reads from HBM leaves now: the keys, the rows' numbers and the first PART_PRELOAD accumulators' arguments
     // (round 6: keys -> row numbers -> one accumulator's arguments after the other were three and more memory round trips per iteration
     // at four waves per SIMD — 7.5 us per 4096 rows, 1.08 ms for 150 M orders whose bytes are worth 0.35)
+    // (estride > 1: the moved rows are RECORDS of estride 32-bit words — key, arguments and row number side by side, grouped.hip's record
+    // form — and `key`, `row_id` and the arguments' `data` point at their word of the first record)
+    int64_t ix[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) ix[u] = ii[u] * estride;
     KT kraw[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) kraw[u] = (live >> u) & 1u ? key[ii[u]] : KT(0);
+    for (int u = 0; u < U; u++) kraw[u] = (live >> u) & 1u ? key[ix[u]] : KT(0);
     uint32_t rid[U];
     if (row_id) {
 #pragma unroll
-      for (int u = 0; u < U; u++) rid[u] = (live >> u) & 1u ? row_id[ii[u]] : 0u;
+      for (int u = 0; u < U; u++) rid[u] = (live >> u) & 1u ? row_id[ix[u]] : 0u;
     } else {
 #pragma unroll
       for (int u = 0; u < U; u++) rid[u] = (uint32_t)ii[u];
@@ -2386,7 +2391,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
     uint64_t plo[PART_PRELOAD][U], phi[PART_PRELOAD][U];
 #pragma unroll
     for (int k = 0; k < PART_PRELOAD; k++)
-      if (k < accs.n && accs.a[k].data && !part_acc_is_count(accs.a[k].kind)) load_values_batch<U>(accs.a[k].val, accs.a[k].data, ii, live, plo[k], phi[k]);
+      if (k < accs.n && accs.a[k].data && !part_acc_is_count(accs.a[k].kind)) load_values_batch<U>(accs.a[k].val, accs.a[k].data, ix, live, plo[k], phi[k]);
     int x[U];
     // (key_map: the key column holds table slots, the value is the slot's group number — hash-interned groups in place; its 16-bit
     // copy in LDS when the launch had room for one)
@@ -2444,7 +2449,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
         continue;
       }
       uint64_t lo[U], hi[U];
-      if (a.data) load_values_batch<U>(a.val, a.data, ii, live, lo, hi);
+      if (a.data) load_values_batch<U>(a.val, a.data, ix, live, lo, hi);
       else {
 #pragma unroll
         for (int u = 0; u < U; u++) lo[u] = hi[u] = 0;
@@ -2680,6 +2685,9 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   }
   std::vector<PartBlock> blocks;
   RangePartition rp;
+  BufPtr records;       // the grouped move's record form: column q of the moved rows is word q of every rec_dwords-word record
+  int rec_dwords = 0;
+  auto moved_col = [&](size_t q) -> const void* { return records ? (const void*)(records->as<uint32_t>() + q) : rp.cols[q]->ptr; };
   if (in_place) {
     const int64_t nb = std::min<int64_t>(std::max<int64_t>((n + (1 << 16) - 1) >> 16, 1), 2048);
     for (int64_t b = 0; b < nb; b++) blocks.push_back(PartBlock{n * b / nb, n * (b + 1) / nb, 0, nb == 1 ? 1 : 0});
@@ -2695,11 +2703,17 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     const GroupSpec gs{(uint64_t)kmin, range, 1ull << (64 - wshift)};
     // (the keys leave as key - kmin in 32 bits when the range allows: half the key bytes of the widened form)
     const bool narrow = range <= (1ull << 32);
+    // (records: 32-bit keys and one or two 4-byte carried columns leave side by side — a third of the move's partial-line stores)
     GroupedRows gr = group_rows_by_key(kc, n, gs, nbits, row_mask, /*want_keys=*/true, /*want_dest=*/false, std::vector<const void*>(src.begin() + 1, src.end()),
-                                       std::vector<int>(widths.begin() + 1, widths.end()), "agg_group_rows", narrow);
+                                       std::vector<int>(widths.begin() + 1, widths.end()), "agg_group_rows", narrow, /*records=*/narrow);
     rp.rows = gr.rows;
-    rp.cols.push_back(gr.keys);
-    for (BufPtr& b : gr.cols) rp.cols.push_back(b);
+    if (gr.records) {
+      records = gr.records;
+      rec_dwords = gr.rec_dwords;
+    } else {
+      rp.cols.push_back(gr.keys);
+      for (BufPtr& b : gr.cols) rp.cols.push_back(b);
+    }
     group_bounds.resize((size_t)gr.P + 1);
     d2h(group_bounds.data(), gr.bounds->ptr, group_bounds.size() * 8);
     widths[0] = gr.key_width;
@@ -2724,7 +2738,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     rp = std::move(rp2);
   }
   for (size_t u = 0; u < all.size(); u++)
-    if (acc_src[u] >= 0) all[u].data = rp.cols[(size_t)acc_src[u]]->ptr;
+    if (acc_src[u] >= 0) all[u].data = moved_col((size_t)acc_src[u]);
   // where every window's rows begin (read off the moved keys), then the workgroups: one per window while its rows are few (its
   // totals then leave as plain stores); else chunks, merged by atomics
   std::vector<long long> begins((size_t)n_windows);
@@ -2780,8 +2794,9 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     for (int w : widths) bytes += n * w;
     ProfileScope psc("agg_dense_accumulate_partitioned", bytes);
     const PartBlock* db = d_blocks->as<PartBlock>();
-    const uint32_t* rid = ids_at >= 0 ? rp.cols[(size_t)ids_at]->as<uint32_t>() : nullptr;
-    const void* mk = in_place ? key : rp.cols[0]->ptr;
+    const uint32_t* rid = ids_at >= 0 ? (const uint32_t*)moved_col((size_t)ids_at) : nullptr;
+    const void* mk = in_place ? key : moved_col(0);
+    const int estride = records ? rec_dwords : 1;
     const uint64_t* km = in_place ? row_mask : nullptr;
     const uint64_t* kmv = in_place ? row_mask_valid : nullptr;
     const int ip = in_place && want_first_rows ? 1 : 0;
@@ -2817,10 +2832,10 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
         lds_bytes += (size_t)key_map_n * 2 + 8;
       }
       switch (kt) {
-        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm); break;
-        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm); break;
-        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm); break;
-        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm); break;
+        case DFGPU_INT64: k_dense_accumulate_parts<int64_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int64_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm, estride); break;
+        case DFGPU_UINT32: k_dense_accumulate_parts<uint32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint32_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm, estride); break;
+        case DFGPU_UINT8: k_dense_accumulate_parts<uint8_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const uint8_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm, estride); break;
+        default: k_dense_accumulate_parts<int32_t><<<nb, PART_BLOCK, lds_bytes, r.stream>>>(db, (const int32_t*)mk, rid, ps, kmin, wshift, cv, wstride, range, fv, km, kmv, ip, key_map, map_lds, istride, rm, estride); break;
       }
       DFGPU_HIP(hipGetLastError());
       first_launch = false;

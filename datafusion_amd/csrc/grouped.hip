@@ -273,6 +273,141 @@ __global__ __launch_bounds__(THREADS, WPS) void k_gp_scatter(KeyCol key, int64_t
   }
 }
 
+// ---- the record form (round 6): 32-bit keys (key - offset) and NC carried 4-byte columns leave as ONE (1 + NC)-dword record per row.
+// What bounds k_gp_scatter at 2048 groups is its stores — runs of 4 rows are 16-byte pieces of a line per column (the pass without its
+// global stores: 0.84 of 2.25 ms for 150 M orders) — and a row's columns side by side make one piece of three: 48 bytes per run, a third
+// of the store instructions.  All planes of a tile are staged at once (the carried columns' loads leave together, one barrier pair per
+// tile instead of one per column).  dynamic LDS: planes u32 [(1 + NC) * TILE] | cnt, goff, delta u32 [P each] | wave totals | start u16 [P]
+template <int KT, int THREADS, int ITEMS, int NC>
+__global__ __launch_bounds__(THREADS, 4) void k_gp_scatter_rec(KeyCol key, int64_t n, GroupSpec gs, int P, const uint64_t* __restrict__ row_mask, int tiles_per_chunk,
+                                                               int64_t n_chunks, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ out_rec, GroupCols cols) {
+  extern __shared__ __align__(16) unsigned char gp_smem[];
+  constexpr int TILE = THREADS * ITEMS;
+  constexpr int NWAVE = THREADS / WAVE;
+  constexpr int GPT = (GP_MAX_GROUPS + THREADS - 1) / THREADS;
+  constexpr int RW = 1 + NC;
+  static_assert(TILE <= (1 << GP_RANK_BITS), "rank field too narrow");
+  uint32_t* s_plane = reinterpret_cast<uint32_t*>(gp_smem);                       // [RW][TILE]
+  unsigned* s_cnt = reinterpret_cast<unsigned*>(gp_smem + (size_t)RW * TILE * 4);
+  unsigned* s_goff = s_cnt + P;
+  unsigned* s_delta = s_goff + P;
+  unsigned* s_wtot = s_delta + P;
+  uint16_t* s_start = reinterpret_cast<uint16_t*>(s_wtot + NWAVE);
+  const unsigned lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const int64_t lo = chunk * (int64_t)tiles_per_chunk * TILE;
+    const int64_t hi = (lo + (int64_t)tiles_per_chunk * TILE) < n ? (lo + (int64_t)tiles_per_chunk * TILE) : n;
+    for (int i = threadIdx.x; i < P; i += THREADS) {
+      s_goff[i] = (unsigned)offsets[(int64_t)i * n_chunks + chunk];
+      s_cnt[i] = 0;
+    }
+    __syncthreads();
+    uint64_t k[ITEMS], knext[ITEMS];
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+      const int64_t i = lo + (int64_t)c * THREADS + threadIdx.x;
+      knext[c] = lo < hi ? load_key<KT>(key, i < hi ? i : hi - 1) : 0ull;
+    }
+    for (int64_t base = lo; base < hi; base += TILE) {
+      unsigned gr[ITEMS];
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) k[c] = knext[c];
+      // ---- group and rank of every row of the tile
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {
+        const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+        const uint64_t idx = k[c] - gs.offset;
+        gr[c] = 0xFFFFFFFFu;
+        if (i < hi && idx < gs.size && gp_row_takes_part(key, row_mask, i)) {
+          const unsigned g = (unsigned)__umul64hi(idx, gs.mul);
+          gr[c] = (g << GP_RANK_BITS) | atomicAdd(&s_cnt[g], 1u);
+        }
+      }
+      // the carried columns' values of the tile: all of them on their way before the scan's barriers
+      uint32_t cv[NC > 0 ? NC : 1][ITEMS];
+#pragma unroll
+      for (int cc = 0; cc < NC; cc++) {
+        const uint32_t* csrc = reinterpret_cast<const uint32_t*>(cols.src[cc]);
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) {
+          const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
+          cv[cc][c] = gr[c] == 0xFFFFFFFFu ? 0u : (csrc ? csrc[i] : (uint32_t)i);   // (no source: the row's number)
+        }
+      }
+      __syncthreads();
+      // ---- exclusive scan of the tile's group counts: thread t owns groups [t * GPT, (t + 1) * GPT)
+      {
+        unsigned c_[GPT], v = 0;
+#pragma unroll
+        for (int q = 0; q < GPT; q++) {
+          const int g = (int)threadIdx.x * GPT + q;
+          c_[q] = g < P ? s_cnt[g] : 0u;
+          v += c_[q];
+        }
+        const unsigned inc = wave_inclusive_sum<unsigned>(v);
+        if (lane == 63) s_wtot[wave] = inc;
+        __syncthreads();
+        unsigned run = inc - v;
+#pragma unroll
+        for (int w = 0; w < NWAVE; w++) run += w < wave ? s_wtot[w] : 0u;
+#pragma unroll
+        for (int q = 0; q < GPT; q++) {
+          const int g = (int)threadIdx.x * GPT + q;
+          if (g < P) {
+            s_start[g] = (uint16_t)run;
+            s_delta[g] = s_goff[g] - run;
+          }
+          run += c_[q];
+        }
+      }
+      __syncthreads();
+      unsigned total = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; w++) total += s_wtot[w];
+      // ---- the tile in group order, plane by plane
+#pragma unroll
+      for (int c = 0; c < ITEMS; c++) {
+        if (gr[c] == 0xFFFFFFFFu) continue;
+        const unsigned g = gr[c] >> GP_RANK_BITS, r = gr[c] & ((1u << GP_RANK_BITS) - 1u);
+        const unsigned ps = (unsigned)s_start[g] + r;
+        s_plane[ps] = (uint32_t)(k[c] - gs.offset);
+#pragma unroll
+        for (int cc = 0; cc < NC; cc++) s_plane[(cc + 1) * TILE + ps] = cv[cc][c];
+      }
+      // the next tile's keys are on their way while this one is written out
+      {
+        const int64_t nb = base + TILE;
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) {
+          const int64_t i = nb + (int64_t)c * THREADS + threadIdx.x;
+          knext[c] = nb < hi ? load_key<KT>(key, i < hi ? i : hi - 1) : 0ull;
+        }
+      }
+      __syncthreads();
+      struct __attribute__((packed, aligned(4))) Rec { uint32_t w[RW]; };
+#pragma unroll
+      for (int j = 0; j < ITEMS; j++) {
+        const unsigned q = threadIdx.x + (unsigned)j * THREADS;
+        if (q < total) {
+          Rec rec;
+          rec.w[0] = s_plane[q];
+#pragma unroll
+          for (int cc = 0; cc < NC; cc++) rec.w[cc + 1] = s_plane[(cc + 1) * TILE + q];
+          const unsigned d = q + s_delta[(unsigned)__umul64hi((uint64_t)rec.w[0], gs.mul)];
+          reinterpret_cast<Rec*>(out_rec)[d] = rec;
+        }
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < P; i += THREADS) {
+        s_goff[i] += s_cnt[i];
+        s_cnt[i] = 0;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 __global__ void k_gp_bounds(const uint64_t* __restrict__ offsets, int P, int64_t n_chunks, uint64_t* __restrict__ bounds) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g <= P) bounds[g] = offsets[(int64_t)g * n_chunks];
@@ -290,7 +425,7 @@ static void gp_with_key_type(int dfgpu_type, F&& f) {
 }
 
 GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs, int nbits, const uint64_t* row_mask, bool want_keys, bool want_dest,
-                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what, bool narrow_keys) {
+                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what, bool narrow_keys, bool records) {
   Runtime& r = rt();
   DFGPU_CHECK(n > 0 && n < 0xFFFFFFFFll, "group_rows_by_key: row count out of range");
   DFGPU_CHECK(nbits >= 1 && (1 << nbits) <= GP_MAX_GROUPS, "group_rows_by_key: bad number of groups");
@@ -334,6 +469,35 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
   const size_t out_rows = (size_t)std::max<int64_t>(out.rows, 1);
   DFGPU_CHECK(!narrow_keys || gs.size <= (1ull << 32), "group_rows_by_key: 32-bit keys need a key range below 2^32");
   out.key_width = narrow_keys ? 4 : 8;
+  // the record form: 32-bit keys and one or two carried 4-byte columns side by side (k_gp_scatter_rec)
+  bool rec_ok = records && narrow_keys && want_keys && !want_dest && (carry_src.size() == 1 || carry_src.size() == 2) && option_on("group.records", true);
+  for (int w : carry_width) rec_ok &= w == 4;
+  if (rec_ok) {
+    const int NC = (int)carry_src.size();
+    out.rec_dwords = 1 + NC;
+    out.records = make_buf(out_rows * (size_t)out.rec_dwords * 4 + 16);
+    GroupCols gc{};
+    gc.n = NC;
+    int64_t moved = out.rows * out.rec_dwords * 4;
+    for (int c = 0; c < NC; c++) {
+      gc.src[c] = carry_src[c];
+      gc.width[c] = 4;
+      moved += carry_src[c] ? n * 4 : 0;
+    }
+    const size_t lds = (size_t)TILE * 4 * (size_t)out.rec_dwords + (size_t)P * 12 + (size_t)(THREADS / WAVE) * 4 + (size_t)P * 2;
+    ProfileScope ps(what ? what : "group_rows_scatter", key_bytes + moved);
+    gp_with_key_type(key.type, [&](auto kt) {
+      constexpr int T = decltype(kt)::value;
+      auto launch = [&](auto kern) {
+        DFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, THREADS, lds, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, offsets->as<uint64_t>(), out.records->as<uint32_t>(), gc);
+      };
+      if (NC == 1) launch(k_gp_scatter_rec<T, THREADS, ITEMS, 1>);
+      else launch(k_gp_scatter_rec<T, THREADS, ITEMS, 2>);
+    });
+    DFGPU_HIP(hipGetLastError());
+    return out;
+  }
   if (want_keys) out.keys = make_buf(out_rows * (size_t)out.key_width + 8);
   if (want_dest) out.dest = make_buf((size_t)n * 4);
   GroupCols gc{};

@@ -32,11 +32,15 @@ struct GroupedRows {
   BufPtr dest;                 // u32 per INPUT row: its position in group order, ~0 = takes no part (want_dest)
   BufPtr bounds;               // u64 [P + 1] on the device: group g = positions bounds[g] .. bounds[g + 1]
   std::vector<BufPtr> cols;    // carried columns in group order
+  BufPtr records;              // the record form (asked for and granted): u32 [rows][rec_dwords] = {key - offset, carried columns...}; keys / cols empty
+  int rec_dwords = 0;
 };
 // Rows of an integer key column moved into 2^nbits (<= GP_MAX_GROUPS) groups of their key's range (NULL keys, rows masked out by `row_mask` and keys
 // outside [offset, offset + size) take no part).  Order inside a group is arbitrary.
 GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs, int nbits, const uint64_t* row_mask, bool want_keys, bool want_dest,
-                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what = nullptr, bool narrow_keys = false);
-// (a carried column of width 4 whose source is null carries the rows' numbers)
+                              const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what = nullptr, bool narrow_keys = false,
+                              bool records = false);
+// (a carried column of width 4 whose source is null carries the rows' numbers; `records`: 32-bit keys and one or two 4-byte carried columns may
+// leave as one record per row — GroupedRows::records — when the caller can read them that way)
 
 }  // namespace dfgpu

@@ -499,6 +499,48 @@ def test_partitioned_group_by_emits_groups_in_first_seen_order_by_either_form(ca
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("filtered", [False, True], ids=["all_rows", "under_a_filter"])
+@pytest.mark.parametrize("form", ["records", "columns"])
+def test_grouped_move_of_narrow_rows_as_records_or_columns(form, filtered):
+    """Q13's shape — COUNT(*), MIN(Date32) by an integer key over a range of hundreds of thousands of values: the key (as a 32-bit offset),
+    the one 4-byte argument and the row number are moved into the key windows as ONE 12-byte record per row (grouped.hip's record form,
+    round 6), or column by column (group.records=0); with a fused FilterExec only the passing rows move.  Same groups in first-seen order,
+    same counts and minima."""
+    from datafusion_amd import ops
+    from datafusion_amd.expr import col, lit
+    from datafusion_amd.table import DeviceTable
+    rng = np.random.default_rng(71)
+    n, distinct = 5_000_000, 400_000
+    codes = rng.integers(0, distinct, n)
+    d = rng.integers(-500, 3000, n).astype(np.int32)
+    w = rng.integers(0, 100, n).astype(np.int32)
+    t = DeviceTable.from_arrow(pa.table({"k": pa.array(codes * 2 - 300_000), "d": pa.array(d, pa.date32()), "w": pa.array(w)}))
+    try:
+        ops.set_options(agg__partitioned_min_rows="1000000")
+        if form == "columns":
+            ops.set_options(group__records="0")
+        ops.profile_enable(True)
+        ops.profile_reset()
+        got = ops.aggregate(t, [(col("k"), "k")], [("count", None, "n"), ("min", col("d"), "first_day")], "Single",
+                            predicate=(col("w") < lit(70, pa.int32())) if filtered else None).to_arrow()
+        stats = ops.profile_stats()
+        ops.profile_enable(False)
+    finally:
+        ops.reset_options()
+    assert "agg_dense_accumulate_partitioned" in stats and stats["agg_group_rows"]["calls"] == 1 and "agg_dense_gather_emit" in stats, sorted(stats)
+    keep = (w < 70) if filtered else np.ones(n, dtype=bool)
+    kc, kd = codes[keep], d[keep]
+    first = np.full(distinct, n, dtype=np.int64)
+    np.minimum.at(first, kc, np.nonzero(keep)[0])
+    present = np.nonzero(first < n)[0]
+    order = present[np.argsort(first[present], kind="stable")]
+    lo = np.full(distinct, 10**6, dtype=np.int64); np.minimum.at(lo, kc, kd)
+    assert got.column("k").to_pylist() == (order * 2 - 300_000).tolist()
+    assert got.column("n").to_pylist() == np.bincount(kc, minlength=distinct)[order].tolist()
+    assert got.column("first_day").cast(pa.int32()).to_pylist() == lo[order].tolist()
+
+
+@pytest.mark.gpu
 def test_final_merge_of_many_partial_states_moves_rows_by_group_number():
     """Final over millions of partial-state rows with a two-column key (hash-interned groups): every row's group number is looked up
     once, the rows are moved into LDS-sized windows of group numbers, accumulated there and merged per group — SUM / AVG / COUNT / MIN
