@@ -469,8 +469,8 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
   const size_t out_rows = (size_t)std::max<int64_t>(out.rows, 1);
   DFGPU_CHECK(!narrow_keys || gs.size <= (1ull << 32), "group_rows_by_key: 32-bit keys need a key range below 2^32");
   out.key_width = narrow_keys ? 4 : 8;
-  // the record form: 32-bit keys and one or two carried 4-byte columns side by side (k_gp_scatter_rec)
-  bool rec_ok = records && narrow_keys && want_keys && !want_dest && (carry_src.size() == 1 || carry_src.size() == 2) && option_on("group.records", true);
+  // the record form: 32-bit keys and one to three carried 4-byte columns side by side (k_gp_scatter_rec)
+  bool rec_ok = records && narrow_keys && want_keys && !want_dest && carry_src.size() >= 1 && carry_src.size() <= 3 && option_on("group.records", true);
   for (int w : carry_width) rec_ok &= w == 4;
   if (rec_ok) {
     const int NC = (int)carry_src.size();
@@ -493,7 +493,8 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
         kern<<<grid, THREADS, lds, r.stream>>>(key, n, gs, P, row_mask, tiles_per_chunk, n_chunks, offsets->as<uint64_t>(), out.records->as<uint32_t>(), gc);
       };
       if (NC == 1) launch(k_gp_scatter_rec<T, THREADS, ITEMS, 1>);
-      else launch(k_gp_scatter_rec<T, THREADS, ITEMS, 2>);
+      else if (NC == 2) launch(k_gp_scatter_rec<T, THREADS, ITEMS, 2>);
+      else launch(k_gp_scatter_rec<T, THREADS, ITEMS, 3>);   // (16-byte records: a whole line per 4-row run; 156 KB of the CU's 160 KB of LDS)
     });
     DFGPU_HIP(hipGetLastError());
     return out;

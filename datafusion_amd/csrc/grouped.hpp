@@ -40,7 +40,7 @@ struct GroupedRows {
 GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs, int nbits, const uint64_t* row_mask, bool want_keys, bool want_dest,
                               const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what = nullptr, bool narrow_keys = false,
                               bool records = false);
-// (a carried column of width 4 whose source is null carries the rows' numbers; `records`: 32-bit keys and one or two 4-byte carried columns may
+// (a carried column of width 4 whose source is null carries the rows' numbers; `records`: 32-bit keys and one to three 4-byte carried columns may
 // leave as one record per row — GroupedRows::records — when the caller can read them that way)
 
 }  // namespace dfgpu

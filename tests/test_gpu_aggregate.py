@@ -521,8 +521,8 @@ def test_grouped_move_of_narrow_rows_as_records_or_columns(form, filtered):
             ops.set_options(group__records="0")
         ops.profile_enable(True)
         ops.profile_reset()
-        got = ops.aggregate(t, [(col("k"), "k")], [("count", None, "n"), ("min", col("d"), "first_day")], "Single",
-                            predicate=(col("w") < lit(70, pa.int32())) if filtered else None).to_arrow()
+        got = ops.aggregate(t, [(col("k"), "k")], [("count", None, "n"), ("min", col("d"), "first_day")] + ([] if filtered else [("max", col("w"), "mw")]), "Single",
+                            predicate=(col("w") < lit(70, pa.int32())) if filtered else None).to_arrow()   # (12-byte records under the filter, 16-byte ones without)
         stats = ops.profile_stats()
         ops.profile_enable(False)
     finally:
@@ -538,6 +538,9 @@ def test_grouped_move_of_narrow_rows_as_records_or_columns(form, filtered):
     assert got.column("k").to_pylist() == (order * 2 - 300_000).tolist()
     assert got.column("n").to_pylist() == np.bincount(kc, minlength=distinct)[order].tolist()
     assert got.column("first_day").cast(pa.int32()).to_pylist() == lo[order].tolist()
+    if not filtered:
+        mw = np.full(distinct, -1, dtype=np.int64); np.maximum.at(mw, kc, w[keep])
+        assert got.column("mw").to_pylist() == mw[order].tolist()
 
 
 @pytest.mark.gpu
