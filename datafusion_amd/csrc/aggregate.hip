@@ -2321,7 +2321,9 @@ struct PartBlock {
 };
 constexpr int PART_PRELOAD = 3;   // accumulators whose arguments are loaded together with the keys
 constexpr int PART_BLOCK = 1024;   // threads per workgroup: the windows' LDS leaves room for one or two workgroups per CU, so they are big
-template <typename KT>
+// U rows per thread and iteration, the first NPRE accumulators' arguments loaded with the keys.  (<8, 1> for moved rows with one argument
+// column — twice the loads in flight per wave — was measured in round 6 and is not instantiated: 0.94 against 0.96 ms, nothing.)
+template <typename KT, int U = 4, int NPRE = PART_PRELOAD>
 __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const PartBlock* __restrict__ blocks, const KT* __restrict__ key, const uint32_t* __restrict__ row_id,
                                                                  PartAccSet accs, long long kmin, int wshift, unsigned long long* __restrict__ cells_v,
                                                                  int64_t vstride, uint64_t vrange, uint32_t* __restrict__ first_row_v,
@@ -2355,7 +2357,6 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
   const unsigned long long base = (unsigned long long)b.part << wshift;
   // FOUR rows per thread at a time (round 4): their keys, then their group numbers (key_map), then each accumulator's four arguments
   // are in flight together — one row at a time, a thread waited for key -> key_map -> LDS in turn at four waves per SIMD
-  constexpr int U = 4;
   for (int64_t i0 = b.begin + threadIdx.x; i0 < b.end; i0 += (int64_t)U * PART_BLOCK) {
     int64_t ii[U];
     uint32_t live = 0;
@@ -2369,7 +2370,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
       if (ok) live |= 1u << u;
     }
     if (!live) continue;
-    // EVERYTHING the iteration reads from HBM leaves now: the keys, the rows' numbers and the first PART_PRELOAD accumulators' arguments
+    // EVERYTHING the iteration reads from HBM leaves now: the keys, the rows' numbers and the first NPRE accumulators' arguments
     // (round 6: keys -> row numbers -> one accumulator's arguments after the other were three and more memory round trips per iteration
     // at four waves per SIMD — 7.5 us per 4096 rows, 1.08 ms for 150 M orders whose bytes are worth 0.35)
     // (estride > 1: the moved rows are RECORDS of estride 32-bit words — key, arguments and row number side by side, grouped.hip's record
@@ -2388,9 +2389,9 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
 #pragma unroll
       for (int u = 0; u < U; u++) rid[u] = (uint32_t)ii[u];
     }
-    uint64_t plo[PART_PRELOAD][U], phi[PART_PRELOAD][U];
+    uint64_t plo[NPRE][U], phi[NPRE][U];
 #pragma unroll
-    for (int k = 0; k < PART_PRELOAD; k++)
+    for (int k = 0; k < NPRE; k++)
       if (k < accs.n && accs.a[k].data && !part_acc_is_count(accs.a[k].kind)) load_values_batch<U>(accs.a[k].val, accs.a[k].data, ix, live, plo[k], phi[k]);
     int x[U];
     // (key_map: the key column holds table slots, the value is the slot's group number — hash-interned groups in place; its 16-bit
@@ -2425,7 +2426,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
       }
     };
 #pragma unroll
-    for (int k = 0; k < PART_PRELOAD; k++) {
+    for (int k = 0; k < NPRE; k++) {
       if (k >= accs.n) continue;
       const PartAcc& a = accs.a[k];
       if (part_acc_is_count(a.kind)) {
@@ -2440,7 +2441,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
       }
       accumulate_rows(a, plo[k], phi[k]);
     }
-    for (int k = PART_PRELOAD; k < accs.n; k++) {   // further accumulators: one batch of loads each
+    for (int k = NPRE; k < accs.n; k++) {   // further accumulators: one batch of loads each
       const PartAcc& a = accs.a[k];
       if (part_acc_is_count(a.kind)) {
 #pragma unroll
@@ -2824,6 +2825,8 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
         u++;
       }
       DFGPU_CHECK(ps.n > 0, "partitioned aggregation: an accumulator does not fit the window");
+      // the accumulators that read an argument column first: they are the ones whose loads leave with the keys (NPRE of the kernel)
+      std::stable_partition(ps.a, ps.a + ps.n, [](const PartAcc& a) { return a.data && !part_acc_is_count(a.kind); });
       size_t lds_bytes = W * (8 * (size_t)ps.ncw + 4 * (size_t)ps.n32 + 4);
       // the slot -> group table as 16-bit words in LDS behind the cells when both fit (in place over table slots: every row looks it up)
       int map_lds = 0;
