@@ -727,45 +727,84 @@ struct EmitSet {
 };
 __global__ __launch_bounds__(BLOCK) void k_emit_set(EmitSet s, int64_t n, unsigned long long* __restrict__ stats) {
   const EmitEntry& e = s.e[blockIdx.y];
-  const int64_t n_round = (n + WAVE - 1) / WAVE * WAVE;
+  // a wave takes U consecutive 64-group words per round: everything it reads of them is requested before the first value is made (round 6:
+  // one group per thread and round was a chain of load -> store round trips, 0.23 ms for 2 x 10 M groups whose bytes are worth 0.06)
+  constexpr int U = 4;
+  const unsigned lane = lane_id();
+  const int64_t n_words = (n + WAVE - 1) / WAVE;
+  const int64_t wv = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  const bool avg = e.kind != 0;
+  const bool need_lo = avg || e.mode != 5, need_hi = avg ? e.mode != 0 : e.mode == 1;
   unsigned long long valid_rows = 0;
   bool overflow = false;
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {   // (whole waves: the ballot)
-    const bool in = i < n;
-    bool ok = false;
-    if (in) {
-      if (e.kind == 0) {
-        ok = !e.seen || e.seen[i] != 0;
-        switch (e.mode) {
-          case 0: ((unsigned long long*)e.dst)[i] = ok ? e.lo[i] : 0ull; break;
-          case 1: ((unsigned long long*)e.dst)[2 * i] = ok ? e.lo[i] : 0ull; ((unsigned long long*)e.dst)[2 * i + 1] = ok ? e.hi[i] : 0ull; break;
-          case 2: ((double*)e.dst)[i] = ok ? f64_from_ordered((int64_t)e.lo[i]) : 0.0; break;
-          case 3: ((int32_t*)e.dst)[i] = ok ? (int32_t)(int64_t)e.lo[i] : 0; break;
-          case 4: ((uint8_t*)e.dst)[i] = ok ? (uint8_t)e.lo[i] : 0; break;
-          default: break;   // 5: the values are in place already (the runs node's interleaved cells), only the validity is made
-        }
-      } else {
-        const unsigned long long c = e.cnt[i];
-        ok = c != 0;
-        if (e.mode) {
-          i128 r = 0;
-          if (ok) {
-            const i128 sum = (i128)(((u128)e.hi[i] << 64) | (u128)e.lo[i]);
-            const i128 mul = (i128)(((u128)e.mul_hi << 64) | (u128)e.mul_lo);
-            if (__builtin_mul_overflow(sum, mul, &r)) overflow = true;  // sum.mul_checked
-            r = r / (i128)c;
+  for (int64_t w0 = wv * U; w0 < n_words; w0 += n_waves * U) {
+    bool in[U];
+    uint32_t sn[U];
+    unsigned long long lo[U], hi[U], cn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = ((w0 + u) << 6) + lane;
+      in[u] = i < n;
+      sn[u] = in[u] && !avg && e.seen ? e.seen[i] : 1u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = ((w0 + u) << 6) + lane;
+      lo[u] = in[u] && need_lo ? e.lo[i] : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = ((w0 + u) << 6) + lane;
+      hi[u] = in[u] && need_hi ? e.hi[i] : 0ull;
+      cn[u] = in[u] && avg ? e.cnt[i] : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = ((w0 + u) << 6) + lane;
+      bool ok = false;
+      if (in[u]) {
+        if (!avg) {
+          ok = sn[u] != 0;
+          switch (e.mode) {
+            case 0: ((unsigned long long*)e.dst)[i] = ok ? lo[u] : 0ull; break;
+            case 1: reinterpret_cast<ulonglong2*>(e.dst)[i] = ok ? make_ulonglong2(lo[u], hi[u]) : make_ulonglong2(0ull, 0ull); break;
+            case 2: ((double*)e.dst)[i] = ok ? f64_from_ordered((int64_t)lo[u]) : 0.0; break;
+            case 3: ((int32_t*)e.dst)[i] = ok ? (int32_t)(int64_t)lo[u] : 0; break;
+            case 4: ((uint8_t*)e.dst)[i] = ok ? (uint8_t)lo[u] : 0; break;
+            default: break;   // 5: the values are in place already (the runs node's interleaved cells), only the validity is made
           }
-          ((i128*)e.dst)[i] = r;
         } else {
-          ((double*)e.dst)[i] = ok ? __longlong_as_double((long long)e.lo[i]) / (double)c : 0.0;
+          const unsigned long long c = cn[u];
+          ok = c != 0;
+          if (e.mode) {
+            i128 r = 0;
+            if (ok) {
+              const i128 sum = (i128)(((u128)hi[u] << 64) | (u128)lo[u]);
+              const i128 mul = (i128)(((u128)e.mul_hi << 64) | (u128)e.mul_lo);
+              if (__builtin_mul_overflow(sum, mul, &r)) overflow = true;  // sum.mul_checked
+              r = r / (i128)c;
+            }
+            ((i128*)e.dst)[i] = r;
+          } else {
+            ((double*)e.dst)[i] = ok ? __longlong_as_double((long long)lo[u]) / (double)c : 0.0;
+          }
         }
       }
+      const uint64_t word = ballot64(ok);
+      if (e.valid_words && lane == 0 && w0 + u < n_words) e.valid_words[w0 + u] = word;
+      if (lane == 0) valid_rows += (unsigned long long)__popcll(word);
     }
-    const uint64_t word = ballot64(ok);
-    if (e.valid_words && lane_id() == 0 && in) e.valid_words[i >> 6] = word;
-    if (lane_id() == 0) valid_rows += (unsigned long long)__popcll(word);
   }
-  if (lane_id() == 0 && valid_rows) atomicAdd(&stats[2 * blockIdx.y], valid_rows);
+  // the column's count of valid rows: one atomic per workgroup, none for a column that is not nullable (the host does not look at it)
+  __shared__ unsigned long long s_valid[BLOCK / WAVE];
+  if (lane == 0) s_valid[threadIdx.x >> 6] = valid_rows;
+  __syncthreads();
+  if (threadIdx.x == 0 && e.valid_words) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / WAVE; w++) t += s_valid[w];
+    if (t) atomicAdd(&stats[2 * blockIdx.y], t);
+  }
   if (overflow) stats[2 * blockIdx.y + 1] = 1ull;
 }
 
