@@ -129,7 +129,16 @@ __global__ __launch_bounds__(BLOCK) void k_count_bits(const uint64_t* __restrict
     s += __popcll(m);
   }
   s = wave_sum(s);
-  if (lane_id() == 0 && s) atomicAdd(out, (unsigned long long)s);
+  // one atomic per workgroup (8192 waves' atomics on one address at the kernel's end were 0.08 of its 0.10 ms over 150 M bits)
+  __shared__ unsigned long long s_part[BLOCK / WAVE];
+  if (lane_id() == 0) s_part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / WAVE; w++) t += s_part[w];
+    if (t) atomicAdd(out, t);
+  }
 }
 
 void pack_bytes_to_bitmap(const uint8_t* bytes, int64_t n, uint64_t* words) {
