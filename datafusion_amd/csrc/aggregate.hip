@@ -826,6 +826,10 @@ struct AggState {
   // every group: 1.0 of the 7.2 ms of GROUP BY l_orderkey at SF100).  lo / hi are stale while this is set; the next update
   // splits it back (split_interleaved).
   BufPtr inter;
+  // set by the ordered-input runs node for an accumulator whose argument cannot be NULL: every group has a value, `seen` was not written
+  // (4 bytes per group the kernel does not store and emit does not read back — 150 M groups: 1.2 GB).  The next update fills it in
+  // (split_interleaved); emit hands the column out without a validity buffer.
+  bool seen_all = false;
 };
 
 struct Aggregate {
@@ -1632,7 +1636,16 @@ __global__ __launch_bounds__(BLOCK) void k_split128(const unsigned long long* __
     hi[i] = cells[2 * i + 1];
   }
 }
+// the seen words the runs node left unwritten (every group has a value) exist again: before any other update reads or extends them
+static void materialize_seen(Aggregate& A, int64_t G) {
+  for (AggState& a : A.aggs) {
+    if (!a.seen_all) continue;
+    if (G > 0 && a.seen) DFGPU_HIP(hipMemsetD32Async((hipDeviceptr_t)a.seen->ptr, 1, (size_t)G, rt().stream));
+    a.seen_all = false;
+  }
+}
 static void split_interleaved(Aggregate& A, int64_t G) {
+  materialize_seen(A, G);
   for (AggState& a : A.aggs) {
     if (!a.inter) continue;
     if (G > 0) {
@@ -3828,6 +3841,11 @@ static bool agg_update_sorted_runs_jit(Aggregate& A, const Table& in, const dfgp
       if (entries[e].kind == ACC_SUM_I128) args.cell[2 * e + 1] = a.hi->as<unsigned long long>();
       args.seen[e] = a.seen->as<uint32_t>();
     }
+    // an argument that cannot be NULL (no validity anywhere under it): every run has a value — the seen words stay unwritten
+    if (!entries[e].is_avg_count && accs[e].val >= 0 && !cp.src_maybe_null[(size_t)accs[e].val] && option_on("agg.runs_seen_all", true)) {
+      args.seen[e] = nullptr;
+      a.seen_all = true;
+    }
   }
   {
     ProfileScope ps("agg_runs_accumulate", n * cp.input_bytes_per_row);
@@ -4515,6 +4533,7 @@ static void agg_update(Aggregate& A, const Table& in, const dfgpu_expr* pred = n
   agg_update_keys_fixed(A, any ? coded : in, pred);
 }
 static void agg_update_keys_fixed(Aggregate& A, const Table& in, const dfgpu_expr* pred) {
+  if (A.ngroups > 0) materialize_seen(A, A.ngroups);   // (a batch after the runs node's)
   // group keys that are dictionary-encoded columns are interned by their indices: every update must use the dictionary of
   // the groups that exist already (all interning paths — LDS cells, dense ranks, hash — rely on this)
   if (A.ngroups > 0)
@@ -4644,7 +4663,7 @@ static Table agg_emit(Aggregate& A) {
       if (A.partial_out()) {
         // state_fields of AVG: [count: UInt64, sum] (average.rs:317-360)
         emit_later(fld(DFGPU_UINT64), a.name + "[count]", 0, 0, a.cnt, nullptr, nullptr, nullptr, 1, false);
-        emit_later(vf, a.name + "[sum]", 0, mode, a.lo, a.hi, a.seen, nullptr, 1, true);
+        emit_later(vf, a.name + "[sum]", 0, mode, a.lo, a.hi, a.seen, nullptr, 1, !a.seen_all);
       } else {
         // raw modes: in_type = argument type Decimal(p,s) -> AVG type Decimal(min(38,p+4), min(38,s+4))
         // (average.rs:219-252).  final modes: in_type = the sum state Decimal(38, s), which no longer tells p: the
@@ -4668,7 +4687,7 @@ static Table agg_emit(Aggregate& A) {
       }
       continue;
     }
-    bool nullable = a.func != DFGPU_AGG_COUNT;
+    bool nullable = a.func != DFGPU_AGG_COUNT && !a.seen_all;
     // partial state field names: format_state_name (expr/src/utils.rs:1416) — `name[sum]` (sum.rs:293-299), `name[count]`
     // (count.rs:317-323), `name[value]` for MIN / MAX (the default AggregateUDFImpl::state_fields, expr/src/udaf.rs:579-585)
     const std::string out_name = !A.partial_out() ? a.name : a.name + (a.func == DFGPU_AGG_SUM ? "[sum]" : a.func == DFGPU_AGG_COUNT ? "[count]" : "[value]");
@@ -4698,6 +4717,11 @@ static Table agg_emit(Aggregate& A) {
       c.name = out_name;
       c.length = G;
       c.data = a.inter;
+      if (a.seen_all) {   // every group has a value: no validity buffer at all
+        c.null_count = 0;
+        out.cols.push_back(std::move(c));
+        continue;
+      }
       // the validity words and the count of valid groups come from the seen flags in k_emit_set's pass (mode 5: no value is written) —
       // a byte per group, the packing of the bytes and a count over the words were three passes over 150 M groups (0.40 of 5.8 ms)
       DFGPU_CHECK(eset.n < EMIT_MAX, "too many aggregate output columns for one GPU aggregate node");
