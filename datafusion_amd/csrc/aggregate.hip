@@ -3850,8 +3850,8 @@ static bool agg_update_sorted_runs_jit(Aggregate& A, const Table& in, const dfgp
   {
     ProfileScope ps("agg_runs_accumulate", n * cp.input_bytes_per_row);
     // (agg.runs_max_blocks: a test's way to make every wave walk many words over a small table.  Measured and dropped in round 6: the next
-    // word's head bits and rows loaded one iteration ahead — 4.4 -> 5.2 ms for 600 M rows: the loads of three words per wave cost more
-    // registers and queue slots than the second round trip they hide)
+    // word's head bits and rows loaded one iteration ahead — 4.4 -> 5.2 ms for 600 M rows; the head bits alone a word ahead — 4.3 -> 4.7 on
+    // the same kind of box: whatever bounds this kernel at 4.3 TB/s, it is not the head bits -> rows round trip)
     const int max_blocks = (int)option_int("agg.runs_max_blocks", 1 << 30);
     jit_launch(f_acc, std::max(1, std::min(grid_for(n_words, BLOCK / WAVE), max_blocks)), BLOCK, 0, &args, sizeof(args));
   }
