@@ -3660,7 +3660,11 @@ extern "C" __global__ __launch_bounds__(BLOCK) void runs_accumulate(Args a) {
                  "      u128 t = P - (h ? Pp : (u128)0);\n"
                  "      if (ext) { const u128 E = scan_u128(Eok" + ks + " ? (((u128)Ehi" + ks + " << 64) | Elo" + ks + ") : (u128)0); if (lane_ == 63) t += E; }\n";
         }
-        src += "      if (plain) { " + cell + "[" + gi + "] = (U64)t; " + cellhi + "[" + gi + "] = (U64)(t >> 64); " + seen_plain + " }\n"
+        // (interleaved cells: both words of a sum leave in one 16-byte store)
+        src += std::string("      if (plain) { ") +
+               (c.inter ? "*reinterpret_cast<ulonglong2*>(" + cell + " + " + gi + ") = make_ulonglong2((U64)t, (U64)(t >> 64)); "
+                        : cell + "[" + gi + "] = (U64)t; " + cellhi + "[" + gi + "] = (U64)(t >> 64); ") +
+               seen_plain + " }\n"
                "      else if (atom && cnt) { " + add128 + " " + seen_atom + " }\n";
         break;
       case ACC_SUM_I64:
