@@ -95,7 +95,7 @@ __device__ __forceinline__ void load_value(const AccDesc& d, int64_t i, uint64_t
 // the values of U rows of one argument column at once: the ValKind is asked ONCE, outside the unrolled loop, so the U loads leave back to
 // back (a switch per load puts every load in a basic block of its own with a wait behind it)
 template <int U>
-__device__ __forceinline__ void load_values_batch(int val, const void* values, const int64_t (&ii)[U], uint32_t live, uint64_t (&lo)[U], uint64_t (&hi)[U]) {
+__device__ __forceinline__ void load_values_batch(int val, const void* values, const int64_t (&ii)[U], uint32_t live, uint64_t (&lo)[U], uint64_t (&hi)[U], int estride = 1) {
 #pragma unroll
   for (int u = 0; u < U; u++) lo[u] = hi[u] = 0;
   switch (val) {
@@ -129,8 +129,19 @@ __device__ __forceinline__ void load_values_batch(int val, const void* values, c
     }
     default: {   // the 64-bit kinds
       uint64_t v[U];
+      if (estride > 1) {   // (records: `ii` counts 32-bit words, the value is two of them — 4-byte aligned)
+        uint32_t a[U], b[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) v[u] = (live >> u) & 1u ? ((const uint64_t*)values)[ii[u]] : 0ull;
+        for (int u = 0; u < U; u++) {
+          a[u] = (live >> u) & 1u ? ((const uint32_t*)values)[ii[u]] : 0u;
+          b[u] = (live >> u) & 1u ? ((const uint32_t*)values)[ii[u] + 1] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = (uint64_t)a[u] | ((uint64_t)b[u] << 32);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = (live >> u) & 1u ? ((const uint64_t*)values)[ii[u]] : 0ull;
+      }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         switch (val) {
@@ -2444,7 +2455,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
     uint64_t plo[NPRE][U], phi[NPRE][U];
 #pragma unroll
     for (int k = 0; k < NPRE; k++)
-      if (k < accs.n && accs.a[k].data && !part_acc_is_count(accs.a[k].kind)) load_values_batch<U>(accs.a[k].val, accs.a[k].data, ix, live, plo[k], phi[k]);
+      if (k < accs.n && accs.a[k].data && !part_acc_is_count(accs.a[k].kind)) load_values_batch<U>(accs.a[k].val, accs.a[k].data, ix, live, plo[k], phi[k], estride);
     int x[U];
     // (key_map: the key column holds table slots, the value is the slot's group number — hash-interned groups in place; its 16-bit
     // copy in LDS when the launch had room for one)
@@ -2502,7 +2513,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dense_accumulate_parts(const Par
         continue;
       }
       uint64_t lo[U], hi[U];
-      if (a.data) load_values_batch<U>(a.val, a.data, ix, live, lo, hi);
+      if (a.data) load_values_batch<U>(a.val, a.data, ix, live, lo, hi, estride);
       else {
 #pragma unroll
         for (int u = 0; u < U; u++) lo[u] = hi[u] = 0;
@@ -2740,7 +2751,8 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
   RangePartition rp;
   BufPtr records;       // the grouped move's record form: column q of the moved rows is word q of every rec_dwords-word record
   int rec_dwords = 0;
-  auto moved_col = [&](size_t q) -> const void* { return records ? (const void*)(records->as<uint32_t>() + q) : rp.cols[q]->ptr; };
+  std::vector<int> rec_off;   // word of the record where carried column q - 1 starts (the key is word 0)
+  auto moved_col = [&](size_t q) -> const void* { return records ? (const void*)(records->as<uint32_t>() + (q == 0 ? 0 : rec_off[q - 1])) : rp.cols[q]->ptr; };
   if (in_place) {
     const int64_t nb = std::min<int64_t>(std::max<int64_t>((n + (1 << 16) - 1) >> 16, 1), 2048);
     for (int64_t b = 0; b < nb; b++) blocks.push_back(PartBlock{n * b / nb, n * (b + 1) / nb, 0, nb == 1 ? 1 : 0});
@@ -2763,6 +2775,7 @@ static bool partitioned_accumulate(const void* key, int kt, int64_t n_in, long l
     if (gr.records) {
       records = gr.records;
       rec_dwords = gr.rec_dwords;
+      rec_off = gr.rec_off;
     } else {
       rp.cols.push_back(gr.keys);
       for (BufPtr& b : gr.cols) rp.cols.push_back(b);

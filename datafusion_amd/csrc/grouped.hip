@@ -329,10 +329,11 @@ __global__ __launch_bounds__(THREADS, 4) void k_gp_scatter_rec(KeyCol key, int64
 #pragma unroll
       for (int cc = 0; cc < NC; cc++) {
         const uint32_t* csrc = reinterpret_cast<const uint32_t*>(cols.src[cc]);
+        const int64_t sdw = cols.sdw[cc], soff = cols.soff[cc];   // (an 8-byte column: two planes, words 0 and 1 of elements two words apart)
 #pragma unroll
         for (int c = 0; c < ITEMS; c++) {
           const int64_t i = base + (int64_t)c * THREADS + threadIdx.x;
-          cv[cc][c] = gr[c] == 0xFFFFFFFFu ? 0u : (csrc ? csrc[i] : (uint32_t)i);   // (no source: the row's number)
+          cv[cc][c] = gr[c] == 0xFFFFFFFFu ? 0u : (csrc ? csrc[i * sdw + soff] : (uint32_t)i);   // (no source: the row's number)
         }
       }
       __syncthreads();
@@ -470,19 +471,31 @@ GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs,
   DFGPU_CHECK(!narrow_keys || gs.size <= (1ull << 32), "group_rows_by_key: 32-bit keys need a key range below 2^32");
   out.key_width = narrow_keys ? 4 : 8;
   // the record form: 32-bit keys and one to three carried 4-byte columns side by side (k_gp_scatter_rec)
-  bool rec_ok = records && narrow_keys && want_keys && !want_dest && carry_src.size() >= 1 && carry_src.size() <= 3 && option_on("group.records", true);
-  for (int w : carry_width) rec_ok &= w == 4;
+  int rec_words = 1;
+  bool rec_ok = records && narrow_keys && want_keys && !want_dest && !carry_src.empty() && option_on("group.records", true);
+  for (int w : carry_width) {
+    rec_ok &= w == 4 || w == 8;
+    rec_words += w / 4;
+  }
+  rec_ok &= rec_words <= 4;
   if (rec_ok) {
-    const int NC = (int)carry_src.size();
-    out.rec_dwords = 1 + NC;
+    const int NC = rec_words - 1;
+    out.rec_dwords = rec_words;
     out.records = make_buf(out_rows * (size_t)out.rec_dwords * 4 + 16);
     GroupCols gc{};
     gc.n = NC;
     int64_t moved = out.rows * out.rec_dwords * 4;
-    for (int c = 0; c < NC; c++) {
-      gc.src[c] = carry_src[c];
-      gc.width[c] = 4;
-      moved += carry_src[c] ? n * 4 : 0;
+    int plane = 0;
+    for (size_t c = 0; c < carry_src.size(); c++) {
+      DFGPU_CHECK(carry_src[c] || carry_width[c] == 4, "group_rows_by_key: a carried column without a source is the 32-bit row number");
+      out.rec_off.push_back(1 + plane);
+      for (int h = 0; h < carry_width[c] / 4; h++, plane++) {
+        gc.src[plane] = carry_src[c];
+        gc.width[plane] = 4;
+        gc.sdw[plane] = carry_width[c] / 4;
+        gc.soff[plane] = h;
+      }
+      moved += carry_src[c] ? n * carry_width[c] : 0;
     }
     const size_t lds = (size_t)TILE * 4 * (size_t)out.rec_dwords + (size_t)P * 12 + (size_t)(THREADS / WAVE) * 4 + (size_t)P * 2;
     ProfileScope ps(what ? what : "group_rows_scatter", key_bytes + moved);

@@ -23,6 +23,9 @@ struct GroupCols {
   void* dst[GP_MAX_COLS];
   int width[GP_MAX_COLS];
   int n;
+  // the record form: plane c of a record = 32-bit word soff[c] of element i of src[c], elements sdw[c] words apart (an 8-byte column is two planes)
+  int sdw[GP_MAX_COLS];
+  int soff[GP_MAX_COLS];
 };
 struct GroupedRows {
   int P = 0;
@@ -34,13 +37,14 @@ struct GroupedRows {
   std::vector<BufPtr> cols;    // carried columns in group order
   BufPtr records;              // the record form (asked for and granted): u32 [rows][rec_dwords] = {key - offset, carried columns...}; keys / cols empty
   int rec_dwords = 0;
+  std::vector<int> rec_off;    // per carried column: the 32-bit word of the record its value starts at (word 0 is the key)
 };
 // Rows of an integer key column moved into 2^nbits (<= GP_MAX_GROUPS) groups of their key's range (NULL keys, rows masked out by `row_mask` and keys
 // outside [offset, offset + size) take no part).  Order inside a group is arbitrary.
 GroupedRows group_rows_by_key(const KeyCol& key, int64_t n, const GroupSpec& gs, int nbits, const uint64_t* row_mask, bool want_keys, bool want_dest,
                               const std::vector<const void*>& carry_src, const std::vector<int>& carry_width, const char* what = nullptr, bool narrow_keys = false,
                               bool records = false);
-// (a carried column of width 4 whose source is null carries the rows' numbers; `records`: 32-bit keys and one to three 4-byte carried columns may
+// (a carried column of width 4 whose source is null carries the rows' numbers; `records`: 32-bit keys and carried 4- / 8-byte columns of at most 12 bytes together may
 // leave as one record per row — GroupedRows::records — when the caller can read them that way)
 
 }  // namespace dfgpu

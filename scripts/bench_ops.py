@@ -162,6 +162,17 @@ def main():
                     note="bytes = N*(8+4) in + groups*(8+8+4) out")
             results[-1]["groups"] = holder["g"]
             oc.free()
+            # the same key with an 8-byte argument: every customer's latest order (the move carries key, o_orderkey and row number: 16-byte records)
+            ok = ops.tpch_orders(args.sf).select(["o_custkey", "o_orderkey"])
+
+            def run_mc8():
+                o = ops.aggregate(ok, [(col("o_custkey"), "o_custkey")], [("count", None, "n"), ("max", col("o_orderkey"), "last_order")], "Single")
+                holder["g8"] = o.num_rows
+                return o
+            measure(f"GROUP BY o_custkey COUNT(*), MAX(o_orderkey) SF{args.sf:g}", run_mc8, ok.num_rows, lambda: ok.num_rows * 16 + holder["g8"] * 24,
+                    note="bytes = N*(8+8) in + groups*(8+8+8) out")
+            results[-1]["groups"] = holder["g8"]
+            ok.free()
         if want("agg_multikey"):
             # a daily report: three key columns (hash-interned groups: ~10 K), three aggregates over 600 M rows
             t = li.select(["l_returnflag", "l_linestatus", "l_shipdate", "l_quantity", "l_extendedprice"])

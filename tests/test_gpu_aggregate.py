@@ -499,30 +499,36 @@ def test_partitioned_group_by_emits_groups_in_first_seen_order_by_either_form(ca
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("filtered", [False, True], ids=["all_rows", "under_a_filter"])
+@pytest.mark.parametrize("case", ["all_rows", "under_a_filter", "int64_argument"])
 @pytest.mark.parametrize("form", ["records", "columns"])
-def test_grouped_move_of_narrow_rows_as_records_or_columns(form, filtered):
+def test_grouped_move_of_narrow_rows_as_records_or_columns(form, case):
     """Q13's shape — COUNT(*), MIN(Date32) by an integer key over a range of hundreds of thousands of values: the key (as a 32-bit offset),
-    the one 4-byte argument and the row number are moved into the key windows as ONE 12-byte record per row (grouped.hip's record form,
-    round 6), or column by column (group.records=0); with a fused FilterExec only the passing rows move.  Same groups in first-seen order,
-    same counts and minima."""
+    the 4-byte arguments and the row number are moved into the key windows as ONE record per row (grouped.hip's record form, round 6:
+    12 bytes under the filter, 16 with a second argument; an 8-byte argument — MAX(Int64), SUM(Int64) — takes two of a record's four
+    words), or column by column (group.records=0); with a fused FilterExec only the passing rows move.  Same groups in first-seen order,
+    same counts, minima, maxima and sums."""
     from datafusion_amd import ops
     from datafusion_amd.expr import col, lit
     from datafusion_amd.table import DeviceTable
     rng = np.random.default_rng(71)
+    filtered = case == "under_a_filter"
     n, distinct = 5_000_000, 400_000
     codes = rng.integers(0, distinct, n)
     d = rng.integers(-500, 3000, n).astype(np.int32)
     w = rng.integers(0, 100, n).astype(np.int32)
-    t = DeviceTable.from_arrow(pa.table({"k": pa.array(codes * 2 - 300_000), "d": pa.array(d, pa.date32()), "w": pa.array(w)}))
+    v = rng.integers(-2**40, 2**40, n)
+    t = DeviceTable.from_arrow(pa.table({"k": pa.array(codes * 2 - 300_000), "d": pa.array(d, pa.date32()), "w": pa.array(w), "v": pa.array(v)}))
+    if case == "int64_argument":
+        aggs = [("count", None, "n"), ("max", col("v"), "mv"), ("sum", col("v"), "sv")]      # (MAX and SUM read the same moved column)
+    else:
+        aggs = [("count", None, "n"), ("min", col("d"), "first_day")] + ([] if filtered else [("max", col("w"), "mw")])
     try:
         ops.set_options(agg__partitioned_min_rows="1000000")
         if form == "columns":
             ops.set_options(group__records="0")
         ops.profile_enable(True)
         ops.profile_reset()
-        got = ops.aggregate(t, [(col("k"), "k")], [("count", None, "n"), ("min", col("d"), "first_day")] + ([] if filtered else [("max", col("w"), "mw")]), "Single",
-                            predicate=(col("w") < lit(70, pa.int32())) if filtered else None).to_arrow()   # (12-byte records under the filter, 16-byte ones without)
+        got = ops.aggregate(t, [(col("k"), "k")], aggs, "Single", predicate=(col("w") < lit(70, pa.int32())) if filtered else None).to_arrow()
         stats = ops.profile_stats()
         ops.profile_enable(False)
     finally:
@@ -534,9 +540,15 @@ def test_grouped_move_of_narrow_rows_as_records_or_columns(form, filtered):
     np.minimum.at(first, kc, np.nonzero(keep)[0])
     present = np.nonzero(first < n)[0]
     order = present[np.argsort(first[present], kind="stable")]
-    lo = np.full(distinct, 10**6, dtype=np.int64); np.minimum.at(lo, kc, kd)
     assert got.column("k").to_pylist() == (order * 2 - 300_000).tolist()
     assert got.column("n").to_pylist() == np.bincount(kc, minlength=distinct)[order].tolist()
+    if case == "int64_argument":
+        mv = np.full(distinct, -2**62, dtype=np.int64); np.maximum.at(mv, kc, v[keep])
+        sv = np.zeros(distinct, dtype=np.int64); np.add.at(sv, kc, v[keep])
+        assert got.column("mv").to_pylist() == mv[order].tolist()
+        assert got.column("sv").to_pylist() == sv[order].tolist()
+        return
+    lo = np.full(distinct, 10**6, dtype=np.int64); np.minimum.at(lo, kc, kd)
     assert got.column("first_day").cast(pa.int32()).to_pylist() == lo[order].tolist()
     if not filtered:
         mw = np.full(distinct, -1, dtype=np.int64); np.maximum.at(mw, kc, w[keep])
